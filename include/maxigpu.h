@@ -1,0 +1,167 @@
+/* include/maxigpu.h -- the C-ABI of libmaxigpu.so: the MI355X (gfx950) voice-bank DSP path
+ * behind the Maximilian class API.
+ *
+ * The reference (micknoise/Maximilian, cited as C = src/maximilian.cpp, H = src/maximilian.h,
+ * L/ = src/libs/) has no FFI: its "plugin API" is the C++ class surface a user's
+ * `void play(double*)` calls once per sample (cpp/commandline/player.cpp:25-44 drives it).
+ * Each entry point below is what a binding for that surface would bind: it renders N samples
+ * of a BANK of V independent instances of one reference class in a single launch.  The host
+ * facade (include/maximilian_bank.hpp) keeps the reference's class/method names on top.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch types cross this boundary.
+ *   - every `d_*` pointer is DEVICE memory (from mxg_malloc, hipMalloc, or a torch tensor's
+ *     data_ptr()); `h_*` is host memory.  Pointers are borrowed for the call only.
+ *   - bank signals are sample-major / voice-minor:  out[n*V + v],  n < N, v < V.
+ *   - state is SoA: one array of length V per reference member, updated in place so
+ *     consecutive calls continue the stream exactly like consecutive play() calls.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the library's default stream).
+ *     Calls are asynchronous on that stream; mxg_sync()/mxg_stream_sync() wait.
+ *   - returns 0 on success, a negative mxg_status otherwise; never throws, never exit()s
+ *     (the reference exit(1)s on a bad FFT size, L/fft.cpp:129-132; here that is
+ *     MXG_ERR_INVALID).  mxg_last_error() gives a thread-local message.
+ *   - there is NO CPU fallback: without a HIP device every compute call fails with
+ *     MXG_ERR_NO_DEVICE.
+ */
+#ifndef MAXIGPU_H
+#define MAXIGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MXG_OK = 0,
+    MXG_ERR_INVALID = -1,   /* bad argument (null pointer, unknown waveform, odd size ...) */
+    MXG_ERR_NO_DEVICE = -2, /* no HIP device / runtime failure at init */
+    MXG_ERR_HIP = -3,       /* a HIP call failed; see mxg_last_error() */
+    MXG_ERR_NOMEM = -4
+} mxg_status;
+
+/* maxiOsc waveforms, numbered as in oracle/maxi_oracle.c.  Reference: C:228-373. */
+typedef enum {
+    MXG_OSC_SINEWAVE = 0,       /* C:228-235 */
+    MXG_OSC_COSWAVE = 1,        /* C:276-283 */
+    MXG_OSC_PHASOR = 2,         /* C:285-291 */
+    MXG_OSC_SAW = 3,            /* C:333-340 */
+    MXG_OSC_TRIANGLE = 4,       /* C:362-373 */
+    MXG_OSC_SQUARE = 5,         /* C:293-300 */
+    MXG_OSC_PULSE = 6,          /* C:302-311  p1 = duty */
+    MXG_OSC_IMPULSE = 7,        /* C:312-319 */
+    MXG_OSC_SINEBUF = 8,        /* C:266-274 */
+    MXG_OSC_SINEBUF4 = 9,       /* C:237-264 */
+    MXG_OSC_SAWN = 10,          /* C:342-359 */
+    MXG_OSC_PHASORBETWEEN = 11  /* C:321-330  p1 = startphase, p2 = endphase */
+} mxg_osc_waveform;
+
+/* maxiFilter kinds.  Reference: C:442-500. */
+typedef enum {
+    MXG_FLT_LORES = 0,   /* C:455-468 */
+    MXG_FLT_HIRES = 1,   /* C:471-484 */
+    MXG_FLT_BANDPASS = 2,/* C:487-500 */
+    MXG_FLT_LOPASS = 3,  /* C:442-446 */
+    MXG_FLT_HIPASS = 4   /* C:449-453 */
+} mxg_filter_kind;
+
+/* ---- library / device ---------------------------------------------------------------- */
+/* Select the HIP device (-1 = current), create the default stream.  Idempotent. */
+int mxg_init(int device);
+const char *mxg_last_error(void);
+const char *mxg_version(void);
+/* maxiSettings::setup (H:138-143): global sampleRate / channels / bufferSize (size_t). */
+int mxg_settings(size_t sampleRate, size_t channels, size_t bufferSize);
+size_t mxg_sample_rate(void);
+
+/* ---- device memory / streams (thin pass-throughs, so a host needs no HIP headers) ----- */
+void *mxg_malloc(size_t bytes);
+int mxg_free(void *d_ptr);
+int mxg_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int mxg_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int mxg_memset(void *d_dst, int value, size_t bytes, void *stream);
+void *mxg_stream_create(void);
+int mxg_stream_destroy(void *stream);
+int mxg_stream_sync(void *stream);
+int mxg_sync(void);
+/* HIP events on `stream`, for timing a launch from the host side of the boundary. */
+void *mxg_event_create(void);
+int mxg_event_destroy(void *event);
+int mxg_event_record(void *event, void *stream);
+int mxg_event_elapsed_ms(void *start, void *stop, float *h_ms);
+
+/* ---- tuning knobs (performance only; results are identical for every setting) ---------- */
+/* key: "osc_vpl" (voices per lane 1|2), "osc_block" (64..1024), "osc_nt" (0|1 non-temporal
+ * stores), "voice_vpl", "voice_block".  Returns previous value or MXG_ERR_INVALID. */
+int mxg_tune(const char *key, int value);
+
+/* ---- maxiOsc bank -------------------------------------------------------------------- */
+/* Renders out[n][v] = bank[v].<waveform>(freq) for n < N, exactly as N consecutive per-sample
+ * calls would (H:169-215).  d_freq is [V] (fps=0, block-constant) or [N][V] (fps=1, audio-rate
+ * modulation).  d_p1/d_p2: per-voice extra arguments (see mxg_osc_waveform), may be NULL when
+ * unused.  d_phase / d_outhold: the members `phase` and `output` (H:173,176), in/out.
+ * maxiOsc::noise (C:214-220) is a global serial rand() stream and is not provided. */
+int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_freq, int fps,
+                   const double *d_p1, const double *d_p2, double *d_phase, double *d_outhold,
+                   double *d_out, void *stream);
+
+/* ---- maxiFilter bank ------------------------------------------------------------------ */
+/* d_st = [5][V]: x, y, outputs[0], outputs[1], outputs[2] (H:289-302), in/out.
+ * lores/hires/bandpass with block-constant cutoff/resonance (cps=rps=0): the coefficients that
+ * need cos/pow/sqrt (C:459-461: c, r; C:492-495: inputs[0..2]) must be supplied precomputed in
+ * d_coef = [3][V] -- computed on the host with the host libm by mxg_filter_coeffs_host(),
+ * which makes the recurrence bit-exact.  With cps or rps = 1 (per-sample modulation, e.g.
+ * 14.monosynth/main.cpp:53) the coefficients are evaluated on the device (cos/sqrt) under the
+ * tolerance stated in DESIGN.md; d_coef is ignored. d_res/d_coef may be NULL for
+ * lopass/hipass. */
+int mxg_filter_render(int kind, size_t V, size_t N, const double *d_in, const double *d_cutoff,
+                      int cps, const double *d_res, int rps, const double *d_coef, double *d_st,
+                      double *d_out, void *stream);
+/* Host-side coefficient evaluation on this machine's libm: kind lores/hires -> h_coef[0]=c,
+ * h_coef[1]=r (C:456-461); bandpass -> h_coef[0..2]=inputs[0..2] (C:489-495).  h_coef is [3][V]. */
+int mxg_filter_coeffs_host(int kind, size_t V, const double *h_cutoff, const double *h_res,
+                           double *h_coef);
+
+/* ---- maxiEnv bank --------------------------------------------------------------------- */
+/* mode 0: adsr(input, trigger) (C:1415-1466)   mode 1: ar(input, attack, release, holdtime,
+ * trigger) (C:1319-1358).  d_in NULL = constant 1.0 input.  d_trig: int32 [N] (tpv=0, one
+ * trigger signal for the whole bank) or [N][V] (tpv=1).  d_par = [4][V] attack, decay,
+ * sustain, release as stored by the setters; d_holdtime int64 [V]; d_dst = [2][V] amplitude,
+ * output; d_ist = int64 [6][V] holdcount, attackphase, decayphase, sustainphase, holdphase,
+ * releasephase.  All state in/out; zero-initialise to match static-storage maxiEnv objects. */
+int mxg_env_render(int mode, size_t V, size_t N, const double *d_in, const int32_t *d_trig,
+                   int tpv, const double *d_par, const int64_t *d_holdtime, double *d_dst,
+                   int64_t *d_ist, double *d_out, void *stream);
+/* maxiEnv setters on the host libm (C:1469-1494): which 0 setAttack 1 setDecay 2 setRelease
+ * 3 setAttackMS. */
+double mxg_env_coeff_host(int which, double ms);
+
+/* ---- fused subtractive voice (saw -> lores -> adsr in registers, one store per sample) ---- */
+/* mode 0: out = adsr(lores(saw(freq), cutoff, res), trig); coefficients hoisted: d_coef =
+ *         [3][V] from mxg_filter_coeffs_host(MXG_FLT_LORES, ...) (bit-exact).
+ * mode 1: e = adsr(1., trig); out = lores(saw(freq), e*cutoff, res) * e  (the call order of
+ *         14.monosynth/main.cpp:50-55); cutoff is modulated per sample, coefficients on device,
+ *         stated tolerance.  d_cutoff/d_res [V] are used, d_coef ignored.
+ * d_ost = [2][V] osc phase/output; d_fst = [5][V] filter state; env arrays as mxg_env_render. */
+int mxg_voice_render(int mode, size_t V, size_t N, const double *d_freq, const double *d_cutoff,
+                     const double *d_res, const double *d_coef, const int32_t *d_trig, int tpv,
+                     const double *d_par, const int64_t *d_holdtime, double *d_ost, double *d_fst,
+                     double *d_dst, int64_t *d_ist, double *d_out, void *stream);
+
+/* ---- maxiMix::stereo + mixdown over voices (C:503-509; user-side sum e.g. 15.polysynth:67) --- */
+/* d_mix[n][0..1] = sum_v ( in[n][v]*sqrt(1-pan_v), in[n][v]*sqrt(pan_v) ).  The per-voice
+ * products are exact; the sum over voices is a fixed-shape tree (deterministic, but not the
+ * reference's sequential order => stated tolerance on the mix). d_mix is [N][2]. */
+int mxg_mix_stereo(size_t V, size_t N, const double *d_in, const double *d_pan, double *d_mix,
+                   void *stream);
+
+/* ---- calibration ----------------------------------------------------------------------- */
+/* Streaming fill of `bytes` at d_dst (8 B/lane or 16 B/lane stores): the measured HBM write
+ * ceiling that bench.py reports next to the nominal 8 TB/s. */
+int mxg_calib_fill(void *d_dst, size_t bytes, int width, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAXIGPU_H */

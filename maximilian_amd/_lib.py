@@ -1,0 +1,85 @@
+"""ctypes binding of libmaxigpu.so (the C-ABI declared in include/maxigpu.h).
+
+There is deliberately no fallback: if the HIP library has not been built, or no HIP
+device is visible when a compute entry point is called, this raises.  Nothing in this
+package imports or calls the CPU oracle under oracle/.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmaxigpu.so")
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/maxigpu.h one to one.
+SIGNATURES = {
+    "mxg_init": (c_int, [c_int]),
+    "mxg_last_error": (c_char_p, []),
+    "mxg_version": (c_char_p, []),
+    "mxg_settings": (c_int, [c_size_t, c_size_t, c_size_t]),
+    "mxg_sample_rate": (c_size_t, []),
+    "mxg_malloc": (c_void_p, [c_size_t]),
+    "mxg_free": (c_int, [c_void_p]),
+    "mxg_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mxg_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mxg_memset": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
+    "mxg_stream_create": (c_void_p, []),
+    "mxg_stream_destroy": (c_int, [c_void_p]),
+    "mxg_stream_sync": (c_int, [c_void_p]),
+    "mxg_sync": (c_int, []),
+    "mxg_event_create": (c_void_p, []),
+    "mxg_event_destroy": (c_int, [c_void_p]),
+    "mxg_event_record": (c_int, [c_void_p, c_void_p]),
+    "mxg_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "mxg_tune": (c_int, [c_char_p, c_int]),
+    "mxg_osc_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_filter_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_int, c_void_p,
+                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_filter_coeffs_host": (c_int, [c_int, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "mxg_env_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_int, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_env_coeff_host": (c_double, [c_int, c_double]),
+    "mxg_voice_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p]),
+    "mxg_mix_stereo": (c_int, [c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_calib_fill": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
+}
+
+
+class MaxiGpuError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmaxigpu.so once (importing torch first, when present, so that both share one
+    HIP runtime -- the library resolves libamdhip64.so.7 by SONAME)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MaxiGpuError(
+            "libmaxigpu.so is not built (%s). Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C maximilian_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    try:
+        import torch  # noqa: F401  (shared HIP runtime; optional)
+    except Exception:  # pragma: no cover
+        pass
+    L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError here == header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(status, what=""):
+    if status < 0:
+        msg = lib().mxg_last_error().decode("utf-8", "replace")
+        raise MaxiGpuError("%s failed (%d): %s" % (what or "libmaxigpu call", status, msg))
+    return status

@@ -1,0 +1,299 @@
+"""Host-side mirror of the reference's operator API, one *bank* of V instances per object.
+
+Names follow the reference (src/maximilian.h): `maxiOscBank.sinebuf(freq, N)` renders what N
+consecutive calls of `maxiOsc::sinebuf(freq[v])` on each of the V oscillators would return,
+as an [N, V] sample-major block that stays on the device.  State (phase, filter memories,
+envelope flags ...) lives in device SoA arrays owned by the bank and carries from block to
+block, exactly like consecutive `play()` callbacks.  Everything here is plumbing over the
+C-ABI (maximilian_amd/_lib.py); no arithmetic on signals happens in Python.
+"""
+import ctypes
+
+import numpy as np
+
+from ._lib import check, lib
+
+OSC_WAVEFORMS = {
+    "sinewave": 0, "coswave": 1, "phasor": 2, "saw": 3, "triangle": 4, "square": 5, "pulse": 6,
+    "impulse": 7, "sinebuf": 8, "sinebuf4": 9, "sawn": 10, "phasorBetween": 11,
+}
+FILTER_KINDS = {"lores": 0, "hires": 1, "bandpass": 2, "lopass": 3, "hipass": 4}
+
+
+class DeviceBuffer:
+    """A typed device allocation (hipMalloc via mxg_malloc) with numpy upload/download."""
+
+    def __init__(self, shape, dtype=np.float64, zero=True):
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self.ptr = lib().mxg_malloc(max(self.nbytes, 8))
+        if not self.ptr:
+            raise MemoryError("mxg_malloc(%d): %s" % (self.nbytes, lib().mxg_last_error().decode()))
+        if zero and self.nbytes:
+            check(lib().mxg_memset(self.ptr, 0, self.nbytes, None), "mxg_memset")
+
+    @classmethod
+    def from_numpy(cls, a, dtype=None):
+        a = np.ascontiguousarray(a, dtype=dtype if dtype is not None else a.dtype)
+        b = cls(a.shape, a.dtype, zero=False)
+        b.upload(a)
+        return b
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.nbytes == self.nbytes, (a.shape, self.shape)
+        if self.nbytes:
+            check(lib().mxg_memcpy_h2d(self.ptr, a.ctypes.data, self.nbytes, None), "mxg_memcpy_h2d")
+        return self
+
+    def numpy(self):
+        out = np.empty(self.shape, self.dtype)
+        if self.nbytes:
+            check(lib().mxg_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, None), "mxg_memcpy_d2h")
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            lib().mxg_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):  # best effort
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr(x):
+    """Device pointer of a DeviceBuffer / torch tensor / raw int / None."""
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return int(x)
+
+
+def _as_dev(x, V, dtype=np.float64):
+    """Per-voice parameter: scalar / array-like -> DeviceBuffer [V]; device objects pass through."""
+    if isinstance(x, DeviceBuffer) or hasattr(x, "data_ptr"):
+        return x
+    a = np.asarray(x, dtype=dtype)
+    if a.ndim == 0:
+        a = np.full(V, a, dtype=dtype)
+    return DeviceBuffer.from_numpy(a)
+
+
+class maxiSettings:
+    """maxiSettings (H:117-163): global sampleRate / channels / bufferSize."""
+    sampleRate, channels, bufferSize = 44100, 2, 1024
+
+    @classmethod
+    def setup(cls, sampleRate, channels, bufferSize):
+        check(lib().mxg_settings(sampleRate, channels, bufferSize), "mxg_settings")
+        cls.sampleRate, cls.channels, cls.bufferSize = sampleRate, channels, bufferSize
+
+
+class _Bank:
+    def __init__(self, voices, stream=None):
+        check(lib().mxg_init(-1), "mxg_init")
+        self.V = int(voices)
+        self.stream = stream
+
+    def _out(self, N, out):
+        return out if out is not None else DeviceBuffer((N, self.V), np.float64, zero=False)
+
+    def sync(self):
+        check(lib().mxg_stream_sync(self.stream), "mxg_stream_sync")
+
+
+class maxiOscBank(_Bank):
+    """V x maxiOsc (H:169-215).  Methods: one per reference waveform, `(freq, N)` -> [N, V]."""
+
+    def __init__(self, voices, stream=None):
+        super().__init__(voices, stream)
+        self.phase = DeviceBuffer(self.V)   # maxiOsc::phase  (ctor sets 0, C:209-212)
+        self.output = DeviceBuffer(self.V)  # maxiOsc::output (held by square/pulse)
+
+    def phaseReset(self, phaseIn):
+        """maxiOsc::phaseReset (C:222-226), per voice."""
+        self.phase.upload(np.broadcast_to(np.asarray(phaseIn, np.float64), (self.V,)))
+
+    def render(self, waveform, freq, N, p1=None, p2=None, out=None, per_sample=False):
+        wf = OSC_WAVEFORMS[waveform] if isinstance(waveform, str) else int(waveform)
+        if per_sample:
+            f = freq if (isinstance(freq, DeviceBuffer) or hasattr(freq, "data_ptr")) else \
+                DeviceBuffer.from_numpy(np.asarray(freq, np.float64).reshape(N, self.V))
+        else:
+            f = _as_dev(freq, self.V)
+        a = None if p1 is None else _as_dev(p1, self.V)
+        b = None if p2 is None else _as_dev(p2, self.V)
+        out = self._out(N, out)
+        check(lib().mxg_osc_render(wf, self.V, N, _ptr(f), 1 if per_sample else 0, _ptr(a), _ptr(b),
+                                   self.phase.ptr, self.output.ptr, _ptr(out), self.stream),
+              "mxg_osc_render")
+        self._keep = (f, a, b)  # keep parameter buffers alive until the next call
+        return out
+
+    def sinewave(self, freq, N, **kw): return self.render("sinewave", freq, N, **kw)
+    def coswave(self, freq, N, **kw): return self.render("coswave", freq, N, **kw)
+    def phasor(self, freq, N, **kw): return self.render("phasor", freq, N, **kw)
+    def saw(self, freq, N, **kw): return self.render("saw", freq, N, **kw)
+    def triangle(self, freq, N, **kw): return self.render("triangle", freq, N, **kw)
+    def square(self, freq, N, **kw): return self.render("square", freq, N, **kw)
+    def pulse(self, freq, duty, N, **kw): return self.render("pulse", freq, N, p1=duty, **kw)
+    def impulse(self, freq, N, **kw): return self.render("impulse", freq, N, **kw)
+    def sinebuf(self, freq, N, **kw): return self.render("sinebuf", freq, N, **kw)
+    def sinebuf4(self, freq, N, **kw): return self.render("sinebuf4", freq, N, **kw)
+    def sawn(self, freq, N, **kw): return self.render("sawn", freq, N, **kw)
+
+    def phasorBetween(self, freq, startphase, endphase, N, **kw):
+        return self.render("phasorBetween", freq, N, p1=startphase, p2=endphase, **kw)
+
+
+def filter_coeffs(kind, cutoff, res):
+    """Host-libm coefficients [3][V] of maxiFilter::lores/hires (c, r; C:456-461) or bandpass
+    (inputs[0..2]; C:489-495), per voice."""
+    k = FILTER_KINDS[kind] if isinstance(kind, str) else int(kind)
+    cutoff = np.ascontiguousarray(cutoff, np.float64)
+    res = np.ascontiguousarray(np.broadcast_to(np.asarray(res, np.float64), cutoff.shape))
+    coef = np.zeros((3, cutoff.size))
+    check(lib().mxg_filter_coeffs_host(k, cutoff.size, cutoff.ctypes.data, res.ctypes.data,
+                                       coef.ctypes.data), "mxg_filter_coeffs_host")
+    return coef
+
+
+class maxiFilterBank(_Bank):
+    """V x maxiFilter (H:289-366)."""
+
+    def __init__(self, voices, stream=None):
+        super().__init__(voices, stream)
+        self.state = DeviceBuffer((5, self.V))  # x, y, outputs[0..2]  (ctor zeros, C:1517)
+
+    def render(self, kind, x, cutoff, resonance=None, out=None, cutoff_per_sample=False,
+               res_per_sample=False):
+        k = FILTER_KINDS[kind] if isinstance(kind, str) else int(kind)
+        N = x.shape[0]
+        coef = None
+        if k in (0, 1, 2) and not (cutoff_per_sample or res_per_sample):
+            cu = np.broadcast_to(np.asarray(cutoff, np.float64), (self.V,))
+            coef = DeviceBuffer.from_numpy(filter_coeffs(k, cu, resonance))
+        cut = cutoff if cutoff_per_sample and not isinstance(cutoff, np.ndarray) else (
+            DeviceBuffer.from_numpy(np.asarray(cutoff, np.float64).reshape(N, self.V))
+            if cutoff_per_sample else _as_dev(cutoff, self.V))
+        rs = None
+        if resonance is not None:
+            rs = (DeviceBuffer.from_numpy(np.asarray(resonance, np.float64).reshape(N, self.V))
+                  if res_per_sample and isinstance(resonance, np.ndarray)
+                  else (resonance if res_per_sample else _as_dev(resonance, self.V)))
+        out = self._out(N, out)
+        check(lib().mxg_filter_render(k, self.V, N, _ptr(x), _ptr(cut), int(cutoff_per_sample),
+                                      _ptr(rs), int(res_per_sample), _ptr(coef), self.state.ptr,
+                                      _ptr(out), self.stream), "mxg_filter_render")
+        self._keep = (cut, rs, coef)
+        return out
+
+    def lores(self, x, cutoff, resonance, **kw): return self.render("lores", x, cutoff, resonance, **kw)
+    def hires(self, x, cutoff, resonance, **kw): return self.render("hires", x, cutoff, resonance, **kw)
+    def bandpass(self, x, cutoff, resonance, **kw): return self.render("bandpass", x, cutoff, resonance, **kw)
+    def lopass(self, x, cutoff, **kw): return self.render("lopass", x, cutoff, None, **kw)
+    def hipass(self, x, cutoff, **kw): return self.render("hipass", x, cutoff, None, **kw)
+
+
+class maxiEnvBank(_Bank):
+    """V x maxiEnv (H:888-932).  No constructor in the reference: all state starts at zero
+    (static-storage objects), holdtime defaults to 1 (H:915)."""
+
+    def __init__(self, voices, stream=None):
+        super().__init__(voices, stream)
+        self.par = np.zeros((4, self.V))  # attack, decay, sustain, release
+        self.holdtime = np.ones(self.V, np.int64)
+        self.dstate = DeviceBuffer((2, self.V))            # amplitude, output
+        self.istate = DeviceBuffer((6, self.V), np.int64)  # holdcount + 5 phase flags
+        self._dirty = True
+
+    def _coeff(self, which, ms):
+        ms = np.broadcast_to(np.asarray(ms, np.float64), (self.V,))
+        f = lib().mxg_env_coeff_host
+        cache = {}
+        return np.array([cache.setdefault(m, f(which, m)) for m in ms.tolist()])
+
+    def setAttack(self, ms): self.par[0] = self._coeff(0, ms); self._dirty = True      # C:1480-1482
+    def setAttackMS(self, ms): self.par[0] = self._coeff(3, ms); self._dirty = True    # C:1486-1488
+    def setDecay(self, ms): self.par[1] = self._coeff(1, ms); self._dirty = True       # C:1475-1477
+    def setSustain(self, level): self.par[2] = np.asarray(level, np.float64); self._dirty = True
+    def setRelease(self, ms): self.par[3] = self._coeff(2, ms); self._dirty = True     # C:1470-1472
+
+    def _params(self):
+        if self._dirty:
+            self._dpar = DeviceBuffer.from_numpy(self.par)
+            self._dhold = DeviceBuffer.from_numpy(self.holdtime)
+            self._dirty = False
+        return self._dpar, self._dhold
+
+    def render(self, mode, x, trigger, N, out=None):
+        dpar, dhold = self._params()
+        trig = trigger
+        tpv = 0
+        if not (isinstance(trigger, DeviceBuffer) or hasattr(trigger, "data_ptr")):
+            t = np.ascontiguousarray(trigger, np.int32)
+            tpv = 1 if t.ndim == 2 else 0
+            trig = DeviceBuffer.from_numpy(t)
+        else:
+            tpv = 1 if len(trigger.shape) == 2 else 0
+        out = self._out(N, out)
+        check(lib().mxg_env_render(mode, self.V, N, _ptr(x), _ptr(trig), tpv, dpar.ptr, dhold.ptr,
+                                   self.dstate.ptr, self.istate.ptr, _ptr(out), self.stream),
+              "mxg_env_render")
+        self._keep = trig
+        return out
+
+    def adsr(self, x, trigger, N, **kw): return self.render(0, x, trigger, N, **kw)
+    def ar(self, x, trigger, N, **kw): return self.render(1, x, trigger, N, **kw)
+
+
+class maxiVoiceBank(_Bank):
+    """V fused subtractive voices: maxiOsc::saw -> maxiFilter::lores -> maxiEnv::adsr
+    (config 3; the per-voice body of 14.monosynth / 15.polysynth), one kernel, one store/sample."""
+
+    def __init__(self, voices, stream=None):
+        super().__init__(voices, stream)
+        self.env = maxiEnvBank(voices, stream)
+        self.osc_state = DeviceBuffer((2, self.V))
+        self.flt_state = DeviceBuffer((5, self.V))
+
+    def render(self, mode, freq, cutoff, resonance, trigger, N, out=None):
+        f = _as_dev(freq, self.V)
+        cu = np.broadcast_to(np.asarray(cutoff, np.float64), (self.V,))
+        rs = np.broadcast_to(np.asarray(resonance, np.float64), (self.V,))
+        coef = None
+        if mode == 0:
+            coef = DeviceBuffer.from_numpy(filter_coeffs(0, cu, rs))
+        dcu, drs = DeviceBuffer.from_numpy(cu), DeviceBuffer.from_numpy(rs)
+        dpar, dhold = self.env._params()
+        trig = trigger
+        if not (isinstance(trigger, DeviceBuffer) or hasattr(trigger, "data_ptr")):
+            trig = DeviceBuffer.from_numpy(np.ascontiguousarray(trigger, np.int32))
+        tpv = 1 if len(trig.shape) == 2 else 0
+        out = self._out(N, out)
+        check(lib().mxg_voice_render(mode, self.V, N, _ptr(f), dcu.ptr, drs.ptr, _ptr(coef), _ptr(trig),
+                                     tpv, dpar.ptr, dhold.ptr, self.osc_state.ptr, self.flt_state.ptr,
+                                     self.env.dstate.ptr, self.env.istate.ptr, _ptr(out), self.stream),
+              "mxg_voice_render")
+        self._keep = (f, dcu, drs, coef, trig)
+        return out
+
+
+class maxiMixBank(_Bank):
+    """maxiMix::stereo over a bank + the mixdown over voices (C:503-509)."""
+
+    def stereo(self, x, pan, out=None):
+        N = x.shape[0]
+        p = _as_dev(pan, self.V)
+        out = out if out is not None else DeviceBuffer((N, 2), np.float64, zero=False)
+        check(lib().mxg_mix_stereo(self.V, N, _ptr(x), _ptr(p), _ptr(out), self.stream),
+              "mxg_mix_stereo")
+        self._keep = p
+        return out

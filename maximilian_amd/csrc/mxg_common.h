@@ -1,0 +1,67 @@
+// mxg_common.h -- shared host/device plumbing for libmaxigpu.so (gfx950 only).
+//
+// Compile contract (see maximilian_amd/csrc/Makefile): hipcc --offload-arch=gfx950 -O3
+// -ffp-contract=off.  The last flag is part of the numerics contract: the reference is
+// compiled without FMA contraction (x86-64 SSE2), so every a*b+c below must stay a separate
+// v_mul_f64 + v_add_f64 or the bank outputs are no longer bit-identical.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/maxigpu.h"
+
+namespace mxg {
+
+// H:55-58
+#define MXG_TWOPI 6.283185307179586476925286766559
+#define MXG_PI 3.1415926535897932384626433832795
+
+// C:53 `float chandiv = 1;` -- multiplications by it are kept so the expression trees
+// match; x*1.0 is exact, the compiler may fold it.
+constexpr double kChandiv = 1.0;
+
+struct Settings {
+    size_t sampleRate = 44100;  // C:57
+    size_t channels = 2;        // C:58
+    size_t bufferSize = 1024;   // C:59
+};
+Settings &settings();
+
+// error plumbing (thread-local message, negative status codes)
+int fail(int status, const char *fmt, ...);
+int check_hip(hipError_t e, const char *what);
+int ensure_init();
+hipStream_t resolve_stream(void *stream);
+int tune_get(const char *key);
+
+#define MXG_HIP(call)                                         \
+    do {                                                      \
+        int _s = ::mxg::check_hip((call), #call);             \
+        if (_s) return _s;                                    \
+    } while (0)
+
+#define MXG_REQUIRE(cond, msg)                                               \
+    do {                                                                     \
+        if (!(cond)) return ::mxg::fail(MXG_ERR_INVALID, "%s: %s", __func__, msg); \
+    } while (0)
+
+// ---- device store helpers ---------------------------------------------------------------
+template <bool NT>
+__device__ __forceinline__ void store1(double *p, double v) {
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+typedef double double2v __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ void store2(double *p, double a, double b) {
+    double2v v = {a, b};
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, reinterpret_cast<double2v *>(p));
+    else
+        *reinterpret_cast<double2v *>(p) = v;
+}
+
+}  // namespace mxg

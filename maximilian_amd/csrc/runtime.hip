@@ -1,0 +1,215 @@
+// runtime.hip -- library state, error plumbing and the memory/stream pass-throughs of the
+// C-ABI (include/maxigpu.h).  No compute lives here.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "mxg_common.h"
+
+namespace mxg {
+
+namespace {
+thread_local char g_err[512] = "";
+std::mutex g_mu;
+bool g_inited = false;
+int g_device = -1;
+hipStream_t g_stream = nullptr;
+Settings g_settings;
+
+struct Tune {
+    const char *key;
+    int value;
+    int lo, hi;
+};
+Tune g_tune[] = {
+    {"osc_vpl", 2, 1, 2},       {"osc_block", 64, 64, 1024},  {"osc_nt", 0, 0, 1},
+    {"voice_vpl", 1, 1, 2},     {"voice_block", 64, 64, 1024}, {"voice_nt", 0, 0, 1},
+    {"mix_block", 256, 64, 1024},
+};
+}  // namespace
+
+Settings &settings() { return g_settings; }
+
+int fail(int status, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+int check_hip(hipError_t e, const char *what) {
+    if (e == hipSuccess) return MXG_OK;
+    return fail(e == hipErrorOutOfMemory ? MXG_ERR_NOMEM : MXG_ERR_HIP, "%s: %s", what,
+                hipGetErrorString(e));
+}
+
+int ensure_init() {
+    if (g_inited) return MXG_OK;
+    return mxg_init(-1);
+}
+
+hipStream_t resolve_stream(void *stream) { return stream ? (hipStream_t)stream : g_stream; }
+
+int tune_get(const char *key) {
+    for (auto &t : g_tune)
+        if (!strcmp(t.key, key)) return t.value;
+    return 0;
+}
+
+}  // namespace mxg
+
+using namespace mxg;
+
+extern "C" {
+
+int mxg_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(MXG_ERR_NO_DEVICE,
+                    "mxg_init: no HIP device visible (%s); libmaxigpu has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    }
+    if (device >= 0) {
+        if (device >= count) return fail(MXG_ERR_INVALID, "mxg_init: device %d of %d", device, count);
+        MXG_HIP(hipSetDevice(device));
+        g_device = device;
+    } else if (g_device < 0) {
+        MXG_HIP(hipGetDevice(&g_device));
+    }
+    if (!g_stream) MXG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_inited = true;
+    return MXG_OK;
+}
+
+const char *mxg_last_error(void) { return g_err; }
+const char *mxg_version(void) { return "maxigpu 0.1 (gfx950)"; }
+
+int mxg_settings(size_t sampleRate, size_t channels, size_t bufferSize) {
+    if (sampleRate == 0) return fail(MXG_ERR_INVALID, "mxg_settings: sampleRate 0");
+    g_settings.sampleRate = sampleRate;
+    g_settings.channels = channels;
+    g_settings.bufferSize = bufferSize;
+    return MXG_OK;
+}
+size_t mxg_sample_rate(void) { return g_settings.sampleRate; }
+
+void *mxg_malloc(size_t bytes) {
+    if (ensure_init()) return nullptr;
+    void *p = nullptr;
+    if (check_hip(hipMalloc(&p, bytes ? bytes : 8), "hipMalloc")) return nullptr;
+    return p;
+}
+int mxg_free(void *d_ptr) {
+    if (!d_ptr) return MXG_OK;
+    MXG_HIP(hipFree(d_ptr));
+    return MXG_OK;
+}
+int mxg_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream) {
+    if (int s = ensure_init()) return s;
+    hipStream_t st = resolve_stream(stream);
+    MXG_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
+    MXG_HIP(hipStreamSynchronize(st));  // h_src is borrowed for the call only
+    return MXG_OK;
+}
+int mxg_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream) {
+    if (int s = ensure_init()) return s;
+    hipStream_t st = resolve_stream(stream);
+    MXG_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+    MXG_HIP(hipStreamSynchronize(st));
+    return MXG_OK;
+}
+int mxg_memset(void *d_dst, int value, size_t bytes, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_HIP(hipMemsetAsync(d_dst, value, bytes, resolve_stream(stream)));
+    return MXG_OK;
+}
+void *mxg_stream_create(void) {
+    if (ensure_init()) return nullptr;
+    hipStream_t s = nullptr;
+    if (check_hip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"))
+        return nullptr;
+    return (void *)s;
+}
+int mxg_stream_destroy(void *stream) {
+    if (stream) MXG_HIP(hipStreamDestroy((hipStream_t)stream));
+    return MXG_OK;
+}
+int mxg_stream_sync(void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_HIP(hipStreamSynchronize(resolve_stream(stream)));
+    return MXG_OK;
+}
+int mxg_sync(void) {
+    if (int s = ensure_init()) return s;
+    MXG_HIP(hipDeviceSynchronize());
+    return MXG_OK;
+}
+void *mxg_event_create(void) {
+    if (ensure_init()) return nullptr;
+    hipEvent_t e = nullptr;
+    if (check_hip(hipEventCreate(&e), "hipEventCreate")) return nullptr;
+    return (void *)e;
+}
+int mxg_event_destroy(void *event) {
+    if (event) MXG_HIP(hipEventDestroy((hipEvent_t)event));
+    return MXG_OK;
+}
+int mxg_event_record(void *event, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(event, "null event");
+    MXG_HIP(hipEventRecord((hipEvent_t)event, resolve_stream(stream)));
+    return MXG_OK;
+}
+int mxg_event_elapsed_ms(void *start, void *stop, float *h_ms) {
+    MXG_REQUIRE(start && stop && h_ms, "null argument");
+    MXG_HIP(hipEventSynchronize((hipEvent_t)stop));
+    MXG_HIP(hipEventElapsedTime(h_ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return MXG_OK;
+}
+
+int mxg_tune(const char *key, int value) {
+    if (!key) return fail(MXG_ERR_INVALID, "mxg_tune: null key");
+    for (auto &t : g_tune) {
+        if (!strcmp(t.key, key)) {
+            if (value < t.lo || value > t.hi || (t.lo == 64 && (value % 64)))
+                return fail(MXG_ERR_INVALID, "mxg_tune: %s=%d out of range [%d,%d]", key, value,
+                            t.lo, t.hi);
+            int prev = t.value;
+            t.value = value;
+            return prev;
+        }
+    }
+    return fail(MXG_ERR_INVALID, "mxg_tune: unknown key %s", key);
+}
+
+// ---- calibration: streaming fill ----------------------------------------------------------
+__global__ void calib_fill8(double *p, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = 1.0;
+}
+__global__ void calib_fill16(double2v *p, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    double2v v = {1.0, 2.0};
+    for (; i < n; i += stride) p[i] = v;
+}
+int mxg_calib_fill(void *d_dst, size_t bytes, int width, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(d_dst && (width == 8 || width == 16), "bad argument");
+    hipStream_t st = resolve_stream(stream);
+    if (width == 8)
+        hipLaunchKernelGGL(calib_fill8, dim3(2048), dim3(256), 0, st, (double *)d_dst, bytes / 8);
+    else
+        hipLaunchKernelGGL(calib_fill16, dim3(2048), dim3(256), 0, st, (double2v *)d_dst,
+                           bytes / 16);
+    return check_hip(hipGetLastError(), "calib_fill launch");
+}
+
+}  // extern "C"

@@ -1,0 +1,461 @@
+// voice.hip -- maxiFilter / maxiEnv voice banks and the fused subtractive voice on gfx950.
+//
+// Path (reference src/maximilian.cpp, cited as C:line):
+//   maxiFilter::lores C:455-468, hires C:471-484, bandpass C:487-500, lopass C:442-446,
+//   hipass C:449-453;  maxiEnv::adsr C:1415-1466 (== 7-arg overload C:1362-1413),
+//   ar C:1319-1358;  maxiOsc::saw C:333-340.
+// One lane owns one voice; filter memories, envelope amplitude and the five phase flags
+// live in VGPRs for the whole block; signals are [N][V] sample-major so a wavefront's
+// loads/stores are 512 contiguous bytes of one row.
+//
+// Numerics.  The recurrences use only + - * and compares => bit-exact.  The lores/hires
+// coefficient pair (c, r) needs cos/pow/sqrt (C:459-461).  When cutoff/resonance are
+// block-constant they are evaluated ON THE HOST with the host libm (mxg_filter_coeffs_host,
+// the same expressions) and uploaded, which keeps the filter bit-exact.  When they are
+// modulated per sample (14.monosynth/main.cpp:53) they are evaluated on the device
+// (lores_coeffs_dev) under the tolerance stated in DESIGN.md -- a recursive filter amplifies
+// a 1-ULP coefficient difference, so no ULP claim is made for that mode.
+#include <math.h>
+
+#include "mxg_common.h"
+
+namespace mxg {
+
+namespace {
+
+// ---- maxiFilter -------------------------------------------------------------------------
+struct Flt {
+    double x, y, o0, o1, o2;
+};
+
+// C:456-461 on the device (modulated mode only).
+__device__ __forceinline__ void lores_coeffs_dev(double cutoff, double resonance, double sr,
+                                                 double &c, double &r) {
+    if (cutoff < 10) cutoff = 10;
+    if (cutoff > sr) cutoff = sr;
+    if (resonance < 1.) resonance = 1.;
+    double z = cos(MXG_TWOPI * cutoff / sr);
+    c = 2 - 2 * z;
+    double zm1 = z - 1.0;
+    // pow(z-1, 3.0): libm's pow is within 1 ULP of the exact cube; (zm1*zm1)*zm1 is within
+    // 1 ULP of it as well.  Both feed the tolerance mode only.
+    double cube = (zm1 * zm1) * zm1;
+    r = (sqrt(2.0) * sqrt(-cube) + resonance * (z - 1)) / (resonance * (z - 1));
+}
+
+__device__ __forceinline__ double flt_lores(Flt &f, double input, double c, double r) {  // C:463-467
+    f.x = f.x + (input - f.y) * c;
+    f.y = f.y + f.x;
+    f.x = f.x * r;
+    return f.y;
+}
+
+template <int KIND, bool MOD>
+__global__ void filter_kernel(size_t V, size_t N, const double *__restrict__ in,
+                              const double *__restrict__ cutoff, int cps,
+                              const double *__restrict__ res, int rps,
+                              const double *__restrict__ coef, double *__restrict__ st,
+                              double *__restrict__ out, double sr) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    Flt f = {st[v], st[V + v], st[2 * V + v], st[3 * V + v], st[4 * V + v]};
+    double c = 0, r = 0, cut0 = 0, res0 = 0;
+    if constexpr (KIND <= MXG_FLT_HIRES && !MOD) {
+        c = coef[v];
+        r = coef[V + v];
+    } else {
+        cut0 = cutoff[v];  // row 0 of [N][V] or the [V] constant
+        res0 = res ? res[v] : 0.0;
+    }
+    // bandpass: constant parameters -> host-libm coefficients; modulated -> device (C:489-495).
+    double b0 = 0, b1 = 0, b2 = 0;
+    auto bp_coeffs = [&](double cu, double rs) {
+        if (cu > (sr * 0.5)) cu = (sr * 0.5);
+        if (rs >= 1.) rs = 0.999999;
+        double z = cos(MXG_TWOPI * cu / sr);
+        b0 = (1 - rs) * (sqrt(rs * (rs - 4.0 * (z * z) + 2.0) + 1));
+        b1 = 2 * z * rs;
+        b2 = (rs * -1) * (rs * -1);
+    };
+    if constexpr (KIND == MXG_FLT_BANDPASS && !MOD) {
+        b0 = coef[v];
+        b1 = coef[V + v];
+        b2 = coef[2 * V + v];
+    }
+
+    const double *ip = in + v;
+    double *op = out + v;
+    const double *cp = cutoff + v;
+    const double *rp = res ? res + v : nullptr;
+#pragma unroll 4
+    for (size_t n = 0; n < N; n++) {
+        double x = *ip;
+        double cu = cut0, rs = res0;
+        if constexpr (MOD) {
+            if (cps) cu = *cp;
+            if (rps) rs = *rp;
+        }
+        double o;
+        if constexpr (KIND == MXG_FLT_LORES || KIND == MXG_FLT_HIRES) {
+            if constexpr (MOD) lores_coeffs_dev(cu, rs, sr, c, r);
+            double y = flt_lores(f, x, c, r);
+            o = (KIND == MXG_FLT_LORES) ? y : x - y;  // C:466 / C:482
+        } else if constexpr (KIND == MXG_FLT_BANDPASS) {  // C:487-500
+            if constexpr (MOD) bp_coeffs(cu, rs);
+            o = b0 * x + b1 * f.o1 + b2 * f.o2;
+            f.o2 = f.o1;
+            f.o1 = o;
+        } else if constexpr (KIND == MXG_FLT_LOPASS) {  // C:442-446
+            o = f.o0 + cu * (x - f.o0);
+            f.o0 = o;
+        } else {  // hipass C:449-453
+            o = x - (f.o0 + cu * (x - f.o0));
+            f.o0 = o;
+        }
+        *op = o;
+        ip += V;
+        op += V;
+        if constexpr (MOD) {
+            if (cps) cp += V;
+            if (rps) rp += V;
+        }
+    }
+    st[v] = f.x;
+    st[V + v] = f.y;
+    st[2 * V + v] = f.o0;
+    st[3 * V + v] = f.o1;
+    st[4 * V + v] = f.o2;
+}
+
+// ---- maxiEnv ----------------------------------------------------------------------------
+struct Env {
+    double attack, decay, sustain, release, amplitude, output;
+    long long holdtime, holdcount;
+    int attackphase, decayphase, sustainphase, holdphase, releasephase;
+};
+
+__device__ __forceinline__ void env_load(Env &e, size_t V, size_t v, const double *par,
+                                         const int64_t *holdtime, const double *dst,
+                                         const int64_t *ist) {
+    e.attack = par[v];
+    e.decay = par[V + v];
+    e.sustain = par[2 * V + v];
+    e.release = par[3 * V + v];
+    e.holdtime = holdtime[v];
+    e.amplitude = dst[v];
+    e.output = dst[V + v];
+    e.holdcount = ist[v];
+    e.attackphase = (int)ist[V + v];
+    e.decayphase = (int)ist[2 * V + v];
+    e.sustainphase = (int)ist[3 * V + v];
+    e.holdphase = (int)ist[4 * V + v];
+    e.releasephase = (int)ist[5 * V + v];
+}
+__device__ __forceinline__ void env_store(const Env &e, size_t V, size_t v, double *dst,
+                                          int64_t *ist) {
+    dst[v] = e.amplitude;
+    dst[V + v] = e.output;
+    ist[v] = e.holdcount;
+    ist[V + v] = e.attackphase;
+    ist[2 * V + v] = e.decayphase;
+    ist[3 * V + v] = e.sustainphase;
+    ist[4 * V + v] = e.holdphase;
+    ist[5 * V + v] = e.releasephase;
+}
+
+// C:1415-1466.  Statement order is the reference's: a sample can pass through several of
+// the `if`s (e.g. attack -> decay in the same call).
+__device__ __forceinline__ double env_adsr(Env &e, double input, int trigger) {
+    if (trigger == 1 && e.attackphase != 1 && e.holdphase != 1 && e.decayphase != 1) {
+        e.holdcount = 0;
+        e.decayphase = 0;
+        e.sustainphase = 0;
+        e.releasephase = 0;
+        e.attackphase = 1;
+    }
+    if (e.attackphase == 1) {
+        e.releasephase = 0;
+        e.amplitude += (1 * e.attack);
+        e.output = input * e.amplitude;
+        if (e.amplitude >= 1) {
+            e.amplitude = 1;
+            e.attackphase = 0;
+            e.decayphase = 1;
+        }
+    }
+    if (e.decayphase == 1) {
+        e.amplitude *= e.decay;
+        e.output = input * e.amplitude;
+        if (e.amplitude <= e.sustain) {
+            e.decayphase = 0;
+            e.holdphase = 1;
+        }
+    }
+    if (e.holdcount < e.holdtime && e.holdphase == 1) {
+        e.output = input * e.amplitude;
+        e.holdcount++;
+    }
+    if (e.holdcount >= e.holdtime && trigger == 1) {
+        e.output = input * e.amplitude;
+    }
+    if (e.holdcount >= e.holdtime && trigger != 1) {
+        e.holdphase = 0;
+        e.releasephase = 1;
+    }
+    if (e.releasephase == 1 && e.amplitude > 0.) {
+        e.amplitude *= e.release;
+        e.output = input * e.amplitude;
+    }
+    return e.output;
+}
+
+// C:1319-1358
+__device__ __forceinline__ double env_ar(Env &e, double input, int trigger) {
+    const double attack = e.attack, release = e.release;
+    const long long holdtime = e.holdtime;
+    if (trigger == 1 && e.attackphase != 1 && e.holdphase != 1) {
+        e.holdcount = 0;
+        e.releasephase = 0;
+        e.attackphase = 1;
+    }
+    if (e.attackphase == 1) {
+        e.amplitude += (1 * attack);
+        e.output = input * e.amplitude;
+    }
+    if (e.amplitude >= 1) {
+        e.amplitude = 1;
+        e.attackphase = 0;
+        e.holdphase = 1;
+    }
+    if (e.holdcount < holdtime && e.holdphase == 1) {
+        e.output = input;
+        e.holdcount++;
+    }
+    if (e.holdcount == holdtime && trigger == 1) {
+        e.output = input;
+    }
+    if (e.holdcount == holdtime && trigger != 1) {
+        e.holdphase = 0;
+        e.releasephase = 1;
+    }
+    if (e.releasephase == 1 && e.amplitude > 0.) {
+        e.amplitude *= release;
+        e.output = input * e.amplitude;
+    }
+    return e.output;
+}
+
+template <int MODE>
+__global__ void env_kernel(size_t V, size_t N, const double *__restrict__ in,
+                           const int32_t *__restrict__ trig, int tpv,
+                           const double *__restrict__ par, const int64_t *__restrict__ holdtime,
+                           double *__restrict__ dst, int64_t *__restrict__ ist,
+                           double *__restrict__ out) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    Env e;
+    env_load(e, V, v, par, holdtime, dst, ist);
+    const double *ip = in ? in + v : nullptr;
+    double *op = out + v;
+#pragma unroll 4
+    for (size_t n = 0; n < N; n++) {
+        double x = ip ? *ip : 1.0;
+        int t = tpv ? trig[n * V + v] : trig[n];
+        double o = (MODE == 0) ? env_adsr(e, x, t) : env_ar(e, x, t);
+        *op = o;
+        op += V;
+        if (ip) ip += V;
+    }
+    env_store(e, V, v, dst, ist);
+}
+
+// ---- fused subtractive voice (K2) ----------------------------------------------------------
+// MODE 0: out = adsr(lores(saw(f), c, r), trig)             (coefficients hoisted, bit-exact)
+// MODE 1: e = adsr(1., trig); out = lores(saw(f), e*cutoff, res) * e   (device coefficients)
+template <int MODE, bool NT>
+__global__ void voice_kernel(size_t V, size_t N, const double *__restrict__ freq,
+                             const double *__restrict__ cutoff, const double *__restrict__ res,
+                             const double *__restrict__ coef, const int32_t *__restrict__ trig,
+                             int tpv, const double *__restrict__ par,
+                             const int64_t *__restrict__ holdtime, double *__restrict__ ost,
+                             double *__restrict__ fst, double *__restrict__ dst,
+                             int64_t *__restrict__ ist, double *__restrict__ out, double sr) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    double phase = ost[v], hold = ost[V + v];
+    Flt f = {fst[v], fst[V + v], fst[2 * V + v], fst[3 * V + v], fst[4 * V + v]};
+    Env e;
+    env_load(e, V, v, par, holdtime, dst, ist);
+    const double inc = (1. / (sr / (freq[v]))) * 2.0;  // C:337
+    double c = 0, r = 0, cut = 0, rs = 0;
+    if constexpr (MODE == 0) {
+        c = coef[v];
+        r = coef[V + v];
+    } else {
+        cut = cutoff[v];
+        rs = res[v];
+    }
+    double *op = out + v;
+#pragma unroll 4
+    for (size_t n = 0; n < N; n++) {
+        int t = tpv ? trig[n * V + v] : trig[n];
+        double o;
+        if constexpr (MODE == 0) {
+            double s = phase;  // saw C:333-340
+            hold = s;
+            if (phase >= 1.0) phase -= 2.0;
+            phase += inc;
+            double y = flt_lores(f, s, c, r);
+            o = env_adsr(e, y, t);
+        } else {
+            double a = env_adsr(e, 1.0, t);
+            double s = phase;
+            hold = s;
+            if (phase >= 1.0) phase -= 2.0;
+            phase += inc;
+            lores_coeffs_dev(a * cut, rs, sr, c, r);
+            double y = flt_lores(f, s, c, r);
+            o = y * a;
+        }
+        store1<NT>(op, o);
+        op += V;
+    }
+    ost[v] = phase;
+    ost[V + v] = hold;
+    fst[v] = f.x;
+    fst[V + v] = f.y;
+    fst[2 * V + v] = f.o0;
+    fst[3 * V + v] = f.o1;
+    fst[4 * V + v] = f.o2;
+    env_store(e, V, v, dst, ist);
+}
+
+inline dim3 grid_for(size_t V, int block) { return dim3((unsigned)((V + block - 1) / block)); }
+
+}  // namespace
+}  // namespace mxg
+
+using namespace mxg;
+
+extern "C" {
+
+int mxg_filter_render(int kind, size_t V, size_t N, const double *d_in, const double *d_cutoff,
+                      int cps, const double *d_res, int rps, const double *d_coef, double *d_st,
+                      double *d_out, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(kind >= 0 && kind <= 4, "unknown filter kind");
+    MXG_REQUIRE(d_in && d_cutoff && d_st && d_out, "null device pointer");
+    MXG_REQUIRE(kind > MXG_FLT_BANDPASS || d_res, "lores/hires/bandpass need d_res");
+    const bool mod = (cps || rps);
+    MXG_REQUIRE(kind > MXG_FLT_BANDPASS || mod || d_coef,
+                "constant-parameter lores/hires/bandpass need d_coef from mxg_filter_coeffs_host");
+    if (V == 0 || N == 0) return MXG_OK;
+    int block = tune_get("voice_block");
+    hipStream_t st = resolve_stream(stream);
+    double sr = (double)settings().sampleRate;
+#define MXG_FLT_LAUNCH(K)                                                                        \
+    if (mod)                                                                                     \
+        hipLaunchKernelGGL((filter_kernel<K, true>), grid_for(V, block), dim3(block), 0, st, V, N, \
+                           d_in, d_cutoff, cps, d_res, rps, d_coef, d_st, d_out, sr);            \
+    else                                                                                         \
+        hipLaunchKernelGGL((filter_kernel<K, false>), grid_for(V, block), dim3(block), 0, st, V, N, \
+                           d_in, d_cutoff, cps, d_res, rps, d_coef, d_st, d_out, sr);
+    switch (kind) {
+        case 0: MXG_FLT_LAUNCH(0) break;
+        case 1: MXG_FLT_LAUNCH(1) break;
+        case 2: MXG_FLT_LAUNCH(2) break;
+        case 3: MXG_FLT_LAUNCH(3) break;
+        case 4: MXG_FLT_LAUNCH(4) break;
+    }
+#undef MXG_FLT_LAUNCH
+    return check_hip(hipGetLastError(), "filter_kernel launch");
+}
+
+// Host libm evaluation of C:456-461 / C:489-495 (no device involved).
+int mxg_filter_coeffs_host(int kind, size_t V, const double *h_cutoff, const double *h_res,
+                           double *h_coef) {
+    MXG_REQUIRE(h_cutoff && h_res && h_coef, "null pointer");
+    MXG_REQUIRE(kind >= MXG_FLT_LORES && kind <= MXG_FLT_BANDPASS, "kind has no coefficients");
+    const size_t sr = settings().sampleRate;
+    for (size_t v = 0; v < V; v++) {
+        double cutoff = h_cutoff[v], resonance = h_res[v];
+        if (kind == MXG_FLT_BANDPASS) {
+            if (cutoff > (sr * 0.5)) cutoff = (sr * 0.5);
+            if (resonance >= 1.) resonance = 0.999999;
+            double z = cos(MXG_TWOPI * cutoff / sr);
+            h_coef[v] = (1 - resonance) * (sqrt(resonance * (resonance - 4.0 * pow(z, 2.0) + 2.0) + 1));
+            h_coef[V + v] = 2 * z * resonance;
+            h_coef[2 * V + v] = pow((resonance * -1), 2);
+        } else {
+            if (cutoff < 10) cutoff = 10;
+            if (cutoff > (sr)) cutoff = (sr);
+            if (resonance < 1.) resonance = 1.;
+            double z = cos(MXG_TWOPI * cutoff / sr);
+            h_coef[v] = 2 - 2 * z;
+            h_coef[V + v] = (sqrt(2.0) * sqrt(-pow((z - 1.0), 3.0)) + resonance * (z - 1)) /
+                            (resonance * (z - 1));
+            h_coef[2 * V + v] = 0.0;
+        }
+    }
+    return MXG_OK;
+}
+
+int mxg_env_render(int mode, size_t V, size_t N, const double *d_in, const int32_t *d_trig,
+                   int tpv, const double *d_par, const int64_t *d_holdtime, double *d_dst,
+                   int64_t *d_ist, double *d_out, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (adsr) or 1 (ar)");
+    MXG_REQUIRE(d_trig && d_par && d_holdtime && d_dst && d_ist && d_out, "null device pointer");
+    if (V == 0 || N == 0) return MXG_OK;
+    int block = tune_get("voice_block");
+    hipStream_t st = resolve_stream(stream);
+    if (mode == 0)
+        hipLaunchKernelGGL((env_kernel<0>), grid_for(V, block), dim3(block), 0, st, V, N, d_in,
+                           d_trig, tpv, d_par, d_holdtime, d_dst, d_ist, d_out);
+    else
+        hipLaunchKernelGGL((env_kernel<1>), grid_for(V, block), dim3(block), 0, st, V, N, d_in,
+                           d_trig, tpv, d_par, d_holdtime, d_dst, d_ist, d_out);
+    return check_hip(hipGetLastError(), "env_kernel launch");
+}
+
+// maxiEnv setters, host libm (C:1469-1494).
+double mxg_env_coeff_host(int which, double ms) {
+    const size_t sr = settings().sampleRate;
+    switch (which) {
+        case 0: return 1 - pow(0.01, 1.0 / (ms * sr * 0.001));  // setAttack   C:1480-1482
+        case 1: return pow(0.01, 1.0 / (ms * sr * 0.001));      // setDecay    C:1475-1477
+        case 2: return pow(0.01, 1.0 / (ms * sr * 0.001));      // setRelease  C:1470-1472
+        case 3: return 1.0 / (ms / 1000.0 * sr);                // setAttackMS C:1486-1488
+    }
+    return 0.0;
+}
+
+int mxg_voice_render(int mode, size_t V, size_t N, const double *d_freq, const double *d_cutoff,
+                     const double *d_res, const double *d_coef, const int32_t *d_trig, int tpv,
+                     const double *d_par, const int64_t *d_holdtime, double *d_ost, double *d_fst,
+                     double *d_dst, int64_t *d_ist, double *d_out, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(mode == 0 || mode == 1, "mode must be 0 or 1");
+    MXG_REQUIRE(d_freq && d_trig && d_par && d_holdtime && d_ost && d_fst && d_dst && d_ist && d_out,
+                "null device pointer");
+    MXG_REQUIRE(mode == 1 || d_coef, "mode 0 needs d_coef from mxg_filter_coeffs_host");
+    MXG_REQUIRE(mode == 0 || (d_cutoff && d_res), "mode 1 needs d_cutoff and d_res");
+    if (V == 0 || N == 0) return MXG_OK;
+    int block = tune_get("voice_block");
+    bool nt = tune_get("voice_nt") != 0;
+    hipStream_t st = resolve_stream(stream);
+    double sr = (double)settings().sampleRate;
+#define MXG_VOICE_LAUNCH(M, T)                                                                  \
+    hipLaunchKernelGGL((voice_kernel<M, T>), grid_for(V, block), dim3(block), 0, st, V, N, d_freq, \
+                       d_cutoff, d_res, d_coef, d_trig, tpv, d_par, d_holdtime, d_ost, d_fst,   \
+                       d_dst, d_ist, d_out, sr)
+    if (mode == 0) {
+        if (nt) MXG_VOICE_LAUNCH(0, true); else MXG_VOICE_LAUNCH(0, false);
+    } else {
+        if (nt) MXG_VOICE_LAUNCH(1, true); else MXG_VOICE_LAUNCH(1, false);
+    }
+#undef MXG_VOICE_LAUNCH
+    return check_hip(hipGetLastError(), "voice_kernel launch");
+}
+
+}  // extern "C"

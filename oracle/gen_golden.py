@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""oracle/gen_golden.py -- generate tests/golden/*.npz from the REFERENCE itself.
+
+Runs the unmodified reference (oracle/_ref/libmaxiref.so = /root/reference sources +
+oracle/ref_harness.cpp, g++ -O2 -ffp-contract=off) on small seeded inputs and stores inputs,
+outputs and final state.  The reference ships no golden vectors of its own, so
+these fixtures are what pins both the plain-C oracle and the HIP path.  Only runnable in the
+build container (needs /root/reference); the .npz files and this script are committed.
+
+    python oracle/gen_golden.py        # rewrites tests/golden/*.npz + MANIFEST.json
+"""
+import hashlib
+import json
+import os
+import platform
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import pyoracle  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF_SRC = "/root/reference/src"
+SEED = 0x4D415849  # "MAXI" 
+
+
+def osc_inputs(V):
+    rng = np.random.default_rng(SEED)
+    freq = np.concatenate([[0.2, 20.0, 55.0, 440.0, 86.1328125, 43.06640625, 11025.0, 22050.0],
+                           rng.uniform(0.1, 20000.0, V - 8)])
+    p2 = rng.uniform(0.3, 1.0, V)
+    p1 = p2 * rng.uniform(0.0, 0.9, V)
+    duty = rng.uniform(-0.1, 1.1, V)
+    return freq, p1, p2, duty
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    R = pyoracle.reference()
+    assert R.kind == "reference"
+    R.settings(44100, 2, 1024)
+    files = {}
+
+    # ---- maxiOsc: every waveform, 2 consecutive blocks (state carry) ----------------------
+    V, N = 32, 160
+    freq, p1, p2, duty = osc_inputs(V)
+    names = ["sinewave", "coswave", "phasor", "saw", "triangle", "square", "pulse", "impulse",
+             "sinebuf", "sinebuf4", "sawn", "phasorBetween"]
+    d = dict(freq=freq, p1=p1, p2=p2, duty=duty, N=N)
+    for wf, name in enumerate(names):
+        a, b = (duty, None) if name == "pulse" else (p1, p2)
+        o1, ph, hd = R.osc(wf, freq, N, p1=a, p2=b)
+        o2, ph2, hd2 = R.osc(wf, freq, N, phase=ph, hold=hd, p1=a, p2=b)
+        d["out_" + name] = np.concatenate([o1, o2])
+        d["phase_" + name] = ph2
+        d["hold_" + name] = hd2
+    # audio-rate frequency modulation (fps=1) on sinebuf and saw
+    rng = np.random.default_rng(SEED + 1)
+    fm = freq[None, :] * (1.0 + 0.25 * rng.uniform(-1, 1, (N, V)))
+    d["fm"] = fm
+    for name in ("sinebuf", "saw", "sawn"):
+        o, ph, hd = R.osc(names.index(name), fm, N, per_sample=True)
+        d["fm_out_" + name] = o
+        d["fm_phase_" + name] = ph
+    # known answer recorded in SURVEY.md 8a (a2): sinewave(440), samples 0..3
+    ka, _, _ = R.osc(0, np.array([440.0]), 4)
+    assert [repr(float(x)) for x in ka[:, 0]] == ["0.0", "0.06264832417874368", "0.1250505236945281",
+                                                  "0.18696144082725336"]
+    d["ka_sinewave440"] = ka[:, 0]
+    np.savez_compressed(os.path.join(GOLD, "osc.npz"), **d)
+    files["osc.npz"] = "maxiOsc, 12 waveforms, V=32, 2x160 samples; fm variants; KAT sinewave(440)"
+
+    # ---- maxiFilter ---------------------------------------------------------------------------
+    V, N = 32, 256
+    rng = np.random.default_rng(SEED + 2)
+    x = rng.uniform(-1, 1, (N, V))
+    cutoff = np.concatenate([[5.0, 10.0, 50000.0, 22050.0], rng.uniform(20, 18000, V - 4)])
+    res = np.concatenate([[0.5, 1.0, 30.0, 2.0], rng.uniform(1, 20, V - 4)])
+    bres = rng.uniform(0.05, 1.2, V)
+    lp = rng.uniform(0.0, 1.0, V)
+    d = dict(x=x, cutoff=cutoff, res=res, bres=bres, lp=lp)
+    for kind, name in enumerate(["lores", "hires", "bandpass", "lopass", "hipass"]):
+        c = lp if kind >= 3 else cutoff
+        r = None if kind >= 3 else (bres if kind == 2 else res)
+        o1, st = R.filter(kind, x[:128], c, r)
+        o2, st = R.filter(kind, x[128:], c, r, state=st)
+        d["out_" + name] = np.concatenate([o1, o2])
+        d["state_" + name] = st
+        if kind <= 2:
+            d["coef_" + name] = R.filter_coeffs(kind, c, r)
+    cm = cutoff[None, :] * (1.0 + 0.5 * rng.uniform(-1, 1, (N, V)))
+    d["cutoff_mod"] = cm
+    o, st = R.filter(0, x, cm, res, cps=True)
+    d["out_lores_mod"] = o
+    np.savez_compressed(os.path.join(GOLD, "filter.npz"), **d)
+    files["filter.npz"] = "maxiFilter 5 kinds, V=32, 2x128 samples + per-sample cutoff lores"
+
+    # ---- maxiEnv ---------------------------------------------------------------------------------
+    V, N = 16, 3000
+    rng = np.random.default_rng(SEED + 3)
+    att = np.array([R.env_coeff(0, ms) for ms in np.concatenate([[0.0, 1.0, 10.0], rng.uniform(0.5, 30, V - 3)])])
+    dec = np.array([R.env_coeff(1, ms) for ms in rng.uniform(1, 40, V)])
+    sus = rng.uniform(0.05, 0.9, V)
+    rel = np.array([R.env_coeff(2, ms) for ms in rng.uniform(2, 30, V)])
+    par = np.stack([att, dec, sus, rel])
+    hold = np.concatenate([[1, 1, 0, 5], rng.integers(1, 200, V - 4)]).astype(np.int64)
+    trig = ((np.arange(N) % 1500) < 700).astype(np.int32)
+    trig_v = (rng.uniform(0, 1, (N, V)) < 0.002).astype(np.int32)
+    xin = rng.uniform(-1, 1, (N, V))
+    d = dict(par=par, hold=hold, trig=trig, trig_v=trig_v, xin=xin,
+             setter_ms=np.array([0.0, 1.0, 10.0, 100.0, 500.0, 1000.0, 2000.0]))
+    d["setters"] = np.array([[R.env_coeff(w, ms) for ms in d["setter_ms"]] for w in range(4)])
+    for mode, name in enumerate(["adsr", "ar"]):
+        o, dst, ist = R.env(mode, None, trig, par, hold)
+        d["out_%s_gate" % name], d["dst_%s_gate" % name], d["ist_%s_gate" % name] = o, dst, ist
+        o, dst, ist = R.env(mode, xin, trig_v, par, hold)
+        d["out_%s_pv" % name], d["dst_%s_pv" % name], d["ist_%s_pv" % name] = o, dst, ist
+    np.savez_compressed(os.path.join(GOLD, "env.npz"), **d)
+    files["env.npz"] = "maxiEnv adsr/ar, V=16, 3000 samples, gate + per-voice impulse triggers; setters"
+
+    # ---- fused subtractive voice (config 3, reduced) ----------------------------------------------
+    V, N = 16, 4096
+    v = np.arange(V) * 4096
+    freq = np.minimum(20 + v * 0.30517578125, 5000.0)
+    cutoff = 200 + 4 * freq
+    res = 1.0 + (np.arange(V) % 16)
+    par = np.stack([np.full(V, R.env_coeff(0, 10)), np.full(V, R.env_coeff(1, 100)), np.full(V, 0.5),
+                    np.full(V, R.env_coeff(2, 500))])
+    hold = np.ones(V, np.int64)
+    trig = ((np.arange(N) % 2048) < 1024).astype(np.int32)
+    d = dict(freq=freq, cutoff=cutoff, res=res, par=par, hold=hold, trig=trig)
+    for mode in (0, 1):
+        cu = cutoff if mode == 0 else np.full(V, 10000.0)
+        o, ost, fst, dst, ist = R.voice(mode, freq, cu, res, trig, par, hold)
+        d["out_mode%d" % mode] = o
+        d["ost_mode%d" % mode], d["fst_mode%d" % mode] = ost, fst
+        d["dst_mode%d" % mode], d["ist_mode%d" % mode] = dst, ist
+    d["coef"] = R.filter_coeffs(0, cutoff, res)
+    np.savez_compressed(os.path.join(GOLD, "voice.npz"), **d)
+    files["voice.npz"] = "saw->lores->adsr voice, V=16, 4096 samples, mode A (hoisted) and B (modulated)"
+
+    # ---- maxiMix::stereo mixdown ----------------------------------------------------------------
+    V, N = 96, 64
+    rng = np.random.default_rng(SEED + 4)
+    x = rng.uniform(-1, 1, (N, V))
+    pan = np.concatenate([[-0.5, 0.0, 1.0, 1.5], rng.uniform(0, 1, V - 4)])
+    np.savez_compressed(os.path.join(GOLD, "mix.npz"), x=x, pan=pan, mix=R.mix_stereo(x, pan))
+    files["mix.npz"] = "maxiMix::stereo + sequential voice sum, V=96, 64 samples"
+
+    sha = hashlib.sha256()
+    for f in ("maximilian.cpp", "maximilian.h", "libs/fft.cpp", "libs/maxiFFT.cpp", "libs/maxiMFCC.cpp",
+              "libs/maxiMFCC.h", "libs/maxiGrains.h"):
+        sha.update(open(os.path.join(REF_SRC, f), "rb").read())
+    manifest = {
+        "generator": "oracle/gen_golden.py",
+        "source": "oracle/_ref/libmaxiref.so (unmodified /root/reference sources + oracle/ref_harness.cpp)",
+        "reference_sources_sha256": sha.hexdigest(),
+        "compiler": subprocess.run(["g++", "--version"], capture_output=True, text=True).stdout.splitlines()[0],
+        "flags": "-std=c++17 -O2 -ffp-contract=off -fno-fast-math (no -march=native)",
+        "libc": " ".join(platform.libc_ver()),
+        "seed": hex(SEED),
+        "files": files,
+    }
+    with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+    for k in sorted(os.listdir(GOLD)):
+        print(k, os.path.getsize(os.path.join(GOLD, k)))
+
+
+if __name__ == "__main__":
+    main()

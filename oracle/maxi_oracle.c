@@ -1,0 +1,564 @@
+/* oracle/maxi_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the per-sample DSP hot path of micknoise/Maximilian
+ * (the reference, mounted read-only at /root/reference; never copied).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and
+ * only as the CHECKER -- the product (libmaxigpu.so) never links, loads or falls back
+ * to it.
+ *
+ * PARITY PINNING: the reference's own tests hold no golden vectors / KATs for this
+ * path.  This restatement is therefore pinned against outputs of
+ * the reference itself, run in the build container: (1) oracle/_ref/libmaxiref.so
+ * (the unmodified reference sources + oracle/ref_harness.cpp) is compared with this
+ * file bit-for-bit on seeded inputs in tests/test_oracle_golden.py, and (2) fixtures
+ * generated from _ref by oracle/gen_golden.py are committed under tests/golden/.
+ *
+ * Every function cites the reference lines it follows (C = src/maximilian.cpp,
+ * H = src/maximilian.h, L/ = src/libs/).  Build flags are part of the contract:
+ * -O2 -ffp-contract=off, no -march=native, no -ffast-math (oracle/Makefile).
+ *
+ * Layout convention: banks are rendered sample-major / voice-minor, out[n*V + v];
+ * state is SoA, one array of length V per reference member.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "maxi_oracle_tables.h"
+
+/* H:55-58 */
+#define MX_PI 3.1415926535897932384626433832795
+#define MX_TWOPI 6.283185307179586476925286766559
+
+/* C:53  `float chandiv = 1;`  (promoted to double wherever it multiplies a double) */
+static const float chandiv = 1;
+
+/* C:57-59  maxiSettings statics (size_t!) */
+static size_t g_sampleRate = 44100;
+static size_t g_channels = 2;
+static size_t g_bufferSize = 1024;
+
+/* sineBuffer[i] for i = -1..513 ; transition[i] for i = 0..1001 (guards, see tables.h) */
+#define SINEBUF(i) (MAXI_SINE_TAB[(i) + 1])
+#define TRANSITION(i) (MAXI_TRANS_TAB[(i)])
+
+const char *mxo_kind(void) { return "port"; }
+
+/* H:138-143 maxiSettings::setup */
+void mxo_settings(size_t sr, size_t ch, size_t buf) {
+    g_sampleRate = sr;
+    g_channels = ch;
+    g_bufferSize = buf;
+}
+
+const double *mxo_sine_table(void) { return &MAXI_SINE_TAB[1]; }
+const double *mxo_transition_table(void) { return &MAXI_TRANS_TAB[0]; }
+double mxo_sine_table_guard(void) { return MAXI_SINE_TAB[0]; }
+double mxo_transition_guard(void) { return MAXI_TRANS_TAB[1001]; }
+
+/* ------------------------------------------------------------------------------------
+ * maxiOsc (H:169-215, C:209-373).  State per voice: phase, output.
+ * One call == one sample of one voice; returns the sample.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    double phase, output;
+} osc_t;
+
+/* C:228-235 */
+static double osc_sinewave(osc_t *o, double frequency) {
+    o->output = sin(o->phase * (MX_TWOPI));
+    if (o->phase >= 1.0) o->phase -= 1.0;
+    o->phase += (1. / (g_sampleRate / (frequency)));
+    return o->output;
+}
+/* C:276-283 */
+static double osc_coswave(osc_t *o, double frequency) {
+    o->output = cos(o->phase * (MX_TWOPI));
+    if (o->phase >= 1.0) o->phase -= 1.0;
+    o->phase += (1. / (g_sampleRate / (frequency)));
+    return o->output;
+}
+/* C:285-291 */
+static double osc_phasor(osc_t *o, double frequency) {
+    o->output = o->phase;
+    if (o->phase >= 1.0) o->phase -= 1.0;
+    o->phase += (1. / (g_sampleRate / (frequency)));
+    return o->output;
+}
+/* C:333-340 */
+static double osc_saw(osc_t *o, double frequency) {
+    o->output = o->phase;
+    if (o->phase >= 1.0) o->phase -= 2.0;
+    o->phase += (1. / (g_sampleRate / (frequency))) * 2.0;
+    return o->output;
+}
+/* C:362-373 */
+static double osc_triangle(osc_t *o, double frequency) {
+    if (o->phase >= 1.0) o->phase -= 1.0;
+    o->phase += (1. / (g_sampleRate / (frequency)));
+    if (o->phase <= 0.5) {
+        o->output = (o->phase - 0.25) * 4;
+    } else {
+        o->output = ((1.0 - o->phase) - 0.25) * 4;
+    }
+    return o->output;
+}
+/* C:293-300 : output is HELD when phase == 0.5 exactly */
+static double osc_square(osc_t *o, double frequency) {
+    if (o->phase < 0.5) o->output = -1;
+    if (o->phase > 0.5) o->output = 1;
+    if (o->phase >= 1.0) o->phase -= 1.0;
+    o->phase += (1. / (g_sampleRate / (frequency)));
+    return o->output;
+}
+/* C:302-311 : output is HELD when phase == duty exactly */
+static double osc_pulse(osc_t *o, double frequency, double duty) {
+    if (duty < 0.) duty = 0;
+    if (duty > 1.) duty = 1;
+    if (o->phase >= 1.0) o->phase -= 1.0;
+    o->phase += (1. / (g_sampleRate / (frequency)));
+    if (o->phase < duty) o->output = -1.;
+    if (o->phase > duty) o->output = 1.;
+    return o->output;
+}
+/* C:312-319 : uses a LOCAL `output`, the member is left untouched */
+static double osc_impulse(osc_t *o, double frequency) {
+    if (o->phase >= 1.0) o->phase -= 1.0;
+    double phaseInc = (1. / (g_sampleRate / (frequency)));
+    double output = o->phase < phaseInc ? 1.0 : 0.0;
+    o->phase += phaseInc;
+    return output;
+}
+/* C:321-330 */
+static double osc_phasorBetween(osc_t *o, double frequency, double startphase, double endphase) {
+    o->output = o->phase;
+    if (o->phase < startphase) {
+        o->phase = startphase;
+    }
+    if (o->phase >= endphase) o->phase = startphase;
+    o->phase += ((endphase - startphase) / (g_sampleRate / (frequency)));
+    return o->output;
+}
+/* C:266-274 : wrap at 511 (not 512); table indices offset by +1/+2; (long) truncates
+ * toward zero so phase in (-1,0) indexes 0. */
+static double osc_sinebuf(osc_t *o, double frequency) {
+    double remainder;
+    o->phase += 512. / (g_sampleRate / (frequency * chandiv));
+    if (o->phase >= 511) o->phase -= 512;
+    remainder = o->phase - floor(o->phase);
+    o->output = (double)((1 - remainder) * SINEBUF(1 + (long)o->phase) +
+                         remainder * SINEBUF(2 + (long)o->phase));
+    return o->output;
+}
+/* C:237-264 : 4-point interpolation; index (long)phase-1 is -1 for phase in (-1,1)\{0}
+ * (out of bounds in the reference; our table carries a 0.0 guard there). */
+static double osc_sinebuf4(osc_t *o, double frequency) {
+    double remainder;
+    double a, b, c, d, a1, a2, a3;
+    o->phase += 512. / (g_sampleRate / (frequency));
+    if (o->phase >= 511) o->phase -= 512;
+    remainder = o->phase - floor(o->phase);
+    if (o->phase == 0) {
+        a = SINEBUF((long)512);
+        b = SINEBUF((long)o->phase);
+        c = SINEBUF((long)o->phase + 1);
+        d = SINEBUF((long)o->phase + 2);
+    } else {
+        a = SINEBUF((long)o->phase - 1);
+        b = SINEBUF((long)o->phase);
+        c = SINEBUF((long)o->phase + 1);
+        d = SINEBUF((long)o->phase + 2);
+    }
+    a1 = 0.5f * (c - a);
+    a2 = a - 2.5 * b + 2.f * c - 0.5f * d;
+    a3 = 0.5f * (d - a) + 1.5f * (b - c);
+    o->output = (double)(((a3 * remainder + a2) * remainder + a1) * remainder + b);
+    return o->output;
+}
+/* C:342-359 : band-limited saw through transition[]; index 1001 is read (x remainder 0)
+ * when temp clamps to exactly +0.5 (guard 0.0). */
+static double osc_sawn(osc_t *o, double frequency) {
+    if (o->phase >= 0.5) o->phase -= 1.0;
+    o->phase += (1. / (g_sampleRate / (frequency)));
+    double temp = (8820.22 / frequency) * o->phase;
+    if (temp < -0.5) {
+        temp = -0.5;
+    }
+    if (temp > 0.5) {
+        temp = 0.5;
+    }
+    temp *= 1000.0f;
+    temp += 500.0f;
+    double remainder = temp - floor(temp);
+    o->output = (double)((1.0f - remainder) * TRANSITION((long)temp) +
+                         remainder * TRANSITION(1 + (long)temp)) -
+                o->phase;
+    return o->output;
+}
+
+static double osc_tick(int wf, osc_t *o, double f, double p1, double p2) {
+    switch (wf) {
+        case 0: return osc_sinewave(o, f);
+        case 1: return osc_coswave(o, f);
+        case 2: return osc_phasor(o, f);
+        case 3: return osc_saw(o, f);
+        case 4: return osc_triangle(o, f);
+        case 5: return osc_square(o, f);
+        case 6: return osc_pulse(o, f, p1);
+        case 7: return osc_impulse(o, f);
+        case 8: return osc_sinebuf(o, f);
+        case 9: return osc_sinebuf4(o, f);
+        case 10: return osc_sawn(o, f);
+        case 11: return osc_phasorBetween(o, f, p1, p2);
+    }
+    return 0.0;
+}
+
+int mxo_osc(int wf, size_t V, size_t N, const double *freq, int fps, const double *p1,
+            const double *p2, double *phase, double *outhold, double *out) {
+    if (wf < 0 || wf > 11) return -1;
+    for (size_t v = 0; v < V; v++) {
+        osc_t o = {phase[v], outhold[v]};
+        double a = p1 ? p1[v] : 0.0, b = p2 ? p2[v] : 0.0;
+        for (size_t n = 0; n < N; n++) {
+            double f = fps ? freq[n * V + v] : freq[v];
+            out[n * V + v] = osc_tick(wf, &o, f, a, b);
+        }
+        phase[v] = o.phase;
+        outhold[v] = o.output;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * maxiFilter (H:289-366, C:442-500, ctor C:1517: x,y,z,c = 0; outputs[] treated as 0).
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    double x, y, o0, o1, o2;
+} flt_t;
+
+/* C:457-462 : the coefficient part of lores/hires */
+static void lores_coeffs(double cutoff, double resonance, double *c, double *r) {
+    if (cutoff < 10) cutoff = 10;
+    if (cutoff > (g_sampleRate)) cutoff = (g_sampleRate);
+    if (resonance < 1.) resonance = 1.;
+    double z = cos(MX_TWOPI * cutoff / g_sampleRate);
+    *c = 2 - 2 * z;
+    *r = (sqrt(2.0) * sqrt(-pow((z - 1.0), 3.0)) + resonance * (z - 1)) / (resonance * (z - 1));
+}
+/* C:455-468 */
+static double flt_lores(flt_t *f, double input, double cutoff1, double resonance) {
+    double c, r;
+    lores_coeffs(cutoff1, resonance, &c, &r);
+    f->x = f->x + (input - f->y) * c;
+    f->y = f->y + f->x;
+    f->x = f->x * r;
+    return f->y;
+}
+/* C:471-484 */
+static double flt_hires(flt_t *f, double input, double cutoff1, double resonance) {
+    double c, r;
+    lores_coeffs(cutoff1, resonance, &c, &r);
+    f->x = f->x + (input - f->y) * c;
+    f->y = f->y + f->x;
+    f->x = f->x * r;
+    return input - f->y;
+}
+/* C:487-500 */
+static double flt_bandpass(flt_t *f, double input, double cutoff1, double resonance) {
+    double cutoff = cutoff1;
+    if (cutoff > (g_sampleRate * 0.5)) cutoff = (g_sampleRate * 0.5);
+    if (resonance >= 1.) resonance = 0.999999;
+    double z = cos(MX_TWOPI * cutoff / g_sampleRate);
+    double i0 = (1 - resonance) * (sqrt(resonance * (resonance - 4.0 * pow(z, 2.0) + 2.0) + 1));
+    double i1 = 2 * z * resonance;
+    double i2 = pow((resonance * -1), 2);
+    double output = i0 * input + i1 * f->o1 + i2 * f->o2;
+    f->o2 = f->o1;
+    f->o1 = output;
+    return output;
+}
+/* C:442-446 */
+static double flt_lopass(flt_t *f, double input, double cutoff) {
+    double output = f->o0 + cutoff * (input - f->o0);
+    f->o0 = output;
+    return output;
+}
+/* C:449-453 (sic: stores the high-passed value back into outputs[0]) */
+static double flt_hipass(flt_t *f, double input, double cutoff) {
+    double output = input - (f->o0 + cutoff * (input - f->o0));
+    f->o0 = output;
+    return output;
+}
+
+int mxo_filter(int kind, size_t V, size_t N, const double *in, const double *cutoff, int cps,
+               const double *res, int rps, double *st, double *out) {
+    if (kind < 0 || kind > 4) return -1;
+    for (size_t v = 0; v < V; v++) {
+        flt_t f = {st[0 * V + v], st[1 * V + v], st[2 * V + v], st[3 * V + v], st[4 * V + v]};
+        for (size_t n = 0; n < N; n++) {
+            double x = in[n * V + v];
+            double c = cps ? cutoff[n * V + v] : cutoff[v];
+            double r = res ? (rps ? res[n * V + v] : res[v]) : 0.0;
+            double o = 0;
+            switch (kind) {
+                case 0: o = flt_lores(&f, x, c, r); break;
+                case 1: o = flt_hires(&f, x, c, r); break;
+                case 2: o = flt_bandpass(&f, x, c, r); break;
+                case 3: o = flt_lopass(&f, x, c); break;
+                case 4: o = flt_hipass(&f, x, c); break;
+            }
+            out[n * V + v] = o;
+        }
+        st[0 * V + v] = f.x;
+        st[1 * V + v] = f.y;
+        st[2 * V + v] = f.o0;
+        st[3 * V + v] = f.o1;
+        st[4 * V + v] = f.o2;
+    }
+    return 0;
+}
+
+/* Host-side coefficients of the hoisted path, [3][V]: lores/hires -> c, r, 0 (C:459-461);
+ * bandpass -> inputs[0..2] (C:492-495). */
+void mxo_filter_coeffs(int kind, size_t V, const double *cutoff, const double *res, double *coef) {
+    for (size_t v = 0; v < V; v++) {
+        if (kind == 2) {
+            double cu = cutoff[v], resonance = res[v];
+            if (cu > (g_sampleRate * 0.5)) cu = (g_sampleRate * 0.5);
+            if (resonance >= 1.) resonance = 0.999999;
+            double z = cos(MX_TWOPI * cu / g_sampleRate);
+            coef[v] = (1 - resonance) * (sqrt(resonance * (resonance - 4.0 * pow(z, 2.0) + 2.0) + 1));
+            coef[V + v] = 2 * z * resonance;
+            coef[2 * V + v] = pow((resonance * -1), 2);
+        } else {
+            lores_coeffs(cutoff[v], res[v], &coef[v], &coef[V + v]);
+            coef[2 * V + v] = 0.0;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * maxiEnv (H:888-932, C:1319-1494).  No constructor: all state starts 0, holdtime = 1.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    double attack, decay, sustain, release, amplitude, output;
+    long holdtime, holdcount;
+    int attackphase, decayphase, sustainphase, holdphase, releasephase;
+} env_t;
+
+/* C:1415-1466 (identical body to the 7-argument overload C:1362-1413) */
+static double env_adsr(env_t *e, double input, int trigger) {
+    if (trigger == 1 && e->attackphase != 1 && e->holdphase != 1 && e->decayphase != 1) {
+        e->holdcount = 0;
+        e->decayphase = 0;
+        e->sustainphase = 0;
+        e->releasephase = 0;
+        e->attackphase = 1;
+    }
+    if (e->attackphase == 1) {
+        e->releasephase = 0;
+        e->amplitude += (1 * e->attack);
+        e->output = input * e->amplitude;
+        if (e->amplitude >= 1) {
+            e->amplitude = 1;
+            e->attackphase = 0;
+            e->decayphase = 1;
+        }
+    }
+    if (e->decayphase == 1) {
+        e->output = input * (e->amplitude *= e->decay);
+        if (e->amplitude <= e->sustain) {
+            e->decayphase = 0;
+            e->holdphase = 1;
+        }
+    }
+    if (e->holdcount < e->holdtime && e->holdphase == 1) {
+        e->output = input * e->amplitude;
+        e->holdcount++;
+    }
+    if (e->holdcount >= e->holdtime && trigger == 1) {
+        e->output = input * e->amplitude;
+    }
+    if (e->holdcount >= e->holdtime && trigger != 1) {
+        e->holdphase = 0;
+        e->releasephase = 1;
+    }
+    if (e->releasephase == 1 && e->amplitude > 0.) {
+        e->output = input * (e->amplitude *= e->release);
+    }
+    return e->output;
+}
+/* C:1319-1358 */
+static double env_ar(env_t *e, double input, double attack, double release, long holdtime,
+                     int trigger) {
+    if (trigger == 1 && e->attackphase != 1 && e->holdphase != 1) {
+        e->holdcount = 0;
+        e->releasephase = 0;
+        e->attackphase = 1;
+    }
+    if (e->attackphase == 1) {
+        e->amplitude += (1 * attack);
+        e->output = input * e->amplitude;
+    }
+    if (e->amplitude >= 1) {
+        e->amplitude = 1;
+        e->attackphase = 0;
+        e->holdphase = 1;
+    }
+    if (e->holdcount < holdtime && e->holdphase == 1) {
+        e->output = input;
+        e->holdcount++;
+    }
+    if (e->holdcount == holdtime && trigger == 1) {
+        e->output = input;
+    }
+    if (e->holdcount == holdtime && trigger != 1) {
+        e->holdphase = 0;
+        e->releasephase = 1;
+    }
+    if (e->releasephase == 1 && e->amplitude > 0.) {
+        e->output = input * (e->amplitude *= release);
+    }
+    return e->output;
+}
+
+static void env_load(env_t *e, size_t V, size_t v, const double *par, const int64_t *holdtime,
+                     const double *dst, const int64_t *ist) {
+    e->attack = par[0 * V + v];
+    e->decay = par[1 * V + v];
+    e->sustain = par[2 * V + v];
+    e->release = par[3 * V + v];
+    e->holdtime = (long)holdtime[v];
+    e->amplitude = dst[0 * V + v];
+    e->output = dst[1 * V + v];
+    e->holdcount = (long)ist[0 * V + v];
+    e->attackphase = (int)ist[1 * V + v];
+    e->decayphase = (int)ist[2 * V + v];
+    e->sustainphase = (int)ist[3 * V + v];
+    e->holdphase = (int)ist[4 * V + v];
+    e->releasephase = (int)ist[5 * V + v];
+}
+static void env_store(const env_t *e, size_t V, size_t v, double *dst, int64_t *ist) {
+    dst[0 * V + v] = e->amplitude;
+    dst[1 * V + v] = e->output;
+    ist[0 * V + v] = e->holdcount;
+    ist[1 * V + v] = e->attackphase;
+    ist[2 * V + v] = e->decayphase;
+    ist[3 * V + v] = e->sustainphase;
+    ist[4 * V + v] = e->holdphase;
+    ist[5 * V + v] = e->releasephase;
+}
+
+int mxo_env(int mode, size_t V, size_t N, const double *in, const int32_t *trig, int tpv,
+            const double *par, const int64_t *holdtime, double *dst, int64_t *ist, double *out) {
+    if (mode < 0 || mode > 1) return -1;
+    for (size_t v = 0; v < V; v++) {
+        env_t e;
+        env_load(&e, V, v, par, holdtime, dst, ist);
+        for (size_t n = 0; n < N; n++) {
+            double x = in ? in[n * V + v] : 1.0;
+            int t = tpv ? trig[n * V + v] : trig[n];
+            out[n * V + v] = mode == 0 ? env_adsr(&e, x, t)
+                                       : env_ar(&e, x, e.attack, e.release, e.holdtime, t);
+        }
+        env_store(&e, V, v, dst, ist);
+    }
+    return 0;
+}
+
+/* C:1469-1494 setters.  which: 0 setAttack 1 setDecay 2 setRelease 3 setAttackMS */
+double mxo_env_coeff(int which, double ms) {
+    switch (which) {
+        case 0: return 1 - pow(0.01, 1.0 / (ms * g_sampleRate * 0.001));
+        case 1: return pow(0.01, 1.0 / (ms * g_sampleRate * 0.001));
+        case 2: return pow(0.01, 1.0 / (ms * g_sampleRate * 0.001));
+        case 3: return 1.0 / (ms / 1000.0 * g_sampleRate);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Fused subtractive voice (config 3): composition of the three restatements above in the
+ * call order of cpp/commandline/maximilian_examples/14.monosynth/main.cpp:50-55 (mode 1)
+ * or osc -> filter -> envelope (mode 0).
+ * ------------------------------------------------------------------------------------ */
+int mxo_voice(int mode, size_t V, size_t N, const double *freq, const double *cutoff,
+              const double *res, const int32_t *trig, int tpv, const double *par,
+              const int64_t *holdtime, double *ost, double *fst, double *dst, int64_t *ist,
+              double *out) {
+    if (mode < 0 || mode > 1) return -1;
+    for (size_t v = 0; v < V; v++) {
+        osc_t o = {ost[v], ost[V + v]};
+        flt_t f = {fst[0 * V + v], fst[1 * V + v], fst[2 * V + v], fst[3 * V + v], fst[4 * V + v]};
+        env_t e;
+        env_load(&e, V, v, par, holdtime, dst, ist);
+        for (size_t n = 0; n < N; n++) {
+            int t = tpv ? trig[n * V + v] : trig[n];
+            double r;
+            if (mode == 0) {
+                double s = osc_saw(&o, freq[v]);
+                double y = flt_lores(&f, s, cutoff[v], res[v]);
+                r = env_adsr(&e, y, t);
+            } else {
+                double a = env_adsr(&e, 1.0, t);
+                double s = osc_saw(&o, freq[v]);
+                double y = flt_lores(&f, s, a * cutoff[v], res[v]);
+                r = y * a;
+            }
+            out[n * V + v] = r;
+        }
+        ost[v] = o.phase;
+        ost[V + v] = o.output;
+        fst[0 * V + v] = f.x;
+        fst[1 * V + v] = f.y;
+        fst[2 * V + v] = f.o0;
+        fst[3 * V + v] = f.o1;
+        fst[4 * V + v] = f.o2;
+        env_store(&e, V, v, dst, ist);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * maxiMix::stereo (C:503-509) + the user-side running sum over voices.
+ * ------------------------------------------------------------------------------------ */
+int mxo_mix_stereo(size_t V, size_t N, const double *in, const double *pan, double *mix) {
+    for (size_t n = 0; n < N; n++) {
+        double l = 0, r = 0;
+        for (size_t v = 0; v < V; v++) {
+            double x = pan[v];
+            if (x > 1) x = 1;
+            if (x < 0) x = 0;
+            double input = in[n * V + v];
+            l += input * sqrt(1.0 - x);
+            r += input * sqrt(x);
+        }
+        mix[2 * n] = l;
+        mix[2 * n + 1] = r;
+    }
+    return 0;
+}
+
+/* CPU-baseline timer (single thread only in the C port; the reference harness has the
+ * threaded one).  Returns seconds for N samples x V voices of waveform wf. */
+#include <time.h>
+double mxo_time_osc(int wf, size_t V, size_t N, const double *freq, int threads, double *sink) {
+    (void)threads;
+    osc_t *bank = (osc_t *)calloc(V, sizeof(osc_t));
+    double *row = (double *)malloc(V * sizeof(double));
+    struct timespec t0, t1;
+    double a = 0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (size_t n = 0; n < N; n++) {
+        for (size_t v = 0; v < V; v++) row[v] = osc_tick(wf, &bank[v], freq[v], 0.5, 1.0);
+        a += row[n % V];
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (sink) *sink = a;
+    free(bank);
+    free(row);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -1,0 +1,172 @@
+"""oracle/pyoracle.py -- ctypes driver for the two CPU checkers.  TEST INFRASTRUCTURE ONLY.
+
+May be imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+(never by maximilian_amd/).  Both libraries export the same mxo_* symbols:
+
+    port()       oracle/liboracle.so        plain-C restatement (oracle/maxi_oracle.c)
+    reference()  oracle/_ref/libmaxiref.so  the unmodified reference + oracle/ref_harness.cpp
+                                            (prebuilt in the build container; may be absent)
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_PATH = os.path.join(HERE, "liboracle.so")
+REF_PATH = os.path.join(HERE, "_ref", "libmaxiref.so")
+
+_SIGS = {
+    "mxo_kind": (c_char_p, []),
+    "mxo_settings": (None, [c_size_t, c_size_t, c_size_t]),
+    "mxo_sine_table_guard": (c_double, []),
+    "mxo_transition_guard": (c_double, []),
+    "mxo_osc": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                        c_void_p, c_void_p]),
+    "mxo_filter": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                           c_void_p, c_void_p]),
+    "mxo_filter_coeffs": (None, [c_int, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "mxo_env": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                        c_void_p, c_void_p, c_void_p]),
+    "mxo_env_coeff": (c_double, [c_int, c_double]),
+    "mxo_voice": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxo_mix_stereo": (c_int, [c_size_t, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "mxo_time_osc": (c_double, [c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p]),
+}
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, np.float64)
+    return a if shape is None else np.ascontiguousarray(np.broadcast_to(a, shape))
+
+
+class Oracle:
+    """Stateless-call wrapper: state arrays are passed in, updated copies are returned."""
+
+    def __init__(self, path):
+        self.path = path
+        self.L = ctypes.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            if not hasattr(self.L, name):
+                continue  # later-added families are checked where used
+            fn = getattr(self.L, name)
+            fn.restype = res
+            fn.argtypes = args
+        self.kind = self.L.mxo_kind().decode()
+
+    def settings(self, sr=44100, ch=2, buf=1024):
+        self.L.mxo_settings(sr, ch, buf)
+
+    # -- maxiOsc ------------------------------------------------------------------------
+    def osc(self, wf, freq, N, phase=None, hold=None, p1=None, p2=None, per_sample=False):
+        freq = np.ascontiguousarray(freq, np.float64)
+        V = freq.shape[-1]
+        phase = np.zeros(V) if phase is None else _f64(phase, (V,)).copy()
+        hold = np.zeros(V) if hold is None else _f64(hold, (V,)).copy()
+        p1 = np.zeros(V) if p1 is None else _f64(p1, (V,))
+        p2 = np.zeros(V) if p2 is None else _f64(p2, (V,))
+        out = np.empty((N, V))
+        rc = self.L.mxo_osc(wf, V, N, _p(freq), int(per_sample), _p(p1), _p(p2), _p(phase), _p(hold),
+                            _p(out))
+        assert rc == 0
+        return out, phase, hold
+
+    # -- maxiFilter -----------------------------------------------------------------------
+    def filter(self, kind, x, cutoff, res=None, state=None, cps=False, rps=False):
+        x = _f64(x)
+        N, V = x.shape
+        cutoff = _f64(cutoff, (N, V) if cps else (V,))
+        r = None if res is None else _f64(res, (N, V) if rps else (V,))
+        st = np.zeros((5, V)) if state is None else _f64(state).copy()
+        out = np.empty((N, V))
+        rc = self.L.mxo_filter(kind, V, N, _p(x), _p(cutoff), int(cps), _p(r), int(rps), _p(st), _p(out))
+        assert rc == 0
+        return out, st
+
+    def filter_coeffs(self, kind, cutoff, res):
+        cutoff = _f64(cutoff)
+        res = _f64(res, cutoff.shape)
+        coef = np.zeros((3, cutoff.size))
+        self.L.mxo_filter_coeffs(kind, cutoff.size, _p(cutoff), _p(res), _p(coef))
+        return coef
+
+    # -- maxiEnv ----------------------------------------------------------------------------
+    def env_coeff(self, which, ms):
+        return self.L.mxo_env_coeff(which, float(ms))
+
+    def env(self, mode, x, trig, par, holdtime, dstate=None, istate=None, N=None):
+        par = _f64(par)
+        V = par.shape[1]
+        trig = np.ascontiguousarray(trig, np.int32)
+        N = trig.shape[0] if N is None else N
+        x = None if x is None else _f64(x, (N, V))
+        holdtime = np.ascontiguousarray(np.broadcast_to(np.asarray(holdtime, np.int64), (V,)))
+        dst = np.zeros((2, V)) if dstate is None else _f64(dstate).copy()
+        ist = np.zeros((6, V), np.int64) if istate is None else np.ascontiguousarray(istate, np.int64).copy()
+        out = np.empty((N, V))
+        rc = self.L.mxo_env(mode, V, N, _p(x), _p(trig), int(trig.ndim == 2), _p(par), _p(holdtime),
+                            _p(dst), _p(ist), _p(out))
+        assert rc == 0
+        return out, dst, ist
+
+    # -- fused subtractive voice ---------------------------------------------------------------
+    def voice(self, mode, freq, cutoff, res, trig, par, holdtime, ost=None, fst=None, dstate=None,
+              istate=None):
+        freq = _f64(freq)
+        V = freq.size
+        cutoff, res, par = _f64(cutoff, (V,)), _f64(res, (V,)), _f64(par)
+        trig = np.ascontiguousarray(trig, np.int32)
+        N = trig.shape[0]
+        holdtime = np.ascontiguousarray(np.broadcast_to(np.asarray(holdtime, np.int64), (V,)))
+        ost = np.zeros((2, V)) if ost is None else _f64(ost).copy()
+        fst = np.zeros((5, V)) if fst is None else _f64(fst).copy()
+        dst = np.zeros((2, V)) if dstate is None else _f64(dstate).copy()
+        ist = np.zeros((6, V), np.int64) if istate is None else np.ascontiguousarray(istate, np.int64).copy()
+        out = np.empty((N, V))
+        rc = self.L.mxo_voice(mode, V, N, _p(freq), _p(cutoff), _p(res), _p(trig), int(trig.ndim == 2),
+                              _p(par), _p(holdtime), _p(ost), _p(fst), _p(dst), _p(ist), _p(out))
+        assert rc == 0
+        return out, ost, fst, dst, ist
+
+    # -- maxiMix ------------------------------------------------------------------------------
+    def mix_stereo(self, x, pan):
+        x = _f64(x)
+        N, V = x.shape
+        pan = _f64(pan, (V,))
+        mix = np.empty((N, 2))
+        rc = self.L.mxo_mix_stereo(V, N, _p(x), _p(pan), _p(mix))
+        assert rc == 0
+        return mix
+
+    # -- CPU baseline timer -----------------------------------------------------------------------
+    def time_osc(self, wf, freq, N, threads=1):
+        freq = _f64(freq)
+        sink = ctypes.c_double(0)
+        return self.L.mxo_time_osc(wf, freq.size, N, _p(freq), threads, ctypes.addressof(sink))
+
+
+_cache = {}
+
+
+def port():
+    if "port" not in _cache:
+        if not os.path.exists(PORT_PATH):
+            raise FileNotFoundError("%s missing: run `make -C oracle liboracle.so`" % PORT_PATH)
+        _cache["port"] = Oracle(PORT_PATH)
+    return _cache["port"]
+
+
+def have_reference():
+    return os.path.exists(REF_PATH)
+
+
+def reference():
+    if "ref" not in _cache:
+        _cache["ref"] = Oracle(REF_PATH)
+    return _cache["ref"]

@@ -1,0 +1,362 @@
+// oracle/ref_harness.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Thin extern "C" driver around the UNMODIFIED reference classes.  It is compiled
+// together with the reference's own sources where they lie under /root/reference
+// (see oracle/Makefile, target _ref/libmaxiref.so); no reference source is copied
+// into this repository.  Built with -fno-access-control so the harness can seed
+// and read back the classes' private state (phase, x, y, amplitude ...), which is
+// how block-to-block state carry is compared against the HIP banks.
+//
+// Every entry point renders a *bank* the way a user's play() would: for each
+// sample n, for each voice v, call the reference's per-sample method once
+// (loop order of cpp/commandline/maximilian_examples/15.polysynth/main.cpp:54-70).
+// Output layout is sample-major / voice-minor: out[n*V + v].
+//
+// The same symbol names (mxo_*) are exported by oracle/maxi_oracle.c (the plain-C
+// restatement), so tests drive both through one ctypes signature table.
+#include "maximilian.h"
+#include "libs/maxiFFT.h"
+#include "libs/maxiMFCC.h"
+#include "libs/maxiGrains.h"
+
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include <chrono>
+
+extern double sineBuffer[514];
+extern double transition[1001];
+
+namespace {
+inline double fq(const double *freq, int fps, size_t n, size_t v, size_t V) {
+    return fps ? freq[n * V + v] : freq[v];
+}
+}  // namespace
+
+extern "C" {
+
+const char *mxo_kind(void) { return "reference"; }
+
+void mxo_settings(size_t sr, size_t ch, size_t buf) { maxiSettings::setup(sr, ch, buf); }
+
+// Raw tables of the reference (src/maximilian.cpp:63, :67-200), for oracle/gen_tables.py.
+const double *mxo_sine_table(void) { return sineBuffer; }
+const double *mxo_transition_table(void) { return transition; }
+// The two out-of-bounds neighbours the reference reads (sinebuf4 -> sineBuffer[-1],
+// sawn -> transition[1001]); exported so the tests can assert what this build holds.
+double mxo_sine_table_guard(void) { return (&sineBuffer[0])[-1]; }
+double mxo_transition_guard(void) { return (&transition[0])[1001]; }
+
+// ---- maxiOsc bank (src/maximilian.cpp:209-373) -------------------------------------
+// wf: 0 sinewave 1 coswave 2 phasor 3 saw 4 triangle 5 square 6 pulse 7 impulse
+//     8 sinebuf 9 sinebuf4 10 sawn 11 phasorBetween
+int mxo_osc(int wf, size_t V, size_t N, const double *freq, int fps, const double *p1,
+            const double *p2, double *phase, double *outhold, double *out) {
+    std::vector<maxiOsc> bank(V);
+    for (size_t v = 0; v < V; v++) {
+        bank[v].phase = phase[v];
+        bank[v].output = outhold[v];
+    }
+    for (size_t n = 0; n < N; n++) {
+        double *row = out + n * V;
+        for (size_t v = 0; v < V; v++) {
+            maxiOsc &o = bank[v];
+            double f = fq(freq, fps, n, v, V);
+            double r;
+            switch (wf) {
+                case 0: r = o.sinewave(f); break;
+                case 1: r = o.coswave(f); break;
+                case 2: r = o.phasor(f); break;
+                case 3: r = o.saw(f); break;
+                case 4: r = o.triangle(f); break;
+                case 5: r = o.square(f); break;
+                case 6: r = o.pulse(f, p1[v]); break;
+                case 7: r = o.impulse(f); break;
+                case 8: r = o.sinebuf(f); break;
+                case 9: r = o.sinebuf4(f); break;
+                case 10: r = o.sawn(f); break;
+                case 11: r = o.phasorBetween(f, p1[v], p2[v]); break;
+                default: return -1;
+            }
+            row[v] = r;
+        }
+    }
+    for (size_t v = 0; v < V; v++) {
+        phase[v] = bank[v].phase;
+        outhold[v] = bank[v].output;
+    }
+    return 0;
+}
+
+// ---- maxiFilter bank (src/maximilian.cpp:442-500) ----------------------------------
+// kind: 0 lores 1 hires 2 bandpass 3 lopass 4 hipass.  st = [5][V]: x, y, outputs[0..2]
+int mxo_filter(int kind, size_t V, size_t N, const double *in, const double *cutoff, int cps,
+               const double *res, int rps, double *st, double *out) {
+    std::vector<maxiFilter> bank(V);
+    for (size_t v = 0; v < V; v++) {
+        maxiFilter &f = bank[v];
+        f.x = st[0 * V + v];
+        f.y = st[1 * V + v];
+        f.outputs[0] = st[2 * V + v];
+        f.outputs[1] = st[3 * V + v];
+        f.outputs[2] = st[4 * V + v];
+    }
+    for (size_t n = 0; n < N; n++) {
+        for (size_t v = 0; v < V; v++) {
+            maxiFilter &f = bank[v];
+            double x = in[n * V + v];
+            double c = cps ? cutoff[n * V + v] : cutoff[v];
+            double r = res ? (rps ? res[n * V + v] : res[v]) : 0.0;
+            double o;
+            switch (kind) {
+                case 0: o = f.lores(x, c, r); break;
+                case 1: o = f.hires(x, c, r); break;
+                case 2: o = f.bandpass(x, c, r); break;
+                case 3: o = f.lopass(x, c); break;
+                case 4: o = f.hipass(x, c); break;
+                default: return -1;
+            }
+            out[n * V + v] = o;
+        }
+    }
+    for (size_t v = 0; v < V; v++) {
+        maxiFilter &f = bank[v];
+        st[0 * V + v] = f.x;
+        st[1 * V + v] = f.y;
+        st[2 * V + v] = f.outputs[0];
+        st[3 * V + v] = f.outputs[1];
+        st[4 * V + v] = f.outputs[2];
+    }
+    return 0;
+}
+
+// The coefficients the hoisted (block-constant) lores/hires/bandpass path uploads: obtained by
+// running the reference filter once on a scratch object and reading back its members
+// (lores/hires: c and r re-derived exactly as C:459-461; bandpass: inputs[0..2], C:492-495).
+// coef = [3][V].
+void mxo_filter_coeffs(int kind, size_t V, const double *cutoff, const double *res, double *coef) {
+    for (size_t v = 0; v < V; v++) {
+        if (kind == 2) {
+            maxiFilter f;
+            f.outputs[1] = f.outputs[2] = 0;
+            f.bandpass(0.0, cutoff[v], res[v]);
+            coef[v] = f.inputs[0];
+            coef[V + v] = f.inputs[1];
+            coef[2 * V + v] = f.inputs[2];
+        } else {
+            double cut = cutoff[v], resonance = res[v];
+            if (cut < 10) cut = 10;
+            if (cut > (maxiSettings::sampleRate)) cut = (maxiSettings::sampleRate);
+            if (resonance < 1.) resonance = 1.;
+            double z = cos(TWOPI * cut / maxiSettings::sampleRate);
+            coef[v] = 2 - 2 * z;
+            coef[V + v] = (sqrt(2.0) * sqrt(-pow((z - 1.0), 3.0)) + resonance * (z - 1)) /
+                          (resonance * (z - 1));
+            coef[2 * V + v] = 0.0;
+            // cross-check against the member the reference itself stores (c, H:303)
+            maxiFilter f;
+            f.lores(0.0, cutoff[v], res[v]);
+            if (f.c != coef[v]) coef[v] = NAN;
+        }
+    }
+}
+
+// ---- maxiEnv bank (src/maximilian.cpp:1319-1494) -----------------------------------
+// par = [4][V]: attack, decay, sustain, release (as the setters would have stored them)
+// dst = [2][V]: amplitude, output.   ist = [6][V]: holdcount, attackphase, decayphase,
+// sustainphase, holdphase, releasephase.  trig: [N] (tpv=0) or [N][V] (tpv=1).
+// in == NULL -> constant 1.0 input (examples 14/15 drive adsr(1., trigger)).
+// mode 0: adsr   mode 1: ar (decay/sustain ignored)
+int mxo_env(int mode, size_t V, size_t N, const double *in, const int32_t *trig, int tpv,
+            const double *par, const int64_t *holdtime, double *dst, int64_t *ist, double *out) {
+    std::vector<maxiEnv> bank(V);
+    for (size_t v = 0; v < V; v++) {
+        maxiEnv &e = bank[v];
+        e.attack = par[0 * V + v];
+        e.decay = par[1 * V + v];
+        e.sustain = par[2 * V + v];
+        e.release = par[3 * V + v];
+        e.holdtime = holdtime[v];
+        e.amplitude = dst[0 * V + v];
+        e.output = dst[1 * V + v];
+        e.holdcount = ist[0 * V + v];
+        e.attackphase = (int)ist[1 * V + v];
+        e.decayphase = (int)ist[2 * V + v];
+        e.sustainphase = (int)ist[3 * V + v];
+        e.holdphase = (int)ist[4 * V + v];
+        e.releasephase = (int)ist[5 * V + v];
+    }
+    for (size_t n = 0; n < N; n++) {
+        for (size_t v = 0; v < V; v++) {
+            maxiEnv &e = bank[v];
+            double x = in ? in[n * V + v] : 1.0;
+            int t = tpv ? trig[n * V + v] : trig[n];
+            double o;
+            if (mode == 0)
+                o = e.adsr(x, t);
+            else
+                o = e.ar(x, e.attack, e.release, e.holdtime, t);
+            out[n * V + v] = o;
+        }
+    }
+    for (size_t v = 0; v < V; v++) {
+        maxiEnv &e = bank[v];
+        dst[0 * V + v] = e.amplitude;
+        dst[1 * V + v] = e.output;
+        ist[0 * V + v] = e.holdcount;
+        ist[1 * V + v] = e.attackphase;
+        ist[2 * V + v] = e.decayphase;
+        ist[3 * V + v] = e.sustainphase;
+        ist[4 * V + v] = e.holdphase;
+        ist[5 * V + v] = e.releasephase;
+    }
+    return 0;
+}
+
+// maxiEnv setters (src/maximilian.cpp:1469-1494): ms -> stored coefficient.
+// which: 0 setAttack 1 setDecay 2 setRelease 3 setAttackMS
+double mxo_env_coeff(int which, double ms) {
+    maxiEnv e{};
+    switch (which) {
+        case 0: e.setAttack(ms); return e.attack;
+        case 1: e.setDecay(ms); return e.decay;
+        case 2: e.setRelease(ms); return e.release;
+        case 3: e.setAttackMS(ms); return e.attack;
+    }
+    return 0;
+}
+
+// ---- fused subtractive voice (config 3; shape of examples 14/15) --------------------
+// mode 0 (A): out = adsr( lores( saw(freq), cutoff, res ), trig )
+// mode 1 (B, 14.monosynth/main.cpp:50-55): e = adsr(1., trig);
+//            out = lores( saw(freq), e*cutoff, res ) * e          (cutoff acts as the scale)
+// ost=[2][V] osc phase/output, fst=[5][V] filter, env state as mxo_env.
+int mxo_voice(int mode, size_t V, size_t N, const double *freq, const double *cutoff,
+              const double *res, const int32_t *trig, int tpv, const double *par,
+              const int64_t *holdtime, double *ost, double *fst, double *dst, int64_t *ist,
+              double *out) {
+    std::vector<maxiOsc> osc(V);
+    std::vector<maxiFilter> flt(V);
+    std::vector<maxiEnv> env(V);
+    for (size_t v = 0; v < V; v++) {
+        osc[v].phase = ost[v];
+        osc[v].output = ost[V + v];
+        maxiFilter &f = flt[v];
+        f.x = fst[0 * V + v];
+        f.y = fst[1 * V + v];
+        f.outputs[0] = fst[2 * V + v];
+        f.outputs[1] = fst[3 * V + v];
+        f.outputs[2] = fst[4 * V + v];
+        maxiEnv &e = env[v];
+        e.attack = par[0 * V + v];
+        e.decay = par[1 * V + v];
+        e.sustain = par[2 * V + v];
+        e.release = par[3 * V + v];
+        e.holdtime = holdtime[v];
+        e.amplitude = dst[0 * V + v];
+        e.output = dst[1 * V + v];
+        e.holdcount = ist[0 * V + v];
+        e.attackphase = (int)ist[1 * V + v];
+        e.decayphase = (int)ist[2 * V + v];
+        e.sustainphase = (int)ist[3 * V + v];
+        e.holdphase = (int)ist[4 * V + v];
+        e.releasephase = (int)ist[5 * V + v];
+    }
+    for (size_t n = 0; n < N; n++) {
+        for (size_t v = 0; v < V; v++) {
+            int t = tpv ? trig[n * V + v] : trig[n];
+            double o;
+            if (mode == 0) {
+                double s = osc[v].saw(freq[v]);
+                double f = flt[v].lores(s, cutoff[v], res[v]);
+                o = env[v].adsr(f, t);
+            } else {
+                double e = env[v].adsr(1.0, t);
+                double s = osc[v].saw(freq[v]);
+                double f = flt[v].lores(s, e * cutoff[v], res[v]);
+                o = f * e;
+            }
+            out[n * V + v] = o;
+        }
+    }
+    for (size_t v = 0; v < V; v++) {
+        ost[v] = osc[v].phase;
+        ost[V + v] = osc[v].output;
+        maxiFilter &f = flt[v];
+        fst[0 * V + v] = f.x;
+        fst[1 * V + v] = f.y;
+        fst[2 * V + v] = f.outputs[0];
+        fst[3 * V + v] = f.outputs[1];
+        fst[4 * V + v] = f.outputs[2];
+        maxiEnv &e = env[v];
+        dst[0 * V + v] = e.amplitude;
+        dst[1 * V + v] = e.output;
+        ist[0 * V + v] = e.holdcount;
+        ist[1 * V + v] = e.attackphase;
+        ist[2 * V + v] = e.decayphase;
+        ist[3 * V + v] = e.sustainphase;
+        ist[4 * V + v] = e.holdphase;
+        ist[5 * V + v] = e.releasephase;
+    }
+    return 0;
+}
+
+// ---- maxiMix::stereo + user-side sum over voices (src/maximilian.cpp:503-509) --------
+// mix[n][0..1] = sum_v (in[n][v]*sqrt(1-x_v), in[n][v]*sqrt(x_v)), summed in voice
+// order exactly as a play() loop would (15.polysynth/main.cpp:67 pattern).
+int mxo_mix_stereo(size_t V, size_t N, const double *in, const double *pan, double *mix) {
+    maxiMix m;
+    std::vector<double> two(2);
+    for (size_t n = 0; n < N; n++) {
+        double l = 0, r = 0;
+        for (size_t v = 0; v < V; v++) {
+            m.stereo(in[n * V + v], two, pan[v]);
+            l += two[0];
+            r += two[1];
+        }
+        mix[2 * n] = l;
+        mix[2 * n + 1] = r;
+    }
+    return 0;
+}
+
+// ---- CPU baseline timer: sinebuf bank sharded over host threads ----------------------
+// Renders N samples x V voices with maxiOsc::sinebuf, voices split in contiguous
+// ranges over `threads` std::threads; returns seconds (steady clock, render loop only).
+double mxo_time_osc(int wf, size_t V, size_t N, const double *freq, int threads, double *sink) {
+    if (threads < 1) threads = 1;
+    std::vector<std::thread> pool;
+    std::vector<double> acc(threads, 0.0);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < threads; t++) {
+        pool.emplace_back([&, t]() {
+            size_t v0 = V * t / threads, v1 = V * (t + 1) / threads, nv = v1 - v0;
+            std::vector<maxiOsc> bank(nv);
+            std::vector<double> row(nv);
+            double a = 0;
+            for (size_t n = 0; n < N; n++) {
+                for (size_t v = 0; v < nv; v++) {
+                    double r;
+                    switch (wf) {
+                        case 9: r = bank[v].sinebuf4(freq[v0 + v]); break;
+                        case 3: r = bank[v].saw(freq[v0 + v]); break;
+                        case 0: r = bank[v].sinewave(freq[v0 + v]); break;
+                        default: r = bank[v].sinebuf(freq[v0 + v]); break;
+                    }
+                    row[v] = r;
+                }
+                a += row[n % nv];
+            }
+            acc[t] = a;
+        });
+    }
+    for (auto &th : pool) th.join();
+    auto t1 = std::chrono::steady_clock::now();
+    double s = 0;
+    for (double a : acc) s += a;
+    if (sink) *sink = s;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+}  // extern "C"

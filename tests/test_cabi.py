@@ -1,0 +1,88 @@
+"""CPU tests (-m "not gpu"): the C-ABI library loads, exports every symbol include/maxigpu.h
+declares, the host-only entry points agree with the oracle, and compute calls fail LOUDLY
+(no CPU fallback) when no HIP device is present."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_bits_equal
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "maxigpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(mxg_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_exported(port):
+    import maximilian_amd as m
+    names = _declared_symbols()
+    assert len(names) >= 25
+    L = ctypes.CDLL(m.LIB_PATH)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    # the Python binding table covers exactly the header
+    assert sorted(m._lib.SIGNATURES) == names
+
+
+def test_product_does_not_touch_oracle():
+    # no file of the product package may reference the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "maximilian_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "liboracle" not in txt and "pyoracle" not in txt and "libmaxiref" not in txt, f
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read().replace("oracle/maxi_oracle.c", "")
+
+
+def test_host_coefficients_match_oracle(port):
+    import maximilian_amd as m
+    from maximilian_amd.banks import filter_coeffs
+    m.lib().mxg_settings(44100, 2, 1024)
+    rng = np.random.default_rng(3)
+    cutoff = np.concatenate([[1.0, 10.0, 44100.0, 1e6], rng.uniform(5, 30000, 500)])
+    res = np.concatenate([[0.0, 1.0, 1.0, 50.0], rng.uniform(0.1, 30, 500)])
+    for kind in (0, 1):
+        assert_bits_equal(filter_coeffs(kind, cutoff, res), port.filter_coeffs(kind, cutoff, res))
+    bres = rng.uniform(0.0, 1.5, cutoff.size)
+    assert_bits_equal(filter_coeffs(2, cutoff, bres), port.filter_coeffs(2, cutoff, bres))
+    f = m.lib().mxg_env_coeff_host
+    for which in range(4):
+        for ms in (0.0, 0.5, 1.0, 10.0, 200.0, 1000.0, 2000.0):
+            a, b = f(which, ms), port.env_coeff(which, ms)
+            assert a == b or (np.isnan(a) and np.isnan(b)) or (np.isinf(a) and np.isinf(b) and a == b), (which, ms)
+
+
+def test_settings_and_tune_validation(port):
+    import maximilian_amd as m
+    L = m.lib()
+    assert L.mxg_settings(0, 2, 1024) < 0
+    assert L.mxg_settings(48000, 2, 512) == 0 and L.mxg_sample_rate() == 48000
+    assert L.mxg_settings(44100, 2, 1024) == 0
+    assert L.mxg_tune(b"no_such_key", 1) < 0
+    assert L.mxg_tune(b"osc_vpl", 3) < 0
+    prev = L.mxg_tune(b"osc_vpl", 1)
+    assert prev in (1, 2)
+    assert L.mxg_tune(b"osc_vpl", prev) == 1
+    assert L.mxg_tune(b"osc_block", 100) < 0  # not a multiple of 64
+    assert b"mxg_tune" in L.mxg_last_error()
+
+
+def test_compute_fails_loudly_without_gpu(port):
+    import maximilian_amd as m
+    L = m.lib()
+    if L.mxg_init(-1) == 0:
+        pytest.skip("a HIP device is visible here")
+    assert L.mxg_init(-1) == -2  # MXG_ERR_NO_DEVICE
+    assert b"no CPU fallback" in L.mxg_last_error()
+    with pytest.raises(m.MaxiGpuError):
+        m.maxiOscBank(8)
+    # raw entry point with dummy pointers: must refuse, not compute
+    z = np.zeros(8)
+    rc = L.mxg_osc_render(8, 8, 8, z.ctypes.data, 0, None, None, z.ctypes.data, z.ctypes.data,
+                          z.ctypes.data, None)
+    assert rc == -2

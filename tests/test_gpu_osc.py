@@ -1,0 +1,142 @@
+"""GPU parity (-m gpu): maxiOsc bank through the C-ABI vs the oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+OSC = ["sinewave", "coswave", "phasor", "saw", "triangle", "square", "pulse", "impulse",
+       "sinebuf", "sinebuf4", "sawn", "phasorBetween"]
+EXACT = [w for w in range(12) if w not in (0, 1)]  # everything but sinewave/coswave is bit-exact
+# sinewave/coswave: device sin/cos vs glibc sin/cos of the same rounded argument
+TRIG_MAX_ULP = 1
+
+
+def _render(mx, wf, freq, N, blocks=1, phase0=None, p1=None, p2=None, per_sample=False):
+    V = freq.shape[-1]
+    bank = mx.maxiOscBank(V)
+    if phase0 is not None:
+        bank.phaseReset(phase0)
+    outs = []
+    for b in range(blocks):
+        f = freq[b * N:(b + 1) * N] if per_sample else freq
+        outs.append(bank.render(wf, f, N, p1=p1, p2=p2, per_sample=per_sample).numpy())
+    return np.concatenate(outs), bank.phase.numpy(), bank.output.numpy()
+
+
+@pytest.mark.parametrize("wf", range(12))
+def test_osc_golden(mx, golden, wf):
+    g = golden("osc.npz")
+    name = OSC[wf]
+    N = int(g["N"])
+    a, b = (g["duty"], None) if name == "pulse" else (g["p1"], g["p2"])
+    out, ph, hd = _render(mx, wf, g["freq"], N, blocks=2, p1=a, p2=b)
+    if wf in EXACT:
+        assert_bits_equal(out, g["out_" + name], name)
+        assert_bits_equal(ph, g["phase_" + name], name + " phase")
+        assert_bits_equal(hd, g["hold_" + name], name + " hold")
+    else:
+        assert ulp_diff(out, g["out_" + name]).max() <= TRIG_MAX_ULP or \
+            np.abs(out - g["out_" + name]).max() <= 2.3e-16
+        assert_bits_equal(ph, g["phase_" + name], name + " phase")
+
+
+def test_kat_sinewave_440(mx, golden):
+    out, _, _ = _render(mx, 0, np.array([440.0]), 4)
+    exp = golden("osc.npz")["ka_sinewave440"]
+    assert np.abs(out[:, 0] - exp).max() <= 2.3e-16
+
+
+@pytest.mark.parametrize("name", ["sinebuf", "saw", "sawn"])
+def test_osc_fm_golden(mx, golden, name):
+    g = golden("osc.npz")
+    out, ph, _ = _render(mx, OSC.index(name), g["fm"], int(g["N"]), per_sample=True)
+    assert_bits_equal(out, g["fm_out_" + name], name)
+    assert_bits_equal(ph, g["fm_phase_" + name], name)
+
+
+@pytest.mark.parametrize("wf", EXACT)
+@pytest.mark.parametrize("V,N,blocks", [(1, 7, 3), (63, 33, 2), (64, 512, 2), (130, 100, 4), (1000, 257, 2)])
+def test_osc_vs_oracle_state_carry(mx, port, wf, V, N, blocks):
+    rng = np.random.default_rng(1000 * wf + V)
+    freq = rng.uniform(0.05, 21000, V)
+    p2 = rng.uniform(0.2, 1.0, V)
+    p1 = rng.uniform(-0.2, 1.2, V) if wf == 6 else p2 * rng.uniform(0, 0.95, V)
+    ph0 = rng.uniform(0, 500, V) if wf in (8, 9) else rng.uniform(0, 1, V)
+    out, ph, hd = _render(mx, wf, freq, N, blocks=blocks, phase0=ph0, p1=p1, p2=p2)
+    eo, eph, ehd = port.osc(wf, freq, N * blocks, phase=ph0, p1=p1, p2=p2)
+    assert_bits_equal(out, eo, OSC[wf])
+    assert_bits_equal(ph, eph, OSC[wf] + " phase")
+    assert_bits_equal(hd, ehd, OSC[wf] + " hold")
+
+
+@pytest.mark.parametrize("wf", [0, 1])
+def test_trig_osc_ulp(mx, port, wf):
+    rng = np.random.default_rng(5 + wf)
+    V, N = 512, 2048
+    freq = np.concatenate([[440.0, 0.2, 20000.0, 11025.0], rng.uniform(0.1, 21000, V - 4)])
+    out, ph, _ = _render(mx, wf, freq, N)
+    eo, eph, _ = port.osc(wf, freq, N)
+    assert_bits_equal(ph, eph, "phase")
+    d = ulp_diff(out, eo)
+    absd = np.abs(out - eo)
+    # <= 1 ULP of the result, or (near zero crossings, where the ULP shrinks) <= 1 ULP of 1.0
+    bad = (d > TRIG_MAX_ULP) & (absd > 1.12e-16)
+    assert not bad.any(), (int(bad.sum()), int(d.max()), float(absd.max()))
+
+
+@pytest.mark.parametrize("vpl,nt,block", [(1, 0, 64), (2, 0, 64), (2, 1, 256), (1, 1, 128)])
+def test_tuning_does_not_change_results(mx, port, vpl, nt, block):
+    L = mx.lib()
+    prev = [L.mxg_tune(b"osc_vpl", vpl), L.mxg_tune(b"osc_nt", nt), L.mxg_tune(b"osc_block", block)]
+    try:
+        rng = np.random.default_rng(77)
+        V, N = 4096 + 2, 300
+        freq = rng.uniform(20, 20000, V)
+        for wf in (8, 9, 10, 3):
+            out, ph, hd = _render(mx, wf, freq, N, blocks=2)
+            eo, eph, _ = port.osc(wf, freq, 2 * N)
+            assert_bits_equal(out, eo, OSC[wf])
+            assert_bits_equal(ph, eph)
+    finally:
+        L.mxg_tune(b"osc_vpl", prev[0]); L.mxg_tune(b"osc_nt", prev[1]); L.mxg_tune(b"osc_block", prev[2])
+
+
+def test_empty_and_invalid(mx):
+    L = mx.lib()
+    bank = mx.maxiOscBank(4)
+    out = mx.DeviceBuffer((4, 4))
+    f = mx.DeviceBuffer.from_numpy(np.full(4, 100.0))
+    assert L.mxg_osc_render(8, 4, 0, f.ptr, 0, None, None, bank.phase.ptr, bank.output.ptr, out.ptr, None) == 0
+    assert L.mxg_osc_render(8, 0, 4, f.ptr, 0, None, None, bank.phase.ptr, bank.output.ptr, out.ptr, None) == 0
+    assert L.mxg_osc_render(12, 4, 4, f.ptr, 0, None, None, bank.phase.ptr, bank.output.ptr, out.ptr, None) == -1
+    assert L.mxg_osc_render(6, 4, 4, f.ptr, 0, None, None, bank.phase.ptr, bank.output.ptr, out.ptr, None) == -1
+    assert L.mxg_osc_render(8, 4, 4, None, 0, None, None, bank.phase.ptr, bank.output.ptr, out.ptr, None) == -1
+    assert b"null" in L.mxg_last_error()
+
+
+def test_config2_full_size_properties(mx, port):
+    """BASELINE config 2 at full size: 65 536 voices, B=512, several blocks with state carried.
+    Checked through size-independent properties + a strided sample of voices against the oracle."""
+    V, B, K = 65536, 512, 4
+    freq = 20.0 + np.arange(V) * 0.30517578125
+    bank = mx.maxiOscBank(V)
+    blocks = [bank.sinebuf(freq, B).numpy() for _ in range(K)]
+    full = np.concatenate(blocks)
+    # (1) splitting the render differently gives the same stream (state carry is exact)
+    bank2 = mx.maxiOscBank(V)
+    a = bank2.sinebuf(freq, 3 * B).numpy()
+    b = bank2.sinebuf(freq, B).numpy()
+    assert_bits_equal(np.concatenate([a, b]), full, "split invariance")
+    assert_bits_equal(bank.phase.numpy(), bank2.phase.numpy(), "phase")
+    # (2) range: the table spans [-0.99997, 0.99997], linear interpolation cannot exceed it
+    assert np.abs(full).max() <= 0.99997
+    # (3) every 97th voice (+ first/last) against the oracle, every sample
+    sel = np.unique(np.concatenate([np.arange(0, V, 97), [V - 1]]))
+    eo, eph, _ = port.osc(8, freq[sel], K * B)
+    assert_bits_equal(full[:, sel], eo, "sampled voices")
+    assert_bits_equal(bank.phase.numpy()[sel], eph, "sampled phases")
+    # (4) phase invariant of sinebuf: always in [-1, 511)
+    ph = bank.phase.numpy()
+    assert ph.min() >= -1.0 and ph.max() < 511.0

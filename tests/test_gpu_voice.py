@@ -1,0 +1,163 @@
+"""GPU parity (-m gpu): maxiFilter / maxiEnv banks, the fused subtractive voice and the
+stereo mixdown through the C-ABI vs the oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+FLT = ["lores", "hires", "bandpass", "lopass", "hipass"]
+# Stated tolerances (DESIGN.md "Numerics"):
+MOD_FILTER_RTOL = 1e-9   # device cos/sqrt coefficients through a recursive filter
+MIX_RTOL = 1e-12         # tree-ordered sum over voices vs sequential sum
+
+
+@pytest.mark.parametrize("kind", range(5))
+def test_filter_golden(mx, golden, kind):
+    g = golden("filter.npz")
+    name = FLT[kind]
+    V = g["x"].shape[1]
+    c = g["lp"] if kind >= 3 else g["cutoff"]
+    r = None if kind >= 3 else (g["bres"] if kind == 2 else g["res"])
+    bank = mx.maxiFilterBank(V)
+    x1, x2 = mx.DeviceBuffer.from_numpy(g["x"][:128]), mx.DeviceBuffer.from_numpy(g["x"][128:])
+    o = np.concatenate([bank.render(kind, x1, c, r).numpy(), bank.render(kind, x2, c, r).numpy()])
+    assert_bits_equal(o, g["out_" + name], name)
+    assert_bits_equal(bank.state.numpy(), g["state_" + name], name + " state")
+
+
+@pytest.mark.parametrize("kind", range(5))
+def test_filter_vs_oracle(mx, port, kind):
+    rng = np.random.default_rng(40 + kind)
+    V, N = 777, 600
+    x = rng.uniform(-1, 1, (N, V))
+    c = rng.uniform(0, 1, V) if kind >= 3 else rng.uniform(1, 30000, V)
+    r = None if kind >= 3 else (rng.uniform(0.01, 1.3, V) if kind == 2 else rng.uniform(0.2, 25, V))
+    bank = mx.maxiFilterBank(V)
+    o = bank.render(kind, mx.DeviceBuffer.from_numpy(x), c, r).numpy()
+    eo, est = port.filter(kind, x, c, r)
+    assert_bits_equal(o, eo, FLT[kind])
+    assert_bits_equal(bank.state.numpy(), est, FLT[kind] + " state")
+
+
+def test_filter_modulated_tolerance(mx, golden):
+    g = golden("filter.npz")
+    V = g["x"].shape[1]
+    bank = mx.maxiFilterBank(V)
+    o = bank.render("lores", mx.DeviceBuffer.from_numpy(g["x"]), g["cutoff_mod"], g["res"],
+                    cutoff_per_sample=True).numpy()
+    e = g["out_lores_mod"]
+    scale = np.abs(e).max(axis=0, keepdims=True)
+    assert (np.abs(o - e) <= MOD_FILTER_RTOL * scale).all(), float((np.abs(o - e) / scale).max())
+
+
+def _env_bank(mx, par, hold):
+    bank = mx.maxiEnvBank(par.shape[1])
+    bank.par[:] = par
+    bank.holdtime[:] = hold
+    bank._dirty = True
+    return bank
+
+
+def test_env_golden_and_setters(mx, golden):
+    g = golden("env.npz")
+    V = g["par"].shape[1]
+    b = mx.maxiEnvBank(len(g["setter_ms"]))
+    b.setAttack(g["setter_ms"]); assert_bits_equal(b.par[0], g["setters"][0])
+    b.setDecay(g["setter_ms"]); assert_bits_equal(b.par[1], g["setters"][1])
+    b.setRelease(g["setter_ms"]); assert_bits_equal(b.par[3], g["setters"][2])
+    b.setAttackMS(g["setter_ms"]); assert_bits_equal(b.par[0], g["setters"][3])
+    for mode, name in enumerate(["adsr", "ar"]):
+        bank = _env_bank(mx, g["par"], g["hold"])
+        N = g["trig"].shape[0]
+        # two blocks, state carried
+        h = N // 2
+        o = np.concatenate([bank.render(mode, None, g["trig"][:h], h).numpy(),
+                            bank.render(mode, None, g["trig"][h:], N - h).numpy()])
+        assert_bits_equal(o, g["out_%s_gate" % name], name)
+        assert_bits_equal(bank.dstate.numpy(), g["dst_%s_gate" % name], name)
+        assert np.array_equal(bank.istate.numpy(), g["ist_%s_gate" % name])
+        bank = _env_bank(mx, g["par"], g["hold"])
+        o = bank.render(mode, mx.DeviceBuffer.from_numpy(g["xin"]), g["trig_v"], N).numpy()
+        assert_bits_equal(o, g["out_%s_pv" % name], name)
+        assert_bits_equal(bank.dstate.numpy(), g["dst_%s_pv" % name], name)
+        assert np.array_equal(bank.istate.numpy(), g["ist_%s_pv" % name])
+
+
+def test_voice_golden_mode_a_bit_exact(mx, golden):
+    g = golden("voice.npz")
+    V = g["freq"].size
+    vb = mx.maxiVoiceBank(V)
+    vb.env.par[:] = g["par"]; vb.env.holdtime[:] = g["hold"]; vb.env._dirty = True
+    N = g["trig"].shape[0]
+    h = 1000
+    o = np.concatenate([vb.render(0, g["freq"], g["cutoff"], g["res"], g["trig"][:h], h).numpy(),
+                        vb.render(0, g["freq"], g["cutoff"], g["res"], g["trig"][h:], N - h).numpy()])
+    assert_bits_equal(o, g["out_mode0"])
+    assert_bits_equal(vb.osc_state.numpy(), g["ost_mode0"])
+    assert_bits_equal(vb.flt_state.numpy(), g["fst_mode0"])
+    assert_bits_equal(vb.env.dstate.numpy(), g["dst_mode0"])
+    assert np.array_equal(vb.env.istate.numpy(), g["ist_mode0"])
+
+
+def test_voice_golden_mode_b_tolerance(mx, golden):
+    g = golden("voice.npz")
+    V = g["freq"].size
+    vb = mx.maxiVoiceBank(V)
+    vb.env.par[:] = g["par"]; vb.env.holdtime[:] = g["hold"]; vb.env._dirty = True
+    N = g["trig"].shape[0]
+    o = vb.render(1, g["freq"], np.full(V, 10000.0), g["res"], g["trig"], N).numpy()
+    e = g["out_mode1"]
+    scale = np.abs(e).max(axis=0, keepdims=True)
+    assert (np.abs(o - e) <= MOD_FILTER_RTOL * scale).all(), float((np.abs(o - e) / scale).max())
+    # the envelope itself has no transcendental in it: exact
+    assert_bits_equal(vb.env.dstate.numpy(), g["dst_mode1"])
+    assert np.array_equal(vb.env.istate.numpy(), g["ist_mode1"])
+    assert_bits_equal(vb.osc_state.numpy(), g["ost_mode1"])
+
+
+def test_config3_full_size(mx, port):
+    """BASELINE config 3 at full size (65 536 voices, mode A), 2 blocks of 512, with a strided
+    sample of voices checked against the oracle and split-invariance for all."""
+    V, B = 65536, 512
+    v = np.arange(V)
+    freq = np.minimum(20 + v * 0.30517578125, 5000.0)
+    cutoff = 200 + 4 * freq
+    res = 1.0 + (v % 16)
+    trig = ((np.arange(2 * B) % 700) < 300).astype(np.int32)
+
+    def mk():
+        vb = mx.maxiVoiceBank(V)
+        vb.env.setAttack(10); vb.env.setDecay(100); vb.env.setSustain(0.5); vb.env.setRelease(500)
+        return vb
+    vb = mk()
+    o = np.concatenate([vb.render(0, freq, cutoff, res, trig[:B], B).numpy(),
+                        vb.render(0, freq, cutoff, res, trig[B:], B).numpy()])
+    vb2 = mk()
+    o2 = vb2.render(0, freq, cutoff, res, trig, 2 * B).numpy()
+    assert_bits_equal(o, o2, "split invariance")
+    sel = np.unique(np.concatenate([np.arange(0, V, 211), [V - 1]]))
+    par = vb.env.par[:, sel]
+    eo = port.voice(0, freq[sel], cutoff[sel], res[sel], trig, par, np.ones(sel.size, np.int64))
+    assert_bits_equal(o[:, sel], eo[0], "sampled voices")
+    assert_bits_equal(vb.flt_state.numpy()[:, sel], eo[2])
+    assert np.array_equal(vb.env.istate.numpy()[:, sel], eo[4])
+
+
+def test_mix_stereo(mx, port, golden):
+    g = golden("mix.npz")
+    V = g["x"].shape[1]
+    m = mx.maxiMixBank(V).stereo(mx.DeviceBuffer.from_numpy(g["x"]), g["pan"]).numpy()
+    e = g["mix"]
+    assert np.abs(m - e).max() <= MIX_RTOL * np.abs(g["x"]).sum(axis=1).max()
+    # larger, vs the oracle, and deterministic run to run
+    rng = np.random.default_rng(9)
+    V, N = 5000, 130
+    x = rng.uniform(-1, 1, (N, V)); pan = rng.uniform(-0.2, 1.2, V)
+    dx = mx.DeviceBuffer.from_numpy(x)
+    a = mx.maxiMixBank(V).stereo(dx, pan).numpy()
+    b = mx.maxiMixBank(V).stereo(dx, pan).numpy()
+    assert_bits_equal(a, b, "deterministic")
+    e = port.mix_stereo(x, pan)
+    assert np.abs(a - e).max() <= MIX_RTOL * V
