@@ -32,14 +32,27 @@ ALGO_BYTES_PER_SAMPLE = 8.0 + 24.0 / BLOCK  # 8 B store + (freq, phase rd, phase
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(freq):
     """The reference CPU loop on this host: bounded sample of the same workload."""
     from oracle import pyoracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
+    # bounded sample: ~3.2 G samples = roughly 20 core-seconds of the reference loop
     if pyoracle.have_reference():
-        o, kind, threads, blocks = pyoracle.reference(), "reference", cores, 8 * max(1, cores // 2)
+        o, kind, threads, blocks = pyoracle.reference(), "reference", cores, 96
     else:
-        o, kind, threads, blocks = pyoracle.port(), "port", 1, 12
+        o, kind, threads, blocks = pyoracle.port(), "port", 1, 48
     o.settings(44100, 2, 1024)
     nsamp = BLOCK * blocks
     secs = o.time_osc(8, freq, nsamp, threads=threads)
@@ -55,8 +68,8 @@ def cpu_baseline(freq):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--waveform", default="sinebuf")
     args = ap.parse_args()
@@ -81,7 +94,12 @@ def main():
     mx._lib.check(L.mxg_init(local), "mxg_init")
     mx.maxiSettings.setup(44100, 2, 1024)
     dev = torch.device("cuda", local)
-    stream = torch.cuda.current_stream().cuda_stream  # launch on torch's stream: events see it
+    # Launch on a non-default torch stream and time with events recorded on the SAME stream
+    # (the C-ABI treats a NULL stream as "the library's own stream").
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
 
     V, B = VOICES_PER_GPU, BLOCK
     wf = mx.OSC_WAVEFORMS[args.waveform]
@@ -109,21 +127,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed clock ramp: an idle MI355X sits in a low-power state (sclk ~500 MHz) and takes
+    # milliseconds of continuous work to reach its sustained clocks; a short --steps run would
+    # otherwise time the ramp instead of the kernel.  Then the W requested warmup steps.
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.3:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    # per-launch duration of the dominant kernel (K1), HIP events on the launch stream
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
+    # Average launch duration of the dominant kernel (K1): two HIP events on the launch stream
+    # bracketing the K back-to-back launches of the timed region (per-launch event pairs would
+    # put ~10 us of host/marker gaps between the kernels; measured in profiles/).
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fence()
     t0 = time.perf_counter()
+    ev0.record()
     for i in range(args.steps):
-        ev[i][0].record()
-        render()
-        ev[i][1].record()
+        step()
+    ev1.record()
     fence()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    k1_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    k1_ms = ev0.elapsed_time(ev1) / args.steps
     if world > 1:
         t = torch.tensor([elapsed, k1_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

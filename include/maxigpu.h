@@ -15,7 +15,8 @@
  *   - bank signals are sample-major / voice-minor:  out[n*V + v],  n < N, v < V.
  *   - state is SoA: one array of length V per reference member, updated in place so
  *     consecutive calls continue the stream exactly like consecutive play() calls.
- *   - `stream` is a hipStream_t passed as void* (NULL = the library's default stream).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the library's own default stream; to
+ *     target HIP's null stream pass hipStreamLegacy, i.e. (void*)1).
  *     Calls are asynchronous on that stream; mxg_sync()/mxg_stream_sync() wait.
  *   - returns 0 on success, a negative mxg_status otherwise; never throws, never exit()s
  *     (the reference exit(1)s on a bad FFT size, L/fft.cpp:129-132; here that is

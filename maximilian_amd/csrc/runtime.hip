@@ -24,8 +24,8 @@ struct Tune {
     int lo, hi;
 };
 Tune g_tune[] = {
-    {"osc_vpl", 2, 1, 2},       {"osc_block", 64, 64, 1024},  {"osc_nt", 0, 0, 1},
-    {"voice_vpl", 1, 1, 2},     {"voice_block", 64, 64, 1024}, {"voice_nt", 0, 0, 1},
+    {"osc_vpl", 1, 1, 2},       {"osc_block", 256, 64, 1024},  {"osc_nt", 0, 0, 1},
+    {"voice_vpl", 1, 1, 2},     {"voice_block", 256, 64, 1024}, {"voice_nt", 0, 0, 1},
     {"mix_block", 256, 64, 1024},
 };
 }  // namespace
