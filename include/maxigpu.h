@@ -157,6 +157,44 @@ int mxg_voice_render(int mode, size_t V, size_t N, const double *d_freq, const d
 int mxg_mix_stereo(size_t V, size_t N, const double *d_in, const double *d_pan, double *d_mix,
                    void *stream);
 
+/* ---- maxiDelayline bank ---------------------------------------------------------------- */
+/* mode 0: dl(input, size, feedback) (C:420-429)   mode 1: dlFromPosition(input, size, feedback,
+ * position) (C:431-439).  d_size int32 [V], d_feedback [V], d_position int32 [V] (mode 1).
+ * d_mem = [cap][V] slot-major ring (the reference's per-object memory[88200*8], H:273, cut to
+ * `cap` slots; every size must be <= cap), zero-initialise like the ctor (C:415-417);
+ * d_phase int32 [V] in/out.  d_in/d_out are [N][V]. */
+int mxg_delay_render(int mode, size_t V, size_t N, const double *d_in, const int32_t *d_size,
+                     const double *d_feedback, const int32_t *d_position, double *d_mem, size_t cap,
+                     int32_t *d_phase, double *d_out, void *stream);
+
+/* ---- maxiSample play family -------------------------------------------------------------- */
+typedef enum {
+    MXG_SMP_PLAY = 0,                    /* play()                       C:740-747   */
+    MXG_SMP_PLAYONCE = 1,                /* playOnce()                   C:982-991   */
+    MXG_SMP_PLAYLOOP = 2,                /* playLoop(start,end)          C:960-967   */
+    MXG_SMP_PLAYUNTIL = 3,               /* playUntil(end)               C:969-978   */
+    MXG_SMP_PLAYATSPEED = 4,             /* playAtSpeed(a)               C:1060-1075 */
+    MXG_SMP_PLAYONCEATSPEED = 5,         /* playOnceAtSpeed(a)           C:994-1003  */
+    MXG_SMP_PLAYUNTILATSPEED = 6,        /* playUntilAtSpeed(end,a)      C:1047-1058 */
+    MXG_SMP_PLAY4 = 7,                   /* play4(a=frequency,start,end) C:884-956   */
+    MXG_SMP_PLAYATSPEEDBETWEENPOINTS = 8 /* playAtSpeedBetweenPoints(a=frequency,start,end) C:823-880 */
+} mxg_sample_mode;
+/* Upload a mono sample (what maxiSample::setSample holds, H:670-678) into a device buffer that
+ * is valid on [-1, len+1] with 0.0 guards: the reference reads amplitudes[len], [len+1]
+ * (C:1063-1064) and [-1] (C:898) out of bounds; zero is the parity convention.
+ * Returns the device pointer to element 0 (NULL on failure); release with mxg_sample_free. */
+double *mxg_sample_upload(const double *h_samples, size_t len);
+int mxg_sample_free(double *d_samples);
+/* V play heads over one shared sample.  d_a: speed or frequency, [V] (aps=0) or [N][V] (aps=1);
+ * d_start/d_end [V] (fractions of the length for playLoop/playUntil*, sample indices for
+ * play4/playAtSpeedBetweenPoints, exactly as in the reference); d_position [V] in/out is the
+ * member `position` (setSample leaves it at len-1, H:677; trigger() sets 0, C:597-600).
+ * mySampleRate is the int member (44100 after setSample): the step divides by the INTEGER
+ * quotient sampleRate/mySampleRate (C:1070). */
+int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, size_t len,
+                      int mySampleRate, const double *d_a, int aps, const double *d_start,
+                      const double *d_end, double *d_position, double *d_out, void *stream);
+
 /* ---- calibration ----------------------------------------------------------------------- */
 /* Streaming fill of `bytes` at d_dst (8 B/lane or 16 B/lane stores): the measured HBM write
  * ceiling that bench.py reports next to the nominal 8 TB/s. */

@@ -7,4 +7,5 @@ package is the thin host-side mirror used by the tests and bench.py: device buff
 """
 from ._lib import LIB_PATH, MaxiGpuError, lib  # noqa: F401
 from .banks import (DeviceBuffer, maxiSettings, maxiOscBank, maxiFilterBank, maxiEnvBank,  # noqa: F401
-                    maxiVoiceBank, maxiMixBank, OSC_WAVEFORMS, FILTER_KINDS)
+                    maxiVoiceBank, maxiMixBank, maxiDelaylineBank, maxiSampleBank, OSC_WAVEFORMS,
+                    FILTER_KINDS, SAMPLE_MODES)

@@ -297,3 +297,116 @@ class maxiMixBank(_Bank):
               "mxg_mix_stereo")
         self._keep = p
         return out
+
+
+class maxiDelaylineBank(_Bank):
+    """V x maxiDelayline (H:266-284).  The ring is `cap` slots per voice (slot-major on device)
+    instead of the reference's fixed 88200*8; `size` <= cap."""
+
+    def __init__(self, voices, cap, stream=None):
+        super().__init__(voices, stream)
+        self.cap = int(cap)
+        self.memory = DeviceBuffer((self.cap, self.V))    # ctor memset 0, C:415-417
+        self.phase = DeviceBuffer(self.V, np.int32)       # static-storage objects start at 0
+
+    def _render(self, mode, x, size, feedback, position, out):
+        N = x.shape[0]
+        sz = _as_dev(size, self.V, np.int32)
+        fb = _as_dev(feedback, self.V)
+        ps = None if position is None else _as_dev(position, self.V, np.int32)
+        out = self._out(N, out)
+        check(lib().mxg_delay_render(mode, self.V, N, _ptr(x), _ptr(sz), _ptr(fb), _ptr(ps),
+                                     self.memory.ptr, self.cap, self.phase.ptr, _ptr(out), self.stream),
+              "mxg_delay_render")
+        self._keep = (sz, fb, ps)
+        return out
+
+    def dl(self, x, size, feedback, out=None):
+        return self._render(0, x, size, feedback, None, out)
+
+    def dlFromPosition(self, x, size, feedback, position, out=None):
+        return self._render(1, x, size, feedback, position, out)
+
+
+SAMPLE_MODES = {"play": 0, "playOnce": 1, "playLoop": 2, "playUntil": 3, "playAtSpeed": 4,
+                "playOnceAtSpeed": 5, "playUntilAtSpeed": 6, "play4": 7, "playAtSpeedBetweenPoints": 8}
+
+
+class maxiSampleBank(_Bank):
+    """V play heads over one maxiSample (H:602-783): the bank shares the sample data the way
+    maxiGrains alias one maxiSample (L/maxiGrains.h:162)."""
+
+    def __init__(self, voices, stream=None):
+        super().__init__(voices, stream)
+        self.d_samples = None
+        self.length = 0
+        self.mySampleRate = int(maxiSettings.sampleRate)  # ctor, C:546
+        self.position = DeviceBuffer(self.V)
+
+    def setSample(self, samples):
+        """maxiSample::setSample (H:670-678): copies the data, mySampleRate=44100, position=len-1."""
+        a = np.ascontiguousarray(samples, np.float64)
+        self.clear()
+        p = lib().mxg_sample_upload(a.ctypes.data, a.size)
+        if not p:
+            raise MemoryError(lib().mxg_last_error().decode())
+        self.d_samples, self.length = p, a.size
+        self.mySampleRate = 44100
+        self.position.upload(np.full(self.V, a.size - 1.0))
+
+    def setSampleAndRate(self, samples, sampleRate):
+        self.setSample(samples)
+        self.mySampleRate = int(sampleRate)
+
+    def trigger(self):
+        """maxiSample::trigger (C:597-600)."""
+        self.position.upload(np.zeros(self.V))
+
+    def setPosition(self, newPos):
+        """maxiSample::setPosition (C:749-751): clamp(newPos,0,1)*length."""
+        p = np.clip(np.broadcast_to(np.asarray(newPos, np.float64), (self.V,)), 0.0, 1.0) * self.length
+        self.position.upload(p)
+
+    def getLength(self):
+        return self.length
+
+    def clear(self):
+        if self.d_samples:
+            lib().mxg_sample_free(self.d_samples)
+            self.d_samples = None
+
+    def render(self, mode, N, a=None, start=None, end=None, out=None, per_sample=False):
+        m = SAMPLE_MODES[mode] if isinstance(mode, str) else int(mode)
+        if per_sample and not (isinstance(a, DeviceBuffer) or hasattr(a, "data_ptr")):
+            a = DeviceBuffer.from_numpy(np.asarray(a, np.float64).reshape(N, self.V))
+        da = None if a is None else (a if per_sample else _as_dev(a, self.V))
+        ds = None if start is None else _as_dev(start, self.V)
+        de = None if end is None else _as_dev(end, self.V)
+        out = self._out(N, out)
+        check(lib().mxg_sample_render(m, self.V, N, self.d_samples, self.length, self.mySampleRate,
+                                      _ptr(da), int(per_sample), _ptr(ds), _ptr(de), self.position.ptr,
+                                      _ptr(out), self.stream), "mxg_sample_render")
+        self._keep = (da, ds, de)
+        return out
+
+    def play(self, N, **kw): return self.render("play", N, **kw)
+    def playOnce(self, N, **kw): return self.render("playOnce", N, **kw)
+    def playLoop(self, start, end, N, **kw): return self.render("playLoop", N, start=start, end=end, **kw)
+    def playUntil(self, end, N, **kw): return self.render("playUntil", N, end=end, **kw)
+    def playAtSpeed(self, speed, N, **kw): return self.render("playAtSpeed", N, a=speed, **kw)
+    def playOnceAtSpeed(self, speed, N, **kw): return self.render("playOnceAtSpeed", N, a=speed, **kw)
+
+    def playUntilAtSpeed(self, end, speed, N, **kw):
+        return self.render("playUntilAtSpeed", N, a=speed, end=end, **kw)
+
+    def play4(self, frequency, start, end, N, **kw):
+        return self.render("play4", N, a=frequency, start=start, end=end, **kw)
+
+    def playAtSpeedBetweenPoints(self, frequency, start, end, N, **kw):
+        return self.render("playAtSpeedBetweenPoints", N, a=frequency, start=start, end=end, **kw)
+
+    def __del__(self):
+        try:
+            self.clear()
+        except Exception:
+            pass

@@ -1,0 +1,286 @@
+// sample.hip -- maxiDelayline and maxiSample (play family) voice banks on gfx950.
+//
+// Path (reference src/maximilian.cpp, cited as C:line):
+//   maxiDelayline::dl C:420-429, dlFromPosition C:431-439;
+//   maxiSample::play C:740-747, playOnce C:982-991, playLoop C:960-967, playUntil C:969-978,
+//   playAtSpeed C:1060-1075, playOnceAtSpeed C:994-1003, playUntilAtSpeed C:1047-1058,
+//   play4 C:884-956, playAtSpeedBetweenPoints C:823-880.
+// One lane owns one voice (one delay line / one play head).  All arithmetic is + - * / floor
+// and integer indexing => bit-exact.
+//
+// HBM layout.  Delay memory of a bank is slot-major: mem[slot*V + v], slot < cap.  Voices
+// that share (size, start phase) -- the normal case for a bank -- then touch one contiguous
+// 512-B row per wavefront per sample (coalesced read-modify-write); voices with different
+// phases degrade to a gather but stay correct.  Algorithmic traffic: 8 B in + 8 B ring read +
+// 8 B ring write + 8 B out = 32 B/sample (K4, HBM-bound).  The reference embeds a fixed
+// 88200*8-slot array in every object (H:273); here the ring is `cap` slots, any size <= cap.
+// maxiSample: one shared, read-only sample buffer per bank (L2/Infinity-Cache resident for the
+// sizes of the configs); per sample a lane gathers 1-4 neighbouring doubles (K5, 8 B out +
+// gather).  The buffer must be valid on [-1, len+1] with zero guards (see maxigpu.h).
+#include "mxg_common.h"
+
+namespace mxg {
+namespace {
+
+template <int MODE>
+__global__ void delay_kernel(size_t V, size_t N, const double *__restrict__ in,
+                             const int32_t *__restrict__ size, const double *__restrict__ feedback,
+                             const int32_t *__restrict__ position, double *__restrict__ mem,
+                             int32_t *__restrict__ phase_io, double *__restrict__ out) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    int ph = phase_io[v];
+    const int sz = size[v];
+    const double fb = feedback[v];
+    int pos = 0;
+    if constexpr (MODE == 1) {
+        pos = position[v];
+        if (pos >= sz) pos = 0;  // C:433
+    }
+    const double *ip = in + v;
+    double *op = out + v;
+    double *m = mem + v;
+    for (size_t n = 0; n < N; n++) {
+        double input = *ip;
+        if (ph >= sz) ph = 0;  // C:421 / C:432
+        double *slot = m + (size_t)ph * V;
+        double cur = *slot;
+        double o;
+        if constexpr (MODE == 0) {
+            o = cur;                                 // C:424
+            *slot = (cur * fb) + (input * fb) * 0.5;  // C:425
+        } else {
+            // the read slot may alias the slot written earlier in this block by this voice:
+            // plain loads/stores of one lane to one address stay ordered.
+            o = m[(size_t)pos * V];                       // C:434
+            *slot = (cur * fb) + (input * fb) * kChandiv;  // C:435
+        }
+        ph += 1;
+        *op = o;
+        ip += V;
+        op += V;
+    }
+    phase_io[v] = ph;
+}
+
+struct Smp {
+    const double *amp;
+    size_t len;
+    double pos;
+    double step_div;  // (double)(sampleRate / mySampleRate), the INTEGER quotient of C:1070
+};
+
+template <int MODE>
+__device__ __forceinline__ double smp_tick(Smp &s, double x, double start, double end, double sr) {
+    const double *A = s.amp;
+    if constexpr (MODE == 0) {  // play C:740-747
+        double o = A[(long long)s.pos];
+        s.pos += 1.0;
+        if ((size_t)(long long)s.pos >= s.len) s.pos = 0;
+        return o;
+    } else if constexpr (MODE == 1) {  // playOnce C:982-991
+        double o = ((size_t)(long long)s.pos < s.len) ? A[(long long)s.pos] : 0.0;
+        s.pos += 1.0;
+        return o;
+    } else if constexpr (MODE == 2) {  // playLoop C:960-967
+        s.pos += 1.0;
+        double lo = (double)s.len * start;
+        if (s.pos < lo) s.pos = lo;
+        if ((double)(long long)s.pos >= (double)s.len * end) s.pos = lo;
+        return A[(long long)s.pos];
+    } else if constexpr (MODE == 3) {  // playUntil C:969-978
+        s.pos += 1.0;
+        if (end > 1.0) end = 1.0;
+        return ((double)(long long)s.pos < (double)s.len * end) ? A[(long long)s.pos] : 0.0;
+    } else if constexpr (MODE == 4) {  // playAtSpeed C:1060-1075
+        long long i = (long long)s.pos;
+        double remainder = s.pos - (double)i;
+        double o = 0.0;
+        if ((size_t)i < s.len) o = ((1 - remainder) * A[1 + i] + remainder * A[2 + i]);
+        s.pos = s.pos + ((x * kChandiv) / s.step_div);
+        if ((size_t)(long long)s.pos >= s.len) s.pos -= (double)s.len;
+        return o;
+    } else if constexpr (MODE == 5) {  // playOnceAtSpeed C:994-1003
+        long long i = (long long)s.pos;
+        double remainder = s.pos - (double)i;
+        double o = 0.0;
+        if ((size_t)(i + 1) < s.len) o = ((1 - remainder) * A[i] + remainder * A[1 + i]);
+        s.pos = s.pos + ((x * kChandiv) / s.step_div);
+        return o;
+    } else if constexpr (MODE == 6) {  // playUntilAtSpeed C:1047-1058
+        long long i = (long long)s.pos;
+        double remainder = s.pos - (double)i;
+        if (end > 1.0) end = 1.0;
+        double o = 0.0;
+        if ((double)i < (double)s.len * end) o = ((1 - remainder) * A[1 + i] + remainder * A[2 + i]);
+        s.pos = s.pos + ((x * kChandiv) / s.step_div);
+        return o;
+    } else if constexpr (MODE == 7) {  // play4 C:884-956 (start/end in samples)
+        double frequency = x, remainder, a, b, c, d;
+        double o;
+        if (frequency > 0.) {
+            if (s.pos < start) s.pos = start;
+            if (s.pos >= end) s.pos = start;
+            s.pos += ((end - start) / (sr / (frequency * kChandiv)));
+            remainder = s.pos - floor(s.pos);
+            a = (s.pos > 0) ? A[(int)(floor(s.pos)) - 1] : A[0];
+            b = A[(long long)s.pos];
+            c = (s.pos < end - 2) ? A[(long long)s.pos + 1] : A[0];
+            d = (s.pos < end - 3) ? A[(long long)s.pos + 2] : A[0];
+            double a1 = 0.5 * (c - a);
+            double a2 = a - 2.5 * b + 2. * c - 0.5 * d;
+            double a3 = 0.5 * (d - a) + 1.5 * (b - c);
+            o = (((a3 * remainder + a2) * remainder + a1) * remainder + b);
+        } else {
+            frequency *= -1.;
+            if (s.pos <= start) s.pos = end;
+            s.pos -= ((end - start) / (sr / (frequency * kChandiv)));
+            remainder = s.pos - floor(s.pos);
+            a = (s.pos > start && s.pos < end - 1) ? A[(long long)s.pos + 1] : A[0];
+            b = A[(long long)s.pos];
+            c = (s.pos > start) ? A[(long long)s.pos - 1] : A[0];
+            d = (s.pos > start + 1) ? A[(long long)s.pos - 2] : A[0];
+            double a1 = 0.5 * (c - a);
+            double a2 = a - 2.5 * b + 2. * c - 0.5 * d;
+            double a3 = 0.5 * (d - a) + 1.5 * (b - c);
+            o = (((a3 * remainder + a2) * -remainder + a1) * -remainder + b);
+        }
+        return o;
+    } else {  // playAtSpeedBetweenPoints C:823-880: `position` passed by value, never advanced
+        double frequency = x, pos = s.pos, remainder, o;
+        const size_t amplen = s.len;
+        if (end >= (double)amplen) end = (double)(amplen - 1);
+        long long a, b;
+        if (frequency > 0.) {
+            if (pos < start) pos = start;
+            if (pos >= end) pos = start;
+            pos += ((end - start) / ((sr) / (frequency * kChandiv)));
+            remainder = pos - floor(pos);
+            long long posl = (long long)floor(pos);
+            a = ((size_t)(posl + 1) < amplen) ? posl + 1 : posl - 1;
+            b = ((size_t)(posl + 2) < amplen) ? posl + 2 : (long long)amplen - 1;
+            o = ((1 - remainder) * A[a] + remainder * A[b]);
+        } else {
+            frequency *= -1.;
+            if (pos <= start) pos = end;
+            pos -= ((end - start) / (sr / (frequency * kChandiv)));
+            remainder = pos - floor(pos);
+            long long posl = (long long)floor(pos);
+            a = (posl - 1 >= 0) ? posl - 1 : 0;
+            b = (posl - 2 >= 0) ? posl - 2 : 0;
+            o = ((-1 - remainder) * A[a] + remainder * A[b]);
+        }
+        return o;
+    }
+}
+
+template <int MODE>
+__global__ void sample_kernel(size_t V, size_t N, const double *__restrict__ amp, size_t len,
+                              double step_div, const double *__restrict__ a, int aps,
+                              const double *__restrict__ start, const double *__restrict__ end,
+                              double *__restrict__ position, double *__restrict__ out, double sr) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    Smp s = {amp, len, position[v], step_div};
+    const double st = start ? start[v] : 0.0, en = end ? end[v] : 1.0;
+    double x = a ? a[v] : 1.0;
+    const double *ap = a ? a + v : nullptr;
+    double *op = out + v;
+#pragma unroll 2
+    for (size_t n = 0; n < N; n++) {
+        if (aps) {
+            x = *ap;
+            ap += V;
+        }
+        *op = smp_tick<MODE>(s, x, st, en, sr);
+        op += V;
+    }
+    position[v] = s.pos;
+}
+
+inline dim3 grid_for(size_t V, int block) { return dim3((unsigned)((V + block - 1) / block)); }
+
+}  // namespace
+}  // namespace mxg
+
+using namespace mxg;
+
+extern "C" {
+
+int mxg_delay_render(int mode, size_t V, size_t N, const double *d_in, const int32_t *d_size,
+                     const double *d_feedback, const int32_t *d_position, double *d_mem, size_t cap,
+                     int32_t *d_phase, double *d_out, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (dl) or 1 (dlFromPosition)");
+    MXG_REQUIRE(d_in && d_size && d_feedback && d_mem && d_phase && d_out, "null device pointer");
+    MXG_REQUIRE(mode == 0 || d_position, "dlFromPosition needs d_position");
+    MXG_REQUIRE(cap > 0, "cap must be > 0");
+    if (V == 0 || N == 0) return MXG_OK;
+    int block = tune_get("voice_block");
+    hipStream_t st = resolve_stream(stream);
+    if (mode == 0)
+        hipLaunchKernelGGL((delay_kernel<0>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_size,
+                           d_feedback, d_position, d_mem, d_phase, d_out);
+    else
+        hipLaunchKernelGGL((delay_kernel<1>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_size,
+                           d_feedback, d_position, d_mem, d_phase, d_out);
+    return check_hip(hipGetLastError(), "delay_kernel launch");
+}
+
+double *mxg_sample_upload(const double *h_samples, size_t len) {
+    if (ensure_init()) return nullptr;
+    if (!h_samples && len) {
+        fail(MXG_ERR_INVALID, "mxg_sample_upload: null samples");
+        return nullptr;
+    }
+    double *base = nullptr;
+    if (check_hip(hipMalloc(&base, (len + 3) * sizeof(double)), "hipMalloc(sample)")) return nullptr;
+    if (check_hip(hipMemset(base, 0, (len + 3) * sizeof(double)), "hipMemset(sample)")) return nullptr;
+    if (len && check_hip(hipMemcpy(base + 1, h_samples, len * sizeof(double), hipMemcpyHostToDevice),
+                         "hipMemcpy(sample)"))
+        return nullptr;
+    return base + 1;
+}
+
+int mxg_sample_free(double *d_samples) {
+    if (!d_samples) return MXG_OK;
+    MXG_HIP(hipFree(d_samples - 1));
+    return MXG_OK;
+}
+
+int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, size_t len,
+                      int mySampleRate, const double *d_a, int aps, const double *d_start,
+                      const double *d_end, double *d_position, double *d_out, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(mode >= 0 && mode <= 8, "unknown maxiSample mode");
+    MXG_REQUIRE(d_samples && d_position && d_out, "null device pointer");
+    MXG_REQUIRE(len > 0, "empty sample");
+    MXG_REQUIRE(mySampleRate > 0, "mySampleRate must be > 0");
+    MXG_REQUIRE(mode < 4 || d_a, "speed/frequency modes need d_a");
+    MXG_REQUIRE(!(mode == 2 || mode == 7 || mode == 8) || (d_start && d_end), "mode needs d_start/d_end");
+    MXG_REQUIRE(!(mode == 3 || mode == 6) || d_end, "mode needs d_end");
+    if (V == 0 || N == 0) return MXG_OK;
+    const size_t q = settings().sampleRate / (size_t)mySampleRate;  // integer division, C:1070
+    const double step_div = (double)q;
+    const double sr = (double)settings().sampleRate;
+    int block = tune_get("voice_block");
+    hipStream_t st = resolve_stream(stream);
+#define MXG_SMP_LAUNCH(M)                                                                          \
+    hipLaunchKernelGGL((sample_kernel<M>), grid_for(V, block), dim3(block), 0, st, V, N, d_samples, \
+                       len, step_div, d_a, aps, d_start, d_end, d_position, d_out, sr)
+    switch (mode) {
+        case 0: MXG_SMP_LAUNCH(0); break;
+        case 1: MXG_SMP_LAUNCH(1); break;
+        case 2: MXG_SMP_LAUNCH(2); break;
+        case 3: MXG_SMP_LAUNCH(3); break;
+        case 4: MXG_SMP_LAUNCH(4); break;
+        case 5: MXG_SMP_LAUNCH(5); break;
+        case 6: MXG_SMP_LAUNCH(6); break;
+        case 7: MXG_SMP_LAUNCH(7); break;
+        case 8: MXG_SMP_LAUNCH(8); break;
+    }
+#undef MXG_SMP_LAUNCH
+    return check_hip(hipGetLastError(), "sample_kernel launch");
+}
+
+}  // extern "C"

@@ -151,6 +151,56 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "mix.npz"), x=x, pan=pan, mix=R.mix_stereo(x, pan))
     files["mix.npz"] = "maxiMix::stereo + sequential voice sum, V=96, 64 samples"
 
+    # ---- maxiDelayline ------------------------------------------------------------------------------
+    V, N, cap = 24, 600, 96
+    rng = np.random.default_rng(SEED + 5)
+    x = rng.uniform(-1, 1, (N, V))
+    size = np.concatenate([[1, 2, cap, 37], rng.integers(3, cap + 1, V - 4)]).astype(np.int32)
+    size[12:] = 64  # half the bank shares one size (the coalesced case)
+    fb = rng.uniform(0.0, 0.95, V)
+    pos = rng.integers(0, cap, V).astype(np.int32)
+    d = dict(x=x, size=size, fb=fb, pos=pos, cap=cap)
+    for mode, name in enumerate(["dl", "dlFromPosition"]):
+        o1, mem, ph = R.delay(mode, x[:250], size, fb, cap, position=pos)
+        o2, mem, ph = R.delay(mode, x[250:], size, fb, cap, position=pos, mem=mem, phase=ph)
+        d["out_" + name], d["mem_" + name], d["phase_" + name] = np.concatenate([o1, o2]), mem, ph
+    np.savez_compressed(os.path.join(GOLD, "delay.npz"), **d)
+    files["delay.npz"] = "maxiDelayline dl/dlFromPosition, V=24, 250+350 samples, cap 96"
+
+    # ---- maxiSample play family ------------------------------------------------------------------------
+    V, N, Ls = 24, 400, 1500
+    rng = np.random.default_rng(SEED + 6)
+    n = np.arange(Ls)
+    smp = np.round((0.5 * np.sin(2 * np.pi * 110 * n / 44100) + 0.25 * np.sin(2 * np.pi * 331 * n / 44100)
+                    + 0.05 * rng.uniform(-1, 1, Ls)) * 32767) / 32767.0  # int16-normalised like C:679
+    d = dict(samples=smp, N=N)
+    modes = ["play", "playOnce", "playLoop", "playUntil", "playAtSpeed", "playOnceAtSpeed",
+             "playUntilAtSpeed", "play4", "playAtSpeedBetweenPoints"]
+    for mode, name in enumerate(modes):
+        pos0 = rng.uniform(1, Ls - 5, V)
+        pos0[0] = Ls - 1.0  # the state setSample() leaves (H:677)
+        if mode in (0, 1):
+            pos0 = np.floor(pos0)
+        a = rng.uniform(0.2, 3.0, V)
+        st, en = rng.uniform(0, 0.4, V), rng.uniform(0.5, 1.1, V)
+        if mode == 2:
+            en = np.minimum(en, 1.0)  # playLoop does not clamp `end` (C:960-967): > 1 reads past the buffer
+        if mode in (7, 8):
+            a = rng.uniform(0.5, 60, V) * np.where(rng.uniform(0, 1, V) < 0.4, -1, 1)
+            st, en = np.floor(rng.uniform(2, 400, V)), np.floor(rng.uniform(500, Ls - 1, V))
+        o1, p = R.sample(mode, smp, N // 2, pos0, a=a, start=st, end=en)
+        o2, p = R.sample(mode, smp, N - N // 2, p, a=a, start=st, end=en)
+        d["pos0_" + name], d["a_" + name], d["start_" + name], d["end_" + name] = pos0, a, st, en
+        d["out_" + name], d["pos_" + name] = np.concatenate([o1, o2]), p
+    # per-sample speed modulation + a non-44100 mySampleRate (integer quotient C:1070) at sr 96000
+    sp = rng.uniform(0.1, 2.5, (N, V))
+    R.settings(96000, 2, 1024)
+    o, p = R.sample(4, smp, N, np.zeros(V), a=sp, aps=True, mySampleRate=44100)
+    R.settings(44100, 2, 1024)
+    d["speed_mod"], d["out_speed_mod_sr96k"], d["pos_speed_mod_sr96k"] = sp, o, p
+    np.savez_compressed(os.path.join(GOLD, "sample.npz"), **d)
+    files["sample.npz"] = "maxiSample 9 play modes, V=24, 200+200 samples over a 1500-sample buffer"
+
     sha = hashlib.sha256()
     for f in ("maximilian.cpp", "maximilian.h", "libs/fft.cpp", "libs/maxiFFT.cpp", "libs/maxiMFCC.cpp",
               "libs/maxiMFCC.h", "libs/maxiGrains.h"):

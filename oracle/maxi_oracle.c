@@ -562,3 +562,278 @@ double mxo_time_osc(int wf, size_t V, size_t N, const double *freq, int threads,
     free(row);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ------------------------------------------------------------------------------------
+ * maxiDelayline (H:266-284, C:415-439).  memory[] is 88200*8 doubles per instance in the
+ * reference; here the ring of a bank is mem[slot*V + v], slot < cap (cap >= every size).
+ * `phase` is an int (unset by the ctor; static-storage objects start at 0).
+ * ------------------------------------------------------------------------------------ */
+/* mode 0: dl (C:420-429)   mode 1: dlFromPosition (C:431-439) */
+int mxo_delay(int mode, size_t V, size_t N, const double *in, const int32_t *size,
+              const double *feedback, const int32_t *position, double *mem, size_t cap,
+              int32_t *phase, double *out) {
+    if (mode < 0 || mode > 1) return -1;
+    for (size_t v = 0; v < V; v++) {
+        int ph = phase[v];
+        const int sz = size[v];
+        const double fb = feedback[v];
+        if ((size_t)sz > cap) return -2;
+        for (size_t n = 0; n < N; n++) {
+            double input = in[n * V + v];
+            double output;
+            if (mode == 0) {
+                if (ph >= sz) {
+                    ph = 0;
+                }
+                output = mem[(size_t)ph * V + v];
+                mem[(size_t)ph * V + v] = (mem[(size_t)ph * V + v] * fb) + (input * fb) * 0.5;
+                ph += 1;
+            } else {
+                int pos = position[v];
+                if (ph >= sz) ph = 0;
+                if (pos >= sz) pos = 0;
+                output = mem[(size_t)pos * V + v];
+                mem[(size_t)ph * V + v] = (mem[(size_t)ph * V + v] * fb) + (input * fb) * chandiv;
+                ph += 1;
+            }
+            out[n * V + v] = output;
+        }
+        phase[v] = ph;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * maxiSample play family (H:602-783, C:740-1075).  One shared buffer `amp` of `len`
+ * doubles for the whole bank (the way maxiGrains alias one maxiSample, L/maxiGrains.h:162).
+ * Guards: the reference reads amplitudes[len], [len+1] (playAtSpeed family, C:1063-1064) and
+ * [-1] (play4 with position in (0,1), C:898) out of bounds; `amp` must therefore be valid on
+ * [-1, len+1] with those three elements 0.0 (the parity convention).
+ * State per voice: position.  mySampleRate is the int member (44100 after setSample, H:676).
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    const double *amp;
+    size_t len;
+    int mySampleRate;
+    double position;
+} smp_t;
+
+/* C:740-747 */
+static double smp_play(smp_t *s) {
+    double output = s->amp[(long)s->position];
+    s->position++;
+    if ((size_t)(long)s->position >= s->len) {
+        s->position = 0;
+    }
+    return output;
+}
+/* C:982-991 */
+static double smp_playOnce(smp_t *s) {
+    double output;
+    if ((size_t)(long)s->position < s->len)
+        output = s->amp[(long)s->position];
+    else {
+        output = 0;
+    }
+    s->position++;
+    return output;
+}
+/* C:960-967 */
+static double smp_playLoop(smp_t *s, double start, double end) {
+    s->position++;
+    size_t sampleLength = s->len;
+    if (s->position < sampleLength * start) s->position = sampleLength * start;
+    if ((long)s->position >= sampleLength * end) s->position = sampleLength * start;
+    return s->amp[(long)s->position];
+}
+/* C:969-978 */
+static double smp_playUntil(smp_t *s, double end) {
+    double output;
+    s->position++;
+    if (end > 1.0) end = 1.0;
+    if ((long)s->position < s->len * end)
+        output = s->amp[(long)s->position];
+    else {
+        output = 0;
+    }
+    return output;
+}
+/* C:1060-1075 : sr/mySampleRate is an INTEGER division (size_t / int) */
+static double smp_playAtSpeed(smp_t *s, double speed) {
+    double output;
+    double remainder = s->position - (long)s->position;
+    if ((size_t)(long)s->position < s->len) {
+        output = ((1 - remainder) * s->amp[1 + (long)s->position] +
+                  remainder * s->amp[2 + (long)s->position]);
+    } else {
+        output = 0;
+    }
+    s->position = s->position + ((speed * chandiv) / (g_sampleRate / (size_t)s->mySampleRate));
+    if ((size_t)(long)s->position >= s->len) {
+        s->position -= s->len;
+    }
+    return output;
+}
+/* C:994-1003 */
+static double smp_playOnceAtSpeed(smp_t *s, double speed) {
+    double output;
+    double remainder = s->position - (long)s->position;
+    if ((size_t)((long)s->position + 1) < s->len)
+        output = ((1 - remainder) * s->amp[(long)s->position] +
+                  remainder * s->amp[1 + (long)s->position]);
+    else
+        output = 0;
+    s->position = s->position + ((speed * chandiv) / (g_sampleRate / (size_t)s->mySampleRate));
+    return output;
+}
+/* C:1047-1058 */
+static double smp_playUntilAtSpeed(smp_t *s, double end, double speed) {
+    double output;
+    double remainder = s->position - (long)s->position;
+    if (end > 1.0) end = 1.0;
+    if ((long)s->position < s->len * end)
+        output = ((1 - remainder) * s->amp[1 + (long)s->position] +
+                  remainder * s->amp[2 + (long)s->position]);
+    else
+        output = 0;
+    s->position = s->position + ((speed * chandiv) / (g_sampleRate / (size_t)s->mySampleRate));
+    return output;
+}
+/* C:884-956 : 4-point interpolated looped read; start/end in SAMPLES */
+static double smp_play4(smp_t *s, double frequency, double start, double end) {
+    double remainder;
+    double a, b, c, d, a1, a2, a3;
+    double output;
+    if (frequency > 0.) {
+        if (s->position < start) {
+            s->position = start;
+        }
+        if (s->position >= end) s->position = start;
+        s->position += ((end - start) / (g_sampleRate / (frequency * chandiv)));
+        remainder = s->position - floor(s->position);
+        if (s->position > 0) {
+            a = s->amp[(int)(floor(s->position)) - 1];
+        } else {
+            a = s->amp[0];
+        }
+        b = s->amp[(long)s->position];
+        if (s->position < end - 2) {
+            c = s->amp[(long)s->position + 1];
+        } else {
+            c = s->amp[0];
+        }
+        if (s->position < end - 3) {
+            d = s->amp[(long)s->position + 2];
+        } else {
+            d = s->amp[0];
+        }
+        a1 = 0.5f * (c - a);
+        a2 = a - 2.5 * b + 2.f * c - 0.5f * d;
+        a3 = 0.5f * (d - a) + 1.5f * (b - c);
+        output = (((a3 * remainder + a2) * remainder + a1) * remainder + b);
+    } else {
+        frequency *= -1.;
+        if (s->position <= start) s->position = end;
+        s->position -= ((end - start) / (g_sampleRate / (frequency * chandiv)));
+        remainder = s->position - floor(s->position);
+        if (s->position > start && s->position < end - 1) {
+            a = s->amp[(long)s->position + 1];
+        } else {
+            a = s->amp[0];
+        }
+        b = s->amp[(long)s->position];
+        if (s->position > start) {
+            c = s->amp[(long)s->position - 1];
+        } else {
+            c = s->amp[0];
+        }
+        if (s->position > start + 1) {
+            d = s->amp[(long)s->position - 2];
+        } else {
+            d = s->amp[0];
+        }
+        a1 = 0.5f * (c - a);
+        a2 = a - 2.5 * b + 2.f * c - 0.5f * d;
+        a3 = 0.5f * (d - a) + 1.5f * (b - c);
+        output = (((a3 * remainder + a2) * -remainder + a1) * -remainder + b);
+    }
+    return output;
+}
+/* C:823-880 : playAtSpeedBetweenPoints passes `position` BY VALUE (C:824) -- the member is
+ * never advanced, every call recomputes from the same position.  Replicated as is. */
+static double smp_playAtSpeedBetweenPoints(smp_t *s, double frequency, double start, double end) {
+    double pos = s->position;
+    double remainder, output;
+    size_t amplen = s->len;
+    if (end >= amplen) end = amplen - 1;
+    long a, b;
+    if (frequency > 0.) {
+        if (pos < start) {
+            pos = start;
+        }
+        if (pos >= end) pos = start;
+        pos += ((end - start) / ((g_sampleRate) / (frequency * chandiv)));
+        remainder = pos - floor(pos);
+        long posl = floor(pos);
+        if ((size_t)(posl + 1) < amplen) {
+            a = posl + 1;
+        } else {
+            a = posl - 1;
+        }
+        if ((size_t)(posl + 2) < amplen) {
+            b = posl + 2;
+        } else {
+            b = amplen - 1;
+        }
+        output = ((1 - remainder) * s->amp[a] + remainder * s->amp[b]);
+    } else {
+        frequency *= -1.;
+        if (pos <= start) pos = end;
+        pos -= ((end - start) / (g_sampleRate / (frequency * chandiv)));
+        remainder = pos - floor(pos);
+        long posl = floor(pos);
+        if (posl - 1 >= 0) {
+            a = posl - 1;
+        } else {
+            a = 0;
+        }
+        if (posl - 2 >= 0) {
+            b = posl - 2;
+        } else {
+            b = 0;
+        }
+        output = ((-1 - remainder) * s->amp[a] + remainder * s->amp[b]);
+    }
+    return output;
+}
+
+/* mode: 0 play 1 playOnce 2 playLoop(start,end) 3 playUntil(end) 4 playAtSpeed(a)
+ * 5 playOnceAtSpeed(a) 6 playUntilAtSpeed(end,a) 7 play4(a=frequency,start,end)
+ * 8 playAtSpeedBetweenPoints(a=frequency,start,end).  a is [V] or [N][V] (aps). */
+int mxo_sample(int mode, size_t V, size_t N, const double *amp, size_t len, int mySampleRate,
+               const double *a, int aps, const double *start, const double *end, double *position,
+               double *out) {
+    if (mode < 0 || mode > 8) return -1;
+    for (size_t v = 0; v < V; v++) {
+        smp_t s = {amp, len, mySampleRate, position[v]};
+        double st = start ? start[v] : 0.0, en = end ? end[v] : 1.0;
+        for (size_t n = 0; n < N; n++) {
+            double x = a ? (aps ? a[n * V + v] : a[v]) : 1.0;
+            double o = 0;
+            switch (mode) {
+                case 0: o = smp_play(&s); break;
+                case 1: o = smp_playOnce(&s); break;
+                case 2: o = smp_playLoop(&s, st, en); break;
+                case 3: o = smp_playUntil(&s, en); break;
+                case 4: o = smp_playAtSpeed(&s, x); break;
+                case 5: o = smp_playOnceAtSpeed(&s, x); break;
+                case 6: o = smp_playUntilAtSpeed(&s, en, x); break;
+                case 7: o = smp_play4(&s, x, st, en); break;
+                case 8: o = smp_playAtSpeedBetweenPoints(&s, x, st, en); break;
+            }
+            out[n * V + v] = o;
+        }
+        position[v] = s.position;
+    }
+    return 0;
+}

@@ -144,6 +144,51 @@ class Oracle:
         assert rc == 0
         return mix
 
+    # -- maxiDelayline ---------------------------------------------------------------------------
+    def delay(self, mode, x, size, feedback, cap, position=None, mem=None, phase=None):
+        x = _f64(x)
+        N, V = x.shape
+        size = np.ascontiguousarray(np.broadcast_to(np.asarray(size, np.int32), (V,)))
+        feedback = _f64(feedback, (V,))
+        position = np.zeros(V, np.int32) if position is None else \
+            np.ascontiguousarray(np.broadcast_to(np.asarray(position, np.int32), (V,)))
+        mem = np.zeros((cap, V)) if mem is None else _f64(mem).copy()
+        phase = np.zeros(V, np.int32) if phase is None else np.ascontiguousarray(phase, np.int32).copy()
+        out = np.empty((N, V))
+        fn = self.L.mxo_delay
+        fn.restype = c_int
+        fn.argtypes = [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                       c_size_t, c_void_p, c_void_p]
+        rc = fn(mode, V, N, _p(x), _p(size), _p(feedback), _p(position), _p(mem), cap, _p(phase), _p(out))
+        assert rc == 0, rc
+        return out, mem, phase
+
+    # -- maxiSample play family ------------------------------------------------------------------
+    @staticmethod
+    def guarded(samples):
+        """[0, samples..., 0, 0] and the offset-1 view the mxo_sample/mxg_sample contract wants."""
+        g = np.zeros(len(samples) + 3)
+        g[1:-2] = samples
+        return g
+
+    def sample(self, mode, samples, N, position, a=None, start=None, end=None, aps=False,
+               mySampleRate=44100):
+        g = self.guarded(np.asarray(samples, np.float64))
+        position = _f64(position).copy()
+        V = position.size
+        a = None if a is None else _f64(a, (N, V) if aps else (V,))
+        start = None if start is None else _f64(start, (V,))
+        end = None if end is None else _f64(end, (V,))
+        out = np.empty((N, V))
+        fn = self.L.mxo_sample
+        fn.restype = c_int
+        fn.argtypes = [c_int, c_size_t, c_size_t, c_void_p, c_size_t, c_int, c_void_p, c_int, c_void_p,
+                       c_void_p, c_void_p, c_void_p]
+        rc = fn(mode, V, N, g.ctypes.data + 8, len(samples), mySampleRate, _p(a), int(aps), _p(start),
+                _p(end), _p(position), _p(out))
+        assert rc == 0, rc
+        return out, position
+
     # -- CPU baseline timer -----------------------------------------------------------------------
     def time_osc(self, wf, freq, N, threads=1):
         freq = _f64(freq)

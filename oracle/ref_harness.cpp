@@ -21,6 +21,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 #include <chrono>
@@ -317,6 +318,67 @@ int mxo_mix_stereo(size_t V, size_t N, const double *in, const double *pan, doub
         }
         mix[2 * n] = l;
         mix[2 * n + 1] = r;
+    }
+    return 0;
+}
+
+// ---- maxiDelayline bank (src/maximilian.cpp:415-439) ------------------------------------------
+// The reference object embeds a 5.6 MB memory[] array (H:273); the harness keeps one object on
+// the heap per voice and mirrors the first `cap` slots to/from mem[slot*V + v].
+int mxo_delay(int mode, size_t V, size_t N, const double *in, const int32_t *size,
+              const double *feedback, const int32_t *position, double *mem, size_t cap,
+              int32_t *phase, double *out) {
+    if (mode < 0 || mode > 1) return -1;
+    for (size_t v = 0; v < V; v++) {
+        if ((size_t)size[v] > cap) return -2;
+        std::unique_ptr<maxiDelayline> d(new maxiDelayline());
+        d->phase = phase[v];
+        for (size_t k = 0; k < cap; k++) d->memory[k] = mem[k * V + v];
+        for (size_t n = 0; n < N; n++) {
+            out[n * V + v] = mode == 0 ? d->dl(in[n * V + v], size[v], feedback[v])
+                                       : d->dlFromPosition(in[n * V + v], size[v], feedback[v], position[v]);
+        }
+        for (size_t k = 0; k < cap; k++) mem[k * V + v] = d->memory[k];
+        phase[v] = d->phase;
+    }
+    return 0;
+}
+
+// ---- maxiSample play family (src/maximilian.cpp:740-1075) ----------------------------------------
+// `amp` points at element 0 of a buffer valid on [-1, len+1] (guards 0.0).  Each voice gets
+// its own maxiSample holding a copy of the data (setSample, H:670-678); the two elements past
+// the end are made deterministic by reserving len+2 and zeroing them in place.
+int mxo_sample(int mode, size_t V, size_t N, const double *amp, size_t len, int mySampleRate,
+               const double *a, int aps, const double *start, const double *end, double *position,
+               double *out) {
+    if (mode < 0 || mode > 8) return -1;
+    std::vector<double> data(amp, amp + len);
+    for (size_t v = 0; v < V; v++) {
+        maxiSample s;
+        s.amplitudes.reserve(len + 2);
+        s.setSample(data);
+        s.amplitudes.data()[len] = 0.0;
+        s.amplitudes.data()[len + 1] = 0.0;
+        s.mySampleRate = mySampleRate;
+        s.position = position[v];
+        double st = start ? start[v] : 0.0, en = end ? end[v] : 1.0;
+        for (size_t n = 0; n < N; n++) {
+            double x = a ? (aps ? a[n * V + v] : a[v]) : 1.0;
+            double o = 0;
+            switch (mode) {
+                case 0: o = s.play(); break;
+                case 1: o = s.playOnce(); break;
+                case 2: o = s.playLoop(st, en); break;
+                case 3: o = s.playUntil(en); break;
+                case 4: o = s.playAtSpeed(x); break;
+                case 5: o = s.playOnceAtSpeed(x); break;
+                case 6: o = s.playUntilAtSpeed(en, x); break;
+                case 7: o = s.play4(x, st, en); break;
+                case 8: o = s.playAtSpeedBetweenPoints(x, st, en); break;
+            }
+            out[n * V + v] = o;
+        }
+        position[v] = s.position;
     }
     return 0;
 }

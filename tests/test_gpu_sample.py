@@ -1,0 +1,96 @@
+"""GPU parity (-m gpu): maxiDelayline and maxiSample banks through the C-ABI vs oracle + golden."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+SMP = ["play", "playOnce", "playLoop", "playUntil", "playAtSpeed", "playOnceAtSpeed",
+       "playUntilAtSpeed", "play4", "playAtSpeedBetweenPoints"]
+
+
+def test_delay_golden(mx, golden):
+    g = golden("delay.npz")
+    cap, V = int(g["cap"]), g["x"].shape[1]
+    for mode, name in enumerate(["dl", "dlFromPosition"]):
+        bank = mx.maxiDelaylineBank(V, cap)
+        x1, x2 = mx.DeviceBuffer.from_numpy(g["x"][:250]), mx.DeviceBuffer.from_numpy(g["x"][250:])
+        if mode == 0:
+            o = np.concatenate([bank.dl(x1, g["size"], g["fb"]).numpy(), bank.dl(x2, g["size"], g["fb"]).numpy()])
+        else:
+            o = np.concatenate([bank.dlFromPosition(x1, g["size"], g["fb"], g["pos"]).numpy(),
+                                bank.dlFromPosition(x2, g["size"], g["fb"], g["pos"]).numpy()])
+        assert_bits_equal(o, g["out_" + name], name)
+        assert_bits_equal(bank.memory.numpy(), g["mem_" + name], name + " mem")
+        assert np.array_equal(bank.phase.numpy(), g["phase_" + name])
+
+
+def test_delay_vs_oracle_large(mx, port):
+    rng = np.random.default_rng(21)
+    V, N, cap = 4096, 700, 300   # N > size: the ring wraps inside one launch
+    x = rng.uniform(-1, 1, (N, V))
+    size = np.where(np.arange(V) % 3 == 0, 257, rng.integers(1, cap + 1, V)).astype(np.int32)
+    fb = rng.uniform(0, 0.9, V)
+    bank = mx.maxiDelaylineBank(V, cap)
+    dx = mx.DeviceBuffer.from_numpy(x)
+    o = bank.dl(dx, size, fb).numpy()
+    e, emem, eph = port.delay(0, x, size, fb, cap)
+    assert_bits_equal(o, e, "dl")
+    assert_bits_equal(bank.memory.numpy(), emem, "mem")
+    assert np.array_equal(bank.phase.numpy(), eph)
+    L = mx.lib()
+    assert L.mxg_delay_render(2, V, N, dx.ptr, None, None, None, bank.memory.ptr, cap, bank.phase.ptr, dx.ptr, None) == -1
+
+
+@pytest.mark.parametrize("mode", range(9))
+def test_sample_golden(mx, golden, mode):
+    g = golden("sample.npz")
+    name = SMP[mode]
+    N = int(g["N"])
+    V = g["pos0_" + name].size
+    bank = mx.maxiSampleBank(V)
+    bank.setSample(g["samples"])
+    assert bank.getLength() == g["samples"].size and bank.mySampleRate == 44100
+    assert np.array_equal(bank.position.numpy(), np.full(V, g["samples"].size - 1.0))  # H:677
+    bank.position.upload(g["pos0_" + name])
+    kw = dict(a=g["a_" + name], start=g["start_" + name], end=g["end_" + name])
+    o = np.concatenate([bank.render(mode, N // 2, **kw).numpy(), bank.render(mode, N - N // 2, **kw).numpy()])
+    assert_bits_equal(o, g["out_" + name], name)
+    assert_bits_equal(bank.position.numpy(), g["pos_" + name], name + " position")
+
+
+def test_sample_speed_mod_sr96k(mx, golden):
+    g = golden("sample.npz")
+    V = g["speed_mod"].shape[1]
+    mx.maxiSettings.setup(96000, 2, 1024)
+    try:
+        bank = mx.maxiSampleBank(V)
+        bank.setSample(g["samples"])
+        bank.trigger()
+        o = bank.playAtSpeed(g["speed_mod"], int(g["N"]), per_sample=True).numpy()
+        p = bank.position.numpy()
+    finally:
+        mx.maxiSettings.setup(44100, 2, 1024)
+    assert_bits_equal(o, g["out_speed_mod_sr96k"])
+    assert_bits_equal(p, g["pos_speed_mod_sr96k"])
+
+
+def test_sample_vs_oracle_large(mx, port):
+    rng = np.random.default_rng(31)
+    V, N, Ls = 3000, 512, 100000
+    smp = rng.uniform(-1, 1, Ls)
+    bank = mx.maxiSampleBank(V)
+    bank.setSample(smp)
+    bank.setPosition(np.arange(V) / V)
+    speed = 0.25 + 1.5 * (np.arange(V) % 97) / 96
+    pos0 = bank.position.numpy()
+    o = bank.playAtSpeed(speed, N).numpy()
+    e, ep = port.sample(4, smp, N, pos0, a=speed)
+    assert_bits_equal(o, e, "playAtSpeed")
+    assert_bits_equal(bank.position.numpy(), ep)
+    # integer-index play(): bit-exact and wraps
+    bank.trigger()
+    o = bank.play(N).numpy()
+    e, _ = port.sample(0, smp, N, np.zeros(V))
+    assert_bits_equal(o, e, "play")

@@ -156,3 +156,71 @@ def test_filter_env_voice_port_vs_reference(port, ref):
         assert np.array_equal(a[4], b[4])
     pan = rng.uniform(-0.1, 1.1, V)
     assert_bits_equal(port.mix_stereo(x, pan), ref.mix_stereo(x, pan))
+
+
+SMP = ["play", "playOnce", "playLoop", "playUntil", "playAtSpeed", "playOnceAtSpeed",
+       "playUntilAtSpeed", "play4", "playAtSpeedBetweenPoints"]
+
+
+def test_delay_golden(port, golden):
+    g = golden("delay.npz")
+    cap = int(g["cap"])
+    for mode, name in enumerate(["dl", "dlFromPosition"]):
+        o1, mem, ph = port.delay(mode, g["x"][:250], g["size"], g["fb"], cap, position=g["pos"])
+        o2, mem, ph = port.delay(mode, g["x"][250:], g["size"], g["fb"], cap, position=g["pos"], mem=mem, phase=ph)
+        assert_bits_equal(np.concatenate([o1, o2]), g["out_" + name], name)
+        assert_bits_equal(mem, g["mem_" + name], name + " mem")
+        assert np.array_equal(ph, g["phase_" + name])
+
+
+@pytest.mark.parametrize("mode", range(9))
+def test_sample_golden(port, golden, mode):
+    g = golden("sample.npz")
+    name = SMP[mode]
+    N = int(g["N"])
+    args = dict(a=g["a_" + name], start=g["start_" + name], end=g["end_" + name])
+    o1, p = port.sample(mode, g["samples"], N // 2, g["pos0_" + name], **args)
+    o2, p = port.sample(mode, g["samples"], N - N // 2, p, **args)
+    assert_bits_equal(np.concatenate([o1, o2]), g["out_" + name], name)
+    assert_bits_equal(p, g["pos_" + name], name + " position")
+
+
+def test_sample_speed_mod_sr96k_golden(port, golden):
+    g = golden("sample.npz")
+    port.settings(96000, 2, 1024)
+    try:
+        o, p = port.sample(4, g["samples"], int(g["N"]), np.zeros(g["speed_mod"].shape[1]),
+                           a=g["speed_mod"], aps=True, mySampleRate=44100)
+    finally:
+        port.settings(44100, 2, 1024)
+    assert_bits_equal(o, g["out_speed_mod_sr96k"])
+    assert_bits_equal(p, g["pos_speed_mod_sr96k"])
+
+
+def test_delay_sample_port_vs_reference(port, ref):
+    rng = np.random.default_rng(11)
+    V, N, cap = 13, 900, 50
+    x = rng.uniform(-1, 1, (N, V))
+    size = rng.integers(1, cap + 1, V)
+    fb = rng.uniform(0, 0.99, V)
+    pos = rng.integers(0, cap + 5, V)
+    for mode in (0, 1):
+        a = port.delay(mode, x, size, fb, cap, position=pos)
+        b = ref.delay(mode, x, size, fb, cap, position=pos)
+        assert_bits_equal(a[0], b[0]); assert_bits_equal(a[1], b[1]); assert np.array_equal(a[2], b[2])
+    Ls = 777
+    smp = rng.uniform(-1, 1, Ls)
+    for mode in range(9):
+        pos0 = rng.uniform(1, Ls - 3, V)
+        if mode in (0, 1):
+            pos0 = np.floor(pos0)
+        a_ = rng.uniform(0.1, 4.0, V)
+        st, en = rng.uniform(0, 0.5, V), rng.uniform(0.4, 1.2, V)
+        if mode == 2:
+            en = np.minimum(en, 1.0)  # playLoop does not clamp `end`: > 1 is an OOB read in the reference
+        if mode in (7, 8):
+            a_ = rng.uniform(0.5, 80, V) * np.where(rng.uniform(0, 1, V) < 0.5, -1, 1)
+            st, en = np.floor(rng.uniform(2, 300, V)), np.floor(rng.uniform(350, Ls - 1, V))
+        a = port.sample(mode, smp, N, pos0, a=a_, start=st, end=en)
+        b = ref.sample(mode, smp, N, pos0, a=a_, start=st, end=en)
+        assert_bits_equal(a[0], b[0], SMP[mode]); assert_bits_equal(a[1], b[1], SMP[mode])
