@@ -195,6 +195,46 @@ int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, siz
                       int mySampleRate, const double *d_a, int aps, const double *d_start,
                       const double *d_end, double *d_position, double *d_out, void *stream);
 
+/* ---- maxiFFT batch ---------------------------------------------------------------------- */
+/* A plan is what maxiFFT::setup(fftSize, hopSize, windowSize) prepares (L/maxiFFT.cpp:45-60): the
+ * Hann window (fft::genWindow type 3, L/fft.cpp:409-413) and the fp32 twiddle sequences the
+ * reference generates by recurrence (L/fft.cpp:161-182, :245-272), replayed on the host.
+ * fftSize: power of two in [8, 8192] (the reference exit(1)s otherwise, L/fft.cpp:129-132 ->
+ * here NULL + MXG_ERR_INVALID); windowSize < fftSize is raised to fftSize as in the reference;
+ * windowSize > fftSize overruns the reference's buffers and is rejected. */
+typedef struct mxg_fft_plan mxg_fft_plan;
+mxg_fft_plan *mxg_fft_plan_create(int fftSize, int hopSize, int windowSize);
+int mxg_fft_plan_destroy(mxg_fft_plan *plan);
+int mxg_fft_plan_bins(const mxg_fft_plan *plan); /* getNumBins() = fftSize/2 */
+/* Transform nframes frames; frame k = d_signal[k*frame_stride .. k*frame_stride + fftSize).
+ * With frame_stride = hopSize over a signal prefixed by (windowSize-hopSize) zeros this is exactly
+ * the sequence of frames maxiFFT::process() analyses (L/maxiFFT.cpp:65-91).  Outputs are
+ * [nframes][bins] fp32, any of them may be NULL: real/imag = getReal()/getImag() (bin 0 packs
+ * DC and Nyquist, L/fft.cpp:274-275), mags/phases = getMagnitudes()/getPhases() (cartToPol,
+ * L/fft.cpp:507-515).  real, imag and mags are bit-exact; phases use the device atan2f. */
+int mxg_fft_batch(const mxg_fft_plan *plan, const float *d_signal, size_t frame_stride,
+                  size_t nframes, float *d_real, float *d_imag, float *d_mags, float *d_phases,
+                  void *stream);
+
+/* ---- maxiMFCC batch --------------------------------------------------------------------- */
+/* maxiMFCC::setup(numBins, numFilters, numCoeffs, minFreq, maxFreq) (L/maxiMFCC.h:56-75): builds
+ * the mel filterbank and DCT tables on the host libm.  Works without a device (tables only). */
+typedef struct mxg_mfcc_plan mxg_mfcc_plan;
+mxg_mfcc_plan *mxg_mfcc_plan_create(unsigned numBins, unsigned numFilters, unsigned numCoeffs,
+                                    double minFreq, double maxFreq);
+int mxg_mfcc_plan_destroy(mxg_mfcc_plan *plan);
+/* Copy out the host tables in the reference's layouts: melFilters[filter + bin*numFilters],
+ * dct[i + j*numCoeffs].  Either may be NULL.  Returns the number of leading bins that carry a
+ * non-zero weight. */
+int mxg_mfcc_plan_tables(const mxg_mfcc_plan *plan, double *h_melFilters, double *h_dct);
+/* mfcc() over nframes spectra d_mags[f*mag_stride + bin] (fp32, as getMagnitudes() yields) ->
+ * d_mfcc [nframes][numCoeffs] (L/maxiMFCC.h:77-81).  Optional: d_melraw = the band sums before
+ * the log (bit-exact with method 0), d_melbands = melBands after log-square, [nframes][numFilters].
+ * method 0: exact sparse evaluation in the reference's summation order; method 1: dense fp64 MFMA
+ * contraction (v_mfma_f64_16x16x4_f64), reordered/fused sums => tolerance. */
+int mxg_mfcc_batch(const mxg_mfcc_plan *plan, const float *d_mags, size_t mag_stride, size_t nframes,
+                   double *d_melraw, double *d_melbands, double *d_mfcc, int method, void *stream);
+
 /* ---- calibration ----------------------------------------------------------------------- */
 /* Streaming fill of `bytes` at d_dst (8 B/lane or 16 B/lane stores): the measured HBM write
  * ceiling that bench.py reports next to the nominal 8 TB/s. */

@@ -9,3 +9,4 @@ from ._lib import LIB_PATH, MaxiGpuError, lib  # noqa: F401
 from .banks import (DeviceBuffer, maxiSettings, maxiOscBank, maxiFilterBank, maxiEnvBank,  # noqa: F401
                     maxiVoiceBank, maxiMixBank, maxiDelaylineBank, maxiSampleBank, OSC_WAVEFORMS,
                     FILTER_KINDS, SAMPLE_MODES)
+from .spectral import maxiFFT, maxiMFCC, frames_in_stream, padded_stream  # noqa: F401

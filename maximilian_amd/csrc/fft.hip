@@ -1,0 +1,392 @@
+// fft.hip -- maxiFFT batch on gfx950: windowed real FFT + polar conversion, one wavefront per frame.
+//
+// Path (reference, L/ = src/libs/): maxiFFT::setup/process L/maxiFFT.cpp:45-91 ->
+// fft::powerSpectrum L/fft.cpp:519-524 -> calcFFT :499-505 (window multiply) -> RealFFT
+// :228-282 (even/odd pack, half-size complex FFT :118-211, real split post-pass) -> cartToPol
+// :507-515.  The reference runs this once per hop inside the per-sample process(); here a batch
+// of frames (frame k = signal[k*frame_stride .. +fftSize)) is transformed per launch.
+//
+// Numerics: everything is fp32, and BIT-EXACT for real/imag/magnitudes.  The reference builds
+// its twiddles by an fp32 recurrence seeded from double sin/cos (L/fft.cpp:161-182, :245-272);
+// those sequences do not depend on the data, so the plan replays the very same recurrences on
+// the host (host libm, fp32 ops, no contraction) and uploads them as tables.  Butterflies inside
+// one stage are independent, so any parallel order gives identical bits as long as each
+// butterfly uses the reference's op sequence (tr = ar*xr - ai*xi as mul,mul,sub ...), which
+// -ffp-contract=off guarantees.  sqrtf is correctly rounded on gfx950 (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt); atan2f is OCML's and carries a stated tolerance.
+//
+// Kernels.  K6a `fft1024_kernel` (fftSize 1024, the size of every config/test in the reference):
+// the 512-point complex FFT is done as three register rounds of three radix-2 stages each, 8
+// complex points per lane, with two padded LDS transposes between rounds; loads are direct
+// global float2 reads in bit-reversed order (each wavefront instruction still covers one full
+// 512-B segment).  K6b `fft_generic_kernel`: any power-of-two size 8..8192, one LDS pass per
+// stage.  HBM bytes per frame: fftSize*4 read + bins*4 per requested output.
+#include <math.h>
+
+#include <vector>
+
+#include "mxg_common.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+struct mxg_fft_plan {
+    int fftSize, hopSize, windowSize, bins, half, numBits;
+    float *d_window;   // [fftSize]
+    float2 *d_tw;      // stage twiddles: entry (h-1)+n = (ar0, ai0) of step n in a stage with BlockEnd h
+    float2 *d_post;    // post-pass (wr, wi) for i = 1 .. half/2-1 at index i
+};
+
+namespace mxg {
+namespace {
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS traffic of ONE wavefront: the DS unit executes a wave's instructions in order, so only
+    // the compiler has to be told not to move accesses across this point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One butterfly, op for op L/fft.cpp:184-192 (j = upper, k = lower input).
+__device__ __forceinline__ void bfly(float2 &xj, float2 &xk, const float2 w) {
+    float tr = w.x * xk.x - w.y * xk.y;
+    float ti = w.x * xk.y + w.y * xk.x;
+    xk.x = xj.x - tr;
+    xk.y = xj.y - ti;
+    xj.x += tr;
+    xj.y += ti;
+}
+
+// Real split post-pass for the pair (i, i3 = half - i), L/fft.cpp:250-268.
+__device__ __forceinline__ void post_pair(float2 &a, float2 &b, const float2 w) {
+    const float wr = w.x, wi = w.y;
+    float h1r = 0.5f * (a.x + b.x);
+    float h1i = 0.5f * (a.y - b.y);
+    float h2r = 0.5f * (a.y + b.y);
+    float h2i = -0.5f * (a.x - b.x);
+    a.x = h1r + wr * h2r - wi * h2i;
+    a.y = h1i + wr * h2i + wi * h2r;
+    b.x = h1r - wr * h2r + wi * h2i;
+    b.y = -h1i + wr * h2i + wi * h2r;
+}
+
+struct FftOut {
+    float *real, *imag, *mags, *phases;
+};
+
+__device__ __forceinline__ void emit_bin(const FftOut &o, size_t base, int bin, float2 v) {
+    if (o.real) o.real[base + bin] = v.x;
+    if (o.imag) o.imag[base + bin] = v.y;
+    if (o.mags || o.phases) {
+        float power = v.x * v.x + v.y * v.y;  // L/fft.cpp:510
+        if (o.mags) o.mags[base + bin] = sqrtf(power);
+        if (o.phases) o.phases[base + bin] = atan2f(v.y, v.x);
+    }
+}
+
+// ---- K6b: generic size -----------------------------------------------------------------------
+constexpr int kWavesPerBlock = 4;
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void fft_generic_kernel(
+    const float *__restrict__ signal, size_t frame_stride, size_t nframes, int fftSize, int numBits,
+    const float *__restrict__ window, const float2 *__restrict__ tw, const float2 *__restrict__ post,
+    FftOut out) {
+    extern __shared__ float2 s_dyn[];
+    const int half = fftSize >> 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float2 *X = s_dyn + (size_t)wave * (half + (half >> 5) + 1);
+    auto P = [](int idx) { return idx + (idx >> 5); };  // one pad slot per 32: breaks pow-2 strides
+    for (size_t f = (size_t)blockIdx.x * kWavesPerBlock + wave; f < nframes;
+         f += (size_t)gridDim.x * kWavesPerBlock) {
+        const float *x = signal + f * frame_stride;
+        for (int i = lane; i < half; i += 64) {
+            float2 v;
+            v.x = x[2 * i] * window[2 * i];          // calcFFT L/fft.cpp:501-503
+            v.y = x[2 * i + 1] * window[2 * i + 1];  // RealFFT pack :238-241
+            int j = (int)(__brev((unsigned)i) >> (32 - numBits));  // :146-150
+            X[P(j)] = v;
+        }
+        wave_lds_sync();
+        for (int s = 0; s < numBits; s++) {
+            const int h = 1 << s;
+            for (int b = lane; b < (half >> 1); b += 64) {
+                int n = b & (h - 1);
+                int j = ((b >> s) << (s + 1)) | n;
+                int k = j + h;
+                float2 xj = X[P(j)], xk = X[P(k)];
+                bfly(xj, xk, tw[h - 1 + n]);
+                X[P(j)] = xj;
+                X[P(k)] = xk;
+            }
+            wave_lds_sync();
+        }
+        const size_t base = f * (size_t)half;
+        for (int i = 1 + lane; i < (half >> 1); i += 64) {
+            float2 a = X[P(i)], b = X[P(half - i)];
+            post_pair(a, b, post[i]);
+            emit_bin(out, base, i, a);
+            emit_bin(out, base, half - i, b);
+        }
+        if (lane == 0) {  // L/fft.cpp:274-275 and the untouched middle bin
+            float2 z = X[P(0)];
+            float2 z0 = {z.x + z.y, z.x - z.y};
+            emit_bin(out, base, 0, z0);
+            if (half >= 2) emit_bin(out, base, half >> 1, X[P(half >> 1)]);
+        }
+        wave_lds_sync();
+    }
+}
+
+// ---- K6a: fftSize 1024 (half = 512 = 8^3) ------------------------------------------------------
+// LDS image of one frame: 512 float2 + 1 pad per 8 (index p = i + i/8): conflict-free for the
+// stride-8 and stride-64 lane patterns of the two transposes (bank maths in DESIGN.md).
+constexpr int kX1024 = 512 + 64;
+
+__device__ __forceinline__ int pad8(int i) { return i + (i >> 3); }
+
+// three in-register radix-2 stages over the 8 points of a lane; w0: 1 twiddle (pairs e,e+1),
+// w1[2]: pairs (e,e+2) with n-offset e&1, w2[4]: pairs (e,e+4) with n-offset e&3.
+__device__ __forceinline__ void round3(float2 (&x)[8], const float2 w0, const float2 (&w1)[2],
+                                       const float2 (&w2)[4]) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) bfly(x[e], x[e + 1], w0);
+#pragma unroll
+    for (int e = 0; e < 8; e++)
+        if ((e & 2) == 0) bfly(x[e], x[e + 2], w1[e & 1]);
+#pragma unroll
+    for (int e = 0; e < 4; e++) bfly(x[e], x[e + 4], w2[e]);
+}
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void fft1024_kernel(
+    const float *__restrict__ signal, size_t frame_stride, size_t nframes,
+    const float *__restrict__ window, const float2 *__restrict__ tw, const float2 *__restrict__ post,
+    FftOut out, int aligned8) {
+    // one __shared__ object: [tw 512][post 256][X per wave]
+    __shared__ float2 s_all[512 + 256 + kWavesPerBlock * kX1024];
+    float2 *s_tw = s_all, *s_post = s_all + 512;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float2 *X = s_all + 768 + wave * kX1024;
+    for (int i = threadIdx.x; i < 511; i += blockDim.x) s_tw[i] = tw[i];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_post[i] = post[i];
+    __syncthreads();
+
+    const int lo = lane & 7, hi = lane >> 3;
+    const int rev6 = (int)(__brev((unsigned)lane) >> 26);
+    // round A twiddles are lane-uniform: stage 0 n=0; stage 1 n=0,1; stage 2 n=0..3
+    const float2 a0 = s_tw[0];
+    const float2 a1[2] = {s_tw[1], s_tw[2]};
+    const float2 a2[4] = {s_tw[3], s_tw[4], s_tw[5], s_tw[6]};
+    // round B: stages 3,4,5 (h = 8,16,32): n = lo, (e&1)*8+lo, (e&3)*8+lo
+    const float2 b0 = s_tw[7 + lo];
+    const float2 b1[2] = {s_tw[15 + lo], s_tw[15 + 8 + lo]};
+    const float2 b2[4] = {s_tw[31 + lo], s_tw[31 + 8 + lo], s_tw[31 + 16 + lo], s_tw[31 + 24 + lo]};
+    // round C: stages 6,7,8 (h = 64,128,256): n = lane, (e&1)*64+lane, (e&3)*64+lane
+    const float2 c0 = s_tw[63 + lane];
+    const float2 c1[2] = {s_tw[127 + lane], s_tw[127 + 64 + lane]};
+    const float2 c2[4] = {s_tw[255 + lane], s_tw[255 + 64 + lane], s_tw[255 + 128 + lane],
+                          s_tw[255 + 192 + lane]};
+
+    // the 8 packed elements a lane loads are the same for every frame: keep their window
+    // coefficients in registers
+    float2 wv[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int rev3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);
+        const int i = rev3 * 64 + rev6;
+        wv[e] = make_float2(window[2 * i], window[2 * i + 1]);
+    }
+
+    for (size_t f = (size_t)blockIdx.x * kWavesPerBlock + wave; f < nframes;
+         f += (size_t)gridDim.x * kWavesPerBlock) {
+        const float *x = signal + f * frame_stride;
+        float2 v[8];
+        // Round A input: lane holds idx = 8*lane + e  <-  packed element i = rev9(idx)
+        //              = rev3(e)*64 + rev6(lane): for each e one 512-B segment per wavefront.
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int rev3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);
+            const int i = rev3 * 64 + rev6;
+            float2 s;
+            if (aligned8) {
+                s = *reinterpret_cast<const float2 *>(x + 2 * i);
+            } else {
+                s.x = x[2 * i];
+                s.y = x[2 * i + 1];
+            }
+            v[e].x = s.x * wv[e].x;  // calcFFT L/fft.cpp:501-503
+            v[e].y = s.y * wv[e].y;
+        }
+        round3(v, a0, a1, a2);
+        // transpose A->B: write idx = 8*lane + e, read idx = hi*64 + e*8 + lo
+#pragma unroll
+        for (int e = 0; e < 8; e++) X[pad8(8 * lane + e)] = v[e];
+        wave_lds_sync();
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = X[pad8(hi * 64 + e * 8 + lo)];
+        round3(v, b0, b1, b2);
+        wave_lds_sync();
+        // transpose B->C: write same positions, read idx = e*64 + lane
+#pragma unroll
+        for (int e = 0; e < 8; e++) X[pad8(hi * 64 + e * 8 + lo)] = v[e];
+        wave_lds_sync();
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = X[pad8(e * 64 + lane)];
+        round3(v, c0, c1, c2);
+        wave_lds_sync();
+        // natural order back to LDS for the (i, 512-i) pairing of the post-pass
+#pragma unroll
+        for (int e = 0; e < 8; e++) X[pad8(e * 64 + lane)] = v[e];
+        wave_lds_sync();
+        const size_t base = f * (size_t)512;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = 1 + lane + 64 * q;  // 1..256
+            if (i < 256) {
+                float2 a = X[pad8(i)], b = X[pad8(512 - i)];
+                post_pair(a, b, s_post[i]);
+                emit_bin(out, base, i, a);
+                emit_bin(out, base, 512 - i, b);
+            } else {  // i == 256 (lane 63, q 3): the untouched middle bin; and bin 0
+                emit_bin(out, base, 256, X[pad8(256)]);
+                float2 z = X[pad8(0)];
+                float2 z0 = {z.x + z.y, z.x - z.y};
+                emit_bin(out, base, 0, z0);
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
+}  // namespace
+}  // namespace mxg
+
+using namespace mxg;
+
+extern "C" {
+
+mxg_fft_plan *mxg_fft_plan_create(int fftSize, int hopSize, int windowSize) {
+    if (ensure_init()) return nullptr;
+    if (fftSize < 8 || fftSize > 8192 || (fftSize & (fftSize - 1))) {
+        fail(MXG_ERR_INVALID, "mxg_fft_plan_create: fftSize %d must be a power of two in [8, 8192] "
+                              "(the reference exit(1)s on a non power of two, fft.cpp:129-132)", fftSize);
+        return nullptr;
+    }
+    int win = windowSize > fftSize ? windowSize : fftSize;  // L/maxiFFT.cpp:48
+    if (win > fftSize) {
+        fail(MXG_ERR_INVALID, "mxg_fft_plan_create: windowSize %d > fftSize %d overruns the reference's "
+                              "window/buffer vectors (maxiFFT.cpp:51-58); not supported", windowSize, fftSize);
+        return nullptr;
+    }
+    if (hopSize <= 0 || hopSize > win) {
+        fail(MXG_ERR_INVALID, "mxg_fft_plan_create: hopSize %d out of (0, %d]", hopSize, win);
+        return nullptr;
+    }
+    const int half = fftSize / 2;
+    int numBits = 0;
+    while (!(half & (1 << numBits))) numBits++;
+    // Hann window, type 3 of fft::genWindow (L/fft.cpp:409-413), double -> float
+    std::vector<float> window(fftSize);
+    for (int i = 0; i < win; i++) window[i] = 0.50 - 0.50 * cos(2 * M_PI * i / (win - 1));
+    // stage twiddles: replay of L/fft.cpp:156-182 for the half-size complex transform
+    std::vector<float2> tw(half);
+    {
+        const double angle_numerator = 2.0 * M_PI;
+        int BlockEnd = 1;
+        for (int BlockSize = 2; BlockSize <= half; BlockSize <<= 1) {
+            double delta_angle = angle_numerator / (double)BlockSize;
+            float sm2 = sin(-2 * delta_angle);
+            float sm1 = sin(-delta_angle);
+            float cm2 = cos(-2 * delta_angle);
+            float cm1 = cos(-delta_angle);
+            float w = 2 * cm1;
+            float ar2 = cm2, ar1 = cm1, ai2 = sm2, ai1 = sm1;
+            for (int n = 0; n < BlockEnd; n++) {
+                float ar0 = w * ar1 - ar2;
+                ar2 = ar1;
+                ar1 = ar0;
+                float ai0 = w * ai1 - ai2;
+                ai2 = ai1;
+                ai1 = ai0;
+                tw[BlockEnd - 1 + n] = make_float2(ar0, ai0);
+            }
+            BlockEnd = BlockSize;
+        }
+    }
+    // post-pass twiddles: replay of L/fft.cpp:233-272
+    std::vector<float2> post(half / 2 > 0 ? half / 2 : 1);
+    {
+        float theta = M_PI / half;
+        float wtemp = float(sin(0.5 * theta));
+        float wpr = -2.0 * wtemp * wtemp;
+        float wpi = float(sin(theta));
+        float wr = 1.0 + wpr;
+        float wi = wpi;
+        post[0] = make_float2(0.f, 0.f);
+        for (int i = 1; i < half / 2; i++) {
+            post[i] = make_float2(wr, wi);
+            wtemp = wr;
+            wr = wtemp * wpr - wi * wpi + wr;
+            wi = wi * wpr + wtemp * wpi + wi;
+        }
+    }
+    mxg_fft_plan *p = new mxg_fft_plan();
+    p->fftSize = fftSize;
+    p->hopSize = hopSize;
+    p->windowSize = win;
+    p->bins = half;
+    p->half = half;
+    p->numBits = numBits;
+    p->d_window = nullptr;
+    p->d_tw = nullptr;
+    p->d_post = nullptr;
+    if (check_hip(hipMalloc(&p->d_window, sizeof(float) * fftSize), "hipMalloc") ||
+        check_hip(hipMalloc(&p->d_tw, sizeof(float2) * tw.size()), "hipMalloc") ||
+        check_hip(hipMalloc(&p->d_post, sizeof(float2) * post.size()), "hipMalloc") ||
+        check_hip(hipMemcpy(p->d_window, window.data(), sizeof(float) * fftSize, hipMemcpyHostToDevice), "hipMemcpy") ||
+        check_hip(hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice), "hipMemcpy") ||
+        check_hip(hipMemcpy(p->d_post, post.data(), sizeof(float2) * post.size(), hipMemcpyHostToDevice), "hipMemcpy")) {
+        mxg_fft_plan_destroy(p);
+        return nullptr;
+    }
+    return p;
+}
+
+int mxg_fft_plan_destroy(mxg_fft_plan *p) {
+    if (!p) return MXG_OK;
+    if (p->d_window) (void)hipFree(p->d_window);
+    if (p->d_tw) (void)hipFree(p->d_tw);
+    if (p->d_post) (void)hipFree(p->d_post);
+    delete p;
+    return MXG_OK;
+}
+
+int mxg_fft_plan_bins(const mxg_fft_plan *p) { return p ? p->bins : MXG_ERR_INVALID; }
+
+int mxg_fft_batch(const mxg_fft_plan *p, const float *d_signal, size_t frame_stride, size_t nframes,
+                  float *d_real, float *d_imag, float *d_mags, float *d_phases, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(p && d_signal, "null plan or signal");
+    MXG_REQUIRE(d_real || d_imag || d_mags || d_phases, "no output requested");
+    if (nframes == 0) return MXG_OK;
+    hipStream_t st = resolve_stream(stream);
+    FftOut out = {d_real, d_imag, d_mags, d_phases};
+    size_t blocks = (nframes + kWavesPerBlock - 1) / kWavesPerBlock;
+    const size_t cap = 256 * 5;  // persistent: <= 5 workgroups per CU, grid-stride over frames
+    if (blocks > cap) blocks = cap;
+    int force_generic = tune_get("fft_generic");
+    if (p->fftSize == 1024 && !force_generic) {
+        int aligned8 = ((((uintptr_t)d_signal) & 7) == 0 && (frame_stride & 1) == 0) ? 1 : 0;
+        hipLaunchKernelGGL(fft1024_kernel, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, st,
+                           d_signal, frame_stride, nframes, p->d_window, p->d_tw, p->d_post, out, aligned8);
+    } else {
+        size_t lds = sizeof(float2) * kWavesPerBlock * (p->half + (p->half >> 5) + 1);
+        hipLaunchKernelGGL(fft_generic_kernel, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, st,
+                           d_signal, frame_stride, nframes, p->fftSize, p->numBits, p->d_window, p->d_tw,
+                           p->d_post, out);
+    }
+    return check_hip(hipGetLastError(), "fft kernel launch");
+}
+
+}  // extern "C"

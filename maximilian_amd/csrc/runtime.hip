@@ -27,6 +27,7 @@ Tune g_tune[] = {
     {"osc_vpl", 1, 1, 2},       {"osc_block", 256, 64, 1024},  {"osc_nt", 0, 0, 1},
     {"voice_vpl", 1, 1, 2},     {"voice_block", 256, 64, 1024}, {"voice_nt", 0, 0, 1},
     {"mix_block", 256, 64, 1024},
+    {"fft_generic", 0, 0, 1},  // 1: force the generic per-stage FFT kernel also for fftSize 1024
 };
 }  // namespace
 

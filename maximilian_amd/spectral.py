@@ -1,0 +1,137 @@
+"""Host-side mirror of maxiFFT / maxiMFCC (src/libs/maxiFFT.h, maxiMFCC.h) in batch form.
+
+`maxiFFT.setup(fftSize, hopSize, windowSize)` keeps the reference's signature; instead of one
+`process(sample)` call per audio sample, `process_signal(signal)` analyses every frame the
+reference would have produced for that stream (same hop buffer semantics: the buffer starts
+with windowSize-hopSize zeros, L/maxiFFT.cpp:56) in one launch.  `maxiMFCC.mfcc(mags)` takes the
+[nframes, bins] magnitudes and returns [nframes, numCoeffs].
+"""
+import numpy as np
+
+from ._lib import check, lib
+from .banks import DeviceBuffer, _ptr
+
+
+def frames_in_stream(nsamples, hopSize, windowSize):
+    """How many times maxiFFT::process() reports a new frame over `nsamples` samples."""
+    return 0 if nsamples < hopSize else (nsamples - hopSize) // hopSize + 1
+
+
+def padded_stream(signal, hopSize, windowSize):
+    """The signal as the hop buffer sees it: (windowSize-hopSize) zeros, then the samples."""
+    signal = np.ascontiguousarray(signal, np.float32)
+    return np.concatenate([np.zeros(windowSize - hopSize, np.float32), signal])
+
+
+class maxiFFT:
+    """maxiFFT (L/maxiFFT.h:45-113) over whole signals / frame batches."""
+    NO_POLAR_CONVERSION, WITH_POLAR_CONVERSION = 0, 1
+
+    def __init__(self, stream=None):
+        self.plan = None
+        self.stream = stream
+
+    def setup(self, fftSize=1024, hopSize=512, windowSize=0):
+        """L/maxiFFT.cpp:45-60."""
+        self.close()
+        check(lib().mxg_init(-1), "mxg_init")
+        p = lib().mxg_fft_plan_create(fftSize, hopSize, windowSize)
+        if not p:
+            raise ValueError(lib().mxg_last_error().decode())
+        self.plan = p
+        self.fftSize, self.hopSize = fftSize, hopSize
+        self.windowSize = max(windowSize, fftSize)  # :48
+        self.bins = fftSize // 2
+
+    def getNumBins(self): return self.bins
+    def getFFTSize(self): return self.fftSize
+    def getHopSize(self): return self.hopSize
+    def getWindowSize(self): return self.windowSize
+
+    def process_frames(self, d_signal, frame_stride, nframes, mode=1, want_complex=False):
+        """Transform nframes frames starting every frame_stride samples in a device signal."""
+        real = imag = mags = phases = None
+        if mode == self.WITH_POLAR_CONVERSION:
+            mags = DeviceBuffer((nframes, self.bins), np.float32, zero=False)
+            phases = DeviceBuffer((nframes, self.bins), np.float32, zero=False)
+        if want_complex or mode == self.NO_POLAR_CONVERSION:
+            real = DeviceBuffer((nframes, self.bins), np.float32, zero=False)
+            imag = DeviceBuffer((nframes, self.bins), np.float32, zero=False)
+        check(lib().mxg_fft_batch(self.plan, _ptr(d_signal), frame_stride, nframes, _ptr(real), _ptr(imag),
+                                  _ptr(mags), _ptr(phases), self.stream), "mxg_fft_batch")
+        self.real, self.imag, self.magnitudes, self.phases = real, imag, mags, phases
+        return nframes
+
+    def process_signal(self, signal, mode=1, want_complex=False):
+        """Every frame process() would report while consuming `signal` sample by sample."""
+        n = frames_in_stream(len(signal), self.hopSize, self.windowSize)
+        buf = DeviceBuffer.from_numpy(padded_stream(signal, self.hopSize, self.windowSize))
+        self._keep = buf
+        if n == 0:
+            self.real = self.imag = self.magnitudes = self.phases = None
+            return 0
+        return self.process_frames(buf, self.hopSize, n, mode, want_complex)
+
+    def getMagnitudes(self): return self.magnitudes
+    def getPhases(self): return self.phases
+    def getReal(self): return self.real
+    def getImag(self): return self.imag
+
+    def close(self):
+        if self.plan:
+            lib().mxg_fft_plan_destroy(self.plan)
+            self.plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class maxiMFCC:
+    """maxiMFCCAnalyser<double> (L/maxiMFCC.h:41-211) over batches of spectra."""
+    EXACT, MFMA = 0, 1
+
+    def __init__(self, stream=None):
+        self.plan = None
+        self.stream = stream
+
+    def setup(self, numBins, numFilters, numCoeffs, minFreq, maxFreq):
+        """L/maxiMFCC.h:56-75."""
+        self.close()
+        p = lib().mxg_mfcc_plan_create(numBins, numFilters, numCoeffs, minFreq, maxFreq)
+        if not p:
+            raise ValueError(lib().mxg_last_error().decode())
+        self.plan = p
+        self.numBins, self.numFilters, self.numCoeffs = numBins, numFilters, numCoeffs
+
+    def tables(self):
+        W = np.zeros(self.numFilters * self.numBins)
+        D = np.zeros(self.numCoeffs * self.numFilters)
+        used = lib().mxg_mfcc_plan_tables(self.plan, W.ctypes.data, D.ctypes.data)
+        return W, D, used
+
+    def mfcc(self, mags, nframes=None, mag_stride=None, method=0, want_bands=False):
+        nframes = mags.shape[0] if nframes is None else nframes
+        mag_stride = self.numBins if mag_stride is None else mag_stride
+        out = DeviceBuffer((nframes, self.numCoeffs), np.float64, zero=False)
+        raw = bands = None
+        if want_bands:
+            raw = DeviceBuffer((nframes, self.numFilters), np.float64, zero=False)
+            bands = DeviceBuffer((nframes, self.numFilters), np.float64, zero=False)
+        check(lib().mxg_mfcc_batch(self.plan, _ptr(mags), mag_stride, nframes, _ptr(raw), _ptr(bands),
+                                   _ptr(out), method, self.stream), "mxg_mfcc_batch")
+        self.melraw, self.melBands = raw, bands
+        return out
+
+    def close(self):
+        if self.plan:
+            lib().mxg_mfcc_plan_destroy(self.plan)
+            self.plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -201,6 +201,28 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "sample.npz"), **d)
     files["sample.npz"] = "maxiSample 9 play modes, V=24, 200+200 samples over a 1500-sample buffer"
 
+    # ---- maxiFFT + maxiMFCC (config 4 signal, reduced) --------------------------------------------------
+    rng = np.random.default_rng(SEED + 7)
+    nsig = 1024 * 8
+    n = np.arange(nsig)
+    k = n // 1024
+    sig = (0.4 * np.sin(2 * np.pi * 220 * n / 44100) + 0.3 * np.sin(2 * np.pi * (440 + 0.01 * k) * n / 44100)
+           + 0.1 * rng.uniform(-1, 1, nsig)).astype(np.float32)
+    d = dict(signal=sig)
+    for (fs, hop, win) in [(1024, 1024, 1024), (1024, 256, 0), (512, 128, 512), (2048, 1024, 2048), (64, 64, 64)]:
+        r = R.fft_stream(sig[:fs * 4 if fs > 1024 else nsig // (2 if hop < 1024 else 1)], fs, hop, win)
+        tag = "%d_%d" % (fs, hop)
+        for key in ("real", "imag", "mags", "phases"):
+            d["%s_%s" % (key, tag)] = r[key]
+    mags = d["mags_1024_1024"]
+    d["db_1024_1024"] = R.fft_to_db(mags[0])
+    for (nf, nc) in [(42, 13), (256, 13), (40, 20)]:
+        mel, mf = R.mfcc(mags, nf, nc, 20.0, 20000.0)
+        d["melbands_%d_%d" % (nf, nc)], d["mfcc_%d_%d" % (nf, nc)] = mel, mf
+    np.savez_compressed(os.path.join(GOLD, "spectral.npz"), **d)
+    files["spectral.npz"] = ("maxiFFT (1024/1024, 1024/256 streaming, 512/128, 2048/1024, 64/64) real/imag/mags/"
+                             "phases + maxiMFCC 512/42/13, 512/256/13, 512/40/20 on the config-4 signal")
+
     sha = hashlib.sha256()
     for f in ("maximilian.cpp", "maximilian.h", "libs/fft.cpp", "libs/maxiFFT.cpp", "libs/maxiMFCC.cpp",
               "libs/maxiMFCC.h", "libs/maxiGrains.h"):

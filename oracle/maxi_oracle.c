@@ -837,3 +837,263 @@ int mxo_sample(int mode, size_t V, size_t N, const double *amp, size_t len, int 
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------
+ * fft / maxiFFT (L/fft.cpp:118-282, 390-534; L/maxiFFT.cpp:45-91).  Everything is fp32
+ * except the trigonometric seeds (double sin/cos rounded to float).  x86-64 SSE evaluates
+ * float expressions in float (FLT_EVAL_METHOD 0), so each `a*b - c*d` below is three
+ * separately rounded float operations -- -ffp-contract=off keeps it that way.
+ * ------------------------------------------------------------------------------------ */
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+static int fft_reverse_bits(int index, int NumBits) { /* L/fft.cpp:74-85 */
+    int i, rev;
+    for (i = rev = 0; i < NumBits; i++) {
+        rev = (rev << 1) | (index & 1);
+        index >>= 1;
+    }
+    return rev;
+}
+
+/* L/fft.cpp:118-211, forward transform only */
+static void fft_complex(int NumSamples, const float *RealIn, const float *ImagIn, float *RealOut,
+                        float *ImagOut) {
+    int NumBits = 0, i, j, k, n, BlockSize, BlockEnd;
+    double angle_numerator = 2.0 * M_PI;
+    float tr, ti;
+    while (!(NumSamples & (1 << NumBits))) NumBits++; /* NumberOfBitsNeeded, :60-72 */
+    for (i = 0; i < NumSamples; i++) {
+        j = fft_reverse_bits(i, NumBits);
+        RealOut[j] = RealIn[i];
+        ImagOut[j] = (ImagIn == NULL) ? 0.0 : ImagIn[i];
+    }
+    BlockEnd = 1;
+    for (BlockSize = 2; BlockSize <= NumSamples; BlockSize <<= 1) {
+        double delta_angle = angle_numerator / (double)BlockSize;
+        float sm2 = sin(-2 * delta_angle);
+        float sm1 = sin(-delta_angle);
+        float cm2 = cos(-2 * delta_angle);
+        float cm1 = cos(-delta_angle);
+        float w = 2 * cm1;
+        float ar0, ar1, ar2, ai0, ai1, ai2;
+        for (i = 0; i < NumSamples; i += BlockSize) {
+            ar2 = cm2;
+            ar1 = cm1;
+            ai2 = sm2;
+            ai1 = sm1;
+            for (j = i, n = 0; n < BlockEnd; j++, n++) {
+                ar0 = w * ar1 - ar2;
+                ar2 = ar1;
+                ar1 = ar0;
+                ai0 = w * ai1 - ai2;
+                ai2 = ai1;
+                ai1 = ai0;
+                k = j + BlockEnd;
+                tr = ar0 * RealOut[k] - ai0 * ImagOut[k];
+                ti = ar0 * ImagOut[k] + ai0 * RealOut[k];
+                RealOut[k] = RealOut[j] - tr;
+                ImagOut[k] = ImagOut[j] - ti;
+                RealOut[j] += tr;
+                ImagOut[j] += ti;
+            }
+        }
+        BlockEnd = BlockSize;
+    }
+}
+
+/* L/fft.cpp:228-282 */
+static void fft_real(int NumSamples, const float *RealIn, float *RealOut, float *ImagOut) {
+    int Half = NumSamples / 2;
+    int i;
+    float theta = M_PI / Half;
+    float *tmpReal = (float *)malloc(Half * sizeof(float));
+    float *tmpImag = (float *)malloc(Half * sizeof(float));
+    for (i = 0; i < Half; i++) {
+        tmpReal[i] = RealIn[2 * i];
+        tmpImag[i] = RealIn[2 * i + 1];
+    }
+    fft_complex(Half, tmpReal, tmpImag, RealOut, ImagOut);
+    float wtemp = (float)(sin(0.5 * theta));
+    float wpr = -2.0 * wtemp * wtemp;
+    float wpi = (float)(sin(theta));
+    float wr = 1.0 + wpr;
+    float wi = wpi;
+    int i3;
+    float h1r, h1i, h2r, h2i;
+    for (i = 1; i < Half / 2; i++) {
+        i3 = Half - i;
+        h1r = 0.5 * (RealOut[i] + RealOut[i3]);
+        h1i = 0.5 * (ImagOut[i] - ImagOut[i3]);
+        h2r = 0.5 * (ImagOut[i] + ImagOut[i3]);
+        h2i = -0.5 * (RealOut[i] - RealOut[i3]);
+        RealOut[i] = h1r + wr * h2r - wi * h2i;
+        ImagOut[i] = h1i + wr * h2i + wi * h2r;
+        RealOut[i3] = h1r - wr * h2r + wi * h2i;
+        ImagOut[i3] = -h1i + wr * h2i + wi * h2r;
+        wtemp = wr;
+        wr = wtemp * wpr - wi * wpi + wr;
+        wi = wi * wpr + wtemp * wpi + wi;
+    }
+    h1r = RealOut[0];
+    RealOut[0] = h1r + ImagOut[0];
+    ImagOut[0] = h1r - ImagOut[0];
+    free(tmpReal);
+    free(tmpImag);
+}
+
+/* maxiFFT streamed over a signal: setup(fftSize, hopSize, windowSize) (L/maxiFFT.cpp:45-60),
+ * then process(value, WITH_POLAR_CONVERSION) for every sample (L/maxiFFT.cpp:65-91); each time
+ * it reports a new frame, real/imag/magnitudes/phases (bins = fftSize/2 each) are appended to
+ * the outputs.  Returns the number of frames, or <0.  Any output pointer may be NULL.
+ * windowSize > fftSize overruns the reference's window/buffer vectors -> rejected (-2). */
+long mxo_fft_stream(const float *signal, size_t nsamples, int fftSize, int hopSize, int windowSize,
+                    size_t max_frames, float *real, float *imag, float *mags, float *phases) {
+    if (fftSize < 4 || (fftSize & (fftSize - 1))) return -1;
+    int win = windowSize > fftSize ? windowSize : fftSize; /* :48 */
+    if (win > fftSize || hopSize <= 0 || hopSize > win) return -2;
+    int bins = fftSize / 2;
+    float *buffer = (float *)calloc(fftSize, sizeof(float));
+    float *window = (float *)calloc(fftSize, sizeof(float));
+    float *in_real = (float *)calloc(fftSize, sizeof(float));
+    float *out_real = (float *)calloc(fftSize, sizeof(float));
+    float *out_img = (float *)calloc(fftSize, sizeof(float));
+    for (int i = 0; i < win; i++) /* genWindow(3,...) Hanning, L/fft.cpp:409-413 */
+        window[i] = 0.50 - 0.50 * cos(2 * M_PI * i / (win - 1));
+    int pos = win - hopSize; /* :56 */
+    size_t frames = 0;
+    for (size_t s = 0; s < nsamples; s++) {
+        buffer[pos++] = signal[s];
+        if (pos == win) {
+            if (frames >= max_frames) break;
+            for (int i = 0; i < fftSize; i++) in_real[i] = buffer[0 + i] * window[i]; /* calcFFT :499-505 */
+            fft_real(fftSize, in_real, out_real, out_img);
+            for (int i = 0; i < bins; i++) { /* cartToPol :507-515 */
+                float power = out_real[i] * out_real[i] + out_img[i] * out_img[i];
+                if (mags) mags[frames * bins + i] = sqrtf(power);
+                if (phases) phases[frames * bins + i] = atan2f(out_img[i], out_real[i]);
+                if (real) real[frames * bins + i] = out_real[i];
+                if (imag) imag[frames * bins + i] = out_img[i];
+            }
+            frames++;
+            memmove(buffer, buffer + hopSize, (win - hopSize) * sizeof(float)); /* :85 */
+            pos = win - hopSize;
+        }
+    }
+    free(buffer);
+    free(window);
+    free(in_real);
+    free(out_real);
+    free(out_img);
+    return (long)frames;
+}
+
+/* fft::convToDB (L/fft.cpp:526-534) over an array */
+void mxo_fft_to_db(const float *in, float *out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        if (in[i] < 0.000001) {
+            out[i] = 0;
+        } else {
+            /* C++: in[i]+1 is float, so log10 resolves to the float overload (log10f) */
+            out[i] = 20.0 * log10f(in[i] + 1);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * maxiMFCCAnalyser<double> (L/maxiMFCC.h:30-211, L/maxiMFCC.cpp:48-66).
+ * ------------------------------------------------------------------------------------ */
+static double mfcc_hzToMel(double hz) { return 2595.0 * (log10(hz / 700.0 + 1.0)); }       /* :30-32 */
+static double mfcc_melToHz(double mel) { return 700.0 * (pow(10, mel / 2595.0) - 1.0); } /* :36-38 */
+
+/* setup() tables.  melFilters[filter + bin*numFilters] (L/maxiMFCC.h:118-182); filter 0 is
+ * never written by the reference (loop starts at 1, :149) -- defined as 0 here, which is what
+ * a fresh mmap'd malloc holds.  dct[i + j*numCoeffs] (:183-203). */
+int mxo_mfcc_tables(unsigned numBins, unsigned numFilters, unsigned numCoeffs, double minFreq,
+                    double maxFreq, double *melFilters, double *dct) {
+    double mel, dMel, maxMel, minMel, nyquist, binFreq, start, thisF, nextF, prevF;
+    unsigned int sampleRate_u = (unsigned int)g_sampleRate; /* `unsigned int sampleRate` member */
+    double sampleRate = sampleRate_u;
+    int numValidBins = numBins;
+    nyquist = sampleRate / 2;
+    if (maxFreq > nyquist) maxFreq = nyquist;
+    maxMel = mfcc_hzToMel(maxFreq);
+    minMel = mfcc_hzToMel(minFreq);
+    dMel = (maxMel - minMel) / (numFilters + 2 - 1);
+    double *filtPos = (double *)malloc(sizeof(double) * (numFilters + 2));
+    mel = minMel;
+    for (unsigned i = 0; i < numFilters + 2; i++) {
+        filtPos[i] = mfcc_melToHz(mel);
+        mel += dMel;
+    }
+    memset(melFilters, 0, sizeof(double) * numFilters * numValidBins);
+    for (unsigned filter = 1; filter < numFilters; filter++) {
+        for (int bin = 0; bin < numValidBins; bin++) {
+            binFreq = (double)sampleRate / (double)numValidBins * (double)bin;
+            thisF = filtPos[filter];
+            nextF = filtPos[filter + 1];
+            prevF = filtPos[filter - 1];
+            int idx = filter + (bin * numFilters);
+            if (binFreq > nextF || binFreq < prevF) {
+                melFilters[idx] = 0;
+            } else {
+                double height = 2.0 / (nextF - prevF);
+                if (binFreq < thisF) {
+                    start = prevF;
+                    melFilters[idx] = (binFreq - start) * (height / (thisF - start));
+                } else {
+                    melFilters[idx] = height + ((binFreq - thisF) * (-height / (nextF - thisF)));
+                }
+            }
+        }
+    }
+    free(filtPos);
+    double k = 3.14159265358979323846 / numFilters;
+    double w1 = 1.0 / (sqrt(numFilters));
+    double w2 = sqrt(2.0 / numFilters);
+    for (unsigned i = 0; i < numCoeffs; i++) {
+        for (unsigned j = 0; j < numFilters; j++) {
+            int idx = i + (j * numCoeffs);
+            if (i == 0)
+                dct[idx] = w1 * cos(k * (i + 1) * (j + 0.5));
+            else
+                dct[idx] = w2 * cos(k * (i + 1) * (j + 0.5));
+        }
+    }
+    return 0;
+}
+
+/* mfcc() over nframes magnitude spectra (mags[f*mag_stride + bin]) -> melBands (after the
+ * log-square, [nframes][numFilters], may be NULL) and coefficients [nframes][numCoeffs].
+ * L/maxiMFCC.cpp:48-66 then L/maxiMFCC.h:98-111. */
+int mxo_mfcc(unsigned numBins, unsigned numFilters, unsigned numCoeffs, double minFreq,
+             double maxFreq, const float *mags, size_t mag_stride, size_t nframes, double *melbands,
+             double *mfcc) {
+    double *W = (double *)malloc(sizeof(double) * numFilters * numBins);
+    double *D = (double *)malloc(sizeof(double) * numCoeffs * numFilters);
+    double *mb = (double *)malloc(sizeof(double) * numFilters);
+    mxo_mfcc_tables(numBins, numFilters, numCoeffs, minFreq, maxFreq, W, D);
+    for (size_t f = 0; f < nframes; f++) {
+        const float *powerSpectrum = mags + f * mag_stride;
+        for (unsigned filter = 0; filter < numFilters; filter++) {
+            mb[filter] = 0.0;
+            for (unsigned bin = 0; bin < numBins; bin++) {
+                int idx = filter + (bin * numFilters);
+                mb[filter] += (W[idx] * powerSpectrum[bin]);
+            }
+        }
+        for (unsigned filter = 0; filter < numFilters; filter++)
+            mb[filter] = mb[filter] > 0.000001 ? log(mb[filter] * mb[filter]) : 0.0;
+        if (melbands) memcpy(melbands + f * numFilters, mb, sizeof(double) * numFilters);
+        double *c = mfcc + f * numCoeffs;
+        for (unsigned i = 0; i < numCoeffs; i++) c[i] = 0.0;
+        for (unsigned i = 0; i < numCoeffs; i++)
+            for (unsigned j = 0; j < numFilters; j++) c[i] += (D[i + (j * numCoeffs)] * mb[j]);
+        for (unsigned i = 0; i < numCoeffs; i++) c[i] /= numCoeffs;
+    }
+    free(W);
+    free(D);
+    free(mb);
+    return 0;
+}

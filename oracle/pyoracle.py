@@ -189,6 +189,54 @@ class Oracle:
         assert rc == 0, rc
         return out, position
 
+    # -- maxiFFT streamed over a signal -------------------------------------------------------------
+    def fft_stream(self, signal, fftSize=1024, hopSize=512, windowSize=0, want=("real", "imag", "mags", "phases")):
+        signal = np.ascontiguousarray(signal, np.float32)
+        win = max(windowSize, fftSize)
+        max_frames = max(0, (signal.size + (win - hopSize) - win) // hopSize + 1) if signal.size else 0
+        bins = fftSize // 2
+        bufs = {k: (np.zeros((max_frames, bins), np.float32) if k in want else None)
+                for k in ("real", "imag", "mags", "phases")}
+        fn = self.L.mxo_fft_stream
+        fn.restype = ctypes.c_long
+        fn.argtypes = [c_void_p, c_size_t, c_int, c_int, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]
+        n = fn(_p(signal), signal.size, fftSize, hopSize, windowSize, max_frames, _p(bufs["real"]),
+               _p(bufs["imag"]), _p(bufs["mags"]), _p(bufs["phases"]))
+        assert n >= 0, n
+        return {k: (v[:n] if v is not None else None) for k, v in bufs.items()}
+
+    def fft_to_db(self, mags):
+        mags = np.ascontiguousarray(mags, np.float32)
+        out = np.empty_like(mags)
+        fn = self.L.mxo_fft_to_db
+        fn.restype = None
+        fn.argtypes = [c_void_p, c_void_p, c_size_t]
+        fn(_p(mags), _p(out), mags.size)
+        return out
+
+    # -- maxiMFCC ---------------------------------------------------------------------------------------
+    def mfcc_tables(self, numBins=512, numFilters=42, numCoeffs=13, minFreq=20.0, maxFreq=20000.0):
+        W = np.zeros(numFilters * numBins)
+        D = np.zeros(numCoeffs * numFilters)
+        fn = self.L.mxo_mfcc_tables
+        fn.restype = c_int
+        fn.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, c_double, c_double, c_void_p, c_void_p]
+        fn(numBins, numFilters, numCoeffs, minFreq, maxFreq, _p(W), _p(D))
+        return W, D
+
+    def mfcc(self, mags, numFilters=42, numCoeffs=13, minFreq=20.0, maxFreq=20000.0):
+        mags = np.ascontiguousarray(mags, np.float32)
+        n, numBins = mags.shape
+        mel = np.zeros((n, numFilters))
+        out = np.zeros((n, numCoeffs))
+        fn = self.L.mxo_mfcc
+        fn.restype = c_int
+        fn.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, c_double, c_double, c_void_p, c_size_t,
+                       c_size_t, c_void_p, c_void_p]
+        rc = fn(numBins, numFilters, numCoeffs, minFreq, maxFreq, _p(mags), numBins, n, _p(mel), _p(out))
+        assert rc == 0
+        return mel, out
+
     # -- CPU baseline timer -----------------------------------------------------------------------
     def time_osc(self, wf, freq, N, threads=1):
         freq = _f64(freq)

@@ -383,6 +383,73 @@ int mxo_sample(int mode, size_t V, size_t N, const double *amp, size_t len, int 
     return 0;
 }
 
+// ---- maxiFFT streamed over a signal (src/libs/maxiFFT.cpp:45-91) ---------------------------------
+long mxo_fft_stream(const float *signal, size_t nsamples, int fftSize, int hopSize, int windowSize,
+                    size_t max_frames, float *real, float *imag, float *mags, float *phases) {
+    if (fftSize < 4 || (fftSize & (fftSize - 1))) return -1;
+    int win = windowSize > fftSize ? windowSize : fftSize;
+    if (win > fftSize || hopSize <= 0 || hopSize > win) return -2;  // would overrun the vectors
+    maxiFFT f;
+    f.setup(fftSize, hopSize, windowSize);
+    const int bins = f.getNumBins();
+    size_t frames = 0;
+    for (size_t s = 0; s < nsamples; s++) {
+        if (frames >= max_frames) break;
+        if (f.process(signal[s], maxiFFT::WITH_POLAR_CONVERSION)) {
+            std::vector<float> &m = f.getMagnitudes();
+            std::vector<float> &p = f.getPhases();
+            for (int i = 0; i < bins; i++) {
+                if (mags) mags[frames * bins + i] = m[i];
+                if (phases) phases[frames * bins + i] = p[i];
+                if (real) real[frames * bins + i] = f.getReal()[i];
+                if (imag) imag[frames * bins + i] = f.getImag()[i];
+            }
+            frames++;
+        }
+    }
+    return (long)frames;
+}
+
+// fft::convToDB (src/libs/fft.cpp:526-534)
+void mxo_fft_to_db(const float *in, float *out, size_t n) {
+    fft f;
+    f.setup((int)(2 * n));
+    f.convToDB(const_cast<float *>(in), out);
+}
+
+// ---- maxiMFCC (src/libs/maxiMFCC.h, maxiMFCC.cpp) ---------------------------------------------------
+// The reference never writes column 0 of melFilters (loop starts at filter 1, maxiMFCC.h:149);
+// the harness zeroes that column after setup() so the oracle is deterministic.
+static void mfcc_setup(maxiMFCC &m, unsigned numBins, unsigned numFilters, unsigned numCoeffs,
+                       double minFreq, double maxFreq) {
+    m.setup(numBins, numFilters, numCoeffs, minFreq, maxFreq);
+    for (unsigned bin = 0; bin < numBins; bin++) m.melFilters[0 + bin * numFilters] = 0.0;
+}
+
+int mxo_mfcc_tables(unsigned numBins, unsigned numFilters, unsigned numCoeffs, double minFreq,
+                    double maxFreq, double *melFilters, double *dct) {
+    maxiMFCC m;
+    mfcc_setup(m, numBins, numFilters, numCoeffs, minFreq, maxFreq);
+    memcpy(melFilters, m.melFilters, sizeof(double) * numFilters * numBins);
+    memcpy(dct, m.dctMatrix, sizeof(double) * numCoeffs * numFilters);
+    return 0;
+}
+
+int mxo_mfcc(unsigned numBins, unsigned numFilters, unsigned numCoeffs, double minFreq,
+             double maxFreq, const float *mags, size_t mag_stride, size_t nframes, double *melbands,
+             double *mfcc) {
+    maxiMFCC m;
+    mfcc_setup(m, numBins, numFilters, numCoeffs, minFreq, maxFreq);
+    std::vector<float> spec(numBins);
+    for (size_t f = 0; f < nframes; f++) {
+        memcpy(spec.data(), mags + f * mag_stride, sizeof(float) * numBins);
+        std::vector<double> &c = m.mfcc(spec);
+        if (melbands) memcpy(melbands + f * numFilters, m.melBands, sizeof(double) * numFilters);
+        memcpy(mfcc + f * numCoeffs, c.data(), sizeof(double) * numCoeffs);
+    }
+    return 0;
+}
+
 // ---- CPU baseline timer: sinebuf bank sharded over host threads ----------------------
 // Renders N samples x V voices with maxiOsc::sinebuf, voices split in contiguous
 // ranges over `threads` std::threads; returns seconds (steady clock, render loop only).

@@ -1,0 +1,145 @@
+"""GPU parity (-m gpu): maxiFFT / maxiMFCC batches through the C-ABI vs oracle + golden."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+# Stated tolerances (DESIGN.md "Numerics"):
+PHASE_ATOL = 2e-6      # rad: device atan2f vs glibc atan2f (both fp32), |phase| <= pi
+MFCC_RTOL = 1e-12      # device log() vs glibc log() through the 42-term DCT (relative to max |band|)
+MFMA_RTOL = 1e-11      # fused/reordered fp64 sums of the MFMA contraction
+
+CASES = [(1024, 1024, 1024), (1024, 256, 0), (512, 128, 512), (2048, 1024, 2048), (64, 64, 64)]
+
+
+def sig_slice(sig, fs, hop):
+    return sig[:fs * 4] if fs > 1024 else sig[:sig.size // (2 if hop < 1024 else 1)]
+
+
+def f32bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def check_fft(f, exp_real, exp_imag, exp_mags, exp_phases, what):
+    assert np.array_equal(f32bits(f.getReal().numpy()), f32bits(exp_real)), what + " real"
+    assert np.array_equal(f32bits(f.getImag().numpy()), f32bits(exp_imag)), what + " imag"
+    assert np.array_equal(f32bits(f.getMagnitudes().numpy()), f32bits(exp_mags)), what + " mags"
+    ph = f.getPhases().numpy()
+    d = np.abs(ph - exp_phases)
+    d = np.minimum(d, 2 * np.pi - d)  # +pi and -pi are the same angle
+    assert d.max() <= PHASE_ATOL, (what, float(d.max()))
+
+
+@pytest.mark.parametrize("generic", [0, 1])
+@pytest.mark.parametrize("fs,hop,win", CASES)
+def test_fft_golden(mx, golden, fs, hop, win, generic):
+    g = golden("spectral.npz")
+    prev = mx.lib().mxg_tune(b"fft_generic", generic)
+    try:
+        f = mx.maxiFFT()
+        f.setup(fs, hop, win)
+        n = f.process_signal(sig_slice(g["signal"], fs, hop), want_complex=True)
+        tag = "%d_%d" % (fs, hop)
+        assert n == g["mags_" + tag].shape[0]
+        check_fft(f, g["real_" + tag], g["imag_" + tag], g["mags_" + tag], g["phases_" + tag], tag)
+    finally:
+        mx.lib().mxg_tune(b"fft_generic", prev)
+
+
+def test_fft_large_vs_oracle_and_unaligned(mx, port):
+    rng = np.random.default_rng(41)
+    nfr = 777
+    sig = rng.uniform(-1, 1, 1024 * nfr + 3).astype(np.float32)
+    f = mx.maxiFFT()
+    f.setup(1024, 1024, 1024)
+    assert f.process_signal(sig[:1024 * nfr], want_complex=True) == nfr
+    e = port.fft_stream(sig[:1024 * nfr], 1024, 1024, 1024)
+    check_fft(f, e["real"], e["imag"], e["mags"], e["phases"], "large")
+    # odd frame stride / unaligned base: frames start every 1025 samples from sample 3
+    d = mx.DeviceBuffer.from_numpy(sig)
+    n2 = 700
+    f.process_frames(d.ptr + 4 * 3, 1025, n2, want_complex=True)
+    frames = np.stack([sig[3 + 1025 * k: 3 + 1025 * k + 1024] for k in range(n2)])
+    e = port.fft_stream(frames.reshape(-1), 1024, 1024, 1024)
+    check_fft(f, e["real"], e["imag"], e["mags"], e["phases"], "unaligned")
+
+
+def test_fft_invalid_sizes(mx):
+    L = mx.lib()
+    for bad in (0, 6, 1000, 16384):
+        assert not L.mxg_fft_plan_create(bad, 4, bad)
+    assert not L.mxg_fft_plan_create(1024, 512, 2048)   # window > fft overruns the reference's buffers
+    assert not L.mxg_fft_plan_create(1024, 0, 1024)
+    assert b"mxg_fft_plan_create" in L.mxg_last_error()
+
+
+def test_fft_linearity_and_parseval_at_scale(mx):
+    """Size-independent properties on a large batch (65 536 frames = 256 MB of input)."""
+    import ctypes
+    nfr = 65536
+    rng = np.random.default_rng(43)
+    base = rng.uniform(-1, 1, 4096 + 1024).astype(np.float32)
+    # frame k = base[k % 4096 : +1024]: build by tiling so the expected spectra repeat with period 4096
+    sig = np.concatenate([base[:4096]] * (nfr * 1024 // 4096 // 1)).astype(np.float32)[:nfr * 1024]
+    f = mx.maxiFFT()
+    f.setup(1024, 1024, 1024)
+    d = mx.DeviceBuffer.from_numpy(sig)
+    f.process_frames(d, 1024, nfr)
+    m = f.getMagnitudes().numpy()
+    # identical frames (period 4 frames) give bit-identical spectra wherever they sit in the batch
+    assert np.array_equal(f32bits(m[:4]), f32bits(m[4:8]))
+    assert np.array_equal(f32bits(m[:4]), f32bits(m[nfr - 4:]))
+    assert np.array_equal(f32bits(m.reshape(-1, 4, 512)[::997]), f32bits(np.broadcast_to(m[:4], (len(m.reshape(-1, 4, 512)[::997]), 4, 512))))
+    # Parseval on the windowed frame (bins 1..511 of the packed real transform), loose fp32 bound
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(1024) / 1023)
+    xw = (sig[:1024].astype(np.float64) * win.astype(np.float32))
+    X = np.fft.rfft(xw)
+    # the fp32 recurrence twiddles of the reference are only ~1e-4 accurate: loose bound by design
+    assert np.allclose(m[0][1:], np.abs(X[1:512]), rtol=1e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize("nf,nc", [(42, 13), (256, 13), (40, 20)])
+def test_mfcc_golden(mx, golden, nf, nc):
+    g = golden("spectral.npz")
+    mags = g["mags_1024_1024"]
+    m = mx.maxiMFCC()
+    m.setup(512, nf, nc, 20.0, 20000.0)
+    out = m.mfcc(mx.DeviceBuffer.from_numpy(mags), want_bands=True).numpy()
+    emel, emf = g["melbands_%d_%d" % (nf, nc)], g["mfcc_%d_%d" % (nf, nc)]
+    bands = m.melBands.numpy()
+    scale = np.abs(emel).max()
+    assert np.abs(bands - emel).max() <= MFCC_RTOL * scale
+    assert np.abs(out - emf).max() <= MFCC_RTOL * scale
+    # zero bands stay exactly zero (the `> 0.000001 ? log : 0` branch)
+    assert np.array_equal(bands == 0.0, emel == 0.0)
+
+
+def test_mfcc_melraw_bit_exact_and_mfma(mx, port):
+    rng = np.random.default_rng(47)
+    nfr = 1000   # not a multiple of 64 or 16: ragged tail
+    sig = rng.uniform(-1, 1, 1024 * nfr).astype(np.float32)
+    f = mx.maxiFFT()
+    f.setup(1024, 1024, 1024)
+    f.process_signal(sig)
+    mags = f.getMagnitudes()
+    hm = mags.numpy()
+    m = mx.maxiMFCC()
+    m.setup(512, 42, 13, 20.0, 20000.0)
+    W, D, used = m.tables()
+    Wm = W.reshape(512, 42)
+    # dense sequential sums in the reference's bin order (numpy cumulative => same order)
+    raw_exp = np.zeros((nfr, 42))
+    for b in range(512):
+        raw_exp += Wm[b][None, :] * hm[:, b:b + 1].astype(np.float64)
+    out = m.mfcc(mags, want_bands=True).numpy()
+    assert_bits_equal(m.melraw.numpy(), raw_exp, "melraw (sparse in-order == dense in-order)")
+    emel, emf = port.mfcc(hm, 42, 13, 20.0, 20000.0)
+    scale = np.abs(emel).max()
+    assert np.abs(out - emf).max() <= MFCC_RTOL * scale
+    # MFMA method: tolerance on the band sums as well
+    out2 = m.mfcc(mags, method=1, want_bands=True).numpy()
+    raw2 = m.melraw.numpy()
+    assert np.abs(raw2 - raw_exp).max() <= MFMA_RTOL * np.abs(raw_exp).max()
+    assert np.abs(out2 - emf).max() <= MFMA_RTOL * scale * 10

@@ -1,0 +1,90 @@
+"""CPU tests (-m "not gpu"): FFT/MFCC oracle vs golden + reference, host tables, stream framing."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+CASES = [(1024, 1024, 1024), (1024, 256, 0), (512, 128, 512), (2048, 1024, 2048), (64, 64, 64)]
+
+
+def sig_slice(sig, fs, hop):
+    return sig[:fs * 4] if fs > 1024 else sig[:sig.size // (2 if hop < 1024 else 1)]
+
+
+def f32bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("fs,hop,win", CASES)
+def test_fft_golden(port, golden, fs, hop, win):
+    g = golden("spectral.npz")
+    r = port.fft_stream(sig_slice(g["signal"], fs, hop), fs, hop, win)
+    for key in ("real", "imag", "mags", "phases"):
+        e = g["%s_%d_%d" % (key, fs, hop)]
+        assert r[key].shape == e.shape
+        assert np.array_equal(f32bits(r[key]), f32bits(e)), key
+
+
+def test_mfcc_golden(port, golden):
+    g = golden("spectral.npz")
+    mags = g["mags_1024_1024"]
+    assert np.array_equal(f32bits(port.fft_to_db(mags[0])), f32bits(g["db_1024_1024"]))
+    for nf, nc in [(42, 13), (256, 13), (40, 20)]:
+        mel, mf = port.mfcc(mags, nf, nc, 20.0, 20000.0)
+        assert_bits_equal(mel, g["melbands_%d_%d" % (nf, nc)])
+        assert_bits_equal(mf, g["mfcc_%d_%d" % (nf, nc)])
+
+
+def test_fft_mfcc_port_vs_reference(port, ref):
+    rng = np.random.default_rng(17)
+    sig = rng.uniform(-1, 1, 5000).astype(np.float32)
+    for fs, hop, win in [(1024, 512, 1024), (256, 64, 0), (8, 4, 8), (4096, 4096, 4096)]:
+        a, b = port.fft_stream(sig, fs, hop, win), ref.fft_stream(sig, fs, hop, win)
+        for key in ("real", "imag", "mags", "phases"):
+            assert a[key].shape == b[key].shape and a[key].shape[0] == sig.size // hop
+            assert np.array_equal(f32bits(a[key]), f32bits(b[key])), (fs, key)
+    mags = port.fft_stream(sig, 1024, 512, 1024)["mags"]
+    for cfg in [(42, 13, 20.0, 20000.0), (256, 13, 20.0, 20000.0), (30, 12, 300.0, 8000.0)]:
+        x, y = port.mfcc(mags, *cfg), ref.mfcc(mags, *cfg)
+        assert_bits_equal(x[0], y[0]); assert_bits_equal(x[1], y[1])
+        assert_bits_equal(port.mfcc_tables(512, *cfg)[0], ref.mfcc_tables(512, *cfg)[0])
+        assert_bits_equal(port.mfcc_tables(512, *cfg)[1], ref.mfcc_tables(512, *cfg)[1])
+
+
+def test_product_mfcc_host_tables(port):
+    """mxg_mfcc_plan_create builds its tables on the host libm: bit-identical to the oracle's."""
+    import maximilian_amd as mx
+    mx.lib().mxg_settings(44100, 2, 1024)
+    for cfg in [(512, 42, 13, 20.0, 20000.0), (512, 256, 13, 20.0, 20000.0), (256, 40, 20, 100.0, 30000.0)]:
+        m = mx.maxiMFCC()
+        m.setup(*cfg)
+        W, D, used = m.tables()
+        We, De = port.mfcc_tables(*cfg)
+        assert_bits_equal(W, We); assert_bits_equal(D, De)
+        nz = np.nonzero(We.reshape(cfg[0], cfg[1]).any(axis=1))[0]
+        assert used == nz.max() + 1
+        # the exact kernel's premise: every filter's support is one contiguous run of bins
+        Wm = We.reshape(cfg[0], cfg[1])
+        for f in range(cfg[1]):
+            idx = np.nonzero(Wm[:, f])[0]
+            assert idx.size == 0 or (np.diff(idx) == 1).all()
+        assert (Wm >= 0).all() and (Wm[:, 0] == 0).all()
+    with pytest.raises(ValueError):
+        mx.maxiMFCC().setup(512, 1, 13, 20.0, 20000.0)
+
+
+def test_stream_framing_matches_oracle(port):
+    """frames_in_stream / padded_stream reproduce maxiFFT::process()'s hop buffer (maxiFFT.cpp:56-87)."""
+    import maximilian_amd as mx
+    rng = np.random.default_rng(2)
+    for n, fs, hop in [(5000, 1024, 256), (1023, 1024, 1024), (1024, 1024, 1024), (300, 64, 16), (10, 64, 16)]:
+        sig = rng.uniform(-1, 1, n).astype(np.float32)
+        r = port.fft_stream(sig, fs, hop, fs)
+        assert mx.frames_in_stream(n, hop, fs) == r["mags"].shape[0]
+        p = mx.padded_stream(sig, hop, fs)
+        nfr = r["mags"].shape[0]
+        assert nfr == 0 or (nfr - 1) * hop + fs <= p.size
+        # frame k of the padded stream, transformed alone (hop = fs), equals frame k of the stream
+        for k in ([0, nfr - 1] if nfr else []):
+            one = port.fft_stream(p[k * hop:k * hop + fs], fs, fs, fs)
+            assert np.array_equal(f32bits(one["mags"][0]), f32bits(r["mags"][k]))
