@@ -143,6 +143,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fft_generic_kernel(
 // LDS image of one frame: 512 float2 + 1 pad per 8 (index p = i + i/8): conflict-free for the
 // stride-8 and stride-64 lane patterns of the two transposes (bank maths in DESIGN.md).
 constexpr int kX1024 = 512 + 64;
+#ifndef MXG_FFT_MINWAVES
+#define MXG_FFT_MINWAVES 3
+#endif
 
 __device__ __forceinline__ int pad8(int i) { return i + (i >> 3); }
 
@@ -159,7 +162,7 @@ __device__ __forceinline__ void round3(float2 (&x)[8], const float2 w0, const fl
     for (int e = 0; e < 4; e++) bfly(x[e], x[e + 4], w2[e]);
 }
 
-__global__ __launch_bounds__(64 * kWavesPerBlock) void fft1024_kernel(
+__global__ __launch_bounds__(64 * kWavesPerBlock, MXG_FFT_MINWAVES) void fft1024_kernel(
     const float *__restrict__ signal, size_t frame_stride, size_t nframes,
     const float *__restrict__ window, const float2 *__restrict__ tw, const float2 *__restrict__ post,
     FftOut out, int aligned8) {
@@ -174,34 +177,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fft1024_kernel(
 
     const int lo = lane & 7, hi = lane >> 3;
     const int rev6 = (int)(__brev((unsigned)lane) >> 26);
-    // round A twiddles are lane-uniform: stage 0 n=0; stage 1 n=0,1; stage 2 n=0..3
-    const float2 a0 = s_tw[0];
-    const float2 a1[2] = {s_tw[1], s_tw[2]};
-    const float2 a2[4] = {s_tw[3], s_tw[4], s_tw[5], s_tw[6]};
-    // round B: stages 3,4,5 (h = 8,16,32): n = lo, (e&1)*8+lo, (e&3)*8+lo
-    const float2 b0 = s_tw[7 + lo];
-    const float2 b1[2] = {s_tw[15 + lo], s_tw[15 + 8 + lo]};
-    const float2 b2[4] = {s_tw[31 + lo], s_tw[31 + 8 + lo], s_tw[31 + 16 + lo], s_tw[31 + 24 + lo]};
-    // round C: stages 6,7,8 (h = 64,128,256): n = lane, (e&1)*64+lane, (e&3)*64+lane
-    const float2 c0 = s_tw[63 + lane];
-    const float2 c1[2] = {s_tw[127 + lane], s_tw[127 + 64 + lane]};
-    const float2 c2[4] = {s_tw[255 + lane], s_tw[255 + 64 + lane], s_tw[255 + 128 + lane],
-                          s_tw[255 + 192 + lane]};
-
-    // the 8 packed elements a lane loads are the same for every frame: keep their window
-    // coefficients in registers
-    float2 wv[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const int rev3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);
-        const int i = rev3 * 64 + rev6;
-        wv[e] = make_float2(window[2 * i], window[2 * i + 1]);
-    }
-
     for (size_t f = (size_t)blockIdx.x * kWavesPerBlock + wave; f < nframes;
          f += (size_t)gridDim.x * kWavesPerBlock) {
         const float *x = signal + f * frame_stride;
         float2 v[8];
+    // round A twiddles are lane-uniform: stage 0 n=0; stage 1 n=0,1; stage 2 n=0..3
+        const float2 a0 = s_tw[0];
+        const float2 a1[2] = {s_tw[1], s_tw[2]};
+        const float2 a2[4] = {s_tw[3], s_tw[4], s_tw[5], s_tw[6]};
+        // round B: stages 3,4,5 (h = 8,16,32): n = lo, (e&1)*8+lo, (e&3)*8+lo
+        const float2 b0 = s_tw[7 + lo];
+        const float2 b1[2] = {s_tw[15 + lo], s_tw[15 + 8 + lo]};
+        const float2 b2[4] = {s_tw[31 + lo], s_tw[31 + 8 + lo], s_tw[31 + 16 + lo], s_tw[31 + 24 + lo]};
+        // round C: stages 6,7,8 (h = 64,128,256): n = lane, (e&1)*64+lane, (e&3)*64+lane
+        const float2 c0 = s_tw[63 + lane];
+        const float2 c1[2] = {s_tw[127 + lane], s_tw[127 + 64 + lane]};
+        const float2 c2[4] = {s_tw[255 + lane], s_tw[255 + 64 + lane], s_tw[255 + 128 + lane],
+                              s_tw[255 + 192 + lane]};
+
         // Round A input: lane holds idx = 8*lane + e  <-  packed element i = rev9(idx)
         //              = rev3(e)*64 + rev6(lane): for each e one 512-B segment per wavefront.
 #pragma unroll
@@ -215,8 +208,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fft1024_kernel(
                 s.x = x[2 * i];
                 s.y = x[2 * i + 1];
             }
-            v[e].x = s.x * wv[e].x;  // calcFFT L/fft.cpp:501-503
-            v[e].y = s.y * wv[e].y;
+            const float2 w = *reinterpret_cast<const float2 *>(window + 2 * i);
+            v[e].x = s.x * w.x;  // calcFFT L/fft.cpp:501-503
+            v[e].y = s.y * w.y;
         }
         round3(v, a0, a1, a2);
         // transpose A->B: write idx = 8*lane + e, read idx = hi*64 + e*8 + lo
@@ -240,7 +234,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fft1024_kernel(
         for (int e = 0; e < 8; e++) X[pad8(e * 64 + lane)] = v[e];
         wave_lds_sync();
         const size_t base = f * (size_t)512;
-#pragma unroll
+#pragma unroll 1
         for (int q = 0; q < 4; q++) {
             const int i = 1 + lane + 64 * q;  // 1..256
             if (i < 256) {

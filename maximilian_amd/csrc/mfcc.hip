@@ -8,48 +8,128 @@
 // cos), so they are bit-identical to the reference's.  Column 0 of melFilters is never written
 // by the reference (its loop starts at filter 1, :149); it is defined as 0 here.
 //
-// K7a `mfcc_exact_kernel` (default).  The reference's melBands[f] = sum_bin W[f][bin]*spec[bin]
-// runs over ALL bins in increasing order, but W is a bank of triangles: outside a filter's
-// support every term is an exact +0.0 (spec >= 0), and x + (+0.0) == x.  Summing only the
-// support, still in increasing bin order, is therefore bit-identical to the dense loop while
-// doing ~1/45 of the work (411 non-zeros of 21 504 for 512/42).  One LANE owns one frame (64
-// frames per wavefront): the sparsity pattern and the coefficients are wave-uniform (scalar
-// loads), every lane is busy, and the spectra of the 64 frames are staged through LDS as a
-// [64][odd stride] tile so that the per-lane row reads are bank-conflict free.  The DCT is
-// accumulated on the fly in the reference's j-order (each finished band updates all
-// coefficients), then divided by numCoeffs.  melraw (pre-log) is bit-exact; log() is OCML's, so
-// melbands/mfcc carry the tolerance stated in DESIGN.md.
+// Exactness argument.  The reference's melBands[f] = sum_bin W[f][bin]*spec[bin] runs over ALL
+// bins in increasing order, but W is a bank of triangles: outside a filter's support every term
+// is an exact +0.0 (spec >= 0), and x + (+0.0) == x.  Summing only the support, still in
+// increasing bin order, is therefore bit-identical to the dense loop while doing ~1/50 of the
+// work (411 non-zeros of 21 504 for 512/42).  The DCT is accumulated on the fly in the
+// reference's j-order (each finished band updates every coefficient), then divided by numCoeffs.
+// melraw (pre-log) is bit-exact; log() is OCML's, so melbands/mfcc carry the tolerance stated
+// in DESIGN.md.
 //
-// K7b `mfcc_mfma_kernel` (method 1): the dense contraction frames[Nx512] x W[512x48] on the fp64
+// K7a `mfcc_stream_kernel` (default).  One LANE owns one frame and streams through its spectrum
+// once, bin-major: the triangles overlap by half, so at any bin at most S (=2 for mel banks)
+// filters are "open"; each open filter lives in a register accumulator slot, and the host-built
+// schedule (per bin: S weights + which slots close) is wave-uniform, staged in LDS and read as
+// broadcasts.  Every lane is busy, no divergence, ~60 VGPRs => full occupancy; spectra are read
+// straight from HBM/L2 as 16-B per-lane loads (each 128-B line is consumed by 8 consecutive
+// loads of the same lane).  Algorithmic bytes/frame: nbUsed*4 read + numCoeffs*8 written.
+// K7a' `mfcc_tile_kernel`: filter-major fallback for banks whose supports overlap more than 4 deep.
+//
+// K7b `mfcc_mfma_kernel` (method 1): the dense contraction frames[N x K] x W[K x 48] on the fp64
 // matrix cores (v_mfma_f64_16x16x4_f64), as the reference's own vDSP branch does with
 // vDSP_mmulD (L/maxiMFCC.cpp:28-37).  FMA chains change the rounding => tolerance on melraw too.
-// On gfx950 the fp64 MFMA rate equals the fp64 VALU rate, so this path is kept for dense
+// On gfx950 the fp64 MFMA rate equals the fp64 VALU FMA rate, so this path exists for dense
 // (non-triangular) filter matrices and as the MFMA-utilisation measurement, not as the fast path.
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "mxg_common.h"
 
 struct mxg_mfcc_plan {
     unsigned numBins, numFilters, numCoeffs, nbUsed;  // nbUsed = 1 + last bin with a non-zero weight
-    std::vector<double> h_W;    // [numFilters + bin*numFilters]  (reference layout)
+    std::vector<double> h_W;    // [filter + bin*numFilters]  (reference layout)
     std::vector<double> h_dct;  // [i + j*numCoeffs]
+    int slots;                  // S: max number of simultaneously open filters (0 = stream kernel n/a)
+    double *d_schedW;           // [nbUsed][S] weight of the filter occupying slot s at this bin (or 0)
+    int *d_schedFin;            // [nbUsed][S] filter closing in slot s after this bin, or -1
     int *d_lo, *d_hi, *d_off;   // per filter: support [lo, hi] (hi < lo = empty), offset into d_Wc
     double *d_Wc;               // compacted weights, filter-major, increasing bin
     double *d_dct;              // [j*numCoeffs + i]
-    double *d_Wpad;             // dense [binsPad][48-multiple] row-major by bin, for the MFMA path
+    double *d_Wpad;             // dense [kPad][nfPad] row-major by bin, for the MFMA path
     unsigned nfPad, kPad;
 };
 
 namespace mxg {
 namespace {
 
-constexpr int kMaxCoeffs = 32;
+// log-square of L/maxiMFCC.cpp:63
+__device__ __forceinline__ double log_square(double mb) { return mb > 0.000001 ? log(mb * mb) : 0.0; }
 
-template <int NC>
-__global__ __launch_bounds__(64) void mfcc_exact_kernel(
+// ---- K7a: bin-major streaming, one lane per frame ------------------------------------------------
+template <int S, int NC>
+__global__ __launch_bounds__(256) void mfcc_stream_kernel(
+    const float *__restrict__ mags, size_t mag_stride, size_t nframes, unsigned numFilters,
+    unsigned nbUsed, const double *__restrict__ schedW, const int *__restrict__ schedFin,
+    const int *__restrict__ lo, const int *__restrict__ hi, const double *__restrict__ dct,
+    double *__restrict__ melraw, double *__restrict__ melbands, double *__restrict__ mfcc,
+    int aligned16) {
+    extern __shared__ double s_dyn[];  // [nbUsed*S] weights | [numFilters*NC] dct | [nbUsed*S] fin (int)
+    double *s_w = s_dyn;
+    double *s_d = s_dyn + (size_t)nbUsed * S;
+    int *s_fin = reinterpret_cast<int *>(s_d + (size_t)numFilters * NC);
+    for (unsigned i = threadIdx.x; i < nbUsed * S; i += blockDim.x) {
+        s_w[i] = schedW[i];
+        s_fin[i] = schedFin[i];
+    }
+    for (unsigned i = threadIdx.x; i < numFilters * NC; i += blockDim.x) s_d[i] = dct[i];
+    __syncthreads();
+    const size_t frame = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (frame >= nframes) return;
+    const float *row = mags + frame * mag_stride;
+    double acc[S], c[NC];
+    if (melraw || melbands) {  // bands with an empty support never close: they are 0 / log-square 0
+        for (unsigned f = 0; f < numFilters; f++)
+            if (hi[f] < lo[f]) {  // wave-uniform
+                if (melraw) melraw[frame * numFilters + f] = 0.0;
+                if (melbands) melbands[frame * numFilters + f] = 0.0;
+            }
+    }
+#pragma unroll
+    for (int s = 0; s < S; s++) acc[s] = 0.0;  // L/maxiMFCC.cpp:52
+#pragma unroll
+    for (int i = 0; i < NC; i++) c[i] = 0.0;  // L/maxiMFCC.h:99-101
+    for (unsigned b0 = 0; b0 < nbUsed; b0 += 4) {
+        float x4[4];
+        if (aligned16) {
+            const float4 t = *reinterpret_cast<const float4 *>(row + b0);  // row padded to >= b0+4
+            x4[0] = t.x; x4[1] = t.y; x4[2] = t.z; x4[3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) x4[j] = (b0 + j < nbUsed) ? row[b0 + j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned b = b0 + j;
+            if (b < nbUsed) {  // wave-uniform
+                const double x = (double)x4[j];
+#pragma unroll
+                for (int s = 0; s < S; s++) acc[s] += (s_w[b * S + s] * x);  // L/maxiMFCC.cpp:57
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    const int f = s_fin[b * S + s];
+                    if (f >= 0) {  // wave-uniform: band f is complete
+                        if (melraw) melraw[frame * numFilters + f] = acc[s];
+                        const double mb = log_square(acc[s]);
+                        if (melbands) melbands[frame * numFilters + f] = mb;
+                        const double *d = s_d + (size_t)f * NC;
+#pragma unroll
+                        for (int i = 0; i < NC; i++) c[i] += (d[i] * mb);  // L/maxiMFCC.h:105
+                        acc[s] = 0.0;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NC; i++) mfcc[frame * NC + i] = c[i] / (double)NC;  // L/maxiMFCC.h:109
+}
+
+// ---- K7a': filter-major over an LDS tile of 64 spectra (fallback, any bank / any numCoeffs) ----
+__global__ __launch_bounds__(64) void mfcc_tile_kernel(
     const float *__restrict__ mags, size_t mag_stride, size_t nframes, unsigned numFilters,
     unsigned numCoeffs, unsigned nbUsed, unsigned tileStride, const int *__restrict__ lo,
     const int *__restrict__ hi, const int *__restrict__ off, const double *__restrict__ Wc,
@@ -67,36 +147,20 @@ __global__ __launch_bounds__(64) void mfcc_exact_kernel(
         if ((size_t)lane < rows) {
             const float *row = s_tile + (size_t)lane * tileStride;
             const size_t frame = f0 + lane;
-            double c[NC > 0 ? NC : 1];
-            double *cl = nullptr;
-#pragma unroll
-            for (int i = 0; i < (NC > 0 ? NC : 1); i++) c[i] = 0.0;
-            if constexpr (NC == 0) {  // generic coefficient count: accumulate in the output row
-                cl = mfcc + frame * numCoeffs;
-                for (unsigned i = 0; i < numCoeffs; i++) cl[i] = 0.0;
-            }
+            double *cl = mfcc + frame * numCoeffs;  // accumulate in the output row
+            for (unsigned i = 0; i < numCoeffs; i++) cl[i] = 0.0;
             for (unsigned f = 0; f < numFilters; f++) {
-                double acc = 0.0;  // L/maxiMFCC.cpp:52
+                double acc = 0.0;
                 const int b0 = lo[f], b1 = hi[f];
                 const double *w = Wc + off[f];
-                for (int b = b0; b <= b1; b++) acc += (w[b - b0] * (double)row[b]);  // :57
+                for (int b = b0; b <= b1; b++) acc += (w[b - b0] * (double)row[b]);
                 if (melraw) melraw[frame * numFilters + f] = acc;
-                double mb = acc > 0.000001 ? log(acc * acc) : 0.0;  // :63
+                const double mb = log_square(acc);
                 if (melbands) melbands[frame * numFilters + f] = mb;
-                const double *d = dct + (size_t)f * numCoeffs;  // dctMatrix[i + j*numCoeffs], j = f
-                if constexpr (NC > 0) {
-#pragma unroll
-                    for (int i = 0; i < NC; i++) c[i] += (d[i] * mb);  // L/maxiMFCC.h:105
-                } else {
-                    for (unsigned i = 0; i < numCoeffs; i++) cl[i] += (d[i] * mb);
-                }
+                const double *d = dct + (size_t)f * numCoeffs;
+                for (unsigned i = 0; i < numCoeffs; i++) cl[i] += (d[i] * mb);
             }
-            if constexpr (NC > 0) {
-#pragma unroll
-                for (int i = 0; i < NC; i++) mfcc[frame * NC + i] = c[i] / (double)numCoeffs;  // :109
-            } else {
-                for (unsigned i = 0; i < numCoeffs; i++) cl[i] = cl[i] / (double)numCoeffs;
-            }
+            for (unsigned i = 0; i < numCoeffs; i++) cl[i] = cl[i] / (double)numCoeffs;
         }
         __syncthreads();
     }
@@ -107,14 +171,13 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 // One wavefront = 16 frames x nfPad filters.  A (spectrum, widened to f64): lane l holds
 // A[row = l&15][k = l>>4]; B (weights): lane l holds B[k = l>>4][col = l&15]; C/D (4 f64 per
-// lane): col = l&15, row = (l>>4) + 4*reg   (f64 16x16x4 layout, cdna guide 3).
+// lane): col = l&15, row = (l>>4) + 4*reg   (f64 16x16x4 layout, cdna guide section 3).
 template <int NT>
 __global__ __launch_bounds__(64) void mfcc_mfma_kernel(
     const float *__restrict__ mags, size_t mag_stride, size_t nframes, unsigned numBins,
     unsigned numFilters, unsigned numCoeffs, unsigned kPad, unsigned nfPad,
-    const double *__restrict__ Wpad,
-    const double *__restrict__ dct, double *__restrict__ melraw, double *__restrict__ melbands,
-    double *__restrict__ mfcc) {
+    const double *__restrict__ Wpad, const double *__restrict__ dct, double *__restrict__ melraw,
+    double *__restrict__ melbands, double *__restrict__ mfcc) {
     __shared__ double s_mb[16 * (NT * 16 + 1)];
     const int lane = threadIdx.x;
     const int r16 = lane & 15, kq = lane >> 4;
@@ -144,7 +207,7 @@ __global__ __launch_bounds__(64) void mfcc_mfma_kernel(
             for (unsigned f = 0; f < numFilters; f++) {
                 double v = s_mb[lane * (NT * 16 + 1) + f];
                 if (melraw) melraw[fr * numFilters + f] = v;
-                double mb = v > 0.000001 ? log(v * v) : 0.0;
+                const double mb = log_square(v);
                 if (melbands) melbands[fr * numFilters + f] = mb;
                 const double *d = dct + (size_t)f * numCoeffs;
                 for (unsigned i = 0; i < numCoeffs; i++) cl[i] += (d[i] * mb);
@@ -157,6 +220,26 @@ __global__ __launch_bounds__(64) void mfcc_mfma_kernel(
 
 double hzToMel(double hz) { return 2595.0 * (log10(hz / 700.0 + 1.0)); }       // L/maxiMFCC.h:30-32
 double melToHz(double mel) { return 700.0 * (pow(10, mel / 2595.0) - 1.0); }  // L/maxiMFCC.h:36-38
+
+void free_device(mxg_mfcc_plan *p) {
+    void *ptrs[] = {p->d_schedW, p->d_schedFin, p->d_lo, p->d_hi, p->d_off, p->d_Wc, p->d_dct, p->d_Wpad};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    p->d_schedW = nullptr;
+    p->d_schedFin = nullptr;
+    p->d_lo = p->d_hi = p->d_off = nullptr;
+    p->d_Wc = p->d_dct = p->d_Wpad = nullptr;
+}
+
+template <typename T>
+bool upload(T **dst, const std::vector<T> &src) {
+    size_t n = src.empty() ? 1 : src.size();
+    if (check_hip(hipMalloc(dst, sizeof(T) * n), "hipMalloc")) return false;
+    if (!src.empty() &&
+        check_hip(hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice), "hipMemcpy"))
+        return false;
+    return true;
+}
 
 }  // namespace
 }  // namespace mxg
@@ -177,6 +260,9 @@ mxg_mfcc_plan *mxg_mfcc_plan_create(unsigned numBins, unsigned numFilters, unsig
     p->numBins = numBins;
     p->numFilters = numFilters;
     p->numCoeffs = numCoeffs;
+    p->slots = 0;
+    p->d_schedW = nullptr;
+    p->d_schedFin = nullptr;
     p->d_lo = p->d_hi = p->d_off = nullptr;
     p->d_Wc = p->d_dct = p->d_Wpad = nullptr;
     // ---- calcMelFilterBank (L/maxiMFCC.h:118-182): `sampleRate` is an unsigned int member
@@ -217,17 +303,21 @@ mxg_mfcc_plan *mxg_mfcc_plan_create(unsigned numBins, unsigned numFilters, unsig
             for (unsigned j = 0; j < numFilters; j++)
                 p->h_dct[i + (size_t)j * numCoeffs] = (i == 0 ? w1 : w2) * cos(k * (i + 1) * (j + 0.5));
     }
-    // ---- device images
+    // ---- supports, compact weights
     std::vector<int> lo(numFilters), hi(numFilters), off(numFilters + 1);
     std::vector<double> Wc;
     unsigned nbUsed = 1;
+    bool nonneg = true;
     for (unsigned f = 0; f < numFilters; f++) {
         int a = (int)numBins, b = -1;
-        for (unsigned bin = 0; bin < numBins; bin++)
-            if (p->h_W[f + (size_t)bin * numFilters] != 0.0) {
+        for (unsigned bin = 0; bin < numBins; bin++) {
+            const double w = p->h_W[f + (size_t)bin * numFilters];
+            if (w != 0.0) {
                 if ((int)bin < a) a = (int)bin;
                 b = (int)bin;
             }
+            if (w < 0.0) nonneg = false;
+        }
         lo[f] = a;
         hi[f] = b;  // b < a: empty support
         off[f] = (int)Wc.size();
@@ -235,49 +325,76 @@ mxg_mfcc_plan *mxg_mfcc_plan_create(unsigned numBins, unsigned numFilters, unsig
         if (b + 1 > (int)nbUsed) nbUsed = b + 1;
     }
     off[numFilters] = (int)Wc.size();
-    if (Wc.empty()) Wc.push_back(0.0);
     p->nbUsed = nbUsed;
+    // ---- bin-major schedule: greedy slot assignment in filter order.  Usable when the bands
+    // close in filter order (so the on-the-fly DCT sees j ascending) and <= 4 are open at once.
+    std::vector<double> schedW;
+    std::vector<int> schedFin;
+    {
+        bool ordered = nonneg;
+        int lastHi = -1;
+        for (unsigned f = 0; f < numFilters; f++)
+            if (hi[f] >= lo[f]) {
+                if (hi[f] < lastHi) ordered = false;
+                lastHi = hi[f];
+            }
+        int S = 0;
+        std::vector<int> slotOf(numFilters, -1);
+        if (ordered) {
+            std::vector<int> busyUntil;  // per slot: hi of the filter occupying it
+            for (unsigned f = 0; f < numFilters && ordered; f++) {
+                if (hi[f] < lo[f]) continue;
+                int s = -1;
+                for (size_t k = 0; k < busyUntil.size(); k++)
+                    if (busyUntil[k] < lo[f]) {
+                        s = (int)k;
+                        break;
+                    }
+                if (s < 0) {
+                    busyUntil.push_back(-1);
+                    s = (int)busyUntil.size() - 1;
+                }
+                busyUntil[s] = hi[f];
+                slotOf[f] = s;
+            }
+            S = (int)busyUntil.size();
+            // two bands closing at the same bin must close in filter order: slots are visited in
+            // slot order, so require slot order == filter order for such ties
+            for (unsigned f = 0; f + 1 < numFilters && ordered; f++)
+                for (unsigned g = f + 1; g < numFilters; g++)
+                    if (slotOf[f] >= 0 && slotOf[g] >= 0 && hi[f] == hi[g] && slotOf[f] > slotOf[g]) ordered = false;
+        }
+        if (ordered && S >= 1 && S <= 4) {
+            p->slots = S == 3 ? 4 : S;  // instantiated for 1, 2, 4
+            const int SS = p->slots;
+            schedW.assign((size_t)nbUsed * SS, 0.0);
+            schedFin.assign((size_t)nbUsed * SS, -1);
+            for (unsigned f = 0; f < numFilters; f++) {
+                if (slotOf[f] < 0) continue;
+                for (int bin = lo[f]; bin <= hi[f]; bin++)
+                    schedW[(size_t)bin * SS + slotOf[f]] = p->h_W[f + (size_t)bin * numFilters];
+                schedFin[(size_t)hi[f] * SS + slotOf[f]] = (int)f;
+            }
+        }
+    }
     p->nfPad = (numFilters + 15) / 16 * 16;
-    p->kPad = (nbUsed + 3) / 4 * 4;  // rows >= numBins are zero weights; the kernel guards the A read
-    std::vector<double> dctT((size_t)numFilters * numCoeffs);  // [j*numCoeffs + i] == reference index
-    for (size_t x = 0; x < dctT.size(); x++) dctT[x] = p->h_dct[x];
+    p->kPad = (nbUsed + 3) / 4 * 4;  // rows >= numBins carry zero weights; the kernel guards the A read
+    std::vector<double> dctT(p->h_dct);  // [j*numCoeffs + i] is the reference's own linear index
     std::vector<double> Wpad((size_t)p->kPad * p->nfPad, 0.0);
     for (unsigned bin = 0; bin < p->kPad && bin < numBins; bin++)
         for (unsigned f = 0; f < numFilters; f++) Wpad[(size_t)bin * p->nfPad + f] = p->h_W[f + (size_t)bin * numFilters];
-    if (ensure_init() ||
-        check_hip(hipMalloc(&p->d_lo, sizeof(int) * numFilters), "hipMalloc") ||
-        check_hip(hipMalloc(&p->d_hi, sizeof(int) * numFilters), "hipMalloc") ||
-        check_hip(hipMalloc(&p->d_off, sizeof(int) * (numFilters + 1)), "hipMalloc") ||
-        check_hip(hipMalloc(&p->d_Wc, sizeof(double) * Wc.size()), "hipMalloc") ||
-        check_hip(hipMalloc(&p->d_dct, sizeof(double) * dctT.size()), "hipMalloc") ||
-        check_hip(hipMalloc(&p->d_Wpad, sizeof(double) * Wpad.size()), "hipMalloc") ||
-        check_hip(hipMemcpy(p->d_lo, lo.data(), sizeof(int) * numFilters, hipMemcpyHostToDevice), "hipMemcpy") ||
-        check_hip(hipMemcpy(p->d_hi, hi.data(), sizeof(int) * numFilters, hipMemcpyHostToDevice), "hipMemcpy") ||
-        check_hip(hipMemcpy(p->d_off, off.data(), sizeof(int) * (numFilters + 1), hipMemcpyHostToDevice), "hipMemcpy") ||
-        check_hip(hipMemcpy(p->d_Wc, Wc.data(), sizeof(double) * Wc.size(), hipMemcpyHostToDevice), "hipMemcpy") ||
-        check_hip(hipMemcpy(p->d_dct, dctT.data(), sizeof(double) * dctT.size(), hipMemcpyHostToDevice), "hipMemcpy") ||
-        check_hip(hipMemcpy(p->d_Wpad, Wpad.data(), sizeof(double) * Wpad.size(), hipMemcpyHostToDevice), "hipMemcpy")) {
-        // Host tables stay valid (mxg_mfcc_plan_tables works without a device); compute calls will fail.
-        if (p->d_lo) (void)hipFree(p->d_lo);
-        if (p->d_hi) (void)hipFree(p->d_hi);
-        if (p->d_off) (void)hipFree(p->d_off);
-        if (p->d_Wc) (void)hipFree(p->d_Wc);
-        if (p->d_dct) (void)hipFree(p->d_dct);
-        if (p->d_Wpad) (void)hipFree(p->d_Wpad);
-        p->d_lo = p->d_hi = p->d_off = nullptr;
-        p->d_Wc = p->d_dct = p->d_Wpad = nullptr;
+    if (ensure_init() || !upload(&p->d_lo, lo) || !upload(&p->d_hi, hi) || !upload(&p->d_off, off) ||
+        !upload(&p->d_Wc, Wc) || !upload(&p->d_dct, dctT) || !upload(&p->d_Wpad, Wpad) ||
+        !upload(&p->d_schedW, schedW) || !upload(&p->d_schedFin, schedFin)) {
+        // Host tables stay valid (mxg_mfcc_plan_tables works without a device); compute calls fail.
+        free_device(p);
     }
     return p;
 }
 
 int mxg_mfcc_plan_destroy(mxg_mfcc_plan *p) {
     if (!p) return MXG_OK;
-    if (p->d_lo) (void)hipFree(p->d_lo);
-    if (p->d_hi) (void)hipFree(p->d_hi);
-    if (p->d_off) (void)hipFree(p->d_off);
-    if (p->d_Wc) (void)hipFree(p->d_Wc);
-    if (p->d_dct) (void)hipFree(p->d_dct);
-    if (p->d_Wpad) (void)hipFree(p->d_Wpad);
+    free_device(p);
     delete p;
     return MXG_OK;
 }
@@ -295,35 +412,45 @@ int mxg_mfcc_batch(const mxg_mfcc_plan *p, const float *d_mags, size_t mag_strid
     MXG_REQUIRE(p && d_mags && d_mfcc, "null plan / mags / mfcc");
     MXG_REQUIRE(p->d_Wc, "plan has no device tables (created without a HIP device)");
     MXG_REQUIRE(mag_stride >= p->numBins, "mag_stride < numBins");
-    MXG_REQUIRE(method == 0 || method == 1, "method must be 0 (exact) or 1 (mfma)");
+    MXG_REQUIRE(method >= 0 && method <= 2, "method must be 0 (exact), 1 (mfma) or 2 (exact, tile kernel)");
     if (nframes == 0) return MXG_OK;
     hipStream_t st = resolve_stream(stream);
-    if (method == 0) {
+    const unsigned NC = p->numCoeffs;
+    const bool stream_ok = p->slots > 0 && (NC == 13 || NC == 20) &&
+                           ((size_t)p->nbUsed * p->slots * 12 + (size_t)p->numFilters * NC * 8) <= 60 * 1024;
+    if (method == 0 && stream_ok) {
+        const int S = p->slots;
+        const size_t lds = (size_t)p->nbUsed * S * (sizeof(double) + sizeof(int)) + (size_t)p->numFilters * NC * sizeof(double);
+        // 16-B row loads need aligned rows and must not run past the row: nbUsed rounded up to 4 <= stride
+        const int aligned16 = ((((uintptr_t)d_mags) & 15) == 0 && (mag_stride & 3) == 0 &&
+                               ((p->nbUsed + 3) / 4 * 4) <= mag_stride) ? 1 : 0;
+        const int block = 256;
+        dim3 grid((unsigned)((nframes + block - 1) / block));
+#define MXG_STREAM_LAUNCH(SS, CC)                                                                     \
+    hipLaunchKernelGGL((mfcc_stream_kernel<SS, CC>), grid, dim3(block), lds, st, d_mags, mag_stride, nframes, \
+                       p->numFilters, p->nbUsed, p->d_schedW, p->d_schedFin, p->d_lo, p->d_hi, p->d_dct, d_melraw, d_melbands, \
+                       d_mfcc, aligned16)
+        if (NC == 13) {
+            if (S == 1) MXG_STREAM_LAUNCH(1, 13); else if (S == 2) MXG_STREAM_LAUNCH(2, 13); else MXG_STREAM_LAUNCH(4, 13);
+        } else {
+            if (S == 1) MXG_STREAM_LAUNCH(1, 20); else if (S == 2) MXG_STREAM_LAUNCH(2, 20); else MXG_STREAM_LAUNCH(4, 20);
+        }
+#undef MXG_STREAM_LAUNCH
+    } else if (method == 0 || method == 2) {
         unsigned tileStride = p->nbUsed | 1u;
         size_t lds = sizeof(float) * 64 * tileStride;
-        MXG_REQUIRE(lds <= 160 * 1024, "filter support too wide for the LDS tile");
+        MXG_REQUIRE(lds <= 64 * 1024, "filter support too wide for the LDS tile");
         size_t blocks = (nframes + 63) / 64;
         if (blocks > 256 * 4) blocks = 256 * 4;
-#define MXG_MFCC_LAUNCH(NC)                                                                       \
-    {                                                                                             \
-        if (lds > 64 * 1024)                                                                      \
-            MXG_HIP(hipFuncSetAttribute((const void *)mfcc_exact_kernel<NC>,                      \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
-        hipLaunchKernelGGL((mfcc_exact_kernel<NC>), dim3((unsigned)blocks), dim3(64), lds, st, d_mags, \
-                           mag_stride, nframes, p->numFilters, p->numCoeffs, p->nbUsed, tileStride, \
-                           p->d_lo, p->d_hi, p->d_off, p->d_Wc, p->d_dct, d_melraw, d_melbands, d_mfcc); \
-    }
-        if (p->numCoeffs == 13)
-            MXG_MFCC_LAUNCH(13)
-        else
-            MXG_MFCC_LAUNCH(0)
-#undef MXG_MFCC_LAUNCH
+        hipLaunchKernelGGL(mfcc_tile_kernel, dim3((unsigned)blocks), dim3(64), lds, st, d_mags, mag_stride, nframes,
+                           p->numFilters, p->numCoeffs, p->nbUsed, tileStride, p->d_lo, p->d_hi, p->d_off, p->d_Wc,
+                           p->d_dct, d_melraw, d_melbands, d_mfcc);
     } else {
         MXG_REQUIRE(p->nfPad <= 64, "mfma method supports up to 64 filters");
         size_t blocks = (nframes + 15) / 16;
         if (blocks > 256 * 16) blocks = 256 * 16;
-#define MXG_MFMA_LAUNCH(NT)                                                                          \
-    hipLaunchKernelGGL((mfcc_mfma_kernel<NT>), dim3((unsigned)blocks), dim3(64), 0, st, d_mags, mag_stride, \
+#define MXG_MFMA_LAUNCH(NT)                                                                            \
+    hipLaunchKernelGGL((mfcc_mfma_kernel<NT>), dim3((unsigned)blocks), dim3(64), 0, st, d_mags, mag_stride,   \
                        nframes, p->numBins, p->numFilters, p->numCoeffs, p->kPad, p->nfPad, p->d_Wpad, p->d_dct, \
                        d_melraw, d_melbands, d_mfcc)
         switch (p->nfPad / 16) {

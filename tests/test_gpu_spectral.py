@@ -138,6 +138,10 @@ def test_mfcc_melraw_bit_exact_and_mfma(mx, port):
     emel, emf = port.mfcc(hm, 42, 13, 20.0, 20000.0)
     scale = np.abs(emel).max()
     assert np.abs(out - emf).max() <= MFCC_RTOL * scale
+    # method 2 = the filter-major tile kernel (fallback path): same bits
+    out3 = m.mfcc(mags, method=2, want_bands=True).numpy()
+    assert_bits_equal(m.melraw.numpy(), raw_exp, "melraw (tile kernel)")
+    assert_bits_equal(out3, out, "mfcc stream kernel == tile kernel")
     # MFMA method: tolerance on the band sums as well
     out2 = m.mfcc(mags, method=1, want_bands=True).numpy()
     raw2 = m.melraw.numpy()
