@@ -235,6 +235,30 @@ int mxg_mfcc_plan_tables(const mxg_mfcc_plan *plan, double *h_melFilters, double
 int mxg_mfcc_batch(const mxg_mfcc_plan *plan, const float *d_mags, size_t mag_stride, size_t nframes,
                    double *d_melraw, double *d_melbands, double *d_mfcc, int method, void *stream);
 
+/* ---- maxiGrains: maxiTimeStretch / maxiStretch banks --------------------------------------- */
+/* Window kinds = the functors of L/maxiGrains.h:18-90: 0 hann 1 hamming 2 cosine 3 rect 4 triangle
+ * 5 triangleNZ 6 blackmanHarris 7 blackmanNutall 8 gaussian(0.3).  A plan holds the window table
+ * maxiGrainWindowCache::getWindow (:112-120) would build for grains of grainLength seconds of a
+ * sample at mySampleRate (host libm); the length must be < sampleRate/2 like the cache (:98). */
+typedef struct mxg_grain_plan mxg_grain_plan;
+mxg_grain_plan *mxg_grain_plan_create(int window_kind, double grainLength, int mySampleRate);
+int mxg_grain_plan_destroy(mxg_grain_plan *plan);
+int mxg_grain_plan_window(const mxg_grain_plan *plan, double *h_window); /* returns sampleDur */
+/* S independent streams over one shared sample (mxg_sample_upload), T samples each, d_out[n*S + s].
+ * mode 0 = maxiTimeStretch<F>::play(speed = a[s], grainLength, overlaps, posMod[s]) (:341-355);
+ * mode 1 = maxiStretch<F>::play(pitchstretch = a[s], timestretch = b[s], grainLength, overlaps,
+ * posMod[s]) with the default loop (whole sample) (:512-530).  d_posmod may be NULL (0).
+ * d_rnd: int32 [S][R], the values `rand() % 10` returns at each spawn, consumed in order per
+ * stream (NULL = 0): the reference draws them from the process-wide rand() stream, which a bank
+ * cannot reproduce.  State, in/out: d_st = [4][S] position, looper, randomOffset, rand cursor
+ * (setPosition(p) == position = clamp(p*len, 0, len-1), :335-338); d_gst = [4][8][S]: the live
+ * grains in creation order: pos, inc, sampleIdx, sampleDur (0 = empty slot).  Synchronous on
+ * `stream` (it reports > 8 live grains / exhausted d_rnd as MXG_ERR_INVALID). */
+int mxg_granular_render(const mxg_grain_plan *plan, int mode, size_t S, size_t T, const double *d_samples,
+                        size_t len, int overlaps, const double *d_a, const double *d_b,
+                        const double *d_posmod, const int32_t *d_rnd, size_t R, double *d_st, double *d_gst,
+                        double *d_out, void *stream);
+
 /* ---- calibration ----------------------------------------------------------------------- */
 /* Streaming fill of `bytes` at d_dst (8 B/lane or 16 B/lane stores): the measured HBM write
  * ceiling that bench.py reports next to the nominal 8 TB/s. */

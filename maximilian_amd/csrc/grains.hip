@@ -1,0 +1,318 @@
+// grains.hip -- maxiTimeStretch / maxiStretch granular banks on gfx950.
+//
+// Path (reference L/ = src/libs/maxiGrains.h): window functors :18-90 and
+// maxiGrainWindowCache::getWindow :112-120 (host, plan creation); maxiGrain ctor :160-181 and
+// maxiGrain::play :216-245 (the non-MAXIGRAINFAST linear path); maxiGrainPlayer::play :270-283;
+// maxiTimeStretch::play :341-355; maxiStretch::play :512-530.
+//
+// One stream = one maxiTimeStretch/maxiStretch object: a scheduler (position, looper,
+// randomOffset) that spawns a grain roughly every grainLength*sr/overlaps samples, and a list of
+// live grains whose outputs are summed IN CREATION ORDER.  Everything is + - * / floor on fp64
+// plus integer indexing, so a stream is bit-exact as long as each grain's position recurrence
+// (pos += inc, wrapped) and the per-sample sum order are kept -- both are, see the kernels.
+// `rand() % 10` (L/maxiGrains.h:352) is a process-wide libc stream in the reference and cannot
+// be reproduced for a bank: the caller supplies the drawn values per stream (d_rnd) or none (0).
+//
+// K8 `granular_kernel`: one lane per stream walks the T samples; up to 8 live grains sit in
+// registers in creation order (FIFO: equal durations inside a plan).  The sample buffer is shared
+// by all streams (35 MB in config 5: L2 / Infinity-Cache resident), the window table is staged in
+// LDS.  Output is [T][S] sample-major like every other bank.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "mxg_common.h"
+
+struct mxg_grain_plan {
+    int window_kind, mySampleRate;
+    double grainLength;
+    unsigned long sampleDur;
+    double *d_window;  // [sampleDur]
+    std::vector<double> h_window;
+};
+
+namespace mxg {
+namespace {
+
+constexpr int kSlots = 8;
+
+double window_value(int kind, unsigned long windowLength, unsigned long windowPos) {  // L/maxiGrains.h:18-97
+    switch (kind) {
+        case 0: return 0.5 * (1.0 - cos((2.0 * MXG_PI * windowPos) / (windowLength - 1)));
+        case 1: return 0.54 - (0.46 * cos((2.0 * MXG_PI * windowPos) / (windowLength - 1)));
+        case 2: return sin((MXG_PI * windowPos) / (windowLength - 1));
+        case 3: return 1;
+        case 4:
+            return (2.0 / (windowLength - 1.0)) *
+                   (((windowLength - 1.0) / 2.0) - fabs(windowPos - ((windowLength - 1.0) / 2.0)));
+        case 5:
+            return (2.0 / windowLength) * ((windowLength / 2.0) - fabs(windowPos - ((windowLength - 1.0) / 2.0)));
+        case 6:
+            return 0.35875 - (0.48829 * cos((2 * MXG_PI * windowPos) / (windowLength - 1))) +
+                   (0.14128 * cos((4 * MXG_PI * windowPos) / (windowLength - 1))) +
+                   (0.01168 * cos((6 * MXG_PI * windowPos) / (windowLength - 1)));
+        case 7:
+            return 0.3635819 - (0.4891775 * cos((2 * MXG_PI * windowPos) / (windowLength - 1))) +
+                   (0.1365995 * cos((4 * MXG_PI * windowPos) / (windowLength - 1))) +
+                   (0.0106411 * cos((6 * MXG_PI * windowPos) / (windowLength - 1)));
+        default: {
+            const double gausDivisor = (-2.0 * 0.3 * 0.3);
+            const double phase = ((windowPos / (double)windowLength) - 0.5) * 2.0;
+            return exp((phase * phase) / gausDivisor);
+        }
+    }
+}
+
+struct GrainArgs {
+    size_t S, T, len, R;
+    const double *amp, *window, *a, *b, *posMod;
+    const int32_t *rnd;
+    double *st, *gst, *out;
+    int *err;
+    double sr, cycleLength, grainLength;
+    int sampleDur, mySampleRate, winInLds;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(64) void granular_kernel(GrainArgs A) {
+    extern __shared__ double s_win[];
+    const double *win = A.window;
+    if (A.winInLds) {
+        for (int i = threadIdx.x; i < A.sampleDur; i += blockDim.x) s_win[i] = A.window[i];
+        __syncthreads();
+        win = s_win;
+    }
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.S) return;
+    const size_t S = A.S;
+    const double dlen = (double)A.len;
+    double position = A.st[s], looper = A.st[S + s], randomOffset = A.st[2 * S + s];
+    size_t cursor = (size_t)A.st[3 * S + s];
+    double gpos[kSlots], ginc[kSlots];
+    int gidx[kSlots], gdur[kSlots];
+    int tail = 0;
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) {
+        gpos[k] = A.gst[(0 * kSlots + k) * S + s];
+        ginc[k] = A.gst[(1 * kSlots + k) * S + s];
+        gidx[k] = (int)A.gst[(2 * kSlots + k) * S + s];
+        gdur[k] = (int)A.gst[(3 * kSlots + k) * S + s];
+        if (gdur[k]) tail = k + 1;
+    }
+    const double speed = A.a[s];
+    const double rate = MODE == 0 ? speed : A.b[s];  // what advances `position` each sample
+    const double pm = A.posMod ? A.posMod[s] : 0.0;
+    // maxiGrain ctor values that are the same for every grain this stream spawns in this launch
+    // (L/maxiGrains.h:160-181): sampleDur, freq = 1/dur, frequency = freq*speed, inc.
+    const double grainSpeed = MODE == 0 ? (speed > 0 ? 1.0 : -1.0) : speed;  // :350
+    const double frequency = (1.0 / A.grainLength) * grainSpeed;
+    const double newInc = (frequency != 0) ? (double)A.sampleDur / (A.sr / frequency) : 0.0;
+    int failed = 0;
+    double *op = A.out + s;
+    for (size_t n = 0; n < A.T; n++) {
+        // ---- scheduler: maxiTimeStretch::play :342-353 / maxiStretch::play :514-525
+        position = position + rate;
+        looper += 1.0;
+        if (MODE == 0) {
+            if (position > dlen) position -= dlen;
+            if (position < 0) position += dlen;
+        } else {  // loopStart 0, loopEnd = loopLength = len (maxiStretch ctor :469-477)
+            if (position >= dlen) position -= dlen;
+            if (position < 0.0) position += dlen;
+        }
+        if (looper > A.cycleLength + randomOffset) {
+            looper -= (A.cycleLength + randomOffset);
+            if (tail == kSlots) {  // compact the holes (only non-FIFO deaths leave any)
+#pragma unroll
+                for (int pass = 0; pass < kSlots - 1; pass++)
+#pragma unroll
+                    for (int k = 0; k < kSlots - 1; k++)
+                        if (gdur[k] == 0) {
+                            gpos[k] = gpos[k + 1]; ginc[k] = ginc[k + 1]; gidx[k] = gidx[k + 1];
+                            gdur[k] = gdur[k + 1]; gdur[k + 1] = 0;
+                        }
+                tail = 0;
+#pragma unroll
+                for (int k = 0; k < kSlots; k++)
+                    if (gdur[k]) tail = k + 1;
+            }
+            if (tail == kSlots) {
+                failed = 1;  // more than 8 grains alive: reported through *err, stream keeps running
+            } else {
+                double p01 = (position / dlen) + pm;
+                p01 = 1.0 < p01 ? 1.0 : p01;
+                p01 = p01 < 0.0 ? 0.0 : p01;
+                const double startPos = floor(dlen * p01);  // (unsigned long)(len*pos), pos >= 0
+                double endPos = startPos + (double)A.sampleDur;
+                endPos = dlen < endPos ? dlen : endPos;
+                const double pos0 = frequency > 0 ? startPos : endPos;
+#pragma unroll
+                for (int k = 0; k < kSlots; k++)
+                    if (k == tail) {
+                        gpos[k] = pos0; ginc[k] = newInc; gidx[k] = 0; gdur[k] = A.sampleDur;
+                    }
+                tail++;
+            }
+            if (A.rnd) {
+                if (cursor < A.R) randomOffset = (double)A.rnd[s * A.R + cursor]; else { failed = 2; randomOffset = 0; }
+                cursor++;
+            } else {
+                randomOffset = 0;
+            }
+        }
+        // ---- maxiGrainPlayer::play :270-283: sum the live grains in creation order
+        double total = 0.0;
+#pragma unroll
+        for (int k = 0; k < kSlots; k++) {
+            if (gdur[k] > 0) {  // maxiGrain::play :216-245
+                const double envValue = win[gidx[k]];
+                double pos = gpos[k] + ginc[k];
+                if (pos >= dlen)
+                    pos -= dlen;
+                else if (pos < 0)
+                    pos += dlen;
+                gpos[k] = pos;
+                const double fl = floor(pos);
+                const double remainder = pos - fl;
+                const long long ia = (long long)fl;
+                long long ib = ia + 1;
+                if ((size_t)ib >= A.len) ib = 0;
+                double o = ((1 - remainder) * A.amp[ia] + remainder * A.amp[ib]);
+                o *= envValue;
+                total += o;
+                gidx[k]++;
+                if (gidx[k] == gdur[k]) gdur[k] = 0;  // finished: erased from the list
+            }
+        }
+        if (tail > 0 && gdur[0] == 0) {  // FIFO: the oldest grain is gone, close ranks
+#pragma unroll
+            for (int k = 0; k < kSlots - 1; k++) {
+                gpos[k] = gpos[k + 1]; ginc[k] = ginc[k + 1]; gidx[k] = gidx[k + 1]; gdur[k] = gdur[k + 1];
+            }
+            gdur[kSlots - 1] = 0;
+            tail--;
+        }
+        *op = total;
+        op += S;
+    }
+    if (failed) atomicMax(A.err, failed);
+    // state out, compacted (live grains first, creation order)
+    A.st[s] = position;
+    A.st[S + s] = looper;
+    A.st[2 * S + s] = randomOffset;
+    A.st[3 * S + s] = (double)cursor;
+#pragma unroll
+    for (int pass = 0; pass < kSlots - 1; pass++)
+#pragma unroll
+        for (int k = 0; k < kSlots - 1; k++)
+            if (gdur[k] == 0) {
+                gpos[k] = gpos[k + 1]; ginc[k] = ginc[k + 1]; gidx[k] = gidx[k + 1];
+                gdur[k] = gdur[k + 1]; gdur[k + 1] = 0;
+            }
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) {
+        const bool live = gdur[k] > 0;
+        A.gst[(0 * kSlots + k) * S + s] = live ? gpos[k] : 0.0;
+        A.gst[(1 * kSlots + k) * S + s] = live ? ginc[k] : 0.0;
+        A.gst[(2 * kSlots + k) * S + s] = live ? (double)gidx[k] : 0.0;
+        A.gst[(3 * kSlots + k) * S + s] = live ? (double)gdur[k] : 0.0;
+    }
+}
+
+int *g_err = nullptr;
+
+}  // namespace
+}  // namespace mxg
+
+using namespace mxg;
+
+extern "C" {
+
+mxg_grain_plan *mxg_grain_plan_create(int window_kind, double grainLength, int mySampleRate) {
+    if (window_kind < 0 || window_kind > 8 || !(grainLength > 0) || mySampleRate <= 0) {
+        fail(MXG_ERR_INVALID, "mxg_grain_plan_create: bad argument");
+        return nullptr;
+    }
+    const unsigned long sampleDur = grainLength * (double)mySampleRate;  // L/maxiGrains.h:164
+    const unsigned long cacheSize = settings().sampleRate / 2.0;         // :98
+    if (sampleDur == 0 || sampleDur >= cacheSize) {
+        fail(MXG_ERR_INVALID, "mxg_grain_plan_create: grain of %lu samples outside (0, %lu) -- the "
+                              "reference's window cache holds up to 500 ms (maxiGrains.h:98)", sampleDur, cacheSize);
+        return nullptr;
+    }
+    mxg_grain_plan *p = new mxg_grain_plan();
+    p->window_kind = window_kind;
+    p->mySampleRate = mySampleRate;
+    p->grainLength = grainLength;
+    p->sampleDur = sampleDur;
+    p->d_window = nullptr;
+    p->h_window.resize(sampleDur);
+    for (unsigned long i = 0; i < sampleDur; i++) p->h_window[i] = window_value(window_kind, sampleDur, i);
+    if (!ensure_init()) {
+        if (check_hip(hipMalloc(&p->d_window, sizeof(double) * sampleDur), "hipMalloc") ||
+            check_hip(hipMemcpy(p->d_window, p->h_window.data(), sizeof(double) * sampleDur, hipMemcpyHostToDevice),
+                      "hipMemcpy")) {
+            if (p->d_window) (void)hipFree(p->d_window);
+            p->d_window = nullptr;
+        }
+    }
+    return p;
+}
+
+int mxg_grain_plan_destroy(mxg_grain_plan *p) {
+    if (!p) return MXG_OK;
+    if (p->d_window) (void)hipFree(p->d_window);
+    delete p;
+    return MXG_OK;
+}
+
+int mxg_grain_plan_window(const mxg_grain_plan *p, double *h_window) {
+    MXG_REQUIRE(p, "null plan");
+    if (h_window) memcpy(h_window, p->h_window.data(), sizeof(double) * p->h_window.size());
+    return (int)p->sampleDur;
+}
+
+int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, const double *d_samples,
+                        size_t len, int overlaps, const double *d_a, const double *d_b,
+                        const double *d_posmod, const int32_t *d_rnd, size_t R, double *d_st, double *d_gst,
+                        double *d_out, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(p && p->d_window, "null plan (or plan created without a HIP device)");
+    MXG_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (maxiTimeStretch) or 1 (maxiStretch)");
+    MXG_REQUIRE(d_samples && d_a && d_st && d_gst && d_out, "null device pointer");
+    MXG_REQUIRE(mode == 0 || d_b, "maxiStretch needs d_b (timestretch)");
+    MXG_REQUIRE(len > 0 && overlaps > 0, "empty sample or overlaps <= 0");
+    if (S == 0 || T == 0) return MXG_OK;
+    hipStream_t st = resolve_stream(stream);
+    if (!g_err) {
+        MXG_HIP(hipMalloc(&g_err, sizeof(int)));
+    }
+    MXG_HIP(hipMemsetAsync(g_err, 0, sizeof(int), st));
+    GrainArgs A;
+    A.S = S; A.T = T; A.len = len; A.R = R;
+    A.amp = d_samples; A.window = p->d_window; A.a = d_a; A.b = d_b; A.posMod = d_posmod;
+    A.rnd = d_rnd; A.st = d_st; A.gst = d_gst; A.out = d_out; A.err = g_err;
+    A.sr = (double)settings().sampleRate;
+    A.cycleLength = p->grainLength * settings().sampleRate / overlaps;  // L/maxiGrains.h:346
+    A.grainLength = p->grainLength;
+    A.sampleDur = (int)p->sampleDur;
+    A.mySampleRate = p->mySampleRate;
+    size_t lds = sizeof(double) * p->sampleDur;
+    A.winInLds = lds <= 60 * 1024;
+    if (!A.winInLds) lds = 0;
+    dim3 grid((unsigned)((S + 63) / 64));
+    if (mode == 0)
+        hipLaunchKernelGGL((granular_kernel<0>), grid, dim3(64), lds, st, A);
+    else
+        hipLaunchKernelGGL((granular_kernel<1>), grid, dim3(64), lds, st, A);
+    MXG_HIP(hipGetLastError());
+    int herr = 0;
+    MXG_HIP(hipMemcpyAsync(&herr, g_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    MXG_HIP(hipStreamSynchronize(st));
+    if (herr == 1) return fail(MXG_ERR_INVALID, "mxg_granular_render: more than 8 grains alive in a stream");
+    if (herr == 2) return fail(MXG_ERR_INVALID, "mxg_granular_render: d_rnd exhausted (R too small)");
+    return MXG_OK;
+}
+
+}  // extern "C"

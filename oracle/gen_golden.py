@@ -223,6 +223,35 @@ def main():
     files["spectral.npz"] = ("maxiFFT (1024/1024, 1024/256 streaming, 512/128, 2048/1024, 64/64) real/imag/mags/"
                              "phases + maxiMFCC 512/42/13, 512/256/13, 512/40/20 on the config-4 signal")
 
+    # ---- maxiGrains: maxiTimeStretch / maxiStretch (config 5, reduced) ------------------------------------
+    rng = np.random.default_rng(SEED + 8)
+    Ls = 44100
+    n = np.arange(Ls)
+    smp = 0.5 * np.sin(2 * np.pi * 110 * n / 44100) + 0.25 * np.sin(2 * np.pi * 331 * n / 44100) \
+        + 0.05 * rng.uniform(-1, 1, Ls)
+    S, T = 12, 5000
+    speed = 0.25 + 1.5 * (np.arange(S) % 97) / 96
+    speed[5] = -0.8
+    st0 = np.zeros((4, S))
+    st0[0] = np.clip(np.arange(S) / S * Ls, 0, Ls - 1)  # setPosition(s/S)
+    rnd = rng.integers(0, 10, (S, 48)).astype(np.int32)
+    ts = rng.uniform(0.3, 1.7, S)
+    d = dict(samples=smp, speed=speed, st0=st0, rnd=rnd, timestretch=ts, T=T)
+    d["windows_2205"] = np.stack([R.grain_window(k, 2205) for k in range(9)])
+    cases = {"ts_hann": (0, 0, 0.05, 4, True), "ts_hamming_norand": (0, 1, 0.03, 3, False),
+             "st_hann": (1, 0, 0.05, 2, True), "st_gauss": (1, 8, 0.021, 5, True)}
+    for name, (mode, w, gl, ov, use_rnd) in cases.items():
+        h = T // 2
+        o1, st, gst, rc = R.granular(mode, w, smp, h, speed, b=ts, rnd=rnd if use_rnd else None,
+                                     grainLength=gl, overlaps=ov, st=st0)
+        assert rc == 0
+        o2, st, gst, rc = R.granular(mode, w, smp, T - h, speed, b=ts, rnd=rnd if use_rnd else None,
+                                     grainLength=gl, overlaps=ov, st=st, gst=gst)
+        assert rc == 0
+        d["out_" + name], d["st_" + name], d["gst_" + name] = np.concatenate([o1, o2]), st, gst
+    np.savez_compressed(os.path.join(GOLD, "grains.npz"), **d)
+    files["grains.npz"] = "maxiTimeStretch/maxiStretch banks, 12 streams x 2500+2500 samples, 4 configs; 9 windows"
+
     sha = hashlib.sha256()
     for f in ("maximilian.cpp", "maximilian.h", "libs/fft.cpp", "libs/maxiFFT.cpp", "libs/maxiMFCC.cpp",
               "libs/maxiMFCC.h", "libs/maxiGrains.h"):

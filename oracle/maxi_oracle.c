@@ -1064,6 +1064,200 @@ int mxo_mfcc_tables(unsigned numBins, unsigned numFilters, unsigned numCoeffs, d
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------
+ * maxiGrains (L/maxiGrains.h): window functors :18-90, maxiGrain :137-251,
+ * maxiGrainPlayer :253-284, maxiTimeStretch::play :341-355, maxiStretch::play :512-530.
+ * ------------------------------------------------------------------------------------ */
+/* window kinds: 0 hann 1 hamming 2 cosine 3 rect 4 triangle 5 triangleNZ 6 blackmanHarris
+ * 7 blackmanNutall 8 gaussian(kurtosis 0.3) */
+static double grain_window_value(int kind, unsigned long windowLength, unsigned long windowPos) {
+    switch (kind) {
+        case 0: return 0.5 * (1.0 - cos((2.0 * MX_PI * windowPos) / (windowLength - 1)));           /* :19-21 */
+        case 1: return 0.54 - (0.46 * cos((2.0 * MX_PI * windowPos) / (windowLength - 1)));         /* :26-28 */
+        case 2: return sin((MX_PI * windowPos) / (windowLength - 1));                               /* :33-35 */
+        case 3: return 1;                                                                          /* :40-42 */
+        case 4:                                                                                    /* :47-49 */
+            return (2.0 / (windowLength - 1.0)) *
+                   (((windowLength - 1.0) / 2.0) - fabs(windowPos - ((windowLength - 1.0) / 2.0)));
+        case 5:                                                                                    /* :54-56 */
+            return (2.0 / windowLength) * ((windowLength / 2.0) - fabs(windowPos - ((windowLength - 1.0) / 2.0)));
+        case 6:                                                                                    /* :61-66 */
+            return 0.35875 - (0.48829 * cos((2 * MX_PI * windowPos) / (windowLength - 1))) +
+                   (0.14128 * cos((4 * MX_PI * windowPos) / (windowLength - 1))) +
+                   (0.01168 * cos((6 * MX_PI * windowPos) / (windowLength - 1)));
+        case 7:                                                                                    /* :71-76 */
+            return 0.3635819 - (0.4891775 * cos((2 * MX_PI * windowPos) / (windowLength - 1))) +
+                   (0.1365995 * cos((4 * MX_PI * windowPos) / (windowLength - 1))) +
+                   (0.0106411 * cos((6 * MX_PI * windowPos) / (windowLength - 1)));
+        case 8: {                                                                                  /* :79-97 */
+            double gausDivisor = (-2.0 * 0.3 * 0.3);
+            double phase = ((windowPos / (double)windowLength) - 0.5) * 2.0;
+            return exp((phase * phase) / gausDivisor);
+        }
+    }
+    return 0;
+}
+
+/* maxiGrainWindowCache::getWindow (:112-120): the table for one length */
+int mxo_grain_window(int kind, unsigned length, double *out) {
+    if (kind < 0 || kind > 8) return -1;
+    for (unsigned i = 0; i < length; i++) out[i] = grain_window_value(kind, length, i);
+    return 0;
+}
+
+#define MXO_GRAIN_SLOTS 8
+typedef struct {
+    double pos, inc;
+    unsigned long sampleIdx, sampleDur; /* sampleDur == 0: empty slot */
+} grain_t;
+
+/* maxiGrain ctor (:160-181) */
+static void grain_init(grain_t *g, size_t len, int mySampleRate, double position, double duration,
+                       double speed) {
+    unsigned long sampleStartPos = len * position;
+    unsigned long sampleDur = duration * (double)mySampleRate;
+    double freq = 1.0 / duration;
+    unsigned long sampleEndPos = len < sampleStartPos + sampleDur ? len : sampleStartPos + sampleDur;
+    double frequency = freq * speed;
+    if (frequency > 0) {
+        g->pos = sampleStartPos;
+    } else {
+        g->pos = sampleEndPos;
+    }
+    if (frequency != 0) {
+        g->inc = sampleDur / (g_sampleRate / frequency);
+    } else
+        g->inc = 0;
+    g->sampleIdx = 0;
+    g->sampleDur = sampleDur;
+}
+
+/* maxiGrain::play (:216-245), non-MAXIGRAINFAST path.  Returns 1 when the grain finished. */
+static int grain_play(grain_t *g, const double *buffer, size_t len, const double *window, double *out) {
+    double output = 0.0;
+    {
+        double envValue = window[g->sampleIdx];
+        double remainder;
+        g->pos += g->inc;
+        if (g->pos >= len)
+            g->pos -= len;
+        else if (g->pos < 0)
+            g->pos += len;
+        long posl = floor(g->pos);
+        remainder = g->pos - posl;
+        long a = posl;
+        long b = posl + 1;
+        if ((size_t)b >= len) {
+            b = 0;
+        }
+        output = (double)((1 - remainder) * buffer[a] + remainder * buffer[b]);
+        output *= envValue;
+    }
+    g->sampleIdx++;
+    *out = output;
+    return g->sampleIdx == g->sampleDur;
+}
+
+/* S independent maxiTimeStretch<F> (mode 0) / maxiStretch<F> (mode 1, loop = whole sample)
+ * objects over one shared sample, T samples each; out[n*S + s].
+ *   mode 0: play(speed=a[s], grainLength, overlaps, posMod[s])                (:341-355)
+ *   mode 1: play(pitchstretch=a[s], timestretch=b[s], grainLength, overlaps, posMod[s]) (:512-530)
+ * rnd: the values `rand() % 10` would have returned, consumed in order per stream, [S][R]
+ * (NULL = all 0); the global rand() stream itself is not reproducible across a bank.
+ * st = [4][S]: position, looper, randomOffset, rand cursor.  gst = [4][8][S]: per slot pos, inc,
+ * sampleIdx, sampleDur (0 = empty); slots hold the live grains in creation order.
+ * `amp` must be valid on [0, len] (one guard element, see mxo_sample).  Returns 0, or -3 if more
+ * than 8 grains are alive at once, -4 if R is exhausted, -2 bad window length. */
+int mxo_granular(int mode, int window_kind, size_t S, size_t T, const double *amp, size_t len,
+                 int mySampleRate, double grainLength, int overlaps, const double *a, const double *b,
+                 const double *posMod, const int32_t *rnd, size_t R, double *st, double *gst, double *out) {
+    if (mode < 0 || mode > 1 || overlaps <= 0) return -1;
+    unsigned long sampleDur = grainLength * (double)mySampleRate;
+    if (sampleDur == 0 || sampleDur >= (unsigned long)(g_sampleRate / 2.0)) return -2; /* cacheSize :98 */
+    double *window = (double *)malloc(sizeof(double) * sampleDur);
+    mxo_grain_window(window_kind, (unsigned)sampleDur, window);
+    int rc = 0;
+    for (size_t s = 0; s < S && rc == 0; s++) {
+        double position = st[0 * S + s], looper = st[1 * S + s], randomOffset = st[2 * S + s];
+        size_t cursor = (size_t)st[3 * S + s];
+        grain_t g[MXO_GRAIN_SLOTS];
+        int count = 0;
+        for (int k = 0; k < MXO_GRAIN_SLOTS; k++) {
+            g[k].pos = gst[(0 * MXO_GRAIN_SLOTS + k) * S + s];
+            g[k].inc = gst[(1 * MXO_GRAIN_SLOTS + k) * S + s];
+            g[k].sampleIdx = (unsigned long)gst[(2 * MXO_GRAIN_SLOTS + k) * S + s];
+            g[k].sampleDur = (unsigned long)gst[(3 * MXO_GRAIN_SLOTS + k) * S + s];
+            if (g[k].sampleDur) count = k + 1;
+        }
+        const unsigned long loopStart = 0, loopEnd = len, loopLength = len; /* maxiStretch ctor :469-477 */
+        for (size_t n = 0; n < T; n++) {
+            double speed = a[s];
+            int spawn = 0;
+            double grainSpeed = 0;
+            if (mode == 0) {
+                position = position + speed;
+                looper++;
+                if (position > len) position -= len;
+                if (position < 0) position += len;
+            } else {
+                position = position + (1 * b[s]);
+                looper++;
+                if (position >= loopEnd) position -= loopLength;
+                if (position < loopStart) position += loopLength;
+            }
+            double cycleLength = grainLength * g_sampleRate / overlaps;
+            if (looper > cycleLength + randomOffset) {
+                looper -= (cycleLength + randomOffset);
+                grainSpeed = mode == 0 ? (speed > 0 ? 1 : -1) : speed;
+                spawn = 1;
+            }
+            if (spawn) {
+                if (count == MXO_GRAIN_SLOTS) {
+                    rc = -3;
+                    break;
+                }
+                double p01 = (position / len) + (posMod ? posMod[s] : 0.0);
+                p01 = 1.0 < p01 ? 1.0 : p01; /* min(1.0, x) */
+                p01 = p01 < 0.0 ? 0.0 : p01; /* max(x, 0.0) */
+                grain_init(&g[count++], len, mySampleRate, p01, grainLength, grainSpeed);
+                if (rnd) {
+                    if (cursor >= R) {
+                        rc = -4;
+                        break;
+                    }
+                    randomOffset = rnd[s * R + cursor++];
+                } else
+                    randomOffset = 0;
+            }
+            /* maxiGrainPlayer::play (:270-283): sum in list order, erase the finished */
+            double total = 0.0;
+            int w = 0;
+            for (int k = 0; k < count; k++) {
+                double o;
+                int fin = grain_play(&g[k], amp, len, window, &o);
+                total += o;
+                if (!fin) g[w++] = g[k];
+            }
+            for (int k = w; k < count; k++) g[k].sampleDur = 0;
+            count = w;
+            out[n * S + s] = total;
+        }
+        st[0 * S + s] = position;
+        st[1 * S + s] = looper;
+        st[2 * S + s] = randomOffset;
+        st[3 * S + s] = (double)cursor;
+        for (int k = 0; k < MXO_GRAIN_SLOTS; k++) {
+            int live = k < count;
+            gst[(0 * MXO_GRAIN_SLOTS + k) * S + s] = live ? g[k].pos : 0.0;
+            gst[(1 * MXO_GRAIN_SLOTS + k) * S + s] = live ? g[k].inc : 0.0;
+            gst[(2 * MXO_GRAIN_SLOTS + k) * S + s] = live ? (double)g[k].sampleIdx : 0.0;
+            gst[(3 * MXO_GRAIN_SLOTS + k) * S + s] = live ? (double)g[k].sampleDur : 0.0;
+        }
+    }
+    free(window);
+    return rc;
+}
+
 /* mfcc() over nframes magnitude spectra (mags[f*mag_stride + bin]) -> melBands (after the
  * log-square, [nframes][numFilters], may be NULL) and coefficients [nframes][numCoeffs].
  * L/maxiMFCC.cpp:48-66 then L/maxiMFCC.h:98-111. */

@@ -237,6 +237,40 @@ class Oracle:
         assert rc == 0
         return mel, out
 
+    # -- maxiGrains ---------------------------------------------------------------------------------------
+    def grain_window(self, kind, length):
+        out = np.zeros(length)
+        fn = self.L.mxo_grain_window
+        fn.restype = c_int
+        fn.argtypes = [c_int, ctypes.c_uint, c_void_p]
+        rc = fn(kind, length, _p(out))
+        assert rc == 0, rc
+        return out
+
+    def granular(self, mode, window_kind, samples, T, a, b=None, posMod=None, rnd=None, grainLength=0.05,
+                 overlaps=4, mySampleRate=44100, st=None, gst=None):
+        """maxiTimeStretch (mode 0) / maxiStretch (mode 1) bank.  Returns (out [T,S], st, gst, rc)."""
+        samples = np.asarray(samples, np.float64)
+        g = np.concatenate([samples, [0.0]])  # guard element amp[len]
+        a = _f64(a)
+        S = a.size
+        b = None if b is None else _f64(b, (S,))
+        posMod = None if posMod is None else _f64(posMod, (S,))
+        R = 0
+        if rnd is not None:
+            rnd = np.ascontiguousarray(rnd, np.int32).reshape(S, -1)
+            R = rnd.shape[1]
+        st = np.zeros((4, S)) if st is None else _f64(st).copy()
+        gst = np.zeros((4, 8, S)) if gst is None else _f64(gst).copy()
+        out = np.zeros((T, S))
+        fn = self.L.mxo_granular
+        fn.restype = c_int
+        fn.argtypes = [c_int, c_int, c_size_t, c_size_t, c_void_p, c_size_t, c_int, c_double, c_int, c_void_p,
+                       c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]
+        rc = fn(mode, window_kind, S, T, _p(g), samples.size, mySampleRate, grainLength, overlaps, _p(a), _p(b),
+                _p(posMod), _p(rnd), R, _p(st), _p(gst), _p(out))
+        return out, st, gst, rc
+
     # -- CPU baseline timer -----------------------------------------------------------------------
     def time_osc(self, wf, freq, N, threads=1):
         freq = _f64(freq)

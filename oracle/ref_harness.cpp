@@ -17,7 +17,25 @@
 #include "maximilian.h"
 #include "libs/maxiFFT.h"
 #include "libs/maxiMFCC.h"
+// maxiTimeStretch/maxiStretch draw `rand() % 10` from the process-wide libc stream
+// (maxiGrains.h:352, :524), which cannot be reproduced per stream in a bank.  The header-only
+// grain code is compiled in THIS translation unit, so its rand() calls are routed to a
+// per-stream queue supplied by the test (the reference source on disk is untouched).
+#include <cstdlib>
+static const int32_t *g_rnd_q = nullptr;
+static size_t g_rnd_n = 0, g_rnd_i = 0;
+static int g_rnd_underrun = 0;
+static int mxo_ref_rand() {
+    if (!g_rnd_q) return 0;
+    if (g_rnd_i >= g_rnd_n) {
+        g_rnd_underrun = 1;
+        return 0;
+    }
+    return g_rnd_q[g_rnd_i++];
+}
+#define rand mxo_ref_rand
 #include "libs/maxiGrains.h"
+#undef rand
 
 #include <cstdint>
 #include <cstring>
@@ -448,6 +466,130 @@ int mxo_mfcc(unsigned numBins, unsigned numFilters, unsigned numCoeffs, double m
         memcpy(mfcc + f * numCoeffs, c.data(), sizeof(double) * numCoeffs);
     }
     return 0;
+}
+
+// ---- maxiGrains: window tables, maxiTimeStretch / maxiStretch banks (src/libs/maxiGrains.h) -------
+extern "C++" {
+template <typename F>
+static int window_of(unsigned length, double *out) {
+    maxiGrainWindowCache<F> cache;
+    if (length >= cache.cacheSize) return -2;
+    double *w = cache.getWindow(length);
+    memcpy(out, w, sizeof(double) * length);
+    return 0;
+}
+}
+int mxo_grain_window(int kind, unsigned length, double *out) {
+    switch (kind) {
+        case 0: return window_of<hannWinFunctor>(length, out);
+        case 1: return window_of<hammingWinFunctor>(length, out);
+        case 2: return window_of<cosineWinFunctor>(length, out);
+        case 3: return window_of<rectWinFunctor>(length, out);
+        case 4: return window_of<triangleWinFunctor>(length, out);
+        case 5: return window_of<triangleNZWinFunctor>(length, out);
+        case 6: return window_of<blackmanHarrisWinFunctor>(length, out);
+        case 7: return window_of<blackmanNutallWinFunctor>(length, out);
+        case 8: return window_of<gaussianWinFunctor>(length, out);
+    }
+    return -1;
+}
+
+// State layout as in oracle/maxi_oracle.c: st = [4][S] position, looper, randomOffset, rand cursor;
+// gst = [4][8][S] per live grain (creation order) pos, inc, sampleIdx, sampleDur.
+extern "C++" {
+template <typename F>
+static int granular_bank(int mode, size_t S, size_t T, maxiSample &smp, double grainLength, int overlaps,
+                         const double *a, const double *b, const double *posMod, const int32_t *rnd, size_t R,
+                         double *st, double *gst, double *out) {
+    int rc = 0;
+    for (size_t s = 0; s < S && rc == 0; s++) {
+        maxiTimeStretch<F> ts(&smp);
+        maxiStretch<F> stx(&smp);
+        maxiGrainPlayer *gp = mode == 0 ? ts.grainPlayer : stx.grainPlayer;
+        maxiGrainWindowCache<F> *wc = mode == 0 ? &ts.windowCache : &stx.windowCache;
+        if (mode == 0) {
+            ts.position = st[0 * S + s];
+            ts.looper = st[1 * S + s];
+            ts.randomOffset = st[2 * S + s];
+        } else {
+            stx.position = st[0 * S + s];
+            stx.looper = st[1 * S + s];
+            stx.randomOffset = st[2 * S + s];
+        }
+        for (int k = 0; k < 8; k++) {  // re-create the carried-over grains, in creation order
+            unsigned long dur = (unsigned long)gst[(3 * 8 + k) * S + s];
+            if (!dur) continue;
+            maxiGrain<F> *g = new maxiGrain<F>(&smp, 0.0, grainLength, 1, wc);
+            g->pos = gst[(0 * 8 + k) * S + s];
+            g->inc = gst[(1 * 8 + k) * S + s];
+            g->sampleIdx = (unsigned long)gst[(2 * 8 + k) * S + s];
+            g->sampleDur = dur;
+            g->window = wc->getWindow(dur);
+            gp->addGrain(g);
+        }
+        g_rnd_q = rnd ? rnd + s * R : nullptr;
+        g_rnd_n = R;
+        g_rnd_i = (size_t)st[3 * S + s];
+        g_rnd_underrun = 0;
+        for (size_t n = 0; n < T; n++) {
+            out[n * S + s] = mode == 0 ? ts.play(a[s], grainLength, overlaps, posMod ? posMod[s] : 0.0)
+                                       : stx.play(a[s], b[s], grainLength, overlaps, posMod ? posMod[s] : 0.0);
+            if (gp->grains.size() > 8) {
+                rc = -3;
+                break;
+            }
+        }
+        if (g_rnd_underrun) rc = -4;
+        st[0 * S + s] = mode == 0 ? ts.position : stx.position;
+        st[1 * S + s] = mode == 0 ? ts.looper : stx.looper;
+        st[2 * S + s] = mode == 0 ? ts.randomOffset : stx.randomOffset;
+        st[3 * S + s] = (double)g_rnd_i;
+        int k = 0;
+        for (maxiGrainBase *gb : gp->grains) {
+            if (k >= 8) break;
+            maxiGrain<F> *g = static_cast<maxiGrain<F> *>(gb);
+            gst[(0 * 8 + k) * S + s] = g->pos;
+            gst[(1 * 8 + k) * S + s] = g->inc;
+            gst[(2 * 8 + k) * S + s] = (double)g->sampleIdx;
+            gst[(3 * 8 + k) * S + s] = (double)g->sampleDur;
+            k++;
+        }
+        for (; k < 8; k++)
+            for (int q = 0; q < 4; q++) gst[(q * 8 + k) * S + s] = 0.0;
+        for (maxiGrainBase *gb : gp->grains) delete gb;  // the reference's players leak live grains
+        gp->grains.clear();
+        g_rnd_q = nullptr;
+    }
+    return rc;
+}
+}  // extern "C++"
+
+int mxo_granular(int mode, int window_kind, size_t S, size_t T, const double *amp, size_t len,
+                 int mySampleRate, double grainLength, int overlaps, const double *a, const double *b,
+                 const double *posMod, const int32_t *rnd, size_t R, double *st, double *gst, double *out) {
+    if (mode < 0 || mode > 1 || overlaps <= 0) return -1;
+    unsigned long sampleDur = grainLength * (double)mySampleRate;
+    if (sampleDur == 0 || sampleDur >= (unsigned long)(maxiSettings::sampleRate / 2.0)) return -2;
+    maxiSample smp;
+    std::vector<double> data(amp, amp + len);
+    smp.amplitudes.reserve(len + 2);
+    smp.setSample(data);
+    smp.amplitudes.data()[len] = amp[len];  // the guard element (see mxo_sample)
+    smp.mySampleRate = mySampleRate;
+#define MXO_G(F) return granular_bank<F>(mode, S, T, smp, grainLength, overlaps, a, b, posMod, rnd, R, st, gst, out)
+    switch (window_kind) {
+        case 0: MXO_G(hannWinFunctor);
+        case 1: MXO_G(hammingWinFunctor);
+        case 2: MXO_G(cosineWinFunctor);
+        case 3: MXO_G(rectWinFunctor);
+        case 4: MXO_G(triangleWinFunctor);
+        case 5: MXO_G(triangleNZWinFunctor);
+        case 6: MXO_G(blackmanHarrisWinFunctor);
+        case 7: MXO_G(blackmanNutallWinFunctor);
+        case 8: MXO_G(gaussianWinFunctor);
+    }
+#undef MXO_G
+    return -1;
 }
 
 // ---- CPU baseline timer: sinebuf bank sharded over host threads ----------------------

@@ -1,0 +1,77 @@
+"""GPU parity (-m gpu): maxiTimeStretch / maxiStretch banks through the C-ABI vs oracle + golden."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+CASES = {"ts_hann": (0, 0, 0.05, 4, True), "ts_hamming_norand": (0, 1, 0.03, 3, False),
+         "st_hann": (1, 0, 0.05, 2, True), "st_gauss": (1, 8, 0.021, 5, True)}
+
+
+def make_bank(mx, mode, window, samples, S):
+    sb = mx.maxiSampleBank(1)
+    sb.setSample(samples)
+    bank = (mx.maxiTimeStretchBank if mode == 0 else mx.maxiStretchBank)(S, sb, window)
+    return bank
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_granular_golden(mx, golden, name):
+    g = golden("grains.npz")
+    mode, w, gl, ov, use_rnd = CASES[name]
+    T = int(g["T"])
+    S = g["speed"].size
+    bank = make_bank(mx, mode, w, g["samples"], S)
+    bank.setPosition(np.arange(S) / S)
+    assert_bits_equal(bank.state.numpy(), g["st0"], "setPosition")
+    h = T // 2
+    rnd = g["rnd"] if use_rnd else None
+    if mode == 0:
+        o1 = bank.play(g["speed"], gl, ov, h, rnd=rnd).numpy()
+        o2 = bank.play(g["speed"], gl, ov, T - h, rnd=rnd).numpy()
+    else:
+        o1 = bank.play(g["speed"], g["timestretch"], gl, ov, h, rnd=rnd).numpy()
+        o2 = bank.play(g["speed"], g["timestretch"], gl, ov, T - h, rnd=rnd).numpy()
+    assert_bits_equal(np.concatenate([o1, o2]), g["out_" + name], name)
+    assert_bits_equal(bank.state.numpy(), g["st_" + name], name + " state")
+    assert_bits_equal(bank.grains.numpy(), g["gst_" + name], name + " grains")
+
+
+def test_granular_vs_oracle_many_streams(mx, port):
+    """Config-5-shaped bank at reduced size: 1000 streams, 0.05 s hann grains, 4 overlaps."""
+    rng = np.random.default_rng(51)
+    Ls = 441000
+    n = np.arange(Ls)
+    smp = 0.5 * np.sin(2 * np.pi * 110 * n / 44100) + 0.25 * np.sin(2 * np.pi * 331 * n / 44100) \
+        + 0.05 * rng.uniform(-1, 1, Ls)
+    S, T = 1000, 3000
+    speed = 0.25 + 1.5 * (np.arange(S) % 97) / 96
+    bank = make_bank(mx, 0, "hann", smp, S)
+    bank.setPosition(np.arange(S) / S)
+    st0 = bank.state.numpy()
+    o = bank.play(speed, 0.05, 4, T).numpy()
+    e, est, egst, rc = port.granular(0, 0, smp, T, speed, grainLength=0.05, overlaps=4, st=st0)
+    assert rc == 0
+    assert_bits_equal(o, e, "timestretch bank")
+    assert_bits_equal(bank.state.numpy(), est)
+    assert_bits_equal(bank.grains.numpy(), egst)
+    # stereo mixdown of the streams (pan x_s = s/(S-1)), within the mix tolerance
+    pan = np.arange(S) / (S - 1.0)
+    m = mx.maxiMixBank(S).stereo(mx.DeviceBuffer.from_numpy(o), pan).numpy()
+    em = port.mix_stereo(e, pan)
+    assert np.abs(m - em).max() <= 1e-12 * S
+
+
+def test_granular_errors(mx):
+    rng = np.random.default_rng(3)
+    smp = rng.uniform(-1, 1, 5000)
+    bank = make_bank(mx, 0, "hann", smp, 4)
+    with pytest.raises(mx.MaxiGpuError):
+        bank.play(1.0, 0.2, 12, 8000)       # > 8 live grains
+    bank = make_bank(mx, 0, "hann", smp, 4)
+    with pytest.raises(mx.MaxiGpuError):
+        bank.play(1.0, 0.05, 4, 4000, rnd=np.zeros((4, 2), np.int32))  # rand queue exhausted
+    with pytest.raises(ValueError):
+        make_bank(mx, 0, "hann", smp, 4).play(1.0, 0.7, 4, 10)         # grain > 500 ms
