@@ -1,0 +1,438 @@
+// include/maximilian_bank.hpp -- C++ host facade over the C-ABI (include/maxigpu.h).
+//
+// Host code stays ordinary C++ (g++, no HIP headers): these classes keep the reference's class
+// and method names (src/maximilian.h, src/libs/*.h) but stand for a BANK of V instances whose
+// state lives in HBM.  Two ways to use a bank:
+//
+//   block API      bank.sinebuf(N)            -> device block [N][V] (one launch), chain it into
+//                                                the next bank (filter, mix ...) without leaving HBM
+//   per-sample API bank.frame(v) / bank.tick() -> what the reference's per-sample call returns for
+//                                                voice v in the current audio frame; blocks of
+//                                                `blockSize` frames are rendered behind the scenes
+//                                                when the frame counter wraps, so an existing
+//                                                `void play(double *output)` keeps its shape
+//                                                (see host/polysynth_host.cpp).
+//
+// Parameters handed to a bank (frequencies, cutoffs, pans ...) are block-rate: they take effect
+// at the next block boundary, the same way the reference's players read control values once
+// per callback buffer.  Every method that can fail throws std::runtime_error carrying
+// mxg_last_error(); nothing here falls back to the CPU.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "maxigpu.h"
+
+namespace maxigpu {
+
+inline void check(int status, const char *what) {
+    if (status < 0) throw std::runtime_error(std::string(what) + ": " + mxg_last_error());
+}
+
+// RAII device array of T (hipMalloc behind mxg_malloc)
+template <typename T>
+class DeviceArray {
+public:
+    DeviceArray() = default;
+    explicit DeviceArray(size_t n, bool zero = true) { resize(n, zero); }
+    DeviceArray(const DeviceArray &) = delete;
+    DeviceArray &operator=(const DeviceArray &) = delete;
+    DeviceArray(DeviceArray &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    DeviceArray &operator=(DeviceArray &&o) noexcept {
+        if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; }
+        return *this;
+    }
+    ~DeviceArray() { release(); }
+    void resize(size_t n, bool zero = true) {
+        release();
+        check(mxg_init(-1), "mxg_init");
+        p_ = static_cast<T *>(mxg_malloc(n * sizeof(T)));
+        if (!p_) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+        n_ = n;
+        if (zero && n) check(mxg_memset(p_, 0, n * sizeof(T), nullptr), "mxg_memset");
+    }
+    void upload(const T *h, size_t n, size_t offset = 0) {
+        check(mxg_memcpy_h2d(p_ + offset, h, n * sizeof(T), nullptr), "mxg_memcpy_h2d");
+    }
+    void upload(const std::vector<T> &h) { upload(h.data(), h.size()); }
+    void download(T *h, size_t n, size_t offset = 0) const {
+        check(mxg_memcpy_d2h(h, p_ + offset, n * sizeof(T), nullptr), "mxg_memcpy_d2h");
+    }
+    std::vector<T> download() const {
+        std::vector<T> h(n_);
+        if (n_) download(h.data(), n_);
+        return h;
+    }
+    T *get() const { return p_; }
+    size_t size() const { return n_; }
+
+private:
+    void release() {
+        if (p_) mxg_free(p_);
+        p_ = nullptr;
+        n_ = 0;
+    }
+    T *p_ = nullptr;
+    size_t n_ = 0;
+};
+
+}  // namespace maxigpu
+
+// maxiSettings (H:117-163)
+class maxiSettings {
+public:
+    static size_t sampleRate, channels, bufferSize;
+    static void setup(size_t initSampleRate, size_t initChannels, size_t initBufferSize) {
+        maxigpu::check(mxg_settings(initSampleRate, initChannels, initBufferSize), "mxg_settings");
+        sampleRate = initSampleRate;
+        channels = initChannels;
+        bufferSize = initBufferSize;
+    }
+    static size_t getSampleRate() { return sampleRate; }
+};
+inline size_t maxiSettings::sampleRate = 44100;
+inline size_t maxiSettings::channels = 2;
+inline size_t maxiSettings::bufferSize = 1024;
+
+namespace maxigpu {
+
+// Common machinery of a bank that produces one [N][V] block per launch and can serve it back
+// frame by frame on the host.
+class BlockServer {
+public:
+    BlockServer(size_t voices, size_t blockSize) : V(voices), B(blockSize), out_(voices * blockSize, false) {}
+    size_t voices() const { return V; }
+    size_t blockSize() const { return B; }
+    double *deviceBlock() const { return out_.get(); }
+
+protected:
+    // per-sample facade: value of voice v in the current frame; fetches the block on first use
+    template <typename RenderFn>
+    double frame(size_t v, RenderFn render) {
+        if (cursor_ == B || host_.empty()) {
+            render(B, out_.get());
+            host_.resize(V * B);
+            out_.download(host_.data(), V * B);
+            cursor_ = 0;
+        }
+        return host_[cursor_ * V + v];
+    }
+    void advance() { if (!host_.empty()) ++cursor_; }
+    size_t V, B;
+    DeviceArray<double> out_;
+    std::vector<double> host_;
+    size_t cursor_ = 0;
+};
+
+}  // namespace maxigpu
+
+// ---- maxiOsc (H:169-215) -------------------------------------------------------------------------
+class maxiOscBank : public maxigpu::BlockServer {
+public:
+    explicit maxiOscBank(size_t voices, size_t blockSize = 512)
+        : BlockServer(voices, blockSize), freq_(voices), p1_(voices), p2_(voices), phase_(voices), hold_(voices) {}
+    void setFrequencies(const std::vector<double> &f) { freq_.upload(f); }
+    void setDuty(const std::vector<double> &d) { p1_.upload(d); }
+    void setPhasorRange(const std::vector<double> &start, const std::vector<double> &end) { p1_.upload(start); p2_.upload(end); }
+    void phaseReset(const std::vector<double> &phaseIn) { phase_.upload(phaseIn); }  // C:222-226
+    std::vector<double> phases() const { return phase_.download(); }
+
+    // block API: N samples of every voice into d_out ([N][V], device), state carried
+    void render(int waveform, size_t N, double *d_out, const double *d_freq_per_sample = nullptr, void *stream = nullptr) {
+        maxigpu::check(mxg_osc_render(waveform, V, N, d_freq_per_sample ? d_freq_per_sample : freq_.get(),
+                                      d_freq_per_sample ? 1 : 0, p1_.get(), p2_.get(), phase_.get(), hold_.get(),
+                                      d_out, stream), "mxg_osc_render");
+    }
+    void sinewave(size_t N, double *d_out) { render(MXG_OSC_SINEWAVE, N, d_out); }
+    void coswave(size_t N, double *d_out) { render(MXG_OSC_COSWAVE, N, d_out); }
+    void phasor(size_t N, double *d_out) { render(MXG_OSC_PHASOR, N, d_out); }
+    void saw(size_t N, double *d_out) { render(MXG_OSC_SAW, N, d_out); }
+    void triangle(size_t N, double *d_out) { render(MXG_OSC_TRIANGLE, N, d_out); }
+    void square(size_t N, double *d_out) { render(MXG_OSC_SQUARE, N, d_out); }
+    void pulse(size_t N, double *d_out) { render(MXG_OSC_PULSE, N, d_out); }
+    void impulse(size_t N, double *d_out) { render(MXG_OSC_IMPULSE, N, d_out); }
+    void sinebuf(size_t N, double *d_out) { render(MXG_OSC_SINEBUF, N, d_out); }
+    void sinebuf4(size_t N, double *d_out) { render(MXG_OSC_SINEBUF4, N, d_out); }
+    void sawn(size_t N, double *d_out) { render(MXG_OSC_SAWN, N, d_out); }
+    void phasorBetween(size_t N, double *d_out) { render(MXG_OSC_PHASORBETWEEN, N, d_out); }
+
+    // per-sample API: `waveform` is fixed for the facade stream; call tick() once per audio frame
+    void setWaveform(int waveform) { waveform_ = waveform; }
+    double frame(size_t v) {
+        return BlockServer::frame(v, [this](size_t N, double *d) { render(waveform_, N, d); });
+    }
+    void tick() { advance(); }
+
+private:
+    maxigpu::DeviceArray<double> freq_, p1_, p2_, phase_, hold_;
+    int waveform_ = MXG_OSC_SINEBUF;
+};
+
+// ---- maxiFilter (H:289-366) ------------------------------------------------------------------------
+class maxiFilterBank {
+public:
+    explicit maxiFilterBank(size_t voices) : V(voices), state_(5 * voices), cutoff_(voices), res_(voices), coef_(3 * voices) {}
+    // block-constant parameters: coefficients on the host libm (bit-exact recurrence)
+    void setParams(int kind, const std::vector<double> &cutoff, const std::vector<double> &resonance) {
+        cutoff_.upload(cutoff);
+        if (kind <= MXG_FLT_BANDPASS) {
+            res_.upload(resonance);
+            std::vector<double> coef(3 * V);
+            maxigpu::check(mxg_filter_coeffs_host(kind, V, cutoff.data(), resonance.data(), coef.data()), "mxg_filter_coeffs_host");
+            coef_.upload(coef);
+        }
+        kind_ = kind;
+    }
+    void render(size_t N, const double *d_in, double *d_out, void *stream = nullptr) {
+        maxigpu::check(mxg_filter_render(kind_, V, N, d_in, cutoff_.get(), 0, res_.get(), 0, coef_.get(), state_.get(),
+                                         d_out, stream), "mxg_filter_render");
+    }
+    // audio-rate modulated cutoff ([N][V] on device), device coefficients, stated tolerance
+    void renderModulated(int kind, size_t N, const double *d_in, const double *d_cutoff, double *d_out, void *stream = nullptr) {
+        maxigpu::check(mxg_filter_render(kind, V, N, d_in, d_cutoff, 1, res_.get(), 0, nullptr, state_.get(), d_out, stream),
+                       "mxg_filter_render");
+    }
+    std::vector<double> state() const { return state_.download(); }
+
+private:
+    size_t V;
+    int kind_ = MXG_FLT_LORES;
+    maxigpu::DeviceArray<double> state_, cutoff_, res_, coef_;
+};
+
+// ---- maxiEnv (H:888-932) ------------------------------------------------------------------------------
+class maxiEnvBank {
+public:
+    explicit maxiEnvBank(size_t voices)
+        : V(voices), par_h_(4 * voices, 0.0), hold_h_(voices, 1), par_(4 * voices), hold_(voices), dst_(2 * voices), ist_(6 * voices) {}
+    void setAttack(double ms) { fill(0, mxg_env_coeff_host(0, ms)); }      // C:1480-1482
+    void setAttackMS(double ms) { fill(0, mxg_env_coeff_host(3, ms)); }    // C:1486-1488
+    void setDecay(double ms) { fill(1, mxg_env_coeff_host(1, ms)); }       // C:1475-1477
+    void setSustain(double level) { fill(2, level); }                     // C:1492-1494
+    void setRelease(double ms) { fill(3, mxg_env_coeff_host(2, ms)); }     // C:1470-1472
+    void setHoldtime(long holdtime) { for (auto &h : hold_h_) h = holdtime; dirty_ = true; }
+    // trigger: int32 [N] on device (shared gate) or [N][V] (per voice)
+    void adsr(size_t N, const double *d_in, const int32_t *d_trig, bool per_voice, double *d_out, void *stream = nullptr) {
+        sync();
+        maxigpu::check(mxg_env_render(0, V, N, d_in, d_trig, per_voice ? 1 : 0, par_.get(), hold_.get(), dst_.get(), ist_.get(),
+                                      d_out, stream), "mxg_env_render");
+    }
+    void ar(size_t N, const double *d_in, const int32_t *d_trig, bool per_voice, double *d_out, void *stream = nullptr) {
+        sync();
+        maxigpu::check(mxg_env_render(1, V, N, d_in, d_trig, per_voice ? 1 : 0, par_.get(), hold_.get(), dst_.get(), ist_.get(),
+                                      d_out, stream), "mxg_env_render");
+    }
+    const double *params() { sync(); return par_.get(); }
+    const int64_t *holdtimes() { sync(); return hold_.get(); }
+    double *dstate() { return dst_.get(); }
+    int64_t *istate() { return ist_.get(); }
+
+private:
+    void fill(int row, double v) { for (size_t i = 0; i < V; i++) par_h_[row * V + i] = v; dirty_ = true; }
+    void sync() { if (dirty_) { par_.upload(par_h_); hold_.upload(hold_h_); dirty_ = false; } }
+    size_t V;
+    std::vector<double> par_h_;
+    std::vector<int64_t> hold_h_;
+    maxigpu::DeviceArray<double> par_;
+    maxigpu::DeviceArray<int64_t> hold_;
+    maxigpu::DeviceArray<double> dst_;
+    maxigpu::DeviceArray<int64_t> ist_;
+    bool dirty_ = true;
+};
+
+// ---- fused subtractive voice: maxiOsc::saw -> maxiFilter::lores -> maxiEnv::adsr -----------------------
+class maxiVoiceBank : public maxigpu::BlockServer {
+public:
+    explicit maxiVoiceBank(size_t voices, size_t blockSize = 512)
+        : BlockServer(voices, blockSize), env(voices), freq_(voices), cutoff_(voices), res_(voices), coef_(3 * voices),
+          ost_(2 * voices), fst_(5 * voices), trig_(blockSize) {}
+    maxiEnvBank env;
+    void setVoices(const std::vector<double> &freq, const std::vector<double> &cutoff, const std::vector<double> &resonance) {
+        freq_.upload(freq);
+        cutoff_.upload(cutoff);
+        res_.upload(resonance);
+        std::vector<double> coef(3 * V);
+        maxigpu::check(mxg_filter_coeffs_host(MXG_FLT_LORES, V, cutoff.data(), resonance.data(), coef.data()), "mxg_filter_coeffs_host");
+        coef_.upload(coef);
+    }
+    // mode 0: coefficients hoisted (bit-exact); mode 1: cutoff = envelope*cutoff per sample (14.monosynth)
+    void render(int mode, size_t N, const int32_t *d_trig, double *d_out, void *stream = nullptr) {
+        maxigpu::check(mxg_voice_render(mode, V, N, freq_.get(), cutoff_.get(), res_.get(), coef_.get(), d_trig, 0, env.params(),
+                                        env.holdtimes(), ost_.get(), fst_.get(), env.dstate(), env.istate(), d_out, stream),
+                       "mxg_voice_render");
+    }
+    // per-sample API: the gate for the NEXT block is whatever setGate() holds when the block is rendered
+    void setGate(const std::vector<int32_t> &gateForBlock) { trig_.upload(gateForBlock); }
+    double frame(size_t v) {
+        return BlockServer::frame(v, [this](size_t N, double *d) { render(0, N, trig_.get(), d); });
+    }
+    void tick() { advance(); }
+
+private:
+    maxigpu::DeviceArray<double> freq_, cutoff_, res_, coef_, ost_, fst_;
+    maxigpu::DeviceArray<int32_t> trig_;
+};
+
+// ---- maxiMix::stereo over a bank + mixdown over voices (C:503-509) ---------------------------------------
+class maxiMixBank {
+public:
+    explicit maxiMixBank(size_t voices) : V(voices), pan_(voices) {}
+    void setPan(const std::vector<double> &x) { pan_.upload(x); }
+    // d_mix: [N][2] on device
+    void stereo(size_t N, const double *d_in, double *d_mix, void *stream = nullptr) {
+        maxigpu::check(mxg_mix_stereo(V, N, d_in, pan_.get(), d_mix, stream), "mxg_mix_stereo");
+    }
+
+private:
+    size_t V;
+    maxigpu::DeviceArray<double> pan_;
+};
+
+// ---- maxiDelayline (H:266-284) ---------------------------------------------------------------------------
+class maxiDelaylineBank {
+public:
+    maxiDelaylineBank(size_t voices, size_t capacity)
+        : V(voices), cap(capacity), mem_(voices * capacity), phase_(voices), size_(voices), fb_(voices), pos_(voices) {}
+    void setParams(const std::vector<int32_t> &size, const std::vector<double> &feedback) { size_.upload(size); fb_.upload(feedback); }
+    void setPositions(const std::vector<int32_t> &position) { pos_.upload(position); }
+    void dl(size_t N, const double *d_in, double *d_out, void *stream = nullptr) {
+        maxigpu::check(mxg_delay_render(0, V, N, d_in, size_.get(), fb_.get(), nullptr, mem_.get(), cap, phase_.get(), d_out, stream),
+                       "mxg_delay_render");
+    }
+    void dlFromPosition(size_t N, const double *d_in, double *d_out, void *stream = nullptr) {
+        maxigpu::check(mxg_delay_render(1, V, N, d_in, size_.get(), fb_.get(), pos_.get(), mem_.get(), cap, phase_.get(), d_out, stream),
+                       "mxg_delay_render");
+    }
+
+private:
+    size_t V, cap;
+    maxigpu::DeviceArray<double> mem_;
+    maxigpu::DeviceArray<int32_t> phase_, size_;
+    maxigpu::DeviceArray<double> fb_;
+    maxigpu::DeviceArray<int32_t> pos_;
+};
+
+// ---- maxiSample play family (H:602-783): V play heads over one sample ---------------------------------------
+class maxiSampleBank {
+public:
+    explicit maxiSampleBank(size_t voices) : V(voices), position_(voices), a_(voices), start_(voices), end_(voices) {}
+    ~maxiSampleBank() { clear(); }
+    maxiSampleBank(const maxiSampleBank &) = delete;
+    maxiSampleBank &operator=(const maxiSampleBank &) = delete;
+    void setSample(const std::vector<double> &sampleData) {  // H:670-678
+        clear();
+        d_samples_ = mxg_sample_upload(sampleData.data(), sampleData.size());
+        if (!d_samples_) throw std::runtime_error(std::string("mxg_sample_upload: ") + mxg_last_error());
+        length_ = sampleData.size();
+        mySampleRate = 44100;
+        position_.upload(std::vector<double>(V, (double)length_ - 1));
+    }
+    void setSampleAndRate(const std::vector<double> &sampleData, int sampleRate) { setSample(sampleData); mySampleRate = sampleRate; }
+    void trigger() { position_.upload(std::vector<double>(V, 0.0)); }  // C:597-600
+    void setPositions(const std::vector<double> &p) { position_.upload(p); }
+    void setSpeeds(const std::vector<double> &a) { a_.upload(a); }
+    void setStartEnd(const std::vector<double> &s, const std::vector<double> &e) { start_.upload(s); end_.upload(e); }
+    size_t getLength() const { return length_; }
+    bool isReady() const { return length_ > 1; }
+    const double *deviceSamples() const { return d_samples_; }
+    void clear() { if (d_samples_) mxg_sample_free(d_samples_); d_samples_ = nullptr; length_ = 0; }
+    void render(int mode, size_t N, double *d_out, void *stream = nullptr) {
+        maxigpu::check(mxg_sample_render(mode, V, N, d_samples_, length_, mySampleRate, a_.get(), 0, start_.get(), end_.get(),
+                                         position_.get(), d_out, stream), "mxg_sample_render");
+    }
+    void play(size_t N, double *d_out) { render(MXG_SMP_PLAY, N, d_out); }
+    void playOnce(size_t N, double *d_out) { render(MXG_SMP_PLAYONCE, N, d_out); }
+    void playAtSpeed(size_t N, double *d_out) { render(MXG_SMP_PLAYATSPEED, N, d_out); }
+    int mySampleRate = 44100;
+
+private:
+    size_t V;
+    double *d_samples_ = nullptr;
+    size_t length_ = 0;
+    maxigpu::DeviceArray<double> position_, a_, start_, end_;
+};
+
+// ---- maxiFFT / maxiMFCC batches (L/maxiFFT.h, L/maxiMFCC.h) ----------------------------------------------------
+class maxiFFTBatch {
+public:
+    enum fftModes { NO_POLAR_CONVERSION = 0, WITH_POLAR_CONVERSION = 1 };
+    ~maxiFFTBatch() { if (plan_) mxg_fft_plan_destroy(plan_); }
+    void setup(int fftSize = 1024, int hopSize = 512, int windowSize = 0) {  // L/maxiFFT.cpp:45-60
+        if (plan_) mxg_fft_plan_destroy(plan_);
+        maxigpu::check(mxg_init(-1), "mxg_init");
+        plan_ = mxg_fft_plan_create(fftSize, hopSize, windowSize);
+        if (!plan_) throw std::runtime_error(std::string("mxg_fft_plan_create: ") + mxg_last_error());
+        fftSize_ = fftSize; hopSize_ = hopSize; bins_ = fftSize / 2;
+    }
+    int getNumBins() const { return bins_; }
+    int getFFTSize() const { return fftSize_; }
+    int getHopSize() const { return hopSize_; }
+    // frames every `frame_stride` samples of a device signal -> [nframes][bins] outputs (any may be null)
+    void process(const float *d_signal, size_t frame_stride, size_t nframes, float *d_mags, float *d_phases,
+                 float *d_real = nullptr, float *d_imag = nullptr, void *stream = nullptr) {
+        maxigpu::check(mxg_fft_batch(plan_, d_signal, frame_stride, nframes, d_real, d_imag, d_mags, d_phases, stream), "mxg_fft_batch");
+    }
+
+private:
+    mxg_fft_plan *plan_ = nullptr;
+    int fftSize_ = 0, hopSize_ = 0, bins_ = 0;
+};
+
+class maxiMFCCBatch {
+public:
+    ~maxiMFCCBatch() { if (plan_) mxg_mfcc_plan_destroy(plan_); }
+    void setup(unsigned numBins, unsigned numFilters, unsigned numCoeffs, double minFreq, double maxFreq) {  // L/maxiMFCC.h:56-75
+        if (plan_) mxg_mfcc_plan_destroy(plan_);
+        plan_ = mxg_mfcc_plan_create(numBins, numFilters, numCoeffs, minFreq, maxFreq);
+        if (!plan_) throw std::runtime_error(std::string("mxg_mfcc_plan_create: ") + mxg_last_error());
+        numBins_ = numBins;
+    }
+    void mfcc(const float *d_mags, size_t nframes, double *d_mfcc, int method = 0, void *stream = nullptr) {  // L/maxiMFCC.h:77-81
+        maxigpu::check(mxg_mfcc_batch(plan_, d_mags, numBins_, nframes, nullptr, nullptr, d_mfcc, method, stream), "mxg_mfcc_batch");
+    }
+
+private:
+    mxg_mfcc_plan *plan_ = nullptr;
+    unsigned numBins_ = 0;
+};
+
+// ---- maxiTimeStretch / maxiStretch banks (L/maxiGrains.h) ---------------------------------------------------------
+class maxiTimeStretchBank {
+public:
+    maxiTimeStretchBank(size_t streams, maxiSampleBank *sample, int window_kind = 0)
+        : S(streams), sample_(sample), window_(window_kind), st_(4 * streams), gst_(32 * streams), speed_(streams) {}
+    ~maxiTimeStretchBank() { if (plan_) mxg_grain_plan_destroy(plan_); }
+    void setPosition(const std::vector<double> &pos01) {  // L/maxiGrains.h:335-338
+        std::vector<double> st = st_.download();
+        const double len = (double)sample_->getLength();
+        for (size_t s = 0; s < S; s++) {
+            double p = pos01[s] * len;
+            st[s] = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
+        }
+        st_.upload(st);
+    }
+    void setSpeeds(const std::vector<double> &speed) { speed_.upload(speed); }
+    // play(speed, grainLength, overlaps) for N samples of every stream -> d_out [N][S]
+    void play(double grainLength, int overlaps, size_t N, double *d_out, void *stream = nullptr) {
+        if (!plan_ || grainLength != grainLength_) {
+            if (plan_) mxg_grain_plan_destroy(plan_);
+            plan_ = mxg_grain_plan_create(window_, grainLength, sample_->mySampleRate);
+            if (!plan_) throw std::runtime_error(std::string("mxg_grain_plan_create: ") + mxg_last_error());
+            grainLength_ = grainLength;
+        }
+        maxigpu::check(mxg_granular_render(plan_, 0, S, N, sample_->deviceSamples(), sample_->getLength(), overlaps, speed_.get(),
+                                           nullptr, nullptr, nullptr, 0, st_.get(), gst_.get(), d_out, stream), "mxg_granular_render");
+    }
+
+private:
+    size_t S;
+    maxiSampleBank *sample_;
+    int window_;
+    mxg_grain_plan *plan_ = nullptr;
+    double grainLength_ = 0;
+    maxigpu::DeviceArray<double> st_, gst_, speed_;
+};
