@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--waveform", default="sinebuf")
+    ap.add_argument("--mixdown", action="store_true",
+                    help="also run the stereo mixdown (K3) each step and reduce it to rank 0 over RCCL")
     args = ap.parse_args()
 
     import torch
@@ -101,18 +103,20 @@ def main():
     stream = tstream.cuda_stream
     assert stream != 0
 
+    from maximilian_amd.dist import MixReducer, bank_parameters, shard_range
+
     V, B = VOICES_PER_GPU, BLOCK
     wf = mx.OSC_WAVEFORMS[args.waveform]
     # this rank's voice shard of the global bank: voices [rank*V, (rank+1)*V)
-    vglob = np.arange(rank * V, (rank + 1) * V, dtype=np.float64)
-    freq_h = 20.0 + (vglob % 65536) * 0.30517578125
+    lo, hi = shard_range(rank, world, V)
+    freq_h, pan_h = bank_parameters(lo, hi, V * world)
     freq = torch.from_numpy(freq_h).to(dev)
     phase = torch.zeros(V, dtype=torch.float64, device=dev)
     hold = torch.zeros(V, dtype=torch.float64, device=dev)
     out = torch.empty((B, V), dtype=torch.float64, device=dev)
-    pan = torch.from_numpy((vglob % 65536) / 65535.0).to(dev)
-    mix = torch.zeros((B, 2), dtype=torch.float64, device=dev)
-    mix_root = torch.zeros((B, 2), dtype=torch.float64, device=dev)
+    pan = torch.from_numpy(pan_h).to(dev)
+    reducer = MixReducer(dist if world > 1 else None,
+                         lambda: torch.zeros((B, 2), dtype=torch.float64, device=dev))
 
     def render():
         mx._lib.check(L.mxg_osc_render(wf, V, B, freq.data_ptr(), 0, None, None, phase.data_ptr(),
@@ -120,6 +124,13 @@ def main():
 
     def step():
         render()
+        if args.mixdown:
+            # maxiMix::stereo + sum over this rank's voices on the GPU, then the single exchange of
+            # the path: an asynchronous RCCL reduce of the [512 x 2] block to rank 0
+            mixbuf = reducer.next_buffer()
+            mx._lib.check(L.mxg_mix_stereo(V, B, out.data_ptr(), pan.data_ptr(), mixbuf.data_ptr(), stream),
+                          "mxg_mix_stereo")
+            reducer.submit()
 
     def fence():
         torch.cuda.synchronize()
@@ -147,6 +158,7 @@ def main():
     for i in range(args.steps):
         step()
     ev1.record()
+    reducer.drain()
     fence()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -176,7 +188,8 @@ def main():
             "config": {"workload": "configs[1]: 65536-voice maxiOsc::%s wavetable bank per GPU, "
                                    "block=512, fp64 out[n][v] stored" % args.waveform,
                        "voices_per_gpu": V, "block": B, "sample_rate": 44100,
-                       "parallelism": "voices sharded x%d" % world},
+                       "parallelism": "voices sharded x%d" % world,
+                       "mixdown": "maxiMix::stereo + RCCL reduce of [512x2] per step" if args.mixdown else "off"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "osc_kernel<%s>" % args.waveform, "kernel_ms": round(k1_ms, 5),
