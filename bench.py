@@ -72,8 +72,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--waveform", default="sinebuf")
-    ap.add_argument("--mixdown", action="store_true",
-                    help="also run the stereo mixdown (K3) each step and reduce it to rank 0 over RCCL")
+    ap.add_argument("--mixdown", nargs="?", const="fused", default=None, choices=["fused", "separate"],
+                    help="also produce the stereo mixdown each step and reduce it to rank 0 over RCCL")
     args = ap.parse_args()
 
     import torch
@@ -123,14 +123,21 @@ def main():
                                        hold.data_ptr(), out.data_ptr(), stream), "mxg_osc_render")
 
     def step():
-        render()
-        if args.mixdown:
-            # maxiMix::stereo + sum over this rank's voices on the GPU, then the single exchange of
-            # the path: an asynchronous RCCL reduce of the [512 x 2] block to rank 0
-            mixbuf = reducer.next_buffer()
+        if not args.mixdown:
+            render()
+            return
+        # render + maxiMix::stereo mixdown of this rank's voices fused in one pass (K1m), then the
+        # single exchange of the path: an asynchronous RCCL reduce of the [512 x 2] block to rank 0
+        mixbuf = reducer.next_buffer()
+        if args.mixdown == "fused":
+            mx._lib.check(L.mxg_osc_render_mix(wf, V, B, freq.data_ptr(), None, None, phase.data_ptr(),
+                                               hold.data_ptr(), out.data_ptr(), pan.data_ptr(),
+                                               mixbuf.data_ptr(), stream), "mxg_osc_render_mix")
+        else:  # "separate": K1 then K3 re-reading the block
+            render()
             mx._lib.check(L.mxg_mix_stereo(V, B, out.data_ptr(), pan.data_ptr(), mixbuf.data_ptr(), stream),
                           "mxg_mix_stereo")
-            reducer.submit()
+        reducer.submit()
 
     def fence():
         torch.cuda.synchronize()

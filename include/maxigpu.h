@@ -107,6 +107,17 @@ int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_freq, int f
                    const double *d_p1, const double *d_p2, double *d_phase, double *d_outhold,
                    double *d_out, void *stream);
 
+/* Render + fused stereo mixdown: as mxg_osc_render (block-constant frequencies) and, in the same
+ * pass, d_mix[n][0..1] = sum_v (out[n][v]*sqrt(1-pan_v), out[n][v]*sqrt(pan_v)) (maxiMix::stereo,
+ * C:503-509, plus the user-side sum over voices).  The per-voice block is never re-read: each
+ * wavefront reduces its 64 voices in LDS and a small second kernel sums the per-wave partials
+ * (fixed order: deterministic; tolerance on the mix as for mxg_mix_stereo).  d_out may be NULL:
+ * then only the mix is produced (what a play() callback needs) and nothing but [N][2] leaves
+ * the chip. */
+int mxg_osc_render_mix(int waveform, size_t V, size_t N, const double *d_freq, const double *d_p1,
+                       const double *d_p2, double *d_phase, double *d_outhold, double *d_out,
+                       const double *d_pan, double *d_mix, void *stream);
+
 /* ---- maxiFilter bank ------------------------------------------------------------------ */
 /* d_st = [5][V]: x, y, outputs[0], outputs[1], outputs[2] (H:289-302), in/out.
  * lores/hires/bandpass with block-constant cutoff/resonance (cps=rps=0): the coefficients that

@@ -36,6 +36,8 @@ SIGNATURES = {
     "mxg_tune": (c_int, [c_char_p, c_int]),
     "mxg_osc_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_osc_render_mix": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_filter_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_int, c_void_p,
                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_filter_coeffs_host": (c_int, [c_int, c_size_t, c_void_p, c_void_p, c_void_p]),

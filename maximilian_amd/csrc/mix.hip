@@ -36,7 +36,22 @@ __global__ __launch_bounds__(kMixThreads) void mix_stereo_kernel(
     const size_t n = blockIdx.x;
     const double *row = in + n * V;
     double l = 0.0, r = 0.0;
-    for (size_t v = threadIdx.x; v < V; v += kMixThreads) {
+    // 4 independent loads in flight per thread; the accumulation order per thread stays
+    // v = t, t+1024, t+2048, ... so the result does not depend on the unrolling.
+    size_t v = threadIdx.x;
+    for (; v + 3 * kMixThreads < V; v += 4 * kMixThreads) {
+        const double x0 = row[v], x1 = row[v + kMixThreads], x2 = row[v + 2 * kMixThreads],
+                     x3 = row[v + 3 * kMixThreads];
+        const double a0 = gains[v], a1 = gains[v + kMixThreads], a2 = gains[v + 2 * kMixThreads],
+                     a3 = gains[v + 3 * kMixThreads];
+        const double b0 = gains[V + v], b1 = gains[V + v + kMixThreads], b2 = gains[V + v + 2 * kMixThreads],
+                     b3 = gains[V + v + 3 * kMixThreads];
+        l += x0 * a0; r += x0 * b0;
+        l += x1 * a1; r += x1 * b1;
+        l += x2 * a2; r += x2 * b2;
+        l += x3 * a3; r += x3 * b3;
+    }
+    for (; v < V; v += kMixThreads) {
         double x = row[v];
         l += x * gains[v];
         r += x * gains[V + v];

@@ -140,3 +140,27 @@ def test_config2_full_size_properties(mx, port):
     # (4) phase invariant of sinebuf: always in [-1, 511)
     ph = bank.phase.numpy()
     assert ph.min() >= -1.0 and ph.max() < 511.0
+
+
+@pytest.mark.parametrize("wf,V,N", [(8, 300, 100), (3, 64, 16), (10, 1000, 37), (9, 4096 + 7, 512), (6, 256, 1)])
+def test_render_mix_fused(mx, port, wf, V, N):
+    """mxg_osc_render_mix: per-voice block bit-exact (same as the plain render), mix within the
+    stated tolerance of the reference's sequential sum, store=False gives the same mix bits."""
+    rng = np.random.default_rng(900 + wf)
+    freq = rng.uniform(20, 15000, V)
+    pan = rng.uniform(-0.1, 1.1, V)
+    p1 = rng.uniform(0.1, 0.9, V)
+    bank = mx.maxiOscBank(V)
+    out1, mix1 = bank.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V))
+    out2, mix2 = bank.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V))
+    o = np.concatenate([out1.numpy(), out2.numpy()])
+    m = np.concatenate([mix1.numpy(), mix2.numpy()])
+    eo, eph, _ = port.osc(wf, freq, 2 * N, p1=p1, p2=np.ones(V))
+    assert_bits_equal(o, eo, OSC[wf])
+    assert_bits_equal(bank.phase.numpy(), eph, "phase")
+    em = port.mix_stereo(eo, pan)
+    assert np.abs(m - em).max() <= 1e-12 * V
+    bank2 = mx.maxiOscBank(V)
+    none, mix3 = bank2.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V), store=False)
+    assert none is None
+    assert_bits_equal(mix3.numpy(), mix1.numpy(), "mix-only mode")
