@@ -220,7 +220,257 @@ __global__ __launch_bounds__(64) void granular_kernel(GrainArgs A) {
     }
 }
 
+// ---- K8a/K8b: time-sharded version ------------------------------------------------------------
+// The only truly serial part of a stream is its scheduler (position += rate with wraps, looper,
+// spawn decisions): ~10 flops per sample.  K8a runs just that, one lane per stream, and records
+// every spawn (sample index, grain start position) plus, per time chunk, how many spawns precede
+// it.  A grain's own recurrence (pos += inc, wrapped) restarts at its birth, so K8b can render any
+// chunk [n0, n1) of any stream independently: one lane per (stream, chunk) first re-creates the
+// grains alive at n0 -- carried-in grains and earlier spawns, in creation order -- by replaying
+// their position recurrence for the n0 - birth elapsed samples (<= one grain length; the same
+// additions in the same order, so bit-identical), then runs the chunk exactly like K8.
+// Parallelism S x chunks instead of S; redundant warm-up work < 10 % for chunks >= half a grain.
+struct SchedArgs {
+    size_t S, T, len, R, G, Tc, C;
+    const double *a, *b, *posMod;
+    const int32_t *rnd;
+    double *st;
+    int32_t *spawn_n;    // [G][S]
+    double *spawn_pos;   // [G][S]
+    int32_t *chunk_first;  // [C+1][S]: spawns before sample c*Tc
+    int *err;
+    double sr, cycleLength, grainLength;
+    int sampleDur;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.S) return;
+    const size_t S = A.S;
+    const double dlen = (double)A.len;
+    double position = A.st[s], looper = A.st[S + s], randomOffset = A.st[2 * S + s];
+    size_t cursor = (size_t)A.st[3 * S + s];
+    const double speed = A.a[s];
+    const double rate = MODE == 0 ? speed : A.b[s];
+    const double pm = A.posMod ? A.posMod[s] : 0.0;
+    const double grainSpeed = MODE == 0 ? (speed > 0 ? 1.0 : -1.0) : speed;
+    const double frequency = (1.0 / A.grainLength) * grainSpeed;
+    size_t count = 0;
+    int failed = 0;
+    size_t nextChunk = 0;
+    for (size_t n = 0; n < A.T; n++) {
+        if (n == nextChunk * A.Tc) {
+            A.chunk_first[nextChunk * S + s] = (int32_t)count;
+            nextChunk++;
+        }
+        position = position + rate;
+        looper += 1.0;
+        if (MODE == 0) {
+            if (position > dlen) position -= dlen;
+            if (position < 0) position += dlen;
+        } else {
+            if (position >= dlen) position -= dlen;
+            if (position < 0.0) position += dlen;
+        }
+        if (looper > A.cycleLength + randomOffset) {
+            looper -= (A.cycleLength + randomOffset);
+            double p01 = (position / dlen) + pm;
+            p01 = 1.0 < p01 ? 1.0 : p01;
+            p01 = p01 < 0.0 ? 0.0 : p01;
+            const double startPos = floor(dlen * p01);
+            double endPos = startPos + (double)A.sampleDur;
+            endPos = dlen < endPos ? dlen : endPos;
+            if (count < A.G) {
+                A.spawn_n[count * S + s] = (int32_t)n;
+                A.spawn_pos[count * S + s] = frequency > 0 ? startPos : endPos;
+            } else {
+                failed = 3;
+            }
+            count++;
+            if (A.rnd) {
+                if (cursor < A.R) randomOffset = (double)A.rnd[s * A.R + cursor]; else { failed = 2; randomOffset = 0; }
+                cursor++;
+            } else {
+                randomOffset = 0;
+            }
+        }
+    }
+    for (; nextChunk <= A.C; nextChunk++) A.chunk_first[nextChunk * S + s] = (int32_t)count;
+    if (failed) atomicMax(A.err, failed);
+    A.st[s] = position;
+    A.st[S + s] = looper;
+    A.st[2 * S + s] = randomOffset;
+    A.st[3 * S + s] = (double)cursor;
+}
+
+struct RenderArgs {
+    size_t S, T, len, G, Tc, C;
+    const double *amp, *window, *a;
+    const int32_t *spawn_n;
+    const double *spawn_pos;
+    const int32_t *chunk_first;
+    const double *gst_in;  // carried-in grains (state before the launch)
+    double *gst_out;       // grains alive after sample T-1 (written by the last chunk's lanes)
+    double *out;
+    int *err;
+    double sr, grainLength;
+    int sampleDur, winInLds, mode;
+};
+
+// one maxiGrain::play step (L/maxiGrains.h:216-245) on (pos, idx); returns the windowed sample
+__device__ __forceinline__ double grain_step(double &pos, int &idx, const double inc, const double dlen,
+                                             const size_t len, const double *amp, const double *win) {
+    const double envValue = win[idx];
+    double p = pos + inc;
+    if (p >= dlen)
+        p -= dlen;
+    else if (p < 0)
+        p += dlen;
+    pos = p;
+    const double fl = floor(p);
+    const double remainder = p - fl;
+    const long long ia = (long long)fl;
+    long long ib = ia + 1;
+    if ((size_t)ib >= len) ib = 0;
+    double o = ((1 - remainder) * amp[ia] + remainder * amp[ib]);
+    o *= envValue;
+    idx++;
+    return o;
+}
+
+// the position recurrence alone, `steps` times (warm-up to a chunk boundary)
+__device__ __forceinline__ double grain_advance(double pos, const double inc, const double dlen, int steps) {
+    for (int i = 0; i < steps; i++) {
+        double p = pos + inc;
+        if (p >= dlen)
+            p -= dlen;
+        else if (p < 0)
+            p += dlen;
+        pos = p;
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(64) void granular_render_kernel(RenderArgs A) {
+    extern __shared__ double s_win[];
+    const double *win = A.window;
+    if (A.winInLds) {
+        for (int i = threadIdx.x; i < A.sampleDur; i += blockDim.x) s_win[i] = A.window[i];
+        __syncthreads();
+        win = s_win;
+    }
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t S = A.S;
+    if (gid >= S * A.C) return;
+    const size_t s = gid % S, c = gid / S;  // consecutive lanes = consecutive streams of one chunk
+    const double dlen = (double)A.len;
+    const size_t n0 = c * A.Tc, n1 = (n0 + A.Tc < A.T) ? n0 + A.Tc : A.T;
+    // per-stream grain constants (maxiGrain ctor, L/maxiGrains.h:160-181)
+    const double speed = A.a[s];
+    const double grainSpeed = A.mode == 0 ? (speed > 0 ? 1.0 : -1.0) : speed;
+    const double frequency = (1.0 / A.grainLength) * grainSpeed;
+    const double newInc = (frequency != 0) ? (double)A.sampleDur / (A.sr / frequency) : 0.0;
+
+    double gpos[kSlots], ginc[kSlots];
+    int gidx[kSlots], gdur[kSlots];
+    int tail = 0, failed = 0;
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) { gpos[k] = 0; ginc[k] = 0; gidx[k] = 0; gdur[k] = 0; }
+    auto push = [&](double pos, double inc, int idx, int dur) {
+        if (tail == kSlots) { failed = 1; return; }
+#pragma unroll
+        for (int k = 0; k < kSlots; k++)
+            if (k == tail) { gpos[k] = pos; ginc[k] = inc; gidx[k] = idx; gdur[k] = dur; }
+        tail++;
+    };
+    // (1) carried-in grains still alive at n0, oldest first
+    for (int k = 0; k < kSlots; k++) {
+        const int dur = (int)A.gst_in[(3 * kSlots + k) * S + s];
+        if (!dur) continue;
+        const int idx = (int)A.gst_in[(2 * kSlots + k) * S + s];
+        if ((long long)idx + (long long)n0 >= dur) continue;  // finished before this chunk
+        const double inc = A.gst_in[(1 * kSlots + k) * S + s];
+        const double pos = grain_advance(A.gst_in[(0 * kSlots + k) * S + s], inc, dlen, (int)n0);
+        push(pos, inc, idx + (int)n0, dur);
+    }
+    // (2) grains spawned in earlier chunks of this launch and still alive at n0, in spawn order
+    const int first = A.chunk_first[c * S + s];
+    int j0 = first;
+    while (j0 > 0 && (long long)A.spawn_n[(size_t)(j0 - 1) * S + s] + A.sampleDur > (long long)n0) j0--;
+    for (int j = j0; j < first; j++) {
+        const int born = A.spawn_n[(size_t)j * S + s];
+        const int steps = (int)n0 - born;
+        push(grain_advance(A.spawn_pos[(size_t)j * S + s], newInc, dlen, steps), newInc, steps, A.sampleDur);
+    }
+    // (3) the chunk itself
+    int jn = first;
+    const int jend = A.chunk_first[(c + 1) * S + s];
+    int nextSpawn = jn < jend ? A.spawn_n[(size_t)jn * S + s] : -1;
+    double *op = A.out + n0 * S + s;
+    for (size_t n = n0; n < n1; n++) {
+        if ((int)n == nextSpawn) {
+            if (tail == kSlots) {  // compact holes (non-FIFO deaths only)
+#pragma unroll
+                for (int pass = 0; pass < kSlots - 1; pass++)
+#pragma unroll
+                    for (int k = 0; k < kSlots - 1; k++)
+                        if (gdur[k] == 0) {
+                            gpos[k] = gpos[k + 1]; ginc[k] = ginc[k + 1]; gidx[k] = gidx[k + 1];
+                            gdur[k] = gdur[k + 1]; gdur[k + 1] = 0;
+                        }
+                tail = 0;
+#pragma unroll
+                for (int k = 0; k < kSlots; k++)
+                    if (gdur[k]) tail = k + 1;
+            }
+            push(A.spawn_pos[(size_t)jn * S + s], newInc, 0, A.sampleDur);
+            jn++;
+            nextSpawn = jn < jend ? A.spawn_n[(size_t)jn * S + s] : -1;
+        }
+        double total = 0.0;
+#pragma unroll
+        for (int k = 0; k < kSlots; k++) {
+            if (gdur[k] > 0) {
+                total += grain_step(gpos[k], gidx[k], ginc[k], dlen, A.len, A.amp, win);
+                if (gidx[k] == gdur[k]) gdur[k] = 0;
+            }
+        }
+        if (tail > 0 && gdur[0] == 0) {
+#pragma unroll
+            for (int k = 0; k < kSlots - 1; k++) {
+                gpos[k] = gpos[k + 1]; ginc[k] = ginc[k + 1]; gidx[k] = gidx[k + 1]; gdur[k] = gdur[k + 1];
+            }
+            gdur[kSlots - 1] = 0;
+            tail--;
+        }
+        *op = total;
+        op += S;
+    }
+    if (failed) atomicMax(A.err, failed);
+    if (c == A.C - 1) {  // grains alive after the last sample: the state handed to the next launch
+#pragma unroll
+        for (int pass = 0; pass < kSlots - 1; pass++)
+#pragma unroll
+            for (int k = 0; k < kSlots - 1; k++)
+                if (gdur[k] == 0) {
+                    gpos[k] = gpos[k + 1]; ginc[k] = ginc[k + 1]; gidx[k] = gidx[k + 1];
+                    gdur[k] = gdur[k + 1]; gdur[k + 1] = 0;
+                }
+#pragma unroll
+        for (int k = 0; k < kSlots; k++) {
+            const bool live = gdur[k] > 0;
+            A.gst_out[(0 * kSlots + k) * S + s] = live ? gpos[k] : 0.0;
+            A.gst_out[(1 * kSlots + k) * S + s] = live ? ginc[k] : 0.0;
+            A.gst_out[(2 * kSlots + k) * S + s] = live ? (double)gidx[k] : 0.0;
+            A.gst_out[(3 * kSlots + k) * S + s] = live ? (double)gdur[k] : 0.0;
+        }
+    }
+}
+
 int *g_err = nullptr;
+void *g_sched_scratch = nullptr;  // spawn lists + chunk table + copy of the carried-in grains, grow-only
+size_t g_sched_scratch_cap = 0;
 
 }  // namespace
 }  // namespace mxg
@@ -302,16 +552,61 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
     A.winInLds = lds <= 60 * 1024;
     if (!A.winInLds) lds = 0;
     dim3 grid((unsigned)((S + 63) / 64));
-    if (mode == 0)
-        hipLaunchKernelGGL((granular_kernel<0>), grid, dim3(64), lds, st, A);
-    else
-        hipLaunchKernelGGL((granular_kernel<1>), grid, dim3(64), lds, st, A);
+    if (!tune_get("grain_chunked")) {  // K8: one lane per stream, serial in time
+        if (mode == 0)
+            hipLaunchKernelGGL((granular_kernel<0>), grid, dim3(64), lds, st, A);
+        else
+            hipLaunchKernelGGL((granular_kernel<1>), grid, dim3(64), lds, st, A);
+    } else {  // K8a scheduler pre-pass + K8b (stream, chunk) render
+        size_t C = (T + 255) / 256;
+        const size_t cmax = (131072 + S - 1) / S;
+        if (C > cmax) C = cmax;
+        if (C < 1) C = 1;
+        const size_t Tc = (T + C - 1) / C;
+        C = (T + Tc - 1) / Tc;
+        const double minCycle = A.cycleLength;  // randomOffset >= 0 only lengthens a cycle
+        const size_t G = (size_t)((double)T / (minCycle > 1.0 ? floor(minCycle) : 1.0)) + 2;
+        const size_t nd = G * S + 4 * kSlots * S;             // doubles: spawn_pos | gst copy
+        const size_t ni = G * S + (C + 1) * S;                // int32: spawn_n | chunk_first
+        const size_t bytes = nd * sizeof(double) + ni * sizeof(int32_t);
+        if (g_sched_scratch_cap < bytes) {
+            if (g_sched_scratch) MXG_HIP(hipFree(g_sched_scratch));
+            g_sched_scratch = nullptr;
+            g_sched_scratch_cap = 0;
+            MXG_HIP(hipMalloc(&g_sched_scratch, bytes));
+            g_sched_scratch_cap = bytes;
+        }
+        double *spawn_pos = (double *)g_sched_scratch;
+        double *gst_copy = spawn_pos + G * S;
+        int32_t *spawn_n = (int32_t *)(gst_copy + 4 * kSlots * S);
+        int32_t *chunk_first = spawn_n + G * S;
+        MXG_HIP(hipMemcpyAsync(gst_copy, d_gst, sizeof(double) * 4 * kSlots * S, hipMemcpyDeviceToDevice, st));
+        SchedArgs Q;
+        Q.S = S; Q.T = T; Q.len = len; Q.R = R; Q.G = G; Q.Tc = Tc; Q.C = C;
+        Q.a = d_a; Q.b = d_b; Q.posMod = d_posmod; Q.rnd = d_rnd; Q.st = d_st;
+        Q.spawn_n = spawn_n; Q.spawn_pos = spawn_pos; Q.chunk_first = chunk_first; Q.err = g_err;
+        Q.sr = A.sr; Q.cycleLength = A.cycleLength; Q.grainLength = A.grainLength; Q.sampleDur = A.sampleDur;
+        if (mode == 0)
+            hipLaunchKernelGGL((granular_sched_kernel<0>), grid, dim3(64), 0, st, Q);
+        else
+            hipLaunchKernelGGL((granular_sched_kernel<1>), grid, dim3(64), 0, st, Q);
+        RenderArgs Rr;
+        Rr.S = S; Rr.T = T; Rr.len = len; Rr.G = G; Rr.Tc = Tc; Rr.C = C;
+        Rr.amp = d_samples; Rr.window = p->d_window; Rr.a = d_a;
+        Rr.spawn_n = spawn_n; Rr.spawn_pos = spawn_pos; Rr.chunk_first = chunk_first;
+        Rr.gst_in = gst_copy; Rr.gst_out = d_gst; Rr.out = d_out; Rr.err = g_err;
+        Rr.sr = A.sr; Rr.grainLength = A.grainLength; Rr.sampleDur = A.sampleDur; Rr.winInLds = A.winInLds;
+        Rr.mode = mode;
+        const size_t lanes = S * C;
+        hipLaunchKernelGGL(granular_render_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), lds, st, Rr);
+    }
     MXG_HIP(hipGetLastError());
     int herr = 0;
     MXG_HIP(hipMemcpyAsync(&herr, g_err, sizeof(int), hipMemcpyDeviceToHost, st));
     MXG_HIP(hipStreamSynchronize(st));
     if (herr == 1) return fail(MXG_ERR_INVALID, "mxg_granular_render: more than 8 grains alive in a stream");
     if (herr == 2) return fail(MXG_ERR_INVALID, "mxg_granular_render: d_rnd exhausted (R too small)");
+    if (herr == 3) return fail(MXG_ERR_INVALID, "mxg_granular_render: internal spawn list overflow");
     return MXG_OK;
 }
 

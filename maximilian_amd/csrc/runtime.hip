@@ -28,6 +28,7 @@ Tune g_tune[] = {
     {"voice_vpl", 1, 1, 2},     {"voice_block", 256, 64, 1024}, {"voice_nt", 0, 0, 1},
     {"mix_block", 256, 64, 1024},
     {"fft_generic", 0, 0, 1},  // 1: force the generic per-stage FFT kernel also for fftSize 1024
+    {"grain_chunked", 1, 0, 1},  // 0: serial-in-time K8 instead of the time-sharded K8a+K8b
 };
 }  // namespace
 

@@ -17,8 +17,16 @@ def make_bank(mx, mode, window, samples, S):
     return bank
 
 
+@pytest.fixture(params=[1, 0], ids=["chunked", "serial"])
+def chunked(mx, request):
+    """Run with the time-sharded K8a+K8b (default) and with the serial K8."""
+    prev = mx.lib().mxg_tune(b"grain_chunked", request.param)
+    yield request.param
+    mx.lib().mxg_tune(b"grain_chunked", prev)
+
+
 @pytest.mark.parametrize("name", list(CASES))
-def test_granular_golden(mx, golden, name):
+def test_granular_golden(mx, golden, name, chunked):
     g = golden("grains.npz")
     mode, w, gl, ov, use_rnd = CASES[name]
     T = int(g["T"])
@@ -39,7 +47,7 @@ def test_granular_golden(mx, golden, name):
     assert_bits_equal(bank.grains.numpy(), g["gst_" + name], name + " grains")
 
 
-def test_granular_vs_oracle_many_streams(mx, port):
+def test_granular_vs_oracle_many_streams(mx, port, chunked):
     """Config-5-shaped bank at reduced size: 1000 streams, 0.05 s hann grains, 4 overlaps."""
     rng = np.random.default_rng(51)
     Ls = 441000
@@ -64,7 +72,7 @@ def test_granular_vs_oracle_many_streams(mx, port):
     assert np.abs(m - em).max() <= 1e-12 * S
 
 
-def test_granular_errors(mx):
+def test_granular_errors(mx, chunked):
     rng = np.random.default_rng(3)
     smp = rng.uniform(-1, 1, 5000)
     bank = make_bank(mx, 0, "hann", smp, 4)
