@@ -256,14 +256,13 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
     const double pm = A.posMod ? A.posMod[s] : 0.0;
     const double grainSpeed = MODE == 0 ? (speed > 0 ? 1.0 : -1.0) : speed;
     const double frequency = (1.0 / A.grainLength) * grainSpeed;
-    size_t count = 0;
+    int count = 0;
     int failed = 0;
-    size_t nextChunk = 0;
-    for (size_t n = 0; n < A.T; n++) {
-        if (n == nextChunk * A.Tc) {
-            A.chunk_first[nextChunk * S + s] = (int32_t)count;
-            nextChunk++;
-        }
+    // The serial part of a stream: keep this loop to the recurrences themselves (the chunk table is
+    // derived from the spawn list afterwards).  thr = cycleLength + randomOffset changes only at a spawn.
+    double thr = A.cycleLength + randomOffset;
+    const int Tn = (int)A.T;
+    for (int n = 0; n < Tn; n++) {
         position = position + rate;
         looper += 1.0;
         if (MODE == 0) {
@@ -273,17 +272,17 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
             if (position >= dlen) position -= dlen;
             if (position < 0.0) position += dlen;
         }
-        if (looper > A.cycleLength + randomOffset) {
-            looper -= (A.cycleLength + randomOffset);
+        if (looper > thr) {
+            looper -= thr;
             double p01 = (position / dlen) + pm;
             p01 = 1.0 < p01 ? 1.0 : p01;
             p01 = p01 < 0.0 ? 0.0 : p01;
             const double startPos = floor(dlen * p01);
             double endPos = startPos + (double)A.sampleDur;
             endPos = dlen < endPos ? dlen : endPos;
-            if (count < A.G) {
-                A.spawn_n[count * S + s] = (int32_t)n;
-                A.spawn_pos[count * S + s] = frequency > 0 ? startPos : endPos;
+            if ((size_t)count < A.G) {
+                A.spawn_n[(size_t)count * S + s] = n;
+                A.spawn_pos[(size_t)count * S + s] = frequency > 0 ? startPos : endPos;
             } else {
                 failed = 3;
             }
@@ -294,9 +293,18 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
             } else {
                 randomOffset = 0;
             }
+            thr = A.cycleLength + randomOffset;
         }
     }
-    for (; nextChunk <= A.C; nextChunk++) A.chunk_first[nextChunk * S + s] = (int32_t)count;
+    {   // chunk_first[c] = number of spawns before sample c*Tc (spawn_n is increasing)
+        const int stored = (size_t)count < A.G ? count : (int)A.G;
+        int j = 0;
+        for (size_t c = 0; c <= A.C; c++) {
+            const long long lim = (long long)(c * A.Tc);
+            while (j < stored && (long long)A.spawn_n[(size_t)j * S + s] < lim) j++;
+            A.chunk_first[c * S + s] = j;
+        }
+    }
     if (failed) atomicMax(A.err, failed);
     A.st[s] = position;
     A.st[S + s] = looper;
@@ -428,12 +436,42 @@ __global__ __launch_bounds__(64) void granular_render_kernel(RenderArgs A) {
             jn++;
             nextSpawn = jn < jend ? A.spawn_n[(size_t)jn * S + s] : -1;
         }
+        // Branch-free over the slots so that the gathers of all live grains are in flight together
+        // (one L2 round trip per sample instead of one per grain); dead slots read element 0 and are
+        // not added.  Slots >= 5 are only walked when some lane of the wave has that many grains.
         double total = 0.0;
+        double va[kSlots], vb[kSlots], ve[kSlots], vr[kSlots];
+        const bool deep = __any(tail > 5);
 #pragma unroll
         for (int k = 0; k < kSlots; k++) {
-            if (gdur[k] > 0) {
-                total += grain_step(gpos[k], gidx[k], ginc[k], dlen, A.len, A.amp, win);
-                if (gidx[k] == gdur[k]) gdur[k] = 0;
+            if (k < 5 || deep) {
+                const bool alive = gdur[k] > 0;
+                double p = gpos[k] + ginc[k];  // maxiGrain::play :222-226
+                if (p >= dlen)
+                    p -= dlen;
+                else if (p < 0)
+                    p += dlen;
+                gpos[k] = alive ? p : gpos[k];
+                const double fl = floor(p);
+                vr[k] = p - fl;
+                long long ia = alive ? (long long)fl : 0;
+                long long ib = ia + 1;
+                if ((size_t)ib >= A.len) ib = 0;
+                va[k] = A.amp[ia];
+                vb[k] = A.amp[ib];
+                ve[k] = win[alive ? gidx[k] : 0];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kSlots; k++) {
+            if (k < 5 || deep) {
+                if (gdur[k] > 0) {
+                    double o = ((1 - vr[k]) * va[k] + vr[k] * vb[k]);  // :236-238
+                    o *= ve[k];
+                    total += o;
+                    gidx[k]++;
+                    if (gidx[k] == gdur[k]) gdur[k] = 0;
+                }
             }
         }
         if (tail > 0 && gdur[0] == 0) {
@@ -559,7 +597,7 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
             hipLaunchKernelGGL((granular_kernel<1>), grid, dim3(64), lds, st, A);
     } else {  // K8a scheduler pre-pass + K8b (stream, chunk) render
         size_t C = (T + 255) / 256;
-        const size_t cmax = (131072 + S - 1) / S;
+        const size_t cmax = ((size_t)tune_get("grain_lanes_k") * 1024 + S - 1) / S;
         if (C > cmax) C = cmax;
         if (C < 1) C = 1;
         const size_t Tc = (T + C - 1) / C;

@@ -29,6 +29,7 @@ Tune g_tune[] = {
     {"mix_block", 256, 64, 1024},
     {"fft_generic", 0, 0, 1},  // 1: force the generic per-stage FFT kernel also for fftSize 1024
     {"grain_chunked", 1, 0, 1},  // 0: serial-in-time K8 instead of the time-sharded K8a+K8b
+    {"grain_lanes_k", 128, 16, 4096},  // K8b: target number of (stream, chunk) lanes, in units of 1024
 };
 }  // namespace
 

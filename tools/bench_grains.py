@@ -5,8 +5,9 @@ import ctypes, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import maximilian_amd as mx
+LK = int(os.environ.get("LANES_K", 128))
 S = int(os.environ.get("STREAMS", 2048)); T = int(os.environ.get("T", 70560)); REPS = int(os.environ.get("REPS", 3))
-L = mx.lib(); mx._lib.check(L.mxg_init(0), "init"); mx.maxiSettings.setup(44100, 2, 1024)
+L = mx.lib(); mx._lib.check(L.mxg_init(0), "init"); mx.maxiSettings.setup(44100, 2, 1024); L.mxg_tune(b"grain_lanes_k", LK)
 rng = np.random.default_rng(0x4D415849)
 Ls = 4410000; n = np.arange(Ls)
 smp = 0.5 * np.sin(2 * np.pi * 110 * n / 44100) + 0.25 * np.sin(2 * np.pi * 331 * n / 44100) + 0.05 * rng.uniform(-1, 1, Ls)
