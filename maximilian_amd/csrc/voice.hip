@@ -165,48 +165,56 @@ __device__ __forceinline__ void env_store(const Env &e, size_t V, size_t v, doub
 
 // C:1415-1466.  Statement order is the reference's: a sample can pass through several of
 // the `if`s (e.g. attack -> decay in the same call).
+// Written as straight-line selects (same statement order, same arithmetic): the lanes of a wave sit
+// in different envelope phases, and as nested `if`s this compiled to ~13 exec-mask regions per
+// sample (26 s_cbranch_execz per 4 samples), 4x slower than the predicated form.
 __device__ __forceinline__ double env_adsr(Env &e, double input, int trigger) {
-    if (trigger == 1 && e.attackphase != 1 && e.holdphase != 1 && e.decayphase != 1) {
-        e.holdcount = 0;
-        e.decayphase = 0;
-        e.sustainphase = 0;
-        e.releasephase = 0;
-        e.attackphase = 1;
-    }
-    if (e.attackphase == 1) {
-        e.releasephase = 0;
-        e.amplitude += (1 * e.attack);
-        e.output = input * e.amplitude;
-        if (e.amplitude >= 1) {
-            e.amplitude = 1;
-            e.attackphase = 0;
-            e.decayphase = 1;
-        }
-    }
-    if (e.decayphase == 1) {
-        e.amplitude *= e.decay;
-        e.output = input * e.amplitude;
-        if (e.amplitude <= e.sustain) {
-            e.decayphase = 0;
-            e.holdphase = 1;
-        }
-    }
-    if (e.holdcount < e.holdtime && e.holdphase == 1) {
-        e.output = input * e.amplitude;
-        e.holdcount++;
-    }
-    if (e.holdcount >= e.holdtime && trigger == 1) {
-        e.output = input * e.amplitude;
-    }
-    if (e.holdcount >= e.holdtime && trigger != 1) {
-        e.holdphase = 0;
-        e.releasephase = 1;
-    }
-    if (e.releasephase == 1 && e.amplitude > 0.) {
-        e.amplitude *= e.release;
-        e.output = input * e.amplitude;
-    }
-    return e.output;
+    const bool t1 = trigger == 1;
+    // C:1417-1423
+    const bool c1 = t1 && e.attackphase != 1 && e.holdphase != 1 && e.decayphase != 1;
+    e.holdcount = c1 ? 0 : e.holdcount;
+    e.decayphase = c1 ? 0 : e.decayphase;
+    e.sustainphase = c1 ? 0 : e.sustainphase;
+    e.releasephase = c1 ? 0 : e.releasephase;
+    e.attackphase = c1 ? 1 : e.attackphase;
+    double amp = e.amplitude, out = e.output;
+    // C:1425-1435  attack
+    const bool a = e.attackphase == 1;
+    e.releasephase = a ? 0 : e.releasephase;
+    const double ampA = amp + (1 * e.attack);
+    amp = a ? ampA : amp;
+    out = a ? input * amp : out;
+    const bool a2 = a && amp >= 1;
+    amp = a2 ? 1.0 : amp;
+    e.attackphase = a2 ? 0 : e.attackphase;
+    e.decayphase = a2 ? 1 : e.decayphase;
+    // C:1438-1444  decay
+    const bool d = e.decayphase == 1;
+    const double ampD = amp * e.decay;
+    amp = d ? ampD : amp;
+    out = d ? input * amp : out;
+    const bool d2 = d && amp <= e.sustain;
+    e.decayphase = d2 ? 0 : e.decayphase;
+    e.holdphase = d2 ? 1 : e.holdphase;
+    // C:1446-1449  hold
+    const bool h = e.holdcount < e.holdtime && e.holdphase == 1;
+    const double held = input * amp;
+    out = h ? held : out;
+    e.holdcount += h ? 1 : 0;
+    // C:1451-1458
+    const bool ge = e.holdcount >= e.holdtime;
+    out = (ge && t1) ? held : out;
+    const bool rel = ge && !t1;
+    e.holdphase = rel ? 0 : e.holdphase;
+    e.releasephase = rel ? 1 : e.releasephase;
+    // C:1460-1463  release
+    const bool r = e.releasephase == 1 && amp > 0.;
+    const double ampR = amp * e.release;
+    amp = r ? ampR : amp;
+    out = r ? input * amp : out;
+    e.amplitude = amp;
+    e.output = out;
+    return out;
 }
 
 // C:1319-1358
@@ -272,7 +280,11 @@ __global__ void env_kernel(size_t V, size_t N, const double *__restrict__ in,
 // ---- fused subtractive voice (K2) ----------------------------------------------------------
 // MODE 0: out = adsr(lores(saw(f), c, r), trig)             (coefficients hoisted, bit-exact)
 // MODE 1: e = adsr(1., trig); out = lores(saw(f), e*cutoff, res) * e   (device coefficients)
-template <int MODE, bool NT>
+// The trigger is read through a scalar load when it is shared by the bank (TPV = false): a
+// per-sample VECTOR load would make every sample wait on vmcnt(0), i.e. on all earlier output
+// stores as well (loads and stores retire in order on one counter) -- measured 3.7x slower.
+// Per-voice triggers (TPV = true) are prefetched one 8-sample chunk ahead for the same reason.
+template <int MODE, bool NT, bool TPV>
 __global__ void voice_kernel(size_t V, size_t N, const double *__restrict__ freq,
                              const double *__restrict__ cutoff, const double *__restrict__ res,
                              const double *__restrict__ coef, const int32_t *__restrict__ trig,
@@ -296,9 +308,30 @@ __global__ void voice_kernel(size_t V, size_t N, const double *__restrict__ freq
         rs = res[v];
     }
     double *op = out + v;
-#pragma unroll 4
-    for (size_t n = 0; n < N; n++) {
-        int t = tpv ? trig[n * V + v] : trig[n];
+    // consume the prologue loads here so no vmcnt(0) is needed inside the loop (see osc.hip K1m)
+    asm volatile("" : "+v"(phase), "+v"(hold), "+v"(c), "+v"(r), "+v"(cut), "+v"(rs));
+    asm volatile("" : "+v"(f.x), "+v"(f.y), "+v"(e.amplitude), "+v"(e.output), "+v"(e.attack), "+v"(e.decay));
+    asm volatile("" : "+v"(e.sustain), "+v"(e.release), "+v"(e.holdtime), "+v"(e.holdcount));
+    constexpr int U = 8;
+    int tn[U];
+    if constexpr (TPV) {
+#pragma unroll
+        for (int i = 0; i < U; i++) tn[i] = ((size_t)i < N) ? trig[(size_t)i * V + v] : 0;
+    }
+    for (size_t n0 = 0; n0 < N; n0 += U) {
+      int tc[U];
+      if constexpr (TPV) {
+#pragma unroll
+        for (int i = 0; i < U; i++) tc[i] = tn[i];
+#pragma unroll
+        for (int i = 0; i < U; i++) tn[i] = (n0 + U + i < N) ? trig[(n0 + U + i) * V + v] : 0;
+      }
+#pragma unroll
+      for (int i = 0; i < U; i++) {
+        const size_t n = n0 + i;
+        if (n >= N) break;
+        int t;
+        if constexpr (TPV) t = tc[i]; else t = trig[n];
         double o;
         if constexpr (MODE == 0) {
             double s = phase;  // saw C:333-340
@@ -319,6 +352,7 @@ __global__ void voice_kernel(size_t V, size_t N, const double *__restrict__ freq
         }
         store1<NT>(op, o);
         op += V;
+      }
     }
     ost[v] = phase;
     ost[V + v] = hold;
@@ -445,15 +479,18 @@ int mxg_voice_render(int mode, size_t V, size_t N, const double *d_freq, const d
     bool nt = tune_get("voice_nt") != 0;
     hipStream_t st = resolve_stream(stream);
     double sr = (double)settings().sampleRate;
-#define MXG_VOICE_LAUNCH(M, T)                                                                  \
-    hipLaunchKernelGGL((voice_kernel<M, T>), grid_for(V, block), dim3(block), 0, st, V, N, d_freq, \
+#define MXG_VOICE_LAUNCH(M, T, P)                                                               \
+    hipLaunchKernelGGL((voice_kernel<M, T, P>), grid_for(V, block), dim3(block), 0, st, V, N, d_freq, \
                        d_cutoff, d_res, d_coef, d_trig, tpv, d_par, d_holdtime, d_ost, d_fst,   \
                        d_dst, d_ist, d_out, sr)
+#define MXG_VOICE_LAUNCH2(M, T) \
+    if (tpv) MXG_VOICE_LAUNCH(M, T, true); else MXG_VOICE_LAUNCH(M, T, false)
     if (mode == 0) {
-        if (nt) MXG_VOICE_LAUNCH(0, true); else MXG_VOICE_LAUNCH(0, false);
+        if (nt) { MXG_VOICE_LAUNCH2(0, true); } else { MXG_VOICE_LAUNCH2(0, false); }
     } else {
-        if (nt) MXG_VOICE_LAUNCH(1, true); else MXG_VOICE_LAUNCH(1, false);
+        if (nt) { MXG_VOICE_LAUNCH2(1, true); } else { MXG_VOICE_LAUNCH2(1, false); }
     }
+#undef MXG_VOICE_LAUNCH2
 #undef MXG_VOICE_LAUNCH
     return check_hip(hipGetLastError(), "voice_kernel launch");
 }
