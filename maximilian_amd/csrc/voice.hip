@@ -87,14 +87,36 @@ __global__ void filter_kernel(size_t V, size_t N, const double *__restrict__ in,
     double *op = out + v;
     const double *cp = cutoff + v;
     const double *rp = res ? res + v : nullptr;
-#pragma unroll 4
-    for (size_t n = 0; n < N; n++) {
-        double x = *ip;
-        double cu = cut0, rs = res0;
+    // Software pipeline: the inputs of chunk k+1 are requested BEFORE chunk k's outputs are stored,
+    // so the wait for them is a counted vmcnt(U) and never drains the store stream (loads and
+    // stores retire in order on one counter; a load issued after a store would wait for it).
+    constexpr int U = 4;
+    double xn[U], cn[U], rn[U];
+#pragma unroll
+    for (int i = 0; i < U; i++) {
+        // clamped index instead of a guarded load: no branch, the surplus values are never used
+        const size_t m = (size_t)i < N ? (size_t)i : N - 1;
+        xn[i] = ip[m * V];
+        cn[i] = (MOD && cps) ? cp[m * V] : cut0;
+        rn[i] = (MOD && rps) ? rp[m * V] : res0;
+    }
+    for (size_t n0 = 0; n0 < N; n0 += U) {
+      double xc[U], cc[U], rc[U];
+#pragma unroll
+      for (int i = 0; i < U; i++) {
+        xc[i] = xn[i]; cc[i] = cn[i]; rc[i] = rn[i];
+        const size_t m = (n0 + U + i < N) ? n0 + U + i : N - 1;
+        xn[i] = ip[m * V];
         if constexpr (MOD) {
-            if (cps) cu = *cp;
-            if (rps) rs = *rp;
+            cn[i] = cps ? cp[m * V] : cut0;
+            rn[i] = rps ? rp[m * V] : res0;
         }
+      }
+#pragma unroll
+      for (int i = 0; i < U; i++) {
+        if (n0 + i >= N) break;
+        double x = xc[i];
+        double cu = cc[i], rs = rc[i];
         double o;
         if constexpr (KIND == MXG_FLT_LORES || KIND == MXG_FLT_HIRES) {
             if constexpr (MOD) lores_coeffs_dev(cu, rs, sr, c, r);
@@ -113,12 +135,8 @@ __global__ void filter_kernel(size_t V, size_t N, const double *__restrict__ in,
             f.o0 = o;
         }
         *op = o;
-        ip += V;
         op += V;
-        if constexpr (MOD) {
-            if (cps) cp += V;
-            if (rps) rp += V;
-        }
+      }
     }
     st[v] = f.x;
     st[V + v] = f.y;
@@ -253,7 +271,7 @@ __device__ __forceinline__ double env_ar(Env &e, double input, int trigger) {
     return e.output;
 }
 
-template <int MODE>
+template <int MODE, bool HASIN, bool TPV>
 __global__ void env_kernel(size_t V, size_t N, const double *__restrict__ in,
                            const int32_t *__restrict__ trig, int tpv,
                            const double *__restrict__ par, const int64_t *__restrict__ holdtime,
@@ -265,14 +283,35 @@ __global__ void env_kernel(size_t V, size_t N, const double *__restrict__ in,
     env_load(e, V, v, par, holdtime, dst, ist);
     const double *ip = in ? in + v : nullptr;
     double *op = out + v;
-#pragma unroll 4
-    for (size_t n = 0; n < N; n++) {
-        double x = ip ? *ip : 1.0;
-        int t = tpv ? trig[n * V + v] : trig[n];
-        double o = (MODE == 0) ? env_adsr(e, x, t) : env_ar(e, x, t);
-        *op = o;
-        op += V;
-        if (ip) ip += V;
+    // software pipeline (see filter_kernel): next chunk's inputs/triggers are requested before this
+    // chunk's outputs are stored
+    constexpr int U = 4;
+    double xn[U];
+    int tn[U];
+#pragma unroll
+    for (int i = 0; i < U; i++) {
+        const size_t m = (size_t)i < N ? (size_t)i : N - 1;
+        if constexpr (HASIN) xn[i] = ip[m * V]; else xn[i] = 1.0;
+        tn[i] = TPV ? trig[m * V + v] : trig[m];
+    }
+    for (size_t n0 = 0; n0 < N; n0 += U) {
+        double xc[U];
+        int tc[U];
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            xc[i] = xn[i];
+            tc[i] = tn[i];
+            const size_t m = (n0 + U + i < N) ? n0 + U + i : N - 1;
+            if constexpr (HASIN) xn[i] = ip[m * V];
+            tn[i] = TPV ? trig[m * V + v] : trig[m];
+        }
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            if (n0 + i >= N) break;
+            double o = (MODE == 0) ? env_adsr(e, xc[i], tc[i]) : env_ar(e, xc[i], tc[i]);
+            *op = o;
+            op += V;
+        }
     }
     env_store(e, V, v, dst, ist);
 }
@@ -316,7 +355,7 @@ __global__ void voice_kernel(size_t V, size_t N, const double *__restrict__ freq
     int tn[U];
     if constexpr (TPV) {
 #pragma unroll
-        for (int i = 0; i < U; i++) tn[i] = ((size_t)i < N) ? trig[(size_t)i * V + v] : 0;
+        for (int i = 0; i < U; i++) tn[i] = trig[((size_t)i < N ? (size_t)i : N - 1) * V + v];
     }
     for (size_t n0 = 0; n0 < N; n0 += U) {
       int tc[U];
@@ -324,7 +363,7 @@ __global__ void voice_kernel(size_t V, size_t N, const double *__restrict__ freq
 #pragma unroll
         for (int i = 0; i < U; i++) tc[i] = tn[i];
 #pragma unroll
-        for (int i = 0; i < U; i++) tn[i] = (n0 + U + i < N) ? trig[(n0 + U + i) * V + v] : 0;
+        for (int i = 0; i < U; i++) tn[i] = trig[((n0 + U + i < N) ? n0 + U + i : N - 1) * V + v];
       }
 #pragma unroll
       for (int i = 0; i < U; i++) {
@@ -443,12 +482,18 @@ int mxg_env_render(int mode, size_t V, size_t N, const double *d_in, const int32
     if (V == 0 || N == 0) return MXG_OK;
     int block = tune_get("voice_block");
     hipStream_t st = resolve_stream(stream);
-    if (mode == 0)
-        hipLaunchKernelGGL((env_kernel<0>), grid_for(V, block), dim3(block), 0, st, V, N, d_in,
-                           d_trig, tpv, d_par, d_holdtime, d_dst, d_ist, d_out);
-    else
-        hipLaunchKernelGGL((env_kernel<1>), grid_for(V, block), dim3(block), 0, st, V, N, d_in,
-                           d_trig, tpv, d_par, d_holdtime, d_dst, d_ist, d_out);
+#define MXG_ENV_LAUNCH(M, I, P)                                                                      \
+    hipLaunchKernelGGL((env_kernel<M, I, P>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_trig, \
+                       tpv, d_par, d_holdtime, d_dst, d_ist, d_out)
+#define MXG_ENV_LAUNCH2(M)                                                  \
+    if (d_in) {                                                             \
+        if (tpv) MXG_ENV_LAUNCH(M, true, true); else MXG_ENV_LAUNCH(M, true, false);   \
+    } else {                                                                \
+        if (tpv) MXG_ENV_LAUNCH(M, false, true); else MXG_ENV_LAUNCH(M, false, false); \
+    }
+    if (mode == 0) { MXG_ENV_LAUNCH2(0) } else { MXG_ENV_LAUNCH2(1) }
+#undef MXG_ENV_LAUNCH2
+#undef MXG_ENV_LAUNCH
     return check_hip(hipGetLastError(), "env_kernel launch");
 }
 
