@@ -76,6 +76,19 @@ struct FftOut {
     float *real, *imag, *mags, *phases;
 };
 
+// compile-time output selection (bit 0 real, 1 imag, 2 mags, 3 phases): a statically known number
+// of stores per frame lets the compiler use counted vmcnt waits for the prefetched next frame.
+template <int OMASK>
+__device__ __forceinline__ void emit_bin_t(const FftOut &o, size_t base, int bin, float2 v) {
+    if constexpr (OMASK & 1) o.real[base + bin] = v.x;
+    if constexpr (OMASK & 2) o.imag[base + bin] = v.y;
+    if constexpr (OMASK & 12) {
+        float power = v.x * v.x + v.y * v.y;  // L/fft.cpp:510
+        if constexpr (OMASK & 4) o.mags[base + bin] = sqrtf(power);
+        if constexpr (OMASK & 8) o.phases[base + bin] = atan2f(v.y, v.x);
+    }
+}
+
 __device__ __forceinline__ void emit_bin(const FftOut &o, size_t base, int bin, float2 v) {
     if (o.real) o.real[base + bin] = v.x;
     if (o.imag) o.imag[base + bin] = v.y;
@@ -162,10 +175,11 @@ __device__ __forceinline__ void round3(float2 (&x)[8], const float2 w0, const fl
     for (int e = 0; e < 4; e++) bfly(x[e], x[e + 4], w2[e]);
 }
 
+template <int OMASK, bool ALIGNED8>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MXG_FFT_MINWAVES) void fft1024_kernel(
     const float *__restrict__ signal, size_t frame_stride, size_t nframes,
     const float *__restrict__ window, const float2 *__restrict__ tw, const float2 *__restrict__ post,
-    FftOut out, int aligned8) {
+    FftOut out) {
     // one __shared__ object: [tw 512][post 256][X per wave]
     __shared__ float2 s_all[512 + 256 + kWavesPerBlock * kX1024];
     float2 *s_tw = s_all, *s_post = s_all + 512;
@@ -177,10 +191,44 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MXG_FFT_MINWAVES) void fft1024
 
     const int lo = lane & 7, hi = lane >> 3;
     const int rev6 = (int)(__brev((unsigned)lane) >> 26);
-    for (size_t f = (size_t)blockIdx.x * kWavesPerBlock + wave; f < nframes;
-         f += (size_t)gridDim.x * kWavesPerBlock) {
-        const float *x = signal + f * frame_stride;
+    // window coefficients of the 8 packed elements this lane loads (same for every frame)
+    float2 wv[8];
+    int li[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int rev3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);
+        li[e] = 2 * (rev3 * 64 + rev6);
+        wv[e] = make_float2(window[li[e]], window[li[e] + 1]);
+    }
+    asm volatile("" : "+v"(wv[0].x), "+v"(wv[0].y), "+v"(wv[1].x), "+v"(wv[1].y), "+v"(wv[2].x), "+v"(wv[2].y),
+                 "+v"(wv[3].x), "+v"(wv[3].y));
+    asm volatile("" : "+v"(wv[4].x), "+v"(wv[4].y), "+v"(wv[5].x), "+v"(wv[5].y), "+v"(wv[6].x), "+v"(wv[6].y),
+                 "+v"(wv[7].x), "+v"(wv[7].y));
+    // Frame loads are software-pipelined: the next frame's 8 reads are issued before this frame's
+    // outputs are stored, so waiting for them never drains the store queue (in-order vmcnt).
+    auto load_frame = [&](size_t fr, float2 (&dst)[8]) {
+        const float *x = signal + (fr < nframes ? fr : nframes - 1) * frame_stride;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            if constexpr (ALIGNED8) {
+                dst[e] = *reinterpret_cast<const float2 *>(x + li[e]);
+            } else {
+                dst[e].x = x[li[e]];
+                dst[e].y = x[li[e] + 1];
+            }
+        }
+    };
+    const size_t fstep = (size_t)gridDim.x * kWavesPerBlock;
+    float2 nxt[8];
+    load_frame((size_t)blockIdx.x * kWavesPerBlock + wave, nxt);
+    for (size_t f = (size_t)blockIdx.x * kWavesPerBlock + wave; f < nframes; f += fstep) {
         float2 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            v[e].x = nxt[e].x * wv[e].x;  // calcFFT L/fft.cpp:501-503
+            v[e].y = nxt[e].y * wv[e].y;
+        }
+        load_frame(f + fstep, nxt);
     // round A twiddles are lane-uniform: stage 0 n=0; stage 1 n=0,1; stage 2 n=0..3
         const float2 a0 = s_tw[0];
         const float2 a1[2] = {s_tw[1], s_tw[2]};
@@ -195,23 +243,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MXG_FFT_MINWAVES) void fft1024
         const float2 c2[4] = {s_tw[255 + lane], s_tw[255 + 64 + lane], s_tw[255 + 128 + lane],
                               s_tw[255 + 192 + lane]};
 
-        // Round A input: lane holds idx = 8*lane + e  <-  packed element i = rev9(idx)
-        //              = rev3(e)*64 + rev6(lane): for each e one 512-B segment per wavefront.
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int rev3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);
-            const int i = rev3 * 64 + rev6;
-            float2 s;
-            if (aligned8) {
-                s = *reinterpret_cast<const float2 *>(x + 2 * i);
-            } else {
-                s.x = x[2 * i];
-                s.y = x[2 * i + 1];
-            }
-            const float2 w = *reinterpret_cast<const float2 *>(window + 2 * i);
-            v[e].x = s.x * w.x;  // calcFFT L/fft.cpp:501-503
-            v[e].y = s.y * w.y;
-        }
+        // Round A input (already in v): lane holds idx = 8*lane + e  <-  packed element
+        // i = rev9(idx) = rev3(e)*64 + rev6(lane): for each e one 512-B segment per wavefront.
         round3(v, a0, a1, a2);
         // transpose A->B: write idx = 8*lane + e, read idx = hi*64 + e*8 + lo
 #pragma unroll
@@ -240,13 +273,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MXG_FFT_MINWAVES) void fft1024
             if (i < 256) {
                 float2 a = X[pad8(i)], b = X[pad8(512 - i)];
                 post_pair(a, b, s_post[i]);
-                emit_bin(out, base, i, a);
-                emit_bin(out, base, 512 - i, b);
+                emit_bin_t<OMASK>(out, base, i, a);
+                emit_bin_t<OMASK>(out, base, 512 - i, b);
             } else {  // i == 256 (lane 63, q 3): the untouched middle bin; and bin 0
-                emit_bin(out, base, 256, X[pad8(256)]);
+                emit_bin_t<OMASK>(out, base, 256, X[pad8(256)]);
                 float2 z = X[pad8(0)];
                 float2 z0 = {z.x + z.y, z.x - z.y};
-                emit_bin(out, base, 0, z0);
+                emit_bin_t<OMASK>(out, base, 0, z0);
             }
         }
         wave_lds_sync();
@@ -370,10 +403,23 @@ int mxg_fft_batch(const mxg_fft_plan *p, const float *d_signal, size_t frame_str
     const size_t cap = 256 * 5;  // persistent: <= 5 workgroups per CU, grid-stride over frames
     if (blocks > cap) blocks = cap;
     int force_generic = tune_get("fft_generic");
-    if (p->fftSize == 1024 && !force_generic) {
-        int aligned8 = ((((uintptr_t)d_signal) & 7) == 0 && (frame_stride & 1) == 0) ? 1 : 0;
-        hipLaunchKernelGGL(fft1024_kernel, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, st,
-                           d_signal, frame_stride, nframes, p->d_window, p->d_tw, p->d_post, out, aligned8);
+    const int omask = (d_real ? 1 : 0) | (d_imag ? 2 : 0) | (d_mags ? 4 : 0) | (d_phases ? 8 : 0);
+    const bool fast_mask = omask == 3 || omask == 4 || omask == 12 || omask == 15;
+    if (p->fftSize == 1024 && !force_generic && fast_mask) {
+        const bool aligned8 = (((uintptr_t)d_signal) & 7) == 0 && (frame_stride & 1) == 0;
+#define MXG_FFT_LAUNCH(M, A)                                                                            \
+    hipLaunchKernelGGL((fft1024_kernel<M, A>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, st, \
+                       d_signal, frame_stride, nframes, p->d_window, p->d_tw, p->d_post, out)
+#define MXG_FFT_LAUNCH2(M) \
+    if (aligned8) MXG_FFT_LAUNCH(M, true); else MXG_FFT_LAUNCH(M, false)
+        switch (omask) {
+            case 3: MXG_FFT_LAUNCH2(3); break;
+            case 4: MXG_FFT_LAUNCH2(4); break;
+            case 12: MXG_FFT_LAUNCH2(12); break;
+            default: MXG_FFT_LAUNCH2(15); break;
+        }
+#undef MXG_FFT_LAUNCH2
+#undef MXG_FFT_LAUNCH
     } else {
         size_t lds = sizeof(float2) * kWavesPerBlock * (p->half + (p->half >> 5) + 1);
         hipLaunchKernelGGL(fft_generic_kernel, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, st,
