@@ -240,8 +240,109 @@ struct SchedArgs {
     int32_t *chunk_first;  // [C+1][S]: spawns before sample c*Tc
     int *err;
     double sr, cycleLength, grainLength;
-    int sampleDur;
+    int sampleDur, fast;
 };
+
+// ---- exact multi-step advance of x <- fl(x + r) --------------------------------------------------
+// The scheduler's two recurrences (position += rate, looper += 1.0) are plain repeated additions
+// between rare events (a wrap, a spawn).  They can be advanced by many steps at once WITHOUT
+// changing a single bit of the result, because IEEE addition is predictable in two situations:
+//  (a) "grid" case: x and r are both multiples of g = 2^q and every partial sum stays below
+//      g*2^53  =>  every addition is exact, x_k = x + k*r  (looper += 1.0 always lands here; so
+//      do rates with short mantissas such as 0.265625);
+//  (b) "binade" case: while the sums stay inside x's binade [2^e, 2^(e+1)) they live on the grid
+//      u = 2^(e-52); r = R*u + f, and round-to-nearest turns each step into +R*u (f < u/2) or
+//      +(R+1)*u (f > u/2), a CONSTANT integer number of ulps  =>  X_k = X + k*c on the mantissa.
+//      (f == u/2, the tie, is resolved by parity one step at a time.)
+// Anything else (binade crossings, the step that crosses the limit, x = 0, subnormals) is done
+// as one ordinary floating-point step, so the sequence is the reference's, bit for bit.
+// Requires x >= 0, r > 0.  Advances at most kmax steps and stops right after the first step
+// whose result crosses the limit (x > limit, or x >= limit if `inclusive`); returns steps taken.
+__device__ __forceinline__ int lowbit_exp(double v) {  // exponent of the lowest set bit of v (v > 0, normal)
+    const long long b = __double_as_longlong(v);
+    const int e = (int)((b >> 52) & 0x7ff);
+    const unsigned long long m = ((unsigned long long)b & 0xFFFFFFFFFFFFFULL) | (1ULL << 52);
+    return e - 1075 + (int)__builtin_ctzll(m);
+}
+
+__device__ int advance_until(double &x, const double r, const double limit, const bool inclusive, int kmax,
+                             bool &crossed) {
+    crossed = false;
+    int done = 0;
+    while (done < kmax) {
+        bool jumped = false;
+        const long long xb = __double_as_longlong(x);
+        const int e = (int)((xb >> 52) & 0x7ff);
+        const int er = (int)((__double_as_longlong(r) >> 52) & 0x7ff);
+        if (er > 0 && er < 0x7ff && e < 0x7ff && (e > 0 || x == 0.0)) {
+            // ---- (a) grid case
+            int q = lowbit_exp(r);
+            if (x != 0.0) {
+                const int qx = lowbit_exp(x);
+                q = qx < q ? qx : q;
+            }
+            // all partial sums up to the one that crosses are <= limit + r: exact if that is < 2^(q+53)
+            const double top = ldexp(1.0, q + 53);
+            if (limit + r < top && x < top) {
+                const double Xs = ldexp(x, -q), Rs = ldexp(r, -q), Ls = ldexp(limit, -q);  // exact scalings
+                // largest k with x + k*r NOT crossed: X + k*R <= L (exclusive) / < L (inclusive)
+                double kk = floor((Ls - Xs) / Rs);  // estimate, fixed up exactly below
+                if (kk < 0) kk = 0;
+                if (kk > (double)(kmax - done)) kk = (double)(kmax - done);
+                long long k = (long long)kk;
+                // integers below 2^53: the products/sums here are exact in double
+                auto not_crossed = [&](long long j) {
+                    const double v = Xs + (double)j * Rs;
+                    return inclusive ? (v < Ls) : (v <= Ls);
+                };
+                while (k > 0 && !not_crossed(k)) k--;
+                while (k < (long long)(kmax - done) && not_crossed(k + 1)) k++;
+                if (k >= 1) {
+                    x = ldexp(Xs + (double)k * Rs, q);
+                    done += (int)k;
+                    jumped = true;
+                }
+            } else if (e > 0) {
+                // ---- (b) binade case
+                const double ru = ldexp(r, 1075 - e);  // r in ulps of x (exact scaling)
+                if (ru < 4503599627370496.0) {         // < 2^52, else the sum leaves the binade at once
+                    const double Rf = floor(ru), fr = ru - Rf;
+                    const long long X = (xb & 0xFFFFFFFFFFFFFLL) | (1LL << 52);
+                    const long long R = (long long)Rf;
+                    const bool tie = fr == 0.5;
+                    const long long c = fr < 0.5 ? R : (fr > 0.5 ? R + 1 : (((X + R) & 1) ? R + 1 : R));
+                    long long j = (long long)(kmax - done);
+                    if (c > 0) {
+                        const long long jb = ((1LL << 53) - 1 - X) / c;  // stay inside the binade
+                        j = jb < j ? jb : j;
+                        const double lu = ldexp(limit, 1075 - e);
+                        if (lu < 9007199254740992.0) {  // limit inside/below this binade's mantissa range
+                            const long long Lq = inclusive ? (long long)ceil(lu) - 1 : (long long)floor(lu);
+                            const long long jl = Lq >= X ? (Lq - X) / c : 0;  // steps that do not cross
+                            j = jl < j ? jl : j;
+                        }
+                    }
+                    if (tie && j > 1) j = 1;
+                    if (j >= 1) {
+                        const long long Xn = X + j * c;
+                        x = __longlong_as_double(((long long)e << 52) | (Xn & 0xFFFFFFFFFFFFFLL));
+                        done += (int)j;
+                        jumped = true;
+                    }
+                }
+            }
+        }
+        if (!jumped) {  // one ordinary step
+            x = x + r;
+            done++;
+            if (inclusive ? x >= limit : x > limit) {
+                crossed = true;
+                return done;
+            }
+        }
+    }
+    return done;
+}
 
 template <int MODE>
 __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
@@ -262,7 +363,49 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
     // derived from the spawn list afterwards).  thr = cycleLength + randomOffset changes only at a spawn.
     double thr = A.cycleLength + randomOffset;
     const int Tn = (int)A.T;
-    for (int n = 0; n < Tn; n++) {
+    auto do_spawn = [&](int n) {  // the body of `if (looper > cycleLength + randomOffset)` (:347-353)
+        looper -= thr;
+        double p01 = (position / dlen) + pm;
+        p01 = 1.0 < p01 ? 1.0 : p01;
+        p01 = p01 < 0.0 ? 0.0 : p01;
+        const double startPos = floor(dlen * p01);
+        double endPos = startPos + (double)A.sampleDur;
+        endPos = dlen < endPos ? dlen : endPos;
+        if ((size_t)count < A.G) {
+            A.spawn_n[(size_t)count * S + s] = n;
+            A.spawn_pos[(size_t)count * S + s] = frequency > 0 ? startPos : endPos;
+        } else {
+            failed = 3;
+        }
+        count++;
+        if (A.rnd) {
+            if (cursor < A.R) randomOffset = (double)A.rnd[s * A.R + cursor]; else { failed = 2; randomOffset = 0; }
+            cursor++;
+        } else {
+            randomOffset = 0;
+        }
+        thr = A.cycleLength + randomOffset;
+    };
+    const bool fast = A.fast && rate > 0.0 && position >= 0.0 && position <= dlen && looper >= 0.0 && thr > 1.0;
+    int nstart = 0;
+    if (fast) {
+        // event-driven: jump from spawn to spawn (looper), dragging position along (with its wraps)
+        int n = 0;
+        while (n < Tn) {
+            bool spawn;
+            const int k = advance_until(looper, 1.0, thr, false, Tn - n, spawn);
+            int rem = k;
+            while (rem > 0) {
+                bool wrapped;
+                rem -= advance_until(position, rate, dlen, MODE == 1, rem, wrapped);
+                if (wrapped) position -= dlen;  // :344 / :516 (the `< 0` branch cannot fire for rate > 0)
+            }
+            n += k;
+            if (spawn) do_spawn(n - 1);
+        }
+        nstart = Tn;
+    }
+    for (int n = nstart; n < Tn; n++) {
         position = position + rate;
         looper += 1.0;
         if (MODE == 0) {
@@ -624,6 +767,7 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         Q.a = d_a; Q.b = d_b; Q.posMod = d_posmod; Q.rnd = d_rnd; Q.st = d_st;
         Q.spawn_n = spawn_n; Q.spawn_pos = spawn_pos; Q.chunk_first = chunk_first; Q.err = g_err;
         Q.sr = A.sr; Q.cycleLength = A.cycleLength; Q.grainLength = A.grainLength; Q.sampleDur = A.sampleDur;
+        Q.fast = tune_get("grain_fast_sched");
         if (mode == 0)
             hipLaunchKernelGGL((granular_sched_kernel<0>), grid, dim3(64), 0, st, Q);
         else

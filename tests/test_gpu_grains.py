@@ -83,3 +83,34 @@ def test_granular_errors(mx, chunked):
         bank.play(1.0, 0.05, 4, 4000, rnd=np.zeros((4, 2), np.int32))  # rand queue exhausted
     with pytest.raises(ValueError):
         make_bank(mx, 0, "hann", smp, 4).play(1.0, 0.7, 4, 10)         # grain > 500 ms
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_fast_scheduler_random_rates(mx, port, mode):
+    """The event-driven scheduler (exact multi-step additions) against the oracle's step-by-step
+    loop for rates with full 53-bit mantissas, tiny/huge rates, negative rates (sequential
+    fallback), several sample lengths (many wraps) and random jitter -- bit-exact state."""
+    rng = np.random.default_rng(77 + mode)
+    S, T = 192, 6000
+    for Ls in (3000, 44100):
+        smp = rng.uniform(-1, 1, Ls)
+        a = rng.uniform(0.01, 3.0, S)
+        a[:8] = [1.0, 0.265625, 2.0 ** -20, 7.3, -0.8, 1e-9, 0.1, 0.30000000000000004]
+        b = rng.uniform(0.05, 4.0, S)
+        b[:6] = [1.0, 0.5, 2.0 ** -30, 13.7, -1.5, 1.0 / 3.0]
+        rnd = rng.integers(0, 10, (S, 64)).astype(np.int32)
+        pm = rng.uniform(-0.05, 0.05, S)
+        bank = make_bank(mx, mode, "hann", smp, S)
+        bank.setPosition(rng.uniform(0, 1, S))
+        st0 = bank.state.numpy()
+        if mode == 0:
+            o = bank.play(a, 0.05, 4, T, posMod=pm, rnd=rnd).numpy()
+        else:
+            o = bank.play(np.abs(a) + 0.05, b, 0.05, 3, T, posMod=pm, rnd=rnd).numpy()
+        aa = a if mode == 0 else np.abs(a) + 0.05
+        e, est, egst, rc = port.granular(mode, 0, smp, T, aa, b=b, posMod=pm, rnd=rnd, grainLength=0.05,
+                                         overlaps=4 if mode == 0 else 3, st=st0)
+        assert rc == 0
+        assert_bits_equal(bank.state.numpy(), est, "scheduler state (Ls=%d)" % Ls)
+        assert_bits_equal(bank.grains.numpy(), egst, "grains")
+        assert_bits_equal(o, e, "output")
