@@ -649,6 +649,154 @@ __global__ __launch_bounds__(64) void granular_render_kernel(RenderArgs A) {
     }
 }
 
+// ---- K8c: coalesced render for unit-increment grains -------------------------------------------------
+// maxiTimeStretch spawns every grain with speed +-1 (L/maxiGrains.h:350); when
+// inc = sampleDur/(sr/(1/grainLength)) is exactly 1.0 (e.g. grainLength 0.05 at 44.1 kHz) a grain
+// reads integer positions pos0 +- 1, +- 2, ...: `pos += inc` is exact, the wrap is a modulo and the
+// interpolation remainder is exactly 0, so sample k of a grain is a closed form of k -- no
+// recurrence left.  Then the lanes of a wavefront can be 64 CONSECUTIVE SAMPLES of one stream:
+// sample-buffer and window reads are contiguous (coalesced) instead of 64 scattered gathers, and
+// each output is still the creation-ordered sum of the same products ((1-0)*buf[a] + 0*buf[b])*win[k].
+// A 256-thread workgroup renders a 64-stream x 64-sample tile (each wave 16 streams, one after the
+// other) into LDS and writes it out transposed, so the [T][S] stores are coalesced too.
+struct UnitArgs {
+    size_t S, T, len, G, C;  // C = number of 64-sample chunks; chunk_first is [C+1][S]
+    const double *amp, *window, *a;
+    const int32_t *spawn_n;
+    const double *spawn_pos;
+    const int32_t *chunk_first;
+    const double *gst_in;
+    double *gst_out, *out;
+    int *err;
+    int sampleDur;
+};
+
+__device__ __forceinline__ long long unit_index(long long t, long long len) {  // t mod len, result in [0,len)
+    while (t >= len) t -= len;
+    while (t < 0) t += len;
+    return t;
+}
+
+// sample of a grain that has made `steps` position steps from pos0 and reads window index widx
+__device__ __forceinline__ double unit_sample(const double *amp, const double *win, long long len, long long pos0,
+                                              long long sgn, long long steps, long long widx) {
+    const long long ia = unit_index(pos0 + steps * sgn, len);  // maxiGrain::play :222-228
+    long long ib = ia + 1;
+    if (ib >= len) ib = 0;  // :231-233
+    const double remainder = 0.0;
+    double o = ((1 - remainder) * amp[ia] + remainder * amp[ib]);  // :236-237, literally
+    o *= win[widx];
+    return o;
+}
+
+__global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
+    __shared__ double s_tile[64 * 65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t S = A.S;
+    const size_t s0 = (size_t)blockIdx.x * 64, c = blockIdx.y, n0 = c * 64;
+    const long long len = (long long)A.len;
+    const long long n = (long long)n0 + lane;
+    for (int si = wave * 16; si < wave * 16 + 16; si++) {
+        const size_t s = s0 + si;
+        double total = 0.0;
+        int alive = 0;
+        if (s < S) {
+            const long long sgn = A.a[s] > 0 ? 1 : -1;  // :350
+            if (n0 < 32768) {  // carried-in grains can only be alive during the first <= sr/2 samples
+                for (int k = 0; k < kSlots; k++) {
+                    const long long dur = (long long)A.gst_in[(3 * kSlots + k) * S + s];
+                    if (!dur) continue;
+                    const long long idx0 = (long long)A.gst_in[(2 * kSlots + k) * S + s];
+                    if (idx0 + (long long)n0 >= dur) continue;
+                    const long long pos = (long long)A.gst_in[(0 * kSlots + k) * S + s];
+                    const long long inc = (long long)A.gst_in[(1 * kSlots + k) * S + s];
+                    const long long kk = idx0 + n;
+                    if (kk < dur && n < (long long)A.T) {
+                        total += unit_sample(A.amp, A.window, len, pos, inc, n + 1, kk);
+                        alive++;
+                    }
+                }
+            }
+            const int first = A.chunk_first[c * S + s], next = A.chunk_first[(c + 1) * S + s];
+            int j0 = first;
+            while (j0 > 0 && (long long)A.spawn_n[(size_t)(j0 - 1) * S + s] + A.sampleDur > (long long)n0) j0--;
+            for (int j = j0; j < next; j++) {
+                const long long born = A.spawn_n[(size_t)j * S + s];
+                const long long pos0 = (long long)A.spawn_pos[(size_t)j * S + s];
+                const long long k = n - born;
+                if (k >= 0 && k < A.sampleDur && n < (long long)A.T) {
+                    total += unit_sample(A.amp, A.window, len, pos0, sgn, k + 1, k);
+                    alive++;
+                }
+            }
+        }
+        if (alive > kSlots) atomicMax(A.err, 1);  // same capacity rule as the register-slot kernels
+        s_tile[lane * 65 + si] = total;
+    }
+    __syncthreads();
+    for (int r = wave * 16; r < wave * 16 + 16; r++) {
+        const size_t nn = n0 + r, s = s0 + lane;
+        if (nn < A.T && s < S) A.out[nn * S + s] = s_tile[r * 65 + lane];
+    }
+}
+
+// grains alive after sample T-1, creation order, closed form (one lane per stream)
+__global__ __launch_bounds__(64) void granular_unit_state_kernel(UnitArgs A) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t S = A.S;
+    if (s >= S) return;
+    const long long len = (long long)A.len, T = (long long)A.T;
+    const long long sgn = A.a[s] > 0 ? 1 : -1;
+    double gp[kSlots], gi[kSlots], gx[kSlots], gd[kSlots];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) { gp[k] = gi[k] = gx[k] = gd[k] = 0.0; }
+    auto push = [&](double p, double i, double x, double d) {
+#pragma unroll
+        for (int k = 0; k < kSlots; k++)
+            if (k == cnt) { gp[k] = p; gi[k] = i; gx[k] = x; gd[k] = d; }
+        cnt++;
+    };
+    for (int k = 0; k < kSlots; k++) {
+        const long long dur = (long long)A.gst_in[(3 * kSlots + k) * S + s];
+        if (!dur) continue;
+        const long long idx0 = (long long)A.gst_in[(2 * kSlots + k) * S + s];
+        if (idx0 + T >= dur) continue;
+        const long long pos = (long long)A.gst_in[(0 * kSlots + k) * S + s];
+        const long long inc = (long long)A.gst_in[(1 * kSlots + k) * S + s];
+        if (cnt < kSlots) push((double)unit_index(pos + T * inc, len), (double)inc, (double)(idx0 + T), (double)dur);
+    }
+    const int count = A.chunk_first[A.C * S + s];
+    int j0 = count;
+    while (j0 > 0 && (long long)A.spawn_n[(size_t)(j0 - 1) * S + s] + A.sampleDur > T) j0--;
+    for (int j = j0; j < count; j++) {
+        const long long born = A.spawn_n[(size_t)j * S + s];
+        const long long pos0 = (long long)A.spawn_pos[(size_t)j * S + s];
+        const long long steps = T - born;
+        if (cnt < kSlots) push((double)unit_index(pos0 + steps * sgn, len), (double)sgn, (double)steps, (double)A.sampleDur);
+    }
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) {
+        A.gst_out[(0 * kSlots + k) * S + s] = gp[k];
+        A.gst_out[(1 * kSlots + k) * S + s] = gi[k];
+        A.gst_out[(2 * kSlots + k) * S + s] = gx[k];
+        A.gst_out[(3 * kSlots + k) * S + s] = gd[k];
+    }
+}
+
+// eligibility of the carried-in grains for K8c: every live one must have inc = +-1 and an integer position
+__global__ void granular_unit_check_kernel(size_t S, const double *__restrict__ gst, int *flag) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    bool bad = false;
+    for (int k = 0; k < kSlots; k++) {
+        if (gst[(3 * kSlots + k) * S + s] == 0.0) continue;
+        const double pos = gst[(0 * kSlots + k) * S + s], inc = gst[(1 * kSlots + k) * S + s];
+        if (!(inc == 1.0 || inc == -1.0) || pos != floor(pos) || pos < 0.0 || pos > 9.0e15) bad = true;
+    }
+    if (bad) atomicMax(flag, 1);
+}
+
 int *g_err = nullptr;
 void *g_sched_scratch = nullptr;  // spawn lists + chunk table + copy of the carried-in grains, grow-only
 size_t g_sched_scratch_cap = 0;
@@ -717,7 +865,7 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
     if (S == 0 || T == 0) return MXG_OK;
     hipStream_t st = resolve_stream(stream);
     if (!g_err) {
-        MXG_HIP(hipMalloc(&g_err, sizeof(int)));
+        MXG_HIP(hipMalloc(&g_err, 2 * sizeof(int)));
     }
     MXG_HIP(hipMemsetAsync(g_err, 0, sizeof(int), st));
     GrainArgs A;
@@ -739,11 +887,28 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         else
             hipLaunchKernelGGL((granular_kernel<1>), grid, dim3(64), lds, st, A);
     } else {  // K8a scheduler pre-pass + K8b (stream, chunk) render
+        // K8c eligibility: maxiTimeStretch, inc exactly 1.0 (the device evaluates the same IEEE division),
+        // carried-in grains on the integer grid too, a window index that exists for every read
+        bool unit = false;
+        if (mode == 0 && tune_get("grain_unit") && T < (size_t)1 << 30 && len < (size_t)1 << 40) {
+            const double frequency = (1.0 / p->grainLength) * 1.0;
+            const double inc = (double)A.sampleDur / (A.sr / frequency);
+            if (inc == 1.0) {
+                MXG_HIP(hipMemsetAsync(g_err + 1, 0, sizeof(int), st));
+                hipLaunchKernelGGL(granular_unit_check_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, S,
+                                   (const double *)d_gst, g_err + 1);
+                int bad = 1;
+                MXG_HIP(hipMemcpyAsync(&bad, g_err + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+                MXG_HIP(hipStreamSynchronize(st));
+                unit = bad == 0;
+            }
+        }
         size_t C = (T + 255) / 256;
         const size_t cmax = ((size_t)tune_get("grain_lanes_k") * 1024 + S - 1) / S;
         if (C > cmax) C = cmax;
         if (C < 1) C = 1;
-        const size_t Tc = (T + C - 1) / C;
+        size_t Tc = (T + C - 1) / C;
+        if (unit) Tc = 64;  // K8c tiles are 64 samples; the chunk table is indexed per tile
         C = (T + Tc - 1) / Tc;
         const double minCycle = A.cycleLength;  // randomOffset >= 0 only lengthens a cycle
         const size_t G = (size_t)((double)T / (minCycle > 1.0 ? floor(minCycle) : 1.0)) + 2;
@@ -772,6 +937,15 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
             hipLaunchKernelGGL((granular_sched_kernel<0>), grid, dim3(64), 0, st, Q);
         else
             hipLaunchKernelGGL((granular_sched_kernel<1>), grid, dim3(64), 0, st, Q);
+        if (unit) {
+            UnitArgs U;
+            U.S = S; U.T = T; U.len = len; U.G = G; U.C = C;
+            U.amp = d_samples; U.window = p->d_window; U.a = d_a;
+            U.spawn_n = spawn_n; U.spawn_pos = spawn_pos; U.chunk_first = chunk_first;
+            U.gst_in = gst_copy; U.gst_out = d_gst; U.out = d_out; U.err = g_err; U.sampleDur = A.sampleDur;
+            hipLaunchKernelGGL(granular_unit_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)C), dim3(256), 0, st, U);
+            hipLaunchKernelGGL(granular_unit_state_kernel, grid, dim3(64), 0, st, U);
+        } else {
         RenderArgs Rr;
         Rr.S = S; Rr.T = T; Rr.len = len; Rr.G = G; Rr.Tc = Tc; Rr.C = C;
         Rr.amp = d_samples; Rr.window = p->d_window; Rr.a = d_a;
@@ -781,6 +955,7 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         Rr.mode = mode;
         const size_t lanes = S * C;
         hipLaunchKernelGGL(granular_render_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), lds, st, Rr);
+        }
     }
     MXG_HIP(hipGetLastError());
     int herr = 0;
