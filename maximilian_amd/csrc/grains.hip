@@ -689,19 +689,36 @@ __device__ __forceinline__ double unit_sample(const double *amp, const double *w
     return o;
 }
 
+constexpr int kCand = 16;  // candidates per stream and tile: <= 8 carried-in + the spawns alive in the tile
+
 __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
     __shared__ double s_tile[64 * 65];
+    __shared__ int s_base[64 * kCand];  // buffer index the grain reads at the tile's first sample (mod len)
+    __shared__ int s_k0[64 * kCand];    // its window index at the tile's first sample (may be < 0: not born yet)
+    __shared__ int s_dur[64 * kCand];
+    __shared__ int s_sgn[64 * kCand];
+    __shared__ int s_cnt[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t S = A.S;
     const size_t s0 = (size_t)blockIdx.x * 64, c = blockIdx.y, n0 = c * 64;
     const long long len = (long long)A.len;
-    const long long n = (long long)n0 + lane;
-    for (int si = wave * 16; si < wave * 16 + 16; si++) {
-        const size_t s = s0 + si;
-        double total = 0.0;
-        int alive = 0;
+    // ---- phase 1: one lane per stream collects that stream's candidate grains (creation order) in LDS,
+    //      so the dependent metadata loads of 64 streams overlap; all 64-bit arithmetic happens here,
+    //      once per grain and tile
+    if (threadIdx.x < 64) {
+        const size_t s = s0 + threadIdx.x;
+        int cnt = 0;
         if (s < S) {
-            const long long sgn = A.a[s] > 0 ? 1 : -1;  // :350
+            const int sgn = A.a[s] > 0 ? 1 : -1;  // :350
+            auto add = [&](long long born, long long dur, long long pos0, long long sg) {
+                // sample k of the grain reads index (pos0 + (k+1)*sg) mod len; at the tile start k = n0 - born
+                const long long k0 = (long long)n0 - born;
+                s_base[threadIdx.x * kCand + cnt] = (int)unit_index(pos0 + (k0 + 1) * sg, len);
+                s_k0[threadIdx.x * kCand + cnt] = (int)k0;
+                s_dur[threadIdx.x * kCand + cnt] = (int)dur;
+                s_sgn[threadIdx.x * kCand + cnt] = (int)sg;
+                cnt++;
+            };
             if (n0 < 32768) {  // carried-in grains can only be alive during the first <= sr/2 samples
                 for (int k = 0; k < kSlots; k++) {
                     const long long dur = (long long)A.gst_in[(3 * kSlots + k) * S + s];
@@ -710,22 +727,59 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
                     if (idx0 + (long long)n0 >= dur) continue;
                     const long long pos = (long long)A.gst_in[(0 * kSlots + k) * S + s];
                     const long long inc = (long long)A.gst_in[(1 * kSlots + k) * S + s];
-                    const long long kk = idx0 + n;
-                    if (kk < dur && n < (long long)A.T) {
-                        total += unit_sample(A.amp, A.window, len, pos, inc, n + 1, kk);
-                        alive++;
-                    }
+                    // as if born at sample -idx0 from position pos - idx0*inc
+                    add(-idx0, dur, pos - idx0 * inc, inc);
                 }
             }
             const int first = A.chunk_first[c * S + s], next = A.chunk_first[(c + 1) * S + s];
             int j0 = first;
             while (j0 > 0 && (long long)A.spawn_n[(size_t)(j0 - 1) * S + s] + A.sampleDur > (long long)n0) j0--;
             for (int j = j0; j < next; j++) {
-                const long long born = A.spawn_n[(size_t)j * S + s];
-                const long long pos0 = (long long)A.spawn_pos[(size_t)j * S + s];
-                const long long k = n - born;
-                if (k >= 0 && k < A.sampleDur && n < (long long)A.T) {
-                    total += unit_sample(A.amp, A.window, len, pos0, sgn, k + 1, k);
+                if (cnt >= kCand) {
+                    atomicMax(A.err, 1);
+                    break;
+                }
+                add(A.spawn_n[(size_t)j * S + s], A.sampleDur, (long long)A.spawn_pos[(size_t)j * S + s], sgn);
+            }
+        }
+        s_cnt[threadIdx.x] = cnt;
+    }
+    __syncthreads();
+    // ---- phase 2: lanes = 64 consecutive samples of one stream; contiguous sample/window reads, 32-bit math
+    const int ilen = (int)A.len;
+    const bool inT = (long long)n0 + lane < (long long)A.T;
+    for (int si = wave * 16; si < wave * 16 + 16; si++) {
+        const int cnt = s_cnt[si];
+        double total = 0.0;
+        int alive = 0;
+        for (int q0 = 0; q0 < cnt; q0 += 8) {
+            double va[8], vb[8], ve[8];
+            bool ok[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {  // issue the reads of up to 8 grains together
+                const int q = q0 + u;
+                ok[u] = false;
+                va[u] = vb[u] = ve[u] = 0.0;
+                if (q < cnt) {  // wave-uniform
+                    const int k = s_k0[si * kCand + q] + lane;
+                    ok[u] = inT && k >= 0 && k < s_dur[si * kCand + q];
+                    int ia = s_base[si * kCand + q] + lane * s_sgn[si * kCand + q];  // |lane*sgn| < 64 <= len
+                    if (ia >= ilen) ia -= ilen;
+                    if (ia < 0) ia += ilen;
+                    int ib = ia + 1;
+                    if (ib >= ilen) ib = 0;  // :231-233
+                    va[u] = A.amp[ia];
+                    vb[u] = A.amp[ib];
+                    ve[u] = A.window[ok[u] ? k : 0];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (ok[u]) {
+                    const double remainder = 0.0;  // pos is an integer: pos - floor(pos)
+                    double o = ((1 - remainder) * va[u] + remainder * vb[u]);  // :236-237, literally
+                    o *= ve[u];
+                    total += o;  // creation order
                     alive++;
                 }
             }
@@ -890,7 +944,7 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         // K8c eligibility: maxiTimeStretch, inc exactly 1.0 (the device evaluates the same IEEE division),
         // carried-in grains on the integer grid too, a window index that exists for every read
         bool unit = false;
-        if (mode == 0 && tune_get("grain_unit") && T < (size_t)1 << 30 && len < (size_t)1 << 40) {
+        if (mode == 0 && tune_get("grain_unit") && T < (size_t)1 << 30 && len >= 128 && len < ((size_t)1 << 31) - 128) {
             const double frequency = (1.0 / p->grainLength) * 1.0;
             const double inc = (double)A.sampleDur / (A.sr / frequency);
             if (inc == 1.0) {
