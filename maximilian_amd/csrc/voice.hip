@@ -90,7 +90,7 @@ __global__ void filter_kernel(size_t V, size_t N, const double *__restrict__ in,
     // Software pipeline: the inputs of chunk k+1 are requested BEFORE chunk k's outputs are stored,
     // so the wait for them is a counted vmcnt(U) and never drains the store stream (loads and
     // stores retire in order on one counter; a load issued after a store would wait for it).
-    constexpr int U = 4;
+    constexpr int U = (KIND >= MXG_FLT_LOPASS) ? 16 : 8;  // measured: 1-pole kinds want more loads in flight
     double xn[U], cn[U], rn[U];
 #pragma unroll
     for (int i = 0; i < U; i++) {
