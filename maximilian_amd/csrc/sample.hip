@@ -23,7 +23,7 @@ namespace mxg {
 namespace {
 
 template <int MODE>
-__global__ void delay_kernel(size_t V, size_t N, const double *__restrict__ in,
+__global__ void __launch_bounds__(256) delay_kernel(size_t V, size_t N, const double *__restrict__ in,
                              const int32_t *__restrict__ size, const double *__restrict__ feedback,
                              const int32_t *__restrict__ position, double *__restrict__ mem,
                              int32_t *__restrict__ phase_io, double *__restrict__ out) {
@@ -40,7 +40,63 @@ __global__ void delay_kernel(size_t V, size_t N, const double *__restrict__ in,
     const double *ip = in + v;
     double *op = out + v;
     double *m = mem + v;
-    for (size_t n = 0; n < N; n++) {
+    size_t n = 0;
+    if constexpr (MODE == 0) {
+        // Pipelined form: the input and ring reads of chunk k+1 are requested before chunk k's two
+        // store streams are issued, so waiting for them is a counted vmcnt and the stores are
+        // never drained.  A ring read may run ahead of the ring writes of the chunk before it
+        // only if they cannot touch the same slot: every line of the wavefront needs
+        // size >= 2U (otherwise the plain loop below renders the block).
+        constexpr int U = 8;
+        const size_t nfull = N / U;
+        if (nfull > 0 && __all(sz >= 2 * U)) {
+            double xi0[U], xi1[U], c0[U], c1[U];
+            int s0[U], s1[U];
+            int ph_prev = ph;
+            auto request = [&](size_t k, double(&xi)[U], double(&c)[U], int(&sl)[U]) {
+                ph_prev = ph;
+#pragma unroll
+                for (int i = 0; i < U; i++) {
+                    const size_t nn = k * U + i;
+                    const size_t mm = (nn < N) ? nn : N - 1;  // clamped: no branch
+                    xi[i] = ip[mm * V];
+                    if (ph >= sz) ph = 0;  // C:421
+                    sl[i] = ph;
+                    c[i] = m[(size_t)ph * V];
+                    ph += 1;
+                }
+            };
+            auto retire = [&](double(&xi)[U], double(&c)[U], int(&sl)[U]) {
+#pragma unroll
+                for (int i = 0; i < U; i++) {
+                    m[(size_t)sl[i] * V] = (c[i] * fb) + (xi[i] * fb) * 0.5;  // C:425
+                    *op = c[i];                                                // C:424
+                    op += V;
+                }
+            };
+            request(0, xi0, c0, s0);
+#pragma unroll
+            for (int i = 0; i < U; i++) {  // keep the prologue's loads out of the loop header's wait
+                asm volatile("" : "+v"(xi0[i]));
+                asm volatile("" : "+v"(c0[i]));
+            }
+            size_t k = 0;
+            for (; k + 1 < nfull; k += 2) {
+                request(k + 1, xi1, c1, s1);
+                retire(xi0, c0, s0);
+                request(k + 2, xi0, c0, s0);
+                retire(xi1, c1, s1);
+            }
+            if (k < nfull) {
+                request(k + 1, xi1, c1, s1);
+                retire(xi0, c0, s0);
+            }
+            ph = ph_prev;  // the last request ran ahead speculatively (loads only)
+            n = nfull * U;
+            ip += n * V;
+        }
+    }
+    for (; n < N; n++) {
         double input = *ip;
         if (ph >= sz) ph = 0;  // C:421 / C:432
         double *slot = m + (size_t)ph * V;
@@ -174,8 +230,133 @@ __device__ __forceinline__ double smp_tick(Smp &s, double x, double start, doubl
     }
 }
 
+// ---- pipelined form ------------------------------------------------------------------------
+// smp_tick split in two: smp_gen advances the play head and emits the gather indices (it never
+// needs a loaded sample value), smp_eval turns the gathered values into the output.  The kernel
+// issues the gathers of chunk k+1 before the stores of chunk k, so waiting for them is a counted
+// vmcnt and the store stream is never drained (loads and stores retire in order on one counter).
+// Guarded reads of the reference (`cond ? A[i] : 0`) become a read of a clamped index plus a
+// select, which loads the same value whenever the reference loads at all.
 template <int MODE>
-__global__ void sample_kernel(size_t V, size_t N, const double *__restrict__ amp, size_t len,
+struct SmpReq {
+    static constexpr int L = (MODE <= 3) ? 1 : (MODE == 7 ? 4 : 2);
+    long long idx[L];
+    double rem;
+    bool ok;   // modes 1,3,4,5,6: the reference's bounds test; modes 7,8: "backward" branch
+};
+
+template <int MODE>
+__device__ __forceinline__ void smp_gen(Smp &s, double x, double start, double end, double sr,
+                                        SmpReq<MODE> &q) {
+    q.rem = 0.0;
+    q.ok = true;
+    if constexpr (MODE == 0) {  // C:740-747
+        q.idx[0] = (long long)s.pos;
+        s.pos += 1.0;
+        if ((size_t)(long long)s.pos >= s.len) s.pos = 0;
+    } else if constexpr (MODE == 1) {  // C:982-991
+        q.ok = (size_t)(long long)s.pos < s.len;
+        q.idx[0] = q.ok ? (long long)s.pos : 0;
+        s.pos += 1.0;
+    } else if constexpr (MODE == 2) {  // C:960-967
+        s.pos += 1.0;
+        double lo = (double)s.len * start;
+        if (s.pos < lo) s.pos = lo;
+        if ((double)(long long)s.pos >= (double)s.len * end) s.pos = lo;
+        q.idx[0] = (long long)s.pos;
+    } else if constexpr (MODE == 3) {  // C:969-978
+        s.pos += 1.0;
+        if (end > 1.0) end = 1.0;
+        q.ok = (double)(long long)s.pos < (double)s.len * end;
+        q.idx[0] = q.ok ? (long long)s.pos : 0;
+    } else if constexpr (MODE == 4 || MODE == 5 || MODE == 6) {  // C:1060-1075, C:994-1003, C:1047-1058
+        long long i = (long long)s.pos;
+        q.rem = s.pos - (double)i;
+        if constexpr (MODE == 4) q.ok = (size_t)i < s.len;
+        if constexpr (MODE == 5) q.ok = (size_t)(i + 1) < s.len;
+        if constexpr (MODE == 6) {
+            if (end > 1.0) end = 1.0;
+            q.ok = (double)i < (double)s.len * end;
+        }
+        const long long first = (MODE == 5) ? i : 1 + i;
+        q.idx[0] = q.ok ? first : 0;
+        q.idx[1] = q.idx[0] + 1;
+        s.pos = s.pos + ((x * kChandiv) / s.step_div);
+        if constexpr (MODE == 4)
+            if ((size_t)(long long)s.pos >= s.len) s.pos -= (double)s.len;
+    } else if constexpr (MODE == 7) {  // C:884-956; idx = {a, b, c, d}
+        double frequency = x;
+        if (frequency > 0.) {
+            if (s.pos < start) s.pos = start;
+            if (s.pos >= end) s.pos = start;
+            s.pos += ((end - start) / (sr / (frequency * kChandiv)));
+            q.rem = s.pos - floor(s.pos);
+            q.idx[0] = (s.pos > 0) ? (long long)((int)(floor(s.pos)) - 1) : 0;
+            q.idx[1] = (long long)s.pos;
+            q.idx[2] = (s.pos < end - 2) ? (long long)s.pos + 1 : 0;
+            q.idx[3] = (s.pos < end - 3) ? (long long)s.pos + 2 : 0;
+            q.ok = false;
+        } else {
+            frequency *= -1.;
+            if (s.pos <= start) s.pos = end;
+            s.pos -= ((end - start) / (sr / (frequency * kChandiv)));
+            q.rem = s.pos - floor(s.pos);
+            q.idx[0] = (s.pos > start && s.pos < end - 1) ? (long long)s.pos + 1 : 0;
+            q.idx[1] = (long long)s.pos;
+            q.idx[2] = (s.pos > start) ? (long long)s.pos - 1 : 0;
+            q.idx[3] = (s.pos > start + 1) ? (long long)s.pos - 2 : 0;
+            q.ok = true;
+        }
+    } else {  // C:823-880: `position` is a by-value parameter there, the head never advances
+        double frequency = x, pos = s.pos;
+        const size_t amplen = s.len;
+        if (end >= (double)amplen) end = (double)(amplen - 1);
+        if (frequency > 0.) {
+            if (pos < start) pos = start;
+            if (pos >= end) pos = start;
+            pos += ((end - start) / ((sr) / (frequency * kChandiv)));
+            q.rem = pos - floor(pos);
+            long long posl = (long long)floor(pos);
+            q.idx[0] = ((size_t)(posl + 1) < amplen) ? posl + 1 : posl - 1;
+            q.idx[1] = ((size_t)(posl + 2) < amplen) ? posl + 2 : (long long)amplen - 1;
+            q.ok = false;
+        } else {
+            frequency *= -1.;
+            if (pos <= start) pos = end;
+            pos -= ((end - start) / (sr / (frequency * kChandiv)));
+            q.rem = pos - floor(pos);
+            long long posl = (long long)floor(pos);
+            q.idx[0] = (posl - 1 >= 0) ? posl - 1 : 0;
+            q.idx[1] = (posl - 2 >= 0) ? posl - 2 : 0;
+            q.ok = true;
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ double smp_eval(const SmpReq<MODE> &q, const double *val) {
+    if constexpr (MODE == 0 || MODE == 2) {
+        return val[0];
+    } else if constexpr (MODE == 1 || MODE == 3) {
+        return q.ok ? val[0] : 0.0;
+    } else if constexpr (MODE == 4 || MODE == 5 || MODE == 6) {
+        double o = ((1 - q.rem) * val[0] + q.rem * val[1]);
+        return q.ok ? o : 0.0;
+    } else if constexpr (MODE == 7) {
+        const double a = val[0], b = val[1], c = val[2], d = val[3];
+        double a1 = 0.5 * (c - a);
+        double a2 = a - 2.5 * b + 2. * c - 0.5 * d;
+        double a3 = 0.5 * (d - a) + 1.5 * (b - c);
+        const double m = q.ok ? -q.rem : q.rem;  // C:950 multiplies by -remainder going backwards
+        return (((a3 * q.rem + a2) * m + a1) * m + b);
+    } else {
+        const double w = q.ok ? (-1 - q.rem) : (1 - q.rem);  // C:872 / C:850
+        return (w * val[0] + q.rem * val[1]);
+    }
+}
+
+template <int MODE, bool XMOD>
+__global__ void __launch_bounds__(256) sample_kernel(size_t V, size_t N, const double *__restrict__ amp, size_t len,
                               double step_div, const double *__restrict__ a, int aps,
                               const double *__restrict__ start, const double *__restrict__ end,
                               double *__restrict__ position, double *__restrict__ out, double sr) {
@@ -183,15 +364,82 @@ __global__ void sample_kernel(size_t V, size_t N, const double *__restrict__ amp
     if (v >= V) return;
     Smp s = {amp, len, position[v], step_div};
     const double st = start ? start[v] : 0.0, en = end ? end[v] : 1.0;
-    double x = a ? a[v] : 1.0;
+    const double x0 = a ? a[v] : 1.0;
     const double *ap = a ? a + v : nullptr;
     double *op = out + v;
-#pragma unroll 2
-    for (size_t n = 0; n < N; n++) {
-        if (aps) {
-            x = *ap;
-            ap += V;
+    using Req = SmpReq<MODE>;
+    constexpr int L = Req::L;
+    constexpr int U = (L == 4) ? 4 : 8;
+    constexpr bool xmod = XMOD;  // per-sample speed input (modes 0-3 ignore it)
+    const size_t nfull = N / U;
+
+    if (nfull > 0) {
+        // Two register sets used alternately (the loop is unrolled by two) so that no loaded value
+        // is ever copied: a copy would be a use, and a use is a wait.  x is requested two chunks
+        // ahead (the head must advance through chunk k+1 before its gathers can be issued), the
+        // gathers one chunk ahead.
+        double x0s[U], x1s[U];
+        Req r0[U], r1[U];
+        double v0[U][L], v1[U][L];
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            x0s[i] = xmod ? ap[(size_t)i * V] : x0;
+            const size_t m = ((size_t)(U + i) < N) ? (size_t)(U + i) : N - 1;
+            x1s[i] = xmod ? ap[m * V] : x0;
         }
+        if constexpr (xmod) {
+            // consume the prologue's x loads here, so that the loop header does not inherit a
+            // pending load it would have to wait for with vmcnt(0) on every iteration
+#pragma unroll
+            for (int i = 0; i < U; i++) asm volatile("" : "+v"(x1s[i]));
+        }
+        double pos_prev = s.pos;
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            smp_gen<MODE>(s, x0s[i], st, en, sr, r0[i]);
+#pragma unroll
+            for (int l = 0; l < L; l++) v0[i][l] = amp[r0[i].idx[l]];
+        }
+#pragma unroll
+        for (int i = 0; i < U; i++)
+#pragma unroll
+            for (int l = 0; l < L; l++) asm volatile("" : "+v"(v0[i][l]));  // same reason as x1s
+        auto stage = [&](size_t k, double(&xuse)[U], double(&xload)[U], Req(&rcur)[U],
+                         double(&vcur)[U][L], Req(&rnext)[U], double(&vnext)[U][L]) {
+            if constexpr (xmod) {  // x of chunk k+2 (clamped index: no branch, surplus unused)
+#pragma unroll
+                for (int i = 0; i < U; i++) {
+                    const size_t n = (k + 2) * U + i;
+                    const size_t m = (n < N) ? n : N - 1;
+                    xload[i] = ap[m * V];
+                }
+            }
+            // advance the head through chunk k+1 and request its gathers.  After the last full
+            // chunk this runs ahead speculatively: pos_prev keeps the state to carry.
+            pos_prev = s.pos;
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                smp_gen<MODE>(s, xuse[i], st, en, sr, rnext[i]);
+#pragma unroll
+                for (int l = 0; l < L; l++) vnext[i][l] = amp[rnext[i].idx[l]];
+            }
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                *op = smp_eval<MODE>(rcur[i], vcur[i]);
+                op += V;
+            }
+        };
+        size_t k = 0;
+        for (; k + 1 < nfull; k += 2) {
+            stage(k, x1s, x0s, r0, v0, r1, v1);
+            stage(k + 1, x0s, x1s, r1, v1, r0, v0);
+        }
+        if (k < nfull) stage(k, x1s, x0s, r0, v0, r1, v1);
+        s.pos = pos_prev;
+    }
+    // ragged tail (< U samples): plain per-sample form
+    for (size_t n = nfull * U; n < N; n++) {
+        const double x = xmod ? ap[n * V] : x0;
         *op = smp_tick<MODE>(s, x, st, en, sr);
         op += V;
     }
@@ -217,6 +465,7 @@ int mxg_delay_render(int mode, size_t V, size_t N, const double *d_in, const int
     MXG_REQUIRE(cap > 0, "cap must be > 0");
     if (V == 0 || N == 0) return MXG_OK;
     int block = tune_get("voice_block");
+    if (block > 256) block = 256;  // delay_kernel is compiled for <= 256 lanes per workgroup
     hipStream_t st = resolve_stream(stream);
     if (mode == 0)
         hipLaunchKernelGGL((delay_kernel<0>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_size,
@@ -264,10 +513,20 @@ int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, siz
     const double step_div = (double)q;
     const double sr = (double)settings().sampleRate;
     int block = tune_get("voice_block");
+    if (block > 256) block = 256;  // sample_kernel is compiled for <= 256 lanes per workgroup
     hipStream_t st = resolve_stream(stream);
-#define MXG_SMP_LAUNCH(M)                                                                          \
-    hipLaunchKernelGGL((sample_kernel<M>), grid_for(V, block), dim3(block), 0, st, V, N, d_samples, \
-                       len, step_div, d_a, aps, d_start, d_end, d_position, d_out, sr)
+    const bool xmod = mode >= 4 && aps;
+#define MXG_SMP_LAUNCH(M)                                                                       \
+    do {                                                                                        \
+        if (M >= 4 && xmod)                                                                     \
+            hipLaunchKernelGGL((sample_kernel<M, (M >= 4)>), grid_for(V, block), dim3(block), 0, \
+                               st, V, N, d_samples, len, step_div, d_a, aps, d_start, d_end,    \
+                               d_position, d_out, sr);                                          \
+        else                                                                                    \
+            hipLaunchKernelGGL((sample_kernel<M, false>), grid_for(V, block), dim3(block), 0,   \
+                               st, V, N, d_samples, len, step_div, d_a, aps, d_start, d_end,    \
+                               d_position, d_out, sr);                                          \
+    } while (0)
     switch (mode) {
         case 0: MXG_SMP_LAUNCH(0); break;
         case 1: MXG_SMP_LAUNCH(1); break;

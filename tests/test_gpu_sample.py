@@ -94,3 +94,66 @@ def test_sample_vs_oracle_large(mx, port):
     o = bank.play(N).numpy()
     e, _ = port.sample(0, smp, N, np.zeros(V))
     assert_bits_equal(o, e, "play")
+
+
+@pytest.mark.parametrize("mode", range(9))
+@pytest.mark.parametrize("N", [1, 7, 8, 9, 16, 21, 203])
+def test_sample_ragged_blocks(mx, golden, port, mode, N):
+    """Block lengths around the pipelined chunk size (8, or 4 for play4): full chunks, odd chunk
+    counts, the speculative run-ahead and the per-sample tail must all leave the same head."""
+    g = golden("sample.npz")
+    name = SMP[mode]
+    V = g["pos0_" + name].size
+    bank = mx.maxiSampleBank(V)
+    bank.setSample(g["samples"])
+    bank.position.upload(g["pos0_" + name])
+    kw = dict(a=g["a_" + name], start=g["start_" + name], end=g["end_" + name])
+    o = bank.render(mode, N, **kw).numpy()
+    e, ep = port.sample(mode, g["samples"], N, g["pos0_" + name], **kw)
+    assert_bits_equal(o, e, f"{name} N={N}")
+    assert_bits_equal(bank.position.numpy(), ep, f"{name} N={N} position")
+
+
+@pytest.mark.parametrize("mode", [4, 5, 6, 7, 8])
+@pytest.mark.parametrize("N", [5, 12, 24, 203])
+def test_sample_per_sample_speed_ragged(mx, golden, port, mode, N):
+    g = golden("sample.npz")
+    name = SMP[mode]
+    V = g["pos0_" + name].size
+    rng = np.random.default_rng(100 + mode)
+    a = g["a_" + name][None, :] * rng.uniform(0.5, 1.5, (N, V))
+    if mode >= 7:
+        a *= np.where(rng.uniform(size=(N, V)) < 0.2, -1.0, 1.0)   # direction flips
+    bank = mx.maxiSampleBank(V)
+    bank.setSample(g["samples"])
+    bank.position.upload(g["pos0_" + name])
+    kw = dict(start=g["start_" + name], end=g["end_" + name])
+    o = bank.render(mode, N, a=a, per_sample=True, **kw).numpy()
+    e, ep = port.sample(mode, g["samples"], N, g["pos0_" + name], a=a, aps=True, **kw)
+    assert_bits_equal(o, e, f"{name} N={N}")
+    assert_bits_equal(bank.position.numpy(), ep, f"{name} N={N} position")
+
+
+@pytest.mark.parametrize("N", [3, 8, 24, 700, 1001])
+@pytest.mark.parametrize("sizes", ["uniform", "ge16", "mixed"])
+def test_delay_pipelined_paths(mx, port, N, sizes):
+    """dl(): wavefronts whose lines all have size >= 16 take the pipelined path, the rest the plain
+    loop; both must give the reference's ring, phase and output, across two carried blocks."""
+    rng = np.random.default_rng(N)
+    V, cap = 1024, 300
+    if sizes == "uniform":
+        size = np.full(V, 257, np.int32)
+    elif sizes == "ge16":
+        size = rng.integers(16, cap + 1, V).astype(np.int32)
+    else:
+        size = rng.integers(1, cap + 1, V).astype(np.int32)
+        size[:256] = rng.integers(16, 40, 256)      # whole wavefronts on the pipelined path
+    x = rng.uniform(-1, 1, (2 * N, V))
+    fb = rng.uniform(0, 0.9, V)
+    bank = mx.maxiDelaylineBank(V, cap)
+    o = np.concatenate([bank.dl(mx.DeviceBuffer.from_numpy(x[:N]), size, fb).numpy(),
+                        bank.dl(mx.DeviceBuffer.from_numpy(x[N:]), size, fb).numpy()])
+    e, emem, eph = port.delay(0, x, size, fb, cap)
+    assert_bits_equal(o, e, "dl")
+    assert_bits_equal(bank.memory.numpy(), emem, "mem")
+    assert np.array_equal(bank.phase.numpy(), eph)
