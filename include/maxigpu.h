@@ -102,10 +102,20 @@ int mxg_tune(const char *key, int value);
  * calls would (H:169-215).  d_freq is [V] (fps=0, block-constant) or [N][V] (fps=1, audio-rate
  * modulation).  d_p1/d_p2: per-voice extra arguments (see mxg_osc_waveform), may be NULL when
  * unused.  d_phase / d_outhold: the members `phase` and `output` (H:173,176), in/out.
- * maxiOsc::noise (C:214-220) is a global serial rand() stream and is not provided. */
+ * maxiOsc::noise (C:214-220) draws from the process-wide rand(): see mxg_osc_noise. */
 int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_freq, int fps,
                    const double *d_p1, const double *d_p2, double *d_phase, double *d_outhold,
                    double *d_out, void *stream);
+
+/* maxiOsc::noise (C:214-220): `float r = rand()/(float)RAND_MAX; output = r*2-1`.  rand() is one
+ * serial process-wide stream (not a per-object state), so which draw a voice sees is decided by
+ * the order of the caller's per-sample loop.  The caller therefore supplies the draws, exactly as
+ * the granular entry point does for its rand() uses: d_rand[n][v] is the value rand() returned for
+ * voice v at sample n (for a voice-inner loop: draw number n*V+v); the kernel applies the
+ * reference's float arithmetic (bit-exact).  count = N*V values; d_outhold ([V], may be NULL)
+ * receives the member `output` (H:176) after the last sample. */
+int mxg_osc_noise(size_t V, size_t N, const int32_t *d_rand, double *d_outhold, double *d_out,
+                  void *stream);
 
 /* Render + fused stereo mixdown: as mxg_osc_render (block-constant frequencies) and, in the same
  * pass, d_mix[n][0..1] = sum_v (out[n][v]*sqrt(1-pan_v), out[n][v]*sqrt(pan_v)) (maxiMix::stereo,
@@ -168,6 +178,15 @@ int mxg_voice_render(int mode, size_t V, size_t N, const double *d_freq, const d
 int mxg_mix_stereo(size_t V, size_t N, const double *d_in, const double *d_pan, double *d_mix,
                    void *stream);
 
+/* maxiMix::stereo (channels 2, C:503-509), quad (4, C:512-522) or ambisonic (8, C:525-541) over a
+ * bank: d_x/d_y/d_z are the per-voice [V] pan arguments (d_y for channels >= 4, d_z for 8).
+ * d_bus, if not NULL, receives the per-voice bus signals bus[n][c][v] = what the reference leaves
+ * in two/four/eight[c] for voice v at sample n (bit-exact, including ambisonic's quirks: z is
+ * never clamped, `z>1` / `z<0` overwrite y, and eight[0..3] = input*(sqrt(..)*1.0 - z)).
+ * d_mix [N][channels] = the sum over voices (fixed-shape tree, tolerance as mxg_mix_stereo). */
+int mxg_mix_bus(int channels, size_t V, size_t N, const double *d_in, const double *d_x,
+                const double *d_y, const double *d_z, double *d_bus, double *d_mix, void *stream);
+
 /* ---- maxiDelayline bank ---------------------------------------------------------------- */
 /* mode 0: dl(input, size, feedback) (C:420-429)   mode 1: dlFromPosition(input, size, feedback,
  * position) (C:431-439).  d_size int32 [V], d_feedback [V], d_position int32 [V] (mode 1).
@@ -188,7 +207,14 @@ typedef enum {
     MXG_SMP_PLAYONCEATSPEED = 5,         /* playOnceAtSpeed(a)           C:994-1003  */
     MXG_SMP_PLAYUNTILATSPEED = 6,        /* playUntilAtSpeed(end,a)      C:1047-1058 */
     MXG_SMP_PLAY4 = 7,                   /* play4(a=frequency,start,end) C:884-956   */
-    MXG_SMP_PLAYATSPEEDBETWEENPOINTS = 8 /* playAtSpeedBetweenPoints(a=frequency,start,end) C:823-880 */
+    MXG_SMP_PLAYATSPEEDBETWEENPOINTS = 8,/* playAtSpeedBetweenPoints(a=frequency,start,end) C:823-880 */
+    /* trigger-driven players, mxg_sample_render_trig only */
+    MXG_SMP_PLAYONZX = 9,                /* playOnZX(trig)                                  C:1006-1011 */
+    MXG_SMP_PLAYONZXATSPEED = 10,        /* playOnZXAtSpeed(trig, a)                        C:1013-1018 */
+    MXG_SMP_PLAYONZXATSPEEDFROMOFFSET = 11, /* playOnZXAtSpeedFromOffset(trig, a, p0=offset) C:1020-1026 */
+    MXG_SMP_PLAYONZXATSPEEDBETWEENPOINTS = 12, /* ...BetweenPoints(trig, a, p0=offset, p1=length) C:1028-1035 */
+    MXG_SMP_LOOPSETPOSONZX = 13,         /* loopSetPosOnZX(trig, p0=pos)                    C:1037-1042 */
+    MXG_SMP_PLAYWITHPHASOR = 14          /* playWithPhasor(trig=pha)                        C:753-816   */
 } mxg_sample_mode;
 /* Upload a mono sample (what maxiSample::setSample holds, H:670-678) into a device buffer that
  * is valid on [-1, len+1] with 0.0 guards: the reference reads amplitudes[len], [len+1]
@@ -205,6 +231,18 @@ int mxg_sample_free(double *d_samples);
 int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, size_t len,
                       int mySampleRate, const double *d_a, int aps, const double *d_start,
                       const double *d_end, double *d_position, double *d_out, void *stream);
+
+/* Trigger-driven players (modes 9-14).  d_trig is the per-sample [N][V] first argument of the
+ * reference call: the trigger signal of playOnZX* / loopSetPosOnZX, or the phasor of
+ * playWithPhasor.  d_a = speed ([V], or [N][V] when aps), d_p0/d_p1 = per-voice offset/length (or
+ * pos), as listed in mxg_sample_mode.  State, in/out: d_position [V]; d_tprev [V] / d_tfirst [V] =
+ * maxiSample::zxTrig's previousValue / firstTrigger (H:593-594: a fresh object holds 1.0 / 1), or
+ * for mode 14 phasorPrev / phasorFirst (H:731-732: 0.0 / 1; d_position is not used and may be NULL).
+ * All of it is compares, + - * / round and integer indexing => bit-exact. */
+int mxg_sample_render_trig(int mode, size_t V, size_t N, const double *d_samples, size_t len,
+                           int mySampleRate, const double *d_trig, const double *d_a, int aps,
+                           const double *d_p0, const double *d_p1, double *d_position,
+                           double *d_tprev, int32_t *d_tfirst, double *d_out, void *stream);
 
 /* ---- maxiFFT batch ---------------------------------------------------------------------- */
 /* A plan is what maxiFFT::setup(fftSize, hopSize, windowSize) prepares (L/maxiFFT.cpp:45-60): the

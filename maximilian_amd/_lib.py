@@ -48,6 +48,12 @@ SIGNATURES = {
                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
     "mxg_mix_stereo": (c_int, [c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_mix_bus": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p]),
+    "mxg_osc_noise": (c_int, [c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_sample_render_trig": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_size_t, c_int, c_void_p, c_void_p,
+                                       c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
     "mxg_delay_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "mxg_sample_upload": (c_void_p, [c_void_p, c_size_t]),

@@ -152,6 +152,18 @@ class maxiOscBank(_Bank):
         self._keep = (f, a, b, pn)
         return out, mix
 
+    def noise(self, rand, out=None):
+        """maxiOsc::noise (C:214-220) from caller-supplied rand() draws, int32 [N][V] (draw n*V+v is the
+        one a voice-inner per-sample loop hands to voice v at sample n)."""
+        if not (isinstance(rand, DeviceBuffer) or hasattr(rand, "data_ptr")):
+            rand = DeviceBuffer.from_numpy(np.ascontiguousarray(rand, np.int32))
+        N = rand.shape[0]
+        out = self._out(N, out)
+        check(lib().mxg_osc_noise(self.V, N, _ptr(rand), self.output.ptr, _ptr(out), self.stream),
+              "mxg_osc_noise")
+        self._keep = rand
+        return out
+
     def sinewave(self, freq, N, **kw): return self.render("sinewave", freq, N, **kw)
     def coswave(self, freq, N, **kw): return self.render("coswave", freq, N, **kw)
     def phasor(self, freq, N, **kw): return self.render("phasor", freq, N, **kw)
@@ -313,6 +325,22 @@ class maxiMixBank(_Bank):
         self._keep = p
         return out
 
+    def bus(self, channels, x, px, py=None, pz=None, out=None, bus=None):
+        """stereo (2) / quad (4, C:512-522) / ambisonic (8, C:525-541): mix [N][channels]; `bus`, if a
+        DeviceBuffer [N][channels][V], also receives the per-voice two/four/eight signals."""
+        N = x.shape[0]
+        dx = _as_dev(px, self.V)
+        dy = None if py is None else _as_dev(py, self.V)
+        dz = None if pz is None else _as_dev(pz, self.V)
+        out = out if out is not None else DeviceBuffer((N, channels), np.float64, zero=False)
+        check(lib().mxg_mix_bus(channels, self.V, N, _ptr(x), _ptr(dx), _ptr(dy), _ptr(dz), _ptr(bus),
+                                _ptr(out), self.stream), "mxg_mix_bus")
+        self._keep = (dx, dy, dz)
+        return out
+
+    def quad(self, x, px, py, **kw): return self.bus(4, x, px, py, **kw)
+    def ambisonic(self, x, px, py, pz, **kw): return self.bus(8, x, px, py, pz, **kw)
+
 
 class maxiDelaylineBank(_Bank):
     """V x maxiDelayline (H:266-284).  The ring is `cap` slots per voice (slot-major on device)
@@ -344,7 +372,10 @@ class maxiDelaylineBank(_Bank):
 
 
 SAMPLE_MODES = {"play": 0, "playOnce": 1, "playLoop": 2, "playUntil": 3, "playAtSpeed": 4,
-                "playOnceAtSpeed": 5, "playUntilAtSpeed": 6, "play4": 7, "playAtSpeedBetweenPoints": 8}
+                "playOnceAtSpeed": 5, "playUntilAtSpeed": 6, "play4": 7, "playAtSpeedBetweenPoints": 8,
+                # trigger-driven (mxg_sample_render_trig)
+                "playOnZX": 9, "playOnZXAtSpeed": 10, "playOnZXAtSpeedFromOffset": 11,
+                "playOnZXAtSpeedBetweenPoints": 12, "loopSetPosOnZX": 13, "playWithPhasor": 14}
 
 
 class maxiSampleBank(_Bank):
@@ -357,6 +388,11 @@ class maxiSampleBank(_Bank):
         self.length = 0
         self.mySampleRate = int(maxiSettings.sampleRate)  # ctor, C:546
         self.position = DeviceBuffer(self.V)
+        # maxiTrigger zxTrig (H:593-594: previousValue = 1, firstTrigger = 1), phasorPrev/First (H:731-732)
+        self.zx_prev = DeviceBuffer.from_numpy(np.ones(self.V))
+        self.zx_first = DeviceBuffer.from_numpy(np.ones(self.V, np.int32))
+        self.phasor_prev = DeviceBuffer(self.V)
+        self.phasor_first = DeviceBuffer.from_numpy(np.ones(self.V, np.int32))
 
     def setSample(self, samples):
         """maxiSample::setSample (H:670-678): copies the data, mySampleRate=44100, position=len-1."""
@@ -403,6 +439,38 @@ class maxiSampleBank(_Bank):
                                       _ptr(out), self.stream), "mxg_sample_render")
         self._keep = (da, ds, de)
         return out
+
+    def render_trig(self, mode, trig, a=None, p0=None, p1=None, out=None, per_sample=False):
+        """Modes 9-14: `trig` is the per-sample [N][V] trigger (or phasor) signal."""
+        m = SAMPLE_MODES[mode] if isinstance(mode, str) else int(mode)
+        if not (isinstance(trig, DeviceBuffer) or hasattr(trig, "data_ptr")):
+            trig = DeviceBuffer.from_numpy(np.ascontiguousarray(trig, np.float64))
+        N = trig.shape[0]
+        if per_sample and not (isinstance(a, DeviceBuffer) or hasattr(a, "data_ptr")):
+            a = DeviceBuffer.from_numpy(np.asarray(a, np.float64).reshape(N, self.V))
+        da = None if a is None else (a if per_sample else _as_dev(a, self.V))
+        d0 = None if p0 is None else _as_dev(p0, self.V)
+        d1 = None if p1 is None else _as_dev(p1, self.V)
+        tprev, tfirst = (self.phasor_prev, self.phasor_first) if m == 14 else (self.zx_prev, self.zx_first)
+        out = self._out(N, out)
+        check(lib().mxg_sample_render_trig(m, self.V, N, self.d_samples, self.length, self.mySampleRate,
+                                           _ptr(trig), _ptr(da), int(per_sample), _ptr(d0), _ptr(d1),
+                                           self.position.ptr, tprev.ptr, tfirst.ptr, _ptr(out), self.stream),
+              "mxg_sample_render_trig")
+        self._keep = (trig, da, d0, d1)
+        return out
+
+    def playOnZX(self, trig, **kw): return self.render_trig("playOnZX", trig, **kw)
+    def playOnZXAtSpeed(self, trig, speed, **kw): return self.render_trig("playOnZXAtSpeed", trig, a=speed, **kw)
+
+    def playOnZXAtSpeedFromOffset(self, trig, speed, offset, **kw):
+        return self.render_trig("playOnZXAtSpeedFromOffset", trig, a=speed, p0=offset, **kw)
+
+    def playOnZXAtSpeedBetweenPoints(self, trig, speed, offset, length, **kw):
+        return self.render_trig("playOnZXAtSpeedBetweenPoints", trig, a=speed, p0=offset, p1=length, **kw)
+
+    def loopSetPosOnZX(self, trig, pos, **kw): return self.render_trig("loopSetPosOnZX", trig, p0=pos, **kw)
+    def playWithPhasor(self, pha, **kw): return self.render_trig("playWithPhasor", pha, **kw)
 
     def play(self, N, **kw): return self.render("play", N, **kw)
     def playOnce(self, N, **kw): return self.render("playOnce", N, **kw)

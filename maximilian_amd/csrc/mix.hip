@@ -1,15 +1,19 @@
-// mix.hip -- maxiMix::stereo over a voice bank + the mixdown over voices (gfx950).
+// mix.hip -- maxiMix::stereo / quad / ambisonic over a voice bank + the mixdown over voices.
 //
-// Reference: maxiMix::stereo, src/maximilian.cpp:503-509:
-//     two[0] = input*sqrt(1.0-x);  two[1] = input*sqrt(x);       (x clamped to [0,1])
-// and the user-side `mix += ...` over voices (e.g. 15.polysynth/main.cpp:67).  The per-voice
-// products are IEEE-exact (sqrt is correctly rounded on gfx950); the SUM over voices is ours:
-// a fixed-shape reduction (1024 strided partial sums per row, then a binary tree), so it is
-// deterministic run to run but not the reference's left-to-right order => the mix carries the
-// tolerance stated in DESIGN.md, the per-voice signals stay bit-exact.
+// Reference, src/maximilian.cpp: stereo C:503-509, quad C:512-522, ambisonic C:525-541.  Every
+// bus output of the reference is `input * gain_c(x[,y[,z]])` with the gain built from sqrt and
+// + - * only, so gains and per-voice products are IEEE-exact here (sqrt is correctly rounded on
+// gfx950).  The user-side `mix += ...` over voices (e.g. 15.polysynth/main.cpp:67) is ours: a
+// fixed-shape reduction (1024 strided partial sums per row and channel, a butterfly inside each
+// wavefront, then the 16 wavefront sums left to right), deterministic run to run but not the
+// reference's left-to-right order => the mix carries the tolerance stated in DESIGN.md, the
+// per-voice bus signals (optional d_bus output) stay bit-exact.
+//
+// ambisonic quirks kept (C:530-531): `if (z>1) y=1; if (z<0) y=0;` -- z itself is never
+// clamped and y is overwritten; eight[0..3] = input*(sqrt(..)*1.0 - z) (precedence as written).
 //
 // K3 (HBM-read bound): one 1024-thread workgroup per sample row; every wavefront load is
-// 512 contiguous bytes of the row; the gains are two [V] arrays (L2/L3 resident, 1 MB).
+// 512 contiguous bytes of the row; the gains are C [V] arrays (L2 resident).
 #include "mxg_common.h"
 
 namespace mxg {
@@ -17,86 +21,158 @@ namespace {
 
 constexpr int kMixThreads = 1024;
 
-// gains[0][v] = sqrt(1-x), gains[1][v] = sqrt(x)   (C:504-507)
-__global__ void pan_gains_kernel(size_t V, const double *__restrict__ pan,
+template <int C>
+__global__ void bus_gains_kernel(size_t V, const double *__restrict__ px,
+                                 const double *__restrict__ py, const double *__restrict__ pz,
                                  double *__restrict__ gains) {
     size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
-    double x = pan[v];
+    double x = px[v];
     if (x > 1) x = 1;
     if (x < 0) x = 0;
-    gains[v] = sqrt(1.0 - x);
-    gains[V + v] = sqrt(x);
+    if constexpr (C == 2) {  // C:504-507
+        gains[v] = sqrt(1.0 - x);
+        gains[V + v] = sqrt(x);
+    } else {
+        double y = py[v];
+        if (y > 1) y = 1;
+        if (y < 0) y = 0;
+        if constexpr (C == 4) {  // C:517-520
+            gains[v] = sqrt((1.0 - x) * y);
+            gains[V + v] = sqrt((1.0 - x) * (1.0 - y));
+            gains[2 * V + v] = sqrt(x * y);
+            gains[3 * V + v] = sqrt(x * (1.0 - y));
+        } else {  // C:530-539
+            const double z = pz[v];
+            if (z > 1) y = 1;
+            if (z < 0) y = 0;
+            gains[v] = (sqrt((1.0 - x) * y) * 1.0 - z);
+            gains[V + v] = (sqrt((1.0 - x) * (1.0 - y)) * 1.0 - z);
+            gains[2 * V + v] = (sqrt(x * y) * 1.0 - z);
+            gains[3 * V + v] = (sqrt(x * (1.0 - y)) * 1.0 - z);
+            gains[4 * V + v] = (sqrt((1.0 - x) * y) * z);
+            gains[5 * V + v] = (sqrt((1.0 - x) * (1.0 - y)) * z);
+            gains[6 * V + v] = sqrt((x * y) * z);
+            gains[7 * V + v] = sqrt((x * (1.0 - y)) * z);
+        }
+    }
 }
 
-__global__ __launch_bounds__(kMixThreads) void mix_stereo_kernel(
+// BUS: also write the per-voice bus signals bus[n][c][v] (what the reference leaves in
+// two/four/eight for voice v at sample n).
+template <int C, bool BUS>
+__global__ __launch_bounds__(kMixThreads) void mix_bus_kernel(
     size_t V, const double *__restrict__ in, const double *__restrict__ gains,
-    double *__restrict__ mix) {
-    __shared__ double s_red[2 * kMixThreads];
+    double *__restrict__ bus, double *__restrict__ mix) {
+    __shared__ double s_red[C][kMixThreads / 64];
     const size_t n = blockIdx.x;
     const double *row = in + n * V;
-    double l = 0.0, r = 0.0;
-    // 4 independent loads in flight per thread; the accumulation order per thread stays
+    double *brow = BUS ? bus + n * C * V : nullptr;
+    double acc[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) acc[c] = 0.0;
+    // U independent row loads in flight per thread; the accumulation order per thread stays
     // v = t, t+1024, t+2048, ... so the result does not depend on the unrolling.
+    constexpr int U = (C == 2) ? 8 : (C == 4 ? 4 : 2);
     size_t v = threadIdx.x;
-    for (; v + 3 * kMixThreads < V; v += 4 * kMixThreads) {
-        const double x0 = row[v], x1 = row[v + kMixThreads], x2 = row[v + 2 * kMixThreads],
-                     x3 = row[v + 3 * kMixThreads];
-        const double a0 = gains[v], a1 = gains[v + kMixThreads], a2 = gains[v + 2 * kMixThreads],
-                     a3 = gains[v + 3 * kMixThreads];
-        const double b0 = gains[V + v], b1 = gains[V + v + kMixThreads], b2 = gains[V + v + 2 * kMixThreads],
-                     b3 = gains[V + v + 3 * kMixThreads];
-        l += x0 * a0; r += x0 * b0;
-        l += x1 * a1; r += x1 * b1;
-        l += x2 * a2; r += x2 * b2;
-        l += x3 * a3; r += x3 * b3;
+    for (; v + (U - 1) * kMixThreads < V; v += U * kMixThreads) {
+        double x[U], g[U][C];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            x[u] = row[v + u * kMixThreads];
+#pragma unroll
+            for (int c = 0; c < C; c++) g[u][c] = gains[(size_t)c * V + v + u * kMixThreads];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const double p = x[u] * g[u][c];
+                if constexpr (BUS) brow[(size_t)c * V + v + u * kMixThreads] = p;
+                acc[c] += p;
+            }
+        }
     }
     for (; v < V; v += kMixThreads) {
-        double x = row[v];
-        l += x * gains[v];
-        r += x * gains[V + v];
-    }
-    s_red[threadIdx.x] = l;
-    s_red[kMixThreads + threadIdx.x] = r;
-    __syncthreads();
-    for (int s = kMixThreads / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            s_red[threadIdx.x] += s_red[threadIdx.x + s];
-            s_red[kMixThreads + threadIdx.x] += s_red[kMixThreads + threadIdx.x + s];
+        const double x = row[v];
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const double p = x * gains[(size_t)c * V + v];
+            if constexpr (BUS) brow[(size_t)c * V + v] = p;
+            acc[c] += p;
         }
-        __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        mix[2 * n] = s_red[0];
-        mix[2 * n + 1] = s_red[kMixThreads];
+    // butterfly inside the wavefront (every lane ends with the same sum), then 16 wave sums
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        double s = acc[c];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+        if (lane == 0) s_red[c][wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < C) {
+        double s = s_red[threadIdx.x][0];
+        for (int w = 1; w < kMixThreads / 64; w++) s += s_red[threadIdx.x][w];
+        mix[C * n + threadIdx.x] = s;
     }
 }
 
 double *g_gains = nullptr;
 size_t g_gains_cap = 0;
 
+template <int C>
+int launch_bus(size_t V, size_t N, const double *d_in, const double *d_x, const double *d_y,
+               const double *d_z, double *d_bus, double *d_mix, hipStream_t st) {
+    if (g_gains_cap < C * V) {  // grow-only scratch for the per-voice gains
+        if (g_gains) MXG_HIP(hipFree(g_gains));
+        g_gains = nullptr;
+        g_gains_cap = 0;
+        MXG_HIP(hipMalloc(&g_gains, sizeof(double) * C * (V ? V : 1)));
+        g_gains_cap = C * V;
+    }
+    if (V)
+        hipLaunchKernelGGL((bus_gains_kernel<C>), dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st,
+                           V, d_x, d_y, d_z, g_gains);
+    if (d_bus)
+        hipLaunchKernelGGL((mix_bus_kernel<C, true>), dim3((unsigned)N), dim3(kMixThreads), 0, st, V,
+                           d_in, g_gains, d_bus, d_mix);
+    else
+        hipLaunchKernelGGL((mix_bus_kernel<C, false>), dim3((unsigned)N), dim3(kMixThreads), 0, st, V,
+                           d_in, g_gains, d_bus, d_mix);
+    return check_hip(hipGetLastError(), "mix_bus launch");
+}
+
 }  // namespace
 }  // namespace mxg
 
 using namespace mxg;
 
-extern "C" int mxg_mix_stereo(size_t V, size_t N, const double *d_in, const double *d_pan,
-                              double *d_mix, void *stream) {
+extern "C" {
+
+int mxg_mix_bus(int channels, size_t V, size_t N, const double *d_in, const double *d_x,
+                const double *d_y, const double *d_z, double *d_bus, double *d_mix, void *stream) {
     if (int s = ensure_init()) return s;
-    MXG_REQUIRE(d_in && d_pan && d_mix, "null device pointer");
+    MXG_REQUIRE(channels == 2 || channels == 4 || channels == 8,
+                "channels must be 2 (stereo), 4 (quad) or 8 (ambisonic)");
+    MXG_REQUIRE(d_in && d_x && d_mix, "null device pointer");
+    MXG_REQUIRE(channels < 4 || d_y, "quad/ambisonic need d_y");
+    MXG_REQUIRE(channels < 8 || d_z, "ambisonic needs d_z");
     if (N == 0) return MXG_OK;
     hipStream_t st = resolve_stream(stream);
-    if (g_gains_cap < 2 * V) {  // grow-only scratch for the per-voice gains
-        if (g_gains) MXG_HIP(hipFree(g_gains));
-        g_gains = nullptr;
-        g_gains_cap = 0;
-        MXG_HIP(hipMalloc(&g_gains, sizeof(double) * 2 * (V ? V : 1)));
-        g_gains_cap = 2 * V;
+    switch (channels) {
+        case 2: return launch_bus<2>(V, N, d_in, d_x, d_y, d_z, d_bus, d_mix, st);
+        case 4: return launch_bus<4>(V, N, d_in, d_x, d_y, d_z, d_bus, d_mix, st);
+        default: return launch_bus<8>(V, N, d_in, d_x, d_y, d_z, d_bus, d_mix, st);
     }
-    if (V)
-        hipLaunchKernelGGL(pan_gains_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V,
-                           d_pan, g_gains);
-    hipLaunchKernelGGL(mix_stereo_kernel, dim3((unsigned)N), dim3(kMixThreads), 0, st, V, d_in,
-                       g_gains, d_mix);
-    return check_hip(hipGetLastError(), "mix_stereo launch");
 }
+
+int mxg_mix_stereo(size_t V, size_t N, const double *d_in, const double *d_pan, double *d_mix,
+                   void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(d_in && d_pan && d_mix, "null device pointer");
+    return mxg_mix_bus(2, V, N, d_in, d_pan, nullptr, nullptr, nullptr, d_mix, stream);
+}
+
+}  // extern "C"

@@ -481,3 +481,38 @@ extern "C" int mxg_osc_render_mix(int waveform, size_t V, size_t N, const double
     hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)N), dim3(256), 0, st, nwaves, partial, d_mix);
     return check_hip(hipGetLastError(), "osc_mix_kernel launch");
 }
+
+// ---- maxiOsc::noise (C:214-220) -----------------------------------------------------------------
+//     float r = rand()/(float)RAND_MAX;  output = r*2-1;
+// rand() is one process-wide serial stream: the caller supplies the draws (see maxigpu.h), the
+// kernel does the reference's float arithmetic.  (float)RAND_MAX = 2^31 exactly; the int -> float
+// conversion rounds to nearest even as cvtsi2ss does; r*2-1 is evaluated in float (int operands
+// convert to float), then widened to the double member.  Pure streaming: 4 B in, 8 B out.
+namespace mxg {
+namespace {
+__global__ void osc_noise_kernel(size_t count, size_t V, size_t N, const int32_t *__restrict__ rnd,
+                                 double *__restrict__ outhold, double *__restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float r = (float)rnd[i] / 2147483648.0f;
+        const double o = (double)(r * 2.0f - 1.0f);
+        out[i] = o;
+        if (outhold && i >= count - V) outhold[i - (count - V)] = o;
+    }
+}
+}  // namespace
+}  // namespace mxg
+
+extern "C" int mxg_osc_noise(size_t V, size_t N, const int32_t *d_rand, double *d_outhold, double *d_out,
+                             void *stream) {
+    using namespace mxg;
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(d_rand && d_out, "null device pointer");
+    if (N == 0 || V == 0) return MXG_OK;
+    const size_t count = V * N;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(osc_noise_kernel, dim3((unsigned)blocks), dim3(256), 0, resolve_stream(stream), count, V,
+                       N, d_rand, d_outhold, d_out);
+    return check_hip(hipGetLastError(), "osc_noise_kernel launch");
+}

@@ -838,6 +838,170 @@ int mxo_sample(int mode, size_t V, size_t N, const double *amp, size_t len, int 
     return 0;
 }
 
+/* maxiTrigger::onZX (H:569-579): previousValue starts at 1, firstTrigger at 1 (H:593-594). */
+typedef struct {
+    double previousValue;
+    int firstTrigger;
+} zx_t;
+
+static double zx_onZX(zx_t *z, double input) {
+    double isZX = 0.0;
+    if ((z->previousValue <= 0.0 || z->firstTrigger) && input > 0) isZX = 1.0;
+    z->previousValue = input;
+    z->firstTrigger = 0;
+    return isZX;
+}
+
+/* maxiSample::setPosition C:749-751 (maxiMap::clamp H:843-854) */
+static void smp_setPosition(smp_t *s, double newPos) {
+    double c = newPos;
+    if (c > 1.0) c = 1.0;
+    else if (c < 0.0) c = 0.0;
+    s->position = c * (double)s->len;
+}
+
+/* C:1006-1042.  trigger() (C:597-600) zeroes position. */
+int mxo_sample_zx(int mode, size_t V, size_t N, const double *amp, size_t len, int mySampleRate,
+                  const double *trig, const double *a, int aps, const double *p0, const double *p1,
+                  double *position, double *zx_prev, int32_t *zx_first, double *out) {
+    if (mode < 0 || mode > 4) return -1;
+    for (size_t v = 0; v < V; v++) {
+        smp_t s = {amp, len, mySampleRate, position[v]};
+        zx_t z = {zx_prev[v], zx_first[v] != 0};
+        for (size_t n = 0; n < N; n++) {
+            const double t = trig[n * V + v];
+            const double x = a ? (aps ? a[n * V + v] : a[v]) : 1.0;
+            double o = 0;
+            if (zx_onZX(&z, t) != 0.0) {
+                if (mode == 4) {
+                    smp_setPosition(&s, p0[v]); /* C:1038-1040 */
+                } else {
+                    s.position = 0; /* trigger() */
+                    if (mode == 2 || mode == 3) s.position = p0[v] * (double)len; /* C:1024, C:1032 */
+                }
+            }
+            switch (mode) {
+                case 0: o = smp_playOnce(&s); break;                             /* C:1010 */
+                case 1: case 2: o = smp_playOnceAtSpeed(&s, x); break;           /* C:1017, C:1026 */
+                case 3: o = smp_playUntilAtSpeed(&s, p0[v] + p1[v], x); break;   /* C:1034 */
+                case 4: o = smp_play(&s); break;                                 /* C:1041 */
+            }
+            out[n * V + v] = o;
+        }
+        position[v] = s.position;
+        zx_prev[v] = z.previousValue;
+        zx_first[v] = z.firstTrigger;
+    }
+    return 0;
+}
+
+/* maxiSample::playWithPhasor C:753-816.  pos1/pos2 are size_t in the reference: `pos1--` at 0
+ * wraps to SIZE_MAX and is then caught by `pos1 >= amplen` -> 0 (the `< 0` tests are dead). */
+int mxo_sample_phasor(size_t V, size_t N, const double *amp, size_t len, const double *pha_in,
+                      double *phasor_prev, int32_t *phasor_first, double *out) {
+    const size_t amplen = len;
+    for (size_t v = 0; v < V; v++) {
+        double phasorPrev = phasor_prev[v];
+        int phasorFirst = phasor_first[v] != 0;
+        for (size_t n = 0; n < N; n++) {
+            double pha = pha_in[n * V + v];
+            if (pha > 1) pha = 1;
+            if (pha < 0) pha = 0;
+            double pos = pha * amplen * 0.99999999999999;
+            if (phasorFirst) {
+                phasorFirst = 0;
+                phasorPrev = pos;
+            }
+            size_t pos1 = (size_t)(round(phasorPrev));
+            size_t pos2 = (size_t)(round(pos));
+            if (pos1 == pos2) {
+                if (pos >= phasorPrev) pos2++;
+                else pos1--;
+            }
+            if (pos2 >= amplen) pos2 = 0;
+            if (pos1 >= amplen) pos1 = 0;
+            double q1, q2;
+            if (pos2 > pos1) {
+                double dist = pos2 - pos1;
+                if (dist == 0) q1 = 0;
+                else q1 = (pos - pos1) / dist;
+            } else {
+                double dist = (amplen - pos1) + pos2;
+                if (dist == 0) q1 = 0;
+                else {
+                    if (pos > pos1) q1 = (pos - pos1) / dist;
+                    else q1 = ((amplen - pos1) + pos) / dist;
+                }
+            }
+            q2 = 1 - q1;
+            out[n * V + v] = (q1 * amp[pos1] + q2 * amp[pos2]);
+            phasorPrev = pos;
+        }
+        phasor_prev[v] = phasorPrev;
+        phasor_first[v] = phasorFirst;
+    }
+    return 0;
+}
+
+/* maxiMix::stereo C:503-509, quad C:512-522, ambisonic C:525-541 (quirks kept: z never clamped,
+ * z>1 / z<0 overwrite y, eight[0..3] = input*(sqrt(..)*1.0-z)) + voice-order sum. */
+int mxo_mix_bus(int C, size_t V, size_t N, const double *in, const double *px, const double *py,
+                const double *pz, double *bus, double *mix) {
+    if (C != 2 && C != 4 && C != 8) return -1;
+    for (size_t n = 0; n < N; n++) {
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t v = 0; v < V; v++) {
+            const double input = in[n * V + v];
+            double o[8], x = px[v], y = 0, z = 0;
+            if (x > 1) x = 1;
+            if (x < 0) x = 0;
+            if (C >= 4) {
+                y = py[v];
+                if (y > 1) y = 1;
+                if (y < 0) y = 0;
+            }
+            if (C == 2) {
+                o[0] = input * sqrt(1.0 - x);
+                o[1] = input * sqrt(x);
+            } else if (C == 4) {
+                o[0] = input * sqrt((1.0 - x) * y);
+                o[1] = input * sqrt((1.0 - x) * (1.0 - y));
+                o[2] = input * sqrt(x * y);
+                o[3] = input * sqrt(x * (1.0 - y));
+            } else {
+                z = pz[v];
+                if (z > 1) y = 1;
+                if (z < 0) y = 0;
+                o[0] = input * (sqrt((1.0 - x) * y) * 1.0 - z);
+                o[1] = input * (sqrt((1.0 - x) * (1.0 - y)) * 1.0 - z);
+                o[2] = input * (sqrt(x * y) * 1.0 - z);
+                o[3] = input * (sqrt(x * (1.0 - y)) * 1.0 - z);
+                o[4] = input * (sqrt((1.0 - x) * y) * z);
+                o[5] = input * (sqrt((1.0 - x) * (1.0 - y)) * z);
+                o[6] = input * sqrt((x * y) * z);
+                o[7] = input * sqrt((x * (1.0 - y)) * z);
+            }
+            for (int c = 0; c < C; c++) {
+                if (bus) bus[(n * C + c) * V + v] = o[c];
+                acc[c] += o[c];
+            }
+        }
+        for (int c = 0; c < C; c++) mix[n * C + c] = acc[c];
+    }
+    return 0;
+}
+
+/* maxiOsc::noise C:214-220 over libc rand(): see oracle/ref_harness.cpp for the draw protocol. */
+int mxo_noise(unsigned seed, size_t V, size_t N, int32_t *rnd, double *out) {
+    srand(seed);
+    for (size_t i = 0; i < V * N; i++) {
+        rnd[i] = rand();
+        float r = rnd[i] / (float)RAND_MAX;
+        out[i] = r * 2 - 1;
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------
  * fft / maxiFFT (L/fft.cpp:118-282, 390-534; L/maxiFFT.cpp:45-91).  Everything is fp32
  * except the trigonometric seeds (double sin/cos rounded to float).  x86-64 SSE evaluates

@@ -144,6 +144,33 @@ class Oracle:
         assert rc == 0
         return mix
 
+    def mix_bus(self, channels, x, px, py=None, pz=None, want_bus=False):
+        """maxiMix::stereo/quad/ambisonic (C:503-541): returns (mix [N][C], bus [N][C][V] or None)."""
+        x = _f64(x)
+        N, V = x.shape
+        px = _f64(px, (V,))
+        py = None if py is None else _f64(py, (V,))
+        pz = None if pz is None else _f64(pz, (V,))
+        mix = np.empty((N, channels))
+        bus = np.empty((N, channels, V)) if want_bus else None
+        fn = self.L.mxo_mix_bus
+        fn.restype = c_int
+        fn.argtypes = [c_int, c_size_t, c_size_t] + [c_void_p] * 6
+        rc = fn(channels, V, N, _p(x), _p(px), _p(py), _p(pz), _p(bus), _p(mix))
+        assert rc == 0, rc
+        return mix, bus
+
+    def noise(self, seed, V, N):
+        """maxiOsc::noise (C:214-220): (rand() draws int32 [N][V], out [N][V]) for srand(seed)."""
+        rnd = np.empty((N, V), np.int32)
+        out = np.empty((N, V))
+        fn = self.L.mxo_noise
+        fn.restype = c_int
+        fn.argtypes = [ctypes.c_uint, c_size_t, c_size_t, c_void_p, c_void_p]
+        rc = fn(seed, V, N, _p(rnd), _p(out))
+        assert rc == 0, rc
+        return rnd, out
+
     # -- maxiDelayline ---------------------------------------------------------------------------
     def delay(self, mode, x, size, feedback, cap, position=None, mem=None, phase=None):
         x = _f64(x)
@@ -188,6 +215,45 @@ class Oracle:
                 _p(end), _p(position), _p(out))
         assert rc == 0, rc
         return out, position
+
+    def sample_zx(self, mode, samples, trig, position, a=None, aps=False, p0=None, p1=None,
+                  zx_prev=None, zx_first=None, mySampleRate=44100):
+        """playOnZX (0), playOnZXAtSpeed (1), ...FromOffset (2), ...BetweenPoints (3), loopSetPosOnZX (4)
+        C:1006-1042.  Returns (out, position, zx_prev, zx_first)."""
+        g = self.guarded(np.asarray(samples, np.float64))
+        trig = _f64(trig)
+        N, V = trig.shape
+        position = _f64(position, (V,)).copy()
+        a = None if a is None else _f64(a, (N, V) if aps else (V,))
+        p0 = None if p0 is None else _f64(p0, (V,))
+        p1 = None if p1 is None else _f64(p1, (V,))
+        zx_prev = np.ones(V) if zx_prev is None else _f64(zx_prev, (V,)).copy()
+        zx_first = np.ones(V, np.int32) if zx_first is None else np.ascontiguousarray(zx_first, np.int32).copy()
+        out = np.empty((N, V))
+        fn = self.L.mxo_sample_zx
+        fn.restype = c_int
+        fn.argtypes = [c_int, c_size_t, c_size_t, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_int,
+                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        rc = fn(mode, V, N, g.ctypes.data + 8, len(samples), mySampleRate, _p(trig), _p(a), int(aps), _p(p0),
+                _p(p1), _p(position), _p(zx_prev), _p(zx_first), _p(out))
+        assert rc == 0, rc
+        return out, position, zx_prev, zx_first
+
+    def sample_phasor(self, samples, pha, phasor_prev=None, phasor_first=None):
+        """maxiSample::playWithPhasor C:753-816.  Returns (out, phasorPrev, phasorFirst)."""
+        g = self.guarded(np.asarray(samples, np.float64))
+        pha = _f64(pha)
+        N, V = pha.shape
+        phasor_prev = np.zeros(V) if phasor_prev is None else _f64(phasor_prev, (V,)).copy()
+        phasor_first = np.ones(V, np.int32) if phasor_first is None else \
+            np.ascontiguousarray(phasor_first, np.int32).copy()
+        out = np.empty((N, V))
+        fn = self.L.mxo_sample_phasor
+        fn.restype = c_int
+        fn.argtypes = [c_size_t, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]
+        rc = fn(V, N, g.ctypes.data + 8, len(samples), _p(pha), _p(phasor_prev), _p(phasor_first), _p(out))
+        assert rc == 0, rc
+        return out, phasor_prev, phasor_first
 
     # -- maxiFFT streamed over a signal -------------------------------------------------------------
     def fft_stream(self, signal, fftSize=1024, hopSize=512, windowSize=0, want=("real", "imag", "mags", "phases")):

@@ -630,4 +630,95 @@ double mxo_time_osc(int wf, size_t V, size_t N, const double *freq, int threads,
     return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// ---- maxiMix::stereo/quad/ambisonic over a bank (src/maximilian.cpp:503-541) ---------------------
+// bus[n][c][v] = what the reference leaves in two/four/eight[c]; mix[n][c] = voice-order sum.
+int mxo_mix_bus(int C, size_t V, size_t N, const double *in, const double *x, const double *y,
+                const double *z, double *bus, double *mix) {
+    if (C != 2 && C != 4 && C != 8) return -1;
+    maxiMix m;
+    std::vector<double> o(C);
+    for (size_t n = 0; n < N; n++) {
+        std::vector<double> acc(C, 0.0);
+        for (size_t v = 0; v < V; v++) {
+            const double i = in[n * V + v];
+            if (C == 2) m.stereo(i, o, x[v]);
+            else if (C == 4) m.quad(i, o, x[v], y[v]);
+            else m.ambisonic(i, o, x[v], y[v], z[v]);
+            for (int c = 0; c < C; c++) {
+                if (bus) bus[(n * C + c) * V + v] = o[c];
+                acc[c] += o[c];
+            }
+        }
+        for (int c = 0; c < C; c++) mix[n * C + c] = acc[c];
+    }
+    return 0;
+}
+
+// ---- maxiOsc::noise (src/maximilian.cpp:214-220) ---------------------------------------------------
+// The reference draws from libc rand().  srand(seed), record count draws, srand(seed) again and
+// let the reference consume the same draws in voice-inner order: out[n*V+v] pairs with rnd[n*V+v].
+int mxo_noise(unsigned seed, size_t V, size_t N, int32_t *rnd, double *out) {
+    srand(seed);
+    for (size_t i = 0; i < V * N; i++) rnd[i] = rand();
+    srand(seed);
+    std::vector<maxiOsc> bank(V);
+    for (size_t n = 0; n < N; n++)
+        for (size_t v = 0; v < V; v++) out[n * V + v] = bank[v].noise();
+    return 0;
+}
+
+// ---- maxiSample trigger-driven players (src/maximilian.cpp:1006-1042) and playWithPhasor (:753-816)
+// mode 0 playOnZX(trig); 1 playOnZXAtSpeed(trig, a); 2 playOnZXAtSpeedFromOffset(trig, a, p0);
+// 3 playOnZXAtSpeedBetweenPoints(trig, a, p0, p1); 4 loopSetPosOnZX(trig, p0).
+// zx_prev/zx_first mirror maxiTrigger::previousValue/firstTrigger (H:593-594; fresh = 1, 1).
+int mxo_sample_zx(int mode, size_t V, size_t N, const double *amp, size_t len, int mySampleRate,
+                  const double *trig, const double *a, int aps, const double *p0, const double *p1,
+                  double *position, double *zx_prev, int32_t *zx_first, double *out) {
+    if (mode < 0 || mode > 4) return -1;
+    std::vector<double> data(amp, amp + len);
+    for (size_t v = 0; v < V; v++) {
+        maxiSample s;
+        s.amplitudes.reserve(len + 2);
+        s.setSample(data);
+        s.amplitudes.data()[len] = 0.0;
+        s.amplitudes.data()[len + 1] = 0.0;
+        s.mySampleRate = mySampleRate;
+        s.position = position[v];
+        s.zxTrig.previousValue = zx_prev[v];
+        s.zxTrig.firstTrigger = zx_first[v] != 0;
+        for (size_t n = 0; n < N; n++) {
+            const double t = trig[n * V + v];
+            const double x = a ? (aps ? a[n * V + v] : a[v]) : 1.0;
+            double o = 0;
+            switch (mode) {
+                case 0: o = s.playOnZX(t); break;
+                case 1: o = s.playOnZXAtSpeed(t, x); break;
+                case 2: o = s.playOnZXAtSpeedFromOffset(t, x, p0[v]); break;
+                case 3: o = s.playOnZXAtSpeedBetweenPoints(t, x, p0[v], p1[v]); break;
+                case 4: o = s.loopSetPosOnZX(t, p0[v]); break;
+            }
+            out[n * V + v] = o;
+        }
+        position[v] = s.position;
+        zx_prev[v] = s.zxTrig.previousValue;
+        zx_first[v] = s.zxTrig.firstTrigger;
+    }
+    return 0;
+}
+
+int mxo_sample_phasor(size_t V, size_t N, const double *amp, size_t len, const double *pha,
+                      double *phasor_prev, int32_t *phasor_first, double *out) {
+    std::vector<double> data(amp, amp + len);
+    for (size_t v = 0; v < V; v++) {
+        maxiSample s;
+        s.setSample(data);
+        s.phasorPrev = phasor_prev[v];
+        s.phasorFirst = phasor_first[v] != 0;
+        for (size_t n = 0; n < N; n++) out[n * V + v] = s.playWithPhasor(pha[n * V + v]);
+        phasor_prev[v] = s.phasorPrev;
+        phasor_first[v] = s.phasorFirst;
+    }
+    return 0;
+}
+
 }  // extern "C"

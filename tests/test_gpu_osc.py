@@ -164,3 +164,18 @@ def test_render_mix_fused(mx, port, wf, V, N):
     none, mix3 = bank2.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V), store=False)
     assert none is None
     assert_bits_equal(mix3.numpy(), mix1.numpy(), "mix-only mode")
+
+
+def test_noise_from_rand_draws(mx, port):
+    """maxiOsc::noise (C:214-220): the caller supplies the rand() draws, the float arithmetic is exact."""
+    V, N = 96, 257
+    rnd, e = port.noise(1234, V, N)
+    bank = mx.maxiOscBank(V)
+    o = bank.noise(rnd).numpy()
+    assert_bits_equal(o, e, "noise")
+    assert_bits_equal(bank.output.numpy(), e[-1], "noise output member")
+    # extremes of the int -> float conversion: 0, RAND_MAX (rounds to 2^31 -> r == 1), odd ties
+    edge = np.array([[0, 2147483647, 2147483583, 2147483584, 16777217, 16777219, 1, 33554434]], np.int32)
+    o = mx.maxiOscBank(8).noise(edge).numpy()
+    r = (edge.astype(np.float32) / np.float32(2147483648.0))
+    assert_bits_equal(o, (r * np.float32(2) - np.float32(1)).astype(np.float64), "noise edges")

@@ -157,3 +157,74 @@ def test_delay_pipelined_paths(mx, port, N, sizes):
     assert_bits_equal(o, e, "dl")
     assert_bits_equal(bank.memory.numpy(), emem, "mem")
     assert np.array_equal(bank.phase.numpy(), eph)
+
+
+ZX = ["playOnZX", "playOnZXAtSpeed", "playOnZXAtSpeedFromOffset", "playOnZXAtSpeedBetweenPoints", "loopSetPosOnZX"]
+
+
+def _zx_case(V, N, seed):
+    rng = np.random.default_rng(seed)
+    smp = rng.uniform(-1, 1, 1500)
+    trig = np.sin(np.arange(N)[:, None] * rng.uniform(0.02, 0.3, V)[None, :] + rng.uniform(0, 6, V))
+    trig[:, ::5] = np.where(rng.uniform(size=(N, (V + 4) // 5)) < 0.05, 1.0, 0.0)   # sparse impulses, exact zeros
+    return dict(smp=smp, trig=trig, a=rng.uniform(0.3, 2.5, V), p0=rng.uniform(0, 0.6, V),
+                p1=rng.uniform(0.1, 0.5, V), pos0=rng.uniform(0, 1499, V))
+
+
+@pytest.mark.parametrize("mode", range(5))
+@pytest.mark.parametrize("N", [5, 64, 203])
+def test_sample_on_zx(mx, port, mode, N):
+    """playOnZX* / loopSetPosOnZX (C:1006-1042): two carried blocks; output, position and the
+    maxiTrigger state must match the reference bit for bit."""
+    V = 200
+    c = _zx_case(V, 2 * N, 50 + mode)
+    bank = mx.maxiSampleBank(V)
+    bank.setSample(c["smp"])
+    bank.position.upload(c["pos0"])
+    name = ZX[mode]
+    kw = dict(a=c["a"] if mode in (1, 2, 3) else None, p0=c["p0"] if mode >= 2 else None,
+              p1=c["p1"] if mode == 3 else None)
+    o = np.concatenate([bank.render_trig(name, c["trig"][:N], **kw).numpy(),
+                        bank.render_trig(name, c["trig"][N:], **kw).numpy()])
+    e, ep, ezp, ezf = port.sample_zx(mode, c["smp"], c["trig"], c["pos0"], a=c["a"], p0=c["p0"], p1=c["p1"])
+    assert_bits_equal(o, e, name)
+    assert_bits_equal(bank.position.numpy(), ep, name + " position")
+    assert_bits_equal(bank.zx_prev.numpy(), ezp, name + " previousValue")
+    assert np.array_equal(bank.zx_first.numpy(), ezf)
+    assert np.abs(e).max() > 0.1
+
+
+def test_sample_on_zx_per_sample_speed(mx, port):
+    V, N = 130, 100
+    c = _zx_case(V, N, 77)
+    sp = c["a"][None, :] * np.random.default_rng(3).uniform(0.5, 1.5, (N, V))
+    bank = mx.maxiSampleBank(V)
+    bank.setSample(c["smp"])
+    bank.position.upload(c["pos0"])
+    o = bank.render_trig("playOnZXAtSpeedBetweenPoints", c["trig"], a=sp, p0=c["p0"], p1=c["p1"], per_sample=True).numpy()
+    e, ep, _, _ = port.sample_zx(3, c["smp"], c["trig"], c["pos0"], a=sp, aps=True, p0=c["p0"], p1=c["p1"])
+    assert_bits_equal(o, e)
+    assert_bits_equal(bank.position.numpy(), ep)
+
+
+@pytest.mark.parametrize("N", [3, 64, 301])
+def test_sample_play_with_phasor(mx, port, N):
+    """playWithPhasor (C:753-816): forward and backward ramps, stalls (pos1 == pos2), out-of-range
+    phasors (clamped), the size_t wrap of pos1-- at 0; two carried blocks."""
+    V = 150
+    rng = np.random.default_rng(N)
+    smp = rng.uniform(-1, 1, 1500)
+    n = np.arange(2 * N)[:, None]
+    pha = (n * rng.uniform(0.0003, 0.01, V)[None, :] + rng.uniform(0, 1, V)) % 1.0
+    pha[:, 1::4] = 1.0 - pha[:, 1::4]                 # backward
+    pha[:, 2::4] = np.round(pha[:, 2::4] * 8) / 8     # staircase: repeated values
+    pha[N // 2: N // 2 + 3, :] = rng.uniform(-0.3, 1.3, (min(3, 2 * N - N // 2), V))[: pha[N // 2: N // 2 + 3].shape[0]]
+    pha[:, 3] = 0.0                                   # stuck at 0: pos >= prev -> pos2++
+    pha[1:, 7] = np.linspace(0.001, 0.0, 2 * N - 1)   # creeping down to 0: pos1-- path
+    bank = mx.maxiSampleBank(V)
+    bank.setSample(smp)
+    o = np.concatenate([bank.playWithPhasor(pha[:N]).numpy(), bank.playWithPhasor(pha[N:]).numpy()])
+    e, epp, epf = port.sample_phasor(smp, pha)
+    assert_bits_equal(o, e, "playWithPhasor")
+    assert_bits_equal(bank.phasor_prev.numpy(), epp)
+    assert np.array_equal(bank.phasor_first.numpy(), epf)

@@ -157,3 +157,30 @@ def test_mix_stereo(mx, port, golden):
     assert_bits_equal(a, b, "deterministic")
     e = port.mix_stereo(x, pan)
     assert np.abs(a - e).max() <= MIX_RTOL * V
+
+
+@pytest.mark.parametrize("channels", [2, 4, 8])
+def test_mix_bus_quad_ambisonic(mx, port, channels):
+    """maxiMix::stereo/quad/ambisonic (C:503-541): per-voice bus signals bit-exact (incl. the
+    ambisonic quirks: z unclamped, z>1/z<0 overwrite y, NaN for negative z); mix within 1e-12*V."""
+    rng = np.random.default_rng(40 + channels)
+    V, N = 5000, 33
+    x = rng.uniform(-1, 1, (N, V))
+    px, py, pz = rng.uniform(-0.2, 1.2, V), rng.uniform(-0.2, 1.2, V), rng.uniform(0.0, 1.3, V)
+    bank = mx.maxiMixBank(V)
+    dx = mx.DeviceBuffer.from_numpy(x)
+    bus = mx.DeviceBuffer((N, channels, V))
+    mix = bank.bus(channels, dx, px, py if channels >= 4 else None, pz if channels == 8 else None, bus=bus).numpy()
+    emix, ebus = port.mix_bus(channels, x, px, py, pz, want_bus=True)
+    assert_bits_equal(bus.numpy(), ebus, "bus")
+    assert np.all(np.isfinite(emix))
+    np.testing.assert_allclose(mix, emix, rtol=0, atol=1e-12 * V)
+    # without the bus output the mix is the same bits (same kernel shape)
+    mix2 = bank.bus(channels, dx, px, py if channels >= 4 else None, pz if channels == 8 else None).numpy()
+    assert_bits_equal(mix2, mix, "mix without bus")
+    if channels == 8:   # negative z -> sqrt of a negative product -> NaN in eight[6], eight[7]
+        pz2 = pz.copy(); pz2[::7] = -0.25
+        bank.bus(8, dx, px, py, pz2, bus=bus)
+        _, ebus = port.mix_bus(8, x, px, py, pz2, want_bus=True)
+        assert np.isnan(ebus).any()
+        assert_bits_equal(bus.numpy(), ebus, "bus with NaN")
