@@ -265,6 +265,15 @@ int mxg_fft_batch(const mxg_fft_plan *plan, const float *d_signal, size_t frame_
                   size_t nframes, float *d_real, float *d_imag, float *d_mags, float *d_phases,
                   void *stream);
 
+/* maxiFFT::magsToDB (fft::convToDB, L/fft.cpp:526-534), spectralFlatness and spectralCentroid
+ * (L/maxiFFT.cpp:113-132) of nframes frames of magnitudes d_mags [nframes][bins] (e.g. the d_mags
+ * output of mxg_fft_batch).  Outputs, any may be NULL: d_db [nframes][bins], d_flatness [nframes],
+ * d_centroid [nframes] (uses maxiSettings::sampleRate).  The per-frame sums run over the bins in the
+ * reference's order in float; centroid is bit-exact, dB and flatness go through the device
+ * log10f/logf/expf (tolerances in DESIGN.md). */
+int mxg_fft_features(const mxg_fft_plan *plan, const float *d_mags, size_t nframes, float *d_db,
+                     float *d_flatness, float *d_centroid, void *stream);
+
 /* ---- maxiMFCC batch --------------------------------------------------------------------- */
 /* maxiMFCC::setup(numBins, numFilters, numCoeffs, minFreq, maxFreq) (L/maxiMFCC.h:56-75): builds
  * the mel filterbank and DCT tables on the host libm.  Works without a device (tables only). */

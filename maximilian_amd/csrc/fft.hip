@@ -291,6 +291,68 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MXG_FFT_MINWAVES) void fft1024
 
 using namespace mxg;
 
+// ---- magsToDB / spectralFlatness / spectralCentroid (L/fft.cpp:526-534, L/maxiFFT.cpp:113-132) ----
+// One wavefront per 64 frames.  The per-frame sums of the reference are sequential float
+// accumulations over the bins, so a lane owns a frame and walks its bins in order; the [64 frames]
+// x [64 bins] tile it walks is loaded coalesced (lane = bin) and transposed through LDS.  The dB
+// conversion is elementwise and is done in the coalesced phase.
+// Arithmetic: `in < 0.000001` compares in double; `20.0*log10(in+1)` = double product of the FLOAT
+// log10 (float overload) rounded to float; flatness/centroid are all-float (fabs(float), size_t i
+// converted to float).  logf/log10f/expf are the device's => stated tolerance; centroid has no
+// transcendental and is bit-exact.
+namespace mxg {
+namespace {
+__global__ __launch_bounds__(64) void fft_features_kernel(const float *__restrict__ mags, size_t nframes,
+                                                           int bins, float binhz, float *__restrict__ db,
+                                                           float *__restrict__ flat, float *__restrict__ cen) {
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x;
+    for (size_t f0 = (size_t)blockIdx.x * 64; f0 < nframes; f0 += (size_t)gridDim.x * 64) {
+        float gm = 0, am = 0, x = 0, y = 0;
+        const int rows = (nframes - f0 < 64) ? (int)(nframes - f0) : 64;
+        for (int b0 = 0; b0 < bins; b0 += 64) {
+            const int b = b0 + lane;
+            const bool bvalid = b < bins;
+#pragma unroll 8
+            for (int r = 0; r < 64; r++) {
+                float v = 0.0f;
+                if (bvalid && r < rows) {
+                    const size_t at = (f0 + r) * (size_t)bins + b;
+                    v = mags[at];
+                    if (db) db[at] = ((double)v < 0.000001) ? 0.0f : (float)(20.0 * (double)log10f(v + 1));
+                }
+                tile[r][lane] = v;
+            }
+            __syncthreads();
+            if (flat || cen) {
+                const int nb = (bins - b0 < 64) ? bins - b0 : 64;
+                for (int j = 0; j < nb; j++) {
+                    const float m = tile[lane][j];
+                    if (flat) {
+                        if (m != 0) gm += logf(m);
+                        am += m;
+                    }
+                    if (cen) {
+                        x += fabsf(m) * (float)(b0 + j);
+                        y += fabsf(m);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (lane < rows) {
+            if (flat) {
+                gm = expf(gm / (float)bins);
+                am /= (float)bins;
+                flat[f0 + lane] = am != 0 ? gm / am : 0.0f;
+            }
+            if (cen) cen[f0 + lane] = y != 0 ? x / y * binhz : 0.0f;
+        }
+    }
+}
+}  // namespace
+}  // namespace mxg
+
 extern "C" {
 
 mxg_fft_plan *mxg_fft_plan_create(int fftSize, int hopSize, int windowSize) {
@@ -427,6 +489,21 @@ int mxg_fft_batch(const mxg_fft_plan *p, const float *d_signal, size_t frame_str
                            p->d_post, out);
     }
     return check_hip(hipGetLastError(), "fft kernel launch");
+}
+
+int mxg_fft_features(const mxg_fft_plan *p, const float *d_mags, size_t nframes, float *d_db,
+                     float *d_flatness, float *d_centroid, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(p && d_mags, "null plan or magnitudes");
+    MXG_REQUIRE(d_db || d_flatness || d_centroid, "no output requested");
+    if (nframes == 0) return MXG_OK;
+    size_t blocks = (nframes + 63) / 64;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    // (float) maxiSettings::sampleRate / fftSize, L/maxiFFT.cpp:131
+    const float binhz = (float)settings().sampleRate / (float)p->fftSize;
+    hipLaunchKernelGGL(fft_features_kernel, dim3((unsigned)blocks), dim3(64), 0, resolve_stream(stream), d_mags,
+                       nframes, p->bins, binhz, d_db, d_flatness, d_centroid);
+    return check_hip(hipGetLastError(), "fft_features_kernel launch");
 }
 
 }  // extern "C"

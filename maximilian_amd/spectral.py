@@ -77,6 +77,28 @@ class maxiFFT:
     def getReal(self): return self.real
     def getImag(self): return self.imag
 
+    def _features(self, mags, db=False, flatness=False, centroid=False):
+        mags = self.magnitudes if mags is None else mags
+        n = mags.shape[0]
+        d = DeviceBuffer((n, self.bins), np.float32, zero=False) if db else None
+        f = DeviceBuffer(n, np.float32, zero=False) if flatness else None
+        c = DeviceBuffer(n, np.float32, zero=False) if centroid else None
+        check(lib().mxg_fft_features(self.plan, _ptr(mags), n, _ptr(d), _ptr(f), _ptr(c), self.stream),
+              "mxg_fft_features")
+        return d, f, c
+
+    def magsToDB(self, mags=None):
+        """maxiFFT::magsToDB (L/maxiFFT.cpp:101-111) for every frame: [nframes, bins] fp32."""
+        return self._features(mags, db=True)[0]
+
+    def spectralFlatness(self, mags=None):
+        """maxiFFT::spectralFlatness (L/maxiFFT.cpp:113-123) per frame."""
+        return self._features(mags, flatness=True)[1]
+
+    def spectralCentroid(self, mags=None):
+        """maxiFFT::spectralCentroid (L/maxiFFT.cpp:125-132) per frame."""
+        return self._features(mags, centroid=True)[2]
+
     def close(self):
         if self.plan:
             lib().mxg_fft_plan_destroy(self.plan)

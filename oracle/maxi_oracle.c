@@ -1165,6 +1165,36 @@ void mxo_fft_to_db(const float *in, float *out, size_t n) {
     }
 }
 
+/* maxiFFT::spectralFlatness L/maxiFFT.cpp:113-123, spectralCentroid :125-132.  All float:
+ * logf/expf; `fabs(magnitudes[i]) * i` resolves to the float overload (pinned against the compiled
+ * reference), and size_t i converts to float. */
+int mxo_fft_features(const float *mags, size_t nframes, int fftSize, float *flatness, float *centroid) {
+    if (fftSize < 4 || (fftSize & (fftSize - 1))) return -1;
+    const size_t bins = (size_t)fftSize / 2;
+    for (size_t k = 0; k < nframes; k++) {
+        const float *m = mags + k * bins;
+        if (flatness) {
+            float geometricMean = 0, arithmaticMean = 0;
+            for (size_t i = 0; i < bins; i++) {
+                if (m[i] != 0) geometricMean += logf(m[i]);
+                arithmaticMean += m[i];
+            }
+            geometricMean = expf(geometricMean / (float)bins);
+            arithmaticMean /= (float)bins;
+            flatness[k] = arithmaticMean != 0 ? geometricMean / arithmaticMean : 0;
+        }
+        if (centroid) {
+            float x = 0, y = 0;
+            for (size_t i = 0; i < bins; i++) {
+                x += fabsf(m[i]) * i;
+                y += fabsf(m[i]);
+            }
+            centroid[k] = y != 0 ? x / y * ((float)g_sampleRate / fftSize) : 0;
+        }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------
  * maxiMFCCAnalyser<double> (L/maxiMFCC.h:30-211, L/maxiMFCC.cpp:48-66).
  * ------------------------------------------------------------------------------------ */

@@ -280,6 +280,19 @@ class Oracle:
         fn(_p(mags), _p(out), mags.size)
         return out
 
+    def fft_features(self, mags, fftSize):
+        """maxiFFT::spectralFlatness / spectralCentroid (L/maxiFFT.cpp:113-132) per frame of [bins] magnitudes."""
+        mags = np.ascontiguousarray(mags, np.float32)
+        nframes = mags.shape[0]
+        flat = np.empty(nframes, np.float32)
+        cen = np.empty(nframes, np.float32)
+        fn = self.L.mxo_fft_features
+        fn.restype = c_int
+        fn.argtypes = [c_void_p, c_size_t, c_int, c_void_p, c_void_p]
+        rc = fn(_p(mags), nframes, fftSize, _p(flat), _p(cen))
+        assert rc == 0, rc
+        return flat, cen
+
     # -- maxiMFCC ---------------------------------------------------------------------------------------
     def mfcc_tables(self, numBins=512, numFilters=42, numCoeffs=13, minFreq=20.0, maxFreq=20000.0):
         W = np.zeros(numFilters * numBins)

@@ -435,6 +435,20 @@ void mxo_fft_to_db(const float *in, float *out, size_t n) {
     f.convToDB(const_cast<float *>(in), out);
 }
 
+// maxiFFT::spectralFlatness / spectralCentroid (src/libs/maxiFFT.cpp:113-132) over frames of magnitudes
+int mxo_fft_features(const float *mags, size_t nframes, int fftSize, float *flatness, float *centroid) {
+    if (fftSize < 4 || (fftSize & (fftSize - 1))) return -1;
+    maxiFFT f;
+    f.setup(fftSize, fftSize, fftSize);
+    const int bins = f.getNumBins();
+    for (size_t k = 0; k < nframes; k++) {
+        for (int i = 0; i < bins; i++) f.magnitudes[i] = mags[k * bins + i];
+        if (flatness) flatness[k] = f.spectralFlatness();
+        if (centroid) centroid[k] = f.spectralCentroid();
+    }
+    return 0;
+}
+
 // ---- maxiMFCC (src/libs/maxiMFCC.h, maxiMFCC.cpp) ---------------------------------------------------
 // The reference never writes column 0 of melFilters (loop starts at filter 1, maxiMFCC.h:149);
 // the harness zeroes that column after setup() so the oracle is deterministic.

@@ -147,3 +147,32 @@ def test_mfcc_melraw_bit_exact_and_mfma(mx, port):
     raw2 = m.melraw.numpy()
     assert np.abs(raw2 - raw_exp).max() <= MFMA_RTOL * np.abs(raw_exp).max()
     assert np.abs(out2 - emf).max() <= MFMA_RTOL * scale * 10
+
+
+@pytest.mark.parametrize("fftSize", [1024, 64, 8])
+def test_fft_features(mx, port, fftSize):
+    """magsToDB / spectralFlatness / spectralCentroid (L/fft.cpp:526-534, L/maxiFFT.cpp:113-132).
+    centroid: float + - * / only, sequential over bins -> bit-exact.  dB: one device log10f vs
+    glibc's, times 20 -> <= 4 ULP of the float result (measured: 3).  flatness: a float sum of `bins` device logf, then expf -> the
+    1-ULP-per-term differences random-walk; bound 4e-6 relative (measured ~1e-6)."""
+    rng = np.random.default_rng(fftSize)
+    bins, n = fftSize // 2, 333
+    m = np.abs(rng.normal(0, 30, (n, bins))).astype(np.float32)
+    m[5] = 0                      # all-zero frame: flatness 0 / centroid 0 branches
+    m[6, ::3] = 0                 # zeros skipped by the log sum
+    m[7, : bins // 2] = 5e-7      # below the dB floor
+    m[8] = -m[8]                  # negative magnitudes: fabs in the centroid, NaN in the flatness
+    f = mx.maxiFFT()
+    f.setup(fftSize, fftSize // 2, fftSize)
+    dm = mx.DeviceBuffer.from_numpy(m)
+    eflat, ecen = port.fft_features(m, fftSize)
+    edb = port.fft_to_db(m)
+    assert_bits_equal(f.spectralCentroid(dm).numpy(), ecen, "centroid")
+    db = f.magsToDB(dm).numpy()
+    assert np.array_equal(db == 0, edb == 0)
+    assert np.abs(db.view(np.int32).astype(np.int64) - edb.view(np.int32).astype(np.int64)).max() <= 4  # ULPs (all >= 0)
+    flat = f.spectralFlatness(dm).numpy()
+    assert np.array_equal(np.isnan(flat), np.isnan(eflat)) and np.isnan(eflat[8])
+    ok = ~np.isnan(eflat)
+    np.testing.assert_allclose(flat[ok], eflat[ok], rtol=4e-6, atol=0)
+    assert flat[5] == 0 and ecen[5] == 0
