@@ -305,7 +305,13 @@ int mxg_grain_plan_window(const mxg_grain_plan *plan, double *h_window); /* retu
 /* S independent streams over one shared sample (mxg_sample_upload), T samples each, d_out[n*S + s].
  * mode 0 = maxiTimeStretch<F>::play(speed = a[s], grainLength, overlaps, posMod[s]) (:341-355);
  * mode 1 = maxiStretch<F>::play(pitchstretch = a[s], timestretch = b[s], grainLength, overlaps,
- * posMod[s]) with the default loop (whole sample) (:512-530).  d_posmod may be NULL (0).
+ * posMod[s]) with the default loop (whole sample) (:512-530);
+ * mode 2 = maxiTimeStretch<F>::playAtPosition(pos = a[n*S + s], grainLength, overlaps) (:359-367):
+ * d_a is the per-sample [T][S] position signal, the member `position` is not touched;
+ * mode 3 = maxiPitchShift<F>::play(speed = a[s], grainLength, overlaps, posMod[s]) (:412-430): the
+ * `looper` slot of d_st holds the member `cycles` (a long), grains are born with
+ * speed - (cycleMod/cycleLength)*0.1 and therefore arbitrary increments; no rand() is drawn.
+ * d_posmod may be NULL (0).
  * d_rnd: int32 [S][R], the values `rand() % 10` returns at each spawn, consumed in order per
  * stream (NULL = 0): the reference draws them from the process-wide rand() stream, which a bank
  * cannot reproduce.  State, in/out: d_st = [4][S] position, looper, randomOffset, rand cursor

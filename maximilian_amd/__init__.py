@@ -10,4 +10,4 @@ from .banks import (DeviceBuffer, maxiSettings, maxiOscBank, maxiFilterBank, max
                     maxiVoiceBank, maxiMixBank, maxiDelaylineBank, maxiSampleBank, OSC_WAVEFORMS,
                     FILTER_KINDS, SAMPLE_MODES)
 from .spectral import maxiFFT, maxiMFCC, frames_in_stream, padded_stream  # noqa: F401
-from .grains import maxiTimeStretchBank, maxiStretchBank, WINDOWS  # noqa: F401
+from .grains import maxiTimeStretchBank, maxiStretchBank, maxiPitchShiftBank, WINDOWS  # noqa: F401

@@ -64,6 +64,121 @@ double window_value(int kind, unsigned long windowLength, unsigned long windowPo
     }
 }
 
+// ---- the per-stream scheduler, one sample at a time ---------------------------------------------
+// MODE 0 maxiTimeStretch::play :341-355, 1 maxiStretch::play :512-530 (loop = whole sample),
+// 2 maxiTimeStretch::playAtPosition :359-367 (a = per-sample pos [T][S]; `position` untouched),
+// 3 maxiPitchShift::play :412-430 (the `looper` slot holds the member `cycles`, a long).
+struct SchedConst {
+    double dlen, cycleLength, grainLength, sr, pm, speed, rate;
+    int sampleDur;
+    const double *a_ps;   // MODE 2: &pos[0][s], stride S
+    size_t S;
+    const int32_t *rnd;   // this stream's rand()%10 draws (or null)
+    size_t R;
+};
+struct SchedState {
+    double position, looper, randomOffset, thr;
+    size_t cursor;
+};
+
+// maxiGrain ctor (L/maxiGrains.h:160-181): where the grain starts and its per-sample increment
+__device__ __forceinline__ void grain_birth(const SchedConst &c, double p01, const double grainSpeed,
+                                            double &pos0, double &inc) {
+    p01 = 1.0 < p01 ? 1.0 : p01;  // max(min(1.0, .), 0.0)
+    p01 = p01 < 0.0 ? 0.0 : p01;
+    const double startPos = floor(c.dlen * p01);  // (unsigned long)(len*pos), pos >= 0
+    double endPos = startPos + (double)c.sampleDur;
+    endPos = c.dlen < endPos ? c.dlen : endPos;
+    const double frequency = (1.0 / c.grainLength) * grainSpeed;
+    pos0 = frequency > 0 ? startPos : endPos;
+    inc = (frequency != 0) ? (double)c.sampleDur / (c.sr / frequency) : 0.0;
+}
+
+// `randomOffset = rand() % 10` (:352 / :525) from the caller-supplied draws
+__device__ __forceinline__ void sched_draw(SchedState &q, const SchedConst &c, int &failed) {
+    if (c.rnd) {
+        if (q.cursor < c.R) q.randomOffset = (double)c.rnd[q.cursor]; else { failed = 2; q.randomOffset = 0; }
+        q.cursor++;
+    } else {
+        q.randomOffset = 0;
+    }
+    q.thr = c.cycleLength + q.randomOffset;
+}
+
+// modes 0/1: the body of `if (looper > cycleLength + randomOffset)` (:347-353 / :519-526)
+template <int MODE>
+__device__ __forceinline__ void sched_spawn01(SchedState &q, const SchedConst &c, double &pos0, double &inc,
+                                              int &failed) {
+    q.looper -= q.thr;
+    const double grainSpeed = MODE == 0 ? (c.speed > 0 ? 1.0 : -1.0) : c.speed;  // :350
+    grain_birth(c, (q.position / c.dlen) + c.pm, grainSpeed, pos0, inc);
+    sched_draw(q, c, failed);
+}
+
+// advances the scheduler by one sample; true if a grain (pos0, inc) is born at this sample
+template <int MODE>
+__device__ __forceinline__ bool sched_step(SchedState &q, const SchedConst &c, size_t n, double &pos0,
+                                           double &inc, int &failed) {
+    if constexpr (MODE == 2) {
+        q.looper += 1.0;
+        double pos = c.a_ps[n * c.S];
+        pos *= c.dlen;
+        if (0 == floor(fmod(q.looper, c.cycleLength))) {  // :362
+            grain_birth(c, (pos / c.dlen), 1.0, pos0, inc);
+            return true;
+        }
+        return false;
+    } else if constexpr (MODE == 3) {
+        q.position = q.position + 1;
+        q.looper += 1.0;  // cycles++
+        if (q.position > c.dlen) q.position = 0;
+        if (q.position < 0) q.position = c.dlen;
+        const double cycleMod = fmod(q.looper, c.cycleLength + q.randomOffset);
+        if (0 == floor(cycleMod)) {
+            const double sp = c.speed - ((cycleMod / c.cycleLength) * 0.1);  // :421
+            grain_birth(c, (q.position / c.dlen) + c.pm, sp, pos0, inc);
+            return true;
+        }
+        return false;
+    } else {
+        q.position = q.position + c.rate;
+        q.looper += 1.0;
+        if (MODE == 0) {
+            if (q.position > c.dlen) q.position -= c.dlen;
+            if (q.position < 0) q.position += c.dlen;
+        } else {  // loopStart 0, loopEnd = loopLength = len (maxiStretch ctor :469-477)
+            if (q.position >= c.dlen) q.position -= c.dlen;
+            if (q.position < 0.0) q.position += c.dlen;
+        }
+        if (q.looper > q.thr) {
+            sched_spawn01<MODE>(q, c, pos0, inc, failed);
+            return true;
+        }
+        return false;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ SchedConst sched_const(size_t s, size_t S, size_t len, size_t R, const double *a,
+                                                  const double *b, const double *posMod, const int32_t *rnd,
+                                                  double cycleLength, double grainLength, double sr,
+                                                  int sampleDur) {
+    SchedConst c;
+    c.dlen = (double)len;
+    c.cycleLength = cycleLength;
+    c.grainLength = grainLength;
+    c.sr = sr;
+    c.pm = posMod ? posMod[s] : 0.0;
+    c.speed = MODE == 2 ? 1.0 : a[s];
+    c.rate = MODE == 1 ? b[s] : c.speed;  // what advances `position` each sample (modes 0/1)
+    c.sampleDur = sampleDur;
+    c.a_ps = a + s;
+    c.S = S;
+    c.rnd = rnd ? rnd + s * R : nullptr;
+    c.R = R;
+    return c;
+}
+
 struct GrainArgs {
     size_t S, T, len, R;
     const double *amp, *window, *a, *b, *posMod;
@@ -87,8 +202,10 @@ __global__ __launch_bounds__(64) void granular_kernel(GrainArgs A) {
     if (s >= A.S) return;
     const size_t S = A.S;
     const double dlen = (double)A.len;
-    double position = A.st[s], looper = A.st[S + s], randomOffset = A.st[2 * S + s];
-    size_t cursor = (size_t)A.st[3 * S + s];
+    SchedState q = {A.st[s], A.st[S + s], A.st[2 * S + s], 0.0, (size_t)A.st[3 * S + s]};
+    const SchedConst sc = sched_const<MODE>(s, S, A.len, A.R, A.a, A.b, A.posMod, A.rnd, A.cycleLength,
+                                            A.grainLength, A.sr, A.sampleDur);
+    q.thr = A.cycleLength + q.randomOffset;
     double gpos[kSlots], ginc[kSlots];
     int gidx[kSlots], gdur[kSlots];
     int tail = 0;
@@ -100,29 +217,12 @@ __global__ __launch_bounds__(64) void granular_kernel(GrainArgs A) {
         gdur[k] = (int)A.gst[(3 * kSlots + k) * S + s];
         if (gdur[k]) tail = k + 1;
     }
-    const double speed = A.a[s];
-    const double rate = MODE == 0 ? speed : A.b[s];  // what advances `position` each sample
-    const double pm = A.posMod ? A.posMod[s] : 0.0;
-    // maxiGrain ctor values that are the same for every grain this stream spawns in this launch
-    // (L/maxiGrains.h:160-181): sampleDur, freq = 1/dur, frequency = freq*speed, inc.
-    const double grainSpeed = MODE == 0 ? (speed > 0 ? 1.0 : -1.0) : speed;  // :350
-    const double frequency = (1.0 / A.grainLength) * grainSpeed;
-    const double newInc = (frequency != 0) ? (double)A.sampleDur / (A.sr / frequency) : 0.0;
     int failed = 0;
     double *op = A.out + s;
     for (size_t n = 0; n < A.T; n++) {
-        // ---- scheduler: maxiTimeStretch::play :342-353 / maxiStretch::play :514-525
-        position = position + rate;
-        looper += 1.0;
-        if (MODE == 0) {
-            if (position > dlen) position -= dlen;
-            if (position < 0) position += dlen;
-        } else {  // loopStart 0, loopEnd = loopLength = len (maxiStretch ctor :469-477)
-            if (position >= dlen) position -= dlen;
-            if (position < 0.0) position += dlen;
-        }
-        if (looper > A.cycleLength + randomOffset) {
-            looper -= (A.cycleLength + randomOffset);
+        // ---- scheduler (sched_step: the reference's play() up to the addGrain)
+        double bornPos, bornInc;
+        if (sched_step<MODE>(q, sc, n, bornPos, bornInc, failed)) {
             if (tail == kSlots) {  // compact the holes (only non-FIFO deaths leave any)
 #pragma unroll
                 for (int pass = 0; pass < kSlots - 1; pass++)
@@ -140,25 +240,12 @@ __global__ __launch_bounds__(64) void granular_kernel(GrainArgs A) {
             if (tail == kSlots) {
                 failed = 1;  // more than 8 grains alive: reported through *err, stream keeps running
             } else {
-                double p01 = (position / dlen) + pm;
-                p01 = 1.0 < p01 ? 1.0 : p01;
-                p01 = p01 < 0.0 ? 0.0 : p01;
-                const double startPos = floor(dlen * p01);  // (unsigned long)(len*pos), pos >= 0
-                double endPos = startPos + (double)A.sampleDur;
-                endPos = dlen < endPos ? dlen : endPos;
-                const double pos0 = frequency > 0 ? startPos : endPos;
 #pragma unroll
                 for (int k = 0; k < kSlots; k++)
                     if (k == tail) {
-                        gpos[k] = pos0; ginc[k] = newInc; gidx[k] = 0; gdur[k] = A.sampleDur;
+                        gpos[k] = bornPos; ginc[k] = bornInc; gidx[k] = 0; gdur[k] = A.sampleDur;
                     }
                 tail++;
-            }
-            if (A.rnd) {
-                if (cursor < A.R) randomOffset = (double)A.rnd[s * A.R + cursor]; else { failed = 2; randomOffset = 0; }
-                cursor++;
-            } else {
-                randomOffset = 0;
             }
         }
         // ---- maxiGrainPlayer::play :270-283: sum the live grains in creation order
@@ -198,10 +285,10 @@ __global__ __launch_bounds__(64) void granular_kernel(GrainArgs A) {
     }
     if (failed) atomicMax(A.err, failed);
     // state out, compacted (live grains first, creation order)
-    A.st[s] = position;
-    A.st[S + s] = looper;
-    A.st[2 * S + s] = randomOffset;
-    A.st[3 * S + s] = (double)cursor;
+    A.st[s] = q.position;
+    A.st[S + s] = q.looper;
+    A.st[2 * S + s] = q.randomOffset;
+    A.st[3 * S + s] = (double)q.cursor;
 #pragma unroll
     for (int pass = 0; pass < kSlots - 1; pass++)
 #pragma unroll
@@ -237,6 +324,7 @@ struct SchedArgs {
     double *st;
     int32_t *spawn_n;    // [G][S]
     double *spawn_pos;   // [G][S]
+    double *spawn_inc;   // [G][S]
     int32_t *chunk_first;  // [C+1][S]: spawns before sample c*Tc
     int *err;
     double sr, cycleLength, grainLength;
@@ -350,94 +438,55 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
     if (s >= A.S) return;
     const size_t S = A.S;
     const double dlen = (double)A.len;
-    double position = A.st[s], looper = A.st[S + s], randomOffset = A.st[2 * S + s];
-    size_t cursor = (size_t)A.st[3 * S + s];
-    const double speed = A.a[s];
-    const double rate = MODE == 0 ? speed : A.b[s];
-    const double pm = A.posMod ? A.posMod[s] : 0.0;
-    const double grainSpeed = MODE == 0 ? (speed > 0 ? 1.0 : -1.0) : speed;
-    const double frequency = (1.0 / A.grainLength) * grainSpeed;
+    SchedState q = {A.st[s], A.st[S + s], A.st[2 * S + s], 0.0, (size_t)A.st[3 * S + s]};
+    const SchedConst sc = sched_const<MODE>(s, S, A.len, A.R, A.a, A.b, A.posMod, A.rnd, A.cycleLength,
+                                            A.grainLength, A.sr, A.sampleDur);
+    const double rate = sc.rate;
     int count = 0;
     int failed = 0;
     // The serial part of a stream: keep this loop to the recurrences themselves (the chunk table is
     // derived from the spawn list afterwards).  thr = cycleLength + randomOffset changes only at a spawn.
-    double thr = A.cycleLength + randomOffset;
+    q.thr = A.cycleLength + q.randomOffset;
     const int Tn = (int)A.T;
-    auto do_spawn = [&](int n) {  // the body of `if (looper > cycleLength + randomOffset)` (:347-353)
-        looper -= thr;
-        double p01 = (position / dlen) + pm;
-        p01 = 1.0 < p01 ? 1.0 : p01;
-        p01 = p01 < 0.0 ? 0.0 : p01;
-        const double startPos = floor(dlen * p01);
-        double endPos = startPos + (double)A.sampleDur;
-        endPos = dlen < endPos ? dlen : endPos;
+    auto record = [&](int n, double pos0, double inc) {
         if ((size_t)count < A.G) {
             A.spawn_n[(size_t)count * S + s] = n;
-            A.spawn_pos[(size_t)count * S + s] = frequency > 0 ? startPos : endPos;
+            A.spawn_pos[(size_t)count * S + s] = pos0;
+            A.spawn_inc[(size_t)count * S + s] = inc;
         } else {
             failed = 3;
         }
         count++;
-        if (A.rnd) {
-            if (cursor < A.R) randomOffset = (double)A.rnd[s * A.R + cursor]; else { failed = 2; randomOffset = 0; }
-            cursor++;
-        } else {
-            randomOffset = 0;
-        }
-        thr = A.cycleLength + randomOffset;
     };
-    const bool fast = A.fast && rate > 0.0 && position >= 0.0 && position <= dlen && looper >= 0.0 && thr > 1.0;
     int nstart = 0;
-    if (fast) {
-        // event-driven: jump from spawn to spawn (looper), dragging position along (with its wraps)
-        int n = 0;
-        while (n < Tn) {
-            bool spawn;
-            const int k = advance_until(looper, 1.0, thr, false, Tn - n, spawn);
-            int rem = k;
-            while (rem > 0) {
-                bool wrapped;
-                rem -= advance_until(position, rate, dlen, MODE == 1, rem, wrapped);
-                if (wrapped) position -= dlen;  // :344 / :516 (the `< 0` branch cannot fire for rate > 0)
+    if constexpr (MODE <= 1) {
+        const bool fast = A.fast && rate > 0.0 && q.position >= 0.0 && q.position <= dlen && q.looper >= 0.0 &&
+                          q.thr > 1.0;
+        if (fast) {
+            // event-driven: jump from spawn to spawn (looper), dragging position along (with its wraps)
+            int n = 0;
+            while (n < Tn) {
+                bool spawn;
+                const int k = advance_until(q.looper, 1.0, q.thr, false, Tn - n, spawn);
+                int rem = k;
+                while (rem > 0) {
+                    bool wrapped;
+                    rem -= advance_until(q.position, rate, dlen, MODE == 1, rem, wrapped);
+                    if (wrapped) q.position -= dlen;  // :344 / :516 (the `< 0` branch cannot fire for rate > 0)
+                }
+                n += k;
+                if (spawn) {
+                    double pos0, inc;
+                    sched_spawn01<MODE>(q, sc, pos0, inc, failed);
+                    record(n - 1, pos0, inc);
+                }
             }
-            n += k;
-            if (spawn) do_spawn(n - 1);
+            nstart = Tn;
         }
-        nstart = Tn;
     }
     for (int n = nstart; n < Tn; n++) {
-        position = position + rate;
-        looper += 1.0;
-        if (MODE == 0) {
-            if (position > dlen) position -= dlen;
-            if (position < 0) position += dlen;
-        } else {
-            if (position >= dlen) position -= dlen;
-            if (position < 0.0) position += dlen;
-        }
-        if (looper > thr) {
-            looper -= thr;
-            double p01 = (position / dlen) + pm;
-            p01 = 1.0 < p01 ? 1.0 : p01;
-            p01 = p01 < 0.0 ? 0.0 : p01;
-            const double startPos = floor(dlen * p01);
-            double endPos = startPos + (double)A.sampleDur;
-            endPos = dlen < endPos ? dlen : endPos;
-            if ((size_t)count < A.G) {
-                A.spawn_n[(size_t)count * S + s] = n;
-                A.spawn_pos[(size_t)count * S + s] = frequency > 0 ? startPos : endPos;
-            } else {
-                failed = 3;
-            }
-            count++;
-            if (A.rnd) {
-                if (cursor < A.R) randomOffset = (double)A.rnd[s * A.R + cursor]; else { failed = 2; randomOffset = 0; }
-                cursor++;
-            } else {
-                randomOffset = 0;
-            }
-            thr = A.cycleLength + randomOffset;
-        }
+        double pos0, inc;
+        if (sched_step<MODE>(q, sc, (size_t)n, pos0, inc, failed)) record(n, pos0, inc);
     }
     {   // chunk_first[c] = number of spawns before sample c*Tc (spawn_n is increasing)
         const int stored = (size_t)count < A.G ? count : (int)A.G;
@@ -449,24 +498,23 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
         }
     }
     if (failed) atomicMax(A.err, failed);
-    A.st[s] = position;
-    A.st[S + s] = looper;
-    A.st[2 * S + s] = randomOffset;
-    A.st[3 * S + s] = (double)cursor;
+    A.st[s] = q.position;
+    A.st[S + s] = q.looper;
+    A.st[2 * S + s] = q.randomOffset;
+    A.st[3 * S + s] = (double)q.cursor;
 }
 
 struct RenderArgs {
     size_t S, T, len, G, Tc, C;
-    const double *amp, *window, *a;
+    const double *amp, *window;
     const int32_t *spawn_n;
-    const double *spawn_pos;
+    const double *spawn_pos, *spawn_inc;
     const int32_t *chunk_first;
     const double *gst_in;  // carried-in grains (state before the launch)
     double *gst_out;       // grains alive after sample T-1 (written by the last chunk's lanes)
     double *out;
     int *err;
-    double sr, grainLength;
-    int sampleDur, winInLds, mode;
+    int sampleDur, winInLds;
 };
 
 // one maxiGrain::play step (L/maxiGrains.h:216-245) on (pos, idx); returns the windowed sample
@@ -517,12 +565,6 @@ __global__ __launch_bounds__(64) void granular_render_kernel(RenderArgs A) {
     const size_t s = gid % S, c = gid / S;  // consecutive lanes = consecutive streams of one chunk
     const double dlen = (double)A.len;
     const size_t n0 = c * A.Tc, n1 = (n0 + A.Tc < A.T) ? n0 + A.Tc : A.T;
-    // per-stream grain constants (maxiGrain ctor, L/maxiGrains.h:160-181)
-    const double speed = A.a[s];
-    const double grainSpeed = A.mode == 0 ? (speed > 0 ? 1.0 : -1.0) : speed;
-    const double frequency = (1.0 / A.grainLength) * grainSpeed;
-    const double newInc = (frequency != 0) ? (double)A.sampleDur / (A.sr / frequency) : 0.0;
-
     double gpos[kSlots], ginc[kSlots];
     int gidx[kSlots], gdur[kSlots];
     int tail = 0, failed = 0;
@@ -552,7 +594,8 @@ __global__ __launch_bounds__(64) void granular_render_kernel(RenderArgs A) {
     for (int j = j0; j < first; j++) {
         const int born = A.spawn_n[(size_t)j * S + s];
         const int steps = (int)n0 - born;
-        push(grain_advance(A.spawn_pos[(size_t)j * S + s], newInc, dlen, steps), newInc, steps, A.sampleDur);
+        const double inc = A.spawn_inc[(size_t)j * S + s];
+        push(grain_advance(A.spawn_pos[(size_t)j * S + s], inc, dlen, steps), inc, steps, A.sampleDur);
     }
     // (3) the chunk itself
     int jn = first;
@@ -575,7 +618,7 @@ __global__ __launch_bounds__(64) void granular_render_kernel(RenderArgs A) {
                 for (int k = 0; k < kSlots; k++)
                     if (gdur[k]) tail = k + 1;
             }
-            push(A.spawn_pos[(size_t)jn * S + s], newInc, 0, A.sampleDur);
+            push(A.spawn_pos[(size_t)jn * S + s], A.spawn_inc[(size_t)jn * S + s], 0, A.sampleDur);
             jn++;
             nextSpawn = jn < jend ? A.spawn_n[(size_t)jn * S + s] : -1;
         }
@@ -912,9 +955,11 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
                         double *d_out, void *stream) {
     if (int s = ensure_init()) return s;
     MXG_REQUIRE(p && p->d_window, "null plan (or plan created without a HIP device)");
-    MXG_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (maxiTimeStretch) or 1 (maxiStretch)");
+    MXG_REQUIRE(mode >= 0 && mode <= 3,
+                "mode must be 0 (maxiTimeStretch::play), 1 (maxiStretch::play), 2 (playAtPosition) or 3 "
+                "(maxiPitchShift::play)");
     MXG_REQUIRE(d_samples && d_a && d_st && d_gst && d_out, "null device pointer");
-    MXG_REQUIRE(mode == 0 || d_b, "maxiStretch needs d_b (timestretch)");
+    MXG_REQUIRE(mode != 1 || d_b, "maxiStretch needs d_b (timestretch)");
     MXG_REQUIRE(len > 0 && overlaps > 0, "empty sample or overlaps <= 0");
     if (S == 0 || T == 0) return MXG_OK;
     hipStream_t st = resolve_stream(stream);
@@ -936,10 +981,12 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
     if (!A.winInLds) lds = 0;
     dim3 grid((unsigned)((S + 63) / 64));
     if (!tune_get("grain_chunked")) {  // K8: one lane per stream, serial in time
-        if (mode == 0)
-            hipLaunchKernelGGL((granular_kernel<0>), grid, dim3(64), lds, st, A);
-        else
-            hipLaunchKernelGGL((granular_kernel<1>), grid, dim3(64), lds, st, A);
+        switch (mode) {
+            case 0: hipLaunchKernelGGL((granular_kernel<0>), grid, dim3(64), lds, st, A); break;
+            case 1: hipLaunchKernelGGL((granular_kernel<1>), grid, dim3(64), lds, st, A); break;
+            case 2: hipLaunchKernelGGL((granular_kernel<2>), grid, dim3(64), lds, st, A); break;
+            default: hipLaunchKernelGGL((granular_kernel<3>), grid, dim3(64), lds, st, A); break;
+        }
     } else {  // K8a scheduler pre-pass + K8b (stream, chunk) render
         // K8c eligibility: maxiTimeStretch, inc exactly 1.0 (the device evaluates the same IEEE division),
         // carried-in grains on the integer grid too, a window index that exists for every read
@@ -966,7 +1013,7 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         C = (T + Tc - 1) / Tc;
         const double minCycle = A.cycleLength;  // randomOffset >= 0 only lengthens a cycle
         const size_t G = (size_t)((double)T / (minCycle > 1.0 ? floor(minCycle) : 1.0)) + 2;
-        const size_t nd = G * S + 4 * kSlots * S;             // doubles: spawn_pos | gst copy
+        const size_t nd = 2 * G * S + 4 * kSlots * S;         // doubles: spawn_pos | spawn_inc | gst copy
         const size_t ni = G * S + (C + 1) * S;                // int32: spawn_n | chunk_first
         const size_t bytes = nd * sizeof(double) + ni * sizeof(int32_t);
         if (g_sched_scratch_cap < bytes) {
@@ -977,20 +1024,24 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
             g_sched_scratch_cap = bytes;
         }
         double *spawn_pos = (double *)g_sched_scratch;
-        double *gst_copy = spawn_pos + G * S;
+        double *spawn_inc = spawn_pos + G * S;
+        double *gst_copy = spawn_inc + G * S;
         int32_t *spawn_n = (int32_t *)(gst_copy + 4 * kSlots * S);
         int32_t *chunk_first = spawn_n + G * S;
         MXG_HIP(hipMemcpyAsync(gst_copy, d_gst, sizeof(double) * 4 * kSlots * S, hipMemcpyDeviceToDevice, st));
         SchedArgs Q;
         Q.S = S; Q.T = T; Q.len = len; Q.R = R; Q.G = G; Q.Tc = Tc; Q.C = C;
         Q.a = d_a; Q.b = d_b; Q.posMod = d_posmod; Q.rnd = d_rnd; Q.st = d_st;
-        Q.spawn_n = spawn_n; Q.spawn_pos = spawn_pos; Q.chunk_first = chunk_first; Q.err = g_err;
+        Q.spawn_n = spawn_n; Q.spawn_pos = spawn_pos; Q.spawn_inc = spawn_inc; Q.chunk_first = chunk_first;
+        Q.err = g_err;
         Q.sr = A.sr; Q.cycleLength = A.cycleLength; Q.grainLength = A.grainLength; Q.sampleDur = A.sampleDur;
         Q.fast = tune_get("grain_fast_sched");
-        if (mode == 0)
-            hipLaunchKernelGGL((granular_sched_kernel<0>), grid, dim3(64), 0, st, Q);
-        else
-            hipLaunchKernelGGL((granular_sched_kernel<1>), grid, dim3(64), 0, st, Q);
+        switch (mode) {
+            case 0: hipLaunchKernelGGL((granular_sched_kernel<0>), grid, dim3(64), 0, st, Q); break;
+            case 1: hipLaunchKernelGGL((granular_sched_kernel<1>), grid, dim3(64), 0, st, Q); break;
+            case 2: hipLaunchKernelGGL((granular_sched_kernel<2>), grid, dim3(64), 0, st, Q); break;
+            default: hipLaunchKernelGGL((granular_sched_kernel<3>), grid, dim3(64), 0, st, Q); break;
+        }
         if (unit) {
             UnitArgs U;
             U.S = S; U.T = T; U.len = len; U.G = G; U.C = C;
@@ -1002,11 +1053,10 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         } else {
         RenderArgs Rr;
         Rr.S = S; Rr.T = T; Rr.len = len; Rr.G = G; Rr.Tc = Tc; Rr.C = C;
-        Rr.amp = d_samples; Rr.window = p->d_window; Rr.a = d_a;
-        Rr.spawn_n = spawn_n; Rr.spawn_pos = spawn_pos; Rr.chunk_first = chunk_first;
+        Rr.amp = d_samples; Rr.window = p->d_window;
+        Rr.spawn_n = spawn_n; Rr.spawn_pos = spawn_pos; Rr.spawn_inc = spawn_inc; Rr.chunk_first = chunk_first;
         Rr.gst_in = gst_copy; Rr.gst_out = d_gst; Rr.out = d_out; Rr.err = g_err;
-        Rr.sr = A.sr; Rr.grainLength = A.grainLength; Rr.sampleDur = A.sampleDur; Rr.winInLds = A.winInLds;
-        Rr.mode = mode;
+        Rr.sampleDur = A.sampleDur; Rr.winInLds = A.winInLds;
         const size_t lanes = S * C;
         hipLaunchKernelGGL(granular_render_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), lds, st, Rr);
         }

@@ -42,8 +42,13 @@ class _GranularBank(_Bank):
             self._plans[key] = p
         return self._plans[key]
 
-    def _render(self, a, b, grainLength, overlaps, posMod, N, rnd, out):
-        da = _as_dev(a, self.V)
+    def _render(self, a, b, grainLength, overlaps, posMod, N, rnd, out, mode=None):
+        mode = self.MODE if mode is None else mode
+        if mode == 2:   # per-sample position signal [N][S]
+            da = a if (isinstance(a, DeviceBuffer) or hasattr(a, "data_ptr")) else \
+                DeviceBuffer.from_numpy(np.ascontiguousarray(a, np.float64).reshape(N, self.V))
+        else:
+            da = _as_dev(a, self.V)
         db = None if b is None else _as_dev(b, self.V)
         dp = None if posMod is None else _as_dev(posMod, self.V)
         dr, R = None, 0
@@ -51,7 +56,7 @@ class _GranularBank(_Bank):
             r = np.ascontiguousarray(rnd, np.int32).reshape(self.V, -1)
             dr, R = DeviceBuffer.from_numpy(r), r.shape[1]
         out = self._out(N, out)
-        check(lib().mxg_granular_render(self._plan(grainLength), self.MODE, self.V, N, self.sample.d_samples,
+        check(lib().mxg_granular_render(self._plan(grainLength), mode, self.V, N, self.sample.d_samples,
                                         self.sample.getLength(), int(overlaps), _ptr(da), _ptr(db), _ptr(dp),
                                         _ptr(dr), R, self.state.ptr, self.grains.ptr, _ptr(out), self.stream),
               "mxg_granular_render")
@@ -75,6 +80,19 @@ class maxiTimeStretchBank(_GranularBank):
 
     def play(self, speed, grainLength, overlaps, N, posMod=None, rnd=None, out=None):
         return self._render(speed, None, grainLength, overlaps, posMod, N, rnd, out)
+
+    def playAtPosition(self, pos, grainLength, overlaps, out=None):
+        """maxiTimeStretch::playAtPosition (L/maxiGrains.h:359-367): `pos` is the [N][S] per-sample
+        normalised position signal the caller iterates itself."""
+        return self._render(pos, None, grainLength, overlaps, None, pos.shape[0], None, out, mode=2)
+
+
+class maxiPitchShiftBank(_GranularBank):
+    """S x maxiPitchShift<F> (L/maxiGrains.h:374-432).  state[1] is the member `cycles`."""
+    MODE = 3
+
+    def play(self, speed, grainLength, overlaps, N, posMod=None, out=None):
+        return self._render(speed, None, grainLength, overlaps, posMod, N, None, out)
 
 
 class maxiStretchBank(_GranularBank):

@@ -1356,6 +1356,9 @@ static int grain_play(grain_t *g, const double *buffer, size_t len, const double
  * objects over one shared sample, T samples each; out[n*S + s].
  *   mode 0: play(speed=a[s], grainLength, overlaps, posMod[s])                (:341-355)
  *   mode 1: play(pitchstretch=a[s], timestretch=b[s], grainLength, overlaps, posMod[s]) (:512-530)
+ *   mode 2: maxiTimeStretch::playAtPosition(pos=a[n*S+s] (per sample), grainLength, overlaps) (:359-367)
+ *   mode 3: maxiPitchShift::play(speed=a[s], grainLength, overlaps, posMod[s])  (:412-430); the
+ *           `looper` slot of st holds the member `cycles` (long)
  * rnd: the values `rand() % 10` would have returned, consumed in order per stream, [S][R]
  * (NULL = all 0); the global rand() stream itself is not reproducible across a bank.
  * st = [4][S]: position, looper, randomOffset, rand cursor.  gst = [4][8][S]: per slot pos, inc,
@@ -1365,7 +1368,7 @@ static int grain_play(grain_t *g, const double *buffer, size_t len, const double
 int mxo_granular(int mode, int window_kind, size_t S, size_t T, const double *amp, size_t len,
                  int mySampleRate, double grainLength, int overlaps, const double *a, const double *b,
                  const double *posMod, const int32_t *rnd, size_t R, double *st, double *gst, double *out) {
-    if (mode < 0 || mode > 1 || overlaps <= 0) return -1;
+    if (mode < 0 || mode > 3 || overlaps <= 0) return -1;
     unsigned long sampleDur = grainLength * (double)mySampleRate;
     if (sampleDur == 0 || sampleDur >= (unsigned long)(g_sampleRate / 2.0)) return -2; /* cacheSize :98 */
     double *window = (double *)malloc(sizeof(double) * sampleDur);
@@ -1385,43 +1388,69 @@ int mxo_granular(int mode, int window_kind, size_t S, size_t T, const double *am
         }
         const unsigned long loopStart = 0, loopEnd = len, loopLength = len; /* maxiStretch ctor :469-477 */
         for (size_t n = 0; n < T; n++) {
-            double speed = a[s];
-            int spawn = 0;
-            double grainSpeed = 0;
-            if (mode == 0) {
-                position = position + speed;
-                looper++;
-                if (position > len) position -= len;
-                if (position < 0) position += len;
-            } else {
-                position = position + (1 * b[s]);
-                looper++;
-                if (position >= loopEnd) position -= loopLength;
-                if (position < loopStart) position += loopLength;
-            }
+            double speed = mode == 2 ? 0.0 : a[s];
+            int spawn = 0, draws = 0;
+            double grainSpeed = 0, grainPos = 0;
             double cycleLength = grainLength * g_sampleRate / overlaps;
-            if (looper > cycleLength + randomOffset) {
-                looper -= (cycleLength + randomOffset);
-                grainSpeed = mode == 0 ? (speed > 0 ? 1 : -1) : speed;
-                spawn = 1;
+            if (mode == 2) { /* playAtPosition :359-367 (position is not touched) */
+                double pos = a[n * S + s];
+                looper++;
+                pos *= len;
+                if (0 == floor(fmod(looper, grainLength * g_sampleRate / overlaps))) {
+                    grainPos = (pos / len);
+                    grainSpeed = 1;
+                    spawn = 1;
+                }
+            } else if (mode == 3) { /* maxiPitchShift::play :412-430 (looper holds `cycles`) */
+                position = position + 1;
+                looper++;
+                if (position > len) position = 0;
+                if (position < 0) position = len;
+                double cycleMod = fmod((long)looper, cycleLength + randomOffset);
+                if (0 == floor(cycleMod)) {
+                    grainSpeed = speed - ((cycleMod / cycleLength) * 0.1);
+                    grainPos = (position / len) + (posMod ? posMod[s] : 0.0);
+                    spawn = 1;
+                }
+            } else {
+                if (mode == 0) {
+                    position = position + speed;
+                    looper++;
+                    if (position > len) position -= len;
+                    if (position < 0) position += len;
+                } else {
+                    position = position + (1 * b[s]);
+                    looper++;
+                    if (position >= loopEnd) position -= loopLength;
+                    if (position < loopStart) position += loopLength;
+                }
+                if (looper > cycleLength + randomOffset) {
+                    looper -= (cycleLength + randomOffset);
+                    grainSpeed = mode == 0 ? (speed > 0 ? 1 : -1) : speed;
+                    grainPos = (position / len) + (posMod ? posMod[s] : 0.0);
+                    spawn = 1;
+                    draws = 1; /* randomOffset = rand() % 10, :352 / :525 */
+                }
             }
             if (spawn) {
                 if (count == MXO_GRAIN_SLOTS) {
                     rc = -3;
                     break;
                 }
-                double p01 = (position / len) + (posMod ? posMod[s] : 0.0);
+                double p01 = grainPos;
                 p01 = 1.0 < p01 ? 1.0 : p01; /* min(1.0, x) */
                 p01 = p01 < 0.0 ? 0.0 : p01; /* max(x, 0.0) */
                 grain_init(&g[count++], len, mySampleRate, p01, grainLength, grainSpeed);
-                if (rnd) {
-                    if (cursor >= R) {
-                        rc = -4;
-                        break;
-                    }
-                    randomOffset = rnd[s * R + cursor++];
-                } else
-                    randomOffset = 0;
+                if (draws) {
+                    if (rnd) {
+                        if (cursor >= R) {
+                            rc = -4;
+                            break;
+                        }
+                        randomOffset = rnd[s * R + cursor++];
+                    } else
+                        randomOffset = 0;
+                }
             }
             /* maxiGrainPlayer::play (:270-283): sum in list order, erase the finished */
             double total = 0.0;

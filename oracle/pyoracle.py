@@ -328,11 +328,12 @@ class Oracle:
 
     def granular(self, mode, window_kind, samples, T, a, b=None, posMod=None, rnd=None, grainLength=0.05,
                  overlaps=4, mySampleRate=44100, st=None, gst=None):
-        """maxiTimeStretch (mode 0) / maxiStretch (mode 1) bank.  Returns (out [T,S], st, gst, rc)."""
+        """maxiTimeStretch::play (mode 0) / maxiStretch::play (1) / maxiTimeStretch::playAtPosition (2, a =
+        per-sample pos [T,S]) / maxiPitchShift::play (3) bank.  Returns (out [T,S], st, gst, rc)."""
         samples = np.asarray(samples, np.float64)
         g = np.concatenate([samples, [0.0]])  # guard element amp[len]
         a = _f64(a)
-        S = a.size
+        S = a.shape[1] if mode == 2 else a.size
         b = None if b is None else _f64(b, (S,))
         posMod = None if posMod is None else _f64(posMod, (S,))
         R = 0

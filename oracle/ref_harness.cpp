@@ -517,18 +517,25 @@ static int granular_bank(int mode, size_t S, size_t T, maxiSample &smp, double g
                          double *st, double *gst, double *out) {
     int rc = 0;
     for (size_t s = 0; s < S && rc == 0; s++) {
+        // mode 0 maxiTimeStretch::play, 1 maxiStretch::play, 2 maxiTimeStretch::playAtPosition
+        // (a = per-sample pos [T][S]), 3 maxiPitchShift::play (st[1] = cycles)
         maxiTimeStretch<F> ts(&smp);
         maxiStretch<F> stx(&smp);
-        maxiGrainPlayer *gp = mode == 0 ? ts.grainPlayer : stx.grainPlayer;
-        maxiGrainWindowCache<F> *wc = mode == 0 ? &ts.windowCache : &stx.windowCache;
-        if (mode == 0) {
+        maxiPitchShift<F> ps(&smp);
+        maxiGrainPlayer *gp = mode == 3 ? ps.grainPlayer : (mode == 1 ? stx.grainPlayer : ts.grainPlayer);
+        maxiGrainWindowCache<F> *wc = mode == 3 ? &ps.windowCache : (mode == 1 ? &stx.windowCache : &ts.windowCache);
+        if (mode == 0 || mode == 2) {
             ts.position = st[0 * S + s];
             ts.looper = st[1 * S + s];
             ts.randomOffset = st[2 * S + s];
-        } else {
+        } else if (mode == 1) {
             stx.position = st[0 * S + s];
             stx.looper = st[1 * S + s];
             stx.randomOffset = st[2 * S + s];
+        } else {
+            ps.position = st[0 * S + s];
+            ps.cycles = (long)st[1 * S + s];
+            ps.randomOffset = st[2 * S + s];
         }
         for (int k = 0; k < 8; k++) {  // re-create the carried-over grains, in creation order
             unsigned long dur = (unsigned long)gst[(3 * 8 + k) * S + s];
@@ -546,17 +553,32 @@ static int granular_bank(int mode, size_t S, size_t T, maxiSample &smp, double g
         g_rnd_i = (size_t)st[3 * S + s];
         g_rnd_underrun = 0;
         for (size_t n = 0; n < T; n++) {
-            out[n * S + s] = mode == 0 ? ts.play(a[s], grainLength, overlaps, posMod ? posMod[s] : 0.0)
-                                       : stx.play(a[s], b[s], grainLength, overlaps, posMod ? posMod[s] : 0.0);
+            const double pm = posMod ? posMod[s] : 0.0;
+            switch (mode) {
+                case 0: out[n * S + s] = ts.play(a[s], grainLength, overlaps, pm); break;
+                case 1: out[n * S + s] = stx.play(a[s], b[s], grainLength, overlaps, pm); break;
+                case 2: out[n * S + s] = ts.playAtPosition(a[n * S + s], grainLength, overlaps); break;
+                default: out[n * S + s] = ps.play(a[s], grainLength, overlaps, pm); break;
+            }
             if (gp->grains.size() > 8) {
                 rc = -3;
                 break;
             }
         }
         if (g_rnd_underrun) rc = -4;
-        st[0 * S + s] = mode == 0 ? ts.position : stx.position;
-        st[1 * S + s] = mode == 0 ? ts.looper : stx.looper;
-        st[2 * S + s] = mode == 0 ? ts.randomOffset : stx.randomOffset;
+        if (mode == 0 || mode == 2) {
+            st[0 * S + s] = ts.position;
+            st[1 * S + s] = ts.looper;
+            st[2 * S + s] = ts.randomOffset;
+        } else if (mode == 1) {
+            st[0 * S + s] = stx.position;
+            st[1 * S + s] = stx.looper;
+            st[2 * S + s] = stx.randomOffset;
+        } else {
+            st[0 * S + s] = ps.position;
+            st[1 * S + s] = (double)ps.cycles;
+            st[2 * S + s] = ps.randomOffset;
+        }
         st[3 * S + s] = (double)g_rnd_i;
         int k = 0;
         for (maxiGrainBase *gb : gp->grains) {
@@ -581,7 +603,7 @@ static int granular_bank(int mode, size_t S, size_t T, maxiSample &smp, double g
 int mxo_granular(int mode, int window_kind, size_t S, size_t T, const double *amp, size_t len,
                  int mySampleRate, double grainLength, int overlaps, const double *a, const double *b,
                  const double *posMod, const int32_t *rnd, size_t R, double *st, double *gst, double *out) {
-    if (mode < 0 || mode > 1 || overlaps <= 0) return -1;
+    if (mode < 0 || mode > 3 || overlaps <= 0) return -1;
     unsigned long sampleDur = grainLength * (double)mySampleRate;
     if (sampleDur == 0 || sampleDur >= (unsigned long)(maxiSettings::sampleRate / 2.0)) return -2;
     maxiSample smp;

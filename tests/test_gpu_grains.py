@@ -114,3 +114,54 @@ def test_fast_scheduler_random_rates(mx, port, mode):
         assert_bits_equal(bank.state.numpy(), est, "scheduler state (Ls=%d)" % Ls)
         assert_bits_equal(bank.grains.numpy(), egst, "grains")
         assert_bits_equal(o, e, "output")
+
+
+@pytest.mark.parametrize("overlaps,window", [(2, "hann"), (4, "cosine"), (3, "gaussian")])
+def test_play_at_position(mx, port, chunked, overlaps, window):
+    """maxiTimeStretch::playAtPosition (L/maxiGrains.h:359-367): caller-driven per-sample position,
+    spawn when floor(fmod(looper, cycle)) == 0; two carried blocks; out, scheduler and grains bit-exact."""
+    rng = np.random.default_rng(60 + overlaps)
+    L, S, T = 30000, 70, 4000
+    smp = rng.uniform(-1, 1, L)
+    pos = ((np.arange(2 * T)[:, None] * rng.uniform(0.2, 2.0, S)[None, :] / L) + rng.uniform(0, 1, S)) % 1.0
+    pos[:, 3] = rng.uniform(-0.2, 1.2, 2 * T)          # clamped to [0, 1]
+    pos[:, 5] = 1.0                                    # grains born at the very end: endPos clamp + wrap
+    bank = make_bank(mx, 0, window, smp, S)
+    o = np.concatenate([bank.playAtPosition(pos[:T], 0.05, overlaps).numpy(),
+                        bank.playAtPosition(pos[T:], 0.05, overlaps).numpy()])
+    w = mx.WINDOWS[window]
+    e1, st, gst, rc = port.granular(2, w, smp, T, pos[:T], grainLength=0.05, overlaps=overlaps)
+    e2, st, gst, rc2 = port.granular(2, w, smp, T, pos[T:], grainLength=0.05, overlaps=overlaps, st=st, gst=gst)
+    assert rc == 0 and rc2 == 0
+    assert_bits_equal(o, np.concatenate([e1, e2]), "playAtPosition")
+    assert_bits_equal(bank.state.numpy(), st, "state")
+    assert_bits_equal(bank.grains.numpy(), gst, "grains")
+    assert np.abs(e2).max() > 0.3
+
+
+@pytest.mark.parametrize("overlaps,gl", [(2, 0.05), (4, 0.05), (3, 0.031)])
+def test_pitch_shift(mx, port, chunked, overlaps, gl):
+    """maxiPitchShift::play (L/maxiGrains.h:412-430): grains with arbitrary (also negative, zero-ish)
+    increments, speed - (cycleMod/cycleLength)*0.1 per grain; two carried blocks, bit-exact."""
+    rng = np.random.default_rng(70 + overlaps)
+    L, S, T = 30000, 90, 4000
+    smp = rng.uniform(-1, 1, L)
+    speed = rng.uniform(-2.0, 2.5, S)
+    speed[:4] = [1.0, 0.5, -1.0, 2.0]
+    pm = rng.uniform(-0.1, 0.1, S)
+    sb = mx.maxiSampleBank(1)
+    sb.setSample(smp)
+    bank = mx.maxiPitchShiftBank(S, sb, "hann")
+    st0 = np.zeros((4, S))
+    st0[0] = rng.uniform(0, L, S)
+    st0[0, 7] = L - 3.0                                # position wraps to 0 inside the block (:415)
+    bank.state.upload(st0)
+    o = np.concatenate([bank.play(speed, gl, overlaps, T, posMod=pm).numpy(),
+                        bank.play(speed, gl, overlaps, T, posMod=pm).numpy()])
+    e1, st, gst, rc = port.granular(3, 0, smp, T, speed, posMod=pm, grainLength=gl, overlaps=overlaps, st=st0)
+    e2, st, gst, rc2 = port.granular(3, 0, smp, T, speed, posMod=pm, grainLength=gl, overlaps=overlaps, st=st, gst=gst)
+    assert rc == 0 and rc2 == 0
+    assert_bits_equal(o, np.concatenate([e1, e2]), "pitchshift")
+    assert_bits_equal(bank.state.numpy(), st, "state")
+    assert_bits_equal(bank.grains.numpy(), gst, "grains")
+    assert np.abs(e2).max() > 0.3
