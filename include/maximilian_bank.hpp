@@ -159,6 +159,10 @@ public:
     void sinebuf4(size_t N, double *d_out) { render(MXG_OSC_SINEBUF4, N, d_out); }
     void sawn(size_t N, double *d_out) { render(MXG_OSC_SAWN, N, d_out); }
     void phasorBetween(size_t N, double *d_out) { render(MXG_OSC_PHASORBETWEEN, N, d_out); }
+    // noise() (C:214-220): d_rand = the rand() draws, int32 [N][V] (draw n*V+v for a voice-inner loop)
+    void noise(size_t N, const int32_t *d_rand, double *d_out, void *stream = nullptr) {
+        maxigpu::check(mxg_osc_noise(V, N, d_rand, hold_.get(), d_out, stream), "mxg_osc_noise");
+    }
 
     // per-sample API: `waveform` is fixed for the facade stream; call tick() once per audio frame
     void setWaveform(int waveform) { waveform_ = waveform; }
@@ -280,16 +284,28 @@ private:
 // ---- maxiMix::stereo over a bank + mixdown over voices (C:503-509) ---------------------------------------
 class maxiMixBank {
 public:
-    explicit maxiMixBank(size_t voices) : V(voices), pan_(voices) {}
+    explicit maxiMixBank(size_t voices) : V(voices), pan_(voices), y_(voices), z_(voices) {}
     void setPan(const std::vector<double> &x) { pan_.upload(x); }
+    void setPan(const std::vector<double> &x, const std::vector<double> &y) { pan_.upload(x); y_.upload(y); }
+    void setPan(const std::vector<double> &x, const std::vector<double> &y, const std::vector<double> &z) {
+        pan_.upload(x); y_.upload(y); z_.upload(z);
+    }
     // d_mix: [N][2] on device
     void stereo(size_t N, const double *d_in, double *d_mix, void *stream = nullptr) {
         maxigpu::check(mxg_mix_stereo(V, N, d_in, pan_.get(), d_mix, stream), "mxg_mix_stereo");
     }
+    // quad (C:512-522): d_mix [N][4]; ambisonic (C:525-541): d_mix [N][8].  d_bus (optional, [N][C][V]) receives
+    // the per-voice four/eight signals.
+    void quad(size_t N, const double *d_in, double *d_mix, double *d_bus = nullptr, void *stream = nullptr) {
+        maxigpu::check(mxg_mix_bus(4, V, N, d_in, pan_.get(), y_.get(), nullptr, d_bus, d_mix, stream), "mxg_mix_bus");
+    }
+    void ambisonic(size_t N, const double *d_in, double *d_mix, double *d_bus = nullptr, void *stream = nullptr) {
+        maxigpu::check(mxg_mix_bus(8, V, N, d_in, pan_.get(), y_.get(), z_.get(), d_bus, d_mix, stream), "mxg_mix_bus");
+    }
 
 private:
     size_t V;
-    maxigpu::DeviceArray<double> pan_;
+    maxigpu::DeviceArray<double> pan_, y_, z_;
 };
 
 // ---- maxiDelayline (H:266-284) ---------------------------------------------------------------------------
@@ -319,7 +335,13 @@ private:
 // ---- maxiSample play family (H:602-783): V play heads over one sample ---------------------------------------
 class maxiSampleBank {
 public:
-    explicit maxiSampleBank(size_t voices) : V(voices), position_(voices), a_(voices), start_(voices), end_(voices) {}
+    explicit maxiSampleBank(size_t voices)
+        : V(voices), position_(voices), a_(voices), start_(voices), end_(voices), zxPrev_(voices), phasorPrev_(voices),
+          zxFirst_(voices), phasorFirst_(voices) {
+        zxPrev_.upload(std::vector<double>(V, 1.0));     // maxiTrigger::previousValue = 1, firstTrigger = 1 (H:593-594)
+        zxFirst_.upload(std::vector<int32_t>(V, 1));
+        phasorFirst_.upload(std::vector<int32_t>(V, 1));  // phasorFirst = 1, phasorPrev = 0 (H:731-732)
+    }
     ~maxiSampleBank() { clear(); }
     maxiSampleBank(const maxiSampleBank &) = delete;
     maxiSampleBank &operator=(const maxiSampleBank &) = delete;
@@ -347,13 +369,27 @@ public:
     void play(size_t N, double *d_out) { render(MXG_SMP_PLAY, N, d_out); }
     void playOnce(size_t N, double *d_out) { render(MXG_SMP_PLAYONCE, N, d_out); }
     void playAtSpeed(size_t N, double *d_out) { render(MXG_SMP_PLAYATSPEED, N, d_out); }
+    // trigger-driven players (C:1006-1042): d_trig [N][V]; speed = setSpeeds(), offset/length (or pos) = setStartEnd()
+    void renderTrig(int mode, size_t N, const double *d_trig, double *d_out, void *stream = nullptr) {
+        const bool ph = mode == MXG_SMP_PLAYWITHPHASOR;
+        maxigpu::check(mxg_sample_render_trig(mode, V, N, d_samples_, length_, mySampleRate, d_trig, a_.get(), 0, start_.get(),
+                                              end_.get(), position_.get(), ph ? phasorPrev_.get() : zxPrev_.get(),
+                                              ph ? phasorFirst_.get() : zxFirst_.get(), d_out, stream), "mxg_sample_render_trig");
+    }
+    void playOnZX(size_t N, const double *d_trig, double *d_out) { renderTrig(MXG_SMP_PLAYONZX, N, d_trig, d_out); }
+    void playOnZXAtSpeed(size_t N, const double *d_trig, double *d_out) { renderTrig(MXG_SMP_PLAYONZXATSPEED, N, d_trig, d_out); }
+    void playOnZXAtSpeedFromOffset(size_t N, const double *d_trig, double *d_out) { renderTrig(MXG_SMP_PLAYONZXATSPEEDFROMOFFSET, N, d_trig, d_out); }
+    void playOnZXAtSpeedBetweenPoints(size_t N, const double *d_trig, double *d_out) { renderTrig(MXG_SMP_PLAYONZXATSPEEDBETWEENPOINTS, N, d_trig, d_out); }
+    void loopSetPosOnZX(size_t N, const double *d_trig, double *d_out) { renderTrig(MXG_SMP_LOOPSETPOSONZX, N, d_trig, d_out); }
+    void playWithPhasor(size_t N, const double *d_pha, double *d_out) { renderTrig(MXG_SMP_PLAYWITHPHASOR, N, d_pha, d_out); }  // C:753-816
     int mySampleRate = 44100;
 
 private:
     size_t V;
     double *d_samples_ = nullptr;
     size_t length_ = 0;
-    maxigpu::DeviceArray<double> position_, a_, start_, end_;
+    maxigpu::DeviceArray<double> position_, a_, start_, end_, zxPrev_, phasorPrev_;
+    maxigpu::DeviceArray<int32_t> zxFirst_, phasorFirst_;
 };
 
 // ---- maxiFFT / maxiMFCC batches (L/maxiFFT.h, L/maxiMFCC.h) ----------------------------------------------------
@@ -375,6 +411,10 @@ public:
     void process(const float *d_signal, size_t frame_stride, size_t nframes, float *d_mags, float *d_phases,
                  float *d_real = nullptr, float *d_imag = nullptr, void *stream = nullptr) {
         maxigpu::check(mxg_fft_batch(plan_, d_signal, frame_stride, nframes, d_real, d_imag, d_mags, d_phases, stream), "mxg_fft_batch");
+    }
+    // magsToDB / spectralFlatness / spectralCentroid (L/maxiFFT.cpp:101-132) for every frame; any output may be null
+    void features(const float *d_mags, size_t nframes, float *d_db, float *d_flatness, float *d_centroid, void *stream = nullptr) {
+        maxigpu::check(mxg_fft_features(plan_, d_mags, nframes, d_db, d_flatness, d_centroid, stream), "mxg_fft_features");
     }
 
 private:
@@ -418,14 +458,26 @@ public:
     void setSpeeds(const std::vector<double> &speed) { speed_.upload(speed); }
     // play(speed, grainLength, overlaps) for N samples of every stream -> d_out [N][S]
     void play(double grainLength, int overlaps, size_t N, double *d_out, void *stream = nullptr) {
+        plan(grainLength);
+        maxigpu::check(mxg_granular_render(plan_, mode_, S, N, sample_->deviceSamples(), sample_->getLength(), overlaps, speed_.get(),
+                                           nullptr, nullptr, nullptr, 0, st_.get(), gst_.get(), d_out, stream), "mxg_granular_render");
+    }
+    // playAtPosition(pos, grainLength, overlaps) (L/maxiGrains.h:359-367): d_pos = the per-sample [N][S] position signal
+    void playAtPosition(const double *d_pos, double grainLength, int overlaps, size_t N, double *d_out, void *stream = nullptr) {
+        plan(grainLength);
+        maxigpu::check(mxg_granular_render(plan_, 2, S, N, sample_->deviceSamples(), sample_->getLength(), overlaps, d_pos, nullptr,
+                                           nullptr, nullptr, 0, st_.get(), gst_.get(), d_out, stream), "mxg_granular_render");
+    }
+
+protected:
+    int mode_ = 0;
+    void plan(double grainLength) {
         if (!plan_ || grainLength != grainLength_) {
             if (plan_) mxg_grain_plan_destroy(plan_);
             plan_ = mxg_grain_plan_create(window_, grainLength, sample_->mySampleRate);
             if (!plan_) throw std::runtime_error(std::string("mxg_grain_plan_create: ") + mxg_last_error());
             grainLength_ = grainLength;
         }
-        maxigpu::check(mxg_granular_render(plan_, 0, S, N, sample_->deviceSamples(), sample_->getLength(), overlaps, speed_.get(),
-                                           nullptr, nullptr, nullptr, 0, st_.get(), gst_.get(), d_out, stream), "mxg_granular_render");
     }
 
 private:
@@ -435,4 +487,11 @@ private:
     mxg_grain_plan *plan_ = nullptr;
     double grainLength_ = 0;
     maxigpu::DeviceArray<double> st_, gst_, speed_;
+};
+
+// ---- maxiPitchShift bank (L/maxiGrains.h:374-432): same grains, speed uncoupled from position ----------------------
+class maxiPitchShiftBank : public maxiTimeStretchBank {
+public:
+    maxiPitchShiftBank(size_t streams, maxiSampleBank *sample, int window_kind = 0)
+        : maxiTimeStretchBank(streams, sample, window_kind) { mode_ = 3; }
 };

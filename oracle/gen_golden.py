@@ -7,7 +7,8 @@ outputs and final state.  The reference ships no golden vectors of its own (SURV
 these fixtures are what pins both the plain-C oracle and the HIP path.  Only runnable in the
 build container (needs /root/reference); the .npz files and this script are committed.
 
-    python oracle/gen_golden.py        # rewrites tests/golden/*.npz + MANIFEST.json
+    python oracle/gen_golden.py              # rewrites tests/golden/*.npz + MANIFEST.json
+    python oracle/gen_golden.py extra.npz    # rewrites only the named files (+ the manifest)
 """
 import hashlib
 import json
@@ -26,6 +27,16 @@ from oracle import pyoracle  # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden")
 REF_SRC = "/root/reference/src"
 SEED = 0x4D415849  # "MAXI" 
+
+
+ONLY = set(sys.argv[1:])
+
+
+def save(fname, **arrays):
+    """np.savez_compressed into tests/golden, unless a selection was given and fname is not in it."""
+    if ONLY and fname not in ONLY:
+        return
+    np.savez_compressed(os.path.join(GOLD, fname), **arrays)
 
 
 def osc_inputs(V):
@@ -71,7 +82,7 @@ def main():
     assert [repr(float(x)) for x in ka[:, 0]] == ["0.0", "0.06264832417874368", "0.1250505236945281",
                                                   "0.18696144082725336"]
     d["ka_sinewave440"] = ka[:, 0]
-    np.savez_compressed(os.path.join(GOLD, "osc.npz"), **d)
+    save("osc.npz", **d)
     files["osc.npz"] = "maxiOsc, 12 waveforms, V=32, 2x160 samples; fm variants; KAT sinewave(440)"
 
     # ---- maxiFilter ---------------------------------------------------------------------------
@@ -96,7 +107,7 @@ def main():
     d["cutoff_mod"] = cm
     o, st = R.filter(0, x, cm, res, cps=True)
     d["out_lores_mod"] = o
-    np.savez_compressed(os.path.join(GOLD, "filter.npz"), **d)
+    save("filter.npz", **d)
     files["filter.npz"] = "maxiFilter 5 kinds, V=32, 2x128 samples + per-sample cutoff lores"
 
     # ---- maxiEnv ---------------------------------------------------------------------------------
@@ -119,7 +130,7 @@ def main():
         d["out_%s_gate" % name], d["dst_%s_gate" % name], d["ist_%s_gate" % name] = o, dst, ist
         o, dst, ist = R.env(mode, xin, trig_v, par, hold)
         d["out_%s_pv" % name], d["dst_%s_pv" % name], d["ist_%s_pv" % name] = o, dst, ist
-    np.savez_compressed(os.path.join(GOLD, "env.npz"), **d)
+    save("env.npz", **d)
     files["env.npz"] = "maxiEnv adsr/ar, V=16, 3000 samples, gate + per-voice impulse triggers; setters"
 
     # ---- fused subtractive voice (config 3, reduced) ----------------------------------------------
@@ -140,7 +151,7 @@ def main():
         d["ost_mode%d" % mode], d["fst_mode%d" % mode] = ost, fst
         d["dst_mode%d" % mode], d["ist_mode%d" % mode] = dst, ist
     d["coef"] = R.filter_coeffs(0, cutoff, res)
-    np.savez_compressed(os.path.join(GOLD, "voice.npz"), **d)
+    save("voice.npz", **d)
     files["voice.npz"] = "saw->lores->adsr voice, V=16, 4096 samples, mode A (hoisted) and B (modulated)"
 
     # ---- maxiMix::stereo mixdown ----------------------------------------------------------------
@@ -148,7 +159,7 @@ def main():
     rng = np.random.default_rng(SEED + 4)
     x = rng.uniform(-1, 1, (N, V))
     pan = np.concatenate([[-0.5, 0.0, 1.0, 1.5], rng.uniform(0, 1, V - 4)])
-    np.savez_compressed(os.path.join(GOLD, "mix.npz"), x=x, pan=pan, mix=R.mix_stereo(x, pan))
+    save("mix.npz", x=x, pan=pan, mix=R.mix_stereo(x, pan))
     files["mix.npz"] = "maxiMix::stereo + sequential voice sum, V=96, 64 samples"
 
     # ---- maxiDelayline ------------------------------------------------------------------------------
@@ -164,7 +175,7 @@ def main():
         o1, mem, ph = R.delay(mode, x[:250], size, fb, cap, position=pos)
         o2, mem, ph = R.delay(mode, x[250:], size, fb, cap, position=pos, mem=mem, phase=ph)
         d["out_" + name], d["mem_" + name], d["phase_" + name] = np.concatenate([o1, o2]), mem, ph
-    np.savez_compressed(os.path.join(GOLD, "delay.npz"), **d)
+    save("delay.npz", **d)
     files["delay.npz"] = "maxiDelayline dl/dlFromPosition, V=24, 250+350 samples, cap 96"
 
     # ---- maxiSample play family ------------------------------------------------------------------------
@@ -198,7 +209,7 @@ def main():
     o, p = R.sample(4, smp, N, np.zeros(V), a=sp, aps=True, mySampleRate=44100)
     R.settings(44100, 2, 1024)
     d["speed_mod"], d["out_speed_mod_sr96k"], d["pos_speed_mod_sr96k"] = sp, o, p
-    np.savez_compressed(os.path.join(GOLD, "sample.npz"), **d)
+    save("sample.npz", **d)
     files["sample.npz"] = "maxiSample 9 play modes, V=24, 200+200 samples over a 1500-sample buffer"
 
     # ---- maxiFFT + maxiMFCC (config 4 signal, reduced) --------------------------------------------------
@@ -219,7 +230,7 @@ def main():
     for (nf, nc) in [(42, 13), (256, 13), (40, 20)]:
         mel, mf = R.mfcc(mags, nf, nc, 20.0, 20000.0)
         d["melbands_%d_%d" % (nf, nc)], d["mfcc_%d_%d" % (nf, nc)] = mel, mf
-    np.savez_compressed(os.path.join(GOLD, "spectral.npz"), **d)
+    save("spectral.npz", **d)
     files["spectral.npz"] = ("maxiFFT (1024/1024, 1024/256 streaming, 512/128, 2048/1024, 64/64) real/imag/mags/"
                              "phases + maxiMFCC 512/42/13, 512/256/13, 512/40/20 on the config-4 signal")
 
@@ -249,8 +260,83 @@ def main():
                                      grainLength=gl, overlaps=ov, st=st, gst=gst)
         assert rc == 0
         d["out_" + name], d["st_" + name], d["gst_" + name] = np.concatenate([o1, o2]), st, gst
-    np.savez_compressed(os.path.join(GOLD, "grains.npz"), **d)
+    save("grains.npz", **d)
     files["grains.npz"] = "maxiTimeStretch/maxiStretch banks, 12 streams x 2500+2500 samples, 4 configs; 9 windows"
+
+    # ---- rows closed later in round 1: noise, quad/ambisonic, trigger-driven maxiSample players,
+    # ---- playWithPhasor, FFT features, playAtPosition, maxiPitchShift ------------------------------------
+    rng = np.random.default_rng(SEED + 9)
+    d = {}
+    V, N = 24, 96
+    d["noise_seed"] = 20260923
+    d["noise_rand"], d["noise_out"] = R.noise(int(d["noise_seed"]), V, N)
+    x = rng.uniform(-1, 1, (N, V))
+    px, py, pz = rng.uniform(-0.2, 1.2, V), rng.uniform(-0.2, 1.2, V), rng.uniform(-0.3, 1.3, V)
+    d["bus_x"], d["bus_px"], d["bus_py"], d["bus_pz"] = x, px, py, pz
+    for C in (2, 4, 8):
+        d["mix_%d" % C], d["bus_%d" % C] = R.mix_bus(C, x, px, py, pz, want_bus=True)
+    Ls = 1500
+    n = np.arange(Ls)
+    smp = np.round((0.5 * np.sin(2 * np.pi * 110 * n / 44100) + 0.25 * np.sin(2 * np.pi * 331 * n / 44100)
+                    + 0.05 * rng.uniform(-1, 1, Ls)) * 32767) / 32767.0
+    N = 300
+    trig = np.sin(np.arange(N)[:, None] * rng.uniform(0.02, 0.3, V)[None, :] + rng.uniform(0, 6, V))
+    trig[:, ::5] = np.where(rng.uniform(size=(N, (V + 4) // 5)) < 0.05, 1.0, 0.0)
+    d["smp"], d["zx_trig"] = smp, trig
+    d["zx_a"], d["zx_p0"], d["zx_p1"] = rng.uniform(0.3, 2.5, V), rng.uniform(0, 0.6, V), rng.uniform(0.1, 0.5, V)
+    d["zx_pos0"] = rng.uniform(0, Ls - 1, V)
+    for mode in range(5):
+        h = N // 2
+        o1, p, zp, zf = R.sample_zx(mode, smp, trig[:h], d["zx_pos0"], a=d["zx_a"], p0=d["zx_p0"], p1=d["zx_p1"])
+        o2, p, zp, zf = R.sample_zx(mode, smp, trig[h:], p, a=d["zx_a"], p0=d["zx_p0"], p1=d["zx_p1"],
+                                    zx_prev=zp, zx_first=zf)
+        d["zx_out_%d" % mode], d["zx_pos_%d" % mode] = np.concatenate([o1, o2]), p
+        d["zx_prev_%d" % mode], d["zx_first_%d" % mode] = zp, zf
+    pha = (np.arange(N)[:, None] * rng.uniform(0.0003, 0.01, V)[None, :] + rng.uniform(0, 1, V)) % 1.0
+    pha[:, 1::4] = 1.0 - pha[:, 1::4]
+    pha[:, 2::4] = np.round(pha[:, 2::4] * 8) / 8
+    pha[150:153] = rng.uniform(-0.3, 1.3, (3, V))
+    pha[:, 3] = 0.0
+    pha[1:, 7] = np.linspace(0.001, 0.0, N - 1)
+    d["phasor_in"] = pha
+    o1, pp, pf = R.sample_phasor(smp, pha[:150])
+    o2, pp, pf = R.sample_phasor(smp, pha[150:], phasor_prev=pp, phasor_first=pf)
+    d["phasor_out"], d["phasor_prev"], d["phasor_first"] = np.concatenate([o1, o2]), pp, pf
+    m = np.abs(rng.normal(0, 30, (40, 512))).astype(np.float32)
+    m[5] = 0
+    m[6, ::3] = 0
+    m[7, :256] = 5e-7
+    d["feat_mags"] = m
+    d["feat_flatness"], d["feat_centroid"] = R.fft_features(m, 1024)
+    d["feat_db"] = R.fft_to_db(m)
+    Ls = 30000
+    gsmp = rng.uniform(-1, 1, Ls)
+    S, T = 12, 3000
+    pos = ((np.arange(T)[:, None] * rng.uniform(0.2, 2.0, S)[None, :] / Ls) + rng.uniform(0, 1, S)) % 1.0
+    pos[:, 3] = rng.uniform(-0.2, 1.2, T)
+    pos[:, 5] = 1.0
+    d["g_samples"], d["pap_pos"] = gsmp, pos
+    h = T // 2
+    o1, st, gst, rc = R.granular(2, 0, gsmp, h, pos[:h], grainLength=0.05, overlaps=4)
+    assert rc == 0
+    o2, st, gst, rc = R.granular(2, 0, gsmp, T - h, pos[h:], grainLength=0.05, overlaps=4, st=st, gst=gst)
+    assert rc == 0
+    d["pap_out"], d["pap_st"], d["pap_gst"] = np.concatenate([o1, o2]), st, gst
+    speed = rng.uniform(-2.0, 2.5, S)
+    speed[:4] = [1.0, 0.5, -1.0, 2.0]
+    pm = rng.uniform(-0.1, 0.1, S)
+    st0 = np.zeros((4, S))
+    st0[0] = rng.uniform(0, Ls, S)
+    st0[0, 7] = Ls - 3.0
+    d["ps_speed"], d["ps_posmod"], d["ps_st0"] = speed, pm, st0
+    o1, st, gst, rc = R.granular(3, 0, gsmp, h, speed, posMod=pm, grainLength=0.05, overlaps=3, st=st0)
+    assert rc == 0
+    o2, st, gst, rc = R.granular(3, 0, gsmp, T - h, speed, posMod=pm, grainLength=0.05, overlaps=3, st=st, gst=gst)
+    assert rc == 0
+    d["ps_out"], d["ps_st"], d["ps_gst"] = np.concatenate([o1, o2]), st, gst
+    save("extra.npz", **d)
+    files["extra.npz"] = ("maxiOsc::noise (srand seed + draws), maxiMix stereo/quad/ambisonic bus, playOnZX* x5, "
+                          "playWithPhasor, magsToDB/spectralFlatness/spectralCentroid, playAtPosition, maxiPitchShift")
 
     sha = hashlib.sha256()
     for f in ("maximilian.cpp", "maximilian.h", "libs/fft.cpp", "libs/maxiFFT.cpp", "libs/maxiMFCC.cpp",

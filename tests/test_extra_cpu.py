@@ -1,0 +1,121 @@
+"""CPU tests (-m "not gpu") for the rows closed late in round 1: maxiOsc::noise, maxiMix quad/ambisonic,
+the trigger-driven maxiSample players, playWithPhasor, magsToDB/spectralFlatness/spectralCentroid,
+maxiTimeStretch::playAtPosition and maxiPitchShift.  The plain-C oracle against (a) tests/golden/extra.npz
+(dumped from the compiled reference by oracle/gen_golden.py) and (b) the compiled reference on fresh
+inputs when oracle/_ref is present.  Bit-exact throughout."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+
+def test_noise_golden(port, golden):
+    g = golden("extra.npz")
+    N, V = g["noise_rand"].shape
+    rnd, out = port.noise(int(g["noise_seed"]), V, N)
+    assert np.array_equal(rnd, g["noise_rand"])          # glibc rand() after srand(seed)
+    assert_bits_equal(out, g["noise_out"], "noise")
+    # the arithmetic alone, from the stored draws (what the HIP kernel is given)
+    r = g["noise_rand"].astype(np.float32) / np.float32(2147483648.0)
+    assert_bits_equal((r * np.float32(2) - np.float32(1)).astype(np.float64), g["noise_out"], "noise formula")
+
+
+@pytest.mark.parametrize("C", [2, 4, 8])
+def test_mix_bus_golden(port, golden, C):
+    g = golden("extra.npz")
+    mix, bus = port.mix_bus(C, g["bus_x"], g["bus_px"], g["bus_py"], g["bus_pz"], want_bus=True)
+    assert_bits_equal(bus, g["bus_%d" % C], "bus")
+    assert_bits_equal(mix, g["mix_%d" % C], "mix")
+    if C == 2:   # same numbers as the older stereo entry point
+        assert_bits_equal(port.mix_stereo(g["bus_x"], g["bus_px"]), mix)
+
+
+@pytest.mark.parametrize("mode", range(5))
+def test_sample_zx_golden(port, golden, mode):
+    g = golden("extra.npz")
+    trig = g["zx_trig"]
+    h = trig.shape[0] // 2
+    kw = dict(a=g["zx_a"], p0=g["zx_p0"], p1=g["zx_p1"])
+    o1, p, zp, zf = port.sample_zx(mode, g["smp"], trig[:h], g["zx_pos0"], **kw)
+    o2, p, zp, zf = port.sample_zx(mode, g["smp"], trig[h:], p, zx_prev=zp, zx_first=zf, **kw)
+    assert_bits_equal(np.concatenate([o1, o2]), g["zx_out_%d" % mode])
+    assert_bits_equal(p, g["zx_pos_%d" % mode])
+    assert_bits_equal(zp, g["zx_prev_%d" % mode])
+    assert np.array_equal(zf, g["zx_first_%d" % mode])
+
+
+def test_sample_phasor_golden(port, golden):
+    g = golden("extra.npz")
+    pha = g["phasor_in"]
+    o1, pp, pf = port.sample_phasor(g["smp"], pha[:150])
+    o2, pp, pf = port.sample_phasor(g["smp"], pha[150:], phasor_prev=pp, phasor_first=pf)
+    assert_bits_equal(np.concatenate([o1, o2]), g["phasor_out"])
+    assert_bits_equal(pp, g["phasor_prev"])
+    assert np.array_equal(pf, g["phasor_first"])
+
+
+def test_fft_features_golden(port, golden):
+    g = golden("extra.npz")
+    flat, cen = port.fft_features(g["feat_mags"], 1024)
+    assert_bits_equal(flat.astype(np.float64), g["feat_flatness"].astype(np.float64), "flatness")
+    assert_bits_equal(cen.astype(np.float64), g["feat_centroid"].astype(np.float64), "centroid")
+    assert_bits_equal(port.fft_to_db(g["feat_mags"]).astype(np.float64), g["feat_db"].astype(np.float64), "dB")
+
+
+def test_play_at_position_and_pitch_shift_golden(port, golden):
+    g = golden("extra.npz")
+    smp, pos = g["g_samples"], g["pap_pos"]
+    T = pos.shape[0]
+    h = T // 2
+    o1, st, gst, rc = port.granular(2, 0, smp, h, pos[:h], grainLength=0.05, overlaps=4)
+    o2, st, gst, rc2 = port.granular(2, 0, smp, T - h, pos[h:], grainLength=0.05, overlaps=4, st=st, gst=gst)
+    assert rc == 0 and rc2 == 0
+    assert_bits_equal(np.concatenate([o1, o2]), g["pap_out"], "playAtPosition")
+    assert_bits_equal(st, g["pap_st"])
+    assert_bits_equal(gst, g["pap_gst"])
+    kw = dict(posMod=g["ps_posmod"], grainLength=0.05, overlaps=3)
+    o1, st, gst, rc = port.granular(3, 0, smp, h, g["ps_speed"], st=g["ps_st0"], **kw)
+    o2, st, gst, rc2 = port.granular(3, 0, smp, T - h, g["ps_speed"], st=st, gst=gst, **kw)
+    assert rc == 0 and rc2 == 0
+    assert_bits_equal(np.concatenate([o1, o2]), g["ps_out"], "maxiPitchShift")
+    assert_bits_equal(st, g["ps_st"])
+    assert_bits_equal(gst, g["ps_gst"])
+
+
+def test_extra_port_vs_reference(port, ref):
+    """Fresh seeded inputs through both CPU checkers (only where oracle/_ref was built)."""
+    rng = np.random.default_rng(99)
+    V, N = 19, 257
+    x = rng.uniform(-1, 1, (N, V))
+    for C in (2, 4, 8):
+        px, py, pz = rng.uniform(-0.2, 1.2, V), rng.uniform(-0.2, 1.2, V), rng.uniform(-0.3, 1.3, V)
+        a, b = port.mix_bus(C, x, px, py, pz, True), ref.mix_bus(C, x, px, py, pz, True)
+        assert_bits_equal(a[0], b[0])
+        assert_bits_equal(a[1], b[1])
+    for u, w in zip(port.noise(5, V, N), ref.noise(5, V, N)):
+        assert np.array_equal(u, w)
+    smp = rng.uniform(-1, 1, 1500)
+    trig = np.sin(np.arange(N)[:, None] * rng.uniform(0.02, 0.3, V)[None, :] + rng.uniform(0, 6, V))
+    sp = rng.uniform(0.3, 2.5, (N, V))
+    for mode in range(5):
+        kw = dict(a=sp, aps=True, p0=rng.uniform(0, 0.6, V), p1=rng.uniform(0.1, 0.5, V))
+        pos0 = rng.uniform(0, 1499, V)
+        for u, w in zip(port.sample_zx(mode, smp, trig, pos0, **kw), ref.sample_zx(mode, smp, trig, pos0, **kw)):
+            assert_bits_equal(np.asarray(u, np.float64), np.asarray(w, np.float64))
+    pha = rng.uniform(-0.1, 1.1, (N, V))
+    pha[:, :8] = (np.arange(N)[:, None] * rng.uniform(0.0005, 0.01, 8)[None, :]) % 1.0
+    for u, w in zip(port.sample_phasor(smp, pha), ref.sample_phasor(smp, pha)):
+        assert_bits_equal(np.asarray(u, np.float64), np.asarray(w, np.float64))
+    m = np.abs(rng.normal(0, 10, (50, 256))).astype(np.float32)
+    for u, w in zip(port.fft_features(m, 512), ref.fft_features(m, 512)):
+        assert np.array_equal(u.view(np.uint32), w.view(np.uint32))
+    L, S, T = 20000, 9, 2500
+    gs = rng.uniform(-1, 1, L)
+    pos = rng.uniform(0, 1, (T, S))
+    for u, w in zip(port.granular(2, 4, gs, T, pos, grainLength=0.04, overlaps=3),
+                    ref.granular(2, 4, gs, T, pos, grainLength=0.04, overlaps=3)):
+        assert_bits_equal(np.asarray(u, np.float64), np.asarray(w, np.float64))
+    speed = rng.uniform(-2, 2.5, S)
+    for u, w in zip(port.granular(3, 6, gs, T, speed, posMod=rng.uniform(-0.1, 0.1, S) * 0 + 0.05, grainLength=0.04, overlaps=3),
+                    ref.granular(3, 6, gs, T, speed, posMod=np.full(S, 0.05), grainLength=0.04, overlaps=3)):
+        assert_bits_equal(np.asarray(u, np.float64), np.asarray(w, np.float64))
