@@ -17,6 +17,8 @@
 // a 1-ULP coefficient difference, so no ULP claim is made for that mode.
 #include <math.h>
 
+#include <type_traits>
+
 #include "mxg_common.h"
 
 namespace mxg {
@@ -51,7 +53,7 @@ __device__ __forceinline__ double flt_lores(Flt &f, double input, double c, doub
 }
 
 template <int KIND, bool MOD>
-__global__ void filter_kernel(size_t V, size_t N, const double *__restrict__ in,
+__global__ void __launch_bounds__(256) filter_kernel(size_t V, size_t N, const double *__restrict__ in,
                               const double *__restrict__ cutoff, int cps,
                               const double *__restrict__ res, int rps,
                               const double *__restrict__ coef, double *__restrict__ st,
@@ -235,6 +237,41 @@ __device__ __forceinline__ double env_adsr(Env &e, double input, int trigger) {
     return out;
 }
 
+// Two steady states of the ADSR in which a sample is one multiply and no flag moves (read off
+// C:1415-1466): SUSTAIN = gate held after the hold time ran out (only C:1451-1453 fires:
+// output = input*amplitude), RELEASE = gate off after it (only C:1455-1463: amplitude *= release
+// while it is > 0).  A wavefront whose lanes are all in one of them, with the (shared, scalar) gate
+// constant over a chunk, runs the chunk without the predicated state machine -- same operations on
+// the same values, so bit-identical, at ~1/6 of the VALU work.
+__device__ __forceinline__ bool env_in_sustain(const Env &e) {
+    return e.attackphase != 1 && e.decayphase != 1 && e.releasephase != 1 && e.holdphase == 1 &&
+           e.holdcount >= e.holdtime;
+}
+__device__ __forceinline__ bool env_in_release(const Env &e) {
+    return e.attackphase != 1 && e.decayphase != 1 && e.releasephase == 1 && e.holdphase != 1 &&
+           e.holdcount >= e.holdtime;
+}
+__device__ __forceinline__ double env_sustain_tick(Env &e, double input) {  // gate == 1
+    e.output = input * e.amplitude;  // C:1452
+    return e.output;
+}
+__device__ __forceinline__ double env_release_tick(Env &e, double input) {  // gate != 1
+    const bool r = e.amplitude > 0.;  // C:1460
+    const double ampR = e.amplitude * e.release;
+    e.amplitude = r ? ampR : e.amplitude;
+    e.output = r ? input * e.amplitude : e.output;
+    return e.output;
+}
+// gate state of a full chunk from its (already fetched, wave-uniform) trigger values:
+// +1 all == 1, -1 all != 1, 0 mixed.  Scalar work.
+template <int U>
+__device__ __forceinline__ int gate_of_chunk(const int (&t)[U]) {
+    int on = 0;
+#pragma unroll
+    for (int i = 0; i < U; i++) on += (t[i] == 1) ? 1 : 0;
+    return on == U ? 1 : (on == 0 ? -1 : 0);
+}
+
 // C:1319-1358
 __device__ __forceinline__ double env_ar(Env &e, double input, int trigger) {
     const double attack = e.attack, release = e.release;
@@ -272,7 +309,7 @@ __device__ __forceinline__ double env_ar(Env &e, double input, int trigger) {
 }
 
 template <int MODE, bool HASIN, bool TPV>
-__global__ void env_kernel(size_t V, size_t N, const double *__restrict__ in,
+__global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const double *__restrict__ in,
                            const int32_t *__restrict__ trig, int tpv,
                            const double *__restrict__ par, const int64_t *__restrict__ holdtime,
                            double *__restrict__ dst, int64_t *__restrict__ ist,
@@ -285,7 +322,7 @@ __global__ void env_kernel(size_t V, size_t N, const double *__restrict__ in,
     double *op = out + v;
     // software pipeline (see filter_kernel): next chunk's inputs/triggers are requested before this
     // chunk's outputs are stored
-    constexpr int U = 4;
+    constexpr int U = 8;  // measured with the steady-state paths: 8 beats 4 on both paths
     double xn[U];
     int tn[U];
 #pragma unroll
@@ -305,12 +342,32 @@ __global__ void env_kernel(size_t V, size_t N, const double *__restrict__ in,
             if constexpr (HASIN) xn[i] = ip[m * V];
             tn[i] = TPV ? trig[m * V + v] : trig[m];
         }
+        int fast = 0;
+        if constexpr (MODE == 0 && !TPV) {
+            const int g = (n0 + U <= N) ? gate_of_chunk<U>(tc) : 0;
+            if (g > 0) fast = __all(env_in_sustain(e)) ? 1 : 0;
+            else if (g < 0) fast = __all(env_in_release(e)) ? 2 : 0;
+        }
+        if (fast == 1) {
 #pragma unroll
-        for (int i = 0; i < U; i++) {
-            if (n0 + i >= N) break;
-            double o = (MODE == 0) ? env_adsr(e, xc[i], tc[i]) : env_ar(e, xc[i], tc[i]);
-            *op = o;
-            op += V;
+            for (int i = 0; i < U; i++) {
+                *op = env_sustain_tick(e, xc[i]);
+                op += V;
+            }
+        } else if (fast == 2) {
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                *op = env_release_tick(e, xc[i]);
+                op += V;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                if (n0 + i >= N) break;
+                double o = (MODE == 0) ? env_adsr(e, xc[i], tc[i]) : env_ar(e, xc[i], tc[i]);
+                *op = o;
+                op += V;
+            }
         }
     }
     env_store(e, V, v, dst, ist);
@@ -324,7 +381,7 @@ __global__ void env_kernel(size_t V, size_t N, const double *__restrict__ in,
 // stores as well (loads and stores retire in order on one counter) -- measured 3.7x slower.
 // Per-voice triggers (TPV = true) are prefetched one 8-sample chunk ahead for the same reason.
 template <int MODE, bool NT, bool TPV>
-__global__ void voice_kernel(size_t V, size_t N, const double *__restrict__ freq,
+__global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const double *__restrict__ freq,
                              const double *__restrict__ cutoff, const double *__restrict__ res,
                              const double *__restrict__ coef, const int32_t *__restrict__ trig,
                              int tpv, const double *__restrict__ par,
@@ -353,24 +410,65 @@ __global__ void voice_kernel(size_t V, size_t N, const double *__restrict__ freq
     asm volatile("" : "+v"(e.sustain), "+v"(e.release), "+v"(e.holdtime), "+v"(e.holdcount));
     constexpr int U = 8;
     int tn[U];
-    if constexpr (TPV) {
 #pragma unroll
-        for (int i = 0; i < U; i++) tn[i] = trig[((size_t)i < N ? (size_t)i : N - 1) * V + v];
+    for (int i = 0; i < U; i++) {
+        const size_t m = (size_t)i < N ? (size_t)i : N - 1;
+        tn[i] = TPV ? trig[m * V + v] : trig[m];  // shared gate: scalar loads, also a chunk ahead
     }
     for (size_t n0 = 0; n0 < N; n0 += U) {
       int tc[U];
-      if constexpr (TPV) {
 #pragma unroll
-        for (int i = 0; i < U; i++) tc[i] = tn[i];
+      for (int i = 0; i < U; i++) tc[i] = tn[i];
 #pragma unroll
-        for (int i = 0; i < U; i++) tn[i] = trig[((n0 + U + i < N) ? n0 + U + i : N - 1) * V + v];
+      for (int i = 0; i < U; i++) {
+        const size_t m = (n0 + U + i < N) ? n0 + U + i : N - 1;
+        tn[i] = TPV ? trig[m * V + v] : trig[m];
+      }
+      int fast = 0;
+      if constexpr (!TPV) {
+        const int g = (n0 + U <= N) ? gate_of_chunk<U>(tc) : 0;
+        if (g > 0) fast = __all(env_in_sustain(e)) ? 1 : 0;
+        else if (g < 0) fast = __all(env_in_release(e)) ? 2 : 0;
+      }
+      if (fast) {  // steady envelope: see env_in_sustain
+        auto steady = [&](auto sustain) {
+            constexpr bool SUS = decltype(sustain)::value;
+            if constexpr (MODE == 1 && SUS) {
+                // the envelope value, hence (cutoff, c, r), is the same for every sample of the chunk
+                lores_coeffs_dev((1.0 * e.amplitude) * cut, rs, sr, c, r);
+            }
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                double o;
+                if constexpr (MODE == 0) {
+                    double s = phase;  // saw C:333-340
+                    hold = s;
+                    if (phase >= 1.0) phase -= 2.0;
+                    phase += inc;
+                    double y = flt_lores(f, s, c, r);
+                    o = SUS ? env_sustain_tick(e, y) : env_release_tick(e, y);
+                } else {
+                    double a = SUS ? env_sustain_tick(e, 1.0) : env_release_tick(e, 1.0);
+                    double s = phase;
+                    hold = s;
+                    if (phase >= 1.0) phase -= 2.0;
+                    phase += inc;
+                    if constexpr (!SUS) lores_coeffs_dev(a * cut, rs, sr, c, r);
+                    double y = flt_lores(f, s, c, r);
+                    o = y * a;
+                }
+                store1<NT>(op, o);
+                op += V;
+            }
+        };
+        if (fast == 1) steady(std::true_type{}); else steady(std::false_type{});
+        continue;
       }
 #pragma unroll
       for (int i = 0; i < U; i++) {
         const size_t n = n0 + i;
         if (n >= N) break;
-        int t;
-        if constexpr (TPV) t = tc[i]; else t = trig[n];
+        const int t = tc[i];
         double o;
         if constexpr (MODE == 0) {
             double s = phase;  // saw C:333-340
@@ -424,6 +522,7 @@ int mxg_filter_render(int kind, size_t V, size_t N, const double *d_in, const do
                 "constant-parameter lores/hires/bandpass need d_coef from mxg_filter_coeffs_host");
     if (V == 0 || N == 0) return MXG_OK;
     int block = tune_get("voice_block");
+    if (block > 256) block = 256;  // the bank kernels are compiled for <= 256 lanes per workgroup (512 VGPRs/lane budget)
     hipStream_t st = resolve_stream(stream);
     double sr = (double)settings().sampleRate;
 #define MXG_FLT_LAUNCH(K)                                                                        \
@@ -481,6 +580,7 @@ int mxg_env_render(int mode, size_t V, size_t N, const double *d_in, const int32
     MXG_REQUIRE(d_trig && d_par && d_holdtime && d_dst && d_ist && d_out, "null device pointer");
     if (V == 0 || N == 0) return MXG_OK;
     int block = tune_get("voice_block");
+    if (block > 256) block = 256;  // the bank kernels are compiled for <= 256 lanes per workgroup (512 VGPRs/lane budget)
     hipStream_t st = resolve_stream(stream);
 #define MXG_ENV_LAUNCH(M, I, P)                                                                      \
     hipLaunchKernelGGL((env_kernel<M, I, P>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_trig, \
@@ -521,6 +621,7 @@ int mxg_voice_render(int mode, size_t V, size_t N, const double *d_freq, const d
     MXG_REQUIRE(mode == 0 || (d_cutoff && d_res), "mode 1 needs d_cutoff and d_res");
     if (V == 0 || N == 0) return MXG_OK;
     int block = tune_get("voice_block");
+    if (block > 256) block = 256;  // the bank kernels are compiled for <= 256 lanes per workgroup (512 VGPRs/lane budget)
     bool nt = tune_get("voice_nt") != 0;
     hipStream_t st = resolve_stream(stream);
     double sr = (double)settings().sampleRate;

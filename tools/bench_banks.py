@@ -22,7 +22,10 @@ print("filter lores (hoisted)  %.1f us  (16 B/sample algorithmic)" % timed(lambd
 print("filter lopass           %.1f us" % timed(lambda: fb.render("lopass", x, np.full(V, 0.3), out=out)))
 eb = mx.maxiEnvBank(V); eb.setAttack(10); eb.setDecay(100); eb.setSustain(0.5); eb.setRelease(500)
 trig = mx.DeviceBuffer.from_numpy(((np.arange(B) % 300) < 150).astype(np.int32))
-print("env adsr (gate)         %.1f us  (16 B/sample)" % timed(lambda: eb.render(0, x, trig, B, out=out)))
+print("env adsr (gate 150/150) %.1f us  (16 B/sample; attack/decay/release every 300 samples: state-machine path)" % timed(lambda: eb.render(0, x, trig, B, out=out)))
+hold = mx.DeviceBuffer.from_numpy(np.ones(B, np.int32))
+for _ in range(4): eb.render(0, x, hold, B, out=out)
+print("env adsr (sustain)      %.1f us  (gate held: steady-state path)" % timed(lambda: eb.render(0, x, hold, B, out=out)))
 db = mx.maxiDelaylineBank(V, 2048)
 print("delay dl size 1024      %.1f us  (32 B/sample)" % timed(lambda: db.dl(x, 1024, 0.5, out=out)))
 sb = mx.maxiSampleBank(V); sb.setSample(rng.uniform(-1, 1, 441000)); sb.setPosition(v / V)
