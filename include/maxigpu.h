@@ -244,6 +244,21 @@ int mxg_sample_render_trig(int mode, size_t V, size_t N, const double *d_samples
                            const double *d_p0, const double *d_p1, double *d_position,
                            double *d_tprev, int32_t *d_tfirst, double *d_out, void *stream);
 
+/* maxiSample::load(fileName, channel) / read() (C:605-692): parse a 16-bit PCM RIFF/WAVE file the way the
+ * reference walks it, upload the payload as int16 and de-interleave + normalise on the device
+ * (amplitudes[i] = short/32767.0, C:679, bit-exact).  Returns the device sample buffer (guarded like
+ * mxg_sample_upload, free with mxg_sample_free) or NULL (cannot open / malformed; the reference returns
+ * false / reads garbage).  *h_len = amplitudes.size() = dataSize/2 -- for a multi-channel file that is the
+ * FULL interleaved length: the reference keeps every (2*channels)-th short at the front and leaves the rest
+ * (C:667-674, see wav.hip).  After read() the member `position` equals the size (C:681): start the bank's
+ * play heads there.  h_hdr (int32[8], may be NULL) receives ChunkSize, SubChunk1Size, Format, Channels,
+ * SampleRate, ByteRate, BlockAlign, BitsPerSample (set the bank's mySampleRate from [4]). */
+double *mxg_sample_load_wav(const char *path, int channel, size_t *h_len, int32_t *h_hdr);
+/* maxiSample::save(filename) (C:698-725): shorts = static_cast<short>(round(a*32767.0)) computed on the
+ * device, written behind the 44-byte header built from h_hdr (same 8 fields).  Synchronous. */
+int mxg_sample_save_wav(const char *path, const double *d_samples, size_t len, const int32_t *h_hdr,
+                        void *stream);
+
 /* ---- maxiFFT batch ---------------------------------------------------------------------- */
 /* A plan is what maxiFFT::setup(fftSize, hopSize, windowSize) prepares (L/maxiFFT.cpp:45-60): the
  * Hann window (fft::genWindow type 3, L/fft.cpp:409-413) and the fp32 twiddle sequences the

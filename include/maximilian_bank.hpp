@@ -354,6 +354,21 @@ public:
         position_.upload(std::vector<double>(V, (double)length_ - 1));
     }
     void setSampleAndRate(const std::vector<double> &sampleData, int sampleRate) { setSample(sampleData); mySampleRate = sampleRate; }
+    // load(fileName, channel) C:605-692: 16-bit PCM WAV, de-interleaved and normalised on the device; position = size (C:681)
+    bool load(const std::string &fileName, int channel = 0) {
+        size_t n = 0;
+        double *p = mxg_sample_load_wav(fileName.c_str(), channel, &n, wavHeader_);
+        if (!p) return false;  // the reference's `result`
+        clear();
+        d_samples_ = p;
+        length_ = n;
+        mySampleRate = wavHeader_[4];
+        position_.upload(std::vector<double>(V, (double)n));
+        return true;
+    }
+    bool save(const std::string &fileName) {  // C:698-725
+        return mxg_sample_save_wav(fileName.c_str(), d_samples_, length_, wavHeader_, nullptr) == MXG_OK;
+    }
     void trigger() { position_.upload(std::vector<double>(V, 0.0)); }  // C:597-600
     void setPositions(const std::vector<double> &p) { position_.upload(p); }
     void setSpeeds(const std::vector<double> &a) { a_.upload(a); }
@@ -388,6 +403,7 @@ private:
     size_t V;
     double *d_samples_ = nullptr;
     size_t length_ = 0;
+    int32_t wavHeader_[8] = {36, 16, 1, 1, 44100, 88200, 2, 16};  // ChunkSize .. BitsPerSample of the last load()
     maxigpu::DeviceArray<double> position_, a_, start_, end_, zxPrev_, phasorPrev_;
     maxigpu::DeviceArray<int32_t> zxFirst_, phasorFirst_;
 };

@@ -8,6 +8,7 @@ block, exactly like consecutive `play()` callbacks.  Everything here is plumbing
 C-ABI (maximilian_amd/_lib.py); no arithmetic on signals happens in Python.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -404,6 +405,36 @@ class maxiSampleBank(_Bank):
         self.d_samples, self.length = p, a.size
         self.mySampleRate = 44100
         self.position.upload(np.full(self.V, a.size - 1.0))
+
+    def load(self, fileName, channel=0):
+        """maxiSample::load (C:605-692): 16-bit PCM WAV -> device amplitudes (de-interleave + /32767.0 on
+        the device).  Returns False if the file cannot be read (the reference's bool).  position = size."""
+        n = ctypes.c_size_t(0)
+        hdr = np.zeros(8, np.int32)
+        p = lib().mxg_sample_load_wav(os.fsencode(fileName), int(channel), ctypes.byref(n), hdr.ctypes.data)
+        if not p:
+            return False
+        self.clear()
+        self.d_samples, self.length = p, n.value
+        self.wav_header = hdr
+        self.mySampleRate = int(hdr[4])
+        self.position.upload(np.full(self.V, float(n.value)))   # C:681
+        return True
+
+    def save(self, fileName):
+        """maxiSample::save (C:698-725) with the header fields of the loaded file (or a mono 16-bit default)."""
+        hdr = getattr(self, "wav_header", None)
+        if hdr is None:
+            hdr = np.array([36 + 2 * self.length, 16, 1, 1, self.mySampleRate, 2 * self.mySampleRate, 2, 16], np.int32)
+        check(lib().mxg_sample_save_wav(os.fsencode(fileName), self.d_samples, self.length, hdr.ctypes.data,
+                                        self.stream), "mxg_sample_save_wav")
+        return True
+
+    def amplitudes(self):
+        """The device sample buffer as a numpy array (for tests)."""
+        out = np.empty(self.length)
+        check(lib().mxg_memcpy_d2h(out.ctypes.data, self.d_samples, out.nbytes, self.stream), "mxg_memcpy_d2h")
+        return out
 
     def setSampleAndRate(self, samples, sampleRate):
         self.setSample(samples)

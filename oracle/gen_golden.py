@@ -338,6 +338,45 @@ def main():
     files["extra.npz"] = ("maxiOsc::noise (srand seed + draws), maxiMix stereo/quad/ambisonic bus, playOnZX* x5, "
                           "playWithPhasor, magsToDB/spectralFlatness/spectralCentroid, playAtPosition, maxiPitchShift")
 
+    # ---- maxiSample::load/save: 16-bit PCM WAV fixtures (synthesised here, never the reference's assets) ----
+    import struct
+    wavdir = os.path.join(GOLD, "wav")
+    os.makedirs(wavdir, exist_ok=True)
+    rng = np.random.default_rng(SEED + 10)
+
+    def wav_bytes(data_i16, channels=1, rate=44100, extra=b"", fmt_extra=b""):
+        data = data_i16.astype("<i2").tobytes()
+        fmt = struct.pack("<HHIIHH", 1, channels, rate, rate * channels * 2, channels * 2, 16) + fmt_extra
+        body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + extra + b"data" + struct.pack("<I", len(data)) + data
+        return b"RIFF" + struct.pack("<I", len(body)) + body
+
+    x = (rng.uniform(-1, 1, 3001) * 32767).astype(np.int16)
+    x[:4] = [32767, -32768, 0, 1]
+    st = (rng.uniform(-1, 1, 2000) * 32767).astype(np.int16)
+    wavs = {"mono": wav_bytes(x), "list": wav_bytes(x, extra=b"LIST" + struct.pack("<I", 10) + b"INFOabcdef"),
+            "fmt18": wav_bytes(x, fmt_extra=b"\x00\x00", rate=22050), "stereo": wav_bytes(st, channels=2)}
+    d = {}
+    if not ONLY or "wav.npz" in ONLY:
+        for k, b in wavs.items():
+            with open(os.path.join(wavdir, k + ".wav"), "wb") as f:
+                f.write(b)
+    for k in wavs:
+        for ch in ((0, 1) if k == "stereo" else (0,)):
+            amp, hdr, pos = R.wav_load(os.path.join(wavdir, k + ".wav"), ch)
+            n = amp.size
+            if k == "stereo":   # beyond the defined prefix the reference reads past its vector (C:669-672)
+                d["defined_%s_%d" % (k, ch)] = len(range(ch * 2, n, 4))
+            d["amp_%s_%d" % (k, ch)], d["hdr_%s_%d" % (k, ch)], d["pos_%s_%d" % (k, ch)] = amp, hdr, pos
+    amp = rng.uniform(-1, 1, 777)
+    amp[:7] = [1.0, -1.0, 0.5 / 32767, 1.5 / 32767, -0.5 / 32767, 2.5 / 32767, -32768 / 32767.0]
+    hdr = np.array([36 + 777 * 2, 16, 1, 1, 44100, 88200, 2, 16], np.int32)
+    d["save_amp"], d["save_hdr"] = amp, hdr
+    if not ONLY or "wav.npz" in ONLY:
+        R.wav_save(os.path.join(wavdir, "saved_by_reference.wav"), amp, hdr)
+    save("wav.npz", **d)
+    files["wav.npz"] = ("maxiSample::load of wav/{mono,list,fmt18,stereo}.wav (amplitudes, header fields, position) and the "
+                        "input of wav/saved_by_reference.wav (maxiSample::save)")
+
     sha = hashlib.sha256()
     for f in ("maximilian.cpp", "maximilian.h", "libs/fft.cpp", "libs/maxiFFT.cpp", "libs/maxiMFCC.cpp",
               "libs/maxiMFCC.h", "libs/maxiGrains.h"):

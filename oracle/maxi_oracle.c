@@ -1514,3 +1514,88 @@ int mxo_mfcc(unsigned numBins, unsigned numFilters, unsigned numCoeffs, double m
     free(mb);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------
+ * maxiSample::load / read (C:605-692) and save (C:698-725): 16-bit PCM RIFF/WAVE.
+ * read(): ChunkSize at byte 4; SubChunk1Size at 16, then format, channels, sampleRate, byteRate,
+ * blockAlign, bitsPerSample read sequentially (bytes 20..35); chunks are walked from
+ * 20 + SubChunk1Size until "data"; the data are read as shorts; for multi-channel files the
+ * reference de-interleaves IN PLACE with `for (i = readChannel*2; i < myDataSize+6; i += myChannels*2)
+ * shortAmps[position++] = shortAmps[i]` -- a SHORT index advanced by a BYTE stride and bounded by
+ * a byte count: it picks every (2*channels)-th short, keeps the vector at its full length (the
+ * tail keeps the interleaved data) and reads past the end of the vector for i >= size.  Those
+ * out-of-range reads are undefined in the reference; here they read 0 (parity: compare the
+ * defined prefix).  amplitudes[i] = short/32767.0; position = size.
+ * hdr as in oracle/ref_harness.cpp.  Returns size, -1 cannot open, -2 malformed.
+ * ------------------------------------------------------------------------------------ */
+#include <stdio.h>
+long mxo_wav_load(const char *path, int channel, double *out, size_t cap, int32_t *hdr, double *position) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;
+    fseek(f, 0, SEEK_END);
+    long fsize = ftell(f);
+    unsigned char *b = (unsigned char *)calloc((size_t)fsize + 16, 1);
+    fseek(f, 0, SEEK_SET);
+    if (fread(b, 1, (size_t)fsize, f) != (size_t)fsize) { fclose(f); free(b); return -2; }
+    fclose(f);
+    if (fsize < 44) { free(b); return -2; }
+    int32_t myChunkSize, mySubChunk1Size, mySampleRate, myByteRate, myDataSize = 0;
+    int16_t myFormat, myChannels, myBlockAlign, myBitsPerSample;
+    memcpy(&myChunkSize, b + 4, 4);
+    memcpy(&mySubChunk1Size, b + 16, 4);
+    memcpy(&myFormat, b + 20, 2);
+    memcpy(&myChannels, b + 22, 2);
+    memcpy(&mySampleRate, b + 24, 4);
+    memcpy(&myByteRate, b + 28, 4);
+    memcpy(&myBlockAlign, b + 32, 2);
+    memcpy(&myBitsPerSample, b + 34, 2);
+    long filePos = 20 + (long)mySubChunk1Size;
+    int datafound = 0;
+    while (!datafound) {
+        if (filePos < 0 || filePos + 8 > fsize) { free(b); return -2; } /* the reference runs into eof here */
+        memcpy(&myDataSize, b + filePos + 4, 4);
+        const int isdata = memcmp(b + filePos, "data", 4) == 0;
+        filePos += 8;
+        if (isdata) datafound = 1; else filePos += myDataSize;
+    }
+    if (myDataSize < 0) { free(b); return -2; }
+    const size_t n = (size_t)myDataSize / 2;
+    int16_t *sh = (int16_t *)calloc(n + 1, sizeof(int16_t));
+    size_t avail = (size_t)(fsize - filePos);
+    if (avail > (size_t)myDataSize) avail = (size_t)myDataSize;
+    memcpy(sh, b + filePos, avail > 2 * n ? 2 * n : avail); /* a short file leaves zeros, as the resized vector does */
+    if (myChannels > 1) {
+        size_t pos = 0;
+        for (long i = (long)channel * 2; i < (long)myDataSize + 6; i += ((long)myChannels * 2)) {
+            const int16_t v = ((size_t)i < n) ? sh[i] : 0; /* i >= n: undefined in the reference */
+            if (pos < n) sh[pos] = v;
+            pos++;
+        }
+    }
+    for (size_t i = 0; i < n && i < cap; i++) out[i] = sh[i] / 32767.0;
+    if (hdr) {
+        hdr[0] = myChunkSize; hdr[1] = mySubChunk1Size; hdr[2] = myFormat; hdr[3] = myChannels;
+        hdr[4] = mySampleRate; hdr[5] = myByteRate; hdr[6] = myBlockAlign; hdr[7] = myBitsPerSample;
+    }
+    if (position) *position = (double)n;
+    free(sh);
+    free(b);
+    return (long)n;
+}
+
+/* save(): shorts = static_cast<short>(round(amplitude*32767.0)); 44-byte header from the members. */
+int mxo_wav_save(const char *path, const double *amp, size_t len, const int32_t *hdr) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    int16_t *sh = (int16_t *)malloc(sizeof(int16_t) * (len ? len : 1));
+    for (size_t i = 0; i < len; i++) sh[i] = (int16_t)(int32_t)round(amp[i] * 32767.0);
+    const int32_t chunk = hdr[0], sub1 = hdr[1], rate = hdr[4], brate = hdr[5], dsize = (int32_t)(len * 2);
+    const int16_t fmt = (int16_t)hdr[2], ch = (int16_t)hdr[3], align = (int16_t)hdr[6], bits = (int16_t)hdr[7];
+    fwrite("RIFF", 1, 4, f); fwrite(&chunk, 4, 1, f); fwrite("WAVE", 1, 4, f); fwrite("fmt ", 1, 4, f);
+    fwrite(&sub1, 4, 1, f); fwrite(&fmt, 2, 1, f); fwrite(&ch, 2, 1, f); fwrite(&rate, 4, 1, f);
+    fwrite(&brate, 4, 1, f); fwrite(&align, 2, 1, f); fwrite(&bits, 2, 1, f); fwrite("data", 1, 4, f);
+    fwrite(&dsize, 4, 1, f); fwrite(sh, 2, len, f);
+    fclose(f);
+    free(sh);
+    return 0;
+}

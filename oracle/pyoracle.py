@@ -351,6 +351,28 @@ class Oracle:
                 _p(posMod), _p(rnd), R, _p(st), _p(gst), _p(out))
         return out, st, gst, rc
 
+    # -- maxiSample::load / save (16-bit PCM WAV) ---------------------------------------------------
+    def wav_load(self, path, channel=0, cap=1 << 22):
+        """Returns (amplitudes, hdr[8] int32, position) or None if the file cannot be opened."""
+        out = np.zeros(cap)
+        hdr = np.zeros(8, np.int32)
+        pos = ctypes.c_double(0)
+        fn = self.L.mxo_wav_load
+        fn.restype = ctypes.c_long
+        fn.argtypes = [ctypes.c_char_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p]
+        n = fn(os.fsencode(path), channel, _p(out), cap, _p(hdr), ctypes.addressof(pos))
+        if n < 0:
+            return None
+        return out[:n].copy(), hdr, pos.value
+
+    def wav_save(self, path, amplitudes, hdr):
+        amplitudes = _f64(amplitudes)
+        hdr = np.ascontiguousarray(hdr, np.int32)
+        fn = self.L.mxo_wav_save
+        fn.restype = c_int
+        fn.argtypes = [ctypes.c_char_p, c_void_p, c_size_t, c_void_p]
+        return fn(os.fsencode(path), _p(amplitudes), amplitudes.size, _p(hdr))
+
     # -- CPU baseline timer -----------------------------------------------------------------------
     def time_osc(self, wf, freq, N, threads=1):
         freq = _f64(freq)

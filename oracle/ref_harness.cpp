@@ -39,6 +39,7 @@ static int mxo_ref_rand() {
 
 #include <cstdint>
 #include <cstring>
+#include <iostream>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -755,6 +756,35 @@ int mxo_sample_phasor(size_t V, size_t N, const double *amp, size_t len, const d
         phasor_first[v] = s.phasorFirst;
     }
     return 0;
+}
+
+// ---- maxiSample::load / read / save (src/maximilian.cpp:605-725) ----------------------------------
+// hdr = {ChunkSize, SubChunk1Size, Format, Channels, SampleRate, ByteRate, BlockAlign, BitsPerSample}
+// Returns amplitudes.size() (or -1 if the file cannot be opened); copies min(size, cap) values.
+// The reference prints "Loading: ..." to stdout; stdout is parked on /dev/null for the call.
+long mxo_wav_load(const char *path, int channel, double *out, size_t cap, int32_t *hdr, double *position) {
+    maxiSample s;
+    fflush(stdout);
+    std::streambuf *old = std::cout.rdbuf(nullptr);
+    bool ok = s.load(path, channel);
+    std::cout.rdbuf(old);
+    if (!ok) return -1;
+    const size_t n = s.amplitudes.size();
+    for (size_t i = 0; i < n && i < cap; i++) out[i] = s.amplitudes[i];
+    if (hdr) {
+        hdr[0] = s.myChunkSize; hdr[1] = s.mySubChunk1Size; hdr[2] = s.myFormat; hdr[3] = s.myChannels;
+        hdr[4] = s.mySampleRate; hdr[5] = s.myByteRate; hdr[6] = s.myBlockAlign; hdr[7] = s.myBitsPerSample;
+    }
+    if (position) *position = s.position;
+    return (long)n;
+}
+
+int mxo_wav_save(const char *path, const double *amp, size_t len, const int32_t *hdr) {
+    maxiSample s;
+    s.amplitudes.assign(amp, amp + len);
+    s.myChunkSize = hdr[0]; s.mySubChunk1Size = hdr[1]; s.myFormat = (short)hdr[2]; s.myChannels = (short)hdr[3];
+    s.mySampleRate = hdr[4]; s.myByteRate = hdr[5]; s.myBlockAlign = (short)hdr[6]; s.myBitsPerSample = (short)hdr[7];
+    return s.save(path) ? 0 : -1;
 }
 
 }  // extern "C"
