@@ -289,6 +289,25 @@ int mxg_fft_batch(const mxg_fft_plan *plan, const float *d_signal, size_t frame_
 int mxg_fft_features(const mxg_fft_plan *plan, const float *d_mags, size_t nframes, float *d_db,
                      float *d_flatness, float *d_centroid, void *stream);
 
+/* ---- maxiIFFT batch (L/maxiFFT.cpp:140-192, SPECTRUM mode) ---------------------------------------- */
+/* maxiIFFT::setup(fftSize, hopSize, windowSize): Hann window over (windowSize ? windowSize : fftSize),
+ * zero beyond (note: not maxiFFT's max(windowSize, fftSize)).  fftSize: power of two in [8, 8192]. */
+typedef struct mxg_ifft_plan mxg_ifft_plan;
+mxg_ifft_plan *mxg_ifft_plan_create(int fftSize, int hopSize, int windowSize);
+int mxg_ifft_plan_destroy(mxg_ifft_plan *plan);
+/* nframes spectra d_mags/d_phases [nframes][bins] -> d_signal [nframes*hopSize]: the samples
+ * maxiIFFT::process(mags, phases) returns when it is called hopSize times per spectrum (the spectrum is
+ * consumed at pos == 0, L/maxiFFT.cpp:156).  Per frame: polToCart (L/fft.cpp:590-604), a full fftSize-point
+ * complex inverse FFT with the reference's fp32 recurrence twiddles, /fftSize, x window (:606-611), then
+ * the overlap-add hop buffer (:176-183) evaluated in the reference's order of additions.  d_buffer
+ * ([fftSize], in/out, may be NULL = a fresh object) is the member `buffer`, so consecutive calls continue
+ * one stream.  d_ifft_out (optional [nframes][fftSize]) receives each frame's windowed inverse transform
+ * (`ifftOut`).  Bit-exact given the same cartesian inputs; the float cos/sin of polToCart are the
+ * device's => tolerance.  COMPLEX mode of the reference copies its inputs into the wrong
+ * arrays (L/fft.cpp:613-619: out_real/out_img, which calcIFFT then overwrites) and is not provided. */
+int mxg_ifft_batch(const mxg_ifft_plan *plan, const float *d_mags, const float *d_phases, size_t nframes,
+                   float *d_buffer, float *d_signal, float *d_ifft_out, void *stream);
+
 /* ---- maxiMFCC batch --------------------------------------------------------------------- */
 /* maxiMFCC::setup(numBins, numFilters, numCoeffs, minFreq, maxFreq) (L/maxiMFCC.h:56-75): builds
  * the mel filterbank and DCT tables on the host libm.  Works without a device (tables only). */

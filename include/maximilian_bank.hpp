@@ -438,6 +438,30 @@ private:
     int fftSize_ = 0, hopSize_ = 0, bins_ = 0;
 };
 
+// maxiIFFT (L/maxiFFT.h:117-156), SPECTRUM mode, over batches of spectra; the overlap-add buffer is carried
+class maxiIFFTBatch {
+public:
+    ~maxiIFFTBatch() { if (plan_) mxg_ifft_plan_destroy(plan_); }
+    void setup(int fftSize = 1024, int hopSize = 512, int windowSize = 0) {  // L/maxiFFT.cpp:140-153
+        if (plan_) mxg_ifft_plan_destroy(plan_);
+        maxigpu::check(mxg_init(-1), "mxg_init");
+        plan_ = mxg_ifft_plan_create(fftSize, hopSize, windowSize);
+        if (!plan_) throw std::runtime_error(std::string("mxg_ifft_plan_create: ") + mxg_last_error());
+        fftSize_ = fftSize; hopSize_ = hopSize;
+        buffer_.resize((size_t)fftSize);  // zero-filled, as setup() leaves `buffer`
+    }
+    int getNumBins() const { return fftSize_ / 2; }
+    // d_mags/d_phases [nframes][bins] -> d_signal [nframes*hopSize]: what process() returns, hopSize calls per spectrum
+    void process(const float *d_mags, const float *d_phases, size_t nframes, float *d_signal, void *stream = nullptr) {
+        maxigpu::check(mxg_ifft_batch(plan_, d_mags, d_phases, nframes, buffer_.get(), d_signal, nullptr, stream), "mxg_ifft_batch");
+    }
+
+private:
+    mxg_ifft_plan *plan_ = nullptr;
+    int fftSize_ = 0, hopSize_ = 0;
+    maxigpu::DeviceArray<float> buffer_;
+};
+
 class maxiMFCCBatch {
 public:
     ~maxiMFCCBatch() { if (plan_) mxg_mfcc_plan_destroy(plan_); }

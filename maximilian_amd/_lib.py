@@ -65,6 +65,9 @@ SIGNATURES = {
     "mxg_fft_plan_bins": (c_int, [c_void_p]),
     "mxg_sample_load_wav": (c_void_p, [c_char_p, c_int, c_void_p, c_void_p]),
     "mxg_sample_save_wav": (c_int, [c_char_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mxg_ifft_plan_create": (c_void_p, [c_int, c_int, c_int]),
+    "mxg_ifft_plan_destroy": (c_int, [c_void_p]),
+    "mxg_ifft_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_fft_features": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_fft_batch": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p]),

@@ -38,6 +38,13 @@ struct mxg_fft_plan {
     float2 *d_post;    // post-pass (wr, wi) for i = 1 .. half/2-1 at index i
 };
 
+// maxiIFFT::setup (L/maxiFFT.cpp:140-153): windowSize ? windowSize : fftSize, Hann over that, zero beyond
+struct mxg_ifft_plan {
+    int fftSize, hopSize, windowSize, bins, numBits;  // numBits = log2(fftSize): the inverse is a FULL-size complex FFT
+    float *d_window;  // [fftSize]
+    float2 *d_tw;     // inverse-direction stage twiddles, same indexing as mxg_fft_plan::d_tw
+};
+
 namespace mxg {
 namespace {
 
@@ -151,6 +158,96 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fft_generic_kernel(
         wave_lds_sync();
     }
 }
+
+// ---- K6i: maxiIFFT (L/maxiFFT.cpp:155-192 SPECTRUM mode; L/fft.cpp:590-611) -----------------------------
+// polToCart (float cos/sin of the phase: device cosf/sinf => stated tolerance), zeroed negative
+// frequencies, a full n-point complex inverse FFT with the reference's fp32 recurrence twiddles
+// (replayed on the host for the inverse angle), /n, times the window.  One wavefront per frame, one
+// LDS pass per stage (the structure of K6b).  ifft_out[f][i] = 0.0f + out_real[i]*window[i] is the
+// zero-filled `ifftOut` of the reference after calcIFFT's `+=`.
+__global__ void ifft_generic_kernel(const float *__restrict__ mags, const float *__restrict__ phases,
+                                    size_t nframes, int n, int numBits, const float *__restrict__ window,
+                                    const float2 *__restrict__ tw, float *__restrict__ ifft_out) {
+    extern __shared__ float2 s_dyn[];
+    const int half = n >> 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    float2 *X = s_dyn + (size_t)wave * (n + (n >> 5) + 1);
+    auto P = [](int idx) { return idx + (idx >> 5); };
+    const float denom = (float)n;
+    for (size_t f = (size_t)blockIdx.x * nwaves + wave; f < nframes; f += (size_t)gridDim.x * nwaves) {
+        const float *m = mags + f * (size_t)half, *ph = phases + f * (size_t)half;
+        for (int i = lane; i < n; i += 64) {
+            float2 v = {0.0f, 0.0f};  // negative frequencies zeroed, L/fft.cpp:601-603
+            if (i < half) {
+                const float mg = m[i], p = ph[i];
+                v.x = mg * cosf(p);  // :597-598
+                v.y = mg * sinf(p);
+            }
+            const int j = (int)(__brev((unsigned)i) >> (32 - numBits));
+            X[P(j)] = v;
+        }
+        wave_lds_sync();
+        for (int s = 0; s < numBits; s++) {
+            const int h = 1 << s;
+            for (int b = lane; b < half; b += 64) {
+                const int nn = b & (h - 1);
+                const int j = ((b >> s) << (s + 1)) | nn;
+                const int k = j + h;
+                float2 xj = X[P(j)], xk = X[P(k)];
+                bfly(xj, xk, tw[h - 1 + nn]);
+                X[P(j)] = xj;
+                X[P(k)] = xk;
+            }
+            wave_lds_sync();
+        }
+        float *o = ifft_out + f * (size_t)n;
+        for (int i = lane; i < n; i += 64) {
+            const float r = X[P(i)].x / denom;  // L/fft.cpp:201-209
+            o[i] = 0.0f + r * window[i];        // :608-610 into the zero-filled ifftOut
+        }
+        wave_lds_sync();
+    }
+}
+
+// The hop buffer of maxiIFFT::process (L/maxiFFT.cpp:176-183): per frame, shift left by hop, zero the
+// tail, add the frame.  Position i of the buffer after frame k is therefore the left-to-right sum
+// (((carried or 0) + o_{m0}[..]) + ... ) + o_k[i] over the frames that overlap it, oldest first -- a closed
+// form each output sample can evaluate on its own, in the reference's order of additions.
+__device__ __forceinline__ float ola_value(const float *__restrict__ ifft_out, const float *__restrict__ buf_in,
+                                           long long k, int i, int n, int hop) {
+    // frames m = k - j contribute o_m[i + j*hop] while i + j*hop < n
+    const int J = (n - 1 - i) / hop;
+    float s;
+    long long m0 = k - J;
+    if (m0 <= 0) {  // the state carried into this launch is older than frame 0
+        const long long q = (long long)i + (k + 1) * hop;
+        s = (buf_in && q < n) ? buf_in[q] : 0.0f;
+        m0 = 0;
+    } else {
+        s = 0.0f;
+    }
+    for (long long mfr = m0; mfr <= k; mfr++) s += ifft_out[(size_t)mfr * n + (size_t)(i + (k - mfr) * hop)];
+    return s;
+}
+
+__global__ void ifft_ola_kernel(const float *__restrict__ ifft_out, size_t nframes, int n, int hop,
+                                const float *__restrict__ buf_in, float *__restrict__ out,
+                                float *__restrict__ buf_out) {
+    const size_t total = nframes * (size_t)hop;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total) {
+        const long long k = (long long)(t / hop);
+        out[t] = ola_value(ifft_out, buf_in, k, (int)(t % hop), n, hop);
+    } else if (t < total + (size_t)n && buf_out) {
+        const int i = (int)(t - total);
+        buf_out[i] = ola_value(ifft_out, buf_in, (long long)nframes - 1, i, n, hop);
+    }
+}
+
+float *g_ifft_scratch = nullptr;
+size_t g_ifft_scratch_cap = 0;  // floats
+float *g_ifft_buf_tmp = nullptr;
+size_t g_ifft_buf_tmp_cap = 0;
 
 // ---- K6a: fftSize 1024 (half = 512 = 8^3) ------------------------------------------------------
 // LDS image of one frame: 512 float2 + 1 pad per 8 (index p = i + i/8): conflict-free for the
@@ -504,6 +601,119 @@ int mxg_fft_features(const mxg_fft_plan *p, const float *d_mags, size_t nframes,
     hipLaunchKernelGGL(fft_features_kernel, dim3((unsigned)blocks), dim3(64), 0, resolve_stream(stream), d_mags,
                        nframes, p->bins, binhz, d_db, d_flatness, d_centroid);
     return check_hip(hipGetLastError(), "fft_features_kernel launch");
+}
+
+mxg_ifft_plan *mxg_ifft_plan_create(int fftSize, int hopSize, int windowSize) {
+    if (ensure_init()) return nullptr;
+    if (fftSize < 8 || fftSize > 8192 || (fftSize & (fftSize - 1))) {
+        fail(MXG_ERR_INVALID, "mxg_ifft_plan_create: fftSize %d must be a power of two in [8, 8192]", fftSize);
+        return nullptr;
+    }
+    const int win = windowSize ? windowSize : fftSize;  // L/maxiFFT.cpp:143
+    if (win < 2 || win > fftSize) {
+        fail(MXG_ERR_INVALID, "mxg_ifft_plan_create: windowSize %d outside [2, fftSize] (genWindow would overrun "
+                              "the reference's window vector, maxiFFT.cpp:151-152)", windowSize);
+        return nullptr;
+    }
+    if (hopSize <= 0 || hopSize > fftSize) {
+        fail(MXG_ERR_INVALID, "mxg_ifft_plan_create: hopSize %d out of (0, %d]", hopSize, fftSize);
+        return nullptr;
+    }
+    int numBits = 0;
+    while (!(fftSize & (1 << numBits))) numBits++;
+    std::vector<float> window(fftSize, 0.0f);
+    for (int i = 0; i < win; i++) window[i] = 0.50 - 0.50 * cos(2 * M_PI * i / (win - 1));  // L/fft.cpp:409-413
+    std::vector<float2> tw(fftSize);
+    {   // replay of L/fft.cpp:137-182 with InverseTransform = true
+        const double angle_numerator = -(2.0 * M_PI);
+        int BlockEnd = 1;
+        for (int BlockSize = 2; BlockSize <= fftSize; BlockSize <<= 1) {
+            double delta_angle = angle_numerator / (double)BlockSize;
+            float sm2 = sin(-2 * delta_angle);
+            float sm1 = sin(-delta_angle);
+            float cm2 = cos(-2 * delta_angle);
+            float cm1 = cos(-delta_angle);
+            float w = 2 * cm1;
+            float ar2 = cm2, ar1 = cm1, ai2 = sm2, ai1 = sm1;
+            for (int n = 0; n < BlockEnd; n++) {
+                float ar0 = w * ar1 - ar2;
+                ar2 = ar1;
+                ar1 = ar0;
+                float ai0 = w * ai1 - ai2;
+                ai2 = ai1;
+                ai1 = ai0;
+                tw[BlockEnd - 1 + n] = make_float2(ar0, ai0);
+            }
+            BlockEnd = BlockSize;
+        }
+    }
+    mxg_ifft_plan *p = new mxg_ifft_plan();
+    p->fftSize = fftSize; p->hopSize = hopSize; p->windowSize = win; p->bins = fftSize / 2; p->numBits = numBits;
+    p->d_window = nullptr; p->d_tw = nullptr;
+    if (check_hip(hipMalloc(&p->d_window, sizeof(float) * fftSize), "hipMalloc") ||
+        check_hip(hipMalloc(&p->d_tw, sizeof(float2) * fftSize), "hipMalloc") ||
+        check_hip(hipMemcpy(p->d_window, window.data(), sizeof(float) * fftSize, hipMemcpyHostToDevice), "hipMemcpy") ||
+        check_hip(hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * fftSize, hipMemcpyHostToDevice), "hipMemcpy")) {
+        mxg_ifft_plan_destroy(p);
+        return nullptr;
+    }
+    return p;
+}
+
+int mxg_ifft_plan_destroy(mxg_ifft_plan *p) {
+    if (!p) return MXG_OK;
+    if (p->d_window) (void)hipFree(p->d_window);
+    if (p->d_tw) (void)hipFree(p->d_tw);
+    delete p;
+    return MXG_OK;
+}
+
+int mxg_ifft_batch(const mxg_ifft_plan *p, const float *d_mags, const float *d_phases, size_t nframes,
+                   float *d_buffer, float *d_signal, float *d_ifft_out, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(p && d_mags && d_phases && d_signal, "null plan or pointer");
+    if (nframes == 0) return MXG_OK;
+    hipStream_t st = resolve_stream(stream);
+    const int n = p->fftSize;
+    float *io = d_ifft_out;
+    if (!io) {  // grow-only scratch for the per-frame transforms
+        const size_t need = nframes * (size_t)n;
+        if (g_ifft_scratch_cap < need) {
+            if (g_ifft_scratch) MXG_HIP(hipFree(g_ifft_scratch));
+            g_ifft_scratch = nullptr;
+            g_ifft_scratch_cap = 0;
+            MXG_HIP(hipMalloc(&g_ifft_scratch, need * sizeof(float)));
+            g_ifft_scratch_cap = need;
+        }
+        io = g_ifft_scratch;
+    }
+    const size_t per_wave = sizeof(float2) * (size_t)(n + (n >> 5) + 1);
+    int waves = n <= 1024 ? 4 : (n <= 2048 ? 2 : 1);
+    const size_t lds = per_wave * waves;
+    if (lds > 64 * 1024)
+        MXG_HIP(hipFuncSetAttribute((const void *)ifft_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    size_t blocks = (nframes + waves - 1) / waves;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(ifft_generic_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, st, d_mags, d_phases, nframes, n,
+                       p->numBits, p->d_window, p->d_tw, io);
+    MXG_HIP(hipGetLastError());
+    // overlap-add: the carried buffer is read while the new one is written -> stage the old one
+    const float *buf_in = nullptr;
+    if (d_buffer) {
+        if (g_ifft_buf_tmp_cap < (size_t)n) {
+            if (g_ifft_buf_tmp) MXG_HIP(hipFree(g_ifft_buf_tmp));
+            g_ifft_buf_tmp = nullptr;
+            g_ifft_buf_tmp_cap = 0;
+            MXG_HIP(hipMalloc(&g_ifft_buf_tmp, sizeof(float) * n));
+            g_ifft_buf_tmp_cap = (size_t)n;
+        }
+        MXG_HIP(hipMemcpyAsync(g_ifft_buf_tmp, d_buffer, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+        buf_in = g_ifft_buf_tmp;
+    }
+    const size_t total = nframes * (size_t)p->hopSize + (size_t)n;
+    hipLaunchKernelGGL(ifft_ola_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, io, nframes, n, p->hopSize,
+                       buf_in, d_signal, d_buffer);
+    return check_hip(hipGetLastError(), "ifft kernels launch");
 }
 
 }  // extern "C"

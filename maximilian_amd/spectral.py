@@ -157,3 +157,51 @@ class maxiMFCC:
             self.close()
         except Exception:
             pass
+
+
+class maxiIFFT:
+    """maxiIFFT (L/maxiFFT.h:117-156, SPECTRUM mode) over batches of spectra: `process_frames(mags, phases)`
+    returns the nframes*hopSize samples `process()` would return when called hopSize times per spectrum;
+    the overlap-add buffer is carried between calls."""
+    SPECTRUM, COMPLEX = 0, 1
+
+    def __init__(self, stream=None):
+        self.plan = None
+        self.stream = stream
+
+    def setup(self, fftSize=1024, hopSize=512, windowSize=0):
+        self.close()
+        p = lib().mxg_ifft_plan_create(int(fftSize), int(hopSize), int(windowSize))
+        if not p:
+            raise ValueError(lib().mxg_last_error().decode())
+        self.plan = p
+        self.fftSize, self.hopSize, self.bins = fftSize, hopSize, fftSize // 2
+        self.windowSize = windowSize if windowSize else fftSize   # L/maxiFFT.cpp:143
+        self.buffer = DeviceBuffer(fftSize, np.float32)           # member `buffer`, zero-filled by setup()
+        self.ifftOut = None
+
+    def getNumBins(self): return self.bins
+
+    def process_frames(self, mags, phases, keep_ifft=False):
+        dm = mags if isinstance(mags, DeviceBuffer) or hasattr(mags, "data_ptr") else \
+            DeviceBuffer.from_numpy(np.ascontiguousarray(mags, np.float32))
+        dp = phases if isinstance(phases, DeviceBuffer) or hasattr(phases, "data_ptr") else \
+            DeviceBuffer.from_numpy(np.ascontiguousarray(phases, np.float32))
+        n = dm.shape[0]
+        out = DeviceBuffer(n * self.hopSize, np.float32, zero=False)
+        self.ifftOut = DeviceBuffer((n, self.fftSize), np.float32, zero=False) if keep_ifft else None
+        check(lib().mxg_ifft_batch(self.plan, _ptr(dm), _ptr(dp), n, self.buffer.ptr, _ptr(out), _ptr(self.ifftOut),
+                                   self.stream), "mxg_ifft_batch")
+        self._keep = (dm, dp)
+        return out
+
+    def close(self):
+        if self.plan:
+            lib().mxg_ifft_plan_destroy(self.plan)
+            self.plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

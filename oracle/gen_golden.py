@@ -377,6 +377,22 @@ def main():
     files["wav.npz"] = ("maxiSample::load of wav/{mono,list,fmt18,stereo}.wav (amplitudes, header fields, position) and the "
                         "input of wav/saved_by_reference.wav (maxiSample::save)")
 
+    # ---- maxiIFFT (SPECTRUM mode), two consecutive calls with the overlap-add buffer carried -----------------
+    rng = np.random.default_rng(SEED + 11)
+    d = {}
+    for (fs, hop, win) in [(1024, 512, 0), (1024, 256, 1024), (64, 16, 48)]:
+        nf = 7
+        m = np.abs(rng.normal(0, 3, (nf, fs // 2))).astype(np.float32)
+        ph = rng.uniform(-np.pi, np.pi, (nf, fs // 2)).astype(np.float32)
+        ph[:, ::3] = 0.0
+        tag = "%d_%d_%d" % (fs, hop, win)
+        o1, io1, buf = R.ifft_stream(m[:3], ph[:3], fs, hop, win)
+        o2, io2, buf = R.ifft_stream(m[3:], ph[3:], fs, hop, win, buffer=buf)
+        d["mags_" + tag], d["phases_" + tag] = m, ph
+        d["signal_" + tag], d["ifftout_" + tag], d["buffer_" + tag] = np.concatenate([o1, o2]), np.concatenate([io1, io2]), buf
+    save("ifft.npz", **d)
+    files["ifft.npz"] = "maxiIFFT 1024/512, 1024/256/1024, 64/16/48: signal, per-frame ifftOut, final overlap-add buffer"
+
     sha = hashlib.sha256()
     for f in ("maximilian.cpp", "maximilian.h", "libs/fft.cpp", "libs/maxiFFT.cpp", "libs/maxiMFCC.cpp",
               "libs/maxiMFCC.h", "libs/maxiGrains.h"):

@@ -1021,12 +1021,13 @@ static int fft_reverse_bits(int index, int NumBits) { /* L/fft.cpp:74-85 */
     return rev;
 }
 
-/* L/fft.cpp:118-211, forward transform only */
-static void fft_complex(int NumSamples, const float *RealIn, const float *ImagIn, float *RealOut,
-                        float *ImagOut) {
+/* L/fft.cpp:118-211 */
+static void fft_complex_dir(int NumSamples, int InverseTransform, const float *RealIn, const float *ImagIn,
+                            float *RealOut, float *ImagOut) {
     int NumBits = 0, i, j, k, n, BlockSize, BlockEnd;
     double angle_numerator = 2.0 * M_PI;
     float tr, ti;
+    if (InverseTransform) angle_numerator = -angle_numerator; /* :137-138 */
     while (!(NumSamples & (1 << NumBits))) NumBits++; /* NumberOfBitsNeeded, :60-72 */
     for (i = 0; i < NumSamples; i++) {
         j = fft_reverse_bits(i, NumBits);
@@ -1065,6 +1066,18 @@ static void fft_complex(int NumSamples, const float *RealIn, const float *ImagIn
         }
         BlockEnd = BlockSize;
     }
+    if (InverseTransform) { /* :201-209 */
+        float denom = (float)NumSamples;
+        for (i = 0; i < NumSamples; i++) {
+            RealOut[i] /= denom;
+            ImagOut[i] /= denom;
+        }
+    }
+}
+
+static void fft_complex(int NumSamples, const float *RealIn, const float *ImagIn, float *RealOut,
+                        float *ImagOut) {
+    fft_complex_dir(NumSamples, 0, RealIn, ImagIn, RealOut, ImagOut);
 }
 
 /* L/fft.cpp:228-282 */
@@ -1597,5 +1610,49 @@ int mxo_wav_save(const char *path, const double *amp, size_t len, const int32_t 
     fwrite(&dsize, 4, 1, f); fwrite(sh, 2, len, f);
     fclose(f);
     free(sh);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * maxiIFFT::setup/process L/maxiFFT.cpp:140-192 (SPECTRUM mode); fft::polToCart L/fft.cpp:590-604,
+ * calcIFFT :606-611, inversePowerSpectrum :622-625.
+ * polToCart: in_real[i] = magnitude[i]*cos(phase[i]) -- fft.cpp includes <math.h>/<iostream>, so the
+ * float argument selects the float overload (cosf/sinf), pinned against the compiled reference; the
+ * upper half (negative frequencies) is zeroed; a FULL n-point complex inverse FFT follows, only its
+ * real part is used: finalOut[i] += out_real[i]*window[i] into a zeroed ifftOut, then the hop buffer
+ * is shifted by hopSize, its tail zeroed and ifftOut added.  window = Hann over windowSize
+ * (windowSize ? windowSize : fftSize), zero beyond.
+ * ------------------------------------------------------------------------------------ */
+int mxo_ifft_stream(const float *mags, const float *phases, size_t nframes, int fftSize, int hopSize,
+                    int windowSize, float *out, float *ifft_out, float *buffer_io) {
+    if (fftSize < 4 || (fftSize & (fftSize - 1)) || hopSize <= 0 || hopSize > fftSize) return -1;
+    if (windowSize > fftSize) return -2;
+    const int n = fftSize, half = fftSize / 2;
+    const int win = windowSize ? windowSize : fftSize; /* :143 */
+    float *window = (float *)calloc(n, sizeof(float));
+    for (int i = 0; i < win; i++) window[i] = 0.50 - 0.50 * cos(2 * M_PI * i / (win - 1));
+    float *in_real = (float *)calloc(n, sizeof(float)), *in_img = (float *)calloc(n, sizeof(float));
+    float *out_real = (float *)calloc(n, sizeof(float)), *out_img = (float *)calloc(n, sizeof(float));
+    float *ifftOut = (float *)calloc(n, sizeof(float)), *buffer = (float *)calloc(n, sizeof(float));
+    if (buffer_io) memcpy(buffer, buffer_io, sizeof(float) * n);
+    for (size_t k = 0; k < nframes; k++) {
+        const float *magnitude = mags + k * half, *phase = phases + k * half;
+        for (int i = 0; i < n; i++) ifftOut[i] = 0;
+        for (int i = 0; i < half; i++) {
+            in_real[i] = magnitude[i] * cosf(phase[i]);
+            in_img[i] = magnitude[i] * sinf(phase[i]);
+        }
+        memset(in_real + half, 0, sizeof(float) * half);
+        memset(in_img + half, 0, sizeof(float) * half);
+        fft_complex_dir(n, 1, in_real, in_img, out_real, out_img);
+        for (int i = 0; i < n; i++) ifftOut[i] += out_real[i] * window[i];
+        if (ifft_out) memcpy(ifft_out + k * n, ifftOut, sizeof(float) * n);
+        memmove(buffer, buffer + hopSize, (n - hopSize) * sizeof(float));
+        memset(buffer + (n - hopSize), 0, hopSize * sizeof(float));
+        for (int i = 0; i < n; i++) buffer[i] += ifftOut[i];
+        for (int i = 0; i < hopSize; i++) out[k * hopSize + i] = buffer[i];
+    }
+    if (buffer_io) memcpy(buffer_io, buffer, sizeof(float) * n);
+    free(window); free(in_real); free(in_img); free(out_real); free(out_img); free(ifftOut); free(buffer);
     return 0;
 }

@@ -293,6 +293,22 @@ class Oracle:
         assert rc == 0, rc
         return flat, cen
 
+    def ifft_stream(self, mags, phases, fftSize=1024, hopSize=512, windowSize=0, buffer=None):
+        """maxiIFFT (L/maxiFFT.cpp:140-192, SPECTRUM mode).  Returns (signal [nframes*hop], ifftOut [nframes][fftSize],
+        buffer [fftSize])."""
+        mags = np.ascontiguousarray(mags, np.float32)
+        phases = np.ascontiguousarray(phases, np.float32)
+        nframes = mags.shape[0]
+        out = np.zeros(nframes * hopSize, np.float32)
+        io = np.zeros((nframes, fftSize), np.float32)
+        buf = np.zeros(fftSize, np.float32) if buffer is None else np.ascontiguousarray(buffer, np.float32).copy()
+        fn = self.L.mxo_ifft_stream
+        fn.restype = c_int
+        fn.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+        rc = fn(_p(mags), _p(phases), nframes, fftSize, hopSize, windowSize, _p(out), _p(io), _p(buf))
+        assert rc == 0, rc
+        return out, io, buf
+
     # -- maxiMFCC ---------------------------------------------------------------------------------------
     def mfcc_tables(self, numBins=512, numFilters=42, numCoeffs=13, minFreq=20.0, maxFreq=20000.0):
         W = np.zeros(numFilters * numBins)

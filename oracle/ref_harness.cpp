@@ -787,4 +787,30 @@ int mxo_wav_save(const char *path, const double *amp, size_t len, const int32_t 
     return s.save(path) ? 0 : -1;
 }
 
+// ---- maxiIFFT (src/libs/maxiFFT.cpp:140-192; fft::polToCart/calcIFFT src/libs/fft.cpp:590-624) ----------
+// nframes spectra (mags/phases [nframes][bins]) -> the nframes*hopSize samples process() returns when it
+// is called hopSize times per spectrum (SPECTRUM mode).  ifft_out (optional, [nframes][fftSize]) = the
+// windowed inverse transform of each frame before overlap-add; buffer (fftSize, in/out) = the member
+// `buffer` (overlap-add state), so consecutive calls continue one stream.
+int mxo_ifft_stream(const float *mags, const float *phases, size_t nframes, int fftSize, int hopSize,
+                    int windowSize, float *out, float *ifft_out, float *buffer) {
+    if (fftSize < 4 || (fftSize & (fftSize - 1)) || hopSize <= 0 || hopSize > fftSize) return -1;
+    if (windowSize > fftSize) return -2;  // genWindow would overrun `window`
+    maxiIFFT f;
+    f.setup(fftSize, hopSize, windowSize);
+    const int bins = f.getNumBins();
+    if (buffer) std::copy(buffer, buffer + fftSize, f.buffer.begin());
+    std::vector<float> m(bins), p(bins);
+    for (size_t k = 0; k < nframes; k++) {
+        std::copy(mags + k * bins, mags + (k + 1) * bins, m.begin());
+        std::copy(phases + k * bins, phases + (k + 1) * bins, p.begin());
+        for (int i = 0; i < hopSize; i++) {
+            out[k * hopSize + i] = f.process(m, p, maxiIFFT::SPECTRUM);
+            if (i == 0 && ifft_out) std::copy(f.ifftOut.begin(), f.ifftOut.end(), ifft_out + k * fftSize);
+        }
+    }
+    if (buffer) std::copy(f.buffer.begin(), f.buffer.end(), buffer);
+    return 0;
+}
+
 }  // extern "C"

@@ -176,3 +176,88 @@ def test_fft_features(mx, port, fftSize):
     ok = ~np.isnan(eflat)
     np.testing.assert_allclose(flat[ok], eflat[ok], rtol=4e-6, atol=0)
     assert flat[5] == 0 and ecen[5] == 0
+
+
+IFFT_CASES = [(1024, 512, 0), (1024, 256, 1024), (64, 16, 48), (8, 8, 0), (2048, 512, 0), (4096, 1024, 0)]
+
+
+@pytest.mark.parametrize("fs,hop,win", IFFT_CASES)
+def test_ifft_zero_phase_bit_exact(mx, port, fs, hop, win):
+    """maxiIFFT with phases == 0: cos = 1, sin = 0 exactly on every libm, so the whole path (full-size
+    complex inverse FFT with replayed fp32 twiddles, /n, window, overlap-add order, buffer carry across two
+    calls) must be bit-identical to the reference."""
+    rng = np.random.default_rng(fs + hop)
+    nf = 11
+    m = np.abs(rng.normal(0, 3, (nf, fs // 2))).astype(np.float32)
+    ph = np.zeros_like(m)
+    f = mx.maxiIFFT()
+    f.setup(fs, hop, win)
+    o1 = f.process_frames(m[:4], ph[:4], keep_ifft=True).numpy()
+    io1 = f.ifftOut.numpy()
+    o2 = f.process_frames(m[4:], ph[4:]).numpy()
+    e1, eio1, buf = port.ifft_stream(m[:4], ph[:4], fs, hop, win)
+    e2, _, buf2 = port.ifft_stream(m[4:], ph[4:], fs, hop, win, buffer=buf)
+    assert np.array_equal(io1.view(np.uint32), eio1.view(np.uint32)), "ifftOut"
+    assert np.array_equal(o1.view(np.uint32), e1.view(np.uint32)), "signal, first call"
+    assert np.array_equal(o2.view(np.uint32), e2.view(np.uint32)), "signal, carried buffer"
+    assert np.array_equal(f.buffer.numpy().view(np.uint32), buf2.view(np.uint32)), "buffer state"
+
+
+@pytest.mark.parametrize("fs,hop,win", IFFT_CASES[:4])
+def test_ifft_random_phase(mx, port, fs, hop, win):
+    """Random phases: polToCart uses the float cos/sin of the device (L/fft.cpp:597-598 resolves to cosf/sinf),
+    which may differ from glibc's by an ULP; the transform is linear, so the output moves by at most
+    ~2^-23 * sum|mag| / n per ULP.  Bound: 4e-7 * (sum of magnitudes of a frame) / n * overlap."""
+    rng = np.random.default_rng(fs * 3 + hop)
+    nf = 9
+    m = np.abs(rng.normal(0, 3, (nf, fs // 2))).astype(np.float32)
+    ph = rng.uniform(-np.pi, np.pi, (nf, fs // 2)).astype(np.float32)
+    f = mx.maxiIFFT()
+    f.setup(fs, hop, win)
+    o = f.process_frames(m, ph).numpy()
+    e, _, buf = port.ifft_stream(m, ph, fs, hop, win)
+    tol = 4e-7 * m.sum(axis=1).max() / fs * (fs // hop)
+    assert np.abs(o - e).max() <= tol
+    assert np.abs(f.buffer.numpy() - buf).max() <= tol
+    assert np.abs(e).max() > 100 * tol
+
+
+def test_fft_ifft_round_trip(mx):
+    """ffttest.cpp's chain maxiFFT(1024, hop) -> maxiIFFT(1024, hop) as a size-independent property: with Hann
+    analysis x Hann synthesis at hop = N/4 the overlap-added w^2 is constant, and the inverse (positive
+    frequencies only, real part) returns half of it, so the output is the delayed input times gain/2 -- up to
+    the reference's packing of DC and Nyquist into bin 0 (L/fft.cpp:274-275), which the inverse treats as an
+    ordinary bin: a few % of a white signal.  Checked: correlation and RMS error, not samples."""
+    fs, hop = 1024, 256
+    rng = np.random.default_rng(5)
+    sig = rng.uniform(-0.5, 0.5, hop * 64).astype(np.float32)
+    fwd = mx.maxiFFT()
+    fwd.setup(fs, hop, fs)
+    n = fwd.process_signal(sig)
+    inv = mx.maxiIFFT()
+    inv.setup(fs, hop, fs)
+    y = inv.process_frames(fwd.getMagnitudes(), fwd.getPhases()).numpy()
+    w = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(fs) / (fs - 1))).astype(np.float64)
+    gain = sum((w[j * hop:(j + 1) * hop] ** 2) for j in range(fs // hop))       # overlap-added w^2 per hop phase
+    delay = fs - hop
+    k0 = fs // hop                                                              # skip the warm-up frames
+    got = y[k0 * hop:(n - 1) * hop].astype(np.float64)
+    ref = sig[k0 * hop - delay:(n - 1) * hop - delay].astype(np.float64)
+    exp = ref * np.tile(gain, got.size // hop) * 0.5
+    assert np.corrcoef(got, exp)[0, 1] > 0.998
+    assert np.sqrt(np.mean((got - exp) ** 2)) < 0.05 * np.sqrt(np.mean(exp ** 2))
+
+
+@pytest.mark.parametrize("fs,hop,win", [(1024, 512, 0), (1024, 256, 1024), (64, 16, 48)])
+def test_ifft_golden(mx, golden, fs, hop, win):
+    """Against the reference's own values (tests/golden/ifft.npz): a third of the phases are exactly 0, the
+    rest random, so the bound is the random-phase one; the zero-phase-only case is bit-exact above."""
+    g = golden("ifft.npz")
+    tag = "%d_%d_%d" % (fs, hop, win)
+    m, ph = g["mags_" + tag], g["phases_" + tag]
+    f = mx.maxiIFFT()
+    f.setup(fs, hop, win)
+    o = np.concatenate([f.process_frames(m[:3], ph[:3]).numpy(), f.process_frames(m[3:], ph[3:]).numpy()])
+    tol = 4e-7 * m.sum(axis=1).max() / fs * (fs // hop)
+    assert np.abs(o - g["signal_" + tag]).max() <= tol
+    assert np.abs(f.buffer.numpy() - g["buffer_" + tag]).max() <= tol

@@ -88,3 +88,28 @@ def test_stream_framing_matches_oracle(port):
         for k in ([0, nfr - 1] if nfr else []):
             one = port.fft_stream(p[k * hop:k * hop + fs], fs, fs, fs)
             assert np.array_equal(f32bits(one["mags"][0]), f32bits(r["mags"][k]))
+
+
+IFFT_TAGS = [(1024, 512, 0), (1024, 256, 1024), (64, 16, 48)]
+
+
+@pytest.mark.parametrize("fs,hop,win", IFFT_TAGS)
+def test_ifft_golden(port, golden, fs, hop, win):
+    """maxiIFFT (L/maxiFFT.cpp:140-192): the restatement against the values dumped from the compiled reference,
+    incl. the overlap-add buffer carried across two calls."""
+    g = golden("ifft.npz")
+    tag = "%d_%d_%d" % (fs, hop, win)
+    m, ph = g["mags_" + tag], g["phases_" + tag]
+    o1, io1, buf = port.ifft_stream(m[:3], ph[:3], fs, hop, win)
+    o2, io2, buf = port.ifft_stream(m[3:], ph[3:], fs, hop, win, buffer=buf)
+    for got, name in ((np.concatenate([o1, o2]), "signal_"), (np.concatenate([io1, io2]), "ifftout_"), (buf, "buffer_")):
+        assert np.array_equal(got.view(np.uint32), g[name + tag].view(np.uint32)), name
+
+
+def test_ifft_port_vs_reference(port, ref):
+    rng = np.random.default_rng(12)
+    for (fs, hop, win) in [(512, 128, 0), (2048, 2048, 0), (8, 2, 6), (256, 64, 100)]:
+        m = np.abs(rng.normal(0, 2, (6, fs // 2))).astype(np.float32)
+        ph = rng.uniform(-4, 4, (6, fs // 2)).astype(np.float32)
+        for u, w in zip(port.ifft_stream(m, ph, fs, hop, win), ref.ifft_stream(m, ph, fs, hop, win)):
+            assert np.array_equal(u.view(np.uint32), w.view(np.uint32))
