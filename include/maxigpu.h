@@ -145,6 +145,39 @@ int mxg_filter_render(int kind, size_t V, size_t N, const double *d_in, const do
 int mxg_filter_coeffs_host(int kind, size_t V, const double *h_cutoff, const double *h_res,
                            double *h_coef);
 
+/* ---- maxiEnvGen bank (H:2268-2547) ------------------------------------------------------------------ */
+/* maxiEnvGen::setup(levels, times, curves, ...) (H:2366-2399) on the host: times in ms, or -46692
+ * (maxiEnvGen::HOLD) for the one allowed hold stage; h_stages [nlevels-1][6] = startlevel, endlevel,
+ * gradient, curve, length (samples), hold.  Returns the number of stages (<= 32) or MXG_ERR_INVALID
+ * where setup() returns false.  setupAR/ASR/ADSR (H:2480-2504) are particular level/time/curve lists. */
+int mxg_envgen_stages_host(size_t nlevels, const double *h_levels, const double *h_times,
+                           const double *h_curves, double *h_stages);
+/* d_out[n][v] = bank[v].play(trigger) (H:2277-2354) for one shared envelope shape d_stages [nstages][6]
+ * (device copy of the table above), loop / retrigger flags, and a trigger signal d_trig that is [N][V]
+ * (tpv = 1) or one shared [N] gate (tpv = 0).  State, in/out: d_dst = [5][V] envval,
+ * stages[phase].currentlevel, previousValue of trigDetector / holdDetector / retriggerDetector;
+ * d_ist = [7][V] int64: phase, state (0 WAITING, 1 TRIGGERED, 2 HOLDING), nxcHappened,
+ * stages[phase].counter, firstTrigger of the three detectors.  A freshly set-up object is all zeros
+ * except previousValue = 1.0 and firstTrigger = 1 (H:593-594).  State machine bit-exact; the value is exact
+ * for curve == 1 and within the device pow's accuracy otherwise. */
+int mxg_envgen_render(size_t V, size_t N, const double *d_trig, int tpv, const double *d_stages, int nstages,
+                      int loop, int retrigger, double *d_dst, int64_t *d_ist, double *d_out, void *stream);
+
+/* ---- maxiDCBlocker / maxiSVF / maxiBiquad banks (H:1255-1486) ------------------------------------ */
+/* kind 0 maxiDCBlocker::play(input, R) H:1261-1266: d_coef = [1][V] R; d_st = [3][V] xm1, ym1, (unused).
+ * kind 1 maxiSVF::play(w, lpmix, bpmix, hpmix, notchmix) H:1303-1317: d_coef = [9][V] g1, g2, g3, g4, k
+ *        (rows 0-4 from mxg_svf_coeffs_host = setCutoff/setResonance -> setParams H:1320-1332) then the
+ *        four mix arguments; d_st = [3][V] v0z, v1, v2.
+ * kind 2 maxiBiquad::play(input) H:1360-1367: d_coef = [5][V] a0, a1, a2, b1, b2 (mxg_biquad_coeffs_host
+ *        = set(type, cutoff, Q, peakGain) H:1376-1478); d_st = [3][V] v[0], v[1], v[2].
+ * Coefficients come from the host libm (tan, pow, sqrt), so the recurrences are bit-exact. */
+int mxg_filter2_render(int kind, size_t V, size_t N, const double *d_in, const double *d_coef,
+                       double *d_st, double *d_out, void *stream);
+int mxg_svf_coeffs_host(size_t V, const double *h_cutoff, const double *h_res, double *h_coef);
+/* h_type[v]: 0 LOWPASS 1 HIGHPASS 2 BANDPASS 3 NOTCH 4 PEAK 5 LOWSHELF 6 HIGHSHELF (H:1349-1358) */
+int mxg_biquad_coeffs_host(size_t V, const int32_t *h_type, const double *h_cutoff, const double *h_Q,
+                           const double *h_peakGain, double *h_coef);
+
 /* ---- maxiEnv bank --------------------------------------------------------------------- */
 /* mode 0: adsr(input, trigger) (C:1415-1466)   mode 1: ar(input, attack, release, holdtime,
  * trigger) (C:1319-1358).  d_in NULL = constant 1.0 input.  d_trig: int32 [N] (tpv=0, one

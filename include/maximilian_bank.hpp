@@ -208,6 +208,66 @@ private:
     maxigpu::DeviceArray<double> state_, cutoff_, res_, coef_;
 };
 
+// ---- maxiDCBlocker / maxiSVF / maxiBiquad (H:1255-1486) --------------------------------------------------
+class maxiDCBlockerBank {
+public:
+    explicit maxiDCBlockerBank(size_t voices) : V(voices), state_(3 * voices), R_(voices) {}
+    void setR(const std::vector<double> &R) { R_.upload(R); }
+    void play(size_t N, const double *d_in, double *d_out, void *stream = nullptr) {  // play(input, R) H:1261-1266
+        maxigpu::check(mxg_filter2_render(0, V, N, d_in, R_.get(), state_.get(), d_out, stream), "mxg_filter2_render");
+    }
+
+private:
+    size_t V;
+    maxigpu::DeviceArray<double> state_, R_;
+};
+
+class maxiSVFBank {
+public:
+    explicit maxiSVFBank(size_t voices) : V(voices), freq_(voices, 1000.0), res_(voices, 1.0), mix_(4 * voices, 0.0), state_(3 * voices), coef_(9 * voices) {}
+    void setCutoff(const std::vector<double> &cutoff) { freq_ = cutoff; dirty_ = true; }   // H:1287-1290
+    void setResonance(const std::vector<double> &q) { res_ = q; dirty_ = true; }          // H:1293-1296
+    void setMix(double lpmix, double bpmix, double hpmix, double notchmix) {              // the play() arguments
+        for (size_t v = 0; v < V; v++) { mix_[v] = lpmix; mix_[V + v] = bpmix; mix_[2 * V + v] = hpmix; mix_[3 * V + v] = notchmix; }
+        dirty_ = true;
+    }
+    void play(size_t N, const double *d_in, double *d_out, void *stream = nullptr) {      // H:1303-1317
+        if (dirty_) {
+            std::vector<double> c(9 * V);
+            maxigpu::check(mxg_svf_coeffs_host(V, freq_.data(), res_.data(), c.data()), "mxg_svf_coeffs_host");
+            std::copy(mix_.begin(), mix_.end(), c.begin() + 5 * V);
+            coef_.upload(c);
+            dirty_ = false;
+        }
+        maxigpu::check(mxg_filter2_render(1, V, N, d_in, coef_.get(), state_.get(), d_out, stream), "mxg_filter2_render");
+    }
+
+private:
+    size_t V;
+    std::vector<double> freq_, res_, mix_;
+    maxigpu::DeviceArray<double> state_, coef_;
+    bool dirty_ = true;
+};
+
+class maxiBiquadBank {
+public:
+    enum filterTypes { LOWPASS, HIGHPASS, BANDPASS, NOTCH, PEAK, LOWSHELF, HIGHSHELF };
+    explicit maxiBiquadBank(size_t voices) : V(voices), state_(3 * voices), coef_(5 * voices) {}
+    void set(filterTypes filtType, const std::vector<double> &cutoff, const std::vector<double> &Q, const std::vector<double> &peakGain) {  // H:1376-1478
+        std::vector<int32_t> t(V, (int32_t)filtType);
+        std::vector<double> c(5 * V);
+        maxigpu::check(mxg_biquad_coeffs_host(V, t.data(), cutoff.data(), Q.data(), peakGain.data(), c.data()), "mxg_biquad_coeffs_host");
+        coef_.upload(c);
+    }
+    void play(size_t N, const double *d_in, double *d_out, void *stream = nullptr) {  // H:1360-1367
+        maxigpu::check(mxg_filter2_render(2, V, N, d_in, coef_.get(), state_.get(), d_out, stream), "mxg_filter2_render");
+    }
+
+private:
+    size_t V;
+    maxigpu::DeviceArray<double> state_, coef_;
+};
+
 // ---- maxiEnv (H:888-932) ------------------------------------------------------------------------------
 class maxiEnvBank {
 public:
@@ -246,6 +306,49 @@ private:
     maxigpu::DeviceArray<double> dst_;
     maxigpu::DeviceArray<int64_t> ist_;
     bool dirty_ = true;
+};
+
+// ---- maxiEnvGen (H:2268-2547): one envelope shape per bank, per-voice or shared trigger signals --------------
+class maxiEnvGenBank {
+public:
+    static constexpr double HOLD = -46692;  // maxiEnvGen::HOLD
+    explicit maxiEnvGenBank(size_t voices) : V(voices), dst_(5 * voices), ist_(7 * voices) { arm(); }
+    bool setup(const std::vector<double> &levels, const std::vector<double> &times, const std::vector<double> &curves,
+               bool looping, bool allowRetrigger = false) {  // H:2366-2399
+        if (!(levels.size() == times.size() + 1 && levels.size() == curves.size() + 1)) return false;
+        std::vector<double> st(6 * times.size());
+        const int n = mxg_envgen_stages_host(levels.size(), levels.data(), times.data(), curves.data(), st.data());
+        if (n < 0) return false;
+        stages_.upload(st);
+        nstages_ = n; loop_ = looping; retrigger_ = allowRetrigger;
+        arm();
+        return true;
+    }
+    void setupAR(double attack, double release) { setup({0, 1, 0}, {attack, release}, {1, 1}, false, false); }
+    void setupASR(double attack, double release) { setup({0, 1, 1, 0}, {attack, HOLD, release}, {1, 1, 1}, false, false); }
+    void setupADSR(double attack, double decay, double sustain, double release) {
+        setup({0, 1, sustain, sustain, 0}, {attack, decay, HOLD, release}, {1, 1, 1, 1}, false, false);
+    }
+    void setRetrigger(bool v) { retrigger_ = v; }
+    void setLoop(bool v) { loop_ = v; }
+    // d_trig: [N][V] (per_voice) or [N] (shared gate), doubles on the device
+    void play(size_t N, const double *d_trig, bool per_voice, double *d_out, void *stream = nullptr) {
+        maxigpu::check(mxg_envgen_render(V, N, d_trig, per_voice ? 1 : 0, stages_.get(), nstages_, loop_ ? 1 : 0, retrigger_ ? 1 : 0,
+                                         dst_.get(), ist_.get(), d_out, stream), "mxg_envgen_render");
+    }
+
+private:
+    void arm() {  // resetAndArm() of fresh objects: WAITING, detectors previousValue = 1 / firstTrigger = 1
+        std::vector<double> d(5 * V, 0.0);
+        std::vector<int64_t> i(7 * V, 0);
+        for (size_t v = 0; v < V; v++) { d[2 * V + v] = d[3 * V + v] = d[4 * V + v] = 1.0; i[4 * V + v] = i[5 * V + v] = i[6 * V + v] = 1; }
+        dst_.upload(d); ist_.upload(i);
+    }
+    size_t V;
+    int nstages_ = 0;
+    bool loop_ = false, retrigger_ = false;
+    maxigpu::DeviceArray<double> stages_, dst_;
+    maxigpu::DeviceArray<int64_t> ist_;
 };
 
 // ---- fused subtractive voice: maxiOsc::saw -> maxiFilter::lores -> maxiEnv::adsr -----------------------

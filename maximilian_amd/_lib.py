@@ -47,6 +47,12 @@ SIGNATURES = {
     "mxg_voice_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
+    "mxg_envgen_stages_host": (c_int, [c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_envgen_render": (c_int, [c_size_t, c_size_t, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
+    "mxg_filter2_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_svf_coeffs_host": (c_int, [c_size_t, c_void_p, c_void_p, c_void_p]),
+    "mxg_biquad_coeffs_host": (c_int, [c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_mix_stereo": (c_int, [c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_mix_bus": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p]),

@@ -230,6 +230,137 @@ class maxiFilterBank(_Bank):
     def hipass(self, x, cutoff, **kw): return self.render("hipass", x, cutoff, None, **kw)
 
 
+class maxiEnvGenBank(_Bank):
+    """V x maxiEnvGen (H:2268-2547) sharing one envelope shape; per-voice (or shared) trigger signals."""
+    HOLD = -46692.0
+
+    def __init__(self, voices, stream=None):
+        super().__init__(voices, stream)
+        self.stages = None
+        self.loop = self.retrigger = False
+        self._arm()
+
+    def _arm(self):
+        d = np.zeros((5, self.V))
+        d[2:5] = 1.0                                   # maxiTrigger::previousValue (H:593)
+        i = np.zeros((7, self.V), np.int64)
+        i[4:7] = 1                                     # firstTrigger (H:594); state WAITING (resetAndArm)
+        self.dstate, self.istate = DeviceBuffer.from_numpy(d), DeviceBuffer.from_numpy(i)
+
+    def setup(self, levels, times, curves, looping, allowRetrigger=False):
+        levels, times, curves = (np.ascontiguousarray(a, np.float64) for a in (levels, times, curves))
+        if not (levels.size == times.size + 1 and levels.size == curves.size + 1):
+            return False                               # H:2395-2398
+        st = np.zeros((times.size, 6))
+        rc = lib().mxg_envgen_stages_host(levels.size, levels.ctypes.data, times.ctypes.data, curves.ctypes.data,
+                                          st.ctypes.data)
+        if rc < 0:
+            return False
+        self.host_stages, self.stages = st, DeviceBuffer.from_numpy(st)
+        self.loop, self.retrigger = bool(looping), bool(allowRetrigger)
+        self._arm()
+        return True
+
+    def setupAR(self, attack, release): return self.setup([0, 1, 0], [attack, release], [1, 1], False, False)
+
+    def setupASR(self, attack, release):
+        return self.setup([0, 1, 1, 0], [attack, self.HOLD, release], [1, 1, 1], False, False)
+
+    def setupADSR(self, attack, decay, sustain, release):
+        return self.setup([0, 1, sustain, sustain, 0], [attack, decay, self.HOLD, release], [1, 1, 1, 1], False, False)
+
+    def setRetrigger(self, val): self.retrigger = bool(val)
+    def setLoop(self, val): self.loop = bool(val)
+
+    def play(self, trigger, out=None):
+        """trigger: [N][V] per voice, or [N] shared."""
+        if not (isinstance(trigger, DeviceBuffer) or hasattr(trigger, "data_ptr")):
+            trigger = DeviceBuffer.from_numpy(np.ascontiguousarray(trigger, np.float64))
+        tpv = len(trigger.shape) == 2
+        N = trigger.shape[0]
+        out = self._out(N, out)
+        check(lib().mxg_envgen_render(self.V, N, _ptr(trigger), int(tpv), self.stages.ptr, self.host_stages.shape[0],
+                                      int(self.loop), int(self.retrigger), self.dstate.ptr, self.istate.ptr, _ptr(out),
+                                      self.stream), "mxg_envgen_render")
+        self._keep = trigger
+        return out
+
+
+class _Filter2Bank(_Bank):
+    KIND = 0
+
+    def __init__(self, voices, stream=None):
+        super().__init__(voices, stream)
+        self.state = DeviceBuffer((3, self.V))
+        self.coef = None
+
+    def _play(self, x, out):
+        N = x.shape[0]
+        out = self._out(N, out)
+        check(lib().mxg_filter2_render(self.KIND, self.V, N, _ptr(x), self.coef.ptr, self.state.ptr, _ptr(out),
+                                       self.stream), "mxg_filter2_render")
+        return out
+
+
+class maxiDCBlockerBank(_Filter2Bank):
+    """V x maxiDCBlocker (H:1255-1267)."""
+    KIND = 0
+
+    def play(self, x, R, out=None):
+        self.coef = _as_dev(R, self.V)
+        return self._play(x, out)
+
+
+class maxiSVFBank(_Filter2Bank):
+    """V x maxiSVF (H:1281-1338); the ctor's setParams(1000, 1) (H:1284)."""
+    KIND = 1
+
+    def __init__(self, voices, stream=None):
+        super().__init__(voices, stream)
+        self.freq = np.full(self.V, 1000.0)
+        self.res = np.full(self.V, 1.0)
+        self._host = None
+
+    def setCutoff(self, cutoff):
+        self.freq = np.ascontiguousarray(np.broadcast_to(np.asarray(cutoff, np.float64), (self.V,)))
+        self._host = None
+
+    def setResonance(self, q):
+        self.res = np.ascontiguousarray(np.broadcast_to(np.asarray(q, np.float64), (self.V,)))
+        self._host = None
+
+    def coefficients(self):
+        if self._host is None:
+            c = np.zeros((5, self.V))
+            check(lib().mxg_svf_coeffs_host(self.V, self.freq.ctypes.data, self.res.ctypes.data, c.ctypes.data),
+                  "mxg_svf_coeffs_host")
+            self._host = c
+        return self._host
+
+    def play(self, w, lpmix, bpmix, hpmix, notchmix, out=None):
+        mix = np.stack([np.broadcast_to(np.asarray(m, np.float64), (self.V,)) for m in (lpmix, bpmix, hpmix, notchmix)])
+        self.coef = DeviceBuffer.from_numpy(np.concatenate([self.coefficients(), mix]))
+        return self._play(w, out)
+
+
+class maxiBiquadBank(_Filter2Bank):
+    """V x maxiBiquad (H:1343-1486)."""
+    KIND = 2
+    LOWPASS, HIGHPASS, BANDPASS, NOTCH, PEAK, LOWSHELF, HIGHSHELF = range(7)
+
+    def set(self, filtType, cutoff, Q, peakGain):
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(filtType, np.int32), (self.V,)))
+        cu, q, g = (np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float64), (self.V,))) for a in (cutoff, Q, peakGain))
+        c = np.zeros((5, self.V))
+        check(lib().mxg_biquad_coeffs_host(self.V, t.ctypes.data, cu.ctypes.data, q.ctypes.data, g.ctypes.data,
+                                           c.ctypes.data), "mxg_biquad_coeffs_host")
+        self.host_coef = c
+        self.coef = DeviceBuffer.from_numpy(c)
+
+    def play(self, x, out=None):
+        return self._play(x, out)
+
+
 class maxiEnvBank(_Bank):
     """V x maxiEnv (H:888-932).  No constructor in the reference: all state starts at zero
     (static-storage objects), holdtime defaults to 1 (H:915)."""

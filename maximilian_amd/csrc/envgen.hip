@@ -1,0 +1,205 @@
+// envgen.hip -- maxiEnvGen (src/maximilian.h:2268-2547) as a voice bank on gfx950.
+//
+// One envelope shape per bank -- the stage table maxiEnvGen::setup builds (H:2366-2399,
+// setupSegmentTime H:2531-2545), evaluated on the host by mxg_envgen_stages_host -- and one trigger
+// signal per voice (or one shared gate).  One lane = one envelope: play() (H:2277-2354) is a three-state
+// machine (WAITING / TRIGGERED / HOLDING, the switch falls through) around three maxiTrigger zero-crossing
+// detectors (H:569-579); the value is linlin(pow(currentlevel, curve), 0, 1, startlevel, endlevel)
+// (H:2302-2304, maxiMap::linlin H:801-805).  Only stages[phase] ever holds a non-zero counter /
+// currentlevel (every way out of a stage zeroes them), so that pair is the whole per-stage state.
+// Counters, phases, states and detectors are integer/compare work: bit-exact.  pow(currentlevel, curve):
+// curve == 1 (setupAR/ASR/ADSR, H:2480-2504) is returned exactly (as the host libm does); other curves use the
+// device pow => tolerance.  HBM: 8 B out (+ 8 B trigger in when per voice) per sample.
+#include <math.h>
+
+#include "mxg_common.h"
+
+namespace mxg {
+namespace {
+
+constexpr int kMaxStages = 32;
+constexpr double kHold = -46692.0;  // maxiEnvGen::HOLD H:2271
+
+struct EgStage {
+    double startlevel, endlevel, gradient, curve;
+    long long length;
+    int hold;
+};
+
+struct EgArgs {
+    size_t V, N;
+    const double *trig;
+    int tpv, nstages, loop, retrigger;
+    const double *stages;  // [nstages][6]
+    double *dst;           // [5][V]
+    int64_t *ist;          // [7][V]
+    double *out;
+};
+
+__device__ __forceinline__ bool on_zx(double &prev, bool &first, double input) {  // H:569-579
+    const bool zx = (prev <= 0.0 || first) && input > 0;
+    prev = input;
+    first = false;
+    return zx;
+}
+
+template <bool TPV>
+__global__ void __launch_bounds__(256) envgen_kernel(EgArgs A) {
+    __shared__ double s_tab[kMaxStages * 6];
+    for (int i = threadIdx.x; i < A.nstages * 6; i += blockDim.x) s_tab[i] = A.stages[i];
+    __syncthreads();
+    const size_t V = A.V, N = A.N;
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    enum { WAITING = 0, TRIGGERED = 1, HOLDING = 2 };
+    double envval = A.dst[v], currentlevel = A.dst[V + v];
+    double tprev = A.dst[2 * V + v], hprev = A.dst[3 * V + v], rprev = A.dst[4 * V + v];
+    long long phase = A.ist[v], counter = A.ist[3 * V + v];
+    int state = (int)A.ist[V + v];
+    bool nxc = A.ist[2 * V + v] != 0;
+    bool tfirst = A.ist[4 * V + v] != 0, hfirst = A.ist[5 * V + v] != 0, rfirst = A.ist[6 * V + v] != 0;
+    const long long S = A.nstages;
+    const bool loop = A.loop != 0, retrigger = A.retrigger != 0;
+    const double *tp = TPV ? A.trig + v : A.trig;
+    double *op = A.out + v;
+    constexpr int U = 8;
+    double tn[U];
+#pragma unroll
+    for (int i = 0; i < U; i++) {
+        const size_t m = (size_t)i < N ? (size_t)i : N - 1;
+        tn[i] = TPV ? tp[m * V] : tp[m];
+    }
+    for (size_t n0 = 0; n0 < N; n0 += U) {
+        double tc[U];
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            tc[i] = tn[i];
+            const size_t m = (n0 + U + i < N) ? n0 + U + i : N - 1;  // clamped prefetch, a chunk ahead of the stores
+            tn[i] = TPV ? tp[m * V] : tp[m];
+        }
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            if (n0 + i >= N) break;
+            const double trigger = tc[i];
+            int entry = state;  // the switch's fall-through, made explicit
+            if (entry == WAITING) {  // H:2279-2292
+                if (on_zx(tprev, tfirst, trigger)) {
+                    state = TRIGGERED;
+                    nxc = false;
+                    entry = TRIGGERED;
+                } else {
+                    entry = -1;
+                }
+            }
+            if (entry == TRIGGERED) {  // H:2293-2329
+                const double *cs = s_tab + 6 * phase;
+                if (on_zx(hprev, hfirst, -trigger)) nxc = true;
+                if (cs[5] != 0) {
+                    state = HOLDING;
+                    entry = HOLDING;
+                } else {
+                    const double curve = cs[3];
+                    double val = (curve == 1.0) ? currentlevel : pow(currentlevel, curve);
+                    val = (1.0 < val) ? 1.0 : val;  // linlin: max(min(val, inMax), inMin)
+                    val = (val < 0.0) ? 0.0 : val;
+                    envval = ((val - 0.0) / (1.0 - 0.0) * (cs[1] - cs[0])) + cs[0];
+                    counter++;
+                    if (counter == (long long)cs[4]) {
+                        counter = 0;
+                        currentlevel = 0;
+                        phase++;
+                    } else {
+                        currentlevel += cs[2];
+                    }
+                    if (retrigger && on_zx(rprev, rfirst, trigger)) {
+                        nxc = false;
+                        counter = 0; currentlevel = 0; phase = 0; state = TRIGGERED;  // reset() H:2402-2410
+                    }
+                    entry = -1;
+                }
+            }
+            if (entry == HOLDING) {  // H:2330-2348
+                if (on_zx(hprev, hfirst, -trigger)) nxc = true;
+                if (nxc) {
+                    state = TRIGGERED;
+                    phase++;
+                }
+                if (retrigger && on_zx(rprev, rfirst, trigger)) {
+                    nxc = false;
+                    counter = 0; currentlevel = 0; phase = 0; state = TRIGGERED;
+                }
+            }
+            if (phase == S) {  // H:2349-2355: reset() / resetAndArm()
+                counter = 0; currentlevel = 0;
+                phase = 0;
+                state = loop ? TRIGGERED : WAITING;
+            }
+            *op = envval;
+            op += V;
+        }
+    }
+    const bool in = phase < S;
+    A.dst[v] = envval;
+    A.dst[V + v] = in ? currentlevel : 0.0;
+    A.dst[2 * V + v] = tprev; A.dst[3 * V + v] = hprev; A.dst[4 * V + v] = rprev;
+    A.ist[v] = phase;
+    A.ist[V + v] = state;
+    A.ist[2 * V + v] = nxc ? 1 : 0;
+    A.ist[3 * V + v] = in ? counter : 0;
+    A.ist[4 * V + v] = tfirst ? 1 : 0; A.ist[5 * V + v] = hfirst ? 1 : 0; A.ist[6 * V + v] = rfirst ? 1 : 0;
+}
+
+}  // namespace
+}  // namespace mxg
+
+using namespace mxg;
+
+extern "C" {
+
+// maxiEnvGen::setup (H:2366-2399) on the host: levels[nlevels], times[nlevels-1] (ms, or maxiEnvGen::HOLD =
+// -46692), curves[nlevels-1] -> h_stages [nlevels-1][6] = startlevel, endlevel, gradient, curve, length, hold.
+// Returns the number of stages, or MXG_ERR_INVALID where setup() returns false (a second HOLD stage).
+int mxg_envgen_stages_host(size_t nlevels, const double *h_levels, const double *h_times, const double *h_curves,
+                           double *h_stages) {
+    MXG_REQUIRE(h_levels && h_times && h_curves && h_stages, "null pointer");
+    MXG_REQUIRE(nlevels >= 2 && nlevels - 1 <= (size_t)kMaxStages, "levels must hold 2..33 values (one more than times/curves)");
+    const size_t sr = settings().sampleRate;
+    double accumulatedTime = 0;
+    bool containsHold = false;
+    for (size_t i = 0; i + 1 < nlevels; i++) {
+        const double stageTime = h_times[i];
+        double length, gradient, hold;
+        if (stageTime == kHold) {  // setupSegmentTime H:2531-2545
+            if (containsHold) return fail(MXG_ERR_INVALID, "maxiEnvGen::setup - only one hold section allowed");
+            length = 0; hold = 1; gradient = 0; containsHold = true;
+        } else {
+            const double len = ((stageTime / 1000.0) * sr) + accumulatedTime;
+            const size_t l = static_cast<size_t>(floor(len));
+            accumulatedTime = len - l;
+            gradient = 1.0 / l;
+            length = (double)l; hold = 0;
+        }
+        double *st = h_stages + 6 * i;
+        st[0] = h_levels[i]; st[1] = h_levels[i + 1]; st[2] = gradient; st[3] = h_curves[i]; st[4] = length; st[5] = hold;
+    }
+    return (int)(nlevels - 1);
+}
+
+int mxg_envgen_render(size_t V, size_t N, const double *d_trig, int tpv, const double *d_stages, int nstages, int loop,
+                      int retrigger, double *d_dst, int64_t *d_ist, double *d_out, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(d_trig && d_stages && d_dst && d_ist && d_out, "null device pointer");
+    MXG_REQUIRE(nstages >= 1 && nstages <= kMaxStages, "nstages out of [1, 32]");
+    if (V == 0 || N == 0) return MXG_OK;
+    int block = tune_get("voice_block");
+    if (block > 256) block = 256;
+    const EgArgs A = {V, N, d_trig, tpv, nstages, loop, retrigger, d_stages, d_dst, d_ist, d_out};
+    const dim3 grid((unsigned)((V + block - 1) / block));
+    if (tpv)
+        hipLaunchKernelGGL((envgen_kernel<true>), grid, dim3(block), 0, resolve_stream(stream), A);
+    else
+        hipLaunchKernelGGL((envgen_kernel<false>), grid, dim3(block), 0, resolve_stream(stream), A);
+    return check_hip(hipGetLastError(), "envgen_kernel launch");
+}
+
+}  // extern "C"

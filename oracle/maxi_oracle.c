@@ -1656,3 +1656,274 @@ int mxo_ifft_stream(const float *mags, const float *phases, size_t nframes, int 
     free(window); free(in_real); free(in_img); free(out_real); free(out_img); free(ifftOut); free(buffer);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------
+ * maxiDCBlocker::play H:1261-1266; maxiSVF::setParams H:1320-1332, play H:1303-1317;
+ * maxiBiquad::set H:1376-1478, play H:1360-1367.  PI = H:55 (3.1415926535897932384626433832795).
+ * Layouts as oracle/ref_harness.cpp (mxo_filter2).
+ * ------------------------------------------------------------------------------------ */
+#define MXO_PI 3.1415926535897932384626433832795
+void mxo_svf_coeffs(double freq, double res, double *c5) {
+    double g = tan(MXO_PI * freq / g_sampleRate);
+    double damping = res == 0 ? 0 : 1.0 / res;
+    double k = damping;
+    double ginv = g / (1.0 + g * (g + k));
+    c5[0] = ginv;                   /* g1 */
+    c5[1] = 2.0 * (g + k) * ginv;   /* g2 */
+    c5[2] = g * ginv;               /* g3 */
+    c5[3] = 2.0 * ginv;             /* g4 */
+    c5[4] = k;
+}
+
+int mxo_biquad_coeffs(int filtType, double cutoff, double Q, double peakGain, double *c5) {
+    double a0 = 0, a1 = 0, a2 = 0, b1 = 0, b2 = 0; /* members keep 0 for an unknown type */
+    const double SQRT2 = sqrt(2.0);
+    double norm = 0;
+    double V = pow(10.0, fabs(peakGain) / 20.0); /* `abs` resolves to the double overload (pinned vs _ref) */
+    double K = tan(MXO_PI * cutoff / g_sampleRate);
+    switch (filtType) {
+        case 0: /* LOWPASS */
+            norm = 1.0 / (1.0 + K / Q + K * K);
+            a0 = K * K * norm; a1 = 2.0 * a0; a2 = a0;
+            b1 = 2.0 * (K * K - 1.0) * norm; b2 = (1.0 - K / Q + K * K) * norm;
+            break;
+        case 1: /* HIGHPASS */
+            norm = 1. / (1. + K / Q + K * K);
+            a0 = 1 * norm; a1 = -2 * a0; a2 = a0;
+            b1 = 2 * (K * K - 1) * norm; b2 = (1 - K / Q + K * K) * norm;
+            break;
+        case 2: /* BANDPASS */
+            norm = 1. / (1. + K / Q + K * K);
+            a0 = K / Q * norm; a1 = 0.; a2 = -a0;
+            b1 = 2. * (K * K - 1.) * norm; b2 = (1. - K / Q + K * K) * norm;
+            break;
+        case 3: /* NOTCH */
+            norm = 1. / (1. + K / Q + K * K);
+            a0 = (1. + K * K) * norm; a1 = 2. * (K * K - 1.) * norm; a2 = a0;
+            b1 = a1; b2 = (1. - K / Q + K * K) * norm;
+            break;
+        case 4: /* PEAK */
+            if (peakGain >= 0.0) {
+                norm = 1. / (1. + 1. / Q * K + K * K);
+                a0 = (1. + V / Q * K + K * K) * norm; a1 = 2. * (K * K - 1.) * norm;
+                a2 = (1. - V / Q * K + K * K) * norm; b1 = a1; b2 = (1. - 1. / Q * K + K * K) * norm;
+            } else {
+                norm = 1. / (1. + V / Q * K + K * K);
+                a0 = (1. + 1 / Q * K + K * K) * norm; a1 = 2. * (K * K - 1) * norm;
+                a2 = (1. - 1. / Q * K + K * K) * norm; b1 = a1; b2 = (1. - V / Q * K + K * K) * norm;
+            }
+            break;
+        case 5: /* LOWSHELF */
+            if (peakGain >= 0.) {
+                norm = 1. / (1. + SQRT2 * K + K * K);
+                a0 = (1. + sqrt(2. * V) * K + V * K * K) * norm; a1 = 2. * (V * K * K - 1.) * norm;
+                a2 = (1. - sqrt(2. * V) * K + V * K * K) * norm; b1 = 2. * (K * K - 1.) * norm;
+                b2 = (1. - SQRT2 * K + K * K) * norm;
+            } else {
+                norm = 1. / (1. + sqrt(2. * V) * K + V * K * K);
+                a0 = (1. + SQRT2 * K + K * K) * norm; a1 = 2. * (K * K - 1.) * norm;
+                a2 = (1. - SQRT2 * K + K * K) * norm; b1 = 2. * (V * K * K - 1.) * norm;
+                b2 = (1. - sqrt(2. * V) * K + V * K * K) * norm;
+            }
+            break;
+        case 6: /* HIGHSHELF */
+            if (peakGain >= 0.) {
+                norm = 1. / (1. + SQRT2 * K + K * K);
+                a0 = (V + sqrt(2. * V) * K + K * K) * norm; a1 = 2. * (K * K - V) * norm;
+                a2 = (V - sqrt(2. * V) * K + K * K) * norm; b1 = 2. * (K * K - 1) * norm;
+                b2 = (1. - SQRT2 * K + K * K) * norm;
+            } else {
+                norm = 1. / (V + sqrt(2. * V) * K + K * K);
+                a0 = (1. + SQRT2 * K + K * K) * norm; a1 = 2. * (K * K - 1.) * norm;
+                a2 = (1. - SQRT2 * K + K * K) * norm; b1 = 2. * (K * K - V) * norm;
+                b2 = (V - sqrt(2. * V) * K + K * K) * norm;
+            }
+            break;
+        default: return -1;
+    }
+    c5[0] = a0; c5[1] = a1; c5[2] = a2; c5[3] = b1; c5[4] = b2;
+    return 0;
+}
+
+int mxo_filter2(int kind, size_t V, size_t N, const double *in, const double *par, double *st, double *coef,
+                double *out) {
+    if (kind < 0 || kind > 2) return -1;
+    for (size_t v = 0; v < V; v++) {
+        double c[5] = {0, 0, 0, 0, 0};
+        if (kind == 0) {
+            double xm1 = st[v], ym1 = st[V + v];
+            const double R = par[v];
+            for (size_t n = 0; n < N; n++) {
+                const double input = in[n * V + v];
+                ym1 = input - xm1 + R * ym1;
+                xm1 = input;
+                out[n * V + v] = ym1;
+            }
+            st[v] = xm1; st[V + v] = ym1;
+        } else if (kind == 1) {
+            mxo_svf_coeffs(par[v], par[V + v], c);
+            const double g1 = c[0], g2 = c[1], g3 = c[2], g4 = c[3], k = c[4];
+            const double lpmix = par[2 * V + v], bpmix = par[3 * V + v], hpmix = par[4 * V + v], notchmix = par[5 * V + v];
+            double v0z = st[v], v1 = st[V + v], v2 = st[2 * V + v];
+            for (size_t n = 0; n < N; n++) {
+                const double w = in[n * V + v];
+                double low, band, high, notch;
+                double v1z = v1;
+                double v2z = v2;
+                double v3 = w + v0z - 2.0 * v2z;
+                v1 += g1 * v3 - g2 * v1z;
+                v2 += g3 * v3 + g4 * v1z;
+                v0z = w;
+                low = v2;
+                band = v1;
+                high = w - k * v1 - v2;
+                notch = w - k * v1;
+                out[n * V + v] = (low * lpmix) + (band * bpmix) + (high * hpmix) + (notch * notchmix);
+            }
+            st[v] = v0z; st[V + v] = v1; st[2 * V + v] = v2;
+        } else {
+            if (mxo_biquad_coeffs((int)par[v], par[V + v], par[2 * V + v], par[3 * V + v], c)) return -2;
+            const double a0 = c[0], a1 = c[1], a2 = c[2], b1 = c[3], b2 = c[4];
+            double v0 = st[v], v1 = st[V + v], v2 = st[2 * V + v];
+            for (size_t n = 0; n < N; n++) {
+                const double input = in[n * V + v];
+                v0 = input - (b1 * v1) - (b2 * v2);
+                double y = (a0 * v0) + (a1 * v1) + (a2 * v2);
+                v2 = v1;
+                v1 = v0;
+                out[n * V + v] = y;
+            }
+            st[v] = v0; st[V + v] = v1; st[2 * V + v] = v2;
+        }
+        if (coef && kind > 0)
+            for (int r = 0; r < 5; r++) coef[r * V + v] = c[r];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * maxiEnvGen H:2268-2547: setup H:2366-2399 + setupSegmentTime H:2531-2545 (stage table), play
+ * H:2277-2354 (switch with fall-through WAITING -> TRIGGERED -> HOLDING), reset H:2402-2410,
+ * resetAndArm H:2413-2416, maxiMap::linlin H:801-805, maxiTrigger::onZX H:569-579.
+ * Only stages[phase] ever holds a non-zero counter/currentlevel (every exit from a stage zeroes
+ * them), so the per-voice state is (counter, currentlevel) of the current stage.
+ * Layouts as oracle/ref_harness.cpp (mxo_envgen).  HOLD = -46692 (H:2271).
+ * ------------------------------------------------------------------------------------ */
+#define MXO_ENVGEN_HOLD (-46692.0)
+typedef struct {
+    double startlevel, endlevel, gradient, curve;
+    size_t length;
+    int hold;
+} envstage_t;
+
+/* returns the number of stages, -2 if a second HOLD stage is found (setup returns 0) */
+int mxo_envgen_stages(size_t nlevels, const double *levels, const double *times, const double *curves,
+                      double *stages6) {
+    double accumulatedTime = 0;
+    int containsHold = 0;
+    for (size_t i = 0; i + 1 < nlevels; i++) {
+        double stageTime = times[i];
+        double length, gradient, hold;
+        if (stageTime == MXO_ENVGEN_HOLD) {
+            if (containsHold) return -2;
+            length = 0; hold = 1; gradient = 0; containsHold = 1;
+        } else {
+            double len = ((stageTime / 1000.0) * g_sampleRate) + accumulatedTime;
+            size_t l = (size_t)(floor(len));
+            accumulatedTime = len - l;
+            gradient = 1.0 / l;
+            length = (double)l; hold = 0;
+        }
+        stages6[i * 6 + 0] = levels[i]; stages6[i * 6 + 1] = levels[i + 1]; stages6[i * 6 + 2] = gradient;
+        stages6[i * 6 + 3] = curves[i]; stages6[i * 6 + 4] = length; stages6[i * 6 + 5] = hold;
+    }
+    return (int)(nlevels - 1);
+}
+
+int mxo_envgen(size_t V, size_t N, const double *trig, int tpv, size_t nlevels, const double *levels,
+               const double *times, const double *curves, int loop, int retrigger, double *dst, int64_t *ist,
+               double *stages_out, double *out) {
+    if (nlevels < 2) return -1;
+    const size_t S = nlevels - 1;
+    double *tab = (double *)malloc(sizeof(double) * 6 * S);
+    if (mxo_envgen_stages(nlevels, levels, times, curves, tab) < 0) { free(tab); return -2; }
+    if (stages_out) memcpy(stages_out, tab, sizeof(double) * 6 * S);
+    enum { WAITING = 0, TRIGGERED = 1, HOLDING = 2 };
+    for (size_t v = 0; v < V; v++) {
+        double envval = dst[v], currentlevel = dst[V + v];
+        size_t phase = (size_t)ist[v], counter = (size_t)ist[3 * V + v];
+        int state = (int)ist[V + v], nxcHappened = ist[2 * V + v] != 0;
+        zx_t trigDetector = {dst[2 * V + v], ist[4 * V + v] != 0};
+        zx_t holdDetector = {dst[3 * V + v], ist[5 * V + v] != 0};
+        zx_t retriggerDetector = {dst[4 * V + v], ist[6 * V + v] != 0};
+        for (size_t n = 0; n < N; n++) {
+            const double trigger = tpv ? trig[n * V + v] : trig[n];
+            int stage_entry = state; /* emulate the fall-through with an explicit cursor */
+            if (stage_entry == WAITING) {
+                if (zx_onZX(&trigDetector, trigger) != 0.0) {
+                    state = TRIGGERED; /* stages.size() > 0 always here */
+                    nxcHappened = 0;
+                    stage_entry = TRIGGERED;
+                } else {
+                    stage_entry = -1; /* break */
+                }
+            }
+            if (stage_entry == TRIGGERED) {
+                const double *cs = tab + 6 * phase;
+                if (zx_onZX(&holdDetector, -trigger) != 0.0) nxcHappened = 1;
+                if (cs[5] != 0) {
+                    state = HOLDING;
+                    stage_entry = HOLDING; /* falls through */
+                } else {
+                    double val = pow(currentlevel, cs[3]);
+                    /* linlin(val, 0, 1, startlevel, endlevel) H:801-805 */
+                    val = (1.0 < val) ? 1.0 : val; /* min(val, inMax) */
+                    val = (val < 0.0) ? 0.0 : val; /* max(., inMin) */
+                    envval = ((val - 0.0) / (1.0 - 0.0) * (cs[1] - cs[0])) + cs[0];
+                    counter++;
+                    if (counter == (size_t)cs[4]) {
+                        counter = 0;
+                        currentlevel = 0;
+                        phase++;
+                    } else {
+                        currentlevel += cs[2];
+                    }
+                    if (retrigger) {
+                        if (zx_onZX(&retriggerDetector, trigger) != 0.0) {
+                            nxcHappened = 0;
+                            counter = 0; currentlevel = 0; phase = 0; state = TRIGGERED; /* reset() */
+                        }
+                    }
+                    stage_entry = -1;
+                }
+            }
+            if (stage_entry == HOLDING) {
+                if (zx_onZX(&holdDetector, -trigger) != 0.0) nxcHappened = 1;
+                if (nxcHappened) {
+                    state = TRIGGERED;
+                    phase++;
+                }
+                if (retrigger) {
+                    if (zx_onZX(&retriggerDetector, trigger) != 0.0) {
+                        nxcHappened = 0;
+                        counter = 0; currentlevel = 0; phase = 0; state = TRIGGERED;
+                    }
+                }
+            }
+            if (phase == S) {
+                counter = 0; currentlevel = 0; /* stages[phase] does not exist: reset() only rewinds */
+                phase = 0;
+                state = loop ? TRIGGERED : WAITING; /* reset() / resetAndArm() */
+            }
+            out[n * V + v] = envval;
+        }
+        dst[v] = envval; dst[V + v] = phase < S ? currentlevel : 0.0;
+        ist[v] = (int64_t)phase; ist[V + v] = state; ist[2 * V + v] = nxcHappened;
+        ist[3 * V + v] = phase < S ? (int64_t)counter : 0;
+        dst[2 * V + v] = trigDetector.previousValue; ist[4 * V + v] = trigDetector.firstTrigger;
+        dst[3 * V + v] = holdDetector.previousValue; ist[5 * V + v] = holdDetector.firstTrigger;
+        dst[4 * V + v] = retriggerDetector.previousValue; ist[6 * V + v] = retriggerDetector.firstTrigger;
+    }
+    free(tab);
+    return 0;
+}

@@ -171,6 +171,54 @@ class Oracle:
         assert rc == 0, rc
         return rnd, out
 
+    def filter2(self, kind, x, par, st=None):
+        """maxiDCBlocker (0; par [1][V] R), maxiSVF (1; par [6][V] cutoff,res,lp,bp,hp,notch), maxiBiquad (2; par [4][V]
+        type,cutoff,Q,peakGain).  Returns (out, st [3][V], coef [5][V])."""
+        x = _f64(x)
+        N, V = x.shape
+        par = _f64(par).reshape(-1, V)
+        st = np.zeros((3, V)) if st is None else _f64(st).copy()
+        coef = np.zeros((5, V))
+        out = np.empty((N, V))
+        fn = self.L.mxo_filter2
+        fn.restype = c_int
+        fn.argtypes = [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        rc = fn(kind, V, N, _p(x), _p(par), _p(st), _p(coef), _p(out))
+        assert rc == 0, rc
+        return out, st, coef
+
+    ENVGEN_HOLD = -46692.0
+
+    @staticmethod
+    def envgen_fresh(V):
+        """State of V freshly set-up maxiEnvGen objects: dst [5][V], ist [7][V] (WAITING, detectors 1.0 / first)."""
+        dst = np.zeros((5, V))
+        dst[2:5] = 1.0
+        ist = np.zeros((7, V), np.int64)
+        ist[4:7] = 1
+        return dst, ist
+
+    def envgen(self, trig, levels, times, curves, loop=False, retrigger=False, dst=None, ist=None, V=None):
+        """maxiEnvGen (H:2268-2547).  trig [N][V] (per voice) or [N] with V given.  Returns (out, dst, ist, stages)."""
+        trig = _f64(trig)
+        tpv = trig.ndim == 2
+        N = trig.shape[0]
+        V = trig.shape[1] if tpv else int(V)
+        levels, times, curves = _f64(levels), _f64(times), _f64(curves)
+        d0, i0 = self.envgen_fresh(V)
+        dst = d0 if dst is None else _f64(dst).copy()
+        ist = i0 if ist is None else np.ascontiguousarray(ist, np.int64).copy()
+        stages = np.zeros((levels.size - 1, 6))
+        out = np.empty((N, V))
+        fn = self.L.mxo_envgen
+        fn.restype = c_int
+        fn.argtypes = [c_size_t, c_size_t, c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                       c_void_p, c_void_p, c_void_p, c_void_p]
+        rc = fn(V, N, _p(trig), int(tpv), levels.size, _p(levels), _p(times), _p(curves), int(loop), int(retrigger),
+                _p(dst), _p(ist), _p(stages), _p(out))
+        assert rc == 0, rc
+        return out, dst, ist, stages
+
     # -- maxiDelayline ---------------------------------------------------------------------------
     def delay(self, mode, x, size, feedback, cap, position=None, mem=None, phase=None):
         x = _f64(x)

@@ -813,4 +813,91 @@ int mxo_ifft_stream(const float *mags, const float *phases, size_t nframes, int 
     return 0;
 }
 
+// ---- maxiDCBlocker H:1255-1267, maxiSVF H:1281-1338, maxiBiquad H:1343-1486 ------------------------------
+// kind 0 DC blocker: par = [1][V] R.                      st = [3][V] xm1, ym1, -
+// kind 1 SVF: par = [6][V] cutoff, res, lpmix, bpmix, hpmix, notchmix.  st = [3][V] v0z, v1, v2
+// kind 2 biquad: par = [4][V] type, cutoff, Q, peakGain.  st = [3][V] v[0], v[1], v[2]
+// coef (optional, [5][V]): SVF g1,g2,g3,g4,k ; biquad a0,a1,a2,b1,b2 -- what setParams()/set() computed.
+int mxo_filter2(int kind, size_t V, size_t N, const double *in, const double *par, double *st, double *coef,
+                double *out) {
+    if (kind < 0 || kind > 2) return -1;
+    for (size_t v = 0; v < V; v++) {
+        if (kind == 0) {
+            maxiDCBlocker d;
+            d.xm1 = st[v];
+            d.ym1 = st[V + v];
+            for (size_t n = 0; n < N; n++) out[n * V + v] = d.play(in[n * V + v], par[v]);
+            st[v] = d.xm1;
+            st[V + v] = d.ym1;
+        } else if (kind == 1) {
+            maxiSVF f;
+            f.setCutoff(par[v]);
+            f.setResonance(par[V + v]);
+            f.v0z = st[v]; f.v1 = st[V + v]; f.v2 = st[2 * V + v];
+            if (coef) { coef[v] = f.g1; coef[V + v] = f.g2; coef[2 * V + v] = f.g3; coef[3 * V + v] = f.g4; coef[4 * V + v] = f.k; }
+            for (size_t n = 0; n < N; n++)
+                out[n * V + v] = f.play(in[n * V + v], par[2 * V + v], par[3 * V + v], par[4 * V + v], par[5 * V + v]);
+            st[v] = f.v0z; st[V + v] = f.v1; st[2 * V + v] = f.v2;
+        } else {
+            maxiBiquad b;
+            b.set((maxiBiquad::filterTypes)(int)par[v], par[V + v], par[2 * V + v], par[3 * V + v]);
+            b.v[0] = st[v]; b.v[1] = st[V + v]; b.v[2] = st[2 * V + v];
+            if (coef) { coef[v] = b.a0; coef[V + v] = b.a1; coef[2 * V + v] = b.a2; coef[3 * V + v] = b.b1; coef[4 * V + v] = b.b2; }
+            for (size_t n = 0; n < N; n++) out[n * V + v] = b.play(in[n * V + v]);
+            st[v] = b.v[0]; st[V + v] = b.v[1]; st[2 * V + v] = b.v[2];
+        }
+    }
+    return 0;
+}
+
+// ---- maxiEnvGen (src/maximilian.h:2268-2547) -----------------------------------------------------------------
+// One envelope shape (levels/times/curves, loop, retrigger) for the bank, one trigger signal per voice
+// (tpv) or shared.  dst = [5][V]: envval, stages[phase].currentlevel, previousValue of trigDetector,
+// holdDetector, retriggerDetector.  ist = [7][V] int64: phase, state (0 WAITING 1 TRIGGERED 2 HOLDING),
+// nxcHappened, stages[phase].counter, firstTrigger of the three detectors.
+// stages_out (optional, [nstages][6]): startlevel, endlevel, gradient, curve, length, hold as setup() left them.
+int mxo_envgen(size_t V, size_t N, const double *trig, int tpv, size_t nlevels, const double *levels,
+               const double *times, const double *curves, int loop, int retrigger, double *dst, int64_t *ist,
+               double *stages_out, double *out) {
+    if (nlevels < 2) return -1;
+    std::vector<double> lv(levels, levels + nlevels), tm(times, times + nlevels - 1), cv(curves, curves + nlevels - 1);
+    for (size_t v = 0; v < V; v++) {
+        maxiEnvGen e;
+        fflush(stdout);
+        std::streambuf *old = std::cout.rdbuf(nullptr);  // setup() prints every stage
+        bool ok = e.setup(lv, tm, cv, loop != 0, retrigger != 0);
+        std::cout.rdbuf(old);
+        if (!ok) return -2;
+        if (v == 0 && stages_out)
+            for (size_t i = 0; i < e.stages.size(); i++) {
+                stages_out[i * 6 + 0] = e.stages[i].startlevel; stages_out[i * 6 + 1] = e.stages[i].endlevel;
+                stages_out[i * 6 + 2] = e.stages[i].gradient;   stages_out[i * 6 + 3] = e.stages[i].curve;
+                stages_out[i * 6 + 4] = (double)e.stages[i].length; stages_out[i * 6 + 5] = e.stages[i].hold;
+            }
+        e.envval = dst[v];
+        e.phase = (size_t)ist[v];
+        e.state = (decltype(e.state))ist[V + v];
+        e.nxcHappened = ist[2 * V + v] != 0;
+        if (e.phase < e.stages.size()) {
+            e.stages[e.phase].currentlevel = dst[V + v];
+            e.stages[e.phase].counter = (size_t)ist[3 * V + v];
+        }
+        e.trigDetector.previousValue = dst[2 * V + v];      e.trigDetector.firstTrigger = ist[4 * V + v] != 0;
+        e.holdDetector.previousValue = dst[3 * V + v];      e.holdDetector.firstTrigger = ist[5 * V + v] != 0;
+        e.retriggerDetector.previousValue = dst[4 * V + v]; e.retriggerDetector.firstTrigger = ist[6 * V + v] != 0;
+        for (size_t n = 0; n < N; n++) out[n * V + v] = e.play(tpv ? trig[n * V + v] : trig[n]);
+        dst[v] = e.envval;
+        ist[v] = (int64_t)e.phase;
+        ist[V + v] = (int64_t)e.state;
+        ist[2 * V + v] = e.nxcHappened;
+        const bool in = e.phase < e.stages.size();
+        dst[V + v] = in ? e.stages[e.phase].currentlevel : 0.0;
+        ist[3 * V + v] = in ? (int64_t)e.stages[e.phase].counter : 0;
+        dst[2 * V + v] = e.trigDetector.previousValue;      ist[4 * V + v] = e.trigDetector.firstTrigger;
+        dst[3 * V + v] = e.holdDetector.previousValue;      ist[5 * V + v] = e.holdDetector.firstTrigger;
+        dst[4 * V + v] = e.retriggerDetector.previousValue; ist[6 * V + v] = e.retriggerDetector.firstTrigger;
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -119,3 +119,45 @@ def test_extra_port_vs_reference(port, ref):
     for u, w in zip(port.granular(3, 6, gs, T, speed, posMod=rng.uniform(-0.1, 0.1, S) * 0 + 0.05, grainLength=0.04, overlaps=3),
                     ref.granular(3, 6, gs, T, speed, posMod=np.full(S, 0.05), grainLength=0.04, overlaps=3)):
         assert_bits_equal(np.asarray(u, np.float64), np.asarray(w, np.float64))
+
+
+def test_filter2_port_vs_reference(port, ref):
+    """maxiDCBlocker / maxiSVF / maxiBiquad (H:1255-1486): restatement == compiled reference, incl. the
+    coefficients setParams()/set() leave in the members."""
+    rng = np.random.default_rng(4)
+    V, N = 35, 500
+    x = rng.uniform(-1, 1, (N, V))
+    R = rng.uniform(0.9, 0.9999, (1, V))
+    for u, w in zip(port.filter2(0, x, R), ref.filter2(0, x, R)):
+        assert_bits_equal(u, w)
+    par = np.stack([rng.uniform(20, 20000, V), rng.uniform(0, 12, V), *rng.uniform(0, 1, (4, V))])
+    par[1, :3] = 0
+    for u, w in zip(port.filter2(1, x, par), ref.filter2(1, x, par)):
+        assert_bits_equal(u, w)
+    for t in range(7):
+        par = np.stack([np.full(V, float(t)), rng.uniform(30, 18000, V), rng.uniform(0.3, 8, V), rng.uniform(-18, 18, V)])
+        for u, w in zip(port.filter2(2, x, par), ref.filter2(2, x, par)):
+            assert_bits_equal(u, w)
+
+
+def test_envgen_port_vs_reference(port, ref):
+    """maxiEnvGen (H:2268-2547): restatement == compiled reference for AR/ASR/ADSR/curved shapes, loop and
+    retrigger on/off, per-voice gates, impulses and a constant-1 trigger, state carried across two calls."""
+    H = port.ENVGEN_HOLD
+    rng = np.random.default_rng(6)
+    V, N = 23, 4000
+    n = np.arange(N)[:, None]
+    trig = np.sign(np.sin(n * rng.uniform(0.002, 0.01, V)[None, :] + rng.uniform(0, 6, V)))
+    trig[:, 3] = 1.0
+    trig[:, 4] = (np.arange(N) % 700 < 5) * 1.0
+    cases = [([0, 1, 0], [10, 40], [1, 1]), ([0, 1, 1, 0], [5, H, 30], [1, 1, 1]),
+             ([0, 1, 0.4, 0.4, 0], [3, 12, H, 25], [1, 1, 1, 1]), ([0, 1, 0.2, 0], [7.3, 11.1, 20.7], [0.5, 2, 3])]
+    for lv, tm, cv in cases:
+        for loop in (0, 1):
+            for retrig in (0, 1):
+                a = port.envgen(trig[:N // 2], lv, tm, cv, loop, retrig)
+                a2 = port.envgen(trig[N // 2:], lv, tm, cv, loop, retrig, dst=a[1], ist=a[2])
+                b = ref.envgen(trig[:N // 2], lv, tm, cv, loop, retrig)
+                b2 = ref.envgen(trig[N // 2:], lv, tm, cv, loop, retrig, dst=b[1], ist=b[2])
+                for u, w in zip(a + a2, b + b2):
+                    assert_bits_equal(np.asarray(u, np.float64), np.asarray(w, np.float64))

@@ -1,0 +1,66 @@
+"""GPU parity (-m gpu): maxiEnvGen bank (H:2268-2547) through the C-ABI vs the oracle.  The state machine
+(phase, state, counters, the three zero-crossing detectors) is bit-exact; the value is bit-exact for
+curve == 1 (setupAR/ASR/ADSR) and within 4 ULP-of-1.0 x level range for other curves (device pow)."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+H = -46692.0
+CASES = {
+    "AR": ([0, 1, 0], [10, 40], [1, 1]),
+    "ASR": ([0, 1, 1, 0], [5, H, 30], [1, 1, 1]),
+    "ADSR": ([0, 1, 0.4, 0.4, 0], [3, 12, H, 25], [1, 1, 1, 1]),
+    "curved": ([0, 1, 0.2, 0], [7.3, 11.1, 20.7], [0.5, 2, 3]),
+}
+
+
+def _trig(V, N, seed):
+    rng = np.random.default_rng(seed)
+    n = np.arange(N)[:, None]
+    t = np.sign(np.sin(n * rng.uniform(0.002, 0.01, V)[None, :] + rng.uniform(0, 6, V)))
+    t[:, 3] = 1.0                                  # constant 1: fires once (firstTrigger), never releases
+    t[:, 4] = (np.arange(N) % 700 < 5) * 1.0       # short impulses with exact zeros between
+    t[:, 5] = 0.0
+    return t
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("loop,retrig", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_envgen_per_voice_triggers(mx, port, name, loop, retrig):
+    lv, tm, cv = CASES[name]
+    V, N = 300, 3001
+    trig = _trig(V, 2 * N, 80)
+    bank = mx.maxiEnvGenBank(V)
+    assert bank.setup(lv, tm, cv, bool(loop), bool(retrig))
+    o = np.concatenate([bank.play(trig[:N]).numpy(), bank.play(trig[N:]).numpy()])
+    e1, d, i, stages = port.envgen(trig[:N], lv, tm, cv, loop, retrig)
+    e2, d, i, _ = port.envgen(trig[N:], lv, tm, cv, loop, retrig, dst=d, ist=i)
+    e = np.concatenate([e1, e2])
+    assert_bits_equal(bank.host_stages, stages, "stage table")
+    assert np.array_equal(bank.istate.numpy(), i), "phase/state/nxc/counter/firstTrigger"
+    assert_bits_equal(bank.dstate.numpy()[2:], d[2:], "detector previousValue")
+    if name == "curved":
+        tol = 4 * 2.2e-16 * 1.0
+        assert np.abs(o - e).max() <= tol
+        assert np.abs(bank.dstate.numpy()[:2] - d[:2]).max() <= tol
+    else:
+        assert_bits_equal(o, e, name)
+        assert_bits_equal(bank.dstate.numpy()[:2], d[:2], "envval, currentlevel")
+    assert e.max() == 1.0 and (e[:, 5] == 0).all()
+
+
+def test_envgen_shared_gate_and_helpers(mx, port):
+    V, N = 130, 5000
+    gate = ((np.arange(N) % 1800) < 900) * 2.0 - 1.0
+    bank = mx.maxiEnvGenBank(V)
+    assert bank.setupADSR(2, 8, 0.3, 20)
+    o = bank.play(gate).numpy()
+    e, d, i, _ = port.envgen(gate, [0, 1, 0.3, 0.3, 0], [2, 8, H, 20], [1, 1, 1, 1], V=V)
+    assert_bits_equal(o, e, "shared gate ADSR")
+    assert np.array_equal(bank.istate.numpy(), i)
+    assert bank.setupAR(1, 2) and bank.setupASR(1, 2)
+    assert bank.setup([0, 1], [1, 2], [1], False) is False                 # size mismatch (H:2395)
+    assert bank.setup([0, 1, 1, 0], [H, H, 5], [1, 1, 1], False) is False  # two HOLD stages (H:2377-2381)
