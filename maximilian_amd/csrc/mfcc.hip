@@ -128,6 +128,121 @@ __global__ __launch_bounds__(256) void mfcc_stream_kernel(
     for (int i = 0; i < NC; i++) mfcc[frame * NC + i] = c[i] / (double)NC;  // L/maxiMFCC.h:109
 }
 
+// ---- K7a-t: the same bin-major stream, spectra staged through LDS ---------------------------------------
+// In K7a a wave's 16-B row loads touch 64 different cache lines per instruction (lane = frame, 2 KB
+// apart) and 16 waves per CU overflow the 32 KB L1.  Here a wavefront first loads a [64 frames x 32
+// bins] tile COALESCED (8 lanes cover the 128 B of one frame, one instruction = 8 frames), parks it in
+// its private LDS tile (row stride 36 floats: 16-B aligned, conflict-free for the per-frame b128 reads)
+// and then walks it lane = frame exactly like K7a.  The next tile's global loads are issued before the
+// current tile is consumed.  Same additions in the same order: bit-identical to K7a.
+constexpr int kTileBins = 32, kTileStride = 36;
+
+template <int S, int NC>
+__global__ __launch_bounds__(256) void mfcc_stream_tiled_kernel(
+    const float *__restrict__ mags, size_t mag_stride, size_t nframes, unsigned numFilters,
+    unsigned nbUsed, const double *__restrict__ schedW, const int *__restrict__ schedFin,
+    const int *__restrict__ lo, const int *__restrict__ hi, const double *__restrict__ dct,
+    double *__restrict__ melraw, double *__restrict__ melbands, double *__restrict__ mfcc) {
+    extern __shared__ double s_dyn[];  // [nbUsed*S] weights | [numFilters*NC] dct | [nbUsed*S] fin (int) | 4 tiles
+    double *s_w = s_dyn;
+    double *s_d = s_dyn + (size_t)nbUsed * S;
+    int *s_fin = reinterpret_cast<int *>(s_d + (size_t)numFilters * NC);
+    // tiles start on a 16-B boundary after the int table
+    float *s_tiles = reinterpret_cast<float *>(s_fin + (((size_t)nbUsed * S + 3) & ~(size_t)3));
+    for (unsigned i = threadIdx.x; i < nbUsed * S; i += blockDim.x) {
+        s_w[i] = schedW[i];
+        s_fin[i] = schedFin[i];
+    }
+    for (unsigned i = threadIdx.x; i < numFilters * NC; i += blockDim.x) s_d[i] = dct[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *tile = s_tiles + (size_t)wave * 64 * kTileStride;
+    const size_t frame0 = ((size_t)blockIdx.x * 4 + wave) * 64;  // this wave's 64 frames
+    if (frame0 >= nframes) return;
+    const size_t frame = frame0 + lane;
+    const bool live = frame < nframes;
+    // coalesced tile load: lane -> (row = lane/8 + 8*k, 4 bins at 4*(lane%8)), k = 0..7
+    const int lrow = lane >> 3, lcol = (lane & 7) * 4;
+    const float *gsrc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        size_t fr = frame0 + lrow + 8 * k;
+        if (fr >= nframes) fr = nframes - 1;  // clamped: valid memory, results of dead rows are discarded
+        gsrc[k] = mags + fr * mag_stride + lcol;
+    }
+    const unsigned ntiles = (nbUsed + kTileBins - 1) / kTileBins;
+    float nxt[8][4];  // plain floats: a float4 array here is not promoted to registers by hipcc
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float4 v4 = *reinterpret_cast<const float4 *>(gsrc[k]);
+        nxt[k][0] = v4.x; nxt[k][1] = v4.y; nxt[k][2] = v4.z; nxt[k][3] = v4.w;
+    }
+    double acc[S], c[NC];
+    if (live && (melraw || melbands)) {  // bands with an empty support never close: they are 0 / log-square 0
+        for (unsigned f = 0; f < numFilters; f++)
+            if (hi[f] < lo[f]) {  // wave-uniform
+                if (melraw) melraw[frame * numFilters + f] = 0.0;
+                if (melbands) melbands[frame * numFilters + f] = 0.0;
+            }
+    }
+#pragma unroll
+    for (int s = 0; s < S; s++) acc[s] = 0.0;  // L/maxiMFCC.cpp:52
+#pragma unroll
+    for (int i = 0; i < NC; i++) c[i] = 0.0;  // L/maxiMFCC.h:99-101
+    for (unsigned t = 0; t < ntiles; t++) {
+        // park tile t, then request tile t+1 (columns clamped to the last tile: surplus unused)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float4 v4 = {nxt[k][0], nxt[k][1], nxt[k][2], nxt[k][3]};
+            *reinterpret_cast<float4 *>(tile + (lrow + 8 * k) * kTileStride + lcol) = v4;
+        }
+        const unsigned tn = (t + 1 < ntiles) ? t + 1 : t;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float4 v4 = *reinterpret_cast<const float4 *>(gsrc[k] + (size_t)tn * kTileBins);
+            nxt[k][0] = v4.x; nxt[k][1] = v4.y; nxt[k][2] = v4.z; nxt[k][3] = v4.w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float *row = tile + lane * kTileStride;
+        const unsigned bbase = t * kTileBins;
+        for (int j4 = 0; j4 < kTileBins / 4; j4++) {
+            const float4 xv = *reinterpret_cast<const float4 *>(row + 4 * j4);
+            const float x4[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned b = bbase + 4 * j4 + j;
+                if (b < nbUsed) {  // wave-uniform
+                    const double x = (double)x4[j];
+#pragma unroll
+                    for (int s = 0; s < S; s++) acc[s] += (s_w[b * S + s] * x);  // L/maxiMFCC.cpp:57
+#pragma unroll
+                    for (int s = 0; s < S; s++) {
+                        const int f = s_fin[b * S + s];
+                        if (f >= 0) {  // wave-uniform: band f is complete
+                            if (live && melraw) melraw[frame * numFilters + f] = acc[s];
+                            const double mb = log_square(acc[s]);
+                            if (live && melbands) melbands[frame * numFilters + f] = mb;
+                            const double *d = s_d + (size_t)f * NC;
+#pragma unroll
+                            for (int i = 0; i < NC; i++) c[i] += (d[i] * mb);  // L/maxiMFCC.h:105
+                            acc[s] = 0.0;
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < NC; i++) mfcc[frame * NC + i] = c[i] / (double)NC;  // L/maxiMFCC.h:109
+    }
+}
+
 // ---- K7a': filter-major over an LDS tile of 64 spectra (fallback, any bank / any numCoeffs) ----
 __global__ __launch_bounds__(64) void mfcc_tile_kernel(
     const float *__restrict__ mags, size_t mag_stride, size_t nframes, unsigned numFilters,
@@ -426,6 +541,24 @@ int mxg_mfcc_batch(const mxg_mfcc_plan *p, const float *d_mags, size_t mag_strid
                                ((p->nbUsed + 3) / 4 * 4) <= mag_stride) ? 1 : 0;
         const int block = 256;
         dim3 grid((unsigned)((nframes + block - 1) / block));
+        // tiled variant: every 32-bin tile the kernel touches must lie inside the (16-B aligned) row
+        const size_t tiledCols = (size_t)((p->nbUsed + kTileBins - 1) / kTileBins) * kTileBins;
+        const size_t ldsT = (((size_t)p->nbUsed * S * sizeof(double) + (size_t)p->numFilters * NC * sizeof(double) +
+                              (((size_t)p->nbUsed * S + 3) & ~(size_t)3) * sizeof(int)) + 15) / 16 * 16 +
+                            4 * 64 * kTileStride * sizeof(float);
+        if (aligned16 && tiledCols <= mag_stride && ldsT <= 64 * 1024 && tune_get("mfcc_tiled")) {
+#define MXG_TILED_LAUNCH(SS, CC)                                                                              \
+    hipLaunchKernelGGL((mfcc_stream_tiled_kernel<SS, CC>), grid, dim3(block), ldsT, st, d_mags, mag_stride, nframes, \
+                       p->numFilters, p->nbUsed, p->d_schedW, p->d_schedFin, p->d_lo, p->d_hi, p->d_dct, d_melraw, d_melbands, \
+                       d_mfcc)
+            if (NC == 13) {
+                if (S == 1) MXG_TILED_LAUNCH(1, 13); else if (S == 2) MXG_TILED_LAUNCH(2, 13); else MXG_TILED_LAUNCH(4, 13);
+            } else {
+                if (S == 1) MXG_TILED_LAUNCH(1, 20); else if (S == 2) MXG_TILED_LAUNCH(2, 20); else MXG_TILED_LAUNCH(4, 20);
+            }
+#undef MXG_TILED_LAUNCH
+            return check_hip(hipGetLastError(), "mfcc kernel launch");
+        }
 #define MXG_STREAM_LAUNCH(SS, CC)                                                                     \
     hipLaunchKernelGGL((mfcc_stream_kernel<SS, CC>), grid, dim3(block), lds, st, d_mags, mag_stride, nframes, \
                        p->numFilters, p->nbUsed, p->d_schedW, p->d_schedFin, p->d_lo, p->d_hi, p->d_dct, d_melraw, d_melbands, \

@@ -261,3 +261,25 @@ def test_ifft_golden(mx, golden, fs, hop, win):
     tol = 4e-7 * m.sum(axis=1).max() / fs * (fs // hop)
     assert np.abs(o - g["signal_" + tag]).max() <= tol
     assert np.abs(f.buffer.numpy() - g["buffer_" + tag]).max() <= tol
+
+
+@pytest.mark.parametrize("nf,nc,nfr", [(42, 13, 1000), (256, 13, 77), (40, 20, 513), (42, 13, 1)])
+def test_mfcc_tiled_equals_row_loads(mx, nf, nc, nfr):
+    """K7a-t (LDS-staged tiles, default) and K7a (per-lane row loads) do the same additions in the same
+    order: melraw, melbands and mfcc must be bit-identical, for ragged frame counts and every (S, NC)."""
+    rng = np.random.default_rng(nf + nfr)
+    mags = mx.DeviceBuffer.from_numpy(np.abs(rng.normal(0, 20, (nfr, 512))).astype(np.float32))
+    m = mx.maxiMFCC()
+    m.setup(512, nf, nc, 20.0, 20000.0)
+    L = mx.lib()
+    res = []
+    for tiled in (1, 0):
+        prev = L.mxg_tune(b"mfcc_tiled", tiled)
+        try:
+            out = m.mfcc(mags, want_bands=True).numpy()
+            res.append((out, m.melraw.numpy(), m.melBands.numpy()))
+        finally:
+            L.mxg_tune(b"mfcc_tiled", prev)
+    for a, b, what in zip(res[0], res[1], ("mfcc", "melraw", "melbands")):
+        assert_bits_equal(a, b, what)
+    assert np.isfinite(res[0][0]).all() and np.abs(res[0][0]).max() > 0
