@@ -184,3 +184,66 @@ def test_mix_bus_quad_ambisonic(mx, port, channels):
         _, ebus = port.mix_bus(8, x, px, py, pz2, want_bus=True)
         assert np.isnan(ebus).any()
         assert_bits_equal(bus.numpy(), ebus, "bus with NaN")
+
+
+def _long_gate(N, period=9000, duty=5000, offset=3):
+    return (((np.arange(N) + offset) % period) < duty).astype(np.int32)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_voice_steady_state_paths_long_sequence(mx, port, mode):
+    """The wave-uniform SUSTAIN / RELEASE fast paths of K2f against the oracle over 30 000 samples in ragged
+    blocks: gate edges fall inside 8-sample chunks, the first wavefront shares one envelope (it enters
+    sustain/release as a whole -> fast paths), the others mix fast and slow envelopes (some lanes still
+    decaying -> state-machine path), and a few voices never finish their attack."""
+    V, N = 192, 30000
+    rng = np.random.default_rng(90 + mode)
+    v = np.arange(V)
+    freq = 50.0 + 13.7 * v
+    cutoff = (200 + 4 * freq) if mode == 0 else np.full(V, 6000.0)
+    res = 1.0 + (v % 4)
+    vb = mx.maxiVoiceBank(V)
+    vb.env.setAttack(2); vb.env.setDecay(20); vb.env.setSustain(0.5); vb.env.setRelease(100)
+    par = vb.env.par
+    par[0, 64:] = rng.uniform(1e-5, 0.05, V - 64)        # attack increments: some reach 1 only after seconds
+    par[1, 64:] = rng.uniform(0.99, 0.99999, V - 64)     # decay factors
+    par[2, 64:] = rng.uniform(0.1, 0.9, V - 64)
+    par[3, 64:] = rng.uniform(0.995, 0.99999, V - 64)
+    vb.env.holdtime[64:] = rng.integers(1, 400, V - 64)
+    vb.env._dirty = True
+    trig = _long_gate(N)
+    cuts = [0, 7, 520, 1031, 8200, 8713, 20011, N]
+    o = np.concatenate([vb.render(mode, freq, cutoff, res, trig[a:b], b - a).numpy() for a, b in zip(cuts[:-1], cuts[1:])])
+    e = port.voice(mode, freq, cutoff, res, trig, vb.env.par, vb.env.holdtime)
+    assert np.array_equal(vb.env.istate.numpy(), e[4]), "envelope flags / holdcount"
+    assert_bits_equal(vb.env.dstate.numpy(), e[3], "envelope amplitude / output")
+    assert_bits_equal(vb.osc_state.numpy(), e[1], "osc state")
+    if mode == 0:
+        assert_bits_equal(o, e[0], "mode A")
+        assert_bits_equal(vb.flt_state.numpy(), e[2])
+    else:
+        assert_close_scaled(o, e[0], MOD_FILTER_RTOL, "mode B")
+    # the sequence really visited the steady states
+    flags = e[4]
+    assert (np.abs(e[0][6000:8000, :64]).max() > 0) and flags.shape[0] == 6
+
+
+def test_env_steady_state_paths_long_sequence(mx, port):
+    V, N = 160, 24000
+    rng = np.random.default_rng(95)
+    x = mx.DeviceBuffer.from_numpy(rng.uniform(-1, 1, (N, V)))
+    bank = mx.maxiEnvBank(V)
+    bank.setAttack(2); bank.setDecay(20); bank.setSustain(0.5); bank.setRelease(100)
+    bank.par[1, 64:] = rng.uniform(0.99, 0.99999, V - 64)
+    bank.par[2, 64:] = rng.uniform(0.1, 0.9, V - 64)
+    bank.holdtime[64:] = rng.integers(1, 400, V - 64)
+    bank._dirty = True
+    trig = _long_gate(N, 7000, 4000, 5)
+    xh = x.numpy()
+    cuts = [0, 5, 1000, 4003, 11000, N]
+    o = np.concatenate([bank.render(0, mx.DeviceBuffer.from_numpy(xh[a:b]), trig[a:b], b - a).numpy()
+                        for a, b in zip(cuts[:-1], cuts[1:])])
+    e, dst, ist = port.env(0, xh, trig, bank.par, bank.holdtime)
+    assert_bits_equal(o, e, "adsr")
+    assert_bits_equal(bank.dstate.numpy(), dst)
+    assert np.array_equal(bank.istate.numpy(), ist)
