@@ -18,7 +18,7 @@ out = mx.DeviceBuffer((B, V), zero=False)
 v = np.arange(V)
 fb = mx.maxiFilterBank(V)
 cut = 200 + 4 * np.minimum(20 + v * 0.305, 5000.0); res = 1.0 + (v % 16)
-print("filter lores (hoisted)  %.1f us  (16 B/sample algorithmic)" % timed(lambda: fb.render("lores", x, cut, res, out=out)))
+print("filter lores (hoisted)  %.1f us  (wall per call INCLUDING the host-libm coefficients of 65 536 voices + upload; kernel alone: see the stats table)" % timed(lambda: fb.render("lores", x, cut, res, out=out)))
 print("filter lopass           %.1f us" % timed(lambda: fb.render("lopass", x, np.full(V, 0.3), out=out)))
 eb = mx.maxiEnvBank(V); eb.setAttack(10); eb.setDecay(100); eb.setSustain(0.5); eb.setRelease(500)
 trig = mx.DeviceBuffer.from_numpy(((np.arange(B) % 300) < 150).astype(np.int32))
