@@ -732,6 +732,10 @@ __device__ __forceinline__ double unit_sample(const double *amp, const double *w
     return o;
 }
 
+#ifndef MXG_UNIT_GROUP
+#define MXG_UNIT_GROUP 1
+#endif
+constexpr int kUnitGroup = MXG_UNIT_GROUP;  // streams rendered together by a wavefront (divides 16)
 constexpr int kCand = 16;  // candidates per stream and tile: <= 8 carried-in + the spawns alive in the tile
 
 __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
@@ -791,44 +795,64 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
     // ---- phase 2: lanes = 64 consecutive samples of one stream; contiguous sample/window reads, 32-bit math
     const int ilen = (int)A.len;
     const bool inT = (long long)n0 + lane < (long long)A.T;
-    for (int si = wave * 16; si < wave * 16 + 16; si++) {
-        const int cnt = s_cnt[si];
-        double total = 0.0;
-        int alive = 0;
-        for (int q0 = 0; q0 < cnt; q0 += 8) {
-            double va[8], vb[8], ve[8];
-            bool ok[8];
+    // kUnitGroup streams can be rendered together (all their gathers issued before any is consumed).  Measured
+    // on config 5: groups of 1 / 2 / 4 -> 2.11 / 2.49 / 3.18 ms end to end, so more loads in flight per wave
+    // do not help (occupancy does); the default stays 1.
+    for (int sg = wave * 16; sg < wave * 16 + 16; sg += kUnitGroup) {
+        int cnt[kUnitGroup], cmax = 0;
 #pragma unroll
-            for (int u = 0; u < 8; u++) {  // issue the reads of up to 8 grains together
-                const int q = q0 + u;
-                ok[u] = false;
-                va[u] = vb[u] = ve[u] = 0.0;
-                if (q < cnt) {  // wave-uniform
-                    const int k = s_k0[si * kCand + q] + lane;
-                    ok[u] = inT && k >= 0 && k < s_dur[si * kCand + q];
-                    int ia = s_base[si * kCand + q] + lane * s_sgn[si * kCand + q];  // |lane*sgn| < 64 <= len
-                    if (ia >= ilen) ia -= ilen;
-                    if (ia < 0) ia += ilen;
-                    int ib = ia + 1;
-                    if (ib >= ilen) ib = 0;  // :231-233
-                    va[u] = A.amp[ia];
-                    vb[u] = A.amp[ib];
-                    ve[u] = A.window[ok[u] ? k : 0];
+        for (int g = 0; g < kUnitGroup; g++) {
+            cnt[g] = s_cnt[sg + g];
+            cmax = cnt[g] > cmax ? cnt[g] : cmax;
+        }
+        double total[kUnitGroup];
+        int alive[kUnitGroup];
+#pragma unroll
+        for (int g = 0; g < kUnitGroup; g++) { total[g] = 0.0; alive[g] = 0; }
+        for (int q0 = 0; q0 < cmax; q0 += 8) {
+            double va[kUnitGroup][8], vb[kUnitGroup][8], ve[kUnitGroup][8];
+            bool ok[kUnitGroup][8];
+#pragma unroll
+            for (int g = 0; g < kUnitGroup; g++) {
+                const int si = sg + g;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {  // issue the reads of up to 8 grains of every stream of the group
+                    const int q = q0 + u;
+                    ok[g][u] = false;
+                    va[g][u] = vb[g][u] = ve[g][u] = 0.0;
+                    if (q < cnt[g]) {  // wave-uniform
+                        const int k = s_k0[si * kCand + q] + lane;
+                        ok[g][u] = inT && k >= 0 && k < s_dur[si * kCand + q];
+                        int ia = s_base[si * kCand + q] + lane * s_sgn[si * kCand + q];  // |lane*sgn| < 64 <= len
+                        if (ia >= ilen) ia -= ilen;
+                        if (ia < 0) ia += ilen;
+                        int ib = ia + 1;
+                        if (ib >= ilen) ib = 0;  // :231-233
+                        va[g][u] = A.amp[ia];
+                        vb[g][u] = A.amp[ib];
+                        ve[g][u] = A.window[ok[g][u] ? k : 0];
+                    }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                if (ok[u]) {
-                    const double remainder = 0.0;  // pos is an integer: pos - floor(pos)
-                    double o = ((1 - remainder) * va[u] + remainder * vb[u]);  // :236-237, literally
-                    o *= ve[u];
-                    total += o;  // creation order
-                    alive++;
+            for (int g = 0; g < kUnitGroup; g++) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (ok[g][u]) {
+                        const double remainder = 0.0;  // pos is an integer: pos - floor(pos)
+                        double o = ((1 - remainder) * va[g][u] + remainder * vb[g][u]);  // :236-237, literally
+                        o *= ve[g][u];
+                        total[g] += o;  // creation order
+                        alive[g]++;
+                    }
                 }
             }
         }
-        if (alive > kSlots) atomicMax(A.err, 1);  // same capacity rule as the register-slot kernels
-        s_tile[lane * 65 + si] = total;
+#pragma unroll
+        for (int g = 0; g < kUnitGroup; g++) {
+            if (alive[g] > kSlots) atomicMax(A.err, 1);  // same capacity rule as the register-slot kernels
+            s_tile[lane * 65 + sg + g] = total[g];
+        }
     }
     __syncthreads();
     for (int r = wave * 16; r < wave * 16 + 16; r++) {
