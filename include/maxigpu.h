@@ -292,6 +292,23 @@ double *mxg_sample_load_wav(const char *path, int channel, size_t *h_len, int32_
 int mxg_sample_save_wav(const char *path, const double *d_samples, size_t len, const int32_t *h_hdr,
                         void *stream);
 
+/* ---- maxiSampler banks (L/maxiSynths.h:137-187, maxiSynths.cpp:262-300) ---------------------------------- */
+/* V = NS * voices slots (voices in {1,2,4,8,16,32} consecutive lanes per sampler), all over one sample
+ * buffer (mxg_sample_upload / mxg_sample_load_wav).  Renders N calls of maxiSampler::play() for every
+ * sampler: per slot envOut = adsr(gain, trigger); if (envOut > 0) { outputs = play4(freq, 0, len)*envOut;
+ * output += outputs/voices; if (trigger == 1 && !sustain) trigger = 0; }.  d_mix [N][NS] = play();
+ * d_outputs (optional) [N][V] = the member outputs[i] after each call.  d_freq [V] from
+ * mxg_sampler_freq_host (pitchRatios[(int)pitch + 67] * ((1./len)*sampleRate), maxiSynths.cpp:297).
+ * Slot state, in/out: d_position [V], d_trigger [V] (envelopes[i].trigger), d_outhold [V] (outputs[i]),
+ * d_dst [2][V] / d_ist [6][V] as mxg_env_render; d_gain [V] = envOutGain, d_par [4][V] + d_holdtime [V] the
+ * envelope parameters.  The control calls (trigger(), midiNoteOn/Off, setPitch: maxiSynths.cpp:351-391,
+ * 484-491) edit that state between renders on the host.  Bit-exact, including the in-order sum. */
+int mxg_sampler_freq_host(size_t V, const double *h_pitch, size_t len, double *h_freq);
+int mxg_sampler_render(size_t V, size_t N, int voices, int sustain, const double *d_samples, size_t len,
+                       const double *d_freq, const double *d_gain, const double *d_par,
+                       const int64_t *d_holdtime, double *d_position, int32_t *d_trigger, double *d_outhold,
+                       double *d_dst, int64_t *d_ist, double *d_mix, double *d_outputs, void *stream);
+
 /* ---- maxiFFT batch ---------------------------------------------------------------------- */
 /* A plan is what maxiFFT::setup(fftSize, hopSize, windowSize) prepares (L/maxiFFT.cpp:45-60): the
  * Hann window (fft::genWindow type 3, L/fft.cpp:409-413) and the fp32 twiddle sequences the

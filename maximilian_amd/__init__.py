@@ -8,7 +8,7 @@ package is the thin host-side mirror used by the tests and bench.py: device buff
 from ._lib import LIB_PATH, MaxiGpuError, lib  # noqa: F401
 from .banks import (DeviceBuffer, maxiSettings, maxiOscBank, maxiFilterBank, maxiEnvBank,  # noqa: F401
                     maxiVoiceBank, maxiMixBank, maxiDelaylineBank, maxiSampleBank, maxiDCBlockerBank,
-                    maxiSVFBank, maxiBiquadBank, maxiEnvGenBank, OSC_WAVEFORMS,
+                    maxiSVFBank, maxiBiquadBank, maxiEnvGenBank, maxiSamplerBank, OSC_WAVEFORMS,
                     FILTER_KINDS, SAMPLE_MODES)
 from .spectral import maxiFFT, maxiIFFT, maxiMFCC, frames_in_stream, padded_stream  # noqa: F401
 from .grains import maxiTimeStretchBank, maxiStretchBank, maxiPitchShiftBank, WINDOWS  # noqa: F401

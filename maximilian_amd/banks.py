@@ -286,6 +286,92 @@ class maxiEnvGenBank(_Bank):
         return out
 
 
+class maxiSamplerBank(_Bank):
+    """NS x maxiSampler (L/maxiSynths.h:137-187) of `voices` slots each, all playing one sample.  The control
+    methods mirror the reference (they edit host copies of the slot state between renders); play(N) renders N
+    calls of maxiSampler::play() for every sampler."""
+
+    def __init__(self, samplers, voices=32, stream=None):
+        super().__init__(samplers * voices, stream)
+        self.NS, self.voices = int(samplers), int(voices)
+        self.sample = maxiSampleBank(1, stream)
+        V = self.V
+        self.sustain = True
+        self.currentVoice = np.zeros(self.NS, np.int64)
+        self.pitch = np.zeros(V)                      # ctor, maxiSynths.cpp:262-283
+        self.gain = np.zeros(V)                       # envOutGain (uninitialised in the reference: 0 here)
+        self.env = maxiEnvBank(V, stream)
+        self.env.setAttack(0); self.env.setDecay(1); self.env.setSustain(1.0); self.env.setRelease(2000)
+        self.position = np.zeros(V)
+        self.trigger_state = np.zeros(V, np.int32)
+        self.outhold = np.zeros(V)
+        self._state_dirty = True
+
+    # -- control side (host), maxiSynths.cpp:303-491 ------------------------------------------------------
+    def load(self, fileName):
+        ok = self.sample.load(fileName)
+        self.position[:] = float(self.sample.getLength()) if ok else self.position
+        self._state_dirty = True
+        return ok
+
+    def setSample(self, samples):
+        self.sample.setSample(samples)
+        self.position[:] = self.sample.getLength() - 1.0      # maxiSample::setSample (H:677)
+        self._state_dirty = True
+
+    def _slots(self, setall):
+        if setall:
+            return np.arange(self.V)
+        return np.arange(self.NS) * self.voices + self.currentVoice
+
+    def _pull(self):
+        if not self._state_dirty:
+            self.position, self.trigger_state, self.outhold = self._dpos.numpy(), self._dtrig.numpy(), self._dout.numpy()
+
+    def setPitch(self, pitch, setall=False):
+        self.pitch[self._slots(setall)] = pitch
+
+    def midiNoteOn(self, pitch, velocity, setall=False):
+        sl = self._slots(setall)
+        self.pitch[sl] = pitch
+        if not setall:
+            self.gain[sl] = velocity / 128
+
+    def midiNoteOff(self, pitch, velocity=0):
+        self._pull()
+        self.trigger_state[self.pitch == pitch] = 0
+        self._state_dirty = True
+
+    def trigger(self):
+        self._pull()
+        sl = self._slots(False)
+        self.trigger_state[sl] = 1
+        self.position[sl] = 0.0
+        self.currentVoice = (self.currentVoice + 1) % self.voices
+        self._state_dirty = True
+
+    def play(self, N, want_outputs=False):
+        V = self.V
+        if self._state_dirty:
+            self._dpos = DeviceBuffer.from_numpy(self.position)
+            self._dtrig = DeviceBuffer.from_numpy(self.trigger_state)
+            self._dout = DeviceBuffer.from_numpy(self.outhold)
+            self._state_dirty = False
+        freq = np.zeros(V)
+        check(lib().mxg_sampler_freq_host(V, self.pitch.ctypes.data, self.sample.getLength(), freq.ctypes.data),
+              "mxg_sampler_freq_host")
+        dfreq, dgain = DeviceBuffer.from_numpy(freq), DeviceBuffer.from_numpy(self.gain)
+        dpar, dhold = self.env._params()
+        mix = DeviceBuffer((N, self.NS), zero=False)
+        self.outputs = DeviceBuffer((N, V), zero=False) if want_outputs else None
+        check(lib().mxg_sampler_render(V, N, self.voices, int(self.sustain), self.sample.d_samples, self.sample.getLength(),
+                                       dfreq.ptr, dgain.ptr, dpar.ptr, dhold.ptr, self._dpos.ptr, self._dtrig.ptr,
+                                       self._dout.ptr, self.env.dstate.ptr, self.env.istate.ptr, mix.ptr,
+                                       _ptr(self.outputs), self.stream), "mxg_sampler_render")
+        self._keep = (dfreq, dgain)
+        return mix
+
+
 class _Filter2Bank(_Bank):
     KIND = 0
 

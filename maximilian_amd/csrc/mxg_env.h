@@ -1,0 +1,171 @@
+// mxg_env.h -- maxiEnv (src/maximilian.cpp:1319-1494) per-lane state and tick functions, shared by the
+// envelope / fused-voice kernels (voice.hip) and the sampler kernel (sampler.hip).
+#pragma once
+#include "mxg_common.h"
+
+namespace mxg {
+namespace {
+
+// ---- maxiEnv ----------------------------------------------------------------------------
+struct Env {
+    double attack, decay, sustain, release, amplitude, output;
+    long long holdtime, holdcount;
+    int attackphase, decayphase, sustainphase, holdphase, releasephase;
+};
+
+__device__ __forceinline__ void env_load(Env &e, size_t V, size_t v, const double *par,
+                                         const int64_t *holdtime, const double *dst,
+                                         const int64_t *ist) {
+    e.attack = par[v];
+    e.decay = par[V + v];
+    e.sustain = par[2 * V + v];
+    e.release = par[3 * V + v];
+    e.holdtime = holdtime[v];
+    e.amplitude = dst[v];
+    e.output = dst[V + v];
+    e.holdcount = ist[v];
+    e.attackphase = (int)ist[V + v];
+    e.decayphase = (int)ist[2 * V + v];
+    e.sustainphase = (int)ist[3 * V + v];
+    e.holdphase = (int)ist[4 * V + v];
+    e.releasephase = (int)ist[5 * V + v];
+}
+__device__ __forceinline__ void env_store(const Env &e, size_t V, size_t v, double *dst,
+                                          int64_t *ist) {
+    dst[v] = e.amplitude;
+    dst[V + v] = e.output;
+    ist[v] = e.holdcount;
+    ist[V + v] = e.attackphase;
+    ist[2 * V + v] = e.decayphase;
+    ist[3 * V + v] = e.sustainphase;
+    ist[4 * V + v] = e.holdphase;
+    ist[5 * V + v] = e.releasephase;
+}
+
+// C:1415-1466.  Statement order is the reference's: a sample can pass through several of
+// the `if`s (e.g. attack -> decay in the same call).
+// Written as straight-line selects (same statement order, same arithmetic): the lanes of a wave sit
+// in different envelope phases, and as nested `if`s this compiled to ~13 exec-mask regions per
+// sample (26 s_cbranch_execz per 4 samples), 4x slower than the predicated form.
+__device__ __forceinline__ double env_adsr(Env &e, double input, int trigger) {
+    const bool t1 = trigger == 1;
+    // C:1417-1423
+    const bool c1 = t1 && e.attackphase != 1 && e.holdphase != 1 && e.decayphase != 1;
+    e.holdcount = c1 ? 0 : e.holdcount;
+    e.decayphase = c1 ? 0 : e.decayphase;
+    e.sustainphase = c1 ? 0 : e.sustainphase;
+    e.releasephase = c1 ? 0 : e.releasephase;
+    e.attackphase = c1 ? 1 : e.attackphase;
+    double amp = e.amplitude, out = e.output;
+    // C:1425-1435  attack
+    const bool a = e.attackphase == 1;
+    e.releasephase = a ? 0 : e.releasephase;
+    const double ampA = amp + (1 * e.attack);
+    amp = a ? ampA : amp;
+    out = a ? input * amp : out;
+    const bool a2 = a && amp >= 1;
+    amp = a2 ? 1.0 : amp;
+    e.attackphase = a2 ? 0 : e.attackphase;
+    e.decayphase = a2 ? 1 : e.decayphase;
+    // C:1438-1444  decay
+    const bool d = e.decayphase == 1;
+    const double ampD = amp * e.decay;
+    amp = d ? ampD : amp;
+    out = d ? input * amp : out;
+    const bool d2 = d && amp <= e.sustain;
+    e.decayphase = d2 ? 0 : e.decayphase;
+    e.holdphase = d2 ? 1 : e.holdphase;
+    // C:1446-1449  hold
+    const bool h = e.holdcount < e.holdtime && e.holdphase == 1;
+    const double held = input * amp;
+    out = h ? held : out;
+    e.holdcount += h ? 1 : 0;
+    // C:1451-1458
+    const bool ge = e.holdcount >= e.holdtime;
+    out = (ge && t1) ? held : out;
+    const bool rel = ge && !t1;
+    e.holdphase = rel ? 0 : e.holdphase;
+    e.releasephase = rel ? 1 : e.releasephase;
+    // C:1460-1463  release
+    const bool r = e.releasephase == 1 && amp > 0.;
+    const double ampR = amp * e.release;
+    amp = r ? ampR : amp;
+    out = r ? input * amp : out;
+    e.amplitude = amp;
+    e.output = out;
+    return out;
+}
+
+// Two steady states of the ADSR in which a sample is one multiply and no flag moves (read off
+// C:1415-1466): SUSTAIN = gate held after the hold time ran out (only C:1451-1453 fires:
+// output = input*amplitude), RELEASE = gate off after it (only C:1455-1463: amplitude *= release
+// while it is > 0).  A wavefront whose lanes are all in one of them, with the (shared, scalar) gate
+// constant over a chunk, runs the chunk without the predicated state machine -- same operations on
+// the same values, so bit-identical, at ~1/6 of the VALU work.
+__device__ __forceinline__ bool env_in_sustain(const Env &e) {
+    return e.attackphase != 1 && e.decayphase != 1 && e.releasephase != 1 && e.holdphase == 1 &&
+           e.holdcount >= e.holdtime;
+}
+__device__ __forceinline__ bool env_in_release(const Env &e) {
+    return e.attackphase != 1 && e.decayphase != 1 && e.releasephase == 1 && e.holdphase != 1 &&
+           e.holdcount >= e.holdtime;
+}
+__device__ __forceinline__ double env_sustain_tick(Env &e, double input) {  // gate == 1
+    e.output = input * e.amplitude;  // C:1452
+    return e.output;
+}
+__device__ __forceinline__ double env_release_tick(Env &e, double input) {  // gate != 1
+    const bool r = e.amplitude > 0.;  // C:1460
+    const double ampR = e.amplitude * e.release;
+    e.amplitude = r ? ampR : e.amplitude;
+    e.output = r ? input * e.amplitude : e.output;
+    return e.output;
+}
+// gate state of a full chunk from its (already fetched, wave-uniform) trigger values:
+// +1 all == 1, -1 all != 1, 0 mixed.  Scalar work.
+template <int U>
+__device__ __forceinline__ int gate_of_chunk(const int (&t)[U]) {
+    int on = 0;
+#pragma unroll
+    for (int i = 0; i < U; i++) on += (t[i] == 1) ? 1 : 0;
+    return on == U ? 1 : (on == 0 ? -1 : 0);
+}
+
+// C:1319-1358
+__device__ __forceinline__ double env_ar(Env &e, double input, int trigger) {
+    const double attack = e.attack, release = e.release;
+    const long long holdtime = e.holdtime;
+    if (trigger == 1 && e.attackphase != 1 && e.holdphase != 1) {
+        e.holdcount = 0;
+        e.releasephase = 0;
+        e.attackphase = 1;
+    }
+    if (e.attackphase == 1) {
+        e.amplitude += (1 * attack);
+        e.output = input * e.amplitude;
+    }
+    if (e.amplitude >= 1) {
+        e.amplitude = 1;
+        e.attackphase = 0;
+        e.holdphase = 1;
+    }
+    if (e.holdcount < holdtime && e.holdphase == 1) {
+        e.output = input;
+        e.holdcount++;
+    }
+    if (e.holdcount == holdtime && trigger == 1) {
+        e.output = input;
+    }
+    if (e.holdcount == holdtime && trigger != 1) {
+        e.holdphase = 0;
+        e.releasephase = 1;
+    }
+    if (e.releasephase == 1 && e.amplitude > 0.) {
+        e.amplitude *= release;
+        e.output = input * e.amplitude;
+    }
+    return e.output;
+}
+
+}  // namespace
+}  // namespace mxg

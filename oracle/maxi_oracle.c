@@ -1927,3 +1927,57 @@ int mxo_envgen(size_t V, size_t N, const double *trig, int tpv, size_t nlevels, 
     free(tab);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------
+ * maxiSampler::play L/maxiSynths.cpp:289-312 (class L/maxiSynths.h:137-187): per voice
+ *   envOut = envelopes[i].adsr(envOutGain[i], envelopes[i].trigger);
+ *   if (envOut > 0) { outputs[i] = samples[i].play4(pitchRatios[(int)pitch[i]+originalPitch] *
+ *       ((1./len)*sampleRate), 0, len) * envOut;  output += outputs[i]/voices;
+ *       if (trigger == 1 && !sustain) trigger = 0; }
+ * originalPitch = 67 (H:152), pitchRatios src/maximilian.h:112.  Layout as oracle/ref_harness.cpp.
+ * ------------------------------------------------------------------------------------ */
+double mxo_sampler_frequency(double pitch, size_t len) {
+    return MAXI_PITCH_RATIOS[(int)pitch + 67] * ((1. / len) * g_sampleRate);
+}
+
+int mxo_sampler(size_t NS, int voices, size_t N, const double *amp, size_t len, int sustain, const double *pitch,
+                const double *gain, const double *par, const int64_t *holdtime, double *position,
+                int32_t *trigger, double *outhold, double *dst, int64_t *ist, double *mix, double *outputs) {
+    if (voices < 1 || voices > 32) return -1;
+    const size_t V = NS * (size_t)voices;
+    for (size_t s = 0; s < NS; s++) {
+        env_t e[32];
+        smp_t sm[32];
+        int trig[32];
+        double outs[32];
+        for (int i = 0; i < voices; i++) {
+            const size_t v = s * voices + i;
+            env_load(&e[i], V, v, par, holdtime, dst, ist);
+            sm[i].amp = amp; sm[i].len = len; sm[i].mySampleRate = 44100; sm[i].position = position[v];
+            trig[i] = trigger[v];
+            outs[i] = outhold[v];
+        }
+        for (size_t n = 0; n < N; n++) {
+            double output = 0;
+            for (int i = 0; i < voices; i++) {
+                const size_t v = s * voices + i;
+                double envOut = env_adsr(&e[i], gain[v], trig[i]);
+                if (envOut > 0.) {
+                    outs[i] = smp_play4(&sm[i], mxo_sampler_frequency(pitch[v], len), 0, len) * envOut;
+                    output += outs[i] / voices;
+                    if (trig[i] == 1 && !sustain) trig[i] = 0;
+                }
+                if (outputs) outputs[n * V + v] = outs[i];
+            }
+            mix[n * NS + s] = output;
+        }
+        for (int i = 0; i < voices; i++) {
+            const size_t v = s * voices + i;
+            env_store(&e[i], V, v, dst, ist);
+            position[v] = sm[i].position;
+            trigger[v] = trig[i];
+            outhold[v] = outs[i];
+        }
+    }
+    return 0;
+}

@@ -437,6 +437,31 @@ class Oracle:
         fn.argtypes = [ctypes.c_char_p, c_void_p, c_size_t, c_void_p]
         return fn(os.fsencode(path), _p(amplitudes), amplitudes.size, _p(hdr))
 
+    # -- maxiSampler (L/maxiSynths.h:137-187) -------------------------------------------------------
+    def sampler(self, voices, samples, N, pitch, gain, par, holdtime, position, trigger, sustain=True, outhold=None,
+                dst=None, ist=None):
+        """NS = V/voices samplers.  Returns (mix [N,NS], outputs [N,V], position, trigger, outhold, dst, ist)."""
+        g = self.guarded(np.asarray(samples, np.float64))
+        pitch = _f64(pitch)
+        V = pitch.size
+        NS = V // voices
+        gain, par = _f64(gain, (V,)), _f64(par)
+        holdtime = np.ascontiguousarray(np.broadcast_to(np.asarray(holdtime, np.int64), (V,)))
+        position = _f64(position, (V,)).copy()
+        trigger = np.ascontiguousarray(np.broadcast_to(np.asarray(trigger, np.int32), (V,))).copy()
+        outhold = np.zeros(V) if outhold is None else _f64(outhold).copy()
+        dst = np.zeros((2, V)) if dst is None else _f64(dst).copy()
+        ist = np.zeros((6, V), np.int64) if ist is None else np.ascontiguousarray(ist, np.int64).copy()
+        mix = np.empty((N, NS))
+        outputs = np.empty((N, V))
+        fn = self.L.mxo_sampler
+        fn.restype = c_int
+        fn.argtypes = [c_size_t, c_int, c_size_t, c_void_p, c_size_t, c_int] + [c_void_p] * 11
+        rc = fn(NS, voices, N, g.ctypes.data + 8, len(samples), int(sustain), _p(pitch), _p(gain), _p(par), _p(holdtime),
+                _p(position), _p(trigger), _p(outhold), _p(dst), _p(ist), _p(mix), _p(outputs))
+        assert rc == 0, rc
+        return mix, outputs, position, trigger, outhold, dst, ist
+
     # -- CPU baseline timer -----------------------------------------------------------------------
     def time_osc(self, wf, freq, N, threads=1):
         freq = _f64(freq)

@@ -17,6 +17,7 @@
 #include "maximilian.h"
 #include "libs/maxiFFT.h"
 #include "libs/maxiMFCC.h"
+#include "libs/maxiSynths.h"
 // maxiTimeStretch/maxiStretch draw `rand() % 10` from the process-wide libc stream
 // (maxiGrains.h:352, :524), which cannot be reproduced per stream in a bank.  The header-only
 // grain code is compiled in THIS translation unit, so its rand() calls are routed to a
@@ -63,6 +64,7 @@ void mxo_settings(size_t sr, size_t ch, size_t buf) { maxiSettings::setup(sr, ch
 // Raw tables of the reference (src/maximilian.cpp:63, :67-200), for oracle/gen_tables.py.
 const double *mxo_sine_table(void) { return sineBuffer; }
 const double *mxo_transition_table(void) { return transition; }
+const double *mxo_pitch_ratios(void) { return pitchRatios; }  // src/maximilian.h:112
 // The two out-of-bounds neighbours the reference reads (sinebuf4 -> sineBuffer[-1],
 // sawn -> transition[1001]); exported so the tests can assert what this build holds.
 double mxo_sine_table_guard(void) { return (&sineBuffer[0])[-1]; }
@@ -896,6 +898,61 @@ int mxo_envgen(size_t V, size_t N, const double *trig, int tpv, size_t nlevels, 
         dst[2 * V + v] = e.trigDetector.previousValue;      ist[4 * V + v] = e.trigDetector.firstTrigger;
         dst[3 * V + v] = e.holdDetector.previousValue;      ist[5 * V + v] = e.holdDetector.firstTrigger;
         dst[4 * V + v] = e.retriggerDetector.previousValue; ist[6 * V + v] = e.retriggerDetector.firstTrigger;
+    }
+    return 0;
+}
+
+// ---- maxiSampler (src/libs/maxiSynths.h:137-187, maxiSynths.cpp:262-300, 484-491) ---------------------------
+// NS samplers of `voices` (<= 32) voices each, V = NS*voices lanes, voice v = sampler v/voices, slot v%voices.
+// Every voice plays the same sample data.  Per-voice in/out state: position, trigger (envelopes[i].trigger),
+// outhold (outputs[i]), envelope dst [2][V] / ist [6][V] as mxo_env.  In: pitch [V], gain (envOutGain) [V],
+// env par [4][V] + holdtime [V].  Out: mix [N][NS] = play(); outputs (optional) [N][V] = outputs[i] after
+// each play().
+int mxo_sampler(size_t NS, int voices, size_t N, const double *amp, size_t len, int sustain, const double *pitch,
+                const double *gain, const double *par, const int64_t *holdtime, double *position,
+                int32_t *trigger, double *outhold, double *dst, int64_t *ist, double *mix, double *outputs) {
+    if (voices < 1 || voices > 32) return -1;
+    const size_t V = NS * (size_t)voices;
+    std::vector<double> data(amp, amp + len);
+    std::unique_ptr<maxiSampler> sp(new maxiSampler());
+    for (size_t s = 0; s < NS; s++) {
+        maxiSampler &m = *sp;
+        m.setNumVoices(voices);
+        m.sustain = sustain != 0;
+        for (int i = 0; i < voices; i++) {
+            const size_t v = s * voices + i;
+            maxiSample &smp = m.samples[i];
+            smp.amplitudes.reserve(len + 2);
+            smp.setSample(data);
+            smp.amplitudes.data()[len] = 0.0;
+            smp.amplitudes.data()[len + 1] = 0.0;
+            smp.position = position[v];
+            m.pitch[i] = pitch[v];
+            m.envOutGain[i] = gain[v];
+            m.outputs[i] = outhold[v];
+            maxiEnv &e = m.envelopes[i];
+            e.attack = par[v]; e.decay = par[V + v]; e.sustain = par[2 * V + v]; e.release = par[3 * V + v];
+            e.holdtime = (long)holdtime[v];
+            e.trigger = trigger[v];
+            e.amplitude = dst[v]; e.output = dst[V + v];
+            e.holdcount = (long)ist[v]; e.attackphase = (int)ist[V + v]; e.decayphase = (int)ist[2 * V + v];
+            e.sustainphase = (int)ist[3 * V + v]; e.holdphase = (int)ist[4 * V + v]; e.releasephase = (int)ist[5 * V + v];
+        }
+        for (size_t n = 0; n < N; n++) {
+            mix[n * NS + s] = m.play();
+            if (outputs)
+                for (int i = 0; i < voices; i++) outputs[n * V + s * voices + i] = m.outputs[i];
+        }
+        for (int i = 0; i < voices; i++) {
+            const size_t v = s * voices + i;
+            position[v] = m.samples[i].position;
+            trigger[v] = m.envelopes[i].trigger;
+            outhold[v] = m.outputs[i];
+            maxiEnv &e = m.envelopes[i];
+            dst[v] = e.amplitude; dst[V + v] = e.output;
+            ist[v] = e.holdcount; ist[V + v] = e.attackphase; ist[2 * V + v] = e.decayphase;
+            ist[3 * V + v] = e.sustainphase; ist[4 * V + v] = e.holdphase; ist[5 * V + v] = e.releasephase;
+        }
     }
     return 0;
 }

@@ -161,3 +161,26 @@ def test_envgen_port_vs_reference(port, ref):
                 b2 = ref.envgen(trig[N // 2:], lv, tm, cv, loop, retrig, dst=b[1], ist=b[2])
                 for u, w in zip(a + a2, b + b2):
                     assert_bits_equal(np.asarray(u, np.float64), np.asarray(w, np.float64))
+
+
+def test_sampler_port_vs_reference(port, ref):
+    """maxiSampler::play (L/maxiSynths.cpp:289-312): restatement == compiled reference, 32/8/5 voices, sustain on/off,
+    with note-offs and re-triggers between two blocks."""
+    rng = np.random.default_rng(8)
+    smp = rng.uniform(-1, 1, 3000)
+    for voices in (32, 8, 5):
+        NS, N = 3, 1200
+        V = NS * voices
+        pitch = rng.integers(-24, 25, V).astype(np.float64)
+        gain = rng.uniform(0.2, 1.0, V)
+        par = np.stack([rng.uniform(0.001, 0.2, V), rng.uniform(0.99, 0.9999, V), rng.uniform(0.3, 1.0, V), rng.uniform(0.99, 0.9999, V)])
+        hold = rng.integers(1, 50, V)
+        trig = (rng.uniform(size=V) < 0.6).astype(np.int32)
+        for sustain in (1, 0):
+            a = port.sampler(voices, smp, N, pitch, gain, par, hold, np.zeros(V), trig, sustain)
+            b = ref.sampler(voices, smp, N, pitch, gain, par, hold, np.zeros(V), trig, sustain)
+            t2 = a[3].copy(); t2[::3] = 0; t2[1::7] = 1
+            a2 = port.sampler(voices, smp, N, pitch, gain, par, hold, a[2], t2, sustain, a[4], a[5], a[6])
+            b2 = ref.sampler(voices, smp, N, pitch, gain, par, hold, b[2], t2, sustain, b[4], b[5], b[6])
+            for u, w in zip(a + a2, b + b2):
+                assert_bits_equal(np.asarray(u, np.float64), np.asarray(w, np.float64))
