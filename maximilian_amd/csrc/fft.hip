@@ -244,10 +244,6 @@ __global__ void ifft_ola_kernel(const float *__restrict__ ifft_out, size_t nfram
     }
 }
 
-float *g_ifft_scratch = nullptr;
-size_t g_ifft_scratch_cap = 0;  // floats
-float *g_ifft_buf_tmp = nullptr;
-size_t g_ifft_buf_tmp_cap = 0;
 
 // ---- K6a: fftSize 1024 (half = 512 = 8^3) ------------------------------------------------------
 // LDS image of one frame: 512 float2 + 1 pad per 8 (index p = i + i/8): conflict-free for the
@@ -677,15 +673,7 @@ int mxg_ifft_batch(const mxg_ifft_plan *p, const float *d_mags, const float *d_p
     const int n = p->fftSize;
     float *io = d_ifft_out;
     if (!io) {  // grow-only scratch for the per-frame transforms
-        const size_t need = nframes * (size_t)n;
-        if (g_ifft_scratch_cap < need) {
-            if (g_ifft_scratch) MXG_HIP(hipFree(g_ifft_scratch));
-            g_ifft_scratch = nullptr;
-            g_ifft_scratch_cap = 0;
-            MXG_HIP(hipMalloc(&g_ifft_scratch, need * sizeof(float)));
-            g_ifft_scratch_cap = need;
-        }
-        io = g_ifft_scratch;
+        if (int s = scratch_get(SCR_IFFT_OUT, st, nframes * (size_t)n * sizeof(float), (void **)&io)) return s;
     }
     const size_t per_wave = sizeof(float2) * (size_t)(n + (n >> 5) + 1);
     int waves = n <= 1024 ? 4 : (n <= 2048 ? 2 : 1);
@@ -700,15 +688,10 @@ int mxg_ifft_batch(const mxg_ifft_plan *p, const float *d_mags, const float *d_p
     // overlap-add: the carried buffer is read while the new one is written -> stage the old one
     const float *buf_in = nullptr;
     if (d_buffer) {
-        if (g_ifft_buf_tmp_cap < (size_t)n) {
-            if (g_ifft_buf_tmp) MXG_HIP(hipFree(g_ifft_buf_tmp));
-            g_ifft_buf_tmp = nullptr;
-            g_ifft_buf_tmp_cap = 0;
-            MXG_HIP(hipMalloc(&g_ifft_buf_tmp, sizeof(float) * n));
-            g_ifft_buf_tmp_cap = (size_t)n;
-        }
-        MXG_HIP(hipMemcpyAsync(g_ifft_buf_tmp, d_buffer, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
-        buf_in = g_ifft_buf_tmp;
+        float *tmp = nullptr;
+        if (int s = scratch_get(SCR_IFFT_BUF, st, sizeof(float) * n, (void **)&tmp)) return s;
+        MXG_HIP(hipMemcpyAsync(tmp, d_buffer, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+        buf_in = tmp;
     }
     const size_t total = nframes * (size_t)p->hopSize + (size_t)n;
     hipLaunchKernelGGL(ifft_ola_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, io, nframes, n, p->hopSize,

@@ -918,9 +918,6 @@ __global__ void granular_unit_check_kernel(size_t S, const double *__restrict__ 
     if (bad) atomicMax(flag, 1);
 }
 
-int *g_err = nullptr;
-void *g_sched_scratch = nullptr;  // spawn lists + chunk table + copy of the carried-in grains, grow-only
-size_t g_sched_scratch_cap = 0;
 
 }  // namespace
 }  // namespace mxg
@@ -987,9 +984,8 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
     MXG_REQUIRE(len > 0 && overlaps > 0, "empty sample or overlaps <= 0");
     if (S == 0 || T == 0) return MXG_OK;
     hipStream_t st = resolve_stream(stream);
-    if (!g_err) {
-        MXG_HIP(hipMalloc(&g_err, 2 * sizeof(int)));
-    }
+    int *g_err = nullptr;  // per-stream error words
+    if (int s = scratch_get(SCR_GRAIN_ERR, st, 2 * sizeof(int), (void **)&g_err)) return s;
     MXG_HIP(hipMemsetAsync(g_err, 0, sizeof(int), st));
     GrainArgs A;
     A.S = S; A.T = T; A.len = len; A.R = R;
@@ -1040,13 +1036,8 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         const size_t nd = 2 * G * S + 4 * kSlots * S;         // doubles: spawn_pos | spawn_inc | gst copy
         const size_t ni = G * S + (C + 1) * S;                // int32: spawn_n | chunk_first
         const size_t bytes = nd * sizeof(double) + ni * sizeof(int32_t);
-        if (g_sched_scratch_cap < bytes) {
-            if (g_sched_scratch) MXG_HIP(hipFree(g_sched_scratch));
-            g_sched_scratch = nullptr;
-            g_sched_scratch_cap = 0;
-            MXG_HIP(hipMalloc(&g_sched_scratch, bytes));
-            g_sched_scratch_cap = bytes;
-        }
+        void *g_sched_scratch = nullptr;  // per-stream: spawn lists + chunk table + copy of the carried-in grains
+        if (int s = scratch_get(SCR_GRAIN_SCHED, st, bytes, &g_sched_scratch)) return s;
         double *spawn_pos = (double *)g_sched_scratch;
         double *spawn_inc = spawn_pos + G * S;
         double *gst_copy = spawn_inc + G * S;

@@ -119,19 +119,11 @@ __global__ __launch_bounds__(kMixThreads) void mix_bus_kernel(
     }
 }
 
-double *g_gains = nullptr;
-size_t g_gains_cap = 0;
-
 template <int C>
 int launch_bus(size_t V, size_t N, const double *d_in, const double *d_x, const double *d_y,
                const double *d_z, double *d_bus, double *d_mix, hipStream_t st) {
-    if (g_gains_cap < C * V) {  // grow-only scratch for the per-voice gains
-        if (g_gains) MXG_HIP(hipFree(g_gains));
-        g_gains = nullptr;
-        g_gains_cap = 0;
-        MXG_HIP(hipMalloc(&g_gains, sizeof(double) * C * (V ? V : 1)));
-        g_gains_cap = C * V;
-    }
+    double *g_gains = nullptr;  // per-stream scratch for the per-voice gains
+    if (int s = scratch_get(SCR_MIX_GAINS, st, sizeof(double) * C * (V ? V : 1), (void **)&g_gains)) return s;
     if (V)
         hipLaunchKernelGGL((bus_gains_kernel<C>), dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st,
                            V, d_x, d_y, d_z, g_gains);

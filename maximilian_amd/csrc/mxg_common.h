@@ -35,6 +35,12 @@ int ensure_init();
 hipStream_t resolve_stream(void *stream);
 int tune_get(const char *key);
 
+// Library-owned scratch, one grow-only buffer per (slot, stream): launches on different streams never share
+// (or resize) each other's temporaries; launches on one stream are ordered by the stream.  Returns MXG_OK and
+// a device pointer of at least `bytes`.
+enum ScratchSlot { SCR_MIX_GAINS, SCR_OSC_MIX, SCR_GRAIN_ERR, SCR_GRAIN_SCHED, SCR_IFFT_OUT, SCR_IFFT_BUF, SCR_SLOTS };
+int scratch_get(ScratchSlot slot, hipStream_t st, size_t bytes, void **out);
+
 #define MXG_HIP(call)                                         \
     do {                                                      \
         int _s = ::mxg::check_hip((call), #call);             \

@@ -391,8 +391,6 @@ osc_mix_fn pick_mix_wf(int wf, bool store) {
     }
     return nullptr;
 }
-double *g_mix_scratch = nullptr;  // [2][V] gains | [N][nwaves][2] partials, grow-only
-size_t g_mix_scratch_cap = 0;
 
 typedef void (*osc_fn)(size_t, size_t, const double *, const double *, const double *, double *,
                        double *, double *, double);
@@ -464,13 +462,8 @@ extern "C" int mxg_osc_render_mix(int waveform, size_t V, size_t N, const double
     const size_t nblocks = (V + block - 1) / block;
     const size_t nwaves = nblocks * (block / 64);
     const size_t need = 2 * V + N * nwaves * 2 + 2;
-    if (g_mix_scratch_cap < need) {
-        if (g_mix_scratch) MXG_HIP(hipFree(g_mix_scratch));
-        g_mix_scratch = nullptr;
-        g_mix_scratch_cap = 0;
-        MXG_HIP(hipMalloc(&g_mix_scratch, sizeof(double) * need));
-        g_mix_scratch_cap = need;
-    }
+    double *g_mix_scratch = nullptr;  // per-stream: [2][V] gains | [N][nwaves][2] partials
+    if (int s = scratch_get(SCR_OSC_MIX, st, sizeof(double) * need, (void **)&g_mix_scratch)) return s;
     double *gains = g_mix_scratch, *partial = g_mix_scratch + 2 * V;
     if (V) {
         hipLaunchKernelGGL(osc_pan_gains_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, d_pan, gains);

@@ -4,7 +4,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
 #include <mutex>
+#include <utility>
 
 #include "mxg_common.h"
 
@@ -58,6 +60,28 @@ int ensure_init() {
 }
 
 hipStream_t resolve_stream(void *stream) { return stream ? (hipStream_t)stream : g_stream; }
+
+namespace {
+struct ScratchBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+std::map<std::pair<int, hipStream_t>, ScratchBuf> g_scratch;
+}  // namespace
+
+int scratch_get(ScratchSlot slot, hipStream_t st, size_t bytes, void **out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    ScratchBuf &b = g_scratch[std::make_pair((int)slot, st)];
+    if (b.cap < bytes || !b.ptr) {
+        if (b.ptr) MXG_HIP(hipFree(b.ptr));  // hipFree waits for the work that may still use the old buffer
+        b.ptr = nullptr;
+        b.cap = 0;
+        MXG_HIP(hipMalloc(&b.ptr, bytes ? bytes : 8));
+        b.cap = bytes ? bytes : 8;
+    }
+    *out = b.ptr;
+    return MXG_OK;
+}
 
 int tune_get(const char *key) {
     for (auto &t : g_tune)
@@ -143,7 +167,19 @@ void *mxg_stream_create(void) {
     return (void *)s;
 }
 int mxg_stream_destroy(void *stream) {
-    if (stream) MXG_HIP(hipStreamDestroy((hipStream_t)stream));
+    if (!stream) return MXG_OK;
+    {   // drop the scratch buffers that belonged to this stream
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto it = g_scratch.begin(); it != g_scratch.end();) {
+            if (it->first.second == (hipStream_t)stream) {
+                if (it->second.ptr) (void)hipFree(it->second.ptr);
+                it = g_scratch.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+    MXG_HIP(hipStreamDestroy((hipStream_t)stream));
     return MXG_OK;
 }
 int mxg_stream_sync(void *stream) {

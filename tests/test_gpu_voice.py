@@ -247,3 +247,26 @@ def test_env_steady_state_paths_long_sequence(mx, port):
     assert_bits_equal(o, e, "adsr")
     assert_bits_equal(bank.dstate.numpy(), dst)
     assert np.array_equal(bank.istate.numpy(), ist)
+
+
+def test_mix_on_two_streams_does_not_share_scratch(mx):
+    """Library scratch (per-voice gains, partials ...) is per (slot, stream): two banks of different sizes
+    issuing back-to-back mixdowns on two streams must get the results they get alone."""
+    L = mx.lib()
+    s1, s2 = L.mxg_stream_create(), L.mxg_stream_create()
+    rng = np.random.default_rng(77)
+    Va, Vb, N = 40000, 9000, 64
+    xa, xb = rng.uniform(-1, 1, (N, Va)), rng.uniform(-1, 1, (N, Vb))
+    pa, pb = rng.uniform(0, 1, Va), rng.uniform(0, 1, Vb)
+    da, db = mx.DeviceBuffer.from_numpy(xa), mx.DeviceBuffer.from_numpy(xb)
+    ea = mx.maxiMixBank(Va).stereo(da, pa).numpy()
+    eb = mx.maxiMixBank(Vb).bus(8, db, pb, pb[::-1].copy(), pb * 0.5).numpy()
+    L.mxg_sync()
+    A, B = mx.maxiMixBank(Va, stream=s1), mx.maxiMixBank(Vb, stream=s2)
+    for _ in range(20):
+        oa = A.stereo(da, pa)
+        ob = B.bus(8, db, pb, pb[::-1].copy(), pb * 0.5)
+    L.mxg_stream_sync(s1); L.mxg_stream_sync(s2)
+    assert_bits_equal(oa.numpy(), ea, "stream 1")
+    assert_bits_equal(ob.numpy(), eb, "stream 2")
+    L.mxg_stream_destroy(s1); L.mxg_stream_destroy(s2)
