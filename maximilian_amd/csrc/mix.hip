@@ -59,63 +59,87 @@ __global__ void bus_gains_kernel(size_t V, const double *__restrict__ px,
 }
 
 // BUS: also write the per-voice bus signals bus[n][c][v] (what the reference leaves in
-// two/four/eight for voice v at sample n).
-template <int C, bool BUS>
+// two/four/eight for voice v at sample n).  R sample rows per workgroup share one read of the gains
+// (an L2 stream as large as the HBM stream for stereo); every row keeps its own accumulators and the
+// per-thread order v = t, t+1024, ... so the bits do not depend on R.
+template <int C, bool BUS, int R>
 __global__ __launch_bounds__(kMixThreads) void mix_bus_kernel(
-    size_t V, const double *__restrict__ in, const double *__restrict__ gains,
+    size_t V, size_t N, const double *__restrict__ in, const double *__restrict__ gains,
     double *__restrict__ bus, double *__restrict__ mix) {
-    __shared__ double s_red[C][kMixThreads / 64];
-    const size_t n = blockIdx.x;
-    const double *row = in + n * V;
-    double *brow = BUS ? bus + n * C * V : nullptr;
-    double acc[C];
+    __shared__ double s_red[R][C][kMixThreads / 64];
+    const size_t n0 = (size_t)blockIdx.x * R;
+    const double *row[R];
+    double *brow[R];
 #pragma unroll
-    for (int c = 0; c < C; c++) acc[c] = 0.0;
-    // U independent row loads in flight per thread; the accumulation order per thread stays
-    // v = t, t+1024, t+2048, ... so the result does not depend on the unrolling.
-    constexpr int U = (C == 2) ? 8 : (C == 4 ? 4 : 2);
+    for (int r = 0; r < R; r++) {
+        const size_t n = (n0 + r < N) ? n0 + r : N - 1;  // a surplus row re-reads the last one, never stored
+        row[r] = in + n * V;
+        brow[r] = BUS ? bus + n * C * V : nullptr;
+    }
+    double acc[R][C];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int c = 0; c < C; c++) acc[r][c] = 0.0;
+    constexpr int U = (C == 2) ? (R == 1 ? 8 : 4) : (C == 4 ? 4 / R + (R > 4) : 2 / R + (R > 1));
+    static_assert(U >= 1, "unroll");
     size_t v = threadIdx.x;
     for (; v + (U - 1) * kMixThreads < V; v += U * kMixThreads) {
-        double x[U], g[U][C];
+        double x[R][U], g[U][C];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            x[u] = row[v + u * kMixThreads];
+#pragma unroll
+            for (int r = 0; r < R; r++) x[r][u] = row[r][v + u * kMixThreads];
 #pragma unroll
             for (int c = 0; c < C; c++) g[u][c] = gains[(size_t)c * V + v + u * kMixThreads];
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
+        for (int r = 0; r < R; r++)
 #pragma unroll
-            for (int c = 0; c < C; c++) {
-                const double p = x[u] * g[u][c];
-                if constexpr (BUS) brow[(size_t)c * V + v + u * kMixThreads] = p;
-                acc[c] += p;
+            for (int u = 0; u < U; u++) {
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const double p = x[r][u] * g[u][c];
+                    if constexpr (BUS) {
+                        if (n0 + r < N) brow[r][(size_t)c * V + v + u * kMixThreads] = p;
+                    }
+                    acc[r][c] += p;
+                }
             }
-        }
     }
     for (; v < V; v += kMixThreads) {
-        const double x = row[v];
 #pragma unroll
-        for (int c = 0; c < C; c++) {
-            const double p = x * gains[(size_t)c * V + v];
-            if constexpr (BUS) brow[(size_t)c * V + v] = p;
-            acc[c] += p;
+        for (int r = 0; r < R; r++) {
+            const double x = row[r][v];
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const double p = x * gains[(size_t)c * V + v];
+                if constexpr (BUS) {
+                    if (n0 + r < N) brow[r][(size_t)c * V + v] = p;
+                }
+                acc[r][c] += p;
+            }
         }
     }
     // butterfly inside the wavefront (every lane ends with the same sum), then 16 wave sums
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int c = 0; c < C; c++) {
-        double s = acc[c];
+    for (int r = 0; r < R; r++)
 #pragma unroll
-        for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
-        if (lane == 0) s_red[c][wave] = s;
-    }
+        for (int c = 0; c < C; c++) {
+            double s = acc[r][c];
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+            if (lane == 0) s_red[r][c][wave] = s;
+        }
     __syncthreads();
-    if (threadIdx.x < C) {
-        double s = s_red[threadIdx.x][0];
-        for (int w = 1; w < kMixThreads / 64; w++) s += s_red[threadIdx.x][w];
-        mix[C * n + threadIdx.x] = s;
+    if (threadIdx.x < R * C) {
+        const int r = threadIdx.x / C, c = threadIdx.x % C;
+        if (n0 + r < N) {
+            double s = s_red[r][c][0];
+            for (int w = 1; w < kMixThreads / 64; w++) s += s_red[r][c][w];
+            mix[C * (n0 + r) + c] = s;
+        }
     }
 }
 
@@ -127,11 +151,15 @@ int launch_bus(size_t V, size_t N, const double *d_in, const double *d_x, const 
     if (V)
         hipLaunchKernelGGL((bus_gains_kernel<C>), dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st,
                            V, d_x, d_y, d_z, g_gains);
+    const int rows = tune_get("mix_rows");
     if (d_bus)
-        hipLaunchKernelGGL((mix_bus_kernel<C, true>), dim3((unsigned)N), dim3(kMixThreads), 0, st, V,
+        hipLaunchKernelGGL((mix_bus_kernel<C, true, 1>), dim3((unsigned)N), dim3(kMixThreads), 0, st, V, N,
                            d_in, g_gains, d_bus, d_mix);
+    else if (rows == 2 && C == 2)
+        hipLaunchKernelGGL((mix_bus_kernel<C, false, 2>), dim3((unsigned)((N + 1) / 2)), dim3(kMixThreads), 0, st, V,
+                           N, d_in, g_gains, d_bus, d_mix);
     else
-        hipLaunchKernelGGL((mix_bus_kernel<C, false>), dim3((unsigned)N), dim3(kMixThreads), 0, st, V,
+        hipLaunchKernelGGL((mix_bus_kernel<C, false, 1>), dim3((unsigned)N), dim3(kMixThreads), 0, st, V, N,
                            d_in, g_gains, d_bus, d_mix);
     return check_hip(hipGetLastError(), "mix_bus launch");
 }

@@ -29,6 +29,7 @@ Tune g_tune[] = {
     {"osc_vpl", 1, 1, 2},       {"osc_block", 256, 64, 1024},  {"osc_nt", 0, 0, 1},
     {"voice_vpl", 1, 1, 2},     {"voice_block", 256, 64, 1024}, {"voice_nt", 0, 0, 1},
     {"mix_block", 256, 64, 1024},
+    {"mix_rows", 2, 1, 2},  // K3: sample rows per workgroup sharing one read of the gains (stereo, no bus output)
     {"fft_generic", 0, 0, 1},  // 1: force the generic per-stage FFT kernel also for fftSize 1024
     {"grain_chunked", 1, 0, 1},  // 0: serial-in-time K8 instead of the time-sharded K8a+K8b
     {"grain_lanes_k", 128, 16, 4096},  // K8b: target number of (stream, chunk) lanes, in units of 1024

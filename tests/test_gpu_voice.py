@@ -270,3 +270,21 @@ def test_mix_on_two_streams_does_not_share_scratch(mx):
     assert_bits_equal(oa.numpy(), ea, "stream 1")
     assert_bits_equal(ob.numpy(), eb, "stream 2")
     L.mxg_stream_destroy(s1); L.mxg_stream_destroy(s2)
+
+
+def test_mix_rows_per_workgroup_same_bits(mx):
+    """K3 with 1 or 2 sample rows per workgroup: same per-thread accumulation order, same reduction => same bits
+    (odd row counts exercise the surplus-row path)."""
+    L = mx.lib()
+    rng = np.random.default_rng(3)
+    V, N = 12345, 33
+    x = mx.DeviceBuffer.from_numpy(rng.uniform(-1, 1, (N, V)))
+    pan = rng.uniform(0, 1, V)
+    res = []
+    for rows in (1, 2):
+        prev = L.mxg_tune(b"mix_rows", rows)
+        try:
+            res.append(mx.maxiMixBank(V).stereo(x, pan).numpy())
+        finally:
+            L.mxg_tune(b"mix_rows", prev)
+    assert_bits_equal(res[0], res[1], "rows 1 vs 2")
