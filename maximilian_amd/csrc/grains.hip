@@ -779,9 +779,29 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
                 }
             }
             const int first = A.chunk_first[c * S + s], next = A.chunk_first[(c + 1) * S + s];
-            int j0 = first;
-            while (j0 > 0 && (long long)A.spawn_n[(size_t)(j0 - 1) * S + s] + A.sampleDur > (long long)n0) j0--;
-            for (int j = j0; j < next; j++) {
+            // spawns of earlier tiles still alive at n0: births increase, so the live ones are a suffix of
+            // [0, first) and at most kSlots long.  Their births/positions are fetched with independent
+            // loads (a walk-back loop would chain one dependent load per grain) and filtered afterwards.
+            int bornB[kSlots];
+            double posB[kSlots];
+#pragma unroll
+            for (int u = 0; u < kSlots; u++) {
+                const int j = first - kSlots + u;
+                const int jc = j < 0 ? 0 : j;
+                bornB[u] = A.spawn_n[(size_t)jc * S + s];
+                posB[u] = A.spawn_pos[(size_t)jc * S + s];
+            }
+#pragma unroll
+            for (int u = 0; u < kSlots; u++) {
+                const int j = first - kSlots + u;
+                if (j >= 0 && (long long)bornB[u] + A.sampleDur > (long long)n0) {
+                    if (cnt >= kCand) { atomicMax(A.err, 1); break; }
+                    add(bornB[u], A.sampleDur, (long long)posB[u], sgn);
+                }
+            }
+            if (first > kSlots && (long long)A.spawn_n[(size_t)(first - kSlots - 1) * S + s] + A.sampleDur > (long long)n0)
+                atomicMax(A.err, 1);  // more than kSlots earlier spawns alive: the capacity rule of every kernel
+            for (int j = first; j < next; j++) {
                 if (cnt >= kCand) {
                     atomicMax(A.err, 1);
                     break;
