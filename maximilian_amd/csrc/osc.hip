@@ -206,7 +206,10 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
     }
     double *o = out + v0;
     const double *fp = freq + v0;
-#pragma unroll 4
+#ifndef MXG_OSC_UNROLL
+#define MXG_OSC_UNROLL 4
+#endif
+#pragma unroll MXG_OSC_UNROLL
     for (size_t n = 0; n < N; n++) {
         double r[VPL];
 #pragma unroll
