@@ -164,6 +164,55 @@ __global__ void __launch_bounds__(256) sample_kernel(SmpArgs A) {
     constexpr bool xmod = XMOD;  // per-sample speed input
     const size_t nfull = N / U;
 
+    if constexpr (MODE == 0) {
+        // play() (C:740-747) with no wrap inside this block for any line of the wavefront: the head just walks
+        // pos, pos+1, ..., so a line's 8 samples of a chunk are 64 contiguous bytes.  Four 16-B loads per chunk
+        // (instead of eight 8-B gathers) request every cache line once instead of relying on the 32 KB L1 to
+        // keep 64 lines per wavefront alive between samples.  Same values, same head afterwards.
+        const long long p0 = (long long)s.pos;
+        const bool straight = (double)p0 == s.pos && p0 >= 0 && (size_t)p0 + N + 1 < A.len;
+        if (nfull > 0 && __all(straight)) {
+            const double *src = amp + p0;
+            double2v a0[4], a1[4];
+            auto request = [&](size_t k, double2v(&d)[4]) {
+                const size_t kk = (k < nfull) ? k : nfull - 1;  // clamped: the run-ahead re-reads the last chunk
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const double *q = src + kk * U + 2 * j;  // 8-B aligned only: two 8-B halves of one 16-B request
+                    d[j] = *reinterpret_cast<const double2v *>(q);
+                }
+            };
+            auto retire = [&](double2v(&d)[4]) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    *op = d[j].x;
+                    op += V;
+                    *op = d[j].y;
+                    op += V;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            request(0, a0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) asm volatile("" : "+v"(a0[j]));
+            size_t k = 0;
+            for (; k + 1 < nfull; k += 2) {
+                request(k + 1, a1);
+                retire(a0);
+                request(k + 2, a0);
+                retire(a1);
+            }
+            if (k < nfull) retire(a0);
+            s.pos = s.pos + (double)(nfull * U);  // exact: integers below 2^53, one addition per sample in the reference
+            for (size_t n = nfull * U; n < N; n++) {
+                *op = amp[(long long)s.pos];
+                op += V;
+                s.pos += 1.0;
+            }
+            A.position[v] = s.pos;
+            return;
+        }
+    }
     if (nfull > 0) {
         // Two register sets used alternately (the loop is unrolled by two) so that no loaded value
         // is ever copied: a copy would be a use, and a use is a wait.  x and trig are requested

@@ -30,4 +30,6 @@ db = mx.maxiDelaylineBank(V, 2048)
 print("delay dl size 1024      %.1f us  (32 B/sample)" % timed(lambda: db.dl(x, 1024, 0.5, out=out)))
 sb = mx.maxiSampleBank(V); sb.setSample(rng.uniform(-1, 1, 441000)); sb.setPosition(v / V)
 print("sample playAtSpeed      %.1f us" % timed(lambda: sb.playAtSpeed(0.5 + (v % 97) / 96.0, B, out=out)))
-print("sample play             %.1f us" % timed(lambda: sb.play(B, out=out)))
+print("sample play             %.1f us  (fractional heads left by playAtSpeed: per-sample gathers)" % timed(lambda: sb.play(B, out=out)))
+sb.position.upload(np.floor(v / V * 441000.0))
+print("sample play (int heads) %.1f us  (heads on integer positions, as after trigger()/load(): 16-B row loads)" % timed(lambda: sb.play(B, out=out)))
