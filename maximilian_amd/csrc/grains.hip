@@ -448,7 +448,14 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
     // derived from the spawn list afterwards).  thr = cycleLength + randomOffset changes only at a spawn.
     q.thr = A.cycleLength + q.randomOffset;
     const int Tn = (int)A.T;
+    // chunk_first[c] = number of spawns before sample c*Tc.  Spawns arrive in increasing n, so the table is
+    // filled as they are recorded -- stores only (a pass over the finished list would chain one dependent
+    // global load per chunk: 1100 chunks x ~0.5 us was most of this kernel's time).
+    size_t cnext = 0;
     auto record = [&](int n, double pos0, double inc) {
+        const int stored = (size_t)count < A.G ? count : (int)A.G;
+        const size_t clast = (size_t)n / A.Tc;  // chunks starting at or before n do not contain this spawn's predecessors only
+        for (; cnext <= clast && cnext <= A.C; cnext++) A.chunk_first[cnext * S + s] = stored;
         if ((size_t)count < A.G) {
             A.spawn_n[(size_t)count * S + s] = n;
             A.spawn_pos[(size_t)count * S + s] = pos0;
@@ -488,14 +495,9 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
         double pos0, inc;
         if (sched_step<MODE>(q, sc, (size_t)n, pos0, inc, failed)) record(n, pos0, inc);
     }
-    {   // chunk_first[c] = number of spawns before sample c*Tc (spawn_n is increasing)
+    {   // chunks after the last spawn
         const int stored = (size_t)count < A.G ? count : (int)A.G;
-        int j = 0;
-        for (size_t c = 0; c <= A.C; c++) {
-            const long long lim = (long long)(c * A.Tc);
-            while (j < stored && (long long)A.spawn_n[(size_t)j * S + s] < lim) j++;
-            A.chunk_first[c * S + s] = j;
-        }
+        for (; cnext <= A.C; cnext++) A.chunk_first[cnext * S + s] = stored;
     }
     if (failed) atomicMax(A.err, failed);
     A.st[s] = q.position;
@@ -829,21 +831,29 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
         int alive[kUnitGroup];
 #pragma unroll
         for (int g = 0; g < kUnitGroup; g++) { total[g] = 0.0; alive[g] = 0; }
+        // lane q (< kCand) fetches candidate q's metadata once; readlane turns it into scalars per grain
+        int mk0[kUnitGroup], mdur[kUnitGroup], mbase[kUnitGroup], msgn[kUnitGroup];
+#pragma unroll
+        for (int g = 0; g < kUnitGroup; g++) {
+            const int at = (sg + g) * kCand + (lane & (kCand - 1));
+            mk0[g] = s_k0[at]; mdur[g] = s_dur[at]; mbase[g] = s_base[at]; msgn[g] = s_sgn[at];
+        }
         for (int q0 = 0; q0 < cmax; q0 += 8) {
             double va[kUnitGroup][8], vb[kUnitGroup][8], ve[kUnitGroup][8];
             bool ok[kUnitGroup][8];
 #pragma unroll
             for (int g = 0; g < kUnitGroup; g++) {
-                const int si = sg + g;
 #pragma unroll
                 for (int u = 0; u < 8; u++) {  // issue the reads of up to 8 grains of every stream of the group
                     const int q = q0 + u;
                     ok[g][u] = false;
                     va[g][u] = vb[g][u] = ve[g][u] = 0.0;
                     if (q < cnt[g]) {  // wave-uniform
-                        const int k = s_k0[si * kCand + q] + lane;
-                        ok[g][u] = inT && k >= 0 && k < s_dur[si * kCand + q];
-                        int ia = s_base[si * kCand + q] + lane * s_sgn[si * kCand + q];  // |lane*sgn| < 64 <= len
+                        const int gk0 = __builtin_amdgcn_readlane(mk0[g], q), gdur = __builtin_amdgcn_readlane(mdur[g], q);
+                        const int gbase = __builtin_amdgcn_readlane(mbase[g], q), gsgn = __builtin_amdgcn_readlane(msgn[g], q);
+                        const int k = gk0 + lane;
+                        ok[g][u] = inT && k >= 0 && k < gdur;
+                        int ia = gbase + lane * gsgn;  // |lane*sgn| < 64 <= len
                         if (ia >= ilen) ia -= ilen;
                         if (ia < 0) ia += ilen;
                         int ib = ia + 1;
