@@ -179,3 +179,48 @@ def test_noise_from_rand_draws(mx, port):
     o = mx.maxiOscBank(8).noise(edge).numpy()
     r = (edge.astype(np.float32) / np.float32(2147483648.0))
     assert_bits_equal(o, (r * np.float32(2) - np.float32(1)).astype(np.float64), "noise edges")
+
+
+def test_render_and_mixdown_are_graph_capturable(mx):
+    """The per-block launch sequence (K1 render + K3 mixdown: gains kernel, mix kernel) makes no synchronising or
+    allocating HIP call in steady state, so it can be captured into a hipGraph on the caller's stream and
+    replayed; K replays must leave the same state and mix as K eager launches."""
+    import torch
+    L = mx.lib()
+    V, B, K = 4096, 128, 5
+    dev = torch.device("cuda", 0)
+    freq = torch.from_numpy(20 + np.arange(V) * 4.8828125).to(dev)
+    pan = torch.from_numpy(np.arange(V) / (V - 1.0)).to(dev)
+
+    def fresh():
+        return (torch.zeros(V, dtype=torch.float64, device=dev), torch.zeros(V, dtype=torch.float64, device=dev),
+                torch.empty((B, V), dtype=torch.float64, device=dev), torch.zeros((B, 2), dtype=torch.float64, device=dev))
+
+    def block(st, phase, hold, out, mix):
+        assert L.mxg_osc_render(8, V, B, freq.data_ptr(), 0, None, None, phase.data_ptr(), hold.data_ptr(),
+                                out.data_ptr(), st) == 0
+        assert L.mxg_mix_stereo(V, B, out.data_ptr(), pan.data_ptr(), mix.data_ptr(), st) == 0
+
+    s = torch.cuda.Stream(device=dev)
+    st = s.cuda_stream
+    # eager reference: K blocks
+    e = fresh()
+    with torch.cuda.stream(s):
+        for _ in range(K):
+            block(st, *e)
+    s.synchronize()
+    # captured: one warm-up block on scratch state (allocates the library scratch for this stream), then capture
+    g_state = fresh()
+    warm = fresh()
+    with torch.cuda.stream(s):
+        block(st, *warm)
+    s.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        block(st, *g_state)
+    for _ in range(K):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(g_state[0], e[0]), "phase after K replays"
+    assert torch.equal(g_state[2], e[2]), "last block"
+    assert torch.equal(g_state[3], e[3]), "last mix"
