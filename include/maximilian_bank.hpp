@@ -58,7 +58,10 @@ public:
     void upload(const T *h, size_t n, size_t offset = 0) {
         check(mxg_memcpy_h2d(p_ + offset, h, n * sizeof(T), nullptr), "mxg_memcpy_h2d");
     }
-    void upload(const std::vector<T> &h) { upload(h.data(), h.size()); }
+    void upload(const std::vector<T> &h) {
+        if (h.size() > n_) resize(h.size(), false);  // an array that was never sized grows to fit
+        upload(h.data(), h.size());
+    }
     void download(T *h, size_t n, size_t offset = 0) const {
         check(mxg_memcpy_d2h(h, p_ + offset, n * sizeof(T), nullptr), "mxg_memcpy_d2h");
     }
@@ -319,6 +322,7 @@ public:
         std::vector<double> st(6 * times.size());
         const int n = mxg_envgen_stages_host(levels.size(), levels.data(), times.data(), curves.data(), st.data());
         if (n < 0) return false;
+        stages_.resize(st.size(), false);
         stages_.upload(st);
         nstages_ = n; loop_ = looping; retrigger_ = allowRetrigger;
         arm();

@@ -33,3 +33,55 @@ def test_polysynth_host_matches_oracle(mx, port, tmp_path):
     pan = v / (V - 1.0)
     exp = port.mix_stereo(voices, pan)
     assert_bits_equal(got, exp, "polysynth host (per-sample facade, host-side voice sum)")
+
+
+def test_facade_smoke_matches_python_mirror(mx, tmp_path):
+    """host/facade_smoke.cpp drives the newer C++ facade classes; the Python mirror makes the same C-ABI calls
+    on inputs rebuilt with the same exact arithmetic, so every dumped block must be byte-identical."""
+    exe = os.path.join(ROOT, "host", "facade_smoke")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")])
+    wav = os.path.join(ROOT, "tests", "golden", "wav", "mono.wav")
+    r = subprocess.run([exe, wav, str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rd = lambda name, dt=np.float64: np.fromfile(tmp_path / (name + ".bin"), dt)
+    mx.maxiSettings.setup(44100, 2, 512)
+    try:
+        V, N = 96, 300
+        i = np.arange(N * V)
+        x = (((i * 37) % 1000) / 1000.0 - 0.5) * 1.6
+        v = np.arange(V)
+        cutoff, q, gain, R = 100.0 + 37.0 * v, 0.5 + 0.05 * v, -12.0 + 0.25 * v, 0.99 + 0.0001 * v
+        px = v / (V - 1)
+        py = 1.0 - px * 0.5
+        dx = mx.DeviceBuffer.from_numpy(x.reshape(N, V))
+        svf = mx.maxiSVFBank(V); svf.setCutoff(cutoff); svf.setResonance(q)
+        assert_bits_equal(svf.play(dx, 0.5, 0.25, 0.125, 1.0).numpy().ravel(), rd("svf"), "svf")
+        bq = mx.maxiBiquadBank(V); bq.set(bq.PEAK, cutoff, q, gain)
+        assert_bits_equal(bq.play(dx).numpy().ravel(), rd("biquad"), "biquad")
+        assert_bits_equal(mx.maxiDCBlockerBank(V).play(dx, R).numpy().ravel(), rd("dcblock"), "dcblock")
+        eg = mx.maxiEnvGenBank(V); eg.setupADSR(2, 3, 0.5, 4)
+        gate = np.where(np.arange(N) % 200 < 120, 1.0, -1.0)
+        assert_bits_equal(eg.play(gate).numpy().ravel(), rd("envgen"), "envgen")
+        assert_bits_equal(mx.maxiMixBank(V).quad(dx, px, py).numpy().ravel(), rd("quad"), "quad")
+        sb = mx.maxiSampleBank(V)
+        assert sb.load(wav)
+        n = np.arange(N)[:, None]
+        trig = ((n * 3 + v[None, :] * 7) % 64) / 32.0 - 1.0
+        assert_bits_equal(sb.playOnZX(trig).numpy().ravel(), rd("playonzx"), "playOnZX")
+        fs, hop, nfr = 256, 64, 40
+        k = np.arange(fs + hop * (nfr - 1))
+        sig = (((k * 29) % 200) / 200.0 - 0.5).astype(np.float32)
+        f = mx.maxiFFT(); f.setup(fs, hop, fs)
+        f.process_frames(mx.DeviceBuffer.from_numpy(sig), hop, nfr)
+        assert np.array_equal(f.getMagnitudes().numpy().ravel().view(np.uint32), rd("mags", np.float32).view(np.uint32))
+        assert np.array_equal(f.spectralCentroid().numpy().view(np.uint32), rd("centroid", np.float32).view(np.uint32))
+        inv = mx.maxiIFFT(); inv.setup(fs, hop, fs)
+        y = inv.process_frames(f.getMagnitudes(), f.getPhases()).numpy()
+        assert np.array_equal(y.view(np.uint32), rd("resynth", np.float32).view(np.uint32))
+        one = mx.maxiSampleBank(1)
+        assert one.load(wav)
+        ps = mx.maxiPitchShiftBank(32, one, "hann")
+        assert_bits_equal(ps.play(0.5 + 0.05 * np.arange(32), 0.01, 3, 1500).numpy().ravel(), rd("pitchshift"), "pitchshift")
+    finally:
+        mx.maxiSettings.setup(44100, 2, 1024)
