@@ -44,7 +44,10 @@ __device__ __forceinline__ bool on_zx(double &prev, bool &first, double input) {
 }
 
 template <bool TPV>
-__global__ void __launch_bounds__(256) envgen_kernel(EgArgs A) {
+// trig / out are separate __restrict__ parameters (not members of A): only then may hipcc read the shared gate
+// with scalar loads; as vector loads they sit in the same in-order queue as the output stores and drain it.
+__global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__restrict__ trig_in,
+                                                      double *__restrict__ out_ptr) {
     __shared__ double s_tab[kMaxStages * 6];
     for (int i = threadIdx.x; i < A.nstages * 6; i += blockDim.x) s_tab[i] = A.stages[i];
     __syncthreads();
@@ -60,8 +63,8 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A) {
     bool tfirst = A.ist[4 * V + v] != 0, hfirst = A.ist[5 * V + v] != 0, rfirst = A.ist[6 * V + v] != 0;
     const long long S = A.nstages;
     const bool loop = A.loop != 0, retrigger = A.retrigger != 0;
-    const double *tp = TPV ? A.trig + v : A.trig;
-    double *op = A.out + v;
+    const double *__restrict__ tp = TPV ? trig_in + v : trig_in;
+    double *__restrict__ op = out_ptr + v;
     constexpr int U = 8;
     double tn[U];
 #pragma unroll
@@ -76,6 +79,32 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A) {
             tc[i] = tn[i];
             const size_t m = (n0 + U + i < N) ? n0 + U + i : N - 1;  // clamped prefetch, a chunk ahead of the stores
             tn[i] = TPV ? tp[m * V] : tp[m];
+        }
+        // Two steady states in which nothing but a detector's previousValue moves and envval is simply repeated:
+        // HOLDING while the trigger stays positive (no negative zero crossing, H:2334-2341) and WAITING while it
+        // stays <= 0 (no trigger, H:2281).  With a shared gate the test is scalar work plus one ballot per chunk.
+        if constexpr (!TPV) {
+            if (n0 + U <= N) {
+                bool allpos = true, allnonpos = true;
+#pragma unroll
+                for (int i = 0; i < U; i++) {
+                    allpos = allpos && tc[i] > 0;
+                    allnonpos = allnonpos && !(tc[i] > 0);
+                }
+                int fast = 0;
+                if (allpos && !retrigger && __all(state == HOLDING && !nxc)) fast = 1;
+                else if (allnonpos && __all(state == WAITING)) fast = 2;
+                if (fast) {
+#pragma unroll
+                    for (int i = 0; i < U; i++) {
+                        *op = envval;
+                        op += V;
+                    }
+                    if (fast == 1) { hprev = -tc[U - 1]; hfirst = false; }  // holdDetector.onZX(-trigger), no crossing
+                    else { tprev = tc[U - 1]; tfirst = false; }            // trigDetector.onZX(trigger), no crossing
+                    continue;
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < U; i++) {
@@ -196,9 +225,9 @@ int mxg_envgen_render(size_t V, size_t N, const double *d_trig, int tpv, const d
     const EgArgs A = {V, N, d_trig, tpv, nstages, loop, retrigger, d_stages, d_dst, d_ist, d_out};
     const dim3 grid((unsigned)((V + block - 1) / block));
     if (tpv)
-        hipLaunchKernelGGL((envgen_kernel<true>), grid, dim3(block), 0, resolve_stream(stream), A);
+        hipLaunchKernelGGL((envgen_kernel<true>), grid, dim3(block), 0, resolve_stream(stream), A, d_trig, d_out);
     else
-        hipLaunchKernelGGL((envgen_kernel<false>), grid, dim3(block), 0, resolve_stream(stream), A);
+        hipLaunchKernelGGL((envgen_kernel<false>), grid, dim3(block), 0, resolve_stream(stream), A, d_trig, d_out);
     return check_hip(hipGetLastError(), "envgen_kernel launch");
 }
 

@@ -62,7 +62,11 @@ line("env adsr (sustain)", timed(lambda: env_call(hold)), 16, "(gate held: stead
 # maxiEnvGen, shared gate
 eg = mx.maxiEnvGenBank(V); eg.setupADSR(10, 100, 0.5, 500)
 gate = D(np.where((np.arange(B) % 300) < 150, 1.0, -1.0))
-line("maxiEnvGen ADSR", timed(lambda: L.mxg_envgen_render(V, B, gate.ptr, 0, eg.stages.ptr, 4, 0, 0, eg.dstate.ptr, eg.istate.ptr, out.ptr, None)), 8)
+eg_call = lambda g: L.mxg_envgen_render(V, B, g.ptr, 0, eg.stages.ptr, 4, 0, 0, eg.dstate.ptr, eg.istate.ptr, out.ptr, None)
+line("maxiEnvGen ADSR (150/150)", timed(lambda: eg_call(gate)), 8, "(gate toggling every 150 samples: stage machine + ramps)")
+held = D(np.ones(B))
+for _ in range(200): eg_call(held)   # finish the release, re-arm, attack + decay: every envelope ends in HOLD
+line("maxiEnvGen ADSR (holding)", timed(lambda: eg_call(held)), 8, "(gate held, every envelope in its HOLD stage: steady-state path)")
 
 # maxiDelayline
 db = mx.maxiDelaylineBank(V, 2048)
