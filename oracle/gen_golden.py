@@ -393,9 +393,65 @@ def main():
     save("ifft.npz", **d)
     files["ifft.npz"] = "maxiIFFT 1024/512, 1024/256/1024, 64/16/48: signal, per-frame ifftOut, final overlap-add buffer"
 
+    # ---- maxiDCBlocker / maxiSVF / maxiBiquad / maxiEnvGen / maxiSampler -----------------------------------
+    rng = np.random.default_rng(SEED + 12)
+    d = {}
+    V, N = 21, 240
+    x = rng.uniform(-1, 1, (N, V))
+    d["f2_x"] = x
+    par = rng.uniform(0.9, 0.9999, (1, V))
+    o1, st, _ = R.filter2(0, x[:100], par)
+    o2, st, _ = R.filter2(0, x[100:], par, st)
+    d["dc_par"], d["dc_out"], d["dc_st"] = par, np.concatenate([o1, o2]), st
+    par = np.stack([rng.uniform(20, 20000, V), rng.uniform(0, 12, V), *rng.uniform(0, 1, (4, V))])
+    par[1, :2] = 0
+    o1, st, c = R.filter2(1, x[:100], par)
+    o2, st, c = R.filter2(1, x[100:], par, st)
+    d["svf_par"], d["svf_out"], d["svf_st"], d["svf_coef"] = par, np.concatenate([o1, o2]), st, c
+    for t in range(7):
+        par = np.stack([np.full(V, float(t)), rng.uniform(30, 18000, V), rng.uniform(0.3, 8, V), rng.uniform(-18, 18, V)])
+        o1, st, c = R.filter2(2, x[:100], par)
+        o2, st, c = R.filter2(2, x[100:], par, st)
+        d["bq_par_%d" % t], d["bq_out_%d" % t], d["bq_st_%d" % t], d["bq_coef_%d" % t] = par, np.concatenate([o1, o2]), st, c
+    H = R.ENVGEN_HOLD
+    N = 3000
+    n = np.arange(N)[:, None]
+    trig = np.sign(np.sin(n * rng.uniform(0.002, 0.01, V)[None, :] + rng.uniform(0, 6, V)))
+    trig[:, 3] = 1.0
+    trig[:, 4] = (np.arange(N) % 700 < 5) * 1.0
+    d["eg_trig"] = trig
+    shapes = {"ar": ([0, 1, 0], [10, 40], [1, 1]), "adsr": ([0, 1, 0.4, 0.4, 0], [3, 12, H, 25], [1, 1, 1, 1]),
+              "curved": ([0, 1, 0.2, 0], [7.3, 11.1, 20.7], [0.5, 2, 3])}
+    for name, (lv, tm, cv) in shapes.items():
+        for loop, retrig in ((0, 0), (1, 1)):
+            o1, ds, is_, stg = R.envgen(trig[:1400], lv, tm, cv, loop, retrig)
+            o2, ds, is_, _ = R.envgen(trig[1400:], lv, tm, cv, loop, retrig, dst=ds, ist=is_)
+            tag = "%s_%d%d" % (name, loop, retrig)
+            d["eg_out_" + tag], d["eg_dst_" + tag], d["eg_ist_" + tag] = np.concatenate([o1, o2]), ds, is_
+        d["eg_levels_" + name], d["eg_times_" + name], d["eg_curves_" + name] = np.array(lv, float), np.array(tm, float), np.array(cv, float)
+        d["eg_stages_" + name] = stg
+    voices, NS, N = 8, 3, 900
+    Vs = voices * NS
+    ssmp = rng.uniform(-1, 1, 3000)
+    d["smp_samples"], d["smp_pitch"], d["smp_gain"] = ssmp, rng.integers(-24, 25, Vs).astype(np.float64), rng.uniform(0.2, 1.0, Vs)
+    d["smp_par"] = np.stack([rng.uniform(0.001, 0.2, Vs), rng.uniform(0.99, 0.9999, Vs), rng.uniform(0.3, 1.0, Vs), rng.uniform(0.99, 0.9999, Vs)])
+    d["smp_hold"] = rng.integers(1, 50, Vs)
+    d["smp_trig0"] = (rng.uniform(size=Vs) < 0.6).astype(np.int32)
+    for sustain in (1, 0):
+        a = R.sampler(voices, ssmp, N, d["smp_pitch"], d["smp_gain"], d["smp_par"], d["smp_hold"], np.zeros(Vs), d["smp_trig0"], sustain)
+        t2 = a[3].copy()
+        t2[::3] = 0
+        t2[1::7] = 1
+        b = R.sampler(voices, ssmp, N, d["smp_pitch"], d["smp_gain"], d["smp_par"], d["smp_hold"], a[2], t2, sustain, a[4], a[5], a[6])
+        for k, nm in enumerate(["mix", "outputs", "position", "trigger", "outhold", "dst", "ist"]):
+            d["smp_%s_a%d" % (nm, sustain)], d["smp_%s_b%d" % (nm, sustain)] = a[k], b[k]
+    save("extra2.npz", **d)
+    files["extra2.npz"] = ("maxiDCBlocker, maxiSVF, maxiBiquad x7 types (outputs, state, coefficients), maxiEnvGen AR/ADSR/curved x "
+                           "loop/retrigger (outputs, detector + stage state, stage tables), maxiSampler 3x8 slots with note-offs")
+
     sha = hashlib.sha256()
     for f in ("maximilian.cpp", "maximilian.h", "libs/fft.cpp", "libs/maxiFFT.cpp", "libs/maxiMFCC.cpp",
-              "libs/maxiMFCC.h", "libs/maxiGrains.h"):
+              "libs/maxiMFCC.h", "libs/maxiGrains.h", "libs/maxiSynths.cpp", "libs/maxiSynths.h"):
         sha.update(open(os.path.join(REF_SRC, f), "rb").read())
     manifest = {
         "generator": "oracle/gen_golden.py",

@@ -184,3 +184,51 @@ def test_sampler_port_vs_reference(port, ref):
             b2 = ref.sampler(voices, smp, N, pitch, gain, par, hold, b[2], t2, sustain, b[4], b[5], b[6])
             for u, w in zip(a + a2, b + b2):
                 assert_bits_equal(np.asarray(u, np.float64), np.asarray(w, np.float64))
+
+
+def test_extra2_golden_filters(port, golden):
+    g = golden("extra2.npz")
+    x = g["f2_x"]
+    o1, st, _ = port.filter2(0, x[:100], g["dc_par"])
+    o2, st, _ = port.filter2(0, x[100:], g["dc_par"], st)
+    assert_bits_equal(np.concatenate([o1, o2]), g["dc_out"], "dcblocker")
+    assert_bits_equal(st, g["dc_st"])
+    o1, st, c = port.filter2(1, x[:100], g["svf_par"])
+    o2, st, c = port.filter2(1, x[100:], g["svf_par"], st)
+    assert_bits_equal(np.concatenate([o1, o2]), g["svf_out"], "svf")
+    assert_bits_equal(st, g["svf_st"])
+    assert_bits_equal(c, g["svf_coef"], "svf coefficients")
+    for t in range(7):
+        o1, st, c = port.filter2(2, x[:100], g["bq_par_%d" % t])
+        o2, st, c = port.filter2(2, x[100:], g["bq_par_%d" % t], st)
+        assert_bits_equal(np.concatenate([o1, o2]), g["bq_out_%d" % t], "biquad %d" % t)
+        assert_bits_equal(st, g["bq_st_%d" % t])
+        assert_bits_equal(c, g["bq_coef_%d" % t], "biquad coefficients %d" % t)
+
+
+@pytest.mark.parametrize("name", ["ar", "adsr", "curved"])
+def test_extra2_golden_envgen(port, golden, name):
+    g = golden("extra2.npz")
+    trig = g["eg_trig"]
+    lv, tm, cv = g["eg_levels_" + name], g["eg_times_" + name], g["eg_curves_" + name]
+    for loop, retrig in ((0, 0), (1, 1)):
+        o1, ds, is_, stg = port.envgen(trig[:1400], lv, tm, cv, loop, retrig)
+        o2, ds, is_, _ = port.envgen(trig[1400:], lv, tm, cv, loop, retrig, dst=ds, ist=is_)
+        tag = "%s_%d%d" % (name, loop, retrig)
+        assert_bits_equal(np.concatenate([o1, o2]), g["eg_out_" + tag], tag)
+        assert_bits_equal(ds, g["eg_dst_" + tag])
+        assert np.array_equal(is_, g["eg_ist_" + tag])
+    assert_bits_equal(stg, g["eg_stages_" + name], "stage table")
+
+
+@pytest.mark.parametrize("sustain", [1, 0])
+def test_extra2_golden_sampler(port, golden, sustain):
+    g = golden("extra2.npz")
+    V = g["smp_pitch"].size
+    args = (8, g["smp_samples"], 900, g["smp_pitch"], g["smp_gain"], g["smp_par"], g["smp_hold"])
+    a = port.sampler(*args, np.zeros(V), g["smp_trig0"], sustain)
+    t2 = a[3].copy(); t2[::3] = 0; t2[1::7] = 1
+    b = port.sampler(*args, a[2], t2, sustain, a[4], a[5], a[6])
+    for k, nm in enumerate(["mix", "outputs", "position", "trigger", "outhold", "dst", "ist"]):
+        assert_bits_equal(np.asarray(a[k], np.float64), np.asarray(g["smp_%s_a%d" % (nm, sustain)], np.float64), nm + " a")
+        assert_bits_equal(np.asarray(b[k], np.float64), np.asarray(g["smp_%s_b%d" % (nm, sustain)], np.float64), nm + " b")

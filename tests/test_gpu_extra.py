@@ -98,3 +98,75 @@ def test_play_at_position_and_pitch_shift_golden(mx, golden, chunked):
         assert_bits_equal(ps.grains.numpy(), g["ps_gst"])
     finally:
         mx.lib().mxg_tune(b"grain_chunked", prev)
+
+
+def test_extra2_golden_filters(mx, golden):
+    """maxiDCBlocker / maxiSVF / maxiBiquad against the reference's own values (tests/golden/extra2.npz)."""
+    g = golden("extra2.npz")
+    x = g["f2_x"]
+    V = x.shape[1]
+    d = lambda a: mx.DeviceBuffer.from_numpy(np.ascontiguousarray(a))
+    dc = mx.maxiDCBlockerBank(V)
+    o = np.concatenate([dc.play(d(x[:100]), g["dc_par"][0]).numpy(), dc.play(d(x[100:]), g["dc_par"][0]).numpy()])
+    assert_bits_equal(o, g["dc_out"], "dcblocker")
+    p = g["svf_par"]
+    svf = mx.maxiSVFBank(V); svf.setCutoff(p[0]); svf.setResonance(p[1])
+    o = np.concatenate([svf.play(d(x[:100]), *p[2:]).numpy(), svf.play(d(x[100:]), *p[2:]).numpy()])
+    assert_bits_equal(svf.coefficients(), g["svf_coef"], "svf coefficients")
+    assert_bits_equal(o, g["svf_out"], "svf")
+    assert_bits_equal(svf.state.numpy(), g["svf_st"])
+    for t in range(7):
+        p = g["bq_par_%d" % t]
+        bq = mx.maxiBiquadBank(V); bq.set(t, p[1], p[2], p[3])
+        o = np.concatenate([bq.play(d(x[:100])).numpy(), bq.play(d(x[100:])).numpy()])
+        assert_bits_equal(bq.host_coef, g["bq_coef_%d" % t], "biquad coefficients %d" % t)
+        assert_bits_equal(o, g["bq_out_%d" % t], "biquad %d" % t)
+        assert_bits_equal(bq.state.numpy(), g["bq_st_%d" % t])
+
+
+@pytest.mark.parametrize("name", ["ar", "adsr", "curved"])
+def test_extra2_golden_envgen(mx, golden, name):
+    g = golden("extra2.npz")
+    trig = g["eg_trig"]
+    lv, tm, cv = g["eg_levels_" + name], g["eg_times_" + name], g["eg_curves_" + name]
+    for loop, retrig in ((0, 0), (1, 1)):
+        bank = mx.maxiEnvGenBank(trig.shape[1])
+        assert bank.setup(lv, tm, cv, bool(loop), bool(retrig))
+        o = np.concatenate([bank.play(trig[:1400]).numpy(), bank.play(trig[1400:]).numpy()])
+        tag = "%s_%d%d" % (name, loop, retrig)
+        assert_bits_equal(bank.host_stages, g["eg_stages_" + name], "stage table")
+        assert np.array_equal(bank.istate.numpy(), g["eg_ist_" + tag])
+        if name == "curved":
+            assert np.abs(o - g["eg_out_" + tag]).max() <= 4 * 2.2e-16
+        else:
+            assert_bits_equal(o, g["eg_out_" + tag], tag)
+            assert_bits_equal(bank.dstate.numpy(), g["eg_dst_" + tag])
+
+
+@pytest.mark.parametrize("sustain", [1, 0])
+def test_extra2_golden_sampler(mx, golden, sustain):
+    g = golden("extra2.npz")
+    L = mx.lib()
+    V, voices, N = g["smp_pitch"].size, 8, 900
+    d = lambda a: mx.DeviceBuffer.from_numpy(np.ascontiguousarray(a))
+    sb = mx.maxiSampleBank(1)
+    sb.setSample(g["smp_samples"])
+    freq = np.zeros(V)
+    assert L.mxg_sampler_freq_host(V, g["smp_pitch"].ctypes.data, g["smp_samples"].size, freq.ctypes.data) == 0
+    dpos, dtrig, dout = d(np.zeros(V)), d(g["smp_trig0"]), d(np.zeros(V))
+    ddst, dist = d(np.zeros((2, V))), d(np.zeros((6, V), np.int64))
+    dfreq, dgain, dpar, dhold = d(freq), d(g["smp_gain"]), d(g["smp_par"]), d(g["smp_hold"].astype(np.int64))
+    for blk in "ab":
+        if blk == "b":
+            t = dtrig.numpy(); t[::3] = 0; t[1::7] = 1; dtrig.upload(t)
+        mix, outputs = mx.DeviceBuffer((N, V // voices)), mx.DeviceBuffer((N, V))
+        assert L.mxg_sampler_render(V, N, voices, sustain, sb.d_samples, g["smp_samples"].size, dfreq.ptr, dgain.ptr,
+                                    dpar.ptr, dhold.ptr, dpos.ptr, dtrig.ptr, dout.ptr, ddst.ptr, dist.ptr, mix.ptr,
+                                    outputs.ptr, None) == 0
+        key = lambda nm: g["smp_%s_%s%d" % (nm, blk, sustain)]
+        assert_bits_equal(mix.numpy(), key("mix"), "play() " + blk)
+        assert_bits_equal(outputs.numpy(), key("outputs"))
+        assert_bits_equal(dpos.numpy(), key("position"))
+        assert np.array_equal(dtrig.numpy(), key("trigger"))
+        assert_bits_equal(ddst.numpy(), key("dst"))
+        assert np.array_equal(dist.numpy(), key("ist"))
