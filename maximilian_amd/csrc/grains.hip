@@ -738,14 +738,15 @@ __device__ __forceinline__ double unit_sample(const double *amp, const double *w
 #define MXG_UNIT_GROUP 1
 #endif
 constexpr int kUnitGroup = MXG_UNIT_GROUP;  // streams rendered together by a wavefront (divides 16)
-constexpr int kCand = 16;  // candidates per stream and tile: <= 8 carried-in + the spawns alive in the tile
+constexpr int kCand = 12;  // candidates per stream and tile: <= 8 alive at the tile's start + spawns inside the tile
+// Candidate metadata is packed into two ints (sampleDur < sr/2 <= 2^15 by the window-cache rule): with the 33 KB
+// transpose tile this keeps a workgroup under 40 KB of LDS, i.e. four workgroups per CU instead of three.
 
 __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
     __shared__ double s_tile[64 * 65];
     __shared__ int s_base[64 * kCand];  // buffer index the grain reads at the tile's first sample (mod len)
-    __shared__ int s_k0[64 * kCand];    // its window index at the tile's first sample (may be < 0: not born yet)
-    __shared__ int s_dur[64 * kCand];
-    __shared__ int s_sgn[64 * kCand];
+    __shared__ int s_kd[64 * kCand];    // bits 0-15: k0 + 64 (window index at the tile's first sample; k0 > -64),
+                                        // bits 16-30: duration, bit 31: direction (1 = backwards)
     __shared__ int s_cnt[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t S = A.S;
@@ -763,9 +764,8 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
                 // sample k of the grain reads index (pos0 + (k+1)*sg) mod len; at the tile start k = n0 - born
                 const long long k0 = (long long)n0 - born;
                 s_base[threadIdx.x * kCand + cnt] = (int)unit_index(pos0 + (k0 + 1) * sg, len);
-                s_k0[threadIdx.x * kCand + cnt] = (int)k0;
-                s_dur[threadIdx.x * kCand + cnt] = (int)dur;
-                s_sgn[threadIdx.x * kCand + cnt] = (int)sg;
+                s_kd[threadIdx.x * kCand + cnt] =
+                    (int)(((unsigned)(k0 + 64) & 0xffffu) | ((unsigned)dur << 16) | (sg < 0 ? 0x80000000u : 0u));
                 cnt++;
             };
             if (n0 < 32768) {  // carried-in grains can only be alive during the first <= sr/2 samples
@@ -832,11 +832,11 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
 #pragma unroll
         for (int g = 0; g < kUnitGroup; g++) { total[g] = 0.0; alive[g] = 0; }
         // lane q (< kCand) fetches candidate q's metadata once; readlane turns it into scalars per grain
-        int mk0[kUnitGroup], mdur[kUnitGroup], mbase[kUnitGroup], msgn[kUnitGroup];
+        int mkd[kUnitGroup], mbase[kUnitGroup];
 #pragma unroll
         for (int g = 0; g < kUnitGroup; g++) {
-            const int at = (sg + g) * kCand + (lane & (kCand - 1));
-            mk0[g] = s_k0[at]; mdur[g] = s_dur[at]; mbase[g] = s_base[at]; msgn[g] = s_sgn[at];
+            const int at = (sg + g) * kCand + (lane < kCand ? lane : 0);
+            mkd[g] = s_kd[at]; mbase[g] = s_base[at];
         }
         for (int q0 = 0; q0 < cmax; q0 += 8) {
             double va[kUnitGroup][8], vb[kUnitGroup][8], ve[kUnitGroup][8];
@@ -849,8 +849,10 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
                     ok[g][u] = false;
                     va[g][u] = vb[g][u] = ve[g][u] = 0.0;
                     if (q < cnt[g]) {  // wave-uniform
-                        const int gk0 = __builtin_amdgcn_readlane(mk0[g], q), gdur = __builtin_amdgcn_readlane(mdur[g], q);
-                        const int gbase = __builtin_amdgcn_readlane(mbase[g], q), gsgn = __builtin_amdgcn_readlane(msgn[g], q);
+                        const unsigned kd = (unsigned)__builtin_amdgcn_readlane(mkd[g], q);
+                        const int gbase = __builtin_amdgcn_readlane(mbase[g], q);
+                        const int gk0 = (int)(kd & 0xffffu) - 64, gdur = (int)((kd >> 16) & 0x7fffu);
+                        const int gsgn = (kd >> 31) ? -1 : 1;
                         const int k = gk0 + lane;
                         ok[g][u] = inT && k >= 0 && k < gdur;
                         int ia = gbase + lane * gsgn;  // |lane*sgn| < 64 <= len
@@ -944,6 +946,7 @@ __global__ void granular_unit_check_kernel(size_t S, const double *__restrict__ 
         if (gst[(3 * kSlots + k) * S + s] == 0.0) continue;
         const double pos = gst[(0 * kSlots + k) * S + s], inc = gst[(1 * kSlots + k) * S + s];
         if (!(inc == 1.0 || inc == -1.0) || pos != floor(pos) || pos < 0.0 || pos > 9.0e15) bad = true;
+        if (gst[(3 * kSlots + k) * S + s] >= 32000.0) bad = true;  // durations are packed into 15 bits by K8c
     }
     if (bad) atomicMax(flag, 1);
 }
@@ -1041,7 +1044,8 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         // K8c eligibility: maxiTimeStretch, inc exactly 1.0 (the device evaluates the same IEEE division),
         // carried-in grains on the integer grid too, a window index that exists for every read
         bool unit = false;
-        if (mode == 0 && tune_get("grain_unit") && T < (size_t)1 << 30 && len >= 128 && len < ((size_t)1 << 31) - 128) {
+        if (mode == 0 && tune_get("grain_unit") && T < (size_t)1 << 30 && len >= 128 && len < ((size_t)1 << 31) - 128 &&
+            p->sampleDur < 32000) {
             const double frequency = (1.0 / p->grainLength) * 1.0;
             const double inc = (double)A.sampleDur / (A.sr / frequency);
             if (inc == 1.0) {
