@@ -353,6 +353,15 @@ __device__ __forceinline__ int lowbit_exp(double v) {  // exponent of the lowest
     return e - 1075 + (int)__builtin_ctzll(m);
 }
 
+// floor(num / den) for 0 <= num < 2^53, 0 < den < 2^53: a double division (both operands exact) is off by at most
+// one, which two multiply-compare fix-ups repair -- a fraction of the cost of the emulated 64-bit integer division.
+__device__ __forceinline__ long long floor_div53(long long num, long long den) {
+    long long q = (long long)((double)num / (double)den);
+    while (q * den > num) q--;
+    while ((q + 1) * den <= num) q++;
+    return q;
+}
+
 __device__ int advance_until(double &x, const double r, const double limit, const bool inclusive, int kmax,
                              bool &crossed) {
     crossed = false;
@@ -401,12 +410,12 @@ __device__ int advance_until(double &x, const double r, const double limit, cons
                     const long long c = fr < 0.5 ? R : (fr > 0.5 ? R + 1 : (((X + R) & 1) ? R + 1 : R));
                     long long j = (long long)(kmax - done);
                     if (c > 0) {
-                        const long long jb = ((1LL << 53) - 1 - X) / c;  // stay inside the binade
+                        const long long jb = floor_div53((1LL << 53) - 1 - X, c);  // stay inside the binade
                         j = jb < j ? jb : j;
                         const double lu = ldexp(limit, 1075 - e);
                         if (lu < 9007199254740992.0) {  // limit inside/below this binade's mantissa range
                             const long long Lq = inclusive ? (long long)ceil(lu) - 1 : (long long)floor(lu);
-                            const long long jl = Lq >= X ? (Lq - X) / c : 0;  // steps that do not cross
+                            const long long jl = Lq >= X ? floor_div53(Lq - X, c) : 0;  // steps that do not cross
                             j = jl < j ? jl : j;
                         }
                     }
