@@ -500,6 +500,52 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
             nstart = Tn;
         }
     }
+    if constexpr (MODE == 2) {
+        // playAtPosition: `looper` just counts samples and a grain is born when floor(fmod(looper, cycle)) == 0
+        // (:362); the position signal is only looked at on those samples.  With an integer-valued looper the
+        // additions are exact, so the kernel jumps from birth to birth: the next one is the smallest integer
+        // >= (m+1)*cycle, located with one multiplication and confirmed with the exact predicate itself
+        // (fmod is exact) on the candidate and its neighbours.
+        const double cyc = A.cycleLength;
+        if (A.fast && cyc > 2.0 && q.looper >= 0.0 && q.looper == floor(q.looper) && q.looper + (double)Tn < 4.0e15) {
+            auto born = [&](double L) { return 0 == floor(fmod(L, cyc)); };
+            const double L0 = q.looper;  // looper before sample 0; sample n sees L0 + n + 1
+            double L = L0;
+            bool ok = true;
+            for (;;) {
+                // smallest integer Lc > L with Lc mod cyc in [0, 1)
+                double Lc;
+                if (born(L + 1.0)) {
+                    Lc = L + 1.0;
+                } else {
+                    double m = floor((L + 1.0) / cyc) + 1.0;
+                    Lc = ceil(m * cyc);
+                    if (Lc <= L + 1.0) Lc = ceil((m + 1.0) * cyc);  // the quotient was rounded down across an integer
+                    if (Lc - 1.0 > L + 1.0 && born(Lc - 1.0)) Lc -= 1.0;
+                    else if (!born(Lc)) Lc += 1.0;
+                    // exactness check: Lc is a birth and the integer before it is not; otherwise walk from L
+                    // (a jump longer than one cycle would mean a birth was skipped)
+                    if (!born(Lc) || (Lc - 1.0 > L && born(Lc - 1.0)) || Lc - L > cyc + 1.0) { ok = false; break; }
+                }
+                const double nn = Lc - L0 - 1.0;  // sample index of that birth
+                if (!(nn < (double)Tn)) break;
+                const int n = (int)nn;
+                double pos = sc.a_ps[(size_t)n * S];
+                pos *= sc.dlen;
+                double pos0, inc;
+                grain_birth(sc, (pos / sc.dlen), 1.0, pos0, inc);
+                record(n, pos0, inc);
+                L = Lc;
+            }
+            if (ok) {
+                q.looper = L0 + (double)Tn;
+                nstart = Tn;
+            } else {  // resume one sample at a time right after the last confirmed birth
+                q.looper = L;
+                nstart = (int)(L - L0);
+            }
+        }
+    }
     for (int n = nstart; n < Tn; n++) {
         double pos0, inc;
         if (sched_step<MODE>(q, sc, (size_t)n, pos0, inc, failed)) record(n, pos0, inc);
@@ -715,9 +761,9 @@ __global__ __launch_bounds__(64) void granular_render_kernel(RenderArgs A) {
 // other) into LDS and writes it out transposed, so the [T][S] stores are coalesced too.
 struct UnitArgs {
     size_t S, T, len, G, C;  // C = number of 64-sample chunks; chunk_first is [C+1][S]
-    const double *amp, *window, *a;
+    const double *amp, *window;
     const int32_t *spawn_n;
-    const double *spawn_pos;
+    const double *spawn_pos, *spawn_inc;  // spawn_inc is +1.0 or -1.0 here: the grain's direction
     const int32_t *chunk_first;
     const double *gst_in;
     double *gst_out, *out;
@@ -768,7 +814,6 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
         const size_t s = s0 + threadIdx.x;
         int cnt = 0;
         if (s < S) {
-            const int sgn = A.a[s] > 0 ? 1 : -1;  // :350
             auto add = [&](long long born, long long dur, long long pos0, long long sg) {
                 // sample k of the grain reads index (pos0 + (k+1)*sg) mod len; at the tile start k = n0 - born
                 const long long k0 = (long long)n0 - born;
@@ -794,20 +839,21 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
             // [0, first) and at most kSlots long.  Their births/positions are fetched with independent
             // loads (a walk-back loop would chain one dependent load per grain) and filtered afterwards.
             int bornB[kSlots];
-            double posB[kSlots];
+            double posB[kSlots], incB[kSlots];
 #pragma unroll
             for (int u = 0; u < kSlots; u++) {
                 const int j = first - kSlots + u;
                 const int jc = j < 0 ? 0 : j;
                 bornB[u] = A.spawn_n[(size_t)jc * S + s];
                 posB[u] = A.spawn_pos[(size_t)jc * S + s];
+                incB[u] = A.spawn_inc[(size_t)jc * S + s];
             }
 #pragma unroll
             for (int u = 0; u < kSlots; u++) {
                 const int j = first - kSlots + u;
                 if (j >= 0 && (long long)bornB[u] + A.sampleDur > (long long)n0) {
                     if (cnt >= kCand) { atomicMax(A.err, 1); break; }
-                    add(bornB[u], A.sampleDur, (long long)posB[u], sgn);
+                    add(bornB[u], A.sampleDur, (long long)posB[u], incB[u] > 0 ? 1 : -1);
                 }
             }
             if (first > kSlots && (long long)A.spawn_n[(size_t)(first - kSlots - 1) * S + s] + A.sampleDur > (long long)n0)
@@ -817,7 +863,8 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
                     atomicMax(A.err, 1);
                     break;
                 }
-                add(A.spawn_n[(size_t)j * S + s], A.sampleDur, (long long)A.spawn_pos[(size_t)j * S + s], sgn);
+                add(A.spawn_n[(size_t)j * S + s], A.sampleDur, (long long)A.spawn_pos[(size_t)j * S + s],
+                    A.spawn_inc[(size_t)j * S + s] > 0 ? 1 : -1);
             }
         }
         s_cnt[threadIdx.x] = cnt;
@@ -908,7 +955,6 @@ __global__ __launch_bounds__(64) void granular_unit_state_kernel(UnitArgs A) {
     const size_t S = A.S;
     if (s >= S) return;
     const long long len = (long long)A.len, T = (long long)A.T;
-    const long long sgn = A.a[s] > 0 ? 1 : -1;
     double gp[kSlots], gi[kSlots], gx[kSlots], gd[kSlots];
     int cnt = 0;
 #pragma unroll
@@ -935,6 +981,7 @@ __global__ __launch_bounds__(64) void granular_unit_state_kernel(UnitArgs A) {
         const long long born = A.spawn_n[(size_t)j * S + s];
         const long long pos0 = (long long)A.spawn_pos[(size_t)j * S + s];
         const long long steps = T - born;
+        const long long sgn = A.spawn_inc[(size_t)j * S + s] > 0 ? 1 : -1;
         if (cnt < kSlots) push((double)unit_index(pos0 + steps * sgn, len), (double)sgn, (double)steps, (double)A.sampleDur);
     }
 #pragma unroll
@@ -1053,7 +1100,8 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         // K8c eligibility: maxiTimeStretch, inc exactly 1.0 (the device evaluates the same IEEE division),
         // carried-in grains on the integer grid too, a window index that exists for every read
         bool unit = false;
-        if (mode == 0 && tune_get("grain_unit") && T < (size_t)1 << 30 && len >= 128 && len < ((size_t)1 << 31) - 128 &&
+        // (maxiTimeStretch::play and playAtPosition spawn every grain with speed +-1; maxiStretch / maxiPitchShift do not)
+        if ((mode == 0 || mode == 2) && tune_get("grain_unit") && T < (size_t)1 << 30 && len >= 128 && len < ((size_t)1 << 31) - 128 &&
             p->sampleDur < 32000) {
             const double frequency = (1.0 / p->grainLength) * 1.0;
             const double inc = (double)A.sampleDur / (A.sr / frequency);
@@ -1103,8 +1151,8 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         if (unit) {
             UnitArgs U;
             U.S = S; U.T = T; U.len = len; U.G = G; U.C = C;
-            U.amp = d_samples; U.window = p->d_window; U.a = d_a;
-            U.spawn_n = spawn_n; U.spawn_pos = spawn_pos; U.chunk_first = chunk_first;
+            U.amp = d_samples; U.window = p->d_window;
+            U.spawn_n = spawn_n; U.spawn_pos = spawn_pos; U.spawn_inc = spawn_inc; U.chunk_first = chunk_first;
             U.gst_in = gst_copy; U.gst_out = d_gst; U.out = d_out; U.err = g_err; U.sampleDur = A.sampleDur;
             hipLaunchKernelGGL(granular_unit_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)C), dim3(256), 0, st, U);
             hipLaunchKernelGGL(granular_unit_state_kernel, grid, dim3(64), 0, st, U);

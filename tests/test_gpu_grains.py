@@ -116,8 +116,15 @@ def test_fast_scheduler_random_rates(mx, port, mode):
         assert_bits_equal(o, e, "output")
 
 
+@pytest.fixture(params=[1, 0], ids=["eventdriven", "stepwise"])
+def fast_sched(mx, request):
+    prev = mx.lib().mxg_tune(b"grain_fast_sched", request.param)
+    yield request.param
+    mx.lib().mxg_tune(b"grain_fast_sched", prev)
+
+
 @pytest.mark.parametrize("overlaps,window", [(2, "hann"), (4, "cosine"), (3, "gaussian")])
-def test_play_at_position(mx, port, chunked, overlaps, window):
+def test_play_at_position(mx, port, chunked, fast_sched, overlaps, window):
     """maxiTimeStretch::playAtPosition (L/maxiGrains.h:359-367): caller-driven per-sample position,
     spawn when floor(fmod(looper, cycle)) == 0; two carried blocks; out, scheduler and grains bit-exact."""
     rng = np.random.default_rng(60 + overlaps)
@@ -165,3 +172,28 @@ def test_pitch_shift(mx, port, chunked, overlaps, gl):
     assert_bits_equal(bank.state.numpy(), st, "state")
     assert_bits_equal(bank.grains.numpy(), gst, "grains")
     assert np.abs(e2).max() > 0.3
+
+
+@pytest.mark.parametrize("gl,overlaps", [(0.05, 4), (0.0123, 3), (0.05, 7), (0.002, 2)])
+def test_play_at_position_event_driven_cycles(mx, port, gl, overlaps):
+    """The birth-to-birth scheduler of playAtPosition for cycle lengths that are integers (0.05 s / 7 is not,
+    0.05*44100/4 = 551.25 is not, 0.002*44100/2 = 44.1 ...), long runs and a looper that starts far from 0."""
+    rng = np.random.default_rng(int(gl * 1e5) + overlaps)
+    L, S, T = 60000, 40, 12000
+    smp = rng.uniform(-1, 1, L)
+    pos = rng.uniform(0, 1, (T, S))
+    sb = mx.maxiSampleBank(1)
+    sb.setSample(smp)
+    bank = mx.maxiTimeStretchBank(S, sb, "hann")
+    st0 = np.zeros((4, S))
+    st0[1] = rng.integers(0, 100000, S).astype(np.float64)        # looper
+    st0[1, 3] = 7.5                                                # not an integer: the stepwise path must take over
+    bank.state.upload(st0)
+    o = bank.playAtPosition(pos, gl, overlaps).numpy()
+    e, st, gst, rc = port.granular(2, 0, smp, T, pos, grainLength=gl, overlaps=overlaps, st=st0)
+    if rc == -3:                                                   # > 8 grains alive: both sides must refuse
+        pytest.skip("capacity")
+    assert rc == 0
+    assert_bits_equal(o, e, "playAtPosition")
+    assert_bits_equal(bank.state.numpy(), st, "state")
+    assert_bits_equal(bank.grains.numpy(), gst, "grains")
