@@ -441,6 +441,21 @@ __device__ int advance_until(double &x, const double r, const double limit, cons
     return done;
 }
 
+// Smallest integer Lc > L (L an integer-valued double) with floor(fmod(Lc, cyc)) == 0, cyc > 2.  The candidate comes
+// from one multiplication; fmod is exact, so the predicate itself confirms it (and that the integer before it is not
+// a birth, and that no whole cycle was jumped).  ok = false: could not be confirmed, the caller walks sample by sample.
+__device__ __forceinline__ double next_birth(double L, double cyc, bool &ok) {
+    auto born = [&](double x) { return 0 == floor(fmod(x, cyc)); };
+    if (born(L + 1.0)) return L + 1.0;
+    const double m = floor((L + 1.0) / cyc) + 1.0;
+    double Lc = ceil(m * cyc);
+    if (Lc <= L + 1.0) Lc = ceil((m + 1.0) * cyc);  // the quotient was rounded down across an integer
+    if (Lc - 1.0 > L + 1.0 && born(Lc - 1.0)) Lc -= 1.0;
+    else if (!born(Lc)) Lc += 1.0;
+    if (!born(Lc) || (Lc - 1.0 > L && born(Lc - 1.0)) || Lc - L > cyc + 1.0) ok = false;
+    return Lc;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -500,49 +515,58 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
             nstart = Tn;
         }
     }
-    if constexpr (MODE == 2) {
-        // playAtPosition: `looper` just counts samples and a grain is born when floor(fmod(looper, cycle)) == 0
-        // (:362); the position signal is only looked at on those samples.  With an integer-valued looper the
-        // additions are exact, so the kernel jumps from birth to birth: the next one is the smallest integer
-        // >= (m+1)*cycle, located with one multiplication and confirmed with the exact predicate itself
-        // (fmod is exact) on the candidate and its neighbours.
-        const double cyc = A.cycleLength;
-        if (A.fast && cyc > 2.0 && q.looper >= 0.0 && q.looper == floor(q.looper) && q.looper + (double)Tn < 4.0e15) {
-            auto born = [&](double L) { return 0 == floor(fmod(L, cyc)); };
-            const double L0 = q.looper;  // looper before sample 0; sample n sees L0 + n + 1
+    if constexpr (MODE == 2 || MODE == 3) {
+        // playAtPosition / maxiPitchShift: the counter (`looper` / `cycles`) just counts samples and a grain is born
+        // when floor(fmod(counter, cycle)) == 0 (:362, :419-420); nothing else happens in between (playAtPosition
+        // reads its position signal on birth samples only; maxiPitchShift's `position` is a +1 ramp with a reset).
+        // With an integer-valued counter the additions are exact, so the kernel jumps from birth to birth
+        // (next_birth: one multiplication, then the exact predicate itself as the judge).
+        const double cyc = MODE == 2 ? A.cycleLength : A.cycleLength + q.randomOffset;
+        bool eligible = A.fast && cyc > 2.0 && q.looper >= 0.0 && q.looper == floor(q.looper) &&
+                        q.looper + (double)Tn < 4.0e15;
+        if constexpr (MODE == 3) eligible = eligible && q.position >= 0.0 && q.position <= dlen;
+        if (eligible) {
+            const double L0 = q.looper;  // counter before sample 0; sample n sees L0 + n + 1
             double L = L0;
+            int ndone = 0;               // samples whose `position` step has been applied (MODE 3)
             bool ok = true;
-            for (;;) {
-                // smallest integer Lc > L with Lc mod cyc in [0, 1)
-                double Lc;
-                if (born(L + 1.0)) {
-                    Lc = L + 1.0;
-                } else {
-                    double m = floor((L + 1.0) / cyc) + 1.0;
-                    Lc = ceil(m * cyc);
-                    if (Lc <= L + 1.0) Lc = ceil((m + 1.0) * cyc);  // the quotient was rounded down across an integer
-                    if (Lc - 1.0 > L + 1.0 && born(Lc - 1.0)) Lc -= 1.0;
-                    else if (!born(Lc)) Lc += 1.0;
-                    // exactness check: Lc is a birth and the integer before it is not; otherwise walk from L
-                    // (a jump longer than one cycle would mean a birth was skipped)
-                    if (!born(Lc) || (Lc - 1.0 > L && born(Lc - 1.0)) || Lc - L > cyc + 1.0) { ok = false; break; }
+            auto ramp = [&](int upto) {  // maxiPitchShift :415-417 for samples [ndone, upto)
+                int rem = upto - ndone;
+                while (rem > 0) {
+                    bool wrapped;
+                    rem -= advance_until(q.position, 1.0, dlen, false, rem, wrapped);
+                    if (wrapped) q.position = 0;  // `if (position > len) position = 0`
                 }
+                ndone = upto;
+            };
+            for (;;) {
+                const double Lc = next_birth(L, cyc, ok);
+                if (!ok) break;
                 const double nn = Lc - L0 - 1.0;  // sample index of that birth
                 if (!(nn < (double)Tn)) break;
                 const int n = (int)nn;
-                double pos = sc.a_ps[(size_t)n * S];
-                pos *= sc.dlen;
                 double pos0, inc;
-                grain_birth(sc, (pos / sc.dlen), 1.0, pos0, inc);
+                if constexpr (MODE == 2) {
+                    double pos = sc.a_ps[(size_t)n * S];
+                    pos *= sc.dlen;
+                    grain_birth(sc, (pos / sc.dlen), 1.0, pos0, inc);
+                } else {
+                    ramp(n + 1);
+                    const double cycleMod = fmod(Lc, cyc);
+                    const double sp = sc.speed - ((cycleMod / sc.cycleLength) * 0.1);  // :421
+                    grain_birth(sc, (q.position / sc.dlen) + sc.pm, sp, pos0, inc);
+                }
                 record(n, pos0, inc);
                 L = Lc;
             }
             if (ok) {
+                if constexpr (MODE == 3) ramp(Tn);
                 q.looper = L0 + (double)Tn;
                 nstart = Tn;
             } else {  // resume one sample at a time right after the last confirmed birth
                 q.looper = L;
                 nstart = (int)(L - L0);
+                if constexpr (MODE == 3) ramp(nstart);
             }
         }
     }

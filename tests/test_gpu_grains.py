@@ -147,7 +147,7 @@ def test_play_at_position(mx, port, chunked, fast_sched, overlaps, window):
 
 
 @pytest.mark.parametrize("overlaps,gl", [(2, 0.05), (4, 0.05), (3, 0.031)])
-def test_pitch_shift(mx, port, chunked, overlaps, gl):
+def test_pitch_shift(mx, port, chunked, fast_sched, overlaps, gl):
     """maxiPitchShift::play (L/maxiGrains.h:412-430): grains with arbitrary (also negative, zero-ish)
     increments, speed - (cycleMod/cycleLength)*0.1 per grain; two carried blocks, bit-exact."""
     rng = np.random.default_rng(70 + overlaps)
@@ -195,5 +195,29 @@ def test_play_at_position_event_driven_cycles(mx, port, gl, overlaps):
         pytest.skip("capacity")
     assert rc == 0
     assert_bits_equal(o, e, "playAtPosition")
+    assert_bits_equal(bank.state.numpy(), st, "state")
+    assert_bits_equal(bank.grains.numpy(), gst, "grains")
+
+
+def test_pitch_shift_event_driven_long_run(mx, port):
+    """maxiPitchShift over a run long enough for `position` to pass the end of the sample (reset to 0, :415) several
+    times, fractional start positions and a cycles counter that starts far from 0."""
+    rng = np.random.default_rng(314)
+    L, S, T = 9000, 48, 30000
+    smp = rng.uniform(-1, 1, L)
+    speed = rng.uniform(-1.5, 2.0, S)
+    pm = rng.uniform(-0.05, 0.05, S)
+    sb = mx.maxiSampleBank(1)
+    sb.setSample(smp)
+    bank = mx.maxiPitchShiftBank(S, sb, "hann")
+    st0 = np.zeros((4, S))
+    st0[0] = rng.uniform(0, L, S)
+    st0[0, :4] = [0.0, L, L - 0.5, 123.25]
+    st0[1] = rng.integers(0, 50000, S).astype(np.float64)
+    bank.state.upload(st0)                                        # (`cycles` is a long in the reference: integers only)
+    o = bank.play(speed, 0.02, 3, T, posMod=pm).numpy()
+    e, st, gst, rc = port.granular(3, 0, smp, T, speed, posMod=pm, grainLength=0.02, overlaps=3, st=st0)
+    assert rc == 0
+    assert_bits_equal(o, e, "pitchshift")
     assert_bits_equal(bank.state.numpy(), st, "state")
     assert_bits_equal(bank.grains.numpy(), gst, "grains")
