@@ -93,8 +93,11 @@ int mxg_event_record(void *event, void *stream);
 int mxg_event_elapsed_ms(void *start, void *stop, float *h_ms);
 
 /* ---- tuning knobs (performance only; results are identical for every setting) ---------- */
-/* key: "osc_vpl" (voices per lane 1|2), "osc_block" (64..1024), "osc_nt" (0|1 non-temporal
- * stores), "voice_vpl", "voice_block".  Returns previous value or MXG_ERR_INVALID. */
+/* key: "osc_vpl" (voices per lane 1|2), "osc_block" (64..1024), "osc_nt" (0|1 non-temporal stores),
+ * "voice_block", "voice_nt", "mix_rows" (sample rows per workgroup of the mixdown, 1|2), "fft_generic",
+ * "mfcc_tiled" (LDS-staged spectra 0|1), "grain_chunked" (time-sharded granular render 0|1), "grain_lanes_k",
+ * "grain_unit" (coalesced unit-increment render 0|1), "grain_fast_sched" (event-driven schedulers 0|1).
+ * The tests flip every one of them and demand identical bits.  Returns the previous value or MXG_ERR_INVALID. */
 int mxg_tune(const char *key, int value);
 
 /* ---- maxiOsc bank -------------------------------------------------------------------- */
