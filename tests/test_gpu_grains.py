@@ -221,3 +221,28 @@ def test_pitch_shift_event_driven_long_run(mx, port):
     assert_bits_equal(o, e, "pitchshift")
     assert_bits_equal(bank.state.numpy(), st, "state")
     assert_bits_equal(bank.grains.numpy(), gst, "grains")
+
+
+@pytest.mark.parametrize("knob,value", [(b"grain_unit", 0), (b"grain_lanes_k", 16), (b"grain_lanes_k", 4096)])
+def test_granular_launch_knobs_same_bits(mx, knob, value):
+    """The coalesced unit-increment render vs the general (stream, chunk) render, and the chunking granularity of
+    the latter: same output, scheduler state and live grains."""
+    L = mx.lib()
+    rng = np.random.default_rng(9)
+    Ls, S, T = 50000, 100, 5000
+    smp = rng.uniform(-1, 1, Ls)
+    speed = rng.uniform(-1.5, 2.0, S)
+
+    def run(mode):
+        bank = make_bank(mx, mode, "hann", smp, S)
+        bank.setPosition(np.arange(S) / S)
+        o = bank.play(speed, 0.05, 4, T).numpy() if mode == 0 else bank.play(speed, np.abs(speed) + 0.1, 0.05, 4, T).numpy()
+        return o, bank.state.numpy(), bank.grains.numpy()
+    ref = run(0) + run(1)
+    prev = L.mxg_tune(knob, value)
+    try:
+        got = run(0) + run(1)
+    finally:
+        L.mxg_tune(knob, prev)
+    for r, g in zip(ref, got):
+        assert_bits_equal(g, r, "%s=%d" % (knob.decode(), value))

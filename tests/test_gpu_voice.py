@@ -288,3 +288,31 @@ def test_mix_rows_per_workgroup_same_bits(mx):
         finally:
             L.mxg_tune(b"mix_rows", prev)
     assert_bits_equal(res[0], res[1], "rows 1 vs 2")
+
+
+@pytest.mark.parametrize("knob,value", [(b"voice_block", 64), (b"voice_block", 1024), (b"voice_nt", 1)])
+def test_voice_launch_knobs_same_bits(mx, knob, value):
+    L = mx.lib()
+    V, N = 700, 300
+    v = np.arange(V)
+    freq, cutoff, res = 50.0 + 7.0 * v, 300.0 + 5.0 * v, 1.0 + (v % 5)
+    trig = ((np.arange(N) % 130) < 70).astype(np.int32)
+    x = mx.DeviceBuffer.from_numpy(np.random.default_rng(4).uniform(-1, 1, (N, V)))
+
+    def run():
+        vb = mx.maxiVoiceBank(V)
+        vb.env.setAttack(1); vb.env.setDecay(5); vb.env.setSustain(0.5); vb.env.setRelease(20)
+        a = vb.render(0, freq, cutoff, res, trig, N).numpy()
+        b = mx.maxiFilterBank(V).render("hires", x, cutoff, res).numpy()
+        eb = mx.maxiEnvBank(V); eb.setAttack(1); eb.setDecay(5); eb.setSustain(0.5); eb.setRelease(20)
+        c = eb.render(0, x, trig, N).numpy()
+        d = mx.maxiSVFBank(V); d.setCutoff(cutoff); d.setResonance(res)
+        return a, b, c, d.play(x, 0.3, 0.3, 0.2, 0.2).numpy()
+    ref = run()
+    prev = L.mxg_tune(knob, value)
+    try:
+        got = run()
+    finally:
+        L.mxg_tune(knob, prev)
+    for r, g, name in zip(ref, got, ("voice", "filter", "env", "svf")):
+        assert_bits_equal(g, r, "%s with %s=%d" % (name, knob.decode(), value))
