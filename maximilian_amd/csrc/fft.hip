@@ -96,6 +96,19 @@ __device__ __forceinline__ void emit_bin_t(const FftOut &o, size_t base, int bin
     }
 }
 
+// K6a form: `row` holds the four output pointers already advanced to this frame (wave-uniform, SGPRs) and the
+// bin is an unsigned 32-bit offset, so the stores need no per-lane 64-bit address arithmetic.
+template <int OMASK>
+__device__ __forceinline__ void emit_row_t(const FftOut &row, unsigned bin, float2 v) {
+    if constexpr (OMASK & 1) row.real[bin] = v.x;
+    if constexpr (OMASK & 2) row.imag[bin] = v.y;
+    if constexpr (OMASK & 12) {
+        float power = v.x * v.x + v.y * v.y;  // L/fft.cpp:510
+        if constexpr (OMASK & 4) row.mags[bin] = sqrtf(power);
+        if constexpr (OMASK & 8) row.phases[bin] = atan2f(v.y, v.x);
+    }
+}
+
 __device__ __forceinline__ void emit_bin(const FftOut &o, size_t base, int bin, float2 v) {
     if (o.real) o.real[base + bin] = v.x;
     if (o.imag) o.imag[base + bin] = v.y;
@@ -276,7 +289,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MXG_FFT_MINWAVES) void fft1024
     // one __shared__ object: [tw 512][post 256][X per wave]
     __shared__ float2 s_all[512 + 256 + kWavesPerBlock * kX1024];
     float2 *s_tw = s_all, *s_post = s_all + 512;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index is uniform: readfirstlane tells hipcc, so frame bases live in SGPRs and the global
+    // loads/stores use the scalar-base + 32-bit-offset form instead of per-lane 64-bit address arithmetic
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float2 *X = s_all + 768 + wave * kX1024;
     for (int i = threadIdx.x; i < 511; i += blockDim.x) s_tw[i] = tw[i];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_post[i] = post[i];
@@ -286,11 +301,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MXG_FFT_MINWAVES) void fft1024
     const int rev6 = (int)(__brev((unsigned)lane) >> 26);
     // window coefficients of the 8 packed elements this lane loads (same for every frame)
     float2 wv[8];
-    int li[8];
+    unsigned li[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         const int rev3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);
-        li[e] = 2 * (rev3 * 64 + rev6);
+        li[e] = 2u * (unsigned)(rev3 * 64 + rev6);
         wv[e] = make_float2(window[li[e]], window[li[e] + 1]);
     }
     asm volatile("" : "+v"(wv[0].x), "+v"(wv[0].y), "+v"(wv[1].x), "+v"(wv[1].y), "+v"(wv[2].x), "+v"(wv[2].y),
@@ -300,7 +315,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MXG_FFT_MINWAVES) void fft1024
     // Frame loads are software-pipelined: the next frame's 8 reads are issued before this frame's
     // outputs are stored, so waiting for them never drains the store queue (in-order vmcnt).
     auto load_frame = [&](size_t fr, float2 (&dst)[8]) {
-        const float *x = signal + (fr < nframes ? fr : nframes - 1) * frame_stride;
+        // the frame index is wave-uniform: pin it to an SGPR so the row base is scalar arithmetic
+        const unsigned fu = __builtin_amdgcn_readfirstlane((unsigned)(fr < nframes ? fr : nframes - 1));
+        const float *x = signal + (size_t)fu * frame_stride;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             if constexpr (ALIGNED8) {
@@ -359,20 +376,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MXG_FFT_MINWAVES) void fft1024
 #pragma unroll
         for (int e = 0; e < 8; e++) X[pad8(e * 64 + lane)] = v[e];
         wave_lds_sync();
-        const size_t base = f * (size_t)512;
+        const size_t base = (size_t)__builtin_amdgcn_readfirstlane((unsigned)f) * (size_t)512;
+        FftOut row = {out.real ? out.real + base : nullptr, out.imag ? out.imag + base : nullptr,
+                      out.mags ? out.mags + base : nullptr, out.phases ? out.phases + base : nullptr};
 #pragma unroll 1
         for (int q = 0; q < 4; q++) {
-            const int i = 1 + lane + 64 * q;  // 1..256
-            if (i < 256) {
-                float2 a = X[pad8(i)], b = X[pad8(512 - i)];
+            const unsigned i = 1u + (unsigned)lane + 64u * (unsigned)q;  // 1..256
+            if (i < 256u) {
+                float2 a = X[pad8((int)i)], b = X[pad8(512 - (int)i)];
                 post_pair(a, b, s_post[i]);
-                emit_bin_t<OMASK>(out, base, i, a);
-                emit_bin_t<OMASK>(out, base, 512 - i, b);
+                emit_row_t<OMASK>(row, i, a);
+                emit_row_t<OMASK>(row, 512u - i, b);
             } else {  // i == 256 (lane 63, q 3): the untouched middle bin; and bin 0
-                emit_bin_t<OMASK>(out, base, 256, X[pad8(256)]);
+                emit_row_t<OMASK>(row, 256u, X[pad8(256)]);
                 float2 z = X[pad8(0)];
                 float2 z0 = {z.x + z.y, z.x - z.y};
-                emit_bin_t<OMASK>(out, base, 0, z0);
+                emit_row_t<OMASK>(row, 0u, z0);
             }
         }
         wave_lds_sync();
@@ -551,6 +570,7 @@ int mxg_fft_batch(const mxg_fft_plan *p, const float *d_signal, size_t frame_str
     if (int s = ensure_init()) return s;
     MXG_REQUIRE(p && d_signal, "null plan or signal");
     MXG_REQUIRE(d_real || d_imag || d_mags || d_phases, "no output requested");
+    MXG_REQUIRE(nframes < ((size_t)1 << 32), "nframes must be < 2^32");
     if (nframes == 0) return MXG_OK;
     hipStream_t st = resolve_stream(stream);
     FftOut out = {d_real, d_imag, d_mags, d_phases};
