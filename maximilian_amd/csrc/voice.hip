@@ -21,6 +21,7 @@
 
 #include "mxg_common.h"
 #include "mxg_env.h"
+#include "mxg_sincos.h"
 
 namespace mxg {
 
@@ -37,7 +38,7 @@ __device__ __forceinline__ void lores_coeffs_dev(double cutoff, double resonance
     if (cutoff < 10) cutoff = 10;
     if (cutoff > sr) cutoff = sr;
     if (resonance < 1.) resonance = 1.;
-    double z = cos(MXG_TWOPI * cutoff / sr);
+    double z = cos_small(MXG_TWOPI * cutoff / sr);  // argument in [0, 2*pi]: the short-range kernel of mxg_sincos.h
     c = 2 - 2 * z;
     double zm1 = z - 1.0;
     // pow(z-1, 3.0): libm's pow is within 1 ULP of the exact cube; (zm1*zm1)*zm1 is within
@@ -75,7 +76,7 @@ __global__ void __launch_bounds__(256) filter_kernel(size_t V, size_t N, const d
     auto bp_coeffs = [&](double cu, double rs) {
         if (cu > (sr * 0.5)) cu = (sr * 0.5);
         if (rs >= 1.) rs = 0.999999;
-        double z = cos(MXG_TWOPI * cu / sr);
+        double z = cos_small(MXG_TWOPI * cu / sr);
         b0 = (1 - rs) * (sqrt(rs * (rs - 4.0 * (z * z) + 2.0) + 1));
         b1 = 2 * z * rs;
         b2 = (rs * -1) * (rs * -1);
