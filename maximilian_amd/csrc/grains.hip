@@ -722,10 +722,13 @@ __global__ __launch_bounds__(64) void granular_render_kernel(RenderArgs A) {
                 const double fl = floor(p);
                 vr[k] = p - fl;
                 long long ia = alive ? (long long)fl : 0;
-                long long ib = ia + 1;
-                if ((size_t)ib >= A.len) ib = 0;
-                va[k] = A.amp[ia];
-                vb[k] = A.amp[ib];
+                // buffer[a] and buffer[a+1] in ONE 16-byte request (8-byte aligned; the uploaded buffer is readable at
+                // [len], mxg_sample_upload's guard): half the gather requests of two 8-byte loads.  The wrap b = 0
+                // (:231-233) is patched in by a second load that only lanes sitting on the last sample issue.
+                const double2v pr = *reinterpret_cast<const double2v *>(A.amp + ia);
+                va[k] = pr.x;
+                vb[k] = pr.y;
+                if ((size_t)(ia + 1) >= A.len) vb[k] = A.amp[0];
                 ve[k] = win[alive ? gidx[k] : 0];
             }
         }
