@@ -155,8 +155,9 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
                            const double *__restrict__ par, const int64_t *__restrict__ holdtime,
                            double *__restrict__ dst, int64_t *__restrict__ ist,
                            double *__restrict__ out) {
-    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V) return;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((gid & ~(size_t)63) >= V) return;  // the whole wavefront is past the bank
+    const size_t v = live_voice(gid, V);
     Env e;
     env_load(e, V, v, par, holdtime, dst, ist);
     const double *ip = in ? in + v : nullptr;
@@ -166,11 +167,17 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
     constexpr int U = 8;  // measured with the steady-state paths: 8 beats 4 on both paths
     double xn[U];
     int tn[U];
+    GateGroup<U> gcur;  // shared gate: see gate_group_load
 #pragma unroll
     for (int i = 0; i < U; i++) {
         const size_t m = (size_t)i < N ? (size_t)i : N - 1;
         if constexpr (HASIN) xn[i] = ip[m * V]; else xn[i] = 1.0;
-        tn[i] = TPV ? trig[m * V + v] : trig[m];
+        if constexpr (TPV) tn[i] = trig[m * V + v];
+    }
+    if constexpr (!TPV) {
+        gate_group_load<U>(gcur, trig, N, 0);
+        gate_group_classify<U>(gcur, N, 0);
+        asm volatile("" : "+v"(gcur.cls));
     }
     for (size_t n0 = 0; n0 < N; n0 += U) {
         double xc[U];
@@ -178,16 +185,25 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
 #pragma unroll
         for (int i = 0; i < U; i++) {
             xc[i] = xn[i];
-            tc[i] = tn[i];
+            if constexpr (TPV) tc[i] = tn[i];
             const size_t m = (n0 + U + i < N) ? n0 + U + i : N - 1;
             if constexpr (HASIN) xn[i] = ip[m * V];
-            tn[i] = TPV ? trig[m * V + v] : trig[m];
+            if constexpr (TPV) tn[i] = trig[m * V + v];
         }
         int fast = 0;
-        if constexpr (MODE == 0 && !TPV) {
-            const int g = (n0 + U <= N) ? gate_of_chunk<U>(tc) : 0;
-            if (g > 0) fast = __all(env_in_sustain(e)) ? 1 : 0;
-            else if (g < 0) fast = __all(env_in_release(e)) ? 2 : 0;
+        if constexpr (!TPV) {
+            const int cc = (int)((n0 / U) & 63);
+            if (cc == 0) {  // launches longer than 64 chunks: one drain of the store stream per 64*U samples
+                if (n0) {
+                    gate_group_load<U>(gcur, trig, N, n0 / (64 * U));
+                    gate_group_classify<U>(gcur, N, n0 / (64 * U));
+                }
+            }
+            const int g = __builtin_amdgcn_readlane(gcur.cls, cc);
+            if constexpr (MODE == 0) {
+                if (g > 0) fast = __all(env_in_sustain(e)) ? 1 : 0;
+                else if (g < 0) fast = __all(env_in_release(e)) ? 2 : 0;
+            }
         }
         if (fast == 1) {
 #pragma unroll
@@ -205,7 +221,10 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
 #pragma unroll
             for (int i = 0; i < U; i++) {
                 if (n0 + i >= N) break;
-                double o = (MODE == 0) ? env_adsr(e, xc[i], tc[i]) : env_ar(e, xc[i], tc[i]);
+                int t;
+                if constexpr (TPV) t = tc[i];
+                else t = __builtin_amdgcn_readlane(gcur.g[i], (int)((n0 / U) & 63));
+                double o = (MODE == 0) ? env_adsr(e, xc[i], t) : env_ar(e, xc[i], t);
                 *op = o;
                 op += V;
             }
@@ -229,8 +248,9 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
                              const int64_t *__restrict__ holdtime, double *__restrict__ ost,
                              double *__restrict__ fst, double *__restrict__ dst,
                              int64_t *__restrict__ ist, double *__restrict__ out, double sr) {
-    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V) return;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((gid & ~(size_t)63) >= V) return;  // the whole wavefront is past the bank
+    const size_t v = live_voice(gid, V);
     double phase = ost[v], hold = ost[V + v];
     Flt f = {fst[v], fst[V + v], fst[2 * V + v], fst[3 * V + v], fst[4 * V + v]};
     Env e;
@@ -251,23 +271,38 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
     asm volatile("" : "+v"(e.sustain), "+v"(e.release), "+v"(e.holdtime), "+v"(e.holdcount));
     constexpr int U = 8;
     int tn[U];
+    GateGroup<U> gcur;  // shared gate: see gate_group_load
+    if constexpr (TPV) {
 #pragma unroll
-    for (int i = 0; i < U; i++) {
-        const size_t m = (size_t)i < N ? (size_t)i : N - 1;
-        tn[i] = TPV ? trig[m * V + v] : trig[m];  // shared gate: scalar loads, also a chunk ahead
+        for (int i = 0; i < U; i++) {
+            const size_t m = (size_t)i < N ? (size_t)i : N - 1;
+            tn[i] = trig[m * V + v];
+        }
+    } else {
+        gate_group_load<U>(gcur, trig, N, 0);
+        gate_group_classify<U>(gcur, N, 0);
+        asm volatile("" : "+v"(gcur.cls));
     }
     for (size_t n0 = 0; n0 < N; n0 += U) {
       int tc[U];
-#pragma unroll
-      for (int i = 0; i < U; i++) tc[i] = tn[i];
-#pragma unroll
-      for (int i = 0; i < U; i++) {
-        const size_t m = (n0 + U + i < N) ? n0 + U + i : N - 1;
-        tn[i] = TPV ? trig[m * V + v] : trig[m];
-      }
       int fast = 0;
-      if constexpr (!TPV) {
-        const int g = (n0 + U <= N) ? gate_of_chunk<U>(tc) : 0;
+      if constexpr (TPV) {
+#pragma unroll
+        for (int i = 0; i < U; i++) tc[i] = tn[i];
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+          const size_t m = (n0 + U + i < N) ? n0 + U + i : N - 1;
+          tn[i] = trig[m * V + v];
+        }
+      } else {
+        const int cc = (int)((n0 / U) & 63);
+        if (cc == 0) {  // launches longer than 64 chunks: one drain of the store stream per 64*U samples
+          if (n0) {
+            gate_group_load<U>(gcur, trig, N, n0 / (64 * U));
+            gate_group_classify<U>(gcur, N, n0 / (64 * U));
+          }
+        }
+        const int g = __builtin_amdgcn_readlane(gcur.cls, cc);
         if (g > 0) fast = __all(env_in_sustain(e)) ? 1 : 0;
         else if (g < 0) fast = __all(env_in_release(e)) ? 2 : 0;
       }
@@ -309,7 +344,9 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
       for (int i = 0; i < U; i++) {
         const size_t n = n0 + i;
         if (n >= N) break;
-        const int t = tc[i];
+        int t;
+        if constexpr (TPV) t = tc[i];
+        else t = __builtin_amdgcn_readlane(gcur.g[i], (int)((n0 / U) & 63));
         double o;
         if constexpr (MODE == 0) {
             double s = phase;  // saw C:333-340
