@@ -13,6 +13,7 @@
 #include <math.h>
 
 #include "mxg_common.h"
+#include "mxg_gate.h"
 
 namespace mxg {
 namespace {
@@ -52,64 +53,79 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__r
     for (int i = threadIdx.x; i < A.nstages * 6; i += blockDim.x) s_tab[i] = A.stages[i];
     __syncthreads();
     const size_t V = A.V, N = A.N;
-    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V) return;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((gid & ~(size_t)63) >= V) return;  // the whole wavefront is past the bank
+    const size_t v = live_voice(gid, V);   // surplus lanes shadow voice V-1 (mxg_gate.h)
     enum { WAITING = 0, TRIGGERED = 1, HOLDING = 2 };
     double envval = A.dst[v], currentlevel = A.dst[V + v];
     double tprev = A.dst[2 * V + v], hprev = A.dst[3 * V + v], rprev = A.dst[4 * V + v];
     long long phase = A.ist[v], counter = A.ist[3 * V + v];
-    int state = (int)A.ist[V + v];
-    bool nxc = A.ist[2 * V + v] != 0;
-    bool tfirst = A.ist[4 * V + v] != 0, hfirst = A.ist[5 * V + v] != 0, rfirst = A.ist[6 * V + v] != 0;
+    long long i_state = A.ist[V + v], i_nxc = A.ist[2 * V + v];
+    long long i_tf = A.ist[4 * V + v], i_hf = A.ist[5 * V + v], i_rf = A.ist[6 * V + v];
+    // consume every prologue load here: a use inside the loop would be a counted wait the compiler has to place
+    // conservatively (vmcnt(4..8) on every chunk = draining the output stores, which share the counter)
+    asm volatile("" : "+v"(envval), "+v"(currentlevel), "+v"(tprev), "+v"(hprev), "+v"(rprev), "+v"(phase), "+v"(counter));
+    asm volatile("" : "+v"(i_state), "+v"(i_nxc), "+v"(i_tf), "+v"(i_hf), "+v"(i_rf));
+    int state = (int)i_state;
+    bool nxc = i_nxc != 0;
+    bool tfirst = i_tf != 0, hfirst = i_hf != 0, rfirst = i_rf != 0;
     const long long S = A.nstages;
     const bool loop = A.loop != 0, retrigger = A.retrigger != 0;
     const double *__restrict__ tp = TPV ? trig_in + v : trig_in;
     double *__restrict__ op = out_ptr + v;
     constexpr int U = 8;
     double tn[U];
+    GateGroup<U, double> gcur;  // shared gate: lane j keeps chunk j's triggers (mxg_gate.h)
+    const auto positive = [](double t) { return t > 0; };
+    if constexpr (TPV) {
 #pragma unroll
-    for (int i = 0; i < U; i++) {
-        const size_t m = (size_t)i < N ? (size_t)i : N - 1;
-        tn[i] = TPV ? tp[m * V] : tp[m];
+        for (int i = 0; i < U; i++) {
+            const size_t m = (size_t)i < N ? (size_t)i : N - 1;
+            tn[i] = tp[m * V];
+        }
+    } else {
+        gate_group_load(gcur, trig_in, N, 0, positive);
+        asm volatile("" : "+v"(gcur.cls));
     }
     for (size_t n0 = 0; n0 < N; n0 += U) {
         double tc[U];
+        if constexpr (TPV) {
 #pragma unroll
-        for (int i = 0; i < U; i++) {
-            tc[i] = tn[i];
-            const size_t m = (n0 + U + i < N) ? n0 + U + i : N - 1;  // clamped prefetch, a chunk ahead of the stores
-            tn[i] = TPV ? tp[m * V] : tp[m];
+            for (int i = 0; i < U; i++) {
+                tc[i] = tn[i];
+                const size_t m = (n0 + U + i < N) ? n0 + U + i : N - 1;  // clamped prefetch, a chunk ahead of the stores
+                tn[i] = tp[m * V];
+            }
         }
         // Two steady states in which nothing but a detector's previousValue moves and envval is simply repeated:
         // HOLDING while the trigger stays positive (no negative zero crossing, H:2334-2341) and WAITING while it
-        // stays <= 0 (no trigger, H:2281).  With a shared gate the test is scalar work plus one ballot per chunk.
+        // stays <= 0, or stays positive after a positive sample (no trigger either way, H:2281 / onZX H:569-579).  With a shared gate the test is one readlane plus one ballot per chunk.
+        const int cc = (int)((n0 / U) & 63);
         if constexpr (!TPV) {
-            if (n0 + U <= N) {
-                bool allpos = true, allnonpos = true;
+            if (cc == 0 && n0) gate_group_load(gcur, trig_in, N, n0 / (64 * U), positive);  // one drain per 64 chunks
+            const int g = lane_value(gcur.cls, cc);
+            int fast = 0;
+            if (g > 0 && !retrigger && __all(state == HOLDING && !nxc)) fast = 1;
+            else if (g < 0 && __all(state == WAITING)) fast = 2;
+            else if (g > 0 && __all(state == WAITING && tprev > 0 && !tfirst)) fast = 2;  // gate still up after the end: no crossing either
+            if (fast) {
 #pragma unroll
                 for (int i = 0; i < U; i++) {
-                    allpos = allpos && tc[i] > 0;
-                    allnonpos = allnonpos && !(tc[i] > 0);
+                    *op = envval;
+                    op += V;
                 }
-                int fast = 0;
-                if (allpos && !retrigger && __all(state == HOLDING && !nxc)) fast = 1;
-                else if (allnonpos && __all(state == WAITING)) fast = 2;
-                if (fast) {
-#pragma unroll
-                    for (int i = 0; i < U; i++) {
-                        *op = envval;
-                        op += V;
-                    }
-                    if (fast == 1) { hprev = -tc[U - 1]; hfirst = false; }  // holdDetector.onZX(-trigger), no crossing
-                    else { tprev = tc[U - 1]; tfirst = false; }            // trigDetector.onZX(trigger), no crossing
-                    continue;
-                }
+                const double last = lane_value(gcur.g[U - 1], cc);
+                if (fast == 1) { hprev = -last; hfirst = false; }  // holdDetector.onZX(-trigger), no crossing
+                else { tprev = last; tfirst = false; }            // trigDetector.onZX(trigger), no crossing
+                continue;
             }
         }
 #pragma unroll
         for (int i = 0; i < U; i++) {
             if (n0 + i >= N) break;
-            const double trigger = tc[i];
+            double trigger;
+            if constexpr (TPV) trigger = tc[i];
+            else trigger = lane_value(gcur.g[i], cc);
             int entry = state;  // the switch's fall-through, made explicit
             if (entry == WAITING) {  // H:2279-2292
                 if (on_zx(tprev, tfirst, trigger)) {

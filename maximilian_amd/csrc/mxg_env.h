@@ -2,6 +2,7 @@
 // envelope / fused-voice kernels (voice.hip) and the sampler kernel (sampler.hip).
 #pragma once
 #include "mxg_common.h"
+#include "mxg_gate.h"
 
 namespace mxg {
 namespace {
@@ -129,42 +130,6 @@ __device__ __forceinline__ int gate_of_chunk(const int (&t)[U]) {
 #pragma unroll
     for (int i = 0; i < U; i++) on += (t[i] == 1) ? 1 : 0;
     return on == U ? 1 : (on == 0 ? -1 : 0);
-}
-
-// A gate shared by the whole bank, 64 chunks of U samples at a time: lane j of every wavefront keeps the U gate
-// values of chunk j of the group and their class (gate_of_chunk), and the kernels pick chunk cc's with v_readlane.
-// This replaces U clamped scalar loads + the class arithmetic per chunk (about 140 scalar instructions, a quarter of
-// the steady-state voice kernel's issue slots at one wavefront per SIMD) by one readlane per chunk.
-// The readlanes need all 64 lanes of a wavefront alive, so the surplus lanes of the bank's last wavefront do not
-// exit: they shadow voice V-1 -- the same loads, the same arithmetic and the same stores of the same values to the same
-// addresses as the lane that owns it.
-__device__ __forceinline__ size_t live_voice(size_t gid, size_t V) { return gid < V ? gid : V - 1; }
-
-template <int U>
-struct GateGroup {
-    int g[U];
-    int cls;
-};
-// A block of up to 64*U samples (the default 512) needs one group, loaded in the kernel prologue; longer launches
-// reload at every group boundary and pay one drain of the store stream there (loads and stores share one in-order
-// counter, and a prefetch consumed 64 chunks later cannot be expressed as a counted wait).
-template <int U>
-__device__ __forceinline__ void gate_group_load(GateGroup<U> &G, const int32_t *__restrict__ trig, size_t N,
-                                                size_t grp) {
-    const size_t c = grp * 64 + (threadIdx.x & 63);
-#pragma unroll
-    for (int i = 0; i < U; i++) {
-        const size_t m = c * U + i;
-        G.g[i] = trig[m < N ? m : N - 1];  // clamped: a surplus lane re-reads the last gate, its class is 0
-    }
-}
-template <int U>
-__device__ __forceinline__ void gate_group_classify(GateGroup<U> &G, size_t N, size_t grp) {
-    const size_t c = grp * 64 + (threadIdx.x & 63);
-    int on = 0;
-#pragma unroll
-    for (int i = 0; i < U; i++) on += (G.g[i] == 1) ? 1 : 0;
-    G.cls = (c * U + U <= N) ? (on == U ? 1 : (on == 0 ? -1 : 0)) : 0;
 }
 
 // C:1319-1358

@@ -167,7 +167,8 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
     constexpr int U = 8;  // measured with the steady-state paths: 8 beats 4 on both paths
     double xn[U];
     int tn[U];
-    GateGroup<U> gcur;  // shared gate: see gate_group_load
+    GateGroup<U, int32_t> gcur;  // shared gate: see gate_group_load
+    const auto gate_on = [](int32_t t) { return t == 1; };  // the test of C:1363 / C:1425
 #pragma unroll
     for (int i = 0; i < U; i++) {
         const size_t m = (size_t)i < N ? (size_t)i : N - 1;
@@ -175,8 +176,7 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
         if constexpr (TPV) tn[i] = trig[m * V + v];
     }
     if constexpr (!TPV) {
-        gate_group_load<U>(gcur, trig, N, 0);
-        gate_group_classify<U>(gcur, N, 0);
+        gate_group_load(gcur, trig, N, 0, gate_on);
         asm volatile("" : "+v"(gcur.cls));
     }
     for (size_t n0 = 0; n0 < N; n0 += U) {
@@ -195,11 +195,10 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
             const int cc = (int)((n0 / U) & 63);
             if (cc == 0) {  // launches longer than 64 chunks: one drain of the store stream per 64*U samples
                 if (n0) {
-                    gate_group_load<U>(gcur, trig, N, n0 / (64 * U));
-                    gate_group_classify<U>(gcur, N, n0 / (64 * U));
+                    gate_group_load(gcur, trig, N, n0 / (64 * U), gate_on);
                 }
             }
-            const int g = __builtin_amdgcn_readlane(gcur.cls, cc);
+            const int g = lane_value(gcur.cls, cc);
             if constexpr (MODE == 0) {
                 if (g > 0) fast = __all(env_in_sustain(e)) ? 1 : 0;
                 else if (g < 0) fast = __all(env_in_release(e)) ? 2 : 0;
@@ -223,7 +222,7 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
                 if (n0 + i >= N) break;
                 int t;
                 if constexpr (TPV) t = tc[i];
-                else t = __builtin_amdgcn_readlane(gcur.g[i], (int)((n0 / U) & 63));
+                else t = lane_value(gcur.g[i], (int)((n0 / U) & 63));
                 double o = (MODE == 0) ? env_adsr(e, xc[i], t) : env_ar(e, xc[i], t);
                 *op = o;
                 op += V;
@@ -271,7 +270,8 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
     asm volatile("" : "+v"(e.sustain), "+v"(e.release), "+v"(e.holdtime), "+v"(e.holdcount));
     constexpr int U = 8;
     int tn[U];
-    GateGroup<U> gcur;  // shared gate: see gate_group_load
+    GateGroup<U, int32_t> gcur;  // shared gate: see gate_group_load
+    const auto gate_on = [](int32_t t) { return t == 1; };  // the test of C:1363 / C:1425
     if constexpr (TPV) {
 #pragma unroll
         for (int i = 0; i < U; i++) {
@@ -279,8 +279,7 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
             tn[i] = trig[m * V + v];
         }
     } else {
-        gate_group_load<U>(gcur, trig, N, 0);
-        gate_group_classify<U>(gcur, N, 0);
+        gate_group_load(gcur, trig, N, 0, gate_on);
         asm volatile("" : "+v"(gcur.cls));
     }
     for (size_t n0 = 0; n0 < N; n0 += U) {
@@ -298,11 +297,10 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
         const int cc = (int)((n0 / U) & 63);
         if (cc == 0) {  // launches longer than 64 chunks: one drain of the store stream per 64*U samples
           if (n0) {
-            gate_group_load<U>(gcur, trig, N, n0 / (64 * U));
-            gate_group_classify<U>(gcur, N, n0 / (64 * U));
+            gate_group_load(gcur, trig, N, n0 / (64 * U), gate_on);
           }
         }
-        const int g = __builtin_amdgcn_readlane(gcur.cls, cc);
+        const int g = lane_value(gcur.cls, cc);
         if (g > 0) fast = __all(env_in_sustain(e)) ? 1 : 0;
         else if (g < 0) fast = __all(env_in_release(e)) ? 2 : 0;
       }
@@ -346,7 +344,7 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
         if (n >= N) break;
         int t;
         if constexpr (TPV) t = tc[i];
-        else t = __builtin_amdgcn_readlane(gcur.g[i], (int)((n0 / U) & 63));
+        else t = lane_value(gcur.g[i], (int)((n0 / U) & 63));
         double o;
         if constexpr (MODE == 0) {
             double s = phase;  // saw C:333-340

@@ -64,3 +64,24 @@ def test_envgen_shared_gate_and_helpers(mx, port):
     assert bank.setupAR(1, 2) and bank.setupASR(1, 2)
     assert bank.setup([0, 1], [1, 2], [1], False) is False                 # size mismatch (H:2395)
     assert bank.setup([0, 1, 1, 0], [H, H, 5], [1, 1, 1], False) is False  # two HOLD stages (H:2377-2381)
+
+
+@pytest.mark.parametrize("shape", ["AR", "ADSR"])
+def test_envgen_shared_gate_steady_states(mx, port, shape):
+    """The wave-uniform steady-state paths with a shared gate: HOLDING under a held gate, WAITING under a low gate, and
+    WAITING under a gate that stays up after the envelope has finished (no zero crossing => no retrigger), across
+    launches of 64-chunk groups and ragged lengths."""
+    V, N = 200, 12000
+    gate = np.ones(N)
+    gate[:37] = -1.0
+    gate[6000:6100] = 0.0          # exact zeros: a release / a re-arm
+    gate[9000:9003] = -2.5
+    lv, tm, cv = CASES[shape]
+    bank = mx.maxiEnvGenBank(V)
+    assert bank.setup(lv, tm, cv, False, False)
+    cuts = [0, 5, 517, 1029, 6050, 9001, N]
+    o = np.concatenate([bank.play(gate[a:b]).numpy() for a, b in zip(cuts[:-1], cuts[1:])])
+    e, d, i, _ = port.envgen(gate, lv, tm, cv, 0, 0, V=V)
+    assert_bits_equal(o, e, shape)
+    assert np.array_equal(bank.istate.numpy(), i)
+    assert_bits_equal(bank.dstate.numpy(), d)

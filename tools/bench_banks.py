@@ -65,7 +65,9 @@ gate = D(np.where((np.arange(B) % 300) < 150, 1.0, -1.0))
 eg_call = lambda g: L.mxg_envgen_render(V, B, g.ptr, 0, eg.stages.ptr, 4, 0, 0, eg.dstate.ptr, eg.istate.ptr, out.ptr, None)
 line("maxiEnvGen ADSR (150/150)", timed(lambda: eg_call(gate)), 8, "(gate toggling every 150 samples: stage machine + ramps)")
 held = D(np.ones(B))
-for _ in range(200): eg_call(held)   # finish the release, re-arm, attack + decay: every envelope ends in HOLD
+low = D(-np.ones(B))
+for _ in range(60): eg_call(low)     # finish the 500 ms release: every envelope back in WAITING
+for _ in range(20): eg_call(held)    # trigger, attack + decay: every envelope ends in HOLD
 line("maxiEnvGen ADSR (holding)", timed(lambda: eg_call(held)), 8, "(gate held, every envelope in its HOLD stage: steady-state path)")
 
 # maxiDelayline
