@@ -20,6 +20,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "mxg_common.h"
@@ -329,6 +330,12 @@ struct SchedArgs {
     int *err;
     double sr, cycleLength, grainLength;
     int sampleDur, fast;
+    // Time slices (mxg_granular_render pipelines the scheduler against the render): this launch covers samples
+    // [n_base, n_base + T) of the call; carry = [2][S] spawn count | next chunk-table row, kept between slices
+    // (null: a single launch).  c_end = last chunk-table row this launch completes.
+    int n_base;
+    int32_t *carry;
+    size_t c_end;
 };
 
 // ---- exact multi-step advance of x <- fl(x + r) --------------------------------------------------
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
     const SchedConst sc = sched_const<MODE>(s, S, A.len, A.R, A.a, A.b, A.posMod, A.rnd, A.cycleLength,
                                             A.grainLength, A.sr, A.sampleDur);
     const double rate = sc.rate;
-    int count = 0;
+    int count = (A.carry && A.n_base) ? A.carry[s] : 0;
     int failed = 0;
     // The serial part of a stream: keep this loop to the recurrences themselves (the chunk table is
     // derived from the spawn list afterwards).  thr = cycleLength + randomOffset changes only at a spawn.
@@ -475,8 +482,9 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
     // chunk_first[c] = number of spawns before sample c*Tc.  Spawns arrive in increasing n, so the table is
     // filled as they are recorded -- stores only (a pass over the finished list would chain one dependent
     // global load per chunk: 1100 chunks x ~0.5 us was most of this kernel's time).
-    size_t cnext = 0;
+    size_t cnext = (A.carry && A.n_base) ? (size_t)A.carry[S + s] : 0;
     auto record = [&](int n, double pos0, double inc) {
+        n += A.n_base;  // sample index within the call
         const int stored = (size_t)count < A.G ? count : (int)A.G;
         const size_t clast = (size_t)n / A.Tc;  // chunks starting at or before n do not contain this spawn's predecessors only
         for (; cnext <= clast && cnext <= A.C; cnext++) A.chunk_first[cnext * S + s] = stored;
@@ -574,9 +582,13 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
         double pos0, inc;
         if (sched_step<MODE>(q, sc, (size_t)n, pos0, inc, failed)) record(n, pos0, inc);
     }
-    {   // chunks after the last spawn
+    {   // chunks after the last spawn (of this slice: up to the row the next slice starts in)
         const int stored = (size_t)count < A.G ? count : (int)A.G;
-        for (; cnext <= A.C; cnext++) A.chunk_first[cnext * S + s] = stored;
+        for (; cnext <= A.c_end; cnext++) A.chunk_first[cnext * S + s] = stored;
+    }
+    if (A.carry) {
+        A.carry[s] = count;
+        A.carry[S + s] = (int32_t)cnext;
     }
     if (failed) atomicMax(A.err, failed);
     A.st[s] = q.position;
@@ -796,6 +808,7 @@ struct UnitArgs {
     double *gst_out, *out;
     int *err;
     int sampleDur;
+    unsigned c0;  // first tile of this launch (time slices)
 };
 
 __device__ __forceinline__ long long unit_index(long long t, long long len) {  // t mod len, result in [0,len)
@@ -838,7 +851,7 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
     __shared__ int s_cnt[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t S = A.S;
-    const size_t s0 = (size_t)blockIdx.x * 64, c = blockIdx.y, n0 = c * 64;
+    const size_t s0 = (size_t)blockIdx.x * 64, c = (size_t)blockIdx.y + A.c0, n0 = c * 64;
     const long long len = (long long)A.len;
     // ---- phase 1: one lane per stream collects that stream's candidate grains (creation order) in LDS,
     //      so the dependent metadata loads of 64 streams overlap; all 64-bit arithmetic happens here,
@@ -1156,6 +1169,25 @@ __global__ void granular_unit_check_kernel(size_t S, const double *__restrict__ 
 
 using namespace mxg;
 
+namespace {
+// The auxiliary stream the sliced unit path renders on, and its fork/join events (created once, never destroyed:
+// they live as long as the library).  Calls from several host threads share them; every use is ordered by events.
+constexpr int kMaxSlices = 32;
+hipStream_t g_aux = nullptr;
+hipEvent_t g_aux_ev[kMaxSlices], g_aux_done;
+std::mutex g_aux_mu;
+int aux_stream_init() {
+    std::lock_guard<std::mutex> lock(g_aux_mu);
+    if (g_aux) return MXG_OK;
+    hipStream_t a = nullptr;
+    MXG_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    for (int i = 0; i < kMaxSlices; i++) MXG_HIP(hipEventCreateWithFlags(&g_aux_ev[i], hipEventDisableTiming));
+    MXG_HIP(hipEventCreateWithFlags(&g_aux_done, hipEventDisableTiming));
+    g_aux = a;
+    return MXG_OK;
+}
+}  // namespace
+
 extern "C" {
 
 mxg_grain_plan *mxg_grain_plan_create(int window_kind, double grainLength, int mySampleRate) {
@@ -1268,7 +1300,7 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         const double minCycle = A.cycleLength;  // randomOffset >= 0 only lengthens a cycle
         const size_t G = (size_t)((double)T / (minCycle > 1.0 ? floor(minCycle) : 1.0)) + 2;
         const size_t nd = 2 * G * S + 4 * kSlots * S;         // doubles: spawn_pos | spawn_inc | gst copy
-        const size_t ni = G * S + (C + 1) * S;                // int32: spawn_n | chunk_first
+        const size_t ni = G * S + (C + 1) * S + 2 * S;        // int32: spawn_n | chunk_first | slice carry
         const size_t bytes = nd * sizeof(double) + ni * sizeof(int32_t);
         void *g_sched_scratch = nullptr;  // per-stream: spawn lists + chunk table + copy of the carried-in grains
         if (int s = scratch_get(SCR_GRAIN_SCHED, st, bytes, &g_sched_scratch)) return s;
@@ -1285,6 +1317,38 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         Q.err = g_err;
         Q.sr = A.sr; Q.cycleLength = A.cycleLength; Q.grainLength = A.grainLength; Q.sampleDur = A.sampleDur;
         Q.fast = tune_get("grain_fast_sched");
+        Q.n_base = 0; Q.carry = nullptr; Q.c_end = C;
+        UnitArgs U;
+        U.S = S; U.T = T; U.len = len; U.G = G; U.C = C;
+        U.amp = d_samples; U.window = p->d_window;
+        U.spawn_n = spawn_n; U.spawn_pos = spawn_pos; U.spawn_inc = spawn_inc; U.chunk_first = chunk_first;
+        U.gst_in = gst_copy; U.gst_out = d_gst; U.out = d_out; U.err = g_err; U.sampleDur = A.sampleDur;
+        U.c0 = 0;
+        // maxiTimeStretch on the unit path: the scheduler is a serial walk per stream (32 wavefronts for 2048 streams)
+        // and the render fills the chip, so the call is cut into time slices and slice i's render (on the library's
+        // auxiliary stream) overlaps slice i+1's scheduling.  The scheduler state carries over in d_st / carry; the
+        // spawn list and the chunk table are the same arrays a single launch fills, so the bits do not change.
+        int slices = tune_get("grain_slices");
+        if ((size_t)slices > C / 16) slices = (int)(C / 16);  // at least 16 tiles (1024 samples) per slice
+        if (unit && mode == 0 && slices > 1) {
+            if (int e = aux_stream_init()) return e;
+            Q.carry = chunk_first + (C + 1) * S;
+            for (int i = 0; i < slices; i++) {
+                const size_t ci = C * (size_t)i / slices, cn = C * (size_t)(i + 1) / slices;
+                Q.n_base = (int)(ci * Tc);
+                Q.T = (cn * Tc < T ? cn * Tc : T) - ci * Tc;
+                Q.c_end = (i == slices - 1) ? C : cn;
+                hipLaunchKernelGGL((granular_sched_kernel<0>), grid, dim3(64), 0, st, Q);
+                MXG_HIP(hipEventRecord(g_aux_ev[i], st));
+                MXG_HIP(hipStreamWaitEvent(g_aux, g_aux_ev[i], 0));
+                U.c0 = (unsigned)ci;
+                hipLaunchKernelGGL(granular_unit_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)(cn - ci)), dim3(256), 0,
+                                   g_aux, U);
+            }
+            MXG_HIP(hipEventRecord(g_aux_done, g_aux));
+            MXG_HIP(hipStreamWaitEvent(st, g_aux_done, 0));
+            hipLaunchKernelGGL(granular_unit_state_kernel, grid, dim3(64), 0, st, U);
+        } else {
         switch (mode) {
             case 0: hipLaunchKernelGGL((granular_sched_kernel<0>), grid, dim3(64), 0, st, Q); break;
             case 1: hipLaunchKernelGGL((granular_sched_kernel<1>), grid, dim3(64), 0, st, Q); break;
@@ -1292,11 +1356,6 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
             default: hipLaunchKernelGGL((granular_sched_kernel<3>), grid, dim3(64), 0, st, Q); break;
         }
         if (unit) {
-            UnitArgs U;
-            U.S = S; U.T = T; U.len = len; U.G = G; U.C = C;
-            U.amp = d_samples; U.window = p->d_window;
-            U.spawn_n = spawn_n; U.spawn_pos = spawn_pos; U.spawn_inc = spawn_inc; U.chunk_first = chunk_first;
-            U.gst_in = gst_copy; U.gst_out = d_gst; U.out = d_out; U.err = g_err; U.sampleDur = A.sampleDur;
             hipLaunchKernelGGL(granular_unit_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)C), dim3(256), 0, st, U);
             hipLaunchKernelGGL(granular_unit_state_kernel, grid, dim3(64), 0, st, U);
         } else {
@@ -1308,6 +1367,7 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         Rr.sampleDur = A.sampleDur; Rr.winInLds = A.winInLds;
         const size_t lanes = S * C;
         hipLaunchKernelGGL(granular_render_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), lds, st, Rr);
+        }
         }
     }
     MXG_HIP(hipGetLastError());
