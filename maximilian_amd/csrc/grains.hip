@@ -1176,8 +1176,9 @@ constexpr int kMaxSlices = 32;
 hipStream_t g_aux = nullptr;
 hipEvent_t g_aux_ev[kMaxSlices], g_aux_done;
 std::mutex g_aux_mu;
+std::mutex g_aux_init_mu;
 int aux_stream_init() {
-    std::lock_guard<std::mutex> lock(g_aux_mu);
+    std::lock_guard<std::mutex> lock(g_aux_init_mu);
     if (g_aux) return MXG_OK;
     hipStream_t a = nullptr;
     MXG_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
@@ -1332,6 +1333,9 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         if ((size_t)slices > C / 16) slices = (int)(C / 16);  // at least 16 tiles (1024 samples) per slice
         if (unit && mode == 0 && slices > 1) {
             if (int e = aux_stream_init()) return e;
+            // one caller at a time enqueues its fork/join: a wait captures the event's latest record, so another
+            // thread re-recording the shared events between a record and its wait would tie the render to the wrong slice
+            std::lock_guard<std::mutex> lock(g_aux_mu);
             Q.carry = chunk_first + (C + 1) * S;
             for (int i = 0; i < slices; i++) {
                 const size_t ci = C * (size_t)i / slices, cn = C * (size_t)(i + 1) / slices;

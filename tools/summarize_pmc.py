@@ -34,9 +34,9 @@ for (cfg, name), d in rows.items():
                                                          w / 1e6, r / 1e6, (w + r) / 1e6))
 out += ["", "Reading (algorithmic bytes per launch in brackets): K2 filter/env 543-548 MB [537]; K4 delay 1079 MB [1074]; fused voice",
         "287 MB [280]; K1 271 MB [270]; K3 mixdown 277 MB read [268 + gains]; K6a FFT mags-only 6444 MB [4295 read + 2147 written];",
-        "K5 sample players 269 MB written [268] plus 88-169 MB of gather reads that miss the caches; K8c granular 1156 MB written",
-        "[1156] plus ~1 GB of sample-buffer reads from HBM (the 35 MB buffer is re-fetched ~28x: 4.9 GB of algorithmic grain reads are",
-        "served mostly by L2 / Infinity Cache).  For K7a-t (MFCC, 16-B per-lane row segments) the doubled FETCH_SIZE is still only",
+        "K5 sample players 269 MB written [268] plus 88-169 MB of gather reads that miss the caches; K8c granular 4 x 289 MB written",
+        "[1156 per call, one launch per time slice] plus 4 x 277 MB of sample-buffer reads from HBM (the 35 MB buffer is re-fetched",
+        "~30x: 4.9 GB of algorithmic grain reads are served mostly by L2 / Infinity Cache).  For K7a-t (MFCC, 16-B per-lane row segments) the doubled FETCH_SIZE is still only",
         "half of the 1.95 GB the kernel must read, i.e. the counter's unit depends on the request width; it is listed as measured.", ""]
 open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))
