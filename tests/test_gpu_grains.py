@@ -247,3 +247,36 @@ def test_granular_launch_knobs_same_bits(mx, knob, value):
         L.mxg_tune(knob, prev)
     for r, g in zip(ref, got):
         assert_bits_equal(g, r, "%s=%d" % (knob.decode(), value))
+
+
+@pytest.mark.parametrize("unit", [1, 0])
+def test_granular_signed_zeros_and_non_finite_samples(mx, port, unit):
+    """`(1-remainder)*buffer[a] + remainder*buffer[b]` with remainder == 0 still depends on buffer[b]: 0*Inf and 0*NaN
+    are NaN, and -0.0 + 0*b is +0.0 or -0.0 with the sign of b.  A sample buffer sprinkled with -0.0, +-Inf and NaN,
+    forward and backward grains, wraps, a ragged last tile and a partial last wavefront: the unit-increment render (whose
+    interior pairs take buffer[a+1] from the neighbouring lane) and the general render both reproduce the oracle."""
+    rng = np.random.default_rng(4242)
+    Ls, S, T = 9000, 70, 3000 + 37
+    smp = rng.uniform(-1, 1, Ls)
+    idx = rng.choice(Ls, 120, replace=False)
+    smp[idx[:40]] = -0.0
+    smp[idx[40:60]] = 0.0
+    smp[idx[60:80]] = np.inf
+    smp[idx[80:100]] = -np.inf
+    smp[idx[100:]] = np.nan
+    smp[[0, Ls - 1]] = [-0.0, np.inf]                       # the wrap pair (b = buffer[0] after a = buffer[len-1])
+    speed = rng.uniform(0.3, 1.8, S) * np.where(np.arange(S) % 3 == 0, -1.0, 1.0)
+    prev = mx.lib().mxg_tune(b"grain_unit", unit)
+    try:
+        bank = make_bank(mx, 0, "hann", smp, S)
+        bank.setPosition(rng.uniform(0, 1, S))
+        st0 = bank.state.numpy()
+        o = bank.play(speed, 0.05, 4, T).numpy()
+    finally:
+        mx.lib().mxg_tune(b"grain_unit", prev)
+    e, est, egst, rc = port.granular(0, 0, smp, T, speed, grainLength=0.05, overlaps=4, st=st0)
+    assert rc == 0
+    assert np.isnan(e).any() and np.isfinite(e).any()
+    assert_bits_equal(o, e, "output")
+    assert_bits_equal(bank.state.numpy(), est, "state")
+    assert_bits_equal(bank.grains.numpy(), egst, "grains")
