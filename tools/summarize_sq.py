@@ -45,6 +45,6 @@ out += ["", "Reading: K1 (`osc_kernel<8>` = sinebuf) spends 60 % of its LDS-acti
         "its wave-cycles (11.5 M of 22.8 M; 18.7 M of 33.8 M before the shared gate moved from scalar loads to `v_readlane`).  K6a FFT: 21 % of LDS cycles are conflicts, VALU issue in 27-38 % of wave-cycles at 4 waves per SIMD (i.e. the VALU pipe",
         "itself is the shared bottleneck).  K8c (`granular_unit_kernel`, one launch per time slice = a quarter of the call): 41 M VALU",
         "instructions per slice (445 M per call before the flattened interior pass, 164 M now); each of the four resident waves of a",
-        "SIMD issues in 28 % of its cycles, i.e. the issue port is the limit now (24 instructions per (grain, tile) pair).", ""]
+        "SIMD issues in 28 % of its cycles (24 instructions per (grain, tile) pair) and waits on a dependency in 17 %.", ""]
 open(os.path.join(ROOT, "profiles", tag + "_sq_counters.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))
