@@ -97,7 +97,7 @@ int mxg_event_elapsed_ms(void *start, void *stop, float *h_ms);
  * "voice_block", "voice_nt", "mix_rows" (sample rows per workgroup of the mixdown, 1|2), "fft_generic",
  * "mfcc_tiled" (LDS-staged spectra 0|1), "grain_chunked" (time-sharded granular render 0|1), "grain_lanes_k",
  * "grain_unit" (coalesced unit-increment render 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_slices" (time slices of a unit-path
- * maxiTimeStretch call whose scheduling and rendering overlap, 1..32).
+ * maxiTimeStretch call whose scheduling and rendering overlap, 1..16).
  * The tests flip every one of them and demand identical bits.  Returns the previous value or MXG_ERR_INVALID. */
 int mxg_tune(const char *key, int value);
 

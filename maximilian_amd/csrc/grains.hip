@@ -1329,8 +1329,12 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         // and the render fills the chip, so the call is cut into time slices and slice i's render (on the library's
         // auxiliary stream) overlaps slice i+1's scheduling.  The scheduler state carries over in d_st / carry; the
         // spawn list and the chunk table are the same arrays a single launch fills, so the bits do not change.
+        // Slice i is twice as long as slice i-1 (weights 1, 2, 4, ...): scheduling a slice takes about half as long as
+        // rendering it, so slice i+1 is scheduled in the time slice i renders and only the short first one is exposed.
         int slices = tune_get("grain_slices");
-        if ((size_t)slices > C / 16) slices = (int)(C / 16);  // at least 16 tiles (1024 samples) per slice
+        while (slices > 1 && C / ((size_t(1) << slices) - 1) < 16) slices--;  // first slice >= 16 tiles (1024 samples)
+        const size_t wsum = (size_t(1) << slices) - 1;
+        auto slice_start = [&](int i) { return i >= slices ? C : C * ((size_t(1) << i) - 1) / wsum; };
         if (unit && mode == 0 && slices > 1) {
             if (int e = aux_stream_init()) return e;
             // one caller at a time enqueues its fork/join: a wait captures the event's latest record, so another
@@ -1338,7 +1342,7 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
             std::lock_guard<std::mutex> lock(g_aux_mu);
             Q.carry = chunk_first + (C + 1) * S;
             for (int i = 0; i < slices; i++) {
-                const size_t ci = C * (size_t)i / slices, cn = C * (size_t)(i + 1) / slices;
+                const size_t ci = slice_start(i), cn = slice_start(i + 1);
                 Q.n_base = (int)(ci * Tc);
                 Q.T = (cn * Tc < T ? cn * Tc : T) - ci * Tc;
                 Q.c_end = (i == slices - 1) ? C : cn;

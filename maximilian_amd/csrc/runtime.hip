@@ -35,7 +35,7 @@ Tune g_tune[] = {
     {"grain_lanes_k", 128, 16, 4096},  // K8b: target number of (stream, chunk) lanes, in units of 1024
     {"grain_unit", 1, 0, 1},  // K8c: coalesced closed-form render when every grain has inc = +-1
     {"grain_fast_sched", 1, 0, 1},  // K8a: event-driven exact multi-step scheduler (0: one step at a time)
-    {"grain_slices", 4, 1, 32},  // K8a/K8c: time slices of a maxiTimeStretch call (scheduling of slice i+1 overlaps render of slice i)
+    {"grain_slices", 4, 1, 16},  // K8a/K8c: time slices of a maxiTimeStretch call (scheduling of slice i+1 overlaps render of slice i)
     {"mfcc_tiled", 1, 0, 1},  // K7a-t: stage spectra through LDS tiles (0: per-lane row loads, K7a)
 };
 }  // namespace

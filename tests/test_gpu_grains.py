@@ -224,7 +224,7 @@ def test_pitch_shift_event_driven_long_run(mx, port):
 
 
 @pytest.mark.parametrize("knob,value", [(b"grain_unit", 0), (b"grain_lanes_k", 16), (b"grain_lanes_k", 4096),
-                                        (b"grain_slices", 1), (b"grain_slices", 2), (b"grain_slices", 32)])
+                                        (b"grain_slices", 1), (b"grain_slices", 2), (b"grain_slices", 16)])
 def test_granular_launch_knobs_same_bits(mx, knob, value):
     """The coalesced unit-increment render vs the general (stream, chunk) render, and the chunking granularity of
     the latter: same output, scheduler state and live grains."""
