@@ -1325,7 +1325,7 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         U.spawn_n = spawn_n; U.spawn_pos = spawn_pos; U.spawn_inc = spawn_inc; U.chunk_first = chunk_first;
         U.gst_in = gst_copy; U.gst_out = d_gst; U.out = d_out; U.err = g_err; U.sampleDur = A.sampleDur;
         U.c0 = 0;
-        // maxiTimeStretch on the unit path: the scheduler is a serial walk per stream (32 wavefronts for 2048 streams)
+        // maxiTimeStretch::play / playAtPosition on the unit path: the scheduler is a serial walk per stream (32 wavefronts for 2048 streams)
         // and the render fills the chip, so the call is cut into time slices and slice i's render (on the library's
         // auxiliary stream) overlaps slice i+1's scheduling.  The scheduler state carries over in d_st / carry; the
         // spawn list and the chunk table are the same arrays a single launch fills, so the bits do not change.
@@ -1335,7 +1335,7 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         while (slices > 1 && C / ((size_t(1) << slices) - 1) < 16) slices--;  // first slice >= 16 tiles (1024 samples)
         const size_t wsum = (size_t(1) << slices) - 1;
         auto slice_start = [&](int i) { return i >= slices ? C : C * ((size_t(1) << i) - 1) / wsum; };
-        if (unit && mode == 0 && slices > 1) {
+        if (unit && slices > 1) {  // mode 0 or 2 (the unit path's modes)
             if (int e = aux_stream_init()) return e;
             // one caller at a time enqueues its fork/join: a wait captures the event's latest record, so another
             // thread re-recording the shared events between a record and its wait would tie the render to the wrong slice
@@ -1346,7 +1346,12 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
                 Q.n_base = (int)(ci * Tc);
                 Q.T = (cn * Tc < T ? cn * Tc : T) - ci * Tc;
                 Q.c_end = (i == slices - 1) ? C : cn;
-                hipLaunchKernelGGL((granular_sched_kernel<0>), grid, dim3(64), 0, st, Q);
+                if (mode == 0) {
+                    hipLaunchKernelGGL((granular_sched_kernel<0>), grid, dim3(64), 0, st, Q);
+                } else {
+                    Q.a = d_a + (size_t)Q.n_base * S;  // playAtPosition reads its position signal [T][S] at the births
+                    hipLaunchKernelGGL((granular_sched_kernel<2>), grid, dim3(64), 0, st, Q);
+                }
                 MXG_HIP(hipEventRecord(g_aux_ev[i], st));
                 MXG_HIP(hipStreamWaitEvent(g_aux, g_aux_ev[i], 0));
                 U.c0 = (unsigned)ci;
