@@ -86,3 +86,24 @@ def test_compute_fails_loudly_without_gpu(port):
     rc = L.mxg_osc_render(8, 8, 8, z.ctypes.data, 0, None, None, z.ctypes.data, z.ctypes.data,
                           z.ctypes.data, None)
     assert rc == -2
+
+
+def test_every_tune_knob_is_documented_and_settable(port):
+    """The knob table of runtime.hip, the list in include/maxigpu.h and mxg_tune() agree: every key is documented,
+    accepts its own current value back, and rejects a value outside its range."""
+    import maximilian_amd as m
+    L = m.lib()
+    src = open(os.path.join(ROOT, "maximilian_amd", "csrc", "runtime.hip")).read()
+    table = src[src.index("Tune g_tune[] = {"):]
+    table = table[:table.index("};")]
+    rows = re.findall(r'\{"(\w+)",\s*(-?\d+),\s*(-?\d+),\s*(-?\d+)\}', table)
+    assert len(rows) >= 12
+    header = open(os.path.join(ROOT, "include", "maxigpu.h")).read()
+    doc = header[header.index("tuning knobs"):header.index("int mxg_tune(")]
+    for key, default, lo, hi in rows:
+        if key not in ("voice_vpl", "mix_block"):          # reserved keys (accepted, not used by a kernel yet)
+            assert '"%s"' % key in doc, "knob %s is missing from the header's list" % key
+        cur = L.mxg_tune(key.encode(), int(default))
+        assert int(lo) <= cur <= int(hi), key
+        assert L.mxg_tune(key.encode(), cur) == int(default), key   # restore; returns what we just set
+        assert L.mxg_tune(key.encode(), int(hi) + 1) < 0, key
