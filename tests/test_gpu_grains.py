@@ -280,3 +280,27 @@ def test_granular_signed_zeros_and_non_finite_samples(mx, port, unit):
     assert_bits_equal(o, e, "output")
     assert_bits_equal(bank.state.numpy(), est, "state")
     assert_bits_equal(bank.grains.numpy(), egst, "grains")
+
+
+def test_scheduler_position_stuck_on_the_wrap_limit(mx, port):
+    """maxiStretch (`position >= len` wraps, L/maxiGrains.h:516) with a rate below half an ulp of the position: a head that
+    sits exactly on len does not move when the rate is added, but the test still fires on the next sample and wraps
+    it; a head just below len stays there for ever.  (Found by the host fuzz of mxg_advance.h.)"""
+    rng = np.random.default_rng(5150)
+    Ls, S, T = 262144, 64, 4000
+    smp = rng.uniform(-1, 1, Ls)
+    speed = rng.uniform(0.5, 1.5, S)
+    rate = np.full(S, 2.0 ** -40)
+    rate[1::4] = 2.0 ** -36 * 1.37
+    rate[2::4] = 0.75
+    st0 = np.zeros((4, S))
+    st0[0] = float(Ls)                       # exactly on the limit
+    st0[0, 3::4] = np.nextafter(float(Ls), 0.0)
+    bank = make_bank(mx, 1, "hann", smp, S)
+    bank.state.upload(st0)
+    o = bank.play(speed, rate, 0.05, 4, T).numpy()
+    e, est, egst, rc = port.granular(1, 0, smp, T, speed, b=rate, grainLength=0.05, overlaps=4, st=st0)
+    assert rc == 0
+    assert_bits_equal(bank.state.numpy(), est, "scheduler state")
+    assert_bits_equal(bank.grains.numpy(), egst, "grains")
+    assert_bits_equal(o, e, "output")

@@ -1,0 +1,17 @@
+"""CPU (-m "not gpu"): the exact multi-step forms of the granular scheduler (maximilian_amd/csrc/mxg_advance.h, used by
+K8a on the device) compiled for the host and fuzzed against the reference's step-by-step recurrences -- hundreds of
+thousands of (start, rate, limit) triples incl. rates below half an ulp of the position, starts on the limit, ties and
+binade crossings; and next_birth against the sample-by-sample `floor(fmod(counter, cycle)) == 0` walk."""
+import os
+import subprocess
+
+from conftest import ROOT
+
+
+def test_exact_multi_step_scheduler_forms_on_host(tmp_path):
+    exe = str(tmp_path / "sched_fuzz")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I" + os.path.join(ROOT, "maximilian_amd", "csrc"),
+                           "-o", exe, os.path.join(ROOT, "tests", "host_sched_fuzz.cpp")])
+    r = subprocess.run([exe, "400000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "0 mismatches" in r.stdout and "next_birth: 100000 cases, 0 mismatches" in r.stdout, r.stdout
