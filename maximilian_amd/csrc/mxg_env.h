@@ -108,7 +108,9 @@ __device__ __forceinline__ bool env_in_sustain(const Env &e) {
            e.holdcount >= e.holdtime;
 }
 __device__ __forceinline__ bool env_in_release(const Env &e) {
-    return e.attackphase != 1 && e.decayphase != 1 && e.releasephase == 1 && e.holdphase != 1 &&
+    // holdphase == 0, not merely != 1: C:1456 stores 0 into it on every such sample, so any other value (a state
+    // uploaded by the host) has to go through the state machine once
+    return e.attackphase != 1 && e.decayphase != 1 && e.releasephase == 1 && e.holdphase == 0 &&
            e.holdcount >= e.holdtime;
 }
 __device__ __forceinline__ double env_sustain_tick(Env &e, double input) {  // gate == 1

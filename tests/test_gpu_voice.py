@@ -316,3 +316,29 @@ def test_voice_launch_knobs_same_bits(mx, knob, value):
         L.mxg_tune(knob, prev)
     for r, g, name in zip(ref, got, ("voice", "filter", "env", "svf")):
         assert_bits_equal(g, r, "%s with %s=%d" % (name, knob.decode(), value))
+
+
+def test_env_arbitrary_uploaded_flags(mx, port):
+    """maxiEnv's five phase members are plain ints a host may set to anything (state upload): with flags drawn from
+    {0, 1, 2} -- several set at once, none set, values that are neither 0 nor 1 -- and a shared gate (so the wave-uniform
+    steady-state tests run on every chunk), output and final state follow the reference's state machine bit for bit."""
+    rng = np.random.default_rng(2718)
+    V, N = 256, 600
+    x = rng.uniform(-1, 1, (N, V))
+    for gate_value in (0, 1):
+        bank = mx.maxiEnvBank(V)
+        bank.setAttack(3); bank.setDecay(30); bank.setSustain(0.4); bank.setRelease(80)
+        bank.holdtime[:] = rng.integers(1, 50, V)
+        bank._dirty = True
+        d0 = np.stack([rng.uniform(0.0, 1.2, V), rng.uniform(-1, 1, V)])
+        i0 = np.concatenate([rng.integers(0, 80, (1, V)), rng.integers(0, 3, (5, V))]).astype(np.int64)
+        i0[1:, :64] = np.array([0, 0, 0, 2, 1])[:, None]      # a whole wavefront: releasephase 1, holdphase 2
+        i0[0, :64] = 1000
+        bank.dstate.upload(d0); bank.istate.upload(i0)
+        trig = np.full(N, gate_value, np.int32)
+        trig[400:] = 1 - gate_value
+        o = bank.render(0, mx.DeviceBuffer.from_numpy(x), trig, N).numpy()
+        e, dst, ist = port.env(0, x, trig, bank.par, bank.holdtime, dstate=d0, istate=i0)
+        assert_bits_equal(o, e, "adsr, gate %d" % gate_value)
+        assert_bits_equal(bank.dstate.numpy(), dst)
+        assert np.array_equal(bank.istate.numpy(), ist)
