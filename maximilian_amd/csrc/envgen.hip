@@ -105,9 +105,12 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__r
             if (cc == 0 && n0) gate_group_load(gcur, trig_in, N, n0 / (64 * U), positive);  // one drain per 64 chunks
             const int g = lane_value(gcur.cls, cc);
             int fast = 0;
-            if (g > 0 && !retrigger && __all(state == HOLDING && !nxc)) fast = 1;
-            else if (g < 0 && __all(state == WAITING)) fast = 2;
-            else if (g > 0 && __all(state == WAITING && tprev > 0 && !tfirst)) fast = 2;  // gate still up after the end: no crossing either
+            // (phase != S: the end-of-envelope test after the switch, H:2349-2355, runs on every sample whatever the
+            // state; only a host-uploaded state can sit on it while WAITING/HOLDING, and then the stage machine handles it)
+            const bool parked = phase != S;
+            if (g > 0 && !retrigger && __all(state == HOLDING && !nxc && parked)) fast = 1;
+            else if (g < 0 && __all(state == WAITING && parked)) fast = 2;
+            else if (g > 0 && __all(state == WAITING && parked && tprev > 0 && !tfirst)) fast = 2;  // gate still up after the end: no crossing either
             if (fast) {
 #pragma unroll
                 for (int i = 0; i < U; i++) {

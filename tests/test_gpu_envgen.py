@@ -85,3 +85,28 @@ def test_envgen_shared_gate_steady_states(mx, port, shape):
     assert_bits_equal(o, e, shape)
     assert np.array_equal(bank.istate.numpy(), i)
     assert_bits_equal(bank.dstate.numpy(), d)
+
+
+@pytest.mark.parametrize("loop", [0, 1])
+def test_envgen_uploaded_state_parked_on_the_end_test(mx, port, loop):
+    """The end-of-envelope test `phase == stages.size` (H:2349-2355) runs after the switch on every sample, whatever the
+    state.  A host-uploaded state that is WAITING with phase already on the end must be reset / re-armed by it, also
+    under a shared gate that keeps every wavefront on the steady-state test."""
+    lv, tm, cv = CASES["ADSR"]
+    V, N = 192, 700
+    bank = mx.maxiEnvGenBank(V)
+    assert bank.setup(lv, tm, cv, bool(loop), False)
+    d0, i0 = port.envgen_fresh(V)
+    rng = np.random.default_rng(99)
+    i0[0, :128] = 4                       # phase == number of stages, state WAITING (two whole wavefronts)
+    d0[0, :128] = rng.uniform(0, 1, 128)  # some envval left over
+    i0[4, ::3] = 0                        # trigDetector.firstTrigger already consumed on a third of the voices
+    d0[2, ::3] = rng.choice([-1.0, 0.5], V)[::3]
+    bank.dstate.upload(d0); bank.istate.upload(i0)
+    gate = -np.ones(N)
+    gate[300:] = 1.0
+    o = bank.play(gate).numpy()
+    e, d, i, _ = port.envgen(gate, lv, tm, cv, loop, 0, dst=d0, ist=i0, V=V)
+    assert_bits_equal(o, e, "uploaded state")
+    assert np.array_equal(bank.istate.numpy(), i)
+    assert_bits_equal(bank.dstate.numpy(), d)
