@@ -254,8 +254,11 @@ typedef enum {
     MXG_SMP_PLAYWITHPHASOR = 14          /* playWithPhasor(trig=pha)                        C:753-816   */
 } mxg_sample_mode;
 /* Upload a mono sample (what maxiSample::setSample holds, H:670-678) into a device buffer that
- * is valid on [-1, len+1] with 0.0 guards: the reference reads amplitudes[len], [len+1]
- * (C:1063-1064) and [-1] (C:898) out of bounds; zero is the parity convention.
+ * is valid on [-4, len+5] with 0.0 guards: the reference reads amplitudes[len], [len+1]
+ * (C:1063-1064) and [-1] (C:898) out of bounds; zero is the parity convention.  The
+ * wider margin backs the players' index clamp: where the reference itself indexes outside its
+ * vector (undefined: a play4 step longer than its loop, playLoop with end > 1, a head uploaded far
+ * outside the sample) the device reads a guard zero, never memory outside this allocation.
  * Returns the device pointer to element 0 (NULL on failure); release with mxg_sample_free. */
 double *mxg_sample_upload(const double *h_samples, size_t len);
 int mxg_sample_free(double *d_samples);

@@ -1,10 +1,35 @@
 // mxg_smp.h -- the maxiSample players (src/maximilian.cpp:740-1075) split into head-advance / gather-index
 // generation (smp_gen) and interpolation (smp_eval); shared by sample.hip and sampler.hip.
 #pragma once
+#if defined(__HIPCC__)
 #include "mxg_common.h"
+#else  // host build of the same text (tests/host_smp.cpp: the players against the oracle over wide parameter ranges)
+#include <math.h>
+#include <stddef.h>
+#define __host__
+#define __device__
+#define __forceinline__ inline
+namespace mxg {
+constexpr double kChandiv = 1.0;
+}
+#endif
 
 namespace mxg {
 namespace {
+
+// Layout of an uploaded sample (mxg_sample_upload / mxg_sample_load_wav): kSmpGuardLo zeros, the len samples, kSmpGuardHi
+// zeros; the pointer handed around is element 0.  [-1], [len] and [len+1] are what the reference's players read next to the
+// buffer inside the ranges it is defined on (C:898, C:1063-1064; zero is the parity convention).  The remaining guards
+// back the index clamp below: outside those ranges (a play4 step longer than its loop, playLoop with end > 1, a head
+// uploaded far outside the sample) the reference indexes outside its vector -- undefined -- and the device reads a
+// guard zero instead of whatever lies, or does not lie, beyond the allocation.
+constexpr int kSmpGuardLo = 4, kSmpGuardHi = 6;
+
+// The head as the index computations see it: unchanged on [-2, len+2] (every position the reference is defined on),
+// pinned to that interval otherwise (NaN -> -2), so derived indices stay within [-4, len+4].
+__device__ __forceinline__ double smp_safe_head(double pos, size_t len) {
+    return fmin(fmax(pos, -2.0), (double)len + 2.0);
+}
 
 struct Smp {
     const double *amp;
@@ -96,7 +121,7 @@ __device__ __forceinline__ void smp_gen(Smp &s, double x, double t, double start
         q.idx[1] = (long long)pos2;
         s.tprev = pos;
     } else if constexpr (B == 0) {  // C:740-747
-        q.idx[0] = (long long)s.pos;
+        q.idx[0] = (long long)smp_safe_head(s.pos, s.len);
         s.pos += 1.0;
         if ((size_t)(long long)s.pos >= s.len) s.pos = 0;
     } else if constexpr (B == 1) {  // C:982-991
@@ -108,12 +133,12 @@ __device__ __forceinline__ void smp_gen(Smp &s, double x, double t, double start
         double lo = (double)s.len * start;
         if (s.pos < lo) s.pos = lo;
         if ((double)(long long)s.pos >= (double)s.len * end) s.pos = lo;
-        q.idx[0] = (long long)s.pos;
+        q.idx[0] = (long long)smp_safe_head(s.pos, s.len);
     } else if constexpr (B == 3) {  // C:969-978
         s.pos += 1.0;
         if (end > 1.0) end = 1.0;
         q.ok = (double)(long long)s.pos < (double)s.len * end;
-        q.idx[0] = q.ok ? (long long)s.pos : 0;
+        q.idx[0] = q.ok ? (long long)smp_safe_head(s.pos, s.len) : 0;
     } else if constexpr (B == 4 || B == 5 || B == 6) {  // C:1060-1075, C:994-1003, C:1047-1058
         long long i = (long long)s.pos;
         q.rem = s.pos - (double)i;
@@ -123,7 +148,10 @@ __device__ __forceinline__ void smp_gen(Smp &s, double x, double t, double start
             if (end > 1.0) end = 1.0;
             q.ok = (double)i < (double)s.len * end;
         }
-        const long long first = (B == 5) ? i : 1 + i;
+        long long first = (B == 5) ? i : 1 + i;
+        // playAtSpeed / playOnceAtSpeed: their bounds test already keeps `first` inside [-1, len]; playUntilAtSpeed only
+        // tests the upper end (a head driven below 0 by a negative speed passes it)
+        if constexpr (B == 6) first = 1 + (long long)smp_safe_head(s.pos, s.len);
         q.idx[0] = q.ok ? first : 0;
         q.idx[1] = q.idx[0] + 1;
         s.pos = s.pos + ((x * kChandiv) / s.step_div);
@@ -136,20 +164,22 @@ __device__ __forceinline__ void smp_gen(Smp &s, double x, double t, double start
             if (s.pos >= end) s.pos = start;
             s.pos += ((end - start) / (sr / (frequency * kChandiv)));
             q.rem = s.pos - floor(s.pos);
-            q.idx[0] = (s.pos > 0) ? (long long)((int)(floor(s.pos)) - 1) : 0;
-            q.idx[1] = (long long)s.pos;
-            q.idx[2] = (s.pos < end - 2) ? (long long)s.pos + 1 : 0;
-            q.idx[3] = (s.pos < end - 3) ? (long long)s.pos + 2 : 0;
+            const double ps = smp_safe_head(s.pos, s.len);
+            q.idx[0] = (s.pos > 0) ? (long long)((int)(floor(ps)) - 1) : 0;
+            q.idx[1] = (long long)ps;
+            q.idx[2] = (s.pos < end - 2) ? (long long)ps + 1 : 0;
+            q.idx[3] = (s.pos < end - 3) ? (long long)ps + 2 : 0;
             q.ok = false;
         } else {
             frequency *= -1.;
             if (s.pos <= start) s.pos = end;
             s.pos -= ((end - start) / (sr / (frequency * kChandiv)));
             q.rem = s.pos - floor(s.pos);
-            q.idx[0] = (s.pos > start && s.pos < end - 1) ? (long long)s.pos + 1 : 0;
-            q.idx[1] = (long long)s.pos;
-            q.idx[2] = (s.pos > start) ? (long long)s.pos - 1 : 0;
-            q.idx[3] = (s.pos > start + 1) ? (long long)s.pos - 2 : 0;
+            const double ps = smp_safe_head(s.pos, s.len);
+            q.idx[0] = (s.pos > start && s.pos < end - 1) ? (long long)ps + 1 : 0;
+            q.idx[1] = (long long)ps;
+            q.idx[2] = (s.pos > start) ? (long long)ps - 1 : 0;
+            q.idx[3] = (s.pos > start + 1) ? (long long)ps - 2 : 0;
             q.ok = true;
         }
     } else {  // C:823-880: `position` is a by-value parameter there, the head never advances
@@ -161,7 +191,7 @@ __device__ __forceinline__ void smp_gen(Smp &s, double x, double t, double start
             if (pos >= end) pos = start;
             pos += ((end - start) / ((sr) / (frequency * kChandiv)));
             q.rem = pos - floor(pos);
-            long long posl = (long long)floor(pos);
+            long long posl = (long long)floor(smp_safe_head(pos, s.len));
             q.idx[0] = ((size_t)(posl + 1) < amplen) ? posl + 1 : posl - 1;
             q.idx[1] = ((size_t)(posl + 2) < amplen) ? posl + 2 : (long long)amplen - 1;
             q.ok = false;
@@ -170,7 +200,7 @@ __device__ __forceinline__ void smp_gen(Smp &s, double x, double t, double start
             if (pos <= start) pos = end;
             pos -= ((end - start) / (sr / (frequency * kChandiv)));
             q.rem = pos - floor(pos);
-            long long posl = (long long)floor(pos);
+            long long posl = (long long)floor(smp_safe_head(pos, s.len));
             q.idx[0] = (posl - 1 >= 0) ? posl - 1 : 0;
             q.idx[1] = (posl - 2 >= 0) ? posl - 2 : 0;
             q.ok = true;

@@ -16,7 +16,7 @@
 // 88200*8-slot array in every object (H:273); here the ring is `cap` slots, any size <= cap.
 // maxiSample: one shared, read-only sample buffer per bank (L2/Infinity-Cache resident for the
 // sizes of the configs); per sample a lane gathers 1-4 neighbouring doubles (K5, 8 B out +
-// gather).  The buffer must be valid on [-1, len+1] with zero guards (see maxigpu.h).
+// gather).  The buffer must be valid on [-4, len+5] with zero guards (mxg_sample_upload's layout, mxg_smp.h).
 #include "mxg_common.h"
 #include "mxg_smp.h"
 
@@ -355,17 +355,18 @@ double *mxg_sample_upload(const double *h_samples, size_t len) {
         return nullptr;
     }
     double *base = nullptr;
-    if (check_hip(hipMalloc(&base, (len + 3) * sizeof(double)), "hipMalloc(sample)")) return nullptr;
-    if (check_hip(hipMemset(base, 0, (len + 3) * sizeof(double)), "hipMemset(sample)")) return nullptr;
-    if (len && check_hip(hipMemcpy(base + 1, h_samples, len * sizeof(double), hipMemcpyHostToDevice),
+    const size_t total = len + kSmpGuardLo + kSmpGuardHi;  // layout: mxg_smp.h
+    if (check_hip(hipMalloc(&base, total * sizeof(double)), "hipMalloc(sample)")) return nullptr;
+    if (check_hip(hipMemset(base, 0, total * sizeof(double)), "hipMemset(sample)")) return nullptr;
+    if (len && check_hip(hipMemcpy(base + kSmpGuardLo, h_samples, len * sizeof(double), hipMemcpyHostToDevice),
                          "hipMemcpy(sample)"))
         return nullptr;
-    return base + 1;
+    return base + kSmpGuardLo;
 }
 
 int mxg_sample_free(double *d_samples) {
     if (!d_samples) return MXG_OK;
-    MXG_HIP(hipFree(d_samples - 1));
+    MXG_HIP(hipFree(d_samples - kSmpGuardLo));
     return MXG_OK;
 }
 

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "mxg_common.h"
+#include "mxg_smp.h"
 
 namespace mxg {
 namespace {
@@ -121,14 +122,15 @@ double *mxg_sample_load_wav(const char *path, int channel, size_t *h_len, int32_
 
     double *base = nullptr;
     int16_t *d_raw = nullptr;
-    if (check_hip(hipMalloc(&base, (n + 3) * sizeof(double)), "hipMalloc(sample)")) return nullptr;
-    if (check_hip(hipMemset(base, 0, (n + 3) * sizeof(double)), "hipMemset(sample)")) return nullptr;
+    const size_t total = n + kSmpGuardLo + kSmpGuardHi;  // same layout as mxg_sample_upload (mxg_smp.h)
+    if (check_hip(hipMalloc(&base, total * sizeof(double)), "hipMalloc(sample)")) return nullptr;
+    if (check_hip(hipMemset(base, 0, total * sizeof(double)), "hipMemset(sample)")) return nullptr;
     if (n) {
         if (check_hip(hipMalloc(&d_raw, n * sizeof(int16_t)), "hipMalloc(wav)")) return nullptr;
         if (check_hip(hipMemcpy(d_raw, sh.data(), n * sizeof(int16_t), hipMemcpyHostToDevice), "hipMemcpy(wav)"))
             return nullptr;
         hipLaunchKernelGGL(wav_to_amplitudes_kernel, dim3(blocks_for(n)), dim3(256), 0, resolve_stream(nullptr), d_raw,
-                           n, (int)channels, channel, (long long)dataSize, base + 1);
+                           n, (int)channels, channel, (long long)dataSize, base + kSmpGuardLo);
         if (check_hip(hipGetLastError(), "wav_to_amplitudes launch")) return nullptr;
         if (check_hip(hipStreamSynchronize(resolve_stream(nullptr)), "wav_to_amplitudes")) return nullptr;
         (void)hipFree(d_raw);
@@ -138,7 +140,7 @@ double *mxg_sample_load_wav(const char *path, int channel, size_t *h_len, int32_
         h_hdr[0] = chunkSize; h_hdr[1] = subChunk1Size; h_hdr[2] = format; h_hdr[3] = channels;
         h_hdr[4] = sampleRate; h_hdr[5] = byteRate; h_hdr[6] = blockAlign; h_hdr[7] = bitsPerSample;
     }
-    return base + 1;
+    return base + kSmpGuardLo;
 }
 
 int mxg_sample_save_wav(const char *path, const double *d_samples, size_t len, const int32_t *h_hdr, void *stream) {

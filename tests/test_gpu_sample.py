@@ -228,3 +228,24 @@ def test_sample_play_with_phasor(mx, port, N):
     assert_bits_equal(o, e, "playWithPhasor")
     assert_bits_equal(bank.phasor_prev.numpy(), epp)
     assert np.array_equal(bank.phasor_first.numpy(), epf)
+
+
+def test_players_outside_the_defined_range_stay_inside_the_buffer(mx):
+    """play4 with a step much longer than its loop, playLoop with end > 1, heads uploaded far outside the sample: the
+    reference indexes outside its vector there (undefined).  The device's gathers are clamped to the uploaded buffer and
+    its guard elements, so such a patch reads zeros instead of memory beyond the allocation: finite, bounded output."""
+    rng = np.random.default_rng(8)
+    V, N = 4096, 300
+    for Ls in (509, 4093):                    # (len + 3) * 8 bytes ends right on a 4 KiB page
+        smp = rng.uniform(-1, 1, Ls)
+        bank = mx.maxiSampleBank(V)
+        bank.setSample(smp)
+        bank.position.upload(rng.uniform(-50.0 * Ls, 50.0 * Ls, V))
+        freq = rng.uniform(500, 20000, V) * np.where(np.arange(V) % 2, -1.0, 1.0)
+        o = bank.render(7, N, a=freq, start=np.full(V, 2.0), end=np.full(V, Ls - 1.0)).numpy()
+        assert np.isfinite(o).all() and np.abs(o).max() < 8.0
+        bank.position.upload(rng.uniform(0, Ls, V))
+        o = bank.render(2, N, start=np.zeros(V), end=np.full(V, 40.0)).numpy()
+        assert np.isfinite(o).all() and np.abs(o).max() <= 1.0
+        o = bank.render(4, N, a=rng.uniform(-3000, 3000, V)).numpy()
+        assert np.isfinite(o).all() and np.abs(o).max() <= 3.0
