@@ -26,17 +26,22 @@ namespace {
 template <int MODE>
 __global__ void __launch_bounds__(256) delay_kernel(size_t V, size_t N, const double *__restrict__ in,
                              const int32_t *__restrict__ size, const double *__restrict__ feedback,
-                             const int32_t *__restrict__ position, double *__restrict__ mem,
+                             const int32_t *__restrict__ position, double *__restrict__ mem, int cap,
                              int32_t *__restrict__ phase_io, double *__restrict__ out) {
     const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
     int ph = phase_io[v];
-    const int sz = size[v];
+    // size as the ring sees it: the reference's `phase >= size` tests (C:421, C:432-433) with size <= 0 reset the phase
+    // on every sample (size 0 here), and a size beyond the bank's capacity -- the reference's own array is 705 600 slots,
+    // a bank's is `cap` -- is held to it.  The tests are unsigned so that an uploaded negative phase or position, which
+    // the reference would use as a negative array index, restarts at slot 0 instead of writing outside the ring.
+    int sz = size[v];
+    sz = sz < 0 ? 0 : (sz > cap ? cap : sz);
     const double fb = feedback[v];
     int pos = 0;
     if constexpr (MODE == 1) {
         pos = position[v];
-        if (pos >= sz) pos = 0;  // C:433
+        if ((unsigned)pos >= (unsigned)sz) pos = 0;  // C:433
     }
     const double *ip = in + v;
     double *op = out + v;
@@ -61,7 +66,7 @@ __global__ void __launch_bounds__(256) delay_kernel(size_t V, size_t N, const do
                     const size_t nn = k * U + i;
                     const size_t mm = (nn < N) ? nn : N - 1;  // clamped: no branch
                     xi[i] = ip[mm * V];
-                    if (ph >= sz) ph = 0;  // C:421
+                    if ((unsigned)ph >= (unsigned)sz) ph = 0;  // C:421
                     sl[i] = ph;
                     c[i] = m[(size_t)ph * V];
                     ph += 1;
@@ -99,7 +104,7 @@ __global__ void __launch_bounds__(256) delay_kernel(size_t V, size_t N, const do
     }
     for (; n < N; n++) {
         double input = *ip;
-        if (ph >= sz) ph = 0;  // C:421 / C:432
+        if ((unsigned)ph >= (unsigned)sz) ph = 0;  // C:421 / C:432
         double *slot = m + (size_t)ph * V;
         double cur = *slot;
         double o;
@@ -334,17 +339,17 @@ int mxg_delay_render(int mode, size_t V, size_t N, const double *d_in, const int
     MXG_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (dl) or 1 (dlFromPosition)");
     MXG_REQUIRE(d_in && d_size && d_feedback && d_mem && d_phase && d_out, "null device pointer");
     MXG_REQUIRE(mode == 0 || d_position, "dlFromPosition needs d_position");
-    MXG_REQUIRE(cap > 0, "cap must be > 0");
+    MXG_REQUIRE(cap > 0 && cap <= 0x7fffffff, "cap must be in 1 .. 2^31-1");
     if (V == 0 || N == 0) return MXG_OK;
     int block = tune_get("voice_block");
     if (block > 256) block = 256;  // delay_kernel is compiled for <= 256 lanes per workgroup
     hipStream_t st = resolve_stream(stream);
     if (mode == 0)
         hipLaunchKernelGGL((delay_kernel<0>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_size,
-                           d_feedback, d_position, d_mem, d_phase, d_out);
+                           d_feedback, d_position, d_mem, (int)cap, d_phase, d_out);
     else
         hipLaunchKernelGGL((delay_kernel<1>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_size,
-                           d_feedback, d_position, d_mem, d_phase, d_out);
+                           d_feedback, d_position, d_mem, (int)cap, d_phase, d_out);
     return check_hip(hipGetLastError(), "delay_kernel launch");
 }
 

@@ -249,3 +249,44 @@ def test_players_outside_the_defined_range_stay_inside_the_buffer(mx):
         assert np.isfinite(o).all() and np.abs(o).max() <= 1.0
         o = bank.render(4, N, a=rng.uniform(-3000, 3000, V)).numpy()
         assert np.isfinite(o).all() and np.abs(o).max() <= 3.0
+
+
+def test_delay_sizes_and_phases_outside_the_ring(mx, port):
+    """size <= 0 is defined in the reference (`phase >= size` resets the phase on every sample: slot 0 only) and must
+    match the oracle.  A size beyond the bank's capacity, or an uploaded negative / huge phase or position, would index
+    outside the ring: the kernel holds size to the capacity and restarts such a phase at slot 0 -- outputs stay finite,
+    phases inside the ring, and the voices next to them are untouched."""
+    rng = np.random.default_rng(33)
+    V, N, cap = 512, 200, 64
+    x = rng.uniform(-1, 1, (N, V))
+    fb = rng.uniform(0, 0.9, V)
+    size = rng.integers(1, cap + 1, V).astype(np.int32)
+    size[::8] = 0
+    size[1::8] = -5
+    bank = mx.maxiDelaylineBank(V, cap)
+    o = bank.dl(mx.DeviceBuffer.from_numpy(x), size, fb).numpy()
+    # `phase >= size` (C:421) is always true for size <= 0, so a negative size behaves like 0 (the port takes 0 .. cap)
+    e, emem, eph = port.delay(0, x, np.maximum(size, 0), fb, cap)
+    assert_bits_equal(o, e, "dl with size <= 0")
+    assert_bits_equal(bank.memory.numpy(), emem, "mem")
+    # undefined in the reference: must stay inside the ring
+    wild = rng.integers(1, cap + 1, V).astype(np.int32)
+    wild[::4] = cap + 1000
+    wild[1::4] = 2 ** 31 - 1
+    bank = mx.maxiDelaylineBank(V, cap)
+    ph = np.zeros(V, np.int32)
+    ph[::3] = -7
+    ph[1::3] = 2 ** 30
+    bank.phase.upload(ph)
+    pos = rng.integers(-(2 ** 31), 2 ** 31 - 1, V).astype(np.int32)
+    for mode_call in (lambda: bank.dl(mx.DeviceBuffer.from_numpy(x), wild, fb),
+                      lambda: bank.dlFromPosition(mx.DeviceBuffer.from_numpy(x), wild, fb, pos)):
+        o = mode_call().numpy()
+        assert np.isfinite(o).all()
+        p = bank.phase.numpy()
+        assert (p >= 0).all() and (p <= cap).all()
+    sane = (np.arange(V) % 4 >= 2) & (np.arange(V) % 3 == 2)           # voices with an in-range size and phase 0
+    e, _, _ = port.delay(0, np.ascontiguousarray(x[:, sane]), wild[sane], fb[sane], cap)
+    bank2 = mx.maxiDelaylineBank(V, cap); bank2.phase.upload(ph)
+    o = bank2.dl(mx.DeviceBuffer.from_numpy(x), wild, fb).numpy()
+    assert_bits_equal(o[:, sane], e, "in-range voices beside the wild ones")
