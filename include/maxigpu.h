@@ -407,8 +407,10 @@ int mxg_grain_plan_window(const mxg_grain_plan *plan, double *h_window); /* retu
  * stream (NULL = 0): the reference draws them from the process-wide rand() stream, which a bank
  * cannot reproduce.  State, in/out: d_st = [4][S] position, looper, randomOffset, rand cursor
  * (setPosition(p) == position = clamp(p*len, 0, len-1), :335-338); d_gst = [4][8][S]: the live
- * grains in creation order: pos, inc, sampleIdx, sampleDur (0 = empty slot).  Synchronous on
- * `stream` (it reports > 8 live grains / exhausted d_rnd as MXG_ERR_INVALID). */
+ * grains in creation order: pos, inc, sampleIdx, sampleDur (0 = empty slot).  A live grain must be
+ * one this plan made (same sampleDur: a bank has one window table per plan, so let grains finish -- or
+ * clear d_gst -- before switching to a plan of another grain length).  Synchronous on `stream` (it
+ * reports > 8 live grains, an exhausted d_rnd or such a foreign / corrupt grain as MXG_ERR_INVALID). */
 int mxg_granular_render(const mxg_grain_plan *plan, int mode, size_t S, size_t T, const double *d_samples,
                         size_t len, int overlaps, const double *d_a, const double *d_b,
                         const double *d_posmod, const int32_t *d_rnd, size_t R, double *d_st, double *d_gst,

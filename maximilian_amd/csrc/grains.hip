@@ -181,6 +181,15 @@ __device__ __forceinline__ SchedConst sched_const(size_t s, size_t S, size_t len
     return c;
 }
 
+// A live grain handed in through d_gst must be one this plan could have made: the plan's duration (a grain keeps its own
+// window in the reference; a bank has one window table per plan, so grains of another grain length have to finish -- or
+// d_gst be cleared -- before the plan changes), a window index inside it, a position inside the sample and a finite
+// step.  Anything else (NaN fails every comparison) is refused with MXG_ERR_INVALID instead of being used as an index.
+__device__ __forceinline__ bool carried_grain_ok(double pos, double inc, double idx, double dur, double dlen,
+                                                 int sampleDur) {
+    return dur == (double)sampleDur && idx >= 0.0 && idx < dur && pos >= 0.0 && pos <= dlen && fabs(inc) <= dlen;
+}
+
 struct GrainArgs {
     size_t S, T, len, R;
     const double *amp, *window, *a, *b, *posMod;
@@ -220,6 +229,15 @@ __global__ __launch_bounds__(64) void granular_kernel(GrainArgs A) {
         if (gdur[k]) tail = k + 1;
     }
     int failed = 0;
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) {
+        const double dur = A.gst[(3 * kSlots + k) * S + s];
+        if (dur != 0.0 && !carried_grain_ok(gpos[k], ginc[k], A.gst[(2 * kSlots + k) * S + s], dur, (double)A.len,
+                                            A.sampleDur)) {
+            failed = 4;
+            gdur[k] = 0;
+        }
+    }
     double *op = A.out + s;
     for (size_t n = 0; n < A.T; n++) {
         // ---- scheduler (sched_step: the reference's play() up to the addGrain)
@@ -548,11 +566,17 @@ __global__ __launch_bounds__(64) void granular_render_kernel(RenderArgs A) {
     };
     // (1) carried-in grains still alive at n0, oldest first
     for (int k = 0; k < kSlots; k++) {
-        const int dur = (int)A.gst_in[(3 * kSlots + k) * S + s];
-        if (!dur) continue;
+        const double ddur = A.gst_in[(3 * kSlots + k) * S + s];
+        if (ddur == 0.0) continue;
+        const double inc = A.gst_in[(1 * kSlots + k) * S + s];
+        if (!carried_grain_ok(A.gst_in[(0 * kSlots + k) * S + s], inc, A.gst_in[(2 * kSlots + k) * S + s], ddur, dlen,
+                              A.sampleDur)) {
+            failed = 4;
+            continue;
+        }
+        const int dur = (int)ddur;
         const int idx = (int)A.gst_in[(2 * kSlots + k) * S + s];
         if ((long long)idx + (long long)n0 >= dur) continue;  // finished before this chunk
-        const double inc = A.gst_in[(1 * kSlots + k) * S + s];
         const double pos = grain_advance(A.gst_in[(0 * kSlots + k) * S + s], inc, dlen, (int)n0);
         push(pos, inc, idx + (int)n0, dur);
     }
@@ -1026,13 +1050,17 @@ __global__ __launch_bounds__(64) void granular_unit_state_kernel(UnitArgs A) {
 }
 
 // eligibility of the carried-in grains for K8c: every live one must have inc = +-1 and an integer position
-__global__ void granular_unit_check_kernel(size_t S, const double *__restrict__ gst, int *flag) {
+__global__ void granular_unit_check_kernel(size_t S, const double *__restrict__ gst, double dlen, int sampleDur,
+                                           int *flag) {
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     bool bad = false;
     for (int k = 0; k < kSlots; k++) {
         if (gst[(3 * kSlots + k) * S + s] == 0.0) continue;
         const double pos = gst[(0 * kSlots + k) * S + s], inc = gst[(1 * kSlots + k) * S + s];
+        // (a grain the plan could not have made goes to the general path, which refuses it)
+        if (!carried_grain_ok(pos, inc, gst[(2 * kSlots + k) * S + s], gst[(3 * kSlots + k) * S + s], dlen, sampleDur))
+            bad = true;
         if (!(inc == 1.0 || inc == -1.0) || pos != floor(pos) || pos < 0.0 || pos > 9.0e15) bad = true;
         if (gst[(3 * kSlots + k) * S + s] >= 32000.0) bad = true;  // durations are packed into 15 bits by K8c
     }
@@ -1160,7 +1188,7 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
             if (inc == 1.0) {
                 MXG_HIP(hipMemsetAsync(g_err + 1, 0, sizeof(int), st));
                 hipLaunchKernelGGL(granular_unit_check_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, S,
-                                   (const double *)d_gst, g_err + 1);
+                                   (const double *)d_gst, (double)len, A.sampleDur, g_err + 1);
                 int bad = 1;
                 MXG_HIP(hipMemcpyAsync(&bad, g_err + 1, sizeof(int), hipMemcpyDeviceToHost, st));
                 MXG_HIP(hipStreamSynchronize(st));
@@ -1266,6 +1294,10 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
     if (herr == 1) return fail(MXG_ERR_INVALID, "mxg_granular_render: more than 8 grains alive in a stream");
     if (herr == 2) return fail(MXG_ERR_INVALID, "mxg_granular_render: d_rnd exhausted (R too small)");
     if (herr == 3) return fail(MXG_ERR_INVALID, "mxg_granular_render: internal spawn list overflow");
+    if (herr == 4)
+        return fail(MXG_ERR_INVALID,
+                    "mxg_granular_render: d_gst holds a live grain this plan could not have made (another grain length, or "
+                    "an index/position outside the window/sample); let live grains finish or clear d_gst first");
     return MXG_OK;
 }
 

@@ -304,3 +304,37 @@ def test_scheduler_position_stuck_on_the_wrap_limit(mx, port):
     assert_bits_equal(bank.state.numpy(), est, "scheduler state")
     assert_bits_equal(bank.grains.numpy(), egst, "grains")
     assert_bits_equal(o, e, "output")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_foreign_or_corrupt_live_grains_are_refused(mx, mode):
+    """d_gst is caller-visible state.  A live grain made by a plan of another grain length (its window index would run
+    past this plan's window table), a negative window index, a position outside the sample or a NaN step are refused
+    with MXG_ERR_INVALID by every render path instead of being used as array indices."""
+    rng = np.random.default_rng(12)
+    Ls, S, T = 20000, 96, 700
+    smp = rng.uniform(-1, 1, Ls)
+    speed = rng.uniform(0.5, 1.5, S)
+    dur = int(0.05 * 44100)
+    good = np.zeros((4, 8, S))
+    good[:, 0, :] = np.array([100.0, 1.0, 10.0, dur])[:, None]        # one live grain per stream, this plan's
+    for what, row, value in (("another grain length", 3, 4410.0), ("negative window index", 2, -3.0),
+                             ("window index past the end", 2, dur + 5.0), ("position outside the sample", 0, 3.0 * Ls),
+                             ("NaN step", 1, np.nan)):
+        for unit in (1, 0):
+            prev = mx.lib().mxg_tune(b"grain_unit", unit)
+            try:
+                bank = make_bank(mx, mode, "hann", smp, S)
+                g = good.copy()
+                g[row, 0, 17] = value
+                bank.grains.upload(g)
+                with pytest.raises(mx.MaxiGpuError, match="could not have made"):
+                    if mode == 0:
+                        bank.play(speed, 0.05, 4, T)
+                    else:
+                        bank.play(speed, speed, 0.05, 4, T)
+                bank.grains.upload(good)                               # the same call with a clean state works
+                o = (bank.play(speed, 0.05, 4, T) if mode == 0 else bank.play(speed, speed, 0.05, 4, T)).numpy()
+                assert np.isfinite(o).all(), what
+            finally:
+                mx.lib().mxg_tune(b"grain_unit", prev)
