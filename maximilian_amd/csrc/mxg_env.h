@@ -1,8 +1,15 @@
 // mxg_env.h -- maxiEnv (src/maximilian.cpp:1319-1494) per-lane state and tick functions, shared by the
 // envelope / fused-voice kernels (voice.hip) and the sampler kernel (sampler.hip).
 #pragma once
+#if defined(__HIPCC__)
 #include "mxg_common.h"
 #include "mxg_gate.h"
+#else  // host build of the same text (tests/host_env.cpp: state machine and steady-state paths against the oracle)
+#include <stddef.h>
+#include <stdint.h>
+#define __device__
+#define __forceinline__ inline
+#endif
 
 namespace mxg {
 namespace {

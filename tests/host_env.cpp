@@ -1,0 +1,28 @@
+// tests/host_env.cpp -- maxiEnv as the device runs it per lane (maximilian_amd/csrc/mxg_env.h: the predicated state machine
+// env_adsr / env_ar and the steady-state sustain / release ticks with their entry tests), compiled for the host.
+// tests/test_env_host.py compares it with the oracle from arbitrary states (any flag values, any amplitude).
+#include "mxg_env.h"
+
+using namespace mxg;
+
+// fast = 1: per sample, take the steady-state tick whenever its entry test holds (what a wavefront does when all its lanes
+// agree); fast = 0: always the state machine.  Both must give the oracle's bits.
+extern "C" int env_host(int mode, int fast, size_t V, size_t N, const double *x, const int32_t *trig, int tpv,
+                        const double *par, const int64_t *holdtime, double *dst, int64_t *ist, double *out) {
+    for (size_t v = 0; v < V; v++) {
+        Env e;
+        env_load(e, V, v, par, holdtime, dst, ist);
+        for (size_t n = 0; n < N; n++) {
+            const double in = x ? x[n * V + v] : 1.0;
+            const int t = tpv ? trig[n * V + v] : trig[n];
+            double o;
+            if (mode == 1) o = env_ar(e, in, t);
+            else if (fast && t == 1 && env_in_sustain(e)) o = env_sustain_tick(e, in);
+            else if (fast && t != 1 && env_in_release(e)) o = env_release_tick(e, in);
+            else o = env_adsr(e, in, t);
+            out[n * V + v] = o;
+        }
+        env_store(e, V, v, dst, ist);
+    }
+    return 0;
+}
