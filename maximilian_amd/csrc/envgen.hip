@@ -14,6 +14,7 @@
 
 #include "mxg_common.h"
 #include "mxg_gate.h"
+#include "mxg_envgen.h"
 
 namespace mxg {
 namespace {
@@ -37,13 +38,6 @@ struct EgArgs {
     double *out;
 };
 
-__device__ __forceinline__ bool on_zx(double &prev, bool &first, double input) {  // H:569-579
-    const bool zx = (prev <= 0.0 || first) && input > 0;
-    prev = input;
-    first = false;
-    return zx;
-}
-
 template <bool TPV>
 // trig / out are separate __restrict__ parameters (not members of A): only then may hipcc read the shared gate
 // with scalar loads; as vector loads they sit in the same in-order queue as the output stores and drain it.
@@ -56,7 +50,7 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__r
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if ((gid & ~(size_t)63) >= V) return;  // the whole wavefront is past the bank
     const size_t v = live_voice(gid, V);   // surplus lanes shadow voice V-1 (mxg_gate.h)
-    enum { WAITING = 0, TRIGGERED = 1, HOLDING = 2 };
+    constexpr int WAITING = EG_WAITING, HOLDING = EG_HOLDING;
     double envval = A.dst[v], currentlevel = A.dst[V + v];
     double tprev = A.dst[2 * V + v], hprev = A.dst[3 * V + v], rprev = A.dst[4 * V + v];
     long long phase = A.ist[v], counter = A.ist[3 * V + v];
@@ -129,59 +123,11 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__r
             double trigger;
             if constexpr (TPV) trigger = tc[i];
             else trigger = lane_value(gcur.g[i], cc);
-            int entry = state;  // the switch's fall-through, made explicit
-            if (entry == WAITING) {  // H:2279-2292
-                if (on_zx(tprev, tfirst, trigger)) {
-                    state = TRIGGERED;
-                    nxc = false;
-                    entry = TRIGGERED;
-                } else {
-                    entry = -1;
-                }
-            }
-            if (entry == TRIGGERED) {  // H:2293-2329
-                const double *cs = s_tab + 6 * phase;
-                if (on_zx(hprev, hfirst, -trigger)) nxc = true;
-                if (cs[5] != 0) {
-                    state = HOLDING;
-                    entry = HOLDING;
-                } else {
-                    const double curve = cs[3];
-                    double val = (curve == 1.0) ? currentlevel : pow(currentlevel, curve);
-                    val = (1.0 < val) ? 1.0 : val;  // linlin: max(min(val, inMax), inMin)
-                    val = (val < 0.0) ? 0.0 : val;
-                    envval = ((val - 0.0) / (1.0 - 0.0) * (cs[1] - cs[0])) + cs[0];
-                    counter++;
-                    if (counter == (long long)cs[4]) {
-                        counter = 0;
-                        currentlevel = 0;
-                        phase++;
-                    } else {
-                        currentlevel += cs[2];
-                    }
-                    if (retrigger && on_zx(rprev, rfirst, trigger)) {
-                        nxc = false;
-                        counter = 0; currentlevel = 0; phase = 0; state = TRIGGERED;  // reset() H:2402-2410
-                    }
-                    entry = -1;
-                }
-            }
-            if (entry == HOLDING) {  // H:2330-2348
-                if (on_zx(hprev, hfirst, -trigger)) nxc = true;
-                if (nxc) {
-                    state = TRIGGERED;
-                    phase++;
-                }
-                if (retrigger && on_zx(rprev, rfirst, trigger)) {
-                    nxc = false;
-                    counter = 0; currentlevel = 0; phase = 0; state = TRIGGERED;
-                }
-            }
-            if (phase == S) {  // H:2349-2355: reset() / resetAndArm()
-                counter = 0; currentlevel = 0;
-                phase = 0;
-                state = loop ? TRIGGERED : WAITING;
-            }
+            EgState e = {envval, currentlevel, tprev, hprev, rprev, tfirst, hfirst, rfirst, phase, counter, state, nxc};
+            envgen_tick(e, s_tab, S, loop, retrigger, trigger);
+            envval = e.envval; currentlevel = e.currentlevel; tprev = e.tprev; hprev = e.hprev; rprev = e.rprev;
+            tfirst = e.tfirst; hfirst = e.hfirst; rfirst = e.rfirst; phase = e.phase; counter = e.counter;
+            state = e.state; nxc = e.nxc;
             *op = envval;
             op += V;
         }
