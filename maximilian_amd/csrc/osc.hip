@@ -15,6 +15,7 @@
 #include "mxg_common.h"
 #include "maxi_tables.h"
 #include "mxg_sincos.h"
+#include "mxg_osc.h"
 
 namespace mxg {
 
@@ -23,148 +24,6 @@ namespace {
 // Device-resident copies of the two static tables (with their guard elements).
 __device__ const double MAXI_SINE_TAB_D[MAXI_SINE_TAB_LEN] = MAXI_SINE_TAB_INIT;
 __device__ const double MAXI_TRANS_TAB_D[MAXI_TRANS_TAB_LEN] = MAXI_TRANS_TAB_INIT;
-
-// Per-voice values that depend only on (frequency, p1, p2): hoisted out of the sample loop
-// when the frequency is block-constant.  Each is the exact sub-expression of the reference.
-struct OscPre {
-    double inc;  // phase increment
-    double k;    // sawn: 8820.22/frequency            (C:346)
-    double p1;   // pulse: clamped duty (C:304-305); phasorBetween: startphase
-    double p2;   // phasorBetween: endphase
-};
-
-template <int WF>
-__device__ __forceinline__ OscPre osc_pre(double f, double sr, double p1, double p2) {
-    OscPre q;
-    q.k = 0.0;
-    q.p1 = p1;
-    q.p2 = p2;
-    if constexpr (WF == MXG_OSC_SINEBUF) {
-        q.inc = 512. / (sr / (f * kChandiv));  // C:269
-    } else if constexpr (WF == MXG_OSC_SINEBUF4) {
-        q.inc = 512. / (sr / (f));  // C:241
-    } else if constexpr (WF == MXG_OSC_SAW) {
-        q.inc = (1. / (sr / (f))) * 2.0;  // C:337
-    } else if constexpr (WF == MXG_OSC_SAWN) {
-        q.inc = (1. / (sr / (f)));  // C:345
-        q.k = (8820.22 / f);        // C:346
-    } else if constexpr (WF == MXG_OSC_PHASORBETWEEN) {
-        q.inc = ((p2 - p1) / (sr / (f)));  // C:328
-    } else if constexpr (WF == MXG_OSC_PULSE) {
-        double duty = p1;
-        if (duty < 0.) duty = 0;  // C:304
-        if (duty > 1.) duty = 1;  // C:305
-        q.p1 = duty;
-        q.inc = (1. / (sr / (f)));  // C:307
-    } else {
-        q.inc = (1. / (sr / (f)));  // C:232, 280, 289, 297, 314, 365
-    }
-    return q;
-}
-
-// One sample of one voice.  `phase`/`hold` are the members `phase`/`output` (H:173,176).
-// s_sine[i+1] == sineBuffer[i] (i=-1..513), s_trans[i] == transition[i] (i=0..1001).
-template <int WF>
-__device__ __forceinline__ double osc_tick(double &phase, double &hold, const OscPre &q,
-                                           const double *s_sine, const double *s_trans) {
-    if constexpr (WF == MXG_OSC_SINEWAVE) {  // C:228-235
-        double r = sin_2pi_phase(phase);
-        hold = r;
-        if (phase >= 1.0) phase -= 1.0;
-        phase += q.inc;
-        return r;
-    } else if constexpr (WF == MXG_OSC_COSWAVE) {  // C:276-283
-        double r = cos_2pi_phase(phase);
-        hold = r;
-        if (phase >= 1.0) phase -= 1.0;
-        phase += q.inc;
-        return r;
-    } else if constexpr (WF == MXG_OSC_PHASOR) {  // C:285-291
-        double r = phase;
-        hold = r;
-        if (phase >= 1.0) phase -= 1.0;
-        phase += q.inc;
-        return r;
-    } else if constexpr (WF == MXG_OSC_SAW) {  // C:333-340
-        double r = phase;
-        hold = r;
-        if (phase >= 1.0) phase -= 2.0;
-        phase += q.inc;
-        return r;
-    } else if constexpr (WF == MXG_OSC_TRIANGLE) {  // C:362-373
-        if (phase >= 1.0) phase -= 1.0;
-        phase += q.inc;
-        double r;
-        if (phase <= 0.5) {
-            r = (phase - 0.25) * 4;
-        } else {
-            r = ((1.0 - phase) - 0.25) * 4;
-        }
-        hold = r;
-        return r;
-    } else if constexpr (WF == MXG_OSC_SQUARE) {  // C:293-300 (output held at phase==0.5)
-        if (phase < 0.5) hold = -1;
-        if (phase > 0.5) hold = 1;
-        if (phase >= 1.0) phase -= 1.0;
-        phase += q.inc;
-        return hold;
-    } else if constexpr (WF == MXG_OSC_PULSE) {  // C:302-311 (output held at phase==duty)
-        if (phase >= 1.0) phase -= 1.0;
-        phase += q.inc;
-        if (phase < q.p1) hold = -1.;
-        if (phase > q.p1) hold = 1.;
-        return hold;
-    } else if constexpr (WF == MXG_OSC_IMPULSE) {  // C:312-319 (member `output` untouched)
-        if (phase >= 1.0) phase -= 1.0;
-        double r = phase < q.inc ? 1.0 : 0.0;
-        phase += q.inc;
-        return r;
-    } else if constexpr (WF == MXG_OSC_PHASORBETWEEN) {  // C:321-330
-        double r = phase;
-        hold = r;
-        if (phase < q.p1) phase = q.p1;
-        if (phase >= q.p2) phase = q.p1;
-        phase += q.inc;
-        return r;
-    } else if constexpr (WF == MXG_OSC_SINEBUF) {  // C:266-274
-        phase += q.inc;
-        if (phase >= 511) phase -= 512;
-        double remainder = phase - floor(phase);
-        int i = (int)phase;  // (long)phase: truncation toward zero; |phase| < 2^31 here
-        double r = (1 - remainder) * s_sine[1 + i + 1] + remainder * s_sine[2 + i + 1];
-        hold = r;
-        return r;
-    } else if constexpr (WF == MXG_OSC_SINEBUF4) {  // C:237-264
-        phase += q.inc;
-        if (phase >= 511) phase -= 512;
-        double remainder = phase - floor(phase);
-        int i = (int)phase;
-        int ia = (phase == 0) ? 512 : i - 1;  // C:245-256; index -1 is the 0.0 guard
-        double a = s_sine[ia + 1];
-        double b = s_sine[i + 1];
-        double c = s_sine[i + 1 + 1];
-        double d = s_sine[i + 2 + 1];
-        double a1 = 0.5 * (c - a);
-        double a2 = a - 2.5 * b + 2. * c - 0.5 * d;
-        double a3 = 0.5 * (d - a) + 1.5 * (b - c);
-        double r = ((a3 * remainder + a2) * remainder + a1) * remainder + b;
-        hold = r;
-        return r;
-    } else {  // MXG_OSC_SAWN  C:342-359
-        if (phase >= 0.5) phase -= 1.0;
-        phase += q.inc;
-        double temp = q.k * phase;
-        if (temp < -0.5) temp = -0.5;
-        if (temp > 0.5) temp = 0.5;
-        temp *= 1000.0;
-        temp += 500.0;
-        double remainder = temp - floor(temp);
-        int i = (int)temp;
-        double r = ((1.0 - remainder) * s_trans[i] + remainder * s_trans[1 + i]) - phase;
-        hold = r;
-        return r;
-    }
-}
 
 template <int WF>
 constexpr bool uses_sine() {
