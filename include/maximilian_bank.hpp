@@ -53,7 +53,10 @@ public:
         p_ = static_cast<T *>(mxg_malloc(n * sizeof(T)));
         if (!p_) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
         n_ = n;
-        if (zero && n) check(mxg_memset(p_, 0, n * sizeof(T), nullptr), "mxg_memset");
+        if (zero && n) {  // complete before any launch on any stream can touch the array
+            check(mxg_memset(p_, 0, n * sizeof(T), nullptr), "mxg_memset");
+            check(mxg_stream_sync(nullptr), "mxg_stream_sync");
+        }
     }
     void upload(const T *h, size_t n, size_t offset = 0) {
         check(mxg_memcpy_h2d(p_ + offset, h, n * sizeof(T), nullptr), "mxg_memcpy_h2d");

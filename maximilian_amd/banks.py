@@ -22,7 +22,13 @@ FILTER_KINDS = {"lores": 0, "hires": 1, "bandpass": 2, "lopass": 3, "hipass": 4}
 
 
 class DeviceBuffer:
-    """A typed device allocation (hipMalloc via mxg_malloc) with numpy upload/download."""
+    """A typed device allocation (hipMalloc via mxg_malloc) with numpy upload/download.
+
+    Stream contract: banks launch on their own `stream`, while allocation-time zeroing and the
+    copies here go through the library's default stream.  So the zeroing is complete before the
+    constructor returns, upload() is synchronous (mxg_memcpy_h2d waits), and numpy() waits for ALL
+    outstanding device work (mxg_sync) before it copies -- a block a kernel on any stream is still
+    writing is never read half-finished, and a first render never races the zero fill."""
 
     def __init__(self, shape, dtype=np.float64, zero=True):
         self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
@@ -33,6 +39,7 @@ class DeviceBuffer:
             raise MemoryError("mxg_malloc(%d): %s" % (self.nbytes, lib().mxg_last_error().decode()))
         if zero and self.nbytes:
             check(lib().mxg_memset(self.ptr, 0, self.nbytes, None), "mxg_memset")
+            check(lib().mxg_stream_sync(None), "mxg_stream_sync")
 
     @classmethod
     def from_numpy(cls, a, dtype=None):
@@ -51,6 +58,7 @@ class DeviceBuffer:
     def numpy(self):
         out = np.empty(self.shape, self.dtype)
         if self.nbytes:
+            check(lib().mxg_sync(), "mxg_sync")  # the producer may have run on any stream
             check(lib().mxg_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, None), "mxg_memcpy_d2h")
         return out
 

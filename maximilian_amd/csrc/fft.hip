@@ -128,11 +128,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fft_generic_kernel(
     FftOut out) {
     extern __shared__ float2 s_dyn[];
     const int half = fftSize >> 1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     float2 *X = s_dyn + (size_t)wave * (half + (half >> 5) + 1);
     auto P = [](int idx) { return idx + (idx >> 5); };  // one pad slot per 32: breaks pow-2 strides
-    for (size_t f = (size_t)blockIdx.x * kWavesPerBlock + wave; f < nframes;
-         f += (size_t)gridDim.x * kWavesPerBlock) {
+    for (size_t f = (size_t)blockIdx.x * nwaves + wave; f < nframes; f += (size_t)gridDim.x * nwaves) {
         const float *x = signal + f * frame_stride;
         for (int i = lane; i < half; i += 64) {
             float2 v;
@@ -596,8 +595,13 @@ int mxg_fft_batch(const mxg_fft_plan *p, const float *d_signal, size_t frame_str
 #undef MXG_FFT_LAUNCH2
 #undef MXG_FFT_LAUNCH
     } else {
-        size_t lds = sizeof(float2) * kWavesPerBlock * (p->half + (p->half >> 5) + 1);
-        hipLaunchKernelGGL(fft_generic_kernel, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, st,
+        // one LDS frame per wave: 4 waves up to 2048 points, 2 at 4096, 1 at 8192 keeps a workgroup under the
+        // 64 KB a launch gets without raising hipFuncAttributeMaxDynamicSharedMemorySize
+        const int waves = p->fftSize <= 2048 ? kWavesPerBlock : (p->fftSize <= 4096 ? 2 : 1);
+        const size_t lds = sizeof(float2) * waves * (p->half + (p->half >> 5) + 1);
+        blocks = (nframes + waves - 1) / waves;
+        if (blocks > cap * (kWavesPerBlock / waves)) blocks = cap * (kWavesPerBlock / waves);
+        hipLaunchKernelGGL(fft_generic_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, st,
                            d_signal, frame_stride, nframes, p->fftSize, p->numBits, p->d_window, p->d_tw,
                            p->d_post, out);
     }

@@ -1103,6 +1103,10 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         return fail(MXG_ERR_INVALID,
                     "mxg_granular_render: d_gst holds a live grain this plan could not have made (another grain length, or "
                     "an index/position outside the window/sample); let live grains finish or clear d_gst first");
+    if (herr == 5)
+        return fail(MXG_ERR_INVALID,
+                    "mxg_granular_render: a grain was born with a NaN/Inf step or one longer than the sample (|speed| too "
+                    "large for this sample length); its reads would leave the buffer");
     return MXG_OK;
 }
 

@@ -39,8 +39,11 @@ struct SchedState {
 };
 
 // maxiGrain ctor (L/maxiGrains.h:160-181): where the grain starts and its per-sample increment
+// A step the reference could not survive either -- NaN/Inf, or longer than the sample so that the single wrap of
+// maxiGrain::play (:219-224) leaves pos outside [0, len) and the reads go out of bounds -- is refused: failed = 5,
+// the grain is born with inc = 0 (it stays inside the buffer) and the launch reports MXG_ERR_INVALID.
 __device__ __forceinline__ void grain_birth(const SchedConst &c, double p01, const double grainSpeed,
-                                            double &pos0, double &inc) {
+                                            double &pos0, double &inc, int &failed) {
     p01 = 1.0 < p01 ? 1.0 : p01;  // max(min(1.0, .), 0.0)
     p01 = p01 < 0.0 ? 0.0 : p01;
     const double startPos = floor(c.dlen * p01);  // (unsigned long)(len*pos), pos >= 0
@@ -49,6 +52,10 @@ __device__ __forceinline__ void grain_birth(const SchedConst &c, double p01, con
     const double frequency = (1.0 / c.grainLength) * grainSpeed;
     pos0 = frequency > 0 ? startPos : endPos;
     inc = (frequency != 0) ? (double)c.sampleDur / (c.sr / frequency) : 0.0;
+    if (!(fabs(inc) <= c.dlen)) {
+        failed = 5;
+        inc = 0.0;
+    }
 }
 
 // `randomOffset = rand() % 10` (:352 / :525) from the caller-supplied draws
@@ -68,7 +75,7 @@ __device__ __forceinline__ void sched_spawn01(SchedState &q, const SchedConst &c
                                               int &failed) {
     q.looper -= q.thr;
     const double grainSpeed = MODE == 0 ? (c.speed > 0 ? 1.0 : -1.0) : c.speed;  // :350
-    grain_birth(c, (q.position / c.dlen) + c.pm, grainSpeed, pos0, inc);
+    grain_birth(c, (q.position / c.dlen) + c.pm, grainSpeed, pos0, inc, failed);
     sched_draw(q, c, failed);
 }
 
@@ -81,7 +88,7 @@ __device__ __forceinline__ bool sched_step(SchedState &q, const SchedConst &c, s
         double pos = c.a_ps[n * c.S];
         pos *= c.dlen;
         if (0 == floor(fmod(q.looper, c.cycleLength))) {  // :362
-            grain_birth(c, (pos / c.dlen), 1.0, pos0, inc);
+            grain_birth(c, (pos / c.dlen), 1.0, pos0, inc, failed);
             return true;
         }
         return false;
@@ -93,7 +100,7 @@ __device__ __forceinline__ bool sched_step(SchedState &q, const SchedConst &c, s
         const double cycleMod = fmod(q.looper, c.cycleLength + q.randomOffset);
         if (0 == floor(cycleMod)) {
             const double sp = c.speed - ((cycleMod / c.cycleLength) * 0.1);  // :421
-            grain_birth(c, (q.position / c.dlen) + c.pm, sp, pos0, inc);
+            grain_birth(c, (q.position / c.dlen) + c.pm, sp, pos0, inc, failed);
             return true;
         }
         return false;
@@ -204,12 +211,12 @@ __device__ __forceinline__ int sched_run_events(SchedState &q, const SchedConst 
                 if constexpr (MODE == 2) {
                     double pos = sc.a_ps[(size_t)n * sc.S];
                     pos *= sc.dlen;
-                    grain_birth(sc, (pos / sc.dlen), 1.0, pos0, inc);
+                    grain_birth(sc, (pos / sc.dlen), 1.0, pos0, inc, failed);
                 } else {
                     ramp(n + 1);
                     const double cycleMod = fmod(Lc, cyc);
                     const double sp = sc.speed - ((cycleMod / sc.cycleLength) * 0.1);  // :421
-                    grain_birth(sc, (q.position / sc.dlen) + sc.pm, sp, pos0, inc);
+                    grain_birth(sc, (q.position / sc.dlen) + sc.pm, sp, pos0, inc, failed);
                 }
                 record(n, pos0, inc);
                 L = Lc;

@@ -55,6 +55,8 @@ __global__ void amplitudes_to_wav_kernel(const double *__restrict__ amp, size_t 
     }
 }
 
+constexpr size_t kWavTruncationSlack = (size_t)16 << 20;  // bytes a data chunk may declare beyond the file's end
+
 unsigned blocks_for(size_t n) {
     size_t b = (n + 255) / 256;
     return (unsigned)(b > 4096 ? 4096 : (b ? b : 1));
@@ -108,32 +110,52 @@ double *mxg_sample_load_wav(const char *path, int channel, size_t *h_len, int32_
         const bool isdata = memcmp(&b[(size_t)filePos], "data", 4) == 0;
         filePos += 8;
         if (isdata) break;
+        // The reference's walk also stops on inFile.eof() (C:651); here every skipped chunk must move the
+        // cursor forward and stay inside the file, so a malformed size field cannot loop or walk backwards.
+        if (dataSize < 0 || (long)dataSize > fsize - filePos) {
+            fail(MXG_ERR_INVALID, "mxg_sample_load_wav: chunk size %d at byte %ld leaves %s", (int)dataSize,
+                 filePos - 8, path);
+            return nullptr;
+        }
         filePos += dataSize;
     }
     if (dataSize < 0 || channel < 0) {
         fail(MXG_ERR_INVALID, "mxg_sample_load_wav: bad data size / channel");
         return nullptr;
     }
-    const size_t n = (size_t)dataSize / 2;  // shortAmps.resize(myDataSize/2), C:665
-    std::vector<int16_t> sh(n ? n : 1, 0);
     size_t avail = (size_t)(fsize - filePos);
-    if (avail > 2 * n) avail = 2 * n;  // a truncated file leaves zeros, like the resized vector
+    // a truncated file leaves zeros, like the resized vector (shortAmps.resize(myDataSize/2), C:665) -- but a
+    // declared size far beyond the bytes that exist is a corrupt header, not a truncation: do not allocate for it
+    if ((size_t)dataSize > avail + kWavTruncationSlack) {
+        fail(MXG_ERR_INVALID, "mxg_sample_load_wav: data chunk declares %d bytes, %zu present in %s", (int)dataSize,
+             avail, path);
+        return nullptr;
+    }
+    const size_t n = (size_t)dataSize / 2;
+    std::vector<int16_t> sh(n ? n : 1, 0);
+    if (avail > 2 * n) avail = 2 * n;
     memcpy(sh.data(), &b[(size_t)filePos], avail);
 
     double *base = nullptr;
     int16_t *d_raw = nullptr;
     const size_t total = n + kSmpGuardLo + kSmpGuardHi;  // same layout as mxg_sample_upload (mxg_smp.h)
     if (check_hip(hipMalloc(&base, total * sizeof(double)), "hipMalloc(sample)")) return nullptr;
-    if (check_hip(hipMemset(base, 0, total * sizeof(double)), "hipMemset(sample)")) return nullptr;
+    auto release = [&]() {  // every error path below gives the device buffers back
+        if (d_raw) (void)hipFree(d_raw);
+        (void)hipFree(base);
+        return (double *)nullptr;
+    };
+    if (check_hip(hipMemset(base, 0, total * sizeof(double)), "hipMemset(sample)")) return release();
     if (n) {
-        if (check_hip(hipMalloc(&d_raw, n * sizeof(int16_t)), "hipMalloc(wav)")) return nullptr;
+        if (check_hip(hipMalloc(&d_raw, n * sizeof(int16_t)), "hipMalloc(wav)")) return release();
         if (check_hip(hipMemcpy(d_raw, sh.data(), n * sizeof(int16_t), hipMemcpyHostToDevice), "hipMemcpy(wav)"))
-            return nullptr;
+            return release();
         hipLaunchKernelGGL(wav_to_amplitudes_kernel, dim3(blocks_for(n)), dim3(256), 0, resolve_stream(nullptr), d_raw,
                            n, (int)channels, channel, (long long)dataSize, base + kSmpGuardLo);
-        if (check_hip(hipGetLastError(), "wav_to_amplitudes launch")) return nullptr;
-        if (check_hip(hipStreamSynchronize(resolve_stream(nullptr)), "wav_to_amplitudes")) return nullptr;
+        if (check_hip(hipGetLastError(), "wav_to_amplitudes launch")) return release();
+        if (check_hip(hipStreamSynchronize(resolve_stream(nullptr)), "wav_to_amplitudes")) return release();
         (void)hipFree(d_raw);
+        d_raw = nullptr;
     }
     *h_len = n;
     if (h_hdr) {

@@ -66,6 +66,20 @@ def test_fft_large_vs_oracle_and_unaligned(mx, port):
     check_fft(f, e["real"], e["imag"], e["mags"], e["phases"], "unaligned")
 
 
+@pytest.mark.parametrize("fs", [4096, 8192, 8, 16])
+def test_fft_generic_extreme_sizes_vs_oracle(mx, port, fs):
+    """The generic kernel at the ends of its range (8..8192): one LDS frame per wave, workgroup shape chosen
+    from the size so the launch stays within 64 KB of LDS."""
+    rng = np.random.default_rng(fs)
+    nfr = 37
+    sig = rng.uniform(-1, 1, fs * nfr).astype(np.float32)
+    f = mx.maxiFFT()
+    f.setup(fs, fs, fs)
+    assert f.process_signal(sig, want_complex=True) == nfr
+    e = port.fft_stream(sig, fs, fs, fs)
+    check_fft(f, e["real"], e["imag"], e["mags"], e["phases"], "size%d" % fs)
+
+
 def test_fft_invalid_sizes(mx):
     L = mx.lib()
     for bad in (0, 6, 1000, 16384):
