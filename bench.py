@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- headline measurement: Msamples/s of the voice-bank render (BASELINE.json).
 
-Workload (BASELINE.json configs[1]): a 65 536-voice maxiOsc::sinebuf
-wavetable bank per GPU, block = 512 samples, freq[v] = 20 + v*0.30517578125 Hz, state carried
-from block to block.  One "step" = one block of the whole bank through the hot path
-(libmaxigpu.so, kernel K1 `osc_kernel<sinebuf>` + the stereo mixdown partials), inputs and
-state resident in HBM.  With --gpus N (one process per GPU, launched by torch.distributed.run)
-every rank renders its own 65 536-voice shard (weak scaling); the only exchange is the
-[512 x 2] fp64 mixdown, reduced to rank 0 over RCCL.
+Default workload = BASELINE.json configs[1]: a 65 536-voice maxiOsc::sinebuf wavetable bank per
+GPU, block = 512 samples, freq[v] = 20 + v*0.30517578125 Hz, state carried from block to block.  One "step" = one
+block of the whole bank through the hot path (libmaxigpu.so): kernel K1m renders the block, stores every voice's
+fp64 sample (out[n][v], the HBM-bound stream) and, in the same pass, forms the maxiMix::stereo mixdown of the rank's
+voices; the [512 x 2] mixes of 16 consecutive blocks are staged in the C-ABI's mix queue and summed onto rank 0 with
+ONE ncclReduce per 16 blocks on the queue's own stream (RCCL over xGMI), overlapped with the next blocks' render.  The
+same work runs at every N (weak scaling: 65 536 voices per GPU); at N = 1 the reduce degenerates to a device copy.
+`--mixdown off` renders without the mixdown (kernel K1 alone), `--mixdown separate` uses K1 + K3.
 
-Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit/...,
-plus "roofline" (dominant kernel vs the 8 TB/s HBM peak, algorithmic bytes 8.047 B/sample,
-duration from HIP events on the launch stream) and "cpu_baseline" (the reference's own CPU
-loop -- oracle/_ref when present, else the plain-C port -- timed on this host on a bounded
-sample; rank 0, N=1 only).
+`--workload config3|config4|config5` runs the other BASELINE configs through the same harness and JSON shape (same
+unit; SURVEY 8d: a "sample" is one voice output, one FFT input sample, one grain-sample).
+
+Prints ONE JSON line on rank 0: metric/value/unit/..., plus
+  "roofline"      the dominant kernel against the 8 TB/s HBM peak (or the fp64 MFMA peak for --mfcc-method mfma):
+                  algorithmic bytes per launch / average launch duration, the duration measured with HIP events the
+                  library records around that kernel on its launch stream (mxg_prof_*) inside the timed region;
+                  "traffic" = HBM bytes per launch from the rocprofv3 PMC passes kept in profiles/pmc_traffic.json;
+  "kernels"       average duration and launches per step of every kernel the step launches;
+  "cpu_baseline"  the reference's own per-sample CPU loop (oracle/_ref, the compiled reference; else the plain-C
+                  port) timed on this host's cores on a bounded sample of the same workload (rank 0, N = 1 only),
+                  multi-threaded ("cores") and single-threaded ("single_thread").
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -28,8 +37,8 @@ sys.path.insert(0, ROOT)
 
 VOICES_PER_GPU = 65536
 BLOCK = 512
-ALGO_BYTES_PER_SAMPLE = 8.0 + 24.0 / BLOCK  # 8 B store + (freq, phase rd, phase wr)/block = 8.047
-HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F64_PEAK_TFLOPS = 78.6  # dense fp64 matrix peak
 
 
 def usable_cores():
@@ -44,43 +53,68 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(freq):
-    """The reference CPU loop on this host: bounded sample of the same workload."""
+def _oracle():
     from oracle import pyoracle
-    cores = usable_cores()
-    # bounded sample: ~3.2 G samples = roughly 20 core-seconds of the reference loop
     if pyoracle.have_reference():
-        o, kind, threads, blocks = pyoracle.reference(), "reference", cores, 96
-    else:
-        o, kind, threads, blocks = pyoracle.port(), "port", 1, 48
+        return pyoracle.reference(), "reference"
+    return pyoracle.port(), "port"
+
+
+def _baseline(run, units_of, sizes, unit_name, what, target_s=6.0):
+    """Time `run(size, threads)` -> seconds on a bounded sample.  A small probe sets the sample size so that the
+    multi-threaded run takes about target_s (and the single-threaded one about half that)."""
+    o, kind = _oracle()
     o.settings(44100, 2, 1024)
-    nsamp = BLOCK * blocks
-    secs = o.time_osc(8, freq, nsamp, threads=threads)
-    return {
-        "value": round(freq.size * nsamp / secs / 1e6, 2), "unit": "Msamples/s", "cores": threads,
-        "kind": kind,
-        "sample": "%d voices x %d samples (%d blocks of %d) maxiOsc::sinebuf, voice-inner loop, "
-                  "voices sharded over %d thread(s); %.2f s wall" % (freq.size, nsamp, blocks, BLOCK,
-                                                                     threads, secs),
-    }
+    cores = usable_cores() if kind == "reference" else 1
+    probe, cap = sizes
+    t = max(run(o, probe, 1), 1e-4)
+    rate1 = units_of(probe) / t
+    n1 = int(min(cap, max(probe, probe * (0.5 * target_s) / t)))
+    s1 = run(o, n1, 1)
+    res = {"unit": "Msamples/s", "kind": kind}
+    if cores > 1:
+        nm = int(min(cap, max(probe, n1 * 2 * cores * 0.7)))
+        sm = run(o, nm, cores)
+        res.update(value=round(units_of(nm) / sm / 1e6, 2), cores=cores,
+                   sample="%s, %s = %d, units sharded over %d threads; %.2f s wall" % (what, unit_name, nm, cores, sm))
+        res["single_thread"] = {"value": round(units_of(n1) / s1 / 1e6, 2), "cores": 1,
+                                "sample": "%s = %d; %.2f s wall" % (unit_name, n1, s1)}
+    else:
+        res.update(value=round(units_of(n1) / s1 / 1e6, 2), cores=1,
+                   sample="%s, %s = %d, one thread; %.2f s wall" % (what, unit_name, n1, s1))
+    return res
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--waveform", default="sinebuf")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"],
                     help="BASELINE.json config to run; the default (config2) is the one the headline metric is quoted on")
-    ap.add_argument("--mixdown", nargs="?", const="fused", default=None, choices=["fused", "separate"],
-                    help="also produce the stereo mixdown each step and reduce it to rank 0 over RCCL")
+    ap.add_argument("--mixdown", default=None, choices=["fused", "separate", "off"],
+                    help="stereo mixdown + cross-GPU reduce in the step (default: fused for config2, separate for "
+                         "config5, off for config3)")
+    ap.add_argument("--mix-depth", type=int, default=16, help="blocks per ncclReduce (M of SURVEY 8e)")
+    ap.add_argument("--voice-mode", type=int, default=0, choices=[0, 1], help="config3: 0 = hoisted coefficients, 1 = 14.monosynth order")
+    ap.add_argument("--mfcc-method", default="sparse", choices=["sparse", "mfma"],
+                    help="config4: exact sparse mel walk (default) or the dense fp64 MFMA contraction")
+    ap.add_argument("--kernel-events", default="inline", choices=["inline", "pass", "off"],
+                    help="per-kernel HIP events inside the timed region (inline), in a separate pass, or not at all")
     args = ap.parse_args()
+    defaults = {"config2": (2000, 100), "config3": (1280, 128), "config4": (20, 3), "config5": (20, 3)}
+    if args.steps is None:
+        args.steps = defaults[args.workload][0]
+    if args.warmup is None:
+        args.warmup = defaults[args.workload][1]
 
     import torch
     import torch.distributed as dist
     import maximilian_amd as mx
+    from maximilian_amd.dist import (MixdownStep, RcclMixQueue, bank_parameters, create_comm, shard_range,
+                                     stream_parameters)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -90,62 +124,100 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     L = mx.lib()
-    mx._lib.check(L.mxg_init(local), "mxg_init")
+    chk = mx._lib.check
+    chk(L.mxg_init(local), "mxg_init")
     mx.maxiSettings.setup(44100, 2, 1024)
     dev = torch.device("cuda", local)
-    # Launch on a non-default torch stream and time with events recorded on the SAME stream
-    # (the C-ABI treats a NULL stream as "the library's own stream").
+    # Launch on a non-default torch stream (the C-ABI treats a NULL stream as "the library's own stream").
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream != 0
-
-    from maximilian_amd.dist import MixReducer, bank_parameters, shard_range
+    # the product's communicator: RCCL through the C-ABI (torch.distributed only carries the 128-byte id)
+    comm = create_comm(dist, rank, world, dev) if world > 1 else None
 
     V, B = VOICES_PER_GPU, BLOCK
     wf = mx.OSC_WAVEFORMS[args.waveform]
-    # this rank's voice shard of the global bank: voices [rank*V, (rank+1)*V)
-    lo, hi = shard_range(rank, world, V)
+    lo, hi = shard_range(rank, world, V)  # this rank's voice shard of the global bank
     freq_h, pan_h = bank_parameters(lo, hi, V * world)
-    freq = torch.from_numpy(freq_h).to(dev)
-    phase = torch.zeros(V, dtype=torch.float64, device=dev)
-    hold = torch.zeros(V, dtype=torch.float64, device=dev)
-    out = torch.empty((B, V), dtype=torch.float64, device=dev)
-    pan = torch.from_numpy(pan_h).to(dev)
-    reducer = MixReducer(dist if world > 1 else None,
-                         lambda: torch.zeros((B, 2), dtype=torch.float64, device=dev))
+    mixdown = args.mixdown or {"config2": "fused", "config3": "off", "config4": "off", "config5": "separate"}[args.workload]
+    queue = None
+    W = {}
 
-    def render():
-        mx._lib.check(L.mxg_osc_render(wf, V, B, freq.data_ptr(), 0, None, None, phase.data_ptr(),
-                                       hold.data_ptr(), out.data_ptr(), stream), "mxg_osc_render")
+    if args.workload == "config2":
+        freq = torch.from_numpy(freq_h).to(dev)
+        phase = torch.zeros(V, dtype=torch.float64, device=dev)
+        hold = torch.zeros(V, dtype=torch.float64, device=dev)
+        out = torch.empty((B, V), dtype=torch.float64, device=dev)
+        pan = torch.from_numpy(pan_h).to(dev)
+        if mixdown != "off":
+            queue = RcclMixQueue(comm, B * 2, args.mix_depth, 0, stream)
 
-    # ---- the other BASELINE configs, same JSON shape, same unit (a "sample" is one voice output,
-    # one FFT input sample, one grain-sample).  They are parity-test cases; the headline stays config2. ----
-    alt = None
-    if args.workload == "config3":
+        def render_mix(slot):
+            if mixdown == "fused":  # K1m: render + store + mix partials in one pass
+                chk(L.mxg_osc_render_mix(wf, V, B, freq.data_ptr(), None, None, phase.data_ptr(), hold.data_ptr(),
+                                         out.data_ptr(), pan.data_ptr(), slot, stream), "mxg_osc_render_mix")
+            else:                   # K1 then K3 re-reading the block
+                chk(L.mxg_osc_render(wf, V, B, freq.data_ptr(), 0, None, None, phase.data_ptr(), hold.data_ptr(),
+                                     out.data_ptr(), stream), "mxg_osc_render")
+                chk(L.mxg_mix_stereo(V, B, out.data_ptr(), pan.data_ptr(), slot, stream), "mxg_mix_stereo")
+
+        if mixdown == "off":
+            def step():
+                chk(L.mxg_osc_render(wf, V, B, freq.data_ptr(), 0, None, None, phase.data_ptr(), hold.data_ptr(),
+                                     out.data_ptr(), stream), "mxg_osc_render")
+        else:
+            step = MixdownStep(render_mix, queue)
+        algo = (8.0 + 24.0 / B) * V * B  # 8 B store + (freq, phase rd, phase wr)/block = 8.047 B/sample
+        if mixdown == "fused":
+            algo += 16.0 * V + 16.0 * B * (V / 256.0)  # + gains read, per-workgroup mix partials written
+        dom = "osc_mix_kernel" if mixdown == "fused" else "osc_kernel"
+
+        def cpu():
+            return _baseline(lambda o, n, th: o.time_osc(wf, freq_h, n, threads=th), lambda n: V * n, (256, 1 << 18),
+                             "samples per voice", "%d voices maxiOsc::%s, voice-inner loop" % (V, args.waveform))
+        W = dict(step=step, samples=V * B, dominant=dom, algo_bytes=algo, dtype="f64", cpu=cpu,
+                 workload="configs[1]: 65536-voice maxiOsc::%s wavetable bank per GPU, block=512, fp64 out[n][v] stored%s"
+                          % (args.waveform, {"fused": " + fused maxiMix::stereo mixdown", "separate": " + K3 mixdown",
+                                             "off": ""}[mixdown]))
+    elif args.workload == "config3":
         K = 128
+        mode = args.voice_mode
         vb = mx.maxiVoiceBank(V, stream=stream)
         vb.env.setAttack(10); vb.env.setDecay(100); vb.env.setSustain(0.5); vb.env.setRelease(500)
         f3 = np.minimum(freq_h, 5000.0)
-        vb.render(0, f3, 200 + 4 * f3, 1.0 + (np.arange(lo, hi) % 16), np.zeros(1, np.int32), 1, out=mx.DeviceBuffer((1, V)))
+        cu3, rs3 = (200 + 4 * f3) if mode == 0 else np.full(V, 10000.0), 1.0 + (np.arange(lo, hi) % 16)
+        out3 = mx.DeviceBuffer((B, V), zero=False)
+        vb.render(mode, f3, cu3, rs3, np.zeros(1, np.int32), 1, out=mx.DeviceBuffer((1, V)))
         vf, vcu, vrs, vcoef, _ = vb._keep
         vpar, vhold = vb.env._params()
         gate = mx.DeviceBuffer.from_numpy(((np.arange(K * B) % 44100) < 22050).astype(np.int32))
+        pan3 = mx.DeviceBuffer.from_numpy(pan_h)
         blk = [0]
+        if mixdown != "off":
+            queue = RcclMixQueue(comm, B * 2, args.mix_depth, 0, stream)
 
-        def step3():
-            mx._lib.check(L.mxg_voice_render(0, V, B, vf.ptr, vcu.ptr, vrs.ptr, vcoef.ptr, gate.ptr + 4 * (blk[0] % K) * B, 0,
-                                             vpar.ptr, vhold.ptr, vb.osc_state.ptr, vb.flt_state.ptr, vb.env.dstate.ptr,
-                                             vb.env.istate.ptr, out.data_ptr(), stream), "mxg_voice_render")
+        def voice_block():
+            chk(L.mxg_voice_render(mode, V, B, vf.ptr, vcu.ptr, vrs.ptr, vcoef.ptr if vcoef is not None else None,
+                                   gate.ptr + 4 * (blk[0] % K) * B, 0, vpar.ptr, vhold.ptr, vb.osc_state.ptr, vb.flt_state.ptr,
+                                   vb.env.dstate.ptr, vb.env.istate.ptr, out3.ptr, stream), "mxg_voice_render")
             blk[0] += 1
-        alt = dict(step=step3, samples=V * B, bytes=(8.0 + 176.0 / B) * V * B, kernel="voice_kernel<0> (saw->lores->adsr, hoisted)",
-                   workload="configs[2]: fused subtractive voice maxiOsc::saw -> maxiFilter::lores -> maxiEnv::adsr, %d voices "
-                            "per GPU, block=512, gate(n) = (n mod 44100) < 22050 cycled over 128 blocks" % V, dtype="f64")
+
+        def render_mix3(slot):
+            voice_block()
+            chk(L.mxg_mix_stereo(V, B, out3.ptr, pan3.ptr, slot, stream), "mxg_mix_stereo")
+        step = voice_block if mixdown == "off" else MixdownStep(render_mix3, queue)
+
+        def cpu():
+            return _baseline(lambda o, n, th: o.time_voice(mode, f3, cu3, rs3, n, threads=th), lambda n: V * n, (32, 1 << 13),
+                             "samples per voice", "%d voices saw->lores->adsr (mode %d), voice-inner loop of 15.polysynth" % (V, mode))
+        W = dict(step=step, samples=V * B, dominant="voice_kernel", algo_bytes=(8.0 + 176.0 / B) * V * B, dtype="f64", cpu=cpu,
+                 workload="configs[2]: fused subtractive voice maxiOsc::saw -> maxiFilter::lores -> maxiEnv::adsr (mode %d), %d voices "
+                          "per GPU, block=512, gate(n) = (n mod 44100) < 22050 cycled over 128 blocks" % (mode, V))
     elif args.workload == "config4":
         NF = 1 << 20
         g = torch.Generator(device=dev); g.manual_seed(0x4D415849 + rank)
@@ -157,56 +229,71 @@ def main():
                 2 * np.pi * (440 + 0.01 * k) * n / 44100) + 0.1 * (2 * torch.rand(n.numel(), dtype=torch.float64, device=dev,
                                                                                   generator=g) - 1)).to(torch.float32)
             del n, k
-        mags = torch.empty((NF, 512), dtype=torch.float32, device=dev)
+        mfma = args.mfcc_method == "mfma"
         mfcc = torch.empty((NF, 13), dtype=torch.float64, device=dev)
         fplan = mx.maxiFFT(); fplan.setup(1024, 1024, 1024)
         mplan = mx.maxiMFCC(); mplan.setup(512, 42, 13, 20.0, 20000.0)
+        fused_ok = hasattr(L, "mxg_fft_mfcc_batch") and not mfma
+        mags = None if fused_ok else torch.empty((NF, 512), dtype=torch.float32, device=dev)
 
-        def step4():
-            mx._lib.check(L.mxg_fft_batch(fplan.plan, sig.data_ptr(), 1024, NF, None, None, mags.data_ptr(), None, stream), "fft")
-            mx._lib.check(L.mxg_mfcc_batch(mplan.plan, mags.data_ptr(), 512, NF, None, None, mfcc.data_ptr(), 0, stream), "mfcc")
-        alt = dict(step=step4, samples=NF * 1024, bytes=4200.0 * NF, kernel="fft1024_kernel + mfcc_stream_tiled_kernel",
-                   workload="configs[3]: maxiFFT(1024,1024,1024) + maxiMFCC(512,42,13,20,20000) over %d frames per GPU per step" % NF,
-                   dtype="f32 (FFT) / f64 (MFCC)")
-    elif args.workload == "config5":
+        def step():
+            if fused_ok:
+                chk(L.mxg_fft_mfcc_batch(fplan.plan, mplan.plan, sig.data_ptr(), 1024, NF, None, None, mfcc.data_ptr(), stream),
+                    "mxg_fft_mfcc_batch")
+            else:
+                chk(L.mxg_fft_batch(fplan.plan, sig.data_ptr(), 1024, NF, None, None, mags.data_ptr(), None, stream), "fft")
+                chk(L.mxg_mfcc_batch(mplan.plan, mags.data_ptr(), 512, NF, None, None, mfcc.data_ptr(), 1 if mfma else 0, stream), "mfcc")
+
+        sig_h = [None]
+
+        def cpu():
+            if sig_h[0] is None:
+                sig_h[0] = sig[:1024 * 65536].cpu().numpy()
+            return _baseline(lambda o, n, th: o.time_spectral(sig_h[0][:n * 1024], threads=th), lambda n: n * 1024, (512, 65536),
+                             "frames", "maxiFFT(1024,1024,1024)::process per sample + maxiMFCC(512,42,13)::mfcc per frame (mfcctest loop)")
+        W = dict(step=step, samples=NF * 1024, dtype="f32 (FFT) / f64 (MFCC)", cpu=cpu,
+                 dominant="mfcc_mfma_kernel" if mfma else ("fft_mfcc_kernel" if fused_ok else "fft1024_kernel"),
+                 algo_bytes=4200.0 * NF if fused_ok else 6144.0 * NF, mfma_flops=2.0 * 512 * 42 * NF if mfma else None,
+                 workload="configs[3]: maxiFFT(1024,1024,1024) + maxiMFCC(512,42,13,20,20000) over %d frames per GPU per step, %s"
+                          % (NF, "dense fp64 MFMA mel contraction" if mfma else ("one fused kernel, exact sparse mel walk" if fused_ok
+                                                                               else "FFT kernel + exact sparse mel walk")))
+    else:  # config5
         S, T, Ls = 2048, 70560, 4410000
         rng5 = np.random.default_rng(0x4D415849)
         n5 = np.arange(Ls)
         smp = 0.5 * np.sin(2 * np.pi * 110 * n5 / 44100) + 0.25 * np.sin(2 * np.pi * 331 * n5 / 44100) + 0.05 * rng5.uniform(-1, 1, Ls)
         sb5 = mx.maxiSampleBank(1, stream=stream); sb5.setSample(smp)
         gb = mx.maxiTimeStretchBank(S, sb5, "hann", stream=stream)
-        s_glob = np.arange(rank * S, (rank + 1) * S)
-        gb.setPosition(s_glob / float(S * world))
-        sp5 = mx.DeviceBuffer.from_numpy(0.25 + 1.5 * (s_glob % 97) / 96)
+        lo5, hi5 = shard_range(rank, world, S)
+        pos5, speed5, pan5_h = stream_parameters(lo5, hi5, S * world)
+        gb.setPosition(pos5)
+        sp5 = mx.DeviceBuffer.from_numpy(speed5)
+        pan5 = mx.DeviceBuffer.from_numpy(pan5_h)
         out5 = mx.DeviceBuffer((T, S), zero=False)
         plan5 = gb._plan(0.05)
+        if mixdown != "off":
+            queue = RcclMixQueue(comm, T * 2, 1, 0, stream)  # one [T][2] = 1.13 MB reduce per render
 
-        def step5():
-            mx._lib.check(L.mxg_granular_render(plan5, 0, S, T, sb5.d_samples, Ls, 4, sp5.ptr, None, None, None, 0,
-                                                gb.state.ptr, gb.grains.ptr, out5.ptr, stream), "mxg_granular_render")
-        alt = dict(step=step5, samples=S * T * 4, bytes=(8.0 * 4 + 8.0) * S * T, kernel="granular_sched_kernel + granular_unit_kernel",
-                   workload="configs[4]: %d maxiTimeStretch<hann> streams per GPU x %d samples per step, grainLength 0.05, overlaps 4 "
-                            "(4 live grains per stream-sample counted)" % (S, T), dtype="f64")
+        def grains():
+            chk(L.mxg_granular_render(plan5, 0, S, T, sb5.d_samples, Ls, 4, sp5.ptr, None, None, None, 0,
+                                      gb.state.ptr, gb.grains.ptr, out5.ptr, stream), "mxg_granular_render")
 
-    def step():
-        if alt is not None:
-            alt["step"]()
-            return
-        if not args.mixdown:
-            render()
-            return
-        # render + maxiMix::stereo mixdown of this rank's voices fused in one pass (K1m), then the
-        # single exchange of the path: an asynchronous RCCL reduce of the [512 x 2] block to rank 0
-        mixbuf = reducer.next_buffer()
-        if args.mixdown == "fused":
-            mx._lib.check(L.mxg_osc_render_mix(wf, V, B, freq.data_ptr(), None, None, phase.data_ptr(),
-                                               hold.data_ptr(), out.data_ptr(), pan.data_ptr(),
-                                               mixbuf.data_ptr(), stream), "mxg_osc_render_mix")
-        else:  # "separate": K1 then K3 re-reading the block
-            render()
-            mx._lib.check(L.mxg_mix_stereo(V, B, out.data_ptr(), pan.data_ptr(), mixbuf.data_ptr(), stream),
-                          "mxg_mix_stereo")
-        reducer.submit()
+        def render_mix5(slot):
+            grains()
+            chk(L.mxg_mix_stereo(S, T, out5.ptr, pan5.ptr, slot, stream), "mxg_mix_stereo")
+        step = grains if mixdown == "off" else MixdownStep(render_mix5, queue)
+
+        def cpu():
+            Sc = 256  # streams of the bounded sample (same parameters as the first 256 of this rank)
+            return _baseline(lambda o, n, th: o.time_grains(smp, speed5[:Sc], pos5[:Sc], n, threads=th), lambda n: Sc * n * 4,
+                             (2048, 70560), "samples per stream", "%d maxiTimeStretch<hann> streams, play(speed,0.05,4), stream-inner "
+                             "loop, 4 grain-samples per stream-sample" % Sc)
+        W = dict(step=step, samples=S * T * 4, dominant="granular_unit_kernel", algo_bytes=(8.0 * 4 + 8.0) * S * T, dtype="f64", cpu=cpu,
+                 workload="configs[4]: %d maxiTimeStretch<hann> streams per GPU x %d samples per step, grainLength 0.05, overlaps 4 "
+                          "(4 live grains per stream-sample counted)%s" % (S, T, "" if mixdown == "off" else
+                                                                          ", maxiMix::stereo to [T][2] + one RCCL reduce per render"))
+
+    step = W["step"]
 
     def fence():
         torch.cuda.synchronize()
@@ -214,66 +301,104 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Untimed clock ramp: an idle MI355X sits in a low-power state (sclk ~500 MHz) and takes
-    # milliseconds of continuous work to reach its sustained clocks; a short --steps run would
-    # otherwise time the ramp instead of the kernel.  Then the W requested warmup steps.
+    def read_kernels(nsteps):
+        res = {}
+        for i in range(L.mxg_prof_count()):
+            lab, ms, cnt = ctypes.c_char_p(), ctypes.c_double(0), ctypes.c_size_t(0)
+            chk(L.mxg_prof_read(i, ctypes.byref(lab), ctypes.byref(ms), ctypes.byref(cnt)), "mxg_prof_read")
+            if cnt.value:
+                res[lab.value.decode()] = {"ms": ms.value / cnt.value, "launches_per_step": cnt.value / float(nsteps)}
+        return res
+
+    # Untimed clock ramp: an idle MI355X sits in a low-power state (sclk ~500 MHz) and takes milliseconds of continuous
+    # work to reach its sustained clocks; a short --steps run would otherwise time the ramp instead of the kernel.
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 0.3:
-        for _ in range(50):
+        for _ in range(50 if args.workload in ("config2", "config3") else 1):
             step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    # Average launch duration of the dominant kernel (K1): two HIP events on the launch stream
-    # bracketing the K back-to-back launches of the timed region (per-launch event pairs would
-    # put ~10 us of host/marker gaps between the kernels; measured in profiles/).
+    if queue is not None:
+        queue.flush()
+    inline = args.kernel_events == "inline"
+    L.mxg_prof_reset()
+    L.mxg_prof_enable(1 if inline else 0)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fence()
     t0 = time.perf_counter()
     ev0.record()
     for i in range(args.steps):
         step()
+    if queue is not None:
+        queue.flush()  # the last (partial) batch's reduce; the launch stream waits for every outstanding reduce
     ev1.record()
-    reducer.drain()
     fence()
     t1 = time.perf_counter()
+    L.mxg_prof_enable(0)
     elapsed = t1 - t0
-    k1_ms = ev0.elapsed_time(ev1) / args.steps
+    step_ms_events = ev0.elapsed_time(ev1) / args.steps
+    kernels = read_kernels(args.steps) if inline else {}
+    if args.kernel_events == "pass":  # same steps again, with the per-kernel events on, outside the timed region
+        psteps = min(args.steps, 200)
+        L.mxg_prof_reset()
+        L.mxg_prof_enable(1)
+        for i in range(psteps):
+            step()
+        if queue is not None:
+            queue.flush()
+        torch.cuda.synchronize()
+        L.mxg_prof_enable(0)
+        kernels = read_kernels(psteps)
+    dom = W["dominant"]
+    dom_ms = kernels[dom]["ms"] if dom in kernels else step_ms_events
     if world > 1:
-        t = torch.tensor([elapsed, k1_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, dom_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, k1_ms = float(t[0]), float(t[1])
+        elapsed, dom_ms = float(t[0]), float(t[1])
 
-    samples_per_step = (alt["samples"] if alt else V * B) * world
-    value = samples_per_step * args.steps / elapsed / 1e6
-    achieved = (alt["bytes"] if alt else ALGO_BYTES_PER_SAMPLE * V * B) / (k1_ms * 1e-3) / 1e9
+    value = W["samples"] * world * args.steps / elapsed / 1e6
+    dom_launches = kernels.get(dom, {}).get("launches_per_step", 1.0)
+    algo_per_launch = W["algo_bytes"] / dom_launches
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc) and alt is None:
-        try:
-            traffic = json.load(open(pmc)).get("k1_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(dom)
+    except Exception:
+        traffic = None
 
     if rank == 0:
+        if W.get("mfma_flops"):
+            ach = W["mfma_flops"] / (dom_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_F64_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "flops_per_launch": W["mfma_flops"]}
+        else:
+            ach = algo_per_launch / (dom_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(algo_per_launch)}
+        roof.update(kernel=dom, kernel_ms=round(dom_ms, 5), launches_per_step=round(dom_launches, 3),
+                    timing="HIP events around the kernel on its launch stream (%s)" % args.kernel_events
+                    if dom in kernels else "HIP events around the whole step")
         res = {
             "metric": "Msamples/s (voice-bank render)", "value": round(value, 1), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": alt["dtype"] if alt else "f64", "data": "synthetic",
-            "config": {"workload": alt["workload"] if alt else "configs[1]: 65536-voice maxiOsc::%s wavetable bank per GPU, "
-                                   "block=512, fp64 out[n][v] stored" % args.waveform,
-                       "voices_per_gpu": V, "block": B, "sample_rate": 44100,
-                       "parallelism": "voices sharded x%d" % world,
-                       "mixdown": "maxiMix::stereo + RCCL reduce of [512x2] per step" if args.mixdown else "off"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": alt["kernel"] if alt else "osc_kernel<%s>" % args.waveform, "kernel_ms": round(k1_ms, 5),
-                         "algorithmic_bytes_per_launch": round(alt["bytes"] if alt else ALGO_BYTES_PER_SAMPLE * V * B)},
-            "realtime_voices_at_44k1": int(value * 1e6 / 44100),
+            "scaling": "weak", "vs_baseline": None, "dtype": W["dtype"], "data": "synthetic",
+            "config": {"workload": W["workload"], "voices_per_gpu": V, "block": B, "sample_rate": 44100,
+                       "parallelism": "units sharded x%d" % world,
+                       "mixdown": {"off": "off"}.get(mixdown, "maxiMix::stereo per block; %s"
+                                                     % ("one ncclReduce per %d blocks on the mix queue's stream" % queue.depth
+                                                        if queue is not None else ""))},
+            "rccl_ranks": world if (queue is not None and world > 1) else (1 if queue is not None else 0),
+            "roofline": roof,
+            "kernels": {k: {"ms": round(v["ms"], 5), "launches_per_step": round(v["launches_per_step"], 3)}
+                        for k, v in sorted(kernels.items())},
+            "step_ms_gpu": round(step_ms_events, 5),
+            "realtime_voices_at_44k1": int(value * 1e6 / 44100) if args.workload in ("config2", "config3") else None,
         }
-        if world == 1 and not args.no_cpu_baseline and alt is None:
-            res["cpu_baseline"] = cpu_baseline(freq_h)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = W["cpu"]()
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

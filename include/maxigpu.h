@@ -92,6 +92,17 @@ int mxg_event_destroy(void *event);
 int mxg_event_record(void *event, void *stream);
 int mxg_event_elapsed_ms(void *start, void *stop, float *h_ms);
 
+/* ---- per-kernel timing (measurement only) --------------------------------------------------------- */
+/* mxg_prof_enable(1): every entry point brackets its kernels with HIP events on the launch stream (one label per
+ * kernel, e.g. "osc_kernel", "fft1024_kernel"); mxg_prof_read(i, ...) waits for label i's events and returns the
+ * summed kernel time and the number of launches since the last mxg_prof_reset().  Off by default (no events, no
+ * overhead).  This is how bench.py measures the average launch duration of the dominant kernel inside its timed
+ * region; the rocprofv3 kernel-trace averages in profiles/ agree with it. */
+int mxg_prof_enable(int on);  /* returns the previous setting */
+int mxg_prof_reset(void);
+int mxg_prof_count(void);
+int mxg_prof_read(int index, const char **h_label, double *h_total_ms, size_t *h_launches);
+
 /* ---- tuning knobs (performance only; results are identical for every setting) ---------- */
 /* key: "osc_vpl" (voices per lane 1|2), "osc_block" (64..1024), "osc_nt" (0|1 non-temporal stores),
  * "voice_block", "voice_nt", "mix_rows" (sample rows per workgroup of the mixdown, 1|2), "fft_generic",
@@ -415,6 +426,49 @@ int mxg_granular_render(const mxg_grain_plan *plan, int mode, size_t S, size_t T
                         size_t len, int overlaps, const double *d_a, const double *d_b,
                         const double *d_posmod, const int32_t *d_rnd, size_t R, double *d_st, double *d_gst,
                         double *d_out, void *stream);
+
+/* ---- multi-GPU mixdown: RCCL over xGMI ------------------------------------------------ */
+/* The reference is single-device; there is nothing to cite but the mix itself (maxiMix, C:503-541, and the user-side
+ * sum over voices, 15.polysynth/main.cpp:67).  Banks shard over the GPUs of a node by contiguous voice / stream /
+ * frame ranges, one process per GPU, private state, no data-path collective -- except that the per-rank
+ * [samples][channels] fp64 mix blocks are summed onto one GPU with ncclReduce(ncclDouble, ncclSum, root).
+ * Sum order across ranks is RCCL's, not the reference's sequential voice order: the mix carries the tolerance of
+ * mxg_mix_stereo, per-voice signals stay bit-exact.
+ * mxg_comm_unique_id: rank 0 obtains the 128-byte ncclUniqueId; the host distributes it (torch.distributed, MPI,
+ * a file ...); every rank then calls mxg_comm_create(id, nranks, rank) on the device it selected with mxg_init.
+ * librccl is resolved at this point (dlopen by SONAME), not when libmaxigpu.so loads. */
+#define MXG_COMM_ID_BYTES 128
+typedef struct mxg_comm mxg_comm;
+int mxg_comm_unique_id(void *h_id);
+mxg_comm *mxg_comm_create(const void *h_id, int nranks, int rank);
+int mxg_comm_destroy(mxg_comm *comm);
+int mxg_comm_rank(const mxg_comm *comm);
+int mxg_comm_size(const mxg_comm *comm);
+/* d_recv (on `root`; on every rank when all != 0) = sum over ranks of d_send[count], in `stream` order (in place
+ * allowed).  comm NULL or a one-rank communicator: a device copy. */
+int mxg_comm_reduce(mxg_comm *comm, const double *d_send, double *d_recv, size_t count, int root, int all,
+                    void *stream);
+/* maxiMix bus over this rank's V voices (as mxg_mix_bus without d_bus) into d_mix [N][channels], then the sum over
+ * ranks into the root's d_mix -- the whole exchange step for a host that reduces block by block. */
+int mxg_mix_reduce(mxg_comm *comm, int channels, size_t V, size_t N, const double *d_in, const double *d_x,
+                   const double *d_y, const double *d_z, double *d_mix, int root, void *stream);
+/* Batched, overlapped form: an 8 KiB [512][2] block is a latency-bound message, so the local mixes of `depth_blocks`
+ * consecutive blocks are staged and reduced with ONE ncclReduce (depth 16 = 128 KiB) on the queue's own stream while
+ * the caller's stream renders the next batch into the second staging buffer (device-side event ordering only; no call
+ * here blocks the host).  Per block:  p = mxg_mixq_slot(q, stream);  <enqueue the local mix of the block into p, e.g.
+ * mxg_osc_render_mix / mxg_mix_stereo with d_mix = p>;  mxg_mixq_push(q, stream).  mxg_mixq_flush reduces a partial
+ * batch and makes `stream` wait for every outstanding reduce.  mxg_mixq_result: device pointer to the most recently
+ * submitted batch's sum [blocks][block_doubles] (meaningful on the root once its reduce has completed, e.g. after
+ * flush + stream sync; overwritten two batches later).  mxg_mixq_set_sink: the root additionally copies every summed
+ * block into a pinned host ring [ring_blocks][block_doubles] (the audio callback's side of the boundary). */
+typedef struct mxg_mixq mxg_mixq;
+mxg_mixq *mxg_mixq_create(mxg_comm *comm, size_t block_doubles, int depth_blocks, int root);
+int mxg_mixq_destroy(mxg_mixq *q);
+int mxg_mixq_set_sink(mxg_mixq *q, double *h_pinned, size_t ring_blocks);
+double *mxg_mixq_slot(mxg_mixq *q, void *stream);
+int mxg_mixq_push(mxg_mixq *q, void *stream);
+int mxg_mixq_flush(mxg_mixq *q, void *stream);
+const double *mxg_mixq_result(const mxg_mixq *q, size_t *h_blocks, size_t *h_batches);
 
 /* ---- calibration ----------------------------------------------------------------------- */
 /* Streaming fill of `bytes` at d_dst (8 B/lane or 16 B/lane stores): the measured HBM write

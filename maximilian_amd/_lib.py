@@ -33,6 +33,10 @@ SIGNATURES = {
     "mxg_event_destroy": (c_int, [c_void_p]),
     "mxg_event_record": (c_int, [c_void_p, c_void_p]),
     "mxg_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "mxg_prof_enable": (c_int, [c_int]),
+    "mxg_prof_reset": (c_int, []),
+    "mxg_prof_count": (c_int, []),
+    "mxg_prof_read": (c_int, [c_int, POINTER(c_char_p), POINTER(c_double), POINTER(c_size_t)]),
     "mxg_tune": (c_int, [c_char_p, c_int]),
     "mxg_osc_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -90,6 +94,21 @@ SIGNATURES = {
     "mxg_granular_render": (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_void_p, c_size_t, c_int, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),
+    "mxg_comm_unique_id": (c_int, [c_void_p]),
+    "mxg_comm_create": (c_void_p, [c_void_p, c_int, c_int]),
+    "mxg_comm_destroy": (c_int, [c_void_p]),
+    "mxg_comm_rank": (c_int, [c_void_p]),
+    "mxg_comm_size": (c_int, [c_void_p]),
+    "mxg_comm_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "mxg_mix_reduce": (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_int, c_void_p]),
+    "mxg_mixq_create": (c_void_p, [c_void_p, c_size_t, c_int, c_int]),
+    "mxg_mixq_destroy": (c_int, [c_void_p]),
+    "mxg_mixq_set_sink": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "mxg_mixq_slot": (c_void_p, [c_void_p, c_void_p]),
+    "mxg_mixq_push": (c_int, [c_void_p, c_void_p]),
+    "mxg_mixq_flush": (c_int, [c_void_p, c_void_p]),
+    "mxg_mixq_result": (c_void_p, [c_void_p, POINTER(c_size_t), POINTER(c_size_t)]),
     "mxg_calib_fill": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
 }
 

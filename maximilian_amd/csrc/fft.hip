@@ -579,7 +579,9 @@ int mxg_fft_batch(const mxg_fft_plan *p, const float *d_signal, size_t frame_str
     int force_generic = tune_get("fft_generic");
     const int omask = (d_real ? 1 : 0) | (d_imag ? 2 : 0) | (d_mags ? 4 : 0) | (d_phases ? 8 : 0);
     const bool fast_mask = omask == 3 || omask == 4 || omask == 12 || omask == 15;
-    if (p->fftSize == 1024 && !force_generic && fast_mask) {
+    const bool fast = p->fftSize == 1024 && !force_generic && fast_mask;
+    KernelTimer kt(fast ? "fft1024_kernel" : "fft_generic_kernel", st);
+    if (fast) {
         const bool aligned8 = (((uintptr_t)d_signal) & 7) == 0 && (frame_stride & 1) == 0;
 #define MXG_FFT_LAUNCH(M, A)                                                                            \
     hipLaunchKernelGGL((fft1024_kernel<M, A>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0, st, \

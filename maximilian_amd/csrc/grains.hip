@@ -975,6 +975,7 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
     if (!A.winInLds) lds = 0;
     dim3 grid((unsigned)((S + 63) / 64));
     if (!tune_get("grain_chunked")) {  // K8: one lane per stream, serial in time
+        KernelTimer kt("granular_kernel", st);
         switch (mode) {
             case 0: hipLaunchKernelGGL((granular_kernel<0>), grid, dim3(64), lds, st, A); break;
             case 1: hipLaunchKernelGGL((granular_kernel<1>), grid, dim3(64), lds, st, A); break;
@@ -1055,15 +1056,19 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
                 Q.n_base = (int)(ci * Tc);
                 Q.T = (cn * Tc < T ? cn * Tc : T) - ci * Tc;
                 Q.c_end = (i == slices - 1) ? C : cn;
-                if (mode == 0) {
-                    hipLaunchKernelGGL((granular_sched_kernel<0>), grid, dim3(64), 0, st, Q);
-                } else {
-                    Q.a = d_a + (size_t)Q.n_base * S;  // playAtPosition reads its position signal [T][S] at the births
-                    hipLaunchKernelGGL((granular_sched_kernel<2>), grid, dim3(64), 0, st, Q);
+                {
+                    KernelTimer kt("granular_sched_kernel", st);
+                    if (mode == 0) {
+                        hipLaunchKernelGGL((granular_sched_kernel<0>), grid, dim3(64), 0, st, Q);
+                    } else {
+                        Q.a = d_a + (size_t)Q.n_base * S;  // playAtPosition reads its position signal [T][S] at the births
+                        hipLaunchKernelGGL((granular_sched_kernel<2>), grid, dim3(64), 0, st, Q);
+                    }
                 }
                 MXG_HIP(hipEventRecord(g_aux_ev[i], st));
                 MXG_HIP(hipStreamWaitEvent(g_aux, g_aux_ev[i], 0));
                 U.c0 = (unsigned)ci;
+                KernelTimer kt("granular_unit_kernel", g_aux);
                 hipLaunchKernelGGL(granular_unit_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)(cn - ci)), dim3(256), 0,
                                    g_aux, U);
             }
@@ -1071,14 +1076,20 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
             MXG_HIP(hipStreamWaitEvent(st, g_aux_done, 0));
             hipLaunchKernelGGL(granular_unit_state_kernel, grid, dim3(64), 0, st, U);
         } else {
+        {
+        KernelTimer kt("granular_sched_kernel", st);
         switch (mode) {
             case 0: hipLaunchKernelGGL((granular_sched_kernel<0>), grid, dim3(64), 0, st, Q); break;
             case 1: hipLaunchKernelGGL((granular_sched_kernel<1>), grid, dim3(64), 0, st, Q); break;
             case 2: hipLaunchKernelGGL((granular_sched_kernel<2>), grid, dim3(64), 0, st, Q); break;
             default: hipLaunchKernelGGL((granular_sched_kernel<3>), grid, dim3(64), 0, st, Q); break;
         }
+        }
         if (unit) {
-            hipLaunchKernelGGL(granular_unit_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)C), dim3(256), 0, st, U);
+            {
+                KernelTimer kt("granular_unit_kernel", st);
+                hipLaunchKernelGGL(granular_unit_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)C), dim3(256), 0, st, U);
+            }
             hipLaunchKernelGGL(granular_unit_state_kernel, grid, dim3(64), 0, st, U);
         } else {
         RenderArgs Rr;
@@ -1088,6 +1099,7 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         Rr.gst_in = gst_copy; Rr.gst_out = d_gst; Rr.out = d_out; Rr.err = g_err;
         Rr.sampleDur = A.sampleDur; Rr.winInLds = A.winInLds;
         const size_t lanes = S * C;
+        KernelTimer kt("granular_render_kernel", st);
         hipLaunchKernelGGL(granular_render_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), lds, st, Rr);
         }
         }

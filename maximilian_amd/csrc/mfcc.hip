@@ -547,6 +547,7 @@ int mxg_mfcc_batch(const mxg_mfcc_plan *p, const float *d_mags, size_t mag_strid
                               (((size_t)p->nbUsed * S + 3) & ~(size_t)3) * sizeof(int)) + 15) / 16 * 16 +
                             4 * 64 * kTileStride * sizeof(float);
         if (aligned16 && tiledCols <= mag_stride && ldsT <= 64 * 1024 && tune_get("mfcc_tiled")) {
+            KernelTimer kt("mfcc_stream_tiled_kernel", st);
 #define MXG_TILED_LAUNCH(SS, CC)                                                                              \
     hipLaunchKernelGGL((mfcc_stream_tiled_kernel<SS, CC>), grid, dim3(block), ldsT, st, d_mags, mag_stride, nframes, \
                        p->numFilters, p->nbUsed, p->d_schedW, p->d_schedFin, p->d_lo, p->d_hi, p->d_dct, d_melraw, d_melbands, \
@@ -563,6 +564,7 @@ int mxg_mfcc_batch(const mxg_mfcc_plan *p, const float *d_mags, size_t mag_strid
     hipLaunchKernelGGL((mfcc_stream_kernel<SS, CC>), grid, dim3(block), lds, st, d_mags, mag_stride, nframes, \
                        p->numFilters, p->nbUsed, p->d_schedW, p->d_schedFin, p->d_lo, p->d_hi, p->d_dct, d_melraw, d_melbands, \
                        d_mfcc, aligned16)
+        KernelTimer kt("mfcc_stream_kernel", st);
         if (NC == 13) {
             if (S == 1) MXG_STREAM_LAUNCH(1, 13); else if (S == 2) MXG_STREAM_LAUNCH(2, 13); else MXG_STREAM_LAUNCH(4, 13);
         } else {
@@ -575,6 +577,7 @@ int mxg_mfcc_batch(const mxg_mfcc_plan *p, const float *d_mags, size_t mag_strid
         MXG_REQUIRE(lds <= 64 * 1024, "filter support too wide for the LDS tile");
         size_t blocks = (nframes + 63) / 64;
         if (blocks > 256 * 4) blocks = 256 * 4;
+        KernelTimer kt("mfcc_tile_kernel", st);
         hipLaunchKernelGGL(mfcc_tile_kernel, dim3((unsigned)blocks), dim3(64), lds, st, d_mags, mag_stride, nframes,
                            p->numFilters, p->numCoeffs, p->nbUsed, tileStride, p->d_lo, p->d_hi, p->d_off, p->d_Wc,
                            p->d_dct, d_melraw, d_melbands, d_mfcc);
@@ -586,6 +589,7 @@ int mxg_mfcc_batch(const mxg_mfcc_plan *p, const float *d_mags, size_t mag_strid
     hipLaunchKernelGGL((mfcc_mfma_kernel<NT>), dim3((unsigned)blocks), dim3(64), 0, st, d_mags, mag_stride,   \
                        nframes, p->numBins, p->numFilters, p->numCoeffs, p->kPad, p->nfPad, p->d_Wpad, p->d_dct, \
                        d_melraw, d_melbands, d_mfcc)
+        KernelTimer kt("mfcc_mfma_kernel", st);
         switch (p->nfPad / 16) {
             case 1: MXG_MFMA_LAUNCH(1); break;
             case 2: MXG_MFMA_LAUNCH(2); break;

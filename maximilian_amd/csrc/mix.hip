@@ -152,6 +152,7 @@ int launch_bus(size_t V, size_t N, const double *d_in, const double *d_x, const 
         hipLaunchKernelGGL((bus_gains_kernel<C>), dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st,
                            V, d_x, d_y, d_z, g_gains);
     const int rows = tune_get("mix_rows");
+    KernelTimer kt("mix_bus_kernel", st);
     if (d_bus)
         hipLaunchKernelGGL((mix_bus_kernel<C, true, 1>), dim3((unsigned)N), dim3(kMixThreads), 0, st, V, N,
                            d_in, g_gains, d_bus, d_mix);

@@ -41,6 +41,16 @@ int tune_get(const char *key);
 enum ScratchSlot { SCR_MIX_GAINS, SCR_OSC_MIX, SCR_GRAIN_ERR, SCR_GRAIN_SCHED, SCR_IFFT_OUT, SCR_IFFT_BUF, SCR_SLOTS };
 int scratch_get(ScratchSlot slot, hipStream_t st, size_t bytes, void **out);
 
+// Optional per-kernel timing (mxg_prof_enable): a KernelTimer around a launch records two HIP events on the launch
+// stream; mxg_prof_read sums the elapsed times per label.  Off by default: then it costs one load and a branch.
+struct KernelTimer {
+    KernelTimer(const char *label, hipStream_t st);
+    ~KernelTimer();
+    int slot;
+    hipStream_t st;
+    hipEvent_t e0;
+};
+
 #define MXG_HIP(call)                                         \
     do {                                                      \
         int _s = ::mxg::check_hip((call), #call);             \

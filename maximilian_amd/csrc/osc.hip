@@ -91,24 +91,115 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
 }
 
 // ---- K1m: K1 + fused maxiMix::stereo partial sums ---------------------------------------------------
-// Same per-voice recurrence and (optional) per-voice store as K1; in addition every wavefront
-// reduces its 64 voices' panned samples (in*sqrt(1-x), in*sqrt(x), C:503-509) to one (L,R) pair
-// per sample, so the mixdown never re-reads the 268 MB block from HBM.  Every 16 samples the 32
-// (sample, channel) rows of products are transposed through a padded LDS tile [32][65]: lane
-// (c = lane&31, h = lane>>5) sums row c over lanes 32h..32h+31 in lane order, the two halves are
-// combined (low half first) and lane c < 32 writes partial[n][wave][channel].  Fixed order =>
-// deterministic.  A second tiny kernel (mix_partials_kernel) sums the per-wave partials.
+// Same per-voice recurrence and (optional) per-voice store as K1; in addition every wavefront reduces its 64 voices'
+// panned samples (in*sqrt(1-x), in*sqrt(x), C:503-509) to one (L,R) pair per sample, so the mixdown never re-reads the
+// 268 MB block from HBM.  The reduction lives entirely in registers: 16 samples are folded by a transposing butterfly --
+// each level takes two vectors, exchanges complementary halves between them and adds, so the number of vectors halves
+// while every vector carries twice as many samples:
+//   level 1  v_permlane32_swap   (lane i <-> i+32)       16 vectors -> 8    [2 samples x 32 partial sums]
+//   level 2  v_permlane16_swap   (row r <-> r^1)          8 -> 4            [4 x 16]
+//   level 3  DPP row_mirror      (lane i <-> 15-i of a row, bank-masked)   4 -> 2   [8 x 8]
+//   level 4  DPP row_half_mirror (lane i <-> 7-i of a half row)            2 -> 1   [16 x 4]
+//   then two quad_perm adds: lane 4j holds the wave's sum for one sample (which one: the same network run once on the
+//   sample indices, `slot`).
+// 15 + 8 = 23 fp64 adds and ~60 32-bit lane moves per 16 samples and channel instead of 16 x 6 shuffle-adds, no LDS
+// round trip in the sample loop (the first K1m transposed through LDS and was latency-bound at one wave per SIMD: 84 us
+// vs 42 us for K1).  The four waves of a workgroup then combine their sums through LDS once per 512 samples and a small
+// second kernel sums the per-workgroup partials in a fixed order => deterministic (but not the reference's sequential
+// order: tolerance on the mix).
 constexpr int kMixChunk = 16;
-constexpr int kMixRow = 65;  // 64 lanes + 1 pad: row stride 130 dwords => conflict-free b64 column reads
+constexpr int kMixSuper = 512;  // samples between two workgroup combines (LDS: 4 waves x 512 x 2 doubles = 32 KB)
+
+template <typename T> struct Fold;
+template <> struct Fold<double> {
+    static __device__ __forceinline__ double join(double x, double y) { return x + y; }
+    static __device__ __forceinline__ void split(double v, unsigned &lo, unsigned &hi) { lo = (unsigned)__double2loint(v); hi = (unsigned)__double2hiint(v); }
+    static __device__ __forceinline__ double make(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
+};
+template <> struct Fold<int> {  // the sample-index network: both operands must name the same sample
+    static __device__ __forceinline__ int join(int x, int y) { return x == y ? x : -1; }
+};
+
+// two 64-lane vectors (samples A, B) -> one: lanes 0-31 = A[i] + A[i+32], lanes 32-63 = B[i-32] + B[i]
+__device__ __forceinline__ double fold32(double a, double b) {
+    unsigned al, ah, bl, bh;
+    Fold<double>::split(a, al, ah);
+    Fold<double>::split(b, bl, bh);
+    auto lo = __builtin_amdgcn_permlane32_swap(al, bl, false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
+    return Fold<double>::make(lo[0], hi[0]) + Fold<double>::make(lo[1], hi[1]);
+}
+__device__ __forceinline__ int fold32(int a, int b) {
+    auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+    return Fold<int>::join((int)r[0], (int)r[1]);
+}
+__device__ __forceinline__ double fold16(double a, double b) {
+    unsigned al, ah, bl, bh;
+    Fold<double>::split(a, al, ah);
+    Fold<double>::split(b, bl, bh);
+    auto lo = __builtin_amdgcn_permlane16_swap(al, bl, false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+    return Fold<double>::make(lo[0], hi[0]) + Fold<double>::make(lo[1], hi[1]);
+}
+__device__ __forceinline__ int fold16(int a, int b) {
+    auto r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
+    return Fold<int>::join((int)r[0], (int)r[1]);
+}
+// DPP exchange: t = x with the lanes of `BANKS_T` replaced by ctrl(y); u = y with the other banks replaced by ctrl(x)
+template <int CTRL, int BANKS_T>
+__device__ __forceinline__ void dpp_exchange(unsigned x, unsigned y, unsigned &t, unsigned &u) {
+    t = (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)y, CTRL, 0xf, BANKS_T, false);
+    u = (unsigned)__builtin_amdgcn_update_dpp((int)y, (int)x, CTRL, 0xf, 0xf ^ BANKS_T, false);
+}
+template <int CTRL, int BANKS_T>
+__device__ __forceinline__ double fold_dpp(double a, double b) {
+    unsigned al, ah, bl, bh, tl, th, ul, uh;
+    Fold<double>::split(a, al, ah);
+    Fold<double>::split(b, bl, bh);
+    dpp_exchange<CTRL, BANKS_T>(al, bl, tl, ul);
+    dpp_exchange<CTRL, BANKS_T>(ah, bh, th, uh);
+    return Fold<double>::make(tl, th) + Fold<double>::make(ul, uh);
+}
+template <int CTRL, int BANKS_T>
+__device__ __forceinline__ int fold_dpp(int a, int b) {
+    unsigned t, u;
+    dpp_exchange<CTRL, BANKS_T>((unsigned)a, (unsigned)b, t, u);
+    return Fold<int>::join((int)t, (int)u);
+}
+constexpr int kDppRowMirror = 0x140, kDppRowHalfMirror = 0x141;
+constexpr int kDppQuadXor1 = 0xB1 /* [1,0,3,2] */, kDppQuadXor2 = 0x4E /* [2,3,0,1] */;
+__device__ __forceinline__ double quad_sum(double v) {
+    unsigned lo, hi;
+    Fold<double>::split(v, lo, hi);
+    double o = Fold<double>::make((unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, kDppQuadXor1, 0xf, 0xf, true),
+                                  (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, kDppQuadXor1, 0xf, 0xf, true));
+    v = v + o;
+    Fold<double>::split(v, lo, hi);
+    o = Fold<double>::make((unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, kDppQuadXor2, 0xf, 0xf, true),
+                           (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, kDppQuadXor2, 0xf, 0xf, true));
+    return v + o;
+}
+// 16 vectors (one per sample) -> one vector: every quad of lanes holds the wave-wide sum of one sample
+template <typename T>
+__device__ __forceinline__ T fold_chunk(const T (&v)[kMixChunk]) {
+    T l1[8], l2[4], l3[2];
+#pragma unroll
+    for (int j = 0; j < 8; j++) l1[j] = fold32(v[2 * j], v[2 * j + 1]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) l2[j] = fold16(l1[2 * j], l1[2 * j + 1]);
+#pragma unroll
+    for (int j = 0; j < 2; j++) l3[j] = fold_dpp<kDppRowMirror, 0xC>(l2[2 * j], l2[2 * j + 1]);
+    return fold_dpp<kDppRowHalfMirror, 0xA>(l3[0], l3[1]);
+}
 
 template <int WF, bool STORE>
 __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const double *__restrict__ freq,
                                                       const double *__restrict__ p1, const double *__restrict__ p2,
                                                       double *__restrict__ phase_io, double *__restrict__ hold_io,
                                                       double *__restrict__ out, const double *__restrict__ gains,
-                                                      double *__restrict__ partial, size_t nwaves, double sr) {
+                                                      double *__restrict__ partial, double sr) {
     constexpr int kTab = uses_sine<WF>() ? MAXI_SINE_TAB_LEN : (WF == MXG_OSC_SAWN ? MAXI_TRANS_TAB_LEN : 1);
-    __shared__ double s_all[kTab + 4 * 2 * (2 * kMixChunk * kMixRow)];
+    __shared__ double s_all[kTab + 4 * kMixSuper * 2];
     double *s_tab = s_all;
     if constexpr (uses_sine<WF>()) {
         for (int i = threadIdx.x; i < MAXI_SINE_TAB_LEN; i += blockDim.x) s_tab[i] = MAXI_SINE_TAB_D[i];
@@ -117,106 +208,96 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *tile = s_all + kTab + wave * 2 * (2 * kMixChunk * kMixRow);
-    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t gwave = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
-    const bool live = v < V;
-    double ph = 0, hd = 0, gl = 0, gr = 0;
-    OscPre q = {0, 0, 0, 0};
-    if (live) {
-        ph = phase_io[v];
-        hd = hold_io[v];
-        gl = gains[v];
-        gr = gains[V + v];
-        q = osc_pre<WF>(freq[v], sr, p1 ? p1[v] : 0.0, p2 ? p2[v] : 0.0);
-    }
-    // Consume the prologue loads HERE.  Otherwise hipcc's waitcnt pass keeps them "pending" at the
-    // loop back-edge and puts s_waitcnt vmcnt(0) in every chunk's preheader, which also drains the
-    // asynchronous output stores each 16 samples (measured: 74 us -> see profiles/).
+    double *s_sum = s_all + kTab;                       // [4 waves][kMixSuper][2]
+    double *my_sum = s_sum + wave * (kMixSuper * 2);
+    // The lane exchanges need all 64 lanes alive, and a per-sample `if (live)` costs an exec-mask region per sample:
+    // the surplus lanes of the bank's last wavefront shadow voice V-1 instead (same loads, same arithmetic, same stores
+    // of the same values to the same addresses) and enter the mix with zero gains.
+    const size_t vraw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = vraw < V;
+    const size_t v = live ? vraw : V - 1;
+    double ph = phase_io[v], hd = hold_io[v];
+    double gl = live ? gains[v] : 0.0, gr = live ? gains[V + v] : 0.0;
+    OscPre q = osc_pre<WF>(freq[v], sr, p1 ? p1[v] : 0.0, p2 ? p2[v] : 0.0);
+    // Consume the prologue loads HERE: otherwise hipcc's waitcnt pass keeps them "pending" at the loop back-edge and
+    // drains the asynchronous output stores with s_waitcnt vmcnt(0) every chunk.
     asm volatile("" : "+v"(ph), "+v"(hd), "+v"(gl), "+v"(gr));
     asm volatile("" : "+v"(q.inc), "+v"(q.k), "+v"(q.p1), "+v"(q.p2));
+    // which sample of a chunk this lane's quad ends up holding: the same network on the sample indices
+    int slot;
+    {
+        int idx[kMixChunk];
+#pragma unroll
+        for (int i = 0; i < kMixChunk; i++) idx[i] = i;
+        slot = fold_chunk<int>(idx);
+    }
     double *o = out + v;
-    const int c = lane & 31, h = lane >> 5;
-    // Software-pipelined over 16-sample chunks with two LDS tiles: iteration k renders chunk k into
-    // tile k&1 while the column sums of chunk k-1 (other tile) are formed -- independent work the
-    // compiler can interleave, so the store stream does not stall behind the LDS round trip.
-    constexpr int kTile = 2 * kMixChunk * kMixRow;
-    const size_t nch = (N + kMixChunk - 1) / kMixChunk;
-    for (size_t k = 0; k <= nch; k++) {
-        double *tw = tile + (k & 1) * kTile;
-        const double *tr = tile + ((k + 1) & 1) * kTile;
-        if (k < nch) {
-            const size_t n0 = k * kMixChunk;
-            const int cnt = (int)((N - n0) < (size_t)kMixChunk ? (N - n0) : (size_t)kMixChunk);
-#pragma unroll 4
-            for (int i = 0; i < cnt; i++) {
-                double r = 0.0;
-                if (live) {
-                    r = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+    for (size_t n0 = 0; n0 < N; n0 += kMixSuper) {
+        const int super = (int)((N - n0) < (size_t)kMixSuper ? (N - n0) : (size_t)kMixSuper);
+        for (int c0 = 0; c0 < super; c0 += kMixChunk) {
+            const int cnt = (super - c0) < kMixChunk ? (super - c0) : kMixChunk;
+            double L[kMixChunk], R[kMixChunk];
+            if (cnt == kMixChunk) {
+#pragma unroll
+                for (int i = 0; i < kMixChunk; i++) {
+                    const double r = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
                     if constexpr (STORE) {
                         *o = r;
                         o += V;
                     }
+                    L[i] = r * gl;  // two[0] = input*sqrt(1.0-x)   C:506
+                    R[i] = r * gr;  // two[1] = input*sqrt(x)       C:507
                 }
-                tw[(2 * i) * kMixRow + lane] = r * gl;      // two[0] = input*sqrt(1.0-x)   C:506
-                tw[(2 * i + 1) * kMixRow + lane] = r * gr;  // two[1] = input*sqrt(x)       C:507
-            }
-        }
-        if (k > 0) {
-            const size_t n0 = (k - 1) * kMixChunk;
-            const int cnt = (int)((N - n0) < (size_t)kMixChunk ? (N - n0) : (size_t)kMixChunk);
-            double s = 0.0;
-            if (c < 2 * cnt) {
-                // four interleaved partial sums keep the fp64 add chains short; fixed order
-                const double *row = tr + c * kMixRow + h * 32;
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            } else {  // ragged last chunk: the state must not advance past N
 #pragma unroll
-                for (int j = 0; j < 32; j += 4) {
-                    s0 += row[j];
-                    s1 += row[j + 1];
-                    s2 += row[j + 2];
-                    s3 += row[j + 3];
+                for (int i = 0; i < kMixChunk; i++) {
+                    double r = 0.0;
+                    if (i < cnt) {
+                        r = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+                        if constexpr (STORE) {
+                            *o = r;
+                            o += V;
+                        }
+                    }
+                    L[i] = r * gl;
+                    R[i] = r * gr;
                 }
-                s = (s0 + s1) + (s2 + s3);
             }
-            const double other = __shfl_xor(s, 32);
-            if (h == 0 && c < 2 * cnt)
-                partial[((n0 + (size_t)(c >> 1)) * nwaves + gwave) * 2 + (c & 1)] = s + other;
+            const double sl = quad_sum(fold_chunk<double>(L));
+            const double sr2 = quad_sum(fold_chunk<double>(R));
+            if ((lane & 3) == 0 && slot >= 0 && slot < cnt) {
+                double2v pr = {sl, sr2};
+                *reinterpret_cast<double2v *>(my_sum + (c0 + slot) * 2) = pr;
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    if (live) {
-        phase_io[v] = ph;
-        hold_io[v] = hd;
-    }
-}
-
-// mix[n][ch] = sum over waves of partial[n][w][ch]: 256 strided partial sums then a binary tree.
-__global__ __launch_bounds__(256) void mix_partials_kernel(size_t nwaves, const double *__restrict__ partial,
-                                                           double *__restrict__ mix) {
-    __shared__ double s_red[2 * 256];
-    const size_t n = blockIdx.x;
-    const double *row = partial + n * nwaves * 2;
-    double l = 0.0, r = 0.0;
-    for (size_t w = threadIdx.x; w < nwaves; w += 256) {
-        l += row[2 * w];
-        r += row[2 * w + 1];
-    }
-    s_red[threadIdx.x] = l;
-    s_red[256 + threadIdx.x] = r;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            s_red[threadIdx.x] += s_red[threadIdx.x + s];
-            s_red[256 + threadIdx.x] += s_red[256 + threadIdx.x + s];
-        }
+        // the four waves' sums of this stretch -> one partial per workgroup, waves added in order 0..3
+        __syncthreads();
+        double *prow = partial + (size_t)blockIdx.x * N * 2 + n0 * 2;
+        for (int i = threadIdx.x; i < super * 2; i += blockDim.x)
+            prow[i] = ((s_sum[i] + s_sum[kMixSuper * 2 + i]) + s_sum[2 * kMixSuper * 2 + i]) + s_sum[3 * kMixSuper * 2 + i];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        mix[2 * n] = s_red[0];
-        mix[2 * n + 1] = s_red[256];
+    phase_io[v] = ph;
+    hold_io[v] = hd;
+}
+
+// mix[i] = sum over workgroups of partial[g][i], i = n*2 + ch: 16 strided partial sums per element (fixed order), then
+// the 16 combined left to right.  Element-major across lanes => coalesced 128-B rows.
+__global__ __launch_bounds__(256) void mix_partials_kernel(size_t ngroups, size_t count, const double *__restrict__ partial,
+                                                           double *__restrict__ mix) {
+    __shared__ double s_red[16][17];
+    const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + e;
+    double s = 0.0;
+    if (i < count)
+        for (size_t w = g; w < ngroups; w += 16) s += partial[w * count + i];
+    s_red[g][e] = s;
+    __syncthreads();
+    if (g == 0 && i < count) {
+        double t = s_red[0][e];
+#pragma unroll
+        for (int k = 1; k < 16; k++) t += s_red[k][e];
+        mix[i] = t;
     }
 }
 
@@ -231,7 +312,7 @@ __global__ void osc_pan_gains_kernel(size_t V, const double *__restrict__ pan, d
 }
 
 typedef void (*osc_mix_fn)(size_t, size_t, const double *, const double *, const double *, double *, double *,
-                           double *, const double *, double *, size_t, double);
+                           double *, const double *, double *, double);
 template <int WF>
 osc_mix_fn pick_mix(bool store) {
     return store ? osc_mix_kernel<WF, true> : osc_mix_kernel<WF, false>;
@@ -304,6 +385,7 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     osc_fn fn = pick_wf(waveform, fps != 0, vpl, nt);
     size_t lanes = (V + vpl - 1) / vpl;
     dim3 grid((unsigned)((lanes + block - 1) / block)), blk((unsigned)block);
+    KernelTimer kt("osc_kernel", resolve_stream(stream));
     hipLaunchKernelGGL(fn, grid, blk, 0, resolve_stream(stream), V, N, d_freq, d_p1, d_p2, d_phase,
                        d_outhold, d_out, (double)settings().sampleRate);
     return check_hip(hipGetLastError(), "osc_kernel launch");
@@ -322,18 +404,20 @@ extern "C" int mxg_osc_render_mix(int waveform, size_t V, size_t N, const double
     hipStream_t st = resolve_stream(stream);
     const int block = 256;
     const size_t nblocks = (V + block - 1) / block;
-    const size_t nwaves = nblocks * (block / 64);
-    const size_t need = 2 * V + N * nwaves * 2 + 2;
-    double *g_mix_scratch = nullptr;  // per-stream: [2][V] gains | [N][nwaves][2] partials
+    const size_t need = 2 * V + N * nblocks * 2 + 2;
+    double *g_mix_scratch = nullptr;  // per-stream: [2][V] gains | [nblocks][N][2] partials
     if (int s = scratch_get(SCR_OSC_MIX, st, sizeof(double) * need, (void **)&g_mix_scratch)) return s;
     double *gains = g_mix_scratch, *partial = g_mix_scratch + 2 * V;
     if (V) {
         hipLaunchKernelGGL(osc_pan_gains_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, d_pan, gains);
         osc_mix_fn fn = pick_mix_wf(waveform, d_out != nullptr);
+        KernelTimer kt("osc_mix_kernel", st);
         hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(block), 0, st, V, N, d_freq, d_p1, d_p2, d_phase,
-                           d_outhold, d_out, gains, partial, nwaves, (double)settings().sampleRate);
+                           d_outhold, d_out, gains, partial, (double)settings().sampleRate);
     }
-    hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)N), dim3(256), 0, st, nwaves, partial, d_mix);
+    KernelTimer kt2("mix_partials_kernel", st);
+    hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((N * 2 + 15) / 16)), dim3(256), 0, st, nblocks, N * 2, partial,
+                       d_mix);
     return check_hip(hipGetLastError(), "osc_mix_kernel launch");
 }
 

@@ -7,6 +7,7 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 #include "mxg_common.h"
 
@@ -83,6 +84,73 @@ int scratch_get(ScratchSlot slot, hipStream_t st, size_t bytes, void **out) {
     }
     *out = b.ptr;
     return MXG_OK;
+}
+
+// ---- per-kernel event timing -------------------------------------------------------------------
+namespace {
+struct ProfSlot {
+    const char *label;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double ms = 0.0;
+    size_t count = 0;
+};
+std::vector<ProfSlot> g_prof;
+std::vector<hipEvent_t> g_prof_free;
+volatile bool g_prof_on = false;
+std::mutex g_prof_mu;
+
+hipEvent_t prof_event() {
+    if (!g_prof_free.empty()) {
+        hipEvent_t e = g_prof_free.back();
+        g_prof_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+// fold finished pairs into the slot's sum; `all` waits for every pair
+void prof_drain(ProfSlot &p, bool all) {
+    size_t done = 0;
+    for (; done < p.pending.size(); done++) {
+        auto &pr = p.pending[done];
+        if (all) (void)hipEventSynchronize(pr.second);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) != hipSuccess) {
+            (void)hipGetLastError();
+            break;  // not finished yet: later pairs on the stream are not either
+        }
+        p.ms += (double)ms;
+        p.count++;
+        g_prof_free.push_back(pr.first);
+        g_prof_free.push_back(pr.second);
+    }
+    p.pending.erase(p.pending.begin(), p.pending.begin() + done);
+}
+}  // namespace
+
+KernelTimer::KernelTimer(const char *label, hipStream_t stream) : slot(-1), st(stream), e0(nullptr) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (size_t i = 0; i < g_prof.size(); i++)
+        if (g_prof[i].label == label || !strcmp(g_prof[i].label, label)) slot = (int)i;
+    if (slot < 0) {
+        g_prof.push_back(ProfSlot());
+        g_prof.back().label = label;
+        slot = (int)g_prof.size() - 1;
+    }
+    e0 = prof_event();
+    if (e0) (void)hipEventRecord(e0, st);
+}
+KernelTimer::~KernelTimer() {
+    if (slot < 0 || !e0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEvent_t e1 = prof_event();
+    if (!e1) return;
+    (void)hipEventRecord(e1, st);
+    ProfSlot &p = g_prof[(size_t)slot];
+    p.pending.emplace_back(e0, e1);
+    if (p.pending.size() >= 1024) prof_drain(p, false);
 }
 
 int tune_get(const char *key) {
@@ -230,6 +298,36 @@ int mxg_tune(const char *key, int value) {
         }
     }
     return fail(MXG_ERR_INVALID, "mxg_tune: unknown key %s", key);
+}
+
+int mxg_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    const int prev = g_prof_on ? 1 : 0;
+    g_prof_on = on != 0;
+    return prev;
+}
+int mxg_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &p : g_prof) {
+        prof_drain(p, true);
+        p.ms = 0.0;
+        p.count = 0;
+    }
+    return MXG_OK;
+}
+int mxg_prof_count(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    return (int)g_prof.size();
+}
+int mxg_prof_read(int index, const char **h_label, double *h_total_ms, size_t *h_launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (index < 0 || (size_t)index >= g_prof.size()) return fail(MXG_ERR_INVALID, "mxg_prof_read: index %d", index);
+    ProfSlot &p = g_prof[(size_t)index];
+    prof_drain(p, true);
+    if (h_label) *h_label = p.label;
+    if (h_total_ms) *h_total_ms = p.ms;
+    if (h_launches) *h_launches = p.count;
+    return MXG_OK;
 }
 
 // ---- calibration: streaming fill ----------------------------------------------------------

@@ -319,6 +319,7 @@ inline dim3 grid_for(size_t V, int block) { return dim3((unsigned)((V + block - 
 template <int M>
 void launch_sample(bool xmod, dim3 grid, dim3 block, hipStream_t st, const SmpArgs &A) {
     constexpr bool kHasSpeed = smp_base(M) >= 4 && M != 14;
+    KernelTimer kt("sample_kernel", st);
     if (kHasSpeed && xmod)
         hipLaunchKernelGGL((sample_kernel<M, kHasSpeed>), grid, block, 0, st, A);
     else
@@ -344,6 +345,7 @@ int mxg_delay_render(int mode, size_t V, size_t N, const double *d_in, const int
     int block = tune_get("voice_block");
     if (block > 256) block = 256;  // delay_kernel is compiled for <= 256 lanes per workgroup
     hipStream_t st = resolve_stream(stream);
+    KernelTimer kt("delay_kernel", st);
     if (mode == 0)
         hipLaunchKernelGGL((delay_kernel<0>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_size,
                            d_feedback, d_position, d_mem, (int)cap, d_phase, d_out);

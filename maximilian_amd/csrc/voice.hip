@@ -408,6 +408,7 @@ int mxg_filter_render(int kind, size_t V, size_t N, const double *d_in, const do
     else                                                                                         \
         hipLaunchKernelGGL((filter_kernel<K, false>), grid_for(V, block), dim3(block), 0, st, V, N, \
                            d_in, d_cutoff, cps, d_res, rps, d_coef, d_st, d_out, sr);
+    KernelTimer kt("filter_kernel", st);
     switch (kind) {
         case 0: MXG_FLT_LAUNCH(0) break;
         case 1: MXG_FLT_LAUNCH(1) break;
@@ -467,6 +468,7 @@ int mxg_env_render(int mode, size_t V, size_t N, const double *d_in, const int32
     } else {                                                                \
         if (tpv) MXG_ENV_LAUNCH(M, false, true); else MXG_ENV_LAUNCH(M, false, false); \
     }
+    KernelTimer kt("env_kernel", st);
     if (mode == 0) { MXG_ENV_LAUNCH2(0) } else { MXG_ENV_LAUNCH2(1) }
 #undef MXG_ENV_LAUNCH2
 #undef MXG_ENV_LAUNCH
@@ -507,6 +509,7 @@ int mxg_voice_render(int mode, size_t V, size_t N, const double *d_freq, const d
                        d_dst, d_ist, d_out, sr)
 #define MXG_VOICE_LAUNCH2(M, T) \
     if (tpv) MXG_VOICE_LAUNCH(M, T, true); else MXG_VOICE_LAUNCH(M, T, false)
+    KernelTimer kt("voice_kernel", st);
     if (mode == 0) {
         if (nt) { MXG_VOICE_LAUNCH2(0, true); } else { MXG_VOICE_LAUNCH2(0, false); }
     } else {

@@ -469,6 +469,52 @@ class Oracle:
         return self.L.mxo_time_osc(wf, freq.size, N, _p(freq), threads, ctypes.addressof(sink))
 
 
+    # -- CPU baselines of BASELINE configs 3/4/5 (bench.py's cpu_baseline leg) ---------------------------
+    # With the compiled reference: the threaded timers of oracle/ref_harness.cpp.  The plain-C port has no such
+    # entry points; it is timed single-threaded around its bank functions (allocation excluded as far as possible).
+    def time_voice(self, mode, freq, cutoff, res, N, threads=1):
+        freq, cutoff, res = _f64(freq), _f64(cutoff), _f64(res)
+        if hasattr(self.L, "mxo_time_voice"):
+            fn = self.L.mxo_time_voice
+            fn.restype = c_double
+            fn.argtypes = [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
+            return fn(mode, freq.size, N, _p(freq), _p(cutoff), _p(res), threads, None)
+        import time
+        par = np.array([[self.env_coeff(0, 10)], [self.env_coeff(1, 100)], [0.5], [self.env_coeff(2, 500)]]) * np.ones((4, freq.size))
+        trig = ((np.arange(N) % 44100) < 22050).astype(np.int32)
+        t0 = time.perf_counter()
+        self.voice(mode, freq, cutoff, res, trig, par, np.ones(freq.size, np.int64))
+        return time.perf_counter() - t0
+
+    def time_spectral(self, signal, threads=1):
+        signal = np.ascontiguousarray(signal, np.float32)
+        nframes = signal.size // 1024
+        if hasattr(self.L, "mxo_time_spectral"):
+            fn = self.L.mxo_time_spectral
+            fn.restype = c_double
+            fn.argtypes = [c_size_t, c_void_p, c_int, c_void_p]
+            return fn(nframes, _p(signal), threads, None)
+        import time
+        t0 = time.perf_counter()
+        e = self.fft_stream(signal[:nframes * 1024], 1024, 1024, 1024, want=("mags",))
+        self.mfcc(e["mags"])
+        return time.perf_counter() - t0
+
+    def time_grains(self, samples, speed, pos01, T, threads=1):
+        samples, speed, pos01 = _f64(samples), _f64(speed), _f64(pos01)
+        if hasattr(self.L, "mxo_time_grains"):
+            fn = self.L.mxo_time_grains
+            fn.restype = c_double
+            fn.argtypes = [c_size_t, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p]
+            return fn(speed.size, T, _p(samples), samples.size, _p(speed), _p(pos01), threads, None)
+        import time
+        st = np.zeros((4, speed.size))
+        st[0] = np.clip(pos01 * samples.size, 0, samples.size - 1)
+        t0 = time.perf_counter()
+        self.granular(0, 0, samples, T, speed, st=st)
+        return time.perf_counter() - t0
+
+
 _cache = {}
 
 

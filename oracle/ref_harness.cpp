@@ -669,6 +669,129 @@ double mxo_time_osc(int wf, size_t V, size_t N, const double *freq, int threads,
     return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// ---- CPU baselines for the other BASELINE configs (SURVEY 8d "CPU baseline"): the reference's own per-sample
+// loops, units sharded contiguously over `threads` std::threads (no shared mutable state), render loop timed only.
+// config 3: per voice saw -> lores -> adsr in the voice-inner order of 15.polysynth/main.cpp:54-70, setAttack(10)
+// setDecay(100) setSustain(0.5) setRelease(500), trig(n) = (n mod 44100) < 22050.  mode 1 = the 14.monosynth:50-55 order
+// (cutoff = adsr * cutoff[v], per-sample coefficients).
+double mxo_time_voice(int mode, size_t V, size_t N, const double *freq, const double *cutoff, const double *res,
+                      int threads, double *sink) {
+    if (threads < 1) threads = 1;
+    std::vector<std::thread> pool;
+    std::vector<double> acc(threads, 0.0);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < threads; t++) {
+        pool.emplace_back([&, t]() {
+            const size_t v0 = V * t / threads, v1 = V * (t + 1) / threads, nv = v1 - v0;
+            std::vector<maxiOsc> osc(nv);
+            std::vector<maxiFilter> flt(nv);
+            std::vector<maxiEnv> env(nv);
+            for (size_t v = 0; v < nv; v++) {
+                memset(&env[v], 0, sizeof(maxiEnv));  // static-storage semantics (maxiEnv has no ctor)
+                env[v].holdtime = 1;
+                env[v].setAttack(10);
+                env[v].setDecay(100);
+                env[v].setSustain(0.5);
+                env[v].setRelease(500);
+                for (int k = 0; k < 3; k++) flt[v].outputs[k] = 0.0;
+            }
+            double a = 0;
+            for (size_t n = 0; n < N; n++) {
+                const int trig = (n % 44100) < 22050 ? 1 : 0;
+                double last = 0;
+                for (size_t v = 0; v < nv; v++) {
+                    if (mode == 0) {
+                        last = env[v].adsr(flt[v].lores(osc[v].saw(freq[v0 + v]), cutoff[v0 + v], res[v0 + v]), trig);
+                    } else {
+                        const double e = env[v].adsr(1.0, trig);
+                        last = flt[v].lores(osc[v].saw(freq[v0 + v]), e * cutoff[v0 + v], res[v0 + v]) * e;
+                    }
+                }
+                a += last;
+            }
+            acc[t] = a;
+        });
+    }
+    for (auto &th : pool) th.join();
+    auto t1 = std::chrono::steady_clock::now();
+    double s = 0;
+    for (double a : acc) s += a;
+    if (sink) *sink = s;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// config 4: the streaming loop of cpp/commandline/tests/mfcctest/mfcctest.cpp:21-32 -- one sample at a time into
+// maxiFFT::process (setup(1024,1024,1024), polar conversion), maxiMFCC::mfcc(512,42,13,20,20000) on every new frame --
+// frames sharded over threads, each thread with its own maxiFFT / maxiMFCC objects.
+double mxo_time_spectral(size_t nframes, const float *signal, int threads, double *sink) {
+    if (threads < 1) threads = 1;
+    std::vector<std::thread> pool;
+    std::vector<double> acc(threads, 0.0);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < threads; t++) {
+        pool.emplace_back([&, t]() {
+            const size_t f0 = nframes * t / threads, f1 = nframes * (t + 1) / threads;
+            maxiFFT f;
+            f.setup(1024, 1024, 1024);
+            maxiMFCC m;
+            mfcc_setup(m, 512, 42, 13, 20.0, 20000.0);
+            double a = 0;
+            for (size_t s = f0 * 1024; s < f1 * 1024; s++) {
+                if (f.process(signal[s], maxiFFT::WITH_POLAR_CONVERSION)) {
+                    std::vector<double> &c = m.mfcc(f.getMagnitudes());
+                    a += c[1];
+                }
+            }
+            acc[t] = a;
+        });
+    }
+    for (auto &th : pool) th.join();
+    auto t1 = std::chrono::steady_clock::now();
+    double s = 0;
+    for (double a : acc) s += a;
+    if (sink) *sink = s;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// config 5: S maxiTimeStretch<hannWinFunctor> streams over one shared maxiSample, play(speed, 0.05, 4, 0)
+// (src/libs/maxiGrains.h:341-355) for T samples, stream-inner loop, streams sharded over threads.  rand() % 10 is
+// routed to the (empty) per-stream queue => 0, as in the parity runs.
+double mxo_time_grains(size_t S, size_t T, const double *amp, size_t len, const double *speed, const double *pos01,
+                       int threads, double *sink) {
+    if (threads < 1) threads = 1;
+    maxiSample smp;
+    std::vector<double> data(amp, amp + len);
+    smp.amplitudes.reserve(len + 2);
+    smp.setSample(data);
+    smp.amplitudes.data()[len] = 0.0;
+    std::vector<std::thread> pool;
+    std::vector<double> acc(threads, 0.0);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < threads; t++) {
+        pool.emplace_back([&, t]() {
+            const size_t s0 = S * t / threads, s1 = S * (t + 1) / threads, ns = s1 - s0;
+            std::vector<std::unique_ptr<maxiTimeStretch<hannWinFunctor>>> ts;
+            for (size_t s = 0; s < ns; s++) {
+                ts.emplace_back(new maxiTimeStretch<hannWinFunctor>(&smp));
+                ts.back()->setPosition(pos01[s0 + s]);
+            }
+            double a = 0;
+            for (size_t n = 0; n < T; n++) {
+                double last = 0;
+                for (size_t s = 0; s < ns; s++) last = ts[s]->play(speed[s0 + s], 0.05, 4, 0.0);
+                a += last;
+            }
+            acc[t] = a;
+        });
+    }
+    for (auto &th : pool) th.join();
+    auto t1 = std::chrono::steady_clock::now();
+    double s = 0;
+    for (double a : acc) s += a;
+    if (sink) *sink = s;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
 // ---- maxiMix::stereo/quad/ambisonic over a bank (src/maximilian.cpp:503-541) ---------------------
 // bus[n][c][v] = what the reference leaves in two/four/eight[c]; mix[n][c] = voice-order sum.
 int mxo_mix_bus(int C, size_t V, size_t N, const double *in, const double *x, const double *y,

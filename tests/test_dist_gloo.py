@@ -1,9 +1,10 @@
 """CPU test (-m "not gpu"): the N>1 path's host logic with world_size 2 over gloo.
 
-Each rank takes its voice shard (maximilian_amd.dist.shard_range / bank_parameters), renders it with
-the CPU oracle standing in for the GPU kernels (the product's kernels need a GPU; the sharding,
-double-buffered reducer and the reduce-to-rank-0 are the code under test), mixes it to stereo and
-hands the [B,2] block to MixReducer.  Rank 0 must end up with the mix of the WHOLE bank."""
+The step function is the product's (maximilian_amd.dist.MixdownStep: slot -> render + local mix -> push, batched M blocks
+per reduce); the kernels need a GPU, so the CPU oracle stands in for them and HostMixQueue (same slot/push/flush protocol as
+the C-ABI's mxg_mixq, reduce over gloo) stands in for the RCCL queue.  Both BASELINE shapes that shard are driven:
+config 2 (voice bank, per-block stereo mixdown, M blocks per reduce incl. a partial last batch) and config 5 (grain
+streams, one [T][2] reduce).  Rank 0 must end up with the mix of the WHOLE bank, compared with the oracle's sequential sum."""
 import os
 import socket
 import sys
@@ -12,6 +13,9 @@ import numpy as np
 import pytest
 
 from conftest import ROOT
+
+CFG2 = dict(Vr=96, B=64, blocks=7, M=3)          # 7 blocks, 3 per reduce: batches of 3, 3 and a flushed 1
+CFG5 = dict(Sr=24, T=1500, L=30000)
 
 
 def _free_port():
@@ -22,38 +26,73 @@ def _free_port():
     return p
 
 
+def _grain_sample(L):
+    n = np.arange(L)
+    rng = np.random.default_rng(0x4D415849)
+    return 0.5 * np.sin(2 * np.pi * 110 * n / 44100) + 0.25 * np.sin(2 * np.pi * 331 * n / 44100) + 0.05 * rng.uniform(-1, 1, L)
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
-    from maximilian_amd.dist import MixReducer, bank_parameters, shard_range
+    from maximilian_amd.dist import (HostMixQueue, MixdownStep, bank_parameters, shard_range, stream_parameters)
     from oracle import pyoracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     orc = pyoracle.port()
     orc.settings(44100, 2, 1024)
-    Vr, B, blocks = 96, 64, 3
-    lo, hi = shard_range(rank, world, Vr)
-    freq, pan = bank_parameters(lo, hi, Vr * world)
-    red = MixReducer(dist, lambda: torch.zeros((B, 2), dtype=torch.float64))
-    phase = hold = None
-    got = []
-    for _ in range(blocks):
-        out, phase, hold = orc.osc(8, freq, B, phase=phase, hold=hold)
-        buf = red.next_buffer()
-        buf.copy_(torch.from_numpy(orc.mix_stereo(out, pan)))
-        res = red.submit()
-        red.drain()
-        got.append(res.clone().numpy())
+
+    # ---- config-2 shape: voice shard, block by block, M blocks per reduce --------------------------------
+    c = CFG2
+    lo, hi = shard_range(rank, world, c["Vr"])
+    freq, pan = bank_parameters(lo, hi, c["Vr"] * world)
+    queue = HostMixQueue(dist, c["B"] * 2, depth_blocks=c["M"])
+    state = {"phase": None, "hold": None}
+    got2 = []
+
+    def render_mix(slot):
+        out, state["phase"], state["hold"] = orc.osc(8, freq, c["B"], phase=state["phase"], hold=state["hold"])
+        slot.copy_(torch.from_numpy(orc.mix_stereo(out, pan).reshape(-1)))
+
+    step = MixdownStep(render_mix, queue)
+    for k in range(c["blocks"]):
+        before = queue.batches
+        step()
+        if queue.batches != before:  # a full batch was submitted: collect it
+            got2.append(queue.result_numpy())
+    step.finish()
+    if queue.last_blocks and len(got2) * c["M"] < c["blocks"]:
+        got2.append(queue.result_numpy())
+    got2 = np.concatenate(got2).reshape(-1, c["B"], 2)
+
+    # ---- config-5 shape: grain-stream shard, one [T][2] reduce -------------------------------------------
+    g = CFG5
+    lo, hi = shard_range(rank, world, g["Sr"])
+    pos, speed, pan5 = stream_parameters(lo, hi, g["Sr"] * world)
+    smp = _grain_sample(g["L"])
+    queue5 = HostMixQueue(dist, g["T"] * 2, depth_blocks=1)
+
+    def render_mix5(slot):
+        st = np.zeros((4, hi - lo))
+        st[0] = np.clip(pos * g["L"], 0, g["L"] - 1)   # setPosition, L/maxiGrains.h:335-338
+        out, _, _, rc = orc.granular(0, 0, smp, g["T"], speed, st=st)
+        assert rc == 0
+        slot.copy_(torch.from_numpy(orc.mix_stereo(out, pan5).reshape(-1)))
+
+    step5 = MixdownStep(render_mix5, queue5)
+    step5()
+    step5.finish()
+    got5 = queue5.result_numpy().reshape(g["T"], 2)
     if rank == 0:
-        q.put(np.stack(got))
+        q.put((got2, got5))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_shard_helpers():
-    from maximilian_amd.dist import bank_parameters, shard_range
+    from maximilian_amd.dist import bank_parameters, shard_range, stream_parameters
     assert shard_range(0, 8, 65536) == (0, 65536) and shard_range(7, 8, 65536) == (7 * 65536, 8 * 65536)
     with pytest.raises(ValueError):
         shard_range(8, 8, 4)
@@ -63,25 +102,59 @@ def test_shard_helpers():
     # shards tile the bank without gaps or overlap
     edges = [shard_range(r, 4, 10) for r in range(4)]
     assert [e[0] for e in edges[1:]] == [e[1] for e in edges[:-1]]
+    pos, speed, pan = stream_parameters(2048, 2052, 16384)
+    assert pos[0] == 2048 / 16384.0 and speed[1] == 0.25 + 1.5 * (2049 % 97) / 96 and pan[0] == 2048 / 16383.0
 
 
-def test_two_rank_mix_reduce_gloo(port):
+def test_host_queue_single_process_batches():
+    """The queue protocol alone (no process group): batches of M, a flushed partial batch, slots land in order."""
+    from maximilian_amd.dist import HostMixQueue, MixdownStep
+    q = HostMixQueue(None, 4, depth_blocks=3)
+    k = [0]
+
+    def fill(slot):
+        slot[:] = float(k[0])
+        k[0] += 1
+    step = MixdownStep(fill, q)
+    seen = []
+    for _ in range(8):
+        b = q.batches
+        step()
+        if q.batches != b:
+            seen.append(q.result_numpy()[:, 0].tolist())
+    step.finish()
+    seen.append(q.result_numpy()[:, 0].tolist())
+    assert seen == [[0.0, 1.0, 2.0], [3.0, 4.0, 5.0], [6.0, 7.0]] and step.blocks == 8
+
+
+def test_two_rank_mixdown_steps_gloo(port):
     import torch.multiprocessing as mp
-    from maximilian_amd.dist import bank_parameters
+    from maximilian_amd.dist import bank_parameters, stream_parameters
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     prt = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, prt, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got2, got5 = q.get(timeout=180)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    # expected: the whole 192-voice bank on one "device", sequential reference sum
-    Vr, B, blocks = 96, 64, 3
-    freq, pan = bank_parameters(0, 2 * Vr, 2 * Vr)
-    out, _, _ = port.osc(8, freq, B * blocks)
-    exp = port.mix_stereo(out, pan).reshape(blocks, B, 2)
-    assert np.abs(got - exp).max() <= 1e-12 * 2 * Vr   # cross-rank sum order != sequential order
-    assert np.abs(got).max() > 0.1
+    # config-2 shape: the whole 192-voice bank on one "device", the reference's sequential sum
+    c = CFG2
+    freq, pan = bank_parameters(0, 2 * c["Vr"], 2 * c["Vr"])
+    out, _, _ = port.osc(8, freq, c["B"] * c["blocks"])
+    exp = port.mix_stereo(out, pan).reshape(c["blocks"], c["B"], 2)
+    assert got2.shape == exp.shape
+    assert np.abs(got2 - exp).max() <= 1e-12 * 2 * c["Vr"]   # cross-rank sum order != sequential order
+    assert np.abs(got2).max() > 0.1
+    # config-5 shape: all 48 streams in one sequential mix
+    g = CFG5
+    pos, speed, pan5 = stream_parameters(0, 2 * g["Sr"], 2 * g["Sr"])
+    st = np.zeros((4, 2 * g["Sr"]))
+    st[0] = np.clip(pos * g["L"], 0, g["L"] - 1)
+    o5, _, _, rc = port.granular(0, 0, _grain_sample(g["L"]), g["T"], speed, st=st)
+    assert rc == 0
+    exp5 = port.mix_stereo(o5, pan5)
+    assert np.abs(got5 - exp5).max() <= 1e-12 * 2 * g["Sr"]
+    assert np.abs(got5).max() > 0.05
