@@ -101,7 +101,9 @@ def main():
     ap.add_argument("--voice-mode", type=int, default=0, choices=[0, 1], help="config3: 0 = hoisted coefficients, 1 = 14.monosynth order")
     ap.add_argument("--mfcc-method", default="sparse", choices=["sparse", "mfma"],
                     help="config4: exact sparse mel walk (default) or the dense fp64 MFMA contraction")
-    ap.add_argument("--kernel-events", default="inline", choices=["inline", "pass", "off"],
+    ap.add_argument("--mfma-fullk", action="store_true",
+                    help="config4 mfma: contract over all 512 bins instead of the 256 that carry mel weight")
+    ap.add_argument("--kernel-events", default="pass", choices=["inline", "pass", "off"],
                     help="per-kernel HIP events inside the timed region (inline), in a separate pass, or not at all")
     args = ap.parse_args()
     defaults = {"config2": (2000, 100), "config3": (1280, 128), "config4": (20, 3), "config5": (20, 3)}
@@ -213,7 +215,7 @@ def main():
         step = voice_block if mixdown == "off" else MixdownStep(render_mix3, queue)
 
         def cpu():
-            return _baseline(lambda o, n, th: o.time_voice(mode, f3, cu3, rs3, n, threads=th), lambda n: V * n, (32, 1 << 13),
+            return _baseline(lambda o, n, th: o.time_voice(mode, f3, cu3, rs3, n, threads=th), lambda n: V * n, (32, 1 << 16),
                              "samples per voice", "%d voices saw->lores->adsr (mode %d), voice-inner loop of 15.polysynth" % (V, mode))
         W = dict(step=step, samples=V * B, dominant="voice_kernel", algo_bytes=(8.0 + 176.0 / B) * V * B, dtype="f64", cpu=cpu,
                  workload="configs[2]: fused subtractive voice maxiOsc::saw -> maxiFilter::lores -> maxiEnv::adsr (mode %d), %d voices "
@@ -230,6 +232,9 @@ def main():
                                                                                   generator=g) - 1)).to(torch.float32)
             del n, k
         mfma = args.mfcc_method == "mfma"
+        kdim = 512 if args.mfma_fullk else 256  # bins the MFMA kernel contracts over (weights beyond bin 232 are zero)
+        if mfma:
+            L.mxg_tune(b"mfcc_mfma_fullk", 1 if args.mfma_fullk else 0)
         mfcc = torch.empty((NF, 13), dtype=torch.float64, device=dev)
         fplan = mx.maxiFFT(); fplan.setup(1024, 1024, 1024)
         mplan = mx.maxiMFCC(); mplan.setup(512, 42, 13, 20.0, 20000.0)
@@ -248,14 +253,17 @@ def main():
 
         def cpu():
             if sig_h[0] is None:
-                sig_h[0] = sig[:1024 * 65536].cpu().numpy()
-            return _baseline(lambda o, n, th: o.time_spectral(sig_h[0][:n * 1024], threads=th), lambda n: n * 1024, (512, 65536),
+                sig_h[0] = sig[:1024 * 262144].cpu().numpy()
+            return _baseline(lambda o, n, th: o.time_spectral(sig_h[0][:n * 1024], threads=th), lambda n: n * 1024, (512, 262144),
                              "frames", "maxiFFT(1024,1024,1024)::process per sample + maxiMFCC(512,42,13)::mfcc per frame (mfcctest loop)")
         W = dict(step=step, samples=NF * 1024, dtype="f32 (FFT) / f64 (MFCC)", cpu=cpu,
-                 dominant="mfcc_mfma_kernel" if mfma else ("fft_mfcc_kernel" if fused_ok else "fft1024_kernel"),
-                 algo_bytes=4200.0 * NF if fused_ok else 6144.0 * NF, mfma_flops=2.0 * 512 * 42 * NF if mfma else None,
+                 dominant="mfcc_mfma_gemm_kernel" if mfma else ("fft_mfcc_kernel" if fused_ok else "fft1024_kernel"),
+                 algo_bytes=4200.0 * NF if fused_ok else 6144.0 * NF,
+                 # MFMA flops ISSUED: 2 x K x 48 (42 filters padded to 3 column blocks of 16) per frame
+                 mfma_flops=2.0 * kdim * 48 * NF if mfma else None,
+                 mfma_note="issued 2*%d*48 flops/frame (useful dense 2*512*42 = 43008)" % kdim if mfma else None,
                  workload="configs[3]: maxiFFT(1024,1024,1024) + maxiMFCC(512,42,13,20,20000) over %d frames per GPU per step, %s"
-                          % (NF, "dense fp64 MFMA mel contraction" if mfma else ("one fused kernel, exact sparse mel walk" if fused_ok
+                          % (NF, "FFT kernel + dense fp64 MFMA mel contraction (K = %d bins)" % kdim if mfma else ("one fused kernel, exact sparse mel walk" if fused_ok
                                                                                else "FFT kernel + exact sparse mel walk")))
     else:  # config5
         S, T, Ls = 2048, 70560, 4410000
@@ -284,9 +292,9 @@ def main():
         step = grains if mixdown == "off" else MixdownStep(render_mix5, queue)
 
         def cpu():
-            Sc = 256  # streams of the bounded sample (same parameters as the first 256 of this rank)
+            Sc = 2048  # streams of the bounded sample: this rank's whole share
             return _baseline(lambda o, n, th: o.time_grains(smp, speed5[:Sc], pos5[:Sc], n, threads=th), lambda n: Sc * n * 4,
-                             (2048, 70560), "samples per stream", "%d maxiTimeStretch<hann> streams, play(speed,0.05,4), stream-inner "
+                             (256, 8 * 70560), "samples per stream", "%d maxiTimeStretch<hann> streams, play(speed,0.05,4), stream-inner "
                              "loop, 4 grain-samples per stream-sample" % Sc)
         W = dict(step=step, samples=S * T * 4, dominant="granular_unit_kernel", algo_bytes=(8.0 * 4 + 8.0) * S * T, dtype="f64", cpu=cpu,
                  workload="configs[4]: %d maxiTimeStretch<hann> streams per GPU x %d samples per step, grainLength 0.05, overlaps 4 "
@@ -371,7 +379,7 @@ def main():
             ach = W["mfma_flops"] / (dom_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F64_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "flops_per_launch": W["mfma_flops"]}
+                    "flops_per_launch": W["mfma_flops"], "note": W.get("mfma_note")}
         else:
             ach = algo_per_launch / (dom_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -395,6 +395,18 @@ int mxg_mfcc_plan_tables(const mxg_mfcc_plan *plan, double *h_melFilters, double
 int mxg_mfcc_batch(const mxg_mfcc_plan *plan, const float *d_mags, size_t mag_stride, size_t nframes,
                    double *d_melraw, double *d_melbands, double *d_mfcc, int method, void *stream);
 
+/* ---- maxiFFT + maxiMFCC in one pass (the loop of cpp/commandline/tests/mfcctest/mfcctest.cpp:21-32 over a batch) ---- */
+/* For every frame k = d_signal[k*frame_stride .. +1024): mags = maxiFFT(1024).process(...) magnitudes (L/fft.cpp:499-511),
+ * then maxiMFCC::mfcc(mags) (L/maxiMFCC.h:77-81) -> d_mfcc [nframes][numCoeffs], in ONE kernel: the magnitudes stay in
+ * LDS, so a frame costs its 4096 B of input and its numCoeffs*8 B of output in HBM traffic.  fft_plan must be a
+ * 1024-point plan and mfcc_plan one for 512 bins with at most 64 filters (otherwise MXG_ERR_INVALID: use mxg_fft_batch +
+ * mxg_mfcc_batch).  Optional outputs (NULL = not produced): d_mags [nframes][512] (bit-exact, as mxg_fft_batch),
+ * d_melraw / d_melbands [nframes][numFilters] (as mxg_mfcc_batch method 0: band sums bit-exact, log-square / mfcc
+ * within the device log's tolerance). */
+int mxg_fft_mfcc_batch(const mxg_fft_plan *fft_plan, const mxg_mfcc_plan *mfcc_plan, const float *d_signal,
+                       size_t frame_stride, size_t nframes, float *d_mags, double *d_melraw, double *d_melbands,
+                       double *d_mfcc, void *stream);
+
 /* ---- maxiGrains: maxiTimeStretch / maxiStretch banks --------------------------------------- */
 /* Window kinds = the functors of L/maxiGrains.h:18-90: 0 hann 1 hamming 2 cosine 3 rect 4 triangle
  * 5 triangleNZ 6 blackmanHarris 7 blackmanNutall 8 gaussian(0.3).  A plan holds the window table

@@ -88,6 +88,8 @@ SIGNATURES = {
     "mxg_mfcc_plan_tables": (c_int, [c_void_p, c_void_p, c_void_p]),
     "mxg_mfcc_batch": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p,
                                c_int, c_void_p]),
+    "mxg_fft_mfcc_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
     "mxg_grain_plan_create": (c_void_p, [c_int, c_double, c_int]),
     "mxg_grain_plan_destroy": (c_int, [c_void_p]),
     "mxg_grain_plan_window": (c_int, [c_void_p, c_void_p]),

@@ -31,53 +31,10 @@
 #define M_PI 3.14159265358979323846
 #endif
 
-struct mxg_fft_plan {
-    int fftSize, hopSize, windowSize, bins, half, numBits;
-    float *d_window;   // [fftSize]
-    float2 *d_tw;      // stage twiddles: entry (h-1)+n = (ar0, ai0) of step n in a stage with BlockEnd h
-    float2 *d_post;    // post-pass (wr, wi) for i = 1 .. half/2-1 at index i
-};
-
-// maxiIFFT::setup (L/maxiFFT.cpp:140-153): windowSize ? windowSize : fftSize, Hann over that, zero beyond
-struct mxg_ifft_plan {
-    int fftSize, hopSize, windowSize, bins, numBits;  // numBits = log2(fftSize): the inverse is a FULL-size complex FFT
-    float *d_window;  // [fftSize]
-    float2 *d_tw;     // inverse-direction stage twiddles, same indexing as mxg_fft_plan::d_tw
-};
+#include "mxg_spectral.h"
 
 namespace mxg {
 namespace {
-
-__device__ __forceinline__ void wave_lds_sync() {
-    // LDS traffic of ONE wavefront: the DS unit executes a wave's instructions in order, so only
-    // the compiler has to be told not to move accesses across this point.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// One butterfly, op for op L/fft.cpp:184-192 (j = upper, k = lower input).
-__device__ __forceinline__ void bfly(float2 &xj, float2 &xk, const float2 w) {
-    float tr = w.x * xk.x - w.y * xk.y;
-    float ti = w.x * xk.y + w.y * xk.x;
-    xk.x = xj.x - tr;
-    xk.y = xj.y - ti;
-    xj.x += tr;
-    xj.y += ti;
-}
-
-// Real split post-pass for the pair (i, i3 = half - i), L/fft.cpp:250-268.
-__device__ __forceinline__ void post_pair(float2 &a, float2 &b, const float2 w) {
-    const float wr = w.x, wi = w.y;
-    float h1r = 0.5f * (a.x + b.x);
-    float h1i = 0.5f * (a.y - b.y);
-    float h2r = 0.5f * (a.y + b.y);
-    float h2i = -0.5f * (a.x - b.x);
-    a.x = h1r + wr * h2r - wi * h2i;
-    a.y = h1i + wr * h2i + wi * h2r;
-    b.x = h1r - wr * h2r + wi * h2i;
-    b.y = -h1i + wr * h2i + wi * h2r;
-}
 
 struct FftOut {
     float *real, *imag, *mags, *phases;
@@ -120,7 +77,6 @@ __device__ __forceinline__ void emit_bin(const FftOut &o, size_t base, int bin, 
 }
 
 // ---- K6b: generic size -----------------------------------------------------------------------
-constexpr int kWavesPerBlock = 4;
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void fft_generic_kernel(
     const float *__restrict__ signal, size_t frame_stride, size_t nframes, int fftSize, int numBits,
@@ -257,29 +213,7 @@ __global__ void ifft_ola_kernel(const float *__restrict__ ifft_out, size_t nfram
 }
 
 
-// ---- K6a: fftSize 1024 (half = 512 = 8^3) ------------------------------------------------------
-// LDS image of one frame: 512 float2 + 1 pad per 8 (index p = i + i/8): conflict-free for the
-// stride-8 and stride-64 lane patterns of the two transposes (bank maths in DESIGN.md).
-constexpr int kX1024 = 512 + 64;
-#ifndef MXG_FFT_MINWAVES
-#define MXG_FFT_MINWAVES 3
-#endif
-
-__device__ __forceinline__ int pad8(int i) { return i + (i >> 3); }
-
-// three in-register radix-2 stages over the 8 points of a lane; w0: 1 twiddle (pairs e,e+1),
-// w1[2]: pairs (e,e+2) with n-offset e&1, w2[4]: pairs (e,e+4) with n-offset e&3.
-__device__ __forceinline__ void round3(float2 (&x)[8], const float2 w0, const float2 (&w1)[2],
-                                       const float2 (&w2)[4]) {
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) bfly(x[e], x[e + 1], w0);
-#pragma unroll
-    for (int e = 0; e < 8; e++)
-        if ((e & 2) == 0) bfly(x[e], x[e + 2], w1[e & 1]);
-#pragma unroll
-    for (int e = 0; e < 4; e++) bfly(x[e], x[e + 4], w2[e]);
-}
-
+// ---- K6a: fftSize 1024 (half = 512 = 8^3): LDS image, pad8 and round3 live in mxg_spectral.h ------------
 template <int OMASK, bool ALIGNED8>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MXG_FFT_MINWAVES) void fft1024_kernel(
     const float *__restrict__ signal, size_t frame_stride, size_t nframes,

@@ -39,25 +39,10 @@
 
 #include "mxg_common.h"
 
-struct mxg_mfcc_plan {
-    unsigned numBins, numFilters, numCoeffs, nbUsed;  // nbUsed = 1 + last bin with a non-zero weight
-    std::vector<double> h_W;    // [filter + bin*numFilters]  (reference layout)
-    std::vector<double> h_dct;  // [i + j*numCoeffs]
-    int slots;                  // S: max number of simultaneously open filters (0 = stream kernel n/a)
-    double *d_schedW;           // [nbUsed][S] weight of the filter occupying slot s at this bin (or 0)
-    int *d_schedFin;            // [nbUsed][S] filter closing in slot s after this bin, or -1
-    int *d_lo, *d_hi, *d_off;   // per filter: support [lo, hi] (hi < lo = empty), offset into d_Wc
-    double *d_Wc;               // compacted weights, filter-major, increasing bin
-    double *d_dct;              // [j*numCoeffs + i]
-    double *d_Wpad;             // dense [kPad][nfPad] row-major by bin, for the MFMA path
-    unsigned nfPad, kPad;
-};
+#include "mxg_spectral.h"
 
 namespace mxg {
 namespace {
-
-// log-square of L/maxiMFCC.cpp:63
-__device__ __forceinline__ double log_square(double mb) { return mb > 0.000001 ? log(mb * mb) : 0.0; }
 
 // ---- K7a: bin-major streaming, one lane per frame ------------------------------------------------
 template <int S, int NC>
@@ -333,17 +318,180 @@ __global__ __launch_bounds__(64) void mfcc_mfma_kernel(
     }
 }
 
+// ---- K7b: the dense contraction as a tiled fp64 MFMA GEMM ---------------------------------------------
+// C[frames x filters] = A[frames x K] (fp32 spectra, widened) x W[K x filters] on v_mfma_f64_16x16x4_f64.
+// A workgroup = 4 wavefronts, each owning a 64-frame x (NT*16)-filter tile: 4 x NT independent accumulators per
+// wave (16 x NT x 4 doubles), so the matrix pipe never waits on its own result.  K is walked in tiles of 32 bins:
+//   A   every wave loads ITS [64 frames x 32 bins] fp32 tile coalesced (8 lanes = the 128 B of one frame row), parks
+//       it in LDS with row stride 34 floats (bank = 2*frame + k: the fragment read `frame = lane&15, k = lane>>4` is
+//       conflict-free) and widens to f64 after the LDS read -- the spectrum crosses HBM once, as fp32;
+//   W   the [32 bins x NT*16] f64 weight tile is loaded once per workgroup (L2-resident: 90-200 KB in all) and shared
+//       by the four waves; row stride NT*16 doubles => the fragment read `k = lane>>4, col = lane&15` is conflict-free.
+// Both are double-buffered: the global loads of tile t+1 are in flight while tile t feeds 8 x 4 x NT MFMAs per wave, one
+// __syncthreads() per tile.  Per 4-bin step a lane issues 4 + NT LDS reads and 4 cvt for 4*NT MFMAs of 64 cycles each.
+// Epilogue (banks up to 64 filters): the accumulators go to LDS as [frame][filter], then EVERY lane owns one frame:
+// log-square, then the DCT in the reference's j order with wave-uniform (scalar-loaded) coefficients.  Larger banks
+// (mfcctest's 512/256/13) run in groups of 64 filters, write the raw band sums and finish in mfcc_logdct_kernel.
+// FMA chains inside the MFMA round differently from the reference's mul-then-add loop => tolerance.
+constexpr int kGemmFrames = 64, kGemmKT = 32, kGemmAStride = 34;
+
+template <int NT, bool EPILOGUE>
+__global__ __launch_bounds__(256) void mfcc_mfma_gemm_kernel(
+    const float *__restrict__ mags, size_t mag_stride, size_t nframes, unsigned numFilters, unsigned numCoeffs,
+    unsigned kTiles, unsigned wStride, unsigned fOff, const double *__restrict__ Wpad, const double *__restrict__ dct,
+    double *__restrict__ melraw, double *__restrict__ melbands, double *__restrict__ mfcc, unsigned rawStride) {
+    extern __shared__ double s_dyn[];
+    constexpr int NW = NT * 16;
+    double *sW = s_dyn;                                                     // [2][32][NW]
+    float *sA = reinterpret_cast<float *>(s_dyn + 2 * kGemmKT * NW);        // [4 waves][2][64][34]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *myA = sA + (size_t)wave * 2 * kGemmFrames * kGemmAStride;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int lrow = lane >> 3, lcol = (lane & 7) * 4;
+    const size_t tilesTotal = (nframes + 4 * kGemmFrames - 1) / (4 * kGemmFrames);
+    for (size_t bt = blockIdx.x; bt < tilesTotal; bt += gridDim.x) {
+        const size_t F0 = (bt * 4 + wave) * kGemmFrames;  // this wave's 64 frames (may start past the end: then all clamped)
+        const float *gsrc[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            size_t fr = F0 + lrow + 8 * i;
+            if (fr >= nframes) fr = nframes - 1;
+            gsrc[i] = mags + fr * mag_stride + lcol;
+        }
+        d4 acc[4][NT];
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+            for (int cb = 0; cb < NT; cb++) acc[rb][cb] = (d4){0.0, 0.0, 0.0, 0.0};
+        float an[8][4];
+        constexpr int kWPer = (16 * NW + 255) / 256;  // double2 loads per thread per weight tile (32*NW doubles / 256 threads)
+        double2v wn[kWPer];
+        auto loadA = [&](unsigned kt) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float4 v4 = *reinterpret_cast<const float4 *>(gsrc[i] + (size_t)kt * kGemmKT);
+                an[i][0] = v4.x; an[i][1] = v4.y; an[i][2] = v4.z; an[i][3] = v4.w;
+            }
+        };
+        auto loadW = [&](unsigned kt) {
+#pragma unroll
+            for (int j = 0; j < kWPer; j++) {
+                const unsigned e = threadIdx.x + 256u * j;  // double2 index inside the tile: row = e / (NW/2)
+                if (e < 16u * NW) {
+                    const unsigned row = e / (NW / 2), c2 = e % (NW / 2);
+                    wn[j] = *reinterpret_cast<const double2v *>(Wpad + ((size_t)kt * kGemmKT + row) * wStride + fOff + 2 * c2);
+                }
+            }
+        };
+        loadA(0);
+        loadW(0);
+        for (unsigned kt = 0; kt < kTiles; kt++) {
+            float *bufA = myA + (kt & 1) * kGemmFrames * kGemmAStride;
+            double *bufW = sW + (kt & 1) * kGemmKT * NW;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float *d = bufA + (lrow + 8 * i) * kGemmAStride + lcol;
+                *reinterpret_cast<float2 *>(d) = make_float2(an[i][0], an[i][1]);
+                *reinterpret_cast<float2 *>(d + 2) = make_float2(an[i][2], an[i][3]);
+            }
+#pragma unroll
+            for (int j = 0; j < kWPer; j++) {
+                const unsigned e = threadIdx.x + 256u * j;
+                if (e < 16u * NW) *reinterpret_cast<double2v *>(bufW + 2 * e) = wn[j];
+            }
+            if (kt + 1 < kTiles) {
+                loadA(kt + 1);
+                loadW(kt + 1);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < kGemmKT / 4; ks++) {
+                double a[4], b[NT];
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) a[rb] = (double)bufA[(rb * 16 + r16) * kGemmAStride + ks * 4 + kq];
+#pragma unroll
+                for (int cb = 0; cb < NT; cb++) b[cb] = bufW[(ks * 4 + kq) * NW + cb * 16 + r16];
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+                    for (int cb = 0; cb < NT; cb++)
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // every wave is done with both operand buffers: the epilogue reuses the LDS
+        if constexpr (EPILOGUE) {
+            const unsigned ES = NW + 1;
+            double *tile = s_dyn + (size_t)wave * kGemmFrames * ES;
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+                for (int cb = 0; cb < NT; cb++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) tile[(rb * 16 + kq + 4 * r) * ES + cb * 16 + r16] = acc[rb][cb][r];
+            wave_lds_sync();
+            const size_t fr = F0 + lane;
+            const bool live = fr < nframes;
+            double *row = tile + lane * ES;
+            for (unsigned f = 0; f < numFilters; f++) {
+                const double v = row[f];
+                const double lv = log_square(v);
+                row[f] = lv;
+                if (live) {
+                    if (melraw) melraw[fr * numFilters + f] = v;
+                    if (melbands) melbands[fr * numFilters + f] = lv;
+                }
+            }
+            for (unsigned i = 0; i < numCoeffs; i++) {
+                double c = 0.0;
+                for (unsigned f = 0; f < numFilters; f++) c += (dct[f * numCoeffs + i] * row[f]);  // L/maxiMFCC.h:105
+                if (live) mfcc[fr * numCoeffs + i] = c / (double)numCoeffs;                         // :109
+            }
+            __syncthreads();
+        } else {
+            // raw band sums of this filter group straight to global [frame][rawStride]
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+                for (int cb = 0; cb < NT; cb++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const size_t fr = F0 + rb * 16 + kq + 4 * r;
+                        const unsigned f = fOff + cb * 16 + r16;
+                        if (fr < nframes && f < numFilters) melraw[fr * rawStride + f] = acc[rb][cb][r];
+                    }
+        }
+    }
+}
+
+// log-square + DCT over raw band sums [nframes][numFilters] (banks wider than one MFMA filter group): lane = frame
+__global__ __launch_bounds__(256) void mfcc_logdct_kernel(size_t nframes, unsigned numFilters, unsigned numCoeffs,
+                                                          const double *__restrict__ raw, const double *__restrict__ dct,
+                                                          double *__restrict__ melbands, double *__restrict__ mfcc) {
+    const size_t fr = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (fr >= nframes) return;
+    double *out = mfcc + fr * numCoeffs;
+    for (unsigned i = 0; i < numCoeffs; i++) out[i] = 0.0;
+    for (unsigned f = 0; f < numFilters; f++) {
+        const double lv = log_square(raw[fr * numFilters + f]);
+        if (melbands) melbands[fr * numFilters + f] = lv;
+        for (unsigned i = 0; i < numCoeffs; i++) out[i] += (dct[f * numCoeffs + i] * lv);
+    }
+    for (unsigned i = 0; i < numCoeffs; i++) out[i] = out[i] / (double)numCoeffs;
+}
+
 double hzToMel(double hz) { return 2595.0 * (log10(hz / 700.0 + 1.0)); }       // L/maxiMFCC.h:30-32
 double melToHz(double mel) { return 700.0 * (pow(10, mel / 2595.0) - 1.0); }  // L/maxiMFCC.h:36-38
 
 void free_device(mxg_mfcc_plan *p) {
-    void *ptrs[] = {p->d_schedW, p->d_schedFin, p->d_lo, p->d_hi, p->d_off, p->d_Wc, p->d_dct, p->d_Wpad};
+    void *ptrs[] = {p->d_schedW, p->d_schedFin, p->d_lo, p->d_hi, p->d_off, p->d_Wc, p->d_dct, p->d_Wpad, p->d_fsW, p->d_fsMeta};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     p->d_schedW = nullptr;
     p->d_schedFin = nullptr;
     p->d_lo = p->d_hi = p->d_off = nullptr;
     p->d_Wc = p->d_dct = p->d_Wpad = nullptr;
+    p->d_fsW = nullptr;
+    p->d_fsMeta = nullptr;
 }
 
 template <typename T>
@@ -380,6 +528,9 @@ mxg_mfcc_plan *mxg_mfcc_plan_create(unsigned numBins, unsigned numFilters, unsig
     p->d_schedFin = nullptr;
     p->d_lo = p->d_hi = p->d_off = nullptr;
     p->d_Wc = p->d_dct = p->d_Wpad = nullptr;
+    p->fsSteps = 0;
+    p->d_fsW = nullptr;
+    p->d_fsMeta = nullptr;
     // ---- calcMelFilterBank (L/maxiMFCC.h:118-182): `sampleRate` is an unsigned int member
     const double sampleRate = (double)(unsigned int)settings().sampleRate;
     const double nyquist = sampleRate / 2;
@@ -492,15 +643,49 @@ mxg_mfcc_plan *mxg_mfcc_plan_create(unsigned numBins, unsigned numFilters, unsig
             }
         }
     }
+    // ---- slot schedule of the fused kernel: longest-processing-time packing of the filters into kFusedSlots lists
+    std::vector<double> fsW;
+    std::vector<int> fsMeta;
+    if (numFilters <= 64 && numCoeffs <= 32 && nbUsed <= 512) {
+        std::vector<unsigned> order;
+        for (unsigned f = 0; f < numFilters; f++)
+            if (hi[f] >= lo[f]) order.push_back(f);
+        std::stable_sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return hi[a] - lo[a] > hi[b] - lo[b]; });
+        std::vector<std::vector<unsigned>> lists(kFusedSlots);
+        std::vector<int> load(kFusedSlots, 0);
+        for (unsigned f : order) {
+            int s = 0;
+            for (int k = 1; k < kFusedSlots; k++)
+                if (load[k] < load[s]) s = k;
+            lists[s].push_back(f);
+            load[s] += hi[f] - lo[f] + 1;
+        }
+        int T = 1;
+        for (int s = 0; s < kFusedSlots; s++) T = load[s] > T ? load[s] : T;
+        fsW.assign((size_t)T * kFusedSlots, 0.0);
+        fsMeta.assign((size_t)T * kFusedSlots, 0);
+        for (int s = 0; s < kFusedSlots; s++) {
+            int t = 0;
+            for (unsigned f : lists[s])
+                for (int bin = lo[f]; bin <= hi[f]; bin++, t++) {
+                    fsW[(size_t)t * kFusedSlots + s] = p->h_W[f + (size_t)bin * numFilters];
+                    fsMeta[(size_t)t * kFusedSlots + s] = bin | (bin == hi[f] ? (int)(f + 1) << 16 : 0);
+                }
+        }
+        p->fsSteps = T;
+    }
     p->nfPad = (numFilters + 15) / 16 * 16;
     p->kPad = (nbUsed + 3) / 4 * 4;  // rows >= numBins carry zero weights; the kernel guards the A read
+    // the GEMM kernel walks K in tiles of 32 bins: rows up to the next multiple of 32 of numBins exist (zeros)
+    const unsigned kRows = (numBins + 31) / 32 * 32;
     std::vector<double> dctT(p->h_dct);  // [j*numCoeffs + i] is the reference's own linear index
-    std::vector<double> Wpad((size_t)p->kPad * p->nfPad, 0.0);
-    for (unsigned bin = 0; bin < p->kPad && bin < numBins; bin++)
+    std::vector<double> Wpad((size_t)kRows * p->nfPad, 0.0);
+    for (unsigned bin = 0; bin < numBins; bin++)
         for (unsigned f = 0; f < numFilters; f++) Wpad[(size_t)bin * p->nfPad + f] = p->h_W[f + (size_t)bin * numFilters];
     if (ensure_init() || !upload(&p->d_lo, lo) || !upload(&p->d_hi, hi) || !upload(&p->d_off, off) ||
         !upload(&p->d_Wc, Wc) || !upload(&p->d_dct, dctT) || !upload(&p->d_Wpad, Wpad) ||
-        !upload(&p->d_schedW, schedW) || !upload(&p->d_schedFin, schedFin)) {
+        !upload(&p->d_schedW, schedW) || !upload(&p->d_schedFin, schedFin) || !upload(&p->d_fsW, fsW) ||
+        !upload(&p->d_fsMeta, fsMeta)) {
         // Host tables stay valid (mxg_mfcc_plan_tables works without a device); compute calls fail.
         free_device(p);
     }
@@ -581,8 +766,55 @@ int mxg_mfcc_batch(const mxg_mfcc_plan *p, const float *d_mags, size_t mag_strid
         hipLaunchKernelGGL(mfcc_tile_kernel, dim3((unsigned)blocks), dim3(64), lds, st, d_mags, mag_stride, nframes,
                            p->numFilters, p->numCoeffs, p->nbUsed, tileStride, p->d_lo, p->d_hi, p->d_off, p->d_Wc,
                            p->d_dct, d_melraw, d_melbands, d_mfcc);
-    } else {
-        MXG_REQUIRE(p->nfPad <= 64, "mfma method supports up to 64 filters");
+    } else if ((((uintptr_t)d_mags) & 15) == 0 && (mag_stride & 3) == 0 && mag_stride >= (p->numBins + 31) / 32 * 32) {
+        // K7b as a tiled GEMM.  K = the bins that carry weight (rounded up to 32), or all of them with mfcc_mfma_fullk.
+        const unsigned kTiles = tune_get("mfcc_mfma_fullk") ? (p->numBins + 31) / 32 : (p->nbUsed + 31) / 32;
+        const size_t tilesTotal = (nframes + 4 * kGemmFrames - 1) / (4 * kGemmFrames);
+        const unsigned blocks = (unsigned)(tilesTotal < 256 ? tilesTotal : 256);  // one 100 KB workgroup per CU
+        auto lds_for = [](int NT, bool epi) {
+            const size_t NW = (size_t)NT * 16;
+            const size_t mainB = sizeof(double) * 2 * kGemmKT * NW + sizeof(float) * 4 * 2 * kGemmFrames * kGemmAStride;
+            const size_t epiB = epi ? sizeof(double) * 4 * kGemmFrames * (NW + 1) : 0;
+            return mainB > epiB ? mainB : epiB;
+        };
+#define MXG_GEMM_LAUNCH(NT, EPI, FOFF, RAW, RAWSTRIDE)                                                                  \
+    do {                                                                                                                \
+        const size_t lds = lds_for(NT, EPI);                                                                            \
+        MXG_HIP(hipFuncSetAttribute((const void *)mfcc_mfma_gemm_kernel<NT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds));                                                                         \
+        hipLaunchKernelGGL((mfcc_mfma_gemm_kernel<NT, EPI>), dim3(blocks), dim3(256), lds, st, d_mags, mag_stride, nframes,   \
+                           p->numFilters, p->numCoeffs, kTiles, p->nfPad, FOFF, p->d_Wpad, p->d_dct, RAW, d_melbands, d_mfcc,  \
+                           RAWSTRIDE);                                                                                  \
+    } while (0)
+        if (p->nfPad <= 64) {
+            KernelTimer kt("mfcc_mfma_gemm_kernel", st);
+            switch (p->nfPad / 16) {
+                case 1: MXG_GEMM_LAUNCH(1, true, 0u, d_melraw, p->numFilters); break;
+                case 2: MXG_GEMM_LAUNCH(2, true, 0u, d_melraw, p->numFilters); break;
+                case 3: MXG_GEMM_LAUNCH(3, true, 0u, d_melraw, p->numFilters); break;
+                default: MXG_GEMM_LAUNCH(4, true, 0u, d_melraw, p->numFilters); break;
+            }
+        } else {  // wide banks (mfcctest: 256 filters): groups of 64 filters, raw sums to memory, then log + DCT
+            double *raw = d_melraw;
+            if (!raw)
+                if (int e = scratch_get(SCR_MFCC_RAW, st, sizeof(double) * nframes * p->numFilters, (void **)&raw)) return e;
+            {
+                KernelTimer kt("mfcc_mfma_gemm_kernel", st);
+                for (unsigned fo = 0; fo < p->nfPad; fo += 64) {
+                    const unsigned left = p->nfPad - fo;
+                    if (left >= 64) MXG_GEMM_LAUNCH(4, false, fo, raw, p->numFilters);
+                    else if (left >= 48) MXG_GEMM_LAUNCH(3, false, fo, raw, p->numFilters);
+                    else if (left >= 32) MXG_GEMM_LAUNCH(2, false, fo, raw, p->numFilters);
+                    else MXG_GEMM_LAUNCH(1, false, fo, raw, p->numFilters);
+                }
+            }
+            KernelTimer kt2("mfcc_logdct_kernel", st);
+            hipLaunchKernelGGL(mfcc_logdct_kernel, dim3((unsigned)((nframes + 255) / 256)), dim3(256), 0, st, nframes,
+                               p->numFilters, p->numCoeffs, raw, p->d_dct, d_melbands, d_mfcc);
+        }
+#undef MXG_GEMM_LAUNCH
+    } else {  // unaligned spectra: the one-wave-per-16-frames kernel
+        MXG_REQUIRE(p->nfPad <= 64, "mfma method on unaligned spectra supports up to 64 filters");
         size_t blocks = (nframes + 15) / 16;
         if (blocks > 256 * 16) blocks = 256 * 16;
 #define MXG_MFMA_LAUNCH(NT)                                                                            \

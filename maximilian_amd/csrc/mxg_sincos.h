@@ -11,9 +11,13 @@
 // is exact) that keeps a
 // (hi, lo) remainder, then the classic minimax kernels for sin and cos on [-pi/4, pi/4] (the
 // coefficient sets published with Sun's fdlibm, k_sin.c / k_cos.c), evaluated with FMAs -- this is
-// libm-internal arithmetic, not one of the reference's expression trees.  Error < 0.85 ULP of the result (+ 2^-62
-// absolute next to a zero of the function), measured on 8 M arguments by tests/host_sincos_accuracy.cpp (0.77): below
-// 1 ULP, so the result and glibc's are the two doubles bracketing the true value -- at most 1 ULP apart.
+// libm-internal arithmetic, not one of the reference's expression trees.  Next to a zero of the function (remainder
+// below 2^-18) the result's own ULP shrinks below that reduction's absolute error (~3e-25, the rounding of k*pio2_lo),
+// so those arguments -- a wave-rare case -- repeat the reduction with fdlibm's three-iteration form (pi/2 in 33-bit
+// pieces whose products with k are exact: 151 bits), which keeps the RELATIVE error of the remainder at 2^-70 or better
+// even for x = fl(k*pi/2).  Error < 0.85 ULP of the result everywhere, measured against quad-precision sinq/cosq by
+// tests/host_sincos_accuracy.cpp (0.77 on 8 M arguments): below 1 ULP, so the result and glibc's are the two doubles
+// bracketing the true value -- at most 1 ULP apart, with no absolute-error escape near the zero crossings.
 // Anything else (|x| > 64, NaN, Inf) goes to the device's generic sin()/cos().
 #pragma once
 #if defined(__HIPCC__)
@@ -31,7 +35,12 @@ namespace sincos_detail {
 constexpr double kInvPio2 = 6.36619772367581382433e-01;  // 2/pi
 constexpr double kPio2Hi = 1.57079632673412561417e+00;   // first 33 bits of pi/2
 constexpr double kPio2Lo = 6.07710050650619224932e-11;   // pi/2 - kPio2Hi
-constexpr double kPio2Lo2 = 2.02226624879595063154e-21;  // pi/2 - kPio2Hi - kPio2Lo (third piece)
+constexpr double kPio2Lo2 = 3.52155982182414973774e-27;  // pi/2 - kPio2Hi - kPio2Lo (third piece; round 1 had fdlibm's
+                                                         // pio2_2t here, the tail after the 33-bit SECOND piece: k*2e-21 off)
+// fdlibm e_rem_pio2.c: pi/2 = kPio2Hi + kPio2_2 + kPio2_3 + kPio2_3t, the first three 33 bits each
+constexpr double kPio2_2 = 6.07710050630396597660e-11, kPio2_2t = 2.02226624879595063154e-21;
+constexpr double kPio2_3 = 2.02226624871116645580e-21, kPio2_3t = 8.47842766036889956997e-32;
+constexpr double kSmallRem = 0x1p-18;  // below this the one-shot reduction's absolute error shows in the result's ULP
 constexpr double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
                  S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
 constexpr double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
@@ -61,6 +70,25 @@ __device__ __forceinline__ int reduce(double x, double &y, double &t) {
     t = ((z - y) - w) - fn * kPio2Lo2;
     return (int)fn;
 }
+// The same remainder to 151 bits of pi/2 (fdlibm's e_rem_pio2.c pieces): every fn*piece product is exact
+// (33 + 6 bits) and every subtraction is an error-free TwoSum, so y + t = x - fn*pi/2 to ~2^-150 absolute.
+__device__ __forceinline__ void two_diff(double a, double b, double &s, double &e) {
+#pragma clang fp contract(off)
+    s = a - b;
+    const double bb = a - s;  // the part of b that was actually subtracted
+    e = (a - (s + bb)) + (bb - b);
+}
+__device__ __forceinline__ void reduce_accurate(double x, double &y, double &t) {
+#pragma clang fp contract(off)
+    const double fn = rint(x * kInvPio2);
+    const double r1 = x - fn * kPio2Hi;  // exact
+    double r2, e2, r3, e3;
+    two_diff(r1, fn * kPio2_2, r2, e2);
+    two_diff(r2, fn * kPio2_3, r3, e3);
+    const double tail = (e2 + e3) - fn * kPio2_3t;
+    y = r3 + tail;
+    t = (r3 - y) + tail;
+}
 }  // namespace sincos_detail
 
 __device__ __forceinline__ double sin_small(double x) {
@@ -68,6 +96,7 @@ __device__ __forceinline__ double sin_small(double x) {
     if (!(fabs(x) <= 64.0)) return sin(x);
     double y, t;
     const int n = reduce(x, y, t) & 3;
+    if (fabs(y) < kSmallRem) reduce_accurate(x, y, t);
     const double s = k_sin(y, t), c = k_cos(y, t);
     const double r = (n & 1) ? c : s;
     return (n & 2) ? -r : r;
@@ -77,6 +106,7 @@ __device__ __forceinline__ double cos_small(double x) {
     if (!(fabs(x) <= 64.0)) return cos(x);
     double y, t;
     const int n = reduce(x, y, t) & 3;
+    if (fabs(y) < kSmallRem) reduce_accurate(x, y, t);
     const double s = k_sin(y, t), c = k_cos(y, t);
     const double r = (n & 1) ? s : c;
     return ((n + 1) & 2) ? -r : r;

@@ -12,6 +12,8 @@
 // Numerics: the expression trees are the reference's, op for op, in fp64, compiled with
 // -ffp-contract=off.  +,-,*,/ and floor are IEEE-exact on gfx950, so every waveform except
 // sinewave/coswave is bit-identical to the reference; those two go through mxg_sincos.h.
+#include <type_traits>
+
 #include "mxg_common.h"
 #include "maxi_tables.h"
 #include "mxg_sincos.h"
@@ -196,7 +198,7 @@ template <int WF, bool STORE>
 __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const double *__restrict__ freq,
                                                       const double *__restrict__ p1, const double *__restrict__ p2,
                                                       double *__restrict__ phase_io, double *__restrict__ hold_io,
-                                                      double *__restrict__ out, const double *__restrict__ gains,
+                                                      double *__restrict__ out, const double *__restrict__ pan,
                                                       double *__restrict__ partial, double sr) {
     constexpr int kTab = uses_sine<WF>() ? MAXI_SINE_TAB_LEN : (WF == MXG_OSC_SAWN ? MAXI_TRANS_TAB_LEN : 1);
     __shared__ double s_all[kTab + 4 * kMixSuper * 2];
@@ -217,7 +219,10 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
     const bool live = vraw < V;
     const size_t v = live ? vraw : V - 1;
     double ph = phase_io[v], hd = hold_io[v];
-    double gl = live ? gains[v] : 0.0, gr = live ? gains[V + v] : 0.0;
+    double x = pan[v];
+    if (x > 1) x = 1;  // C:504
+    if (x < 0) x = 0;  // C:505
+    double gl = live ? sqrt(1.0 - x) : 0.0, gr = live ? sqrt(x) : 0.0;
     OscPre q = osc_pre<WF>(freq[v], sr, p1 ? p1[v] : 0.0, p2 ? p2[v] : 0.0);
     // Consume the prologue loads HERE: otherwise hipcc's waitcnt pass keeps them "pending" at the loop back-edge and
     // drains the asynchronous output stores with s_waitcnt vmcnt(0) every chunk.
@@ -236,39 +241,50 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
         const int super = (int)((N - n0) < (size_t)kMixSuper ? (N - n0) : (size_t)kMixSuper);
         for (int c0 = 0; c0 < super; c0 += kMixChunk) {
             const int cnt = (super - c0) < kMixChunk ? (super - c0) : kMixChunk;
-            double L[kMixChunk], R[kMixChunk];
-            if (cnt == kMixChunk) {
+            // The butterfly consumes the samples as they arrive (a binary counter: after sample 2j+1 the pair folds, after
+            // every 4th the two pair sums fold, ...), so the lane exchanges sit BETWEEN the per-sample stores instead of in
+            // one 200-instruction stretch without a store behind them; sched_barrier pins that order against hipcc's
+            // list scheduler, which otherwise clusters the folds after the sixteenth store.
+            auto chunk = [&](auto full_tag) {
+            constexpr bool kFull = decltype(full_tag)::value;
+            double l1L[8], l1R[8], l2L[4], l2R[4], l3L[2], l3R[2], pL = 0.0, pR = 0.0;
 #pragma unroll
-                for (int i = 0; i < kMixChunk; i++) {
-                    const double r = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+            for (int i = 0; i < kMixChunk; i++) {
+                double r = 0.0;
+                if (kFull || i < cnt) {  // ragged last chunk: the state must not advance past N
+                    r = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
                     if constexpr (STORE) {
                         *o = r;
                         o += V;
                     }
-                    L[i] = r * gl;  // two[0] = input*sqrt(1.0-x)   C:506
-                    R[i] = r * gr;  // two[1] = input*sqrt(x)       C:507
                 }
-            } else {  // ragged last chunk: the state must not advance past N
-#pragma unroll
-                for (int i = 0; i < kMixChunk; i++) {
-                    double r = 0.0;
-                    if (i < cnt) {
-                        r = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
-                        if constexpr (STORE) {
-                            *o = r;
-                            o += V;
-                        }
-                    }
-                    L[i] = r * gl;
-                    R[i] = r * gr;
+                const double L = r * gl;  // two[0] = input*sqrt(1.0-x)   C:506
+                const double R = r * gr;  // two[1] = input*sqrt(x)       C:507
+                if ((i & 1) == 0) {
+                    pL = L;
+                    pR = R;
+                } else {
+                    l1L[i >> 1] = fold32(pL, L);
+                    l1R[i >> 1] = fold32(pR, R);
                 }
+                if ((i & 3) == 3) {
+                    l2L[i >> 2] = fold16(l1L[(i >> 1) - 1], l1L[i >> 1]);
+                    l2R[i >> 2] = fold16(l1R[(i >> 1) - 1], l1R[i >> 1]);
+                }
+                if ((i & 7) == 7) {
+                    l3L[i >> 3] = fold_dpp<kDppRowMirror, 0xC>(l2L[(i >> 2) - 1], l2L[i >> 2]);
+                    l3R[i >> 3] = fold_dpp<kDppRowMirror, 0xC>(l2R[(i >> 2) - 1], l2R[i >> 2]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            const double sl = quad_sum(fold_chunk<double>(L));
-            const double sr2 = quad_sum(fold_chunk<double>(R));
+            const double sl = quad_sum(fold_dpp<kDppRowHalfMirror, 0xA>(l3L[0], l3L[1]));
+            const double sr2 = quad_sum(fold_dpp<kDppRowHalfMirror, 0xA>(l3R[0], l3R[1]));
             if ((lane & 3) == 0 && slot >= 0 && slot < cnt) {
                 double2v pr = {sl, sr2};
                 *reinterpret_cast<double2v *>(my_sum + (c0 + slot) * 2) = pr;
             }
+            };
+            if (cnt == kMixChunk) chunk(std::true_type{}); else chunk(std::false_type{});
         }
         // the four waves' sums of this stretch -> one partial per workgroup, waves added in order 0..3
         __syncthreads();
@@ -281,34 +297,30 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
     hold_io[v] = hd;
 }
 
-// mix[i] = sum over workgroups of partial[g][i], i = n*2 + ch: 16 strided partial sums per element (fixed order), then
-// the 16 combined left to right.  Element-major across lanes => coalesced 128-B rows.
-__global__ __launch_bounds__(256) void mix_partials_kernel(size_t ngroups, size_t count, const double *__restrict__ partial,
-                                                           double *__restrict__ mix) {
-    __shared__ double s_red[16][17];
-    const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const size_t i = (size_t)blockIdx.x * 16 + e;
+// mix[i] = sum over workgroups of partial[g][i], i = n*2 + ch.  A workgroup owns 64 consecutive elements (one coalesced
+// 512-B row segment per load); its 16 waves each add the groups g = w, w+16, ... in order (independent loads, all in
+// flight), then the 16 wave sums are combined left to right: a fixed order for a fixed number of workgroups.
+constexpr int kPartWaves = 16;
+__global__ __launch_bounds__(64 * kPartWaves) void mix_partials_kernel(size_t ngroups, size_t count,
+                                                                       const double *__restrict__ partial,
+                                                                       double *__restrict__ mix) {
+    __shared__ double s_red[kPartWaves][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
     double s = 0.0;
-    if (i < count)
-        for (size_t w = g; w < ngroups; w += 16) s += partial[w * count + i];
-    s_red[g][e] = s;
+    if (i < count) {
+        const double *p = partial + i;
+#pragma unroll 8
+        for (size_t g = w; g < ngroups; g += kPartWaves) s += p[g * count];
+    }
+    s_red[w][lane] = s;
     __syncthreads();
-    if (g == 0 && i < count) {
-        double t = s_red[0][e];
+    if (w == 0 && i < count) {
+        double t = s_red[0][lane];
 #pragma unroll
-        for (int k = 1; k < 16; k++) t += s_red[k][e];
+        for (int k = 1; k < kPartWaves; k++) t += s_red[k][lane];
         mix[i] = t;
     }
-}
-
-__global__ void osc_pan_gains_kernel(size_t V, const double *__restrict__ pan, double *__restrict__ gains) {
-    size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V) return;
-    double x = pan[v];
-    if (x > 1) x = 1;  // C:504
-    if (x < 0) x = 0;  // C:505
-    gains[v] = sqrt(1.0 - x);
-    gains[V + v] = sqrt(x);
 }
 
 typedef void (*osc_mix_fn)(size_t, size_t, const double *, const double *, const double *, double *, double *,
@@ -404,20 +416,18 @@ extern "C" int mxg_osc_render_mix(int waveform, size_t V, size_t N, const double
     hipStream_t st = resolve_stream(stream);
     const int block = 256;
     const size_t nblocks = (V + block - 1) / block;
-    const size_t need = 2 * V + N * nblocks * 2 + 2;
-    double *g_mix_scratch = nullptr;  // per-stream: [2][V] gains | [nblocks][N][2] partials
-    if (int s = scratch_get(SCR_OSC_MIX, st, sizeof(double) * need, (void **)&g_mix_scratch)) return s;
-    double *gains = g_mix_scratch, *partial = g_mix_scratch + 2 * V;
+    const size_t need = N * nblocks * 2 + 2;
+    double *partial = nullptr;  // per-stream scratch: [nblocks][N][2] per-workgroup sums
+    if (int s = scratch_get(SCR_OSC_MIX, st, sizeof(double) * need, (void **)&partial)) return s;
     if (V) {
-        hipLaunchKernelGGL(osc_pan_gains_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, d_pan, gains);
         osc_mix_fn fn = pick_mix_wf(waveform, d_out != nullptr);
         KernelTimer kt("osc_mix_kernel", st);
         hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(block), 0, st, V, N, d_freq, d_p1, d_p2, d_phase,
-                           d_outhold, d_out, gains, partial, (double)settings().sampleRate);
+                           d_outhold, d_out, d_pan, partial, (double)settings().sampleRate);
     }
     KernelTimer kt2("mix_partials_kernel", st);
-    hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((N * 2 + 15) / 16)), dim3(256), 0, st, nblocks, N * 2, partial,
-                       d_mix);
+    hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((N * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, nblocks, N * 2,
+                       partial, d_mix);
     return check_hip(hipGetLastError(), "osc_mix_kernel launch");
 }
 

@@ -37,6 +37,7 @@ Tune g_tune[] = {
     {"grain_unit", 1, 0, 1},  // K8c: coalesced closed-form render when every grain has inc = +-1
     {"grain_fast_sched", 1, 0, 1},  // K8a: event-driven exact multi-step scheduler (0: one step at a time)
     {"grain_slices", 4, 1, 16},  // K8a/K8c: time slices of a maxiTimeStretch call (scheduling of slice i+1 overlaps render of slice i)
+    {"mfcc_mfma_fullk", 0, 0, 1},  // K7b: contract over all numBins bins (1) instead of the bins that carry weight
     {"mfcc_tiled", 1, 0, 1},  // K7a-t: stage spectra through LDS tiles (0: per-lane row loads, K7a)
 };
 }  // namespace

@@ -147,6 +147,22 @@ class maxiMFCC:
         self.melraw, self.melBands = raw, bands
         return out
 
+    def mfcc_of_frames(self, fft, signal, nframes, frame_stride=None, want_mags=False, want_bands=False):
+        """maxiFFT(1024) magnitudes -> mfcc() for `nframes` frames of `signal` in ONE kernel (mxg_fft_mfcc_batch):
+        the per-frame body of mfcctest.cpp:21-32.  `fft` is a maxiFFT set up for 1024 points; returns the [nframes,
+        numCoeffs] DeviceBuffer; .mags / .melraw / .melBands hold the optional outputs."""
+        frame_stride = fft.fftSize if frame_stride is None else frame_stride
+        out = DeviceBuffer((nframes, self.numCoeffs), np.float64, zero=False)
+        mags = DeviceBuffer((nframes, self.numBins), np.float32, zero=False) if want_mags else None
+        raw = bands = None
+        if want_bands:
+            raw = DeviceBuffer((nframes, self.numFilters), np.float64, zero=False)
+            bands = DeviceBuffer((nframes, self.numFilters), np.float64, zero=False)
+        check(lib().mxg_fft_mfcc_batch(fft.plan, self.plan, _ptr(signal), frame_stride, nframes, _ptr(mags), _ptr(raw),
+                                       _ptr(bands), _ptr(out), self.stream), "mxg_fft_mfcc_batch")
+        self.mags, self.melraw, self.melBands = mags, raw, bands
+        return out
+
     def close(self):
         if self.plan:
             lib().mxg_mfcc_plan_destroy(self.plan)

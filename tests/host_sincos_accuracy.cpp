@@ -1,9 +1,10 @@
 // tests/host_sincos_accuracy.cpp -- error bound of maximilian_amd/csrc/mxg_sincos.h (the sin/cos behind
 // maxiOsc::sinewave / coswave and the modulated lores/bandpass coefficients on the device), measured on the host against
-// long-double sinl/cosl and against glibc's double sin/cos (what the reference calls).  Built with FMA contraction on
+// quad-precision sinq/cosq (libquadmath) and against glibc's double sin/cos (what the reference calls).  Built with FMA contraction on
 // (-mfma -ffp-contract=fast), the closest host equivalent of the device's `#pragma clang fp contract(fast)` kernels.
 // Run by tests/test_sincos_host.py.
 #include <math.h>
+#include <quadmath.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -12,9 +13,10 @@
 
 #include "mxg_sincos.h"
 
-static double ulp_of(long double v) {
+typedef __float128 quad;
+static double ulp_of(quad v) {
     int e;
-    frexpl(fabsl(v), &e);          // |v| = m * 2^e, m in [0.5, 1)
+    frexpq(fabsq(v), &e);          // |v| = m * 2^e, m in [0.5, 1)
     if (e < -1021) e = -1021;
     return ldexp(1.0, e - 53);
 }
@@ -31,36 +33,36 @@ int main(int argc, char **argv) {
     const long cases = argc > 1 ? atol(argv[1]) : 2000000;
     std::mt19937_64 g(0x4D415849);
     std::uniform_real_distribution<double> u(-1.0, 1.0);
-    double worst_s = 0, worst_c = 0, arg_s = 0, arg_c = 0, worst_abs = 0;
+    double worst_s = 0, worst_c = 0, arg_s = 0, arg_c = 0;
     long long worst_vs_libm = 0;
     for (long i = 0; i < cases; i++) {
         double x;
-        switch (i % 4) {
+        switch (i % 6) {
             case 0: x = 64.0 * u(g); break;                                // the whole fast-path domain
             case 1: x = (0.5 + 0.5 * u(g)) * MXG_TWOPI; break;               // an oscillator's phase * TWOPI
             case 2: x = (double)(long)(40.0 * u(g)) * 1.5707963267948966 + 1e-3 * u(g); break;  // near multiples of pi/2
+            case 3: {  // the doubles AT and right next to fl(k*pi/2): the zero crossings themselves (phase 0.25, 0.5 ...)
+                x = (double)(long)(40.0 * u(g)) * 1.5707963267948966;
+                const int steps = (int)(g() % 9) - 4;
+                for (int k = 0; k < (steps < 0 ? -steps : steps); k++) x = nextafter(x, steps < 0 ? -1e9 : 1e9);
+                break;
+            }
+            case 4: x = (double)(long)(40.0 * u(g)) * 1.5707963267948966 + ldexp(u(g), -(int)(10 + g() % 40)); break;  // closing in on them
             default: x = ldexp(u(g), -(int)(g() % 60)); break;              // tiny arguments
         }
         const double s = mxg::sin_small(x), c = mxg::cos_small(x);
-        const long double ts = sinl((long double)x), tc = cosl((long double)x);
-        // Contract: |result - f(x)| < 0.85 ulp(f(x)) + 2^-62.  Below 1 ULP is what matters: the result and glibc's (itself
-        // within 1 ULP of f) are then the two doubles that bracket f(x), i.e. at most 1 ULP apart.  The absolute term is the
-        // three-constant reduction's error; it only shows within ~2^-8 of a zero of f, where ulp(f) drops below 2^-60.
-        const long double as = fabsl((long double)s - ts), ac = fabsl((long double)c - tc);
-        const double es = (double)((as > 0x1p-62L ? as - 0x1p-62L : 0.0L) / ulp_of(ts));
-        const double ec = (double)((ac > 0x1p-62L ? ac - 0x1p-62L : 0.0L) / ulp_of(tc));
+        const quad ts = sinq((quad)x), tc = cosq((quad)x);
+        // Contract: |result - f(x)| < 0.85 ulp(f(x)) everywhere, zero crossings included.  Below 1 ULP is what matters:
+        // the result and glibc's (itself within 1 ULP of f) are then the two doubles that bracket f(x), at most 1 ULP apart.
+        const double es = (double)(fabsq((quad)s - ts) / ulp_of(ts));
+        const double ec = (double)(fabsq((quad)c - tc) / ulp_of(tc));
         if (es > worst_s) { worst_s = es; arg_s = x; }
         if (ec > worst_c) { worst_c = ec; arg_c = x; }
-        if (fabsl(ts) < 0x1p-10L && (double)(as * 0x1p53L) > worst_abs) worst_abs = (double)(as * 0x1p53L);
-        if (fabsl(tc) < 0x1p-10L && (double)(ac * 0x1p53L) > worst_abs) worst_abs = (double)(ac * 0x1p53L);
         const long long d1 = bits_diff(s, sin(x)), d2 = bits_diff(c, cos(x));
-        // near a zero of the function the result's own ULP shrinks with it; the reduction's absolute error (a few 1e-22)
-        // can then exceed it -- the device test states the bound as "1 ULP of the result or 1 ULP of 1.0" for that reason
-        if (fabs(s) > 1e-3 && d1 > worst_vs_libm) worst_vs_libm = d1;
-        if (fabs(c) > 1e-3 && d2 > worst_vs_libm) worst_vs_libm = d2;
+        if (d1 > worst_vs_libm) worst_vs_libm = d1;
+        if (d2 > worst_vs_libm) worst_vs_libm = d2;
     }
-    printf("sin: max (error - 2^-62) %.4f ULP at x=%a; cos: %.4f ULP at x=%a; near zeros: max abs error %.3g x 2^-53; "
-           "vs glibc sin/cos: max %lld ULP (%ld cases)\n",
-           worst_s, arg_s, worst_c, arg_c, worst_abs, worst_vs_libm, cases);
-    return (worst_s < 0.85 && worst_c < 0.85 && worst_abs < 2e-3 && worst_vs_libm <= 1) ? 0 : 1;
+    printf("sin: max error %.4f ULP at x=%a; cos: %.4f ULP at x=%a; vs glibc sin/cos: max %lld ULP (%ld cases)\n",
+           worst_s, arg_s, worst_c, arg_c, worst_vs_libm, cases);
+    return (worst_s < 0.85 && worst_c < 0.85 && worst_vs_libm <= 1) ? 0 : 1;
 }

@@ -4,7 +4,7 @@ compared with the oracle where it is defined; otherwise the call must simply not
 import numpy as np
 import pytest
 
-from conftest import assert_bits_equal
+from conftest import assert_bits_equal, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +34,7 @@ def test_small_and_ragged_banks_vs_oracle(mx, port, V, N):
         o = bank.render(wf, freq, N).numpy()
         e, ph, _ = port.osc(wf, freq, N)
         if wf == 0:
-            assert np.abs(o - e).max() <= 2.3e-16
+            assert ulp_diff(o, e).max() <= 1
         else:
             assert_bits_equal(o, e, "waveform %d" % wf)
             assert_bits_equal(bank.phase.numpy(), ph)

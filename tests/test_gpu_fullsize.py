@@ -54,6 +54,16 @@ def test_config4_full_size_fft_mfcc(mx, port):
     assert np.abs(hc - emf).max() <= MFCC_RTOL * np.abs(emel).max()
     assert torch.equal(mags[:4], mags[N - 4:]) and torch.equal(mfcc[:4], mfcc[N - 4:])
     assert bool(torch.isfinite(mfcc).all())
+    # the fused kernel over the same 1 M frames: every coefficient and every magnitude identical to the two-kernel path
+    mags_f = torch.empty((N, 512), dtype=torch.float32, device=dev)
+    mfcc_f = torch.empty((N, 13), dtype=torch.float64, device=dev)
+    assert L.mxg_fft_mfcc_batch(f.plan, m.plan, sig.data_ptr(), 1024, N, mags_f.data_ptr(), None, None, mfcc_f.data_ptr(), None) == 0
+    L.mxg_sync()
+    assert torch.equal(mags_f, mags) and torch.equal(mfcc_f, mfcc)
+    mfcc_f.zero_()
+    assert L.mxg_fft_mfcc_batch(f.plan, m.plan, sig.data_ptr(), 1024, N, None, None, None, mfcc_f.data_ptr(), None) == 0
+    L.mxg_sync()
+    assert torch.equal(mfcc_f, mfcc)
 
 
 def test_config5_full_size_granular_share(mx, port):

@@ -37,15 +37,14 @@ def test_osc_golden(mx, golden, wf):
         assert_bits_equal(ph, g["phase_" + name], name + " phase")
         assert_bits_equal(hd, g["hold_" + name], name + " hold")
     else:
-        assert ulp_diff(out, g["out_" + name]).max() <= TRIG_MAX_ULP or \
-            np.abs(out - g["out_" + name]).max() <= 2.3e-16
+        assert ulp_diff(out, g["out_" + name]).max() <= TRIG_MAX_ULP   # every sample, zero crossings included
         assert_bits_equal(ph, g["phase_" + name], name + " phase")
 
 
 def test_kat_sinewave_440(mx, golden):
     out, _, _ = _render(mx, 0, np.array([440.0]), 4)
     exp = golden("osc.npz")["ka_sinewave440"]
-    assert np.abs(out[:, 0] - exp).max() <= 2.3e-16
+    assert ulp_diff(out[:, 0], exp).max() <= TRIG_MAX_ULP
 
 
 @pytest.mark.parametrize("name", ["sinebuf", "saw", "sawn"])
@@ -80,10 +79,12 @@ def test_trig_osc_ulp(mx, port, wf):
     eo, eph, _ = port.osc(wf, freq, N)
     assert_bits_equal(ph, eph, "phase")
     d = ulp_diff(out, eo)
-    absd = np.abs(out - eo)
-    # <= 1 ULP of the result, or (near zero crossings, where the ULP shrinks) <= 1 ULP of 1.0
-    bad = (d > TRIG_MAX_ULP) & (absd > 1.12e-16)
-    assert not bad.any(), (int(bad.sum()), int(d.max()), float(absd.max()))
+    # <= 1 ULP of the RESULT on every sample: no absolute-error allowance near the zero crossings (round 1 needed one:
+    # a wrong third reduction constant left k*2e-21 in the remainder).  11025 Hz = sr/4 puts phases exactly on 0.25,
+    # 0.5, 0.75: x = fl(k*pi/2), the hardest arguments.
+    assert int(d.max()) <= TRIG_MAX_ULP, (int((d > TRIG_MAX_ULP).sum()), int(d.max()), float(np.abs(out - eo).max()))
+    print("sinewave/coswave wf=%d: %d of %d samples differ from glibc (all by 1 ULP), 0 above 1 ULP"
+          % (wf, int((d > 0).sum()), d.size))
 
 
 @pytest.mark.parametrize("vpl,nt,block", [(1, 0, 64), (2, 0, 64), (2, 1, 256), (1, 1, 128)])
@@ -142,7 +143,8 @@ def test_config2_full_size_properties(mx, port):
     assert ph.min() >= -1.0 and ph.max() < 511.0
 
 
-@pytest.mark.parametrize("wf,V,N", [(8, 300, 100), (3, 64, 16), (10, 1000, 37), (9, 4096 + 7, 512), (6, 256, 1)])
+@pytest.mark.parametrize("wf,V,N", [(8, 300, 100), (3, 64, 16), (10, 1000, 37), (9, 4096 + 7, 512), (6, 256, 1), (8, 700, 1100),
+                                      (4, 130, 530)])
 def test_render_mix_fused(mx, port, wf, V, N):
     """mxg_osc_render_mix: per-voice block bit-exact (same as the plain render), mix within the
     stated tolerance of the reference's sequential sum, store=False gives the same mix bits."""

@@ -130,6 +130,77 @@ def test_mfcc_golden(mx, golden, nf, nc):
     assert np.array_equal(bands == 0.0, emel == 0.0)
 
 
+@pytest.mark.parametrize("nf,nc,nfr,off", [(42, 13, 1003, 0), (40, 20, 77, 0), (64, 13, 8, 0), (42, 13, 250, 3), (13, 5, 1, 0)])
+def test_fused_fft_mfcc_vs_two_kernels_and_oracle(mx, port, nf, nc, nfr, off):
+    """mxg_fft_mfcc_batch (one kernel, magnitudes kept in LDS): magnitudes and raw band sums bit-identical to the
+    separate kernels (and the magnitudes to the oracle's), mfcc within the log tolerance -- for ragged frame counts
+    (not a multiple of the 8-frame group), an unaligned / odd-stride signal, 40x20 and 64-filter banks, with and
+    without the optional outputs."""
+    rng = np.random.default_rng(nf * 100 + nfr)
+    stride = 1024 if off == 0 else 1025
+    sig = (rng.uniform(-1, 1, stride * nfr + 8) * np.repeat(10.0 ** rng.uniform(-4, 0, nfr + 1), stride)[:stride * nfr + 8]
+           ).astype(np.float32)
+    d = mx.DeviceBuffer.from_numpy(sig)
+    f = mx.maxiFFT()
+    f.setup(1024, 1024, 1024)
+    m = mx.maxiMFCC()
+    m.setup(512, nf, nc, 20.0, 20000.0)
+    base = d.ptr + 4 * off
+    out = m.mfcc_of_frames(f, base, nfr, frame_stride=stride, want_mags=True, want_bands=True).numpy()
+    mags, raw, bands = m.mags.numpy(), m.melraw.numpy(), m.melBands.numpy()
+    f.process_frames(base, stride, nfr)
+    mags2 = f.getMagnitudes()
+    assert np.array_equal(f32bits(mags), f32bits(mags2.numpy())), "fused magnitudes != mxg_fft_batch magnitudes"
+    out2 = m.mfcc(mags2, want_bands=True).numpy()
+    assert_bits_equal(raw, m.melraw.numpy(), "raw band sums: fused vs mxg_mfcc_batch")
+    assert_bits_equal(bands, m.melBands.numpy(), "melBands: same device log on the same sums")
+    assert_bits_equal(out, out2, "mfcc: same DCT order on the same bands")
+    frames = np.stack([sig[off + stride * k: off + stride * k + 1024] for k in range(nfr)])
+    e = port.fft_stream(frames.reshape(-1), 1024, 1024, 1024, want=("mags",))["mags"]
+    assert np.array_equal(f32bits(mags), f32bits(e)), "fused magnitudes != oracle"
+    emel, emf = port.mfcc(e, nf, nc, 20.0, 20000.0)
+    assert np.abs(out - emf).max() <= MFCC_RTOL * max(np.abs(emel).max(), 1e-300)
+    # mfcc-only launch (no optional outputs: the half-spectrum variant of the kernel): identical coefficients
+    out3 = m.mfcc_of_frames(f, base, nfr, frame_stride=stride).numpy()
+    assert_bits_equal(out3, out, "mfcc-only variant")
+
+
+def test_fused_fft_mfcc_tiny_and_silent_frames(mx, port):
+    """Magnitudes around the sqrt's small-input branch (power < 2^-96) and all-zero frames: bit-exact magnitudes,
+    zero bands stay exactly zero."""
+    rng = np.random.default_rng(5)
+    nfr = 24
+    sig = np.zeros((nfr, 1024), np.float32)
+    for k in range(1, nfr):
+        sig[k] = (rng.uniform(-1, 1, 1024) * 10.0 ** (-2.5 * k)).astype(np.float32)   # down to denormal spectra
+    f = mx.maxiFFT()
+    f.setup(1024, 1024, 1024)
+    m = mx.maxiMFCC()
+    m.setup(512, 42, 13, 20.0, 20000.0)
+    out = m.mfcc_of_frames(f, mx.DeviceBuffer.from_numpy(sig), nfr, want_mags=True, want_bands=True).numpy()
+    e = port.fft_stream(sig.reshape(-1), 1024, 1024, 1024, want=("mags",))["mags"]
+    assert np.array_equal(f32bits(m.mags.numpy()), f32bits(e))
+    emel, emf = port.mfcc(e, 42, 13, 20.0, 20000.0)
+    assert np.array_equal(m.melBands.numpy() == 0.0, emel == 0.0)
+    assert np.abs(out - emf).max() <= MFCC_RTOL * max(np.abs(emel).max(), 1.0)
+    assert (out[0] == 0).all()
+
+
+def test_fused_fft_mfcc_rejects_what_it_cannot_do(mx):
+    L = mx.lib()
+    f = mx.maxiFFT(); f.setup(512, 512, 512)
+    m = mx.maxiMFCC(); m.setup(512, 42, 13, 20.0, 20000.0)
+    b = mx.DeviceBuffer(4096, np.float32)
+    o = mx.DeviceBuffer((4, 13))
+    assert L.mxg_fft_mfcc_batch(f.plan, m.plan, b.ptr, 512, 4, None, None, None, o.ptr, None) == -1   # not a 1024-point plan
+    f.setup(1024, 1024, 1024)
+    m.setup(512, 256, 13, 20.0, 20000.0)   # mfcctest's bank: 256 filters -> two-kernel path
+    assert L.mxg_fft_mfcc_batch(f.plan, m.plan, b.ptr, 1024, 4, None, None, None, o.ptr, None) == -1
+    m.setup(512, 42, 13, 20.0, 20000.0)
+    assert L.mxg_fft_mfcc_batch(f.plan, m.plan, b.ptr, 1024, 0, None, None, None, o.ptr, None) == 0     # empty batch
+    assert L.mxg_fft_mfcc_batch(f.plan, m.plan, None, 1024, 4, None, None, None, o.ptr, None) == -1
+
+
 def test_mfcc_melraw_bit_exact_and_mfma(mx, port):
     rng = np.random.default_rng(47)
     nfr = 1000   # not a multiple of 64 or 16: ragged tail
@@ -161,6 +232,39 @@ def test_mfcc_melraw_bit_exact_and_mfma(mx, port):
     raw2 = m.melraw.numpy()
     assert np.abs(raw2 - raw_exp).max() <= MFMA_RTOL * np.abs(raw_exp).max()
     assert np.abs(out2 - emf).max() <= MFMA_RTOL * scale * 10
+
+
+@pytest.mark.parametrize("nf,nc,nfr,fullk,unaligned", [(42, 13, 1000, 0, False), (42, 13, 257, 1, False), (256, 13, 700, 0, False),
+                                                        (64, 20, 64, 0, False), (16, 5, 1, 1, False), (42, 13, 300, 0, True)])
+def test_mfma_gemm_vs_exact(mx, port, nf, nc, nfr, fullk, unaligned):
+    """Method 1 (dense fp64 MFMA contraction, tiled GEMM kernel): band sums and mfcc against the exact sparse path --
+    mfcctest's 512/256/13 bank (filter groups of 64 + the log/DCT kernel), K trimmed to the weighted bins or all 512,
+    ragged frame counts, and the single-wave kernel for spectra that are not 16-byte aligned."""
+    rng = np.random.default_rng(nf + nfr)
+    mags = (np.abs(rng.standard_normal((nfr + 1, 512))) * 10.0 ** rng.uniform(-3, 1.5, (nfr + 1, 1))).astype(np.float32)
+    d = mx.DeviceBuffer.from_numpy(mags.reshape(-1))
+    base = d.ptr + (4 * 3 if unaligned else 0)      # 12-byte offset: rows of 512 floats starting at element 3
+    hm = mags.reshape(-1)[3 if unaligned else 0:][:nfr * 512].reshape(nfr, 512)
+    m = mx.maxiMFCC()
+    m.setup(512, nf, nc, 20.0, 20000.0)
+    prev = mx.lib().mxg_tune(b"mfcc_mfma_fullk", fullk)
+    try:
+        exact = m.mfcc(base, nframes=nfr, want_bands=True).numpy()
+        rawx = m.melraw.numpy()
+        dense = m.mfcc(base, nframes=nfr, method=1, want_bands=True).numpy()
+        rawd, bandsd = m.melraw.numpy(), m.melBands.numpy()
+    finally:
+        mx.lib().mxg_tune(b"mfcc_mfma_fullk", prev)
+    rel = (np.abs(rawd - rawx).max(axis=1) / np.maximum(np.abs(rawx).max(axis=1), 1e-300)).max()
+    assert rel <= 1e-13, rel
+    emel, emf = port.mfcc(hm, nf, nc, 20.0, 20000.0)
+    scale = max(np.abs(emel).max(), 1.0)
+    assert np.abs(bandsd - emel).max() <= MFMA_RTOL * scale
+    assert np.abs(dense - emf).max() <= MFMA_RTOL * scale
+    assert np.abs(dense - exact).max() <= MFMA_RTOL * scale
+    # without the optional outputs (the wide bank then uses library scratch for the raw sums): same coefficients
+    dense2 = m.mfcc(base, nframes=nfr, method=1).numpy()
+    assert_bits_equal(dense2, dense, "mfma method with / without optional outputs")
 
 
 @pytest.mark.parametrize("fftSize", [1024, 64, 8])
