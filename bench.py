@@ -3,12 +3,13 @@
 
 Default workload = BASELINE.json configs[1] (SURVEY.md 8d row 2): a 65 536-voice maxiOsc::sinebuf wavetable bank per
 GPU, block = 512 samples, freq[v] = 20 + v*0.30517578125 Hz, state carried from block to block.  One "step" = one
-block of the whole bank through the hot path (libmaxigpu.so): kernel K1m renders the block, stores every voice's
-fp64 sample (out[n][v], the HBM-bound stream) and, in the same pass, forms the maxiMix::stereo mixdown of the rank's
-voices; the [512 x 2] mixes of 16 consecutive blocks are staged in the C-ABI's mix queue and summed onto rank 0 with
-ONE ncclReduce per 16 blocks on the queue's own stream (RCCL over xGMI), overlapped with the next blocks' render.  The
-same work runs at every N (weak scaling: 65 536 voices per GPU); at N = 1 the reduce degenerates to a device copy.
-`--mixdown off` renders without the mixdown (kernel K1 alone), `--mixdown separate` uses K1 + K3.
+block of the whole bank through the hot path (libmaxigpu.so): kernel K1 renders the block and stores every voice's fp64
+sample (out[n][v], the HBM-bound stream).  With more than one GPU (one process per GPU, weak scaling: 65 536 voices
+each) the step ALSO carries the path's one exchange: kernel K1m renders, stores and, in the same pass, forms the
+maxiMix::stereo mixdown of the rank's voices; the [512 x 2] mixes of 16 consecutive blocks are staged in the C-ABI's mix
+queue and summed onto rank 0 with ONE ncclReduce per 16 blocks on the queue's own stream (RCCL over xGMI), overlapped
+with the next blocks' render.  So an N > 1 step does more than an N = 1 step (the fused mixdown costs K1m 48 us against
+K1's 42 us on one MI355X: `--mixdown fused` at N = 1 shows it); `--mixdown off|fused|separate` forces either form.
 
 `--workload config3|config4|config5` runs the other BASELINE configs through the same harness and JSON shape (same
 unit; SURVEY 8d: a "sample" is one voice output, one FFT input sample, one grain-sample).
@@ -95,12 +96,14 @@ def main():
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"],
                     help="BASELINE.json config to run; the default (config2) is the one the headline metric is quoted on")
     ap.add_argument("--mixdown", default=None, choices=["fused", "separate", "off"],
-                    help="stereo mixdown + cross-GPU reduce in the step (default: fused for config2, separate for "
-                         "config5, off for config3)")
+                    help="stereo mixdown + cross-GPU reduce in the step (default: on whenever --gpus > 1 -- fused into the "
+                         "render for config2, K3 for config3 -- and always for config5; off on one GPU)")
     ap.add_argument("--mix-depth", type=int, default=16, help="blocks per ncclReduce (M of SURVEY 8e)")
     ap.add_argument("--voice-mode", type=int, default=0, choices=[0, 1], help="config3: 0 = hoisted coefficients, 1 = 14.monosynth order")
     ap.add_argument("--mfcc-method", default="sparse", choices=["sparse", "mfma"],
                     help="config4: exact sparse mel walk (default) or the dense fp64 MFMA contraction")
+    ap.add_argument("--mix-only", action="store_true", help="config2 fused: do not store the per-voice block (VALU/LDS time of K1m)")
+    ap.add_argument("--tune", action="append", default=[], help="KEY=VALUE passed to mxg_tune (A/B experiments)")
     ap.add_argument("--mfma-fullk", action="store_true",
                     help="config4 mfma: contract over all 512 bins instead of the 256 that carry mel weight")
     ap.add_argument("--kernel-events", default="pass", choices=["inline", "pass", "off"],
@@ -133,6 +136,9 @@ def main():
     chk = mx._lib.check
     chk(L.mxg_init(local), "mxg_init")
     mx.maxiSettings.setup(44100, 2, 1024)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        chk(L.mxg_tune(k.encode(), int(v)), "mxg_tune " + kv)
     dev = torch.device("cuda", local)
     # Launch on a non-default torch stream (the C-ABI treats a NULL stream as "the library's own stream").
     tstream = torch.cuda.Stream(device=dev)
@@ -146,7 +152,11 @@ def main():
     wf = mx.OSC_WAVEFORMS[args.waveform]
     lo, hi = shard_range(rank, world, V)  # this rank's voice shard of the global bank
     freq_h, pan_h = bank_parameters(lo, hi, V * world)
-    mixdown = args.mixdown or {"config2": "fused", "config3": "off", "config4": "off", "config5": "separate"}[args.workload]
+    # config 2/3: the cross-GPU mixdown (and its RCCL reduce) is part of the step whenever there is more than one GPU;
+    # a single GPU renders the bank without it unless asked (--mixdown fused|separate).  config 5 is DEFINED with the
+    # stereo mixdown (BASELINE configs[4]), so it always mixes.
+    mixdown = args.mixdown or {"config2": "fused" if world > 1 else "off", "config3": "separate" if world > 1 else "off",
+                               "config4": "off", "config5": "separate"}[args.workload]
     queue = None
     W = {}
 
@@ -162,7 +172,7 @@ def main():
         def render_mix(slot):
             if mixdown == "fused":  # K1m: render + store + mix partials in one pass
                 chk(L.mxg_osc_render_mix(wf, V, B, freq.data_ptr(), None, None, phase.data_ptr(), hold.data_ptr(),
-                                         out.data_ptr(), pan.data_ptr(), slot, stream), "mxg_osc_render_mix")
+                                         None if args.mix_only else out.data_ptr(), pan.data_ptr(), slot, stream), "mxg_osc_render_mix")
             else:                   # K1 then K3 re-reading the block
                 chk(L.mxg_osc_render(wf, V, B, freq.data_ptr(), 0, None, None, phase.data_ptr(), hold.data_ptr(),
                                      out.data_ptr(), stream), "mxg_osc_render")
@@ -243,7 +253,7 @@ def main():
 
         def step():
             if fused_ok:
-                chk(L.mxg_fft_mfcc_batch(fplan.plan, mplan.plan, sig.data_ptr(), 1024, NF, None, None, mfcc.data_ptr(), stream),
+                chk(L.mxg_fft_mfcc_batch(fplan.plan, mplan.plan, sig.data_ptr(), 1024, NF, None, None, None, mfcc.data_ptr(), stream),
                     "mxg_fft_mfcc_batch")
             else:
                 chk(L.mxg_fft_batch(fplan.plan, sig.data_ptr(), 1024, NF, None, None, mags.data_ptr(), None, stream), "fft")
@@ -360,6 +370,10 @@ def main():
         kernels = read_kernels(psteps)
     dom = W["dominant"]
     dom_ms = kernels[dom]["ms"] if dom in kernels else step_ms_events
+    # an event pair around every launch adds ~2 us of marker overhead to a ~40 us kernel; the launches of one step
+    # cannot take longer than the step itself (timed region, events off), so that bound caps the per-launch figure
+    if dom in kernels:
+        dom_ms = min(dom_ms, step_ms_events / max(kernels[dom]["launches_per_step"], 1.0))
     if world > 1:
         t = torch.tensor([elapsed, dom_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

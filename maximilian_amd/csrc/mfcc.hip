@@ -322,33 +322,44 @@ __global__ __launch_bounds__(64) void mfcc_mfma_kernel(
 // C[frames x filters] = A[frames x K] (fp32 spectra, widened) x W[K x filters] on v_mfma_f64_16x16x4_f64.
 // A workgroup = 4 wavefronts, each owning a 64-frame x (NT*16)-filter tile: 4 x NT independent accumulators per
 // wave (16 x NT x 4 doubles), so the matrix pipe never waits on its own result.  K is walked in tiles of 32 bins:
-//   A   every wave loads ITS [64 frames x 32 bins] fp32 tile coalesced (8 lanes = the 128 B of one frame row), parks
-//       it in LDS with row stride 34 floats (bank = 2*frame + k: the fragment read `frame = lane&15, k = lane>>4` is
-//       conflict-free) and widens to f64 after the LDS read -- the spectrum crosses HBM once, as fp32;
-//   W   the [32 bins x NT*16] f64 weight tile is loaded once per workgroup (L2-resident: 90-200 KB in all) and shared
-//       by the four waves; row stride NT*16 doubles => the fragment read `k = lane>>4, col = lane&15` is conflict-free.
-// Both are double-buffered: the global loads of tile t+1 are in flight while tile t feeds 8 x 4 x NT MFMAs per wave, one
-// __syncthreads() per tile.  Per 4-bin step a lane issues 4 + NT LDS reads and 4 cvt for 4*NT MFMAs of 64 cycles each.
-// Epilogue (banks up to 64 filters): the accumulators go to LDS as [frame][filter], then EVERY lane owns one frame:
-// log-square, then the DCT in the reference's j order with wave-uniform (scalar-loaded) coefficients.  Larger banks
-// (mfcctest's 512/256/13) run in groups of 64 filters, write the raw band sums and finish in mfcc_logdct_kernel.
+//   A   every wave loads ITS [64 frames x 32 bins] fp32 tile coalesced (8 lanes = the 128 B of one frame row) into
+//       registers one tile ahead, parks it in its private LDS tile with row stride 34 floats (bank = 2*frame + k: the
+//       fragment read `frame = lane&15, k = lane>>4` is conflict-free) and widens to f64 after the LDS read -- the
+//       spectrum crosses HBM once, as fp32;
+//   W   the [32 bins x NT*16] f64 weight tile is loaded once per workgroup (L2-resident: 90-200 KB in all), double-
+//       buffered in LDS and shared by the four waves; row stride NT*16 doubles => the fragment read `k = lane>>4,
+//       col = lane&15` is conflict-free.
+// One __syncthreads() per tile (for W; the A tile is wave-private).  Per 4-bin step a lane issues 4 + NT LDS reads and
+// 4 cvt for 4*NT MFMAs of 64 cycles each.  ~60 KB of LDS and <= 256 registers => TWO workgroups per CU: while one wave
+// of a SIMD runs its VALU epilogue or waits for its first tile, the other keeps the matrix pipe busy (with one wave
+// per SIMD the pipe idled ~60 % of the time: 1.75 ms per 1 M frames at K = 512, profiles/).
+// Epilogue (banks up to 64 filters), in two halves of 32 frames so the staging tile stays small: the accumulators go to
+// LDS as [frame][filter]; lane = (frame = lane&31, h = lane>>5) takes the filters / coefficients of parity h:
+// log-square, then the DCT in the reference's j order (L/maxiMFCC.h:98-111).  Larger banks (mfcctest's 512/256/13) run
+// in groups of 64 filters, write the raw band sums and finish in mfcc_logdct_kernel.
 // FMA chains inside the MFMA round differently from the reference's mul-then-add loop => tolerance.
 constexpr int kGemmFrames = 64, kGemmKT = 32, kGemmAStride = 34;
 
 template <int NT, bool EPILOGUE>
-__global__ __launch_bounds__(256) void mfcc_mfma_gemm_kernel(
+__global__ __launch_bounds__(256, 2) void mfcc_mfma_gemm_kernel(
     const float *__restrict__ mags, size_t mag_stride, size_t nframes, unsigned numFilters, unsigned numCoeffs,
     unsigned kTiles, unsigned wStride, unsigned fOff, const double *__restrict__ Wpad, const double *__restrict__ dct,
     double *__restrict__ melraw, double *__restrict__ melbands, double *__restrict__ mfcc, unsigned rawStride) {
     extern __shared__ double s_dyn[];
     constexpr int NW = NT * 16;
+    constexpr unsigned ES = NW + 1;                                         // epilogue row stride (doubles)
     double *sW = s_dyn;                                                     // [2][32][NW]
-    float *sA = reinterpret_cast<float *>(s_dyn + 2 * kGemmKT * NW);        // [4 waves][2][64][34]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float *myA = sA + (size_t)wave * 2 * kGemmFrames * kGemmAStride;
+    // per wave: the A tile [64][34] floats, reused as the epilogue tile [32][ES] doubles
+    constexpr size_t kWaveBytes = (sizeof(float) * kGemmFrames * kGemmAStride > sizeof(double) * 32 * ES)
+                                      ? sizeof(float) * kGemmFrames * kGemmAStride : sizeof(double) * 32 * ES;
+    char *wbase = reinterpret_cast<char *>(s_dyn + 2 * kGemmKT * NW) + (size_t)wave * ((kWaveBytes + 15) & ~(size_t)15);
+    float *myA = reinterpret_cast<float *>(wbase);
+    double *tile = reinterpret_cast<double *>(wbase);
     const int r16 = lane & 15, kq = lane >> 4;
     const int lrow = lane >> 3, lcol = (lane & 7) * 4;
     const size_t tilesTotal = (nframes + 4 * kGemmFrames - 1) / (4 * kGemmFrames);
+    constexpr int kWPer = (16 * NW + 255) / 256;  // double2 loads per thread per weight tile (32*NW doubles / 256 threads)
     for (size_t bt = blockIdx.x; bt < tilesTotal; bt += gridDim.x) {
         const size_t F0 = (bt * 4 + wave) * kGemmFrames;  // this wave's 64 frames (may start past the end: then all clamped)
         const float *gsrc[8];
@@ -364,7 +375,6 @@ __global__ __launch_bounds__(256) void mfcc_mfma_gemm_kernel(
 #pragma unroll
             for (int cb = 0; cb < NT; cb++) acc[rb][cb] = (d4){0.0, 0.0, 0.0, 0.0};
         float an[8][4];
-        constexpr int kWPer = (16 * NW + 255) / 256;  // double2 loads per thread per weight tile (32*NW doubles / 256 threads)
         double2v wn[kWPer];
         auto loadA = [&](unsigned kt) {
 #pragma unroll
@@ -386,11 +396,10 @@ __global__ __launch_bounds__(256) void mfcc_mfma_gemm_kernel(
         loadA(0);
         loadW(0);
         for (unsigned kt = 0; kt < kTiles; kt++) {
-            float *bufA = myA + (kt & 1) * kGemmFrames * kGemmAStride;
             double *bufW = sW + (kt & 1) * kGemmKT * NW;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                float *d = bufA + (lrow + 8 * i) * kGemmAStride + lcol;
+                float *d = myA + (lrow + 8 * i) * kGemmAStride + lcol;
                 *reinterpret_cast<float2 *>(d) = make_float2(an[i][0], an[i][1]);
                 *reinterpret_cast<float2 *>(d + 2) = make_float2(an[i][2], an[i][3]);
             }
@@ -403,12 +412,12 @@ __global__ __launch_bounds__(256) void mfcc_mfma_gemm_kernel(
                 loadA(kt + 1);
                 loadW(kt + 1);
             }
-            __syncthreads();
+            __syncthreads();  // W tile kt visible; every wave has left tile kt-1 (so W buffer (kt+1)&1 may be refilled next)
 #pragma unroll
             for (int ks = 0; ks < kGemmKT / 4; ks++) {
                 double a[4], b[NT];
 #pragma unroll
-                for (int rb = 0; rb < 4; rb++) a[rb] = (double)bufA[(rb * 16 + r16) * kGemmAStride + ks * 4 + kq];
+                for (int rb = 0; rb < 4; rb++) a[rb] = (double)myA[(rb * 16 + r16) * kGemmAStride + ks * 4 + kq];
 #pragma unroll
                 for (int cb = 0; cb < NT; cb++) b[cb] = bufW[(ks * 4 + kq) * NW + cb * 16 + r16];
 #pragma unroll
@@ -417,36 +426,39 @@ __global__ __launch_bounds__(256) void mfcc_mfma_gemm_kernel(
                     for (int cb = 0; cb < NT; cb++)
                         acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
             }
+            wave_lds_sync();  // this wave's A tile is consumed before the next iteration overwrites it
         }
-        __syncthreads();  // every wave is done with both operand buffers: the epilogue reuses the LDS
         if constexpr (EPILOGUE) {
-            const unsigned ES = NW + 1;
-            double *tile = s_dyn + (size_t)wave * kGemmFrames * ES;
+            const int ef = lane & 31, eh = lane >> 5;
 #pragma unroll
-            for (int rb = 0; rb < 4; rb++)
+            for (int half = 0; half < 2; half++) {
 #pragma unroll
-                for (int cb = 0; cb < NT; cb++)
+                for (int rbl = 0; rbl < 2; rbl++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) tile[(rb * 16 + kq + 4 * r) * ES + cb * 16 + r16] = acc[rb][cb][r];
-            wave_lds_sync();
-            const size_t fr = F0 + lane;
-            const bool live = fr < nframes;
-            double *row = tile + lane * ES;
-            for (unsigned f = 0; f < numFilters; f++) {
-                const double v = row[f];
-                const double lv = log_square(v);
-                row[f] = lv;
-                if (live) {
-                    if (melraw) melraw[fr * numFilters + f] = v;
-                    if (melbands) melbands[fr * numFilters + f] = lv;
+                    for (int cb = 0; cb < NT; cb++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) tile[(rbl * 16 + kq + 4 * r) * ES + cb * 16 + r16] = acc[half * 2 + rbl][cb][r];
+                wave_lds_sync();
+                const size_t fr = F0 + half * 32 + ef;
+                const bool live = fr < nframes;
+                double *row = tile + ef * ES;
+                for (unsigned f = eh; f < numFilters; f += 2) {
+                    const double v = row[f];
+                    const double lv = log_square(v);
+                    row[f] = lv;
+                    if (live) {
+                        if (melraw) melraw[fr * numFilters + f] = v;
+                        if (melbands) melbands[fr * numFilters + f] = lv;
+                    }
                 }
+                wave_lds_sync();
+                for (unsigned i = eh; i < numCoeffs; i += 2) {
+                    double c = 0.0;
+                    for (unsigned f = 0; f < numFilters; f++) c += (dct[f * numCoeffs + i] * row[f]);  // L/maxiMFCC.h:105
+                    if (live) mfcc[fr * numCoeffs + i] = c / (double)numCoeffs;                         // :109
+                }
+                wave_lds_sync();
             }
-            for (unsigned i = 0; i < numCoeffs; i++) {
-                double c = 0.0;
-                for (unsigned f = 0; f < numFilters; f++) c += (dct[f * numCoeffs + i] * row[f]);  // L/maxiMFCC.h:105
-                if (live) mfcc[fr * numCoeffs + i] = c / (double)numCoeffs;                         // :109
-            }
-            __syncthreads();
         } else {
             // raw band sums of this filter group straight to global [frame][rawStride]
 #pragma unroll
@@ -460,6 +472,7 @@ __global__ __launch_bounds__(256) void mfcc_mfma_gemm_kernel(
                         if (fr < nframes && f < numFilters) melraw[fr * rawStride + f] = acc[rb][cb][r];
                     }
         }
+        __syncthreads();  // nobody refills W buffer 0 for the next frame tile while a slower wave still multiplies
     }
 }
 
@@ -770,12 +783,11 @@ int mxg_mfcc_batch(const mxg_mfcc_plan *p, const float *d_mags, size_t mag_strid
         // K7b as a tiled GEMM.  K = the bins that carry weight (rounded up to 32), or all of them with mfcc_mfma_fullk.
         const unsigned kTiles = tune_get("mfcc_mfma_fullk") ? (p->numBins + 31) / 32 : (p->nbUsed + 31) / 32;
         const size_t tilesTotal = (nframes + 4 * kGemmFrames - 1) / (4 * kGemmFrames);
-        const unsigned blocks = (unsigned)(tilesTotal < 256 ? tilesTotal : 256);  // one 100 KB workgroup per CU
-        auto lds_for = [](int NT, bool epi) {
+        const unsigned blocks = (unsigned)(tilesTotal < 512 ? tilesTotal : 512);  // two ~60 KB workgroups per CU
+        auto lds_for = [](int NT, bool) {
             const size_t NW = (size_t)NT * 16;
-            const size_t mainB = sizeof(double) * 2 * kGemmKT * NW + sizeof(float) * 4 * 2 * kGemmFrames * kGemmAStride;
-            const size_t epiB = epi ? sizeof(double) * 4 * kGemmFrames * (NW + 1) : 0;
-            return mainB > epiB ? mainB : epiB;
+            const size_t a = sizeof(float) * kGemmFrames * kGemmAStride, e = sizeof(double) * 32 * (NW + 1);
+            return sizeof(double) * 2 * kGemmKT * NW + 4 * (((a > e ? a : e) + 15) & ~(size_t)15);
         };
 #define MXG_GEMM_LAUNCH(NT, EPI, FOFF, RAW, RAWSTRIDE)                                                                  \
     do {                                                                                                                \

@@ -94,23 +94,24 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
 
 // ---- K1m: K1 + fused maxiMix::stereo partial sums ---------------------------------------------------
 // Same per-voice recurrence and (optional) per-voice store as K1; in addition every wavefront reduces its 64 voices'
-// panned samples (in*sqrt(1-x), in*sqrt(x), C:503-509) to one (L,R) pair per sample, so the mixdown never re-reads the
-// 268 MB block from HBM.  The reduction lives entirely in registers: 16 samples are folded by a transposing butterfly --
-// each level takes two vectors, exchanges complementary halves between them and adds, so the number of vectors halves
-// while every vector carries twice as many samples:
-//   level 1  v_permlane32_swap   (lane i <-> i+32)       16 vectors -> 8    [2 samples x 32 partial sums]
-//   level 2  v_permlane16_swap   (row r <-> r^1)          8 -> 4            [4 x 16]
-//   level 3  DPP row_mirror      (lane i <-> 15-i of a row, bank-masked)   4 -> 2   [8 x 8]
-//   level 4  DPP row_half_mirror (lane i <-> 7-i of a half row)            2 -> 1   [16 x 4]
-//   then two quad_perm adds: lane 4j holds the wave's sum for one sample (which one: the same network run once on the
-//   sample indices, `slot`).
-// 15 + 8 = 23 fp64 adds and ~60 32-bit lane moves per 16 samples and channel instead of 16 x 6 shuffle-adds, no LDS
-// round trip in the sample loop (the first K1m transposed through LDS and was latency-bound at one wave per SIMD: 84 us
-// vs 42 us for K1).  The four waves of a workgroup then combine their sums through LDS once per 512 samples and a small
-// second kernel sums the per-workgroup partials in a fixed order => deterministic (but not the reference's sequential
-// order: tolerance on the mix).
+// panned samples (in*sqrt(1-x), in*sqrt(x), C:503-509) per sample, so the mixdown never re-reads the 268 MB block from
+// HBM.  The reduction is a transposing butterfly in registers: each level takes two vectors, exchanges complementary
+// lanes between them and adds, so the number of vectors halves while every vector carries twice as many samples.
+// Measured issue costs on gfx950 (tools/ubench): any 32-bit VALU op incl. a DPP move 4.35 clk per wave64, an fp64
+// add/mul 4.35, v_permlane16/32_swap 16, ds_bpermute 24.  So the four transposing levels for a chunk of 16 samples use
+// the exchanges that stay inside a row of 16 lanes (DPP), largest level first where the pairs are most numerous:
+//   level 1  row_mirror      (lane i <-> 15-i, bank-masked DPP moves)   16 vectors -> 8     5 ops per fold
+//   level 2  row_half_mirror (lane i <-> 7-i)                            8 -> 4            5 ops
+//   level 3  quad_perm xor 2 (select + DPP)                              4 -> 2            7 ops
+//   level 4  quad_perm xor 1                                             2 -> 1            7 ops
+// = 81 VALU ops per channel and 16 samples (the first version exchanged across rows with v_permlane swaps: 48 of them,
+// 768 clk per chunk, VALU-bound at 48 us against 42 us for K1).  After level 4 lane l holds, for one of the 16 samples
+// (which one: the same network run once on the sample indices, `slot`), the sum over ITS ROW of 16 voices; the four row
+// sums are not combined in registers at all: every lane stores its (L, R) pair to LDS [wave][row][sample] and the
+// workgroup's combine pass -- which has to add the four waves anyway -- adds 16 terms instead of 4, in a fixed order.
+// A small second kernel sums the per-workgroup partials => deterministic (but not the reference's sequential order:
+// tolerance on the mix).
 constexpr int kMixChunk = 16;
-constexpr int kMixSuper = 512;  // samples between two workgroup combines (LDS: 4 waves x 512 x 2 doubles = 32 KB)
 
 template <typename T> struct Fold;
 template <> struct Fold<double> {
@@ -118,41 +119,14 @@ template <> struct Fold<double> {
     static __device__ __forceinline__ void split(double v, unsigned &lo, unsigned &hi) { lo = (unsigned)__double2loint(v); hi = (unsigned)__double2hiint(v); }
     static __device__ __forceinline__ double make(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
 };
-template <> struct Fold<int> {  // the sample-index network: both operands must name the same sample
-    static __device__ __forceinline__ int join(int x, int y) { return x == y ? x : -1; }
-};
 
-// two 64-lane vectors (samples A, B) -> one: lanes 0-31 = A[i] + A[i+32], lanes 32-63 = B[i-32] + B[i]
-__device__ __forceinline__ double fold32(double a, double b) {
-    unsigned al, ah, bl, bh;
-    Fold<double>::split(a, al, ah);
-    Fold<double>::split(b, bl, bh);
-    auto lo = __builtin_amdgcn_permlane32_swap(al, bl, false, false);
-    auto hi = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
-    return Fold<double>::make(lo[0], hi[0]) + Fold<double>::make(lo[1], hi[1]);
-}
-__device__ __forceinline__ int fold32(int a, int b) {
-    auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
-    return Fold<int>::join((int)r[0], (int)r[1]);
-}
-__device__ __forceinline__ double fold16(double a, double b) {
-    unsigned al, ah, bl, bh;
-    Fold<double>::split(a, al, ah);
-    Fold<double>::split(b, bl, bh);
-    auto lo = __builtin_amdgcn_permlane16_swap(al, bl, false, false);
-    auto hi = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
-    return Fold<double>::make(lo[0], hi[0]) + Fold<double>::make(lo[1], hi[1]);
-}
-__device__ __forceinline__ int fold16(int a, int b) {
-    auto r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
-    return Fold<int>::join((int)r[0], (int)r[1]);
-}
 // DPP exchange: t = x with the lanes of `BANKS_T` replaced by ctrl(y); u = y with the other banks replaced by ctrl(x)
 template <int CTRL, int BANKS_T>
 __device__ __forceinline__ void dpp_exchange(unsigned x, unsigned y, unsigned &t, unsigned &u) {
     t = (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)y, CTRL, 0xf, BANKS_T, false);
     u = (unsigned)__builtin_amdgcn_update_dpp((int)y, (int)x, CTRL, 0xf, 0xf ^ BANKS_T, false);
 }
+// banks BANKS_T of the result carry sample B (its lanes added to their mirror partners), the others sample A
 template <int CTRL, int BANKS_T>
 __device__ __forceinline__ double fold_dpp(double a, double b) {
     unsigned al, ah, bl, bh, tl, th, ul, uh;
@@ -166,10 +140,65 @@ template <int CTRL, int BANKS_T>
 __device__ __forceinline__ int fold_dpp(int a, int b) {
     unsigned t, u;
     dpp_exchange<CTRL, BANKS_T>((unsigned)a, (unsigned)b, t, u);
-    return Fold<int>::join((int)t, (int)u);
+    return (int)t == (int)u ? (int)t : -1;  // both operands must name the same sample
+}
+// lanes with `bit` set keep sample B, the others sample A; each adds the partner lane (quad_perm QP) of its own sample
+template <int QP>
+__device__ __forceinline__ double fold_quad(double a, double b, bool bit) {
+    const double keep = bit ? b : a, send = bit ? a : b;
+    unsigned lo, hi;
+    Fold<double>::split(send, lo, hi);
+    const double got = Fold<double>::make((unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, QP, 0xf, 0xf, true),
+                                          (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, QP, 0xf, 0xf, true));
+    return keep + got;
+}
+template <int QP>
+__device__ __forceinline__ int fold_quad(int a, int b, bool bit) {
+    const int keep = bit ? b : a, send = bit ? a : b;
+    const int got = __builtin_amdgcn_update_dpp(0, send, QP, 0xf, 0xf, true);
+    return keep == got ? keep : -1;
 }
 constexpr int kDppRowMirror = 0x140, kDppRowHalfMirror = 0x141;
 constexpr int kDppQuadXor1 = 0xB1 /* [1,0,3,2] */, kDppQuadXor2 = 0x4E /* [2,3,0,1] */;
+// 16 vectors (one per sample) -> one vector: lane l holds, for sample slot(l), the sum over the 16 lanes of its row
+template <typename T>
+__device__ __forceinline__ T fold_chunk(const T (&v)[kMixChunk], int lane) {
+    T l1[8], l2[4], l3[2];
+#pragma unroll
+    for (int j = 0; j < 8; j++) l1[j] = fold_dpp<kDppRowMirror, 0xC>(v[2 * j], v[2 * j + 1]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) l2[j] = fold_dpp<kDppRowHalfMirror, 0xA>(l1[2 * j], l1[2 * j + 1]);
+#pragma unroll
+    for (int j = 0; j < 2; j++) l3[j] = fold_quad<kDppQuadXor2>(l2[2 * j], l2[2 * j + 1], (lane & 2) != 0);
+    return fold_quad<kDppQuadXor1>(l3[0], l3[1], (lane & 1) != 0);
+}
+
+// ---- variant 0: cross-row levels first with v_permlane32/16_swap, then mirror / half-mirror, then a quad reduction:
+// every quad of lanes ends up with the wave-wide sum of one sample (no row sums for the workgroup pass to add)
+__device__ __forceinline__ double fold32(double a, double b) {
+    unsigned al, ah, bl, bh;
+    Fold<double>::split(a, al, ah);
+    Fold<double>::split(b, bl, bh);
+    auto lo = __builtin_amdgcn_permlane32_swap(al, bl, false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
+    return Fold<double>::make(lo[0], hi[0]) + Fold<double>::make(lo[1], hi[1]);
+}
+__device__ __forceinline__ int fold32(int a, int b) {
+    auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+    return (int)r[0] == (int)r[1] ? (int)r[0] : -1;
+}
+__device__ __forceinline__ double fold16(double a, double b) {
+    unsigned al, ah, bl, bh;
+    Fold<double>::split(a, al, ah);
+    Fold<double>::split(b, bl, bh);
+    auto lo = __builtin_amdgcn_permlane16_swap(al, bl, false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+    return Fold<double>::make(lo[0], hi[0]) + Fold<double>::make(lo[1], hi[1]);
+}
+__device__ __forceinline__ int fold16(int a, int b) {
+    auto r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
+    return (int)r[0] == (int)r[1] ? (int)r[0] : -1;
+}
 __device__ __forceinline__ double quad_sum(double v) {
     unsigned lo, hi;
     Fold<double>::split(v, lo, hi);
@@ -181,9 +210,8 @@ __device__ __forceinline__ double quad_sum(double v) {
                            (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, kDppQuadXor2, 0xf, 0xf, true));
     return v + o;
 }
-// 16 vectors (one per sample) -> one vector: every quad of lanes holds the wave-wide sum of one sample
 template <typename T>
-__device__ __forceinline__ T fold_chunk(const T (&v)[kMixChunk]) {
+__device__ __forceinline__ T fold_chunk_swap(const T (&v)[kMixChunk]) {
     T l1[8], l2[4], l3[2];
 #pragma unroll
     for (int j = 0; j < 8; j++) l1[j] = fold32(v[2 * j], v[2 * j + 1]);
@@ -194,14 +222,18 @@ __device__ __forceinline__ T fold_chunk(const T (&v)[kMixChunk]) {
     return fold_dpp<kDppRowHalfMirror, 0xA>(l3[0], l3[1]);
 }
 
-template <int WF, bool STORE>
+// VAR 0: permlane-swap butterfly, 4 LDS rows per window (one per wave).  VAR 1: all-DPP butterfly, 16 rows (wave x row).
+template <int WF, bool STORE, int VAR, int WIN>
 __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const double *__restrict__ freq,
                                                       const double *__restrict__ p1, const double *__restrict__ p2,
                                                       double *__restrict__ phase_io, double *__restrict__ hold_io,
                                                       double *__restrict__ out, const double *__restrict__ pan,
                                                       double *__restrict__ partial, double sr) {
     constexpr int kTab = uses_sine<WF>() ? MAXI_SINE_TAB_LEN : (WF == MXG_OSC_SAWN ? MAXI_TRANS_TAB_LEN : 1);
-    __shared__ double s_all[kTab + 4 * kMixSuper * 2];
+    constexpr int kTabPad = (kTab + 1) & ~1;  // the (L, R) pairs below are 16-byte stores
+    constexpr int kRows = VAR == 0 ? 4 : 16;  // LDS rows the workgroup pass adds per output
+    constexpr int kMixWin = WIN;
+    __shared__ __attribute__((aligned(16))) double s_all[kTabPad + kRows * kMixWin * 2];
     double *s_tab = s_all;
     if constexpr (uses_sine<WF>()) {
         for (int i = threadIdx.x; i < MAXI_SINE_TAB_LEN; i += blockDim.x) s_tab[i] = MAXI_SINE_TAB_D[i];
@@ -210,8 +242,8 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *s_sum = s_all + kTab;                       // [4 waves][kMixSuper][2]
-    double *my_sum = s_sum + wave * (kMixSuper * 2);
+    double *s_part = s_all + kTabPad;                                     // [kRows][kMixWin][2]
+    double *my_part = s_part + (VAR == 0 ? wave : wave * 4 + (lane >> 4)) * (kMixWin * 2);
     // The lane exchanges need all 64 lanes alive, and a per-sample `if (live)` costs an exec-mask region per sample:
     // the surplus lanes of the bank's last wavefront shadow voice V-1 instead (same loads, same arithmetic, same stores
     // of the same values to the same addresses) and enter the mix with zero gains.
@@ -228,69 +260,54 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
     // drains the asynchronous output stores with s_waitcnt vmcnt(0) every chunk.
     asm volatile("" : "+v"(ph), "+v"(hd), "+v"(gl), "+v"(gr));
     asm volatile("" : "+v"(q.inc), "+v"(q.k), "+v"(q.p1), "+v"(q.p2));
-    // which sample of a chunk this lane's quad ends up holding: the same network on the sample indices
+    // which sample of a chunk this lane ends up holding: the same network on the sample indices
     int slot;
     {
         int idx[kMixChunk];
 #pragma unroll
         for (int i = 0; i < kMixChunk; i++) idx[i] = i;
-        slot = fold_chunk<int>(idx);
+        slot = VAR == 0 ? fold_chunk_swap<int>(idx) : fold_chunk<int>(idx, lane);
+        if (VAR == 0 && (lane & 3) != 0) slot = -1;  // one lane per quad stores
     }
     double *o = out + v;
-    for (size_t n0 = 0; n0 < N; n0 += kMixSuper) {
-        const int super = (int)((N - n0) < (size_t)kMixSuper ? (N - n0) : (size_t)kMixSuper);
-        for (int c0 = 0; c0 < super; c0 += kMixChunk) {
-            const int cnt = (super - c0) < kMixChunk ? (super - c0) : kMixChunk;
-            // The butterfly consumes the samples as they arrive (a binary counter: after sample 2j+1 the pair folds, after
-            // every 4th the two pair sums fold, ...), so the lane exchanges sit BETWEEN the per-sample stores instead of in
-            // one 200-instruction stretch without a store behind them; sched_barrier pins that order against hipcc's
-            // list scheduler, which otherwise clusters the folds after the sixteenth store.
+    for (size_t n0 = 0; n0 < N; n0 += kMixWin) {
+        const int span = (int)((N - n0) < (size_t)kMixWin ? (N - n0) : (size_t)kMixWin);
+        for (int c0 = 0; c0 < span; c0 += kMixChunk) {
+            const int cnt = (span - c0) < kMixChunk ? (span - c0) : kMixChunk;
             auto chunk = [&](auto full_tag) {
-            constexpr bool kFull = decltype(full_tag)::value;
-            double l1L[8], l1R[8], l2L[4], l2R[4], l3L[2], l3R[2], pL = 0.0, pR = 0.0;
+                constexpr bool kFull = decltype(full_tag)::value;
+                double L[kMixChunk], R[kMixChunk];
 #pragma unroll
-            for (int i = 0; i < kMixChunk; i++) {
-                double r = 0.0;
-                if (kFull || i < cnt) {  // ragged last chunk: the state must not advance past N
-                    r = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
-                    if constexpr (STORE) {
-                        *o = r;
-                        o += V;
+                for (int i = 0; i < kMixChunk; i++) {
+                    double r = 0.0;
+                    if (kFull || i < cnt) {  // ragged last chunk: the state must not advance past N
+                        r = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+                        if constexpr (STORE) {
+                            *o = r;
+                            o += V;
+                        }
                     }
+                    L[i] = r * gl;  // two[0] = input*sqrt(1.0-x)   C:506
+                    R[i] = r * gr;  // two[1] = input*sqrt(x)       C:507
                 }
-                const double L = r * gl;  // two[0] = input*sqrt(1.0-x)   C:506
-                const double R = r * gr;  // two[1] = input*sqrt(x)       C:507
-                if ((i & 1) == 0) {
-                    pL = L;
-                    pR = R;
-                } else {
-                    l1L[i >> 1] = fold32(pL, L);
-                    l1R[i >> 1] = fold32(pR, R);
-                }
-                if ((i & 3) == 3) {
-                    l2L[i >> 2] = fold16(l1L[(i >> 1) - 1], l1L[i >> 1]);
-                    l2R[i >> 2] = fold16(l1R[(i >> 1) - 1], l1R[i >> 1]);
-                }
-                if ((i & 7) == 7) {
-                    l3L[i >> 3] = fold_dpp<kDppRowMirror, 0xC>(l2L[(i >> 2) - 1], l2L[i >> 2]);
-                    l3R[i >> 3] = fold_dpp<kDppRowMirror, 0xC>(l2R[(i >> 2) - 1], l2R[i >> 2]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const double sl = quad_sum(fold_dpp<kDppRowHalfMirror, 0xA>(l3L[0], l3L[1]));
-            const double sr2 = quad_sum(fold_dpp<kDppRowHalfMirror, 0xA>(l3R[0], l3R[1]));
-            if ((lane & 3) == 0 && slot >= 0 && slot < cnt) {
-                double2v pr = {sl, sr2};
-                *reinterpret_cast<double2v *>(my_sum + (c0 + slot) * 2) = pr;
-            }
+                double2v pr;
+                if constexpr (VAR == 0)
+                    pr = (double2v){quad_sum(fold_chunk_swap<double>(L)), quad_sum(fold_chunk_swap<double>(R))};
+                else
+                    pr = (double2v){fold_chunk<double>(L, lane), fold_chunk<double>(R, lane)};
+                if (slot >= 0 && slot < cnt) *reinterpret_cast<double2v *>(my_part + (c0 + slot) * 2) = pr;
             };
             if (cnt == kMixChunk) chunk(std::true_type{}); else chunk(std::false_type{});
         }
-        // the four waves' sums of this stretch -> one partial per workgroup, waves added in order 0..3
+        // 4 waves x 4 rows of this window -> one partial per workgroup: 16 terms, added in the order wave 0 row 0..3, wave 1 ...
         __syncthreads();
         double *prow = partial + (size_t)blockIdx.x * N * 2 + n0 * 2;
-        for (int i = threadIdx.x; i < super * 2; i += blockDim.x)
-            prow[i] = ((s_sum[i] + s_sum[kMixSuper * 2 + i]) + s_sum[2 * kMixSuper * 2 + i]) + s_sum[3 * kMixSuper * 2 + i];
+        for (int i = threadIdx.x; i < span * 2; i += blockDim.x) {
+            double t = s_part[i];
+#pragma unroll
+            for (int k = 1; k < kRows; k++) t += s_part[k * (kMixWin * 2) + i];
+            prow[i] = t;
+        }
         __syncthreads();
     }
     phase_io[v] = ph;
@@ -326,23 +343,31 @@ __global__ __launch_bounds__(64 * kPartWaves) void mix_partials_kernel(size_t ng
 typedef void (*osc_mix_fn)(size_t, size_t, const double *, const double *, const double *, double *, double *,
                            double *, const double *, double *, double);
 template <int WF>
-osc_mix_fn pick_mix(bool store) {
-    return store ? osc_mix_kernel<WF, true> : osc_mix_kernel<WF, false>;
+osc_mix_fn pick_mix(bool store, int var) {
+    if (WF == MXG_OSC_SINEBUF) {  // the A/B variants are only instantiated for the bench waveform
+        switch (var) {
+            case 1: return store ? osc_mix_kernel<WF, true, 0, 128> : osc_mix_kernel<WF, false, 0, 128>;
+            case 2: return store ? osc_mix_kernel<WF, true, 1, 128> : osc_mix_kernel<WF, false, 1, 128>;
+            case 3: return store ? osc_mix_kernel<WF, true, 1, 512> : osc_mix_kernel<WF, false, 1, 512>;
+            default: break;
+        }
+    }
+    return store ? osc_mix_kernel<WF, true, 0, 512> : osc_mix_kernel<WF, false, 0, 512>;
 }
-osc_mix_fn pick_mix_wf(int wf, bool store) {
+osc_mix_fn pick_mix_wf(int wf, bool store, int var) {
     switch (wf) {
-        case 0: return pick_mix<0>(store);
-        case 1: return pick_mix<1>(store);
-        case 2: return pick_mix<2>(store);
-        case 3: return pick_mix<3>(store);
-        case 4: return pick_mix<4>(store);
-        case 5: return pick_mix<5>(store);
-        case 6: return pick_mix<6>(store);
-        case 7: return pick_mix<7>(store);
-        case 8: return pick_mix<8>(store);
-        case 9: return pick_mix<9>(store);
-        case 10: return pick_mix<10>(store);
-        case 11: return pick_mix<11>(store);
+        case 0: return pick_mix<0>(store, var);
+        case 1: return pick_mix<1>(store, var);
+        case 2: return pick_mix<2>(store, var);
+        case 3: return pick_mix<3>(store, var);
+        case 4: return pick_mix<4>(store, var);
+        case 5: return pick_mix<5>(store, var);
+        case 6: return pick_mix<6>(store, var);
+        case 7: return pick_mix<7>(store, var);
+        case 8: return pick_mix<8>(store, var);
+        case 9: return pick_mix<9>(store, var);
+        case 10: return pick_mix<10>(store, var);
+        case 11: return pick_mix<11>(store, var);
     }
     return nullptr;
 }
@@ -420,7 +445,9 @@ extern "C" int mxg_osc_render_mix(int waveform, size_t V, size_t N, const double
     double *partial = nullptr;  // per-stream scratch: [nblocks][N][2] per-workgroup sums
     if (int s = scratch_get(SCR_OSC_MIX, st, sizeof(double) * need, (void **)&partial)) return s;
     if (V) {
-        osc_mix_fn fn = pick_mix_wf(waveform, d_out != nullptr);
+        osc_mix_fn fn = pick_mix_wf(waveform, d_out != nullptr, tune_get("osc_mix_var"));
+        if (tune_get("osc_mix_var") == 3 && waveform == MXG_OSC_SINEBUF)
+            MXG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 0));
         KernelTimer kt("osc_mix_kernel", st);
         hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(block), 0, st, V, N, d_freq, d_p1, d_p2, d_phase,
                            d_outhold, d_out, d_pan, partial, (double)settings().sampleRate);

@@ -43,6 +43,18 @@ __device__ __forceinline__ float exact_sqrtf(float x) {
     return r;
 }
 
+// the `a` half of post_pair (L/fft.cpp:250-262): bin i of the real transform from X[i] and X[half - i]
+__device__ __forceinline__ float2 post_lo(const float2 a, const float2 b, const float2 w) {
+    const float h1r = 0.5f * (a.x + b.x);
+    const float h1i = 0.5f * (a.y - b.y);
+    const float h2r = 0.5f * (a.y + b.y);
+    const float h2i = -0.5f * (a.x - b.x);
+    float2 r;
+    r.x = h1r + w.x * h2r - w.y * h2i;
+    r.y = h1i + w.x * h2i + w.y * h2r;
+    return r;
+}
+
 struct FusedArgs {
     const float *signal;
     size_t frame_stride, nframes;
@@ -61,10 +73,9 @@ struct FusedArgs {
 template <bool FULL, bool WRITE_MAGS, bool ALIGNED8>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const FusedArgs A) {
     extern __shared__ double s_dyn[];
-    // [tw 512 float2][post 256 float2][fsW steps*8 f64][dct NF*NC f64][fsMeta steps*8 i32] | per wave: X, M, mel
+    // [tw 512 float2][fsW steps*8 f64][dct NF*NC f64][fsMeta steps*8 i32] | per wave: X, mel, M
     float2 *s_tw = reinterpret_cast<float2 *>(s_dyn);
-    float2 *s_post = s_tw + 512;
-    double *s_w = reinterpret_cast<double *>(s_post + 256);
+    double *s_w = reinterpret_cast<double *>(s_tw + 512);
     double *s_d = s_w + (size_t)A.steps * kFusedSlots;
     int *s_meta = reinterpret_cast<int *>(s_d + (size_t)A.numFilters * A.numCoeffs);
     const size_t metaInts = ((size_t)A.steps * kFusedSlots + 3) & ~(size_t)3;
@@ -75,7 +86,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const 
     double *s_mel = reinterpret_cast<double *>(wbase + sizeof(float2) * kX1024);
     float *M = reinterpret_cast<float *>(wbase + sizeof(float2) * kX1024 + sizeof(double) * kGroup * A.nfp);
     for (int i = threadIdx.x; i < 511; i += blockDim.x) s_tw[i] = A.tw[i];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_post[i] = A.post[i];
     for (int i = threadIdx.x; i < A.steps * kFusedSlots; i += blockDim.x) {
         s_w[i] = A.fsW[i];
         s_meta[i] = A.fsMeta[i];
@@ -98,6 +108,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const 
                  "+v"(wv[3].x), "+v"(wv[3].y));
     asm volatile("" : "+v"(wv[4].x), "+v"(wv[4].y), "+v"(wv[5].x), "+v"(wv[5].y), "+v"(wv[6].x), "+v"(wv[6].y),
                  "+v"(wv[7].x), "+v"(wv[7].y));
+    // post-pass: twiddles of this lane's four pairs in registers; LDS slots of the pairs (i, 512 - i), i = 1 + lane + 64q,
+    // are one base each plus a compile-time offset: pad8(i0 + 64q) = pad8(i0) + 72q
+    float2 pw[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) pw[q] = A.post[(1 + lane + 64 * q) < 256 ? 1 + lane + 64 * q : 255];
+    asm volatile("" : "+v"(pw[0].x), "+v"(pw[0].y), "+v"(pw[1].x), "+v"(pw[1].y), "+v"(pw[2].x), "+v"(pw[2].y),
+                 "+v"(pw[3].x), "+v"(pw[3].y));
+    const int pa0 = pad8(1 + lane), pb0 = pad8(511 - lane);
+    const int zidx = lane == 0 ? 0 : 256;  // lanes 0 / 63 also own bin 0 / the middle bin
     const size_t nframes = A.nframes;
     auto load_frame = [&](size_t fr, float2 (&dst)[8]) {
         const unsigned fu = __builtin_amdgcn_readfirstlane((unsigned)(fr < nframes ? fr : nframes - 1));
@@ -164,34 +183,36 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const 
                 grow = A.mags + (size_t)__builtin_amdgcn_readfirstlane((unsigned)(f0 + j < nframes ? f0 + j : nframes - 1)) * 512;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const unsigned i = 1u + (unsigned)lane + 64u * (unsigned)q;  // 1..256
-                const unsigned ic = i < 256u ? i : 255u;
-                float2 a = X[pad8((int)ic)], b = X[pad8(512 - (int)ic)];
-                post_pair(a, b, s_post[ic]);
-                float ma = exact_sqrtf(a.x * a.x + a.y * a.y);  // L/fft.cpp:510-511
-                if (q == 3 && i == 256u) {  // lane 63: the untouched middle bin
-                    const float2 z = X[pad8(256)];
-                    ma = exact_sqrtf(z.x * z.x + z.y * z.y);
-                }
-                Mrow[i] = ma;
-                if constexpr (WRITE_MAGS)
-                    if (frame_live) grow[i] = ma;
+                const float2 xa = X[pa0 + 72 * q], xb = X[pb0 - 72 * q];
+                const bool own = q < 3 || lane < 63;  // lane 63's fourth pair would be bin 256: handled below
                 if constexpr (FULL) {
-                    if (i < 256u) {
-                        const float mb = exact_sqrtf(b.x * b.x + b.y * b.y);
-                        Mrow[512u - i] = mb;
+                    float2 a = xa, b = xb;
+                    post_pair(a, b, pw[q]);
+                    const float ma = exact_sqrtf(a.x * a.x + a.y * a.y), mb = exact_sqrtf(b.x * b.x + b.y * b.y);
+                    if (own) {
+                        Mrow[1 + lane + 64 * q] = ma;
+                        Mrow[511 - lane - 64 * q] = mb;
                         if constexpr (WRITE_MAGS)
-                            if (frame_live) grow[512u - i] = mb;
+                            if (frame_live) {
+                                grow[1 + lane + 64 * q] = ma;
+                                grow[511 - lane - 64 * q] = mb;
+                            }
                     }
+                } else {
+                    const float2 a = post_lo(xa, xb, pw[q]);
+                    const float ma = exact_sqrtf(a.x * a.x + a.y * a.y);  // L/fft.cpp:510-511
+                    if (own) Mrow[1 + lane + 64 * q] = ma;
                 }
             }
-            if (lane == 0) {  // bin 0 packs DC and Nyquist (L/fft.cpp:274-275)
-                const float2 z = X[pad8(0)];
-                const float zr = z.x + z.y, zi = z.x - z.y;
-                const float m0 = exact_sqrtf(zr * zr + zi * zi);
-                Mrow[0] = m0;
-                if constexpr (WRITE_MAGS)
-                    if (frame_live) grow[0] = m0;
+            {   // bin 0 packs DC and Nyquist (L/fft.cpp:274-275); bin 256 passes through untouched
+                const float2 z = X[pad8(zidx)];
+                const float zr = lane == 0 ? z.x + z.y : z.x, zi = lane == 0 ? z.x - z.y : z.y;
+                const float mz = exact_sqrtf(zr * zr + zi * zi);
+                if (lane == 0 || lane == 63) {
+                    Mrow[zidx] = mz;
+                    if constexpr (WRITE_MAGS)
+                        if (frame_live) grow[zidx] = mz;
+                }
             }
             wave_lds_sync();
         }
@@ -258,15 +279,16 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
     A.signal = d_signal; A.frame_stride = frame_stride; A.nframes = nframes;
     A.window = fp->d_window; A.tw = fp->d_tw; A.post = fp->d_post;
     A.numFilters = mp->numFilters; A.numCoeffs = mp->numCoeffs; A.nbUsed = mp->nbUsed;
-    const bool full = d_mags != nullptr || mp->nbUsed > 257;
-    A.mstride = full ? 520 : 264;                 // 257 (or 512) magnitudes + pad, = 8 mod 32 banks per frame row
+    MXG_REQUIRE(mp->nbUsed <= 257, "mel bank reaches beyond bin 256");  // binFreq = sr/numBins*bin never does
+    const bool full = d_mags != nullptr;
+    A.mstride = full ? 520 : 264;                 // the post-pass writes bins 0..256 (0..511 with magnitudes out) + pad, = 8 mod 32
     A.nfp = mp->numFilters | 1u;                  // odd row stride for the band rows
     if (A.nfp == mp->numFilters) A.nfp += 2;
     A.steps = mp->fsSteps; A.fsW = mp->d_fsW; A.fsMeta = mp->d_fsMeta; A.dct = mp->d_dct;
     A.mags = d_mags; A.melraw = d_melraw; A.melbands = d_melbands; A.mfcc = d_mfcc;
     const size_t metaInts = ((size_t)A.steps * kFusedSlots + 3) & ~(size_t)3;
     const size_t perWave = sizeof(float2) * kX1024 + sizeof(float) * kGroup * A.mstride + sizeof(double) * kGroup * A.nfp;
-    const size_t lds = sizeof(float2) * 768 + sizeof(double) * ((size_t)A.steps * kFusedSlots + (size_t)A.numFilters * A.numCoeffs) +
+    const size_t lds = sizeof(float2) * 512 + sizeof(double) * ((size_t)A.steps * kFusedSlots + (size_t)A.numFilters * A.numCoeffs) +
                        sizeof(int) * metaInts + kWavesPerBlock * perWave;
     MXG_REQUIRE(lds <= 160 * 1024, "filter bank too large for the fused kernel's LDS layout");
     const size_t ngroups = (nframes + kGroup - 1) / kGroup;

@@ -1,0 +1,14 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r02c
+mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_gpu_osc.py tests/test_gpu_spectral.py tests/test_gpu_fullparity.py::test_config4_mfma_all_frames -m gpu -q > $O/pytest.log 2>&1
+echo "pytest rc=$?" >> $O/pytest.log
+tail -8 $O/pytest.log
+for args in "--tune osc_mix_var=0" "--tune osc_mix_var=1" "--tune osc_mix_var=2" "--tune osc_mix_var=3" "--mixdown off" \
+   "--workload config4" "--workload config4 --mfcc-method mfma" "--workload config4 --mfcc-method mfma --mfma-fullk"; do
+  echo "== bench.py $args" >> $O/bench.log
+  timeout 600 python bench.py --no-cpu-baseline $args >> $O/bench.log 2>> $O/bench.err
+done
+grep -c value $O/bench.log
