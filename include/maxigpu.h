@@ -108,7 +108,8 @@ int mxg_prof_read(int index, const char **h_label, double *h_total_ms, size_t *h
  * "voice_block", "voice_nt", "mix_rows" (sample rows per workgroup of the mixdown, 1|2), "fft_generic",
  * "mfcc_tiled" (LDS-staged spectra 0|1), "grain_chunked" (time-sharded granular render 0|1), "grain_lanes_k",
  * "grain_unit" (coalesced unit-increment render 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_slices" (time slices of a unit-path
- * maxiTimeStretch call whose scheduling and rendering overlap, 1..16).
+ * maxiTimeStretch call whose scheduling and rendering overlap, 1..16), "osc_mix_var" (layout of K1m's lane-exchange butterfly, 0..3),
+ * "mfcc_mfma_fullk" (the MFMA mel contraction runs over all numBins bins instead of the ones that carry weight, 0|1).
  * The tests flip every one of them and demand identical bits.  Returns the previous value or MXG_ERR_INVALID. */
 int mxg_tune(const char *key, int value);
 
