@@ -102,6 +102,9 @@ int mxg_prof_enable(int on);  /* returns the previous setting */
 int mxg_prof_reset(void);
 int mxg_prof_count(void);
 int mxg_prof_read(int index, const char **h_label, double *h_total_ms, size_t *h_launches);
+/* Average interval of `pairs` EMPTY event pairs on `stream` (two records back to back, nothing between): the marker
+ * overhead every figure of mxg_prof_read carries, for a caller that wants to subtract it. */
+int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
 
 /* ---- tuning knobs (performance only; results are identical for every setting) ---------- */
 /* key: "osc_vpl" (voices per lane 1|2), "osc_block" (64..1024), "osc_nt" (0|1 non-temporal stores),

@@ -37,6 +37,7 @@ SIGNATURES = {
     "mxg_prof_reset": (c_int, []),
     "mxg_prof_count": (c_int, []),
     "mxg_prof_read": (c_int, [c_int, POINTER(c_char_p), POINTER(c_double), POINTER(c_size_t)]),
+    "mxg_prof_overhead_ms": (c_int, [c_void_p, c_int, POINTER(c_double)]),
     "mxg_tune": (c_int, [c_char_p, c_int]),
     "mxg_osc_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p]),

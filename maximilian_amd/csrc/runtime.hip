@@ -332,6 +332,33 @@ int mxg_prof_read(int index, const char **h_label, double *h_total_ms, size_t *h
     return MXG_OK;
 }
 
+int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(pairs > 0 && pairs <= 4096 && h_ms, "bad argument");
+    hipStream_t st = resolve_stream(stream);
+    MXG_HIP(hipStreamSynchronize(st));
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev((size_t)pairs);
+    for (auto &p : ev) {
+        MXG_HIP(hipEventCreate(&p.first));
+        MXG_HIP(hipEventCreate(&p.second));
+    }
+    for (auto &p : ev) {  // exactly what a KernelTimer does around a launch, with no launch in between
+        MXG_HIP(hipEventRecord(p.first, st));
+        MXG_HIP(hipEventRecord(p.second, st));
+    }
+    MXG_HIP(hipStreamSynchronize(st));
+    double sum = 0.0;
+    for (auto &p : ev) {
+        float ms = 0.f;
+        MXG_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+        sum += (double)ms;
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    *h_ms = sum / pairs;
+    return MXG_OK;
+}
+
 // ---- calibration: streaming fill ----------------------------------------------------------
 __global__ void calib_fill8(double *p, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
