@@ -380,6 +380,41 @@ int mxg_ifft_plan_destroy(mxg_ifft_plan *plan);
 int mxg_ifft_batch(const mxg_ifft_plan *plan, const float *d_mags, const float *d_phases, size_t nframes,
                    float *d_buffer, float *d_signal, float *d_ifft_out, void *stream);
 
+/* maxiIFFT::process(real, imag, COMPLEX) (L/maxiFFT.cpp:155-192 with fftModes COMPLEX).  The reference's
+ * fft::inverseFFTComplex (L/fft.cpp:613-619) copies its inputs into out_real/out_img -- the arrays calcIFFT then overwrites
+ * with the inverse transform of in_real/in_img, which COMPLEX mode never writes.  On a fresh object those are the zeros
+ * of fft::setup, so every frame's inverse transform is exactly 0 and the call returns the carried hop buffer running
+ * out: as_reference = 1 reproduces that, bit for bit.  as_reference = 0 is what the function was written to do: real/imag
+ * [nframes][bins] go to the transform's inputs (negative frequencies zero, like polToCart), everything after -- the
+ * full-size inverse FFT with replayed twiddles, /fftSize, window, overlap-add -- exactly as mxg_ifft_batch; bit-exact
+ * against the reference's own calcIFFT fed that way (oracle/ref_harness.cpp). */
+int mxg_ifft_batch_complex(const mxg_ifft_plan *plan, const float *d_real, const float *d_imag, size_t nframes,
+                           int as_reference, float *d_buffer, float *d_signal, float *d_ifft_out, void *stream);
+
+/* ---- maxiConvolve (L/maxiConvolve.cpp:13-107): partitioned convolution over a frequency delay line ------------------ */
+/* maxiConvolve::setup(impulseFile, fftsize, hopsize) with the impulse already in memory: h_amplitudes [len] = the
+ * loaded maxiSample's amplitudes, position0 = its play head (load()/read() leave it at len, C:681).  Replicated: the
+ * impulse is played with play() (C:740-747; the first read is amplitudes[len], one past the end = 0 here) len times
+ * into maxiFFT::setup(fftsize, fftsize, hopsize) -- hop = fftsize, full Hann window: non-overlapping frames (:35-40);
+ * then getNumBins() - len % getNumBins() zeros (:41-45, which may or may not complete a last frame); the frames'
+ * real / imaginary spectra are divided by the largest positive real / imaginary value (:47-52, float division).
+ * The analysis runs on the device (mxg_fft_batch, bit-exact); NULL on failure. */
+typedef struct mxg_convolve mxg_convolve;
+mxg_convolve *mxg_convolve_create(const double *h_amplitudes, size_t len, double position0, int fftsize, int hopsize);
+int mxg_convolve_destroy(mxg_convolve *c);
+int mxg_convolve_frames(const mxg_convolve *c);  /* impulseReal.size() */
+/* the normalised impulse spectra [frames][bins]; either pointer may be NULL */
+int mxg_convolve_impulse(const mxg_convolve *c, float *h_real, float *h_imag);
+/* play(w) (:76-107) for nblocks*fftsize consecutive samples d_in -> d_out (float, device).  The delay line, the current
+ * sums and maxiIFFT's buffer are the object's state and carry from call to call.  Per fftsize samples: the input frame's
+ * spectrum enters the delay line; sumReal/sumImag = sum over k of impulse[k] (x) FDL[k] accumulated in float in k order
+ * (bin 0: real*real and imag*imag only, :86-87); block b of the output is the maxiIFFT (COMPLEX mode,
+ * setup(fftsize, fftsize, hopsize)) of the sums formed at the end of block b-1.
+ * mode 0 = as the reference computes (the COMPLEX-mode defect above: silence, while the state still advances);
+ * mode 1 = as intended (the sums reach the inverse transform).  Both bit-exact against the oracle. */
+int mxg_convolve_play(mxg_convolve *c, const float *d_in, size_t nblocks, float *d_out, int mode, void *stream);
+int mxg_convolve_reset(mxg_convolve *c);
+
 /* ---- maxiMFCC batch --------------------------------------------------------------------- */
 /* maxiMFCC::setup(numBins, numFilters, numCoeffs, minFreq, maxFreq) (L/maxiMFCC.h:56-75): builds
  * the mel filterbank and DCT tables on the host libm.  Works without a device (tables only). */

@@ -10,5 +10,5 @@ from .banks import (DeviceBuffer, maxiSettings, maxiOscBank, maxiFilterBank, max
                     maxiVoiceBank, maxiMixBank, maxiDelaylineBank, maxiSampleBank, maxiDCBlockerBank,
                     maxiSVFBank, maxiBiquadBank, maxiEnvGenBank, maxiSamplerBank, OSC_WAVEFORMS,
                     FILTER_KINDS, SAMPLE_MODES)
-from .spectral import maxiFFT, maxiIFFT, maxiMFCC, frames_in_stream, padded_stream  # noqa: F401
+from .spectral import maxiConvolve, maxiFFT, maxiIFFT, maxiMFCC, frames_in_stream, padded_stream  # noqa: F401
 from .grains import maxiTimeStretchBank, maxiStretchBank, maxiPitchShiftBank, WINDOWS  # noqa: F401

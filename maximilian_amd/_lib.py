@@ -79,6 +79,13 @@ SIGNATURES = {
     "mxg_ifft_plan_create": (c_void_p, [c_int, c_int, c_int]),
     "mxg_ifft_plan_destroy": (c_int, [c_void_p]),
     "mxg_ifft_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_ifft_batch_complex": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_convolve_create": (c_void_p, [c_void_p, c_size_t, c_double, c_int, c_int]),
+    "mxg_convolve_destroy": (c_int, [c_void_p]),
+    "mxg_convolve_frames": (c_int, [c_void_p]),
+    "mxg_convolve_impulse": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "mxg_convolve_play": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
+    "mxg_convolve_reset": (c_int, [c_void_p]),
     "mxg_sampler_freq_host": (c_int, [c_size_t, c_void_p, c_size_t, c_void_p]),
     "mxg_sampler_render": (c_int, [c_size_t, c_size_t, c_int, c_int, c_void_p, c_size_t] + [c_void_p] * 12),
     "mxg_fft_features": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),

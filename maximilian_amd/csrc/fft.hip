@@ -133,6 +133,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fft_generic_kernel(
 // (replayed on the host for the inverse angle), /n, times the window.  One wavefront per frame, one
 // LDS pass per stage (the structure of K6b).  ifft_out[f][i] = 0.0f + out_real[i]*window[i] is the
 // zero-filled `ifftOut` of the reference after calcIFFT's `+=`.
+// INPUT 0: SPECTRUM mode (magnitudes, phases -> polToCart).  1: cartesian inputs (mags = real, phases = imag: what
+// inverseFFTComplex was meant to transform).  2: the transform inputs are all zero (what the reference's COMPLEX mode
+// actually transforms on a fresh object, L/fft.cpp:613-619 -- see mxg_ifft_batch_complex).
+template <int INPUT>
 __global__ void ifft_generic_kernel(const float *__restrict__ mags, const float *__restrict__ phases,
                                     size_t nframes, int n, int numBits, const float *__restrict__ window,
                                     const float2 *__restrict__ tw, float *__restrict__ ifft_out) {
@@ -146,10 +150,15 @@ __global__ void ifft_generic_kernel(const float *__restrict__ mags, const float 
         const float *m = mags + f * (size_t)half, *ph = phases + f * (size_t)half;
         for (int i = lane; i < n; i += 64) {
             float2 v = {0.0f, 0.0f};  // negative frequencies zeroed, L/fft.cpp:601-603
-            if (i < half) {
+            if (INPUT != 2 && i < half) {
                 const float mg = m[i], p = ph[i];
-                v.x = mg * cosf(p);  // :597-598
-                v.y = mg * sinf(p);
+                if constexpr (INPUT == 0) {
+                    v.x = mg * cosf(p);  // :597-598
+                    v.y = mg * sinf(p);
+                } else {
+                    v.x = mg;
+                    v.y = p;
+                }
             }
             const int j = (int)(__brev((unsigned)i) >> (32 - numBits));
             X[P(j)] = v;
@@ -624,10 +633,10 @@ int mxg_ifft_plan_destroy(mxg_ifft_plan *p) {
     return MXG_OK;
 }
 
-int mxg_ifft_batch(const mxg_ifft_plan *p, const float *d_mags, const float *d_phases, size_t nframes,
-                   float *d_buffer, float *d_signal, float *d_ifft_out, void *stream) {
+static int ifft_batch_impl(int input, const mxg_ifft_plan *p, const float *d_a, const float *d_b, size_t nframes,
+                           float *d_buffer, float *d_signal, float *d_ifft_out, void *stream) {
     if (int s = ensure_init()) return s;
-    MXG_REQUIRE(p && d_mags && d_phases && d_signal, "null plan or pointer");
+    MXG_REQUIRE(p && d_signal && (input == 2 || (d_a && d_b)), "null plan or pointer");
     if (nframes == 0) return MXG_OK;
     hipStream_t st = resolve_stream(stream);
     const int n = p->fftSize;
@@ -638,12 +647,16 @@ int mxg_ifft_batch(const mxg_ifft_plan *p, const float *d_mags, const float *d_p
     const size_t per_wave = sizeof(float2) * (size_t)(n + (n >> 5) + 1);
     int waves = n <= 1024 ? 4 : (n <= 2048 ? 2 : 1);
     const size_t lds = per_wave * waves;
-    if (lds > 64 * 1024)
-        MXG_HIP(hipFuncSetAttribute((const void *)ifft_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    typedef void (*kern_t)(const float *, const float *, size_t, int, int, const float *, const float2 *, float *);
+    kern_t k = input == 0 ? ifft_generic_kernel<0> : (input == 1 ? ifft_generic_kernel<1> : ifft_generic_kernel<2>);
+    if (lds > 64 * 1024) MXG_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     size_t blocks = (nframes + waves - 1) / waves;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(ifft_generic_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, st, d_mags, d_phases, nframes, n,
-                       p->numBits, p->d_window, p->d_tw, io);
+    {
+        KernelTimer kt("ifft_generic_kernel", st);
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * waves), lds, st, d_a, d_b, nframes, n, p->numBits, p->d_window,
+                           p->d_tw, io);
+    }
     MXG_HIP(hipGetLastError());
     // overlap-add: the carried buffer is read while the new one is written -> stage the old one
     const float *buf_in = nullptr;
@@ -657,6 +670,16 @@ int mxg_ifft_batch(const mxg_ifft_plan *p, const float *d_mags, const float *d_p
     hipLaunchKernelGGL(ifft_ola_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, io, nframes, n, p->hopSize,
                        buf_in, d_signal, d_buffer);
     return check_hip(hipGetLastError(), "ifft kernels launch");
+}
+
+int mxg_ifft_batch(const mxg_ifft_plan *p, const float *d_mags, const float *d_phases, size_t nframes,
+                   float *d_buffer, float *d_signal, float *d_ifft_out, void *stream) {
+    return ifft_batch_impl(0, p, d_mags, d_phases, nframes, d_buffer, d_signal, d_ifft_out, stream);
+}
+
+int mxg_ifft_batch_complex(const mxg_ifft_plan *p, const float *d_real, const float *d_imag, size_t nframes,
+                           int as_reference, float *d_buffer, float *d_signal, float *d_ifft_out, void *stream) {
+    return ifft_batch_impl(as_reference ? 2 : 1, p, d_real, d_imag, nframes, d_buffer, d_signal, d_ifft_out, stream);
 }
 
 }  // extern "C"

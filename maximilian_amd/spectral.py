@@ -221,3 +221,54 @@ class maxiIFFT:
             self.close()
         except Exception:
             pass
+
+
+class maxiConvolve:
+    """maxiConvolve (L/maxiConvolve.cpp): partitioned convolution.  `setup(amplitudes, fftsize, hopsize)` takes the
+    impulse as the loaded maxiSample holds it (the reference loads it from a file name); `play(x, mode)` renders what
+    play(w) returns for every sample of x (a whole number of fftsize blocks), state carried between calls.
+    mode 0 = as the reference computes (its COMPLEX-mode maxiIFFT never sees the sums: silence), 1 = as intended."""
+
+    def __init__(self, stream=None):
+        self.h = None
+        self.stream = stream
+
+    def setup(self, amplitudes, fftsize=1024, hopsize=256, position0=None):
+        self.close()
+        a = np.ascontiguousarray(amplitudes, np.float64)
+        pos = float(a.size if position0 is None else position0)   # load()/read() leave the play head at size (C:681)
+        h = lib().mxg_convolve_create(a.ctypes.data, a.size, pos, fftsize, hopsize)
+        if not h:
+            raise ValueError(lib().mxg_last_error().decode())
+        self.h, self.fftsize, self.hopsize, self.bins = h, fftsize, hopsize, fftsize // 2
+        self.frames = lib().mxg_convolve_frames(h)
+
+    def impulse(self):
+        r = np.zeros((self.frames, self.bins), np.float32)
+        i = np.zeros((self.frames, self.bins), np.float32)
+        check(lib().mxg_convolve_impulse(self.h, r.ctypes.data, i.ctypes.data), "mxg_convolve_impulse")
+        return r, i
+
+    def play(self, x, mode=0, out=None):
+        if not (isinstance(x, DeviceBuffer) or hasattr(x, "data_ptr")):
+            x = DeviceBuffer.from_numpy(np.ascontiguousarray(x, np.float32))
+        n = int(np.prod(x.shape))
+        assert n % self.fftsize == 0, "a whole number of fftsize blocks"
+        out = out if out is not None else DeviceBuffer(n, np.float32, zero=False)
+        check(lib().mxg_convolve_play(self.h, _ptr(x), n // self.fftsize, _ptr(out), mode, self.stream), "mxg_convolve_play")
+        self._keep = x
+        return out
+
+    def reset(self):
+        check(lib().mxg_convolve_reset(self.h), "mxg_convolve_reset")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mxg_convolve_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

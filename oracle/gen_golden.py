@@ -449,8 +449,24 @@ def main():
     files["extra2.npz"] = ("maxiDCBlocker, maxiSVF, maxiBiquad x7 types (outputs, state, coefficients), maxiEnvGen AR/ADSR/curved x "
                            "loop/retrigger (outputs, detector + stage state, stage tables), maxiSampler 3x8 slots with note-offs")
 
+    # ---- maxiConvolve: impulse analysis + play(), as the reference computes (mode 0) and as intended (mode 1) ----
+    rng = np.random.default_rng(SEED + 77)
+    d = {}
+    for tag, (Li, F, H) in {"a": (5000, 1024, 256), "b": (1800, 256, 64), "c": (2049, 1024, 256)}.items():
+        pcm = (rng.uniform(-1, 1, Li) * np.exp(-np.arange(Li) / (Li / 6.0)) * 24000).astype(np.int16)
+        x = rng.uniform(-1, 1, F * 9).astype(np.float32)
+        d["pcm_" + tag], d["x_" + tag], d["cfg_" + tag] = pcm, x, np.array([F, H])
+        for mode in (0, 1):
+            o, ir, ii = R.convolve(pcm, x, F, H, mode)
+            d["out%d_%s" % (mode, tag)] = o
+        d["impR_" + tag], d["impI_" + tag] = ir, ii
+    save("convolve.npz", **d)
+    files["convolve.npz"] = ("maxiConvolve setup (impulse frames, normalised) + play() over 9 input frames for 1024/256 (5 and 2 "
+                             "impulse frames) and 256/64: mode 0 = the reference verbatim (silence), mode 1 = sums routed to the "
+                             "inverse transform's inputs through the reference's own calcIFFT")
+
     sha = hashlib.sha256()
-    for f in ("maximilian.cpp", "maximilian.h", "libs/fft.cpp", "libs/maxiFFT.cpp", "libs/maxiMFCC.cpp",
+    for f in ("libs/maxiConvolve.cpp", "libs/maxiConvolve.h", "libs/maxiFFT.h", "libs/fft.h", "maximilian.cpp", "maximilian.h", "libs/fft.cpp", "libs/maxiFFT.cpp", "libs/maxiMFCC.cpp",
               "libs/maxiMFCC.h", "libs/maxiGrains.h", "libs/maxiSynths.cpp", "libs/maxiSynths.h"):
         sha.update(open(os.path.join(REF_SRC, f), "rb").read())
     manifest = {

@@ -1658,6 +1658,121 @@ int mxo_ifft_stream(const float *mags, const float *phases, size_t nframes, int 
 }
 
 /* ------------------------------------------------------------------------------------
+ * maxiConvolve (L/maxiConvolve.cpp:13-107): partitioned convolution over a frequency delay line.
+ * setup(impulseFile, fftsize, hopsize):
+ *   - the impulse maxiSample is loaded (amplitudes = pcm/32767.0, position = size, C:679-681) and played with
+ *     play() (C:740-747) getLength() times into maxiFFT::setup(fftsize, fftsize, hopsize) -- note the argument
+ *     order: hop = fftsize, window = max(hopsize, fftsize): non-overlapping Hann-windowed frames (:35-40);
+ *     the first play() reads amplitudes[size] (one past the end: 0 here, as the guard of every sample bank);
+ *   - then getNumBins() - (len % getNumBins()) zeros are fed (:41-45): whether that completes a last frame
+ *     depends on len (the count uses bins, not fftsize: a partial last frame is usually dropped);
+ *   - every frame's real/imag spectra are divided by the largest positive real / imaginary value seen (:47-52).
+ * play(w) (:76-107): inFFT (same setup) takes w; on a new frame the spectrum is pushed to the front of the delay
+ * line and sumReal/sumImag = sum over k of impulse[k] (x) FDL[k] (bin 0: real*real and imag*imag only, :86-87),
+ * accumulated in float in k order; then ifft.process(sumReal, sumImag, COMPLEX) every sample.
+ * maxiIFFT in COMPLEX mode (L/fft.cpp:613-619) copies real/imag into out_real/out_img, which calcIFFT then
+ * OVERWRITES with the inverse transform of in_real/in_img -- never written in this mode, zeros from setup() -- so
+ * the reference convolver returns silence.  mode 0 reproduces that; mode 1 ("as intended") routes the sums to
+ * the transform inputs (negative frequencies zero, like polToCart) and is otherwise the same maxiIFFT
+ * (setup(fftsize, fftsize, hopsize): hop = fftsize, Hann over the first `hopsize` samples, zero beyond).
+ * pcm: the 16-bit impulse.  Returns the number of impulse frames (<0 on error); imp_real/imp_imag (optional)
+ * receive them [frames][bins], at most cap_frames.
+ * ------------------------------------------------------------------------------------ */
+long mxo_convolve(const int16_t *pcm, size_t len, int fftsize, int hopsize, const float *in, size_t n, float *out,
+                  int mode, float *imp_real, float *imp_imag, size_t cap_frames) {
+    if (fftsize < 4 || (fftsize & (fftsize - 1)) || hopsize <= 0 || hopsize > fftsize || len == 0) return -1;
+    const int bins = fftsize / 2, F = fftsize;
+    double *amp = (double *)calloc(len + 1, sizeof(double)); /* + the element one past the end */
+    for (size_t i = 0; i < len; i++) amp[i] = pcm[i] / 32767.0;
+    float *window = (float *)calloc(F, sizeof(float));
+    for (int i = 0; i < F; i++) window[i] = 0.50 - 0.50 * cos(2 * M_PI * i / (F - 1)); /* windowSize = fftsize */
+    float *buffer = (float *)calloc(F, sizeof(float)), *in_real = (float *)calloc(F, sizeof(float));
+    float *o_re = (float *)calloc(F, sizeof(float)), *o_im = (float *)calloc(F, sizeof(float));
+    /* ---- analyseImpulse ---- */
+    size_t frames_cap = len / F + 2, nfr = 0;
+    float *iR = (float *)calloc(frames_cap * bins, sizeof(float)), *iI = (float *)calloc(frames_cap * bins, sizeof(float));
+    float maxReal = 0, maxImag = 0;
+    double position = (double)len; /* after load()/read() */
+    int pos = 0;                   /* windowSize - hopSize = 0 */
+    size_t total = len + (size_t)(bins - (int)(len % (size_t)bins));
+    for (size_t s = 0; s < total; s++) {
+        float v = 0;
+        if (s < len) { /* impulse.play() */
+            v = (float)amp[(long)position];
+            position++;
+            if ((long)position >= (long)len) position = 0;
+        }
+        buffer[pos++] = v;
+        if (pos == F) {
+            for (int i = 0; i < F; i++) in_real[i] = buffer[i] * window[i];
+            fft_real(F, in_real, o_re, o_im);
+            for (int i = 0; i < bins; i++) {
+                iR[nfr * bins + i] = o_re[i];
+                if (o_re[i] > maxReal) maxReal = o_re[i];
+                iI[nfr * bins + i] = o_im[i];
+                if (o_im[i] > maxImag) maxImag = o_im[i];
+            }
+            nfr++;
+            pos = 0;
+        }
+    }
+    for (size_t i = 0; i < nfr * (size_t)bins; i++) {
+        iR[i] /= maxReal;
+        iI[i] /= maxImag;
+    }
+    if (imp_real) memcpy(imp_real, iR, sizeof(float) * bins * (nfr < cap_frames ? nfr : cap_frames));
+    if (imp_imag) memcpy(imp_imag, iI, sizeof(float) * bins * (nfr < cap_frames ? nfr : cap_frames));
+    /* ---- play ---- */
+    float *fdlR = (float *)calloc((nfr ? nfr : 1) * bins, sizeof(float)), *fdlI = (float *)calloc((nfr ? nfr : 1) * bins, sizeof(float));
+    float *sumR = (float *)calloc(bins, sizeof(float)), *sumI = (float *)calloc(bins, sizeof(float));
+    float *iwin = (float *)calloc(F, sizeof(float));
+    for (int i = 0; i < hopsize; i++) iwin[i] = 0.50 - 0.50 * cos(2 * M_PI * i / (hopsize - 1)); /* maxiIFFT window */
+    float *t_re = (float *)calloc(F, sizeof(float)), *t_im = (float *)calloc(F, sizeof(float));
+    float *r_re = (float *)calloc(F, sizeof(float)), *r_im = (float *)calloc(F, sizeof(float));
+    float *obuf = (float *)calloc(F, sizeof(float));
+    size_t head = 0; /* ring: logical FDL[k] = row (head + k) % nfr */
+    int ipos = 0, opos = 0;
+    memset(buffer, 0, sizeof(float) * F);
+    for (size_t s = 0; s < n; s++) {
+        buffer[ipos++] = in[s];
+        if (ipos == F) {
+            ipos = 0;
+            for (int i = 0; i < F; i++) in_real[i] = buffer[i] * window[i];
+            fft_real(F, in_real, o_re, o_im);
+            if (nfr) { /* push_front + pop_back */
+                head = (head + nfr - 1) % nfr;
+                memcpy(fdlR + head * bins, o_re, sizeof(float) * bins);
+                memcpy(fdlI + head * bins, o_im, sizeof(float) * bins);
+            }
+            for (int i = 0; i < bins; i++) sumR[i] = sumI[i] = 0;
+            for (size_t k = 0; k < nfr; k++) {
+                const float *ir = iR + k * bins, *ii = iI + k * bins;
+                const float *fr = fdlR + ((head + k) % nfr) * bins, *fi = fdlI + ((head + k) % nfr) * bins;
+                sumR[0] += (ir[0] * fr[0]);
+                sumI[0] += (ii[0] * fi[0]);
+                for (int i = 1; i < bins; i++) {
+                    sumR[i] += (ir[i] * fr[i]) - (ii[i] * fi[i]);
+                    sumI[i] += (ir[i] * fi[i]) + (ii[i] * fr[i]);
+                }
+            }
+        }
+        if (opos == 0) { /* maxiIFFT::process, pos == 0 */
+            if (mode == 1) {
+                for (int i = 0; i < bins; i++) { t_re[i] = sumR[i]; t_im[i] = sumI[i]; }
+            } /* mode 0: the transform inputs stay as setup() left them: zeros */
+            fft_complex_dir(F, 1, t_re, t_im, r_re, r_im);
+            /* hop = fftsize: the shift moves nothing, the whole buffer is cleared, then += ifftOut (0 + out*window) */
+            for (int i = 0; i < F; i++) obuf[i] = 0.0f + (0.0f + r_re[i] * iwin[i]);
+        }
+        out[s] = obuf[opos];
+        if (++opos == F) opos = 0;
+    }
+    free(amp); free(window); free(buffer); free(in_real); free(o_re); free(o_im); free(iR); free(iI);
+    free(fdlR); free(fdlI); free(sumR); free(sumI); free(iwin); free(t_re); free(t_im); free(r_re); free(r_im); free(obuf);
+    return (long)nfr;
+}
+
+/* ------------------------------------------------------------------------------------
  * maxiDCBlocker::play H:1261-1266; maxiSVF::setParams H:1320-1332, play H:1303-1317;
  * maxiBiquad::set H:1376-1478, play H:1360-1367.  PI = H:55 (3.1415926535897932384626433832795).
  * Layouts as oracle/ref_harness.cpp (mxo_filter2).

@@ -469,6 +469,23 @@ class Oracle:
         return self.L.mxo_time_osc(wf, freq.size, N, _p(freq), threads, ctypes.addressof(sink))
 
 
+    # -- maxiConvolve (L/maxiConvolve.cpp) ------------------------------------------------------------------
+    def convolve(self, pcm, x, fftsize=1024, hopsize=256, mode=0):
+        """maxiConvolve::setup(16-bit impulse, fftsize, hopsize) then play(x[s]) for every sample.  mode 0 = as the
+        reference computes (silence), 1 = sums routed to the inverse transform's inputs.  Returns (out, impReal, impImag)."""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        x = np.ascontiguousarray(x, np.float32)
+        bins = fftsize // 2
+        cap = pcm.size // fftsize + 2
+        out = np.zeros(x.size, np.float32)
+        ir, ii = np.zeros((cap, bins), np.float32), np.zeros((cap, bins), np.float32)
+        fn = self.L.mxo_convolve
+        fn.restype = ctypes.c_long
+        fn.argtypes = [c_void_p, c_size_t, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p, c_size_t]
+        nfr = fn(_p(pcm), pcm.size, fftsize, hopsize, _p(x), x.size, _p(out), mode, _p(ir), _p(ii), cap)
+        assert nfr >= 0, nfr
+        return out, ir[:nfr], ii[:nfr]
+
     # -- CPU baselines of BASELINE configs 3/4/5 (bench.py's cpu_baseline leg) ---------------------------
     # With the compiled reference: the threaded timers of oracle/ref_harness.cpp.  The plain-C port has no such
     # entry points; it is timed single-threaded around its bank functions (allocation excluded as far as possible).

@@ -18,6 +18,7 @@
 #include "libs/maxiFFT.h"
 #include "libs/maxiMFCC.h"
 #include "libs/maxiSynths.h"
+#include "libs/maxiConvolve.h"
 // maxiTimeStretch/maxiStretch draw `rand() % 10` from the process-wide libc stream
 // (maxiGrains.h:352, :524), which cannot be reproduced per stream in a bank.  The header-only
 // grain code is compiled in THIS translation unit, so its rand() calls are routed to a
@@ -39,6 +40,8 @@ static int mxo_ref_rand() {
 #undef rand
 
 #include <cstdint>
+#include <cstdio>
+#include <unistd.h>
 #include <cstring>
 #include <iostream>
 #include <memory>
@@ -790,6 +793,85 @@ double mxo_time_grains(size_t S, size_t T, const double *amp, size_t len, const 
     for (double a : acc) s += a;
     if (sink) *sink = s;
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// ---- maxiConvolve (src/libs/maxiConvolve.cpp:13-107) ------------------------------------------------
+// The impulse goes through the reference's own file path: the 16-bit samples are written as a mono WAV and
+// maxiConvolve::setup(file, fftsize, hopsize) loads and analyses it.  mode 0: play(w) verbatim (silence: COMPLEX mode of
+// maxiIFFT transforms its never-written inputs, fft.cpp:613-619).  mode 1 ("as intended"): play()'s own body, with the
+// last line replaced by maxiIFFT::process's body in which the sums are routed to the transform INPUTS.
+long mxo_convolve(const int16_t *pcm, size_t len, int fftsize, int hopsize, const float *in, size_t n, float *out,
+                  int mode, float *imp_real, float *imp_imag, size_t cap_frames) {
+    char path[64];
+    snprintf(path, sizeof(path), "/tmp/mxo_convolve_%d_%p.wav", (int)getpid(), (void *)pcm);
+    {
+        FILE *f = fopen(path, "wb");
+        if (!f) return -2;
+        const int32_t dsize = (int32_t)(len * 2), chunk = 36 + dsize, sub1 = 16, rate = 44100, brate = 88200;
+        const int16_t fmt = 1, ch = 1, align = 2, bits = 16;
+        fwrite("RIFF", 1, 4, f); fwrite(&chunk, 4, 1, f); fwrite("WAVE", 1, 4, f); fwrite("fmt ", 1, 4, f);
+        fwrite(&sub1, 4, 1, f); fwrite(&fmt, 2, 1, f); fwrite(&ch, 2, 1, f); fwrite(&rate, 4, 1, f);
+        fwrite(&brate, 4, 1, f); fwrite(&align, 2, 1, f); fwrite(&bits, 2, 1, f); fwrite("data", 1, 4, f);
+        fwrite(&dsize, 4, 1, f); fwrite(pcm, 2, len, f);
+        fclose(f);
+    }
+    maxiConvolve c;
+    std::streambuf *old = std::cout.rdbuf(nullptr);  // setup() prints "Impulse loaded"
+    c.setup(path, fftsize, hopsize);
+    std::cout.rdbuf(old);
+    remove(path);
+    const size_t nfr = c.impulseReal.size();
+    const int bins = c.inFFT.getNumBins();
+    for (size_t k = 0; k < nfr && k < cap_frames; k++) {
+        if (imp_real) memcpy(imp_real + k * bins, c.impulseReal[k].data(), sizeof(float) * bins);
+        if (imp_imag) memcpy(imp_imag + k * bins, c.impulseImag[k].data(), sizeof(float) * bins);
+    }
+    for (size_t s = 0; s < n; s++) {
+        if (mode == 0) {
+            out[s] = c.play(in[s]);
+            continue;
+        }
+        const float w = in[s];
+        if (c.inFFT.process(w, maxiFFT::NO_POLAR_CONVERSION)) {  // :77-99, verbatim
+            vector<float> realFrame;
+            realFrame.assign(c.inFFT.getReal(), c.inFFT.getReal() + c.inFFT.getNumBins());
+            c.FDLReal.push_front(realFrame);
+            c.FDLReal.pop_back();
+            vector<float> imagFrame;
+            imagFrame.assign(c.inFFT.getImag(), c.inFFT.getImag() + c.inFFT.getNumBins());
+            c.FDLImag.push_front(imagFrame);
+            c.FDLImag.pop_back();
+            std::fill(c.sumReal.begin(), c.sumReal.end(), 0);
+            std::fill(c.sumImag.begin(), c.sumImag.end(), 0);
+            auto impRealIt = c.impulseReal.begin();
+            auto impImagIt = c.impulseImag.begin();
+            auto fdlRealIt = c.FDLReal.begin();
+            for (auto fdlImagIt = c.FDLImag.begin(); fdlImagIt != c.FDLImag.end(); ++fdlRealIt, ++fdlImagIt, ++impRealIt, ++impImagIt) {
+                c.sumReal[0] += ((*impRealIt)[0] * (*fdlRealIt)[0]);
+                c.sumImag[0] += ((*impImagIt)[0] * (*fdlImagIt)[0]);
+                for (int i = 1; i < (int)c.sumReal.size(); i++) {
+                    c.sumReal[i] += ((*impRealIt)[i] * (*fdlRealIt)[i]) - ((*impImagIt)[i] * (*fdlImagIt)[i]);
+                    c.sumImag[i] += ((*impRealIt)[i] * (*fdlImagIt)[i]) + ((*impImagIt)[i] * (*fdlRealIt)[i]);
+                }
+            }
+        }
+        maxiIFFT &f = c.ifft;  // maxiIFFT::process (maxiFFT.cpp:155-192) with the inputs routed to in_real / in_img
+        if (0 == f.pos) {
+            std::fill(f.ifftOut.begin(), f.ifftOut.end(), 0);
+            for (int i = 0; i < f._fft.half; i++) {
+                f._fft.in_real[i] = c.sumReal[i];
+                f._fft.in_img[i] = c.sumImag[i];
+            }
+            f._fft.calcIFFT(0, &f.ifftOut[0], &f.window[0]);
+            memcpy(&f.buffer[0], &f.buffer[0] + f.hopSize, (f.fftSize - f.hopSize) * sizeof(float));
+            memset(&f.buffer[0] + (f.fftSize - f.hopSize), 0, f.hopSize * sizeof(float));
+            for (int i = 0; i < f.fftSize; i++) f.buffer[i] += f.ifftOut[i];
+        }
+        f.nextValue = f.buffer[f.pos];
+        if (f.hopSize == ++f.pos) f.pos = 0;
+        out[s] = f.nextValue;
+    }
+    return (long)nfr;
 }
 
 // ---- maxiMix::stereo/quad/ambisonic over a bank (src/maximilian.cpp:503-541) ---------------------

@@ -113,3 +113,28 @@ def test_ifft_port_vs_reference(port, ref):
         ph = rng.uniform(-4, 4, (6, fs // 2)).astype(np.float32)
         for u, w in zip(port.ifft_stream(m, ph, fs, hop, win), ref.ifft_stream(m, ph, fs, hop, win)):
             assert np.array_equal(u.view(np.uint32), w.view(np.uint32))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_convolve_port_matches_golden(port, golden, tag):
+    """maxiConvolve: the plain-C restatement against the fixtures dumped from the compiled reference, both modes
+    (0 = the reference verbatim: silence; 1 = sums routed to the inverse transform's inputs)."""
+    g = golden("convolve.npz")
+    F, H = (int(v) for v in g["cfg_" + tag])
+    for mode in (0, 1):
+        o, r, i = port.convolve(g["pcm_" + tag], g["x_" + tag], F, H, mode)
+        assert np.array_equal(o.view(np.uint32), g["out%d_%s" % (mode, tag)].view(np.uint32))
+    assert np.array_equal(r.view(np.uint32), g["impR_" + tag].view(np.uint32))
+    assert np.array_equal(i.view(np.uint32), g["impI_" + tag].view(np.uint32))
+    assert not g["out0_" + tag].any() and np.abs(g["out1_" + tag]).max() > 0.01
+
+
+def test_convolve_port_matches_reference(port, ref):
+    rng = np.random.default_rng(99)
+    for Li, F, H in [(700, 64, 16), (6000, 512, 128), (2049, 1024, 256), (100, 1024, 256)]:
+        pcm = (rng.uniform(-1, 1, Li) * 20000).astype(np.int16)
+        x = rng.uniform(-1, 1, F * 5 + 7).astype(np.float32)
+        for mode in (0, 1):
+            a, b = ref.convolve(pcm, x, F, H, mode), port.convolve(pcm, x, F, H, mode)
+            for u, v in zip(a, b):
+                assert np.array_equal(u.view(np.uint32), v.view(np.uint32))
