@@ -82,6 +82,15 @@ int mxg_free(void *d_ptr);
 int mxg_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int mxg_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int mxg_memset(void *d_dst, int value, size_t bytes, void *stream);
+/* Asynchronous forms: the copy is only enqueued on `stream`; the host buffer must stay valid (and for a real overlap be
+ * pinned: mxg_host_alloc) until the stream has passed it -- mxg_event_record + mxg_event_sync / mxg_event_query.  Together
+ * with the render entry points (all of which only enqueue) this is the asynchronous double-buffering of SURVEY 8(b):
+ * render block k+1 and its download on a stream while the audio thread still serves block k.  A bank's state is the
+ * caller's own device SoA arrays, so a "state get/set" is a copy of those arrays (mxg_memcpy_d2h / _h2d). */
+int mxg_memcpy_h2d_async(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int mxg_memcpy_d2h_async(void *h_dst, const void *d_src, size_t bytes, void *stream);
+void *mxg_host_alloc(size_t bytes); /* pinned host memory */
+int mxg_host_free(void *h_ptr);
 void *mxg_stream_create(void);
 int mxg_stream_destroy(void *stream);
 int mxg_stream_sync(void *stream);
@@ -91,6 +100,14 @@ void *mxg_event_create(void);
 int mxg_event_destroy(void *event);
 int mxg_event_record(void *event, void *stream);
 int mxg_event_elapsed_ms(void *start, void *stop, float *h_ms);
+int mxg_event_sync(void *event);
+int mxg_event_query(void *event); /* 1 = complete, 0 = not yet, < 0 error */
+int mxg_stream_wait_event(void *stream, void *event);
+
+/* The headless host: cpp/commandline/player.cpp:25-44 `routing()` restated without RtAudio -- calls the user's
+ * `void play(double *output)` (src/maximilian.cpp:205-207) once per frame and copies `channels` doubles per frame into
+ * the interleaved buffer.  h_lastValues [channels] persists between calls like the callback's userData. */
+int mxg_host_render(void (*play)(double *), size_t channels, size_t nFrames, double *h_interleaved, double *h_lastValues);
 
 /* ---- per-kernel timing (measurement only) --------------------------------------------------------- */
 /* mxg_prof_enable(1): every entry point brackets its kernels with HIP events on the launch stream (one label per
@@ -387,7 +404,7 @@ int mxg_ifft_batch(const mxg_ifft_plan *plan, const float *d_mags, const float *
  * out: as_reference = 1 reproduces that, bit for bit.  as_reference = 0 is what the function was written to do: real/imag
  * [nframes][bins] go to the transform's inputs (negative frequencies zero, like polToCart), everything after -- the
  * full-size inverse FFT with replayed twiddles, /fftSize, window, overlap-add -- exactly as mxg_ifft_batch; bit-exact
- * against the reference's own calcIFFT fed that way (oracle/ref_harness.cpp). */
+ * against the reference's own calcIFFT fed that way (tests/test_gpu_convolve.py). */
 int mxg_ifft_batch_complex(const mxg_ifft_plan *plan, const float *d_real, const float *d_imag, size_t nframes,
                            int as_reference, float *d_buffer, float *d_signal, float *d_ifft_out, void *stream);
 
@@ -411,7 +428,7 @@ int mxg_convolve_impulse(const mxg_convolve *c, float *h_real, float *h_imag);
  * (bin 0: real*real and imag*imag only, :86-87); block b of the output is the maxiIFFT (COMPLEX mode,
  * setup(fftsize, fftsize, hopsize)) of the sums formed at the end of block b-1.
  * mode 0 = as the reference computes (the COMPLEX-mode defect above: silence, while the state still advances);
- * mode 1 = as intended (the sums reach the inverse transform).  Both bit-exact against the oracle. */
+ * mode 1 = as intended (the sums reach the inverse transform).  Both bit-exact against the reference (tests/test_gpu_convolve.py). */
 int mxg_convolve_play(mxg_convolve *c, const float *d_in, size_t nblocks, float *d_out, int mode, void *stream);
 int mxg_convolve_reset(mxg_convolve *c);
 

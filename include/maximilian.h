@@ -1,0 +1,803 @@
+// include/maximilian.h -- the DROP-IN header: the reference's own class names and per-sample method signatures
+// (src/maximilian.h, src/libs/maxiFFT.h, src/libs/maxiMFCC.h of micknoise/Maximilian), executed on the GPU through
+// the C-ABI of libmaxigpu.so (include/maxigpu.h).  An unmodified `void setup(); void play(double *output);` patch --
+// e.g. cpp/commandline/maximilian_examples/14.monosynth/main.cpp or 15.polysynth/main.cpp -- compiles against this
+// file instead of the reference's src/maximilian.h and produces the reference's samples bit for bit (sinewave /
+// coswave: <= 1 ULP); tests/test_gpu_dropin.py builds those two example files verbatim and checks exactly that.
+//
+// How a one-sample call is served by a block renderer.  Every maxiOsc / maxiEnv / maxiFilter / maxiSample object is a
+// SLOT of a process-wide pool (one pool per class).  A call `osc.pulse(f, d)` is looked up in the block the pool has
+// already rendered for that slot under the prediction "the object keeps being called with the arguments of its last
+// call".  While the prediction holds, a call is an array read; blocks grow 1 -> 2 -> ... -> 512 samples as long as it
+// keeps holding, objects called in lock-step (the `for (i < 6)` of a polysynth) are rendered together in ONE launch
+// (voices of a bank), and at the full block length the NEXT block is rendered asynchronously on the pool's stream into
+// pinned host memory while the current one is being served (no render inside the audio thread in steady state).
+// When a call arrives with other arguments -- a new pitch, a trigger, an input that is itself a signal -- the slot is
+// rewound to the state it had at that sample (the block is re-advanced from its start state: same kernel, same bits)
+// and continues from there with blocks of one sample.  Nothing is ever computed on the CPU: an object whose arguments
+// change every sample (a filter fed by an oscillator) costs one small launch per call -- correct, and as slow as that
+// sounds; the throughput path for such graphs is the fused bank API (include/maximilian_bank.hpp, maxiVoiceBank).
+// State is authoritative on the host between launches (a few doubles per object), so rewinding and regrouping are
+// plain copies.  maxiFilter's cos/pow/sqrt coefficients are evaluated with THIS machine's libm
+// (mxg_filter_coeffs_host), which is what keeps the recursive filter bit-identical to the reference.
+//
+// Not thread-safe, like the reference: all calls come from the one audio thread (cpp/commandline/player.cpp:25-44).
+#pragma once
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <limits>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "maxigpu.h"
+
+using namespace std;  // the reference header does (src/maximilian.h:54); example patches rely on it (cout, vector)
+
+#ifndef PI
+#define PI 3.1415926535897932384626433832795
+#endif
+#define TWOPI 6.283185307179586476925286766559
+
+namespace maxigpu {
+namespace ps {  // per-sample engine
+
+inline void check(int status, const char *what) {
+    if (status < 0) throw std::runtime_error(std::string(what) + ": " + mxg_last_error());
+}
+
+constexpr size_t kMaxBlock = 512;
+
+template <typename T>
+struct DevBuf {  // grow-only device array
+    T *p = nullptr;
+    size_t n = 0;
+    T *need(size_t count) {
+        if (count > n) {
+            if (p) mxg_free(p);
+            p = static_cast<T *>(mxg_malloc(count * sizeof(T)));
+            if (!p) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+            n = count;
+        }
+        return p;
+    }
+    ~DevBuf() { if (p) mxg_free(p); }
+};
+template <typename T>
+struct PinBuf {  // grow-only pinned host array
+    T *p = nullptr;
+    size_t n = 0;
+    T *need(size_t count) {
+        if (count > n) {
+            if (p) mxg_host_free(p);
+            p = static_cast<T *>(mxg_host_alloc(count * sizeof(T)));
+            if (!p) throw std::runtime_error(std::string("mxg_host_alloc: ") + mxg_last_error());
+            n = count;
+        }
+        return p;
+    }
+    ~PinBuf() { if (p) mxg_host_free(p); }
+};
+
+struct Call {  // one per-sample call: which method, with which arguments (compared bit for bit)
+    int method = -1;
+    const void *key = nullptr;  // objects that can share a launch must agree on it (e.g. the sample buffer)
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool same(const Call &o) const { return method == o.method && key == o.key && !std::memcmp(a, o.a, sizeof(a)); }
+};
+
+struct Slot {
+    Call sig;                      // the prediction the cached block was rendered under
+    std::vector<double> blk;       // cached outputs
+    size_t pos = 0, len = 0;       // blk[pos .. len) not yet served
+    size_t nextLen = 1;
+    std::vector<double> sd, ed;    // state (doubles) at the block's first sample / after its last
+    std::vector<int64_t> si, ei;
+    int group = -1;                // index of the asynchronous next-block render this slot is part of
+};
+
+// One render of L samples for a set of slots, kept alive so the next block can continue on the device.
+struct Group {
+    std::vector<Slot *> m;
+    std::vector<Call> sig;
+    size_t L = 0;
+    bool pending = false;  // an asynchronous render of the NEXT block is in flight
+    void *event = nullptr;
+    DevBuf<double> d_state, d_par, d_in, d_out;
+    DevBuf<int64_t> d_istate, d_ipar;
+    DevBuf<int32_t> d_trig;
+    PinBuf<double> h_out, h_state;
+    PinBuf<int64_t> h_istate;
+    ~Group() { if (event) mxg_event_destroy(event); }
+};
+
+class Pool {
+public:
+    Pool(int nD_, int nI_) : nD(nD_), nI(nI_) {}
+    virtual ~Pool() {
+        for (Group *g : groups) delete g;
+        if (stream) mxg_stream_destroy(stream);
+    }
+    void attach(Slot &s) {
+        s.sd.assign(nD, 0.0);
+        s.ed.assign(nD, 0.0);
+        s.si.assign(nI, 0);
+        s.ei.assign(nI, 0);
+        slots.push_back(&s);
+    }
+    void detach(Slot &s) {
+        leave_group(s);
+        slots.erase(std::remove(slots.begin(), slots.end(), &s), slots.end());
+    }
+    // the object's state at its current sample, cached block dropped (before the host edits or reads state)
+    void settle(Slot &s) {
+        leave_group(s);
+        if (s.pos < s.len) {
+            if (s.pos > 0) advance(s, s.pos);
+        } else if (s.len > 0) {
+            s.sd = s.ed;
+            s.si = s.ei;
+        }
+        s.pos = s.len = 0;
+        s.nextLen = 1;
+        s.sig.method = -1;
+    }
+    double call(Slot &s, const Call &c) {
+        if (s.pos < s.len && s.sig.same(c)) return s.blk[s.pos++];
+        return miss(s, c);
+    }
+    size_t launches = 0, async_hits = 0;  // statistics (tests)
+
+protected:
+    // Enqueue on `stream` the render of G.L samples for G.m under G.sig, starting from the state in G.d_state /
+    // G.d_istate ([nD][n] / [nI][n], already on the device), updating that state in place and writing d_out [L][n].
+    virtual void enqueue(Group &G) = 0;
+    int nD, nI;
+    void *stream = nullptr;
+
+private:
+    std::vector<Slot *> slots;
+    std::vector<Group *> groups;
+
+    void ensure_stream() {
+        if (!stream) {
+            check(mxg_init(-1), "mxg_init");
+            stream = mxg_stream_create();
+            if (!stream) throw std::runtime_error(std::string("mxg_stream_create: ") + mxg_last_error());
+        }
+    }
+    void leave_group(Slot &s) {
+        if (s.group < 0) return;
+        Group &G = *groups[(size_t)s.group];
+        for (Slot *&u : G.m)
+            if (u == &s) u = nullptr;  // its column of the pending block is simply never installed
+        s.group = -1;
+    }
+    Group &free_group() {
+        for (size_t i = 0; i < groups.size(); i++) {
+            Group &G = *groups[i];
+            bool used = G.pending;
+            if (used) {  // a pending group nobody waits for any more can be recycled once its render has finished
+                bool any = false;
+                for (Slot *u : G.m) any = any || u;
+                if (!any && mxg_event_query(G.event) == 1) used = G.pending = false;
+            }
+            if (!used) return G;
+        }
+        groups.push_back(new Group());
+        groups.back()->event = mxg_event_create();
+        return *groups.back();
+    }
+    int index_of(const Group &G) const {
+        for (size_t i = 0; i < groups.size(); i++)
+            if (groups[i] == &G) return (int)i;
+        return -1;
+    }
+    // upload the members' start states and run one block synchronously; fills blk / ed / ei of every member
+    void render_now(Group &G) {
+        ensure_stream();
+        const size_t n = G.m.size(), L = G.L;
+        double *hs = G.h_state.need((size_t)nD * n + 1);
+        int64_t *hi = G.h_istate.need((size_t)nI * n + 1);
+        for (size_t j = 0; j < n; j++) {
+            for (int k = 0; k < nD; k++) hs[(size_t)k * n + j] = G.m[j]->sd[(size_t)k];
+            for (int k = 0; k < nI; k++) hi[(size_t)k * n + j] = G.m[j]->si[(size_t)k];
+        }
+        if (nD) check(mxg_memcpy_h2d_async(G.d_state.need((size_t)nD * n), hs, sizeof(double) * nD * n, stream), "h2d state");
+        if (nI) check(mxg_memcpy_h2d_async(G.d_istate.need((size_t)nI * n), hi, sizeof(int64_t) * nI * n, stream), "h2d istate");
+        G.d_out.need(L * n);
+        enqueue(G);
+        fetch(G);
+        check(mxg_stream_sync(stream), "mxg_stream_sync");
+        install(G);
+        launches++;
+    }
+    void fetch(Group &G) {  // asynchronous download of the block and of the state after it
+        const size_t n = G.m.size();
+        check(mxg_memcpy_d2h_async(G.h_out.need(G.L * n), G.d_out.p, sizeof(double) * G.L * n, stream), "d2h out");
+        if (nD) check(mxg_memcpy_d2h_async(G.h_state.need((size_t)nD * n + 1), G.d_state.p, sizeof(double) * nD * n, stream), "d2h state");
+        if (nI) check(mxg_memcpy_d2h_async(G.h_istate.need((size_t)nI * n + 1), G.d_istate.p, sizeof(int64_t) * nI * n, stream), "d2h istate");
+    }
+    void install(Group &G) {
+        const size_t n = G.m.size(), L = G.L;
+        for (size_t j = 0; j < n; j++) {
+            Slot *u = G.m[j];
+            if (!u) continue;
+            u->blk.resize(L);
+            for (size_t t = 0; t < L; t++) u->blk[t] = G.h_out.p[t * n + j];
+            for (int k = 0; k < nD; k++) u->ed[(size_t)k] = G.h_state.p[(size_t)k * n + j];
+            for (int k = 0; k < nI; k++) u->ei[(size_t)k] = G.h_istate.p[(size_t)k * n + j];
+            u->pos = 0;
+            u->len = L;
+            u->sig = G.sig[j];
+            u->nextLen = L;
+        }
+    }
+    // the block after the one just installed, rendered while that one is served
+    void prefetch(Group &G) {
+        enqueue(G);  // continues from the state the previous block left on the device
+        fetch(G);
+        check(mxg_event_record(G.event, stream), "mxg_event_record");
+        G.pending = true;
+        const int gi = index_of(G);
+        for (Slot *u : G.m)
+            if (u) u->group = gi;
+        launches++;
+    }
+    // re-run the first `count` samples of the slot's block from its start state: the state AT sample `count`
+    void advance(Slot &s, size_t count) {
+        Group &G = free_group();
+        G.m.assign(1, &s);
+        G.sig.assign(1, s.sig);
+        G.L = count;
+        const std::vector<double> keep_ed = s.ed;
+        render_now(G);
+        s.sd = s.ed;
+        s.si = s.ei;
+        (void)keep_ed;
+        s.group = -1;
+    }
+    double miss(Slot &s, const Call &c) {
+        const bool consumed = s.pos >= s.len;
+        if (consumed && s.group >= 0 && s.sig.same(c)) {  // the asynchronous next block was rendered for exactly this call
+            Group &G = *groups[(size_t)s.group];
+            check(mxg_event_sync(G.event), "mxg_event_sync");  // normally long complete
+            G.pending = false;
+            bool intact = true;
+            for (size_t j = 0; j < G.m.size(); j++) {
+                Slot *u = G.m[j];
+                if (u && u->pos < u->len) {  // not in lock-step after all: that member keeps its own block
+                    u->group = -1;
+                    G.m[j] = u = nullptr;
+                }
+                if (!u) {
+                    intact = false;
+                    continue;
+                }
+                u->sd = u->ed;
+                u->si = u->ei;
+                u->group = -1;
+            }
+            install(G);
+            async_hits++;
+            if (intact) prefetch(G);
+            return s.blk[s.pos++];
+        }
+        leave_group(s);
+        size_t L;
+        if (!consumed) {  // the prediction failed inside a block: back to the state at this sample
+            if (s.pos > 0) advance(s, s.pos);
+            L = 1;
+        } else {
+            if (s.len > 0) {
+                s.sd = s.ed;
+                s.si = s.ei;
+            }
+            L = (s.len > 0 && s.sig.same(c)) ? std::min(2 * s.nextLen, kMaxBlock) : 1;
+        }
+        s.pos = s.len = 0;
+        Group &G = free_group();
+        G.m.assign(1, &s);
+        G.sig.assign(1, c);
+        G.L = L;
+        // objects called in lock-step with this one: same method, also at the end of their block, same growth
+        for (Slot *u : slots) {
+            if (u == &s || u->group >= 0 || u->len == 0 || u->pos < u->len) continue;
+            if (u->sig.method != c.method || u->sig.key != c.key) continue;
+            if (std::min(2 * u->nextLen, kMaxBlock) != L) continue;
+            u->sd = u->ed;
+            u->si = u->ei;
+            G.m.push_back(u);
+            G.sig.push_back(u->sig);
+        }
+        render_now(G);
+        if (L == kMaxBlock) prefetch(G);
+        return s.blk[s.pos++];
+    }
+};
+
+template <typename P>
+P &pool() {
+    static P *p = new P;  // never destroyed: objects with static storage outlive any order the runtime tears things down in
+    return *p;
+}
+
+// ---- the pools -------------------------------------------------------------------------------------------
+struct OscPool : Pool {  // state: phase, output (H:173,176)
+    OscPool() : Pool(2, 0) {}
+    void enqueue(Group &G) override {
+        const size_t n = G.m.size();
+        const int wf = G.sig[0].method;
+        std::vector<double> hp(3 * n);
+        for (size_t j = 0; j < n; j++)
+            for (int k = 0; k < 3; k++) hp[(size_t)k * n + j] = G.sig[j].a[k];
+        double *dp = G.d_par.need(3 * n);
+        check(mxg_memcpy_h2d(dp, hp.data(), sizeof(double) * 3 * n, stream), "h2d osc");
+        if (wf == 12) {  // noise(): a[0] holds the rand() draw
+            std::vector<int32_t> ht(G.L * n);
+            for (size_t t = 0; t < G.L; t++)
+                for (size_t j = 0; j < n; j++) ht[t * n + j] = (int32_t)G.sig[j].a[0];
+            check(mxg_memcpy_h2d(G.d_trig.need(G.L * n), ht.data(), sizeof(int32_t) * G.L * n, stream), "h2d rand");
+            check(mxg_osc_noise(n, G.L, G.d_trig.p, G.d_state.p + n, G.d_out.p, stream), "mxg_osc_noise");
+            return;
+        }
+        check(mxg_osc_render(wf, n, G.L, dp, 0, dp + n, dp + 2 * n, G.d_state.p, G.d_state.p + n, G.d_out.p, stream),
+              "mxg_osc_render");
+    }
+};
+
+struct EnvPool : Pool {  // state: amplitude, output | holdcount, attack/decay/sustain/hold/release phase (H:888-932)
+    EnvPool() : Pool(2, 6) {}
+    void enqueue(Group &G) override {
+        const size_t n = G.m.size(), L = G.L;
+        const int mode = G.sig[0].method;  // 0 adsr, 1 ar
+        std::vector<double> in(L * n), par(4 * n);
+        std::vector<int32_t> trig(L * n);
+        std::vector<int64_t> hold(n);
+        for (size_t j = 0; j < n; j++) {
+            const double *a = G.sig[j].a;  // input, trigger, attack, decay, sustain, release, holdtime
+            for (size_t t = 0; t < L; t++) {
+                in[t * n + j] = a[0];
+                trig[t * n + j] = (int32_t)a[1];
+            }
+            for (int k = 0; k < 4; k++) par[(size_t)k * n + j] = a[2 + k];
+            hold[j] = (int64_t)a[6];
+        }
+        check(mxg_memcpy_h2d(G.d_in.need(L * n), in.data(), sizeof(double) * L * n, stream), "h2d env in");
+        check(mxg_memcpy_h2d(G.d_trig.need(L * n), trig.data(), sizeof(int32_t) * L * n, stream), "h2d env trig");
+        check(mxg_memcpy_h2d(G.d_par.need(4 * n), par.data(), sizeof(double) * 4 * n, stream), "h2d env par");
+        check(mxg_memcpy_h2d(G.d_ipar.need(n), hold.data(), sizeof(int64_t) * n, stream), "h2d env hold");
+        check(mxg_env_render(mode, n, L, G.d_in.p, G.d_trig.p, 1, G.d_par.p, G.d_ipar.p, G.d_state.p, G.d_istate.p, G.d_out.p,
+                             stream), "mxg_env_render");
+    }
+};
+
+struct FilterPool : Pool {  // state: x, y, outputs[0..2] (H:289-302)
+    FilterPool() : Pool(5, 0) {}
+    void enqueue(Group &G) override {
+        const size_t n = G.m.size(), L = G.L;
+        const int kind = G.sig[0].method;
+        std::vector<double> in(L * n), cut(n), res(n), coef(3 * n, 0.0);
+        for (size_t j = 0; j < n; j++) {
+            const double *a = G.sig[j].a;  // input, cutoff, resonance
+            for (size_t t = 0; t < L; t++) in[t * n + j] = a[0];
+            cut[j] = a[1];
+            res[j] = a[2];
+        }
+        if (kind <= MXG_FLT_BANDPASS)  // cos / pow / sqrt of C:459-461, :492-495 on the host libm
+            check(mxg_filter_coeffs_host(kind, n, cut.data(), res.data(), coef.data()), "mxg_filter_coeffs_host");
+        double *dp = G.d_par.need(5 * n);
+        check(mxg_memcpy_h2d(G.d_in.need(L * n), in.data(), sizeof(double) * L * n, stream), "h2d flt in");
+        check(mxg_memcpy_h2d(dp, cut.data(), sizeof(double) * n, stream), "h2d flt cutoff");
+        check(mxg_memcpy_h2d(dp + n, res.data(), sizeof(double) * n, stream), "h2d flt res");
+        check(mxg_memcpy_h2d(dp + 2 * n, coef.data(), sizeof(double) * 3 * n, stream), "h2d flt coef");
+        check(mxg_filter_render(kind, n, L, G.d_in.p, dp, 0, dp + n, 0, dp + 2 * n, G.d_state.p, G.d_out.p, stream),
+              "mxg_filter_render");
+    }
+};
+
+struct SamplePool : Pool {  // state: position (H:606); key = the device sample buffer
+    SamplePool() : Pool(1, 0) {}
+    struct Buf { double *d = nullptr; size_t len = 0; int rate = 44100; };
+    void enqueue(Group &G) override {
+        const size_t n = G.m.size();
+        const Buf *b = static_cast<const Buf *>(G.sig[0].key);
+        std::vector<double> par(3 * n);
+        for (size_t j = 0; j < n; j++)
+            for (int k = 0; k < 3; k++) par[(size_t)k * n + j] = G.sig[j].a[k];  // speed / frequency, start, end
+        double *dp = G.d_par.need(3 * n);
+        check(mxg_memcpy_h2d(dp, par.data(), sizeof(double) * 3 * n, stream), "h2d smp");
+        check(mxg_sample_render(G.sig[0].method, n, G.L, b->d, b->len, b->rate, dp, 0, dp + n, dp + 2 * n, G.d_state.p,
+                                G.d_out.p, stream), "mxg_sample_render");
+    }
+};
+
+}  // namespace ps
+}  // namespace maxigpu
+
+// ---- maxiSettings (H:117-163) -----------------------------------------------------------------------------
+class maxiSettings {
+public:
+    static size_t sampleRate, channels, bufferSize;
+    static void setup(size_t initSampleRate, size_t initChannels, size_t initBufferSize) {
+        maxigpu::ps::check(mxg_settings(initSampleRate, initChannels, initBufferSize), "mxg_settings");
+        sampleRate = initSampleRate;
+        channels = initChannels;
+        bufferSize = initBufferSize;
+    }
+    static void setSampleRate(size_t sampleRate_) { setup(sampleRate_, channels, bufferSize); }
+    static void setNumChannels(size_t channels_) { setup(sampleRate, channels_, bufferSize); }
+    static void setBufferSize(size_t bufferSize_) { setup(sampleRate, channels, bufferSize_); }
+    static size_t getSampleRate() { return sampleRate; }
+    static size_t getNumChannels() { return channels; }
+    static size_t getBufferSize() { return bufferSize; }
+};
+inline size_t maxiSettings::sampleRate = 44100;
+inline size_t maxiSettings::channels = 2;
+inline size_t maxiSettings::bufferSize = 1024;
+
+// ---- maxiOsc (H:169-215; C:209-373) -------------------------------------------------------------------------
+class maxiOsc {
+    using Pool = maxigpu::ps::OscPool;
+    maxigpu::ps::Slot slot_;
+    double run(int wf, double f, double p1 = 0.0, double p2 = 0.0) {
+        maxigpu::ps::Call c;
+        c.method = wf;
+        c.a[0] = f; c.a[1] = p1; c.a[2] = p2;
+        return maxigpu::ps::pool<Pool>().call(slot_, c);
+    }
+
+public:
+    maxiOsc() { maxigpu::ps::pool<Pool>().attach(slot_); }
+    ~maxiOsc() { maxigpu::ps::pool<Pool>().detach(slot_); }
+    maxiOsc(const maxiOsc &o) { maxigpu::ps::pool<Pool>().attach(slot_); copy_state(o); }
+    maxiOsc &operator=(const maxiOsc &o) { if (this != &o) copy_state(o); return *this; }
+    double sinewave(double frequency) { return run(MXG_OSC_SINEWAVE, frequency); }
+    double coswave(double frequency) { return run(MXG_OSC_COSWAVE, frequency); }
+    double phasor(double frequency) { return run(MXG_OSC_PHASOR, frequency); }
+    double phasorBetween(double frequency, double startphase, double endphase) { return run(MXG_OSC_PHASORBETWEEN, frequency, startphase, endphase); }
+    double saw(double frequency) { return run(MXG_OSC_SAW, frequency); }
+    double triangle(double frequency) { return run(MXG_OSC_TRIANGLE, frequency); }
+    double square(double frequency) { return run(MXG_OSC_SQUARE, frequency); }
+    double pulse(double frequency, double duty) { return run(MXG_OSC_PULSE, frequency, duty); }
+    double impulse(double frequency) { return run(MXG_OSC_IMPULSE, frequency); }
+    double sinebuf(double frequency) { return run(MXG_OSC_SINEBUF, frequency); }
+    double sinebuf4(double frequency) { return run(MXG_OSC_SINEBUF4, frequency); }
+    double sawn(double frequency) { return run(MXG_OSC_SAWN, frequency); }
+    double noise() { return run(12, (double)rand()); }  // C:214-220: the process-wide rand() stream, drawn here in call order
+    void phaseReset(double phaseIn) {                    // C:222-226
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        slot_.sd[0] = phaseIn;
+    }
+
+private:
+    void copy_state(const maxiOsc &o) {
+        maxigpu::ps::pool<Pool>().settle(const_cast<maxiOsc &>(o).slot_);
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        slot_.sd = o.slot_.sd;
+    }
+};
+
+// ---- maxiEnv (H:888-932; C:1319-1494) ---------------------------------------------------------------------
+class maxiEnv {
+    using Pool = maxigpu::ps::EnvPool;
+    maxigpu::ps::Slot slot_;
+    double run(int mode, double in, int trig, double at, double de, double su, double re, long hold) {
+        maxigpu::ps::Call c;
+        c.method = mode;
+        c.a[0] = in; c.a[1] = (double)trig; c.a[2] = at; c.a[3] = de; c.a[4] = su; c.a[5] = re; c.a[6] = (double)hold;
+        return maxigpu::ps::pool<Pool>().call(slot_, c);
+    }
+
+public:
+    maxiEnv() { maxigpu::ps::pool<Pool>().attach(slot_); }
+    ~maxiEnv() { maxigpu::ps::pool<Pool>().detach(slot_); }
+    maxiEnv(const maxiEnv &) = delete;
+    maxiEnv &operator=(const maxiEnv &) = delete;
+    double ar(double input, double attack = 1, double release = 0.9, long holdtime = 1, int trigger = 0) {
+        return run(1, input, trigger, attack, 0.0, 0.0, release, holdtime);
+    }
+    double adsr(double input, double attack = 1, double decay = 0.99, double sustain = 0.125, double release = 0.9,
+                long holdtime = 1, int trigger = 0) {
+        return run(0, input, trigger, attack, decay, sustain, release, holdtime);
+    }
+    double adsr(double input, int trigger) { return run(0, input, trigger, attack, decay, sustain, release, holdtime); }
+    // the members user code reads and writes (static-storage objects start at 0, like the reference's globals)
+    double attack = 0, decay = 0, sustain = 0, release = 0;
+    int trigger = 0;
+    long holdtime = 1;
+    void setRelease(double releaseMS) { release = mxg_env_coeff_host(2, releaseMS); }  // C:1469-1472
+    void setDecay(double decayMS) { decay = mxg_env_coeff_host(1, decayMS); }          // C:1474-1477
+    void setAttack(double attackMS) { attack = mxg_env_coeff_host(0, attackMS); }      // C:1479-1482
+    void setAttackMS(double attackMS) { attack = mxg_env_coeff_host(3, attackMS); }    // C:1485-1488
+    void setSustain(double sustainL) { sustain = sustainL; }                          // C:1491-1494
+    int getTrigger() const { return trigger; }
+    void setTrigger(int trigger_) { trigger = trigger_; }
+};
+
+// ---- maxiFilter (H:289-366; C:442-500) ---------------------------------------------------------------------
+class maxiFilter {
+    using Pool = maxigpu::ps::FilterPool;
+    maxigpu::ps::Slot slot_;
+    double run(int kind, double in, double cut, double res) {
+        maxigpu::ps::Call c;
+        c.method = kind;
+        c.a[0] = in; c.a[1] = cut; c.a[2] = res;
+        return maxigpu::ps::pool<Pool>().call(slot_, c);
+    }
+
+public:
+    maxiFilter() { maxigpu::ps::pool<Pool>().attach(slot_); }
+    ~maxiFilter() { maxigpu::ps::pool<Pool>().detach(slot_); }
+    maxiFilter(const maxiFilter &) = delete;
+    maxiFilter &operator=(const maxiFilter &) = delete;
+    double cutoff = 0, resonance = 0;
+    double lores(double input, double cutoff1, double resonance_) { return run(MXG_FLT_LORES, input, cutoff1, resonance_); }
+    double hires(double input, double cutoff1, double resonance_) { return run(MXG_FLT_HIRES, input, cutoff1, resonance_); }
+    double bandpass(double input, double cutoff1, double resonance_) { return run(MXG_FLT_BANDPASS, input, cutoff1, resonance_); }
+    double lopass(double input, double cutoff_) { return run(MXG_FLT_LOPASS, input, cutoff_, 0.0); }
+    double hipass(double input, double cutoff_) { return run(MXG_FLT_HIPASS, input, cutoff_, 0.0); }
+    void setCutoff(double cut) { cutoff = cut; }
+    void setResonance(double res) { resonance = res; }
+    double getCutoff() const { return cutoff; }
+    double getResonance() const { return resonance; }
+};
+
+// ---- maxiSample (H:602-790; C:605-1075): the play family over a buffer uploaded once ---------------------------------
+class maxiSample {
+    using Pool = maxigpu::ps::SamplePool;
+    maxigpu::ps::Slot slot_;
+    Pool::Buf buf_;
+    double run(int mode, double a = 0.0, double start = 0.0, double end = 0.0) {
+        if (!buf_.d) return 0.0;
+        maxigpu::ps::Call c;
+        c.method = mode;
+        c.key = &buf_;
+        c.a[0] = a; c.a[1] = start; c.a[2] = end;
+        return maxigpu::ps::pool<Pool>().call(slot_, c);
+    }
+    void drop() {
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        if (buf_.d) mxg_sample_free(buf_.d);
+        buf_.d = nullptr;
+        buf_.len = 0;
+    }
+
+public:
+    int mySampleRate = 44100;
+    maxiSample() { maxigpu::ps::pool<Pool>().attach(slot_); }
+    ~maxiSample() { drop(); maxigpu::ps::pool<Pool>().detach(slot_); }
+    maxiSample(const maxiSample &) = delete;
+    maxiSample &operator=(const maxiSample &) = delete;
+    bool load(string fileName, int channel = 0) {  // C:605-609 -> read() C:612-692
+        drop();
+        size_t len = 0;
+        int32_t hdr[8];
+        buf_.d = mxg_sample_load_wav(fileName.c_str(), channel, &len, hdr);
+        if (!buf_.d) {
+            printf("ERROR: Could not load sample.");  // C:686
+            return false;
+        }
+        buf_.len = len;
+        buf_.rate = mySampleRate = hdr[4];
+        slot_.sd[0] = (double)len;  // position = size, C:681
+        return true;
+    }
+    void setSample(vector<double> &sampleData) {  // H:670-678
+        drop();
+        buf_.d = mxg_sample_upload(sampleData.data(), sampleData.size());
+        if (!buf_.d) throw std::runtime_error(std::string("mxg_sample_upload: ") + mxg_last_error());
+        buf_.len = sampleData.size();
+        buf_.rate = mySampleRate = 44100;
+        slot_.sd[0] = (double)sampleData.size() - 1;
+    }
+    void setSampleAndRate(vector<double> &sampleData, int sampleRate) {  // H:684-688
+        setSample(sampleData);
+        buf_.rate = mySampleRate = sampleRate;
+    }
+    size_t getLength() { return buf_.len; }
+    bool isReady() { return buf_.len > 1; }
+    void trigger() {  // C:597-600
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        slot_.sd[0] = 0;
+    }
+    void setPosition(double newPos) {  // C:749-751
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        slot_.sd[0] = (newPos < 0.0 ? 0.0 : (newPos > 1.0 ? 1.0 : newPos)) * (double)buf_.len;
+    }
+    double play() { return run(MXG_SMP_PLAY); }
+    double playOnce() { return run(MXG_SMP_PLAYONCE); }
+    double playLoop(double start, double end) { return run(MXG_SMP_PLAYLOOP, 0.0, start, end); }
+    double playUntil(double end) { return run(MXG_SMP_PLAYUNTIL, 0.0, 0.0, end); }
+    double playAtSpeed(double speed) { return run(MXG_SMP_PLAYATSPEED, speed); }
+    double playOnceAtSpeed(double speed) { return run(MXG_SMP_PLAYONCEATSPEED, speed); }
+    double playUntilAtSpeed(double end, double speed) { return run(MXG_SMP_PLAYUNTILATSPEED, speed, 0.0, end); }
+    double play4(double frequency, double start, double end) { return run(MXG_SMP_PLAY4, frequency, start, end); }
+    double playAtSpeedBetweenPoints(double frequency, double start, double end) {
+        return run(MXG_SMP_PLAYATSPEEDBETWEENPOINTS, frequency, start, end);
+    }
+};
+
+// ---- maxiDelayline (H:266-284; C:415-439): the ring lives on the device, one sample per launch --------------------
+class maxiDelayline {
+    static constexpr size_t kCap = 88200 * 8;  // double memory[88200 * 8], H:273
+    double *d_mem_ = nullptr, *d_io_ = nullptr;
+    int32_t *d_i_ = nullptr;
+    int32_t phase_ = 0;
+    void init() {
+        if (d_mem_) return;
+        maxigpu::ps::check(mxg_init(-1), "mxg_init");
+        d_mem_ = static_cast<double *>(mxg_malloc(sizeof(double) * kCap));
+        d_io_ = static_cast<double *>(mxg_malloc(sizeof(double) * 4));
+        d_i_ = static_cast<int32_t *>(mxg_malloc(sizeof(int32_t) * 4));
+        if (!d_mem_ || !d_io_ || !d_i_) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+        maxigpu::ps::check(mxg_memset(d_mem_, 0, sizeof(double) * kCap, nullptr), "mxg_memset");  // ctor memset, C:415-417
+    }
+    double run(int mode, double input, int size, double feedback, int position) {
+        init();
+        const double hio[2] = {input, feedback};
+        const int32_t hi[3] = {size, position, phase_};
+        maxigpu::ps::check(mxg_memcpy_h2d(d_io_, hio, sizeof(hio), nullptr), "h2d");
+        maxigpu::ps::check(mxg_memcpy_h2d(d_i_, hi, sizeof(hi), nullptr), "h2d");
+        maxigpu::ps::check(mxg_delay_render(mode, 1, 1, d_io_, d_i_, d_io_ + 1, d_i_ + 1, d_mem_, kCap, d_i_ + 2, d_io_ + 2, nullptr),
+                           "mxg_delay_render");
+        double out = 0;
+        maxigpu::ps::check(mxg_memcpy_d2h(&out, d_io_ + 2, sizeof(double), nullptr), "d2h");
+        maxigpu::ps::check(mxg_memcpy_d2h(&phase_, d_i_ + 2, sizeof(int32_t), nullptr), "d2h");
+        return out;
+    }
+
+public:
+    maxiDelayline() = default;
+    ~maxiDelayline() {
+        if (d_mem_) mxg_free(d_mem_);
+        if (d_io_) mxg_free(d_io_);
+        if (d_i_) mxg_free(d_i_);
+    }
+    maxiDelayline(const maxiDelayline &) = delete;
+    maxiDelayline &operator=(const maxiDelayline &) = delete;
+    double dl(double input, int size, double feedback) { return run(0, input, size, feedback, 0); }
+    double dlFromPosition(double input, int size, double feedback, int position) { return run(1, input, size, feedback, position); }
+};
+
+// ---- maxiFFT (L/maxiFFT.h:47-110; L/maxiFFT.cpp:45-132): the hop buffer on the host, every frame on the device ---------------
+class maxiFFT {
+public:
+    enum fftModes { NO_POLAR_CONVERSION = 0, WITH_POLAR_CONVERSION = 1 };
+    maxiFFT() {}
+    ~maxiFFT() { release(); }
+    maxiFFT(const maxiFFT &) = delete;
+    maxiFFT &operator=(const maxiFFT &) = delete;
+    void setup(int _fftSize = 1024, int _hopSize = 512, int _windowSize = 0) {  // L/maxiFFT.cpp:45-60
+        release();
+        plan_ = mxg_fft_plan_create(_fftSize, _hopSize, _windowSize);
+        if (!plan_) throw std::runtime_error(std::string("mxg_fft_plan_create: ") + mxg_last_error());
+        fftSize = _fftSize;
+        windowSize = _windowSize > fftSize ? _windowSize : fftSize;
+        bins = fftSize / 2;
+        hopSize = _hopSize;
+        buffer.assign(fftSize, 0);
+        magnitudes.assign(bins, 0);
+        magnitudesDB.assign(bins, 0);
+        phases.assign(bins, 0);
+        real_.assign(bins, 0);
+        imag_.assign(bins, 0);
+        pos = windowSize - hopSize;
+        newFFT = 0;
+        d_in_ = static_cast<float *>(mxg_malloc(sizeof(float) * fftSize));
+        d_out_ = static_cast<float *>(mxg_malloc(sizeof(float) * 4 * bins));
+        if (!d_in_ || !d_out_) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+    }
+    bool process(float value, fftModes mode = maxiFFT::WITH_POLAR_CONVERSION) {  // L/maxiFFT.cpp:65-91
+        buffer[pos++] = value;
+        newFFT = pos == windowSize;
+        if (newFFT) {
+            maxigpu::ps::check(mxg_memcpy_h2d(d_in_, buffer.data(), sizeof(float) * fftSize, nullptr), "h2d frame");
+            float *re = d_out_, *im = d_out_ + bins, *mg = d_out_ + 2 * bins, *ph = d_out_ + 3 * bins;
+            const bool polar = mode == WITH_POLAR_CONVERSION;
+            maxigpu::ps::check(mxg_fft_batch(plan_, d_in_, (size_t)fftSize, 1, re, im, polar ? mg : nullptr, polar ? ph : nullptr,
+                                             nullptr), "mxg_fft_batch");
+            maxigpu::ps::check(mxg_memcpy_d2h(real_.data(), re, sizeof(float) * bins, nullptr), "d2h real");
+            maxigpu::ps::check(mxg_memcpy_d2h(imag_.data(), im, sizeof(float) * bins, nullptr), "d2h imag");
+            if (polar) {
+                maxigpu::ps::check(mxg_memcpy_d2h(magnitudes.data(), mg, sizeof(float) * bins, nullptr), "d2h mags");
+                maxigpu::ps::check(mxg_memcpy_d2h(phases.data(), ph, sizeof(float) * bins, nullptr), "d2h phases");
+            }
+            std::memmove(&buffer[0], &buffer[0] + hopSize, (windowSize - hopSize) * sizeof(float));
+            pos = windowSize - hopSize;
+        }
+        return newFFT;
+    }
+    float *getReal() { return real_.data(); }
+    float *getImag() { return imag_.data(); }
+    std::vector<float> &getMagnitudes() { return magnitudes; }
+    std::vector<float> &getPhases() { return phases; }
+    std::vector<float> &getMagnitudesDB() { return magsToDB(); }
+    std::vector<float> &magsToDB() {  // fft::convToDB, L/fft.cpp:526-534, on the device
+        features(true, false, false);
+        return magnitudesDB;
+    }
+    float spectralFlatness() { features(false, true, false); return feat_[0]; }  // L/maxiFFT.cpp:113-123
+    float spectralCentroid() { features(false, false, true); return feat_[1]; }  // :125-132
+    int getNumBins() { return bins; }
+    int getFFTSize() { return fftSize; }
+    int getHopSize() { return hopSize; }
+    int getWindowSize() { return windowSize; }
+
+private:
+    void features(bool db, bool flat, bool cen) {
+        float *mg = d_out_ + 2 * bins;
+        maxigpu::ps::check(mxg_memcpy_h2d(mg, magnitudes.data(), sizeof(float) * bins, nullptr), "h2d mags");
+        float *ddb = d_out_, *df = d_out_ + bins;  // reuse the real / imag staging
+        maxigpu::ps::check(mxg_fft_features(plan_, mg, 1, db ? ddb : nullptr, flat ? df : nullptr, cen ? df + 1 : nullptr, nullptr),
+                           "mxg_fft_features");
+        if (db) maxigpu::ps::check(mxg_memcpy_d2h(magnitudesDB.data(), ddb, sizeof(float) * bins, nullptr), "d2h db");
+        if (flat) maxigpu::ps::check(mxg_memcpy_d2h(&feat_[0], df, sizeof(float), nullptr), "d2h flatness");
+        if (cen) maxigpu::ps::check(mxg_memcpy_d2h(&feat_[1], df + 1, sizeof(float), nullptr), "d2h centroid");
+    }
+    void release() {
+        if (plan_) mxg_fft_plan_destroy(plan_);
+        if (d_in_) mxg_free(d_in_);
+        if (d_out_) mxg_free(d_out_);
+        plan_ = nullptr;
+        d_in_ = d_out_ = nullptr;
+    }
+    mxg_fft_plan *plan_ = nullptr;
+    float *d_in_ = nullptr, *d_out_ = nullptr;
+    int fftSize = 0, windowSize = 0, hopSize = 0, bins = 0, pos = 0;
+    bool newFFT = false;
+    std::vector<float> buffer, magnitudes, magnitudesDB, phases, real_, imag_;
+    float feat_[2] = {0, 0};
+};
+
+// ---- maxiMFCC (L/maxiMFCC.h:41-211) ------------------------------------------------------------------------------
+class maxiMFCC {
+public:
+    maxiMFCC() {}
+    ~maxiMFCC() { release(); }
+    maxiMFCC(const maxiMFCC &) = delete;
+    maxiMFCC &operator=(const maxiMFCC &) = delete;
+    void setup(unsigned int numBins, unsigned int numFilters, unsigned int numCoeffs, double minFreq, double maxFreq) {  // :56-75
+        release();
+        plan_ = mxg_mfcc_plan_create(numBins, numFilters, numCoeffs, minFreq, maxFreq);
+        if (!plan_) throw std::runtime_error(std::string("mxg_mfcc_plan_create: ") + mxg_last_error());
+        numBins_ = numBins;
+        coeffs_.assign(numCoeffs, 0.0);
+        d_in_ = static_cast<float *>(mxg_malloc(sizeof(float) * numBins));
+        d_out_ = static_cast<double *>(mxg_malloc(sizeof(double) * numCoeffs));
+        if (!d_in_ || !d_out_) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+    }
+    vector<double> &mfcc(vector<float> &powerSpectrum) {  // :77-81
+        maxigpu::ps::check(mxg_memcpy_h2d(d_in_, powerSpectrum.data(), sizeof(float) * numBins_, nullptr), "h2d spectrum");
+        maxigpu::ps::check(mxg_mfcc_batch(plan_, d_in_, numBins_, 1, nullptr, nullptr, d_out_, 0, nullptr), "mxg_mfcc_batch");
+        maxigpu::ps::check(mxg_memcpy_d2h(coeffs_.data(), d_out_, sizeof(double) * coeffs_.size(), nullptr), "d2h mfcc");
+        return coeffs_;
+    }
+
+private:
+    void release() {
+        if (plan_) mxg_mfcc_plan_destroy(plan_);
+        if (d_in_) mxg_free(d_in_);
+        if (d_out_) mxg_free(d_out_);
+        plan_ = nullptr;
+        d_in_ = nullptr;
+        d_out_ = nullptr;
+    }
+    mxg_mfcc_plan *plan_ = nullptr;
+    unsigned numBins_ = 0;
+    float *d_in_ = nullptr;
+    double *d_out_ = nullptr;
+    vector<double> coeffs_;
+};
+
+// ---- the plugin API (src/maximilian.cpp:205-207; cpp/commandline/player.cpp:21-44) ------------------------------------
+void setup();
+void play(double *output);

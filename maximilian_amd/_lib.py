@@ -24,6 +24,14 @@ SIGNATURES = {
     "mxg_free": (c_int, [c_void_p]),
     "mxg_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mxg_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mxg_memcpy_h2d_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mxg_memcpy_d2h_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mxg_host_alloc": (c_void_p, [c_size_t]),
+    "mxg_host_free": (c_int, [c_void_p]),
+    "mxg_event_sync": (c_int, [c_void_p]),
+    "mxg_event_query": (c_int, [c_void_p]),
+    "mxg_stream_wait_event": (c_int, [c_void_p, c_void_p]),
+    "mxg_host_render": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "mxg_memset": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
     "mxg_stream_create": (c_void_p, []),
     "mxg_stream_destroy": (c_int, [c_void_p]),

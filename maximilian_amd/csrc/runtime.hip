@@ -226,6 +226,26 @@ int mxg_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream) {
     MXG_HIP(hipStreamSynchronize(st));
     return MXG_OK;
 }
+int mxg_memcpy_h2d_async(void *d_dst, const void *h_src, size_t bytes, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, resolve_stream(stream)));
+    return MXG_OK;
+}
+int mxg_memcpy_d2h_async(void *h_dst, const void *d_src, size_t bytes, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, resolve_stream(stream)));
+    return MXG_OK;
+}
+void *mxg_host_alloc(size_t bytes) {
+    if (ensure_init()) return nullptr;
+    void *p = nullptr;
+    if (check_hip(hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault), "hipHostMalloc")) return nullptr;
+    return p;
+}
+int mxg_host_free(void *h_ptr) {
+    if (h_ptr) MXG_HIP(hipHostFree(h_ptr));
+    return MXG_OK;
+}
 int mxg_memset(void *d_dst, int value, size_t bytes, void *stream) {
     if (int s = ensure_init()) return s;
     MXG_HIP(hipMemsetAsync(d_dst, value, bytes, resolve_stream(stream)));
@@ -278,6 +298,38 @@ int mxg_event_record(void *event, void *stream) {
     if (int s = ensure_init()) return s;
     MXG_REQUIRE(event, "null event");
     MXG_HIP(hipEventRecord((hipEvent_t)event, resolve_stream(stream)));
+    return MXG_OK;
+}
+int mxg_event_sync(void *event) {
+    MXG_REQUIRE(event, "null event");
+    MXG_HIP(hipEventSynchronize((hipEvent_t)event));
+    return MXG_OK;
+}
+int mxg_event_query(void *event) {  // 1 complete, 0 still running
+    MXG_REQUIRE(event, "null event");
+    hipError_t e = hipEventQuery((hipEvent_t)event);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return check_hip(e, "hipEventQuery");
+}
+int mxg_stream_wait_event(void *stream, void *event) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(event, "null event");
+    MXG_HIP(hipStreamWaitEvent(resolve_stream(stream), (hipEvent_t)event, 0));
+    return MXG_OK;
+}
+// cpp/commandline/player.cpp:25-44 `routing()`, restated without RtAudio: play() once per frame, then `channels`
+// doubles copied to the interleaved buffer.  lastValues persists across calls like the callback's userData.
+int mxg_host_render(void (*play)(double *), size_t channels, size_t nFrames, double *h_interleaved, double *h_lastValues) {
+    MXG_REQUIRE(play && h_interleaved && h_lastValues && channels > 0, "null argument");
+    double *buffer = h_interleaved;
+    for (size_t i = 0; i < nFrames; i++) {
+        play(h_lastValues);
+        for (size_t j = 0; j < channels; j++) *buffer++ = h_lastValues[j];
+    }
     return MXG_OK;
 }
 int mxg_event_elapsed_ms(void *start, void *stop, float *h_ms) {

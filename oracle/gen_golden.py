@@ -465,6 +465,20 @@ def main():
                              "impulse frames) and 256/64: mode 0 = the reference verbatim (silence), mode 1 = sums routed to the "
                              "inverse transform's inputs through the reference's own calcIFFT")
 
+    # ---- the reference's own example patches through the headless host (oracle/example_host.cpp): the oracle of the
+    # drop-in header include/maximilian.h.  01 = cpp/commandline/main.cpp (BASELINE config 1: 1x sinewave(440), 44 100
+    # frames x 2 ch), 14 = 14.monosynth (96 000 frames: the first metronome tick falls at 88 200), 15 = 15.polysynth.
+    d = {}
+    for ex, frames in (("01", 44100), ("14", 96000), ("15", 16384)):
+        tmp = os.path.join("/tmp", "mxo_example_%s.f64" % ex)
+        subprocess.run([os.path.join(HERE, "_ref", "example_" + ex), str(frames), tmp], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+        d["ex" + ex] = np.fromfile(tmp, np.float64).reshape(frames, 2)
+        os.remove(tmp)
+    save("dropin.npz", **d)
+    files["dropin.npz"] = ("cpp/commandline/main.cpp (44100 frames), 14.monosynth (96000), 15.polysynth (16384) of the reference, "
+                           "compiled with the unmodified reference library and run through oracle/example_host.cpp (routing() restated)")
+
     sha = hashlib.sha256()
     for f in ("libs/maxiConvolve.cpp", "libs/maxiConvolve.h", "libs/maxiFFT.h", "libs/fft.h", "maximilian.cpp", "maximilian.h", "libs/fft.cpp", "libs/maxiFFT.cpp", "libs/maxiMFCC.cpp",
               "libs/maxiMFCC.h", "libs/maxiGrains.h", "libs/maxiSynths.cpp", "libs/maxiSynths.h"):

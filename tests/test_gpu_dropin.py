@@ -1,0 +1,55 @@
+"""GPU (-m gpu): the DROP-IN boundary.  host/dropin_{01,14,15} are the reference's own example patches --
+cpp/commandline/main.cpp (BASELINE config 1), maximilian_examples/14.monosynth/main.cpp and 15.polysynth/main.cpp --
+compiled VERBATIM (host/Makefile, where /root/reference exists) against include/maximilian.h, whose maxiOsc / maxiEnv /
+maxiFilter run on the GPU through the C-ABI, and driven by mxg_host_render (the loop of cpp/commandline/player.cpp:25-44).
+Expected samples: tests/golden/dropin.npz, dumped from the SAME source files linked with the unmodified reference
+library (oracle/example_host.cpp).  14 and 15 must match bit for bit (pulse / sinebuf / phasor oscillators, the lores
+filter with host-libm coefficients, the adsr state machine, and the user code's own host arithmetic in between);
+01 (sinewave) within 1 ULP."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_bits_equal, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def run_dropin(ex, frames, tmp_path):
+    exe = os.path.join(ROOT, "host", "dropin_" + ex)
+    if not os.path.exists(exe):
+        pytest.fail("host/dropin_%s is not built (python -c 'import __graft_entry__ as g; g.build()' where /root/reference exists)" % ex)
+    out = str(tmp_path / ("dropin_%s.f64" % ex))
+    r = subprocess.run([exe, str(frames), out], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    return np.fromfile(out, np.float64).reshape(frames, 2), r.stderr
+
+
+def test_config1_sinewave_patch(golden, tmp_path):
+    """cpp/commandline/main.cpp verbatim: one maxiOsc::sinewave(440) into both channels, 44 100 frames.  Constant
+    arguments: after the block length has doubled up to 512 every block is rendered asynchronously ahead of the audio
+    thread (the statistics line reports them)."""
+    exp = golden("dropin.npz")["ex01"]
+    got, log = run_dropin("01", exp.shape[0], tmp_path)
+    assert ulp_diff(got, exp).max() <= 1
+    assert np.array_equal(got[:, 0].view(np.uint64), got[:, 1].view(np.uint64))
+    m = re.search(r"osc (\d+) \(async blocks (\d+)\)", log)
+    launches, hits = int(m.group(1)), int(m.group(2))
+    assert hits >= 44100 // 512 - 3 and launches <= 120, log     # ~86 blocks of 512 + the 10 doublings
+
+
+def test_monosynth_patch_bit_exact(golden, tmp_path):
+    exp = golden("dropin.npz")["ex14"]
+    got, log = run_dropin("14", exp.shape[0], tmp_path)
+    assert_bits_equal(got, exp, "14.monosynth through the drop-in header")
+    assert np.abs(exp).max() > 0.5      # the tick at frame 88 200 is inside the window
+
+
+def test_polysynth_patch_bit_exact(golden, tmp_path):
+    exp = golden("dropin.npz")["ex15"]
+    got, log = run_dropin("15", exp.shape[0], tmp_path)
+    assert_bits_equal(got, exp, "15.polysynth through the drop-in header")
+    assert np.abs(exp).max() > 0.05
