@@ -103,6 +103,10 @@ def main():
     ap.add_argument("--mfcc-method", default="sparse", choices=["sparse", "mfma"],
                     help="config4: exact sparse mel walk (default) or the dense fp64 MFMA contraction")
     ap.add_argument("--mix-only", action="store_true", help="config2 fused: do not store the per-voice block (VALU/LDS time of K1m)")
+    ap.add_argument("--out-buffers", type=int, default=1,
+                    help="config2: rotate the per-voice output over this many 268 MB blocks (1 = the block renderer's own "
+                         "steady state: one block buffer reused, largely absorbed by the 256 MB Infinity Cache; 8 = every "
+                         "block's stores have to reach HBM)")
     ap.add_argument("--tune", action="append", default=[], help="KEY=VALUE passed to mxg_tune (A/B experiments)")
     ap.add_argument("--mfma-fullk", action="store_true",
                     help="config4 mfma: contract over all 512 bins instead of the 256 that carry mel weight")
@@ -156,7 +160,7 @@ def main():
     # a single GPU renders the bank without it unless asked (--mixdown fused|separate).  config 5 is DEFINED with the
     # stereo mixdown (BASELINE configs[4]), so it always mixes.
     mixdown = args.mixdown or {"config2": "fused" if world > 1 else "off", "config3": "separate" if world > 1 else "off",
-                               "config4": "off", "config5": "separate"}[args.workload]
+                               "config4": "off", "config5": "fused"}[args.workload]
     queue = None
     W = {}
 
@@ -164,7 +168,14 @@ def main():
         freq = torch.from_numpy(freq_h).to(dev)
         phase = torch.zeros(V, dtype=torch.float64, device=dev)
         hold = torch.zeros(V, dtype=torch.float64, device=dev)
-        out = torch.empty((B, V), dtype=torch.float64, device=dev)
+        outs = [torch.empty((B, V), dtype=torch.float64, device=dev) for _ in range(max(1, args.out_buffers))]
+        oi = [0]
+
+        class _Rot:  # the block buffer of the current step
+            @staticmethod
+            def data_ptr():
+                return outs[oi[0] % len(outs)].data_ptr()
+        out = _Rot
         pan = torch.from_numpy(pan_h).to(dev)
         if mixdown != "off":
             queue = RcclMixQueue(comm, B * 2, args.mix_depth, 0, stream)
@@ -182,8 +193,13 @@ def main():
             def step():
                 chk(L.mxg_osc_render(wf, V, B, freq.data_ptr(), 0, None, None, phase.data_ptr(), hold.data_ptr(),
                                      out.data_ptr(), stream), "mxg_osc_render")
+                oi[0] += 1
         else:
-            step = MixdownStep(render_mix, queue)
+            _mstep = MixdownStep(render_mix, queue)
+
+            def step():
+                _mstep()
+                oi[0] += 1
         algo = (8.0 + 24.0 / B) * V * B  # 8 B store + (freq, phase rd, phase wr)/block = 8.047 B/sample
         if mixdown == "fused":
             algo += 16.0 * V + 16.0 * B * (V / 256.0)  # + gains read, per-workgroup mix partials written
@@ -193,9 +209,10 @@ def main():
             return _baseline(lambda o, n, th: o.time_osc(wf, freq_h, n, threads=th), lambda n: V * n, (256, 1 << 18),
                              "samples per voice", "%d voices maxiOsc::%s, voice-inner loop" % (V, args.waveform))
         W = dict(step=step, samples=V * B, dominant=dom, algo_bytes=algo, dtype="f64", cpu=cpu,
-                 workload="configs[1]: 65536-voice maxiOsc::%s wavetable bank per GPU, block=512, fp64 out[n][v] stored%s"
+                 workload="configs[1]: 65536-voice maxiOsc::%s wavetable bank per GPU, block=512, fp64 out[n][v] stored%s%s"
                           % (args.waveform, {"fused": " + fused maxiMix::stereo mixdown", "separate": " + K3 mixdown",
-                                             "off": ""}[mixdown]))
+                                             "off": ""}[mixdown],
+                             "" if args.out_buffers <= 1 else ", output rotated over %d block buffers" % args.out_buffers))
     elif args.workload == "config3":
         K = 128
         mode = args.voice_mode
@@ -297,8 +314,12 @@ def main():
                                       gb.state.ptr, gb.grains.ptr, out5.ptr, stream), "mxg_granular_render")
 
         def render_mix5(slot):
-            grains()
-            chk(L.mxg_mix_stereo(S, T, out5.ptr, pan5.ptr, slot, stream), "mxg_mix_stereo")
+            if mixdown == "fused":  # the unit kernel mixes each 64 x 64 tile while it is in LDS
+                chk(L.mxg_granular_render_mix(plan5, 0, S, T, sb5.d_samples, Ls, 4, sp5.ptr, None, None, None, 0, gb.state.ptr,
+                                              gb.grains.ptr, out5.ptr, pan5.ptr, slot, stream), "mxg_granular_render_mix")
+            else:
+                grains()
+                chk(L.mxg_mix_stereo(S, T, out5.ptr, pan5.ptr, slot, stream), "mxg_mix_stereo")
         step = grains if mixdown == "off" else MixdownStep(render_mix5, queue)
 
         def cpu():

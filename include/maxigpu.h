@@ -129,6 +129,7 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "mfcc_tiled" (LDS-staged spectra 0|1), "grain_chunked" (time-sharded granular render 0|1), "grain_lanes_k",
  * "grain_unit" (coalesced unit-increment render 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_slices" (time slices of a unit-path
  * maxiTimeStretch call whose scheduling and rendering overlap, 1..16), "osc_mix_var" (layout of K1m's lane-exchange butterfly, 0..3),
+ * "osc_split" (time parts per voice group in K1: 0 automatic, 1|2|4),
  * "mfcc_mfma_fullk" (the MFMA mel contraction runs over all numBins bins instead of the ones that carry weight, 0|1).
  * The tests flip every one of them and demand identical bits.  Returns the previous value or MXG_ERR_INVALID. */
 int mxg_tune(const char *key, int value);
@@ -303,6 +304,12 @@ int mxg_sample_free(double *d_samples);
 int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, size_t len,
                       int mySampleRate, const double *d_a, int aps, const double *d_start,
                       const double *d_end, double *d_position, double *d_out, void *stream);
+
+/* maxiSample::playAtSpeedBetweenPointsFromPos(frequency, start, end, pos) (C:826-880) with the CALLER's position signal
+ * d_pos [N][V]: the member `position` takes no part (it is the by-value parameter of C:823-825), so the call is a pure
+ * function of its arguments.  d_freq [V] (fps = 0) or [N][V]; d_start / d_end [V] in samples.  Bit-exact. */
+int mxg_sample_render_frompos(size_t V, size_t N, const double *d_samples, size_t len, const double *d_freq, int fps,
+                              const double *d_start, const double *d_end, const double *d_pos, double *d_out, void *stream);
 
 /* Trigger-driven players (modes 9-14).  d_trig is the per-sample [N][V] first argument of the
  * reference call: the trigger signal of playOnZX* / loopSetPosOnZX, or the phasor of
@@ -494,6 +501,16 @@ int mxg_granular_render(const mxg_grain_plan *plan, int mode, size_t S, size_t T
                         size_t len, int overlaps, const double *d_a, const double *d_b,
                         const double *d_posmod, const int32_t *d_rnd, size_t R, double *d_st, double *d_gst,
                         double *d_out, void *stream);
+
+/* mxg_granular_render plus the maxiMix::stereo mixdown of the S streams (C:503-509 and the user-side sum,
+ * e.g. ofApp.cpp:166-173 of the reference's granular example): d_pan [S], d_mix [T][2] -- BASELINE configs[4]'s "stereo
+ * mixdown".  On the unit-increment path (maxiTimeStretch at 44.1 kHz) the render kernel mixes each 64-stream x 64-sample
+ * tile while it still sits in LDS, so the [T][S] block is not read back; every other path runs mxg_mix_stereo after the
+ * render.  Per-stream outputs bit-exact as mxg_granular_render; the sum over streams is tree-ordered (mix tolerance). */
+int mxg_granular_render_mix(const mxg_grain_plan *plan, int mode, size_t S, size_t T, const double *d_samples,
+                            size_t len, int overlaps, const double *d_a, const double *d_b,
+                            const double *d_posmod, const int32_t *d_rnd, size_t R, double *d_st, double *d_gst,
+                            double *d_out, const double *d_pan, double *d_mix, void *stream);
 
 /* ---- multi-GPU mixdown: RCCL over xGMI ------------------------------------------------ */
 /* The reference is single-device; there is nothing to cite but the mix itself (maxiMix, C:503-541, and the user-side

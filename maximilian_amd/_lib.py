@@ -70,6 +70,8 @@ SIGNATURES = {
     "mxg_mix_bus": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p]),
     "mxg_osc_noise": (c_int, [c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_sample_render_frompos": (c_int, [c_size_t, c_size_t, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p]),
     "mxg_sample_render_trig": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_size_t, c_int, c_void_p, c_void_p,
                                        c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
@@ -112,6 +114,9 @@ SIGNATURES = {
     "mxg_granular_render": (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_void_p, c_size_t, c_int, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),
+    "mxg_granular_render_mix": (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_void_p, c_size_t, c_int, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p]),
     "mxg_comm_unique_id": (c_int, [c_void_p]),
     "mxg_comm_create": (c_void_p, [c_void_p, c_int, c_int]),
     "mxg_comm_destroy": (c_int, [c_void_p]),

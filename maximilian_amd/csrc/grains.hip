@@ -25,6 +25,7 @@
 
 #include "mxg_common.h"
 #include "mxg_sched.h"
+#include "mxg_lanefold.h"
 
 struct mxg_grain_plan {
     int window_kind, mySampleRate;
@@ -514,6 +515,9 @@ struct UnitArgs {
     int *err;
     int sampleDur;
     unsigned c0;  // first tile of this launch (time slices)
+    // fused maxiMix::stereo mixdown of the tile (NULL = off): pan [S], mixpart [stream tiles][T][2]
+    const double *pan;
+    double *mixpart;
 };
 
 __device__ __forceinline__ long long unit_index(long long t, long long len) {  // t mod len, result in [0,len)
@@ -808,6 +812,31 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
         const size_t nn = n0 + r, s = s0 + lane;
         if (nn < A.T && s < S) A.out[nn * S + s] = s_tile[r * 65 + lane];
     }
+    if (A.pan) {  // maxiMix::stereo (C:503-509) of the tile's 64 streams, 16 sample rows per wave: the butterfly of K1m
+        const size_t s = s0 + lane;
+        double x = s < S ? A.pan[s] : 0.0;
+        if (x > 1) x = 1;
+        if (x < 0) x = 0;
+        const double gl = sqrt(1.0 - x), gr = sqrt(x);
+        double L[kMixChunk], R[kMixChunk];
+        int idx[kMixChunk];
+#pragma unroll
+        for (int i = 0; i < kMixChunk; i++) {
+            const int r = wave * 16 + i;
+            const double v = (s < S && n0 + r < A.T) ? s_tile[r * 65 + lane] : 0.0;
+            L[i] = v * gl;
+            R[i] = v * gr;
+            idx[i] = i;
+        }
+        const int slot = fold_chunk_swap<int>(idx);
+        const double sl = quad_sum(fold_chunk_swap<double>(L)), sr = quad_sum(fold_chunk_swap<double>(R));
+        const size_t nn = n0 + wave * 16 + (size_t)(slot < 0 ? 0 : slot);
+        if ((lane & 3) == 0 && slot >= 0 && nn < A.T) {
+            double *dst = A.mixpart + ((size_t)blockIdx.x * A.T + nn) * 2;
+            dst[0] = sl;
+            dst[1] = sr;
+        }
+    }
 }
 
 // grains alive after sample T-1, creation order, closed form (one lane per stream)
@@ -944,11 +973,34 @@ int mxg_grain_plan_window(const mxg_grain_plan *p, double *h_window) {
     return (int)p->sampleDur;
 }
 
+static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, size_t T, const double *d_samples,
+                                size_t len, int overlaps, const double *d_a, const double *d_b,
+                                const double *d_posmod, const int32_t *d_rnd, size_t R, double *d_st, double *d_gst,
+                                double *d_out, const double *d_pan, double *d_mix, void *stream);
+
 int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, const double *d_samples,
                         size_t len, int overlaps, const double *d_a, const double *d_b,
                         const double *d_posmod, const int32_t *d_rnd, size_t R, double *d_st, double *d_gst,
                         double *d_out, void *stream) {
+    return granular_render_impl(p, mode, S, T, d_samples, len, overlaps, d_a, d_b, d_posmod, d_rnd, R, d_st, d_gst, d_out,
+                                nullptr, nullptr, stream);
+}
+
+int mxg_granular_render_mix(const mxg_grain_plan *p, int mode, size_t S, size_t T, const double *d_samples,
+                            size_t len, int overlaps, const double *d_a, const double *d_b,
+                            const double *d_posmod, const int32_t *d_rnd, size_t R, double *d_st, double *d_gst,
+                            double *d_out, const double *d_pan, double *d_mix, void *stream) {
+    MXG_REQUIRE(d_pan && d_mix, "null pan / mix");
+    return granular_render_impl(p, mode, S, T, d_samples, len, overlaps, d_a, d_b, d_posmod, d_rnd, R, d_st, d_gst, d_out,
+                                d_pan, d_mix, stream);
+}
+
+static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, size_t T, const double *d_samples,
+                                size_t len, int overlaps, const double *d_a, const double *d_b,
+                                const double *d_posmod, const int32_t *d_rnd, size_t R, double *d_st, double *d_gst,
+                                double *d_out, const double *d_pan, double *d_mix, void *stream) {
     if (int s = ensure_init()) return s;
+    bool mixed = false;  // the unit path mixes inside its render kernel; every other path runs K3 afterwards
     MXG_REQUIRE(p && p->d_window, "null plan (or plan created without a HIP device)");
     MXG_REQUIRE(mode >= 0 && mode <= 3,
                 "mode must be 0 (maxiTimeStretch::play), 1 (maxiStretch::play), 2 (playAtPosition) or 3 "
@@ -1035,6 +1087,13 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         U.spawn_n = spawn_n; U.spawn_pos = spawn_pos; U.spawn_inc = spawn_inc; U.chunk_first = chunk_first;
         U.gst_in = gst_copy; U.gst_out = d_gst; U.out = d_out; U.err = g_err; U.sampleDur = A.sampleDur;
         U.c0 = 0;
+        U.pan = nullptr;
+        U.mixpart = nullptr;
+        const size_t stiles = (S + 63) / 64;
+        if (unit && d_pan) {
+            if (int e = scratch_get(SCR_GRAIN_MIX, st, sizeof(double) * stiles * T * 2, (void **)&U.mixpart)) return e;
+            U.pan = d_pan;
+        }
         // maxiTimeStretch::play / playAtPosition on the unit path: the scheduler is a serial walk per stream (32 wavefronts for 2048 streams)
         // and the render fills the chip, so the call is cut into time slices and slice i's render (on the library's
         // auxiliary stream) overlaps slice i+1's scheduling.  The scheduler state carries over in d_st / carry; the
@@ -1075,6 +1134,11 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
             MXG_HIP(hipEventRecord(g_aux_done, g_aux));
             MXG_HIP(hipStreamWaitEvent(st, g_aux_done, 0));
             hipLaunchKernelGGL(granular_unit_state_kernel, grid, dim3(64), 0, st, U);
+            if (U.pan) {
+                hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((T * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, stiles,
+                                   T * 2, U.mixpart, d_mix);
+                mixed = true;
+            }
         } else {
         {
         KernelTimer kt("granular_sched_kernel", st);
@@ -1091,6 +1155,11 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
                 hipLaunchKernelGGL(granular_unit_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)C), dim3(256), 0, st, U);
             }
             hipLaunchKernelGGL(granular_unit_state_kernel, grid, dim3(64), 0, st, U);
+            if (U.pan) {
+                hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((T * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, stiles,
+                                   T * 2, U.mixpart, d_mix);
+                mixed = true;
+            }
         } else {
         RenderArgs Rr;
         Rr.S = S; Rr.T = T; Rr.len = len; Rr.G = G; Rr.Tc = Tc; Rr.C = C;
@@ -1105,6 +1174,9 @@ int mxg_granular_render(const mxg_grain_plan *p, int mode, size_t S, size_t T, c
         }
     }
     MXG_HIP(hipGetLastError());
+    if (d_pan && !mixed) {
+        if (int e = mxg_mix_stereo(S, T, d_out, d_pan, d_mix, stream)) return e;
+    }
     int herr = 0;
     MXG_HIP(hipMemcpyAsync(&herr, g_err, sizeof(int), hipMemcpyDeviceToHost, st));
     MXG_HIP(hipStreamSynchronize(st));

@@ -160,5 +160,32 @@ __device__ __forceinline__ double osc_tick(double &phase, double &hold, const Os
     }
 }
 
+// The recurrence of one sample WITHOUT its output: exactly the phase operations of osc_tick, in its order.  For the
+// waveforms whose tick always overwrites `hold` it is left alone (a later tick sets it); square / pulse / impulse update
+// `hold` conditionally, so they run their (cheap) tick.
+template <int WF>
+__device__ __forceinline__ void osc_skip(double &phase, double &hold, const OscPre &q, const double *s_sine,
+                                         const double *s_trans) {
+    if constexpr (WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE || WF == MXG_OSC_PHASOR || WF == MXG_OSC_TRIANGLE) {
+        if (phase >= 1.0) phase -= 1.0;
+        phase += q.inc;
+    } else if constexpr (WF == MXG_OSC_SAW) {
+        if (phase >= 1.0) phase -= 2.0;
+        phase += q.inc;
+    } else if constexpr (WF == MXG_OSC_PHASORBETWEEN) {
+        if (phase < q.p1) phase = q.p1;
+        if (phase >= q.p2) phase = q.p1;
+        phase += q.inc;
+    } else if constexpr (WF == MXG_OSC_SINEBUF || WF == MXG_OSC_SINEBUF4) {
+        phase += q.inc;
+        if (phase >= 511) phase -= 512;
+    } else if constexpr (WF == MXG_OSC_SAWN) {
+        if (phase >= 0.5) phase -= 1.0;
+        phase += q.inc;
+    } else {
+        (void)osc_tick<WF>(phase, hold, q, s_sine, s_trans);
+    }
+}
+
 }  // namespace
 }  // namespace mxg

@@ -18,6 +18,7 @@
 #include "maxi_tables.h"
 #include "mxg_sincos.h"
 #include "mxg_osc.h"
+#include "mxg_lanefold.h"
 
 namespace mxg {
 
@@ -65,13 +66,28 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
             q[j].p2 = b;
         }
     }
-    double *o = out + v0;
+    // Time split (gridDim.y parts): 65 536 voices are one wavefront per SIMD, and a lone wavefront issues one VALU
+    // instruction per ~4.4 clk whatever it is (tools/ubench: fp64 4.35 clk at one wave per SIMD, 2.27 at four).  For the
+    // waveforms whose OUTPUT is the expensive part (sinewave / coswave: ~100 fp64 ops per sample against 3 for the phase
+    // ramp) part p first advances the recurrence over the samples of parts 0..p-1 without producing them -- the same
+    // additions in the same order, so the same bits -- and then renders its own stretch; the last part stores the state.
+    const size_t plen = (N + gridDim.y - 1) / gridDim.y;
+    const size_t nA = blockIdx.y * plen < N ? blockIdx.y * plen : N;
+    const size_t nB = nA + plen < N ? nA + plen : N;
+    if constexpr (!FPS) {
+#pragma unroll 4
+        for (size_t n = 0; n < nA; n++) {
+#pragma unroll
+            for (int j = 0; j < VPL; j++) osc_skip<WF>(ph[j], hd[j], q[j], s_tab, s_tab);
+        }
+    }
+    double *o = out + nA * V + v0;
     const double *fp = freq + v0;
 #ifndef MXG_OSC_UNROLL
 #define MXG_OSC_UNROLL 4
 #endif
 #pragma unroll MXG_OSC_UNROLL
-    for (size_t n = 0; n < N; n++) {
+    for (size_t n = nA; n < nB; n++) {
         double r[VPL];
 #pragma unroll
         for (int j = 0; j < VPL; j++) {
@@ -85,10 +101,12 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
         o += V;
         if constexpr (FPS) fp += V;
     }
+    if (blockIdx.y + 1 == gridDim.y) {
 #pragma unroll
-    for (int j = 0; j < VPL; j++) {
-        phase_io[v0 + j] = ph[j];
-        hold_io[v0 + j] = hd[j];
+        for (int j = 0; j < VPL; j++) {
+            phase_io[v0 + j] = ph[j];
+            hold_io[v0 + j] = hd[j];
+        }
     }
 }
 
@@ -111,116 +129,8 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
 // workgroup's combine pass -- which has to add the four waves anyway -- adds 16 terms instead of 4, in a fixed order.
 // A small second kernel sums the per-workgroup partials => deterministic (but not the reference's sequential order:
 // tolerance on the mix).
-constexpr int kMixChunk = 16;
 
-template <typename T> struct Fold;
-template <> struct Fold<double> {
-    static __device__ __forceinline__ double join(double x, double y) { return x + y; }
-    static __device__ __forceinline__ void split(double v, unsigned &lo, unsigned &hi) { lo = (unsigned)__double2loint(v); hi = (unsigned)__double2hiint(v); }
-    static __device__ __forceinline__ double make(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
-};
-
-// DPP exchange: t = x with the lanes of `BANKS_T` replaced by ctrl(y); u = y with the other banks replaced by ctrl(x)
-template <int CTRL, int BANKS_T>
-__device__ __forceinline__ void dpp_exchange(unsigned x, unsigned y, unsigned &t, unsigned &u) {
-    t = (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)y, CTRL, 0xf, BANKS_T, false);
-    u = (unsigned)__builtin_amdgcn_update_dpp((int)y, (int)x, CTRL, 0xf, 0xf ^ BANKS_T, false);
-}
-// banks BANKS_T of the result carry sample B (its lanes added to their mirror partners), the others sample A
-template <int CTRL, int BANKS_T>
-__device__ __forceinline__ double fold_dpp(double a, double b) {
-    unsigned al, ah, bl, bh, tl, th, ul, uh;
-    Fold<double>::split(a, al, ah);
-    Fold<double>::split(b, bl, bh);
-    dpp_exchange<CTRL, BANKS_T>(al, bl, tl, ul);
-    dpp_exchange<CTRL, BANKS_T>(ah, bh, th, uh);
-    return Fold<double>::make(tl, th) + Fold<double>::make(ul, uh);
-}
-template <int CTRL, int BANKS_T>
-__device__ __forceinline__ int fold_dpp(int a, int b) {
-    unsigned t, u;
-    dpp_exchange<CTRL, BANKS_T>((unsigned)a, (unsigned)b, t, u);
-    return (int)t == (int)u ? (int)t : -1;  // both operands must name the same sample
-}
-// lanes with `bit` set keep sample B, the others sample A; each adds the partner lane (quad_perm QP) of its own sample
-template <int QP>
-__device__ __forceinline__ double fold_quad(double a, double b, bool bit) {
-    const double keep = bit ? b : a, send = bit ? a : b;
-    unsigned lo, hi;
-    Fold<double>::split(send, lo, hi);
-    const double got = Fold<double>::make((unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, QP, 0xf, 0xf, true),
-                                          (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, QP, 0xf, 0xf, true));
-    return keep + got;
-}
-template <int QP>
-__device__ __forceinline__ int fold_quad(int a, int b, bool bit) {
-    const int keep = bit ? b : a, send = bit ? a : b;
-    const int got = __builtin_amdgcn_update_dpp(0, send, QP, 0xf, 0xf, true);
-    return keep == got ? keep : -1;
-}
-constexpr int kDppRowMirror = 0x140, kDppRowHalfMirror = 0x141;
-constexpr int kDppQuadXor1 = 0xB1 /* [1,0,3,2] */, kDppQuadXor2 = 0x4E /* [2,3,0,1] */;
-// 16 vectors (one per sample) -> one vector: lane l holds, for sample slot(l), the sum over the 16 lanes of its row
-template <typename T>
-__device__ __forceinline__ T fold_chunk(const T (&v)[kMixChunk], int lane) {
-    T l1[8], l2[4], l3[2];
-#pragma unroll
-    for (int j = 0; j < 8; j++) l1[j] = fold_dpp<kDppRowMirror, 0xC>(v[2 * j], v[2 * j + 1]);
-#pragma unroll
-    for (int j = 0; j < 4; j++) l2[j] = fold_dpp<kDppRowHalfMirror, 0xA>(l1[2 * j], l1[2 * j + 1]);
-#pragma unroll
-    for (int j = 0; j < 2; j++) l3[j] = fold_quad<kDppQuadXor2>(l2[2 * j], l2[2 * j + 1], (lane & 2) != 0);
-    return fold_quad<kDppQuadXor1>(l3[0], l3[1], (lane & 1) != 0);
-}
-
-// ---- variant 0: cross-row levels first with v_permlane32/16_swap, then mirror / half-mirror, then a quad reduction:
-// every quad of lanes ends up with the wave-wide sum of one sample (no row sums for the workgroup pass to add)
-__device__ __forceinline__ double fold32(double a, double b) {
-    unsigned al, ah, bl, bh;
-    Fold<double>::split(a, al, ah);
-    Fold<double>::split(b, bl, bh);
-    auto lo = __builtin_amdgcn_permlane32_swap(al, bl, false, false);
-    auto hi = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
-    return Fold<double>::make(lo[0], hi[0]) + Fold<double>::make(lo[1], hi[1]);
-}
-__device__ __forceinline__ int fold32(int a, int b) {
-    auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
-    return (int)r[0] == (int)r[1] ? (int)r[0] : -1;
-}
-__device__ __forceinline__ double fold16(double a, double b) {
-    unsigned al, ah, bl, bh;
-    Fold<double>::split(a, al, ah);
-    Fold<double>::split(b, bl, bh);
-    auto lo = __builtin_amdgcn_permlane16_swap(al, bl, false, false);
-    auto hi = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
-    return Fold<double>::make(lo[0], hi[0]) + Fold<double>::make(lo[1], hi[1]);
-}
-__device__ __forceinline__ int fold16(int a, int b) {
-    auto r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
-    return (int)r[0] == (int)r[1] ? (int)r[0] : -1;
-}
-__device__ __forceinline__ double quad_sum(double v) {
-    unsigned lo, hi;
-    Fold<double>::split(v, lo, hi);
-    double o = Fold<double>::make((unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, kDppQuadXor1, 0xf, 0xf, true),
-                                  (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, kDppQuadXor1, 0xf, 0xf, true));
-    v = v + o;
-    Fold<double>::split(v, lo, hi);
-    o = Fold<double>::make((unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, kDppQuadXor2, 0xf, 0xf, true),
-                           (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, kDppQuadXor2, 0xf, 0xf, true));
-    return v + o;
-}
-template <typename T>
-__device__ __forceinline__ T fold_chunk_swap(const T (&v)[kMixChunk]) {
-    T l1[8], l2[4], l3[2];
-#pragma unroll
-    for (int j = 0; j < 8; j++) l1[j] = fold32(v[2 * j], v[2 * j + 1]);
-#pragma unroll
-    for (int j = 0; j < 4; j++) l2[j] = fold16(l1[2 * j], l1[2 * j + 1]);
-#pragma unroll
-    for (int j = 0; j < 2; j++) l3[j] = fold_dpp<kDppRowMirror, 0xC>(l2[2 * j], l2[2 * j + 1]);
-    return fold_dpp<kDppRowHalfMirror, 0xA>(l3[0], l3[1]);
-}
+// the lane-exchange helpers (Fold, fold_dpp, fold_quad, fold_chunk, fold32/16, quad_sum, fold_chunk_swap) live in mxg_lanefold.h
 
 // VAR 0: permlane-swap butterfly, 4 LDS rows per window (one per wave).  VAR 1: all-DPP butterfly, 16 rows (wave x row).
 template <int WF, bool STORE, int VAR, int WIN>
@@ -314,32 +224,6 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
     hold_io[v] = hd;
 }
 
-// mix[i] = sum over workgroups of partial[g][i], i = n*2 + ch.  A workgroup owns 64 consecutive elements (one coalesced
-// 512-B row segment per load); its 16 waves each add the groups g = w, w+16, ... in order (independent loads, all in
-// flight), then the 16 wave sums are combined left to right: a fixed order for a fixed number of workgroups.
-constexpr int kPartWaves = 16;
-__global__ __launch_bounds__(64 * kPartWaves) void mix_partials_kernel(size_t ngroups, size_t count,
-                                                                       const double *__restrict__ partial,
-                                                                       double *__restrict__ mix) {
-    __shared__ double s_red[kPartWaves][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const size_t i = (size_t)blockIdx.x * 64 + lane;
-    double s = 0.0;
-    if (i < count) {
-        const double *p = partial + i;
-#pragma unroll 8
-        for (size_t g = w; g < ngroups; g += kPartWaves) s += p[g * count];
-    }
-    s_red[w][lane] = s;
-    __syncthreads();
-    if (w == 0 && i < count) {
-        double t = s_red[0][lane];
-#pragma unroll
-        for (int k = 1; k < kPartWaves; k++) t += s_red[k][lane];
-        mix[i] = t;
-    }
-}
-
 typedef void (*osc_mix_fn)(size_t, size_t, const double *, const double *, const double *, double *, double *,
                            double *, const double *, double *, double);
 template <int WF>
@@ -421,7 +305,20 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     bool nt = tune_get("osc_nt") != 0;
     osc_fn fn = pick_wf(waveform, fps != 0, vpl, nt);
     size_t lanes = (V + vpl - 1) / vpl;
-    dim3 grid((unsigned)((lanes + block - 1) / block)), blk((unsigned)block);
+    // time parts: only where the output dominates the recurrence (sinewave, coswave) and the bank is too small to give
+    // every SIMD four wavefronts by itself
+    int split = tune_get("osc_split");
+    if (split == 0) {
+        split = 1;
+        if (!fps && (waveform == MXG_OSC_SINEWAVE || waveform == MXG_OSC_COSWAVE)) {
+            const size_t waves = (lanes + 63) / 64;
+            split = waves >= 4096 ? 1 : (waves >= 2048 ? 2 : 4);
+        }
+    }
+    if (fps) split = 1;
+    // every part must render at least one sample: the last part's ticks leave the member `output` of the final sample
+    while (split > 1 && (size_t)(split - 1) * ((N + split - 1) / split) >= N) split--;
+    dim3 grid((unsigned)((lanes + block - 1) / block), (unsigned)split), blk((unsigned)block);
     KernelTimer kt("osc_kernel", resolve_stream(stream));
     hipLaunchKernelGGL(fn, grid, blk, 0, resolve_stream(stream), V, N, d_freq, d_p1, d_p2, d_phase,
                        d_outhold, d_out, (double)settings().sampleRate);

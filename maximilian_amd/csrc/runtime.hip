@@ -29,6 +29,7 @@ struct Tune {
 Tune g_tune[] = {
     {"osc_vpl", 1, 1, 2},       {"osc_block", 256, 64, 1024},  {"osc_nt", 0, 0, 1},
     {"voice_vpl", 1, 1, 2},     {"voice_block", 256, 64, 1024}, {"voice_nt", 0, 0, 1},
+    {"osc_split", 0, 0, 4},  // K1: time parts per voice group (0 = automatic: 4 for sinewave / coswave on small banks, else 1)
     {"osc_mix_var", 0, 0, 3},  // K1m A/B (sinebuf): 0 swap butterfly, window 512; 1 same, window 128; 2 DPP butterfly 128; 3 DPP 512
     {"mix_block", 256, 64, 1024},
     {"mix_rows", 2, 1, 2},  // K3: sample rows per workgroup sharing one read of the gains (stereo, no bus output)

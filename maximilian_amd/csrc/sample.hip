@@ -326,12 +326,51 @@ void launch_sample(bool xmod, dim3 grid, dim3 block, hipStream_t st, const SmpAr
         hipLaunchKernelGGL((sample_kernel<M, false>), grid, block, 0, st, A);
 }
 
+// maxiSample::playAtSpeedBetweenPointsFromPos (C:826-880) with the caller's `pos`: a pure function of its arguments (the
+// member `position` is neither read nor written), so a block is one lane per (sample, voice)
+__global__ __launch_bounds__(256) void sample_frompos_kernel(size_t V, size_t N, const double *__restrict__ amp, size_t len,
+                                                             const double *__restrict__ freq, int fps,
+                                                             const double *__restrict__ start, const double *__restrict__ end,
+                                                             const double *__restrict__ pos, double *__restrict__ out, double sr) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * V) return;
+    const size_t v = t % V;
+    Smp s;
+    s.amp = amp;
+    s.len = len;
+    s.pos = pos[t];
+    s.step_div = 1.0;
+    s.tprev = 0.0;
+    s.tfirst = false;
+    s.p0 = s.p1 = 0.0;
+    SmpReq<8> q;
+    smp_gen<8>(s, fps ? freq[t] : freq[v], 0.0, start[v], end[v], sr, q);
+    double val[2];
+    val[0] = amp[q.idx[0]];
+    val[1] = amp[q.idx[1]];
+    out[t] = smp_eval<8>(q, val);
+}
+
 }  // namespace
 }  // namespace mxg
 
 using namespace mxg;
 
 extern "C" {
+
+int mxg_sample_render_frompos(size_t V, size_t N, const double *d_samples, size_t len, const double *d_freq, int fps,
+                              const double *d_start, const double *d_end, const double *d_pos, double *d_out, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(d_samples && d_freq && d_start && d_end && d_pos && d_out, "null device pointer");
+    MXG_REQUIRE(len > 0, "empty sample");
+    if (V == 0 || N == 0) return MXG_OK;
+    hipStream_t st = resolve_stream(stream);
+    const size_t n = V * N;
+    KernelTimer kt("sample_frompos_kernel", st);
+    hipLaunchKernelGGL(sample_frompos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, V, N, d_samples, len, d_freq,
+                       fps, d_start, d_end, d_pos, d_out, (double)settings().sampleRate);
+    return check_hip(hipGetLastError(), "sample_frompos_kernel launch");
+}
 
 int mxg_delay_render(int mode, size_t V, size_t N, const double *d_in, const int32_t *d_size,
                      const double *d_feedback, const int32_t *d_position, double *d_mem, size_t cap,

@@ -62,7 +62,7 @@ def test_config2_64_blocks_every_sample(mx, port, wf, name):
           % (name, K, B, V, K * B * V / 1e9))
 
 
-VOICE_B_RTOL = 1e-9   # mode B: device cos/sqrt coefficients through a recursive filter, scaled by the voice's peak
+VOICE_B_RTOL = 1e-11  # mode B: device cos/sqrt coefficients through a recursive filter, scaled by the voice's peak
 
 
 @pytest.mark.parametrize("mode", [0, 1])

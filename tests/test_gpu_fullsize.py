@@ -4,7 +4,7 @@ units is compared with the oracle, and size-independent properties cover the res
 import numpy as np
 import pytest
 
-from conftest import assert_bits_equal
+from conftest import assert_bits_equal, mix_tol
 
 pytestmark = pytest.mark.gpu
 
@@ -99,4 +99,4 @@ def test_config5_full_size_granular_share(mx, port):
     mix = mx.maxiMixBank(S).stereo(blk, pan).numpy()
     x = blk.numpy()
     ref = np.stack([(x * np.sqrt(1.0 - pan)).sum(1), (x * np.sqrt(pan)).sum(1)], axis=1)
-    assert np.abs(mix - ref).max() <= 1e-12 * S * max(1.0, np.abs(x).max())
+    assert np.abs(mix - ref).max() <= mix_tol(S, np.abs(x).max())

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import assert_bits_equal, ulp_diff
+from conftest import assert_bits_equal, ulp_diff, mix_tol
 
 pytestmark = pytest.mark.gpu
 
@@ -161,11 +161,36 @@ def test_render_mix_fused(mx, port, wf, V, N):
     assert_bits_equal(o, eo, OSC[wf])
     assert_bits_equal(bank.phase.numpy(), eph, "phase")
     em = port.mix_stereo(eo, pan)
-    assert np.abs(m - em).max() <= 1e-12 * V
+    assert np.abs(m - em).max() <= mix_tol(V, np.abs(eo).max())
     bank2 = mx.maxiOscBank(V)
     none, mix3 = bank2.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V), store=False)
     assert none is None
     assert_bits_equal(mix3.numpy(), mix1.numpy(), "mix-only mode")
+
+
+@pytest.mark.parametrize("wf,V,N", [(0, 1000, 601), (1, 64, 3), (8, 300, 512), (6, 129, 77), (10, 70, 1), (5, 4096, 130)])
+def test_osc_time_split_same_bits(mx, wf, V, N):
+    """mxg_tune("osc_split"): rendering a block in 2 or 4 time parts (part p first advances the recurrence over the
+    earlier parts' samples without producing them) gives the same samples, phases and output members as one part --
+    two consecutive blocks, so the state written by the last part is exercised."""
+    rng = np.random.default_rng(wf * 7 + N)
+    freq, p1 = rng.uniform(20, 15000, V), rng.uniform(0.1, 0.9, V)
+    L = mx.lib()
+    prev = L.mxg_tune(b"osc_split", 1)
+    ref = None
+    try:
+        for split in (1, 2, 4, 0):
+            L.mxg_tune(b"osc_split", split)
+            bank = mx.maxiOscBank(V)
+            o = np.concatenate([bank.render(wf, freq, N, p1=p1, p2=np.ones(V)).numpy() for _ in range(2)])
+            cur = (o, bank.phase.numpy(), bank.output.numpy())
+            if ref is None:
+                ref = cur
+            else:
+                for a, b, what in zip(cur, ref, ("samples", "phase", "output member")):
+                    assert_bits_equal(a, b, "%s, split %d" % (what, split))
+    finally:
+        L.mxg_tune(b"osc_split", prev)
 
 
 def test_noise_from_rand_draws(mx, port):

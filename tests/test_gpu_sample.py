@@ -290,3 +290,30 @@ def test_delay_sizes_and_phases_outside_the_ring(mx, port):
     bank2 = mx.maxiDelaylineBank(V, cap); bank2.phase.upload(ph)
     o = bank2.dl(mx.DeviceBuffer.from_numpy(x), wild, fb).numpy()
     assert_bits_equal(o[:, sane], e, "in-range voices beside the wild ones")
+
+
+def test_play_at_speed_between_points_from_pos(mx, port):
+    """maxiSample::playAtSpeedBetweenPointsFromPos (C:826-880) with a caller-supplied position signal [N][V]: forward
+    and backward frequencies, positions before `start`, beyond `end` and on the last samples of the buffer."""
+    rng = np.random.default_rng(828)
+    Ls, V, N = 3000, 37, 50
+    smp = rng.uniform(-1, 1, Ls)
+    freq = np.where(rng.uniform(size=V) < 0.5, 1, -1) * rng.uniform(0.5, 40, V)
+    start, end = rng.uniform(0, 1000, V), rng.uniform(1500, Ls + 50, V)
+    pos = rng.uniform(-10, Ls + 5, (N, V))
+    pos[0, :5] = [0, Ls - 1, Ls - 2, Ls, 1]
+    sb = mx.maxiSampleBank(V)
+    sb.setSample(smp)
+    L = mx.lib()
+    d = [mx.DeviceBuffer.from_numpy(a) for a in (freq, start, end, pos)]
+    out = mx.DeviceBuffer((N, V), zero=False)
+    assert L.mxg_sample_render_frompos(V, N, sb.d_samples, Ls, d[0].ptr, 0, d[1].ptr, d[2].ptr, d[3].ptr, out.ptr, None) == 0
+    exp = np.stack([port.sample(8, smp, 1, pos[n], a=freq, start=start, end=end)[0][0] for n in range(N)])
+    assert_bits_equal(out.numpy(), exp, "playAtSpeedBetweenPointsFromPos")
+    # per-sample frequencies
+    fm = freq[None, :] * rng.uniform(0.5, 2.0, (N, V))
+    dfm = mx.DeviceBuffer.from_numpy(fm)
+    assert L.mxg_sample_render_frompos(V, N, sb.d_samples, Ls, dfm.ptr, 1, d[1].ptr, d[2].ptr, d[3].ptr, out.ptr, None) == 0
+    exp = np.stack([port.sample(8, smp, 1, pos[n], a=fm[n], start=start, end=end)[0][0] for n in range(N)])
+    assert_bits_equal(out.numpy(), exp, "playAtSpeedBetweenPointsFromPos, per-sample frequency")
+    assert L.mxg_sample_render_frompos(V, N, sb.d_samples, Ls, None, 0, d[1].ptr, d[2].ptr, d[3].ptr, out.ptr, None) == -1

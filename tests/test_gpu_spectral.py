@@ -165,6 +165,21 @@ def test_fused_fft_mfcc_vs_two_kernels_and_oracle(mx, port, nf, nc, nfr, off):
     assert_bits_equal(out3, out, "mfcc-only variant")
 
 
+def test_survey_mfcc_anchor_on_device(mx, port):
+    """SURVEY 8(c)'s anchor (third frame of sawn(220), fft 1024/512/1024, mfcc 512/42/13/20/20000) through the device
+    path: streaming maxiFFT + maxiMFCC, within the log tolerance of the recorded glibc values."""
+    sig, _, _ = port.osc(10, np.array([220.0]), 1024 * 3)
+    f = mx.maxiFFT()
+    f.setup(1024, 512, 1024)
+    assert f.process_signal(sig[:, 0].astype(np.float32)) >= 3
+    m = mx.maxiMFCC()
+    m.setup(512, 42, 13, 20.0, 20000.0)
+    out = m.mfcc(f.getMagnitudes()).numpy()
+    anchor = {0: 0.40082902638055068, 1: -0.31312622651102895, 12: 0.32965843633589265}
+    for i, v in anchor.items():
+        assert abs(out[2, i] - v) <= 1e-13
+
+
 def test_fused_fft_mfcc_tiny_and_silent_frames(mx, port):
     """Magnitudes around the sqrt's small-input branch (power < 2^-96) and all-zero frames: bit-exact magnitudes,
     zero bands stay exactly zero."""

@@ -3,14 +3,13 @@ stereo mixdown through the C-ABI vs the oracle and the golden vectors."""
 import numpy as np
 import pytest
 
-from conftest import assert_bits_equal, assert_close_scaled
+from conftest import assert_bits_equal, assert_close_scaled, mix_tol
 
 pytestmark = pytest.mark.gpu
 
 FLT = ["lores", "hires", "bandpass", "lopass", "hipass"]
 # Stated tolerances (DESIGN.md "Numerics"):
-MOD_FILTER_RTOL = 1e-9   # device cos/sqrt coefficients through a recursive filter
-MIX_RTOL = 1e-12         # tree-ordered sum over voices vs sequential sum
+MOD_FILTER_RTOL = 1e-11  # device cos/sqrt coefficients (<= 1 ULP each) through a recursive filter; measured 2.4e-13 over 128 blocks x 65536 voices (r02)
 
 
 @pytest.mark.parametrize("kind", range(5))
@@ -146,7 +145,7 @@ def test_mix_stereo(mx, port, golden):
     V = g["x"].shape[1]
     m = mx.maxiMixBank(V).stereo(mx.DeviceBuffer.from_numpy(g["x"]), g["pan"]).numpy()
     e = g["mix"]
-    assert np.abs(m - e).max() <= MIX_RTOL * np.abs(g["x"]).sum(axis=1).max()
+    assert np.abs(m - e).max() <= mix_tol(V, np.abs(g["x"]).max())
     # larger, vs the oracle, and deterministic run to run
     rng = np.random.default_rng(9)
     V, N = 5000, 130
@@ -156,13 +155,13 @@ def test_mix_stereo(mx, port, golden):
     b = mx.maxiMixBank(V).stereo(dx, pan).numpy()
     assert_bits_equal(a, b, "deterministic")
     e = port.mix_stereo(x, pan)
-    assert np.abs(a - e).max() <= MIX_RTOL * V
+    assert np.abs(a - e).max() <= mix_tol(V)
 
 
 @pytest.mark.parametrize("channels", [2, 4, 8])
 def test_mix_bus_quad_ambisonic(mx, port, channels):
     """maxiMix::stereo/quad/ambisonic (C:503-541): per-voice bus signals bit-exact (incl. the
-    ambisonic quirks: z unclamped, z>1/z<0 overwrite y, NaN for negative z); mix within 1e-12*V."""
+    ambisonic quirks: z unclamped, z>1/z<0 overwrite y, NaN for negative z); mix within conftest.mix_tol."""
     rng = np.random.default_rng(40 + channels)
     V, N = 5000, 33
     x = rng.uniform(-1, 1, (N, V))
@@ -174,7 +173,7 @@ def test_mix_bus_quad_ambisonic(mx, port, channels):
     emix, ebus = port.mix_bus(channels, x, px, py, pz, want_bus=True)
     assert_bits_equal(bus.numpy(), ebus, "bus")
     assert np.all(np.isfinite(emix))
-    np.testing.assert_allclose(mix, emix, rtol=0, atol=1e-12 * V)
+    np.testing.assert_allclose(mix, emix, rtol=0, atol=mix_tol(V, np.abs(x).max()))
     # without the bus output the mix is the same bits (same kernel shape)
     mix2 = bank.bus(channels, dx, px, py if channels >= 4 else None, pz if channels == 8 else None).numpy()
     assert_bits_equal(mix2, mix, "mix without bus")

@@ -224,3 +224,12 @@ def test_delay_sample_port_vs_reference(port, ref):
         a = port.sample(mode, smp, N, pos0, a=a_, start=st, end=en)
         b = ref.sample(mode, smp, N, pos0, a=a_, start=st, end=en)
         assert_bits_equal(a[0], b[0], SMP[mode]); assert_bits_equal(a[1], b[1], SMP[mode])
+
+
+def test_survey_mfcc_anchor(port):
+    """SURVEY 8(c)'s recorded anchor: the third frame of sawn(220) through fft.setup(1024, 512, 1024) and
+    mfcc.setup(512, 42, 13, 20, 20000) (g++ 11.4 / glibc of this image)."""
+    sig, _, _ = port.osc(10, np.array([220.0]), 1024 * 3)
+    e = port.fft_stream(sig[:, 0].astype(np.float32), 1024, 512, 1024, want=("mags",))
+    _, mf = port.mfcc(e["mags"], 42, 13, 20.0, 20000.0)
+    assert mf[2, 0] == 0.40082902638055068 and mf[2, 1] == -0.31312622651102895 and mf[2, 12] == 0.32965843633589265
