@@ -530,7 +530,7 @@ int mxg_comm_destroy(mxg_comm *comm);
 int mxg_comm_rank(const mxg_comm *comm);
 int mxg_comm_size(const mxg_comm *comm);
 /* d_recv (on `root`; on every rank when all != 0) = sum over ranks of d_send[count], in `stream` order (in place
- * allowed).  comm NULL or a one-rank communicator: a device copy. */
+ * allowed).  comm NULL: a device copy (a one-rank communicator goes through RCCL like any other). */
 int mxg_comm_reduce(mxg_comm *comm, const double *d_send, double *d_recv, size_t count, int root, int all,
                     void *stream);
 /* maxiMix bus over this rank's V voices (as mxg_mix_bus without d_bus) into d_mix [N][channels], then the sum over

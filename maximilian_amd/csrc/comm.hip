@@ -82,7 +82,7 @@ struct mxg_comm {
 };
 
 struct mxg_mixq {
-    mxg_comm *comm = nullptr;  // NULL: single GPU, the "reduce" is a device copy
+    mxg_comm *comm = nullptr;  // NULL: no communicator, the "reduce" is a device copy
     size_t block = 0;          // doubles per block (samples * channels)
     int depth = 1;             // M blocks per reduce
     int root = 0;
@@ -111,7 +111,7 @@ int mixq_submit(mxg_mixq *q, hipStream_t caller) {
     const size_t count = (size_t)q->fill * q->block;
     MXG_HIP(hipEventRecord(q->filled[b], caller));
     MXG_HIP(hipStreamWaitEvent(q->qstream, q->filled[b], 0));
-    if (q->comm && q->comm->nranks > 1) {
+    if (q->comm) {  // a one-rank communicator still goes through RCCL (the path a 1-GPU box can execute)
         MXG_NCCL(g_rccl.Reduce(q->stage[b], q->result[b], count, ncclDouble, ncclSum, q->root, q->comm->comm, q->qstream));
     } else {
         MXG_HIP(hipMemcpyAsync(q->result[b], q->stage[b], count * sizeof(double), hipMemcpyDeviceToDevice, q->qstream));
@@ -185,7 +185,7 @@ int mxg_comm_reduce(mxg_comm *c, const double *d_send, double *d_recv, size_t co
     const int nranks = c ? c->nranks : 1;
     MXG_REQUIRE(root >= 0 && root < nranks, "root outside the communicator");
     if (count == 0) return MXG_OK;
-    if (nranks == 1) {
+    if (!c) {
         if (d_recv != d_send)
             MXG_HIP(hipMemcpyAsync(d_recv, d_send, count * sizeof(double), hipMemcpyDeviceToDevice, st));
         return MXG_OK;
