@@ -496,15 +496,15 @@ double hzToMel(double hz) { return 2595.0 * (log10(hz / 700.0 + 1.0)); }       /
 double melToHz(double mel) { return 700.0 * (pow(10, mel / 2595.0) - 1.0); }  // L/maxiMFCC.h:36-38
 
 void free_device(mxg_mfcc_plan *p) {
-    void *ptrs[] = {p->d_schedW, p->d_schedFin, p->d_lo, p->d_hi, p->d_off, p->d_Wc, p->d_dct, p->d_Wpad, p->d_fsW, p->d_fsMeta};
+    void *ptrs[] = {p->d_schedW, p->d_schedFin, p->d_lo, p->d_hi, p->d_off, p->d_Wc, p->d_dct, p->d_Wpad, p->d_fs8, p->d_fs16};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     p->d_schedW = nullptr;
     p->d_schedFin = nullptr;
     p->d_lo = p->d_hi = p->d_off = nullptr;
     p->d_Wc = p->d_dct = p->d_Wpad = nullptr;
-    p->d_fsW = nullptr;
-    p->d_fsMeta = nullptr;
+    p->d_fs8 = nullptr;
+    p->d_fs16 = nullptr;
 }
 
 template <typename T>
@@ -542,8 +542,10 @@ mxg_mfcc_plan *mxg_mfcc_plan_create(unsigned numBins, unsigned numFilters, unsig
     p->d_lo = p->d_hi = p->d_off = nullptr;
     p->d_Wc = p->d_dct = p->d_Wpad = nullptr;
     p->fsSteps = 0;
-    p->d_fsW = nullptr;
-    p->d_fsMeta = nullptr;
+    p->d_fs8 = nullptr;
+    p->fs16Steps = 0;
+    p->fsMinBin = 0;
+    p->d_fs16 = nullptr;
     // ---- calcMelFilterBank (L/maxiMFCC.h:118-182): `sampleRate` is an unsigned int member
     const double sampleRate = (double)(unsigned int)settings().sampleRate;
     const double nyquist = sampleRate / 2;
@@ -656,36 +658,44 @@ mxg_mfcc_plan *mxg_mfcc_plan_create(unsigned numBins, unsigned numFilters, unsig
             }
         }
     }
-    // ---- slot schedule of the fused kernel: longest-processing-time packing of the filters into kFusedSlots lists
-    std::vector<double> fsW;
-    std::vector<int> fsMeta;
+    // ---- slot schedules of the fused kernel: longest-processing-time packing of the filters into 8 / 16 lists
+    std::vector<mxg_fs_entry> fs8, fs16;
     if (numFilters <= 64 && numCoeffs <= 32 && nbUsed <= 512) {
         std::vector<unsigned> order;
+        int minBin = (int)numBins;
         for (unsigned f = 0; f < numFilters; f++)
-            if (hi[f] >= lo[f]) order.push_back(f);
+            if (hi[f] >= lo[f]) {
+                order.push_back(f);
+                minBin = lo[f] < minBin ? lo[f] : minBin;
+            }
         std::stable_sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return hi[a] - lo[a] > hi[b] - lo[b]; });
-        std::vector<std::vector<unsigned>> lists(kFusedSlots);
-        std::vector<int> load(kFusedSlots, 0);
-        for (unsigned f : order) {
-            int s = 0;
-            for (int k = 1; k < kFusedSlots; k++)
-                if (load[k] < load[s]) s = k;
-            lists[s].push_back(f);
-            load[s] += hi[f] - lo[f] + 1;
-        }
-        int T = 1;
-        for (int s = 0; s < kFusedSlots; s++) T = load[s] > T ? load[s] : T;
-        fsW.assign((size_t)T * kFusedSlots, 0.0);
-        fsMeta.assign((size_t)T * kFusedSlots, 0);
-        for (int s = 0; s < kFusedSlots; s++) {
-            int t = 0;
-            for (unsigned f : lists[s])
-                for (int bin = lo[f]; bin <= hi[f]; bin++, t++) {
-                    fsW[(size_t)t * kFusedSlots + s] = p->h_W[f + (size_t)bin * numFilters];
-                    fsMeta[(size_t)t * kFusedSlots + s] = bin | (bin == hi[f] ? (int)(f + 1) << 16 : 0);
-                }
-        }
-        p->fsSteps = T;
+        auto pack = [&](int slots, std::vector<mxg_fs_entry> &tab) {
+            std::vector<std::vector<unsigned>> lists(slots);
+            std::vector<int> load(slots, 0);
+            for (unsigned f : order) {
+                int s = 0;
+                for (int k = 1; k < slots; k++)
+                    if (load[k] < load[s]) s = k;
+                lists[s].push_back(f);
+                load[s] += hi[f] - lo[f] + 1;
+            }
+            int T = 1;
+            for (int s = 0; s < slots; s++) T = load[s] > T ? load[s] : T;
+            T = (T + kMelBatch - 1) / kMelBatch * kMelBatch;
+            // padding steps (after a list's last filter, and the two look-ahead batches): weight 0 on a bin that is always formed
+            const mxg_fs_entry pad = {0.0, (order.empty() ? 1 : minBin) * 4, 0};
+            tab.assign((size_t)(T + 2 * kMelBatch) * slots, pad);
+            for (int s = 0; s < slots; s++) {
+                int t = 0;
+                for (unsigned f : lists[s])
+                    for (int bin = lo[f]; bin <= hi[f]; bin++, t++)
+                        tab[(size_t)t * slots + s] = {p->h_W[f + (size_t)bin * numFilters], bin * 4, bin == hi[f] ? (int)(f + 1) : 0};
+            }
+            return T;
+        };
+        p->fsSteps = pack(kFusedSlots, fs8);
+        p->fs16Steps = pack(kFusedSlots16, fs16);
+        p->fsMinBin = order.empty() ? 1 : minBin;
     }
     p->nfPad = (numFilters + 15) / 16 * 16;
     p->kPad = (nbUsed + 3) / 4 * 4;  // rows >= numBins carry zero weights; the kernel guards the A read
@@ -697,8 +707,8 @@ mxg_mfcc_plan *mxg_mfcc_plan_create(unsigned numBins, unsigned numFilters, unsig
         for (unsigned f = 0; f < numFilters; f++) Wpad[(size_t)bin * p->nfPad + f] = p->h_W[f + (size_t)bin * numFilters];
     if (ensure_init() || !upload(&p->d_lo, lo) || !upload(&p->d_hi, hi) || !upload(&p->d_off, off) ||
         !upload(&p->d_Wc, Wc) || !upload(&p->d_dct, dctT) || !upload(&p->d_Wpad, Wpad) ||
-        !upload(&p->d_schedW, schedW) || !upload(&p->d_schedFin, schedFin) || !upload(&p->d_fsW, fsW) ||
-        !upload(&p->d_fsMeta, fsMeta)) {
+        !upload(&p->d_schedW, schedW) || !upload(&p->d_schedFin, schedFin) || !upload(&p->d_fs8, fs8) ||
+        !upload(&p->d_fs16, fs16)) {
         // Host tables stay valid (mxg_mfcc_plan_tables works without a device); compute calls fail.
         free_device(p);
     }

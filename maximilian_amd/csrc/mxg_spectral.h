@@ -21,6 +21,11 @@ struct mxg_ifft_plan {
     float2 *d_tw;     // inverse-direction stage twiddles, same indexing as mxg_fft_plan::d_tw
 };
 
+struct mxg_fs_entry {  // one step of one slot of the 16-slot mel walk (16 bytes: one ds_read_b128)
+    double w;
+    int off, fid;
+};
+
 struct mxg_mfcc_plan {
     unsigned numBins, numFilters, numCoeffs, nbUsed;  // nbUsed = 1 + last bin with a non-zero weight
     std::vector<double> h_W;    // [filter + bin*numFilters]  (reference layout)
@@ -33,15 +38,19 @@ struct mxg_mfcc_plan {
     double *d_dct;              // [j*numCoeffs + i]
     double *d_Wpad;             // dense [kPad][nfPad] row-major by bin, for the MFMA path
     unsigned nfPad, kPad;
-    // Slot schedule of the fused FFT+MFCC kernel (spectral.hip): the filters are packed into kFusedSlots lists of about
-    // equal total support length; list s is walked one bin per step, so step t of slot s is (bin, weight, filter that
-    // ends here or -1).  fsSteps = the longest list (shorter ones are padded with weight-0 steps AFTER their last
-    // filter).  fsSteps == 0: the fused kernel is not applicable to this bank.
-    int fsSteps;
-    double *d_fsW;              // [fsSteps][kFusedSlots]
-    int *d_fsMeta;              // [fsSteps][kFusedSlots]: bin | (filter + 1) << 16 on the last bin of a filter
+    // Slot schedules of the fused FFT+MFCC kernels (spectral.hip): the filters are packed into kFusedSlots (8-wave form) and
+    // kFusedSlots16 (16-wave form) lists of about equal total support length; list s is walked one bin per step, so step t of
+    // slot s is the entry {weight, byte offset of the bin in a magnitude row, filter + 1 on the last bin of a filter else 0}.
+    // fsSteps / fs16Steps = the longest list rounded up to kMelBatch; shorter lists are padded AFTER their last filter, and two
+    // look-ahead batches of padding rows follow (weight 0 on bin fsMinBin).  fsSteps == 0: the fused kernel does not apply.
+    int fsSteps, fs16Steps;
+    mxg_fs_entry *d_fs8;   // [fsSteps + 2 * kMelBatch][kFusedSlots]
+    mxg_fs_entry *d_fs16;  // [fs16Steps + 2 * kMelBatch][kFusedSlots16]
+    int fsMinBin;          // lowest bin any filter reads (>= 1: bin 0 is then never formed)
 };
 constexpr int kFusedSlots = 8;
+constexpr int kFusedSlots16 = 16;
+constexpr int kMelBatch = 4;
 
 namespace mxg {
 namespace {
@@ -89,17 +98,68 @@ constexpr int kX1024 = 512 + 64;
 
 __device__ __forceinline__ int pad8(int i) { return i + (i >> 3); }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// TWO butterflies (L/fft.cpp:184-192 each) as ten packed instructions -- the reference's ten roundings per butterfly, none
+// fused -- with the operand swizzles and sign flips done by the VOP3P modifiers instead of register moves:
+//   p = (w.x*k.x, w.x*k.y)    q = (-(w.y*k.y), w.y*k.x)    t = p + q = (tr, ti)    k = j - t    j = j + t
+// (a - b and a + (-b) are the same IEEE operation and the sign of a product is exact, so these are the reference's bits.)
+// hipcc's own packing of bfly() spends 7-8 instructions per butterfly (both a - b and a + b are formed as packed pairs
+// and one half of each is kept with a v_mov).  gfx950 needs one wait state between a packed write and a read of the
+// result: inside the block the two butterflies are interleaved so no dependent pair is adjacent; the s_nop at either end
+// covers whatever the compiler schedules next to the block.
+#define MXG_BFLY2_BODY(WC)                                                                                                \
+    v2f p1, q1, p2, q2;                                                                                                   \
+    asm("s_nop 0\n\t"                                                                                                     \
+        "v_pk_mul_f32 %[p1], %[w1], %[k1] op_sel_hi:[0,1]\n\t"                                                            \
+        "v_pk_mul_f32 %[q1], %[w1], %[k1] op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]\n\t"                                  \
+        "v_pk_mul_f32 %[p2], %[w2], %[k2] op_sel_hi:[0,1]\n\t"                                                            \
+        "v_pk_mul_f32 %[q2], %[w2], %[k2] op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]\n\t"                                  \
+        "v_pk_add_f32 %[p1], %[p1], %[q1]\n\t"                                                                            \
+        "v_pk_add_f32 %[p2], %[p2], %[q2]\n\t"                                                                            \
+        "v_pk_add_f32 %[k1], %[j1], %[p1] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                                  \
+        "v_pk_add_f32 %[j1], %[j1], %[p1]\n\t"                                                                            \
+        "v_pk_add_f32 %[k2], %[j2], %[p2] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                                  \
+        "v_pk_add_f32 %[j2], %[j2], %[p2]\n\t"                                                                            \
+        "s_nop 0"                                                                                                         \
+        : [j1] "+v"(j1), [k1] "+v"(k1), [j2] "+v"(j2), [k2] "+v"(k2), [p1] "=&v"(p1), [q1] "=&v"(q1), [p2] "=&v"(p2),     \
+          [q2] "=&v"(q2)                                                                                                  \
+        : [w1] WC(w1), [w2] WC(w2))
+__device__ __forceinline__ void bfly2(v2f &j1, v2f &k1, const v2f w1, v2f &j2, v2f &k2, const v2f w2) { MXG_BFLY2_BODY("v"); }
+// the same with wave-uniform twiddles held in scalar register pairs (each instruction reads one of them: one constant-bus operand)
+__device__ __forceinline__ void bfly2_s(v2f &j1, v2f &k1, const v2f w1, v2f &j2, v2f &k2, const v2f w2) { MXG_BFLY2_BODY("s"); }
+#undef MXG_BFLY2_BODY
+
+__device__ __forceinline__ v2f as_v2f(const float2 a) { return v2f{a.x, a.y}; }
+
 // three in-register radix-2 stages over the 8 points of a lane; w0: 1 twiddle (pairs e,e+1),
 // w1[2]: pairs (e,e+2) with n-offset e&1, w2[4]: pairs (e,e+4) with n-offset e&3.
-__device__ __forceinline__ void round3(float2 (&x)[8], const float2 w0, const float2 (&w1)[2],
-                                       const float2 (&w2)[4]) {
+__device__ __forceinline__ void round3(v2f (&x)[8], const v2f w0, const v2f (&w1)[2], const v2f (&w2)[4]) {
+    bfly2(x[0], x[1], w0, x[2], x[3], w0);
+    bfly2(x[4], x[5], w0, x[6], x[7], w0);
+    bfly2(x[0], x[2], w1[0], x[1], x[3], w1[1]);
+    bfly2(x[4], x[6], w1[0], x[5], x[7], w1[1]);
+    bfly2(x[0], x[4], w2[0], x[1], x[5], w2[1]);
+    bfly2(x[2], x[6], w2[2], x[3], x[7], w2[3]);
+}
+// round 1 of K6a: the seven twiddles are the same for every lane (scalar registers)
+__device__ __forceinline__ void round3_s(v2f (&x)[8], const v2f (&w)[7]) {
+    bfly2_s(x[0], x[1], w[0], x[2], x[3], w[0]);
+    bfly2_s(x[4], x[5], w[0], x[6], x[7], w[0]);
+    bfly2_s(x[0], x[2], w[1], x[1], x[3], w[2]);
+    bfly2_s(x[4], x[6], w[1], x[5], x[7], w[2]);
+    bfly2_s(x[0], x[4], w[3], x[1], x[5], w[4]);
+    bfly2_s(x[2], x[6], w[5], x[3], x[7], w[6]);
+}
+__device__ __forceinline__ void round3(float2 (&x)[8], const float2 w0, const float2 (&w1)[2], const float2 (&w2)[4]) {
+    v2f y[8];
 #pragma unroll
-    for (int e = 0; e < 8; e += 2) bfly(x[e], x[e + 1], w0);
+    for (int e = 0; e < 8; e++) y[e] = as_v2f(x[e]);
+    const v2f u1[2] = {as_v2f(w1[0]), as_v2f(w1[1])};
+    const v2f u2[4] = {as_v2f(w2[0]), as_v2f(w2[1]), as_v2f(w2[2]), as_v2f(w2[3])};
+    round3(y, as_v2f(w0), u1, u2);
 #pragma unroll
-    for (int e = 0; e < 8; e++)
-        if ((e & 2) == 0) bfly(x[e], x[e + 2], w1[e & 1]);
-#pragma unroll
-    for (int e = 0; e < 4; e++) bfly(x[e], x[e + 4], w2[e]);
+    for (int e = 0; e < 8; e++) x[e] = make_float2(y[e].x, y[e].y);
 }
 
 // log-square of L/maxiMFCC.cpp:63

@@ -40,6 +40,7 @@ Tune g_tune[] = {
     {"grain_fast_sched", 1, 0, 1},  // K8a: event-driven exact multi-step scheduler (0: one step at a time)
     {"grain_slices", 4, 1, 16},  // K8a/K8c: time slices of a maxiTimeStretch call (scheduling of slice i+1 overlaps render of slice i)
     {"mfcc_mfma_fullk", 0, 0, 1},  // K7b: contract over all numBins bins (1) instead of the bins that carry weight
+    {"fused_waves16", 0, 0, 1},  // K67: 1 = the 16-waves-per-CU form of the fused FFT+MFCC kernel when applicable (measured slower: 1.72 vs 1.51 ms)
     {"mfcc_tiled", 1, 0, 1},  // K7a-t: stage spectra through LDS tiles (0: per-lane row loads, K7a)
 };
 }  // namespace

@@ -55,184 +55,339 @@ __device__ __forceinline__ float2 post_lo(const float2 a, const float2 b, const 
     return r;
 }
 
+// post_lo for TWO pairs, squares of the results: q = (r.x*r.x, r.y*r.y) with r = post_lo(a, b, w) -- the same operations in
+// the same order (h1 = 0.5*(a.x+b.x, a.y-b.y); h2 = (0.5*(a.y+b.y), -0.5*(a.x-b.x)); r = (h1 + w.x*h2) -/+ w.y*h2 swapped),
+// 9 packed instructions per pair with the swizzles and signs in the VOP3P modifiers (see bfly2 in mxg_spectral.h; a
+// source negation is exact, and -0.5*d == 0.5*(-d)).  The 0.5 is an inline constant read from the low half for both lanes.
+__device__ __forceinline__ void post_lo_sq2(const v2f a1, const v2f b1, const v2f w1, const v2f a2, const v2f b2, const v2f w2,
+                                            v2f &q1, v2f &q2) {
+    v2f s1, t1, s2, t2, m1, n1, m2, n2;
+    asm("s_nop 0\n\t"
+        "v_pk_add_f32 %[s1], %[a1], %[b1] neg_hi:[0,1]\n\t"                              // (a.x+b.x, a.y-b.y)
+        "v_pk_add_f32 %[t1], %[a1], %[b1] op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[0,1]\n\t" // (a.y+b.y, a.x-b.x)
+        "v_pk_add_f32 %[s2], %[a2], %[b2] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[t2], %[a2], %[b2] op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[s1], %[s1], 0.5 op_sel_hi:[1,0]\n\t"                             // h1
+        "v_pk_mul_f32 %[t1], %[t1], 0.5 op_sel_hi:[1,0] neg_hi:[1,0]\n\t"                // h2 = (h2r, h2i)
+        "v_pk_mul_f32 %[s2], %[s2], 0.5 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %[t2], %[t2], 0.5 op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %[m1], %[w1], %[t1] op_sel_hi:[0,1]\n\t"                           // (wr*h2r, wr*h2i)
+        "v_pk_mul_f32 %[n1], %[w1], %[t1] op_sel:[1,1] op_sel_hi:[1,0]\n\t"              // (wi*h2i, wi*h2r)
+        "v_pk_mul_f32 %[m2], %[w2], %[t2] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[n2], %[w2], %[t2] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %[s1], %[s1], %[m1]\n\t"                                           // (h1r + wr*h2r, h1i + wr*h2i)
+        "v_pk_add_f32 %[s2], %[s2], %[m2]\n\t"
+        "v_pk_add_f32 %[s1], %[s1], %[n1] neg_lo:[0,1]\n\t"                              // (.. - wi*h2i, .. + wi*h2r)
+        "v_pk_add_f32 %[s2], %[s2], %[n2] neg_lo:[0,1]\n\t"
+        "v_pk_mul_f32 %[q1], %[s1], %[s1]\n\t"
+        "v_pk_mul_f32 %[q2], %[s2], %[s2]\n\t"
+        "s_nop 0"
+        : [s1] "=&v"(s1), [t1] "=&v"(t1), [s2] "=&v"(s2), [t2] "=&v"(t2), [m1] "=&v"(m1), [n1] "=&v"(n1), [m2] "=&v"(m2),
+          [n2] "=&v"(n2), [q1] "=&v"(q1), [q2] "=&v"(q2)
+        : [a1] "v"(a1), [b1] "v"(b1), [w1] "v"(w1), [a2] "v"(a2), [b2] "v"(b2), [w2] "v"(w2));
+}
+
+// One coefficient of the DCT (L/maxiMFCC.h:98-111): c = sum_j dct[j][i] * band[j], j ascending -- the reference's sequential
+// sum.  The table and band values of eight terms are requested before the first is used and the next eight before these are
+// consumed: as a plain loop hipcc waits for every pair of LDS reads (one exposed LDS latency per term; for 42 filters x 13
+// coefficients that was a quarter of the fused kernel's time).
+__device__ __forceinline__ double dct_dot(const double *d, const unsigned dstride, const double *m, const unsigned nf) {
+    constexpr int U = 8;
+    double c = 0.0, dv[U], mv[U];
+    const unsigned full = nf / U * U;
+    if (full) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            dv[u] = d[u * dstride];
+            mv[u] = m[u];
+        }
+    }
+    for (unsigned jf = 0; jf < full; jf += U) {
+        double dn[U], mn[U];
+        const unsigned nxt = jf + U < full ? jf + U : jf;  // the last batch re-reads itself (unused)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            dn[u] = d[(nxt + u) * dstride];
+            mn[u] = m[nxt + u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) c += (dv[u] * mv[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            dv[u] = dn[u];
+            mv[u] = mn[u];
+        }
+    }
+    for (unsigned jf = full; jf < nf; jf++) c += (d[jf * dstride] * m[jf]);
+    return c;
+}
+
+// The mel walk of one wavefront: lane = (frame of the group, slot); the slot's filter list is walked one table entry per step,
+// so every band sum is the reference's sequential sum over the filter's support in increasing bin order (L/maxiMFCC.cpp:52-60;
+// terms outside the support are exact +0.0 in the reference: bit-identical, see mfcc.hip).  An entry is one ds_read_b128, a
+// magnitude one LDS gather; the loop is software-pipelined two batches deep (entries two batches ahead, gathers one) so no
+// LDS latency sits between the dependent fp64 adds.  `fs` points at the slot's column of a table with `steps` rows
+// (a multiple of kMelBatch) + two batches of padding rows.
+template <int SLOTS>
+__device__ __forceinline__ void mel_walk(const char *Mrow, double *melrow, const mxg_fs_entry *fs, const int steps) {
+    double acc = 0.0;  // L/maxiMFCC.cpp:52
+    mxg_fs_entry cur[kMelBatch], nx[kMelBatch];
+    float x[kMelBatch];
+#pragma unroll
+    for (int i = 0; i < kMelBatch; i++) cur[i] = fs[i * SLOTS];
+#pragma unroll
+    for (int i = 0; i < kMelBatch; i++) x[i] = *reinterpret_cast<const float *>(Mrow + cur[i].off);
+#pragma unroll
+    for (int i = 0; i < kMelBatch; i++) nx[i] = fs[(kMelBatch + i) * SLOTS];
+    for (int t0 = 0; t0 < steps; t0 += kMelBatch) {
+        float xn[kMelBatch];
+        mxg_fs_entry nn[kMelBatch];
+#pragma unroll
+        for (int i = 0; i < kMelBatch; i++) xn[i] = *reinterpret_cast<const float *>(Mrow + nx[i].off);
+#pragma unroll
+        for (int i = 0; i < kMelBatch; i++) nn[i] = fs[(t0 + 2 * kMelBatch + i) * SLOTS];
+#pragma unroll
+        for (int i = 0; i < kMelBatch; i++) {
+            acc += (cur[i].w * (double)x[i]);  // L/maxiMFCC.cpp:57
+            if (cur[i].fid) {
+                melrow[cur[i].fid - 1] = acc;
+                acc = 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kMelBatch; i++) {
+            cur[i] = nx[i];
+            x[i] = xn[i];
+            nx[i] = nn[i];
+        }
+    }
+}
+
 struct FusedArgs {
     const float *signal;
     size_t frame_stride, nframes;
     const float *window;
     const float2 *tw, *post;
-    unsigned numFilters, numCoeffs, nbUsed, mstride, nfp;
+    unsigned numFilters, numCoeffs, nbUsed, mstride, nfp, dctPad;
     int steps;
-    const double *fsW;
-    const int *fsMeta;
+    int edgeBins;  // the bank reads bin 0 or bin 256 (or the magnitudes are written out): form them
+    const mxg_fs_entry *fs;
     const double *dct;
     float *mags;
     double *melraw, *melbands, *mfcc;
 };
 
 // FULL: magnitudes of all 512 bins are needed (written out, or the bank reaches beyond bin 256)
+//
+// Two frames are in flight per wavefront (A, B: two X images in LDS, two register sets): between two LDS round trips the
+// kernel issues the same phase of both frames, so frame B's transpose latency is covered by frame A's butterflies and vice
+// versa -- at two waves per SIMD nothing else would cover it (measured: 34 % of wave cycles waiting on a counter, LDS pipe
+// 61 % busy with the twiddles still in LDS).  The 21 stage twiddles a lane needs never change: rounds 2 and 3 hold theirs in
+// 28 VGPRs, round 1's seven are wave-uniform and live in SGPRs; LDS carries only the transposes, the magnitude rows and the
+// mel tables.
 template <bool FULL, bool WRITE_MAGS, bool ALIGNED8>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const FusedArgs A) {
     extern __shared__ double s_dyn[];
-    // [tw 512 float2][fsW steps*8 f64][dct NF*NC f64][fsMeta steps*8 i32] | per wave: X, mel, M
-    float2 *s_tw = reinterpret_cast<float2 *>(s_dyn);
-    double *s_w = reinterpret_cast<double *>(s_tw + 512);
-    double *s_d = s_w + (size_t)A.steps * kFusedSlots;
-    int *s_meta = reinterpret_cast<int *>(s_d + (size_t)A.numFilters * A.numCoeffs);
-    const size_t metaInts = ((size_t)A.steps * kFusedSlots + 3) & ~(size_t)3;
+    // [fs (steps + 2 batches) * 8 entries][dct NF*NC f64, padded to 16 B] | per wave: XA (= band rows), XB, M
+    mxg_fs_entry *s_fs = reinterpret_cast<mxg_fs_entry *>(s_dyn);
+    const int fsRows = A.steps + 2 * kMelBatch;
+    double *s_d = reinterpret_cast<double *>(s_fs + (size_t)fsRows * kFusedSlots);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t perWaveBytes = sizeof(float2) * kX1024 + sizeof(float) * kGroup * A.mstride + sizeof(double) * kGroup * A.nfp;
-    char *wbase = reinterpret_cast<char *>(s_meta + metaInts) + (size_t)wave * perWaveBytes;
-    float2 *X = reinterpret_cast<float2 *>(wbase);
-    double *s_mel = reinterpret_cast<double *>(wbase + sizeof(float2) * kX1024);
-    float *M = reinterpret_cast<float *>(wbase + sizeof(float2) * kX1024 + sizeof(double) * kGroup * A.nfp);
-    for (int i = threadIdx.x; i < 511; i += blockDim.x) s_tw[i] = A.tw[i];
-    for (int i = threadIdx.x; i < A.steps * kFusedSlots; i += blockDim.x) {
-        s_w[i] = A.fsW[i];
-        s_meta[i] = A.fsMeta[i];
-    }
+    const size_t perWaveBytes = 2 * sizeof(float2) * kX1024 + sizeof(float) * kGroup * A.mstride;
+    char *wbase = reinterpret_cast<char *>(s_d + A.dctPad) + (size_t)wave * perWaveBytes;
+    v2f *XA = reinterpret_cast<v2f *>(wbase), *XB = XA + kX1024;
+    double *s_mel = reinterpret_cast<double *>(wbase);  // the band rows live on XA between the last post-pass and the next frame
+    float *M = reinterpret_cast<float *>(wbase + 2 * sizeof(float2) * kX1024);
+    for (int i = threadIdx.x; i < fsRows * kFusedSlots; i += blockDim.x) s_fs[i] = A.fs[i];
     for (unsigned i = threadIdx.x; i < A.numFilters * A.numCoeffs; i += blockDim.x) s_d[i] = A.dct[i];
-    for (unsigned i = lane; i < kGroup * A.nfp; i += 64) s_mel[i] = 0.0;  // filters with an empty support stay 0
     __syncthreads();
 
     const int lo = lane & 7, hi = lane >> 3;
     const int rev6 = (int)(__brev((unsigned)lane) >> 26);
-    float2 wv[8];
+    v2f wv[8];
     unsigned li[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         const int rev3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);
         li[e] = 2u * (unsigned)(rev3 * 64 + rev6);
-        wv[e] = make_float2(A.window[li[e]], A.window[li[e] + 1]);
+        wv[e] = v2f{A.window[li[e]], A.window[li[e] + 1]};
     }
-    asm volatile("" : "+v"(wv[0].x), "+v"(wv[0].y), "+v"(wv[1].x), "+v"(wv[1].y), "+v"(wv[2].x), "+v"(wv[2].y),
-                 "+v"(wv[3].x), "+v"(wv[3].y));
-    asm volatile("" : "+v"(wv[4].x), "+v"(wv[4].y), "+v"(wv[5].x), "+v"(wv[5].y), "+v"(wv[6].x), "+v"(wv[6].y),
-                 "+v"(wv[7].x), "+v"(wv[7].y));
+    // stage twiddles (L/fft.cpp:161-182 replayed on the host): round 1 wave-uniform, rounds 2 / 3 per lane
+    v2f ta[7], tb[7], tc[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const float2 t = A.tw[i];
+        ta[i].x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(t.x)));
+        ta[i].y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(t.y)));
+    }
+    {
+        const int bi[7] = {7, 15, 23, 31, 39, 47, 55}, ci[7] = {63, 127, 191, 255, 319, 383, 447};
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            tb[i] = as_v2f(A.tw[bi[i] + lo]);
+            tc[i] = as_v2f(A.tw[ci[i] + lane]);
+        }
+    }
     // post-pass: twiddles of this lane's four pairs in registers; LDS slots of the pairs (i, 512 - i), i = 1 + lane + 64q,
     // are one base each plus a compile-time offset: pad8(i0 + 64q) = pad8(i0) + 72q
-    float2 pw[4];
+    v2f pw[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) pw[q] = A.post[(1 + lane + 64 * q) < 256 ? 1 + lane + 64 * q : 255];
-    asm volatile("" : "+v"(pw[0].x), "+v"(pw[0].y), "+v"(pw[1].x), "+v"(pw[1].y), "+v"(pw[2].x), "+v"(pw[2].y),
-                 "+v"(pw[3].x), "+v"(pw[3].y));
+    for (int q = 0; q < 4; q++) pw[q] = as_v2f(A.post[(1 + lane + 64 * q) < 256 ? 1 + lane + 64 * q : 255]);
+    // every loop-invariant table value is consumed here: a use inside the loop would let hipcc re-load it per frame
+#pragma unroll
+    for (int e = 0; e < 8; e++) asm volatile("" : "+v"(wv[e]));
+#pragma unroll
+    for (int i = 0; i < 7; i++) asm volatile("" : "+v"(tb[i]), "+v"(tc[i]));
+#pragma unroll
+    for (int q = 0; q < 4; q++) asm volatile("" : "+v"(pw[q]));
     const int pa0 = pad8(1 + lane), pb0 = pad8(511 - lane);
     const int zidx = lane == 0 ? 0 : 256;  // lanes 0 / 63 also own bin 0 / the middle bin
     const size_t nframes = A.nframes;
-    auto load_frame = [&](size_t fr, float2 (&dst)[8]) {
+    auto load_frame = [&](size_t fr, v2f (&dst)[8]) {
         const unsigned fu = __builtin_amdgcn_readfirstlane((unsigned)(fr < nframes ? fr : nframes - 1));
         const float *x = A.signal + (size_t)fu * A.frame_stride;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             if constexpr (ALIGNED8) {
-                dst[e] = *reinterpret_cast<const float2 *>(x + li[e]);
+                dst[e] = *reinterpret_cast<const v2f *>(x + li[e]);
             } else {
                 dst[e].x = x[li[e]];
                 dst[e].y = x[li[e] + 1];
             }
         }
     };
+    // real split post-pass (L/fft.cpp:245-275) + magnitudes (cartToPol :510-511) of one frame into its row of the tile
+    // bin 0 packs DC and Nyquist (L/fft.cpp:274-275); bin 256 passes through untouched
+    auto post_edge = [&](const v2f *X, const int j, const size_t f0) {
+        float *Mrow = M + j * A.mstride;
+        const v2f z = X[pad8(zidx)];
+        const float zr = lane == 0 ? z.x + z.y : z.x, zi = lane == 0 ? z.x - z.y : z.y;
+        const float mz = exact_sqrtf(zr * zr + zi * zi);
+        if (lane == 0 || lane == 63) {
+            Mrow[zidx] = mz;
+            if constexpr (WRITE_MAGS)
+                if (f0 + (size_t)j < nframes)
+                    A.mags[(size_t)__builtin_amdgcn_readfirstlane((unsigned)(f0 + j)) * 512 + zidx] = mz;
+        }
+    };
+    // the full post-pass (both halves of every pair) + magnitudes of one frame, for the launches that need all 512 bins
+    auto post_frame = [&](const v2f *X, const int j, const size_t f0) {
+        float *Mrow = M + j * A.mstride;
+        const bool frame_live = f0 + (size_t)j < nframes;  // wave-uniform
+        float *grow = nullptr;
+        if constexpr (WRITE_MAGS)
+            grow = A.mags + (size_t)__builtin_amdgcn_readfirstlane((unsigned)(f0 + j < nframes ? f0 + j : nframes - 1)) * 512;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const v2f xa = X[pa0 + 72 * q], xb = X[pb0 - 72 * q];
+            float2 a = make_float2(xa.x, xa.y), b = make_float2(xb.x, xb.y);
+            post_pair(a, b, make_float2(pw[q].x, pw[q].y));
+            const float ma = exact_sqrtf(a.x * a.x + a.y * a.y), mb = exact_sqrtf(b.x * b.x + b.y * b.y);
+            if (q < 3 || lane < 63) {
+                Mrow[1 + lane + 64 * q] = ma;
+                Mrow[511 - lane - 64 * q] = mb;
+                if constexpr (WRITE_MAGS)
+                    if (frame_live) {
+                        grow[1 + lane + 64 * q] = ma;
+                        grow[511 - lane - 64 * q] = mb;
+                    }
+            }
+        }
+        post_edge(X, j, f0);
+    };
     const size_t ngroups = (nframes + kGroup - 1) / kGroup;
     const size_t gstep = (size_t)gridDim.x * kWavesPerBlock;
     const size_t g0 = (size_t)blockIdx.x * kWavesPerBlock + wave;
-    float2 nxt[8];
-    load_frame(g0 * kGroup, nxt);
+    v2f nA[8], nB[8];
+    load_frame(g0 * kGroup, nA);
+    load_frame(g0 * kGroup + 1, nB);
     const int mj = lane >> 3, ms = lane & 7;  // mel walk: frame of the group, slot
+    const v2f b1[2] = {tb[1], tb[2]}, b2[4] = {tb[3], tb[4], tb[5], tb[6]};
+    const v2f c1[2] = {tc[1], tc[2]}, c2[4] = {tc[3], tc[4], tc[5], tc[6]};
     for (size_t g = g0; g < ngroups; g += gstep) {
         const size_t f0 = g * kGroup;
 #pragma unroll 1
-        for (int j = 0; j < kGroup; j++) {
-            float2 v[8];
+        for (int j = 0; j < kGroup; j += 2) {
+            v2f vA[8], vB[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                v[e].x = nxt[e].x * wv[e].x;  // calcFFT L/fft.cpp:501-503
-                v[e].y = nxt[e].y * wv[e].y;
+                vA[e] = nA[e] * wv[e];  // calcFFT L/fft.cpp:501-503
+                vB[e] = nB[e] * wv[e];
             }
-            load_frame(j + 1 < kGroup ? f0 + j + 1 : (g + gstep) * kGroup, nxt);
-            const float2 a0 = s_tw[0];
-            const float2 a1[2] = {s_tw[1], s_tw[2]};
-            const float2 a2[4] = {s_tw[3], s_tw[4], s_tw[5], s_tw[6]};
-            const float2 b0 = s_tw[7 + lo];
-            const float2 b1[2] = {s_tw[15 + lo], s_tw[15 + 8 + lo]};
-            const float2 b2[4] = {s_tw[31 + lo], s_tw[31 + 8 + lo], s_tw[31 + 16 + lo], s_tw[31 + 24 + lo]};
-            const float2 c0 = s_tw[63 + lane];
-            const float2 c1[2] = {s_tw[127 + lane], s_tw[127 + 64 + lane]};
-            const float2 c2[4] = {s_tw[255 + lane], s_tw[255 + 64 + lane], s_tw[255 + 128 + lane], s_tw[255 + 192 + lane]};
-            round3(v, a0, a1, a2);
+            const size_t fnext = j + 2 < kGroup ? f0 + j + 2 : (g + gstep) * kGroup;
+            load_frame(fnext, nA);
+            load_frame(fnext + 1, nB);
+            round3_s(vA, ta);
+            round3_s(vB, ta);
 #pragma unroll
-            for (int e = 0; e < 8; e++) X[pad8(8 * lane + e)] = v[e];
+            for (int e = 0; e < 8; e++) XA[pad8(8 * lane + e)] = vA[e];
+#pragma unroll
+            for (int e = 0; e < 8; e++) XB[pad8(8 * lane + e)] = vB[e];
             wave_lds_sync();
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = X[pad8(hi * 64 + e * 8 + lo)];
-            round3(v, b0, b1, b2);
+            for (int e = 0; e < 8; e++) vA[e] = XA[pad8(hi * 64 + e * 8 + lo)];
+#pragma unroll
+            for (int e = 0; e < 8; e++) vB[e] = XB[pad8(hi * 64 + e * 8 + lo)];
+            __builtin_amdgcn_sched_barrier(0);  // both frames' reads are in flight before the first butterfly waits
+            round3(vA, tb[0], b1, b2);
+            round3(vB, tb[0], b1, b2);
             wave_lds_sync();
 #pragma unroll
-            for (int e = 0; e < 8; e++) X[pad8(hi * 64 + e * 8 + lo)] = v[e];
+            for (int e = 0; e < 8; e++) XA[pad8(hi * 64 + e * 8 + lo)] = vA[e];
+#pragma unroll
+            for (int e = 0; e < 8; e++) XB[pad8(hi * 64 + e * 8 + lo)] = vB[e];
             wave_lds_sync();
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = X[pad8(e * 64 + lane)];
-            round3(v, c0, c1, c2);
+            for (int e = 0; e < 8; e++) vA[e] = XA[pad8(e * 64 + lane)];
+#pragma unroll
+            for (int e = 0; e < 8; e++) vB[e] = XB[pad8(e * 64 + lane)];
+            __builtin_amdgcn_sched_barrier(0);
+            round3(vA, tc[0], c1, c2);
+            round3(vB, tc[0], c1, c2);
             wave_lds_sync();
 #pragma unroll
-            for (int e = 0; e < 8; e++) X[pad8(e * 64 + lane)] = v[e];
-            wave_lds_sync();
-            // real split post-pass (L/fft.cpp:245-275) + magnitudes (cartToPol :510-511) into the tile row of frame j
-            float *Mrow = M + j * A.mstride;
-            const bool frame_live = f0 + (size_t)j < nframes;  // wave-uniform
-            float *grow = nullptr;
-            if constexpr (WRITE_MAGS)
-                grow = A.mags + (size_t)__builtin_amdgcn_readfirstlane((unsigned)(f0 + j < nframes ? f0 + j : nframes - 1)) * 512;
+            for (int e = 0; e < 8; e++) XA[pad8(e * 64 + lane)] = vA[e];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float2 xa = X[pa0 + 72 * q], xb = X[pb0 - 72 * q];
-                const bool own = q < 3 || lane < 63;  // lane 63's fourth pair would be bin 256: handled below
-                if constexpr (FULL) {
-                    float2 a = xa, b = xb;
-                    post_pair(a, b, pw[q]);
-                    const float ma = exact_sqrtf(a.x * a.x + a.y * a.y), mb = exact_sqrtf(b.x * b.x + b.y * b.y);
-                    if (own) {
-                        Mrow[1 + lane + 64 * q] = ma;
-                        Mrow[511 - lane - 64 * q] = mb;
-                        if constexpr (WRITE_MAGS)
-                            if (frame_live) {
-                                grow[1 + lane + 64 * q] = ma;
-                                grow[511 - lane - 64 * q] = mb;
-                            }
+            for (int e = 0; e < 8; e++) XB[pad8(e * 64 + lane)] = vB[e];
+            wave_lds_sync();
+            if constexpr (!FULL) {
+                // low half of the post-pass for both frames: all sixteen LDS reads are requested before the first is used
+                v2f pa[2][4], pb[2][4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    pa[0][q] = XA[pa0 + 72 * q];
+                    pb[0][q] = XA[pb0 - 72 * q];
+                    pa[1][q] = XB[pa0 + 72 * q];
+                    pb[1][q] = XB[pb0 - 72 * q];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
+                    float *Mrow = M + (j + f) * A.mstride;
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2) {
+                        v2f sq0, sq1;
+                        post_lo_sq2(pa[f][q], pb[f][q], pw[q], pa[f][q + 1], pb[f][q + 1], pw[q + 1], sq0, sq1);
+                        const float m0 = exact_sqrtf(sq0.x + sq0.y), m1 = exact_sqrtf(sq1.x + sq1.y);  // L/fft.cpp:510-511
+                        // bins the bank never reads are not kept (mstride <= 264); lane 63's fourth pair would be bin 256: below
+                        if (1u + (unsigned)lane + 64u * q < A.mstride) Mrow[1 + lane + 64 * q] = m0;
+                        if (65u + (unsigned)lane + 64u * q < A.mstride && (q + 1 < 3 || lane < 63)) Mrow[65 + lane + 64 * q] = m1;
                     }
-                } else {
-                    const float2 a = post_lo(xa, xb, pw[q]);
-                    const float ma = exact_sqrtf(a.x * a.x + a.y * a.y);  // L/fft.cpp:510-511
-                    if (own) Mrow[1 + lane + 64 * q] = ma;
                 }
-            }
-            {   // bin 0 packs DC and Nyquist (L/fft.cpp:274-275); bin 256 passes through untouched
-                const float2 z = X[pad8(zidx)];
-                const float zr = lane == 0 ? z.x + z.y : z.x, zi = lane == 0 ? z.x - z.y : z.y;
-                const float mz = exact_sqrtf(zr * zr + zi * zi);
-                if (lane == 0 || lane == 63) {
-                    Mrow[zidx] = mz;
-                    if constexpr (WRITE_MAGS)
-                        if (frame_live) grow[zidx] = mz;
+                if (A.edgeBins) {
+                    post_edge(XA, j, f0);
+                    post_edge(XB, j + 1, f0);
                 }
+            } else {
+                post_frame(XA, j, f0);
+                post_frame(XB, j + 1, f0);
             }
             wave_lds_sync();
         }
         // ---- mel walk: lane (mj, ms) walks slot ms's filter list over frame mj's magnitudes -----------------
-        {
-            const float *Mrow = M + mj * A.mstride;
-            double *melrow = s_mel + mj * A.nfp;
-            double acc = 0.0;  // L/maxiMFCC.cpp:52
-            for (int t = 0; t < A.steps; t++) {
-                const int meta = s_meta[t * kFusedSlots + ms];
-                const double w = s_w[t * kFusedSlots + ms];
-                const double x = (double)Mrow[meta & 0xffff];
-                acc += (w * x);  // L/maxiMFCC.cpp:57
-                const int fid = meta >> 16;
-                if (fid) {
-                    melrow[fid - 1] = acc;
-                    acc = 0.0;
-                }
-            }
-        }
+        for (unsigned i = lane; i < kGroup * A.nfp; i += 64) s_mel[i] = 0.0;  // filters with an empty support stay 0
+        wave_lds_sync();
+        mel_walk<kFusedSlots>(reinterpret_cast<const char *>(M + mj * A.mstride), s_mel + mj * A.nfp, s_fs + ms, A.steps);
         wave_lds_sync();
         // ---- log-square (L/maxiMFCC.cpp:63), one band per lane ---------------------------------------------
         for (unsigned idx = lane; idx < kGroup * A.numFilters; idx += 64) {
@@ -249,13 +404,188 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const 
         // ---- DCT (L/maxiMFCC.h:98-111): lane = (frame, coefficient), j ascending ---------------------------
         for (unsigned p = lane; p < kGroup * A.numCoeffs; p += 64) {
             const unsigned jj = p / A.numCoeffs, i = p - jj * A.numCoeffs;
-            const double *mrow = s_mel + jj * A.nfp;
-            double c = 0.0;
-            for (unsigned jf = 0; jf < A.numFilters; jf++) c += (s_d[jf * A.numCoeffs + i] * mrow[jf]);
+            const double c = dct_dot(s_d + i, A.numCoeffs, s_mel + jj * A.nfp, A.numFilters);
             if (f0 + jj < nframes) A.mfcc[(f0 + jj) * A.numCoeffs + i] = c / (double)A.numCoeffs;
         }
+        wave_lds_sync();  // the next frame's first transpose overwrites the band rows
+    }
+}
+
+// ---- the 16-wave form (fft_mfcc16_kernel) -----------------------------------------------------------------------------
+// Same arithmetic, laid out for FOUR wavefronts per SIMD.  Issue costs measured with tools/ubench (profiles/r02_ubench.md):
+// one wave per SIMD issues a VALU op every 4.35 clk, two waves 2.4 clk per SIMD, four waves 1.7 clk -- the kernel above
+// (2 workgroups of 4 waves per CU: its 15.8 KB of LDS per wave and 162 VGPRs allow no more) leaves almost half of the
+// issue rate unused.  Here ONE 1024-thread workgroup per CU shares the tables; a wave owns 8 KB of LDS:
+//   X      the FFT transposes (4608 B), re-used for the band rows of the mel stage once the last frame's post-pass is done;
+//   M      magnitude rows of FOUR frames, only the bins the bank reads (row stride = nbUsed rounded up to 8 mod 16 floats,
+//          so the four rows start 8 banks apart);
+// and at most 128 VGPRs (round-1 twiddles are wave-uniform: SGPRs).  The mel walk runs lane = (frame of 4, slot of 16) over
+// the 16-list packing of the plan; a step is one 16-byte table entry {weight, byte offset, closing filter} and one LDS
+// gather, and the loop is software-pipelined two batches deep (entries two batches ahead, gathers one) so that no LDS
+// latency sits between the dependent fp64 adds.  Per-filter sums are still the reference's sequential sums (bit-identical
+// to the kernel above and to mxg_mfcc_batch).  Used when no magnitudes are requested and the bank reads bins [1, 256].
+constexpr int kGroup16 = 4;
+constexpr int kWaves16 = 16;
+
+struct Fused16Args {
+    const float *signal;
+    size_t frame_stride, nframes;
+    const float *window;
+    const float2 *tw, *post;
+    unsigned numFilters, numCoeffs, mstride, nfp, dctPad;
+    int steps;
+    const mxg_fs_entry *fs;
+    const double *dct;
+    double *melraw, *melbands, *mfcc;
+};
+
+template <bool ALIGNED8>
+__global__ __launch_bounds__(64 * kWaves16) void fft_mfcc16_kernel(const Fused16Args A) {
+    extern __shared__ double s_dyn[];
+    // [tw 512 float2][fs (steps + 2 batches) * 16 entries][dct NF*NC f64, padded to 16 B] | per wave: X (= band rows), M
+    float2 *s_tw = reinterpret_cast<float2 *>(s_dyn);
+    mxg_fs_entry *s_fs = reinterpret_cast<mxg_fs_entry *>(s_tw + 512);
+    const int fsRows = A.steps + 2 * kMelBatch;
+    double *s_d = reinterpret_cast<double *>(s_fs + (size_t)fsRows * kFusedSlots16);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t perWaveBytes = sizeof(float2) * kX1024 + sizeof(float) * kGroup16 * A.mstride;
+    char *wbase = reinterpret_cast<char *>(s_d + A.dctPad) + (size_t)wave * perWaveBytes;
+    float2 *X = reinterpret_cast<float2 *>(wbase);
+    double *s_mel = reinterpret_cast<double *>(wbase);
+    float *M = reinterpret_cast<float *>(wbase + sizeof(float2) * kX1024);
+    for (int i = threadIdx.x; i < 511; i += blockDim.x) s_tw[i] = A.tw[i];
+    for (int i = threadIdx.x; i < fsRows * kFusedSlots16; i += blockDim.x) s_fs[i] = A.fs[i];
+    for (unsigned i = threadIdx.x; i < A.numFilters * A.numCoeffs; i += blockDim.x) s_d[i] = A.dct[i];
+    __syncthreads();
+
+    const int lo = lane & 7, hi = lane >> 3;
+    const int rev6 = (int)(__brev((unsigned)lane) >> 26);
+    float2 wv[8];
+    unsigned li[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int rev3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);
+        li[e] = 2u * (unsigned)(rev3 * 64 + rev6);
+        wv[e] = make_float2(A.window[li[e]], A.window[li[e] + 1]);
+    }
+    asm volatile("" : "+v"(wv[0].x), "+v"(wv[0].y), "+v"(wv[1].x), "+v"(wv[1].y), "+v"(wv[2].x), "+v"(wv[2].y),
+                 "+v"(wv[3].x), "+v"(wv[3].y));
+    asm volatile("" : "+v"(wv[4].x), "+v"(wv[4].y), "+v"(wv[5].x), "+v"(wv[5].y), "+v"(wv[6].x), "+v"(wv[6].y),
+                 "+v"(wv[7].x), "+v"(wv[7].y));
+    float2 pw[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) pw[q] = A.post[(1 + lane + 64 * q) < 256 ? 1 + lane + 64 * q : 255];
+    asm volatile("" : "+v"(pw[0].x), "+v"(pw[0].y), "+v"(pw[1].x), "+v"(pw[1].y), "+v"(pw[2].x), "+v"(pw[2].y),
+                 "+v"(pw[3].x), "+v"(pw[3].y));
+    // round-1 twiddles are the same for every lane: scalar registers
+    float2 ta[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const float2 t = A.tw[i];
+        ta[i].x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(t.x)));
+        ta[i].y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(t.y)));
+    }
+    const int pa0 = pad8(1 + lane), pb0 = pad8(511 - lane);
+    const size_t nframes = A.nframes;
+    auto load_frame = [&](size_t fr, float2 (&dst)[8]) {
+        const unsigned fu = __builtin_amdgcn_readfirstlane((unsigned)(fr < nframes ? fr : nframes - 1));
+        const float *x = A.signal + (size_t)fu * A.frame_stride;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            if constexpr (ALIGNED8) {
+                dst[e] = *reinterpret_cast<const float2 *>(x + li[e]);
+            } else {
+                dst[e].x = x[li[e]];
+                dst[e].y = x[li[e] + 1];
+            }
+        }
+    };
+    const size_t ngroups = (nframes + kGroup16 - 1) / kGroup16;
+    const size_t gstep = (size_t)gridDim.x * kWaves16;
+    const size_t g0 = (size_t)blockIdx.x * kWaves16 + wave;
+    float2 nxt[8];
+    load_frame(g0 * kGroup16, nxt);
+    const int mj = lane >> 4, ms = lane & 15;  // mel walk: frame of the group, slot
+    for (size_t g = g0; g < ngroups; g += gstep) {
+        const size_t f0 = g * kGroup16;
+#pragma unroll 1
+        for (int j = 0; j < kGroup16; j++) {
+            float2 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                v[e].x = nxt[e].x * wv[e].x;  // calcFFT L/fft.cpp:501-503
+                v[e].y = nxt[e].y * wv[e].y;
+            }
+            load_frame(j + 1 < kGroup16 ? f0 + j + 1 : (g + gstep) * kGroup16, nxt);
+            {
+                const float2 a1[2] = {ta[1], ta[2]};
+                const float2 a2[4] = {ta[3], ta[4], ta[5], ta[6]};
+                round3(v, ta[0], a1, a2);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) X[pad8(8 * lane + e)] = v[e];
+            wave_lds_sync();
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = X[pad8(hi * 64 + e * 8 + lo)];
+            {
+                const float2 b0 = s_tw[7 + lo];
+                const float2 b1[2] = {s_tw[15 + lo], s_tw[15 + 8 + lo]};
+                const float2 b2[4] = {s_tw[31 + lo], s_tw[31 + 8 + lo], s_tw[31 + 16 + lo], s_tw[31 + 24 + lo]};
+                round3(v, b0, b1, b2);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int e = 0; e < 8; e++) X[pad8(hi * 64 + e * 8 + lo)] = v[e];
+            wave_lds_sync();
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = X[pad8(e * 64 + lane)];
+            {
+                const float2 c0 = s_tw[63 + lane];
+                const float2 c1[2] = {s_tw[127 + lane], s_tw[127 + 64 + lane]};
+                const float2 c2[4] = {s_tw[255 + lane], s_tw[255 + 64 + lane], s_tw[255 + 128 + lane], s_tw[255 + 192 + lane]};
+                round3(v, c0, c1, c2);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int e = 0; e < 8; e++) X[pad8(e * 64 + lane)] = v[e];
+            wave_lds_sync();
+            // real split post-pass (L/fft.cpp:245-275), low half only, + magnitudes (cartToPol :510-511) into row j of M
+            float *Mrow = M + j * A.mstride;
+#pragma unroll
+            for (int q = 0; q < 4; q += 2) {
+                v2f sq0, sq1;
+                post_lo_sq2(as_v2f(X[pa0 + 72 * q]), as_v2f(X[pb0 - 72 * q]), as_v2f(pw[q]), as_v2f(X[pa0 + 72 * (q + 1)]),
+                            as_v2f(X[pb0 - 72 * (q + 1)]), as_v2f(pw[q + 1]), sq0, sq1);
+                const float m0 = exact_sqrtf(sq0.x + sq0.y), m1 = exact_sqrtf(sq1.x + sq1.y);
+                if (1u + (unsigned)lane + 64u * q < A.mstride) Mrow[1 + lane + 64 * q] = m0;  // bins the bank never reads are not kept
+                if (65u + (unsigned)lane + 64u * q < A.mstride) Mrow[65 + lane + 64 * q] = m1;
+            }
+            wave_lds_sync();
+        }
+        // ---- mel walk: lane (mj, ms) walks slot ms's filter list over frame mj's magnitudes -----------------
+        for (unsigned i = lane; i < kGroup16 * A.nfp; i += 64) s_mel[i] = 0.0;  // filters with an empty support stay 0
         wave_lds_sync();
-        // the raw sums of the next group land on the same cells; cells of empty filters hold log_square(0) = 0
+        mel_walk<kFusedSlots16>(reinterpret_cast<const char *>(M + mj * A.mstride), s_mel + mj * A.nfp, s_fs + ms, A.steps);
+        wave_lds_sync();
+        // ---- log-square (L/maxiMFCC.cpp:63), one band per lane ---------------------------------------------
+        for (unsigned idx = lane; idx < kGroup16 * A.numFilters; idx += 64) {
+            const unsigned jj = idx / A.numFilters, ff = idx - jj * A.numFilters;
+            const double raw = s_mel[jj * A.nfp + ff];
+            const double lv = log_square(raw);
+            s_mel[jj * A.nfp + ff] = lv;
+            if (f0 + jj < nframes) {
+                if (A.melraw) A.melraw[(f0 + jj) * A.numFilters + ff] = raw;
+                if (A.melbands) A.melbands[(f0 + jj) * A.numFilters + ff] = lv;
+            }
+        }
+        wave_lds_sync();
+        // ---- DCT (L/maxiMFCC.h:98-111): lane = (frame, coefficient), j ascending ---------------------------
+        for (unsigned p = lane; p < kGroup16 * A.numCoeffs; p += 64) {
+            const unsigned jj = p / A.numCoeffs, i = p - jj * A.numCoeffs;
+            const double c = dct_dot(s_d + i, A.numCoeffs, s_mel + jj * A.nfp, A.numFilters);
+            if (f0 + jj < nframes) A.mfcc[(f0 + jj) * A.numCoeffs + i] = c / (double)A.numCoeffs;
+        }
+        wave_lds_sync();  // the next frame's first transpose overwrites the band rows
     }
 }
 
@@ -271,10 +601,36 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
     MXG_REQUIRE(fp && mp && d_signal && d_mfcc, "null plan / signal / mfcc");
     MXG_REQUIRE(fp->fftSize == 1024, "the fused kernel is specialised for fftSize 1024 (use mxg_fft_batch + mxg_mfcc_batch)");
     MXG_REQUIRE(mp->numBins == 512, "the mfcc plan must be set up for the 512 bins of a 1024-point maxiFFT");
-    MXG_REQUIRE(mp->fsSteps > 0 && mp->d_fsW, "this filter bank has no fused schedule (numFilters > 64?): use the two-kernel path");
+    MXG_REQUIRE(mp->fsSteps > 0 && mp->d_fs8, "this filter bank has no fused schedule (numFilters > 64?): use the two-kernel path");
     MXG_REQUIRE(nframes < ((size_t)1 << 32), "nframes must be < 2^32");
     if (nframes == 0) return MXG_OK;
     hipStream_t st = resolve_stream(stream);
+    const bool aligned8 = (((uintptr_t)d_signal) & 7) == 0 && (frame_stride & 1) == 0;
+    if (!d_mags && mp->fs16Steps > 0 && mp->fsMinBin >= 1 && mp->nbUsed <= 256 && tune_get("fused_waves16")) {
+        Fused16Args B;
+        B.signal = d_signal; B.frame_stride = frame_stride; B.nframes = nframes;
+        B.window = fp->d_window; B.tw = fp->d_tw; B.post = fp->d_post;
+        B.numFilters = mp->numFilters; B.numCoeffs = mp->numCoeffs;
+        B.mstride = (mp->nbUsed + 7) / 16 * 16 + 8;  // smallest stride >= nbUsed that is 8 mod 16: the four rows start 8 or 24 banks apart
+        B.nfp = mp->numFilters | 1u;
+        B.dctPad = (mp->numFilters * mp->numCoeffs + 1) & ~1u;
+        B.steps = mp->fs16Steps; B.fs = mp->d_fs16; B.dct = mp->d_dct;
+        B.melraw = d_melraw; B.melbands = d_melbands; B.mfcc = d_mfcc;
+        const size_t perWave = sizeof(float2) * kX1024 + sizeof(float) * kGroup16 * B.mstride;
+        const size_t lds = sizeof(float2) * 512 + sizeof(mxg_fs_entry) * (size_t)(B.steps + 2 * kMelBatch) * kFusedSlots16 +
+                           sizeof(double) * B.dctPad + kWaves16 * perWave;
+        if (lds <= 160 * 1024 && sizeof(double) * kGroup16 * B.nfp <= sizeof(float2) * kX1024) {
+            const size_t ngroups = (nframes + kGroup16 - 1) / kGroup16;
+            size_t blocks = (ngroups + kWaves16 - 1) / kWaves16;
+            if (blocks > 256) blocks = 256;  // persistent: one 16-wave workgroup per CU, grid-stride over groups of 4 frames
+            typedef void (*kern16_t)(const Fused16Args);
+            kern16_t k = aligned8 ? fft_mfcc16_kernel<true> : fft_mfcc16_kernel<false>;
+            if (lds > 64 * 1024) MXG_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            KernelTimer kt("fft_mfcc_kernel", st);
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * kWaves16), lds, st, B);
+            return check_hip(hipGetLastError(), "fft_mfcc16_kernel launch");
+        }
+    }
     FusedArgs A;
     A.signal = d_signal; A.frame_stride = frame_stride; A.nframes = nframes;
     A.window = fp->d_window; A.tw = fp->d_tw; A.post = fp->d_post;
@@ -282,20 +638,22 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
     MXG_REQUIRE(mp->nbUsed <= 257, "mel bank reaches beyond bin 256");  // binFreq = sr/numBins*bin never does
     const bool full = d_mags != nullptr;
     A.mstride = full ? 520 : 264;                 // the post-pass writes bins 0..256 (0..511 with magnitudes out) + pad, = 8 mod 32
+    // a bank that reads neither bin 0 nor bin 256 keeps only the bins below nbUsed (stride 8 mod 32 floats): with the two X
+    // images that is what lets two workgroups share a CU's 160 KB
+    if (!full && mp->fsMinBin >= 1 && mp->nbUsed <= 256) A.mstride = (mp->nbUsed + 23) / 32 * 32 + 8;
     A.nfp = mp->numFilters | 1u;                  // odd row stride for the band rows
-    if (A.nfp == mp->numFilters) A.nfp += 2;
-    A.steps = mp->fsSteps; A.fsW = mp->d_fsW; A.fsMeta = mp->d_fsMeta; A.dct = mp->d_dct;
+    A.dctPad = (mp->numFilters * mp->numCoeffs + 1) & ~1u;
+    A.steps = mp->fsSteps; A.fs = mp->d_fs8; A.dct = mp->d_dct;
+    A.edgeBins = full || mp->fsMinBin < 1 || mp->nbUsed > 256;
     A.mags = d_mags; A.melraw = d_melraw; A.melbands = d_melbands; A.mfcc = d_mfcc;
-    const size_t metaInts = ((size_t)A.steps * kFusedSlots + 3) & ~(size_t)3;
-    const size_t perWave = sizeof(float2) * kX1024 + sizeof(float) * kGroup * A.mstride + sizeof(double) * kGroup * A.nfp;
-    const size_t lds = sizeof(float2) * 512 + sizeof(double) * ((size_t)A.steps * kFusedSlots + (size_t)A.numFilters * A.numCoeffs) +
-                       sizeof(int) * metaInts + kWavesPerBlock * perWave;
+    const size_t perWave = 2 * sizeof(float2) * kX1024 + sizeof(float) * kGroup * A.mstride;
+    const size_t lds = sizeof(mxg_fs_entry) * (size_t)(A.steps + 2 * kMelBatch) * kFusedSlots + sizeof(double) * A.dctPad +
+                       kWavesPerBlock * perWave;
     MXG_REQUIRE(lds <= 160 * 1024, "filter bank too large for the fused kernel's LDS layout");
     const size_t ngroups = (nframes + kGroup - 1) / kGroup;
     size_t blocks = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
     const size_t cap = 256 * 2;  // persistent: two workgroups per CU, grid-stride over groups of 8 frames
     if (blocks > cap) blocks = cap;
-    const bool aligned8 = (((uintptr_t)d_signal) & 7) == 0 && (frame_stride & 1) == 0;
     typedef void (*kern_t)(const FusedArgs);
     kern_t k;
     if (d_mags)

@@ -130,8 +130,18 @@ def test_mfcc_golden(mx, golden, nf, nc):
     assert np.array_equal(bands == 0.0, emel == 0.0)
 
 
-@pytest.mark.parametrize("nf,nc,nfr,off", [(42, 13, 1003, 0), (40, 20, 77, 0), (64, 13, 8, 0), (42, 13, 250, 3), (13, 5, 1, 0)])
-def test_fused_fft_mfcc_vs_two_kernels_and_oracle(mx, port, nf, nc, nfr, off):
+@pytest.fixture(params=[0, 1], ids=["waves8", "waves16"])
+def fused_form(mx, request):
+    """Both forms of the fused kernel: 8 waves per CU (8 frames x 8 slots per wavefront, two frames in flight; the default)
+    and 16 waves per CU (4 frames x 16 slots; only when no magnitudes are requested)."""
+    prev = mx.lib().mxg_tune(b"fused_waves16", request.param)
+    yield request.param
+    mx.lib().mxg_tune(b"fused_waves16", prev)
+
+
+@pytest.mark.parametrize("nf,nc,nfr,off", [(42, 13, 1003, 0), (40, 20, 77, 0), (64, 13, 8, 0), (42, 13, 250, 3), (13, 5, 1, 0),
+                                           (42, 13, 16 * 4 * 256 + 5, 0)])
+def test_fused_fft_mfcc_vs_two_kernels_and_oracle(mx, port, fused_form, nf, nc, nfr, off):
     """mxg_fft_mfcc_batch (one kernel, magnitudes kept in LDS): magnitudes and raw band sums bit-identical to the
     separate kernels (and the magnitudes to the oracle's), mfcc within the log tolerance -- for ragged frame counts
     (not a multiple of the 8-frame group), an unaligned / odd-stride signal, 40x20 and 64-filter banks, with and
@@ -163,6 +173,11 @@ def test_fused_fft_mfcc_vs_two_kernels_and_oracle(mx, port, nf, nc, nfr, off):
     # mfcc-only launch (no optional outputs: the half-spectrum variant of the kernel): identical coefficients
     out3 = m.mfcc_of_frames(f, base, nfr, frame_stride=stride).numpy()
     assert_bits_equal(out3, out, "mfcc-only variant")
+    # bands without magnitudes (the 16-wave form when enabled): raw sums and bands still the same bits
+    out4 = m.mfcc_of_frames(f, base, nfr, frame_stride=stride, want_bands=True).numpy()
+    assert_bits_equal(out4, out, "mfcc, bands-only variant")
+    assert_bits_equal(m.melraw.numpy(), raw, "raw band sums, bands-only variant")
+    assert_bits_equal(m.melBands.numpy(), bands, "melBands, bands-only variant")
 
 
 def test_survey_mfcc_anchor_on_device(mx, port):
@@ -180,7 +195,7 @@ def test_survey_mfcc_anchor_on_device(mx, port):
         assert abs(out[2, i] - v) <= 1e-13
 
 
-def test_fused_fft_mfcc_tiny_and_silent_frames(mx, port):
+def test_fused_fft_mfcc_tiny_and_silent_frames(mx, port, fused_form):
     """Magnitudes around the sqrt's small-input branch (power < 2^-96) and all-zero frames: bit-exact magnitudes,
     zero bands stay exactly zero."""
     rng = np.random.default_rng(5)
@@ -199,6 +214,8 @@ def test_fused_fft_mfcc_tiny_and_silent_frames(mx, port):
     assert np.array_equal(m.melBands.numpy() == 0.0, emel == 0.0)
     assert np.abs(out - emf).max() <= MFCC_RTOL * max(np.abs(emel).max(), 1.0)
     assert (out[0] == 0).all()
+    out2 = m.mfcc_of_frames(f, mx.DeviceBuffer.from_numpy(sig), nfr, want_bands=True).numpy()   # no magnitudes out
+    assert_bits_equal(out2, out, "mfcc without magnitudes")
 
 
 def test_fused_fft_mfcc_rejects_what_it_cannot_do(mx):
