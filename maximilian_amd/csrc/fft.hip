@@ -48,7 +48,7 @@ __device__ __forceinline__ void emit_bin_t(const FftOut &o, size_t base, int bin
     if constexpr (OMASK & 2) o.imag[base + bin] = v.y;
     if constexpr (OMASK & 12) {
         float power = v.x * v.x + v.y * v.y;  // L/fft.cpp:510
-        if constexpr (OMASK & 4) o.mags[base + bin] = sqrtf(power);
+        if constexpr (OMASK & 4) o.mags[base + bin] = exact_sqrtf(power);
         if constexpr (OMASK & 8) o.phases[base + bin] = atan2f(v.y, v.x);
     }
 }
@@ -61,7 +61,7 @@ __device__ __forceinline__ void emit_row_t(const FftOut &row, unsigned bin, floa
     if constexpr (OMASK & 2) row.imag[bin] = v.y;
     if constexpr (OMASK & 12) {
         float power = v.x * v.x + v.y * v.y;  // L/fft.cpp:510
-        if constexpr (OMASK & 4) row.mags[bin] = sqrtf(power);
+        if constexpr (OMASK & 4) row.mags[bin] = exact_sqrtf(power);
         if constexpr (OMASK & 8) row.phases[bin] = atan2f(v.y, v.x);
     }
 }
@@ -71,7 +71,7 @@ __device__ __forceinline__ void emit_bin(const FftOut &o, size_t base, int bin, 
     if (o.imag) o.imag[base + bin] = v.y;
     if (o.mags || o.phases) {
         float power = v.x * v.x + v.y * v.y;  // L/fft.cpp:510
-        if (o.mags) o.mags[base + bin] = sqrtf(power);
+        if (o.mags) o.mags[base + bin] = exact_sqrtf(power);
         if (o.phases) o.phases[base + bin] = atan2f(v.y, v.x);
     }
 }

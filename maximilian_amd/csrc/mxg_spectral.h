@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "mxg_common.h"
+#include "mxg_log.h"
 
 struct mxg_fft_plan {
     int fftSize, hopSize, windowSize, bins, half, numBits;
@@ -162,8 +163,24 @@ __device__ __forceinline__ void round3(float2 (&x)[8], const float2 w0, const fl
     for (int e = 0; e < 8; e++) x[e] = make_float2(y[e].x, y[e].y);
 }
 
+// sqrtf.  hipcc's correctly-rounded sqrtf expands to ~25 instructions (v_sqrt_f32, the +-1 ulp residual test, and a 2^32
+// pre-scale for inputs below 2^-96 whose v_sqrt_f32 result would be denormal-inaccurate).  exact_sqrtf() is Markstein's
+// sequence from the hardware reciprocal square root: g = x*r, h = r/2, g + (x - g*g)*h -- the residual is exact in an fma and
+// the final fma rounds ONCE, so the result is the correctly rounded root whenever the candidate g is close enough; whether
+// that holds depends on the values v_rsq_f32 actually returns, so it was checked EXHAUSTIVELY on the device: all 1 879 048 192
+// floats in [2^-96, FLT_MAX] give the bits of (float)sqrt((double)x) (tools/ubench/sqrt_probe.hip, profiles/r02_sqrt_probe.txt;
+// so does the previous form, v_sqrt_f32 + a two-sided residual test, at twice the instructions).  Zero, inputs below 2^-96,
+// Inf and NaN take the generic routine in a branch no wavefront normally enters.
+__device__ __forceinline__ float exact_sqrtf(float x) {
+    if (__builtin_expect(__float_as_uint(x) - 0x0F800000u >= 0x7F800000u - 0x0F800000u, 0)) return sqrtf(x);
+    const float r = __builtin_amdgcn_rsqf(x);
+    const float g = x * r, h = 0.5f * r;
+    const float d = __builtin_fmaf(-g, g, x);  // x - g*g, one rounding
+    return __builtin_fmaf(d, h, g);
+}
+
 // log-square of L/maxiMFCC.cpp:63
-__device__ __forceinline__ double log_square(double mb) { return mb > 0.000001 ? log(mb * mb) : 0.0; }
+__device__ __forceinline__ double log_square(double mb) { return mb > 0.000001 ? fast_log(mb * mb) : 0.0; }
 
 }  // namespace
 }  // namespace mxg

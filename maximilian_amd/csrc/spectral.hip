@@ -20,28 +20,13 @@
 //   log pass   the 8 x numFilters raw band sums, one per lane, log(mb*mb) (device log: the tolerance of method 0);
 //   DCT        lane = (frame, coefficient): the 42-term sum in the reference's j order, / numCoeffs, stored coalesced.
 // HBM traffic per frame = the algorithmic 4200 B (+2048 B when the magnitudes are also requested).
-//
-// sqrtf.  hipcc's correctly-rounded sqrtf expands to ~25 instructions (v_sqrt_f32, the +-1 ulp residual test, and a
-// 2^32 pre-scale for inputs below 2^-96 whose v_sqrt_f32 result would be denormal-inaccurate).  exact_sqrtf() keeps the
-// residual test and moves the rare small-input case into a branch that no lane of a wavefront normally takes.
+// Magnitudes use exact_sqrtf (mxg_spectral.h): correctly rounded for every float, checked exhaustively on the device.
 #include "mxg_spectral.h"
 
 namespace mxg {
 namespace {
 
 constexpr int kGroup = 8;  // frames per mel phase = 64 lanes / kFusedSlots
-
-// correctly rounded sqrt of a finite non-negative float (0, inf and NaN pass through v_sqrt_f32 unchanged)
-__device__ __forceinline__ float exact_sqrtf(float x) {
-    if (__builtin_expect(x < 0x1p-96f && x > 0.0f, 0)) return sqrtf(x);
-    const float s = __builtin_amdgcn_sqrtf(x);  // <= 1 ulp
-    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
-    const float rd = __builtin_fmaf(-sd, s, x);  // x - sd*s, one rounding
-    const float ru = __builtin_fmaf(-su, s, x);
-    float r = rd <= 0.0f ? sd : s;
-    r = ru > 0.0f ? su : r;
-    return r;
-}
 
 // the `a` half of post_pair (L/fft.cpp:250-262): bin i of the real transform from X[i] and X[half - i]
 __device__ __forceinline__ float2 post_lo(const float2 a, const float2 b, const float2 w) {
