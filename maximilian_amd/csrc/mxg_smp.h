@@ -23,7 +23,10 @@ namespace {
 // back the index clamp below: outside those ranges (a play4 step longer than its loop, playLoop with end > 1, a head
 // uploaded far outside the sample) the reference indexes outside its vector -- undefined -- and the device reads a
 // guard zero instead of whatever lies, or does not lie, beyond the allocation.
-constexpr int kSmpGuardLo = 4, kSmpGuardHi = 6;
+// kSmpWindow: sample.hip's time-part kernel fetches the indices of a chunk as one window of that many consecutive doubles per
+// voice, starting at the chunk's lowest index (<= len+4): the high guard covers a window that starts on the last index.
+constexpr int kSmpWindow = 16;
+constexpr int kSmpGuardLo = 4, kSmpGuardHi = 6 + kSmpWindow;
 
 // The head as the index computations see it: unchanged on [-2, len+2] (every position the reference is defined on),
 // pinned to that interval otherwise (NaN -> -2), so derived indices stay within [-4, len+4].

@@ -18,6 +18,7 @@
 // sizes of the configs); per sample a lane gathers 1-4 neighbouring doubles (K5, 8 B out +
 // gather).  The buffer must be valid on [-4, len+5] with zero guards (mxg_sample_upload's layout, mxg_smp.h).
 #include "mxg_common.h"
+#include "mxg_advance.h"
 #include "mxg_smp.h"
 
 namespace mxg {
@@ -314,7 +315,151 @@ __global__ void __launch_bounds__(256) sample_kernel(SmpArgs A) {
     }
 }
 
+// ---- time parts for the *AtSpeed players ---------------------------------------------------------------------------------
+// 65 536 voices are one wavefront per SIMD, and the speed players spend ~35 VALU instructions per sample on the head
+// (floor, remainder, bounds, wrap) plus two gathers: with nothing else resident every latency and every issue slot is
+// exposed (87 us per 65 536 x 512 block against 42 us for the stores; staging the gathers through LDS windows was measured
+// and changed nothing -- the texture path is not the limit).  So a block is cut into gridDim.y time parts, like K1's
+// sinewave: part p first moves the head over the samples before it WITHOUT rendering them.  The head's recurrence is
+// pos <- fl(pos + step) with, for playAtSpeed, pos -= len once it reaches len (C:1071-1073); advance_until (mxg_advance.h,
+// the exact multi-step form written for the grain schedulers and fuzzed against the one-step recurrence on the host)
+// advances it by hundreds of samples at a time without changing a bit.  It needs step > 0 and pos >= 0: every part tests
+// the same initial state, and a wavefront with any other voice is rendered whole by part 0.  The last part (or part 0)
+// stores the head.  Block-constant speed only; per-sample speed inputs take sample_kernel.
+//
+// More resident wavefronts alone made it SLOWER (96 -> 125 us): every lane keeps its own cache line alive for ~16 samples, and
+// 16 wavefronts x 64 lines are four times the 32 KB L1.  So the parts do not gather through the L1 at all when they can avoid
+// it: the indices of one voice over a chunk of 8 samples are local (for |speed| < 1.85 they fall inside 16 consecutive
+// doubles), and the wavefront fetches each voice's window cooperatively -- 8 lanes x 16 bytes cover one voice's 128 bytes, one
+// instruction covers 8 voices (8-16 lines instead of 64), 8 instructions the wavefront; the pieces go to LDS (144-byte rows)
+// and every lane picks its own values with ds_read.  Whether a chunk qualifies (every lane local, no wrap inside the chunk) is
+// one ballot per chunk; the others take per-lane gathers.  Same values either way.  (The window path alone, at one wavefront
+// per SIMD, had changed nothing either: 87 us.  It takes both.)
+constexpr int kRowDoubles = kSmpWindow + 2;  // 144-byte rows: 16-byte aligned pieces, consecutive voices 4 banks apart
+
+__device__ __forceinline__ void smp_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int B>
+__device__ __forceinline__ void smp_skip(double &pos, const double step, const double dlen, size_t n) {
+    while (n > 0) {
+        bool crossed;
+        const int kmax = n > (size_t)(1 << 30) ? (1 << 30) : (int)n;
+        n -= (size_t)advance_until(pos, step, B == 4 ? dlen : HUGE_VAL, true, kmax, crossed);
+        if (B == 4 && crossed) pos -= dlen;  // C:1072-1073
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) sample_parts_kernel(SmpArgs A, const size_t part_len) {
+    __shared__ double s_win[4 * 64 * kRowDoubles];
+    const size_t V = A.V, N = A.N;
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    constexpr int B = smp_base(MODE);
+    static_assert(B >= 4 && B <= 6, "the *AtSpeed players");
+    Smp s = {A.amp, A.len, A.position[v], A.step_div, 0.0, false, 0.0, 0.0};
+    const double st = A.start ? A.start[v] : 0.0, en = A.end ? A.end[v] : 1.0;
+    const double x0 = A.a[v], sr = A.sr;
+    const double step = (x0 * kChandiv) / s.step_div;  // the increment of smp_gen (C:1070)
+    const bool can_skip = __all(step > 0.0 && step < HUGE_VAL && s.pos >= 0.0 && s.pos < HUGE_VAL);
+    size_t n0 = 0, n1 = N;
+    bool writer = blockIdx.y == 0;
+    if (can_skip) {
+        n0 = (size_t)blockIdx.y * part_len;
+        n1 = n0 + part_len < N ? n0 + part_len : N;
+        writer = blockIdx.y + 1 == gridDim.y;
+        smp_skip<B>(s.pos, step, (double)s.len, n0);
+    } else if (blockIdx.y != 0) {
+        return;
+    }
+    const double *amp = A.amp;
+    double *op = A.out + n0 * V + v;
+    using Req = SmpReq<MODE>;
+    constexpr int U = 8;
+    const int lane = threadIdx.x & 63;
+    double *win = s_win + (threadIdx.x >> 6) * (64 * kRowDoubles);
+    const bool can_stage = __popcll(__ballot(true)) == 64 && A.len < ((size_t)1 << 30);  // full wavefront, 32-bit indices
+    size_t n = n0;
+    for (; n + U <= n1; n += U) {
+        Req r[U];
+        double val[U][2];
+#pragma unroll
+        for (int i = 0; i < U; i++) smp_gen<MODE>(s, x0, 0.0, st, en, sr, r[i]);
+        bool staged = false;
+        int base = 0;
+        if (can_stage) {
+            int lo = (int)r[0].idx[0], hi = lo;  // idx[1] = idx[0] + 1 for these players (mxg_smp.h)
+#pragma unroll
+            for (int i = 1; i < U; i++) {
+                const int ix = (int)r[i].idx[0];
+                lo = ix < lo ? ix : lo;
+                hi = ix > hi ? ix : hi;
+            }
+            staged = __all(hi + 1 - lo < kSmpWindow);
+            base = lo;
+        }
+        if (staged) {
+            double2v c[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {  // piece j: 16 bytes of the window of voice 8j + lane/8
+                const int b = __shfl(base, 8 * j + (lane >> 3));
+                c[j] = *reinterpret_cast<const double2v *>(amp + b + 2 * (lane & 7));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                *reinterpret_cast<double2v *>(win + (8 * j + (lane >> 3)) * kRowDoubles + 2 * (lane & 7)) = c[j];
+            smp_lds_sync();
+            const double *row = win + lane * kRowDoubles - base;
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                val[i][0] = row[(int)r[i].idx[0]];
+                val[i][1] = row[(int)r[i].idx[1]];
+            }
+            smp_lds_sync();
+        } else {
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                val[i][0] = amp[r[i].idx[0]];
+                val[i][1] = amp[r[i].idx[1]];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            *op = smp_eval<MODE>(r[i], val[i]);
+            op += V;
+        }
+    }
+    for (; n < n1; n++) {
+        Req q;
+        double val[2];
+        smp_gen<MODE>(s, x0, 0.0, st, en, sr, q);
+        val[0] = amp[q.idx[0]];
+        val[1] = amp[q.idx[1]];
+        *op = smp_eval<MODE>(q, val);
+        op += V;
+    }
+    if (writer) A.position[v] = s.pos;
+}
+
 inline dim3 grid_for(size_t V, int block) { return dim3((unsigned)((V + block - 1) / block)); }
+
+// time parts for a block-constant *AtSpeed launch: enough to put ~4 wavefronts on every SIMD, each part >= 32 samples
+inline int speed_parts(size_t V, size_t N, size_t *part_len) {
+    int split = tune_get("smp_split");
+    if (split == 0) {
+        const size_t waves = (V + 63) / 64;
+        split = waves >= 4096 ? 1 : (int)(4096 / (waves ? waves : 1));
+        if (split > 8) split = 8;
+    }
+    while (split > 1 && N / (size_t)split < 32) split--;
+    size_t len = ((N + split - 1) / split + 7) / 8 * 8;
+    while (split > 1 && (size_t)(split - 1) * len >= N) split--;  // every part renders at least one sample
+    *part_len = len;
+    return split;
+}
 
 template <int M>
 void launch_sample(bool xmod, dim3 grid, dim3 block, hipStream_t st, const SmpArgs &A) {
@@ -436,6 +581,18 @@ int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, siz
                        d_start, d_end, d_position, nullptr, nullptr, d_out};
     const bool xmod = mode >= 4 && aps;
     const dim3 grid = grid_for(V, block);
+    if (mode >= 4 && mode <= 6 && !xmod) {
+        size_t part_len = N;
+        const int split = speed_parts(V, N, &part_len);
+        if (split > 1) {
+            const dim3 pgrid(grid.x, (unsigned)split);
+            KernelTimer kt("sample_parts_kernel", st);
+            if (mode == 4) hipLaunchKernelGGL((sample_parts_kernel<4>), pgrid, dim3(block), 0, st, A, part_len);
+            if (mode == 5) hipLaunchKernelGGL((sample_parts_kernel<5>), pgrid, dim3(block), 0, st, A, part_len);
+            if (mode == 6) hipLaunchKernelGGL((sample_parts_kernel<6>), pgrid, dim3(block), 0, st, A, part_len);
+            return check_hip(hipGetLastError(), "sample_parts_kernel launch");
+        }
+    }
     switch (mode) {
         case 0: launch_sample<0>(xmod, grid, dim3(block), st, A); break;
         case 1: launch_sample<1>(xmod, grid, dim3(block), st, A); break;

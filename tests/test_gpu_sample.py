@@ -317,3 +317,106 @@ def test_play_at_speed_between_points_from_pos(mx, port):
     exp = np.stack([port.sample(8, smp, 1, pos[n], a=fm[n], start=start, end=end)[0][0] for n in range(N)])
     assert_bits_equal(out.numpy(), exp, "playAtSpeedBetweenPointsFromPos, per-sample frequency")
     assert L.mxg_sample_render_frompos(V, N, sb.d_samples, Ls, None, 0, d[1].ptr, d[2].ptr, d[3].ptr, out.ptr, None) == -1
+
+
+def _mixed_speeds(V, rng, reverse):
+    """Waves 0-1 and 3: slow voices; wave 2: a few fast ones; with `reverse` every third voice runs backwards."""
+    sp = rng.uniform(0.2, 1.7, V)
+    sp[128:192:7] = rng.uniform(2.0, 3.5, sp[128:192:7].size)
+    if reverse:
+        sp[1::3] *= -1.0
+    return sp
+
+
+@pytest.mark.parametrize("mode", [4, 5, 6, 7, 8])
+@pytest.mark.parametrize("Ls,split", [(20000, 0), (700, 0), (700, 1), (700, 3), (20000, 8)])
+def test_sample_speed_players_full_waves(mx, port, mode, Ls, split):
+    """The interpolating players over full wavefronts, three carried blocks of ragged lengths, long and short (many wraps)
+    buffers -- and, for playAtSpeed / playOnceAtSpeed / playUntilAtSpeed, every setting of the time-part knob: a part skips to
+    its first sample with the exact multi-step head advance, so the bits (and the head left behind) cannot depend on it."""
+    rng = np.random.default_rng(900 + mode + Ls)
+    V = 256
+    smp = rng.uniform(-1, 1, Ls)
+    speed = _mixed_speeds(V, rng, reverse=mode >= 7)   # head step per output sample
+    if mode >= 7:
+        # play4 / playAtSpeedBetweenPoints(frequency, start, end): start / end in samples, step = (end-start)*f/sr (C:826-940)
+        start = np.floor(rng.uniform(2, Ls * 0.3, V)); end = np.floor(start + rng.uniform(Ls * 0.2, Ls * 0.6, V))
+        start[192:] = np.floor(rng.uniform(2, Ls - 90, 64)); end[192:] = start[192:] + np.floor(rng.uniform(20, 60, 64))
+        a = speed * 44100.0 / (end - start)
+        pos0 = start + np.floor(rng.uniform(0, 1, V) * (end - start - 1))
+    else:
+        a = speed
+        start = np.zeros(V)
+        end = rng.uniform(0.3, 1.0, V) if mode == 6 else np.ones(V)     # playUntilAtSpeed: end as a fraction
+        pos0 = rng.uniform(0, Ls - 2, V)
+    bank = mx.maxiSampleBank(V)
+    bank.setSample(smp)
+    bank.position.upload(pos0)
+    kw = dict(a=a, start=start, end=end)
+    blocks = [203, 64, 9]
+    prev = mx.lib().mxg_tune(b"smp_split", split)
+    try:
+        o = np.concatenate([bank.render(mode, n, **kw).numpy() for n in blocks])
+    finally:
+        mx.lib().mxg_tune(b"smp_split", prev)
+    e, ep = port.sample(mode, smp, sum(blocks), pos0, **kw)
+    assert_bits_equal(o, e, "mode %d" % mode)
+    assert_bits_equal(bank.position.numpy(), ep, "position")
+    assert np.abs(e).max() > 0.1
+
+
+@pytest.mark.parametrize("mode", [4, 5, 6])
+def test_sample_time_parts_corner_heads(mx, port, mode):
+    """Heads and speeds the skip must not touch or must get exactly right: negative and zero speeds and negative heads in the
+    wavefront (part 0 renders it whole), a step below half an ulp of the head (the head does not move), a head sitting
+    exactly on len, steps longer than the buffer, a huge playOnce head."""
+    Ls, N = 1000, 512
+    rng = np.random.default_rng(77 + mode)
+    smp = rng.uniform(-1, 1, Ls)
+    V = 192
+    a = rng.uniform(0.3, 1.5, V); pos0 = rng.uniform(0, Ls - 1, V)
+    a[64:128:5] = [-0.7, 0.0, -2.5, 1e-300, -1e-3, 0.9, 1.1, -0.4, 0.0, 3.0, -1.0, 0.5, -0.2][:len(a[64:128:5])]  # wave 1: mixed signs
+    if mode == 6:
+        a = np.abs(a)                        # playUntilAtSpeed only tests the upper bound: a head below 0 is the reference's UB
+    else:
+        pos0[70] = -3.5
+    a[130] = 1e-14; pos0[130] = 800.0        # below half an ulp of 800: stuck
+    pos0[131] = float(Ls)                    # exactly on the wrap limit
+    a[132] = 2500.0                          # longer than the buffer
+    a[133] = 999.5; pos0[133] = 0.25
+    if mode == 5:
+        pos0[134] = 1e15; a[134] = 0.75       # far beyond the sample: silence, the head keeps adding
+    end = rng.uniform(0.4, 1.0, V)
+    bank = mx.maxiSampleBank(V)
+    bank.setSample(smp)
+    bank.position.upload(pos0)
+    kw = dict(a=a, start=np.zeros(V), end=end)
+    o = np.concatenate([bank.render(mode, N, **kw).numpy(), bank.render(mode, 100, **kw).numpy()])
+    e, ep = port.sample(mode, smp, N + 100, pos0, **kw)
+    assert_bits_equal(o, e, "mode %d" % mode)
+    assert_bits_equal(bank.position.numpy(), ep, "position")
+
+
+def test_sample_zx_and_phasor_slow_full_waves(mx, port):
+    """Trigger-driven players and playWithPhasor on full wavefronts of slow voices, retriggers included."""
+    V, N = 192, 300
+    c = _zx_case(V, N, 333)
+    c["a"] = np.random.default_rng(4).uniform(0.3, 1.7, V)
+    for mode in (1, 2, 3):
+        bank = mx.maxiSampleBank(V)
+        bank.setSample(c["smp"])
+        bank.position.upload(c["pos0"])
+        kw = dict(a=c["a"], p0=c["p0"] if mode >= 2 else None, p1=c["p1"] if mode == 3 else None)
+        o = bank.render_trig(ZX[mode], c["trig"], **kw).numpy()
+        e, ep, _, _ = port.sample_zx(mode, c["smp"], c["trig"], c["pos0"], a=c["a"], p0=c["p0"], p1=c["p1"])
+        assert_bits_equal(o, e, ZX[mode])
+        assert_bits_equal(bank.position.numpy(), ep, ZX[mode] + " position")
+    rng = np.random.default_rng(8)
+    smp = rng.uniform(-1, 1, 4000)
+    pha = (np.arange(N)[:, None] * rng.uniform(0.00005, 0.0004, V)[None, :] + rng.uniform(0, 1, V)) % 1.0
+    pha[:, 1::2] = 1.0 - pha[:, 1::2]
+    bank = mx.maxiSampleBank(V)
+    bank.setSample(smp)
+    o = bank.playWithPhasor(pha).numpy()
+    e, _, _ = port.sample_phasor(smp, pha)
+    assert_bits_equal(o, e, "playWithPhasor, slow ramps")

@@ -136,5 +136,8 @@ def test_convolve_port_matches_reference(port, ref):
         x = rng.uniform(-1, 1, F * 5 + 7).astype(np.float32)
         for mode in (0, 1):
             a, b = ref.convolve(pcm, x, F, H, mode), port.convolve(pcm, x, F, H, mode)
-            for u, v in zip(a, b):
-                assert np.array_equal(u.view(np.uint32), v.view(np.uint32))
+            for which, (u, v) in enumerate(zip(a, b)):
+                same = np.array_equal(u.view(np.uint32), v.view(np.uint32))
+                assert same, ("impulse %d, fft %d, hop %d, mode %d, array %d (0 out, 1 impR, 2 impI): %d of %d differ, "
+                              "max |ref| %.3g, max |port| %.3g" % (Li, F, H, mode, which, int((u != v).sum()), u.size,
+                                                                  np.abs(u).max(), np.abs(v).max()))
