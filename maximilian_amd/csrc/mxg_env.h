@@ -7,6 +7,7 @@
 #else  // host build of the same text (tests/host_env.cpp: state machine and steady-state paths against the oracle)
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 #define __device__
 #define __forceinline__ inline
 #endif
@@ -131,6 +132,65 @@ __device__ __forceinline__ double env_release_tick(Env &e, double input) {  // g
     e.output = r ? input * e.amplitude : e.output;
     return e.output;
 }
+// The general steady chunk: U samples during which no flag of this envelope moves, whatever stage it is in.  Read off
+// C:1415-1466 with a constant gate, a lane that stays inside ONE stage for the whole chunk executes per sample
+//   attack   amplitude += attack                 output = input*amplitude     (while amplitude < 1)
+//   decay    amplitude *= decay                  output = input*amplitude     (while amplitude > sustain)
+//   hold     holdcount++ (up to holdtime)        output = input*amplitude
+//   sustain  (hold over, gate on)                output = input*amplitude
+//   release  amplitude *= release (gate off)     output = input*amplitude     (while amplitude > 0)
+//   idle     nothing                              output unchanged
+// i.e. amplitude = amplitude*m + a with (m, a) = (1, attack), (decay, 0), (1, 0), (release, 0) -- x*1 and x+0 are exact for
+// the non-negative amplitudes admitted here, so the two roundings are the reference's one -- and one multiply.  The lanes of a
+// wavefront may each be in a DIFFERENT stage (a polyphonic bank is), which is what the sustain / release paths above cannot
+// take.  The chunk is computed speculatively on a copy of the state; it is valid if the stage's own exit test would have been
+// false on every sample, which for these monotone recurrences is a test of the LAST value (attack: < 1, decay: > sustain,
+// release: > 0) plus the conditions on the flags below.  Returns false (and must then be discarded) otherwise; the caller
+// commits only if every lane of the wavefront returned true, else the chunk goes through env_adsr.  ~6 operations per sample
+// instead of ~100.
+template <int U>
+__device__ __forceinline__ bool env_steady_chunk(Env &e, const double (&x)[U], const bool gate, double (&o)[U]) {
+    const bool ap = e.attackphase == 1, dp = e.decayphase == 1, hp = e.holdphase == 1, rp = e.releasephase == 1;
+    const bool ge = e.holdcount >= e.holdtime;
+    long long hb;
+    {
+        double t = e.amplitude;
+#if defined(__HIPCC__)
+        hb = __double_as_longlong(t);
+#else
+        memcpy(&hb, &t, 8);
+#endif
+    }
+    const bool nonneg = hb >= 0;  // sign bit clear: +0 and positive values (and positive NaNs, which fail every test below)
+    // stage of this lane (exactly one phase flag set, the others exactly as the stage leaves them)
+    const bool A = ap && !dp && !hp && e.releasephase == 0 && (gate || !ge) && e.attack > 0.0;  // (C:1426 stores 0 there)
+    const bool D = dp && !ap && !hp && !rp && (gate || !ge) && e.decay > 0.0 && e.decay <= 1.0;
+    // hold / sustain: with the gate on the count simply saturates at holdtime (C:1446-1453 give the same output either side);
+    // with the gate off the sample on which it reaches holdtime starts the release (C:1455-1458), so that chunk is not steady
+    const bool H = hp && !ap && !dp && !rp && (gate || e.holdcount + (long long)U < e.holdtime);
+    const bool R = !gate && rp && !ap && !dp && e.holdphase == 0 && ge && e.amplitude > 0.0 && e.release > 0.0 && e.release <= 1.0;
+    // idle: gate off, no stage active, and neither C:1455-1458 nor C:1460-1463 would change anything
+    const bool Z = !gate && !ap && !dp && !hp && !(rp && e.amplitude > 0.0) && (!ge || (e.holdphase == 0 && rp));
+    const double m = D ? e.decay : (R ? e.release : 1.0);
+    const double a = A ? e.attack : 0.0;
+    double amp = e.amplitude, out = e.output;
+#pragma unroll
+    for (int i = 0; i < U; i++) {
+        amp = (amp * m) + a;
+        out = Z ? out : x[i] * amp;
+        o[i] = out;
+    }
+    bool ok = nonneg && (A || D || H || R || Z);
+    ok = ok && (!A || amp < 1.0) && (!D || amp > e.sustain) && (!R || amp > 0.0);
+    e.amplitude = amp;
+    e.output = out;
+    if (H && e.holdcount < e.holdtime) {
+        const long long c = e.holdcount + (long long)U;
+        e.holdcount = c < e.holdtime ? c : e.holdtime;
+    }
+    return ok;
+}
+
 // gate state of a full chunk from its (already fetched, wave-uniform) trigger values:
 // +1 all == 1, -1 all != 1, 0 mixed.  Scalar work.
 template <int U>

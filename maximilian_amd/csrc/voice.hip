@@ -204,6 +204,37 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
                 else if (g < 0) fast = __all(env_in_release(e)) ? 2 : 0;
             }
         }
+        if constexpr (MODE == 0) {
+            // neither all-sustain nor all-release: the general steady chunk (mxg_env.h) -- every lane inside one stage of
+            // its own for the whole chunk, gate constant per lane; computed on a copy, committed if every lane accepts
+            if (fast == 0 && n0 + U <= N) {
+                bool lane_gate, constant;
+                if constexpr (TPV) {
+                    lane_gate = tc[0] == 1;
+                    constant = true;
+#pragma unroll
+                    for (int i = 1; i < U; i++) constant = constant && ((tc[i] == 1) == lane_gate);
+                } else {
+                    const int g = lane_value(gcur.cls, (int)((n0 / U) & 63));
+                    lane_gate = g > 0;
+                    constant = g != 0;
+                }
+                if (__all(constant)) {
+                    Env s = e;
+                    double o[U];
+                    const bool ok = env_steady_chunk<U>(s, xc, lane_gate, o);
+                    if (__all(ok)) {
+                        e = s;
+#pragma unroll
+                        for (int i = 0; i < U; i++) {
+                            *op = o[i];
+                            op += V;
+                        }
+                        continue;
+                    }
+                }
+            }
+        }
         if (fast == 1) {
 #pragma unroll
             for (int i = 0; i < U; i++) {
@@ -337,6 +368,54 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
         };
         if (fast == 1) steady(std::true_type{}); else steady(std::false_type{});
         continue;
+      }
+      if constexpr (MODE == 0) {
+        // The general steady chunk (mxg_env.h): the oscillator and the filter do not depend on the envelope, so their 8
+        // samples are formed first; the envelope then takes them in one speculative chunk if every lane of the wavefront stays
+        // inside a stage of its own (attack, decay, hold ... each lane a different one), else sample by sample.
+        if (n0 + U <= N) {
+            bool lane_gate, constant;
+            if constexpr (TPV) {
+                lane_gate = tc[0] == 1;
+                constant = true;
+#pragma unroll
+                for (int i = 1; i < U; i++) constant = constant && ((tc[i] == 1) == lane_gate);
+            } else {
+                const int g = lane_value(gcur.cls, (int)((n0 / U) & 63));
+                lane_gate = g > 0;
+                constant = g != 0;
+            }
+            if (__all(constant)) {
+                double y[U], o[U];
+#pragma unroll
+                for (int i = 0; i < U; i++) {
+                    double s = phase;  // saw C:333-340
+                    hold = s;
+                    if (phase >= 1.0) phase -= 2.0;
+                    phase += inc;
+                    y[i] = flt_lores(f, s, c, r);
+                }
+                Env s2 = e;
+                const bool ok = env_steady_chunk<U>(s2, y, lane_gate, o);
+                if (__all(ok)) {
+                    e = s2;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < U; i++) {
+                        int t;
+                        if constexpr (TPV) t = tc[i];
+                        else t = lane_value(gcur.g[i], (int)((n0 / U) & 63));
+                        o[i] = env_adsr(e, y[i], t);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < U; i++) {
+                    store1<NT>(op, o[i]);
+                    op += V;
+                }
+                continue;
+            }
+        }
       }
 #pragma unroll
       for (int i = 0; i < U; i++) {

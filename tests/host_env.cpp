@@ -6,12 +6,42 @@
 using namespace mxg;
 
 // fast = 1: per sample, take the steady-state tick whenever its entry test holds (what a wavefront does when all its lanes
-// agree); fast = 0: always the state machine.  Both must give the oracle's bits.
+// agree); fast = 2: the general steady chunk; fast = 0: always the state machine.  All must give the oracle's bits.
 extern "C" int env_host(int mode, int fast, size_t V, size_t N, const double *x, const int32_t *trig, int tpv,
                         const double *par, const int64_t *holdtime, double *dst, int64_t *ist, double *out) {
+    int steady = 0;  // fast = 2: chunks taken by env_steady_chunk, per mille of all full chunks
+    size_t chunks = 0;
     for (size_t v = 0; v < V; v++) {
         Env e;
         env_load(e, V, v, par, holdtime, dst, ist);
+        if (fast == 2 && mode == 0) {
+            // fast = 2: chunks of 8 samples with a constant gate go through env_steady_chunk when it accepts them (what a
+            // wavefront does when every lane accepts), everything else through the state machine
+            constexpr int U = 8;
+            size_t n = 0;
+            for (; n + U <= N; n += U) {
+                double xc[U], o[U];
+                bool constant = true;
+                const int t0 = tpv ? trig[n * V + v] : trig[n];
+                for (int i = 0; i < U; i++) {
+                    xc[i] = x ? x[(n + i) * V + v] : 1.0;
+                    const int t = tpv ? trig[(n + i) * V + v] : trig[n + i];
+                    constant = constant && ((t == 1) == (t0 == 1));
+                }
+                Env s = e;
+                chunks++;
+                if (constant && env_steady_chunk<U>(s, xc, t0 == 1, o)) {
+                    e = s;
+                    steady++;
+                    for (int i = 0; i < U; i++) out[(n + i) * V + v] = o[i];
+                } else {
+                    for (int i = 0; i < U; i++) out[(n + i) * V + v] = env_adsr(e, xc[i], tpv ? trig[(n + i) * V + v] : trig[n + i]);
+                }
+            }
+            for (; n < N; n++) out[n * V + v] = env_adsr(e, x ? x[n * V + v] : 1.0, tpv ? trig[n * V + v] : trig[n]);
+            env_store(e, V, v, dst, ist);
+            continue;
+        }
         for (size_t n = 0; n < N; n++) {
             const double in = x ? x[n * V + v] : 1.0;
             const int t = tpv ? trig[n * V + v] : trig[n];
@@ -24,5 +54,5 @@ extern "C" int env_host(int mode, int fast, size_t V, size_t N, const double *x,
         }
         env_store(e, V, v, dst, ist);
     }
-    return 0;
+    return chunks ? (int)((double)steady * 1000.0 / (double)chunks) : 0;
 }
