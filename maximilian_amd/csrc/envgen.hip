@@ -117,6 +117,28 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__r
                 continue;
             }
         }
+        // The general steady chunk (mxg_envgen.h): every lane inside a ramp, a hold or the wait of its own for these U samples.
+        // Computed on a copy; committed if the whole wavefront accepts, else the chunk goes through the stage machine.
+        if (n0 + U <= N) {
+            double tt[U], oo[U];
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                if constexpr (TPV) tt[i] = tc[i];
+                else tt[i] = lane_value(gcur.g[i], cc);
+            }
+            EgState s = {envval, currentlevel, tprev, hprev, rprev, tfirst, hfirst, rfirst, phase, counter, state, nxc};
+            const bool ok = envgen_steady_chunk<U>(s, s_tab, S, retrigger, tt, oo);
+            if (__all(ok)) {
+                envval = s.envval; currentlevel = s.currentlevel; tprev = s.tprev; hprev = s.hprev; rprev = s.rprev;
+                tfirst = s.tfirst; hfirst = s.hfirst; rfirst = s.rfirst; counter = s.counter; nxc = s.nxc;
+#pragma unroll
+                for (int i = 0; i < U; i++) {
+                    *op = oo[i];
+                    op += V;
+                }
+                continue;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < U; i++) {
             if (n0 + i >= N) break;

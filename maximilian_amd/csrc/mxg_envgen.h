@@ -95,6 +95,57 @@ __device__ __forceinline__ double envgen_tick(EgState &e, const double *tab, lon
     return e.envval;
 }
 
+// The steady chunk: U samples during which this envelope neither changes state nor leaves its stage, whatever it is doing.
+// Read off play() (H:2277-2356), a lane that is
+//   RAMP   TRIGGERED inside a timed linear stage with more than U samples of it left: per sample the value of the stage's line,
+//          counter++, currentlevel += gradient; the hold detector may set nxcHappened (it only matters later, in the HOLD
+//          stage); a retrigger crossing would reset the envelope;
+//   HOLD   HOLDING with no negative crossing seen: the value stands; a crossing of -trigger leaves the stage;
+//   WAIT   WAITING: the value stands; a positive crossing of the trigger starts the envelope;
+// runs the chunk with the stage row read once, the three zero-crossing detectors (H:569-579) advanced exactly as the state
+// machine advances them, and ~1/5 of the instructions.  The lanes of a wavefront may each be in a different one of the three.
+// Computed on a copy of the state: returns false -- discard the copy -- if an exit condition fired on any of the U samples
+// (a crossing that changes the state, the stage running out) or the lane is in none of them (a HOLD stage entered while
+// TRIGGERED, phase == S); the caller commits only if every lane returned true, else the chunk goes through envgen_tick.
+template <int U>
+__device__ __forceinline__ bool envgen_steady_chunk(EgState &e, const double *tab, long long S, bool retrigger,
+                                                    const double (&t)[U], double (&o)[U]) {
+    if (e.phase < 0 || e.phase >= S) return false;  // (H:2349-2355 fires on phase == S in every state)
+    const double *cs = tab + 6 * e.phase;
+    const double start = cs[0], span = cs[1] - cs[0], gradient = cs[2], curve = cs[3];
+    const long long length = (long long)cs[4];
+    // (linear stages only -- every stage of setupAR / setupASR / setupADSR: a curved stage is dominated by its pow() either way)
+    const bool ramp = e.state == EG_TRIGGERED && cs[5] == 0 && curve == 1.0 && e.counter >= 0 && e.counter + (long long)U < length;
+    const bool hold = e.state == EG_HOLDING && !e.nxc;
+    const bool wait = e.state == EG_WAITING;
+    bool ok = ramp || hold || wait;
+    double envval = e.envval, cl = e.currentlevel;
+    bool nxc = e.nxc;
+#pragma unroll
+    for (int i = 0; i < U; i++) {
+        if (wait) {
+            if (on_zx(e.tprev, e.tfirst, t[i])) ok = false;  // H:2281: the envelope starts
+        } else {
+            const bool neg = on_zx(e.hprev, e.hfirst, -t[i]);  // H:2294 / H:2331
+            nxc = nxc || neg;
+            if (hold && neg) ok = false;                        // H:2334: the hold ends
+            if (retrigger && on_zx(e.rprev, e.rfirst, t[i])) ok = false;  // H:2323 / H:2341: reset
+        }
+        double val = cl;  // H:2302-2304 with curve == 1, as envgen_tick
+        val = (1.0 < val) ? 1.0 : val;
+        val = (val < 0.0) ? 0.0 : val;
+        const double nv = ((val - 0.0) / (1.0 - 0.0) * span) + start;
+        envval = ramp ? nv : envval;
+        cl = ramp ? cl + gradient : cl;
+        o[i] = envval;
+    }
+    e.envval = envval;
+    e.currentlevel = cl;
+    e.nxc = nxc;
+    if (ramp) e.counter += (long long)U;
+    return ok;
+}
+
 // the [5][V] / [7][V] state arrays of mxg_envgen_render
 __device__ __forceinline__ void envgen_load(EgState &e, size_t V, size_t v, const double *dst, const int64_t *ist) {
     e.envval = dst[v]; e.currentlevel = dst[V + v];

@@ -816,10 +816,48 @@ long mxo_convolve(const int16_t *pcm, size_t len, int fftsize, int hopsize, cons
         fclose(f);
     }
     maxiConvolve c;
-    std::streambuf *old = std::cout.rdbuf(nullptr);  // setup() prints "Impulse loaded"
-    c.setup(path, fftsize, hopsize);
-    std::cout.rdbuf(old);
-    remove(path);
+    {
+        // maxiConvolve::setup (maxiConvolve.cpp:13-70) driven step by step instead of called: its impulse analysis starts by
+        // reading amplitudes[len] -- maxiSample::load leaves position = size (maximilian.cpp:681) and play() reads before it
+        // wraps (:740-744) -- i.e. one element past its vector, which is whatever the heap holds there (usually 0, now and then
+        // not: the analysis then differs from run to run).  The oracle's convention for that element is 0 (as for every
+        // player), so the sample is given a zeroed spare element before the reference's own objects do the analysis.
+        std::streambuf *old = std::cout.rdbuf(nullptr);  // load() prints the channel count
+        maxiSample impulse;
+        impulse.load(path);
+        std::cout.rdbuf(old);
+        remove(path);
+        impulse.amplitudes.push_back(0.0);
+        impulse.amplitudes.pop_back();  // capacity stays: [len] is readable and 0
+        maxiFFT fft;
+        fft.setup(fftsize, fftsize, hopsize);
+        float maxReal = 0, maxImag = 0;
+        const int nb = fft.getNumBins();
+        auto keep = [&]() {
+            c.impulseReal.emplace_back(fft.getReal(), fft.getReal() + nb);
+            c.impulseImag.emplace_back(fft.getImag(), fft.getImag() + nb);
+            for (float r : c.impulseReal.back()) if (r > maxReal) maxReal = r;
+            for (float q : c.impulseImag.back()) if (q > maxImag) maxImag = q;
+        };
+        const long L = (long)impulse.getLength();
+        for (long i = 0; i < L; i++)
+            if (fft.process(impulse.play(), maxiFFT::NO_POLAR_CONVERSION)) keep();
+        for (int i = 0; i < nb - (int)(L % nb); i++)
+            if (fft.process(0, maxiFFT::NO_POLAR_CONVERSION)) keep();
+        for (size_t k = 0; k < c.impulseReal.size(); k++)
+            for (int j = 0; j < nb; j++) {
+                c.impulseReal[k][j] /= maxReal;
+                c.impulseImag[k][j] /= maxImag;
+            }
+        c.inFFT.setup(fftsize, fftsize, hopsize);
+        c.ifft.setup(fftsize, fftsize, hopsize);
+        for (size_t k = 0; k < c.impulseReal.size(); k++) {
+            c.FDLReal.push_front(std::vector<float>(nb, 0.0f));
+            c.FDLImag.push_front(std::vector<float>(nb, 0.0f));
+        }
+        c.sumReal.assign(nb, 0.0f);
+        c.sumImag.assign(nb, 0.0f);
+    }
     const size_t nfr = c.impulseReal.size();
     const int bins = c.inFFT.getNumBins();
     for (size_t k = 0; k < nfr && k < cap_frames; k++) {

@@ -27,13 +27,14 @@ def eg_host(tmp_path_factory):
     lib = ctypes.CDLL(so)
     lib.envgen_host.restype = ctypes.c_int
     lib.envgen_host.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
-                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     return lib
 
 
 @pytest.mark.parametrize("name", list(CASES))
 @pytest.mark.parametrize("loop,retrig", [(0, 0), (0, 1), (1, 0), (1, 1)])
-def test_envgen_on_host_matches_oracle_from_arbitrary_states(eg_host, port, name, loop, retrig):
+@pytest.mark.parametrize("fast", [0, 1])
+def test_envgen_on_host_matches_oracle_from_arbitrary_states(eg_host, port, name, loop, retrig, fast):
     lv, tm, cv = CASES[name]
     S = len(tm)
     rng = np.random.default_rng(hash((name, loop, retrig)) % 2 ** 32)
@@ -57,9 +58,38 @@ def test_envgen_on_host_matches_oracle_from_arbitrary_states(eg_host, port, name
     stages = np.ascontiguousarray(stages)
     dst, ist, out = d0.copy(), i0.copy(), np.empty((N, V))
     rc = eg_host.envgen_host(V, N, trig.ctypes.data, 1, stages.ctypes.data, S, loop, retrig, dst.ctypes.data,
-                             ist.ctypes.data, out.ctypes.data)
-    assert rc == 0
+                             ist.ctypes.data, out.ctypes.data, fast)
+    assert rc >= 0
     e, ed, ei, _ = port.envgen(trig, lv, tm, cv, loop, retrig, dst=d0, ist=i0)
     assert_bits_equal(out, e, name)                       # (host pow == the oracle's pow: the curved case is exact here too)
+    assert np.array_equal(ist, ei), "phase / state / nxc / counter / firstTrigger"
+    assert_bits_equal(dst, ed, "envval, currentlevel, detector history")
+
+
+@pytest.mark.parametrize("loop,retrig", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_envgen_steady_chunks_over_long_stages(eg_host, port, loop, retrig):
+    """envgen_steady_chunk (ramp / hold / wait, each lane in its own) on envelopes whose stages last tens to thousands of
+    samples under gates that stay put for a while: stage ends, hold releases, triggers and retriggers anywhere inside a
+    chunk, counters close to the stage length, exact-zero gate values."""
+    rng = np.random.default_rng(31 + 2 * loop + retrig)
+    lv, tm, cv = [0, 1, 0.45, 0.45, 0], [4.0, 21.3, H, 37.7], [1, 1, 1, 1]
+    S = len(tm)
+    V, N = 3000, 2400
+    period = rng.integers(60, 1500, V)
+    n = np.arange(N)[:, None]
+    trig = np.where(((n + rng.integers(0, 1500, V)[None, :]) % period[None, :]) < (rng.uniform(0.05, 0.95, V) * period)[None, :],
+                    1.0, -1.0)
+    trig[:, ::13] = np.where(trig[:, ::13] > 0, 0.7, 0.0)           # gates that rest on exactly 0
+    d0 = np.zeros((5, V)); i0 = np.zeros((7, V), np.int64)
+    i0[4:7] = 1                                                        # fresh detectors (firstTrigger set)
+    _, _, _, stages = port.envgen(trig[:1], lv, tm, cv, loop, retrig)
+    stages = np.ascontiguousarray(stages)
+    dst, ist, out = d0.copy(), i0.copy(), np.empty((N, V))
+    rc = eg_host.envgen_host(V, N, trig.ctypes.data, 1, stages.ctypes.data, S, loop, retrig, dst.ctypes.data,
+                             ist.ctypes.data, out.ctypes.data, 1)
+    print("steady chunks: %.1f %%" % (rc / 10.0))
+    assert rc >= 500
+    e, ed, ei, _ = port.envgen(trig, lv, tm, cv, loop, retrig, dst=d0, ist=i0)
+    assert_bits_equal(out, e, "steady chunks")
     assert np.array_equal(ist, ei), "phase / state / nxc / counter / firstTrigger"
     assert_bits_equal(dst, ed, "envval, currentlevel, detector history")
