@@ -127,7 +127,7 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
 /* key: "osc_vpl" (voices per lane 1|2), "osc_block" (64..1024), "osc_nt" (0|1 non-temporal stores),
  * "voice_block", "voice_nt", "mix_rows" (sample rows per workgroup of the mixdown, 1|2), "fft_generic",
  * "mfcc_tiled" (LDS-staged spectra 0|1), "grain_chunked" (time-sharded granular render 0|1), "grain_lanes_k",
- * "grain_unit" (coalesced unit-increment render 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_slices" (time slices of a unit-path
+ * "grain_unit" (coalesced unit-increment render 0|1), "grain_line" (tile render for arbitrary increments 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_slices" (time slices of a unit-path
  * maxiTimeStretch call whose scheduling and rendering overlap, 1..16), "osc_mix_var" (layout of K1m's lane-exchange butterfly, 0..3),
  * "osc_split" (time parts per voice group in K1: 0 automatic, 1|2|4),
  * "smp_split" (time parts of a block-constant playAtSpeed / playOnceAtSpeed / playUntilAtSpeed launch: 0 automatic, 1..8),

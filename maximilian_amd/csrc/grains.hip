@@ -515,6 +515,7 @@ struct UnitArgs {
     int *err;
     int sampleDur;
     unsigned c0;  // first tile of this launch (time slices)
+    unsigned ltiles, cend;  // K8d: consecutive tiles per workgroup, one past the last tile of this launch
     // fused maxiMix::stereo mixdown of the tile (NULL = off): pan [S], mixpart [stream tiles][T][2]
     const double *pan;
     double *mixpart;
@@ -551,6 +552,42 @@ constexpr int kFlatFlag = 1 << 30;          // in s_cnt: the stream-tile goes th
 constexpr int kCand = 12;  // candidates per stream and tile: <= 8 alive at the tile's start + spawns inside the tile
 // Candidate metadata is packed into two ints (sampleDur < sr/2 <= 2^15 by the window-cache rule): with the 33 KB
 // transpose tile this keeps a workgroup under 40 KB of LDS, i.e. four workgroups per CU instead of three.
+
+// The finished [64 samples][64 streams] tile (LDS, row stride 65): coalesced [T][S] stores, 16 sample rows per wave, and
+// -- when a pan is given -- the maxiMix::stereo partial sums of the tile's 64 streams (shared by K8c and K8d).
+__device__ __forceinline__ void tile_epilogue(const UnitArgs &A, const double *s_tile, const size_t s0, const size_t n0,
+                                              const int lane, const int wave) {
+    const size_t S = A.S;
+    for (int r = wave * 16; r < wave * 16 + 16; r++) {
+        const size_t nn = n0 + r, s = s0 + lane;
+        if (nn < A.T && s < S) A.out[nn * S + s] = s_tile[r * 65 + lane];
+    }
+    if (A.pan) {  // maxiMix::stereo (C:503-509) of the tile's 64 streams, 16 sample rows per wave: the butterfly of K1m
+        const size_t s = s0 + lane;
+        double x = s < S ? A.pan[s] : 0.0;
+        if (x > 1) x = 1;
+        if (x < 0) x = 0;
+        const double gl = sqrt(1.0 - x), gr = sqrt(x);
+        double L[kMixChunk], R[kMixChunk];
+        int idx[kMixChunk];
+#pragma unroll
+        for (int i = 0; i < kMixChunk; i++) {
+            const int r = wave * 16 + i;
+            const double v = (s < S && n0 + r < A.T) ? s_tile[r * 65 + lane] : 0.0;
+            L[i] = v * gl;
+            R[i] = v * gr;
+            idx[i] = i;
+        }
+        const int slot = fold_chunk_swap<int>(idx);
+        const double sl = quad_sum(fold_chunk_swap<double>(L)), sr = quad_sum(fold_chunk_swap<double>(R));
+        const size_t nn = n0 + wave * 16 + (size_t)(slot < 0 ? 0 : slot);
+        if ((lane & 3) == 0 && slot >= 0 && nn < A.T) {
+            double *dst = A.mixpart + ((size_t)blockIdx.x * A.T + nn) * 2;
+            dst[0] = sl;
+            dst[1] = sr;
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
     __shared__ double s_tile[64 * 65];
@@ -808,35 +845,7 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
         }
     }
     __syncthreads();
-    for (int r = wave * 16; r < wave * 16 + 16; r++) {
-        const size_t nn = n0 + r, s = s0 + lane;
-        if (nn < A.T && s < S) A.out[nn * S + s] = s_tile[r * 65 + lane];
-    }
-    if (A.pan) {  // maxiMix::stereo (C:503-509) of the tile's 64 streams, 16 sample rows per wave: the butterfly of K1m
-        const size_t s = s0 + lane;
-        double x = s < S ? A.pan[s] : 0.0;
-        if (x > 1) x = 1;
-        if (x < 0) x = 0;
-        const double gl = sqrt(1.0 - x), gr = sqrt(x);
-        double L[kMixChunk], R[kMixChunk];
-        int idx[kMixChunk];
-#pragma unroll
-        for (int i = 0; i < kMixChunk; i++) {
-            const int r = wave * 16 + i;
-            const double v = (s < S && n0 + r < A.T) ? s_tile[r * 65 + lane] : 0.0;
-            L[i] = v * gl;
-            R[i] = v * gr;
-            idx[i] = i;
-        }
-        const int slot = fold_chunk_swap<int>(idx);
-        const double sl = quad_sum(fold_chunk_swap<double>(L)), sr = quad_sum(fold_chunk_swap<double>(R));
-        const size_t nn = n0 + wave * 16 + (size_t)(slot < 0 ? 0 : slot);
-        if ((lane & 3) == 0 && slot >= 0 && nn < A.T) {
-            double *dst = A.mixpart + ((size_t)blockIdx.x * A.T + nn) * 2;
-            dst[0] = sl;
-            dst[1] = sr;
-        }
-    }
+    tile_epilogue(A, s_tile, s0, n0, lane, wave);
 }
 
 // grains alive after sample T-1, creation order, closed form (one lane per stream)
@@ -873,6 +882,334 @@ __global__ __launch_bounds__(64) void granular_unit_state_kernel(UnitArgs A) {
         const long long steps = T - born;
         const long long sgn = A.spawn_inc[(size_t)j * S + s] > 0 ? 1 : -1;
         if (cnt < kSlots) push((double)unit_index(pos0 + steps * sgn, len), (double)sgn, (double)steps, (double)A.sampleDur);
+    }
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) {
+        A.gst_out[(0 * kSlots + k) * S + s] = gp[k];
+        A.gst_out[(1 * kSlots + k) * S + s] = gi[k];
+        A.gst_out[(2 * kSlots + k) * S + s] = gx[k];
+        A.gst_out[(3 * kSlots + k) * S + s] = gd[k];
+    }
+}
+
+// ---- K8d: tile render for arbitrary increments (maxiStretch, maxiPitchShift, maxiTimeStretch off the integer grid) ------
+// K8b gives a lane one (stream, chunk) and walks it in time: every wavefront load touches 64 different grains, i.e. 64
+// different cache lines, five times per sample -- 320 live lines per wavefront against a 32 KB L1: every gather misses, and
+// the kernel moves ~90 GB from L2 for 1.2 GB of output (4.5-4.9 ms for the config-5 shape whatever the number of lanes).
+// Here, as in K8c, the lanes of a wavefront are 64 CONSECUTIVE SAMPLES of one stream, so a grain's reads of one tile are
+// neighbours (64*inc elements) and its window reads contiguous.  That needs sample k of a grain without walking to it.  The
+// position is a recurrence, pos <- fl(pos + inc) with a wrap at len (maxiGrain::play, L/maxiGrains.h:222-228), not a closed
+// form -- but inside one binade it IS one on the mantissa grid: X_k = X + k*c with c the (constant) number of ulps
+// round-to-nearest adds per step (add_line, mxg_advance.h; fuzzed on the host against the recurrence).  Per (grain, tile):
+//   phase 1  the position at the tile's first sample ("anchor") by the exact multi-step advance_until from the grain's
+//            start, and the line through it if the next 65 steps stay inside its binade without reaching len;
+//   phase 2  lane L evaluates step L + 1 (+ offset for grains born inside the tile) on the line, reads buffer[a], buffer[a+1]
+//            as one 16-byte request and the window, and adds the product in creation order.
+// A (grain, tile) pair without a line (the tile in which the grain wraps or crosses a binade, a tie, a backward grain)
+// walks its at most 64 steps per lane.  Same additions, same products, same order: bit-identical to K8 / K8b.
+// A workgroup renders kLineTiles consecutive tiles and carries the anchors from one to the next on their lines, so the
+// multi-step advance (~1 us per grain with its divisions) runs once per grain and span; the render is sliced against the
+// scheduler like K8c.  Measured, config-5 shape: maxiStretch 4.91 -> 2.60 ms, maxiPitchShift 4.45 -> 2.81 ms per call.  What is
+// left is not latency (4, 8 or 16 pairs in flight: the same time), not instruction count (halving it changed nothing) and not
+// bytes: SQ counters show ~1200 wavefront cycles per (grain, tile) pair, half of them on vmcnt -- every lane of the 16-byte
+// gather is its own address for the texture path, ~1 lane per clock per CU, and a grain-sample needs one whatever the kernel.
+// Tried on top and dropped: fetching a pair's span (64*inc + 2 elements) with ONE coalesced wavefront load into LDS and picking
+// buffer[a], buffer[a+1] from there -- 0.54 -> 0.93 ms per slice (16 KB more LDS: two workgroups per CU instead of three).  The
+// kernel is bound by its phase structure at 8-12 resident wavefronts per CU (four barriers per tile, the per-tile anchor update
+// with a dependent global load, 64-lane-wide phases 1a); more tiles in flight per CU is the lever, i.e. less LDS per tile.
+struct LineCand {  // 24 bytes: 64 streams x 12 candidates + the 33 KB tile keep a workgroup under 53 KB (three per CU)
+    double anchor;  // position after the steps that precede the current tile (the grain's start position until it is born)
+    long long c;    // ulps per step on the anchor's binade, when the line holds
+    int src;        // where the grain's increment lives: j >= 0 spawn j of the stream, -(k+1) carried-in slot k
+    short kb;       // age of the grain at the current tile's first sample: window index of lane L is kb + L
+    unsigned char flags;  // bit 0: the line holds for steps 1 .. 65
+    unsigned char negoff; // lane L evaluates step L + 1 - negoff from the anchor (> 0: born inside the tile; 64: not born yet)
+};
+
+__device__ __forceinline__ double grain_advance_fast(double pos, const double inc, const double dlen, int steps) {
+    if (!(inc > 0.0) || !(pos >= 0.0)) return grain_advance(pos, inc, dlen, steps);  // backwards / NaN: the plain walk
+    while (steps > 0) {
+        bool crossed;
+        steps -= advance_until(pos, inc, dlen, true, steps, crossed);
+        if (crossed) pos -= dlen;  // :223-224
+    }
+    return pos;
+}
+
+constexpr int kLineTiles = 4;  // consecutive tiles per workgroup: the anchors are carried from tile to tile
+
+constexpr int kLineBatch = 4;  // pairs whose gathers are in flight together (4 / 8 / 16 measured: 0.54 / 0.60 / 0.87 ms per slice)
+
+__global__ __launch_bounds__(256) void granular_line_kernel(UnitArgs A) {
+    __shared__ double s_tile[64 * 65];
+    __shared__ LineCand s_cand[64 * kCand];
+    __shared__ int s_cnt[64];
+    // (the wave index in a scalar register: the walk over (stream, candidate) pairs below is scalar control flow only then)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t S = A.S;
+    const size_t s0 = (size_t)blockIdx.x * 64;
+    const size_t cA = (size_t)blockIdx.y * A.ltiles + A.c0;
+    const size_t cB = cA + A.ltiles < A.cend ? cA + A.ltiles : A.cend;
+    const size_t nA = cA * 64;  // first sample of the span
+    const double dlen = (double)A.len;
+    auto inc_of = [&](const int src, const size_t s) {
+        return src >= 0 ? A.spawn_inc[(size_t)src * S + s] : A.gst_in[(1 * kSlots + (size_t)(-src - 1)) * S + s];
+    };
+    auto set_age = [&](LineCand &q, const long long kb) {  // age at the current tile's first sample (< 0: not born yet)
+        q.kb = (short)(kb < -32768 ? -32768 : kb);
+        q.negoff = (unsigned char)(kb >= 0 ? 0 : (kb < -64 ? 64 : -kb));
+    };
+    // ---- phase 1a: one lane per stream lists the grains that play anywhere in the span, in creation order
+    if (threadIdx.x < 64) {
+        const size_t s = s0 + threadIdx.x;
+        int cnt = 0;
+        if (s < S) {
+            // a grain born at sample `born`; its reference position `pos` is the one it has at age `age`
+            auto add = [&](long long born, long long age, double pos, int src) {
+                LineCand &q = s_cand[threadIdx.x * kCand + cnt];
+                const long long kb = (long long)nA - born;
+                q.anchor = pos;
+                q.c = kb - age > 0 ? kb - age : 0;  // phase 1b: steps from the reference position to the span's first sample
+                q.src = src;
+                q.flags = 0;
+                set_age(q, kb);
+                cnt++;
+            };
+            if (nA < 32768) {  // carried-in grains can only be alive during the first <= sr/2 samples
+                for (int k = 0; k < kSlots; k++) {
+                    const double ddur = A.gst_in[(3 * kSlots + k) * S + s];
+                    if (ddur == 0.0) continue;
+                    const double pos = A.gst_in[(0 * kSlots + k) * S + s], inc = A.gst_in[(1 * kSlots + k) * S + s];
+                    const double didx = A.gst_in[(2 * kSlots + k) * S + s];
+                    if (!carried_grain_ok(pos, inc, didx, ddur, dlen, A.sampleDur)) {
+                        atomicMax(A.err, 4);
+                        continue;
+                    }
+                    const long long idx0 = (long long)didx;
+                    if (idx0 + (long long)nA >= (long long)A.sampleDur) continue;  // finished before the span
+                    add(-idx0, idx0, pos, -(k + 1));
+                }
+            }
+            const int first = A.chunk_first[cA * S + s], next = A.chunk_first[cB * S + s];
+            int bornB[kSlots];
+            double posB[kSlots];
+#pragma unroll
+            for (int u = 0; u < kSlots; u++) {  // independent loads (a walk-back loop would chain them), filtered afterwards
+                const int j = first - kSlots + u;
+                const int jc = j < 0 ? 0 : j;
+                bornB[u] = A.spawn_n[(size_t)jc * S + s];
+                posB[u] = A.spawn_pos[(size_t)jc * S + s];
+            }
+#pragma unroll
+            for (int u = 0; u < kSlots; u++) {
+                const int j = first - kSlots + u;
+                if (j >= 0 && (long long)bornB[u] + A.sampleDur > (long long)nA) {
+                    if (cnt >= kCand) { atomicMax(A.err, 1); break; }
+                    add(bornB[u], 0, posB[u], j);
+                }
+            }
+            if (first > kSlots && (long long)A.spawn_n[(size_t)(first - kSlots - 1) * S + s] + A.sampleDur > (long long)nA)
+                atomicMax(A.err, 1);  // more than kSlots earlier spawns alive: the capacity rule of every kernel
+            for (int j = first; j < next; j++) {
+                if (cnt >= kCand) {
+                    atomicMax(A.err, 1);
+                    break;
+                }
+                add(A.spawn_n[(size_t)j * S + s], 0, A.spawn_pos[(size_t)j * S + s], j);
+            }
+        }
+        s_cnt[threadIdx.x] = cnt;
+    }
+    __syncthreads();
+    for (size_t c = cA; c < cB; c++) {
+        const size_t n0 = c * 64;
+        // ---- phase 1b / 1c, all 256 lanes: the anchor of every (stream, candidate) pair at this tile's first sample -- from the
+        //      grain's reference position by the exact multi-step advance (first tile), from the previous tile's anchor by the
+        //      steps that tile took (on its line, or walked) -- and the line through it
+        for (int pidx = threadIdx.x; pidx < 64 * kCand; pidx += 256) {
+            const int st = pidx / kCand, q = pidx - st * kCand;
+            if (q >= s_cnt[st]) continue;
+            LineCand &cd = s_cand[pidx];
+            const double inc = inc_of(cd.src, s0 + st);
+            double anchor = cd.anchor;
+            if (c == cA) {
+                anchor = grain_advance_fast(anchor, inc, dlen, (int)cd.c);
+            } else {
+                const int kb = cd.kb;  // age at the previous tile's first sample
+                const int steps = kb >= 0 ? 64 : (kb > -64 ? 64 + kb : 0);
+                if (steps > 0) {
+                    if (cd.flags & 1) {
+                        const long long ab = __double_as_longlong(anchor);
+                        const long long Xk = ((ab & 0xFFFFFFFFFFFFFLL) | (1LL << 52)) + (long long)steps * cd.c;
+                        anchor = __longlong_as_double((ab & 0x7FF0000000000000LL) | (Xk & 0xFFFFFFFFFFFFFLL));
+                    } else {
+                        anchor = grain_advance(anchor, inc, dlen, steps);
+                    }
+                }
+                set_age(cd, (long long)kb + 64);
+            }
+            const AddLine l = add_line(anchor, inc, dlen, 65);
+            cd.anchor = anchor;
+            cd.c = l.c;
+            cd.flags = l.ok ? 1 : 0;
+        }
+        __syncthreads();
+        // ---- phase 2: lanes = 64 consecutive samples of one stream.  The (stream, candidate) pairs of the wavefront's 16
+        //      streams are walked in (stream, creation) order, kLineBatch at a time: all their gathers are requested before the
+        //      first is consumed (the kernel is latency-bound: one exposed memory latency per batch), and a stream's sum is
+        //      flushed to the tile when the walk moves on to the next stream.
+        const bool inT = (long long)n0 + lane < (long long)A.T;
+        const double amp0 = A.amp[0];
+#pragma unroll
+        for (int i = 0; i < 16; i++) s_tile[lane * 65 + wave * 16 + i] = 0.0;  // streams without a candidate stay silent
+        // The pairs of the wavefront's 16 streams, flattened: lane p of a round stands for pair base + p and fetches its metadata
+        // (one LDS round trip per 64 pairs); the walk below takes each pair's values from that lane with v_readlane.
+        int pre = lane < 16 ? s_cnt[wave * 16 + lane] : 0;  // -> inclusive prefix sums of the 16 candidate counts
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int t = __shfl_up(pre, d);
+            if (lane >= d) pre += t;
+        }
+        const int P = __builtin_amdgcn_readlane(pre, 15);
+        int cur = -1, alive = 0;
+        double total = 0.0;
+        auto flush = [&]() {
+            if (alive > kSlots) atomicMax(A.err, 1);  // same capacity rule as the register-slot kernels
+            if (cur >= 0) s_tile[lane * 65 + wave * 16 + cur] = total;
+        };
+        for (int base = 0; base < P; base += 64) {
+            const int p = base + lane;
+            int stl = 0;  // stream (0..15) of pair p: the number of inclusive prefixes <= p
+#pragma unroll
+            for (int i = 0; i < 15; i++) stl += (__builtin_amdgcn_readlane(pre, i) <= p) ? 1 : 0;
+            const int before = __shfl(pre, stl > 0 ? stl - 1 : 0);
+            const int ql = p - (stl > 0 ? before : 0);
+            const bool have = p < P;
+            const LineCand *cp = s_cand + (wave * 16 + stl) * kCand + (have ? ql : 0);
+            const long long m_anchor = have ? __double_as_longlong(cp->anchor) : 0;
+            const long long m_c = have ? cp->c : 0;
+            const int m_src = have ? cp->src : 0;
+            const int m_meta = have ? (((int)cp->kb << 16) | ((int)cp->negoff << 8) | (int)cp->flags) : 0;
+            const int m_alo = (int)m_anchor, m_ahi = (int)(m_anchor >> 32), m_clo = (int)m_c, m_chi = (int)(m_c >> 32);
+            const int nround = P - base < 64 ? P - base : 64;
+            for (int j0 = 0; j0 < nround; j0 += kLineBatch) {
+                int pst[kLineBatch];
+                double2v vab[kLineBatch];
+                double ve[kLineBatch], rem[kLineBatch];
+                bool ok[kLineBatch], wrapb[kLineBatch];
+#pragma unroll
+                for (int u = 0; u < kLineBatch; u++) {
+                    pst[u] = -1;
+                    ok[u] = false;
+                    wrapb[u] = false;
+                    rem[u] = 0.0;
+                    ve[u] = 0.0;
+                    vab[u] = double2v{0.0, 0.0};
+                    const int j = j0 + u;
+                    if (j < nround) {  // wave-uniform
+                        pst[u] = __builtin_amdgcn_readlane(stl, j);
+                        const unsigned long long ab = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(m_ahi, j) << 32) |
+                                                      (unsigned)__builtin_amdgcn_readlane(m_alo, j);
+                        const unsigned clo = (unsigned)__builtin_amdgcn_readlane(m_clo, j);
+                        const unsigned chi = (unsigned)__builtin_amdgcn_readlane(m_chi, j);
+                        const int meta = __builtin_amdgcn_readlane(m_meta, j);
+                        const int kb = meta >> 16;
+                        // window index and step of this lane; the lanes outside the grain's life read clamped (valid) addresses
+                        const unsigned ku = (unsigned)(kb + lane);
+                        const unsigned m = (unsigned)(lane + 1 - ((meta >> 8) & 0xff));
+                        ok[u] = inT && ku < (unsigned)A.sampleDur;
+                        double pos;
+                        if (meta & 1) {
+                            // step m on the line: inside the binade, adding m*c ulps is adding m*c to the bit pattern (m <= 64, c < 2^52)
+                            const unsigned long long pb = ab + (unsigned long long)m * clo + ((unsigned long long)(m * chi) << 32);
+                            pos = __longlong_as_double((long long)pb);
+                        } else {
+                            const double inc = inc_of(__builtin_amdgcn_readlane(m_src, j), s0 + wave * 16 + pst[u]);
+                            pos = __longlong_as_double((long long)ab);
+                            for (unsigned i = 0; i < 64; i++) {
+                                if (i < m && ok[u]) {
+                                    double p2 = pos + inc;  // :222-226
+                                    if (p2 >= dlen)
+                                        p2 -= dlen;
+                                    else if (p2 < 0)
+                                        p2 += dlen;
+                                    pos = p2;
+                                }
+                            }
+                        }
+                        // 0 <= pos < len < 2^31 on every live lane: floor and the index through the 32-bit conversions
+                        const int ia32 = (int)pos;
+                        rem[u] = pos - (double)ia32;  // pos - floor(pos)
+                        const unsigned iu = (unsigned)ia32 < (unsigned)A.len ? (unsigned)ia32 : 0u;
+                        wrapb[u] = (size_t)iu + 1 >= A.len;                       // :231-233
+                        vab[u] = *reinterpret_cast<const double2v *>(A.amp + iu);  // buffer[a], buffer[a+1]: [len] is readable (guard)
+                        const unsigned kc = ku < (unsigned)A.sampleDur ? ku : 0u;
+                        ve[u] = A.window[kc];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kLineBatch; u++) {
+                    if (pst[u] >= 0) {  // wave-uniform
+                        if (pst[u] != cur) {
+                            flush();
+                            cur = pst[u];
+                            total = 0.0;
+                            alive = 0;
+                        }
+                        if (ok[u]) {
+                            const double vb = wrapb[u] ? amp0 : vab[u].y;
+                            double o = ((1 - rem[u]) * vab[u].x + rem[u] * vb);  // :236-237
+                            o *= ve[u];
+                            total += o;  // creation order
+                            alive++;
+                        }
+                    }
+                }
+            }
+        }
+        flush();
+        __syncthreads();
+        tile_epilogue(A, s_tile, s0, n0, lane, wave);
+        __syncthreads();  // the tile and the candidate list are reused by the next tile of the span
+    }
+}
+
+// grains alive after sample T-1, creation order (one lane per stream): positions by the exact multi-step advance
+__global__ __launch_bounds__(64) void granular_line_state_kernel(UnitArgs A) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t S = A.S;
+    if (s >= S) return;
+    const double dlen = (double)A.len;
+    const long long T = (long long)A.T;
+    double gp[kSlots], gi[kSlots], gx[kSlots], gd[kSlots];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) { gp[k] = gi[k] = gx[k] = gd[k] = 0.0; }
+    auto push = [&](double p, double i, double x, double d) {
+#pragma unroll
+        for (int k = 0; k < kSlots; k++)
+            if (k == cnt) { gp[k] = p; gi[k] = i; gx[k] = x; gd[k] = d; }
+        cnt++;
+    };
+    for (int k = 0; k < kSlots; k++) {
+        const double ddur = A.gst_in[(3 * kSlots + k) * S + s];
+        if (ddur == 0.0) continue;
+        const double pos = A.gst_in[(0 * kSlots + k) * S + s], inc = A.gst_in[(1 * kSlots + k) * S + s];
+        const double didx = A.gst_in[(2 * kSlots + k) * S + s];
+        if (!carried_grain_ok(pos, inc, didx, ddur, dlen, A.sampleDur)) continue;
+        const long long idx0 = (long long)didx;
+        if (idx0 + T >= (long long)A.sampleDur) continue;
+        if (cnt < kSlots) push(grain_advance_fast(pos, inc, dlen, (int)T), inc, (double)(idx0 + T), ddur);
+    }
+    const int count = A.chunk_first[A.C * S + s];
+    int j0 = count;
+    while (j0 > 0 && (long long)A.spawn_n[(size_t)(j0 - 1) * S + s] + A.sampleDur > T) j0--;
+    for (int j = j0; j < count; j++) {
+        const long long born = A.spawn_n[(size_t)j * S + s];
+        const double inc = A.spawn_inc[(size_t)j * S + s];
+        const long long steps = T - born;
+        if (cnt < kSlots)
+            push(grain_advance_fast(A.spawn_pos[(size_t)j * S + s], inc, dlen, (int)steps), inc, (double)steps, (double)A.sampleDur);
     }
 #pragma unroll
     for (int k = 0; k < kSlots; k++) {
@@ -1058,7 +1395,9 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         if (C > cmax) C = cmax;
         if (C < 1) C = 1;
         size_t Tc = (T + C - 1) / C;
-        if (unit) Tc = 64;  // K8c tiles are 64 samples; the chunk table is indexed per tile
+        // K8d (tile render for arbitrary increments) takes what K8c cannot: any mode, any increment
+        const bool line = !unit && tune_get("grain_line") && T < (size_t)1 << 30 && len >= 128 && len < ((size_t)1 << 31) - 128;
+        if (unit || line) Tc = 64;  // K8c / K8d tiles are 64 samples; the chunk table is indexed per tile
         C = (T + Tc - 1) / Tc;
         const double minCycle = A.cycleLength;  // randomOffset >= 0 only lengthens a cycle
         const size_t G = (size_t)((double)T / (minCycle > 1.0 ? floor(minCycle) : 1.0)) + 2;
@@ -1090,7 +1429,7 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         U.pan = nullptr;
         U.mixpart = nullptr;
         const size_t stiles = (S + 63) / 64;
-        if (unit && d_pan) {
+        if ((unit || line) && d_pan) {
             if (int e = scratch_get(SCR_GRAIN_MIX, st, sizeof(double) * stiles * T * 2, (void **)&U.mixpart)) return e;
             U.pan = d_pan;
         }
@@ -1104,7 +1443,12 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         while (slices > 1 && C / ((size_t(1) << slices) - 1) < 16) slices--;  // first slice >= 16 tiles (1024 samples)
         const size_t wsum = (size_t(1) << slices) - 1;
         auto slice_start = [&](int i) { return i >= slices ? C : C * ((size_t(1) << i) - 1) / wsum; };
-        if (unit && slices > 1) {  // mode 0 or 2 (the unit path's modes)
+        // consecutive K8d tiles per workgroup: as many as keep (alive at the span's start) + (born in the span) within kCand
+        int lt = (int)((double)(kCand - kSlots - 1) * minCycle / 64.0);
+        lt = lt < 1 ? 1 : (lt > kLineTiles ? kLineTiles : lt);
+        U.ltiles = (unsigned)lt;
+        U.cend = (unsigned)C;
+        if ((unit || line) && slices > 1) {  // the tile renders: any mode
             if (int e = aux_stream_init()) return e;
             // one caller at a time enqueues its fork/join: a wait captures the event's latest record, so another
             // thread re-recording the shared events between a record and its wait would tie the render to the wrong slice
@@ -1119,21 +1463,35 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
                     KernelTimer kt("granular_sched_kernel", st);
                     if (mode == 0) {
                         hipLaunchKernelGGL((granular_sched_kernel<0>), grid, dim3(64), 0, st, Q);
-                    } else {
+                    } else if (mode == 1) {
+                        hipLaunchKernelGGL((granular_sched_kernel<1>), grid, dim3(64), 0, st, Q);
+                    } else if (mode == 2) {
                         Q.a = d_a + (size_t)Q.n_base * S;  // playAtPosition reads its position signal [T][S] at the births
                         hipLaunchKernelGGL((granular_sched_kernel<2>), grid, dim3(64), 0, st, Q);
+                    } else {
+                        hipLaunchKernelGGL((granular_sched_kernel<3>), grid, dim3(64), 0, st, Q);
                     }
                 }
                 MXG_HIP(hipEventRecord(g_aux_ev[i], st));
                 MXG_HIP(hipStreamWaitEvent(g_aux, g_aux_ev[i], 0));
                 U.c0 = (unsigned)ci;
-                KernelTimer kt("granular_unit_kernel", g_aux);
-                hipLaunchKernelGGL(granular_unit_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)(cn - ci)), dim3(256), 0,
-                                   g_aux, U);
+                if (unit) {
+                    KernelTimer kt("granular_unit_kernel", g_aux);
+                    hipLaunchKernelGGL(granular_unit_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)(cn - ci)), dim3(256), 0,
+                                       g_aux, U);
+                } else {
+                    U.cend = (unsigned)cn;
+                    KernelTimer kt("granular_line_kernel", g_aux);
+                    hipLaunchKernelGGL(granular_line_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)((cn - ci + lt - 1) / lt)),
+                                       dim3(256), 0, g_aux, U);
+                }
             }
             MXG_HIP(hipEventRecord(g_aux_done, g_aux));
             MXG_HIP(hipStreamWaitEvent(st, g_aux_done, 0));
-            hipLaunchKernelGGL(granular_unit_state_kernel, grid, dim3(64), 0, st, U);
+            if (unit)
+                hipLaunchKernelGGL(granular_unit_state_kernel, grid, dim3(64), 0, st, U);
+            else
+                hipLaunchKernelGGL(granular_line_state_kernel, grid, dim3(64), 0, st, U);
             if (U.pan) {
                 hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((T * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, stiles,
                                    T * 2, U.mixpart, d_mix);
@@ -1155,6 +1513,17 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
                 hipLaunchKernelGGL(granular_unit_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)C), dim3(256), 0, st, U);
             }
             hipLaunchKernelGGL(granular_unit_state_kernel, grid, dim3(64), 0, st, U);
+            if (U.pan) {
+                hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((T * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, stiles,
+                                   T * 2, U.mixpart, d_mix);
+                mixed = true;
+            }
+        } else if (line) {
+            {
+                KernelTimer kt("granular_line_kernel", st);
+                hipLaunchKernelGGL(granular_line_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)((C + lt - 1) / lt)), dim3(256), 0, st, U);
+            }
+            hipLaunchKernelGGL(granular_line_state_kernel, grid, dim3(64), 0, st, U);
             if (U.pan) {
                 hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((T * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, stiles,
                                    T * 2, U.mixpart, d_mix);

@@ -130,6 +130,41 @@ MXG_HD_NOINLINE int advance_until(double &x, const double r, const double limit,
     return done;
 }
 
+// ---- the next n additions of x <- fl(x + r) as a LINE on x's mantissa grid -----------------------------------------
+// The binade case of advance_until stated for a fixed number of steps, so that step k can be evaluated on its own (a lane
+// per step): inside x's binade [2^e, 2^(e+1)) every partial sum is an integer multiple of u = 2^(e-52); r = (R + f) u with
+// 0 <= f < 1, and round-to-nearest adds R ulps (f < 1/2) or R + 1 ulps (f > 1/2) on EVERY step:  X_k = X + k c,
+// x_k = X_k * u.  ok = false when that does not hold for all k <= n: r <= 0 or not normal, x not a positive normal number,
+// r >= 2^52 ulps, the tie f == 1/2 (then the parity of X decides step by step), a sum leaving the binade, or a sum
+// reaching `limit` (the caller's wrap).  The value after k steps is add_line_at(l, k).
+struct AddLine {
+    long long X, c;
+    int e;
+    bool ok;
+};
+MXG_HD AddLine add_line(const double x, const double r, const double limit, const int n) {
+    AddLine l = {0, 0, 0, false};
+    const long long xb = __double_as_longlong(x), rb = __double_as_longlong(r);
+    const int e = (int)((xb >> 52) & 0x7ff), er = (int)((rb >> 52) & 0x7ff);
+    if (xb < 0 || rb <= 0 || e == 0 || e == 0x7ff || er == 0 || er == 0x7ff) return l;  // signs, zero, subnormal, Inf, NaN
+    const double ru = ldexp(r, 1075 - e);  // r in ulps of x (exact scaling; may underflow to 0 or a subnormal: f then < 1/2)
+    if (!(ru < 4503599627370496.0)) return l;
+    const double Rf = floor(ru), fr = ru - Rf;
+    if (fr == 0.5) return l;
+    l.X = (xb & 0xFFFFFFFFFFFFFLL) | (1LL << 52);
+    l.c = (long long)Rf + (fr > 0.5 ? 1 : 0);
+    l.e = e;
+    const long long Xn = l.X + (long long)n * l.c;  // < 2^53 + 2^7 * 2^52: no overflow for n <= 128
+    if (n < 0 || n > 128 || Xn > (1LL << 53) - 1) return l;
+    const double last = __longlong_as_double(((long long)e << 52) | (Xn & 0xFFFFFFFFFFFFFLL));
+    l.ok = last < limit;
+    return l;
+}
+MXG_HD double add_line_at(const AddLine &l, const int k) {
+    const long long Xk = l.X + (long long)k * l.c;
+    return __longlong_as_double(((long long)l.e << 52) | (Xk & 0xFFFFFFFFFFFFFLL));
+}
+
 // Smallest integer Lc > L (L an integer-valued double) with floor(fmod(Lc, cyc)) == 0, cyc > 2.  The candidate comes
 // from one multiplication; fmod is exact, so the predicate itself confirms it (and that the integer before it is not
 // a birth, and that no whole cycle was jumped).  ok = false: could not be confirmed, the caller walks sample by sample.

@@ -37,6 +37,7 @@ Tune g_tune[] = {
     {"fft_generic", 0, 0, 1},  // 1: force the generic per-stage FFT kernel also for fftSize 1024
     {"grain_chunked", 1, 0, 1},  // 0: serial-in-time K8 instead of the time-sharded K8a+K8b
     {"grain_lanes_k", 128, 16, 4096},  // K8b: target number of (stream, chunk) lanes, in units of 1024
+    {"grain_line", 1, 0, 1},  // K8d: tile render for arbitrary increments (0: the (stream, chunk) walk K8b)
     {"grain_unit", 1, 0, 1},  // K8c: coalesced closed-form render when every grain has inc = +-1
     {"grain_fast_sched", 1, 0, 1},  // K8a: event-driven exact multi-step scheduler (0: one step at a time)
     {"grain_slices", 4, 1, 16},  // K8a/K8c: time slices of a maxiTimeStretch call (scheduling of slice i+1 overlaps render of slice i)

@@ -70,6 +70,45 @@ int main(int argc, char **argv) {
         }
         jumps += da;
     }
+    // add_line: every one of the next n sums, on its own, against the recurrence
+    long line_bad = 0, line_ok = 0;
+    for (long i = 0; i < cases; i++) {
+        double r;
+        switch (g() % 6) {
+            case 0: r = 0.25 + 1.5 * u01(g); break;
+            case 1: r = (double)(1 + g() % 512) / 256.0; break;
+            case 2: r = ldexp(1.0 + u01(g), -(int)(g() % 70)); break;     // far below an ulp of x too
+            case 3: r = 1.0; break;
+            case 4: r = ldexp(1.0 + (double)(g() % 3) * 0.5, -(int)(g() % 12)) ; break;  // exact halves of an ulp: ties
+            default: r = u01(g) * 1e-3 + 1e-9; break;
+        }
+        double x0;
+        switch (g() % 5) {
+            case 0: x0 = 1.0 + u01(g) * 4.4e6; break;
+            case 1: x0 = ldexp(1.0, (int)(g() % 24)) - r * (double)(g() % 70); if (!(x0 > 0)) x0 = 1.0; break;  // about to leave its binade
+            case 2: x0 = (double)(1 + g() % 100000); break;
+            case 3: x0 = u01(g); break;
+            default: x0 = ldexp(1.0 + u01(g), (int)(g() % 22)); break;
+        }
+        const double limit = (g() & 1) ? 4.41e6 : x0 + r * (double)(g() % 200);
+        const int n = 1 + (int)(g() % 128);
+        const AddLine l = add_line(x0, r, limit, n);
+        if (!l.ok) continue;
+        line_ok++;
+        double x = x0;
+        for (int k = 1; k <= n; k++) {
+            x = x + r;
+            if (bits(add_line_at(l, k)) != bits(x) || !(x < limit)) {
+                if (line_bad < 5) printf("add_line mismatch: x0=%a r=%a n=%d step %d: %a vs %a (limit %a)\n", x0, r, n, k,
+                                         add_line_at(l, k), x, limit);
+                line_bad++;
+                break;
+            }
+        }
+    }
+    printf("add_line: %ld of %ld cases accepted, %ld wrong\n", line_ok, cases, line_bad);
+    bad += line_bad;
+    if (line_ok < cases / 4) bad++;  // the fuzz is meant to exercise the accepted case
     long nb_bad = 0, nb_fallback = 0;
     for (long i = 0; i < cases / 4; i++) {
         double cyc;

@@ -10,6 +10,12 @@ CASES = {"ts_hann": (0, 0, 0.05, 4, True), "ts_hamming_norand": (0, 1, 0.03, 3, 
          "st_hann": (1, 0, 0.05, 2, True), "st_gauss": (1, 8, 0.021, 5, True)}
 
 
+def _sample_bank(mx, samples):
+    sb = mx.maxiSampleBank(1)
+    sb.setSample(samples)
+    return sb
+
+
 def make_bank(mx, mode, window, samples, S):
     sb = mx.maxiSampleBank(1)
     sb.setSample(samples)
@@ -17,12 +23,15 @@ def make_bank(mx, mode, window, samples, S):
     return bank
 
 
-@pytest.fixture(params=[1, 0], ids=["chunked", "serial"])
+@pytest.fixture(params=[(1, 1), (1, 0), (0, 1)], ids=["tiles", "walk", "serial"])
 def chunked(mx, request):
-    """Run with the time-sharded K8a+K8b (default) and with the serial K8."""
-    prev = mx.lib().mxg_tune(b"grain_chunked", request.param)
-    yield request.param
+    """Run with the scheduler pre-pass + tile renders (K8a + K8c / K8d, the default), with the (stream, chunk) walk K8b in
+    place of K8d, and with the serial K8."""
+    prev = mx.lib().mxg_tune(b"grain_chunked", request.param[0])
+    prev2 = mx.lib().mxg_tune(b"grain_line", request.param[1])
+    yield request.param[0]
     mx.lib().mxg_tune(b"grain_chunked", prev)
+    mx.lib().mxg_tune(b"grain_line", prev2)
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -223,7 +232,7 @@ def test_pitch_shift_event_driven_long_run(mx, port):
     assert_bits_equal(bank.grains.numpy(), gst, "grains")
 
 
-@pytest.mark.parametrize("knob,value", [(b"grain_unit", 0), (b"grain_lanes_k", 16), (b"grain_lanes_k", 4096),
+@pytest.mark.parametrize("knob,value", [(b"grain_unit", 0), (b"grain_line", 0), (b"grain_lanes_k", 16), (b"grain_lanes_k", 4096),
                                         (b"grain_slices", 1), (b"grain_slices", 2), (b"grain_slices", 16)])
 def test_granular_launch_knobs_same_bits(mx, knob, value):
     """The coalesced unit-increment render vs the general (stream, chunk) render, and the chunking granularity of
@@ -380,3 +389,39 @@ def test_granular_render_with_fused_mixdown(mx, port, mode, S, T):
     err = max(np.abs(m1 - em).max(), np.abs(m0 - em).max())
     print("granular mixdown S=%d: max |mix - sequential sum| = %.3e (%.2e x S x peak)" % (S, err, err / (S * scale)))
     assert err <= mix_tol(S, scale)
+
+
+@pytest.mark.parametrize("mode", [1, 3])
+@pytest.mark.parametrize("Ls", [300, 70000])
+def test_tile_render_lines_and_their_exceptions(mx, port, mode, Ls):
+    """K8d evaluates sample k of a grain on a line over the mantissa grid of its binade; the (grain, tile) pairs without one
+    walk their steps: grains wrapping around a short sample several times per tile row, positions crossing powers of two,
+    increments whose ulp remainder is exactly one half in some binade (ties), increments far below an ulp... plus backward
+    grains, three carried launches of ragged lengths (live grains carried in) and a ragged last tile.  Bit-identical to the
+    port, scheduler and live-grain state included."""
+    rng = np.random.default_rng(60 + mode + Ls)
+    S = 160
+    smp = rng.uniform(-1, 1, Ls)
+    speed = rng.uniform(0.2, 2.2, S)
+    speed[::5] = 1.0 + 2.0 ** -rng.integers(18, 46, speed[::5].size)     # short mantissas: exact halves of an ulp somewhere
+    speed[1::16] = 2.0 ** -rng.integers(1, 30, speed[1::16].size)           # tiny steps: many samples per buffer element
+    speed[2::16] *= -1.0                                                     # backwards
+    speed[3::16] = rng.uniform(4.0, 30.0, speed[3::16].size)               # several buffer elements per sample
+    if mode == 1:
+        bank = mx.maxiStretchBank(S, _sample_bank(mx, smp), "hann")
+        play = lambda n: bank.play(speed, np.abs(speed) * 0.7 + 0.05, 0.05, 4, n).numpy()
+        ref = lambda n, st, gst: port.granular(1, 0, smp, n, speed, b=np.abs(speed) * 0.7 + 0.05, st=st, gst=gst)
+    else:
+        bank = mx.maxiPitchShiftBank(S, _sample_bank(mx, smp), "hann")
+        play = lambda n: bank.play(speed, 0.05, 4, n).numpy()
+        ref = lambda n, st, gst: port.granular(3, 0, smp, n, speed, st=st, gst=gst)
+    bank.setPosition(np.arange(S) / S)
+    st, gst = bank.state.numpy(), bank.grains.numpy()
+    for n in (3000, 1000, 333):
+        o = play(n)
+        e, st, gst, rc = ref(n, st, gst)
+        assert rc == 0
+        assert_bits_equal(o, e, "mode %d, %d samples" % (mode, n))
+        assert_bits_equal(bank.state.numpy(), st, "scheduler state")
+        assert_bits_equal(bank.grains.numpy(), gst, "live grains")
+
