@@ -440,6 +440,8 @@ def main():
                                                      % ("one ncclReduce per %d blocks on the mix queue's stream" % queue.depth
                                                         if queue is not None else ""))},
             "rccl_ranks": world if (queue is not None and world > 1) else (1 if queue is not None else 0),
+            "like_for_like_single_gpu": ("this line includes the maxiMix mixdown + reduce in every step; the default N=1 line does not -- "
+                                         "compare with `bench.py --mixdown fused` (DESIGN.md section 6)") if world > 1 and queue is not None else None,
             "roofline": roof,
             "kernels": {k: {"ms": round(v["ms"], 5), "launches_per_step": round(v["launches_per_step"], 3)}
                         for k, v in sorted(kernels.items())},
