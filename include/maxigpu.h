@@ -129,7 +129,7 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "mfcc_tiled" (LDS-staged spectra 0|1), "grain_chunked" (time-sharded granular render 0|1), "grain_lanes_k",
  * "grain_unit" (coalesced unit-increment render 0|1), "grain_line" (tile render for arbitrary increments 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_slices" (time slices of a unit-path
  * maxiTimeStretch call whose scheduling and rendering overlap, 1..16), "osc_mix_var" (layout of K1m's lane-exchange butterfly, 0..3),
- * "osc_split" (time parts per voice group in K1: 0 automatic, 1|2|4),
+ * "osc_split" (time parts per voice group in K1: 0 automatic, 1..8),
  * "smp_split" (time parts of a block-constant playAtSpeed / playOnceAtSpeed / playUntilAtSpeed launch: 0 automatic, 1..8),
  * "mfcc_mfma_fullk" (the MFMA mel contraction runs over all numBins bins instead of the ones that carry weight, 0|1).
  * "fused_waves16" (mxg_fft_mfcc_batch: the 16-waves-per-CU form of the fused kernel when the request allows it, 0|1).
