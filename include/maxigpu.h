@@ -230,6 +230,9 @@ int mxg_env_render(int mode, size_t V, size_t N, const double *d_in, const int32
 /* maxiEnv setters on the host libm (C:1469-1494): which 0 setAttack 1 setDecay 2 setRelease
  * 3 setAttackMS. */
 double mxg_env_coeff_host(int which, double ms);
+/* maxiConvert::mtof (H:941, C:1498-1500): the reference's 129-entry table of six-decimal literals, bit for bit (host side;
+ * midinote outside [0, 128], which the reference indexes out of bounds, returns 0). */
+double mxg_mtof_host(int midinote);
 
 /* ---- fused subtractive voice (saw -> lores -> adsr in registers, one store per sample) ---- */
 /* mode 0: out = adsr(lores(saw(freq), cutoff, res), trig); coefficients hoisted: d_coef =

@@ -523,6 +523,17 @@ public:
     void setTrigger(int trigger_) { trigger = trigger_; }
 };
 
+// ---- maxiConvert (H:937-962) -- conversions a patch does on the host, as the reference does -----------------------
+class maxiConvert {
+public:
+    static double mtof(int midinote) { return mxg_mtof_host(midinote); }  // C:1498-1500 (table lookup)
+    static size_t msToSamps(double timeMs) { return static_cast<size_t>(timeMs / 1000.0 * maxiSettings::sampleRate); }
+    static double sampsToMs(size_t samples) { return samples / maxiSettings::sampleRate * 1000.0; }  // (integer division first, H:950)
+    static double ampToDbs(double amp) { return std::log10(amp) * 20.0; }
+    static double dbsToAmp(double dbs) { return std::pow(10.0, dbs * 0.05); }
+};
+using convert = maxiConvert;  // H:964
+
 // ---- maxiFilter (H:289-366; C:442-500) ---------------------------------------------------------------------
 class maxiFilter {
     using Pool = maxigpu::ps::FilterPool;

@@ -57,6 +57,7 @@ SIGNATURES = {
     "mxg_env_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_env_coeff_host": (c_double, [c_int, c_double]),
+    "mxg_mtof_host": (c_double, [c_int]),
     "mxg_voice_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),

@@ -19,6 +19,7 @@
 
 #include <type_traits>
 
+#include "maxi_tables.h"
 #include "mxg_common.h"
 #include "mxg_env.h"
 #include "mxg_sincos.h"
@@ -565,6 +566,10 @@ double mxg_env_coeff_host(int which, double ms) {
     }
     return 0.0;
 }
+
+// maxiConvert::mtof (H:941, C:1498-1500): mtofarray[midinote], the reference's literals (maxi_tables.h, generated from the
+// compiled reference)
+double mxg_mtof_host(int midinote) { return (midinote >= 0 && midinote <= 128) ? MAXI_MTOF[midinote] : 0.0; }
 
 int mxg_voice_render(int mode, size_t V, size_t N, const double *d_freq, const double *d_cutoff,
                      const double *d_res, const double *d_coef, const int32_t *d_trig, int tpv,

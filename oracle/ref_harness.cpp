@@ -68,6 +68,8 @@ void mxo_settings(size_t sr, size_t ch, size_t buf) { maxiSettings::setup(sr, ch
 const double *mxo_sine_table(void) { return sineBuffer; }
 const double *mxo_transition_table(void) { return transition; }
 const double *mxo_pitch_ratios(void) { return pitchRatios; }  // src/maximilian.h:112
+extern double mtofarray[129];                                  // src/maximilian.cpp:203
+const double *mxo_mtof_table(void) { return mtofarray; }       // what maxiConvert::mtof indexes (maximilian.cpp:1498-1500)
 // The two out-of-bounds neighbours the reference reads (sinebuf4 -> sineBuffer[-1],
 // sawn -> transition[1001]); exported so the tests can assert what this build holds.
 double mxo_sine_table_guard(void) { return (&sineBuffer[0])[-1]; }

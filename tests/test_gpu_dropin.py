@@ -70,6 +70,7 @@ EXAMPLES = {
     "08d": ("8.Counting4: counter rate from a sawn LFO, array lookup, square / sawn", 0.0),
     "10": ("10.Filters: adsr gated by a counter, sawn through lores with the envelope on its cutoff", 0.0),
     "13": ("13.Advanced-Filters: sawn through the patch's own float biquad", 0.0),
+    "16": ("16.Replicant: seven oscillators, adsr / ar with explicit coefficients, two lores filters, a delay line, mtof", 0.0),
 }
 
 
