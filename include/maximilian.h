@@ -523,6 +523,27 @@ public:
     void setTrigger(int trigger_) { trigger = trigger_; }
 };
 
+// ---- maxiMix (H:372-420; C:503-541) ------------------------------------------------------------------------------
+// Stateless: one voice, one sample through the bank's bus kernel, whose per-voice bus signals are what the reference leaves in
+// two / four / eight (bit-exact, ambisonic's quirks included).  A launch per call -- a panner's input changes every sample by
+// nature; banks mix on the device (mxg_mix_bus, mxg_osc_render_mix).
+class maxiMix {
+    static void run(int channels, double input, double x, double y, double z, double *out) {
+        using maxigpu::ps::check;
+        static maxigpu::ps::DevBuf<double> d;  // [in, x, y, z | bus 8 | mix 8]
+        double *p = d.need(20);
+        const double h[4] = {input, x, y, z};
+        check(mxg_memcpy_h2d(p, h, sizeof(h), nullptr), "h2d mix");
+        check(mxg_mix_bus(channels, 1, 1, p, p + 1, p + 2, p + 3, p + 4, p + 12, nullptr), "mxg_mix_bus");
+        check(mxg_memcpy_d2h(out, p + 4, sizeof(double) * channels, nullptr), "d2h mix");
+    }
+
+public:
+    void stereo(double input, std::vector<double> &two, double x) { run(2, input, x, 0.0, 0.0, two.data()); }
+    void quad(double input, std::vector<double> &four, double x, double y) { run(4, input, x, y, 0.0, four.data()); }
+    void ambisonic(double input, std::vector<double> &eight, double x, double y, double z) { run(8, input, x, y, z, eight.data()); }
+};
+
 // ---- maxiConvert (H:937-962) -- conversions a patch does on the host, as the reference does -----------------------
 class maxiConvert {
 public:

@@ -171,8 +171,23 @@ using namespace mxg;
 
 extern "C" {
 
+namespace {
+// The HIP runtime draws from / reseeds the process-wide libc PRNG while it initialises (measured: the first rand() after
+// hipGetDeviceCount + hipStreamCreate is 2081652679 instead of 1804289383).  maxiOsc::noise (C:214-220) and the grain jitter
+// (L/maxiGrains.h:352) ARE that stream in the reference, so a host that links this library must find it where the reference
+// would: glibc's rand() shares random()'s state, so the initialisation runs on a throw-away state array and the caller's is
+// switched back in afterwards, untouched.
+struct LibcPrngGuard {
+    char scratch[128];
+    char *saved;
+    LibcPrngGuard() { saved = initstate(1u, scratch, sizeof(scratch)); }
+    ~LibcPrngGuard() { if (saved) setstate(saved); }
+};
+}  // namespace
+
 int mxg_init(int device) {
     std::lock_guard<std::mutex> lk(g_mu);
+    LibcPrngGuard prng;
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
@@ -207,6 +222,7 @@ size_t mxg_sample_rate(void) { return g_settings.sampleRate; }
 
 void *mxg_malloc(size_t bytes) {
     if (ensure_init()) return nullptr;
+    LibcPrngGuard prng;  // (the first allocation initialises more of the runtime)
     void *p = nullptr;
     if (check_hip(hipMalloc(&p, bytes ? bytes : 8), "hipMalloc")) return nullptr;
     return p;

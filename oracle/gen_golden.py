@@ -479,7 +479,7 @@ def main():
     # ten more of the reference's example patches (maximilian_examples/2 .. 13), 6000 frames each, left channel only (they write
     # the same value to both, 13.Advanced-Filters writes channel 0 only)
     d2 = {}
-    for ex in ("02", "03", "04", "05", "06", "08b", "08c", "08d", "10", "13", "16"):
+    for ex in ("02", "03", "04", "05", "06", "08b", "08c", "08d", "10", "11", "13", "16"):
         tmp = os.path.join("/tmp", "mxo_example_%s.f64" % ex)
         frames = 30000 if ex == "16" else 6000   # 16.Replicant: six of its 9 Hz metronome ticks
         subprocess.run([os.path.join(HERE, "_ref", "example_" + ex), str(frames), tmp], check=True, stdout=subprocess.DEVNULL,
@@ -487,7 +487,7 @@ def main():
         d2["ex" + ex] = np.fromfile(tmp, np.float64).reshape(frames, 2)[:, 0].copy()
         os.remove(tmp)
     save("dropin_examples.npz", **d2)
-    files["dropin_examples.npz"] = ("maximilian_examples 2.TwoTones, 3.AM1, 4.AM2, 5.FM1, 6.FM2, 8.Counting2/3/4, 10.Filters, 13.Advanced-Filters, 16.Replicant of "
+    files["dropin_examples.npz"] = ("maximilian_examples 2.TwoTones, 3.AM1, 4.AM2, 5.FM1, 6.FM2, 8.Counting2/3/4, 10.Filters, 11.Mixing, 13.Advanced-Filters, 16.Replicant of "
                                     "the reference: 6000 frames (16: 30000) of channel 0 each, compiled with the unmodified reference library")
     files["dropin.npz"] = ("cpp/commandline/main.cpp (44100 frames), 14.monosynth (96000), 15.polysynth (16384) of the reference, "
                            "compiled with the unmodified reference library and run through oracle/example_host.cpp (routing() restated)")
