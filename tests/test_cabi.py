@@ -57,6 +57,20 @@ def test_host_coefficients_match_oracle(port):
             assert a == b or (np.isnan(a) and np.isnan(b)) or (np.isinf(a) and np.isinf(b) and a == b), (which, ms)
 
 
+def test_mtof_table_is_the_reference_literals(ref):
+    """maxiConvert::mtof (src/maximilian.cpp:1498-1500) indexes mtofarray[129] (cpp:203): the product's host table has the
+    same 129 doubles, bit for bit, and answers 0 outside the table instead of reading past it."""
+    import ctypes
+    import maximilian_amd as m
+    f = m.lib().mxg_mtof_host
+    ref.L.mxo_mtof_table.restype = ctypes.POINTER(ctypes.c_double)
+    want = np.array([ref.L.mxo_mtof_table()[i] for i in range(129)])
+    got = np.array([f(i) for i in range(129)])
+    assert_bits_equal(got, want)
+    assert f(69) == 440.0 and f(57) == 220.0
+    assert f(-1) == 0.0 and f(129) == 0.0
+
+
 def test_settings_and_tune_validation(port):
     import maximilian_amd as m
     L = m.lib()
