@@ -70,6 +70,7 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__r
     constexpr int U = 8;
     double tn[U];
     GateGroup<U, double> gcur;  // shared gate: lane j keeps chunk j's triggers (mxg_gate.h)
+    int gflags = 0;             // ... and whether the trigger (bit 0) / its negation (bit 1) crosses zero upwards inside chunk j
     const auto positive = [](double t) { return t > 0; };
     if constexpr (TPV) {
 #pragma unroll
@@ -79,8 +80,11 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__r
         }
     } else {
         gate_group_load(gcur, trig_in, N, 0, positive);
-        asm volatile("" : "+v"(gcur.cls));
+        const EgCross xg = envgen_cross<U>(gcur.g);
+        gflags = (xg.pos ? 1 : 0) | (xg.neg ? 2 : 0);
+        asm volatile("" : "+v"(gcur.cls), "+v"(gflags));
     }
+    EgRow row = envgen_row(s_tab, A.nstages, phase);  // the stage row of `phase`, re-read when the stage machine has run
     for (size_t n0 = 0; n0 < N; n0 += U) {
         double tc[U];
         if constexpr (TPV) {
@@ -96,7 +100,11 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__r
         // stays <= 0, or stays positive after a positive sample (no trigger either way, H:2281 / onZX H:569-579).  With a shared gate the test is one readlane plus one ballot per chunk.
         const int cc = (int)((n0 / U) & 63);
         if constexpr (!TPV) {
-            if (cc == 0 && n0) gate_group_load(gcur, trig_in, N, n0 / (64 * U), positive);  // one drain per 64 chunks
+            if (cc == 0 && n0) {  // one drain per 64 chunks
+                gate_group_load(gcur, trig_in, N, n0 / (64 * U), positive);
+                const EgCross xg = envgen_cross<U>(gcur.g);
+                gflags = (xg.pos ? 1 : 0) | (xg.neg ? 2 : 0);
+            }
             const int g = lane_value(gcur.cls, cc);
             int fast = 0;
             // (phase != S: the end-of-envelope test after the switch, H:2349-2355, runs on every sample whatever the
@@ -120,14 +128,19 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__r
         // The general steady chunk (mxg_envgen.h): every lane inside a ramp, a hold or the wait of its own for these U samples.
         // Computed on a copy; committed if the whole wavefront accepts, else the chunk goes through the stage machine.
         if (n0 + U <= N) {
-            double tt[U], oo[U];
-#pragma unroll
-            for (int i = 0; i < U; i++) {
-                if constexpr (TPV) tt[i] = tc[i];
-                else tt[i] = lane_value(gcur.g[i], cc);
+            double oo[U];
+            EgCross x;
+            if constexpr (TPV) {
+                x = envgen_cross<U>(tc);
+            } else {  // shared gate: the chunk's crossings were worked out once per group, by lane cc
+                const int f = lane_value(gflags, cc);
+                x.first = lane_value(gcur.g[0], cc);
+                x.last = lane_value(gcur.g[U - 1], cc);
+                x.pos = (f & 1) != 0;
+                x.neg = (f & 2) != 0;
             }
             EgState s = {envval, currentlevel, tprev, hprev, rprev, tfirst, hfirst, rfirst, phase, counter, state, nxc};
-            const bool ok = envgen_steady_chunk<U>(s, s_tab, S, retrigger, tt, oo);
+            const bool ok = envgen_steady_chunk<U>(s, row, retrigger, x, oo);
             if (__all(ok)) {
                 envval = s.envval; currentlevel = s.currentlevel; tprev = s.tprev; hprev = s.hprev; rprev = s.rprev;
                 tfirst = s.tfirst; hfirst = s.hfirst; rfirst = s.rfirst; counter = s.counter; nxc = s.nxc;
@@ -153,6 +166,7 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__r
             *op = envval;
             op += V;
         }
+        row = envgen_row(s_tab, S, phase);
     }
     const bool in = phase < S;
     A.dst[v] = envval;

@@ -102,47 +102,80 @@ __device__ __forceinline__ double envgen_tick(EgState &e, const double *tab, lon
 //          stage); a retrigger crossing would reset the envelope;
 //   HOLD   HOLDING with no negative crossing seen: the value stands; a crossing of -trigger leaves the stage;
 //   WAIT   WAITING: the value stands; a positive crossing of the trigger starts the envelope;
-// runs the chunk with the stage row read once, the three zero-crossing detectors (H:569-579) advanced exactly as the state
-// machine advances them, and ~1/5 of the instructions.  The lanes of a wavefront may each be in a different one of the three.
-// Computed on a copy of the state: returns false -- discard the copy -- if an exit condition fired on any of the U samples
-// (a crossing that changes the state, the stage running out) or the lane is in none of them (a HOLD stage entered while
-// TRIGGERED, phase == S); the caller commits only if every lane returned true, else the chunk goes through envgen_tick.
+// runs the chunk from the stage row it keeps in registers (EgRow, re-read only when the stage machine has moved `phase`), with
+// the three zero-crossing detectors (H:569-579) advanced in ONE step: a detector fed x[0..U) from (previousValue, firstTrigger)
+// fires somewhere in the chunk iff  ((previousValue <= 0 || firstTrigger) && x[0] > 0)  or  x[i-1] <= 0 && x[i] > 0  for some
+// 0 < i < U, and ends at (x[U-1], false) either way; the second term does not depend on the envelope (EgCross -- per chunk,
+// per wavefront for a shared gate).  Straight-line code, ~1/10 of the stage machine's instructions; the lanes of a wavefront
+// may each be in a different one of the three.  Computed on a copy of the state: returns false -- discard the copy -- if an
+// exit condition fires inside the chunk (a crossing that changes the state, the stage running out) or the lane is in none of
+// the three (a HOLD stage entered while TRIGGERED, phase == S, a curved stage, currentlevel outside [0, 1] where linlin's clamp
+// would act); the caller commits only if every lane returned true, else the chunk goes through envgen_tick.
+struct EgRow {
+    double start, span, gradient;
+    long long length;
+    bool timed_linear;  // a timed stage (no HOLD) with curve == 1 (every stage of setupAR / setupASR / setupADSR) and gradient >= 0
+    bool valid;         // phase inside the table (phase == S -- reachable through an uploaded state -- is play()'s end-of-envelope
+                        // test, H:2349-2355, which runs on every sample in every state: never a steady chunk)
+};
+__device__ __forceinline__ EgRow envgen_row(const double *tab, long long S, long long phase) {
+    EgRow r = {0.0, 0.0, 0.0, 0, false, false};
+    if (phase < 0 || phase >= S) return r;
+    r.valid = true;
+    const double *cs = tab + 6 * phase;
+    r.start = cs[0];
+    r.span = cs[1] - cs[0];
+    r.gradient = cs[2];
+    r.length = (long long)cs[4];
+    r.timed_linear = cs[5] == 0 && cs[3] == 1.0 && cs[2] >= 0.0;
+    return r;
+}
+struct EgCross {
+    double first, last;  // t[0], t[U-1]
+    bool pos, neg;       // a crossing between two samples of the chunk: of the trigger (trigDetector / retriggerDetector), of -trigger (holdDetector)
+};
 template <int U>
-__device__ __forceinline__ bool envgen_steady_chunk(EgState &e, const double *tab, long long S, bool retrigger,
-                                                    const double (&t)[U], double (&o)[U]) {
-    if (e.phase < 0 || e.phase >= S) return false;  // (H:2349-2355 fires on phase == S in every state)
-    const double *cs = tab + 6 * e.phase;
-    const double start = cs[0], span = cs[1] - cs[0], gradient = cs[2], curve = cs[3];
-    const long long length = (long long)cs[4];
-    // (linear stages only -- every stage of setupAR / setupASR / setupADSR: a curved stage is dominated by its pow() either way)
-    const bool ramp = e.state == EG_TRIGGERED && cs[5] == 0 && curve == 1.0 && e.counter >= 0 && e.counter + (long long)U < length;
+__device__ __forceinline__ EgCross envgen_cross(const double (&t)[U]) {
+    EgCross c = {t[0], t[U - 1], false, false};
+#pragma unroll
+    for (int i = 1; i < U; i++) {
+        c.pos = c.pos || (t[i - 1] <= 0.0 && t[i] > 0);
+        c.neg = c.neg || (-t[i - 1] <= 0.0 && -t[i] > 0);
+    }
+    return c;
+}
+template <int U>
+__device__ __forceinline__ bool envgen_steady_chunk(EgState &e, const EgRow &r, bool retrigger, const EgCross &x, double (&o)[U]) {
+    // linlin's clamp (H:801-805) is the identity on [0, 1]; currentlevel only grows (gradient >= 0), so the first and the last
+    // level used bound the chunk.  (U - 1) additions in the reference's order:
+    double cl[U + 1];
+    cl[0] = e.currentlevel;
+#pragma unroll
+    for (int i = 0; i < U; i++) cl[i + 1] = cl[i] + r.gradient;
+    const bool ramp = e.state == EG_TRIGGERED && r.timed_linear && e.counter >= 0 && e.counter + (long long)U < r.length &&
+                      cl[0] >= 0.0 && cl[U - 1] <= 1.0;
     const bool hold = e.state == EG_HOLDING && !e.nxc;
     const bool wait = e.state == EG_WAITING;
-    bool ok = ramp || hold || wait;
-    double envval = e.envval, cl = e.currentlevel;
-    bool nxc = e.nxc;
+    const bool trig_fires = ((e.tprev <= 0.0 || e.tfirst) && x.first > 0) || x.pos;    // H:2281
+    const bool hold_fires = ((e.hprev <= 0.0 || e.hfirst) && -x.first > 0) || x.neg;   // H:2294 / H:2331
+    const bool retr_fires = ((e.rprev <= 0.0 || e.rfirst) && x.first > 0) || x.pos;    // H:2323 / H:2341
+    const bool ok = r.valid && (wait ? !trig_fires : ((ramp || (hold && !hold_fires)) && !(retrigger && retr_fires)));
 #pragma unroll
     for (int i = 0; i < U; i++) {
-        if (wait) {
-            if (on_zx(e.tprev, e.tfirst, t[i])) ok = false;  // H:2281: the envelope starts
-        } else {
-            const bool neg = on_zx(e.hprev, e.hfirst, -t[i]);  // H:2294 / H:2331
-            nxc = nxc || neg;
-            if (hold && neg) ok = false;                        // H:2334: the hold ends
-            if (retrigger && on_zx(e.rprev, e.rfirst, t[i])) ok = false;  // H:2323 / H:2341: reset
-        }
-        double val = cl;  // H:2302-2304 with curve == 1, as envgen_tick
-        val = (1.0 < val) ? 1.0 : val;
-        val = (val < 0.0) ? 0.0 : val;
-        const double nv = ((val - 0.0) / (1.0 - 0.0) * span) + start;
-        envval = ramp ? nv : envval;
-        cl = ramp ? cl + gradient : cl;
-        o[i] = envval;
+        const double nv = cl[i] * r.span + r.start;  // H:2302-2304 with curve == 1 and the clamp an identity
+        o[i] = ramp ? nv : e.envval;
     }
-    e.envval = envval;
-    e.currentlevel = cl;
-    e.nxc = nxc;
-    if (ramp) e.counter += (long long)U;
+    e.envval = o[U - 1];
+    e.currentlevel = ramp ? cl[U] : e.currentlevel;
+    e.counter = ramp ? e.counter + (long long)U : e.counter;
+    e.tprev = wait ? x.last : e.tprev;
+    e.tfirst = e.tfirst && !wait;
+    e.nxc = e.nxc || (!wait && hold_fires);
+    e.hprev = wait ? e.hprev : -x.last;
+    e.hfirst = e.hfirst && wait;
+    const bool re = retrigger && !wait;
+    e.rprev = re ? x.last : e.rprev;
+    e.rfirst = e.rfirst && !re;
     return ok;
 }
 

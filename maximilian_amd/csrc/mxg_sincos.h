@@ -46,17 +46,37 @@ constexpr double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-
 constexpr double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                  C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
 
+// One fused multiply-add, a*b + c.  On the device it is spelled as the three-address VOP3 instruction: left to itself hipcc
+// turns a Horner chain over constants into v_fmac (two-address) and re-copies every coefficient into the accumulator register
+// first -- 17 moves next to the 9 FMAs of the two chains below, a fifth of sinewave's instructions at one wavefront per SIMD.
+// The coefficient goes in as the instruction's one scalar operand (`k`: wave-uniform, an SGPR pair set up outside the loop).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double fma_k(double a, double b, double k) {  // a*b + k
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+    return d;
+}
+__device__ __forceinline__ double fma_kk(double a, double k1, double k0) {  // a*k1 + k0
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k1), "v"(k0));
+    return d;
+}
+#else
+__device__ __forceinline__ double fma_k(double a, double b, double k) { return fma(a, b, k); }
+__device__ __forceinline__ double fma_kk(double a, double k1, double k0) { return fma(a, k1, k0); }
+#endif
+
 // sin and cos of y + t on [-pi/4, pi/4] (t = tail of the reduced argument)
 __device__ __forceinline__ double k_sin(double y, double t) {
 #pragma clang fp contract(fast)
     const double z = y * y, v = z * y;
-    const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double r = fma_k(z, fma_k(z, fma_k(z, fma_kk(z, S6, S5), S4), S3), S2);
     return y - ((z * (0.5 * t - v * r) - t) - v * S1);
 }
 __device__ __forceinline__ double k_cos(double y, double t) {
 #pragma clang fp contract(fast)
     const double z = y * y;
-    const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double r = z * fma_k(z, fma_k(z, fma_k(z, fma_k(z, fma_kk(z, C6, C5), C4), C3), C2), C1);
     const double hz = 0.5 * z, w = 1.0 - hz;
     return w + (((1.0 - w) - hz) + (z * r - y * t));
 }

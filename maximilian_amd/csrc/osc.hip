@@ -38,7 +38,7 @@ template <int WF, bool FPS, int VPL, bool NT>
 __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
                            const double *__restrict__ p1, const double *__restrict__ p2,
                            double *__restrict__ phase_io, double *__restrict__ hold_io,
-                           double *__restrict__ out, double sr) {
+                           double *__restrict__ out, double sr, int *part_ctrs) {
     // All LDS in ONE array (a second __shared__ object perturbs hipcc's waitcnt placement).
     __shared__ double s_tab[uses_sine<WF>() ? MAXI_SINE_TAB_LEN
                                             : (WF == MXG_OSC_SAWN ? MAXI_TRANS_TAB_LEN : 1)];
@@ -71,6 +71,9 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
     // waveforms whose OUTPUT is the expensive part (sinewave / coswave: ~100 fp64 ops per sample against 3 for the phase
     // ramp) part p first advances the recurrence over the samples of parts 0..p-1 without producing them -- the same
     // additions in the same order, so the same bits -- and then renders its own stretch; the last part stores the state.
+    // The last part stores the state; the others tell it when they have read theirs (part_signal / part_wait, mxg_common.h).
+    int *const part_ctr = gridDim.y > 1 ? part_counter(part_ctrs) : nullptr;
+    if (blockIdx.y + 1 != gridDim.y) part_signal(part_ctr);
     const size_t plen = (N + gridDim.y - 1) / gridDim.y;
     const size_t nA = blockIdx.y * plen < N ? blockIdx.y * plen : N;
     const size_t nB = nA + plen < N ? nA + plen : N;
@@ -102,6 +105,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
         if constexpr (FPS) fp += V;
     }
     if (blockIdx.y + 1 == gridDim.y) {
+        part_wait(part_ctr, (int)gridDim.y - 1);
 #pragma unroll
         for (int j = 0; j < VPL; j++) {
             phase_io[v0 + j] = ph[j];
@@ -257,7 +261,7 @@ osc_mix_fn pick_mix_wf(int wf, bool store, int var) {
 }
 
 typedef void (*osc_fn)(size_t, size_t, const double *, const double *, const double *, double *,
-                       double *, double *, double);
+                       double *, double *, double, int *);
 
 template <int WF>
 osc_fn pick(bool fps, int vpl, bool nt) {
@@ -319,9 +323,12 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     // every part must render at least one sample: the last part's ticks leave the member `output` of the final sample
     while (split > 1 && (size_t)(split - 1) * ((N + split - 1) / split) >= N) split--;
     dim3 grid((unsigned)((lanes + block - 1) / block), (unsigned)split), blk((unsigned)block);
+    int *part_ctrs = nullptr;
+    if (split > 1)
+        if (int s = part_counters_get(resolve_stream(stream), (size_t)grid.x * ((block + 63) / 64), &part_ctrs)) return s;
     KernelTimer kt("osc_kernel", resolve_stream(stream));
     hipLaunchKernelGGL(fn, grid, blk, 0, resolve_stream(stream), V, N, d_freq, d_p1, d_p2, d_phase,
-                       d_outhold, d_out, (double)settings().sampleRate);
+                       d_outhold, d_out, (double)settings().sampleRate, part_ctrs);
     return check_hip(hipGetLastError(), "osc_kernel launch");
 }
 

@@ -92,6 +92,23 @@ int scratch_get(ScratchSlot slot, hipStream_t st, size_t bytes, void **out) {
     return MXG_OK;
 }
 
+int part_counters_get(hipStream_t st, size_t wavefronts, int **out) {
+    const size_t bytes = (wavefronts ? wavefronts : 1) * sizeof(int);
+    std::lock_guard<std::mutex> lk(g_mu);
+    ScratchBuf &b = g_scratch[std::make_pair((int)SCR_PART_SYNC, st)];
+    if (b.cap < bytes || !b.ptr) {
+        if (b.ptr) MXG_HIP(hipFree(b.ptr));
+        b.ptr = nullptr;
+        b.cap = 0;
+        const size_t cap = bytes < 65536 ? 65536 : bytes;
+        MXG_HIP(hipMalloc(&b.ptr, cap));
+        b.cap = cap;
+        MXG_HIP(hipMemsetAsync(b.ptr, 0, cap, st));  // ordered before the launch that uses it; launches leave it zero
+    }
+    *out = (int *)b.ptr;
+    return MXG_OK;
+}
+
 // ---- per-kernel event timing -------------------------------------------------------------------
 namespace {
 struct ProfSlot {

@@ -353,7 +353,7 @@ __device__ __forceinline__ void smp_skip(double &pos, const double step, const d
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(256) sample_parts_kernel(SmpArgs A, const size_t part_len) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) sample_parts_kernel(SmpArgs A, const size_t part_len, int *part_ctrs) {
     __shared__ double s_win[4 * 64 * kRowDoubles];
     const size_t V = A.V, N = A.N;
     const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -366,11 +366,14 @@ __global__ void __launch_bounds__(256) sample_parts_kernel(SmpArgs A, const size
     const double step = (x0 * kChandiv) / s.step_div;  // the increment of smp_gen (C:1070)
     const bool can_skip = __all(step > 0.0 && step < HUGE_VAL && s.pos >= 0.0 && s.pos < HUGE_VAL);
     size_t n0 = 0, n1 = N;
-    bool writer = blockIdx.y == 0;
+    // the writer of the head: the last part, or part 0 where it renders the whole wavefront; the other parts tell it when they
+    // have read theirs (part_signal / part_wait, mxg_common.h) -- also the parts that only looked at it to decide can_skip
+    const bool writer = can_skip ? blockIdx.y + 1 == gridDim.y : blockIdx.y == 0;
+    int *const part_ctr = gridDim.y > 1 ? part_counter(part_ctrs) : nullptr;
+    if (!writer) part_signal(part_ctr);
     if (can_skip) {
         n0 = (size_t)blockIdx.y * part_len;
         n1 = n0 + part_len < N ? n0 + part_len : N;
-        writer = blockIdx.y + 1 == gridDim.y;
         smp_skip<B>(s.pos, step, (double)s.len, n0);
     } else if (blockIdx.y != 0) {
         return;
@@ -381,14 +384,74 @@ __global__ void __launch_bounds__(256) sample_parts_kernel(SmpArgs A, const size
     constexpr int U = 8;
     const int lane = threadIdx.x & 63;
     double *win = s_win + (threadIdx.x >> 6) * (64 * kRowDoubles);
+    double *row = win + lane * kRowDoubles;
     const bool can_stage = __popcll(__ballot(true)) == 64 && A.len < ((size_t)1 << 30);  // full wavefront, 32-bit indices
-    size_t n = n0;
-    for (; n + U <= n1; n += U) {
+    // One chunk of U samples, in the two halves a software pipeline needs (loads and stores retire in order on ONE counter, so
+    // a wait for a load also waits for every store issued before it -- and a store takes microseconds when HBM's write queues are
+    // full; the loads of chunk k+1 are therefore issued BEFORE the stores of chunk k and waited for after them):
+    //   fetch    advance the head over the chunk (smp_gen), decide window / gathers, issue the loads into c[];
+    //   land     put c[] into this wavefront's LDS rows (the wait for the loads is here);
+    //   render   every lane reads its taps from its row, interpolates and stores.
+    // A chunk whose indices do not fit a window is gathered per lane and parked in the lane's own row (pairs at 2i, 2i+1), so
+    // `render` is the same code either way.
+    struct Chunk {
+        double rem[U];
+        int tap[U];   // offset of the first tap in the lane's row; the second is the next double
+        unsigned ok;  // bit i: the reference's bounds test of sample i
+        bool staged;
+    };
+    double2v c[U];  // the loads in flight: only ever one chunk's (fetched after the previous one has landed)
+    // The head in 32 bits.  A part that skipped (step > 0, head >= 0) with the sample and the head below 2^30 needs none of the
+    // 64-bit conversions of smp_gen: (long long)pos == (int)pos, the bounds tests compare ints, and playAtSpeed's wrap
+    // `if ((size_t)(long long)pos >= len) pos -= len` (C:1072-1073) has pos in [len, 2 len) where it fires (step < len), so the
+    // subtraction is exact (Sterbenz) and the new integer part is the old one minus len: ONE v_cvt_i32_f64 per sample, carried.
+    const int len32 = (int)(A.len < ((size_t)1 << 30) ? A.len : 0);
+    const double dlen = (double)A.len;
+    bool fast = can_skip && len32 > 0;
+    if constexpr (B == 4) fast = fast && __all(step < dlen && s.pos + step < 2.0 * dlen);
+    else fast = fast && __all(s.pos + step * (double)(n1 - n0 + 2) < 1073741824.0);
+    const double endc = en > 1.0 ? 1.0 : en;  // C:1050
+    int icur = fast ? (int)s.pos : 0;
+    auto fetch = [&](Chunk &C) {
         Req r[U];
-        double val[U][2];
+        if (fast) {
 #pragma unroll
-        for (int i = 0; i < U; i++) smp_gen<MODE>(s, x0, 0.0, st, en, sr, r[i]);
-        bool staged = false;
+            for (int i = 0; i < U; i++) {
+                const int ip = icur;
+                const double di = (double)ip;
+                r[i].rem = s.pos - di;
+                int first = ip + 1;
+                if constexpr (B == 4) r[i].ok = ip < len32;
+                if constexpr (B == 5) {
+                    r[i].ok = ip + 1 < len32;
+                    first = ip;
+                }
+                if constexpr (B == 6) {
+                    r[i].ok = di < dlen * endc;
+                    first = 1 + (ip < len32 + 2 ? ip : len32 + 2);  // 1 + (long long)smp_safe_head(pos, len) for pos >= 0
+                }
+                const int i0 = r[i].ok ? first : 0;
+                r[i].idx[0] = i0;
+                r[i].idx[1] = i0 + 1;
+                s.pos = s.pos + step;
+                icur = (int)s.pos;
+                if constexpr (B == 4) {
+                    const bool wrap = icur >= len32;
+                    s.pos = wrap ? s.pos - dlen : s.pos;
+                    icur = wrap ? icur - len32 : icur;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < U; i++) smp_gen<MODE>(s, x0, 0.0, st, en, sr, r[i]);
+        }
+        C.ok = 0;
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            C.rem[i] = r[i].rem;
+            C.ok |= r[i].ok ? (1u << i) : 0u;
+        }
+        C.staged = false;
         int base = 0;
         if (can_stage) {
             int lo = (int)r[0].idx[0], hi = lo;  // idx[1] = idx[0] + 1 for these players (mxg_smp.h)
@@ -398,39 +461,70 @@ __global__ void __launch_bounds__(256) sample_parts_kernel(SmpArgs A, const size
                 lo = ix < lo ? ix : lo;
                 hi = ix > hi ? ix : hi;
             }
-            staged = __all(hi + 1 - lo < kSmpWindow);
+            C.staged = __all(hi + 1 - lo < kSmpWindow);
             base = lo;
         }
-        if (staged) {
-            double2v c[8];
+        if (C.staged) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) {  // piece j: 16 bytes of the window of voice 8j + lane/8
+            for (int j = 0; j < U; j++) {  // piece j: 16 bytes of the window of voice 8j + lane/8
                 const int b = __shfl(base, 8 * j + (lane >> 3));
                 c[j] = *reinterpret_cast<const double2v *>(amp + b + 2 * (lane & 7));
+                C.tap[j] = (int)r[j].idx[0] - base;
             }
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                *reinterpret_cast<double2v *>(win + (8 * j + (lane >> 3)) * kRowDoubles + 2 * (lane & 7)) = c[j];
-            smp_lds_sync();
-            const double *row = win + lane * kRowDoubles - base;
-#pragma unroll
-            for (int i = 0; i < U; i++) {
-                val[i][0] = row[(int)r[i].idx[0]];
-                val[i][1] = row[(int)r[i].idx[1]];
-            }
-            smp_lds_sync();
         } else {
 #pragma unroll
             for (int i = 0; i < U; i++) {
-                val[i][0] = amp[r[i].idx[0]];
-                val[i][1] = amp[r[i].idx[1]];
+                c[i].x = amp[r[i].idx[0]];
+                c[i].y = amp[r[i].idx[1]];
+                C.tap[i] = 2 * i;
             }
         }
+    };
+    auto land = [&](const Chunk &C) {
+        if (C.staged) {
+#pragma unroll
+            for (int j = 0; j < U; j++)
+                *reinterpret_cast<double2v *>(win + (8 * j + (lane >> 3)) * kRowDoubles + 2 * (lane & 7)) = c[j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < U; i++) *reinterpret_cast<double2v *>(row + 2 * i) = c[i];
+        }
+        smp_lds_sync();
+    };
+    auto render = [&](const Chunk &C) {
+        Req q;
 #pragma unroll
         for (int i = 0; i < U; i++) {
-            *op = smp_eval<MODE>(r[i], val[i]);
+            const double val[2] = {row[C.tap[i]], row[C.tap[i] + 1]};
+            q.rem = C.rem[i];
+            q.ok = (C.ok >> i) & 1u;
+            *op = smp_eval<MODE>(q, val);
             op += V;
         }
+        smp_lds_sync();  // the rows are free again
+    };
+    size_t n = n0;
+    const size_t nchunks = (n1 - n0) / U;
+    if (nchunks) {
+        Chunk Ca, Cb;
+        fetch(Ca);
+        land(Ca);
+        size_t k = 0;  // Ca has landed chunk k
+        while (true) {
+            const bool more_b = k + 1 < nchunks;
+            if (more_b) fetch(Cb);
+            render(Ca);
+            if (!more_b) break;
+            land(Cb);
+            k++;
+            const bool more_a = k + 1 < nchunks;
+            if (more_a) fetch(Ca);
+            render(Cb);
+            if (!more_a) break;
+            land(Ca);
+            k++;
+        }
+        n = n0 + nchunks * U;
     }
     for (; n < n1; n++) {
         Req q;
@@ -441,17 +535,21 @@ __global__ void __launch_bounds__(256) sample_parts_kernel(SmpArgs A, const size
         *op = smp_eval<MODE>(q, val);
         op += V;
     }
-    if (writer) A.position[v] = s.pos;
+    if (writer) {
+        part_wait(part_ctr, (int)gridDim.y - 1);
+        A.position[v] = s.pos;
+    }
 }
 
 inline dim3 grid_for(size_t V, int block) { return dim3((unsigned)((V + block - 1) / block)); }
 
-// time parts for a block-constant *AtSpeed launch: enough to put ~4 wavefronts on every SIMD, each part >= 32 samples
+// time parts for a block-constant *AtSpeed launch: the kernel keeps three wavefronts per SIMD resident (~160 VGPRs); two rounds
+// of them measured best at 65 536 voices (69 us with 6 parts against 76 with 4 and 84 with 3), each part >= 32 samples
 inline int speed_parts(size_t V, size_t N, size_t *part_len) {
     int split = tune_get("smp_split");
     if (split == 0) {
         const size_t waves = (V + 63) / 64;
-        split = waves >= 4096 ? 1 : (int)(4096 / (waves ? waves : 1));
+        split = waves >= 6144 ? 1 : (int)(6144 / (waves ? waves : 1));
         if (split > 8) split = 8;
     }
     while (split > 1 && N / (size_t)split < 32) split--;
@@ -586,10 +684,12 @@ int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, siz
         const int split = speed_parts(V, N, &part_len);
         if (split > 1) {
             const dim3 pgrid(grid.x, (unsigned)split);
+            int *part_ctrs = nullptr;
+            if (int e = part_counters_get(st, (size_t)grid.x * ((block + 63) / 64), &part_ctrs)) return e;
             KernelTimer kt("sample_parts_kernel", st);
-            if (mode == 4) hipLaunchKernelGGL((sample_parts_kernel<4>), pgrid, dim3(block), 0, st, A, part_len);
-            if (mode == 5) hipLaunchKernelGGL((sample_parts_kernel<5>), pgrid, dim3(block), 0, st, A, part_len);
-            if (mode == 6) hipLaunchKernelGGL((sample_parts_kernel<6>), pgrid, dim3(block), 0, st, A, part_len);
+            if (mode == 4) hipLaunchKernelGGL((sample_parts_kernel<4>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);
+            if (mode == 5) hipLaunchKernelGGL((sample_parts_kernel<5>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);
+            if (mode == 6) hipLaunchKernelGGL((sample_parts_kernel<6>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);
             return check_hip(hipGetLastError(), "sample_parts_kernel launch");
         }
     }

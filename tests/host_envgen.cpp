@@ -21,7 +21,8 @@ extern "C" int envgen_host(size_t V, size_t N, const double *trig, int tpv, cons
                 for (int i = 0; i < U; i++) t[i] = tpv ? trig[(n + i) * V + v] : trig[n + i];
                 EgState s = e;
                 chunks++;
-                if (envgen_steady_chunk<U>(s, stages, nstages, retrigger != 0, t, o)) {
+                const EgRow row = envgen_row(stages, nstages, e.phase);
+                if (envgen_steady_chunk<U>(s, row, retrigger != 0, envgen_cross<U>(t), o)) {
                     e = s;
                     steady++;
                     for (int i = 0; i < U; i++) out[(n + i) * V + v] = o[i];

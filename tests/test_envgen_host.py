@@ -50,7 +50,10 @@ def test_envgen_on_host_matches_oracle_from_arbitrary_states(eg_host, port, name
     d0[2:5] = rng.choice([-1.0, 0.0, 0.5, 1.0], (3, V))  # detector history
     i0 = np.zeros((7, V), np.int64)
     i0[0] = rng.integers(0, S, V)                        # phase (a valid stage)
+    i0[0, ::17] = S                                      # ... or parked on the end-of-envelope test (an uploaded state, H:2349-2355)
     i0[1] = rng.integers(0, 3, V)                        # WAITING / TRIGGERED / HOLDING
+    i0[1, ::17] = 0                                      # (WAITING, and not triggered on the first sample: any other way the
+    trig[0, ::17] = -1.0                                 # reference would index past its stage vector before the test resets it)
     i0[2] = rng.integers(0, 2, V)                        # nxcHappened
     i0[3] = rng.integers(0, 30, V)                       # counter
     i0[4:7] = rng.integers(0, 2, (3, V))                 # firstTrigger flags
