@@ -397,6 +397,33 @@ def test_sample_time_parts_corner_heads(mx, port, mode):
     assert_bits_equal(bank.position.numpy(), ep, "position")
 
 
+@pytest.mark.parametrize("mode", [4, 5])
+def test_sample_time_parts_many_short_launches(mx, port, mode):
+    """The head is read by every time part and stored by one: with 40 samples per part the storing part is done in no time,
+    and nothing but the kernel's own part_signal / part_wait keeps another part from starting on the new head.  300 launches of
+    a bank wide enough that its workgroups do not all start together."""
+    Ls, V, N, reps = 3000, 8192, 160, 300
+    rng = np.random.default_rng(5 + mode)
+    smp = rng.uniform(-1, 1, Ls)
+    a = rng.uniform(0.3, 1.6, V)
+    pos0 = rng.uniform(0, Ls - 2, V) if mode == 4 else rng.uniform(0, 8, V)
+    bank = mx.maxiSampleBank(V)
+    bank.setSample(smp)
+    bank.position.upload(pos0)
+    da = mx.DeviceBuffer.from_numpy(a)
+    ring = [mx.DeviceBuffer((N, V), zero=False) for _ in range(3)]
+    prev = mx.lib().mxg_tune(b"smp_split", 4)
+    try:
+        for r in range(reps):                                     # enqueued back to back, nothing in between
+            bank.render(mode, N, a=da, out=ring[r % 3])
+        o = np.concatenate([ring[r % 3].numpy() for r in range(reps - 3, reps)])
+    finally:
+        mx.lib().mxg_tune(b"smp_split", prev)
+    e, ep = port.sample(mode, smp, N * reps, pos0, a=a)
+    assert_bits_equal(o, e[-3 * N:], "mode %d" % mode)
+    assert_bits_equal(bank.position.numpy(), ep, "position")
+
+
 def test_sample_zx_and_phasor_slow_full_waves(mx, port):
     """Trigger-driven players and playWithPhasor on full wavefronts of slow voices, retriggers included."""
     V, N = 192, 300
