@@ -1,5 +1,5 @@
 #!/bin/bash
-# scratch experiment: envgen chunk rewrite, sincos three-address FMA, pipelined speed players
+# GPU run: parity tests of the time-part kernels + per-bank times + the osc_split / smp_split sweeps (results in gpurun_out/exp)
 O=gpurun_out/exp; mkdir -p $O
 timeout 1500 python -m pytest tests/test_gpu_envgen.py tests/test_gpu_sample.py tests/test_gpu_osc.py tests/test_gpu_sampler.py tests/test_gpu_edges.py -m gpu -q -x > $O/pytest.log 2>&1
 tail -5 $O/pytest.log
