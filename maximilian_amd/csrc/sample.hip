@@ -399,6 +399,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) s
         int tap[U];   // offset of the first tap in the lane's row; the second is the next double
         unsigned ok;  // bit i: the reference's bounds test of sample i
         bool staged;
+        bool allok;   // wave-uniform: every sample of every lane passed it (no select needed)
     };
     double2v c[U];  // the loads in flight: only ever one chunk's (fetched after the previous one has landed)
     // The head in 32 bits.  A part that skipped (step > 0, head >= 0) with the sample and the head below 2^30 needs none of the
@@ -414,7 +415,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) s
     int icur = fast ? (int)s.pos : 0;
     auto fetch = [&](Chunk &C) {
         Req r[U];
+        // Most chunks cross nothing: the head only moves forward, so if the LAST sample of the chunk still passes the bounds
+        // test and the head has not reached `len` after it, no sample of the chunk wrapped or failed.  Such a chunk is the bare
+        // recurrence (5 instructions per sample instead of 17); it is computed first, on copies, and kept if every lane agrees.
+        bool smooth = false;
         if (fast) {
+            double p = s.pos;
+            int ic = icur, ilast = 0;
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                ilast = ic;
+                r[i].rem = p - (double)ic;
+                r[i].idx[0] = (B == 5) ? ic : ic + 1;
+                r[i].ok = true;
+                p = p + step;
+                ic = (int)p;
+            }
+            bool good;
+            if constexpr (B == 4) good = ic < len32;
+            else if constexpr (B == 5) good = ilast + 1 < len32;
+            else good = (double)ilast < dlen * endc;
+            smooth = __all(good);
+            if (smooth) {
+                s.pos = p;
+                icur = ic;
+            }
+        }
+        if (smooth) {
+#pragma unroll
+            for (int i = 0; i < U; i++) r[i].idx[1] = r[i].idx[0] + 1;
+        } else if (fast) {
 #pragma unroll
             for (int i = 0; i < U; i++) {
                 const int ip = icur;
@@ -454,16 +484,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) s
         C.staged = false;
         int base = 0;
         if (can_stage) {
-            int lo = (int)r[0].idx[0], hi = lo;  // idx[1] = idx[0] + 1 for these players (mxg_smp.h)
+            int lo = (int)r[0].idx[0], hi = (int)r[U - 1].idx[0];  // idx[1] = idx[0] + 1 for these players (mxg_smp.h)
+            if (!smooth) {  // (a smooth chunk's indices ascend)
+                hi = lo;
 #pragma unroll
-            for (int i = 1; i < U; i++) {
-                const int ix = (int)r[i].idx[0];
-                lo = ix < lo ? ix : lo;
-                hi = ix > hi ? ix : hi;
+                for (int i = 1; i < U; i++) {
+                    const int ix = (int)r[i].idx[0];
+                    lo = ix < lo ? ix : lo;
+                    hi = ix > hi ? ix : hi;
+                }
             }
             C.staged = __all(hi + 1 - lo < kSmpWindow);
             base = lo;
         }
+        C.allok = smooth;
         if (C.staged) {
 #pragma unroll
             for (int j = 0; j < U; j++) {  // piece j: 16 bytes of the window of voice 8j + lane/8
@@ -493,13 +527,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) s
     };
     auto render = [&](const Chunk &C) {
         Req q;
+        if (C.allok) {
 #pragma unroll
-        for (int i = 0; i < U; i++) {
-            const double val[2] = {row[C.tap[i]], row[C.tap[i] + 1]};
-            q.rem = C.rem[i];
-            q.ok = (C.ok >> i) & 1u;
-            *op = smp_eval<MODE>(q, val);
-            op += V;
+            for (int i = 0; i < U; i++) {
+                const double val[2] = {row[C.tap[i]], row[C.tap[i] + 1]};
+                q.rem = C.rem[i];
+                q.ok = true;
+                *op = smp_eval<MODE>(q, val);
+                op += V;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                const double val[2] = {row[C.tap[i]], row[C.tap[i] + 1]};
+                q.rem = C.rem[i];
+                q.ok = (C.ok >> i) & 1u;
+                *op = smp_eval<MODE>(q, val);
+                op += V;
+            }
         }
         smp_lds_sync();  // the rows are free again
     };
@@ -683,8 +728,8 @@ int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, siz
         size_t part_len = N;
         const int split = speed_parts(V, N, &part_len);
         if (split > 1) {
-            const dim3 pgrid(grid.x, (unsigned)split);
             int *part_ctrs = nullptr;
+            const dim3 pgrid(grid.x, (unsigned)split);
             if (int e = part_counters_get(st, (size_t)grid.x * ((block + 63) / 64), &part_ctrs)) return e;
             KernelTimer kt("sample_parts_kernel", st);
             if (mode == 4) hipLaunchKernelGGL((sample_parts_kernel<4>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);

@@ -329,7 +329,7 @@ def _mixed_speeds(V, rng, reverse):
 
 
 @pytest.mark.parametrize("mode", [4, 5, 6, 7, 8])
-@pytest.mark.parametrize("Ls,split", [(20000, 0), (700, 0), (700, 1), (700, 3), (20000, 8)])
+@pytest.mark.parametrize("Ls,split", [(20000, 0), (700, 0), (700, 1), (700, 3), (700, 2), (20000, 8), (20000, 5)])
 def test_sample_speed_players_full_waves(mx, port, mode, Ls, split):
     """The interpolating players over full wavefronts, three carried blocks of ragged lengths, long and short (many wraps)
     buffers -- and, for playAtSpeed / playOnceAtSpeed / playUntilAtSpeed, every setting of the time-part knob: a part skips to
