@@ -352,7 +352,7 @@ __device__ __forceinline__ void smp_skip(double &pos, const double step, const d
     }
 }
 
-template <int MODE>
+template <int MODE, bool PIPE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) sample_parts_kernel(SmpArgs A, const size_t part_len, int *part_ctrs) {
     __shared__ double s_win[4 * 64 * kRowDoubles];
     const size_t V = A.V, N = A.N;
@@ -550,7 +550,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) s
     };
     size_t n = n0;
     const size_t nchunks = (n1 - n0) / U;
-    if (nchunks) {
+    if (nchunks && !PIPE) {
+        for (size_t k = 0; k < nchunks; k++) {
+            Chunk C;
+            fetch(C);
+            land(C);
+            render(C);
+        }
+        n = n0 + nchunks * U;
+    } else if (nchunks) {
         Chunk Ca, Cb;
         fetch(Ca);
         land(Ca);
@@ -731,10 +739,11 @@ int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, siz
             int *part_ctrs = nullptr;
             const dim3 pgrid(grid.x, (unsigned)split);
             if (int e = part_counters_get(st, (size_t)grid.x * ((block + 63) / 64), &part_ctrs)) return e;
+            const bool pipe = tune_get("smp_pipe") != 0;
             KernelTimer kt("sample_parts_kernel", st);
-            if (mode == 4) hipLaunchKernelGGL((sample_parts_kernel<4>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);
-            if (mode == 5) hipLaunchKernelGGL((sample_parts_kernel<5>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);
-            if (mode == 6) hipLaunchKernelGGL((sample_parts_kernel<6>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);
+            if (mode == 4) { if (pipe) hipLaunchKernelGGL((sample_parts_kernel<4, true>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs); else hipLaunchKernelGGL((sample_parts_kernel<4, false>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs); }
+            if (mode == 5) { if (pipe) hipLaunchKernelGGL((sample_parts_kernel<5, true>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs); else hipLaunchKernelGGL((sample_parts_kernel<5, false>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs); }
+            if (mode == 6) { if (pipe) hipLaunchKernelGGL((sample_parts_kernel<6, true>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs); else hipLaunchKernelGGL((sample_parts_kernel<6, false>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs); }
             return check_hip(hipGetLastError(), "sample_parts_kernel launch");
         }
     }

@@ -329,11 +329,14 @@ def _mixed_speeds(V, rng, reverse):
 
 
 @pytest.mark.parametrize("mode", [4, 5, 6, 7, 8])
-@pytest.mark.parametrize("Ls,split", [(20000, 0), (700, 0), (700, 1), (700, 3), (700, 2), (20000, 8), (20000, 5)])
+@pytest.mark.parametrize("Ls,split", [(20000, 0), (700, 0), (700, 1), (700, 3), (700, 2), (20000, 8), (20000, 5), (700, -3), (20000, -6)])
 def test_sample_speed_players_full_waves(mx, port, mode, Ls, split):
     """The interpolating players over full wavefronts, three carried blocks of ragged lengths, long and short (many wraps)
     buffers -- and, for playAtSpeed / playOnceAtSpeed / playUntilAtSpeed, every setting of the time-part knob: a part skips to
-    its first sample with the exact multi-step head advance, so the bits (and the head left behind) cannot depend on it."""
+    its first sample with the exact multi-step head advance, so the bits (and the head left behind) cannot depend on it.
+    (A negative split: that many parts without the software pipeline, smp_pipe 0.)"""
+    pipe = 0 if split < 0 else 1
+    split = abs(split)
     rng = np.random.default_rng(900 + mode + Ls)
     V = 256
     smp = rng.uniform(-1, 1, Ls)
@@ -355,10 +358,12 @@ def test_sample_speed_players_full_waves(mx, port, mode, Ls, split):
     kw = dict(a=a, start=start, end=end)
     blocks = [203, 64, 9]
     prev = mx.lib().mxg_tune(b"smp_split", split)
+    prev_pipe = mx.lib().mxg_tune(b"smp_pipe", pipe)
     try:
         o = np.concatenate([bank.render(mode, n, **kw).numpy() for n in blocks])
     finally:
         mx.lib().mxg_tune(b"smp_split", prev)
+        mx.lib().mxg_tune(b"smp_pipe", prev_pipe)
     e, ep = port.sample(mode, smp, sum(blocks), pos0, **kw)
     assert_bits_equal(o, e, "mode %d" % mode)
     assert_bits_equal(bank.position.numpy(), ep, "position")

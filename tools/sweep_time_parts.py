@@ -28,10 +28,12 @@ L.mxg_tune(b"osc_split", 0)
 rng = np.random.default_rng(1)
 sb = mx.maxiSampleBank(V); sb.setSample(rng.uniform(-1, 1, 441000)); sb.setPosition(v / V)
 dsp = D(0.5 + (v % 97) / 96.0)
-for split in (0, 1, 2, 3, 4, 6, 8):
-    L.mxg_tune(b"smp_split", split)
-    row = []
-    for mode in (4, 5):
-        sb.setPosition(v / V * 0.5)
-        row.append("mode%d %.1f" % (mode, timed(lambda: L.mxg_sample_render(mode, V, B, sb.d_samples, sb.length, 44100, dsp.ptr, 0, None, None, sb.position.ptr, out.ptr, None), 100)))
-    print("smp_split", split, " | ".join(row), flush=True)
+for pipe in (1, 0):
+    L.mxg_tune(b"smp_pipe", pipe)
+    for split in (0, 1, 2, 3, 4, 6, 8):
+        L.mxg_tune(b"smp_split", split)
+        row = []
+        for mode in (4, 5):
+            sb.setPosition(v / V * 0.5)
+            row.append("mode%d %.1f" % (mode, timed(lambda: L.mxg_sample_render(mode, V, B, sb.d_samples, sb.length, 44100, dsp.ptr, 0, None, None, sb.position.ptr, out.ptr, None), 100)))
+        print("smp_pipe", pipe, "smp_split", split, " | ".join(row), flush=True)
