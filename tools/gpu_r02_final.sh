@@ -12,6 +12,7 @@ bash tools/profile_r02.sh r02 > $O/profile.log 2>&1
 timeout 600 python tools/bench_banks.py > $O/banks.txt 2> $O/banks.err
 timeout 600 python tools/bench_waveforms.py > $O/waveforms.txt 2> $O/waveforms.err
 timeout 900 python tools/sweep_banks.py > $O/sweep.md 2> $O/sweep.err
+timeout 600 python tools/sweep_time_parts.py > $O/time_parts.txt 2> $O/time_parts.err
 cd /tmp && export TMPDIR=/tmp
 for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_ANY"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
