@@ -420,6 +420,21 @@ struct SamplePool : Pool {  // state: position (H:606); key = the device sample 
     }
 };
 
+struct EnvGenPool : Pool {  // state of mxg_envgen_render: [5] doubles, [7] int64; key = the object's stage table
+    EnvGenPool() : Pool(5, 7) {}
+    struct Shape { double *d_stages = nullptr; int nstages = 0; bool loop = false, retrigger = false; };
+    void enqueue(Group &G) override {
+        const size_t n = G.m.size(), L = G.L;
+        const Shape *sh = static_cast<const Shape *>(G.sig[0].key);
+        std::vector<double> trig(L * n);
+        for (size_t j = 0; j < n; j++)
+            for (size_t t = 0; t < L; t++) trig[t * n + j] = G.sig[j].a[0];
+        check(mxg_memcpy_h2d(G.d_in.need(L * n), trig.data(), sizeof(double) * L * n, stream), "h2d envgen trig");
+        check(mxg_envgen_render(n, L, G.d_in.p, 1, sh->d_stages, sh->nstages, sh->loop, sh->retrigger, G.d_state.p, G.d_istate.p,
+                                G.d_out.p, stream), "mxg_envgen_render");
+    }
+};
+
 }  // namespace ps
 }  // namespace maxigpu
 
@@ -588,6 +603,7 @@ class maxiSample {
     using Pool = maxigpu::ps::SamplePool;
     maxigpu::ps::Slot slot_;
     Pool::Buf buf_;
+    int32_t hdr_[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // chunk size, fmt size, format, channels, rate, byte rate, block align, bits (mxg_sample_load_wav)
     double run(int mode, double a = 0.0, double start = 0.0, double end = 0.0) {
         if (!buf_.d) return 0.0;
         maxigpu::ps::Call c;
@@ -620,8 +636,14 @@ public:
         }
         buf_.len = len;
         buf_.rate = mySampleRate = hdr[4];
+        for (int i = 0; i < 8; i++) hdr_[i] = hdr[i];
         slot_.sd[0] = (double)len;  // position = size, C:681
         return true;
+    }
+    string getSummary() {  // C:727-733: the header fields read() kept
+        return " Format: " + std::to_string(hdr_[2]) + "\n Channels: " + std::to_string(hdr_[3]) + "\n SampleRate: " +
+               std::to_string(mySampleRate) + "\n ByteRate: " + std::to_string(hdr_[5]) + "\n BlockAlign: " + std::to_string(hdr_[6]) +
+               "\n BitsPerSample: " + std::to_string(hdr_[7]);
     }
     void setSample(vector<double> &sampleData) {  // H:670-678
         drop();
@@ -828,6 +850,145 @@ private:
     float *d_in_ = nullptr;
     double *d_out_ = nullptr;
     vector<double> coeffs_;
+};
+
+// ---- maxiEnvGen (H:2268-2547): one envelope = one slot of the maxiEnvGen bank -------------------------------------------------
+class maxiEnvGen {
+    using Pool = maxigpu::ps::EnvGenPool;
+    maxigpu::ps::Slot slot_;
+    Pool::Shape shape_;
+    Pool &pool() { return maxigpu::ps::pool<Pool>(); }
+    void drop_table() {
+        if (shape_.d_stages) mxg_free(shape_.d_stages);
+        shape_.d_stages = nullptr;
+        shape_.nstages = 0;
+    }
+
+public:
+    static constexpr double HOLD = -46692;  // H:2271
+    maxiEnvGen() {
+        pool().attach(slot_);
+        slot_.sd[2] = slot_.sd[3] = slot_.sd[4] = 1.0;  // maxiTrigger: previousValue = 1, firstTrigger = 1 (H:593-594)
+        slot_.si[4] = slot_.si[5] = slot_.si[6] = 1;
+    }
+    ~maxiEnvGen() { pool().detach(slot_); drop_table(); }
+    maxiEnvGen(const maxiEnvGen &) = delete;
+    maxiEnvGen &operator=(const maxiEnvGen &) = delete;
+    double play(double trigger) {  // H:2277-2356
+        if (!shape_.d_stages) {  // no stages: a WAITING envelope only feeds its trigger detector (H:2279-2287)
+            pool().settle(slot_);
+            if (slot_.si[1] == 0) {
+                slot_.sd[2] = trigger;
+                slot_.si[4] = 0;
+            }
+            return slot_.sd[0];
+        }
+        maxigpu::ps::Call c;
+        c.method = 0;
+        c.key = &shape_;
+        c.a[0] = trigger;
+        return pool().call(slot_, c);
+    }
+    bool setup(vector<double> levels, vector<double> times, vector<double> curves, bool looping, bool allowRetrigger = false) {  // H:2366-2399
+        if (!(levels.size() == times.size() + 1 && levels.size() == curves.size() + 1)) {
+            cout << "maxiEnv::setup - levels array should be one longer than times and curves\n";
+            return 0;
+        }
+        pool().settle(slot_);
+        std::vector<double> tab(6 * times.size() + 6);
+        const int ns = times.empty() ? 0 : mxg_envgen_stages_host(levels.size(), levels.data(), times.data(), curves.data(), tab.data());
+        if (ns < 0) {
+            cout << "maxiEnv::setup - only one hold section allowed\n";
+            return 0;
+        }
+        drop_table();
+        if (ns > 0) {
+            maxigpu::ps::check(mxg_init(-1), "mxg_init");
+            shape_.d_stages = static_cast<double *>(mxg_malloc(sizeof(double) * 6 * ns));
+            if (!shape_.d_stages) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+            maxigpu::ps::check(mxg_memcpy_h2d(shape_.d_stages, tab.data(), sizeof(double) * 6 * ns, nullptr), "h2d stages");
+            shape_.nstages = ns;
+        }
+        shape_.loop = looping;
+        shape_.retrigger = allowRetrigger;
+        resetAndArm();
+        return 1;
+    }
+    void reset() {  // H:2402-2410
+        pool().settle(slot_);
+        slot_.sd[1] = 0.0;  // stages[phase].currentlevel
+        slot_.si[3] = 0;    // stages[phase].counter
+        slot_.si[0] = 0;    // phase
+        slot_.si[1] = 1;    // TRIGGERED
+    }
+    void resetAndArm() {  // H:2413-2416
+        reset();
+        slot_.si[1] = 0;  // WAITING
+    }
+    void setupAR(const double attack, const double release) { setup({0, 1, 0}, {attack, release}, {1, 1}, false, false); }
+    void setupASR(const double attack, const double release) { setup({0, 1, 1, 0}, {attack, maxiEnvGen::HOLD, release}, {1, 1, 1}, false, false); }
+    void setupADSR(const double attack, const double decay, const double sustain, const double release) {
+        setup({0, 1, sustain, sustain, 0}, {attack, decay, maxiEnvGen::HOLD, release}, {1, 1, 1, 1}, false, false);
+    }
+    void setRetrigger(const bool val) { pool().settle(slot_); shape_.retrigger = val; }
+    bool getRetrigger() { return shape_.retrigger; }
+    void setLoop(const bool val) { pool().settle(slot_); shape_.loop = val; }
+    bool getLoop() { return shape_.loop; }
+};
+
+// ---- maxiIFFT (L/maxiFFT.h:117-156; L/maxiFFT.cpp:141-192): one inverse transform per hop on the device -------------------------
+class maxiIFFT {
+public:
+    enum fftModes { SPECTRUM = 0, COMPLEX = 1 };
+    maxiIFFT() {}
+    ~maxiIFFT() { release(); }
+    maxiIFFT(const maxiIFFT &) = delete;
+    maxiIFFT &operator=(const maxiIFFT &) = delete;
+    void setup(int _fftSize = 1024, int _hopSize = 512, int _windowSize = 0) {  // L/maxiFFT.cpp:141-152
+        release();
+        plan_ = mxg_ifft_plan_create(_fftSize, _hopSize, _windowSize);
+        if (!plan_) throw std::runtime_error(std::string("mxg_ifft_plan_create: ") + mxg_last_error());
+        fftSize = _fftSize;
+        hopSize = _hopSize;
+        bins = fftSize / 2;
+        pos = 0;
+        hop_.assign(hopSize, 0.0f);
+        d_in_ = static_cast<float *>(mxg_malloc(sizeof(float) * 2 * bins));
+        d_buffer_ = static_cast<float *>(mxg_malloc(sizeof(float) * fftSize));
+        d_signal_ = static_cast<float *>(mxg_malloc(sizeof(float) * hopSize));
+        if (!d_in_ || !d_buffer_ || !d_signal_) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+        maxigpu::ps::check(mxg_memset(d_buffer_, 0, sizeof(float) * fftSize, nullptr), "mxg_memset");  // buffer.resize(fftSize, 0)
+    }
+    float process(std::vector<float> &data1, std::vector<float> &data2, fftModes mode = maxiIFFT::SPECTRUM) {  // :154-192
+        using maxigpu::ps::check;
+        if (0 == pos) {  // the spectrum is consumed here; the overlap-add buffer lives on the device
+            check(mxg_memcpy_h2d(d_in_, data1.data(), sizeof(float) * bins, nullptr), "h2d spectrum");
+            check(mxg_memcpy_h2d(d_in_ + bins, data2.data(), sizeof(float) * bins, nullptr), "h2d spectrum");
+            if (mode == SPECTRUM)
+                check(mxg_ifft_batch(plan_, d_in_, d_in_ + bins, 1, d_buffer_, d_signal_, nullptr, nullptr), "mxg_ifft_batch");
+            else  // the reference's COMPLEX mode as it computes (L/fft.cpp:613-619: the inputs never reach the transform)
+                check(mxg_ifft_batch_complex(plan_, d_in_, d_in_ + bins, 1, 1, d_buffer_, d_signal_, nullptr, nullptr), "mxg_ifft_batch_complex");
+            check(mxg_memcpy_d2h(hop_.data(), d_signal_, sizeof(float) * hopSize, nullptr), "d2h hop");
+        }
+        const float nextValue = hop_[pos];
+        if (hopSize == ++pos) pos = 0;
+        return nextValue;
+    }
+    int getNumBins() { return bins; }
+
+private:
+    void release() {
+        if (plan_) mxg_ifft_plan_destroy(plan_);
+        if (d_in_) mxg_free(d_in_);
+        if (d_buffer_) mxg_free(d_buffer_);
+        if (d_signal_) mxg_free(d_signal_);
+        plan_ = nullptr;
+        d_in_ = d_buffer_ = d_signal_ = nullptr;
+    }
+    mxg_ifft_plan *plan_ = nullptr;
+    float *d_in_ = nullptr, *d_buffer_ = nullptr, *d_signal_ = nullptr;
+    int fftSize = 0, hopSize = 0, bins = 0, pos = 0;
+    std::vector<float> hop_;
 };
 
 // ---- the plugin API (src/maximilian.cpp:205-207; cpp/commandline/player.cpp:21-44) ------------------------------------

@@ -486,8 +486,25 @@ def main():
                        stderr=subprocess.DEVNULL)
         d2["ex" + ex] = np.fromfile(tmp, np.float64).reshape(frames, 2)[:, 0].copy()
         os.remove(tmp)
+    # 12.SamplePlayer loads "../../../beat2.wav" relative to the working directory: the golden run (and the GPU test) put
+    # tests/golden/wav/mono.wav (3001 samples: the head wraps inside the 6000 frames) there under that name
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        cwd = os.path.join(td, "a", "b", "c")
+        os.makedirs(cwd)
+        shutil.copy(os.path.join(GOLD, "wav", "mono.wav"), os.path.join(td, "beat2.wav"))
+        tmp = os.path.join(td, "ex12.f64")
+        subprocess.run([os.path.join(HERE, "_ref", "example_12"), "6000", tmp], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, cwd=cwd)
+        d2["ex12"] = np.fromfile(tmp, np.float64).reshape(6000, 2)[:, 0].copy()
+        # 20.FFT_example over the same file: play() -> maxiFFT(1024, 512, 1024) -> bins shifted by a looping maxiEnvGen -> maxiIFFT
+        tmp = os.path.join(td, "ex20.f64")
+        subprocess.run([os.path.join(HERE, "_ref", "example_20"), "8192", tmp], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, cwd=cwd)
+        d2["ex20"] = np.fromfile(tmp, np.float64).reshape(8192, 2)[:, 0].copy()
     save("dropin_examples.npz", **d2)
-    files["dropin_examples.npz"] = ("maximilian_examples 2.TwoTones, 3.AM1, 4.AM2, 5.FM1, 6.FM2, 8.Counting2/3/4, 10.Filters, 11.Mixing, 13.Advanced-Filters, 16.Replicant of "
+    files["dropin_examples.npz"] = ("maximilian_examples 2.TwoTones, 3.AM1, 4.AM2, 5.FM1, 6.FM2, 8.Counting2/3/4, 10.Filters, 11.Mixing, 12.SamplePlayer and 20.FFT_example (8192 frames; both over tests/golden/wav/mono.wav), 13.Advanced-Filters, 16.Replicant of "
                                     "the reference: 6000 frames (16: 30000) of channel 0 each, compiled with the unmodified reference library")
     files["dropin.npz"] = ("cpp/commandline/main.cpp (44100 frames), 14.monosynth (96000), 15.polysynth (16384) of the reference, "
                            "compiled with the unmodified reference library and run through oracle/example_host.cpp (routing() restated)")

@@ -18,14 +18,14 @@ from conftest import ROOT, assert_bits_equal, ulp_diff
 pytestmark = pytest.mark.gpu
 
 
-def run_dropin(ex, frames, tmp_path):
+def run_dropin(ex, frames, tmp_path, cwd=None, stdout=subprocess.DEVNULL):
     exe = os.path.join(ROOT, "host", "dropin_" + ex)
     if not os.path.exists(exe):
         pytest.fail("host/dropin_%s is not built (python -c 'import __graft_entry__ as g; g.build()' where /root/reference exists)" % ex)
     out = str(tmp_path / ("dropin_%s.f64" % ex))
-    r = subprocess.run([exe, str(frames), out], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=900)
+    r = subprocess.run([exe, str(frames), out], stdout=stdout, stderr=subprocess.PIPE, text=True, timeout=900, cwd=cwd)
     assert r.returncode == 0, r.stderr
-    return np.fromfile(out, np.float64).reshape(frames, 2), r.stderr
+    return np.fromfile(out, np.float64).reshape(frames, 2), (r.stderr if stdout is subprocess.DEVNULL else r.stdout)
 
 
 def test_config1_sinewave_patch(golden, tmp_path):
@@ -59,6 +59,7 @@ def test_polysynth_patch_bit_exact(golden, tmp_path):
 # how closely it can match.  Patches built only from the wavetable / ramp oscillators, the envelope and the filter are
 # bit-identical; a sinewave is within 1 ULP of glibc's, so sums / products of sinewaves carry a few ULP, and where a sinewave
 # drives another oscillator's FREQUENCY (FM) the carrier's phase inherits that last-bit difference and integrates it.
+FFT_EXAMPLE_TOL = 1e-6   # measured 8.9e-8 on a peak of 0.635 (float32 output; cosf / sinf of arguments up to a few hundred)
 EXAMPLES = {
     "02": ("2.TwoTones: sinewave(440) + sinewave(441)", 4.5e-16),
     "03": ("3.AM1: sinewave(440) * sinewave(1)", 3.5e-16),
@@ -89,3 +90,57 @@ def test_more_reference_examples_verbatim(golden, tmp_path, ex):
     else:
         assert err <= tol, what
     assert np.nanmax(np.abs(exp)) > 0.05    # (8.Counting2's sawn leaves its table on some samples: NaN in the reference too)
+
+
+def test_sample_player_patch_bit_exact(golden, tmp_path):
+    """12.SamplePlayer verbatim: maxiSample::load of "../../../beat2.wav" (relative to the working directory, as the patch
+    writes it; the file put there is tests/golden/wav/mono.wav), getSummary() printed by setup(), playAtSpeed(0.68) -- the head
+    starts on `size` (C:681), wraps on the first call and once more inside the 6000 frames."""
+    import shutil
+    exp = golden("dropin_examples.npz")["ex12"]
+    cwd = tmp_path / "a" / "b" / "c"
+    cwd.mkdir(parents=True)
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "wav", "mono.wav"), str(tmp_path / "beat2.wav"))
+    got, printed = run_dropin("12", exp.shape[0], tmp_path, cwd=str(cwd), stdout=subprocess.PIPE)
+    # playAtSpeed interpolates amplitudes[1 + i] and [2 + i] for every head i < len (C:1061-1064): on the last two positions
+    # before a wrap the reference reads past its vector (the golden stream holds whatever followed it on the heap, a denormal
+    # here); the device reads the zero guards (mxg_smp.h).  Those samples -- found by replaying the head -- are compared to
+    # nothing; every other one bit for bit.
+    L, pos, beyond = 3001, 3001.0, []
+    for n in range(exp.shape[0]):
+        i = int(pos)
+        if L - 2 <= i < L:
+            beyond.append(n)
+        pos = pos + (0.68 * 1.0) / (44100 // 44100)
+        if int(pos) >= L:
+            pos -= L
+    assert 1 <= len(beyond) <= 4, beyond
+    keep = np.ones(exp.shape[0], bool)
+    keep[beyond] = False
+    assert_bits_equal(got[keep, 0], exp[keep], "12.SamplePlayer through the drop-in header")
+    assert np.all(np.abs(got[beyond, 0]) <= 1.0)
+    assert np.array_equal(got[:, 0].view(np.uint64), got[:, 1].view(np.uint64))
+    assert np.abs(exp).max() > 0.05
+    want = " Format: 1\n Channels: 1\n SampleRate: 44100\n ByteRate: 88200\n BlockAlign: 2\n BitsPerSample: 16"
+    assert want in printed, printed    # maxiSample::getSummary (C:727-733)
+
+
+def test_fft_example_patch(golden, tmp_path):
+    """20.FFT_example verbatim (it includes "libs/maxim.h" next to "maximilian.h"): maxiSample::play() -> maxiFFT(1024, 512,
+    1024) -> the bins moved by a looping maxiEnvGen::play(1) (512 calls per frame) -> maxiIFFT::process(mags, phases) every
+    sample.  The patch hands the MAGNITUDES to the inverse transform as phases too, so polToCart takes cos / sin of values up to
+    a few hundred: the device's cosf / sinf against glibc's (the one documented tolerance of the inverse path, DESIGN.md section 4);
+    everything else -- forward transform, envelope, overlap-add -- is exact."""
+    import shutil
+    exp = golden("dropin_examples.npz")["ex20"]
+    cwd = tmp_path / "a" / "b" / "c"
+    cwd.mkdir(parents=True)
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "wav", "mono.wav"), str(tmp_path / "beat2.wav"))
+    got, printed = run_dropin("20", exp.shape[0], tmp_path, cwd=str(cwd), stdout=subprocess.PIPE)
+    assert np.array_equal(got[:, 0].view(np.uint64), got[:, 1].view(np.uint64))
+    assert np.abs(exp).max() > 0.05
+    err = np.abs(got[:, 0] - exp).max()
+    print("20.FFT_example: max |difference| %.3e, peak %.3f" % (err, np.abs(exp).max()))
+    assert_bits_equal(got[:512, 0], exp[:512], "before the first spectrum: the empty overlap-add buffer")
+    assert err <= FFT_EXAMPLE_TOL
+    assert printed.count("SC: ") == exp.shape[0] // 512    # spectralCentroid printed once per frame
