@@ -90,7 +90,7 @@ struct PinBuf {  // grow-only pinned host array
 struct Call {  // one per-sample call: which method, with which arguments (compared bit for bit)
     int method = -1;
     const void *key = nullptr;  // objects that can share a launch must agree on it (e.g. the sample buffer)
-    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool same(const Call &o) const { return method == o.method && key == o.key && !std::memcmp(a, o.a, sizeof(a)); }
 };
 
@@ -417,6 +417,23 @@ struct SamplePool : Pool {  // state: position (H:606); key = the device sample 
         check(mxg_memcpy_h2d(dp, par.data(), sizeof(double) * 3 * n, stream), "h2d smp");
         check(mxg_sample_render(G.sig[0].method, n, G.L, b->d, b->len, b->rate, dp, 0, dp + n, dp + 2 * n, G.d_state.p,
                                 G.d_out.p, stream), "mxg_sample_render");
+    }
+};
+
+struct Filter2Pool : Pool {  // maxiDCBlocker / maxiSVF / maxiBiquad: three doubles of state each (mxg_filter2_render)
+    Filter2Pool() : Pool(3, 0) {}
+    void enqueue(Group &G) override {
+        const size_t n = G.m.size(), L = G.L;
+        const int kind = G.sig[0].method;                    // 0 DC blocker, 1 SVF, 2 biquad
+        const size_t rows = kind == 0 ? 1 : (kind == 1 ? 9 : 5);  // coefficient rows, call arguments a[1 .. rows]
+        std::vector<double> in(L * n), coef(rows * n);
+        for (size_t j = 0; j < n; j++) {
+            for (size_t t = 0; t < L; t++) in[t * n + j] = G.sig[j].a[0];
+            for (size_t k = 0; k < rows; k++) coef[k * n + j] = G.sig[j].a[1 + k];
+        }
+        check(mxg_memcpy_h2d(G.d_in.need(L * n), in.data(), sizeof(double) * L * n, stream), "h2d filter2 in");
+        check(mxg_memcpy_h2d(G.d_par.need(rows * n), coef.data(), sizeof(double) * rows * n, stream), "h2d filter2 coef");
+        check(mxg_filter2_render(kind, n, L, G.d_in.p, G.d_par.p, G.d_state.p, G.d_out.p, stream), "mxg_filter2_render");
     }
 };
 
@@ -850,6 +867,79 @@ private:
     float *d_in_ = nullptr;
     double *d_out_ = nullptr;
     vector<double> coeffs_;
+};
+
+// ---- maxiDCBlocker (H:1255-1267), maxiSVF (H:1281-1338), maxiBiquad (H:1343-1486) -----------------------------------------------
+// The coefficient formulas (tan, pow, sqrt) run on the host libm (mxg_svf_coeffs_host / mxg_biquad_coeffs_host), the recurrences on
+// the device: bit-exact.
+class maxiDCBlocker {
+    using Pool = maxigpu::ps::Filter2Pool;
+    maxigpu::ps::Slot slot_;
+
+public:
+    maxiDCBlocker() { maxigpu::ps::pool<Pool>().attach(slot_); }
+    ~maxiDCBlocker() { maxigpu::ps::pool<Pool>().detach(slot_); }
+    maxiDCBlocker(const maxiDCBlocker &) = delete;
+    maxiDCBlocker &operator=(const maxiDCBlocker &) = delete;
+    double play(double input, double R) {
+        maxigpu::ps::Call c;
+        c.method = 0;
+        c.a[0] = input;
+        c.a[1] = R;
+        return maxigpu::ps::pool<Pool>().call(slot_, c);
+    }
+};
+
+class maxiSVF {
+    using Pool = maxigpu::ps::Filter2Pool;
+    maxigpu::ps::Slot slot_;
+    double coef_[5] = {0, 0, 0, 0, 0};  // g1, g2, g3, g4, k
+    double freq = 1000, res = 1;
+    void setParams(double _freq, double _res) {  // H:1320-1332
+        freq = _freq;
+        res = _res;
+        maxigpu::ps::check(mxg_svf_coeffs_host(1, &freq, &res, coef_), "mxg_svf_coeffs_host");
+    }
+
+public:
+    maxiSVF() { maxigpu::ps::pool<Pool>().attach(slot_); setParams(1000, 1); }
+    ~maxiSVF() { maxigpu::ps::pool<Pool>().detach(slot_); }
+    maxiSVF(const maxiSVF &) = delete;
+    maxiSVF &operator=(const maxiSVF &) = delete;
+    void setCutoff(double cutoff) { setParams(cutoff, res); }
+    void setResonance(double q) { setParams(freq, q); }
+    double play(double w, double lpmix, double bpmix, double hpmix, double notchmix) {
+        maxigpu::ps::Call c;
+        c.method = 1;
+        c.a[0] = w;
+        for (int i = 0; i < 5; i++) c.a[1 + i] = coef_[i];
+        c.a[6] = lpmix; c.a[7] = bpmix; c.a[8] = hpmix; c.a[9] = notchmix;
+        return maxigpu::ps::pool<Pool>().call(slot_, c);
+    }
+};
+
+class maxiBiquad {
+    using Pool = maxigpu::ps::Filter2Pool;
+    maxigpu::ps::Slot slot_;
+    double coef_[5] = {0, 0, 0, 0, 0};  // a0, a1, a2, b1, b2 (H:1481)
+
+public:
+    enum filterTypes { LOWPASS, HIGHPASS, BANDPASS, NOTCH, PEAK, LOWSHELF, HIGHSHELF };
+    maxiBiquad() { maxigpu::ps::pool<Pool>().attach(slot_); }
+    ~maxiBiquad() { maxigpu::ps::pool<Pool>().detach(slot_); }
+    maxiBiquad(const maxiBiquad &) = delete;
+    maxiBiquad &operator=(const maxiBiquad &) = delete;
+    double play(double input) {
+        maxigpu::ps::Call c;
+        c.method = 2;
+        c.a[0] = input;
+        for (int i = 0; i < 5; i++) c.a[1 + i] = coef_[i];
+        return maxigpu::ps::pool<Pool>().call(slot_, c);
+    }
+    void set(filterTypes filtType, double cutoff, double Q, double peakGain) {  // H:1376-1478
+        const int32_t t = (int32_t)filtType;
+        maxigpu::ps::check(mxg_biquad_coeffs_host(1, &t, &cutoff, &Q, &peakGain, coef_), "mxg_biquad_coeffs_host");
+    }
 };
 
 // ---- maxiEnvGen (H:2268-2547): one envelope = one slot of the maxiEnvGen bank -------------------------------------------------

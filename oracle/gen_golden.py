@@ -503,9 +503,16 @@ def main():
         subprocess.run([os.path.join(HERE, "_ref", "example_20"), "8192", tmp], check=True, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL, cwd=cwd)
         d2["ex20"] = np.fromfile(tmp, np.float64).reshape(8192, 2)[:, 0].copy()
+    # tests/patches/filters2_patch.cpp (maxiSVF, maxiBiquad x3, maxiDCBlocker, maxiEnvGen ADSR gated by an oscillator) built against
+    # the reference: both channels (output, envelope), 20 000 frames = trigger, attack, decay, hold and release
+    tmp = os.path.join("/tmp", "mxo_example_p1.f64")
+    subprocess.run([os.path.join(HERE, "_ref", "example_p1"), "20000", tmp], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    p1 = np.fromfile(tmp, np.float64).reshape(20000, 2)
+    os.remove(tmp)
+    d2["exp1"], d2["exp1_env"] = p1[:, 0].copy(), p1[:, 1].copy()
     save("dropin_examples.npz", **d2)
     files["dropin_examples.npz"] = ("maximilian_examples 2.TwoTones, 3.AM1, 4.AM2, 5.FM1, 6.FM2, 8.Counting2/3/4, 10.Filters, 11.Mixing, 12.SamplePlayer and 20.FFT_example (8192 frames; both over tests/golden/wav/mono.wav), 13.Advanced-Filters, 16.Replicant of "
-                                    "the reference: 6000 frames (16: 30000) of channel 0 each, compiled with the unmodified reference library")
+                                    "the reference: 6000 frames (16: 30000) of channel 0 each, compiled with the unmodified reference library; exp1 / exp1_env: tests/patches/filters2_patch.cpp the same way (20000 frames, both channels)")
     files["dropin.npz"] = ("cpp/commandline/main.cpp (44100 frames), 14.monosynth (96000), 15.polysynth (16384) of the reference, "
                            "compiled with the unmodified reference library and run through oracle/example_host.cpp (routing() restated)")
 

@@ -144,3 +144,18 @@ def test_fft_example_patch(golden, tmp_path):
     assert_bits_equal(got[:512, 0], exp[:512], "before the first spectrum: the empty overlap-add buffer")
     assert err <= FFT_EXAMPLE_TOL
     assert printed.count("SC: ") == exp.shape[0] // 512    # spectralCentroid printed once per frame
+
+
+def test_newer_filter_and_envelope_classes_bit_exact(golden, tmp_path):
+    """tests/patches/filters2_patch.cpp -- maxiSVF (with a cutoff change every 1500 samples), three maxiBiquad types, maxiDCBlocker and
+    a maxiEnvGen ADSR (trigger, attack, decay, HOLD while the gate is up, release) gated by maxiOsc::square -- compiled against the
+    reference (golden) and against the drop-in header: coefficients from the host libm, recurrences on the device, every sample of
+    both channels bit-identical."""
+    g = golden("dropin_examples.npz")
+    exp, env = g["exp1"], g["exp1_env"]
+    got, _ = run_dropin("p1", exp.shape[0], tmp_path)
+    assert_bits_equal(got[:, 1], env, "maxiEnvGen ADSR")
+    assert_bits_equal(got[:, 0], exp, "SVF -> biquads -> DC blocker")
+    assert env.max() == 1.0 and np.all(env[7000:11000] == env[8000]) and 0.39 < env[8000] < 0.41   # the peak, the HOLD plateau
+    assert env[14000] < 1e-3 and np.all(np.diff(env[11100:13500]) < 0)                            # the release, run to its end
+    assert np.abs(exp).max() > 0.3
