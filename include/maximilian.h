@@ -576,6 +576,24 @@ public:
     void ambisonic(double input, std::vector<double> &eight, double x, double y, double z) { run(8, input, x, y, z, eight.data()); }
 };
 
+// ---- maxiMap (H:788-854): range mappings a patch evaluates on the host, with the host libm like the reference -----------------------
+class maxiMap {
+public:
+    static double linlin(double val, double inMin, double inMax, double outMin, double outMax) {  // H:801-805
+        val = max(min(val, inMax), inMin);
+        return ((val - inMin) / (inMax - inMin) * (outMax - outMin)) + outMin;
+    }
+    static double linexp(double val, double inMin, double inMax, double outMin, double outMax) {  // H:815-820
+        val = max(min(val, inMax), inMin);
+        return pow((outMax / outMin), (val - inMin) / (inMax - inMin)) * outMin;
+    }
+    static double explin(double val, double inMin, double inMax, double outMin, double outMax) {  // H:830-835
+        val = max(min(val, inMax), inMin);
+        return (log(val / inMin) / log(inMax / inMin) * (outMax - outMin)) + outMin;
+    }
+    static double clamp(double v, const double low, const double high) { return v > high ? high : (v < low ? low : v); }  // H:843-854
+};
+
 // ---- maxiConvert (H:937-962) -- conversions a patch does on the host, as the reference does -----------------------
 class maxiConvert {
 public:

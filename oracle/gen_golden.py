@@ -510,9 +510,19 @@ def main():
     p1 = np.fromfile(tmp, np.float64).reshape(20000, 2)
     os.remove(tmp)
     d2["exp1"], d2["exp1_env"] = p1[:, 0].copy(), p1[:, 1].copy()
+    # the reference's own test programs of this path (cpp/commandline/tests/{ffttest,mfcctest,svftest}), 8192 frames of channel 0;
+    # mfcctest prints mfccs[1] once per frame: the printed numbers are kept too
+    for tag in ("tfft", "tmfcc", "tsvf"):
+        tmp = os.path.join("/tmp", "mxo_example_%s.f64" % tag)
+        r = subprocess.run([os.path.join(HERE, "_ref", "example_" + tag), "8192", tmp], check=True, stdout=subprocess.PIPE,
+                           stderr=subprocess.DEVNULL, text=True)
+        d2["ex" + tag] = np.fromfile(tmp, np.float64).reshape(8192, 2)[:, 0].copy()
+        os.remove(tmp)
+        if tag == "tmfcc":
+            d2["extmfcc_printed"] = np.array([float(x) for x in r.stdout.replace("Setup", "").split()])
     save("dropin_examples.npz", **d2)
     files["dropin_examples.npz"] = ("maximilian_examples 2.TwoTones, 3.AM1, 4.AM2, 5.FM1, 6.FM2, 8.Counting2/3/4, 10.Filters, 11.Mixing, 12.SamplePlayer and 20.FFT_example (8192 frames; both over tests/golden/wav/mono.wav), 13.Advanced-Filters, 16.Replicant of "
-                                    "the reference: 6000 frames (16: 30000) of channel 0 each, compiled with the unmodified reference library; exp1 / exp1_env: tests/patches/filters2_patch.cpp the same way (20000 frames, both channels)")
+                                    "the reference: 6000 frames (16: 30000) of channel 0 each, compiled with the unmodified reference library; exp1 / exp1_env: tests/patches/filters2_patch.cpp the same way (20000 frames, both channels); extfft / extmfcc (+ the mfccs[1] it prints per frame) / extsvf: the reference's own cpp/commandline/tests ffttest, mfcctest, svftest, 8192 frames")
     files["dropin.npz"] = ("cpp/commandline/main.cpp (44100 frames), 14.monosynth (96000), 15.polysynth (16384) of the reference, "
                            "compiled with the unmodified reference library and run through oracle/example_host.cpp (routing() restated)")
 

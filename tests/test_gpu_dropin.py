@@ -159,3 +159,43 @@ def test_newer_filter_and_envelope_classes_bit_exact(golden, tmp_path):
     assert env.max() == 1.0 and np.all(env[7000:11000] == env[8000]) and 0.39 < env[8000] < 0.41   # the peak, the HOLD plateau
     assert env[14000] < 1e-3 and np.all(np.diff(env[11100:13500]) < 0)                            # the release, run to its end
     assert np.abs(exp).max() > 0.3
+
+
+# ---- the reference's OWN test programs of this path (cpp/commandline/tests/{ffttest,mfcctest,svftest}), compiled verbatim -------
+def test_reference_ffttest_verbatim(golden, tmp_path):
+    """ffttest.cpp: sawn(maxiMap::linexp(phasor(0.2), 0, 1, 100, 5000)) -> maxiFFT(1024, 256) -> magnitudes moved up ten bins ->
+    maxiIFFT(1024, 256)::process(mags, phases, maxiIFFT::fftModes::SPECTRUM) every sample.  The forward transform is exact;
+    the phases (atan2f) and the inverse's polToCart (cosf / sinf) are the device's: the tolerance of the inverse path."""
+    exp = golden("dropin_examples.npz")["extfft"]
+    got, _ = run_dropin("tfft", exp.shape[0], tmp_path)
+    assert np.array_equal(got[:, 0].view(np.uint64), got[:, 1].view(np.uint64))
+    err = np.abs(got[:, 0] - exp).max()
+    print("ffttest: max |difference| %.3e, peak %.3f" % (err, np.abs(exp).max()))
+    assert np.abs(exp).max() > 0.3 and err <= FFT_EXAMPLE_TOL
+
+
+def test_reference_mfcctest_verbatim(golden, tmp_path):
+    """mfcctest.cpp: the same source -> maxiFFT(1024, 256, 1024)::process(w, maxiFFT::WITH_POLAR_CONVERSION) -> maxiMFCC(512 bins,
+    256 filters, 13 coefficients)::mfcc(mags), mfccs[1] printed once per frame.  The signal is bit-identical; the printed
+    coefficients (six significant digits, as `cout <<` writes them) are the reference's."""
+    g = golden("dropin_examples.npz")
+    exp, printed = g["extmfcc"], g["extmfcc_printed"]
+    got, out = run_dropin("tmfcc", exp.shape[0], tmp_path, stdout=subprocess.PIPE)
+    assert_bits_equal(got[:, 0], exp, "mfcctest's signal")
+    vals = np.array([float(x) for x in out.replace("Setup", "").split()])
+    assert vals.shape == printed.shape == (exp.shape[0] // 256,)
+    assert np.all(np.abs(vals - printed) <= 1.5e-6 * np.abs(printed) + 1e-9), (vals, printed)
+    assert np.abs(printed).max() > 0.5
+
+
+def test_reference_svftest_verbatim(golden, tmp_path):
+    """svftest.cpp: maxiSVF with setCutoff(40 + |sinewave(0.5)| * 500) and setResonance(phasor(0.2) * 1.2) on EVERY sample, saw(100)
+    through its low-pass output.  The cutoff carries the sinewave's <= 1 ULP, tan() and the recursive filter pass it on: a
+    relative tolerance like the modulated lores (tests/test_gpu_voice.py MOD_FILTER_RTOL = 1e-11), stated against the peak."""
+    MOD_FILTER_RTOL = 1e-11
+    exp = golden("dropin_examples.npz")["extsvf"]
+    got, _ = run_dropin("tsvf", exp.shape[0], tmp_path)
+    assert np.array_equal(got[:, 0].view(np.uint64), got[:, 1].view(np.uint64))
+    err = np.abs(got[:, 0] - exp).max() / np.abs(exp).max()
+    print("svftest: max relative difference %.3e (allowed %.1e)" % (err, MOD_FILTER_RTOL))
+    assert np.abs(exp).max() > 0.05 and err <= MOD_FILTER_RTOL
