@@ -35,8 +35,9 @@ def test_product_does_not_touch_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in txt and "pyoracle" not in txt and "libmaxiref" not in txt, f
-    for f in os.listdir(os.path.join(ROOT, "include")):
-        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read().replace("oracle/maxi_oracle.c", "")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "include")):
+        for f in files:
+            assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("oracle/maxi_oracle.c", ""), f
 
 
 def test_host_coefficients_match_oracle(port):
