@@ -786,6 +786,7 @@ public:
         if (!d_in_ || !d_out_) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
     }
     bool process(float value, fftModes mode = maxiFFT::WITH_POLAR_CONVERSION) {  // L/maxiFFT.cpp:65-91
+        if (!plan_) throw std::logic_error("maxiFFT::process before setup()");  // (the reference writes through an empty vector)
         buffer[pos++] = value;
         newFFT = pos == windowSize;
         if (newFFT) {
@@ -865,6 +866,8 @@ public:
         if (!d_in_ || !d_out_) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
     }
     vector<double> &mfcc(vector<float> &powerSpectrum) {  // :77-81
+        if (!plan_) throw std::logic_error("maxiMFCC::mfcc before setup()");
+        if (powerSpectrum.size() < numBins_) throw std::length_error("maxiMFCC::mfcc: fewer values than bins");
         maxigpu::ps::check(mxg_memcpy_h2d(d_in_, powerSpectrum.data(), sizeof(float) * numBins_, nullptr), "h2d spectrum");
         maxigpu::ps::check(mxg_mfcc_batch(plan_, d_in_, numBins_, 1, nullptr, nullptr, d_out_, 0, nullptr), "mxg_mfcc_batch");
         maxigpu::ps::check(mxg_memcpy_d2h(coeffs_.data(), d_out_, sizeof(double) * coeffs_.size(), nullptr), "d2h mfcc");
@@ -1069,6 +1072,8 @@ public:
     }
     float process(std::vector<float> &data1, std::vector<float> &data2, fftModes mode = maxiIFFT::SPECTRUM) {  // :154-192
         using maxigpu::ps::check;
+        if (!plan_) throw std::logic_error("maxiIFFT::process before setup()");
+        if ((int)data1.size() < bins || (int)data2.size() < bins) throw std::length_error("maxiIFFT::process: fewer values than bins");
         if (0 == pos) {  // the spectrum is consumed here; the overlap-add buffer lives on the device
             check(mxg_memcpy_h2d(d_in_, data1.data(), sizeof(float) * bins, nullptr), "h2d spectrum");
             check(mxg_memcpy_h2d(d_in_ + bins, data2.data(), sizeof(float) * bins, nullptr), "h2d spectrum");
