@@ -62,6 +62,14 @@ def mx():
     return m
 
 
+# Optimisation / instrumentation flags of the host builds of the device headers (tests/host_*.cpp).  MXG_HOST_UBSAN=1 swaps -O2
+# for UndefinedBehaviorSanitizer (+ float-cast-overflow), aborting on the first report: tests/test_host_ubsan.py re-runs those
+# suites that way, so the arithmetic the kernels share with their host harnesses is checked for signed overflow, out-of-range
+# float -> int casts, misaligned or out-of-bounds accesses the compiler can see, ...
+HOST_OPT = (["-O1", "-fsanitize=undefined,float-cast-overflow", "-fno-sanitize-recover=all"]
+            if os.environ.get("MXG_HOST_UBSAN") else ["-O2"])
+
+
 def bits(a):
     return np.ascontiguousarray(a, np.float64).view(np.uint64)
 

@@ -9,13 +9,14 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, assert_bits_equal
+
+from conftest import HOST_OPT, ROOT, assert_bits_equal
 
 
 @pytest.fixture(scope="module")
 def env_host(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("env") / "libenv_host.so")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared",
+    subprocess.check_call(["g++", "-std=c++17"] + HOST_OPT + ["-ffp-contract=off", "-fPIC", "-shared",
                            "-I" + os.path.join(ROOT, "maximilian_amd", "csrc"), "-o", so,
                            os.path.join(ROOT, "tests", "host_env.cpp")])
     lib = ctypes.CDLL(so)

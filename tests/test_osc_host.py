@@ -9,7 +9,8 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, assert_bits_equal
+
+from conftest import HOST_OPT, ROOT, assert_bits_equal
 
 NAMES = {2: "phasor", 3: "saw", 4: "triangle", 5: "square", 6: "pulse", 7: "impulse", 8: "sinebuf", 9: "sinebuf4",
          10: "sawn", 11: "phasorBetween"}
@@ -18,7 +19,7 @@ NAMES = {2: "phasor", 3: "saw", 4: "triangle", 5: "square", 6: "pulse", 7: "impu
 @pytest.fixture(scope="module")
 def osc_host(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("osc") / "libosc_host.so")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared",
+    subprocess.check_call(["g++", "-std=c++17"] + HOST_OPT + ["-ffp-contract=off", "-fPIC", "-shared",
                            "-I" + os.path.join(ROOT, "maximilian_amd", "csrc"), "-o", so,
                            os.path.join(ROOT, "tests", "host_osc.cpp")])
     lib = ctypes.CDLL(so)

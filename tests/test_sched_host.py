@@ -5,12 +5,12 @@ binade crossings; and next_birth against the sample-by-sample `floor(fmod(counte
 import os
 import subprocess
 
-from conftest import ROOT
+from conftest import HOST_OPT, ROOT
 
 
 def test_exact_multi_step_scheduler_forms_on_host(tmp_path):
     exe = str(tmp_path / "sched_fuzz")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I" + os.path.join(ROOT, "maximilian_amd", "csrc"),
+    subprocess.check_call(["g++", "-std=c++17"] + HOST_OPT + ["-ffp-contract=off", "-I" + os.path.join(ROOT, "maximilian_amd", "csrc"),
                            "-o", exe, os.path.join(ROOT, "tests", "host_sched_fuzz.cpp")])
     r = subprocess.run([exe, "400000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:]
@@ -21,7 +21,7 @@ def test_event_driven_walk_equals_the_one_sample_step_on_host(tmp_path):
     """sched_run_events (what K8a runs per stream, mxg_sched.h) against sched_step over random streams of all four modes:
     same births at the same samples with the same (pos0, inc) bits and the same final scheduler state."""
     exe = str(tmp_path / "sched_events")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I" + os.path.join(ROOT, "maximilian_amd", "csrc"),
+    subprocess.check_call(["g++", "-std=c++17"] + HOST_OPT + ["-ffp-contract=off", "-I" + os.path.join(ROOT, "maximilian_amd", "csrc"),
                            "-o", exe, os.path.join(ROOT, "tests", "host_sched_events.cpp")])
     r = subprocess.run([exe, "15000"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]

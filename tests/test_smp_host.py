@@ -8,7 +8,8 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, assert_bits_equal
+
+from conftest import HOST_OPT, ROOT, assert_bits_equal
 
 MODES = ["play", "playOnce", "playLoop", "playUntil", "playAtSpeed", "playOnceAtSpeed", "playUntilAtSpeed", "play4",
          "playAtSpeedBetweenPoints"]
@@ -17,7 +18,7 @@ MODES = ["play", "playOnce", "playLoop", "playUntil", "playAtSpeed", "playOnceAt
 @pytest.fixture(scope="module")
 def smp_host(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("smp") / "libsmp_host.so")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared",
+    subprocess.check_call(["g++", "-std=c++17"] + HOST_OPT + ["-ffp-contract=off", "-fPIC", "-shared",
                            "-I" + os.path.join(ROOT, "maximilian_amd", "csrc"), "-o", so,
                            os.path.join(ROOT, "tests", "host_smp.cpp")])
     lib = ctypes.CDLL(so)
