@@ -11,7 +11,9 @@ V, B = 65536, 512
 nbytes = V * B * 8
 MB2 = 2 << 20
 L.mxg_malloc.restype = ctypes.c_void_p
-pool = L.mxg_malloc(ctypes.c_size_t(2 * nbytes + (5 << 30)))
+POOL_EXTRA = int(os.environ.get('POOL_GB', '5')) << 30
+pool = L.mxg_malloc(ctypes.c_size_t(2 * nbytes + POOL_EXTRA))
+assert pool, 'pool allocation failed'
 base = (pool + MB2 - 1) // MB2 * MB2
 rng = np.random.default_rng(1)
 xin = rng.uniform(-1, 1, (B, V))
@@ -33,6 +35,22 @@ OFFS = [0, 256, 1024, 2048, 4096, 1 << 17, 1 << 18, 1 << 19, 1 << 24, 1 << 25, 1
 if len(sys.argv) > 1:
     OFFS = [int(a, 0) for a in sys.argv[1:]]
 for off in OFFS:
+    if off + nbytes > nbytes + POOL_EXTRA - (64 << 20):
+        continue   # beyond the pool
     out = ctypes.c_void_p(obase + off)
     t = timed(lambda: L.mxg_filter_render(0, V, B, ctypes.c_void_p(base), dcut.ptr, 0, dres.ptr, 0, dcoef.ptr, fst.ptr, out, None))
     print("out = in + %d MB + %8d B   filter lores %.1f us  (%.0f GB/s of 16 B/sample)" % ((obase - base) >> 20, off, t, 16 * V * B / t / 1e3), flush=True)
+
+# ---- separately allocated blocks: what a host gets from hipMalloc as it comes (arguments: none) ---------------------------------------
+if len(sys.argv) == 1:
+    L.mxg_free(ctypes.c_void_p(pool))
+    times, keep = [], []
+    for trial in range(12):
+        a = L.mxg_malloc(ctypes.c_size_t(nbytes)); b = L.mxg_malloc(ctypes.c_size_t(nbytes))
+        keep.append(L.mxg_malloc(ctypes.c_size_t((trial % 5 + 1) * (33 << 20))))   # odd-sized neighbours: vary where the next pair lands
+        L.mxg_memcpy_h2d(ctypes.c_void_p(a), xin.ctypes.data, ctypes.c_size_t(nbytes), None)
+        t0 = timed(lambda: L.mxg_filter_render(0, V, B, ctypes.c_void_p(a), dcut.ptr, 0, dres.ptr, 0, dcoef.ptr, fst.ptr, ctypes.c_void_p(b), None), 60)
+        times.append(t0)
+        L.mxg_free(ctypes.c_void_p(a)); L.mxg_free(ctypes.c_void_p(b))
+    for k in keep: L.mxg_free(ctypes.c_void_p(k))
+    print("filter lores over 12 separately allocated pairs of blocks: %s us" % " ".join("%.0f" % t for t in times), flush=True)
