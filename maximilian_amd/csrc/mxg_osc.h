@@ -57,18 +57,20 @@ __device__ __forceinline__ OscPre osc_pre(double f, double sr, double p1, double
 }
 
 // One sample of one voice.  `phase`/`hold` are the members `phase`/`output` (H:173,176).
-// s_sine[i+1] == sineBuffer[i] (i=-1..513), s_trans[i] == transition[i] (i=0..1001).
-template <int WF>
+// s_sine[i+1] == sineBuffer[i] (i=-1..513), s_trans[i] == transition[i] (i=0..1001); for sinewave / coswave s_sine is the
+// sin / cos table MXG_SINTAB of mxg_sincos.h instead.
+// TRUST (sinewave / coswave only): the caller has checked 0 <= inc <= 1 and 0 <= phase <= 2, which the recurrence then keeps.
+template <int WF, bool TRUST = false>
 __device__ __forceinline__ double osc_tick(double &phase, double &hold, const OscPre &q,
                                            const double *s_sine, const double *s_trans) {
     if constexpr (WF == MXG_OSC_SINEWAVE) {  // C:228-235
-        double r = sin_2pi_phase(phase);
+        double r = sin_2pi_phase<TRUST>(phase, s_sine);
         hold = r;
         if (phase >= 1.0) phase -= 1.0;
         phase += q.inc;
         return r;
     } else if constexpr (WF == MXG_OSC_COSWAVE) {  // C:276-283
-        double r = cos_2pi_phase(phase);
+        double r = cos_2pi_phase<TRUST>(phase, s_sine);
         hold = r;
         if (phase >= 1.0) phase -= 1.0;
         phase += q.inc;

@@ -1,5 +1,10 @@
 // mxg_sincos.h -- sin/cos of (phase * TWOPI) for maxiOsc::sinewave / coswave (C:230, C:278).
 //
+// Two routines.  The oscillators use the TABLE form at the end of this file (sincos_tab: 512-entry double-double table in LDS,
+// correctly rounded on every argument tested, ~32 instructions).  The Cody-Waite + fdlibm-kernel form described next (sin_small /
+// cos_small, no table) came first; it remains for callers without a table at hand (the modulated lores / bandpass coefficients of
+// the fused voice) and is measured by the same host test.
+//
 // The reference evaluates glibc sin()/cos() on the ROUNDED product x = phase*TWOPI.  glibc's
 // result is within 1 ULP of the true value (in practice correctly rounded almost always).
 // The device path must therefore produce sin(x) to well under 1 ULP so the two differ by at
@@ -132,13 +137,61 @@ __device__ __forceinline__ double cos_small(double x) {
     return ((n + 1) & 2) ? -r : r;
 }
 
-__device__ __forceinline__ double sin_2pi_phase(double phase) {
-    double x = phase * (MXG_TWOPI);
-    return sin_small(x);
+// ---- the table form (round 2): sin / cos of a + b, a = k*pi/256 from a table, |b| <= pi/512 ----------------------------------------
+// The oscillators call this one.  x = k*h + b with h = pi/256 held in three pieces (39 + 39 + 53 bits: k*P1 and k*P2 are exact for
+// k < 2^13, i.e. |x| <= 64, so b = (bh, bl) is good to 2^-120 absolute -- relative 2^-60 even for the double nearest a zero of
+// the function, with no special case); sin(a), cos(a) come as double-double (S, C) from a 512-entry table in LDS; sin b - b and
+// cos b - 1 are three-term polynomials (|b| < 0.0062: the next terms are below 2^-75 of the result).  Then
+//     sin(a + b) = S + (S (cos b - 1) + C sin b),     cos(a + b) = C + (C (cos b - 1) - S sin b),
+// with the one term that can be as large as the leading one, C*bh (resp. S*bh), kept exact (product + FMA remainder) and added to
+// the leading term with its rounding error recovered (Fast2Sum: |S_hi| >= sin(pi/256) > |C*bh| whenever S_hi is not exactly 0).
+// ~32 instructions against ~50 for the reduction + both fdlibm kernels + quadrant select above, and MORE accurate: measured
+// max error 0.5000 ULP against quad precision on 6 M arguments (whole domain, zero crossings and their neighbours, table
+// points and their neighbours, tiny arguments: tests/host_sincos_accuracy.cpp) -- i.e. correctly rounded on every one of them.
+// tab = MXG_SINTAB (mxg_sintab.h) in LDS / memory.  |x| > 64, NaN, Inf: the routines above.
+#include "mxg_sintab.h"
+#if defined(__HIPCC__)
+#define MXG_NO_CONTRACT  // the library is built with -ffp-contract=off: only the fma() calls below fuse
+#else
+#define MXG_NO_CONTRACT __attribute__((optimize("fp-contract=off")))  // host builds of this text (tests): the same
+#endif
+// TRUST: the caller guarantees 0 <= x <= 64 (an oscillator whose phase stays in [0, 2]): no range test, no sign to restore.
+template <bool COS, bool TRUST = false>
+MXG_NO_CONTRACT __device__ __forceinline__ double sincos_tab(double x, const double *tab) {
+    if constexpr (!TRUST)
+        if (!(fabs(x) <= 64.0)) return COS ? cos(x) : sin(x);
+    const double ax = TRUST ? x : fabs(x);
+    const double fk = rint(ax * MXG_SINTAB_INVH);
+    const double r1 = fma(-fk, MXG_SINTAB_P1, ax);  // exact
+    const double w = fk * MXG_SINTAB_P2;            // exact
+    const double bh = r1 - w;
+    const double bl = fma(-fk, MXG_SINTAB_P3, (r1 - bh) - w);
+    const double *e = tab + 4 * ((int)fk & 511);
+    const double Sh = e[0], Sl = e[1], Ch = e[2], Cl = e[3];
+    const double z = bh * bh;
+    using sincos_detail::fma_k;
+    using sincos_detail::fma_kk;
+    const double sc = fma(bh * z, fma_k(z, fma_kk(z, -1.0 / 5040, 1.0 / 120), -1.0 / 6), bl);  // sin b - bh
+    const double cm1 = z * fma_k(z, fma_kk(z, -1.0 / 720, 1.0 / 24), -0.5);                    // cos b - 1
+    const double Ah = COS ? Ch : Sh, Al = COS ? Cl : Sl, Bh = COS ? -Sh : Ch, Bl = COS ? -Sl : Cl;
+    double t = fma(Bh, sc, Ah * cm1);
+    t = t + fma(Bl, bh, Al);
+    const double ph = Bh * bh, pl = fma(Bh, bh, -ph);
+    const double s = Ah + ph, err = ph - (s - Ah);
+    const double r = s + (err + (pl + t));
+    if constexpr (TRUST) return r;
+    return (!COS && x < 0) ? -r : r;
 }
-__device__ __forceinline__ double cos_2pi_phase(double phase) {
+
+template <bool TRUST = false>
+__device__ __forceinline__ double sin_2pi_phase(double phase, const double *sintab) {
     double x = phase * (MXG_TWOPI);
-    return cos_small(x);
+    return sincos_tab<false, TRUST>(x, sintab);
+}
+template <bool TRUST = false>
+__device__ __forceinline__ double cos_2pi_phase(double phase, const double *sintab) {
+    double x = phase * (MXG_TWOPI);
+    return sincos_tab<true, TRUST>(x, sintab);
 }
 
 }  // namespace mxg

@@ -28,9 +28,28 @@ namespace {
 __device__ const double MAXI_SINE_TAB_D[MAXI_SINE_TAB_LEN] = MAXI_SINE_TAB_INIT;
 __device__ const double MAXI_TRANS_TAB_D[MAXI_TRANS_TAB_LEN] = MAXI_TRANS_TAB_INIT;
 
+__device__ const double MXG_SINTAB_D[MXG_SINTAB_LEN] = {MXG_SINTAB_VALUES};
+
 template <int WF>
 constexpr bool uses_sine() {
     return WF == MXG_OSC_SINEBUF || WF == MXG_OSC_SINEBUF4;
+}
+// the table a waveform's tick reads from LDS: sineBuffer (sinebuf / sinebuf4), transition (sawn), sin / cos of k*pi/256 (sinewave / coswave)
+template <int WF>
+constexpr int tab_len() {
+    return uses_sine<WF>() ? MAXI_SINE_TAB_LEN
+                           : (WF == MXG_OSC_SAWN ? MAXI_TRANS_TAB_LEN
+                                                 : ((WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE) ? MXG_SINTAB_LEN : 1));
+}
+template <int WF>
+__device__ __forceinline__ void load_tab(double *s_tab) {  // (the caller synchronises)
+    if constexpr (uses_sine<WF>()) {
+        for (int i = threadIdx.x; i < MAXI_SINE_TAB_LEN; i += blockDim.x) s_tab[i] = MAXI_SINE_TAB_D[i];
+    } else if constexpr (WF == MXG_OSC_SAWN) {
+        for (int i = threadIdx.x; i < MAXI_TRANS_TAB_LEN; i += blockDim.x) s_tab[i] = MAXI_TRANS_TAB_D[i];
+    } else if constexpr (WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE) {
+        for (int i = threadIdx.x; i < MXG_SINTAB_LEN; i += blockDim.x) s_tab[i] = MXG_SINTAB_D[i];
+    }
 }
 
 // K1: one lane = VPL adjacent voices; the N-sample recurrence runs in registers.
@@ -40,13 +59,9 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
                            double *__restrict__ phase_io, double *__restrict__ hold_io,
                            double *__restrict__ out, double sr, int *part_ctrs) {
     // All LDS in ONE array (a second __shared__ object perturbs hipcc's waitcnt placement).
-    __shared__ double s_tab[uses_sine<WF>() ? MAXI_SINE_TAB_LEN
-                                            : (WF == MXG_OSC_SAWN ? MAXI_TRANS_TAB_LEN : 1)];
-    if constexpr (uses_sine<WF>()) {
-        for (int i = threadIdx.x; i < MAXI_SINE_TAB_LEN; i += blockDim.x) s_tab[i] = MAXI_SINE_TAB_D[i];
-        __syncthreads();
-    } else if constexpr (WF == MXG_OSC_SAWN) {
-        for (int i = threadIdx.x; i < MAXI_TRANS_TAB_LEN; i += blockDim.x) s_tab[i] = MAXI_TRANS_TAB_D[i];
+    __shared__ __attribute__((aligned(16))) double s_tab[tab_len<WF>()];
+    if constexpr (tab_len<WF>() > 1) {
+        load_tab<WF>(s_tab);
         __syncthreads();
     }
     const size_t v0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VPL;
@@ -89,20 +104,44 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
 #ifndef MXG_OSC_UNROLL
 #define MXG_OSC_UNROLL 4
 #endif
-#pragma unroll MXG_OSC_UNROLL
-    for (size_t n = nA; n < nB; n++) {
-        double r[VPL];
+    // sinewave / coswave with 0 <= inc <= 1 and the phase in [0, 2] on every lane of the wavefront (any audio frequency from a
+    // fresh or carried bank): the argument of sin / cos stays in [0, 4 pi], so the table routine needs neither its range test nor
+    // a sign (mxg_sincos.h, TRUST)
+    bool trust = false;
+    if constexpr ((WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE) && !FPS) {
+        bool ok = true;
 #pragma unroll
-        for (int j = 0; j < VPL; j++) {
-            if constexpr (FPS) q[j] = osc_pre<WF>(fp[j], sr, q[j].p1, q[j].p2);
-            r[j] = osc_tick<WF>(ph[j], hd[j], q[j], s_tab, s_tab);
+        for (int j = 0; j < VPL; j++) ok = ok && q[j].inc >= 0.0 && q[j].inc <= 1.0 && ph[j] >= 0.0 && ph[j] <= 2.0;
+        trust = __all(ok);
+    }
+    if (trust) {
+#pragma unroll MXG_OSC_UNROLL
+        for (size_t n = nA; n < nB; n++) {
+            double r[VPL];
+#pragma unroll
+            for (int j = 0; j < VPL; j++) r[j] = osc_tick<WF, true>(ph[j], hd[j], q[j], s_tab, s_tab);
+            if constexpr (VPL == 2)
+                store2<NT>(o, r[0], r[1]);
+            else
+                store1<NT>(o, r[0]);
+            o += V;
         }
-        if constexpr (VPL == 2)
-            store2<NT>(o, r[0], r[1]);
-        else
-            store1<NT>(o, r[0]);
-        o += V;
-        if constexpr (FPS) fp += V;
+    } else {
+#pragma unroll MXG_OSC_UNROLL
+        for (size_t n = nA; n < nB; n++) {
+            double r[VPL];
+#pragma unroll
+            for (int j = 0; j < VPL; j++) {
+                if constexpr (FPS) q[j] = osc_pre<WF>(fp[j], sr, q[j].p1, q[j].p2);
+                r[j] = osc_tick<WF>(ph[j], hd[j], q[j], s_tab, s_tab);
+            }
+            if constexpr (VPL == 2)
+                store2<NT>(o, r[0], r[1]);
+            else
+                store1<NT>(o, r[0]);
+            o += V;
+            if constexpr (FPS) fp += V;
+        }
     }
     if (blockIdx.y + 1 == gridDim.y) {
         part_wait(part_ctr, (int)gridDim.y - 1);
@@ -143,17 +182,13 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
                                                       double *__restrict__ phase_io, double *__restrict__ hold_io,
                                                       double *__restrict__ out, const double *__restrict__ pan,
                                                       double *__restrict__ partial, double sr) {
-    constexpr int kTab = uses_sine<WF>() ? MAXI_SINE_TAB_LEN : (WF == MXG_OSC_SAWN ? MAXI_TRANS_TAB_LEN : 1);
+    constexpr int kTab = tab_len<WF>();
     constexpr int kTabPad = (kTab + 1) & ~1;  // the (L, R) pairs below are 16-byte stores
     constexpr int kRows = VAR == 0 ? 4 : 16;  // LDS rows the workgroup pass adds per output
     constexpr int kMixWin = WIN;
     __shared__ __attribute__((aligned(16))) double s_all[kTabPad + kRows * kMixWin * 2];
     double *s_tab = s_all;
-    if constexpr (uses_sine<WF>()) {
-        for (int i = threadIdx.x; i < MAXI_SINE_TAB_LEN; i += blockDim.x) s_tab[i] = MAXI_SINE_TAB_D[i];
-    } else if constexpr (WF == MXG_OSC_SAWN) {
-        for (int i = threadIdx.x; i < MAXI_TRANS_TAB_LEN; i += blockDim.x) s_tab[i] = MAXI_TRANS_TAB_D[i];
-    }
+    load_tab<WF>(s_tab);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *s_part = s_all + kTabPad;                                     // [kRows][kMixWin][2]

@@ -29,15 +29,19 @@ static long long bits_diff(double a, double b) {
     return llabs(x - y);
 }
 
+static const double kSinTab[MXG_SINTAB_LEN] = {MXG_SINTAB_VALUES};
+
 int main(int argc, char **argv) {
     const long cases = argc > 1 ? atol(argv[1]) : 2000000;
+    double worst_ts = 0, worst_tc = 0, arg_ts = 0, arg_tc = 0;
     std::mt19937_64 g(0x4D415849);
     std::uniform_real_distribution<double> u(-1.0, 1.0);
     double worst_s = 0, worst_c = 0, arg_s = 0, arg_c = 0;
     long long worst_vs_libm = 0;
     for (long i = 0; i < cases; i++) {
         double x;
-        switch (i % 6) {
+        switch (i % 7) {
+            case 6: x = (double)(long)(5000.0 * fabs(u(g))) * 0.01227184630308513 + ldexp(u(g), -(int)(8 + g() % 45)); break;  // the table's points and their neighbours
             case 0: x = 64.0 * u(g); break;                                // the whole fast-path domain
             case 1: x = (0.5 + 0.5 * u(g)) * MXG_TWOPI; break;               // an oscillator's phase * TWOPI
             case 2: x = (double)(long)(40.0 * u(g)) * 1.5707963267948966 + 1e-3 * u(g); break;  // near multiples of pi/2
@@ -61,7 +65,17 @@ int main(int argc, char **argv) {
         const long long d1 = bits_diff(s, sin(x)), d2 = bits_diff(c, cos(x));
         if (d1 > worst_vs_libm) worst_vs_libm = d1;
         if (d2 > worst_vs_libm) worst_vs_libm = d2;
+        // the table form the oscillators use (sincos_tab): same contract, and it is held to correct rounding + a hair
+        const double st = mxg::sincos_tab<false>(x, kSinTab), ct = mxg::sincos_tab<true>(x, kSinTab);
+        const double ets = (double)(fabsq((quad)st - ts) / ulp_of(ts)), etc = (double)(fabsq((quad)ct - tc) / ulp_of(tc));
+        if (ets > worst_ts) { worst_ts = ets; arg_ts = x; }
+        if (etc > worst_tc) { worst_tc = etc; arg_tc = x; }
+        const long long d3 = bits_diff(st, sin(x)), d4 = bits_diff(ct, cos(x));
+        if (d3 > worst_vs_libm) worst_vs_libm = d3;
+        if (d4 > worst_vs_libm) worst_vs_libm = d4;
     }
+    printf("table form: sin max error %.4f ULP at x=%a; cos %.4f ULP at x=%a\n", worst_ts, arg_ts, worst_tc, arg_tc);
+    if (!(worst_ts < 0.51 && worst_tc < 0.51)) return 1;
     printf("sin: max error %.4f ULP at x=%a; cos: %.4f ULP at x=%a; vs glibc sin/cos: max %lld ULP (%ld cases)\n",
            worst_s, arg_s, worst_c, arg_c, worst_vs_libm, cases);
     return (worst_s < 0.85 && worst_c < 0.85 && worst_vs_libm <= 1) ? 0 : 1;
