@@ -56,6 +56,16 @@ __device__ __forceinline__ OscPre osc_pre(double f, double sr, double p1, double
     return q;
 }
 
+// `if (phase >= 1.0) phase -= 1.0;` (C:231, C:279) as compare + ONE select + subtract: the subtrahend is 1.0 or +0.0, assembled from
+// its high word (x - 0.0 is x for every x, -0.0 and NaN included), instead of a subtract and a two-word select.
+__device__ __forceinline__ double wrap_at_one(double phase) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return phase - __hiloint2double(phase >= 1.0 ? 0x3FF00000 : 0, 0);
+#else
+    return phase >= 1.0 ? phase - 1.0 : phase;
+#endif
+}
+
 // One sample of one voice.  `phase`/`hold` are the members `phase`/`output` (H:173,176).
 // s_sine[i+1] == sineBuffer[i] (i=-1..513), s_trans[i] == transition[i] (i=0..1001); for sinewave / coswave s_sine is the
 // sin / cos table MXG_SINTAB of mxg_sincos.h instead.
@@ -66,13 +76,13 @@ __device__ __forceinline__ double osc_tick(double &phase, double &hold, const Os
     if constexpr (WF == MXG_OSC_SINEWAVE) {  // C:228-235
         double r = sin_2pi_phase<TRUST>(phase, s_sine);
         hold = r;
-        if (phase >= 1.0) phase -= 1.0;
+        phase = wrap_at_one(phase);
         phase += q.inc;
         return r;
     } else if constexpr (WF == MXG_OSC_COSWAVE) {  // C:276-283
         double r = cos_2pi_phase<TRUST>(phase, s_sine);
         hold = r;
-        if (phase >= 1.0) phase -= 1.0;
+        phase = wrap_at_one(phase);
         phase += q.inc;
         return r;
     } else if constexpr (WF == MXG_OSC_PHASOR) {  // C:285-291
@@ -169,7 +179,7 @@ template <int WF>
 __device__ __forceinline__ void osc_skip(double &phase, double &hold, const OscPre &q, const double *s_sine,
                                          const double *s_trans) {
     if constexpr (WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE || WF == MXG_OSC_PHASOR || WF == MXG_OSC_TRIANGLE) {
-        if (phase >= 1.0) phase -= 1.0;
+        phase = wrap_at_one(phase);
         phase += q.inc;
     } else if constexpr (WF == MXG_OSC_SAW) {
         if (phase >= 1.0) phase -= 2.0;
