@@ -344,12 +344,13 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     bool nt = tune_get("osc_nt") != 0;
     osc_fn fn = pick_wf(waveform, fps != 0, vpl, nt);
     size_t lanes = (V + vpl - 1) / vpl;
-    // time parts: only where the output dominates the recurrence (sinewave, coswave) and the bank is too small to give
-    // every SIMD four wavefronts by itself
+    // time parts: only where the output dominates the recurrence (sinewave, coswave, sinebuf4) and the bank is too small to give
+    // every SIMD two wavefronts by itself
     int split = tune_get("osc_split");
     if (split == 0) {
         split = 1;
-        if (!fps && (waveform == MXG_OSC_SINEWAVE || waveform == MXG_OSC_COSWAVE)) {
+        if (!fps && (waveform == MXG_OSC_SINEWAVE || waveform == MXG_OSC_COSWAVE || waveform == MXG_OSC_SINEBUF4)) {  // (sinebuf4: four
+            // table reads and a cubic per sample at one wavefront per SIMD: 62 us whole, 55-56 in two parts)
             const size_t waves = (lanes + 63) / 64;
             split = waves >= 2048 ? 1 : 2;  // (with the table routine two parts are best at 65 536 voices: 60-62 us; one part 65-69, four 64)
         }

@@ -14,7 +14,11 @@ out = mx.DeviceBuffer((B, V), zero=False)
 rnd = mx.DeviceBuffer.from_numpy(np.random.default_rng(1).integers(0, 2**31 - 1, (B, V)).astype(np.int32))
 e0, e1 = L.mxg_event_create(), L.mxg_event_create(); ms = ctypes.c_float()
 def timed(fn, reps=300):
-    for _ in range(100): fn()
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.25:      # clock ramp: an idle MI355X needs continuous work to reach its sustained clocks
+        for _ in range(20): fn()
+        L.mxg_sync()
     L.mxg_event_record(e0, None)
     for _ in range(reps): fn()
     L.mxg_event_record(e1, None); L.mxg_event_elapsed_ms(e0, e1, ctypes.byref(ms)); return ms.value / reps * 1e3
