@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""tools/sweep_osc_split.py -- maxiOsc::sinewave / coswave at 65 536 voices x 512 against the number of time parts (knob osc_split),
+two passes (HIP events after a warm-up of 200 launches)."""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd())
