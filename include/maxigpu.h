@@ -132,6 +132,7 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "osc_split" (time parts per voice group in K1: 0 automatic, 1..8),
  * "smp_split" (time parts of a block-constant playAtSpeed / playOnceAtSpeed / playUntilAtSpeed launch: 0 automatic, 1..8),
  * "smp_pipe" (that launch issues the window loads of chunk k+1 before the stores of chunk k, 0|1),
+ * "ifft_stream" (mxg_ifft_batch: inverse transform and hop buffer in one kernel: 0 never, 1 where hop >= fftSize / 2, 2 wherever it fits),
  * "mfcc_mfma_fullk" (the MFMA mel contraction runs over all numBins bins instead of the ones that carry weight, 0|1).
  * "fused_waves16" (mxg_fft_mfcc_batch: the 16-waves-per-CU form of the fused kernel when the request allows it, 0|1).
  * The tests flip every one of them and demand identical bits.  Returns the previous value or MXG_ERR_INVALID. */

@@ -136,6 +136,93 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fft_generic_kernel(
 // INPUT 0: SPECTRUM mode (magnitudes, phases -> polToCart).  1: cartesian inputs (mags = real, phases = imag: what
 // inverseFFTComplex was meant to transform).  2: the transform inputs are all zero (what the reference's COMPLEX mode
 // actually transforms on a fresh object, L/fft.cpp:613-619 -- see mxg_ifft_batch_complex).
+// One frame: polToCart into bit-reversed order, the inverse transform in LDS (`X`, padded 1 per 32), for one wavefront.
+template <int INPUT>
+__device__ __forceinline__ void ifft_frame(const float *__restrict__ m, const float *__restrict__ ph, const int n, const int numBits,
+                                           const float2 *s_tw, float2 *X, const int lane) {
+    const int half = n >> 1;
+    auto P = [](int idx) { return idx + (idx >> 5); };
+    // polToCart (L/fft.cpp:590-604) into bit-reversed order.  Bins half .. n-1 are zero and land on the ODD slots, so the first
+    // stage -- x_j +- (1, 0) * 0 -- only copies x_j to its neighbour (it can differ from the reference in the sign of a zero,
+    // which no later sum, product or the final `0 + r * window` can turn into anything else): both slots are written here.
+    for (int i = lane; i < half; i += 64) {
+        float2 v = {0.0f, 0.0f};
+        if constexpr (INPUT != 2) {
+            const float mg = m[i], p = ph[i];
+            if constexpr (INPUT == 0) {
+                float sn, cs;
+                sincosf(p, &sn, &cs);
+                v.x = mg * cs;  // :597-598
+                v.y = mg * sn;
+            } else {
+                v.x = mg;
+                v.y = p;
+            }
+        }
+        const int j = (int)(__brev((unsigned)i) >> (32 - numBits));  // even: i < half has its top bit clear
+        X[P(j)] = v;
+        X[P(j + 1)] = v;
+    }
+    wave_lds_sync();
+    // stages in groups: the values {j + m h} go through up to three consecutive stages in registers -- the same butterflies on
+    // the same operands, a third of the LDS passes (1024 points: stages 1-3, 4-6, 7-9)
+    int st = 1;
+    for (; st + 2 < numBits; st += 3) {
+        const int h = 1 << st;
+        for (int q = lane; q < (n >> 3); q += 64) {
+            const int nn = q & (h - 1);
+            const int j = ((q >> st) << (st + 3)) | nn;
+            float2 x[8];
+#pragma unroll
+            for (int mm = 0; mm < 8; mm++) x[mm] = X[P(j + mm * h)];
+            const float2 w0 = s_tw[h - 1 + nn];
+#pragma unroll
+            for (int mm = 0; mm < 8; mm += 2) bfly(x[mm], x[mm + 1], w0);
+            const float2 w1a = s_tw[2 * h - 1 + nn], w1b = s_tw[2 * h - 1 + nn + h];
+            bfly(x[0], x[2], w1a);
+            bfly(x[1], x[3], w1b);
+            bfly(x[4], x[6], w1a);
+            bfly(x[5], x[7], w1b);
+#pragma unroll
+            for (int mm = 0; mm < 4; mm++) bfly(x[mm], x[mm + 4], s_tw[4 * h - 1 + nn + mm * h]);
+#pragma unroll
+            for (int mm = 0; mm < 8; mm++) X[P(j + mm * h)] = x[mm];
+        }
+        wave_lds_sync();
+    }
+    for (; st + 1 < numBits; st += 2) {
+        const int h = 1 << st;
+        for (int q = lane; q < (n >> 2); q += 64) {
+            const int nn = q & (h - 1);
+            const int j = ((q >> st) << (st + 2)) | nn;
+            float2 x0 = X[P(j)], x1 = X[P(j + h)], x2 = X[P(j + 2 * h)], x3 = X[P(j + 3 * h)];
+            const float2 w = s_tw[h - 1 + nn];
+            bfly(x0, x1, w);
+            bfly(x2, x3, w);
+            bfly(x0, x2, s_tw[2 * h - 1 + nn]);
+            bfly(x1, x3, s_tw[2 * h - 1 + nn + h]);
+            X[P(j)] = x0;
+            X[P(j + h)] = x1;
+            X[P(j + 2 * h)] = x2;
+            X[P(j + 3 * h)] = x3;
+        }
+        wave_lds_sync();
+    }
+    for (; st < numBits; st++) {
+        const int h = 1 << st;
+        for (int b = lane; b < half; b += 64) {
+            const int nn = b & (h - 1);
+            const int j = ((b >> st) << (st + 1)) | nn;
+            const int k = j + h;
+            float2 xj = X[P(j)], xk = X[P(k)];
+            bfly(xj, xk, s_tw[h - 1 + nn]);
+            X[P(j)] = xj;
+            X[P(k)] = xk;
+        }
+        wave_lds_sync();
+    }
+}
+
 template <int INPUT>
 __global__ void ifft_generic_kernel(const float *__restrict__ mags, const float *__restrict__ phases,
                                     size_t nframes, int n, int numBits, const float *__restrict__ window,
@@ -143,45 +230,82 @@ __global__ void ifft_generic_kernel(const float *__restrict__ mags, const float 
     extern __shared__ float2 s_dyn[];
     const int half = n >> 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    float2 *X = s_dyn + (size_t)wave * (n + (n >> 5) + 1);
+    // [twiddles n - 1 (+1)] | per wave: X, padded 1 per 32
+    float2 *s_tw = s_dyn;
+    float2 *X = s_dyn + n + (size_t)wave * (n + (n >> 5) + 1);
+    for (int i = threadIdx.x; i < n - 1; i += blockDim.x) s_tw[i] = tw[i];
+    __syncthreads();
     auto P = [](int idx) { return idx + (idx >> 5); };
-    const float denom = (float)n;
+    const float inv = 1.0f / (float)n;  // n is a power of two: x * inv is x / n, correctly rounded either way (L/fft.cpp:201-209 divides)
     for (size_t f = (size_t)blockIdx.x * nwaves + wave; f < nframes; f += (size_t)gridDim.x * nwaves) {
-        const float *m = mags + f * (size_t)half, *ph = phases + f * (size_t)half;
-        for (int i = lane; i < n; i += 64) {
-            float2 v = {0.0f, 0.0f};  // negative frequencies zeroed, L/fft.cpp:601-603
-            if (INPUT != 2 && i < half) {
-                const float mg = m[i], p = ph[i];
-                if constexpr (INPUT == 0) {
-                    v.x = mg * cosf(p);  // :597-598
-                    v.y = mg * sinf(p);
-                } else {
-                    v.x = mg;
-                    v.y = p;
-                }
-            }
-            const int j = (int)(__brev((unsigned)i) >> (32 - numBits));
-            X[P(j)] = v;
-        }
-        wave_lds_sync();
-        for (int s = 0; s < numBits; s++) {
-            const int h = 1 << s;
-            for (int b = lane; b < half; b += 64) {
-                const int nn = b & (h - 1);
-                const int j = ((b >> s) << (s + 1)) | nn;
-                const int k = j + h;
-                float2 xj = X[P(j)], xk = X[P(k)];
-                bfly(xj, xk, tw[h - 1 + nn]);
-                X[P(j)] = xj;
-                X[P(k)] = xk;
-            }
-            wave_lds_sync();
-        }
+        ifft_frame<INPUT>(mags + f * (size_t)half, phases + f * (size_t)half, n, numBits, s_tw, X, lane);
         float *o = ifft_out + f * (size_t)n;
         for (int i = lane; i < n; i += 64) {
-            const float r = X[P(i)].x / denom;  // L/fft.cpp:201-209
+            const float r = X[P(i)].x * inv;  // L/fft.cpp:201-209
             o[i] = 0.0f + r * window[i];        // :608-610 into the zero-filled ifftOut
         }
+        wave_lds_sync();
+    }
+}
+
+// K6s: the same transform with maxiIFFT::process's hop buffer (L/maxiFFT.cpp:176-183) carried in LDS, so `ifftOut` never goes to
+// HBM (4 KB written and 4 KB read back per 1024-point frame otherwise).  A wavefront owns `chunk` consecutive frames and streams
+// through them as the reference does: shift the buffer left by hop, zero the tail, add the frame (two LDS images, so the shift is
+// a read of one and a write of the other), hand out the first hop samples.  The buffer a chunk starts from is that of the frame
+// before it, which only the R = ceil(n / hop) - 1 frames before THAT one still reach: the wavefront first runs those R frames from
+// an empty buffer without output (everything older has been shifted out, so the additions that remain are the reference's, in
+// its order); chunk 0 starts from the carried buffer instead.  The wavefront of the last frame leaves the buffer behind.
+template <int INPUT>
+__global__ void ifft_stream_kernel(const float *__restrict__ mags, const float *__restrict__ phases, size_t nframes, int n,
+                                   int numBits, int hop, int chunk, const float *__restrict__ window,
+                                   const float2 *__restrict__ tw, const float *__restrict__ buf_in, float *__restrict__ out,
+                                   float *__restrict__ buf_out, float *__restrict__ ifft_out) {
+    extern __shared__ float2 s_dyn[];
+    const int half = n >> 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    // [twiddles n] | per wave: X (n + n/32 + 1 float2) | two hop-buffer images (2 n floats = n float2)
+    const size_t per_wave = (size_t)(n + (n >> 5) + 1) + (size_t)n;
+    float2 *s_tw = s_dyn;
+    float2 *X = s_dyn + n + (size_t)wave * per_wave;
+    float *B0 = reinterpret_cast<float *>(X + (n + (n >> 5) + 1)), *B1 = B0 + n;
+    for (int i = threadIdx.x; i < n - 1; i += blockDim.x) s_tw[i] = tw[i];
+    __syncthreads();
+    auto P = [](int idx) { return idx + (idx >> 5); };
+    const float inv = 1.0f / (float)n;
+    const long long R = (long long)((n + hop - 1) / hop) - 1;
+    const size_t nchunks = (nframes + (size_t)chunk - 1) / (size_t)chunk;
+    for (size_t c = (size_t)blockIdx.x * nwaves + wave; c < nchunks; c += (size_t)gridDim.x * nwaves) {
+        const long long a = (long long)c * chunk;
+        const long long b = a + chunk < (long long)nframes ? a + chunk : (long long)nframes;
+        long long f0 = a - R;
+        float *cur = B0, *nxt = B1;
+        if (f0 <= 0) {  // (chunk >= R: only chunk 0) the carried buffer, or a fresh object's zeros
+            f0 = 0;
+            for (int i = lane; i < n; i += 64) cur[i] = buf_in ? buf_in[i] : 0.0f;
+        } else {
+            for (int i = lane; i < n; i += 64) cur[i] = 0.0f;
+        }
+        wave_lds_sync();
+        for (long long f = f0; f < b; f++) {
+            ifft_frame<INPUT>(mags + (size_t)f * (size_t)half, phases + (size_t)f * (size_t)half, n, numBits, s_tw, X, lane);
+            const bool live = f >= a;  // wave-uniform: the R frames before the chunk only rebuild the buffer
+            for (int i = lane; i < n; i += 64) {
+                const float r = X[P(i)].x * inv;          // L/fft.cpp:201-209
+                const float io = 0.0f + r * window[i];    // :608-610 into the zero-filled ifftOut
+                const float v = (i + hop < n ? cur[i + hop] : 0.0f) + io;  // L/maxiFFT.cpp:176-183
+                nxt[i] = v;
+                if (live) {
+                    if (i < hop) out[(size_t)f * (size_t)hop + (size_t)i] = v;
+                    if (ifft_out) ifft_out[(size_t)f * (size_t)n + (size_t)i] = io;
+                }
+            }
+            wave_lds_sync();
+            float *t = cur;
+            cur = nxt;
+            nxt = t;
+        }
+        if (b == (long long)nframes && buf_out)
+            for (int i = lane; i < n; i += 64) buf_out[i] = cur[i];
         wave_lds_sync();
     }
 }
@@ -640,13 +764,48 @@ static int ifft_batch_impl(int input, const mxg_ifft_plan *p, const float *d_a, 
     if (nframes == 0) return MXG_OK;
     hipStream_t st = resolve_stream(stream);
     const int n = p->fftSize;
+    // the streaming form: transform + hop buffer in one kernel (K6s) whenever a frame overlaps at most 15 later ones
+    const long long R = (long long)((n + p->hopSize - 1) / p->hopSize) - 1;
+    // Measured at 1024 points, 262 144 frames: hop 1024 1.75 ms streaming vs 1.88 ms as two kernels, hop 512 1.66 vs 1.61, hop 256
+    // 1.68 vs 1.49 (the streaming wavefront carries 8 KB more LDS, re-runs R frames per chunk and adds an LDS pass per frame): it is
+    // the default where a frame overlaps at most one later one; knob ifft_stream = 2 forces it wherever it fits.
+    const int want = tune_get("ifft_stream");
+    if (p->hopSize <= n && R <= 15 && n <= 4096 && (want == 2 || (want == 1 && R <= 1))) {  // (8192 points: X + two buffer images exceed the LDS)
+        const float *buf_in = nullptr;
+        if (d_buffer) {  // chunk 0 reads the carried buffer while the last chunk's wavefront writes the new one: stage the old one
+            float *tmp = nullptr;
+            if (int s = scratch_get(SCR_IFFT_BUF, st, sizeof(float) * n, (void **)&tmp)) return s;
+            MXG_HIP(hipMemcpyAsync(tmp, d_buffer, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+            buf_in = tmp;
+        }
+        long long chunk = 64;
+        if (nframes < (size_t)64 * 2048) {
+            chunk = (long long)((nframes + 2047) / 2048);
+            const long long lo = 4 * R > 8 ? 4 * R : 8;
+            chunk = chunk < lo ? lo : chunk;
+        }
+        const int waves = n <= 1024 ? 4 : (n <= 2048 ? 2 : 1);
+        const size_t per_wave = sizeof(float2) * ((size_t)(n + (n >> 5) + 1) + (size_t)n);
+        const size_t lds = per_wave * waves + sizeof(float2) * (size_t)n;
+        typedef void (*skern_t)(const float *, const float *, size_t, int, int, int, int, const float *, const float2 *, const float *,
+                                float *, float *, float *);
+        skern_t k = input == 0 ? ifft_stream_kernel<0> : (input == 1 ? ifft_stream_kernel<1> : ifft_stream_kernel<2>);
+        if (lds > 64 * 1024) MXG_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const size_t nchunks = (nframes + (size_t)chunk - 1) / (size_t)chunk;
+        size_t blocks = (nchunks + waves - 1) / waves;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        KernelTimer kt("ifft_stream_kernel", st);
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * waves), lds, st, d_a, d_b, nframes, n, p->numBits, p->hopSize, (int)chunk,
+                           p->d_window, p->d_tw, buf_in, d_signal, d_buffer, d_ifft_out);
+        return check_hip(hipGetLastError(), "ifft_stream_kernel launch");
+    }
     float *io = d_ifft_out;
     if (!io) {  // grow-only scratch for the per-frame transforms
         if (int s = scratch_get(SCR_IFFT_OUT, st, nframes * (size_t)n * sizeof(float), (void **)&io)) return s;
     }
     const size_t per_wave = sizeof(float2) * (size_t)(n + (n >> 5) + 1);
     int waves = n <= 1024 ? 4 : (n <= 2048 ? 2 : 1);
-    const size_t lds = per_wave * waves;
+    const size_t lds = per_wave * waves + sizeof(float2) * (size_t)n;  // + the stage twiddles
     typedef void (*kern_t)(const float *, const float *, size_t, int, int, const float *, const float2 *, float *);
     kern_t k = input == 0 ? ifft_generic_kernel<0> : (input == 1 ? ifft_generic_kernel<1> : ifft_generic_kernel<2>);
     if (lds > 64 * 1024) MXG_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

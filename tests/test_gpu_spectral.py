@@ -353,6 +353,34 @@ def test_ifft_zero_phase_bit_exact(mx, port, fs, hop, win):
     assert np.array_equal(f.buffer.numpy().view(np.uint32), buf2.view(np.uint32)), "buffer state"
 
 
+@pytest.mark.parametrize("stream", [2, 1, 0])
+@pytest.mark.parametrize("fs,hop,win,nf", [(1024, 256, 0, 700), (1024, 128, 1024, 300), (1024, 1024, 0, 150), (256, 96, 200, 500),
+                                           (2048, 512, 0, 130), (8192, 2048, 0, 9)])
+def test_ifft_many_frames_both_forms_bit_exact(mx, port, fs, hop, win, nf, stream):
+    """Zero phases again (everything exact), but enough frames that the streaming kernel cuts them into chunks whose hop buffer is
+    rebuilt from the frames before them -- against the reference's one sequential stream, in two calls with the buffer carried;
+    and the two-kernel form (knob ifft_stream 0; 8192 points always take it; 1 = the default mix) on the same data."""
+    rng = np.random.default_rng(fs + hop + nf)
+    m = np.abs(rng.normal(0, 3, (nf, fs // 2))).astype(np.float32)
+    ph = np.zeros_like(m)
+    cut = nf // 3
+    prev = mx.lib().mxg_tune(b"ifft_stream", stream)
+    try:
+        f = mx.maxiIFFT()
+        f.setup(fs, hop, win)
+        o1 = f.process_frames(m[:cut], ph[:cut]).numpy()
+        o2 = f.process_frames(m[cut:], ph[cut:], keep_ifft=True).numpy()
+        io2 = f.ifftOut.numpy()
+    finally:
+        mx.lib().mxg_tune(b"ifft_stream", prev)
+    e1, _, buf = port.ifft_stream(m[:cut], ph[:cut], fs, hop, win)
+    e2, eio2, buf2 = port.ifft_stream(m[cut:], ph[cut:], fs, hop, win, buffer=buf)
+    assert np.array_equal(o1.view(np.uint32), e1.view(np.uint32)), "signal, first call"
+    assert np.array_equal(o2.view(np.uint32), e2.view(np.uint32)), "signal, carried buffer"
+    assert np.array_equal(io2.view(np.uint32), eio2.view(np.uint32)), "ifftOut"
+    assert np.array_equal(f.buffer.numpy().view(np.uint32), buf2.view(np.uint32)), "buffer state"
+
+
 @pytest.mark.parametrize("fs,hop,win", IFFT_CASES[:4])
 def test_ifft_random_phase(mx, port, fs, hop, win):
     """Random phases: polToCart uses the float cos/sin of the device (L/fft.cpp:597-598 resolves to cosf/sinf),
