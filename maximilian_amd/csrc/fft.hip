@@ -76,6 +76,66 @@ __device__ __forceinline__ void emit_bin(const FftOut &o, size_t base, int bin, 
     }
 }
 
+// Stages st0 .. numBits-1 of the radix-2 transform of `npts` complex points held in LDS (X, padded 1 per 32), for one wavefront:
+// up to three consecutive stages per LDS pass on eight values in registers -- the same butterflies on the same operands as one
+// stage per pass (a butterfly of stage s pairs values 2^s apart and takes twiddle tw[2^s - 1 + position inside the half-block]).
+__device__ __forceinline__ void lds_stages(float2 *X, const int npts, const int numBits, const float2 *tw, int st, const int lane) {
+    auto P = [](int idx) { return idx + (idx >> 5); };
+    for (; st + 2 < numBits; st += 3) {
+        const int h = 1 << st;
+        for (int q = lane; q < (npts >> 3); q += 64) {
+            const int nn = q & (h - 1);
+            const int j = ((q >> st) << (st + 3)) | nn;
+            float2 x[8];
+#pragma unroll
+            for (int mm = 0; mm < 8; mm++) x[mm] = X[P(j + mm * h)];
+            const float2 w0 = tw[h - 1 + nn];
+#pragma unroll
+            for (int mm = 0; mm < 8; mm += 2) bfly(x[mm], x[mm + 1], w0);
+            const float2 w1a = tw[2 * h - 1 + nn], w1b = tw[2 * h - 1 + nn + h];
+            bfly(x[0], x[2], w1a);
+            bfly(x[1], x[3], w1b);
+            bfly(x[4], x[6], w1a);
+            bfly(x[5], x[7], w1b);
+#pragma unroll
+            for (int mm = 0; mm < 4; mm++) bfly(x[mm], x[mm + 4], tw[4 * h - 1 + nn + mm * h]);
+#pragma unroll
+            for (int mm = 0; mm < 8; mm++) X[P(j + mm * h)] = x[mm];
+        }
+        wave_lds_sync();
+    }
+    for (; st + 1 < numBits; st += 2) {
+        const int h = 1 << st;
+        for (int q = lane; q < (npts >> 2); q += 64) {
+            const int nn = q & (h - 1);
+            const int j = ((q >> st) << (st + 2)) | nn;
+            float2 x0 = X[P(j)], x1 = X[P(j + h)], x2 = X[P(j + 2 * h)], x3 = X[P(j + 3 * h)];
+            const float2 w = tw[h - 1 + nn];
+            bfly(x0, x1, w);
+            bfly(x2, x3, w);
+            bfly(x0, x2, tw[2 * h - 1 + nn]);
+            bfly(x1, x3, tw[2 * h - 1 + nn + h]);
+            X[P(j)] = x0;
+            X[P(j + h)] = x1;
+            X[P(j + 2 * h)] = x2;
+            X[P(j + 3 * h)] = x3;
+        }
+        wave_lds_sync();
+    }
+    for (; st < numBits; st++) {
+        const int h = 1 << st;
+        for (int b = lane; b < (npts >> 1); b += 64) {
+            const int nn = b & (h - 1);
+            const int j = ((b >> st) << (st + 1)) | nn;
+            float2 xj = X[P(j)], xk = X[P(j + h)];
+            bfly(xj, xk, tw[h - 1 + nn]);
+            X[P(j)] = xj;
+            X[P(j + h)] = xk;
+        }
+        wave_lds_sync();
+    }
+}
+
 // ---- K6b: generic size -----------------------------------------------------------------------
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void fft_generic_kernel(
@@ -85,7 +145,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fft_generic_kernel(
     extern __shared__ float2 s_dyn[];
     const int half = fftSize >> 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    float2 *X = s_dyn + (size_t)wave * (half + (half >> 5) + 1);
+    // [stage twiddles half - 1 (+1)] | per wave: X
+    float2 *s_tw = s_dyn;
+    float2 *X = s_dyn + half + (size_t)wave * (half + (half >> 5) + 1);
+    for (int i = threadIdx.x; i < half - 1; i += blockDim.x) s_tw[i] = tw[i];
+    __syncthreads();
     auto P = [](int idx) { return idx + (idx >> 5); };  // one pad slot per 32: breaks pow-2 strides
     for (size_t f = (size_t)blockIdx.x * nwaves + wave; f < nframes; f += (size_t)gridDim.x * nwaves) {
         const float *x = signal + f * frame_stride;
@@ -97,19 +161,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fft_generic_kernel(
             X[P(j)] = v;
         }
         wave_lds_sync();
-        for (int s = 0; s < numBits; s++) {
-            const int h = 1 << s;
-            for (int b = lane; b < (half >> 1); b += 64) {
-                int n = b & (h - 1);
-                int j = ((b >> s) << (s + 1)) | n;
-                int k = j + h;
-                float2 xj = X[P(j)], xk = X[P(k)];
-                bfly(xj, xk, tw[h - 1 + n]);
-                X[P(j)] = xj;
-                X[P(k)] = xk;
-            }
-            wave_lds_sync();
-        }
+        lds_stages(X, half, numBits, s_tw, 0, lane);
         const size_t base = f * (size_t)half;
         for (int i = 1 + lane; i < (half >> 1); i += 64) {
             float2 a = X[P(i)], b = X[P(half - i)];
@@ -164,63 +216,7 @@ __device__ __forceinline__ void ifft_frame(const float *__restrict__ m, const fl
         X[P(j + 1)] = v;
     }
     wave_lds_sync();
-    // stages in groups: the values {j + m h} go through up to three consecutive stages in registers -- the same butterflies on
-    // the same operands, a third of the LDS passes (1024 points: stages 1-3, 4-6, 7-9)
-    int st = 1;
-    for (; st + 2 < numBits; st += 3) {
-        const int h = 1 << st;
-        for (int q = lane; q < (n >> 3); q += 64) {
-            const int nn = q & (h - 1);
-            const int j = ((q >> st) << (st + 3)) | nn;
-            float2 x[8];
-#pragma unroll
-            for (int mm = 0; mm < 8; mm++) x[mm] = X[P(j + mm * h)];
-            const float2 w0 = s_tw[h - 1 + nn];
-#pragma unroll
-            for (int mm = 0; mm < 8; mm += 2) bfly(x[mm], x[mm + 1], w0);
-            const float2 w1a = s_tw[2 * h - 1 + nn], w1b = s_tw[2 * h - 1 + nn + h];
-            bfly(x[0], x[2], w1a);
-            bfly(x[1], x[3], w1b);
-            bfly(x[4], x[6], w1a);
-            bfly(x[5], x[7], w1b);
-#pragma unroll
-            for (int mm = 0; mm < 4; mm++) bfly(x[mm], x[mm + 4], s_tw[4 * h - 1 + nn + mm * h]);
-#pragma unroll
-            for (int mm = 0; mm < 8; mm++) X[P(j + mm * h)] = x[mm];
-        }
-        wave_lds_sync();
-    }
-    for (; st + 1 < numBits; st += 2) {
-        const int h = 1 << st;
-        for (int q = lane; q < (n >> 2); q += 64) {
-            const int nn = q & (h - 1);
-            const int j = ((q >> st) << (st + 2)) | nn;
-            float2 x0 = X[P(j)], x1 = X[P(j + h)], x2 = X[P(j + 2 * h)], x3 = X[P(j + 3 * h)];
-            const float2 w = s_tw[h - 1 + nn];
-            bfly(x0, x1, w);
-            bfly(x2, x3, w);
-            bfly(x0, x2, s_tw[2 * h - 1 + nn]);
-            bfly(x1, x3, s_tw[2 * h - 1 + nn + h]);
-            X[P(j)] = x0;
-            X[P(j + h)] = x1;
-            X[P(j + 2 * h)] = x2;
-            X[P(j + 3 * h)] = x3;
-        }
-        wave_lds_sync();
-    }
-    for (; st < numBits; st++) {
-        const int h = 1 << st;
-        for (int b = lane; b < half; b += 64) {
-            const int nn = b & (h - 1);
-            const int j = ((b >> st) << (st + 1)) | nn;
-            const int k = j + h;
-            float2 xj = X[P(j)], xk = X[P(k)];
-            bfly(xj, xk, s_tw[h - 1 + nn]);
-            X[P(j)] = xj;
-            X[P(k)] = xk;
-        }
-        wave_lds_sync();
-    }
+    lds_stages(X, n, numBits, s_tw, 1, lane);
 }
 
 template <int INPUT>
@@ -664,10 +660,11 @@ int mxg_fft_batch(const mxg_fft_plan *p, const float *d_signal, size_t frame_str
 #undef MXG_FFT_LAUNCH2
 #undef MXG_FFT_LAUNCH
     } else {
-        // one LDS frame per wave: 4 waves up to 2048 points, 2 at 4096, 1 at 8192 keeps a workgroup under the
-        // 64 KB a launch gets without raising hipFuncAttributeMaxDynamicSharedMemorySize
+        // one LDS frame per wave: 4 waves up to 2048 points, 2 at 4096, 1 at 8192
         const int waves = p->fftSize <= 2048 ? kWavesPerBlock : (p->fftSize <= 4096 ? 2 : 1);
-        const size_t lds = sizeof(float2) * waves * (p->half + (p->half >> 5) + 1);
+        const size_t lds = sizeof(float2) * (waves * (size_t)(p->half + (p->half >> 5) + 1) + (size_t)p->half);  // X per wave + stage twiddles
+        if (lds > 64 * 1024)  // (8192 points: 33.8 KB + 32 KB)
+            MXG_HIP(hipFuncSetAttribute((const void *)fft_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         blocks = (nframes + waves - 1) / waves;
         if (blocks > cap * (kWavesPerBlock / waves)) blocks = cap * (kWavesPerBlock / waves);
         hipLaunchKernelGGL(fft_generic_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, st,
