@@ -13,8 +13,11 @@ e0, e1 = L.mxg_event_create(), L.mxg_event_create(); ms = ctypes.c_float()
 
 
 def timed(fn, reps):
-    for _ in range(max(20, reps // 5)): fn()
-    L.mxg_stream_sync(None)
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.2:       # clock ramp: an idle MI355X needs continuous work to reach its sustained clocks
+        for _ in range(10): fn()
+        L.mxg_stream_sync(None)
     L.mxg_event_record(e0, None)
     for _ in range(reps): fn()
     L.mxg_event_record(e1, None); L.mxg_event_elapsed_ms(e0, e1, ctypes.byref(ms)); return ms.value / reps * 1e3
