@@ -124,8 +124,8 @@ int mxg_prof_read(int index, const char **h_label, double *h_total_ms, size_t *h
 int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
 
 /* ---- tuning knobs (performance only; results are identical for every setting) ---------- */
-/* key: "osc_vpl" (voices per lane 1|2), "osc_block" (64..1024), "osc_nt" (0|1 non-temporal stores),
- * "voice_block", "voice_nt", "mix_rows" (sample rows per workgroup of the mixdown, 1|2), "fft_generic",
+/* key: "osc_vpl" (voices per lane 1|2), "osc_block" (64..1024), "osc_nt" (non-temporal stores: 0 never, 1 always, 2 by the size of the output block),
+ * "voice_block", "voice_nt" (as osc_nt), "mix_rows" (sample rows per workgroup of the mixdown, 1|2), "fft_generic",
  * "mfcc_tiled" (LDS-staged spectra 0|1), "grain_chunked" (time-sharded granular render 0|1), "grain_lanes_k",
  * "grain_unit" (coalesced unit-increment render 0|1), "grain_line" (tile render for arbitrary increments 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_slices" (time slices of a unit-path
  * maxiTimeStretch call whose scheduling and rendering overlap, 1..16), "osc_mix_var" (layout of K1m's lane-exchange butterfly, 0..3),

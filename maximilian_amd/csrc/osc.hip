@@ -341,7 +341,12 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     int vpl = tune_get("osc_vpl");
     if (fps || (V & 1) || (((uintptr_t)d_out) & 15)) vpl = 1;
     int block = tune_get("osc_block");
-    bool nt = tune_get("osc_nt") != 0;
+    // non-temporal stores: a loss while the block fits the 256 MB Infinity Cache next to whatever reads it (65 536 voices: 42 -> 47 us)
+    // and a gain once it is two to four times that (131 072 voices x 512: 113 -> 99 us; 262 144: 217 -> 209; a 4 GB block: 815 -> 850),
+    // tools/sweep_osc_nt.py.  Knob 2 (default) = by the size of the block.
+    const int nt_knob = tune_get("osc_nt");
+    const size_t out_bytes = V * N * sizeof(double);
+    bool nt = nt_knob == 1 || (nt_knob == 2 && out_bytes > ((size_t)300 << 20) && out_bytes <= ((size_t)1200 << 20));
     osc_fn fn = pick_wf(waveform, fps != 0, vpl, nt);
     size_t lanes = (V + vpl - 1) / vpl;
     // time parts: only where the output dominates the recurrence (sinewave, coswave, sinebuf4) and the bank is too small to give

@@ -28,8 +28,8 @@ struct Tune {
     int lo, hi;
 };
 Tune g_tune[] = {
-    {"osc_vpl", 1, 1, 2},       {"osc_block", 256, 64, 1024},  {"osc_nt", 0, 0, 1},
-    {"voice_vpl", 1, 1, 2},     {"voice_block", 256, 64, 1024}, {"voice_nt", 0, 0, 1},
+    {"osc_vpl", 1, 1, 2},       {"osc_block", 256, 64, 1024},  {"osc_nt", 2, 0, 2},
+    {"voice_vpl", 1, 1, 2},     {"voice_block", 256, 64, 1024}, {"voice_nt", 2, 0, 2},
     {"osc_split", 0, 0, 8},  // K1: time parts per voice group (0 = automatic: 4 for sinewave / coswave on small banks, else 1)
     {"osc_mix_var", 0, 0, 3},  // K1m A/B (sinebuf): 0 swap butterfly, window 512; 1 same, window 128; 2 DPP butterfly 128; 3 DPP 512
     {"ifft_stream", 1, 0, 2},  // maxiIFFT: transform + hop buffer in one kernel (0: never; 1: where hop >= fftSize / 2; 2: wherever it fits)

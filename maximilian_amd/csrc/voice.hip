@@ -584,7 +584,9 @@ int mxg_voice_render(int mode, size_t V, size_t N, const double *d_freq, const d
     if (V == 0 || N == 0) return MXG_OK;
     int block = tune_get("voice_block");
     if (block > 256) block = 256;  // the bank kernels are compiled for <= 256 lanes per workgroup (512 VGPRs/lane budget)
-    bool nt = tune_get("voice_nt") != 0;
+    const int nt_knob = tune_get("voice_nt");  // 2 (default): by the size of the block, as K1 (osc.hip)
+    const size_t out_bytes = V * N * sizeof(double);
+    bool nt = nt_knob == 1 || (nt_knob == 2 && out_bytes > ((size_t)300 << 20) && out_bytes <= ((size_t)1200 << 20));
     hipStream_t st = resolve_stream(stream);
     double sr = (double)settings().sampleRate;
 #define MXG_VOICE_LAUNCH(M, T, P)                                                               \
