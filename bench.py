@@ -103,16 +103,38 @@ def main():
     ap.add_argument("--mfcc-method", default="sparse", choices=["sparse", "mfma"],
                     help="config4: exact sparse mel walk (default) or the dense fp64 MFMA contraction")
     ap.add_argument("--mix-only", action="store_true", help="config2 fused: do not store the per-voice block (VALU/LDS time of K1m)")
-    ap.add_argument("--out-buffers", type=int, default=1,
-                    help="config2: rotate the per-voice output over this many 268 MB blocks (1 = the block renderer's own "
-                         "steady state: one block buffer reused, largely absorbed by the 256 MB Infinity Cache; 8 = every "
-                         "block's stores have to reach HBM)")
+    ap.add_argument("--out-buffers", type=int, default=0,
+                    help="config2/3: rotate the per-voice output over this many block buffers.  0 (default) = as many as it "
+                         "takes to touch >= 2 GiB before a line is rewritten (8 at 65 536 voices: 8x the 256 MB Infinity "
+                         "Cache, so every block's stores reach HBM); 1 = one block buffer reused (a block renderer's own "
+                         "steady state, partly absorbed by the Infinity Cache: reported as roofline.frac_single_buffer)")
+    ap.add_argument("--voices", type=int, default=0,
+                    help="config2/3: voices per GPU (default 65 536 = BASELINE configs[1]); the default config2 run ALSO measures "
+                         "a 131 072-voice bank (north_star: >= 10^5 voices) and reports it as `north_star_bank`")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="testing only: ranks of a --gpus N run share the visible GPUs (rank r uses device r mod count), the "
+                         "id/barrier traffic goes over gloo and the mix queue reduces locally (no RCCL: two ranks cannot share "
+                         "one device in a communicator); exercises the launch + N-rank harness on a 1-GPU box")
     ap.add_argument("--tune", action="append", default=[], help="KEY=VALUE passed to mxg_tune (A/B experiments)")
     ap.add_argument("--mfma-fullk", action="store_true",
                     help="config4 mfma: contract over all 512 bins instead of the 256 that carry mel weight")
     ap.add_argument("--kernel-events", default="pass", choices=["inline", "pass", "off"],
                     help="per-kernel HIP events inside the timed region (inline), in a separate pass, or not at all")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: become the launcher.  One process per GPU under torch.distributed.run
+        # (the same command line the driver uses for N > 1); rank 0 prints the JSON line.
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
+        env.setdefault("OMP_NUM_THREADS", "1")
+        os.execvpe(cmd[0], cmd, env)
     defaults = {"config2": (2000, 100), "config3": (1280, 128), "config4": (20, 3), "config5": (20, 3)}
     if args.steps is None:
         args.steps = defaults[args.workload][0]
@@ -130,11 +152,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists for the product path)")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus N` by itself, or under "
+                         "torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+    ndev = torch.cuda.device_count()
+    if local >= ndev:
+        if not args.share_gpu:
+            raise SystemExit("bench.py: rank %d needs GPU %d but this node shows %d GPU(s): --gpus %d needs %d GPUs"
+                             % (rank, local, ndev, args.gpus, args.gpus))
+        local = local % ndev
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        if args.share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     L = mx.lib()
     chk = mx._lib.check
@@ -150,9 +183,10 @@ def main():
     stream = tstream.cuda_stream
     assert stream != 0
     # the product's communicator: RCCL through the C-ABI (torch.distributed only carries the 128-byte id)
-    comm = create_comm(dist, rank, world, dev) if world > 1 else None
+    comm = create_comm(dist, rank, world, dev) if (world > 1 and not args.share_gpu) else None
 
-    V, B = VOICES_PER_GPU, BLOCK
+    V, B = (args.voices or VOICES_PER_GPU), BLOCK
+    nbuf = args.out_buffers if args.out_buffers > 0 else max(1, -(-(1 << 31) // (V * B * 8)))
     wf = mx.OSC_WAVEFORMS[args.waveform]
     lo, hi = shard_range(rank, world, V)  # this rank's voice shard of the global bank
     freq_h, pan_h = bank_parameters(lo, hi, V * world)
@@ -164,55 +198,82 @@ def main():
     queue = None
     W = {}
 
-    if args.workload == "config2":
-        freq = torch.from_numpy(freq_h).to(dev)
-        phase = torch.zeros(V, dtype=torch.float64, device=dev)
-        hold = torch.zeros(V, dtype=torch.float64, device=dev)
-        outs = [torch.empty((B, V), dtype=torch.float64, device=dev) for _ in range(max(1, args.out_buffers))]
-        oi = [0]
+    class OscBank:
+        """One rank's maxiOsc bank of `Vb` voices with its block buffers; step() renders one block (K1, or K1m / K1 + K3 with
+        the mixdown into `q`'s current slot)."""
 
-        class _Rot:  # the block buffer of the current step
-            @staticmethod
-            def data_ptr():
-                return outs[oi[0] % len(outs)].data_ptr()
-        out = _Rot
-        pan = torch.from_numpy(pan_h).to(dev)
+        def __init__(self, Vb, buffers, mix, q, lo_v=0, total=None):
+            fh, ph = bank_parameters(lo_v, lo_v + Vb, total or Vb)
+            self.V, self.freq_h, self.mix, self.q = Vb, fh, mix, q
+            self.freq = torch.from_numpy(fh).to(dev)
+            self.pan = torch.from_numpy(ph).to(dev)
+            self.phase = torch.zeros(Vb, dtype=torch.float64, device=dev)
+            self.hold = torch.zeros(Vb, dtype=torch.float64, device=dev)
+            self.outs = [torch.empty((B, Vb), dtype=torch.float64, device=dev) for _ in range(buffers)]
+            self.i = 0
+            self.mstep = MixdownStep(self.render_mix, q) if mix != "off" else None
+            self.algo = (8.0 + 24.0 / B) * Vb * B  # 8 B store + (freq, phase rd, phase wr)/block = 8.047 B/sample
+            if mix == "fused":
+                self.algo += 16.0 * Vb + 16.0 * B * (Vb / 256.0)  # + gains read, per-workgroup mix partials written
+            self.dominant = "osc_mix_kernel" if mix == "fused" else "osc_kernel"
+
+        def out_ptr(self):
+            return self.outs[self.i % len(self.outs)].data_ptr()
+
+        def render_mix(self, slot):
+            if self.mix == "fused":  # K1m: render + store + mix partials in one pass
+                chk(L.mxg_osc_render_mix(wf, self.V, B, self.freq.data_ptr(), None, None, self.phase.data_ptr(),
+                                         self.hold.data_ptr(), None if args.mix_only else self.out_ptr(), self.pan.data_ptr(),
+                                         slot, stream), "mxg_osc_render_mix")
+            else:                    # K1 then K3 re-reading the block
+                chk(L.mxg_osc_render(wf, self.V, B, self.freq.data_ptr(), 0, None, None, self.phase.data_ptr(),
+                                     self.hold.data_ptr(), self.out_ptr(), stream), "mxg_osc_render")
+                chk(L.mxg_mix_stereo(self.V, B, self.out_ptr(), self.pan.data_ptr(), slot, stream), "mxg_mix_stereo")
+
+        def step(self):
+            if self.mstep is None:
+                chk(L.mxg_osc_render(wf, self.V, B, self.freq.data_ptr(), 0, None, None, self.phase.data_ptr(),
+                                     self.hold.data_ptr(), self.out_ptr(), stream), "mxg_osc_render")
+            else:
+                self.mstep()
+            self.i += 1
+
+        def with_queue(self, q):
+            """The same bank and buffers, mixing into another queue (the like-for-like pass without the reduce)."""
+            o = OscBank.__new__(OscBank)
+            o.__dict__.update(self.__dict__)
+            o.q, o.mstep = q, MixdownStep(o.render_mix, q)
+            return o
+
+    def time_steps(fn, n, warm=20):
+        """ms per call of fn over n back-to-back calls (HIP events on the launch stream)."""
+        for _ in range(warm):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+
+    local_queue = None  # the same mix queue without a communicator (device copies): the step with the reduce taken out
+    if args.workload == "config2":
         if mixdown != "off":
             queue = RcclMixQueue(comm, B * 2, args.mix_depth, 0, stream)
-
-        def render_mix(slot):
-            if mixdown == "fused":  # K1m: render + store + mix partials in one pass
-                chk(L.mxg_osc_render_mix(wf, V, B, freq.data_ptr(), None, None, phase.data_ptr(), hold.data_ptr(),
-                                         None if args.mix_only else out.data_ptr(), pan.data_ptr(), slot, stream), "mxg_osc_render_mix")
-            else:                   # K1 then K3 re-reading the block
-                chk(L.mxg_osc_render(wf, V, B, freq.data_ptr(), 0, None, None, phase.data_ptr(), hold.data_ptr(),
-                                     out.data_ptr(), stream), "mxg_osc_render")
-                chk(L.mxg_mix_stereo(V, B, out.data_ptr(), pan.data_ptr(), slot, stream), "mxg_mix_stereo")
-
-        if mixdown == "off":
-            def step():
-                chk(L.mxg_osc_render(wf, V, B, freq.data_ptr(), 0, None, None, phase.data_ptr(), hold.data_ptr(),
-                                     out.data_ptr(), stream), "mxg_osc_render")
-                oi[0] += 1
-        else:
-            _mstep = MixdownStep(render_mix, queue)
-
-            def step():
-                _mstep()
-                oi[0] += 1
-        algo = (8.0 + 24.0 / B) * V * B  # 8 B store + (freq, phase rd, phase wr)/block = 8.047 B/sample
-        if mixdown == "fused":
-            algo += 16.0 * V + 16.0 * B * (V / 256.0)  # + gains read, per-workgroup mix partials written
-        dom = "osc_mix_kernel" if mixdown == "fused" else "osc_kernel"
+        bank = OscBank(V, nbuf, mixdown, queue, lo, V * world)
+        if queue is not None and world > 1:
+            local_queue = RcclMixQueue(None, B * 2, args.mix_depth, 0, stream)
 
         def cpu():
-            return _baseline(lambda o, n, th: o.time_osc(wf, freq_h, n, threads=th), lambda n: V * n, (256, 1 << 18),
+            return _baseline(lambda o, n, th: o.time_osc(wf, bank.freq_h, n, threads=th), lambda n: V * n, (256, 1 << 18),
                              "samples per voice", "%d voices maxiOsc::%s, voice-inner loop" % (V, args.waveform))
-        W = dict(step=step, samples=V * B, dominant=dom, algo_bytes=algo, dtype="f64", cpu=cpu,
-                 workload="configs[1]: 65536-voice maxiOsc::%s wavetable bank per GPU, block=512, fp64 out[n][v] stored%s%s"
-                          % (args.waveform, {"fused": " + fused maxiMix::stereo mixdown", "separate": " + K3 mixdown",
-                                             "off": ""}[mixdown],
-                             "" if args.out_buffers <= 1 else ", output rotated over %d block buffers" % args.out_buffers))
+        W = dict(step=bank.step, samples=V * B, dominant=bank.dominant, algo_bytes=bank.algo, dtype="f64", cpu=cpu,
+                 local_step=bank.with_queue(local_queue).step if local_queue is not None else None,
+                 workload="configs[1]: %d-voice maxiOsc::%s wavetable bank per GPU, block=512, fp64 out[n][v] stored%s, output "
+                          "rotated over %d block buffer(s) = %.2f GB touched before a line is rewritten"
+                          % (V, args.waveform, {"fused": " + fused maxiMix::stereo mixdown", "separate": " + K3 mixdown",
+                                                "off": ""}[mixdown], nbuf, nbuf * V * B * 8 / 1e9))
     elif args.workload == "config3":
         K = 128
         mode = args.voice_mode
@@ -220,7 +281,7 @@ def main():
         vb.env.setAttack(10); vb.env.setDecay(100); vb.env.setSustain(0.5); vb.env.setRelease(500)
         f3 = np.minimum(freq_h, 5000.0)
         cu3, rs3 = (200 + 4 * f3) if mode == 0 else np.full(V, 10000.0), 1.0 + (np.arange(lo, hi) % 16)
-        out3 = mx.DeviceBuffer((B, V), zero=False)
+        outs3 = [mx.DeviceBuffer((B, V), zero=False) for _ in range(nbuf)]
         vb.render(mode, f3, cu3, rs3, np.zeros(1, np.int32), 1, out=mx.DeviceBuffer((1, V)))
         vf, vcu, vrs, vcoef, _ = vb._keep
         vpar, vhold = vb.env._params()
@@ -229,24 +290,30 @@ def main():
         blk = [0]
         if mixdown != "off":
             queue = RcclMixQueue(comm, B * 2, args.mix_depth, 0, stream)
+            if world > 1:
+                local_queue = RcclMixQueue(None, B * 2, args.mix_depth, 0, stream)
 
         def voice_block():
+            o3 = outs3[blk[0] % nbuf]
             chk(L.mxg_voice_render(mode, V, B, vf.ptr, vcu.ptr, vrs.ptr, vcoef.ptr if vcoef is not None else None,
                                    gate.ptr + 4 * (blk[0] % K) * B, 0, vpar.ptr, vhold.ptr, vb.osc_state.ptr, vb.flt_state.ptr,
-                                   vb.env.dstate.ptr, vb.env.istate.ptr, out3.ptr, stream), "mxg_voice_render")
+                                   vb.env.dstate.ptr, vb.env.istate.ptr, o3.ptr, stream), "mxg_voice_render")
             blk[0] += 1
+            return o3
 
         def render_mix3(slot):
-            voice_block()
-            chk(L.mxg_mix_stereo(V, B, out3.ptr, pan3.ptr, slot, stream), "mxg_mix_stereo")
+            o3 = voice_block()
+            chk(L.mxg_mix_stereo(V, B, o3.ptr, pan3.ptr, slot, stream), "mxg_mix_stereo")
         step = voice_block if mixdown == "off" else MixdownStep(render_mix3, queue)
 
         def cpu():
             return _baseline(lambda o, n, th: o.time_voice(mode, f3, cu3, rs3, n, threads=th), lambda n: V * n, (32, 1 << 16),
                              "samples per voice", "%d voices saw->lores->adsr (mode %d), voice-inner loop of 15.polysynth" % (V, mode))
         W = dict(step=step, samples=V * B, dominant="voice_kernel", algo_bytes=(8.0 + 176.0 / B) * V * B, dtype="f64", cpu=cpu,
+                 local_step=MixdownStep(render_mix3, local_queue) if local_queue is not None else None,
                  workload="configs[2]: fused subtractive voice maxiOsc::saw -> maxiFilter::lores -> maxiEnv::adsr (mode %d), %d voices "
-                          "per GPU, block=512, gate(n) = (n mod 44100) < 22050 cycled over 128 blocks" % (mode, V))
+                          "per GPU, block=512, gate(n) = (n mod 44100) < 22050 cycled over 128 blocks, output rotated over %d block "
+                          "buffer(s)" % (mode, V, nbuf))
     elif args.workload == "config4":
         NF = 1 << 20
         g = torch.Generator(device=dev); g.manual_seed(0x4D415849 + rank)
@@ -308,6 +375,8 @@ def main():
         plan5 = gb._plan(0.05)
         if mixdown != "off":
             queue = RcclMixQueue(comm, T * 2, 1, 0, stream)  # one [T][2] = 1.13 MB reduce per render
+            if world > 1:
+                local_queue = RcclMixQueue(None, T * 2, 1, 0, stream)
 
         def grains():
             chk(L.mxg_granular_render(plan5, 0, S, T, sb5.d_samples, Ls, 4, sp5.ptr, None, None, None, 0,
@@ -328,6 +397,7 @@ def main():
                              (256, 8 * 70560), "samples per stream", "%d maxiTimeStretch<hann> streams, play(speed,0.05,4), stream-inner "
                              "loop, 4 grain-samples per stream-sample" % Sc)
         W = dict(step=step, samples=S * T * 4, dominant="granular_unit_kernel", algo_bytes=(8.0 * 4 + 8.0) * S * T, dtype="f64", cpu=cpu,
+                 local_step=MixdownStep(render_mix5, local_queue) if local_queue is not None else None,
                  workload="configs[4]: %d maxiTimeStretch<hann> streams per GPU x %d samples per step, grainLength 0.05, overlaps 4 "
                           "(4 live grains per stream-sample counted)%s" % (S, T, "" if mixdown == "off" else
                                                                           ", maxiMix::stereo to [T][2] + one RCCL reduce per render"))
@@ -395,15 +465,72 @@ def main():
         kernels = read_kernels(psteps)
     event_overhead = kernels.pop("_event_pair_overhead_ms", None)
     dom = W["dominant"]
-    dom_ms = kernels[dom]["ms"] if dom in kernels else step_ms_events
+    dom_ms_events = kernels[dom]["ms"] if dom in kernels else None
+    dom_ms = dom_ms_events if dom_ms_events is not None else step_ms_events
     # an event pair around every launch adds ~2 us of marker overhead to a ~40 us kernel; the launches of one step
     # cannot take longer than the step itself (timed region, events off), so that bound caps the per-launch figure
+    # (both raw figures are printed: roofline.kernel_ms_events / kernel_ms_step_bound)
+    dom_ms_step = step_ms_events / max(kernels[dom]["launches_per_step"], 1.0) if dom in kernels else step_ms_events
     if dom in kernels:
-        dom_ms = min(dom_ms, step_ms_events / max(kernels[dom]["launches_per_step"], 1.0))
+        dom_ms = min(dom_ms, dom_ms_step)
+
+    # ---- N > 1: the SAME step with the reduce taken out (mix queue without a communicator), same run, same buffers ----
+    local_ms = None
+    if W.get("local_step") is not None:
+        fence()
+        ls = W["local_step"]
+        nl = max(10, min(args.steps, 400))
+        local_ms = time_steps(lambda: ls(), nl, warm=min(20, nl))
+        local_queue.flush()
+        torch.cuda.synchronize()
     if world > 1:
-        t = torch.tensor([elapsed, dom_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, dom_ms, local_ms or 0.0], dtype=torch.float64)
+        if not args.share_gpu:
+            t = t.to(dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dom_ms = float(t[0]), float(t[1])
+        elapsed, dom_ms, local_ms = float(t[0]), float(t[1]), (float(t[2]) or None)
+
+    # ---- N = 1, config 2: what the headline is made of -----------------------------------------------------------------
+    extras = {}
+    if world == 1 and args.workload == "config2" and mixdown == "off" and not args.tune:
+        nb = V * B * 8
+        n_x = max(50, min(args.steps, 500))
+        # (a) the same kernel into ONE reused block buffer (partly absorbed by the 256 MB Infinity Cache)
+        one = OscBank(V, 1, "off", None)
+        extras["single_buffer_ms"] = time_steps(one.step, n_x)
+        del one
+        # (b) the measured write ceiling: the best pure store streams of csrc/calib.hip over the SAME rotating buffers
+        ceil_ms = {}
+        for name, (w, fl, pat, blk) in {"flat 16 B plain": (16, 0, 0, 256), "flat 16 B nt": (16, 1, 0, 256),
+                                        "cols 8 B plain (K1's shape)": (8, 0, 1, 256), "cols 8 B nt": (8, 1, 1, 256)}.items():
+            k = [0]
+
+            def fill():
+                chk(L.mxg_calib_fill_ex(bank.outs[k[0] % len(bank.outs)].data_ptr(), B, V * 8, w, fl, pat, blk, 0, 0, stream), "calib")
+                k[0] += 1
+            ceil_ms[name] = time_steps(fill, n_x)
+        best = min(ceil_ms, key=ceil_ms.get)
+        extras["write_ceiling"] = {"GB/s": round(nb / ceil_ms[best] / 1e6, 1), "pattern": best,
+                                   "all_GB/s": {k_: round(nb / v_ / 1e6, 1) for k_, v_ in ceil_ms.items()},
+                                   "note": "pure store streams (csrc/calib.hip) over this run's rotating block buffers"}
+        # (c) the north star's bank size: >= 10^5 voices (131 072), block buffers rotated the same way
+        if not args.voices:
+            V2 = 131072
+            nb2 = V2 * B * 8
+            b2 = OscBank(V2, max(1, -(-(1 << 31) // nb2)), "off", None)
+            ms2 = time_steps(b2.step, n_x)
+            k2 = [0]
+
+            def fill2():
+                chk(L.mxg_calib_fill_ex(b2.outs[k2[0] % len(b2.outs)].data_ptr(), B, V2 * 8, 16, 1, 0, 256, 0, 0, stream), "calib")
+                k2[0] += 1
+            c2 = time_steps(fill2, n_x)
+            extras["north_star_bank"] = {
+                "voices": V2, "block": B, "ms_per_step": round(ms2, 5), "value": round(V2 * B / ms2 / 1e3, 1), "unit": "Msamples/s",
+                "block_buffers": len(b2.outs), "frac_hbm_peak": round(b2.algo / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "write_ceiling_GB/s": round(nb2 / c2 / 1e6, 1), "frac_of_measured_write_ceiling": round(c2 / ms2 * b2.algo / nb2, 4),
+                "realtime_factor_at_44k1": round(B / 44100.0 / (ms2 * 1e-3), 1)}
+            del b2
 
     value = W["samples"] * world * args.steps / elapsed / 1e6
     dom_launches = kernels.get(dom, {}).get("launches_per_step", 1.0)
@@ -424,8 +551,19 @@ def main():
             ach = algo_per_launch / (dom_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this command)"
+                    if traffic is not None else None,
                     "algorithmic_bytes_per_launch": round(algo_per_launch)}
+            if "single_buffer_ms" in extras:
+                roof["frac_single_buffer"] = round(algo_per_launch / (extras["single_buffer_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                roof["single_buffer_note"] = ("the same launches into ONE reused block buffer: the 256 MB Infinity Cache absorbs part of a "
+                                              "268 MB block rewritten every step -- not an HBM rate")
+            if "write_ceiling" in extras:
+                roof["write_ceiling"] = extras["write_ceiling"]
+                roof["frac_of_measured_write_ceiling"] = round(ach / extras["write_ceiling"]["GB/s"], 4)
         roof.update(kernel=dom, kernel_ms=round(dom_ms, 5), launches_per_step=round(dom_launches, 3),
+                    kernel_ms_events=round(dom_ms_events, 5) if dom_ms_events is not None else None,
+                    kernel_ms_step_bound=round(dom_ms_step, 5),
                     timing="HIP events around the kernel on its launch stream (%s), capped by the step time; an empty event pair "
                            "measures %.2f us" % (args.kernel_events, (event_overhead or 0) * 1e3)
                     if dom in kernels else "HIP events around the whole step")
@@ -439,21 +577,35 @@ def main():
                        "mixdown": {"off": "off"}.get(mixdown, "maxiMix::stereo per block; %s"
                                                      % ("one ncclReduce per %d blocks on the mix queue's stream" % queue.depth
                                                         if queue is not None else ""))},
-            "rccl_ranks": world if (queue is not None and world > 1) else (1 if queue is not None else 0),
-            "like_for_like_single_gpu": ("this line includes the maxiMix mixdown + reduce in every step; the default N=1 line does not -- "
-                                         "compare with `bench.py --mixdown fused` (DESIGN.md section 6)") if world > 1 and queue is not None else None,
+            "rccl_ranks": (world if (queue is not None and world > 1 and comm is not None) else
+                           (1 if (queue is not None and comm is not None) else 0)),
             "roofline": roof,
             "kernels": {k: {"ms": round(v["ms"], 5), "launches_per_step": round(v["launches_per_step"], 3)}
                         for k, v in sorted(kernels.items())},
             "step_ms_gpu": round(step_ms_events, 5),
             "realtime_voices_at_44k1": int(value * 1e6 / 44100) if args.workload in ("config2", "config3") else None,
         }
+        if local_ms:
+            # per-GPU efficiency of the exchange: the identical step (render + local mixdown into the queue) with the reduce
+            # replaced by a device copy, timed in this run on every rank (max over ranks), over the step with the reduce
+            step_ms = elapsed / args.steps * 1e3
+            res["per_gpu_efficiency"] = round(min(1.0, local_ms / step_ms), 4)
+            res["step_ms_without_reduce"] = round(local_ms, 5)
+            res["value_like_for_like_n1"] = round(W["samples"] / local_ms / 1e3, 1)
+            res["efficiency_note"] = ("value_like_for_like_n1 = one GPU running this exact step (mixdown included) without the "
+                                      "reduce; value / (n_gpus x value_like_for_like_n1) = per_gpu_efficiency.  The default N=1 line "
+                                      "renders the bank WITHOUT the mixdown (BASELINE configs[1] as named)")
+        if args.share_gpu:
+            res["share_gpu_test"] = True
+        if "north_star_bank" in extras:
+            res["north_star_bank"] = extras["north_star_bank"]
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = W["cpu"]()
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":

@@ -138,6 +138,15 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * The tests flip every one of them and demand identical bits.  Returns the previous value or MXG_ERR_INVALID. */
 int mxg_tune(const char *key, int value);
 
+/* Asynchronous device errors.  A kernel that detects, while it runs, a failure no argument check could see -- a time-split
+ * launch whose writer part never got its sibling parts' signals (its state is then NOT stored), a granular render that ran out
+ * of rand() draws or met a live grain its plan could not have made -- stores a code in a word of pinned host memory.  No call
+ * synchronises for it: the NEXT call of any entry point (and every synchronising call -- mxg_stream_sync, mxg_sync,
+ * mxg_memcpy_d2h -- after its wait) returns the failure as its status with the message in mxg_last_error(), once, and clears
+ * it.  mxg_last_async_error() is that check by itself: MXG_OK, or the pending failure.  (Render entry points therefore never
+ * block the host, and their launch sequences can be captured into a hipGraph; a captured launch reports the same way.) */
+int mxg_last_async_error(void);
+
 /* ---- maxiOsc bank -------------------------------------------------------------------- */
 /* Renders out[n][v] = bank[v].<waveform>(freq) for n < N, exactly as N consecutive per-sample
  * calls would (H:169-215).  d_freq is [V] (fps=0, block-constant) or [N][V] (fps=1, audio-rate
@@ -551,7 +560,9 @@ int mxg_mix_reduce(mxg_comm *comm, int channels, size_t V, size_t N, const doubl
  * mxg_osc_render_mix / mxg_mix_stereo with d_mix = p>;  mxg_mixq_push(q, stream).  mxg_mixq_flush reduces a partial
  * batch and makes `stream` wait for every outstanding reduce.  mxg_mixq_result: device pointer to the most recently
  * submitted batch's sum [blocks][block_doubles] (meaningful on the root once its reduce has completed, e.g. after
- * flush + stream sync; overwritten two batches later).  mxg_mixq_set_sink: the root additionally copies every summed
+ * flush + stream sync; the reduce of the batch after next overwrites it ON THE QUEUE'S STREAM -- a consumer that reads it with
+ * work enqueued on a stream calls mxg_mixq_release(q, that stream) after enqueueing its reads, and the overwriting reduce is
+ * ordered behind them; a consumer that synchronises and copies before it pushes further blocks needs nothing).  mxg_mixq_set_sink: the root additionally copies every summed
  * block into a pinned host ring [ring_blocks][block_doubles] (the audio callback's side of the boundary). */
 typedef struct mxg_mixq mxg_mixq;
 mxg_mixq *mxg_mixq_create(mxg_comm *comm, size_t block_doubles, int depth_blocks, int root);
@@ -561,11 +572,19 @@ double *mxg_mixq_slot(mxg_mixq *q, void *stream);
 int mxg_mixq_push(mxg_mixq *q, void *stream);
 int mxg_mixq_flush(mxg_mixq *q, void *stream);
 const double *mxg_mixq_result(const mxg_mixq *q, size_t *h_blocks, size_t *h_batches);
+int mxg_mixq_release(mxg_mixq *q, void *stream);
 
 /* ---- calibration ----------------------------------------------------------------------- */
 /* Streaming fill of `bytes` at d_dst (8 B/lane or 16 B/lane stores): the measured HBM write
  * ceiling that bench.py reports next to the nominal 8 TB/s. */
 int mxg_calib_fill(void *d_dst, size_t bytes, int width, void *stream);
+/* The same measurement over the store shapes the bank kernels could use (csrc/calib.hip): a region of `rows` rows of
+ * `row_bytes` bytes; pattern 0 = grid-stride fill (`blocks` workgroups, 0 = 2048), 1 = column walk (a lane owns `width`
+ * bytes of a row and stores them row after row: the shape of out[n*V + v]), 2 = column walk in two time halves;
+ * flavour 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 sc0; block = threads per workgroup; xcd = 1 renumbers the
+ * workgroups so that every XCD owns one contiguous eighth of a row.  tools/write_ceiling.py, profiles/r03_write_ceiling.md. */
+int mxg_calib_fill_ex(void *d_dst, size_t rows, size_t row_bytes, int width, int flavour, int pattern, int block,
+                      int blocks, int xcd, void *stream);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,7 @@ SIGNATURES = {
     "mxg_prof_read": (c_int, [c_int, POINTER(c_char_p), POINTER(c_double), POINTER(c_size_t)]),
     "mxg_prof_overhead_ms": (c_int, [c_void_p, c_int, POINTER(c_double)]),
     "mxg_tune": (c_int, [c_char_p, c_int]),
+    "mxg_last_async_error": (c_int, []),
     "mxg_osc_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_osc_render_mix": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -133,7 +134,9 @@ SIGNATURES = {
     "mxg_mixq_push": (c_int, [c_void_p, c_void_p]),
     "mxg_mixq_flush": (c_int, [c_void_p, c_void_p]),
     "mxg_mixq_result": (c_void_p, [c_void_p, POINTER(c_size_t), POINTER(c_size_t)]),
+    "mxg_mixq_release": (c_int, [c_void_p, c_void_p]),
     "mxg_calib_fill": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
+    "mxg_calib_fill_ex": (c_int, [c_void_p, c_size_t, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 

@@ -18,12 +18,25 @@
 // already loaded (one runtime per process), in a plain C++ host it is /opt/rocm/lib's.  libmaxigpu.so itself keeps
 // loading on machines without RCCL; the comm entry points then fail loudly (MXG_ERR_INVALID + message).
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 #include <string.h>
 
 #include <mutex>
 
 #include "mxg_common.h"
+#include "mxg_mixq_core.h"
+
+// The RCCL entry points are resolved with dlsym, so only a handful of types are needed at compile time: use the installed
+// header where there is one and the same few declarations (ABI of NCCL 2.x / RCCL) where there is not -- libmaxigpu.so builds
+// and loads on a ROCm install without the RCCL development files.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclDouble = 8 } ncclDataType_t;  // ncclFloat64
+#endif
 
 namespace mxg {
 namespace {
@@ -81,60 +94,30 @@ struct mxg_comm {
     int nranks = 1, rank = 0;
 };
 
-struct mxg_mixq {
+// the device interface of the queue protocol (mxg_mixq_core.h) on HIP + RCCL
+struct HipMixDev {
+    typedef hipStream_t Stream;
+    typedef hipEvent_t Event;
     mxg_comm *comm = nullptr;  // NULL: no communicator, the "reduce" is a device copy
-    size_t block = 0;          // doubles per block (samples * channels)
-    int depth = 1;             // M blocks per reduce
-    int root = 0;
-    double *stage[2] = {nullptr, nullptr};   // [M][block] local mixes
-    double *result[2] = {nullptr, nullptr};  // [M][block] reduced (meaningful on the root)
-    hipEvent_t filled[2] = {nullptr, nullptr};   // recorded on the caller's stream when a staging buffer is complete
-    hipEvent_t reduced[2] = {nullptr, nullptr};  // recorded on the queue's stream when its reduce has finished
-    bool in_flight[2] = {false, false};
-    hipStream_t qstream = nullptr;
-    int cur = 0;         // staging buffer being filled
-    int fill = 0;        // blocks pushed into it
-    bool slot_out = false;
-    int last = -1;       // buffer of the most recently submitted batch
-    size_t last_blocks = 0;
-    size_t batches = 0;
-    double *h_sink = nullptr;  // optional pinned host ring [sink_blocks][block] the root copies every batch into
-    size_t sink_blocks = 0, sink_pos = 0;
+    int record(Event e, Stream s) { return mxg::check_hip(hipEventRecord(e, s), "hipEventRecord"); }
+    int wait(Stream s, Event e) { return mxg::check_hip(hipStreamWaitEvent(s, e, 0), "hipStreamWaitEvent"); }
+    int reduce(const double *send, double *recv, size_t count, int root, Stream s) {
+        using namespace mxg;
+        if (comm)  // a one-rank communicator still goes through RCCL (the path a 1-GPU box can execute)
+            return check_nccl(g_rccl.Reduce(send, recv, count, ncclDouble, ncclSum, root, comm->comm, s), "ncclReduce");
+        return check_hip(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+    }
+    int copy_to_host(double *h, const double *d, size_t count, Stream s) {
+        return mxg::check_hip(hipMemcpyAsync(h, d, count * sizeof(double), hipMemcpyDeviceToHost, s), "hipMemcpyAsync");
+    }
+    bool is_root(int root) { return !comm || comm->rank == root; }
+};
+
+struct mxg_mixq : mxg::MixQueueCore<HipMixDev> {
+    HipMixDev hip;
 };
 
 using namespace mxg;
-
-namespace {
-
-int mixq_submit(mxg_mixq *q, hipStream_t caller) {
-    const int b = q->cur;
-    const size_t count = (size_t)q->fill * q->block;
-    MXG_HIP(hipEventRecord(q->filled[b], caller));
-    MXG_HIP(hipStreamWaitEvent(q->qstream, q->filled[b], 0));
-    if (q->comm) {  // a one-rank communicator still goes through RCCL (the path a 1-GPU box can execute)
-        MXG_NCCL(g_rccl.Reduce(q->stage[b], q->result[b], count, ncclDouble, ncclSum, q->root, q->comm->comm, q->qstream));
-    } else {
-        MXG_HIP(hipMemcpyAsync(q->result[b], q->stage[b], count * sizeof(double), hipMemcpyDeviceToDevice, q->qstream));
-    }
-    const bool is_root = !q->comm || q->comm->rank == q->root;
-    if (q->h_sink && is_root) {  // the root's audio side: the summed blocks go to the pinned ring, block by block
-        for (int i = 0; i < q->fill; i++) {
-            MXG_HIP(hipMemcpyAsync(q->h_sink + (q->sink_pos % q->sink_blocks) * q->block, q->result[b] + (size_t)i * q->block,
-                                   q->block * sizeof(double), hipMemcpyDeviceToHost, q->qstream));
-            q->sink_pos++;
-        }
-    }
-    MXG_HIP(hipEventRecord(q->reduced[b], q->qstream));
-    q->in_flight[b] = true;
-    q->last = b;
-    q->last_blocks = (size_t)q->fill;
-    q->batches++;
-    q->cur ^= 1;
-    q->fill = 0;
-    return MXG_OK;
-}
-
-}  // namespace
 
 extern "C" {
 
@@ -211,7 +194,8 @@ mxg_mixq *mxg_mixq_create(mxg_comm *c, size_t block_doubles, int depth_blocks, i
         return nullptr;
     }
     mxg_mixq *q = new mxg_mixq;
-    q->comm = c;
+    q->hip.comm = c;
+    q->dev = &q->hip;
     q->block = block_doubles;
     q->depth = depth_blocks;
     q->root = root;
@@ -222,6 +206,7 @@ mxg_mixq *mxg_mixq_create(mxg_comm *c, size_t block_doubles, int depth_blocks, i
         ok = ok && hipMemset(q->stage[b], 0, bytes) == hipSuccess && hipMemset(q->result[b], 0, bytes) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&q->filled[b], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&q->reduced[b], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&q->consumed[b], hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) {
         fail(MXG_ERR_HIP, "mxg_mixq_create: %s", hipGetErrorString(hipGetLastError()));
@@ -239,6 +224,7 @@ int mxg_mixq_destroy(mxg_mixq *q) {
         if (q->result[b]) (void)hipFree(q->result[b]);
         if (q->filled[b]) (void)hipEventDestroy(q->filled[b]);
         if (q->reduced[b]) (void)hipEventDestroy(q->reduced[b]);
+        if (q->consumed[b]) (void)hipEventDestroy(q->consumed[b]);
     }
     if (q->qstream) (void)hipStreamDestroy(q->qstream);
     delete q;
@@ -260,35 +246,25 @@ double *mxg_mixq_slot(mxg_mixq *q, void *stream) {
         fail(MXG_ERR_INVALID, "mxg_mixq_slot: null queue");
         return nullptr;
     }
-    hipStream_t st = resolve_stream(stream);
-    const int b = q->cur;
-    if (q->fill == 0 && q->in_flight[b]) {
-        // the reduce that last read this staging buffer must be done before the caller's stream overwrites it
-        if (check_hip(hipStreamWaitEvent(st, q->reduced[b], 0), "hipStreamWaitEvent")) return nullptr;
-        q->in_flight[b] = false;
-    }
-    q->slot_out = true;
-    return q->stage[b] + (size_t)q->fill * q->block;
+    int status = 0;
+    return q->slot(resolve_stream(stream), &status);
 }
 
 int mxg_mixq_push(mxg_mixq *q, void *stream) {
     MXG_REQUIRE(q, "null queue");
     MXG_REQUIRE(q->slot_out, "mxg_mixq_push without mxg_mixq_slot");
-    q->slot_out = false;
-    q->fill++;
-    if (q->fill < q->depth) return MXG_OK;
-    return mixq_submit(q, resolve_stream(stream));
+    return q->push(resolve_stream(stream));
 }
 
 int mxg_mixq_flush(mxg_mixq *q, void *stream) {
     MXG_REQUIRE(q, "null queue");
     MXG_REQUIRE(!q->slot_out, "a slot is still open (mxg_mixq_slot without mxg_mixq_push)");
-    hipStream_t st = resolve_stream(stream);
-    if (q->fill > 0)
-        if (int s = mixq_submit(q, st)) return s;
-    for (int b = 0; b < 2; b++)
-        if (q->in_flight[b]) MXG_HIP(hipStreamWaitEvent(st, q->reduced[b], 0));  // in_flight stays set: slot() re-waits, harmless
-    return MXG_OK;
+    return q->flush(resolve_stream(stream));
+}
+
+int mxg_mixq_release(mxg_mixq *q, void *stream) {
+    MXG_REQUIRE(q, "null queue");
+    return q->release(resolve_stream(stream));
 }
 
 const double *mxg_mixq_result(const mxg_mixq *q, size_t *h_blocks, size_t *h_batches) {

@@ -40,9 +40,6 @@ int tune_get(const char *key);
 // a device pointer of at least `bytes`.
 enum ScratchSlot { SCR_MIX_GAINS, SCR_OSC_MIX, SCR_GRAIN_ERR, SCR_GRAIN_SCHED, SCR_IFFT_OUT, SCR_IFFT_BUF, SCR_MFCC_RAW, SCR_CONVOLVE, SCR_GRAIN_MIX, SCR_PART_SYNC, SCR_SLOTS };
 int scratch_get(ScratchSlot slot, hipStream_t st, size_t bytes, void **out);
-// the per-wavefront counters of the time-part kernels (part_signal / part_wait below): zero when handed out for the first time,
-// and every launch leaves them zero again
-int part_counters_get(hipStream_t st, size_t wavefronts, int **out);
 
 // Optional per-kernel timing (mxg_prof_enable): a KernelTimer around a launch records two HIP events on the launch
 // stream; mxg_prof_read sums the elapsed times per label.  Off by default: then it costs one load and a branch.
@@ -65,15 +62,41 @@ struct KernelTimer {
         if (!(cond)) return ::mxg::fail(MXG_ERR_INVALID, "%s: %s", __func__, msg); \
     } while (0)
 
+// ---- asynchronous device errors ------------------------------------------------------------------------------------
+// A kernel that detects a failure the host cannot see at launch time (a time part that never got its signals, a grain render
+// with an exhausted rand() queue ...) stores a code in ONE word of pinned, device-mapped host memory.  Nothing synchronises for
+// it: the NEXT C-ABI call of any kind finds the word set, returns MXG_ERR_HIP / MXG_ERR_INVALID with the message, and clears it
+// (mxg_last_async_error() does the same on request) -- so a failure is reported once, loudly, at the first call after it.
+enum AsyncError {
+    ASYNC_OK = 0,
+    ASYNC_GRAIN_BASE = 100,   // + the granular render's code 1..5 (grains.hip)
+    ASYNC_PART_TIMEOUT = 16,  // part_wait gave up: the state of that launch was NOT stored
+};
+int *async_error_word();  // device-visible address of the word (valid after mxg_init)
+int async_error_poll();   // host: MXG_OK, or the pending error as a status (+ message), cleared
+
 // ---- time parts: who may overwrite the state ----------------------------------------------------------------------
 // A kernel cut into gridDim.y time parts reads its per-voice state in EVERY part and stores the new state from ONE of them (the
 // writer).  Nothing orders the workgroups of a launch: with little work per part the writer can be done before another part of the
 // same voices has even started, and that part would then start from the NEW state.  So every other part signals, per wavefront,
 // once its state loads have returned, and the writer waits for those signals before it stores.  Workgroups are dispatched in
-// order (x fastest, then y) and the writer is the part with the most work in front of its store, so the wait is normally over
-// before it begins; it is bounded anyway (a kernel never hangs on a stale counter).  The writer leaves the counter at zero.
-__device__ __forceinline__ int *part_counter(int *ctrs) {
-    return ctrs ? ctrs + ((size_t)blockIdx.x * ((blockDim.x + 63) >> 6) + (threadIdx.x >> 6)) : nullptr;
+// order (x fastest, then y) and the writer is ALWAYS the last part (the last dispatched, with the most work in front of its
+// store), so it never waits for work that has not been dispatched yet and the wait is normally over before it begins.  It is
+// bounded anyway (`spin_limit` polls, knob part_spin_limit): on a time-out the writer reports ASYNC_PART_TIMEOUT through the
+// async error word and does NOT store -- the launch's state is lost, loudly, instead of a late part silently starting from
+// the new state -- and leaves the counter as it is; the host zeroes the counters again before the next split launch after an
+// error.  Otherwise the writer leaves the counter at zero.
+struct PartSync {
+    int *ctrs = nullptr;   // one counter per wavefront of gridDim.x (zero between launches)
+    int *err = nullptr;    // the async error word
+    int spin_limit = 1 << 20;
+    int others = 0;        // signals the writer waits for (parts - 1; the fault-injection knob part_fault adds one that never comes)
+};
+// counters for a launch of `wavefronts` wavefronts per part in `parts` time parts on stream st
+int part_sync_get(hipStream_t st, size_t wavefronts, int parts, PartSync *out);
+
+__device__ __forceinline__ int *part_counter(const PartSync &ps) {
+    return ps.ctrs ? ps.ctrs + ((size_t)blockIdx.x * ((blockDim.x + 63) >> 6) + (threadIdx.x >> 6)) : nullptr;
 }
 __device__ __forceinline__ void part_signal(int *ctr) {
     if (!ctr) return;
@@ -81,14 +104,35 @@ __device__ __forceinline__ void part_signal(int *ctr) {
     if ((threadIdx.x & 63) == (unsigned)(__ffsll((unsigned long long)__ballot(1)) - 1))
         __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void part_wait(int *ctr, int others) {
-    if (!ctr) return;
+// true: every other part has read its state -- store yours.  false: timed out (reported), do not store.
+__device__ __forceinline__ bool part_wait(int *ctr, const PartSync &ps) {
+    if (!ctr) return true;
+    int ok = 1;
     if ((threadIdx.x & 63) == (unsigned)(__ffsll((unsigned long long)__ballot(1)) - 1)) {
-        for (int spins = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < others && spins < (1 << 20); spins++)
+        int spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ps.others && spins < ps.spin_limit) {
             __builtin_amdgcn_s_sleep(8);
-        __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            spins++;
+        }
+        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ps.others) {
+            __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            ok = 0;
+            if (ps.err) __hip_atomic_store(ps.err, (int)ASYNC_PART_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
+    ok = __shfl(ok, __ffsll((unsigned long long)__ballot(1)) - 1);
     __builtin_amdgcn_wave_barrier();
+    return ok != 0;
+}
+
+// ---- XCD-aware workgroup numbering ---------------------------------------------------------------------------------
+// Workgroups are handed to the eight XCDs round-robin (workgroup b runs on XCD b mod 8, each with its own 4 MB L2).  With
+// xcd != 0 and a grid that is a multiple of 8, workgroup b takes the unit range that gives every XCD one CONTIGUOUS eighth of
+// the bank (of a row) instead of every eighth piece.
+__device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nblk, int xcd) {
+    if (!xcd || (nblk & 7)) return b;
+    return (b & 7) * (nblk >> 3) + (b >> 3);
 }
 
 // ---- device store helpers ---------------------------------------------------------------

@@ -57,14 +57,14 @@ template <int WF, bool FPS, int VPL, bool NT>
 __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
                            const double *__restrict__ p1, const double *__restrict__ p2,
                            double *__restrict__ phase_io, double *__restrict__ hold_io,
-                           double *__restrict__ out, double sr, int *part_ctrs) {
+                           double *__restrict__ out, double sr, PartSync psync, int xcd) {
     // All LDS in ONE array (a second __shared__ object perturbs hipcc's waitcnt placement).
     __shared__ __attribute__((aligned(16))) double s_tab[tab_len<WF>()];
     if constexpr (tab_len<WF>() > 1) {
         load_tab<WF>(s_tab);
         __syncthreads();
     }
-    const size_t v0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VPL;
+    const size_t v0 = ((size_t)xcd_block(blockIdx.x, gridDim.x, xcd) * blockDim.x + threadIdx.x) * VPL;
     if (v0 >= V) return;
 
     double ph[VPL], hd[VPL];
@@ -87,7 +87,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
     // ramp) part p first advances the recurrence over the samples of parts 0..p-1 without producing them -- the same
     // additions in the same order, so the same bits -- and then renders its own stretch; the last part stores the state.
     // The last part stores the state; the others tell it when they have read theirs (part_signal / part_wait, mxg_common.h).
-    int *const part_ctr = gridDim.y > 1 ? part_counter(part_ctrs) : nullptr;
+    int *const part_ctr = gridDim.y > 1 ? part_counter(psync) : nullptr;
     if (blockIdx.y + 1 != gridDim.y) part_signal(part_ctr);
     const size_t plen = (N + gridDim.y - 1) / gridDim.y;
     const size_t nA = blockIdx.y * plen < N ? blockIdx.y * plen : N;
@@ -143,8 +143,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
             if constexpr (FPS) fp += V;
         }
     }
-    if (blockIdx.y + 1 == gridDim.y) {
-        part_wait(part_ctr, (int)gridDim.y - 1);
+    if (blockIdx.y + 1 == gridDim.y && part_wait(part_ctr, psync)) {
 #pragma unroll
         for (int j = 0; j < VPL; j++) {
             phase_io[v0 + j] = ph[j];
@@ -296,7 +295,7 @@ osc_mix_fn pick_mix_wf(int wf, bool store, int var) {
 }
 
 typedef void (*osc_fn)(size_t, size_t, const double *, const double *, const double *, double *,
-                       double *, double *, double, int *);
+                       double *, double *, double, PartSync, int);
 
 template <int WF>
 osc_fn pick(bool fps, int vpl, bool nt) {
@@ -364,12 +363,12 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     // every part must render at least one sample: the last part's ticks leave the member `output` of the final sample
     while (split > 1 && (size_t)(split - 1) * ((N + split - 1) / split) >= N) split--;
     dim3 grid((unsigned)((lanes + block - 1) / block), (unsigned)split), blk((unsigned)block);
-    int *part_ctrs = nullptr;
+    PartSync psync;
     if (split > 1)
-        if (int s = part_counters_get(resolve_stream(stream), (size_t)grid.x * ((block + 63) / 64), &part_ctrs)) return s;
+        if (int s = part_sync_get(resolve_stream(stream), (size_t)grid.x * ((block + 63) / 64), split, &psync)) return s;
     KernelTimer kt("osc_kernel", resolve_stream(stream));
     hipLaunchKernelGGL(fn, grid, blk, 0, resolve_stream(stream), V, N, d_freq, d_p1, d_p2, d_phase,
-                       d_outhold, d_out, (double)settings().sampleRate, part_ctrs);
+                       d_outhold, d_out, (double)settings().sampleRate, psync, tune_get("osc_xcd"));
     return check_hip(hipGetLastError(), "osc_kernel launch");
 }
 

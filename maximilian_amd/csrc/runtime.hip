@@ -30,6 +30,9 @@ struct Tune {
 Tune g_tune[] = {
     {"osc_vpl", 1, 1, 2},       {"osc_block", 256, 64, 1024},  {"osc_nt", 2, 0, 2},
     {"voice_vpl", 1, 1, 2},     {"voice_block", 256, 64, 1024}, {"voice_nt", 2, 0, 2},
+    {"part_spin_limit", 1 << 20, 1, 1 << 24},  // time parts: polls (x s_sleep 8) before the writer gives up and reports ASYNC_PART_TIMEOUT
+    {"part_fault", 0, 0, 1},  // fault injection for the tests: the writer waits for one signal more than will ever come
+    {"osc_xcd", 0, 0, 1},  // K1: 1 = every XCD renders one contiguous eighth of the bank (workgroup renumbering, mxg_common.h)
     {"osc_split", 0, 0, 8},  // K1: time parts per voice group (0 = automatic: 4 for sinewave / coswave on small banks, else 1)
     {"osc_mix_var", 0, 0, 3},  // K1m A/B (sinebuf): 0 swap butterfly, window 512; 1 same, window 128; 2 DPP butterfly 128; 3 DPP 512
     {"ifft_stream", 1, 0, 2},  // maxiIFFT: transform + hop buffer in one kernel (0: never; 1: where hop >= fftSize / 2; 2: wherever it fits)
@@ -67,7 +70,7 @@ int check_hip(hipError_t e, const char *what) {
 }
 
 int ensure_init() {
-    if (g_inited) return MXG_OK;
+    if (g_inited) return async_error_poll();
     return mxg_init(-1);
 }
 
@@ -95,7 +98,42 @@ int scratch_get(ScratchSlot slot, hipStream_t st, size_t bytes, void **out) {
     return MXG_OK;
 }
 
-int part_counters_get(hipStream_t st, size_t wavefronts, int **out) {
+namespace {
+int *g_async_host = nullptr;  // pinned, device-mapped: kernels store a code, the host polls it without synchronising
+int *g_async_dev = nullptr;
+bool g_part_dirty = false;    // a part time-out left counters non-zero: zero them before the next split launch
+}  // namespace
+
+int *async_error_word() { return g_async_dev; }
+
+int async_error_poll() {
+    if (!g_async_host) return MXG_OK;
+    const int code = __atomic_load_n(g_async_host, __ATOMIC_ACQUIRE);
+    if (code == ASYNC_OK) return MXG_OK;
+    __atomic_store_n(g_async_host, 0, __ATOMIC_RELEASE);
+    if (code == ASYNC_PART_TIMEOUT) {
+        g_part_dirty = true;
+        return fail(MXG_ERR_HIP, "asynchronous device error from an earlier launch: a time-split kernel (osc / sample *AtSpeed) timed out "
+                                 "waiting for its sibling parts; the per-voice state of that launch was not stored");
+    }
+    switch (code - ASYNC_GRAIN_BASE) {
+        case 1: return fail(MXG_ERR_INVALID, "mxg_granular_render (earlier launch): more than 8 grains alive in a stream");
+        case 2: return fail(MXG_ERR_INVALID, "mxg_granular_render (earlier launch): d_rnd exhausted (R too small)");
+        case 3: return fail(MXG_ERR_INVALID, "mxg_granular_render (earlier launch): internal spawn list overflow");
+        case 4:
+            return fail(MXG_ERR_INVALID,
+                        "mxg_granular_render (earlier launch): d_gst holds a live grain this plan could not have made (another grain "
+                        "length, or an index/position outside the window/sample); let live grains finish or clear d_gst first");
+        case 5:
+            return fail(MXG_ERR_INVALID,
+                        "mxg_granular_render (earlier launch): a grain was born with a NaN/Inf step or one longer than the sample "
+                        "(|speed| too large for this sample length); its reads would leave the buffer");
+        default: break;
+    }
+    return fail(MXG_ERR_HIP, "asynchronous device error %d from an earlier launch", code);
+}
+
+int part_sync_get(hipStream_t st, size_t wavefronts, int parts, PartSync *out) {
     const size_t bytes = (wavefronts ? wavefronts : 1) * sizeof(int);
     std::lock_guard<std::mutex> lk(g_mu);
     ScratchBuf &b = g_scratch[std::make_pair((int)SCR_PART_SYNC, st)];
@@ -108,7 +146,18 @@ int part_counters_get(hipStream_t st, size_t wavefronts, int **out) {
         b.cap = cap;
         MXG_HIP(hipMemsetAsync(b.ptr, 0, cap, st));  // ordered before the launch that uses it; launches leave it zero
     }
-    *out = (int *)b.ptr;
+    if (g_part_dirty) {  // after a reported time-out: every stream's counters start from zero again
+        for (auto &kv : g_scratch)
+            if (kv.first.first == (int)SCR_PART_SYNC && kv.second.ptr) {
+                MXG_HIP(hipStreamSynchronize(kv.first.second));
+                MXG_HIP(hipMemset(kv.second.ptr, 0, kv.second.cap));
+            }
+        g_part_dirty = false;
+    }
+    out->ctrs = (int *)b.ptr;
+    out->err = g_async_dev;
+    out->spin_limit = tune_get("part_spin_limit");
+    out->others = parts - 1 + (tune_get("part_fault") ? 1 : 0);
     return MXG_OK;
 }
 
@@ -224,6 +273,11 @@ int mxg_init(int device) {
         MXG_HIP(hipGetDevice(&g_device));
     }
     if (!g_stream) MXG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (!g_async_host) {
+        MXG_HIP(hipHostMalloc((void **)&g_async_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        *g_async_host = 0;
+        MXG_HIP(hipHostGetDevicePointer((void **)&g_async_dev, g_async_host, 0));
+    }
     g_inited = true;
     return MXG_OK;
 }
@@ -264,7 +318,7 @@ int mxg_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream) {
     hipStream_t st = resolve_stream(stream);
     MXG_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
     MXG_HIP(hipStreamSynchronize(st));
-    return MXG_OK;
+    return async_error_poll();  // whatever the work before the copy reported
 }
 int mxg_memcpy_h2d_async(void *d_dst, const void *h_src, size_t bytes, void *stream) {
     if (int s = ensure_init()) return s;
@@ -317,13 +371,14 @@ int mxg_stream_destroy(void *stream) {
 int mxg_stream_sync(void *stream) {
     if (int s = ensure_init()) return s;
     MXG_HIP(hipStreamSynchronize(resolve_stream(stream)));
-    return MXG_OK;
+    return async_error_poll();
 }
 int mxg_sync(void) {
     if (int s = ensure_init()) return s;
     MXG_HIP(hipDeviceSynchronize());
-    return MXG_OK;
+    return async_error_poll();
 }
+int mxg_last_async_error(void) { return async_error_poll(); }
 void *mxg_event_create(void) {
     if (ensure_init()) return nullptr;
     hipEvent_t e = nullptr;

@@ -353,7 +353,7 @@ __device__ __forceinline__ void smp_skip(double &pos, const double step, const d
 }
 
 template <int MODE, bool PIPE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) sample_parts_kernel(SmpArgs A, const size_t part_len, int *part_ctrs) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) sample_parts_kernel(SmpArgs A, const size_t part_len, PartSync psync) {
     __shared__ double s_win[4 * 64 * kRowDoubles];
     const size_t V = A.V, N = A.N;
     const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -366,16 +366,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) s
     const double step = (x0 * kChandiv) / s.step_div;  // the increment of smp_gen (C:1070)
     const bool can_skip = __all(step > 0.0 && step < HUGE_VAL && s.pos >= 0.0 && s.pos < HUGE_VAL);
     size_t n0 = 0, n1 = N;
-    // the writer of the head: the last part, or part 0 where it renders the whole wavefront; the other parts tell it when they
-    // have read theirs (part_signal / part_wait, mxg_common.h) -- also the parts that only looked at it to decide can_skip
-    const bool writer = can_skip ? blockIdx.y + 1 == gridDim.y : blockIdx.y == 0;
-    int *const part_ctr = gridDim.y > 1 ? part_counter(part_ctrs) : nullptr;
+    // the writer of the head is ALWAYS the last part (the last dispatched: it never waits for work that is not resident yet) --
+    // where the wavefront cannot skip, the last part renders it whole; the other parts tell it when they have read the head
+    // (part_signal / part_wait, mxg_common.h), also the parts that only looked at it to decide can_skip
+    const bool writer = blockIdx.y + 1 == gridDim.y;
+    int *const part_ctr = gridDim.y > 1 ? part_counter(psync) : nullptr;
     if (!writer) part_signal(part_ctr);
     if (can_skip) {
         n0 = (size_t)blockIdx.y * part_len;
         n1 = n0 + part_len < N ? n0 + part_len : N;
         smp_skip<B>(s.pos, step, (double)s.len, n0);
-    } else if (blockIdx.y != 0) {
+    } else if (!writer) {
         return;
     }
     const double *amp = A.amp;
@@ -588,10 +589,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) s
         *op = smp_eval<MODE>(q, val);
         op += V;
     }
-    if (writer) {
-        part_wait(part_ctr, (int)gridDim.y - 1);
-        A.position[v] = s.pos;
-    }
+    if (writer && part_wait(part_ctr, psync)) A.position[v] = s.pos;
 }
 
 inline dim3 grid_for(size_t V, int block) { return dim3((unsigned)((V + block - 1) / block)); }
@@ -736,9 +734,9 @@ int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, siz
         size_t part_len = N;
         const int split = speed_parts(V, N, &part_len);
         if (split > 1) {
-            int *part_ctrs = nullptr;
+            PartSync part_ctrs;
             const dim3 pgrid(grid.x, (unsigned)split);
-            if (int e = part_counters_get(st, (size_t)grid.x * ((block + 63) / 64), &part_ctrs)) return e;
+            if (int e = part_sync_get(st, (size_t)grid.x * ((block + 63) / 64), split, &part_ctrs)) return e;
             const bool pipe = tune_get("smp_pipe") != 0;
             KernelTimer kt("sample_parts_kernel", st);
             if (mode == 4) { if (pipe) hipLaunchKernelGGL((sample_parts_kernel<4, true>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs); else hipLaunchKernelGGL((sample_parts_kernel<4, false>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs); }

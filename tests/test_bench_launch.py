@@ -1,0 +1,62 @@
+"""bench.py's launcher: `python bench.py --gpus N` by itself must start N ranks (torch.distributed.run, one process per GPU)
+and fail -- if it has to -- only on the number of GPUs, never on how it was started.
+
+CPU part (-m "not gpu"): without any GPU every rank stops at "needs a HIP device", after the launcher has spawned both.
+GPU part (-m gpu, one MI355X): (a) `--gpus 2` reaches the device-count check of rank 1 and says so; (b) `--gpus 2 --share-gpu`
+runs the whole two-rank harness on the one device (gloo carries the barriers, the mix queue reduces locally) and prints the one
+JSON line with n_gpus = 2, per_gpu_efficiency and value_like_for_like_n1."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+ENV = dict(os.environ, OMP_NUM_THREADS="1")
+ENV.pop("WORLD_SIZE", None)
+ENV.pop("RANK", None)
+ENV.pop("LOCAL_RANK", None)
+
+
+def _run(args, timeout=600):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                          env=ENV, cwd=ROOT)
+
+
+def test_self_launch_spawns_ranks_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: covered by the gpu tests below")
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert r.returncode != 0
+    err = r.stderr + r.stdout
+    assert "needs a HIP device" in err, err[-3000:]
+    assert "launch with torch.distributed.run" not in err and "WORLD_SIZE=" not in err, err[-3000:]
+    # both ranks were started (torch.distributed.run reports the failed ranks)
+    assert "rank" in err.lower()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_a_one_gpu_box_fail_only_at_the_device_count():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node has two GPUs")
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert r.returncode != 0
+    err = r.stderr + r.stdout
+    assert "--gpus 2 needs 2 GPUs" in err, err[-3000:]
+
+
+@pytest.mark.gpu
+def test_two_ranks_sharing_one_gpu_print_the_scaling_fields():
+    r = _run(["--gpus", "2", "--share-gpu", "--steps", "64", "--warmup", "8", "--no-cpu-baseline"])
+    assert r.returncode == 0, (r.stderr + r.stdout)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["share_gpu_test"] is True and d["scaling"] == "weak"
+    assert 0.0 < d["per_gpu_efficiency"] <= 1.0
+    assert d["value_like_for_like_n1"] > 0 and d["step_ms_without_reduce"] > 0
+    assert d["roofline"]["kernel"] == "osc_mix_kernel"

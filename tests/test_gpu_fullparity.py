@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import pytest
 
-from conftest import assert_bits_equal
+from conftest import assert_bits_equal, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -60,6 +60,79 @@ def test_config2_64_blocks_every_sample(mx, port, wf, name):
     assert_bits_equal(bank.phase.numpy(), eph, "phase after 64 blocks")
     print("config 2 %s: %d blocks x %d samples x %d voices = %.2f G samples, all bit-identical to the oracle"
           % (name, K, B, V, K * B * V / 1e9))
+
+
+@pytest.mark.parametrize("wf,name", [(0, "sinewave"), (1, "coswave")])
+def test_config2_64_blocks_trig_every_sample(mx, port, wf, name):
+    """maxiOsc::sinewave / coswave (C:228-235, 276-283) over the full config-2 length: the phase recurrence is bit-exact
+    (it is carried from block to block, so a single wrong bit would show in every later block) and EVERY output sample is
+    within 1 ULP of the oracle's glibc sin / cos of the same phase -- no absolute escape.  At 65 536 voices the launch takes
+    the two-part time split (osc.hip: split = 2 below 2048 wavefronts), so this is also that path against the oracle."""
+    K = 64
+    freq = 20.0 + np.arange(V) * 0.30517578125
+    bank = mx.maxiOscBank(V)
+    out = mx.DeviceBuffer((B, V), zero=False)
+    sh = shards(V, NTHREADS)
+    state = [(None, None)] * len(sh)
+    hist = np.zeros(3, np.int64)  # samples at 0 ULP, at 1 ULP, above
+    with ThreadPoolExecutor(len(sh)) as pool:
+        for k in range(K):
+            bank.render(wf, freq, B, out=out)
+            got = out.numpy()
+            gph = bank.phase.numpy()
+
+            def one(i):
+                a, b = sh[i]
+                e, ph, hd = port.osc(wf, freq[a:b], B, phase=state[i][0], hold=state[i][1])
+                state[i] = (ph, hd)
+                d = ulp_diff(got[:, a:b], e)
+                return (int((d == 0).sum()), int((d == 1).sum()), int((d > 1).sum()),
+                        count_mismatch(gph[a:b], ph))
+            r = np.array(list(pool.map(one, range(len(sh)))))
+            hist += r[:, :3].sum(axis=0)
+            assert r[:, 3].sum() == 0, "%s: phase differs after block %d" % (name, k)
+            assert hist[2] == 0, "%s: %d samples above 1 ULP by block %d" % (name, hist[2], k)
+    total = K * B * V
+    assert hist.sum() == total
+    print("config 2 %s: %.2f G samples: %d identical to glibc, %d at 1 ULP (%.4f %%), 0 above; phase bit-identical in every block"
+          % (name, total / 1e9, hist[0], hist[1], 100.0 * hist[1] / total))
+
+
+@pytest.mark.parametrize("voices,blocks", [(131072, 4), (1048576, 4)])
+@pytest.mark.parametrize("wf,name", [(8, "sinebuf"), (9, "sinebuf4"), (0, "sinewave")])
+def test_large_banks_every_sample(mx, port, voices, blocks, wf, name):
+    """The north star's >= 10^5-voice banks: 131 072 voices (a 537 MB block: the non-temporal store flavour, osc.hip picks
+    it by block size) and 1 048 576 voices (4.3 GB block, plain stores, 16 384 wavefronts = 16 per SIMD), carried
+    blocks, every sample against the oracle: wavetable forms bit-exact, sinewave <= 1 ULP with a bit-exact phase."""
+    if voices > 200000 and wf != 8:
+        pytest.skip("the 1 M-voice bank is checked for sinebuf (the store path is shared)")
+    freq = 20.0 + (np.arange(voices) % 65536) * 0.30517578125 + (np.arange(voices) // 65536) * 0.001953125
+    bank = mx.maxiOscBank(voices)
+    out = mx.DeviceBuffer((B, voices), zero=False)
+    sh = shards(voices, max(NTHREADS, 8))
+    state = [(None, None)] * len(sh)
+    ones = 0
+    with ThreadPoolExecutor(min(len(sh), NTHREADS)) as pool:
+        for k in range(blocks):
+            bank.render(wf, freq, B, out=out)
+            got = out.numpy()
+
+            def one(i):
+                a, b = sh[i]
+                e, ph, hd = port.osc(wf, freq[a:b], B, phase=state[i][0], hold=state[i][1])
+                state[i] = (ph, hd)
+                if wf == 0:
+                    d = ulp_diff(got[:, a:b], e)
+                    return int((d > 1).sum()), int((d == 1).sum())
+                return count_mismatch(got[:, a:b], e), 0
+            r = np.array(list(pool.map(one, range(len(sh)))))
+            assert r[:, 0].sum() == 0, "%s, %d voices: %d samples off in block %d" % (name, voices, r[:, 0].sum(), k)
+            ones += int(r[:, 1].sum())
+            del got
+    assert_bits_equal(bank.phase.numpy(), np.concatenate([s[0] for s in state]), "phase after %d blocks" % blocks)
+    print("%s, %d voices x %d blocks x %d samples = %.2f G samples: %s" % (
+        name, voices, blocks, B, voices * blocks * B / 1e9,
+        "all within 1 ULP (%d at 1 ULP), phase bit-identical" % ones if wf == 0 else "all bit-identical to the oracle"))
 
 
 VOICE_B_RTOL = 1e-11  # mode B: device cos/sqrt coefficients through a recursive filter, scaled by the voice's peak
@@ -148,6 +221,67 @@ def test_config4_mfma_all_frames(mx, port):
     sel = torch.arange(0, N, 9973, device=dev)
     emel, emf = port.mfcc(mags[sel].cpu().numpy(), 42, 13, 20.0, 20000.0)
     assert np.abs(dense[sel].cpu().numpy() - emf).max() <= 1e-11 * max(1.0, np.abs(emel).max())
+
+
+MFCC_RTOL = 1e-12  # x the frame set's largest band log-energy: device log (mxg_log.h, < 0.75 ULP) vs glibc log, then the 42-term DCT
+
+
+def test_config4_all_frames_vs_oracle(mx, port):
+    """Config 4 at its full size, EVERY frame against the oracle: 1 048 576 frames x 1024 points of SURVEY 8d's signal through
+    the fused kernel (mxg_fft_mfcc_batch, magnitudes requested as well); per frame the oracle runs maxiFFT(1024,1024,1024)
+    (window, packed real FFT with its fp32 twiddle recurrences, cartToPol) and maxiMFCC(512,42,13,20,20000):
+    magnitudes bit-exact (fp32), mfcc within MFCC_RTOL.  The host side shards the frames over its cores."""
+    import torch
+    N = 1 << 20
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x4D415849)
+    sig = torch.empty(N * 1024, dtype=torch.float32, device=dev)
+    chunk = 1 << 16
+    for c0 in range(0, N, chunk):
+        n = torch.arange(c0 * 1024, (c0 + chunk) * 1024, dtype=torch.float64, device=dev)
+        k = torch.div(n, 1024, rounding_mode="floor")
+        x = (0.4 * torch.sin(2 * np.pi * 220 * n / 44100) + 0.3 * torch.sin(2 * np.pi * (440 + 0.01 * k) * n / 44100)
+             + 0.1 * (2 * torch.rand(n.numel(), dtype=torch.float64, device=dev, generator=g) - 1))
+        sig[c0 * 1024:(c0 + chunk) * 1024] = x.to(torch.float32)
+        del n, k, x
+    mags = torch.empty((N, 512), dtype=torch.float32, device=dev)
+    mfcc = torch.empty((N, 13), dtype=torch.float64, device=dev)
+    L = mx.lib()
+    f = mx.maxiFFT()
+    f.setup(1024, 1024, 1024)
+    m = mx.maxiMFCC()
+    m.setup(512, 42, 13, 20.0, 20000.0)
+    torch.cuda.synchronize()
+    assert L.mxg_fft_mfcc_batch(f.plan, m.plan, sig.data_ptr(), 1024, N, mags.data_ptr(), None, None, mfcc.data_ptr(), None) == 0
+    L.mxg_sync()
+    # the default call (no magnitudes written) must give the same coefficients
+    mfcc2 = torch.empty_like(mfcc)
+    assert L.mxg_fft_mfcc_batch(f.plan, m.plan, sig.data_ptr(), 1024, N, None, None, None, mfcc2.data_ptr(), None) == 0
+    L.mxg_sync()
+    assert torch.equal(mfcc, mfcc2)
+    task = 4096
+    bad_mags, worst, scale = 0, 0.0, 0.0
+    with ThreadPoolExecutor(NTHREADS) as pool:
+        for c0 in range(0, N, chunk):
+            hs = sig[c0 * 1024:(c0 + chunk) * 1024].cpu().numpy()
+            hm = mags[c0:c0 + chunk].cpu().numpy()
+            hc = mfcc[c0:c0 + chunk].cpu().numpy()
+
+            def one(t0):
+                e = port.fft_stream(hs[t0 * 1024:(t0 + task) * 1024], 1024, 1024, 1024, want=("mags",))["mags"]
+                assert e.shape == (task, 512)
+                nb = int((e.view(np.uint32) != hm[t0:t0 + task].view(np.uint32)).sum())
+                emel, emf = port.mfcc(e, 42, 13, 20.0, 20000.0)
+                return nb, float(np.abs(hc[t0:t0 + task] - emf).max()), float(np.abs(emel).max())
+            for nb, err, sc in pool.map(one, range(0, chunk, task)):
+                bad_mags += nb
+                worst = max(worst, err)
+                scale = max(scale, sc)
+            assert bad_mags == 0, "magnitudes differ in frames [%d, %d)" % (c0, c0 + chunk)
+    print("config 4: %d frames, all %d magnitudes bit-identical to the oracle; mfcc max |err| %.3e (tolerance %.1e x %.2f)"
+          % (N, N * 512, worst, MFCC_RTOL, scale))
+    assert worst <= MFCC_RTOL * scale
 
 
 def test_config5_all_streams(mx, port):

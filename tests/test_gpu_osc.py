@@ -251,3 +251,39 @@ def test_render_and_mixdown_are_graph_capturable(mx):
     assert torch.equal(g_state[0], e[0]), "phase after K replays"
     assert torch.equal(g_state[2], e[2]), "last block"
     assert torch.equal(g_state[3], e[3]), "last mix"
+
+
+def test_time_part_timeout_is_reported_and_state_kept(mx, port):
+    """A time-split launch whose writer part does not get its sibling parts' signals (forced: knob part_fault makes it wait for
+    one signal more than will ever come, part_spin_limit bounds the wait) must fail LOUDLY: the next synchronising call returns
+    MXG_ERR_HIP with a message, the per-voice state of that launch is NOT stored (so no later launch starts from a state a late
+    part may not have seen), and the following launches work again with zeroed counters and give the oracle's bits."""
+    L = mx.lib()
+    V, N = 4096, 256
+    freq = 20.0 + np.arange(V) * 0.3
+    bank = mx.maxiOscBank(V)
+    L.mxg_tune(b"osc_split", 2)
+    first = bank.render(8, freq, N).numpy()            # a clean split launch: sinebuf in two time parts
+    ph1 = bank.phase.numpy()
+    e1, eph1, _ = port.osc(8, freq, N)
+    assert_bits_equal(first, e1)
+    assert_bits_equal(ph1, eph1)
+    L.mxg_tune(b"part_fault", 1)
+    L.mxg_tune(b"part_spin_limit", 50)
+    try:
+        bank.render(8, freq, N)                        # enqueues; the kernel times out on the device
+        rc = L.mxg_stream_sync(bank.stream)
+        assert rc < 0, "the time-out was not reported at the synchronising call"
+        assert b"timed out" in L.mxg_last_error()
+        assert L.mxg_last_async_error() == 0           # reported once, then cleared
+    finally:
+        L.mxg_tune(b"part_fault", 0)
+        L.mxg_tune(b"part_spin_limit", 1 << 20)
+    assert_bits_equal(bank.phase.numpy(), ph1, "state must not be stored by a launch that timed out")
+    second = bank.render(8, freq, N).numpy()           # the block again, from the kept state, counters re-zeroed
+    e2, eph2, _ = port.osc(8, freq, N, phase=eph1)
+    assert_bits_equal(second, e2)
+    third = bank.render(8, freq, N).numpy()
+    e3, _, _ = port.osc(8, freq, N, phase=eph2)
+    assert_bits_equal(third, e3)
+    L.mxg_tune(b"osc_split", 0)
