@@ -135,6 +135,12 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "ifft_stream" (mxg_ifft_batch: inverse transform and hop buffer in one kernel: 0 never, 1 where hop >= fftSize / 2, 2 wherever it fits),
  * "mfcc_mfma_fullk" (the MFMA mel contraction runs over all numBins bins instead of the ones that carry weight, 0|1).
  * "fused_waves16" (mxg_fft_mfcc_batch: the 16-waves-per-CU form of the fused kernel when the request allows it, 0|1).
+ * "osc_store" (K1's store stream: -1 automatic by bank size; one voice per lane: 0 plain 8-byte stores, 1 non-temporal, 2 / 3 / 4 two
+ * samples of a lane pair exchanged into one 16-byte store per lane, plain / write-through (sc1) / non-temporal; two voices per lane:
+ * 0 plain, 1 non-temporal, 2 write-through 16-byte stores), "osc_xcd" (workgroups renumbered so that each of the eight XCDs renders
+ * one contiguous eighth of the bank, 0|1), "grain_sync" (mxg_granular_render reads its error word back before it returns, 0|1;
+ * default 0: deferred, see mxg_last_async_error), "part_spin_limit" (polls a time-split kernel's writer part makes before it gives up
+ * and reports through mxg_last_async_error), "part_fault" (test-only fault injection: that writer waits for a signal that never comes).
  * The tests flip every one of them and demand identical bits.  Returns the previous value or MXG_ERR_INVALID. */
 int mxg_tune(const char *key, int value);
 

@@ -519,7 +519,13 @@ struct UnitArgs {
     // fused maxiMix::stereo mixdown of the tile (NULL = off): pan [S], mixpart [stream tiles][T][2]
     const double *pan;
     double *mixpart;
+    // which tile renderer a call takes is decided ON THE DEVICE when it depends on device state (the carried-in grains of a
+    // maxiTimeStretch on the integer grid: granular_unit_check_kernel writes *sel = 0 if K8c applies): both renderers are
+    // enqueued and the one whose `want` differs from *sel returns at once -- no read-back, no host synchronisation
+    const int *sel;
+    int want;
 };
+__device__ __forceinline__ bool unit_args_skip(const UnitArgs &A) { return A.sel && (*A.sel != 0) != (A.want != 0); }
 
 __device__ __forceinline__ long long unit_index(long long t, long long len) {  // t mod len, result in [0,len)
     while (t >= len) t -= len;
@@ -590,6 +596,7 @@ __device__ __forceinline__ void tile_epilogue(const UnitArgs &A, const double *s
 }
 
 __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
+    if (unit_args_skip(A)) return;
     __shared__ double s_tile[64 * 65];
     __shared__ int s_base[64 * kCand];  // buffer index the grain reads at the tile's first sample (mod len)
     __shared__ int s_kd[64 * kCand];    // bits 0-15: k0 + 64 (window index at the tile's first sample; k0 > -64),
@@ -850,6 +857,7 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
 
 // grains alive after sample T-1, creation order, closed form (one lane per stream)
 __global__ __launch_bounds__(64) void granular_unit_state_kernel(UnitArgs A) {
+    if (unit_args_skip(A)) return;
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t S = A.S;
     if (s >= S) return;
@@ -941,6 +949,7 @@ constexpr int kLineTiles = 4;  // consecutive tiles per workgroup: the anchors a
 constexpr int kLineBatch = 4;  // pairs whose gathers are in flight together (4 / 8 / 16 measured: 0.54 / 0.60 / 0.87 ms per slice)
 
 __global__ __launch_bounds__(256) void granular_line_kernel(UnitArgs A) {
+    if (unit_args_skip(A)) return;
     __shared__ double s_tile[64 * 65];
     __shared__ LineCand s_cand[64 * kCand];
     __shared__ int s_cnt[64];
@@ -1176,6 +1185,7 @@ __global__ __launch_bounds__(256) void granular_line_kernel(UnitArgs A) {
 
 // grains alive after sample T-1, creation order (one lane per stream): positions by the exact multi-step advance
 __global__ __launch_bounds__(64) void granular_line_state_kernel(UnitArgs A) {
+    if (unit_args_skip(A)) return;
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t S = A.S;
     if (s >= S) return;
@@ -1310,6 +1320,12 @@ int mxg_grain_plan_window(const mxg_grain_plan *p, double *h_window) {
     return (int)p->sampleDur;
 }
 
+// forwards a render's error word (0 = fine) to the library's async error word (mxg_common.h)
+__global__ void grain_err_publish_kernel(const int *err, int *async_word) {
+    const int e = *err;
+    if (e && async_word) __hip_atomic_store(async_word, (int)mxg::ASYNC_GRAIN_BASE + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, size_t T, const double *d_samples,
                                 size_t len, int overlaps, const double *d_a, const double *d_b,
                                 const double *d_posmod, const int32_t *d_rnd, size_t R, double *d_st, double *d_gst,
@@ -1376,6 +1392,12 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         // carried-in grains on the integer grid too, a window index that exists for every read
         bool unit = false;
         // (maxiTimeStretch::play and playAtPosition spawn every grain with speed +-1; maxiStretch / maxiPitchShift do not)
+        // `both`: the static conditions for K8c hold and whether the carried-in grains allow it is only known on the device:
+        // K8c and K8d are both enqueued, predicated on the check kernel's word (UnitArgs::sel).  Only with the K8d knob off
+        // (A/B runs) the word is read back and the host picks, as before.
+        bool both = false;
+        const bool line_ok = tune_get("grain_line") && T < (size_t)1 << 30 && len >= 128 && len < ((size_t)1 << 31) - 128 &&
+                             p->sampleDur < 32768;
         if ((mode == 0 || mode == 2) && tune_get("grain_unit") && T < (size_t)1 << 30 && len >= 128 && len < ((size_t)1 << 31) - 128 &&
             p->sampleDur < 32000) {
             const double frequency = (1.0 / p->grainLength) * 1.0;
@@ -1384,10 +1406,15 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
                 MXG_HIP(hipMemsetAsync(g_err + 1, 0, sizeof(int), st));
                 hipLaunchKernelGGL(granular_unit_check_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, S,
                                    (const double *)d_gst, (double)len, A.sampleDur, g_err + 1);
-                int bad = 1;
-                MXG_HIP(hipMemcpyAsync(&bad, g_err + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-                MXG_HIP(hipStreamSynchronize(st));
-                unit = bad == 0;
+                if (line_ok && !tune_get("grain_sync")) {
+                    both = true;
+                    unit = true;
+                } else {
+                    int bad = 1;
+                    MXG_HIP(hipMemcpyAsync(&bad, g_err + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+                    MXG_HIP(hipStreamSynchronize(st));
+                    unit = bad == 0;
+                }
             }
         }
         size_t C = (T + 255) / 256;
@@ -1396,7 +1423,9 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         if (C < 1) C = 1;
         size_t Tc = (T + C - 1) / C;
         // K8d (tile render for arbitrary increments) takes what K8c cannot: any mode, any increment
-        const bool line = !unit && tune_get("grain_line") && T < (size_t)1 << 30 && len >= 128 && len < ((size_t)1 << 31) - 128;
+        // (grain ages travel as 16-bit values in its candidate metadata and carried-in grains are only looked for over the first
+        // 32 768 samples: a grain of 32 768 samples or more -- 0.4 s at 96 kHz -- takes the (stream, chunk) walk K8b)
+        const bool line = !unit && line_ok;
         if (unit || line) Tc = 64;  // K8c / K8d tiles are 64 samples; the chunk table is indexed per tile
         C = (T + Tc - 1) / Tc;
         const double minCycle = A.cycleLength;  // randomOffset >= 0 only lengthens a cycle
@@ -1428,6 +1457,8 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         U.c0 = 0;
         U.pan = nullptr;
         U.mixpart = nullptr;
+        U.sel = both ? g_err + 1 : nullptr;
+        U.want = 0;
         const size_t stiles = (S + 63) / 64;
         if ((unit || line) && d_pan) {
             if (int e = scratch_get(SCR_GRAIN_MIX, st, sizeof(double) * stiles * T * 2, (void **)&U.mixpart)) return e;
@@ -1476,10 +1507,14 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
                 MXG_HIP(hipStreamWaitEvent(g_aux, g_aux_ev[i], 0));
                 U.c0 = (unsigned)ci;
                 if (unit) {
+                    U.want = 0;
+                    U.cend = (unsigned)C;
                     KernelTimer kt("granular_unit_kernel", g_aux);
                     hipLaunchKernelGGL(granular_unit_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)(cn - ci)), dim3(256), 0,
                                        g_aux, U);
-                } else {
+                }
+                if (!unit || both) {
+                    U.want = 1;
                     U.cend = (unsigned)cn;
                     KernelTimer kt("granular_line_kernel", g_aux);
                     hipLaunchKernelGGL(granular_line_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)((cn - ci + lt - 1) / lt)),
@@ -1488,10 +1523,14 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
             }
             MXG_HIP(hipEventRecord(g_aux_done, g_aux));
             MXG_HIP(hipStreamWaitEvent(st, g_aux_done, 0));
-            if (unit)
+            if (unit) {
+                U.want = 0;
                 hipLaunchKernelGGL(granular_unit_state_kernel, grid, dim3(64), 0, st, U);
-            else
+            }
+            if (!unit || both) {
+                U.want = 1;
                 hipLaunchKernelGGL(granular_line_state_kernel, grid, dim3(64), 0, st, U);
+            }
             if (U.pan) {
                 hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((T * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, stiles,
                                    T * 2, U.mixpart, d_mix);
@@ -1508,17 +1547,27 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         }
         }
         if (unit) {
+            U.want = 0;
             {
                 KernelTimer kt("granular_unit_kernel", st);
                 hipLaunchKernelGGL(granular_unit_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)C), dim3(256), 0, st, U);
             }
             hipLaunchKernelGGL(granular_unit_state_kernel, grid, dim3(64), 0, st, U);
+            if (both) {
+                U.want = 1;
+                {
+                    KernelTimer kt("granular_line_kernel", st);
+                    hipLaunchKernelGGL(granular_line_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)((C + lt - 1) / lt)), dim3(256), 0, st, U);
+                }
+                hipLaunchKernelGGL(granular_line_state_kernel, grid, dim3(64), 0, st, U);
+            }
             if (U.pan) {
                 hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((T * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, stiles,
                                    T * 2, U.mixpart, d_mix);
                 mixed = true;
             }
         } else if (line) {
+            U.want = 1;
             {
                 KernelTimer kt("granular_line_kernel", st);
                 hipLaunchKernelGGL(granular_line_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)((C + lt - 1) / lt)), dim3(256), 0, st, U);
@@ -1546,20 +1595,17 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
     if (d_pan && !mixed) {
         if (int e = mxg_mix_stereo(S, T, d_out, d_pan, d_mix, stream)) return e;
     }
+    if (!tune_get("grain_sync")) {
+        // deferred: the render's error word (1..5, below) is forwarded to the library's async error word by a one-lane kernel at
+        // the end of the stream's work; the next call of any entry point -- or the caller's next synchronising call -- returns
+        // it (mxg_last_async_error, include/maxigpu.h).  Nothing here blocks the host, and the whole sequence can be captured.
+        hipLaunchKernelGGL(grain_err_publish_kernel, dim3(1), dim3(1), 0, st, (const int *)g_err, async_error_word());
+        return check_hip(hipGetLastError(), "mxg_granular_render launch");
+    }
     int herr = 0;
     MXG_HIP(hipMemcpyAsync(&herr, g_err, sizeof(int), hipMemcpyDeviceToHost, st));
     MXG_HIP(hipStreamSynchronize(st));
-    if (herr == 1) return fail(MXG_ERR_INVALID, "mxg_granular_render: more than 8 grains alive in a stream");
-    if (herr == 2) return fail(MXG_ERR_INVALID, "mxg_granular_render: d_rnd exhausted (R too small)");
-    if (herr == 3) return fail(MXG_ERR_INVALID, "mxg_granular_render: internal spawn list overflow");
-    if (herr == 4)
-        return fail(MXG_ERR_INVALID,
-                    "mxg_granular_render: d_gst holds a live grain this plan could not have made (another grain length, or "
-                    "an index/position outside the window/sample); let live grains finish or clear d_gst first");
-    if (herr == 5)
-        return fail(MXG_ERR_INVALID,
-                    "mxg_granular_render: a grain was born with a NaN/Inf step or one longer than the sample (|speed| too "
-                    "large for this sample length); its reads would leave the buffer");
+    if (herr) return async_error_status(ASYNC_GRAIN_BASE + herr);
     return MXG_OK;
 }
 

@@ -74,6 +74,7 @@ enum AsyncError {
 };
 int *async_error_word();  // device-visible address of the word (valid after mxg_init)
 int async_error_poll();   // host: MXG_OK, or the pending error as a status (+ message), cleared
+int async_error_status(int code);  // the status + message of one code
 
 // ---- time parts: who may overwrite the state ----------------------------------------------------------------------
 // A kernel cut into gridDim.y time parts reads its per-voice state in EVERY part and stores the new state from ONE of them (the
@@ -136,21 +137,44 @@ __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nblk, int xcd
 }
 
 // ---- device store helpers ---------------------------------------------------------------
-template <bool NT>
+// Store flavours of the out[n*V + v] streams (measured with csrc/calib.hip, profiles/r03_write_ceiling.md): 0 plain,
+// 1 non-temporal, 2 write-through (`sc1`: the line leaves the XCD's L2 with the store instead of by eviction -- the fastest
+// 16-byte stream while a block is within a few times the Infinity Cache, no gain beyond).
+template <int ST>
 __device__ __forceinline__ void store1(double *p, double v) {
-    if constexpr (NT)
+    if constexpr (ST == 1)
         __builtin_nontemporal_store(v, p);
+    else if constexpr (ST == 2)
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
     else
         *p = v;
 }
 typedef double double2v __attribute__((ext_vector_type(2)));
-template <bool NT>
+template <int ST>
 __device__ __forceinline__ void store2(double *p, double a, double b) {
     double2v v = {a, b};
-    if constexpr (NT)
+    if constexpr (ST == 1)
         __builtin_nontemporal_store(v, reinterpret_cast<double2v *>(p));
+    else if constexpr (ST == 2)  // (the wait states a following write of the four data registers needs: hipcc does not add them after asm)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
     else
         *reinterpret_cast<double2v *>(p) = v;
+}
+// Two samples of one voice per lane -> one 16-byte store per lane: lanes 2k and 2k+1 (voices v, v+1) swap one value, so that
+// the even lane holds sample n of both voices (16 contiguous bytes of row n) and the odd lane sample n+1 of both (row n+1).
+// One wave store then covers 512 contiguous bytes in each of two rows with 16 bytes per lane.  `o` is the lane's own
+// pointer: out + (n + (lane & 1)) * V + (v & ~1); both lanes of a pair must be live (V even).
+template <int ST>
+__device__ __forceinline__ void store_pair_rows(double *o, double r0, double r1) {
+    const unsigned x0 = (unsigned)__double2loint(r0), x1 = (unsigned)__double2hiint(r0);
+    const unsigned y0 = (unsigned)__double2loint(r1), y1 = (unsigned)__double2hiint(r1);
+    constexpr int kQuadXor1 = 0xB1;  // quad_perm [1,0,3,2]
+    // a = r0 with the odd lanes replaced by the partner's r1; b = r1 with the even lanes replaced by the partner's r0
+    const unsigned a0 = (unsigned)__builtin_amdgcn_update_dpp((int)x0, (int)y0, kQuadXor1, 0xf, 0xA, false);
+    const unsigned a1 = (unsigned)__builtin_amdgcn_update_dpp((int)x1, (int)y1, kQuadXor1, 0xf, 0xA, false);
+    const unsigned b0 = (unsigned)__builtin_amdgcn_update_dpp((int)y0, (int)x0, kQuadXor1, 0xf, 0x5, false);
+    const unsigned b1 = (unsigned)__builtin_amdgcn_update_dpp((int)y1, (int)x1, kQuadXor1, 0xf, 0x5, false);
+    store2<ST>(o, __hiloint2double((int)a1, (int)a0), __hiloint2double((int)b1, (int)b0));
 }
 
 }  // namespace mxg

@@ -53,7 +53,10 @@ __device__ __forceinline__ void load_tab(double *s_tab) {  // (the caller synchr
 }
 
 // K1: one lane = VPL adjacent voices; the N-sample recurrence runs in registers.
-template <int WF, bool FPS, int VPL, bool NT>
+// ST: store flavour (mxg_common.h: 0 plain, 1 nt, 2 sc1).  PX (VPL = 1): two samples per lane pair leave as one 16-byte store per
+// lane (store_pair_rows) -- every SIMD keeps its own wavefront of voices, and the store stream is the 16-byte one that the
+// calibration kernels measure fastest.
+template <int WF, bool FPS, int VPL, int ST, bool PX>
 __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
                            const double *__restrict__ p1, const double *__restrict__ p2,
                            double *__restrict__ phase_io, double *__restrict__ hold_io,
@@ -114,34 +117,40 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
         for (int j = 0; j < VPL; j++) ok = ok && q[j].inc >= 0.0 && q[j].inc <= 1.0 && ph[j] >= 0.0 && ph[j] <= 2.0;
         trust = __all(ok);
     }
-    if (trust) {
-#pragma unroll MXG_OSC_UNROLL
-        for (size_t n = nA; n < nB; n++) {
-            double r[VPL];
-#pragma unroll
-            for (int j = 0; j < VPL; j++) r[j] = osc_tick<WF, true>(ph[j], hd[j], q[j], s_tab, s_tab);
-            if constexpr (VPL == 2)
-                store2<NT>(o, r[0], r[1]);
-            else
-                store1<NT>(o, r[0]);
-            o += V;
+    auto run = [&](auto trust_tag) {
+        constexpr bool kTrust = decltype(trust_tag)::value;
+        size_t n = nA;
+        if constexpr (PX && VPL == 1 && !FPS) {
+            double *op = out + (nA + (threadIdx.x & 1)) * V + (v0 & ~(size_t)1);
+#pragma unroll 2
+            for (; n + 2 <= nB; n += 2) {
+                const double r0 = osc_tick<WF, kTrust>(ph[0], hd[0], q[0], s_tab, s_tab);
+                const double r1 = osc_tick<WF, kTrust>(ph[0], hd[0], q[0], s_tab, s_tab);
+                store_pair_rows<ST>(op, r0, r1);
+                op += 2 * V;
+            }
+            o = out + n * V + v0;
         }
-    } else {
 #pragma unroll MXG_OSC_UNROLL
-        for (size_t n = nA; n < nB; n++) {
+        for (; n < nB; n++) {
             double r[VPL];
 #pragma unroll
             for (int j = 0; j < VPL; j++) {
                 if constexpr (FPS) q[j] = osc_pre<WF>(fp[j], sr, q[j].p1, q[j].p2);
-                r[j] = osc_tick<WF>(ph[j], hd[j], q[j], s_tab, s_tab);
+                r[j] = osc_tick<WF, kTrust>(ph[j], hd[j], q[j], s_tab, s_tab);
             }
             if constexpr (VPL == 2)
-                store2<NT>(o, r[0], r[1]);
+                store2<ST>(o, r[0], r[1]);
             else
-                store1<NT>(o, r[0]);
+                store1<ST>(o, r[0]);
             o += V;
             if constexpr (FPS) fp += V;
         }
+    };
+    if constexpr ((WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE) && !FPS) {
+        if (trust) run(std::true_type{}); else run(std::false_type{});
+    } else {
+        run(std::false_type{});
     }
     if (blockIdx.y + 1 == gridDim.y && part_wait(part_ctr, psync)) {
 #pragma unroll
@@ -297,27 +306,35 @@ osc_mix_fn pick_mix_wf(int wf, bool store, int var) {
 typedef void (*osc_fn)(size_t, size_t, const double *, const double *, const double *, double *,
                        double *, double *, double, PartSync, int);
 
+// store: 0 plain 8 B, 1 nt 8 B, 2 pair rows (16 B) plain, 3 pair rows sc1, 4 pair rows nt      (one voice per lane)
+//        0 plain 16 B, 1 nt 16 B, 2 sc1 16 B                                                  (two voices per lane)
 template <int WF>
-osc_fn pick(bool fps, int vpl, bool nt) {
-    if (fps) return osc_kernel<WF, true, 1, false>;
-    if (vpl == 2) return nt ? osc_kernel<WF, false, 2, true> : osc_kernel<WF, false, 2, false>;
-    return nt ? osc_kernel<WF, false, 1, true> : osc_kernel<WF, false, 1, false>;
+osc_fn pick(bool fps, int vpl, int store) {
+    if (fps) return osc_kernel<WF, true, 1, 0, false>;
+    if (vpl == 2) return store == 2 ? osc_kernel<WF, false, 2, 2, false> : (store == 1 ? osc_kernel<WF, false, 2, 1, false> : osc_kernel<WF, false, 2, 0, false>);
+    switch (store) {
+        case 1: return osc_kernel<WF, false, 1, 1, false>;
+        case 2: return osc_kernel<WF, false, 1, 0, true>;
+        case 3: return osc_kernel<WF, false, 1, 2, true>;
+        case 4: return osc_kernel<WF, false, 1, 1, true>;
+        default: return osc_kernel<WF, false, 1, 0, false>;
+    }
 }
 
-osc_fn pick_wf(int wf, bool fps, int vpl, bool nt) {
+osc_fn pick_wf(int wf, bool fps, int vpl, int store) {
     switch (wf) {
-        case 0: return pick<0>(fps, vpl, nt);
-        case 1: return pick<1>(fps, vpl, nt);
-        case 2: return pick<2>(fps, vpl, nt);
-        case 3: return pick<3>(fps, vpl, nt);
-        case 4: return pick<4>(fps, vpl, nt);
-        case 5: return pick<5>(fps, vpl, nt);
-        case 6: return pick<6>(fps, vpl, nt);
-        case 7: return pick<7>(fps, vpl, nt);
-        case 8: return pick<8>(fps, vpl, nt);
-        case 9: return pick<9>(fps, vpl, nt);
-        case 10: return pick<10>(fps, vpl, nt);
-        case 11: return pick<11>(fps, vpl, nt);
+        case 0: return pick<0>(fps, vpl, store);
+        case 1: return pick<1>(fps, vpl, store);
+        case 2: return pick<2>(fps, vpl, store);
+        case 3: return pick<3>(fps, vpl, store);
+        case 4: return pick<4>(fps, vpl, store);
+        case 5: return pick<5>(fps, vpl, store);
+        case 6: return pick<6>(fps, vpl, store);
+        case 7: return pick<7>(fps, vpl, store);
+        case 8: return pick<8>(fps, vpl, store);
+        case 9: return pick<9>(fps, vpl, store);
+        case 10: return pick<10>(fps, vpl, store);
+        case 11: return pick<11>(fps, vpl, store);
     }
     return nullptr;
 }
@@ -346,7 +363,12 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     const int nt_knob = tune_get("osc_nt");
     const size_t out_bytes = V * N * sizeof(double);
     bool nt = nt_knob == 1 || (nt_knob == 2 && out_bytes > ((size_t)300 << 20) && out_bytes <= ((size_t)1200 << 20));
-    osc_fn fn = pick_wf(waveform, fps != 0, vpl, nt);
+    // the store stream (pick<WF>): knob osc_store >= 0 names it, -1 (default) = by bank size (osc_store_auto below)
+    int store = tune_get("osc_store");
+    if (store < 0) store = nt ? 1 : 0;
+    if (vpl == 2 && store > 2) store = 0;
+    if (vpl == 1 && store >= 2 && (fps || (V & 1) || (((uintptr_t)d_out) & 15))) store = store == 4 ? 1 : 0;  // pair rows need whole pairs
+    osc_fn fn = pick_wf(waveform, fps != 0, vpl, store);
     size_t lanes = (V + vpl - 1) / vpl;
     // time parts: only where the output dominates the recurrence (sinewave, coswave, sinebuf4) and the bank is too small to give
     // every SIMD two wavefronts by itself

@@ -30,8 +30,9 @@ struct Tune {
 Tune g_tune[] = {
     {"osc_vpl", 1, 1, 2},       {"osc_block", 256, 64, 1024},  {"osc_nt", 2, 0, 2},
     {"voice_vpl", 1, 1, 2},     {"voice_block", 256, 64, 1024}, {"voice_nt", 2, 0, 2},
-    {"part_spin_limit", 1 << 20, 1, 1 << 24},  // time parts: polls (x s_sleep 8) before the writer gives up and reports ASYNC_PART_TIMEOUT
+    {"part_spin_limit", 1048576, 1, 16777216},  // time parts: polls (x s_sleep 8) before the writer gives up and reports ASYNC_PART_TIMEOUT
     {"part_fault", 0, 0, 1},  // fault injection for the tests: the writer waits for one signal more than will ever come
+    {"osc_store", -1, -1, 4},  // K1 store stream (osc.hip pick<WF>): -1 automatic; one voice per lane: 0 plain 8 B, 1 nt 8 B, 2 / 3 / 4 pair rows (16 B) plain / sc1 / nt; two voices per lane: 0 plain, 1 nt, 2 sc1
     {"osc_xcd", 0, 0, 1},  // K1: 1 = every XCD renders one contiguous eighth of the bank (workgroup renumbering, mxg_common.h)
     {"osc_split", 0, 0, 8},  // K1: time parts per voice group (0 = automatic: 4 for sinewave / coswave on small banks, else 1)
     {"osc_mix_var", 0, 0, 3},  // K1m A/B (sinebuf): 0 swap butterfly, window 512; 1 same, window 128; 2 DPP butterfly 128; 3 DPP 512
@@ -46,6 +47,7 @@ Tune g_tune[] = {
     {"grain_line", 1, 0, 1},  // K8d: tile render for arbitrary increments (0: the (stream, chunk) walk K8b)
     {"grain_unit", 1, 0, 1},  // K8c: coalesced closed-form render when every grain has inc = +-1
     {"grain_fast_sched", 1, 0, 1},  // K8a: event-driven exact multi-step scheduler (0: one step at a time)
+    {"grain_sync", 0, 0, 1},  // 1: mxg_granular_render reads its error word back before it returns (the round-1/2 behaviour); 0: deferred
     {"grain_slices", 4, 1, 16},  // K8a/K8c: time slices of a maxiTimeStretch call (scheduling of slice i+1 overlaps render of slice i)
     {"mfcc_mfma_fullk", 0, 0, 1},  // K7b: contract over all numBins bins (1) instead of the bins that carry weight
     {"fused_waves16", 0, 0, 1},  // K67: 1 = the 16-waves-per-CU form of the fused FFT+MFCC kernel when applicable (measured slower: 1.72 vs 1.51 ms)
@@ -106,31 +108,36 @@ bool g_part_dirty = false;    // a part time-out left counters non-zero: zero th
 
 int *async_error_word() { return g_async_dev; }
 
+int async_error_status(int code) {
+    if (code == ASYNC_OK) return MXG_OK;
+    if (code == ASYNC_PART_TIMEOUT) {
+        g_part_dirty = true;
+        return fail(MXG_ERR_HIP, "asynchronous device error: a time-split kernel (osc / sample *AtSpeed) timed out waiting for its "
+                                 "sibling parts; the per-voice state of that launch was not stored");
+    }
+    switch (code - ASYNC_GRAIN_BASE) {
+        case 1: return fail(MXG_ERR_INVALID, "mxg_granular_render: more than 8 grains alive in a stream");
+        case 2: return fail(MXG_ERR_INVALID, "mxg_granular_render: d_rnd exhausted (R too small)");
+        case 3: return fail(MXG_ERR_INVALID, "mxg_granular_render: internal spawn list overflow");
+        case 4:
+            return fail(MXG_ERR_INVALID,
+                        "mxg_granular_render: d_gst holds a live grain this plan could not have made (another grain length, or "
+                        "an index/position outside the window/sample); let live grains finish or clear d_gst first");
+        case 5:
+            return fail(MXG_ERR_INVALID,
+                        "mxg_granular_render: a grain was born with a NaN/Inf step or one longer than the sample (|speed| too "
+                        "large for this sample length); its reads would leave the buffer");
+        default: break;
+    }
+    return fail(MXG_ERR_HIP, "asynchronous device error %d", code);
+}
+
 int async_error_poll() {
     if (!g_async_host) return MXG_OK;
     const int code = __atomic_load_n(g_async_host, __ATOMIC_ACQUIRE);
     if (code == ASYNC_OK) return MXG_OK;
     __atomic_store_n(g_async_host, 0, __ATOMIC_RELEASE);
-    if (code == ASYNC_PART_TIMEOUT) {
-        g_part_dirty = true;
-        return fail(MXG_ERR_HIP, "asynchronous device error from an earlier launch: a time-split kernel (osc / sample *AtSpeed) timed out "
-                                 "waiting for its sibling parts; the per-voice state of that launch was not stored");
-    }
-    switch (code - ASYNC_GRAIN_BASE) {
-        case 1: return fail(MXG_ERR_INVALID, "mxg_granular_render (earlier launch): more than 8 grains alive in a stream");
-        case 2: return fail(MXG_ERR_INVALID, "mxg_granular_render (earlier launch): d_rnd exhausted (R too small)");
-        case 3: return fail(MXG_ERR_INVALID, "mxg_granular_render (earlier launch): internal spawn list overflow");
-        case 4:
-            return fail(MXG_ERR_INVALID,
-                        "mxg_granular_render (earlier launch): d_gst holds a live grain this plan could not have made (another grain "
-                        "length, or an index/position outside the window/sample); let live grains finish or clear d_gst first");
-        case 5:
-            return fail(MXG_ERR_INVALID,
-                        "mxg_granular_render (earlier launch): a grain was born with a NaN/Inf step or one longer than the sample "
-                        "(|speed| too large for this sample length); its reads would leave the buffer");
-        default: break;
-    }
-    return fail(MXG_ERR_HIP, "asynchronous device error %d from an earlier launch", code);
+    return async_error_status(code);
 }
 
 int part_sync_get(hipStream_t st, size_t wavefronts, int parts, PartSync *out) {

@@ -697,10 +697,12 @@ double *mxg_sample_upload(const double *h_samples, size_t len) {
     double *base = nullptr;
     const size_t total = len + kSmpGuardLo + kSmpGuardHi;  // layout: mxg_smp.h
     if (check_hip(hipMalloc(&base, total * sizeof(double)), "hipMalloc(sample)")) return nullptr;
-    if (check_hip(hipMemset(base, 0, total * sizeof(double)), "hipMemset(sample)")) return nullptr;
-    if (len && check_hip(hipMemcpy(base + kSmpGuardLo, h_samples, len * sizeof(double), hipMemcpyHostToDevice),
-                         "hipMemcpy(sample)"))
+    if (check_hip(hipMemset(base, 0, total * sizeof(double)), "hipMemset(sample)") ||
+        (len && check_hip(hipMemcpy(base + kSmpGuardLo, h_samples, len * sizeof(double), hipMemcpyHostToDevice),
+                          "hipMemcpy(sample)"))) {
+        (void)hipFree(base);  // (the message of the failed call stays in mxg_last_error)
         return nullptr;
+    }
     return base + kSmpGuardLo;
 }
 

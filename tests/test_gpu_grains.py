@@ -85,11 +85,21 @@ def test_granular_errors(mx, chunked):
     rng = np.random.default_rng(3)
     smp = rng.uniform(-1, 1, 5000)
     bank = make_bank(mx, 0, "hann", smp, 4)
-    with pytest.raises(mx.MaxiGpuError):
-        bank.play(1.0, 0.2, 12, 8000)       # > 8 live grains
+    # errors a kernel detects are deferred (mxg_last_async_error, include/maxigpu.h): the render call only enqueues; the
+    # failure is the status of the next synchronising call -- here the download of the block
+    with pytest.raises(mx.MaxiGpuError, match="more than 8 grains"):
+        bank.play(1.0, 0.2, 12, 8000).numpy()       # > 8 live grains
+    assert mx.lib().mxg_last_async_error() == 0     # reported once
     bank = make_bank(mx, 0, "hann", smp, 4)
-    with pytest.raises(mx.MaxiGpuError):
-        bank.play(1.0, 0.05, 4, 4000, rnd=np.zeros((4, 2), np.int32))  # rand queue exhausted
+    with pytest.raises(mx.MaxiGpuError, match="d_rnd exhausted"):
+        bank.play(1.0, 0.05, 4, 4000, rnd=np.zeros((4, 2), np.int32)).numpy()  # rand queue exhausted
+    prev = mx.lib().mxg_tune(b"grain_sync", 1)      # the synchronous form returns it from the call itself
+    try:
+        bank = make_bank(mx, 0, "hann", smp, 4)
+        with pytest.raises(mx.MaxiGpuError, match="more than 8 grains"):
+            bank.play(1.0, 0.2, 12, 8000)
+    finally:
+        mx.lib().mxg_tune(b"grain_sync", prev)
     with pytest.raises(ValueError):
         make_bank(mx, 0, "hann", smp, 4).play(1.0, 0.7, 4, 10)         # grain > 500 ms
 
@@ -339,9 +349,9 @@ def test_foreign_or_corrupt_live_grains_are_refused(mx, mode):
                 bank.grains.upload(g)
                 with pytest.raises(mx.MaxiGpuError, match="could not have made"):
                     if mode == 0:
-                        bank.play(speed, 0.05, 4, T)
+                        bank.play(speed, 0.05, 4, T).numpy()
                     else:
-                        bank.play(speed, speed, 0.05, 4, T)
+                        bank.play(speed, speed, 0.05, 4, T).numpy()
                 bank.grains.upload(good)                               # the same call with a clean state works
                 o = (bank.play(speed, 0.05, 4, T) if mode == 0 else bank.play(speed, speed, 0.05, 4, T)).numpy()
                 assert np.isfinite(o).all(), what
@@ -425,3 +435,55 @@ def test_tile_render_lines_and_their_exceptions(mx, port, mode, Ls):
         assert_bits_equal(bank.state.numpy(), st, "scheduler state")
         assert_bits_equal(bank.grains.numpy(), gst, "live grains")
 
+
+
+def test_config5_render_is_asynchronous_and_graph_capturable(mx):
+    """mxg_granular_render_mix (maxiTimeStretch + fused stereo mixdown: the config-5 step) makes no synchronising HIP call --
+    the path choice that depends on device state is taken on the device, errors are deferred (mxg_last_async_error) -- so its
+    launch sequence, fork / join onto the library's auxiliary stream included, can be captured into a hipGraph.  K replays
+    must leave the outputs, the scheduler state and the live grains of K eager calls."""
+    import torch
+    L = mx.lib()
+    S, T, Ls, K = 256, 4096, 200000, 3
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    smp = rng.uniform(-1, 1, Ls)
+    sb = mx.maxiSampleBank(1)
+    sb.setSample(smp)
+    speed = torch.from_numpy(0.25 + 1.5 * (np.arange(S) % 97) / 96).to(dev)
+    pan = torch.from_numpy(np.arange(S) / (S - 1.0)).to(dev)
+    plan = L.mxg_grain_plan_create(0, 0.05, 44100)
+    assert plan
+
+    def fresh():
+        st0 = np.zeros((4, S))
+        st0[0] = np.arange(S) / S * Ls
+        return (torch.from_numpy(st0).to(dev), torch.zeros((4, 8, S), dtype=torch.float64, device=dev),
+                torch.empty((T, S), dtype=torch.float64, device=dev), torch.zeros((T, 2), dtype=torch.float64, device=dev))
+
+    def call(st, state, grains, out, mix):
+        assert L.mxg_granular_render_mix(plan, 0, S, T, sb.d_samples, Ls, 4, speed.data_ptr(), None, None, None, 0,
+                                         state.data_ptr(), grains.data_ptr(), out.data_ptr(), pan.data_ptr(), mix.data_ptr(), st) == 0
+
+    s = torch.cuda.Stream(device=dev)
+    st = s.cuda_stream
+    e = fresh()
+    with torch.cuda.stream(s):
+        for _ in range(K):
+            call(st, *e)
+    s.synchronize()
+    assert L.mxg_last_async_error() == 0
+    g_state, warm = fresh(), fresh()
+    with torch.cuda.stream(s):
+        call(st, *warm)                      # allocates the library's per-stream scratch and its auxiliary stream
+    s.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        call(st, *g_state)
+    for _ in range(K):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert L.mxg_last_async_error() == 0
+    for i, what in enumerate(("scheduler state", "live grains", "last block", "last mix")):
+        assert torch.equal(g_state[i], e[i]), what
+    L.mxg_grain_plan_destroy(plan)

@@ -104,6 +104,31 @@ def test_tuning_does_not_change_results(mx, port, vpl, nt, block):
         L.mxg_tune(b"osc_vpl", prev[0]); L.mxg_tune(b"osc_nt", prev[1]); L.mxg_tune(b"osc_block", prev[2])
 
 
+@pytest.mark.parametrize("vpl,store,block,xcd", [(1, 2, 256, 0), (1, 3, 256, 1), (1, 4, 128, 0), (1, 3, 64, 0), (2, 2, 256, 1),
+                                                 (2, 0, 512, 1), (1, 0, 256, 1), (1, 3, 1024, 1)])
+@pytest.mark.parametrize("V,N", [(4096 + 2, 301), (512, 2), (8192, 64), (4097, 33)])
+def test_store_streams_do_not_change_results(mx, port, vpl, store, block, xcd, V, N):
+    """The store stream of K1 is a launch knob (osc_store: 8-byte plain / nt, the 16-byte pair-row exchange in three flavours,
+    16-byte stores of two voices per lane; osc_xcd: XCD-contiguous workgroup numbering): every choice must give the oracle's
+    bits, odd block lengths (a trailing single row), odd banks (pair rows fall back to 8-byte stores) and time parts included."""
+    L = mx.lib()
+    prev = [L.mxg_tune(b"osc_vpl", vpl), L.mxg_tune(b"osc_store", store), L.mxg_tune(b"osc_block", block), L.mxg_tune(b"osc_xcd", xcd)]
+    try:
+        rng = np.random.default_rng(V + N)
+        freq = rng.uniform(20, 20000, V)
+        for wf in (8, 9, 2, 0):
+            out, ph, hd = _render(mx, wf, freq, N, blocks=2)
+            eo, eph, _ = port.osc(wf, freq, 2 * N)
+            if wf == 0:
+                assert ulp_diff(out, eo).max() <= TRIG_MAX_ULP
+            else:
+                assert_bits_equal(out, eo, OSC[wf])
+            assert_bits_equal(ph, eph)
+    finally:
+        L.mxg_tune(b"osc_vpl", prev[0]); L.mxg_tune(b"osc_store", prev[1]); L.mxg_tune(b"osc_block", prev[2])
+        L.mxg_tune(b"osc_xcd", prev[3])
+
+
 def test_empty_and_invalid(mx):
     L = mx.lib()
     bank = mx.maxiOscBank(4)

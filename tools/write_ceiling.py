@@ -82,11 +82,12 @@ def variants_for(V):
             fill("cols w%d %s blk256" % (w, FLAV[fl]), w, fl, 1, 256)
     for blk in (128, 512, 1024):
         fill("cols w8 plain blk%d" % blk, 8, 0, 1, blk)
-        fill("cols w8 nt blk%d" % blk, 8, 1, 1, blk)
-    for blk in (256, 1024):
+    for blk in (256,):
         fill("cols w8 plain blk%d xcd" % blk, 8, 0, 1, blk, xcd=1)
-        fill("cols w8 nt blk%d xcd" % blk, 8, 1, 1, blk, xcd=1)
         fill("cols w16 plain blk%d xcd" % blk, 16, 0, 1, blk, xcd=1)
+        fill("cols w16 sc1 blk%d xcd" % blk, 16, 2, 1, blk, xcd=1)
+    fill("cols w16 sc1 blk512", 16, 2, 1, 512)
+    fill("cols w16 plain blk512", 16, 0, 1, 512)
     fill("cols w8 plain blk256 halves", 8, 0, 2, 256)
     fill("cols w8 plain blk256 same", 8, 0, 1, 256, rot=False)
     fill("cols w8 nt blk256 same", 8, 1, 1, 256, rot=False)
@@ -96,22 +97,28 @@ def variants_for(V):
     phase, hold = mx.DeviceBuffer(V), mx.DeviceBuffer(V)
     keep = (freq, phase, hold)
 
-    def k1(name, vpl, nt, blk, xcd=0, rot=True, wf=8):
+    STORE1 = {0: "8B plain", 1: "8B nt", 2: "pair-rows 16B plain", 3: "pair-rows 16B sc1", 4: "pair-rows 16B nt"}
+    STORE2 = {0: "16B plain", 1: "16B nt", 2: "16B sc1"}
+
+    def k1(name, vpl, store, blk, xcd=0, rot=True, wf=8):
         def f(i):
-            L.mxg_tune(b"osc_vpl", vpl); L.mxg_tune(b"osc_nt", nt); L.mxg_tune(b"osc_block", blk); L.mxg_tune(b"osc_xcd", xcd)
+            L.mxg_tune(b"osc_vpl", vpl); L.mxg_tune(b"osc_store", store); L.mxg_tune(b"osc_block", blk); L.mxg_tune(b"osc_xcd", xcd)
             chk(L.mxg_osc_render(wf, V, B, freq.ptr, 0, None, None, phase.ptr, hold.ptr, region(rot), None), name)
         out[name] = f
-    for vpl in (1, 2):
-        for nt in (0, 1):
-            for blk in (256, 512, 1024):
-                k1("K1 sinebuf vpl%d %s blk%d" % (vpl, "nt" if nt else "plain", blk), vpl, nt, blk)
-    for nt in (0, 1):
-        k1("K1 sinebuf vpl1 %s blk256 xcd" % ("nt" if nt else "plain"), 1, nt, 256, xcd=1)
-        k1("K1 sinebuf vpl1 %s blk1024 xcd" % ("nt" if nt else "plain"), 1, nt, 1024, xcd=1)
-    k1("K1 sinebuf default knobs", 1, 2, 256)
-    k1("K1 sinebuf default knobs same", 1, 2, 256, rot=False)
-    k1("K1 sinebuf4 default knobs", 1, 2, 256, wf=9)
-    k1("K1 saw default knobs", 1, 2, 256, wf=2)
+    for xcd in (0, 1):
+        for st, nm in STORE1.items():
+            k1("K1 sinebuf 1v/lane %s blk256%s" % (nm, " xcd" if xcd else ""), 1, st, 256, xcd)
+        for st, nm in STORE2.items():
+            for blk in (256, 512):
+                k1("K1 sinebuf 2v/lane %s blk%d%s" % (nm, blk, " xcd" if xcd else ""), 2, st, blk, xcd)
+    k1("K1 sinebuf 1v/lane pair-rows 16B sc1 blk128", 1, 3, 128)
+    k1("K1 sinebuf 1v/lane pair-rows 16B plain blk512", 1, 2, 512)
+    k1("K1 sinebuf default knobs", 1, -1, 256)
+    k1("K1 sinebuf default knobs same", 1, -1, 256, rot=False)
+    k1("K1 sinebuf4 default knobs", 1, -1, 256, wf=9)
+    k1("K1 sinebuf4 pair-rows 16B sc1", 1, 3, 256, wf=9)
+    k1("K1 saw default knobs", 1, -1, 256, wf=2)
+    k1("K1 saw pair-rows 16B sc1", 1, 3, 256, wf=2)
     return out, nbytes, keep
 
 
@@ -148,7 +155,7 @@ for V in [int(x) for x in args.voices.split(",")]:
         emit("| %s | %.1f | %.1f | %.0f | %.3f |" % (k, med * 1e3, mn * 1e3, gbs, gbs / 8000))
         if "same" in k:
             continue
-        if k.startswith("K1 sinebuf vpl") or k == "K1 sinebuf default knobs":
+        if k.startswith("K1 sinebuf 1v") or k.startswith("K1 sinebuf 2v") or k == "K1 sinebuf default knobs":
             if best_k1 is None or med < best_k1[1]:
                 best_k1 = (k, med)
         elif not k.startswith("K1"):
@@ -157,7 +164,7 @@ for V in [int(x) for x in args.voices.split(",")]:
     d = float(np.median(res["K1 sinebuf default knobs"]))
     summary.append((V, nbytes, best_fill, best_k1, d))
     # knobs back to their defaults
-    L.mxg_tune(b"osc_vpl", 1); L.mxg_tune(b"osc_nt", 2); L.mxg_tune(b"osc_block", 256); L.mxg_tune(b"osc_xcd", 0)
+    L.mxg_tune(b"osc_vpl", 1); L.mxg_tune(b"osc_store", -1); L.mxg_tune(b"osc_block", 256); L.mxg_tune(b"osc_xcd", 0)
     del keep
 
 emit()
