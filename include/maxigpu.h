@@ -124,7 +124,7 @@ int mxg_prof_read(int index, const char **h_label, double *h_total_ms, size_t *h
 int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
 
 /* ---- tuning knobs (performance only; results are identical for every setting) ---------- */
-/* key: "osc_vpl" (voices per lane 1|2), "osc_block" (64..1024), "osc_nt" (non-temporal stores: 0 never, 1 always, 2 by the size of the output block),
+/* key: "osc_vpl" (voices per lane: 0 automatic, 1|2), "osc_block" (64..1024), "osc_nt" (non-temporal stores: 0 never, 1 always, 2 by the size of the output block),
  * "voice_block", "voice_nt" (as osc_nt), "mix_rows" (sample rows per workgroup of the mixdown, 1|2), "fft_generic",
  * "mfcc_tiled" (LDS-staged spectra 0|1), "grain_chunked" (time-sharded granular render 0|1), "grain_lanes_k",
  * "grain_unit" (coalesced unit-increment render 0|1), "grain_line" (tile render for arbitrary increments 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_slices" (time slices of a unit-path
@@ -138,7 +138,7 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "osc_store" (K1's store stream: -1 automatic by bank size; one voice per lane: 0 plain 8-byte stores, 1 non-temporal, 2 / 3 / 4 two
  * samples of a lane pair exchanged into one 16-byte store per lane, plain / write-through (sc1) / non-temporal; two voices per lane:
  * 0 plain, 1 non-temporal, 2 write-through 16-byte stores), "osc_xcd" (workgroups renumbered so that each of the eight XCDs renders
- * one contiguous eighth of the bank, 0|1), "grain_sync" (mxg_granular_render reads its error word back before it returns, 0|1;
+ * one contiguous eighth of the bank: -1 automatic, 0|1), "grain_sync" (mxg_granular_render reads its error word back before it returns, 0|1;
  * default 0: deferred, see mxg_last_async_error), "part_spin_limit" (polls a time-split kernel's writer part makes before it gives up
  * and reports through mxg_last_async_error), "part_fault" (test-only fault injection: that writer waits for a signal that never comes).
  * The tests flip every one of them and demand identical bits.  Returns the previous value or MXG_ERR_INVALID. */

@@ -166,15 +166,20 @@ __device__ __forceinline__ void store2(double *p, double a, double b) {
 // pointer: out + (n + (lane & 1)) * V + (v & ~1); both lanes of a pair must be live (V even).
 template <int ST>
 __device__ __forceinline__ void store_pair_rows(double *o, double r0, double r1) {
-    const unsigned x0 = (unsigned)__double2loint(r0), x1 = (unsigned)__double2hiint(r0);
-    const unsigned y0 = (unsigned)__double2loint(r1), y1 = (unsigned)__double2hiint(r1);
-    constexpr int kQuadXor1 = 0xB1;  // quad_perm [1,0,3,2]
-    // a = r0 with the odd lanes replaced by the partner's r1; b = r1 with the even lanes replaced by the partner's r0
-    const unsigned a0 = (unsigned)__builtin_amdgcn_update_dpp((int)x0, (int)y0, kQuadXor1, 0xf, 0xA, false);
-    const unsigned a1 = (unsigned)__builtin_amdgcn_update_dpp((int)x1, (int)y1, kQuadXor1, 0xf, 0xA, false);
-    const unsigned b0 = (unsigned)__builtin_amdgcn_update_dpp((int)y0, (int)x0, kQuadXor1, 0xf, 0x5, false);
-    const unsigned b1 = (unsigned)__builtin_amdgcn_update_dpp((int)y1, (int)x1, kQuadXor1, 0xf, 0x5, false);
-    store2<ST>(o, __hiloint2double((int)a1, (int)a0), __hiloint2double((int)b1, (int)b0));
+    const bool odd = (threadIdx.x & 1) != 0;
+    const int x0 = __double2loint(r0), x1 = __double2hiint(r0), y0 = __double2loint(r1), y1 = __double2hiint(r1);
+    constexpr int kQuadXor1 = 0xB1;  // quad_perm [1,0,3,2]: the partner lane (DPP bank masks select groups of four lanes, not a
+    // lane parity, so the parity is a select -- which hipcc folds with the DPP move into ONE v_cndmask_b32_dpp per dword)
+    // a = sample n of voice 2k:   the even lane's own r0 / for the odd lane (row n+1): the partner's r1
+    // b = sample n of voice 2k+1: the partner's r0      / the odd lane's own r1
+    // (the exchanges are evaluated by every lane BEFORE the selects: a DPP read under a divergent branch would see a masked partner)
+    const int py0 = __builtin_amdgcn_update_dpp(0, y0, kQuadXor1, 0xf, 0xf, true);
+    const int py1 = __builtin_amdgcn_update_dpp(0, y1, kQuadXor1, 0xf, 0xf, true);
+    const int px0 = __builtin_amdgcn_update_dpp(0, x0, kQuadXor1, 0xf, 0xf, true);
+    const int px1 = __builtin_amdgcn_update_dpp(0, x1, kQuadXor1, 0xf, 0xf, true);
+    const int a0 = odd ? py0 : x0, a1 = odd ? py1 : x1;
+    const int b0 = odd ? y0 : px0, b1 = odd ? y1 : px1;
+    store2<ST>(o, __hiloint2double(a1, a0), __hiloint2double(b1, b0));
 }
 
 }  // namespace mxg

@@ -354,20 +354,43 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     MXG_REQUIRE(waveform != MXG_OSC_PHASORBETWEEN || (d_p1 && d_p2),
                 "phasorBetween needs d_p1/d_p2 (start/end phase)");
     if (V == 0 || N == 0) return MXG_OK;
-    int vpl = tune_get("osc_vpl");
-    if (fps || (V & 1) || (((uintptr_t)d_out) & 15)) vpl = 1;
-    int block = tune_get("osc_block");
-    // non-temporal stores: a loss while the block fits the 256 MB Infinity Cache next to whatever reads it (65 536 voices: 42 -> 47 us)
-    // and a gain once it is two to four times that (131 072 voices x 512: 113 -> 99 us; 262 144: 217 -> 209; a 4 GB block: 815 -> 850),
-    // tools/sweep_osc_nt.py.  Knob 2 (default) = by the size of the block.
-    const int nt_knob = tune_get("osc_nt");
+    // ---- the store stream --------------------------------------------------------------------------------------------
+    // Knobs osc_vpl (0 = automatic), osc_store (-1 = automatic), osc_xcd (-1 = automatic) name it; left alone, it goes by the
+    // bank size, from the rotated-destination sweep of tools/sweep_osc_store.py (profiles/r03_osc_store.md), MI355X, 512-sample
+    // blocks, fraction of the 8 TB/s peak:
+    //   fewer than 131 072 voices (<= one wavefront per SIMD and voice): ONE voice per lane, two samples of a lane pair exchanged
+    //     into one write-through 16-byte store per lane (pair rows, sc1)               65 536 voices: 50 -> 42 us, 0.67 -> 0.80
+    //   from 131 072 voices: TWO voices per lane, write-through 16-byte stores        131 072 voices: 102 -> 86 us, 0.66 -> 0.78
+    //   from 196 608 voices also XCD-contiguous workgroup numbering                   262 144: 212 -> 189 us; 1 048 576: 816 -> 753 us
+    //   small blocks (< 64 MB: they live in the caches) keep plain 8-byte stores.
+    const bool pairs_ok = !fps && !(V & 1) && !(((uintptr_t)d_out) & 15);
     const size_t out_bytes = V * N * sizeof(double);
-    bool nt = nt_knob == 1 || (nt_knob == 2 && out_bytes > ((size_t)300 << 20) && out_bytes <= ((size_t)1200 << 20));
-    // the store stream (pick<WF>): knob osc_store >= 0 names it, -1 (default) = by bank size (osc_store_auto below)
-    int store = tune_get("osc_store");
-    if (store < 0) store = nt ? 1 : 0;
+    int vpl = tune_get("osc_vpl"), store = tune_get("osc_store"), xcd = tune_get("osc_xcd");
+    const bool automatic = vpl == 0 && store < 0;
+    if (automatic) {
+        vpl = 1;
+        store = 0;
+        if (pairs_ok && out_bytes >= ((size_t)64 << 20)) {
+            if (V >= 131072) {
+                vpl = 2;
+                store = 2;
+            } else {
+                store = 3;
+            }
+        }
+        if (xcd < 0) xcd = V >= 196608 ? 1 : 0;
+    } else {
+        if (vpl == 0) vpl = 1;
+        if (store < 0) {  // (the round-2 rule for 8-byte stores, knob osc_nt: non-temporal by block size)
+            const int nt_knob = tune_get("osc_nt");
+            store = (nt_knob == 1 || (nt_knob == 2 && out_bytes > ((size_t)300 << 20) && out_bytes <= ((size_t)1200 << 20))) ? 1 : 0;
+        }
+        if (xcd < 0) xcd = 0;
+    }
+    if (!pairs_ok) vpl = 1;
+    int block = tune_get("osc_block");
     if (vpl == 2 && store > 2) store = 0;
-    if (vpl == 1 && store >= 2 && (fps || (V & 1) || (((uintptr_t)d_out) & 15))) store = store == 4 ? 1 : 0;  // pair rows need whole pairs
+    if (vpl == 1 && store >= 2 && !pairs_ok) store = store == 4 ? 1 : 0;  // pair rows need whole pairs
     osc_fn fn = pick_wf(waveform, fps != 0, vpl, store);
     size_t lanes = (V + vpl - 1) / vpl;
     // time parts: only where the output dominates the recurrence (sinewave, coswave, sinebuf4) and the bank is too small to give
@@ -390,7 +413,7 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
         if (int s = part_sync_get(resolve_stream(stream), (size_t)grid.x * ((block + 63) / 64), split, &psync)) return s;
     KernelTimer kt("osc_kernel", resolve_stream(stream));
     hipLaunchKernelGGL(fn, grid, blk, 0, resolve_stream(stream), V, N, d_freq, d_p1, d_p2, d_phase,
-                       d_outhold, d_out, (double)settings().sampleRate, psync, tune_get("osc_xcd"));
+                       d_outhold, d_out, (double)settings().sampleRate, psync, xcd);
     return check_hip(hipGetLastError(), "osc_kernel launch");
 }
 

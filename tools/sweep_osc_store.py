@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""tools/sweep_osc_store.py -- which store stream K1 should take at which bank size (the table behind osc.hip's automatic choice).
+
+For V = 16 384 ... 1 048 576 voices x 512 samples and four waveforms (sinebuf, sinebuf4, saw: store-bound; sinewave:
+VALU-heavy), every store stream of mxg_osc_render (knobs osc_vpl / osc_store / osc_xcd) is timed with the destination rotating
+through an arena (>= 2 GiB touched before a line is rewritten: HBM rates) and, for the smaller banks, also into ONE reused block
+buffer (what a block renderer sees; partly an Infinity-Cache rate).  Interleaved rounds in one process, median.  Prints a
+markdown table: us per block and the fraction of the 8 TB/s peak on 8 B per sample."""
+import argparse
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import maximilian_amd as mx  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--reps", type=int, default=6)
+ap.add_argument("--voices", default="16384,32768,65536,98304,131072,196608,262144,524288,1048576")
+ap.add_argument("--waveforms", default="8,9,2,0")
+ap.add_argument("--out", default=None)
+args = ap.parse_args()
+
+L = mx.lib()
+chk = mx._lib.check
+chk(L.mxg_init(0), "init")
+B = 512
+ARENA = 6 << 30
+arena = L.mxg_malloc(ARENA)
+assert arena
+chk(L.mxg_memset(arena, 0, ARENA, None), "memset")
+chk(L.mxg_sync(), "sync")
+e0, e1 = L.mxg_event_create(), L.mxg_event_create()
+ms = ctypes.c_float()
+NAMES = {8: "sinebuf", 9: "sinebuf4", 2: "saw", 0: "sinewave"}
+# (label, osc_vpl, osc_store, osc_xcd)
+MODES = [("auto", 0, -1, -1), ("1v 8B plain", 1, 0, 0), ("1v 8B nt", 1, 1, 0), ("1v pair-rows plain", 1, 2, 0), ("1v pair-rows sc1", 1, 3, 0),
+         ("1v pair-rows nt", 1, 4, 0), ("1v pair-rows sc1 xcd", 1, 3, 1), ("1v 8B plain xcd", 1, 0, 1), ("2v 16B plain", 2, 0, 0),
+         ("2v 16B sc1", 2, 2, 0), ("2v 16B sc1 xcd", 2, 2, 1), ("2v 16B plain xcd", 2, 0, 1)]
+
+
+def timed(fn, reps):
+    chk(L.mxg_event_record(e0, None), "rec")
+    for _ in range(reps):
+        fn()
+    chk(L.mxg_event_record(e1, None), "rec")
+    chk(L.mxg_event_sync(e1), "sync")
+    chk(L.mxg_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "elapsed")
+    return ms.value / reps
+
+
+lines = []
+
+
+def emit(s=""):
+    print(s, flush=True)
+    lines.append(s)
+
+
+emit("# K1 store streams by bank size (MI355X, 512-sample blocks; us per block / fraction of 8 TB/s on 8 B per sample)")
+emit()
+emit("`python tools/sweep_osc_store.py`: rotated = the destination walks a 6 GiB arena; same = one reused block buffer.  "
+     "%d rounds x %d launches, median.  `auto` is the library's own choice (knob osc_store = -1)." % (args.rounds, args.reps))
+for wf in [int(x) for x in args.waveforms.split(",")]:
+    emit()
+    emit("## %s" % NAMES.get(wf, str(wf)))
+    emit()
+    emit("| voices | " + " | ".join(m[0] for m in MODES) + " | best |")
+    emit("|---|" + "---|" * (len(MODES) + 1))
+    for rot in (True, False):
+        for V in [int(x) for x in args.voices.split(",")]:
+            nbytes = V * B * 8
+            if not rot and nbytes > (600 << 20):
+                continue
+            regions = max(1, ARENA // nbytes)
+            ctr = [0]
+            freq = mx.DeviceBuffer.from_numpy(20.0 + (np.arange(V) % 65536) * 0.30517578125)
+            phase, hold = mx.DeviceBuffer(V), mx.DeviceBuffer(V)
+
+            def run(vpl, store, xcd):
+                L.mxg_tune(b"osc_vpl", vpl); L.mxg_tune(b"osc_store", store); L.mxg_tune(b"osc_xcd", xcd)
+                ctr[0] += 1
+                dst = arena + ((ctr[0] % regions) * nbytes if rot else 0)
+                chk(L.mxg_osc_render(wf, V, B, freq.ptr, 0, None, None, phase.ptr, hold.ptr, dst, None), "render")
+            res = {m[0]: [] for m in MODES}
+            for rnd in range(args.rounds + 1):
+                for name, vpl, store, xcd in MODES:
+                    t = timed(lambda: run(vpl, store, xcd), args.reps)
+                    if rnd:
+                        res[name].append(t)
+            med = {k: float(np.median(v)) for k, v in res.items()}
+            best = min((k for k in med if k != "auto"), key=med.get)
+            emit("| %d %s | " % (V, "rotated" if rot else "same") +
+                 " | ".join("%.1f / %.3f" % (med[m[0]] * 1e3, nbytes / med[m[0]] / 1e6 / 8000) for m in MODES) + " | %s |" % best)
+            L.mxg_tune(b"osc_vpl", 0); L.mxg_tune(b"osc_store", -1); L.mxg_tune(b"osc_xcd", -1)
+            del freq, phase, hold
+if args.out:
+    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+    open(args.out, "w").write("\n".join(lines) + "\n")

@@ -113,11 +113,11 @@ def variants_for(V):
                 k1("K1 sinebuf 2v/lane %s blk%d%s" % (nm, blk, " xcd" if xcd else ""), 2, st, blk, xcd)
     k1("K1 sinebuf 1v/lane pair-rows 16B sc1 blk128", 1, 3, 128)
     k1("K1 sinebuf 1v/lane pair-rows 16B plain blk512", 1, 2, 512)
-    k1("K1 sinebuf default knobs", 1, -1, 256)
-    k1("K1 sinebuf default knobs same", 1, -1, 256, rot=False)
-    k1("K1 sinebuf4 default knobs", 1, -1, 256, wf=9)
+    k1("K1 sinebuf default knobs", 0, -1, 256, xcd=-1)
+    k1("K1 sinebuf default knobs same", 0, -1, 256, xcd=-1, rot=False)
+    k1("K1 sinebuf4 default knobs", 0, -1, 256, xcd=-1, wf=9)
     k1("K1 sinebuf4 pair-rows 16B sc1", 1, 3, 256, wf=9)
-    k1("K1 saw default knobs", 1, -1, 256, wf=2)
+    k1("K1 saw default knobs", 0, -1, 256, xcd=-1, wf=2)
     k1("K1 saw pair-rows 16B sc1", 1, 3, 256, wf=2)
     return out, nbytes, keep
 
@@ -164,7 +164,7 @@ for V in [int(x) for x in args.voices.split(",")]:
     d = float(np.median(res["K1 sinebuf default knobs"]))
     summary.append((V, nbytes, best_fill, best_k1, d))
     # knobs back to their defaults
-    L.mxg_tune(b"osc_vpl", 1); L.mxg_tune(b"osc_store", -1); L.mxg_tune(b"osc_block", 256); L.mxg_tune(b"osc_xcd", 0)
+    L.mxg_tune(b"osc_vpl", 0); L.mxg_tune(b"osc_store", -1); L.mxg_tune(b"osc_block", 256); L.mxg_tune(b"osc_xcd", -1)
     del keep
 
 emit()
