@@ -137,7 +137,8 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "fused_waves16" (mxg_fft_mfcc_batch: the 16-waves-per-CU form of the fused kernel when the request allows it, 0|1).
  * "osc_store" (K1's store stream: -1 automatic by bank size; one voice per lane: 0 plain 8-byte stores, 1 non-temporal, 2 / 3 / 4 two
  * samples of a lane pair exchanged into one 16-byte store per lane, plain / write-through (sc1) / non-temporal; two voices per lane:
- * 0 plain, 1 non-temporal, 2 write-through 16-byte stores), "osc_xcd" (workgroups renumbered so that each of the eight XCDs renders
+ * 0 plain, 1 non-temporal, 2 write-through 16-byte stores), "voice_store" / "voice_xcd" (the same for the fused voice kernel; one voice
+ * per lane only), "osc_xcd" (workgroups renumbered so that each of the eight XCDs renders
  * one contiguous eighth of the bank: -1 automatic, 0|1), "grain_sync" (mxg_granular_render reads its error word back before it returns, 0|1;
  * default 0: deferred, see mxg_last_async_error), "part_spin_limit" (polls a time-split kernel's writer part makes before it gives up
  * and reports through mxg_last_async_error), "part_fault" (test-only fault injection: that writer waits for a signal that never comes).

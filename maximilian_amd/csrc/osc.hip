@@ -355,14 +355,17 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
                 "phasorBetween needs d_p1/d_p2 (start/end phase)");
     if (V == 0 || N == 0) return MXG_OK;
     // ---- the store stream --------------------------------------------------------------------------------------------
-    // Knobs osc_vpl (0 = automatic), osc_store (-1 = automatic), osc_xcd (-1 = automatic) name it; left alone, it goes by the
-    // bank size, from the rotated-destination sweep of tools/sweep_osc_store.py (profiles/r03_osc_store.md), MI355X, 512-sample
-    // blocks, fraction of the 8 TB/s peak:
-    //   fewer than 131 072 voices (<= one wavefront per SIMD and voice): ONE voice per lane, two samples of a lane pair exchanged
-    //     into one write-through 16-byte store per lane (pair rows, sc1)               65 536 voices: 50 -> 42 us, 0.67 -> 0.80
-    //   from 131 072 voices: TWO voices per lane, write-through 16-byte stores        131 072 voices: 102 -> 86 us, 0.66 -> 0.78
-    //   from 196 608 voices also XCD-contiguous workgroup numbering                   262 144: 212 -> 189 us; 1 048 576: 816 -> 753 us
-    //   small blocks (< 64 MB: they live in the caches) keep plain 8-byte stores.
+    // Knobs osc_vpl (0 = automatic), osc_store (-1 = automatic), osc_xcd (-1 = automatic) name it; left alone, it goes by
+    // waveform class and bank size, from the rotated-destination sweep of tools/sweep_osc_store.py (profiles/r03_osc_store.md;
+    // MI355X, 512-sample blocks, fraction of the 8 TB/s peak on 8 B per sample):
+    //   pair rows = ONE voice per lane, two samples of a lane pair exchanged into one write-through (sc1) 16-byte store per lane;
+    //   2v        = TWO voices per lane, write-through 16-byte stores (half the wavefronts: only where one lane can carry two voices'
+    //               arithmetic without exposing its latency).
+    //   table forms (sinebuf, sawn):  < 49 152 voices plain 8-byte stores (the block lives in the caches; 32 768: 31 us against 37);
+    //       < 98 304 pair rows (65 536: 51 -> 40.5 us, 0.66 -> 0.83); from there 2v (98 304: 79 -> 67; 131 072: 101 -> 88 us, 0.67 -> 0.77);
+    //   ramps (phasor, saw, triangle, square, pulse, impulse, phasorBetween): 2v already from 65 536 voices (saw: 49 -> 40 us);
+    //   VALU-heavy forms (sinewave, coswave, sinebuf4): pair rows at every size (65 536 sinewave: 69 -> 65, sinebuf4 60 -> 57);
+    //   from 262 144 voices XCD-contiguous workgroup numbering (262 144 sinebuf: 215 -> 192 us; 1 048 576: 818 -> 755 us, 0.66 -> 0.71).
     const bool pairs_ok = !fps && !(V & 1) && !(((uintptr_t)d_out) & 15);
     const size_t out_bytes = V * N * sizeof(double);
     int vpl = tune_get("osc_vpl"), store = tune_get("osc_store"), xcd = tune_get("osc_xcd");
@@ -370,15 +373,21 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     if (automatic) {
         vpl = 1;
         store = 0;
-        if (pairs_ok && out_bytes >= ((size_t)64 << 20)) {
-            if (V >= 131072) {
-                vpl = 2;
-                store = 2;
-            } else {
-                store = 3;
+        const bool heavy = waveform == MXG_OSC_SINEWAVE || waveform == MXG_OSC_COSWAVE || waveform == MXG_OSC_SINEBUF4;
+        const bool table = waveform == MXG_OSC_SINEBUF || waveform == MXG_OSC_SAWN;
+        if (pairs_ok) {
+            if (heavy) {
+                if (out_bytes >= ((size_t)32 << 20)) store = 3;
+            } else if (out_bytes >= ((size_t)192 << 20)) {
+                if (V >= (table ? 98304u : 65536u)) {
+                    vpl = 2;
+                    store = 2;
+                } else {
+                    store = 3;
+                }
             }
         }
-        if (xcd < 0) xcd = V >= 196608 ? 1 : 0;
+        if (xcd < 0) xcd = V >= 262144 ? 1 : 0;
     } else {
         if (vpl == 0) vpl = 1;
         if (store < 0) {  // (the round-2 rule for 8-byte stores, knob osc_nt: non-temporal by block size)

@@ -32,6 +32,8 @@ Tune g_tune[] = {
     {"voice_vpl", 1, 1, 2},     {"voice_block", 256, 64, 1024}, {"voice_nt", 2, 0, 2},
     {"part_spin_limit", 1048576, 1, 16777216},  // time parts: polls (x s_sleep 8) before the writer gives up and reports ASYNC_PART_TIMEOUT
     {"part_fault", 0, 0, 1},  // fault injection for the tests: the writer waits for one signal more than will ever come
+    {"voice_store", -1, -1, 4},  // K2f store stream: -1 automatic, 0 plain 8 B, 1 nt 8 B, 2 / 3 / 4 pair rows (16 B) plain / sc1 / nt
+    {"voice_xcd", -1, -1, 1},
     {"osc_store", -1, -1, 4},  // K1 store stream (osc.hip pick<WF>): -1 automatic; one voice per lane: 0 plain 8 B, 1 nt 8 B, 2 / 3 / 4 pair rows (16 B) plain / sc1 / nt; two voices per lane: 0 plain, 1 nt, 2 sc1
     {"osc_xcd", -1, -1, 1},  // K1: 1 = every XCD renders one contiguous eighth of the bank (workgroup renumbering, mxg_common.h)
     {"osc_split", 0, 0, 8},  // K1: time parts per voice group (0 = automatic: 4 for sinewave / coswave on small banks, else 1)

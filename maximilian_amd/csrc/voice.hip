@@ -271,17 +271,21 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
 // per-sample VECTOR load would make every sample wait on vmcnt(0), i.e. on all earlier output
 // stores as well (loads and stores retire in order on one counter) -- measured 3.7x slower.
 // Per-voice triggers (TPV = true) are prefetched one 8-sample chunk ahead for the same reason.
-template <int MODE, bool NT, bool TPV>
+// ST / PX: the store stream as in K1 (osc.hip): ST = 0 plain, 1 nt, 2 sc1; PX = two samples of a lane pair leave as ONE 16-byte
+// store per lane (store_pair_rows, mxg_common.h; V even, out 16-byte aligned).  xcd: XCD-contiguous workgroup numbering.
+template <int MODE, int ST, bool PX, bool TPV>
 __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const double *__restrict__ freq,
                              const double *__restrict__ cutoff, const double *__restrict__ res,
                              const double *__restrict__ coef, const int32_t *__restrict__ trig,
                              int tpv, const double *__restrict__ par,
                              const int64_t *__restrict__ holdtime, double *__restrict__ ost,
                              double *__restrict__ fst, double *__restrict__ dst,
-                             int64_t *__restrict__ ist, double *__restrict__ out, double sr) {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+                             int64_t *__restrict__ ist, double *__restrict__ out, double sr, int xcd) {
+    const size_t gid = (size_t)xcd_block(blockIdx.x, gridDim.x, xcd) * blockDim.x + threadIdx.x;
     if ((gid & ~(size_t)63) >= V) return;  // the whole wavefront is past the bank
-    const size_t v = live_voice(gid, V);
+    // (pair rows: the surplus lanes of the last wavefront shadow the last PAIR of voices, parity kept, so that they exchange
+    // among themselves and store the values their owners store, to the same addresses)
+    const size_t v = PX ? (gid < V ? gid : V - 2 + (gid & 1)) : live_voice(gid, V);
     double phase = ost[v], hold = ost[V + v];
     Flt f = {fst[v], fst[V + v], fst[2 * V + v], fst[3 * V + v], fst[4 * V + v]};
     Env e;
@@ -296,6 +300,24 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
         rs = res[v];
     }
     double *op = out + v;
+    double *pp = out + (size_t)(threadIdx.x & 1) * V + (v & ~(size_t)1);  // pair rows: this lane's 16 bytes of row n + (lane & 1)
+    // one chunk of U samples to the output: pairs of rows as 16-byte stores, or sample by sample
+    auto emit = [&](const double (&o)[8]) {
+        if constexpr (PX) {
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                store_pair_rows<ST>(pp, o[i], o[i + 1]);
+                pp += 2 * V;
+            }
+            op += 8 * V;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                store1<ST>(op, o[i]);
+                op += V;
+            }
+        }
+    };
     // consume the prologue loads here so no vmcnt(0) is needed inside the loop (see osc.hip K1m)
     asm volatile("" : "+v"(phase), "+v"(hold), "+v"(c), "+v"(r), "+v"(cut), "+v"(rs));
     asm volatile("" : "+v"(f.x), "+v"(f.y), "+v"(e.amplitude), "+v"(e.output), "+v"(e.attack), "+v"(e.decay));
@@ -343,6 +365,7 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
                 // the envelope value, hence (cutoff, c, r), is the same for every sample of the chunk
                 lores_coeffs_dev((1.0 * e.amplitude) * cut, rs, sr, c, r);
             }
+            double ov[U];
 #pragma unroll
             for (int i = 0; i < U; i++) {
                 double o;
@@ -363,9 +386,14 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
                     double y = flt_lores(f, s, c, r);
                     o = y * a;
                 }
-                store1<NT>(op, o);
-                op += V;
+                if constexpr (PX) {
+                    ov[i] = o;
+                } else {
+                    store1<ST>(op, o);
+                    op += V;
+                }
             }
+            if constexpr (PX) emit(ov);
         };
         if (fast == 1) steady(std::true_type{}); else steady(std::false_type{});
         continue;
@@ -409,15 +437,13 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
                         o[i] = env_adsr(e, y[i], t);
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < U; i++) {
-                    store1<NT>(op, o[i]);
-                    op += V;
-                }
+                emit(o);
                 continue;
             }
         }
       }
+      double og[U];
+      const bool whole = n0 + U <= N;  // (wave-uniform)
 #pragma unroll
       for (int i = 0; i < U; i++) {
         const size_t n = n0 + i;
@@ -443,9 +469,15 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
             double y = flt_lores(f, s, c, r);
             o = y * a;
         }
-        store1<NT>(op, o);
-        op += V;
+        if (PX && whole) {
+            og[i] = o;
+        } else {  // (a ragged last chunk goes out sample by sample, whatever the store stream)
+            store1<ST>(op, o);
+            op += V;
+        }
       }
+      if constexpr (PX)
+        if (whole) emit(og);
     }
     ost[v] = phase;
     ost[V + v] = hold;
@@ -584,23 +616,42 @@ int mxg_voice_render(int mode, size_t V, size_t N, const double *d_freq, const d
     if (V == 0 || N == 0) return MXG_OK;
     int block = tune_get("voice_block");
     if (block > 256) block = 256;  // the bank kernels are compiled for <= 256 lanes per workgroup (512 VGPRs/lane budget)
-    const int nt_knob = tune_get("voice_nt");  // 2 (default): by the size of the block, as K1 (osc.hip)
+    // the store stream, as K1's (osc.hip, profiles/r03_osc_store.md): knob voice_store -1 = automatic (pair rows of write-through
+    // 16-byte stores wherever whole pairs exist; XCD-contiguous numbering from 262 144 voices), 0 / 1 plain / nt 8-byte stores
+    // (-1 with voice_nt set: the round-2 rule), 2 / 3 / 4 pair rows plain / sc1 / nt
+    const int nt_knob = tune_get("voice_nt");
     const size_t out_bytes = V * N * sizeof(double);
-    bool nt = nt_knob == 1 || (nt_knob == 2 && out_bytes > ((size_t)300 << 20) && out_bytes <= ((size_t)1200 << 20));
+    const bool pairs_ok = !(V & 1) && !(((uintptr_t)d_out) & 15) && V >= 2;
+    int store = tune_get("voice_store"), xcd = tune_get("voice_xcd");
+    if (store < 0) {
+        if (nt_knob != 2) store = nt_knob == 1 ? 1 : 0;
+        else store = pairs_ok && out_bytes >= ((size_t)32 << 20) ? 3 : 0;
+    }
+    if (store >= 2 && !pairs_ok) store = store == 4 ? 1 : 0;
+    if (xcd < 0) xcd = V >= 262144 ? 1 : 0;
     hipStream_t st = resolve_stream(stream);
     double sr = (double)settings().sampleRate;
-#define MXG_VOICE_LAUNCH(M, T, P)                                                               \
-    hipLaunchKernelGGL((voice_kernel<M, T, P>), grid_for(V, block), dim3(block), 0, st, V, N, d_freq, \
+#define MXG_VOICE_LAUNCH(M, S, X, P)                                                               \
+    hipLaunchKernelGGL((voice_kernel<M, S, X, P>), grid_for(V, block), dim3(block), 0, st, V, N, d_freq, \
                        d_cutoff, d_res, d_coef, d_trig, tpv, d_par, d_holdtime, d_ost, d_fst,   \
-                       d_dst, d_ist, d_out, sr)
-#define MXG_VOICE_LAUNCH2(M, T) \
-    if (tpv) MXG_VOICE_LAUNCH(M, T, true); else MXG_VOICE_LAUNCH(M, T, false)
+                       d_dst, d_ist, d_out, sr, xcd)
+#define MXG_VOICE_LAUNCH2(M, S, X) \
+    if (tpv) MXG_VOICE_LAUNCH(M, S, X, true); else MXG_VOICE_LAUNCH(M, S, X, false)
+#define MXG_VOICE_LAUNCH3(M)                           \
+    switch (store) {                                   \
+        case 1: MXG_VOICE_LAUNCH2(M, 1, false); break; \
+        case 2: MXG_VOICE_LAUNCH2(M, 0, true); break;  \
+        case 3: MXG_VOICE_LAUNCH2(M, 2, true); break;  \
+        case 4: MXG_VOICE_LAUNCH2(M, 1, true); break;  \
+        default: MXG_VOICE_LAUNCH2(M, 0, false); break; \
+    }
     KernelTimer kt("voice_kernel", st);
     if (mode == 0) {
-        if (nt) { MXG_VOICE_LAUNCH2(0, true); } else { MXG_VOICE_LAUNCH2(0, false); }
+        MXG_VOICE_LAUNCH3(0)
     } else {
-        if (nt) { MXG_VOICE_LAUNCH2(1, true); } else { MXG_VOICE_LAUNCH2(1, false); }
+        MXG_VOICE_LAUNCH3(1)
     }
+#undef MXG_VOICE_LAUNCH3
 #undef MXG_VOICE_LAUNCH2
 #undef MXG_VOICE_LAUNCH
     return check_hip(hipGetLastError(), "voice_kernel launch");

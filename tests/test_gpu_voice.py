@@ -317,6 +317,38 @@ def test_voice_launch_knobs_same_bits(mx, knob, value):
         assert_bits_equal(g, r, "%s with %s=%d" % (name, knob.decode(), value))
 
 
+@pytest.mark.parametrize("store,xcd", [(2, 0), (3, 1), (4, 0), (3, 0), (1, 1)])
+@pytest.mark.parametrize("V,N", [(700, 301), (64, 8), (2050, 512), (701, 77), (4096, 1000)])
+@pytest.mark.parametrize("mode,tpv", [(0, False), (0, True), (1, False)])
+def test_voice_store_streams_same_bits(mx, port, store, xcd, V, N, mode, tpv):
+    """The fused voice's store stream (voice_store: pair rows of 16-byte stores in three flavours, non-temporal 8-byte stores;
+    voice_xcd: XCD-contiguous workgroup numbering) against the oracle: banks with a partial last wavefront (its surplus lanes
+    shadow the last pair of voices), odd banks (pair rows fall back to 8-byte stores), blocks that are not a multiple of the
+    8-sample chunk, per-voice triggers, both voice modes."""
+    L = mx.lib()
+    v = np.arange(V)
+    freq, cutoff, res = 50.0 + 7.0 * (v % 600), 300.0 + 5.0 * (v % 800), 1.0 + (v % 5)
+    rng = np.random.default_rng(V + N)
+    trig = ((np.arange(N) % 130) < 70).astype(np.int32)
+    if tpv:
+        trig = (((np.arange(N)[:, None] + 3 * v[None, :]) % 130) < 70).astype(np.int32)
+    prev = [L.mxg_tune(b"voice_store", store), L.mxg_tune(b"voice_xcd", xcd)]
+    try:
+        vb = mx.maxiVoiceBank(V)
+        vb.env.setAttack(1); vb.env.setDecay(5); vb.env.setSustain(0.5); vb.env.setRelease(20)
+        cu = cutoff if mode == 0 else np.full(V, 9000.0)
+        got = np.concatenate([vb.render(mode, freq, cu, res, trig, N).numpy() for _ in range(2)])
+    finally:
+        L.mxg_tune(b"voice_store", prev[0]); L.mxg_tune(b"voice_xcd", prev[1])
+    t2 = np.concatenate([trig, trig])
+    e = port.voice(mode, freq, cu, res, t2, vb.env.par, vb.env.holdtime)[0]
+    if mode == 0:
+        assert_bits_equal(got, e, "voice_store=%d" % store)
+    else:
+        assert_close_scaled(got, e, 1e-11, "voice_store=%d mode B" % store)
+    del rng
+
+
 def test_env_arbitrary_uploaded_flags(mx, port):
     """maxiEnv's five phase members are plain ints a host may set to anything (state upload): with flags drawn from
     {0, 1, 2} -- several set at once, none set, values that are neither 0 nor 1 -- and a shared gate (so the wave-uniform
