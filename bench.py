@@ -501,8 +501,9 @@ def main():
         del one
         # (b) the measured write ceiling: the best pure store streams of csrc/calib.hip over the SAME rotating buffers
         ceil_ms = {}
-        for name, (w, fl, pat, blk) in {"flat 16 B plain": (16, 0, 0, 256), "flat 16 B nt": (16, 1, 0, 256),
-                                        "cols 8 B plain (K1's shape)": (8, 0, 1, 256), "cols 8 B nt": (8, 1, 1, 256)}.items():
+        for name, (w, fl, pat, blk) in {"grid-stride fill, 16 B plain": (16, 0, 0, 256), "column walk, 8 B plain": (8, 0, 1, 256),
+                                        "column walk, 16 B plain": (16, 0, 1, 256), "column walk, 16 B sc1 (write-through)": (16, 2, 1, 256),
+                                        "column walk, 16 B sc1 nt": (16, 4, 1, 256)}.items():
             k = [0]
 
             def fill():
@@ -512,7 +513,8 @@ def main():
         best = min(ceil_ms, key=ceil_ms.get)
         extras["write_ceiling"] = {"GB/s": round(nb / ceil_ms[best] / 1e6, 1), "pattern": best,
                                    "all_GB/s": {k_: round(nb / v_ / 1e6, 1) for k_, v_ in ceil_ms.items()},
-                                   "note": "pure store streams (csrc/calib.hip) over this run's rotating block buffers"}
+                                   "note": "the fastest of the pure store streams of csrc/calib.hip (no arithmetic, a lane owns 8 or 16 bytes of a row "
+                                           "and walks down the rows) over this run's rotating block buffers; profiles/r03_write_ceiling.md has the full family"}
         # (c) the north star's bank size: >= 10^5 voices (131 072), block buffers rotated the same way
         if not args.voices:
             V2 = 131072
@@ -522,13 +524,13 @@ def main():
             k2 = [0]
 
             def fill2():
-                chk(L.mxg_calib_fill_ex(b2.outs[k2[0] % len(b2.outs)].data_ptr(), B, V2 * 8, 16, 1, 0, 256, 0, 0, stream), "calib")
+                chk(L.mxg_calib_fill_ex(b2.outs[k2[0] % len(b2.outs)].data_ptr(), B, V2 * 8, 16, 2, 1, 256, 0, 0, stream), "calib")
                 k2[0] += 1
             c2 = time_steps(fill2, n_x)
             extras["north_star_bank"] = {
                 "voices": V2, "block": B, "ms_per_step": round(ms2, 5), "value": round(V2 * B / ms2 / 1e3, 1), "unit": "Msamples/s",
                 "block_buffers": len(b2.outs), "frac_hbm_peak": round(b2.algo / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "write_ceiling_GB/s": round(nb2 / c2 / 1e6, 1), "frac_of_measured_write_ceiling": round(c2 / ms2 * b2.algo / nb2, 4),
+                "write_ceiling_GB/s": round(nb2 / c2 / 1e6, 1), "write_ceiling_pattern": "column walk, 16 B sc1 (write-through)", "frac_of_measured_write_ceiling": round(c2 / ms2 * b2.algo / nb2, 4),
                 "realtime_factor_at_44k1": round(B / 44100.0 / (ms2 * 1e-3), 1)}
             del b2
 

@@ -129,17 +129,18 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "mfcc_tiled" (LDS-staged spectra 0|1), "grain_chunked" (time-sharded granular render 0|1), "grain_lanes_k",
  * "grain_unit" (coalesced unit-increment render 0|1), "grain_line" (tile render for arbitrary increments 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_slices" (time slices of a unit-path
  * maxiTimeStretch call whose scheduling and rendering overlap, 1..16), "osc_mix_var" (layout of K1m's lane-exchange butterfly, 0..3),
- * "osc_split" (time parts per voice group in K1: 0 automatic, 1..8),
+ * "osc_split" (time parts per voice group in K1: 0 automatic, 1..8), "osc_mix_split" (the same for the fused render + mixdown K1m,
+ * 0 automatic, 1..4), "osc_mix_store" (K1m's per-voice block: 0 automatic, 1 plain 8-byte stores, 2 pair rows of 16-byte stores),
  * "smp_split" (time parts of a block-constant playAtSpeed / playOnceAtSpeed / playUntilAtSpeed launch: 0 automatic, 1..8),
  * "smp_pipe" (that launch issues the window loads of chunk k+1 before the stores of chunk k, 0|1),
  * "ifft_stream" (mxg_ifft_batch: inverse transform and hop buffer in one kernel: 0 never, 1 where hop >= fftSize / 2, 2 wherever it fits),
  * "mfcc_mfma_fullk" (the MFMA mel contraction runs over all numBins bins instead of the ones that carry weight, 0|1).
  * "fused_waves16" (mxg_fft_mfcc_batch: the 16-waves-per-CU form of the fused kernel when the request allows it, 0|1).
- * "osc_store" (K1's store stream: -1 automatic by bank size; one voice per lane: 0 plain 8-byte stores, 1 non-temporal, 2 / 3 / 4 two
- * samples of a lane pair exchanged into one 16-byte store per lane, plain / write-through (sc1) / non-temporal; two voices per lane:
- * 0 plain, 1 non-temporal, 2 write-through 16-byte stores), "voice_store" / "voice_xcd" (the same for the fused voice kernel; one voice
+ * "osc_store" (K1's store stream: 0 automatic by waveform and bank size; one voice per lane: 1 plain 8-byte stores, 2 non-temporal,
+ * 3 / 4 / 5 two samples of a lane pair exchanged into one 16-byte store per lane, plain / write-through (sc1) / non-temporal; two
+ * voices per lane: 1 plain, 2 non-temporal, 3 write-through 16-byte stores), "voice_store" / "voice_xcd" (the same for the fused voice kernel; one voice
  * per lane only), "osc_xcd" (workgroups renumbered so that each of the eight XCDs renders
- * one contiguous eighth of the bank: -1 automatic, 0|1), "grain_sync" (mxg_granular_render reads its error word back before it returns, 0|1;
+ * one contiguous eighth of the bank: 0 automatic, 1 off, 2 on), "grain_sync" (mxg_granular_render reads its error word back before it returns, 0|1;
  * default 0: deferred, see mxg_last_async_error), "part_spin_limit" (polls a time-split kernel's writer part makes before it gives up
  * and reports through mxg_last_async_error), "part_fault" (test-only fault injection: that writer waits for a signal that never comes).
  * The tests flip every one of them and demand identical bits.  Returns the previous value or MXG_ERR_INVALID. */

@@ -183,13 +183,19 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
 
 // the lane-exchange helpers (Fold, fold_dpp, fold_quad, fold_chunk, fold32/16, quad_sum, fold_chunk_swap) live in mxg_lanefold.h
 
-// VAR 0: permlane-swap butterfly, 4 LDS rows per window (one per wave).  VAR 1: all-DPP butterfly, 16 rows (wave x row).
-template <int WF, bool STORE, int VAR, int WIN>
+// STORE: 0 = mix only (no per-voice block), 1 = plain 8-byte stores, 2 = pair rows of write-through 16-byte stores (as K1, V even and
+// `out` 16-byte aligned).  VAR 0: permlane-swap butterfly, 4 LDS rows per window (one per wave).  VAR 1: all-DPP butterfly, 16
+// rows (wave x row; A/B only).  Time parts (gridDim.y, round 3): the kernel is VALU-issue bound at one wavefront per SIMD (43 us
+// of arithmetic for a 65 536 x 512 block against ~41 us of stores), and a second resident wavefront nearly doubles the issue
+// rate -- so a block is cut into two time parts like K1's sinewave: part p advances the phase over the samples before it with
+// osc_skip (the same additions: the same bits), renders its stretch and mixes it into its own rows of the partial buffer; the
+// last part stores the state (part_signal / part_wait).
+template <int WF, int STORE, int VAR, int WIN>
 __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const double *__restrict__ freq,
                                                       const double *__restrict__ p1, const double *__restrict__ p2,
                                                       double *__restrict__ phase_io, double *__restrict__ hold_io,
                                                       double *__restrict__ out, const double *__restrict__ pan,
-                                                      double *__restrict__ partial, double sr) {
+                                                      double *__restrict__ partial, double sr, PartSync psync) {
     constexpr int kTab = tab_len<WF>();
     constexpr int kTabPad = (kTab + 1) & ~1;  // the (L, R) pairs below are 16-byte stores
     constexpr int kRows = VAR == 0 ? 4 : 16;  // LDS rows the workgroup pass adds per output
@@ -202,11 +208,12 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
     double *s_part = s_all + kTabPad;                                     // [kRows][kMixWin][2]
     double *my_part = s_part + (VAR == 0 ? wave : wave * 4 + (lane >> 4)) * (kMixWin * 2);
     // The lane exchanges need all 64 lanes alive, and a per-sample `if (live)` costs an exec-mask region per sample:
-    // the surplus lanes of the bank's last wavefront shadow voice V-1 instead (same loads, same arithmetic, same stores
-    // of the same values to the same addresses) and enter the mix with zero gains.
+    // the surplus lanes of the bank's last wavefront shadow a live voice instead (same loads, same arithmetic, same stores
+    // of the same values to the same addresses) and enter the mix with zero gains -- voice V-1, or with pair rows the last
+    // PAIR of voices, parity kept, so that they exchange among themselves.
     const size_t vraw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = vraw < V;
-    const size_t v = live ? vraw : V - 1;
+    const size_t v = live ? vraw : (STORE == 2 ? V - 2 + (vraw & 1) : V - 1);
     double ph = phase_io[v], hd = hold_io[v];
     double x = pan[v];
     if (x > 1) x = 1;  // C:504
@@ -217,6 +224,14 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
     // drains the asynchronous output stores with s_waitcnt vmcnt(0) every chunk.
     asm volatile("" : "+v"(ph), "+v"(hd), "+v"(gl), "+v"(gr));
     asm volatile("" : "+v"(q.inc), "+v"(q.k), "+v"(q.p1), "+v"(q.p2));
+    // time parts: this part renders [nA, nB); part lengths are whole mix chunks, so a chunk never straddles two parts
+    int *const part_ctr = gridDim.y > 1 ? part_counter(psync) : nullptr;
+    if (blockIdx.y + 1 != gridDim.y) part_signal(part_ctr);
+    const size_t plen = ((N + gridDim.y - 1) / gridDim.y + kMixChunk - 1) / kMixChunk * kMixChunk;
+    const size_t nA = blockIdx.y * plen < N ? blockIdx.y * plen : N;
+    const size_t nB = nA + plen < N ? nA + plen : N;
+#pragma unroll 4
+    for (size_t n = 0; n < nA; n++) osc_skip<WF>(ph, hd, q, s_tab, s_tab);
     // which sample of a chunk this lane ends up holding: the same network on the sample indices
     int slot;
     {
@@ -226,26 +241,42 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
         slot = VAR == 0 ? fold_chunk_swap<int>(idx) : fold_chunk<int>(idx, lane);
         if (VAR == 0 && (lane & 3) != 0) slot = -1;  // one lane per quad stores
     }
-    double *o = out + v;
-    for (size_t n0 = 0; n0 < N; n0 += kMixWin) {
-        const int span = (int)((N - n0) < (size_t)kMixWin ? (N - n0) : (size_t)kMixWin);
+    double *o = out + nA * V + v;
+    double *op = out + (nA + (threadIdx.x & 1)) * V + (v & ~(size_t)1);  // pair rows: this lane's 16 bytes of row n + (lane & 1)
+    for (size_t n0 = nA; n0 < nB; n0 += kMixWin) {
+        const int span = (int)((nB - n0) < (size_t)kMixWin ? (nB - n0) : (size_t)kMixWin);
         for (int c0 = 0; c0 < span; c0 += kMixChunk) {
             const int cnt = (span - c0) < kMixChunk ? (span - c0) : kMixChunk;
             auto chunk = [&](auto full_tag) {
                 constexpr bool kFull = decltype(full_tag)::value;
                 double L[kMixChunk], R[kMixChunk];
+                if constexpr (kFull && STORE == 2) {
 #pragma unroll
-                for (int i = 0; i < kMixChunk; i++) {
-                    double r = 0.0;
-                    if (kFull || i < cnt) {  // ragged last chunk: the state must not advance past N
-                        r = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
-                        if constexpr (STORE) {
-                            *o = r;
-                            o += V;
-                        }
+                    for (int i = 0; i < kMixChunk; i += 2) {
+                        const double r0 = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+                        const double r1 = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+                        store_pair_rows<2>(op, r0, r1);
+                        op += 2 * V;
+                        L[i] = r0 * gl;      // two[0] = input*sqrt(1.0-x)   C:506
+                        R[i] = r0 * gr;      // two[1] = input*sqrt(x)       C:507
+                        L[i + 1] = r1 * gl;
+                        R[i + 1] = r1 * gr;
                     }
-                    L[i] = r * gl;  // two[0] = input*sqrt(1.0-x)   C:506
-                    R[i] = r * gr;  // two[1] = input*sqrt(x)       C:507
+                    o += (size_t)kMixChunk * V;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kMixChunk; i++) {
+                        double r = 0.0;
+                        if (kFull || i < cnt) {  // ragged last chunk: the state must not advance past N
+                            r = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+                            if constexpr (STORE != 0) {
+                                *o = r;
+                                o += V;
+                            }
+                        }
+                        L[i] = r * gl;  // two[0] = input*sqrt(1.0-x)   C:506
+                        R[i] = r * gr;  // two[1] = input*sqrt(x)       C:507
+                    }
                 }
                 double2v pr;
                 if constexpr (VAR == 0)
@@ -267,25 +298,28 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
         }
         __syncthreads();
     }
-    phase_io[v] = ph;
-    hold_io[v] = hd;
+    if (blockIdx.y + 1 == gridDim.y && part_wait(part_ctr, psync)) {
+        phase_io[v] = ph;
+        hold_io[v] = hd;
+    }
 }
 
 typedef void (*osc_mix_fn)(size_t, size_t, const double *, const double *, const double *, double *, double *,
-                           double *, const double *, double *, double);
+                           double *, const double *, double *, double, PartSync);
+// store: 0 none, 1 plain, 2 pair rows (sc1); var / window A/B forms only for the bench waveform
 template <int WF>
-osc_mix_fn pick_mix(bool store, int var) {
-    if (WF == MXG_OSC_SINEBUF) {  // the A/B variants are only instantiated for the bench waveform
+osc_mix_fn pick_mix(int store, int var) {
+    if (WF == MXG_OSC_SINEBUF) {
         switch (var) {
-            case 1: return store ? osc_mix_kernel<WF, true, 0, 128> : osc_mix_kernel<WF, false, 0, 128>;
-            case 2: return store ? osc_mix_kernel<WF, true, 1, 128> : osc_mix_kernel<WF, false, 1, 128>;
-            case 3: return store ? osc_mix_kernel<WF, true, 1, 512> : osc_mix_kernel<WF, false, 1, 512>;
+            case 1: return store ? osc_mix_kernel<WF, 1, 0, 128> : osc_mix_kernel<WF, 0, 0, 128>;
+            case 2: return store ? osc_mix_kernel<WF, 1, 1, 128> : osc_mix_kernel<WF, 0, 1, 128>;
+            case 3: return store ? osc_mix_kernel<WF, 1, 1, 512> : osc_mix_kernel<WF, 0, 1, 512>;
             default: break;
         }
     }
-    return store ? osc_mix_kernel<WF, true, 0, 512> : osc_mix_kernel<WF, false, 0, 512>;
+    return store == 2 ? osc_mix_kernel<WF, 2, 0, 256> : (store == 1 ? osc_mix_kernel<WF, 1, 0, 256> : osc_mix_kernel<WF, 0, 0, 256>);
 }
-osc_mix_fn pick_mix_wf(int wf, bool store, int var) {
+osc_mix_fn pick_mix_wf(int wf, int store, int var) {
     switch (wf) {
         case 0: return pick_mix<0>(store, var);
         case 1: return pick_mix<1>(store, var);
@@ -355,7 +389,7 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
                 "phasorBetween needs d_p1/d_p2 (start/end phase)");
     if (V == 0 || N == 0) return MXG_OK;
     // ---- the store stream --------------------------------------------------------------------------------------------
-    // Knobs osc_vpl (0 = automatic), osc_store (-1 = automatic), osc_xcd (-1 = automatic) name it; left alone, it goes by
+    // Knobs osc_vpl, osc_store, osc_xcd (0 = automatic each) name it; left alone, it goes by
     // waveform class and bank size, from the rotated-destination sweep of tools/sweep_osc_store.py (profiles/r03_osc_store.md;
     // MI355X, 512-sample blocks, fraction of the 8 TB/s peak on 8 B per sample):
     //   pair rows = ONE voice per lane, two samples of a lane pair exchanged into one write-through (sc1) 16-byte store per lane;
@@ -368,7 +402,7 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     //   from 262 144 voices XCD-contiguous workgroup numbering (262 144 sinebuf: 215 -> 192 us; 1 048 576: 818 -> 755 us, 0.66 -> 0.71).
     const bool pairs_ok = !fps && !(V & 1) && !(((uintptr_t)d_out) & 15);
     const size_t out_bytes = V * N * sizeof(double);
-    int vpl = tune_get("osc_vpl"), store = tune_get("osc_store"), xcd = tune_get("osc_xcd");
+    int vpl = tune_get("osc_vpl"), store = tune_get("osc_store") - 1, xcd = tune_get("osc_xcd") - 1;  // (knob value 0 = automatic)
     const bool automatic = vpl == 0 && store < 0;
     if (automatic) {
         vpl = 1;
@@ -443,12 +477,28 @@ extern "C" int mxg_osc_render_mix(int waveform, size_t V, size_t N, const double
     double *partial = nullptr;  // per-stream scratch: [nblocks][N][2] per-workgroup sums
     if (int s = scratch_get(SCR_OSC_MIX, st, sizeof(double) * need, (void **)&partial)) return s;
     if (V) {
-        osc_mix_fn fn = pick_mix_wf(waveform, d_out != nullptr, tune_get("osc_mix_var"));
-        if (tune_get("osc_mix_var") == 3 && waveform == MXG_OSC_SINEBUF)
+        // per-voice block: pair rows of write-through 16-byte stores where whole pairs exist (knob osc_mix_store: 0 automatic,
+        // 1 plain 8-byte stores, 2 pair rows); time parts (knob osc_mix_split: 0 automatic = two below 2048 wavefronts)
+        const int var = tune_get("osc_mix_var");
+        int store = 0;
+        if (d_out) {
+            const bool pairs_ok = !(V & 1) && !(((uintptr_t)d_out) & 15) && V >= 2;
+            const int knob = tune_get("osc_mix_store");
+            store = (pairs_ok && var == 0 && (knob == 2 || (knob == 0 && V * N * sizeof(double) >= ((size_t)32 << 20)))) ? 2 : 1;
+        }
+        int split = tune_get("osc_mix_split");
+        if (split == 0) split = nblocks * 4 >= 2048 ? 1 : 2;
+        if (var != 0) split = 1;
+        while (split > 1 && (size_t)(split - 1) * (((N + split - 1) / split + kMixChunk - 1) / kMixChunk * kMixChunk) >= N) split--;
+        PartSync psync;
+        if (split > 1)
+            if (int s2 = part_sync_get(st, nblocks * 4, split, &psync)) return s2;
+        osc_mix_fn fn = pick_mix_wf(waveform, store, var);
+        if (var == 3 && waveform == MXG_OSC_SINEBUF)
             MXG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 0));
         KernelTimer kt("osc_mix_kernel", st);
-        hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(block), 0, st, V, N, d_freq, d_p1, d_p2, d_phase,
-                           d_outhold, d_out, d_pan, partial, (double)settings().sampleRate);
+        hipLaunchKernelGGL(fn, dim3((unsigned)nblocks, (unsigned)split), dim3(block), 0, st, V, N, d_freq, d_p1, d_p2, d_phase,
+                           d_outhold, d_out, d_pan, partial, (double)settings().sampleRate, psync);
     }
     KernelTimer kt2("mix_partials_kernel", st);
     hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((N * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, nblocks, N * 2,

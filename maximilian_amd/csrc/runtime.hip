@@ -32,11 +32,13 @@ Tune g_tune[] = {
     {"voice_vpl", 1, 1, 2},     {"voice_block", 256, 64, 1024}, {"voice_nt", 2, 0, 2},
     {"part_spin_limit", 1048576, 1, 16777216},  // time parts: polls (x s_sleep 8) before the writer gives up and reports ASYNC_PART_TIMEOUT
     {"part_fault", 0, 0, 1},  // fault injection for the tests: the writer waits for one signal more than will ever come
-    {"voice_store", -1, -1, 4},  // K2f store stream: -1 automatic, 0 plain 8 B, 1 nt 8 B, 2 / 3 / 4 pair rows (16 B) plain / sc1 / nt
-    {"voice_xcd", -1, -1, 1},
-    {"osc_store", -1, -1, 4},  // K1 store stream (osc.hip pick<WF>): -1 automatic; one voice per lane: 0 plain 8 B, 1 nt 8 B, 2 / 3 / 4 pair rows (16 B) plain / sc1 / nt; two voices per lane: 0 plain, 1 nt, 2 sc1
-    {"osc_xcd", -1, -1, 1},  // K1: 1 = every XCD renders one contiguous eighth of the bank (workgroup renumbering, mxg_common.h)
+    {"voice_store", 0, 0, 5},  // K2f store stream: 0 automatic, 1 plain 8 B, 2 nt 8 B, 3 / 4 / 5 pair rows (16 B) plain / sc1 / nt
+    {"voice_xcd", 0, 0, 2},    // 0 automatic, 1 natural workgroup order, 2 XCD-contiguous
+    {"osc_store", 0, 0, 5},  // K1 store stream (osc.hip pick<WF>): 0 automatic; one voice per lane: 1 plain 8 B, 2 nt 8 B, 3 / 4 / 5 pair rows (16 B) plain / sc1 / nt; two voices per lane: 1 plain, 2 nt, 3 sc1
+    {"osc_xcd", 0, 0, 2},  // K1: 1 = every XCD renders one contiguous eighth of the bank (workgroup renumbering, mxg_common.h)
     {"osc_split", 0, 0, 8},  // K1: time parts per voice group (0 = automatic: 4 for sinewave / coswave on small banks, else 1)
+    {"osc_mix_store", 0, 0, 2},  // K1m per-voice block: 0 automatic, 1 plain 8-byte stores, 2 pair rows of write-through 16-byte stores
+    {"osc_mix_split", 0, 0, 4},  // K1m time parts (0 automatic: two below 2048 wavefronts)
     {"osc_mix_var", 0, 0, 3},  // K1m A/B (sinebuf): 0 swap butterfly, window 512; 1 same, window 128; 2 DPP butterfly 128; 3 DPP 512
     {"ifft_stream", 1, 0, 2},  // maxiIFFT: transform + hop buffer in one kernel (0: never; 1: where hop >= fftSize / 2; 2: wherever it fits)
     {"smp_pipe", 1, 0, 1},   // K5: the time-part kernel's loads of chunk k+1 issued before the stores of chunk k (0: chunk after chunk)

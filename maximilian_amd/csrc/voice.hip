@@ -616,13 +616,13 @@ int mxg_voice_render(int mode, size_t V, size_t N, const double *d_freq, const d
     if (V == 0 || N == 0) return MXG_OK;
     int block = tune_get("voice_block");
     if (block > 256) block = 256;  // the bank kernels are compiled for <= 256 lanes per workgroup (512 VGPRs/lane budget)
-    // the store stream, as K1's (osc.hip, profiles/r03_osc_store.md): knob voice_store -1 = automatic (pair rows of write-through
-    // 16-byte stores wherever whole pairs exist; XCD-contiguous numbering from 262 144 voices), 0 / 1 plain / nt 8-byte stores
-    // (-1 with voice_nt set: the round-2 rule), 2 / 3 / 4 pair rows plain / sc1 / nt
+    // the store stream, as K1's (osc.hip, profiles/r03_osc_store.md): knob voice_store 0 = automatic (pair rows of write-through
+    // 16-byte stores wherever whole pairs exist; XCD-contiguous numbering from 262 144 voices), 1 / 2 plain / nt 8-byte stores
+    // (0 with voice_nt set: the round-2 rule), 3 / 4 / 5 pair rows plain / sc1 / nt
     const int nt_knob = tune_get("voice_nt");
     const size_t out_bytes = V * N * sizeof(double);
     const bool pairs_ok = !(V & 1) && !(((uintptr_t)d_out) & 15) && V >= 2;
-    int store = tune_get("voice_store"), xcd = tune_get("voice_xcd");
+    int store = tune_get("voice_store") - 1, xcd = tune_get("voice_xcd") - 1;  // (knob value 0 = automatic)
     if (store < 0) {
         if (nt_knob != 2) store = nt_knob == 1 ? 1 : 0;
         else store = pairs_ok && out_bytes >= ((size_t)32 << 20) ? 3 : 0;

@@ -104,8 +104,8 @@ def test_tuning_does_not_change_results(mx, port, vpl, nt, block):
         L.mxg_tune(b"osc_vpl", prev[0]); L.mxg_tune(b"osc_nt", prev[1]); L.mxg_tune(b"osc_block", prev[2])
 
 
-@pytest.mark.parametrize("vpl,store,block,xcd", [(1, 2, 256, 0), (1, 3, 256, 1), (1, 4, 128, 0), (1, 3, 64, 0), (2, 2, 256, 1),
-                                                 (2, 0, 512, 1), (1, 0, 256, 1), (1, 3, 1024, 1)])
+@pytest.mark.parametrize("vpl,store,block,xcd", [(1, 3, 256, 1), (1, 4, 256, 2), (1, 5, 128, 1), (1, 4, 64, 1), (2, 3, 256, 2),
+                                                 (2, 1, 512, 2), (1, 1, 256, 2), (1, 4, 1024, 2), (0, 0, 256, 0)])
 @pytest.mark.parametrize("V,N", [(4096 + 2, 301), (512, 2), (8192, 64), (4097, 33)])
 def test_store_streams_do_not_change_results(mx, port, vpl, store, block, xcd, V, N):
     """The store stream of K1 is a launch knob (osc_store: 8-byte plain / nt, the 16-byte pair-row exchange in three flavours,
@@ -191,6 +191,21 @@ def test_render_mix_fused(mx, port, wf, V, N):
     none, mix3 = bank2.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V), store=False)
     assert none is None
     assert_bits_equal(mix3.numpy(), mix1.numpy(), "mix-only mode")
+    # launch knobs of K1m: the per-voice block as pair rows of 16-byte stores or plain stores, one to four time parts --
+    # the block, the carried phase AND the mix (same additions in the same tree) must not change by a bit
+    L = mx.lib()
+    for store, split in ((2, 1), (1, 1), (2, 2), (1, 3), (2, 4)):
+        prev = [L.mxg_tune(b"osc_mix_store", store), L.mxg_tune(b"osc_mix_split", split)]
+        try:
+            bank3 = mx.maxiOscBank(V)
+            o3, m3 = bank3.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V))
+            assert_bits_equal(o3.numpy(), out1.numpy(), "store %d split %d" % (store, split))
+            assert_bits_equal(m3.numpy(), mix1.numpy(), "mix, store %d split %d" % (store, split))
+            o3, m3 = bank3.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V))
+            assert_bits_equal(o3.numpy(), out2.numpy(), "second block, store %d split %d" % (store, split))
+            assert_bits_equal(bank3.phase.numpy(), eph, "phase, store %d split %d" % (store, split))
+        finally:
+            L.mxg_tune(b"osc_mix_store", prev[0]); L.mxg_tune(b"osc_mix_split", prev[1])
 
 
 @pytest.mark.parametrize("wf,V,N", [(0, 1000, 601), (1, 64, 3), (8, 300, 512), (6, 129, 77), (10, 70, 1), (5, 4096, 130)])

@@ -317,7 +317,7 @@ def test_voice_launch_knobs_same_bits(mx, knob, value):
         assert_bits_equal(g, r, "%s with %s=%d" % (name, knob.decode(), value))
 
 
-@pytest.mark.parametrize("store,xcd", [(2, 0), (3, 1), (4, 0), (3, 0), (1, 1)])
+@pytest.mark.parametrize("store,xcd", [(3, 1), (4, 2), (5, 1), (4, 1), (2, 2)])
 @pytest.mark.parametrize("V,N", [(700, 301), (64, 8), (2050, 512), (701, 77), (4096, 1000)])
 @pytest.mark.parametrize("mode,tpv", [(0, False), (0, True), (1, False)])
 def test_voice_store_streams_same_bits(mx, port, store, xcd, V, N, mode, tpv):

@@ -37,9 +37,9 @@ e0, e1 = L.mxg_event_create(), L.mxg_event_create()
 ms = ctypes.c_float()
 NAMES = {8: "sinebuf", 9: "sinebuf4", 2: "saw", 0: "sinewave"}
 # (label, osc_vpl, osc_store, osc_xcd)
-MODES = [("auto", 0, -1, -1), ("1v 8B plain", 1, 0, 0), ("1v 8B nt", 1, 1, 0), ("1v pair-rows plain", 1, 2, 0), ("1v pair-rows sc1", 1, 3, 0),
-         ("1v pair-rows nt", 1, 4, 0), ("1v pair-rows sc1 xcd", 1, 3, 1), ("1v 8B plain xcd", 1, 0, 1), ("2v 16B plain", 2, 0, 0),
-         ("2v 16B sc1", 2, 2, 0), ("2v 16B sc1 xcd", 2, 2, 1), ("2v 16B plain xcd", 2, 0, 1)]
+MODES = [("auto", 0, 0, 0), ("1v 8B plain", 1, 1, 1), ("1v 8B nt", 1, 2, 1), ("1v pair-rows plain", 1, 3, 1), ("1v pair-rows sc1", 1, 4, 1),
+         ("1v pair-rows nt", 1, 5, 1), ("1v pair-rows sc1 xcd", 1, 4, 2), ("1v 8B plain xcd", 1, 1, 2), ("2v 16B plain", 2, 1, 1),
+         ("2v 16B sc1", 2, 3, 1), ("2v 16B sc1 xcd", 2, 3, 2), ("2v 16B plain xcd", 2, 1, 2)]
 
 
 def timed(fn, reps):
@@ -63,7 +63,7 @@ def emit(s=""):
 emit("# K1 store streams by bank size (MI355X, 512-sample blocks; us per block / fraction of 8 TB/s on 8 B per sample)")
 emit()
 emit("`python tools/sweep_osc_store.py`: rotated = the destination walks a 6 GiB arena; same = one reused block buffer.  "
-     "%d rounds x %d launches, median.  `auto` is the library's own choice (knob osc_store = -1)." % (args.rounds, args.reps))
+     "%d rounds x %d launches, median.  `auto` is the library's own choice (every knob 0)." % (args.rounds, args.reps))
 for wf in [int(x) for x in args.waveforms.split(",")]:
     emit()
     emit("## %s" % NAMES.get(wf, str(wf)))
@@ -95,7 +95,7 @@ for wf in [int(x) for x in args.waveforms.split(",")]:
             best = min((k for k in med if k != "auto"), key=med.get)
             emit("| %d %s | " % (V, "rotated" if rot else "same") +
                  " | ".join("%.1f / %.3f" % (med[m[0]] * 1e3, nbytes / med[m[0]] / 1e6 / 8000) for m in MODES) + " | %s |" % best)
-            L.mxg_tune(b"osc_vpl", 0); L.mxg_tune(b"osc_store", -1); L.mxg_tune(b"osc_xcd", -1)
+            L.mxg_tune(b"osc_vpl", 0); L.mxg_tune(b"osc_store", 0); L.mxg_tune(b"osc_xcd", 0)
             del freq, phase, hold
 if args.out:
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)

@@ -97,28 +97,26 @@ def variants_for(V):
     phase, hold = mx.DeviceBuffer(V), mx.DeviceBuffer(V)
     keep = (freq, phase, hold)
 
-    STORE1 = {0: "8B plain", 1: "8B nt", 2: "pair-rows 16B plain", 3: "pair-rows 16B sc1", 4: "pair-rows 16B nt"}
-    STORE2 = {0: "16B plain", 1: "16B nt", 2: "16B sc1"}
+    STORE1 = {1: "8B plain", 2: "8B nt", 3: "pair-rows 16B plain", 4: "pair-rows 16B sc1", 5: "pair-rows 16B nt"}
+    STORE2 = {1: "16B plain", 2: "16B nt", 3: "16B sc1"}
 
-    def k1(name, vpl, store, blk, xcd=0, rot=True, wf=8):
+    def k1(name, vpl, store, blk, xcd=1, rot=True, wf=8):
         def f(i):
             L.mxg_tune(b"osc_vpl", vpl); L.mxg_tune(b"osc_store", store); L.mxg_tune(b"osc_block", blk); L.mxg_tune(b"osc_xcd", xcd)
             chk(L.mxg_osc_render(wf, V, B, freq.ptr, 0, None, None, phase.ptr, hold.ptr, region(rot), None), name)
         out[name] = f
-    for xcd in (0, 1):
+    for xcd in (1, 2):
         for st, nm in STORE1.items():
-            k1("K1 sinebuf 1v/lane %s blk256%s" % (nm, " xcd" if xcd else ""), 1, st, 256, xcd)
+            k1("K1 sinebuf 1v/lane %s blk256%s" % (nm, " xcd" if xcd == 2 else ""), 1, st, 256, xcd)
         for st, nm in STORE2.items():
             for blk in (256, 512):
-                k1("K1 sinebuf 2v/lane %s blk%d%s" % (nm, blk, " xcd" if xcd else ""), 2, st, blk, xcd)
-    k1("K1 sinebuf 1v/lane pair-rows 16B sc1 blk128", 1, 3, 128)
-    k1("K1 sinebuf 1v/lane pair-rows 16B plain blk512", 1, 2, 512)
-    k1("K1 sinebuf default knobs", 0, -1, 256, xcd=-1)
-    k1("K1 sinebuf default knobs same", 0, -1, 256, xcd=-1, rot=False)
-    k1("K1 sinebuf4 default knobs", 0, -1, 256, xcd=-1, wf=9)
-    k1("K1 sinebuf4 pair-rows 16B sc1", 1, 3, 256, wf=9)
-    k1("K1 saw default knobs", 0, -1, 256, xcd=-1, wf=2)
-    k1("K1 saw pair-rows 16B sc1", 1, 3, 256, wf=2)
+                k1("K1 sinebuf 2v/lane %s blk%d%s" % (nm, blk, " xcd" if xcd == 2 else ""), 2, st, blk, xcd)
+    k1("K1 sinebuf 1v/lane pair-rows 16B sc1 blk128", 1, 4, 128, 1)
+    k1("K1 sinebuf 1v/lane pair-rows 16B plain blk512", 1, 3, 512, 1)
+    k1("K1 sinebuf default knobs", 0, 0, 256, xcd=0)
+    k1("K1 sinebuf default knobs same", 0, 0, 256, xcd=0, rot=False)
+    k1("K1 sinebuf4 default knobs", 0, 0, 256, xcd=0, wf=9)
+    k1("K1 saw default knobs", 0, 0, 256, xcd=0, wf=2)
     return out, nbytes, keep
 
 
@@ -164,7 +162,7 @@ for V in [int(x) for x in args.voices.split(",")]:
     d = float(np.median(res["K1 sinebuf default knobs"]))
     summary.append((V, nbytes, best_fill, best_k1, d))
     # knobs back to their defaults
-    L.mxg_tune(b"osc_vpl", 0); L.mxg_tune(b"osc_store", -1); L.mxg_tune(b"osc_block", 256); L.mxg_tune(b"osc_xcd", -1)
+    L.mxg_tune(b"osc_vpl", 0); L.mxg_tune(b"osc_store", 0); L.mxg_tune(b"osc_block", 256); L.mxg_tune(b"osc_xcd", 0)
     del keep
 
 emit()
