@@ -347,6 +347,11 @@ int mxg_sample_render_trig(int mode, size_t V, size_t N, const double *d_samples
                            const double *d_p0, const double *d_p1, double *d_position,
                            double *d_tprev, int32_t *d_tfirst, double *d_out, void *stream);
 
+/* int32 <-> int64 copies of a device array (hosts that carry every integer member of a slot as int64 -- include/maximilian.h --
+ * feed the int32 flag arrays above through these). */
+int mxg_i64_from_i32(int64_t *d_dst, const int32_t *d_src, size_t n, void *stream);
+int mxg_i32_from_i64(int32_t *d_dst, const int64_t *d_src, size_t n, void *stream);
+
 /* maxiSample::load(fileName, channel) / read() (C:605-692): parse a 16-bit PCM RIFF/WAVE file the way the
  * reference walks it, upload the payload as int16 and de-interleave + normalise on the device
  * (amplitudes[i] = short/32767.0, C:679, bit-exact).  Returns the device sample buffer (guarded like
@@ -462,6 +467,11 @@ int mxg_convolve_impulse(const mxg_convolve *c, float *h_real, float *h_imag);
  * mode 1 = as intended (the sums reach the inverse transform).  Both bit-exact against the reference (tests/test_gpu_convolve.py). */
 int mxg_convolve_play(mxg_convolve *c, const float *d_in, size_t nblocks, float *d_out, int mode, void *stream);
 int mxg_convolve_reset(mxg_convolve *c);
+/* The two halves of one block of play(), for a host that is called once per sample (include/maxiConvolve.h): the output of the
+ * NEXT fftsize samples depends only on the sums the previous input frame left, so it can be fetched before those samples'
+ * inputs exist; mxg_convolve_input then takes the fftsize inputs (delay line, sums).  output + input == play(nblocks = 1). */
+int mxg_convolve_output(mxg_convolve *c, float *d_out, int mode, void *stream);
+int mxg_convolve_input(mxg_convolve *c, const float *d_in, void *stream);
 
 /* ---- maxiMFCC batch --------------------------------------------------------------------- */
 /* maxiMFCC::setup(numBins, numFilters, numCoeffs, minFreq, maxFreq) (L/maxiMFCC.h:56-75): builds

@@ -404,19 +404,43 @@ struct FilterPool : Pool {  // state: x, y, outputs[0..2] (H:289-302)
     }
 };
 
-struct SamplePool : Pool {  // state: position (H:606); key = the device sample buffer
-    SamplePool() : Pool(1, 0) {}
+// state: position, zxTrig.previousValue, phasorPrev | zxTrig.firstTrigger, phasorFirst (H:606, 593-594, 731-732); key = the
+// device sample buffer.  Call arguments: a[0] speed / frequency, a[1] a[2] start, end (or offset, length / pos of the playOnZX
+// family), a[3] the per-sample first argument of the trigger-driven players (trigger signal, phasor) or the caller's `pos`.
+struct SamplePool : Pool {
+    SamplePool() : Pool(3, 2) {}
     struct Buf { double *d = nullptr; size_t len = 0; int rate = 44100; };
+    static constexpr int kFromPos = 15;  // playAtSpeedBetweenPointsFromPos: a pure function of its arguments
     void enqueue(Group &G) override {
-        const size_t n = G.m.size();
+        const size_t n = G.m.size(), L = G.L;
         const Buf *b = static_cast<const Buf *>(G.sig[0].key);
+        const int mode = G.sig[0].method;
         std::vector<double> par(3 * n);
         for (size_t j = 0; j < n; j++)
-            for (int k = 0; k < 3; k++) par[(size_t)k * n + j] = G.sig[j].a[k];  // speed / frequency, start, end
+            for (int k = 0; k < 3; k++) par[(size_t)k * n + j] = G.sig[j].a[k];
         double *dp = G.d_par.need(3 * n);
         check(mxg_memcpy_h2d(dp, par.data(), sizeof(double) * 3 * n, stream), "h2d smp");
-        check(mxg_sample_render(G.sig[0].method, n, G.L, b->d, b->len, b->rate, dp, 0, dp + n, dp + 2 * n, G.d_state.p,
-                                G.d_out.p, stream), "mxg_sample_render");
+        if (mode <= MXG_SMP_PLAYATSPEEDBETWEENPOINTS) {
+            check(mxg_sample_render(mode, n, L, b->d, b->len, b->rate, dp, 0, dp + n, dp + 2 * n, G.d_state.p, G.d_out.p, stream),
+                  "mxg_sample_render");
+            return;
+        }
+        std::vector<double> sig(L * n);  // the first argument, held over the block (the prediction)
+        for (size_t j = 0; j < n; j++)
+            for (size_t t = 0; t < L; t++) sig[t * n + j] = G.sig[j].a[3];
+        check(mxg_memcpy_h2d(G.d_in.need(L * n), sig.data(), sizeof(double) * L * n, stream), "h2d smp signal");
+        if (mode == kFromPos) {
+            check(mxg_sample_render_frompos(n, L, b->d, b->len, dp, 0, dp + n, dp + 2 * n, G.d_in.p, G.d_out.p, stream),
+                  "mxg_sample_render_frompos");
+            return;
+        }
+        const bool pha = mode == MXG_SMP_PLAYWITHPHASOR;  // its own previous value / first flag (H:731-732)
+        int32_t *tf = G.d_trig.need(n);
+        int64_t *flag = G.d_istate.p + (pha ? n : 0);
+        check(mxg_i32_from_i64(tf, flag, n, stream), "mxg_i32_from_i64");
+        check(mxg_sample_render_trig(mode, n, L, b->d, b->len, b->rate, G.d_in.p, dp, 0, dp + n, dp + 2 * n, G.d_state.p,
+                                     G.d_state.p + (pha ? 2 : 1) * n, tf, G.d_out.p, stream), "mxg_sample_render_trig");
+        check(mxg_i64_from_i32(flag, tf, n, stream), "mxg_i64_from_i32");
     }
 };
 
@@ -633,35 +657,120 @@ public:
     double getResonance() const { return resonance; }
 };
 
+// ---- maxiTrigger (H:564-596), maxiLagExp (H:499-560): host-side helpers of the reference, plain arithmetic -----------
+class maxiTrigger {
+public:
+    double onZX(double input) {  // H:569-579
+        double isZX = 0.0;
+        if ((previousValue <= 0.0 || firstTrigger) && input > 0) isZX = 1.0;
+        previousValue = input;
+        firstTrigger = 0;
+        return isZX;
+    }
+    double onChanged(double input, double tolerance) {  // H:582-591
+        double changed = 0;
+        if (std::abs(input - previousValue) > tolerance) changed = 1;
+        previousValue = input;
+        return changed;
+    }
+
+private:
+    double previousValue = 1;
+    bool firstTrigger = 1;
+};
+template <class T>
+class maxiLagExp {  // H:499-560
+public:
+    T alpha, alphaReciprocal;
+    T val;
+    maxiLagExp() { init(0.5, 0.0); }
+    maxiLagExp(T initAlpha, T initVal) { init(initAlpha, initVal); }
+    void init(T initAlpha, T initVal) {
+        alpha = initAlpha;
+        alphaReciprocal = 1.0 - alpha;
+        val = initVal;
+    }
+    inline void addSample(T newVal) { val = (alpha * newVal) + (alphaReciprocal * val); }
+    void setAlpha(T alpha_) { alpha = alpha_; }
+    void setAlphaReciprocal(T alphaReciprocal_) { alphaReciprocal = alphaReciprocal_; }
+    void setVal(T val_) { val = val_; }
+    T getAlpha() const { return alpha; }
+    T getAlphaReciprocal() const { return alphaReciprocal; }
+    inline T value() const { return val; }
+};
+
 // ---- maxiSample (H:602-790; C:605-1075): the play family over a buffer uploaded once ---------------------------------
+// The buffer lives on the device.  The members that EDIT it (normalise, autoTrim, loopRecord) work on a host copy fetched on
+// first use and write back what they changed -- setup-time utilities of the reference, not the per-sample path -- with the
+// reference's own expressions.  `amplitudes` itself is not a member: read it with getAmplitudes().
 class maxiSample {
     using Pool = maxigpu::ps::SamplePool;
     maxigpu::ps::Slot slot_;
     Pool::Buf buf_;
-    int32_t hdr_[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // chunk size, fmt size, format, channels, rate, byte rate, block align, bits (mxg_sample_load_wav)
-    double run(int mode, double a = 0.0, double start = 0.0, double end = 0.0) {
+    std::vector<double> host_;  // host copy of the buffer (normalise / autoTrim / loopRecord / getAmplitudes), empty = not fetched
+    double recordPosition_ = 0;
+    maxiLagExp<double> loopRecordLag_;
+    double run(int mode, double a = 0.0, double p0 = 0.0, double p1 = 0.0, double sig = 0.0) {
         if (!buf_.d) return 0.0;
         maxigpu::ps::Call c;
         c.method = mode;
         c.key = &buf_;
-        c.a[0] = a; c.a[1] = start; c.a[2] = end;
+        c.a[0] = a; c.a[1] = p0; c.a[2] = p1; c.a[3] = sig;
         return maxigpu::ps::pool<Pool>().call(slot_, c);
+    }
+    void fresh_state() {  // what a newly constructed maxiSample holds: zxTrig {1, first}, phasorPrev 0, phasorFirst (H:593-594, 731-732)
+        slot_.sd[1] = 1.0;
+        slot_.sd[2] = 0.0;
+        slot_.si[0] = 1;
+        slot_.si[1] = 1;
     }
     void drop() {
         maxigpu::ps::pool<Pool>().settle(slot_);
         if (buf_.d) mxg_sample_free(buf_.d);
         buf_.d = nullptr;
         buf_.len = 0;
+        host_.clear();
+    }
+    void upload(const double *data, size_t n) {
+        buf_.d = mxg_sample_upload(data, n);
+        if (!buf_.d) throw std::runtime_error(std::string("mxg_sample_upload: ") + mxg_last_error());
+        buf_.len = n;
+    }
+    void fetch_host() {
+        if (host_.size() == buf_.len) return;
+        host_.assign(buf_.len, 0.0);
+        if (buf_.len) maxigpu::ps::check(mxg_memcpy_d2h(host_.data(), buf_.d, sizeof(double) * buf_.len, nullptr), "d2h sample");
     }
 
 public:
+    short myChannels = 0;
     int mySampleRate = 44100;
-    maxiSample() { maxigpu::ps::pool<Pool>().attach(slot_); }
+    short myBitsPerSample = 0;
+    string myPath;
+    int myChunkSize = 0, mySubChunk1Size = 0, readChannel = 0;
+    short myFormat = 0;
+    int myByteRate = 0;
+    short myBlockAlign = 0;
+    maxiSample() { maxigpu::ps::pool<Pool>().attach(slot_); fresh_state(); }
     ~maxiSample() { drop(); maxigpu::ps::pool<Pool>().detach(slot_); }
     maxiSample(const maxiSample &) = delete;
-    maxiSample &operator=(const maxiSample &) = delete;
+    maxiSample &operator=(const maxiSample &source) {  // H:626-637: position = 0, the source's channels and samples, the GLOBAL rate
+        if (this == &source) return *this;
+        maxiSample &src = const_cast<maxiSample &>(source);
+        src.fetch_host();
+        const std::vector<double> data = src.host_;
+        drop();
+        upload(data.data(), data.size());
+        myChannels = source.myChannels;
+        buf_.rate = mySampleRate = (int)maxiSettings::sampleRate;
+        slot_.sd[0] = 0;
+        recordPosition_ = 0;
+        return *this;
+    }
     bool load(string fileName, int channel = 0) {  // C:605-609 -> read() C:612-692
         drop();
+        myPath = fileName;
+        readChannel = channel;
         size_t len = 0;
         int32_t hdr[8];
         buf_.d = mxg_sample_load_wav(fileName.c_str(), channel, &len, hdr);
@@ -670,21 +779,26 @@ public:
             return false;
         }
         buf_.len = len;
+        myChunkSize = hdr[0]; mySubChunk1Size = hdr[1]; myFormat = (short)hdr[2]; myChannels = (short)hdr[3];
         buf_.rate = mySampleRate = hdr[4];
-        for (int i = 0; i < 8; i++) hdr_[i] = hdr[i];
+        myByteRate = hdr[5]; myBlockAlign = (short)hdr[6]; myBitsPerSample = (short)hdr[7];
         slot_.sd[0] = (double)len;  // position = size, C:681
         return true;
     }
+    bool save() { return save(myPath); }  // C:694-696
+    bool save(string filename) {           // C:698-725: shorts = round(a * 32767) on the device behind the 44-byte header of the members
+        if (!buf_.d) return false;
+        const int32_t hdr[8] = {myChunkSize, mySubChunk1Size, myFormat, myChannels, mySampleRate, myByteRate, myBlockAlign, myBitsPerSample};
+        return mxg_sample_save_wav(filename.c_str(), buf_.d, buf_.len, hdr, nullptr) == MXG_OK;
+    }
     string getSummary() {  // C:727-733: the header fields read() kept
-        return " Format: " + std::to_string(hdr_[2]) + "\n Channels: " + std::to_string(hdr_[3]) + "\n SampleRate: " +
-               std::to_string(mySampleRate) + "\n ByteRate: " + std::to_string(hdr_[5]) + "\n BlockAlign: " + std::to_string(hdr_[6]) +
-               "\n BitsPerSample: " + std::to_string(hdr_[7]);
+        return " Format: " + std::to_string(myFormat) + "\n Channels: " + std::to_string(myChannels) + "\n SampleRate: " +
+               std::to_string(mySampleRate) + "\n ByteRate: " + std::to_string(myByteRate) + "\n BlockAlign: " + std::to_string(myBlockAlign) +
+               "\n BitsPerSample: " + std::to_string(myBitsPerSample);
     }
     void setSample(vector<double> &sampleData) {  // H:670-678
         drop();
-        buf_.d = mxg_sample_upload(sampleData.data(), sampleData.size());
-        if (!buf_.d) throw std::runtime_error(std::string("mxg_sample_upload: ") + mxg_last_error());
-        buf_.len = sampleData.size();
+        upload(sampleData.data(), sampleData.size());
         buf_.rate = mySampleRate = 44100;
         slot_.sd[0] = (double)sampleData.size() - 1;
     }
@@ -692,9 +806,16 @@ public:
         setSample(sampleData);
         buf_.rate = mySampleRate = sampleRate;
     }
+    const vector<double> &getAmplitudes() { fetch_host(); return host_; }  // (the reference's public member `amplitudes`, read-only)
     size_t getLength() { return buf_.len; }
     bool isReady() { return buf_.len > 1; }
+    void clear() { drop(); }  // H:691: amplitudes.clear()
     void trigger() {  // C:597-600
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        slot_.sd[0] = 0;
+        recordPosition_ = 0;
+    }
+    void reset() {  // H:725
         maxigpu::ps::pool<Pool>().settle(slot_);
         slot_.sd[0] = 0;
     }
@@ -713,6 +834,101 @@ public:
     double playAtSpeedBetweenPoints(double frequency, double start, double end) {
         return run(MXG_SMP_PLAYATSPEEDBETWEENPOINTS, frequency, start, end);
     }
+    double playAtSpeedBetweenPointsFromPos(double frequency, double start, double end, double pos) {  // C:826-880 (pos by value)
+        return run(Pool::kFromPos, frequency, start, end, pos);
+    }
+    // the trigger-driven players (C:1006-1042) and playWithPhasor (C:753-816): zxTrig / phasorPrev / phasorFirst are slot state
+    double playWithPhasor(double pha) { return run(MXG_SMP_PLAYWITHPHASOR, 0.0, 0.0, 0.0, pha); }
+    double playOnZX(double trig) { return run(MXG_SMP_PLAYONZX, 0.0, 0.0, 0.0, trig); }
+    double playOnZXAtSpeed(double trig, double speed) { return run(MXG_SMP_PLAYONZXATSPEED, speed, 0.0, 0.0, trig); }
+    double playOnZXAtSpeedFromOffset(double trig, double speed, double offset) {
+        return run(MXG_SMP_PLAYONZXATSPEEDFROMOFFSET, speed, offset, 0.0, trig);
+    }
+    double playOnZXAtSpeedBetweenPoints(double trig, double speed, double offset, double length) {
+        return run(MXG_SMP_PLAYONZXATSPEEDBETWEENPOINTS, speed, offset, length, trig);
+    }
+    double loopSetPosOnZX(double trig, double position) { return run(MXG_SMP_LOOPSETPOSONZX, 0.0, position, 0.0, trig); }
+    // ---- buffer editing (host copy, the reference's expressions) ----
+    void normalise(double maxLevel) {  // C:1126-1137
+        if (!buf_.len) return;
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        fetch_host();
+        double maxValue = 0;
+        for (size_t i = 0; i < host_.size(); i++)
+            if (std::abs(host_[i]) > maxValue) maxValue = std::abs(host_[i]);
+        float scale = maxLevel / maxValue;
+        for (size_t i = 0; i < host_.size(); i++) host_[i] = round(scale * host_[i]);
+        maxigpu::ps::check(mxg_memcpy_h2d(buf_.d, host_.data(), sizeof(double) * host_.size(), nullptr), "h2d sample");
+    }
+    // C:1139-1190.  The reference assigns the (still empty) trimmed vector to `amplitudes` BEFORE it copies the kept range out of
+    // it (C:1167-1172: undefined behaviour, in practice a crash); what it is evidently meant to do is restated here: keep
+    // [startMarker, endMarker), position = 0, then the fade of C:1179-1186 literally (its `fadeSize` IS the whole length for
+    // anything longer than 100 samples, and every element is scaled from both ends).
+    void autoTrim(float alpha, float threshold, bool trimStart, bool trimEnd) {
+        if (!buf_.len) return;
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        fetch_host();
+        size_t startMarker = 0;
+        if (trimStart) {
+            maxiLagExp<double> startLag(alpha, 0);
+            while (startMarker < host_.size()) {
+                startLag.addSample(std::abs(host_[startMarker]));
+                if (startLag.value() > threshold) break;
+                startMarker++;
+            }
+        }
+        int endMarker = (int)host_.size() - 1;
+        if (trimEnd) {
+            maxiLagExp<float> endLag(alpha, 0);
+            while (endMarker > 0) {
+                endLag.addSample(std::abs(host_[(size_t)endMarker]));
+                if (endLag.value() > threshold) break;
+                endMarker--;
+            }
+        }
+        cout << "Autotrim: start: " << startMarker << ", end: " << endMarker << endl;
+        if ((size_t)endMarker > startMarker) {
+            const size_t newLength = (size_t)endMarker - startMarker;
+            std::vector<double> newAmps(host_.begin() + (long)startMarker, host_.begin() + (long)(startMarker + newLength));
+            size_t fadeSize = 100;
+            if (newAmps.size() > fadeSize) fadeSize = newAmps.size();
+            for (size_t i = 0; i < fadeSize && i < newAmps.size(); i++) {
+                double factor = i / (double)fadeSize;
+                newAmps[i] = round(newAmps[i] * factor);
+                newAmps[newAmps.size() - 1 - i] = round(newAmps[newAmps.size() - 1 - i] * factor);
+            }
+            const int rate = buf_.rate;
+            drop();
+            upload(newAmps.data(), newAmps.size());
+            host_ = newAmps;
+            buf_.rate = rate;
+            slot_.sd[0] = 0;
+            recordPosition_ = 0;
+        }
+    }
+    // H:706-722: one sample recorded into the buffer; the element it changes goes to the device at once (and whatever block a
+    // player had rendered ahead is dropped: a play() of a later sample must see it)
+    void loopRecord(double newSample, const bool recordEnabled, const double recordMix, double start, double end) {
+        if (!buf_.len) return;
+        fetch_host();
+        loopRecordLag_.addSample(recordEnabled);
+        if (recordPosition_ < start * host_.size()) recordPosition_ = start * host_.size();
+        if (recordEnabled) {
+            double currentSample = host_[(size_t)(int)recordPosition_] / 32767.0;
+            newSample = (recordMix * currentSample) + ((1.0 - recordMix) * newSample);
+            newSample *= loopRecordLag_.value();
+            const size_t at = (size_t)(unsigned long)recordPosition_;
+            if (at < host_.size()) {
+                maxigpu::ps::pool<Pool>().settle(slot_);
+                host_[at] = newSample * 32767;
+                maxigpu::ps::check(mxg_memcpy_h2d(buf_.d + at, &host_[at], sizeof(double), nullptr), "h2d sample element");
+            }
+        }
+        ++recordPosition_;
+        if (recordPosition_ >= end * host_.size()) recordPosition_ = start * host_.size();
+    }
+    // (for the grain classes below: the device buffer they render from)
+    const double *deviceSamples() const { return buf_.d; }
 };
 
 // ---- maxiDelayline (H:266-284; C:415-439): the ring lives on the device, one sample per launch --------------------

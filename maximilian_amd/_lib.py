@@ -98,6 +98,8 @@ SIGNATURES = {
     "mxg_convolve_impulse": (c_int, [c_void_p, c_void_p, c_void_p]),
     "mxg_convolve_play": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
     "mxg_convolve_reset": (c_int, [c_void_p]),
+    "mxg_convolve_output": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "mxg_convolve_input": (c_int, [c_void_p, c_void_p, c_void_p]),
     "mxg_sampler_freq_host": (c_int, [c_size_t, c_void_p, c_size_t, c_void_p]),
     "mxg_sampler_render": (c_int, [c_size_t, c_size_t, c_int, c_int, c_void_p, c_size_t] + [c_void_p] * 12),
     "mxg_fft_features": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -135,6 +137,8 @@ SIGNATURES = {
     "mxg_mixq_flush": (c_int, [c_void_p, c_void_p]),
     "mxg_mixq_result": (c_void_p, [c_void_p, POINTER(c_size_t), POINTER(c_size_t)]),
     "mxg_mixq_release": (c_int, [c_void_p, c_void_p]),
+    "mxg_i64_from_i32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mxg_i32_from_i64": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mxg_calib_fill": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
     "mxg_calib_fill_ex": (c_int, [c_void_p, c_size_t, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }

@@ -201,4 +201,48 @@ int mxg_convolve_play(mxg_convolve *c, const float *d_in, size_t nblocks, float 
     return MXG_OK;
 }
 
+// play() in the two halves a per-sample host needs (include/maxiConvolve.h): the output block of the NEXT fftsize samples depends
+// only on the sums the previous input frame left (:76-107: maxiIFFT consumes them from the sample after that frame on), so it can
+// be fetched before those samples' inputs exist; the input block then updates the delay line and the sums.
+// mxg_convolve_output followed by mxg_convolve_input == mxg_convolve_play(nblocks = 1), bit for bit.
+int mxg_convolve_output(mxg_convolve *c, float *d_out, int mode, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(c && d_out, "null object or pointer");
+    MXG_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (as the reference computes) or 1 (as intended)");
+    return mxg_ifft_batch_complex(c->iplan, c->d_sumR, c->d_sumI, 1, mode == 0 ? 1 : 0, c->d_obuf, d_out, nullptr, resolve_stream(stream));
+}
+
+int mxg_convolve_input(mxg_convolve *c, const float *d_in, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(c && d_in, "null object or pointer");
+    hipStream_t st = resolve_stream(stream);
+    const int F = c->fftsize, bins = c->bins, nfr = c->frames;
+    const size_t tail = nfr > 1 ? (size_t)nfr - 1 : 0;
+    float *scr = nullptr;
+    const size_t hist = (tail + 1) * (size_t)bins, sums = 2 * (size_t)bins;
+    if (int s = scratch_get(SCR_CONVOLVE, st, sizeof(float) * 2 * (hist + sums), (void **)&scr)) return s;
+    float *HR = scr, *HI = scr + hist, *SR = scr + 2 * hist, *SI = SR + sums;
+    if (tail) {
+        MXG_HIP(hipMemcpyAsync(HR, c->d_tailR, sizeof(float) * tail * bins, hipMemcpyDeviceToDevice, st));
+        MXG_HIP(hipMemcpyAsync(HI, c->d_tailI, sizeof(float) * tail * bins, hipMemcpyDeviceToDevice, st));
+    }
+    if (int s = mxg_fft_batch(c->fplan, d_in, (size_t)F, 1, HR + tail * bins, HI + tail * bins, nullptr, nullptr, st)) return s;
+    if (nfr > 0) {
+        KernelTimer kt("conv_mac_kernel", st);
+        hipLaunchKernelGGL(conv_mac_kernel, dim3((unsigned)((bins + 255) / 256)), dim3(256), 0, st, nfr, bins, (size_t)1, c->d_impR,
+                           c->d_impI, HR, HI, SR, SI);
+        MXG_HIP(hipGetLastError());
+    } else {
+        MXG_HIP(hipMemsetAsync(SR + bins, 0, sizeof(float) * bins, st));
+        MXG_HIP(hipMemsetAsync(SI + bins, 0, sizeof(float) * bins, st));
+    }
+    MXG_HIP(hipMemcpyAsync(c->d_sumR, SR + bins, sizeof(float) * bins, hipMemcpyDeviceToDevice, st));
+    MXG_HIP(hipMemcpyAsync(c->d_sumI, SI + bins, sizeof(float) * bins, hipMemcpyDeviceToDevice, st));
+    if (tail) {
+        MXG_HIP(hipMemcpyAsync(c->d_tailR, HR + bins, sizeof(float) * tail * bins, hipMemcpyDeviceToDevice, st));
+        MXG_HIP(hipMemcpyAsync(c->d_tailI, HI + bins, sizeof(float) * tail * bins, hipMemcpyDeviceToDevice, st));
+    }
+    return MXG_OK;
+}
+
 }  // extern "C"

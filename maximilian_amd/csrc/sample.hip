@@ -650,7 +650,35 @@ __global__ __launch_bounds__(256) void sample_frompos_kernel(size_t V, size_t N,
 
 using namespace mxg;
 
+namespace mxg {
+namespace {
+__global__ void widen_i32_kernel(int64_t *dst, const int32_t *src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (int64_t)src[i];
+}
+__global__ void narrow_i64_kernel(int32_t *dst, const int64_t *src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (int32_t)src[i];
+}
+}  // namespace
+}  // namespace mxg
+
 extern "C" {
+
+// State plumbing for hosts that keep every integer member as int64 (the per-sample engine of include/maximilian.h): the flag
+// arrays of the trigger-driven players (maxiTrigger::firstTrigger, phasorFirst) are int32 on this ABI.
+int mxg_i64_from_i32(int64_t *d_dst, const int32_t *d_src, size_t n, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(d_dst && d_src, "null device pointer");
+    if (n) hipLaunchKernelGGL(widen_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, resolve_stream(stream), d_dst, d_src, n);
+    return check_hip(hipGetLastError(), "widen_i32_kernel launch");
+}
+int mxg_i32_from_i64(int32_t *d_dst, const int64_t *d_src, size_t n, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(d_dst && d_src, "null device pointer");
+    if (n) hipLaunchKernelGGL(narrow_i64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, resolve_stream(stream), d_dst, d_src, n);
+    return check_hip(hipGetLastError(), "narrow_i64_kernel launch");
+}
 
 int mxg_sample_render_frompos(size_t V, size_t N, const double *d_samples, size_t len, const double *d_freq, int fps,
                               const double *d_start, const double *d_end, const double *d_pos, double *d_out, void *stream) {

@@ -199,3 +199,43 @@ def test_reference_svftest_verbatim(golden, tmp_path):
     err = np.abs(got[:, 0] - exp).max() / np.abs(exp).max()
     print("svftest: max relative difference %.3e (allowed %.1e)" % (err, MOD_FILTER_RTOL))
     assert np.abs(exp).max() > 0.05 and err <= MOD_FILTER_RTOL
+
+
+# ---- round 3: the rest of the drop-in surface (include/maxiGrains.h, maxiConvolve.h, maxiSynths.h, maxiSample's trigger-driven
+# players and buffer editors), each through a patch compiled both ways -------------------------------------------------------
+def _run_patch(tag, frames, tmp_path):
+    import shutil
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "wav", "mono.wav"), str(tmp_path / "mono.wav"))
+    return run_dropin(tag, frames, tmp_path, cwd=str(tmp_path))
+
+
+def test_granular_patch_bit_exact(golden, tmp_path):
+    """tests/patches/granular_patch.cpp: maxiTimeStretch<hann>, maxiPitchShift<hamming> and maxiStretch<triangle> called once per
+    sample with stepping arguments, next to a maxiOsc::noise() that shares the process-wide rand() stream with the grain schedulers'
+    jitter (`randomOffset = rand() % 10`, L/maxiGrains.h:352): every sample of both channels identical to the reference's, i.e. the
+    grain arithmetic, the schedulers, the rewinds at argument changes AND the order of the rand() draws."""
+    g = golden("dropin_r3.npz")
+    got, log = _run_patch("p2", g["exp2_l"].shape[0], tmp_path)
+    assert_bits_equal(got[:, 0], g["exp2_l"], "granular patch, left")
+    assert_bits_equal(got[:, 1], g["exp2_r"], "granular patch, right")
+    assert np.abs(g["exp2_l"]).max() > 0.5
+
+
+def test_sample_trigger_players_and_editors_patch_bit_exact(golden, tmp_path):
+    """tests/patches/sampler_zx_patch.cpp: playOnZX / ...AtSpeed / ...FromOffset / ...BetweenPoints, loopSetPosOnZX, playWithPhasor
+    under a phasor, playAtSpeedBetweenPointsFromPos, operator=, normalise, reset and loopRecord into a sample that is playing."""
+    g = golden("dropin_r3.npz")
+    got, _ = _run_patch("p3", g["exp3_l"].shape[0], tmp_path)
+    assert_bits_equal(got[:, 0], g["exp3_l"], "trigger-driven players")
+    assert_bits_equal(got[:, 1], g["exp3_r"], "normalise / reset / loopRecord + play")
+
+
+def test_convolve_and_sampler_patch_bit_exact(golden, tmp_path):
+    """tests/patches/convolve_sampler_patch.cpp: maxiConvolve::setup(file, 256, 64) + play(w) per sample (the reference's output:
+    its COMPLEX-mode inverse never sees the sums, so silence -- reproduced) and an eight-slot maxiSampler driven by midiNoteOn /
+    trigger / midiNoteOff / setPitch between play() calls."""
+    g = golden("dropin_r3.npz")
+    got, _ = _run_patch("p4", g["exp4_l"].shape[0], tmp_path)
+    assert_bits_equal(got[:, 0], g["exp4_l"], "maxiConvolve")
+    assert_bits_equal(got[:, 1], g["exp4_r"], "maxiSampler")
+    assert np.abs(g["exp4_r"]).max() > 0.05
