@@ -621,6 +621,10 @@ public:
 
 protected:
     int mode_ = 0;
+    mxg_grain_plan *plan_handle() const { return plan_; }
+    const double *speeds() const { return speed_.get(); }
+    double *state() { return st_.get(); }
+    double *grains() { return gst_.get(); }
     void plan(double grainLength) {
         if (!plan_ || grainLength != grainLength_) {
             if (plan_) mxg_grain_plan_destroy(plan_);
@@ -644,4 +648,142 @@ class maxiPitchShiftBank : public maxiTimeStretchBank {
 public:
     maxiPitchShiftBank(size_t streams, maxiSampleBank *sample, int window_kind = 0)
         : maxiTimeStretchBank(streams, sample, window_kind) { mode_ = 3; }
+};
+
+// ---- maxiStretch bank (L/maxiGrains.h:437-542): pitch (grain speed) and time stretch uncoupled, the default loop ----------
+class maxiStretchBank : public maxiTimeStretchBank {
+public:
+    maxiStretchBank(size_t streams, maxiSampleBank *sample, int window_kind = 0)
+        : maxiTimeStretchBank(streams, sample, window_kind), nS_(streams), smp_(sample), rate_(streams) { mode_ = 1; }
+    void setPitch(const std::vector<double> &pitchstretch) { setSpeeds(pitchstretch); }  // the first argument of play()
+    void setRate(const std::vector<double> &timestretch) { rate_.upload(timestretch); }   // the second
+    // play(pitchstretch, timestretch, grainLength, overlaps) for N samples of every stream -> d_out [N][S]; d_rnd (optional):
+    // int32 [S][R], the values rand() % 10 returns at the spawns of each stream (NULL: 0, no jitter)
+    void play(double grainLength, int overlaps, size_t N, double *d_out, const int32_t *d_rnd = nullptr, size_t R = 0,
+              void *stream = nullptr) {
+        plan(grainLength);
+        maxigpu::check(mxg_granular_render(plan_handle(), 1, nS_, N, smp_->deviceSamples(), smp_->getLength(), overlaps, speeds(),
+                                           rate_.get(), nullptr, d_rnd, R, state(), grains(), d_out, stream), "mxg_granular_render");
+    }
+
+private:
+    size_t nS_;
+    maxiSampleBank *smp_;
+    maxigpu::DeviceArray<double> rate_;
+};
+
+// ---- maxiConvolve (L/maxiConvolve.h:19-34, maxiConvolve.cpp:13-107), block form --------------------------------------------
+// setup() analyses the impulse (a maxiSampleBank's buffer, its play head where load() left it); play() takes nblocks * fftsize
+// input samples at once.  as_intended = false reproduces what the reference computes (its COMPLEX-mode inverse never receives the
+// sums: silence after the window), true what it was written to do; both bit-exact (include/maxigpu.h, mxg_convolve_play).
+class maxiConvolveBlock {
+public:
+    ~maxiConvolveBlock() { if (c_) mxg_convolve_destroy(c_); }
+    void setup(const std::vector<double> &impulse, double position0, int fftsize = 1024, int hopsize = 256) {
+        if (c_) mxg_convolve_destroy(c_);
+        c_ = mxg_convolve_create(impulse.data(), impulse.size(), position0, fftsize, hopsize);
+        if (!c_) throw std::runtime_error(std::string("mxg_convolve_create: ") + mxg_last_error());
+        fftsize_ = fftsize;
+    }
+    int frames() const { return c_ ? mxg_convolve_frames(c_) : 0; }
+    int fftSize() const { return fftsize_; }
+    void play(const float *d_in, size_t nblocks, float *d_out, bool as_intended = false, void *stream = nullptr) {
+        maxigpu::check(mxg_convolve_play(c_, d_in, nblocks, d_out, as_intended ? 1 : 0, stream), "mxg_convolve_play");
+    }
+    void reset() { maxigpu::check(mxg_convolve_reset(c_), "mxg_convolve_reset"); }
+
+private:
+    mxg_convolve *c_ = nullptr;
+    int fftsize_ = 0;
+};
+
+// ---- maxiSampler banks (L/maxiSynths.h:137-187, maxiSynths.cpp:262-491) ------------------------------------------------------
+// NS samplers of `voices` slots each over one sample; the control methods edit host copies of the slot state between renders,
+// exactly as the reference's methods edit its members; play(N) renders N calls of maxiSampler::play() for every sampler.
+class maxiSamplerBank {
+public:
+    maxiSamplerBank(size_t samplers, int voices, maxiSampleBank *sample)
+        : NS(samplers), voices_(voices), V(samplers * (size_t)voices), sample_(sample), pitch_(V, 0.0), gain_(V, 0.0), par_(4 * V),
+          hold_(V, 1), position_(V, 0.0), trig_(V, 0), outhold_(V, 0.0), dst_(2 * V, 0.0), ist_(6 * V, 0), currentVoice_(samplers, 0),
+          d_freq_(V), d_gain_(V), d_par_(4 * V), d_hold_(V), d_pos_(V), d_trig_(V), d_outhold_(V), d_dst_(2 * V), d_ist_(6 * V) {
+        for (size_t v = 0; v < V; v++) {  // ctor, maxiSynths.cpp:262-283
+            par_[0 * V + v] = mxg_env_coeff_host(0, 0);
+            par_[1 * V + v] = mxg_env_coeff_host(1, 1);
+            par_[2 * V + v] = 1.;
+            par_[3 * V + v] = mxg_env_coeff_host(2, 2000);
+            position_[v] = (double)sample->getLength();  // after load(); setSample leaves len - 1: use resetPositions()
+        }
+    }
+    bool sustain = true;
+    void resetPositions(double p) { pull(); std::fill(position_.begin(), position_.end(), p); dirty_ = true; }
+    void setPitch(size_t sampler, double pitchIn, bool setall = false) { for (size_t v : slots(sampler, setall)) pitch_[v] = pitchIn; }
+    void midiNoteOn(size_t sampler, double pitchIn, double velocity, bool setall = false) {  // :341-358
+        for (size_t v : slots(sampler, setall)) {
+            pitch_[v] = pitchIn;
+            if (!setall) gain_[v] = velocity / 128;
+        }
+    }
+    void midiNoteOff(size_t sampler, double pitchIn) {  // :360-372
+        pull();
+        for (int i = 0; i < voices_; i++)
+            if (pitch_[sampler * voices_ + i] == pitchIn) trig_[sampler * voices_ + i] = 0;
+        dirty_ = true;
+    }
+    void setEnvelope(size_t sampler, int which /*0 attack 1 decay 2 sustain 3 release*/, double value, bool setall = true) {
+        const double c = which == 2 ? value : mxg_env_coeff_host(which == 3 ? 2 : which, value);
+        for (size_t v : slots(sampler, setall)) par_[(size_t)which * V + v] = c;
+    }
+    void trigger(size_t sampler) {  // :484-491
+        pull();
+        const size_t v = sampler * voices_ + (size_t)currentVoice_[sampler];
+        trig_[v] = 1;
+        position_[v] = 0;
+        currentVoice_[sampler] = (currentVoice_[sampler] + 1) % voices_;
+        dirty_ = true;
+    }
+    // N calls of play() for every sampler -> d_mix [N][NS]
+    void play(size_t N, double *d_mix, void *stream = nullptr) {
+        if (dirty_) {
+            d_pos_.upload(position_); d_trig_.upload(trig_); d_outhold_.upload(outhold_); d_dst_.upload(dst_); d_ist_.upload(ist_);
+            dirty_ = false;
+        }
+        std::vector<double> freq(V);
+        maxigpu::check(mxg_sampler_freq_host(V, pitch_.data(), sample_->getLength(), freq.data()), "mxg_sampler_freq_host");
+        d_freq_.upload(freq); d_gain_.upload(gain_); d_par_.upload(par_); d_hold_.upload(hold_);
+        maxigpu::check(mxg_sampler_render(V, N, voices_, sustain ? 1 : 0, sample_->deviceSamples(), sample_->getLength(), d_freq_.get(),
+                                          d_gain_.get(), d_par_.get(), d_hold_.get(), d_pos_.get(), d_trig_.get(), d_outhold_.get(),
+                                          d_dst_.get(), d_ist_.get(), d_mix, nullptr, stream), "mxg_sampler_render");
+        fresh_ = false;
+    }
+
+private:
+    size_t NS;
+    int voices_;
+    size_t V;
+    maxiSampleBank *sample_;
+    std::vector<double> pitch_, gain_, par_;
+    std::vector<int64_t> hold_;
+    std::vector<double> position_;
+    std::vector<int32_t> trig_;
+    std::vector<double> outhold_, dst_;
+    std::vector<int64_t> ist_;
+    std::vector<int> currentVoice_;
+    maxigpu::DeviceArray<double> d_freq_, d_gain_, d_par_;
+    maxigpu::DeviceArray<int64_t> d_hold_;
+    maxigpu::DeviceArray<double> d_pos_;
+    maxigpu::DeviceArray<int32_t> d_trig_;
+    maxigpu::DeviceArray<double> d_outhold_, d_dst_;
+    maxigpu::DeviceArray<int64_t> d_ist_;
+    bool dirty_ = true, fresh_ = true;
+    std::vector<size_t> slots(size_t sampler, bool setall) const {
+        std::vector<size_t> r;
+        if (setall) for (int i = 0; i < voices_; i++) r.push_back(sampler * voices_ + (size_t)i);
+        else r.push_back(sampler * voices_ + (size_t)currentVoice_[sampler]);
+        return r;
+    }
+    void pull() {  // the device state back to the host copies (after a render)
+        if (dirty_ || fresh_) return;
+        position_ = d_pos_.download(); trig_ = d_trig_.download(); outhold_ = d_outhold_.download();
+        dst_ = d_dst_.download(); ist_ = d_ist_.download();
+    }
 };

@@ -478,7 +478,7 @@ extern "C" int mxg_osc_render_mix(int waveform, size_t V, size_t N, const double
     if (int s = scratch_get(SCR_OSC_MIX, st, sizeof(double) * need, (void **)&partial)) return s;
     if (V) {
         // per-voice block: pair rows of write-through 16-byte stores where whole pairs exist (knob osc_mix_store: 0 automatic,
-        // 1 plain 8-byte stores, 2 pair rows); time parts (knob osc_mix_split: 0 automatic = two below 2048 wavefronts)
+        // 1 plain 8-byte stores, 2 pair rows); time parts (knob osc_mix_split: 0 automatic = one)
         const int var = tune_get("osc_mix_var");
         int store = 0;
         if (d_out) {
@@ -487,7 +487,8 @@ extern "C" int mxg_osc_render_mix(int waveform, size_t V, size_t N, const double
             store = (pairs_ok && var == 0 && (knob == 2 || (knob == 0 && V * N * sizeof(double) >= ((size_t)32 << 20)))) ? 2 : 1;
         }
         int split = tune_get("osc_mix_split");
-        if (split == 0) split = nblocks * 4 >= 2048 ? 1 : 2;
+        if (split == 0) split = 1;  // (measured, MI355X 65 536 x 512 rotated: 1 part 51.1 us, 2 parts 53.6, 3 parts 54.8 -- the lane folds' permlane
+        // swaps do not overlap across wavefronts; the knob stays for other shapes)
         if (var != 0) split = 1;
         while (split > 1 && (size_t)(split - 1) * (((N + split - 1) / split + kMixChunk - 1) / kMixChunk * kMixChunk) >= N) split--;
         PartSync psync;
