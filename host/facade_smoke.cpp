@@ -107,6 +107,40 @@ int main(int argc, char **argv) {
         DeviceArray<double> gout(T * S);
         ps.play(0.01, 3, T, gout.get());
         dump(dir, "pitchshift", gout);
+
+        // round 3: maxiStretch bank, the block convolver and a bank of samplers
+        maxiStretchBank sbk(S, &one, 4);  // triangle window
+        std::vector<double> rate(S);
+        for (size_t s = 0; s < S; s++) rate[s] = 0.25 + 0.05 * s;
+        sbk.setPitch(speed);
+        sbk.setRate(rate);
+        sbk.play(0.02, 2, T, gout.get());
+        dump(dir, "stretch", gout);
+
+        std::vector<double> imp = one.download();
+        maxiConvolveBlock cv;
+        cv.setup(imp, (double)imp.size(), fs, hop);
+        const size_t nb = 6;
+        std::vector<float> cin(nb * fs);
+        for (size_t i = 0; i < cin.size(); i++) cin[i] = (float)((double)((i * 13) % 97) / 97.0 - 0.5);
+        DeviceArray<float> dcin(cin.size()), dcout(cin.size());
+        dcin.upload(cin);
+        cv.play(dcin.get(), nb, dcout.get(), true);
+        dump(dir, "convolve", dcout);
+
+        const size_t NS = 3, NP = 900;
+        maxiSamplerBank sp(NS, 4, &one);
+        DeviceArray<double> smix(NP * NS);
+        for (size_t k = 0; k < NS; k++) {
+            sp.midiNoteOn(k, -2.0 + 3.0 * k, 100.0 + k);
+            sp.trigger(k);
+        }
+        sp.play(300, smix.get());
+        sp.midiNoteOff(1, 1.0);
+        sp.midiNoteOn(0, 4.0, 64.0);
+        sp.trigger(0);
+        sp.play(600, smix.get() + 300 * NS);
+        dump(dir, "sampler", smix);
         mxg_sync();
     } catch (const std::exception &e) {
         fprintf(stderr, "facade_smoke: %s\n", e.what());

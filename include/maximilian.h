@@ -150,6 +150,14 @@ public:
         s.nextLen = 1;
         s.sig.method = -1;
     }
+    // forget the cached block WITHOUT computing the state at the current sample (the object is going away, or its state is about
+    // to be overwritten anyway): no launch -- in particular none from a destructor that runs during static destruction
+    void discard(Slot &s) {
+        leave_group(s);
+        s.pos = s.len = 0;
+        s.nextLen = 1;
+        s.sig.method = -1;
+    }
     double call(Slot &s, const Call &c) {
         if (s.pos < s.len && s.sig.same(c)) return s.blk[s.pos++];
         return miss(s, c);
@@ -724,8 +732,8 @@ class maxiSample {
         slot_.si[0] = 1;
         slot_.si[1] = 1;
     }
-    void drop() {
-        maxigpu::ps::pool<Pool>().settle(slot_);
+    void drop() {  // (every caller replaces the play head afterwards, or destroys the object)
+        maxigpu::ps::pool<Pool>().discard(slot_);
         if (buf_.d) mxg_sample_free(buf_.d);
         buf_.d = nullptr;
         buf_.len = 0;

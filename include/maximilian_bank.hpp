@@ -486,6 +486,11 @@ public:
     size_t getLength() const { return length_; }
     bool isReady() const { return length_ > 1; }
     const double *deviceSamples() const { return d_samples_; }
+    std::vector<double> download() const {  // the buffer as the reference's public `amplitudes` would hold it
+        std::vector<double> h(length_);
+        if (length_) maxigpu::check(mxg_memcpy_d2h(h.data(), d_samples_, sizeof(double) * length_, nullptr), "mxg_memcpy_d2h");
+        return h;
+    }
     void clear() { if (d_samples_) mxg_sample_free(d_samples_); d_samples_ = nullptr; length_ = 0; }
     void render(int mode, size_t N, double *d_out, void *stream = nullptr) {
         maxigpu::check(mxg_sample_render(mode, V, N, d_samples_, length_, mySampleRate, a_.get(), 0, start_.get(), end_.get(),

@@ -83,5 +83,38 @@ def test_facade_smoke_matches_python_mirror(mx, tmp_path):
         assert one.load(wav)
         ps = mx.maxiPitchShiftBank(32, one, "hann")
         assert_bits_equal(ps.play(0.5 + 0.05 * np.arange(32), 0.01, 3, 1500).numpy().ravel(), rd("pitchshift"), "pitchshift")
+        # round 3: maxiStretchBank, maxiConvolveBlock, maxiSamplerBank of include/maximilian_bank.hpp
+        sk = mx.maxiStretchBank(32, one, "triangle")
+        assert_bits_equal(sk.play(0.5 + 0.05 * np.arange(32), 0.25 + 0.05 * np.arange(32), 0.02, 2, 1500).numpy().ravel(), rd("stretch"),
+                          "stretch")
+        cv = mx.maxiConvolve()
+        cv.setup(one.amplitudes(), fs, hop)
+        cin = (((np.arange(6 * fs) * 13) % 97) / 97.0 - 0.5).astype(np.float32)
+        assert np.array_equal(cv.play(cin, mode=1).numpy().view(np.uint32), rd("convolve", np.float32).view(np.uint32))
+        sp = mx.maxiSamplerBank(3, 4)
+        assert sp.load(wav)
+        for k in range(3):                      # midiNoteOn / trigger on sampler k only (the bank's methods act on every sampler's
+            sp.pitch[k * 4 + sp.currentVoice[k]] = -2.0 + 3.0 * k   # current slot at once: set the slots directly)
+            sp.gain[k * 4 + sp.currentVoice[k]] = (100.0 + k) / 128
+            sp._pull()
+            sl = k * 4 + sp.currentVoice[k]
+            sp.trigger_state[sl] = 1
+            sp.position[sl] = 0.0
+            sp.currentVoice[k] = (sp.currentVoice[k] + 1) % 4
+            sp._state_dirty = True
+        a = sp.play(300).numpy()
+        sp._pull()
+        for i in range(4):                      # midiNoteOff(1, 1.0)
+            if sp.pitch[4 + i] == 1.0:
+                sp.trigger_state[4 + i] = 0
+        sp._state_dirty = True
+        sl = 0 * 4 + sp.currentVoice[0]         # midiNoteOn(0, 4.0, 64.0); trigger(0)
+        sp.pitch[sl] = 4.0
+        sp.gain[sl] = 64.0 / 128
+        sp.trigger_state[sl] = 1
+        sp.position[sl] = 0.0
+        sp.currentVoice[0] = (sp.currentVoice[0] + 1) % 4
+        b = sp.play(600).numpy()
+        assert_bits_equal(np.concatenate([a, b]).ravel(), rd("sampler"), "sampler bank")
     finally:
         mx.maxiSettings.setup(44100, 2, 1024)
