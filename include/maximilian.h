@@ -116,6 +116,8 @@ struct Group {
     DevBuf<int32_t> d_trig;
     PinBuf<double> h_out, h_state;
     PinBuf<int64_t> h_istate;
+    PinBuf<unsigned char> h_stage;  // pinned staging of one enqueue's parameter uploads (asynchronous copies: no host wait per array)
+    size_t stage_off = 0;
     ~Group() { if (event) mxg_event_destroy(event); }
 };
 
@@ -170,6 +172,18 @@ protected:
     virtual void enqueue(Group &G) = 0;
     int nD, nI;
     void *stream = nullptr;
+    // parameter uploads of one enqueue: copied into the group's pinned staging area and sent asynchronously on the pool's stream
+    // (a synchronous copy per array cost one host wait each: four of them per filter call).  The staging area is free again
+    // when the render that used it has been waited for -- which every caller of enqueue does before it enqueues for that group again.
+    void stage_begin(Group &G, size_t bytes) {
+        G.h_stage.need(bytes + 256);
+        G.stage_off = 0;
+    }
+    void put(Group &G, void *d_dst, const void *h_src, size_t bytes, const char *what) {
+        std::memcpy(G.h_stage.p + G.stage_off, h_src, bytes);
+        check(mxg_memcpy_h2d_async(d_dst, G.h_stage.p + G.stage_off, bytes, stream), what);
+        G.stage_off += (bytes + 15) & ~(size_t)15;
+    }
 
 private:
     std::vector<Slot *> slots;
@@ -348,12 +362,13 @@ struct OscPool : Pool {  // state: phase, output (H:173,176)
         for (size_t j = 0; j < n; j++)
             for (int k = 0; k < 3; k++) hp[(size_t)k * n + j] = G.sig[j].a[k];
         double *dp = G.d_par.need(3 * n);
-        check(mxg_memcpy_h2d(dp, hp.data(), sizeof(double) * 3 * n, stream), "h2d osc");
+        stage_begin(G, sizeof(double) * 3 * n + sizeof(int32_t) * G.L * n);
+        put(G, dp, hp.data(), sizeof(double) * 3 * n, "h2d osc");
         if (wf == 12) {  // noise(): a[0] holds the rand() draw
             std::vector<int32_t> ht(G.L * n);
             for (size_t t = 0; t < G.L; t++)
                 for (size_t j = 0; j < n; j++) ht[t * n + j] = (int32_t)G.sig[j].a[0];
-            check(mxg_memcpy_h2d(G.d_trig.need(G.L * n), ht.data(), sizeof(int32_t) * G.L * n, stream), "h2d rand");
+            put(G, G.d_trig.need(G.L * n), ht.data(), sizeof(int32_t) * G.L * n, "h2d rand");
             check(mxg_osc_noise(n, G.L, G.d_trig.p, G.d_state.p + n, G.d_out.p, stream), "mxg_osc_noise");
             return;
         }
@@ -379,10 +394,11 @@ struct EnvPool : Pool {  // state: amplitude, output | holdcount, attack/decay/s
             for (int k = 0; k < 4; k++) par[(size_t)k * n + j] = a[2 + k];
             hold[j] = (int64_t)a[6];
         }
-        check(mxg_memcpy_h2d(G.d_in.need(L * n), in.data(), sizeof(double) * L * n, stream), "h2d env in");
-        check(mxg_memcpy_h2d(G.d_trig.need(L * n), trig.data(), sizeof(int32_t) * L * n, stream), "h2d env trig");
-        check(mxg_memcpy_h2d(G.d_par.need(4 * n), par.data(), sizeof(double) * 4 * n, stream), "h2d env par");
-        check(mxg_memcpy_h2d(G.d_ipar.need(n), hold.data(), sizeof(int64_t) * n, stream), "h2d env hold");
+        stage_begin(G, sizeof(double) * (L * n + 4 * n) + sizeof(int32_t) * L * n + sizeof(int64_t) * n + 64);
+        put(G, G.d_in.need(L * n), in.data(), sizeof(double) * L * n, "h2d env in");
+        put(G, G.d_trig.need(L * n), trig.data(), sizeof(int32_t) * L * n, "h2d env trig");
+        put(G, G.d_par.need(4 * n), par.data(), sizeof(double) * 4 * n, "h2d env par");
+        put(G, G.d_ipar.need(n), hold.data(), sizeof(int64_t) * n, "h2d env hold");
         check(mxg_env_render(mode, n, L, G.d_in.p, G.d_trig.p, 1, G.d_par.p, G.d_ipar.p, G.d_state.p, G.d_istate.p, G.d_out.p,
                              stream), "mxg_env_render");
     }
@@ -403,10 +419,11 @@ struct FilterPool : Pool {  // state: x, y, outputs[0..2] (H:289-302)
         if (kind <= MXG_FLT_BANDPASS)  // cos / pow / sqrt of C:459-461, :492-495 on the host libm
             check(mxg_filter_coeffs_host(kind, n, cut.data(), res.data(), coef.data()), "mxg_filter_coeffs_host");
         double *dp = G.d_par.need(5 * n);
-        check(mxg_memcpy_h2d(G.d_in.need(L * n), in.data(), sizeof(double) * L * n, stream), "h2d flt in");
-        check(mxg_memcpy_h2d(dp, cut.data(), sizeof(double) * n, stream), "h2d flt cutoff");
-        check(mxg_memcpy_h2d(dp + n, res.data(), sizeof(double) * n, stream), "h2d flt res");
-        check(mxg_memcpy_h2d(dp + 2 * n, coef.data(), sizeof(double) * 3 * n, stream), "h2d flt coef");
+        stage_begin(G, sizeof(double) * (L * n + 5 * n) + 64);
+        put(G, G.d_in.need(L * n), in.data(), sizeof(double) * L * n, "h2d flt in");
+        put(G, dp, cut.data(), sizeof(double) * n, "h2d flt cutoff");
+        put(G, dp + n, res.data(), sizeof(double) * n, "h2d flt res");
+        put(G, dp + 2 * n, coef.data(), sizeof(double) * 3 * n, "h2d flt coef");
         check(mxg_filter_render(kind, n, L, G.d_in.p, dp, 0, dp + n, 0, dp + 2 * n, G.d_state.p, G.d_out.p, stream),
               "mxg_filter_render");
     }
@@ -427,7 +444,8 @@ struct SamplePool : Pool {
         for (size_t j = 0; j < n; j++)
             for (int k = 0; k < 3; k++) par[(size_t)k * n + j] = G.sig[j].a[k];
         double *dp = G.d_par.need(3 * n);
-        check(mxg_memcpy_h2d(dp, par.data(), sizeof(double) * 3 * n, stream), "h2d smp");
+        stage_begin(G, sizeof(double) * (3 * n + L * n) + 64);
+        put(G, dp, par.data(), sizeof(double) * 3 * n, "h2d smp");
         if (mode <= MXG_SMP_PLAYATSPEEDBETWEENPOINTS) {
             check(mxg_sample_render(mode, n, L, b->d, b->len, b->rate, dp, 0, dp + n, dp + 2 * n, G.d_state.p, G.d_out.p, stream),
                   "mxg_sample_render");
@@ -436,7 +454,7 @@ struct SamplePool : Pool {
         std::vector<double> sig(L * n);  // the first argument, held over the block (the prediction)
         for (size_t j = 0; j < n; j++)
             for (size_t t = 0; t < L; t++) sig[t * n + j] = G.sig[j].a[3];
-        check(mxg_memcpy_h2d(G.d_in.need(L * n), sig.data(), sizeof(double) * L * n, stream), "h2d smp signal");
+        put(G, G.d_in.need(L * n), sig.data(), sizeof(double) * L * n, "h2d smp signal");
         if (mode == kFromPos) {
             check(mxg_sample_render_frompos(n, L, b->d, b->len, dp, 0, dp + n, dp + 2 * n, G.d_in.p, G.d_out.p, stream),
                   "mxg_sample_render_frompos");
@@ -463,8 +481,9 @@ struct Filter2Pool : Pool {  // maxiDCBlocker / maxiSVF / maxiBiquad: three doub
             for (size_t t = 0; t < L; t++) in[t * n + j] = G.sig[j].a[0];
             for (size_t k = 0; k < rows; k++) coef[k * n + j] = G.sig[j].a[1 + k];
         }
-        check(mxg_memcpy_h2d(G.d_in.need(L * n), in.data(), sizeof(double) * L * n, stream), "h2d filter2 in");
-        check(mxg_memcpy_h2d(G.d_par.need(rows * n), coef.data(), sizeof(double) * rows * n, stream), "h2d filter2 coef");
+        stage_begin(G, sizeof(double) * (L * n + rows * n) + 64);
+        put(G, G.d_in.need(L * n), in.data(), sizeof(double) * L * n, "h2d filter2 in");
+        put(G, G.d_par.need(rows * n), coef.data(), sizeof(double) * rows * n, "h2d filter2 coef");
         check(mxg_filter2_render(kind, n, L, G.d_in.p, G.d_par.p, G.d_state.p, G.d_out.p, stream), "mxg_filter2_render");
     }
 };
@@ -478,7 +497,8 @@ struct EnvGenPool : Pool {  // state of mxg_envgen_render: [5] doubles, [7] int6
         std::vector<double> trig(L * n);
         for (size_t j = 0; j < n; j++)
             for (size_t t = 0; t < L; t++) trig[t * n + j] = G.sig[j].a[0];
-        check(mxg_memcpy_h2d(G.d_in.need(L * n), trig.data(), sizeof(double) * L * n, stream), "h2d envgen trig");
+        stage_begin(G, sizeof(double) * L * n + 64);
+        put(G, G.d_in.need(L * n), trig.data(), sizeof(double) * L * n, "h2d envgen trig");
         check(mxg_envgen_render(n, L, G.d_in.p, 1, sh->d_stages, sh->nstages, sh->loop, sh->retrigger, G.d_state.p, G.d_istate.p,
                                 G.d_out.p, stream), "mxg_envgen_render");
     }

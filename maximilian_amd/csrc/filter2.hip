@@ -93,6 +93,7 @@ int mxg_filter2_render(int kind, size_t V, size_t N, const double *d_in, const d
     if (block > 256) block = 256;
     const dim3 grid((unsigned)((V + block - 1) / block));
     hipStream_t st = resolve_stream(stream);
+    if (scan_applies(V, N)) return scan_filter_launch(kind, V, N, d_in, d_coef, d_st, d_out, st);  // tolerance mode (scan.hip)
     switch (kind) {
         case 0: hipLaunchKernelGGL((filter2_kernel<0>), grid, dim3(block), 0, st, V, N, d_in, d_coef, d_st, d_out); break;
         case 1: hipLaunchKernelGGL((filter2_kernel<1>), grid, dim3(block), 0, st, V, N, d_in, d_coef, d_st, d_out); break;

@@ -62,6 +62,10 @@ struct KernelTimer {
         if (!(cond)) return ::mxg::fail(MXG_ERR_INVALID, "%s: %s", __func__, msg); \
     } while (0)
 
+// ---- small banks of linear filters, parallel in time (scan.hip; tolerance mode, knob "time_parallel") ---------------------
+bool scan_applies(size_t V, size_t N);
+int scan_filter_launch(int kind, size_t V, size_t N, const double *in, const double *coef, double *st, double *out, hipStream_t s);
+
 // ---- asynchronous device errors ------------------------------------------------------------------------------------
 // A kernel that detects a failure the host cannot see at launch time (a time part that never got its signals, a grain render
 // with an exhausted rand() queue ...) stores a code in ONE word of pinned, device-mapped host memory.  Nothing synchronises for

@@ -513,6 +513,8 @@ int mxg_filter_render(int kind, size_t V, size_t N, const double *d_in, const do
     if (block > 256) block = 256;  // the bank kernels are compiled for <= 256 lanes per workgroup (512 VGPRs/lane budget)
     hipStream_t st = resolve_stream(stream);
     double sr = (double)settings().sampleRate;
+    if (!mod && (kind == MXG_FLT_LORES || kind == MXG_FLT_HIRES) && scan_applies(V, N))  // tolerance mode (scan.hip)
+        return scan_filter_launch(kind == MXG_FLT_LORES ? 3 : 4, V, N, d_in, d_coef, d_st, d_out, st);
 #define MXG_FLT_LAUNCH(K)                                                                        \
     if (mod)                                                                                     \
         hipLaunchKernelGGL((filter_kernel<K, true>), grid_for(V, block), dim3(block), 0, st, V, N, \
