@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--voices", type=int, default=0,
                     help="config2/3: voices per GPU (default 65 536 = BASELINE configs[1]); the default config2 run ALSO measures "
                          "a 131 072-voice bank (north_star: >= 10^5 voices) and reports it as `north_star_bank`")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="config2, one GPU: skip the extra measurements of the default run (single-buffer pass, write-ceiling fills, "
+                         "the 131 072-voice bank) -- for profiler passes, so that only the headline launches are traced")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: ranks of a --gpus N run share the visible GPUs (rank r uses device r mod count), the "
                          "id/barrier traffic goes over gloo and the mix queue reduces locally (no RCCL: two ranks cannot share "
@@ -492,7 +495,7 @@ def main():
 
     # ---- N = 1, config 2: what the headline is made of -----------------------------------------------------------------
     extras = {}
-    if world == 1 and args.workload == "config2" and mixdown == "off" and not args.tune:
+    if world == 1 and args.workload == "config2" and mixdown == "off" and not args.tune and not args.no_extras:
         nb = V * B * 8
         n_x = max(50, min(args.steps, 500))
         # (a) the same kernel into ONE reused block buffer (partly absorbed by the 256 MB Infinity Cache)

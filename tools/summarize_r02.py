@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/summarize_r02.py [tag] -- condense gpurun_out/prof_<tag>/ (tools/profile_r02.sh) into profiles/:
+"""tools/summarize_r02.py [tag] -- condense gpurun_out/prof_<tag>/ (tools/profile_r02.sh / profile_r03.sh) into profiles/:
   profiles/<tag>_<workload>_summary.md      per kernel: rocprofv3 kernel-trace average duration (timed launches), PMC HBM
                                              traffic per launch, next to the un-profiled bench.py line of the same command
   profiles/<tag>_<workload>_kernel_stats.csv the rocprofv3 --stats table, verbatim
@@ -73,7 +73,7 @@ for wl in sorted(d for d in os.listdir(src) if os.path.isdir(os.path.join(src, d
             mf[lab][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = ["# rocprofv3 summary `%s` / %s (MI355X)" % (tag, wl), "",
            "Command: `python bench.py %s` under `rocprofv3 --kernel-trace --stats` (per-kernel averages over the timed launches, i.e. the last"
-           % " ".join(bench.get("_args", [])) if False else "Passes: `rocprofv3 --kernel-trace --stats`, `--pmc WRITE_SIZE`, `--pmc FETCH_SIZE` (separate runs, tools/profile_r02.sh); "
+           % " ".join(bench.get("_args", [])) if False else "Passes: `rocprofv3 --kernel-trace --stats`, `--pmc WRITE_SIZE`, `--pmc FETCH_SIZE` (separate runs, tools/profile_r02.sh / profile_r03.sh); "
            "durations are averages over the second half of each kernel's launches (clock ramp and warm-up excluded).", "",
            "| kernel | launches | avg us (kernel-trace) | median | bench.py kernel_ms (HIP events, un-profiled) | WRITE_SIZE MB | FETCH_SIZE x2 MB | HBM traffic MB | VGPR | LDS B | grid x wg |",
            "|---|---|---|---|---|---|---|---|---|---|---|"]
@@ -85,7 +85,8 @@ for wl in sorted(d for d in os.listdir(src) if os.path.isdir(os.path.join(src, d
         w, f = p.get("WRITE_SIZE"), p.get("FETCH_SIZE")
         tot = (w or 0) + (f or 0) if (w is not None or f is not None) else None
         if tot is not None:
-            traffic[lab if wl != "config2_mix" or lab != "osc_kernel" else lab] = round(tot)
+            base_wl = wl in ("config2", "config2_mix", "config3", "config4", "config4_mfma", "config5")
+            traffic[lab if base_wl else "%s@%s" % (lab, wl)] = round(tot)  # (variants of a workload keep their own key)
         m = meta[lab]
         ev = bk.get(lab, {}).get("ms")
         out.append("| `%s` | %d | %.2f | %.2f | %s | %s | %s | %s | %s | %s | %s x %s |" % (
