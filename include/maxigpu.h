@@ -132,7 +132,7 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "time_parallel" (THE ONE EXCEPTION to "identical results": 1 lets banks of at most 4096 linear filters with block-constant
  * coefficients -- maxiBiquad, maxiSVF, maxiDCBlocker through mxg_filter2_render, lores / hires through mxg_filter_render -- and blocks
  * of 64 * {1..32} samples be cut along time and joined by a wavefront scan: a 6-voice x 512-sample block in a few microseconds
- * instead of 23-28, with reordered arithmetic: |error| <= 1e-12 x the block's peak; default 0 = the bit-exact kernels),
+ * instead of 23-28, with reordered arithmetic: |error| <= 1e-10 x the block's peak (measured <= 5e-12); default 0 = the bit-exact kernels),
  * "osc_split" (time parts per voice group in K1: 0 automatic, 1..8), "osc_mix_split" (the same for the fused render + mixdown K1m,
  * 0 automatic, 1..4), "osc_mix_store" (K1m's per-voice block: 0 automatic, 1 plain 8-byte stores, 2 pair rows of 16-byte stores),
  * "smp_split" (time parts of a block-constant playAtSpeed / playOnceAtSpeed / playUntilAtSpeed launch: 0 automatic, 1..8),

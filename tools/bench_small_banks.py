@@ -41,7 +41,7 @@ def timed(fn, reps=50):
     return ms.value / reps * 1e3
 
 
-emit("# Small banks: microseconds per 512-sample block (MI355X), lane-per-voice (bit-exact) vs time-parallel scan (tolerance 1e-12)")
+emit("# Small banks: microseconds per 512-sample block (MI355X), lane-per-voice (bit-exact) vs time-parallel scan (tolerance 1e-10)")
 emit()
 emit("`python tools/bench_small_banks.py`: back-to-back launches on one stream (launch overhead included), 50 per measurement, median of 7.")
 emit()
