@@ -160,10 +160,10 @@ int part_sync_get(hipStream_t st, size_t wavefronts, int parts, PartSync *out) {
     }
     if (g_part_dirty) {  // after a reported time-out: every stream's counters start from zero again
         for (auto &kv : g_scratch)
-            if (kv.first.first == (int)SCR_PART_SYNC && kv.second.ptr) {
-                MXG_HIP(hipStreamSynchronize(kv.first.second));
-                MXG_HIP(hipMemset(kv.second.ptr, 0, kv.second.cap));
-            }
+            if (kv.first.first == (int)SCR_PART_SYNC && kv.second.ptr)
+                // ON the stream the counters belong to: ordered after its earlier launches and before its next one (a memset on the
+                // null stream is not ordered against these non-blocking streams and could land in the middle of the next kernel)
+                MXG_HIP(hipMemsetAsync(kv.second.ptr, 0, kv.second.cap, kv.first.second));
         g_part_dirty = false;
     }
     out->ctrs = (int *)b.ptr;
