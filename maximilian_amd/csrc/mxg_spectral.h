@@ -13,6 +13,8 @@ struct mxg_fft_plan {
     float *d_window;   // [fftSize]
     float2 *d_tw;      // stage twiddles: entry (h-1)+n = (ar0, ai0) of step n in a stage with BlockEnd h
     float2 *d_post;    // post-pass (wr, wi) for i = 1 .. half/2-1 at index i
+    float2 *d_tw8;     // fftSize 1024 only, tolerance mode (knob fft_exact = 0): correctly rounded radix-8 input twiddles,
+                       // [8][7] for the second register round (lane & 7) followed by [64][7] for the third (lane); see round8_t
 };
 
 // maxiIFFT::setup (L/maxiFFT.cpp:140-153): windowSize ? windowSize : fftSize, Hann over that, zero beyond
@@ -161,6 +163,95 @@ __device__ __forceinline__ void round3(float2 (&x)[8], const float2 w0, const fl
     round3(y, as_v2f(w0), u1, u2);
 #pragma unroll
     for (int e = 0; e < 8; e++) x[e] = make_float2(y[e].x, y[e].y);
+}
+
+// ---- tolerance mode (knob fft_exact = 0): the same three register rounds as TRUE radix-8 butterflies ------------------------
+// A round of the exact kernel is three radix-2 stages, every butterfly a full complex multiply by a twiddle the reference
+// generates with an fp32 recurrence (5 packed instructions each, 60 per round).  Mathematically the seven twiddles of a lane are
+// w2[0]^m times eighth roots of unity, so the round is: multiply the inputs x1..x7 by T_e = e^(i m_e theta), m = 4,2,6,1,5,3,7
+// (7 complex multiplies, 2 packed instructions each with an FMA), then an 8-point DFT whose only non-trivial factors are
+// e^(i pi/4), e^(i 3pi/4) (one add + one multiply by 1/sqrt(2) each) and i (a free operand swizzle): 42 packed instructions per
+// round, 28 in the first round (theta = 0).  The T_e are correctly rounded from double (mxg_fft_plan::d_tw8) -- closer to the true
+// transform than the reference's recurrences -- and the operations are reordered and fused: NOT the reference's bits.  Tolerance
+// stated and tested in tests/test_gpu_spectral.py (magnitudes within 4e-7 x the frame's largest magnitude).
+__device__ __forceinline__ void cmul2_t(v2f &k1, const v2f w1, v2f &k2, const v2f w2) {  // k <- k * w, two at a time
+    v2f p1, p2, r1, r2;
+    asm("s_nop 0\n\t"
+        "v_pk_mul_f32 %[p1], %[w1], %[k1] op_sel_hi:[0,1]\n\t"                                           // (w.x*k.x, w.x*k.y)
+        "v_pk_mul_f32 %[p2], %[w2], %[k2] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %[r1], %[w1], %[k1], %[p1] op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"   // (p.x - w.y*k.y, p.y + w.y*k.x)
+        "v_pk_fma_f32 %[r2], %[w2], %[k2], %[p2] op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "s_nop 0"
+        : [p1] "=&v"(p1), [p2] "=&v"(p2), [r1] "=&v"(r1), [r2] "=&v"(r2)
+        : [w1] "v"(w1), [k1] "v"(k1), [w2] "v"(w2), [k2] "v"(k2));
+    k1 = r1;
+    k2 = r2;
+}
+// (j, k) <- (j + i*k, j - i*k) for two pairs: i*k = (-k.y, k.x) is an operand swizzle
+__device__ __forceinline__ void bft_rot2(v2f &j1, v2f &k1, v2f &j2, v2f &k2) {
+    v2f a1, b1, a2, b2;
+    asm("s_nop 0\n\t"
+        "v_pk_add_f32 %[a1], %[j1], %[k1] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %[a2], %[j2], %[k2] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %[b1], %[j1], %[k1] op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[b2], %[j2], %[k2] op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "s_nop 0"
+        : [a1] "=&v"(a1), [b1] "=&v"(b1), [a2] "=&v"(a2), [b2] "=&v"(b2)
+        : [j1] "v"(j1), [k1] "v"(k1), [j2] "v"(j2), [k2] "v"(k2));
+    j1 = a1; k1 = b1; j2 = a2; k2 = b2;
+}
+// pair 1: k1 <- e^(i pi/4) k1 = c (k.x - k.y, k.x + k.y); pair 2: k2 <- e^(i 3pi/4) k2 = c (-k.x - k.y, k.x - k.y); then (j +- k).
+// c = (1/sqrt(2), .) in the low half of `c`.
+__device__ __forceinline__ void bft_w8pair(v2f &j1, v2f &k1, v2f &j2, v2f &k2, const v2f c) {
+    v2f t1, t2, a1, b1, a2, b2;
+    asm("s_nop 0\n\t"
+        "v_pk_add_f32 %[t1], %[k1], %[k1] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %[t2], %[k2], %[k2] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,1] neg_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %[t1], %[t1], %[c] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %[t2], %[t2], %[c] op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %[a1], %[j1], %[t1]\n\t"
+        "v_pk_add_f32 %[a2], %[j2], %[t2]\n\t"
+        "v_pk_add_f32 %[b1], %[j1], %[t1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[b2], %[j2], %[t2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "s_nop 0"
+        : [t1] "=&v"(t1), [t2] "=&v"(t2), [a1] "=&v"(a1), [b1] "=&v"(b1), [a2] "=&v"(a2), [b2] "=&v"(b2)
+        : [j1] "v"(j1), [k1] "v"(k1), [j2] "v"(j2), [k2] "v"(k2), [c] "v"(c));
+    j1 = a1; k1 = b1; j2 = a2; k2 = b2;
+}
+// the 8-point DFT of a round (inputs already carry their twiddles), element pairing as round3()
+__device__ __forceinline__ void radix8_t(v2f (&x)[8], const v2f c) {
+    v2f y[8];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {  // stage A: (0,1) (2,3) (4,5) (6,7)
+        y[e] = x[e] + x[e + 1];
+        y[e + 1] = x[e] - x[e + 1];
+    }
+    // stage B: (0,2) (4,6) plain; (1,3) (5,7) with k <- i k
+    x[0] = y[0] + y[2]; x[2] = y[0] - y[2];
+    x[4] = y[4] + y[6]; x[6] = y[4] - y[6];
+    bft_rot2(y[1], y[3], y[5], y[7]);
+    x[1] = y[1]; x[3] = y[3]; x[5] = y[5]; x[7] = y[7];
+    // stage C: (0,4) plain; (2,6) with k <- i k; (1,5) with k <- e^(i pi/4) k; (3,7) with k <- e^(i 3pi/4) k
+    y[0] = x[0] + x[4]; y[4] = x[0] - x[4];
+    v2f d0 = x[2], d1 = x[6], d2 = x[2], d3 = x[6];  // (one rot2 block on the pair twice would waste two instructions: do it by hand)
+    asm("s_nop 0\n\t"
+        "v_pk_add_f32 %[a], %[j], %[k] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %[b], %[j], %[k] op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "s_nop 0"
+        : [a] "=&v"(d2), [b] "=&v"(d3)
+        : [j] "v"(d0), [k] "v"(d1));
+    y[2] = d2; y[6] = d3;
+    bft_w8pair(x[1], x[5], x[3], x[7], c);
+    x[0] = y[0]; x[4] = y[4]; x[2] = y[2]; x[6] = y[6];
+}
+// one tolerance-mode round: input twiddles T[0..6] for x1..x7, then the 8-point DFT
+__device__ __forceinline__ void round8_t(v2f (&x)[8], const v2f (&T)[7], const v2f c) {
+    cmul2_t(x[1], T[0], x[2], T[1]);
+    cmul2_t(x[3], T[2], x[4], T[3]);
+    cmul2_t(x[5], T[4], x[6], T[5]);
+    v2f dummy = x[7];
+    cmul2_t(x[7], T[6], dummy, T[6]);
+    radix8_t(x, c);
 }
 
 // sqrtf.  hipcc's correctly-rounded sqrtf expands to ~25 instructions (v_sqrt_f32, the +-1 ulp residual test, and a 2^32
