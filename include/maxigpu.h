@@ -129,7 +129,10 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "mfcc_tiled" (LDS-staged spectra 0|1), "grain_chunked" (time-sharded granular render 0|1), "grain_lanes_k",
  * "grain_unit" (coalesced unit-increment render 0|1), "grain_line" (tile render for arbitrary increments 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_slices" (time slices of a unit-path
  * maxiTimeStretch call whose scheduling and rendering overlap, 1..16), "osc_mix_var" (layout of K1m's lane-exchange butterfly, 0..3),
- * "time_parallel" (THE ONE EXCEPTION to "identical results": 1 lets banks of at most 4096 linear filters with block-constant
+ * "fft_exact" (1 default; 0 = TOLERANCE MODE of mxg_fft_mfcc_batch: the 512-point transform as true radix-8 butterflies with correctly
+ * rounded twiddles and fused multiply-adds, hardware square root -- about a quarter fewer instructions; magnitudes within 4e-7 x the
+ * frame's largest magnitude of the reference's, mfcc within 1e-5; bit-exactness is given up, accuracy against the TRUE transform is not),
+ * "time_parallel" (the other exception to "identical results": 1 lets banks of at most 4096 linear filters with block-constant
  * coefficients -- maxiBiquad, maxiSVF, maxiDCBlocker through mxg_filter2_render, lores / hires through mxg_filter_render -- and blocks
  * of 64 * {1..32} samples be cut along time and joined by a wavefront scan: a 6-voice x 512-sample block in a few microseconds
  * instead of 23-28, with reordered arithmetic: |error| <= 1e-10 x the block's peak (measured <= 5e-12); default 0 = the bit-exact kernels),

@@ -604,6 +604,29 @@ mxg_fft_plan *mxg_fft_plan_create(int fftSize, int hopSize, int windowSize) {
     p->d_window = nullptr;
     p->d_tw = nullptr;
     p->d_post = nullptr;
+    p->d_tw8 = nullptr;
+    if (fftSize == 1024) {
+        // tolerance mode of the fused kernel (spectral.hip, round8_t): a lane's round is x_e *= T_e = e^(+i m_e theta), m = 4,2,6,1,5,3,7
+        // for e = 1..7 (the sign convention of L/fft.cpp:161-182: twiddle n of a stage is (cos, +sin)(2 pi n / BlockSize)), then an
+        // 8-point DFT; theta = 2 pi (lane & 7) / 64 in the second round, 2 pi lane / 512 in the third.  Correctly rounded from double.
+        std::vector<float2> tw8((8 + 64) * 7);
+        const int mexp[7] = {4, 2, 6, 1, 5, 3, 7};
+        for (int l = 0; l < 8; l++)
+            for (int e = 0; e < 7; e++) {
+                const double a = 2.0 * M_PI * (double)(l * mexp[e]) / 64.0;
+                tw8[(size_t)l * 7 + e] = make_float2((float)cos(a), (float)sin(a));
+            }
+        for (int l = 0; l < 64; l++)
+            for (int e = 0; e < 7; e++) {
+                const double a = 2.0 * M_PI * (double)(l * mexp[e]) / 512.0;
+                tw8[56 + (size_t)l * 7 + e] = make_float2((float)cos(a), (float)sin(a));
+            }
+        if (check_hip(hipMalloc(&p->d_tw8, sizeof(float2) * tw8.size()), "hipMalloc") ||
+            check_hip(hipMemcpy(p->d_tw8, tw8.data(), sizeof(float2) * tw8.size(), hipMemcpyHostToDevice), "hipMemcpy")) {
+            mxg_fft_plan_destroy(p);
+            return nullptr;
+        }
+    }
     if (check_hip(hipMalloc(&p->d_window, sizeof(float) * fftSize), "hipMalloc") ||
         check_hip(hipMalloc(&p->d_tw, sizeof(float2) * tw.size()), "hipMalloc") ||
         check_hip(hipMalloc(&p->d_post, sizeof(float2) * post.size()), "hipMalloc") ||
@@ -619,6 +642,7 @@ mxg_fft_plan *mxg_fft_plan_create(int fftSize, int hopSize, int windowSize) {
 int mxg_fft_plan_destroy(mxg_fft_plan *p) {
     if (!p) return MXG_OK;
     if (p->d_window) (void)hipFree(p->d_window);
+    if (p->d_tw8) (void)hipFree(p->d_tw8);
     if (p->d_tw) (void)hipFree(p->d_tw);
     if (p->d_post) (void)hipFree(p->d_post);
     delete p;

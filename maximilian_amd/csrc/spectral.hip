@@ -153,6 +153,7 @@ struct FusedArgs {
     size_t frame_stride, nframes;
     const float *window;
     const float2 *tw, *post;
+    const float2 *tw8;  // tolerance mode: radix-8 input twiddles ([8][7] by lane & 7, then [64][7] by lane; mxg_fft_plan::d_tw8)
     unsigned numFilters, numCoeffs, nbUsed, mstride, nfp, dctPad;
     int steps;
     int edgeBins;  // the bank reads bin 0 or bin 256 (or the magnitudes are written out): form them
@@ -170,7 +171,12 @@ struct FusedArgs {
 // 61 % busy with the twiddles still in LDS).  The 21 stage twiddles a lane needs never change: rounds 2 and 3 hold theirs in
 // 28 VGPRs, round 1's seven are wave-uniform and live in SGPRs; LDS carries only the transposes, the magnitude rows and the
 // mel tables.
-template <bool FULL, bool WRITE_MAGS, bool ALIGNED8>
+//
+// TOL (knob fft_exact = 0, tolerance mode): the three register rounds are true radix-8 butterflies with correctly rounded input
+// twiddles and FMAs (round8_t, mxg_spectral.h: 112 packed instructions per frame instead of 180), the magnitudes take the
+// hardware square root (v_sqrt_f32, <= 1 ulp) instead of the correctly rounded sequence.  Not the reference's bits: magnitudes
+// within 4e-7 of the frame's largest, mfcc within 1e-5 (tests/test_gpu_spectral.py); everything else as in the exact kernel.
+template <bool FULL, bool WRITE_MAGS, bool ALIGNED8, bool TOL>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const FusedArgs A) {
     extern __shared__ double s_dyn[];
     // [fs (steps + 2 batches) * 8 entries][dct NF*NC f64, padded to 16 B] | per wave: XA (= band rows), XB, M
@@ -209,10 +215,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const 
         const int bi[7] = {7, 15, 23, 31, 39, 47, 55}, ci[7] = {63, 127, 191, 255, 319, 383, 447};
 #pragma unroll
         for (int i = 0; i < 7; i++) {
-            tb[i] = as_v2f(A.tw[bi[i] + lo]);
-            tc[i] = as_v2f(A.tw[ci[i] + lane]);
+            if constexpr (TOL) {  // the input twiddles T_1..T_7 of the second / third round
+                tb[i] = as_v2f(A.tw8[lo * 7 + i]);
+                tc[i] = as_v2f(A.tw8[56 + lane * 7 + i]);
+            } else {
+                tb[i] = as_v2f(A.tw[bi[i] + lo]);
+                tc[i] = as_v2f(A.tw[ci[i] + lane]);
+            }
         }
     }
+    const v2f c8 = {0.70710678118654752440f, 0.70710678118654752440f};
+    auto msqrt = [](float x) { return TOL ? __builtin_amdgcn_sqrtf(x) : exact_sqrtf(x); };
     // post-pass: twiddles of this lane's four pairs in registers; LDS slots of the pairs (i, 512 - i), i = 1 + lane + 64q,
     // are one base each plus a compile-time offset: pad8(i0 + 64q) = pad8(i0) + 72q
     v2f pw[4];
@@ -247,7 +260,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const 
         float *Mrow = M + j * A.mstride;
         const v2f z = X[pad8(zidx)];
         const float zr = lane == 0 ? z.x + z.y : z.x, zi = lane == 0 ? z.x - z.y : z.y;
-        const float mz = exact_sqrtf(zr * zr + zi * zi);
+        const float mz = msqrt(zr * zr + zi * zi);
         if (lane == 0 || lane == 63) {
             Mrow[zidx] = mz;
             if constexpr (WRITE_MAGS)
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const 
             const v2f xa = X[pa0 + 72 * q], xb = X[pb0 - 72 * q];
             float2 a = make_float2(xa.x, xa.y), b = make_float2(xb.x, xb.y);
             post_pair(a, b, make_float2(pw[q].x, pw[q].y));
-            const float ma = exact_sqrtf(a.x * a.x + a.y * a.y), mb = exact_sqrtf(b.x * b.x + b.y * b.y);
+            const float ma = msqrt(a.x * a.x + a.y * a.y), mb = msqrt(b.x * b.x + b.y * b.y);
             if (q < 3 || lane < 63) {
                 Mrow[1 + lane + 64 * q] = ma;
                 Mrow[511 - lane - 64 * q] = mb;
@@ -302,8 +315,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const 
             const size_t fnext = j + 2 < kGroup ? f0 + j + 2 : (g + gstep) * kGroup;
             load_frame(fnext, nA);
             load_frame(fnext + 1, nB);
-            round3_s(vA, ta);
-            round3_s(vB, ta);
+            if constexpr (TOL) {
+                radix8_t(vA, c8);
+                radix8_t(vB, c8);
+            } else {
+                round3_s(vA, ta);
+                round3_s(vB, ta);
+            }
 #pragma unroll
             for (int e = 0; e < 8; e++) XA[pad8(8 * lane + e)] = vA[e];
 #pragma unroll
@@ -314,8 +332,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const 
 #pragma unroll
             for (int e = 0; e < 8; e++) vB[e] = XB[pad8(hi * 64 + e * 8 + lo)];
             __builtin_amdgcn_sched_barrier(0);  // both frames' reads are in flight before the first butterfly waits
-            round3(vA, tb[0], b1, b2);
-            round3(vB, tb[0], b1, b2);
+            if constexpr (TOL) {
+                round8_t(vA, tb, c8);
+                round8_t(vB, tb, c8);
+            } else {
+                round3(vA, tb[0], b1, b2);
+                round3(vB, tb[0], b1, b2);
+            }
             wave_lds_sync();
 #pragma unroll
             for (int e = 0; e < 8; e++) XA[pad8(hi * 64 + e * 8 + lo)] = vA[e];
@@ -327,8 +350,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const 
 #pragma unroll
             for (int e = 0; e < 8; e++) vB[e] = XB[pad8(e * 64 + lane)];
             __builtin_amdgcn_sched_barrier(0);
-            round3(vA, tc[0], c1, c2);
-            round3(vB, tc[0], c1, c2);
+            if constexpr (TOL) {
+                round8_t(vA, tc, c8);
+                round8_t(vB, tc, c8);
+            } else {
+                round3(vA, tc[0], c1, c2);
+                round3(vB, tc[0], c1, c2);
+            }
             wave_lds_sync();
 #pragma unroll
             for (int e = 0; e < 8; e++) XA[pad8(e * 64 + lane)] = vA[e];
@@ -353,7 +381,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const 
                     for (int q = 0; q < 4; q += 2) {
                         v2f sq0, sq1;
                         post_lo_sq2(pa[f][q], pb[f][q], pw[q], pa[f][q + 1], pb[f][q + 1], pw[q + 1], sq0, sq1);
-                        const float m0 = exact_sqrtf(sq0.x + sq0.y), m1 = exact_sqrtf(sq1.x + sq1.y);  // L/fft.cpp:510-511
+                        const float m0 = msqrt(sq0.x + sq0.y), m1 = msqrt(sq1.x + sq1.y);  // L/fft.cpp:510-511
                         // bins the bank never reads are not kept (mstride <= 264); lane 63's fourth pair would be bin 256: below
                         if (1u + (unsigned)lane + 64u * q < A.mstride) Mrow[1 + lane + 64 * q] = m0;
                         if (65u + (unsigned)lane + 64u * q < A.mstride && (q + 1 < 3 || lane < 63)) Mrow[65 + lane + 64 * q] = m1;
@@ -618,8 +646,9 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
     }
     FusedArgs A;
     A.signal = d_signal; A.frame_stride = frame_stride; A.nframes = nframes;
-    A.window = fp->d_window; A.tw = fp->d_tw; A.post = fp->d_post;
+    A.window = fp->d_window; A.tw = fp->d_tw; A.post = fp->d_post; A.tw8 = fp->d_tw8;
     A.numFilters = mp->numFilters; A.numCoeffs = mp->numCoeffs; A.nbUsed = mp->nbUsed;
+    const bool tol = !tune_get("fft_exact") && fp->d_tw8 != nullptr;  // tolerance mode (reordered, fused arithmetic): opt-in
     MXG_REQUIRE(mp->nbUsed <= 257, "mel bank reaches beyond bin 256");  // binFreq = sr/numBins*bin never does
     const bool full = d_mags != nullptr;
     A.mstride = full ? 520 : 264;                 // the post-pass writes bins 0..256 (0..511 with magnitudes out) + pad, = 8 mod 32
@@ -642,11 +671,13 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
     typedef void (*kern_t)(const FusedArgs);
     kern_t k;
     if (d_mags)
-        k = aligned8 ? fft_mfcc_kernel<true, true, true> : fft_mfcc_kernel<true, true, false>;
+        k = tol ? (aligned8 ? fft_mfcc_kernel<true, true, true, true> : fft_mfcc_kernel<true, true, false, true>)
+                : (aligned8 ? fft_mfcc_kernel<true, true, true, false> : fft_mfcc_kernel<true, true, false, false>);
     else if (full)
-        k = aligned8 ? fft_mfcc_kernel<true, false, true> : fft_mfcc_kernel<true, false, false>;
+        k = aligned8 ? fft_mfcc_kernel<true, false, true, false> : fft_mfcc_kernel<true, false, false, false>;
     else
-        k = aligned8 ? fft_mfcc_kernel<false, false, true> : fft_mfcc_kernel<false, false, false>;
+        k = tol ? (aligned8 ? fft_mfcc_kernel<false, false, true, true> : fft_mfcc_kernel<false, false, false, true>)
+                : (aligned8 ? fft_mfcc_kernel<false, false, true, false> : fft_mfcc_kernel<false, false, false, false>);
     if (lds > 64 * 1024) MXG_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer kt("fft_mfcc_kernel", st);
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, st, A);

@@ -461,3 +461,46 @@ def test_mfcc_tiled_equals_row_loads(mx, nf, nc, nfr):
     for a, b, what in zip(res[0], res[1], ("mfcc", "melraw", "melbands")):
         assert_bits_equal(a, b, what)
     assert np.isfinite(res[0][0]).all() and np.abs(res[0][0]).max() > 0
+
+
+# ---- tolerance mode of the fused kernel (knob fft_exact = 0): true radix-8 butterflies, correctly rounded twiddles, FMAs, hardware
+# sqrt.  Reordered arithmetic => stated tolerances instead of bits (north_star: "a stated fp tolerance for the FFT path") ------
+TOL_MAG_REL = 4e-7    # |mag - oracle| <= TOL_MAG_REL x the frame's largest oracle magnitude (about 3 fp32 ulps of the peak)
+TOL_MFCC_ABS = 1e-5   # |mfcc - oracle|: a magnitude error d on a band of size B moves log(B^2) by 2 d / B, before the 42-term DCT / 13
+
+
+@pytest.mark.parametrize("nf,nc,nfr,off", [(42, 13, 1000, 0), (42, 13, 37, 1), (40, 20, 513, 0), (64, 13, 9, 0)])
+def test_fused_tolerance_mode_within_stated_tolerance(mx, port, nf, nc, nfr, off):
+    rng = np.random.default_rng(nf * 7 + nfr)
+    stride = 1024 if off == 0 else 1025
+    n = np.arange(stride * nfr + 8)
+    sig = (0.4 * np.sin(2 * np.pi * 220 * n / 44100) + 0.3 * np.sin(2 * np.pi * 1337.5 * n / 44100) +
+           0.1 * rng.uniform(-1, 1, n.size)).astype(np.float32)
+    sig[: stride * 3] *= 1e-3                                   # a few quiet frames
+    d = mx.DeviceBuffer.from_numpy(sig)
+    f = mx.maxiFFT(); f.setup(1024, 1024, 1024)
+    m = mx.maxiMFCC(); m.setup(512, nf, nc, 20.0, 20000.0)
+    base = d.ptr + 4 * off
+    exact = m.mfcc_of_frames(f, base, nfr, frame_stride=stride, want_mags=True).numpy()
+    mags_exact = m.mags.numpy()
+    L = mx.lib()
+    prev = L.mxg_tune(b"fft_exact", 0)
+    try:
+        out = m.mfcc_of_frames(f, base, nfr, frame_stride=stride, want_mags=True).numpy()
+        mags = m.mags.numpy()
+        out_nomags = m.mfcc_of_frames(f, base, nfr, frame_stride=stride).numpy()     # the half-spectrum variant of the kernel
+    finally:
+        L.mxg_tune(b"fft_exact", prev)
+    frames = np.stack([sig[off + stride * k: off + stride * k + 1024] for k in range(nfr)])
+    e = port.fft_stream(frames.reshape(-1), 1024, 1024, 1024, want=("mags",))["mags"]
+    assert np.array_equal(f32bits(mags_exact), f32bits(e)), "the exact kernel must not be disturbed"
+    peak = np.maximum(e.max(axis=1, keepdims=True), 1e-30)
+    rel = float((np.abs(mags.astype(np.float64) - e) / peak).max())
+    emel, emf = port.mfcc(e, nf, nc, 20.0, 20000.0)
+    err = float(np.abs(out - emf).max())
+    print("tolerance mode, %d filters, %d frames: magnitudes %.2e of the frame peak (stated %.0e), mfcc %.2e (stated %.0e); "
+          "exact kernel mfcc %.2e" % (nf, nfr, rel, TOL_MAG_REL, err, TOL_MFCC_ABS, np.abs(exact - emf).max()))
+    assert rel <= TOL_MAG_REL
+    assert err <= TOL_MFCC_ABS
+    assert np.abs(out_nomags - emf).max() <= TOL_MFCC_ABS
+    assert (mags != mags_exact).any(), "tolerance mode produced the exact kernel's bits: the knob did not engage"
