@@ -130,8 +130,9 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "grain_unit" (coalesced unit-increment render 0|1), "grain_line" (tile render for arbitrary increments 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_slices" (time slices of a unit-path
  * maxiTimeStretch call whose scheduling and rendering overlap, 1..16), "osc_mix_var" (layout of K1m's lane-exchange butterfly, 0..3),
  * "fft_exact" (1 default; 0 = TOLERANCE MODE of mxg_fft_mfcc_batch: the 512-point transform as true radix-8 butterflies with correctly
- * rounded twiddles and fused multiply-adds, hardware square root -- about a quarter fewer instructions; magnitudes within 4e-7 x the
- * frame's largest magnitude of the reference's, mfcc within 1e-5; bit-exactness is given up, accuracy against the TRUE transform is not),
+ * rounded twiddles and fused multiply-adds, hardware square root -- about a quarter fewer instructions; magnitudes within 6e-7 x the
+ * frame's peak of the TRUE transform and -- because the reference's fp32 twiddle recurrences drift by ~1e-4 -- within 4e-4 of the reference's,
+ * mfcc within 5e-4 of the reference's; bit-exactness is given up, accuracy is gained),
  * "time_parallel" (the other exception to "identical results": 1 lets banks of at most 4096 linear filters with block-constant
  * coefficients -- maxiBiquad, maxiSVF, maxiDCBlocker through mxg_filter2_render, lores / hires through mxg_filter_render -- and blocks
  * of 64 * {1..32} samples be cut along time and joined by a wavefront scan: a 6-voice x 512-sample block in a few microseconds

@@ -174,8 +174,9 @@ struct FusedArgs {
 //
 // TOL (knob fft_exact = 0, tolerance mode): the three register rounds are true radix-8 butterflies with correctly rounded input
 // twiddles and FMAs (round8_t, mxg_spectral.h: 112 packed instructions per frame instead of 180), the magnitudes take the
-// hardware square root (v_sqrt_f32, <= 1 ulp) instead of the correctly rounded sequence.  Not the reference's bits: magnitudes
-// within 4e-7 of the frame's largest, mfcc within 1e-5 (tests/test_gpu_spectral.py); everything else as in the exact kernel.
+// hardware square root (v_sqrt_f32, <= 1 ulp) and log2 instead of the correctly rounded sequences.  Not the reference's bits: within
+// 6e-7 of a frame's peak of the TRUE transform, and -- the reference's fp32 twiddle recurrences drift by ~1e-4 -- within 4e-4 of the
+// reference's magnitudes, 5e-4 of its mfcc (tests/test_gpu_spectral.py); everything else as in the exact kernel.
 template <bool FULL, bool WRITE_MAGS, bool ALIGNED8, bool TOL>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const FusedArgs A) {
     extern __shared__ double s_dyn[];
@@ -406,7 +407,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const 
         for (unsigned idx = lane; idx < kGroup * A.numFilters; idx += 64) {
             const unsigned jj = idx / A.numFilters, ff = idx - jj * A.numFilters;
             const double raw = s_mel[jj * A.nfp + ff];
-            const double lv = log_square(raw);
+            // tolerance mode: log(mb * mb) = 2 ln 2 * log2(mb) through the hardware's fp32 log2 (abs. error ~1e-6 on values of
+            // magnitude <= 30): two orders below the distance between the reference's transform and the true one
+            const double lv = TOL ? (raw > 0.000001 ? 1.3862943611198906 * (double)__builtin_amdgcn_logf((float)raw) : 0.0)
+                                  : log_square(raw);
             s_mel[jj * A.nfp + ff] = lv;
             if (f0 + jj < nframes) {
                 if (A.melraw) A.melraw[(f0 + jj) * A.numFilters + ff] = raw;

@@ -464,9 +464,13 @@ def test_mfcc_tiled_equals_row_loads(mx, nf, nc, nfr):
 
 
 # ---- tolerance mode of the fused kernel (knob fft_exact = 0): true radix-8 butterflies, correctly rounded twiddles, FMAs, hardware
-# sqrt.  Reordered arithmetic => stated tolerances instead of bits (north_star: "a stated fp tolerance for the FFT path") ------
-TOL_MAG_REL = 4e-7    # |mag - oracle| <= TOL_MAG_REL x the frame's largest oracle magnitude (about 3 fp32 ulps of the peak)
-TOL_MFCC_ABS = 1e-5   # |mfcc - oracle|: a magnitude error d on a band of size B moves log(B^2) by 2 d / B, before the 42-term DCT / 13
+# sqrt and log2.  Reordered arithmetic => stated tolerances instead of bits (north_star: "a stated fp tolerance for the FFT path").
+# What the tolerance is made of: the REFERENCE's transform is itself only accurate to ~1e-4 of a frame's peak -- its twiddles come
+# from fp32 recurrences that drift (L/fft.cpp:161-182, :245-272); the exact kernel reproduces that drift bit for bit, the tolerance
+# kernel uses correctly rounded twiddles and lands ~1000x closer to the true DFT.  So two bounds are asserted:
+TOL_MAG_TRUE = 6e-7   # |mag - true DFT magnitude (float64 numpy)| <= this x the frame's peak: a few fp32 ulps of the peak
+TOL_MAG_REF = 4e-4    # |mag - reference| <= this x the frame's peak: the reference's own distance from the true transform
+TOL_MFCC_REF = 5e-4   # |mfcc - reference mfcc|: that magnitude difference through log and the 42-term DCT / 13
 
 
 @pytest.mark.parametrize("nf,nc,nfr,off", [(42, 13, 1000, 0), (42, 13, 37, 1), (40, 20, 513, 0), (64, 13, 9, 0)])
@@ -494,13 +498,23 @@ def test_fused_tolerance_mode_within_stated_tolerance(mx, port, nf, nc, nfr, off
     frames = np.stack([sig[off + stride * k: off + stride * k + 1024] for k in range(nfr)])
     e = port.fft_stream(frames.reshape(-1), 1024, 1024, 1024, want=("mags",))["mags"]
     assert np.array_equal(f32bits(mags_exact), f32bits(e)), "the exact kernel must not be disturbed"
-    peak = np.maximum(e.max(axis=1, keepdims=True), 1e-30)
-    rel = float((np.abs(mags.astype(np.float64) - e) / peak).max())
+    # the true transform: float64 FFT of the frame times the plan's float32 Hann window (L/fft.cpp:409-413); the reference's
+    # RealFFT leaves the spectrum of the packed half-length transform, i.e. half the DFT (its 0.5 * (...) split, :250-268)
+    win = (0.50 - 0.50 * np.cos(2 * np.pi * np.arange(1024) / 1023.0)).astype(np.float32).astype(np.float64)
+    true = 0.5 * np.abs(np.fft.rfft(frames.astype(np.float64) * win, axis=1))[:, :512]
+    peak = np.maximum(true[:, 1:].max(axis=1, keepdims=True), 1e-30)
+    scale_ok = np.abs(e[:, 1:] - true[:, 1:]).max() / peak.max()
+    assert scale_ok < 1e-2, "the float64 model of the reference's magnitudes is wrong (scale)"
+    d_true = float((np.abs(mags[:, 1:].astype(np.float64) - true[:, 1:]) / peak).max())
+    d_ref = float((np.abs(mags.astype(np.float64) - e) / np.maximum(e.max(axis=1, keepdims=True), 1e-30)).max())
+    ref_true = float((np.abs(e[:, 1:].astype(np.float64) - true[:, 1:]) / peak).max())
     emel, emf = port.mfcc(e, nf, nc, 20.0, 20000.0)
     err = float(np.abs(out - emf).max())
-    print("tolerance mode, %d filters, %d frames: magnitudes %.2e of the frame peak (stated %.0e), mfcc %.2e (stated %.0e); "
-          "exact kernel mfcc %.2e" % (nf, nfr, rel, TOL_MAG_REL, err, TOL_MFCC_ABS, np.abs(exact - emf).max()))
-    assert rel <= TOL_MAG_REL
-    assert err <= TOL_MFCC_ABS
-    assert np.abs(out_nomags - emf).max() <= TOL_MFCC_ABS
-    assert (mags != mags_exact).any(), "tolerance mode produced the exact kernel's bits: the knob did not engage"
+    print("tolerance mode, %d filters, %d frames, x frame peak: |tol - true DFT| %.2e (stated %.0e), |reference - true DFT| %.2e, "
+          "|tol - reference| %.2e (stated %.0e); mfcc |tol - reference| %.2e (stated %.0e), exact kernel %.2e"
+          % (nf, nfr, d_true, TOL_MAG_TRUE, ref_true, d_ref, TOL_MAG_REF, err, TOL_MFCC_REF, np.abs(exact - emf).max()))
+    assert d_true <= TOL_MAG_TRUE
+    assert d_ref <= TOL_MAG_REF
+    assert err <= TOL_MFCC_REF
+    assert np.abs(out_nomags - emf).max() <= TOL_MFCC_REF
+    assert d_true < 0.1 * ref_true, "the tolerance kernel is supposed to be much closer to the true transform than the reference is"
