@@ -498,10 +498,10 @@ def test_fused_tolerance_mode_within_stated_tolerance(mx, port, nf, nc, nfr, off
     frames = np.stack([sig[off + stride * k: off + stride * k + 1024] for k in range(nfr)])
     e = port.fft_stream(frames.reshape(-1), 1024, 1024, 1024, want=("mags",))["mags"]
     assert np.array_equal(f32bits(mags_exact), f32bits(e)), "the exact kernel must not be disturbed"
-    # the true transform: float64 FFT of the frame times the plan's float32 Hann window (L/fft.cpp:409-413); the reference's
-    # RealFFT leaves the spectrum of the packed half-length transform, i.e. half the DFT (its 0.5 * (...) split, :250-268)
+    # the true transform: float64 FFT of the frame times the plan's float32 Hann window (L/fft.cpp:409-413); bins 1..511 of the
+    # reference's RealFFT are the DFT's (bin 0 packs DC and Nyquist, :274-275, and is left out of this comparison)
     win = (0.50 - 0.50 * np.cos(2 * np.pi * np.arange(1024) / 1023.0)).astype(np.float32).astype(np.float64)
-    true = 0.5 * np.abs(np.fft.rfft(frames.astype(np.float64) * win, axis=1))[:, :512]
+    true = np.abs(np.fft.rfft(frames.astype(np.float64) * win, axis=1))[:, :512]
     peak = np.maximum(true[:, 1:].max(axis=1, keepdims=True), 1e-30)
     scale_ok = np.abs(e[:, 1:] - true[:, 1:]).max() / peak.max()
     assert scale_ok < 1e-2, "the float64 model of the reference's magnitudes is wrong (scale)"
