@@ -129,7 +129,8 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "mfcc_tiled" (LDS-staged spectra 0|1), "grain_chunked" (time-sharded granular render 0|1), "grain_lanes_k",
  * "grain_unit" (coalesced unit-increment render 0|1), "grain_line" (tile render for arbitrary increments 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_slices" (time slices of a unit-path
  * maxiTimeStretch call whose scheduling and rendering overlap, 1..16), "osc_mix_var" (layout of K1m's lane-exchange butterfly, 0..3),
- * "fft_exact" (1 default; 0 = TOLERANCE MODE of mxg_fft_mfcc_batch: the 512-point transform as true radix-8 butterflies with correctly
+ * "rw_store" (the read + write bank kernels' 16-byte pair-row streams: 0 automatic, 1 off, 2 / 3 / 4 on with plain / write-through /
+ * non-temporal stores), "fft_exact" (1 default; 0 = TOLERANCE MODE of mxg_fft_mfcc_batch: the 512-point transform as true radix-8 butterflies with correctly
  * rounded twiddles and fused multiply-adds, hardware square root -- about a quarter fewer instructions; magnitudes within 6e-7 x the
  * frame's peak of the TRUE transform and -- because the reference's fp32 twiddle recurrences drift by ~1e-4 -- within 4e-4 of the reference's,
  * mfcc within 5e-4 of the reference's; bit-exactness is given up, accuracy is gained),

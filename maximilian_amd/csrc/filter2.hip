@@ -76,6 +76,74 @@ __global__ void __launch_bounds__(256) filter2_kernel(size_t V, size_t N, const 
     st[2 * V + v] = s2;
 }
 
+// The same recurrences with 16-BYTE read and write streams (round 3): a lane still owns one voice, but the input of two samples
+// arrives as one 16-byte load per lane (two voices of one row) and leaves as one 16-byte store, the lanes of a pair swapping one
+// value each way (pair_rows_swap / store_pair_rows, mxg_common.h).  V even, N even, both blocks 16-byte aligned; same bits.
+template <int KIND, int ST>
+__global__ void __launch_bounds__(256) filter2_pairs_kernel(size_t V, size_t N, const double *__restrict__ in,
+                                                            const double *__restrict__ coef, double *__restrict__ st,
+                                                            double *__restrict__ out) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    double s0 = st[v], s1 = st[V + v], s2 = st[2 * V + v];
+    constexpr int NC = KIND == 0 ? 1 : (KIND == 1 ? 9 : 5);
+    double c[NC];
+#pragma unroll
+    for (int r = 0; r < NC; r++) c[r] = coef[(size_t)r * V + v];
+    const size_t odd = threadIdx.x & 1, vp = v & ~(size_t)1;
+    const double *ip = in + vp;
+    double *op = out + odd * V + vp;  // this lane's 16 bytes of row n + (lane & 1)
+    constexpr int U = 8;
+    double2v xn[U / 2];
+    auto row_of = [&](size_t n) { const size_t r = n + odd; return r < N ? r : N - 1; };  // clamped: no branch, surplus unused
+#pragma unroll
+    for (int j = 0; j < U / 2; j++) xn[j] = *reinterpret_cast<const double2v *>(ip + row_of(2 * j) * V);
+    for (size_t n0 = 0; n0 < N; n0 += U) {
+        double xc[U];
+#pragma unroll
+        for (int j = 0; j < U / 2; j++) {
+            pair_rows_swap(xn[j], xc[2 * j], xc[2 * j + 1]);
+            xn[j] = *reinterpret_cast<const double2v *>(ip + row_of(n0 + U + 2 * j) * V);
+        }
+        double o[U];
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            const double x = xc[i];
+            if constexpr (KIND == 0) {
+                s1 = x - s0 + c[0] * s1;
+                s0 = x;
+                o[i] = s1;
+            } else if constexpr (KIND == 1) {
+                const double v1z = s1;
+                const double v2z = s2;
+                const double v3 = x + s0 - 2.0 * v2z;
+                s1 += c[0] * v3 - c[1] * v1z;
+                s2 += c[2] * v3 + c[3] * v1z;
+                s0 = x;
+                const double low = s2, band = s1;
+                const double high = x - c[4] * s1 - s2;
+                const double notch = x - c[4] * s1;
+                o[i] = (low * c[5]) + (band * c[6]) + (high * c[7]) + (notch * c[8]);
+            } else {
+                s0 = x - (c[3] * s1) - (c[4] * s2);
+                o[i] = (c[0] * s0) + (c[1] * s1) + (c[2] * s2);
+                s2 = s1;
+                s1 = s0;
+            }
+            if (n0 + i + 1 == N) {  // the state after the LAST sample of the block (a ragged last chunk computes past it)
+                st[v] = s0;
+                st[V + v] = s1;
+                st[2 * V + v] = s2;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U / 2; j++) {
+            if (n0 + 2 * j < N) store_pair_rows<ST>(op, o[2 * j], o[2 * j + 1]);  // (N even: a pair is inside or outside as a whole; wave-uniform)
+            op += 2 * V;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace mxg
 
@@ -94,6 +162,21 @@ int mxg_filter2_render(int kind, size_t V, size_t N, const double *d_in, const d
     const dim3 grid((unsigned)((V + block - 1) / block));
     hipStream_t st = resolve_stream(stream);
     if (scan_applies(V, N)) return scan_filter_launch(kind, V, N, d_in, d_coef, d_st, d_out, st);  // tolerance mode (scan.hip)
+    // 16-byte pair-row streams (knob rw_store: 0 automatic, 1 off, 2 / 3 / 4 plain / write-through / non-temporal stores)
+    int rw = tune_get("rw_store");
+    const bool pairs_ok = !(V & 1) && !(N & 1) && !(((uintptr_t)d_in) & 15) && !(((uintptr_t)d_out) & 15);
+    if (rw == 0) rw = (V * N * sizeof(double) >= ((size_t)64 << 20)) ? 3 : 1;
+    if (rw >= 2 && pairs_ok) {
+        KernelTimer kt("filter2_kernel", st);
+#define MXG_F2P(K)                                                                                                   \
+    if (rw == 2) hipLaunchKernelGGL((filter2_pairs_kernel<K, 0>), grid, dim3(block), 0, st, V, N, d_in, d_coef, d_st, d_out); \
+    else if (rw == 3) hipLaunchKernelGGL((filter2_pairs_kernel<K, 2>), grid, dim3(block), 0, st, V, N, d_in, d_coef, d_st, d_out); \
+    else hipLaunchKernelGGL((filter2_pairs_kernel<K, 1>), grid, dim3(block), 0, st, V, N, d_in, d_coef, d_st, d_out);
+        if (kind == 0) { MXG_F2P(0) } else if (kind == 1) { MXG_F2P(1) } else { MXG_F2P(2) }
+#undef MXG_F2P
+        return check_hip(hipGetLastError(), "filter2_pairs_kernel launch");
+    }
+    KernelTimer kt("filter2_kernel", st);
     switch (kind) {
         case 0: hipLaunchKernelGGL((filter2_kernel<0>), grid, dim3(block), 0, st, V, N, d_in, d_coef, d_st, d_out); break;
         case 1: hipLaunchKernelGGL((filter2_kernel<1>), grid, dim3(block), 0, st, V, N, d_in, d_coef, d_st, d_out); break;

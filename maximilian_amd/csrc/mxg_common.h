@@ -186,4 +186,18 @@ __device__ __forceinline__ void store_pair_rows(double *o, double r0, double r1)
     store2<ST>(o, __hiloint2double(a1, a0), __hiloint2double(b1, b0));
 }
 
+// The mirror image for a READ stream in[n*V + v]: the lane loads 16 bytes -- two voices of its row n + (lane & 1), from
+// in + (n + (lane & 1)) * V + (v & ~1) -- and the pair swaps one value, after which every lane holds samples n (r0) and n + 1 (r1) of
+// ITS voice.  The load (`raw`) and the swap are separate so that a kernel can request a chunk ahead and swap when it consumes.
+__device__ __forceinline__ void pair_rows_swap(const double2v raw, double &r0, double &r1) {
+    const bool odd = (threadIdx.x & 1) != 0;
+    // even lane: raw = (x[n][2k], x[n][2k+1]) keeps .x, needs the partner's .x; odd lane: raw = (x[n+1][2k], x[n+1][2k+1]) keeps .y, needs the partner's .y
+    const double send = odd ? raw.x : raw.y;
+    const int s0 = __double2loint(send), s1 = __double2hiint(send);
+    const int g0 = __builtin_amdgcn_update_dpp(0, s0, 0xB1, 0xf, 0xf, true), g1 = __builtin_amdgcn_update_dpp(0, s1, 0xB1, 0xf, 0xf, true);
+    const double recv = __hiloint2double(g1, g0);
+    r0 = odd ? recv : raw.x;
+    r1 = odd ? raw.y : recv;
+}
+
 }  // namespace mxg

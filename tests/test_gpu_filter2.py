@@ -77,3 +77,37 @@ def test_biquad_mixed_types_and_errors(mx, port):
     with pytest.raises(mx.MaxiGpuError):
         bank.set(9, cutoff, Q, gain)
     assert mx.lib().mxg_filter2_render(3, V, N, 1, 1, 1, 1, None) == -1
+
+
+@pytest.mark.parametrize("rw", [1, 2, 3, 4])
+@pytest.mark.parametrize("V,N", [(700, 300), (64, 8), (2050, 514), (4096, 1000), (701, 64), (256, 7)])
+def test_pair_row_streams_same_bits(mx, port, rw, V, N):
+    """The read + write kernels' 16-byte pair-row streams (knob rw_store; csrc/filter2.hip filter2_pairs_kernel): a lane pair swaps one
+    value on the way in and one on the way out, nothing else changes -- every kind, partial last wavefronts, blocks that are not a
+    multiple of the 8-sample chunk; odd banks / odd blocks fall back to the 8-byte kernels.  All against the oracle, state carried."""
+    L = mx.lib()
+    rng = np.random.default_rng(V + N)
+    x = _x(V, 2 * N, V)
+    prev = L.mxg_tune(b"rw_store", rw)
+    try:
+        R = rng.uniform(0.9, 0.9999, V)
+        b = mx.maxiDCBlockerBank(V)
+        o = np.concatenate([b.play(mx.DeviceBuffer.from_numpy(x[:N]), R).numpy(), b.play(mx.DeviceBuffer.from_numpy(x[N:]), R).numpy()])
+        e, st, _ = port.filter2(0, x, R[None, :])
+        assert_bits_equal(o, e, "dcblocker rw_store=%d" % rw)
+        assert_bits_equal(b.state.numpy()[:2], st[:2])
+        cutoff, res = rng.uniform(20, 20000, V), rng.uniform(0.3, 12, V)
+        b = mx.maxiSVFBank(V); b.setCutoff(cutoff); b.setResonance(res)
+        o = np.concatenate([b.play(mx.DeviceBuffer.from_numpy(x[:N]), 0.5, 0.25, 0.125, 0.6).numpy(),
+                            b.play(mx.DeviceBuffer.from_numpy(x[N:]), 0.5, 0.25, 0.125, 0.6).numpy()])
+        e, st, _ = port.filter2(1, x, np.stack([cutoff, res, np.full(V, 0.5), np.full(V, 0.25), np.full(V, 0.125), np.full(V, 0.6)]))
+        assert_bits_equal(o, e, "svf rw_store=%d" % rw)
+        assert_bits_equal(b.state.numpy(), st)
+        typ = (np.arange(V) % 7).astype(np.float64)
+        cut, q, gain = rng.uniform(100, 8000, V), rng.uniform(0.4, 3, V), rng.uniform(-9, 9, V)
+        b = mx.maxiBiquadBank(V); b.set(typ.astype(np.int32), cut, q, gain)
+        o = np.concatenate([b.play(mx.DeviceBuffer.from_numpy(x[:N])).numpy(), b.play(mx.DeviceBuffer.from_numpy(x[N:])).numpy()])
+        e, st, _ = port.filter2(2, x, np.stack([typ, cut, q, gain]))
+        assert_bits_equal(o, e, "biquad rw_store=%d" % rw)
+    finally:
+        L.mxg_tune(b"rw_store", prev)
