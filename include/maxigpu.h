@@ -144,6 +144,8 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "smp_pipe" (that launch issues the window loads of chunk k+1 before the stores of chunk k, 0|1),
  * "ifft_stream" (mxg_ifft_batch: inverse transform and hop buffer in one kernel: 0 never, 1 where hop >= fftSize / 2, 2 wherever it fits),
  * "mfcc_mfma_fullk" (the MFMA mel contraction runs over all numBins bins instead of the ones that carry weight, 0|1).
+ * "fused_layout" (mxg_fft_mfcc_batch: 0 automatic, 1 = two frames in flight per wavefront and two 4-wave workgroups per CU, 2 = one
+ * frame in flight and one 12-wave workgroup per CU; same bits either way),
  * "fused_waves16" (mxg_fft_mfcc_batch: the 16-waves-per-CU form of the fused kernel when the request allows it, 0|1).
  * "osc_store" (K1's store stream: 0 automatic by waveform and bank size; one voice per lane: 1 plain 8-byte stores, 2 non-temporal,
  * 3 / 4 / 5 two samples of a lane pair exchanged into one 16-byte store per lane, plain / write-through (sc1) / non-temporal; two

@@ -605,6 +605,9 @@ mxg_fft_plan *mxg_fft_plan_create(int fftSize, int hopSize, int windowSize) {
     p->d_tw = nullptr;
     p->d_post = nullptr;
     p->d_tw8 = nullptr;
+    // the stage-opening twiddles of the first two stages are exactly (1, 0) (the recurrence w * ar1 - ar2 is exact there): the fused
+    // kernel then skips those multiplications (spectral.hip, round3_s1); verified here rather than assumed
+    p->round1Trivial = half >= 4 && tw[0].x == 1.0f && tw[0].y == 0.0f && tw[1].x == 1.0f && tw[1].y == 0.0f;
     if (fftSize == 1024) {
         // tolerance mode of the fused kernel (spectral.hip, round8_t): a lane's round is x_e *= T_e = e^(+i m_e theta), m = 4,2,6,1,5,3,7
         // for e = 1..7 (the sign convention of L/fft.cpp:161-182: twiddle n of a stage is (cos, +sin)(2 pi n / BlockSize)), then an

@@ -681,7 +681,7 @@ mxg_mfcc_plan *mxg_mfcc_plan_create(unsigned numBins, unsigned numFilters, unsig
             }
             int T = 1;
             for (int s = 0; s < slots; s++) T = load[s] > T ? load[s] : T;
-            T = (T + kMelBatch - 1) / kMelBatch * kMelBatch;
+            T = (T + 2 * kMelBatch - 1) / (2 * kMelBatch) * (2 * kMelBatch);  // the walk alternates between two batches
             // padding steps (after a list's last filter, and the two look-ahead batches): weight 0 on a bin that is always formed
             const mxg_fs_entry pad = {0.0, (order.empty() ? 1 : minBin) * 4, 0};
             tab.assign((size_t)(T + 2 * kMelBatch) * slots, pad);

@@ -15,6 +15,7 @@ struct mxg_fft_plan {
     float2 *d_post;    // post-pass (wr, wi) for i = 1 .. half/2-1 at index i
     float2 *d_tw8;     // fftSize 1024 only, tolerance mode (knob fft_exact = 0): correctly rounded radix-8 input twiddles,
                        // [8][7] for the second register round (lane & 7) followed by [64][7] for the third (lane); see round8_t
+    int round1Trivial; // d_tw[0] and d_tw[1] (the opening twiddles of stages 1 and 2) are exactly (1, 0)
 };
 
 // maxiIFFT::setup (L/maxiFFT.cpp:140-153): windowSize ? windowSize : fftSize, Hann over that, zero beyond
@@ -44,7 +45,7 @@ struct mxg_mfcc_plan {
     // Slot schedules of the fused FFT+MFCC kernels (spectral.hip): the filters are packed into kFusedSlots (8-wave form) and
     // kFusedSlots16 (16-wave form) lists of about equal total support length; list s is walked one bin per step, so step t of
     // slot s is the entry {weight, byte offset of the bin in a magnitude row, filter + 1 on the last bin of a filter else 0}.
-    // fsSteps / fs16Steps = the longest list rounded up to kMelBatch; shorter lists are padded AFTER their last filter, and two
+    // fsSteps / fs16Steps = the longest list rounded up to 2 * kMelBatch; shorter lists are padded AFTER their last filter, and two
     // look-ahead batches of padding rows follow (weight 0 on bin fsMinBin).  fsSteps == 0: the fused kernel does not apply.
     int fsSteps, fs16Steps;
     mxg_fs_entry *d_fs8;   // [fsSteps + 2 * kMelBatch][kFusedSlots]
@@ -151,6 +152,28 @@ __device__ __forceinline__ void round3_s(v2f (&x)[8], const v2f (&w)[7]) {
     bfly2_s(x[4], x[5], w[0], x[6], x[7], w[0]);
     bfly2_s(x[0], x[2], w[1], x[1], x[3], w[2]);
     bfly2_s(x[4], x[6], w[1], x[5], x[7], w[2]);
+    bfly2_s(x[0], x[4], w[3], x[1], x[5], w[4]);
+    bfly2_s(x[2], x[6], w[5], x[3], x[7], w[6]);
+}
+// round 1 when w[0] and w[1] are exactly (1, 0) (mxg_fft_plan::round1Trivial): for finite k the product (1, 0) * k is k -- tr = 1*k.x -
+// 0*k.y, ti = 1*k.y + 0*k.x, the zero products only decide the SIGN OF A ZERO result -- so the six butterflies of stages 1 and 2
+// that open a block are an add and a subtract (2 packed instructions instead of 5).  Values downstream are the reference's except
+// for signs of zeros, which the magnitudes (re^2 + im^2) do not see: used by the fused kernel only (it emits magnitudes and
+// mfcc, never real / imag).  A frame holding Inf / NaN is non-finite garbage either way, not necessarily the same garbage.
+__device__ __forceinline__ void round3_s1(v2f (&x)[8], const v2f (&w)[7]) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const v2f t = x[e + 1];
+        x[e + 1] = x[e] - t;
+        x[e] = x[e] + t;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e += 4) {
+        const v2f t = x[e + 2];
+        x[e + 2] = x[e] - t;
+        x[e] = x[e] + t;
+    }
+    bfly2_s(x[1], x[3], w[2], x[5], x[7], w[2]);
     bfly2_s(x[0], x[4], w[3], x[1], x[5], w[4]);
     bfly2_s(x[2], x[6], w[5], x[3], x[7], w[6]);
 }
@@ -269,6 +292,28 @@ __device__ __forceinline__ float exact_sqrtf(float x) {
     const float g = x * r, h = 0.5f * r;
     const float d = __builtin_fmaf(-g, g, x);  // x - g*g, one rounding
     return __builtin_fmaf(d, h, g);
+}
+
+// exact_sqrtf of FOUR values behind ONE range test (the generic routine for all four when any of them is zero, below 2^-96, Inf or
+// NaN: sqrtf is correctly rounded too, so the bits are the same either way)
+__device__ __forceinline__ void exact_sqrtf4(const float (&x)[4], float (&r)[4]) {
+    unsigned worst = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned u = __float_as_uint(x[i]) - 0x0F800000u;
+        worst = u > worst ? u : worst;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float rr = __builtin_amdgcn_rsqf(x[i]);
+        const float g = x[i] * rr, h = 0.5f * rr;
+        const float d = __builtin_fmaf(-g, g, x[i]);
+        r[i] = __builtin_fmaf(d, h, g);
+    }
+    if (__builtin_expect(worst >= 0x7F800000u - 0x0F800000u, 0)) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = sqrtf(x[i]);
+    }
 }
 
 // log-square of L/maxiMFCC.cpp:63

@@ -112,38 +112,41 @@ __device__ __forceinline__ double dct_dot(const double *d, const unsigned dstrid
 // terms outside the support are exact +0.0 in the reference: bit-identical, see mfcc.hip).  An entry is one ds_read_b128, a
 // magnitude one LDS gather; the loop is software-pipelined two batches deep (entries two batches ahead, gathers one) so no
 // LDS latency sits between the dependent fp64 adds.  `fs` points at the slot's column of a table with `steps` rows
-// (a multiple of kMelBatch) + two batches of padding rows.
+// (a multiple of 2 * kMelBatch) + two batches of padding rows.
 template <int SLOTS>
 __device__ __forceinline__ void mel_walk(const char *Mrow, double *melrow, const mxg_fs_entry *fs, const int steps) {
     double acc = 0.0;  // L/maxiMFCC.cpp:52
-    mxg_fs_entry cur[kMelBatch], nx[kMelBatch];
-    float x[kMelBatch];
+    // Two entry batches P, Q and their gathered magnitudes, used alternately (`steps` is a multiple of 2 * kMelBatch): while a
+    // batch is consumed, the other batch's magnitudes are gathered and each consumed entry's registers are refilled with the
+    // entry two batches on -- every LDS result has a whole batch of dependent fp64 adds to arrive, and no register is copied
+    // (as a rotating three-buffer pipeline hipcc spent 24 of 81 instructions per 8 steps on v_mov).
+    mxg_fs_entry P[kMelBatch], Q[kMelBatch];
+    float xP[kMelBatch], xQ[kMelBatch];
 #pragma unroll
-    for (int i = 0; i < kMelBatch; i++) cur[i] = fs[i * SLOTS];
+    for (int i = 0; i < kMelBatch; i++) P[i] = fs[i * SLOTS];
 #pragma unroll
-    for (int i = 0; i < kMelBatch; i++) x[i] = *reinterpret_cast<const float *>(Mrow + cur[i].off);
+    for (int i = 0; i < kMelBatch; i++) Q[i] = fs[(kMelBatch + i) * SLOTS];
 #pragma unroll
-    for (int i = 0; i < kMelBatch; i++) nx[i] = fs[(kMelBatch + i) * SLOTS];
-    for (int t0 = 0; t0 < steps; t0 += kMelBatch) {
-        float xn[kMelBatch];
-        mxg_fs_entry nn[kMelBatch];
-#pragma unroll
-        for (int i = 0; i < kMelBatch; i++) xn[i] = *reinterpret_cast<const float *>(Mrow + nx[i].off);
-#pragma unroll
-        for (int i = 0; i < kMelBatch; i++) nn[i] = fs[(t0 + 2 * kMelBatch + i) * SLOTS];
+    for (int i = 0; i < kMelBatch; i++) xP[i] = *reinterpret_cast<const float *>(Mrow + P[i].off);
+    auto consume = [&](const mxg_fs_entry &e, const float x) {
+        acc += (e.w * (double)x);  // L/maxiMFCC.cpp:57
+        if (e.fid) {
+            melrow[e.fid - 1] = acc;
+            acc = 0.0;
+        }
+    };
+    for (int t0 = 0; t0 < steps; t0 += 2 * kMelBatch) {
 #pragma unroll
         for (int i = 0; i < kMelBatch; i++) {
-            acc += (cur[i].w * (double)x[i]);  // L/maxiMFCC.cpp:57
-            if (cur[i].fid) {
-                melrow[cur[i].fid - 1] = acc;
-                acc = 0.0;
-            }
+            xQ[i] = *reinterpret_cast<const float *>(Mrow + Q[i].off);
+            consume(P[i], xP[i]);
+            P[i] = fs[(t0 + 2 * kMelBatch + i) * SLOTS];
         }
 #pragma unroll
         for (int i = 0; i < kMelBatch; i++) {
-            cur[i] = nx[i];
-            x[i] = xn[i];
-            nx[i] = nn[i];
+            xP[i] = *reinterpret_cast<const float *>(Mrow + P[i].off);
+            consume(Q[i], xQ[i]);
+            Q[i] = fs[(t0 + 3 * kMelBatch + i) * SLOTS];
         }
     }
 }
@@ -157,6 +160,10 @@ struct FusedArgs {
     unsigned numFilters, numCoeffs, nbUsed, mstride, nfp, dctPad;
     int steps;
     int edgeBins;  // the bank reads bin 0 or bin 256 (or the magnitudes are written out): form them
+    int mUncond;   // every lane may store its four magnitudes (bins 1 + lane + 64 q <= 256) without a test: the row is long enough, or
+                   // `mslack` floats follow the tile -- a row's overhang lands on the NEXT row's first bins, which that frame's own
+                   // post-pass rewrites afterwards (the DS unit executes a wavefront's stores in order), the last row's on the slack
+    unsigned mslack;
     const mxg_fs_entry *fs;
     const double *dct;
     float *mags;
@@ -177,19 +184,27 @@ struct FusedArgs {
 // hardware square root (v_sqrt_f32, <= 1 ulp) and log2 instead of the correctly rounded sequences.  Not the reference's bits: within
 // 6e-7 of a frame's peak of the TRUE transform, and -- the reference's fp32 twiddle recurrences drift by ~1e-4 -- within 4e-4 of the
 // reference's magnitudes, 5e-4 of its mfcc (tests/test_gpu_spectral.py); everything else as in the exact kernel.
-template <bool FULL, bool WRITE_MAGS, bool ALIGNED8, bool TOL>
-__global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const FusedArgs A) {
+// MODE: 0 exact; 1 exact with the opening twiddles of stages 1 and 2 known to be (1, 0) (round3_s1); 2 tolerance mode.
+// NF, WAVES: the layout.  NF = 2, WAVES = 4 is the two-frames-in-flight form above (two workgroups per CU: 2 wavefronts per SIMD,
+// <= 256 VGPRs).  NF = 1, WAVES = 12 keeps ONE frame in flight per wavefront and one 768-thread workgroup per CU: 3 wavefronts per
+// SIMD (<= 168 VGPRs; one X image instead of two is what lets twelve 8-frame magnitude tiles fit the 160 KB) -- the third
+// wavefront covers the transposes' latency instead of the second frame, and the VALU issues faster with three to pick from.
+template <bool FULL, bool WRITE_MAGS, bool ALIGNED8, int MODE, int NF, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(const FusedArgs A) {
+    constexpr bool TOL = MODE == 2;
     extern __shared__ double s_dyn[];
     // [fs (steps + 2 batches) * 8 entries][dct NF*NC f64, padded to 16 B] | per wave: XA (= band rows), XB, M
     mxg_fs_entry *s_fs = reinterpret_cast<mxg_fs_entry *>(s_dyn);
     const int fsRows = A.steps + 2 * kMelBatch;
     double *s_d = reinterpret_cast<double *>(s_fs + (size_t)fsRows * kFusedSlots);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t perWaveBytes = 2 * sizeof(float2) * kX1024 + sizeof(float) * kGroup * A.mstride;
+    const size_t perWaveBytes = NF * sizeof(float2) * kX1024 + sizeof(float) * (kGroup * A.mstride + A.mslack);
     char *wbase = reinterpret_cast<char *>(s_d + A.dctPad) + (size_t)wave * perWaveBytes;
-    v2f *XA = reinterpret_cast<v2f *>(wbase), *XB = XA + kX1024;
-    double *s_mel = reinterpret_cast<double *>(wbase);  // the band rows live on XA between the last post-pass and the next frame
-    float *M = reinterpret_cast<float *>(wbase + 2 * sizeof(float2) * kX1024);
+    v2f *X[NF];
+#pragma unroll
+    for (int f = 0; f < NF; f++) X[f] = reinterpret_cast<v2f *>(wbase) + f * kX1024;
+    double *s_mel = reinterpret_cast<double *>(wbase);  // the band rows live on X[0] between the last post-pass and the next frame
+    float *M = reinterpret_cast<float *>(wbase + NF * sizeof(float2) * kX1024);
     for (int i = threadIdx.x; i < fsRows * kFusedSlots; i += blockDim.x) s_fs[i] = A.fs[i];
     for (unsigned i = threadIdx.x; i < A.numFilters * A.numCoeffs; i += blockDim.x) s_d[i] = A.dct[i];
     __syncthreads();
@@ -295,106 +310,118 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void fft_mfcc_kernel(const 
         post_edge(X, j, f0);
     };
     const size_t ngroups = (nframes + kGroup - 1) / kGroup;
-    const size_t gstep = (size_t)gridDim.x * kWavesPerBlock;
-    const size_t g0 = (size_t)blockIdx.x * kWavesPerBlock + wave;
-    v2f nA[8], nB[8];
-    load_frame(g0 * kGroup, nA);
-    load_frame(g0 * kGroup + 1, nB);
+    const size_t gstep = (size_t)gridDim.x * WAVES;
+    const size_t g0 = (size_t)blockIdx.x * WAVES + wave;
+    v2f nx[NF][8];
+#pragma unroll
+    for (int f = 0; f < NF; f++) load_frame(g0 * kGroup + f, nx[f]);
     const int mj = lane >> 3, ms = lane & 7;  // mel walk: frame of the group, slot
     const v2f b1[2] = {tb[1], tb[2]}, b2[4] = {tb[3], tb[4], tb[5], tb[6]};
     const v2f c1[2] = {tc[1], tc[2]}, c2[4] = {tc[3], tc[4], tc[5], tc[6]};
     for (size_t g = g0; g < ngroups; g += gstep) {
         const size_t f0 = g * kGroup;
 #pragma unroll 1
-        for (int j = 0; j < kGroup; j += 2) {
-            v2f vA[8], vB[8];
+        for (int j = 0; j < kGroup; j += NF) {
+            v2f v[NF][8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                vA[e] = nA[e] * wv[e];  // calcFFT L/fft.cpp:501-503
-                vB[e] = nB[e] * wv[e];
+            for (int f = 0; f < NF; f++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[f][e] = nx[f][e] * wv[e];  // calcFFT L/fft.cpp:501-503
+            const size_t fnext = j + NF < kGroup ? f0 + j + NF : (g + gstep) * kGroup;
+#pragma unroll
+            for (int f = 0; f < NF; f++) load_frame(fnext + f, nx[f]);
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                if constexpr (TOL)
+                    radix8_t(v[f], c8);
+                else if constexpr (MODE == 1)
+                    round3_s1(v[f], ta);
+                else
+                    round3_s(v[f], ta);
             }
-            const size_t fnext = j + 2 < kGroup ? f0 + j + 2 : (g + gstep) * kGroup;
-            load_frame(fnext, nA);
-            load_frame(fnext + 1, nB);
-            if constexpr (TOL) {
-                radix8_t(vA, c8);
-                radix8_t(vB, c8);
-            } else {
-                round3_s(vA, ta);
-                round3_s(vB, ta);
-            }
 #pragma unroll
-            for (int e = 0; e < 8; e++) XA[pad8(8 * lane + e)] = vA[e];
+            for (int f = 0; f < NF; f++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) XB[pad8(8 * lane + e)] = vB[e];
+                for (int e = 0; e < 8; e++) X[f][pad8(8 * lane + e)] = v[f][e];
             wave_lds_sync();
 #pragma unroll
-            for (int e = 0; e < 8; e++) vA[e] = XA[pad8(hi * 64 + e * 8 + lo)];
+            for (int f = 0; f < NF; f++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) vB[e] = XB[pad8(hi * 64 + e * 8 + lo)];
-            __builtin_amdgcn_sched_barrier(0);  // both frames' reads are in flight before the first butterfly waits
-            if constexpr (TOL) {
-                round8_t(vA, tb, c8);
-                round8_t(vB, tb, c8);
-            } else {
-                round3(vA, tb[0], b1, b2);
-                round3(vB, tb[0], b1, b2);
+                for (int e = 0; e < 8; e++) v[f][e] = X[f][pad8(hi * 64 + e * 8 + lo)];
+            __builtin_amdgcn_sched_barrier(0);  // every frame's reads are in flight before the first butterfly waits
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                if constexpr (TOL)
+                    round8_t(v[f], tb, c8);
+                else
+                    round3(v[f], tb[0], b1, b2);
             }
             wave_lds_sync();
 #pragma unroll
-            for (int e = 0; e < 8; e++) XA[pad8(hi * 64 + e * 8 + lo)] = vA[e];
+            for (int f = 0; f < NF; f++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) XB[pad8(hi * 64 + e * 8 + lo)] = vB[e];
+                for (int e = 0; e < 8; e++) X[f][pad8(hi * 64 + e * 8 + lo)] = v[f][e];
             wave_lds_sync();
 #pragma unroll
-            for (int e = 0; e < 8; e++) vA[e] = XA[pad8(e * 64 + lane)];
+            for (int f = 0; f < NF; f++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) vB[e] = XB[pad8(e * 64 + lane)];
+                for (int e = 0; e < 8; e++) v[f][e] = X[f][pad8(e * 64 + lane)];
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (TOL) {
-                round8_t(vA, tc, c8);
-                round8_t(vB, tc, c8);
-            } else {
-                round3(vA, tc[0], c1, c2);
-                round3(vB, tc[0], c1, c2);
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                if constexpr (TOL)
+                    round8_t(v[f], tc, c8);
+                else
+                    round3(v[f], tc[0], c1, c2);
             }
             wave_lds_sync();
 #pragma unroll
-            for (int e = 0; e < 8; e++) XA[pad8(e * 64 + lane)] = vA[e];
+            for (int f = 0; f < NF; f++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) XB[pad8(e * 64 + lane)] = vB[e];
+                for (int e = 0; e < 8; e++) X[f][pad8(e * 64 + lane)] = v[f][e];
             wave_lds_sync();
             if constexpr (!FULL) {
-                // low half of the post-pass for both frames: all sixteen LDS reads are requested before the first is used
-                v2f pa[2][4], pb[2][4];
+                // low half of the post-pass: all the LDS reads are requested before the first is used
+                v2f pa[NF][4], pb[NF][4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    pa[0][q] = XA[pa0 + 72 * q];
-                    pb[0][q] = XA[pb0 - 72 * q];
-                    pa[1][q] = XB[pa0 + 72 * q];
-                    pb[1][q] = XB[pb0 - 72 * q];
-                }
+                for (int f = 0; f < NF; f++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        pa[f][q] = X[f][pa0 + 72 * q];
+                        pb[f][q] = X[f][pb0 - 72 * q];
+                    }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int f = 0; f < 2; f++) {
+                for (int f = 0; f < NF; f++) {
                     float *Mrow = M + (j + f) * A.mstride;
+                    v2f sq[4];
+                    post_lo_sq2(pa[f][0], pb[f][0], pw[0], pa[f][1], pb[f][1], pw[1], sq[0], sq[1]);
+                    post_lo_sq2(pa[f][2], pb[f][2], pw[2], pa[f][3], pb[f][3], pw[3], sq[2], sq[3]);
+                    float m[4];
+                    if constexpr (TOL) {
 #pragma unroll
-                    for (int q = 0; q < 4; q += 2) {
-                        v2f sq0, sq1;
-                        post_lo_sq2(pa[f][q], pb[f][q], pw[q], pa[f][q + 1], pb[f][q + 1], pw[q + 1], sq0, sq1);
-                        const float m0 = msqrt(sq0.x + sq0.y), m1 = msqrt(sq1.x + sq1.y);  // L/fft.cpp:510-511
-                        // bins the bank never reads are not kept (mstride <= 264); lane 63's fourth pair would be bin 256: below
-                        if (1u + (unsigned)lane + 64u * q < A.mstride) Mrow[1 + lane + 64 * q] = m0;
-                        if (65u + (unsigned)lane + 64u * q < A.mstride && (q + 1 < 3 || lane < 63)) Mrow[65 + lane + 64 * q] = m1;
+                        for (int q = 0; q < 4; q++) m[q] = __builtin_amdgcn_sqrtf(sq[q].x + sq[q].y);
+                    } else {
+                        const float ss[4] = {sq[0].x + sq[0].y, sq[1].x + sq[1].y, sq[2].x + sq[2].y, sq[3].x + sq[3].y};
+                        exact_sqrtf4(ss, m);  // L/fft.cpp:510-511
+                    }
+                    if (A.mUncond) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) Mrow[1 + lane + 64 * q] = m[q];
+                    } else {
+                        // bins the bank never reads are not kept; lane 63's fourth pair would be bin 256: post_edge
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (1u + (unsigned)lane + 64u * q < A.mstride && (q < 3 || lane < 63)) Mrow[1 + lane + 64 * q] = m[q];
                     }
                 }
                 if (A.edgeBins) {
-                    post_edge(XA, j, f0);
-                    post_edge(XB, j + 1, f0);
+#pragma unroll
+                    for (int f = 0; f < NF; f++) post_edge(X[f], j + f, f0);
                 }
             } else {
-                post_frame(XA, j, f0);
-                post_frame(XB, j + 1, f0);
+#pragma unroll
+                for (int f = 0; f < NF; f++) post_frame(X[f], j + f, f0);
             }
             wave_lds_sync();
         }
@@ -664,26 +691,50 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
     A.steps = mp->fsSteps; A.fs = mp->d_fs8; A.dct = mp->d_dct;
     A.edgeBins = full || mp->fsMinBin < 1 || mp->nbUsed > 256;
     A.mags = d_mags; A.melraw = d_melraw; A.melbands = d_melbands; A.mfcc = d_mfcc;
-    const size_t perWave = 2 * sizeof(float2) * kX1024 + sizeof(float) * kGroup * A.mstride;
-    const size_t lds = sizeof(mxg_fs_entry) * (size_t)(A.steps + 2 * kMelBatch) * kFusedSlots + sizeof(double) * A.dctPad +
-                       kWavesPerBlock * perWave;
+    const size_t tablesBytes = sizeof(mxg_fs_entry) * (size_t)(A.steps + 2 * kMelBatch) * kFusedSlots + sizeof(double) * A.dctPad;
+    // layout (knob fused_layout): 1 = two frames in flight, two 4-wave workgroups per CU; 2 = one frame in flight, one 12-wave
+    // workgroup per CU (only without the full magnitude rows: twelve 8 x 520 tiles do not fit); 0 = automatic
+    constexpr int kWaves1 = 12;
+    auto lds_for = [&](int nf, int waves, unsigned slack) {
+        return tablesBytes + waves * (nf * sizeof(float2) * kX1024 + sizeof(float) * (kGroup * A.mstride + slack));
+    };
+    const unsigned slackWanted = A.mstride >= 257 ? 0u : (257 - A.mstride + 1) & ~1u;  // per-wave regions stay 8-byte aligned
+    int layout = (int)tune_get("fused_layout");
+    if (layout == 0) layout = 1;
+    if (layout == 2 && (full || lds_for(1, kWaves1, 0) > 160 * 1024)) layout = 1;
+    const int nf = layout == 2 ? 1 : 2, waves = layout == 2 ? kWaves1 : kWavesPerBlock, wgPerCU = layout == 2 ? 1 : 2;
+    // unconditional magnitude stores (see FusedArgs::mUncond): rows of >= 257 floats, or a slack behind the tile that still lets
+    // the layout's workgroups share a CU
+    A.mslack = 0;
+    A.mUncond = A.mstride >= 257;
+    if (!A.mUncond && wgPerCU * lds_for(nf, waves, slackWanted) <= 160 * 1024) {
+        A.mslack = slackWanted;
+        A.mUncond = 1;
+    }
+    const size_t lds = lds_for(nf, waves, A.mslack);
     MXG_REQUIRE(lds <= 160 * 1024, "filter bank too large for the fused kernel's LDS layout");
     const size_t ngroups = (nframes + kGroup - 1) / kGroup;
-    size_t blocks = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
-    const size_t cap = 256 * 2;  // persistent: two workgroups per CU, grid-stride over groups of 8 frames
+    size_t blocks = (ngroups + waves - 1) / waves;
+    const size_t cap = 256 * (size_t)wgPerCU;  // persistent: grid-stride over groups of 8 frames
     if (blocks > cap) blocks = cap;
     typedef void (*kern_t)(const FusedArgs);
     kern_t k;
+    const int mode = tol ? 2 : (fp->round1Trivial ? 1 : 0);
+#define MXG_PICK(FULL_, WM_, NF_, W_)                                                                                          \
+    (mode == 2   ? (aligned8 ? fft_mfcc_kernel<FULL_, WM_, true, 2, NF_, W_> : fft_mfcc_kernel<FULL_, WM_, false, 2, NF_, W_>) \
+     : mode == 1 ? (aligned8 ? fft_mfcc_kernel<FULL_, WM_, true, 1, NF_, W_> : fft_mfcc_kernel<FULL_, WM_, false, 1, NF_, W_>) \
+                 : (aligned8 ? fft_mfcc_kernel<FULL_, WM_, true, 0, NF_, W_> : fft_mfcc_kernel<FULL_, WM_, false, 0, NF_, W_>))
     if (d_mags)
-        k = tol ? (aligned8 ? fft_mfcc_kernel<true, true, true, true> : fft_mfcc_kernel<true, true, false, true>)
-                : (aligned8 ? fft_mfcc_kernel<true, true, true, false> : fft_mfcc_kernel<true, true, false, false>);
+        k = MXG_PICK(true, true, 2, kWavesPerBlock);
     else if (full)
-        k = aligned8 ? fft_mfcc_kernel<true, false, true, false> : fft_mfcc_kernel<true, false, false, false>;
+        k = MXG_PICK(true, false, 2, kWavesPerBlock);
+    else if (layout == 2)
+        k = MXG_PICK(false, false, 1, kWaves1);
     else
-        k = tol ? (aligned8 ? fft_mfcc_kernel<false, false, true, true> : fft_mfcc_kernel<false, false, false, true>)
-                : (aligned8 ? fft_mfcc_kernel<false, false, true, false> : fft_mfcc_kernel<false, false, false, false>);
+        k = MXG_PICK(false, false, 2, kWavesPerBlock);
+#undef MXG_PICK
     if (lds > 64 * 1024) MXG_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer kt("fft_mfcc_kernel", st);
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, st, A);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * (unsigned)waves), lds, st, A);
     return check_hip(hipGetLastError(), "fft_mfcc_kernel launch");
 }

@@ -130,13 +130,17 @@ def test_mfcc_golden(mx, golden, nf, nc):
     assert np.array_equal(bands == 0.0, emel == 0.0)
 
 
-@pytest.fixture(params=[0, 1], ids=["waves8", "waves16"])
+@pytest.fixture(params=[0, 1, 2], ids=["waves8", "waves16", "waves12"])
 def fused_form(mx, request):
-    """Both forms of the fused kernel: 8 waves per CU (8 frames x 8 slots per wavefront, two frames in flight; the default)
-    and 16 waves per CU (4 frames x 16 slots; only when no magnitudes are requested)."""
-    prev = mx.lib().mxg_tune(b"fused_waves16", request.param)
+    """The forms of the fused kernel: 8 waves per CU (8 frames x 8 slots per wavefront, two frames in flight; knob fused_layout 1),
+    16 waves per CU (4 frames x 16 slots; only when no magnitudes are requested) and 12 waves per CU (one frame in flight,
+    fused_layout 2; only without the full magnitude rows)."""
+    L = mx.lib()
+    prev16 = L.mxg_tune(b"fused_waves16", 1 if request.param == 1 else 0)
+    prevl = L.mxg_tune(b"fused_layout", 2 if request.param == 2 else 1)
     yield request.param
-    mx.lib().mxg_tune(b"fused_waves16", prev)
+    L.mxg_tune(b"fused_waves16", prev16)
+    L.mxg_tune(b"fused_layout", prevl)
 
 
 @pytest.mark.parametrize("nf,nc,nfr,off", [(42, 13, 1003, 0), (40, 20, 77, 0), (64, 13, 8, 0), (42, 13, 250, 3), (13, 5, 1, 0),
@@ -493,6 +497,12 @@ def test_fused_tolerance_mode_within_stated_tolerance(mx, port, nf, nc, nfr, off
         out = m.mfcc_of_frames(f, base, nfr, frame_stride=stride, want_mags=True).numpy()
         mags = m.mags.numpy()
         out_nomags = m.mfcc_of_frames(f, base, nfr, frame_stride=stride).numpy()     # the half-spectrum variant of the kernel
+        prevl = L.mxg_tune(b"fused_layout", 2)                                        # ... and its 12-wave layout: the same arithmetic
+        try:
+            out_nomags12 = m.mfcc_of_frames(f, base, nfr, frame_stride=stride).numpy()
+        finally:
+            L.mxg_tune(b"fused_layout", prevl)
+        assert np.array_equal(out_nomags12.view(np.uint64), out_nomags.view(np.uint64)), "tolerance mode: layouts differ"
     finally:
         L.mxg_tune(b"fft_exact", prev)
     frames = np.stack([sig[off + stride * k: off + stride * k + 1024] for k in range(nfr)])
