@@ -159,7 +159,8 @@ __device__ __forceinline__ void round3_s(v2f (&x)[8], const v2f (&w)[7]) {
 // 0*k.y, ti = 1*k.y + 0*k.x, the zero products only decide the SIGN OF A ZERO result -- so the six butterflies of stages 1 and 2
 // that open a block are an add and a subtract (2 packed instructions instead of 5).  Values downstream are the reference's except
 // for signs of zeros, which the magnitudes (re^2 + im^2) do not see: used by the fused kernel only (it emits magnitudes and
-// mfcc, never real / imag).  A frame holding Inf / NaN is non-finite garbage either way, not necessarily the same garbage.
+// mfcc, never real / imag).  For Inf / NaN the products matter (0 * Inf = NaN: the reference turns a frame holding one such
+// sample into NaN in every bin); the fused kernel detects those frames behind its square-root range test and writes the NaNs.
 __device__ __forceinline__ void round3_s1(v2f (&x)[8], const v2f (&w)[7]) {
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
@@ -294,9 +295,9 @@ __device__ __forceinline__ float exact_sqrtf(float x) {
     return __builtin_fmaf(d, h, g);
 }
 
-// exact_sqrtf of FOUR values behind ONE range test (the generic routine for all four when any of them is zero, below 2^-96, Inf or
-// NaN: sqrtf is correctly rounded too, so the bits are the same either way)
-__device__ __forceinline__ void exact_sqrtf4(const float (&x)[4], float (&r)[4]) {
+// exact_sqrtf of FOUR values behind ONE range test: r[] holds Markstein's result for every value; returns true when one of them
+// is zero, below 2^-96, Inf or NaN -- the caller then takes sqrtf() (correctly rounded too: the same bits) for all four.
+__device__ __forceinline__ bool exact_sqrtf4_try(const float (&x)[4], float (&r)[4]) {
     unsigned worst = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -310,10 +311,7 @@ __device__ __forceinline__ void exact_sqrtf4(const float (&x)[4], float (&r)[4])
         const float d = __builtin_fmaf(-g, g, x[i]);
         r[i] = __builtin_fmaf(d, h, g);
     }
-    if (__builtin_expect(worst >= 0x7F800000u - 0x0F800000u, 0)) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) r[i] = sqrtf(x[i]);
-    }
+    return worst >= 0x7F800000u - 0x0F800000u;
 }
 
 // log-square of L/maxiMFCC.cpp:63

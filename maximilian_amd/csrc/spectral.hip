@@ -211,62 +211,63 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
 
     const int lo = lane & 7, hi = lane >> 3;
     const int rev6 = (int)(__brev((unsigned)lane) >> 26);
-    v2f wv[8];
-    unsigned li[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const int rev3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);
-        li[e] = 2u * (unsigned)(rev3 * 64 + rev6);
-        wv[e] = v2f{A.window[li[e]], A.window[li[e] + 1]};
-    }
-    // stage twiddles (L/fft.cpp:161-182 replayed on the host): round 1 wave-uniform, rounds 2 / 3 per lane
-    v2f ta[7], tb[7], tc[7];
+    // element e of a lane is sample pair 64 * rev3(e) + rev6(lane) of the frame: one per-lane offset + a compile-time one
+    constexpr int kRev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    // stage twiddles (L/fft.cpp:161-182 replayed on the host): round 1 wave-uniform (scalar registers), rounds 2 / 3 per lane.
+    // The per-lane tables (window, rounds 2 / 3, post-pass: 52 VGPRs) are loaded at the top of every GROUP of 8 frames, through a
+    // pointer the compiler cannot see through, so that they are dead during the mel / log / DCT phase (26 L1-resident loads per
+    // group) -- what lets the 12-wave layout live in 168 registers -- and pinned so that they are not re-loaded per frame.
+    v2f wv[8], ta[7], tb[7], tc[7], pw[4];
 #pragma unroll
     for (int i = 0; i < 7; i++) {
         const float2 t = A.tw[i];
         ta[i].x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(t.x)));
         ta[i].y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(t.y)));
     }
-    {
+    auto load_tables = [&]() {
+        const float *winb = A.window;
+        const float2 *tw = A.tw, *tw8 = A.tw8, *post = A.post;
+        asm volatile("" : "+s"(winb), "+s"(tw), "+s"(tw8), "+s"(post));
+        const float *win = winb + 2 * rev6;
+#pragma unroll
+        for (int e = 0; e < 8; e++) wv[e] = v2f{win[128 * kRev3[e]], win[128 * kRev3[e] + 1]};
         const int bi[7] = {7, 15, 23, 31, 39, 47, 55}, ci[7] = {63, 127, 191, 255, 319, 383, 447};
 #pragma unroll
         for (int i = 0; i < 7; i++) {
             if constexpr (TOL) {  // the input twiddles T_1..T_7 of the second / third round
-                tb[i] = as_v2f(A.tw8[lo * 7 + i]);
-                tc[i] = as_v2f(A.tw8[56 + lane * 7 + i]);
+                tb[i] = as_v2f(tw8[lo * 7 + i]);
+                tc[i] = as_v2f(tw8[56 + lane * 7 + i]);
             } else {
-                tb[i] = as_v2f(A.tw[bi[i] + lo]);
-                tc[i] = as_v2f(A.tw[ci[i] + lane]);
+                tb[i] = as_v2f(tw[bi[i] + lo]);
+                tc[i] = as_v2f(tw[ci[i] + lane]);
             }
         }
-    }
+        // post-pass: twiddles of this lane's four pairs; LDS slots of the pairs (i, 512 - i), i = 1 + lane + 64q, are one base each
+        // plus a compile-time offset: pad8(i0 + 64q) = pad8(i0) + 72q
+#pragma unroll
+        for (int q = 0; q < 4; q++) pw[q] = as_v2f(post[(1 + lane + 64 * q) < 256 ? 1 + lane + 64 * q : 255]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) asm volatile("" : "+v"(wv[e]));
+#pragma unroll
+        for (int i = 0; i < 7; i++) asm volatile("" : "+v"(tb[i]), "+v"(tc[i]));
+#pragma unroll
+        for (int q = 0; q < 4; q++) asm volatile("" : "+v"(pw[q]));
+    };
     const v2f c8 = {0.70710678118654752440f, 0.70710678118654752440f};
     auto msqrt = [](float x) { return TOL ? __builtin_amdgcn_sqrtf(x) : exact_sqrtf(x); };
-    // post-pass: twiddles of this lane's four pairs in registers; LDS slots of the pairs (i, 512 - i), i = 1 + lane + 64q,
-    // are one base each plus a compile-time offset: pad8(i0 + 64q) = pad8(i0) + 72q
-    v2f pw[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) pw[q] = as_v2f(A.post[(1 + lane + 64 * q) < 256 ? 1 + lane + 64 * q : 255]);
-    // every loop-invariant table value is consumed here: a use inside the loop would let hipcc re-load it per frame
-#pragma unroll
-    for (int e = 0; e < 8; e++) asm volatile("" : "+v"(wv[e]));
-#pragma unroll
-    for (int i = 0; i < 7; i++) asm volatile("" : "+v"(tb[i]), "+v"(tc[i]));
-#pragma unroll
-    for (int q = 0; q < 4; q++) asm volatile("" : "+v"(pw[q]));
     const int pa0 = pad8(1 + lane), pb0 = pad8(511 - lane);
     const int zidx = lane == 0 ? 0 : 256;  // lanes 0 / 63 also own bin 0 / the middle bin
     const size_t nframes = A.nframes;
     auto load_frame = [&](size_t fr, v2f (&dst)[8]) {
         const unsigned fu = __builtin_amdgcn_readfirstlane((unsigned)(fr < nframes ? fr : nframes - 1));
-        const float *x = A.signal + (size_t)fu * A.frame_stride;
+        const float *x = A.signal + (size_t)fu * A.frame_stride + 2 * rev6;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             if constexpr (ALIGNED8) {
-                dst[e] = *reinterpret_cast<const v2f *>(x + li[e]);
+                dst[e] = *reinterpret_cast<const v2f *>(x + 128 * kRev3[e]);
             } else {
-                dst[e].x = x[li[e]];
-                dst[e].y = x[li[e] + 1];
+                dst[e].x = x[128 * kRev3[e]];
+                dst[e].y = x[128 * kRev3[e] + 1];
             }
         }
     };
@@ -316,10 +317,11 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
 #pragma unroll
     for (int f = 0; f < NF; f++) load_frame(g0 * kGroup + f, nx[f]);
     const int mj = lane >> 3, ms = lane & 7;  // mel walk: frame of the group, slot
-    const v2f b1[2] = {tb[1], tb[2]}, b2[4] = {tb[3], tb[4], tb[5], tb[6]};
-    const v2f c1[2] = {tc[1], tc[2]}, c2[4] = {tc[3], tc[4], tc[5], tc[6]};
     for (size_t g = g0; g < ngroups; g += gstep) {
         const size_t f0 = g * kGroup;
+        load_tables();
+        const v2f b1[2] = {tb[1], tb[2]}, b2[4] = {tb[3], tb[4], tb[5], tb[6]};
+        const v2f c1[2] = {tc[1], tc[2]}, c2[4] = {tc[3], tc[4], tc[5], tc[6]};
 #pragma unroll 1
         for (int j = 0; j < kGroup; j += NF) {
             v2f v[NF][8];
@@ -391,9 +393,11 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
                         pb[f][q] = X[f][pb0 - 72 * q];
                     }
                 __builtin_amdgcn_sched_barrier(0);
+                bool garbage[NF];
 #pragma unroll
                 for (int f = 0; f < NF; f++) {
                     float *Mrow = M + (j + f) * A.mstride;
+                    garbage[f] = false;
                     v2f sq[4];
                     post_lo_sq2(pa[f][0], pb[f][0], pw[0], pa[f][1], pb[f][1], pw[1], sq[0], sq[1]);
                     post_lo_sq2(pa[f][2], pb[f][2], pw[2], pa[f][3], pb[f][3], pw[3], sq[2], sq[3]);
@@ -403,7 +407,31 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
                         for (int q = 0; q < 4; q++) m[q] = __builtin_amdgcn_sqrtf(sq[q].x + sq[q].y);
                     } else {
                         const float ss[4] = {sq[0].x + sq[0].y, sq[1].x + sq[1].y, sq[2].x + sq[2].y, sq[3].x + sq[3].y};
-                        exact_sqrtf4(ss, m);  // L/fft.cpp:510-511
+                        const bool slow = exact_sqrtf4_try(ss, m);  // L/fft.cpp:510-511
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) != 0, 0)) {  // some lane saw 0, a tiny value, Inf or NaN
+                            if constexpr (MODE == 1) {
+                                // round3_s1 skipped the (1, 0) products: exact while the transform stays finite.  Every windowed
+                                // sample below 2^40 keeps it finite (|X| < 2^50, squares < 2^101); a frame with a larger, infinite
+                                // or NaN sample gets what the reference computes for Inf / NaN: NaN in every bin.
+                                const size_t fr = f0 + j + f;
+                                const unsigned fu = __builtin_amdgcn_readfirstlane((unsigned)(fr < nframes ? fr : nframes - 1));
+                                const float *x = A.signal + (size_t)fu * A.frame_stride + 2 * rev6;
+                                bool bad = false;
+#pragma unroll
+                                for (int e = 0; e < 8; e++) {
+                                    const float a = x[128 * kRev3[e]] * wv[e].x, b = x[128 * kRev3[e] + 1] * wv[e].y;
+                                    bad |= !(__builtin_fabsf(a) < 0x1p40f) || !(__builtin_fabsf(b) < 0x1p40f);
+                                }
+                                garbage[f] = __builtin_amdgcn_ballot_w64(bad) != 0;
+                            }
+                            if (garbage[f]) {
+#pragma unroll
+                                for (int q = 0; q < 4; q++) m[q] = __builtin_nanf("");
+                            } else if (slow) {
+#pragma unroll
+                                for (int q = 0; q < 4; q++) m[q] = sqrtf(ss[q]);
+                            }
+                        }
                     }
                     if (A.mUncond) {
 #pragma unroll
@@ -417,7 +445,10 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
                 }
                 if (A.edgeBins) {
 #pragma unroll
-                    for (int f = 0; f < NF; f++) post_edge(X[f], j + f, f0);
+                    for (int f = 0; f < NF; f++) {
+                        post_edge(X[f], j + f, f0);
+                        if (garbage[f] && (lane == 0 || lane == 63)) M[(j + f) * A.mstride + zidx] = __builtin_nanf("");
+                    }
                 }
             } else {
 #pragma unroll
@@ -724,14 +755,18 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
     (mode == 2   ? (aligned8 ? fft_mfcc_kernel<FULL_, WM_, true, 2, NF_, W_> : fft_mfcc_kernel<FULL_, WM_, false, 2, NF_, W_>) \
      : mode == 1 ? (aligned8 ? fft_mfcc_kernel<FULL_, WM_, true, 1, NF_, W_> : fft_mfcc_kernel<FULL_, WM_, false, 1, NF_, W_>) \
                  : (aligned8 ? fft_mfcc_kernel<FULL_, WM_, true, 0, NF_, W_> : fft_mfcc_kernel<FULL_, WM_, false, 0, NF_, W_>))
-    if (d_mags)
-        k = MXG_PICK(true, true, 2, kWavesPerBlock);
+#define MXG_PICK_FULL(WM_)                                                                                                     \
+    (tol ? (aligned8 ? fft_mfcc_kernel<true, WM_, true, 2, 2, kWavesPerBlock> : fft_mfcc_kernel<true, WM_, false, 2, 2, kWavesPerBlock>) \
+         : (aligned8 ? fft_mfcc_kernel<true, WM_, true, 0, 2, kWavesPerBlock> : fft_mfcc_kernel<true, WM_, false, 0, 2, kWavesPerBlock>))
+    if (d_mags)  // all 512 bins: the generic first round (MODE 1's non-finite handling lives in the half-spectrum post-pass)
+        k = MXG_PICK_FULL(true);
     else if (full)
-        k = MXG_PICK(true, false, 2, kWavesPerBlock);
+        k = MXG_PICK_FULL(false);
     else if (layout == 2)
         k = MXG_PICK(false, false, 1, kWaves1);
     else
         k = MXG_PICK(false, false, 2, kWavesPerBlock);
+#undef MXG_PICK_FULL
 #undef MXG_PICK
     if (lds > 64 * 1024) MXG_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer kt("fft_mfcc_kernel", st);

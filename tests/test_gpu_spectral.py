@@ -184,6 +184,43 @@ def test_fused_fft_mfcc_vs_two_kernels_and_oracle(mx, port, fused_form, nf, nc, 
     assert_bits_equal(m.melBands.numpy(), bands, "melBands, bands-only variant")
 
 
+def test_fused_non_finite_frames(mx, port, fused_form):
+    """Frames holding Inf / NaN samples.  The reference multiplies every sample by a twiddle of (1, 0) in the first stage, so one such
+    sample becomes NaN in every bin (0 * Inf), the band sums are NaN, `mb > 0.000001` is false and the frame's mfcc are all zero.  The
+    half-spectrum kernel skips those products (round3_s1) and restores exactly this behind its square-root range test: magnitudes
+    NaN where the oracle's are, mfcc the oracle's bits, and the finite frames around them untouched."""
+    rng = np.random.default_rng(99)
+    nfr = 40
+    sig = rng.uniform(-1, 1, 1024 * nfr).astype(np.float32)
+    sig[3 * 1024 + 100] = np.nan
+    sig[8 * 1024 + 0] = np.inf           # times window[0] = 0: NaN
+    sig[9 * 1024 + 513] = -np.inf
+    sig[17 * 1024 + 1023] = np.inf
+    sig[33 * 1024 + 7] = np.nan
+    sig[33 * 1024 + 8] = np.inf
+    bad = [3, 8, 9, 17, 33]
+    d = mx.DeviceBuffer.from_numpy(sig)
+    f = mx.maxiFFT(); f.setup(1024, 1024, 1024)
+    m = mx.maxiMFCC(); m.setup(512, 42, 13, 20.0, 20000.0)
+    full = m.mfcc_of_frames(f, d.ptr, nfr, want_mags=True, want_bands=True).numpy()   # all 512 bins: the generic first round
+    mags, raw_full = m.mags.numpy(), m.melraw.numpy()
+    half = m.mfcc_of_frames(f, d.ptr, nfr, want_bands=True).numpy()                   # the half-spectrum kernel
+    raw_half = m.melraw.numpy()
+    with np.errstate(all="ignore"):
+        e = port.fft_stream(sig, 1024, 1024, 1024, want=("mags",))["mags"]
+        emel, emf = port.mfcc(e, 42, 13, 20.0, 20000.0)
+    assert np.isnan(e[bad]).all() and np.isfinite(np.delete(e, bad, axis=0)).all(), "the oracle's picture of these frames"
+    assert np.array_equal(np.isnan(mags), np.isnan(e))
+    good = np.setdiff1d(np.arange(nfr), bad)
+    assert np.array_equal(f32bits(mags[good]), f32bits(e[good]))
+    assert np.array_equal(np.isnan(raw_half), np.isnan(raw_full)) and np.isnan(raw_half[bad]).sum(axis=1).min() >= 40  # (an empty filter stays 0)
+    assert_bits_equal(raw_half[good], raw_full[good], "band sums of the finite frames")
+    assert_bits_equal(half, full, "mfcc: half-spectrum kernel vs full kernel")
+    assert np.array_equal(half[bad], np.zeros((len(bad), 13))), "NaN band sums take the `: 0` branch, as in the reference"
+    assert np.array_equal(emf[bad], np.zeros((len(bad), 13)))
+    assert np.abs(half[good] - emf[good]).max() <= MFCC_RTOL * max(np.abs(emel[good]).max(), 1e-300)
+
+
 def test_survey_mfcc_anchor_on_device(mx, port):
     """SURVEY 8(c)'s anchor (third frame of sawn(220), fft 1024/512/1024, mfcc 512/42/13/20/20000) through the device
     path: streaming maxiFFT + maxiMFCC, within the log tolerance of the recorded glibc values."""
