@@ -689,7 +689,7 @@ mxg_mfcc_plan *mxg_mfcc_plan_create(unsigned numBins, unsigned numFilters, unsig
                 int t = 0;
                 for (unsigned f : lists[s])
                     for (int bin = lo[f]; bin <= hi[f]; bin++, t++)
-                        tab[(size_t)t * slots + s] = {p->h_W[f + (size_t)bin * numFilters], bin * 4, bin == hi[f] ? (int)(f + 1) : 0};
+                        tab[(size_t)t * slots + s] = {p->h_W[f + (size_t)bin * numFilters], bin * 4, bin == hi[f] ? (int)(f + 1) * 8 : 0};
             }
             return T;
         };

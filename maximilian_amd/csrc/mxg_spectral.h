@@ -44,7 +44,7 @@ struct mxg_mfcc_plan {
     unsigned nfPad, kPad;
     // Slot schedules of the fused FFT+MFCC kernels (spectral.hip): the filters are packed into kFusedSlots (8-wave form) and
     // kFusedSlots16 (16-wave form) lists of about equal total support length; list s is walked one bin per step, so step t of
-    // slot s is the entry {weight, byte offset of the bin in a magnitude row, filter + 1 on the last bin of a filter else 0}.
+    // slot s is the entry {weight, byte offset of the bin in a magnitude row, 8 * (filter + 1) on the last bin of a filter else 0}.
     // fsSteps / fs16Steps = the longest list rounded up to 2 * kMelBatch; shorter lists are padded AFTER their last filter, and two
     // look-ahead batches of padding rows follow (weight 0 on bin fsMinBin).  fsSteps == 0: the fused kernel does not apply.
     int fsSteps, fs16Steps;

@@ -107,6 +107,47 @@ __device__ __forceinline__ double dct_dot(const double *d, const unsigned dstrid
     return c;
 }
 
+// The same sum with the table stored coefficient-major (row i = the nf factors of coefficient i, rows and band rows 16-byte aligned):
+// a term pair is one ds_read_b128 of each operand at a compile-time offset from two pointers -- as the strided form above hipcc
+// spent as many instructions on addresses as on the arithmetic.  Batches of eight terms, the next batch requested before this one
+// is consumed; c accumulates in j order with unfused multiply-adds, as the reference does.
+typedef double d2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double dct_dot_rows(const double *d, const double *m, const unsigned nf) {
+    constexpr int U = 4;  // pairs per batch
+    const d2f *dp = reinterpret_cast<const d2f *>(d), *mp = reinterpret_cast<const d2f *>(m);
+    const unsigned pairs = nf / 2, full = pairs / U * U;
+    double c = 0.0;
+    d2f dv[U], mv[U];
+    if (full) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            dv[u] = dp[u];
+            mv[u] = mp[u];
+        }
+    }
+    for (unsigned pf = 0; pf < full; pf += U) {
+        d2f dn[U], mn[U];
+        const unsigned nxt = pf + U < full ? pf + U : pf;  // the last batch re-reads itself (unused)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            dn[u] = dp[nxt + u];
+            mn[u] = mp[nxt + u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            c += (dv[u].x * mv[u].x);
+            c += (dv[u].y * mv[u].y);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            dv[u] = dn[u];
+            mv[u] = mn[u];
+        }
+    }
+    for (unsigned j = 2 * full; j < nf; j++) c += (d[j] * m[j]);
+    return c;
+}
+
 // The mel walk of one wavefront: lane = (frame of the group, slot); the slot's filter list is walked one table entry per step,
 // so every band sum is the reference's sequential sum over the filter's support in increasing bin order (L/maxiMFCC.cpp:52-60;
 // terms outside the support are exact +0.0 in the reference: bit-identical, see mfcc.hip).  An entry is one ds_read_b128, a
@@ -130,8 +171,8 @@ __device__ __forceinline__ void mel_walk(const char *Mrow, double *melrow, const
     for (int i = 0; i < kMelBatch; i++) xP[i] = *reinterpret_cast<const float *>(Mrow + P[i].off);
     auto consume = [&](const mxg_fs_entry &e, const float x) {
         acc += (e.w * (double)x);  // L/maxiMFCC.cpp:57
-        if (e.fid) {
-            melrow[e.fid - 1] = acc;
+        if (e.fid) {  // the entry closes filter e.fid / 8 - 1: fid is the byte offset of the slot AFTER its band sum
+            *reinterpret_cast<double *>(reinterpret_cast<char *>(melrow) + e.fid - 8) = acc;
             acc = 0.0;
         }
     };
@@ -199,24 +240,37 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
     double *s_d = reinterpret_cast<double *>(s_fs + (size_t)fsRows * kFusedSlots);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t perWaveBytes = NF * sizeof(float2) * kX1024 + sizeof(float) * (kGroup * A.mstride + A.mslack);
-    char *wbase = reinterpret_cast<char *>(s_d + A.dctPad) + (size_t)wave * perWaveBytes;
+    v2f *s_twl = reinterpret_cast<v2f *>(s_d + A.dctPad);  // NF == 1: [8][7] round-2 twiddles by lane & 7, then [64][7] round-3 by lane
+    constexpr int kTwl = NF == 1 ? (8 + 64) * 7 : 0;
+    char *wbase = reinterpret_cast<char *>(s_twl + kTwl) + (size_t)wave * perWaveBytes;
     v2f *X[NF];
 #pragma unroll
     for (int f = 0; f < NF; f++) X[f] = reinterpret_cast<v2f *>(wbase) + f * kX1024;
     double *s_mel = reinterpret_cast<double *>(wbase);  // the band rows live on X[0] between the last post-pass and the next frame
     float *M = reinterpret_cast<float *>(wbase + NF * sizeof(float2) * kX1024);
     for (int i = threadIdx.x; i < fsRows * kFusedSlots; i += blockDim.x) s_fs[i] = A.fs[i];
-    for (unsigned i = threadIdx.x; i < A.numFilters * A.numCoeffs; i += blockDim.x) s_d[i] = A.dct[i];
+    for (unsigned t = threadIdx.x; t < A.numFilters * A.numCoeffs; t += blockDim.x) {  // A.dct is [j][i]; LDS rows are [i][nfp]
+        const unsigned j = t / A.numCoeffs, i = t - j * A.numCoeffs;
+        s_d[i * A.nfp + j] = A.dct[t];
+    }
+    if constexpr (NF == 1) {
+        const int bi[7] = {7, 15, 23, 31, 39, 47, 55}, ci[7] = {63, 127, 191, 255, 319, 383, 447};
+        for (int t = threadIdx.x; t < kTwl; t += blockDim.x) {
+            const int row = t / 7, i = t - row * 7;  // rows 0..7: round 2 (lane & 7 = row); rows 8..71: round 3 (lane = row - 8)
+            s_twl[t] = TOL ? as_v2f(A.tw8[t]) : as_v2f(row < 8 ? A.tw[bi[i] + row] : A.tw[ci[i] + row - 8]);
+        }
+    }
     __syncthreads();
 
     const int lo = lane & 7, hi = lane >> 3;
     const int rev6 = (int)(__brev((unsigned)lane) >> 26);
     // element e of a lane is sample pair 64 * rev3(e) + rev6(lane) of the frame: one per-lane offset + a compile-time one
     constexpr int kRev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
-    // stage twiddles (L/fft.cpp:161-182 replayed on the host): round 1 wave-uniform (scalar registers), rounds 2 / 3 per lane.
-    // The per-lane tables (window, rounds 2 / 3, post-pass: 52 VGPRs) are loaded at the top of every GROUP of 8 frames, through a
-    // pointer the compiler cannot see through, so that they are dead during the mel / log / DCT phase (26 L1-resident loads per
-    // group) -- what lets the 12-wave layout live in 168 registers -- and pinned so that they are not re-loaded per frame.
+    // stage twiddles (L/fft.cpp:161-182 replayed on the host): round 1 wave-uniform (scalar registers), rounds 2 / 3 per lane,
+    // loaded once and pinned so that they are not re-loaded per frame.  (Re-loading them from global memory at the top of every
+    // group of 8 frames, to have them dead during the mel / log / DCT phase, was measured: the exposed L2 latency costs 6 %.)
+    // The 12-wave layout (168 VGPRs) keeps a copy of the round 2 / 3 twiddles in LDS instead and re-reads THAT per group
+    // (14 ds_read_b64): 28 registers free while the logs and the DCT run, which is where hipcc spilled.
     v2f wv[8], ta[7], tb[7], tc[7], pw[4];
 #pragma unroll
     for (int i = 0; i < 7; i++) {
@@ -225,10 +279,8 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
         ta[i].y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(t.y)));
     }
     auto load_tables = [&]() {
-        const float *winb = A.window;
+        const float *win = A.window + 2 * rev6;
         const float2 *tw = A.tw, *tw8 = A.tw8, *post = A.post;
-        asm volatile("" : "+s"(winb), "+s"(tw), "+s"(tw8), "+s"(post));
-        const float *win = winb + 2 * rev6;
 #pragma unroll
         for (int e = 0; e < 8; e++) wv[e] = v2f{win[128 * kRev3[e]], win[128 * kRev3[e] + 1]};
         const int bi[7] = {7, 15, 23, 31, 39, 47, 55}, ci[7] = {63, 127, 191, 255, 319, 383, 447};
@@ -317,9 +369,20 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
 #pragma unroll
     for (int f = 0; f < NF; f++) load_frame(g0 * kGroup + f, nx[f]);
     const int mj = lane >> 3, ms = lane & 7;  // mel walk: frame of the group, slot
+    load_tables();
     for (size_t g = g0; g < ngroups; g += gstep) {
         const size_t f0 = g * kGroup;
-        load_tables();
+        if constexpr (NF == 1) {
+            const v2f *tl = s_twl;
+            asm volatile("" : "+v"(tl));  // (not hoisted out of the group loop)
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                tb[i] = tl[lo * 7 + i];
+                tc[i] = tl[56 + lane * 7 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 7; i++) asm volatile("" : "+v"(tb[i]), "+v"(tc[i]));
+        }
         const v2f b1[2] = {tb[1], tb[2]}, b2[4] = {tb[3], tb[4], tb[5], tb[6]};
         const v2f c1[2] = {tc[1], tc[2]}, c2[4] = {tc[3], tc[4], tc[5], tc[6]};
 #pragma unroll 1
@@ -479,7 +542,7 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
         // ---- DCT (L/maxiMFCC.h:98-111): lane = (frame, coefficient), j ascending ---------------------------
         for (unsigned p = lane; p < kGroup * A.numCoeffs; p += 64) {
             const unsigned jj = p / A.numCoeffs, i = p - jj * A.numCoeffs;
-            const double c = dct_dot(s_d + i, A.numCoeffs, s_mel + jj * A.nfp, A.numFilters);
+            const double c = dct_dot_rows(s_d + i * A.nfp, s_mel + jj * A.nfp, A.numFilters);
             if (f0 + jj < nframes) A.mfcc[(f0 + jj) * A.numCoeffs + i] = c / (double)A.numCoeffs;
         }
         wave_lds_sync();  // the next frame's first transpose overwrites the band rows
@@ -717,8 +780,11 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
     // a bank that reads neither bin 0 nor bin 256 keeps only the bins below nbUsed (stride 8 mod 32 floats): with the two X
     // images that is what lets two workgroups share a CU's 160 KB
     if (!full && mp->fsMinBin >= 1 && mp->nbUsed <= 256) A.mstride = (mp->nbUsed + 23) / 32 * 32 + 8;
-    A.nfp = mp->numFilters | 1u;                  // odd row stride for the band rows
-    A.dctPad = (mp->numFilters * mp->numCoeffs + 1) & ~1u;
+    // row stride (doubles) of the band rows and of the coefficient-major DCT table: even (16-byte aligned rows for ds_read_b128) with
+    // an odd half, so that the rows of 16 consecutive coefficients start in 16 different 16-byte bank slots
+    A.nfp = (mp->numFilters + 1) & ~1u;
+    if (!((A.nfp / 2) & 1)) A.nfp += 2;
+    A.dctPad = mp->numCoeffs * A.nfp;
     A.steps = mp->fsSteps; A.fs = mp->d_fs8; A.dct = mp->d_dct;
     A.edgeBins = full || mp->fsMinBin < 1 || mp->nbUsed > 256;
     A.mags = d_mags; A.melraw = d_melraw; A.melbands = d_melbands; A.mfcc = d_mfcc;
@@ -727,9 +793,10 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
     // workgroup per CU (only without the full magnitude rows: twelve 8 x 520 tiles do not fit); 0 = automatic
     constexpr int kWaves1 = 12;
     auto lds_for = [&](int nf, int waves, unsigned slack) {
-        return tablesBytes + waves * (nf * sizeof(float2) * kX1024 + sizeof(float) * (kGroup * A.mstride + slack));
+        return tablesBytes + (nf == 1 ? sizeof(float2) * (8 + 64) * 7 : 0) +
+               waves * (nf * sizeof(float2) * kX1024 + sizeof(float) * (kGroup * A.mstride + slack));
     };
-    const unsigned slackWanted = A.mstride >= 257 ? 0u : (257 - A.mstride + 1) & ~1u;  // per-wave regions stay 8-byte aligned
+    const unsigned slackWanted = A.mstride >= 257 ? 0u : (257 - A.mstride + 3) & ~3u;  // per-wave regions stay 16-byte aligned
     int layout = (int)tune_get("fused_layout");
     if (layout == 0) layout = 1;
     if (layout == 2 && (full || lds_for(1, kWaves1, 0) > 160 * 1024)) layout = 1;
