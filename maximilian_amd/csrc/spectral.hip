@@ -72,6 +72,31 @@ __device__ __forceinline__ void post_lo_sq2(const v2f a1, const v2f b1, const v2
         : [a1] "v"(a1), [b1] "v"(b1), [w1] "v"(w1), [a2] "v"(a2), [b2] "v"(b2), [w2] "v"(w2));
 }
 
+// Tolerance mode: the same pair with FMAs and the halving folded into the twiddle (wh = 0.5 * w, exact):
+//   s = (a.x+b.x, a.y-b.y)   t = (a.y+b.y, a.x-b.x)   r = 0.5 s + (wh.x t.x + wh.y t.y, -wh.x t.y + wh.y t.x)   q = r * r
+// six packed instructions per pair instead of nine (reordered and fused: not the reference's roundings).
+__device__ __forceinline__ void post_lo_sq2_t(const v2f a1, const v2f b1, const v2f w1, const v2f a2, const v2f b2, const v2f w2,
+                                              v2f &q1, v2f &q2) {
+    v2f s1, t1, s2, t2, m1, m2;
+    asm("s_nop 0\n\t"
+        "v_pk_add_f32 %[s1], %[a1], %[b1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[t1], %[a1], %[b1] op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[s2], %[a2], %[b2] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[t2], %[a2], %[b2] op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[m1], %[w1], %[t1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"                        // (wx tx, -wx ty)
+        "v_pk_mul_f32 %[m2], %[w2], %[t2] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %[m1], %[w1], %[t1], %[m1] op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"             // + (wy ty, wy tx)
+        "v_pk_fma_f32 %[m2], %[w2], %[t2], %[m2] op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %[s1], %[s1], 0.5, %[m1] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %[s2], %[s2], 0.5, %[m2] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_mul_f32 %[q1], %[s1], %[s1]\n\t"
+        "v_pk_mul_f32 %[q2], %[s2], %[s2]\n\t"
+        "s_nop 0"
+        : [s1] "=&v"(s1), [t1] "=&v"(t1), [s2] "=&v"(s2), [t2] "=&v"(t2), [m1] "=&v"(m1), [m2] "=&v"(m2), [q1] "=&v"(q1),
+          [q2] "=&v"(q2)
+        : [a1] "v"(a1), [b1] "v"(b1), [w1] "v"(w1), [a2] "v"(a2), [b2] "v"(b2), [w2] "v"(w2));
+}
+
 // One coefficient of the DCT (L/maxiMFCC.h:98-111): c = sum_j dct[j][i] * band[j], j ascending -- the reference's sequential
 // sum.  The table and band values of eight terms are requested before the first is used and the next eight before these are
 // consumed: as a plain loop hipcc waits for every pair of LDS reads (one exposed LDS latency per term; for 42 filters x 13
@@ -192,6 +217,61 @@ __device__ __forceinline__ void mel_walk(const char *Mrow, double *melrow, const
     }
 }
 
+// ---- tolerance mode: the mel / log / DCT stage in fp32 --------------------------------------------------------------------
+// (band sums of <= 40 terms and 42-term DCT sums in fp32 with FMAs: ~1e-6 relative on the sums, ~1e-5 absolute on a coefficient --
+// an order below the 1.3e-4 by which the reference's own transform misses the true one; stated with the mode's other tolerances)
+struct fs32_entry {  // the slot table re-staged for fp32: 16 bytes, one ds_read_b128
+    float w;
+    int off, fid, pad;  // fid: 4 * (filter + 1) on the last bin of a filter, else 0
+};
+template <int SLOTS>
+__device__ __forceinline__ void mel_walk_t(const char *Mrow, float *melrow, const fs32_entry *fs, const int steps) {
+    float acc = 0.0f;
+    fs32_entry P[kMelBatch], Q[kMelBatch];
+    float xP[kMelBatch], xQ[kMelBatch];
+#pragma unroll
+    for (int i = 0; i < kMelBatch; i++) P[i] = fs[i * SLOTS];
+#pragma unroll
+    for (int i = 0; i < kMelBatch; i++) Q[i] = fs[(kMelBatch + i) * SLOTS];
+#pragma unroll
+    for (int i = 0; i < kMelBatch; i++) xP[i] = *reinterpret_cast<const float *>(Mrow + P[i].off);
+    auto consume = [&](const fs32_entry &e, const float x) {
+        acc = __builtin_fmaf(e.w, x, acc);
+        if (e.fid) {
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(melrow) + e.fid - 4) = acc;
+            acc = 0.0f;
+        }
+    };
+    for (int t0 = 0; t0 < steps; t0 += 2 * kMelBatch) {
+#pragma unroll
+        for (int i = 0; i < kMelBatch; i++) {
+            xQ[i] = *reinterpret_cast<const float *>(Mrow + Q[i].off);
+            consume(P[i], xP[i]);
+            P[i] = fs[(t0 + 2 * kMelBatch + i) * SLOTS];
+        }
+#pragma unroll
+        for (int i = 0; i < kMelBatch; i++) {
+            xP[i] = *reinterpret_cast<const float *>(Mrow + P[i].off);
+            consume(Q[i], xQ[i]);
+            Q[i] = fs[(t0 + 3 * kMelBatch + i) * SLOTS];
+        }
+    }
+}
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float dct_dot_rows_f(const float *d, const float *m, const unsigned nf) {
+    const f4v *dp = reinterpret_cast<const f4v *>(d), *mp = reinterpret_cast<const f4v *>(m);
+    const unsigned octs = (nf + 7) / 8;  // (both rows are padded with zeros to a multiple of 8 floats)
+    float c = 0.0f;
+    for (unsigned o = 0; o < octs; o++) {
+        const f4v d0 = dp[2 * o], m0 = mp[2 * o], d1 = dp[2 * o + 1], m1 = mp[2 * o + 1];
+        c = __builtin_fmaf(d0.x, m0.x, c); c = __builtin_fmaf(d0.y, m0.y, c);
+        c = __builtin_fmaf(d0.z, m0.z, c); c = __builtin_fmaf(d0.w, m0.w, c);
+        c = __builtin_fmaf(d1.x, m1.x, c); c = __builtin_fmaf(d1.y, m1.y, c);
+        c = __builtin_fmaf(d1.z, m1.z, c); c = __builtin_fmaf(d1.w, m1.w, c);
+    }
+    return c;
+}
+
 struct FusedArgs {
     const float *signal;
     size_t frame_stride, nframes;
@@ -199,6 +279,7 @@ struct FusedArgs {
     const float2 *tw, *post;
     const float2 *tw8;  // tolerance mode: radix-8 input twiddles ([8][7] by lane & 7, then [64][7] by lane; mxg_fft_plan::d_tw8)
     unsigned numFilters, numCoeffs, nbUsed, mstride, nfp, dctPad;
+    unsigned nfpf;  // tolerance mode: row stride (floats) of the fp32 band rows / DCT rows: >= numFilters rounded up to 8, nfpf / 4 odd
     int steps;
     int edgeBins;  // the bank reads bin 0 or bin 256 (or the magnitudes are written out): form them
     int mUncond;   // every lane may store its four magnitudes (bins 1 + lane + 64 q <= 256) without a test: the row is long enough, or
@@ -248,10 +329,25 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
     for (int f = 0; f < NF; f++) X[f] = reinterpret_cast<v2f *>(wbase) + f * kX1024;
     double *s_mel = reinterpret_cast<double *>(wbase);  // the band rows live on X[0] between the last post-pass and the next frame
     float *M = reinterpret_cast<float *>(wbase + NF * sizeof(float2) * kX1024);
-    for (int i = threadIdx.x; i < fsRows * kFusedSlots; i += blockDim.x) s_fs[i] = A.fs[i];
-    for (unsigned t = threadIdx.x; t < A.numFilters * A.numCoeffs; t += blockDim.x) {  // A.dct is [j][i]; LDS rows are [i][nfp]
-        const unsigned j = t / A.numCoeffs, i = t - j * A.numCoeffs;
-        s_d[i * A.nfp + j] = A.dct[t];
+    fs32_entry *s_fs32 = reinterpret_cast<fs32_entry *>(s_dyn);  // tolerance mode: the same tables in fp32, in the same place
+    float *s_df = reinterpret_cast<float *>(s_d);
+    if constexpr (TOL) {
+        for (int i = threadIdx.x; i < fsRows * kFusedSlots; i += blockDim.x) {
+            const mxg_fs_entry e = A.fs[i];
+            s_fs32[i] = fs32_entry{(float)e.w, e.off, e.fid / 2, 0};
+        }
+        for (unsigned t = threadIdx.x; t < A.numCoeffs * A.nfpf; t += blockDim.x) s_df[t] = 0.0f;
+        __syncthreads();
+        for (unsigned t = threadIdx.x; t < A.numFilters * A.numCoeffs; t += blockDim.x) {
+            const unsigned j = t / A.numCoeffs, i = t - j * A.numCoeffs;
+            s_df[i * A.nfpf + j] = (float)A.dct[t];
+        }
+    } else {
+        for (int i = threadIdx.x; i < fsRows * kFusedSlots; i += blockDim.x) s_fs[i] = A.fs[i];
+        for (unsigned t = threadIdx.x; t < A.numFilters * A.numCoeffs; t += blockDim.x) {  // A.dct is [j][i]; LDS rows are [i][nfp]
+            const unsigned j = t / A.numCoeffs, i = t - j * A.numCoeffs;
+            s_d[i * A.nfp + j] = A.dct[t];
+        }
     }
     if constexpr (NF == 1) {
         const int bi[7] = {7, 15, 23, 31, 39, 47, 55}, ci[7] = {63, 127, 191, 255, 319, 383, 447};
@@ -298,6 +394,10 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
         // plus a compile-time offset: pad8(i0 + 64q) = pad8(i0) + 72q
 #pragma unroll
         for (int q = 0; q < 4; q++) pw[q] = as_v2f(post[(1 + lane + 64 * q) < 256 ? 1 + lane + 64 * q : 255]);
+        if constexpr (TOL && !FULL) {  // post_lo_sq2_t takes half the twiddle
+#pragma unroll
+            for (int q = 0; q < 4; q++) pw[q] = pw[q] * 0.5f;
+        }
 #pragma unroll
         for (int e = 0; e < 8; e++) asm volatile("" : "+v"(wv[e]));
 #pragma unroll
@@ -462,8 +562,13 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
                     float *Mrow = M + (j + f) * A.mstride;
                     garbage[f] = false;
                     v2f sq[4];
-                    post_lo_sq2(pa[f][0], pb[f][0], pw[0], pa[f][1], pb[f][1], pw[1], sq[0], sq[1]);
-                    post_lo_sq2(pa[f][2], pb[f][2], pw[2], pa[f][3], pb[f][3], pw[3], sq[2], sq[3]);
+                    if constexpr (TOL) {
+                        post_lo_sq2_t(pa[f][0], pb[f][0], pw[0], pa[f][1], pb[f][1], pw[1], sq[0], sq[1]);
+                        post_lo_sq2_t(pa[f][2], pb[f][2], pw[2], pa[f][3], pb[f][3], pw[3], sq[2], sq[3]);
+                    } else {
+                        post_lo_sq2(pa[f][0], pb[f][0], pw[0], pa[f][1], pb[f][1], pw[1], sq[0], sq[1]);
+                        post_lo_sq2(pa[f][2], pb[f][2], pw[2], pa[f][3], pb[f][3], pw[3], sq[2], sq[3]);
+                    }
                     float m[4];
                     if constexpr (TOL) {
 #pragma unroll
@@ -519,6 +624,34 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
             }
             wave_lds_sync();
         }
+        if constexpr (TOL) {
+            // ---- tolerance mode: the same three phases in fp32 (mel_walk_t, v_log_f32, dct_dot_rows_f) ---------------------------
+            float *s_melf = reinterpret_cast<float *>(s_mel);
+            for (unsigned i = lane; i < kGroup * A.nfpf; i += 64) s_melf[i] = 0.0f;  // empty filters and the row padding stay 0
+            wave_lds_sync();
+            mel_walk_t<kFusedSlots>(reinterpret_cast<const char *>(M + mj * A.mstride), s_melf + mj * A.nfpf, s_fs32 + ms, A.steps);
+            wave_lds_sync();
+            for (unsigned idx = lane; idx < kGroup * A.numFilters; idx += 64) {
+                const unsigned jj = idx / A.numFilters, ff = idx - jj * A.numFilters;
+                const float raw = s_melf[jj * A.nfpf + ff];
+                // log(mb * mb) = 2 ln 2 * log2(mb) through the hardware's fp32 log2 (abs. error ~1e-6 on values of magnitude <= 30)
+                const float lv = raw > 0.000001f ? 1.3862943611198906f * __builtin_amdgcn_logf(raw) : 0.0f;
+                s_melf[jj * A.nfpf + ff] = lv;
+                if (f0 + jj < nframes) {
+                    if (A.melraw) A.melraw[(f0 + jj) * A.numFilters + ff] = (double)raw;
+                    if (A.melbands) A.melbands[(f0 + jj) * A.numFilters + ff] = (double)lv;
+                }
+            }
+            wave_lds_sync();
+            const float rcpNC = 1.0f / (float)A.numCoeffs;
+            for (unsigned p = lane; p < kGroup * A.numCoeffs; p += 64) {
+                const unsigned jj = p / A.numCoeffs, i = p - jj * A.numCoeffs;
+                const float c = dct_dot_rows_f(s_df + i * A.nfpf, s_melf + jj * A.nfpf, A.numFilters);
+                if (f0 + jj < nframes) A.mfcc[(f0 + jj) * A.numCoeffs + i] = (double)(c * rcpNC);
+            }
+            wave_lds_sync();
+            continue;
+        }
         // ---- mel walk: lane (mj, ms) walks slot ms's filter list over frame mj's magnitudes -----------------
         for (unsigned i = lane; i < kGroup * A.nfp; i += 64) s_mel[i] = 0.0;  // filters with an empty support stay 0
         wave_lds_sync();
@@ -528,10 +661,7 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
         for (unsigned idx = lane; idx < kGroup * A.numFilters; idx += 64) {
             const unsigned jj = idx / A.numFilters, ff = idx - jj * A.numFilters;
             const double raw = s_mel[jj * A.nfp + ff];
-            // tolerance mode: log(mb * mb) = 2 ln 2 * log2(mb) through the hardware's fp32 log2 (abs. error ~1e-6 on values of
-            // magnitude <= 30): two orders below the distance between the reference's transform and the true one
-            const double lv = TOL ? (raw > 0.000001 ? 1.3862943611198906 * (double)__builtin_amdgcn_logf((float)raw) : 0.0)
-                                  : log_square(raw);
+            const double lv = log_square(raw);
             s_mel[jj * A.nfp + ff] = lv;
             if (f0 + jj < nframes) {
                 if (A.melraw) A.melraw[(f0 + jj) * A.numFilters + ff] = raw;
@@ -784,7 +914,11 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
     // an odd half, so that the rows of 16 consecutive coefficients start in 16 different 16-byte bank slots
     A.nfp = (mp->numFilters + 1) & ~1u;
     if (!((A.nfp / 2) & 1)) A.nfp += 2;
+    A.nfpf = (mp->numFilters + 7) & ~7u;
+    if (!((A.nfpf / 4) & 1)) A.nfpf += 4;
     A.dctPad = mp->numCoeffs * A.nfp;
+    if (A.dctPad < (mp->numCoeffs * A.nfpf + 1) / 2) A.dctPad = (mp->numCoeffs * A.nfpf + 1) / 2;  // (tiny banks: the fp32 rows are longer)
+    A.dctPad = (A.dctPad + 1) & ~1u;
     A.steps = mp->fsSteps; A.fs = mp->d_fs8; A.dct = mp->d_dct;
     A.edgeBins = full || mp->fsMinBin < 1 || mp->nbUsed > 256;
     A.mags = d_mags; A.melraw = d_melraw; A.melbands = d_melbands; A.mfcc = d_mfcc;
