@@ -185,7 +185,14 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
 
 // STORE: 0 = mix only (no per-voice block), 1 = plain 8-byte stores, 2 = pair rows of write-through 16-byte stores (as K1, V even and
 // `out` 16-byte aligned).  VAR 0: permlane-swap butterfly, 4 LDS rows per window (one per wave).  VAR 1: all-DPP butterfly, 16
-// rows (wave x row; A/B only).  Time parts (gridDim.y, round 3): the kernel is VALU-issue bound at one wavefront per SIMD (43 us
+// rows (wave x row; A/B only).  VAR 2 (round 3): the CROSS-ROW half of the reduction on the matrix pipe.  v_mfma_f64_16x16x4
+// computes D[i][j] += sum_k A[i][k] B[k][j] with lane l supplying A[l & 15][l >> 4] and B[l >> 4][l & 15]: give it B = the lane's
+// own product (x * gain: no data movement) and A = [i == s] for sample s of the chunk, and after 16 samples D row s holds, in
+// column j, the sum of that sample over lanes j, j + 16, j + 32, j + 48 -- the two levels that cost 48 v_permlane swaps of 16 clk
+// per chunk and channel now run beside the oscillator's VALU work (two 64-cycle MFMAs per sample on an otherwise idle pipe), and
+// the transposition comes for free: lane l's register r holds sample 4 r + (l >> 4).  What is left is the sum over the 16 lanes
+// of a row for four vectors: row_mirror, row_half_mirror, quad sum (21 VALU per chunk and channel instead of ~110).  The fp64
+// MFMA adds the four products in its own order: covered by the mix tolerance (the sum was tree-ordered already).  Time parts (gridDim.y, round 3): the kernel is VALU-issue bound at one wavefront per SIMD (43 us
 // of arithmetic for a 65 536 x 512 block against ~41 us of stores), and a second resident wavefront nearly doubles the issue
 // rate -- so a block is cut into two time parts like K1's sinewave: part p advances the phase over the samples before it with
 // osc_skip (the same additions: the same bits), renders its stretch and mixes it into its own rows of the partial buffer; the
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
                                                       double *__restrict__ partial, double sr, PartSync psync) {
     constexpr int kTab = tab_len<WF>();
     constexpr int kTabPad = (kTab + 1) & ~1;  // the (L, R) pairs below are 16-byte stores
-    constexpr int kRows = VAR == 0 ? 4 : 16;  // LDS rows the workgroup pass adds per output
+    constexpr int kRows = VAR == 1 ? 16 : 4;  // LDS rows the workgroup pass adds per output
     constexpr int kMixWin = WIN;
     __shared__ __attribute__((aligned(16))) double s_all[kTabPad + kRows * kMixWin * 2];
     double *s_tab = s_all;
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *s_part = s_all + kTabPad;                                     // [kRows][kMixWin][2]
-    double *my_part = s_part + (VAR == 0 ? wave : wave * 4 + (lane >> 4)) * (kMixWin * 2);
+    double *my_part = s_part + (VAR != 1 ? wave : wave * 4 + (lane >> 4)) * (kMixWin * 2);
     // The lane exchanges need all 64 lanes alive, and a per-sample `if (live)` costs an exec-mask region per sample:
     // the surplus lanes of the bank's last wavefront shadow a live voice instead (same loads, same arithmetic, same stores
     // of the same values to the same addresses) and enter the mix with zero gains -- voice V-1, or with pair rows the last
@@ -238,8 +245,13 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
         int idx[kMixChunk];
 #pragma unroll
         for (int i = 0; i < kMixChunk; i++) idx[i] = i;
-        slot = VAR == 0 ? fold_chunk_swap<int>(idx) : fold_chunk<int>(idx, lane);
-        if (VAR == 0 && (lane & 3) != 0) slot = -1;  // one lane per quad stores
+        if constexpr (VAR == 2) {  // register r of the MFMA result holds sample 4 r + (lane >> 4); then the in-row network
+            const int q = lane >> 4;
+            slot = fold_dpp<kDppRowHalfMirror, 0xA>(fold_dpp<kDppRowMirror, 0xC>(q, 4 + q), fold_dpp<kDppRowMirror, 0xC>(8 + q, 12 + q));
+        } else {
+            slot = VAR == 0 ? fold_chunk_swap<int>(idx) : fold_chunk<int>(idx, lane);
+        }
+        if (VAR != 1 && (lane & 3) != 0) slot = -1;  // one lane per quad stores
     }
     double *o = out + nA * V + v;
     double *op = out + (nA + (threadIdx.x & 1)) * V + (v & ~(size_t)1);  // pair rows: this lane's 16 bytes of row n + (lane & 1)
@@ -250,6 +262,42 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
             auto chunk = [&](auto full_tag) {
                 constexpr bool kFull = decltype(full_tag)::value;
                 double L[kMixChunk], R[kMixChunk];
+                if constexpr (VAR == 2) {
+                    typedef double d4v __attribute__((ext_vector_type(4)));
+                    d4v DL = {0.0, 0.0, 0.0, 0.0}, DR = {0.0, 0.0, 0.0, 0.0};
+                    const int l16 = lane & 15;
+#pragma unroll
+                    for (int i = 0; i < kMixChunk; i += 2) {
+                        double r0 = 0.0, r1 = 0.0;
+                        if (kFull || i < cnt) r0 = osc_tick<WF>(ph, hd, q, s_tab, s_tab);  // ragged last chunk: the state must not advance past N
+                        if (kFull || i + 1 < cnt) r1 = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+                        if constexpr (STORE == 2) {
+                            if constexpr (kFull) {
+                                store_pair_rows<2>(op, r0, r1);
+                                op += 2 * V;
+                            } else {
+                                if (i < cnt) o[0] = r0;
+                                if (i + 1 < cnt) o[V] = r1;
+                                o += 2 * V;
+                            }
+                        } else if constexpr (STORE == 1) {
+                            if (kFull || i < cnt) o[0] = r0;
+                            if (kFull || i + 1 < cnt) o[V] = r1;
+                            o += 2 * V;
+                        }
+                        const double s0 = l16 == i ? 1.0 : 0.0, s1 = l16 == i + 1 ? 1.0 : 0.0;
+                        DL = __builtin_amdgcn_mfma_f64_16x16x4f64(s0, r0 * gl, DL, 0, 0, 0);  // two[0] = input*sqrt(1.0-x)   C:506
+                        DR = __builtin_amdgcn_mfma_f64_16x16x4f64(s0, r0 * gr, DR, 0, 0, 0);  // two[1] = input*sqrt(x)       C:507
+                        DL = __builtin_amdgcn_mfma_f64_16x16x4f64(s1, r1 * gl, DL, 0, 0, 0);
+                        DR = __builtin_amdgcn_mfma_f64_16x16x4f64(s1, r1 * gr, DR, 0, 0, 0);
+                    }
+                    if constexpr (kFull && STORE == 2) o += (size_t)kMixChunk * V;
+                    const double2v pr2 = {
+                        quad_sum(fold_dpp<kDppRowHalfMirror, 0xA>(fold_dpp<kDppRowMirror, 0xC>(DL[0], DL[1]), fold_dpp<kDppRowMirror, 0xC>(DL[2], DL[3]))),
+                        quad_sum(fold_dpp<kDppRowHalfMirror, 0xA>(fold_dpp<kDppRowMirror, 0xC>(DR[0], DR[1]), fold_dpp<kDppRowMirror, 0xC>(DR[2], DR[3])))};
+                    if (slot >= 0 && slot < cnt) *reinterpret_cast<double2v *>(my_part + (c0 + slot) * 2) = pr2;
+                    return;
+                }
                 if constexpr (kFull && STORE == 2) {
 #pragma unroll
                     for (int i = 0; i < kMixChunk; i += 2) {
@@ -317,6 +365,8 @@ osc_mix_fn pick_mix(int store, int var) {
             default: break;
         }
     }
+    if (var == 4)  // the matrix-pipe form
+        return store == 2 ? osc_mix_kernel<WF, 2, 2, 256> : (store == 1 ? osc_mix_kernel<WF, 1, 2, 256> : osc_mix_kernel<WF, 0, 2, 256>);
     return store == 2 ? osc_mix_kernel<WF, 2, 0, 256> : (store == 1 ? osc_mix_kernel<WF, 1, 0, 256> : osc_mix_kernel<WF, 0, 0, 256>);
 }
 osc_mix_fn pick_mix_wf(int wf, int store, int var) {

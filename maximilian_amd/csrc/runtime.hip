@@ -42,7 +42,7 @@ Tune g_tune[] = {
     {"osc_split", 0, 0, 8},  // K1: time parts per voice group (0 = automatic: 4 for sinewave / coswave on small banks, else 1)
     {"osc_mix_store", 0, 0, 2},  // K1m per-voice block: 0 automatic, 1 plain 8-byte stores, 2 pair rows of write-through 16-byte stores
     {"osc_mix_split", 0, 0, 4},  // K1m time parts (0 automatic: two below 2048 wavefronts)
-    {"osc_mix_var", 0, 0, 3},  // K1m A/B (sinebuf): 0 swap butterfly, window 512; 1 same, window 128; 2 DPP butterfly 128; 3 DPP 512
+    {"osc_mix_var", 0, 0, 4},  // K1m A/B: 0 swap butterfly; 1 same, window 128; 2 DPP butterfly 128; 3 DPP 512 (1-3: sinebuf only); 4 cross-row sums on the matrix pipe
     {"ifft_stream", 1, 0, 2},  // maxiIFFT: transform + hop buffer in one kernel (0: never; 1: where hop >= fftSize / 2; 2: wherever it fits)
     {"smp_pipe", 1, 0, 1},   // K5: the time-part kernel's loads of chunk k+1 issued before the stores of chunk k (0: chunk after chunk)
     {"smp_split", 0, 0, 8},  // K5: time parts of a block-constant *AtSpeed launch (0 = automatic: ~4 wavefronts per SIMD)

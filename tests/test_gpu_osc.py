@@ -206,6 +206,21 @@ def test_render_mix_fused(mx, port, wf, V, N):
             assert_bits_equal(bank3.phase.numpy(), eph, "phase, store %d split %d" % (store, split))
         finally:
             L.mxg_tune(b"osc_mix_store", prev[0]); L.mxg_tune(b"osc_mix_split", prev[1])
+    # the matrix-pipe form of the cross-row sums (osc_mix_var 4): the per-voice block and the phase are the same bits; the mix is
+    # summed in another order (four products per MFMA, then the rows): within the same stated tolerance of the reference's sum
+    for store, split in ((2, 1), (1, 2), (0, 1)):
+        prev = [L.mxg_tune(b"osc_mix_var", 4), L.mxg_tune(b"osc_mix_store", max(store, 1)), L.mxg_tune(b"osc_mix_split", split)]
+        try:
+            bank4 = mx.maxiOscBank(V)
+            o4, m4 = bank4.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V), store=store != 0)
+            o5, m5 = bank4.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V), store=store != 0)
+            if store:
+                assert_bits_equal(np.concatenate([o4.numpy(), o5.numpy()]), eo, "matrix-pipe form, store %d" % store)
+            assert_bits_equal(bank4.phase.numpy(), eph, "phase, matrix-pipe form")
+            m45 = np.concatenate([m4.numpy(), m5.numpy()])
+            assert np.abs(m45 - em).max() <= mix_tol(V, np.abs(eo).max())
+        finally:
+            L.mxg_tune(b"osc_mix_var", prev[0]); L.mxg_tune(b"osc_mix_store", prev[1]); L.mxg_tune(b"osc_mix_split", prev[2])
 
 
 @pytest.mark.parametrize("wf,V,N", [(0, 1000, 601), (1, 64, 3), (8, 300, 512), (6, 129, 77), (10, 70, 1), (5, 4096, 130)])
