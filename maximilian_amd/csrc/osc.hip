@@ -185,14 +185,17 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
 
 // STORE: 0 = mix only (no per-voice block), 1 = plain 8-byte stores, 2 = pair rows of write-through 16-byte stores (as K1, V even and
 // `out` 16-byte aligned).  VAR 0: permlane-swap butterfly, 4 LDS rows per window (one per wave).  VAR 1: all-DPP butterfly, 16
-// rows (wave x row; A/B only).  VAR 2 (round 3): the CROSS-ROW half of the reduction on the matrix pipe.  v_mfma_f64_16x16x4
-// computes D[i][j] += sum_k A[i][k] B[k][j] with lane l supplying A[l & 15][l >> 4] and B[l >> 4][l & 15]: give it B = the lane's
-// own product (x * gain: no data movement) and A = [i == s] for sample s of the chunk, and after 16 samples D row s holds, in
-// column j, the sum of that sample over lanes j, j + 16, j + 32, j + 48 -- the two levels that cost 48 v_permlane swaps of 16 clk
-// per chunk and channel now run beside the oscillator's VALU work (two 64-cycle MFMAs per sample on an otherwise idle pipe), and
-// the transposition comes for free: lane l's register r holds sample 4 r + (l >> 4).  What is left is the sum over the 16 lanes
-// of a row for four vectors: row_mirror, row_half_mirror, quad sum (21 VALU per chunk and channel instead of ~110).  The fp64
-// MFMA adds the four products in its own order: covered by the mix tolerance (the sum was tree-ordered already).  Time parts (gridDim.y, round 3): the kernel is VALU-issue bound at one wavefront per SIMD (43 us
+// rows (wave x row; A/B only).  VAR 2 (round 3): the CROSS-ROW half of the reduction on the matrix pipe.  v_mfma_f64_4x4x4 (four
+// 4 x 4 x 4 blocks, 16 cycles) computes D[b][i][j] += sum_k A[b][i][k] B[b][k][j]; the operand layout, probed on the device
+// (tools/ubench/mfma_probe.hip): lane l = 16 k + 4 b + c supplies A[b][i = c][k] and B[b][k][j = c], and lane 16 i + 4 b + j receives
+// D[b][i][j] -- k is the ROW of 16 lanes.  Give it B = the lane's own product (x * gain: no data movement) and A = [c == s & 3]
+// for sample s, accumulate four samples into one register, and lane (row i, column q) holds the sum of sample 4 g + i over lanes
+// q, q + 16, q + 32, q + 48: the two levels that cost 48 v_permlane swaps of 16 clk per chunk and channel run beside the
+// oscillator's VALU work (two 16-cycle MFMAs per sample on an otherwise idle pipe), and the transposition comes for free.  What
+// is left is the sum over the 16 lanes of a row for four vectors: row_mirror, row_half_mirror, quad sum (21 VALU per chunk and
+// channel instead of ~110).  The MFMA adds the four products in its own order: covered by the mix tolerance (the sum was
+// tree-ordered already).  (v_mfma_f64_16x16x4 does the same job with a 16-row selector at 64 cycles per instruction: measured
+// 85 us -- at one wavefront per SIMD the in-order issue waits for the busy matrix pipe.)  Time parts (gridDim.y, round 3): the kernel is VALU-issue bound at one wavefront per SIMD (43 us
 // of arithmetic for a 65 536 x 512 block against ~41 us of stores), and a second resident wavefront nearly doubles the issue
 // rate -- so a block is cut into two time parts like K1's sinewave: part p advances the phase over the samples before it with
 // osc_skip (the same additions: the same bits), renders its stretch and mixes it into its own rows of the partial buffer; the
@@ -263,9 +266,8 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
                 constexpr bool kFull = decltype(full_tag)::value;
                 double L[kMixChunk], R[kMixChunk];
                 if constexpr (VAR == 2) {
-                    typedef double d4v __attribute__((ext_vector_type(4)));
-                    d4v DL = {0.0, 0.0, 0.0, 0.0}, DR = {0.0, 0.0, 0.0, 0.0};
-                    const int l16 = lane & 15;
+                    double DL[4] = {0.0, 0.0, 0.0, 0.0}, DR[4] = {0.0, 0.0, 0.0, 0.0};
+                    const int l4 = lane & 3;
 #pragma unroll
                     for (int i = 0; i < kMixChunk; i += 2) {
                         double r0 = 0.0, r1 = 0.0;
@@ -285,11 +287,11 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
                             if (kFull || i + 1 < cnt) o[V] = r1;
                             o += 2 * V;
                         }
-                        const double s0 = l16 == i ? 1.0 : 0.0, s1 = l16 == i + 1 ? 1.0 : 0.0;
-                        DL = __builtin_amdgcn_mfma_f64_16x16x4f64(s0, r0 * gl, DL, 0, 0, 0);  // two[0] = input*sqrt(1.0-x)   C:506
-                        DR = __builtin_amdgcn_mfma_f64_16x16x4f64(s0, r0 * gr, DR, 0, 0, 0);  // two[1] = input*sqrt(x)       C:507
-                        DL = __builtin_amdgcn_mfma_f64_16x16x4f64(s1, r1 * gl, DL, 0, 0, 0);
-                        DR = __builtin_amdgcn_mfma_f64_16x16x4f64(s1, r1 * gr, DR, 0, 0, 0);
+                        const double s0 = l4 == (i & 3) ? 1.0 : 0.0, s1 = l4 == ((i + 1) & 3) ? 1.0 : 0.0;
+                        DL[i >> 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(s0, r0 * gl, DL[i >> 2], 0, 0, 0);  // two[0] = input*sqrt(1.0-x)   C:506
+                        DR[i >> 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(s0, r0 * gr, DR[i >> 2], 0, 0, 0);  // two[1] = input*sqrt(x)       C:507
+                        DL[i >> 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(s1, r1 * gl, DL[i >> 2], 0, 0, 0);
+                        DR[i >> 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(s1, r1 * gr, DR[i >> 2], 0, 0, 0);
                     }
                     if constexpr (kFull && STORE == 2) o += (size_t)kMixChunk * V;
                     const double2v pr2 = {
