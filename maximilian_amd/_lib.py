@@ -9,7 +9,7 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmaxigpu.so")
+LIB_PATH = os.environ.get("MXG_LIB") or os.path.join(_HERE, "libmaxigpu.so")  # (MXG_LIB: an A/B build of the same ABI, tools only)
 
 _lib = None
 

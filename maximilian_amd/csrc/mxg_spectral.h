@@ -138,37 +138,24 @@ __device__ __forceinline__ v2f as_v2f(const float2 a) { return v2f{a.x, a.y}; }
 
 // three in-register radix-2 stages over the 8 points of a lane; w0: 1 twiddle (pairs e,e+1),
 // w1[2]: pairs (e,e+2) with n-offset e&1, w2[4]: pairs (e,e+4) with n-offset e&3.
-// The six double butterflies of a round are ONE asm block: between two blocks hipcc cannot know that the first packed result is
-// not read at once and each block carries its own pair of s_nop; in the order below no instruction reads the result of the one
-// before it across a block boundary either (checked pair by pair: the closest is two instructions apart), so a round is 60
-// packed instructions between one s_nop at either end (12 blocks' worth of them before).
-#define MXG_B2(j1, k1, w1, j2, k2, w2)                                                                                  \
-    "v_pk_mul_f32 %[p1], %[" #w1 "], %[" #k1 "] op_sel_hi:[0,1]\n\t"                                                    \
-    "v_pk_mul_f32 %[q1], %[" #w1 "], %[" #k1 "] op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]\n\t"                          \
-    "v_pk_mul_f32 %[p2], %[" #w2 "], %[" #k2 "] op_sel_hi:[0,1]\n\t"                                                    \
-    "v_pk_mul_f32 %[q2], %[" #w2 "], %[" #k2 "] op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]\n\t"                          \
-    "v_pk_add_f32 %[p1], %[p1], %[q1]\n\t"                                                                             \
-    "v_pk_add_f32 %[p2], %[p2], %[q2]\n\t"                                                                             \
-    "v_pk_add_f32 %[" #k1 "], %[" #j1 "], %[p1] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                          \
-    "v_pk_add_f32 %[" #j1 "], %[" #j1 "], %[p1]\n\t"                                                                    \
-    "v_pk_add_f32 %[" #k2 "], %[" #j2 "], %[p2] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                          \
-    "v_pk_add_f32 %[" #j2 "], %[" #j2 "], %[p2]\n\t"
-#define MXG_ROUND_OPERANDS(WC)                                                                                          \
-    : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]), [x6] "+v"(x[6]), \
-      [x7] "+v"(x[7]), [p1] "=&v"(p1), [q1] "=&v"(q1), [p2] "=&v"(p2), [q2] "=&v"(q2)                                   \
-    : [a0] WC(a0), [b0] WC(b0), [b1] WC(b1), [c0] WC(c0), [c1] WC(c1), [c2] WC(c2), [c3] WC(c3)
-__device__ __forceinline__ void round3(v2f (&x)[8], const v2f a0, const v2f (&w1)[2], const v2f (&w2)[4]) {
-    v2f p1, q1, p2, q2;
-    const v2f b0 = w1[0], b1 = w1[1], c0 = w2[0], c1 = w2[1], c2 = w2[2], c3 = w2[3];
-    asm("s_nop 0\n\t" MXG_B2(x0, x1, a0, x2, x3, a0) MXG_B2(x4, x5, a0, x6, x7, a0) MXG_B2(x0, x2, b0, x1, x3, b1)
-            MXG_B2(x4, x6, b0, x5, x7, b1) MXG_B2(x0, x4, c0, x1, x5, c1) MXG_B2(x2, x6, c2, x3, x7, c3) "s_nop 0" MXG_ROUND_OPERANDS("v"));
+// (A round as ONE 60-instruction asm block -- 2 s_nop instead of 12 -- was measured against this form on the same device,
+// tools/ab_config4.sh: 1.393 / 1.389 / 1.398 ms against 1.387 / 1.378 / 1.402 ms for 1 M frames, no difference.)
+__device__ __forceinline__ void round3(v2f (&x)[8], const v2f w0, const v2f (&w1)[2], const v2f (&w2)[4]) {
+    bfly2(x[0], x[1], w0, x[2], x[3], w0);
+    bfly2(x[4], x[5], w0, x[6], x[7], w0);
+    bfly2(x[0], x[2], w1[0], x[1], x[3], w1[1]);
+    bfly2(x[4], x[6], w1[0], x[5], x[7], w1[1]);
+    bfly2(x[0], x[4], w2[0], x[1], x[5], w2[1]);
+    bfly2(x[2], x[6], w2[2], x[3], x[7], w2[3]);
 }
 // round 1 of K6a: the seven twiddles are the same for every lane (scalar registers)
 __device__ __forceinline__ void round3_s(v2f (&x)[8], const v2f (&w)[7]) {
-    v2f p1, q1, p2, q2;
-    const v2f a0 = w[0], b0 = w[1], b1 = w[2], c0 = w[3], c1 = w[4], c2 = w[5], c3 = w[6];
-    asm("s_nop 0\n\t" MXG_B2(x0, x1, a0, x2, x3, a0) MXG_B2(x4, x5, a0, x6, x7, a0) MXG_B2(x0, x2, b0, x1, x3, b1)
-            MXG_B2(x4, x6, b0, x5, x7, b1) MXG_B2(x0, x4, c0, x1, x5, c1) MXG_B2(x2, x6, c2, x3, x7, c3) "s_nop 0" MXG_ROUND_OPERANDS("s"));
+    bfly2_s(x[0], x[1], w[0], x[2], x[3], w[0]);
+    bfly2_s(x[4], x[5], w[0], x[6], x[7], w[0]);
+    bfly2_s(x[0], x[2], w[1], x[1], x[3], w[2]);
+    bfly2_s(x[4], x[6], w[1], x[5], x[7], w[2]);
+    bfly2_s(x[0], x[4], w[3], x[1], x[5], w[4]);
+    bfly2_s(x[2], x[6], w[5], x[3], x[7], w[6]);
 }
 // round 1 when w[0] and w[1] are exactly (1, 0) (mxg_fft_plan::round1Trivial): for finite k the product (1, 0) * k is k -- tr = 1*k.x -
 // 0*k.y, ti = 1*k.y + 0*k.x, the zero products only decide the SIGN OF A ZERO result -- so the six butterflies of stages 1 and 2
@@ -189,9 +176,9 @@ __device__ __forceinline__ void round3_s1(v2f (&x)[8], const v2f (&w)[7]) {
         x[e + 2] = x[e] - t;
         x[e] = x[e] + t;
     }
-    v2f p1, q1, p2, q2;
-    const v2f a0 = w[0], b0 = w[1], b1 = w[2], c0 = w[3], c1 = w[4], c2 = w[5], c3 = w[6];  // (a0, b0: operands of the list, unused)
-    asm("s_nop 0\n\t" MXG_B2(x1, x3, b1, x5, x7, b1) MXG_B2(x0, x4, c0, x1, x5, c1) MXG_B2(x2, x6, c2, x3, x7, c3) "s_nop 0" MXG_ROUND_OPERANDS("s"));
+    bfly2_s(x[1], x[3], w[2], x[5], x[7], w[2]);
+    bfly2_s(x[0], x[4], w[3], x[1], x[5], w[4]);
+    bfly2_s(x[2], x[6], w[5], x[3], x[7], w[6]);
 }
 __device__ __forceinline__ void round3(float2 (&x)[8], const float2 w0, const float2 (&w1)[2], const float2 (&w2)[4]) {
     v2f y[8];
