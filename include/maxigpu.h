@@ -614,6 +614,13 @@ int mxg_calib_fill(void *d_dst, size_t bytes, int width, void *stream);
  * workgroups so that every XCD owns one contiguous eighth of a row.  tools/write_ceiling.py, profiles/r03_write_ceiling.md. */
 int mxg_calib_fill_ex(void *d_dst, size_t rows, size_t row_bytes, int width, int flavour, int pattern, int block,
                       int blocks, int xcd, void *stream);
+/* The READ side: a pure load stream over `bytes` at d_src.  pattern 0 = grid-stride read; 1 = the fused FFT + MFCC kernel's input
+ * stream (persistent wavefronts, groups of 8 consecutive 4096-byte frames per wavefront, one frame ahead in flight) with everything
+ * but the loads removed (bytes a multiple of 32 768); width 8 or 16 bytes per lane; flavour 0 plain, 1 non-temporal; `blocks`
+ * workgroups of `block` threads; d_sink: 8 bytes that are never written in practice.  tools/read_ceiling.py,
+ * profiles/r03_read_ceiling.md. */
+int mxg_calib_read_ex(const void *d_src, size_t bytes, int width, int flavour, int pattern, int block, int blocks, void *d_sink,
+                      void *stream);
 
 #ifdef __cplusplus
 }

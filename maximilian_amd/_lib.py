@@ -141,6 +141,7 @@ SIGNATURES = {
     "mxg_i32_from_i64": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mxg_calib_fill": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
     "mxg_calib_fill_ex": (c_int, [c_void_p, c_size_t, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mxg_calib_read_ex": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 
 

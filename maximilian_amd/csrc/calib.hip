@@ -1,4 +1,4 @@
-// calib.hip -- measurement kernels for the HBM *write* ceiling of the box (no reference counterpart: they exist so that
+// calib.hip -- measurement kernels for the HBM *write* ceiling of the box (and, further down, the READ ceiling) (no reference counterpart: they exist so that
 // bench.py and profiles/r03_write_ceiling.md can quote the voice-bank render against what a pure store stream of the same
 // shape reaches on this GPU, next to the 8 TB/s spec).
 //
@@ -88,8 +88,88 @@ cols_fn pick_cols(int f) {
     }
 }
 
+// ---- the READ side (round 3): what a pure load stream reaches, for the fused FFT + MFCC kernel's 4 KB-per-frame input ----------
+//   pattern 0  grid-stride read of the flat region
+//   pattern 1  the fused kernel's stream: persistent wavefronts, a wavefront takes groups of 8 consecutive 4096-byte frames (group
+//              g0 + k * waves), a frame as 4096 / (64 * width) loads of `width` bytes per lane at 64 * width-byte spacing, the next
+//              frame's loads issued before this frame's values are consumed -- K67 with everything but the loads removed
+// width 8 or 16; flavour 0 plain, 1 non-temporal.  Every value is folded into a per-thread sum that is stored only if it hits an
+// impossible value, so the loads cannot be removed.
+template <int WIDTH, int FLAV>
+__device__ __forceinline__ double ld_sum(const char *p) {
+    if constexpr (WIDTH == 8) {
+        const double v = FLAV ? __builtin_nontemporal_load((const double *)p) : *(const double *)p;
+        return v;
+    } else {
+        const double2v v = FLAV ? __builtin_nontemporal_load((const double2v *)p) : *(const double2v *)p;
+        return v.x + v.y;
+    }
+}
+template <int WIDTH, int FLAV>
+__global__ void calib_read_flat(const char *src, size_t bytes, double *sink) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * WIDTH;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * WIDTH;
+    double acc = 0.0;
+#pragma unroll 8
+    for (; i + WIDTH <= bytes; i += stride) acc += ld_sum<WIDTH, FLAV>(src + i);
+    if (acc == 1.2345e300) sink[0] = acc;
+}
+template <int WIDTH, int FLAV>
+__global__ void calib_read_frames(const char *src, size_t nframes, double *sink) {
+    constexpr int L = 4096 / (64 * WIDTH);  // loads per lane and frame
+    const int lane = threadIdx.x & 63;
+    const size_t waves = (size_t)gridDim.x * (blockDim.x >> 6), w0 = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const size_t ngroups = nframes / 8;
+    double acc = 0.0, cur[L], nxt[L];
+    auto load = [&](size_t fr, double (&d)[L]) {
+        const char *x = src + (fr < nframes ? fr : nframes - 1) * 4096 + (size_t)lane * WIDTH;
+#pragma unroll
+        for (int e = 0; e < L; e++) d[e] = ld_sum<WIDTH, FLAV>(x + (size_t)e * 64 * WIDTH);
+    };
+    load(w0 * 8, nxt);
+    for (size_t g = w0; g < ngroups; g += waves) {
+#pragma unroll 1
+        for (int j = 0; j < 8; j++) {
+#pragma unroll
+            for (int e = 0; e < L; e++) cur[e] = nxt[e];
+            load(j + 1 < 8 ? g * 8 + j + 1 : (g + waves) * 8, nxt);
+#pragma unroll
+            for (int e = 0; e < L; e++) acc += cur[e];
+        }
+    }
+    if (acc == 1.2345e300) sink[0] = acc;
+}
+
 }  // namespace
 }  // namespace mxg
+
+extern "C" int mxg_calib_read_ex(const void *d_src, size_t bytes, int width, int flavour, int pattern, int block, int blocks,
+                                 void *d_sink, void *stream) {
+    using namespace mxg;
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(d_src && d_sink && (width == 8 || width == 16), "width is 8 or 16");
+    MXG_REQUIRE(flavour >= 0 && flavour <= 1 && pattern >= 0 && pattern <= 1, "unknown flavour / pattern");
+    MXG_REQUIRE(block >= 64 && block <= 1024 && (block & 63) == 0 && blocks > 0, "block is a multiple of 64 up to 1024, blocks > 0");
+    MXG_REQUIRE((((uintptr_t)d_src) & 15) == 0 && (pattern == 0 || bytes % 32768 == 0), "misaligned region / not whole groups of 8 frames");
+    if (bytes == 0) return MXG_OK;
+    hipStream_t st = resolve_stream(stream);
+    KernelTimer kt("calib_read", st);
+    const dim3 grid((unsigned)blocks), blk((unsigned)block);
+#define MXG_RD(K, ...)                                                                                    \
+    do {                                                                                                  \
+        if (width == 8) {                                                                                 \
+            if (flavour) hipLaunchKernelGGL((K<8, 1>), grid, blk, 0, st, __VA_ARGS__);                     \
+            else hipLaunchKernelGGL((K<8, 0>), grid, blk, 0, st, __VA_ARGS__);                             \
+        } else {                                                                                          \
+            if (flavour) hipLaunchKernelGGL((K<16, 1>), grid, blk, 0, st, __VA_ARGS__);                    \
+            else hipLaunchKernelGGL((K<16, 0>), grid, blk, 0, st, __VA_ARGS__);                            \
+        }                                                                                                 \
+    } while (0)
+    if (pattern == 0) MXG_RD(calib_read_flat, (const char *)d_src, bytes, (double *)d_sink);
+    else MXG_RD(calib_read_frames, (const char *)d_src, bytes / 4096, (double *)d_sink);
+#undef MXG_RD
+    return check_hip(hipGetLastError(), "calib_read_ex launch");
+}
 
 extern "C" int mxg_calib_fill_ex(void *d_dst, size_t rows, size_t row_bytes, int width, int flavour, int pattern, int block,
                                  int blocks, int xcd, void *stream) {

@@ -23,6 +23,13 @@
 // Magnitudes use exact_sqrtf (mxg_spectral.h): correctly rounded for every float, checked exhaustively on the device.
 #include "mxg_spectral.h"
 
+#ifndef MXG_ABLATE
+#define MXG_ABLATE 0  // timing experiments only (wrong results): 1 no mel / log / DCT phase, 2 no butterflies, 3 no transposes
+#endif
+#ifndef MXG_FUSED_SKEW
+#define MXG_FUSED_SKEW 1  // frame-by-frame phase order of the fused kernel's two frames in flight (0: both frames per phase; A/B)
+#endif
+
 namespace mxg {
 namespace {
 
@@ -495,6 +502,63 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
             const size_t fnext = j + NF < kGroup ? f0 + j + NF : (g + gstep) * kGroup;
 #pragma unroll
             for (int f = 0; f < NF; f++) load_frame(fnext + f, nx[f]);
+#if MXG_FUSED_SKEW
+            // Frame by frame inside a phase: a frame's butterflies, its transpose stores and the transpose READS are issued together,
+            // then the other frame's -- so a frame's LDS round trip flies while the other frame's 60 packed butterflies run, instead
+            // of both frames' reads being requested just before the first butterfly that needs them (the DS unit executes one
+            // wavefront's instructions in order: the write -> read sequence of a frame needs no wait, only the compiler fence).
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+#if MXG_ABLATE != 2
+                if constexpr (TOL)
+                    radix8_t(v[f], c8);
+                else if constexpr (MODE == 1)
+                    round3_s1(v[f], ta);
+                else
+                    round3_s(v[f], ta);
+#endif
+#if MXG_ABLATE != 3
+#pragma unroll
+                for (int e = 0; e < 8; e++) X[f][pad8(8 * lane + e)] = v[f][e];
+                wave_lds_sync();
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[f][e] = X[f][pad8(hi * 64 + e * 8 + lo)];
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+#if MXG_ABLATE != 2
+                if constexpr (TOL)
+                    round8_t(v[f], tb, c8);
+                else
+                    round3(v[f], tb[0], b1, b2);
+#endif
+                wave_lds_sync();
+#if MXG_ABLATE != 3
+#pragma unroll
+                for (int e = 0; e < 8; e++) X[f][pad8(hi * 64 + e * 8 + lo)] = v[f][e];
+                wave_lds_sync();
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[f][e] = X[f][pad8(e * 64 + lane)];
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+#if MXG_ABLATE != 2
+                if constexpr (TOL)
+                    round8_t(v[f], tc, c8);
+                else
+                    round3(v[f], tc[0], c1, c2);
+#endif
+                wave_lds_sync();
+#pragma unroll
+                for (int e = 0; e < 8; e++) X[f][pad8(e * 64 + lane)] = v[f][e];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wave_lds_sync();
+#else
 #pragma unroll
             for (int f = 0; f < NF; f++) {
                 if constexpr (TOL)
@@ -545,6 +609,7 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
 #pragma unroll
                 for (int e = 0; e < 8; e++) X[f][pad8(e * 64 + lane)] = v[f][e];
             wave_lds_sync();
+#endif
             if constexpr (!FULL) {
                 // low half of the post-pass: all the LDS reads are requested before the first is used
                 v2f pa[NF][4], pb[NF][4];
@@ -624,6 +689,11 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
             }
             wave_lds_sync();
         }
+#if MXG_ABLATE == 1
+        if (lane < kGroup * A.numCoeffs && f0 + lane / A.numCoeffs < nframes) A.mfcc[f0 * A.numCoeffs + lane] = (double)M[lane];
+        wave_lds_sync();
+        continue;
+#endif
         if constexpr (TOL) {
             // ---- tolerance mode: the same three phases in fp32 (mel_walk_t, v_log_f32, dct_dot_rows_f) ---------------------------
             float *s_melf = reinterpret_cast<float *>(s_mel);
