@@ -353,7 +353,15 @@ def main():
                 sig_h[0] = sig[:1024 * 262144].cpu().numpy()
             return _baseline(lambda o, n, th: o.time_spectral(sig_h[0][:n * 1024], threads=th), lambda n: n * 1024, (512, 262144),
                              "frames", "maxiFFT(1024,1024,1024)::process per sample + maxiMFCC(512,42,13)::mfcc per frame (mfcctest loop)")
-        W = dict(step=step, samples=NF * 1024, dtype="f32 (FFT) / f64 (MFCC)", cpu=cpu,
+        def read_ceiling():  # the kernel's own input stream with everything but the loads removed (csrc/calib.hip), same buffer
+            sink = torch.zeros(8, dtype=torch.float64, device=dev)
+            out = {}
+            for name, (w, fl, blk, blks) in {"8 B plain loads, 512 x 256 threads (the launch shape)": (8, 0, 256, 512),
+                                             "8 B non-temporal loads, 1024 x 512 threads": (8, 1, 512, 1024)}.items():
+                out[name] = time_steps(lambda: chk(L.mxg_calib_read_ex(sig.data_ptr(), NF * 4096, w, fl, 1, blk, blks, sink.data_ptr(),
+                                                                       stream), "calib_read"), 6, warm=3)
+            return out
+        W = dict(step=step, samples=NF * 1024, dtype="f32 (FFT) / f64 (MFCC)", cpu=cpu, read_ceiling=read_ceiling if fused_ok else None,
                  dominant="mfcc_mfma_gemm_kernel" if mfma else ("fft_mfcc_kernel" if fused_ok else "fft1024_kernel"),
                  algo_bytes=4200.0 * NF if fused_ok else 6144.0 * NF,
                  # MFMA flops ISSUED: 2 x K x 48 (42 filters padded to 3 column blocks of 16) per frame
@@ -498,6 +506,14 @@ def main():
 
     # ---- N = 1, config 2: what the headline is made of -----------------------------------------------------------------
     extras = {}
+    if world == 1 and W.get("read_ceiling") and not args.no_extras and hasattr(L, "mxg_calib_read_ex"):
+        rc = W["read_ceiling"]()
+        best = min(rc, key=rc.get)
+        nb_r = (1 << 20) * 4096
+        extras["read_ceiling"] = {"GB/s": round(nb_r / rc[best] / 1e6, 1), "pattern": best,
+                                  "all_GB/s": {k_: round(nb_r / v_ / 1e6, 1) for k_, v_ in rc.items()},
+                                  "note": "pure load streams of the fused kernel's shape (persistent wavefronts, groups of 8 consecutive 4 KB frames, "
+                                          "one frame ahead in flight) over this run's 4.3 GB signal; profiles/r03_read_ceiling.md has the full family"}
     if world == 1 and args.workload == "config2" and mixdown == "off" and not args.tune and not args.no_extras:
         nb = V * B * 8
         n_x = max(50, min(args.steps, 500))
@@ -569,6 +585,9 @@ def main():
             if "write_ceiling" in extras:
                 roof["write_ceiling"] = extras["write_ceiling"]
                 roof["frac_of_measured_write_ceiling"] = round(ach / extras["write_ceiling"]["GB/s"], 4)
+            if "read_ceiling" in extras:
+                roof["read_ceiling"] = extras["read_ceiling"]
+                roof["frac_of_measured_read_ceiling"] = round(ach / extras["read_ceiling"]["GB/s"], 4)
         if W.get("l2_bytes"):
             l2 = W["l2_bytes"] / dom_launches / (dom_ms * 1e-3) / 1e9
             roof["l2_gather_model"] = {"bytes_per_launch": round(W["l2_bytes"] / dom_launches), "achieved_GB/s": round(l2, 1), "l2_peak_GB/s": 34500.0,
