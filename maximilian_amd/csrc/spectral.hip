@@ -24,7 +24,10 @@
 #include "mxg_spectral.h"
 
 #ifndef MXG_ABLATE
-#define MXG_ABLATE 0  // timing experiments only (wrong results): 1 no mel / log / DCT phase, 2 no butterflies, 3 no transposes
+#define MXG_ABLATE 0  // timing experiments only (wrong results), bit mask: 1 no mel / log / DCT phase, 2 no butterflies, 4 no transposes, 8 no post-pass
+#endif
+#ifndef MXG_FUSED_NTLOAD
+#define MXG_FUSED_NTLOAD 1  // frame loads as non-temporal loads: every input byte is read once (same device: 1.315 -> 1.292 ms exact, 1.061 -> 1.043 ms tolerance mode)
 #endif
 #ifndef MXG_FUSED_SKEW
 #define MXG_FUSED_SKEW 1  // frame-by-frame phase order of the fused kernel's two frames in flight (0: both frames per phase; A/B)
@@ -423,7 +426,11 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             if constexpr (ALIGNED8) {
+#if MXG_FUSED_NTLOAD
+                dst[e] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(x + 128 * kRev3[e]));
+#else
                 dst[e] = *reinterpret_cast<const v2f *>(x + 128 * kRev3[e]);
+#endif
             } else {
                 dst[e].x = x[128 * kRev3[e]];
                 dst[e].y = x[128 * kRev3[e] + 1];
@@ -509,7 +516,7 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
             // wavefront's instructions in order: the write -> read sequence of a frame needs no wait, only the compiler fence).
 #pragma unroll
             for (int f = 0; f < NF; f++) {
-#if MXG_ABLATE != 2
+#if !(MXG_ABLATE & 2)
                 if constexpr (TOL)
                     radix8_t(v[f], c8);
                 else if constexpr (MODE == 1)
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
                 else
                     round3_s(v[f], ta);
 #endif
-#if MXG_ABLATE != 3
+#if !(MXG_ABLATE & 4)
 #pragma unroll
                 for (int e = 0; e < 8; e++) X[f][pad8(8 * lane + e)] = v[f][e];
                 wave_lds_sync();
@@ -528,14 +535,14 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
             }
 #pragma unroll
             for (int f = 0; f < NF; f++) {
-#if MXG_ABLATE != 2
+#if !(MXG_ABLATE & 2)
                 if constexpr (TOL)
                     round8_t(v[f], tb, c8);
                 else
                     round3(v[f], tb[0], b1, b2);
 #endif
                 wave_lds_sync();
-#if MXG_ABLATE != 3
+#if !(MXG_ABLATE & 4)
 #pragma unroll
                 for (int e = 0; e < 8; e++) X[f][pad8(hi * 64 + e * 8 + lo)] = v[f][e];
                 wave_lds_sync();
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
             }
 #pragma unroll
             for (int f = 0; f < NF; f++) {
-#if MXG_ABLATE != 2
+#if !(MXG_ABLATE & 2)
                 if constexpr (TOL)
                     round8_t(v[f], tc, c8);
                 else
@@ -627,12 +634,19 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
                     float *Mrow = M + (j + f) * A.mstride;
                     garbage[f] = false;
                     v2f sq[4];
+#if MXG_ABLATE & 8
+                    sq[0] = pa[f][0]; sq[1] = pa[f][1]; sq[2] = pb[f][2]; sq[3] = pb[f][3];
+                    if constexpr (false) {
+#else
                     if constexpr (TOL) {
+#endif
                         post_lo_sq2_t(pa[f][0], pb[f][0], pw[0], pa[f][1], pb[f][1], pw[1], sq[0], sq[1]);
                         post_lo_sq2_t(pa[f][2], pb[f][2], pw[2], pa[f][3], pb[f][3], pw[3], sq[2], sq[3]);
                     } else {
+#if !(MXG_ABLATE & 8)
                         post_lo_sq2(pa[f][0], pb[f][0], pw[0], pa[f][1], pb[f][1], pw[1], sq[0], sq[1]);
                         post_lo_sq2(pa[f][2], pb[f][2], pw[2], pa[f][3], pb[f][3], pw[3], sq[2], sq[3]);
+#endif
                     }
                     float m[4];
                     if constexpr (TOL) {
@@ -689,7 +703,7 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
             }
             wave_lds_sync();
         }
-#if MXG_ABLATE == 1
+#if MXG_ABLATE & 1
         if (lane < kGroup * A.numCoeffs && f0 + lane / A.numCoeffs < nframes) A.mfcc[f0 * A.numCoeffs + lane] = (double)M[lane];
         wave_lds_sync();
         continue;
