@@ -70,6 +70,10 @@ __device__ __forceinline__ double wrap_at_one(double phase) {
 // s_sine[i+1] == sineBuffer[i] (i=-1..513), s_trans[i] == transition[i] (i=0..1001); for sinewave / coswave s_sine is the
 // sin / cos table MXG_SINTAB of mxg_sincos.h instead.
 // TRUST (sinewave / coswave only): the caller has checked 0 <= inc <= 1 and 0 <= phase <= 2, which the recurrence then keeps.
+#ifndef MXG_SB4_PAIRS
+#define MXG_SB4_PAIRS 1  // sinebuf4's four table values as two aligned 16-byte LDS reads from a parity copy of the table
+#endif
+constexpr int kSineOddOff = 515;  // (odd and >= the table's 515 entries: element i of the second copy is 16-byte aligned for odd i; osc.hip asserts)
 template <int WF, bool TRUST = false>
 __device__ __forceinline__ double osc_tick(double &phase, double &hold, const OscPre &q,
                                            const double *s_sine, const double *s_trans) {
@@ -145,11 +149,23 @@ __device__ __forceinline__ double osc_tick(double &phase, double &hold, const Os
         if (phase >= 511) phase -= 512;
         double remainder = phase - floor(phase);
         int i = (int)phase;
+#if defined(__HIP_DEVICE_COMPILE__) && MXG_SB4_PAIRS
+        // a, b, c, d = s_sine[i .. i + 3]: two aligned 16-byte LDS reads from the copy of the table in which element i starts a
+        // 16-byte slot (even i: the table itself; odd i: the second copy, kSineOddOff elements on -- see load_tab) instead of four
+        // 8-byte ones; phase == 0 reads sineBuffer[512] for `a` (C:245-256; index -1 is the 0.0 guard s_sine[0])
+        typedef double pair2 __attribute__((ext_vector_type(2)));
+        const double *t = s_sine + i + (i & 1) * kSineOddOff;
+        const pair2 ab = *reinterpret_cast<const pair2 *>(t), cd = *reinterpret_cast<const pair2 *>(t + 2);
+        double a = ab.x;
+        if (__builtin_expect(phase == 0, 0)) a = s_sine[513];
+        const double b = ab.y, c = cd.x, d = cd.y;
+#else
         int ia = (phase == 0) ? 512 : i - 1;  // C:245-256; index -1 is the 0.0 guard
         double a = s_sine[ia + 1];
         double b = s_sine[i + 1];
         double c = s_sine[i + 1 + 1];
         double d = s_sine[i + 2 + 1];
+#endif
         double a1 = 0.5 * (c - a);
         double a2 = a - 2.5 * b + 2. * c - 0.5 * d;
         double a3 = 0.5 * (d - a) + 1.5 * (b - c);

@@ -35,16 +35,20 @@ constexpr bool uses_sine() {
     return WF == MXG_OSC_SINEBUF || WF == MXG_OSC_SINEBUF4;
 }
 // the table a waveform's tick reads from LDS: sineBuffer (sinebuf / sinebuf4), transition (sawn), sin / cos of k*pi/256 (sinewave / coswave)
+static_assert((kSineOddOff & 1) == 1 && kSineOddOff >= MAXI_SINE_TAB_LEN, "parity copy of the sine table");
 template <int WF>
 constexpr int tab_len() {
-    return uses_sine<WF>() ? MAXI_SINE_TAB_LEN
+    return (WF == MXG_OSC_SINEBUF4 && MXG_SB4_PAIRS) ? kSineOddOff + MAXI_SINE_TAB_LEN + 1 : uses_sine<WF>() ? MAXI_SINE_TAB_LEN
                            : (WF == MXG_OSC_SAWN ? MAXI_TRANS_TAB_LEN
                                                  : ((WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE) ? MXG_SINTAB_LEN : 1));
 }
 template <int WF>
 __device__ __forceinline__ void load_tab(double *s_tab) {  // (the caller synchronises)
     if constexpr (uses_sine<WF>()) {
-        for (int i = threadIdx.x; i < MAXI_SINE_TAB_LEN; i += blockDim.x) s_tab[i] = MAXI_SINE_TAB_D[i];
+        for (int i = threadIdx.x; i < MAXI_SINE_TAB_LEN; i += blockDim.x) {
+            s_tab[i] = MAXI_SINE_TAB_D[i];
+            if constexpr (WF == MXG_OSC_SINEBUF4 && MXG_SB4_PAIRS) s_tab[kSineOddOff + i] = MAXI_SINE_TAB_D[i];  // the parity copy (osc_tick)
+        }
     } else if constexpr (WF == MXG_OSC_SAWN) {
         for (int i = threadIdx.x; i < MAXI_TRANS_TAB_LEN; i += blockDim.x) s_tab[i] = MAXI_TRANS_TAB_D[i];
     } else if constexpr (WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE) {
