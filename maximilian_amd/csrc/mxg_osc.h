@@ -71,7 +71,8 @@ __device__ __forceinline__ double wrap_at_one(double phase) {
 // sin / cos table MXG_SINTAB of mxg_sincos.h instead.
 // TRUST (sinewave / coswave only): the caller has checked 0 <= inc <= 1 and 0 <= phase <= 2, which the recurrence then keeps.
 #ifndef MXG_SB4_PAIRS
-#define MXG_SB4_PAIRS 1  // sinebuf4's four table values as two aligned 16-byte LDS reads from a parity copy of the table
+#define MXG_SB4_PAIRS 0  // 1: sinebuf4's four table values as two aligned 16-byte LDS reads from a parity copy of the table (A/B: measured
+                        // SLOWER on the same device, 59.0 against 57.3 us for 65 536 x 512 -- the kernel is not bound by LDS cycles)
 #endif
 constexpr int kSineOddOff = 515;  // (odd and >= the table's 515 entries: element i of the second copy is 16-byte aligned for odd i; osc.hip asserts)
 template <int WF, bool TRUST = false>
