@@ -25,7 +25,8 @@ struct mxg_ifft_plan {
     float2 *d_tw;     // inverse-direction stage twiddles, same indexing as mxg_fft_plan::d_tw
 };
 
-struct mxg_fs_entry {  // one step of one slot of the 16-slot mel walk (16 bytes: one ds_read_b128)
+struct alignas(16) mxg_fs_entry {  // one step of one slot of the mel walk (16 bytes, 16-byte aligned: ONE ds_read_b128 -- as an
+                                    // 8-byte-aligned struct hipcc read it with ds_read2_b64, twice the LDS cycles)
     double w;
     int off, fid;
 };

@@ -189,40 +189,44 @@ __device__ __forceinline__ double dct_dot_rows(const double *d, const double *m,
 // magnitude one LDS gather; the loop is software-pipelined two batches deep (entries two batches ahead, gathers one) so no
 // LDS latency sits between the dependent fp64 adds.  `fs` points at the slot's column of a table with `steps` rows
 // (a multiple of 2 * kMelBatch) + two batches of padding rows.
+typedef int i4e __attribute__((ext_vector_type(4)));
 template <int SLOTS>
 __device__ __forceinline__ void mel_walk(const char *Mrow, double *melrow, const mxg_fs_entry *fs, const int steps) {
     double acc = 0.0;  // L/maxiMFCC.cpp:52
     // Two entry batches P, Q and their gathered magnitudes, used alternately (`steps` is a multiple of 2 * kMelBatch): while a
     // batch is consumed, the other batch's magnitudes are gathered and each consumed entry's registers are refilled with the
     // entry two batches on -- every LDS result has a whole batch of dependent fp64 adds to arrive, and no register is copied
-    // (as a rotating three-buffer pipeline hipcc spent 24 of 81 instructions per 8 steps on v_mov).
-    mxg_fs_entry P[kMelBatch], Q[kMelBatch];
+    // (as a rotating three-buffer pipeline hipcc spent 24 of 81 instructions per 8 steps on v_mov).  An entry is fetched as ONE
+    // 16-byte vector (x, y = the weight's bits, z = byte offset of the bin, w = 8 * (filter + 1) on a filter's last bin else 0):
+    // read member by member hipcc uses ds_read2_b64, twice the LDS cycles of ds_read_b128.
+    const i4e *tab = reinterpret_cast<const i4e *>(fs);
+    i4e P[kMelBatch], Q[kMelBatch];
     float xP[kMelBatch], xQ[kMelBatch];
 #pragma unroll
-    for (int i = 0; i < kMelBatch; i++) P[i] = fs[i * SLOTS];
+    for (int i = 0; i < kMelBatch; i++) P[i] = tab[i * SLOTS];
 #pragma unroll
-    for (int i = 0; i < kMelBatch; i++) Q[i] = fs[(kMelBatch + i) * SLOTS];
+    for (int i = 0; i < kMelBatch; i++) Q[i] = tab[(kMelBatch + i) * SLOTS];
 #pragma unroll
-    for (int i = 0; i < kMelBatch; i++) xP[i] = *reinterpret_cast<const float *>(Mrow + P[i].off);
-    auto consume = [&](const mxg_fs_entry &e, const float x) {
-        acc += (e.w * (double)x);  // L/maxiMFCC.cpp:57
-        if (e.fid) {  // the entry closes filter e.fid / 8 - 1: fid is the byte offset of the slot AFTER its band sum
-            *reinterpret_cast<double *>(reinterpret_cast<char *>(melrow) + e.fid - 8) = acc;
+    for (int i = 0; i < kMelBatch; i++) xP[i] = *reinterpret_cast<const float *>(Mrow + P[i].z);
+    auto consume = [&](const i4e &e, const float x) {
+        acc += (__hiloint2double(e.y, e.x) * (double)x);  // L/maxiMFCC.cpp:57
+        if (e.w) {  // the entry closes filter e.w / 8 - 1: the byte offset of the slot AFTER its band sum
+            *reinterpret_cast<double *>(reinterpret_cast<char *>(melrow) + e.w - 8) = acc;
             acc = 0.0;
         }
     };
     for (int t0 = 0; t0 < steps; t0 += 2 * kMelBatch) {
 #pragma unroll
         for (int i = 0; i < kMelBatch; i++) {
-            xQ[i] = *reinterpret_cast<const float *>(Mrow + Q[i].off);
+            xQ[i] = *reinterpret_cast<const float *>(Mrow + Q[i].z);
             consume(P[i], xP[i]);
-            P[i] = fs[(t0 + 2 * kMelBatch + i) * SLOTS];
+            P[i] = tab[(t0 + 2 * kMelBatch + i) * SLOTS];
         }
 #pragma unroll
         for (int i = 0; i < kMelBatch; i++) {
-            xP[i] = *reinterpret_cast<const float *>(Mrow + P[i].off);
+            xP[i] = *reinterpret_cast<const float *>(Mrow + P[i].z);
             consume(Q[i], xQ[i]);
-            Q[i] = fs[(t0 + 3 * kMelBatch + i) * SLOTS];
+            Q[i] = tab[(t0 + 3 * kMelBatch + i) * SLOTS];
         }
     }
 }
@@ -230,40 +234,44 @@ __device__ __forceinline__ void mel_walk(const char *Mrow, double *melrow, const
 // ---- tolerance mode: the mel / log / DCT stage in fp32 --------------------------------------------------------------------
 // (band sums of <= 40 terms and 42-term DCT sums in fp32 with FMAs: ~1e-6 relative on the sums, ~1e-5 absolute on a coefficient --
 // an order below the 1.3e-4 by which the reference's own transform misses the true one; stated with the mode's other tolerances)
-struct fs32_entry {  // the slot table re-staged for fp32: 16 bytes, one ds_read_b128
+struct alignas(16) fs32_entry {  // the slot table re-staged for fp32: 16 bytes, one ds_read_b128
     float w;
     int off, fid, pad;  // fid: 4 * (filter + 1) on the last bin of a filter, else 0
 };
+typedef int i4v __attribute__((ext_vector_type(4)));
 template <int SLOTS>
 __device__ __forceinline__ void mel_walk_t(const char *Mrow, float *melrow, const fs32_entry *fs, const int steps) {
     float acc = 0.0f;
-    fs32_entry P[kMelBatch], Q[kMelBatch];
+    // (an entry is fetched as ONE 16-byte vector: read member by member hipcc fetches the three used words with ds_read_b96,
+    // which takes twice the LDS cycles of ds_read_b128)
+    const i4v *tab = reinterpret_cast<const i4v *>(fs);
+    i4v P[kMelBatch], Q[kMelBatch];  // x = weight bits, y = byte offset of the bin, z = 4 * (filter + 1) on a filter's last bin else 0
     float xP[kMelBatch], xQ[kMelBatch];
 #pragma unroll
-    for (int i = 0; i < kMelBatch; i++) P[i] = fs[i * SLOTS];
+    for (int i = 0; i < kMelBatch; i++) P[i] = tab[i * SLOTS];
 #pragma unroll
-    for (int i = 0; i < kMelBatch; i++) Q[i] = fs[(kMelBatch + i) * SLOTS];
+    for (int i = 0; i < kMelBatch; i++) Q[i] = tab[(kMelBatch + i) * SLOTS];
 #pragma unroll
-    for (int i = 0; i < kMelBatch; i++) xP[i] = *reinterpret_cast<const float *>(Mrow + P[i].off);
-    auto consume = [&](const fs32_entry &e, const float x) {
-        acc = __builtin_fmaf(e.w, x, acc);
-        if (e.fid) {
-            *reinterpret_cast<float *>(reinterpret_cast<char *>(melrow) + e.fid - 4) = acc;
+    for (int i = 0; i < kMelBatch; i++) xP[i] = *reinterpret_cast<const float *>(Mrow + P[i].y);
+    auto consume = [&](const i4v &e, const float x) {
+        acc = __builtin_fmaf(__int_as_float(e.x), x, acc);
+        if (e.z) {
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(melrow) + e.z - 4) = acc;
             acc = 0.0f;
         }
     };
     for (int t0 = 0; t0 < steps; t0 += 2 * kMelBatch) {
 #pragma unroll
         for (int i = 0; i < kMelBatch; i++) {
-            xQ[i] = *reinterpret_cast<const float *>(Mrow + Q[i].off);
+            xQ[i] = *reinterpret_cast<const float *>(Mrow + Q[i].y);
             consume(P[i], xP[i]);
-            P[i] = fs[(t0 + 2 * kMelBatch + i) * SLOTS];
+            P[i] = tab[(t0 + 2 * kMelBatch + i) * SLOTS];
         }
 #pragma unroll
         for (int i = 0; i < kMelBatch; i++) {
-            xP[i] = *reinterpret_cast<const float *>(Mrow + P[i].off);
+            xP[i] = *reinterpret_cast<const float *>(Mrow + P[i].y);
             consume(Q[i], xQ[i]);
-            Q[i] = fs[(t0 + 3 * kMelBatch + i) * SLOTS];
+            Q[i] = tab[(t0 + 3 * kMelBatch + i) * SLOTS];
         }
     }
 }
@@ -324,7 +332,7 @@ struct FusedArgs {
 template <bool FULL, bool WRITE_MAGS, bool ALIGNED8, int MODE, int NF, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(const FusedArgs A) {
     constexpr bool TOL = MODE == 2;
-    extern __shared__ double s_dyn[];
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     // [fs (steps + 2 batches) * 8 entries][dct NF*NC f64, padded to 16 B] | per wave: XA (= band rows), XB, M
     mxg_fs_entry *s_fs = reinterpret_cast<mxg_fs_entry *>(s_dyn);
     const int fsRows = A.steps + 2 * kMelBatch;
@@ -793,7 +801,7 @@ struct Fused16Args {
 
 template <bool ALIGNED8>
 __global__ __launch_bounds__(64 * kWaves16) void fft_mfcc16_kernel(const Fused16Args A) {
-    extern __shared__ double s_dyn[];
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     // [tw 512 float2][fs (steps + 2 batches) * 16 entries][dct NF*NC f64, padded to 16 B] | per wave: X (= band rows), M
     float2 *s_tw = reinterpret_cast<float2 *>(s_dyn);
     mxg_fs_entry *s_fs = reinterpret_cast<mxg_fs_entry *>(s_tw + 512);
