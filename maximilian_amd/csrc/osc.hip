@@ -492,15 +492,23 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     if (vpl == 1 && store >= 2 && !pairs_ok) store = store == 4 ? 1 : 0;  // pair rows need whole pairs
     osc_fn fn = pick_wf(waveform, fps != 0, vpl, store);
     size_t lanes = (V + vpl - 1) / vpl;
-    // time parts: only where the output dominates the recurrence (sinewave, coswave, sinebuf4) and the bank is too small to give
-    // every SIMD two wavefronts by itself
+    // time parts.  (a) Where the output dominates the recurrence (sinewave, coswave, sinebuf4) and the bank is too small to give every
+    // SIMD two wavefronts by itself: two parts.  (b) SMALL banks (fewer wavefronts than the 1024 SIMDs) of the waveforms whose phase
+    // skip is much cheaper than their tick (the table oscillators: sinebuf, sinebuf4, sawn, sinewave, coswave): a block is one chain of
+    // N dependent steps per wavefront, 27-30 us for 512 samples however few voices there are; cut into up to eight parts it is 14.6 us
+    // at 1024 voices, 17.0 at 4096, 20.1 at 16 384 (sinebuf; profiles/r03_small_osc_banks.md).  Same bits (the skip is the same
+    // additions); the other waveforms' tick IS their recurrence, parts would only repeat it.
     int split = tune_get("osc_split");
     if (split == 0) {
         split = 1;
-        if (!fps && (waveform == MXG_OSC_SINEWAVE || waveform == MXG_OSC_COSWAVE || waveform == MXG_OSC_SINEBUF4)) {  // (sinebuf4: four
-            // table reads and a cubic per sample at one wavefront per SIMD: 62 us whole, 55-56 in two parts)
-            const size_t waves = (lanes + 63) / 64;
-            split = waves >= 2048 ? 1 : 2;  // (with the table routine two parts are best at 65 536 voices: 60-62 us; one part 65-69, four 64)
+        const size_t waves = (lanes + 63) / 64;
+        const bool heavy = waveform == MXG_OSC_SINEWAVE || waveform == MXG_OSC_COSWAVE || waveform == MXG_OSC_SINEBUF4;
+        const bool table = heavy || waveform == MXG_OSC_SINEBUF || waveform == MXG_OSC_SAWN;
+        if (!fps && heavy) split = waves >= 2048 ? 1 : 2;  // (sinewave at 65 536 voices: 60-62 us in two parts; one part 65-69, four 64)
+        if (!fps && table && waves < 1024) {
+            int want = 1;
+            while (want < 8 && (size_t)(2 * want) * waves <= 1024) want *= 2;
+            if (want > split) split = want;
         }
     }
     if (fps) split = 1;
@@ -543,8 +551,16 @@ extern "C" int mxg_osc_render_mix(int waveform, size_t V, size_t N, const double
             store = (pairs_ok && var == 0 && (knob == 2 || (knob == 0 && V * N * sizeof(double) >= ((size_t)32 << 20)))) ? 2 : 1;
         }
         int split = tune_get("osc_mix_split");
-        if (split == 0) split = 1;  // (measured, MI355X 65 536 x 512 rotated: 1 part 51.1 us, 2 parts 53.6, 3 parts 54.8 -- the lane folds' permlane
-        // swaps do not overlap across wavefronts; the knob stays for other shapes)
+        if (split == 0) {
+            split = 1;  // (measured, MI355X 65 536 x 512 rotated: 1 part 51.1 us, 2 parts 53.6, 3 parts 54.8 -- the lane folds' permlane swaps do
+            // not overlap across wavefronts).  SMALL banks of the table oscillators are another matter, as in mxg_osc_render: fewer
+            // wavefronts than SIMDs, one chain of N dependent steps each -- up to eight parts
+            const bool table = waveform == MXG_OSC_SINEWAVE || waveform == MXG_OSC_COSWAVE || waveform == MXG_OSC_SINEBUF4 ||
+                               waveform == MXG_OSC_SINEBUF || waveform == MXG_OSC_SAWN;
+            const size_t waves = nblocks * 4;
+            if (table && waves < 1024)
+                while (split < 8 && (size_t)(2 * split) * waves <= 1024) split *= 2;
+        }
         if (var != 0) split = 1;
         while (split > 1 && (size_t)(split - 1) * (((N + split - 1) / split + kMixChunk - 1) / kMixChunk * kMixChunk) >= N) split--;
         PartSync psync;

@@ -39,7 +39,7 @@ Tune g_tune[] = {
     {"voice_xcd", 0, 0, 2},    // 0 automatic, 1 natural workgroup order, 2 XCD-contiguous
     {"osc_store", 0, 0, 5},  // K1 store stream (osc.hip pick<WF>): 0 automatic; one voice per lane: 1 plain 8 B, 2 nt 8 B, 3 / 4 / 5 pair rows (16 B) plain / sc1 / nt; two voices per lane: 1 plain, 2 nt, 3 sc1
     {"osc_xcd", 0, 0, 2},  // K1: 1 = every XCD renders one contiguous eighth of the bank (workgroup renumbering, mxg_common.h)
-    {"osc_split", 0, 0, 8},  // K1: time parts per voice group (0 = automatic: 4 for sinewave / coswave on small banks, else 1)
+    {"osc_split", 0, 0, 8},  // K1: time parts per voice group (0 = automatic: 2 for sinewave / coswave / sinebuf4 below 131 072 voices; up to 8 for the table oscillators on banks smaller than the machine; else 1)
     {"osc_mix_store", 0, 0, 2},  // K1m per-voice block: 0 automatic, 1 plain 8-byte stores, 2 pair rows of write-through 16-byte stores
     {"osc_mix_split", 0, 0, 4},  // K1m time parts (0 automatic: two below 2048 wavefronts)
     {"osc_mix_var", 0, 0, 4},  // K1m A/B: 0 swap butterfly; 1 same, window 128; 2 DPP butterfly 128; 3 DPP 512 (1-3: sinebuf only); 4 cross-row sums on the matrix pipe
