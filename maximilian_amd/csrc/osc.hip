@@ -507,7 +507,7 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
         if (!fps && heavy) split = waves >= 2048 ? 1 : 2;  // (sinewave at 65 536 voices: 60-62 us in two parts; one part 65-69, four 64)
         if (!fps && table && waves < 1024) {
             int want = 1;
-            while (want < 8 && (size_t)(2 * want) * waves <= 1024) want *= 2;
+            while (want < 8 && (size_t)(2 * want) * waves <= 1024 && (size_t)(2 * want) * 64 <= N) want *= 2;  // (a part renders >= 64 samples)
             if (want > split) split = want;
         }
     }
@@ -559,7 +559,7 @@ extern "C" int mxg_osc_render_mix(int waveform, size_t V, size_t N, const double
                                waveform == MXG_OSC_SINEBUF || waveform == MXG_OSC_SAWN;
             const size_t waves = nblocks * 4;
             if (table && waves < 1024)
-                while (split < 8 && (size_t)(2 * split) * waves <= 1024) split *= 2;
+                while (split < 8 && (size_t)(2 * split) * waves <= 1024 && (size_t)(2 * split) * 64 <= N) split *= 2;  // (a part renders >= 64 samples)
         }
         if (var != 0) split = 1;
         while (split > 1 && (size_t)(split - 1) * (((N + split - 1) / split + kMixChunk - 1) / kMixChunk * kMixChunk) >= N) split--;
