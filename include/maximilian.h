@@ -94,15 +94,103 @@ struct Call {  // one per-sample call: which method, with which arguments (compa
     bool same(const Call &o) const { return method == o.method && key == o.key && !std::memcmp(a, o.a, sizeof(a)); }
 };
 
+// ---- derived arguments ------------------------------------------------------------------------------------------------------
+// "The same arguments as the last call" cannot predict an argument that is itself a signal: `VCF.lores((VCO1out+VCO2out)*0.5, ...)`,
+// `mySine.sinewave(440+(myOtherSine.sinewave(1)*100))`.  But such an argument is a small expression of what OTHER objects returned a
+// moment ago, and those objects' next outputs are already sitting in their cached blocks.  When an argument stops matching, the pool
+// looks for a form  x | x*a | x+b | x*a+b | (x+b)*a | ((x+b)*a)+c | x1+x2 | (x1+x2)*a | x1*x2  over the most recent outputs that
+// reproduces it BIT FOR BIT (constants fitted from two observations and rounded to short decimals); a form that has reproduced three
+// consecutive calls is used to fill a per-sample argument array for the consumer's next block from the producers' cached blocks.
+// Nothing is trusted: every real call is still compared bit for bit with the predicted argument of its sample, a mismatch rewinds
+// the object exactly as a changed constant does.  No signal arithmetic happens here -- the expression is only evaluated to GUESS the
+// number the patch's own C++ is about to compute.  (Environment MXG_PS_DERIVE=0 turns the guessing off.)
+struct Hyp {
+    int k = -1, form = 0;     // argument index; 1 x  2 x*a  3 x+b  4 x*a+b  5 (x+b)*a  6 x1+x2  7 (x1+x2)*a  8 x1*x2  9 ((x+b)*a)+c
+    uint64_t s1 = 0, s2 = 0;  // producer slot ids
+    int64_t d1 = 0, d2 = 0;   // producer call ordinal = consumer call ordinal + d
+    double a = 0, b = 0, c = 0;
+    int streak = 0;           // consecutive calls reproduced
+};
+
 struct Slot {
-    Call sig;                      // the prediction the cached block was rendered under
+    Call sig;                      // the prediction the cached block was rendered under (its first sample, where arguments are derived)
     std::vector<double> blk;       // cached outputs
     size_t pos = 0, len = 0;       // blk[pos .. len) not yet served
     size_t nextLen = 1;
     std::vector<double> sd, ed;    // state (doubles) at the block's first sample / after its last
     std::vector<int64_t> si, ei;
     int group = -1;                // index of the asynchronous next-block render this slot is part of
+    // derived arguments
+    uint64_t id = 0, count = 0;    // count = calls served so far = the ordinal of the next call
+    uint64_t lastTick = 0;
+    double lastOut = 0, prevOut = 0;  // outputs of calls count - 1, count - 2
+    int nOut = 0;                  // how many of them exist (0, 1, 2)
+    std::vector<Hyp> hyps;
+    std::vector<std::vector<double>> dv;  // dv[k]: per-sample value of argument k over the cached block (empty: the constant sig.a[k])
+    double lastArg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool hasLastArg = false;
 };
+
+inline uint64_t &ps_tick() { static uint64_t t = 0; return t; }
+inline std::vector<Slot *> &ps_live() { static std::vector<Slot *> *v = new std::vector<Slot *>; return *v; }  // (never destroyed: see pool())
+inline Slot *ps_slot(uint64_t id) {
+    for (Slot *s : ps_live())
+        if (s->id == id) return s;
+    return nullptr;
+}
+inline bool ps_derive_on() {
+    static const bool on = [] { const char *e = std::getenv("MXG_PS_DERIVE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+inline bool ps_same_bits(double x, double y) { return !std::memcmp(&x, &y, sizeof(double)); }
+// what slot X returned (or is predicted to return) at call ordinal `ord`
+inline bool ps_out_at(const Slot &X, uint64_t ord, double &v) {
+    const uint64_t base = X.count - X.pos;  // ordinal of blk[0]
+    if (X.len > 0 && ord >= base && ord < base + X.len) { v = X.blk[(size_t)(ord - base)]; return true; }
+    if (X.nOut >= 1 && ord + 1 == X.count) { v = X.lastOut; return true; }
+    if (X.nOut >= 2 && ord + 2 == X.count) { v = X.prevOut; return true; }
+    return false;
+}
+inline uint64_t ps_last_ord(const Slot &X) {  // the last ordinal ps_out_at can answer (valid when X.count > 0 or a block is cached)
+    const uint64_t base = X.count - X.pos;
+    return X.len > 0 ? base + X.len - 1 : X.count - 1;
+}
+inline double ps_nice(double x) {  // the shortest decimal within a few ulps: patch constants are literals like 440, 0.5, 10000
+    if (!(x == x) || x == 0.0 || std::isinf(x)) return x;
+    for (int digits = 3; digits <= 15; digits += 3) {
+        char buf[40];
+        std::snprintf(buf, sizeof buf, "%.*g", digits, x);
+        const double y = std::strtod(buf, nullptr);
+        if (std::fabs(y - x) <= 8.0 * DBL_EPSILON * std::fabs(x)) return y;
+    }
+    return x;
+}
+inline double ps_eval(const Hyp &h, double x1, double x2) {  // (statement by statement: the roundings of the patch's own expression)
+    double t;
+    switch (h.form) {
+        case 1: return x1;
+        case 2: t = x1 * h.a; return t;
+        case 3: t = x1 + h.b; return t;
+        case 4: t = x1 * h.a; t = t + h.b; return t;
+        case 5: t = x1 + h.b; t = t * h.a; return t;
+        case 6: t = x1 + x2; return t;
+        case 7: t = x1 + x2; t = t * h.a; return t;
+        case 8: t = x1 * x2; return t;
+        case 9: t = x1 + h.b; t = t * h.a; t = t + h.c; return t;
+    }
+    return 0.0;
+}
+inline bool ps_predict(const Hyp &h, uint64_t ord, double &v) {
+    const Slot *X1 = ps_slot(h.s1);
+    double x1 = 0, x2 = 0;
+    if (!X1 || !ps_out_at(*X1, (uint64_t)((int64_t)ord + h.d1), x1)) return false;
+    if (h.form == 6 || h.form == 7 || h.form == 8) {
+        const Slot *X2 = ps_slot(h.s2);
+        if (!X2 || !ps_out_at(*X2, (uint64_t)((int64_t)ord + h.d2), x2)) return false;
+    }
+    v = ps_eval(h, x1, x2);
+    return true;
+}
 
 // One render of L samples for a set of slots, kept alive so the next block can continue on the device.
 struct Group {
@@ -118,6 +206,22 @@ struct Group {
     PinBuf<int64_t> h_istate;
     PinBuf<unsigned char> h_stage;  // pinned staging of one enqueue's parameter uploads (asynchronous copies: no host wait per array)
     size_t stage_off = 0;
+    std::vector<std::vector<std::vector<double>>> dv;  // [member][argument][sample]: derived arguments of this render (empty: constant)
+    double arg(size_t j, int k, size_t t) const {       // argument k of member j at sample t of the block
+        if (j < dv.size() && (size_t)k < dv[j].size() && !dv[j][(size_t)k].empty()) return dv[j][(size_t)k][t];
+        return sig[j].a[k];
+    }
+    bool varies(int k) const {
+        for (const auto &m : dv)
+            if ((size_t)k < m.size() && !m[(size_t)k].empty()) return true;
+        return false;
+    }
+    bool any_derived() const {
+        for (const auto &m : dv)
+            for (const auto &a : m)
+                if (!a.empty()) return true;
+        return false;
+    }
     ~Group() { if (event) mxg_event_destroy(event); }
 };
 
@@ -134,10 +238,15 @@ public:
         s.si.assign(nI, 0);
         s.ei.assign(nI, 0);
         slots.push_back(&s);
+        static uint64_t next_id = 0;
+        s.id = ++next_id;
+        ps_live().push_back(&s);
     }
     void detach(Slot &s) {
         leave_group(s);
         slots.erase(std::remove(slots.begin(), slots.end(), &s), slots.end());
+        auto &live = ps_live();
+        live.erase(std::remove(live.begin(), live.end(), &s), live.end());  // (forms that name it stop evaluating: ps_slot fails)
     }
     // the object's state at its current sample, cached block dropped (before the host edits or reads state)
     void settle(Slot &s) {
@@ -151,6 +260,7 @@ public:
         s.pos = s.len = 0;
         s.nextLen = 1;
         s.sig.method = -1;
+        s.dv.clear();
     }
     // forget the cached block WITHOUT computing the state at the current sample (the object is going away, or its state is about
     // to be overwritten anyway): no launch -- in particular none from a destructor that runs during static destruction
@@ -159,12 +269,156 @@ public:
         s.pos = s.len = 0;
         s.nextLen = 1;
         s.sig.method = -1;
+        s.dv.clear();
     }
     double call(Slot &s, const Call &c) {
-        if (s.pos < s.len && s.sig.same(c)) return s.blk[s.pos++];
-        return miss(s, c);
+        const double r = (s.pos < s.len && matches(s, c)) ? s.blk[s.pos++] : miss(s, c);
+        s.prevOut = s.lastOut;
+        s.lastOut = r;
+        if (s.nOut < 2) s.nOut++;
+        s.count++;
+        s.lastTick = ++ps_tick();
+        return r;
     }
-    size_t launches = 0, async_hits = 0;  // statistics (tests)
+    size_t launches = 0, async_hits = 0, derived_blocks = 0;  // statistics (tests)
+
+protected:
+    // bit mask of the argument indices of `method` that may be DERIVED (predicted per sample from other objects' outputs): the ones
+    // this pool's enqueue() reads through Group::arg(j, k, t)
+    virtual unsigned derivable(int /*method*/) const { return 0; }
+
+private:
+    // the cached block was rendered for exactly this call at its current sample
+    static bool matches(const Slot &s, const Call &c) {
+        if (s.dv.empty()) return s.sig.same(c);
+        if (c.method != s.sig.method || c.key != s.sig.key) return false;
+        for (size_t k = 0; k < 10; k++) {
+            const double want = (k < s.dv.size() && !s.dv[k].empty()) ? s.dv[k][s.pos] : s.sig.a[k];
+            if (!ps_same_bits(want, c.a[k])) return false;
+        }
+        return true;
+    }
+    // ---- learning the forms (called on a miss, before the call is served: its ordinal is s.count) ----------------------------------
+    void learn(Slot &s, const Call &c) {
+        const unsigned mask = ps_derive_on() ? derivable(c.method) : 0u;
+        const uint64_t o = s.count;
+        for (int k = 0; k < 10; k++) {
+            if (!(mask >> k & 1u)) continue;
+            const double v = c.a[k];
+            bool have = false;
+            for (size_t i = 0; i < s.hyps.size();) {  // forms on trial and forms in use: reproduce this call or go
+                Hyp &h = s.hyps[i];
+                if (h.k != k) { i++; continue; }
+                double pv;
+                if (ps_predict(h, o, pv) && ps_same_bits(pv, v)) {
+                    h.streak++;
+                    have = true;
+                    i++;
+                } else {
+                    s.hyps.erase(s.hyps.begin() + (long)i);
+                }
+            }
+            if (!have && s.hasLastArg && !ps_same_bits(v, s.lastArg[k])) propose(s, k, o, v);
+        }
+        // forms of arguments that are not derivable for this method (the object switched methods): drop
+        for (size_t i = 0; i < s.hyps.size();)
+            if (!(mask >> s.hyps[i].k & 1u)) s.hyps.erase(s.hyps.begin() + (long)i); else i++;
+        std::memcpy(s.lastArg, c.a, sizeof(s.lastArg));
+        s.hasLastArg = true;
+    }
+    void propose(Slot &s, int k, uint64_t o, double v) {
+        // the objects that returned a value most recently (this sample's graph evaluation), newest first
+        std::vector<Slot *> recent;
+        for (Slot *X : ps_live())
+            if (X != &s && X->nOut >= 1 && ps_tick() - X->lastTick < 64) recent.push_back(X);
+        std::sort(recent.begin(), recent.end(), [](const Slot *p, const Slot *q) { return p->lastTick > q->lastTick; });
+        if (recent.size() > 6) recent.resize(6);
+        const double vp = s.lastArg[k];  // the argument one call ago (s.hasLastArg)
+        size_t added = 0;
+        auto push = [&](Hyp h) {
+            if (added >= 8) return;
+            h.k = k;
+            h.streak = 1;
+            s.hyps.push_back(h);
+            added++;
+        };
+        for (Slot *X : recent) {
+            const double x = X->lastOut;
+            Hyp h;
+            h.s1 = X->id;
+            h.d1 = (int64_t)(X->count - 1) - (int64_t)o;
+            if (ps_same_bits(x, v)) { h.form = 1; push(h); continue; }
+            double xp;
+            if (!(o >= 1 && ps_out_at(*X, (uint64_t)((int64_t)(o - 1) + h.d1), xp)) || xp == x) continue;
+            auto fits = [&](const Hyp &t) { return ps_same_bits(ps_eval(t, x, 0), v) && ps_same_bits(ps_eval(t, xp, 0), vp); };
+            if (x != 0.0) { h.form = 2; h.a = ps_nice(v / x); if (fits(h)) { push(h); continue; } }
+            h.form = 3; h.b = ps_nice(v - x); if (fits(h)) { push(h); continue; }
+            const double slope = ps_nice((v - vp) / (x - xp));
+            if (slope == slope && slope != 0.0 && !std::isinf(slope)) {
+                h.a = slope;
+                h.form = 4; h.b = ps_nice(v - x * slope); if (fits(h)) { push(h); continue; }
+                h.form = 5; h.b = ps_nice(v / slope - x); if (fits(h)) { push(h); continue; }
+                h.form = 9;  // ((x + b) * a) + c with a small integer b (15.polysynth: 250 + ((pitch + lfo) * 1000))
+                bool found = false;
+                for (int b = -12; b <= 12 && !found; b++) {
+                    if (b == 0) continue;
+                    h.b = (double)b;
+                    h.c = ps_nice(v - (x + h.b) * slope);
+                    if (fits(h)) { push(h); found = true; }
+                }
+            }
+        }
+        // two sources: the sum or the product of two recent outputs, optionally scaled
+        for (size_t i = 0; i < recent.size() && i < 4; i++)
+            for (size_t j = i + 1; j < recent.size() && j < 4; j++) {
+                Slot *X1 = recent[i], *X2 = recent[j];
+                Hyp h;
+                h.s1 = X1->id; h.d1 = (int64_t)(X1->count - 1) - (int64_t)o;
+                h.s2 = X2->id; h.d2 = (int64_t)(X2->count - 1) - (int64_t)o;
+                const double x1 = X1->lastOut, x2 = X2->lastOut;
+                h.form = 6; if (ps_same_bits(ps_eval(h, x1, x2), v)) { push(h); continue; }
+                h.form = 8; if (ps_same_bits(ps_eval(h, x1, x2), v)) { push(h); continue; }
+                if (x1 + x2 != 0.0) {
+                    h.form = 7; h.a = ps_nice(v / (x1 + x2));
+                    if (ps_same_bits(ps_eval(h, x1, x2), v)) push(h);
+                }
+            }
+    }
+    // the forms in use for the block that starts at ordinal o: per derivable argument the longest-standing one that has reproduced
+    // three calls in a row; `span` = how many samples from o on every one of them can be evaluated
+    bool derive_for(const Slot &s, unsigned mask, uint64_t o, std::vector<const Hyp *> &use, size_t &span) const {
+        use.assign(10, nullptr);
+        span = kMaxBlock;
+        bool any = false;
+        for (const Hyp &h : s.hyps) {
+            if (h.streak < 3 || !(mask >> h.k & 1u)) continue;
+            if (use[(size_t)h.k] && use[(size_t)h.k]->streak >= h.streak) continue;
+            use[(size_t)h.k] = &h;
+        }
+        for (int k = 0; k < 10; k++) {
+            const Hyp *h = use[(size_t)k];
+            if (!h) continue;
+            const Slot *X1 = ps_slot(h->s1), *X2 = (h->form >= 6 && h->form <= 8) ? ps_slot(h->s2) : nullptr;
+            if (!X1 || ((h->form >= 6 && h->form <= 8) && !X2)) { use[(size_t)k] = nullptr; continue; }
+            auto room = [&](const Slot &X, int64_t d) -> int64_t { return (int64_t)ps_last_ord(X) - ((int64_t)o + d) + 1; };
+            int64_t r = room(*X1, h->d1);
+            if (X2) r = std::min(r, room(*X2, h->d2));
+            if (r < 1) { use[(size_t)k] = nullptr; continue; }
+            span = std::min(span, (size_t)r);
+            any = true;
+        }
+        return any;
+    }
+    static void fill_derived(const std::vector<const Hyp *> &use, uint64_t o, size_t L, std::vector<std::vector<double>> &dv) {
+        dv.assign(10, std::vector<double>());
+        for (int k = 0; k < 10; k++) {
+            if (!use[(size_t)k]) continue;
+            dv[(size_t)k].resize(L);
+            for (size_t t = 0; t < L; t++) ps_predict(*use[(size_t)k], o + t, dv[(size_t)k][t]);
+        }
+    }
+
+public:
 
 protected:
     // Enqueue on `stream` the render of G.L samples for G.m under G.sig, starting from the state in G.d_state /
@@ -261,6 +515,10 @@ private:
             u->len = L;
             u->sig = G.sig[j];
             u->nextLen = L;
+            if (j < G.dv.size()) u->dv = G.dv[j]; else u->dv.clear();
+            bool any = false;
+            for (const auto &a : u->dv) any = any || !a.empty();
+            if (!any) u->dv.clear();
         }
     }
     // the block after the one just installed, rendered while that one is served
@@ -279,6 +537,7 @@ private:
         Group &G = free_group();
         G.m.assign(1, &s);
         G.sig.assign(1, s.sig);
+        G.dv.assign(1, s.dv);  // the same (verified) derived arguments for the samples re-run
         G.L = count;
         const std::vector<double> keep_ed = s.ed;
         render_now(G);
@@ -314,6 +573,9 @@ private:
             return s.blk[s.pos++];
         }
         leave_group(s);
+        learn(s, c);
+        const unsigned mask = ps_derive_on() ? derivable(c.method) : 0u;
+        const bool was_derived = !s.dv.empty();
         size_t L;
         if (!consumed) {  // the prediction failed inside a block: back to the state at this sample
             if (s.pos > 0) advance(s, s.pos);
@@ -323,25 +585,58 @@ private:
                 s.sd = s.ed;
                 s.si = s.ei;
             }
-            L = (s.len > 0 && s.sig.same(c)) ? std::min(2 * s.nextLen, kMaxBlock) : 1;
+            L = (s.len > 0 && (s.sig.same(c) || was_derived)) ? std::min(2 * s.nextLen, kMaxBlock) : 1;
+        }
+        // derived arguments for the new block, as far as the producers' cached blocks reach
+        std::vector<const Hyp *> use;
+        size_t span = 0;
+        std::vector<std::vector<double>> dv0;
+        const bool derived = mask && derive_for(s, mask, s.count, use, span);
+        if (derived) {
+            if (consumed && L < 2) L = 2;  // the forms have just reproduced three calls: start growing
+            L = std::min(L, span);
+            fill_derived(use, s.count, L, dv0);
+            derived_blocks++;
+        } else if (was_derived && !s.sig.same(c)) {
+            L = 1;
         }
         s.pos = s.len = 0;
+        s.dv.clear();
         Group &G = free_group();
         G.m.assign(1, &s);
         G.sig.assign(1, c);
+        G.dv.assign(1, dv0);
         G.L = L;
         // objects called in lock-step with this one: same method, also at the end of their block, same growth
         for (Slot *u : slots) {
             if (u == &s || u->group >= 0 || u->len == 0 || u->pos < u->len) continue;
             if (u->sig.method != c.method || u->sig.key != c.key) continue;
+            if (!u->dv.empty() || !u->hyps.empty()) {  // a member with derived arguments: its own forms, evaluated at ITS next ordinal
+                std::vector<const Hyp *> uu;
+                size_t uspan = 0;
+                if (!derive_for(*u, mask, u->count, uu, uspan)) continue;
+                if (std::min(std::max<size_t>(std::min(2 * u->nextLen, kMaxBlock), 2), uspan) != L) continue;
+                std::vector<std::vector<double>> udv;
+                fill_derived(uu, u->count, L, udv);
+                Call uc = u->sig;
+                for (size_t k = 0; k < 10; k++)
+                    if (!udv[k].empty()) uc.a[k] = udv[k][0];
+                u->sd = u->ed;
+                u->si = u->ei;
+                G.m.push_back(u);
+                G.sig.push_back(uc);
+                G.dv.push_back(udv);
+                continue;
+            }
             if (std::min(2 * u->nextLen, kMaxBlock) != L) continue;
             u->sd = u->ed;
             u->si = u->ei;
             G.m.push_back(u);
             G.sig.push_back(u->sig);
+            G.dv.push_back(std::vector<std::vector<double>>());
         }
         render_now(G);
-        if (L == kMaxBlock) prefetch(G);
+        if (L == kMaxBlock && !G.any_derived()) prefetch(G);
         return s.blk[s.pos++];
     }
 };
@@ -355,6 +650,7 @@ P &pool() {
 // ---- the pools -------------------------------------------------------------------------------------------
 struct OscPool : Pool {  // state: phase, output (H:173,176)
     OscPool() : Pool(2, 0) {}
+    unsigned derivable(int method) const override { return method == 12 ? 0u : 1u; }  // the frequency (not noise()'s rand() draw)
     void enqueue(Group &G) override {
         const size_t n = G.m.size();
         const int wf = G.sig[0].method;
@@ -362,8 +658,18 @@ struct OscPool : Pool {  // state: phase, output (H:173,176)
         for (size_t j = 0; j < n; j++)
             for (int k = 0; k < 3; k++) hp[(size_t)k * n + j] = G.sig[j].a[k];
         double *dp = G.d_par.need(3 * n);
-        stage_begin(G, sizeof(double) * 3 * n + sizeof(int32_t) * G.L * n);
+        stage_begin(G, sizeof(double) * 3 * n + (sizeof(int32_t) + sizeof(double)) * G.L * n + 64);
         put(G, dp, hp.data(), sizeof(double) * 3 * n, "h2d osc");
+        if (wf != 12 && G.varies(0)) {  // a derived frequency: one value per sample, [L][n] (the kernel's per-sample form: the same
+            // `phase += 1./(sampleRate/frequency)` with this sample's frequency, as a call with that argument computes)
+            std::vector<double> hf(G.L * n);
+            for (size_t t = 0; t < G.L; t++)
+                for (size_t j = 0; j < n; j++) hf[t * n + j] = G.arg(j, 0, t);
+            put(G, G.d_in.need(G.L * n), hf.data(), sizeof(double) * G.L * n, "h2d osc freq");
+            check(mxg_osc_render(wf, n, G.L, G.d_in.p, 1, dp + n, dp + 2 * n, G.d_state.p, G.d_state.p + n, G.d_out.p, stream),
+                  "mxg_osc_render");
+            return;
+        }
         if (wf == 12) {  // noise(): a[0] holds the rand() draw
             std::vector<int32_t> ht(G.L * n);
             for (size_t t = 0; t < G.L; t++)
@@ -379,6 +685,7 @@ struct OscPool : Pool {  // state: phase, output (H:173,176)
 
 struct EnvPool : Pool {  // state: amplitude, output | holdcount, attack/decay/sustain/hold/release phase (H:888-932)
     EnvPool() : Pool(2, 6) {}
+    unsigned derivable(int) const override { return 1u; }  // the input signal
     void enqueue(Group &G) override {
         const size_t n = G.m.size(), L = G.L;
         const int mode = G.sig[0].method;  // 0 adsr, 1 ar
@@ -388,7 +695,7 @@ struct EnvPool : Pool {  // state: amplitude, output | holdcount, attack/decay/s
         for (size_t j = 0; j < n; j++) {
             const double *a = G.sig[j].a;  // input, trigger, attack, decay, sustain, release, holdtime
             for (size_t t = 0; t < L; t++) {
-                in[t * n + j] = a[0];
+                in[t * n + j] = G.arg(j, 0, t);
                 trig[t * n + j] = (int32_t)a[1];
             }
             for (int k = 0; k < 4; k++) par[(size_t)k * n + j] = a[2 + k];
@@ -406,13 +713,14 @@ struct EnvPool : Pool {  // state: amplitude, output | holdcount, attack/decay/s
 
 struct FilterPool : Pool {  // state: x, y, outputs[0..2] (H:289-302)
     FilterPool() : Pool(5, 0) {}
+    unsigned derivable(int) const override { return 1u; }  // the input signal (cutoff / resonance: host-libm coefficients per block)
     void enqueue(Group &G) override {
         const size_t n = G.m.size(), L = G.L;
         const int kind = G.sig[0].method;
         std::vector<double> in(L * n), cut(n), res(n), coef(3 * n, 0.0);
         for (size_t j = 0; j < n; j++) {
             const double *a = G.sig[j].a;  // input, cutoff, resonance
-            for (size_t t = 0; t < L; t++) in[t * n + j] = a[0];
+            for (size_t t = 0; t < L; t++) in[t * n + j] = G.arg(j, 0, t);
             cut[j] = a[1];
             res[j] = a[2];
         }
@@ -472,13 +780,14 @@ struct SamplePool : Pool {
 
 struct Filter2Pool : Pool {  // maxiDCBlocker / maxiSVF / maxiBiquad: three doubles of state each (mxg_filter2_render)
     Filter2Pool() : Pool(3, 0) {}
+    unsigned derivable(int) const override { return 1u; }  // the input signal
     void enqueue(Group &G) override {
         const size_t n = G.m.size(), L = G.L;
         const int kind = G.sig[0].method;                    // 0 DC blocker, 1 SVF, 2 biquad
         const size_t rows = kind == 0 ? 1 : (kind == 1 ? 9 : 5);  // coefficient rows, call arguments a[1 .. rows]
         std::vector<double> in(L * n), coef(rows * n);
         for (size_t j = 0; j < n; j++) {
-            for (size_t t = 0; t < L; t++) in[t * n + j] = G.sig[j].a[0];
+            for (size_t t = 0; t < L; t++) in[t * n + j] = G.arg(j, 0, t);
             for (size_t k = 0; k < rows; k++) coef[k * n + j] = G.sig[j].a[1 + k];
         }
         stage_begin(G, sizeof(double) * (L * n + rows * n) + 64);
