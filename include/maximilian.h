@@ -129,6 +129,7 @@ struct Slot {
     std::vector<std::vector<double>> dv;  // dv[k]: per-sample value of argument k over the cached block (empty: the constant sig.a[k])
     double lastArg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool hasLastArg = false;
+    int unstable = 0;              // > 0: an argument NO form explains changed a few calls ago -- blocks of one sample until it settles
 };
 
 inline uint64_t &ps_tick() { static uint64_t t = 0; return t; }
@@ -323,6 +324,16 @@ private:
         // forms of arguments that are not derivable for this method (the object switched methods): drop
         for (size_t i = 0; i < s.hyps.size();)
             if (!(mask >> s.hyps[i].k & 1u)) s.hyps.erase(s.hyps.begin() + (long)i); else i++;
+        // an argument that changed and that no form in use (three calls reproduced) explains: a block longer than one sample would
+        // only be rendered to be rewound at its second call (10.Filters: a derivable input beside a cutoff that follows an envelope)
+        if (s.unstable > 0) s.unstable--;
+        if (s.hasLastArg)
+            for (int k = 0; k < 10; k++) {
+                if (ps_same_bits(c.a[k], s.lastArg[k])) continue;
+                bool explained = false;
+                for (const Hyp &h : s.hyps) explained = explained || (h.k == k && h.streak >= 3);
+                if (!explained) s.unstable = 8;
+            }
         std::memcpy(s.lastArg, c.a, sizeof(s.lastArg));
         s.hasLastArg = true;
     }
@@ -591,7 +602,7 @@ private:
         std::vector<const Hyp *> use;
         size_t span = 0;
         std::vector<std::vector<double>> dv0;
-        const bool derived = mask && derive_for(s, mask, s.count, use, span);
+        const bool derived = mask && s.unstable == 0 && derive_for(s, mask, s.count, use, span);
         if (derived) {
             if (consumed && L < 2) L = 2;  // the forms have just reproduced three calls: start growing
             L = std::min(L, span);
