@@ -130,6 +130,8 @@ struct Slot {
     double lastArg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool hasLastArg = false;
     int unstable = 0;              // > 0: an argument NO form explains changed a few calls ago -- blocks of one sample until it settles
+    int fitFails[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // consecutive fruitless searches per argument (the search backs off)
+    uint64_t fitAgain[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 inline uint64_t &ps_tick() { static uint64_t t = 0; return t; }
@@ -156,15 +158,19 @@ inline uint64_t ps_last_ord(const Slot &X) {  // the last ordinal ps_out_at can 
     const uint64_t base = X.count - X.pos;
     return X.len > 0 ? base + X.len - 1 : X.count - 1;
 }
-inline double ps_nice(double x) {  // the shortest decimal within a few ulps: patch constants are literals like 440, 0.5, 10000
-    if (!(x == x) || x == 0.0 || std::isinf(x)) return x;
-    for (int digits = 3; digits <= 15; digits += 3) {
+// The shortest decimal (<= 12 significant digits) within `rel` of x -- patch constants are literals like 440, 0.5, 10000, and a constant
+// recovered from two observations carries their rounding noise.  false: x is not such a number (an argument that is no affine form of
+// the producer: nothing is fitted, nothing is paid).
+inline bool ps_nice(double x, double rel, double &y) {
+    if (!(x == x) || std::isinf(x)) return false;
+    if (x == 0.0) { y = 0.0; return true; }
+    for (int digits = 3; digits <= 12; digits += 3) {
         char buf[40];
         std::snprintf(buf, sizeof buf, "%.*g", digits, x);
-        const double y = std::strtod(buf, nullptr);
-        if (std::fabs(y - x) <= 8.0 * DBL_EPSILON * std::fabs(x)) return y;
+        y = std::strtod(buf, nullptr);
+        if (std::fabs(y - x) <= rel * std::fabs(x)) return true;
     }
-    return x;
+    return false;
 }
 inline double ps_eval(const Hyp &h, double x1, double x2) {  // (statement by statement: the roundings of the patch's own expression)
     double t;
@@ -319,7 +325,14 @@ private:
                     s.hyps.erase(s.hyps.begin() + (long)i);
                 }
             }
-            if (!have && s.hasLastArg && !ps_same_bits(v, s.lastArg[k])) propose(s, k, o, v);
+            if (!have && s.hasLastArg && !ps_same_bits(v, s.lastArg[k]) && o >= s.fitAgain[k]) {
+                if (propose(s, k, o, v)) {
+                    s.fitFails[k] = 0;
+                } else {  // nothing fits (a non-linear map, a random draw): look again after 4, 8, ... 256 calls
+                    s.fitFails[k] = std::min(s.fitFails[k] + 1, 7);
+                    s.fitAgain[k] = o + ((uint64_t)2 << s.fitFails[k]);
+                }
+            }
         }
         // forms of arguments that are not derivable for this method (the object switched methods): drop
         for (size_t i = 0; i < s.hyps.size();)
@@ -337,7 +350,7 @@ private:
         std::memcpy(s.lastArg, c.a, sizeof(s.lastArg));
         s.hasLastArg = true;
     }
-    void propose(Slot &s, int k, uint64_t o, double v) {
+    bool propose(Slot &s, int k, uint64_t o, double v) {
         // the objects that returned a value most recently (this sample's graph evaluation), newest first
         std::vector<Slot *> recent;
         for (Slot *X : ps_live())
@@ -360,23 +373,23 @@ private:
             h.d1 = (int64_t)(X->count - 1) - (int64_t)o;
             if (ps_same_bits(x, v)) { h.form = 1; push(h); continue; }
             double xp;
-            if (!(o >= 1 && ps_out_at(*X, (uint64_t)((int64_t)(o - 1) + h.d1), xp)) || xp == x) continue;
+            if (!(o >= 1 && ps_out_at(*X, (uint64_t)((int64_t)(o - 1) + h.d1), xp)) || xp == x || v == vp) continue;
             auto fits = [&](const Hyp &t) { return ps_same_bits(ps_eval(t, x, 0), v) && ps_same_bits(ps_eval(t, xp, 0), vp); };
-            if (x != 0.0) { h.form = 2; h.a = ps_nice(v / x); if (fits(h)) { push(h); continue; } }
-            h.form = 3; h.b = ps_nice(v - x); if (fits(h)) { push(h); continue; }
-            const double slope = ps_nice((v - vp) / (x - xp));
-            if (slope == slope && slope != 0.0 && !std::isinf(slope)) {
-                h.a = slope;
-                h.form = 4; h.b = ps_nice(v - x * slope); if (fits(h)) { push(h); continue; }
-                h.form = 5; h.b = ps_nice(v / slope - x); if (fits(h)) { push(h); continue; }
-                h.form = 9;  // ((x + b) * a) + c with a small integer b (15.polysynth: 250 + ((pitch + lfo) * 1000))
-                bool found = false;
-                for (int b = -12; b <= 12 && !found; b++) {
-                    if (b == 0) continue;
-                    h.b = (double)b;
-                    h.c = ps_nice(v - (x + h.b) * slope);
-                    if (fits(h)) { push(h); found = true; }
-                }
+            // constants recovered from the two observations carry their rounding noise, amplified by the cancellation in the differences
+            const double amp = 8.0 * DBL_EPSILON * (1.0 + (std::fabs(v) + std::fabs(vp)) / std::fabs(v - vp) + (std::fabs(x) + std::fabs(xp)) / std::fabs(x - xp));
+            const double tol = std::min(amp, 1e-6);
+            if (x != 0.0 && ps_nice(v / x, 8.0 * DBL_EPSILON, h.a)) { h.form = 2; if (fits(h)) { push(h); continue; } }
+            if (ps_nice(v - x, tol, h.b)) { h.form = 3; if (fits(h)) { push(h); continue; } }
+            double slope;
+            if (!ps_nice((v - vp) / (x - xp), tol, slope) || slope == 0.0) continue;
+            h.a = slope;
+            if (ps_nice(v - x * slope, tol, h.b)) { h.form = 4; if (fits(h)) { push(h); continue; } }
+            if (ps_nice(v / slope - x, tol, h.b)) { h.form = 5; if (fits(h)) { push(h); continue; } }
+            h.form = 9;  // ((x + b) * a) + c with a small integer b (15.polysynth: 250 + ((pitch + lfo) * 1000))
+            for (int b = -12; b <= 12; b++) {
+                if (b == 0) continue;
+                h.b = (double)b;
+                if (ps_nice(v - (x + h.b) * slope, tol, h.c) && fits(h)) { push(h); break; }
             }
         }
         // two sources: the sum or the product of two recent outputs, optionally scaled
@@ -389,11 +402,12 @@ private:
                 const double x1 = X1->lastOut, x2 = X2->lastOut;
                 h.form = 6; if (ps_same_bits(ps_eval(h, x1, x2), v)) { push(h); continue; }
                 h.form = 8; if (ps_same_bits(ps_eval(h, x1, x2), v)) { push(h); continue; }
-                if (x1 + x2 != 0.0) {
-                    h.form = 7; h.a = ps_nice(v / (x1 + x2));
+                if (x1 + x2 != 0.0 && ps_nice(v / (x1 + x2), 8.0 * DBL_EPSILON, h.a)) {
+                    h.form = 7;
                     if (ps_same_bits(ps_eval(h, x1, x2), v)) push(h);
                 }
             }
+        return added > 0;
     }
     // the forms in use for the block that starts at ordinal o: per derivable argument the longest-standing one that has reproduced
     // three calls in a row; `span` = how many samples from o on every one of them can be evaluated
