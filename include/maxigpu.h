@@ -209,6 +209,13 @@ int mxg_osc_render_mix(int waveform, size_t V, size_t N, const double *d_freq, c
 int mxg_filter_render(int kind, size_t V, size_t N, const double *d_in, const double *d_cutoff,
                       int cps, const double *d_res, int rps, const double *d_coef, double *d_st,
                       double *d_out, void *stream);
+/* lores / hires / bandpass with PER-SAMPLE coefficients computed by the caller: d_coef_ps = [N][3][V], rows as mxg_filter_coeffs_host
+ * writes them (c, r, unused | inputs[0..2]) for the cutoff / resonance of that sample.  The bit-exact form of a modulated cutoff
+ * (the reference evaluates cos / pow / sqrt with the host libm on every call, src/maximilian.cpp:456-461): mxg_filter_render's own
+ * per-sample mode evaluates them on the device, under a tolerance.  include/maximilian.h uses this when a cutoff follows another
+ * object's output. */
+int mxg_filter_render_coefs(int kind, size_t V, size_t N, const double *d_in, const double *d_coef_ps, double *d_st, double *d_out,
+                            void *stream);
 /* Host-side coefficient evaluation on this machine's libm: kind lores/hires -> h_coef[0]=c,
  * h_coef[1]=r (C:456-461); bandpass -> h_coef[0..2]=inputs[0..2] (C:489-495).  h_coef is [3][V]. */
 int mxg_filter_coeffs_host(int kind, size_t V, const double *h_cutoff, const double *h_res,

@@ -738,7 +738,7 @@ struct EnvPool : Pool {  // state: amplitude, output | holdcount, attack/decay/s
 
 struct FilterPool : Pool {  // state: x, y, outputs[0..2] (H:289-302)
     FilterPool() : Pool(5, 0) {}
-    unsigned derivable(int) const override { return 1u; }  // the input signal (cutoff / resonance: host-libm coefficients per block)
+    unsigned derivable(int) const override { return 7u; }  // the input signal, the cutoff, the resonance
     void enqueue(Group &G) override {
         const size_t n = G.m.size(), L = G.L;
         const int kind = G.sig[0].method;
@@ -748,6 +748,35 @@ struct FilterPool : Pool {  // state: x, y, outputs[0..2] (H:289-302)
             for (size_t t = 0; t < L; t++) in[t * n + j] = G.arg(j, 0, t);
             cut[j] = a[1];
             res[j] = a[2];
+        }
+        const bool moving = G.varies(1) || G.varies(2);  // a derived cutoff / resonance: one value per sample
+        if (moving && kind <= MXG_FLT_BANDPASS) {
+            // the coefficients of EVERY sample with the host libm (cos / pow / sqrt of C:459-461, :492-495, as the reference evaluates
+            // them on every call), rows [L][3][n]
+            std::vector<double> cps(L * 3 * n, 0.0);
+            for (size_t t = 0; t < L; t++) {
+                for (size_t j = 0; j < n; j++) {
+                    cut[j] = G.arg(j, 1, t);
+                    res[j] = G.arg(j, 2, t);
+                }
+                check(mxg_filter_coeffs_host(kind, n, cut.data(), res.data(), cps.data() + t * 3 * n), "mxg_filter_coeffs_host");
+            }
+            stage_begin(G, sizeof(double) * (L * n + L * 3 * n) + 64);
+            put(G, G.d_in.need(L * n), in.data(), sizeof(double) * L * n, "h2d flt in");
+            put(G, G.d_par.need(L * 3 * n), cps.data(), sizeof(double) * L * 3 * n, "h2d flt coefs");
+            check(mxg_filter_render_coefs(kind, n, L, G.d_in.p, G.d_par.p, G.d_state.p, G.d_out.p, stream), "mxg_filter_render_coefs");
+            return;
+        }
+        if (moving) {  // lopass / hipass use the cutoff itself (C:442-453): the kernel's per-sample form is the same arithmetic
+            std::vector<double> cs(L * n);
+            for (size_t t = 0; t < L; t++)
+                for (size_t j = 0; j < n; j++) cs[t * n + j] = G.arg(j, 1, t);
+            stage_begin(G, sizeof(double) * 2 * L * n + 64);
+            put(G, G.d_in.need(L * n), in.data(), sizeof(double) * L * n, "h2d flt in");
+            put(G, G.d_par.need(L * n), cs.data(), sizeof(double) * L * n, "h2d flt cutoffs");
+            check(mxg_filter_render(kind, n, L, G.d_in.p, G.d_par.p, 1, nullptr, 0, nullptr, G.d_state.p, G.d_out.p, stream),
+                  "mxg_filter_render");
+            return;
         }
         if (kind <= MXG_FLT_BANDPASS)  // cos / pow / sqrt of C:459-461, :492-495 on the host libm
             check(mxg_filter_coeffs_host(kind, n, cut.data(), res.data(), coef.data()), "mxg_filter_coeffs_host");

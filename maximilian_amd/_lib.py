@@ -54,6 +54,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_filter_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_int, c_void_p,
                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_filter_render_coefs": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_filter_coeffs_host": (c_int, [c_int, c_size_t, c_void_p, c_void_p, c_void_p]),
     "mxg_env_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

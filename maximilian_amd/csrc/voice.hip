@@ -150,6 +150,38 @@ __global__ void __launch_bounds__(256) filter_kernel(size_t V, size_t N, const d
     st[4 * V + v] = f.o2;
 }
 
+// lores / hires / bandpass with the coefficients given PER SAMPLE (coef [N][3][V]: c, r, - or inputs[0..2]), computed by the caller
+// with the host libm (mxg_filter_coeffs_host per sample): the bit-exact form of a modulated cutoff -- what the per-sample engine of
+// include/maximilian.h renders when a cutoff follows another object's output (14.monosynth's `ADSRout*10000`).  Small banks, short
+// blocks: a plain loop.
+template <int KIND>
+__global__ void __launch_bounds__(256) filter_coefps_kernel(size_t V, size_t N, const double *__restrict__ in,
+                                                             const double *__restrict__ coef, double *__restrict__ st,
+                                                             double *__restrict__ out) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    Flt f = {st[v], st[V + v], st[2 * V + v], st[3 * V + v], st[4 * V + v]};
+    for (size_t n = 0; n < N; n++) {
+        const double x = in[n * V + v];
+        const double *cp = coef + (n * 3) * V + v;
+        double o;
+        if constexpr (KIND == MXG_FLT_BANDPASS) {  // C:487-500
+            o = cp[0] * x + cp[V] * f.o1 + cp[2 * V] * f.o2;
+            f.o2 = f.o1;
+            f.o1 = o;
+        } else {
+            const double y = flt_lores(f, x, cp[0], cp[V]);
+            o = (KIND == MXG_FLT_LORES) ? y : x - y;  // C:466 / C:482
+        }
+        out[n * V + v] = o;
+    }
+    st[v] = f.x;
+    st[V + v] = f.y;
+    st[2 * V + v] = f.o0;
+    st[3 * V + v] = f.o1;
+    st[4 * V + v] = f.o2;
+}
+
 template <int MODE, bool HASIN, bool TPV>
 __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const double *__restrict__ in,
                            const int32_t *__restrict__ trig, int tpv,
@@ -532,6 +564,23 @@ int mxg_filter_render(int kind, size_t V, size_t N, const double *d_in, const do
     }
 #undef MXG_FLT_LAUNCH
     return check_hip(hipGetLastError(), "filter_kernel launch");
+}
+
+int mxg_filter_render_coefs(int kind, size_t V, size_t N, const double *d_in, const double *d_coef_ps, double *d_st, double *d_out,
+                            void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(kind >= MXG_FLT_LORES && kind <= MXG_FLT_BANDPASS, "lores, hires or bandpass (lopass / hipass take a per-sample cutoff in mxg_filter_render)");
+    MXG_REQUIRE(d_in && d_coef_ps && d_st && d_out, "null device pointer");
+    if (V == 0 || N == 0) return MXG_OK;
+    hipStream_t st = resolve_stream(stream);
+    KernelTimer kt("filter_coefps_kernel", st);
+    const int block = 256;
+    switch (kind) {
+        case 0: hipLaunchKernelGGL((filter_coefps_kernel<0>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_coef_ps, d_st, d_out); break;
+        case 1: hipLaunchKernelGGL((filter_coefps_kernel<1>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_coef_ps, d_st, d_out); break;
+        default: hipLaunchKernelGGL((filter_coefps_kernel<2>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_coef_ps, d_st, d_out); break;
+    }
+    return check_hip(hipGetLastError(), "filter_coefps_kernel launch");
 }
 
 // Host libm evaluation of C:456-461 / C:489-495 (no device involved).

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from conftest import assert_bits_equal, assert_close_scaled, mix_tol
+from maximilian_amd import banks
 
 pytestmark = pytest.mark.gpu
 
@@ -373,3 +374,31 @@ def test_env_arbitrary_uploaded_flags(mx, port):
         assert_bits_equal(o, e, "adsr, gate %d" % gate_value)
         assert_bits_equal(bank.dstate.numpy(), dst)
         assert np.array_equal(bank.istate.numpy(), ist)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_filter_per_sample_host_coefficients_bit_exact(mx, port, kind):
+    """mxg_filter_render_coefs: lores / hires / bandpass with the coefficients of every sample computed by the caller with the host
+    libm (mxg_filter_coeffs_host per sample) -- the bit-exact form of a modulated cutoff, against the oracle called with a
+    per-sample cutoff and resonance (the reference evaluates cos / pow / sqrt on every call); two blocks, state carried."""
+    rng = np.random.default_rng(40 + kind)
+    V, N = 37, 300
+    x = rng.uniform(-1, 1, (2 * N, V))
+    cut = rng.uniform(30, 9000, (2 * N, V))
+    res = rng.uniform(0.2, 12, (2 * N, V)) if kind != 2 else rng.uniform(0.05, 0.95, (2 * N, V))
+    e, est = port.filter(kind, x, cut, res, cps=True, rps=True)
+    L = mx.lib()
+    chk = mx._lib.check
+    st = mx.DeviceBuffer((5, V))
+    outs = []
+    for b in range(2):
+        coefs = np.zeros((N, 3, V))
+        for t in range(N):
+            coefs[t] = banks.filter_coeffs(kind, cut[b * N + t], res[b * N + t])
+        d_in = mx.DeviceBuffer.from_numpy(np.ascontiguousarray(x[b * N:(b + 1) * N]))
+        d_c = mx.DeviceBuffer.from_numpy(coefs)
+        d_o = mx.DeviceBuffer((N, V), np.float64, zero=False)
+        chk(L.mxg_filter_render_coefs(kind, V, N, d_in.ptr, d_c.ptr, st.ptr, d_o.ptr, None), "mxg_filter_render_coefs")
+        outs.append(d_o.numpy())
+    assert_bits_equal(np.concatenate(outs), e, "per-sample host coefficients vs the oracle's per-call coefficients")
+    assert_bits_equal(st.numpy(), est, "carried state")
