@@ -55,6 +55,32 @@ def test_polysynth_patch_bit_exact(golden, tmp_path):
     assert np.abs(exp).max() > 0.05
 
 
+def _launches(log):
+    m = re.search(r"launches: osc (\d+) .*?env (\d+) .*?filter (\d+)", log)
+    return int(m.group(1)) + int(m.group(2)) + int(m.group(3))
+
+
+@pytest.mark.parametrize("ex,frames,max_launches_per_1000", [("14", 20000, 150), ("15", 12000, 400), ("05", 6000, 150), ("10", 6000, 250)])
+def test_signal_arguments_are_predicted_per_sample(tmp_path, ex, frames, max_launches_per_1000):
+    """Derived arguments (include/maximilian.h): a cutoff that follows an envelope, a frequency that follows an LFO, a filter input
+    that is the sum of two oscillators are predicted per sample from the producers' cached blocks, so these patches render in blocks
+    instead of one launch per call -- and with the prediction switched off (MXG_PS_DERIVE=0) the output is the same bits, at one
+    launch per call and object.  (That those bits are the reference's is what the tests around this one check.)"""
+    got, log = run_dropin(ex, frames, tmp_path)
+    n_on = _launches(log)
+    env = dict(os.environ, MXG_PS_DERIVE="0")
+    exe = os.path.join(ROOT, "host", "dropin_" + ex)
+    out2 = str(tmp_path / "off.f64")
+    r = subprocess.run([exe, str(frames), out2], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr
+    off = np.fromfile(out2, np.float64).reshape(frames, 2)
+    n_off = _launches(r.stderr)
+    assert np.array_equal(got.view(np.uint64), off.view(np.uint64)), "derived-argument prediction changed the samples"
+    print("%s: %d launches with derived arguments, %d without, %d frames" % (ex, n_on, n_off, frames))
+    assert n_on * 1000 <= max_launches_per_1000 * frames, log
+    assert n_off >= 5 * n_on, "the patch was expected to need one launch per call without the prediction"
+
+
 # ten more of the reference's own example patches, compiled verbatim (host/Makefile dropin_<tag>): what each one exercises and
 # how closely it can match.  Patches built only from the wavetable / ramp oscillators, the envelope and the filter are
 # bit-identical; a sinewave is within 1 ULP of glibc's, so sums / products of sinewaves carry a few ULP, and where a sinewave
