@@ -14,9 +14,12 @@
 // pinned host memory while the current one is being served (no render inside the audio thread in steady state).
 // When a call arrives with other arguments -- a new pitch, a trigger, an input that is itself a signal -- the slot is
 // rewound to the state it had at that sample (the block is re-advanced from its start state: same kernel, same bits)
-// and continues from there with blocks of one sample.  Nothing is ever computed on the CPU: an object whose arguments
-// change every sample (a filter fed by an oscillator) costs one small launch per call -- correct, and as slow as that
-// sounds; the throughput path for such graphs is the fused bank API (include/maximilian_bank.hpp, maxiVoiceBank).
+// and continues from there with blocks of one sample.  Nothing of the signal path is ever computed on the CPU.  An
+// argument that is itself a signal (a filter fed by `(VCO1out+VCO2out)*0.5`, a cutoff of `ADSRout*10000`) is predicted
+// PER SAMPLE: the pool recognises small expressions of other objects' recent outputs and fills the consumer's next block
+// from the producers' cached blocks ("derived arguments", below; every call is still verified bit for bit).  Only an
+// argument it cannot recognise (a pow / fabs of another output, noise()'s rand() draw) costs one small launch per call;
+// the throughput path for big graphs is the fused bank API (include/maximilian_bank.hpp, maxiVoiceBank).
 // State is authoritative on the host between launches (a few doubles per object), so rewinding and regrouping are
 // plain copies.  maxiFilter's cos/pow/sqrt coefficients are evaluated with THIS machine's libm
 // (mxg_filter_coeffs_host), which is what keeps the recursive filter bit-identical to the reference.
