@@ -169,7 +169,8 @@ int mxg_last_async_error(void);
 /* ---- maxiOsc bank -------------------------------------------------------------------- */
 /* Renders out[n][v] = bank[v].<waveform>(freq) for n < N, exactly as N consecutive per-sample
  * calls would (H:169-215).  d_freq is [V] (fps=0, block-constant) or [N][V] (fps=1, audio-rate
- * modulation).  d_p1/d_p2: per-voice extra arguments (see mxg_osc_waveform), may be NULL when
+ * modulation); fps=2: d_freq AND d_p1 are [N][V] (a pulse width / start phase that changes per
+ * sample as well).  d_p1/d_p2: per-voice extra arguments (see mxg_osc_waveform), may be NULL when
  * unused.  d_phase / d_outhold: the members `phase` and `output` (H:173,176), in/out.
  * maxiOsc::noise (C:214-220) draws from the process-wide rand(): see mxg_osc_noise. */
 int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_freq, int fps,

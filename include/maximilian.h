@@ -678,7 +678,9 @@ P &pool() {
 // ---- the pools -------------------------------------------------------------------------------------------
 struct OscPool : Pool {  // state: phase, output (H:173,176)
     OscPool() : Pool(2, 0) {}
-    unsigned derivable(int method) const override { return method == 12 ? 0u : 1u; }  // the frequency (not noise()'s rand() draw)
+    unsigned derivable(int method) const override {  // the frequency; pulse's width too (not noise()'s rand() draw)
+        return method == 12 ? 0u : (method == MXG_OSC_PULSE ? 3u : 1u);
+    }
     void enqueue(Group &G) override {
         const size_t n = G.m.size();
         const int wf = G.sig[0].method;
@@ -686,16 +688,22 @@ struct OscPool : Pool {  // state: phase, output (H:173,176)
         for (size_t j = 0; j < n; j++)
             for (int k = 0; k < 3; k++) hp[(size_t)k * n + j] = G.sig[j].a[k];
         double *dp = G.d_par.need(3 * n);
-        stage_begin(G, sizeof(double) * 3 * n + (sizeof(int32_t) + sizeof(double)) * G.L * n + 64);
+        stage_begin(G, sizeof(double) * 3 * n + (sizeof(int32_t) + 2 * sizeof(double)) * G.L * n + 64);
         put(G, dp, hp.data(), sizeof(double) * 3 * n, "h2d osc");
-        if (wf != 12 && G.varies(0)) {  // a derived frequency: one value per sample, [L][n] (the kernel's per-sample form: the same
-            // `phase += 1./(sampleRate/frequency)` with this sample's frequency, as a call with that argument computes)
-            std::vector<double> hf(G.L * n);
+        if (wf != 12 && (G.varies(0) || G.varies(1))) {  // a derived frequency (/ pulse width): one value per sample, [L][n] (the
+            // kernel's per-sample form: the same `phase += 1./(sampleRate/frequency)` with this sample's frequency, as a call with
+            // that argument computes)
+            const bool w = G.varies(1);
+            std::vector<double> hf((w ? 2 : 1) * G.L * n);
             for (size_t t = 0; t < G.L; t++)
-                for (size_t j = 0; j < n; j++) hf[t * n + j] = G.arg(j, 0, t);
-            put(G, G.d_in.need(G.L * n), hf.data(), sizeof(double) * G.L * n, "h2d osc freq");
-            check(mxg_osc_render(wf, n, G.L, G.d_in.p, 1, dp + n, dp + 2 * n, G.d_state.p, G.d_state.p + n, G.d_out.p, stream),
-                  "mxg_osc_render");
+                for (size_t j = 0; j < n; j++) {
+                    hf[t * n + j] = G.arg(j, 0, t);
+                    if (w) hf[G.L * n + t * n + j] = G.arg(j, 1, t);
+                }
+            double *df = G.d_in.need(2 * G.L * n);
+            put(G, df, hf.data(), sizeof(double) * hf.size(), "h2d osc freq");
+            check(mxg_osc_render(wf, n, G.L, df, w ? 2 : 1, w ? df + G.L * n : dp + n, dp + 2 * n, G.d_state.p, G.d_state.p + n, G.d_out.p,
+                                 stream), "mxg_osc_render");
             return;
         }
         if (wf == 12) {  // noise(): a[0] holds the rand() draw

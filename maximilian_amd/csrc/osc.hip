@@ -64,7 +64,8 @@ template <int WF, bool FPS, int VPL, int ST, bool PX>
 __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
                            const double *__restrict__ p1, const double *__restrict__ p2,
                            double *__restrict__ phase_io, double *__restrict__ hold_io,
-                           double *__restrict__ out, double sr, PartSync psync, int xcd) {
+                           double *__restrict__ out, double sr, PartSync psync, int xcd, int p1ps) {
+    // (p1ps, FPS only: p1 is [N][V] too -- a pulse width / start phase per sample, for the per-sample engine's derived arguments)
     // All LDS in ONE array (a second __shared__ object perturbs hipcc's waitcnt placement).
     __shared__ __attribute__((aligned(16))) double s_tab[tab_len<WF>()];
     if constexpr (tab_len<WF>() > 1) {
@@ -108,6 +109,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
     }
     double *o = out + nA * V + v0;
     const double *fp = freq + v0;
+    const double *pp = (FPS && p1ps) ? p1 + v0 : nullptr;
 #ifndef MXG_OSC_UNROLL
 #define MXG_OSC_UNROLL 4
 #endif
@@ -140,7 +142,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
             double r[VPL];
 #pragma unroll
             for (int j = 0; j < VPL; j++) {
-                if constexpr (FPS) q[j] = osc_pre<WF>(fp[j], sr, q[j].p1, q[j].p2);
+                if constexpr (FPS) q[j] = osc_pre<WF>(fp[j], sr, pp ? pp[j] : q[j].p1, q[j].p2);
                 r[j] = osc_tick<WF, kTrust>(ph[j], hd[j], q[j], s_tab, s_tab);
             }
             if constexpr (VPL == 2)
@@ -148,7 +150,10 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
             else
                 store1<ST>(o, r[0]);
             o += V;
-            if constexpr (FPS) fp += V;
+            if constexpr (FPS) {
+                fp += V;
+                if (pp) pp += V;
+            }
         }
     };
     if constexpr ((WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE) && !FPS) {
@@ -394,7 +399,7 @@ osc_mix_fn pick_mix_wf(int wf, int store, int var) {
 }
 
 typedef void (*osc_fn)(size_t, size_t, const double *, const double *, const double *, double *,
-                       double *, double *, double, PartSync, int);
+                       double *, double *, double, PartSync, int, int);
 
 // store: 0 plain 8 B, 1 nt 8 B, 2 pair rows (16 B) plain, 3 pair rows sc1, 4 pair rows nt      (one voice per lane)
 //        0 plain 16 B, 1 nt 16 B, 2 sc1 16 B                                                  (two voices per lane)
@@ -443,6 +448,7 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     MXG_REQUIRE(waveform != MXG_OSC_PULSE || d_p1, "pulse needs d_p1 (duty)");
     MXG_REQUIRE(waveform != MXG_OSC_PHASORBETWEEN || (d_p1 && d_p2),
                 "phasorBetween needs d_p1/d_p2 (start/end phase)");
+    MXG_REQUIRE(fps >= 0 && fps <= 2 && (fps != 2 || d_p1), "fps is 0, 1 (d_freq [N][V]) or 2 (d_freq and d_p1 [N][V])");
     if (V == 0 || N == 0) return MXG_OK;
     // ---- the store stream --------------------------------------------------------------------------------------------
     // Knobs osc_vpl, osc_store, osc_xcd (0 = automatic each) name it; left alone, it goes by
@@ -520,7 +526,7 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
         if (int s = part_sync_get(resolve_stream(stream), (size_t)grid.x * ((block + 63) / 64), split, &psync)) return s;
     KernelTimer kt("osc_kernel", resolve_stream(stream));
     hipLaunchKernelGGL(fn, grid, blk, 0, resolve_stream(stream), V, N, d_freq, d_p1, d_p2, d_phase,
-                       d_outhold, d_out, (double)settings().sampleRate, psync, xcd);
+                       d_outhold, d_out, (double)settings().sampleRate, psync, xcd, fps == 2 ? 1 : 0);
     return check_hip(hipGetLastError(), "osc_kernel launch");
 }
 

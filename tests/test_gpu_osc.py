@@ -342,3 +342,30 @@ def test_time_part_timeout_is_reported_and_state_kept(mx, port):
     e3, _, _ = port.osc(8, freq, N, phase=eph2)
     assert_bits_equal(third, e3)
     L.mxg_tune(b"osc_split", 0)
+
+
+def test_pulse_width_and_frequency_per_sample(mx, port):
+    """mxg_osc_render fps = 2: frequency AND p1 (the pulse width; phasorBetween's start phase) per sample, [N][V] each -- what the
+    per-sample engine renders when a patch writes `sound.pulse(f, mod.phasor(1))` (16.Replicant).  Against the oracle called one
+    sample at a time with that sample's arguments and the carried state: the same bits."""
+    rng = np.random.default_rng(77)
+    V, N = 24, 300
+    L = mx.lib()
+    chk = mx._lib.check
+    for name in ("pulse", "phasorBetween"):
+        wf = mx.OSC_WAVEFORMS[name]
+        freq = rng.uniform(20, 3000, (N, V))
+        p1 = rng.uniform(0.05, 0.95, (N, V))
+        p2 = np.full(V, 1.5)
+        ph, hd = np.zeros(V), np.zeros(V)
+        exp = np.empty((N, V))
+        for n in range(N):
+            o, ph, hd = port.osc(wf, freq[n], 1, phase=ph, hold=hd, p1=p1[n], p2=p2)
+            exp[n] = o[0]
+        DB = mx.DeviceBuffer
+        d_f, d_p1, d_p2 = DB.from_numpy(freq), DB.from_numpy(p1), DB.from_numpy(p2)
+        d_ph, d_hd = DB(V), DB(V)
+        d_o = DB((N, V), np.float64, zero=False)
+        chk(L.mxg_osc_render(wf, V, N, d_f.ptr, 2, d_p1.ptr, d_p2.ptr, d_ph.ptr, d_hd.ptr, d_o.ptr, None), "mxg_osc_render fps=2")
+        assert_bits_equal(d_o.numpy(), exp, "fps = 2, waveform %d" % wf)
+        assert_bits_equal(d_ph.numpy(), ph, "phase")
