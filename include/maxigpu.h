@@ -89,6 +89,7 @@ int mxg_memset(void *d_dst, int value, size_t bytes, void *stream);
  * caller's own device SoA arrays, so a "state get/set" is a copy of those arrays (mxg_memcpy_d2h / _h2d). */
 int mxg_memcpy_h2d_async(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int mxg_memcpy_d2h_async(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int mxg_memcpy_d2d_async(void *d_dst, const void *d_src, size_t bytes, void *stream);  /* device to device, in stream order */
 void *mxg_host_alloc(size_t bytes); /* pinned host memory */
 int mxg_host_free(void *h_ptr);
 void *mxg_stream_create(void);

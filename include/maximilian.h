@@ -216,6 +216,8 @@ struct Group {
     PinBuf<int64_t> h_istate;
     PinBuf<unsigned char> h_stage;  // pinned staging of one enqueue's parameter uploads (asynchronous copies: no host wait per array)
     size_t stage_off = 0;
+    bool restart = false;  // this render starts at the members' BLOCK START state again (a rewind): pools whose state is partly on the
+                           // device (the delay line's memory) undo the block they rendered last before they render
     std::vector<std::vector<std::vector<double>>> dv;  // [member][argument][sample]: derived arguments of this render (empty: constant)
     double arg(size_t j, int k, size_t t) const {       // argument k of member j at sample t of the block
         if (j < dv.size() && (size_t)k < dv[j].size() && !dv[j][(size_t)k].empty()) return dv[j][(size_t)k][t];
@@ -296,6 +298,7 @@ protected:
     // bit mask of the argument indices of `method` that may be DERIVED (predicted per sample from other objects' outputs): the ones
     // this pool's enqueue() reads through Group::arg(j, k, t)
     virtual unsigned derivable(int /*method*/) const { return 0; }
+    virtual bool can_prefetch() const { return true; }  // (false: a render mutates device memory that a rewind must be able to undo)
 
 private:
     // the cached block was rendered for exactly this call at its current sample
@@ -566,6 +569,7 @@ private:
         G.m.assign(1, &s);
         G.sig.assign(1, s.sig);
         G.dv.assign(1, s.dv);  // the same (verified) derived arguments for the samples re-run
+        G.restart = true;
         G.L = count;
         const std::vector<double> keep_ed = s.ed;
         render_now(G);
@@ -605,8 +609,9 @@ private:
         const unsigned mask = ps_derive_on() ? derivable(c.method) : 0u;
         const bool was_derived = !s.dv.empty();
         size_t L;
+        bool rewound_at_start = false;
         if (!consumed) {  // the prediction failed inside a block: back to the state at this sample
-            if (s.pos > 0) advance(s, s.pos);
+            if (s.pos > 0) advance(s, s.pos); else rewound_at_start = true;  // (at its first sample: the new render starts there again)
             L = 1;
         } else {
             if (s.len > 0) {
@@ -634,6 +639,7 @@ private:
         G.m.assign(1, &s);
         G.sig.assign(1, c);
         G.dv.assign(1, dv0);
+        G.restart = rewound_at_start;
         G.L = L;
         // objects called in lock-step with this one: same method, also at the end of their block, same growth
         for (Slot *u : slots) {
@@ -664,7 +670,7 @@ private:
             G.dv.push_back(std::vector<std::vector<double>>());
         }
         render_now(G);
-        if (L == kMaxBlock && !G.any_derived()) prefetch(G);
+        if (L == kMaxBlock && !G.any_derived() && can_prefetch()) prefetch(G);
         return s.blk[s.pos++];
     }
 };
@@ -875,6 +881,58 @@ struct EnvGenPool : Pool {  // state of mxg_envgen_render: [5] doubles, [7] int6
         put(G, G.d_in.need(L * n), trig.data(), sizeof(double) * L * n, "h2d envgen trig");
         check(mxg_envgen_render(n, L, G.d_in.p, 1, sh->d_stages, sh->nstages, sh->loop, sh->retrigger, G.d_state.p, G.d_istate.p,
                                 G.d_out.p, stream), "mxg_envgen_render");
+    }
+};
+
+// maxiDelayline (H:268-284; C:415-439): the 88200 * 8 doubles of `memory` live on the device, per object (key).  state: phase.
+// A render writes the cells it passes; a rewind (Group::restart) first puts back the cells the previous render of that object
+// overwrote -- saved, in the order they were first touched, before every render (at most kMaxBlock of them: a block is <= 512
+// samples, and a line shorter than that is saved whole) -- so the re-run starts from the memory the block started from.  No
+// asynchronous next block (it would write ahead of a block that may still be rewound); one object per launch.
+struct DelayPool : Pool {
+    DelayPool() : Pool(0, 1) {}
+    static constexpr size_t kCap = 88200 * 8;  // double memory[88200 * 8], H:273
+    struct Line {
+        double *d_mem = nullptr, *d_save = nullptr;
+        int32_t *d_i = nullptr;  // size, position, phase
+        size_t saved_first = 0, saved_n = 0, saved_wrap = 0;  // the last render's cells: [first, first + n - wrap) then [0, wrap)
+        bool saved = false;
+    };
+    unsigned derivable(int) const override { return 1u; }  // the input signal
+    bool can_prefetch() const override { return false; }
+    void enqueue(Group &G) override {
+        if (G.m.size() != 1) throw std::runtime_error("maxiDelayline: one object per launch");
+        Line *ln = const_cast<Line *>(static_cast<const Line *>(G.sig[0].key));
+        const size_t L = G.L;
+        const double *a = G.sig[0].a;  // input, size, feedback, position
+        const int mode = G.sig[0].method;
+        const int32_t size = (int32_t)a[1];
+        if (size < 1 || (size_t)size > kCap) throw std::runtime_error("maxiDelayline: size out of range");
+        if (G.restart && ln->saved) {  // undo the block rendered last
+            const size_t head = ln->saved_n - ln->saved_wrap;
+            if (head) check(mxg_memcpy_d2d_async(ln->d_mem + ln->saved_first, ln->d_save, sizeof(double) * head, stream), "d2d restore");
+            if (ln->saved_wrap) check(mxg_memcpy_d2d_async(ln->d_mem, ln->d_save + head, sizeof(double) * ln->saved_wrap, stream), "d2d restore");
+        }
+        // the cells this render passes: from the start phase (0 if it is >= size, C:421) on, wrapping at `size`
+        const Slot *u = G.m[0];
+        const int64_t ph0 = u ? u->si[0] : 0;
+        const size_t first = (ph0 >= size || ph0 < 0) ? 0 : (size_t)ph0;
+        const size_t n = std::min(L, (size_t)size);
+        const size_t head = std::min(n, (size_t)size - first), wrap = n - head;
+        check(mxg_memcpy_d2d_async(ln->d_save, ln->d_mem + first, sizeof(double) * head, stream), "d2d save");
+        if (wrap) check(mxg_memcpy_d2d_async(ln->d_save + head, ln->d_mem, sizeof(double) * wrap, stream), "d2d save");
+        ln->saved_first = first; ln->saved_n = n; ln->saved_wrap = wrap; ln->saved = true;
+        std::vector<double> in(L + 1);
+        for (size_t t = 0; t < L; t++) in[t] = G.arg(0, 0, t);
+        in[L] = a[2];  // feedback
+        const int32_t hi[2] = {size, (int32_t)a[3]};
+        stage_begin(G, sizeof(double) * (L + 1) + sizeof(hi) + 64);
+        put(G, G.d_in.need(L + 1), in.data(), sizeof(double) * (L + 1), "h2d delay in");
+        put(G, ln->d_i, hi, sizeof(hi), "h2d delay size");
+        check(mxg_i32_from_i64(ln->d_i + 2, G.d_istate.p, 1, stream), "mxg_i32_from_i64");
+        check(mxg_delay_render(mode, 1, L, G.d_in.p, ln->d_i, G.d_in.p + L, ln->d_i + 1, ln->d_mem, kCap, ln->d_i + 2, G.d_out.p, stream),
+              "mxg_delay_render");
+        check(mxg_i64_from_i32(G.d_istate.p, ln->d_i + 2, 1, stream), "mxg_i64_from_i32");
     }
 };
 
@@ -1335,39 +1393,36 @@ public:
 
 // ---- maxiDelayline (H:266-284; C:415-439): the ring lives on the device, one sample per launch --------------------
 class maxiDelayline {
-    static constexpr size_t kCap = 88200 * 8;  // double memory[88200 * 8], H:273
-    double *d_mem_ = nullptr, *d_io_ = nullptr;
-    int32_t *d_i_ = nullptr;
-    int32_t phase_ = 0;
+    using Pool = maxigpu::ps::DelayPool;
+    maxigpu::ps::Slot slot_;
+    Pool::Line line_;
     void init() {
-        if (d_mem_) return;
+        if (line_.d_mem) return;
         maxigpu::ps::check(mxg_init(-1), "mxg_init");
-        d_mem_ = static_cast<double *>(mxg_malloc(sizeof(double) * kCap));
-        d_io_ = static_cast<double *>(mxg_malloc(sizeof(double) * 4));
-        d_i_ = static_cast<int32_t *>(mxg_malloc(sizeof(int32_t) * 4));
-        if (!d_mem_ || !d_io_ || !d_i_) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
-        maxigpu::ps::check(mxg_memset(d_mem_, 0, sizeof(double) * kCap, nullptr), "mxg_memset");  // ctor memset, C:415-417
+        line_.d_mem = static_cast<double *>(mxg_malloc(sizeof(double) * Pool::kCap));
+        line_.d_save = static_cast<double *>(mxg_malloc(sizeof(double) * maxigpu::ps::kMaxBlock));
+        line_.d_i = static_cast<int32_t *>(mxg_malloc(sizeof(int32_t) * 4));
+        if (!line_.d_mem || !line_.d_save || !line_.d_i) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+        maxigpu::ps::check(mxg_memset(line_.d_mem, 0, sizeof(double) * Pool::kCap, nullptr), "mxg_memset");  // ctor memset, C:415-417
+        maxigpu::ps::check(mxg_sync(), "mxg_sync");
     }
     double run(int mode, double input, int size, double feedback, int position) {
         init();
-        const double hio[2] = {input, feedback};
-        const int32_t hi[3] = {size, position, phase_};
-        maxigpu::ps::check(mxg_memcpy_h2d(d_io_, hio, sizeof(hio), nullptr), "h2d");
-        maxigpu::ps::check(mxg_memcpy_h2d(d_i_, hi, sizeof(hi), nullptr), "h2d");
-        maxigpu::ps::check(mxg_delay_render(mode, 1, 1, d_io_, d_i_, d_io_ + 1, d_i_ + 1, d_mem_, kCap, d_i_ + 2, d_io_ + 2, nullptr),
-                           "mxg_delay_render");
-        double out = 0;
-        maxigpu::ps::check(mxg_memcpy_d2h(&out, d_io_ + 2, sizeof(double), nullptr), "d2h");
-        maxigpu::ps::check(mxg_memcpy_d2h(&phase_, d_i_ + 2, sizeof(int32_t), nullptr), "d2h");
-        return out;
+        maxigpu::ps::Call c;
+        c.method = mode;
+        c.key = &line_;
+        c.a[0] = input; c.a[1] = (double)size; c.a[2] = feedback; c.a[3] = (double)position;
+        return maxigpu::ps::pool<Pool>().call(slot_, c);
     }
 
 public:
-    maxiDelayline() = default;
+    maxiDelayline() { maxigpu::ps::pool<Pool>().attach(slot_); }
     ~maxiDelayline() {
-        if (d_mem_) mxg_free(d_mem_);
-        if (d_io_) mxg_free(d_io_);
-        if (d_i_) mxg_free(d_i_);
+        maxigpu::ps::pool<Pool>().discard(slot_);
+        maxigpu::ps::pool<Pool>().detach(slot_);
+        if (line_.d_mem) mxg_free(line_.d_mem);
+        if (line_.d_save) mxg_free(line_.d_save);
+        if (line_.d_i) mxg_free(line_.d_i);
     }
     maxiDelayline(const maxiDelayline &) = delete;
     maxiDelayline &operator=(const maxiDelayline &) = delete;

@@ -26,6 +26,7 @@ SIGNATURES = {
     "mxg_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mxg_memcpy_h2d_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mxg_memcpy_d2h_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mxg_memcpy_d2d_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mxg_host_alloc": (c_void_p, [c_size_t]),
     "mxg_host_free": (c_int, [c_void_p]),
     "mxg_event_sync": (c_int, [c_void_p]),

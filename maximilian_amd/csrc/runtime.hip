@@ -345,6 +345,11 @@ int mxg_memcpy_d2h_async(void *h_dst, const void *d_src, size_t bytes, void *str
     MXG_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, resolve_stream(stream)));
     return MXG_OK;
 }
+int mxg_memcpy_d2d_async(void *d_dst, const void *d_src, size_t bytes, void *stream) {
+    if (int s = ensure_init()) return s;
+    if (bytes) MXG_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, resolve_stream(stream)));
+    return MXG_OK;
+}
 void *mxg_host_alloc(size_t bytes) {
     if (ensure_init()) return nullptr;
     void *p = nullptr;
