@@ -8,7 +8,7 @@
 // How a one-sample call is served by a block renderer.  Every maxiOsc / maxiEnv / maxiFilter / maxiSample object is a
 // SLOT of a process-wide pool (one pool per class).  A call `osc.pulse(f, d)` is looked up in the block the pool has
 // already rendered for that slot under the prediction "the object keeps being called with the arguments of its last
-// call".  While the prediction holds, a call is an array read; blocks grow 1 -> 2 -> ... -> 512 samples as long as it
+// call".  While the prediction holds, a call is an array read; blocks grow 1 -> 8 -> 64 -> 512 samples as long as it
 // keeps holding, objects called in lock-step (the `for (i < 6)` of a polysynth) are rendered together in ONE launch
 // (voices of a bank), and at the full block length the NEXT block is rendered asynchronously on the pool's stream into
 // pinned host memory while the current one is being served (no render inside the audio thread in steady state).
@@ -301,6 +301,10 @@ protected:
     virtual bool can_prefetch() const { return true; }  // (false: a render mutates device memory that a rewind must be able to undo)
 
 private:
+    // blocks grow 1 -> 8 -> 64 -> 512 while the prediction holds: a longer block costs the GPU nothing more than a short one (the
+    // launch and the round trip are the cost), a failed prediction costs one re-run of the samples already served whatever the length
+    static constexpr size_t kGrow = 8;
+    static size_t grow(size_t len) { return std::min(kGrow * std::max<size_t>(len, 1), kMaxBlock); }
     // the cached block was rendered for exactly this call at its current sample
     static bool matches(const Slot &s, const Call &c) {
         if (s.dv.empty()) return s.sig.same(c);
@@ -618,7 +622,7 @@ private:
                 s.sd = s.ed;
                 s.si = s.ei;
             }
-            L = (s.len > 0 && (s.sig.same(c) || was_derived)) ? std::min(2 * s.nextLen, kMaxBlock) : 1;
+            L = (s.len > 0 && (s.sig.same(c) || was_derived)) ? grow(s.nextLen) : 1;
         }
         // derived arguments for the new block, as far as the producers' cached blocks reach
         std::vector<const Hyp *> use;
@@ -626,7 +630,7 @@ private:
         std::vector<std::vector<double>> dv0;
         const bool derived = mask && s.unstable == 0 && derive_for(s, mask, s.count, use, span);
         if (derived) {
-            if (consumed && L < 2) L = 2;  // the forms have just reproduced three calls: start growing
+            if (consumed && L < kGrow) L = kGrow;  // the forms have just reproduced three calls: start growing
             L = std::min(L, span);
             fill_derived(use, s.count, L, dv0);
             derived_blocks++;
@@ -649,7 +653,7 @@ private:
                 std::vector<const Hyp *> uu;
                 size_t uspan = 0;
                 if (!derive_for(*u, mask, u->count, uu, uspan)) continue;
-                if (std::min(std::max<size_t>(std::min(2 * u->nextLen, kMaxBlock), 2), uspan) != L) continue;
+                if (std::min(std::max<size_t>(grow(u->nextLen), kGrow), uspan) != L) continue;
                 std::vector<std::vector<double>> udv;
                 fill_derived(uu, u->count, L, udv);
                 Call uc = u->sig;
@@ -662,7 +666,7 @@ private:
                 G.dv.push_back(udv);
                 continue;
             }
-            if (std::min(2 * u->nextLen, kMaxBlock) != L) continue;
+            if (grow(u->nextLen) != L) continue;
             u->sd = u->ed;
             u->si = u->ei;
             G.m.push_back(u);
