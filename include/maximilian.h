@@ -388,19 +388,39 @@ private:
             // constants recovered from the two observations carry their rounding noise, amplified by the cancellation in the differences
             const double amp = 8.0 * DBL_EPSILON * (1.0 + (std::fabs(v) + std::fabs(vp)) / std::fabs(v - vp) + (std::fabs(x) + std::fabs(xp)) / std::fabs(x - xp));
             const double tol = std::min(amp, 1e-6);
-            if (x != 0.0 && ps_nice(v / x, 8.0 * DBL_EPSILON, h.a)) { h.form = 2; if (fits(h)) { push(h); continue; } }
-            if (ps_nice(v - x, tol, h.b)) { h.form = 3; if (fits(h)) { push(h); continue; } }
+            // a constant: the short decimal near the estimate if there is one (a literal), else the estimate itself and its
+            // neighbours (a variable of the patch, e.g. a pitch from mtof) -- whichever reproduces BOTH observations
+            auto settle = [&](double est, double &slot) {
+                double cand[6];
+                int nc = 0;
+                if (ps_nice(est, tol, cand[nc])) nc++;
+                const double up = std::nextafter(est, HUGE_VAL), dn = std::nextafter(est, -HUGE_VAL);
+                cand[nc++] = est;
+                cand[nc++] = up;
+                cand[nc++] = dn;
+                cand[nc++] = std::nextafter(up, HUGE_VAL);
+                cand[nc++] = std::nextafter(dn, -HUGE_VAL);
+                for (int i = 0; i < nc; i++) {
+                    slot = cand[i];
+                    if (fits(h)) return true;
+                }
+                return false;
+            };
+            if (x != 0.0) { h.form = 2; if (settle(v / x, h.a)) { push(h); continue; } }
+            h.form = 3; if (settle(v - x, h.b)) { push(h); continue; }
             double slope;
-            if (!ps_nice((v - vp) / (x - xp), tol, slope) || slope == 0.0) continue;
+            if (!ps_nice((v - vp) / (x - xp), tol, slope) || slope == 0.0) continue;  // (a multiplier is a literal)
             h.a = slope;
-            if (ps_nice(v - x * slope, tol, h.b)) { h.form = 4; if (fits(h)) { push(h); continue; } }
-            if (ps_nice(v / slope - x, tol, h.b)) { h.form = 5; if (fits(h)) { push(h); continue; } }
+            h.form = 4; if (settle(v - x * slope, h.b)) { push(h); continue; }
+            h.form = 5; if (settle(v / slope - x, h.b)) { push(h); continue; }
             h.form = 9;  // ((x + b) * a) + c with a small integer b (15.polysynth: 250 + ((pitch + lfo) * 1000))
-            for (int b = -12; b <= 12; b++) {
+            bool got = false;
+            for (int b = -12; b <= 12 && !got; b++) {
                 if (b == 0) continue;
                 h.b = (double)b;
-                if (ps_nice(v - (x + h.b) * slope, tol, h.c) && fits(h)) { push(h); break; }
+                got = settle(v - (x + h.b) * slope, h.c);
             }
+            if (got) push(h);
         }
         // two sources: the sum or the product of two recent outputs, optionally scaled
         for (size_t i = 0; i < recent.size() && i < 4; i++)
