@@ -60,19 +60,39 @@ inline void check(int status, const char *what) {
 constexpr size_t kMaxBlock = 512;
 
 template <typename T>
-struct DevBuf {  // grow-only device array
-    T *p = nullptr;
-    size_t n = 0;
+struct DevBuf {  // grow-only device array -- with a twin in pinned, device-mapped HOST memory for the renders of a few samples (`mapped`:
+                 // the kernel reads its arguments from and writes its results to host memory directly, no copy commands at all)
+    T *p = nullptr;  // the array of the current mode
+    T *dev = nullptr, *map = nullptr;
+    size_t n = 0, mn = 0;
+    bool mapped = false;
     T *need(size_t count) {
+        if (mapped) {
+            if (count > mn) {
+                if (map) mxg_host_free(map);
+                map = static_cast<T *>(mxg_host_alloc(count * sizeof(T)));
+                if (!map) throw std::runtime_error(std::string("mxg_host_alloc: ") + mxg_last_error());
+                mn = count;
+            }
+            return p = map;
+        }
         if (count > n) {
-            if (p) mxg_free(p);
-            p = static_cast<T *>(mxg_malloc(count * sizeof(T)));
-            if (!p) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+            if (dev) mxg_free(dev);
+            dev = static_cast<T *>(mxg_malloc(count * sizeof(T)));
+            if (!dev) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
             n = count;
         }
-        return p;
+        return p = dev;
     }
-    ~DevBuf() { if (p) mxg_free(p); }
+    void mode(bool m) { mapped = m; p = m ? map : dev; }
+    bool holds(const void *q) const {  // q points into the mapped twin
+        const char *c = static_cast<const char *>(q), *b = reinterpret_cast<const char *>(map);
+        return map && c >= b && c < b + mn * sizeof(T);
+    }
+    ~DevBuf() {
+        if (dev) mxg_free(dev);
+        if (map) mxg_host_free(map);
+    }
 };
 template <typename T>
 struct PinBuf {  // grow-only pinned host array
@@ -216,6 +236,16 @@ struct Group {
     PinBuf<int64_t> h_istate;
     PinBuf<unsigned char> h_stage;  // pinned staging of one enqueue's parameter uploads (asynchronous copies: no host wait per array)
     size_t stage_off = 0;
+    bool zc = false;  // this render is ZERO-COPY: state, arguments and results live in mapped host memory (renders of a few samples:
+                      // a launch and a stream wait instead of five to eight copy commands around them)
+    void set_mode(bool m) {
+        zc = m;
+        d_state.mode(m); d_par.mode(m); d_in.mode(m); d_out.mode(m);
+        d_istate.mode(m); d_ipar.mode(m); d_trig.mode(m);
+    }
+    bool in_mapped(const void *q) const {
+        return d_state.holds(q) || d_par.holds(q) || d_in.holds(q) || d_out.holds(q) || d_istate.holds(q) || d_ipar.holds(q) || d_trig.holds(q);
+    }
     bool restart = false;  // this render starts at the members' BLOCK START state again (a rewind): pools whose state is partly on the
                            // device (the delay line's memory) undo the block they rendered last before they render
     std::vector<std::vector<std::vector<double>>> dv;  // [member][argument][sample]: derived arguments of this render (empty: constant)
@@ -489,6 +519,10 @@ protected:
         G.stage_off = 0;
     }
     void put(Group &G, void *d_dst, const void *h_src, size_t bytes, const char *what) {
+        if (G.zc && G.in_mapped(d_dst)) {  // the destination IS host memory: written here, read by the kernel over the bus
+            std::memcpy(d_dst, h_src, bytes);
+            return;
+        }
         std::memcpy(G.h_stage.p + G.stage_off, h_src, bytes);
         check(mxg_memcpy_h2d_async(d_dst, G.h_stage.p + G.stage_off, bytes, stream), what);
         G.stage_off += (bytes + 15) & ~(size_t)15;
@@ -533,20 +567,28 @@ private:
         return -1;
     }
     // upload the members' start states and run one block synchronously; fills blk / ed / ei of every member
+    static constexpr size_t kZeroCopy = 64;  // outputs (samples x members) up to which a render runs on mapped host memory
+    static bool zero_copy_on() {
+        static const bool on = [] { const char *e = std::getenv("MXG_PS_ZEROCOPY"); return !(e && e[0] == '0'); }();
+        return on;
+    }
     void render_now(Group &G) {
         ensure_stream();
         const size_t n = G.m.size(), L = G.L;
-        double *hs = G.h_state.need((size_t)nD * n + 1);
-        int64_t *hi = G.h_istate.need((size_t)nI * n + 1);
+        G.set_mode(zero_copy_on() && L * n <= kZeroCopy);
+        double *hs = G.zc ? G.d_state.need((size_t)nD * n + 1) : G.h_state.need((size_t)nD * n + 1);
+        int64_t *hi = G.zc ? G.d_istate.need((size_t)nI * n + 1) : G.h_istate.need((size_t)nI * n + 1);
         for (size_t j = 0; j < n; j++) {
             for (int k = 0; k < nD; k++) hs[(size_t)k * n + j] = G.m[j]->sd[(size_t)k];
             for (int k = 0; k < nI; k++) hi[(size_t)k * n + j] = G.m[j]->si[(size_t)k];
         }
-        if (nD) check(mxg_memcpy_h2d_async(G.d_state.need((size_t)nD * n), hs, sizeof(double) * nD * n, stream), "h2d state");
-        if (nI) check(mxg_memcpy_h2d_async(G.d_istate.need((size_t)nI * n), hi, sizeof(int64_t) * nI * n, stream), "h2d istate");
+        if (!G.zc) {
+            if (nD) check(mxg_memcpy_h2d_async(G.d_state.need((size_t)nD * n), hs, sizeof(double) * nD * n, stream), "h2d state");
+            if (nI) check(mxg_memcpy_h2d_async(G.d_istate.need((size_t)nI * n), hi, sizeof(int64_t) * nI * n, stream), "h2d istate");
+        }
         G.d_out.need(L * n);
         enqueue(G);
-        fetch(G);
+        if (!G.zc) fetch(G);
         check(mxg_stream_sync(stream), "mxg_stream_sync");
         install(G);
         launches++;
@@ -559,13 +601,15 @@ private:
     }
     void install(Group &G) {
         const size_t n = G.m.size(), L = G.L;
+        const double *ho = G.zc ? G.d_out.p : G.h_out.p, *hsd = G.zc ? G.d_state.p : G.h_state.p;
+        const int64_t *hsi = G.zc ? G.d_istate.p : G.h_istate.p;
         for (size_t j = 0; j < n; j++) {
             Slot *u = G.m[j];
             if (!u) continue;
             u->blk.resize(L);
-            for (size_t t = 0; t < L; t++) u->blk[t] = G.h_out.p[t * n + j];
-            for (int k = 0; k < nD; k++) u->ed[(size_t)k] = G.h_state.p[(size_t)k * n + j];
-            for (int k = 0; k < nI; k++) u->ei[(size_t)k] = G.h_istate.p[(size_t)k * n + j];
+            for (size_t t = 0; t < L; t++) u->blk[t] = ho[t * n + j];
+            for (int k = 0; k < nD; k++) u->ed[(size_t)k] = hsd[(size_t)k * n + j];
+            for (int k = 0; k < nI; k++) u->ei[(size_t)k] = hsi[(size_t)k * n + j];
             u->pos = 0;
             u->len = L;
             u->sig = G.sig[j];
