@@ -1114,12 +1114,14 @@ public:
 class maxiMix {
     static void run(int channels, double input, double x, double y, double z, double *out) {
         using maxigpu::ps::check;
-        static maxigpu::ps::DevBuf<double> d;  // [in, x, y, z | bus 8 | mix 8]
-        double *p = d.need(20);
-        const double h[4] = {input, x, y, z};
-        check(mxg_memcpy_h2d(p, h, sizeof(h), nullptr), "h2d mix");
+        // [in, x, y, z | bus 8 | mix 8] in pinned, device-mapped host memory: the kernel reads and writes it over the bus -- a launch
+        // and a wait, no copy commands (as the pools' zero-copy renders)
+        static maxigpu::ps::PinBuf<double> *d = new maxigpu::ps::PinBuf<double>;  // (never destroyed: static-destruction order)
+        double *p = d->need(20);
+        p[0] = input; p[1] = x; p[2] = y; p[3] = z;
         check(mxg_mix_bus(channels, 1, 1, p, p + 1, p + 2, p + 3, p + 4, p + 12, nullptr), "mxg_mix_bus");
-        check(mxg_memcpy_d2h(out, p + 4, sizeof(double) * channels, nullptr), "d2h mix");
+        check(mxg_stream_sync(nullptr), "mxg_stream_sync");
+        for (int c = 0; c < channels; c++) out[c] = p[4 + c];
     }
 
 public:
