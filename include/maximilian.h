@@ -152,6 +152,7 @@ struct Slot {
     std::vector<std::vector<double>> dv;  // dv[k]: per-sample value of argument k over the cached block (empty: the constant sig.a[k])
     double lastArg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool hasLastArg = false;
+    uint64_t misses = 0;           // calls that were not served from the cached block (statistics)
     int unstable = 0;              // > 0: an argument NO form explains changed a few calls ago -- blocks of one sample until it settles
     int fitFails[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // consecutive fruitless searches per argument (the search backs off)
     uint64_t fitAgain[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -396,7 +397,7 @@ private:
         for (Slot *X : ps_live())
             if (X != &s && X->nOut >= 1 && ps_tick() - X->lastTick < 64) recent.push_back(X);
         std::sort(recent.begin(), recent.end(), [](const Slot *p, const Slot *q) { return p->lastTick > q->lastTick; });
-        if (recent.size() > 6) recent.resize(6);
+        if (recent.size() > 12) recent.resize(12);
         const double vp = s.lastArg[k];  // the argument one call ago (s.hasLastArg)
         size_t added = 0;
         auto push = [&](Hyp h) {
@@ -647,6 +648,7 @@ private:
         s.group = -1;
     }
     double miss(Slot &s, const Call &c) {
+        s.misses++;
         const bool consumed = s.pos >= s.len;
         if (consumed && s.group >= 0 && s.sig.same(c)) {  // the asynchronous next block was rendered for exactly this call
             Group &G = *groups[(size_t)s.group];

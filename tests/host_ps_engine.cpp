@@ -1,0 +1,111 @@
+// tests/host_ps_engine.cpp -- the per-sample engine of include/maximilian.h (block prediction, derived arguments, rewinds, lock-step
+// groups, zero-copy renders) driven on the HOST: the C-ABI entry points the engine itself uses (memory, copies, streams, events) are
+// stubbed with plain host memory, and a test pool renders a simple recurrence on the CPU.  This is a harness for the engine's LOGIC
+// (tests/test_ps_engine_host.py, -m "not gpu"); the product pools render through libmaxigpu.so and have no such path.
+//
+// A "patch" of eight objects is called once per sample, in order, with arguments computed from the values the earlier calls RETURNED
+// -- constants, affine forms of one output, the sum of two outputs, a non-linear map, a constant that changes now and then, and a
+// one-call perturbation every few hundred samples (a prediction that fails inside a block).  Every returned value must equal, bit for
+// bit, what the same recurrence gives when it is simply evaluated call by call; the derivable objects must need far fewer renders than
+// calls, the non-linear one about one per call.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../include/maxigpu.h"
+
+// ---- the C-ABI the engine uses, on host memory ------------------------------------------------------------------------------------
+extern "C" {
+int mxg_init(int) { return 0; }
+const char *mxg_last_error(void) { return "stub"; }
+void *mxg_malloc(size_t b) { return std::calloc(b ? b : 8, 1); }
+int mxg_free(void *p) { std::free(p); return 0; }
+void *mxg_host_alloc(size_t b) { return std::calloc(b ? b : 8, 1); }
+int mxg_host_free(void *p) { std::free(p); return 0; }
+int mxg_memcpy_h2d_async(void *d, const void *s, size_t b, void *) { std::memcpy(d, s, b); return 0; }
+int mxg_memcpy_d2h_async(void *d, const void *s, size_t b, void *) { std::memcpy(d, s, b); return 0; }
+int mxg_memcpy_d2d_async(void *d, const void *s, size_t b, void *) { std::memmove(d, s, b); return 0; }
+void *mxg_stream_create(void) { static int dummy; return &dummy; }
+int mxg_stream_destroy(void *) { return 0; }
+int mxg_stream_sync(void *) { return 0; }
+void *mxg_event_create(void) { return std::malloc(8); }
+int mxg_event_destroy(void *e) { std::free(e); return 0; }
+int mxg_event_record(void *, void *) { return 0; }
+int mxg_event_sync(void *) { return 0; }
+int mxg_event_query(void *) { return 1; }
+}
+
+#include "../include/maximilian.h"
+
+using namespace maxigpu::ps;
+
+// a ramp whose rate follows a0 (it never settles, so every downstream argument keeps moving):
+//   y <- y + 0.001 + a0 * 0.001, wrapped into [0, 1);   out = (2 y - 1) * a2 + a1     (state: y; a0, a1 derivable, a2 a plain parameter)
+static double step(double &y, double a0, double a1, double a2) {
+    y = y + 0.001 + a0 * 0.001;
+    if (y >= 1.0) y -= 1.0;
+    if (y < 0.0) y += 1.0;
+    return (2.0 * y - 1.0) * a2 + a1;
+}
+struct TestPool : Pool {
+    TestPool() : Pool(1, 0) {}
+    unsigned derivable(int) const override { return 3u; }
+    void enqueue(Group &G) override {
+        const size_t n = G.m.size();
+        for (size_t j = 0; j < n; j++) {
+            double y = G.d_state.p[j];
+            for (size_t t = 0; t < G.L; t++) G.d_out.p[t * n + j] = step(y, G.arg(j, 0, t), G.arg(j, 1, t), G.sig[j].a[2]);
+            G.d_state.p[j] = y;
+        }
+    }
+};
+struct Obj {
+    Slot slot;
+    double y = 0;  // the truth: the same recurrence, call by call
+    Obj() { pool<TestPool>().attach(slot); }
+    ~Obj() { pool<TestPool>().detach(slot); }
+    double call(double a0, double a1, double a2, double &truth) {
+        Call c;
+        c.method = 0;
+        c.a[0] = a0; c.a[1] = a1; c.a[2] = a2;
+        truth = step(y, a0, a1, a2);
+        return pool<TestPool>().call(slot, c);
+    }
+};
+
+int main(int argc, char **argv) {
+    const long frames = argc > 1 ? std::atol(argv[1]) : 30000;
+    Obj A, B, C, D, E, F0, F1, G;
+    long bad = 0, calls = 0;
+    auto chk = [&](double got, double truth, const char *who, long n) {
+        calls++;
+        if (std::memcmp(&got, &truth, 8)) {
+            if (bad < 5) std::printf("MISMATCH %s at frame %ld: %.17g != %.17g\n", who, n, got, truth);
+            bad++;
+        }
+    };
+    double gain = 0.25, t;
+    for (long n = 0; n < frames; n++) {
+        if (n % 4100 == 4099) gain = gain == 0.25 ? 0.75 : 0.25;  // a parameter that changes now and then
+        const double a = A.call(0.37, 0.0, 1.0, t); chk(a, t, "A (constant arguments)", n);
+        double barg = a * 3.0 + 1.0;                                   // x * a + b
+        if (n % 777 == 776) barg += 1e-9;                              // one call off the form: a prediction fails inside a block
+        const double b = B.call(barg, 0.0, gain, t); chk(b, t, "B (x*3+1, perturbed every 777 frames)", n);
+        const double c = C.call(a + b, 0.5, 1.0, t); chk(c, t, "C (x1 + x2)", n);
+        const double d = D.call(std::fabs(std::sin(c)), 0.0, 1.0, t); chk(d, t, "D (a non-linear map: never derived)", n);
+        const double e = E.call((c + 2.0) * 0.125, b, 0.5, t); chk(e, t, "E ((x+b)*a and a second derived argument)", n);
+        const double f0 = F0.call(e, 0.0, 1.0, t); chk(f0, t, "F0 (identity; lock-step with F1)", n);
+        const double f1 = F1.call(e, 0.0, 1.0, t); chk(f1, t, "F1", n);
+        const double g = G.call(f0 * f1, 523.2511306011972 + (a * 1.5), 1.0, t); chk(g, t, "G (x1*x2; x*a + a constant that is no short decimal)", n);
+    }
+    const Obj *objs[8] = {&A, &B, &C, &D, &E, &F0, &F1, &G};
+    const char *names = "ABCDEFfG";
+    for (int i = 0; i < 8; i++) std::printf("  %c: %llu of %ld calls not served from a cached block\n", names[i], (unsigned long long)objs[i]->slot.misses, frames);
+    TestPool &P = pool<TestPool>();
+    std::printf("%ld frames, %ld calls, %ld mismatches; %zu renders (%zu blocks with derived arguments, %zu asynchronous blocks)\n", frames, calls, bad,
+                P.launches, P.derived_blocks, P.async_hits);
+    // (eight objects: one render per call would be `calls` renders; D alone -- a non-linear map -- needs ~frames of them.  The caller
+    // judges the counts: they depend on MXG_PS_DERIVE.)
+    return bad == 0 ? 0 : 1;
+}
