@@ -74,7 +74,84 @@ struct Obj {
     }
 };
 
+// ---- randomised patches: `fuzz <frames> <seed>` ---------------------------------------------------------------------------------
+// A random graph of objects (each argument a constant, a form of one or two EARLIER objects' outputs, or a non-linear map), random
+// events (a one-call perturbation, a constant that changes, an object's state settled through the pool as a setter does, an object
+// destroyed and replaced while others' forms still name it), compared call by call with the plain evaluation.
+struct Rng {
+    unsigned long long s;
+    unsigned next() { s = s * 6364136223846793005ULL + 1442695040888963407ULL; return (unsigned)(s >> 33); }
+    double uni() { return next() / 2147483648.0; }
+    int below(int n) { return (int)(next() % (unsigned)n); }
+};
+struct Recipe { int kind = 0, p1 = 0, p2 = 0; double a = 1, b = 0; };  // 0 const b | 1 x | 2 x*a+b | 3 (x+b)*a | 4 x1+x2 | 5 x1*x2 | 6 sin(x) | 7 (x1+x2)*a
+static double eval(const Recipe &r, const double *out) {
+    double t;
+    switch (r.kind) {
+        case 1: return out[r.p1];
+        case 2: t = out[r.p1] * r.a; t = t + r.b; return t;
+        case 3: t = out[r.p1] + r.b; t = t * r.a; return t;
+        case 4: t = out[r.p1] + out[r.p2]; return t;
+        case 5: t = out[r.p1] * out[r.p2]; return t;
+        case 6: return std::sin(out[r.p1] * 3.0);
+        case 7: t = out[r.p1] + out[r.p2]; t = t * r.a; return t;
+    }
+    return r.b;
+}
+static int fuzz(long frames, unsigned long long seed) {
+    Rng R{seed * 2654435761ULL + 12345};
+    const int N = 6 + R.below(7);
+    const double nice[8] = {0.5, 2.0, 1.5, 0.125, 3.0, 10.0, 0.75, 440.0};
+    std::vector<Obj *> obj((size_t)N);
+    std::vector<Recipe> r0((size_t)N), r1((size_t)N);
+    std::vector<double> par((size_t)N, 1.0), out((size_t)N, 0.0);
+    auto recipe = [&](int i) {
+        Recipe r;
+        r.kind = i == 0 ? 0 : R.below(8);
+        r.p1 = i ? R.below(i) : 0;
+        r.p2 = i ? R.below(i) : 0;
+        r.a = nice[R.below(8)] * (R.below(4) ? 1.0 : 0.001);
+        r.b = R.below(3) ? nice[R.below(8)] * 0.01 : R.uni();  // a short decimal, or any double
+        return r;
+    };
+    for (int i = 0; i < N; i++) { obj[(size_t)i] = new Obj; r0[(size_t)i] = recipe(i); r1[(size_t)i] = recipe(i); if (R.below(2)) r1[(size_t)i].kind = 0; }
+    long bad = 0;
+    for (long n = 0; n < frames; n++) {
+        const int ev = R.below(400);
+        const int who = R.below(N);
+        if (ev == 0) r0[(size_t)who].b += 0.25;                         // a constant changes
+        if (ev == 1) par[(size_t)who] = par[(size_t)who] == 1.0 ? 0.5 : 1.0;
+        if (ev == 2) {                                                   // a setter: settle the object, edit its state, mirror the edit
+            pool<TestPool>().settle(obj[(size_t)who]->slot);
+            obj[(size_t)who]->slot.sd[0] = 0.125;
+            obj[(size_t)who]->y = 0.125;
+        }
+        if (ev == 3 && who > 0) {                                        // the object goes away and a fresh one takes its place
+            delete obj[(size_t)who];
+            obj[(size_t)who] = new Obj;
+        }
+        if (ev == 4) r0[(size_t)who] = recipe(who);                      // the patch changes what it feeds the object
+        for (int i = 0; i < N; i++) {
+            double a0 = eval(r0[(size_t)i], out.data()), a1 = eval(r1[(size_t)i], out.data());
+            if (ev == 5 && i == who) a0 += 1e-7;                         // one call off every form
+            double t;
+            const double got = obj[(size_t)i]->call(a0, a1, par[(size_t)i], t);
+            if (std::memcmp(&got, &t, 8)) {
+                if (bad < 5) std::printf("MISMATCH seed %llu object %d of %d frame %ld: %.17g != %.17g\n", seed, i, N, n, got, t);
+                bad++;
+            }
+            out[(size_t)i] = got;
+        }
+    }
+    TestPool &P = pool<TestPool>();
+    std::printf("fuzz seed %llu: %d objects, %ld frames, %ld mismatches; %zu renders, %zu blocks with derived arguments\n", seed, N, frames, bad, P.launches,
+                P.derived_blocks);
+    for (Obj *o : obj) delete o;
+    return bad == 0 ? 0 : 1;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && !std::strcmp(argv[1], "fuzz")) return fuzz(argc > 2 ? std::atol(argv[2]) : 20000, argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 1);
     const long frames = argc > 1 ? std::atol(argv[1]) : 30000;
     Obj A, B, C, D, E, F0, F1, G;
     long bad = 0, calls = 0;

@@ -47,3 +47,12 @@ def test_same_values_without_the_prediction_and_without_zero_copy(harness):
     assert renders > 6 * FRAMES, out                               # "the same arguments as the last call" only: a render per call
     rc, bad, renders, derived, misses, out = run(harness, MXG_PS_ZEROCOPY="0")
     assert rc == 0 and bad == 0 and derived > 100, out
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 5, 8, 13, 21, 34])
+def test_random_patches_with_setters_replacements_and_perturbations(harness, seed):
+    """`fuzz`: a random graph (every argument a constant, a form of earlier objects' outputs, or a sine of one), with random events --
+    a one-call perturbation, a changed constant, a setter (settle + state edit), an object destroyed and replaced while other objects'
+    forms still name it, a changed recipe -- every returned value bit-identical to the call-by-call evaluation."""
+    r = subprocess.run([harness, "fuzz", "12000", str(seed)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-1500:]
