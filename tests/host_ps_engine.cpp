@@ -15,25 +15,41 @@
 
 #include "../include/maxigpu.h"
 
-// ---- the C-ABI the engine uses, on host memory ------------------------------------------------------------------------------------
+// ---- the C-ABI the engine uses, on host memory, with a DEFERRED stream ------------------------------------------------------------
+// Copies, kernels (the test pool's renders) and event records are queued and run only when the host waits (stream / event sync) or
+// when an event is polled -- in order, like a stream -- so the engine's asynchronous next-block renders, event polls and buffer
+// re-use are exercised against work that has really not happened yet.  (MXG_STUB_EAGER=1: everything runs at once.)
+#include <deque>
+#include <functional>
+#include <vector>
+static std::deque<std::function<void()>> g_q;
+static const bool g_eager = [] { const char *e = std::getenv("MXG_STUB_EAGER"); return e && e[0] == '1'; }();
+static void submit(std::function<void()> f) { if (g_eager) f(); else g_q.push_back(std::move(f)); }
+static void drain() { while (!g_q.empty()) { auto f = std::move(g_q.front()); g_q.pop_front(); f(); } }
+struct StubEvent { bool done = true; };
 extern "C" {
 int mxg_init(int) { return 0; }
 const char *mxg_last_error(void) { return "stub"; }
 void *mxg_malloc(size_t b) { return std::calloc(b ? b : 8, 1); }
-int mxg_free(void *p) { std::free(p); return 0; }
+int mxg_free(void *p) { drain(); std::free(p); return 0; }
 void *mxg_host_alloc(size_t b) { return std::calloc(b ? b : 8, 1); }
-int mxg_host_free(void *p) { std::free(p); return 0; }
-int mxg_memcpy_h2d_async(void *d, const void *s, size_t b, void *) { std::memcpy(d, s, b); return 0; }
-int mxg_memcpy_d2h_async(void *d, const void *s, size_t b, void *) { std::memcpy(d, s, b); return 0; }
-int mxg_memcpy_d2d_async(void *d, const void *s, size_t b, void *) { std::memmove(d, s, b); return 0; }
+int mxg_host_free(void *p) { drain(); std::free(p); return 0; }
+// (an asynchronous H2D copy reads its pinned source when the stream reaches it: the engine must keep it intact until then)
+int mxg_memcpy_h2d_async(void *d, const void *s, size_t b, void *) { submit([=] { std::memcpy(d, s, b); }); return 0; }
+int mxg_memcpy_d2h_async(void *d, const void *s, size_t b, void *) { submit([=] { std::memcpy(d, s, b); }); return 0; }
+int mxg_memcpy_d2d_async(void *d, const void *s, size_t b, void *) { submit([=] { std::memmove(d, s, b); }); return 0; }
 void *mxg_stream_create(void) { static int dummy; return &dummy; }
-int mxg_stream_destroy(void *) { return 0; }
-int mxg_stream_sync(void *) { return 0; }
-void *mxg_event_create(void) { return std::malloc(8); }
-int mxg_event_destroy(void *e) { std::free(e); return 0; }
-int mxg_event_record(void *, void *) { return 0; }
-int mxg_event_sync(void *) { return 0; }
-int mxg_event_query(void *) { return 1; }
+int mxg_stream_destroy(void *) { drain(); return 0; }
+int mxg_stream_sync(void *) { drain(); return 0; }
+void *mxg_event_create(void) { return new StubEvent; }
+int mxg_event_destroy(void *e) { drain(); delete static_cast<StubEvent *>(e); return 0; }
+int mxg_event_record(void *e, void *) { StubEvent *ev = static_cast<StubEvent *>(e); ev->done = false; submit([ev] { ev->done = true; }); return 0; }
+int mxg_event_sync(void *e) { StubEvent *ev = static_cast<StubEvent *>(e); while (!ev->done && !g_q.empty()) { auto f = std::move(g_q.front()); g_q.pop_front(); f(); } return 0; }
+int mxg_event_query(void *e) {  // a poll lets the stream make a little progress, like a device running beside the host
+    StubEvent *ev = static_cast<StubEvent *>(e);
+    for (int i = 0; i < 3 && !ev->done && !g_q.empty(); i++) { auto f = std::move(g_q.front()); g_q.pop_front(); f(); }
+    return ev->done ? 1 : 0;
+}
 }
 
 #include "../include/maximilian.h"
@@ -51,13 +67,21 @@ static double step(double &y, double a0, double a1, double a2) {
 struct TestPool : Pool {
     TestPool() : Pool(1, 0) {}
     unsigned derivable(int) const override { return 3u; }
-    void enqueue(Group &G) override {
-        const size_t n = G.m.size();
+    void enqueue(Group &G) override {  // "launch": the arguments are captured now (as a launch copies its parameters), the work runs later
+        const size_t n = G.m.size(), L = G.L;
+        std::vector<double> a0(L * n), a1(L * n), a2(n);
         for (size_t j = 0; j < n; j++) {
-            double y = G.d_state.p[j];
-            for (size_t t = 0; t < G.L; t++) G.d_out.p[t * n + j] = step(y, G.arg(j, 0, t), G.arg(j, 1, t), G.sig[j].a[2]);
-            G.d_state.p[j] = y;
+            a2[j] = G.sig[j].a[2];
+            for (size_t t = 0; t < L; t++) { a0[t * n + j] = G.arg(j, 0, t); a1[t * n + j] = G.arg(j, 1, t); }
         }
+        double *st = G.d_state.p, *out = G.d_out.p;
+        submit([=] {
+            for (size_t j = 0; j < n; j++) {
+                double y = st[j];
+                for (size_t t = 0; t < L; t++) out[t * n + j] = step(y, a0[t * n + j], a1[t * n + j], a2[j]);
+                st[j] = y;
+            }
+        });
     }
 };
 struct Obj {
