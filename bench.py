@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="config2, one GPU: skip the extra measurements of the default run (single-buffer pass, write-ceiling fills, "
                          "the 131 072-voice bank) -- for profiler passes, so that only the headline launches are traced")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="config2, one GPU: skip the `configs` object of the default run (configs 3, 4, 4-mfma, 5 and the fused-mixdown "
+                         "step measured the short way in the same process)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: ranks of a --gpus N run share the visible GPUs (rank r uses device r mod count), the "
                          "id/barrier traffic goes over gloo and the mix queue reduces locally (no RCCL: two ranks cannot share "
@@ -198,8 +201,6 @@ def main():
     # stereo mixdown (BASELINE configs[4]), so it always mixes.
     mixdown = args.mixdown or {"config2": "fused" if world > 1 else "off", "config3": "separate" if world > 1 else "off",
                                "config4": "off", "config5": "fused"}[args.workload]
-    queue = None
-    W = {}
 
     class OscBank:
         """One rank's maxiOsc bank of `Vb` voices with its block buffers; step() renders one block (K1, or K1m / K1 + K3 with
@@ -224,10 +225,10 @@ def main():
             return self.outs[self.i % len(self.outs)].data_ptr()
 
         def render_mix(self, slot):
-            if self.mix == "fused":  # K1m: render + store + mix partials in one pass
-                chk(L.mxg_osc_render_mix(wf, self.V, B, self.freq.data_ptr(), None, None, self.phase.data_ptr(),
-                                         self.hold.data_ptr(), None if args.mix_only else self.out_ptr(), self.pan.data_ptr(),
-                                         slot, stream), "mxg_osc_render_mix")
+            if self.mix == "fused":  # K1m: render + store + per-workgroup mix rows in one pass; the (grouped) queue adds the rows
+                chk(L.mxg_osc_render_mix_rows(wf, self.V, B, self.freq.data_ptr(), None, None, self.phase.data_ptr(),
+                                              self.hold.data_ptr(), None if args.mix_only else self.out_ptr(), self.pan.data_ptr(),
+                                              slot, stream), "mxg_osc_render_mix_rows")
             else:                    # K1 then K3 re-reading the block
                 chk(L.mxg_osc_render(wf, self.V, B, self.freq.data_ptr(), 0, None, None, self.phase.data_ptr(),
                                      self.hold.data_ptr(), self.out_ptr(), stream), "mxg_osc_render")
@@ -260,162 +261,176 @@ def main():
         torch.cuda.synchronize()
         return a.elapsed_time(b) / n
 
-    local_queue = None  # the same mix queue without a communicator (device copies): the step with the reduce taken out
-    if args.workload == "config2":
-        if mixdown != "off":
-            queue = RcclMixQueue(comm, B * 2, args.mix_depth, 0, stream)
-        bank = OscBank(V, nbuf, mixdown, queue, lo, V * world)
-        if queue is not None and world > 1:
-            local_queue = RcclMixQueue(None, B * 2, args.mix_depth, 0, stream)
+    def build_workload(workload, mixdown, mfcc_method="sparse", voice_mode=0):
+        """One BASELINE config as a dict: step(), samples per step, the dominant kernel and its algorithmic bytes (or flops) per
+        step, the CPU baseline closure, the mix queue(s)."""
+        queue = None
+        local_queue = None  # the same mix queue without a communicator (device copies): the step with the reduce taken out
+        W = {}
+        if workload == "config2":
+            # fused: the render leaves one partial mix row per workgroup of 256 voices in the queue's slot and the queue adds the rows of
+            # a whole batch on ITS stream in front of the reduce -- the render stream carries one kernel per block
+            groups2 = L.mxg_osc_mix_groups(V) if mixdown == "fused" else 1
+            if mixdown != "off":
+                queue = RcclMixQueue(comm, B * 2, args.mix_depth, 0, stream, groups=groups2)
+            bank = OscBank(V, nbuf, mixdown, queue, lo, V * world)
+            if queue is not None and world > 1:
+                local_queue = RcclMixQueue(None, B * 2, args.mix_depth, 0, stream, groups=groups2)
 
-        def cpu():
-            return _baseline(lambda o, n, th: o.time_osc(wf, bank.freq_h, n, threads=th), lambda n: V * n, (256, 1 << 18),
-                             "samples per voice", "%d voices maxiOsc::%s, voice-inner loop" % (V, args.waveform))
-        W = dict(step=bank.step, samples=V * B, dominant=bank.dominant, algo_bytes=bank.algo, dtype="f64", cpu=cpu,
-                 local_step=bank.with_queue(local_queue).step if local_queue is not None else None,
-                 workload="configs[1]: %d-voice maxiOsc::%s wavetable bank per GPU, block=512, fp64 out[n][v] stored%s, output "
-                          "rotated over %d block buffer(s) = %.2f GB touched before a line is rewritten"
-                          % (V, args.waveform, {"fused": " + fused maxiMix::stereo mixdown", "separate": " + K3 mixdown",
-                                                "off": ""}[mixdown], nbuf, nbuf * V * B * 8 / 1e9))
-    elif args.workload == "config3":
-        K = 128
-        mode = args.voice_mode
-        vb = mx.maxiVoiceBank(V, stream=stream)
-        vb.env.setAttack(10); vb.env.setDecay(100); vb.env.setSustain(0.5); vb.env.setRelease(500)
-        f3 = np.minimum(freq_h, 5000.0)
-        cu3, rs3 = (200 + 4 * f3) if mode == 0 else np.full(V, 10000.0), 1.0 + (np.arange(lo, hi) % 16)
-        outs3 = [mx.DeviceBuffer((B, V), zero=False) for _ in range(nbuf)]
-        vb.render(mode, f3, cu3, rs3, np.zeros(1, np.int32), 1, out=mx.DeviceBuffer((1, V)))
-        vf, vcu, vrs, vcoef, _ = vb._keep
-        vpar, vhold = vb.env._params()
-        gate = mx.DeviceBuffer.from_numpy(((np.arange(K * B) % 44100) < 22050).astype(np.int32))
-        pan3 = mx.DeviceBuffer.from_numpy(pan_h)
-        blk = [0]
-        if mixdown != "off":
-            queue = RcclMixQueue(comm, B * 2, args.mix_depth, 0, stream)
-            if world > 1:
-                local_queue = RcclMixQueue(None, B * 2, args.mix_depth, 0, stream)
+            def cpu():
+                return _baseline(lambda o, n, th: o.time_osc(wf, bank.freq_h, n, threads=th), lambda n: V * n, (256, 1 << 18),
+                                 "samples per voice", "%d voices maxiOsc::%s, voice-inner loop" % (V, args.waveform))
+            W = dict(bank=bank, step=bank.step, samples=V * B, dominant=bank.dominant, algo_bytes=bank.algo, dtype="f64", cpu=cpu,
+                     local_step=bank.with_queue(local_queue).step if local_queue is not None else None,
+                     workload="configs[1]: %d-voice maxiOsc::%s wavetable bank per GPU, block=512, fp64 out[n][v] stored%s, output "
+                              "rotated over %d block buffer(s) = %.2f GB touched before a line is rewritten"
+                              % (V, args.waveform, {"fused": " + fused maxiMix::stereo mixdown", "separate": " + K3 mixdown",
+                                                    "off": ""}[mixdown], nbuf, nbuf * V * B * 8 / 1e9))
+        elif workload == "config3":
+            K = 128
+            mode = voice_mode
+            vb = mx.maxiVoiceBank(V, stream=stream)
+            vb.env.setAttack(10); vb.env.setDecay(100); vb.env.setSustain(0.5); vb.env.setRelease(500)
+            f3 = np.minimum(freq_h, 5000.0)
+            cu3, rs3 = (200 + 4 * f3) if mode == 0 else np.full(V, 10000.0), 1.0 + (np.arange(lo, hi) % 16)
+            outs3 = [mx.DeviceBuffer((B, V), zero=False) for _ in range(nbuf)]
+            vb.render(mode, f3, cu3, rs3, np.zeros(1, np.int32), 1, out=mx.DeviceBuffer((1, V)))
+            vf, vcu, vrs, vcoef, _ = vb._keep
+            vpar, vhold = vb.env._params()
+            gate = mx.DeviceBuffer.from_numpy(((np.arange(K * B) % 44100) < 22050).astype(np.int32))
+            pan3 = mx.DeviceBuffer.from_numpy(pan_h)
+            blk = [0]
+            if mixdown != "off":
+                queue = RcclMixQueue(comm, B * 2, args.mix_depth, 0, stream)
+                if world > 1:
+                    local_queue = RcclMixQueue(None, B * 2, args.mix_depth, 0, stream)
 
-        def voice_block():
-            o3 = outs3[blk[0] % nbuf]
-            chk(L.mxg_voice_render(mode, V, B, vf.ptr, vcu.ptr, vrs.ptr, vcoef.ptr if vcoef is not None else None,
-                                   gate.ptr + 4 * (blk[0] % K) * B, 0, vpar.ptr, vhold.ptr, vb.osc_state.ptr, vb.flt_state.ptr,
-                                   vb.env.dstate.ptr, vb.env.istate.ptr, o3.ptr, stream), "mxg_voice_render")
-            blk[0] += 1
-            return o3
+            def voice_block():
+                o3 = outs3[blk[0] % nbuf]
+                chk(L.mxg_voice_render(mode, V, B, vf.ptr, vcu.ptr, vrs.ptr, vcoef.ptr if vcoef is not None else None,
+                                       gate.ptr + 4 * (blk[0] % K) * B, 0, vpar.ptr, vhold.ptr, vb.osc_state.ptr, vb.flt_state.ptr,
+                                       vb.env.dstate.ptr, vb.env.istate.ptr, o3.ptr, stream), "mxg_voice_render")
+                blk[0] += 1
+                return o3
 
-        def render_mix3(slot):
-            o3 = voice_block()
-            chk(L.mxg_mix_stereo(V, B, o3.ptr, pan3.ptr, slot, stream), "mxg_mix_stereo")
-        step = voice_block if mixdown == "off" else MixdownStep(render_mix3, queue)
+            def render_mix3(slot):
+                o3 = voice_block()
+                chk(L.mxg_mix_stereo(V, B, o3.ptr, pan3.ptr, slot, stream), "mxg_mix_stereo")
+            step = voice_block if mixdown == "off" else MixdownStep(render_mix3, queue)
 
-        def cpu():
-            return _baseline(lambda o, n, th: o.time_voice(mode, f3, cu3, rs3, n, threads=th), lambda n: V * n, (32, 1 << 16),
-                             "samples per voice", "%d voices saw->lores->adsr (mode %d), voice-inner loop of 15.polysynth" % (V, mode))
-        W = dict(step=step, samples=V * B, dominant="voice_kernel", algo_bytes=(8.0 + 176.0 / B) * V * B, dtype="f64", cpu=cpu,
-                 local_step=MixdownStep(render_mix3, local_queue) if local_queue is not None else None,
-                 workload="configs[2]: fused subtractive voice maxiOsc::saw -> maxiFilter::lores -> maxiEnv::adsr (mode %d), %d voices "
-                          "per GPU, block=512, gate(n) = (n mod 44100) < 22050 cycled over 128 blocks, output rotated over %d block "
-                          "buffer(s)" % (mode, V, nbuf))
-    elif args.workload == "config4":
-        NF = 1 << 20
-        g = torch.Generator(device=dev); g.manual_seed(0x4D415849 + rank)
-        sig = torch.empty(NF * 1024, dtype=torch.float32, device=dev)
-        for c0 in range(0, NF, 1 << 16):
-            n = torch.arange(c0 * 1024, (c0 + (1 << 16)) * 1024, dtype=torch.float64, device=dev)
-            k = torch.div(n, 1024, rounding_mode="floor")
-            sig[c0 * 1024:(c0 + (1 << 16)) * 1024] = (0.4 * torch.sin(2 * np.pi * 220 * n / 44100) + 0.3 * torch.sin(
-                2 * np.pi * (440 + 0.01 * k) * n / 44100) + 0.1 * (2 * torch.rand(n.numel(), dtype=torch.float64, device=dev,
-                                                                                  generator=g) - 1)).to(torch.float32)
-            del n, k
-        mfma = args.mfcc_method == "mfma"
-        kdim = 512 if args.mfma_fullk else 256  # bins the MFMA kernel contracts over (weights beyond bin 232 are zero)
-        if mfma:
-            L.mxg_tune(b"mfcc_mfma_fullk", 1 if args.mfma_fullk else 0)
-        mfcc = torch.empty((NF, 13), dtype=torch.float64, device=dev)
-        fplan = mx.maxiFFT(); fplan.setup(1024, 1024, 1024)
-        mplan = mx.maxiMFCC(); mplan.setup(512, 42, 13, 20.0, 20000.0)
-        fused_ok = hasattr(L, "mxg_fft_mfcc_batch") and not mfma
-        mags = None if fused_ok else torch.empty((NF, 512), dtype=torch.float32, device=dev)
+            def cpu():
+                return _baseline(lambda o, n, th: o.time_voice(mode, f3, cu3, rs3, n, threads=th), lambda n: V * n, (32, 1 << 16),
+                                 "samples per voice", "%d voices saw->lores->adsr (mode %d), voice-inner loop of 15.polysynth" % (V, mode))
+            W = dict(step=step, samples=V * B, dominant="voice_kernel", algo_bytes=(8.0 + 176.0 / B) * V * B, dtype="f64", cpu=cpu,
+                     local_step=MixdownStep(render_mix3, local_queue) if local_queue is not None else None,
+                     workload="configs[2]: fused subtractive voice maxiOsc::saw -> maxiFilter::lores -> maxiEnv::adsr (mode %d), %d voices "
+                              "per GPU, block=512, gate(n) = (n mod 44100) < 22050 cycled over 128 blocks, output rotated over %d block "
+                              "buffer(s)" % (mode, V, nbuf))
+        elif workload == "config4":
+            NF = 1 << 20
+            g = torch.Generator(device=dev); g.manual_seed(0x4D415849 + rank)
+            sig = torch.empty(NF * 1024, dtype=torch.float32, device=dev)
+            for c0 in range(0, NF, 1 << 16):
+                n = torch.arange(c0 * 1024, (c0 + (1 << 16)) * 1024, dtype=torch.float64, device=dev)
+                k = torch.div(n, 1024, rounding_mode="floor")
+                sig[c0 * 1024:(c0 + (1 << 16)) * 1024] = (0.4 * torch.sin(2 * np.pi * 220 * n / 44100) + 0.3 * torch.sin(
+                    2 * np.pi * (440 + 0.01 * k) * n / 44100) + 0.1 * (2 * torch.rand(n.numel(), dtype=torch.float64, device=dev,
+                                                                                      generator=g) - 1)).to(torch.float32)
+                del n, k
+            mfma = mfcc_method == "mfma"
+            kdim = 512 if args.mfma_fullk else 256  # bins the MFMA kernel contracts over (weights beyond bin 232 are zero)
+            if mfma:
+                L.mxg_tune(b"mfcc_mfma_fullk", 1 if args.mfma_fullk else 0)
+            mfcc = torch.empty((NF, 13), dtype=torch.float64, device=dev)
+            fplan = mx.maxiFFT(); fplan.setup(1024, 1024, 1024)
+            mplan = mx.maxiMFCC(); mplan.setup(512, 42, 13, 20.0, 20000.0)
+            fused_ok = hasattr(L, "mxg_fft_mfcc_batch") and not mfma
+            mags = None if fused_ok else torch.empty((NF, 512), dtype=torch.float32, device=dev)
 
-        def step():
-            if fused_ok:
-                chk(L.mxg_fft_mfcc_batch(fplan.plan, mplan.plan, sig.data_ptr(), 1024, NF, None, None, None, mfcc.data_ptr(), stream),
-                    "mxg_fft_mfcc_batch")
-            else:
-                chk(L.mxg_fft_batch(fplan.plan, sig.data_ptr(), 1024, NF, None, None, mags.data_ptr(), None, stream), "fft")
-                chk(L.mxg_mfcc_batch(mplan.plan, mags.data_ptr(), 512, NF, None, None, mfcc.data_ptr(), 1 if mfma else 0, stream), "mfcc")
+            def step():
+                if fused_ok:
+                    chk(L.mxg_fft_mfcc_batch(fplan.plan, mplan.plan, sig.data_ptr(), 1024, NF, None, None, None, mfcc.data_ptr(), stream),
+                        "mxg_fft_mfcc_batch")
+                else:
+                    chk(L.mxg_fft_batch(fplan.plan, sig.data_ptr(), 1024, NF, None, None, mags.data_ptr(), None, stream), "fft")
+                    chk(L.mxg_mfcc_batch(mplan.plan, mags.data_ptr(), 512, NF, None, None, mfcc.data_ptr(), 1 if mfma else 0, stream), "mfcc")
 
-        sig_h = [None]
+            sig_h = [None]
 
-        def cpu():
-            if sig_h[0] is None:
-                sig_h[0] = sig[:1024 * 262144].cpu().numpy()
-            return _baseline(lambda o, n, th: o.time_spectral(sig_h[0][:n * 1024], threads=th), lambda n: n * 1024, (512, 262144),
-                             "frames", "maxiFFT(1024,1024,1024)::process per sample + maxiMFCC(512,42,13)::mfcc per frame (mfcctest loop)")
-        def read_ceiling():  # the kernel's own input stream with everything but the loads removed (csrc/calib.hip), same buffer
-            sink = torch.zeros(8, dtype=torch.float64, device=dev)
-            out = {}
-            for name, (w, fl, blk, blks) in {"8 B plain loads, 512 x 256 threads (the launch shape)": (8, 0, 256, 512),
-                                             "8 B non-temporal loads, 1024 x 512 threads": (8, 1, 512, 1024)}.items():
-                out[name] = time_steps(lambda: chk(L.mxg_calib_read_ex(sig.data_ptr(), NF * 4096, w, fl, 1, blk, blks, sink.data_ptr(),
-                                                                       stream), "calib_read"), 6, warm=3)
-            return out
-        W = dict(step=step, samples=NF * 1024, dtype="f32 (FFT) / f64 (MFCC)", cpu=cpu, read_ceiling=read_ceiling if fused_ok else None,
-                 dominant="mfcc_mfma_gemm_kernel" if mfma else ("fft_mfcc_kernel" if fused_ok else "fft1024_kernel"),
-                 algo_bytes=4200.0 * NF if fused_ok else 6144.0 * NF,
-                 # MFMA flops ISSUED: 2 x K x 48 (42 filters padded to 3 column blocks of 16) per frame
-                 mfma_flops=2.0 * kdim * 48 * NF if mfma else None,
-                 mfma_note="issued 2*%d*48 flops/frame (useful dense 2*512*42 = 43008)" % kdim if mfma else None,
-                 workload="configs[3]: maxiFFT(1024,1024,1024) + maxiMFCC(512,42,13,20,20000) over %d frames per GPU per step, %s"
-                          % (NF, "FFT kernel + dense fp64 MFMA mel contraction (K = %d bins)" % kdim if mfma else ("one fused kernel, exact sparse mel walk" if fused_ok
-                                                                               else "FFT kernel + exact sparse mel walk")))
-    else:  # config5
-        S, T, Ls = 2048, 70560, 4410000
-        rng5 = np.random.default_rng(0x4D415849)
-        n5 = np.arange(Ls)
-        smp = 0.5 * np.sin(2 * np.pi * 110 * n5 / 44100) + 0.25 * np.sin(2 * np.pi * 331 * n5 / 44100) + 0.05 * rng5.uniform(-1, 1, Ls)
-        sb5 = mx.maxiSampleBank(1, stream=stream); sb5.setSample(smp)
-        gb = mx.maxiTimeStretchBank(S, sb5, "hann", stream=stream)
-        lo5, hi5 = shard_range(rank, world, S)
-        pos5, speed5, pan5_h = stream_parameters(lo5, hi5, S * world)
-        gb.setPosition(pos5)
-        sp5 = mx.DeviceBuffer.from_numpy(speed5)
-        pan5 = mx.DeviceBuffer.from_numpy(pan5_h)
-        out5 = mx.DeviceBuffer((T, S), zero=False)
-        plan5 = gb._plan(0.05)
-        if mixdown != "off":
-            queue = RcclMixQueue(comm, T * 2, 1, 0, stream)  # one [T][2] = 1.13 MB reduce per render
-            if world > 1:
-                local_queue = RcclMixQueue(None, T * 2, 1, 0, stream)
+            def cpu():
+                if sig_h[0] is None:
+                    sig_h[0] = sig[:1024 * 262144].cpu().numpy()
+                return _baseline(lambda o, n, th: o.time_spectral(sig_h[0][:n * 1024], threads=th), lambda n: n * 1024, (512, 262144),
+                                 "frames", "maxiFFT(1024,1024,1024)::process per sample + maxiMFCC(512,42,13)::mfcc per frame (mfcctest loop)")
+            def read_ceiling():  # the kernel's own input stream with everything but the loads removed (csrc/calib.hip), same buffer
+                sink = torch.zeros(8, dtype=torch.float64, device=dev)
+                out = {}
+                for name, (w, fl, blk, blks) in {"8 B plain loads, 512 x 256 threads (the launch shape)": (8, 0, 256, 512),
+                                                 "8 B non-temporal loads, 1024 x 512 threads": (8, 1, 512, 1024)}.items():
+                    out[name] = time_steps(lambda: chk(L.mxg_calib_read_ex(sig.data_ptr(), NF * 4096, w, fl, 1, blk, blks, sink.data_ptr(),
+                                                                           stream), "calib_read"), 6, warm=3)
+                return out
+            W = dict(step=step, samples=NF * 1024, dtype="f32 (FFT) / f64 (MFCC)", cpu=cpu, read_ceiling=read_ceiling if fused_ok else None,
+                     dominant="mfcc_mfma_gemm_kernel" if mfma else ("fft_mfcc_kernel" if fused_ok else "fft1024_kernel"),
+                     algo_bytes=4200.0 * NF if fused_ok else 6144.0 * NF,
+                     # MFMA flops ISSUED: 2 x K x 48 (42 filters padded to 3 column blocks of 16) per frame
+                     mfma_flops=2.0 * kdim * 48 * NF if mfma else None,
+                     mfma_note="issued 2*%d*48 flops/frame (useful dense 2*512*42 = 43008)" % kdim if mfma else None,
+                     workload="configs[3]: maxiFFT(1024,1024,1024) + maxiMFCC(512,42,13,20,20000) over %d frames per GPU per step, %s"
+                              % (NF, "FFT kernel + dense fp64 MFMA mel contraction (K = %d bins)" % kdim if mfma else ("one fused kernel, exact sparse mel walk" if fused_ok
+                                                                                   else "FFT kernel + exact sparse mel walk")))
+        else:  # config5
+            S, T, Ls = 2048, 70560, 4410000
+            rng5 = np.random.default_rng(0x4D415849)
+            n5 = np.arange(Ls)
+            smp = 0.5 * np.sin(2 * np.pi * 110 * n5 / 44100) + 0.25 * np.sin(2 * np.pi * 331 * n5 / 44100) + 0.05 * rng5.uniform(-1, 1, Ls)
+            sb5 = mx.maxiSampleBank(1, stream=stream); sb5.setSample(smp)
+            gb = mx.maxiTimeStretchBank(S, sb5, "hann", stream=stream)
+            lo5, hi5 = shard_range(rank, world, S)
+            pos5, speed5, pan5_h = stream_parameters(lo5, hi5, S * world)
+            gb.setPosition(pos5)
+            sp5 = mx.DeviceBuffer.from_numpy(speed5)
+            pan5 = mx.DeviceBuffer.from_numpy(pan5_h)
+            out5 = mx.DeviceBuffer((T, S), zero=False)
+            plan5 = gb._plan(0.05)
+            if mixdown != "off":
+                queue = RcclMixQueue(comm, T * 2, 1, 0, stream)  # one [T][2] = 1.13 MB reduce per render
+                if world > 1:
+                    local_queue = RcclMixQueue(None, T * 2, 1, 0, stream)
 
-        def grains():
-            chk(L.mxg_granular_render(plan5, 0, S, T, sb5.d_samples, Ls, 4, sp5.ptr, None, None, None, 0,
-                                      gb.state.ptr, gb.grains.ptr, out5.ptr, stream), "mxg_granular_render")
+            def grains():
+                chk(L.mxg_granular_render(plan5, 0, S, T, sb5.d_samples, Ls, 4, sp5.ptr, None, None, None, 0,
+                                          gb.state.ptr, gb.grains.ptr, out5.ptr, stream), "mxg_granular_render")
 
-        def render_mix5(slot):
-            if mixdown == "fused":  # the unit kernel mixes each 64 x 64 tile while it is in LDS
-                chk(L.mxg_granular_render_mix(plan5, 0, S, T, sb5.d_samples, Ls, 4, sp5.ptr, None, None, None, 0, gb.state.ptr,
-                                              gb.grains.ptr, out5.ptr, pan5.ptr, slot, stream), "mxg_granular_render_mix")
-            else:
-                grains()
-                chk(L.mxg_mix_stereo(S, T, out5.ptr, pan5.ptr, slot, stream), "mxg_mix_stereo")
-        step = grains if mixdown == "off" else MixdownStep(render_mix5, queue)
+            def render_mix5(slot):
+                if mixdown == "fused":  # the unit kernel mixes each 64 x 64 tile while it is in LDS
+                    chk(L.mxg_granular_render_mix(plan5, 0, S, T, sb5.d_samples, Ls, 4, sp5.ptr, None, None, None, 0, gb.state.ptr,
+                                                  gb.grains.ptr, out5.ptr, pan5.ptr, slot, stream), "mxg_granular_render_mix")
+                else:
+                    grains()
+                    chk(L.mxg_mix_stereo(S, T, out5.ptr, pan5.ptr, slot, stream), "mxg_mix_stereo")
+            step = grains if mixdown == "off" else MixdownStep(render_mix5, queue)
 
-        def cpu():
-            Sc = 2048  # streams of the bounded sample: this rank's whole share
-            return _baseline(lambda o, n, th: o.time_grains(smp, speed5[:Sc], pos5[:Sc], n, threads=th), lambda n: Sc * n * 4,
-                             (256, 8 * 70560), "samples per stream", "%d maxiTimeStretch<hann> streams, play(speed,0.05,4), stream-inner "
-                             "loop, 4 grain-samples per stream-sample" % Sc)
-        W = dict(step=step, samples=S * T * 4, dominant="granular_unit_kernel", algo_bytes=(8.0 * 4 + 8.0) * S * T, dtype="f64", cpu=cpu,
-                 # what the render actually moves, all of it from L2 / Infinity Cache (the 35 MB sample and the 17.6 KB window are resident):
-                 # per stream-sample 4 live grains x (buffer[a], buffer[a+1] = 16 B + 8 B of window) + the 8-byte store
-                 l2_bytes=(4 * 24.0 + 8.0) * S * T,
-                 local_step=MixdownStep(render_mix5, local_queue) if local_queue is not None else None,
-                 workload="configs[4]: %d maxiTimeStretch<hann> streams per GPU x %d samples per step, grainLength 0.05, overlaps 4 "
-                          "(4 live grains per stream-sample counted)%s" % (S, T, "" if mixdown == "off" else
-                                                                          ", maxiMix::stereo to [T][2] + one RCCL reduce per render"))
+            def cpu():
+                Sc = 2048  # streams of the bounded sample: this rank's whole share
+                return _baseline(lambda o, n, th: o.time_grains(smp, speed5[:Sc], pos5[:Sc], n, threads=th), lambda n: Sc * n * 4,
+                                 (256, 8 * 70560), "samples per stream", "%d maxiTimeStretch<hann> streams, play(speed,0.05,4), stream-inner "
+                                 "loop, 4 grain-samples per stream-sample" % Sc)
+            W = dict(step=step, samples=S * T * 4, dominant="granular_unit_kernel", algo_bytes=(8.0 * 4 + 8.0) * S * T, dtype="f64", cpu=cpu,
+                     # what the render actually moves, all of it from L2 / Infinity Cache (the 35 MB sample and the 17.6 KB window are resident):
+                     # per stream-sample 4 live grains x (buffer[a], buffer[a+1] = 16 B + 8 B of window) + the 8-byte store
+                     l2_bytes=(4 * 24.0 + 8.0) * S * T,
+                     local_step=MixdownStep(render_mix5, local_queue) if local_queue is not None else None,
+                     workload="configs[4]: %d maxiTimeStretch<hann> streams per GPU x %d samples per step, grainLength 0.05, overlaps 4 "
+                              "(4 live grains per stream-sample counted)%s" % (S, T, "" if mixdown == "off" else
+                                                                              ", maxiMix::stereo to [T][2] + one RCCL reduce per render"))
 
+        W["queue"], W["local_queue"], W["mixdown"] = queue, local_queue, mixdown
+        return W
+
+    W = build_workload(args.workload, mixdown, args.mfcc_method, args.voice_mode)
+    queue, local_queue = W["queue"], W["local_queue"]
+    bank = W.get("bank")
     step = W["step"]
 
     def fence():
@@ -556,6 +571,87 @@ def main():
                 "realtime_factor_at_44k1": round(B / 44100.0 / (ms2 * 1e-3), 1)}
             del b2
 
+    # ---- N = 1 default run: every other GPU config of BASELINE.json, in the same line ("configs") -------------------------------
+    def quick(Wq, steps, warm):
+        """One config measured the short way: `steps` timed steps between two events on the launch stream (queue flushed inside the
+        timed region), then a pass with the library's per-kernel events on; the roofline of its dominant kernel as for the headline."""
+        q, st = Wq["queue"], Wq["step"]
+        for _ in range(warm):
+            st()
+        if q is not None:
+            q.flush()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(steps):
+            st()
+        if q is not None:
+            q.flush()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / steps
+        psteps = min(steps, 100)
+        L.mxg_prof_reset()
+        L.mxg_prof_enable(1)
+        for _ in range(psteps):
+            st()
+        if q is not None:
+            q.flush()
+        torch.cuda.synchronize()
+        L.mxg_prof_enable(0)
+        kern = read_kernels(psteps)
+        kern.pop("_event_pair_overhead_ms", None)
+        dom_k = Wq["dominant"]
+        lps = kern.get(dom_k, {}).get("launches_per_step", 1.0)
+        k_ms = min(kern[dom_k]["ms"], ms / max(lps, 1.0)) if dom_k in kern else ms
+        ent = {"workload": Wq["workload"], "steps": steps, "warmup": warm, "ms_per_step": round(ms, 5),
+               "value": round(Wq["samples"] / ms / 1e3, 1), "unit": "Msamples/s", "dtype": Wq["dtype"]}
+        tr = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(dom_k)
+        except Exception:
+            pass
+        if Wq.get("mfma_flops"):
+            ach_k = Wq["mfma_flops"] / lps / (k_ms * 1e-3) / 1e12
+            ent["roofline"] = {"bound": "mfma", "kernel": dom_k, "kernel_ms": round(k_ms, 5), "launches_per_step": round(lps, 3),
+                               "flops_per_launch": Wq["mfma_flops"] / lps, "achieved": round(ach_k, 2), "peak": MFMA_F64_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(ach_k / MFMA_F64_PEAK_TFLOPS, 4), "note": Wq.get("mfma_note"), "traffic": tr}
+        else:
+            apl = Wq["algo_bytes"] / lps
+            ach_k = apl / (k_ms * 1e-3) / 1e9
+            ent["roofline"] = {"bound": "hbm", "kernel": dom_k, "kernel_ms": round(k_ms, 5), "launches_per_step": round(lps, 3),
+                               "algorithmic_bytes_per_launch": round(apl), "achieved": round(ach_k, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(ach_k / HBM_PEAK_GBS, 4), "traffic": tr}
+            # the whole step (every kernel it launches, gaps included) against the same peak
+            ent["roofline"]["step_frac"] = round(Wq["algo_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if Wq.get("l2_bytes"):
+                ent["roofline"]["l2_gather_GB/s"] = round(Wq["l2_bytes"] / lps / (k_ms * 1e-3) / 1e9, 1)
+        ent["kernels"] = {k: {"ms": round(v["ms"], 5), "launches_per_step": round(v["launches_per_step"], 3)} for k, v in sorted(kern.items())}
+        return ent
+
+    configs = {}
+    if (world == 1 and args.workload == "config2" and mixdown == "off" and not args.tune and not args.no_extras and not args.voices
+            and not args.no_configs):
+        for name, (wl, md, meth, st_, wm_) in {
+                "config2_mixdown": ("config2", "fused", "sparse", 400, 50),  # the N > 1 step on one GPU: K1m + grouped mix queue, no communicator
+                "config3": ("config3", "off", "sparse", 256, 64),
+                "config4": ("config4", "off", "sparse", 10, 2),
+                "config4_mfma": ("config4", "off", "mfma", 6, 2),
+                "config5": ("config5", "fused", "sparse", 10, 2)}.items():
+            try:
+                Wq = build_workload(wl, md, meth, 0)
+                configs[name] = quick(Wq, st_, wm_)
+                for qq in (Wq["queue"], Wq["local_queue"]):
+                    if qq is not None:
+                        qq.close()
+                del Wq
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+            except Exception as e:  # a failing extra must not take the headline with it: it is reported, loudly, in its place
+                configs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if "config2_mixdown" in configs and "ms_per_step" in configs["config2_mixdown"]:
+            configs["config2_mixdown"]["step_vs_headline"] = round(configs["config2_mixdown"]["ms_per_step"] / (elapsed / args.steps * 1e3), 4)
+
     value = W["samples"] * world * args.steps / elapsed / 1e6
     dom_launches = kernels.get(dom, {}).get("launches_per_step", 1.0)
     algo_per_launch = W["algo_bytes"] / dom_launches
@@ -633,6 +729,8 @@ def main():
             res["share_gpu_test"] = True
         if "north_star_bank" in extras:
             res["north_star_bank"] = extras["north_star_bank"]
+        if configs:
+            res["configs"] = configs
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = W["cpu"]()
         print(json.dumps(res), flush=True)

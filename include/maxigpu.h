@@ -129,7 +129,7 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "voice_block", "voice_nt" (as osc_nt), "mix_rows" (sample rows per workgroup of the mixdown, 1|2), "fft_generic",
  * "mfcc_tiled" (LDS-staged spectra 0|1), "grain_chunked" (time-sharded granular render 0|1), "grain_lanes_k",
  * "grain_unit" (coalesced unit-increment render 0|1), "grain_line" (tile render for arbitrary increments 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_slices" (time slices of a unit-path
- * maxiTimeStretch call whose scheduling and rendering overlap, 1..16), "osc_mix_var" (layout of K1m's lane-exchange butterfly, 0..3; 4 = cross-row sums on the matrix pipe),
+ * maxiTimeStretch call whose scheduling and rendering overlap, 1..16), "osc_mix_win" (K1m: samples per workgroup combine window, 0 automatic, 128 or 256),
  * "rw_store" (the read + write bank kernels' 16-byte pair-row streams: 0 automatic, 1 off, 2 / 3 / 4 on with plain / write-through /
  * non-temporal stores), "fft_exact" (1 default; 0 = TOLERANCE MODE of mxg_fft_mfcc_batch: the 512-point transform as true radix-8 butterflies with correctly
  * rounded twiddles and fused multiply-adds, hardware square root -- about a quarter fewer instructions; magnitudes within 6e-7 x the
@@ -139,6 +139,7 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * coefficients -- maxiBiquad, maxiSVF, maxiDCBlocker through mxg_filter2_render, lores / hires through mxg_filter_render -- and blocks
  * of 64 * {1..32} samples be cut along time and joined by a wavefront scan: a 6-voice x 512-sample block in a few microseconds
  * instead of 23-28, with reordered arithmetic: |error| <= 1e-10 x the block's peak (measured <= 5e-12); default 0 = the bit-exact kernels),
+ * "osc_persist" (K1 on a persistent grid of k wavefronts per SIMD with equal shares of voices x samples: 0 automatic, 1 off, 2 / 3 / 4 = k 1 / 2 / 4),
  * "osc_split" (time parts per voice group in K1: 0 automatic, 1..8), "osc_mix_split" (the same for the fused render + mixdown K1m,
  * 0 automatic, 1..4), "osc_mix_store" (K1m's per-voice block: 0 automatic, 1 plain 8-byte stores, 2 pair rows of 16-byte stores),
  * "smp_split" (time parts of a block-constant playAtSpeed / playOnceAtSpeed / playUntilAtSpeed launch: 0 automatic, 1..8),
@@ -190,14 +191,23 @@ int mxg_osc_noise(size_t V, size_t N, const int32_t *d_rand, double *d_outhold, 
 
 /* Render + fused stereo mixdown: as mxg_osc_render (block-constant frequencies) and, in the same
  * pass, d_mix[n][0..1] = sum_v (out[n][v]*sqrt(1-pan_v), out[n][v]*sqrt(pan_v)) (maxiMix::stereo,
- * C:503-509, plus the user-side sum over voices).  The per-voice block is never re-read: each
- * wavefront reduces its 64 voices in LDS and a small second kernel sums the per-wave partials
- * (fixed order: deterministic; tolerance on the mix as for mxg_mix_stereo).  d_out may be NULL:
- * then only the mix is produced (what a play() callback needs) and nothing but [N][2] leaves
- * the chip. */
+ * C:503-509, plus the user-side sum over voices, 15.polysynth/main.cpp:67).  The per-voice block is
+ * never re-read: each workgroup sums its 256 voices through an LDS transpose and a small second
+ * kernel adds the per-workgroup rows (fixed order: deterministic; tolerance on the mix as for
+ * mxg_mix_stereo).  d_out may be NULL: then only the mix is produced (what a play() callback needs)
+ * and nothing but [N][2] leaves the chip. */
 int mxg_osc_render_mix(int waveform, size_t V, size_t N, const double *d_freq, const double *d_p1,
                        const double *d_p2, double *d_phase, double *d_outhold, double *d_out,
                        const double *d_pan, double *d_mix, void *stream);
+/* The same render WITHOUT the second kernel: d_rows[g][n][0..1], g < mxg_osc_mix_groups(V) = ceil(V / 256), holds the
+ * mix of voices [256 g, 256 g + 256); the mix is their sum in ascending g.  For a caller that adds the rows elsewhere:
+ * a grouped mix queue (mxg_mixq_create_grouped) does it once per batch on its own stream, so that the render stream
+ * carries ONE kernel per block; mxg_mix_rows_sum(groups, count = N * 2, d_rows, d_mix) is that sum as a call. */
+size_t mxg_osc_mix_groups(size_t V);
+int mxg_osc_render_mix_rows(int waveform, size_t V, size_t N, const double *d_freq, const double *d_p1,
+                            const double *d_p2, double *d_phase, double *d_outhold, double *d_out,
+                            const double *d_pan, double *d_rows, void *stream);
+int mxg_mix_rows_sum(size_t groups, size_t count, const double *d_rows, double *d_mix, void *stream);
 
 /* ---- maxiFilter bank ------------------------------------------------------------------ */
 /* d_st = [5][V]: x, y, outputs[0], outputs[1], outputs[2] (H:289-302), in/out.
@@ -604,6 +614,9 @@ int mxg_mix_reduce(mxg_comm *comm, int channels, size_t V, size_t N, const doubl
  * block into a pinned host ring [ring_blocks][block_doubles] (the audio callback's side of the boundary). */
 typedef struct mxg_mixq mxg_mixq;
 mxg_mixq *mxg_mixq_create(mxg_comm *comm, size_t block_doubles, int depth_blocks, int root);
+/* Grouped slots: mxg_mixq_slot hands out [groups][block_doubles] -- the rows of mxg_osc_render_mix_rows -- and the queue adds the
+ * rows of a whole batch with one kernel on ITS stream in front of the reduce (groups = 1: the plain queue). */
+mxg_mixq *mxg_mixq_create_grouped(mxg_comm *comm, size_t block_doubles, int depth_blocks, int root, size_t groups);
 int mxg_mixq_destroy(mxg_mixq *q);
 int mxg_mixq_set_sink(mxg_mixq *q, double *h_pinned, size_t ring_blocks);
 double *mxg_mixq_slot(mxg_mixq *q, void *stream);

@@ -53,6 +53,10 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_osc_render_mix": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_osc_mix_groups": (c_size_t, [c_size_t]),
+    "mxg_osc_render_mix_rows": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_mix_rows_sum": (c_int, [c_size_t, c_size_t, c_void_p, c_void_p, c_void_p]),
     "mxg_filter_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_int, c_void_p,
                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_filter_render_coefs": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -132,6 +136,7 @@ SIGNATURES = {
     "mxg_mix_reduce": (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int, c_void_p]),
     "mxg_mixq_create": (c_void_p, [c_void_p, c_size_t, c_int, c_int]),
+    "mxg_mixq_create_grouped": (c_void_p, [c_void_p, c_size_t, c_int, c_int, c_size_t]),
     "mxg_mixq_destroy": (c_int, [c_void_p]),
     "mxg_mixq_set_sink": (c_int, [c_void_p, c_void_p, c_size_t]),
     "mxg_mixq_slot": (c_void_p, [c_void_p, c_void_p]),

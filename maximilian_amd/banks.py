@@ -146,14 +146,22 @@ class maxiOscBank(_Bank):
         self._keep = (f, a, b)  # keep parameter buffers alive until the next call
         return out
 
-    def render_mix(self, waveform, freq, pan, N, p1=None, p2=None, out=None, store=True, mix=None):
+    def render_mix(self, waveform, freq, pan, N, p1=None, p2=None, out=None, store=True, mix=None, rows=None):
         """Render + fused maxiMix::stereo mixdown in one pass (mxg_osc_render_mix).
-        Returns (out [N,V] or None, mix [N,2])."""
+        Returns (out [N,V] or None, mix [N,2]).  rows: a device pointer / buffer [mxg_osc_mix_groups(V)][N][2] (e.g. a
+        grouped mix queue's slot) -- then the per-workgroup rows are left there (mxg_osc_render_mix_rows) and no mix is
+        formed here; returns (out, None)."""
         wf = OSC_WAVEFORMS[waveform] if isinstance(waveform, str) else int(waveform)
         f, pn = _as_dev(freq, self.V), _as_dev(pan, self.V)
         a = None if p1 is None else _as_dev(p1, self.V)
         b = None if p2 is None else _as_dev(p2, self.V)
         out = (self._out(N, out) if store else None)
+        if rows is not None:
+            check(lib().mxg_osc_render_mix_rows(wf, self.V, N, _ptr(f), _ptr(a), _ptr(b), self.phase.ptr,
+                                                self.output.ptr, _ptr(out), _ptr(pn), _ptr(rows), self.stream),
+                  "mxg_osc_render_mix_rows")
+            self._keep = (f, a, b, pn)
+            return out, None
         mix = mix if mix is not None else DeviceBuffer((N, 2), np.float64, zero=False)
         check(lib().mxg_osc_render_mix(wf, self.V, N, _ptr(f), _ptr(a), _ptr(b), self.phase.ptr,
                                        self.output.ptr, _ptr(out), _ptr(pn), _ptr(mix), self.stream),

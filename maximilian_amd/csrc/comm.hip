@@ -24,6 +24,7 @@
 
 #include "mxg_common.h"
 #include "mxg_mixq_core.h"
+#include "mxg_lanefold.h"  // mix_partials_kernel: the fold of grouped slots
 
 // The RCCL entry points are resolved with dlsym, so only a handful of types are needed at compile time: use the installed
 // header where there is one and the same few declarations (ABI of NCCL 2.x / RCCL) where there is not -- libmaxigpu.so builds
@@ -110,6 +111,15 @@ struct HipMixDev {
     int copy_to_host(double *h, const double *d, size_t count, Stream s) {
         return mxg::check_hip(hipMemcpyAsync(h, d, count * sizeof(double), hipMemcpyDeviceToHost, s), "hipMemcpyAsync");
     }
+    // dst[k][i] = sum over the `groups` rows of block k, rows in ascending order within each of 16 interleaved chains, then the
+    // chains left to right (mix_partials_kernel): one launch for the whole batch, on the queue's stream
+    int fold(const double *src, double *dst, size_t blocks, size_t groups, size_t block, Stream s) {
+        using namespace mxg;
+        if (blocks == 0) return MXG_OK;
+        hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((block + 63) / 64), (unsigned)blocks), dim3(64 * kPartWaves), 0, s,
+                           groups, block, src, dst);
+        return check_hip(hipGetLastError(), "mix queue fold launch");
+    }
     bool is_root(int root) { return !comm || comm->rank == root; }
 };
 
@@ -132,7 +142,7 @@ int mxg_comm_unique_id(void *h_id) {
 }
 
 mxg_comm *mxg_comm_create(const void *h_id, int nranks, int rank) {
-    if (ensure_init()) return nullptr;
+    if (ensure_init_only()) return nullptr;
     if (!h_id || nranks < 1 || rank < 0 || rank >= nranks) {
         fail(MXG_ERR_INVALID, "mxg_comm_create: bad id / rank %d of %d", rank, nranks);
         return nullptr;
@@ -188,9 +198,14 @@ int mxg_mix_reduce(mxg_comm *c, int channels, size_t V, size_t N, const double *
 }
 
 mxg_mixq *mxg_mixq_create(mxg_comm *c, size_t block_doubles, int depth_blocks, int root) {
-    if (ensure_init()) return nullptr;
-    if (block_doubles == 0 || depth_blocks < 1 || depth_blocks > 4096 || root < 0 || root >= (c ? c->nranks : 1)) {
-        fail(MXG_ERR_INVALID, "mxg_mixq_create: bad block size / depth / root");
+    return mxg_mixq_create_grouped(c, block_doubles, depth_blocks, root, 1);
+}
+
+mxg_mixq *mxg_mixq_create_grouped(mxg_comm *c, size_t block_doubles, int depth_blocks, int root, size_t groups) {
+    if (ensure_init_only()) return nullptr;
+    if (block_doubles == 0 || depth_blocks < 1 || depth_blocks > 4096 || root < 0 || root >= (c ? c->nranks : 1) || groups < 1 ||
+        groups > ((size_t)1 << 20)) {
+        fail(MXG_ERR_INVALID, "mxg_mixq_create: bad block size / depth / root / groups");
         return nullptr;
     }
     mxg_mixq *q = new mxg_mixq;
@@ -199,11 +214,13 @@ mxg_mixq *mxg_mixq_create(mxg_comm *c, size_t block_doubles, int depth_blocks, i
     q->block = block_doubles;
     q->depth = depth_blocks;
     q->root = root;
+    q->groups = groups;
     const size_t bytes = block_doubles * (size_t)depth_blocks * sizeof(double);
     bool ok = hipStreamCreateWithFlags(&q->qstream, hipStreamNonBlocking) == hipSuccess;
     for (int b = 0; b < 2 && ok; b++) {
         ok = ok && hipMalloc(&q->stage[b], bytes) == hipSuccess && hipMalloc(&q->result[b], bytes) == hipSuccess;
         ok = ok && hipMemset(q->stage[b], 0, bytes) == hipSuccess && hipMemset(q->result[b], 0, bytes) == hipSuccess;
+        if (groups > 1) ok = ok && hipMalloc(&q->gstage[b], bytes * groups) == hipSuccess && hipMemset(q->gstage[b], 0, bytes * groups) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&q->filled[b], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&q->reduced[b], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&q->consumed[b], hipEventDisableTiming) == hipSuccess;
@@ -222,6 +239,7 @@ int mxg_mixq_destroy(mxg_mixq *q) {
     for (int b = 0; b < 2; b++) {
         if (q->stage[b]) (void)hipFree(q->stage[b]);
         if (q->result[b]) (void)hipFree(q->result[b]);
+        if (q->gstage[b]) (void)hipFree(q->gstage[b]);
         if (q->filled[b]) (void)hipEventDestroy(q->filled[b]);
         if (q->reduced[b]) (void)hipEventDestroy(q->reduced[b]);
         if (q->consumed[b]) (void)hipEventDestroy(q->consumed[b]);

@@ -78,7 +78,7 @@ int mxg_convolve_destroy(mxg_convolve *c) {
 }
 
 mxg_convolve *mxg_convolve_create(const double *h_amp, size_t len, double position0, int fftsize, int hopsize) {
-    if (ensure_init()) return nullptr;
+    if (ensure_init_only()) return nullptr;
     if (!h_amp || len == 0 || fftsize < 8 || fftsize > 8192 || (fftsize & (fftsize - 1)) || hopsize <= 0 || hopsize > fftsize) {
         fail(MXG_ERR_INVALID, "mxg_convolve_create: bad impulse / fftsize %d / hopsize %d", fftsize, hopsize);
         return nullptr;

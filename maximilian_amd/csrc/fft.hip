@@ -530,7 +530,7 @@ __global__ __launch_bounds__(64) void fft_features_kernel(const float *__restric
 extern "C" {
 
 mxg_fft_plan *mxg_fft_plan_create(int fftSize, int hopSize, int windowSize) {
-    if (ensure_init()) return nullptr;
+    if (ensure_init_only()) return nullptr;
     if (fftSize < 8 || fftSize > 8192 || (fftSize & (fftSize - 1))) {
         fail(MXG_ERR_INVALID, "mxg_fft_plan_create: fftSize %d must be a power of two in [8, 8192] "
                               "(the reference exit(1)s on a non power of two, fft.cpp:129-132)", fftSize);
@@ -717,7 +717,7 @@ int mxg_fft_features(const mxg_fft_plan *p, const float *d_mags, size_t nframes,
 }
 
 mxg_ifft_plan *mxg_ifft_plan_create(int fftSize, int hopSize, int windowSize) {
-    if (ensure_init()) return nullptr;
+    if (ensure_init_only()) return nullptr;
     if (fftSize < 8 || fftSize > 8192 || (fftSize & (fftSize - 1))) {
         fail(MXG_ERR_INVALID, "mxg_ifft_plan_create: fftSize %d must be a power of two in [8, 8192]", fftSize);
         return nullptr;

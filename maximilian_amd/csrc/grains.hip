@@ -1296,7 +1296,7 @@ mxg_grain_plan *mxg_grain_plan_create(int window_kind, double grainLength, int m
     p->d_window = nullptr;
     p->h_window.resize(sampleDur);
     for (unsigned long i = 0; i < sampleDur; i++) p->h_window[i] = window_value(window_kind, sampleDur, i);
-    if (!ensure_init()) {
+    if (!ensure_init_only()) {
         if (check_hip(hipMalloc(&p->d_window, sizeof(double) * sampleDur), "hipMalloc") ||
             check_hip(hipMemcpy(p->d_window, p->h_window.data(), sizeof(double) * sampleDur, hipMemcpyHostToDevice),
                       "hipMemcpy")) {

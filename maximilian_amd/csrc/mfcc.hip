@@ -705,7 +705,7 @@ mxg_mfcc_plan *mxg_mfcc_plan_create(unsigned numBins, unsigned numFilters, unsig
     std::vector<double> Wpad((size_t)kRows * p->nfPad, 0.0);
     for (unsigned bin = 0; bin < numBins; bin++)
         for (unsigned f = 0; f < numFilters; f++) Wpad[(size_t)bin * p->nfPad + f] = p->h_W[f + (size_t)bin * numFilters];
-    if (ensure_init() || !upload(&p->d_lo, lo) || !upload(&p->d_hi, hi) || !upload(&p->d_off, off) ||
+    if (ensure_init_only() || !upload(&p->d_lo, lo) || !upload(&p->d_hi, hi) || !upload(&p->d_off, off) ||
         !upload(&p->d_Wc, Wc) || !upload(&p->d_dct, dctT) || !upload(&p->d_Wpad, Wpad) ||
         !upload(&p->d_schedW, schedW) || !upload(&p->d_schedFin, schedFin) || !upload(&p->d_fs8, fs8) ||
         !upload(&p->d_fs16, fs16)) {

@@ -31,9 +31,11 @@ Settings &settings();
 // error plumbing (thread-local message, negative status codes)
 int fail(int status, const char *fmt, ...);
 int check_hip(hipError_t e, const char *what);
-int ensure_init();
+int ensure_init();       // compute / sync entry points: init on first use + report a pending asynchronous device error
+int ensure_init_only();  // allocation, copies, creation: init on first use, pending errors stay pending
 hipStream_t resolve_stream(void *stream);
 int tune_get(const char *key);
+int device_cus();  // compute units of the device (256 on MI355X)
 
 // Library-owned scratch, one grow-only buffer per (slot, stream): launches on different streams never share
 // (or resize) each other's temporaries; launches on one stream are ordered by the stream.  Returns MXG_OK and

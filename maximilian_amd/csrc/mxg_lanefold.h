@@ -121,7 +121,8 @@ __device__ __forceinline__ T fold_chunk_swap(const T (&v)[kMixChunk]) {
 
 // mix[i] = sum over workgroups of partial[g][i], i = n*2 + ch.  A workgroup owns 64 consecutive elements (one coalesced
 // 512-B row segment per load); its 16 waves each add the groups g = w, w+16, ... in order (independent loads, all in
-// flight), then the 16 wave sums are combined left to right: a fixed order for a fixed number of workgroups.
+// flight), then the 16 wave sums are combined left to right: a fixed order for a fixed number of workgroups.  blockIdx.y = block k of
+// a batch (the mix queue's fold: partial[k][g][i] -> mix[k][i]).
 constexpr int kPartWaves = 16;
 __global__ __launch_bounds__(64 * kPartWaves) void mix_partials_kernel(size_t ngroups, size_t count,
                                                                        const double *__restrict__ partial,
@@ -130,6 +131,8 @@ __global__ __launch_bounds__(64 * kPartWaves) void mix_partials_kernel(size_t ng
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * 64 + lane;
     double s = 0.0;
+    partial += (size_t)blockIdx.y * ngroups * count;
+    mix += (size_t)blockIdx.y * count;
     if (i < count) {
         const double *p = partial + i;
 #pragma unroll 8

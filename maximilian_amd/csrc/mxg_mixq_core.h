@@ -11,7 +11,10 @@
 //     reduce(stage[b] -> result[b]) on qstream                ONE reduce per batch
 //     [root, optional] result[b] -> pinned host ring, block by block
 //     reduced[b]  recorded on qstream
-// and the caller goes on with the OTHER staging buffer while the reduce runs.  Before the first slot of a buffer is handed out
+// and the caller goes on with the OTHER staging buffer while the reduce runs.  Grouped slots (groups > 1, round 4): the caller's
+// kernel leaves `groups` partial rows per block (K1m: one per workgroup of 256 voices) in gstage[b] and the QUEUE adds them, for the
+// whole batch at once, on qstream in front of the reduce (fold) -- the per-block "sum the workgroup rows" kernel leaves the render
+// stream.  Before the first slot of a buffer is handed out
 // again the caller's stream waits reduced[b] (the reduce that last READ this staging buffer).  flush() submits a partial batch
 // and makes the caller's stream wait for every outstanding reduce.  Nothing here blocks the host.
 #pragma once
@@ -24,6 +27,7 @@ namespace mxg {
 //   int record(Event, Stream);  int wait(Stream, Event);
 //   int reduce(const double *send, double *recv, size_t count, int root, Stream);   // sum over ranks onto root
 //   int copy_to_host(double *h_dst, const double *d_src, size_t count, Stream);
+//   int fold(const double *src, double *dst, size_t blocks, size_t groups, size_t block, Stream);   // dst[k][i] = sum_g src[k][g][i], g ascending
 //   bool is_root(int root);
 template <class Dev>
 struct MixQueueCore {
@@ -36,6 +40,8 @@ struct MixQueueCore {
     int root = 0;
     double *stage[2] = {nullptr, nullptr};   // [M][block] local mixes
     double *result[2] = {nullptr, nullptr};  // [M][block] reduced (meaningful on the root)
+    size_t groups = 1;                       // partial rows per block the caller's kernel writes (1: it writes the mix itself)
+    double *gstage[2] = {nullptr, nullptr};  // [M][groups][block] (groups > 1 only): what slot() hands out
     Event filled[2] = {}, reduced[2] = {}, consumed[2] = {};
     bool in_flight[2] = {false, false};      // a reduce has been enqueued that reads stage[b]
     bool has_consumer[2] = {false, false};   // release() recorded reads of result[b] that the next reduce into it must wait for
@@ -60,6 +66,8 @@ struct MixQueueCore {
 #endif
             has_consumer[b] = false;
         }
+        if (groups > 1)
+            if (int s = dev->fold(gstage[b], stage[b], (size_t)fill, groups, block, qstream)) return s;
         if (int s = dev->reduce(stage[b], result[b], count, root, qstream)) return s;
         if (h_sink && dev->is_root(root)) {
             for (int i = 0; i < fill; i++) {
@@ -83,14 +91,15 @@ struct MixQueueCore {
         const int b = cur;
         *status = 0;
         if (fill == 0 && in_flight[b]) {
-            // the reduce that last read this staging buffer must be done before the caller's stream overwrites it
+            // the reduce (and, with groups, the fold in front of it) that last read this staging buffer must be done before the
+            // caller's stream overwrites it
 #ifndef MXG_MIXQ_MUTATE_NO_SLOT_WAIT  // (tests/host_mixq.cpp builds a mutant without this wait and must catch it)
             if ((*status = dev->wait(st, reduced[b]))) return nullptr;
 #endif
             in_flight[b] = false;
         }
         slot_out = true;
-        return stage[b] + (size_t)fill * block;
+        return groups > 1 ? gstage[b] + (size_t)fill * groups * block : stage[b] + (size_t)fill * block;
     }
 
     int push(Stream st) {

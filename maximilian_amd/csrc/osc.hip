@@ -170,63 +170,168 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
     }
 }
 
+// ---- K1p: K1 on a persistent grid ---------------------------------------------------------------------
+// K1 launches one wavefront per 64 voices: a 65 536-voice bank is exactly one wavefront per SIMD (1024 of them), the regime its
+// store stream is fastest in (0.83 of the HBM peak), but 98 304 voices are 1.5 wavefronts per SIMD, 196 608 three, and the time per
+// voice goes up by a fifth (profiles/r03_osc_store.md).  Here the grid is a property of the MACHINE -- k wavefronts per SIMD -- and
+// the block of C = V / 64 voice columns x N samples is cut into equal SHARES of the linear work index c * N + n: a wavefront renders
+// a tail piece of one column, some whole columns, and a head piece of another, whatever V is.  A piece that starts at sample a > 0
+// first advances the recurrence over samples 0 .. a-1 (osc_skip: the same additions, the same bits, as K1's time parts); the piece
+// that ends at N stores the state, after every other piece of its column has signalled that its state loads have returned
+// (part_signal / part_wait on one counter per column).  A wavefront renders its HEAD piece (a reader: it signals at once) first and
+// its TAIL piece (a writer) last, so a writer never waits for work that sits behind another writer's wait.
+template <int WF, int ST, bool PX>
+__global__ __launch_bounds__(256) void osc_persist_kernel(size_t V, size_t N, const double *__restrict__ freq,
+                                                          const double *__restrict__ p1, const double *__restrict__ p2,
+                                                          double *__restrict__ phase_io, double *__restrict__ hold_io,
+                                                          double *__restrict__ out, double sr, PartSync psync, size_t share, int xcd) {
+    __shared__ __attribute__((aligned(16))) double s_tab[tab_len<WF>()];
+    if constexpr (tab_len<WF>() > 1) {
+        load_tab<WF>(s_tab);
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const size_t p = (size_t)xcd_block(blockIdx.x, gridDim.x, xcd) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const size_t C = (V + 63) >> 6, W = C * N;
+    const size_t w0 = p * share;
+    if (w0 >= W) return;
+    const size_t w1 = w0 + share < W ? w0 + share : W;
+    const size_t c0 = w0 / N, a0 = w0 - c0 * N;
+    const size_t c1 = (w1 - 1) / N, b1 = w1 - c1 * N;  // the piece of column c1 ends at b1 (1 .. N)
+
+    auto piece = [&](size_t c, size_t a, size_t b) {
+        const size_t v = c * 64 + lane;
+        if (v >= V) return;  // (pair rows: V is even, a pair of lanes is live or dead together)
+        double ph = phase_io[v], hd = hold_io[v];
+        const OscPre q = osc_pre<WF>(freq[v], sr, p1 ? p1[v] : 0.0, p2 ? p2[v] : 0.0);
+        int *const ctr = psync.ctrs + c;
+        if (b < N) part_signal(ctr);  // (waits for the loads above)
+        bool trust = false;
+        if constexpr (WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE)
+            trust = __all(q.inc >= 0.0 && q.inc <= 1.0 && ph >= 0.0 && ph <= 2.0);
+#pragma unroll 4
+        for (size_t n = 0; n < a; n++) osc_skip<WF>(ph, hd, q, s_tab, s_tab);
+        auto run = [&](auto trust_tag) {
+            constexpr bool kTrust = decltype(trust_tag)::value;
+            size_t n = a;
+            if constexpr (PX) {
+                double *op = out + (a + (lane & 1)) * V + (v & ~(size_t)1);
+#pragma unroll 2
+                for (; n + 2 <= b; n += 2) {
+                    const double r0 = osc_tick<WF, kTrust>(ph, hd, q, s_tab, s_tab);
+                    const double r1 = osc_tick<WF, kTrust>(ph, hd, q, s_tab, s_tab);
+                    store_pair_rows<ST>(op, r0, r1);
+                    op += 2 * V;
+                }
+            }
+            double *o = out + n * V + v;
+#pragma unroll 4
+            for (; n < b; n++) {
+                store1<PX ? 0 : ST>(o, osc_tick<WF, kTrust>(ph, hd, q, s_tab, s_tab));
+                o += V;
+            }
+        };
+        if (trust) run(std::true_type{}); else run(std::false_type{});
+        if (b == N) {
+            // the other pieces of this column: the wavefronts whose shares overlap [c N, (c + 1) N)
+            const size_t first = (c * N) / share, last = ((c + 1) * N - 1) / share;
+            PartSync ps = psync;
+            ps.others += (int)(last - first);
+            if (part_wait(ps.others ? ctr : nullptr, ps)) {
+                phase_io[v] = ph;
+                hold_io[v] = hd;
+            }
+        }
+    };
+    if (c0 == c1) {
+        piece(c0, a0, b1);
+        return;
+    }
+    if (b1 < N) piece(c1, 0, b1);
+    for (size_t c = c0 + 1; c < c1; c++) piece(c, 0, N);
+    if (b1 == N) piece(c1, 0, N);
+    piece(c0, a0, N);
+}
+
+typedef void (*osc_persist_fn)(size_t, size_t, const double *, const double *, const double *, double *, double *, double *, double,
+                               PartSync, size_t, int);
+// store: 0 plain 8 B, 1 nt 8 B, 2 pair rows plain, 3 pair rows sc1, 4 pair rows nt
+template <int WF>
+osc_persist_fn pick_persist(int store) {
+    switch (store) {
+        case 1: return osc_persist_kernel<WF, 1, false>;
+        case 2: return osc_persist_kernel<WF, 0, true>;
+        case 3: return osc_persist_kernel<WF, 2, true>;
+        case 4: return osc_persist_kernel<WF, 1, true>;
+        default: return osc_persist_kernel<WF, 0, false>;
+    }
+}
+osc_persist_fn pick_persist_wf(int wf, int store) {
+    switch (wf) {
+        case 0: return pick_persist<0>(store);
+        case 1: return pick_persist<1>(store);
+        case 2: return pick_persist<2>(store);
+        case 3: return pick_persist<3>(store);
+        case 4: return pick_persist<4>(store);
+        case 5: return pick_persist<5>(store);
+        case 6: return pick_persist<6>(store);
+        case 7: return pick_persist<7>(store);
+        case 8: return pick_persist<8>(store);
+        case 9: return pick_persist<9>(store);
+        case 10: return pick_persist<10>(store);
+        case 11: return pick_persist<11>(store);
+    }
+    return nullptr;
+}
+
 // ---- K1m: K1 + fused maxiMix::stereo partial sums ---------------------------------------------------
-// Same per-voice recurrence and (optional) per-voice store as K1; in addition every wavefront reduces its 64 voices'
-// panned samples (in*sqrt(1-x), in*sqrt(x), C:503-509) per sample, so the mixdown never re-reads the 268 MB block from
-// HBM.  The reduction is a transposing butterfly in registers: each level takes two vectors, exchanges complementary
-// lanes between them and adds, so the number of vectors halves while every vector carries twice as many samples.
-// Measured issue costs on gfx950 (tools/ubench): any 32-bit VALU op incl. a DPP move 4.35 clk per wave64, an fp64
-// add/mul 4.35, v_permlane16/32_swap 16, ds_bpermute 24.  So the four transposing levels for a chunk of 16 samples use
-// the exchanges that stay inside a row of 16 lanes (DPP), largest level first where the pairs are most numerous:
-//   level 1  row_mirror      (lane i <-> 15-i, bank-masked DPP moves)   16 vectors -> 8     5 ops per fold
-//   level 2  row_half_mirror (lane i <-> 7-i)                            8 -> 4            5 ops
-//   level 3  quad_perm xor 2 (select + DPP)                              4 -> 2            7 ops
-//   level 4  quad_perm xor 1                                             2 -> 1            7 ops
-// = 81 VALU ops per channel and 16 samples (the first version exchanged across rows with v_permlane swaps: 48 of them,
-// 768 clk per chunk, VALU-bound at 48 us against 42 us for K1).  After level 4 lane l holds, for one of the 16 samples
-// (which one: the same network run once on the sample indices, `slot`), the sum over ITS ROW of 16 voices; the four row
-// sums are not combined in registers at all: every lane stores its (L, R) pair to LDS [wave][row][sample] and the
-// workgroup's combine pass -- which has to add the four waves anyway -- adds 16 terms instead of 4, in a fixed order.
-// A small second kernel sums the per-workgroup partials => deterministic (but not the reference's sequential order:
-// tolerance on the mix).
-
-// the lane-exchange helpers (Fold, fold_dpp, fold_quad, fold_chunk, fold32/16, quad_sum, fold_chunk_swap) live in mxg_lanefold.h
-
-// STORE: 0 = mix only (no per-voice block), 1 = plain 8-byte stores, 2 = pair rows of write-through 16-byte stores (as K1, V even and
-// `out` 16-byte aligned).  VAR 0: permlane-swap butterfly, 4 LDS rows per window (one per wave).  VAR 1: all-DPP butterfly, 16
-// rows (wave x row; A/B only).  VAR 2 (round 3): the CROSS-ROW half of the reduction on the matrix pipe.  v_mfma_f64_4x4x4 (four
-// 4 x 4 x 4 blocks, 16 cycles) computes D[b][i][j] += sum_k A[b][i][k] B[b][k][j]; the operand layout, probed on the device
-// (tools/ubench/mfma_probe.hip): lane l = 16 k + 4 b + c supplies A[b][i = c][k] and B[b][k][j = c], and lane 16 i + 4 b + j receives
-// D[b][i][j] -- k is the ROW of 16 lanes.  Give it B = the lane's own product (x * gain: no data movement) and A = [c == s & 3]
-// for sample s, accumulate four samples into one register, and lane (row i, column q) holds the sum of sample 4 g + i over lanes
-// q, q + 16, q + 32, q + 48: the two levels that cost 48 v_permlane swaps of 16 clk per chunk and channel run beside the
-// oscillator's VALU work (two 16-cycle MFMAs per sample on an otherwise idle pipe), and the transposition comes for free.  What
-// is left is the sum over the 16 lanes of a row for four vectors: row_mirror, row_half_mirror, quad sum (21 VALU per chunk and
-// channel instead of ~110).  The MFMA adds the four products in its own order: covered by the mix tolerance (the sum was
-// tree-ordered already).  (v_mfma_f64_16x16x4 does the same job with a 16-row selector at 64 cycles per instruction: measured
-// 85 us -- at one wavefront per SIMD the in-order issue waits for the busy matrix pipe.)  Time parts (gridDim.y, round 3): the kernel is VALU-issue bound at one wavefront per SIMD (43 us
-// of arithmetic for a 65 536 x 512 block against ~41 us of stores), and a second resident wavefront nearly doubles the issue
-// rate -- so a block is cut into two time parts like K1's sinewave: part p advances the phase over the samples before it with
+// Same per-voice recurrence and (optional) per-voice store as K1; in addition every workgroup forms the panned sum of its
+// 256 voices (in*sqrt(1-x), in*sqrt(x), C:503-509; the sum over voices is the user's `mix +=` loop, 15.polysynth/main.cpp:67)
+// per sample, so the mixdown never re-reads the 268 MB block from HBM.
+//
+// Round 4: the sum over the 64 voices of a wavefront goes through an LDS TRANSPOSE instead of a lane butterfly.  Lanes are
+// voices while the oscillator ticks; every lane drops its RAW sample into a [16 samples][64 voices] tile of the wavefront
+// (one ds_write_b64 per sample: 16 contiguous lanes cover 128 bytes, conflict-free), and once 16 samples are in, the
+// wavefront re-reads the tile the other way round: lane (s = lane & 15, q = lane >> 4) fetches sample s of the 16 voices
+// 16 q .. 16 q + 15 (8 x ds_read_b128), multiplies them with THOSE voices' gains -- which it keeps in registers, 16 + 16
+// doubles -- and adds the 16 products per channel in a fixed tree.  Two exchange steps fold the four voice quarters
+// (v_permlane32_swap, then a ds_bpermute by 16 lanes).  Per 16 samples and lane that is 62 fp64 operations, 16 LDS writes,
+// 8 LDS reads and ~10 exchange instructions: ~6 instructions per voice-sample on top of the oscillator's tick, where the
+// register butterfly it replaces (rounds 1-3: DPP mirrors, permlane swaps, or the matrix pipe for the cross-row half) cost
+// ~40 and left the kernel VALU-bound at 48-50 us against K1's 41 us.
+// Tile layout: voice quarter q, sample s, voice j of the quarter at byte q * 2304 + s * 144 + j * 8.  The row stride of 144 B
+// moves consecutive samples by nine 16-byte bank groups, so the 16 lanes the LDS serves per cycle of a ds_read_b128 (each lane
+// group of MI355X_MICROARCH.md's table holds every s exactly once) fall on 16 different groups; 2304 B = 9 x 256 keeps the
+// quarters bank-neutral.
+// The workgroup's four wavefront sums per sample are added left to right once per window of WIN samples, and the
+// per-workgroup rows [workgroup][N][2] are the kernel's output: mix_partials_kernel (or the mix queue, which does it once per
+// batch on its own stream: comm.hip) adds them in workgroup order.  A fixed order everywhere => deterministic, but not the
+// reference's sequential voice order: tolerance on the mix, per-voice signals bit-exact.
+//
+// STORE: 0 = mix only (no per-voice block), 1 = plain 8-byte stores, 2 = pair rows of write-through 16-byte stores (as K1, V
+// even and `out` 16-byte aligned).  Time parts (gridDim.y) as in K1: part p advances the phase over the samples before it with
 // osc_skip (the same additions: the same bits), renders its stretch and mixes it into its own rows of the partial buffer; the
 // last part stores the state (part_signal / part_wait).
-template <int WF, int STORE, int VAR, int WIN>
+constexpr int kTileRow = 18;              // doubles per (quarter, sample) row: 16 voices + 2 of padding (144 B)
+constexpr int kTileQuarter = 16 * kTileRow;  // 288 doubles = 2304 B
+constexpr int kTileWave = 4 * kTileQuarter;  // 1152 doubles = 9 KB per wavefront
+
+template <int WF, int STORE, int WIN>
 __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const double *__restrict__ freq,
                                                       const double *__restrict__ p1, const double *__restrict__ p2,
                                                       double *__restrict__ phase_io, double *__restrict__ hold_io,
                                                       double *__restrict__ out, const double *__restrict__ pan,
                                                       double *__restrict__ partial, double sr, PartSync psync) {
     constexpr int kTab = tab_len<WF>();
-    constexpr int kTabPad = (kTab + 1) & ~1;  // the (L, R) pairs below are 16-byte stores
-    constexpr int kRows = VAR == 1 ? 16 : 4;  // LDS rows the workgroup pass adds per output
-    constexpr int kMixWin = WIN;
-    __shared__ __attribute__((aligned(16))) double s_all[kTabPad + kRows * kMixWin * 2];
+    constexpr int kTabPad = (kTab + 1) & ~1;  // the tiles are read with 16-byte loads
+    __shared__ __attribute__((aligned(16))) double s_all[kTabPad + 4 * kTileWave + 4 * WIN * 2];
     double *s_tab = s_all;
     load_tab<WF>(s_tab);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *s_part = s_all + kTabPad;                                     // [kRows][kMixWin][2]
-    double *my_part = s_part + (VAR != 1 ? wave : wave * 4 + (lane >> 4)) * (kMixWin * 2);
-    // The lane exchanges need all 64 lanes alive, and a per-sample `if (live)` costs an exec-mask region per sample:
+    double *tile = s_all + kTabPad + wave * kTileWave;
+    double *s_part = s_all + kTabPad + 4 * kTileWave;  // [4 waves][WIN][2]
+    double *my_part = s_part + wave * (WIN * 2);
+    // The transposed read needs all 64 lanes alive, and a per-sample `if (live)` costs an exec-mask region per sample:
     // the surplus lanes of the bank's last wavefront shadow a live voice instead (same loads, same arithmetic, same stores
     // of the same values to the same addresses) and enter the mix with zero gains -- voice V-1, or with pair rows the last
     // PAIR of voices, parity kept, so that they exchange among themselves.
@@ -237,12 +342,25 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
     double x = pan[v];
     if (x > 1) x = 1;  // C:504
     if (x < 0) x = 0;  // C:505
-    double gl = live ? sqrt(1.0 - x) : 0.0, gr = live ? sqrt(x) : 0.0;
+    // the gains of the 16 voices this lane sums, handed round through the (still unused) tile
+    const int ts = lane & 15, tq = lane >> 4;
+    double gl[16], gr[16];
+    tile[lane] = live ? sqrt(1.0 - x) : 0.0;  // two[0] = input*sqrt(1.0-x)   C:506
+    tile[64 + lane] = live ? sqrt(x) : 0.0;   // two[1] = input*sqrt(x)       C:507
+    __syncthreads();  // (the table and the gains)
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        gl[j] = tile[16 * tq + j];
+        gr[j] = tile[64 + 16 * tq + j];
+    }
     OscPre q = osc_pre<WF>(freq[v], sr, p1 ? p1[v] : 0.0, p2 ? p2[v] : 0.0);
     // Consume the prologue loads HERE: otherwise hipcc's waitcnt pass keeps them "pending" at the loop back-edge and
     // drains the asynchronous output stores with s_waitcnt vmcnt(0) every chunk.
-    asm volatile("" : "+v"(ph), "+v"(hd), "+v"(gl), "+v"(gr));
+    asm volatile("" : "+v"(ph), "+v"(hd));
     asm volatile("" : "+v"(q.inc), "+v"(q.k), "+v"(q.p1), "+v"(q.p2));
+#pragma unroll
+    for (int j = 0; j < 16; j++) asm volatile("" : "+v"(gl[j]), "+v"(gr[j]));
+    __syncthreads();  // every lane has its gains: the tile is free
     // time parts: this part renders [nA, nB); part lengths are whole mix chunks, so a chunk never straddles two parts
     int *const part_ctr = gridDim.y > 1 ? part_counter(psync) : nullptr;
     if (blockIdx.y + 1 != gridDim.y) part_signal(part_ctr);
@@ -251,64 +369,16 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
     const size_t nB = nA + plen < N ? nA + plen : N;
 #pragma unroll 4
     for (size_t n = 0; n < nA; n++) osc_skip<WF>(ph, hd, q, s_tab, s_tab);
-    // which sample of a chunk this lane ends up holding: the same network on the sample indices
-    int slot;
-    {
-        int idx[kMixChunk];
-#pragma unroll
-        for (int i = 0; i < kMixChunk; i++) idx[i] = i;
-        if constexpr (VAR == 2) {  // register r of the MFMA result holds sample 4 r + (lane >> 4); then the in-row network
-            const int q = lane >> 4;
-            slot = fold_dpp<kDppRowHalfMirror, 0xA>(fold_dpp<kDppRowMirror, 0xC>(q, 4 + q), fold_dpp<kDppRowMirror, 0xC>(8 + q, 12 + q));
-        } else {
-            slot = VAR == 0 ? fold_chunk_swap<int>(idx) : fold_chunk<int>(idx, lane);
-        }
-        if (VAR != 1 && (lane & 3) != 0) slot = -1;  // one lane per quad stores
-    }
+    double *tw = tile + tq * kTileQuarter + ts;  // this VOICE's column: + i * kTileRow for sample i of the chunk
+    const double2v *tr = reinterpret_cast<const double2v *>(tile + tq * kTileQuarter + ts * kTileRow);  // sample ts, quarter tq
     double *o = out + nA * V + v;
     double *op = out + (nA + (threadIdx.x & 1)) * V + (v & ~(size_t)1);  // pair rows: this lane's 16 bytes of row n + (lane & 1)
-    for (size_t n0 = nA; n0 < nB; n0 += kMixWin) {
-        const int span = (int)((nB - n0) < (size_t)kMixWin ? (nB - n0) : (size_t)kMixWin);
+    for (size_t n0 = nA; n0 < nB; n0 += WIN) {
+        const int span = (int)((nB - n0) < (size_t)WIN ? (nB - n0) : (size_t)WIN);
         for (int c0 = 0; c0 < span; c0 += kMixChunk) {
             const int cnt = (span - c0) < kMixChunk ? (span - c0) : kMixChunk;
             auto chunk = [&](auto full_tag) {
                 constexpr bool kFull = decltype(full_tag)::value;
-                double L[kMixChunk], R[kMixChunk];
-                if constexpr (VAR == 2) {
-                    double DL[4] = {0.0, 0.0, 0.0, 0.0}, DR[4] = {0.0, 0.0, 0.0, 0.0};
-                    const int l4 = lane & 3;
-#pragma unroll
-                    for (int i = 0; i < kMixChunk; i += 2) {
-                        double r0 = 0.0, r1 = 0.0;
-                        if (kFull || i < cnt) r0 = osc_tick<WF>(ph, hd, q, s_tab, s_tab);  // ragged last chunk: the state must not advance past N
-                        if (kFull || i + 1 < cnt) r1 = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
-                        if constexpr (STORE == 2) {
-                            if constexpr (kFull) {
-                                store_pair_rows<2>(op, r0, r1);
-                                op += 2 * V;
-                            } else {
-                                if (i < cnt) o[0] = r0;
-                                if (i + 1 < cnt) o[V] = r1;
-                                o += 2 * V;
-                            }
-                        } else if constexpr (STORE == 1) {
-                            if (kFull || i < cnt) o[0] = r0;
-                            if (kFull || i + 1 < cnt) o[V] = r1;
-                            o += 2 * V;
-                        }
-                        const double s0 = l4 == (i & 3) ? 1.0 : 0.0, s1 = l4 == ((i + 1) & 3) ? 1.0 : 0.0;
-                        DL[i >> 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(s0, r0 * gl, DL[i >> 2], 0, 0, 0);  // two[0] = input*sqrt(1.0-x)   C:506
-                        DR[i >> 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(s0, r0 * gr, DR[i >> 2], 0, 0, 0);  // two[1] = input*sqrt(x)       C:507
-                        DL[i >> 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(s1, r1 * gl, DL[i >> 2], 0, 0, 0);
-                        DR[i >> 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(s1, r1 * gr, DR[i >> 2], 0, 0, 0);
-                    }
-                    if constexpr (kFull && STORE == 2) o += (size_t)kMixChunk * V;
-                    const double2v pr2 = {
-                        quad_sum(fold_dpp<kDppRowHalfMirror, 0xA>(fold_dpp<kDppRowMirror, 0xC>(DL[0], DL[1]), fold_dpp<kDppRowMirror, 0xC>(DL[2], DL[3]))),
-                        quad_sum(fold_dpp<kDppRowHalfMirror, 0xA>(fold_dpp<kDppRowMirror, 0xC>(DR[0], DR[1]), fold_dpp<kDppRowMirror, 0xC>(DR[2], DR[3])))};
-                    if (slot >= 0 && slot < cnt) *reinterpret_cast<double2v *>(my_part + (c0 + slot) * 2) = pr2;
-                    return;
-                }
                 if constexpr (kFull && STORE == 2) {
 #pragma unroll
                     for (int i = 0; i < kMixChunk; i += 2) {
@@ -316,10 +386,8 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
                         const double r1 = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
                         store_pair_rows<2>(op, r0, r1);
                         op += 2 * V;
-                        L[i] = r0 * gl;      // two[0] = input*sqrt(1.0-x)   C:506
-                        R[i] = r0 * gr;      // two[1] = input*sqrt(x)       C:507
-                        L[i + 1] = r1 * gl;
-                        R[i + 1] = r1 * gr;
+                        tw[i * kTileRow] = r0;
+                        tw[(i + 1) * kTileRow] = r1;
                     }
                     o += (size_t)kMixChunk * V;
                 } else {
@@ -333,28 +401,39 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
                                 o += V;
                             }
                         }
-                        L[i] = r * gl;  // two[0] = input*sqrt(1.0-x)   C:506
-                        R[i] = r * gr;  // two[1] = input*sqrt(x)       C:507
+                        tw[i * kTileRow] = r;
                     }
+                    if constexpr (STORE == 2) op += (size_t)kMixChunk * V;  // (only the bank's last chunk comes here)
                 }
-                double2v pr;
-                if constexpr (VAR == 0)
-                    pr = (double2v){quad_sum(fold_chunk_swap<double>(L)), quad_sum(fold_chunk_swap<double>(R))};
-                else
-                    pr = (double2v){fold_chunk<double>(L, lane), fold_chunk<double>(R, lane)};
-                if (slot >= 0 && slot < cnt) *reinterpret_cast<double2v *>(my_part + (c0 + slot) * 2) = pr;
+                // the wavefront's LDS operations execute in order: the transposed reads below see the writes above
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                double2v xv[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) xv[k] = tr[k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // (the next chunk's writes stay behind these reads)
+                double pl[8], pr[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    pl[k] = xv[k].x * gl[2 * k] + xv[k].y * gl[2 * k + 1];
+                    pr[k] = xv[k].x * gr[2 * k] + xv[k].y * gr[2 * k + 1];
+                }
+                const double sl = ((pl[0] + pl[1]) + (pl[2] + pl[3])) + ((pl[4] + pl[5]) + (pl[6] + pl[7]));
+                const double sr2 = ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]));
+                // quarters: lanes 0-31 <- left sums of quarters (0, 2) / (1, 3), lanes 32-63 the right sums; then the two rows of 16
+                double t = fold32(sl, sr2);
+                t = t + __shfl_xor(t, 16);
+                if ((lane & 16) == 0 && ts < cnt) my_part[(c0 + ts) * 2 + (lane >> 5)] = t;
             };
             if (cnt == kMixChunk) chunk(std::true_type{}); else chunk(std::false_type{});
         }
-        // 4 waves x 4 rows of this window -> one partial per workgroup: 16 terms, added in the order wave 0 row 0..3, wave 1 ...
+        // 4 wavefront sums of this window -> one partial row per workgroup, added in the order wave 0, 1, 2, 3
         __syncthreads();
         double *prow = partial + (size_t)blockIdx.x * N * 2 + n0 * 2;
-        for (int i = threadIdx.x; i < span * 2; i += blockDim.x) {
-            double t = s_part[i];
-#pragma unroll
-            for (int k = 1; k < kRows; k++) t += s_part[k * (kMixWin * 2) + i];
-            prow[i] = t;
-        }
+        for (int i = threadIdx.x; i < span * 2; i += blockDim.x)
+            prow[i] = ((s_part[i] + s_part[WIN * 2 + i]) + s_part[2 * WIN * 2 + i]) + s_part[3 * WIN * 2 + i];
         __syncthreads();
     }
     if (blockIdx.y + 1 == gridDim.y && part_wait(part_ctr, psync)) {
@@ -365,35 +444,27 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
 
 typedef void (*osc_mix_fn)(size_t, size_t, const double *, const double *, const double *, double *, double *,
                            double *, const double *, double *, double, PartSync);
-// store: 0 none, 1 plain, 2 pair rows (sc1); var / window A/B forms only for the bench waveform
+// store: 0 none, 1 plain, 2 pair rows (sc1); win: samples per workgroup combine (128 where three workgroups must share a CU)
 template <int WF>
-osc_mix_fn pick_mix(int store, int var) {
-    if (WF == MXG_OSC_SINEBUF) {
-        switch (var) {
-            case 1: return store ? osc_mix_kernel<WF, 1, 0, 128> : osc_mix_kernel<WF, 0, 0, 128>;
-            case 2: return store ? osc_mix_kernel<WF, 1, 1, 128> : osc_mix_kernel<WF, 0, 1, 128>;
-            case 3: return store ? osc_mix_kernel<WF, 1, 1, 512> : osc_mix_kernel<WF, 0, 1, 512>;
-            default: break;
-        }
-    }
-    if (var == 4)  // the matrix-pipe form
-        return store == 2 ? osc_mix_kernel<WF, 2, 2, 256> : (store == 1 ? osc_mix_kernel<WF, 1, 2, 256> : osc_mix_kernel<WF, 0, 2, 256>);
-    return store == 2 ? osc_mix_kernel<WF, 2, 0, 256> : (store == 1 ? osc_mix_kernel<WF, 1, 0, 256> : osc_mix_kernel<WF, 0, 0, 256>);
+osc_mix_fn pick_mix(int store, int win) {
+    if (win == 128)
+        return store == 2 ? osc_mix_kernel<WF, 2, 128> : (store == 1 ? osc_mix_kernel<WF, 1, 128> : osc_mix_kernel<WF, 0, 128>);
+    return store == 2 ? osc_mix_kernel<WF, 2, 256> : (store == 1 ? osc_mix_kernel<WF, 1, 256> : osc_mix_kernel<WF, 0, 256>);
 }
-osc_mix_fn pick_mix_wf(int wf, int store, int var) {
+osc_mix_fn pick_mix_wf(int wf, int store, int win) {
     switch (wf) {
-        case 0: return pick_mix<0>(store, var);
-        case 1: return pick_mix<1>(store, var);
-        case 2: return pick_mix<2>(store, var);
-        case 3: return pick_mix<3>(store, var);
-        case 4: return pick_mix<4>(store, var);
-        case 5: return pick_mix<5>(store, var);
-        case 6: return pick_mix<6>(store, var);
-        case 7: return pick_mix<7>(store, var);
-        case 8: return pick_mix<8>(store, var);
-        case 9: return pick_mix<9>(store, var);
-        case 10: return pick_mix<10>(store, var);
-        case 11: return pick_mix<11>(store, var);
+        case 0: return pick_mix<0>(store, win);
+        case 1: return pick_mix<1>(store, win);
+        case 2: return pick_mix<2>(store, win);
+        case 3: return pick_mix<3>(store, win);
+        case 4: return pick_mix<4>(store, win);
+        case 5: return pick_mix<5>(store, win);
+        case 6: return pick_mix<6>(store, win);
+        case 7: return pick_mix<7>(store, win);
+        case 8: return pick_mix<8>(store, win);
+        case 9: return pick_mix<9>(store, win);
+        case 10: return pick_mix<10>(store, win);
+        case 11: return pick_mix<11>(store, win);
     }
     return nullptr;
 }
@@ -496,6 +567,23 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     int block = tune_get("osc_block");
     if (vpl == 2 && store > 2) store = 0;
     if (vpl == 1 && store >= 2 && !pairs_ok) store = store == 4 ? 1 : 0;  // pair rows need whole pairs
+    // the persistent grid (K1p; knob osc_persist: 0 automatic, 1 off, 2 / 3 / 4 = one / two / four wavefronts per SIMD)
+    const int persist = tune_get("osc_persist");
+    if (persist >= 2 && !fps) {
+        hipStream_t st = resolve_stream(stream);
+        int pstore = store;
+        if (vpl == 2) pstore = pairs_ok ? (store == 2 ? 3 : (store == 1 ? 4 : 2)) : 0;  // (a lane carries one voice here)
+        if (pstore >= 2 && !pairs_ok) pstore = pstore == 4 ? 1 : 0;
+        const size_t C = (V + 63) / 64, W = C * N;
+        const size_t waves = (size_t)device_cus() * 4 * (size_t)(persist == 2 ? 1 : (persist == 3 ? 2 : 4));
+        size_t share = ((W + waves - 1) / waves + 15) / 16 * 16;
+        PartSync psync;
+        if (int s = part_sync_get(st, C, 1, &psync)) return s;
+        KernelTimer kt("osc_kernel", st);
+        hipLaunchKernelGGL(pick_persist_wf(waveform, pstore), dim3((unsigned)(waves / 4)), dim3(256), 0, st, V, N, d_freq, d_p1, d_p2,
+                           d_phase, d_outhold, d_out, (double)settings().sampleRate, psync, share, xcd);
+        return check_hip(hipGetLastError(), "osc_persist_kernel launch");
+    }
     osc_fn fn = pick_wf(waveform, fps != 0, vpl, store);
     size_t lanes = (V + vpl - 1) / vpl;
     // time parts.  (a) Where the output dominates the recurrence (sinewave, coswave, sinebuf4) and the bank is too small to give every
@@ -530,6 +618,75 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     return check_hip(hipGetLastError(), "osc_kernel launch");
 }
 
+namespace mxg {
+namespace {
+// K1m launch: render (+ optional per-voice block) and the per-workgroup mix rows d_rows[(V + 255) / 256][N][2]
+int osc_mix_launch(int waveform, size_t V, size_t N, const double *d_freq, const double *d_p1, const double *d_p2,
+                   double *d_phase, double *d_outhold, double *d_out, const double *d_pan, double *d_rows, hipStream_t st) {
+    const int block = 256;
+    const size_t nblocks = (V + block - 1) / block;
+    // per-voice block: pair rows of write-through 16-byte stores where whole pairs exist (knob osc_mix_store: 0 automatic,
+    // 1 plain 8-byte stores, 2 pair rows); time parts (knob osc_mix_split: 0 automatic)
+    int store = 0;
+    if (d_out) {
+        const bool pairs_ok = !(V & 1) && !(((uintptr_t)d_out) & 15) && V >= 2;
+        const int knob = tune_get("osc_mix_store");
+        store = (pairs_ok && (knob == 2 || (knob == 0 && V * N * sizeof(double) >= ((size_t)32 << 20)))) ? 2 : 1;
+    }
+    int split = tune_get("osc_mix_split");
+    if (split == 0) {
+        split = 1;
+        // SMALL banks of the table oscillators, as in mxg_osc_render: fewer wavefronts than SIMDs, one chain of N dependent
+        // steps each -- up to eight parts
+        const bool table = waveform == MXG_OSC_SINEWAVE || waveform == MXG_OSC_COSWAVE || waveform == MXG_OSC_SINEBUF4 ||
+                           waveform == MXG_OSC_SINEBUF || waveform == MXG_OSC_SAWN;
+        const size_t waves = nblocks * 4;
+        if (table && waves < 1024)
+            while (split < 8 && (size_t)(2 * split) * waves <= 1024 && (size_t)(2 * split) * 64 <= N) split *= 2;  // (a part renders >= 64 samples)
+    }
+    while (split > 1 && (size_t)(split - 1) * (((N + split - 1) / split + kMixChunk - 1) / kMixChunk * kMixChunk) >= N) split--;
+    PartSync psync;
+    if (split > 1)
+        if (int s2 = part_sync_get(st, nblocks * 4, split, &psync)) return s2;
+    // the combine window: 256 samples (57 KB of LDS: two workgroups per CU) up to 131 072 voices, 128 (49 KB: three) beyond
+    int win = tune_get("osc_mix_win");
+    if (win == 0) win = nblocks * (size_t)split > 512 ? 128 : 256;
+    osc_mix_fn fn = pick_mix_wf(waveform, store, win);
+    KernelTimer kt("osc_mix_kernel", st);
+    hipLaunchKernelGGL(fn, dim3((unsigned)nblocks, (unsigned)split), dim3(block), 0, st, V, N, d_freq, d_p1, d_p2, d_phase,
+                       d_outhold, d_out, d_pan, d_rows, (double)settings().sampleRate, psync);
+    return check_hip(hipGetLastError(), "osc_mix_kernel launch");
+}
+}  // namespace
+}  // namespace mxg
+
+extern "C" size_t mxg_osc_mix_groups(size_t V) { return (V + 255) / 256; }
+
+extern "C" int mxg_mix_rows_sum(size_t groups, size_t count, const double *d_rows, double *d_mix, void *stream) {
+    using namespace mxg;
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(d_mix && (d_rows || groups == 0), "null device pointer");
+    if (count == 0) return MXG_OK;
+    hipStream_t st = resolve_stream(stream);
+    KernelTimer kt("mix_partials_kernel", st);
+    hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64 * kPartWaves), 0, st, groups, count, d_rows,
+                       d_mix);
+    return check_hip(hipGetLastError(), "mix_partials_kernel launch");
+}
+
+extern "C" int mxg_osc_render_mix_rows(int waveform, size_t V, size_t N, const double *d_freq, const double *d_p1,
+                                       const double *d_p2, double *d_phase, double *d_outhold, double *d_out,
+                                       const double *d_pan, double *d_rows, void *stream) {
+    using namespace mxg;
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(waveform >= 0 && waveform <= 11, "unknown waveform");
+    MXG_REQUIRE(d_freq && d_phase && d_outhold && d_pan && d_rows, "null device pointer");
+    MXG_REQUIRE(waveform != MXG_OSC_PULSE || d_p1, "pulse needs d_p1 (duty)");
+    MXG_REQUIRE(waveform != MXG_OSC_PHASORBETWEEN || (d_p1 && d_p2), "phasorBetween needs d_p1/d_p2");
+    if (N == 0 || V == 0) return MXG_OK;
+    return osc_mix_launch(waveform, V, N, d_freq, d_p1, d_p2, d_phase, d_outhold, d_out, d_pan, d_rows, resolve_stream(stream));
+}
+
 extern "C" int mxg_osc_render_mix(int waveform, size_t V, size_t N, const double *d_freq, const double *d_p1,
                                   const double *d_p2, double *d_phase, double *d_outhold, double *d_out,
                                   const double *d_pan, double *d_mix, void *stream) {
@@ -541,51 +698,15 @@ extern "C" int mxg_osc_render_mix(int waveform, size_t V, size_t N, const double
     MXG_REQUIRE(waveform != MXG_OSC_PHASORBETWEEN || (d_p1 && d_p2), "phasorBetween needs d_p1/d_p2");
     if (N == 0) return MXG_OK;
     hipStream_t st = resolve_stream(stream);
-    const int block = 256;
-    const size_t nblocks = (V + block - 1) / block;
-    const size_t need = N * nblocks * 2 + 2;
-    double *partial = nullptr;  // per-stream scratch: [nblocks][N][2] per-workgroup sums
-    if (int s = scratch_get(SCR_OSC_MIX, st, sizeof(double) * need, (void **)&partial)) return s;
-    if (V) {
-        // per-voice block: pair rows of write-through 16-byte stores where whole pairs exist (knob osc_mix_store: 0 automatic,
-        // 1 plain 8-byte stores, 2 pair rows); time parts (knob osc_mix_split: 0 automatic = one)
-        const int var = tune_get("osc_mix_var");
-        int store = 0;
-        if (d_out) {
-            const bool pairs_ok = !(V & 1) && !(((uintptr_t)d_out) & 15) && V >= 2;
-            const int knob = tune_get("osc_mix_store");
-            store = (pairs_ok && var == 0 && (knob == 2 || (knob == 0 && V * N * sizeof(double) >= ((size_t)32 << 20)))) ? 2 : 1;
-        }
-        int split = tune_get("osc_mix_split");
-        if (split == 0) {
-            split = 1;  // (measured, MI355X 65 536 x 512 rotated: 1 part 51.1 us, 2 parts 53.6, 3 parts 54.8 -- the lane folds' permlane swaps do
-            // not overlap across wavefronts).  SMALL banks of the table oscillators are another matter, as in mxg_osc_render: fewer
-            // wavefronts than SIMDs, one chain of N dependent steps each -- up to eight parts
-            const bool table = waveform == MXG_OSC_SINEWAVE || waveform == MXG_OSC_COSWAVE || waveform == MXG_OSC_SINEBUF4 ||
-                               waveform == MXG_OSC_SINEBUF || waveform == MXG_OSC_SAWN;
-            const size_t waves = nblocks * 4;
-            if (table && waves < 1024)
-                while (split < 8 && (size_t)(2 * split) * waves <= 1024 && (size_t)(2 * split) * 64 <= N) split *= 2;  // (a part renders >= 64 samples)
-        }
-        if (var != 0) split = 1;
-        while (split > 1 && (size_t)(split - 1) * (((N + split - 1) / split + kMixChunk - 1) / kMixChunk * kMixChunk) >= N) split--;
-        PartSync psync;
-        if (split > 1)
-            if (int s2 = part_sync_get(st, nblocks * 4, split, &psync)) return s2;
-        osc_mix_fn fn = pick_mix_wf(waveform, store, var);
-        if (var == 3 && waveform == MXG_OSC_SINEBUF)
-            MXG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 0));
-        KernelTimer kt("osc_mix_kernel", st);
-        // a bank of one workgroup (<= 256 voices): its "partial" row IS the mix -- written in place, no second kernel (4-5 us of an
-        // 18 us call at 64 voices)
-        hipLaunchKernelGGL(fn, dim3((unsigned)nblocks, (unsigned)split), dim3(block), 0, st, V, N, d_freq, d_p1, d_p2, d_phase,
-                           d_outhold, d_out, d_pan, nblocks == 1 ? d_mix : partial, (double)settings().sampleRate, psync);
-        if (nblocks == 1) return check_hip(hipGetLastError(), "osc_mix_kernel launch");
-    }
-    KernelTimer kt2("mix_partials_kernel", st);
-    hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((N * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, nblocks, N * 2,
-                       partial, d_mix);
-    return check_hip(hipGetLastError(), "osc_mix_kernel launch");
+    const size_t nblocks = mxg_osc_mix_groups(V);
+    // a bank of one workgroup (<= 256 voices): its row IS the mix -- written in place, no second kernel (4-5 us of an 18 us
+    // call at 64 voices)
+    if (nblocks == 1) return osc_mix_launch(waveform, V, N, d_freq, d_p1, d_p2, d_phase, d_outhold, d_out, d_pan, d_mix, st);
+    double *rows = nullptr;  // per-stream scratch: [nblocks][N][2] per-workgroup sums
+    if (int s = scratch_get(SCR_OSC_MIX, st, sizeof(double) * (N * nblocks * 2 + 2), (void **)&rows)) return s;
+    if (V)
+        if (int s = osc_mix_launch(waveform, V, N, d_freq, d_p1, d_p2, d_phase, d_outhold, d_out, d_pan, rows, st)) return s;
+    return mxg_mix_rows_sum(nblocks, N * 2, rows, d_mix, stream);
 }
 
 // ---- maxiOsc::noise (C:214-220) -----------------------------------------------------------------

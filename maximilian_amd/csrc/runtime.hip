@@ -39,10 +39,11 @@ Tune g_tune[] = {
     {"voice_xcd", 0, 0, 2},    // 0 automatic, 1 natural workgroup order, 2 XCD-contiguous
     {"osc_store", 0, 0, 5},  // K1 store stream (osc.hip pick<WF>): 0 automatic; one voice per lane: 1 plain 8 B, 2 nt 8 B, 3 / 4 / 5 pair rows (16 B) plain / sc1 / nt; two voices per lane: 1 plain, 2 nt, 3 sc1
     {"osc_xcd", 0, 0, 2},  // K1: 1 = every XCD renders one contiguous eighth of the bank (workgroup renumbering, mxg_common.h)
+    {"osc_persist", 0, 0, 4},  // K1p: the persistent grid (a fixed number of wavefronts per SIMD, equal shares of voices x samples): 0 automatic, 1 off, 2 / 3 / 4 = one / two / four wavefronts per SIMD
     {"osc_split", 0, 0, 8},  // K1: time parts per voice group (0 = automatic: 2 for sinewave / coswave / sinebuf4 below 131 072 voices; up to 8 for the table oscillators on banks smaller than the machine; else 1)
     {"osc_mix_store", 0, 0, 2},  // K1m per-voice block: 0 automatic, 1 plain 8-byte stores, 2 pair rows of write-through 16-byte stores
     {"osc_mix_split", 0, 0, 4},  // K1m time parts (0 automatic: two below 2048 wavefronts)
-    {"osc_mix_var", 0, 0, 4},  // K1m A/B: 0 swap butterfly; 1 same, window 128; 2 DPP butterfly 128; 3 DPP 512 (1-3: sinebuf only); 4 cross-row sums on the matrix pipe
+    {"osc_mix_win", 0, 0, 256},  // K1m: samples per workgroup combine window (0 automatic: 256, 128 from 131 073 voices; 128 / 256)
     {"ifft_stream", 1, 0, 2},  // maxiIFFT: transform + hop buffer in one kernel (0: never; 1: where hop >= fftSize / 2; 2: wherever it fits)
     {"smp_pipe", 1, 0, 1},   // K5: the time-part kernel's loads of chunk k+1 issued before the stores of chunk k (0: chunk after chunk)
     {"smp_split", 0, 0, 8},  // K5: time parts of a block-constant *AtSpeed launch (0 = automatic: ~4 wavefronts per SIMD)
@@ -79,12 +80,30 @@ int check_hip(hipError_t e, const char *what) {
                 hipGetErrorString(e));
 }
 
-int ensure_init() {
-    if (g_inited) return async_error_poll();
+// Compute and synchronisation entry points: initialise on first use and report (once, then clear) a pending asynchronous device
+// error -- the call that finds one returns it and does NOT run.  Everything else (allocation, copies, plan / queue / event
+// creation, uploads) goes through ensure_init_only(): a pending error must not turn a malloc into NULL or a plan into a
+// half-built object; it stays pending for the next compute or sync call.
+int ensure_init_only() {
+    if (g_inited) return MXG_OK;
     return mxg_init(-1);
+}
+int ensure_init() {
+    if (int s = ensure_init_only()) return s;
+    return async_error_poll();
 }
 
 hipStream_t resolve_stream(void *stream) { return stream ? (hipStream_t)stream : g_stream; }
+
+int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, g_device >= 0 ? g_device : 0) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus;
+}
 
 namespace {
 struct ScratchBuf {
@@ -119,7 +138,10 @@ int *async_error_word() { return g_async_dev; }
 int async_error_status(int code) {
     if (code == ASYNC_OK) return MXG_OK;
     if (code == ASYNC_PART_TIMEOUT) {
-        g_part_dirty = true;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);  // (read under g_mu by part_sync_get)
+            g_part_dirty = true;
+        }
         return fail(MXG_ERR_HIP, "asynchronous device error: a time-split kernel (osc / sample *AtSpeed) timed out waiting for its "
                                  "sibling parts; the per-voice state of that launch was not stored");
     }
@@ -142,9 +164,8 @@ int async_error_status(int code) {
 
 int async_error_poll() {
     if (!g_async_host) return MXG_OK;
-    const int code = __atomic_load_n(g_async_host, __ATOMIC_ACQUIRE);
-    if (code == ASYNC_OK) return MXG_OK;
-    __atomic_store_n(g_async_host, 0, __ATOMIC_RELEASE);
+    if (__atomic_load_n(g_async_host, __ATOMIC_ACQUIRE) == ASYNC_OK) return MXG_OK;  // (the common case: no write to the shared word)
+    const int code = __atomic_exchange_n(g_async_host, 0, __ATOMIC_ACQ_REL);  // one step: a code stored in between is not lost
     return async_error_status(code);
 }
 
@@ -310,7 +331,7 @@ int mxg_settings(size_t sampleRate, size_t channels, size_t bufferSize) {
 size_t mxg_sample_rate(void) { return g_settings.sampleRate; }
 
 void *mxg_malloc(size_t bytes) {
-    if (ensure_init()) return nullptr;
+    if (ensure_init_only()) return nullptr;
     LibcPrngGuard prng;  // (the first allocation initialises more of the runtime)
     void *p = nullptr;
     if (check_hip(hipMalloc(&p, bytes ? bytes : 8), "hipMalloc")) return nullptr;
@@ -322,36 +343,36 @@ int mxg_free(void *d_ptr) {
     return MXG_OK;
 }
 int mxg_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream) {
-    if (int s = ensure_init()) return s;
+    if (int s = ensure_init_only()) return s;
     hipStream_t st = resolve_stream(stream);
     MXG_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
     MXG_HIP(hipStreamSynchronize(st));  // h_src is borrowed for the call only
     return MXG_OK;
 }
 int mxg_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream) {
-    if (int s = ensure_init()) return s;
+    if (int s = ensure_init_only()) return s;
     hipStream_t st = resolve_stream(stream);
     MXG_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
     MXG_HIP(hipStreamSynchronize(st));
     return async_error_poll();  // whatever the work before the copy reported
 }
 int mxg_memcpy_h2d_async(void *d_dst, const void *h_src, size_t bytes, void *stream) {
-    if (int s = ensure_init()) return s;
+    if (int s = ensure_init_only()) return s;
     MXG_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, resolve_stream(stream)));
     return MXG_OK;
 }
 int mxg_memcpy_d2h_async(void *h_dst, const void *d_src, size_t bytes, void *stream) {
-    if (int s = ensure_init()) return s;
+    if (int s = ensure_init_only()) return s;
     MXG_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, resolve_stream(stream)));
     return MXG_OK;
 }
 int mxg_memcpy_d2d_async(void *d_dst, const void *d_src, size_t bytes, void *stream) {
-    if (int s = ensure_init()) return s;
+    if (int s = ensure_init_only()) return s;
     if (bytes) MXG_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, resolve_stream(stream)));
     return MXG_OK;
 }
 void *mxg_host_alloc(size_t bytes) {
-    if (ensure_init()) return nullptr;
+    if (ensure_init_only()) return nullptr;
     void *p = nullptr;
     if (check_hip(hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault), "hipHostMalloc")) return nullptr;
     return p;
@@ -361,12 +382,12 @@ int mxg_host_free(void *h_ptr) {
     return MXG_OK;
 }
 int mxg_memset(void *d_dst, int value, size_t bytes, void *stream) {
-    if (int s = ensure_init()) return s;
+    if (int s = ensure_init_only()) return s;
     MXG_HIP(hipMemsetAsync(d_dst, value, bytes, resolve_stream(stream)));
     return MXG_OK;
 }
 void *mxg_stream_create(void) {
-    if (ensure_init()) return nullptr;
+    if (ensure_init_only()) return nullptr;
     hipStream_t s = nullptr;
     if (check_hip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"))
         return nullptr;
@@ -400,7 +421,7 @@ int mxg_sync(void) {
 }
 int mxg_last_async_error(void) { return async_error_poll(); }
 void *mxg_event_create(void) {
-    if (ensure_init()) return nullptr;
+    if (ensure_init_only()) return nullptr;
     hipEvent_t e = nullptr;
     if (check_hip(hipEventCreate(&e), "hipEventCreate")) return nullptr;
     return (void *)e;
@@ -410,7 +431,7 @@ int mxg_event_destroy(void *event) {
     return MXG_OK;
 }
 int mxg_event_record(void *event, void *stream) {
-    if (int s = ensure_init()) return s;
+    if (int s = ensure_init_only()) return s;
     MXG_REQUIRE(event, "null event");
     MXG_HIP(hipEventRecord((hipEvent_t)event, resolve_stream(stream)));
     return MXG_OK;
@@ -431,7 +452,7 @@ int mxg_event_query(void *event) {  // 1 complete, 0 still running
     return check_hip(e, "hipEventQuery");
 }
 int mxg_stream_wait_event(void *stream, void *event) {
-    if (int s = ensure_init()) return s;
+    if (int s = ensure_init_only()) return s;
     MXG_REQUIRE(event, "null event");
     MXG_HIP(hipStreamWaitEvent(resolve_stream(stream), (hipEvent_t)event, 0));
     return MXG_OK;
@@ -500,7 +521,7 @@ int mxg_prof_read(int index, const char **h_label, double *h_total_ms, size_t *h
 }
 
 int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms) {
-    if (int s = ensure_init()) return s;
+    if (int s = ensure_init_only()) return s;
     MXG_REQUIRE(pairs > 0 && pairs <= 4096 && h_ms, "bad argument");
     hipStream_t st = resolve_stream(stream);
     MXG_HIP(hipStreamSynchronize(st));

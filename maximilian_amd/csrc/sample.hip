@@ -717,7 +717,7 @@ int mxg_delay_render(int mode, size_t V, size_t N, const double *d_in, const int
 }
 
 double *mxg_sample_upload(const double *h_samples, size_t len) {
-    if (ensure_init()) return nullptr;
+    if (ensure_init_only()) return nullptr;
     if (!h_samples && len) {
         fail(MXG_ERR_INVALID, "mxg_sample_upload: null samples");
         return nullptr;

@@ -70,7 +70,7 @@ using namespace mxg;
 extern "C" {
 
 double *mxg_sample_load_wav(const char *path, int channel, size_t *h_len, int32_t *h_hdr) {
-    if (ensure_init()) return nullptr;
+    if (ensure_init_only()) return nullptr;
     if (!path || !h_len) {
         fail(MXG_ERR_INVALID, "mxg_sample_load_wav: null argument");
         return nullptr;

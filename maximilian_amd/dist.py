@@ -72,11 +72,12 @@ def create_comm(dist, rank, world, device=None):
 class RcclMixQueue:
     """mxg_mixq: batched, overlapped sum-reduce of [block_doubles] mix blocks to `root` (include/maxigpu.h)."""
 
-    def __init__(self, comm, block_doubles, depth_blocks=16, root=0, stream=None):
+    def __init__(self, comm, block_doubles, depth_blocks=16, root=0, stream=None, groups=1):
         from ._lib import lib
         self.L = lib()
-        self.block, self.depth, self.stream = int(block_doubles), int(depth_blocks), stream
-        self.q = self.L.mxg_mixq_create(comm, self.block, self.depth, root)
+        self.block, self.depth, self.stream, self.groups = int(block_doubles), int(depth_blocks), stream, int(groups)
+        # groups > 1: a slot is [groups][block] partial rows (mxg_osc_render_mix_rows) which the queue adds on its own stream
+        self.q = self.L.mxg_mixq_create_grouped(comm, self.block, self.depth, root, self.groups)
         if not self.q:
             raise RuntimeError("mxg_mixq_create: " + self.L.mxg_last_error().decode())
 
@@ -128,9 +129,11 @@ class HostMixQueue:
     tests).  Same batching, same double buffering, same result semantics -- so the step function the product runs is
     the one the CPU tests exercise."""
 
-    def __init__(self, dist, block_doubles, depth_blocks=16, root=0):
+    def __init__(self, dist, block_doubles, depth_blocks=16, root=0, groups=1):
         import torch
-        self.dist, self.block, self.depth, self.root = dist, int(block_doubles), int(depth_blocks), root
+        self.dist, self.block, self.depth, self.root, self.groups = dist, int(block_doubles), int(depth_blocks), root, int(groups)
+        # groups > 1: a slot is [groups][block] partial rows, added in ascending order when the batch is submitted (mxg_mixq's fold)
+        self.gstage = [torch.zeros((self.depth, self.groups, self.block), dtype=torch.float64) for _ in range(2)] if self.groups > 1 else None
         self.stage = [torch.zeros((self.depth, self.block), dtype=torch.float64) for _ in range(2)]
         self.res = [torch.zeros((self.depth, self.block), dtype=torch.float64) for _ in range(2)]
         self.work = [None, None]
@@ -146,10 +149,18 @@ class HostMixQueue:
             self.work[b].wait()
             self.work[b] = None
         self.slot_out = True
+        if self.gstage is not None:
+            return self.gstage[b][self.fill]  # a [groups][block] view
         return self.stage[b][self.fill]  # a [block] view the caller fills in place
 
     def _submit(self):
         b = self.cur
+        if self.gstage is not None:
+            for k in range(self.fill):
+                acc = self.gstage[b][k][0].clone()
+                for g in range(1, self.groups):
+                    acc += self.gstage[b][k][g]
+                self.stage[b][k].copy_(acc)
         self.res[b][:self.fill].copy_(self.stage[b][:self.fill])
         if self._multi():
             self.work[b] = self.dist.reduce(self.res[b][:self.fill], dst=self.root, op=self.dist.ReduceOp.SUM, async_op=True)

@@ -165,6 +165,18 @@ struct FakeDev {
         });
         return 0;
     }
+    int fold(const double *src, double *dst, size_t blocks, size_t groups, size_t block, Stream s) {
+        s->enqueue([src, dst, blocks, groups, block] {
+            for (size_t k = 0; k < blocks; k++)
+                for (size_t i = 0; i < block; i++) {
+                    double t = src[(k * groups) * block + i];
+                    for (size_t g = 1; g < groups; g++) t += src[(k * groups + g) * block + i];
+                    dst[k * block + i] = t;
+                    if ((i & 63) == 0) std::this_thread::yield();  // (read slowly: a premature refill of the rows is caught)
+                }
+        });
+        return 0;
+    }
     bool is_root(int root) { return rank == root; }
 };
 
@@ -176,10 +188,13 @@ struct RankCtx {
     FakeEvent ev[6];
     mxg::MixQueueCore<FakeDev> q;
     std::vector<double> mem[4];
+    std::vector<double> gmem[2];
     std::vector<double> sink;
 };
 
-int run_case(size_t block, int depth, size_t blocks, int delay_us, unsigned seed, bool verbose) {
+// groups > 1: a slot is [groups][block] rows -- row 0 carries value(), row g > 0 the constant g (all exact), so the fold's sum is
+// value + groups (groups - 1) / 2
+int run_case(size_t block, int depth, size_t blocks, int delay_us, unsigned seed, bool verbose, size_t groups = 1) {
     Fabric fab;
     std::atomic<int> errors{0};
     RankCtx R[2];
@@ -193,6 +208,8 @@ int run_case(size_t block, int depth, size_t blocks, int delay_us, unsigned seed
         c.qs.reset(new FakeStream(seed * 11 + r * 5 + 2, delay_us));
         c.reader.reset(new FakeStream(seed * 13 + r * 7 + 3, delay_us * 3));
         for (int b = 0; b < 4; b++) c.mem[b].assign(block * (size_t)depth, -1.0);
+        for (int b = 0; b < 2; b++) c.gmem[b].assign(groups > 1 ? block * (size_t)depth * groups : 1, -5.0);
+        c.q.groups = groups;
         c.q.dev = &c.dev;
         c.q.block = block;
         c.q.depth = depth;
@@ -200,6 +217,7 @@ int run_case(size_t block, int depth, size_t blocks, int delay_us, unsigned seed
         for (int b = 0; b < 2; b++) {
             c.q.stage[b] = c.mem[b].data();
             c.q.result[b] = c.mem[2 + b].data();
+            if (groups > 1) c.q.gstage[b] = c.gmem[b].data();
             c.q.filled[b] = &c.ev[b];
             c.q.reduced[b] = &c.ev[2 + b];
             c.q.consumed[b] = &c.ev[4 + b];
@@ -225,8 +243,10 @@ int run_case(size_t block, int depth, size_t blocks, int delay_us, unsigned seed
                 errors++;
                 return;
             }
-            c.caller->enqueue([slot, r, k, block] {  // the "kernel" that renders + mixes block k into its slot
+            c.caller->enqueue([slot, r, k, block, groups] {  // the "kernel" that renders + mixes block k into its slot
                 for (size_t i = 0; i < block; i++) slot[i] = value(r, k, i);
+                for (size_t g = 1; g < groups; g++)
+                    for (size_t i = 0; i < block; i++) slot[g * block + i] = (double)g;
             });
             const size_t before = c.q.batches;
             if (c.q.push(c.caller.get())) errors++;
@@ -278,9 +298,10 @@ int run_case(size_t block, int depth, size_t blocks, int delay_us, unsigned seed
     t1.join();
     // after flush + sync: result() of the last batch, every asynchronous read, the sink ring
     size_t bad_seen = 0, bad_sink = 0, bad_last = 0;
+    const double gsum = (double)(groups * (groups - 1));  // both ranks' rows 1 .. groups - 1
     for (size_t k = 0; k < blocks; k++)
         for (size_t i = 0; i < block; i++) {
-            const double want = value(0, k, i) + value(1, k, i);
+            const double want = value(0, k, i) + value(1, k, i) + gsum;
             if (seen[k * block + i] != want) bad_seen++;
             const double sc = sink_copy[k * block + i];
             if (sc != -4.0 && sc != want) bad_sink++;
@@ -290,18 +311,18 @@ int run_case(size_t block, int depth, size_t blocks, int delay_us, unsigned seed
         const size_t first = blocks - c.q.last_blocks;
         for (size_t k = 0; k < c.q.last_blocks; k++)
             for (size_t i = 0; i < block; i++)
-                if (c.q.result[c.q.last][k * block + i] != value(0, first + k, i) + value(1, first + k, i)) bad_last++;
+                if (c.q.result[c.q.last][k * block + i] != value(0, first + k, i) + value(1, first + k, i) + gsum) bad_last++;
         // the ring's final content: the last `ring` blocks
         for (size_t k = blocks > ring ? blocks - ring : 0; k < blocks; k++)
             for (size_t i = 0; i < block; i++)
-                if (c.sink[(k % ring) * block + i] != value(0, k, i) + value(1, k, i)) bad_sink++;
+                if (c.sink[(k % ring) * block + i] != value(0, k, i) + value(1, k, i) + gsum) bad_sink++;
     }
     const size_t expect_batches = (blocks + (size_t)depth - 1) / (size_t)depth;
     int bad = errors.load() + (R[0].q.batches != expect_batches) + (R[1].q.batches != expect_batches);
     if (verbose || bad || bad_seen || bad_sink || bad_last)
-        printf("case block=%zu depth=%d blocks=%zu delay=%dus seed=%u: batches %zu/%zu, wrong async reads %zu, wrong sink %zu, "
+        printf("case block=%zu depth=%d blocks=%zu groups=%zu delay=%dus seed=%u: batches %zu/%zu, wrong async reads %zu, wrong sink %zu, "
                "wrong last result %zu, protocol errors %d\n",
-               block, depth, blocks, delay_us, seed, R[0].q.batches, expect_batches, bad_seen, bad_sink, bad_last, errors.load());
+               block, depth, blocks, groups, delay_us, seed, R[0].q.batches, expect_batches, bad_seen, bad_sink, bad_last, errors.load());
     return bad + (bad_seen != 0) + (bad_sink != 0) + (bad_last != 0);
 }
 
@@ -317,6 +338,13 @@ int main(int argc, char **argv) {
         for (auto &c : cfg) {
             failed += run_case(c[0], (int)c[1], c[2], rnd % 3 == 0 ? 0 : 40 * (rnd % 3), 1000u + (unsigned)rnd * 97u + (unsigned)cases,
                                false) != 0;
+            cases++;
+        }
+        // grouped slots (the config-2 step: the queue folds [groups][block] rows per block on its own stream before the reduce)
+        const size_t gcfg[][4] = {{64, 3, 7, 4}, {128, 16, 50, 3}, {32, 2, 21, 7}};
+        for (auto &c : gcfg) {
+            failed += run_case(c[0], (int)c[1], c[2], rnd % 3 == 0 ? 0 : 40 * (rnd % 3), 5000u + (unsigned)rnd * 89u + (unsigned)cases,
+                               false, c[3]) != 0;
             cases++;
         }
     }

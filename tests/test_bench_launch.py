@@ -60,3 +60,26 @@ def test_two_ranks_sharing_one_gpu_print_the_scaling_fields():
     assert 0.0 < d["per_gpu_efficiency"] <= 1.0
     assert d["value_like_for_like_n1"] > 0 and d["step_ms_without_reduce"] > 0
     assert d["roofline"]["kernel"] == "osc_mix_kernel"
+
+
+@pytest.mark.gpu
+def test_default_line_carries_every_gpu_config():
+    """The command the driver runs (`bench.py --gpus 1 --steps K --warmup W`) reports configs 3, 4, 4-mfma, 5 and the fused-mixdown
+    step next to the headline: each with its own ms_per_step, value and the roofline of its dominant kernel."""
+    r = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"], timeout=900)
+    assert r.returncode == 0, (r.stderr + r.stdout)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["roofline"]["kernel"] == "osc_kernel" and 0.3 < d["roofline"]["frac"] < 1.0
+    want = {"config2_mixdown": "osc_mix_kernel", "config3": "voice_kernel", "config4": "fft_mfcc_kernel",
+            "config4_mfma": "mfcc_mfma_gemm_kernel", "config5": "granular_unit_kernel"}
+    assert set(d["configs"]) == set(want), d["configs"].keys()
+    for name, kernel in want.items():
+        c = d["configs"][name]
+        assert "error" not in c, c
+        assert c["ms_per_step"] > 0 and c["value"] > 0 and c["roofline"]["kernel"] == kernel, c
+        assert 0.0 < c["roofline"]["frac"] < 1.0 and c["roofline"]["kernel_ms"] <= c["ms_per_step"] * 1.001, c
+        assert ("flops_per_launch" in c["roofline"]) == (name == "config4_mfma")
+    # the fused-mixdown step (what every rank of an N > 1 run does per block) costs about what the plain render costs
+    assert d["configs"]["config2_mixdown"]["step_vs_headline"] < 1.25

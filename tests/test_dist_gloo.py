@@ -14,7 +14,7 @@ import pytest
 
 from conftest import ROOT, mix_tol
 
-CFG2 = dict(Vr=96, B=64, blocks=7, M=3)          # 7 blocks, 3 per reduce: batches of 3, 3 and a flushed 1
+CFG2 = dict(Vr=96, B=64, blocks=7, M=3, G=32)    # 7 blocks, 3 per reduce: batches of 3, 3 and a flushed 1; slots of 3 rows of 32 voices
 CFG5 = dict(Sr=24, T=1500, L=30000)
 
 
@@ -48,13 +48,18 @@ def _worker(rank, world, port, q):
     c = CFG2
     lo, hi = shard_range(rank, world, c["Vr"])
     freq, pan = bank_parameters(lo, hi, c["Vr"] * world)
-    queue = HostMixQueue(dist, c["B"] * 2, depth_blocks=c["M"])
+    # grouped slots, as the product's config-2 step uses them (mxg_osc_render_mix_rows + mxg_mixq_create_grouped): the render
+    # leaves one partial mix per group of voices (256 on the device, G here) and the queue adds the rows when it submits a batch
+    groups = -(-c["Vr"] // c["G"])
+    queue = HostMixQueue(dist, c["B"] * 2, depth_blocks=c["M"], groups=groups)
     state = {"phase": None, "hold": None}
     got2 = []
 
     def render_mix(slot):
         out, state["phase"], state["hold"] = orc.osc(8, freq, c["B"], phase=state["phase"], hold=state["hold"])
-        slot.copy_(torch.from_numpy(orc.mix_stereo(out, pan).reshape(-1)))
+        for g in range(groups):
+            sl = slice(g * c["G"], (g + 1) * c["G"])
+            slot[g].copy_(torch.from_numpy(orc.mix_stereo(out[:, sl], pan[sl]).reshape(-1)))
 
     step = MixdownStep(render_mix, queue)
     for k in range(c["blocks"]):

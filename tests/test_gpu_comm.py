@@ -73,6 +73,34 @@ def test_mix_queue_batches(mx, comm1, with_comm, depth, nblocks):
         assert_bits_equal(got[k].reshape(B, 2), expect[k], "block %d" % k)
 
 
+@pytest.mark.parametrize("with_comm", [False, True])
+@pytest.mark.parametrize("depth,nblocks", [(16, 37), (4, 3), (1, 2)])
+def test_grouped_mix_queue(mx, comm1, with_comm, depth, nblocks):
+    """mxg_mixq_create_grouped + mxg_osc_render_mix_rows (the config-2 step of bench.py --gpus N): the render leaves the
+    per-workgroup rows in the queue's slot and the QUEUE adds them, batch by batch, on its own stream -- the results are the bits
+    of the un-queued mxg_osc_render_mix (same rows, same order of additions)."""
+    from maximilian_amd.dist import RcclMixQueue, bank_parameters
+    L = mx.lib()
+    expect = _bank_mixes(mx, nblocks)
+    G = L.mxg_osc_mix_groups(V)
+    q = RcclMixQueue(comm1 if with_comm else None, B * 2, depth, groups=G)
+    freq, pan = bank_parameters(0, V, V)
+    bank = mx.maxiOscBank(V)
+    got = []
+    for k in range(nblocks):
+        bank.render_mix("sinebuf", freq, pan, B, store=False, rows=q.slot())
+        q.push()
+        if (k + 1) % depth == 0:
+            got.extend(q.result_numpy())
+    if nblocks % depth:
+        got.extend(q.result_numpy())
+    q.close()
+    assert len(got) == nblocks
+    for k in range(nblocks):
+        assert_bits_equal(got[k].reshape(B, 2), expect[k], "block %d" % k)
+    assert not L.mxg_mixq_create_grouped(None, 64, 2, 0, 0)
+
+
 def test_queue_protocol_errors(mx):
     from maximilian_amd.dist import RcclMixQueue
     L = mx.lib()

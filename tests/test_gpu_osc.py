@@ -129,6 +129,34 @@ def test_store_streams_do_not_change_results(mx, port, vpl, store, block, xcd, V
         L.mxg_tune(b"osc_xcd", prev[3])
 
 
+@pytest.mark.parametrize("persist,store", [(2, 4), (3, 1), (4, 3), (2, 2), (3, 5)])
+@pytest.mark.parametrize("V,N", [(4096 + 2, 301), (512, 2), (70000, 64), (4097, 33), (98304, 48), (64, 1000)])
+def test_persistent_grid_same_bits(mx, port, persist, store, V, N):
+    """K1 on a persistent grid (knob osc_persist: k wavefronts per SIMD, the block of voice columns x samples cut into equal shares:
+    tail piece, whole columns, head piece per wavefront; pieces that start inside a column skip to their first sample; the piece
+    that ends a column stores the state after the others have signalled): the oracle's bits for the samples and the carried state,
+    whatever the shares look like -- many pieces per column (small banks), many columns per wavefront, ragged last columns, odd
+    banks (8-byte stores), every store flavour."""
+    L = mx.lib()
+    prev = [L.mxg_tune(b"osc_persist", persist), L.mxg_tune(b"osc_store", store)]
+    try:
+        rng = np.random.default_rng(V * 3 + N)
+        freq = rng.uniform(20, 20000, V)
+        for wf in ((8, 9, 2, 0, 6) if V < 50000 else (8,)):
+            p1 = rng.uniform(0.1, 0.9, V)
+            out, ph, hd = _render(mx, wf, freq, N, blocks=3, p1=p1 if wf == 6 else None)
+            eo, eph, ehd = port.osc(wf, freq, 3 * N, p1=p1 if wf == 6 else None)
+            if wf == 0:
+                assert ulp_diff(out, eo).max() <= TRIG_MAX_ULP
+            else:
+                assert_bits_equal(out, eo, OSC[wf])
+            assert_bits_equal(ph, eph, "phase")
+            if wf == 6:
+                assert_bits_equal(hd, ehd, "output member")
+    finally:
+        L.mxg_tune(b"osc_persist", prev[0]); L.mxg_tune(b"osc_store", prev[1])
+
+
 def test_empty_and_invalid(mx):
     L = mx.lib()
     bank = mx.maxiOscBank(4)
@@ -206,21 +234,28 @@ def test_render_mix_fused(mx, port, wf, V, N):
             assert_bits_equal(bank3.phase.numpy(), eph, "phase, store %d split %d" % (store, split))
         finally:
             L.mxg_tune(b"osc_mix_store", prev[0]); L.mxg_tune(b"osc_mix_split", prev[1])
-    # the matrix-pipe form of the cross-row sums (osc_mix_var 4): the per-voice block and the phase are the same bits; the mix is
-    # summed in another order (four products per MFMA, then the rows): within the same stated tolerance of the reference's sum
-    for store, split in ((2, 1), (1, 2), (0, 1)):
-        prev = [L.mxg_tune(b"osc_mix_var", 4), L.mxg_tune(b"osc_mix_store", max(store, 1)), L.mxg_tune(b"osc_mix_split", split)]
+    # the rows form (what a grouped mix queue's slot receives): rows [ceil(V / 256)][N][2], added by mxg_mix_rows_sum = the same mix
+    # bits; the combine window (osc_mix_win 128 / 256) changes neither the rows nor the block
+    G = L.mxg_osc_mix_groups(V)
+    assert G == (V + 255) // 256
+    for win in (128, 256):
+        prev = L.mxg_tune(b"osc_mix_win", win)
         try:
             bank4 = mx.maxiOscBank(V)
-            o4, m4 = bank4.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V), store=store != 0)
-            o5, m5 = bank4.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V), store=store != 0)
-            if store:
-                assert_bits_equal(np.concatenate([o4.numpy(), o5.numpy()]), eo, "matrix-pipe form, store %d" % store)
-            assert_bits_equal(bank4.phase.numpy(), eph, "phase, matrix-pipe form")
-            m45 = np.concatenate([m4.numpy(), m5.numpy()])
-            assert np.abs(m45 - em).max() <= mix_tol(V, np.abs(eo).max())
+            rows = mx.DeviceBuffer((G, N, 2))
+            o4, none = bank4.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V), rows=rows)
+            assert none is None
+            assert_bits_equal(o4.numpy(), out1.numpy(), "rows form, window %d" % win)
+            msum = mx.DeviceBuffer((N, 2))
+            mx._lib.check(L.mxg_mix_rows_sum(G, N * 2, rows.ptr, msum.ptr, None), "mxg_mix_rows_sum")
+            assert_bits_equal(msum.numpy(), mix1.numpy(), "sum of the rows, window %d" % win)
+            r = rows.numpy()
+            for g in range(G):  # every row is the mix of its own 256 voices
+                sl = slice(256 * g, min(V, 256 * g + 256))
+                eg = port.mix_stereo(eo[:N, sl], pan[sl])
+                assert np.abs(r[g] - eg).max() <= mix_tol(256, np.abs(eo).max())
         finally:
-            L.mxg_tune(b"osc_mix_var", prev[0]); L.mxg_tune(b"osc_mix_store", prev[1]); L.mxg_tune(b"osc_mix_split", prev[2])
+            L.mxg_tune(b"osc_mix_win", prev)
 
 
 @pytest.mark.parametrize("wf,V,N", [(0, 1000, 601), (1, 64, 3), (8, 300, 512), (6, 129, 77), (10, 70, 1), (5, 4096, 130)])

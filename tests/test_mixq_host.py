@@ -24,14 +24,14 @@ def _build(tmp_path, name, defs=()):
 def test_mix_queue_protocol_two_ranks_many_batches(tmp_path):
     r = subprocess.run([_build(tmp_path, "mixq"), "12"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert "72 cases, 0 failed" in r.stdout, r.stdout[-3000:]
+    assert "108 cases, 0 failed" in r.stdout, r.stdout[-3000:]
 
 
 @pytest.mark.parametrize("mutant", ["MXG_MIXQ_MUTATE_NO_SLOT_WAIT", "MXG_MIXQ_MUTATE_NO_CONSUMED_WAIT"])
 def test_mix_queue_harness_catches_a_missing_wait(tmp_path, mutant):
     exe = _build(tmp_path, "mixq_mut", ["-D" + mutant])
     # the mutants are RACES: whether one shows in a given run depends on the worker threads' timing (a loaded machine can hide
-    # it for 72 cases).  The harness has to catch it within a few attempts of growing length, not necessarily in the first.
+    # it for 108 cases).  The harness has to catch it within a few attempts of growing length, not necessarily in the first.
     out = ""
     for rounds in ("12", "24", "48", "96"):
         r = subprocess.run([exe, rounds], capture_output=True, text=True, timeout=600)
