@@ -42,14 +42,14 @@ public:
         const vector<double> &amps = impulse.getAmplitudes();
         const double position0 = loaded ? (double)amps.size() : (double)amps.size() - 1;  // C:681 / H:677
         c_ = mxg_convolve_create(amps.data(), amps.size(), position0, fftsize, hopsize);
-        if (!c_) throw std::runtime_error(std::string("mxg_convolve_create: ") + mxg_last_error());
+        if (!c_) maxigpu::ps::fatal(std::string("mxg_convolve_create: ") + mxg_last_error());
         F_ = fftsize;
         in_.assign((size_t)F_, 0.0f);
         out_.assign((size_t)F_, 0.0f);
         pos_ = 0;
         if (d_io_) mxg_free(d_io_);
         d_io_ = static_cast<float *>(mxg_malloc(sizeof(float) * 2 * (size_t)F_));
-        if (!d_io_) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+        if (!d_io_) maxigpu::ps::fatal(std::string("mxg_malloc: ") + mxg_last_error());
     }
     float play(float w) {  // L/maxiConvolve.cpp:76-107
         if (!c_) return 0.0f;

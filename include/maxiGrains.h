@@ -83,7 +83,7 @@ private:
         for (auto &p : plans_)
             if (p.first == key) return p.second;
         mxg_grain_plan *pl = mxg_grain_plan_create(kind_, grainLength, sample_->mySampleRate);
-        if (!pl) throw std::runtime_error(std::string("mxg_grain_plan_create: ") + mxg_last_error());
+        if (!pl) maxigpu::ps::fatal(std::string("mxg_grain_plan_create: ") + mxg_last_error());
         plans_.push_back(std::make_pair(key, pl));
         return pl;
     }
@@ -110,7 +110,7 @@ private:
         check(mxg_init(-1), "mxg_init");
         if (!d_) {
             d_ = static_cast<double *>(mxg_malloc(sizeof(double) * kDoubles));
-            if (!d_) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+            if (!d_) maxigpu::ps::fatal(std::string("mxg_malloc: ") + mxg_last_error());
         }
         double *d_st = d_, *d_gst = d_ + 4, *d_par = d_ + 36, *d_out = d_ + 39;
         int32_t *d_rnd = reinterpret_cast<int32_t *>(d_ + 39 + kMaxBlock);

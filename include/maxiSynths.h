@@ -7,7 +7,8 @@
 // back; a control call first rewinds the sampler to the state it had at the current sample (the block is re-rendered from its
 // start state up to there: same kernel, same bits), then edits that state on the host exactly as the reference's method does.
 // Limits against the reference: every slot plays the SAME sample (load / setSample with setall, the reference's default; a
-// per-slot load is refused), and the unused members (LFO1-4, filters, distortion: never touched by maxiSampler::play) are absent.
+// per-slot load is refused with a printed error), the voice count must be 1, 2, 4, 8, 16 or 32 (setNumVoices prints an error for any
+// other count and play() then returns silence: the reference accepts any count up to 32), and the unused members (LFO1-4, filters, distortion: never touched by maxiSampler::play) are absent.
 #pragma once
 #include "maximilian.h"
 
@@ -53,7 +54,7 @@ class maxiSampler {
         if (!d_) {
             check(mxg_init(-1), "mxg_init");
             d_ = static_cast<char *>(mxg_malloc(kBytes));
-            if (!d_) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+            if (!d_) maxigpu::ps::fatal(std::string("mxg_malloc: ") + mxg_last_error());
         }
         const Lay l = layout();
         std::vector<double> dst(2 * V);
@@ -153,9 +154,14 @@ public:
     void setNumVoices(int numVoices) {
         settle();
         voices = numVoices;
+        // (the reference accepts any count <= 32; here the slots of one sampler are gathered with lane shuffles in groups of a power of two)
+        if (!valid()) maxigpu::ps::complain("maxiSampler::setNumVoices: this backend renders 1, 2, 4, 8, 16 or 32 voices -- other counts play silence");
     }
     void load(string inFile, bool setall = true) {  // maxiSynths.cpp:303-321: samples[i].load(inFile) for every slot
-        if (!setall) throw std::runtime_error("maxiSampler::load(file, false): one sample per sampler on this backend (see include/maxiSynths.h)");
+        if (!setall) {  // (the reference loads the file into slot `currentVoice` only)
+            maxigpu::ps::complain("maxiSampler::load(file, false): one sample per sampler on this backend (see include/maxiSynths.h) -- not loaded");
+            return;
+        }
         settle();
         if (d_samples_) mxg_sample_free(d_samples_);
         int32_t hdr[8];
@@ -171,7 +177,7 @@ public:
         settle();
         if (d_samples_) mxg_sample_free(d_samples_);
         d_samples_ = mxg_sample_upload(sampleData.data(), sampleData.size());
-        if (!d_samples_) throw std::runtime_error(std::string("mxg_sample_upload: ") + mxg_last_error());
+        if (!d_samples_) maxigpu::ps::fatal(std::string("mxg_sample_upload: ") + mxg_last_error());
         len_ = sampleData.size();
         for (int i = 0; i < kMax; i++) cur_.position[i] = (double)len_ - 1;
     }

@@ -140,6 +140,7 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * of 64 * {1..32} samples be cut along time and joined by a wavefront scan: a 6-voice x 512-sample block in a few microseconds
  * instead of 23-28, with reordered arithmetic: |error| <= 1e-10 x the block's peak (measured <= 5e-12); default 0 = the bit-exact kernels),
  * "osc_persist" (K1 on a persistent grid of k wavefronts per SIMD with equal shares of voices x samples: 0 automatic, 1 off, 2 / 3 / 4 = k 1 / 2 / 4),
+ * "osc_passes" / "osc_mix_passes" (K1 / K1m: voice groups a wavefront renders one after the other, the grid covering 1 / passes of the bank: 0 automatic, 1..64),
  * "osc_split" (time parts per voice group in K1: 0 automatic, 1..8), "osc_mix_split" (the same for the fused render + mixdown K1m,
  * 0 automatic, 1..4), "osc_mix_store" (K1m's per-voice block: 0 automatic, 1 plain 8-byte stores, 2 pair rows of 16-byte stores),
  * "smp_split" (time parts of a block-constant playAtSpeed / playOnceAtSpeed / playUntilAtSpeed launch: 0 automatic, 1..8),

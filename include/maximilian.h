@@ -53,8 +53,27 @@ using namespace std;  // the reference header does (src/maximilian.h:54); exampl
 namespace maxigpu {
 namespace ps {  // per-sample engine
 
+// Device failures (a HIP error, an exhausted allocation) have no counterpart in the reference, whose classes never fail: they raise
+// std::runtime_error -- or, built with -DMAXIGPU_NO_EXCEPTIONS (a host that runs play() on an audio thread and cannot unwind through
+// its C callback), print the message and abort().  API misuse the reference lets pass (process() before setup(), a short vector)
+// never throws: it prints once and returns silence / false (complain()).
+[[noreturn]] inline void fatal(const std::string &msg) {
+#ifdef MAXIGPU_NO_EXCEPTIONS
+    std::fprintf(stderr, "maxigpu: %s\n", msg.c_str());
+    std::abort();
+#else
+    throw std::runtime_error(msg);
+#endif
+}
 inline void check(int status, const char *what) {
-    if (status < 0) throw std::runtime_error(std::string(what) + ": " + mxg_last_error());
+    if (status < 0) fatal(std::string(what) + ": " + mxg_last_error());
+}
+inline void complain(const char *msg) {  // the reference's style (printf("ERROR: ...")), once per message
+    static std::vector<const char *> *seen = new std::vector<const char *>;
+    for (const char *m : *seen)
+        if (m == msg) return;
+    seen->push_back(msg);
+    std::fprintf(stderr, "ERROR: %s\n", msg);
 }
 
 constexpr size_t kMaxBlock = 512;
@@ -71,7 +90,7 @@ struct DevBuf {  // grow-only device array -- with a twin in pinned, device-mapp
             if (count > mn) {
                 if (map) mxg_host_free(map);
                 map = static_cast<T *>(mxg_host_alloc(count * sizeof(T)));
-                if (!map) throw std::runtime_error(std::string("mxg_host_alloc: ") + mxg_last_error());
+                if (!map) maxigpu::ps::fatal(std::string("mxg_host_alloc: ") + mxg_last_error());
                 mn = count;
             }
             return p = map;
@@ -79,7 +98,7 @@ struct DevBuf {  // grow-only device array -- with a twin in pinned, device-mapp
         if (count > n) {
             if (dev) mxg_free(dev);
             dev = static_cast<T *>(mxg_malloc(count * sizeof(T)));
-            if (!dev) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+            if (!dev) maxigpu::ps::fatal(std::string("mxg_malloc: ") + mxg_last_error());
             n = count;
         }
         return p = dev;
@@ -102,7 +121,7 @@ struct PinBuf {  // grow-only pinned host array
         if (count > n) {
             if (p) mxg_host_free(p);
             p = static_cast<T *>(mxg_host_alloc(count * sizeof(T)));
-            if (!p) throw std::runtime_error(std::string("mxg_host_alloc: ") + mxg_last_error());
+            if (!p) maxigpu::ps::fatal(std::string("mxg_host_alloc: ") + mxg_last_error());
             n = count;
         }
         return p;
@@ -537,7 +556,7 @@ private:
         if (!stream) {
             check(mxg_init(-1), "mxg_init");
             stream = mxg_stream_create();
-            if (!stream) throw std::runtime_error(std::string("mxg_stream_create: ") + mxg_last_error());
+            if (!stream) maxigpu::ps::fatal(std::string("mxg_stream_create: ") + mxg_last_error());
         }
     }
     void leave_group(Slot &s) {
@@ -752,6 +771,35 @@ P &pool() {
 }
 
 // ---- the pools -------------------------------------------------------------------------------------------
+// A public DATA member of a reference class whose value lives in the slot's state (the device's, between blocks): a read or a
+// write first settles the slot -- the state at the object's current sample, cached block dropped -- like the class's own setters.
+// (Reading such a member every sample costs the block cache: a patch that does it runs one launch per sample.)
+template <class PoolT, typename T, bool IS_INT, int IDX>
+class StateMember {
+    Slot *s_;
+    T get() const {
+        pool<PoolT>().settle(*s_);
+        return IS_INT ? (T)s_->si[IDX] : (T)s_->sd[IDX];
+    }
+    void put(T v) {
+        pool<PoolT>().settle(*s_);
+        if (IS_INT) s_->si[IDX] = (int64_t)v; else s_->sd[IDX] = (double)v;
+    }
+
+public:
+    explicit StateMember(Slot &s) : s_(&s) {}
+    StateMember(const StateMember &) = delete;  // (bound to ONE object's slot: the owner's copy operations copy the state itself)
+    operator T() const { return get(); }
+    StateMember &operator=(T v) { put(v); return *this; }
+    StateMember &operator=(const StateMember &o) { put(o.get()); return *this; }
+    StateMember &operator+=(T v) { put(get() + v); return *this; }
+    StateMember &operator-=(T v) { put(get() - v); return *this; }
+    StateMember &operator*=(T v) { put(get() * v); return *this; }
+    StateMember &operator/=(T v) { put(get() / v); return *this; }
+    StateMember &operator++() { put(get() + 1); return *this; }
+    StateMember &operator--() { put(get() - 1); return *this; }
+};
+
 struct OscPool : Pool {  // state: phase, output (H:173,176)
     OscPool() : Pool(2, 0) {}
     unsigned derivable(int method) const override {  // the frequency; pulse's width too (not noise()'s rand() draw)
@@ -971,13 +1019,16 @@ struct DelayPool : Pool {
     unsigned derivable(int) const override { return 1u; }  // the input signal
     bool can_prefetch() const override { return false; }
     void enqueue(Group &G) override {
-        if (G.m.size() != 1) throw std::runtime_error("maxiDelayline: one object per launch");
+        if (G.m.size() != 1) fatal("maxiDelayline: one object per launch");  // (an engine invariant, not a user error)
         Line *ln = const_cast<Line *>(static_cast<const Line *>(G.sig[0].key));
         const size_t L = G.L;
         const double *a = G.sig[0].a;  // input, size, feedback, position
         const int mode = G.sig[0].method;
-        const int32_t size = (int32_t)a[1];
-        if (size < 1 || (size_t)size > kCap) throw std::runtime_error("maxiDelayline: size out of range");
+        int32_t size = (int32_t)a[1];
+        if (size < 1 || (size_t)size > kCap) {  // the reference indexes memory[88200 * 8] with it unchecked (C:420-429): out of bounds there,
+            complain("maxiDelayline: size outside [1, 705600] -- clamped");  // clamped into the ring here
+            size = size < 1 ? 1 : (int32_t)kCap;
+        }
         if (G.restart && ln->saved) {  // undo the block rendered last
             const size_t head = ln->saved_n - ln->saved_wrap;
             if (head) check(mxg_memcpy_d2d_async(ln->d_mem + ln->saved_first, ln->d_save, sizeof(double) * head, stream), "d2d restore");
@@ -1086,8 +1137,9 @@ class maxiEnv {
 public:
     maxiEnv() { maxigpu::ps::pool<Pool>().attach(slot_); }
     ~maxiEnv() { maxigpu::ps::pool<Pool>().detach(slot_); }
-    maxiEnv(const maxiEnv &) = delete;
-    maxiEnv &operator=(const maxiEnv &) = delete;
+    // a plain value type in the reference (H:888-932): a copy is a second envelope that continues from the same state
+    maxiEnv(const maxiEnv &o) { maxigpu::ps::pool<Pool>().attach(slot_); copy_from(o); }
+    maxiEnv &operator=(const maxiEnv &o) { if (this != &o) copy_from(o); return *this; }
     double ar(double input, double attack = 1, double release = 0.9, long holdtime = 1, int trigger = 0) {
         return run(1, input, trigger, attack, 0.0, 0.0, release, holdtime);
     }
@@ -1100,6 +1152,16 @@ public:
     double attack = 0, decay = 0, sustain = 0, release = 0;
     int trigger = 0;
     long holdtime = 1;
+    double input = 0;  // (H:895: declared, never written by the class -- the methods' parameter shadows it)
+    // the running state (H:896, 901, 916-918): device state behind the slot, readable and writable like the reference's members
+    maxigpu::ps::StateMember<Pool, double, false, 0> amplitude{slot_};
+    maxigpu::ps::StateMember<Pool, double, false, 1> output{slot_};
+    maxigpu::ps::StateMember<Pool, long, true, 0> holdcount{slot_};
+    maxigpu::ps::StateMember<Pool, int, true, 1> attackphase{slot_};
+    maxigpu::ps::StateMember<Pool, int, true, 2> decayphase{slot_};
+    maxigpu::ps::StateMember<Pool, int, true, 3> sustainphase{slot_};
+    maxigpu::ps::StateMember<Pool, int, true, 4> holdphase{slot_};
+    maxigpu::ps::StateMember<Pool, int, true, 5> releasephase{slot_};
     void setRelease(double releaseMS) { release = mxg_env_coeff_host(2, releaseMS); }  // C:1469-1472
     void setDecay(double decayMS) { decay = mxg_env_coeff_host(1, decayMS); }          // C:1474-1477
     void setAttack(double attackMS) { attack = mxg_env_coeff_host(0, attackMS); }      // C:1479-1482
@@ -1107,6 +1169,16 @@ public:
     void setSustain(double sustainL) { sustain = sustainL; }                          // C:1491-1494
     int getTrigger() const { return trigger; }
     void setTrigger(int trigger_) { trigger = trigger_; }
+
+private:
+    void copy_from(const maxiEnv &o) {
+        maxigpu::ps::pool<Pool>().settle(const_cast<maxiEnv &>(o).slot_);
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        slot_.sd = o.slot_.sd;
+        slot_.si = o.slot_.si;
+        attack = o.attack; decay = o.decay; sustain = o.sustain; release = o.release;
+        trigger = o.trigger; holdtime = o.holdtime; input = o.input;
+    }
 };
 
 // ---- maxiMix (H:372-420; C:503-541) ------------------------------------------------------------------------------
@@ -1175,18 +1247,37 @@ class maxiFilter {
 public:
     maxiFilter() { maxigpu::ps::pool<Pool>().attach(slot_); }
     ~maxiFilter() { maxigpu::ps::pool<Pool>().detach(slot_); }
-    maxiFilter(const maxiFilter &) = delete;
-    maxiFilter &operator=(const maxiFilter &) = delete;
+    maxiFilter(const maxiFilter &o) { maxigpu::ps::pool<Pool>().attach(slot_); copy_from(o); }  // (a value type in the reference, H:289-366)
+    maxiFilter &operator=(const maxiFilter &o) { if (this != &o) copy_from(o); return *this; }
     double cutoff = 0, resonance = 0;
-    double lores(double input, double cutoff1, double resonance_) { return run(MXG_FLT_LORES, input, cutoff1, resonance_); }
-    double hires(double input, double cutoff1, double resonance_) { return run(MXG_FLT_HIRES, input, cutoff1, resonance_); }
-    double bandpass(double input, double cutoff1, double resonance_) { return run(MXG_FLT_BANDPASS, input, cutoff1, resonance_); }
+    // (the member `cutoff` receives the clamped cutoff1, C:456-458, 472-474, 488-489; `resonance` is shadowed by the parameter)
+    double lores(double input, double cutoff1, double resonance_) {
+        cutoff = cutoff1 < 10 ? 10 : (cutoff1 > (double)maxiSettings::sampleRate ? (double)maxiSettings::sampleRate : cutoff1);
+        return run(MXG_FLT_LORES, input, cutoff1, resonance_);
+    }
+    double hires(double input, double cutoff1, double resonance_) {
+        cutoff = cutoff1 < 10 ? 10 : (cutoff1 > (double)maxiSettings::sampleRate ? (double)maxiSettings::sampleRate : cutoff1);
+        return run(MXG_FLT_HIRES, input, cutoff1, resonance_);
+    }
+    double bandpass(double input, double cutoff1, double resonance_) {
+        cutoff = cutoff1 > (maxiSettings::sampleRate * 0.5) ? (maxiSettings::sampleRate * 0.5) : cutoff1;
+        return run(MXG_FLT_BANDPASS, input, cutoff1, resonance_);
+    }
     double lopass(double input, double cutoff_) { return run(MXG_FLT_LOPASS, input, cutoff_, 0.0); }
     double hipass(double input, double cutoff_) { return run(MXG_FLT_HIPASS, input, cutoff_, 0.0); }
     void setCutoff(double cut) { cutoff = cut; }
     void setResonance(double res) { resonance = res; }
     double getCutoff() const { return cutoff; }
     double getResonance() const { return resonance; }
+
+private:
+    void copy_from(const maxiFilter &o) {
+        maxigpu::ps::pool<Pool>().settle(const_cast<maxiFilter &>(o).slot_);
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        slot_.sd = o.slot_.sd;
+        cutoff = o.cutoff;
+        resonance = o.resonance;
+    }
 };
 
 // ---- maxiTrigger (H:564-596), maxiLagExp (H:499-560): host-side helpers of the reference, plain arithmetic -----------
@@ -1265,7 +1356,7 @@ class maxiSample {
     }
     void upload(const double *data, size_t n) {
         buf_.d = mxg_sample_upload(data, n);
-        if (!buf_.d) throw std::runtime_error(std::string("mxg_sample_upload: ") + mxg_last_error());
+        if (!buf_.d) maxigpu::ps::fatal(std::string("mxg_sample_upload: ") + mxg_last_error());
         buf_.len = n;
     }
     void fetch_host() {
@@ -1474,7 +1565,7 @@ class maxiDelayline {
         line_.d_mem = static_cast<double *>(mxg_malloc(sizeof(double) * Pool::kCap));
         line_.d_save = static_cast<double *>(mxg_malloc(sizeof(double) * maxigpu::ps::kMaxBlock));
         line_.d_i = static_cast<int32_t *>(mxg_malloc(sizeof(int32_t) * 4));
-        if (!line_.d_mem || !line_.d_save || !line_.d_i) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+        if (!line_.d_mem || !line_.d_save || !line_.d_i) maxigpu::ps::fatal(std::string("mxg_malloc: ") + mxg_last_error());
         maxigpu::ps::check(mxg_memset(line_.d_mem, 0, sizeof(double) * Pool::kCap, nullptr), "mxg_memset");  // ctor memset, C:415-417
         maxigpu::ps::check(mxg_sync(), "mxg_sync");
     }
@@ -1513,7 +1604,7 @@ public:
     void setup(int _fftSize = 1024, int _hopSize = 512, int _windowSize = 0) {  // L/maxiFFT.cpp:45-60
         release();
         plan_ = mxg_fft_plan_create(_fftSize, _hopSize, _windowSize);
-        if (!plan_) throw std::runtime_error(std::string("mxg_fft_plan_create: ") + mxg_last_error());
+        if (!plan_) maxigpu::ps::fatal(std::string("mxg_fft_plan_create: ") + mxg_last_error());
         fftSize = _fftSize;
         windowSize = _windowSize > fftSize ? _windowSize : fftSize;
         bins = fftSize / 2;
@@ -1528,10 +1619,13 @@ public:
         newFFT = 0;
         d_in_ = static_cast<float *>(mxg_malloc(sizeof(float) * fftSize));
         d_out_ = static_cast<float *>(mxg_malloc(sizeof(float) * 4 * bins));
-        if (!d_in_ || !d_out_) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+        if (!d_in_ || !d_out_) maxigpu::ps::fatal(std::string("mxg_malloc: ") + mxg_last_error());
     }
     bool process(float value, fftModes mode = maxiFFT::WITH_POLAR_CONVERSION) {  // L/maxiFFT.cpp:65-91
-        if (!plan_) throw std::logic_error("maxiFFT::process before setup()");  // (the reference writes through an empty vector)
+        if (!plan_) {  // (the reference writes through an empty vector here; no frame ever completes)
+            maxigpu::ps::complain("maxiFFT::process before setup()");
+            return false;
+        }
         buffer[pos++] = value;
         newFFT = pos == windowSize;
         if (newFFT) {
@@ -1603,16 +1697,18 @@ public:
     void setup(unsigned int numBins, unsigned int numFilters, unsigned int numCoeffs, double minFreq, double maxFreq) {  // :56-75
         release();
         plan_ = mxg_mfcc_plan_create(numBins, numFilters, numCoeffs, minFreq, maxFreq);
-        if (!plan_) throw std::runtime_error(std::string("mxg_mfcc_plan_create: ") + mxg_last_error());
+        if (!plan_) maxigpu::ps::fatal(std::string("mxg_mfcc_plan_create: ") + mxg_last_error());
         numBins_ = numBins;
         coeffs_.assign(numCoeffs, 0.0);
         d_in_ = static_cast<float *>(mxg_malloc(sizeof(float) * numBins));
         d_out_ = static_cast<double *>(mxg_malloc(sizeof(double) * numCoeffs));
-        if (!d_in_ || !d_out_) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+        if (!d_in_ || !d_out_) maxigpu::ps::fatal(std::string("mxg_malloc: ") + mxg_last_error());
     }
     vector<double> &mfcc(vector<float> &powerSpectrum) {  // :77-81
-        if (!plan_) throw std::logic_error("maxiMFCC::mfcc before setup()");
-        if (powerSpectrum.size() < numBins_) throw std::length_error("maxiMFCC::mfcc: fewer values than bins");
+        if (!plan_ || powerSpectrum.size() < numBins_) {  // (the reference reads past the vector / through null tables here)
+            maxigpu::ps::complain(!plan_ ? "maxiMFCC::mfcc before setup()" : "maxiMFCC::mfcc: fewer values than bins");
+            return coeffs_;
+        }
         maxigpu::ps::check(mxg_memcpy_h2d(d_in_, powerSpectrum.data(), sizeof(float) * numBins_, nullptr), "h2d spectrum");
         maxigpu::ps::check(mxg_mfcc_batch(plan_, d_in_, numBins_, 1, nullptr, nullptr, d_out_, 0, nullptr), "mxg_mfcc_batch");
         maxigpu::ps::check(mxg_memcpy_d2h(coeffs_.data(), d_out_, sizeof(double) * coeffs_.size(), nullptr), "d2h mfcc");
@@ -1761,7 +1857,7 @@ public:
         if (ns > 0) {
             maxigpu::ps::check(mxg_init(-1), "mxg_init");
             shape_.d_stages = static_cast<double *>(mxg_malloc(sizeof(double) * 6 * ns));
-            if (!shape_.d_stages) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+            if (!shape_.d_stages) maxigpu::ps::fatal(std::string("mxg_malloc: ") + mxg_last_error());
             maxigpu::ps::check(mxg_memcpy_h2d(shape_.d_stages, tab.data(), sizeof(double) * 6 * ns, nullptr), "h2d stages");
             shape_.nstages = ns;
         }
@@ -1803,7 +1899,7 @@ public:
     void setup(int _fftSize = 1024, int _hopSize = 512, int _windowSize = 0) {  // L/maxiFFT.cpp:141-152
         release();
         plan_ = mxg_ifft_plan_create(_fftSize, _hopSize, _windowSize);
-        if (!plan_) throw std::runtime_error(std::string("mxg_ifft_plan_create: ") + mxg_last_error());
+        if (!plan_) maxigpu::ps::fatal(std::string("mxg_ifft_plan_create: ") + mxg_last_error());
         fftSize = _fftSize;
         hopSize = _hopSize;
         bins = fftSize / 2;
@@ -1812,13 +1908,15 @@ public:
         d_in_ = static_cast<float *>(mxg_malloc(sizeof(float) * 2 * bins));
         d_buffer_ = static_cast<float *>(mxg_malloc(sizeof(float) * fftSize));
         d_signal_ = static_cast<float *>(mxg_malloc(sizeof(float) * hopSize));
-        if (!d_in_ || !d_buffer_ || !d_signal_) throw std::runtime_error(std::string("mxg_malloc: ") + mxg_last_error());
+        if (!d_in_ || !d_buffer_ || !d_signal_) maxigpu::ps::fatal(std::string("mxg_malloc: ") + mxg_last_error());
         maxigpu::ps::check(mxg_memset(d_buffer_, 0, sizeof(float) * fftSize, nullptr), "mxg_memset");  // buffer.resize(fftSize, 0)
     }
     float process(std::vector<float> &data1, std::vector<float> &data2, fftModes mode = maxiIFFT::SPECTRUM) {  // :154-192
         using maxigpu::ps::check;
-        if (!plan_) throw std::logic_error("maxiIFFT::process before setup()");
-        if ((int)data1.size() < bins || (int)data2.size() < bins) throw std::length_error("maxiIFFT::process: fewer values than bins");
+        if (!plan_ || (int)data1.size() < bins || (int)data2.size() < bins) {
+            maxigpu::ps::complain(!plan_ ? "maxiIFFT::process before setup()" : "maxiIFFT::process: fewer values than bins");
+            return 0.0f;
+        }
         if (0 == pos) {  // the spectrum is consumed here; the overlap-add buffer lives on the device
             check(mxg_memcpy_h2d(d_in_, data1.data(), sizeof(float) * bins, nullptr), "h2d spectrum");
             check(mxg_memcpy_h2d(d_in_ + bins, data2.data(), sizeof(float) * bins, nullptr), "h2d spectrum");

@@ -64,15 +64,20 @@ template <int WF, bool FPS, int VPL, int ST, bool PX>
 __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
                            const double *__restrict__ p1, const double *__restrict__ p2,
                            double *__restrict__ phase_io, double *__restrict__ hold_io,
-                           double *__restrict__ out, double sr, PartSync psync, int xcd, int p1ps) {
+                           double *__restrict__ out, double sr, PartSync psync, int xcd, int p1ps, int passes) {
     // (p1ps, FPS only: p1 is [N][V] too -- a pulse width / start phase per sample, for the per-sample engine's derived arguments)
+    // passes (round 4): the grid covers 1 / passes of the bank and every wavefront renders `passes` voice groups one after the other
+    // (group stride = the grid's width): banks beyond the machine's 1024 wavefronts keep the access pattern of the 65 536-voice bank --
+    // every resident wavefront walking down the SAME rows at the same time, one contiguous row slice per pass -- instead of 2, 3, ...
+    // wavefronts per SIMD drifting apart over rows that are megabytes long (profiles/r04_osc_grid.md)
     // All LDS in ONE array (a second __shared__ object perturbs hipcc's waitcnt placement).
     __shared__ __attribute__((aligned(16))) double s_tab[tab_len<WF>()];
     if constexpr (tab_len<WF>() > 1) {
         load_tab<WF>(s_tab);
         __syncthreads();
     }
-    const size_t v0 = ((size_t)xcd_block(blockIdx.x, gridDim.x, xcd) * blockDim.x + threadIdx.x) * VPL;
+    for (int pass = 0; pass < passes; pass++) {
+    const size_t v0 = (((size_t)pass * gridDim.x + xcd_block(blockIdx.x, gridDim.x, xcd)) * blockDim.x + threadIdx.x) * VPL;
     if (v0 >= V) return;
 
     double ph[VPL], hd[VPL];
@@ -168,6 +173,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
             hold_io[v0 + j] = hd[j];
         }
     }
+    }  // passes (time parts are launched with one pass only: the part counters are per wavefront of the grid)
 }
 
 // ---- K1p: K1 on a persistent grid ---------------------------------------------------------------------
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
                                                       const double *__restrict__ p1, const double *__restrict__ p2,
                                                       double *__restrict__ phase_io, double *__restrict__ hold_io,
                                                       double *__restrict__ out, const double *__restrict__ pan,
-                                                      double *__restrict__ partial, double sr, PartSync psync) {
+                                                      double *__restrict__ partial, double sr, PartSync psync, int passes) {
     constexpr int kTab = tab_len<WF>();
     constexpr int kTabPad = (kTab + 1) & ~1;  // the tiles are read with 16-byte loads
     __shared__ __attribute__((aligned(16))) double s_all[kTabPad + 4 * kTileWave + 4 * WIN * 2];
@@ -335,7 +341,12 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
     // the surplus lanes of the bank's last wavefront shadow a live voice instead (same loads, same arithmetic, same stores
     // of the same values to the same addresses) and enter the mix with zero gains -- voice V-1, or with pair rows the last
     // PAIR of voices, parity kept, so that they exchange among themselves.
-    const size_t vraw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // passes: as K1 -- the workgroup renders `passes` groups of 256 voices one after the other (group stride = the grid's width)
+    for (int pass = 0; pass < passes; pass++) {
+    const size_t wg = (size_t)pass * gridDim.x + blockIdx.x;
+    if (wg * blockDim.x >= V) break;
+    if (pass) __syncthreads();  // (the last window's combine has read s_part; the tile is handed the next gains)
+    const size_t vraw = wg * blockDim.x + threadIdx.x;
     const bool live = vraw < V;
     const size_t v = live ? vraw : (STORE == 2 ? V - 2 + (vraw & 1) : V - 1);
     double ph = phase_io[v], hd = hold_io[v];
@@ -431,7 +442,7 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
         }
         // 4 wavefront sums of this window -> one partial row per workgroup, added in the order wave 0, 1, 2, 3
         __syncthreads();
-        double *prow = partial + (size_t)blockIdx.x * N * 2 + n0 * 2;
+        double *prow = partial + wg * N * 2 + n0 * 2;
         for (int i = threadIdx.x; i < span * 2; i += blockDim.x)
             prow[i] = ((s_part[i] + s_part[WIN * 2 + i]) + s_part[2 * WIN * 2 + i]) + s_part[3 * WIN * 2 + i];
         __syncthreads();
@@ -440,10 +451,11 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
         phase_io[v] = ph;
         hold_io[v] = hd;
     }
+    }  // passes (time parts are launched with one pass only)
 }
 
 typedef void (*osc_mix_fn)(size_t, size_t, const double *, const double *, const double *, double *, double *,
-                           double *, const double *, double *, double, PartSync);
+                           double *, const double *, double *, double, PartSync, int);
 // store: 0 none, 1 plain, 2 pair rows (sc1); win: samples per workgroup combine (128 where three workgroups must share a CU)
 template <int WF>
 osc_mix_fn pick_mix(int store, int win) {
@@ -470,7 +482,7 @@ osc_mix_fn pick_mix_wf(int wf, int store, int win) {
 }
 
 typedef void (*osc_fn)(size_t, size_t, const double *, const double *, const double *, double *,
-                       double *, double *, double, PartSync, int, int);
+                       double *, double *, double, PartSync, int, int, int);
 
 // store: 0 plain 8 B, 1 nt 8 B, 2 pair rows (16 B) plain, 3 pair rows sc1, 4 pair rows nt      (one voice per lane)
 //        0 plain 16 B, 1 nt 16 B, 2 sc1 16 B                                                  (two voices per lane)
@@ -608,13 +620,20 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     if (fps) split = 1;
     // every part must render at least one sample: the last part's ticks leave the member `output` of the final sample
     while (split > 1 && (size_t)(split - 1) * ((N + split - 1) / split) >= N) split--;
-    dim3 grid((unsigned)((lanes + block - 1) / block), (unsigned)split), blk((unsigned)block);
+    // passes: voice groups a wavefront renders one after the other (knob osc_passes, 0 automatic)
+    int passes = tune_get("osc_passes");
+    if (passes == 0) passes = 1;
+    if (split > 1) passes = 1;
+    size_t nblk = (lanes + block - 1) / block;
+    if ((size_t)passes > nblk) passes = (int)nblk;
+    nblk = (nblk + passes - 1) / passes;
+    dim3 grid((unsigned)nblk, (unsigned)split), blk((unsigned)block);
     PartSync psync;
     if (split > 1)
         if (int s = part_sync_get(resolve_stream(stream), (size_t)grid.x * ((block + 63) / 64), split, &psync)) return s;
     KernelTimer kt("osc_kernel", resolve_stream(stream));
     hipLaunchKernelGGL(fn, grid, blk, 0, resolve_stream(stream), V, N, d_freq, d_p1, d_p2, d_phase,
-                       d_outhold, d_out, (double)settings().sampleRate, psync, xcd, fps == 2 ? 1 : 0);
+                       d_outhold, d_out, (double)settings().sampleRate, psync, xcd, fps == 2 ? 1 : 0, passes);
     return check_hip(hipGetLastError(), "osc_kernel launch");
 }
 
@@ -650,11 +669,16 @@ int osc_mix_launch(int waveform, size_t V, size_t N, const double *d_freq, const
         if (int s2 = part_sync_get(st, nblocks * 4, split, &psync)) return s2;
     // the combine window: 256 samples (57 KB of LDS: two workgroups per CU) up to 131 072 voices, 128 (49 KB: three) beyond
     int win = tune_get("osc_mix_win");
-    if (win == 0) win = nblocks * (size_t)split > 512 ? 128 : 256;
+    if (win == 0) win = nblocks * (size_t)split > 512 ? 128 : 256;  // (TODO after the passes sweep: by workgroups per CU)
     osc_mix_fn fn = pick_mix_wf(waveform, store, win);
+    int passes = tune_get("osc_mix_passes");  // voice groups a workgroup renders one after the other (0 automatic)
+    if (passes == 0) passes = 1;
+    if (split > 1) passes = 1;
+    if ((size_t)passes > nblocks) passes = (int)nblocks;
+    const size_t grid_x = (nblocks + passes - 1) / passes;
     KernelTimer kt("osc_mix_kernel", st);
-    hipLaunchKernelGGL(fn, dim3((unsigned)nblocks, (unsigned)split), dim3(block), 0, st, V, N, d_freq, d_p1, d_p2, d_phase,
-                       d_outhold, d_out, d_pan, d_rows, (double)settings().sampleRate, psync);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid_x, (unsigned)split), dim3(block), 0, st, V, N, d_freq, d_p1, d_p2, d_phase,
+                       d_outhold, d_out, d_pan, d_rows, (double)settings().sampleRate, psync, passes);
     return check_hip(hipGetLastError(), "osc_mix_kernel launch");
 }
 }  // namespace

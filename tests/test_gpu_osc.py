@@ -157,6 +157,28 @@ def test_persistent_grid_same_bits(mx, port, persist, store, V, N):
         L.mxg_tune(b"osc_persist", prev[0]); L.mxg_tune(b"osc_store", prev[1])
 
 
+@pytest.mark.parametrize("vpl,store,passes,V,N", [(1, 4, 2, 4096 + 2, 301), (2, 3, 3, 70000, 33), (1, 2, 5, 4097, 64), (1, 4, 64, 512, 8),
+                                                    (2, 3, 2, 131072, 16), (1, 4, 3, 98304, 16)])
+def test_passes_same_bits(mx, port, vpl, store, passes, V, N):
+    """Knob osc_passes: the grid covers 1 / passes of the bank and every wavefront renders `passes` voice groups one after the other --
+    the oracle's bits and carried state for every grouping, ragged last groups and more passes than workgroups included."""
+    L = mx.lib()
+    prev = [L.mxg_tune(b"osc_vpl", vpl), L.mxg_tune(b"osc_store", store), L.mxg_tune(b"osc_passes", passes)]
+    try:
+        rng = np.random.default_rng(V + passes)
+        freq = rng.uniform(20, 20000, V)
+        for wf in ((8, 2, 0) if V < 50000 else (8,)):
+            out, ph, hd = _render(mx, wf, freq, N, blocks=2)
+            eo, eph, _ = port.osc(wf, freq, 2 * N)
+            if wf == 0:
+                assert ulp_diff(out, eo).max() <= TRIG_MAX_ULP
+            else:
+                assert_bits_equal(out, eo, OSC[wf])
+            assert_bits_equal(ph, eph, "phase")
+    finally:
+        L.mxg_tune(b"osc_vpl", prev[0]); L.mxg_tune(b"osc_store", prev[1]); L.mxg_tune(b"osc_passes", prev[2])
+
+
 def test_empty_and_invalid(mx):
     L = mx.lib()
     bank = mx.maxiOscBank(4)
@@ -234,6 +256,19 @@ def test_render_mix_fused(mx, port, wf, V, N):
             assert_bits_equal(bank3.phase.numpy(), eph, "phase, store %d split %d" % (store, split))
         finally:
             L.mxg_tune(b"osc_mix_store", prev[0]); L.mxg_tune(b"osc_mix_split", prev[1])
+    # passes (a workgroup renders several groups of 256 voices one after the other): the same rows, the same bits
+    for mp in (2, 5):
+        prev = L.mxg_tune(b"osc_mix_passes", mp)
+        try:
+            bank5 = mx.maxiOscBank(V)
+            o5, m5 = bank5.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V))
+            assert_bits_equal(o5.numpy(), out1.numpy(), "passes %d" % mp)
+            assert_bits_equal(m5.numpy(), mix1.numpy(), "mix, passes %d" % mp)
+            o5, m5 = bank5.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V))
+            assert_bits_equal(o5.numpy(), out2.numpy(), "second block, passes %d" % mp)
+            assert_bits_equal(bank5.phase.numpy(), eph, "phase, passes %d" % mp)
+        finally:
+            L.mxg_tune(b"osc_mix_passes", prev)
     # the rows form (what a grouped mix queue's slot receives): rows [ceil(V / 256)][N][2], added by mxg_mix_rows_sum = the same mix
     # bits; the combine window (osc_mix_win 128 / 256) changes neither the rows nor the block
     G = L.mxg_osc_mix_groups(V)
