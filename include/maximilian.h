@@ -1359,6 +1359,28 @@ class maxiSample {
         if (!buf_.d) maxigpu::ps::fatal(std::string("mxg_sample_upload: ") + mxg_last_error());
         buf_.len = n;
     }
+    double amp_get(size_t i) {
+        fetch_host();
+        return i < host_.size() ? host_[i] : 0.0;
+    }
+    void amp_set(size_t i, double v) {
+        fetch_host();
+        if (i >= host_.size()) return;
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        host_[i] = v;
+        maxigpu::ps::check(mxg_memcpy_h2d(buf_.d + i, &host_[i], sizeof(double), nullptr), "h2d sample element");
+    }
+    void amp_assign(const std::vector<double> &v) {  // `amplitudes = v`: the buffer only
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        const int rate = buf_.rate;
+        if (buf_.d) mxg_sample_free(buf_.d);
+        buf_.d = nullptr;
+        buf_.len = 0;
+        host_.clear();
+        if (!v.empty()) upload(v.data(), v.size());
+        host_ = v;
+        buf_.rate = rate;
+    }
     void fetch_host() {
         if (host_.size() == buf_.len) return;
         host_.assign(buf_.len, 0.0);
@@ -1376,7 +1398,26 @@ public:
     short myBlockAlign = 0;
     maxiSample() { maxigpu::ps::pool<Pool>().attach(slot_); fresh_state(); }
     ~maxiSample() { drop(); maxigpu::ps::pool<Pool>().detach(slot_); }
-    maxiSample(const maxiSample &) = delete;
+    // The implicit copy constructor of the reference copies EVERYTHING (buffer, play head, trigger state, header fields) -- unlike
+    // its operator=, which resets the head and takes the global rate (H:626-637).
+    maxiSample(const maxiSample &source) {
+        maxigpu::ps::pool<Pool>().attach(slot_);
+        maxiSample &src = const_cast<maxiSample &>(source);
+        maxigpu::ps::pool<Pool>().settle(src.slot_);
+        if (src.buf_.d && src.buf_.len) {
+            src.fetch_host();
+            upload(src.host_.data(), src.host_.size());
+            host_ = src.host_;
+        }
+        buf_.rate = src.buf_.rate;
+        slot_.sd = src.slot_.sd;
+        slot_.si = src.slot_.si;
+        recordPosition_ = src.recordPosition_;
+        loopRecordLag_ = src.loopRecordLag_;
+        myChannels = src.myChannels; mySampleRate = src.mySampleRate; myBitsPerSample = src.myBitsPerSample; myPath = src.myPath;
+        myChunkSize = src.myChunkSize; mySubChunk1Size = src.mySubChunk1Size; readChannel = src.readChannel; myFormat = src.myFormat;
+        myByteRate = src.myByteRate; myBlockAlign = src.myBlockAlign;
+    }
     maxiSample &operator=(const maxiSample &source) {  // H:626-637: position = 0, the source's channels and samples, the GLOBAL rate
         if (this == &source) return *this;
         maxiSample &src = const_cast<maxiSample &>(source);
@@ -1429,7 +1470,45 @@ public:
         setSample(sampleData);
         buf_.rate = mySampleRate = sampleRate;
     }
-    const vector<double> &getAmplitudes() { fetch_host(); return host_; }  // (the reference's public member `amplitudes`, read-only)
+    const vector<double> &getAmplitudes() { fetch_host(); return host_; }
+    // The reference's public member `vector<double> amplitudes` (H:621) over the device buffer: size / element reads go through a
+    // host copy fetched on demand; an element write lands in the host copy and on the device at once (the play head's cached block is
+    // dropped first: a later play() must see it); assigning a vector replaces the buffer and -- as in the reference -- touches neither
+    // the play head nor the rates.  (The grain classes of include/maxiGrains.h take the device buffer, not this view.)
+    class Amplitudes {
+        maxiSample *s_;
+
+    public:
+        explicit Amplitudes(maxiSample *s) : s_(s) {}
+        Amplitudes(const Amplitudes &) = delete;  // (bound to ONE sample: maxiSample's own copy operations copy the buffer)
+        class Ref {
+            maxiSample *s_;
+            size_t i_;
+
+        public:
+            Ref(maxiSample *s, size_t i) : s_(s), i_(i) {}
+            operator double() const { return s_->amp_get(i_); }
+            Ref &operator=(double v) { s_->amp_set(i_, v); return *this; }
+            Ref &operator=(const Ref &o) { s_->amp_set(i_, (double)o); return *this; }
+            Ref &operator+=(double v) { s_->amp_set(i_, s_->amp_get(i_) + v); return *this; }
+            Ref &operator-=(double v) { s_->amp_set(i_, s_->amp_get(i_) - v); return *this; }
+            Ref &operator*=(double v) { s_->amp_set(i_, s_->amp_get(i_) * v); return *this; }
+            Ref &operator/=(double v) { s_->amp_set(i_, s_->amp_get(i_) / v); return *this; }
+        };
+        size_t size() const { return s_->buf_.len; }
+        bool empty() const { return s_->buf_.len == 0; }
+        Ref operator[](size_t i) { return Ref(s_, i); }
+        double operator[](size_t i) const { return s_->amp_get(i); }
+        Ref at(size_t i) { return Ref(s_, i); }
+        operator const std::vector<double> &() const { s_->fetch_host(); return s_->host_; }
+        std::vector<double>::const_iterator begin() const { s_->fetch_host(); return s_->host_.begin(); }
+        std::vector<double>::const_iterator end() const { s_->fetch_host(); return s_->host_.end(); }
+        const double *data() const { s_->fetch_host(); return s_->host_.data(); }
+        Amplitudes &operator=(const std::vector<double> &v) { s_->amp_assign(v); return *this; }
+        Amplitudes &operator=(const Amplitudes &o) { o.s_->fetch_host(); s_->amp_assign(std::vector<double>(o.s_->host_)); return *this; }
+        void clear() { s_->clear(); }
+    };
+    Amplitudes amplitudes{this};
     size_t getLength() { return buf_.len; }
     bool isReady() { return buf_.len > 1; }
     void clear() { drop(); }  // H:691: amplitudes.clear()
@@ -1587,10 +1666,28 @@ public:
         if (line_.d_save) mxg_free(line_.d_save);
         if (line_.d_i) mxg_free(line_.d_i);
     }
-    maxiDelayline(const maxiDelayline &) = delete;
-    maxiDelayline &operator=(const maxiDelayline &) = delete;
+    // (H:266-284: a value type whose copy carries the 5.6 MB ring -- here a device-to-device copy of it)
+    maxiDelayline(const maxiDelayline &o) { maxigpu::ps::pool<Pool>().attach(slot_); copy_from(o); }
+    maxiDelayline &operator=(const maxiDelayline &o) { if (this != &o) copy_from(o); return *this; }
     double dl(double input, int size, double feedback) { return run(0, input, size, feedback, 0); }
     double dlFromPosition(double input, int size, double feedback, int position) { return run(1, input, size, feedback, position); }
+
+private:
+    void copy_from(const maxiDelayline &o) {
+        maxiDelayline &src = const_cast<maxiDelayline &>(o);
+        maxigpu::ps::pool<Pool>().settle(src.slot_);
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        if (src.line_.d_mem) {
+            init();
+            maxigpu::ps::check(mxg_memcpy_d2d_async(line_.d_mem, src.line_.d_mem, sizeof(double) * Pool::kCap, nullptr), "d2d ring");
+            maxigpu::ps::check(mxg_stream_sync(nullptr), "mxg_stream_sync");
+        } else if (line_.d_mem) {
+            maxigpu::ps::check(mxg_memset(line_.d_mem, 0, sizeof(double) * Pool::kCap, nullptr), "mxg_memset");
+        }
+        line_.saved = false;
+        slot_.sd = o.slot_.sd;
+        slot_.si = o.slot_.si;
+    }
 };
 
 // ---- maxiFFT (L/maxiFFT.h:47-110; L/maxiFFT.cpp:45-132): the hop buffer on the host, every frame on the device ---------------
@@ -1599,10 +1696,12 @@ public:
     enum fftModes { NO_POLAR_CONVERSION = 0, WITH_POLAR_CONVERSION = 1 };
     maxiFFT() {}
     ~maxiFFT() { release(); }
-    maxiFFT(const maxiFFT &) = delete;
-    maxiFFT &operator=(const maxiFFT &) = delete;
+    // (a value type in the reference: a copy is a second analyser with the same hop buffer and the same last frame)
+    maxiFFT(const maxiFFT &o) { copy_from(o); }
+    maxiFFT &operator=(const maxiFFT &o) { if (this != &o) copy_from(o); return *this; }
     void setup(int _fftSize = 1024, int _hopSize = 512, int _windowSize = 0) {  // L/maxiFFT.cpp:45-60
         release();
+        askedWindow_ = _windowSize;
         plan_ = mxg_fft_plan_create(_fftSize, _hopSize, _windowSize);
         if (!plan_) maxigpu::ps::fatal(std::string("mxg_fft_plan_create: ") + mxg_last_error());
         fftSize = _fftSize;
@@ -1679,6 +1778,19 @@ private:
         plan_ = nullptr;
         d_in_ = d_out_ = nullptr;
     }
+    void copy_from(const maxiFFT &o) {
+        if (!o.plan_) {
+            release();
+            return;
+        }
+        setup(o.fftSize, o.hopSize, o.askedWindow_);
+        buffer = o.buffer; magnitudes = o.magnitudes; magnitudesDB = o.magnitudesDB; phases = o.phases; real_ = o.real_; imag_ = o.imag_;
+        pos = o.pos;
+        newFFT = o.newFFT;
+        feat_[0] = o.feat_[0];
+        feat_[1] = o.feat_[1];
+    }
+    int askedWindow_ = 0;
     mxg_fft_plan *plan_ = nullptr;
     float *d_in_ = nullptr, *d_out_ = nullptr;
     int fftSize = 0, windowSize = 0, hopSize = 0, bins = 0, pos = 0;
@@ -1692,10 +1804,11 @@ class maxiMFCC {
 public:
     maxiMFCC() {}
     ~maxiMFCC() { release(); }
-    maxiMFCC(const maxiMFCC &) = delete;
-    maxiMFCC &operator=(const maxiMFCC &) = delete;
+    maxiMFCC(const maxiMFCC &o) { copy_from(o); }
+    maxiMFCC &operator=(const maxiMFCC &o) { if (this != &o) copy_from(o); return *this; }
     void setup(unsigned int numBins, unsigned int numFilters, unsigned int numCoeffs, double minFreq, double maxFreq) {  // :56-75
         release();
+        numFilters_ = numFilters; minFreq_ = minFreq; maxFreq_ = maxFreq;
         plan_ = mxg_mfcc_plan_create(numBins, numFilters, numCoeffs, minFreq, maxFreq);
         if (!plan_) maxigpu::ps::fatal(std::string("mxg_mfcc_plan_create: ") + mxg_last_error());
         numBins_ = numBins;
@@ -1724,8 +1837,17 @@ private:
         d_in_ = nullptr;
         d_out_ = nullptr;
     }
+    void copy_from(const maxiMFCC &o) {
+        if (!o.plan_) {
+            release();
+            return;
+        }
+        setup(o.numBins_, o.numFilters_, (unsigned)o.coeffs_.size(), o.minFreq_, o.maxFreq_);
+        coeffs_ = o.coeffs_;
+    }
     mxg_mfcc_plan *plan_ = nullptr;
-    unsigned numBins_ = 0;
+    unsigned numBins_ = 0, numFilters_ = 0;
+    double minFreq_ = 0, maxFreq_ = 0;
     float *d_in_ = nullptr;
     double *d_out_ = nullptr;
     vector<double> coeffs_;
@@ -1741,14 +1863,21 @@ class maxiDCBlocker {
 public:
     maxiDCBlocker() { maxigpu::ps::pool<Pool>().attach(slot_); }
     ~maxiDCBlocker() { maxigpu::ps::pool<Pool>().detach(slot_); }
-    maxiDCBlocker(const maxiDCBlocker &) = delete;
-    maxiDCBlocker &operator=(const maxiDCBlocker &) = delete;
+    maxiDCBlocker(const maxiDCBlocker &o) { maxigpu::ps::pool<Pool>().attach(slot_); copy_from(o); }
+    maxiDCBlocker &operator=(const maxiDCBlocker &o) { if (this != &o) copy_from(o); return *this; }
     double play(double input, double R) {
         maxigpu::ps::Call c;
         c.method = 0;
         c.a[0] = input;
         c.a[1] = R;
         return maxigpu::ps::pool<Pool>().call(slot_, c);
+    }
+
+private:
+    void copy_from(const maxiDCBlocker &o) {
+        maxigpu::ps::pool<Pool>().settle(const_cast<maxiDCBlocker &>(o).slot_);
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        slot_.sd = o.slot_.sd;
     }
 };
 
@@ -1766,8 +1895,8 @@ class maxiSVF {
 public:
     maxiSVF() { maxigpu::ps::pool<Pool>().attach(slot_); setParams(1000, 1); }
     ~maxiSVF() { maxigpu::ps::pool<Pool>().detach(slot_); }
-    maxiSVF(const maxiSVF &) = delete;
-    maxiSVF &operator=(const maxiSVF &) = delete;
+    maxiSVF(const maxiSVF &o) { maxigpu::ps::pool<Pool>().attach(slot_); copy_from(o); }
+    maxiSVF &operator=(const maxiSVF &o) { if (this != &o) copy_from(o); return *this; }
     void setCutoff(double cutoff) { setParams(cutoff, res); }
     void setResonance(double q) { setParams(freq, q); }
     double play(double w, double lpmix, double bpmix, double hpmix, double notchmix) {
@@ -1777,6 +1906,16 @@ public:
         for (int i = 0; i < 5; i++) c.a[1 + i] = coef_[i];
         c.a[6] = lpmix; c.a[7] = bpmix; c.a[8] = hpmix; c.a[9] = notchmix;
         return maxigpu::ps::pool<Pool>().call(slot_, c);
+    }
+
+private:
+    void copy_from(const maxiSVF &o) {
+        maxigpu::ps::pool<Pool>().settle(const_cast<maxiSVF &>(o).slot_);
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        slot_.sd = o.slot_.sd;
+        for (int i = 0; i < 5; i++) coef_[i] = o.coef_[i];
+        freq = o.freq;
+        res = o.res;
     }
 };
 
@@ -1789,8 +1928,8 @@ public:
     enum filterTypes { LOWPASS, HIGHPASS, BANDPASS, NOTCH, PEAK, LOWSHELF, HIGHSHELF };
     maxiBiquad() { maxigpu::ps::pool<Pool>().attach(slot_); }
     ~maxiBiquad() { maxigpu::ps::pool<Pool>().detach(slot_); }
-    maxiBiquad(const maxiBiquad &) = delete;
-    maxiBiquad &operator=(const maxiBiquad &) = delete;
+    maxiBiquad(const maxiBiquad &o) { maxigpu::ps::pool<Pool>().attach(slot_); copy_from(o); }
+    maxiBiquad &operator=(const maxiBiquad &o) { if (this != &o) copy_from(o); return *this; }
     double play(double input) {
         maxigpu::ps::Call c;
         c.method = 2;
@@ -1801,6 +1940,14 @@ public:
     void set(filterTypes filtType, double cutoff, double Q, double peakGain) {  // H:1376-1478
         const int32_t t = (int32_t)filtType;
         maxigpu::ps::check(mxg_biquad_coeffs_host(1, &t, &cutoff, &Q, &peakGain, coef_), "mxg_biquad_coeffs_host");
+    }
+
+private:
+    void copy_from(const maxiBiquad &o) {
+        maxigpu::ps::pool<Pool>().settle(const_cast<maxiBiquad &>(o).slot_);
+        maxigpu::ps::pool<Pool>().settle(slot_);
+        slot_.sd = o.slot_.sd;
+        for (int i = 0; i < 5; i++) coef_[i] = o.coef_[i];
     }
 };
 
@@ -1824,8 +1971,8 @@ public:
         slot_.si[4] = slot_.si[5] = slot_.si[6] = 1;
     }
     ~maxiEnvGen() { pool().detach(slot_); drop_table(); }
-    maxiEnvGen(const maxiEnvGen &) = delete;
-    maxiEnvGen &operator=(const maxiEnvGen &) = delete;
+    maxiEnvGen(const maxiEnvGen &o) { pool().attach(slot_); copy_from(o); }  // (H:2268-2547: a value type -- vectors of stages)
+    maxiEnvGen &operator=(const maxiEnvGen &o) { if (this != &o) copy_from(o); return *this; }
     double play(double trigger) {  // H:2277-2356
         if (!shape_.d_stages) {  // no stages: a WAITING envelope only feeds its trigger detector (H:2279-2287)
             pool().settle(slot_);
@@ -1886,6 +2033,24 @@ public:
     bool getRetrigger() { return shape_.retrigger; }
     void setLoop(const bool val) { pool().settle(slot_); shape_.loop = val; }
     bool getLoop() { return shape_.loop; }
+
+private:
+    void copy_from(const maxiEnvGen &o) {  // its own copy of the stage table on the device, the same running state
+        pool().settle(const_cast<maxiEnvGen &>(o).slot_);
+        pool().settle(slot_);
+        drop_table();
+        if (o.shape_.d_stages && o.shape_.nstages > 0) {
+            shape_.d_stages = static_cast<double *>(mxg_malloc(sizeof(double) * 6 * o.shape_.nstages));
+            if (!shape_.d_stages) maxigpu::ps::fatal(std::string("mxg_malloc: ") + mxg_last_error());
+            maxigpu::ps::check(mxg_memcpy_d2d_async(shape_.d_stages, o.shape_.d_stages, sizeof(double) * 6 * o.shape_.nstages, nullptr), "d2d stages");
+            maxigpu::ps::check(mxg_stream_sync(nullptr), "mxg_stream_sync");
+            shape_.nstages = o.shape_.nstages;
+        }
+        shape_.loop = o.shape_.loop;
+        shape_.retrigger = o.shape_.retrigger;
+        slot_.sd = o.slot_.sd;
+        slot_.si = o.slot_.si;
+    }
 };
 
 // ---- maxiIFFT (L/maxiFFT.h:117-156; L/maxiFFT.cpp:141-192): one inverse transform per hop on the device -------------------------
@@ -1894,10 +2059,11 @@ public:
     enum fftModes { SPECTRUM = 0, COMPLEX = 1 };
     maxiIFFT() {}
     ~maxiIFFT() { release(); }
-    maxiIFFT(const maxiIFFT &) = delete;
-    maxiIFFT &operator=(const maxiIFFT &) = delete;
+    maxiIFFT(const maxiIFFT &o) { copy_from(o); }
+    maxiIFFT &operator=(const maxiIFFT &o) { if (this != &o) copy_from(o); return *this; }
     void setup(int _fftSize = 1024, int _hopSize = 512, int _windowSize = 0) {  // L/maxiFFT.cpp:141-152
         release();
+        askedWindow_ = _windowSize;
         plan_ = mxg_ifft_plan_create(_fftSize, _hopSize, _windowSize);
         if (!plan_) maxigpu::ps::fatal(std::string("mxg_ifft_plan_create: ") + mxg_last_error());
         fftSize = _fftSize;
@@ -1941,6 +2107,18 @@ private:
         plan_ = nullptr;
         d_in_ = d_buffer_ = d_signal_ = nullptr;
     }
+    void copy_from(const maxiIFFT &o) {  // the overlap-add buffer lives on the device: copied there
+        if (!o.plan_) {
+            release();
+            return;
+        }
+        setup(o.fftSize, o.hopSize, o.askedWindow_);
+        maxigpu::ps::check(mxg_memcpy_d2d_async(d_buffer_, o.d_buffer_, sizeof(float) * fftSize, nullptr), "d2d overlap-add buffer");
+        maxigpu::ps::check(mxg_stream_sync(nullptr), "mxg_stream_sync");
+        hop_ = o.hop_;
+        pos = o.pos;
+    }
+    int askedWindow_ = 0;
     mxg_ifft_plan *plan_ = nullptr;
     float *d_in_ = nullptr, *d_buffer_ = nullptr, *d_signal_ = nullptr;
     int fftSize = 0, hopSize = 0, bins = 0, pos = 0;

@@ -146,12 +146,20 @@ __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nblk, int xcd
 // Store flavours of the out[n*V + v] streams (measured with csrc/calib.hip, profiles/r03_write_ceiling.md): 0 plain,
 // 1 non-temporal, 2 write-through (`sc1`: the line leaves the XCD's L2 with the store instead of by eviction -- the fastest
 // 16-byte stream while a block is within a few times the Infinity Cache, no gain beyond).
+#ifndef MXG_STORE_CLOBBER
+#define MXG_STORE_CLOBBER 1  // A/B (tools/build_ab.sh): 1 = the write-through store asm carries a "memory" clobber
+#endif
+#if MXG_STORE_CLOBBER
+#define MXG_STORE_CLOBBER_LIST : "memory"
+#else
+#define MXG_STORE_CLOBBER_LIST
+#endif
 template <int ST>
 __device__ __forceinline__ void store1(double *p, double v) {
     if constexpr (ST == 1)
         __builtin_nontemporal_store(v, p);
     else if constexpr (ST == 2)
-        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) MXG_STORE_CLOBBER_LIST);  // (see store2)
     else
         *p = v;
 }
@@ -162,7 +170,10 @@ __device__ __forceinline__ void store2(double *p, double a, double b) {
     if constexpr (ST == 1)
         __builtin_nontemporal_store(v, reinterpret_cast<double2v *>(p));
     else if constexpr (ST == 2)  // (the wait states a following write of the four data registers needs: hipcc does not add them after asm)
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+        // No "memory" clobber: the block is write-only for the kernel that stores it, and a clobber would pin every LDS table read of
+        // the NEXT sample behind this store -- two samples' reads in flight instead of a chunk's (round 4).  `volatile` keeps the
+        // store itself and its order among the other volatile asm statements.
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) MXG_STORE_CLOBBER_LIST);
     else
         *reinterpret_cast<double2v *>(p) = v;
 }

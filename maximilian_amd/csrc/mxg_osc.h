@@ -189,6 +189,98 @@ __device__ __forceinline__ double osc_tick(double &phase, double &hold, const Os
     }
 }
 
+// K consecutive samples of one voice, for kernels that run ONE wavefront per SIMD: the same operations per sample as osc_tick, in
+// three sweeps -- the K phase steps (with index and remainder), the table reads of all K samples, the K interpolations -- with a
+// scheduling fence between them, so that every LDS read of the chunk is in flight before the first result is needed.  (Left to itself
+// the scheduler finishes a sample before it starts the next to save registers, and a lone wavefront then waits out the LDS latency
+// K times.)  Only the operations of DIFFERENT samples change places: the bits are osc_tick's.
+template <int WF, int K>
+__device__ __forceinline__ void osc_tick_chunk(double &phase, double &hold, const OscPre &q, const double *s_sine,
+                                               const double *s_trans, double (&r)[K]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (WF == MXG_OSC_SINEBUF) {  // C:266-274
+        double rem[K], t0[K], t1[K];
+        int idx[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            phase += q.inc;
+            if (phase >= 511) phase -= 512;
+            rem[i] = phase - floor(phase);
+            idx[i] = (int)phase;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            t0[i] = s_sine[1 + idx[i] + 1];
+            t1[i] = s_sine[2 + idx[i] + 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < K; i++) r[i] = (1 - rem[i]) * t0[i] + rem[i] * t1[i];
+        hold = r[K - 1];
+        return;
+    } else if constexpr (WF == MXG_OSC_SINEBUF4) {  // C:237-264
+        double rem[K], a[K], b[K], c[K], d[K];
+        int idx[K], ia[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            phase += q.inc;
+            if (phase >= 511) phase -= 512;
+            rem[i] = phase - floor(phase);
+            idx[i] = (int)phase;
+            ia[i] = (phase == 0) ? 512 : idx[i] - 1;  // C:245-256; index -1 is the 0.0 guard
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            a[i] = s_sine[ia[i] + 1];
+            b[i] = s_sine[idx[i] + 1];
+            c[i] = s_sine[idx[i] + 1 + 1];
+            d[i] = s_sine[idx[i] + 2 + 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const double a1 = 0.5 * (c[i] - a[i]);
+            const double a2 = a[i] - 2.5 * b[i] + 2. * c[i] - 0.5 * d[i];
+            const double a3 = 0.5 * (d[i] - a[i]) + 1.5 * (b[i] - c[i]);
+            r[i] = ((a3 * rem[i] + a2) * rem[i] + a1) * rem[i] + b[i];
+        }
+        hold = r[K - 1];
+        return;
+    } else if constexpr (WF == MXG_OSC_SAWN) {  // C:342-359
+        double rem[K], t0[K], t1[K], phs[K];
+        int idx[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            if (phase >= 0.5) phase -= 1.0;
+            phase += q.inc;
+            double temp = q.k * phase;
+            if (temp < -0.5) temp = -0.5;
+            if (temp > 0.5) temp = 0.5;
+            temp *= 1000.0;
+            temp += 500.0;
+            rem[i] = temp - floor(temp);
+            idx[i] = (int)temp;
+            phs[i] = phase;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            t0[i] = s_trans[idx[i]];
+            t1[i] = s_trans[1 + idx[i]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < K; i++) r[i] = ((1.0 - rem[i]) * t0[i] + rem[i] * t1[i]) - phs[i];
+        hold = r[K - 1];
+        return;
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < K; i++) r[i] = osc_tick<WF>(phase, hold, q, s_sine, s_trans);
+}
+
 // The recurrence of one sample WITHOUT its output: exactly the phase operations of osc_tick, in its order.  For the
 // waveforms whose tick always overwrites `hold` it is left alone (a later tick sets it); square / pulse / impulse update
 // `hold` conditionally, so they run their (cheap) tick.

@@ -133,6 +133,23 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
         size_t n = nA;
         if constexpr (PX && VPL == 1 && !FPS) {
             double *op = out + (nA + (threadIdx.x & 1)) * V + (v0 & ~(size_t)1);
+            // the table oscillators eight samples at a time: all of a chunk's LDS reads in flight at once (osc_tick_chunk, mxg_osc.h)
+#ifndef MXG_K1_CHUNK
+#define MXG_K1_CHUNK 8  // A/B: 0 = sample pairs only
+#endif
+            if constexpr (MXG_K1_CHUNK > 0 && !kTrust && (WF == MXG_OSC_SINEBUF || WF == MXG_OSC_SINEBUF4 || WF == MXG_OSC_SAWN)) {
+                constexpr int kC = MXG_K1_CHUNK > 0 ? MXG_K1_CHUNK : 2;
+                for (; n + kC <= nB; n += kC) {
+                    double r[kC];
+                    osc_tick_chunk<WF, kC>(ph[0], hd[0], q[0], s_tab, s_tab, r);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < kC; i += 2) {
+                        store_pair_rows<ST>(op, r[i], r[i + 1]);
+                        op += 2 * V;
+                    }
+                }
+            }
 #pragma unroll 2
             for (; n + 2 <= nB; n += 2) {
                 const double r0 = osc_tick<WF, kTrust>(ph[0], hd[0], q[0], s_tab, s_tab);
@@ -391,16 +408,39 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
             auto chunk = [&](auto full_tag) {
                 constexpr bool kFull = decltype(full_tag)::value;
                 if constexpr (kFull && STORE == 2) {
+                    // the 16 ticks first (osc_tick_chunk: every table read of the chunk in flight at once -- at one wavefront per SIMD the
+                    // LDS latency of a tick is otherwise exposed sample by sample), stores and tile writes after them
+                    double r[kMixChunk];
+#ifndef MXG_K1M_CHUNK
+#define MXG_K1M_CHUNK 1  // A/B: 0 = tick by tick
+#endif
+#if MXG_K1M_CHUNK
+                    osc_tick_chunk<WF, kMixChunk>(ph, hd, q, s_tab, s_tab, r);
+                    __builtin_amdgcn_sched_barrier(0);
+#else
+#pragma unroll
+                    for (int i = 0; i < kMixChunk; i++) r[i] = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+#endif
 #pragma unroll
                     for (int i = 0; i < kMixChunk; i += 2) {
-                        const double r0 = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
-                        const double r1 = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
-                        store_pair_rows<2>(op, r0, r1);
+                        store_pair_rows<2>(op, r[i], r[i + 1]);
                         op += 2 * V;
-                        tw[i * kTileRow] = r0;
-                        tw[(i + 1) * kTileRow] = r1;
+                        tw[i * kTileRow] = r[i];
+                        tw[(i + 1) * kTileRow] = r[i + 1];
                     }
                     o += (size_t)kMixChunk * V;
+                } else if constexpr (kFull) {
+                    double r[kMixChunk];
+                    osc_tick_chunk<WF, kMixChunk>(ph, hd, q, s_tab, s_tab, r);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < kMixChunk; i++) {
+                        if constexpr (STORE != 0) {
+                            *o = r[i];
+                            o += V;
+                        }
+                        tw[i * kTileRow] = r[i];
+                    }
                 } else {
 #pragma unroll
                     for (int i = 0; i < kMixChunk; i++) {

@@ -265,3 +265,18 @@ def test_convolve_and_sampler_patch_bit_exact(golden, tmp_path):
     assert_bits_equal(got[:, 0], g["exp4_l"], "maxiConvolve")
     assert_bits_equal(got[:, 1], g["exp4_r"], "maxiSampler")
     assert np.abs(g["exp4_r"]).max() > 0.05
+
+
+def test_public_members_and_value_semantics_patch_bit_exact(golden, tmp_path):
+    """tests/patches/public_members_patch.cpp (round 4): every public member of maxiOsc / maxiFilter / maxiSample / maxiEnv, the classes in
+    std::vector, copy construction and copy assignment in mid-flight, `maxiEnv::amplitude / holdcount / *phase` and `maxiSample::amplitudes`
+    read and written from user code, `maxiFilter::cutoff` as lores() leaves it -- the same source compiled against the reference gives
+    the golden stream."""
+    g = golden("dropin_r4.npz")
+    got, _ = _run_patch("p5", g["exp5_l"].shape[0], tmp_path)
+    # channel 0 carries sinewave / coswave (within 1 ULP of glibc each) through filters: a tolerance; channel 1 (envelopes, samples) exact
+    err = np.abs(got[:, 0] - g["exp5_l"]).max()
+    print("public members patch, left: max |difference| %.3e on a peak of %.3f" % (err, np.abs(g["exp5_l"]).max()))
+    assert err <= 1e-12 * max(1.0, np.abs(g["exp5_l"]).max())
+    assert_bits_equal(got[:, 1], g["exp5_r"], "envelopes and samples: members, copies")
+    assert np.abs(g["exp5_r"]).max() > 0.5

@@ -66,7 +66,7 @@ emit("us per block / fraction of 8 TB/s on 8 B per sample; waves = wavefronts of
 emit()
 emit("## K1 (mxg_osc_render, waveform %d)" % args.wf)
 emit()
-for V in [int(x) for x in args.voices.split(",")]:
+for V in [int(x) for x in args.voices.split(",") if x]:
     nbytes = V * B * 8
     regions = max(1, ARENA // nbytes)
     ctr = [0]
@@ -101,7 +101,7 @@ for V in [int(x) for x in args.voices.split(",")]:
 
 emit("## K1m (mxg_osc_render_mix_rows, waveform %d, per-voice block stored)" % args.wf)
 emit()
-for V in [int(x) for x in args.mix_voices.split(",")]:
+for V in [int(x) for x in args.mix_voices.split(",") if x]:
     nbytes = V * B * 8
     regions = max(1, ARENA // nbytes)
     ctr = [0]
