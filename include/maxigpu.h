@@ -139,7 +139,6 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * coefficients -- maxiBiquad, maxiSVF, maxiDCBlocker through mxg_filter2_render, lores / hires through mxg_filter_render -- and blocks
  * of 64 * {1..32} samples be cut along time and joined by a wavefront scan: a 6-voice x 512-sample block in a few microseconds
  * instead of 23-28, with reordered arithmetic: |error| <= 1e-10 x the block's peak (measured <= 5e-12); default 0 = the bit-exact kernels),
- * "osc_persist" (K1 on a persistent grid of k wavefronts per SIMD with equal shares of voices x samples: 0 automatic, 1 off, 2 / 3 / 4 = k 1 / 2 / 4),
  * "osc_passes" / "osc_mix_passes" (K1 / K1m: voice groups a wavefront renders one after the other, the grid covering 1 / passes of the bank: 0 automatic, 1..64),
  * "osc_split" (time parts per voice group in K1: 0 automatic, 1..8), "osc_mix_split" (the same for the fused render + mixdown K1m,
  * 0 automatic, 1..4), "osc_mix_store" (K1m's per-voice block: 0 automatic, 1 plain 8-byte stores, 2 pair rows of 16-byte stores),
@@ -209,6 +208,18 @@ int mxg_osc_render_mix_rows(int waveform, size_t V, size_t N, const double *d_fr
                             const double *d_p2, double *d_phase, double *d_outhold, double *d_out,
                             const double *d_pan, double *d_rows, void *stream);
 int mxg_mix_rows_sum(size_t groups, size_t count, const double *d_rows, double *d_mix, void *stream);
+
+/* EXTENSION (no reference counterpart; SURVEY.md 8(d) row 2, north_star "HBM-read roofline on the wavetable path"):
+ * maxiOsc::sinebuf (C:266-274) with a table PER VOICE.  d_tables[V][514] (16-byte aligned) plays the part of the reference's one
+ * shared `double sineBuffer[514]` (C:63) for voice v: out = (1-rem)*T_v[1+(long)phase] + rem*T_v[2+(long)phase], same phase
+ * recurrence, same expression order -- a bank whose tables all hold sineBuffer gives mxg_osc_render(MXG_OSC_SINEBUF)'s bits.
+ * 4112 B of table are read per voice and block (8.03 B per sample at N = 512), each exactly once.  N <= 512.
+ * Outputs, either or both: d_out [N][V] (the per-voice block) and the fused maxiMix::stereo mixdown as partial rows
+ * d_rows[g][n][0..1], g < mxg_osc_tables_groups(V) (d_pan [V] given): the mix is the sum of the rows in ascending g
+ * (mxg_mix_rows_sum, or a grouped mix queue).  d_phase / d_outhold as for mxg_osc_render. */
+size_t mxg_osc_tables_groups(size_t V);
+int mxg_osc_render_tables(size_t V, size_t N, const double *d_freq, const double *d_tables, double *d_phase,
+                          double *d_outhold, double *d_out, const double *d_pan, double *d_rows, void *stream);
 
 /* ---- maxiFilter bank ------------------------------------------------------------------ */
 /* d_st = [5][V]: x, y, outputs[0], outputs[1], outputs[2] (H:289-302), in/out.

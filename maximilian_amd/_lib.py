@@ -57,6 +57,8 @@ SIGNATURES = {
     "mxg_osc_render_mix_rows": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_mix_rows_sum": (c_int, [c_size_t, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "mxg_osc_tables_groups": (c_size_t, [c_size_t]),
+    "mxg_osc_render_tables": (c_int, [c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_filter_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_int, c_void_p,
                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_filter_render_coefs": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -169,6 +169,26 @@ class maxiOscBank(_Bank):
         self._keep = (f, a, b, pn)
         return out, mix
 
+    def sinebuf_tables(self, freq, tables, N, pan=None, store=True, out=None):
+        """EXTENSION: sinebuf with a 514-entry table per voice (mxg_osc_render_tables).  tables: [V][514] (numpy or device).
+        Returns (out [N,V] or None, mix [N,2] or None): the mix is formed from the kernel's partial rows with mxg_mix_rows_sum."""
+        f = _as_dev(freq, self.V)
+        tb = tables if isinstance(tables, DeviceBuffer) or hasattr(tables, "data_ptr") else DeviceBuffer.from_numpy(
+            np.ascontiguousarray(tables, np.float64))
+        out = self._out(N, out) if store else None
+        pn = rows = mix = None
+        if pan is not None:
+            pn = _as_dev(pan, self.V)
+            G = lib().mxg_osc_tables_groups(self.V)
+            rows = DeviceBuffer((G, N, 2), np.float64)
+        check(lib().mxg_osc_render_tables(self.V, N, _ptr(f), _ptr(tb), self.phase.ptr, self.output.ptr, _ptr(out), _ptr(pn), _ptr(rows),
+                                          self.stream), "mxg_osc_render_tables")
+        if pan is not None:
+            mix = DeviceBuffer((N, 2), np.float64, zero=False)
+            check(lib().mxg_mix_rows_sum(G, N * 2, rows.ptr, mix.ptr, self.stream), "mxg_mix_rows_sum")
+        self._keep = (f, tb, pn, rows)
+        return out, mix
+
     def noise(self, rand, out=None):
         """maxiOsc::noise (C:214-220) from caller-supplied rand() draws, int32 [N][V] (draw n*V+v is the
         one a voice-inner per-sample loop hands to voice v at sample n)."""

@@ -40,7 +40,7 @@ int device_cus();  // compute units of the device (256 on MI355X)
 // Library-owned scratch, one grow-only buffer per (slot, stream): launches on different streams never share
 // (or resize) each other's temporaries; launches on one stream are ordered by the stream.  Returns MXG_OK and
 // a device pointer of at least `bytes`.
-enum ScratchSlot { SCR_MIX_GAINS, SCR_OSC_MIX, SCR_GRAIN_ERR, SCR_GRAIN_SCHED, SCR_IFFT_OUT, SCR_IFFT_BUF, SCR_MFCC_RAW, SCR_CONVOLVE, SCR_GRAIN_MIX, SCR_PART_SYNC, SCR_SLOTS };
+enum ScratchSlot { SCR_MIX_GAINS, SCR_OSC_MIX, SCR_GRAIN_ERR, SCR_GRAIN_SCHED, SCR_IFFT_OUT, SCR_IFFT_BUF, SCR_MFCC_RAW, SCR_CONVOLVE, SCR_GRAIN_MIX, SCR_PART_SYNC, SCR_OSCTAB_MARKS, SCR_SLOTS };
 int scratch_get(ScratchSlot slot, hipStream_t st, size_t bytes, void **out);
 
 // Optional per-kernel timing (mxg_prof_enable): a KernelTimer around a launch records two HIP events on the launch

@@ -189,70 +189,33 @@ __device__ __forceinline__ double osc_tick(double &phase, double &hold, const Os
     }
 }
 
-// K consecutive samples of one voice, for kernels that run ONE wavefront per SIMD: the same operations per sample as osc_tick, in
-// three sweeps -- the K phase steps (with index and remainder), the table reads of all K samples, the K interpolations -- with a
-// scheduling fence between them, so that every LDS read of the chunk is in flight before the first result is needed.  (Left to itself
-// the scheduler finishes a sample before it starts the next to save registers, and a lone wavefront then waits out the LDS latency
-// K times.)  Only the operations of DIFFERENT samples change places: the bits are osc_tick's.
-template <int WF, int K>
-__device__ __forceinline__ void osc_tick_chunk(double &phase, double &hold, const OscPre &q, const double *s_sine,
-                                               const double *s_trans, double (&r)[K]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (WF == MXG_OSC_SINEBUF) {  // C:266-274
-        double rem[K], t0[K], t1[K];
-        int idx[K];
+// K consecutive samples of one voice in three stages, for kernels that run ONE wavefront per SIMD: (1) the K phase steps, with index
+// and remainder; (2) the table reads of all K samples; (3) the K interpolations.  The same operations per sample as osc_tick -- only
+// operations of DIFFERENT samples change places, so the bits are osc_tick's -- but every LDS read of the chunk is in flight before the
+// first result is needed, and a caller can put other work between (2) and (3) while the (bank-conflicted) reads drain.  Left to
+// itself the scheduler finishes a sample before it starts the next to save registers, and a lone wavefront waits out the LDS
+// latency K times.  Table forms with two reads per sample only: sinebuf (C:266-274) and sawn (C:342-359).
+template <int WF>
+constexpr bool osc_has_pipe() {
+    return WF == MXG_OSC_SINEBUF || WF == MXG_OSC_SAWN;
+}
+template <int K>
+struct OscPipe {
+    int idx[K];
+    double rem[K], aux[K];  // aux: sawn's phase (subtracted from the interpolated value)
+    double t0[K], t1[K];
+};
+// (the K phase steps in two halves, for a caller that puts other instructions between them)
+template <int WF, int K, int HALF>
+__device__ __forceinline__ void osc_pipe_phase_half(double &phase, const OscPre &q, OscPipe<K> &p) {
 #pragma unroll
-        for (int i = 0; i < K; i++) {
+    for (int i = HALF * (K / 2); i < (HALF + 1) * (K / 2); i++) {
+        if constexpr (WF == MXG_OSC_SINEBUF) {
             phase += q.inc;
             if (phase >= 511) phase -= 512;
-            rem[i] = phase - floor(phase);
-            idx[i] = (int)phase;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < K; i++) {
-            t0[i] = s_sine[1 + idx[i] + 1];
-            t1[i] = s_sine[2 + idx[i] + 1];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < K; i++) r[i] = (1 - rem[i]) * t0[i] + rem[i] * t1[i];
-        hold = r[K - 1];
-        return;
-    } else if constexpr (WF == MXG_OSC_SINEBUF4) {  // C:237-264
-        double rem[K], a[K], b[K], c[K], d[K];
-        int idx[K], ia[K];
-#pragma unroll
-        for (int i = 0; i < K; i++) {
-            phase += q.inc;
-            if (phase >= 511) phase -= 512;
-            rem[i] = phase - floor(phase);
-            idx[i] = (int)phase;
-            ia[i] = (phase == 0) ? 512 : idx[i] - 1;  // C:245-256; index -1 is the 0.0 guard
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < K; i++) {
-            a[i] = s_sine[ia[i] + 1];
-            b[i] = s_sine[idx[i] + 1];
-            c[i] = s_sine[idx[i] + 1 + 1];
-            d[i] = s_sine[idx[i] + 2 + 1];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < K; i++) {
-            const double a1 = 0.5 * (c[i] - a[i]);
-            const double a2 = a[i] - 2.5 * b[i] + 2. * c[i] - 0.5 * d[i];
-            const double a3 = 0.5 * (d[i] - a[i]) + 1.5 * (b[i] - c[i]);
-            r[i] = ((a3 * rem[i] + a2) * rem[i] + a1) * rem[i] + b[i];
-        }
-        hold = r[K - 1];
-        return;
-    } else if constexpr (WF == MXG_OSC_SAWN) {  // C:342-359
-        double rem[K], t0[K], t1[K], phs[K];
-        int idx[K];
-#pragma unroll
-        for (int i = 0; i < K; i++) {
+            p.rem[i] = phase - floor(phase);
+            p.idx[i] = (int)phase + 2;
+        } else {
             if (phase >= 0.5) phase -= 1.0;
             phase += q.inc;
             double temp = q.k * phase;
@@ -260,20 +223,49 @@ __device__ __forceinline__ void osc_tick_chunk(double &phase, double &hold, cons
             if (temp > 0.5) temp = 0.5;
             temp *= 1000.0;
             temp += 500.0;
-            rem[i] = temp - floor(temp);
-            idx[i] = (int)temp;
-            phs[i] = phase;
+            p.rem[i] = temp - floor(temp);
+            p.idx[i] = (int)temp;
+            p.aux[i] = phase;
         }
-        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int WF, int K>
+__device__ __forceinline__ void osc_pipe_phase(double &phase, const OscPre &q, OscPipe<K> &p) {
+    osc_pipe_phase_half<WF, K, 0>(phase, q, p);
+    osc_pipe_phase_half<WF, K, 1>(phase, q, p);
+}
+template <int WF, int K>
+__device__ __forceinline__ void osc_pipe_fetch(OscPipe<K> &p, const double *s_tab) {
 #pragma unroll
-        for (int i = 0; i < K; i++) {
-            t0[i] = s_trans[idx[i]];
-            t1[i] = s_trans[1 + idx[i]];
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < K; i++) {
+        p.t0[i] = s_tab[p.idx[i]];
+        p.t1[i] = s_tab[p.idx[i] + 1];
+    }
+}
+template <int WF, int K>
+__device__ __forceinline__ void osc_pipe_finish(const OscPipe<K> &p, double (&r)[K], double &hold) {
 #pragma unroll
-        for (int i = 0; i < K; i++) r[i] = ((1.0 - rem[i]) * t0[i] + rem[i] * t1[i]) - phs[i];
-        hold = r[K - 1];
+    for (int i = 0; i < K; i++) {
+        if constexpr (WF == MXG_OSC_SINEBUF)
+            r[i] = (1 - p.rem[i]) * p.t0[i] + p.rem[i] * p.t1[i];
+        else
+            r[i] = ((1.0 - p.rem[i]) * p.t0[i] + p.rem[i] * p.t1[i]) - p.aux[i];
+    }
+    hold = r[K - 1];
+}
+
+// K samples at once where the waveform has the staged form (all LDS reads of the chunk in flight), tick by tick elsewhere
+template <int WF, int K>
+__device__ __forceinline__ void osc_tick_chunk(double &phase, double &hold, const OscPre &q, const double *s_sine,
+                                               const double *s_trans, double (&r)[K]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (osc_has_pipe<WF>()) {
+        OscPipe<K> p;
+        osc_pipe_phase<WF, K>(phase, q, p);
+        __builtin_amdgcn_sched_barrier(0);
+        osc_pipe_fetch<WF, K>(p, WF == MXG_OSC_SINEBUF ? s_sine : s_trans);
+        __builtin_amdgcn_sched_barrier(0);
+        osc_pipe_finish<WF, K>(p, r, hold);
         return;
     }
 #endif

@@ -64,7 +64,10 @@ template <int WF, bool FPS, int VPL, int ST, bool PX>
 __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
                            const double *__restrict__ p1, const double *__restrict__ p2,
                            double *__restrict__ phase_io, double *__restrict__ hold_io,
-                           double *__restrict__ out, double sr, PartSync psync, int xcd, int p1ps, int passes) {
+                           double *__restrict__ out, double sr, PartSync psync, int xcd, int p1ps, int passes, size_t v_begin,
+                           size_t v_end) {
+    // [v_begin, v_end): the voices of the bank this launch renders (V stays the bank's size = the row pitch of `out`): a large bank
+    // is rendered as a few launches of the grid shapes that stream best (osc_plan below)
     // (p1ps, FPS only: p1 is [N][V] too -- a pulse width / start phase per sample, for the per-sample engine's derived arguments)
     // passes (round 4): the grid covers 1 / passes of the bank and every wavefront renders `passes` voice groups one after the other
     // (group stride = the grid's width): banks beyond the machine's 1024 wavefronts keep the access pattern of the 65 536-voice bank --
@@ -77,8 +80,8 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
         __syncthreads();
     }
     for (int pass = 0; pass < passes; pass++) {
-    const size_t v0 = (((size_t)pass * gridDim.x + xcd_block(blockIdx.x, gridDim.x, xcd)) * blockDim.x + threadIdx.x) * VPL;
-    if (v0 >= V) return;
+    const size_t v0 = v_begin + (((size_t)pass * gridDim.x + xcd_block(blockIdx.x, gridDim.x, xcd)) * blockDim.x + threadIdx.x) * VPL;
+    if (v0 >= v_end) return;
 
     double ph[VPL], hd[VPL];
     OscPre q[VPL];
@@ -133,23 +136,6 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
         size_t n = nA;
         if constexpr (PX && VPL == 1 && !FPS) {
             double *op = out + (nA + (threadIdx.x & 1)) * V + (v0 & ~(size_t)1);
-            // the table oscillators eight samples at a time: all of a chunk's LDS reads in flight at once (osc_tick_chunk, mxg_osc.h)
-#ifndef MXG_K1_CHUNK
-#define MXG_K1_CHUNK 8  // A/B: 0 = sample pairs only
-#endif
-            if constexpr (MXG_K1_CHUNK > 0 && !kTrust && (WF == MXG_OSC_SINEBUF || WF == MXG_OSC_SINEBUF4 || WF == MXG_OSC_SAWN)) {
-                constexpr int kC = MXG_K1_CHUNK > 0 ? MXG_K1_CHUNK : 2;
-                for (; n + kC <= nB; n += kC) {
-                    double r[kC];
-                    osc_tick_chunk<WF, kC>(ph[0], hd[0], q[0], s_tab, s_tab, r);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < kC; i += 2) {
-                        store_pair_rows<ST>(op, r[i], r[i + 1]);
-                        op += 2 * V;
-                    }
-                }
-            }
 #pragma unroll 2
             for (; n + 2 <= nB; n += 2) {
                 const double r0 = osc_tick<WF, kTrust>(ph[0], hd[0], q[0], s_tab, s_tab);
@@ -193,120 +179,6 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
     }  // passes (time parts are launched with one pass only: the part counters are per wavefront of the grid)
 }
 
-// ---- K1p: K1 on a persistent grid ---------------------------------------------------------------------
-// K1 launches one wavefront per 64 voices: a 65 536-voice bank is exactly one wavefront per SIMD (1024 of them), the regime its
-// store stream is fastest in (0.83 of the HBM peak), but 98 304 voices are 1.5 wavefronts per SIMD, 196 608 three, and the time per
-// voice goes up by a fifth (profiles/r03_osc_store.md).  Here the grid is a property of the MACHINE -- k wavefronts per SIMD -- and
-// the block of C = V / 64 voice columns x N samples is cut into equal SHARES of the linear work index c * N + n: a wavefront renders
-// a tail piece of one column, some whole columns, and a head piece of another, whatever V is.  A piece that starts at sample a > 0
-// first advances the recurrence over samples 0 .. a-1 (osc_skip: the same additions, the same bits, as K1's time parts); the piece
-// that ends at N stores the state, after every other piece of its column has signalled that its state loads have returned
-// (part_signal / part_wait on one counter per column).  A wavefront renders its HEAD piece (a reader: it signals at once) first and
-// its TAIL piece (a writer) last, so a writer never waits for work that sits behind another writer's wait.
-template <int WF, int ST, bool PX>
-__global__ __launch_bounds__(256) void osc_persist_kernel(size_t V, size_t N, const double *__restrict__ freq,
-                                                          const double *__restrict__ p1, const double *__restrict__ p2,
-                                                          double *__restrict__ phase_io, double *__restrict__ hold_io,
-                                                          double *__restrict__ out, double sr, PartSync psync, size_t share, int xcd) {
-    __shared__ __attribute__((aligned(16))) double s_tab[tab_len<WF>()];
-    if constexpr (tab_len<WF>() > 1) {
-        load_tab<WF>(s_tab);
-        __syncthreads();
-    }
-    const int lane = threadIdx.x & 63;
-    const size_t p = (size_t)xcd_block(blockIdx.x, gridDim.x, xcd) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const size_t C = (V + 63) >> 6, W = C * N;
-    const size_t w0 = p * share;
-    if (w0 >= W) return;
-    const size_t w1 = w0 + share < W ? w0 + share : W;
-    const size_t c0 = w0 / N, a0 = w0 - c0 * N;
-    const size_t c1 = (w1 - 1) / N, b1 = w1 - c1 * N;  // the piece of column c1 ends at b1 (1 .. N)
-
-    auto piece = [&](size_t c, size_t a, size_t b) {
-        const size_t v = c * 64 + lane;
-        if (v >= V) return;  // (pair rows: V is even, a pair of lanes is live or dead together)
-        double ph = phase_io[v], hd = hold_io[v];
-        const OscPre q = osc_pre<WF>(freq[v], sr, p1 ? p1[v] : 0.0, p2 ? p2[v] : 0.0);
-        int *const ctr = psync.ctrs + c;
-        if (b < N) part_signal(ctr);  // (waits for the loads above)
-        bool trust = false;
-        if constexpr (WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE)
-            trust = __all(q.inc >= 0.0 && q.inc <= 1.0 && ph >= 0.0 && ph <= 2.0);
-#pragma unroll 4
-        for (size_t n = 0; n < a; n++) osc_skip<WF>(ph, hd, q, s_tab, s_tab);
-        auto run = [&](auto trust_tag) {
-            constexpr bool kTrust = decltype(trust_tag)::value;
-            size_t n = a;
-            if constexpr (PX) {
-                double *op = out + (a + (lane & 1)) * V + (v & ~(size_t)1);
-#pragma unroll 2
-                for (; n + 2 <= b; n += 2) {
-                    const double r0 = osc_tick<WF, kTrust>(ph, hd, q, s_tab, s_tab);
-                    const double r1 = osc_tick<WF, kTrust>(ph, hd, q, s_tab, s_tab);
-                    store_pair_rows<ST>(op, r0, r1);
-                    op += 2 * V;
-                }
-            }
-            double *o = out + n * V + v;
-#pragma unroll 4
-            for (; n < b; n++) {
-                store1<PX ? 0 : ST>(o, osc_tick<WF, kTrust>(ph, hd, q, s_tab, s_tab));
-                o += V;
-            }
-        };
-        if (trust) run(std::true_type{}); else run(std::false_type{});
-        if (b == N) {
-            // the other pieces of this column: the wavefronts whose shares overlap [c N, (c + 1) N)
-            const size_t first = (c * N) / share, last = ((c + 1) * N - 1) / share;
-            PartSync ps = psync;
-            ps.others += (int)(last - first);
-            if (part_wait(ps.others ? ctr : nullptr, ps)) {
-                phase_io[v] = ph;
-                hold_io[v] = hd;
-            }
-        }
-    };
-    if (c0 == c1) {
-        piece(c0, a0, b1);
-        return;
-    }
-    if (b1 < N) piece(c1, 0, b1);
-    for (size_t c = c0 + 1; c < c1; c++) piece(c, 0, N);
-    if (b1 == N) piece(c1, 0, N);
-    piece(c0, a0, N);
-}
-
-typedef void (*osc_persist_fn)(size_t, size_t, const double *, const double *, const double *, double *, double *, double *, double,
-                               PartSync, size_t, int);
-// store: 0 plain 8 B, 1 nt 8 B, 2 pair rows plain, 3 pair rows sc1, 4 pair rows nt
-template <int WF>
-osc_persist_fn pick_persist(int store) {
-    switch (store) {
-        case 1: return osc_persist_kernel<WF, 1, false>;
-        case 2: return osc_persist_kernel<WF, 0, true>;
-        case 3: return osc_persist_kernel<WF, 2, true>;
-        case 4: return osc_persist_kernel<WF, 1, true>;
-        default: return osc_persist_kernel<WF, 0, false>;
-    }
-}
-osc_persist_fn pick_persist_wf(int wf, int store) {
-    switch (wf) {
-        case 0: return pick_persist<0>(store);
-        case 1: return pick_persist<1>(store);
-        case 2: return pick_persist<2>(store);
-        case 3: return pick_persist<3>(store);
-        case 4: return pick_persist<4>(store);
-        case 5: return pick_persist<5>(store);
-        case 6: return pick_persist<6>(store);
-        case 7: return pick_persist<7>(store);
-        case 8: return pick_persist<8>(store);
-        case 9: return pick_persist<9>(store);
-        case 10: return pick_persist<10>(store);
-        case 11: return pick_persist<11>(store);
-    }
-    return nullptr;
-}
-
 // ---- K1m: K1 + fused maxiMix::stereo partial sums ---------------------------------------------------
 // Same per-voice recurrence and (optional) per-voice store as K1; in addition every workgroup forms the panned sum of its
 // 256 voices (in*sqrt(1-x), in*sqrt(x), C:503-509; the sum over voices is the user's `mix +=` loop, 15.polysynth/main.cpp:67)
@@ -347,13 +219,14 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
                                                       double *__restrict__ partial, double sr, PartSync psync, int passes) {
     constexpr int kTab = tab_len<WF>();
     constexpr int kTabPad = (kTab + 1) & ~1;  // the tiles are read with 16-byte loads
-    __shared__ __attribute__((aligned(16))) double s_all[kTabPad + 4 * kTileWave + 4 * WIN * 2];
+    __shared__ __attribute__((aligned(16))) double s_all[kTabPad + 4 * kTileWave + 4 * WIN * 2 + 256];
     double *s_tab = s_all;
     load_tab<WF>(s_tab);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *tile = s_all + kTabPad + wave * kTileWave;
     double *s_part = s_all + kTabPad + 4 * kTileWave;  // [4 waves][WIN][2]
     double *my_part = s_part + wave * (WIN * 2);
+    double *s_dump = s_part + 4 * WIN * 2;  // [256]: where the lanes that hold no sum drop their value
     // The transposed read needs all 64 lanes alive, and a per-sample `if (live)` costs an exec-mask region per sample:
     // the surplus lanes of the bank's last wavefront shadow a live voice instead (same loads, same arithmetic, same stores
     // of the same values to the same addresses) and enter the mix with zero gains -- voice V-1, or with pair rows the last
@@ -403,7 +276,116 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
     double *op = out + (nA + (threadIdx.x & 1)) * V + (v & ~(size_t)1);  // pair rows: this lane's 16 bytes of row n + (lane & 1)
     for (size_t n0 = nA; n0 < nB; n0 += WIN) {
         const int span = (int)((nB - n0) < (size_t)WIN ? (nB - n0) : (size_t)WIN);
-        for (int c0 = 0; c0 < span; c0 += kMixChunk) {
+        // the voice sum of one chunk: the tile read back transposed, 16 products per channel added in a fixed tree, the four voice
+        // quarters folded (lanes 0-31 <- left sums of quarters (0, 2) / (1, 3), lanes 32-63 the right sums; then the two rows of 16)
+        auto tile_load = [&](double2v (&xv)[8]) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) xv[k] = tr[k];
+        };
+        // (pure VALU: products, the tree, v_permlane32_swap and v_permlane16_swap -- nothing that queues behind LDS reads in flight)
+        auto tile_products = [&](const double2v (&xv)[8], double &sl, double &sr2) {
+            double pl[8], pr[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                pl[k] = xv[k].x * gl[2 * k] + xv[k].y * gl[2 * k + 1];
+                pr[k] = xv[k].x * gr[2 * k] + xv[k].y * gr[2 * k + 1];
+            }
+            sl = ((pl[0] + pl[1]) + (pl[2] + pl[3])) + ((pl[4] + pl[5]) + (pl[6] + pl[7]));
+            sr2 = ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]));
+        };
+        auto tile_fold = [&](double sl, double sr2) {
+            const double t = fold32(sl, sr2);
+            return fold16(t, t);  // lane l <- t[l] + t[l ^ 16]
+        };
+        auto tile_value = [&](const double2v (&xv)[8]) {
+            double sl, sr2;
+            tile_products(xv, sl, sr2);
+            return tile_fold(sl, sr2);
+        };
+        // lanes 0-15 hold the left sums of samples c0 + lane, lanes 32-47 the right sums; the other lanes (and samples beyond cnt) write
+        // into a scratch row instead -- a select on the address, not a branch around the store
+        auto tile_put = [&](double t, int c0, int cnt) {
+            double *dst = ((lane & 16) == 0 && ts < cnt) ? my_part + (c0 + ts) * 2 + (lane >> 5) : s_dump + threadIdx.x;
+            *dst = t;
+        };
+        auto tile_sum = [&](const double2v (&xv)[8], int c0, int cnt) { tile_put(tile_value(xv), c0, cnt); };
+        int c_first = 0;
+        // Table oscillators with pair rows (or no per-voice block): the chunks of a window as a software pipeline.  While the
+        // (bank-conflicted) table reads of chunk c + 1 drain, the wavefront adds up chunk c -- a lone wavefront otherwise sits out
+        // ~60 clk per sample on s_waitcnt (SQ_WAIT_ANY, profiles/r04_k1m_sq.md).  LDS operations complete in order, so the tile
+        // reads of chunk c are issued BEFORE the table reads of chunk c + 1 and the sums need only them.
+        if constexpr (osc_has_pipe<WF>() && STORE != 1) {
+            const int full = span / kMixChunk;
+            if (full > 0) {
+                OscPipe<kMixChunk> P;
+                osc_pipe_phase<WF, kMixChunk>(ph, q, P);
+                __builtin_amdgcn_sched_barrier(0);
+                osc_pipe_fetch<WF, kMixChunk>(P, s_tab);
+                double t_prev = 0.0;  // the sums of chunk c - 1: written with chunk c's tile, so that no LDS write sits behind the table reads
+                // The eight pair-row stores of a chunk are SPREAD over the iteration (S(j) below): the four wavefronts of a CU run this
+                // code in step, and eight 1-KiB stores back to back from each of them is a 32 KB burst on the CU's store path with the
+                // arithmetic standing still behind it (K1 with its stores in groups of four: 49 us against 41, profiles/r04_k1_chunk_ab.md).
+                auto body = [&](int c, auto last_tag) {
+                    constexpr bool kLast = decltype(last_tag)::value;
+                    double r[kMixChunk];
+                    auto S = [&](int j) {
+                        if constexpr (STORE == 2) {
+                            store_pair_rows<2>(op, r[2 * j], r[2 * j + 1]);
+                            op += 2 * V;
+                        }
+                    };
+                    __builtin_amdgcn_sched_barrier(0);
+                    osc_pipe_finish<WF, kMixChunk>(P, r, hd);  // (waits for the table reads of this chunk)
+                    __builtin_amdgcn_sched_barrier(0);
+                    S(0);
+#pragma unroll
+                    for (int i = 0; i < kMixChunk; i++) tw[i * kTileRow] = r[i];
+                    tile_put(t_prev, (c - 1) * kMixChunk, c > 0 ? kMixChunk : 0);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    double2v xv[8];
+                    tile_load(xv);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();  // (the next chunk's tile writes stay behind these reads)
+                    __builtin_amdgcn_sched_barrier(0);
+                    S(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!kLast) {
+                        osc_pipe_phase_half<WF, kMixChunk, 0>(ph, q, P);
+                        __builtin_amdgcn_sched_barrier(0);
+                        S(2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        osc_pipe_phase_half<WF, kMixChunk, 1>(ph, q, P);
+                        __builtin_amdgcn_sched_barrier(0);
+                        S(3);
+                        __builtin_amdgcn_sched_barrier(0);
+                        osc_pipe_fetch<WF, kMixChunk>(P, s_tab);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        S(2);
+                        S(3);
+                    }
+                    S(4);
+                    __builtin_amdgcn_sched_barrier(0);
+                    double vl, vr;
+                    tile_products(xv, vl, vr);
+                    __builtin_amdgcn_sched_barrier(0);
+                    S(5);
+                    __builtin_amdgcn_sched_barrier(0);
+                    t_prev = tile_fold(vl, vr);
+                    __builtin_amdgcn_sched_barrier(0);
+                    S(6);
+                    S(7);
+                };
+                for (int c = 0; c + 1 < full; c++) body(c, std::false_type{});
+                body(full - 1, std::true_type{});
+                tile_put(t_prev, (full - 1) * kMixChunk, kMixChunk);
+                if constexpr (STORE == 2) o += (size_t)full * kMixChunk * V;
+                c_first = full * kMixChunk;
+            }
+        }
+        for (int c0 = c_first; c0 < span; c0 += kMixChunk) {
             const int cnt = (span - c0) < kMixChunk ? (span - c0) : kMixChunk;
             auto chunk = [&](auto full_tag) {
                 constexpr bool kFull = decltype(full_tag)::value;
@@ -461,22 +443,10 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 double2v xv[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) xv[k] = tr[k];
+                tile_load(xv);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();  // (the next chunk's writes stay behind these reads)
-                double pl[8], pr[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    pl[k] = xv[k].x * gl[2 * k] + xv[k].y * gl[2 * k + 1];
-                    pr[k] = xv[k].x * gr[2 * k] + xv[k].y * gr[2 * k + 1];
-                }
-                const double sl = ((pl[0] + pl[1]) + (pl[2] + pl[3])) + ((pl[4] + pl[5]) + (pl[6] + pl[7]));
-                const double sr2 = ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]));
-                // quarters: lanes 0-31 <- left sums of quarters (0, 2) / (1, 3), lanes 32-63 the right sums; then the two rows of 16
-                double t = fold32(sl, sr2);
-                t = t + __shfl_xor(t, 16);
-                if ((lane & 16) == 0 && ts < cnt) my_part[(c0 + ts) * 2 + (lane >> 5)] = t;
+                tile_sum(xv, c0, cnt);
             };
             if (cnt == kMixChunk) chunk(std::true_type{}); else chunk(std::false_type{});
         }
@@ -522,7 +492,7 @@ osc_mix_fn pick_mix_wf(int wf, int store, int win) {
 }
 
 typedef void (*osc_fn)(size_t, size_t, const double *, const double *, const double *, double *,
-                       double *, double *, double, PartSync, int, int, int);
+                       double *, double *, double, PartSync, int, int, int, size_t, size_t);
 
 // store: 0 plain 8 B, 1 nt 8 B, 2 pair rows (16 B) plain, 3 pair rows sc1, 4 pair rows nt      (one voice per lane)
 //        0 plain 16 B, 1 nt 16 B, 2 sc1 16 B                                                  (two voices per lane)
@@ -561,6 +531,107 @@ osc_fn pick_wf(int wf, bool fps, int vpl, int store) {
 
 }  // namespace mxg
 
+namespace mxg {
+namespace {
+// one launch of K1 over the voices [v_begin, v_end) of a bank
+struct OscLaunch {
+    int waveform = 0;
+    size_t V = 0, N = 0;
+    const double *freq = nullptr, *p1 = nullptr, *p2 = nullptr;
+    int fps = 0;
+    double *phase = nullptr, *hold = nullptr, *out = nullptr;
+    hipStream_t st = nullptr;
+    bool pairs_ok = false;
+    size_t v_begin = 0, v_end = 0;
+    int vpl = 1, store = 0, xcd = 0;  // store: osc.hip pick<WF> numbering (0 plain 8 B ...)
+    int split = 0, passes = 0, block = 256;  // 0 = automatic
+};
+
+// The store stream of ONE launch over `count` voices, by waveform class and size (MI355X, 512-sample blocks, destination rotated;
+// profiles/r03_osc_store.md, profiles/r04_osc_grid.md; fraction of the 8 TB/s peak on 8 B per sample):
+//   pair rows = ONE voice per lane, two samples of a lane pair exchanged into one write-through (sc1) 16-byte store per lane;
+//   2v        = TWO voices per lane, write-through 16-byte stores (half the wavefronts).
+//   table forms (sinebuf, sawn):  < 49 152 voices plain 8-byte stores (the block lives in the caches);
+//       < 81 920 pair rows (65 536: 51 -> 40 us, 0.66 -> 0.84); from there 2v (81 920: 61 us; 98 304: 63.5, 0.79; 131 072: 88, 0.76);
+//   ramps (phasor, saw, triangle, square, pulse, impulse, phasorBetween): 2v already from 65 536 voices (saw: 49 -> 40 us);
+//   VALU-heavy forms (sinewave, coswave, sinebuf4): pair rows at every size (65 536 sinewave: 69 -> 65, sinebuf4 60 -> 57), from
+//   262 144 voices XCD-contiguous workgroup numbering.
+void osc_single_rule(OscLaunch &L, size_t count) {
+    const int wf = L.waveform;
+    const bool heavy = wf == MXG_OSC_SINEWAVE || wf == MXG_OSC_COSWAVE || wf == MXG_OSC_SINEBUF4;
+    const bool table = wf == MXG_OSC_SINEBUF || wf == MXG_OSC_SAWN;
+    const size_t bytes = count * L.N * sizeof(double);
+    L.vpl = 1;
+    L.store = 0;
+    L.xcd = 0;
+    if (L.pairs_ok) {
+        if (heavy) {
+            if (bytes >= ((size_t)32 << 20)) L.store = 3;
+            L.xcd = count >= 262144 ? 1 : 0;
+        } else if (bytes >= ((size_t)192 << 20)) {
+            if (count >= (table ? 81920u : 65536u)) {
+                L.vpl = 2;
+                L.store = 2;
+                L.xcd = count >= 262144 ? 1 : 0;
+            } else {
+                L.store = 3;
+            }
+        }
+    }
+}
+
+int osc_launch(const OscLaunch &L) {
+    int vpl = L.vpl, store = L.store, block = L.block ? L.block : 256;
+    const bool fps = L.fps != 0;
+    const size_t count = L.v_end - L.v_begin;
+    if (count == 0) return MXG_OK;
+    const bool pairs_ok = L.pairs_ok && !(L.v_begin & 1) && !(count & 1);
+    if (!pairs_ok) vpl = 1;
+    if (vpl == 2 && store > 2) store = 0;
+    if (vpl == 1 && store >= 2 && !pairs_ok) store = store == 4 ? 1 : 0;  // pair rows need whole pairs
+    osc_fn fn = pick_wf(L.waveform, fps, vpl, store);
+    const size_t lanes = (count + vpl - 1) / vpl;
+    // time parts.  (a) Where the output dominates the recurrence (sinewave, coswave, sinebuf4) and the bank is too small to give every
+    // SIMD two wavefronts by itself: two parts.  (b) SMALL banks (fewer wavefronts than the 1024 SIMDs) of the waveforms whose phase
+    // skip is much cheaper than their tick (the table oscillators: sinebuf, sinebuf4, sawn, sinewave, coswave): a block is one chain of
+    // N dependent steps per wavefront, 27-30 us for 512 samples however few voices there are; cut into up to eight parts it is 14.6 us
+    // at 1024 voices, 17.0 at 4096, 20.1 at 16 384 (sinebuf; profiles/r03_small_osc_banks.md).  Same bits (the skip is the same
+    // additions); the other waveforms' tick IS their recurrence, parts would only repeat it.
+    int split = L.split;
+    if (split == 0) {
+        split = 1;
+        const size_t waves = (lanes + 63) / 64;
+        const int wf = L.waveform;
+        const bool heavy = wf == MXG_OSC_SINEWAVE || wf == MXG_OSC_COSWAVE || wf == MXG_OSC_SINEBUF4;
+        const bool table = heavy || wf == MXG_OSC_SINEBUF || wf == MXG_OSC_SAWN;
+        if (!fps && heavy) split = waves >= 2048 ? 1 : 2;  // (sinewave at 65 536 voices: 60-62 us in two parts; one part 65-69, four 64)
+        if (!fps && table && waves < 1024) {
+            int want = 1;
+            while (want < 8 && (size_t)(2 * want) * waves <= 1024 && (size_t)(2 * want) * 64 <= L.N) want *= 2;  // (a part renders >= 64 samples)
+            if (want > split) split = want;
+        }
+    }
+    if (fps) split = 1;
+    // every part must render at least one sample: the last part's ticks leave the member `output` of the final sample
+    while (split > 1 && (size_t)(split - 1) * ((L.N + split - 1) / split) >= L.N) split--;
+    // passes: voice groups a wavefront renders one after the other (the grid covers 1 / passes of the range)
+    int passes = L.passes > 0 ? L.passes : 1;
+    if (split > 1) passes = 1;
+    size_t nblk = (lanes + block - 1) / block;
+    if ((size_t)passes > nblk) passes = (int)nblk;
+    nblk = (nblk + passes - 1) / passes;
+    dim3 grid((unsigned)nblk, (unsigned)split), blk((unsigned)block);
+    PartSync psync;
+    if (split > 1)
+        if (int s = part_sync_get(L.st, (size_t)grid.x * ((block + 63) / 64), split, &psync)) return s;
+    KernelTimer kt("osc_kernel", L.st);
+    hipLaunchKernelGGL(fn, grid, blk, 0, L.st, L.V, L.N, L.freq, L.p1, L.p2, L.phase, L.hold, L.out, (double)settings().sampleRate, psync,
+                       L.xcd, L.fps == 2 ? 1 : 0, passes, L.v_begin, L.v_end);
+    return check_hip(hipGetLastError(), "osc_kernel launch");
+}
+}  // namespace
+}  // namespace mxg
+
 extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_freq, int fps,
                               const double *d_p1, const double *d_p2, double *d_phase,
                               double *d_outhold, double *d_out, void *stream) {
@@ -573,108 +644,63 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
                 "phasorBetween needs d_p1/d_p2 (start/end phase)");
     MXG_REQUIRE(fps >= 0 && fps <= 2 && (fps != 2 || d_p1), "fps is 0, 1 (d_freq [N][V]) or 2 (d_freq and d_p1 [N][V])");
     if (V == 0 || N == 0) return MXG_OK;
-    // ---- the store stream --------------------------------------------------------------------------------------------
-    // Knobs osc_vpl, osc_store, osc_xcd (0 = automatic each) name it; left alone, it goes by
-    // waveform class and bank size, from the rotated-destination sweep of tools/sweep_osc_store.py (profiles/r03_osc_store.md;
-    // MI355X, 512-sample blocks, fraction of the 8 TB/s peak on 8 B per sample):
-    //   pair rows = ONE voice per lane, two samples of a lane pair exchanged into one write-through (sc1) 16-byte store per lane;
-    //   2v        = TWO voices per lane, write-through 16-byte stores (half the wavefronts: only where one lane can carry two voices'
-    //               arithmetic without exposing its latency).
-    //   table forms (sinebuf, sawn):  < 49 152 voices plain 8-byte stores (the block lives in the caches; 32 768: 31 us against 37);
-    //       < 98 304 pair rows (65 536: 51 -> 40.5 us, 0.66 -> 0.83); from there 2v (98 304: 79 -> 67; 131 072: 101 -> 88 us, 0.67 -> 0.77);
-    //   ramps (phasor, saw, triangle, square, pulse, impulse, phasorBetween): 2v already from 65 536 voices (saw: 49 -> 40 us);
-    //   VALU-heavy forms (sinewave, coswave, sinebuf4): pair rows at every size (65 536 sinewave: 69 -> 65, sinebuf4 60 -> 57);
-    //   from 262 144 voices XCD-contiguous workgroup numbering (262 144 sinebuf: 215 -> 192 us; 1 048 576: 818 -> 755 us, 0.66 -> 0.71).
+    // the store stream: knobs osc_vpl, osc_store, osc_xcd, osc_passes, osc_split (0 = automatic each); left alone, osc_single_rule / the plan
+    // of launches below
     const bool pairs_ok = !fps && !(V & 1) && !(((uintptr_t)d_out) & 15);
-    const size_t out_bytes = V * N * sizeof(double);
+    hipStream_t st = resolve_stream(stream);
+    OscLaunch L0;
+    L0.waveform = waveform; L0.V = V; L0.N = N; L0.freq = d_freq; L0.fps = fps; L0.p1 = d_p1; L0.p2 = d_p2; L0.phase = d_phase;
+    L0.hold = d_outhold; L0.out = d_out; L0.st = st; L0.pairs_ok = pairs_ok;
     int vpl = tune_get("osc_vpl"), store = tune_get("osc_store") - 1, xcd = tune_get("osc_xcd") - 1;  // (knob value 0 = automatic)
     const bool automatic = vpl == 0 && store < 0;
-    if (automatic) {
-        vpl = 1;
-        store = 0;
-        const bool heavy = waveform == MXG_OSC_SINEWAVE || waveform == MXG_OSC_COSWAVE || waveform == MXG_OSC_SINEBUF4;
-        const bool table = waveform == MXG_OSC_SINEBUF || waveform == MXG_OSC_SAWN;
-        if (pairs_ok) {
-            if (heavy) {
-                if (out_bytes >= ((size_t)32 << 20)) store = 3;
-            } else if (out_bytes >= ((size_t)192 << 20)) {
-                if (V >= (table ? 98304u : 65536u)) {
-                    vpl = 2;
-                    store = 2;
-                } else {
-                    store = 3;
-                }
-            }
+    const bool heavy = waveform == MXG_OSC_SINEWAVE || waveform == MXG_OSC_COSWAVE || waveform == MXG_OSC_SINEBUF4;
+    if (automatic && pairs_ok && !heavy && xcd < 0 && tune_get("osc_passes") == 0 && tune_get("osc_split") == 0 &&
+        V * N * sizeof(double) >= ((size_t)352 << 20)) {
+        // ---- large banks of the store-bound waveforms: a plan of launches (round 4, profiles/r04_osc_grid.md) ----------------------------
+        // What streams best is a grid of exactly THREE wavefronts per CU, two voices per lane, every wavefront walking down the same
+        // rows at the same time: 768 wavefronts = 98 304 voices per pass at 0.79-0.80 of the HBM peak, pass after pass (196 608 voices in
+        // two passes 126 us, 393 216 in four 251 us) -- where one wavefront per 128 voices over the whole bank gives 1536, 3072 ...
+        // wavefronts that drift apart over megabyte rows (0.62-0.69), and uneven grids (683, 640 wavefronts) leave CUs idle.  So: as
+        // many 98 304-voice passes as fit, in one launch; the remainder as a second launch in the best shape for ITS size (the
+        // single-launch rules below), unless a 131 072-voice tail (1024 wavefronts, 0.75-0.77) is cheaper than 98 304 + a small rest.
+        const size_t kPass = 98304;
+        size_t k = V / kPass;
+        size_t rest = V - k * kPass;
+        if (k > 0 && rest > 0 && rest < 40960 && rest + kPass <= 131072) {  // e.g. 131 072 = one 1024-wavefront launch, not 98 304 + 32 768
+            k--;
+            rest += kPass;
         }
-        if (xcd < 0) xcd = V >= 262144 ? 1 : 0;
+        if (k > 0) {
+            OscLaunch A = L0;
+            A.v_begin = 0; A.v_end = k * kPass; A.vpl = 2; A.store = 2; A.xcd = 0; A.split = 1; A.passes = (int)k; A.block = 256;
+            if (int s2 = osc_launch(A)) return s2;
+        }
+        if (rest > 0) {
+            OscLaunch B = L0;
+            B.v_begin = k * kPass; B.v_end = V;
+            osc_single_rule(B, rest);
+            if (int s2 = osc_launch(B)) return s2;
+        }
+        return MXG_OK;
+    }
+    OscLaunch A = L0;
+    A.v_begin = 0; A.v_end = V;
+    if (automatic) {
+        osc_single_rule(A, V);
+        if (xcd >= 0) A.xcd = xcd;
     } else {
         if (vpl == 0) vpl = 1;
         if (store < 0) {  // (the round-2 rule for 8-byte stores, knob osc_nt: non-temporal by block size)
+            const size_t out_bytes = V * N * sizeof(double);
             const int nt_knob = tune_get("osc_nt");
             store = (nt_knob == 1 || (nt_knob == 2 && out_bytes > ((size_t)300 << 20) && out_bytes <= ((size_t)1200 << 20))) ? 1 : 0;
         }
-        if (xcd < 0) xcd = 0;
+        A.vpl = vpl; A.store = store; A.xcd = xcd < 0 ? 0 : xcd;
     }
-    if (!pairs_ok) vpl = 1;
-    int block = tune_get("osc_block");
-    if (vpl == 2 && store > 2) store = 0;
-    if (vpl == 1 && store >= 2 && !pairs_ok) store = store == 4 ? 1 : 0;  // pair rows need whole pairs
-    // the persistent grid (K1p; knob osc_persist: 0 automatic, 1 off, 2 / 3 / 4 = one / two / four wavefronts per SIMD)
-    const int persist = tune_get("osc_persist");
-    if (persist >= 2 && !fps) {
-        hipStream_t st = resolve_stream(stream);
-        int pstore = store;
-        if (vpl == 2) pstore = pairs_ok ? (store == 2 ? 3 : (store == 1 ? 4 : 2)) : 0;  // (a lane carries one voice here)
-        if (pstore >= 2 && !pairs_ok) pstore = pstore == 4 ? 1 : 0;
-        const size_t C = (V + 63) / 64, W = C * N;
-        const size_t waves = (size_t)device_cus() * 4 * (size_t)(persist == 2 ? 1 : (persist == 3 ? 2 : 4));
-        size_t share = ((W + waves - 1) / waves + 15) / 16 * 16;
-        PartSync psync;
-        if (int s = part_sync_get(st, C, 1, &psync)) return s;
-        KernelTimer kt("osc_kernel", st);
-        hipLaunchKernelGGL(pick_persist_wf(waveform, pstore), dim3((unsigned)(waves / 4)), dim3(256), 0, st, V, N, d_freq, d_p1, d_p2,
-                           d_phase, d_outhold, d_out, (double)settings().sampleRate, psync, share, xcd);
-        return check_hip(hipGetLastError(), "osc_persist_kernel launch");
-    }
-    osc_fn fn = pick_wf(waveform, fps != 0, vpl, store);
-    size_t lanes = (V + vpl - 1) / vpl;
-    // time parts.  (a) Where the output dominates the recurrence (sinewave, coswave, sinebuf4) and the bank is too small to give every
-    // SIMD two wavefronts by itself: two parts.  (b) SMALL banks (fewer wavefronts than the 1024 SIMDs) of the waveforms whose phase
-    // skip is much cheaper than their tick (the table oscillators: sinebuf, sinebuf4, sawn, sinewave, coswave): a block is one chain of
-    // N dependent steps per wavefront, 27-30 us for 512 samples however few voices there are; cut into up to eight parts it is 14.6 us
-    // at 1024 voices, 17.0 at 4096, 20.1 at 16 384 (sinebuf; profiles/r03_small_osc_banks.md).  Same bits (the skip is the same
-    // additions); the other waveforms' tick IS their recurrence, parts would only repeat it.
-    int split = tune_get("osc_split");
-    if (split == 0) {
-        split = 1;
-        const size_t waves = (lanes + 63) / 64;
-        const bool heavy = waveform == MXG_OSC_SINEWAVE || waveform == MXG_OSC_COSWAVE || waveform == MXG_OSC_SINEBUF4;
-        const bool table = heavy || waveform == MXG_OSC_SINEBUF || waveform == MXG_OSC_SAWN;
-        if (!fps && heavy) split = waves >= 2048 ? 1 : 2;  // (sinewave at 65 536 voices: 60-62 us in two parts; one part 65-69, four 64)
-        if (!fps && table && waves < 1024) {
-            int want = 1;
-            while (want < 8 && (size_t)(2 * want) * waves <= 1024 && (size_t)(2 * want) * 64 <= N) want *= 2;  // (a part renders >= 64 samples)
-            if (want > split) split = want;
-        }
-    }
-    if (fps) split = 1;
-    // every part must render at least one sample: the last part's ticks leave the member `output` of the final sample
-    while (split > 1 && (size_t)(split - 1) * ((N + split - 1) / split) >= N) split--;
-    // passes: voice groups a wavefront renders one after the other (knob osc_passes, 0 automatic)
-    int passes = tune_get("osc_passes");
-    if (passes == 0) passes = 1;
-    if (split > 1) passes = 1;
-    size_t nblk = (lanes + block - 1) / block;
-    if ((size_t)passes > nblk) passes = (int)nblk;
-    nblk = (nblk + passes - 1) / passes;
-    dim3 grid((unsigned)nblk, (unsigned)split), blk((unsigned)block);
-    PartSync psync;
-    if (split > 1)
-        if (int s = part_sync_get(resolve_stream(stream), (size_t)grid.x * ((block + 63) / 64), split, &psync)) return s;
-    KernelTimer kt("osc_kernel", resolve_stream(stream));
-    hipLaunchKernelGGL(fn, grid, blk, 0, resolve_stream(stream), V, N, d_freq, d_p1, d_p2, d_phase,
-                       d_outhold, d_out, (double)settings().sampleRate, psync, xcd, fps == 2 ? 1 : 0, passes);
-    return check_hip(hipGetLastError(), "osc_kernel launch");
+    A.block = tune_get("osc_block");
+    A.split = tune_get("osc_split");
+    A.passes = tune_get("osc_passes");
+    return osc_launch(A);
 }
 
 namespace mxg {

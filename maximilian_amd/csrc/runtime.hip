@@ -39,7 +39,6 @@ Tune g_tune[] = {
     {"voice_xcd", 0, 0, 2},    // 0 automatic, 1 natural workgroup order, 2 XCD-contiguous
     {"osc_store", 0, 0, 5},  // K1 store stream (osc.hip pick<WF>): 0 automatic; one voice per lane: 1 plain 8 B, 2 nt 8 B, 3 / 4 / 5 pair rows (16 B) plain / sc1 / nt; two voices per lane: 1 plain, 2 nt, 3 sc1
     {"osc_xcd", 0, 0, 2},  // K1: 1 = every XCD renders one contiguous eighth of the bank (workgroup renumbering, mxg_common.h)
-    {"osc_persist", 0, 0, 4},  // K1p: the persistent grid (a fixed number of wavefronts per SIMD, equal shares of voices x samples): 0 automatic, 1 off, 2 / 3 / 4 = one / two / four wavefronts per SIMD
     {"osc_passes", 0, 0, 64},  // K1: voice groups a wavefront renders one after the other (0 automatic; the grid covers 1 / passes of the bank)
     {"osc_mix_passes", 0, 0, 64},  // K1m: the same for the fused render + mixdown
     {"osc_split", 0, 0, 8},  // K1: time parts per voice group (0 = automatic: 2 for sinewave / coswave / sinebuf4 below 131 072 voices; up to 8 for the table oscillators on banks smaller than the machine; else 1)

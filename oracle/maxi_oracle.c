@@ -232,6 +232,28 @@ int mxo_osc(int wf, size_t V, size_t N, const double *freq, int fps, const doubl
     return 0;
 }
 
+/* EXTENSION (no reference counterpart; the checker of mxg_osc_render_tables): maxiOsc::sinebuf, C:266-274, with the voice's own
+ * 514-entry table T_v = tables + 514 v in the place of sineBuffer -- the statements of osc_sinebuf above, the table apart.  Pinned by
+ * construction: with every T_v = sineBuffer it must return mxo_osc(8, ...)'s bits (tests/test_extra_cpu.py), and those are the
+ * reference's (tests/test_oracle_golden.py). */
+int mxo_osc_tables(size_t V, size_t N, const double *freq, const double *tables, double *phase, double *outhold, double *out) {
+    for (size_t v = 0; v < V; v++) {
+        const double *T = tables + 514 * v;
+        double ph = phase[v], o = outhold[v];
+        for (size_t n = 0; n < N; n++) {
+            double remainder;
+            ph += 512. / (g_sampleRate / (freq[v] * chandiv));
+            if (ph >= 511) ph -= 512;
+            remainder = ph - floor(ph);
+            o = (double)((1 - remainder) * T[1 + (long)ph] + remainder * T[2 + (long)ph]);
+            out[n * V + v] = o;
+        }
+        phase[v] = ph;
+        outhold[v] = o;
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------
  * maxiFilter (H:289-366, C:442-500, ctor C:1517: x,y,z,c = 0; outputs[] treated as 0).
  * ------------------------------------------------------------------------------------ */

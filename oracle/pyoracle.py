@@ -34,6 +34,7 @@ _SIGS = {
                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxo_mix_stereo": (c_int, [c_size_t, c_size_t, c_void_p, c_void_p, c_void_p]),
     "mxo_time_osc": (c_double, [c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p]),
+    "mxo_osc_tables": (c_int, [c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),  # (port only: an extension)
 }
 
 
@@ -76,6 +77,24 @@ class Oracle:
                             _p(out))
         assert rc == 0
         return out, phase, hold
+
+    def osc_tables(self, freq, tables, N, phase=None, hold=None):
+        """EXTENSION (port only): sinebuf with a 514-entry table per voice, tables [V][514]."""
+        freq = np.ascontiguousarray(freq, np.float64)
+        V = freq.shape[-1]
+        tables = _f64(tables, (V, 514))
+        phase = np.zeros(V) if phase is None else _f64(phase, (V,)).copy()
+        hold = np.zeros(V) if hold is None else _f64(hold, (V,)).copy()
+        out = np.empty((N, V))
+        rc = self.L.mxo_osc_tables(V, N, _p(freq), _p(tables), _p(phase), _p(hold), _p(out))
+        assert rc == 0
+        return out, phase, hold
+
+    def sine_table(self):
+        """sineBuffer[0..513] (C:63) as the oracle holds it."""
+        self.L.mxo_sine_table.restype = ctypes.POINTER(c_double)
+        p = self.L.mxo_sine_table()
+        return np.array([p[i] for i in range(514)])
 
     # -- maxiFilter -----------------------------------------------------------------------
     def filter(self, kind, x, cutoff, res=None, state=None, cps=False, rps=False):

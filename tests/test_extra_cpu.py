@@ -232,3 +232,24 @@ def test_extra2_golden_sampler(port, golden, sustain):
     for k, nm in enumerate(["mix", "outputs", "position", "trigger", "outhold", "dst", "ist"]):
         assert_bits_equal(np.asarray(a[k], np.float64), np.asarray(g["smp_%s_a%d" % (nm, sustain)], np.float64), nm + " a")
         assert_bits_equal(np.asarray(b[k], np.float64), np.asarray(g["smp_%s_b%d" % (nm, sustain)], np.float64), nm + " b")
+
+
+def test_osc_tables_extension_is_sinebuf_when_every_table_is_sinebuffer(port):
+    """The checker of the per-voice wavetable EXTENSION (mxo_osc_tables; no reference counterpart) restates C:266-274 with the voice's
+    own table: with every table = sineBuffer it must give mxo_osc(sinebuf)'s bits -- which tests/test_oracle_golden.py pins to the
+    reference -- over carried blocks, wraps at 511 and phases in (-1, 0) included."""
+    rng = np.random.default_rng(77)
+    V, N = 300, 700
+    freq = rng.uniform(20, 20000, V)
+    T = port.sine_table()
+    assert T.shape == (514,) and abs(T[128] - 1.0) < 1e-4
+    tabs = np.tile(T, (V, 1))
+    o1, ph1, hd1 = port.osc_tables(freq, tabs, N)
+    o2, ph2, hd2 = port.osc_tables(freq, tabs, N, phase=ph1, hold=hd1)
+    e, eph, ehd = port.osc(8, freq, 2 * N)
+    assert np.array_equal(np.concatenate([o1, o2]).view(np.uint64), e.view(np.uint64))
+    assert np.array_equal(ph2.view(np.uint64), eph.view(np.uint64)) and np.array_equal(hd2.view(np.uint64), ehd.view(np.uint64))
+    # and with tables of its own a voice follows ITS table: a constant table gives the constant
+    tabs2 = np.tile(np.arange(V, dtype=np.float64)[:, None], (1, 514))
+    o3, _, _ = port.osc_tables(freq, tabs2, 5)
+    assert np.array_equal(o3, np.tile(np.arange(V, dtype=np.float64), (5, 1)))

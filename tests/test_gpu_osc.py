@@ -129,34 +129,6 @@ def test_store_streams_do_not_change_results(mx, port, vpl, store, block, xcd, V
         L.mxg_tune(b"osc_xcd", prev[3])
 
 
-@pytest.mark.parametrize("persist,store", [(2, 4), (3, 1), (4, 3), (2, 2), (3, 5)])
-@pytest.mark.parametrize("V,N", [(4096 + 2, 301), (512, 2), (70000, 64), (4097, 33), (98304, 48), (64, 1000)])
-def test_persistent_grid_same_bits(mx, port, persist, store, V, N):
-    """K1 on a persistent grid (knob osc_persist: k wavefronts per SIMD, the block of voice columns x samples cut into equal shares:
-    tail piece, whole columns, head piece per wavefront; pieces that start inside a column skip to their first sample; the piece
-    that ends a column stores the state after the others have signalled): the oracle's bits for the samples and the carried state,
-    whatever the shares look like -- many pieces per column (small banks), many columns per wavefront, ragged last columns, odd
-    banks (8-byte stores), every store flavour."""
-    L = mx.lib()
-    prev = [L.mxg_tune(b"osc_persist", persist), L.mxg_tune(b"osc_store", store)]
-    try:
-        rng = np.random.default_rng(V * 3 + N)
-        freq = rng.uniform(20, 20000, V)
-        for wf in ((8, 9, 2, 0, 6) if V < 50000 else (8,)):
-            p1 = rng.uniform(0.1, 0.9, V)
-            out, ph, hd = _render(mx, wf, freq, N, blocks=3, p1=p1 if wf == 6 else None)
-            eo, eph, ehd = port.osc(wf, freq, 3 * N, p1=p1 if wf == 6 else None)
-            if wf == 0:
-                assert ulp_diff(out, eo).max() <= TRIG_MAX_ULP
-            else:
-                assert_bits_equal(out, eo, OSC[wf])
-            assert_bits_equal(ph, eph, "phase")
-            if wf == 6:
-                assert_bits_equal(hd, ehd, "output member")
-    finally:
-        L.mxg_tune(b"osc_persist", prev[0]); L.mxg_tune(b"osc_store", prev[1])
-
-
 @pytest.mark.parametrize("vpl,store,passes,V,N", [(1, 4, 2, 4096 + 2, 301), (2, 3, 3, 70000, 33), (1, 2, 5, 4097, 64), (1, 4, 64, 512, 8),
                                                     (2, 3, 2, 131072, 16), (1, 4, 3, 98304, 16)])
 def test_passes_same_bits(mx, port, vpl, store, passes, V, N):
@@ -177,6 +149,24 @@ def test_passes_same_bits(mx, port, vpl, store, passes, V, N):
             assert_bits_equal(ph, eph, "phase")
     finally:
         L.mxg_tune(b"osc_vpl", prev[0]); L.mxg_tune(b"osc_store", prev[1]); L.mxg_tune(b"osc_passes", prev[2])
+
+
+@pytest.mark.parametrize("wf,V,N", [(8, 2 * 98304 + 4098, 256), (3, 98304 + 65536 + 2, 300), (8, 131072, 352), (10, 3 * 98304, 176)])
+def test_large_bank_launch_plan_same_bits(mx, port, wf, V, N):
+    """Banks beyond ~350 MB per block are rendered as a PLAN of launches (osc.hip: passes of 98 304 voices on a grid of three wavefronts
+    per CU, then the remainder in the shape that suits its size): two carried blocks, every 499th voice and the voices around every
+    boundary of the plan against the oracle, the carried phase of all of them."""
+    rng = np.random.default_rng(V)
+    freq = rng.uniform(20, 20000, V)
+    bank = mx.maxiOscBank(V)
+    o1 = bank.render(wf, freq, N).numpy()
+    o2 = bank.render(wf, freq, N).numpy()
+    edges = [k * 98304 + d for k in range(1, V // 98304 + 1) for d in (-2, -1, 0, 1) if 0 <= k * 98304 + d < V]
+    sel = np.unique(np.concatenate([np.arange(0, V, 499), edges, [V - 2, V - 1]]).astype(np.int64))
+    eo, eph, ehd = port.osc(wf, freq[sel], 2 * N)
+    assert_bits_equal(np.concatenate([o1[:, sel], o2[:, sel]]), eo, OSC[wf])
+    assert_bits_equal(bank.phase.numpy()[sel], eph, "phase")
+    assert_bits_equal(bank.output.numpy()[sel], ehd, "output member")
 
 
 def test_empty_and_invalid(mx):

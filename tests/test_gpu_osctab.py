@@ -1,0 +1,68 @@
+"""GPU (-m gpu): the per-voice wavetable EXTENSION (mxg_osc_render_tables, csrc/osctab.hip; SURVEY 8(d) row 2's optional HBM-read
+variant -- the reference has one shared sineBuffer, C:63).  Parity: (a) every table = sineBuffer  =>  the bits of the shared-table
+sinebuf, i.e. the reference's; (b) arbitrary tables against the port's restatement of C:266-274 with a table argument
+(oracle/maxi_oracle.c mxo_osc_tables, itself pinned by (a) on the CPU); the fused mixdown within the mix tolerance."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal, mix_tol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("V,N", [(1000, 512), (64, 512), (4099, 300), (16, 37), (17, 16), (5000, 256), (40000, 512)])
+def test_tables_bank_with_the_shared_table_is_sinebuf(mx, port, V, N):
+    rng = np.random.default_rng(V + N)
+    freq = rng.uniform(20, 20000, V)
+    tabs = np.tile(port.sine_table(), (V, 1))
+    bank = mx.maxiOscBank(V)
+    ref = mx.maxiOscBank(V)
+    d_tabs = mx.DeviceBuffer.from_numpy(tabs)
+    for blk in range(2):
+        got, _ = bank.sinebuf_tables(freq, d_tabs, N)
+        exp = ref.sinebuf(freq, N)
+        assert_bits_equal(got.numpy(), exp.numpy(), "block %d" % blk)
+    assert_bits_equal(bank.phase.numpy(), ref.phase.numpy(), "phase")
+    assert_bits_equal(bank.output.numpy(), ref.output.numpy(), "output member")
+
+
+@pytest.mark.parametrize("V,N", [(1000, 512), (300, 100), (4099, 333), (33, 512)])
+def test_tables_bank_against_the_oracle(mx, port, V, N):
+    rng = np.random.default_rng(3 * V + N)
+    freq = rng.uniform(20, 20000, V)
+    pan = rng.uniform(-0.1, 1.1, V)
+    tabs = rng.uniform(-1, 1, (V, 514))
+    bank = mx.maxiOscBank(V)
+    d_tabs = mx.DeviceBuffer.from_numpy(tabs)
+    o1, m1 = bank.sinebuf_tables(freq, d_tabs, N, pan=pan)
+    o2, m2 = bank.sinebuf_tables(freq, d_tabs, N, pan=pan)
+    eo, eph, ehd = port.osc_tables(freq, tabs, 2 * N)
+    assert_bits_equal(np.concatenate([o1.numpy(), o2.numpy()]), eo, "per-voice tables")
+    assert_bits_equal(bank.phase.numpy(), eph, "phase")
+    assert_bits_equal(bank.output.numpy(), ehd, "output member")
+    em = port.mix_stereo(eo, pan)
+    m = np.concatenate([m1.numpy(), m2.numpy()])
+    assert np.abs(m - em).max() <= mix_tol(V, np.abs(eo).max())
+    # mix only (no per-voice block: the measured form): the same mix bits, the same carried state
+    bank2 = mx.maxiOscBank(V)
+    none, m3 = bank2.sinebuf_tables(freq, d_tabs, N, pan=pan, store=False)
+    assert none is None
+    assert_bits_equal(m3.numpy(), m1.numpy(), "mix-only form")
+    none, m4 = bank2.sinebuf_tables(freq, d_tabs, N, pan=pan, store=False)
+    assert_bits_equal(m4.numpy(), m2.numpy(), "mix-only form, second block")
+    assert_bits_equal(bank2.phase.numpy(), eph, "phase, mix-only form")
+
+
+def test_tables_invalid(mx):
+    L = mx.lib()
+    V = 32
+    bank = mx.maxiOscBank(V)
+    f = mx.DeviceBuffer.from_numpy(np.full(V, 100.0))
+    t = mx.DeviceBuffer((V, 514))
+    out = mx.DeviceBuffer((600, V))
+    assert L.mxg_osc_render_tables(V, 600, f.ptr, t.ptr, bank.phase.ptr, bank.output.ptr, out.ptr, None, None, None) == -1   # N > 512
+    assert b"512" in L.mxg_last_error()
+    assert L.mxg_osc_render_tables(V, 16, f.ptr, t.ptr, bank.phase.ptr, bank.output.ptr, None, None, None, None) == -1     # nothing to produce
+    assert L.mxg_osc_render_tables(V, 16, f.ptr, None, bank.phase.ptr, bank.output.ptr, out.ptr, None, None, None) == -1
+    assert L.mxg_osc_render_tables(0, 16, f.ptr, t.ptr, bank.phase.ptr, bank.output.ptr, out.ptr, None, None, None) == 0
+    assert L.mxg_osc_tables_groups(1) == 1 and L.mxg_osc_tables_groups(1 << 20) == 256
