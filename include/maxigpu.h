@@ -129,7 +129,7 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "voice_block", "voice_nt" (as osc_nt), "mix_rows" (sample rows per workgroup of the mixdown, 1|2), "fft_generic",
  * "mfcc_tiled" (LDS-staged spectra 0|1), "grain_chunked" (time-sharded granular render 0|1), "grain_lanes_k",
  * "grain_unit" (coalesced unit-increment render 0|1), "grain_line" (tile render for arbitrary increments 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_slices" (time slices of a unit-path
- * maxiTimeStretch call whose scheduling and rendering overlap, 1..16), "osc_mix_win" (K1m: samples per workgroup combine window, 0 automatic, 128 or 256),
+ * maxiTimeStretch call whose scheduling and rendering overlap, 1..16), "osc_mix_win" (K1m: samples per workgroup combine window, 0 automatic, 128 or 256), "osc_mix_pc" (K1m as producer / consumer wavefront pairs: 0 automatic, 1 off, 2 on),
  * "rw_store" (the read + write bank kernels' 16-byte pair-row streams: 0 automatic, 1 off, 2 / 3 / 4 on with plain / write-through /
  * non-temporal stores), "fft_exact" (1 default; 0 = TOLERANCE MODE of mxg_fft_mfcc_batch: the 512-point transform as true radix-8 butterflies with correctly
  * rounded twiddles and fused multiply-adds, hardware square root -- about a quarter fewer instructions; magnitudes within 6e-7 x the
@@ -139,6 +139,7 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * coefficients -- maxiBiquad, maxiSVF, maxiDCBlocker through mxg_filter2_render, lores / hires through mxg_filter_render -- and blocks
  * of 64 * {1..32} samples be cut along time and joined by a wavefront scan: a 6-voice x 512-sample block in a few microseconds
  * instead of 23-28, with reordered arithmetic: |error| <= 1e-10 x the block's peak (measured <= 5e-12); default 0 = the bit-exact kernels),
+ * "osc_plan" (K1, banks beyond ~350 MB per block: rendered as passes of 98 304 voices + a remainder launch; 0 automatic, 1 never, 2 / 3 always),
  * "osc_passes" / "osc_mix_passes" (K1 / K1m: voice groups a wavefront renders one after the other, the grid covering 1 / passes of the bank: 0 automatic, 1..64),
  * "osc_split" (time parts per voice group in K1: 0 automatic, 1..8), "osc_mix_split" (the same for the fused render + mixdown K1m,
  * 0 automatic, 1..4), "osc_mix_store" (K1m's per-voice block: 0 automatic, 1 plain 8-byte stores, 2 pair rows of 16-byte stores),

@@ -464,6 +464,188 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
     }  // passes (time parts are launched with one pass only)
 }
 
+// ---- K1m, producer / consumer form (round 4) ----------------------------------------------------------------------------
+// One wavefront per SIMD cannot hide anything from itself: in K1 the wavefront spends more than half of its time waiting for the
+// store path to take its next store (the kernel is HBM-bound: that IS the roofline), and every instruction the voice sum adds to
+// that wavefront is time on top (K1 41 us, the fused kernel above 50 us, its arithmetic alone 39 us: profiles/r04_k1m_sq.md).  Here
+// the two jobs run on DIFFERENT wavefronts of the same SIMD: a workgroup is four PRODUCERS (K1's instruction stream -- tick, pair-row
+// store -- plus one ds_write_b64 per sample into a tile) and four CONSUMERS (the transposed tile read, 16 + 16 multiply-adds per
+// lane, the fold: the arithmetic of the fused kernel's second half), consumer w + 4 serving producer w.  The consumer's instructions
+// issue while its producer waits for the store path, so the block costs what K1 costs plus the tile writes.
+// Hand-off: per pair a ring of kPcRing tiles in LDS and two counters, `prod` (chunks written) and `cons` (chunks read), single
+// writer each.  The LDS executes a wavefront's operations in order, so the counter store that follows the tile writes is seen after
+// them, and the counter store that follows the tile READS is performed after them; the polls are relaxed workgroup-scope loads with
+// an s_sleep between them.  No barrier inside a window; the two barriers per window (combine of the four consumer rows) are shared
+// by all eight wavefronts.  The sums, their order and therefore the rows' bits are the fused kernel's.
+constexpr int kPcRing = 2;
+__device__ __forceinline__ int lds_flag_load(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <int WF, int STORE, int WIN>
+__global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, const double *__restrict__ freq,
+                                                        const double *__restrict__ p1, const double *__restrict__ p2,
+                                                        double *__restrict__ phase_io, double *__restrict__ hold_io,
+                                                        double *__restrict__ out, const double *__restrict__ pan,
+                                                        double *__restrict__ partial, double sr, int passes) {
+    constexpr int kTab = tab_len<WF>();
+    constexpr int kTabPad = (kTab + 1) & ~1;
+    __shared__ __attribute__((aligned(16))) double s_all[kTabPad + 4 * kPcRing * kTileWave + 4 * WIN * 2 + 256 + 8];
+    double *s_tab = s_all;
+    load_tab<WF>(s_tab);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool producer = wave < 4;
+    const int pw = wave & 3;  // the pair
+    double *ring = s_all + kTabPad + pw * (kPcRing * kTileWave);
+    double *s_part = s_all + kTabPad + 4 * kPcRing * kTileWave;  // [4 pairs][WIN][2]
+    double *my_part = s_part + pw * (WIN * 2);
+    double *s_dump = s_part + 4 * WIN * 2;                       // [256]
+    int *flags = reinterpret_cast<int *>(s_dump + 256);          // [4 pairs][2]: prod, cons
+    int *f_prod = flags + 2 * pw, *f_cons = flags + 2 * pw + 1;
+    const int ts = lane & 15, tq = lane >> 4;
+    for (int pass = 0; pass < passes; pass++) {
+        const size_t wg = (size_t)pass * gridDim.x + blockIdx.x;
+        if (wg * 256 >= V) break;
+        if (pass) __syncthreads();
+        if (threadIdx.x < 8) flags[threadIdx.x] = 0;
+        const size_t vraw = wg * 256 + (size_t)pw * 64 + lane;
+        const bool live = vraw < V;
+        const size_t v = live ? vraw : (STORE == 2 ? V - 2 + (vraw & 1) : V - 1);
+        if (producer) {
+            double x = pan[v];
+            if (x > 1) x = 1;  // C:504
+            if (x < 0) x = 0;  // C:505
+            ring[lane] = live ? sqrt(1.0 - x) : 0.0;  // two[0] = input*sqrt(1.0-x)   C:506
+            ring[64 + lane] = live ? sqrt(x) : 0.0;   // two[1] = input*sqrt(x)       C:507
+        }
+        __syncthreads();  // (the table, the gains, the counters)
+        double gl[16], gr[16];
+        if (!producer) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                gl[j] = ring[16 * tq + j];
+                gr[j] = ring[64 + 16 * tq + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) asm volatile("" : "+v"(gl[j]), "+v"(gr[j]));
+        }
+        __syncthreads();  // every consumer has its gains: the ring is free
+        if (producer) {
+            double ph = phase_io[v], hd = hold_io[v];
+            OscPre q = osc_pre<WF>(freq[v], sr, p1 ? p1[v] : 0.0, p2 ? p2[v] : 0.0);
+            asm volatile("" : "+v"(ph), "+v"(hd));
+            asm volatile("" : "+v"(q.inc), "+v"(q.k), "+v"(q.p1), "+v"(q.p2));
+            double *o = out + v;
+            double *op = out + (size_t)(threadIdx.x & 1) * V + (v & ~(size_t)1);
+            int k = 0;
+            for (size_t n0 = 0; n0 < N; n0 += WIN) {
+                const int span = (int)((N - n0) < (size_t)WIN ? (N - n0) : (size_t)WIN);
+                for (int c0 = 0; c0 < span; c0 += kMixChunk, k++) {
+                    const int cnt = (span - c0) < kMixChunk ? (span - c0) : kMixChunk;
+                    double *tw = ring + (k % kPcRing) * kTileWave + tq * kTileQuarter + ts;
+                    if (k >= kPcRing)  // the consumer must be done with the tile this chunk overwrites (it normally is, long since)
+                        while (lds_flag_load(f_cons) < k - kPcRing + 1) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                    if (cnt == kMixChunk && STORE == 2) {
+#pragma unroll
+                        for (int i = 0; i < kMixChunk; i += 2) {
+                            const double r0 = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+                            const double r1 = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+                            store_pair_rows<2>(op, r0, r1);
+                            op += 2 * V;
+                            tw[i * kTileRow] = r0;
+                            tw[(i + 1) * kTileRow] = r1;
+                        }
+                        o += (size_t)kMixChunk * V;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < kMixChunk; i++) {
+                            double r = 0.0;
+                            if (i < cnt) {  // ragged last chunk: the state must not advance past N
+                                r = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+                                if constexpr (STORE != 0) {
+                                    *o = r;
+                                    o += V;
+                                }
+                            }
+                            tw[i * kTileRow] = r;
+                        }
+                        if constexpr (STORE == 2) op += (size_t)kMixChunk * V;
+                    }
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    lds_flag_store(f_prod, k + 1);  // (behind the tile writes in the LDS queue)
+                }
+                __syncthreads();
+                double *prow = partial + wg * N * 2 + n0 * 2;
+                for (int i = threadIdx.x; i < span * 2; i += blockDim.x)
+                    prow[i] = ((s_part[i] + s_part[WIN * 2 + i]) + s_part[2 * WIN * 2 + i]) + s_part[3 * WIN * 2 + i];
+                __syncthreads();
+            }
+            phase_io[v] = ph;
+            hold_io[v] = hd;
+        } else {
+            int k = 0;
+            for (size_t n0 = 0; n0 < N; n0 += WIN) {
+                const int span = (int)((N - n0) < (size_t)WIN ? (N - n0) : (size_t)WIN);
+                for (int c0 = 0; c0 < span; c0 += kMixChunk, k++) {
+                    const int cnt = (span - c0) < kMixChunk ? (span - c0) : kMixChunk;
+                    while (lds_flag_load(f_prod) <= k) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                    const double2v *tr =
+                        reinterpret_cast<const double2v *>(ring + (k % kPcRing) * kTileWave + tq * kTileQuarter + ts * kTileRow);
+                    double2v xv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) xv[j] = tr[j];
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    lds_flag_store(f_cons, k + 1);  // (behind the tile reads in the LDS queue)
+                    double pl[8], pr[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        pl[j] = xv[j].x * gl[2 * j] + xv[j].y * gl[2 * j + 1];
+                        pr[j] = xv[j].x * gr[2 * j] + xv[j].y * gr[2 * j + 1];
+                    }
+                    const double sl = ((pl[0] + pl[1]) + (pl[2] + pl[3])) + ((pl[4] + pl[5]) + (pl[6] + pl[7]));
+                    const double sr2 = ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]));
+                    double t = fold32(sl, sr2);
+                    t = fold16(t, t);
+                    double *dst = ((lane & 16) == 0 && ts < cnt) ? my_part + (c0 + ts) * 2 + (lane >> 5) : s_dump + (threadIdx.x & 255);
+                    *dst = t;
+                }
+                __syncthreads();
+                double *prow = partial + wg * N * 2 + n0 * 2;
+                for (int i = threadIdx.x; i < span * 2; i += blockDim.x)
+                    prow[i] = ((s_part[i] + s_part[WIN * 2 + i]) + s_part[2 * WIN * 2 + i]) + s_part[3 * WIN * 2 + i];
+                __syncthreads();
+            }
+        }
+    }
+}
+
+typedef void (*osc_mixpc_fn)(size_t, size_t, const double *, const double *, const double *, double *, double *, double *,
+                             const double *, double *, double, int);
+template <int WF>
+osc_mixpc_fn pick_mixpc(int store) {
+    return store == 2 ? osc_mixpc_kernel<WF, 2, 256> : (store == 1 ? osc_mixpc_kernel<WF, 1, 256> : osc_mixpc_kernel<WF, 0, 256>);
+}
+osc_mixpc_fn pick_mixpc_wf(int wf, int store) {
+    switch (wf) {
+        case 0: return pick_mixpc<0>(store);
+        case 1: return pick_mixpc<1>(store);
+        case 2: return pick_mixpc<2>(store);
+        case 3: return pick_mixpc<3>(store);
+        case 4: return pick_mixpc<4>(store);
+        case 5: return pick_mixpc<5>(store);
+        case 6: return pick_mixpc<6>(store);
+        case 7: return pick_mixpc<7>(store);
+        case 8: return pick_mixpc<8>(store);
+        case 9: return pick_mixpc<9>(store);
+        case 10: return pick_mixpc<10>(store);
+        case 11: return pick_mixpc<11>(store);
+    }
+    return nullptr;
+}
+
 typedef void (*osc_mix_fn)(size_t, size_t, const double *, const double *, const double *, double *, double *,
                            double *, const double *, double *, double, PartSync, int);
 // store: 0 none, 1 plain, 2 pair rows (sc1); win: samples per workgroup combine (128 where three workgroups must share a CU)
@@ -654,7 +836,12 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     int vpl = tune_get("osc_vpl"), store = tune_get("osc_store") - 1, xcd = tune_get("osc_xcd") - 1;  // (knob value 0 = automatic)
     const bool automatic = vpl == 0 && store < 0;
     const bool heavy = waveform == MXG_OSC_SINEWAVE || waveform == MXG_OSC_COSWAVE || waveform == MXG_OSC_SINEBUF4;
-    if (automatic && pairs_ok && !heavy && xcd < 0 && tune_get("osc_passes") == 0 && tune_get("osc_split") == 0 &&
+    // (Row pitches that are multiples of 2 MB -- 262 144 voices and its multiples -- take the passes badly: 524 288 voices 0.56, 1 048 576
+    // 0.64 against 0.68-0.71 for one launch over the whole bank; 262 144 itself wants the XCD-contiguous numbering, 0.80 against 0.73.
+    // profiles/r04_osc_grid.md.)
+    int plan = tune_get("osc_plan");  // 0 automatic, 1 never, 2 / 3 always (main launch with natural / XCD-contiguous numbering)
+    if (plan == 0) plan = (V % 262144) ? 2 : (V == 262144 ? 3 : 1);
+    if (automatic && pairs_ok && !heavy && xcd < 0 && tune_get("osc_passes") == 0 && tune_get("osc_split") == 0 && plan != 1 &&
         V * N * sizeof(double) >= ((size_t)352 << 20)) {
         // ---- large banks of the store-bound waveforms: a plan of launches (round 4, profiles/r04_osc_grid.md) ----------------------------
         // What streams best is a grid of exactly THREE wavefronts per CU, two voices per lane, every wavefront walking down the same
@@ -672,7 +859,7 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
         }
         if (k > 0) {
             OscLaunch A = L0;
-            A.v_begin = 0; A.v_end = k * kPass; A.vpl = 2; A.store = 2; A.xcd = 0; A.split = 1; A.passes = (int)k; A.block = 256;
+            A.v_begin = 0; A.v_end = k * kPass; A.vpl = 2; A.store = 2; A.xcd = plan == 3 ? 1 : 0; A.split = 1; A.passes = (int)k; A.block = 256;
             if (int s2 = osc_launch(A)) return s2;
         }
         if (rest > 0) {
@@ -742,6 +929,14 @@ int osc_mix_launch(int waveform, size_t V, size_t N, const double *d_freq, const
     if (split > 1) passes = 1;
     if ((size_t)passes > nblocks) passes = (int)nblocks;
     const size_t grid_x = (nblocks + passes - 1) / passes;
+    // the producer / consumer form (knob osc_mix_pc: 0 automatic, 1 off, 2 on): whole blocks (no time parts)
+    const int pc = tune_get("osc_mix_pc");
+    if (split == 1 && (pc == 2 || (pc == 0 && nblocks >= 128))) {
+        KernelTimer kt("osc_mix_kernel", st);
+        hipLaunchKernelGGL(pick_mixpc_wf(waveform, store), dim3((unsigned)grid_x), dim3(512), 0, st, V, N, d_freq, d_p1, d_p2, d_phase,
+                           d_outhold, d_out, d_pan, d_rows, (double)settings().sampleRate, passes);
+        return check_hip(hipGetLastError(), "osc_mixpc_kernel launch");
+    }
     KernelTimer kt("osc_mix_kernel", st);
     hipLaunchKernelGGL(fn, dim3((unsigned)grid_x, (unsigned)split), dim3(block), 0, st, V, N, d_freq, d_p1, d_p2, d_phase,
                        d_outhold, d_out, d_pan, d_rows, (double)settings().sampleRate, psync, passes);

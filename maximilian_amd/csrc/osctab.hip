@@ -22,6 +22,7 @@
 // running sum of ITS sample over all rounds in registers; the per-workgroup rows [workgroup][N][2] are added by mix_partials_kernel.
 #include "mxg_common.h"
 #include "mxg_lanefold.h"
+#include "mxg_osc.h"
 
 namespace mxg {
 namespace {
@@ -32,20 +33,28 @@ constexpr int kTabVoices = 16;       // voices per round
 constexpr int kTabRound = kTabVoices * kTabLen;  // doubles per LDS buffer (65 792 B)
 
 // pass 1: the phase of every voice at the start of each time part, and after the block
-__global__ void osctab_marks_kernel(size_t V, size_t N, size_t PL, const double *__restrict__ freq, double *__restrict__ phase_io,
+template <int PL>
+__global__ void osctab_marks_kernel(size_t V, size_t N, const double *__restrict__ freq, double *__restrict__ phase_io,
                                     double *__restrict__ marks, double sr) {
     const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
     double ph = phase_io[v];
     const double inc = 512. / (sr / (freq[v] * kChandiv));  // C:269
-    size_t n = 0;
+    const int whole = (int)(N / PL);  // parts that lie inside the block completely
+#pragma unroll 1
     for (int t = 0; t < kTabParts; t++) {
         marks[(size_t)t * V + v] = ph;
-        const size_t end = (size_t)(t + 1) * PL < N ? (size_t)(t + 1) * PL : N;
-#pragma unroll 4
-        for (; n < end; n++) {
-            ph += inc;
-            if (ph >= 511) ph -= 512;  // C:270
+        if (t < whole) {
+#pragma unroll
+            for (int k = 0; k < PL; k++) {
+                ph += inc;
+                if (ph >= 511) ph -= 512;  // C:270
+            }
+        } else {
+            for (size_t n = (size_t)t * PL; n < N; n++) {
+                ph += inc;
+                if (ph >= 511) ph -= 512;
+            }
         }
     }
     phase_io[v] = ph;
@@ -68,6 +77,9 @@ __device__ __forceinline__ void tables_issue(const double *__restrict__ tables, 
     }
 }
 
+// One lane = (voice u of the round, time part t).  The per-voice values of round g + 1 (mark, frequency, pan) are requested while
+// round g is rendered; inside a round the table reads of a whole 16-sample chunk are in flight at once and the second chunk's drain
+// under the first chunk's fold (osc_pipe_*, mxg_osc.h: at one wavefront per SIMD nothing else hides an LDS or a memory latency).
 template <int CH, bool STORE, bool MIX>
 __global__ __launch_bounds__(256) void osctab_kernel(size_t V, size_t N, const double *__restrict__ freq,
                                                      const double *__restrict__ tables, const double *__restrict__ marks,
@@ -84,50 +96,87 @@ __global__ __launch_bounds__(256) void osctab_kernel(size_t V, size_t N, const d
     double acc[CH][2];
 #pragma unroll
     for (int c = 0; c < CH; c++) acc[c][0] = acc[c][1] = 0.0;
+    // the sample N - 1 (the member `output` after the block) belongs to part t_last, chunk c_last, position i_last
+    const int t_last = (int)((N - 1) / PL), c_last = (int)(((N - 1) % PL) / kMixChunk), i_last = (int)((N - 1) % kMixChunk);
+    auto voice_of = [&](size_t g) {  // a surplus lane shadows the bank's last voice (a table that IS in the buffer), gain 0
+        const size_t vraw = g * kTabVoices + u;
+        return vraw < V ? vraw : V - 1;
+    };
+    double n_mark = 0.0, n_freq = 1.0, n_pan = 0.0;
     if (g0 < g1) {
         tables_issue(tables, g0, V, s_tab);
+        const size_t v = voice_of(g0);
+        n_mark = marks[(size_t)t * V + v];
+        n_freq = freq[v];
+        if constexpr (MIX) n_pan = pan[v];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     for (size_t g = g0; g < g1; g++) {
         const int b = (int)((g - g0) & 1);
-        if (g + 1 < g1) tables_issue(tables, g + 1, V, s_tab + (b ^ 1) * kTabRound);
+        double ph = n_mark;
+        const double inc = 512. / (sr / (n_freq * kChandiv));  // C:269
+        double x = n_pan;
+        if (g + 1 < g1) {
+            tables_issue(tables, g + 1, V, s_tab + (b ^ 1) * kTabRound);
+            const size_t vn = voice_of(g + 1);
+            n_mark = marks[(size_t)t * V + vn];
+            n_freq = freq[vn];
+            if constexpr (MIX) n_pan = pan[vn];
+        }
         const size_t first = g * kTabVoices;
-        const size_t vraw = first + u;
-        const bool live = vraw < V;
-        const size_t v = live ? vraw : V - 1;  // a surplus lane shadows the bank's last voice (a table that IS in the buffer), gain 0
-        const double *T = s_tab + b * kTabRound + (v - first) * kTabLen;
-        double ph = marks[(size_t)t * V + v];
-        const double inc = 512. / (sr / (freq[v] * kChandiv));
+        const bool live = first + u < V;
+        const size_t v = voice_of(g);
+        const double *T = s_tab + b * kTabRound + (v - first) * kTabLen - 1;  // T[i + 1] == table[i]: the layout osc_pipe_* index
         double gl = 0.0, gr = 0.0;
         if constexpr (MIX) {
-            double x = pan[v];
             if (x > 1) x = 1;  // C:504
             if (x < 0) x = 0;  // C:505
             gl = live ? sqrt(1.0 - x) : 0.0;  // two[0] = input*sqrt(1.0-x)   C:506
             gr = live ? sqrt(x) : 0.0;        // two[1] = input*sqrt(x)       C:507
         }
+        OscPre q;
+        q.inc = inc; q.k = 0.0; q.p1 = 0.0; q.p2 = 0.0;
+        double hd = 0.0;
+        OscPipe<kMixChunk> P[CH];
+        osc_pipe_phase<MXG_OSC_SINEBUF, kMixChunk>(ph, q, P[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        osc_pipe_fetch<MXG_OSC_SINEBUF, kMixChunk>(P[0], T);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (CH == 2) {
+            osc_pipe_phase<MXG_OSC_SINEBUF, kMixChunk>(ph, q, P[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int c = 0; c < CH; c++) {
-            double L[kMixChunk], R[kMixChunk];
-            const size_t nb = (size_t)t * PL + (size_t)c * kMixChunk;
-#pragma unroll
-            for (int i = 0; i < kMixChunk; i++) {
-                ph += inc;                                // C:269
-                if (ph >= 511) ph -= 512;                 // C:270
-                const double rem = ph - floor(ph);        // C:271
-                const int idx = (int)ph;                  // (long)phase: truncation toward zero
-                double r = (1 - rem) * T[1 + idx] + rem * T[2 + idx];  // C:272
-                const size_t n = nb + i;
-                if (n >= N) r = 0.0;
-                if (live && n < N) {
-                    if constexpr (STORE) out[n * V + v] = r;
-                    if (n + 1 == N) hold_io[v] = r;
-                }
-                L[i] = r * gl;
-                R[i] = r * gr;
+            double r[kMixChunk];
+            osc_pipe_finish<MXG_OSC_SINEBUF, kMixChunk>(P[c], r, hd);
+            __builtin_amdgcn_sched_barrier(0);
+            if (CH == 2 && c == 0) {
+                osc_pipe_fetch<MXG_OSC_SINEBUF, kMixChunk>(P[1], T);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (MIX) {
+            const size_t nb = (size_t)t * PL + (size_t)c * kMixChunk;
+            if constexpr (STORE) {
+                if (live) {
+#pragma unroll
+                    for (int i = 0; i < kMixChunk; i++)
+                        if (nb + i < N) out[(nb + i) * V + v] = r[i];
+                }
+            }
+            if (t == t_last && c == c_last && live) {  // (one row of lanes per round)
+                double h = r[0];
+#pragma unroll
+                for (int i = 1; i < kMixChunk; i++) h = i == i_last ? r[i] : h;
+                hold_io[v] = h;
+            }
+            if constexpr (MIX) {  // (samples at or beyond N are summed too and never written out)
+                double L[kMixChunk], R[kMixChunk];
+#pragma unroll
+                for (int i = 0; i < kMixChunk; i++) {
+                    L[i] = r[i] * gl;
+                    R[i] = r[i] * gr;
+                }
                 acc[c][0] += fold_chunk<double>(L, lane);
                 acc[c][1] += fold_chunk<double>(R, lane);
             }
@@ -185,8 +234,12 @@ extern "C" int mxg_osc_render_tables(size_t V, size_t N, const double *d_freq, c
     if (int s = scratch_get(SCR_OSCTAB_MARKS, st, sizeof(double) * kTabParts * V, (void **)&marks)) return s;
     {
         KernelTimer kt("osctab_marks_kernel", st);
-        hipLaunchKernelGGL(osctab_marks_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, N, (size_t)(ch * kMixChunk), d_freq,
-                           d_phase, marks, (double)settings().sampleRate);
+        if (ch == 1)
+            hipLaunchKernelGGL(osctab_marks_kernel<16>, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, N, d_freq, d_phase, marks,
+                               (double)settings().sampleRate);
+        else
+            hipLaunchKernelGGL(osctab_marks_kernel<32>, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, N, d_freq, d_phase, marks,
+                               (double)settings().sampleRate);
     }
     const size_t grid = mxg_osc_tables_groups(V);
     KernelTimer kt("osctab_kernel", st);

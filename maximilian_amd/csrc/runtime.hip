@@ -39,11 +39,13 @@ Tune g_tune[] = {
     {"voice_xcd", 0, 0, 2},    // 0 automatic, 1 natural workgroup order, 2 XCD-contiguous
     {"osc_store", 0, 0, 5},  // K1 store stream (osc.hip pick<WF>): 0 automatic; one voice per lane: 1 plain 8 B, 2 nt 8 B, 3 / 4 / 5 pair rows (16 B) plain / sc1 / nt; two voices per lane: 1 plain, 2 nt, 3 sc1
     {"osc_xcd", 0, 0, 2},  // K1: 1 = every XCD renders one contiguous eighth of the bank (workgroup renumbering, mxg_common.h)
+    {"osc_plan", 0, 0, 3},  // K1, large banks: the plan of launches (98 304-voice passes + a remainder launch): 0 automatic, 1 never, 2 / 3 always (natural / XCD-contiguous numbering)
     {"osc_passes", 0, 0, 64},  // K1: voice groups a wavefront renders one after the other (0 automatic; the grid covers 1 / passes of the bank)
     {"osc_mix_passes", 0, 0, 64},  // K1m: the same for the fused render + mixdown
     {"osc_split", 0, 0, 8},  // K1: time parts per voice group (0 = automatic: 2 for sinewave / coswave / sinebuf4 below 131 072 voices; up to 8 for the table oscillators on banks smaller than the machine; else 1)
     {"osc_mix_store", 0, 0, 2},  // K1m per-voice block: 0 automatic, 1 plain 8-byte stores, 2 pair rows of write-through 16-byte stores
     {"osc_mix_split", 0, 0, 4},  // K1m time parts (0 automatic: two below 2048 wavefronts)
+    {"osc_mix_pc", 0, 0, 2},  // K1m: producer / consumer wavefront pairs (0 automatic: from 32 768 voices, whole blocks only; 1 off; 2 on)
     {"osc_mix_win", 0, 0, 256},  // K1m: samples per workgroup combine window (0 automatic: 256, 128 from 131 073 voices; 128 / 256)
     {"ifft_stream", 1, 0, 2},  // maxiIFFT: transform + hop buffer in one kernel (0: never; 1: where hop >= fftSize / 2; 2: wherever it fits)
     {"smp_pipe", 1, 0, 1},   // K5: the time-part kernel's loads of chunk k+1 issued before the stores of chunk k (0: chunk after chunk)
