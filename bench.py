@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--waveform", default="sinebuf")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"],
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5", "tables"],
                     help="BASELINE.json config to run; the default (config2) is the one the headline metric is quoted on")
     ap.add_argument("--mixdown", default=None, choices=["fused", "separate", "off"],
                     help="stereo mixdown + cross-GPU reduce in the step (default: on whenever --gpus > 1 -- fused into the "
@@ -141,7 +141,7 @@ def main():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
         env.setdefault("OMP_NUM_THREADS", "1")
         os.execvpe(cmd[0], cmd, env)
-    defaults = {"config2": (2000, 100), "config3": (1280, 128), "config4": (20, 3), "config5": (20, 3)}
+    defaults = {"config2": (2000, 100), "config3": (1280, 128), "config4": (20, 3), "config5": (20, 3), "tables": (200, 20)}
     if args.steps is None:
         args.steps = defaults[args.workload][0]
     if args.warmup is None:
@@ -200,7 +200,7 @@ def main():
     # a single GPU renders the bank without it unless asked (--mixdown fused|separate).  config 5 is DEFINED with the
     # stereo mixdown (BASELINE configs[4]), so it always mixes.
     mixdown = args.mixdown or {"config2": "fused" if world > 1 else "off", "config3": "separate" if world > 1 else "off",
-                               "config4": "off", "config5": "fused"}[args.workload]
+                               "config4": "off", "config5": "fused", "tables": "off"}[args.workload]
 
     class OscBank:
         """One rank's maxiOsc bank of `Vb` voices with its block buffers; step() renders one block (K1, or K1m / K1 + K3 with
@@ -286,6 +286,29 @@ def main():
                               "rotated over %d block buffer(s) = %.2f GB touched before a line is rewritten"
                               % (V, args.waveform, {"fused": " + fused maxiMix::stereo mixdown", "separate": " + K3 mixdown",
                                                     "off": ""}[mixdown], nbuf, nbuf * V * B * 8 / 1e9))
+        elif workload == "tables":
+            # EXTENSION (north_star's "HBM-read roofline on the wavetable path"): every voice its own 514-entry table,
+            # 131 072 voices (>= 10^5), the fused maxiMix::stereo mixdown as output -- the READ stream is the bound
+            Vt = 131072
+            ft = torch.from_numpy(bank_parameters(0, Vt, Vt)[0]).to(dev)
+            pt = torch.from_numpy(bank_parameters(0, Vt, Vt)[1]).to(dev)
+            one = torch.sin(2 * np.pi * torch.arange(514, dtype=torch.float64, device=dev) / 512.0)
+            tabs = (one[None, :] * (1.0 + 1e-3 * torch.arange(Vt, dtype=torch.float64, device=dev)[:, None] / Vt)).contiguous()  # 539 MB
+            pht = torch.zeros(Vt, dtype=torch.float64, device=dev)
+            hdt = torch.zeros(Vt, dtype=torch.float64, device=dev)
+            Gt = L.mxg_osc_tables_groups(Vt)
+            rowst = torch.zeros((Gt, B, 2), dtype=torch.float64, device=dev)
+            mixt = torch.zeros((B, 2), dtype=torch.float64, device=dev)
+
+            def step_tables():
+                chk(L.mxg_osc_render_tables(Vt, B, ft.data_ptr(), tabs.data_ptr(), pht.data_ptr(), hdt.data_ptr(), None, pt.data_ptr(),
+                                            rowst.data_ptr(), stream), "mxg_osc_render_tables")
+                chk(L.mxg_mix_rows_sum(Gt, B * 2, rowst.data_ptr(), mixt.data_ptr(), stream), "mxg_mix_rows_sum")
+            W = dict(step=step_tables, samples=Vt * B, dominant="osctab_kernel", algo_bytes=Vt * (514 * 8.0 + 24.0), dtype="f64", cpu=None,
+                     local_step=None,
+                     workload="EXTENSION of configs[1] (not in the reference, which has one shared sineBuffer): %d-voice maxiOsc::sinebuf bank "
+                              "with a 514-entry table PER VOICE (4112 B read per voice and block, 8.03 B per sample), block=512, fused "
+                              "maxiMix::stereo mixdown as output (no per-voice store): the HBM-READ form of the wavetable path" % Vt)
         elif workload == "config3":
             K = 128
             mode = voice_mode
@@ -634,6 +657,7 @@ def main():
             and not args.no_configs):
         for name, (wl, md, meth, st_, wm_) in {
                 "config2_mixdown": ("config2", "fused", "sparse", 400, 50),  # the N > 1 step on one GPU: K1m + grouped mix queue, no communicator
+                "config2_tables": ("tables", "off", "sparse", 100, 20),  # the per-voice wavetable extension: the HBM-read roofline
                 "config3": ("config3", "off", "sparse", 256, 64),
                 "config4": ("config4", "off", "sparse", 10, 2),
                 "config4_mfma": ("config4", "off", "mfma", 6, 2),
@@ -732,7 +756,7 @@ def main():
         if configs:
             res["configs"] = configs
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = W["cpu"]()
+            res["cpu_baseline"] = W["cpu"]() if W.get("cpu") else None
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

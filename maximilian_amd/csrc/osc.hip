@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
 // them, and the counter store that follows the tile READS is performed after them; the polls are relaxed workgroup-scope loads with
 // an s_sleep between them.  No barrier inside a window; the two barriers per window (combine of the four consumer rows) are shared
 // by all eight wavefronts.  The sums, their order and therefore the rows' bits are the fused kernel's.
-constexpr int kPcRing = 2;
+constexpr int kPcRing = 3;
 __device__ __forceinline__ int lds_flag_load(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
@@ -537,13 +537,17 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
             double *o = out + v;
             double *op = out + (size_t)(threadIdx.x & 1) * V + (v & ~(size_t)1);
             int k = 0;
+            int seen = 0;  // `cons` as last read: requested at the start of a chunk, looked at one chunk later (no wait on the way)
+            __builtin_amdgcn_s_setprio(2);  // the store-bound stream is the critical one: the consumer takes the issue slots it leaves
             for (size_t n0 = 0; n0 < N; n0 += WIN) {
                 const int span = (int)((N - n0) < (size_t)WIN ? (N - n0) : (size_t)WIN);
                 for (int c0 = 0; c0 < span; c0 += kMixChunk, k++) {
                     const int cnt = (span - c0) < kMixChunk ? (span - c0) : kMixChunk;
                     double *tw = ring + (k % kPcRing) * kTileWave + tq * kTileQuarter + ts;
-                    if (k >= kPcRing)  // the consumer must be done with the tile this chunk overwrites (it normally is, long since)
-                        while (lds_flag_load(f_cons) < k - kPcRing + 1) __builtin_amdgcn_s_sleep(1);
+                    // the consumer must be done with the tile this chunk overwrites: it normally was a chunk ago (`seen`)
+                    if (seen < k - kPcRing + 1)
+                        while ((seen = lds_flag_load(f_cons)) < k - kPcRing + 1) __builtin_amdgcn_s_sleep(1);
+                    const int seen_next = lds_flag_load(f_cons);
                     asm volatile("" ::: "memory");
                     if (cnt == kMixChunk && STORE == 2) {
 #pragma unroll
@@ -552,8 +556,10 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
                             const double r1 = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
                             store_pair_rows<2>(op, r0, r1);
                             op += 2 * V;
+#ifndef MXG_PC_NOTILE  // (A/B: the producer without its tile writes)
                             tw[i * kTileRow] = r0;
                             tw[(i + 1) * kTileRow] = r1;
+#endif
                         }
                         o += (size_t)kMixChunk * V;
                     } else {
@@ -574,6 +580,7 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
                     asm volatile("" ::: "memory");
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     lds_flag_store(f_prod, k + 1);  // (behind the tile writes in the LDS queue)
+                    seen = seen_next;
                 }
                 __syncthreads();
                 double *prow = partial + wg * N * 2 + n0 * 2;
@@ -581,6 +588,7 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
                     prow[i] = ((s_part[i] + s_part[WIN * 2 + i]) + s_part[2 * WIN * 2 + i]) + s_part[3 * WIN * 2 + i];
                 __syncthreads();
             }
+            __builtin_amdgcn_s_setprio(0);
             phase_io[v] = ph;
             hold_io[v] = hd;
         } else {
@@ -589,11 +597,15 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
                 const int span = (int)((N - n0) < (size_t)WIN ? (N - n0) : (size_t)WIN);
                 for (int c0 = 0; c0 < span; c0 += kMixChunk, k++) {
                     const int cnt = (span - c0) < kMixChunk ? (span - c0) : kMixChunk;
-                    while (lds_flag_load(f_prod) <= k) __builtin_amdgcn_s_sleep(1);
+                    while (lds_flag_load(f_prod) <= k) __builtin_amdgcn_s_sleep(4);
                     asm volatile("" ::: "memory");
                     const double2v *tr =
                         reinterpret_cast<const double2v *>(ring + (k % kPcRing) * kTileWave + tq * kTileQuarter + ts * kTileRow);
                     double2v xv[8];
+#ifdef MXG_PC_NOCONSUME  // (A/B: the consumer only keeps the counters moving)
+                    lds_flag_store(f_cons, k + 1);
+                    continue;
+#endif
 #pragma unroll
                     for (int j = 0; j < 8; j++) xv[j] = tr[j];
                     asm volatile("" ::: "memory");

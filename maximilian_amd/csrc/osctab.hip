@@ -28,30 +28,43 @@ namespace mxg {
 namespace {
 
 constexpr int kTabLen = 514;         // doubles per voice (sineBuffer[514], C:63)
-constexpr int kTabParts = 16;        // lanes per voice = time parts per block
-constexpr int kTabVoices = 16;       // voices per round
-constexpr int kTabRound = kTabVoices * kTabLen;  // doubles per LDS buffer (65 792 B)
+constexpr int kTabParts = 16;        // time parts per block (32 samples each), one mark per part and voice
+constexpr int kTabVoices = 8;        // voices per round
+constexpr int kTabHdr = kTabParts * kTabVoices + 3 * kTabVoices;  // per-round header: marks[16][8], inc[8], gl[8], gr[8] (152 doubles)
+constexpr int kTabRound = kTabVoices * kTabLen + kTabHdr;         // doubles per LDS buffer: 4112 + 152 = 4264 (34 112 B)
+constexpr int kTabRing = 4;          // LDS buffers: one in use, three rounds of DMA in flight
+static_assert(kTabRound * 8 == 8 * 4096 + 84 * 16, "a round is 8 full 4 KiB pieces + 84 sixteen-byte pieces");
 
-// pass 1: the phase of every voice at the start of each time part, and after the block
-template <int PL>
-__global__ void osctab_marks_kernel(size_t V, size_t N, const double *__restrict__ freq, double *__restrict__ phase_io,
-                                    double *__restrict__ marks, double sr) {
+// pass 1 (lanes = voices): the recurrence without its output -- the same additions in the same order, the same bits -- leaving per
+// group of 8 voices ONE contiguous header: the phase at the start of each 32-sample part, the increment, the two gains.  The main
+// kernel fetches it with the group's tables, by DMA: no ordinary load in its loop (hipcc waits vmcnt(0) at the use of one while
+// LDS-DMA pieces are in flight, which would drain the ring every round).
+__global__ void osctab_marks_kernel(size_t V, size_t N, const double *__restrict__ freq, const double *__restrict__ pan,
+                                    double *__restrict__ phase_io, double *__restrict__ hdr, double sr) {
     const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
+    double *h = hdr + (v / kTabVoices) * kTabHdr;
+    const int u = (int)(v % kTabVoices);
     double ph = phase_io[v];
     const double inc = 512. / (sr / (freq[v] * kChandiv));  // C:269
-    const int whole = (int)(N / PL);  // parts that lie inside the block completely
+    h[kTabParts * kTabVoices + u] = inc;
+    double x = pan ? pan[v] : 0.0;
+    if (x > 1) x = 1;  // C:504
+    if (x < 0) x = 0;  // C:505
+    h[kTabParts * kTabVoices + kTabVoices + u] = sqrt(1.0 - x);  // two[0] = input*sqrt(1.0-x)   C:506
+    h[kTabParts * kTabVoices + 2 * kTabVoices + u] = sqrt(x);    // two[1] = input*sqrt(x)       C:507
+    const int whole = (int)(N / 32);  // parts that lie inside the block completely
 #pragma unroll 1
     for (int t = 0; t < kTabParts; t++) {
-        marks[(size_t)t * V + v] = ph;
+        h[t * kTabVoices + u] = ph;
         if (t < whole) {
 #pragma unroll
-            for (int k = 0; k < PL; k++) {
+            for (int k = 0; k < 32; k++) {
                 ph += inc;
                 if (ph >= 511) ph -= 512;  // C:270
             }
         } else {
-            for (size_t n = (size_t)t * PL; n < N; n++) {
+            for (size_t n = (size_t)t * 32; n < N; n++) {
                 ph += inc;
                 if (ph >= 511) ph -= 512;
             }
@@ -60,151 +73,151 @@ __global__ void osctab_marks_kernel(size_t V, size_t N, const double *__restrict
     phase_io[v] = ph;
 }
 
-// the tables of voice group g -> one LDS buffer (16 x 4112 B, or less for the bank's last group): 16-byte pieces, lane-linear
-__device__ __forceinline__ void tables_issue(const double *__restrict__ tables, size_t g, size_t V, double *buf) {
+// 8 lanes (one sample group of 8 voices) -> per lane the sum over the 8 voices of ONE of 8 samples: the last three levels of
+// mxg_lanefold.h's transposing butterfly (row_half_mirror, quad xor 2, quad xor 1)
+template <typename T>
+__device__ __forceinline__ T fold8(const T (&v)[8], int lane) {
+    T l2[4], l3[2];
+#pragma unroll
+    for (int j = 0; j < 4; j++) l2[j] = fold_dpp<kDppRowHalfMirror, 0xA>(v[2 * j], v[2 * j + 1]);
+#pragma unroll
+    for (int j = 0; j < 2; j++) l3[j] = fold_quad<kDppQuadXor2>(l2[2 * j], l2[2 * j + 1], (lane & 2) != 0);
+    return fold_quad<kDppQuadXor1>(l3[0], l3[1], (lane & 1) != 0);
+}
+
+// round g (its 8 tables + its header) -> one LDS buffer, 16-byte pieces, lane-linear, by all 512 threads: 4 pieces per lane + a fifth
+// for threads 0..83 (the last 128 B of the tables and the 1216 B of the header)
+__device__ __forceinline__ void round_issue(const double *__restrict__ tables, const double *__restrict__ hdr, size_t g, size_t V,
+                                            double *buf) {
     const size_t first = g * kTabVoices;
     const size_t nv = V - first < (size_t)kTabVoices ? V - first : (size_t)kTabVoices;
-    const unsigned bytes = (unsigned)(nv * kTabLen * sizeof(double));
+    const unsigned tbytes = (unsigned)(nv * kTabLen * sizeof(double));  // (the bank's last group may be short)
     const char *src = reinterpret_cast<const char *>(tables + first * kTabLen);
+    const char *hsrc = reinterpret_cast<const char *>(hdr + g * kTabHdr);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     char *dst = reinterpret_cast<char *>(buf) + wave * 1024;
 #pragma unroll
-    for (int i = 0; i <= 16; i++) {  // 17 x 4 KiB >= 65 792 B
-        const unsigned off = (unsigned)(i * 256 + (int)threadIdx.x) * 16u;
-        if (off < bytes)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
-                                             (__attribute__((address_space(3))) void *)(dst + i * 4096), 16, 0, 0);
+    for (int i = 0; i < 4; i++) {
+        unsigned off = (unsigned)(i * 512 + (int)threadIdx.x) * 16u;
+        if (off >= tbytes) off = 0;  // (a short last group: re-read its first bytes)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                         (__attribute__((address_space(3))) void *)(dst + i * 8192), 16, 0, 0);
+    }
+    if (threadIdx.x < 84) {  // bytes [32768, 34112) of the buffer
+        const unsigned off = 32768u + threadIdx.x * 16u;
+        const char *p = off < 8u * kTabLen * 8u ? (off < tbytes ? src + off : src) : hsrc + (off - 8u * kTabLen * 8u);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                         (__attribute__((address_space(3))) void *)(dst + 4 * 8192), 16, 0, 0);
     }
 }
 
-// One lane = (voice u of the round, time part t).  The per-voice values of round g + 1 (mark, frequency, pan) are requested while
-// round g is rendered; inside a round the table reads of a whole 16-sample chunk are in flight at once and the second chunk's drain
-// under the first chunk's fold (osc_pipe_*, mxg_osc.h: at one wavefront per SIMD nothing else hides an LDS or a memory latency).
-template <int CH, bool STORE, bool MIX>
-__global__ __launch_bounds__(256) void osctab_kernel(size_t V, size_t N, const double *__restrict__ freq,
-                                                     const double *__restrict__ tables, const double *__restrict__ marks,
-                                                     double *__restrict__ hold_io, double *__restrict__ out,
-                                                     const double *__restrict__ pan, double *__restrict__ rows, double sr) {
-    __shared__ __attribute__((aligned(16))) double s_tab[2 * kTabRound];
+// One lane = (voice u of the round, time part t, half h): 16 samples [32 t + 16 h, 32 t + 16 h + 16) of voice u; the second half first
+// advances the recurrence over the first half's 16 samples.  256 lanes = 8 voices x 16 parts x 2 halves = one round; the workgroup's
+// 512 lanes render TWO rounds side by side (lanes 0-255 the even rounds of its range, lanes 256-511 the odd ones): two wavefronts per
+// SIMD, so that one round's LDS latencies and bank conflicts hide behind the other's arithmetic.  Inside a round the table reads of all
+// 16 samples are in flight at once (osc_pipe_*, mxg_osc.h).  Ring of four buffers: two rounds in use, the next two arriving by DMA.
+template <bool STORE, bool MIX>
+__global__ __launch_bounds__(512) void osctab_kernel(size_t V, size_t N, const double *__restrict__ tables,
+                                                     const double *__restrict__ hdr, double *__restrict__ hold_io,
+                                                     double *__restrict__ out, double *__restrict__ rows) {
+    __shared__ __attribute__((aligned(16))) double s_buf[kTabRing * kTabRound];
     const int lane = threadIdx.x & 63;
-    const int u = threadIdx.x & 15, t = threadIdx.x >> 4;
-    constexpr int PL = CH * kMixChunk;
+    const int side = threadIdx.x >> 8, tid8 = threadIdx.x & 255;
+    const int u = tid8 & 7, h = (tid8 >> 3) & 1, t = tid8 >> 4;
     const size_t groups = (V + kTabVoices - 1) / kTabVoices;
     const size_t per = (groups + gridDim.x - 1) / gridDim.x;
     const size_t g0 = (size_t)blockIdx.x * per;
     const size_t g1 = g0 + per < groups ? g0 + per : groups;
-    double acc[CH][2];
+    // the mixdown: every lane keeps the running sums of ITS 16 samples over the voices it meets (voice u of every other round of this
+    // workgroup) -- two multiply-adds per sample and round, nothing crosses lanes inside the loop; the lanes of a sample group are
+    // folded once, after the last round
+    double accL[kMixChunk], accR[kMixChunk];
 #pragma unroll
-    for (int c = 0; c < CH; c++) acc[c][0] = acc[c][1] = 0.0;
-    // the sample N - 1 (the member `output` after the block) belongs to part t_last, chunk c_last, position i_last
-    const int t_last = (int)((N - 1) / PL), c_last = (int)(((N - 1) % PL) / kMixChunk), i_last = (int)((N - 1) % kMixChunk);
-    auto voice_of = [&](size_t g) {  // a surplus lane shadows the bank's last voice (a table that IS in the buffer), gain 0
-        const size_t vraw = g * kTabVoices + u;
-        return vraw < V ? vraw : V - 1;
-    };
-    double n_mark = 0.0, n_freq = 1.0, n_pan = 0.0;
-    if (g0 < g1) {
-        tables_issue(tables, g0, V, s_tab);
-        const size_t v = voice_of(g0);
-        n_mark = marks[(size_t)t * V + v];
-        n_freq = freq[v];
-        if constexpr (MIX) n_pan = pan[v];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    for (size_t g = g0; g < g1; g++) {
-        const int b = (int)((g - g0) & 1);
-        double ph = n_mark;
-        const double inc = 512. / (sr / (n_freq * kChandiv));  // C:269
-        double x = n_pan;
-        if (g + 1 < g1) {
-            tables_issue(tables, g + 1, V, s_tab + (b ^ 1) * kTabRound);
-            const size_t vn = voice_of(g + 1);
-            n_mark = marks[(size_t)t * V + vn];
-            n_freq = freq[vn];
-            if constexpr (MIX) n_pan = pan[vn];
-        }
+    for (int i = 0; i < kMixChunk; i++) accL[i] = accR[i] = 0.0;
+    const size_t nb = (size_t)t * 32 + (size_t)h * 16;  // this lane's first sample
+    const bool has_last = N - 1 >= nb && N - 1 < nb + 16;
+    const int i_last = (int)((N - 1) & 15);
+    for (int k = 0; k < 2; k++)
+        if (g0 + k < g1) round_issue(tables, hdr, g0 + k, V, s_buf + k * kTabRound);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (size_t gp = g0; gp < g1; gp += 2) {  // the pair of rounds (gp, gp + 1)
+        const int b0 = (int)((gp - g0) % kTabRing);
+        __builtin_amdgcn_s_barrier();  // everybody's pieces of this pair have landed; everybody is done with the previous pair's buffers ...
+        asm volatile("" ::: "memory");
+        for (int k = 0; k < 2; k++)    // ... which the next pair may now overwrite
+            if (gp + 2 + k < g1) round_issue(tables, hdr, gp + 2 + k, V, s_buf + ((b0 + 2 + k) % kTabRing) * kTabRound);
+        const size_t g = gp + side;
+        if (g < g1) {
+        const int b = (b0 + side) % kTabRing;
+        const double *B = s_buf + b * kTabRound;
+        const double *H = B + kTabVoices * kTabLen;
         const size_t first = g * kTabVoices;
         const bool live = first + u < V;
-        const size_t v = voice_of(g);
-        const double *T = s_tab + b * kTabRound + (v - first) * kTabLen - 1;  // T[i + 1] == table[i]: the layout osc_pipe_* index
+        const int uu = live ? u : 0;  // a surplus lane shadows the group's first voice (a table that IS in the buffer), gain 0
+        const double *T = B + uu * kTabLen - 1;  // T[i + 1] == table[i]: the layout osc_pipe_* index
+        double ph = H[t * kTabVoices + uu];
+        OscPre q;
+        q.inc = H[kTabParts * kTabVoices + uu]; q.k = 0.0; q.p1 = 0.0; q.p2 = 0.0;
         double gl = 0.0, gr = 0.0;
         if constexpr (MIX) {
-            if (x > 1) x = 1;  // C:504
-            if (x < 0) x = 0;  // C:505
-            gl = live ? sqrt(1.0 - x) : 0.0;  // two[0] = input*sqrt(1.0-x)   C:506
-            gr = live ? sqrt(x) : 0.0;        // two[1] = input*sqrt(x)       C:507
+            gl = live ? H[kTabParts * kTabVoices + kTabVoices + uu] : 0.0;
+            gr = live ? H[kTabParts * kTabVoices + 2 * kTabVoices + uu] : 0.0;
         }
-        OscPre q;
-        q.inc = inc; q.k = 0.0; q.p1 = 0.0; q.p2 = 0.0;
-        double hd = 0.0;
-        OscPipe<kMixChunk> P[CH];
-        osc_pipe_phase<MXG_OSC_SINEBUF, kMixChunk>(ph, q, P[0]);
+        if (h) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                ph += q.inc;
+                if (ph >= 511) ph -= 512;
+            }
+        }
+        double hd = 0.0, r[kMixChunk];
+        OscPipe<kMixChunk> P;
+        osc_pipe_phase<MXG_OSC_SINEBUF, kMixChunk>(ph, q, P);
         __builtin_amdgcn_sched_barrier(0);
-        osc_pipe_fetch<MXG_OSC_SINEBUF, kMixChunk>(P[0], T);
+        osc_pipe_fetch<MXG_OSC_SINEBUF, kMixChunk>(P, T);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (CH == 2) {
-            osc_pipe_phase<MXG_OSC_SINEBUF, kMixChunk>(ph, q, P[1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        osc_pipe_finish<MXG_OSC_SINEBUF, kMixChunk>(P, r, hd);
+        if constexpr (STORE) {
+            if (live) {
 #pragma unroll
-        for (int c = 0; c < CH; c++) {
-            double r[kMixChunk];
-            osc_pipe_finish<MXG_OSC_SINEBUF, kMixChunk>(P[c], r, hd);
-            __builtin_amdgcn_sched_barrier(0);
-            if (CH == 2 && c == 0) {
-                osc_pipe_fetch<MXG_OSC_SINEBUF, kMixChunk>(P[1], T);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const size_t nb = (size_t)t * PL + (size_t)c * kMixChunk;
-            if constexpr (STORE) {
-                if (live) {
-#pragma unroll
-                    for (int i = 0; i < kMixChunk; i++)
-                        if (nb + i < N) out[(nb + i) * V + v] = r[i];
-                }
-            }
-            if (t == t_last && c == c_last && live) {  // (one row of lanes per round)
-                double h = r[0];
-#pragma unroll
-                for (int i = 1; i < kMixChunk; i++) h = i == i_last ? r[i] : h;
-                hold_io[v] = h;
-            }
-            if constexpr (MIX) {  // (samples at or beyond N are summed too and never written out)
-                double L[kMixChunk], R[kMixChunk];
-#pragma unroll
-                for (int i = 0; i < kMixChunk; i++) {
-                    L[i] = r[i] * gl;
-                    R[i] = r[i] * gr;
-                }
-                acc[c][0] += fold_chunk<double>(L, lane);
-                acc[c][1] += fold_chunk<double>(R, lane);
+                for (int i = 0; i < kMixChunk; i++)
+                    if (nb + i < N) out[(nb + i) * V + first + u] = r[i];
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next round have landed ...
-        __syncthreads();                                   // ... and everybody's; and everybody is done with this round's buffer
+        if (has_last && live) {  // the member `output` after the block: sample N - 1
+            double hv = r[0];
+#pragma unroll
+            for (int i = 1; i < kMixChunk; i++) hv = i == i_last ? r[i] : hv;
+            hold_io[first + u] = hv;
+        }
+        if constexpr (MIX) {  // (samples at or beyond N are summed too and never written out)
+#pragma unroll
+            for (int i = 0; i < kMixChunk; i++) {
+                accL[i] += r[i] * gl;
+                accR[i] += r[i] * gr;
+            }
+        }
+        }  // (g < g1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's pieces of the next pair have landed
     }
     if constexpr (MIX) {
-        int idx[kMixChunk];
+        int idx[8];
 #pragma unroll
-        for (int i = 0; i < kMixChunk; i++) idx[i] = i;
-        const int slot = fold_chunk<int>(idx, lane);  // which sample of a chunk this lane's sums belong to
+        for (int i = 0; i < 8; i++) idx[i] = i;
+        const int slot = fold8<int>(idx, lane);  // which of 8 samples this lane's sums belong to
 #pragma unroll
-        for (int c = 0; c < CH; c++) {
-            const size_t n = (size_t)t * PL + (size_t)c * kMixChunk + slot;
-            if (slot >= 0 && n < N) {
-                double2v pr = {acc[c][0], acc[c][1]};
-                *reinterpret_cast<double2v *>(rows + ((size_t)blockIdx.x * N + n) * 2) = pr;
+        for (int j = 0; j < 2; j++) {
+            double L[8], R[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                L[i] = accL[8 * j + i];
+                R[i] = accR[8 * j + i];
             }
+            const double2v pr = {fold8<double>(L, lane), fold8<double>(R, lane)};
+            const size_t n = nb + 8 * j + slot;
+            if (slot >= 0 && n < N) *reinterpret_cast<double2v *>(rows + (((size_t)blockIdx.x * 2 + side) * N + n) * 2) = pr;
         }
     }
-}
-
-typedef void (*osctab_fn)(size_t, size_t, const double *, const double *, const double *, double *, double *, const double *, double *,
-                          double);
-osctab_fn pick_tab(int ch, bool store, bool mix) {
-    if (ch == 1) return store ? (mix ? osctab_kernel<1, true, true> : osctab_kernel<1, true, false>) : osctab_kernel<1, false, true>;
-    return store ? (mix ? osctab_kernel<2, true, true> : osctab_kernel<2, true, false>) : osctab_kernel<2, false, true>;
 }
 
 }  // namespace
@@ -212,11 +225,14 @@ osctab_fn pick_tab(int ch, bool store, bool mix) {
 
 using namespace mxg;
 
+static size_t tables_grid(size_t V) {  // persistent: one workgroup per CU, two rounds at a time each
+    const size_t pairs = ((V + kTabVoices - 1) / kTabVoices + 1) / 2;
+    const size_t cus = (size_t)device_cus();
+    return pairs < cus ? pairs : cus;
+}
 extern "C" size_t mxg_osc_tables_groups(size_t V) {
     if (ensure_init_only()) return 0;
-    const size_t groups = (V + kTabVoices - 1) / kTabVoices;
-    const size_t cus = (size_t)device_cus();
-    return groups < cus ? groups : cus;
+    return 2 * tables_grid(V);  // a partial mix row per workgroup and side
 }
 
 extern "C" int mxg_osc_render_tables(size_t V, size_t N, const double *d_freq, const double *d_tables, double *d_phase,
@@ -225,25 +241,25 @@ extern "C" int mxg_osc_render_tables(size_t V, size_t N, const double *d_freq, c
     MXG_REQUIRE(d_freq && d_tables && d_phase && d_outhold, "null device pointer");
     MXG_REQUIRE(d_out || d_pan, "nothing to produce: give d_out (the per-voice block), d_pan + d_rows (the mixdown), or both");
     MXG_REQUIRE(!d_pan || d_rows, "the mixdown needs d_rows");
-    MXG_REQUIRE(N <= (size_t)kTabParts * 2 * kMixChunk, "blocks of at most 512 samples (16 lanes per voice x 32 samples)");
+    MXG_REQUIRE(N <= (size_t)kTabParts * 32, "blocks of at most 512 samples (16 time parts of 32 samples per voice)");
     MXG_REQUIRE(!(((uintptr_t)d_tables) & 15), "d_tables must be 16-byte aligned");
     if (V == 0 || N == 0) return MXG_OK;
     hipStream_t st = resolve_stream(stream);
-    const int ch = N <= (size_t)kTabParts * kMixChunk ? 1 : 2;
-    double *marks = nullptr;  // [16][V] per-stream scratch
-    if (int s = scratch_get(SCR_OSCTAB_MARKS, st, sizeof(double) * kTabParts * V, (void **)&marks)) return s;
+    const size_t groups = (V + kTabVoices - 1) / kTabVoices;
+    double *hdr = nullptr;  // [groups][152] per-stream scratch: marks, increments, gains
+    if (int s = scratch_get(SCR_OSCTAB_MARKS, st, sizeof(double) * kTabHdr * groups, (void **)&hdr)) return s;
     {
         KernelTimer kt("osctab_marks_kernel", st);
-        if (ch == 1)
-            hipLaunchKernelGGL(osctab_marks_kernel<16>, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, N, d_freq, d_phase, marks,
-                               (double)settings().sampleRate);
-        else
-            hipLaunchKernelGGL(osctab_marks_kernel<32>, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, N, d_freq, d_phase, marks,
-                               (double)settings().sampleRate);
+        hipLaunchKernelGGL(osctab_marks_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, N, d_freq, d_pan, d_phase, hdr,
+                           (double)settings().sampleRate);
     }
-    const size_t grid = mxg_osc_tables_groups(V);
+    const size_t grid = tables_grid(V);
     KernelTimer kt("osctab_kernel", st);
-    hipLaunchKernelGGL(pick_tab(ch, d_out != nullptr, d_pan != nullptr), dim3((unsigned)grid), dim3(256), 0, st, V, N, d_freq, d_tables,
-                       marks, d_outhold, d_out, d_pan, d_rows, (double)settings().sampleRate);
+    if (d_out && d_pan)
+        hipLaunchKernelGGL((osctab_kernel<true, true>), dim3((unsigned)grid), dim3(512), 0, st, V, N, d_tables, hdr, d_outhold, d_out, d_rows);
+    else if (d_out)
+        hipLaunchKernelGGL((osctab_kernel<true, false>), dim3((unsigned)grid), dim3(512), 0, st, V, N, d_tables, hdr, d_outhold, d_out, d_rows);
+    else
+        hipLaunchKernelGGL((osctab_kernel<false, true>), dim3((unsigned)grid), dim3(512), 0, st, V, N, d_tables, hdr, d_outhold, d_out, d_rows);
     return check_hip(hipGetLastError(), "osctab_kernel launch");
 }

@@ -150,6 +150,77 @@ __global__ void __launch_bounds__(256) filter_kernel(size_t V, size_t N, const d
     st[4 * V + v] = f.o2;
 }
 
+// The block-constant forms with 16-BYTE read and write streams (round 4; the scheme of filter2_pairs_kernel, round 3): a lane still
+// owns one voice, but the input of two samples arrives as one 16-byte load per lane (two voices of one row) and leaves as one 16-byte
+// store, the lanes of a pair swapping one value each way (pair_rows_swap / store_pair_rows, mxg_common.h).  V even, N even, both
+// blocks 16-byte aligned; the same recurrences in the same order: the same bits.
+template <int KIND, int ST>
+__global__ void __launch_bounds__(256) filter_pairs_kernel(size_t V, size_t N, const double *__restrict__ in,
+                                                           const double *__restrict__ cutoff, const double *__restrict__ coef,
+                                                           double *__restrict__ st, double *__restrict__ out) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    Flt f = {st[v], st[V + v], st[2 * V + v], st[3 * V + v], st[4 * V + v]};
+    double c = 0, r = 0, b0 = 0, b1 = 0, b2 = 0, cu = 0;
+    if constexpr (KIND <= MXG_FLT_HIRES) {
+        c = coef[v];
+        r = coef[V + v];
+    } else if constexpr (KIND == MXG_FLT_BANDPASS) {
+        b0 = coef[v];
+        b1 = coef[V + v];
+        b2 = coef[2 * V + v];
+    } else {
+        cu = cutoff[v];
+    }
+    const size_t odd = threadIdx.x & 1, vp = v & ~(size_t)1;
+    const double *ip = in + vp;
+    double *op = out + odd * V + vp;  // this lane's 16 bytes of row n + (lane & 1)
+    constexpr int U = 8;
+    double2v xn[U / 2];
+    auto row_of = [&](size_t n) { const size_t rr = n + odd; return rr < N ? rr : N - 1; };  // clamped: no branch, surplus unused
+#pragma unroll
+    for (int j = 0; j < U / 2; j++) xn[j] = *reinterpret_cast<const double2v *>(ip + row_of(2 * j) * V);
+    for (size_t n0 = 0; n0 < N; n0 += U) {
+        double xc[U];
+#pragma unroll
+        for (int j = 0; j < U / 2; j++) {
+            pair_rows_swap(xn[j], xc[2 * j], xc[2 * j + 1]);
+            xn[j] = *reinterpret_cast<const double2v *>(ip + row_of(n0 + U + 2 * j) * V);
+        }
+        double o[U];
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            const double x = xc[i];
+            if constexpr (KIND == MXG_FLT_LORES || KIND == MXG_FLT_HIRES) {
+                const double y = flt_lores(f, x, c, r);
+                o[i] = (KIND == MXG_FLT_LORES) ? y : x - y;  // C:466 / C:482
+            } else if constexpr (KIND == MXG_FLT_BANDPASS) {  // C:487-500
+                o[i] = b0 * x + b1 * f.o1 + b2 * f.o2;
+                f.o2 = f.o1;
+                f.o1 = o[i];
+            } else if constexpr (KIND == MXG_FLT_LOPASS) {  // C:442-446
+                o[i] = f.o0 + cu * (x - f.o0);
+                f.o0 = o[i];
+            } else {  // hipass C:449-453
+                o[i] = x - (f.o0 + cu * (x - f.o0));
+                f.o0 = o[i];
+            }
+            if (n0 + i + 1 == N) {  // the state after the LAST sample of the block (a ragged last chunk computes past it)
+                st[v] = f.x;
+                st[V + v] = f.y;
+                st[2 * V + v] = f.o0;
+                st[3 * V + v] = f.o1;
+                st[4 * V + v] = f.o2;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U / 2; j++) {
+            if (n0 + 2 * j < N) store_pair_rows<ST>(op, o[2 * j], o[2 * j + 1]);  // (N even: a pair is inside or outside as a whole)
+            op += 2 * V;
+        }
+    }
+}
+
 // lores / hires / bandpass with the coefficients given PER SAMPLE (coef [N][3][V]: c, r, - or inputs[0..2]), computed by the caller
 // with the host libm (mxg_filter_coeffs_host per sample): the bit-exact form of a modulated cutoff -- what the per-sample engine of
 // include/maximilian.h renders when a cutoff follows another object's output (14.monosynth's `ADSRout*10000`).  Small banks, short
@@ -547,6 +618,29 @@ int mxg_filter_render(int kind, size_t V, size_t N, const double *d_in, const do
     double sr = (double)settings().sampleRate;
     if (!mod && (kind == MXG_FLT_LORES || kind == MXG_FLT_HIRES) && scan_applies(V, N))  // tolerance mode (scan.hip)
         return scan_filter_launch(kind == MXG_FLT_LORES ? 3 : 4, V, N, d_in, d_coef, d_st, d_out, st);
+    // 16-byte pair-row streams for the block-constant forms (knob rw_store, as mxg_filter2_render: 0 automatic = write-through stores
+    // for blocks from 64 MB, 1 off, 2 / 3 / 4 plain / write-through / non-temporal stores)
+    {
+        int rw = tune_get("rw_store");
+        const bool pairs_ok = !mod && !(V & 1) && !(N & 1) && !(((uintptr_t)d_in) & 15) && !(((uintptr_t)d_out) & 15);
+        if (rw == 0) rw = (V * N * sizeof(double) >= ((size_t)64 << 20)) ? 3 : 1;
+        if (rw >= 2 && pairs_ok) {
+            KernelTimer kt("filter_kernel", st);
+#define MXG_FLP(K)                                                                                                                       \
+    if (rw == 2) hipLaunchKernelGGL((filter_pairs_kernel<K, 0>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_cutoff, d_coef, d_st, d_out); \
+    else if (rw == 3) hipLaunchKernelGGL((filter_pairs_kernel<K, 2>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_cutoff, d_coef, d_st, d_out); \
+    else hipLaunchKernelGGL((filter_pairs_kernel<K, 1>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_cutoff, d_coef, d_st, d_out);
+            switch (kind) {
+                case 0: MXG_FLP(0) break;
+                case 1: MXG_FLP(1) break;
+                case 2: MXG_FLP(2) break;
+                case 3: MXG_FLP(3) break;
+                default: MXG_FLP(4) break;
+            }
+#undef MXG_FLP
+            return check_hip(hipGetLastError(), "filter_pairs_kernel launch");
+        }
+    }
 #define MXG_FLT_LAUNCH(K)                                                                        \
     if (mod)                                                                                     \
         hipLaunchKernelGGL((filter_kernel<K, true>), grid_for(V, block), dim3(block), 0, st, V, N, \

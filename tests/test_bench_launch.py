@@ -72,7 +72,7 @@ def test_default_line_carries_every_gpu_config():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["roofline"]["kernel"] == "osc_kernel" and 0.3 < d["roofline"]["frac"] < 1.0
-    want = {"config2_mixdown": "osc_mix_kernel", "config3": "voice_kernel", "config4": "fft_mfcc_kernel",
+    want = {"config2_mixdown": "osc_mix_kernel", "config2_tables": "osctab_kernel", "config3": "voice_kernel", "config4": "fft_mfcc_kernel",
             "config4_mfma": "mfcc_mfma_gemm_kernel", "config5": "granular_unit_kernel"}
     assert set(d["configs"]) == set(want), d["configs"].keys()
     for name, kernel in want.items():
@@ -82,4 +82,4 @@ def test_default_line_carries_every_gpu_config():
         assert 0.0 < c["roofline"]["frac"] < 1.0 and c["roofline"]["kernel_ms"] <= c["ms_per_step"] * 1.001, c
         assert ("flops_per_launch" in c["roofline"]) == (name == "config4_mfma")
     # the fused-mixdown step (what every rank of an N > 1 run does per block) costs about what the plain render costs
-    assert d["configs"]["config2_mixdown"]["step_vs_headline"] < 1.25
+    assert d["configs"]["config2_mixdown"]["step_vs_headline"] < 1.22

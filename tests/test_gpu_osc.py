@@ -209,7 +209,7 @@ def test_config2_full_size_properties(mx, port):
 
 
 @pytest.mark.parametrize("wf,V,N", [(8, 300, 100), (3, 64, 16), (10, 1000, 37), (9, 4096 + 7, 512), (6, 256, 1), (8, 700, 1100),
-                                      (4, 130, 530)])
+                                      (4, 130, 530), (8, 40000, 512), (10, 33000, 48)])
 def test_render_mix_fused(mx, port, wf, V, N):
     """mxg_osc_render_mix: per-voice block bit-exact (same as the plain render), mix within the
     stated tolerance of the reference's sequential sum, store=False gives the same mix bits."""
@@ -246,6 +246,22 @@ def test_render_mix_fused(mx, port, wf, V, N):
             assert_bits_equal(bank3.phase.numpy(), eph, "phase, store %d split %d" % (store, split))
         finally:
             L.mxg_tune(b"osc_mix_store", prev[0]); L.mxg_tune(b"osc_mix_split", prev[1])
+    # the two forms of the kernel -- one wavefront does everything (osc_mix_pc 1) / producer + consumer wavefront pairs (2) -- add the
+    # same products in the same tree: the same bits for the block, the carried state and the mix
+    for pc in (1, 2):
+        prev = L.mxg_tune(b"osc_mix_pc", pc)
+        try:
+            bank6 = mx.maxiOscBank(V)
+            o6, m6 = bank6.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V))
+            assert_bits_equal(o6.numpy(), out1.numpy(), "osc_mix_pc %d" % pc)
+            assert_bits_equal(m6.numpy(), mix1.numpy(), "mix, osc_mix_pc %d" % pc)
+            o6, m6 = bank6.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V))
+            assert_bits_equal(o6.numpy(), out2.numpy(), "second block, osc_mix_pc %d" % pc)
+            assert_bits_equal(m6.numpy(), mix2.numpy(), "second mix, osc_mix_pc %d" % pc)
+            assert_bits_equal(bank6.phase.numpy(), eph, "phase, osc_mix_pc %d" % pc)
+            none, m7 = bank6.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V), store=False)
+        finally:
+            L.mxg_tune(b"osc_mix_pc", prev)
     # passes (a workgroup renders several groups of 256 voices one after the other): the same rows, the same bits
     for mp in (2, 5):
         prev = L.mxg_tune(b"osc_mix_passes", mp)

@@ -65,4 +65,4 @@ def test_tables_invalid(mx):
     assert L.mxg_osc_render_tables(V, 16, f.ptr, t.ptr, bank.phase.ptr, bank.output.ptr, None, None, None, None) == -1     # nothing to produce
     assert L.mxg_osc_render_tables(V, 16, f.ptr, None, bank.phase.ptr, bank.output.ptr, out.ptr, None, None, None) == -1
     assert L.mxg_osc_render_tables(0, 16, f.ptr, t.ptr, bank.phase.ptr, bank.output.ptr, out.ptr, None, None, None) == 0
-    assert L.mxg_osc_tables_groups(1) == 1 and L.mxg_osc_tables_groups(1 << 20) == 256
+    assert L.mxg_osc_tables_groups(1) == 2 and L.mxg_osc_tables_groups(1 << 20) == 512

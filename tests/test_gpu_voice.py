@@ -41,6 +41,29 @@ def test_filter_vs_oracle(mx, port, kind):
     assert_bits_equal(bank.state.numpy(), est, FLT[kind] + " state")
 
 
+@pytest.mark.parametrize("kind", range(5))
+@pytest.mark.parametrize("rw", [1, 2, 3, 4])
+@pytest.mark.parametrize("V,N", [(778, 600), (4096, 130), (2, 2), (1000, 7 * 8 + 6)])
+def test_filter_pair_row_streams_same_bits(mx, port, kind, rw, V, N):
+    """The block-constant maxiFilter kernels with 16-byte pair-row read and write streams (knob rw_store, csrc/voice.hip
+    filter_pairs_kernel): two carried blocks, output and state bit for bit the oracle's, ragged last chunks included."""
+    L = mx.lib()
+    rng = np.random.default_rng(kind * 7 + rw + V)
+    x = rng.uniform(-1, 1, (2 * N, V))
+    c = rng.uniform(0, 1, V) if kind >= 3 else rng.uniform(1, 30000, V)
+    r = None if kind >= 3 else (rng.uniform(0.01, 1.3, V) if kind == 2 else rng.uniform(0.2, 25, V))
+    prev = L.mxg_tune(b"rw_store", rw)
+    try:
+        bank = mx.maxiFilterBank(V)
+        o1 = bank.render(kind, mx.DeviceBuffer.from_numpy(x[:N]), c, r).numpy()
+        o2 = bank.render(kind, mx.DeviceBuffer.from_numpy(x[N:]), c, r).numpy()
+    finally:
+        L.mxg_tune(b"rw_store", prev)
+    eo, est = port.filter(kind, x, c, r)
+    assert_bits_equal(np.concatenate([o1, o2]), eo, FLT[kind] + " rw_store=%d" % rw)
+    assert_bits_equal(bank.state.numpy(), est, FLT[kind] + " state")
+
+
 def test_filter_modulated_tolerance(mx, golden):
     g = golden("filter.npz")
     V = g["x"].shape[1]
