@@ -1388,8 +1388,8 @@ class maxiSample {
     }
 
 public:
-    short myChannels = 0;
-    int mySampleRate = 44100;
+    short myChannels = 1;      // C:546: the constructor's initialiser list -- myChannels(1), mySampleRate(maxiSettings::sampleRate)
+    int mySampleRate = (int)maxiSettings::sampleRate;
     short myBitsPerSample = 0;
     string myPath;
     int myChunkSize = 0, mySubChunk1Size = 0, readChannel = 0;

@@ -74,12 +74,21 @@ def bits(a):
     return np.ascontiguousarray(a, np.float64).view(np.uint64)
 
 
-def mix_tol(units, peak=1.0):
+def mix_tol(units, peak=1.0, sums=None):
     """Absolute tolerance of a maxiMix mixdown over `units` voices/streams.  The only non-bit-exact step of the path:
     the products x*gain are the reference's bits, the sum is tree-ordered on the device and sequential in the
-    reference (src/maximilian.cpp:404-410 applied unit after unit), so the two differ by rounding of partial sums:
-    measured <= 2.2e-17 * units * peak on the GPU (r02: 65536 voices, 2048 streams); 1e-15 leaves ~50x."""
-    return 1e-15 * units * max(1.0, float(peak))
+    reference (src/maximilian.cpp:404-410 applied unit after unit), so the two differ by the rounding of partial sums.  Each of the
+    `units` additions rounds by at most eps/2 of the running sum S, the roundings add up like a random walk: ~ eps * sqrt(units) * S.
+    For voices with unrelated phases S ~ sqrt(units) * peak, which gives the linear form eps * units * peak -- measured <= 2.2e-17 *
+    units * peak on the GPU (r02: 65536 voices, 2048 streams); 1e-15 leaves ~50x.  Where the voices are COHERENT (a bank started from
+    phase 0: the first samples of all its voices have the same sign, S ~ units * peak / 2) the reference's own sequential sum is that
+    much less accurate; pass the expected sums (`sums`) and the bound scales with their magnitude:
+    1e-15 * sqrt(units) * max(|sums|, sqrt(units) * peak)."""
+    u = float(units)
+    scale = max(1.0, float(peak)) * np.sqrt(u)
+    if sums is not None:
+        scale = max(scale, float(np.abs(sums).max()))
+    return 1e-15 * np.sqrt(u) * scale
 
 
 def assert_bits_equal(a, b, what=""):

@@ -97,8 +97,8 @@ void play(double *output) {
         s3.amplitudes[10] = 0.75;      // element write
         s3.amplitudes[11] = s3.amplitudes[10] * 0.5 + s1.amplitudes[11];
     }
-    if (n >= 1000) {
-        sv += s3.playOnce() + 0.5 * s3.amplitudes[(size_t)(n % 6000)] + 0.001 * (double)s3.amplitudes.size();
+    if (n >= 1000 && n < 20000) {  // (index < 2500: inside the buffer also while it holds 3000 samples; none after clear())
+        sv += s3.playOnce() + 0.5 * s3.amplitudes[(size_t)(n % 2500)] + 0.001 * (double)s3.amplitudes.size();
     }
     if (n == 8000) {
         maxiSample sc(s2);             // copy construction: the play head travels with it

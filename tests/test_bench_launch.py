@@ -82,4 +82,5 @@ def test_default_line_carries_every_gpu_config():
         assert 0.0 < c["roofline"]["frac"] < 1.0 and c["roofline"]["kernel_ms"] <= c["ms_per_step"] * 1.001, c
         assert ("flops_per_launch" in c["roofline"]) == (name == "config4_mfma")
     # the fused-mixdown step (what every rank of an N > 1 run does per block) costs about what the plain render costs
-    assert d["configs"]["config2_mixdown"]["step_vs_headline"] < 1.22
+    # (against the headline's GPU-side step time: at the driver's 20 steps the wall-clock figure carries ~3 us of fence per step)
+    assert d["configs"]["config2_mixdown"]["ms_per_step"] < 1.2 * d["step_ms_gpu"], (d["configs"]["config2_mixdown"], d["step_ms_gpu"])
