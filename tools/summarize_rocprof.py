@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""tools/summarize_rocprof.py [tag] -- condense gpurun_out/prof_<tag>/ (tools/profile_r04.sh; rounds 2-3: profile_r02/r03.sh) into profiles/:
+  profiles/<tag>_<workload>_summary.md      per kernel: rocprofv3 kernel-trace average duration (timed launches), PMC HBM
+                                             traffic per launch, next to the un-profiled bench.py line of the same command
+  profiles/<tag>_<workload>_kernel_stats.csv the rocprofv3 --stats table, verbatim
+  profiles/pmc_traffic.json                  HBM bytes per launch by kernel label (what bench.py reports as roofline.traffic)
+Counter units as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports half the bytes of
+a wide coalesced read stream, so it is doubled (WRITE_SIZE as reported)."""
+import collections
+import csv
+import json
+import os
+import shutil
+import statistics
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+LABELS = ["osc_mixpc_kernel", "osc_mix_kernel", "osctab_marks_kernel", "osctab_kernel", "osc_kernel", "mix_partials_kernel", "voice_kernel", "fft_mfcc_kernel", "fft1024_kernel",
+          "mfcc_mfma_gemm_kernel", "mfcc_stream_tiled_kernel", "granular_unit_kernel", "granular_sched_kernel",
+          "granular_unit_state_kernel", "mix_bus_kernel", "bus_gains_kernel"]
+
+
+def label_of(name):
+    for lab in LABELS:
+        if lab + "<" in name or lab + "(" in name or name.endswith(lab) or ("::" + lab) in name:
+            return lab
+    return None
+
+
+def read(path):
+    return list(csv.DictReader(open(path))) if os.path.exists(path) else []
+
+
+traffic = {}
+for wl in sorted(d for d in os.listdir(src) if os.path.isdir(os.path.join(src, d))):
+    base = os.path.join(src, wl)
+    kt = read(os.path.join(base, "kt", "b_kernel_trace.csv"))
+    if not kt:
+        continue
+    shutil.copy(os.path.join(base, "kt", "b_kernel_stats.csv"), os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, wl)))
+    bench = {}
+    try:
+        bench = json.loads(open(os.path.join(src, wl + ".bench.json")).read().strip().splitlines()[-1])
+    except Exception:
+        pass
+    steps_traced = int(open(os.path.join(src, wl + ".kt.log")).read().split('"steps": ')[1].split(",")[0]) if os.path.exists(
+        os.path.join(src, wl + ".kt.log")) and '"steps": ' in open(os.path.join(src, wl + ".kt.log")).read() else None
+    durs = collections.OrderedDict()
+    meta = {}
+    for r in kt:
+        lab = label_of(r["Kernel_Name"])
+        if lab is None:
+            continue
+        durs.setdefault(lab, []).append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+        meta[lab] = r
+    pm = {}
+    for sub, cname, corr in (("pmc_w", "WRITE_SIZE", 1.0), ("pmc_r", "FETCH_SIZE", 2.0)):
+        acc = collections.defaultdict(list)
+        for r in read(os.path.join(base, sub, "b_counter_collection.csv")):
+            lab = label_of(r["Kernel_Name"])
+            if lab and r["Counter_Name"] == cname:
+                acc[lab].append(float(r["Counter_Value"]))
+        for lab, v in acc.items():
+            v = v[len(v) // 3:]  # drop the warm-up / ramp launches
+            pm.setdefault(lab, {})[cname] = statistics.mean(v) * 1024 * corr
+    mf = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in read(os.path.join(base, "pmc_mfma", "b_counter_collection.csv")):
+        lab = label_of(r["Kernel_Name"])
+        if lab:
+            mf[lab][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = ["# rocprofv3 summary `%s` / %s (MI355X)" % (tag, wl), "",
+           "Command: `python bench.py %s` under `rocprofv3 --kernel-trace --stats` (per-kernel averages over the timed launches, i.e. the last"
+           % " ".join(bench.get("_args", [])) if False else "Passes: `rocprofv3 --kernel-trace --stats`, `--pmc WRITE_SIZE`, `--pmc FETCH_SIZE` (separate runs, tools/profile_r04.sh); "
+           "durations are averages over the second half of each kernel's launches (clock ramp and warm-up excluded).", "",
+           "| kernel | launches | avg us (kernel-trace) | median | bench.py kernel_ms (HIP events, un-profiled) | WRITE_SIZE MB | FETCH_SIZE x2 MB | HBM traffic MB | VGPR | LDS B | grid x wg |",
+           "|---|---|---|---|---|---|---|---|---|---|---|"]
+    bk = bench.get("kernels", {})
+    for lab, v in durs.items():
+        v.sort()
+        d = [x[1] for x in v][len(v) // 2:]
+        p = pm.get(lab, {})
+        w, f = p.get("WRITE_SIZE"), p.get("FETCH_SIZE")
+        tot = (w or 0) + (f or 0) if (w is not None or f is not None) else None
+        if tot is not None:
+            base_wl = wl in ("config2", "config2_mix", "config2_tables", "config3", "config4", "config4_mfma", "config5")
+            traffic[lab if base_wl else "%s@%s" % (lab, wl)] = round(tot)  # (variants of a workload keep their own key)
+        m = meta[lab]
+        ev = bk.get(lab, {}).get("ms")
+        out.append("| `%s` | %d | %.2f | %.2f | %s | %s | %s | %s | %s | %s | %s x %s |" % (
+            lab, len(v), statistics.mean(d), statistics.median(d), ("%.2f us" % (ev * 1e3)) if ev else "-",
+            "%.1f" % (w / 1e6) if w is not None else "-", "%.1f" % (f / 1e6) if f is not None else "-",
+            "%.1f" % (tot / 1e6) if tot is not None else "-", m.get("VGPR_Count", "?"), m.get("LDS_Block_Size", "?"),
+            m.get("Grid_Size_X", "?"), m.get("Workgroup_Size_X", "?")))
+    if mf:
+        out += ["", "MFMA counters (`--pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES`, per launch).  "
+                "MFMA_MOPS_F64 counts 512-flop units (MFMA_MOPS x 512 = flops ISSUED to the matrix pipe); utilisation = those flops / kernel "
+                "time / the 78.6 TFLOP/s dense fp64 peak.  (Round 3 printed MFMA_BUSY / SQ_BUSY here: the two counters are collected per SIMD and "
+                "per shader engine respectively, their ratio means nothing -- VERDICT r03 weak #3.)", "",
+                "| kernel | MFMA_MOPS_F64 | flops issued | kernel us | MFMA TFLOP/s | of 78.6 |", "|---|---|---|---|---|---|"]
+        for lab, c in mf.items():
+            g = {k: statistics.mean(x) for k, x in c.items()}
+            if g.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0) > 0 and lab in durs:
+                dd = sorted(x[1] for x in durs[lab])
+                us = statistics.mean(dd[len(dd) // 2:])
+                fl = g["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0
+                out.append("| `%s` | %.4g | %.4g | %.1f | %.1f | %.3f |" % (lab, g["SQ_INSTS_VALU_MFMA_MOPS_F64"], fl, us, fl / us / 1e6, fl / us / 1e6 / 78.6))
+    if bench:
+        rf = bench["roofline"]
+        out += ["", "Un-profiled bench line of the same workload (`%s`):" % bench["config"]["workload"][:60], "",
+                "* value %.0f %s, ms_per_step %.4f, step_ms_gpu %s" % (bench["value"], bench["unit"], bench["ms_per_step"], bench.get("step_ms_gpu")),
+                "* roofline: `%s` %.5f ms per launch, achieved %s %s of %s = frac %.3f" % (
+                    rf["kernel"], rf["kernel_ms"], rf["achieved"], rf["unit"], rf["peak"], rf["frac"]),
+                "", "```json", json.dumps(bench), "```"]
+    out += ["", "Profiled passes run at lower clocks than un-profiled ones (MI355X_MICROARCH.md, DVFS), so the kernel-trace duration is an upper bound "
+            "on the HIP-event duration of the un-profiled run."]
+    open(os.path.join(dst, "%s_%s_summary.md" % (tag, wl)), "w").write("\n".join(out) + "\n")
+    print("\n".join(out[:14]))
+    print()
+traffic["source"] = "profiles/%s_*_summary.md (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE x2, separate passes)" % tag
+json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps(traffic, indent=1))
