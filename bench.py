@@ -176,6 +176,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     L = mx.lib()
+    CAL = mx.calib()  # measurement probes: libmaxicalib.so (include/maxicalib.h)
     chk = mx._lib.check
     chk(L.mxg_init(local), "mxg_init")
     mx.maxiSettings.setup(44100, 2, 1024)
@@ -390,7 +391,7 @@ def main():
                 out = {}
                 for name, (w, fl, blk, blks) in {"8 B plain loads, 512 x 256 threads (the launch shape)": (8, 0, 256, 512),
                                                  "8 B non-temporal loads, 1024 x 512 threads": (8, 1, 512, 1024)}.items():
-                    out[name] = time_steps(lambda: chk(L.mxg_calib_read_ex(sig.data_ptr(), NF * 4096, w, fl, 1, blk, blks, sink.data_ptr(),
+                    out[name] = time_steps(lambda: chk(CAL.mxg_calib_read_ex(sig.data_ptr(), NF * 4096, w, fl, 1, blk, blks, sink.data_ptr(),
                                                                            stream), "calib_read"), 6, warm=3)
                 return out
             W = dict(step=step, samples=NF * 1024, dtype="f32 (FFT) / f64 (MFCC)", cpu=cpu, read_ceiling=read_ceiling if fused_ok else None,
@@ -544,7 +545,7 @@ def main():
 
     # ---- N = 1, config 2: what the headline is made of -----------------------------------------------------------------
     extras = {}
-    if world == 1 and W.get("read_ceiling") and not args.no_extras and hasattr(L, "mxg_calib_read_ex"):
+    if world == 1 and W.get("read_ceiling") and not args.no_extras and hasattr(CAL, "mxg_calib_read_ex"):
         rc = W["read_ceiling"]()
         best = min(rc, key=rc.get)
         nb_r = (1 << 20) * 4096
@@ -567,7 +568,7 @@ def main():
             k = [0]
 
             def fill():
-                chk(L.mxg_calib_fill_ex(bank.outs[k[0] % len(bank.outs)].data_ptr(), B, V * 8, w, fl, pat, blk, 0, 0, stream), "calib")
+                chk(CAL.mxg_calib_fill_ex(bank.outs[k[0] % len(bank.outs)].data_ptr(), B, V * 8, w, fl, pat, blk, 0, 0, stream), "calib")
                 k[0] += 1
             ceil_ms[name] = time_steps(fill, n_x)
         best = min(ceil_ms, key=ceil_ms.get)
@@ -584,7 +585,7 @@ def main():
             k2 = [0]
 
             def fill2():
-                chk(L.mxg_calib_fill_ex(b2.outs[k2[0] % len(b2.outs)].data_ptr(), B, V2 * 8, 16, 2, 1, 256, 0, 0, stream), "calib")
+                chk(CAL.mxg_calib_fill_ex(b2.outs[k2[0] % len(b2.outs)].data_ptr(), B, V2 * 8, 16, 2, 1, 256, 0, 0, stream), "calib")
                 k2[0] += 1
             c2 = time_steps(fill2, n_x)
             extras["north_star_bank"] = {

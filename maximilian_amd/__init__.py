@@ -5,7 +5,7 @@ maximilian_amd/csrc/*.hip, and the C++ host facade include/maximilian_bank.hpp. 
 package is the thin host-side mirror used by the tests and bench.py: device buffers, and
 `*Bank` classes whose methods carry the reference's names (maxiOsc::sinebuf -> maxiOscBank.sinebuf).
 """
-from ._lib import LIB_PATH, MaxiGpuError, lib  # noqa: F401
+from ._lib import LIB_PATH, MaxiGpuError, calib, lib  # noqa: F401
 from .banks import (DeviceBuffer, maxiSettings, maxiOscBank, maxiFilterBank, maxiEnvBank,  # noqa: F401
                     maxiVoiceBank, maxiMixBank, maxiDelaylineBank, maxiSampleBank, maxiDCBlockerBank,
                     maxiSVFBank, maxiBiquadBank, maxiEnvGenBank, maxiSamplerBank, OSC_WAVEFORMS,

@@ -148,10 +148,31 @@ SIGNATURES = {
     "mxg_mixq_release": (c_int, [c_void_p, c_void_p]),
     "mxg_i64_from_i32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mxg_i32_from_i64": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+}
+
+
+# measurement only (include/maxicalib.h, libmaxicalib.so): the bandwidth probes of bench.py and tools/*_ceiling.py
+CALIB_PATH = os.path.join(_HERE, "libmaxicalib.so")
+CALIB_SIGNATURES = {
     "mxg_calib_fill": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
     "mxg_calib_fill_ex": (c_int, [c_void_p, c_size_t, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mxg_calib_read_ex": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
+_calib = None
+
+
+def calib():
+    """Load libmaxicalib.so (after libmaxigpu.so, whose runtime it links against)."""
+    global _calib
+    if _calib is None:
+        lib()
+        C = ctypes.CDLL(CALIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in CALIB_SIGNATURES.items():
+            fn = getattr(C, name)
+            fn.restype = res
+            fn.argtypes = args
+        _calib = C
+    return _calib
 
 
 class MaxiGpuError(RuntimeError):

@@ -11,6 +11,7 @@
 // xcd = 1 renumbers the workgroups so that the eight XCDs (workgroup id mod 8) each own one contiguous eighth of a row
 // instead of every eighth 2-KB piece.
 #include "mxg_common.h"
+#include "../../include/maxicalib.h"
 
 namespace mxg {
 namespace {
@@ -194,3 +195,34 @@ extern "C" int mxg_calib_fill_ex(void *d_dst, size_t rows, size_t row_bytes, int
     }
     return check_hip(hipGetLastError(), "calib_fill_ex launch");
 }
+
+// ---- the plain grid-stride fill (rounds 1-2's write ceiling; tools/sweep_osc.py) ---------------------------------------------
+namespace mxg {
+namespace {
+__global__ void calib_fill8(double *p, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = 1.0;
+}
+__global__ void calib_fill16(double2v *p, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    double2v v = {1.0, 2.0};
+    for (; i < n; i += stride) p[i] = v;
+}
+}  // namespace
+}  // namespace mxg
+
+extern "C" int mxg_calib_fill(void *d_dst, size_t bytes, int width, void *stream) {
+    using namespace mxg;
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(d_dst && (width == 8 || width == 16), "bad argument");
+    hipStream_t st = resolve_stream(stream);
+    if (width == 8)
+        hipLaunchKernelGGL(calib_fill8, dim3(2048), dim3(256), 0, st, (double *)d_dst, bytes / 8);
+    else
+        hipLaunchKernelGGL(calib_fill16, dim3(2048), dim3(256), 0, st, (double2v *)d_dst,
+                           bytes / 16);
+    return check_hip(hipGetLastError(), "calib_fill launch");
+}
+

@@ -27,6 +27,9 @@
 namespace mxg {
 namespace {
 
+#ifndef MXG_TAB_AUX
+#define MXG_TAB_AUX 2  // A/B: 0 = default cache policy
+#endif
 constexpr int kTabLen = 514;         // doubles per voice (sineBuffer[514], C:63)
 constexpr int kTabParts = 16;        // time parts per block (32 samples each), one mark per part and voice
 constexpr int kTabVoices = 8;        // voices per round
@@ -61,7 +64,9 @@ __global__ void osctab_marks_kernel(size_t V, size_t N, const double *__restrict
 #pragma unroll
             for (int k = 0; k < 32; k++) {
                 ph += inc;
-                if (ph >= 511) ph -= 512;  // C:270
+                // `if (ph >= 511) ph -= 512;` (C:270) as compare + ONE select + subtract: the subtrahend is 512.0 or +0.0, assembled from
+                // its high word (x - 0.0 is x for every x) -- four dependent instructions per step instead of five on this latency-bound chain
+                ph = ph - __hiloint2double(ph >= 511 ? 0x40800000 : 0, 0);
             }
         } else {
             for (size_t n = (size_t)t * 32; n < N; n++) {
@@ -100,8 +105,9 @@ __device__ __forceinline__ void round_issue(const double *__restrict__ tables, c
     for (int i = 0; i < 4; i++) {
         unsigned off = (unsigned)(i * 512 + (int)threadIdx.x) * 16u;
         if (off >= tbytes) off = 0;  // (a short last group: re-read its first bytes)
+        // (aux = 2: non-temporal -- every table byte is read once by one CU; MI355X_MICROARCH.md "nt-weights")
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
-                                         (__attribute__((address_space(3))) void *)(dst + i * 8192), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(dst + i * 8192), 16, 0, MXG_TAB_AUX);
     }
     if (threadIdx.x < 84) {  // bytes [32768, 34112) of the buffer
         const unsigned off = 32768u + threadIdx.x * 16u;

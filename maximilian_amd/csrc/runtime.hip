@@ -550,28 +550,4 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms) {
     return MXG_OK;
 }
 
-// ---- calibration: streaming fill ----------------------------------------------------------
-__global__ void calib_fill8(double *p, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) p[i] = 1.0;
-}
-__global__ void calib_fill16(double2v *p, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    double2v v = {1.0, 2.0};
-    for (; i < n; i += stride) p[i] = v;
-}
-int mxg_calib_fill(void *d_dst, size_t bytes, int width, void *stream) {
-    if (int s = ensure_init()) return s;
-    MXG_REQUIRE(d_dst && (width == 8 || width == 16), "bad argument");
-    hipStream_t st = resolve_stream(stream);
-    if (width == 8)
-        hipLaunchKernelGGL(calib_fill8, dim3(2048), dim3(256), 0, st, (double *)d_dst, bytes / 8);
-    else
-        hipLaunchKernelGGL(calib_fill16, dim3(2048), dim3(256), 0, st, (double2v *)d_dst,
-                           bytes / 16);
-    return check_hip(hipGetLastError(), "calib_fill launch");
-}
-
 }  // extern "C"

@@ -28,6 +28,7 @@ ap.add_argument("--out", default=None)
 args = ap.parse_args()
 
 L = mx.lib()
+CAL = mx.calib()  # measurement probes: libmaxicalib.so
 chk = mx._lib.check
 chk(L.mxg_init(0), "init")
 NF = args.frames
@@ -63,7 +64,7 @@ for pattern, pname in ((1, "frame stream"), (0, "grid-stride")):
             for block, blocks in ((256, 512), (768, 256), (256, 1024), (256, 2048), (512, 1024)):
                 name = "%s, %d-byte %s loads, %d x %d threads" % (pname, width, fname, blocks, block)
                 variants.append((name, lambda p=pattern, w=width, f=flav, b=block, g=blocks:
-                                 chk(L.mxg_calib_read_ex(src, NBYTES, w, f, p, b, g, sink, None), "read")))
+                                 chk(CAL.mxg_calib_read_ex(src, NBYTES, w, f, p, b, g, sink, None), "read")))
 
 f = mx.maxiFFT(); f.setup(1024, 1024, 1024)
 m = mx.maxiMFCC(); m.setup(512, 42, 13, 20.0, 20000.0)

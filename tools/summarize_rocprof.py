@@ -119,6 +119,8 @@ for wl in sorted(d for d in os.listdir(src) if os.path.isdir(os.path.join(src, d
     open(os.path.join(dst, "%s_%s_summary.md" % (tag, wl)), "w").write("\n".join(out) + "\n")
     print("\n".join(out[:14]))
     print()
+if "osc_mixpc_kernel" in traffic:  # (bench.py's label for either form of K1m is osc_mix_kernel)
+    traffic.setdefault("osc_mix_kernel", traffic["osc_mixpc_kernel"])
 traffic["source"] = "profiles/%s_*_summary.md (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE x2, separate passes)" % tag
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(traffic, indent=1))

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import maximilian_amd as mx  # noqa: E402
 
 L = mx.lib()
+CAL = mx.calib()  # measurement probes: libmaxicalib.so
 mx._lib.check(L.mxg_init(0), "init")
 V, B = 65536, 512
 wf = int(sys.argv[1]) if len(sys.argv) > 1 else 8
@@ -34,7 +35,7 @@ def timed(fn, reps=int(os.environ.get("REPS", "5"))):
 nbytes = V * B * 8
 variants = {}
 for w in (8, 16):
-    variants["fill%d" % w] = (lambda w=w: L.mxg_calib_fill(out.ptr, nbytes, w, None))
+    variants["fill%d" % w] = (lambda w=w: CAL.mxg_calib_fill(out.ptr, nbytes, w, None))
 for vpl, nt, blk in itertools.product((1, 2), (0, 1), (64, 128, 256)):
     def f(vpl=vpl, nt=nt, blk=blk):
         L.mxg_tune(b"osc_vpl", vpl); L.mxg_tune(b"osc_nt", nt); L.mxg_tune(b"osc_block", blk)

@@ -30,6 +30,7 @@ ap.add_argument("--quick", action="store_true")
 args = ap.parse_args()
 
 L = mx.lib()
+CAL = mx.calib()  # measurement probes: libmaxicalib.so
 chk = mx._lib.check
 chk(L.mxg_init(0), "init")
 B = 512
@@ -66,7 +67,7 @@ def variants_for(V):
     out = {}
 
     def fill(name, width, flav, pattern, block, blocks=0, xcd=0, rot=True):
-        out[name] = lambda i: chk(L.mxg_calib_fill_ex(region(rot), B, V * 8, width, flav, pattern, block, blocks, xcd, None), name)
+        out[name] = lambda i: chk(CAL.mxg_calib_fill_ex(region(rot), B, V * 8, width, flav, pattern, block, blocks, xcd, None), name)
 
     # grid-stride fills
     for w in (8, 16):
