@@ -24,7 +24,10 @@
 namespace mxg {
 namespace {
 
-template <int MODE>
+// PX (dl only): 0 = 8-byte input / output streams; 1 / 2 / 3 = the whole chunks take their input and leave their output as 16-byte pair
+// rows (pair_rows_swap / store_pair_rows, mxg_common.h) with plain / write-through / non-temporal stores -- V even, both blocks 16-byte
+// aligned (round 4).  The ring keeps its slot-major 8-byte accesses: its rows are per-voice phases, not sample numbers.
+template <int MODE, int PX>
 __global__ void __launch_bounds__(256) delay_kernel(size_t V, size_t N, const double *__restrict__ in,
                              const int32_t *__restrict__ size, const double *__restrict__ feedback,
                              const int32_t *__restrict__ position, double *__restrict__ mem, int cap,
@@ -60,13 +63,27 @@ __global__ void __launch_bounds__(256) delay_kernel(size_t V, size_t N, const do
             double xi0[U], xi1[U], c0[U], c1[U];
             int s0[U], s1[U];
             int ph_prev = ph;
+            constexpr int PST = PX == 2 ? 2 : (PX == 3 ? 1 : 0);
+            const size_t odd = threadIdx.x & 1, vp = v & ~(size_t)1;
+            const double *ipp = in + vp;             // pair rows: the lane reads 16 bytes of row n + (lane & 1) ...
+            double *opp = out + odd * V + vp;        // ... and writes 16 bytes of it
             auto request = [&](size_t k, double(&xi)[U], double(&c)[U], int(&sl)[U]) {
                 ph_prev = ph;
+                if constexpr (PX != 0) {  // (xi[2j], xi[2j+1] hold the RAW 16 bytes until retire swaps them)
+#pragma unroll
+                    for (int j = 0; j < U / 2; j++) {
+                        const size_t nn = k * U + 2 * j + odd;
+                        const size_t mm = (nn < N) ? nn : N - 1;  // clamped: no branch
+                        const double2v raw = *reinterpret_cast<const double2v *>(ipp + mm * V);
+                        xi[2 * j] = raw.x;
+                        xi[2 * j + 1] = raw.y;
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < U; i++) {
                     const size_t nn = k * U + i;
                     const size_t mm = (nn < N) ? nn : N - 1;  // clamped: no branch
-                    xi[i] = ip[mm * V];
+                    if constexpr (PX == 0) xi[i] = ip[mm * V];
                     if ((unsigned)ph >= (unsigned)sz) ph = 0;  // C:421
                     sl[i] = ph;
                     c[i] = m[(size_t)ph * V];
@@ -74,11 +91,28 @@ __global__ void __launch_bounds__(256) delay_kernel(size_t V, size_t N, const do
                 }
             };
             auto retire = [&](double(&xi)[U], double(&c)[U], int(&sl)[U]) {
+                if constexpr (PX != 0) {
+#pragma unroll
+                    for (int j = 0; j < U / 2; j++) {
+                        const double2v raw = {xi[2 * j], xi[2 * j + 1]};
+                        pair_rows_swap(raw, xi[2 * j], xi[2 * j + 1]);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < U; i++) {
                     m[(size_t)sl[i] * V] = (c[i] * fb) + (xi[i] * fb) * 0.5;  // C:425
-                    *op = c[i];                                                // C:424
-                    op += V;
+                    if constexpr (PX == 0) {
+                        *op = c[i];                                            // C:424
+                        op += V;
+                    }
+                }
+                if constexpr (PX != 0) {
+#pragma unroll
+                    for (int j = 0; j < U / 2; j++) {
+                        store_pair_rows<PST>(opp, c[2 * j], c[2 * j + 1]);
+                        opp += 2 * V;
+                    }
+                    op += (size_t)U * V;
                 }
             };
             request(0, xi0, c0, s0);

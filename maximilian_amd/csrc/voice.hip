@@ -253,7 +253,9 @@ __global__ void __launch_bounds__(256) filter_coefps_kernel(size_t V, size_t N, 
     st[4 * V + v] = f.o2;
 }
 
-template <int MODE, bool HASIN, bool TPV>
+// PX: 0 = 8-byte input / output streams; 1 / 2 / 3 = 16-byte pair rows both ways (pair_rows_swap / store_pair_rows, mxg_common.h) with
+// plain / write-through / non-temporal stores -- V even, N even, both blocks 16-byte aligned (round 4; the same ticks in the same order).
+template <int MODE, bool HASIN, bool TPV, int PX>
 __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const double *__restrict__ in,
                            const int32_t *__restrict__ trig, int tpv,
                            const double *__restrict__ par, const int64_t *__restrict__ holdtime,
@@ -261,23 +263,49 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
                            double *__restrict__ out) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if ((gid & ~(size_t)63) >= V) return;  // the whole wavefront is past the bank
-    const size_t v = live_voice(gid, V);
+    // (pair rows: the surplus lanes of the last wavefront shadow the last PAIR of voices, parity kept: voice_kernel)
+    const size_t v = PX ? (gid < V ? gid : V - 2 + (gid & 1)) : live_voice(gid, V);
+    constexpr int PST = PX == 2 ? 2 : (PX == 3 ? 1 : 0);
     Env e;
     env_load(e, V, v, par, holdtime, dst, ist);
-    const double *ip = in ? in + v : nullptr;
-    double *op = out + v;
+    const size_t odd = threadIdx.x & 1, vp = v & ~(size_t)1;
+    const double *ip = in ? in + (PX ? vp : v) : nullptr;
+    double *op = PX ? out + odd * V + vp : out + v;  // pair rows: this lane's 16 bytes of row n + (lane & 1)
+    // one chunk of U outputs, the first `cnt` of them inside the block (cnt even with pair rows: N is)
+    auto emit = [&](const double (&o)[8], size_t cnt) {
+        if constexpr (PX != 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if ((size_t)(2 * j) < cnt) store_pair_rows<PST>(op, o[2 * j], o[2 * j + 1]);
+                op += 2 * V;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if ((size_t)i < cnt) *op = o[i];
+                op += V;
+            }
+        }
+    };
     // software pipeline (see filter_kernel): next chunk's inputs/triggers are requested before this
     // chunk's outputs are stored
     constexpr int U = 8;  // measured with the steady-state paths: 8 beats 4 on both paths
     double xn[U];
+    double2v xr[U / 2];  // pair rows: the raw 16-byte loads of the next chunk
     int tn[U];
     GateGroup<U, int32_t> gcur;  // shared gate: see gate_group_load
     const auto gate_on = [](int32_t t) { return t == 1; };  // the test of C:1363 / C:1425
+    auto row_of = [&](size_t n) { const size_t rr = n + odd; return rr < N ? rr : N - 1; };  // clamped: no branch, surplus unused
 #pragma unroll
     for (int i = 0; i < U; i++) {
         const size_t m = (size_t)i < N ? (size_t)i : N - 1;
-        if constexpr (HASIN) xn[i] = ip[m * V]; else xn[i] = 1.0;
+        if constexpr (!HASIN) xn[i] = 1.0;
+        else if constexpr (PX == 0) xn[i] = ip[m * V];
         if constexpr (TPV) tn[i] = trig[m * V + v];
+    }
+    if constexpr (HASIN && PX != 0) {
+#pragma unroll
+        for (int j = 0; j < U / 2; j++) xr[j] = *reinterpret_cast<const double2v *>(ip + row_of(2 * j) * V);
     }
     if constexpr (!TPV) {
         gate_group_load(gcur, trig, N, 0, gate_on);
@@ -286,12 +314,19 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
     for (size_t n0 = 0; n0 < N; n0 += U) {
         double xc[U];
         int tc[U];
+        if constexpr (HASIN && PX != 0) {
+#pragma unroll
+            for (int j = 0; j < U / 2; j++) {
+                pair_rows_swap(xr[j], xc[2 * j], xc[2 * j + 1]);
+                xr[j] = *reinterpret_cast<const double2v *>(ip + row_of(n0 + U + 2 * j) * V);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < U; i++) {
-            xc[i] = xn[i];
+            if constexpr (!(HASIN && PX != 0)) xc[i] = xn[i];
             if constexpr (TPV) tc[i] = tn[i];
             const size_t m = (n0 + U + i < N) ? n0 + U + i : N - 1;
-            if constexpr (HASIN) xn[i] = ip[m * V];
+            if constexpr (HASIN && PX == 0) xn[i] = ip[m * V];
             if constexpr (TPV) tn[i] = trig[m * V + v];
         }
         int fast = 0;
@@ -329,28 +364,22 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
                     const bool ok = env_steady_chunk<U>(s, xc, lane_gate, o);
                     if (__all(ok)) {
                         e = s;
-#pragma unroll
-                        for (int i = 0; i < U; i++) {
-                            *op = o[i];
-                            op += V;
-                        }
+                        emit(o, U);
                         continue;
                     }
                 }
             }
         }
-        if (fast == 1) {
+        // (fast paths: the gate class of the chunk is constant, which a ragged last chunk's class covers as well -- but the state
+        // must stop at sample N: they take whole chunks only)
+        double o[U];
+        const size_t cnt = N - n0 < (size_t)U ? N - n0 : (size_t)U;
+        if (fast == 1 && cnt == (size_t)U) {
 #pragma unroll
-            for (int i = 0; i < U; i++) {
-                *op = env_sustain_tick(e, xc[i]);
-                op += V;
-            }
-        } else if (fast == 2) {
+            for (int i = 0; i < U; i++) o[i] = env_sustain_tick(e, xc[i]);
+        } else if (fast == 2 && cnt == (size_t)U) {
 #pragma unroll
-            for (int i = 0; i < U; i++) {
-                *op = env_release_tick(e, xc[i]);
-                op += V;
-            }
+            for (int i = 0; i < U; i++) o[i] = env_release_tick(e, xc[i]);
         } else {
 #pragma unroll
             for (int i = 0; i < U; i++) {
@@ -358,11 +387,10 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
                 int t;
                 if constexpr (TPV) t = tc[i];
                 else t = lane_value(gcur.g[i], (int)((n0 / U) & 63));
-                double o = (MODE == 0) ? env_adsr(e, xc[i], t) : env_ar(e, xc[i], t);
-                *op = o;
-                op += V;
+                o[i] = (MODE == 0) ? env_adsr(e, xc[i], t) : env_ar(e, xc[i], t);
             }
         }
+        emit(o, cnt);
     }
     env_store(e, V, v, dst, ist);
 }
@@ -716,18 +744,32 @@ int mxg_env_render(int mode, size_t V, size_t N, const double *d_in, const int32
     int block = tune_get("voice_block");
     if (block > 256) block = 256;  // the bank kernels are compiled for <= 256 lanes per workgroup (512 VGPRs/lane budget)
     hipStream_t st = resolve_stream(stream);
-#define MXG_ENV_LAUNCH(M, I, P)                                                                      \
-    hipLaunchKernelGGL((env_kernel<M, I, P>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_trig, \
+    // 16-byte pair-row streams (knob rw_store, as mxg_filter_render: 0 automatic = write-through stores for blocks from 64 MB, 1 off,
+    // 2 / 3 / 4 plain / write-through / non-temporal stores)
+    int rw = tune_get("rw_store");
+    const bool pairs_ok = V >= 2 && !(V & 1) && !(N & 1) && !(((uintptr_t)d_in) & 15) && !(((uintptr_t)d_out) & 15);
+    if (rw == 0) rw = (V * N * sizeof(double) >= ((size_t)64 << 20)) ? 3 : 1;
+    const int px = (rw >= 2 && pairs_ok) ? rw - 1 : 0;
+#define MXG_ENV_LAUNCH(M, I, P, X)                                                                      \
+    hipLaunchKernelGGL((env_kernel<M, I, P, X>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_trig, \
                        tpv, d_par, d_holdtime, d_dst, d_ist, d_out)
+#define MXG_ENV_LAUNCH1(M, I, P)                        \
+    switch (px) {                                       \
+        case 1: MXG_ENV_LAUNCH(M, I, P, 1); break;      \
+        case 2: MXG_ENV_LAUNCH(M, I, P, 2); break;      \
+        case 3: MXG_ENV_LAUNCH(M, I, P, 3); break;      \
+        default: MXG_ENV_LAUNCH(M, I, P, 0); break;     \
+    }
 #define MXG_ENV_LAUNCH2(M)                                                  \
     if (d_in) {                                                             \
-        if (tpv) MXG_ENV_LAUNCH(M, true, true); else MXG_ENV_LAUNCH(M, true, false);   \
+        if (tpv) { MXG_ENV_LAUNCH1(M, true, true) } else { MXG_ENV_LAUNCH1(M, true, false) }   \
     } else {                                                                \
-        if (tpv) MXG_ENV_LAUNCH(M, false, true); else MXG_ENV_LAUNCH(M, false, false); \
+        if (tpv) { MXG_ENV_LAUNCH1(M, false, true) } else { MXG_ENV_LAUNCH1(M, false, false) } \
     }
     KernelTimer kt("env_kernel", st);
     if (mode == 0) { MXG_ENV_LAUNCH2(0) } else { MXG_ENV_LAUNCH2(1) }
 #undef MXG_ENV_LAUNCH2
+#undef MXG_ENV_LAUNCH1
 #undef MXG_ENV_LAUNCH
     return check_hip(hipGetLastError(), "env_kernel launch");
 }

@@ -106,6 +106,37 @@ def test_env_golden_and_setters(mx, golden):
         assert np.array_equal(bank.istate.numpy(), g["ist_%s_pv" % name])
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("rw", [1, 2, 3, 4])
+@pytest.mark.parametrize("V,N,hasin,tpv", [(778, 600, True, False), (4096, 130, True, True), (2, 2, True, False),
+                                           (1000, 7 * 8 + 6, False, False), (130, 302, False, True), (64, 64, True, False)])
+def test_env_pair_row_streams_same_bits(mx, port, mode, rw, V, N, hasin, tpv):
+    """maxiEnv banks with 16-byte pair-row input / output streams (knob rw_store, csrc/voice.hip env_kernel PX): two carried blocks
+    over toggling gates, sustained stretches and ragged last chunks; output and every state member bit for bit the oracle's."""
+    L = mx.lib()
+    rng = np.random.default_rng(mode * 11 + rw + V + N)
+    x = rng.uniform(-1, 1, (2 * N, V)) if hasin else None
+    n = np.arange(2 * N)
+    if tpv:
+        trig = ((n[:, None] + 37 * np.arange(V)[None, :]) % 211 < 120).astype(np.int32)
+    else:
+        trig = ((n % 170) < 110).astype(np.int32)
+    par = np.stack([rng.uniform(0.001, 0.05, V), rng.uniform(0.99, 0.9999, V), rng.uniform(0.2, 0.9, V), rng.uniform(0.99, 0.9999, V)])
+    hold = rng.integers(1, 40, V).astype(np.int64)
+    prev = L.mxg_tune(b"rw_store", rw)
+    try:
+        bank = _env_bank(mx, par, hold)
+        xin = (lambda a: mx.DeviceBuffer.from_numpy(np.ascontiguousarray(a))) if hasin else (lambda a: None)
+        o1 = bank.render(mode, xin(x[:N]) if hasin else None, trig[:N], N).numpy()
+        o2 = bank.render(mode, xin(x[N:]) if hasin else None, trig[N:], N).numpy()
+    finally:
+        L.mxg_tune(b"rw_store", prev)
+    eo, edst, eist = port.env(mode, x, trig, par, hold)
+    assert_bits_equal(np.concatenate([o1, o2]), eo, "env mode %d rw_store=%d" % (mode, rw))
+    assert_bits_equal(bank.dstate.numpy(), edst, "env dstate")
+    assert np.array_equal(bank.istate.numpy(), eist)
+
+
 def test_voice_golden_mode_a_bit_exact(mx, golden):
     g = golden("voice.npz")
     V = g["freq"].size
