@@ -36,9 +36,10 @@ struct EgArgs {
     double *dst;           // [5][V]
     int64_t *ist;          // [7][V]
     double *out;
+    int px_store;          // pair-row store flavour of the whole chunks (emit_chunk, mxg_common.h); 0 = 8-byte stores
 };
 
-template <bool TPV>
+template <bool TPV, bool PX>
 // trig / out are separate __restrict__ parameters (not members of A): only then may hipcc read the shared gate
 // with scalar loads; as vector loads they sit in the same in-order queue as the output stores and drain it.
 __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__restrict__ trig_in,
@@ -49,7 +50,8 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__r
     const size_t V = A.V, N = A.N;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if ((gid & ~(size_t)63) >= V) return;  // the whole wavefront is past the bank
-    const size_t v = live_voice(gid, V);   // surplus lanes shadow voice V-1 (mxg_gate.h)
+    // surplus lanes shadow voice V-1 (mxg_gate.h); with pair rows the last PAIR of voices, parity kept (voice_kernel, voice.hip)
+    const size_t v = PX ? (gid < V ? gid : V - 2 + (gid & 1)) : live_voice(gid, V);
     constexpr int WAITING = EG_WAITING, HOLDING = EG_HOLDING;
     double envval = A.dst[v], currentlevel = A.dst[V + v];
     double tprev = A.dst[2 * V + v], hprev = A.dst[3 * V + v], rprev = A.dst[4 * V + v];
@@ -66,7 +68,7 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__r
     const long long S = A.nstages;
     const bool loop = A.loop != 0, retrigger = A.retrigger != 0;
     const double *__restrict__ tp = TPV ? trig_in + v : trig_in;
-    double *__restrict__ op = out_ptr + v;
+    double *op = out_ptr + v;
     constexpr int U = 8;
     double tn[U];
     GateGroup<U, double> gcur;  // shared gate: lane j keeps chunk j's triggers (mxg_gate.h)
@@ -113,12 +115,9 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__r
             if (g > 0 && !retrigger && __all(state == HOLDING && !nxc && parked)) fast = 1;
             else if (g < 0 && __all(state == WAITING && parked)) fast = 2;
             else if (g > 0 && __all(state == WAITING && parked && tprev > 0 && !tfirst)) fast = 2;  // gate still up after the end: no crossing either
-            if (fast) {
-#pragma unroll
-                for (int i = 0; i < U; i++) {
-                    *op = envval;
-                    op += V;
-                }
+            if (fast && n0 + U <= N) {
+                const double oo[U] = {envval, envval, envval, envval, envval, envval, envval, envval};
+                emit_chunk<PX>(op, V, oo, A.px_store);
                 const double last = lane_value(gcur.g[U - 1], cc);
                 if (fast == 1) { hprev = -last; hfirst = false; }  // holdDetector.onZX(-trigger), no crossing
                 else { tprev = last; tfirst = false; }            // trigDetector.onZX(trigger), no crossing
@@ -144,14 +143,12 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__r
             if (__all(ok)) {
                 envval = s.envval; currentlevel = s.currentlevel; tprev = s.tprev; hprev = s.hprev; rprev = s.rprev;
                 tfirst = s.tfirst; hfirst = s.hfirst; rfirst = s.rfirst; counter = s.counter; nxc = s.nxc;
-#pragma unroll
-                for (int i = 0; i < U; i++) {
-                    *op = oo[i];
-                    op += V;
-                }
+                emit_chunk<PX>(op, V, oo, A.px_store);
                 continue;
             }
         }
+        double og[U];
+        const bool whole = n0 + U <= N;  // (wave-uniform; a ragged last chunk goes out sample by sample)
 #pragma unroll
         for (int i = 0; i < U; i++) {
             if (n0 + i >= N) break;
@@ -163,9 +160,15 @@ __global__ void __launch_bounds__(256) envgen_kernel(EgArgs A, const double *__r
             envval = e.envval; currentlevel = e.currentlevel; tprev = e.tprev; hprev = e.hprev; rprev = e.rprev;
             tfirst = e.tfirst; hfirst = e.hfirst; rfirst = e.rfirst; phase = e.phase; counter = e.counter;
             state = e.state; nxc = e.nxc;
-            *op = envval;
-            op += V;
+            if (PX && whole) {
+                og[i] = envval;
+            } else {
+                *op = envval;
+                op += V;
+            }
         }
+        if constexpr (PX)
+            if (whole) emit_chunk<PX>(op, V, og, A.px_store);
         row = envgen_row(s_tab, S, phase);
     }
     const bool in = phase < S;
@@ -223,12 +226,19 @@ int mxg_envgen_render(size_t V, size_t N, const double *d_trig, int tpv, const d
     if (V == 0 || N == 0) return MXG_OK;
     int block = tune_get("voice_block");
     if (block > 256) block = 256;
-    const EgArgs A = {V, N, d_trig, tpv, nstages, loop, retrigger, d_stages, d_dst, d_ist, d_out};
+    // the output stream (knob rw_store: 0 automatic = pair rows of write-through stores for blocks from 64 MB, 1 the 8-byte stores,
+    // 2 / 3 / 4 pair rows with plain / write-through / non-temporal stores)
+    const EgArgs A = {V, N, d_trig, tpv, nstages, loop, retrigger, d_stages, d_dst, d_ist, d_out, rw_store_choice(V, N, d_out)};
     const dim3 grid((unsigned)((V + block - 1) / block));
-    if (tpv)
-        hipLaunchKernelGGL((envgen_kernel<true>), grid, dim3(block), 0, resolve_stream(stream), A, d_trig, d_out);
-    else
-        hipLaunchKernelGGL((envgen_kernel<false>), grid, dim3(block), 0, resolve_stream(stream), A, d_trig, d_out);
+    hipStream_t st = resolve_stream(stream);
+    KernelTimer kt("envgen_kernel", st);
+    if (tpv) {
+        if (A.px_store) hipLaunchKernelGGL((envgen_kernel<true, true>), grid, dim3(block), 0, st, A, d_trig, d_out);
+        else hipLaunchKernelGGL((envgen_kernel<true, false>), grid, dim3(block), 0, st, A, d_trig, d_out);
+    } else {
+        if (A.px_store) hipLaunchKernelGGL((envgen_kernel<false, true>), grid, dim3(block), 0, st, A, d_trig, d_out);
+        else hipLaunchKernelGGL((envgen_kernel<false, false>), grid, dim3(block), 0, st, A, d_trig, d_out);
+    }
     return check_hip(hipGetLastError(), "envgen_kernel launch");
 }
 

@@ -36,6 +36,15 @@ int ensure_init_only();  // allocation, copies, creation: init on first use, pen
 hipStream_t resolve_stream(void *stream);
 int tune_get(const char *key);
 int device_cus();  // compute units of the device (256 on MI355X)
+// The out[n*V + v] stream of the read+write / write-only bank kernels (knob rw_store: 0 automatic = 16-byte pair rows of write-through stores
+// for blocks from 64 MB, 1 the 8-byte stores, 2 / 3 / 4 pair rows with plain / write-through / non-temporal stores): 0 = 8-byte stores, else
+// the px_store flavour of emit_chunk (1 / 2 / 3).  Pair rows need V even and a 16-byte aligned block.
+inline int rw_store_choice(size_t V, size_t N, const void *d_out) {
+    int rw = tune_get("rw_store");
+    if (rw == 0) rw = (V * N * sizeof(double) >= ((size_t)64 << 20)) ? 3 : 1;
+    const bool pairs_ok = V >= 2 && !(V & 1) && !(((uintptr_t)d_out) & 15);
+    return (rw >= 2 && pairs_ok) ? rw - 1 : 0;
+}
 
 // Library-owned scratch, one grow-only buffer per (slot, stream): launches on different streams never share
 // (or resize) each other's temporaries; launches on one stream are ordered by the stream.  Returns MXG_OK and
@@ -177,40 +186,91 @@ __device__ __forceinline__ void store2(double *p, double a, double b) {
     else
         *reinterpret_cast<double2v *>(p) = v;
 }
-// Two samples of one voice per lane -> one 16-byte store per lane: lanes 2k and 2k+1 (voices v, v+1) swap one value, so that
-// the even lane holds sample n of both voices (16 contiguous bytes of row n) and the odd lane sample n+1 of both (row n+1).
-// One wave store then covers 512 contiguous bytes in each of two rows with 16 bytes per lane.  `o` is the lane's own
-// pointer: out + (n + (lane & 1)) * V + (v & ~1); both lanes of a pair must be live (V even).
-template <int ST>
-__device__ __forceinline__ void store_pair_rows(double *o, double r0, double r1) {
+// The exchange inside a lane pair (lanes 2k, 2k+1) that both pair-row streams are made of: every lane gives (x, y) and gets
+//     a = even lane ? its own x : the partner's y,        b = odd lane ? its own y : the partner's x.
+// Four VALU instructions: one v_cndmask_b32_dpp per dword (the DPP operand is the partner's value, quad_perm [1,0,3,2]; the lane parity
+// is the select mask, in VCC: VOP2 is the only encoding that takes a DPP operand on gfx950, and it reads VCC).  Left to hipcc the same
+// exchange is a v_mov_b32_dpp plus a v_cndmask_b32_e64 per dword -- 8 instructions per 16-byte store, 10 per 16-byte load with the
+// selects around it -- which is 10 % of the VALU-bound oscillators (sinewave, sinebuf4: profiles/r04_heavy_osc.md).
+// Both lanes of a pair must be live.  (s_mov + s_nop: the two wait states between a VALU write of a VGPR and a DPP read of it, which
+// hipcc's hazard recognizer does not insert in front of inline asm.)
+// ASM = false: the exchange written with __builtin_amdgcn_update_dpp and selects, as in rounds 1-3 -- kept for the kernels whose
+// time is their store stream's and whose loop was tuned in that form (K1's sinebuf: osc.hip).
+template <bool ASM = true>
+__device__ __forceinline__ void pair_exchange(double x, double y, double &a, double &b) {
+    const int x0 = __double2loint(x), x1 = __double2hiint(x), y0 = __double2loint(y), y1 = __double2hiint(y);
+    int a0, a1, b0, b1;
+    if constexpr (ASM) {
+    const unsigned long long even = 0x5555555555555555ull;  // (workgroups are whole wavefronts: lane parity = thread parity)
+    asm("s_mov_b64 vcc, %8\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32_dpp %0, %6, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_cndmask_b32_dpp %1, %7, %5, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_not_b64 vcc, vcc\n\t"
+        "v_cndmask_b32_dpp %2, %4, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_cndmask_b32_dpp %3, %5, %7, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
+        : "v"(x0), "v"(x1), "v"(y0), "v"(y1), "s"(even)
+        : "vcc", "scc");
+    } else {
     const bool odd = (threadIdx.x & 1) != 0;
-    const int x0 = __double2loint(r0), x1 = __double2hiint(r0), y0 = __double2loint(r1), y1 = __double2hiint(r1);
-    constexpr int kQuadXor1 = 0xB1;  // quad_perm [1,0,3,2]: the partner lane (DPP bank masks select groups of four lanes, not a
-    // lane parity, so the parity is a select -- which hipcc folds with the DPP move into ONE v_cndmask_b32_dpp per dword)
-    // a = sample n of voice 2k:   the even lane's own r0 / for the odd lane (row n+1): the partner's r1
-    // b = sample n of voice 2k+1: the partner's r0      / the odd lane's own r1
+    constexpr int kQuadXor1 = 0xB1;  // quad_perm [1,0,3,2]: the partner lane
     // (the exchanges are evaluated by every lane BEFORE the selects: a DPP read under a divergent branch would see a masked partner)
     const int py0 = __builtin_amdgcn_update_dpp(0, y0, kQuadXor1, 0xf, 0xf, true);
     const int py1 = __builtin_amdgcn_update_dpp(0, y1, kQuadXor1, 0xf, 0xf, true);
     const int px0 = __builtin_amdgcn_update_dpp(0, x0, kQuadXor1, 0xf, 0xf, true);
     const int px1 = __builtin_amdgcn_update_dpp(0, x1, kQuadXor1, 0xf, 0xf, true);
-    const int a0 = odd ? py0 : x0, a1 = odd ? py1 : x1;
-    const int b0 = odd ? y0 : px0, b1 = odd ? y1 : px1;
-    store2<ST>(o, __hiloint2double(a1, a0), __hiloint2double(b1, b0));
+    a0 = odd ? py0 : x0, a1 = odd ? py1 : x1;
+    b0 = odd ? y0 : px0, b1 = odd ? y1 : px1;
+    }
+    a = __hiloint2double(a1, a0);
+    b = __hiloint2double(b1, b0);
+}
+
+// Two samples of one voice per lane -> one 16-byte store per lane: lanes 2k and 2k+1 (voices v, v+1) swap one value, so that
+// the even lane holds sample n of both voices (16 contiguous bytes of row n) and the odd lane sample n+1 of both (row n+1).
+// One wave store then covers 512 contiguous bytes in each of two rows with 16 bytes per lane.  `o` is the lane's own
+// pointer: out + (n + (lane & 1)) * V + (v & ~1); both lanes of a pair must be live (V even).
+// (a = sample n of voice 2k: the even lane's own r0 / for the odd lane, whose row is n+1, the partner's r1; b = voice 2k+1 likewise)
+template <int ST, bool ASM = true>
+__device__ __forceinline__ void store_pair_rows(double *o, double r0, double r1) {
+    double a, b;
+    pair_exchange<ASM>(r0, r1, a, b);
+    store2<ST>(o, a, b);
+}
+
+// One chunk of U consecutive samples of the lane's voice to the out[n*V + v] stream; `op` = out + n*V + v, advanced by U rows.
+// PX: as 16-byte pair rows (store_pair_rows) -- V even, out 16-byte aligned, both lanes of every pair live on the same chunk, lane parity =
+// voice parity; px_store (wave-uniform): 1 / 2 / 3 = plain / write-through / non-temporal stores.  !PX: 8-byte stores.
+template <bool PX, int U>
+__device__ __forceinline__ void emit_chunk(double *&op, size_t V, const double (&o)[U], int px_store) {
+    if constexpr (PX) {
+        double *pp = op + ((threadIdx.x & 1) ? V - 1 : 0);  // this lane's 16 bytes of row n + (lane & 1): out + (n + odd) * V + (v & ~1)
+        if (px_store == 2) {
+#pragma unroll
+            for (int j = 0; j < U / 2; j++) store_pair_rows<2>(pp + (size_t)(2 * j) * V, o[2 * j], o[2 * j + 1]);
+        } else if (px_store == 3) {
+#pragma unroll
+            for (int j = 0; j < U / 2; j++) store_pair_rows<1>(pp + (size_t)(2 * j) * V, o[2 * j], o[2 * j + 1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < U / 2; j++) store_pair_rows<0>(pp + (size_t)(2 * j) * V, o[2 * j], o[2 * j + 1]);
+        }
+        op += (size_t)U * V;
+    } else {
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            *op = o[i];
+            op += V;
+        }
+    }
 }
 
 // The mirror image for a READ stream in[n*V + v]: the lane loads 16 bytes -- two voices of its row n + (lane & 1), from
-// in + (n + (lane & 1)) * V + (v & ~1) -- and the pair swaps one value, after which every lane holds samples n (r0) and n + 1 (r1) of
-// ITS voice.  The load (`raw`) and the swap are separate so that a kernel can request a chunk ahead and swap when it consumes.
-__device__ __forceinline__ void pair_rows_swap(const double2v raw, double &r0, double &r1) {
-    const bool odd = (threadIdx.x & 1) != 0;
-    // even lane: raw = (x[n][2k], x[n][2k+1]) keeps .x, needs the partner's .x; odd lane: raw = (x[n+1][2k], x[n+1][2k+1]) keeps .y, needs the partner's .y
-    const double send = odd ? raw.x : raw.y;
-    const int s0 = __double2loint(send), s1 = __double2hiint(send);
-    const int g0 = __builtin_amdgcn_update_dpp(0, s0, 0xB1, 0xf, 0xf, true), g1 = __builtin_amdgcn_update_dpp(0, s1, 0xB1, 0xf, 0xf, true);
-    const double recv = __hiloint2double(g1, g0);
-    r0 = odd ? recv : raw.x;
-    r1 = odd ? raw.y : recv;
-}
+// in + (n + (lane & 1)) * V + (v & ~1) -- and the pair makes the same exchange, after which every lane holds samples n (r0) and n + 1
+// (r1) of ITS voice (even lane: raw = (x[n][2k], x[n][2k+1]) keeps .x and gets the partner's .x = x[n+1][2k]; odd lane: raw =
+// (x[n+1][2k], x[n+1][2k+1]) keeps .y and gets the partner's .y).  The load (`raw`) and the swap are separate so that a kernel can
+// request a chunk ahead and swap when it consumes.
+__device__ __forceinline__ void pair_rows_swap(const double2v raw, double &r0, double &r1) { pair_exchange(raw.x, raw.y, r0, r1); }
 
 }  // namespace mxg

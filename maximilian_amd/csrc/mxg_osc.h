@@ -25,6 +25,7 @@ struct OscPre {
     double k;    // sawn: 8820.22/frequency            (C:346)
     double p1;   // pulse: clamped duty (C:304-305); phasorBetween: startphase
     double p2;   // phasorBetween: endphase
+    SinTabK sk;  // sinewave / coswave: two coefficients of sincos_tab in vector registers (mxg_sincos.h; a kernel's loop sets them opaque)
 };
 
 template <int WF>
@@ -33,6 +34,7 @@ __device__ __forceinline__ OscPre osc_pre(double f, double sr, double p1, double
     q.k = 0.0;
     q.p1 = p1;
     q.p2 = p2;
+    q.sk = {1.0 / 120, 1.0 / 24};
     if constexpr (WF == MXG_OSC_SINEBUF) {
         q.inc = 512. / (sr / (f * kChandiv));  // C:269
     } else if constexpr (WF == MXG_OSC_SINEBUF4) {
@@ -58,36 +60,64 @@ __device__ __forceinline__ OscPre osc_pre(double f, double sr, double p1, double
 
 // `if (phase >= 1.0) phase -= 1.0;` (C:231, C:279) as compare + ONE select + subtract: the subtrahend is 1.0 or +0.0, assembled from
 // its high word (x - 0.0 is x for every x, -0.0 and NaN included), instead of a subtract and a two-word select.
+// UNIT (the TRUST forms of sinewave / coswave): the caller guarantees +0.0 <= phase < 2, where the statement is the fractional part --
+// v_fract_f64, one instruction: x - floor(x) is x itself below 1 and the exact x - 1 from 1 to 2 (the instruction's clamp to the double
+// below 1.0 never acts on exact differences; a -0.0, which the subtraction would keep and fract would not, is excluded by the caller).
+template <bool UNIT = false>
 __device__ __forceinline__ double wrap_at_one(double phase) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (UNIT) return __builtin_amdgcn_fract(phase);
     return phase - __hiloint2double(phase >= 1.0 ? 0x3FF00000 : 0, 0);
 #else
     return phase >= 1.0 ? phase - 1.0 : phase;
 #endif
 }
 
+// `if (phase >= 511) phase -= 512;` (C:240, C:269) the same way: compare, one select of the subtrahend's high word (512.0 or +0.0), subtract.
+// FAST = false: the plain statement as hipcc compiles it (subtract, compare, two-word select) -- K1's sinebuf keeps it: that kernel is
+// bound by its store stream, and every leaner form of its loop measured SLOWER (profiles/r04_heavy_osc.md).
+template <bool FAST>
+__device__ __forceinline__ double wrap_at_511(double phase) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (FAST) return phase - __hiloint2double(phase >= 511 ? 0x40800000 : 0, 0);
+#endif
+    if (phase >= 511) phase -= 512;
+    return phase;
+}
+
 // One sample of one voice.  `phase`/`hold` are the members `phase`/`output` (H:173,176).
 // s_sine[i+1] == sineBuffer[i] (i=-1..513), s_trans[i] == transition[i] (i=0..1001); for sinewave / coswave s_sine is the
 // sin / cos table MXG_SINTAB of mxg_sincos.h instead.
-// TRUST (sinewave / coswave only): the caller has checked 0 <= inc <= 1 and 0 <= phase <= 2, which the recurrence then keeps.
+// TRUST (sinewave / coswave only): the caller has checked +0.0 <= inc < 1 and +0.0 <= phase < 2 (sign bits clear), which the
+// recurrence then keeps: fract(phase) <= 1 - 2^-53 and inc <= 1 - 2^-53 add up to at most 2 - 2^-52, a double below 2.
 #ifndef MXG_SB4_PAIRS
 #define MXG_SB4_PAIRS 0  // 1: sinebuf4's four table values as two aligned 16-byte LDS reads from a parity copy of the table (A/B: measured
                         // SLOWER on the same device, 59.0 against 57.3 us for 65 536 x 512 -- the kernel is not bound by LDS cycles)
 #endif
+// Tick flavours (osc_tick's FL, a kernel's choice): bit 0 = sinebuf / sawn read their second table value from a copy of the table
+// tab_copy doubles on (two ds_read_b64, ~7 LDS cycles each at unrelated addresses, where hipcc merges two reads off one base into a
+// ds_read2_b64 of ~20); bit 1 = the three-instruction phase wrap (wrap_at_511<true>).  The VALU- and LDS-bound kernels take both
+// (K1m, K1's sawn: 52 -> 46 us); K1's sinebuf takes neither (see wrap_at_511).
+constexpr int kTickLean = 3;
+template <int WF, int FL>
+constexpr int tab_copy() {
+    return (FL & 1) ? (WF == MXG_OSC_SINEBUF ? 520 : (WF == MXG_OSC_SAWN ? 1008 : 0)) : 0;
+}
+constexpr int kSb4Copy = 520;     // sinebuf4 on the device: four copies of the 515-entry table this far apart (osc_tick; osc.hip load_tab)
 constexpr int kSineOddOff = 515;  // (odd and >= the table's 515 entries: element i of the second copy is 16-byte aligned for odd i; osc.hip asserts)
-template <int WF, bool TRUST = false>
+template <int WF, bool TRUST = false, int FL = 0>
 __device__ __forceinline__ double osc_tick(double &phase, double &hold, const OscPre &q,
                                            const double *s_sine, const double *s_trans) {
     if constexpr (WF == MXG_OSC_SINEWAVE) {  // C:228-235
-        double r = sin_2pi_phase<TRUST>(phase, s_sine);
+        double r = sin_2pi_phase<TRUST>(phase, s_sine, q.sk);
         hold = r;
-        phase = wrap_at_one(phase);
+        phase = wrap_at_one<TRUST>(phase);
         phase += q.inc;
         return r;
     } else if constexpr (WF == MXG_OSC_COSWAVE) {  // C:276-283
-        double r = cos_2pi_phase<TRUST>(phase, s_sine);
+        double r = cos_2pi_phase<TRUST>(phase, s_sine, q.sk);
         hold = r;
-        phase = wrap_at_one(phase);
+        phase = wrap_at_one<TRUST>(phase);
         phase += q.inc;
         return r;
     } else if constexpr (WF == MXG_OSC_PHASOR) {  // C:285-291
@@ -139,15 +169,15 @@ __device__ __forceinline__ double osc_tick(double &phase, double &hold, const Os
         return r;
     } else if constexpr (WF == MXG_OSC_SINEBUF) {  // C:266-274
         phase += q.inc;
-        if (phase >= 511) phase -= 512;
+        phase = wrap_at_511<(FL & 2) != 0>(phase);
         double remainder = phase - floor(phase);
         int i = (int)phase;  // (long)phase: truncation toward zero; |phase| < 2^31 here
-        double r = (1 - remainder) * s_sine[1 + i + 1] + remainder * s_sine[2 + i + 1];
+        double r = (1 - remainder) * s_sine[1 + i + 1] + remainder * s_sine[2 + i + 1 + tab_copy<WF, FL>()];
         hold = r;
         return r;
     } else if constexpr (WF == MXG_OSC_SINEBUF4) {  // C:237-264
         phase += q.inc;
-        if (phase >= 511) phase -= 512;
+        phase = wrap_at_511<true>(phase);
         double remainder = phase - floor(phase);
         int i = (int)phase;
 #if defined(__HIP_DEVICE_COMPILE__) && MXG_SB4_PAIRS
@@ -160,6 +190,21 @@ __device__ __forceinline__ double osc_tick(double &phase, double &hold, const Os
         double a = ab.x;
         if (__builtin_expect(phase == 0, 0)) a = s_sine[513];
         const double b = ab.y, c = cd.x, d = cd.y;
+#elif defined(__HIP_DEVICE_COMPILE__)
+        // a, b, c, d = sineBuffer[i-1 .. i+2] = s_sine[i .. i+3] from ONE address; `phase == 0` -- a voice at rest: frequency 0 -- reads
+        // sineBuffer[512] for `a` instead (C:245-256; index -1 is the 0.0 guard s_sine[0]).  That case is taken out of line behind a
+        // wave-level test: as a per-lane select of the INDEX it costs a select and a second address (3 of the 33 VALU instructions
+        // of a kernel that is bound by them) on every sample of every voice.
+        // Four ds_read_b64 (~7 LDS cycles each at 64 unrelated addresses), not the two ds_read2_b64 hipcc makes of four reads off one
+        // base (~20 each: that instruction is served 16 lanes at a time over 32 banks, and the LDS pipe of a CU, shared by its four
+        // SIMDs, would become the bound in place of the VALU): the kernels keep FOUR copies of the table, kSb4Copy doubles apart --
+        // further than a ds_read2's offsets reach -- and element i + j comes from copy j.
+        const double *t = s_sine + i;
+        double a = t[0];
+        const double b = t[kSb4Copy + 1], c = t[2 * kSb4Copy + 2], d = t[3 * kSb4Copy + 3];
+        if (__builtin_expect(__any(phase == 0), 0)) {
+            if (phase == 0) a = s_sine[513];
+        }
 #else
         int ia = (phase == 0) ? 512 : i - 1;  // C:245-256; index -1 is the 0.0 guard
         double a = s_sine[ia + 1];
@@ -183,7 +228,7 @@ __device__ __forceinline__ double osc_tick(double &phase, double &hold, const Os
         temp += 500.0;
         double remainder = temp - floor(temp);
         int i = (int)temp;
-        double r = ((1.0 - remainder) * s_trans[i] + remainder * s_trans[1 + i]) - phase;
+        double r = ((1.0 - remainder) * s_trans[i] + remainder * s_trans[1 + i + tab_copy<WF, FL>()]) - phase;
         hold = r;
         return r;
     }
@@ -212,7 +257,7 @@ __device__ __forceinline__ void osc_pipe_phase_half(double &phase, const OscPre 
     for (int i = HALF * (K / 2); i < (HALF + 1) * (K / 2); i++) {
         if constexpr (WF == MXG_OSC_SINEBUF) {
             phase += q.inc;
-            if (phase >= 511) phase -= 512;
+            phase = wrap_at_511<true>(phase);
             p.rem[i] = phase - floor(phase);
             p.idx[i] = (int)phase + 2;
         } else {
@@ -239,7 +284,7 @@ __device__ __forceinline__ void osc_pipe_fetch(OscPipe<K> &p, const double *s_ta
 #pragma unroll
     for (int i = 0; i < K; i++) {
         p.t0[i] = s_tab[p.idx[i]];
-        p.t1[i] = s_tab[p.idx[i] + 1];
+        p.t1[i] = s_tab[p.idx[i] + 1 + tab_copy<WF, kTickLean>()];
     }
 }
 template <int WF, int K>
@@ -270,7 +315,7 @@ __device__ __forceinline__ void osc_tick_chunk(double &phase, double &hold, cons
     }
 #endif
 #pragma unroll
-    for (int i = 0; i < K; i++) r[i] = osc_tick<WF>(phase, hold, q, s_sine, s_trans);
+    for (int i = 0; i < K; i++) r[i] = osc_tick<WF, false, kTickLean>(phase, hold, q, s_sine, s_trans);
 }
 
 // The recurrence of one sample WITHOUT its output: exactly the phase operations of osc_tick, in its order.  For the
@@ -291,7 +336,7 @@ __device__ __forceinline__ void osc_skip(double &phase, double &hold, const OscP
         phase += q.inc;
     } else if constexpr (WF == MXG_OSC_SINEBUF || WF == MXG_OSC_SINEBUF4) {
         phase += q.inc;
-        if (phase >= 511) phase -= 512;
+        phase = wrap_at_511<true>(phase);
     } else if constexpr (WF == MXG_OSC_SAWN) {
         if (phase >= 0.5) phase -= 1.0;
         phase += q.inc;

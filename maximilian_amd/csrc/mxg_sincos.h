@@ -155,9 +155,24 @@ __device__ __forceinline__ double cos_small(double x) {
 #else
 #define MXG_NO_CONTRACT __attribute__((optimize("fp-contract=off")))  // host builds of this text (tests): the same
 #endif
-// TRUST: the caller guarantees 0 <= x <= 64 (an oscillator whose phase stays in [0, 2]): no range test, no sign to restore.
+// The two polynomial coefficients that enter an FMA next to another constant (z*k1 + k0: gfx950 takes ONE scalar operand per VALU
+// instruction, so k0 sits in a vector register).  A caller with a loop passes them in, loaded once and made opaque to the optimizer --
+// which otherwise re-creates each from its literal with a v_mov_b64 per sample (round 4: 1 of sinewave's 43 instructions).
+struct SinTabK {
+    double s120, c24;
+};
+__device__ __forceinline__ SinTabK sintab_k() {
+    SinTabK k = {1.0 / 120, 1.0 / 24};
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(k.s120), "+v"(k.c24));
+#endif
+    return k;
+}
+// TRUST: the caller guarantees 0 <= x <= 4 pi (an oscillator whose phase stays in [0, 2]) AND a table of MXG_SINTAB_WIDE_LEN doubles
+// (entries 0 .. 1024: the period and its repetition): no range test, no sign to restore, no index wrap.
+#define MXG_SINTAB_WIDE_LEN (4 * 1025)
 template <bool COS, bool TRUST = false>
-MXG_NO_CONTRACT __device__ __forceinline__ double sincos_tab(double x, const double *tab) {
+MXG_NO_CONTRACT __device__ __forceinline__ double sincos_tab(double x, const double *tab, const SinTabK k = {1.0 / 120, 1.0 / 24}) {
     if constexpr (!TRUST)
         if (!(fabs(x) <= 64.0)) return COS ? cos(x) : sin(x);
     const double ax = TRUST ? x : fabs(x);
@@ -166,13 +181,13 @@ MXG_NO_CONTRACT __device__ __forceinline__ double sincos_tab(double x, const dou
     const double w = fk * MXG_SINTAB_P2;            // exact
     const double bh = r1 - w;
     const double bl = fma(-fk, MXG_SINTAB_P3, (r1 - bh) - w);
-    const double *e = tab + 4 * ((int)fk & 511);
+    const double *e = tab + 4 * (TRUST ? (int)fk : ((int)fk & 511));
     const double Sh = e[0], Sl = e[1], Ch = e[2], Cl = e[3];
     const double z = bh * bh;
     using sincos_detail::fma_k;
     using sincos_detail::fma_kk;
-    const double sc = fma(bh * z, fma_k(z, fma_kk(z, -1.0 / 5040, 1.0 / 120), -1.0 / 6), bl);  // sin b - bh
-    const double cm1 = z * fma_k(z, fma_kk(z, -1.0 / 720, 1.0 / 24), -0.5);                    // cos b - 1
+    const double sc = fma(bh * z, fma_k(z, fma_kk(z, -1.0 / 5040, k.s120), -1.0 / 6), bl);  // sin b - bh
+    const double cm1 = z * fma_k(z, fma_kk(z, -1.0 / 720, k.c24), -0.5);                    // cos b - 1
     const double Ah = COS ? Ch : Sh, Al = COS ? Cl : Sl, Bh = COS ? -Sh : Ch, Bl = COS ? -Sl : Cl;
     double t = fma(Bh, sc, Ah * cm1);
     t = t + fma(Bl, bh, Al);
@@ -184,14 +199,14 @@ MXG_NO_CONTRACT __device__ __forceinline__ double sincos_tab(double x, const dou
 }
 
 template <bool TRUST = false>
-__device__ __forceinline__ double sin_2pi_phase(double phase, const double *sintab) {
+__device__ __forceinline__ double sin_2pi_phase(double phase, const double *sintab, const SinTabK k = {1.0 / 120, 1.0 / 24}) {
     double x = phase * (MXG_TWOPI);
-    return sincos_tab<false, TRUST>(x, sintab);
+    return sincos_tab<false, TRUST>(x, sintab, k);
 }
 template <bool TRUST = false>
-__device__ __forceinline__ double cos_2pi_phase(double phase, const double *sintab) {
+__device__ __forceinline__ double cos_2pi_phase(double phase, const double *sintab, const SinTabK k = {1.0 / 120, 1.0 / 24}) {
     double x = phase * (MXG_TWOPI);
-    return sincos_tab<true, TRUST>(x, sintab);
+    return sincos_tab<true, TRUST>(x, sintab, k);
 }
 
 }  // namespace mxg

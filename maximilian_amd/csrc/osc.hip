@@ -36,23 +36,37 @@ constexpr bool uses_sine() {
 }
 // the table a waveform's tick reads from LDS: sineBuffer (sinebuf / sinebuf4), transition (sawn), sin / cos of k*pi/256 (sinewave / coswave)
 static_assert((kSineOddOff & 1) == 1 && kSineOddOff >= MAXI_SINE_TAB_LEN, "parity copy of the sine table");
-template <int WF>
+static_assert(tab_copy<MXG_OSC_SINEBUF, 1>() >= MAXI_SINE_TAB_LEN, "sinebuf's table copy");
+static_assert(tab_copy<MXG_OSC_SAWN, 1>() >= MAXI_TRANS_TAB_LEN, "sawn's table copy");
+static_assert(kSb4Copy >= MAXI_SINE_TAB_LEN && (kSb4Copy - 2) * 8 > 255 * 8, "sinebuf4's table copies: disjoint, and out of a ds_read2_b64's reach");
+template <int WF, int FL = 0>
 constexpr int tab_len() {
-    return (WF == MXG_OSC_SINEBUF4 && MXG_SB4_PAIRS) ? kSineOddOff + MAXI_SINE_TAB_LEN + 1 : uses_sine<WF>() ? MAXI_SINE_TAB_LEN
-                           : (WF == MXG_OSC_SAWN ? MAXI_TRANS_TAB_LEN
-                                                 : ((WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE) ? MXG_SINTAB_LEN : 1));
+    return (WF == MXG_OSC_SINEBUF4 && MXG_SB4_PAIRS) ? kSineOddOff + MAXI_SINE_TAB_LEN + 1
+           : WF == MXG_OSC_SINEBUF4                  ? 4 * kSb4Copy
+           : uses_sine<WF>()                         ? tab_copy<WF, FL>() + MAXI_SINE_TAB_LEN
+                           : (WF == MXG_OSC_SAWN ? tab_copy<WF, FL>() + MAXI_TRANS_TAB_LEN
+                                                 : ((WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE) ? MXG_SINTAB_WIDE_LEN : 1));
 }
-template <int WF>
+template <int WF, int FL = 0>
 __device__ __forceinline__ void load_tab(double *s_tab) {  // (the caller synchronises)
     if constexpr (uses_sine<WF>()) {
         for (int i = threadIdx.x; i < MAXI_SINE_TAB_LEN; i += blockDim.x) {
             s_tab[i] = MAXI_SINE_TAB_D[i];
             if constexpr (WF == MXG_OSC_SINEBUF4 && MXG_SB4_PAIRS) s_tab[kSineOddOff + i] = MAXI_SINE_TAB_D[i];  // the parity copy (osc_tick)
+            if constexpr (tab_copy<WF, FL>() != 0) s_tab[tab_copy<WF, FL>() + i] = MAXI_SINE_TAB_D[i];  // sinebuf: the copy (osc_tick)
+            if constexpr (WF == MXG_OSC_SINEBUF4 && !MXG_SB4_PAIRS) {  // the four copies (osc_tick)
+                s_tab[kSb4Copy + i] = MAXI_SINE_TAB_D[i];
+                s_tab[2 * kSb4Copy + i] = MAXI_SINE_TAB_D[i];
+                s_tab[3 * kSb4Copy + i] = MAXI_SINE_TAB_D[i];
+            }
         }
     } else if constexpr (WF == MXG_OSC_SAWN) {
-        for (int i = threadIdx.x; i < MAXI_TRANS_TAB_LEN; i += blockDim.x) s_tab[i] = MAXI_TRANS_TAB_D[i];
+        for (int i = threadIdx.x; i < MAXI_TRANS_TAB_LEN; i += blockDim.x) {
+            s_tab[i] = MAXI_TRANS_TAB_D[i];
+            if constexpr (tab_copy<WF, FL>() != 0) s_tab[tab_copy<WF, FL>() + i] = MAXI_TRANS_TAB_D[i];
+        }
     } else if constexpr (WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE) {
-        for (int i = threadIdx.x; i < MXG_SINTAB_LEN; i += blockDim.x) s_tab[i] = MXG_SINTAB_D[i];
+        for (int i = threadIdx.x; i < MXG_SINTAB_WIDE_LEN; i += blockDim.x) s_tab[i] = MXG_SINTAB_D[i & (MXG_SINTAB_LEN - 1)];  // entries 0 .. 1024
     }
 }
 
@@ -74,9 +88,15 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
     // every resident wavefront walking down the SAME rows at the same time, one contiguous row slice per pass -- instead of 2, 3, ...
     // wavefronts per SIMD drifting apart over rows that are megabytes long (profiles/r04_osc_grid.md)
     // All LDS in ONE array (a second __shared__ object perturbs hipcc's waitcnt placement).
-    __shared__ __attribute__((aligned(16))) double s_tab[tab_len<WF>()];
-    if constexpr (tab_len<WF>() > 1) {
-        load_tab<WF>(s_tab);
+    // Which form of the tick and of the loop a waveform gets is decided by MEASUREMENT (profiles/r04_heavy_osc.md): the VALU-bound
+    // ones (sinewave, coswave, sinebuf4) and sawn take the lean forms -- 32-bit trip count, two table copies, three-instruction wrap:
+    // sawn 52 -> 46 us, sinebuf4 57 -> 52, sinewave 61 -> 58 -- while sinebuf and the table-free waveforms, whose time is the store
+    // stream's, keep the loop they were tuned with: every one of these changes made sinebuf SLOWER (41 -> 46 us with all three).
+    constexpr bool kLean = WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE || WF == MXG_OSC_SINEBUF4 || WF == MXG_OSC_SAWN;
+    constexpr int kFL = kLean ? kTickLean : 0;
+    __shared__ __attribute__((aligned(16))) double s_tab[tab_len<WF, kFL>()];
+    if constexpr (tab_len<WF, kFL>() > 1) {
+        load_tab<WF, kFL>(s_tab);
         __syncthreads();
     }
     for (int pass = 0; pass < passes; pass++) {
@@ -121,27 +141,46 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
 #ifndef MXG_OSC_UNROLL
 #define MXG_OSC_UNROLL 4
 #endif
-    // sinewave / coswave with 0 <= inc <= 1 and the phase in [0, 2] on every lane of the wavefront (any audio frequency from a
-    // fresh or carried bank): the argument of sin / cos stays in [0, 4 pi], so the table routine needs neither its range test nor
-    // a sign (mxg_sincos.h, TRUST)
+
+    // sinewave / coswave with 0 <= inc < 1 and the phase in [0, 2) on every lane of the wavefront (any audio frequency from a
+    // fresh or carried bank): the argument of sin / cos stays in [0, 4 pi), so the table routine needs neither its range test nor
+    // a sign nor an index wrap (mxg_sincos.h, TRUST: the LDS table holds the period twice), and the phase wrap is v_fract_f64
     bool trust = false;
     if constexpr ((WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE) && !FPS) {
         bool ok = true;
 #pragma unroll
-        for (int j = 0; j < VPL; j++) ok = ok && q[j].inc >= 0.0 && q[j].inc <= 1.0 && ph[j] >= 0.0 && ph[j] <= 2.0;
+        for (int j = 0; j < VPL; j++)  // (sign bits clear: a -0.0 phase or increment takes the general form)
+            ok = ok && q[j].inc >= 0.0 && q[j].inc < 1.0 && ph[j] >= 0.0 && ph[j] < 2.0 && (__double2hiint(ph[j]) | __double2hiint(q[j].inc)) >= 0;
         trust = __all(ok);
+        if (trust) {
+#pragma unroll
+            for (int j = 0; j < VPL; j++) q[j].sk = sintab_k();  // the two vector-register coefficients, loaded once (mxg_sincos.h)
+        }
     }
     auto run = [&](auto trust_tag) {
         constexpr bool kTrust = decltype(trust_tag)::value;
         size_t n = nA;
         if constexpr (PX && VPL == 1 && !FPS) {
             double *op = out + (nA + (threadIdx.x & 1)) * V + (v0 & ~(size_t)1);
+            if constexpr (!kLean) {
 #pragma unroll 2
-            for (; n + 2 <= nB; n += 2) {
-                const double r0 = osc_tick<WF, kTrust>(ph[0], hd[0], q[0], s_tab, s_tab);
-                const double r1 = osc_tick<WF, kTrust>(ph[0], hd[0], q[0], s_tab, s_tab);
-                store_pair_rows<ST>(op, r0, r1);
-                op += 2 * V;
+                for (; n + 2 <= nB; n += 2) {
+                    const double r0 = osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab);
+                    const double r1 = osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab);
+                    store_pair_rows<ST, false>(op, r0, r1);
+                    op += 2 * V;
+                }
+            } else {
+                // (a 32-bit trip count: gfx950 has no scalar 64-bit less-than, and hipcc then tests a size_t bound with two VALU
+                // instructions per iteration -- in a loop whose VALU-bound forms have ~35 per sample)
+                const unsigned pairs = (unsigned)((nB - nA) >> 1);
+                for (unsigned k = 0; k < pairs; k++) {
+                    const double r0 = osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab);
+                    const double r1 = osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab);
+                    store_pair_rows<ST>(op, r0, r1);
+                    op += 2 * V;
+                }
+                n = nA + 2 * (size_t)pairs;
             }
             o = out + n * V + v0;
         }
@@ -151,7 +190,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
 #pragma unroll
             for (int j = 0; j < VPL; j++) {
                 if constexpr (FPS) q[j] = osc_pre<WF>(fp[j], sr, pp ? pp[j] : q[j].p1, q[j].p2);
-                r[j] = osc_tick<WF, kTrust>(ph[j], hd[j], q[j], s_tab, s_tab);
+                r[j] = osc_tick<WF, kTrust, kFL>(ph[j], hd[j], q[j], s_tab, s_tab);
             }
             if constexpr (VPL == 2)
                 store2<ST>(o, r[0], r[1]);
@@ -217,11 +256,11 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
                                                       double *__restrict__ phase_io, double *__restrict__ hold_io,
                                                       double *__restrict__ out, const double *__restrict__ pan,
                                                       double *__restrict__ partial, double sr, PartSync psync, int passes) {
-    constexpr int kTab = tab_len<WF>();
+    constexpr int kTab = tab_len<WF, kTickLean>();
     constexpr int kTabPad = (kTab + 1) & ~1;  // the tiles are read with 16-byte loads
     __shared__ __attribute__((aligned(16))) double s_all[kTabPad + 4 * kTileWave + 4 * WIN * 2 + 256];
     double *s_tab = s_all;
-    load_tab<WF>(s_tab);
+    load_tab<WF, kTickLean>(s_tab);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *tile = s_all + kTabPad + wave * kTileWave;
     double *s_part = s_all + kTabPad + 4 * kTileWave;  // [4 waves][WIN][2]
@@ -401,7 +440,7 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
                     __builtin_amdgcn_sched_barrier(0);
 #else
 #pragma unroll
-                    for (int i = 0; i < kMixChunk; i++) r[i] = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+                    for (int i = 0; i < kMixChunk; i++) r[i] = osc_tick<WF, false, kTickLean>(ph, hd, q, s_tab, s_tab);
 #endif
 #pragma unroll
                     for (int i = 0; i < kMixChunk; i += 2) {
@@ -428,7 +467,7 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
                     for (int i = 0; i < kMixChunk; i++) {
                         double r = 0.0;
                         if (kFull || i < cnt) {  // ragged last chunk: the state must not advance past N
-                            r = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+                            r = osc_tick<WF, false, kTickLean>(ph, hd, q, s_tab, s_tab);
                             if constexpr (STORE != 0) {
                                 *o = r;
                                 o += V;
@@ -487,11 +526,11 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
                                                         double *__restrict__ phase_io, double *__restrict__ hold_io,
                                                         double *__restrict__ out, const double *__restrict__ pan,
                                                         double *__restrict__ partial, double sr, int passes) {
-    constexpr int kTab = tab_len<WF>();
+    constexpr int kTab = tab_len<WF, kTickLean>();
     constexpr int kTabPad = (kTab + 1) & ~1;
     __shared__ __attribute__((aligned(16))) double s_all[kTabPad + 4 * kPcRing * kTileWave + 4 * WIN * 2 + 256 + 8];
     double *s_tab = s_all;
-    load_tab<WF>(s_tab);
+    load_tab<WF, kTickLean>(s_tab);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool producer = wave < 4;
     const int pw = wave & 3;  // the pair
@@ -552,8 +591,8 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
                     if (cnt == kMixChunk && STORE == 2) {
 #pragma unroll
                         for (int i = 0; i < kMixChunk; i += 2) {
-                            const double r0 = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
-                            const double r1 = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+                            const double r0 = osc_tick<WF, false, kTickLean>(ph, hd, q, s_tab, s_tab);
+                            const double r1 = osc_tick<WF, false, kTickLean>(ph, hd, q, s_tab, s_tab);
                             store_pair_rows<2>(op, r0, r1);
                             op += 2 * V;
 #ifndef MXG_PC_NOTILE  // (A/B: the producer without its tile writes)
@@ -567,7 +606,7 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
                         for (int i = 0; i < kMixChunk; i++) {
                             double r = 0.0;
                             if (i < cnt) {  // ragged last chunk: the state must not advance past N
-                                r = osc_tick<WF>(ph, hd, q, s_tab, s_tab);
+                                r = osc_tick<WF, false, kTickLean>(ph, hd, q, s_tab, s_tab);
                                 if constexpr (STORE != 0) {
                                     *o = r;
                                     o += V;
@@ -837,6 +876,7 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     MXG_REQUIRE(waveform != MXG_OSC_PHASORBETWEEN || (d_p1 && d_p2),
                 "phasorBetween needs d_p1/d_p2 (start/end phase)");
     MXG_REQUIRE(fps >= 0 && fps <= 2 && (fps != 2 || d_p1), "fps is 0, 1 (d_freq [N][V]) or 2 (d_freq and d_p1 [N][V])");
+    MXG_REQUIRE(N <= 0xffffffffull, "a block holds at most 2^32 - 1 samples per voice");
     if (V == 0 || N == 0) return MXG_OK;
     // the store stream: knobs osc_vpl, osc_store, osc_xcd, osc_passes, osc_split (0 = automatic each); left alone, osc_single_rule / the plan
     // of launches below

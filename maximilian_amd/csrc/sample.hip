@@ -172,9 +172,12 @@ struct SmpArgs {
     double *tprev;        // [V] in/out, modes 9-14
     int32_t *tfirst;      // [V] in/out, modes 9-14
     double *out;
+    int px_store;         // pair-row store flavour (smp_emit), 0 = 8-byte stores
 };
 
-template <int MODE, bool XMOD>
+// PX: the whole chunks leave as 16-byte pair rows (emit_chunk, mxg_common.h) -- V even, out 16-byte aligned (round 4; same values, same
+// order per voice); SmpArgs::px_store: 1 / 2 / 3 = plain / write-through / non-temporal stores.
+template <int MODE, bool XMOD, bool PX>
 __global__ void __launch_bounds__(256) sample_kernel(SmpArgs A) {
     const size_t V = A.V, N = A.N;
     const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -223,13 +226,8 @@ __global__ void __launch_bounds__(256) sample_kernel(SmpArgs A) {
                 }
             };
             auto retire = [&](double2v(&d)[4]) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    *op = d[j].x;
-                    op += V;
-                    *op = d[j].y;
-                    op += V;
-                }
+                const double o[8] = {d[0].x, d[0].y, d[1].x, d[1].y, d[2].x, d[2].y, d[3].x, d[3].y};
+                emit_chunk<PX>(op, V, o, A.px_store);
                 __builtin_amdgcn_sched_barrier(0);
             };
             request(0, a0);
@@ -311,11 +309,10 @@ __global__ void __launch_bounds__(256) sample_kernel(SmpArgs A) {
 #pragma unroll
                 for (int l = 0; l < L; l++) vnext[i][l] = amp[rnext[i].idx[l]];
             }
+            double o[U];
 #pragma unroll
-            for (int i = 0; i < U; i++) {
-                *op = smp_eval<MODE>(rcur[i], vcur[i]);
-                op += V;
-            }
+            for (int i = 0; i < U; i++) o[i] = smp_eval<MODE>(rcur[i], vcur[i]);
+            emit_chunk<PX>(op, V, o, A.px_store);
             // keep the next stage's arithmetic on this stage's input loads from being scheduled
             // up here, in front of the stores (it would have to wait for loads just issued)
             __builtin_amdgcn_sched_barrier(0);
@@ -386,7 +383,7 @@ __device__ __forceinline__ void smp_skip(double &pos, const double step, const d
     }
 }
 
-template <int MODE, bool PIPE>
+template <int MODE, bool PIPE, bool PX>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) sample_parts_kernel(SmpArgs A, const size_t part_len, PartSync psync) {
     __shared__ double s_win[4 * 64 * kRowDoubles];
     const size_t V = A.V, N = A.N;
@@ -562,14 +559,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) s
     };
     auto render = [&](const Chunk &C) {
         Req q;
+        double o[U];
         if (C.allok) {
 #pragma unroll
             for (int i = 0; i < U; i++) {
                 const double val[2] = {row[C.tap[i]], row[C.tap[i] + 1]};
                 q.rem = C.rem[i];
                 q.ok = true;
-                *op = smp_eval<MODE>(q, val);
-                op += V;
+                o[i] = smp_eval<MODE>(q, val);
             }
         } else {
 #pragma unroll
@@ -577,10 +574,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) s
                 const double val[2] = {row[C.tap[i]], row[C.tap[i] + 1]};
                 q.rem = C.rem[i];
                 q.ok = (C.ok >> i) & 1u;
-                *op = smp_eval<MODE>(q, val);
-                op += V;
+                o[i] = smp_eval<MODE>(q, val);
             }
         }
+        emit_chunk<PX>(op, V, o, A.px_store);
         smp_lds_sync();  // the rows are free again
     };
     size_t n = n0;
@@ -648,10 +645,13 @@ template <int M>
 void launch_sample(bool xmod, dim3 grid, dim3 block, hipStream_t st, const SmpArgs &A) {
     constexpr bool kHasSpeed = smp_base(M) >= 4 && M != 14;
     KernelTimer kt("sample_kernel", st);
-    if (kHasSpeed && xmod)
-        hipLaunchKernelGGL((sample_kernel<M, kHasSpeed>), grid, block, 0, st, A);
-    else
-        hipLaunchKernelGGL((sample_kernel<M, false>), grid, block, 0, st, A);
+    if (kHasSpeed && xmod) {
+        if (A.px_store) hipLaunchKernelGGL((sample_kernel<M, kHasSpeed, true>), grid, block, 0, st, A);
+        else hipLaunchKernelGGL((sample_kernel<M, kHasSpeed, false>), grid, block, 0, st, A);
+    } else {
+        if (A.px_store) hipLaunchKernelGGL((sample_kernel<M, false, true>), grid, block, 0, st, A);
+        else hipLaunchKernelGGL((sample_kernel<M, false, false>), grid, block, 0, st, A);
+    }
 }
 
 // maxiSample::playAtSpeedBetweenPointsFromPos (C:826-880) with the caller's `pos`: a pure function of its arguments (the
@@ -741,12 +741,20 @@ int mxg_delay_render(int mode, size_t V, size_t N, const double *d_in, const int
     if (block > 256) block = 256;  // delay_kernel is compiled for <= 256 lanes per workgroup
     hipStream_t st = resolve_stream(stream);
     KernelTimer kt("delay_kernel", st);
-    if (mode == 0)
-        hipLaunchKernelGGL((delay_kernel<0>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_size,
-                           d_feedback, d_position, d_mem, (int)cap, d_phase, d_out);
-    else
-        hipLaunchKernelGGL((delay_kernel<1>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_size,
-                           d_feedback, d_position, d_mem, (int)cap, d_phase, d_out);
+    // 16-byte pair-row input / output streams for dl (knob rw_store: 0 automatic = write-through stores for blocks from 64 MB, 1 off,
+    // 2 / 3 / 4 plain / write-through / non-temporal stores)
+    int rw = tune_get("rw_store");
+    const bool pairs_ok = mode == 0 && !(V & 1) && !(((uintptr_t)d_in) & 15) && !(((uintptr_t)d_out) & 15);
+    if (rw == 0) rw = (V * N * sizeof(double) >= ((size_t)64 << 20)) ? 3 : 1;
+#define MXG_DL(M, X)                                                                                              \
+    hipLaunchKernelGGL((delay_kernel<M, X>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_size, d_feedback, \
+                       d_position, d_mem, (int)cap, d_phase, d_out)
+    if (mode == 1) MXG_DL(1, 0);
+    else if (!pairs_ok || rw < 2) MXG_DL(0, 0);
+    else if (rw == 2) MXG_DL(0, 1);
+    else if (rw == 3) MXG_DL(0, 2);
+    else MXG_DL(0, 3);
+#undef MXG_DL
     return check_hip(hipGetLastError(), "delay_kernel launch");
 }
 
@@ -791,7 +799,7 @@ int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, siz
     if (block > 256) block = 256;  // sample_kernel is compiled for <= 256 lanes per workgroup
     hipStream_t st = resolve_stream(stream);
     const SmpArgs A = {V, N, d_samples, len, (double)q, (double)settings().sampleRate, d_a, nullptr,
-                       d_start, d_end, d_position, nullptr, nullptr, d_out};
+                       d_start, d_end, d_position, nullptr, nullptr, d_out, rw_store_choice(V, N, d_out)};
     const bool xmod = mode >= 4 && aps;
     const dim3 grid = grid_for(V, block);
     if (mode >= 4 && mode <= 6 && !xmod) {
@@ -803,9 +811,18 @@ int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, siz
             if (int e = part_sync_get(st, (size_t)grid.x * ((block + 63) / 64), split, &part_ctrs)) return e;
             const bool pipe = tune_get("smp_pipe") != 0;
             KernelTimer kt("sample_parts_kernel", st);
-            if (mode == 4) { if (pipe) hipLaunchKernelGGL((sample_parts_kernel<4, true>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs); else hipLaunchKernelGGL((sample_parts_kernel<4, false>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs); }
-            if (mode == 5) { if (pipe) hipLaunchKernelGGL((sample_parts_kernel<5, true>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs); else hipLaunchKernelGGL((sample_parts_kernel<5, false>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs); }
-            if (mode == 6) { if (pipe) hipLaunchKernelGGL((sample_parts_kernel<6, true>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs); else hipLaunchKernelGGL((sample_parts_kernel<6, false>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs); }
+#define MXG_PARTS(M)                                                                                                                  \
+    if (pipe) {                                                                                                                       \
+        if (A.px_store) hipLaunchKernelGGL((sample_parts_kernel<M, true, true>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);   \
+        else hipLaunchKernelGGL((sample_parts_kernel<M, true, false>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);            \
+    } else {                                                                                                                          \
+        if (A.px_store) hipLaunchKernelGGL((sample_parts_kernel<M, false, true>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);  \
+        else hipLaunchKernelGGL((sample_parts_kernel<M, false, false>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);           \
+    }
+            if (mode == 4) { MXG_PARTS(4) }
+            if (mode == 5) { MXG_PARTS(5) }
+            if (mode == 6) { MXG_PARTS(6) }
+#undef MXG_PARTS
             return check_hip(hipGetLastError(), "sample_parts_kernel launch");
         }
     }
@@ -842,7 +859,7 @@ int mxg_sample_render_trig(int mode, size_t V, size_t N, const double *d_samples
     if (block > 256) block = 256;
     hipStream_t st = resolve_stream(stream);
     const SmpArgs A = {V, N, d_samples, len, (double)q, (double)settings().sampleRate, d_a, d_trig,
-                       d_p0, d_p1, d_position, d_tprev, d_tfirst, d_out};
+                       d_p0, d_p1, d_position, d_tprev, d_tfirst, d_out, rw_store_choice(V, N, d_out)};
     const bool xmod = aps != 0;
     const dim3 grid = grid_for(V, block);
     switch (mode) {

@@ -136,18 +136,29 @@ def test_sample_per_sample_speed_ragged(mx, golden, port, mode, N):
 
 @pytest.mark.parametrize("N", [3, 8, 24, 700, 1001])
 @pytest.mark.parametrize("sizes", ["uniform", "ge16", "mixed"])
-def test_delay_pipelined_paths(mx, port, N, sizes):
+@pytest.mark.parametrize("rw,V", [(0, 1024), (2, 1024), (3, 1000), (4, 130), (3, 1023)])
+def test_delay_pipelined_paths(mx, port, N, sizes, rw, V):
     """dl(): wavefronts whose lines all have size >= 16 take the pipelined path, the rest the plain
-    loop; both must give the reference's ring, phase and output, across two carried blocks."""
+    loop; both must give the reference's ring, phase and output, across two carried blocks.  rw: knob rw_store -- the whole chunks
+    of the pipelined path with 16-byte pair-row input / output streams (even banks; an odd bank keeps the 8-byte streams)."""
     rng = np.random.default_rng(N)
-    V, cap = 1024, 300
+    cap = 300
+    L = mx.lib()
+    prev = L.mxg_tune(b"rw_store", rw)
+    try:
+        _delay_pipelined_case(mx, port, rng, N, sizes, V, cap)
+    finally:
+        L.mxg_tune(b"rw_store", prev)
+
+
+def _delay_pipelined_case(mx, port, rng, N, sizes, V, cap):
     if sizes == "uniform":
         size = np.full(V, 257, np.int32)
     elif sizes == "ge16":
         size = rng.integers(16, cap + 1, V).astype(np.int32)
     else:
         size = rng.integers(1, cap + 1, V).astype(np.int32)
-        size[:256] = rng.integers(16, 40, 256)      # whole wavefronts on the pipelined path
+        size[:min(256, V)] = rng.integers(16, 40, min(256, V))      # whole wavefronts on the pipelined path
     x = rng.uniform(-1, 1, (2 * N, V))
     fb = rng.uniform(0, 0.9, V)
     bank = mx.maxiDelaylineBank(V, cap)

@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import maximilian_amd as mx
 L = mx.lib(); mx._lib.check(L.mxg_init(0), "init"); mx.maxiSettings.setup(44100, 2, 1024)
 V, B = 65536, 512
+if len(sys.argv) > 2 and sys.argv[1] == "--rw":    # knob rw_store: 1 = 8-byte streams, 2 / 3 / 4 = 16-byte pair rows plain / sc1 / nt (0 automatic)
+    L.mxg_tune(b"rw_store", int(sys.argv[2]))
+    print("# rw_store", sys.argv[2])
 rng = np.random.default_rng(1)
 e0, e1 = L.mxg_event_create(), L.mxg_event_create(); ms = ctypes.c_float()
 D = mx.DeviceBuffer.from_numpy
