@@ -226,9 +226,8 @@ int mxg_envgen_render(size_t V, size_t N, const double *d_trig, int tpv, const d
     if (V == 0 || N == 0) return MXG_OK;
     int block = tune_get("voice_block");
     if (block > 256) block = 256;
-    // the output stream (knob rw_store: 0 automatic = pair rows of write-through stores for blocks from 64 MB, 1 the 8-byte stores,
-    // 2 / 3 / 4 pair rows with plain / write-through / non-temporal stores)
-    const EgArgs A = {V, N, d_trig, tpv, nstages, loop, retrigger, d_stages, d_dst, d_ist, d_out, rw_store_choice(V, N, d_out)};
+    // the output stream (knob rw_store, rw_store_choice in mxg_common.h: automatic = pair rows of non-temporal stores from 98 304 voices)
+    const EgArgs A = {V, N, d_trig, tpv, nstages, loop, retrigger, d_stages, d_dst, d_ist, d_out, rw_store_choice(V, N, d_out, RW_ENVGEN)};
     const dim3 grid((unsigned)((V + block - 1) / block));
     hipStream_t st = resolve_stream(stream);
     KernelTimer kt("envgen_kernel", st);

@@ -36,12 +36,24 @@ int ensure_init_only();  // allocation, copies, creation: init on first use, pen
 hipStream_t resolve_stream(void *stream);
 int tune_get(const char *key);
 int device_cus();  // compute units of the device (256 on MI355X)
-// The out[n*V + v] stream of the read+write / write-only bank kernels (knob rw_store: 0 automatic = 16-byte pair rows of write-through stores
-// for blocks from 64 MB, 1 the 8-byte stores, 2 / 3 / 4 pair rows with plain / write-through / non-temporal stores): 0 = 8-byte stores, else
-// the px_store flavour of emit_chunk (1 / 2 / 3).  Pair rows need V even and a 16-byte aligned block.
-inline int rw_store_choice(size_t V, size_t N, const void *d_out) {
+// The out[n*V + v] stream of the read+write / write-only bank kernels (knob rw_store: 0 automatic, 1 the 8-byte stores, 2 / 3 / 4 16-byte
+// pair rows with plain / write-through / non-temporal stores): returns 0 = 8-byte stores, else the px_store flavour of emit_chunk (1 / 2 / 3).
+// Pair rows need V even and a 16-byte aligned block.  Automatic, from tools/sweep_rw_store.py over rotating 4 GiB arenas
+// (profiles/r04_rw_store.md), for blocks from 64 MB: kernels that READ a block and write one (maxiFilter, maxiEnv, filter2) take the
+// write-through pair rows (65 536 voices: lores 117 -> 98 us, adsr in sustain 116 -> 96); kernels that only WRITE (maxiSample, maxiEnvGen)
+// and maxiDelayline (whose ring traffic dominates) the non-temporal ones (131 072 voices: playAtSpeed 140 -> 120 us, maxiEnvGen 120 -> 106;
+// write-through is SLOWER than 8-byte stores there) -- maxiEnvGen only from 98 304 voices: at 65 536 its state-machine path is faster
+// with 8-byte stores (55 against 60-62 us).
+enum RwFamily { RW_READ_WRITE, RW_WRITE_ONLY, RW_ENVGEN };
+inline int rw_store_choice(size_t V, size_t N, const void *d_out, RwFamily fam = RW_READ_WRITE) {
     int rw = tune_get("rw_store");
-    if (rw == 0) rw = (V * N * sizeof(double) >= ((size_t)64 << 20)) ? 3 : 1;
+    if (rw == 0) {
+        const bool big = V * N * sizeof(double) >= ((size_t)64 << 20);
+        if (!big) rw = 1;
+        else if (fam == RW_READ_WRITE) rw = 3;
+        else if (fam == RW_WRITE_ONLY) rw = 4;
+        else rw = V >= 98304 ? 4 : 1;
+    }
     const bool pairs_ok = V >= 2 && !(V & 1) && !(((uintptr_t)d_out) & 15);
     return (rw >= 2 && pairs_ok) ? rw - 1 : 0;
 }

@@ -741,11 +741,10 @@ int mxg_delay_render(int mode, size_t V, size_t N, const double *d_in, const int
     if (block > 256) block = 256;  // delay_kernel is compiled for <= 256 lanes per workgroup
     hipStream_t st = resolve_stream(stream);
     KernelTimer kt("delay_kernel", st);
-    // 16-byte pair-row input / output streams for dl (knob rw_store: 0 automatic = write-through stores for blocks from 64 MB, 1 off,
-    // 2 / 3 / 4 plain / write-through / non-temporal stores)
-    int rw = tune_get("rw_store");
-    const bool pairs_ok = mode == 0 && !(V & 1) && !(((uintptr_t)d_in) & 15) && !(((uintptr_t)d_out) & 15);
-    if (rw == 0) rw = (V * N * sizeof(double) >= ((size_t)64 << 20)) ? 3 : 1;
+    // 16-byte pair-row input / output streams for dl (knob rw_store, rw_store_choice in mxg_common.h: automatic = non-temporal stores for
+    // blocks from 64 MB)
+    const bool pairs_ok = mode == 0 && !(((uintptr_t)d_in) & 15);
+    const int rw = pairs_ok ? 1 + rw_store_choice(V, N, d_out, RW_WRITE_ONLY) : 1;  // (1 = 8-byte streams, 2 / 3 / 4 as the knob)
 #define MXG_DL(M, X)                                                                                              \
     hipLaunchKernelGGL((delay_kernel<M, X>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_size, d_feedback, \
                        d_position, d_mem, (int)cap, d_phase, d_out)
@@ -799,7 +798,7 @@ int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, siz
     if (block > 256) block = 256;  // sample_kernel is compiled for <= 256 lanes per workgroup
     hipStream_t st = resolve_stream(stream);
     const SmpArgs A = {V, N, d_samples, len, (double)q, (double)settings().sampleRate, d_a, nullptr,
-                       d_start, d_end, d_position, nullptr, nullptr, d_out, rw_store_choice(V, N, d_out)};
+                       d_start, d_end, d_position, nullptr, nullptr, d_out, rw_store_choice(V, N, d_out, RW_WRITE_ONLY)};
     const bool xmod = mode >= 4 && aps;
     const dim3 grid = grid_for(V, block);
     if (mode >= 4 && mode <= 6 && !xmod) {
@@ -859,7 +858,7 @@ int mxg_sample_render_trig(int mode, size_t V, size_t N, const double *d_samples
     if (block > 256) block = 256;
     hipStream_t st = resolve_stream(stream);
     const SmpArgs A = {V, N, d_samples, len, (double)q, (double)settings().sampleRate, d_a, d_trig,
-                       d_p0, d_p1, d_position, d_tprev, d_tfirst, d_out, rw_store_choice(V, N, d_out)};
+                       d_p0, d_p1, d_position, d_tprev, d_tfirst, d_out, rw_store_choice(V, N, d_out, RW_WRITE_ONLY)};
     const bool xmod = aps != 0;
     const dim3 grid = grid_for(V, block);
     switch (mode) {
