@@ -166,7 +166,11 @@ int mxg_tune(const char *key, int value);
  * synchronises for it: the NEXT call of any entry point (and every synchronising call -- mxg_stream_sync, mxg_sync,
  * mxg_memcpy_d2h -- after its wait) returns the failure as its status with the message in mxg_last_error(), once, and clears
  * it.  mxg_last_async_error() is that check by itself: MXG_OK, or the pending failure.  (Render entry points therefore never
- * block the host, and their launch sequences can be captured into a hipGraph; a captured launch reports the same way.) */
+ * block the host, and their launch sequences can be captured into a hipGraph; a captured launch reports the same way.)
+ * After a time-part time-out the caller must synchronise that stream and treat the state of every bank rendered on it since the failed
+ * launch as invalid (launches already enqueued behind it may have run from stale part counters): re-upload or re-create those banks.
+ * "rw_store" (mxg_tune) is documented with the render entry points that honour it (maxiFilter, maxiEnv, maxiDelayline, maxiSample,
+ * maxiEnvGen, filter2: 0 automatic, 1 8-byte streams, 2 / 3 / 4 16-byte pair rows with plain / write-through / non-temporal stores). */
 int mxg_last_async_error(void);
 
 /* ---- maxiOsc bank -------------------------------------------------------------------- */

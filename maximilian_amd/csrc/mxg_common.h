@@ -114,6 +114,11 @@ int async_error_status(int code);  // the status + message of one code
 // async error word and does NOT store -- the launch's state is lost, loudly, instead of a late part silently starting from
 // the new state -- and leaves the counter as it is; the host zeroes the counters again before the next split launch after an
 // error.  Otherwise the writer leaves the counter at zero.
+// CONTRACT after ASYNC_PART_TIMEOUT: the counters of that stream are not epoch-based, so split launches that were already
+// enqueued behind the failed one start from stale counts and may store early.  A caller that sees MXG_ERR_ASYNC with this code must
+// synchronise the stream and treat every bank state rendered on it since the failed launch as invalid (re-upload or re-create the
+// banks); include/maxigpu.h says so at mxg_last_async_error.  The time-out itself means a device that made no progress for
+// spin_limit x ~0.5 us on work that was dispatched BEFORE the writer -- it has only ever been seen under fault injection (knob part_fault).
 struct PartSync {
     int *ctrs = nullptr;   // one counter per wavefront of gridDim.x (zero between launches)
     int *err = nullptr;    // the async error word
