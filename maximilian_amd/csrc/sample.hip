@@ -383,8 +383,11 @@ __device__ __forceinline__ void smp_skip(double &pos, const double step, const d
     }
 }
 
+#ifndef MXG_SMP_WPE
+#define MXG_SMP_WPE 3  // A/B (tools/build_ab.sh): wavefronts per SIMD the time-part kernel is compiled for
+#endif
 template <int MODE, bool PIPE, bool PX>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) sample_parts_kernel(SmpArgs A, const size_t part_len, PartSync psync) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MXG_SMP_WPE))) sample_parts_kernel(SmpArgs A, const size_t part_len, PartSync psync) {
     __shared__ double s_win[4 * 64 * kRowDoubles];
     const size_t V = A.V, N = A.N;
     const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
