@@ -675,24 +675,35 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
 
 typedef void (*osc_mixpc_fn)(size_t, size_t, const double *, const double *, const double *, double *, double *, double *,
                              const double *, double *, double, int);
+// win: the combine window.  512 (a whole block of the usual length in ONE window: the producers meet a barrier only at the end of the
+// block, instead of waiting for the consumers' last chunk twice per block) where the waveform's table leaves room for [4][512][2] sums in
+// the 160 KB; 256 otherwise.
 template <int WF>
-osc_mixpc_fn pick_mixpc(int store) {
+constexpr bool mixpc_fits_512() {
+    return ((((tab_len<WF, kTickLean>() + 1) & ~1) + 4 * kPcRing * kTileWave + 4 * 512 * 2 + 256 + 8) * sizeof(double)) <= 160 * 1024;
+}
+template <int WF>
+osc_mixpc_fn pick_mixpc(int store, int win) {
+    if constexpr (mixpc_fits_512<WF>()) {
+        if (win == 512)
+            return store == 2 ? osc_mixpc_kernel<WF, 2, 512> : (store == 1 ? osc_mixpc_kernel<WF, 1, 512> : osc_mixpc_kernel<WF, 0, 512>);
+    }
     return store == 2 ? osc_mixpc_kernel<WF, 2, 256> : (store == 1 ? osc_mixpc_kernel<WF, 1, 256> : osc_mixpc_kernel<WF, 0, 256>);
 }
-osc_mixpc_fn pick_mixpc_wf(int wf, int store) {
+osc_mixpc_fn pick_mixpc_wf(int wf, int store, int win) {
     switch (wf) {
-        case 0: return pick_mixpc<0>(store);
-        case 1: return pick_mixpc<1>(store);
-        case 2: return pick_mixpc<2>(store);
-        case 3: return pick_mixpc<3>(store);
-        case 4: return pick_mixpc<4>(store);
-        case 5: return pick_mixpc<5>(store);
-        case 6: return pick_mixpc<6>(store);
-        case 7: return pick_mixpc<7>(store);
-        case 8: return pick_mixpc<8>(store);
-        case 9: return pick_mixpc<9>(store);
-        case 10: return pick_mixpc<10>(store);
-        case 11: return pick_mixpc<11>(store);
+        case 0: return pick_mixpc<0>(store, win);
+        case 1: return pick_mixpc<1>(store, win);
+        case 2: return pick_mixpc<2>(store, win);
+        case 3: return pick_mixpc<3>(store, win);
+        case 4: return pick_mixpc<4>(store, win);
+        case 5: return pick_mixpc<5>(store, win);
+        case 6: return pick_mixpc<6>(store, win);
+        case 7: return pick_mixpc<7>(store, win);
+        case 8: return pick_mixpc<8>(store, win);
+        case 9: return pick_mixpc<9>(store, win);
+        case 10: return pick_mixpc<10>(store, win);
+        case 11: return pick_mixpc<11>(store, win);
     }
     return nullptr;
 }
@@ -985,7 +996,9 @@ int osc_mix_launch(int waveform, size_t V, size_t N, const double *d_freq, const
     const int pc = tune_get("osc_mix_pc");
     if (split == 1 && (pc == 2 || (pc == 0 && nblocks >= 128))) {
         KernelTimer kt("osc_mix_kernel", st);
-        hipLaunchKernelGGL(pick_mixpc_wf(waveform, store), dim3((unsigned)grid_x), dim3(512), 0, st, V, N, d_freq, d_p1, d_p2, d_phase,
+        int pcwin = tune_get("osc_mix_pcwin");  // 0 automatic, 256, 512
+        if (pcwin == 0) pcwin = 512;
+        hipLaunchKernelGGL(pick_mixpc_wf(waveform, store, pcwin), dim3((unsigned)grid_x), dim3(512), 0, st, V, N, d_freq, d_p1, d_p2, d_phase,
                            d_outhold, d_out, d_pan, d_rows, (double)settings().sampleRate, passes);
         return check_hip(hipGetLastError(), "osc_mixpc_kernel launch");
     }

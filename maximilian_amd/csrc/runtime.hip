@@ -46,6 +46,7 @@ Tune g_tune[] = {
     {"osc_mix_store", 0, 0, 2},  // K1m per-voice block: 0 automatic, 1 plain 8-byte stores, 2 pair rows of write-through 16-byte stores
     {"osc_mix_split", 0, 0, 4},  // K1m time parts (0 automatic: two below 2048 wavefronts)
     {"osc_mix_pc", 0, 0, 2},  // K1m: producer / consumer wavefront pairs (0 automatic: from 32 768 voices, whole blocks only; 1 off; 2 on)
+    {"osc_mix_pcwin", 0, 0, 512},  // K1m, producer / consumer form: combine window (0 automatic = 512 where the waveform's table leaves room, 256 / 512)
     {"osc_mix_win", 0, 0, 256},  // K1m: samples per workgroup combine window (0 automatic: 256, 128 from 131 073 voices; 128 / 256)
     {"ifft_stream", 1, 0, 2},  // maxiIFFT: transform + hop buffer in one kernel (0: never; 1: where hop >= fftSize / 2; 2: wherever it fits)
     {"smp_pipe", 1, 0, 1},   // K5: the time-part kernel's loads of chunk k+1 issued before the stores of chunk k (0: chunk after chunk)

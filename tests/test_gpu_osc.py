@@ -248,8 +248,9 @@ def test_render_mix_fused(mx, port, wf, V, N):
             L.mxg_tune(b"osc_mix_store", prev[0]); L.mxg_tune(b"osc_mix_split", prev[1])
     # the two forms of the kernel -- one wavefront does everything (osc_mix_pc 1) / producer + consumer wavefront pairs (2) -- add the
     # same products in the same tree: the same bits for the block, the carried state and the mix
-    for pc in (1, 2):
+    for pc, pcwin in ((1, 0), (2, 256), (2, 512)):   # (osc_mix_pcwin: the producer / consumer form's combine window)
         prev = L.mxg_tune(b"osc_mix_pc", pc)
+        prev_win = L.mxg_tune(b"osc_mix_pcwin", pcwin)
         try:
             bank6 = mx.maxiOscBank(V)
             o6, m6 = bank6.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V))
@@ -262,6 +263,7 @@ def test_render_mix_fused(mx, port, wf, V, N):
             none, m7 = bank6.render_mix(wf, freq, pan, N, p1=p1, p2=np.ones(V), store=False)
         finally:
             L.mxg_tune(b"osc_mix_pc", prev)
+            L.mxg_tune(b"osc_mix_pcwin", prev_win)
     # passes (a workgroup renders several groups of 256 voices one after the other): the same rows, the same bits
     for mp in (2, 5):
         prev = L.mxg_tune(b"osc_mix_passes", mp)
