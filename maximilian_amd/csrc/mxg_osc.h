@@ -279,12 +279,31 @@ __device__ __forceinline__ void osc_pipe_phase(double &phase, const OscPre &q, O
     osc_pipe_phase_half<WF, K, 0>(phase, q, p);
     osc_pipe_phase_half<WF, K, 1>(phase, q, p);
 }
-template <int WF, int K>
+// FL: the caller's table layout (bit 0: the second value comes from the table's copy, tab_copy; K1m's kernels) -- 0: one plain table
+// (the per-voice tables of osctab.hip)
+// FL bit 2 (a table without a copy, e.g. a voice's own): the second value is read at the first one's LDS address plus an 8 the optimizer
+// cannot see through -- one more integer addition per sample, but two ds_read_b64 instead of one ds_read2_b64 (see tab_copy).
+template <int WF, int K, int FL = kTickLean>
 __device__ __forceinline__ void osc_pipe_fetch(OscPipe<K> &p, const double *s_tab) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr ((FL & 4) != 0) {
+        typedef __attribute__((address_space(3))) const double lds_cd;
+        unsigned eight = 8;
+        asm volatile("" : "+v"(eight));
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            lds_cd *a = (lds_cd *)(s_tab + p.idx[i]);  // (s_tab is LDS: the generic pointer's low 32 bits are the LDS address)
+            p.t0[i] = *a;
+            p.t1[i] = *(lds_cd *)(uintptr_t)((unsigned)(uintptr_t)a + eight);
+        }
+        return;
+    }
+#endif
+    const double *s_next = s_tab + 1 + tab_copy<WF, FL>();
 #pragma unroll
     for (int i = 0; i < K; i++) {
         p.t0[i] = s_tab[p.idx[i]];
-        p.t1[i] = s_tab[p.idx[i] + 1 + tab_copy<WF, kTickLean>()];
+        p.t1[i] = s_next[p.idx[i]];
     }
 }
 template <int WF, int K>

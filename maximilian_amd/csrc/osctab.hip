@@ -180,7 +180,10 @@ __global__ __launch_bounds__(512) void osctab_kernel(size_t V, size_t N, const d
         OscPipe<kMixChunk> P;
         osc_pipe_phase<MXG_OSC_SINEBUF, kMixChunk>(ph, q, P);
         __builtin_amdgcn_sched_barrier(0);
-        osc_pipe_fetch<MXG_OSC_SINEBUF, kMixChunk>(P, T);
+#ifndef MXG_TAB_SPLIT_READS
+#define MXG_TAB_SPLIT_READS 1  // A/B (tools/build_ab.sh): 0 = the two table values of a sample as one ds_read2_b64
+#endif
+        osc_pipe_fetch<MXG_OSC_SINEBUF, kMixChunk, MXG_TAB_SPLIT_READS ? 4 : 0>(P, T);  // (a voice's own table: no copy to read from)
         __builtin_amdgcn_sched_barrier(0);
         osc_pipe_finish<MXG_OSC_SINEBUF, kMixChunk>(P, r, hd);
         if constexpr (STORE) {
