@@ -1077,6 +1077,48 @@ __global__ void osc_noise_kernel(size_t count, size_t V, size_t N, const int32_t
         if (outhold && i >= count - V) outhold[i - (count - V)] = o;
     }
 }
+// The column walk that makes K1's store stream fast, for a kernel without state (round 4): a lane owns two adjacent voices and every OTHER
+// row (even lanes the even rows, odd lanes the odd ones), so that a wavefront's accesses are 256 contiguous bytes of draws and 512 of
+// output in each of two rows, and walks down the block; the draws of the next chunk of rows are requested before this chunk's stores
+// (loads and stores retire in order on one counter).  A grid-stride element-wise kernel reaches 0.62 of 8 TB/s on its 12 B per sample
+// whatever the access width -- with write-through 16-byte stores 0.30 -- this form [see profiles/r04_banks.md].  ST: store flavour.
+typedef int int2v __attribute__((ext_vector_type(2)));
+template <int ST>
+__global__ void __launch_bounds__(256) osc_noise_walk_kernel(size_t V, size_t N, const int32_t *__restrict__ rnd,
+                                                             double *__restrict__ outhold, double *__restrict__ out) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;  // (V even: pairs are live or dead together; nothing crosses lanes here anyway)
+    const size_t odd = threadIdx.x & 1, vp = v & ~(size_t)1;
+    const int32_t *ip = rnd + vp;
+    double *op = out + vp;
+    constexpr int U = 8;  // rows per lane and chunk (16 rows of the block)
+    const size_t rows = (N + 1 - odd) / 2;  // rows n = 2 j + odd < N
+    auto row_at = [&](size_t j) { return (j < rows ? 2 * j + odd : (rows ? 2 * (rows - 1) + odd : 0)); };  // clamped: no branch
+    if (rows == 0) return;
+    int2v nx[U];
+#pragma unroll
+    for (int i = 0; i < U; i++) nx[i] = __builtin_nontemporal_load(reinterpret_cast<const int2v *>(ip + row_at(i) * V));
+    for (size_t j0 = 0; j0 < rows; j0 += U) {
+        int2v cur[U];
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            cur[i] = nx[i];
+            nx[i] = __builtin_nontemporal_load(reinterpret_cast<const int2v *>(ip + row_at(j0 + U + i) * V));
+        }
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            if (j0 + i >= rows) break;
+            const size_t n = 2 * (j0 + i) + odd;
+            const float r0 = (float)cur[i].x / 2147483648.0f, r1 = (float)cur[i].y / 2147483648.0f;
+            const double o0 = (double)(r0 * 2.0f - 1.0f), o1 = (double)(r1 * 2.0f - 1.0f);
+            store2<ST>(op + n * V, o0, o1);
+            if (outhold && n + 1 == N) {  // the member `output`: the last row
+                outhold[vp] = o0;
+                outhold[vp + 1] = o1;
+            }
+        }
+    }
+}
 }  // namespace
 }  // namespace mxg
 
@@ -1087,9 +1129,21 @@ extern "C" int mxg_osc_noise(size_t V, size_t N, const int32_t *d_rand, double *
     MXG_REQUIRE(d_rand && d_out, "null device pointer");
     if (N == 0 || V == 0) return MXG_OK;
     const size_t count = V * N;
+    hipStream_t st = resolve_stream(stream);
+    KernelTimer kt("osc_noise_kernel", st);
+    // the column walk where whole voice pairs exist (knob rw_store as for the read + write bank kernels: 0 automatic = write-through stores
+    // for blocks from 64 MB, 1 the element-wise kernel, 2 / 3 / 4 plain / write-through / non-temporal 16-byte stores)
+    int flavour = (!(V & 1) && !(((uintptr_t)d_rand) & 7)) ? rw_store_choice(V, N, d_out, RW_READ_WRITE) : 0;
+    if (flavour == 2 && tune_get("rw_store") == 0 && V < 98304) flavour = 3;  // (measured: 65 536 voices 67.5 us non-temporal / 69.7 write-through; 131 072: 145 / 143)
+    if (flavour) {
+        const dim3 grid((unsigned)((V + 255) / 256));
+        if (flavour == 2) hipLaunchKernelGGL(osc_noise_walk_kernel<2>, grid, dim3(256), 0, st, V, N, d_rand, d_outhold, d_out);
+        else if (flavour == 3) hipLaunchKernelGGL(osc_noise_walk_kernel<1>, grid, dim3(256), 0, st, V, N, d_rand, d_outhold, d_out);
+        else hipLaunchKernelGGL(osc_noise_walk_kernel<0>, grid, dim3(256), 0, st, V, N, d_rand, d_outhold, d_out);
+        return check_hip(hipGetLastError(), "osc_noise_walk_kernel launch");
+    }
     size_t blocks = (count + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(osc_noise_kernel, dim3((unsigned)blocks), dim3(256), 0, resolve_stream(stream), count, V,
-                       N, d_rand, d_outhold, d_out);
+    hipLaunchKernelGGL(osc_noise_kernel, dim3((unsigned)blocks), dim3(256), 0, st, count, V, N, d_rand, d_outhold, d_out);
     return check_hip(hipGetLastError(), "osc_noise_kernel launch");
 }

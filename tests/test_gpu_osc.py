@@ -326,12 +326,17 @@ def test_osc_time_split_same_bits(mx, wf, V, N):
         L.mxg_tune(b"osc_split", prev)
 
 
-def test_noise_from_rand_draws(mx, port):
-    """maxiOsc::noise (C:214-220): the caller supplies the rand() draws, the float arithmetic is exact."""
-    V, N = 96, 257
-    rnd, e = port.noise(1234, V, N)
+@pytest.mark.parametrize("V,N,rw", [(96, 257, 0), (96, 257, 2), (96, 257, 3), (100, 33, 4), (98, 40, 3), (4, 1, 3), (2, 2, 4), (97, 12, 3), (4096, 513, 4), (700, 16, 2), (700, 17, 3)])
+def test_noise_from_rand_draws(mx, port, V, N, rw):
+    """maxiOsc::noise (C:214-220): the caller supplies the rand() draws, the float arithmetic is exact.  rw: knob rw_store -- the
+    column walk of round 4 (a lane owns two voices and every other row; odd banks keep the element-wise kernel)."""
+    rnd, e = port.noise(1234 + V, V, N)
     bank = mx.maxiOscBank(V)
-    o = bank.noise(rnd).numpy()
+    prev = mx.lib().mxg_tune(b"rw_store", rw)
+    try:
+        o = bank.noise(rnd).numpy()
+    finally:
+        mx.lib().mxg_tune(b"rw_store", prev)
     assert_bits_equal(o, e, "noise")
     assert_bits_equal(bank.output.numpy(), e[-1], "noise output member")
     # extremes of the int -> float conversion: 0, RAND_MAX (rounds to 2^31 -> r == 1), odd ties
