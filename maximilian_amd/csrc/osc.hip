@@ -1083,7 +1083,7 @@ __global__ void osc_noise_kernel(size_t count, size_t V, size_t N, const int32_t
 // (loads and stores retire in order on one counter).  A grid-stride element-wise kernel reaches 0.62 of 8 TB/s on its 12 B per sample
 // whatever the access width -- with write-through 16-byte stores 0.30 -- this form [see profiles/r04_banks.md].  ST: store flavour.
 typedef int int2v __attribute__((ext_vector_type(2)));
-template <int ST>
+template <int ST, int U>
 __global__ void __launch_bounds__(256) osc_noise_walk_kernel(size_t V, size_t N, const int32_t *__restrict__ rnd,
                                                              double *__restrict__ outhold, double *__restrict__ out) {
     const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1091,7 +1091,7 @@ __global__ void __launch_bounds__(256) osc_noise_walk_kernel(size_t V, size_t N,
     const size_t odd = threadIdx.x & 1, vp = v & ~(size_t)1;
     const int32_t *ip = rnd + vp;
     double *op = out + vp;
-    constexpr int U = 8;  // rows per lane and chunk (16 rows of the block)
+    // U: rows per lane and chunk (2 U rows of the block; U 8-byte loads in flight per lane: knob rw_chunk)
     const size_t rows = (N + 1 - odd) / 2;  // rows n = 2 j + odd < N
     auto row_at = [&](size_t j) { return (j < rows ? 2 * j + odd : (rows ? 2 * (rows - 1) + odd : 0)); };  // clamped: no branch
     if (rows == 0) return;
@@ -1137,9 +1137,15 @@ extern "C" int mxg_osc_noise(size_t V, size_t N, const int32_t *d_rand, double *
     if (flavour == 2 && tune_get("rw_store") == 0 && V < 98304) flavour = 3;  // (measured: 65 536 voices 67.5 us non-temporal / 69.7 write-through; 131 072: 145 / 143)
     if (flavour) {
         const dim3 grid((unsigned)((V + 255) / 256));
-        if (flavour == 2) hipLaunchKernelGGL(osc_noise_walk_kernel<2>, grid, dim3(256), 0, st, V, N, d_rand, d_outhold, d_out);
-        else if (flavour == 3) hipLaunchKernelGGL(osc_noise_walk_kernel<1>, grid, dim3(256), 0, st, V, N, d_rand, d_outhold, d_out);
-        else hipLaunchKernelGGL(osc_noise_walk_kernel<0>, grid, dim3(256), 0, st, V, N, d_rand, d_outhold, d_out);
+        int chunk = tune_get("rw_chunk");
+        if (chunk == 0) chunk = 8;
+#define MXG_NW(S)                                                                                                                     \
+    if (chunk == 4) hipLaunchKernelGGL((osc_noise_walk_kernel<S, 4>), grid, dim3(256), 0, st, V, N, d_rand, d_outhold, d_out);          \
+    else if (chunk == 32) hipLaunchKernelGGL((osc_noise_walk_kernel<S, 32>), grid, dim3(256), 0, st, V, N, d_rand, d_outhold, d_out);   \
+    else if (chunk == 16) hipLaunchKernelGGL((osc_noise_walk_kernel<S, 16>), grid, dim3(256), 0, st, V, N, d_rand, d_outhold, d_out);   \
+    else hipLaunchKernelGGL((osc_noise_walk_kernel<S, 8>), grid, dim3(256), 0, st, V, N, d_rand, d_outhold, d_out);
+        if (flavour == 2) { MXG_NW(2) } else if (flavour == 3) { MXG_NW(1) } else { MXG_NW(0) }
+#undef MXG_NW
         return check_hip(hipGetLastError(), "osc_noise_walk_kernel launch");
     }
     size_t blocks = (count + 255) / 256;

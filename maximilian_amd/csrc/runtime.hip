@@ -32,6 +32,7 @@ Tune g_tune[] = {
     {"voice_vpl", 1, 1, 2},     {"voice_block", 256, 64, 1024}, {"voice_nt", 2, 0, 2},
     {"part_spin_limit", 1048576, 1, 16777216},  // time parts: polls (x s_sleep 8) before the writer gives up and reports ASYNC_PART_TIMEOUT
     {"part_fault", 0, 0, 1},  // fault injection for the tests: the writer waits for one signal more than will ever come
+    {"rw_chunk", 0, 0, 32},  // samples per chunk of the pair-row read + write kernels (16-byte loads in flight per lane = half of it): 0 automatic, 8 / 16 / 32
     {"rw_store", 0, 0, 4},  // read + write bank kernels (filter2 ...): 16-byte pair-row streams: 0 automatic (on for blocks >= 64 MB), 1 off, 2 / 3 / 4 on with plain / write-through / non-temporal stores
     {"fft_exact", 1, 0, 1},  // 0: mxg_fft_mfcc_batch (fftSize 1024) runs its tolerance-mode kernel: true radix-8 butterflies with correctly rounded twiddles and FMAs, hardware sqrt -- NOT the reference's bits (tolerance in the header)
     {"time_parallel", 0, 0, 1},  // 1: small banks of linear filters (biquad, SVF, DC blocker, hoisted lores / hires) are cut along TIME and joined by a wavefront scan (scan.hip) -- reordered arithmetic: a tolerance mode, not bit-exact

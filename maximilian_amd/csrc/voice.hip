@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) filter_kernel(size_t V, size_t N, const d
 // owns one voice, but the input of two samples arrives as one 16-byte load per lane (two voices of one row) and leaves as one 16-byte
 // store, the lanes of a pair swapping one value each way (pair_rows_swap / store_pair_rows, mxg_common.h).  V even, N even, both
 // blocks 16-byte aligned; the same recurrences in the same order: the same bits.
-template <int KIND, int ST>
+template <int KIND, int ST, int U>
 __global__ void __launch_bounds__(256) filter_pairs_kernel(size_t V, size_t N, const double *__restrict__ in,
                                                            const double *__restrict__ cutoff, const double *__restrict__ coef,
                                                            double *__restrict__ st, double *__restrict__ out) {
@@ -175,7 +175,8 @@ __global__ void __launch_bounds__(256) filter_pairs_kernel(size_t V, size_t N, c
     const size_t odd = threadIdx.x & 1, vp = v & ~(size_t)1;
     const double *ip = in + vp;
     double *op = out + odd * V + vp;  // this lane's 16 bytes of row n + (lane & 1)
-    constexpr int U = 8;
+    // (U samples per chunk = U / 2 16-byte loads in flight per lane: 8 -> 4 MB over the whole machine at 65 536 voices, where HBM's
+    // latency x bandwidth is ~12 MB; knob rw_chunk)
     double2v xn[U / 2];
     auto row_of = [&](size_t n) { const size_t rr = n + odd; return rr < N ? rr : N - 1; };  // clamped: no branch, surplus unused
 #pragma unroll
@@ -654,10 +655,17 @@ int mxg_filter_render(int kind, size_t V, size_t N, const double *d_in, const do
         if (rw == 0) rw = (V * N * sizeof(double) >= ((size_t)64 << 20)) ? 3 : 1;
         if (rw >= 2 && pairs_ok) {
             KernelTimer kt("filter_kernel", st);
-#define MXG_FLP(K)                                                                                                                       \
-    if (rw == 2) hipLaunchKernelGGL((filter_pairs_kernel<K, 0>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_cutoff, d_coef, d_st, d_out); \
-    else if (rw == 3) hipLaunchKernelGGL((filter_pairs_kernel<K, 2>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_cutoff, d_coef, d_st, d_out); \
-    else hipLaunchKernelGGL((filter_pairs_kernel<K, 1>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_cutoff, d_coef, d_st, d_out);
+#define MXG_FLP2(K, S)                                                                                                              \
+    if (chunk == 4) hipLaunchKernelGGL((filter_pairs_kernel<K, S, 4>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_cutoff, d_coef, d_st, d_out); \
+    else if (chunk == 32) hipLaunchKernelGGL((filter_pairs_kernel<K, S, 32>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_cutoff, d_coef, d_st, d_out); \
+    else if (chunk == 16) hipLaunchKernelGGL((filter_pairs_kernel<K, S, 16>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_cutoff, d_coef, d_st, d_out); \
+    else hipLaunchKernelGGL((filter_pairs_kernel<K, S, 8>), grid_for(V, block), dim3(block), 0, st, V, N, d_in, d_cutoff, d_coef, d_st, d_out);
+#define MXG_FLP(K)                     \
+    if (rw == 2) { MXG_FLP2(K, 0) }    \
+    else if (rw == 3) { MXG_FLP2(K, 2) } \
+    else { MXG_FLP2(K, 1) }
+            int chunk = tune_get("rw_chunk");  // samples per chunk of the pair-row kernels: 0 automatic, 8 / 16 / 32
+            if (chunk == 0) chunk = 8;
             switch (kind) {
                 case 0: MXG_FLP(0) break;
                 case 1: MXG_FLP(1) break;
@@ -665,6 +673,7 @@ int mxg_filter_render(int kind, size_t V, size_t N, const double *d_in, const do
                 case 3: MXG_FLP(3) break;
                 default: MXG_FLP(4) break;
             }
+#undef MXG_FLP2
 #undef MXG_FLP
             return check_hip(hipGetLastError(), "filter_pairs_kernel launch");
         }

@@ -333,10 +333,12 @@ def test_noise_from_rand_draws(mx, port, V, N, rw):
     rnd, e = port.noise(1234 + V, V, N)
     bank = mx.maxiOscBank(V)
     prev = mx.lib().mxg_tune(b"rw_store", rw)
+    prev_chunk = mx.lib().mxg_tune(b"rw_chunk", (0, 0, 4, 16, 32)[rw])   # (rows per lane and chunk of the column walk)
     try:
         o = bank.noise(rnd).numpy()
     finally:
         mx.lib().mxg_tune(b"rw_store", prev)
+        mx.lib().mxg_tune(b"rw_chunk", prev_chunk)
     assert_bits_equal(o, e, "noise")
     assert_bits_equal(bank.output.numpy(), e[-1], "noise output member")
     # extremes of the int -> float conversion: 0, RAND_MAX (rounds to 2^31 -> r == 1), odd ties

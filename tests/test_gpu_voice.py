@@ -53,12 +53,14 @@ def test_filter_pair_row_streams_same_bits(mx, port, kind, rw, V, N):
     c = rng.uniform(0, 1, V) if kind >= 3 else rng.uniform(1, 30000, V)
     r = None if kind >= 3 else (rng.uniform(0.01, 1.3, V) if kind == 2 else rng.uniform(0.2, 25, V))
     prev = L.mxg_tune(b"rw_store", rw)
+    prev_chunk = L.mxg_tune(b"rw_chunk", (0, 4, 16, 32, 8)[rw])   # (samples per chunk of the pair-row kernel: every instantiation)
     try:
         bank = mx.maxiFilterBank(V)
         o1 = bank.render(kind, mx.DeviceBuffer.from_numpy(x[:N]), c, r).numpy()
         o2 = bank.render(kind, mx.DeviceBuffer.from_numpy(x[N:]), c, r).numpy()
     finally:
         L.mxg_tune(b"rw_store", prev)
+        L.mxg_tune(b"rw_chunk", prev_chunk)
     eo, est = port.filter(kind, x, c, r)
     assert_bits_equal(np.concatenate([o1, o2]), eo, FLT[kind] + " rw_store=%d" % rw)
     assert_bits_equal(bank.state.numpy(), est, FLT[kind] + " state")
