@@ -154,6 +154,9 @@ __global__ void __launch_bounds__(256) filter_kernel(size_t V, size_t N, const d
 // owns one voice, but the input of two samples arrives as one 16-byte load per lane (two voices of one row) and leaves as one 16-byte
 // store, the lanes of a pair swapping one value each way (pair_rows_swap / store_pair_rows, mxg_common.h).  V even, N even, both
 // blocks 16-byte aligned; the same recurrences in the same order: the same bits.
+#ifndef MXG_FLT_SPREAD
+#define MXG_FLT_SPREAD 0  // A/B (tools/build_ab.sh): 1 = every pair of samples is stored as soon as it is computed
+#endif
 template <int KIND, int ST, int U>
 __global__ void __launch_bounds__(256) filter_pairs_kernel(size_t V, size_t N, const double *__restrict__ in,
                                                            const double *__restrict__ cutoff, const double *__restrict__ coef,
@@ -213,12 +216,22 @@ __global__ void __launch_bounds__(256) filter_pairs_kernel(size_t V, size_t N, c
                 st[3 * V + v] = f.o1;
                 st[4 * V + v] = f.o2;
             }
+#if MXG_FLT_SPREAD
+            // a pair leaves as soon as it exists (K1's cadence: two ticks, one store) instead of the chunk's stores back to back
+            if (i & 1) {
+                if (n0 + i - 1 < N) store_pair_rows<ST>(op, o[i - 1], o[i]);  // (N even: a pair is inside or outside as a whole)
+                op += 2 * V;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
         }
+#if !MXG_FLT_SPREAD
 #pragma unroll
         for (int j = 0; j < U / 2; j++) {
             if (n0 + 2 * j < N) store_pair_rows<ST>(op, o[2 * j], o[2 * j + 1]);  // (N even: a pair is inside or outside as a whole)
             op += 2 * V;
         }
+#endif
     }
 }
 
