@@ -334,7 +334,18 @@ public:
         s.dv.clear();
     }
     double call(Slot &s, const Call &c) {
-        const double r = (s.pos < s.len && matches(s, c)) ? s.blk[s.pos++] : miss(s, c);
+        double r;
+        if (s.pos < s.len && matches(s, c)) {
+            r = s.blk[s.pos++];
+            // a hit on a block with DERIVED arguments: the arguments move from sample to sample, and learn() (which runs on misses only)
+            // pairs `lastArg` with the producers' outputs one call ago -- so it has to be this call's, not the last miss's
+            if (!s.dv.empty()) {
+                std::memcpy(s.lastArg, c.a, sizeof(s.lastArg));
+                s.hasLastArg = true;
+            }
+        } else {
+            r = miss(s, c);
+        }
         s.prevOut = s.lastOut;
         s.lastOut = r;
         if (s.nOut < 2) s.nOut++;
