@@ -150,7 +150,7 @@ def main():
     import torch
     import torch.distributed as dist
     import maximilian_amd as mx
-    from maximilian_amd.dist import (MixdownStep, RcclMixQueue, bank_parameters, create_comm, shard_range,
+    from maximilian_amd.dist import (MixdownStep, RcclMixQueue, TorchMixQueue, bank_parameters, create_comm, shard_range,
                                      stream_parameters)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -190,7 +190,31 @@ def main():
     stream = tstream.cuda_stream
     assert stream != 0
     # the product's communicator: RCCL through the C-ABI (torch.distributed only carries the 128-byte id)
-    comm = create_comm(dist, rank, world, dev) if (world > 1 and not args.share_gpu) else None
+    comm, exchange = None, None
+    force_torch = os.environ.get("MXG_BENCH_FORCE_TORCH_EXCHANGE") == "1"  # (tests: exercise the fallback)
+    if world > 1 and force_torch:
+        exchange = "FALLBACK: torch.distributed.reduce (forced by MXG_BENCH_FORCE_TORCH_EXCHANGE)"
+    elif world > 1 and not args.share_gpu:
+        try:
+            comm = create_comm(dist, rank, world, dev)
+            exchange = "ncclReduce on the library's own RCCL communicator (mxg_comm / mxg_mixq)"
+        except Exception as e:  # (never seen; a scaling run that dies here would measure nothing at all)
+            exchange = "FALLBACK: torch.distributed.reduce (mxg_comm_create failed on rank %d: %s)" % (rank, e)
+    if world > 1 and not args.share_gpu and not force_torch:
+        # every rank takes the same path, or the reduces would never meet
+        ok = torch.tensor([1 if comm else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm:
+                L.mxg_comm_destroy(comm)
+                exchange = "FALLBACK: torch.distributed.reduce (mxg_comm_create failed on another rank)"
+            comm = None
+
+    def make_queue(block_doubles, depth, groups=1):
+        """The mix queue of the step: the library's (RCCL communicator inside libmaxigpu.so); the torch fallback only if that could not be made."""
+        if world > 1 and comm is None and (force_torch or not args.share_gpu):
+            return TorchMixQueue(dist, block_doubles, depth, 0, stream, dev, groups=groups)
+        return RcclMixQueue(comm, block_doubles, depth, 0, stream, groups=groups)
 
     V, B = (args.voices or VOICES_PER_GPU), BLOCK
     nbuf = args.out_buffers if args.out_buffers > 0 else max(1, -(-(1 << 31) // (V * B * 8)))
@@ -273,7 +297,7 @@ def main():
             # a whole batch on ITS stream in front of the reduce -- the render stream carries one kernel per block
             groups2 = L.mxg_osc_mix_groups(V) if mixdown == "fused" else 1
             if mixdown != "off":
-                queue = RcclMixQueue(comm, B * 2, args.mix_depth, 0, stream, groups=groups2)
+                queue = make_queue(B * 2, args.mix_depth, groups2)
             bank = OscBank(V, nbuf, mixdown, queue, lo, V * world)
             if queue is not None and world > 1:
                 local_queue = RcclMixQueue(None, B * 2, args.mix_depth, 0, stream, groups=groups2)
@@ -325,7 +349,7 @@ def main():
             pan3 = mx.DeviceBuffer.from_numpy(pan_h)
             blk = [0]
             if mixdown != "off":
-                queue = RcclMixQueue(comm, B * 2, args.mix_depth, 0, stream)
+                queue = make_queue(B * 2, args.mix_depth)
                 if world > 1:
                     local_queue = RcclMixQueue(None, B * 2, args.mix_depth, 0, stream)
 
@@ -418,7 +442,7 @@ def main():
             out5 = mx.DeviceBuffer((T, S), zero=False)
             plan5 = gb._plan(0.05)
             if mixdown != "off":
-                queue = RcclMixQueue(comm, T * 2, 1, 0, stream)  # one [T][2] = 1.13 MB reduce per render
+                queue = make_queue(T * 2, 1)  # one [T][2] = 1.13 MB reduce per render
                 if world > 1:
                     local_queue = RcclMixQueue(None, T * 2, 1, 0, stream)
 
@@ -738,6 +762,7 @@ def main():
                        "mixdown": {"off": "off"}.get(mixdown, "maxiMix::stereo per block; %s"
                                                      % ("one ncclReduce per %d blocks on the mix queue's stream" % queue.depth
                                                         if queue is not None else ""))},
+            "exchange": exchange,
             "rccl_ranks": (world if (queue is not None and world > 1 and comm is not None) else
                            (1 if (queue is not None and comm is not None) else 0)),
             "roofline": roof,

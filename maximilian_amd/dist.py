@@ -192,6 +192,78 @@ class HostMixQueue:
         return self.res[self.last][:self.last_blocks].numpy().copy()
 
 
+class TorchMixQueue:
+    """FALLBACK exchange for bench.py only: the slot / push / flush protocol of mxg_mixq with torch DEVICE tensors as staging and
+    torch.distributed.reduce (RCCL through torch's own communicator) as the sum -- used when the library's communicator cannot be
+    created on a multi-GPU node (mxg_comm_create failing), so that the scaling run still measures a real cross-GPU reduce and says
+    so in its line.  Same batching, same double buffering; the per-workgroup rows of a grouped slot are added by the library's own
+    kernel (mxg_mix_rows_sum) on the launch stream.  The launch stream must be torch's current stream."""
+
+    def __init__(self, dist, block_doubles, depth_blocks=16, root=0, stream=None, device=None, groups=1):
+        import torch
+        from ._lib import lib
+        self.L, self.dist = lib(), dist
+        self.block, self.depth, self.root, self.stream, self.groups = int(block_doubles), int(depth_blocks), root, stream, int(groups)
+        kw = dict(dtype=torch.float64, device=device)
+        self.gstage = [torch.zeros((self.depth, self.groups, self.block), **kw) for _ in range(2)] if self.groups > 1 else None
+        self.stage = [torch.zeros((self.depth, self.block), **kw) for _ in range(2)]
+        self.work = [None, None]
+        self.cur, self.fill, self.last, self.last_blocks, self.batches = 0, 0, -1, 0, 0
+        self.slot_out = False
+
+    def slot_tensor(self):
+        b = self.cur
+        if self.fill == 0 and self.work[b] is not None:
+            self.work[b].wait()  # (the current stream waits for the reduce that last read this buffer; the host does not)
+            self.work[b] = None
+        self.slot_out = True
+        return self.gstage[b][self.fill] if self.gstage is not None else self.stage[b][self.fill]
+
+    def slot(self):
+        return self.slot_tensor().data_ptr()
+
+    def _submit(self):
+        from ._lib import check
+        b = self.cur
+        if self.gstage is not None:
+            for k in range(self.fill):
+                check(self.L.mxg_mix_rows_sum(self.groups, self.block, self.gstage[b][k].data_ptr(), self.stage[b][k].data_ptr(),
+                                              self.stream), "mxg_mix_rows_sum")
+        self.work[b] = self.dist.reduce(self.stage[b][:self.fill], dst=self.root, op=self.dist.ReduceOp.SUM, async_op=True)
+        self.last, self.last_blocks = b, self.fill
+        self.batches += 1
+        self.cur ^= 1
+        self.fill = 0
+
+    def push(self):
+        assert self.slot_out, "push without slot"
+        self.slot_out = False
+        self.fill += 1
+        if self.fill == self.depth:
+            self._submit()
+
+    def flush(self):
+        assert not self.slot_out
+        if self.fill:
+            self._submit()
+        for b in range(2):
+            if self.work[b] is not None:
+                self.work[b].wait()
+                self.work[b] = None
+
+    def result_numpy(self):
+        import torch
+        self.flush()
+        if self.stage[0].is_cuda:
+            torch.cuda.synchronize()
+        if self.last < 0:
+            return np.empty((0, self.block))
+        return self.stage[self.last][:self.last_blocks].cpu().numpy().copy()
+
+    def close(self):
+        pass
+
+
 class MixdownStep:
     """One block of the sharded path.  `render_mix(slot)` enqueues this rank's render + local maxiMix mixdown of one
     block, writing the [block_doubles] mix at `slot` (a device pointer for RcclMixQueue, a host tensor view for

@@ -20,9 +20,9 @@ ENV.pop("RANK", None)
 ENV.pop("LOCAL_RANK", None)
 
 
-def _run(args, timeout=600):
+def _run(args, timeout=600, env=None):
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
-                          env=ENV, cwd=ROOT)
+                          env=dict(ENV, **(env or {})), cwd=ROOT)
 
 
 def test_self_launch_spawns_ranks_without_a_gpu():
@@ -60,6 +60,21 @@ def test_two_ranks_sharing_one_gpu_print_the_scaling_fields():
     assert 0.0 < d["per_gpu_efficiency"] <= 1.0
     assert d["value_like_for_like_n1"] > 0 and d["step_ms_without_reduce"] > 0
     assert d["roofline"]["kernel"] == "osc_mix_kernel"
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_the_fallback_exchange():
+    """bench.py's safety net for a multi-GPU node on which mxg_comm_create fails: the same step with torch tensors as staging and
+    torch.distributed.reduce as the sum (maximilian_amd.dist.TorchMixQueue), forced here over gloo with two ranks on one GPU; the
+    line says so."""
+    r = _run(["--gpus", "2", "--share-gpu", "--steps", "64", "--warmup", "8", "--no-cpu-baseline"],
+             env={"MXG_BENCH_FORCE_TORCH_EXCHANGE": "1"})
+    assert r.returncode == 0, (r.stderr + r.stdout)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["exchange"].startswith("FALLBACK: torch.distributed.reduce"), d.get("exchange")
+    assert d["value"] > 0 and 0.0 < d["per_gpu_efficiency"] <= 1.0
 
 
 @pytest.mark.gpu

@@ -90,8 +90,22 @@ def _worker(rank, world, port, q):
     step5()
     step5.finish()
     got5 = queue5.result_numpy().reshape(g["T"], 2)
+    # ---- bench.py's fallback exchange (TorchMixQueue: torch tensors as staging, torch.distributed.reduce): the same protocol ------
+    from maximilian_amd.dist import TorchMixQueue
+    tq = TorchMixQueue(dist, 6, depth_blocks=2, root=0, stream=None, device=None, groups=1)
+    got_t = []
+    for k in range(5):  # batches of 2, 2 and a flushed 1
+        before = tq.batches
+        tq.slot_tensor().copy_(torch.full((6,), float((k + 1) * (rank + 1)), dtype=torch.float64) + torch.arange(6, dtype=torch.float64))
+        tq.push()
+        if tq.batches != before:
+            got_t.append(tq.result_numpy())
+    tq.flush()
+    if len(got_t) * 2 < 5:
+        got_t.append(tq.result_numpy())
+    got_t = np.concatenate(got_t)
     if rank == 0:
-        q.put((got2, got5))
+        q.put((got2, got5, got_t))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -141,7 +155,7 @@ def test_two_rank_mixdown_steps_gloo(port):
     procs = [ctx.Process(target=_worker, args=(r, 2, prt, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got2, got5 = q.get(timeout=180)
+    got2, got5, got_t = q.get(timeout=180)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -163,3 +177,6 @@ def test_two_rank_mixdown_steps_gloo(port):
     exp5 = port.mix_stereo(o5, pan5)
     assert np.abs(got5 - exp5).max() <= mix_tol(2 * g["Sr"], np.abs(o5).max())
     assert np.abs(got5).max() > 0.05
+    # the fallback queue: block k of rank r is (k + 1)(r + 1) + arange(6); the root holds the sum over both ranks
+    exp_t = np.stack([3.0 * (k + 1) + 2.0 * np.arange(6) for k in range(5)])
+    assert np.array_equal(got_t, exp_t)
