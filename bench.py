@@ -141,6 +141,8 @@ def main():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
         env.setdefault("OMP_NUM_THREADS", "1")
         os.execvpe(cmd[0], cmd, env)
+    # (under torch.distributed.run the environment is the launcher's: make sure of dmabuf IPC before HIP / RCCL are loaded)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     defaults = {"config2": (2000, 100), "config3": (1280, 128), "config4": (20, 3), "config5": (20, 3), "tables": (200, 20)}
     if args.steps is None:
         args.steps = defaults[args.workload][0]
