@@ -117,7 +117,9 @@ int async_error_status(int code);  // the status + message of one code
 // CONTRACT after ASYNC_PART_TIMEOUT: the counters of that stream are not epoch-based, so split launches that were already
 // enqueued behind the failed one start from stale counts and may store early.  A caller that sees MXG_ERR_ASYNC with this code must
 // synchronise the stream and treat every bank state rendered on it since the failed launch as invalid (re-upload or re-create the
-// banks); include/maxigpu.h says so at mxg_last_async_error.  The time-out itself means a device that made no progress for
+// banks); include/maxigpu.h says so at mxg_last_async_error.  (Epoch-based counters -- the writer waiting for a per-launch target instead
+// of resetting to zero -- would close that window, but the target would be a kernel argument frozen into a captured hipGraph: a replayed
+// split launch would then find its wait already satisfied, SILENTLY.  The reset-to-zero form is what keeps these launches replayable.)  The time-out itself means a device that made no progress for
 // spin_limit x ~0.5 us on work that was dispatched BEFORE the writer -- it has only ever been seen under fault injection (knob part_fault).
 struct PartSync {
     int *ctrs = nullptr;   // one counter per wavefront of gridDim.x (zero between launches)
