@@ -135,12 +135,9 @@ __device__ __forceinline__ double osc_tick(double &phase, double &hold, const Os
     } else if constexpr (WF == MXG_OSC_TRIANGLE) {  // C:362-373
         if (phase >= 1.0) phase -= 1.0;
         phase += q.inc;
-        double r;
-        if (phase <= 0.5) {
-            r = (phase - 0.25) * 4;
-        } else {
-            r = ((1.0 - phase) - 0.25) * 4;
-        }
+        // (the branch of C:366-370 selects the operand, then ONE subtract-multiply: the same two operations on the taken side)
+        const double t = (phase <= 0.5) ? phase : (1.0 - phase);
+        const double r = (t - 0.25) * 4;
         hold = r;
         return r;
     } else if constexpr (WF == MXG_OSC_SQUARE) {  // C:293-300 (output held at phase==0.5)
@@ -152,6 +149,8 @@ __device__ __forceinline__ double osc_tick(double &phase, double &hold, const Os
     } else if constexpr (WF == MXG_OSC_PULSE) {  // C:302-311 (output held at phase==duty)
         if (phase >= 1.0) phase -= 1.0;
         phase += q.inc;
+        // (measured, round 4: the sign of phase - duty copied onto 1.0, with the equal / NaN case behind a wave-level branch, is 3
+        // instructions shorter and 25 % SLOWER -- 57.5 against 46.4 us at 65 536 voices: a scalar branch per voice and sample)
         if (phase < q.p1) hold = -1.;
         if (phase > q.p1) hold = 1.;
         return hold;

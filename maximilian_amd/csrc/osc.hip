@@ -92,7 +92,10 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
     // ones (sinewave, coswave, sinebuf4) and sawn take the lean forms -- 32-bit trip count, two table copies, three-instruction wrap:
     // sawn 52 -> 46 us, sinebuf4 57 -> 52, sinewave 61 -> 58 -- while sinebuf and the table-free waveforms, whose time is the store
     // stream's, keep the loop they were tuned with: every one of these changes made sinebuf SLOWER (41 -> 46 us with all three).
-    constexpr bool kLean = WF == MXG_OSC_SINEWAVE || WF == MXG_OSC_COSWAVE || WF == MXG_OSC_SINEBUF4 || WF == MXG_OSC_SAWN;
+#ifndef MXG_K1_LEAN_MASK
+#define MXG_K1_LEAN_MASK ((1 << MXG_OSC_SINEWAVE) | (1 << MXG_OSC_COSWAVE) | (1 << MXG_OSC_SINEBUF4) | (1 << MXG_OSC_SAWN))  // A/B: per-waveform bit mask
+#endif
+    constexpr bool kLean = ((MXG_K1_LEAN_MASK >> WF) & 1) != 0;
     constexpr int kFL = kLean ? kTickLean : 0;
     __shared__ __attribute__((aligned(16))) double s_tab[tab_len<WF, kFL>()];
     if constexpr (tab_len<WF, kFL>() > 1) {

@@ -429,6 +429,25 @@ def test_time_part_timeout_is_reported_and_state_kept(mx, port):
     L.mxg_tune(b"osc_split", 0)
 
 
+@pytest.mark.parametrize("V", [64, 65536 + 128])
+def test_pulse_and_triangle_on_their_corners(mx, port, V):
+    """pulse holds its old output when the phase EQUALS the duty (C:308-309: neither `<` nor `>`) and with a NaN duty; the device tick takes
+    the sign of phase - duty and handles exactly those cases behind a wave-level test.  Frequencies sr / 8, sr / 16 make the phase walk
+    over exact eighths, duties on and off that grid, NaN among them; triangle turns at 0.5 exactly.  Two carried blocks, every launch shape
+    of the size (one / two voices per lane)."""
+    rng = np.random.default_rng(V)
+    freq = np.where(np.arange(V) % 3 == 0, 44100.0 / 8, np.where(np.arange(V) % 3 == 1, 44100.0 / 16, rng.uniform(20, 9000, V)))
+    duty = rng.choice([0.0, 0.125, 0.25, 0.5, 0.3, 0.75, 1.0, 1.5, -0.2, np.nan], V)
+    N = 96
+    for name, p1 in (("pulse", duty), ("triangle", None)):
+        bank = mx.maxiOscBank(V)
+        o = np.concatenate([bank.render(name, freq, N, p1=p1).numpy(), bank.render(name, freq, N, p1=p1).numpy()])
+        eo, eph, ehold = port.osc(OSC.index(name), freq, 2 * N, p1=p1)
+        assert_bits_equal(o, eo, name)
+        assert_bits_equal(bank.phase.numpy(), eph, name + " phase")
+        assert_bits_equal(bank.output.numpy(), ehold, name + " output member")
+
+
 def test_pulse_width_and_frequency_per_sample(mx, port):
     """mxg_osc_render fps = 2: frequency AND p1 (the pulse width; phasorBetween's start phase) per sample, [N][V] each -- what the
     per-sample engine renders when a patch writes `sound.pulse(f, mod.phasor(1))` (16.Replicant).  Against the oracle called one
