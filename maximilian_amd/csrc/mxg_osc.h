@@ -191,9 +191,8 @@ __device__ __forceinline__ double osc_tick(double &phase, double &hold, const Os
         const double b = ab.y, c = cd.x, d = cd.y;
 #elif defined(__HIP_DEVICE_COMPILE__)
         // a, b, c, d = sineBuffer[i-1 .. i+2] = s_sine[i .. i+3] from ONE address; `phase == 0` -- a voice at rest: frequency 0 -- reads
-        // sineBuffer[512] for `a` instead (C:245-256; index -1 is the 0.0 guard s_sine[0]).  That case is taken out of line behind a
-        // wave-level test: as a per-lane select of the INDEX it costs a select and a second address (3 of the 33 VALU instructions
-        // of a kernel that is bound by them) on every sample of every voice.
+        // sineBuffer[512] for `a` instead (C:245-256; index -1 is the 0.0 guard s_sine[0]): a select of the VALUE after the read (as a
+        // select of the INDEX it costs a second address on every sample of every voice).
         // Four ds_read_b64 (~7 LDS cycles each at 64 unrelated addresses), not the two ds_read2_b64 hipcc makes of four reads off one
         // base (~20 each: that instruction is served 16 lanes at a time over 32 banks, and the LDS pipe of a CU, shared by its four
         // SIMDs, would become the bound in place of the VALU): the kernels keep FOUR copies of the table, kSb4Copy doubles apart --
@@ -201,9 +200,17 @@ __device__ __forceinline__ double osc_tick(double &phase, double &hold, const Os
         const double *t = s_sine + i;
         double a = t[0];
         const double b = t[kSb4Copy + 1], c = t[2 * kSb4Copy + 2], d = t[3 * kSb4Copy + 3];
+#ifndef MXG_SB4_BRANCH
+#define MXG_SB4_BRANCH 0  // A/B (tools/build_ab.sh): 1 = the rest case out of line behind a wave-level test -- two VALU instructions fewer
+                          // and 1.5 % SLOWER (53.4 against 52.6 us): a scalar branch per sample costs more than it saves (pulse: 25 %)
+#endif
+#if MXG_SB4_BRANCH
         if (__builtin_expect(__any(phase == 0), 0)) {
             if (phase == 0) a = s_sine[513];
         }
+#else
+        a = (phase == 0) ? s_sine[513] : a;
+#endif
 #else
         int ia = (phase == 0) ? 512 : i - 1;  // C:245-256; index -1 is the 0.0 guard
         double a = s_sine[ia + 1];
