@@ -205,6 +205,23 @@ __device__ __forceinline__ void store2(double *p, double a, double b) {
     else
         *reinterpret_cast<double2v *>(p) = v;
 }
+// A 16-byte store at a WAVE-UNIFORM base plus a per-lane byte offset.  For the write-through flavour this is a buffer store the compiler
+// KNOWS about (`__builtin_amdgcn_raw_buffer_store_b128`, aux = sc1) instead of store2's inline asm: hipcc does not count an asm store in
+// its vmcnt bookkeeping, so in a loop that also LOADS every `s_waitcnt vmcnt(n)` it places is short by the asm stores in flight -- and the
+// wait for a chunk's loads then drains the stores issued after them (found late in round 4: filter_pairs_kernel waited for vmcnt(0)
+// once per chunk).  Loops without loads (K1) are unaffected and keep the asm form.  `ubase` must be uniform (kernel argument + uniform
+// index): a divergent one would cost a waterfall loop.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int ST>
+__device__ __forceinline__ void store2_at(double *ubase, unsigned off, double a, double b) {
+    if constexpr (ST == 2) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ubase, 0, 0xffffffff, 0x00020000);
+        const double2v v = {a, b};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)off, 0, 16 /* sc1 */);
+    } else {
+        store2<ST>(reinterpret_cast<double *>(reinterpret_cast<char *>(ubase) + off), a, b);
+    }
+}
 // The exchange inside a lane pair (lanes 2k, 2k+1) that both pair-row streams are made of: every lane gives (x, y) and gets
 //     a = even lane ? its own x : the partner's y,        b = odd lane ? its own y : the partner's x.
 // Four VALU instructions: one v_cndmask_b32_dpp per dword (the DPP operand is the partner's value, quad_perm [1,0,3,2]; the lane parity
@@ -256,6 +273,14 @@ __device__ __forceinline__ void store_pair_rows(double *o, double r0, double r1)
     double a, b;
     pair_exchange<ASM>(r0, r1, a, b);
     store2<ST>(o, a, b);
+}
+
+// store_pair_rows at a wave-uniform base + per-lane byte offset (store2_at: the compiler-visible write-through store)
+template <int ST, bool ASM = true>
+__device__ __forceinline__ void store_pair_rows_at(double *ubase, unsigned off, double r0, double r1) {
+    double a, b;
+    pair_exchange<ASM>(r0, r1, a, b);
+    store2_at<ST>(ubase, off, a, b);
 }
 
 // One chunk of U consecutive samples of the lane's voice to the out[n*V + v] stream; `op` = out + n*V + v, advanced by U rows.

@@ -177,19 +177,31 @@ __global__ void __launch_bounds__(256) filter_pairs_kernel(size_t V, size_t N, c
     }
     const size_t odd = threadIdx.x & 1, vp = v & ~(size_t)1;
     const double *ip = in + vp;
-    double *op = out + odd * V + vp;  // this lane's 16 bytes of row n + (lane & 1)
+    const unsigned op_off = (unsigned)((odd * V + vp) * sizeof(double));  // this lane's 16 bytes of row n + (lane & 1), from row n's start
     // (U samples per chunk = U / 2 16-byte loads in flight per lane: 8 -> 4 MB over the whole machine at 65 536 voices, where HBM's
     // latency x bandwidth is ~12 MB; knob rw_chunk)
     double2v xn[U / 2];
     auto row_of = [&](size_t n) { const size_t rr = n + odd; return rr < N ? rr : N - 1; };  // clamped: no branch, surplus unused
 #pragma unroll
     for (int j = 0; j < U / 2; j++) xn[j] = *reinterpret_cast<const double2v *>(ip + row_of(2 * j) * V);
-    for (size_t n0 = 0; n0 < N; n0 += U) {
+    // consume the prologue's loads HERE: a single s_waitcnt at the loop header has to serve the entry path too, where these are the only
+    // operations in flight -- vmcnt(0) -- and would then drain the stores of every iteration (see sample.hip, delay_kernel)
+#pragma unroll
+    for (int j = 0; j < U / 2; j++) asm volatile("" : "+v"(xn[j]));
+    asm volatile("" : "+v"(f.x), "+v"(f.y), "+v"(f.o0), "+v"(f.o1), "+v"(f.o2));  // (the state and the coefficients likewise)
+    asm volatile("" : "+v"(c), "+v"(r), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(cu));
+    // One chunk.  LAST = false: a whole chunk that is not the block's last -- no test of the sample number anywhere (twelve wave-uniform
+    // tests = scalar branches per chunk of eight samples in the first form).  LAST = true: the chunk that holds sample N - 1 (ragged or
+    // not): the state is stored after exactly that sample.  Measured (round 4, same box, A/B builds): with the branches and with asm
+    // stores that drained the store queue once per chunk 91.7-93.2 us; without either 93.5-94.0 us; without the branches but still
+    // draining 104-111 us; a fixed pause per chunk changed nothing -- the kernel sits on the memory system's rate either way.
+    auto chunk = [&](const size_t n0, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
         double xc[U];
 #pragma unroll
         for (int j = 0; j < U / 2; j++) {
             pair_rows_swap(xn[j], xc[2 * j], xc[2 * j + 1]);
-            xn[j] = *reinterpret_cast<const double2v *>(ip + row_of(n0 + U + 2 * j) * V);
+            if constexpr (!LAST) xn[j] = *reinterpret_cast<const double2v *>(ip + row_of(n0 + U + 2 * j) * V);
         }
         double o[U];
 #pragma unroll
@@ -209,30 +221,23 @@ __global__ void __launch_bounds__(256) filter_pairs_kernel(size_t V, size_t N, c
                 o[i] = x - (f.o0 + cu * (x - f.o0));
                 f.o0 = o[i];
             }
-            if (n0 + i + 1 == N) {  // the state after the LAST sample of the block (a ragged last chunk computes past it)
-                st[v] = f.x;
-                st[V + v] = f.y;
-                st[2 * V + v] = f.o0;
-                st[3 * V + v] = f.o1;
-                st[4 * V + v] = f.o2;
+            if constexpr (LAST) {
+                if (n0 + i + 1 == N) {  // the state after the LAST sample of the block (a ragged last chunk computes past it)
+                    st[v] = f.x;
+                    st[V + v] = f.y;
+                    st[2 * V + v] = f.o0;
+                    st[3 * V + v] = f.o1;
+                    st[4 * V + v] = f.o2;
+                }
             }
-#if MXG_FLT_SPREAD
-            // a pair leaves as soon as it exists (K1's cadence: two ticks, one store) instead of the chunk's stores back to back
-            if (i & 1) {
-                if (n0 + i - 1 < N) store_pair_rows<ST>(op, o[i - 1], o[i]);  // (N even: a pair is inside or outside as a whole)
-                op += 2 * V;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#endif
         }
-#if !MXG_FLT_SPREAD
 #pragma unroll
-        for (int j = 0; j < U / 2; j++) {
-            if (n0 + 2 * j < N) store_pair_rows<ST>(op, o[2 * j], o[2 * j + 1]);  // (N even: a pair is inside or outside as a whole)
-            op += 2 * V;
-        }
-#endif
-    }
+        for (int j = 0; j < U / 2; j++)  // (N even: a pair is inside or outside as a whole)
+            if (!LAST || n0 + 2 * j < N) store_pair_rows_at<ST>(out + (n0 + 2 * j) * V, op_off, o[2 * j], o[2 * j + 1]);
+    };
+    size_t n0 = 0;
+    for (; n0 + U < N; n0 += U) chunk(n0, std::false_type{});
+    chunk(n0, std::true_type{});
 }
 
 // lores / hires / bandpass with the coefficients given PER SAMPLE (coef [N][3][V]: c, r, - or inputs[0..2]), computed by the caller

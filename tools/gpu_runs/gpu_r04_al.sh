@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04al
 mkdir -p $O
 cd $R
-for round in 1 2; do for lib in libmaxigpu.so ab_fltspread.so; do
+for round in 1 2; do for lib in libmaxigpu.so ab_fltold.so; do
 MXG_LIB=$R/maximilian_amd/$lib python - <<'PY' 2>&1 | grep -v amdgpu | tee -a $O/ab.txt
 import ctypes, numpy as np, sys, os
 sys.path.insert(0, os.getcwd())
