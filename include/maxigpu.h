@@ -157,6 +157,8 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * one contiguous eighth of the bank: 0 automatic, 1 off, 2 on), "grain_sync" (mxg_granular_render reads its error word back before it returns, 0|1;
  * default 0: deferred, see mxg_last_async_error), "part_spin_limit" (polls a time-split kernel's writer part makes before it gives up
  * and reports through mxg_last_async_error), "part_fault" (test-only fault injection: that writer waits for a signal that never comes).
+ * "rw_chunk" (samples per chunk of the pair-row maxiFilter kernel / rows per chunk of the noise column walk: 0 automatic = 8, 4 / 8 / 16 / 32;
+ * measured: 8 is the optimum, fewer loads in flight starve the read stream, longer chunks burst the stores).
  * The tests flip every one of them and demand identical bits.  Returns the previous value or MXG_ERR_INVALID. */
 int mxg_tune(const char *key, int value);
 
@@ -169,8 +171,6 @@ int mxg_tune(const char *key, int value);
  * block the host, and their launch sequences can be captured into a hipGraph; a captured launch reports the same way.)
  * After a time-part time-out the caller must synchronise that stream and treat the state of every bank rendered on it since the failed
  * launch as invalid (launches already enqueued behind it may have run from stale part counters): re-upload or re-create those banks.
- * "rw_chunk" (samples per chunk of the pair-row maxiFilter kernel / rows per chunk of the noise column walk: 0 automatic = 8, 4 / 8 / 16 / 32;
- * measured: 8 is the optimum, fewer loads in flight starve the read stream, longer chunks burst the stores).
  * "rw_store" (mxg_tune) is documented with the render entry points that honour it (maxiFilter, maxiEnv, maxiDelayline, maxiSample,
  * maxiEnvGen, filter2: 0 automatic, 1 8-byte streams, 2 / 3 / 4 16-byte pair rows with plain / write-through / non-temporal stores). */
 int mxg_last_async_error(void);
