@@ -504,11 +504,21 @@ def main():
 
     # Untimed clock ramp: an idle MI355X sits in a low-power state (sclk ~500 MHz) and takes milliseconds of continuous
     # work to reach its sustained clocks; a short --steps run would otherwise time the ramp instead of the kernel.
+    # With more than one rank the NUMBER of ramp steps must be the same everywhere -- every full batch of the mix queue is a collective,
+    # matched by order: ranks that leave a wall-clock loop after different step counts leave unmatched reduces behind and the run hangs
+    # at its first fence -- so rank 0's clock decides, chunk by chunk, and tells the others.
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.3:
+    while True:
         for _ in range(50 if args.workload in ("config2", "config3") else 1):
             step()
         torch.cuda.synchronize()
+        go = time.perf_counter() - t_ramp < 0.3
+        if world > 1:
+            flag = torch.tensor([1 if go else 0], device=dev, dtype=torch.int32)
+            dist.broadcast(flag, src=0)
+            go = bool(int(flag.item()))
+        if not go:
+            break
     for _ in range(args.warmup):
         step()
     if queue is not None:
