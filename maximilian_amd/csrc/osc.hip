@@ -811,12 +811,20 @@ void osc_single_rule(OscLaunch &L, size_t count) {
     L.vpl = 1;
     L.store = 0;
     L.xcd = 0;
+    L.passes = 0;
     if (L.pairs_ok) {
         if (heavy) {
             if (bytes >= ((size_t)32 << 20)) L.store = 3;
             L.xcd = count >= 262144 ? 1 : 0;
         } else if (bytes >= ((size_t)192 << 20)) {
-            if (count >= (table ? 81920u : 65536u)) {
+            // (tools/sweep_osc_mid.py, late round 4: between the 65 536- and the 98 304-voice shapes -- 2.1 to 2.7 wavefronts of 128
+            // voices per CU -- sinebuf is fastest as TWO passes of half the range with one voice per lane and non-temporal 8-byte
+            // stores: 69 632 ... 81 920 voices 57-59 us against 64-67; sawn keeps its pair rows -- the lean loop -- up to 98 304:
+            // 64.6 against 81.0 us at 81 920)
+            if (wf == MXG_OSC_SINEBUF && count >= 67584 && count < 88064) {
+                L.store = 1;
+                L.passes = 2;
+            } else if (count >= (wf == MXG_OSC_SAWN ? 98304u : table ? 81920u : 65536u)) {
                 L.vpl = 2;
                 L.store = 2;
                 L.xcd = count >= 262144 ? 1 : 0;
@@ -952,7 +960,7 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     }
     A.block = tune_get("osc_block");
     A.split = tune_get("osc_split");
-    A.passes = tune_get("osc_passes");
+    if (const int kp = tune_get("osc_passes")) A.passes = kp;  // (else what the automatic rule chose, or one)
     return osc_launch(A);
 }
 

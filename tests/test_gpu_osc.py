@@ -151,17 +151,20 @@ def test_passes_same_bits(mx, port, vpl, store, passes, V, N):
         L.mxg_tune(b"osc_vpl", prev[0]); L.mxg_tune(b"osc_store", prev[1]); L.mxg_tune(b"osc_passes", prev[2])
 
 
-@pytest.mark.parametrize("wf,V,N", [(8, 2 * 98304 + 4098, 256), (3, 98304 + 65536 + 2, 300), (8, 131072, 352), (10, 3 * 98304, 176)])
+@pytest.mark.parametrize("wf,V,N", [(8, 2 * 98304 + 4098, 256), (3, 98304 + 65536 + 2, 300), (8, 131072, 352), (10, 3 * 98304, 176),
+                                      (8, 73728 + 2, 384), (8, 81920, 320), (10, 81920, 320), (8, 98304 + 73728, 256), (8, 86016, 300)])
 def test_large_bank_launch_plan_same_bits(mx, port, wf, V, N):
     """Banks beyond ~350 MB per block are rendered as a PLAN of launches (osc.hip: passes of 98 304 voices on a grid of three wavefronts
     per CU, then the remainder in the shape that suits its size): two carried blocks, every 499th voice and the voices around every
-    boundary of the plan against the oracle, the carried phase of all of them."""
+    boundary of the plan against the oracle, the carried phase of all of them.  (Sizes between 65 536 and 98 304 voices: the two-pass
+    non-temporal form of sinebuf, sawn's pair rows, on their own and as the remainder of a plan.)"""
     rng = np.random.default_rng(V)
     freq = rng.uniform(20, 20000, V)
     bank = mx.maxiOscBank(V)
     o1 = bank.render(wf, freq, N).numpy()
     o2 = bank.render(wf, freq, N).numpy()
     edges = [k * 98304 + d for k in range(1, V // 98304 + 1) for d in (-2, -1, 0, 1) if 0 <= k * 98304 + d < V]
+    edges += [V // 2 + d for d in (-130, -129, -128, -2, -1, 0, 1, 127, 128, 129)]  # (a two-pass launch splits the range near its middle)
     sel = np.unique(np.concatenate([np.arange(0, V, 499), edges, [V - 2, V - 1]]).astype(np.int64))
     eo, eph, ehd = port.osc(wf, freq[sel], 2 * N)
     assert_bits_equal(np.concatenate([o1[:, sel], o2[:, sel]]), eo, OSC[wf])
