@@ -72,3 +72,75 @@ def test_hostile_parameters_do_not_fault(mx, port):
         c = np.clip(np.nan_to_num(cut, nan=0.5), 0, 1) if kind >= 3 else cut
         o = mx.maxiFilterBank(V).render(name, dx, c, res).numpy()
         assert_bits_equal(o, port.filter(kind, x, c, res)[0], name)
+
+
+@pytest.mark.parametrize("rw", [0, 3, 4])
+def test_blocks_that_are_only_8_byte_aligned(mx, port, rw):
+    """The 16-byte pair-row streams need 16-byte aligned blocks; a block that starts 8 bytes into an allocation (a caller's view into a
+    larger buffer) must fall back to the 8-byte streams, automatically or with the pair rows requested by the knob, and give the same
+    bits: K1 (sinebuf, large enough for the pair-row rule), maxiFilter, maxiEnv, maxiDelayline, maxiSample, maxiEnvGen, noise."""
+    L = mx.lib()
+    chk = mx._lib.check
+    V, N = 1026, 48
+    rng = np.random.default_rng(rw)
+    big_in = mx.DeviceBuffer.from_numpy(np.concatenate([[0.0], rng.uniform(-1, 1, N * V)]))   # the block starts at element 1
+    big_out = mx.DeviceBuffer(N * V + 1)
+    x = big_in.numpy()[1:].reshape(N, V)
+    pin, pout = big_in.ptr + 8, big_out.ptr + 8
+
+    keep = []
+
+    def D(a):   # (device copies of the parameters must outlive the asynchronous launches that read them)
+        keep.append(mx.DeviceBuffer.from_numpy(a))
+        return keep[-1].ptr
+
+    def result():
+        return big_out.numpy()[1:].reshape(N, V).copy()
+
+    prev = L.mxg_tune(b"rw_store", rw)
+    prev_osc = L.mxg_tune(b"osc_store", 4 if rw else 0)   # (K1: pair rows requested -- must be refused for this block)
+    try:
+        # K1
+        freq = rng.uniform(20, 9000, V)
+        bank = mx.maxiOscBank(V)
+        chk(L.mxg_osc_render(8, V, N, D(freq), 0, None, None, bank.phase.ptr, bank.output.ptr, pout, None), "osc")
+        assert_bits_equal(result(), port.osc(8, freq, N)[0], "sinebuf")
+        # maxiFilter lopass
+        c = rng.uniform(0, 1, V)
+        fb = mx.maxiFilterBank(V)
+        chk(L.mxg_filter_render(3, V, N, pin, D(c), 0, None, 0, None, fb.state.ptr, pout, None), "lopass")
+        assert_bits_equal(result(), port.filter(3, x, c, None)[0], "lopass")
+        # maxiEnv adsr
+        eb = mx.maxiEnvBank(V); eb.setAttack(5); eb.setDecay(20); eb.setSustain(0.5); eb.setRelease(40)
+        dpar, dhold = eb._params()
+        trig = ((np.arange(N) % 30) < 20).astype(np.int32)
+        chk(L.mxg_env_render(0, V, N, pin, D(trig), 0, dpar.ptr, dhold.ptr, eb.dstate.ptr, eb.istate.ptr, pout,
+                             None), "adsr")
+        assert_bits_equal(result(), port.env(0, x, trig, eb.par, eb.holdtime)[0], "adsr")
+        # maxiDelayline
+        db = mx.maxiDelaylineBank(V, 64)
+        size = np.full(V, 40, np.int32); fbk = np.full(V, 0.5)
+        chk(L.mxg_delay_render(0, V, N, pin, D(size), D(fbk), None,
+                               db.memory.ptr, 64, db.phase.ptr, pout, None), "dl")
+        assert_bits_equal(result(), port.delay(0, x, size, fbk, 64)[0], "dl")
+        # maxiSample playAtSpeed
+        smp = rng.uniform(-1, 1, 5000)
+        sb = mx.maxiSampleBank(V); sb.setSample(smp)
+        pos0 = rng.uniform(0, 4000, V); sb.position.upload(pos0)
+        sp = rng.uniform(0.5, 1.5, V)
+        chk(L.mxg_sample_render(4, V, N, sb.d_samples, sb.length, 44100, D(sp), 0, None, None,
+                                sb.position.ptr, pout, None), "playAtSpeed")
+        assert_bits_equal(result(), port.sample(4, smp, N, pos0, a=sp)[0], "playAtSpeed")
+        # maxiEnvGen
+        eg = mx.maxiEnvGenBank(V); assert eg.setupADSR(2, 5, 0.4, 10)
+        gate = np.where((np.arange(N) % 30) < 20, 1.0, -1.0)
+        chk(L.mxg_envgen_render(V, N, D(gate), 0, eg.stages.ptr, 4, 0, 0, eg.dstate.ptr, eg.istate.ptr, pout,
+                                None), "envgen")
+        assert_bits_equal(result(), port.envgen(gate, [0, 1, 0.4, 0.4, 0], [2, 5, -46692.0, 10], [1, 1, 1, 1], V=V)[0], "envgen")
+        # noise
+        rnd, e = port.noise(77, V, N)
+        chk(L.mxg_osc_noise(V, N, D(np.ascontiguousarray(rnd, np.int32)), None, pout, None), "noise")
+        assert_bits_equal(result(), e, "noise")
+    finally:
+        L.mxg_tune(b"rw_store", prev)
+        L.mxg_tune(b"osc_store", prev_osc)
