@@ -7,8 +7,7 @@
 // back; a control call first rewinds the sampler to the state it had at the current sample (the block is re-rendered from its
 // start state up to there: same kernel, same bits), then edits that state on the host exactly as the reference's method does.
 // Limits against the reference: every slot plays the SAME sample (load / setSample with setall, the reference's default; a
-// per-slot load is refused with a printed error), the voice count must be 1, 2, 4, 8, 16 or 32 (setNumVoices prints an error for any
-// other count and play() then returns silence: the reference accepts any count up to 32), and the unused members (LFO1-4, filters, distortion: never touched by maxiSampler::play) are absent.
+// per-slot load is refused with a printed error), and the unused members (LFO1-4, filters, distortion: never touched by maxiSampler::play) are absent.
 #pragma once
 #include "maximilian.h"
 
@@ -122,7 +121,7 @@ class maxiSampler {
         pos_ = 0;
         nextLen_ = 1;
     }
-    bool valid() const { return voices == 1 || voices == 2 || voices == 4 || voices == 8 || voices == 16 || voices == 32; }
+    bool valid() const { return voices >= 1 && voices <= kMax; }  // (the reference's arrays hold 32 slots: beyond that it reads out of bounds)
 
 public:
     size_t launches = 0;
@@ -153,9 +152,8 @@ public:
     maxiSampler &operator=(const maxiSampler &) = delete;
     void setNumVoices(int numVoices) {
         settle();
-        voices = numVoices;
-        // (the reference accepts any count <= 32; here the slots of one sampler are gathered with lane shuffles in groups of a power of two)
-        if (!valid()) maxigpu::ps::complain("maxiSampler::setNumVoices: this backend renders 1, 2, 4, 8, 16 or 32 voices -- other counts play silence");
+        voices = numVoices;  // maxiSynths.cpp:284-289: any count; the slot arrays hold 32
+        if (!valid()) maxigpu::ps::complain("maxiSampler::setNumVoices: 1 .. 32 voices (the reference's slot arrays hold 32) -- other counts play silence");
     }
     void load(string inFile, bool setall = true) {  // maxiSynths.cpp:303-321: samples[i].load(inFile) for every slot
         if (!setall) {  // (the reference loads the file into slot `currentVoice` only)

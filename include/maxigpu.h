@@ -149,7 +149,12 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "mfcc_mfma_fullk" (the MFMA mel contraction runs over all numBins bins instead of the ones that carry weight, 0|1).
  * "fused_layout" (mxg_fft_mfcc_batch: 0 automatic, 1 = two frames in flight per wavefront and two 4-wave workgroups per CU, 2 = one
  * frame in flight and one 12-wave workgroup per CU; same bits either way),
- * "fused_waves16" (mxg_fft_mfcc_batch: the 16-waves-per-CU form of the fused kernel when the request allows it, 0|1).
+ * "fused_waves16" (mxg_fft_mfcc_batch: the 16-waves-per-CU form of the fused kernel when the request allows it, 0|1),
+ * "fused_mel" (mxg_fft_mfcc_batch, the stage after the magnitudes: 0 automatic; 1 = sparse mel walk, logs and DCT on the vector ALU in
+ * the reference's summation orders; 2 = the same walk -- band sums bit-exact -- with the DCT's 42-term sums on the matrix pipe
+ * (v_mfma_f64_4x4x4_4b_f64: fused multiply-adds, within 1e-13 x the largest band log of form 1); 3 = the mel contraction on the matrix
+ * pipe as well, banded per quad of filters: band sums within 1e-13 x the frame's largest band, mfcc within 1e-11 -- the north star's
+ * "MFMA for the mel-filterbank x frame contraction" inside the one-kernel path).
  * "osc_store" (K1's store stream: 0 automatic by waveform and bank size; one voice per lane: 1 plain 8-byte stores, 2 non-temporal,
  * 3 / 4 / 5 two samples of a lane pair exchanged into one 16-byte store per lane, plain / write-through (sc1) / non-temporal; two
  * voices per lane: 1 plain, 2 non-temporal, 3 write-through 16-byte stores), "voice_store" / "voice_xcd" (the same for the fused voice kernel; one voice
@@ -417,7 +422,7 @@ int mxg_sample_save_wav(const char *path, const double *d_samples, size_t len, c
                         void *stream);
 
 /* ---- maxiSampler banks (L/maxiSynths.h:137-187, maxiSynths.cpp:262-300) ---------------------------------- */
-/* V = NS * voices slots (voices in {1,2,4,8,16,32} consecutive lanes per sampler), all over one sample
+/* V = NS * voices slots (any voices in 1 .. 32, as maxiSampler::setNumVoices accepts: maxiSynths.cpp:284-289), all over one sample
  * buffer (mxg_sample_upload / mxg_sample_load_wav).  Renders N calls of maxiSampler::play() for every
  * sampler: per slot envOut = adsr(gain, trigger); if (envOut > 0) { outputs = play4(freq, 0, len)*envOut;
  * output += outputs/voices; if (trigger == 1 && !sustain) trigger = 0; }.  d_mix [N][NS] = play();
@@ -533,6 +538,14 @@ int mxg_mfcc_plan_destroy(mxg_mfcc_plan *plan);
  * dct[i + j*numCoeffs].  Either may be NULL.  Returns the number of leading bins that carry a
  * non-zero weight. */
 int mxg_mfcc_plan_tables(const mxg_mfcc_plan *plan, double *h_melFilters, double *h_dct);
+/* The same tables cut for the matrix pipe (knob "fused_mel" of mxg_fft_mfcc_batch): filters in quads, two quads per pair,
+ * each quad contracting over a band of 16 * nb[pair] bins from base[pair][quad] on.  h_nb [6], h_base [6][2],
+ * h_W [(batches + 1) * 128] = [batch][half][lane32 = 8 k + 4 quad + filter-of-quad][2] weights (melFilters of
+ * L/maxiMFCC.h:118-182, zero outside a filter's support), h_D [4][6][32] = dct (L/maxiMFCC.h:183-203) as
+ * [coefficient quad][pair][8 filter-of-quad + 4 quad + coefficient-of-quad].  Any pointer may be NULL.  Returns the number
+ * of batches, 0 when the bank has no such tables (more than 48 filters or 16 coefficients, a filter reading bin 0 or beyond
+ * bin 255).  Works without a device. */
+int mxg_mfcc_plan_matrix_tables(const mxg_mfcc_plan *plan, int *h_nb, int *h_base, double *h_W, size_t capW, double *h_D);
 /* mfcc() over nframes spectra d_mags[f*mag_stride + bin] (fp32, as getMagnitudes() yields) ->
  * d_mfcc [nframes][numCoeffs] (L/maxiMFCC.h:77-81).  Optional: d_melraw = the band sums before
  * the log (bit-exact with method 0), d_melbands = melBands after log-square, [nframes][numFilters].

@@ -1399,6 +1399,47 @@ class maxiSample {
     }
 
 public:
+    // `maxiTrigger zxTrig` (H:606): the zero-crossing detector of the playOnZX family.  Its two private fields are slot state
+    // (the trigger-driven players advance them on the device), so the member is a view of them with maxiTrigger's own two methods
+    // (H:569-591): a direct call settles the slot first, like every other public member that lives in the slot.
+    class ZxTrigMember {
+        maxigpu::ps::Slot *s_;
+
+    public:
+        explicit ZxTrigMember(maxigpu::ps::Slot &s) : s_(&s) {}
+        ZxTrigMember(const ZxTrigMember &) = delete;  // (bound to ONE object's slot; the owner's copy operations copy the state)
+        ZxTrigMember &operator=(const ZxTrigMember &o) {  // `a.zxTrig = b.zxTrig`: the two fields
+            maxigpu::ps::pool<Pool>().settle(*o.s_);
+            const double pv = o.s_->sd[1];
+            const int64_t ft = o.s_->si[0];
+            maxigpu::ps::pool<Pool>().settle(*s_);
+            s_->sd[1] = pv;
+            s_->si[0] = ft;
+            return *this;
+        }
+        ZxTrigMember &operator=(const maxiTrigger &) {  // a fresh maxiTrigger is all one can assign from outside: {1, first}
+            maxigpu::ps::pool<Pool>().settle(*s_);
+            s_->sd[1] = 1.0;
+            s_->si[0] = 1;
+            return *this;
+        }
+        double onZX(double input) {  // H:569-579
+            maxigpu::ps::pool<Pool>().settle(*s_);
+            double isZX = 0.0;
+            if ((s_->sd[1] <= 0.0 || s_->si[0]) && input > 0) isZX = 1.0;
+            s_->sd[1] = input;
+            s_->si[0] = 0;
+            return isZX;
+        }
+        double onChanged(double input, double tolerance) {  // H:582-591
+            maxigpu::ps::pool<Pool>().settle(*s_);
+            double changed = 0;
+            if (std::abs(input - s_->sd[1]) > tolerance) changed = 1;
+            s_->sd[1] = input;
+            return changed;
+        }
+    };
+    ZxTrigMember zxTrig{slot_};
     short myChannels = 1;      // C:546: the constructor's initialiser list -- myChannels(1), mySampleRate(maxiSettings::sampleRate)
     int mySampleRate = (int)maxiSettings::sampleRate;
     short myBitsPerSample = 0;

@@ -116,6 +116,7 @@ SIGNATURES = {
     "mxg_mfcc_plan_create": (c_void_p, [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, c_double, c_double]),
     "mxg_mfcc_plan_destroy": (c_int, [c_void_p]),
     "mxg_mfcc_plan_tables": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "mxg_mfcc_plan_matrix_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mxg_mfcc_batch": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p,
                                c_int, c_void_p]),
     "mxg_fft_mfcc_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -496,9 +496,11 @@ double hzToMel(double hz) { return 2595.0 * (log10(hz / 700.0 + 1.0)); }       /
 double melToHz(double mel) { return 700.0 * (pow(10, mel / 2595.0) - 1.0); }  // L/maxiMFCC.h:36-38
 
 void free_device(mxg_mfcc_plan *p) {
-    void *ptrs[] = {p->d_schedW, p->d_schedFin, p->d_lo, p->d_hi, p->d_off, p->d_Wc, p->d_dct, p->d_Wpad, p->d_fs8, p->d_fs16};
+    void *ptrs[] = {p->d_schedW, p->d_schedFin, p->d_lo, p->d_hi, p->d_off, p->d_Wc, p->d_dct, p->d_Wpad, p->d_fs8, p->d_fs16,
+                    p->d_mmW, p->d_mmD};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    p->d_mmW = p->d_mmD = nullptr;
     p->d_schedW = nullptr;
     p->d_schedFin = nullptr;
     p->d_lo = p->d_hi = p->d_off = nullptr;
@@ -546,6 +548,9 @@ mxg_mfcc_plan *mxg_mfcc_plan_create(unsigned numBins, unsigned numFilters, unsig
     p->fs16Steps = 0;
     p->fsMinBin = 0;
     p->d_fs16 = nullptr;
+    p->mmOk = 0;
+    p->mmBatches = 0;
+    p->d_mmW = p->d_mmD = nullptr;
     // ---- calcMelFilterBank (L/maxiMFCC.h:118-182): `sampleRate` is an unsigned int member
     const double sampleRate = (double)(unsigned int)settings().sampleRate;
     const double nyquist = sampleRate / 2;
@@ -697,6 +702,77 @@ mxg_mfcc_plan *mxg_mfcc_plan_create(unsigned numBins, unsigned numFilters, unsig
         p->fs16Steps = pack(kFusedSlots16, fs16);
         p->fsMinBin = order.empty() ? 1 : minBin;
     }
+    // ---- matrix-pipe tables of the fused kernel (mxg_spectral.h: quads of filters, pairs of quads, banded K ranges)
+    std::vector<double> mmW, mmD;
+    if (numFilters <= 4 * 2 * kMmPairs && numCoeffs <= 4 * kMmCoefQuads && numBins == 512) {
+        bool ok = true;
+        int total = 0;
+        for (int pr = 0; pr < kMmPairs && ok; pr++) {
+            int need = 1;
+            for (int gs = 0; gs < 2; gs++) {
+                int a = (int)numBins, b = -1;  // the quad's band
+                for (unsigned f = 4 * (2 * pr + gs); f < 4 * (2 * pr + gs) + 4 && f < numFilters; f++)
+                    if (hi[f] >= lo[f]) {
+                        a = lo[f] < a ? lo[f] : a;
+                        b = hi[f] > b ? hi[f] : b;
+                    }
+                if (b < a) {  // an empty quad reads the first bins with zero weights
+                    p->mmBase[pr][gs] = 0;
+                    continue;
+                }
+                if (a < 1 || b > 255) ok = false;  // bin 0 is never formed by the half-spectrum post-pass, the tile ends at bin 256
+                p->mmBase[pr][gs] = a / 4 * 4;
+                const int len = b - p->mmBase[pr][gs] + 1;
+                need = (len + 15) / 16 > need ? (len + 15) / 16 : need;
+            }
+            p->mmNb[pr] = need;
+            for (int gs = 0; gs < 2; gs++)  // every lane's reads stay inside the 260-float row
+                if (p->mmBase[pr][gs] + 16 * need > 260) p->mmBase[pr][gs] = (260 - 16 * need) / 4 * 4;
+            for (int gs = 0; gs < 2; gs++)
+                if (p->mmBase[pr][gs] < 0) ok = false;
+            total += need;
+        }
+        if (ok) {
+            p->mmBatches = total;
+            mmW.assign((size_t)(total + 1) * 128, 0.0);
+            int t0 = 0;
+            for (int pr = 0; pr < kMmPairs; pr++) {
+                const int S = 4 * p->mmNb[pr];
+                for (int s4 = 0; s4 < p->mmNb[pr]; s4++)
+                    for (int h = 0; h < 2; h++)
+                        for (int l32 = 0; l32 < 32; l32++)
+                            for (int e = 0; e < 2; e++) {
+                                const int k = l32 >> 3, gs = (l32 >> 2) & 1, i = l32 & 3;
+                                const unsigned f = 4 * (2 * pr + gs) + i;
+                                const int bin = p->mmBase[pr][gs] + k * S + 4 * s4 + 2 * h + e;
+                                double w = 0.0;
+                                if (f < numFilters && bin >= 0 && bin < (int)numBins) w = p->h_W[f + (size_t)bin * numFilters];
+                                mmW[(((size_t)(t0 + s4) * 2 + h) * 32 + l32) * 2 + e] = w;
+                            }
+                t0 += p->mmNb[pr];
+            }
+            // every non-zero weight must have landed in the table exactly once (a band that was shifted to stay inside the row
+            // could lose its first bins): count them
+            size_t nzTab = 0, nzRef = 0;
+            for (double w : mmW) nzTab += w != 0.0;
+            for (double w : p->h_W) nzRef += w != 0.0;
+            if (nzTab != nzRef) ok = false;
+            mmD.assign((size_t)kMmCoefQuads * kMmPairs * 32, 0.0);
+            for (int q = 0; q < kMmCoefQuads; q++)
+                for (int pr = 0; pr < kMmPairs; pr++)
+                    for (int l32 = 0; l32 < 32; l32++) {
+                        const int k = l32 >> 3, gs = (l32 >> 2) & 1, i = l32 & 3;
+                        const unsigned coef = 4 * q + i, f = 4 * (2 * pr + gs) + k;
+                        if (coef < numCoeffs && f < numFilters)
+                            mmD[((size_t)q * kMmPairs + pr) * 32 + l32] = p->h_dct[coef + (size_t)f * numCoeffs];
+                    }
+        }
+        p->mmOk = ok ? 1 : 0;
+        if (ok) {
+            p->h_mmW = mmW;
+            p->h_mmD = mmD;
+        }
+    }
     p->nfPad = (numFilters + 15) / 16 * 16;
     p->kPad = (nbUsed + 3) / 4 * 4;  // rows >= numBins carry zero weights; the kernel guards the A read
     // the GEMM kernel walks K in tiles of 32 bins: rows up to the next multiple of 32 of numBins exist (zeros)
@@ -708,7 +784,7 @@ mxg_mfcc_plan *mxg_mfcc_plan_create(unsigned numBins, unsigned numFilters, unsig
     if (ensure_init_only() || !upload(&p->d_lo, lo) || !upload(&p->d_hi, hi) || !upload(&p->d_off, off) ||
         !upload(&p->d_Wc, Wc) || !upload(&p->d_dct, dctT) || !upload(&p->d_Wpad, Wpad) ||
         !upload(&p->d_schedW, schedW) || !upload(&p->d_schedFin, schedFin) || !upload(&p->d_fs8, fs8) ||
-        !upload(&p->d_fs16, fs16)) {
+        !upload(&p->d_fs16, fs16) || !upload(&p->d_mmW, mmW) || !upload(&p->d_mmD, mmD)) {
         // Host tables stay valid (mxg_mfcc_plan_tables works without a device); compute calls fail.
         free_device(p);
     }
@@ -727,6 +803,19 @@ int mxg_mfcc_plan_tables(const mxg_mfcc_plan *p, double *h_melFilters, double *h
     if (h_melFilters) memcpy(h_melFilters, p->h_W.data(), sizeof(double) * p->h_W.size());
     if (h_dct) memcpy(h_dct, p->h_dct.data(), sizeof(double) * p->h_dct.size());
     return (int)p->nbUsed;
+}
+
+int mxg_mfcc_plan_matrix_tables(const mxg_mfcc_plan *p, int *h_nb, int *h_base, double *h_W, size_t capW, double *h_D) {
+    MXG_REQUIRE(p, "null plan");
+    if (!p->mmOk) return 0;
+    if (h_nb) memcpy(h_nb, p->mmNb, sizeof(p->mmNb));
+    if (h_base) memcpy(h_base, p->mmBase, sizeof(p->mmBase));
+    if (h_W) {
+        MXG_REQUIRE(capW >= p->h_mmW.size(), "h_W too small (need (batches + 1) * 128 doubles)");
+        memcpy(h_W, p->h_mmW.data(), sizeof(double) * p->h_mmW.size());
+    }
+    if (h_D) memcpy(h_D, p->h_mmD.data(), sizeof(double) * p->h_mmD.size());
+    return p->mmBatches;
 }
 
 int mxg_mfcc_batch(const mxg_mfcc_plan *p, const float *d_mags, size_t mag_stride, size_t nframes,

@@ -52,7 +52,25 @@ struct mxg_mfcc_plan {
     mxg_fs_entry *d_fs8;   // [fsSteps + 2 * kMelBatch][kFusedSlots]
     mxg_fs_entry *d_fs16;  // [fs16Steps + 2 * kMelBatch][kFusedSlots16]
     int fsMinBin;          // lowest bin any filter reads (>= 1: bin 0 is then never formed)
+    // Matrix-pipe tables of the fused kernel (knob fused_mel, spectral.hip): the mel contraction and the DCT as products of
+    // 4 x 4 blocks on v_mfma_f64_4x4x4_4b_f64.  The filters are cut into quads (4 consecutive filters), two quads form a pair
+    // p = 0 .. kMmPairs - 1 (quads 2p and 2p + 1); a quad's weights are non-zero only inside a band of bins, so quad (p, gs)
+    // contracts over the 16 * mmNb[p] bins from mmBase[p][gs] on (a multiple of 4; the pair's two bands are padded to the same
+    // length with zero weights) -- ~3 x fewer multiply-adds than a dense 16-filter column block and 21 x fewer than the dense
+    // product.  Operand lanes (A: lane 16 k + 4 b + i = A_b[i][k]; B: lane 16 k + 4 b + j = B_b[k][j]; D: lane 16 i + 4 b + j):
+    // block b = 2 gs + fh (gs: which quad of the pair, fh: which half of the 8 frames), i = filter of the quad, j = frame of
+    // the half, k = quarter of the band (lane k walks bins base + k * 4 * nb ... one by one: its magnitudes of four
+    // consecutive steps are ONE 16-byte LDS read).
+    //   d_mmW [batch t][half h][lane32 = 8 k + 4 gs + i][e]   weight of step 4 t' + 2 h + e (t' = batch inside its pair),
+    //                                                          batches of all pairs back to back + one padding batch
+    //   d_mmD [q][p][lane32 = 8 k + 4 gs + i]                 dct[coefficient 4 q + i][filter 4 (2 p + gs) + k]
+    // mmOk == 0: the bank does not fit (more than 48 filters or 16 coefficients, a filter reading bin 0 or beyond bin 255).
+    int mmOk, mmBatches;
+    int mmNb[6], mmBase[6][2];
+    double *d_mmW, *d_mmD;
+    std::vector<double> h_mmW, h_mmD;  // host copies (mxg_mfcc_plan_matrix_tables: the CPU suite replays the blocks with them)
 };
+constexpr int kMmPairs = 6, kMmCoefQuads = 4;
 constexpr int kFusedSlots = 8;
 constexpr int kFusedSlots16 = 16;
 constexpr int kMelBatch = 4;

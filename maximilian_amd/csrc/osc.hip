@@ -520,6 +520,13 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
 // an s_sleep between them.  No barrier inside a window; the two barriers per window (combine of the four consumer rows) are shared
 // by all eight wavefronts.  The sums, their order and therefore the rows' bits are the fused kernel's.
 constexpr int kPcRing = 3;
+#ifndef MXG_PC_FL
+#define MXG_PC_FL kTickLean  // A/B: the producers' tick flavour (0 = K1's own sinebuf tick: one table copy, the generic wrap)
+#endif
+#ifndef MXG_PC_ASMX
+#define MXG_PC_ASMX 1  // A/B: 0 = K1's compiler-scheduled pair exchange in the producers
+#endif
+constexpr int kPcFL = MXG_PC_FL;
 __device__ __forceinline__ int lds_flag_load(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
@@ -529,11 +536,11 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
                                                         double *__restrict__ phase_io, double *__restrict__ hold_io,
                                                         double *__restrict__ out, const double *__restrict__ pan,
                                                         double *__restrict__ partial, double sr, int passes) {
-    constexpr int kTab = tab_len<WF, kTickLean>();
+    constexpr int kTab = tab_len<WF, kPcFL>();
     constexpr int kTabPad = (kTab + 1) & ~1;
     __shared__ __attribute__((aligned(16))) double s_all[kTabPad + 4 * kPcRing * kTileWave + 4 * WIN * 2 + 256 + 8];
     double *s_tab = s_all;
-    load_tab<WF, kTickLean>(s_tab);
+    load_tab<WF, kPcFL>(s_tab);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool producer = wave < 4;
     const int pw = wave & 3;  // the pair
@@ -594,9 +601,9 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
                     if (cnt == kMixChunk && STORE == 2) {
 #pragma unroll
                         for (int i = 0; i < kMixChunk; i += 2) {
-                            const double r0 = osc_tick<WF, false, kTickLean>(ph, hd, q, s_tab, s_tab);
-                            const double r1 = osc_tick<WF, false, kTickLean>(ph, hd, q, s_tab, s_tab);
-                            store_pair_rows<2>(op, r0, r1);
+                            const double r0 = osc_tick<WF, false, kPcFL>(ph, hd, q, s_tab, s_tab);
+                            const double r1 = osc_tick<WF, false, kPcFL>(ph, hd, q, s_tab, s_tab);
+                            store_pair_rows<2, MXG_PC_ASMX != 0>(op, r0, r1);
                             op += 2 * V;
 #ifndef MXG_PC_NOTILE  // (A/B: the producer without its tile writes)
                             tw[i * kTileRow] = r0;
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
                         for (int i = 0; i < kMixChunk; i++) {
                             double r = 0.0;
                             if (i < cnt) {  // ragged last chunk: the state must not advance past N
-                                r = osc_tick<WF, false, kTickLean>(ph, hd, q, s_tab, s_tab);
+                                r = osc_tick<WF, false, kPcFL>(ph, hd, q, s_tab, s_tab);
                                 if constexpr (STORE != 0) {
                                     *o = r;
                                     o += V;
@@ -683,7 +690,7 @@ typedef void (*osc_mixpc_fn)(size_t, size_t, const double *, const double *, con
 // the 160 KB; 256 otherwise.
 template <int WF>
 constexpr bool mixpc_fits_512() {
-    return ((((tab_len<WF, kTickLean>() + 1) & ~1) + 4 * kPcRing * kTileWave + 4 * 512 * 2 + 256 + 8) * sizeof(double)) <= 160 * 1024;
+    return ((((tab_len<WF, kPcFL>() + 1) & ~1) + 4 * kPcRing * kTileWave + 4 * 512 * 2 + 256 + 8) * sizeof(double)) <= 160 * 1024;
 }
 template <int WF>
 osc_mixpc_fn pick_mixpc(int store, int win) {

@@ -30,6 +30,9 @@ namespace {
 #ifndef MXG_TAB_AUX
 #define MXG_TAB_AUX 2  // A/B: 0 = default cache policy
 #endif
+#ifndef MXG_TAB_SIDEFOLD
+#define MXG_TAB_SIDEFOLD 1  // A/B: 0 = a partial mix row per workgroup AND side (round 4: twice the rows for the row sum)
+#endif
 constexpr int kTabLen = 514;         // doubles per voice (sineBuffer[514], C:63)
 constexpr int kTabParts = 16;        // time parts per block (32 samples each), one mark per part and voice
 constexpr int kTabVoices = 8;        // voices per round
@@ -37,6 +40,30 @@ constexpr int kTabHdr = kTabParts * kTabVoices + 3 * kTabVoices;  // per-round h
 constexpr int kTabRound = kTabVoices * kTabLen + kTabHdr;         // doubles per LDS buffer: 4112 + 152 = 4264 (34 112 B)
 constexpr int kTabRing = 4;          // LDS buffers: one in use, three rounds of DMA in flight
 static_assert(kTabRound * 8 == 8 * 4096 + 84 * 16, "a round is 8 full 4 KiB pieces + 84 sixteen-byte pieces");
+
+// The wrap test ahead of the add.  C:270 tests the SUM: `phase += inc; if (phase >= 511) phase -= 512;` -- add, compare, select,
+// subtract, four dependent fp64 operations per step of a chain that nothing else can hide (the marks pass IS that chain, 512 steps per
+// voice).  d -> fl(d + inc) is monotone, so there is one double `thr` with  fl(ph + inc) >= 511  <=>  ph >= thr  for every ph that is
+// not a NaN (a NaN fails both tests): the compare then runs BESIDE the add and the chain is add -> subtract.  thr is found by bisection
+// over the doubles' order with the add itself as the oracle: no reasoning about roundings to get wrong.  Returns false where the search
+// would not bracket (inc not in (0, 511): a negative, zero, absurd or non-finite frequency): the caller keeps the reference's form.
+__device__ __forceinline__ long long dbl_key(double d) {  // order-preserving map double -> integer (both zeros -> 0)
+    const long long b = __double_as_longlong(d);
+    return b < 0 ? (long long)0x8000000000000000ull - b : b;
+}
+__device__ __forceinline__ double key_dbl(long long k) {
+    return __longlong_as_double(k < 0 ? (long long)0x8000000000000000ull - k : k);
+}
+__device__ __forceinline__ bool wrap_threshold(const double inc, double &thr) {
+    if (!(inc > 0.0 && inc < 511.0)) return false;
+    long long lo = dbl_key(-2.0), hi = dbl_key(511.0);  // fl(-2 + inc) < 511 <= fl(511 + inc)
+    while (hi - lo > 1) {
+        const long long mid = lo + (hi - lo) / 2;
+        if (key_dbl(mid) + inc >= 511) hi = mid; else lo = mid;
+    }
+    thr = key_dbl(hi);
+    return true;
+}
 
 // pass 1 (lanes = voices): the recurrence without its output -- the same additions in the same order, the same bits -- leaving per
 // group of 8 voices ONE contiguous header: the phase at the start of each 32-sample part, the increment, the two gains.  The main
@@ -57,16 +84,30 @@ __global__ void osctab_marks_kernel(size_t V, size_t N, const double *__restrict
     h[kTabParts * kTabVoices + kTabVoices + u] = sqrt(1.0 - x);  // two[0] = input*sqrt(1.0-x)   C:506
     h[kTabParts * kTabVoices + 2 * kTabVoices + u] = sqrt(x);    // two[1] = input*sqrt(x)       C:507
     const int whole = (int)(N / 32);  // parts that lie inside the block completely
+    double thr = 0.0;
+#ifndef MXG_TAB_THR
+#define MXG_TAB_THR 1  // A/B: 0 = the round-4 chain (compare on the sum)
+#endif
+    const bool ahead = MXG_TAB_THR && __all(wrap_threshold(inc, thr));  // (wave-uniform choice of the loop form)
 #pragma unroll 1
     for (int t = 0; t < kTabParts; t++) {
         h[t * kTabVoices + u] = ph;
         if (t < whole) {
+            if (ahead) {
 #pragma unroll
-            for (int k = 0; k < 32; k++) {
-                ph += inc;
-                // `if (ph >= 511) ph -= 512;` (C:270) as compare + ONE select + subtract: the subtrahend is 512.0 or +0.0, assembled from
-                // its high word (x - 0.0 is x for every x) -- four dependent instructions per step instead of five on this latency-bound chain
-                ph = ph - __hiloint2double(ph >= 511 ? 0x40800000 : 0, 0);
+                for (int k = 0; k < 32; k++) {
+                    const double sum = ph + inc;                                             // C:269
+                    const double sub = __hiloint2double(ph >= thr ? 0x40800000 : 0, 0);      // 512.0 where C:270's test holds, else +0.0
+                    ph = sum - sub;                                                          // (x - 0.0 is x for every x)
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 32; k++) {
+                    ph += inc;
+                    // `if (ph >= 511) ph -= 512;` (C:270) as compare + ONE select + subtract: the subtrahend is 512.0 or +0.0, assembled from
+                    // its high word (x - 0.0 is x for every x)
+                    ph = ph - __hiloint2double(ph >= 511 ? 0x40800000 : 0, 0);
+                }
             }
         } else {
             for (size_t n = (size_t)t * 32; n < N; n++) {
@@ -214,6 +255,7 @@ __global__ __launch_bounds__(512) void osctab_kernel(size_t V, size_t N, const d
 #pragma unroll
         for (int i = 0; i < 8; i++) idx[i] = i;
         const int slot = fold8<int>(idx, lane);  // which of 8 samples this lane's sums belong to
+        double2v pr[2];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             double L[8], R[8];
@@ -222,10 +264,37 @@ __global__ __launch_bounds__(512) void osctab_kernel(size_t V, size_t N, const d
                 L[i] = accL[8 * j + i];
                 R[i] = accR[8 * j + i];
             }
-            const double2v pr = {fold8<double>(L, lane), fold8<double>(R, lane)};
-            const size_t n = nb + 8 * j + slot;
-            if (slot >= 0 && n < N) *reinterpret_cast<double2v *>(rows + (((size_t)blockIdx.x * 2 + side) * N + n) * 2) = pr;
+            pr[j] = double2v{fold8<double>(L, lane), fold8<double>(R, lane)};
         }
+#if MXG_TAB_SIDEFOLD
+        // the two sides of the workgroup (even / odd rounds of its range) meet in LDS -- the table ring is free after the last round
+        // -- and ONE row per workgroup leaves, side 0's sum + side 1's: half the rows for the row sum to read.  Every sample n of the
+        // block belongs to exactly one lane of each side (n = nb + 8 j + slot), so the meeting place is indexed by n.
+        double2v *meet = reinterpret_cast<double2v *>(s_buf);
+        __syncthreads();  // every wavefront is out of the ring
+        if (side == 1 && slot >= 0) {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                if (nb + 8 * j + slot < N) meet[nb + 8 * j + slot] = pr[j];
+        }
+        __syncthreads();
+        if (side == 0 && slot >= 0) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const size_t n = nb + 8 * j + slot;
+                if (n < N) {
+                    const double2v o = meet[n];
+                    *reinterpret_cast<double2v *>(rows + ((size_t)blockIdx.x * N + n) * 2) = double2v{pr[j].x + o.x, pr[j].y + o.y};
+                }
+            }
+        }
+#else
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const size_t n = nb + 8 * j + slot;
+            if (slot >= 0 && n < N) *reinterpret_cast<double2v *>(rows + (((size_t)blockIdx.x * 2 + side) * N + n) * 2) = pr[j];
+        }
+#endif
     }
 }
 
@@ -241,7 +310,7 @@ static size_t tables_grid(size_t V) {  // persistent: one workgroup per CU, two 
 }
 extern "C" size_t mxg_osc_tables_groups(size_t V) {
     if (ensure_init_only()) return 0;
-    return 2 * tables_grid(V);  // a partial mix row per workgroup and side
+    return (MXG_TAB_SIDEFOLD ? 1 : 2) * tables_grid(V);  // a partial mix row per workgroup (its two sides are added in LDS)
 }
 
 extern "C" int mxg_osc_render_tables(size_t V, size_t N, const double *d_freq, const double *d_tables, double *d_phase,

@@ -10,9 +10,12 @@
 // The control side (trigger(), midiNoteOn/Off: round-robin slot allocation, maxiSynths.cpp:351-391, 484-491)
 // changes slot state between play() calls and stays on the host (the facade / Python mirror): the kernel
 // renders N samples of every slot between two control events.
-// One lane = one slot; a sampler's slots are `voices` consecutive lanes of one wavefront (voices divides
-// 64), so the sampler's output is the in-order sum of the active slots' outputs[i]/voices, gathered
-// across lanes with __shfl -- the reference's left-to-right order, hence bit-exact.
+// One lane = one slot; a sampler's slots are consecutive lanes of one wavefront -- `voices` live lanes at the
+// start of a group of `stride` = the next power of two (any count 1 .. 32, as the reference accepts:
+// maxiSynths.cpp:284-289; the surplus lanes of a group shadow a live slot and store nothing) -- so the
+// sampler's output is the in-order sum of the active slots' outputs[i]/voices, gathered across lanes with
+// __shfl -- the reference's left-to-right order, hence bit-exact.  The arrays stay unpadded: slot i of
+// sampler s is element s * voices + i.
 #include "mxg_common.h"
 #include "mxg_env.h"
 #include "mxg_smp.h"
@@ -23,7 +26,7 @@ namespace {
 
 struct SamplerArgs {
     size_t V, N;
-    int voices, sustain;
+    int voices, stride, sustain;  // stride: lanes per sampler (the next power of two >= voices)
     const double *amp;
     size_t len;
     const double *freq, *gain, *par;
@@ -38,9 +41,13 @@ struct SamplerArgs {
 
 __global__ void __launch_bounds__(256) sampler_kernel(SamplerArgs A) {
     const size_t V = A.V, N = A.N;
-    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = v < V;
-    const size_t vc = valid ? v : V - 1;  // lanes past the bank shadow the last slot (never stored)
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t sampler = t / (size_t)A.stride;
+    const int slot = (int)(t % (size_t)A.stride);
+    const size_t NS = V / (size_t)A.voices;
+    const bool valid = sampler < NS && slot < A.voices;
+    const size_t v = sampler * (size_t)A.voices + (size_t)slot;
+    const size_t vc = valid ? v : V - 1;  // surplus lanes shadow the last slot (never stored, never summed)
     Env e;
     env_load(e, V, vc, A.par, A.holdtime, A.dst, A.ist);
     Smp s = {A.amp, A.len, A.position[vc], 1.0, 0.0, false, 0.0, 0.0};
@@ -50,9 +57,7 @@ __global__ void __launch_bounds__(256) sampler_kernel(SamplerArgs A) {
     const double dvoices = (double)A.voices;
     const double end = (double)A.len;  // play4(freq, 0, samples[i].getLength())
     const int lane = threadIdx.x & 63;
-    const int g0 = lane - (lane % A.voices);  // first lane of this sampler
-    const size_t sampler = v / (size_t)A.voices;
-    const size_t NS = V / (size_t)A.voices;
+    const int g0 = lane - (lane % A.stride);  // first lane of this sampler
     for (size_t n = 0; n < N; n++) {
         const double envOut = env_adsr(e, gain, trigger);
         const bool active = envOut > 0.;
@@ -111,16 +116,19 @@ int mxg_sampler_render(size_t V, size_t N, int voices, int sustain, const double
                        double *d_position, int32_t *d_trigger, double *d_outhold, double *d_dst, int64_t *d_ist,
                        double *d_mix, double *d_outputs, void *stream) {
     if (int s = ensure_init()) return s;
-    MXG_REQUIRE(voices >= 1 && voices <= 32 && (64 % voices) == 0, "voices must be 1, 2, 4, 8, 16 or 32");
+    MXG_REQUIRE(voices >= 1 && voices <= 32, "voices must be 1 .. 32 (maxiSampler holds 32 slots, src/libs/maxiSynths.h:170-175)");
     MXG_REQUIRE(V % (size_t)voices == 0, "V must be a whole number of samplers");
     MXG_REQUIRE(d_samples && d_freq && d_gain && d_par && d_holdtime && d_position && d_trigger && d_outhold &&
                     d_dst && d_ist && d_mix, "null device pointer");
     MXG_REQUIRE(len > 0, "empty sample");
     if (V == 0 || N == 0) return MXG_OK;
-    const SamplerArgs A = {V, N, voices, sustain, d_samples, len, d_freq, d_gain, d_par, d_holdtime, d_position,
+    int stride = 1;
+    while (stride < voices) stride *= 2;
+    const SamplerArgs A = {V, N, voices, stride, sustain, d_samples, len, d_freq, d_gain, d_par, d_holdtime, d_position,
                            d_trigger, d_outhold, d_dst, d_ist, d_mix, d_outputs, (double)settings().sampleRate};
     const int block = 256;
-    hipLaunchKernelGGL(sampler_kernel, dim3((unsigned)((V + block - 1) / block)), dim3(block), 0, resolve_stream(stream), A);
+    const size_t lanes = V / (size_t)voices * (size_t)stride;
+    hipLaunchKernelGGL(sampler_kernel, dim3((unsigned)((lanes + block - 1) / block)), dim3(block), 0, resolve_stream(stream), A);
     return check_hip(hipGetLastError(), "sampler_kernel launch");
 }
 

@@ -290,6 +290,75 @@ __device__ __forceinline__ float dct_dot_rows_f(const float *d, const float *m, 
     return c;
 }
 
+// ---- the mel contraction and the DCT on the matrix pipe (knob fused_mel; tables: mxg_mfcc_plan::d_mmW / d_mmD) ------------------
+// v_mfma_f64_4x4x4_4b_f64 multiplies four independent 4 x 4 x 4 blocks: A lane 16 k + 4 b + i = A_b[i][k], B lane 16 k + 4 b + j =
+// B_b[k][j], D lane 16 i + 4 b + j = D_b[i][j] (tools/ubench/mfma_probe.hip, profiles/r02_ubench.md).  For a group of 8 frames
+// block b = 2 gs + fh multiplies the weights of quad gs of a filter pair (A_b[i][k]: filter i of the quad, bin of quarter k) by
+// the magnitudes of the frames 4 fh .. 4 fh + 3 (B_b[k][j]); four instructions consume one 16-byte magnitude read and two 16-byte
+// weight reads per lane.  Sixteen clocks of the matrix pipe per instruction, no vector ALU work except the fp32 -> fp64
+// conversions.  The band sums leave in D layout (lane = filter-of-quad i, block, frame-of-half j), which is exactly the B layout
+// of the DCT's instructions (k = filter of the quad): the logs are taken in place and the DCT is 24 more instructions
+// (4 coefficient quads x 6 pairs) followed by ONE cross-lane add (the two quads of a pair sit 8 lanes apart).  Sums are fused
+// multiply-adds in the matrix pipe's order: not the reference's sequential sums -- within 1e-13 of a frame's largest band.
+struct MmLane {
+    int k, gs, fh, ij, lane32;
+};
+__device__ __forceinline__ MmLane mm_lane(const int lane) {
+    MmLane L;
+    L.k = lane >> 4; L.gs = (lane >> 3) & 1; L.fh = (lane >> 2) & 1; L.ij = lane & 3;
+    L.lane32 = 8 * L.k + 4 * L.gs + L.ij;
+    return L;
+}
+typedef float f4e __attribute__((ext_vector_type(4)));
+struct MmArgs {
+    int nb[kMmPairs], base[kMmPairs][2];
+};
+__device__ __forceinline__ void mel_mfma(const float *M, const unsigned mstride, const double *s_mmW, const MmArgs &mm,
+                                         const MmLane &L, double (&acc)[kMmPairs]) {
+    const float *mrow = M + (4 * L.fh + L.ij) * mstride;
+    const d2f *wq = reinterpret_cast<const d2f *>(s_mmW) + L.lane32;  // [(batch * 2 + half) * 32 + lane32]
+#pragma unroll
+    for (int p = 0; p < kMmPairs; p++) {
+        const int nb = mm.nb[p];
+        const int base = L.gs ? mm.base[p][1] : mm.base[p][0];
+        const f4e *mp = reinterpret_cast<const f4e *>(mrow + base + L.k * 4 * nb);
+        double a = 0.0;
+        f4e f = mp[0];
+        d2f w0 = wq[0], w1 = wq[32];
+        for (int s4 = 0; s4 < nb; s4++) {
+            const int sn = s4 + 1 < nb ? s4 + 1 : s4;  // the last batch re-reads itself (unused)
+            const f4e fn = mp[sn];
+            const d2f w0n = wq[sn * 64], w1n = wq[sn * 64 + 32];
+            a = __builtin_amdgcn_mfma_f64_4x4x4f64(w0.x, (double)f.x, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f64_4x4x4f64(w0.y, (double)f.y, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f64_4x4x4f64(w1.x, (double)f.z, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f64_4x4x4f64(w1.y, (double)f.w, a, 0, 0, 0);
+            f = fn; w0 = w0n; w1 = w1n;
+        }
+        acc[p] = a;
+        wq += nb * 64;
+    }
+}
+// log-square in place, then the DCT; C[q] of the lanes with gs == 0 = coefficient 4 q + (lane >> 4) of frame 4 fh + ij, not yet
+// divided by numCoeffs
+__device__ __forceinline__ void dct_mfma(const double (&lg)[kMmPairs], const double *s_mmD, const MmLane &L,
+                                         double (&C)[kMmCoefQuads]) {
+    const double *dq = s_mmD + L.lane32;
+#pragma unroll
+    for (int q = 0; q < kMmCoefQuads; q++) {
+        double dv[kMmPairs];
+#pragma unroll
+        for (int p = 0; p < kMmPairs; p++) dv[p] = dq[(q * kMmPairs + p) * 32];
+        double c = 0.0;
+#pragma unroll
+        for (int p = 0; p < kMmPairs; p++) c = __builtin_amdgcn_mfma_f64_4x4x4f64(dv[p], lg[p], c, 0, 0, 0);
+        // the other quad of the pair: 8 lanes on inside the row of 16 (row_ror:8)
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(c), 0x128, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(c), 0x128, 0xf, 0xf, false);
+        C[q] = c + __hiloint2double(hi, lo);
+    }
+}
+
 struct FusedArgs {
     const float *signal;
     size_t frame_stride, nframes;
@@ -308,6 +377,9 @@ struct FusedArgs {
     const double *dct;
     float *mags;
     double *melraw, *melbands, *mfcc;
+    const double *mmW, *mmD;  // MEL >= 1: the matrix-pipe tables (mxg_mfcc_plan::d_mmW / d_mmD)
+    int mmBatches;
+    MmArgs mm;
 };
 
 // FULL: magnitudes of all 512 bins are needed (written out, or the bank reaches beyond bin 256)
@@ -329,17 +401,23 @@ struct FusedArgs {
 // <= 256 VGPRs).  NF = 1, WAVES = 12 keeps ONE frame in flight per wavefront and one 768-thread workgroup per CU: 3 wavefronts per
 // SIMD (<= 168 VGPRs; one X image instead of two is what lets twelve 8-frame magnitude tiles fit the 160 KB) -- the third
 // wavefront covers the transposes' latency instead of the second frame, and the VALU issues faster with three to pick from.
-template <bool FULL, bool WRITE_MAGS, bool ALIGNED8, int MODE, int NF, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(const FusedArgs A) {
+// MEL (knob fused_mel): 0 = the sparse mel walk, logs one band per lane, DCT one coefficient per lane (vector ALU, the reference's
+// summation orders); 2 = the same walk (band sums bit-exact), then the logs in matrix layout and the DCT on the matrix pipe
+// (dct_mfma: the DCT's 42-term sums are fused multiply-adds -- they only ever saw the device log's values, the mfcc tolerance is
+// unchanged); 1 = the mel contraction on the matrix pipe as well (mel_mfma: band sums within 1e-13 of the largest band).
+// MEL >= 1 runs as ONE 8-wave workgroup per CU (the tables once per CU) on rows of 260 floats (bins 0 .. 256, bin 0 kept at 0).
+template <bool FULL, bool WRITE_MAGS, bool ALIGNED8, int MODE, int NF, int WAVES, int MEL = 0>
+__global__ __launch_bounds__(64 * WAVES, NF == 2 ? (WAVES == 8 ? 2 : 2) : 1) void fft_mfcc_kernel(const FusedArgs A) {
     constexpr bool TOL = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-    // [fs (steps + 2 batches) * 8 entries][dct NF*NC f64, padded to 16 B] | per wave: XA (= band rows), XB, M
+    // [fs (steps + 2 batches) * 8 entries | mmW][dct NF*NC f64, padded to 16 B | mmD] | per wave: XA (= band rows), XB, M
     mxg_fs_entry *s_fs = reinterpret_cast<mxg_fs_entry *>(s_dyn);
     const int fsRows = A.steps + 2 * kMelBatch;
-    double *s_d = reinterpret_cast<double *>(s_fs + (size_t)fsRows * kFusedSlots);
+    double *s_mmW = reinterpret_cast<double *>(s_dyn);
+    double *s_d = MEL == 1 ? s_mmW + (size_t)(A.mmBatches + 1) * 128 : reinterpret_cast<double *>(s_fs + (size_t)fsRows * kFusedSlots);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t perWaveBytes = NF * sizeof(float2) * kX1024 + sizeof(float) * (kGroup * A.mstride + A.mslack);
-    v2f *s_twl = reinterpret_cast<v2f *>(s_d + A.dctPad);  // NF == 1: [8][7] round-2 twiddles by lane & 7, then [64][7] round-3 by lane
+    v2f *s_twl = reinterpret_cast<v2f *>(s_d + (MEL >= 1 ? kMmCoefQuads * kMmPairs * 32 : A.dctPad));  // NF == 1: [8][7] round-2 twiddles by lane & 7, then [64][7] round-3 by lane
     constexpr int kTwl = NF == 1 ? (8 + 64) * 7 : 0;
     char *wbase = reinterpret_cast<char *>(s_twl + kTwl) + (size_t)wave * perWaveBytes;
     v2f *X[NF];
@@ -349,7 +427,15 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
     float *M = reinterpret_cast<float *>(wbase + NF * sizeof(float2) * kX1024);
     fs32_entry *s_fs32 = reinterpret_cast<fs32_entry *>(s_dyn);  // tolerance mode: the same tables in fp32, in the same place
     float *s_df = reinterpret_cast<float *>(s_d);
-    if constexpr (TOL) {
+    if constexpr (MEL >= 1) {
+        if constexpr (MEL == 1) {
+            for (int i = threadIdx.x; i < (A.mmBatches + 1) * 128; i += blockDim.x) s_mmW[i] = A.mmW[i];
+        } else {
+            for (int i = threadIdx.x; i < fsRows * kFusedSlots; i += blockDim.x) s_fs[i] = A.fs[i];
+        }
+        for (int i = threadIdx.x; i < kMmCoefQuads * kMmPairs * 32; i += blockDim.x) s_d[i] = A.mmD[i];
+        if (lane < kGroup) M[lane * A.mstride] = 0.0f;  // bin 0 of every row: never formed, read with zero weights
+    } else if constexpr (TOL) {
         for (int i = threadIdx.x; i < fsRows * kFusedSlots; i += blockDim.x) {
             const mxg_fs_entry e = A.fs[i];
             s_fs32[i] = fs32_entry{(float)e.w, e.off, e.fid / 2, 0};
@@ -716,7 +802,39 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
         wave_lds_sync();
         continue;
 #endif
-        if constexpr (TOL) {
+        // ---- matrix layout tail (MEL >= 1): logs in place, DCT on the matrix pipe, one coalescing-free store per coefficient quad
+        auto finish_mm = [&](const MmLane &L, const double (&acc)[kMmPairs]) {
+            double lg[kMmPairs];
+#pragma unroll
+            for (int p = 0; p < kMmPairs; p++) lg[p] = log_square(acc[p]);  // L/maxiMFCC.cpp:63
+            const size_t fr = f0 + 4 * L.fh + L.ij;
+            if (A.melraw || A.melbands) {
+#pragma unroll
+                for (int p = 0; p < kMmPairs; p++) {
+                    const unsigned ff = 4 * (2 * p + L.gs) + L.k;
+                    if (ff < A.numFilters && fr < nframes) {
+                        if (A.melraw) A.melraw[fr * A.numFilters + ff] = acc[p];
+                        if (A.melbands) A.melbands[fr * A.numFilters + ff] = lg[p];
+                    }
+                }
+            }
+            double C[kMmCoefQuads];
+            dct_mfma(lg, s_d, L, C);
+            if (L.gs == 0 && fr < nframes) {
+#pragma unroll
+                for (int q = 0; q < kMmCoefQuads; q++)
+                    if (4u * q + L.k < A.numCoeffs) A.mfcc[fr * A.numCoeffs + 4 * q + L.k] = C[q] / (double)A.numCoeffs;  // L/maxiMFCC.h:108
+            }
+        };
+        if constexpr (MEL == 1) {
+            const MmLane L = mm_lane(lane);
+            double acc[kMmPairs];
+            mel_mfma(M, A.mstride, s_mmW, A.mm, L, acc);
+            finish_mm(L, acc);
+            wave_lds_sync();
+            continue;
+        }
+        if constexpr (TOL && MEL == 0) {
             // ---- tolerance mode: the same three phases in fp32 (mel_walk_t, v_log_f32, dct_dot_rows_f) ---------------------------
             float *s_melf = reinterpret_cast<float *>(s_mel);
             for (unsigned i = lane; i < kGroup * A.nfpf; i += 64) s_melf[i] = 0.0f;  // empty filters and the row padding stay 0
@@ -749,6 +867,15 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? 2 : 1) void fft_mfcc_kernel(c
         wave_lds_sync();
         mel_walk<kFusedSlots>(reinterpret_cast<const char *>(M + mj * A.mstride), s_mel + mj * A.nfp, s_fs + ms, A.steps);
         wave_lds_sync();
+        if constexpr (MEL == 2) {  // the exact band sums into matrix layout (rows of nfp >= 48 doubles, zeros beyond numFilters)
+            const MmLane L = mm_lane(lane);
+            double acc[kMmPairs];
+#pragma unroll
+            for (int p = 0; p < kMmPairs; p++) acc[p] = s_mel[(4 * L.fh + L.ij) * A.nfp + 4 * (2 * p + L.gs) + L.k];
+            finish_mm(L, acc);
+            wave_lds_sync();
+            continue;
+        }
         // ---- log-square (L/maxiMFCC.cpp:63), one band per lane ---------------------------------------------
         for (unsigned idx = lane; idx < kGroup * A.numFilters; idx += 64) {
             const unsigned jj = idx / A.numFilters, ff = idx - jj * A.numFilters;
@@ -1026,7 +1153,29 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
     int layout = (int)tune_get("fused_layout");
     if (layout == 0) layout = tol ? 2 : 1;  // measured (1 M frames): exact 1.36 / 1.34-1.38 ms, tolerance mode 1.10 / 1.06 ms for layouts 1 / 2
     if (layout == 2 && (full || lds_for(1, kWaves1, 0) > 160 * 1024)) layout = 1;
-    const int nf = layout == 2 ? 1 : 2, waves = layout == 2 ? kWaves1 : kWavesPerBlock, wgPerCU = layout == 2 ? 1 : 2;
+    // mel / log / DCT stage (knob fused_mel): the matrix-pipe forms need the plan's quad tables, a half-spectrum launch and a bank
+    // inside bins [1, 255]; they run as one 8-wave workgroup per CU on rows of 260 floats
+    int mel = (int)tune_get("fused_mel");
+    if (mel == 0) mel = 1;  // automatic
+    const bool mmOk = mp->mmOk && mp->d_mmW && mp->d_mmD && !full && !A.edgeBins;
+    const int MEL = mel == 3 && mmOk ? 1 : (mel == 2 && mmOk ? 2 : 0);
+    if (MEL) {
+        layout = 1;
+        A.mstride = 260;
+        A.mmW = mp->d_mmW; A.mmD = mp->d_mmD; A.mmBatches = mp->mmBatches;
+        for (int pr = 0; pr < kMmPairs; pr++) {
+            A.mm.nb[pr] = mp->mmNb[pr];
+            A.mm.base[pr][0] = mp->mmBase[pr][0];
+            A.mm.base[pr][1] = mp->mmBase[pr][1];
+        }
+        if (MEL == 2) A.nfp = 50;  // band rows of >= 48 doubles (the matrix layout reads quads up to filter 47), 16-byte aligned, odd half
+    } else {
+        A.mmW = A.mmD = nullptr;
+        A.mmBatches = 0;
+    }
+    constexpr int kWavesMm = 8;
+    const int nf = layout == 2 ? 1 : 2, waves = MEL ? kWavesMm : (layout == 2 ? kWaves1 : kWavesPerBlock),
+              wgPerCU = MEL || layout == 2 ? 1 : 2;
     // unconditional magnitude stores (see FusedArgs::mUncond): rows of >= 257 floats, or a slack behind the tile that still lets
     // the layout's workgroups share a CU
     A.mslack = 0;
@@ -1035,7 +1184,12 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
         A.mslack = slackWanted;
         A.mUncond = 1;
     }
-    const size_t lds = lds_for(nf, waves, A.mslack);
+    size_t lds = lds_for(nf, waves, A.mslack);
+    if (MEL)  // [mmW (batches + 1) KB | fs][mmD 6 KB] + 8 waves x (two X images + the 8 x 260 tile)
+        lds = (MEL == 1 ? sizeof(double) * 128 * (size_t)(A.mmBatches + 1) : sizeof(mxg_fs_entry) * (size_t)(A.steps + 2 * kMelBatch) * kFusedSlots) +
+              sizeof(double) * kMmCoefQuads * kMmPairs * 32 + waves * (nf * sizeof(float2) * kX1024 + sizeof(float) * kGroup * A.mstride);
+    if (MEL && (lds > 160 * 1024 || sizeof(double) * kGroup * A.nfp > sizeof(float2) * kX1024))
+        return fail(MXG_ERR_INVALID, "fused_mel %d: the tables do not fit the LDS (%zu bytes)", mel, lds);
     MXG_REQUIRE(lds <= 160 * 1024, "filter bank too large for the fused kernel's LDS layout");
     const size_t ngroups = (nframes + kGroup - 1) / kGroup;
     size_t blocks = (ngroups + waves - 1) / waves;
@@ -1055,6 +1209,14 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
         k = MXG_PICK_FULL(true);
     else if (full)
         k = MXG_PICK_FULL(false);
+    else if (MEL == 1)
+        k = mode == 2   ? (aligned8 ? fft_mfcc_kernel<false, false, true, 2, 2, kWavesMm, 1> : fft_mfcc_kernel<false, false, false, 2, 2, kWavesMm, 1>)
+            : mode == 1 ? (aligned8 ? fft_mfcc_kernel<false, false, true, 1, 2, kWavesMm, 1> : fft_mfcc_kernel<false, false, false, 1, 2, kWavesMm, 1>)
+                        : (aligned8 ? fft_mfcc_kernel<false, false, true, 0, 2, kWavesMm, 1> : fft_mfcc_kernel<false, false, false, 0, 2, kWavesMm, 1>);
+    else if (MEL == 2)
+        k = mode == 2   ? (aligned8 ? fft_mfcc_kernel<false, false, true, 2, 2, kWavesMm, 2> : fft_mfcc_kernel<false, false, false, 2, 2, kWavesMm, 2>)
+            : mode == 1 ? (aligned8 ? fft_mfcc_kernel<false, false, true, 1, 2, kWavesMm, 2> : fft_mfcc_kernel<false, false, false, 1, 2, kWavesMm, 2>)
+                        : (aligned8 ? fft_mfcc_kernel<false, false, true, 0, 2, kWavesMm, 2> : fft_mfcc_kernel<false, false, false, 0, 2, kWavesMm, 2>);
     else if (layout == 2)
         k = MXG_PICK(false, false, 1, kWaves1);
     else

@@ -114,6 +114,16 @@ void play(double *output) {
         s3.trigger();
     }
     if (n >= 16000 && n < 20000) sv += s3.play4(0.5, 100, 5000) + s3.playAtSpeedBetweenPoints(1.5, 200, 4000);
+    // the public member zxTrig (H:606), called directly from user code and then driven by a player: the detector's state is shared
+    if (n >= 12000 && n < 14000) {
+        const double tr = ((n / 250) & 1) ? 1.0 : -1.0;
+        if ((n % 500) == 125) sv += 2.0 * s2.zxTrig.onZX(tr) + s2.zxTrig.onChanged(tr * 0.5, 0.1);
+        sv += 0.5 * s2.playOnZX(tr);
+    }
+    if (n == 14000) {
+        s1.zxTrig = s2.zxTrig;         // maxiTrigger's implicit copy assignment
+        sv += s1.zxTrig.onZX(1.0);
+    }
     if (n == 20000) s3.clear();
     if (n >= 20000) sv += (double)s3.amplitudes.size() + s3.isReady();
     output[0] = g + held * (n >= 6000);

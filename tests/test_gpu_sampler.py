@@ -19,7 +19,7 @@ def _case(voices, NS, seed):
         hold=rng.integers(1, 50, V), trig=(rng.uniform(size=V) < 0.6).astype(np.int32))
 
 
-@pytest.mark.parametrize("voices", [32, 8, 1])
+@pytest.mark.parametrize("voices", [32, 8, 1, 3, 6, 21, 31])
 @pytest.mark.parametrize("sustain", [1, 0])
 def test_sampler_render_vs_oracle(mx, port, voices, sustain):
     NS, N = 7, 1500
@@ -58,7 +58,7 @@ def test_sampler_render_vs_oracle(mx, port, voices, sustain):
         assert_bits_equal(ddst.numpy(), e[5], "env amplitude/output")
         assert np.array_equal(dist.numpy(), e[6])
     assert np.abs(e[0]).max() > 0.01
-    assert L.mxg_sampler_render(V, N, 5, sustain, sb.d_samples, c["smp"].size, dfreq.ptr, dgain.ptr, dpar.ptr, dhold.ptr,
+    assert L.mxg_sampler_render(V, N, 33, sustain, sb.d_samples, c["smp"].size, dfreq.ptr, dgain.ptr, dpar.ptr, dhold.ptr,
                                 dpos.ptr, dtrig.ptr, dout.ptr, ddst.ptr, dist.ptr, mix.ptr, None, None) == -1
 
 

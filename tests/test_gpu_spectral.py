@@ -221,6 +221,93 @@ def test_fused_non_finite_frames(mx, port, fused_form):
     assert np.abs(half[good] - emf[good]).max() <= MFCC_RTOL * max(np.abs(emel[good]).max(), 1e-300)
 
 
+MM_BAND_RTOL = 1e-13   # matrix-pipe mel contraction (fused_mel 3): fused multiply-adds in the matrix pipe's order, x the frame's largest band
+MM_DCT_RTOL = 1e-13    # matrix-pipe DCT (fused_mel 2 and 3) against the sequential DCT on the SAME logs, x the largest |band log|
+
+
+@pytest.mark.parametrize("nf,nc,nfr,off", [(42, 13, 1003, 0), (42, 13, 250, 3), (13, 5, 1, 0), (48, 16, 77, 0), (26, 13, 100, 0),
+                                           (40, 20, 77, 0), (64, 13, 9, 0), (42, 13, 8 * 8 * 256 + 13, 0)])
+@pytest.mark.parametrize("mel", [2, 3])
+def test_fused_matrix_pipe_forms(mx, port, mel, nf, nc, nfr, off):
+    """Knob fused_mel: 2 = the sparse walk (band sums bit-exact) with the logs in matrix layout and the DCT on
+    v_mfma_f64_4x4x4; 3 = the banded mel contraction on the matrix pipe as well.  Against the vector form (fused_mel 1) on the
+    same device and against the oracle; banks the quad tables do not cover (more than 48 filters / 16 coefficients) fall back to
+    the vector form and must give its bits."""
+    rng = np.random.default_rng(nf * 100 + nfr + mel)
+    stride = 1024 if off == 0 else 1025
+    sig = (rng.uniform(-1, 1, stride * nfr + 8) * np.repeat(10.0 ** rng.uniform(-4, 0, nfr + 1), stride)[:stride * nfr + 8]
+           ).astype(np.float32)
+    d = mx.DeviceBuffer.from_numpy(sig)
+    f = mx.maxiFFT(); f.setup(1024, 1024, 1024)
+    m = mx.maxiMFCC(); m.setup(512, nf, nc, 20.0, 20000.0)
+    base = d.ptr + 4 * off
+    L = mx.lib()
+    prev = L.mxg_tune(b"fused_mel", 1)
+    try:
+        ref = m.mfcc_of_frames(f, base, nfr, frame_stride=stride, want_bands=True).numpy()
+        raw1, bands1 = m.melraw.numpy(), m.melBands.numpy()
+        L.mxg_tune(b"fused_mel", mel)
+        out = m.mfcc_of_frames(f, base, nfr, frame_stride=stride, want_bands=True).numpy()
+        raw, bands = m.melraw.numpy(), m.melBands.numpy()
+        out_only = m.mfcc_of_frames(f, base, nfr, frame_stride=stride).numpy()
+    finally:
+        L.mxg_tune(b"fused_mel", prev)
+    assert_bits_equal(out_only, out, "mfcc-only launch vs launch with the band outputs")
+    covered = nf <= 48 and nc <= 16
+    top = max(np.abs(bands1).max(), 1e-300)
+    if not covered:
+        assert_bits_equal(out, ref, "bank outside the quad tables: the vector form's bits")
+        assert_bits_equal(raw, raw1, "band sums")
+        return
+    if mel == 2:
+        assert_bits_equal(raw, raw1, "fused_mel 2: the walk's band sums")
+        assert_bits_equal(bands, bands1, "fused_mel 2: the same log on the same sums")
+        assert np.abs(out - ref).max() <= MM_DCT_RTOL * top
+    else:
+        rowmax = np.maximum(np.abs(raw1).max(axis=1, keepdims=True), 1e-300)
+        assert (np.abs(raw - raw1) / rowmax).max() <= MM_BAND_RTOL
+        assert np.array_equal(raw == 0.0, raw1 == 0.0), "empty filters stay exactly zero"
+        assert np.abs(out - ref).max() <= MFMA_RTOL * max(1.0, top)
+    frames = np.stack([sig[off + stride * k: off + stride * k + 1024] for k in range(nfr)])
+    e = port.fft_stream(frames.reshape(-1), 1024, 1024, 1024, want=("mags",))["mags"]
+    emel, emf = port.mfcc(e, nf, nc, 20.0, 20000.0)
+    assert np.abs(out - emf).max() <= (MFCC_RTOL if mel == 2 else MFMA_RTOL) * max(np.abs(emel).max(), 1.0)
+
+
+@pytest.mark.parametrize("mel", [2, 3])
+def test_fused_matrix_pipe_non_finite_and_silent_frames(mx, port, mel):
+    """NaN / Inf frames (every band NaN -> the reference's `: 0` branch -> mfcc 0) must not leak into the other frames of their
+    8-frame group (a matrix block multiplies the frames of one half column by column), and silent frames stay exactly zero."""
+    rng = np.random.default_rng(7 + mel)
+    nfr = 40
+    sig = rng.uniform(-1, 1, 1024 * nfr).astype(np.float32)
+    sig[3 * 1024 + 100] = np.nan
+    sig[9 * 1024 + 513] = -np.inf
+    sig[17 * 1024 + 1023] = np.inf
+    sig[20 * 1024: 22 * 1024] = 0.0
+    bad, silent = [3, 9, 17], [20, 21]
+    d = mx.DeviceBuffer.from_numpy(sig)
+    f = mx.maxiFFT(); f.setup(1024, 1024, 1024)
+    m = mx.maxiMFCC(); m.setup(512, 42, 13, 20.0, 20000.0)
+    L = mx.lib()
+    prev = L.mxg_tune(b"fused_mel", 1)
+    try:
+        ref = m.mfcc_of_frames(f, d.ptr, nfr, want_bands=True).numpy()
+        raw1 = m.melraw.numpy()
+        L.mxg_tune(b"fused_mel", mel)
+        out = m.mfcc_of_frames(f, d.ptr, nfr, want_bands=True).numpy()
+        raw = m.melraw.numpy()
+    finally:
+        L.mxg_tune(b"fused_mel", prev)
+    # (filter 0 has no support: the walk never visits it and leaves 0, the matrix product multiplies its zero weights with the NaN
+    # magnitudes like the reference's dense loop does, L/maxiMFCC.cpp:52-60 -- NaN; both take the `: 0` branch of :63)
+    assert np.array_equal(np.isnan(raw[:, 1:]), np.isnan(raw1[:, 1:])) and np.isfinite(np.delete(raw, bad, axis=0)).all()
+    assert np.array_equal(out[bad], np.zeros((len(bad), 13))) and np.array_equal(out[silent], np.zeros((2, 13)))
+    good = np.setdiff1d(np.arange(nfr), bad)
+    assert np.isfinite(out[good]).all()
+    assert np.abs(out[good] - ref[good]).max() <= (MM_DCT_RTOL if mel == 2 else MFMA_RTOL) * 30.0
+
+
 def test_survey_mfcc_anchor_on_device(mx, port):
     """SURVEY 8(c)'s anchor (third frame of sawn(220), fft 1024/512/1024, mfcc 512/42/13/20/20000) through the device
     path: streaming maxiFFT + maxiMFCC, within the log tolerance of the recorded glibc values."""

@@ -141,3 +141,82 @@ def test_convolve_port_matches_reference(port, ref):
                 assert same, ("impulse %d, fft %d, hop %d, mode %d, array %d (0 out, 1 impR, 2 impI): %d of %d differ, "
                               "max |ref| %.3g, max |port| %.3g" % (Li, F, H, mode, which, int((u != v).sum()), u.size,
                                                                   np.abs(u).max(), np.abs(v).max()))
+
+
+def _mfma_4x4x4_4b(a, b, c):
+    """v_mfma_f64_4x4x4_4b_f64 on 64-lane operand vectors, as measured on gfx950 (tools/ubench/mfma_probe.hip): four independent
+    4 x 4 x 4 blocks; A lane 16 k + 4 blk + i = A_blk[i][k], B lane 16 k + 4 blk + j = B_blk[k][j], D lane 16 i + 4 blk + j."""
+    d = np.array(c, np.float64).copy()
+    for blk in range(4):
+        for i in range(4):
+            for j in range(4):
+                acc = d[16 * i + 4 * blk + j]
+                for k in range(4):
+                    acc += a[16 * k + 4 * blk + i] * b[16 * k + 4 * blk + j]
+                d[16 * i + 4 * blk + j] = acc
+    return d
+
+
+@pytest.mark.parametrize("cfg", [(42, 13, 20.0, 20000.0), (48, 16, 20.0, 20000.0), (13, 5, 20.0, 20000.0), (26, 13, 300.0, 8000.0),
+                                 (30, 12, 50.0, 22050.0)])
+def test_matrix_pipe_tables_replay(port, cfg):
+    """The quad tables of knob fused_mel (mxg_mfcc_plan_matrix_tables): replaying the fused kernel's lane program on the host --
+    the same lane -> (quarter k, quad gs, frame half fh, row i / column j) maps, the same batches -- reproduces the oracle's band
+    sums and mfcc within the stated tolerances.  What this pins without a GPU: the tables cover every non-zero weight exactly
+    once, every read stays inside a 260-float magnitude row, and the D layout of the mel product IS the B layout of the DCT."""
+    import ctypes
+    import maximilian_amd as mx
+    nf, nc, lo_f, hi_f = cfg
+    mx.lib().mxg_settings(44100, 2, 1024)
+    port.settings(44100, 2, 1024)
+    m = mx.maxiMFCC()
+    m.setup(512, nf, nc, lo_f, hi_f)
+    nb = (ctypes.c_int * 6)()
+    base = (ctypes.c_int * 12)()
+    W = np.zeros(64 * 128)
+    D = np.zeros(4 * 6 * 32)
+    batches = mx.lib().mxg_mfcc_plan_matrix_tables(m.plan, nb, base, W.ctypes.data, W.size, D.ctypes.data)
+    assert batches == sum(nb) and batches > 0
+    rng = np.random.default_rng(nf)
+    mags = (np.abs(rng.normal(size=(8, 512))) * 10.0 ** rng.uniform(-3, 1.5, (8, 1))).astype(np.float32)
+    M = np.zeros((8, 260), np.float32)
+    M[:, 1:257] = mags[:, 1:257]          # the tile the post-pass leaves: bins 1 .. 256, bin 0 kept at zero
+    lanes = np.arange(64)
+    k, gs, fh, ij = lanes >> 4, (lanes >> 3) & 1, (lanes >> 2) & 1, lanes & 3
+    lane32 = 8 * k + 4 * gs + ij
+    acc = np.zeros((6, 64))
+    t0 = 0
+    for p in range(6):
+        a = np.zeros(64)
+        for s4 in range(nb[p]):
+            for u in range(4):
+                h, e = u >> 1, u & 1
+                w = W[(((t0 + s4) * 2 + h) * 32 + lane32) * 2 + e]
+                col = np.array([base[2 * p + g] for g in gs]) + k * 4 * nb[p] + 4 * s4 + u
+                assert col.min() >= 0 and col.max() < 260
+                x = M[4 * fh + ij, col].astype(np.float64)
+                a = _mfma_4x4x4_4b(w, x, a)
+        acc[p] = a
+        t0 += nb[p]
+    emel_raw = np.zeros((8, nf))
+    Wd, Dd = port.mfcc_tables(512, nf, nc, lo_f, hi_f)
+    Wd = np.asarray(Wd).reshape(512, nf)
+    for f in range(nf):
+        emel_raw[:, f] = mags.astype(np.float64) @ Wd[:, f]
+    got_raw = np.zeros((8, 48))
+    for p in range(6):
+        got_raw[4 * fh + ij, 4 * (2 * p + gs) + k] = acc[p]
+    assert np.abs(got_raw[:, :nf] - emel_raw).max() <= 1e-13 * np.abs(emel_raw).max()
+    assert (got_raw[:, nf:] == 0).all()
+    lg = np.where(acc > 0.000001, np.log(np.maximum(acc, 1e-6) ** 2), 0.0)
+    out = np.zeros((8, 16))
+    for q in range(4):
+        c = np.zeros(64)
+        for p in range(6):
+            c = _mfma_4x4x4_4b(D[(q * 6 + p) * 32 + lane32], lg[p], c)
+        c = c + c[lanes ^ 8]                                    # row_ror:8: the other quad of the pair
+        sel = gs == 0
+        out[(4 * fh + ij)[sel], (4 * q + k)[sel]] = c[sel] / nc
+    emel, emf = port.mfcc(mags, nf, nc, lo_f, hi_f)
+    assert np.abs(out[:, :nc] - emf).max() <= 1e-11 * max(1.0, np.abs(emel).max())
+    assert (out[:, nc:] == 0).all()
