@@ -38,6 +38,7 @@ public:
     }
     // the same from a sample already in memory (its play head where load() / setSample() left it)
     void setup(maxiSample &impulse, int fftsize = 1024, int hopsize = 256, bool loaded = true) {
+        MAXIGPU_TRY {
         if (c_) mxg_convolve_destroy(c_);
         const vector<double> &amps = impulse.getAmplitudes();
         const double position0 = loaded ? (double)amps.size() : (double)amps.size() - 1;  // C:681 / H:677
@@ -50,6 +51,8 @@ public:
         if (d_io_) mxg_free(d_io_);
         d_io_ = static_cast<float *>(mxg_malloc(sizeof(float) * 2 * (size_t)F_));
         if (!d_io_) maxigpu::ps::fatal(std::string("mxg_malloc: ") + mxg_last_error());
+        }
+        MAXIGPU_CATCH(return)
     }
     float play(float w) {  // L/maxiConvolve.cpp:76-107
         if (!c_) return 0.0f;

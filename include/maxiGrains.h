@@ -79,6 +79,7 @@ private:
     static constexpr size_t kDoubles = 4 + 32 + 3 + kMaxBlock + 2;
 
     mxg_grain_plan *plan(double grainLength) {
+        MAXIGPU_TRY {
         const std::pair<double, int> key(grainLength, sample_->mySampleRate);
         for (auto &p : plans_)
             if (p.first == key) return p.second;
@@ -86,6 +87,8 @@ private:
         if (!pl) maxigpu::ps::fatal(std::string("mxg_grain_plan_create: ") + mxg_last_error());
         plans_.push_back(std::make_pair(key, pl));
         return pl;
+        }
+        MAXIGPU_CATCH(return nullptr)
     }
     void drop_block() {
         blk_.clear();
@@ -107,6 +110,7 @@ private:
         return k;
     }
     void render(size_t L) {
+        MAXIGPU_TRY {
         check(mxg_init(-1), "mxg_init");
         if (!d_) {
             d_ = static_cast<double *>(mxg_malloc(sizeof(double) * kDoubles));
@@ -135,6 +139,8 @@ private:
         spawn_at_end_ = (mode == 0 || mode == 1) && back[3] != 0.0;  // the kernel consumed the placeholder: a grain was born in the block
         pos_ = 0;
         launches++;
+        }
+        MAXIGPU_CATCH(return)
     }
     double serve() {
         const double out = blk_[pos_++];

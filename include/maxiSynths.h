@@ -48,6 +48,7 @@ class maxiSampler {
 
     // state rows are [row][voices] on the device (V = voices): repack from the fixed-size host arrays
     void upload(const State &s) {
+        MAXIGPU_TRY {
         using maxigpu::ps::check;
         const size_t V = (size_t)voices;
         if (!d_) {
@@ -76,6 +77,8 @@ class maxiSampler {
         check(mxg_memcpy_h2d(l.gain, gain_, sizeof(double) * V, nullptr), "h2d");
         check(mxg_memcpy_h2d(l.par, par.data(), sizeof(double) * 4 * V, nullptr), "h2d");
         check(mxg_memcpy_h2d(l.hold, hold_, sizeof(int64_t) * V, nullptr), "h2d");
+        }
+        MAXIGPU_CATCH(return)
     }
     void download(State &s) {
         using maxigpu::ps::check;
@@ -172,12 +175,15 @@ public:
         for (int i = 0; i < kMax; i++) cur_.position[i] = (double)len_;  // maxiSample::read leaves position = size, C:681
     }
     void setSample(vector<double> &sampleData) {  // every samples[i].setSample(sampleData) (H:670-678)
+        MAXIGPU_TRY {
         settle();
         if (d_samples_) mxg_sample_free(d_samples_);
         d_samples_ = mxg_sample_upload(sampleData.data(), sampleData.size());
         if (!d_samples_) maxigpu::ps::fatal(std::string("mxg_sample_upload: ") + mxg_last_error());
         len_ = sampleData.size();
         for (int i = 0; i < kMax; i++) cur_.position[i] = (double)len_ - 1;
+        }
+        MAXIGPU_CATCH(return)
     }
     double play() {  // maxiSynths.cpp:291-311
         if (!d_samples_ || !len_ || !valid()) return output = 0;

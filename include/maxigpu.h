@@ -150,7 +150,7 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "fused_layout" (mxg_fft_mfcc_batch: 0 automatic, 1 = two frames in flight per wavefront and two 4-wave workgroups per CU, 2 = one
  * frame in flight and one 12-wave workgroup per CU; same bits either way),
  * "fused_waves16" (mxg_fft_mfcc_batch: the 16-waves-per-CU form of the fused kernel when the request allows it, 0|1),
- * "fused_mel" (mxg_fft_mfcc_batch, the stage after the magnitudes: 0 automatic; 1 = sparse mel walk, logs and DCT on the vector ALU in
+ * "fused_mel" (mxg_fft_mfcc_batch, the stage after the magnitudes: 0 automatic = 3, or 2 when d_melraw / d_melbands are requested; 1 = sparse mel walk, logs and DCT on the vector ALU in
  * the reference's summation orders; 2 = the same walk -- band sums bit-exact -- with the DCT's 42-term sums on the matrix pipe
  * (v_mfma_f64_4x4x4_4b_f64: fused multiply-adds, within 1e-13 x the largest band log of form 1); 3 = the mel contraction on the matrix
  * pipe as well, banded per quad of filters: band sums within 1e-13 x the frame's largest band, mfcc within 1e-11 -- the north star's
@@ -190,6 +190,14 @@ int mxg_last_async_error(void);
 int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_freq, int fps,
                    const double *d_p1, const double *d_p2, double *d_phase, double *d_outhold,
                    double *d_out, void *stream);
+/* The same with a row pitch: sample n of voice v goes to d_out[n * out_pitch_bytes / 8 + v] (out_pitch_bytes a multiple of 8, >= V * 8;
+ * a multiple of 16 keeps the 16-byte store streams).  mxg_osc_render is this call with out_pitch_bytes = V * 8.  Why a caller
+ * would pad: when V * 8 is a multiple of 2 MB (262 144 voices and its multiples) the same column of every row lands on the same HBM
+ * channel and the store stream runs at 0.68-0.71 of the peak instead of 0.75-0.80; a pitch of V * 8 + 256 ... 4096 bytes removes
+ * that (profiles/r05_osc_pitch.md).  src/maximilian.cpp:266-274 per voice, nothing else changes. */
+int mxg_osc_render_pitch(int waveform, size_t V, size_t N, const double *d_freq, int fps,
+                         const double *d_p1, const double *d_p2, double *d_phase, double *d_outhold,
+                         double *d_out, size_t out_pitch_bytes, void *stream);
 
 /* maxiOsc::noise (C:214-220): `float r = rand()/(float)RAND_MAX; output = r*2-1`.  rand() is one
  * serial process-wide stream (not a per-object state), so which draw a voice sees is decided by

@@ -53,20 +53,50 @@ using namespace std;  // the reference header does (src/maximilian.h:54); exampl
 namespace maxigpu {
 namespace ps {  // per-sample engine
 
-// Device failures (a HIP error, an exhausted allocation) have no counterpart in the reference, whose classes never fail: they raise
-// std::runtime_error -- or, built with -DMAXIGPU_NO_EXCEPTIONS (a host that runs play() on an audio thread and cannot unwind through
-// its C callback), print the message and abort().  API misuse the reference lets pass (process() before setup(), a short vector)
-// never throws: it prints once and returns silence / false (complain()).
+// Device failures (a HIP error, an exhausted allocation, no device at all) have no counterpart in the reference, whose classes never
+// fail, never throw and never exit from a per-sample call (its one runtime complaint is printf("ERROR: Could not load sample."),
+// src/maximilian.cpp:686, after which play() returns silence).  Same here by default: the FIRST failure prints one line to stderr,
+// marks the engine dead, and from then on every per-sample call returns silence (0 / false) without touching the device; the C-ABI's
+// own status stays readable through mxg_last_error() / mxg_last_async_error().  A C-ABI call that reports a failure does not unwind
+// (check(): the C-ABI validates every pointer it is handed, so whatever follows a failed call fails too, quietly, and results that
+// were to be produced stay zeros); a failed ALLOCATION or plan creation (fatal()) unwinds to the public method that was called with an
+// internal exception that never leaves this header (MAXIGPU_TRY / MAXIGPU_CATCH).  Two opt-ins: -DMAXIGPU_THROW (the round-4
+// behaviour: std::runtime_error out of the failing call, for a host that wants to handle it) and -DMAXIGPU_NO_EXCEPTIONS (a build
+// without exception support cannot unwind: the failure prints and abort()s -- choose it only where a dead device should end the
+// process).  API misuse the reference lets pass (process() before setup(), a short vector) never throws in any build: it prints
+// once and returns silence / false (complain()).
+struct DeviceFailure {};
+inline bool &dead() {
+    static bool d = false;
+    return d;
+}
 [[noreturn]] inline void fatal(const std::string &msg) {
-#ifdef MAXIGPU_NO_EXCEPTIONS
+#if defined(MAXIGPU_NO_EXCEPTIONS)
     std::fprintf(stderr, "maxigpu: %s\n", msg.c_str());
     std::abort();
-#else
+#elif defined(MAXIGPU_THROW)
     throw std::runtime_error(msg);
+#else
+    if (!dead()) std::fprintf(stderr, "ERROR: maxigpu: %s -- the device path is off, every unit generator returns silence from here on\n", msg.c_str());
+    dead() = true;
+    throw DeviceFailure{};
 #endif
 }
+#if defined(MAXIGPU_NO_EXCEPTIONS) || defined(MAXIGPU_THROW)
+#define MAXIGPU_TRY if (true)
+#define MAXIGPU_CATCH(...) else { __VA_ARGS__; }
+#else
+#define MAXIGPU_TRY try
+#define MAXIGPU_CATCH(...) catch (const maxigpu::ps::DeviceFailure &) { __VA_ARGS__; }
+#endif
 inline void check(int status, const char *what) {
-    if (status < 0) fatal(std::string(what) + ": " + mxg_last_error());
+    if (status >= 0) return;
+#if defined(MAXIGPU_NO_EXCEPTIONS) || defined(MAXIGPU_THROW)
+    fatal(std::string(what) + ": " + mxg_last_error());
+#else
+    if (!dead()) std::fprintf(stderr, "ERROR: maxigpu: %s: %s -- the device path is off, every unit generator returns silence from here on\n", what, mxg_last_error());
+    dead() = true;
+#endif
 }
 inline void complain(const char *msg) {  // the reference's style (printf("ERROR: ...")), once per message
     static std::vector<const char *> *seen = new std::vector<const char *>;
@@ -314,7 +344,10 @@ public:
     void settle(Slot &s) {
         leave_group(s);
         if (s.pos < s.len) {
-            if (s.pos > 0) advance(s, s.pos);
+            if (s.pos > 0 && !dead()) {
+                MAXIGPU_TRY { advance(s, s.pos); }
+                MAXIGPU_CATCH((void)0)
+            }
         } else if (s.len > 0) {
             s.sd = s.ed;
             s.si = s.ei;
@@ -343,8 +376,11 @@ public:
                 std::memcpy(s.lastArg, c.a, sizeof(s.lastArg));
                 s.hasLastArg = true;
             }
+        } else if (dead()) {
+            r = 0.0;  // (a device failure was reported once: silence, as after the reference's "ERROR: Could not load sample.")
         } else {
-            r = miss(s, c);
+            MAXIGPU_TRY { r = miss(s, c); }
+            MAXIGPU_CATCH(r = 0.0)
         }
         s.prevOut = s.lastOut;
         s.lastOut = r;
@@ -1366,9 +1402,12 @@ class maxiSample {
         host_.clear();
     }
     void upload(const double *data, size_t n) {
+        MAXIGPU_TRY {
         buf_.d = mxg_sample_upload(data, n);
         if (!buf_.d) maxigpu::ps::fatal(std::string("mxg_sample_upload: ") + mxg_last_error());
         buf_.len = n;
+        }
+        MAXIGPU_CATCH(return)
     }
     double amp_get(size_t i) {
         fetch_host();
@@ -1691,6 +1730,7 @@ class maxiDelayline {
     maxigpu::ps::Slot slot_;
     Pool::Line line_;
     void init() {
+        MAXIGPU_TRY {
         if (line_.d_mem) return;
         maxigpu::ps::check(mxg_init(-1), "mxg_init");
         line_.d_mem = static_cast<double *>(mxg_malloc(sizeof(double) * Pool::kCap));
@@ -1699,6 +1739,8 @@ class maxiDelayline {
         if (!line_.d_mem || !line_.d_save || !line_.d_i) maxigpu::ps::fatal(std::string("mxg_malloc: ") + mxg_last_error());
         maxigpu::ps::check(mxg_memset(line_.d_mem, 0, sizeof(double) * Pool::kCap, nullptr), "mxg_memset");  // ctor memset, C:415-417
         maxigpu::ps::check(mxg_sync(), "mxg_sync");
+        }
+        MAXIGPU_CATCH(return)
     }
     double run(int mode, double input, int size, double feedback, int position) {
         init();
@@ -1752,6 +1794,7 @@ public:
     maxiFFT(const maxiFFT &o) { copy_from(o); }
     maxiFFT &operator=(const maxiFFT &o) { if (this != &o) copy_from(o); return *this; }
     void setup(int _fftSize = 1024, int _hopSize = 512, int _windowSize = 0) {  // L/maxiFFT.cpp:45-60
+        MAXIGPU_TRY {
         release();
         askedWindow_ = _windowSize;
         plan_ = mxg_fft_plan_create(_fftSize, _hopSize, _windowSize);
@@ -1771,6 +1814,8 @@ public:
         d_in_ = static_cast<float *>(mxg_malloc(sizeof(float) * fftSize));
         d_out_ = static_cast<float *>(mxg_malloc(sizeof(float) * 4 * bins));
         if (!d_in_ || !d_out_) maxigpu::ps::fatal(std::string("mxg_malloc: ") + mxg_last_error());
+        }
+        MAXIGPU_CATCH(return)
     }
     bool process(float value, fftModes mode = maxiFFT::WITH_POLAR_CONVERSION) {  // L/maxiFFT.cpp:65-91
         if (!plan_) {  // (the reference writes through an empty vector here; no frame ever completes)
@@ -1859,6 +1904,7 @@ public:
     maxiMFCC(const maxiMFCC &o) { copy_from(o); }
     maxiMFCC &operator=(const maxiMFCC &o) { if (this != &o) copy_from(o); return *this; }
     void setup(unsigned int numBins, unsigned int numFilters, unsigned int numCoeffs, double minFreq, double maxFreq) {  // :56-75
+        MAXIGPU_TRY {
         release();
         numFilters_ = numFilters; minFreq_ = minFreq; maxFreq_ = maxFreq;
         plan_ = mxg_mfcc_plan_create(numBins, numFilters, numCoeffs, minFreq, maxFreq);
@@ -1868,6 +1914,8 @@ public:
         d_in_ = static_cast<float *>(mxg_malloc(sizeof(float) * numBins));
         d_out_ = static_cast<double *>(mxg_malloc(sizeof(double) * numCoeffs));
         if (!d_in_ || !d_out_) maxigpu::ps::fatal(std::string("mxg_malloc: ") + mxg_last_error());
+        }
+        MAXIGPU_CATCH(return)
     }
     vector<double> &mfcc(vector<float> &powerSpectrum) {  // :77-81
         if (!plan_ || powerSpectrum.size() < numBins_) {  // (the reference reads past the vector / through null tables here)
@@ -2041,6 +2089,7 @@ public:
         return pool().call(slot_, c);
     }
     bool setup(vector<double> levels, vector<double> times, vector<double> curves, bool looping, bool allowRetrigger = false) {  // H:2366-2399
+        MAXIGPU_TRY {
         if (!(levels.size() == times.size() + 1 && levels.size() == curves.size() + 1)) {
             cout << "maxiEnv::setup - levels array should be one longer than times and curves\n";
             return 0;
@@ -2064,6 +2113,8 @@ public:
         shape_.retrigger = allowRetrigger;
         resetAndArm();
         return 1;
+        }
+        MAXIGPU_CATCH(return false)
     }
     void reset() {  // H:2402-2410
         pool().settle(slot_);
@@ -2088,6 +2139,7 @@ public:
 
 private:
     void copy_from(const maxiEnvGen &o) {  // its own copy of the stage table on the device, the same running state
+        MAXIGPU_TRY {
         pool().settle(const_cast<maxiEnvGen &>(o).slot_);
         pool().settle(slot_);
         drop_table();
@@ -2102,6 +2154,8 @@ private:
         shape_.retrigger = o.shape_.retrigger;
         slot_.sd = o.slot_.sd;
         slot_.si = o.slot_.si;
+        }
+        MAXIGPU_CATCH(return)
     }
 };
 
@@ -2114,6 +2168,7 @@ public:
     maxiIFFT(const maxiIFFT &o) { copy_from(o); }
     maxiIFFT &operator=(const maxiIFFT &o) { if (this != &o) copy_from(o); return *this; }
     void setup(int _fftSize = 1024, int _hopSize = 512, int _windowSize = 0) {  // L/maxiFFT.cpp:141-152
+        MAXIGPU_TRY {
         release();
         askedWindow_ = _windowSize;
         plan_ = mxg_ifft_plan_create(_fftSize, _hopSize, _windowSize);
@@ -2128,6 +2183,8 @@ public:
         d_signal_ = static_cast<float *>(mxg_malloc(sizeof(float) * hopSize));
         if (!d_in_ || !d_buffer_ || !d_signal_) maxigpu::ps::fatal(std::string("mxg_malloc: ") + mxg_last_error());
         maxigpu::ps::check(mxg_memset(d_buffer_, 0, sizeof(float) * fftSize, nullptr), "mxg_memset");  // buffer.resize(fftSize, 0)
+        }
+        MAXIGPU_CATCH(return)
     }
     float process(std::vector<float> &data1, std::vector<float> &data2, fftModes mode = maxiIFFT::SPECTRUM) {  // :154-192
         using maxigpu::ps::check;

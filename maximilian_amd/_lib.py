@@ -51,6 +51,8 @@ SIGNATURES = {
     "mxg_last_async_error": (c_int, []),
     "mxg_osc_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_osc_render_pitch": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mxg_osc_render_mix": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_osc_mix_groups": (c_size_t, [c_size_t]),

@@ -130,7 +130,9 @@ class maxiOscBank(_Bank):
         """maxiOsc::phaseReset (C:222-226), per voice."""
         self.phase.upload(np.broadcast_to(np.asarray(phaseIn, np.float64), (self.V,)))
 
-    def render(self, waveform, freq, N, p1=None, p2=None, out=None, per_sample=False):
+    def render(self, waveform, freq, N, p1=None, p2=None, out=None, per_sample=False, pitch=None):
+        """`pitch`: row pitch of the output in DOUBLES (mxg_osc_render_pitch): the block is then a [N, pitch] buffer whose first V
+        columns are the voices (the rest is padding nobody writes); None = V."""
         wf = OSC_WAVEFORMS[waveform] if isinstance(waveform, str) else int(waveform)
         if per_sample:
             f = freq if (isinstance(freq, DeviceBuffer) or hasattr(freq, "data_ptr")) else \
@@ -139,6 +141,12 @@ class maxiOscBank(_Bank):
             f = _as_dev(freq, self.V)
         a = None if p1 is None else _as_dev(p1, self.V)
         b = None if p2 is None else _as_dev(p2, self.V)
+        if pitch is not None and int(pitch) != self.V:
+            out = out if out is not None else DeviceBuffer((N, int(pitch)), np.float64)
+            check(lib().mxg_osc_render_pitch(wf, self.V, N, _ptr(f), 1 if per_sample else 0, _ptr(a), _ptr(b), self.phase.ptr,
+                                             self.output.ptr, _ptr(out), int(pitch) * 8, self.stream), "mxg_osc_render_pitch")
+            self._keep = (f, a, b)
+            return out
         out = self._out(N, out)
         check(lib().mxg_osc_render(wf, self.V, N, _ptr(f), 1 if per_sample else 0, _ptr(a), _ptr(b),
                                    self.phase.ptr, self.output.ptr, _ptr(out), self.stream),

@@ -79,7 +79,9 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
                            const double *__restrict__ p1, const double *__restrict__ p2,
                            double *__restrict__ phase_io, double *__restrict__ hold_io,
                            double *__restrict__ out, double sr, PartSync psync, int xcd, int p1ps, int passes, size_t v_begin,
-                           size_t v_end) {
+                           size_t v_end, size_t P) {
+    // P: the row pitch of `out` in doubles (>= V; mxg_osc_render_pitch -- a bank whose natural pitch V * 8 is a multiple of 2 MB puts
+    // the same column of every row on the same HBM channel: a caller that pads its rows by a few hundred bytes removes that)
     // [v_begin, v_end): the voices of the bank this launch renders (V stays the bank's size = the row pitch of `out`): a large bank
     // is rendered as a few launches of the grid shapes that stream best (osc_plan below)
     // (p1ps, FPS only: p1 is [N][V] too -- a pulse width / start phase per sample, for the per-sample engine's derived arguments)
@@ -138,7 +140,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
             for (int j = 0; j < VPL; j++) osc_skip<WF>(ph[j], hd[j], q[j], s_tab, s_tab);
         }
     }
-    double *o = out + nA * V + v0;
+    double *o = out + nA * P + v0;
     const double *fp = freq + v0;
     const double *pp = (FPS && p1ps) ? p1 + v0 : nullptr;
 #ifndef MXG_OSC_UNROLL
@@ -164,14 +166,14 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
         constexpr bool kTrust = decltype(trust_tag)::value;
         size_t n = nA;
         if constexpr (PX && VPL == 1 && !FPS) {
-            double *op = out + (nA + (threadIdx.x & 1)) * V + (v0 & ~(size_t)1);
+            double *op = out + (nA + (threadIdx.x & 1)) * P + (v0 & ~(size_t)1);
             if constexpr (!kLean) {
 #pragma unroll 2
                 for (; n + 2 <= nB; n += 2) {
                     const double r0 = osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab);
                     const double r1 = osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab);
                     store_pair_rows<ST, false>(op, r0, r1);
-                    op += 2 * V;
+                    op += 2 * P;
                 }
             } else {
                 // (a 32-bit trip count: gfx950 has no scalar 64-bit less-than, and hipcc then tests a size_t bound with two VALU
@@ -181,11 +183,11 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
                     const double r0 = osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab);
                     const double r1 = osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab);
                     store_pair_rows<ST>(op, r0, r1);
-                    op += 2 * V;
+                    op += 2 * P;
                 }
                 n = nA + 2 * (size_t)pairs;
             }
-            o = out + n * V + v0;
+            o = out + n * P + v0;
         }
 #pragma unroll MXG_OSC_UNROLL
         for (; n < nB; n++) {
@@ -199,7 +201,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
                 store2<ST>(o, r[0], r[1]);
             else
                 store1<ST>(o, r[0]);
-            o += V;
+            o += P;
             if constexpr (FPS) {
                 fp += V;
                 if (pp) pp += V;
@@ -746,7 +748,7 @@ osc_mix_fn pick_mix_wf(int wf, int store, int win) {
 }
 
 typedef void (*osc_fn)(size_t, size_t, const double *, const double *, const double *, double *,
-                       double *, double *, double, PartSync, int, int, int, size_t, size_t);
+                       double *, double *, double, PartSync, int, int, int, size_t, size_t, size_t);
 
 // store: 0 plain 8 B, 1 nt 8 B, 2 pair rows (16 B) plain, 3 pair rows sc1, 4 pair rows nt      (one voice per lane)
 //        0 plain 16 B, 1 nt 16 B, 2 sc1 16 B                                                  (two voices per lane)
@@ -790,7 +792,7 @@ namespace {
 // one launch of K1 over the voices [v_begin, v_end) of a bank
 struct OscLaunch {
     int waveform = 0;
-    size_t V = 0, N = 0;
+    size_t V = 0, N = 0, P = 0;  // P: row pitch of `out` in doubles
     const double *freq = nullptr, *p1 = nullptr, *p2 = nullptr;
     int fps = 0;
     double *phase = nullptr, *hold = nullptr, *out = nullptr;
@@ -888,7 +890,7 @@ int osc_launch(const OscLaunch &L) {
         if (int s = part_sync_get(L.st, (size_t)grid.x * ((block + 63) / 64), split, &psync)) return s;
     KernelTimer kt("osc_kernel", L.st);
     hipLaunchKernelGGL(fn, grid, blk, 0, L.st, L.V, L.N, L.freq, L.p1, L.p2, L.phase, L.hold, L.out, (double)settings().sampleRate, psync,
-                       L.xcd, L.fps == 2 ? 1 : 0, passes, L.v_begin, L.v_end);
+                       L.xcd, L.fps == 2 ? 1 : 0, passes, L.v_begin, L.v_end, L.P ? L.P : L.V);
     return check_hip(hipGetLastError(), "osc_kernel launch");
 }
 }  // namespace
@@ -897,8 +899,17 @@ int osc_launch(const OscLaunch &L) {
 extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_freq, int fps,
                               const double *d_p1, const double *d_p2, double *d_phase,
                               double *d_outhold, double *d_out, void *stream) {
+    return mxg_osc_render_pitch(waveform, V, N, d_freq, fps, d_p1, d_p2, d_phase, d_outhold, d_out, V * sizeof(double), stream);
+}
+
+extern "C" int mxg_osc_render_pitch(int waveform, size_t V, size_t N, const double *d_freq, int fps,
+                                    const double *d_p1, const double *d_p2, double *d_phase,
+                                    double *d_outhold, double *d_out, size_t out_pitch_bytes, void *stream) {
     using namespace mxg;
     if (int s = ensure_init()) return s;
+    MXG_REQUIRE(out_pitch_bytes % sizeof(double) == 0 && out_pitch_bytes >= V * sizeof(double),
+                "out_pitch_bytes must be a multiple of 8 and at least V * 8");
+    const size_t P = out_pitch_bytes / sizeof(double);
     MXG_REQUIRE(waveform >= 0 && waveform <= 11, "unknown waveform");
     MXG_REQUIRE(d_freq && d_phase && d_outhold && d_out, "null device pointer");
     MXG_REQUIRE(waveform != MXG_OSC_PULSE || d_p1, "pulse needs d_p1 (duty)");
@@ -909,10 +920,10 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     if (V == 0 || N == 0) return MXG_OK;
     // the store stream: knobs osc_vpl, osc_store, osc_xcd, osc_passes, osc_split (0 = automatic each); left alone, osc_single_rule / the plan
     // of launches below
-    const bool pairs_ok = !fps && !(V & 1) && !(((uintptr_t)d_out) & 15);
+    const bool pairs_ok = !fps && !(V & 1) && !(P & 1) && !(((uintptr_t)d_out) & 15);  // (16-byte pair rows: every row 16-byte aligned)
     hipStream_t st = resolve_stream(stream);
     OscLaunch L0;
-    L0.waveform = waveform; L0.V = V; L0.N = N; L0.freq = d_freq; L0.fps = fps; L0.p1 = d_p1; L0.p2 = d_p2; L0.phase = d_phase;
+    L0.waveform = waveform; L0.V = V; L0.P = P; L0.N = N; L0.freq = d_freq; L0.fps = fps; L0.p1 = d_p1; L0.p2 = d_p2; L0.phase = d_phase;
     L0.hold = d_outhold; L0.out = d_out; L0.st = st; L0.pairs_ok = pairs_ok;
     int vpl = tune_get("osc_vpl"), store = tune_get("osc_store") - 1, xcd = tune_get("osc_xcd") - 1;  // (knob value 0 = automatic)
     const bool automatic = vpl == 0 && store < 0;
@@ -921,7 +932,7 @@ extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_
     // 0.64 against 0.68-0.71 for one launch over the whole bank; 262 144 itself wants the XCD-contiguous numbering, 0.80 against 0.73.
     // profiles/r04_osc_grid.md.)
     int plan = tune_get("osc_plan");  // 0 automatic, 1 never, 2 / 3 always (main launch with natural / XCD-contiguous numbering)
-    if (plan == 0) plan = (V % 262144) ? 2 : (V == 262144 ? 3 : 1);
+    if (plan == 0) plan = (P % 262144) ? 2 : (V == 262144 ? 3 : 1);  // (the PITCH decides: padded rows take the passes well)
     if (automatic && pairs_ok && !heavy && xcd < 0 && tune_get("osc_passes") == 0 && tune_get("osc_split") == 0 && plan != 1 &&
         V * N * sizeof(double) >= ((size_t)352 << 20)) {
         // ---- large banks of the store-bound waveforms: a plan of launches (round 4, profiles/r04_osc_grid.md) ----------------------------

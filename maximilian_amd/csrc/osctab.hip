@@ -41,7 +41,7 @@ constexpr int kTabRound = kTabVoices * kTabLen + kTabHdr;         // doubles per
 constexpr int kTabRing = 4;          // LDS buffers: one in use, three rounds of DMA in flight
 static_assert(kTabRound * 8 == 8 * 4096 + 84 * 16, "a round is 8 full 4 KiB pieces + 84 sixteen-byte pieces");
 
-// The wrap test ahead of the add.  C:270 tests the SUM: `phase += inc; if (phase >= 511) phase -= 512;` -- add, compare, select,
+// (An experiment that stays as an A/B form, MXG_TAB_CMPX 2.)  The wrap test ahead of the add.  C:270 tests the SUM: `phase += inc; if (phase >= 511) phase -= 512;` -- add, compare, select,
 // subtract, four dependent fp64 operations per step of a chain that nothing else can hide (the marks pass IS that chain, 512 steps per
 // voice).  d -> fl(d + inc) is monotone, so there is one double `thr` with  fl(ph + inc) >= 511  <=>  ph >= thr  for every ph that is
 // not a NaN (a NaN fails both tests): the compare then runs BESIDE the add and the chain is add -> subtract.  thr is found by bisection
@@ -84,16 +84,33 @@ __global__ void osctab_marks_kernel(size_t V, size_t N, const double *__restrict
     h[kTabParts * kTabVoices + kTabVoices + u] = sqrt(1.0 - x);  // two[0] = input*sqrt(1.0-x)   C:506
     h[kTabParts * kTabVoices + 2 * kTabVoices + u] = sqrt(x);    // two[1] = input*sqrt(x)       C:507
     const int whole = (int)(N / 32);  // parts that lie inside the block completely
-    double thr = 0.0;
-#ifndef MXG_TAB_THR
-#define MXG_TAB_THR 1  // A/B: 0 = the round-4 chain (compare on the sum)
+#ifndef MXG_TAB_CMPX
+#define MXG_TAB_CMPX 1  // A/B: 0 = compare + select + subtract (round 4), 2 = the wrap test ahead of the add (wrap_threshold)
 #endif
-    const bool ahead = MXG_TAB_THR && __all(wrap_threshold(inc, thr));  // (wave-uniform choice of the loop form)
+    // The pass is bound by VALU issue, not by the chain's latency: measured, 131 072 voices (two wavefronts per SIMD) take twice the
+    // time of 65 536 (one), and a chain with the compare taken off the critical path (MXG_TAB_CMPX 2: five instructions per step instead
+    // of four + a wait state) takes the same 17-18 us (profiles/r05_k1t.md).  So the step is cut to THREE vector instructions: the add,
+    // a compare that writes the EXEC mask itself (v_cmpx), the subtraction under that mask; the mask is restored on the scalar unit,
+    // which issues beside the vector ALU.  `ph + (-512.0)` is `ph - 512` bit for bit; a NaN fails the compare as it fails `>=`.
+    double thr = 0.0;
+    const bool ahead = MXG_TAB_CMPX == 2 && __all(wrap_threshold(inc, thr));  // (wave-uniform choice of the loop form)
+    const unsigned long long live = __builtin_amdgcn_read_exec();
+    const double c511 = 511.0, cm512 = -512.0;
 #pragma unroll 1
     for (int t = 0; t < kTabParts; t++) {
         h[t * kTabVoices + u] = ph;
         if (t < whole) {
-            if (ahead) {
+            if (MXG_TAB_CMPX == 1) {
+#pragma unroll
+                for (int k = 0; k < 32; k += 4)
+                    asm volatile("v_add_f64 %0, %0, %1\n\tv_cmpx_le_f64 %2, %0\n\tv_add_f64 %0, %0, %3\n\ts_mov_b64 exec, %4\n\t"
+                                 "v_add_f64 %0, %0, %1\n\tv_cmpx_le_f64 %2, %0\n\tv_add_f64 %0, %0, %3\n\ts_mov_b64 exec, %4\n\t"
+                                 "v_add_f64 %0, %0, %1\n\tv_cmpx_le_f64 %2, %0\n\tv_add_f64 %0, %0, %3\n\ts_mov_b64 exec, %4\n\t"
+                                 "v_add_f64 %0, %0, %1\n\tv_cmpx_le_f64 %2, %0\n\tv_add_f64 %0, %0, %3\n\ts_mov_b64 exec, %4"
+                                 : "+v"(ph)
+                                 : "v"(inc), "s"(c511), "s"(cm512), "s"(live)
+                                 : "vcc");
+            } else if (ahead) {
 #pragma unroll
                 for (int k = 0; k < 32; k++) {
                     const double sum = ph + inc;                                             // C:269

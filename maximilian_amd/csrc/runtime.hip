@@ -64,7 +64,7 @@ Tune g_tune[] = {
     {"grain_slices", 4, 1, 16},  // K8a/K8c: time slices of a maxiTimeStretch call (scheduling of slice i+1 overlaps render of slice i)
     {"mfcc_mfma_fullk", 0, 0, 1},  // K7b: contract over all numBins bins (1) instead of the bins that carry weight
     {"fused_layout", 0, 0, 2},   // K67: 0 automatic; 1 two frames in flight, two 4-wave workgroups per CU; 2 one frame in flight, one 12-wave workgroup per CU
-    {"fused_mel", 0, 0, 3},  // K67 mel / log / DCT stage: 0 automatic; 1 sparse walk + vector DCT (round-4 form); 2 sparse walk (band sums bit-exact) + DCT on the matrix pipe; 3 mel contraction AND DCT on the matrix pipe (v_mfma_f64_4x4x4, banded; band sums 1e-13)
+    {"fused_mel", 0, 0, 3},  // K67 mel / log / DCT stage: 0 automatic (3, or 2 when the band sums are requested); 1 sparse walk + vector DCT (round-4 form); 2 sparse walk (band sums bit-exact) + DCT on the matrix pipe; 3 mel contraction AND DCT on the matrix pipe (v_mfma_f64_4x4x4, banded; band sums 1e-13)
     {"fused_waves16", 0, 0, 1},  // K67: 1 = the 16-waves-per-CU form of the fused FFT+MFCC kernel when applicable (measured slower: 1.72 vs 1.51 ms)
     {"mfcc_tiled", 1, 0, 1},  // K7a-t: stage spectra through LDS tiles (0: per-lane row loads, K7a)
 };

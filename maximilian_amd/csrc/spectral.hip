@@ -316,27 +316,34 @@ struct MmArgs {
 __device__ __forceinline__ void mel_mfma(const float *M, const unsigned mstride, const double *s_mmW, const MmArgs &mm,
                                          const MmLane &L, double (&acc)[kMmPairs]) {
     const float *mrow = M + (4 * L.fh + L.ij) * mstride;
-    const d2f *wq = reinterpret_cast<const d2f *>(s_mmW) + L.lane32;  // [(batch * 2 + half) * 32 + lane32]
+    const d2f *wq = reinterpret_cast<const d2f *>(s_mmW) + L.lane32;  // [(batch * 2 + half) * 32 + lane32]: 64 per batch, pairs back to back
+    const f4e *mp0[kMmPairs + 1];
+#pragma unroll
+    for (int p = 0; p < kMmPairs; p++)
+        mp0[p] = reinterpret_cast<const f4e *>(mrow + (L.gs ? mm.base[p][1] : mm.base[p][0]) + L.k * 4 * mm.nb[p]);
+    mp0[kMmPairs] = mp0[kMmPairs - 1];  // (what the last batch "prefetches": its own pair's start; the table has a padding batch)
+    // one batch ahead: the three 16-byte reads of batch t + 1 are requested before the four matrix instructions of batch t issue
+    // (left to itself hipcc puts the reads at the top of the loop body and waits for them at once: one exposed LDS latency per batch)
+    f4e f = mp0[0][0];
+    d2f w0 = wq[0], w1 = wq[32];
 #pragma unroll
     for (int p = 0; p < kMmPairs; p++) {
         const int nb = mm.nb[p];
-        const int base = L.gs ? mm.base[p][1] : mm.base[p][0];
-        const f4e *mp = reinterpret_cast<const f4e *>(mrow + base + L.k * 4 * nb);
         double a = 0.0;
-        f4e f = mp[0];
-        d2f w0 = wq[0], w1 = wq[32];
         for (int s4 = 0; s4 < nb; s4++) {
-            const int sn = s4 + 1 < nb ? s4 + 1 : s4;  // the last batch re-reads itself (unused)
-            const f4e fn = mp[sn];
-            const d2f w0n = wq[sn * 64], w1n = wq[sn * 64 + 32];
+            const f4e *np = s4 + 1 < nb ? mp0[p] + (s4 + 1) : mp0[p + 1];
+            const f4e fn = *np;
+            const d2f w0n = wq[64], w1n = wq[96];
+            __builtin_amdgcn_sched_barrier(0);
             a = __builtin_amdgcn_mfma_f64_4x4x4f64(w0.x, (double)f.x, a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f64_4x4x4f64(w0.y, (double)f.y, a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f64_4x4x4f64(w1.x, (double)f.z, a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f64_4x4x4f64(w1.y, (double)f.w, a, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             f = fn; w0 = w0n; w1 = w1n;
+            wq += 64;
         }
         acc[p] = a;
-        wq += nb * 64;
     }
 }
 // log-square in place, then the DCT; C[q] of the lanes with gs == 0 = coefficient 4 q + (lane >> 4) of frame 4 fh + ij, not yet
@@ -406,8 +413,9 @@ struct FusedArgs {
 // (dct_mfma: the DCT's 42-term sums are fused multiply-adds -- they only ever saw the device log's values, the mfcc tolerance is
 // unchanged); 1 = the mel contraction on the matrix pipe as well (mel_mfma: band sums within 1e-13 of the largest band).
 // MEL >= 1 runs as ONE 8-wave workgroup per CU (the tables once per CU) on rows of 260 floats (bins 0 .. 256, bin 0 kept at 0).
+// (no-load-store-opt: see the Makefile -- the transposes want plain 8-byte LDS accesses, not hipcc's fused ds_read2 / ds_write2 forms)
 template <bool FULL, bool WRITE_MAGS, bool ALIGNED8, int MODE, int NF, int WAVES, int MEL = 0>
-__global__ __launch_bounds__(64 * WAVES, NF == 2 ? (WAVES == 8 ? 2 : 2) : 1) void fft_mfcc_kernel(const FusedArgs A) {
+__global__ __launch_bounds__(64 * WAVES, NF == 1 ? 1 : 2) __attribute__((target("no-load-store-opt"))) void fft_mfcc_kernel(const FusedArgs A) {
     constexpr bool TOL = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     // [fs (steps + 2 batches) * 8 entries | mmW][dct NF*NC f64, padded to 16 B | mmD] | per wave: XA (= band rows), XB, M
@@ -416,15 +424,22 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? (WAVES == 8 ? 2 : 2) : 1) voi
     double *s_mmW = reinterpret_cast<double *>(s_dyn);
     double *s_d = MEL == 1 ? s_mmW + (size_t)(A.mmBatches + 1) * 128 : reinterpret_cast<double *>(s_fs + (size_t)fsRows * kFusedSlots);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t perWaveBytes = NF * sizeof(float2) * kX1024 + sizeof(float) * (kGroup * A.mstride + A.mslack);
+    // SHARED (the matrix-pipe forms): the NF frames in flight of a wavefront use ONE X image.  The phases are issued frame by frame
+    // -- frame f's transpose store, its transposed reads, THEN frame f + 1's store -- and the DS unit executes a wavefront's
+    // operations in order, so f's reads have been performed when f + 1's stores land on the same addresses: no wait, the LDS that
+    // the second image took is what lets more frames be in flight (NF = 4: eight per SIMD instead of four).
+    constexpr bool SHARED = MEL >= 1;
+    static_assert(!SHARED || MXG_FUSED_SKEW, "the shared X image needs the frame-by-frame phase order");
+    constexpr int kImages = SHARED ? 1 : NF;
+    const size_t perWaveBytes = kImages * sizeof(float2) * kX1024 + sizeof(float) * (kGroup * A.mstride + A.mslack);
     v2f *s_twl = reinterpret_cast<v2f *>(s_d + (MEL >= 1 ? kMmCoefQuads * kMmPairs * 32 : A.dctPad));  // NF == 1: [8][7] round-2 twiddles by lane & 7, then [64][7] round-3 by lane
     constexpr int kTwl = NF == 1 ? (8 + 64) * 7 : 0;
     char *wbase = reinterpret_cast<char *>(s_twl + kTwl) + (size_t)wave * perWaveBytes;
     v2f *X[NF];
 #pragma unroll
-    for (int f = 0; f < NF; f++) X[f] = reinterpret_cast<v2f *>(wbase) + f * kX1024;
+    for (int f = 0; f < NF; f++) X[f] = reinterpret_cast<v2f *>(wbase) + (SHARED ? 0 : f) * kX1024;
     double *s_mel = reinterpret_cast<double *>(wbase);  // the band rows live on X[0] between the last post-pass and the next frame
-    float *M = reinterpret_cast<float *>(wbase + NF * sizeof(float2) * kX1024);
+    float *M = reinterpret_cast<float *>(wbase + kImages * sizeof(float2) * kX1024);
     fs32_entry *s_fs32 = reinterpret_cast<fs32_entry *>(s_dyn);  // tolerance mode: the same tables in fp32, in the same place
     float *s_df = reinterpret_cast<float *>(s_d);
     if constexpr (MEL >= 1) {
@@ -656,6 +671,15 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? (WAVES == 8 ? 2 : 2) : 1) voi
                 wave_lds_sync();
 #pragma unroll
                 for (int e = 0; e < 8; e++) X[f][pad8(e * 64 + lane)] = v[f][e];
+                if constexpr (SHARED) {  // the post-pass reads of THIS frame before the next frame's store lands on the image
+                    static_assert(!SHARED || !FULL, "the shared image serves the half-spectrum post-pass only");
+                    wave_lds_sync();
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        v[f][2 * q] = X[f][pa0 + 72 * q];
+                        v[f][2 * q + 1] = X[f][pb0 - 72 * q];
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             wave_lds_sync();
@@ -718,8 +742,13 @@ __global__ __launch_bounds__(64 * WAVES, NF == 2 ? (WAVES == 8 ? 2 : 2) : 1) voi
                 for (int f = 0; f < NF; f++)
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        pa[f][q] = X[f][pa0 + 72 * q];
-                        pb[f][q] = X[f][pb0 - 72 * q];
+                        if constexpr (SHARED) {  // (requested inside the third phase, frame by frame)
+                            pa[f][q] = v[f][2 * q];
+                            pb[f][q] = v[f][2 * q + 1];
+                        } else {
+                            pa[f][q] = X[f][pa0 + 72 * q];
+                            pb[f][q] = X[f][pb0 - 72 * q];
+                        }
                     }
                 __builtin_amdgcn_sched_barrier(0);
                 bool garbage[NF];
@@ -1156,7 +1185,10 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
     // mel / log / DCT stage (knob fused_mel): the matrix-pipe forms need the plan's quad tables, a half-spectrum launch and a bank
     // inside bins [1, 255]; they run as one 8-wave workgroup per CU on rows of 260 floats
     int mel = (int)tune_get("fused_mel");
-    if (mel == 0) mel = 1;  // automatic
+    // automatic: the matrix pipe for the DCT always (the DCT only ever saw the device log's values: the mfcc tolerance does not move),
+    // for the mel contraction too when the caller does not ask for the band sums -- a caller who reads d_melraw / d_melbands gets the
+    // sparse walk's sums, bit for bit the reference's (measured, 2^20 frames: 1.30 / 1.19 / 1.13 ms for forms 1 / 2 / 3)
+    if (mel == 0) mel = (d_melraw || d_melbands) ? 2 : 3;
     const bool mmOk = mp->mmOk && mp->d_mmW && mp->d_mmD && !full && !A.edgeBins;
     const int MEL = mel == 3 && mmOk ? 1 : (mel == 2 && mmOk ? 2 : 0);
     if (MEL) {
@@ -1174,7 +1206,11 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
         A.mmBatches = 0;
     }
     constexpr int kWavesMm = 8;
-    const int nf = layout == 2 ? 1 : 2, waves = MEL ? kWavesMm : (layout == 2 ? kWaves1 : kWavesPerBlock),
+    // (four frames in flight per wavefront -- the shared image leaves the LDS for it -- were measured: 256 VGPRs do not hold them
+    // without spills and the tables re-read from LDS, 1.41 ms against 1.14: profiles/r05_config4_summary.md)
+    // (likewise three frames in flight in groups of six: no spills, 1.21 ms against 1.14 -- more frames per wavefront do not help, the
+    // kernel is not waiting for its own LDS round trips)
+    const int nf = MEL ? 2 : (layout == 2 ? 1 : 2), waves = MEL ? kWavesMm : (layout == 2 ? kWaves1 : kWavesPerBlock),
               wgPerCU = MEL || layout == 2 ? 1 : 2;
     // unconditional magnitude stores (see FusedArgs::mUncond): rows of >= 257 floats, or a slack behind the tile that still lets
     // the layout's workgroups share a CU
@@ -1185,9 +1221,9 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
         A.mUncond = 1;
     }
     size_t lds = lds_for(nf, waves, A.mslack);
-    if (MEL)  // [mmW (batches + 1) KB | fs][mmD 6 KB] + 8 waves x (two X images + the 8 x 260 tile)
+    if (MEL)  // [mmW (batches + 1) KB | fs][mmD 6 KB] + 8 waves x (ONE X image + the 8 x 260 tile)
         lds = (MEL == 1 ? sizeof(double) * 128 * (size_t)(A.mmBatches + 1) : sizeof(mxg_fs_entry) * (size_t)(A.steps + 2 * kMelBatch) * kFusedSlots) +
-              sizeof(double) * kMmCoefQuads * kMmPairs * 32 + waves * (nf * sizeof(float2) * kX1024 + sizeof(float) * kGroup * A.mstride);
+              sizeof(double) * kMmCoefQuads * kMmPairs * 32 + waves * (sizeof(float2) * kX1024 + sizeof(float) * kGroup * A.mstride);
     if (MEL && (lds > 160 * 1024 || sizeof(double) * kGroup * A.nfp > sizeof(float2) * kX1024))
         return fail(MXG_ERR_INVALID, "fused_mel %d: the tables do not fit the LDS (%zu bytes)", mel, lds);
     MXG_REQUIRE(lds <= 160 * 1024, "filter bank too large for the fused kernel's LDS layout");
@@ -1209,14 +1245,15 @@ extern "C" int mxg_fft_mfcc_batch(const mxg_fft_plan *fp, const mxg_mfcc_plan *m
         k = MXG_PICK_FULL(true);
     else if (full)
         k = MXG_PICK_FULL(false);
+#define MXG_PICK_MM(NF_, MEL_)                                                                                                       \
+    (mode == 2   ? (aligned8 ? fft_mfcc_kernel<false, false, true, 2, NF_, kWavesMm, MEL_> : fft_mfcc_kernel<false, false, false, 2, NF_, kWavesMm, MEL_>) \
+     : mode == 1 ? (aligned8 ? fft_mfcc_kernel<false, false, true, 1, NF_, kWavesMm, MEL_> : fft_mfcc_kernel<false, false, false, 1, NF_, kWavesMm, MEL_>) \
+                 : (aligned8 ? fft_mfcc_kernel<false, false, true, 0, NF_, kWavesMm, MEL_> : fft_mfcc_kernel<false, false, false, 0, NF_, kWavesMm, MEL_>))
     else if (MEL == 1)
-        k = mode == 2   ? (aligned8 ? fft_mfcc_kernel<false, false, true, 2, 2, kWavesMm, 1> : fft_mfcc_kernel<false, false, false, 2, 2, kWavesMm, 1>)
-            : mode == 1 ? (aligned8 ? fft_mfcc_kernel<false, false, true, 1, 2, kWavesMm, 1> : fft_mfcc_kernel<false, false, false, 1, 2, kWavesMm, 1>)
-                        : (aligned8 ? fft_mfcc_kernel<false, false, true, 0, 2, kWavesMm, 1> : fft_mfcc_kernel<false, false, false, 0, 2, kWavesMm, 1>);
+        k = MXG_PICK_MM(2, 1);
     else if (MEL == 2)
-        k = mode == 2   ? (aligned8 ? fft_mfcc_kernel<false, false, true, 2, 2, kWavesMm, 2> : fft_mfcc_kernel<false, false, false, 2, 2, kWavesMm, 2>)
-            : mode == 1 ? (aligned8 ? fft_mfcc_kernel<false, false, true, 1, 2, kWavesMm, 2> : fft_mfcc_kernel<false, false, false, 1, 2, kWavesMm, 2>)
-                        : (aligned8 ? fft_mfcc_kernel<false, false, true, 0, 2, kWavesMm, 2> : fft_mfcc_kernel<false, false, false, 0, 2, kWavesMm, 2>);
+        k = MXG_PICK_MM(2, 2);
+#undef MXG_PICK_MM
     else if (layout == 2)
         k = MXG_PICK(false, false, 1, kWaves1);
     else

@@ -45,3 +45,32 @@ def test_config1_known_answers(golden):
     ex01 = golden("dropin.npz")["ex01"]
     assert ex01[:4, 0].tolist() == [0.0, 0.062648324178743678, 0.1250505236945281, 0.18696144082725336]
     assert np.array_equal(ex01[:, 0], ex01[:, 1])
+
+
+def test_device_failure_is_one_printed_line_and_silence(tmp_path):
+    """Without a HIP device (this container) a patch built against the drop-in header must behave like the reference after its own one
+    runtime complaint (printf("ERROR: Could not load sample."), src/maximilian.cpp:686): ONE line on stderr, no exception, no abort,
+    every unit generator returns silence -- and nothing is computed on the CPU instead (the product has no fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the device path works here")
+    exe = os.path.join(ROOT, "host", "dropin_01")
+    src = os.path.join(REF, EXAMPLES["01"])
+    if os.path.exists(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "dropin_01"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(exe):
+        pytest.skip("host/dropin_01 not built (needs /root/reference)")
+    out = str(tmp_path / "o.f64")
+    r = subprocess.run([exe, "2000", out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count("ERROR: maxigpu") == 1 and "no CPU fallback" in r.stderr
+    got = np.fromfile(out, np.float64)
+    assert got.size == 4000 and not got.any(), "silence, not a CPU rendering"
+
+
+@pytest.mark.parametrize("flags", [[], ["-DMAXIGPU_THROW"], ["-fno-exceptions", "-DMAXIGPU_NO_EXCEPTIONS"]])
+def test_header_builds_in_every_failure_mode(flags):
+    for patch in ("public_members_patch.cpp", "convolve_sampler_patch.cpp", "granular_patch.cpp"):
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wno-unused-variable", "-I" + os.path.join(ROOT, "include")] + flags +
+                           [os.path.join(ROOT, "tests", "patches", patch)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]

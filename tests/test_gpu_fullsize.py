@@ -61,9 +61,16 @@ def test_config4_full_size_fft_mfcc(mx, port):
     L.mxg_sync()
     assert torch.equal(mags_f, mags) and torch.equal(mfcc_f, mfcc)
     mfcc_f.zero_()
-    assert L.mxg_fft_mfcc_batch(f.plan, m.plan, sig.data_ptr(), 1024, N, None, None, None, mfcc_f.data_ptr(), None) == 0
-    L.mxg_sync()
+    prev = L.mxg_tune(b"fused_mel", 1)  # the vector form of the half-spectrum kernel: the two-kernel path's bits
+    try:
+        assert L.mxg_fft_mfcc_batch(f.plan, m.plan, sig.data_ptr(), 1024, N, None, None, None, mfcc_f.data_ptr(), None) == 0
+        L.mxg_sync()
+    finally:
+        L.mxg_tune(b"fused_mel", prev)
     assert torch.equal(mfcc_f, mfcc)
+    assert L.mxg_fft_mfcc_batch(f.plan, m.plan, sig.data_ptr(), 1024, N, None, None, None, mfcc_f.data_ptr(), None) == 0  # the default form
+    L.mxg_sync()
+    assert (mfcc_f - mfcc).abs().max().item() <= 1e-11
 
 
 def test_config5_full_size_granular_share(mx, port):

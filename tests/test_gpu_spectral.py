@@ -138,9 +138,11 @@ def fused_form(mx, request):
     L = mx.lib()
     prev16 = L.mxg_tune(b"fused_waves16", 1 if request.param == 1 else 0)
     prevl = L.mxg_tune(b"fused_layout", 2 if request.param == 2 else 1)
-    yield request.param
+    prevm = L.mxg_tune(b"fused_mel", 1)  # the vector form: what these layouts are layouts OF (mfcc bits = mxg_mfcc_batch's DCT order);
+    yield request.param                  # the matrix-pipe forms have their own tests below
     L.mxg_tune(b"fused_waves16", prev16)
     L.mxg_tune(b"fused_layout", prevl)
+    L.mxg_tune(b"fused_mel", prevm)
 
 
 @pytest.mark.parametrize("nf,nc,nfr,off", [(42, 13, 1003, 0), (40, 20, 77, 0), (64, 13, 8, 0), (42, 13, 250, 3), (13, 5, 1, 0),
@@ -272,6 +274,36 @@ def test_fused_matrix_pipe_forms(mx, port, mel, nf, nc, nfr, off):
     e = port.fft_stream(frames.reshape(-1), 1024, 1024, 1024, want=("mags",))["mags"]
     emel, emf = port.mfcc(e, nf, nc, 20.0, 20000.0)
     assert np.abs(out - emf).max() <= (MFCC_RTOL if mel == 2 else MFMA_RTOL) * max(np.abs(emel).max(), 1.0)
+
+
+def test_fused_automatic_form(mx, port):
+    """fused_mel 0 (the default): a launch that asks for the band sums gets the sparse walk's (bit for bit the separate kernels' and the
+    reference's sequential sums); a launch that asks for the coefficients only takes the matrix pipe for the mel contraction too -- its
+    mfcc within the matrix form's stated distance of the first launch's, and both within the device log's tolerance of the oracle."""
+    rng = np.random.default_rng(2024)
+    nfr = 777
+    sig = (rng.uniform(-1, 1, 1024 * nfr) * np.repeat(10.0 ** rng.uniform(-4, 0, nfr), 1024)).astype(np.float32)
+    d = mx.DeviceBuffer.from_numpy(sig)
+    f = mx.maxiFFT(); f.setup(1024, 1024, 1024)
+    m = mx.maxiMFCC(); m.setup(512, 42, 13, 20.0, 20000.0)
+    L = mx.lib()
+    prev = L.mxg_tune(b"fused_mel", 0)
+    try:
+        with_bands = m.mfcc_of_frames(f, d.ptr, nfr, want_bands=True).numpy()
+        raw = m.melraw.numpy()
+        only = m.mfcc_of_frames(f, d.ptr, nfr).numpy()
+        L.mxg_tune(b"fused_mel", 1)
+        m.mfcc_of_frames(f, d.ptr, nfr, want_bands=True)
+        raw1 = m.melraw.numpy()
+    finally:
+        L.mxg_tune(b"fused_mel", prev)
+    assert_bits_equal(raw, raw1, "band sums of the automatic form when they are requested")
+    e = port.fft_stream(sig, 1024, 1024, 1024, want=("mags",))["mags"]
+    emel, emf = port.mfcc(e, 42, 13, 20.0, 20000.0)
+    top = max(np.abs(emel).max(), 1.0)
+    assert np.abs(only - with_bands).max() <= MFMA_RTOL * top
+    assert np.abs(with_bands - emf).max() <= MFCC_RTOL * top
+    assert np.abs(only - emf).max() <= MFMA_RTOL * top
 
 
 @pytest.mark.parametrize("mel", [2, 3])
