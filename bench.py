@@ -87,18 +87,21 @@ def _baseline(run, units_of, sizes, unit_name, what, target_s=6.0):
 
 
 def share_estimate(kernels, dom, step_ms):
-    """(kernel_ms, step-bound) of the dominant kernel: step_ms x (its event time / every kernel's event time) / its launches per step;
-    without per-kernel figures the whole step."""
+    """(kernel_ms, step-bound) of the dominant kernel.  A step that launches ONLY this kernel: the GPU-side step time / launches per step
+    (no per-kernel markers in the timed region; an upper bound on the launch duration: it carries the launch gaps).  A step of several
+    kernels (some of them on other streams, overlapping): the HIP events around this kernel's own launches (they carry the marker
+    pair, ~2-4 us: conservative)."""
     if dom not in kernels:
         return step_ms, step_ms
-    tot = sum(v["ms"] * v["launches_per_step"] for v in kernels.values())
-    mine = kernels[dom]["ms"] * kernels[dom]["launches_per_step"]
     lps = max(kernels[dom]["launches_per_step"], 1e-9)
-    return step_ms * (mine / tot) / lps, step_ms / max(lps, 1.0)
+    bound = step_ms / max(lps, 1.0)
+    only = all(k == dom or v["launches_per_step"] * v["ms"] < 0.02 * step_ms for k, v in kernels.items())
+    return (bound if only else min(kernels[dom]["ms"], bound)), bound
 
 
-ESTIMATOR = ("GPU-side step time (HIP events around the timed steps) x the kernel's share of the per-kernel event time / launches per "
-             "step: an upper bound on the average launch duration for a single-kernel step (launch gaps included)")
+ESTIMATOR = ("single-kernel step: GPU-side step time (two HIP events around the timed steps, no markers inside) / launches per step = an "
+             "upper bound on the average launch duration (launch gaps included); step of several kernels: HIP events around this "
+             "kernel's own launches (marker pair included: conservative), never more than the step")
 
 
 def main():
@@ -115,7 +118,7 @@ def main():
                          "render for config2, K3 for config3 -- and always for config5; off on one GPU)")
     ap.add_argument("--mix-depth", type=int, default=16, help="blocks per ncclReduce (M of SURVEY 8e)")
     ap.add_argument("--voice-mode", type=int, default=0, choices=[0, 1], help="config3: 0 = hoisted coefficients, 1 = 14.monosynth order")
-    ap.add_argument("--mfcc-method", default="sparse", choices=["sparse", "mfma", "mfma-gemm"],
+    ap.add_argument("--mfcc-method", default="sparse", choices=["sparse", "walk", "mfma", "mfma-gemm"],
                     help="config4: the fused kernel with the exact sparse mel walk (default), the fused kernel with the mel contraction "
                          "and the DCT on the matrix pipe (mfma: knob fused_mel 3, banded v_mfma_f64_4x4x4), or the round-2 two-kernel "
                          "route (mfma-gemm: FFT kernel + dense fp64 MFMA GEMM over the stored magnitudes)")
@@ -431,7 +434,7 @@ def main():
             fused_ok = hasattr(L, "mxg_fft_mfcc_batch") and not mfma
             mags = None if fused_ok else torch.empty((NF, 512), dtype=torch.float32, device=dev)
 
-            fused_mel_knob = 3 if mm else int(dict(kv.split("=") for kv in args.tune).get("fused_mel", 0))
+            fused_mel_knob = 3 if mm else (2 if mfcc_method == "walk" else int(dict(kv.split("=") for kv in args.tune).get("fused_mel", 0)))
 
             def step():
                 if fused_ok:
@@ -467,12 +470,17 @@ def main():
                      mfma_note="issued 2*%d*48 flops/frame (useful dense 2*512*42 = 43008)" % kdim if mfma else None,
                      # the fused matrix form stays HBM-bound (4200 B per frame); what its matrix pipe does is reported beside the roofline:
                      # per 8 frames 4 x batches (mel) + 24 (DCT) v_mfma_f64_4x4x4_4b instructions of 512 flops each
-                     matrix_flops=(4 * mm_batches + 24) * 512.0 * NF / 8 if mm else None,
+                     matrix_flops=(4 * mm_batches + 24) * 512.0 * NF / 8 if mm else (24 * 512.0 * NF / 8 if mfcc_method == "walk" else None),
                      workload="configs[3]: maxiFFT(1024,1024,1024) + maxiMFCC(512,42,13,20,20000) over %d frames per GPU per step, %s"
                               % (NF, "FFT kernel + dense fp64 MFMA mel contraction (K = %d bins)" % kdim if mfma else
                                  ("one fused kernel, exact FFT, mel contraction + DCT on the matrix pipe (v_mfma_f64_4x4x4_4b, banded per quad of "
                                   "filters: band sums within 1e-13, mfcc within 1e-11 of the exact form)" if mm else
-                                  ("one fused kernel, exact sparse mel walk" if fused_ok else "FFT kernel + exact sparse mel walk"))))
+                                  ("one fused kernel, exact FFT, sparse mel walk (band sums bit for bit the reference's sequential sums), DCT on "
+                                   "the matrix pipe (fused_mel 2)" if mfcc_method == "walk" else
+                                   ("one fused kernel in the library's default form (exact FFT: magnitudes bit-exact; only the coefficients "
+                                    "are requested, so the mel contraction and the DCT run on the matrix pipe -- fused_mel 0 = 3 here; "
+                                    "band sums within 1e-13, mfcc within the device log's 1e-12 of the reference)" if fused_ok
+                                    else "FFT kernel + exact sparse mel walk")))))
         else:  # config5
             S, T, Ls = 2048, 70560, 4410000
             rng5 = np.random.default_rng(0x4D415849)
@@ -772,7 +780,8 @@ def main():
                 "config3": ("config3", "off", "sparse", 256, 64),
                 "config3_modB": ("config3", "off", "modB", 64, 16),  # cutoff modulated per sample (14.monosynth/main.cpp:53)
                 "config4": ("config4", "off", "sparse", 10, 2),
-                "config4_mfma": ("config4", "off", "mfma", 10, 2),
+                "config4_walk": ("config4", "off", "walk", 10, 2),   # band sums bit-exact (sparse walk), DCT on the matrix pipe
+                "config4_mfma": ("config4", "off", "mfma", 10, 2),   # mel contraction + DCT on the matrix pipe, the knob set explicitly
                 "config5": ("config5", "fused", "sparse", 10, 2)}.items():
             try:
                 Wq = build_workload(wl, md, "sparse" if meth == "modB" else meth, 1 if meth == "modB" else 0)
@@ -788,6 +797,40 @@ def main():
         if "config2_mixdown" in configs and "ms_per_step" in configs["config2_mixdown"]:
             # against the headline's GPU-side step (events): both are event-timed; the wall-clock ms_per_step of a 20-step run carries the fence
             configs["config2_mixdown"]["step_vs_headline"] = round(configs["config2_mixdown"]["ms_per_step"] / step_ms_events, 4)
+
+    # ---- N > 1 default run: BASELINE's multi-GPU config (configs[4]: granular time-stretch, streams sharded over the ranks, ONE
+    # stereo reduce per render) measured in the same launch: every rank the same fixed number of steps (the reduce is a collective),
+    # barrier + synchronize on both sides, the slowest rank's time
+    if (world > 1 and args.workload == "config2" and not args.tune and not args.no_configs and not args.voices):
+        c5 = {}
+        try:
+            W5 = build_workload("config5", "fused")
+            n5, w5 = 6, 2
+            for _ in range(w5):
+                W5["step"]()
+            W5["queue"].flush()
+            fence()
+            t5 = time.perf_counter()
+            for _ in range(n5):
+                W5["step"]()
+            W5["queue"].flush()
+            fence()
+            e5 = time.perf_counter() - t5
+            t = torch.tensor([e5], dtype=torch.float64)
+            if not args.share_gpu:
+                t = t.to(dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e5 = float(t[0])
+            c5 = {"workload": W5["workload"], "steps": n5, "warmup": w5, "n_gpus": world, "ms_per_step": round(e5 / n5 * 1e3, 4),
+                  "value": round(W5["samples"] * world * n5 / e5 / 1e6, 1), "unit": "Msamples/s", "dtype": W5["dtype"], "scaling": "weak",
+                  "note": "whole-job grain-samples per second over %d ranks, barrier-bracketed wall clock, max over ranks" % world}
+            for qq in (W5["queue"], W5["local_queue"]):
+                if qq is not None:
+                    qq.close()
+            del W5
+        except Exception as e:
+            c5 = {"error": "%s: %s" % (type(e).__name__, e)}
+        configs["config5"] = c5
 
     value = W["samples"] * world * args.steps / elapsed / 1e6
     dom_launches = kernels.get(dom, {}).get("launches_per_step", 1.0)

@@ -101,7 +101,15 @@ struct HipMixDev {
     typedef hipEvent_t Event;
     mxg_comm *comm = nullptr;  // NULL: no communicator, the "reduce" is a device copy
     int record(Event e, Stream s) { return mxg::check_hip(hipEventRecord(e, s), "hipEventRecord"); }
-    int wait(Stream s, Event e) { return mxg::check_hip(hipStreamWaitEvent(s, e, 0), "hipStreamWaitEvent"); }
+    // An event that has already completed orders nothing any more: no dependency packet goes on the stream.  (The render stream's
+    // wait for the reduce that last read a staging buffer -- two batches back, long done -- cost it a ~9 us bubble once per batch:
+    // profiles/r05_k1m_gaps.md.)  Not while the stream is being captured: a graph must carry the edge.
+    int wait(Stream s, Event e) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone && hipEventQuery(e) == hipSuccess) return MXG_OK;
+        (void)hipGetLastError();  // (hipEventQuery's hipErrorNotReady is not an error)
+        return mxg::check_hip(hipStreamWaitEvent(s, e, 0), "hipStreamWaitEvent");
+    }
     int reduce(const double *send, double *recv, size_t count, int root, Stream s) {
         using namespace mxg;
         if (comm)  // a one-rank communicator still goes through RCCL (the path a 1-GPU box can execute)
@@ -221,9 +229,11 @@ mxg_mixq *mxg_mixq_create_grouped(mxg_comm *c, size_t block_doubles, int depth_b
         ok = ok && hipMalloc(&q->stage[b], bytes) == hipSuccess && hipMalloc(&q->result[b], bytes) == hipSuccess;
         ok = ok && hipMemset(q->stage[b], 0, bytes) == hipSuccess && hipMemset(q->result[b], 0, bytes) == hipSuccess;
         if (groups > 1) ok = ok && hipMalloc(&q->gstage[b], bytes * groups) == hipSuccess && hipMemset(q->gstage[b], 0, bytes * groups) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&q->filled[b], hipEventDisableTiming) == hipSuccess;
+        // filled / consumed order streams of THIS device only: no system-scope fence on their record (the render stream records one
+        // per batch); reduced also publishes the root's copy to the pinned host ring: it keeps the default fences
+        ok = ok && hipEventCreateWithFlags(&q->filled[b], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&q->reduced[b], hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&q->consumed[b], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&q->consumed[b], hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
     }
     if (!ok) {
         fail(MXG_ERR_HIP, "mxg_mixq_create: %s", hipGetErrorString(hipGetLastError()));

@@ -344,7 +344,7 @@ __global__ void ifft_ola_kernel(const float *__restrict__ ifft_out, size_t nfram
 
 // ---- K6a: fftSize 1024 (half = 512 = 8^3): LDS image, pad8 and round3 live in mxg_spectral.h ------------
 template <int OMASK, bool ALIGNED8>
-__global__ __launch_bounds__(64 * kWavesPerBlock, MXG_FFT_MINWAVES) void fft1024_kernel(
+__global__ __launch_bounds__(64 * kWavesPerBlock, MXG_FFT_MINWAVES) __attribute__((target("no-load-store-opt"))) void fft1024_kernel(
     const float *__restrict__ signal, size_t frame_stride, size_t nframes,
     const float *__restrict__ window, const float2 *__restrict__ tw, const float2 *__restrict__ post,
     FftOut out) {

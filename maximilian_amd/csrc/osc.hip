@@ -528,6 +528,12 @@ constexpr int kPcRing = 3;
 #ifndef MXG_PC_ASMX
 #define MXG_PC_ASMX 1  // A/B: 0 = K1's compiler-scheduled pair exchange in the producers
 #endif
+#ifndef MXG_PC_CSLEEP
+#define MXG_PC_CSLEEP 4  // A/B: the consumer's poll interval (units of 64 clocks)
+#endif
+#ifndef MXG_PC_PRIO
+#define MXG_PC_PRIO 2  // A/B: the producers' issue priority
+#endif
 constexpr int kPcFL = MXG_PC_FL;
 __device__ __forceinline__ int lds_flag_load(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
             double *op = out + (size_t)(threadIdx.x & 1) * V + (v & ~(size_t)1);
             int k = 0;
             int seen = 0;  // `cons` as last read: requested at the start of a chunk, looked at one chunk later (no wait on the way)
-            __builtin_amdgcn_s_setprio(2);  // the store-bound stream is the critical one: the consumer takes the issue slots it leaves
+            __builtin_amdgcn_s_setprio(MXG_PC_PRIO);  // the store-bound stream is the critical one: the consumer takes the issue slots it leaves
             for (size_t n0 = 0; n0 < N; n0 += WIN) {
                 const int span = (int)((N - n0) < (size_t)WIN ? (N - n0) : (size_t)WIN);
                 for (int c0 = 0; c0 < span; c0 += kMixChunk, k++) {
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
                 const int span = (int)((N - n0) < (size_t)WIN ? (N - n0) : (size_t)WIN);
                 for (int c0 = 0; c0 < span; c0 += kMixChunk, k++) {
                     const int cnt = (span - c0) < kMixChunk ? (span - c0) : kMixChunk;
-                    while (lds_flag_load(f_prod) <= k) __builtin_amdgcn_s_sleep(4);
+                    while (lds_flag_load(f_prod) <= k) __builtin_amdgcn_s_sleep(MXG_PC_CSLEEP);
                     asm volatile("" ::: "memory");
                     const double2v *tr =
                         reinterpret_cast<const double2v *>(ring + (k % kPcRing) * kTileWave + tq * kTileQuarter + ts * kTileRow);

@@ -60,6 +60,11 @@ def test_two_ranks_sharing_one_gpu_print_the_scaling_fields():
     assert 0.0 < d["per_gpu_efficiency"] <= 1.0
     assert d["value_like_for_like_n1"] > 0 and d["step_ms_without_reduce"] > 0
     assert d["roofline"]["kernel"] == "osc_mix_kernel"
+    # BASELINE's multi-GPU config (configs[4]: granular time-stretch, streams sharded over the ranks, one stereo reduce per render)
+    # rides along in every N > 1 line
+    c5 = d["configs"]["config5"]
+    assert "error" not in c5, c5
+    assert c5["n_gpus"] == 2 and c5["value"] > 0 and c5["ms_per_step"] > 0 and c5["scaling"] == "weak"
 
 
 @pytest.mark.gpu
@@ -81,21 +86,28 @@ def test_two_ranks_with_the_fallback_exchange():
 def test_default_line_carries_every_gpu_config():
     """The command the driver runs (`bench.py --gpus 1 --steps K --warmup W`) reports configs 3, 4, 4-mfma, 5 and the fused-mixdown
     step next to the headline: each with its own ms_per_step, value and the roofline of its dominant kernel."""
-    r = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"], timeout=900)
+    r = _run(["--gpus", "1", "--steps", "20", "--warmup", "5"], timeout=1200)
     assert r.returncode == 0, (r.stderr + r.stdout)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["roofline"]["kernel"] == "osc_kernel" and 0.3 < d["roofline"]["frac"] < 1.0
-    want = {"config2_mixdown": "osc_mix_kernel", "config2_tables": "osctab_kernel", "config3": "voice_kernel", "config4": "fft_mfcc_kernel",
-            "config4_mfma": "mfcc_mfma_gemm_kernel", "config5": "granular_unit_kernel"}
+    assert d["roofline"]["estimator"] and 0.3 < d["roofline"]["frac_wall"] <= d["roofline"]["frac"] * 1.02
+    assert d["cpu_baseline"]["value"] > 0
+    want = {"config2_mixdown": "osc_mix_kernel", "config2_tables": "osctab_kernel", "config3": "voice_kernel", "config3_modB": "voice_kernel",
+            "config4": "fft_mfcc_kernel", "config4_walk": "fft_mfcc_kernel", "config4_mfma": "fft_mfcc_kernel", "config5": "granular_unit_kernel"}
     assert set(d["configs"]) == set(want), d["configs"].keys()
     for name, kernel in want.items():
         c = d["configs"][name]
         assert "error" not in c, c
         assert c["ms_per_step"] > 0 and c["value"] > 0 and c["roofline"]["kernel"] == kernel, c
         assert 0.0 < c["roofline"]["frac"] < 1.0 and c["roofline"]["kernel_ms"] <= c["ms_per_step"] * 1.001, c
-        assert ("flops_per_launch" in c["roofline"]) == (name == "config4_mfma")
+        assert ("matrix_pipe" in c["roofline"]) == (name in ("config4_mfma", "config4_walk")), c["roofline"].keys()
+        if name != "config2_tables":  # (the per-voice-table extension has no reference CPU path to time)
+            assert c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["kind"] in ("reference", "port"), c.get("cpu_baseline")
+    # the matrix-pipe form of config 4 is the library's default when only the coefficients are requested: the two entries measure the same kernel
+    assert abs(d["configs"]["config4"]["ms_per_step"] / d["configs"]["config4_mfma"]["ms_per_step"] - 1.0) < 0.08
+    assert d["configs"]["config4_mfma"]["ms_per_step"] <= d["configs"]["config4_walk"]["ms_per_step"] * 1.03
     # the fused-mixdown step (what every rank of an N > 1 run does per block) costs about what the plain render costs
     # (against the headline's GPU-side step time: at the driver's 20 steps the wall-clock figure carries ~3 us of fence per step)
     # (a regression guard, not the claim: measured 1.07-1.27 by box -- K1 39.9-44.6 us, the mixdown step 47.5-51.7; round 3: 1.32)

@@ -476,3 +476,29 @@ def test_pulse_width_and_frequency_per_sample(mx, port):
         chk(L.mxg_osc_render(wf, V, N, d_f.ptr, 2, d_p1.ptr, d_p2.ptr, d_ph.ptr, d_hd.ptr, d_o.ptr, None), "mxg_osc_render fps=2")
         assert_bits_equal(d_o.numpy(), exp, "fps = 2, waveform %d" % wf)
         assert_bits_equal(d_ph.numpy(), ph, "phase")
+
+
+@pytest.mark.parametrize("wf", [8, 3, 0, 10, 6])
+@pytest.mark.parametrize("V,N,pad", [(4096, 301, 32), (4098, 64, 2), (4097, 33, 1), (70000, 40, 512), (2 * 98304 + 4098, 96, 34), (512, 2, 6)])
+def test_row_pitch_same_bits(mx, wf, V, N, pad):
+    """mxg_osc_render_pitch: the block written with a row pitch of V + pad doubles holds, in its first V columns, the bits of the
+    unpadded render (pair-row, two-voices-per-lane and 8-byte store paths, odd pitches, the launch plan of large banks), the padding
+    columns are never written, and the state afterwards is the same."""
+    freq = 20.0 + np.arange(V) * (15000.0 / V)
+    p1 = np.full(V, 0.3) if wf == 6 else None
+    a = mx.maxiOscBank(V)
+    ref = np.concatenate([a.render(wf, freq, N, p1=p1).numpy(), a.render(wf, freq, N, p1=p1).numpy()])
+    b = mx.maxiOscBank(V)
+    buf = mx.DeviceBuffer.from_numpy(np.full((N, V + pad), -7.0))
+    got = []
+    for _ in range(2):
+        b.render(wf, freq, N, p1=p1, out=buf, pitch=V + pad)
+        g = buf.numpy()
+        assert (g[:, V:] == -7.0).all(), "padding columns touched"
+        got.append(g[:, :V].copy())
+    assert_bits_equal(np.concatenate(got), ref, "padded rows vs natural rows")
+    assert_bits_equal(b.phase.numpy(), a.phase.numpy(), "phase")
+    assert_bits_equal(b.output.numpy(), a.output.numpy(), "output")
+    L = mx.lib()
+    assert L.mxg_osc_render_pitch(wf, V, N, 1, 0, None, None, 1, 1, 1, (V - 1) * 8, None) < 0   # pitch below the bank
+    assert L.mxg_osc_render_pitch(wf, V, N, 1, 0, None, None, 1, 1, 1, V * 8 + 4, None) < 0     # not a multiple of 8

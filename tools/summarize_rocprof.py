@@ -14,7 +14,7 @@ import shutil
 import statistics
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
@@ -67,13 +67,28 @@ for wl in sorted(d for d in os.listdir(src) if os.path.isdir(os.path.join(src, d
             v = v[len(v) // 3:]  # drop the warm-up / ramp launches
             pm.setdefault(lab, {})[cname] = statistics.mean(v) * 1024 * corr
     mf = collections.defaultdict(lambda: collections.defaultdict(list))
+    mfd = collections.defaultdict(float)
     for r in read(os.path.join(base, "pmc_mfma", "b_counter_collection.csv")):
         lab = label_of(r["Kernel_Name"])
         if lab:
-            mf[lab][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            mfd[(lab, r["Counter_Name"], r["Dispatch_Id"])] += float(r["Counter_Value"])  # (a counter's instances summed per dispatch)
+    for (lab, cn, _), v in mfd.items():
+        mf[lab][cn].append(v)
+    extra = {}
+    for sub in ("pmc_f64", "pmc_clk"):
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in read(os.path.join(base, sub, "b_counter_collection.csv")):
+            lab = label_of(r["Kernel_Name"])
+            if lab:
+                acc[lab][(r["Counter_Name"], r["Dispatch_Id"])].append(float(r["Counter_Value"]))
+        for lab, c in acc.items():
+            per = collections.defaultdict(list)
+            for (cn, _), vals in c.items():
+                per[cn].append(sum(vals))  # (a counter's instances -- SEs, XCDs -- summed per dispatch)
+            extra.setdefault(lab, {}).update({cn: statistics.mean(v[len(v) // 3:]) for cn, v in per.items()})
     out = ["# rocprofv3 summary `%s` / %s (MI355X)" % (tag, wl), "",
            "Command: `python bench.py %s` under `rocprofv3 --kernel-trace --stats` (per-kernel averages over the timed launches, i.e. the last"
-           % " ".join(bench.get("_args", [])) if False else "Passes: `rocprofv3 --kernel-trace --stats`, `--pmc WRITE_SIZE`, `--pmc FETCH_SIZE` (separate runs, tools/profile_r04.sh); "
+           % " ".join(bench.get("_args", [])) if False else "Passes: `rocprofv3 --kernel-trace --stats`, `--pmc WRITE_SIZE`, `--pmc FETCH_SIZE` (separate runs, tools/profile_%s.sh)" % tag + "; "
            "durations are averages over the second half of each kernel's launches (clock ramp and warm-up excluded).", "",
            "| kernel | launches | avg us (kernel-trace) | median | bench.py kernel_ms (HIP events, un-profiled) | WRITE_SIZE MB | FETCH_SIZE x2 MB | HBM traffic MB | VGPR | LDS B | grid x wg |",
            "|---|---|---|---|---|---|---|---|---|---|---|"]
@@ -85,7 +100,7 @@ for wl in sorted(d for d in os.listdir(src) if os.path.isdir(os.path.join(src, d
         w, f = p.get("WRITE_SIZE"), p.get("FETCH_SIZE")
         tot = (w or 0) + (f or 0) if (w is not None or f is not None) else None
         if tot is not None:
-            base_wl = wl in ("config2", "config2_mix", "config2_tables", "config3", "config4", "config4_mfma", "config5")
+            base_wl = wl in ("config2", "config2_mix", "config2_tables", "config3", "config4", "config4_gemm", "config5")
             traffic[lab if base_wl else "%s@%s" % (lab, wl)] = round(tot)  # (variants of a workload keep their own key)
         m = meta[lab]
         ev = bk.get(lab, {}).get("ms")
@@ -107,6 +122,25 @@ for wl in sorted(d for d in os.listdir(src) if os.path.isdir(os.path.join(src, d
                 us = statistics.mean(dd[len(dd) // 2:])
                 fl = g["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0
                 out.append("| `%s` | %.4g | %.4g | %.1f | %.1f | %.3f |" % (lab, g["SQ_INSTS_VALU_MFMA_MOPS_F64"], fl, us, fl / us / 1e6, fl / us / 1e6 / 78.6))
+    if extra:
+        out += ["", "Further counter passes (per launch, instances summed):", ""]
+        for lab, c in extra.items():
+            out.append("* `%s`: %s" % (lab, ", ".join("%s = %.4g" % kv for kv in sorted(c.items()))))
+            if "SQ_INSTS_VALU_ADD_F64" in c and bench.get("config"):
+                samples = 65536 * 512
+                flops = (c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + 2 * c.get("SQ_INSTS_VALU_FMA_F64", 0)) * 64.0
+                out.append("  => %.1f fp64 flops per sample (ADD + MUL + 2 FMA wave-instructions x 64 lanes / %d samples per launch)" % (flops / samples, samples))
+                traffic["voice_kernel_modB"] = {"fp64_flops_per_sample": round(flops / samples, 2), "source": "profiles/%s_%s_summary.md" % (tag, wl)}
+            if "GRBM_GUI_ACTIVE" in c and lab in durs:
+                dd = sorted(x[1] for x in durs[lab])
+                us = statistics.mean(dd[len(dd) // 2:])
+                out.append("  => effective shader clock while the kernel runs: GRBM_GUI_ACTIVE / duration = %.0f MHz (profiled pass)" % (c["GRBM_GUI_ACTIVE"] / us))
+    if mf and wl == "config4_mfma":
+        for lab, c in mf.items():
+            g = {k: statistics.mean(x) for k, x in c.items()}
+            if g.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0) > 0:
+                traffic["fft_mfcc_kernel_matrix_pipe"] = {"SQ_INSTS_VALU_MFMA_MOPS_F64": g["SQ_INSTS_VALU_MFMA_MOPS_F64"], "flops_issued": g["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0,
+                                                          "SQ_VALU_MFMA_BUSY_CYCLES": g.get("SQ_VALU_MFMA_BUSY_CYCLES"), "source": "profiles/%s_%s_summary.md" % (tag, wl)}
     if bench:
         rf = bench["roofline"]
         out += ["", "Un-profiled bench line of the same workload (`%s`):" % bench["config"]["workload"][:60], "",
