@@ -198,9 +198,10 @@ __device__ __forceinline__ void store2(double *p, double a, double b) {
     if constexpr (ST == 1)
         __builtin_nontemporal_store(v, reinterpret_cast<double2v *>(p));
     else if constexpr (ST == 2)  // (the wait states a following write of the four data registers needs: hipcc does not add them after asm)
-        // No "memory" clobber: the block is write-only for the kernel that stores it, and a clobber would pin every LDS table read of
-        // the NEXT sample behind this store -- two samples' reads in flight instead of a chunk's (round 4).  `volatile` keeps the
-        // store itself and its order among the other volatile asm statements.
+        // The "memory" clobber is the MEASURED default (MXG_STORE_CLOBBER 1 above): without it hipcc may hoist the next samples' LDS table
+        // reads over this store -- a whole chunk's reads in flight instead of two samples' -- which looked right and measured slower on
+        // K1's store-bound loop (round 4 A/B builds; the switch stays for such experiments).  `volatile` keeps the store itself and its
+        // order among the other volatile asm statements.
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) MXG_STORE_CLOBBER_LIST);
     else
         *reinterpret_cast<double2v *>(p) = v;

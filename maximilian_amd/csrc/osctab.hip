@@ -38,7 +38,7 @@ constexpr int kTabParts = 16;        // time parts per block (32 samples each), 
 constexpr int kTabVoices = 8;        // voices per round
 constexpr int kTabHdr = kTabParts * kTabVoices + 3 * kTabVoices;  // per-round header: marks[16][8], inc[8], gl[8], gr[8] (152 doubles)
 constexpr int kTabRound = kTabVoices * kTabLen + kTabHdr;         // doubles per LDS buffer: 4112 + 152 = 4264 (34 112 B)
-constexpr int kTabRing = 4;          // LDS buffers: one in use, three rounds of DMA in flight
+constexpr int kTabRing = 4;          // LDS buffers: the pair of rounds in use + the next pair arriving by DMA (the loop waits vmcnt(0) once per pair)
 static_assert(kTabRound * 8 == 8 * 4096 + 84 * 16, "a round is 8 full 4 KiB pieces + 84 sixteen-byte pieces");
 
 // (An experiment that stays as an A/B form, MXG_TAB_CMPX 2.)  The wrap test ahead of the add.  C:270 tests the SUM: `phase += inc; if (phase >= 511) phase -= 512;` -- add, compare, select,

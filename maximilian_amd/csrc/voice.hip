@@ -669,7 +669,10 @@ int mxg_filter_render(int kind, size_t V, size_t N, const double *d_in, const do
     // for blocks from 64 MB, 1 off, 2 / 3 / 4 plain / write-through / non-temporal stores)
     {
         int rw = tune_get("rw_store");
-        const bool pairs_ok = !mod && !(V & 1) && !(N & 1) && !(((uintptr_t)d_in) & 15) && !(((uintptr_t)d_out) & 15);
+        // (filter_pairs_kernel addresses its rows with 32-bit byte offsets from a wave-uniform base: rows of 2 GiB and more -- 2^28
+        // voices -- keep the 8-byte kernel, whose pointers are 64-bit)
+        const bool pairs_ok = !mod && !(V & 1) && !(N & 1) && !(((uintptr_t)d_in) & 15) && !(((uintptr_t)d_out) & 15) &&
+                              2 * (unsigned long long)V * sizeof(double) < (1ull << 32);
         if (rw == 0) rw = (V * N * sizeof(double) >= ((size_t)64 << 20)) ? 3 : 1;
         if (rw >= 2 && pairs_ok) {
             KernelTimer kt("filter_kernel", st);

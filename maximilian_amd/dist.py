@@ -132,7 +132,8 @@ class HostMixQueue:
     def __init__(self, dist, block_doubles, depth_blocks=16, root=0, groups=1):
         import torch
         self.dist, self.block, self.depth, self.root, self.groups = dist, int(block_doubles), int(depth_blocks), root, int(groups)
-        # groups > 1: a slot is [groups][block] partial rows, added in ascending order when the batch is submitted (mxg_mixq's fold)
+        # groups > 1: a slot is [groups][block] partial rows, added when the batch is submitted in the device fold's order (16 interleaved
+        # chains, then the chains left to right: mix_partials_kernel) -- the same roundings as mxg_mixq
         self.gstage = [torch.zeros((self.depth, self.groups, self.block), dtype=torch.float64) for _ in range(2)] if self.groups > 1 else None
         self.stage = [torch.zeros((self.depth, self.block), dtype=torch.float64) for _ in range(2)]
         self.res = [torch.zeros((self.depth, self.block), dtype=torch.float64) for _ in range(2)]
@@ -154,12 +155,19 @@ class HostMixQueue:
         return self.stage[b][self.fill]  # a [block] view the caller fills in place
 
     def _submit(self):
+        import torch
         b = self.cur
         if self.gstage is not None:
-            for k in range(self.fill):
-                acc = self.gstage[b][k][0].clone()
-                for g in range(1, self.groups):
-                    acc += self.gstage[b][k][g]
+            for k in range(self.fill):  # mix_partials_kernel's order (mxg_lanefold.h): 16 interleaved chains g = w, w + 16, ... each
+                chains = []            # summed from 0.0 in ascending g, then the chains added left to right
+                for w in range(16):
+                    c = torch.zeros(self.block, dtype=torch.float64)
+                    for g in range(w, self.groups, 16):
+                        c += self.gstage[b][k][g]
+                    chains.append(c)
+                acc = chains[0]
+                for c in chains[1:]:
+                    acc = acc + c
                 self.stage[b][k].copy_(acc)
         self.res[b][:self.fill].copy_(self.stage[b][:self.fill])
         if self._multi():

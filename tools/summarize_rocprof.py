@@ -84,7 +84,9 @@ for wl in sorted(d for d in os.listdir(src) if os.path.isdir(os.path.join(src, d
         for lab, c in acc.items():
             per = collections.defaultdict(list)
             for (cn, _), vals in c.items():
-                per[cn].append(sum(vals))  # (a counter's instances -- SEs, XCDs -- summed per dispatch)
+                # a counter's instances (SEs, XCDs) summed per dispatch -- except the GRBM clock counter, one instance per XCD counting the
+                # same cycles: averaged
+                per[cn].append(sum(vals) / len(vals) if cn.startswith("GRBM") else sum(vals))
             extra.setdefault(lab, {}).update({cn: statistics.mean(v[len(v) // 3:]) for cn, v in per.items()})
     out = ["# rocprofv3 summary `%s` / %s (MI355X)" % (tag, wl), "",
            "Command: `python bench.py %s` under `rocprofv3 --kernel-trace --stats` (per-kernel averages over the timed launches, i.e. the last"
@@ -134,7 +136,8 @@ for wl in sorted(d for d in os.listdir(src) if os.path.isdir(os.path.join(src, d
             if "GRBM_GUI_ACTIVE" in c and lab in durs:
                 dd = sorted(x[1] for x in durs[lab])
                 us = statistics.mean(dd[len(dd) // 2:])
-                out.append("  => effective shader clock while the kernel runs: GRBM_GUI_ACTIVE / duration = %.0f MHz (profiled pass)" % (c["GRBM_GUI_ACTIVE"] / us))
+                out.append("  => effective shader clock while the kernel runs: GRBM_GUI_ACTIVE / 8 XCDs / duration = %.0f MHz (profiled pass; rocprofv3 "
+                           "reports the counter summed over the eight XCDs)" % (c["GRBM_GUI_ACTIVE"] / 8.0 / us))
     if mf and wl == "config4_mfma":
         for lab, c in mf.items():
             g = {k: statistics.mean(x) for k, x in c.items()}
