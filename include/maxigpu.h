@@ -128,8 +128,8 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
 /* key: "osc_vpl" (voices per lane: 0 automatic, 1|2), "osc_block" (64..1024), "osc_nt" (non-temporal stores: 0 never, 1 always, 2 by the size of the output block),
  * "voice_block", "voice_nt" (as osc_nt), "mix_rows" (sample rows per workgroup of the mixdown, 1|2), "fft_generic",
  * "mfcc_tiled" (LDS-staged spectra 0|1), "grain_chunked" (time-sharded granular render 0|1), "grain_lanes_k",
- * "grain_unit" (coalesced unit-increment render 0|1), "grain_line" (tile render for arbitrary increments 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_slices" (time slices of a unit-path
- * maxiTimeStretch call whose scheduling and rendering overlap, 1..16), "osc_mix_win" (K1m: samples per workgroup combine window, 0 automatic, 128 or 256), "osc_mix_pcwin" (the same for the producer / consumer form: 0 automatic, 256 or 512), "osc_mix_pc" (K1m as producer / consumer wavefront pairs: 0 automatic, 1 off, 2 on),
+ * "grain_unit" (coalesced unit-increment render 0|1), "grain_line" (tile render for arbitrary increments 0|1), "grain_fast_sched" (event-driven schedulers 0|1), "grain_streamed" (unit-path maxiTimeStretch call as ONE launch whose scheduler lanes
+ * and tile renders run side by side, 1 default; 0 = time slices on the library's auxiliary streams), "grain_slices" (those time slices, 1..16), "osc_mix_win" (K1m: samples per workgroup combine window, 0 automatic, 128 or 256), "osc_mix_pcwin" (the same for the producer / consumer form: 0 automatic, 256 or 512), "osc_mix_pc" (K1m as producer / consumer wavefront pairs: 0 automatic, 1 off, 2 on),
  * "rw_store" (the read + write bank kernels' 16-byte pair-row streams: 0 automatic, 1 off, 2 / 3 / 4 on with plain / write-through /
  * non-temporal stores), "fft_exact" (1 default; 0 = TOLERANCE MODE of mxg_fft_mfcc_batch: the 512-point transform as true radix-8 butterflies with correctly
  * rounded twiddles and fused multiply-adds, hardware square root -- about a quarter fewer instructions; magnitudes within 6e-7 x the

@@ -243,16 +243,31 @@ struct SchedArgs {
     size_t c_end;
 };
 
-template <int MODE>
-__global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= A.S) return;
+// Loads and stores of the scheduler's lists.  COH = the streamed form (the renders of the same launch read what the scheduler lanes
+// write while both run, possibly on another XCD with its own L2): relaxed atomics at agent scope, i.e. write-through stores and
+// loads that are not served from a stale line; ordering comes from the progress word (sched_walk / granular_unit_kernel).
+template <bool COH, typename T>
+__device__ __forceinline__ T ld_list(const T *p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH, typename T>
+__device__ __forceinline__ void st_list(T *p, T v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// K8a for stream s over A.T samples.  STREAMED: one launch schedules the whole call while the tile renders of the SAME launch
+// consume the lists; prog[s] = number of chunk-table rows of this stream that are complete (rows 0 .. prog - 1, and with them
+// every spawn they count).  A row is published one event late -- at the next spawn, after an `s_waitcnt vmcnt(0)` that by then
+// only finds stores issued a spawn ago -- so the walk never waits for its own stores; the sample-by-sample walk publishes at
+// every tile boundary it passes.
+template <int MODE, bool STREAMED>
+__device__ __forceinline__ void sched_walk(const SchedArgs &A, const size_t s, int *prog) {
     const size_t S = A.S;
-    const double dlen = (double)A.len;
     SchedState q = {A.st[s], A.st[S + s], A.st[2 * S + s], 0.0, (size_t)A.st[3 * S + s]};
     const SchedConst sc = sched_const<MODE>(s, S, A.len, A.R, A.a, A.b, A.posMod, A.rnd, A.cycleLength,
                                             A.grainLength, A.sr, A.sampleDur);
-    const double rate = sc.rate;
     int count = (A.carry && A.n_base) ? A.carry[s] : 0;
     int failed = 0;
     // The serial part of a stream: keep this loop to the recurrences themselves (the chunk table is
@@ -263,15 +278,27 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
     // filled as they are recorded -- stores only (a pass over the finished list would chain one dependent
     // global load per chunk: 1100 chunks x ~0.5 us was most of this kernel's time).
     size_t cnext = (A.carry && A.n_base) ? (size_t)A.carry[S + s] : 0;
+    auto publish = [&]() {
+        if constexpr (STREAMED) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(prog + s, (int)cnext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto rows_to = [&](size_t clast, int stored) {  // rows cnext .. clast say `stored`
+        for (; cnext <= clast && cnext <= A.C; cnext++) st_list<STREAMED>(A.chunk_first + cnext * S + s, (int32_t)stored);
+    };
     auto record = [&](int n, double pos0, double inc) {
         n += A.n_base;  // sample index within the call
         const int stored = (size_t)count < A.G ? count : (int)A.G;
-        const size_t clast = (size_t)n / A.Tc;  // chunks starting at or before n do not contain this spawn's predecessors only
-        for (; cnext <= clast && cnext <= A.C; cnext++) A.chunk_first[cnext * S + s] = stored;
+        if constexpr (STREAMED) {  // what the previous event stored is complete by now: publish it before storing more
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(prog + s, (int)cnext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        rows_to((size_t)n / A.Tc, stored);  // chunks starting at or before n: this spawn's predecessors only
         if ((size_t)count < A.G) {
-            A.spawn_n[(size_t)count * S + s] = n;
-            A.spawn_pos[(size_t)count * S + s] = pos0;
-            A.spawn_inc[(size_t)count * S + s] = inc;
+            st_list<STREAMED>(A.spawn_n + (size_t)count * S + s, (int32_t)n);
+            st_list<STREAMED>(A.spawn_pos + (size_t)count * S + s, pos0);
+            st_list<STREAMED>(A.spawn_inc + (size_t)count * S + s, inc);
         } else {
             failed = 3;
         }
@@ -281,11 +308,19 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
     for (int n = nstart; n < Tn; n++) {
         double pos0, inc;
         if (sched_step<MODE>(q, sc, (size_t)n, pos0, inc, failed)) record(n, pos0, inc);
+        if constexpr (STREAMED) {
+            // the slow walk passes a tile boundary (STREAMED: Tc = 64, n_base = 0): rows up to the tile that starts at n + 1 are final
+            if (((n + 1) & 63) == 0) {
+                rows_to((size_t)(n + 1) >> 6, (size_t)count < A.G ? count : (int)A.G);
+                publish();
+            }
+        }
     }
     {   // chunks after the last spawn (of this slice: up to the row the next slice starts in)
         const int stored = (size_t)count < A.G ? count : (int)A.G;
-        for (; cnext <= A.c_end; cnext++) A.chunk_first[cnext * S + s] = stored;
+        for (; cnext <= A.c_end; cnext++) st_list<STREAMED>(A.chunk_first + cnext * S + s, (int32_t)stored);
     }
+    publish();
     if (A.carry) {
         A.carry[s] = count;
         A.carry[S + s] = (int32_t)cnext;
@@ -295,6 +330,13 @@ __global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
     A.st[S + s] = q.looper;
     A.st[2 * S + s] = q.randomOffset;
     A.st[3 * S + s] = (double)q.cursor;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void granular_sched_kernel(SchedArgs A) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.S) return;
+    sched_walk<MODE, false>(A, s, nullptr);
 }
 
 struct RenderArgs {
@@ -562,7 +604,7 @@ constexpr int kCand = 12;  // candidates per stream and tile: <= 8 alive at the 
 // The finished [64 samples][64 streams] tile (LDS, row stride 65): coalesced [T][S] stores, 16 sample rows per wave, and
 // -- when a pan is given -- the maxiMix::stereo partial sums of the tile's 64 streams (shared by K8c and K8d).
 __device__ __forceinline__ void tile_epilogue(const UnitArgs &A, const double *s_tile, const size_t s0, const size_t n0,
-                                              const int lane, const int wave) {
+                                              const int lane, const int wave, const unsigned stile) {
     const size_t S = A.S;
     for (int r = wave * 16; r < wave * 16 + 16; r++) {
         const size_t nn = n0 + r, s = s0 + lane;
@@ -588,14 +630,91 @@ __device__ __forceinline__ void tile_epilogue(const UnitArgs &A, const double *s
         const double sl = quad_sum(fold_chunk_swap<double>(L)), sr = quad_sum(fold_chunk_swap<double>(R));
         const size_t nn = n0 + wave * 16 + (size_t)(slot < 0 ? 0 : slot);
         if ((lane & 3) == 0 && slot >= 0 && nn < A.T) {
-            double *dst = A.mixpart + ((size_t)blockIdx.x * A.T + nn) * 2;
+            double *dst = A.mixpart + ((size_t)stile * A.T + nn) * 2;
             dst[0] = sl;
             dst[1] = sr;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
+// grains alive after sample T-1, creation order, closed form (one lane per stream)
+template <bool COH>
+__device__ __forceinline__ void unit_state_lane(const UnitArgs &A, const size_t s) {
+    const size_t S = A.S;
+    const long long len = (long long)A.len, T = (long long)A.T;
+    double gp[kSlots], gi[kSlots], gx[kSlots], gd[kSlots];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) { gp[k] = gi[k] = gx[k] = gd[k] = 0.0; }
+    auto push = [&](double p, double i, double x, double d) {
+#pragma unroll
+        for (int k = 0; k < kSlots; k++)
+            if (k == cnt) { gp[k] = p; gi[k] = i; gx[k] = x; gd[k] = d; }
+        cnt++;
+    };
+    for (int k = 0; k < kSlots; k++) {
+        const long long dur = (long long)A.gst_in[(3 * kSlots + k) * S + s];
+        if (!dur) continue;
+        const long long idx0 = (long long)A.gst_in[(2 * kSlots + k) * S + s];
+        if (idx0 + T >= dur) continue;
+        const long long pos = (long long)A.gst_in[(0 * kSlots + k) * S + s];
+        const long long inc = (long long)A.gst_in[(1 * kSlots + k) * S + s];
+        if (cnt < kSlots) push((double)unit_index(pos + T * inc, len), (double)inc, (double)(idx0 + T), (double)dur);
+    }
+    const int count = ld_list<COH>(A.chunk_first + A.C * S + s);
+    int j0 = count;
+    while (j0 > 0 && (long long)ld_list<COH>(A.spawn_n + (size_t)(j0 - 1) * S + s) + A.sampleDur > T) j0--;
+    for (int j = j0; j < count; j++) {
+        const long long born = ld_list<COH>(A.spawn_n + (size_t)j * S + s);
+        const long long pos0 = (long long)ld_list<COH>(A.spawn_pos + (size_t)j * S + s);
+        const long long steps = T - born;
+        const long long sgn = ld_list<COH>(A.spawn_inc + (size_t)j * S + s) > 0 ? 1 : -1;
+        if (cnt < kSlots) push((double)unit_index(pos0 + steps * sgn, len), (double)sgn, (double)steps, (double)A.sampleDur);
+    }
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) {
+        A.gst_out[(0 * kSlots + k) * S + s] = gp[k];
+        A.gst_out[(1 * kSlots + k) * S + s] = gi[k];
+        A.gst_out[(2 * kSlots + k) * S + s] = gx[k];
+        A.gst_out[(3 * kSlots + k) * S + s] = gd[k];
+    }
+}
+__global__ __launch_bounds__(64) void granular_unit_state_kernel(UnitArgs A) {
+    if (unit_args_skip(A)) return;
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.S) return;
+    unit_state_lane<false>(A, s);
+}
+
+// SMODE < 0: the tile renderer alone (grid = stream tiles x tiles of the slice; the lists are complete when it starts).
+// SMODE = 0 / 2 (maxiTimeStretch::play / playAtPosition), the STREAMED form: one launch for the whole call, 1-D grid.  The first
+// `nsched` workgroups are the scheduler (their wavefront 0: one lane per stream, sched_walk<SMODE, true>, then the grains alive
+// after the call); every other workgroup renders one tile, tiles in dispatch order, and starts by waiting until the 64 streams of
+// its tile have published the two chunk-table rows it reads (Q.prog).  Workgroups are dispatched in index order, so the scheduler
+// wavefronts are resident before the first renderer polls; the scheduler needs about half the time the renders need (0.41 us
+// against 0.79 us per tile row on config 5), so after the first few rows nobody waits.  A renderer that sees no progress for
+// kStreamSpin polls reports error 6 and renders silence instead of reading rows that do not exist yet.
+// (Before: four time slices on two streams -- the cross-queue event hops, the first slice's scheduler and the launch gaps between
+// the slices were ~10 % of the config-5 step, profiles/r05_config5_timeline.md.)
+constexpr int kStreamSpin = 1 << 22;
+template <int SMODE>
+__global__ __launch_bounds__(256, 4) void granular_unit_kernel(UnitArgs A, SchedArgs Q, int *prog, unsigned nsched) {
+    constexpr bool COH = SMODE >= 0;
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if constexpr (COH) {
+        if (blockIdx.x < nsched) {
+            if (threadIdx.x >= 64) return;
+            const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+            if (s >= A.S) return;
+            __builtin_amdgcn_s_setprio(3);
+            sched_walk<(SMODE >= 0 ? SMODE : 0), true>(Q, s, prog);
+            if (!unit_args_skip(A)) unit_state_lane<true>(A, s);
+            return;
+        }
+        const unsigned idx = blockIdx.x - nsched, stiles = (unsigned)((A.S + 63) / 64);
+        bx = idx % stiles;
+        by = idx / stiles;
+    }
     if (unit_args_skip(A)) return;
     __shared__ double s_tile[64 * 65];
     __shared__ int s_base[64 * kCand];  // buffer index the grain reads at the tile's first sample (mod len)
@@ -604,8 +723,28 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
     __shared__ int s_cnt[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t S = A.S;
-    const size_t s0 = (size_t)blockIdx.x * 64, c = (size_t)blockIdx.y + A.c0, n0 = c * 64;
+    const size_t s0 = (size_t)bx * 64, c = (size_t)by + A.c0, n0 = c * 64;
     const long long len = (long long)A.len;
+    bool listed = true;  // the rows and spawns this tile reads exist
+    if constexpr (COH) {
+        if (threadIdx.x < 64) {
+            const size_t s = s0 + threadIdx.x;
+            const int need = (int)c + 2;  // rows c and c + 1
+            int spins = 0, seen = -1;
+            for (;;) {
+                const int have = s < S ? __hip_atomic_load(prog + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+                if (__all(have >= need)) break;
+                if (__any(have != seen)) spins = 0;  // some stream moved: the count is of polls WITHOUT progress
+                seen = have;
+                if (++spins > kStreamSpin) {
+                    listed = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            if (!listed && threadIdx.x == 0) atomicMax(A.err, 6);
+        }
+    }
     // ---- phase 1: one lane per stream collects that stream's candidate grains (creation order) in LDS,
     //      so the dependent metadata loads of 64 streams overlap; all 64-bit arithmetic happens here,
     //      once per grain and tile
@@ -615,7 +754,7 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
         // interior candidates (bit 8+q of ibits): alive on all 64 samples of the tile, neither buffer index wraps in it
         const bool fullTile1 = (long long)n0 + 64 <= (long long)A.T;
         int ibits = 0;
-        if (s < S) {
+        if (s < S && listed) {
             auto add = [&](long long born, long long dur, long long pos0, long long sg) {
                 // sample k of the grain reads index (pos0 + (k+1)*sg) mod len; at the tile start k = n0 - born
                 const long long k0 = (long long)n0 - born;
@@ -639,7 +778,7 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
                     add(-idx0, dur, pos - idx0 * inc, inc);
                 }
             }
-            const int first = A.chunk_first[c * S + s], next = A.chunk_first[(c + 1) * S + s];
+            const int first = ld_list<COH>(A.chunk_first + c * S + s), next = ld_list<COH>(A.chunk_first + (c + 1) * S + s);
             // spawns of earlier tiles still alive at n0: births increase, so the live ones are a suffix of
             // [0, first) and at most kSlots long.  Their births/positions are fetched with independent
             // loads (a walk-back loop would chain one dependent load per grain) and filtered afterwards.
@@ -649,9 +788,9 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
             for (int u = 0; u < kSlots; u++) {
                 const int j = first - kSlots + u;
                 const int jc = j < 0 ? 0 : j;
-                bornB[u] = A.spawn_n[(size_t)jc * S + s];
-                posB[u] = A.spawn_pos[(size_t)jc * S + s];
-                incB[u] = A.spawn_inc[(size_t)jc * S + s];
+                bornB[u] = ld_list<COH>(A.spawn_n + (size_t)jc * S + s);
+                posB[u] = ld_list<COH>(A.spawn_pos + (size_t)jc * S + s);
+                incB[u] = ld_list<COH>(A.spawn_inc + (size_t)jc * S + s);
             }
 #pragma unroll
             for (int u = 0; u < kSlots; u++) {
@@ -661,15 +800,15 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
                     add(bornB[u], A.sampleDur, (long long)posB[u], incB[u] > 0 ? 1 : -1);
                 }
             }
-            if (first > kSlots && (long long)A.spawn_n[(size_t)(first - kSlots - 1) * S + s] + A.sampleDur > (long long)n0)
+            if (first > kSlots && (long long)ld_list<COH>(A.spawn_n + (size_t)(first - kSlots - 1) * S + s) + A.sampleDur > (long long)n0)
                 atomicMax(A.err, 1);  // more than kSlots earlier spawns alive: the capacity rule of every kernel
             for (int j = first; j < next; j++) {
                 if (cnt >= kCand) {
                     atomicMax(A.err, 1);
                     break;
                 }
-                add(A.spawn_n[(size_t)j * S + s], A.sampleDur, (long long)A.spawn_pos[(size_t)j * S + s],
-                    A.spawn_inc[(size_t)j * S + s] > 0 ? 1 : -1);
+                add(ld_list<COH>(A.spawn_n + (size_t)j * S + s), A.sampleDur, (long long)ld_list<COH>(A.spawn_pos + (size_t)j * S + s),
+                    ld_list<COH>(A.spawn_inc + (size_t)j * S + s) > 0 ? 1 : -1);
             }
         }
         s_cnt[threadIdx.x] = cnt | ((cnt > 0 && cnt <= kSlots) ? kFlatFlag : 0) |
@@ -852,52 +991,7 @@ __global__ __launch_bounds__(256) void granular_unit_kernel(UnitArgs A) {
         }
     }
     __syncthreads();
-    tile_epilogue(A, s_tile, s0, n0, lane, wave);
-}
-
-// grains alive after sample T-1, creation order, closed form (one lane per stream)
-__global__ __launch_bounds__(64) void granular_unit_state_kernel(UnitArgs A) {
-    if (unit_args_skip(A)) return;
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t S = A.S;
-    if (s >= S) return;
-    const long long len = (long long)A.len, T = (long long)A.T;
-    double gp[kSlots], gi[kSlots], gx[kSlots], gd[kSlots];
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < kSlots; k++) { gp[k] = gi[k] = gx[k] = gd[k] = 0.0; }
-    auto push = [&](double p, double i, double x, double d) {
-#pragma unroll
-        for (int k = 0; k < kSlots; k++)
-            if (k == cnt) { gp[k] = p; gi[k] = i; gx[k] = x; gd[k] = d; }
-        cnt++;
-    };
-    for (int k = 0; k < kSlots; k++) {
-        const long long dur = (long long)A.gst_in[(3 * kSlots + k) * S + s];
-        if (!dur) continue;
-        const long long idx0 = (long long)A.gst_in[(2 * kSlots + k) * S + s];
-        if (idx0 + T >= dur) continue;
-        const long long pos = (long long)A.gst_in[(0 * kSlots + k) * S + s];
-        const long long inc = (long long)A.gst_in[(1 * kSlots + k) * S + s];
-        if (cnt < kSlots) push((double)unit_index(pos + T * inc, len), (double)inc, (double)(idx0 + T), (double)dur);
-    }
-    const int count = A.chunk_first[A.C * S + s];
-    int j0 = count;
-    while (j0 > 0 && (long long)A.spawn_n[(size_t)(j0 - 1) * S + s] + A.sampleDur > T) j0--;
-    for (int j = j0; j < count; j++) {
-        const long long born = A.spawn_n[(size_t)j * S + s];
-        const long long pos0 = (long long)A.spawn_pos[(size_t)j * S + s];
-        const long long steps = T - born;
-        const long long sgn = A.spawn_inc[(size_t)j * S + s] > 0 ? 1 : -1;
-        if (cnt < kSlots) push((double)unit_index(pos0 + steps * sgn, len), (double)sgn, (double)steps, (double)A.sampleDur);
-    }
-#pragma unroll
-    for (int k = 0; k < kSlots; k++) {
-        A.gst_out[(0 * kSlots + k) * S + s] = gp[k];
-        A.gst_out[(1 * kSlots + k) * S + s] = gi[k];
-        A.gst_out[(2 * kSlots + k) * S + s] = gx[k];
-        A.gst_out[(3 * kSlots + k) * S + s] = gd[k];
-    }
+    tile_epilogue(A, s_tile, s0, n0, lane, wave, bx);
 }
 
 // ---- K8d: tile render for arbitrary increments (maxiStretch, maxiPitchShift, maxiTimeStretch off the integer grid) ------
@@ -1178,7 +1272,7 @@ __global__ __launch_bounds__(256) void granular_line_kernel(UnitArgs A) {
         }
         flush();
         __syncthreads();
-        tile_epilogue(A, s_tile, s0, n0, lane, wave);
+        tile_epilogue(A, s_tile, s0, n0, lane, wave, blockIdx.x);
         __syncthreads();  // the tile and the candidate list are reused by the next tile of the span
     }
 }
@@ -1230,20 +1324,33 @@ __global__ __launch_bounds__(64) void granular_line_state_kernel(UnitArgs A) {
     }
 }
 
-// eligibility of the carried-in grains for K8c: every live one must have inc = +-1 and an integer position
-__global__ void granular_unit_check_kernel(size_t S, const double *__restrict__ gst, double dlen, int sampleDur,
-                                           int *flag) {
+// The first kernel of a chunked call: keeps a copy of the carried-in grains (the renders read the copy, the state kernels
+// overwrite d_gst while they run), clears the streamed form's progress words and, with `check`, decides K8c's eligibility: every live carried-in grain must have
+// inc = +-1 and an integer position (*flag = 1 otherwise; the word is zero between calls, see grain_err_publish_kernel).
+__global__ void granular_prologue_kernel(size_t S, const double *__restrict__ gst, double *__restrict__ gst_copy, double dlen,
+                                         int sampleDur, int check, int *flag, int32_t *prog) {
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
+    prog[s] = 0;  // the streamed form's progress words: no chunk-table row of this call exists yet
     bool bad = false;
+    double v[4][kSlots];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int k = 0; k < kSlots; k++) v[j][k] = gst[(j * kSlots + k) * S + s];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int k = 0; k < kSlots; k++) gst_copy[(j * kSlots + k) * S + s] = v[j][k];
+    if (!check) return;
+#pragma unroll
     for (int k = 0; k < kSlots; k++) {
-        if (gst[(3 * kSlots + k) * S + s] == 0.0) continue;
-        const double pos = gst[(0 * kSlots + k) * S + s], inc = gst[(1 * kSlots + k) * S + s];
+        if (v[3][k] == 0.0) continue;
+        const double pos = v[0][k], inc = v[1][k];
         // (a grain the plan could not have made goes to the general path, which refuses it)
-        if (!carried_grain_ok(pos, inc, gst[(2 * kSlots + k) * S + s], gst[(3 * kSlots + k) * S + s], dlen, sampleDur))
-            bad = true;
+        if (!carried_grain_ok(pos, inc, v[2][k], v[3][k], dlen, sampleDur)) bad = true;
         if (!(inc == 1.0 || inc == -1.0) || pos != floor(pos) || pos < 0.0 || pos > 9.0e15) bad = true;
-        if (gst[(3 * kSlots + k) * S + s] >= 32000.0) bad = true;  // durations are packed into 15 bits by K8c
+        if (v[3][k] >= 32000.0) bad = true;  // durations are packed into 15 bits by K8c
     }
     if (bad) atomicMax(flag, 1);
 }
@@ -1258,8 +1365,8 @@ namespace {
 // The auxiliary stream the sliced unit path renders on, and its fork/join events (created once, never destroyed:
 // they live as long as the library).  Calls from several host threads share them; every use is ordered by events.
 constexpr int kMaxSlices = 32;
-hipStream_t g_aux = nullptr;
-hipEvent_t g_aux_ev[kMaxSlices], g_aux_done;
+hipStream_t g_aux = nullptr, g_aux2 = nullptr;  // g_aux2: the renderer that is NOT taken when both are enqueued (UnitArgs::sel)
+hipEvent_t g_aux_ev[kMaxSlices], g_aux_done, g_aux2_done;
 std::mutex g_aux_mu;
 std::mutex g_aux_init_mu;
 int aux_stream_init() {
@@ -1267,8 +1374,10 @@ int aux_stream_init() {
     if (g_aux) return MXG_OK;
     hipStream_t a = nullptr;
     MXG_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    MXG_HIP(hipStreamCreateWithFlags(&g_aux2, hipStreamNonBlocking));
     for (int i = 0; i < kMaxSlices; i++) MXG_HIP(hipEventCreateWithFlags(&g_aux_ev[i], hipEventDisableTiming));
     MXG_HIP(hipEventCreateWithFlags(&g_aux_done, hipEventDisableTiming));
+    MXG_HIP(hipEventCreateWithFlags(&g_aux2_done, hipEventDisableTiming));
     g_aux = a;
     return MXG_OK;
 }
@@ -1320,10 +1429,13 @@ int mxg_grain_plan_window(const mxg_grain_plan *p, double *h_window) {
     return (int)p->sampleDur;
 }
 
-// forwards a render's error word (0 = fine) to the library's async error word (mxg_common.h)
-__global__ void grain_err_publish_kernel(const int *err, int *async_word) {
-    const int e = *err;
+// forwards a render's error word (0 = fine) to the library's async error word (mxg_common.h) and leaves both words of the
+// stream (error | K8c eligibility) at zero for the next call: the last kernel of a call, so a call starts without a memset
+__global__ void grain_err_publish_kernel(int *err, int *async_word) {
+    const int e = err[0];
     if (e && async_word) __hip_atomic_store(async_word, (int)mxg::ASYNC_GRAIN_BASE + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    err[0] = 0;
+    err[1] = 0;
 }
 
 static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, size_t T, const double *d_samples,
@@ -1363,9 +1475,11 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
     MXG_REQUIRE(len > 0 && overlaps > 0, "empty sample or overlaps <= 0");
     if (S == 0 || T == 0) return MXG_OK;
     hipStream_t st = resolve_stream(stream);
-    int *g_err = nullptr;  // per-stream error words
-    if (int s = scratch_get(SCR_GRAIN_ERR, st, 2 * sizeof(int), (void **)&g_err)) return s;
-    MXG_HIP(hipMemsetAsync(g_err, 0, sizeof(int), st));
+    int *g_err = nullptr;  // per-stream words: the render's error | K8c eligibility.  Zero between calls: the publish kernel that ends a
+                           // call clears them (the synchronous A/B path: a memset after its read-back), so only a new allocation pays a memset.
+    bool err_fresh = false;
+    if (int s = scratch_get(SCR_GRAIN_ERR, st, 2 * sizeof(int), (void **)&g_err, &err_fresh)) return s;
+    if (err_fresh) MXG_HIP(hipMemsetAsync(g_err, 0, 2 * sizeof(int), st));
     GrainArgs A;
     A.S = S; A.T = T; A.len = len; A.R = R;
     A.amp = d_samples; A.window = p->d_window; A.a = d_a; A.b = d_b; A.posMod = d_posmod;
@@ -1398,23 +1512,40 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         bool both = false;
         const bool line_ok = tune_get("grain_line") && T < (size_t)1 << 30 && len >= 128 && len < ((size_t)1 << 31) - 128 &&
                              p->sampleDur < 32768;
+        // the prologue kernel also decides K8c's eligibility on the device (g_err[1]) when the static conditions hold
+        bool check = false;
         if ((mode == 0 || mode == 2) && tune_get("grain_unit") && T < (size_t)1 << 30 && len >= 128 && len < ((size_t)1 << 31) - 128 &&
             p->sampleDur < 32000) {
             const double frequency = (1.0 / p->grainLength) * 1.0;
             const double inc = (double)A.sampleDur / (A.sr / frequency);
-            if (inc == 1.0) {
-                MXG_HIP(hipMemsetAsync(g_err + 1, 0, sizeof(int), st));
-                hipLaunchKernelGGL(granular_unit_check_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, S,
-                                   (const double *)d_gst, (double)len, A.sampleDur, g_err + 1);
-                if (line_ok && !tune_get("grain_sync")) {
-                    both = true;
-                    unit = true;
-                } else {
-                    int bad = 1;
-                    MXG_HIP(hipMemcpyAsync(&bad, g_err + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-                    MXG_HIP(hipStreamSynchronize(st));
-                    unit = bad == 0;
-                }
+            check = inc == 1.0;
+        }
+        // scratch (per stream): spawn lists + chunk table + copy of the carried-in grains, sized for 64-sample tiles (the finest
+        // chunking) so that it can be taken before the path is known
+        const double minCycle = A.cycleLength;  // randomOffset >= 0 only lengthens a cycle
+        const size_t G = (size_t)((double)T / (minCycle > 1.0 ? floor(minCycle) : 1.0)) + 2;
+        const size_t nd = 2 * G * S + 4 * kSlots * S;                 // doubles: spawn_pos | spawn_inc | gst copy
+        const size_t ni = G * S + ((T + 63) / 64 + 1) * S + 3 * S;    // int32: spawn_n | chunk_first | slice carry | progress (streamed form)
+        const size_t bytes = nd * sizeof(double) + ni * sizeof(int32_t);
+        void *g_sched_scratch = nullptr;
+        if (int s = scratch_get(SCR_GRAIN_SCHED, st, bytes, &g_sched_scratch)) return s;
+        double *spawn_pos = (double *)g_sched_scratch;
+        double *spawn_inc = spawn_pos + G * S;
+        double *gst_copy = spawn_inc + G * S;
+        int32_t *spawn_n = (int32_t *)(gst_copy + 4 * kSlots * S);
+        int32_t *chunk_first = spawn_n + G * S;
+        int32_t *prog = chunk_first + ((T + 63) / 64 + 1) * S + 2 * S;
+        hipLaunchKernelGGL(granular_prologue_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, S, (const double *)d_gst,
+                           gst_copy, (double)len, A.sampleDur, check ? 1 : 0, g_err + 1, prog);
+        if (check) {
+            if (line_ok && !tune_get("grain_sync")) {
+                both = true;
+                unit = true;
+            } else {
+                int bad = 1;
+                MXG_HIP(hipMemcpyAsync(&bad, g_err + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+                MXG_HIP(hipStreamSynchronize(st));
+                unit = bad == 0;
             }
         }
         size_t C = (T + 255) / 256;
@@ -1428,19 +1559,6 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         const bool line = !unit && line_ok;
         if (unit || line) Tc = 64;  // K8c / K8d tiles are 64 samples; the chunk table is indexed per tile
         C = (T + Tc - 1) / Tc;
-        const double minCycle = A.cycleLength;  // randomOffset >= 0 only lengthens a cycle
-        const size_t G = (size_t)((double)T / (minCycle > 1.0 ? floor(minCycle) : 1.0)) + 2;
-        const size_t nd = 2 * G * S + 4 * kSlots * S;         // doubles: spawn_pos | spawn_inc | gst copy
-        const size_t ni = G * S + (C + 1) * S + 2 * S;        // int32: spawn_n | chunk_first | slice carry
-        const size_t bytes = nd * sizeof(double) + ni * sizeof(int32_t);
-        void *g_sched_scratch = nullptr;  // per-stream: spawn lists + chunk table + copy of the carried-in grains
-        if (int s = scratch_get(SCR_GRAIN_SCHED, st, bytes, &g_sched_scratch)) return s;
-        double *spawn_pos = (double *)g_sched_scratch;
-        double *spawn_inc = spawn_pos + G * S;
-        double *gst_copy = spawn_inc + G * S;
-        int32_t *spawn_n = (int32_t *)(gst_copy + 4 * kSlots * S);
-        int32_t *chunk_first = spawn_n + G * S;
-        MXG_HIP(hipMemcpyAsync(gst_copy, d_gst, sizeof(double) * 4 * kSlots * S, hipMemcpyDeviceToDevice, st));
         SchedArgs Q;
         Q.S = S; Q.T = T; Q.len = len; Q.R = R; Q.G = G; Q.Tc = Tc; Q.C = C;
         Q.a = d_a; Q.b = d_b; Q.posMod = d_posmod; Q.rnd = d_rnd; Q.st = d_st;
@@ -1470,7 +1588,9 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         // spawn list and the chunk table are the same arrays a single launch fills, so the bits do not change.
         // Slice i is twice as long as slice i-1 (weights 1, 2, 4, ...): scheduling a slice takes about half as long as
         // rendering it, so slice i+1 is scheduled in the time slice i renders and only the short first one is exposed.
-        int slices = tune_get("grain_slices");
+        const size_t nsched = (S + 63) / 64;
+        const bool streamed = unit && tune_get("grain_streamed") && nsched + stiles * C < ((size_t)1 << 31);
+        int slices = streamed ? 1 : tune_get("grain_slices");
         while (slices > 1 && C / ((size_t(1) << slices) - 1) < 16) slices--;  // first slice >= 16 tiles (1024 samples)
         const size_t wsum = (size_t(1) << slices) - 1;
         auto slice_start = [&](int i) { return i >= slices ? C : C * ((size_t(1) << i) - 1) / wsum; };
@@ -1479,7 +1599,34 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         lt = lt < 1 ? 1 : (lt > kLineTiles ? kLineTiles : lt);
         U.ltiles = (unsigned)lt;
         U.cend = (unsigned)C;
-        if ((unit || line) && slices > 1) {  // the tile renders: any mode
+        if (streamed) {
+            // K8c, one launch: scheduler lanes and tile renders side by side (granular_unit_kernel<SMODE>), on the caller's stream
+            U.want = 0;
+            U.c0 = 0;
+            U.cend = (unsigned)C;
+            {
+                KernelTimer kt("granular_unit_kernel", st);
+                const dim3 g((unsigned)(nsched + stiles * C));
+                if (mode == 0) {
+                    hipLaunchKernelGGL((granular_unit_kernel<0>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched);
+                } else {
+                    hipLaunchKernelGGL((granular_unit_kernel<2>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched);
+                }
+            }
+            if (both) {  // the carried-in grains may send the call to K8d (UnitArgs::sel): it then renders after the lists are complete
+                U.want = 1;
+                {
+                    KernelTimer kt("granular_line_kernel", st);
+                    hipLaunchKernelGGL(granular_line_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)((C + lt - 1) / lt)), dim3(256), 0, st, U);
+                }
+                hipLaunchKernelGGL(granular_line_state_kernel, grid, dim3(64), 0, st, U);
+            }
+            if (U.pan) {
+                hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((T * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, stiles,
+                                   T * 2, U.mixpart, d_mix);
+                mixed = true;
+            }
+        } else if ((unit || line) && slices > 1) {  // the tile renders: any mode
             if (int e = aux_stream_init()) return e;
             // one caller at a time enqueues its fork/join: a wait captures the event's latest record, so another
             // thread re-recording the shared events between a record and its wait would tie the render to the wrong slice
@@ -1504,25 +1651,29 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
                     }
                 }
                 MXG_HIP(hipEventRecord(g_aux_ev[i], st));
-                MXG_HIP(hipStreamWaitEvent(g_aux, g_aux_ev[i], 0));
+                // With both renderers enqueued, the one that returns at once (UnitArgs::sel) still costs its dispatch (4-5 us a
+                // slice): it gets a stream of its own instead of a place in the chain of the one that renders.
+                hipStream_t su = g_aux, sl = both ? g_aux2 : g_aux;
                 U.c0 = (unsigned)ci;
                 if (unit) {
+                    MXG_HIP(hipStreamWaitEvent(su, g_aux_ev[i], 0));
                     U.want = 0;
                     U.cend = (unsigned)C;
-                    KernelTimer kt("granular_unit_kernel", g_aux);
-                    hipLaunchKernelGGL(granular_unit_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)(cn - ci)), dim3(256), 0,
-                                       g_aux, U);
+                    KernelTimer kt("granular_unit_kernel", su);
+                    hipLaunchKernelGGL((granular_unit_kernel<-1>), dim3((unsigned)((S + 63) / 64), (unsigned)(cn - ci)), dim3(256), 0,
+                                       su, U, Q, (int *)nullptr, 0u);
                 }
                 if (!unit || both) {
+                    MXG_HIP(hipStreamWaitEvent(sl, g_aux_ev[i], 0));
                     U.want = 1;
                     U.cend = (unsigned)cn;
-                    KernelTimer kt("granular_line_kernel", g_aux);
+                    KernelTimer kt("granular_line_kernel", sl);
                     hipLaunchKernelGGL(granular_line_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)((cn - ci + lt - 1) / lt)),
-                                       dim3(256), 0, g_aux, U);
+                                       dim3(256), 0, sl, U);
                 }
             }
-            MXG_HIP(hipEventRecord(g_aux_done, g_aux));
-            MXG_HIP(hipStreamWaitEvent(st, g_aux_done, 0));
+            // the grains alive after the call follow from the scheduler's lists alone (closed forms / the exact multi-step
+            // advance), and the renders read the COPY of the carried-in grains: the state kernels run beside the last slice's render
             if (unit) {
                 U.want = 0;
                 hipLaunchKernelGGL(granular_unit_state_kernel, grid, dim3(64), 0, st, U);
@@ -1530,6 +1681,12 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
             if (!unit || both) {
                 U.want = 1;
                 hipLaunchKernelGGL(granular_line_state_kernel, grid, dim3(64), 0, st, U);
+            }
+            MXG_HIP(hipEventRecord(g_aux_done, g_aux));
+            MXG_HIP(hipStreamWaitEvent(st, g_aux_done, 0));
+            if (both) {
+                MXG_HIP(hipEventRecord(g_aux2_done, g_aux2));
+                MXG_HIP(hipStreamWaitEvent(st, g_aux2_done, 0));
             }
             if (U.pan) {
                 hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((T * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, stiles,
@@ -1550,7 +1707,8 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
             U.want = 0;
             {
                 KernelTimer kt("granular_unit_kernel", st);
-                hipLaunchKernelGGL(granular_unit_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)C), dim3(256), 0, st, U);
+                hipLaunchKernelGGL((granular_unit_kernel<-1>), dim3((unsigned)((S + 63) / 64), (unsigned)C), dim3(256), 0, st, U, Q,
+                                   (int *)nullptr, 0u);
             }
             hipLaunchKernelGGL(granular_unit_state_kernel, grid, dim3(64), 0, st, U);
             if (both) {
@@ -1599,11 +1757,12 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         // deferred: the render's error word (1..5, below) is forwarded to the library's async error word by a one-lane kernel at
         // the end of the stream's work; the next call of any entry point -- or the caller's next synchronising call -- returns
         // it (mxg_last_async_error, include/maxigpu.h).  Nothing here blocks the host, and the whole sequence can be captured.
-        hipLaunchKernelGGL(grain_err_publish_kernel, dim3(1), dim3(1), 0, st, (const int *)g_err, async_error_word());
+        hipLaunchKernelGGL(grain_err_publish_kernel, dim3(1), dim3(1), 0, st, g_err, async_error_word());
         return check_hip(hipGetLastError(), "mxg_granular_render launch");
     }
     int herr = 0;
     MXG_HIP(hipMemcpyAsync(&herr, g_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    MXG_HIP(hipMemsetAsync(g_err, 0, 2 * sizeof(int), st));  // (the words are zero between calls)
     MXG_HIP(hipStreamSynchronize(st));
     if (herr) return async_error_status(ASYNC_GRAIN_BASE + herr);
     return MXG_OK;

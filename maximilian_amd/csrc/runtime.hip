@@ -61,6 +61,7 @@ Tune g_tune[] = {
     {"grain_unit", 1, 0, 1},  // K8c: coalesced closed-form render when every grain has inc = +-1
     {"grain_fast_sched", 1, 0, 1},  // K8a: event-driven exact multi-step scheduler (0: one step at a time)
     {"grain_sync", 0, 0, 1},  // 1: mxg_granular_render reads its error word back before it returns (the round-1/2 behaviour); 0: deferred
+    {"grain_streamed", 1, 0, 1},  // K8c: scheduler lanes and tile renders in ONE launch (0: time slices on the auxiliary streams, grain_slices)
     {"grain_slices", 4, 1, 16},  // K8a/K8c: time slices of a maxiTimeStretch call (scheduling of slice i+1 overlaps render of slice i)
     {"mfcc_mfma_fullk", 0, 0, 1},  // K7b: contract over all numBins bins (1) instead of the bins that carry weight
     {"fused_layout", 0, 0, 2},   // K67: 0 automatic; 1 two frames in flight, two 4-wave workgroups per CU; 2 one frame in flight, one 12-wave workgroup per CU
@@ -119,9 +120,10 @@ struct ScratchBuf {
 std::map<std::pair<int, hipStream_t>, ScratchBuf> g_scratch;
 }  // namespace
 
-int scratch_get(ScratchSlot slot, hipStream_t st, size_t bytes, void **out) {
+int scratch_get(ScratchSlot slot, hipStream_t st, size_t bytes, void **out, bool *fresh) {
     std::lock_guard<std::mutex> lk(g_mu);
     ScratchBuf &b = g_scratch[std::make_pair((int)slot, st)];
+    if (fresh) *fresh = b.cap < bytes || !b.ptr;
     if (b.cap < bytes || !b.ptr) {
         if (b.ptr) MXG_HIP(hipFree(b.ptr));  // hipFree waits for the work that may still use the old buffer
         b.ptr = nullptr;
@@ -163,6 +165,10 @@ int async_error_status(int code) {
             return fail(MXG_ERR_INVALID,
                         "mxg_granular_render: a grain was born with a NaN/Inf step or one longer than the sample (|speed| too "
                         "large for this sample length); its reads would leave the buffer");
+        case 6:
+            return fail(MXG_ERR_HIP,
+                        "mxg_granular_render: a tile render saw no scheduler progress for its whole polling budget (streamed form); "
+                        "that tile was rendered as silence");
         default: break;
     }
     return fail(MXG_ERR_HIP, "asynchronous device error %d", code);

@@ -242,11 +242,16 @@ def test_pitch_shift_event_driven_long_run(mx, port):
     assert_bits_equal(bank.grains.numpy(), gst, "grains")
 
 
-@pytest.mark.parametrize("knob,value", [(b"grain_unit", 0), (b"grain_line", 0), (b"grain_lanes_k", 16), (b"grain_lanes_k", 4096),
-                                        (b"grain_slices", 1), (b"grain_slices", 2), (b"grain_slices", 16)])
-def test_granular_launch_knobs_same_bits(mx, knob, value):
-    """The coalesced unit-increment render vs the general (stream, chunk) render, and the chunking granularity of
-    the latter: same output, scheduler state and live grains."""
+@pytest.mark.parametrize("knobs", [{b"grain_unit": 0}, {b"grain_line": 0}, {b"grain_lanes_k": 16}, {b"grain_lanes_k": 4096},
+                                   {b"grain_streamed": 0}, {b"grain_streamed": 0, b"grain_slices": 1},
+                                   {b"grain_streamed": 0, b"grain_slices": 2}, {b"grain_streamed": 0, b"grain_slices": 16},
+                                   {b"grain_streamed": 1, b"grain_fast_sched": 0}],
+                         ids=lambda k: ",".join("%s=%d" % (a.decode(), b) for a, b in k.items()))
+def test_granular_launch_knobs_same_bits(mx, knobs):
+    """The coalesced unit-increment render vs the general (stream, chunk) render, the chunking granularity of the latter, the
+    unit path as ONE launch (scheduler lanes beside the tile renders, the default) vs time slices on the auxiliary streams, and
+    the one-launch form with the sample-by-sample scheduler (rows published at tile boundaries): same output, scheduler state
+    and live grains."""
     L = mx.lib()
     rng = np.random.default_rng(9)
     Ls, S, T = 50000, 100, 5000
@@ -259,13 +264,45 @@ def test_granular_launch_knobs_same_bits(mx, knob, value):
         o = bank.play(speed, 0.05, 4, T).numpy() if mode == 0 else bank.play(speed, np.abs(speed) + 0.1, 0.05, 4, T).numpy()
         return o, bank.state.numpy(), bank.grains.numpy()
     ref = run(0) + run(1)
-    prev = L.mxg_tune(knob, value)
+    prev = {k: L.mxg_tune(k, v) for k, v in knobs.items()}
     try:
         got = run(0) + run(1)
     finally:
-        L.mxg_tune(knob, prev)
+        for k, v in prev.items():
+            L.mxg_tune(k, v)
     for r, g in zip(ref, got):
-        assert_bits_equal(g, r, "%s=%d" % (knob.decode(), value))
+        assert_bits_equal(g, r, str(knobs))
+
+
+def test_granular_streamed_renders_wait_for_slow_schedulers(mx, port):
+    """The one-launch unit path with streams whose scheduler walks sample by sample (negative speeds) next to event-driven ones,
+    over enough tiles that renders are dispatched long before their rows exist: they wait on the progress words, and the bits
+    are those of the sliced form and of the oracle."""
+    L = mx.lib()
+    rng = np.random.default_rng(77)
+    Ls, S, T = 30000, 200, 64 * 600 + 17
+    smp = rng.uniform(-1, 1, Ls)
+    speed = rng.uniform(0.2, 2.0, S) * np.where(np.arange(S) % 7 == 3, -1.0, 1.0)
+    pos0 = rng.uniform(0, 1, S)
+
+    def run():
+        bank = make_bank(mx, 0, "hann", smp, S)
+        bank.setPosition(pos0)
+        st0 = bank.state.numpy()
+        o = bank.play(speed, 0.05, 4, T).numpy()
+        return o, bank.state.numpy(), bank.grains.numpy(), st0
+    got = run()
+    prev = L.mxg_tune(b"grain_streamed", 0)
+    try:
+        ref = run()
+    finally:
+        L.mxg_tune(b"grain_streamed", prev)
+    for g, r, what in zip(got[:3], ref[:3], ("output", "state", "grains")):
+        assert_bits_equal(g, r, what)
+    sel = np.arange(0, S, 13)
+    e, est, egst, rc = port.granular(0, 0, smp, T, speed[sel], grainLength=0.05, overlaps=4, st=got[3][:, sel])
+    assert rc == 0
+    assert_bits_equal(got[0][:, sel], e, "oracle")
 
 
 @pytest.mark.parametrize("unit", [1, 0])
