@@ -8,8 +8,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-run() {  # name, trace-steps, pmc-steps, bench args...
+run() {  # name, trace-steps, pmc-steps, bench args...   (ONLY="config5 config4": just those workloads)
   name=$1; ts=$2; ps=$3; shift 3
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $name "; then return; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name/kt -o b -- \
       python $R/bench.py --no-cpu-baseline --kernel-events off --steps $ts --warmup 3 "$@" > $OUT/$name.kt.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/$name/pmc_w -o b -- \
@@ -30,6 +31,7 @@ run config4_mfma 6 3 --workload config4 --mfcc-method mfma
 run config4_gemm 6 3 --workload config4 --mfcc-method mfma-gemm --mfma-fullk
 run config5 6 3 --workload config5
 # the matrix pipe of the fused kernel (default form = the matrix form) and the chip clock while it runs
+if [ -z "$ONLY" ]; then
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/config4_mfma/pmc_mfma -o b -- \
     python $R/bench.py --no-cpu-baseline --kernel-events off --steps 3 --warmup 2 --workload config4 --mfcc-method mfma > $OUT/config4_mfma.mfma.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/config4_mfma/pmc_clk -o b -- \
@@ -37,6 +39,7 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/config4_mfma/pmc_clk
 # fp64 flops of the per-sample-modulated voice
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU --output-format csv -d $OUT/config3_modB/pmc_f64 -o b -- \
     python $R/bench.py --no-cpu-baseline --kernel-events off --steps 16 --warmup 2 --workload config3 --voice-mode 1 > $OUT/config3_modB.f64.log 2>&1
+fi
 # keep what travels back small: the counter CSVs of torch's start-up kernels are not needed
 find $OUT -name "*agent_info.csv" -delete; find $OUT -name "*.db" -delete; du -sh $OUT
 cd $R

@@ -35,6 +35,10 @@ def read(path):
 
 
 traffic = {}
+try:  # a partial re-run (ONLY=... tools/profile_r05.sh) refreshes its own keys and keeps the others
+    traffic = json.load(open(os.path.join(dst, "pmc_traffic.json")))
+except Exception:
+    traffic = {}
 for wl in sorted(d for d in os.listdir(src) if os.path.isdir(os.path.join(src, d))):
     base = os.path.join(src, wl)
     kt = read(os.path.join(base, "kt", "b_kernel_trace.csv"))
