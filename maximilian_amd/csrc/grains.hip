@@ -688,7 +688,7 @@ __global__ __launch_bounds__(64) void granular_unit_state_kernel(UnitArgs A) {
 
 // SMODE < 0: the tile renderer alone (grid = stream tiles x tiles of the slice; the lists are complete when it starts).
 // SMODE = 0 / 2 (maxiTimeStretch::play / playAtPosition), the STREAMED form: one launch for the whole call, 1-D grid.  The first
-// `nsched` workgroups are the scheduler (their wavefront 0: one lane per stream, sched_walk<SMODE, true>, then the grains alive
+// `nsched` workgroups are the scheduler (one lane per stream, 256 streams a workgroup: sched_walk<SMODE, true>, then the grains alive
 // after the call); every other workgroup renders one tile, tiles in dispatch order, and starts by waiting until the 64 streams of
 // its tile have published the two chunk-table rows it reads (Q.prog).  Workgroups are dispatched in index order, so the scheduler
 // wavefronts are resident before the first renderer polls; the scheduler needs about half the time the renders need (0.41 us
@@ -703,8 +703,7 @@ __global__ __launch_bounds__(256, 4) void granular_unit_kernel(UnitArgs A, Sched
     unsigned bx = blockIdx.x, by = blockIdx.y;
     if constexpr (COH) {
         if (blockIdx.x < nsched) {
-            if (threadIdx.x >= 64) return;
-            const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+            const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
             if (s >= A.S) return;
             __builtin_amdgcn_s_setprio(3);
             sched_walk<(SMODE >= 0 ? SMODE : 0), true>(Q, s, prog);
@@ -1038,11 +1037,80 @@ __device__ __forceinline__ double grain_advance_fast(double pos, const double in
     return pos;
 }
 
+// grains alive after sample T-1, creation order (one lane per stream): positions by the exact multi-step advance
+template <bool COH>
+__device__ __forceinline__ void line_state_lane(const UnitArgs &A, const size_t s) {
+    const size_t S = A.S;
+    const double dlen = (double)A.len;
+    const long long T = (long long)A.T;
+    double gp[kSlots], gi[kSlots], gx[kSlots], gd[kSlots];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) { gp[k] = gi[k] = gx[k] = gd[k] = 0.0; }
+    auto push = [&](double p, double i, double x, double d) {
+#pragma unroll
+        for (int k = 0; k < kSlots; k++)
+            if (k == cnt) { gp[k] = p; gi[k] = i; gx[k] = x; gd[k] = d; }
+        cnt++;
+    };
+    for (int k = 0; k < kSlots; k++) {
+        const double ddur = A.gst_in[(3 * kSlots + k) * S + s];
+        if (ddur == 0.0) continue;
+        const double pos = A.gst_in[(0 * kSlots + k) * S + s], inc = A.gst_in[(1 * kSlots + k) * S + s];
+        const double didx = A.gst_in[(2 * kSlots + k) * S + s];
+        if (!carried_grain_ok(pos, inc, didx, ddur, dlen, A.sampleDur)) continue;
+        const long long idx0 = (long long)didx;
+        if (idx0 + T >= (long long)A.sampleDur) continue;
+        if (cnt < kSlots) push(grain_advance_fast(pos, inc, dlen, (int)T), inc, (double)(idx0 + T), ddur);
+    }
+    const int count = ld_list<COH>(A.chunk_first + A.C * S + s);
+    int j0 = count;
+    while (j0 > 0 && (long long)ld_list<COH>(A.spawn_n + (size_t)(j0 - 1) * S + s) + A.sampleDur > T) j0--;
+    for (int j = j0; j < count; j++) {
+        const long long born = ld_list<COH>(A.spawn_n + (size_t)j * S + s);
+        const double inc = ld_list<COH>(A.spawn_inc + (size_t)j * S + s);
+        const long long steps = T - born;
+        if (cnt < kSlots)
+            push(grain_advance_fast(ld_list<COH>(A.spawn_pos + (size_t)j * S + s), inc, dlen, (int)steps), inc, (double)steps, (double)A.sampleDur);
+    }
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) {
+        A.gst_out[(0 * kSlots + k) * S + s] = gp[k];
+        A.gst_out[(1 * kSlots + k) * S + s] = gi[k];
+        A.gst_out[(2 * kSlots + k) * S + s] = gx[k];
+        A.gst_out[(3 * kSlots + k) * S + s] = gd[k];
+    }
+}
+__global__ __launch_bounds__(64) void granular_line_state_kernel(UnitArgs A) {
+    if (unit_args_skip(A)) return;
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.S) return;
+    line_state_lane<false>(A, s);
+}
+
 constexpr int kLineTiles = 4;  // consecutive tiles per workgroup: the anchors are carried from tile to tile
 
 constexpr int kLineBatch = 4;  // pairs whose gathers are in flight together (4 / 8 / 16 measured: 0.54 / 0.60 / 0.87 ms per slice)
 
-__global__ __launch_bounds__(256) void granular_line_kernel(UnitArgs A) {
+// SMODE as for granular_unit_kernel: < 0 the renderer alone, 0 .. 3 the streamed form of that scheduler mode (1-D grid: `nsched`
+// scheduler workgroups, then one workgroup per (stream tile, span of ltiles tiles), spans in dispatch order).
+template <int SMODE>
+__global__ __launch_bounds__(256, 3) void granular_line_kernel(UnitArgs A, SchedArgs Q, int *prog, unsigned nsched) {
+    constexpr bool COH = SMODE >= 0;
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if constexpr (COH) {
+        if (blockIdx.x < nsched) {
+            const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+            if (s >= A.S) return;
+            __builtin_amdgcn_s_setprio(3);
+            sched_walk<(SMODE >= 0 ? SMODE : 0), true>(Q, s, prog);
+            if (!unit_args_skip(A)) line_state_lane<true>(A, s);
+            return;
+        }
+        const unsigned idx = blockIdx.x - nsched, stiles = (unsigned)((A.S + 63) / 64);
+        bx = idx % stiles;
+        by = idx / stiles;
+    }
     if (unit_args_skip(A)) return;
     __shared__ double s_tile[64 * 65];
     __shared__ LineCand s_cand[64 * kCand];
@@ -1050,14 +1118,34 @@ __global__ __launch_bounds__(256) void granular_line_kernel(UnitArgs A) {
     // (the wave index in a scalar register: the walk over (stream, candidate) pairs below is scalar control flow only then)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t S = A.S;
-    const size_t s0 = (size_t)blockIdx.x * 64;
-    const size_t cA = (size_t)blockIdx.y * A.ltiles + A.c0;
+    const size_t s0 = (size_t)bx * 64;
+    const size_t cA = (size_t)by * A.ltiles + A.c0;
     const size_t cB = cA + A.ltiles < A.cend ? cA + A.ltiles : A.cend;
     const size_t nA = cA * 64;  // first sample of the span
     const double dlen = (double)A.len;
     auto inc_of = [&](const int src, const size_t s) {
-        return src >= 0 ? A.spawn_inc[(size_t)src * S + s] : A.gst_in[(1 * kSlots + (size_t)(-src - 1)) * S + s];
+        return src >= 0 ? ld_list<COH>(A.spawn_inc + (size_t)src * S + s) : A.gst_in[(1 * kSlots + (size_t)(-src - 1)) * S + s];
     };
+    bool listed = true;  // the rows and spawns this span reads exist
+    if constexpr (COH) {
+        if (threadIdx.x < 64) {
+            const size_t s = s0 + threadIdx.x;
+            const int need = (int)cB + 1;  // rows cA .. cB
+            int spins = 0, seen = -1;
+            for (;;) {
+                const int have = s < S ? __hip_atomic_load(prog + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+                if (__all(have >= need)) break;
+                if (__any(have != seen)) spins = 0;  // some stream moved: the count is of polls WITHOUT progress
+                seen = have;
+                if (++spins > kStreamSpin) {
+                    listed = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            if (!listed && threadIdx.x == 0) atomicMax(A.err, 6);
+        }
+    }
     auto set_age = [&](LineCand &q, const long long kb) {  // age at the current tile's first sample (< 0: not born yet)
         q.kb = (short)(kb < -32768 ? -32768 : kb);
         q.negoff = (unsigned char)(kb >= 0 ? 0 : (kb < -64 ? 64 : -kb));
@@ -1066,7 +1154,7 @@ __global__ __launch_bounds__(256) void granular_line_kernel(UnitArgs A) {
     if (threadIdx.x < 64) {
         const size_t s = s0 + threadIdx.x;
         int cnt = 0;
-        if (s < S) {
+        if (s < S && listed) {
             // a grain born at sample `born`; its reference position `pos` is the one it has at age `age`
             auto add = [&](long long born, long long age, double pos, int src) {
                 LineCand &q = s_cand[threadIdx.x * kCand + cnt];
@@ -1093,15 +1181,15 @@ __global__ __launch_bounds__(256) void granular_line_kernel(UnitArgs A) {
                     add(-idx0, idx0, pos, -(k + 1));
                 }
             }
-            const int first = A.chunk_first[cA * S + s], next = A.chunk_first[cB * S + s];
+            const int first = ld_list<COH>(A.chunk_first + cA * S + s), next = ld_list<COH>(A.chunk_first + cB * S + s);
             int bornB[kSlots];
             double posB[kSlots];
 #pragma unroll
             for (int u = 0; u < kSlots; u++) {  // independent loads (a walk-back loop would chain them), filtered afterwards
                 const int j = first - kSlots + u;
                 const int jc = j < 0 ? 0 : j;
-                bornB[u] = A.spawn_n[(size_t)jc * S + s];
-                posB[u] = A.spawn_pos[(size_t)jc * S + s];
+                bornB[u] = ld_list<COH>(A.spawn_n + (size_t)jc * S + s);
+                posB[u] = ld_list<COH>(A.spawn_pos + (size_t)jc * S + s);
             }
 #pragma unroll
             for (int u = 0; u < kSlots; u++) {
@@ -1111,14 +1199,14 @@ __global__ __launch_bounds__(256) void granular_line_kernel(UnitArgs A) {
                     add(bornB[u], 0, posB[u], j);
                 }
             }
-            if (first > kSlots && (long long)A.spawn_n[(size_t)(first - kSlots - 1) * S + s] + A.sampleDur > (long long)nA)
+            if (first > kSlots && (long long)ld_list<COH>(A.spawn_n + (size_t)(first - kSlots - 1) * S + s) + A.sampleDur > (long long)nA)
                 atomicMax(A.err, 1);  // more than kSlots earlier spawns alive: the capacity rule of every kernel
             for (int j = first; j < next; j++) {
                 if (cnt >= kCand) {
                     atomicMax(A.err, 1);
                     break;
                 }
-                add(A.spawn_n[(size_t)j * S + s], 0, A.spawn_pos[(size_t)j * S + s], j);
+                add(ld_list<COH>(A.spawn_n + (size_t)j * S + s), 0, ld_list<COH>(A.spawn_pos + (size_t)j * S + s), j);
             }
         }
         s_cnt[threadIdx.x] = cnt;
@@ -1272,55 +1360,8 @@ __global__ __launch_bounds__(256) void granular_line_kernel(UnitArgs A) {
         }
         flush();
         __syncthreads();
-        tile_epilogue(A, s_tile, s0, n0, lane, wave, blockIdx.x);
+        tile_epilogue(A, s_tile, s0, n0, lane, wave, bx);
         __syncthreads();  // the tile and the candidate list are reused by the next tile of the span
-    }
-}
-
-// grains alive after sample T-1, creation order (one lane per stream): positions by the exact multi-step advance
-__global__ __launch_bounds__(64) void granular_line_state_kernel(UnitArgs A) {
-    if (unit_args_skip(A)) return;
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t S = A.S;
-    if (s >= S) return;
-    const double dlen = (double)A.len;
-    const long long T = (long long)A.T;
-    double gp[kSlots], gi[kSlots], gx[kSlots], gd[kSlots];
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < kSlots; k++) { gp[k] = gi[k] = gx[k] = gd[k] = 0.0; }
-    auto push = [&](double p, double i, double x, double d) {
-#pragma unroll
-        for (int k = 0; k < kSlots; k++)
-            if (k == cnt) { gp[k] = p; gi[k] = i; gx[k] = x; gd[k] = d; }
-        cnt++;
-    };
-    for (int k = 0; k < kSlots; k++) {
-        const double ddur = A.gst_in[(3 * kSlots + k) * S + s];
-        if (ddur == 0.0) continue;
-        const double pos = A.gst_in[(0 * kSlots + k) * S + s], inc = A.gst_in[(1 * kSlots + k) * S + s];
-        const double didx = A.gst_in[(2 * kSlots + k) * S + s];
-        if (!carried_grain_ok(pos, inc, didx, ddur, dlen, A.sampleDur)) continue;
-        const long long idx0 = (long long)didx;
-        if (idx0 + T >= (long long)A.sampleDur) continue;
-        if (cnt < kSlots) push(grain_advance_fast(pos, inc, dlen, (int)T), inc, (double)(idx0 + T), ddur);
-    }
-    const int count = A.chunk_first[A.C * S + s];
-    int j0 = count;
-    while (j0 > 0 && (long long)A.spawn_n[(size_t)(j0 - 1) * S + s] + A.sampleDur > T) j0--;
-    for (int j = j0; j < count; j++) {
-        const long long born = A.spawn_n[(size_t)j * S + s];
-        const double inc = A.spawn_inc[(size_t)j * S + s];
-        const long long steps = T - born;
-        if (cnt < kSlots)
-            push(grain_advance_fast(A.spawn_pos[(size_t)j * S + s], inc, dlen, (int)steps), inc, (double)steps, (double)A.sampleDur);
-    }
-#pragma unroll
-    for (int k = 0; k < kSlots; k++) {
-        A.gst_out[(0 * kSlots + k) * S + s] = gp[k];
-        A.gst_out[(1 * kSlots + k) * S + s] = gi[k];
-        A.gst_out[(2 * kSlots + k) * S + s] = gx[k];
-        A.gst_out[(3 * kSlots + k) * S + s] = gd[k];
     }
 }
 
@@ -1588,8 +1629,8 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         // spawn list and the chunk table are the same arrays a single launch fills, so the bits do not change.
         // Slice i is twice as long as slice i-1 (weights 1, 2, 4, ...): scheduling a slice takes about half as long as
         // rendering it, so slice i+1 is scheduled in the time slice i renders and only the short first one is exposed.
-        const size_t nsched = (S + 63) / 64;
-        const bool streamed = unit && tune_get("grain_streamed") && nsched + stiles * C < ((size_t)1 << 31);
+        const size_t nsched = (S + 255) / 256;  // scheduler workgroups of the streamed form (256 lanes = 256 streams each)
+        const bool streamed = (unit || line) && tune_get("grain_streamed") && nsched + stiles * C < ((size_t)1 << 31);
         int slices = streamed ? 1 : tune_get("grain_slices");
         while (slices > 1 && C / ((size_t(1) << slices) - 1) < 16) slices--;  // first slice >= 16 tiles (1024 samples)
         const size_t wsum = (size_t(1) << slices) - 1;
@@ -1599,7 +1640,7 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         lt = lt < 1 ? 1 : (lt > kLineTiles ? kLineTiles : lt);
         U.ltiles = (unsigned)lt;
         U.cend = (unsigned)C;
-        if (streamed) {
+        if (streamed && unit) {
             // K8c, one launch: scheduler lanes and tile renders side by side (granular_unit_kernel<SMODE>), on the caller's stream
             U.want = 0;
             U.c0 = 0;
@@ -1617,13 +1658,31 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
                 U.want = 1;
                 {
                     KernelTimer kt("granular_line_kernel", st);
-                    hipLaunchKernelGGL(granular_line_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)((C + lt - 1) / lt)), dim3(256), 0, st, U);
+                    hipLaunchKernelGGL((granular_line_kernel<-1>), dim3((unsigned)((S + 63) / 64), (unsigned)((C + lt - 1) / lt)), dim3(256), 0, st, U, Q, (int *)nullptr, 0u);
                 }
                 hipLaunchKernelGGL(granular_line_state_kernel, grid, dim3(64), 0, st, U);
             }
             if (U.pan) {
-                hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((T * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, stiles,
-                                   T * 2, U.mixpart, d_mix);
+                mix_partials_launch(st, stiles, T * 2, U.mixpart, d_mix);
+                mixed = true;
+            }
+        } else if (streamed) {
+            // K8d, one launch (any scheduler mode): granular_line_kernel<mode>
+            U.want = 1;
+            U.c0 = 0;
+            U.cend = (unsigned)C;
+            {
+                KernelTimer kt("granular_line_kernel", st);
+                const dim3 g((unsigned)(nsched + stiles * ((C + lt - 1) / lt)));
+                switch (mode) {
+                    case 0: hipLaunchKernelGGL((granular_line_kernel<0>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched); break;
+                    case 1: hipLaunchKernelGGL((granular_line_kernel<1>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched); break;
+                    case 2: hipLaunchKernelGGL((granular_line_kernel<2>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched); break;
+                    default: hipLaunchKernelGGL((granular_line_kernel<3>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched); break;
+                }
+            }
+            if (U.pan) {
+                mix_partials_launch(st, stiles, T * 2, U.mixpart, d_mix);
                 mixed = true;
             }
         } else if ((unit || line) && slices > 1) {  // the tile renders: any mode
@@ -1668,8 +1727,8 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
                     U.want = 1;
                     U.cend = (unsigned)cn;
                     KernelTimer kt("granular_line_kernel", sl);
-                    hipLaunchKernelGGL(granular_line_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)((cn - ci + lt - 1) / lt)),
-                                       dim3(256), 0, sl, U);
+                    hipLaunchKernelGGL((granular_line_kernel<-1>), dim3((unsigned)((S + 63) / 64), (unsigned)((cn - ci + lt - 1) / lt)),
+                                       dim3(256), 0, sl, U, Q, (int *)nullptr, 0u);
                 }
             }
             // the grains alive after the call follow from the scheduler's lists alone (closed forms / the exact multi-step
@@ -1689,8 +1748,7 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
                 MXG_HIP(hipStreamWaitEvent(st, g_aux2_done, 0));
             }
             if (U.pan) {
-                hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((T * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, stiles,
-                                   T * 2, U.mixpart, d_mix);
+                mix_partials_launch(st, stiles, T * 2, U.mixpart, d_mix);
                 mixed = true;
             }
         } else {
@@ -1715,25 +1773,23 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
                 U.want = 1;
                 {
                     KernelTimer kt("granular_line_kernel", st);
-                    hipLaunchKernelGGL(granular_line_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)((C + lt - 1) / lt)), dim3(256), 0, st, U);
+                    hipLaunchKernelGGL((granular_line_kernel<-1>), dim3((unsigned)((S + 63) / 64), (unsigned)((C + lt - 1) / lt)), dim3(256), 0, st, U, Q, (int *)nullptr, 0u);
                 }
                 hipLaunchKernelGGL(granular_line_state_kernel, grid, dim3(64), 0, st, U);
             }
             if (U.pan) {
-                hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((T * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, stiles,
-                                   T * 2, U.mixpart, d_mix);
+                mix_partials_launch(st, stiles, T * 2, U.mixpart, d_mix);
                 mixed = true;
             }
         } else if (line) {
             U.want = 1;
             {
                 KernelTimer kt("granular_line_kernel", st);
-                hipLaunchKernelGGL(granular_line_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)((C + lt - 1) / lt)), dim3(256), 0, st, U);
+                hipLaunchKernelGGL((granular_line_kernel<-1>), dim3((unsigned)((S + 63) / 64), (unsigned)((C + lt - 1) / lt)), dim3(256), 0, st, U, Q, (int *)nullptr, 0u);
             }
             hipLaunchKernelGGL(granular_line_state_kernel, grid, dim3(64), 0, st, U);
             if (U.pan) {
-                hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((T * 2 + 63) / 64)), dim3(64 * kPartWaves), 0, st, stiles,
-                                   T * 2, U.mixpart, d_mix);
+                mix_partials_launch(st, stiles, T * 2, U.mixpart, d_mix);
                 mixed = true;
             }
         } else {

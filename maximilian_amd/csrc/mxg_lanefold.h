@@ -148,5 +148,42 @@ __global__ __launch_bounds__(64 * kPartWaves) void mix_partials_kernel(size_t ng
     }
 }
 
+// The same fold for a SMALL, fixed number of groups (the granular tile renders: one row per 64 streams), one lane per element and no
+// workgroup step: all NG loads of a lane are in flight together, and the additions are the ones mix_partials_kernel makes in the
+// order it makes them (wave w's chain 0.0 + p[w] + p[w + 16] + ..., then the sixteen chains left to right) -- the same bits.
+// 2048 streams x 70 560 samples: 15.0 -> ~8 us (the 1024-lane workgroups of the general kernel were mostly launch cost there).
+template <int NG>
+__global__ __launch_bounds__(256) void mix_partials_flat_kernel(size_t count, const double *__restrict__ partial, double *__restrict__ mix) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double v[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) v[g] = partial[(size_t)g * count + i];
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kPartWaves; w++) {
+        double s = 0.0;
+#pragma unroll
+        for (int g = w; g < NG; g += kPartWaves) s += v[g];
+        t = w == 0 ? s : t + s;
+    }
+    mix[i] = t;
+}
+// ngroups x count -> count on stream st with whichever of the two kernels fits
+inline void mix_partials_launch(hipStream_t st, size_t ngroups, size_t count, const double *partial, double *mix) {
+    const dim3 g((unsigned)((count + 255) / 256)), b(256);
+    if (ngroups == 16) {
+        hipLaunchKernelGGL((mix_partials_flat_kernel<16>), g, b, 0, st, count, partial, mix);
+    } else if (ngroups == 32) {
+        hipLaunchKernelGGL((mix_partials_flat_kernel<32>), g, b, 0, st, count, partial, mix);
+    } else if (ngroups == 48) {
+        hipLaunchKernelGGL((mix_partials_flat_kernel<48>), g, b, 0, st, count, partial, mix);
+    } else if (ngroups == 64) {
+        hipLaunchKernelGGL((mix_partials_flat_kernel<64>), g, b, 0, st, count, partial, mix);
+    } else {
+        hipLaunchKernelGGL(mix_partials_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64 * kPartWaves), 0, st, ngroups, count, partial, mix);
+    }
+}
+
 }  // namespace
 }  // namespace mxg
