@@ -705,9 +705,10 @@ __global__ __launch_bounds__(256, 4) void granular_unit_kernel(UnitArgs A, Sched
         if (blockIdx.x < nsched) {
             const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
             if (s >= A.S) return;
+            if (unit_args_skip(A)) return;  // (both renderers are enqueued and the other one was picked: it schedules, too)
             __builtin_amdgcn_s_setprio(3);
             sched_walk<(SMODE >= 0 ? SMODE : 0), true>(Q, s, prog);
-            if (!unit_args_skip(A)) unit_state_lane<true>(A, s);
+            unit_state_lane<true>(A, s);
             return;
         }
         const unsigned idx = blockIdx.x - nsched, stiles = (unsigned)((A.S + 63) / 64);
@@ -1102,9 +1103,10 @@ __global__ __launch_bounds__(256, 3) void granular_line_kernel(UnitArgs A, Sched
         if (blockIdx.x < nsched) {
             const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
             if (s >= A.S) return;
+            if (unit_args_skip(A)) return;  // (both renderers are enqueued and the other one was picked: it schedules, too)
             __builtin_amdgcn_s_setprio(3);
             sched_walk<(SMODE >= 0 ? SMODE : 0), true>(Q, s, prog);
-            if (!unit_args_skip(A)) line_state_lane<true>(A, s);
+            line_state_lane<true>(A, s);
             return;
         }
         const unsigned idx = blockIdx.x - nsched, stiles = (unsigned)((A.S + 63) / 64);
@@ -1640,8 +1642,24 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         lt = lt < 1 ? 1 : (lt > kLineTiles ? kLineTiles : lt);
         U.ltiles = (unsigned)lt;
         U.cend = (unsigned)C;
+        auto launch_line_streamed = [&]() {  // K8d, one launch (any scheduler mode): granular_line_kernel<mode>
+            U.want = 1;
+            U.c0 = 0;
+            U.cend = (unsigned)C;
+            KernelTimer kt("granular_line_kernel", st);
+            const dim3 g((unsigned)(nsched + stiles * ((C + lt - 1) / lt)));
+            switch (mode) {
+                case 0: hipLaunchKernelGGL((granular_line_kernel<0>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched); break;
+                case 1: hipLaunchKernelGGL((granular_line_kernel<1>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched); break;
+                case 2: hipLaunchKernelGGL((granular_line_kernel<2>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched); break;
+                default: hipLaunchKernelGGL((granular_line_kernel<3>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched); break;
+            }
+        };
         if (streamed && unit) {
-            // K8c, one launch: scheduler lanes and tile renders side by side (granular_unit_kernel<SMODE>), on the caller's stream
+            // K8c, one launch: scheduler lanes and tile renders side by side (granular_unit_kernel<SMODE>), on the caller's stream.
+            // With both renderers enqueued (UnitArgs::sel) each is a complete streamed launch -- scheduler, renders, state -- and
+            // every workgroup of the one that was not picked returns at once.
+            if (both) launch_line_streamed();
             U.want = 0;
             U.c0 = 0;
             U.cend = (unsigned)C;
@@ -1654,33 +1672,12 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
                     hipLaunchKernelGGL((granular_unit_kernel<2>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched);
                 }
             }
-            if (both) {  // the carried-in grains may send the call to K8d (UnitArgs::sel): it then renders after the lists are complete
-                U.want = 1;
-                {
-                    KernelTimer kt("granular_line_kernel", st);
-                    hipLaunchKernelGGL((granular_line_kernel<-1>), dim3((unsigned)((S + 63) / 64), (unsigned)((C + lt - 1) / lt)), dim3(256), 0, st, U, Q, (int *)nullptr, 0u);
-                }
-                hipLaunchKernelGGL(granular_line_state_kernel, grid, dim3(64), 0, st, U);
-            }
             if (U.pan) {
                 mix_partials_launch(st, stiles, T * 2, U.mixpart, d_mix);
                 mixed = true;
             }
         } else if (streamed) {
-            // K8d, one launch (any scheduler mode): granular_line_kernel<mode>
-            U.want = 1;
-            U.c0 = 0;
-            U.cend = (unsigned)C;
-            {
-                KernelTimer kt("granular_line_kernel", st);
-                const dim3 g((unsigned)(nsched + stiles * ((C + lt - 1) / lt)));
-                switch (mode) {
-                    case 0: hipLaunchKernelGGL((granular_line_kernel<0>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched); break;
-                    case 1: hipLaunchKernelGGL((granular_line_kernel<1>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched); break;
-                    case 2: hipLaunchKernelGGL((granular_line_kernel<2>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched); break;
-                    default: hipLaunchKernelGGL((granular_line_kernel<3>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched); break;
-                }
-            }
+            launch_line_streamed();
             if (U.pan) {
                 mix_partials_launch(st, stiles, T * 2, U.mixpart, d_mix);
                 mixed = true;

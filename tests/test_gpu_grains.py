@@ -305,6 +305,41 @@ def test_granular_streamed_renders_wait_for_slow_schedulers(mx, port):
     assert_bits_equal(got[0][:, sel], e, "oracle")
 
 
+@pytest.mark.parametrize("streamed", [1, 0])
+def test_time_stretch_with_off_grid_carried_grains_picks_the_general_renderer_on_the_device(mx, port, streamed):
+    """maxiTimeStretch with unit increments takes the closed-form tile render K8c -- unless a carried-in grain sits between two
+    buffer elements.  That is device state: both renderers are enqueued, a word written by the call's first kernel picks one, and
+    every workgroup of the other returns at once (in the one-launch form: its scheduler lanes too).  Live grains uploaded at
+    x.5 positions in every third stream: the call must equal the port, and so must the next call (which finds grains K8d left)."""
+    L = mx.lib()
+    rng = np.random.default_rng(515)
+    Ls, S, T = 20000, 150, 64 * 40 + 9
+    smp = rng.uniform(-1, 1, Ls)
+    speed = rng.uniform(0.3, 1.7, S)
+    prev = L.mxg_tune(b"grain_streamed", streamed)
+    try:
+        bank = make_bank(mx, 0, "hann", smp, S)
+        bank.setPosition(rng.uniform(0, 1, S))
+        dur = int(0.05 * 44100)
+        gst = np.zeros((4, 8, S))
+        for s in range(0, S, 3):
+            gst[0, 0, s] = 100.5 + 7 * s
+            gst[1, 0, s] = 1.0 if s % 2 else -1.0
+            gst[2, 0, s] = 10 + s
+            gst[3, 0, s] = dur
+        bank.grains.upload(gst)
+        st = bank.state.numpy()
+        for n in (T, 1000):
+            o = bank.play(speed, 0.05, 4, n).numpy()
+            e, st, gst, rc = port.granular(0, 0, smp, n, speed, grainLength=0.05, overlaps=4, st=st, gst=gst)
+            assert rc == 0
+            assert_bits_equal(o, e, "output (%d samples)" % n)
+            assert_bits_equal(bank.state.numpy(), st, "scheduler state")
+            assert_bits_equal(bank.grains.numpy(), gst, "live grains")
+    finally:
+        L.mxg_tune(b"grain_streamed", prev)
+
+
 @pytest.mark.parametrize("unit", [1, 0])
 def test_granular_signed_zeros_and_non_finite_samples(mx, port, unit):
     """`(1-remainder)*buffer[a] + remainder*buffer[b]` with remainder == 0 still depends on buffer[b]: 0*Inf and 0*NaN
