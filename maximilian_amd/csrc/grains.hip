@@ -594,6 +594,11 @@ constexpr int kUnitGroup = MXG_UNIT_GROUP;  // streams rendered together by a wa
 #ifndef MXG_UNIT_BATCH
 #define MXG_UNIT_BATCH 8
 #endif
+#ifndef MXG_UNIT_DPP
+#define MXG_UNIT_DPP 0  // A/B: 1 = an interior pair's buffer[a] as an 8-byte load, buffer[a + 1] from the neighbour lane (wave_shl / wave_shr)
+                        // + one single-lane load: same bits, half the address cycles -- and 829 -> 1008 us per config-5 step (round 5):
+                        // the kernel is bound by issue and latency, not by the texture addresser; 0 = one 16-byte request per lane
+#endif
 constexpr int kUnitBatch = MXG_UNIT_BATCH;  // interior (grain, tile) pairs in flight per wavefront
 constexpr int kInteriorFlag = 1 << 29;      // in s_cnt: every candidate of the stream is interior to the tile
 constexpr int kFlatFlag = 1 << 30;          // in s_cnt: the stream-tile goes through the flattened phase 2a (1..kSlots candidates)
@@ -866,15 +871,24 @@ __global__ __launch_bounds__(256, 4) void granular_unit_kernel(UnitArgs A, Sched
                     const int gk0 = (int)(kd & 0xffffu) - 64;
                     const bool back = (kd >> 31) != 0;
                     if constexpr (INTERIOR) {
-                        // scalar bases + a non-negative per-lane byte offset: buffer[a], buffer[a+1] as one 16-byte
-                        // request at base + lane (forwards) or base - lane (backwards)
+                        // scalar bases + a non-negative per-lane byte offset: base + lane (forwards) or base - lane (backwards)
                         const char *pa = reinterpret_cast<const char *>(A.amp + (back ? gbase - 63 : gbase));
                         const char *pw = reinterpret_cast<const char *>(A.window + gk0);
                         const unsigned off = back ? voff_b : voff_f;
-                        vab[u] = *reinterpret_cast<const double2v *>(pa + off);
+#if MXG_UNIT_DPP
+                        // buffer[a] alone (8 bytes a lane: half the address cycles of the 16-byte form); buffer[a + 1] IS the next
+                        // lane's buffer[a] (forwards: lane + 1, backwards: lane - 1) and comes by a wavefront shift when the pair is
+                        // consumed -- except for the one lane at the end, which loads its neighbour element itself
+                        vab[u].x = *reinterpret_cast<const double *>(pa + off);
+                        vab[u].y = 0.0;  // (the end lane's neighbour element is 8 bytes after its own in either direction: ONE lane loads it)
+                        if (lane == (back ? 0 : 63)) vab[u].y = *reinterpret_cast<const double *>(pa + off + 8);
+                        wrap[u] = back;  // (here: the direction of the shift)
+#else
+                        vab[u] = *reinterpret_cast<const double2v *>(pa + off);  // buffer[a], buffer[a+1] as one 16-byte request
+                        wrap[u] = false;
+#endif
                         ve[u] = *reinterpret_cast<const double *>(pw + voff_f);
                         ok[u] = true;
-                        wrap[u] = false;
                     } else {
                         const int gdur = (int)((kd >> 16) & 0x7fffu), gsgn = back ? -1 : 1;
                         const int k = gk0 + lane;
@@ -900,6 +914,21 @@ __global__ __launch_bounds__(256, 4) void granular_unit_kernel(UnitArgs A, Sched
                         }
                         const double remainder = 0.0;  // pos is an integer: pos - floor(pos)
                         if constexpr (INTERIOR) {
+#if MXG_UNIT_DPP
+                            {
+                                const int alo = __double2loint(vab[u].x), ahi = __double2hiint(vab[u].x);
+                                const int elo = __double2loint(vab[u].y), ehi = __double2hiint(vab[u].y);
+                                int blo, bhi;
+                                if (wrap[u]) {  // (wave-uniform) backwards: lane L's buffer[a + 1] is lane L - 1's buffer[a]
+                                    blo = __builtin_amdgcn_update_dpp(elo, alo, 0x138, 0xf, 0xf, false);  // wave_shr:1
+                                    bhi = __builtin_amdgcn_update_dpp(ehi, ahi, 0x138, 0xf, 0xf, false);
+                                } else {        // forwards: lane L + 1's
+                                    blo = __builtin_amdgcn_update_dpp(elo, alo, 0x130, 0xf, 0xf, false);  // wave_shl:1
+                                    bhi = __builtin_amdgcn_update_dpp(ehi, ahi, 0x130, 0xf, 0xf, false);
+                                }
+                                vab[u].y = __hiloint2double(bhi, blo);
+                            }
+#endif
                             double o = ((1 - remainder) * vab[u].x + remainder * vab[u].y);  // :236-237, literally
                             o *= ve[u];
                             total += o;  // creation order
