@@ -599,8 +599,11 @@ int mxg_grain_plan_window(const mxg_grain_plan *plan, double *h_window); /* retu
  * (setPosition(p) == position = clamp(p*len, 0, len-1), :335-338); d_gst = [4][8][S]: the live
  * grains in creation order: pos, inc, sampleIdx, sampleDur (0 = empty slot).  A live grain must be
  * one this plan made (same sampleDur: a bank has one window table per plan, so let grains finish -- or
- * clear d_gst -- before switching to a plan of another grain length).  Synchronous on `stream` (it
- * reports > 8 live grains, an exhausted d_rnd or such a foreign / corrupt grain as MXG_ERR_INVALID). */
+ * clear d_gst -- before switching to a plan of another grain length).  The call only enqueues on `stream`; what the device finds while
+ * it renders -- more than 8 live grains in a stream, an exhausted d_rnd, such a foreign / corrupt grain, a grain born with a step its
+ * reads could not survive: MXG_ERR_INVALID -- is reported by the next synchronising call or by mxg_last_async_error (knob "grain_sync" 1:
+ * by the call itself, which then waits).  A tile-rendered call is ONE launch whose first workgroups are the per-stream schedulers and whose
+ * other workgroups render tiles as the schedulers' lists reach them (knob "grain_streamed"). */
 int mxg_granular_render(const mxg_grain_plan *plan, int mode, size_t S, size_t T, const double *d_samples,
                         size_t len, int overlaps, const double *d_a, const double *d_b,
                         const double *d_posmod, const int32_t *d_rnd, size_t R, double *d_st, double *d_gst,
