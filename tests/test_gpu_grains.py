@@ -559,3 +559,54 @@ def test_config5_render_is_asynchronous_and_graph_capturable(mx):
     for i, what in enumerate(("scheduler state", "live grains", "last block", "last mix")):
         assert torch.equal(g_state[i], e[i]), what
     L.mxg_grain_plan_destroy(plan)
+
+
+def test_one_launch_granular_calls_on_two_streams_at_once(mx):
+    """Two banks rendered on two streams with nothing ordering them: their one-launch calls (scheduler workgroups + tile renders that
+    poll them) share the device, and each render only ever waits for scheduler workgroups of ITS OWN launch, which were dispatched
+    before it.  Three calls per stream, interleaved enqueue, a large unrelated kernel in between; outputs, scheduler state and live
+    grains equal the same calls made one stream after the other."""
+    import torch
+    L = mx.lib()
+    S, T, Ls, K = 512, 64 * 300, 150000, 3
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(15)
+    smp = rng.uniform(-1, 1, Ls)
+    sb = mx.maxiSampleBank(1)
+    sb.setSample(smp)
+    plan = L.mxg_grain_plan_create(0, 0.05, 44100)
+    assert plan
+    speeds = [torch.from_numpy(0.3 + 1.4 * ((np.arange(S) * (3 + 2 * b)) % 89) / 88).to(dev) for b in range(2)]
+    pan = torch.from_numpy(np.arange(S) / (S - 1.0)).to(dev)
+
+    def fresh(b):
+        st0 = np.zeros((4, S))
+        st0[0] = ((np.arange(S) * (b + 1)) % S) / S * Ls
+        return (torch.from_numpy(st0).to(dev), torch.zeros((4, 8, S), dtype=torch.float64, device=dev),
+                torch.empty((T, S), dtype=torch.float64, device=dev), torch.zeros((T, 2), dtype=torch.float64, device=dev))
+
+    def call(st, b, state, grains, out, mix):
+        assert L.mxg_granular_render_mix(plan, 0, S, T, sb.d_samples, Ls, 4, speeds[b].data_ptr(), None, None, None, 0,
+                                         state.data_ptr(), grains.data_ptr(), out.data_ptr(), pan.data_ptr(), mix.data_ptr(), st) == 0
+
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    ref = [fresh(b) for b in range(2)]
+    for b in range(2):                       # one stream after the other
+        with torch.cuda.stream(streams[b]):
+            for _ in range(K):
+                call(streams[b].cuda_stream, b, *ref[b])
+        streams[b].synchronize()
+    got = [fresh(b) for b in range(2)]
+    big = torch.empty((4096, 4096), dtype=torch.float32, device=dev).normal_()
+    torch.cuda.synchronize()
+    for _ in range(K):                       # both at once
+        for b in range(2):
+            with torch.cuda.stream(streams[b]):
+                call(streams[b].cuda_stream, b, *got[b])
+        big = big @ big * 1e-4               # (the default stream: a third party on the device)
+    torch.cuda.synchronize()
+    assert L.mxg_last_async_error() == 0
+    for b in range(2):
+        for i, what in enumerate(("scheduler state", "live grains", "last block", "last mix")):
+            assert torch.equal(got[b][i], ref[b][i]), "stream %d: %s" % (b, what)
+    L.mxg_grain_plan_destroy(plan)
