@@ -104,6 +104,77 @@ ESTIMATOR = ("single-kernel step: GPU-side step time (two HIP events around the 
              "kernel's own launches (marker pair included: conservative), never more than the step")
 
 
+def _sig(x, n=5):
+    return float("%.*g" % (n, x)) if isinstance(x, float) else x
+
+
+def compact_line(res, tag):
+    """The default (short) form of the JSON line: the same numbers, texts said once.  The driver keeps an 8 KB tail of the line, so every
+    `configs.*.{ms_per_step, value, roofline.{frac, step_frac, kernel_ms, traffic}, cpu_baseline.value}` has to fit in well under that;
+    `--verbose` prints the long form (workload texts, estimator notes, per-kernel tables)."""
+    out = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                               "vs_baseline", "dtype", "data")}
+    cfg = dict(res["config"])
+    if tag:
+        cfg["workload"] = tag
+    out["config"] = cfg
+    r = res["roofline"]
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "launches_per_step", "algorithmic_bytes_per_launch",
+            "flops_per_launch", "frac_wall", "frac_single_buffer", "frac_of_measured_write_ceiling", "frac_of_measured_read_ceiling")
+    ro = {k: _sig(r[k]) for k in keep if r.get(k) is not None or k == "traffic"}
+    for c in ("write_ceiling", "read_ceiling"):
+        if c in r:
+            ro[c + "_GB/s"] = r[c]["GB/s"]
+    if "l2_gather_model" in r:
+        ro["l2_gather_GB/s"] = r["l2_gather_model"]["achieved_GB/s"]
+    out["roofline"] = ro
+    cb = res.get("cpu_baseline")
+    if cb:
+        o = {k: cb[k] for k in ("value", "unit", "cores", "kind") if k in cb}
+        o["sample"] = cb.get("sample", "")[:150]
+        if "single_thread" in cb:
+            o["single_thread"] = cb["single_thread"]["value"]
+        out["cpu_baseline"] = o
+    elif "cpu_baseline" in res:
+        out["cpu_baseline"] = None
+    for k in ("exchange", "rccl_ranks", "step_ms_gpu", "realtime_voices_at_44k1", "per_gpu_efficiency", "step_ms_without_reduce",
+              "value_like_for_like_n1", "share_gpu_test"):
+        if res.get(k) is not None:
+            out[k] = res[k]
+    if "north_star_bank" in res:
+        out["north_star_bank"] = {k: res["north_star_bank"][k] for k in ("voices", "ms_per_step", "value", "frac_hbm_peak",
+                                                                        "frac_of_measured_write_ceiling", "realtime_factor_at_44k1")}
+    out["notes"] = {"kernel_ms": "single-kernel step: GPU-side step time / launches (upper bound, gaps included); multi-kernel step: HIP "
+                                 "events around the kernel's own launches, never more than the step",
+                    "traffic": "HBM bytes per launch, rocprofv3 --pmc passes of the same commands (profiles/pmc_traffic.json)",
+                    "cpu_baseline": "the compiled reference on this host's cores; per config a ~1 s sample",
+                    "long_form": "bench.py --verbose"}
+    cs = {}
+    for name, c in res.get("configs", {}).items():
+        if "error" in c:
+            cs[name] = c
+            continue
+        e = {"workload": c.get("tag") or c["workload"][:110], "ms_per_step": c["ms_per_step"], "value": c["value"]}
+        for k in ("n_gpus", "scaling", "steps", "step_vs_headline", "step_vs_config3"):
+            if k in c:
+                e[k] = c[k]
+        if "roofline" in c:
+            q = c["roofline"]
+            e["roofline"] = {k: _sig(q[k]) for k in ("bound", "kernel", "kernel_ms", "achieved", "unit", "frac", "step_frac", "kernel_frac", "traffic",
+                                                    "l2_gather_GB/s") if k in q}
+            if "matrix_pipe" in q:
+                e["roofline"]["matrix_pipe"] = {"achieved_TFLOP/s": q["matrix_pipe"]["achieved_TFLOP/s"], "utilisation": q["matrix_pipe"]["utilisation"]}
+            if "fp64_valu" in q:
+                e["roofline"]["fp64_valu"] = {"achieved_TFLOP/s": q["fp64_valu"]["achieved_TFLOP/s"], "frac": q["fp64_valu"]["frac"]}
+        if c.get("cpu_baseline"):
+            b = c["cpu_baseline"]
+            e["cpu_baseline"] = {k: b[k] for k in ("value", "cores", "kind", "error") if k in b}
+        cs[name] = e
+    if cs:
+        out["configs"] = cs
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +215,9 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="KEY=VALUE passed to mxg_tune (A/B experiments)")
     ap.add_argument("--mfma-fullk", action="store_true",
                     help="config4 mfma: contract over all 512 bins instead of the 256 that carry mel weight")
+    ap.add_argument("--verbose", action="store_true",
+                    help="print the long form of the line (full workload texts, estimator notes, per-kernel tables in every `configs` entry); "
+                         "the default line is the compact form (< 7000 characters: the driver keeps an 8 KB tail)")
     ap.add_argument("--kernel-events", default="pass", choices=["inline", "pass", "off"],
                     help="per-kernel HIP events inside the timed region (inline), in a separate pass, or not at all")
     args = ap.parse_args()
@@ -246,7 +320,7 @@ def main():
     # config 2/3: the cross-GPU mixdown (and its RCCL reduce) is part of the step whenever there is more than one GPU;
     # a single GPU renders the bank without it unless asked (--mixdown fused|separate).  config 5 is DEFINED with the
     # stereo mixdown (BASELINE configs[4]), so it always mixes.
-    mixdown = args.mixdown or {"config2": "fused" if world > 1 else "off", "config3": "separate" if world > 1 else "off",
+    mixdown = args.mixdown or {"config2": "fused" if world > 1 else "off", "config3": "fused" if world > 1 else "off",
                                "config4": "off", "config5": "fused", "tables": "off"}[args.workload]
 
     class OscBank:
@@ -328,6 +402,8 @@ def main():
                 return _baseline(lambda o, n, th: o.time_osc(wf, bank.freq_h, n, threads=th), lambda n: V * n, (256, 1 << 18),
                                  "samples per voice", "%d voices maxiOsc::%s, voice-inner loop" % (V, args.waveform), target_s)
             W = dict(bank=bank, step=bank.step, samples=V * B, dominant=bank.dominant, algo_bytes=bank.algo, dtype="f64", cpu=cpu,
+                     tag="configs[1]: %d-voice maxiOsc::%s bank, block 512, out[n][v] stored%s, %d rotated buffers"
+                         % (V, args.waveform, {"fused": " + fused stereo mixdown", "separate": " + K3 mixdown", "off": ""}[mixdown], nbuf),
                      local_step=bank.with_queue(local_queue).step if local_queue is not None else None,
                      workload="configs[1]: %d-voice maxiOsc::%s wavetable bank per GPU, block=512, fp64 out[n][v] stored%s, output "
                               "rotated over %d block buffer(s) = %.2f GB touched before a line is rewritten"
@@ -352,6 +428,7 @@ def main():
                                             rowst.data_ptr(), stream), "mxg_osc_render_tables")
                 chk(L.mxg_mix_rows_sum(Gt, B * 2, rowst.data_ptr(), mixt.data_ptr(), stream), "mxg_mix_rows_sum")
             W = dict(step=step_tables, samples=Vt * B, dominant="osctab_kernel", algo_bytes=Vt * (514 * 8.0 + 24.0), dtype="f64", cpu=None,
+                     tag="EXTENSION: %d-voice sinebuf bank, one 514-entry table PER VOICE (HBM-read form), fused mixdown out" % Vt,
                      local_step=None,
                      workload="EXTENSION of configs[1] (not in the reference, which has one shared sineBuffer): %d-voice maxiOsc::sinebuf bank "
                               "with a 514-entry table PER VOICE (4112 B read per voice and block, 8.03 B per sample), block=512, fused "
@@ -370,10 +447,12 @@ def main():
             gate = mx.DeviceBuffer.from_numpy(((np.arange(K * B) % 44100) < 22050).astype(np.int32))
             pan3 = mx.DeviceBuffer.from_numpy(pan_h)
             blk = [0]
+            # fused (round 6): K2f leaves one partial mix row per workgroup of 256 voices in the grouped queue's slot, as K1m does
+            groups3 = L.mxg_osc_mix_groups(V) if mixdown == "fused" else 1
             if mixdown != "off":
-                queue = make_queue(B * 2, args.mix_depth)
+                queue = make_queue(B * 2, args.mix_depth, groups3)
                 if world > 1:
-                    local_queue = RcclMixQueue(None, B * 2, args.mix_depth, 0, stream)
+                    local_queue = RcclMixQueue(None, B * 2, args.mix_depth, 0, stream, groups=groups3)
 
             def voice_block():
                 o3 = outs3[blk[0] % nbuf]
@@ -384,7 +463,15 @@ def main():
                 return o3
 
             def render_mix3(slot):
-                o3 = voice_block()
+                if mixdown == "fused":  # render + store + per-workgroup mix rows in one pass; the (grouped) queue adds the rows
+                    o3 = outs3[blk[0] % nbuf]
+                    chk(L.mxg_voice_render_mix_rows(mode, V, B, vf.ptr, vcu.ptr, vrs.ptr, vcoef.ptr if vcoef is not None else None,
+                                                    gate.ptr + 4 * (blk[0] % K) * B, 0, vpar.ptr, vhold.ptr, vb.osc_state.ptr,
+                                                    vb.flt_state.ptr, vb.env.dstate.ptr, vb.env.istate.ptr, o3.ptr, pan3.ptr, slot, stream),
+                        "mxg_voice_render_mix_rows")
+                    blk[0] += 1
+                    return
+                o3 = voice_block()  # K2f then K3 re-reading the block
                 chk(L.mxg_mix_stereo(V, B, o3.ptr, pan3.ptr, slot, stream), "mxg_mix_stereo")
             step = voice_block if mixdown == "off" else MixdownStep(render_mix3, queue)
 
@@ -397,14 +484,20 @@ def main():
                     fps3 = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["voice_kernel_modB"]["fp64_flops_per_sample"]
                 except Exception:
                     fps3 = None
-            W = dict(step=step, samples=V * B, dominant="voice_kernel", algo_bytes=(8.0 + 176.0 / B) * V * B, dtype="f64", cpu=cpu,
+            algo3 = (8.0 + 176.0 / B) * V * B
+            if mixdown == "fused":
+                algo3 += 8.0 * V + 16.0 * B * (V / 256.0)  # + pan read, per-workgroup mix rows written
+            W = dict(step=step, samples=V * B, dominant="voice_kernel", algo_bytes=algo3, dtype="f64", cpu=cpu,
+                     tag="configs[2]: %d voices saw->lores->adsr (mode %s), block 512%s" % (V, "AB"[mode], {"fused": " + fused stereo mixdown",
+                                                                                                       "separate": " + K3 mixdown", "off": ""}[mixdown]),
                      fp64_flops=fps3 * V * B if fps3 else None,
                      fp64_note="%.1f fp64 flops per sample = (SQ_INSTS_VALU_ADD_F64 + MUL_F64 + 2 FMA_F64) x 64 lanes / samples, rocprofv3 --pmc of this "
                                "workload (profiles/pmc_traffic.json); compute-bound: cos / pow / sqrt per sample on the device" % fps3 if fps3 else None,
                      local_step=MixdownStep(render_mix3, local_queue) if local_queue is not None else None,
                      workload="configs[2]: fused subtractive voice maxiOsc::saw -> maxiFilter::lores -> maxiEnv::adsr (mode %d), %d voices "
                               "per GPU, block=512, gate(n) = (n mod 44100) < 22050 cycled over 128 blocks, output rotated over %d block "
-                              "buffer(s)" % (mode, V, nbuf))
+                              "buffer(s)%s" % (mode, V, nbuf, {"fused": " + fused maxiMix::stereo mixdown", "separate": " + K3 mixdown",
+                                                               "off": ""}[mixdown]))
         elif workload == "config4":
             NF = 1 << 20
             g = torch.Generator(device=dev); g.manual_seed(0x4D415849 + rank)
@@ -464,6 +557,9 @@ def main():
                 return out
             W = dict(step=step, samples=NF * 1024, dtype="f32 (FFT) / f64 (MFCC)", cpu=cpu, read_ceiling=read_ceiling if fused_ok else None,
                      dominant="mfcc_mfma_gemm_kernel" if mfma else ("fft_mfcc_kernel" if fused_ok else "fft1024_kernel"),
+                     tag="configs[3]: maxiFFT(1024)+maxiMFCC(512,42,13) x %d frames, %s" % (NF, "FFT kernel + dense MFMA GEMM" if mfma else (
+                         "fused, exact FFT, matrix-pipe mel+DCT" if mm else ("fused, exact FFT, exact band sums (walk), matrix DCT" if
+                                                                            mfcc_method == "walk" else "fused, library default form"))),
                      algo_bytes=4200.0 * NF if fused_ok else 6144.0 * NF,
                      # MFMA flops ISSUED: 2 x K x 48 (42 filters padded to 3 column blocks of 16) per frame
                      mfma_flops=2.0 * kdim * 48 * NF if mfma else None,
@@ -519,6 +615,7 @@ def main():
                                  (256, 8 * 70560), "samples per stream", "%d maxiTimeStretch<hann> streams, play(speed,0.05,4), stream-inner "
                                  "loop, 4 grain-samples per stream-sample" % Sc, target_s)
             W = dict(step=step, samples=S * T * 4, dominant="granular_unit_kernel", algo_bytes=(8.0 * 4 + 8.0) * S * T, dtype="f64", cpu=cpu,
+                     tag="configs[4]: %d maxiTimeStretch<hann> streams x %d samples, 4 overlaps%s" % (S, T, "" if mixdown == "off" else " + stereo mixdown"),
                      # what the render actually moves, all of it from L2 / Infinity Cache (the 35 MB sample and the 17.6 KB window are resident):
                      # per stream-sample 4 live grains x (buffer[a], buffer[a+1] = 16 B + 8 B of window) + the 8-byte store
                      l2_bytes=(4 * 24.0 + 8.0) * S * T,
@@ -720,7 +817,7 @@ def main():
         dom_k = Wq["dominant"]
         lps = kern.get(dom_k, {}).get("launches_per_step", 1.0)
         k_ms, _ = share_estimate(kern, dom_k, ms)
-        ent = {"workload": Wq["workload"], "steps": steps, "warmup": warm, "ms_per_step": round(ms, 5),
+        ent = {"workload": Wq["workload"], "tag": Wq.get("tag"), "steps": steps, "warmup": warm, "ms_per_step": round(ms, 5),
                "value": round(Wq["samples"] / ms / 1e3, 1), "unit": "Msamples/s", "dtype": Wq["dtype"]}
         tr = None
         try:
@@ -778,6 +875,7 @@ def main():
                 "config2_mixdown": ("config2", "fused", "sparse", 400, 50),  # the N > 1 step on one GPU: K1m + grouped mix queue, no communicator
                 "config2_tables": ("tables", "off", "sparse", 100, 20),  # the per-voice wavetable extension: the HBM-read roofline
                 "config3": ("config3", "off", "sparse", 256, 64),
+                "config3_mixdown": ("config3", "fused", "sparse", 256, 64),  # config 3's N > 1 step on one GPU: K2f with the mixdown fused + grouped queue
                 "config3_modB": ("config3", "off", "modB", 64, 16),  # cutoff modulated per sample (14.monosynth/main.cpp:53)
                 "config4": ("config4", "off", "sparse", 10, 2),
                 "config4_walk": ("config4", "off", "walk", 10, 2),   # band sums bit-exact (sparse walk), DCT on the matrix pipe
@@ -797,40 +895,48 @@ def main():
         if "config2_mixdown" in configs and "ms_per_step" in configs["config2_mixdown"]:
             # against the headline's GPU-side step (events): both are event-timed; the wall-clock ms_per_step of a 20-step run carries the fence
             configs["config2_mixdown"]["step_vs_headline"] = round(configs["config2_mixdown"]["ms_per_step"] / step_ms_events, 4)
+        if all("ms_per_step" in configs.get(k_, {}) for k_ in ("config3", "config3_mixdown")):
+            configs["config3_mixdown"]["step_vs_config3"] = round(configs["config3_mixdown"]["ms_per_step"] / configs["config3"]["ms_per_step"], 4)
 
     # ---- N > 1 default run: BASELINE's multi-GPU config (configs[4]: granular time-stretch, streams sharded over the ranks, ONE
     # stereo reduce per render) measured in the same launch: every rank the same fixed number of steps (the reduce is a collective),
     # barrier + synchronize on both sides, the slowest rank's time
     if (world > 1 and args.workload == "config2" and not args.tune and not args.no_configs and not args.voices):
-        c5 = {}
-        try:
-            W5 = build_workload("config5", "fused")
-            n5, w5 = 6, 2
-            for _ in range(w5):
-                W5["step"]()
-            W5["queue"].flush()
-            fence()
-            t5 = time.perf_counter()
-            for _ in range(n5):
-                W5["step"]()
-            W5["queue"].flush()
-            fence()
-            e5 = time.perf_counter() - t5
-            t = torch.tensor([e5], dtype=torch.float64)
-            if not args.share_gpu:
-                t = t.to(dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e5 = float(t[0])
-            c5 = {"workload": W5["workload"], "steps": n5, "warmup": w5, "n_gpus": world, "ms_per_step": round(e5 / n5 * 1e3, 4),
-                  "value": round(W5["samples"] * world * n5 / e5 / 1e6, 1), "unit": "Msamples/s", "dtype": W5["dtype"], "scaling": "weak",
-                  "note": "whole-job grain-samples per second over %d ranks, barrier-bracketed wall clock, max over ranks" % world}
-            for qq in (W5["queue"], W5["local_queue"]):
-                if qq is not None:
-                    qq.close()
-            del W5
-        except Exception as e:
-            c5 = {"error": "%s: %s" % (type(e).__name__, e)}
-        configs["config5"] = c5
+        def sharded(wl, n5, w5, what):
+            """One more BASELINE config in the same N-rank launch: units sharded over the ranks, its mixdown reduced through the library's
+            queue; every rank the same fixed number of steps, barrier + synchronize on both sides, the slowest rank's wall clock."""
+            try:
+                W5 = build_workload(wl, "fused")
+                for _ in range(w5):
+                    W5["step"]()
+                W5["queue"].flush()
+                fence()
+                t5 = time.perf_counter()
+                for _ in range(n5):
+                    W5["step"]()
+                W5["queue"].flush()
+                fence()
+                e5 = time.perf_counter() - t5
+                t = torch.tensor([e5], dtype=torch.float64)
+                if not args.share_gpu:
+                    t = t.to(dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                e5 = float(t[0])
+                c5 = {"workload": W5["workload"], "tag": W5.get("tag"), "steps": n5, "warmup": w5, "n_gpus": world, "ms_per_step": round(e5 / n5 * 1e3, 4),
+                      "value": round(W5["samples"] * world * n5 / e5 / 1e6, 1), "unit": "Msamples/s", "dtype": W5["dtype"], "scaling": "weak",
+                      "note": "whole-job %s per second over %d ranks, barrier-bracketed wall clock, max over ranks" % (what, world)}
+                for qq in (W5["queue"], W5["local_queue"]):
+                    if qq is not None:
+                        qq.close()
+                del W5
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                return c5
+            except Exception as e:
+                return {"error": "%s: %s" % (type(e).__name__, e)}
+        configs["config5"] = sharded("config5", 6, 2, "grain-samples")
+        # config 3 sharded the same way: K2f with the maxiMix::stereo mixdown fused (mxg_voice_render_mix_rows), one reduce per 16 blocks
+        configs["config3"] = sharded("config3", 640, 128, "voice samples")
 
     value = W["samples"] * world * args.steps / elapsed / 1e6
     dom_launches = kernels.get(dom, {}).get("launches_per_step", 1.0)
@@ -917,7 +1023,9 @@ def main():
             res["configs"] = configs
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = W["cpu"]() if W.get("cpu") else None
-        print(json.dumps(res), flush=True)
+        if not args.verbose:
+            res = compact_line(res, W.get("tag"))
+        print(json.dumps(res, separators=(",", ":")), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

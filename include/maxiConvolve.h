@@ -55,7 +55,7 @@ public:
         MAXIGPU_CATCH(return)
     }
     float play(float w) {  // L/maxiConvolve.cpp:76-107
-        if (!c_) return 0.0f;
+        if (!c_ || maxigpu::ps::dead()) return 0.0f;  // (a dead device path: silence, nothing touches the device)
         if (pos_ == 0) {
             maxigpu::ps::check(mxg_convolve_output(c_, d_io_ + F_, asIntended ? 1 : 0, nullptr), "mxg_convolve_output");
             maxigpu::ps::check(mxg_memcpy_d2h(out_.data(), d_io_ + F_, sizeof(float) * (size_t)F_, nullptr), "d2h convolve block");

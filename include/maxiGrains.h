@@ -53,7 +53,7 @@ public:
     size_t launches = 0;
 
     double play(int mode, double a, double b, double grainLength, int overlaps, double posMod) {
-        if (!sample_ || !sample_->deviceSamples() || sample_->getLength() == 0) return 0.0;
+        if (dead() || !sample_ || !sample_->deviceSamples() || sample_->getLength() == 0) return 0.0;
         Call c;
         c.method = mode;
         c.a[0] = a; c.a[1] = b; c.a[2] = grainLength; c.a[3] = (double)overlaps; c.a[4] = posMod;
@@ -62,6 +62,8 @@ public:
         settle();
         sig_ = c;
         render(next_len(c));
+        // (a refused call -- e.g. more overlaps than the renderer's eight live grains -- or a device failure leaves no block: silence)
+        if (blk_.empty() || pos_ >= blk_.size() || dead()) return 0.0;
         return serve();
     }
 
@@ -124,23 +126,32 @@ private:
         for (int i = 0; i < 32; i++) h[4 + i] = gst_[i];
         h[36] = sig_.a[0]; h[37] = sig_.a[1]; h[38] = sig_.a[4];
         const int32_t zero = 0;
-        check(mxg_memcpy_h2d(d_, h, sizeof(h), nullptr), "h2d grain state");
-        check(mxg_memcpy_h2d(d_rnd, &zero, sizeof(zero), nullptr), "h2d grain draw");
+        bool ok = check(mxg_memcpy_h2d(d_, h, sizeof(h), nullptr), "h2d grain state");
+        ok = check(mxg_memcpy_h2d(d_rnd, &zero, sizeof(zero), nullptr), "h2d grain draw") && ok;
         const int mode = sig_.method;
-        check(mxg_granular_render(plan(sig_.a[2]), mode, 1, L, sample_->deviceSamples(), sample_->getLength(), (int)sig_.a[3], d_par,
-                                  mode == 1 ? d_par + 1 : nullptr, mode == 2 ? nullptr : d_par + 2, (mode == 0 || mode == 1) ? d_rnd : nullptr,
-                                  1, d_st, d_gst, d_out, nullptr), "mxg_granular_render");
-        double back[36];
-        blk_.resize(L);
-        check(mxg_memcpy_d2h(back, d_, sizeof(back), nullptr), "d2h grain state");  // (synchronises; reports a deferred render error)
-        check(mxg_memcpy_d2h(blk_.data(), d_out, sizeof(double) * L, nullptr), "d2h grain block");
+        ok = check(mxg_granular_render(plan(sig_.a[2]), mode, 1, L, sample_->deviceSamples(), sample_->getLength(), (int)sig_.a[3], d_par,
+                                       mode == 1 ? d_par + 1 : nullptr, mode == 2 ? nullptr : d_par + 2, (mode == 0 || mode == 1) ? d_rnd : nullptr,
+                                       1, d_st, d_gst, d_out, nullptr), "mxg_granular_render") && ok;
+        double back[36] = {0};
+        blk_.assign(L, 0.0);
+        ok = check(mxg_memcpy_d2h(back, d_, sizeof(back), nullptr), "d2h grain state") && ok;  // (synchronises; reports a deferred render error)
+        ok = check(mxg_memcpy_d2h(blk_.data(), d_out, sizeof(double) * L, nullptr), "d2h grain block") && ok;
+        if (!ok) {  // nothing of this launch is used: the stream keeps the state it had, the call returns silence
+            abandon();
+            return;
+        }
         for (int i = 0; i < 4; i++) est_[i] = back[i];
         for (int i = 0; i < 32; i++) egst_[i] = back[4 + i];
         spawn_at_end_ = (mode == 0 || mode == 1) && back[3] != 0.0;  // the kernel consumed the placeholder: a grain was born in the block
         pos_ = 0;
         launches++;
         }
-        MAXIGPU_CATCH(return)
+        MAXIGPU_CATCH(abandon(); return)
+    }
+    void abandon() {  // a launch that failed or was refused: no block, the end state = the start state
+        for (int i = 0; i < 4; i++) est_[i] = st_[i];
+        for (int i = 0; i < 32; i++) egst_[i] = gst_[i];
+        drop_block();
     }
     double serve() {
         const double out = blk_[pos_++];

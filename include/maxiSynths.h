@@ -112,6 +112,11 @@ class maxiSampler {
     }
     // the state at the current sample, cached block dropped: before any control method edits it
     void settle() {
+        if (maxigpu::ps::dead()) {
+            blk_.clear();
+            pos_ = 0;
+            return;
+        }
         if (!blk_.empty()) {
             if (pos_ == blk_.size()) {
                 cur_ = end_;
@@ -186,7 +191,7 @@ public:
         MAXIGPU_CATCH(return)
     }
     double play() {  // maxiSynths.cpp:291-311
-        if (!d_samples_ || !len_ || !valid()) return output = 0;
+        if (!d_samples_ || !len_ || !valid() || maxigpu::ps::dead()) return output = 0;  // (a dead device path: silence, nothing touches the device)
         if (pos_ >= blk_.size()) {
             if (!blk_.empty()) cur_ = end_;
             const size_t L = blk_.empty() ? nextLen_ : std::min(2 * blk_.size(), maxigpu::ps::kMaxBlock);

@@ -153,12 +153,14 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * "fused_mel" (mxg_fft_mfcc_batch, the stage after the magnitudes: 0 automatic = 3, or 2 when d_melraw / d_melbands are requested; 1 = sparse mel walk, logs and DCT on the vector ALU in
  * the reference's summation orders; 2 = the same walk -- band sums bit-exact -- with the DCT's 42-term sums on the matrix pipe
  * (v_mfma_f64_4x4x4_4b_f64: fused multiply-adds, within 1e-13 x the largest band log of form 1); 3 = the mel contraction on the matrix
- * pipe as well, banded per quad of filters: band sums within 1e-13 x the frame's largest band, mfcc within 1e-11 -- the north star's
+ * pipe as well, banded per quad of filters: band sums within 4e-15 x the frame's largest band (measured 2.2e-16), mfcc within 1e-13 of form 1
+ * (measured 1.4e-15) -- the north star's
  * "MFMA for the mel-filterbank x frame contraction" inside the one-kernel path).
  * "osc_store" (K1's store stream: 0 automatic by waveform and bank size; one voice per lane: 1 plain 8-byte stores, 2 non-temporal,
  * 3 / 4 / 5 two samples of a lane pair exchanged into one 16-byte store per lane, plain / write-through (sc1) / non-temporal; two
  * voices per lane: 1 plain, 2 non-temporal, 3 write-through 16-byte stores), "voice_store" / "voice_xcd" (the same for the fused voice kernel; one voice
- * per lane only), "osc_xcd" (workgroups renumbered so that each of the eight XCDs renders
+ * per lane only), "voice_mix_store" (the store stream of mxg_voice_render_mix*: 0 automatic = "voice_store"'s rule, 1 ... 5 its flavours),
+ * "osc_xcd" (workgroups renumbered so that each of the eight XCDs renders
  * one contiguous eighth of the bank: 0 automatic, 1 off, 2 on), "grain_sync" (mxg_granular_render reads its error word back before it returns, 0|1;
  * default 0: deferred, see mxg_last_async_error), "part_spin_limit" (polls a time-split kernel's writer part makes before it gives up
  * and reports through mxg_last_async_error), "part_fault" (test-only fault injection: that writer waits for a signal that never comes).
@@ -326,6 +328,20 @@ int mxg_voice_render(int mode, size_t V, size_t N, const double *d_freq, const d
                      const double *d_res, const double *d_coef, const int32_t *d_trig, int tpv,
                      const double *d_par, const int64_t *d_holdtime, double *d_ost, double *d_fst,
                      double *d_dst, int64_t *d_ist, double *d_out, void *stream);
+/* The same render with the maxiMix::stereo mixdown of the bank fused into it (C:503-509 applied voice after voice, the sum over
+ * voices of the user's loop: 15.polysynth/main.cpp:54-70) -- the block is never read back.  d_out may be NULL (mix only).  The per-voice
+ * block and every state array get mxg_voice_render's bits; the sum over voices is a fixed tree (tolerance on the mix, as
+ * mxg_osc_render_mix).  _rows: d_rows[mxg_osc_mix_groups(V)][N][2], one row per 256 voices -- what a grouped mix queue's slot takes
+ * (mxg_mixq_create_grouped) or mxg_mix_rows_sum adds; _mix: d_mix[N][2] (rows in library scratch + the row sum on `stream`).
+ * Knob "voice_mix_store": the store stream of this form (0 automatic, 1 ... 5 as "voice_store"). */
+int mxg_voice_render_mix_rows(int mode, size_t V, size_t N, const double *d_freq, const double *d_cutoff, const double *d_res,
+                              const double *d_coef, const int32_t *d_trig, int tpv, const double *d_par, const int64_t *d_holdtime,
+                              double *d_ost, double *d_fst, double *d_dst, int64_t *d_ist, double *d_out, const double *d_pan,
+                              double *d_rows, void *stream);
+int mxg_voice_render_mix(int mode, size_t V, size_t N, const double *d_freq, const double *d_cutoff, const double *d_res,
+                         const double *d_coef, const int32_t *d_trig, int tpv, const double *d_par, const int64_t *d_holdtime,
+                         double *d_ost, double *d_fst, double *d_dst, int64_t *d_ist, double *d_out, const double *d_pan, double *d_mix,
+                         void *stream);
 
 /* ---- maxiMix::stereo + mixdown over voices (C:503-509; user-side sum e.g. 15.polysynth:67) --- */
 /* d_mix[n][0..1] = sum_v ( in[n][v]*sqrt(1-pan_v), in[n][v]*sqrt(pan_v) ).  The per-voice

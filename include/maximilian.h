@@ -57,7 +57,8 @@ namespace ps {  // per-sample engine
 // fail, never throw and never exit from a per-sample call (its one runtime complaint is printf("ERROR: Could not load sample."),
 // src/maximilian.cpp:686, after which play() returns silence).  Same here by default: the FIRST failure prints one line to stderr,
 // marks the engine dead, and from then on every per-sample call returns silence (0 / false) without touching the device; the C-ABI's
-// own status stays readable through mxg_last_error() / mxg_last_async_error().  A C-ABI call that reports a failure does not unwind
+// own status stays readable through mxg_last_error() / mxg_last_async_error().  (A refused ARGUMENT -- MXG_ERR_INVALID -- is not a device
+// failure: it silences the one call, see check().)  A C-ABI call that reports a failure does not unwind
 // (check(): the C-ABI validates every pointer it is handed, so whatever follows a failed call fails too, quietly, and results that
 // were to be produced stay zeros); a failed ALLOCATION or plan creation (fatal()) unwinds to the public method that was called with an
 // internal exception that never leaves this header (MAXIGPU_TRY / MAXIGPU_CATCH).  Two opt-ins: -DMAXIGPU_THROW (the round-4
@@ -89,21 +90,37 @@ inline bool &dead() {
 #define MAXIGPU_TRY try
 #define MAXIGPU_CATCH(...) catch (const maxigpu::ps::DeviceFailure &) { __VA_ARGS__; }
 #endif
-inline void check(int status, const char *what) {
-    if (status >= 0) return;
-#if defined(MAXIGPU_NO_EXCEPTIONS) || defined(MAXIGPU_THROW)
-    fatal(std::string(what) + ": " + mxg_last_error());
-#else
-    if (!dead()) std::fprintf(stderr, "ERROR: maxigpu: %s: %s -- the device path is off, every unit generator returns silence from here on\n", what, mxg_last_error());
-    dead() = true;
-#endif
-}
 inline void complain(const char *msg) {  // the reference's style (printf("ERROR: ...")), once per message
     static std::vector<const char *> *seen = new std::vector<const char *>;
     for (const char *m : *seen)
         if (m == msg) return;
     seen->push_back(msg);
     std::fprintf(stderr, "ERROR: %s\n", msg);
+}
+// The status of a C-ABI call; true = it succeeded.  Only a DEVICE failure (a HIP error, no device, an exhausted allocation) turns the
+// engine off for the whole process.  MXG_ERR_INVALID -- an argument or a capacity the C-ABI refuses, e.g. maxiTimeStretch::play with
+// more overlaps than the renderer's eight live grains, overlaps <= 0 -- is the CALLER's object only: one printed line per call site
+// (in the reference's printf("ERROR: ...") style), that object returns silence for the call, every other unit generator plays on
+// (the reference plays such calls with no global effect).
+inline bool check(int status, const char *what) {
+    if (status >= 0) return true;
+    if (status == MXG_ERR_INVALID) {
+        static std::vector<const char *> *seen = new std::vector<const char *>;
+        bool said = false;
+        for (const char *m : *seen) said = said || m == what;
+        if (!said) {
+            seen->push_back(what);
+            std::fprintf(stderr, "ERROR: maxigpu: %s: %s -- this call returns silence\n", what, mxg_last_error());
+        }
+        return false;
+    }
+#if defined(MAXIGPU_NO_EXCEPTIONS) || defined(MAXIGPU_THROW)
+    fatal(std::string(what) + ": " + mxg_last_error());
+#else
+    if (!dead()) std::fprintf(stderr, "ERROR: maxigpu: %s: %s -- the device path is off, every unit generator returns silence from here on\n", what, mxg_last_error());
+    dead() = true;
+    return false;
+#endif
 }
 
 constexpr size_t kMaxBlock = 512;
@@ -1824,6 +1841,11 @@ public:
         }
         buffer[pos++] = value;
         newFFT = pos == windowSize;
+        if (newFFT && maxigpu::ps::dead()) {  // the device path is off: the hop buffer keeps moving, the last spectrum stays
+            std::memmove(&buffer[0], &buffer[0] + hopSize, (windowSize - hopSize) * sizeof(float));
+            pos = windowSize - hopSize;
+            return newFFT = false;
+        }
         if (newFFT) {
             maxigpu::ps::check(mxg_memcpy_h2d(d_in_, buffer.data(), sizeof(float) * fftSize, nullptr), "h2d frame");
             float *re = d_out_, *im = d_out_ + bins, *mg = d_out_ + 2 * bins, *ph = d_out_ + 3 * bins;
@@ -1859,6 +1881,7 @@ public:
 
 private:
     void features(bool db, bool flat, bool cen) {
+        if (!plan_ || maxigpu::ps::dead()) return;
         float *mg = d_out_ + 2 * bins;
         maxigpu::ps::check(mxg_memcpy_h2d(mg, magnitudes.data(), sizeof(float) * bins, nullptr), "h2d mags");
         float *ddb = d_out_, *df = d_out_ + bins;  // reuse the real / imag staging
@@ -1920,6 +1943,10 @@ public:
     vector<double> &mfcc(vector<float> &powerSpectrum) {  // :77-81
         if (!plan_ || powerSpectrum.size() < numBins_) {  // (the reference reads past the vector / through null tables here)
             maxigpu::ps::complain(!plan_ ? "maxiMFCC::mfcc before setup()" : "maxiMFCC::mfcc: fewer values than bins");
+            return coeffs_;
+        }
+        if (maxigpu::ps::dead()) {
+            std::fill(coeffs_.begin(), coeffs_.end(), 0.0);
             return coeffs_;
         }
         maxigpu::ps::check(mxg_memcpy_h2d(d_in_, powerSpectrum.data(), sizeof(float) * numBins_, nullptr), "h2d spectrum");
@@ -2192,6 +2219,7 @@ public:
             maxigpu::ps::complain(!plan_ ? "maxiIFFT::process before setup()" : "maxiIFFT::process: fewer values than bins");
             return 0.0f;
         }
+        if (maxigpu::ps::dead()) return 0.0f;
         if (0 == pos) {  // the spectrum is consumed here; the overlap-add buffer lives on the device
             check(mxg_memcpy_h2d(d_in_, data1.data(), sizeof(float) * bins, nullptr), "h2d spectrum");
             check(mxg_memcpy_h2d(d_in_ + bins, data2.data(), sizeof(float) * bins, nullptr), "h2d spectrum");

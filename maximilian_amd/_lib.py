@@ -72,6 +72,12 @@ SIGNATURES = {
     "mxg_voice_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
+    "mxg_voice_render_mix_rows": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_voice_render_mix": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_envgen_stages_host": (c_int, [c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_envgen_render": (c_int, [c_size_t, c_size_t, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p]),

@@ -574,6 +574,31 @@ class maxiVoiceBank(_Bank):
         self._keep = (f, dcu, drs, coef, trig)
         return out
 
+    def render_mix(self, mode, freq, cutoff, resonance, trigger, pan, N, out=None, store=True, mix=None, rows=None):
+        """render() + the fused maxiMix::stereo mixdown of the bank in the same kernel (mxg_voice_render_mix).
+        Returns (out [N,V] or None, mix [N,2]).  rows: a device pointer / buffer [mxg_osc_mix_groups(V)][N][2] (e.g. a grouped
+        mix queue's slot) -- then the per-workgroup rows are left there (mxg_voice_render_mix_rows); returns (out, None)."""
+        f, pn = _as_dev(freq, self.V), _as_dev(pan, self.V)
+        cu = np.broadcast_to(np.asarray(cutoff, np.float64), (self.V,))
+        rs = np.broadcast_to(np.asarray(resonance, np.float64), (self.V,))
+        coef = DeviceBuffer.from_numpy(filter_coeffs(0, cu, rs)) if mode == 0 else None
+        dcu, drs = DeviceBuffer.from_numpy(cu), DeviceBuffer.from_numpy(rs)
+        dpar, dhold = self.env._params()
+        trig = trigger
+        if not (isinstance(trigger, DeviceBuffer) or hasattr(trigger, "data_ptr")):
+            trig = DeviceBuffer.from_numpy(np.ascontiguousarray(trigger, np.int32))
+        tpv = 1 if len(trig.shape) == 2 else 0
+        out = self._out(N, out) if store else None
+        args = (mode, self.V, N, _ptr(f), dcu.ptr, drs.ptr, _ptr(coef), _ptr(trig), tpv, dpar.ptr, dhold.ptr, self.osc_state.ptr,
+                self.flt_state.ptr, self.env.dstate.ptr, self.env.istate.ptr, _ptr(out), _ptr(pn))
+        self._keep = (f, dcu, drs, coef, trig, pn)
+        if rows is not None:
+            check(lib().mxg_voice_render_mix_rows(*args, _ptr(rows), self.stream), "mxg_voice_render_mix_rows")
+            return out, None
+        mix = mix if mix is not None else DeviceBuffer((N, 2), np.float64, zero=False)
+        check(lib().mxg_voice_render_mix(*args, _ptr(mix), self.stream), "mxg_voice_render_mix")
+        return out, mix
+
 
 class maxiMixBank(_Bank):
     """maxiMix::stereo over a bank + the mixdown over voices (C:503-509)."""

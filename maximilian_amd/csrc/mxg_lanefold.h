@@ -119,6 +119,65 @@ __device__ __forceinline__ T fold_chunk_swap(const T (&v)[kMixChunk]) {
     return fold_dpp<kDppRowHalfMirror, 0xA>(l3[0], l3[1]);
 }
 
+// ---- the [16 samples][64 voices] mixdown tile of K1m (osc.hip) and K2f's mixdown form (voice.hip) ---------------------------------
+// Voice quarter q, sample s, voice j of the quarter at double q * kTileQuarter + s * kTileRow + j: the row stride of 144 B moves
+// consecutive samples by nine 16-byte bank groups (see osc.hip, K1m).
+constexpr int kTileRow = 18;                 // doubles per (quarter, sample) row: 16 voices + 2 of padding (144 B)
+constexpr int kTileQuarter = 16 * kTileRow;  // 288 doubles = 2304 B
+constexpr int kTileWave = 4 * kTileQuarter;  // 1152 doubles = 9 KB per wavefront
+constexpr int kPcRing = 3;                   // tiles per producer / consumer pair
+__device__ __forceinline__ int lds_flag_load(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// One combine window of a producer / consumer workgroup (8 wavefronts): the four consumer rows s_part[4][WIN][2] of `span` samples are
+// added left to right into the workgroup's row `prow`; both barriers are met by all eight wavefronts.
+template <int WIN>
+__device__ __forceinline__ void mixpc_window_close(const double *s_part, double *prow, int span) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < span * 2; i += blockDim.x)
+        prow[i] = ((s_part[i] + s_part[WIN * 2 + i]) + s_part[2 * WIN * 2 + i]) + s_part[3 * WIN * 2 + i];
+    __syncthreads();
+}
+
+// The CONSUMER wavefront of a pair over a whole block of N samples (the arithmetic of osc_mixpc_kernel's consumer branch, the same
+// order of additions: C:503-509 per voice, the user's `mix +=` over voices as a fixed tree).  ring: the pair's kPcRing tiles; f_prod /
+// f_cons: the pair's counters; gl / gr: the gains of the 16 voices this lane sums; wg_rows: this workgroup's rows [N][2].
+template <int WIN, int SLEEP>
+__device__ __forceinline__ void mixpc_consume(size_t N, double *ring, int *f_prod, int *f_cons, const double (&gl)[16], const double (&gr)[16],
+                                              double *s_part, double *my_part, double *s_dump, double *wg_rows) {
+    const int lane = threadIdx.x & 63, ts = lane & 15, tq = lane >> 4;
+    int k = 0;
+    for (size_t n0 = 0; n0 < N; n0 += WIN) {
+        const int span = (int)((N - n0) < (size_t)WIN ? (N - n0) : (size_t)WIN);
+        for (int c0 = 0; c0 < span; c0 += kMixChunk, k++) {
+            const int cnt = (span - c0) < kMixChunk ? (span - c0) : kMixChunk;
+            while (lds_flag_load(f_prod) <= k) __builtin_amdgcn_s_sleep(SLEEP);
+            asm volatile("" ::: "memory");
+            const double2v *tr = reinterpret_cast<const double2v *>(ring + (k % kPcRing) * kTileWave + tq * kTileQuarter + ts * kTileRow);
+            double2v xv[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) xv[j] = tr[j];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            lds_flag_store(f_cons, k + 1);  // (behind the tile reads in the LDS queue)
+            double pl[8], pr[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                pl[j] = xv[j].x * gl[2 * j] + xv[j].y * gl[2 * j + 1];
+                pr[j] = xv[j].x * gr[2 * j] + xv[j].y * gr[2 * j + 1];
+            }
+            const double sl = ((pl[0] + pl[1]) + (pl[2] + pl[3])) + ((pl[4] + pl[5]) + (pl[6] + pl[7]));
+            const double sr2 = ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]));
+            double t = fold32(sl, sr2);
+            t = fold16(t, t);
+            // lanes 0-15 hold the left sums of samples c0 + lane, lanes 32-47 the right sums; the others drop theirs in a scratch row
+            double *dst = ((lane & 16) == 0 && ts < cnt) ? my_part + (c0 + ts) * 2 + (lane >> 5) : s_dump + (threadIdx.x & 255);
+            *dst = t;
+        }
+        mixpc_window_close<WIN>(s_part, wg_rows + n0 * 2, span);
+    }
+}
+
 // mix[i] = sum over workgroups of partial[g][i], i = n*2 + ch.  A workgroup owns 64 consecutive elements (one coalesced
 // 512-B row segment per load); its 16 waves each add the groups g = w, w+16, ... in order (independent loads, all in
 // flight), then the 16 wave sums are combined left to right: a fixed order for a fixed number of workgroups.  blockIdx.y = block k of

@@ -251,9 +251,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
 // even and `out` 16-byte aligned).  Time parts (gridDim.y) as in K1: part p advances the phase over the samples before it with
 // osc_skip (the same additions: the same bits), renders its stretch and mixes it into its own rows of the partial buffer; the
 // last part stores the state (part_signal / part_wait).
-constexpr int kTileRow = 18;              // doubles per (quarter, sample) row: 16 voices + 2 of padding (144 B)
-constexpr int kTileQuarter = 16 * kTileRow;  // 288 doubles = 2304 B
-constexpr int kTileWave = 4 * kTileQuarter;  // 1152 doubles = 9 KB per wavefront
+// (tile geometry kTileRow / kTileQuarter / kTileWave: mxg_lanefold.h -- shared with K2f's mixdown form, voice.hip)
 
 template <int WF, int STORE, int WIN>
 __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const double *__restrict__ freq,
@@ -521,7 +519,7 @@ __global__ __launch_bounds__(256) void osc_mix_kernel(size_t V, size_t N, const 
 // them, and the counter store that follows the tile READS is performed after them; the polls are relaxed workgroup-scope loads with
 // an s_sleep between them.  No barrier inside a window; the two barriers per window (combine of the four consumer rows) are shared
 // by all eight wavefronts.  The sums, their order and therefore the rows' bits are the fused kernel's.
-constexpr int kPcRing = 3;
+// (kPcRing, lds_flag_load / lds_flag_store: mxg_lanefold.h)
 #ifndef MXG_PC_FL
 #define MXG_PC_FL kTickLean  // A/B: the producers' tick flavour (0 = K1's own sinebuf tick: one table copy, the generic wrap)
 #endif
@@ -535,8 +533,6 @@ constexpr int kPcRing = 3;
 #define MXG_PC_PRIO 2  // A/B: the producers' issue priority
 #endif
 constexpr int kPcFL = MXG_PC_FL;
-__device__ __forceinline__ int lds_flag_load(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 template <int WF, int STORE, int WIN>
 __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, const double *__restrict__ freq,

@@ -450,6 +450,13 @@ __global__ __launch_bounds__(64 * WAVES, NF == 1 ? 1 : 2) __attribute__((target(
         }
         for (int i = threadIdx.x; i < kMmCoefQuads * kMmPairs * 32; i += blockDim.x) s_d[i] = A.mmD[i];
         if (lane < kGroup) M[lane * A.mstride] = 0.0f;  // bin 0 of every row: never formed, read with zero weights
+        // ... and the row's tail behind bin 256 (floats 257 .. mstride - 1), which nobody stores: a band moved down to end at the row's
+        // last float (mfcc.hip: base + 16 nb <= 260) reads it with zero weights, and 0 x (whatever bit pattern the LDS held) may be NaN
+        // (reachable with e.g. setup(512, 46, 13, 20, 21900))
+        if (lane < kGroup * 3) {
+            const unsigned tail = 257u + (unsigned)(lane / kGroup);
+            if (tail < A.mstride) M[(lane % kGroup) * A.mstride + tail] = 0.0f;
+        }
     } else if constexpr (TOL) {
         for (int i = threadIdx.x; i < fsRows * kFusedSlots; i += blockDim.x) {
             const mxg_fs_entry e = A.fs[i];

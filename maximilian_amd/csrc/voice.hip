@@ -22,6 +22,7 @@
 #include "maxi_tables.h"
 #include "mxg_common.h"
 #include "mxg_env.h"
+#include "mxg_lanefold.h"
 #include "mxg_sincos.h"
 
 namespace mxg {
@@ -423,16 +424,71 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
 // Per-voice triggers (TPV = true) are prefetched one 8-sample chunk ahead for the same reason.
 // ST / PX: the store stream as in K1 (osc.hip): ST = 0 plain, 1 nt, 2 sc1; PX = two samples of a lane pair leave as ONE 16-byte
 // store per lane (store_pair_rows, mxg_common.h; V even, out 16-byte aligned).  xcd: XCD-contiguous workgroup numbering.
-template <int MODE, int ST, bool PX, bool TPV>
-__global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const double *__restrict__ freq,
+//
+// MIX (round 6): the fused maxiMix::stereo mixdown (C:503-509 applied voice after voice, summed in user code: 15.polysynth/main.cpp:54-70),
+// K1m's producer / consumer form (osc.hip, osc_mixpc_kernel).  A workgroup is 512 lanes: wavefronts 0-3 are the PRODUCERS -- this
+// kernel's instruction stream for 64 voices each, plus one ds_write_b64 per sample into a [16 samples][64 voices] tile -- and wavefronts
+// 4-7 the CONSUMERS (mixpc_consume, mxg_lanefold.h: the transposed tile read, 16 + 16 products per lane, a fixed tree), consumer w + 4
+// serving producer w on the same SIMD at lower priority.  Output besides the block: the per-workgroup rows partial[workgroup][N][2],
+// the layout of mxg_osc_render_mix_rows, so that the grouped mix queue (comm.hip) folds them the same way.  ST = 3: no per-voice
+// block at all (out may be null).  The ticks, their order and the per-voice stores are the ones of MIX = false: the same bits.
+constexpr int kVoiceMixWin = 512;
+template <int MODE, int ST, bool PX, bool TPV, bool MIX>
+__global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t N, const double *__restrict__ freq,
                              const double *__restrict__ cutoff, const double *__restrict__ res,
                              const double *__restrict__ coef, const int32_t *__restrict__ trig,
                              int tpv, const double *__restrict__ par,
                              const int64_t *__restrict__ holdtime, double *__restrict__ ost,
                              double *__restrict__ fst, double *__restrict__ dst,
-                             int64_t *__restrict__ ist, double *__restrict__ out, double sr, int xcd) {
-    const size_t gid = (size_t)xcd_block(blockIdx.x, gridDim.x, xcd) * blockDim.x + threadIdx.x;
-    if ((gid & ~(size_t)63) >= V) return;  // the whole wavefront is past the bank
+                             int64_t *__restrict__ ist, double *__restrict__ out, double sr, int xcd,
+                             const double *__restrict__ pan, double *__restrict__ partial) {
+    constexpr int WIN = kVoiceMixWin;
+    const size_t wg = (size_t)xcd_block(blockIdx.x, gridDim.x, xcd);
+    const size_t gid = MIX ? wg * 256 + (threadIdx.x & 255) : wg * blockDim.x + threadIdx.x;  // (MIX: 256 voices per workgroup of 512 lanes)
+    // mixdown form: the pair's ring of tiles, the four consumer rows of a window, the scratch row, the counters
+    double *ring = nullptr, *s_part = nullptr, *my_part = nullptr, *s_dump = nullptr;
+    int *f_prod = nullptr, *f_cons = nullptr;
+    const int lane = threadIdx.x & 63, ts = lane & 15, tq = lane >> 4;
+    if constexpr (MIX) {
+        __shared__ __attribute__((aligned(16))) double s_all[4 * kPcRing * kTileWave + 4 * WIN * 2 + 256 + 8];
+        const int pw = (threadIdx.x >> 6) & 3;  // the pair
+        ring = s_all + pw * (kPcRing * kTileWave);
+        s_part = s_all + 4 * kPcRing * kTileWave;  // [4 pairs][WIN][2]
+        my_part = s_part + pw * (WIN * 2);
+        s_dump = s_part + 4 * WIN * 2;  // [256]
+        int *flags = reinterpret_cast<int *>(s_dump + 256);  // [4 pairs][2]: prod, cons
+        f_prod = flags + 2 * pw;
+        f_cons = flags + 2 * pw + 1;
+        const bool producer = threadIdx.x < 256;
+        if (threadIdx.x < 8) flags[threadIdx.x] = 0;
+        if (producer) {
+            const bool live = gid < V;
+            double x = pan[live ? gid : V - 1];
+            if (x > 1) x = 1;  // C:504
+            if (x < 0) x = 0;  // C:505
+            ring[lane] = live ? sqrt(1.0 - x) : 0.0;  // two[0] = input*sqrt(1.0-x)   C:506
+            ring[64 + lane] = live ? sqrt(x) : 0.0;   // two[1] = input*sqrt(x)       C:507
+        }
+        __syncthreads();  // (the gains, the counters)
+        if (!producer) {
+            double gl[16], gr[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                gl[j] = ring[16 * tq + j];
+                gr[j] = ring[64 + 16 * tq + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) asm volatile("" : "+v"(gl[j]), "+v"(gr[j]));
+            __syncthreads();  // every consumer has its gains: the ring is free
+            mixpc_consume<WIN, 4>(N, ring, f_prod, f_cons, gl, gr, s_part, my_part, s_dump, partial + wg * N * 2);
+            return;
+        }
+        __syncthreads();
+        // (no early exit below: a producer wavefront past the bank shadows the bank's last voices -- the same loads, arithmetic and
+        // stores of the same values to the same addresses -- with zero gains, so that every barrier is met)
+    } else {
+        if ((gid & ~(size_t)63) >= V) return;  // the whole wavefront is past the bank
+    }
     // (pair rows: the surplus lanes of the last wavefront shadow the last PAIR of voices, parity kept, so that they exchange
     // among themselves and store the values their owners store, to the same addresses)
     const size_t v = PX ? (gid < V ? gid : V - 2 + (gid & 1)) : live_voice(gid, V);
@@ -452,8 +508,56 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
     double *op = out + v;
     double *pp = out + (size_t)(threadIdx.x & 1) * V + (v & ~(size_t)1);  // pair rows: this lane's 16 bytes of row n + (lane & 1)
     // one chunk of U samples to the output: pairs of rows as 16-byte stores, or sample by sample
+    // mixdown form: tile k of the pair's ring holds samples 16 k .. 16 k + 15 of the block (windows are whole tiles); ns = rows written
+    // so far (wave-uniform).  The consumer must be done with the tile that a new one overwrites -- it normally was a tile ago (`seen`
+    // is requested at the start of a tile and looked at one tile later: no wait on the way).
+    int tk = 0, ns = 0, seen = 0, seen_next = 0;
+    auto tile_rows = [&](const double *o, int cnt) {  // cnt rows from o[0..cnt)
+        if constexpr (MIX) {
+            if (ns == 0) {
+                if (seen < tk - kPcRing + 1)
+                    while ((seen = lds_flag_load(f_cons)) < tk - kPcRing + 1) __builtin_amdgcn_s_sleep(1);
+                seen_next = lds_flag_load(f_cons);
+                asm volatile("" ::: "memory");
+            }
+            double *tw = ring + (tk % kPcRing) * kTileWave + tq * kTileQuarter + ts + ns * kTileRow;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (i < cnt) tw[i * kTileRow] = o[i];
+            ns += cnt;
+            if (ns == kMixChunk) {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                lds_flag_store(f_prod, tk + 1);  // (behind the tile writes in the LDS queue)
+                seen = seen_next;
+                ns = 0;
+                tk++;
+            }
+        }
+    };
+    auto tile_flush = [&]() {  // a ragged last tile: zero rows behind the block's last sample, then publish
+        if constexpr (MIX) {
+            if (ns) {
+                double *tw = ring + (tk % kPcRing) * kTileWave + tq * kTileQuarter + ts;
+                for (int i = ns; i < kMixChunk; i++) tw[i * kTileRow] = 0.0;
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                lds_flag_store(f_prod, tk + 1);
+                ns = 0;
+                tk++;
+            }
+        }
+    };
+    auto put1 = [&](double o) {  // one sample, sample by sample (ragged last chunk; 8-byte store streams)
+        if constexpr (ST != 3) {
+            store1<ST>(op, o);
+            op += V;
+        }
+        tile_rows(&o, 1);
+    };
     auto emit = [&](const double (&o)[8]) {
-        if constexpr (PX) {
+        if constexpr (ST == 3) {
+        } else if constexpr (PX) {
 #pragma unroll
             for (int i = 0; i < 8; i += 2) {
                 store_pair_rows<ST>(pp, o[i], o[i + 1]);
@@ -467,6 +571,7 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
                 op += V;
             }
         }
+        tile_rows(o, 8);
     };
     // consume the prologue loads here so no vmcnt(0) is needed inside the loop (see osc.hip K1m)
     asm volatile("" : "+v"(phase), "+v"(hold), "+v"(c), "+v"(r), "+v"(cut), "+v"(rs));
@@ -486,7 +591,10 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
         gate_group_load(gcur, trig, N, 0, gate_on);
         asm volatile("" : "+v"(gcur.cls));
     }
+    if constexpr (MIX) __builtin_amdgcn_s_setprio(2);  // the store-bound stream is the critical one: the consumer takes the issue slots it leaves
     for (size_t n0 = 0; n0 < N; n0 += U) {
+      if constexpr (MIX)
+        if (n0 && (n0 & (size_t)(WIN - 1)) == 0) mixpc_window_close<WIN>(s_part, partial + wg * N * 2 + (n0 - WIN) * 2, WIN);
       int tc[U];
       int fast = 0;
       if constexpr (TPV) {
@@ -536,14 +644,14 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
                     double y = flt_lores(f, s, c, r);
                     o = y * a;
                 }
-                if constexpr (PX) {
+                if constexpr (PX || MIX) {
                     ov[i] = o;
                 } else {
                     store1<ST>(op, o);
                     op += V;
                 }
             }
-            if constexpr (PX) emit(ov);
+            if constexpr (PX || MIX) emit(ov);
         };
         if (fast == 1) steady(std::true_type{}); else steady(std::false_type{});
         continue;
@@ -619,15 +727,20 @@ __global__ void __launch_bounds__(256) voice_kernel(size_t V, size_t N, const do
             double y = flt_lores(f, s, c, r);
             o = y * a;
         }
-        if (PX && whole) {
+        if ((PX || MIX) && whole) {
             og[i] = o;
         } else {  // (a ragged last chunk goes out sample by sample, whatever the store stream)
-            store1<ST>(op, o);
-            op += V;
+            put1(o);
         }
       }
-      if constexpr (PX)
+      if constexpr (PX || MIX)
         if (whole) emit(og);
+    }
+    if constexpr (MIX) {
+        tile_flush();
+        const size_t w0 = (N - 1) / WIN * WIN;
+        mixpc_window_close<WIN>(s_part, partial + wg * N * 2 + w0 * 2, (int)(N - w0));
+        __builtin_amdgcn_s_setprio(0);
     }
     ost[v] = phase;
     ost[V + v] = hold;
@@ -820,17 +933,12 @@ double mxg_env_coeff_host(int which, double ms) {
 // compiled reference)
 double mxg_mtof_host(int midinote) { return (midinote >= 0 && midinote <= 128) ? MAXI_MTOF[midinote] : 0.0; }
 
-int mxg_voice_render(int mode, size_t V, size_t N, const double *d_freq, const double *d_cutoff,
-                     const double *d_res, const double *d_coef, const int32_t *d_trig, int tpv,
-                     const double *d_par, const int64_t *d_holdtime, double *d_ost, double *d_fst,
-                     double *d_dst, int64_t *d_ist, double *d_out, void *stream) {
-    if (int s = ensure_init()) return s;
-    MXG_REQUIRE(mode == 0 || mode == 1, "mode must be 0 or 1");
-    MXG_REQUIRE(d_freq && d_trig && d_par && d_holdtime && d_ost && d_fst && d_dst && d_ist && d_out,
-                "null device pointer");
-    MXG_REQUIRE(mode == 1 || d_coef, "mode 0 needs d_coef from mxg_filter_coeffs_host");
-    MXG_REQUIRE(mode == 0 || (d_cutoff && d_res), "mode 1 needs d_cutoff and d_res");
-    if (V == 0 || N == 0) return MXG_OK;
+// The launch of K2f: d_pan / d_rows null = the block only; both given = the mixdown form (MIX, see voice_kernel), d_out optional.
+static int voice_launch(int mode, size_t V, size_t N, const double *d_freq, const double *d_cutoff, const double *d_res,
+                        const double *d_coef, const int32_t *d_trig, int tpv, const double *d_par, const int64_t *d_holdtime,
+                        double *d_ost, double *d_fst, double *d_dst, int64_t *d_ist, double *d_out, const double *d_pan, double *d_rows,
+                        hipStream_t st) {
+    const bool mix = d_rows != nullptr;
     int block = tune_get("voice_block");
     if (block > 256) block = 256;  // the bank kernels are compiled for <= 256 lanes per workgroup (512 VGPRs/lane budget)
     // the store stream, as K1's (osc.hip, profiles/r03_osc_store.md): knob voice_store 0 = automatic (pair rows of write-through
@@ -855,32 +963,104 @@ int mxg_voice_render(int mode, size_t V, size_t N, const double *d_freq, const d
     }
     if (store >= 2 && !pairs_ok) store = store == 4 ? 1 : 0;
     if (xcd < 0) xcd = 0;
-    hipStream_t st = resolve_stream(stream);
+    if (mix) {
+        // the mixdown form's own store knob (voice_mix_store: 0 automatic = the rule above, 1 ... 5 = voice_store's flavours)
+        const int ms = tune_get("voice_mix_store") - 1;
+        if (ms >= 0) store = (ms >= 2 && !pairs_ok) ? (ms == 4 ? 1 : 0) : ms;
+        if (!d_out) store = 5;  // no per-voice block
+        block = 512;            // 256 voices per workgroup: four producer + four consumer wavefronts
+    }
+    const dim3 grid = mix ? grid_for(V, 256) : grid_for(V, block);
     double sr = (double)settings().sampleRate;
-#define MXG_VOICE_LAUNCH(M, S, X, P)                                                               \
-    hipLaunchKernelGGL((voice_kernel<M, S, X, P>), grid_for(V, block), dim3(block), 0, st, V, N, d_freq, \
+#define MXG_VOICE_LAUNCH(M, S, X, P, MX)                                                            \
+    hipLaunchKernelGGL((voice_kernel<M, S, X, P, MX>), grid, dim3(block), 0, st, V, N, d_freq, \
                        d_cutoff, d_res, d_coef, d_trig, tpv, d_par, d_holdtime, d_ost, d_fst,   \
-                       d_dst, d_ist, d_out, sr, xcd)
-#define MXG_VOICE_LAUNCH2(M, S, X) \
-    if (tpv) MXG_VOICE_LAUNCH(M, S, X, true); else MXG_VOICE_LAUNCH(M, S, X, false)
-#define MXG_VOICE_LAUNCH3(M)                           \
-    switch (store) {                                   \
-        case 1: MXG_VOICE_LAUNCH2(M, 1, false); break; \
-        case 2: MXG_VOICE_LAUNCH2(M, 0, true); break;  \
-        case 3: MXG_VOICE_LAUNCH2(M, 2, true); break;  \
-        case 4: MXG_VOICE_LAUNCH2(M, 1, true); break;  \
-        default: MXG_VOICE_LAUNCH2(M, 0, false); break; \
+                       d_dst, d_ist, d_out, sr, xcd, d_pan, d_rows)
+#define MXG_VOICE_LAUNCH2(M, S, X, MX) \
+    if (tpv) MXG_VOICE_LAUNCH(M, S, X, true, MX); else MXG_VOICE_LAUNCH(M, S, X, false, MX)
+#define MXG_VOICE_LAUNCH3(M, MX)                           \
+    switch (store) {                                       \
+        case 1: MXG_VOICE_LAUNCH2(M, 1, false, MX); break; \
+        case 2: MXG_VOICE_LAUNCH2(M, 0, true, MX); break;  \
+        case 3: MXG_VOICE_LAUNCH2(M, 2, true, MX); break;  \
+        case 4: MXG_VOICE_LAUNCH2(M, 1, true, MX); break;  \
+        default: MXG_VOICE_LAUNCH2(M, 0, false, MX); break; \
     }
     KernelTimer kt("voice_kernel", st);
-    if (mode == 0) {
-        MXG_VOICE_LAUNCH3(0)
+    if (mix) {
+        if (store == 5) {
+            if (mode == 0) { MXG_VOICE_LAUNCH2(0, 3, false, true); } else { MXG_VOICE_LAUNCH2(1, 3, false, true); }
+        } else if (mode == 0) {
+            MXG_VOICE_LAUNCH3(0, true)
+        } else {
+            MXG_VOICE_LAUNCH3(1, true)
+        }
+    } else if (mode == 0) {
+        MXG_VOICE_LAUNCH3(0, false)
     } else {
-        MXG_VOICE_LAUNCH3(1)
+        MXG_VOICE_LAUNCH3(1, false)
     }
 #undef MXG_VOICE_LAUNCH3
 #undef MXG_VOICE_LAUNCH2
 #undef MXG_VOICE_LAUNCH
     return check_hip(hipGetLastError(), "voice_kernel launch");
+}
+
+int mxg_voice_render(int mode, size_t V, size_t N, const double *d_freq, const double *d_cutoff,
+                     const double *d_res, const double *d_coef, const int32_t *d_trig, int tpv,
+                     const double *d_par, const int64_t *d_holdtime, double *d_ost, double *d_fst,
+                     double *d_dst, int64_t *d_ist, double *d_out, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(mode == 0 || mode == 1, "mode must be 0 or 1");
+    MXG_REQUIRE(d_freq && d_trig && d_par && d_holdtime && d_ost && d_fst && d_dst && d_ist && d_out,
+                "null device pointer");
+    MXG_REQUIRE(mode == 1 || d_coef, "mode 0 needs d_coef from mxg_filter_coeffs_host");
+    MXG_REQUIRE(mode == 0 || (d_cutoff && d_res), "mode 1 needs d_cutoff and d_res");
+    if (V == 0 || N == 0) return MXG_OK;
+    return voice_launch(mode, V, N, d_freq, d_cutoff, d_res, d_coef, d_trig, tpv, d_par, d_holdtime, d_ost, d_fst, d_dst, d_ist, d_out,
+                        nullptr, nullptr, resolve_stream(stream));
+}
+
+// K2f + the fused maxiMix::stereo mixdown (C:503-509 per voice, the sum over voices of 15.polysynth/main.cpp:54-70): the block (d_out,
+// optional) and the per-workgroup rows d_rows[mxg_osc_mix_groups(V)][N][2] -- the layout of mxg_osc_render_mix_rows, what a grouped mix
+// queue's slot takes (mxg_mixq_create_grouped).
+int mxg_voice_render_mix_rows(int mode, size_t V, size_t N, const double *d_freq, const double *d_cutoff, const double *d_res,
+                              const double *d_coef, const int32_t *d_trig, int tpv, const double *d_par, const int64_t *d_holdtime,
+                              double *d_ost, double *d_fst, double *d_dst, int64_t *d_ist, double *d_out, const double *d_pan,
+                              double *d_rows, void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(mode == 0 || mode == 1, "mode must be 0 or 1");
+    MXG_REQUIRE(d_freq && d_trig && d_par && d_holdtime && d_ost && d_fst && d_dst && d_ist && d_pan && d_rows, "null device pointer");
+    MXG_REQUIRE(mode == 1 || d_coef, "mode 0 needs d_coef from mxg_filter_coeffs_host");
+    MXG_REQUIRE(mode == 0 || (d_cutoff && d_res), "mode 1 needs d_cutoff and d_res");
+    if (V == 0 || N == 0) return MXG_OK;
+    return voice_launch(mode, V, N, d_freq, d_cutoff, d_res, d_coef, d_trig, tpv, d_par, d_holdtime, d_ost, d_fst, d_dst, d_ist, d_out,
+                        d_pan, d_rows, resolve_stream(stream));
+}
+
+// The same with the mix itself as the result, d_mix[N][2]: rows in per-stream scratch + the row sum on the caller's stream.
+int mxg_voice_render_mix(int mode, size_t V, size_t N, const double *d_freq, const double *d_cutoff, const double *d_res,
+                         const double *d_coef, const int32_t *d_trig, int tpv, const double *d_par, const int64_t *d_holdtime,
+                         double *d_ost, double *d_fst, double *d_dst, int64_t *d_ist, double *d_out, const double *d_pan, double *d_mix,
+                         void *stream) {
+    if (int s = ensure_init()) return s;
+    MXG_REQUIRE(mode == 0 || mode == 1, "mode must be 0 or 1");
+    MXG_REQUIRE(d_freq && d_trig && d_par && d_holdtime && d_ost && d_fst && d_dst && d_ist && d_pan && d_mix, "null device pointer");
+    MXG_REQUIRE(mode == 1 || d_coef, "mode 0 needs d_coef from mxg_filter_coeffs_host");
+    MXG_REQUIRE(mode == 0 || (d_cutoff && d_res), "mode 1 needs d_cutoff and d_res");
+    if (N == 0) return MXG_OK;
+    hipStream_t st = resolve_stream(stream);
+    const size_t groups = (V + 255) / 256;
+    if (V == 0) return check_hip(hipMemsetAsync(d_mix, 0, N * 2 * sizeof(double), st), "voice mix memset");
+    if (groups == 1)  // a bank of one workgroup: its row IS the mix
+        return voice_launch(mode, V, N, d_freq, d_cutoff, d_res, d_coef, d_trig, tpv, d_par, d_holdtime, d_ost, d_fst, d_dst, d_ist, d_out,
+                            d_pan, d_mix, st);
+    double *rows = nullptr;  // per-stream scratch: [groups][N][2]
+    if (int s = scratch_get(SCR_OSC_MIX, st, sizeof(double) * (N * groups * 2 + 2), (void **)&rows)) return s;
+    if (int s = voice_launch(mode, V, N, d_freq, d_cutoff, d_res, d_coef, d_trig, tpv, d_par, d_holdtime, d_ost, d_fst, d_dst, d_ist, d_out,
+                             d_pan, rows, st))
+        return s;
+    return mxg_mix_rows_sum(groups, N * 2, rows, d_mix, stream);
 }
 
 }  // extern "C"

@@ -65,6 +65,12 @@ def test_two_ranks_sharing_one_gpu_print_the_scaling_fields():
     c5 = d["configs"]["config5"]
     assert "error" not in c5, c5
     assert c5["n_gpus"] == 2 and c5["value"] > 0 and c5["ms_per_step"] > 0 and c5["scaling"] == "weak"
+    # ... and so does config 3 sharded the same way: K2f with the maxiMix::stereo mixdown fused (mxg_voice_render_mix_rows), the rows folded
+    # and reduced through the grouped mix queue (round 6)
+    c3 = d["configs"]["config3"]
+    assert "error" not in c3, c3
+    assert c3["n_gpus"] == 2 and c3["value"] > 0 and c3["ms_per_step"] > 0 and c3["scaling"] == "weak" and "fused" in c3["workload"]
+    assert len(lines[0]) < 7000
 
 
 @pytest.mark.gpu
@@ -90,11 +96,14 @@ def test_default_line_carries_every_gpu_config():
     assert r.returncode == 0, (r.stderr + r.stdout)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    # the driver keeps an 8 KB tail of the line: the whole line has to fit; texts are said once (`notes`), --verbose has the rest
+    assert len(lines[0]) < 7000, len(lines[0])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["roofline"]["kernel"] == "osc_kernel" and 0.3 < d["roofline"]["frac"] < 1.0
-    assert d["roofline"]["estimator"] and 0.3 < d["roofline"]["frac_wall"] <= d["roofline"]["frac"] * 1.02
-    assert d["cpu_baseline"]["value"] > 0
+    assert d["notes"]["kernel_ms"] and 0.3 < d["roofline"]["frac_wall"] <= d["roofline"]["frac"] * 1.02
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] in ("reference", "port")
     want = {"config2_mixdown": "osc_mix_kernel", "config2_tables": "osctab_kernel", "config3": "voice_kernel", "config3_modB": "voice_kernel",
+            "config3_mixdown": "voice_kernel",
             "config4": "fft_mfcc_kernel", "config4_walk": "fft_mfcc_kernel", "config4_mfma": "fft_mfcc_kernel", "config5": "granular_unit_kernel"}
     assert set(d["configs"]) == set(want), d["configs"].keys()
     for name, kernel in want.items():
@@ -103,6 +112,7 @@ def test_default_line_carries_every_gpu_config():
         assert c["ms_per_step"] > 0 and c["value"] > 0 and c["roofline"]["kernel"] == kernel, c
         assert 0.0 < c["roofline"]["frac"] < 1.0 and c["roofline"]["kernel_ms"] <= c["ms_per_step"] * 1.001, c
         assert ("matrix_pipe" in c["roofline"]) == (name in ("config4_mfma", "config4_walk")), c["roofline"].keys()
+        assert len(c["workload"]) <= 120
         if name != "config2_tables":  # (the per-voice-table extension has no reference CPU path to time)
             assert c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["kind"] in ("reference", "port"), c.get("cpu_baseline")
     # the matrix-pipe form of config 4 is the library's default when only the coefficients are requested: the two entries measure the same kernel
@@ -114,3 +124,6 @@ def test_default_line_carries_every_gpu_config():
     # (against the headline's GPU-side step time: at the driver's 20 steps the wall-clock figure carries ~3 us of fence per step)
     # (a regression guard, not the claim: measured 1.07-1.27 by box -- K1 39.9-44.6 us, the mixdown step 47.5-51.7; round 3: 1.32)
     assert d["configs"]["config2_mixdown"]["ms_per_step"] < 1.3 * d["step_ms_gpu"], (d["configs"]["config2_mixdown"], d["step_ms_gpu"])
+    # config 3's N > 1 step on one GPU (K2f with the mixdown fused, producer / consumer wavefronts): VERDICT r05 #1 asks <= 1.15 x config 3's
+    # own step (measured 1.10); the guard leaves room for a box's mood
+    assert d["configs"]["config3_mixdown"]["step_vs_config3"] < 1.25, d["configs"]["config3_mixdown"]

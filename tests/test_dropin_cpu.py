@@ -70,7 +70,7 @@ def test_device_failure_is_one_printed_line_and_silence(tmp_path):
 
 @pytest.mark.parametrize("flags", [[], ["-DMAXIGPU_THROW"], ["-fno-exceptions", "-DMAXIGPU_NO_EXCEPTIONS"]])
 def test_header_builds_in_every_failure_mode(flags):
-    for patch in ("public_members_patch.cpp", "convolve_sampler_patch.cpp", "granular_patch.cpp"):
+    for patch in ("public_members_patch.cpp", "convolve_sampler_patch.cpp", "granular_patch.cpp", "refused_call_patch.cpp"):
         r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wno-unused-variable", "-I" + os.path.join(ROOT, "include")] + flags +
                            [os.path.join(ROOT, "tests", "patches", patch)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-3000:]

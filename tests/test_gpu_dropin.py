@@ -280,3 +280,18 @@ def test_public_members_and_value_semantics_patch_bit_exact(golden, tmp_path):
     assert err <= 1e-12 * max(1.0, np.abs(g["exp5_l"]).max())
     assert_bits_equal(got[:, 1], g["exp5_r"], "envelopes and samples: members, copies")
     assert np.abs(g["exp5_r"]).max() > 0.5
+
+
+def test_refused_call_silences_that_object_only(golden, tmp_path):
+    """ADVICE r05: an argument the C-ABI refuses (MXG_ERR_INVALID: maxiTimeStretch::play with ten overlapping grains -- the renderer
+    holds eight -- then overlaps = 0) is NOT a device failure: one printed line per call site, that call returns silence, and every
+    other unit generator plays on -- the left channel is still cpp/commandline/main.cpp's sinewave(440) stream, to the ULP."""
+    frames = 12000
+    got, log = run_dropin("p6", frames, tmp_path)
+    exp = golden("dropin.npz")["ex01"][:frames, 0]
+    assert ulp_diff(got[:, 0], exp).max() <= 1
+    # (the first eight grains are fine -- one spawn per 220.5 samples -- and play as in the reference; the ninth spawn is refused, and from
+    # there on, and through the overlaps = 0 calls from frame 6000, the object is silent)
+    assert got[:1500, 1].any() and not got[2100:, 1].any(), "the refused granular calls return silence"
+    assert "the device path is off" not in log, log
+    assert 1 <= log.count("this call returns silence") <= 4, log

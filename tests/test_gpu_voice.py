@@ -406,6 +406,89 @@ def test_voice_store_streams_same_bits(mx, port, store, xcd, V, N, mode, tpv):
     del rng
 
 
+@pytest.mark.parametrize("V,N", [(700, 301), (64, 8), (2050, 512), (701, 77), (4096, 1000), (256, 1), (300, 13), (33000, 48), (1024, 1536)])
+@pytest.mark.parametrize("mode,tpv", [(0, False), (0, True), (1, False)])
+def test_voice_render_mix_fused(mx, port, V, N, mode, tpv):
+    """mxg_voice_render_mix / _mix_rows (K2f + the fused maxiMix::stereo mixdown, producer / consumer wavefront pairs): the per-voice
+    block and every state array get mxg_voice_render's bits = the oracle's (mode A) over two carried blocks; the mix is within the
+    stated tolerance of the reference's sequential sum (C:503-509 voice after voice, 15.polysynth/main.cpp:54-70); the mix-only form,
+    every store stream and the rows form give the same mix bits.  Banks with a partial last wavefront / workgroup, odd banks, blocks
+    that are not multiples of the 8-sample chunk, the 16-sample tile or the 512-sample window."""
+    L = mx.lib()
+    v = np.arange(V)
+    freq, cutoff, res = 50.0 + 7.0 * (v % 600), 300.0 + 5.0 * (v % 800), 1.0 + (v % 5)
+    pan = np.random.default_rng(V * 7 + N).uniform(-0.1, 1.1, V)
+    trig = ((np.arange(N) % 130) < 70).astype(np.int32)
+    if tpv:
+        trig = (((np.arange(N)[:, None] + 3 * v[None, :]) % 130) < 70).astype(np.int32)
+    cu = cutoff if mode == 0 else np.full(V, 9000.0)
+
+    def bank():
+        vb = mx.maxiVoiceBank(V)
+        vb.env.setAttack(1); vb.env.setDecay(5); vb.env.setSustain(0.5); vb.env.setRelease(20)
+        return vb
+
+    def state(vb):
+        return [vb.osc_state.numpy(), vb.flt_state.numpy(), vb.env.dstate.numpy(), vb.env.istate.numpy().astype(np.float64)]
+    ref = bank()
+    plain = [ref.render(mode, freq, cu, res, trig, N).numpy() for _ in range(2)]
+    vb = bank()
+    got, mixes = [], []
+    for _ in range(2):
+        o, m = vb.render_mix(mode, freq, cu, res, trig, pan, N)
+        got.append(o.numpy()); mixes.append(m.numpy())
+    for k in range(2):
+        assert_bits_equal(got[k], plain[k], "block %d: the mixdown form against mxg_voice_render" % k)
+    for a, b, name in zip(state(vb), state(ref), ("osc", "filter", "env double", "env int")):
+        assert_bits_equal(a, b, name + " state")
+    t2 = np.concatenate([trig, trig])
+    e = port.voice(mode, freq, cu, res, t2, vb.env.par, vb.env.holdtime)[0]
+    o2 = np.concatenate(got)
+    if mode == 0:
+        assert_bits_equal(o2, e, "mixdown form against the oracle")
+    else:
+        assert_close_scaled(o2, e, 1e-11, "mixdown form mode B")
+    # the mix against the reference's order of additions over the DEVICE's per-voice values (mode B's are within 1e-11 of the oracle's)
+    fin = np.where(np.isfinite(o2), o2, 0.0)
+    if np.isfinite(o2).all():
+        em = port.mix_stereo(o2, pan)
+        assert np.abs(np.concatenate(mixes) - em).max() <= mix_tol(V, np.abs(fin).max(), sums=em)
+    # mix only (no per-voice block), every store stream, the rows form: the same additions in the same tree
+    vb2 = bank()
+    for k in range(2):
+        none, m = vb2.render_mix(mode, freq, cu, res, trig, pan, N, store=False)
+        assert none is None
+        assert_bits_equal(m.numpy(), mixes[k], "mix-only form, block %d" % k)
+    for a, b, name in zip(state(vb2), state(ref), ("osc", "filter", "env double", "env int")):
+        assert_bits_equal(a, b, name + " state, mix-only form")
+    for store in (1, 2, 3, 4, 5):
+        prev = L.mxg_tune(b"voice_mix_store", store)
+        try:
+            vb3 = bank()
+            for k in range(2):
+                o, m = vb3.render_mix(mode, freq, cu, res, trig, pan, N)
+                assert_bits_equal(o.numpy(), plain[k], "voice_mix_store %d block %d" % (store, k))
+                assert_bits_equal(m.numpy(), mixes[k], "voice_mix_store %d mix %d" % (store, k))
+        finally:
+            L.mxg_tune(b"voice_mix_store", prev)
+    G = L.mxg_osc_mix_groups(V)
+    rows = mx.DeviceBuffer((G, N, 2), np.float64)
+    vb4 = bank()
+    o, none = vb4.render_mix(mode, freq, cu, res, trig, pan, N, rows=rows)
+    assert none is None
+    assert_bits_equal(o.numpy(), plain[0], "rows form, block")
+    m4 = mx.DeviceBuffer((N, 2), np.float64)
+    mx._lib.check(L.mxg_mix_rows_sum(G, N * 2, rows.ptr, m4.ptr, None), "mxg_mix_rows_sum")
+    assert_bits_equal(m4.numpy(), mixes[0], "rows form, mix")
+    # every row is the sum of ITS 256 voices
+    r = rows.numpy()
+    if np.isfinite(o2).all():
+        for g in sorted({0, G // 2, G - 1}):
+            sl = slice(256 * g, min(V, 256 * (g + 1)))
+            eg = port.mix_stereo(got[0][:, sl], pan[sl])
+            assert np.abs(r[g] - eg).max() <= mix_tol(256, np.abs(got[0][:, sl]).max(), sums=eg)
+
+
 def test_env_arbitrary_uploaded_flags(mx, port):
     """maxiEnv's five phase members are plain ints a host may set to anything (state upload): with flags drawn from
     {0, 1, 2} -- several set at once, none set, values that are neither 0 nor 1 -- and a shared gate (so the wave-uniform
