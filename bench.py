@@ -278,6 +278,8 @@ def main():
     mx.maxiSettings.setup(44100, 2, 1024)
     for kv in args.tune:
         k, v = kv.split("=")
+        if k.startswith("tables_"):  # (bench switches, not library knobs)
+            continue
         chk(L.mxg_tune(k.encode(), int(v)), "mxg_tune " + kv)
     dev = torch.device("cuda", local)
     # Launch on a non-default torch stream (the C-ABI treats a NULL stream as "the library's own stream").
@@ -423,10 +425,18 @@ def main():
             rowst = torch.zeros((Gt, B, 2), dtype=torch.float64, device=dev)
             mixt = torch.zeros((B, 2), dtype=torch.float64, device=dev)
 
+            tk = dict(kv.split("=") for kv in args.tune)  # (A/B switches of this bench, not library knobs: tables_ahead, tables_sum)
+            # (measured, one box, 131 072 voices: serial 146 us; pipelined 120; row sum inside the kernel +8.5 us on either -- its two
+            # cross-XCD hand-offs are write-through round trips -- so the step keeps the 6-us row-sum kernel: profiles/r06_k1t.md)
+            t_ahead, t_sum = int(tk.get("tables_ahead", 1)), int(tk.get("tables_sum", 0))
+
             def step_tables():
-                chk(L.mxg_osc_render_tables(Vt, B, ft.data_ptr(), tabs.data_ptr(), pht.data_ptr(), hdt.data_ptr(), None, pt.data_ptr(),
-                                            rowst.data_ptr(), stream), "mxg_osc_render_tables")
-                chk(L.mxg_mix_rows_sum(Gt, B * 2, rowst.data_ptr(), mixt.data_ptr(), stream), "mxg_mix_rows_sum")
+                # round 6: pipelined blocks -- the next block's phase recurrence walks beside this block's table traffic (tables_ahead=0:
+                # round 5's marks kernel in front of every render); tables_sum=1: the row sum inside the render kernel
+                chk(L.mxg_osc_render_tables_ex(Vt, B, ft.data_ptr(), tabs.data_ptr(), pht.data_ptr(), hdt.data_ptr(), None, pt.data_ptr(),
+                                               rowst.data_ptr(), mixt.data_ptr() if t_sum else None, t_ahead, stream), "mxg_osc_render_tables_ex")
+                if not t_sum:
+                    chk(L.mxg_mix_rows_sum(Gt, B * 2, rowst.data_ptr(), mixt.data_ptr(), stream), "mxg_mix_rows_sum")
             W = dict(step=step_tables, samples=Vt * B, dominant="osctab_kernel", algo_bytes=Vt * (514 * 8.0 + 24.0), dtype="f64", cpu=None,
                      tag="EXTENSION: %d-voice sinebuf bank, one 514-entry table PER VOICE (HBM-read form), fused mixdown out" % Vt,
                      local_step=None,

@@ -160,7 +160,7 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * 3 / 4 / 5 two samples of a lane pair exchanged into one 16-byte store per lane, plain / write-through (sc1) / non-temporal; two
  * voices per lane: 1 plain, 2 non-temporal, 3 write-through 16-byte stores), "voice_store" / "voice_xcd" (the same for the fused voice kernel; one voice
  * per lane only), "voice_mix_store" (the store stream of mxg_voice_render_mix*: 0 automatic = "voice_store"'s rule, 1 ... 5 its flavours),
- * "osc_xcd" (workgroups renumbered so that each of the eight XCDs renders
+ * "grain_spin_limit" (see mxg_granular_retries), "osc_xcd" (workgroups renumbered so that each of the eight XCDs renders
  * one contiguous eighth of the bank: 0 automatic, 1 off, 2 on), "grain_sync" (mxg_granular_render reads its error word back before it returns, 0|1;
  * default 0: deferred, see mxg_last_async_error), "part_spin_limit" (polls a time-split kernel's writer part makes before it gives up
  * and reports through mxg_last_async_error), "part_fault" (test-only fault injection: that writer waits for a signal that never comes).
@@ -181,6 +181,11 @@ int mxg_tune(const char *key, int value);
  * "rw_store" (mxg_tune) is documented with the render entry points that honour it (maxiFilter, maxiEnv, maxiDelayline, maxiSample,
  * maxiEnvGen, filter2: 0 automatic, 1 8-byte streams, 2 / 3 / 4 16-byte pair rows with plain / write-through / non-temporal stores). */
 int mxg_last_async_error(void);
+/* Streamed granular launches (mxg_granular_render*, one-launch form) whose tile renders gave up waiting for the scheduler workgroups of
+ * their own launch -- a pre-empted or partitioned device -- and were therefore rendered AGAIN by the kernel that follows every such
+ * launch (the renderer-alone form over the completed lists: the same bits, no silence, no error).  A statistic: 0 on a healthy device.
+ * Counted when the call's last kernel has run.  Knob "grain_spin_limit" (polls without progress before a render gives up; 0 = 2^22). */
+int mxg_granular_retries(void);
 
 /* ---- maxiOsc bank -------------------------------------------------------------------- */
 /* Renders out[n][v] = bank[v].<waveform>(freq) for n < N, exactly as N consecutive per-sample
@@ -242,6 +247,18 @@ int mxg_mix_rows_sum(size_t groups, size_t count, const double *d_rows, double *
 size_t mxg_osc_tables_groups(size_t V);
 int mxg_osc_render_tables(size_t V, size_t N, const double *d_freq, const double *d_tables, double *d_phase,
                           double *d_outhold, double *d_out, const double *d_pan, double *d_rows, void *stream);
+/* The same render with two additions (round 6), each optional and neither changing a bit of the block, the rows or the carried phase:
+ *   d_mix [N][2] (needs d_pan + d_rows): the sum of the rows, formed INSIDE the render kernel by the workgroups that finish last --
+ *     mxg_mix_rows_sum's additions in its order, no second launch;
+ *   flags & MXG_TABLES_AHEAD: pipelined blocks.  The phase recurrence of a block (512 dependent steps per voice) has to run before
+ *     the block's tables are rendered; with this flag the render of block k also walks block k + 1's, beside its table traffic, so
+ *     from the second call on a call is ONE kernel.  The caller's promise: the next call on this stream has the same V and N, the same
+ *     d_freq / d_pan (pointers AND contents) and d_phase untouched in between.  A call that breaks the pattern (other arguments, no
+ *     flag) is still correct as long as d_phase was not written: d_phase always holds the phase after the last rendered block.
+ *     Banks of more than 512 voices per workgroup (131 072 on a 256-CU device) ignore the flag. */
+#define MXG_TABLES_AHEAD 1
+int mxg_osc_render_tables_ex(size_t V, size_t N, const double *d_freq, const double *d_tables, double *d_phase, double *d_outhold,
+                             double *d_out, const double *d_pan, double *d_rows, double *d_mix, int flags, void *stream);
 
 /* ---- maxiFilter bank ------------------------------------------------------------------ */
 /* d_st = [5][V]: x, y, outputs[0], outputs[1], outputs[2] (H:289-302), in/out.

@@ -61,6 +61,8 @@ SIGNATURES = {
     "mxg_mix_rows_sum": (c_int, [c_size_t, c_size_t, c_void_p, c_void_p, c_void_p]),
     "mxg_osc_tables_groups": (c_size_t, [c_size_t]),
     "mxg_osc_render_tables": (c_int, [c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mxg_osc_render_tables_ex": (c_int, [c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_int, c_void_p]),
     "mxg_filter_render": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_int, c_void_p,
                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mxg_filter_render_coefs": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -146,6 +148,7 @@ SIGNATURES = {
     "mxg_comm_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "mxg_mix_reduce": (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int, c_void_p]),
+    "mxg_granular_retries": (c_int, []),
     "mxg_mixq_create": (c_void_p, [c_void_p, c_size_t, c_int, c_int]),
     "mxg_mixq_create_grouped": (c_void_p, [c_void_p, c_size_t, c_int, c_int, c_size_t]),
     "mxg_mixq_destroy": (c_int, [c_void_p]),

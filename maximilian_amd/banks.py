@@ -177,9 +177,30 @@ class maxiOscBank(_Bank):
         self._keep = (f, a, b, pn)
         return out, mix
 
-    def sinebuf_tables(self, freq, tables, N, pan=None, store=True, out=None):
+    def sinebuf_tables(self, freq, tables, N, pan=None, store=True, out=None, ahead=False, fused_sum=False):
         """EXTENSION: sinebuf with a 514-entry table per voice (mxg_osc_render_tables).  tables: [V][514] (numpy or device).
-        Returns (out [N,V] or None, mix [N,2] or None): the mix is formed from the kernel's partial rows with mxg_mix_rows_sum."""
+        Returns (out [N,V] or None, mix [N,2] or None): the mix is formed from the kernel's partial rows with mxg_mix_rows_sum, or
+        (fused_sum) inside the render kernel.  ahead: the pipelined form (MXG_TABLES_AHEAD): freq / pan must then be the SAME device
+        buffers from call to call (pass DeviceBuffers) and self.phase untouched in between."""
+        if ahead or fused_sum:
+            f = _as_dev(freq, self.V)
+            tb = tables if isinstance(tables, DeviceBuffer) or hasattr(tables, "data_ptr") else DeviceBuffer.from_numpy(
+                np.ascontiguousarray(tables, np.float64))
+            out = self._out(N, out) if store else None
+            pn = rows = mix = None
+            if pan is not None:
+                pn = _as_dev(pan, self.V)
+                G = lib().mxg_osc_tables_groups(self.V)
+                rows = DeviceBuffer((G, N, 2), np.float64)
+                mix = DeviceBuffer((N, 2), np.float64, zero=False)
+            check(lib().mxg_osc_render_tables_ex(self.V, N, _ptr(f), _ptr(tb), self.phase.ptr, self.output.ptr, _ptr(out), _ptr(pn), _ptr(rows),
+                                                 _ptr(mix) if (fused_sum and mix is not None) else None, 1 if ahead else 0, self.stream),
+                  "mxg_osc_render_tables_ex")
+            if pan is not None and not fused_sum:
+                check(lib().mxg_mix_rows_sum(G, N * 2, rows.ptr, mix.ptr, self.stream), "mxg_mix_rows_sum")
+            self._keep = (f, tb, pn, rows)
+            self.last_rows = rows
+            return out, mix
         f = _as_dev(freq, self.V)
         tb = tables if isinstance(tables, DeviceBuffer) or hasattr(tables, "data_ptr") else DeviceBuffer.from_numpy(
             np.ascontiguousarray(tables, np.float64))

@@ -566,6 +566,9 @@ struct UnitArgs {
     // enqueued and the one whose `want` differs from *sel returns at once -- no read-back, no host synchronisation
     const int *sel;
     int want;
+    // streamed form: the stream's retry word (set by a tile render that gave up polling) and the polling budget
+    int *retry;
+    int spin_limit;
 };
 __device__ __forceinline__ bool unit_args_skip(const UnitArgs &A) { return A.sel && (*A.sel != 0) != (A.want != 0); }
 
@@ -698,17 +701,23 @@ __global__ __launch_bounds__(64) void granular_unit_state_kernel(UnitArgs A) {
 // its tile have published the two chunk-table rows it reads (Q.prog).  Workgroups are dispatched in index order, so the scheduler
 // wavefronts are resident before the first renderer polls; the scheduler needs about half the time the renders need (0.41 us
 // against 0.79 us per tile row on config 5), so after the first few rows nobody waits.  A renderer that sees no progress for
-// kStreamSpin polls reports error 6 and renders silence instead of reading rows that do not exist yet.
+// its polling budget gives up (its tile stays silent for the moment) and raises the retry word: see below.
 // (Before: four time slices on two streams -- the cross-queue event hops, the first slice's scheduler and the launch gaps between
 // the slices were ~10 % of the config-5 step, profiles/r05_config5_timeline.md.)
+// Round 6: a time-out no longer ends in silence.  The tile that gave up raises the stream's RETRY word (A.retry) instead of an error; when
+// the launch has ended the lists are complete whatever happened (the scheduler workgroups got their turn at the latest once the
+// renderers had given up), and the retry kernel that follows every streamed launch (granular_retry_kernel: a small persistent grid that
+// returns at once while the word is zero) renders the call's tiles again with the renderer-alone form -- the sliced form's kernels, the
+// same bits.  Knob "grain_spin_limit" lowers the polling budget (tests force the path with it); mxg_granular_retries() counts them.
 constexpr int kStreamSpin = 1 << 22;
 template <int SMODE>
-__global__ __launch_bounds__(256, 4) void granular_unit_kernel(UnitArgs A, SchedArgs Q, int *prog, unsigned nsched) {
+__device__ __forceinline__ void granular_unit_body(const UnitArgs &A, const SchedArgs &Q, int *prog, const unsigned nsched, const unsigned bxi,
+                                                   const unsigned byi) {
     constexpr bool COH = SMODE >= 0;
-    unsigned bx = blockIdx.x, by = blockIdx.y;
+    unsigned bx = bxi, by = byi;
     if constexpr (COH) {
-        if (blockIdx.x < nsched) {
-            const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+        if (bxi < nsched) {
+            const size_t s = (size_t)bxi * 256 + threadIdx.x;
             if (s >= A.S) return;
             if (unit_args_skip(A)) return;  // (both renderers are enqueued and the other one was picked: it schedules, too)
             __builtin_amdgcn_s_setprio(3);
@@ -716,7 +725,7 @@ __global__ __launch_bounds__(256, 4) void granular_unit_kernel(UnitArgs A, Sched
             unit_state_lane<true>(A, s);
             return;
         }
-        const unsigned idx = blockIdx.x - nsched, stiles = (unsigned)((A.S + 63) / 64);
+        const unsigned idx = bxi - nsched, stiles = (unsigned)((A.S + 63) / 64);
         bx = idx % stiles;
         by = idx / stiles;
     }
@@ -741,13 +750,13 @@ __global__ __launch_bounds__(256, 4) void granular_unit_kernel(UnitArgs A, Sched
                 if (__all(have >= need)) break;
                 if (__any(have != seen)) spins = 0;  // some stream moved: the count is of polls WITHOUT progress
                 seen = have;
-                if (++spins > kStreamSpin) {
+                if (++spins > A.spin_limit) {
                     listed = false;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(16);
             }
-            if (!listed && threadIdx.x == 0) atomicMax(A.err, 6);
+            if (!listed && threadIdx.x == 0) __hip_atomic_store(A.retry, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // ---- phase 1: one lane per stream collects that stream's candidate grains (creation order) in LDS,
@@ -1022,6 +1031,10 @@ __global__ __launch_bounds__(256, 4) void granular_unit_kernel(UnitArgs A, Sched
     __syncthreads();
     tile_epilogue(A, s_tile, s0, n0, lane, wave, bx);
 }
+template <int SMODE>
+__global__ __launch_bounds__(256, 4) void granular_unit_kernel(UnitArgs A, SchedArgs Q, int *prog, unsigned nsched) {
+    granular_unit_body<SMODE>(A, Q, prog, nsched, blockIdx.x, blockIdx.y);
+}
 
 // ---- K8d: tile render for arbitrary increments (maxiStretch, maxiPitchShift, maxiTimeStretch off the integer grid) ------
 // K8b gives a lane one (stream, chunk) and walks it in time: every wavefront load touches 64 different grains, i.e. 64
@@ -1125,12 +1138,13 @@ constexpr int kLineBatch = 4;  // pairs whose gathers are in flight together (4 
 // SMODE as for granular_unit_kernel: < 0 the renderer alone, 0 .. 3 the streamed form of that scheduler mode (1-D grid: `nsched`
 // scheduler workgroups, then one workgroup per (stream tile, span of ltiles tiles), spans in dispatch order).
 template <int SMODE>
-__global__ __launch_bounds__(256, 3) void granular_line_kernel(UnitArgs A, SchedArgs Q, int *prog, unsigned nsched) {
+__device__ __forceinline__ void granular_line_body(const UnitArgs &A, const SchedArgs &Q, int *prog, const unsigned nsched, const unsigned bxi,
+                                                   const unsigned byi) {
     constexpr bool COH = SMODE >= 0;
-    unsigned bx = blockIdx.x, by = blockIdx.y;
+    unsigned bx = bxi, by = byi;
     if constexpr (COH) {
-        if (blockIdx.x < nsched) {
-            const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+        if (bxi < nsched) {
+            const size_t s = (size_t)bxi * 256 + threadIdx.x;
             if (s >= A.S) return;
             if (unit_args_skip(A)) return;  // (both renderers are enqueued and the other one was picked: it schedules, too)
             __builtin_amdgcn_s_setprio(3);
@@ -1138,7 +1152,7 @@ __global__ __launch_bounds__(256, 3) void granular_line_kernel(UnitArgs A, Sched
             line_state_lane<true>(A, s);
             return;
         }
-        const unsigned idx = blockIdx.x - nsched, stiles = (unsigned)((A.S + 63) / 64);
+        const unsigned idx = bxi - nsched, stiles = (unsigned)((A.S + 63) / 64);
         bx = idx % stiles;
         by = idx / stiles;
     }
@@ -1168,13 +1182,13 @@ __global__ __launch_bounds__(256, 3) void granular_line_kernel(UnitArgs A, Sched
                 if (__all(have >= need)) break;
                 if (__any(have != seen)) spins = 0;  // some stream moved: the count is of polls WITHOUT progress
                 seen = have;
-                if (++spins > kStreamSpin) {
+                if (++spins > A.spin_limit) {
                     listed = false;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(16);
             }
-            if (!listed && threadIdx.x == 0) atomicMax(A.err, 6);
+            if (!listed && threadIdx.x == 0) __hip_atomic_store(A.retry, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     auto set_age = [&](LineCand &q, const long long kb) {  // age at the current tile's first sample (< 0: not born yet)
@@ -1395,6 +1409,24 @@ __global__ __launch_bounds__(256, 3) void granular_line_kernel(UnitArgs A, Sched
         __syncthreads();  // the tile and the candidate list are reused by the next tile of the span
     }
 }
+template <int SMODE>
+__global__ __launch_bounds__(256, 3) void granular_line_kernel(UnitArgs A, SchedArgs Q, int *prog, unsigned nsched) {
+    granular_line_body<SMODE>(A, Q, prog, nsched, blockIdx.x, blockIdx.y);
+}
+
+// The retry of a streamed launch whose renderers gave up (see granular_unit_body): grid = (stream tiles, a few rows), every workgroup
+// returns at once unless the stream's retry word is set; otherwise it renders rows blockIdx.y, blockIdx.y + gridDim.y, ... of the call
+// with the renderer-alone form (rows = tiles for K8c, spans of ltiles tiles for K8d) -- ALL of them, so that nothing depends on which
+// tiles had given up.  The lists are complete: this kernel starts after the streamed launch has ended.
+template <bool LINE>
+__global__ __launch_bounds__(256) void granular_retry_kernel(UnitArgs A, SchedArgs Q, unsigned rows) {
+    if (__hip_atomic_load(A.retry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    for (unsigned by = blockIdx.y; by < rows; by += gridDim.y) {
+        if constexpr (LINE) granular_line_body<-1>(A, Q, nullptr, 0u, blockIdx.x, by);
+        else granular_unit_body<-1>(A, Q, nullptr, 0u, blockIdx.x, by);
+        __syncthreads();
+    }
+}
 
 // The first kernel of a chunked call: keeps a copy of the carried-in grains (the renders read the copy, the state kernels
 // overwrite d_gst while they run), clears the streamed form's progress words and, with `check`, decides K8c's eligibility: every live carried-in grain must have
@@ -1506,8 +1538,11 @@ int mxg_grain_plan_window(const mxg_grain_plan *p, double *h_window) {
 __global__ void grain_err_publish_kernel(int *err, int *async_word) {
     const int e = err[0];
     if (e && async_word) __hip_atomic_store(async_word, (int)mxg::ASYNC_GRAIN_BASE + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // a streamed launch that was rendered again (err[2]): counted in the word behind the async error word (mxg_granular_retries)
+    if (err[2] && async_word) __hip_atomic_fetch_add(async_word + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     err[0] = 0;
     err[1] = 0;
+    err[2] = 0;
 }
 
 static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, size_t T, const double *d_samples,
@@ -1550,8 +1585,8 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
     int *g_err = nullptr;  // per-stream words: the render's error | K8c eligibility.  Zero between calls: the publish kernel that ends a
                            // call clears them (the synchronous A/B path: a memset after its read-back), so only a new allocation pays a memset.
     bool err_fresh = false;
-    if (int s = scratch_get(SCR_GRAIN_ERR, st, 2 * sizeof(int), (void **)&g_err, &err_fresh)) return s;
-    if (err_fresh) MXG_HIP(hipMemsetAsync(g_err, 0, 2 * sizeof(int), st));
+    if (int s = scratch_get(SCR_GRAIN_ERR, st, 4 * sizeof(int), (void **)&g_err, &err_fresh)) return s;  // (+ the streamed form's retry word)
+    if (err_fresh) MXG_HIP(hipMemsetAsync(g_err, 0, 4 * sizeof(int), st));
     GrainArgs A;
     A.S = S; A.T = T; A.len = len; A.R = R;
     A.amp = d_samples; A.window = p->d_window; A.a = d_a; A.b = d_b; A.posMod = d_posmod;
@@ -1649,6 +1684,8 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         U.mixpart = nullptr;
         U.sel = both ? g_err + 1 : nullptr;
         U.want = 0;
+        U.retry = g_err + 2;
+        U.spin_limit = tune_get("grain_spin_limit") > 0 ? tune_get("grain_spin_limit") : kStreamSpin;
         const size_t stiles = (S + 63) / 64;
         if ((unit || line) && d_pan) {
             if (int e = scratch_get(SCR_GRAIN_MIX, st, sizeof(double) * stiles * T * 2, (void **)&U.mixpart)) return e;
@@ -1683,6 +1720,8 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
                 case 2: hipLaunchKernelGGL((granular_line_kernel<2>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched); break;
                 default: hipLaunchKernelGGL((granular_line_kernel<3>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched); break;
             }
+            const unsigned rows = (unsigned)((C + lt - 1) / lt);  // the retry (returns at once unless a render gave up)
+            hipLaunchKernelGGL((granular_retry_kernel<true>), dim3((unsigned)stiles, rows < 24u ? rows : 24u), dim3(256), 0, st, U, Q, rows);
         };
         if (streamed && unit) {
             // K8c, one launch: scheduler lanes and tile renders side by side (granular_unit_kernel<SMODE>), on the caller's stream.
@@ -1700,6 +1739,8 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
                 } else {
                     hipLaunchKernelGGL((granular_unit_kernel<2>), g, dim3(256), 0, st, U, Q, prog, (unsigned)nsched);
                 }
+                const unsigned rows = (unsigned)C;  // the retry (returns at once unless a render gave up)
+                hipLaunchKernelGGL((granular_retry_kernel<false>), dim3((unsigned)stiles, rows < 32u ? rows : 32u), dim3(256), 0, st, U, Q, rows);
             }
             if (U.pan) {
                 mix_partials_launch(st, stiles, T * 2, U.mixpart, d_mix);
@@ -1844,7 +1885,7 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
     }
     int herr = 0;
     MXG_HIP(hipMemcpyAsync(&herr, g_err, sizeof(int), hipMemcpyDeviceToHost, st));
-    MXG_HIP(hipMemsetAsync(g_err, 0, 2 * sizeof(int), st));  // (the words are zero between calls)
+    MXG_HIP(hipMemsetAsync(g_err, 0, 4 * sizeof(int), st));  // (the words are zero between calls)
     MXG_HIP(hipStreamSynchronize(st));
     if (herr) return async_error_status(ASYNC_GRAIN_BASE + herr);
     return MXG_OK;

@@ -20,6 +20,9 @@
 // measured form is the fused maxiMix::stereo mixdown (C:503-509 + the user's sum over voices): the 16 voices of a round sit in the 16
 // lanes of a DPP row, a transposing butterfly (mxg_lanefold.h) turns 16 samples x 16 voices into 16 sums, and every lane keeps the
 // running sum of ITS sample over all rounds in registers; the per-workgroup rows [workgroup][N][2] are added by mix_partials_kernel.
+#include <map>
+#include <mutex>
+
 #include "mxg_common.h"
 #include "mxg_lanefold.h"
 #include "mxg_osc.h"
@@ -69,8 +72,9 @@ __device__ __forceinline__ bool wrap_threshold(const double inc, double &thr) {
 // group of 8 voices ONE contiguous header: the phase at the start of each 32-sample part, the increment, the two gains.  The main
 // kernel fetches it with the group's tables, by DMA: no ordinary load in its loop (hipcc waits vmcnt(0) at the use of one while
 // LDS-DMA pieces are in flight, which would drain the ring every round).
+// phase_out: where the phase after the block goes -- phase_io itself, or (the pipelined form, below) the carry array.
 __global__ void osctab_marks_kernel(size_t V, size_t N, const double *__restrict__ freq, const double *__restrict__ pan,
-                                    double *__restrict__ phase_io, double *__restrict__ hdr, double sr) {
+                                    const double *__restrict__ phase_io, double *__restrict__ phase_out, double *__restrict__ hdr, double sr) {
     const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
     double *h = hdr + (v / kTabVoices) * kTabHdr;
@@ -133,7 +137,43 @@ __global__ void osctab_marks_kernel(size_t V, size_t N, const double *__restrict
             }
         }
     }
-    phase_io[v] = ph;
+    phase_out[v] = ph;
+}
+
+// ---- the marks pass ONE BLOCK AHEAD, inside the render kernel (round 6) ---------------------------------------------------------------
+// Block k + 1's marks need only block k's: they do not have to sit in front of their own render.  In the pipelined form
+// (mxg_osc_render_tables_ex, flag MXG_TABLES_AHEAD) the render kernel of block k ALSO runs the recurrence of block k + 1: the workgroup
+// that renders voice groups [g0, g1) has 512 lanes and at most 512 voices, so lane j walks voice 8 g0 + j -- 16 steps per pair of
+// rounds, at the end of the iteration, where the wavefront would otherwise wait for the next pair's DMA -- and leaves that voice's
+// marks, increment and gains in the OTHER header buffer.  No second kernel, no second stream, no event.  The caller's promise: the next
+// call comes with the same V, N, frequencies and pans and has not touched d_phase in between; a call that does not match (or comes
+// without the flag) finds d_phase holding the phase after the last RENDERED block and starts over with the marks kernel above.
+// carry[v]: in = the phase block k + 1 starts from (left by the previous launch's duty, or by the marks kernel), out = where it ends.
+struct TabAhead {
+    const double *freq, *pan;
+    double *carry, *phase_io, *hdr_next;
+    double sr;
+};
+// The row sum inside the render kernel (mix != null): the workgroup that finishes LAST among those whose index is w mod 16 adds their
+// rows in index order -- mix_partials_kernel's chain w (mxg_lanefold.h) -- and the last of those sixteen adds the chains left to right:
+// the additions of mxg_mix_rows_sum in its order, the same bits, without a second launch.  tickets: 17 counters, zero between launches
+// (the workgroup that completes a count resets it); chains: [16][N][2].
+struct TabSum {
+    double *mix, *chains;
+    int *tickets;
+};
+// sixteen steps of C:269-270 (the marks kernel's three-instruction step; `live` = the EXEC mask to restore)
+__device__ __forceinline__ void marks_steps16(double &ph, const double inc, const unsigned long long live) {
+    const double c511 = 511.0, cm512 = -512.0;
+#pragma unroll
+    for (int k = 0; k < 16; k += 4)
+        asm volatile("v_add_f64 %0, %0, %1\n\tv_cmpx_le_f64 %2, %0\n\tv_add_f64 %0, %0, %3\n\ts_mov_b64 exec, %4\n\t"
+                     "v_add_f64 %0, %0, %1\n\tv_cmpx_le_f64 %2, %0\n\tv_add_f64 %0, %0, %3\n\ts_mov_b64 exec, %4\n\t"
+                     "v_add_f64 %0, %0, %1\n\tv_cmpx_le_f64 %2, %0\n\tv_add_f64 %0, %0, %3\n\ts_mov_b64 exec, %4\n\t"
+                     "v_add_f64 %0, %0, %1\n\tv_cmpx_le_f64 %2, %0\n\tv_add_f64 %0, %0, %3\n\ts_mov_b64 exec, %4"
+                     : "+v"(ph)
+                     : "v"(inc), "s"(c511), "s"(cm512), "s"(live)
+                     : "vcc");
 }
 
 // 8 lanes (one sample group of 8 voices) -> per lane the sum over the 8 voices of ONE of 8 samples: the last three levels of
@@ -180,10 +220,10 @@ __device__ __forceinline__ void round_issue(const double *__restrict__ tables, c
 // 512 lanes render TWO rounds side by side (lanes 0-255 the even rounds of its range, lanes 256-511 the odd ones): two wavefronts per
 // SIMD, so that one round's LDS latencies and bank conflicts hide behind the other's arithmetic.  Inside a round the table reads of all
 // 16 samples are in flight at once (osc_pipe_*, mxg_osc.h).  Ring of four buffers: two rounds in use, the next two arriving by DMA.
-template <bool STORE, bool MIX>
+template <bool STORE, bool MIX, bool AHEAD>
 __global__ __launch_bounds__(512) void osctab_kernel(size_t V, size_t N, const double *__restrict__ tables,
                                                      const double *__restrict__ hdr, double *__restrict__ hold_io,
-                                                     double *__restrict__ out, double *__restrict__ rows) {
+                                                     double *__restrict__ out, double *__restrict__ rows, TabAhead AH, TabSum SM) {
     __shared__ __attribute__((aligned(16))) double s_buf[kTabRing * kTabRound];
     const int lane = threadIdx.x & 63;
     const int side = threadIdx.x >> 8, tid8 = threadIdx.x & 255;
@@ -201,6 +241,60 @@ __global__ __launch_bounds__(512) void osctab_kernel(size_t V, size_t N, const d
     const size_t nb = (size_t)t * 32 + (size_t)h * 16;  // this lane's first sample
     const bool has_last = N - 1 >= nb && N - 1 < nb + 16;
     const int i_last = (int)((N - 1) & 15);
+    // the next block's marks (AHEAD): this lane's voice, its duty in units of 16 steps (unit q: part q / 2, half q % 2; a mark is left
+    // at the start of every part), `upi` units per pair of rounds.  A mark waits in a register until the NEXT iteration has issued its DMA,
+    // so that the store is long complete when that iteration ends on vmcnt(0).
+    const size_t mv = g0 * kTabVoices + threadIdx.x;
+    const size_t mvend = g1 * kTabVoices < V ? g1 * kTabVoices : V;
+    const bool mlive = AHEAD && g0 < g1 && mv < mvend;
+    double mph = 0.0, minc = 0.0, mpend = 0.0;
+    int mq = 0, mpend_t = -1, upi = 0;
+    double *mh = nullptr;
+    if constexpr (AHEAD) {
+        const size_t vv = mlive ? mv : 0;
+        mph = AH.carry[vv];
+        const double f = AH.freq[vv];
+        double x = AH.pan ? AH.pan[vv] : 0.0;
+        mh = AH.hdr_next + (vv / kTabVoices) * kTabHdr + (vv % kTabVoices);
+        minc = 512. / (AH.sr / (f * kChandiv));  // C:269
+        if (x > 1) x = 1;  // C:504
+        if (x < 0) x = 0;  // C:505
+        if (mlive) {
+            AH.phase_io[vv] = mph;  // the phase after the block THIS launch renders: what d_phase holds when the call has completed
+            mh[kTabParts * kTabVoices] = minc;
+            mh[kTabParts * kTabVoices + kTabVoices] = sqrt(1.0 - x);  // two[0] = input*sqrt(1.0-x)   C:506
+            mh[kTabParts * kTabVoices + 2 * kTabVoices] = sqrt(x);    // two[1] = input*sqrt(x)       C:507
+        }
+        const size_t npairs = (g1 - g0 + 1) / 2;
+        upi = npairs ? (int)((2 * kTabParts + npairs - 1) / npairs) : 2 * kTabParts;
+    }
+    auto marks_units = [&](int units) {  // (wave-uniform control flow; every lane of the wavefront is active here)
+        if constexpr (AHEAD) {
+            const unsigned long long live = __builtin_amdgcn_read_exec();
+            for (int i = 0; i < units && mq < 2 * kTabParts; i++, mq++) {
+                if ((mq & 1) == 0) {
+                    if (mpend_t >= 0 && mlive) mh[mpend_t * kTabVoices] = mpend;  // (more than one mark per iteration: small banks only)
+                    mpend = mph;
+                    mpend_t = mq >> 1;
+                }
+                const size_t n0 = (size_t)mq * 16;
+                if (n0 + 16 <= N) {
+                    marks_steps16(mph, minc, live);
+                } else {
+                    for (size_t n = n0; n < N; n++) {
+                        mph += minc;
+                        if (mph >= 511) mph -= 512;
+                    }
+                }
+            }
+        }
+    };
+    auto marks_flush = [&]() {
+        if constexpr (AHEAD) {
+            if (mpend_t >= 0 && mlive) mh[mpend_t * kTabVoices] = mpend;
+            mpend_t = -1;
+        }
+    };
     for (int k = 0; k < 2; k++)
         if (g0 + k < g1) round_issue(tables, hdr, g0 + k, V, s_buf + k * kTabRound);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -210,6 +304,7 @@ __global__ __launch_bounds__(512) void osctab_kernel(size_t V, size_t N, const d
         asm volatile("" ::: "memory");
         for (int k = 0; k < 2; k++)    // ... which the next pair may now overwrite
             if (gp + 2 + k < g1) round_issue(tables, hdr, gp + 2 + k, V, s_buf + ((b0 + 2 + k) % kTabRing) * kTabRound);
+        marks_flush();  // (the mark of the previous iteration: its store travels with this iteration's DMA)
         const size_t g = gp + side;
         if (g < g1) {
         const int b = (b0 + side) % kTabRing;
@@ -265,7 +360,13 @@ __global__ __launch_bounds__(512) void osctab_kernel(size_t V, size_t N, const d
             }
         }
         }  // (g < g1)
+        marks_units(upi);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's pieces of the next pair have landed
+    }
+    if constexpr (AHEAD) {
+        marks_units(2 * kTabParts);  // (whatever is left: nothing when the duty divided evenly)
+        marks_flush();
+        if (mlive) AH.carry[mv] = mph;
     }
     if constexpr (MIX) {
         int idx[8];
@@ -301,7 +402,67 @@ __global__ __launch_bounds__(512) void osctab_kernel(size_t V, size_t N, const d
                 const size_t n = nb + 8 * j + slot;
                 if (n < N) {
                     const double2v o = meet[n];
-                    *reinterpret_cast<double2v *>(rows + ((size_t)blockIdx.x * N + n) * 2) = double2v{pr[j].x + o.x, pr[j].y + o.y};
+                    double *rp = rows + ((size_t)blockIdx.x * N + n) * 2;
+                    if (SM.mix) {  // (read by a workgroup of another XCD in this launch: write-through, like the lists of grains.hip)
+                        __hip_atomic_store(rp, pr[j].x + o.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(rp + 1, pr[j].y + o.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        *reinterpret_cast<double2v *>(rp) = double2v{pr[j].x + o.x, pr[j].y + o.y};
+                    }
+                }
+            }
+        }
+        if (SM.mix) {
+            // Cross-XCD hand-off WITHOUT fences (an agent-scope fence writes back and invalidates the XCD's whole L2: measured +55 us per
+            // block with one per workgroup): the rows and chains travel as relaxed agent-scope atomics -- write-through stores, loads that
+            // never take a stale L2 line -- and a ticket is drawn only after this wavefront's stores have been acknowledged (vmcnt(0)).
+            __shared__ int s_last;
+            const unsigned G = gridDim.x, w = blockIdx.x % kPartWaves;
+            const size_t count = N * 2;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int members = (int)((G - w + kPartWaves - 1) / kPartWaves);
+                s_last = __hip_atomic_fetch_add(SM.tickets + w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1;
+            }
+            __syncthreads();
+            if (s_last) {
+                for (size_t i = threadIdx.x; i < count; i += blockDim.x) {
+                    double c = 0.0;
+                    for (size_t gb = w; gb < G; gb += 16 * kPartWaves) {  // sixteen rows in flight at a time (a load per addition would be a round trip each)
+                        double v[16];
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const size_t g = gb + (size_t)k * kPartWaves;
+                            v[k] = __hip_atomic_load(rows + (g < G ? g : (size_t)w) * count + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 16; k++)
+                            if (gb + (size_t)k * kPartWaves < G) c += v[k];
+                    }
+                    __hip_atomic_store(SM.chains + (size_t)w * count + i, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    __hip_atomic_store(SM.tickets + w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int nchains = G < (unsigned)kPartWaves ? (int)G : kPartWaves;
+                    s_last = __hip_atomic_fetch_add(SM.tickets + kPartWaves, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nchains - 1;
+                }
+                __syncthreads();
+                if (s_last) {
+                    for (size_t i = threadIdx.x; i < count; i += blockDim.x) {
+                        // (chains of indices no workgroup has are 0.0, as the wavefronts of mix_partials_kernel that meet no row leave them)
+                        double v[kPartWaves];
+#pragma unroll
+                        for (unsigned k = 0; k < (unsigned)kPartWaves; k++)
+                            v[k] = __hip_atomic_load(SM.chains + (size_t)(k < G ? k : 0) * count + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        double t2 = v[0];
+#pragma unroll
+                        for (unsigned k = 1; k < (unsigned)kPartWaves; k++) t2 += k < G ? v[k] : 0.0;
+                        SM.mix[i] = t2;
+                    }
+                    if (threadIdx.x == 0) __hip_atomic_store(SM.tickets + kPartWaves, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -330,31 +491,90 @@ extern "C" size_t mxg_osc_tables_groups(size_t V) {
     return (MXG_TAB_SIDEFOLD ? 1 : 2) * tables_grid(V);  // a partial mix row per workgroup (its two sides are added in LDS)
 }
 
-extern "C" int mxg_osc_render_tables(size_t V, size_t N, const double *d_freq, const double *d_tables, double *d_phase,
-                                     double *d_outhold, double *d_out, const double *d_pan, double *d_rows, void *stream) {
+namespace {
+// the pipelined form's memory, per stream: which block the second header buffer was prepared for
+struct TabAheadCtx {
+    bool valid = false;
+    size_t V = 0, N = 0;
+    const double *freq = nullptr, *pan = nullptr;
+    double *phase = nullptr;
+    int parity = 0;  // the header buffer the NEXT call renders from
+};
+std::mutex g_tab_mu;
+std::map<hipStream_t, TabAheadCtx> g_tab_ctx;
+}  // namespace
+
+extern "C" int mxg_osc_render_tables_ex(size_t V, size_t N, const double *d_freq, const double *d_tables, double *d_phase,
+                                        double *d_outhold, double *d_out, const double *d_pan, double *d_rows, double *d_mix, int flags,
+                                        void *stream) {
     if (int s = ensure_init()) return s;
     MXG_REQUIRE(d_freq && d_tables && d_phase && d_outhold, "null device pointer");
     MXG_REQUIRE(d_out || d_pan, "nothing to produce: give d_out (the per-voice block), d_pan + d_rows (the mixdown), or both");
     MXG_REQUIRE(!d_pan || d_rows, "the mixdown needs d_rows");
+    MXG_REQUIRE(!d_mix || d_pan, "d_mix is the sum of the mixdown's rows: it needs d_pan and d_rows");
     MXG_REQUIRE(N <= (size_t)kTabParts * 32, "blocks of at most 512 samples (16 time parts of 32 samples per voice)");
     MXG_REQUIRE(!(((uintptr_t)d_tables) & 15), "d_tables must be 16-byte aligned");
+    MXG_REQUIRE((flags & ~MXG_TABLES_AHEAD) == 0, "unknown flag");
     if (V == 0 || N == 0) return MXG_OK;
     hipStream_t st = resolve_stream(stream);
     const size_t groups = (V + kTabVoices - 1) / kTabVoices;
-    double *hdr = nullptr;  // [groups][152] per-stream scratch: marks, increments, gains
-    if (int s = scratch_get(SCR_OSCTAB_MARKS, st, sizeof(double) * kTabHdr * groups, (void **)&hdr)) return s;
-    {
-        KernelTimer kt("osctab_marks_kernel", st);
-        hipLaunchKernelGGL(osctab_marks_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, N, d_freq, d_pan, d_phase, hdr,
-                           (double)settings().sampleRate);
-    }
     const size_t grid = tables_grid(V);
+    const double sr = (double)settings().sampleRate;
+    // the pipelined form: a workgroup's lanes (512) walk the marks of its own voices -- every workgroup must have at most 512
+    const size_t per = (groups + grid - 1) / grid;
+    const bool ahead = (flags & MXG_TABLES_AHEAD) && per * kTabVoices <= 512;
+    double *hdr = nullptr, *hdr2 = nullptr, *carry = nullptr;  // [groups][152] per-stream scratch: marks, increments, gains
+    bool fresh = false, fresh2 = false, fresh3 = false;
+    if (int s = scratch_get(SCR_OSCTAB_MARKS, st, sizeof(double) * kTabHdr * groups, (void **)&hdr, &fresh)) return s;
+    TabAhead AH{nullptr, nullptr, nullptr, nullptr, nullptr, sr};
+    std::lock_guard<std::mutex> lock(g_tab_mu);
+    TabAheadCtx &C = g_tab_ctx[st];
+    if (!ahead) {
+        C.valid = false;  // (d_phase holds the phase after the last rendered block: start over from it)
+        KernelTimer kt("osctab_marks_kernel", st);
+        hipLaunchKernelGGL(osctab_marks_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, N, d_freq, d_pan, d_phase, d_phase, hdr, sr);
+    } else {
+        if (int s = scratch_get(SCR_OSCTAB_MARKS2, st, sizeof(double) * kTabHdr * groups, (void **)&hdr2, &fresh2)) return s;
+        if (int s = scratch_get(SCR_OSCTAB_CARRY, st, sizeof(double) * V, (void **)&carry, &fresh3)) return s;
+        const bool match = C.valid && !fresh && !fresh2 && !fresh3 && C.V == V && C.N == N && C.freq == d_freq && C.pan == d_pan && C.phase == d_phase;
+        if (!match) {  // nothing prepared for this block: its marks now, the phase after it into the carry array
+            C.parity = 0;
+            KernelTimer kt("osctab_marks_kernel", st);
+            hipLaunchKernelGGL(osctab_marks_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, N, d_freq, d_pan, d_phase, carry, hdr, sr);
+        }
+        double *cur = C.parity ? hdr2 : hdr, *nxt = C.parity ? hdr : hdr2;
+        AH = TabAhead{d_freq, d_pan, carry, d_phase, nxt, sr};
+        hdr = cur;
+        C.valid = true; C.V = V; C.N = N; C.freq = d_freq; C.pan = d_pan; C.phase = d_phase;
+        C.parity ^= 1;
+    }
+    TabSum SM{nullptr, nullptr, nullptr};
+    if (d_mix) {
+        char *sumscr = nullptr;  // 17 tickets (in the first 128 bytes: a fixed place whatever N) + [16][N][2] chains
+        bool fresh4 = false;
+        const size_t cb = sizeof(double) * kPartWaves * N * 2;
+        if (int s = scratch_get(SCR_OSCTAB_SUM, st, 128 + cb, (void **)&sumscr, &fresh4)) return s;
+        int *tickets = reinterpret_cast<int *>(sumscr);
+        if (fresh4) MXG_HIP(hipMemsetAsync(tickets, 0, 128, st));
+        SM = TabSum{d_mix, reinterpret_cast<double *>(sumscr + 128), tickets};
+    }
     KernelTimer kt("osctab_kernel", st);
-    if (d_out && d_pan)
-        hipLaunchKernelGGL((osctab_kernel<true, true>), dim3((unsigned)grid), dim3(512), 0, st, V, N, d_tables, hdr, d_outhold, d_out, d_rows);
-    else if (d_out)
-        hipLaunchKernelGGL((osctab_kernel<true, false>), dim3((unsigned)grid), dim3(512), 0, st, V, N, d_tables, hdr, d_outhold, d_out, d_rows);
-    else
-        hipLaunchKernelGGL((osctab_kernel<false, true>), dim3((unsigned)grid), dim3(512), 0, st, V, N, d_tables, hdr, d_outhold, d_out, d_rows);
+#define MXG_TAB_LAUNCH(S, M, A) \
+    hipLaunchKernelGGL((osctab_kernel<S, M, A>), dim3((unsigned)grid), dim3(512), 0, st, V, N, d_tables, hdr, d_outhold, d_out, d_rows, AH, SM)
+    if (ahead) {
+        if (d_out && d_pan) MXG_TAB_LAUNCH(true, true, true);
+        else if (d_out) MXG_TAB_LAUNCH(true, false, true);
+        else MXG_TAB_LAUNCH(false, true, true);
+    } else {
+        if (d_out && d_pan) MXG_TAB_LAUNCH(true, true, false);
+        else if (d_out) MXG_TAB_LAUNCH(true, false, false);
+        else MXG_TAB_LAUNCH(false, true, false);
+    }
+#undef MXG_TAB_LAUNCH
     return check_hip(hipGetLastError(), "osctab_kernel launch");
+}
+
+extern "C" int mxg_osc_render_tables(size_t V, size_t N, const double *d_freq, const double *d_tables, double *d_phase,
+                                     double *d_outhold, double *d_out, const double *d_pan, double *d_rows, void *stream) {
+    return mxg_osc_render_tables_ex(V, N, d_freq, d_tables, d_phase, d_outhold, d_out, d_pan, d_rows, nullptr, 0, stream);
 }

@@ -62,6 +62,7 @@ Tune g_tune[] = {
     {"grain_unit", 1, 0, 1},  // K8c: coalesced closed-form render when every grain has inc = +-1
     {"grain_fast_sched", 1, 0, 1},  // K8a: event-driven exact multi-step scheduler (0: one step at a time)
     {"grain_sync", 0, 0, 1},  // 1: mxg_granular_render reads its error word back before it returns (the round-1/2 behaviour); 0: deferred
+    {"grain_spin_limit", 0, 0, 1 << 22},  // polls without progress before a streamed tile render gives up and the call is rendered again (0 = 2^22)
     {"grain_streamed", 1, 0, 1},  // K8c: scheduler lanes and tile renders in ONE launch (0: time slices on the auxiliary streams, grain_slices)
     {"grain_slices", 4, 1, 16},  // K8a/K8c: time slices of a maxiTimeStretch call (scheduling of slice i+1 overlaps render of slice i)
     {"mfcc_mfma_fullk", 0, 0, 1},  // K7b: contract over all numBins bins (1) instead of the bins that carry weight
@@ -166,10 +167,9 @@ int async_error_status(int code) {
             return fail(MXG_ERR_INVALID,
                         "mxg_granular_render: a grain was born with a NaN/Inf step or one longer than the sample (|speed| too "
                         "large for this sample length); its reads would leave the buffer");
-        case 6:
+        case 6:  // (rounds 5 only: since round 6 such a call is rendered again, mxg_granular_retries counts them)
             return fail(MXG_ERR_HIP,
-                        "mxg_granular_render: a tile render saw no scheduler progress for its whole polling budget (streamed form); "
-                        "that tile was rendered as silence");
+                        "mxg_granular_render: a tile render saw no scheduler progress for its whole polling budget (streamed form)");
         default: break;
     }
     return fail(MXG_ERR_HIP, "asynchronous device error %d", code);
@@ -324,7 +324,8 @@ int mxg_init(int device) {
     if (!g_stream) MXG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
     if (!g_async_host) {
         MXG_HIP(hipHostMalloc((void **)&g_async_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
-        *g_async_host = 0;
+        g_async_host[0] = 0;
+        g_async_host[1] = 0;  // (the word behind the error word: streamed granular launches that were rendered again)
         MXG_HIP(hipHostGetDevicePointer((void **)&g_async_dev, g_async_host, 0));
     }
     g_inited = true;
@@ -332,6 +333,8 @@ int mxg_init(int device) {
 }
 
 const char *mxg_last_error(void) { return g_err; }
+
+int mxg_granular_retries(void) { return g_async_host ? __atomic_load_n(g_async_host + 1, __ATOMIC_ACQUIRE) : 0; }
 const char *mxg_version(void) { return "maxigpu 0.1 (gfx950)"; }
 
 int mxg_settings(size_t sampleRate, size_t channels, size_t bufferSize) {

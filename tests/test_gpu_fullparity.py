@@ -190,6 +190,51 @@ def test_config3_128_blocks_every_sample(mx, port, mode):
         assert scaled.max() <= VOICE_B_RTOL
 
 
+def test_config3_mixdown_full_bank(mx, port):
+    """Config 3's N > 1 step at its full size (65 536 voices x 512, K2f with the maxiMix::stereo mixdown fused: mxg_voice_render_mix_rows),
+    16 carried blocks through attack / decay / sustain / release: every block and every state array bit-identical to mxg_voice_render's
+    (itself bit-identical to the oracle over 128 blocks: test_config3_128_blocks_every_sample), the rows' sum within mix_tol of the
+    reference's voice-after-voice sum (C:503-509, 15.polysynth/main.cpp:54-70) over the same per-voice values."""
+    from conftest import mix_tol
+    K = 16
+    freq = np.minimum(20.0 + np.arange(V) * 0.30517578125, 5000.0)
+    cutoff, res = 200 + 4 * freq, 1.0 + (np.arange(V) % 16)
+    pan = np.arange(V) / (V - 1.0)
+    gate = ((np.arange(K * B) % 4410) < 2205).astype(np.int32)   # (ten times faster than config 3's gate: every stage within 16 blocks)
+    banks = [mx.maxiVoiceBank(V), mx.maxiVoiceBank(V)]
+    for vb in banks:
+        vb.env.setAttack(10); vb.env.setDecay(100); vb.env.setSustain(0.5); vb.env.setRelease(500)
+    L = mx.lib()
+    G = L.mxg_osc_mix_groups(V)
+    rows = mx.DeviceBuffer((G, B, 2), np.float64)
+    mix = mx.DeviceBuffer((B, 2), np.float64)
+    worst = 0.0
+    for k in range(K):
+        trig = gate[k * B:(k + 1) * B]
+        a = banks[0].render(0, freq, cutoff, res, trig, B).numpy()
+        o, _ = banks[1].render_mix(0, freq, cutoff, res, trig, pan, B, rows=rows)
+        assert count_mismatch(o.numpy(), a) == 0, "block %d" % k
+        mx._lib.check(L.mxg_mix_rows_sum(G, B * 2, rows.ptr, mix.ptr, None), "mxg_mix_rows_sum")
+        em = port.mix_stereo(a, pan)
+        gm = mix.numpy()
+        # (config 3's high cutoffs x resonances let some voices run away to Inf / NaN within a few blocks -- in the reference too: a row
+        # that holds one is NaN on both sides)
+        fin = np.isfinite(em)
+        assert np.array_equal(fin, np.isfinite(gm)), "block %d: non-finite mix rows differ" % k
+        if not fin.any():
+            continue
+        af = np.where(np.isfinite(a), a, 0.0)
+        err = np.abs(np.where(fin, gm - em, 0.0)).max()
+        tol = mix_tol(V, np.abs(af).max(), sums=np.where(fin, em, 0.0))
+        worst = max(worst, err / tol)
+        assert err <= tol, "mix of block %d: %.3e > %.3e" % (k, err, tol)
+    for x, y, name in ((banks[0].osc_state, banks[1].osc_state, "osc"), (banks[0].flt_state, banks[1].flt_state, "filter"),
+                       (banks[0].env.dstate, banks[1].env.dstate, "env")):
+        assert_bits_equal(y.numpy(), x.numpy(), name + " state after %d blocks" % K)
+    assert np.array_equal(banks[0].env.istate.numpy(), banks[1].env.istate.numpy())
+    print("config 3 mixdown form: %d blocks x %d x %d bit-identical to the plain render, mix within %.2f of mix_tol" % (K, B, V, worst))
+
+
 def test_config4_mfma_all_frames(mx, port):
     """The dense fp64 MFMA mel contraction (method 1) over 1 048 576 frames: every frame against the exact sparse path
     on the device, a strided sample against the oracle."""

@@ -305,6 +305,58 @@ def test_granular_streamed_renders_wait_for_slow_schedulers(mx, port):
     assert_bits_equal(got[0][:, sel], e, "oracle")
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_streamed_renders_that_give_up_are_rendered_again(mx, port, mode):
+    """a tile render of the one-launch form that sees no scheduler progress for its polling budget must not leave
+    silence.  Forced here with the budget lowered to one poll (knob grain_spin_limit): most renders give up at once, the retry
+    kernel that follows the launch renders every tile again from the completed lists, and output, scheduler state, live grains and
+    the fused mixdown are the sliced form's bits = the oracle's; no asynchronous error is raised; mxg_granular_retries() counts the
+    calls that took the detour.  mode 0 = K8c (unit increments), mode 1 = K8d (maxiStretch)."""
+    L = mx.lib()
+    rng = np.random.default_rng(606 + mode)
+    Ls, S, T = 30000, 200, 64 * 300 + 17
+    smp = rng.uniform(-1, 1, Ls)
+    speed = rng.uniform(0.2, 2.0, S) * np.where(np.arange(S) % 7 == 3, -1.0, 1.0)
+    stretch = rng.uniform(0.5, 1.5, S)
+    pan = rng.uniform(0, 1, S)
+    pos0 = rng.uniform(0, 1, S)
+
+    def run():
+        bank = make_bank(mx, mode, "hann", smp, S)
+        bank.setPosition(pos0)
+        st0 = bank.state.numpy()
+        out = mx.DeviceBuffer((T, S), zero=False)
+        mix = mx.DeviceBuffer((T, 2))
+        a, b, dp = mx.DeviceBuffer.from_numpy(speed), mx.DeviceBuffer.from_numpy(stretch), mx.DeviceBuffer.from_numpy(pan)
+        assert L.mxg_granular_render_mix(bank._plan(0.05), mode, S, T, bank.sample.d_samples, Ls, 4, a.ptr, b.ptr if mode == 1 else None,
+                                         None, None, 0, bank.state.ptr, bank.grains.ptr, out.ptr, dp.ptr, mix.ptr, None) == 0
+        assert L.mxg_sync() == 0, L.mxg_last_error()
+        return out.numpy(), bank.state.numpy(), bank.grains.numpy(), mix.numpy(), st0
+    prev = L.mxg_tune(b"grain_streamed", 0)
+    try:
+        ref = run()
+    finally:
+        L.mxg_tune(b"grain_streamed", prev)
+    before = L.mxg_granular_retries()
+    calm = run()
+    assert L.mxg_granular_retries() == before, "a healthy launch takes no detour"
+    prev = L.mxg_tune(b"grain_spin_limit", 1)
+    try:
+        got = run()
+    finally:
+        L.mxg_tune(b"grain_spin_limit", prev)
+    assert L.mxg_granular_retries() > before, "the lowered polling budget must have forced at least one retry"
+    assert L.mxg_last_async_error() == 0
+    for g, c, r, what in zip(got[:4], calm[:4], ref[:4], ("output", "state", "grains", "mix")):
+        assert_bits_equal(g, r, what + " (forced retry vs sliced form)")
+        assert_bits_equal(c, r, what + " (one launch vs sliced form)")
+    sel = np.arange(0, S, 13)
+    e, est, egst, rc = port.granular(mode, 0, smp, T, speed[sel], grainLength=0.05, overlaps=4, st=got[4][:, sel],
+                                     **({"b": stretch[sel]} if mode == 1 else {}))
+    assert rc == 0
+    assert_bits_equal(got[0][:, sel], e, "oracle")
+
+
 @pytest.mark.parametrize("streamed", [1, 0])
 def test_time_stretch_with_off_grid_carried_grains_picks_the_general_renderer_on_the_device(mx, port, streamed):
     """maxiTimeStretch with unit increments takes the closed-form tile render K8c -- unless a carried-in grain sits between two

@@ -53,6 +53,40 @@ def test_tables_bank_against_the_oracle(mx, port, V, N):
     assert_bits_equal(bank2.phase.numpy(), eph, "phase, mix-only form")
 
 
+@pytest.mark.parametrize("V,N", [(1000, 512), (300, 100), (4099, 333), (33, 512), (17, 16), (40000, 512), (131072, 512), (131073, 512)])
+@pytest.mark.parametrize("store", [False, True])
+def test_tables_pipelined_blocks_and_fused_row_sum(mx, port, V, N, store):
+    """Round 6: mxg_osc_render_tables_ex with MXG_TABLES_AHEAD -- the render of block k also walks block k + 1's
+    phase recurrence, so from the second call on a call is one kernel -- and with d_mix, the row sum formed inside the render kernel by
+    the workgroups that finish last.  Five carried blocks: every block, every mix, the carried phase after EVERY call and the `output`
+    member must be the plain two-kernel path's bits (mxg_osc_render_tables + mxg_mix_rows_sum); then the pattern is broken (a call
+    without the flag, a call with another N) and picked up again, still the same bits.  131 073 voices: more than 512 voices per
+    workgroup, the flag is ignored."""
+    if V > 100000 and store:
+        pytest.skip("per-voice blocks of the large banks are covered by the mix-only form")
+    rng = np.random.default_rng(5 * V + N)
+    freq = mx.DeviceBuffer.from_numpy(rng.uniform(20, 20000, V))
+    pan = mx.DeviceBuffer.from_numpy(rng.uniform(-0.1, 1.1, V))
+    d_tabs = mx.DeviceBuffer.from_numpy(rng.uniform(-1, 1, (V, 514)))
+    ref, bank = mx.maxiOscBank(V), mx.maxiOscBank(V)
+    plan = [(N, True), (N, True), (N, True), (N, False), (N, True), (max(N // 2, 1), True), (N, True), (N, True)]
+    for k, (n, ahead) in enumerate(plan):
+        eo, em = ref.sinebuf_tables(freq, d_tabs, n, pan=pan, store=store)
+        go, gm = bank.sinebuf_tables(freq, d_tabs, n, pan=pan, store=store, ahead=ahead, fused_sum=True)
+        if store:
+            assert_bits_equal(go.numpy(), eo.numpy(), "block %d" % k)
+        assert_bits_equal(gm.numpy(), em.numpy(), "mix %d (row sum inside the kernel)" % k)
+        assert_bits_equal(bank.phase.numpy(), ref.phase.numpy(), "d_phase after call %d" % k)
+        assert_bits_equal(bank.output.numpy(), ref.output.numpy(), "output member after call %d" % k)
+    # and against the oracle (small banks: the port walks every sample)
+    if V <= 5000:
+        fh, th = freq.numpy(), d_tabs.numpy()
+        total = sum(n for n, _ in plan)
+        eo, eph, ehd = port.osc_tables(fh, th, total)
+        assert_bits_equal(bank.phase.numpy(), eph, "phase vs the oracle")
+        assert_bits_equal(bank.output.numpy(), ehd, "output member vs the oracle")
+
+
 def test_tables_invalid(mx):
     L = mx.lib()
     V = 32
