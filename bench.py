@@ -182,7 +182,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--waveform", default="sinebuf")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5", "tables"],
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5", "tables", "sample_bank"],
                     help="BASELINE.json config to run; the default (config2) is the one the headline metric is quoted on")
     ap.add_argument("--mixdown", default=None, choices=["fused", "separate", "off"],
                     help="stereo mixdown + cross-GPU reduce in the step (default: on whenever --gpus > 1 -- fused into the "
@@ -237,7 +237,7 @@ def main():
         os.execvpe(cmd[0], cmd, env)
     # (under torch.distributed.run the environment is the launcher's: make sure of dmabuf IPC before HIP / RCCL are loaded)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    defaults = {"config2": (2000, 100), "config3": (1280, 128), "config4": (20, 3), "config5": (20, 3), "tables": (200, 20)}
+    defaults = {"config2": (2000, 100), "config3": (1280, 128), "config4": (20, 3), "config5": (20, 3), "tables": (200, 20), "sample_bank": (200, 20)}
     if args.steps is None:
         args.steps = defaults[args.workload][0]
     if args.warmup is None:
@@ -323,7 +323,7 @@ def main():
     # a single GPU renders the bank without it unless asked (--mixdown fused|separate).  config 5 is DEFINED with the
     # stereo mixdown (BASELINE configs[4]), so it always mixes.
     mixdown = args.mixdown or {"config2": "fused" if world > 1 else "off", "config3": "fused" if world > 1 else "off",
-                               "config4": "off", "config5": "fused", "tables": "off"}[args.workload]
+                               "config4": "off", "config5": "fused", "tables": "off", "sample_bank": "off"}[args.workload]
 
     class OscBank:
         """One rank's maxiOsc bank of `Vb` voices with its block buffers; step() renders one block (K1, or K1m / K1 + K3 with
@@ -443,6 +443,49 @@ def main():
                      workload="EXTENSION of configs[1] (not in the reference, which has one shared sineBuffer): %d-voice maxiOsc::sinebuf bank "
                               "with a 514-entry table PER VOICE (4112 B read per voice and block, 8.03 B per sample), block=512, fused "
                               "maxiMix::stereo mixdown as output (no per-voice store): the HBM-READ form of the wavetable path" % Vt)
+        elif workload == "sample_bank":
+            # north_star: "coalesced HBM reads of ... maxiSample buffers" -- measured where the samples cannot live on chip: 65 536 play
+            # heads of maxiSample::playAtSpeed (C:1060-1075) over ONE 8.6 GB sample, each head in its own region (16 368 elements apart),
+            # speeds spread over [0.5, 1.5] (mean 1: 8 B of sample read + 8 B written per output sample).  A region is revisited after
+            # ~32 blocks = 8.6 GB of other traffic: every sample byte comes from HBM.
+            Vs, Ls = 65536, (1 << 30) - (1 << 20)
+            arena = torch.empty(Ls + 64, dtype=torch.float64, device=dev)  # the guarded layout of mxg_sample_upload: [-4, len + 5] valid
+            arena[:8].zero_(); arena[Ls:].zero_()
+            for c0 in range(0, Ls, 1 << 26):
+                c1 = min(Ls, c0 + (1 << 26))
+                xs = torch.arange(c0, c1, dtype=torch.float64, device=dev)
+                arena[8 + c0:8 + c1] = torch.frac(xs * 0.3183098861837907) - 0.5
+                del xs
+            d_smp = arena.data_ptr() + 64
+            vv = np.arange(Vs)
+            speed_h = 0.5 + (vv * 40503 % Vs) / float(Vs)          # a permutation of the grid over [0.5, 1.5)
+            pos_h = (vv * (Ls // Vs)).astype(np.float64) + 0.25
+            d_speed = mx.DeviceBuffer.from_numpy(speed_h)
+            d_pos = mx.DeviceBuffer.from_numpy(pos_h)
+            outs_s = [mx.DeviceBuffer((B, Vs), zero=False) for _ in range(max(1, -(-(1 << 31) // (Vs * B * 8))))]
+            kb = [0]
+
+            def step_sample():
+                o = outs_s[kb[0] % len(outs_s)]
+                chk(L.mxg_sample_render(4, Vs, B, d_smp, Ls, 44100, d_speed.ptr, 0, None, None, d_pos.ptr, o.ptr, stream), "mxg_sample_render")
+                kb[0] += 1
+
+            def cpu(target_s=6.0):
+                o, kind = _oracle()
+                o.settings(44100, 2, 1024)
+                Vc, Nc, Lc = 4096, 4096, 1 << 22
+                smp_c = np.modf(np.arange(Lc) * 0.3183098861837907)[0] - 0.5
+                t0 = time.perf_counter()
+                o.sample(4, smp_c, Nc, (np.arange(Vc) * (Lc // Vc)).astype(np.float64) + 0.25, a=speed_h[:Vc])
+                dt = time.perf_counter() - t0
+                return {"unit": "Msamples/s", "kind": kind, "value": round(Vc * Nc / dt / 1e6, 2), "cores": 1,
+                        "sample": "maxiSample::playAtSpeed, %d heads x %d samples over a 4 Mi-element sample, one thread; %.2f s wall" % (Vc, Nc, dt)}
+            W = dict(step=step_sample, samples=Vs * B, dominant="sample_parts_kernel", algo_bytes=(16.0 + 24.0 / B) * Vs * B, dtype="f64", cpu=cpu,
+                     local_step=None, keep=(arena,),
+                     tag="maxiSample::playAtSpeed, %d heads over one 8.6 GB sample (HBM-resident: each head its own region), block 512" % Vs,
+                     workload="north_star's sample path where the sample cannot live on chip: %d play heads of maxiSample::playAtSpeed over one "
+                              "%.1f GB sample, heads %d elements apart, speeds over [0.5, 1.5) (mean 1: 8 B read + 8 B written per sample), "
+                              "block=512, output rotated over %d block buffers" % (Vs, Ls * 8 / 1e9, Ls // Vs, len(outs_s)))
         elif workload == "config3":
             K = 128
             mode = voice_mode
@@ -884,6 +927,7 @@ def main():
         for name, (wl, md, meth, st_, wm_) in {
                 "config2_mixdown": ("config2", "fused", "sparse", 400, 50),  # the N > 1 step on one GPU: K1m + grouped mix queue, no communicator
                 "config2_tables": ("tables", "off", "sparse", 100, 20),  # the per-voice wavetable extension: the HBM-read roofline
+                "sample_bank": ("sample_bank", "off", "sparse", 100, 20),  # maxiSample::playAtSpeed over an HBM-resident 8.6 GB sample
                 "config3": ("config3", "off", "sparse", 256, 64),
                 "config3_mixdown": ("config3", "fused", "sparse", 256, 64),  # config 3's N > 1 step on one GPU: K2f with the mixdown fused + grouped queue
                 "config3_modB": ("config3", "off", "modB", 64, 16),  # cutoff modulated per sample (14.monosynth/main.cpp:53)

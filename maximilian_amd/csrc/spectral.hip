@@ -24,10 +24,13 @@
 #include "mxg_spectral.h"
 
 #ifndef MXG_ABLATE
-#define MXG_ABLATE 0  // timing experiments only (wrong results), bit mask: 1 no mel / log / DCT phase, 2 no butterflies, 4 no transposes, 8 no post-pass
+#define MXG_ABLATE 0  // timing experiments only (wrong results), bit mask: 1 no mel / log / DCT phase, 2 no butterflies, 4 no transposes, 8 no post-pass, 16 no frame loads (the prologue's frames are transformed again and again), 32 only the FIRST in-loop transpose removed
 #endif
 #ifndef MXG_FUSED_NTLOAD
 #define MXG_FUSED_NTLOAD 1  // frame loads as non-temporal loads: every input byte is read once (same device: 1.315 -> 1.292 ms exact, 1.061 -> 1.043 ms tolerance mode)
+#endif
+#ifndef MXG_FUSED_PF
+#define MXG_FUSED_PF 1  // frame sets in flight from HBM per wavefront: 1 = the next iteration's only; 2 = two iterations ahead (+32 VGPRs), measured the SAME time (profiles/r06_config4.md): A/B only
 #endif
 #ifndef MXG_FUSED_SKEW
 #define MXG_FUSED_SKEW 1  // frame-by-frame phase order of the fused kernel's two frames in flight (0: both frames per phase; A/B)
@@ -595,9 +598,16 @@ __global__ __launch_bounds__(64 * WAVES, NF == 1 ? 1 : 2) __attribute__((target(
     const size_t ngroups = (nframes + kGroup - 1) / kGroup;
     const size_t gstep = (size_t)gridDim.x * WAVES;
     const size_t g0 = (size_t)blockIdx.x * WAVES + wave;
-    v2f nx[NF][8];
+    // Frames in flight from HBM: PF sets (round 6 tried two -- the set an iteration consumes requested two iterations = ~4 us earlier
+    // instead of one: the same time, the kernel does not wait for late frames; profiles/r06_config4.md).  The loop over the group is
+    // unrolled by two so that the sets are fixed registers.
+    constexpr int PF = (MEL >= 1 && !FULL) ? MXG_FUSED_PF : 1;  // (the vector forms have no 32 registers to spare: one set, as before)
+    static_assert(kGroup % (2 * NF) == 0, "the group loop is unrolled by two sets of NF frames");
+    v2f nxb[PF][NF][8];
 #pragma unroll
-    for (int f = 0; f < NF; f++) load_frame(g0 * kGroup + f, nx[f]);
+    for (int p = 0; p < PF; p++)
+#pragma unroll
+        for (int f = 0; f < NF; f++) load_frame(g0 * kGroup + p * NF + f, nxb[p][f]);
     const int mj = lane >> 3, ms = lane & 7;  // mel walk: frame of the group, slot
     load_tables();
     for (size_t g = g0; g < ngroups; g += gstep) {
@@ -616,15 +626,24 @@ __global__ __launch_bounds__(64 * WAVES, NF == 1 ? 1 : 2) __attribute__((target(
         const v2f b1[2] = {tb[1], tb[2]}, b2[4] = {tb[3], tb[4], tb[5], tb[6]};
         const v2f c1[2] = {tc[1], tc[2]}, c2[4] = {tc[3], tc[4], tc[5], tc[6]};
 #pragma unroll 1
-        for (int j = 0; j < kGroup; j += NF) {
+        for (int jj = 0; jj < kGroup; jj += 2 * NF) {
+          auto body = [&](const int j, v2f (&nx)[NF][8]) {
             v2f v[NF][8];
 #pragma unroll
             for (int f = 0; f < NF; f++)
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[f][e] = nx[f][e] * wv[e];  // calcFFT L/fft.cpp:501-503
-            const size_t fnext = j + NF < kGroup ? f0 + j + NF : (g + gstep) * kGroup;
+            const int jn = j + PF * NF;  // the set that takes this one's registers: PF iterations ahead
+            const size_t fnext = jn < kGroup ? f0 + jn : (g + gstep) * kGroup + (jn - kGroup);
+#if !(MXG_ABLATE & 16)
 #pragma unroll
             for (int f = 0; f < NF; f++) load_frame(fnext + f, nx[f]);
+#else
+#pragma unroll
+            for (int f = 0; f < NF; f++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) asm volatile("" : "+v"(nx[f][e]));
+#endif
 #if MXG_FUSED_SKEW
             // Frame by frame inside a phase: a frame's butterflies, its transpose stores and the transpose READS are issued together,
             // then the other frame's -- so a frame's LDS round trip flies while the other frame's 60 packed butterflies run, instead
@@ -640,7 +659,7 @@ __global__ __launch_bounds__(64 * WAVES, NF == 1 ? 1 : 2) __attribute__((target(
                 else
                     round3_s(v[f], ta);
 #endif
-#if !(MXG_ABLATE & 4)
+#if !(MXG_ABLATE & (4 | 32))
 #pragma unroll
                 for (int e = 0; e < 8; e++) X[f][pad8(8 * lane + e)] = v[f][e];
                 wave_lds_sync();
@@ -832,6 +851,9 @@ __global__ __launch_bounds__(64 * WAVES, NF == 1 ? 1 : 2) __attribute__((target(
                 for (int f = 0; f < NF; f++) post_frame(X[f], j + f, f0);
             }
             wave_lds_sync();
+          };
+          body(jj, nxb[0]);
+          body(jj + NF, nxb[PF - 1]);
         }
 #if MXG_ABLATE & 1
         if (lane < kGroup * A.numCoeffs && f0 + lane / A.numCoeffs < nframes) A.mfcc[f0 * A.numCoeffs + lane] = (double)M[lane];
