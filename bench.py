@@ -471,12 +471,17 @@ def main():
                 kb[0] += 1
 
             def cpu(target_s=6.0):
-                o, kind = _oracle()
+                # (the plain-C port: V heads over ONE sample array, like the bank; the compiled reference's harness gives every voice its
+                # own maxiSample, i.e. a copy of the sample per voice, which would time the copies)
+                from oracle import pyoracle
+                o, kind = pyoracle.port(), "port"
                 o.settings(44100, 2, 1024)
                 Vc, Nc, Lc = 4096, 4096, 1 << 22
                 smp_c = np.modf(np.arange(Lc) * 0.3183098861837907)[0] - 0.5
+                pos_c = (np.arange(Vc) * (Lc // Vc)).astype(np.float64) + 0.25
+                o.sample(4, smp_c, 16, pos_c, a=speed_h[:Vc])
                 t0 = time.perf_counter()
-                o.sample(4, smp_c, Nc, (np.arange(Vc) * (Lc // Vc)).astype(np.float64) + 0.25, a=speed_h[:Vc])
+                o.sample(4, smp_c, Nc, pos_c, a=speed_h[:Vc])
                 dt = time.perf_counter() - t0
                 return {"unit": "Msamples/s", "kind": kind, "value": round(Vc * Nc / dt / 1e6, 2), "cores": 1,
                         "sample": "maxiSample::playAtSpeed, %d heads x %d samples over a 4 Mi-element sample, one thread; %.2f s wall" % (Vc, Nc, dt)}

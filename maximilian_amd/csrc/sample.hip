@@ -630,12 +630,16 @@ inline dim3 grid_for(size_t V, int block) { return dim3((unsigned)((V + block - 
 
 // time parts for a block-constant *AtSpeed launch: the kernel keeps three wavefronts per SIMD resident (~160 VGPRs); two rounds
 // of them measured best at 65 536 voices (69 us with 6 parts against 76 with 4 and 84 with 3), each part >= 32 samples
-inline int speed_parts(size_t V, size_t N, size_t *part_len) {
+inline int speed_parts(size_t V, size_t N, size_t sample_len, size_t *part_len) {
     int split = tune_get("smp_split");
     if (split == 0) {
         const size_t waves = (V + 63) / 64;
         split = waves >= 6144 ? 1 : (int)(6144 / (waves ? waves : 1));
         if (split > 8) split = 8;
+        // a sample far beyond the 256 MB Infinity Cache: the heads read HBM, and every extra part is one more place per voice that is being
+        // read at the same time -- two parts measured best there (65 536 heads over an 8.6 GB sample: 1 / 2 / 3 / 4 / 6 / 8 parts = 190 /
+        // 137 / 151 / 152 / 152 / 147 us, profiles/r06_sample_bank.md)
+        if (sample_len * sizeof(double) > ((size_t)1 << 30) && split > 2) split = 2;
     }
     while (split > 1 && N / (size_t)split < 32) split--;
     size_t len = ((N + split - 1) / split + 7) / 8 * 8;
@@ -806,7 +810,7 @@ int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, siz
     const dim3 grid = grid_for(V, block);
     if (mode >= 4 && mode <= 6 && !xmod) {
         size_t part_len = N;
-        const int split = speed_parts(V, N, &part_len);
+        const int split = speed_parts(V, N, len, &part_len);
         if (split > 1) {
             PartSync part_ctrs;
             const dim3 pgrid(grid.x, (unsigned)split);

@@ -49,6 +49,34 @@ __device__ __forceinline__ void lores_coeffs_dev(double cutoff, double resonance
     r = (sqrt(2.0) * sqrt(-cube) + resonance * (z - 1)) / (resonance * (z - 1));
 }
 
+// The same pair through ONE sine (round 6, the fused voice's modulated mode: 65 -> ~35 vector instructions per sample).  With
+// s = sin(theta / 2), theta = TWOPI*cutoff/sr in [0, 2 pi]:  z = cos(theta) = 1 - 2 s^2, so  c = 2 - 2 z = 4 s^2  and, the square roots of
+// C:461 taken symbolically,  sqrt(2) * sqrt(-(z - 1)^3) = 4 s^3  and  r = (4 s^3 - 2 res s^2) / (-2 res s^2) = 1 - (2 / res) s:
+// no cos, no cube, two square roots and a division fewer -- and no cancellation in z - 1, so these are the TRUE coefficients where the
+// reference's own carry its rounding of z (relative 1e-16 / (1 - z): up to 1e-10 at a 10 Hz cutoff).  Tolerance mode either way (DESIGN.md:
+// 1e-11 of the voice's peak; the worst case of the difference, cutoff = amplitude * 10000 at the bottom of a release, is 1e-13).
+// kr = 2 / max(res, 1) (C:458) and pisr = pi / sr are hoisted by the caller.  Where z rounds to 1 (cutoff clamped to sr: theta = 2 pi)
+// the reference has c = 0 and r = 0 / 0: reproduced.
+__device__ __forceinline__ void lores_coeffs_sin(double cutoff, const double kr, const double pisr, const double sr, double &c, double &r) {
+    using namespace sincos_detail;
+    if (cutoff < 10) cutoff = 10;
+    if (cutoff > sr) cutoff = sr;
+    const double phi = cutoff * pisr;  // theta / 2 in [0, pi]
+    constexpr double kPiHi = 2.0 * kPio2Hi, kPiLo = 2.0 * kPio2Lo;
+    const double y = phi > 0.5 * (kPiHi + kPiLo) ? (kPiHi - phi) + kPiLo : phi;  // sin(pi - phi) = sin(phi): y in [0, pi/2]
+    const bool far = y > 0.25 * (kPiHi + kPiLo);
+    const double w = far ? (kPio2Hi - y) + kPio2Lo : y;                           // sin(y) = cos(pi/2 - y): |w| <= pi/4
+    const double sn = k_sin(w, 0.0), cs = k_cos(w, 0.0);
+    const double sv = far ? cs : sn;
+    const double m = 2.0 * (sv * sv);  // 1 - z
+    c = 2.0 * m;
+    r = 1.0 - kr * sv;
+    if (!(m > 0x1p-54)) {  // z = fl(1 - m) = 1: C:459-461 give c = 2 - 2 = 0 and r = 0 / 0 (a NaN cutoff lands here as well)
+        c = m != m ? m : 0.0;
+        r = __builtin_nan("");
+    }
+}
+
 __device__ __forceinline__ double flt_lores(Flt &f, double input, double c, double r) {  // C:463-467
     f.x = f.x + (input - f.y) * c;
     f.y = f.y + f.x;
@@ -497,13 +525,15 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
     Env e;
     env_load(e, V, v, par, holdtime, dst, ist);
     const double inc = (1. / (sr / (freq[v]))) * 2.0;  // C:337
-    double c = 0, r = 0, cut = 0, rs = 0;
+    double c = 0, r = 0, cut = 0, rs = 0, kr = 0;
+    const double pisr = MXG_PI / sr;
     if constexpr (MODE == 0) {
         c = coef[v];
         r = coef[V + v];
     } else {
         cut = cutoff[v];
         rs = res[v];
+        kr = 2.0 / (rs < 1. ? 1. : rs);  // C:458; a NaN resonance stays NaN (rs < 1 is false, 2 / NaN)
     }
     double *op = out + v;
     double *pp = out + (size_t)(threadIdx.x & 1) * V + (v & ~(size_t)1);  // pair rows: this lane's 16 bytes of row n + (lane & 1)
@@ -574,7 +604,7 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
         tile_rows(o, 8);
     };
     // consume the prologue loads here so no vmcnt(0) is needed inside the loop (see osc.hip K1m)
-    asm volatile("" : "+v"(phase), "+v"(hold), "+v"(c), "+v"(r), "+v"(cut), "+v"(rs));
+    asm volatile("" : "+v"(phase), "+v"(hold), "+v"(c), "+v"(r), "+v"(cut), "+v"(rs), "+v"(kr));
     asm volatile("" : "+v"(f.x), "+v"(f.y), "+v"(e.amplitude), "+v"(e.output), "+v"(e.attack), "+v"(e.decay));
     asm volatile("" : "+v"(e.sustain), "+v"(e.release), "+v"(e.holdtime), "+v"(e.holdcount));
     constexpr int U = 8;
@@ -621,7 +651,7 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
             constexpr bool SUS = decltype(sustain)::value;
             if constexpr (MODE == 1 && SUS) {
                 // the envelope value, hence (cutoff, c, r), is the same for every sample of the chunk
-                lores_coeffs_dev((1.0 * e.amplitude) * cut, rs, sr, c, r);
+                lores_coeffs_sin((1.0 * e.amplitude) * cut, kr, pisr, sr, c, r);
             }
             double ov[U];
 #pragma unroll
@@ -640,7 +670,7 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
                     hold = s;
                     if (phase >= 1.0) phase -= 2.0;
                     phase += inc;
-                    if constexpr (!SUS) lores_coeffs_dev(a * cut, rs, sr, c, r);
+                    if constexpr (!SUS) lores_coeffs_sin(a * cut, kr, pisr, sr, c, r);
                     double y = flt_lores(f, s, c, r);
                     o = y * a;
                 }
@@ -700,6 +730,44 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
             }
         }
       }
+      if constexpr (MODE == 1) {
+        // The same speculative chunk for the modulated voice (round 6): here the ENVELOPE comes first (14.monosynth/main.cpp:50-55: the
+        // envelope's output scales the cutoff), so its eight values are formed in one steady chunk (input 1.0: output = amplitude) if
+        // every lane stays inside a stage of its own, and the oscillator, the coefficients and the filter follow sample by sample.
+        if (n0 + U <= N) {
+            bool lane_gate, constant;
+            if constexpr (TPV) {
+                lane_gate = tc[0] == 1;
+                constant = true;
+#pragma unroll
+                for (int i = 1; i < U; i++) constant = constant && ((tc[i] == 1) == lane_gate);
+            } else {
+                const int g = lane_value(gcur.cls, (int)((n0 / U) & 63));
+                lane_gate = g > 0;
+                constant = g != 0;
+            }
+            if (__all(constant)) {
+                const double ones[U] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+                double av[U], o[U];
+                Env s2 = e;
+                const bool ok = env_steady_chunk<U>(s2, ones, lane_gate, av);
+                if (__all(ok)) {
+                    e = s2;
+#pragma unroll
+                    for (int i = 0; i < U; i++) {
+                        double s = phase;  // saw C:333-340
+                        hold = s;
+                        if (phase >= 1.0) phase -= 2.0;
+                        phase += inc;
+                        lores_coeffs_sin(av[i] * cut, kr, pisr, sr, c, r);
+                        o[i] = flt_lores(f, s, c, r) * av[i];
+                    }
+                    emit(o);
+                    continue;
+                }
+            }
+        }
+      }
       double og[U];
       const bool whole = n0 + U <= N;  // (wave-uniform)
 #pragma unroll
@@ -723,7 +791,7 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
             hold = s;
             if (phase >= 1.0) phase -= 2.0;
             phase += inc;
-            lores_coeffs_dev(a * cut, rs, sr, c, r);
+            lores_coeffs_sin(a * cut, kr, pisr, sr, c, r);
             double y = flt_lores(f, s, c, r);
             o = y * a;
         }

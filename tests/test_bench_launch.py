@@ -103,7 +103,7 @@ def test_default_line_carries_every_gpu_config():
     assert d["notes"]["kernel_ms"] and 0.3 < d["roofline"]["frac_wall"] <= d["roofline"]["frac"] * 1.02
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] in ("reference", "port")
     want = {"config2_mixdown": "osc_mix_kernel", "config2_tables": "osctab_kernel", "config3": "voice_kernel", "config3_modB": "voice_kernel",
-            "config3_mixdown": "voice_kernel",
+            "config3_mixdown": "voice_kernel", "sample_bank": "sample_parts_kernel",
             "config4": "fft_mfcc_kernel", "config4_walk": "fft_mfcc_kernel", "config4_mfma": "fft_mfcc_kernel", "config5": "granular_unit_kernel"}
     assert set(d["configs"]) == set(want), d["configs"].keys()
     for name, kernel in want.items():
