@@ -486,7 +486,7 @@ def main():
                 return {"unit": "Msamples/s", "kind": kind, "value": round(Vc * Nc / dt / 1e6, 2), "cores": 1,
                         "sample": "maxiSample::playAtSpeed, %d heads x %d samples over a 4 Mi-element sample, one thread; %.2f s wall" % (Vc, Nc, dt)}
             W = dict(step=step_sample, samples=Vs * B, dominant="sample_parts_kernel", algo_bytes=(16.0 + 24.0 / B) * Vs * B, dtype="f64", cpu=cpu,
-                     local_step=None, keep=(arena,),
+                     local_step=None, keep=(arena,), traffic_key="sample_parts_kernel@sample_bank",
                      tag="maxiSample::playAtSpeed, %d heads over one 8.6 GB sample (HBM-resident: each head its own region), block 512" % Vs,
                      workload="north_star's sample path where the sample cannot live on chip: %d play heads of maxiSample::playAtSpeed over one "
                               "%.1f GB sample, heads %d elements apart, speeds over [0.5, 1.5) (mean 1: 8 B read + 8 B written per sample), "
@@ -546,6 +546,7 @@ def main():
             if mixdown == "fused":
                 algo3 += 8.0 * V + 16.0 * B * (V / 256.0)  # + pan read, per-workgroup mix rows written
             W = dict(step=step, samples=V * B, dominant="voice_kernel", algo_bytes=algo3, dtype="f64", cpu=cpu,
+                     traffic_key="voice_kernel@config3_modB" if mode == 1 else ("voice_kernel@config3_mix" if mixdown == "fused" else None),
                      tag="configs[2]: %d voices saw->lores->adsr (mode %s), block 512%s" % (V, "AB"[mode], {"fused": " + fused stereo mixdown",
                                                                                                        "separate": " + K3 mixdown", "off": ""}[mixdown]),
                      fp64_flops=fps3 * V * B if fps3 else None,
@@ -615,6 +616,7 @@ def main():
                 return out
             W = dict(step=step, samples=NF * 1024, dtype="f32 (FFT) / f64 (MFCC)", cpu=cpu, read_ceiling=read_ceiling if fused_ok else None,
                      dominant="mfcc_mfma_gemm_kernel" if mfma else ("fft_mfcc_kernel" if fused_ok else "fft1024_kernel"),
+                     traffic_key="fft_mfcc_kernel@config4_mfma" if mm else ("fft_mfcc_kernel@config4_walk" if mfcc_method == "walk" else None),
                      tag="configs[3]: maxiFFT(1024)+maxiMFCC(512,42,13) x %d frames, %s" % (NF, "FFT kernel + dense MFMA GEMM" if mfma else (
                          "fused, exact FFT, matrix-pipe mel+DCT" if mm else ("fused, exact FFT, exact band sums (walk), matrix DCT" if
                                                                             mfcc_method == "walk" else "fused, library default form"))),
@@ -878,8 +880,9 @@ def main():
         ent = {"workload": Wq["workload"], "tag": Wq.get("tag"), "steps": steps, "warmup": warm, "ms_per_step": round(ms, 5),
                "value": round(Wq["samples"] / ms / 1e3, 1), "unit": "Msamples/s", "dtype": Wq["dtype"]}
         tr = None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(dom_k)
+        try:  # (a variant of a workload keeps its own counter figure under kernel@workload: tools/summarize_rocprof.py)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            tr = tj.get(Wq.get("traffic_key") or dom_k, tj.get(dom_k))
         except Exception:
             pass
         if Wq.get("mfma_flops"):
@@ -1002,7 +1005,8 @@ def main():
     algo_per_launch = W["algo_bytes"] / dom_launches
     traffic = None
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(dom)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        traffic = tj.get(W.get("traffic_key") or dom, tj.get(dom))
     except Exception:
         traffic = None
 

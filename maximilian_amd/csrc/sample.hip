@@ -386,7 +386,7 @@ __device__ __forceinline__ void smp_skip(double &pos, const double step, const d
 #ifndef MXG_SMP_WPE
 #define MXG_SMP_WPE 3  // A/B (tools/build_ab.sh): wavefronts per SIMD the time-part kernel is compiled for
 #endif
-template <int MODE, bool PIPE, bool PX>
+template <int MODE, bool PIPE, bool PX, bool RING>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MXG_SMP_WPE))) sample_parts_kernel(SmpArgs A, const size_t part_len, PartSync psync) {
     __shared__ double s_win[4 * 64 * kRowDoubles];
     const size_t V = A.V, N = A.N;
@@ -431,11 +431,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MXG_SM
     // `render` is the same code either way.
     struct Chunk {
         double rem[U];
-        int tap[U];   // offset of the first tap in the lane's row; the second is the next double
+        int tap[U];   // offset of the first tap in the lane's row; the second is the next double (ring: the next double modulo 16)
+        unsigned slots;  // ring chunks, loader view: nibble j = 8 | the ring slot (0..7) piece j of this lane goes to, 0 = nothing to load
         unsigned ok;  // bit i: the reference's bounds test of sample i
         bool staged;
+        bool ring;    // wave-uniform: the rows are used as rings (below)
         bool allok;   // wave-uniform: every sample of every lane passed it (no select needed)
     };
+    // Round 6 -- the row as a RING of eight 16-byte pieces (absolute piece p = sample index / 2 lives in slot p & 7, so sample index i is
+    // at double i & 15 of the row): consecutive chunks of a forward-moving head overlap by half a window, and re-fetching the overlap
+    // is harmless while the sample sits in L2 but DOUBLES the HBM traffic of a bank whose heads are spread over gigabytes (every
+    // XCD streams its L2's worth of other voices' windows between two chunks of one wavefront: FETCH_SIZE 563 MB per 268 MB block,
+    // profiles/r06_sample_bank.md).  A smooth chunk (forward, no wrap, every lane's span within eight pieces) therefore loads only the
+    // pieces behind the last one it holds: `ring_end` = one past that piece, per voice; a chunk of any other kind uses the rows the
+    // old way and forgets the ring.  The (first, end) pair of pieces a voice wants travels to its eight loader lanes through the two
+    // padding doubles of its own row.
+    int ring_end = -(1 << 30);
     double2v c[U];  // the loads in flight: only ever one chunk's (fetched after the previous one has landed)
     // The head in 32 bits.  A part that skipped (step > 0, head >= 0) with the sample and the head below 2^30 needs none of the
     // 64-bit conversions of smp_gen: (long long)pos == (int)pos, the bounds tests compare ints, and playAtSpeed's wrap
@@ -517,6 +528,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MXG_SM
             C.ok |= r[i].ok ? (1u << i) : 0u;
         }
         C.staged = false;
+        C.ring = false;
+        if (RING && can_stage && smooth) {
+            const int plo = (int)r[0].idx[0] >> 1, phi = ((int)r[U - 1].idx[0] + 1) >> 1;  // pieces of the first / the last tap
+            C.ring = __all(phi - plo < 8) && A.len < ((size_t)1 << 30);
+            if (C.ring) {
+                // at least the last piece is (re)loaded, so that the count fits three bits: first piece * 8 + (pieces - 1) in one word
+                int first = ring_end > plo ? ring_end : plo;
+                first = first < phi ? first : phi;
+                const unsigned want = ((unsigned)first << 3) | (unsigned)(phi - first);
+                ring_end = phi + 1;
+                C.slots = 0;
+#pragma unroll
+                for (int j = 0; j < U; j++) {  // piece (lane & 7) of what voice 8j + lane/8 still needs
+                    const unsigned w = (unsigned)__shfl((int)want, 8 * j + (lane >> 3));
+                    const bool need = (unsigned)(lane & 7) <= (w & 7u);
+                    // (a lane with nothing to fetch repeats the voice's last piece -- the line its neighbour requests anyway -- so that c[]
+                    // is overwritten as a whole: a predicated load would keep the previous chunk's 32 registers alive through this function)
+                    const unsigned pc = (w >> 3) + (need ? (unsigned)(lane & 7) : (w & 7u));
+                    C.slots |= need ? (8u | (pc & 7u)) << (4 * j) : 0u;
+                    c[j] = *reinterpret_cast<const double2v *>(amp + 2 * (size_t)pc);
+                    C.tap[j] = (int)r[j].idx[0] & (kSmpWindow - 1);
+                }
+                C.staged = true;
+                C.allok = true;
+                return;
+            }
+        }
+        ring_end = -(1 << 30);
         int base = 0;
         if (can_stage) {
             int lo = (int)r[0].idx[0], hi = (int)r[U - 1].idx[0];  // idx[1] = idx[0] + 1 for these players (mxg_smp.h)
@@ -550,6 +589,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MXG_SM
         }
     };
     auto land = [&](const Chunk &C) {
+        if (RING && C.ring) {
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const unsigned nb = (C.slots >> (4 * j)) & 15u;
+                if (nb) *reinterpret_cast<double2v *>(win + (8 * j + (lane >> 3)) * kRowDoubles + 2 * (nb & 7u)) = c[j];
+            }
+            smp_lds_sync();
+            return;
+        }
         if (C.staged) {
 #pragma unroll
             for (int j = 0; j < U; j++)
@@ -564,9 +612,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MXG_SM
         Req q;
         double o[U];
         if (C.allok) {
+            const int wrap = (RING && C.ring) ? kSmpWindow - 1 : 2 * kSmpWindow - 1;  // (a ring's second tap wraps at 16; a window's never reaches it)
 #pragma unroll
             for (int i = 0; i < U; i++) {
-                const double val[2] = {row[C.tap[i]], row[C.tap[i] + 1]};
+                const double val[2] = {row[C.tap[i]], row[(C.tap[i] + 1) & wrap]};
                 q.rem = C.rem[i];
                 q.ok = true;
                 o[i] = smp_eval<MODE>(q, val);
@@ -817,18 +866,25 @@ int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, siz
             if (int e = part_sync_get(st, (size_t)grid.x * ((block + 63) / 64), split, &part_ctrs)) return e;
             const bool pipe = tune_get("smp_pipe") != 0;
             KernelTimer kt("sample_parts_kernel", st);
-#define MXG_PARTS(M)                                                                                                                  \
-    if (pipe) {                                                                                                                       \
-        if (A.px_store) hipLaunchKernelGGL((sample_parts_kernel<M, true, true>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);   \
-        else hipLaunchKernelGGL((sample_parts_kernel<M, true, false>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);            \
-    } else {                                                                                                                          \
-        if (A.px_store) hipLaunchKernelGGL((sample_parts_kernel<M, false, true>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);  \
-        else hipLaunchKernelGGL((sample_parts_kernel<M, false, false>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);           \
+            // rows as rings (only the pieces behind the last one held are fetched): for samples beyond the Infinity Cache, where re-fetching
+            // the overlap of consecutive windows doubled the HBM traffic (knob smp_ring: 0 automatic, 1 off, 2 on); measured, 65 536 heads:
+            // 8.6 GB sample 142 -> 128 us, the shared 3.5 MB sample 72 -> 81 us (profiles/r06_sample_bank.md)
+            const int ring_knob = tune_get("smp_ring");
+            const bool ring = ring_knob == 2 || (ring_knob == 0 && len * sizeof(double) > ((size_t)1 << 30));
+#define MXG_PARTS2(M, P, R)                                                                                                          \
+    if (A.px_store) hipLaunchKernelGGL((sample_parts_kernel<M, P, true, R>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);      \
+    else hipLaunchKernelGGL((sample_parts_kernel<M, P, false, R>), pgrid, dim3(block), 0, st, A, part_len, part_ctrs);
+#define MXG_PARTS(M)                                                \
+    if (pipe) {                                                     \
+        if (ring) { MXG_PARTS2(M, true, true) } else { MXG_PARTS2(M, true, false) }   \
+    } else {                                                        \
+        if (ring) { MXG_PARTS2(M, false, true) } else { MXG_PARTS2(M, false, false) } \
     }
             if (mode == 4) { MXG_PARTS(4) }
             if (mode == 5) { MXG_PARTS(5) }
             if (mode == 6) { MXG_PARTS(6) }
 #undef MXG_PARTS
+#undef MXG_PARTS2
             return check_hip(hipGetLastError(), "sample_parts_kernel launch");
         }
     }

@@ -382,6 +382,40 @@ def test_sample_speed_players_full_waves(mx, port, mode, Ls, split):
 
 
 @pytest.mark.parametrize("mode", [4, 5, 6])
+@pytest.mark.parametrize("Ls,split,slow", [(20000, 0, False), (700, 3, False), (20000, 5, True), (700, -3, True), (300000, 2, False)])
+def test_sample_speed_players_ring_rows(mx, port, mode, Ls, split, slow):
+    """Round 6: the time-part kernel's window rows used as RINGS (knob smp_ring 2; automatic for samples beyond 1 GiB) -- a smooth chunk
+    fetches only the 16-byte pieces behind the last one its voice holds.  Same bits as the oracle over three carried blocks: mixed speeds
+    (a wavefront with fast voices falls back to windows or gathers chunk by chunk and forgets its ring), very slow heads (chunks that need
+    nothing new), short samples (wraps inside a block), every part count, with and without the software pipeline."""
+    pipe = 0 if split < 0 else 1
+    split = abs(split)
+    rng = np.random.default_rng(1900 + mode + Ls)
+    V = 256
+    smp = rng.uniform(-1, 1, Ls)
+    a = _mixed_speeds(V, rng, reverse=False)
+    if slow:
+        a[:64] = rng.uniform(0.001, 0.05, 64)      # wave 0: heads that stay inside one piece for many chunks
+        a[64:128] = rng.uniform(0.9, 1.1, 64)
+    end = rng.uniform(0.3, 1.0, V) if mode == 6 else np.ones(V)
+    pos0 = rng.uniform(0, Ls - 2, V)
+    bank = mx.maxiSampleBank(V)
+    bank.setSample(smp)
+    bank.position.upload(pos0)
+    kw = dict(a=a, start=np.zeros(V), end=end)
+    blocks = [512, 203, 64]
+    L = mx.lib()
+    prev = [L.mxg_tune(b"smp_split", split), L.mxg_tune(b"smp_pipe", pipe), L.mxg_tune(b"smp_ring", 2)]
+    try:
+        o = np.concatenate([bank.render(mode, n, **kw).numpy() for n in blocks])
+    finally:
+        L.mxg_tune(b"smp_split", prev[0]); L.mxg_tune(b"smp_pipe", prev[1]); L.mxg_tune(b"smp_ring", prev[2])
+    e, ep = port.sample(mode, smp, sum(blocks), pos0, **kw)
+    assert_bits_equal(o, e, "mode %d, rows as rings" % mode)
+    assert_bits_equal(bank.position.numpy(), ep, "position")
+
+
+@pytest.mark.parametrize("mode", [4, 5, 6])
 def test_sample_time_parts_corner_heads(mx, port, mode):
     """Heads and speeds the skip must not touch or must get exactly right: negative and zero speeds and negative heads in the
     wavefront (part 0 renders it whole), a step below half an ulp of the head (the head does not move), a head sitting

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/summarize_rocprof.py [tag] -- condense gpurun_out/prof_<tag>/ (tools/profile_r04.sh; rounds 2-3: profile_r02/r03.sh) into profiles/:
+"""tools/summarize_rocprof.py [tag] -- condense gpurun_out/prof_<tag>/ (tools/profile_r06.sh; earlier rounds: profile_r0N.sh) into profiles/:
   profiles/<tag>_<workload>_summary.md      per kernel: rocprofv3 kernel-trace average duration (timed launches), PMC HBM
                                              traffic per launch, next to the un-profiled bench.py line of the same command
   profiles/<tag>_<workload>_kernel_stats.csv the rocprofv3 --stats table, verbatim
@@ -14,13 +14,13 @@ import shutil
 import statistics
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 LABELS = ["osc_mixpc_kernel", "osc_mix_kernel", "osctab_marks_kernel", "osctab_kernel", "osc_kernel", "mix_partials_kernel", "voice_kernel", "fft_mfcc_kernel", "fft1024_kernel",
           "mfcc_mfma_gemm_kernel", "mfcc_stream_tiled_kernel", "granular_unit_kernel", "granular_sched_kernel",
-          "granular_unit_state_kernel", "mix_bus_kernel", "bus_gains_kernel"]
+          "granular_unit_state_kernel", "granular_retry_kernel", "sample_parts_kernel", "mix_bus_kernel", "bus_gains_kernel"]
 
 
 def label_of(name):
