@@ -430,13 +430,23 @@ def main():
             # cross-XCD hand-offs are write-through round trips -- so the step keeps the 6-us row-sum kernel: profiles/r06_k1t.md)
             t_ahead, t_sum = int(tk.get("tables_ahead", 1)), int(tk.get("tables_sum", 0))
 
-            def step_tables():
+            # tables_queue=1 (default): the rows go into a slot of a GROUPED mix queue, as K1m's and K2f's do -- the queue adds the rows of 16
+            # blocks with one kernel on ITS stream (and would reduce them over RCCL); tables_queue=0: the row-sum kernel behind every render
+            t_queue = int(tk.get("tables_queue", 1)) and not t_sum
+            if t_queue:
+                queue = make_queue(B * 2, args.mix_depth, Gt)
+
+            def render_tables(rows_ptr, mix_ptr):
                 # round 6: pipelined blocks -- the next block's phase recurrence walks beside this block's table traffic (tables_ahead=0:
                 # round 5's marks kernel in front of every render); tables_sum=1: the row sum inside the render kernel
                 chk(L.mxg_osc_render_tables_ex(Vt, B, ft.data_ptr(), tabs.data_ptr(), pht.data_ptr(), hdt.data_ptr(), None, pt.data_ptr(),
-                                               rowst.data_ptr(), mixt.data_ptr() if t_sum else None, t_ahead, stream), "mxg_osc_render_tables_ex")
+                                               rows_ptr, mix_ptr, t_ahead, stream), "mxg_osc_render_tables_ex")
+
+            def step_plain():
+                render_tables(rowst.data_ptr(), mixt.data_ptr() if t_sum else None)
                 if not t_sum:
                     chk(L.mxg_mix_rows_sum(Gt, B * 2, rowst.data_ptr(), mixt.data_ptr(), stream), "mxg_mix_rows_sum")
+            step_tables = MixdownStep(lambda slot: render_tables(slot, None), queue) if t_queue else step_plain
             W = dict(step=step_tables, samples=Vt * B, dominant="osctab_kernel", algo_bytes=Vt * (514 * 8.0 + 24.0), dtype="f64", cpu=None,
                      tag="EXTENSION: %d-voice sinebuf bank, one 514-entry table PER VOICE (HBM-read form), fused mixdown out" % Vt,
                      local_step=None,

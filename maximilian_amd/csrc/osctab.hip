@@ -30,6 +30,9 @@
 namespace mxg {
 namespace {
 
+#ifndef MXG_TAB_ABLATE
+#define MXG_TAB_ABLATE 0  // timing experiments only (wrong results): 1 = no rendering (DMA + barriers only), 2 = no DMA inside the loop (the first pair's tables rendered again and again)
+#endif
 #ifndef MXG_TAB_AUX
 #define MXG_TAB_AUX 2  // A/B: 0 = default cache policy
 #endif
@@ -41,8 +44,7 @@ constexpr int kTabParts = 16;        // time parts per block (32 samples each), 
 constexpr int kTabVoices = 8;        // voices per round
 constexpr int kTabHdr = kTabParts * kTabVoices + 3 * kTabVoices;  // per-round header: marks[16][8], inc[8], gl[8], gr[8] (152 doubles)
 constexpr int kTabRound = kTabVoices * kTabLen + kTabHdr;         // doubles per LDS buffer: 4112 + 152 = 4264 (34 112 B)
-constexpr int kTabRing = 4;          // LDS buffers: the pair of rounds in use + the next pair arriving by DMA (the loop waits vmcnt(0) once per pair)
-static_assert(kTabRound * 8 == 8 * 4096 + 84 * 16, "a round is 8 full 4 KiB pieces + 84 sixteen-byte pieces");
+static_assert(kTabRound * 8 == 2048 * 16 + 84 * 16, "a round is 8 full 4 KiB pieces + 84 sixteen-byte pieces");
 
 // (An experiment that stays as an A/B form, MXG_TAB_CMPX 2.)  The wrap test ahead of the add.  C:270 tests the SUM: `phase += inc; if (phase >= 511) phase -= 512;` -- add, compare, select,
 // subtract, four dependent fp64 operations per step of a chain that nothing else can hide (the marks pass IS that chain, 512 steps per
@@ -190,6 +192,7 @@ __device__ __forceinline__ T fold8(const T (&v)[8], int lane) {
 
 // round g (its 8 tables + its header) -> one LDS buffer, 16-byte pieces, lane-linear, by all 512 threads: 4 pieces per lane + a fifth
 // for threads 0..83 (the last 128 B of the tables and the 1216 B of the header)
+template <int NT>  // threads of the workgroup (512: 4 pieces per lane, 256: 8) + a last one for threads 0..83
 __device__ __forceinline__ void round_issue(const double *__restrict__ tables, const double *__restrict__ hdr, size_t g, size_t V,
                                             double *buf) {
     const size_t first = g * kTabVoices;
@@ -200,18 +203,18 @@ __device__ __forceinline__ void round_issue(const double *__restrict__ tables, c
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     char *dst = reinterpret_cast<char *>(buf) + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        unsigned off = (unsigned)(i * 512 + (int)threadIdx.x) * 16u;
+    for (int i = 0; i < 2048 / NT; i++) {
+        unsigned off = (unsigned)(i * NT + (int)threadIdx.x) * 16u;
         if (off >= tbytes) off = 0;  // (a short last group: re-read its first bytes)
         // (aux = 2: non-temporal -- every table byte is read once by one CU; MI355X_MICROARCH.md "nt-weights")
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
-                                         (__attribute__((address_space(3))) void *)(dst + i * 8192), 16, 0, MXG_TAB_AUX);
+                                         (__attribute__((address_space(3))) void *)(dst + i * (NT * 16)), 16, 0, MXG_TAB_AUX);
     }
     if (threadIdx.x < 84) {  // bytes [32768, 34112) of the buffer
         const unsigned off = 32768u + threadIdx.x * 16u;
         const char *p = off < 8u * kTabLen * 8u ? (off < tbytes ? src + off : src) : hsrc + (off - 8u * kTabLen * 8u);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
-                                         (__attribute__((address_space(3))) void *)(dst + 4 * 8192), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(dst + 32768), 16, 0, 0);
     }
 }
 
@@ -220,13 +223,21 @@ __device__ __forceinline__ void round_issue(const double *__restrict__ tables, c
 // 512 lanes render TWO rounds side by side (lanes 0-255 the even rounds of its range, lanes 256-511 the odd ones): two wavefronts per
 // SIMD, so that one round's LDS latencies and bank conflicts hide behind the other's arithmetic.  Inside a round the table reads of all
 // 16 samples are in flight at once (osc_pipe_*, mxg_osc.h).  Ring of four buffers: two rounds in use, the next two arriving by DMA.
-template <bool STORE, bool MIX, bool AHEAD>
-__global__ __launch_bounds__(512) void osctab_kernel(size_t V, size_t N, const double *__restrict__ tables,
+// SIDES (round 6): 2 = a workgroup of 512 lanes renders two rounds side by side, one barrier for both (rounds 4-5); 1 = a workgroup of 256
+// lanes renders one round at a time with a ring of two buffers, TWO such workgroups per CU (the same 136 KB of LDS, the same two wavefronts
+// per SIMD).  The two workgroups of a CU drift apart, so one of them is always waiting for ITS next round while the other computes: the CU
+// has a DMA in flight all the time, where the lockstep pair issued 67 KB at once and then drained it to nothing before issuing again --
+// the kernel was bound by the latency of that burst, not by its arithmetic (the kernel without rendering took 101-109 us of its 112-119,
+// the kernel without DMA 87: profiles/r06_k1t.md).
+template <bool STORE, bool MIX, bool AHEAD, int SIDES>
+__global__ __launch_bounds__(256 * SIDES) void osctab_kernel(size_t V, size_t N, const double *__restrict__ tables,
                                                      const double *__restrict__ hdr, double *__restrict__ hold_io,
                                                      double *__restrict__ out, double *__restrict__ rows, TabAhead AH, TabSum SM) {
-    __shared__ __attribute__((aligned(16))) double s_buf[kTabRing * kTabRound];
+    constexpr int kRing = 2 * SIDES;  // LDS buffers: the SIDES rounds in use + the next SIDES arriving by DMA
+    constexpr int NT = 256 * SIDES;
+    __shared__ __attribute__((aligned(16))) double s_buf[kRing * kTabRound];
     const int lane = threadIdx.x & 63;
-    const int side = threadIdx.x >> 8, tid8 = threadIdx.x & 255;
+    const int side = SIDES == 2 ? threadIdx.x >> 8 : 0, tid8 = threadIdx.x & 255;
     const int u = tid8 & 7, h = (tid8 >> 3) & 1, t = tid8 >> 4;
     const size_t groups = (V + kTabVoices - 1) / kTabVoices;
     const size_t per = (groups + gridDim.x - 1) / gridDim.x;
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(512) void osctab_kernel(size_t V, size_t N, const d
             mh[kTabParts * kTabVoices + kTabVoices] = sqrt(1.0 - x);  // two[0] = input*sqrt(1.0-x)   C:506
             mh[kTabParts * kTabVoices + 2 * kTabVoices] = sqrt(x);    // two[1] = input*sqrt(x)       C:507
         }
-        const size_t npairs = (g1 - g0 + 1) / 2;
+        const size_t npairs = (g1 - g0 + SIDES - 1) / SIDES;  // iterations of the loop below
         upi = npairs ? (int)((2 * kTabParts + npairs - 1) / npairs) : 2 * kTabParts;
     }
     auto marks_units = [&](int units) {  // (wave-uniform control flow; every lane of the wavefront is active here)
@@ -295,19 +306,21 @@ __global__ __launch_bounds__(512) void osctab_kernel(size_t V, size_t N, const d
             mpend_t = -1;
         }
     };
-    for (int k = 0; k < 2; k++)
-        if (g0 + k < g1) round_issue(tables, hdr, g0 + k, V, s_buf + k * kTabRound);
+    for (int k = 0; k < SIDES; k++)
+        if (g0 + k < g1) round_issue<NT>(tables, hdr, g0 + k, V, s_buf + k * kTabRound);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (size_t gp = g0; gp < g1; gp += 2) {  // the pair of rounds (gp, gp + 1)
-        const int b0 = (int)((gp - g0) % kTabRing);
-        __builtin_amdgcn_s_barrier();  // everybody's pieces of this pair have landed; everybody is done with the previous pair's buffers ...
+    for (size_t gp = g0; gp < g1; gp += SIDES) {  // the rounds (gp, ..., gp + SIDES - 1)
+        const int b0 = (int)((gp - g0) % kRing);
+        __builtin_amdgcn_s_barrier();  // everybody's pieces of these rounds have landed; everybody is done with the previous rounds' buffers ...
         asm volatile("" ::: "memory");
-        for (int k = 0; k < 2; k++)    // ... which the next pair may now overwrite
-            if (gp + 2 + k < g1) round_issue(tables, hdr, gp + 2 + k, V, s_buf + ((b0 + 2 + k) % kTabRing) * kTabRound);
+#if !(MXG_TAB_ABLATE & 2)
+        for (int k = 0; k < SIDES; k++)    // ... which the next rounds may now overwrite
+            if (gp + SIDES + k < g1) round_issue<NT>(tables, hdr, gp + SIDES + k, V, s_buf + ((b0 + SIDES + k) % kRing) * kTabRound);
+#endif
         marks_flush();  // (the mark of the previous iteration: its store travels with this iteration's DMA)
         const size_t g = gp + side;
-        if (g < g1) {
-        const int b = (b0 + side) % kTabRing;
+        if (g < g1 && !(MXG_TAB_ABLATE & 1)) {
+        const int b = (MXG_TAB_ABLATE & 2) ? side : (b0 + side) % kRing;
         const double *B = s_buf + b * kTabRound;
         const double *H = B + kTabVoices * kTabLen;
         const size_t first = g * kTabVoices;
@@ -383,6 +396,14 @@ __global__ __launch_bounds__(512) void osctab_kernel(size_t V, size_t N, const d
                 R[i] = accR[8 * j + i];
             }
             pr[j] = double2v{fold8<double>(L, lane), fold8<double>(R, lane)};
+        }
+        if constexpr (SIDES == 1) {  // one round at a time: this workgroup's row as it is
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const size_t n = nb + 8 * j + slot;
+                if (slot >= 0 && n < N) *reinterpret_cast<double2v *>(rows + ((size_t)blockIdx.x * N + n) * 2) = pr[j];
+            }
+            return;
         }
 #if MXG_TAB_SIDEFOLD
         // the two sides of the workgroup (even / odd rounds of its range) meet in LDS -- the table ring is free after the last round
@@ -481,14 +502,23 @@ __global__ __launch_bounds__(512) void osctab_kernel(size_t V, size_t N, const d
 
 using namespace mxg;
 
-static size_t tables_grid(size_t V) {  // persistent: one workgroup per CU, two rounds at a time each
-    const size_t pairs = ((V + kTabVoices - 1) / kTabVoices + 1) / 2;
+// knob tab_sides: 0 automatic = 1; 1 = workgroups of 256 lanes, one round at a time, two per CU; 2 = workgroups of 512 lanes, two rounds
+// side by side (rounds 4-5)
+static int tables_sides() {
+    const int k = tune_get("tab_sides");
+    return k == 2 ? 2 : 1;
+}
+static size_t tables_grid(size_t V, int sides) {  // persistent: 136 KB of LDS per CU either way
+    const size_t groups = (V + kTabVoices - 1) / kTabVoices;
     const size_t cus = (size_t)device_cus();
+    if (sides == 1) return groups < 2 * cus ? groups : 2 * cus;
+    const size_t pairs = (groups + 1) / 2;
     return pairs < cus ? pairs : cus;
 }
 extern "C" size_t mxg_osc_tables_groups(size_t V) {
     if (ensure_init_only()) return 0;
-    return (MXG_TAB_SIDEFOLD ? 1 : 2) * tables_grid(V);  // a partial mix row per workgroup (its two sides are added in LDS)
+    const int sides = tables_sides();
+    return ((MXG_TAB_SIDEFOLD || sides == 1) ? 1 : 2) * tables_grid(V, sides);  // a partial mix row per workgroup
 }
 
 namespace {
@@ -518,11 +548,13 @@ extern "C" int mxg_osc_render_tables_ex(size_t V, size_t N, const double *d_freq
     if (V == 0 || N == 0) return MXG_OK;
     hipStream_t st = resolve_stream(stream);
     const size_t groups = (V + kTabVoices - 1) / kTabVoices;
-    const size_t grid = tables_grid(V);
+    int sides = tables_sides();
+    if (d_mix) sides = 2;  // (the row sum inside the kernel is written for the side-by-side form)
+    const size_t grid = tables_grid(V, sides);
     const double sr = (double)settings().sampleRate;
-    // the pipelined form: a workgroup's lanes (512) walk the marks of its own voices -- every workgroup must have at most 512
+    // the pipelined form: a workgroup's lanes walk the marks of its own voices -- every workgroup must have at most as many voices as lanes
     const size_t per = (groups + grid - 1) / grid;
-    const bool ahead = (flags & MXG_TABLES_AHEAD) && per * kTabVoices <= 512;
+    const bool ahead = (flags & MXG_TABLES_AHEAD) && per * kTabVoices <= (size_t)256 * sides;
     double *hdr = nullptr, *hdr2 = nullptr, *carry = nullptr;  // [groups][152] per-stream scratch: marks, increments, gains
     bool fresh = false, fresh2 = false, fresh3 = false;
     if (int s = scratch_get(SCR_OSCTAB_MARKS, st, sizeof(double) * kTabHdr * groups, (void **)&hdr, &fresh)) return s;
@@ -559,16 +591,19 @@ extern "C" int mxg_osc_render_tables_ex(size_t V, size_t N, const double *d_freq
         SM = TabSum{d_mix, reinterpret_cast<double *>(sumscr + 128), tickets};
     }
     KernelTimer kt("osctab_kernel", st);
-#define MXG_TAB_LAUNCH(S, M, A) \
-    hipLaunchKernelGGL((osctab_kernel<S, M, A>), dim3((unsigned)grid), dim3(512), 0, st, V, N, d_tables, hdr, d_outhold, d_out, d_rows, AH, SM)
+#define MXG_TAB_LAUNCH(S, M, A)                                                                                                            \
+    if (sides == 2)                                                                                                                        \
+        hipLaunchKernelGGL((osctab_kernel<S, M, A, 2>), dim3((unsigned)grid), dim3(512), 0, st, V, N, d_tables, hdr, d_outhold, d_out, d_rows, AH, SM); \
+    else                                                                                                                                   \
+        hipLaunchKernelGGL((osctab_kernel<S, M, A, 1>), dim3((unsigned)grid), dim3(256), 0, st, V, N, d_tables, hdr, d_outhold, d_out, d_rows, AH, SM)
     if (ahead) {
-        if (d_out && d_pan) MXG_TAB_LAUNCH(true, true, true);
-        else if (d_out) MXG_TAB_LAUNCH(true, false, true);
-        else MXG_TAB_LAUNCH(false, true, true);
+        if (d_out && d_pan) { MXG_TAB_LAUNCH(true, true, true); }
+        else if (d_out) { MXG_TAB_LAUNCH(true, false, true); }
+        else { MXG_TAB_LAUNCH(false, true, true); }
     } else {
-        if (d_out && d_pan) MXG_TAB_LAUNCH(true, true, false);
-        else if (d_out) MXG_TAB_LAUNCH(true, false, false);
-        else MXG_TAB_LAUNCH(false, true, false);
+        if (d_out && d_pan) { MXG_TAB_LAUNCH(true, true, false); }
+        else if (d_out) { MXG_TAB_LAUNCH(true, false, false); }
+        else { MXG_TAB_LAUNCH(false, true, false); }
     }
 #undef MXG_TAB_LAUNCH
     return check_hip(hipGetLastError(), "osctab_kernel launch");

@@ -52,6 +52,7 @@ Tune g_tune[] = {
     {"osc_mix_win", 0, 0, 256},  // K1m: samples per workgroup combine window (0 automatic: 256, 128 from 131 073 voices; 128 / 256)
     {"ifft_stream", 1, 0, 2},  // maxiIFFT: transform + hop buffer in one kernel (0: never; 1: where hop >= fftSize / 2; 2: wherever it fits)
     {"smp_pipe", 1, 0, 1},   // K5: the time-part kernel's loads of chunk k+1 issued before the stores of chunk k (0: chunk after chunk)
+    {"tab_sides", 0, 0, 2},  // K1t: 0 automatic (= 1), 1 workgroups of 256 lanes / one round at a time / two per CU, 2 workgroups of 512 lanes / two rounds side by side
     {"smp_ring", 0, 0, 2},   // K5 time-part kernel: rows as rings, only new 16-byte pieces fetched (0 automatic: samples beyond 1 GiB, 1 off, 2 on)
     {"smp_split", 0, 0, 8},  // K5: time parts of a block-constant *AtSpeed launch (0 = automatic: ~4 wavefronts per SIMD)
     {"mix_block", 256, 64, 1024},
