@@ -6,7 +6,11 @@
 // cpp/commandline/maximilian_examples/15.polysynth/main.cpp:54-70 (oscillator -> lores filter ->
 // ADSR, summed over voices, panned with maxiMix::stereo), for V voices instead of 6.
 //
-//   polysynth_host <voices> <frames> <out.f64>     writes frames*channels interleaved doubles
+//   polysynth_host <voices> <frames> <out.f64> [gpumix]    writes frames*channels interleaved doubles
+//
+// With `gpumix` the voice sum is not formed in play() at all: the bank renders the block WITH the maxiMix::stereo mixdown fused into the
+// same kernel (mxg_voice_render_mix, round 6) and play() reads the frame's two mix values -- the tree-ordered sum of the same
+// per-voice products, within conftest.mix_tol of the voice-order sum below.
 //
 // The banks render 512-frame blocks on the GPU; play() keeps its per-sample shape and sums the
 // voices on the host in voice order, so the output is bit-identical to the reference CPU loop
@@ -14,6 +18,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "maximilian_bank.hpp"
@@ -22,6 +27,7 @@ static size_t g_voices = 64;
 static maxiVoiceBank *voices = nullptr;
 static std::vector<double> panL, panR;
 static size_t g_frame = 0;
+static bool g_gpumix = false;
 static const size_t kBlock = 512;
 
 void setup() {
@@ -39,6 +45,11 @@ void setup() {
         panR[v] = std::sqrt(x);
     }
     voices->setVoices(freq, cutoff, res);
+    if (g_gpumix) {
+        std::vector<double> pan(g_voices);
+        for (size_t v = 0; v < g_voices; v++) pan[v] = g_voices > 1 ? (double)v / (double)(g_voices - 1) : 0.5;
+        voices->setPan(pan);
+    }
     voices->env.setAttack(10);
     voices->env.setDecay(100);
     voices->env.setSustain(0.5);
@@ -50,6 +61,13 @@ void play(double *output) {
         std::vector<int32_t> gate(kBlock);
         for (size_t i = 0; i < kBlock; i++) gate[i] = ((g_frame + i) % 4096) < 2048 ? 1 : 0;
         voices->setGate(gate);
+    }
+    if (g_gpumix) {  // the mixdown came with the block
+        output[0] = voices->mixFrame(0);
+        output[1] = voices->mixFrame(1);
+        voices->tick();
+        g_frame++;
+        return;
     }
     double l = 0, r = 0;
     for (size_t v = 0; v < g_voices; v++) {  // 15.polysynth/main.cpp:54-68
@@ -79,6 +97,7 @@ int main(int argc, char **argv) {
     }
     g_voices = (size_t)std::atol(argv[1]);
     const size_t frames = (size_t)std::atol(argv[2]);
+    g_gpumix = argc > 4 && std::string(argv[4]) == "gpumix";
     try {
         setup();
         std::vector<double> out(frames * maxiSettings::channels);

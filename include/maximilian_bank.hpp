@@ -379,16 +379,42 @@ public:
                                         env.holdtimes(), ost_.get(), fst_.get(), env.dstate(), env.istate(), d_out, stream),
                        "mxg_voice_render");
     }
+    // The same block with the maxiMix::stereo mixdown of the bank fused into the render (round 6: mxg_voice_render_mix) -- what the user
+    // code of 15.polysynth/main.cpp:54-70 computes voice after voice (`mymix.stereo(out, outputs, pan)` + the sums), here as d_mix [N][2]
+    // from ONE kernel that never re-reads the block.  d_out may be nullptr (mix only).  setPan() first.
+    void setPan(const std::vector<double> &x) { pan_.upload(x); }
+    void renderMix(int mode, size_t N, const int32_t *d_trig, double *d_out, double *d_mix, void *stream = nullptr) {
+        maxigpu::check(mxg_voice_render_mix(mode, V, N, freq_.get(), cutoff_.get(), res_.get(), coef_.get(), d_trig, 0, env.params(),
+                                            env.holdtimes(), ost_.get(), fst_.get(), env.dstate(), env.istate(), d_out, pan_.get(), d_mix,
+                                            stream), "mxg_voice_render_mix");
+    }
     // per-sample API: the gate for the NEXT block is whatever setGate() holds when the block is rendered
     void setGate(const std::vector<int32_t> &gateForBlock) { trig_.upload(gateForBlock); }
     double frame(size_t v) {
         return BlockServer::frame(v, [this](size_t N, double *d) { render(0, N, trig_.get(), d); });
     }
-    void tick() { advance(); }
+    // per-sample API of the mixed bank: channel ch (0 / 1) of the current frame's stereo mix, formed on the device
+    double mixFrame(int ch) {
+        if (mcursor_ == B || mix_host_.empty()) {
+            if (mix_.size() < 2 * B) mix_.resize(2 * B, false);
+            renderMix(0, B, trig_.get(), nullptr, mix_.get());
+            mix_host_.resize(2 * B);
+            mix_.download(mix_host_.data(), 2 * B);
+            mcursor_ = 0;
+        }
+        return mix_host_[mcursor_ * 2 + ch];
+    }
+    void tick() {
+        advance();
+        if (!mix_host_.empty()) ++mcursor_;
+    }
 
 private:
     maxigpu::DeviceArray<double> freq_, cutoff_, res_, coef_, ost_, fst_;
     maxigpu::DeviceArray<int32_t> trig_;
+    maxigpu::DeviceArray<double> pan_, mix_;
+    std::vector<double> mix_host_;
+    size_t mcursor_ = 0;
 };
 
 // ---- maxiMix::stereo over a bank + mixdown over voices (C:503-509) ---------------------------------------

@@ -64,10 +64,19 @@ __device__ __forceinline__ void lores_coeffs_sin(double cutoff, const double kr,
     const double phi = cutoff * pisr;  // theta / 2 in [0, pi]
     constexpr double kPiHi = 2.0 * kPio2Hi, kPiLo = 2.0 * kPio2Lo;
     const double y = phi > 0.5 * (kPiHi + kPiLo) ? (kPiHi - phi) + kPiLo : phi;  // sin(pi - phi) = sin(phi): y in [0, pi/2]
-    const bool far = y > 0.25 * (kPiHi + kPiLo);
-    const double w = far ? (kPio2Hi - y) + kPio2Lo : y;                           // sin(y) = cos(pi/2 - y): |w| <= pi/4
-    const double sn = k_sin(w, 0.0), cs = k_cos(w, 0.0);
-    const double sv = far ? cs : sn;
+    // sin on [0, pi/2] as ONE odd polynomial (the Taylor coefficients through y^21: truncation 1.3e-18 at pi/2; ten fused multiply-adds
+    // with the coefficient as the instruction's scalar operand) instead of fdlibm's two kernels on a folded argument and a select
+    const double z = y * y;
+    double pq = fma_kk(z, 1.9572941063391263e-20, -8.2206352466243295e-18);
+    pq = fma_k(z, pq, 2.8114572543455206e-15);
+    pq = fma_k(z, pq, -7.6471637318198164e-13);
+    pq = fma_k(z, pq, 1.6059043836821613e-10);
+    pq = fma_k(z, pq, -2.5052108385441720e-08);
+    pq = fma_k(z, pq, 2.7557319223985893e-06);
+    pq = fma_k(z, pq, -1.9841269841269841e-04);
+    pq = fma_k(z, pq, 8.3333333333333332e-03);
+    pq = fma_k(z, pq, -1.6666666666666666e-01);
+    const double sv = y + (y * z) * pq;
     const double m = 2.0 * (sv * sv);  // 1 - z
     c = 2.0 * m;
     r = 1.0 - kr * sv;

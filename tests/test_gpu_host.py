@@ -35,6 +35,31 @@ def test_polysynth_host_matches_oracle(mx, port, tmp_path):
     assert_bits_equal(got, exp, "polysynth host (per-sample facade, host-side voice sum)")
 
 
+def test_polysynth_host_with_the_mixdown_on_the_device(mx, port, tmp_path):
+    """The same patch with `gpumix`: play() does not sum the voices, the bank renders every block WITH the maxiMix::stereo mixdown fused
+    into the voice kernel (maxiVoiceBank::renderMix / mixFrame -> mxg_voice_render_mix) and hands out the frame's two mix values: the
+    tree-ordered sum of the same per-voice products, within mix_tol of the reference's voice-order sum; a bank wider than one workgroup."""
+    from conftest import mix_tol
+    exe = os.path.join(ROOT, "host", "polysynth_host")
+    V, frames = 700, 3000
+    out = tmp_path / "polymix.f64"
+    r = subprocess.run([exe, str(V), str(frames), str(out), "gpumix"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(out, np.float64).reshape(frames, 2)
+    v = np.arange(V)
+    freq = np.minimum(20.0 + (v * 97 % 16384) * 0.30517578125, 5000.0)
+    par = np.stack([np.full(V, port.env_coeff(0, 10)), np.full(V, port.env_coeff(1, 100)), np.full(V, 0.5),
+                    np.full(V, port.env_coeff(2, 500))])
+    nblk = (frames + 511) // 512 * 512
+    gate = ((np.arange(nblk) % 4096) < 2048).astype(np.int32)
+    voices = port.voice(0, freq, 200 + 4 * freq, 1.0 + (v % 16), gate, par, np.ones(V, np.int64))[0][:frames]
+    exp = port.mix_stereo(voices, v / (V - 1.0))
+    fin = np.isfinite(exp)
+    assert np.array_equal(fin, np.isfinite(got))
+    assert np.abs(np.where(fin, got - exp, 0.0)).max() <= mix_tol(V, np.abs(np.where(np.isfinite(voices), voices, 0.0)).max(), sums=np.where(fin, exp, 0.0))
+    assert np.abs(np.where(fin, exp, 0.0)).max() > 1e-3
+
+
 def test_facade_smoke_matches_python_mirror(mx, tmp_path):
     """host/facade_smoke.cpp drives the newer C++ facade classes; the Python mirror makes the same C-ABI calls
     on inputs rebuilt with the same exact arithmetic, so every dumped block must be byte-identical."""
