@@ -212,8 +212,13 @@ __global__ void __launch_bounds__(256) sample_kernel(SmpArgs A) {
         // pos, pos+1, ..., so a line's 8 samples of a chunk are 64 contiguous bytes.  Four 16-B loads per chunk
         // (instead of eight 8-B gathers) request every cache line once instead of relying on the 32 KB L1 to
         // keep 64 lines per wavefront alive between samples.  Same values, same head afterwards.
+        // (round 6: heads BETWEEN two elements too -- what playAtSpeed leaves behind.  The index is (long)pos and pos grows by exactly 1.0
+        // per sample, so sample k reads element p0 + k as long as no addition rounds the head up to the next integer: below 2^31 an ulp is
+        // at most 2^-22, and a fraction of at most 1 - 2^-20 survives every binade crossing of the block.  The head after the block is the
+        // exact multi-step sum of mxg_advance.h, the reference's one addition per sample.)
         const long long p0 = (long long)s.pos;
-        const bool straight = (double)p0 == s.pos && p0 >= 0 && (size_t)p0 + N + 1 < A.len;
+        const double frac0 = s.pos - (double)p0;
+        const bool straight = s.pos >= 0.0 && frac0 <= 1.0 - 0x1p-20 && (size_t)p0 + N + 1 < A.len && A.len < ((size_t)1 << 31);
         if (nfull > 0 && __all(straight)) {
             const double *src = amp + p0;
             double2v a0[4], a1[4];
@@ -241,7 +246,15 @@ __global__ void __launch_bounds__(256) sample_kernel(SmpArgs A) {
                 retire(a1);
             }
             if (k < nfull) retire(a0);
-            s.pos = s.pos + (double)(nfull * U);  // exact: integers below 2^53, one addition per sample in the reference
+            if (__all(frac0 == 0.0)) {
+                s.pos = s.pos + (double)(nfull * U);  // exact: integers below 2^53, one addition per sample in the reference
+            } else {
+                size_t left = nfull * U;
+                while (left > 0) {
+                    bool crossed;
+                    left -= (size_t)advance_until(s.pos, 1.0, HUGE_VAL, true, left > (size_t)(1 << 30) ? (1 << 30) : (int)left, crossed);
+                }
+            }
             for (size_t n = nfull * U; n < N; n++) {
                 *op = amp[(long long)s.pos];
                 op += V;

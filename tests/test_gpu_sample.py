@@ -96,6 +96,33 @@ def test_sample_vs_oracle_large(mx, port):
     assert_bits_equal(o, e, "play")
 
 
+@pytest.mark.parametrize("Ls,N", [(200000, 512), (5000, 512), (70000, 203)])
+def test_play_with_heads_between_elements(mx, port, Ls, N):
+    """maxiSample::play() (C:740-747) from heads that sit BETWEEN two elements -- what playAtSpeed leaves behind: the index is (long)pos
+    and the head grows by 1.0 per sample, so a full wavefront of such heads that does not wrap inside the block takes the 16-byte row
+    loads of the integer-head path (round 6), with the head after the block from the exact multi-step sum.  Heads just below powers of
+    two (the fraction loses a bit at every binade crossing), fractions within 2^-20 of the next integer (must NOT take the path: an
+    addition may round up to it), heads that wrap, three carried blocks."""
+    rng = np.random.default_rng(Ls + N)
+    V = 256
+    smp = rng.uniform(-1, 1, Ls)
+    span = max(Ls - 3 * N - 8, 16)
+    pos0 = rng.uniform(0, span, V)
+    pos0[0:64] = np.floor(pos0[0:64]) + rng.uniform(0.001, 0.999, 64)            # wave 0: plain fractional heads
+    pw = 2.0 ** np.arange(1, 12)
+    pos0[64:64 + pw.size] = pw - rng.uniform(0.01, 0.9, pw.size)                  # wave 1: binade crossings inside the block
+    pos0[100] = 1000.0 + (1.0 - 2.0 ** -30)                                       # wave 1: a fraction that may round up: general path
+    pos0[128:192] = np.floor(pos0[128:192])                                       # wave 2: integer heads (the old straight path)
+    pos0[192:256] = Ls - rng.uniform(1, 2 * N, 64)                                # wave 3: wraps inside the blocks
+    bank = mx.maxiSampleBank(V)
+    bank.setSample(smp)
+    bank.position.upload(pos0)
+    o = np.concatenate([bank.render(0, N).numpy() for _ in range(3)])
+    e, ep = port.sample(0, smp, 3 * N, pos0)
+    assert_bits_equal(o, e, "play, heads between elements")
+    assert_bits_equal(bank.position.numpy(), ep, "head after three blocks")
+
+
 @pytest.mark.parametrize("mode", range(9))
 @pytest.mark.parametrize("N", [1, 7, 8, 9, 16, 21, 203])
 def test_sample_ragged_blocks(mx, golden, port, mode, N):
