@@ -1688,7 +1688,10 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
         U.spin_limit = tune_get("grain_spin_limit") > 0 ? tune_get("grain_spin_limit") : kStreamSpin;
         const size_t stiles = (S + 63) / 64;
         if ((unit || line) && d_pan) {
-            if (int e = scratch_get(SCR_GRAIN_MIX, st, sizeof(double) * stiles * T * 2, (void **)&U.mixpart)) return e;
+            if (int e = scratch_get(SCR_GRAIN_MIX, st, sizeof(double) * stiles * T * 2, (void **)&U.mixpart)) {
+                (void)hipMemsetAsync(g_err, 0, 4 * sizeof(int), st);  // (the prologue has written the eligibility word: zero between calls)
+                return e;
+            }
             U.pan = d_pan;
         }
         // maxiTimeStretch::play / playAtPosition on the unit path: the scheduler is a serial walk per stream (32 wavefronts for 2048 streams)
@@ -1753,7 +1756,10 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
                 mixed = true;
             }
         } else if ((unit || line) && slices > 1) {  // the tile renders: any mode
-            if (int e = aux_stream_init()) return e;
+            if (int e = aux_stream_init()) {
+                (void)hipMemsetAsync(g_err, 0, 4 * sizeof(int), st);
+                return e;
+            }
             // one caller at a time enqueues its fork/join: a wait captures the event's latest record, so another
             // thread re-recording the shared events between a record and its wait would tie the render to the wrong slice
             std::lock_guard<std::mutex> lock(g_aux_mu);
@@ -1874,7 +1880,10 @@ static int granular_render_impl(const mxg_grain_plan *p, int mode, size_t S, siz
     }
     MXG_HIP(hipGetLastError());
     if (d_pan && !mixed) {
-        if (int e = mxg_mix_stereo(S, T, d_out, d_pan, d_mix, stream)) return e;
+        if (int e = mxg_mix_stereo(S, T, d_out, d_pan, d_mix, stream)) {
+            (void)hipMemsetAsync(g_err, 0, 4 * sizeof(int), st);
+            return e;
+        }
     }
     if (!tune_get("grain_sync")) {
         // deferred: the render's error word (1..5, below) is forwarded to the library's async error word by a one-lane kernel at
