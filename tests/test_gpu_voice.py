@@ -406,7 +406,8 @@ def test_voice_store_streams_same_bits(mx, port, store, xcd, V, N, mode, tpv):
     del rng
 
 
-@pytest.mark.parametrize("V,N", [(700, 301), (64, 8), (2050, 512), (701, 77), (4096, 1000), (256, 1), (300, 13), (33000, 48), (1024, 1536)])
+@pytest.mark.parametrize("V,N", [(700, 301), (64, 8), (2050, 512), (701, 77), (4096, 1000), (256, 1), (300, 13), (33000, 48), (1024, 1536),
+                                 (1, 100), (63, 530), (700, 1100), (2, 16)])
 @pytest.mark.parametrize("mode,tpv", [(0, False), (0, True), (1, False)])
 def test_voice_render_mix_fused(mx, port, V, N, mode, tpv):
     """mxg_voice_render_mix / _mix_rows (K2f + the fused maxiMix::stereo mixdown, producer / consumer wavefront pairs): the per-voice
