@@ -948,7 +948,9 @@ def main():
                 "sample_bank": ("sample_bank", "off", "sparse", 100, 20),  # maxiSample::playAtSpeed over an HBM-resident 8.6 GB sample
                 "config3": ("config3", "off", "sparse", 256, 64),
                 "config3_mixdown": ("config3", "fused", "sparse", 256, 64),  # config 3's N > 1 step on one GPU: K2f with the mixdown fused + grouped queue
-                "config3_modB": ("config3", "off", "modB", 64, 16),  # cutoff modulated per sample (14.monosynth/main.cpp:53)
+                # cutoff modulated per sample (14.monosynth/main.cpp:53).  128 steps = one whole cycle of the gate (the
+                # cost of a block depends on the envelope's stage: half a cycle measured 43 or 59 us depending on where it started)
+                "config3_modB": ("config3", "off", "modB", 128, 16),
                 "config4": ("config4", "off", "sparse", 10, 2),
                 "config4_walk": ("config4", "off", "walk", 10, 2),   # band sums bit-exact (sparse walk), DCT on the matrix pipe
                 "config4_mfma": ("config4", "off", "mfma", 10, 2),   # mel contraction + DCT on the matrix pipe, the knob set explicitly
