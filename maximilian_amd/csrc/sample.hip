@@ -400,7 +400,7 @@ __device__ __forceinline__ void smp_skip(double &pos, const double step, const d
 #define MXG_SMP_WPE 3  // A/B (tools/build_ab.sh): wavefronts per SIMD the time-part kernel is compiled for
 #endif
 template <int MODE, bool PIPE, bool PX, bool RING>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MXG_SMP_WPE))) sample_parts_kernel(SmpArgs A, const size_t part_len, PartSync psync) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RING ? 2 : MXG_SMP_WPE))) sample_parts_kernel(SmpArgs A, const size_t part_len, PartSync psync) {
     __shared__ double s_win[4 * 64 * kRowDoubles];
     const size_t V = A.V, N = A.N;
     const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -647,7 +647,142 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MXG_SM
     };
     size_t n = n0;
     const size_t nchunks = (n1 - n0) / U;
-    if (nchunks && !PIPE) {
+    bool lean_done = false;
+    if constexpr (RING && PIPE) {
+        // ---- the lean part (round 6, the HBM-resident bank): TWO chunks of window loads in flight -------------------------------------------
+        // Without its window loads this kernel takes 64 of its 127 us on the 8.6 GB bank, and 59 % of a resident wavefront's cycles are
+        // spent parked on s_waitcnt (profiles/r06_sample_bank.md): with one chunk in flight per wavefront it is bound by the LATENCY of its
+        // loads.  A second chunk in flight needs a second set of load registers and a third set of per-chunk metadata -- 256 registers
+        // and spills with the general chunk (rem[8], tap[8], flags per chunk).  So a part whose chunks are ALL smooth ring chunks for every
+        // lane of the wavefront -- known up front: forward, step <= 1.7 (at most eight pieces per chunk), no bounds test fails and nothing
+        // wraps before the part's last whole chunk -- carries per chunk only the head it started from: render replays the eight additions
+        // (the same operations: the same remainders and indices) instead of reading them back.
+        bool lean = fast && can_stage && nchunks >= 3;
+        if (lean) {
+            const double pend = s.pos + step * (double)(nchunks * U + 1);  // beyond the head after the part's last whole chunk
+            bool ok = step <= 1.7;
+            if constexpr (B == 4) ok = ok && pend + 2.0 < dlen;
+            if constexpr (B == 5) ok = ok && pend + 3.0 < dlen;
+            if constexpr (B == 6) ok = ok && pend + 2.0 < dlen * endc && pend + 4.0 < dlen;
+            lean = __all(ok);
+        }
+        if (lean) {
+            struct Lean {
+                double p0;       // the head at the chunk's first sample
+                int ic0;         // its integer part
+                unsigned slots;  // loader view, as Chunk::slots
+            };
+            double2v cA[U], cB[U], cC[U];
+            auto lfetch = [&](Lean &Lc, double2v (&cc)[U]) {
+                Lc.p0 = s.pos;
+                Lc.ic0 = icur;
+                double ph = s.pos;
+                int ic = icur, ilast = icur;
+#pragma unroll
+                for (int i = 0; i < U; i++) {
+                    ilast = ic;
+                    ph = ph + step;
+                    ic = (int)ph;
+                }
+                const int i_first = (B == 5) ? icur : icur + 1;             // first tap of the first sample (mxg_smp.h, B = 4 / 5 / 6)
+                const int i_last = ((B == 5) ? ilast : ilast + 1) + 1;      // second tap of the last
+                s.pos = ph;
+                icur = ic;
+                const int plo = i_first >> 1, phi = i_last >> 1;
+                int first = ring_end > plo ? ring_end : plo;
+                first = first < phi ? first : phi;
+                const unsigned want = ((unsigned)first << 3) | (unsigned)(phi - first);
+                ring_end = phi + 1;
+                Lc.slots = 0;
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const unsigned w = (unsigned)__shfl((int)want, 8 * j + (lane >> 3));
+                    const bool need = (unsigned)(lane & 7) <= (w & 7u);
+                    const unsigned pc = (w >> 3) + (need ? (unsigned)(lane & 7) : (w & 7u));
+                    Lc.slots |= need ? (8u | (pc & 7u)) << (4 * j) : 0u;
+                    cc[j] = *reinterpret_cast<const double2v *>(amp + 2 * (size_t)pc);
+                }
+            };
+            auto lland = [&](const Lean &Lc, const double2v (&cc)[U]) {
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const unsigned nb = (Lc.slots >> (4 * j)) & 15u;
+                    if (nb) *reinterpret_cast<double2v *>(win + (8 * j + (lane >> 3)) * kRowDoubles + 2 * (nb & 7u)) = cc[j];
+                }
+                smp_lds_sync();
+            };
+            auto lrender = [&](const Lean &Lc) {
+                double ph = Lc.p0;
+                int ic = Lc.ic0;
+                double o[U];
+                Req q;
+#pragma unroll
+                for (int i = 0; i < U; i++) {
+                    const int t0 = ((B == 5) ? ic : ic + 1) & (kSmpWindow - 1);
+                    const double val[2] = {row[t0], row[(t0 + 1) & (kSmpWindow - 1)]};
+                    q.rem = ph - (double)ic;
+                    q.ok = true;
+                    o[i] = smp_eval<MODE>(q, val);
+                    ph = ph + step;
+                    ic = (int)ph;
+                }
+                emit_chunk<PX>(op, V, o, A.px_store);
+                smp_lds_sync();  // the rows are free again
+            };
+#ifndef MXG_SMP_LEAN_DEPTH
+#define MXG_SMP_LEAN_DEPTH 2  // chunks of window loads in flight per wavefront in a lean part (A/B: 3 -- 246 registers, measured the same gain as 2)
+#endif
+#if MXG_SMP_LEAN_DEPTH == 3
+            double2v cD[U];
+            Lean L0, L1, L2, L3;
+            lfetch(L0, cA);
+            lland(L0, cA);
+            lfetch(L1, cB);
+            lfetch(L2, cC);  // (nchunks >= 3)
+            size_t k = 0;  // L0 holds chunk k (landed); L1's and L2's loads are in flight
+#define MXG_LEAN_STEP(LN, CN, LR, LL, CL)                 \
+    if (k + 3 < nchunks) lfetch(LN, CN);                  \
+    lrender(LR);                                          \
+    if (k + 1 >= nchunks) break;                          \
+    lland(LL, CL);                                        \
+    k++;
+            while (true) {
+                MXG_LEAN_STEP(L3, cD, L0, L1, cB)
+                MXG_LEAN_STEP(L0, cA, L1, L2, cC)
+                MXG_LEAN_STEP(L1, cB, L2, L3, cD)
+                MXG_LEAN_STEP(L2, cC, L3, L0, cA)
+            }
+#undef MXG_LEAN_STEP
+#else
+            Lean L0, L1, L2;
+            lfetch(L0, cA);
+            lland(L0, cA);
+            lfetch(L1, cB);
+            size_t k = 0;  // L0 holds chunk k (landed), L1's loads are in flight
+            while (true) {
+                if (k + 2 < nchunks) lfetch(L2, cC);
+                lrender(L0);
+                if (k + 1 >= nchunks) break;
+                lland(L1, cB);
+                k++;
+                if (k + 2 < nchunks) lfetch(L0, cA);
+                lrender(L1);
+                if (k + 1 >= nchunks) break;
+                lland(L2, cC);
+                k++;
+                if (k + 2 < nchunks) lfetch(L1, cB);
+                lrender(L2);
+                if (k + 1 >= nchunks) break;
+                lland(L0, cA);
+                k++;
+            }
+#endif
+            n = n0 + nchunks * U;
+            lean_done = true;
+        }
+    }
+    if (lean_done) {
+    } else if (nchunks && !PIPE) {
         for (size_t k = 0; k < nchunks; k++) {
             Chunk C;
             fetch(C);
