@@ -8,7 +8,7 @@ import maximilian_amd as mx
 L = mx.lib(); mx._lib.check(L.mxg_init(0), "init"); mx.maxiSettings.setup(44100, 2, 1024)
 V, B = 65536, 512
 v = np.arange(V)
-for k in ("split",):
+for k in ("split", "ring"):
     if os.environ.get("SMP_" + k.upper()):
         L.mxg_tune(("smp_" + k).encode(), int(os.environ["SMP_" + k.upper()]))
 rng = np.random.default_rng(1)
