@@ -187,7 +187,10 @@ def main():
     ap.add_argument("--mixdown", default=None, choices=["fused", "separate", "off"],
                     help="stereo mixdown + cross-GPU reduce in the step (default: on whenever --gpus > 1 -- fused into the "
                          "render for config2, K3 for config3 -- and always for config5; off on one GPU)")
-    ap.add_argument("--mix-depth", type=int, default=16, help="blocks per ncclReduce (M of SURVEY 8e)")
+    ap.add_argument("--mix-depth", type=int, default=32,
+                    help="blocks per ncclReduce (M of SURVEY 8e).  32 since round 6: every batch costs the render stream a fixed ~50-85 us (its "
+                         "event record drains the back-to-back kernels, the fold shares the machine) -- the N > 1 step on one GPU, M = 8 / 16 / 32 / "
+                         "64: 51.7 / 49.7 / 44.4 / 44.0 us against K1's 40.6 (profiles/r06_mix_depth.md)")
     ap.add_argument("--voice-mode", type=int, default=0, choices=[0, 1], help="config3: 0 = hoisted coefficients, 1 = 14.monosynth order")
     ap.add_argument("--mfcc-method", default="sparse", choices=["sparse", "walk", "mfma", "mfma-gemm"],
                     help="config4: the fused kernel with the exact sparse mel walk (default), the fused kernel with the mel contraction "
