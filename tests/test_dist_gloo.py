@@ -2,7 +2,8 @@
 
 The step function is the product's (maximilian_amd.dist.MixdownStep: slot -> render + local mix -> push, batched M blocks
 per reduce); the kernels need a GPU, so the CPU oracle stands in for them and HostMixQueue (same slot/push/flush protocol as
-the C-ABI's mxg_mixq, reduce over gloo) stands in for the RCCL queue.  Both BASELINE shapes that shard are driven:
+the C-ABI's mxg_mixq, reduce over gloo) stands in for the RCCL queue.  The BASELINE shapes that shard are driven (round 6: config 3
+too -- the subtractive voice bank with carried state, one partial mix row per group of voices, as mxg_voice_render_mix_rows leaves them):
 config 2 (voice bank, per-block stereo mixdown, M blocks per reduce incl. a partial last batch) and config 5 (grain
 streams, one [T][2] reduce).  Rank 0 must end up with the mix of the WHOLE bank, compared with the oracle's sequential sum."""
 import os
@@ -16,6 +17,13 @@ from conftest import ROOT, mix_tol
 
 CFG2 = dict(Vr=96, B=64, blocks=7, M=3, G=32)    # 7 blocks, 3 per reduce: batches of 3, 3 and a flushed 1; slots of 3 rows of 32 voices
 CFG5 = dict(Sr=24, T=1500, L=30000)
+CFG3 = dict(Vr=80, B=64, blocks=5, M=2, G=32)    # config 3 sharded (round 6): subtractive voices, carried state, grouped slots of 3 rows
+
+
+def _voice_params(lo, hi):
+    v = np.arange(lo, hi)
+    freq = np.minimum(20.0 + v * 7.0, 5000.0)
+    return freq, 200 + 4 * freq, 1.0 + (v % 5)
 
 
 def _free_port():
@@ -90,6 +98,41 @@ def _worker(rank, world, port, q):
     step5()
     step5.finish()
     got5 = queue5.result_numpy().reshape(g["T"], 2)
+    # ---- config-3 shape (round 6: mxg_voice_render_mix_rows into a grouped slot): voice shard saw -> lores -> adsr with carried state,
+    # one partial mix row per group of voices, M blocks per reduce --------------------------------------------------------------------
+    c3 = CFG3
+    lo3, hi3 = shard_range(rank, world, c3["Vr"])
+    f3, cu3, rs3 = _voice_params(lo3, hi3)
+    pan3 = np.arange(lo3, hi3) / (c3["Vr"] * world - 1.0)
+    par3 = np.stack([np.full(hi3 - lo3, orc.env_coeff(0, 1)), np.full(hi3 - lo3, orc.env_coeff(1, 5)), np.full(hi3 - lo3, 0.5),
+                     np.full(hi3 - lo3, orc.env_coeff(2, 20))])
+    hold3 = np.ones(hi3 - lo3, np.int64)
+    groups3 = -(-c3["Vr"] // c3["G"])
+    queue3 = HostMixQueue(dist, c3["B"] * 2, depth_blocks=c3["M"], groups=groups3)
+    vs = {"k": 0, "st": (None, None, None, None)}
+    got3 = []
+
+    def render_mix3(slot):
+        n0 = vs["k"] * c3["B"]
+        trig = ((np.arange(n0, n0 + c3["B"]) % 130) < 70).astype(np.int32)
+        out, ost, fst, dst, ist = orc.voice(0, f3, cu3, rs3, trig, par3, hold3, ost=vs["st"][0], fst=vs["st"][1], dstate=vs["st"][2],
+                                            istate=vs["st"][3])
+        vs["st"] = (ost, fst, dst, ist)
+        vs["k"] += 1
+        for g in range(groups3):
+            sl = slice(g * c3["G"], min((g + 1) * c3["G"], hi3 - lo3))
+            slot[g].copy_(torch.from_numpy(orc.mix_stereo(out[:, sl], pan3[sl]).reshape(-1)))
+
+    step3 = MixdownStep(render_mix3, queue3)
+    for k in range(c3["blocks"]):
+        before = queue3.batches
+        step3()
+        if queue3.batches != before:
+            got3.append(queue3.result_numpy())
+    step3.finish()
+    if queue3.last_blocks and len(got3) * c3["M"] < c3["blocks"]:
+        got3.append(queue3.result_numpy())
+    got3 = np.concatenate(got3).reshape(-1, c3["B"], 2)
     # ---- bench.py's fallback exchange (TorchMixQueue: torch tensors as staging, torch.distributed.reduce): the same protocol ------
     from maximilian_amd.dist import TorchMixQueue
     tq = TorchMixQueue(dist, 6, depth_blocks=2, root=0, stream=None, device=None, groups=1)
@@ -105,7 +148,7 @@ def _worker(rank, world, port, q):
         got_t.append(tq.result_numpy())
     got_t = np.concatenate(got_t)
     if rank == 0:
-        q.put((got2, got5, got_t))
+        q.put((got2, got5, got_t, got3))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -155,7 +198,7 @@ def test_two_rank_mixdown_steps_gloo(port):
     procs = [ctx.Process(target=_worker, args=(r, 2, prt, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got2, got5, got_t = q.get(timeout=180)
+    got2, got5, got_t, got3 = q.get(timeout=180)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -177,6 +220,17 @@ def test_two_rank_mixdown_steps_gloo(port):
     exp5 = port.mix_stereo(o5, pan5)
     assert np.abs(got5 - exp5).max() <= mix_tol(2 * g["Sr"], np.abs(o5).max())
     assert np.abs(got5).max() > 0.05
+    # config-3 shape: the whole 160-voice bank on one "device", five carried blocks, the reference's voice-order sum
+    c3 = CFG3
+    f3, cu3, rs3 = _voice_params(0, 2 * c3["Vr"])
+    V3 = 2 * c3["Vr"]
+    par3 = np.stack([np.full(V3, port.env_coeff(0, 1)), np.full(V3, port.env_coeff(1, 5)), np.full(V3, 0.5), np.full(V3, port.env_coeff(2, 20))])
+    trig3 = ((np.arange(c3["B"] * c3["blocks"]) % 130) < 70).astype(np.int32)
+    o3 = port.voice(0, f3, cu3, rs3, trig3, par3, np.ones(V3, np.int64))[0]
+    exp3 = port.mix_stereo(o3, np.arange(V3) / (V3 - 1.0)).reshape(c3["blocks"], c3["B"], 2)
+    assert got3.shape == exp3.shape
+    assert np.abs(got3 - exp3).max() <= mix_tol(V3, np.abs(o3).max(), sums=exp3)
+    assert np.abs(got3).max() > 0.05
     # the fallback queue: block k of rank r is (k + 1)(r + 1) + arange(6); the root holds the sum over both ranks
     exp_t = np.stack([3.0 * (k + 1) + 2.0 * np.arange(6) for k in range(5)])
     assert np.array_equal(got_t, exp_t)
