@@ -1033,7 +1033,10 @@ static int voice_launch(int mode, size_t V, size_t N, const double *d_freq, cons
         // 0.61 -> 0.71)
         if (nt_knob != 2) store = nt_knob == 1 ? 1 : 0;
         else if (out_bytes < ((size_t)192 << 20)) store = 0;
-        else if (V < 98304) store = pairs_ok ? 4 : 1;
+        // (round 6, re-measured on the current kernel, two boxes, interleaved: at 65 536 voices non-temporal 8-BYTE stores beat the pair rows
+        // for mode A -- 47.2-47.7 against 48.1-48.7 us -- and clearly for the mixdown form, whose producers share their SIMDs with the
+        // consumers -- 50.4-50.6 against 53.1-53.3 us; mode B is indifferent, 60.6-62.1 against 60.7-61.5, and keeps the pair rows)
+        else if (V < 98304) store = (mode == 0 || mix) ? 1 : (pairs_ok ? 4 : 1);
         else if (V < 196608) store = pairs_ok ? 3 : 1;
         else store = 1;
         if (xcd < 0) xcd = V >= 98304 ? 1 : 0;
