@@ -56,7 +56,11 @@ __device__ __forceinline__ void env_store(const Env &e, size_t V, size_t v, doub
 // Written as straight-line selects (same statement order, same arithmetic): the lanes of a wave sit
 // in different envelope phases, and as nested `if`s this compiled to ~13 exec-mask regions per
 // sample (26 s_cbranch_execz per 4 samples), 4x slower than the predicated form.
-__device__ __forceinline__ double env_adsr(Env &e, double input, int trigger) {
+// GAIN form (round 6): every assignment of C:1425-1463 to `output` is input * (the amplitude at that statement), so one call leaves
+// output = input * g with g the amplitude at the LAST such statement that fired, or leaves output alone (upd = false) -- a select among
+// products of one input is the product with the selected factor, the same bits.  The state machine is this function; env_adsr
+// multiplies once.  The fused voice's two-stage form (voice.hip, voice_split_kernel) runs the gains a stage ahead of the filter.
+__device__ __forceinline__ double env_adsr_gain(Env &e, int trigger, bool &upd) {
     const bool t1 = trigger == 1;
     // C:1417-1423
     const bool c1 = t1 && e.attackphase != 1 && e.holdphase != 1 && e.decayphase != 1;
@@ -65,13 +69,13 @@ __device__ __forceinline__ double env_adsr(Env &e, double input, int trigger) {
     e.sustainphase = c1 ? 0 : e.sustainphase;
     e.releasephase = c1 ? 0 : e.releasephase;
     e.attackphase = c1 ? 1 : e.attackphase;
-    double amp = e.amplitude, out = e.output;
+    double amp = e.amplitude, g = 0.0;
     // C:1425-1435  attack
     const bool a = e.attackphase == 1;
     e.releasephase = a ? 0 : e.releasephase;
     const double ampA = amp + (1 * e.attack);
     amp = a ? ampA : amp;
-    out = a ? input * amp : out;
+    g = a ? amp : g;
     const bool a2 = a && amp >= 1;
     amp = a2 ? 1.0 : amp;
     e.attackphase = a2 ? 0 : e.attackphase;
@@ -80,18 +84,18 @@ __device__ __forceinline__ double env_adsr(Env &e, double input, int trigger) {
     const bool d = e.decayphase == 1;
     const double ampD = amp * e.decay;
     amp = d ? ampD : amp;
-    out = d ? input * amp : out;
+    g = d ? amp : g;
     const bool d2 = d && amp <= e.sustain;
     e.decayphase = d2 ? 0 : e.decayphase;
     e.holdphase = d2 ? 1 : e.holdphase;
     // C:1446-1449  hold
     const bool h = e.holdcount < e.holdtime && e.holdphase == 1;
-    const double held = input * amp;
-    out = h ? held : out;
+    g = h ? amp : g;
     e.holdcount += h ? 1 : 0;
     // C:1451-1458
     const bool ge = e.holdcount >= e.holdtime;
-    out = (ge && t1) ? held : out;
+    const bool s = ge && t1;
+    g = s ? amp : g;
     const bool rel = ge && !t1;
     e.holdphase = rel ? 0 : e.holdphase;
     e.releasephase = rel ? 1 : e.releasephase;
@@ -99,10 +103,16 @@ __device__ __forceinline__ double env_adsr(Env &e, double input, int trigger) {
     const bool r = e.releasephase == 1 && amp > 0.;
     const double ampR = amp * e.release;
     amp = r ? ampR : amp;
-    out = r ? input * amp : out;
+    g = r ? amp : g;
     e.amplitude = amp;
-    e.output = out;
-    return out;
+    upd = a || d || h || s || r;
+    return g;
+}
+__device__ __forceinline__ double env_adsr(Env &e, double input, int trigger) {
+    bool upd;
+    const double g = env_adsr_gain(e, trigger, upd);
+    e.output = upd ? input * g : e.output;
+    return e.output;
 }
 
 // Two steady states of the ADSR in which a sample is one multiply and no flag moves (read off
@@ -148,8 +158,9 @@ __device__ __forceinline__ double env_release_tick(Env &e, double input) {  // g
 // release: > 0) plus the conditions on the flags below.  Returns false (and must then be discarded) otherwise; the caller
 // commits only if every lane of the wavefront returned true, else the chunk goes through env_adsr.  ~6 operations per sample
 // instead of ~100.
+// (gain form, as env_adsr_gain: g[i] = the amplitude sample i multiplies its input by, upd = false for an idle lane, whose output stays)
 template <int U>
-__device__ __forceinline__ bool env_steady_chunk(Env &e, const double (&x)[U], const bool gate, double (&o)[U]) {
+__device__ __forceinline__ bool env_steady_gains(Env &e, const bool gate, double (&g)[U], bool &upd) {
     const bool ap = e.attackphase == 1, dp = e.decayphase == 1, hp = e.holdphase == 1, rp = e.releasephase == 1;
     const bool ge = e.holdcount >= e.holdtime;
     long long hb;
@@ -173,21 +184,34 @@ __device__ __forceinline__ bool env_steady_chunk(Env &e, const double (&x)[U], c
     const bool Z = !gate && !ap && !dp && !hp && !(rp && e.amplitude > 0.0) && (!ge || (e.holdphase == 0 && rp));
     const double m = D ? e.decay : (R ? e.release : 1.0);
     const double a = A ? e.attack : 0.0;
-    double amp = e.amplitude, out = e.output;
+    double amp = e.amplitude;
 #pragma unroll
     for (int i = 0; i < U; i++) {
         amp = (amp * m) + a;
-        out = Z ? out : x[i] * amp;
-        o[i] = out;
+        g[i] = amp;
     }
     bool ok = nonneg && (A || D || H || R || Z);
     ok = ok && (!A || amp < 1.0) && (!D || amp > e.sustain) && (!R || amp > 0.0);
     e.amplitude = amp;
-    e.output = out;
     if (H && e.holdcount < e.holdtime) {
         const long long c = e.holdcount + (long long)U;
         e.holdcount = c < e.holdtime ? c : e.holdtime;
     }
+    upd = !Z;
+    return ok;
+}
+template <int U>
+__device__ __forceinline__ bool env_steady_chunk(Env &e, const double (&x)[U], const bool gate, double (&o)[U]) {
+    double g[U];
+    bool upd;
+    const bool ok = env_steady_gains<U>(e, gate, g, upd);
+    double out = e.output;
+#pragma unroll
+    for (int i = 0; i < U; i++) {
+        out = upd ? x[i] * g[i] : out;
+        o[i] = out;
+    }
+    e.output = out;
     return ok;
 }
 

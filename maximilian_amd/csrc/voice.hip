@@ -86,6 +86,27 @@ __device__ __forceinline__ void lores_coeffs_sin(double cutoff, const double kr,
     }
 }
 
+// The same pair where theta / 2 = cutoff * pi / sr <= pi / 4 for certain (cutoff <= sr / 4, tested by the caller for a whole chunk and wavefront:
+// 14.monosynth's envelope x 10 000 Hz at 44.1 kHz never leaves that range): no fold, no upper clamp, the Taylor polynomial through y^15
+// (truncation y^16 / 17! <= 5.9e-17 of the value at pi / 4) and no z = 1 case (the caller checks 10 * pi / sr > 2^-26, so m > 2^-51) --
+// 14 vector instructions instead of ~37.  K2f on a lone wavefront is bound by its instruction COUNT (profiles/r06_k2f_split.md), so this
+// is mode B's lever.  nkr = -2 / max(res, 1).  Tolerance mode: within an ulp of lores_coeffs_sin's s, c = 4 s^2 the same expression.
+__device__ __forceinline__ void lores_coeffs_sin_small(double cutoff, const double nkr, const double pisr, double &c, double &r) {
+    using namespace sincos_detail;
+    asm("v_max_f64 %0, %1, %2" : "=v"(cutoff) : "v"(cutoff), "s"(10.0));  // C:456 (not a NaN here: the caller's test; fmax() would canonicalize first)
+    const double y = cutoff * pisr;
+    const double z = y * y;
+    double pq = fma_kk(z, -7.6471637318198164e-13, 1.6059043836821613e-10);
+    pq = fma_k(z, pq, -2.5052108385441720e-08);
+    pq = fma_k(z, pq, 2.7557319223985893e-06);
+    pq = fma_k(z, pq, -1.9841269841269841e-04);
+    pq = fma_k(z, pq, 8.3333333333333332e-03);
+    pq = fma_k(z, pq, -1.6666666666666666e-01);
+    const double sv = fma(y * z, pq, y);
+    c = 4.0 * (sv * sv);
+    r = fma(nkr, sv, 1.0);
+}
+
 __device__ __forceinline__ double flt_lores(Flt &f, double input, double c, double r) {  // C:463-467
     f.x = f.x + (input - f.y) * c;
     f.y = f.y + f.x;
@@ -452,6 +473,27 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
     env_store(e, V, v, dst, ist);
 }
 
+// maxiOsc::saw (C:333-340) for the fused voice: output = phase; if (phase >= 1.0) phase -= 2.0; phase += 1/(sr/f) * 2.
+// The conditional subtraction is ONE addition of -2.0 or -0.0 (x + -0.0 = x for every x, both zeros and NaNs included; the two
+// constants differ in their high word only): compare, select one dword, add -- the same bits in four instructions where compare,
+// subtract and a two-dword select take five.  K2f on a lone wavefront is bound by its instruction count (profiles/r06_k2f_split.md).
+template <bool ONE_ADD>
+__device__ __forceinline__ double saw_tick(double &phase, double &hold, const double inc) {
+    const double s = phase;
+    hold = s;
+    if constexpr (ONE_ADD) {
+        const int hi = phase >= 1.0 ? (int)0xC0000000 : (int)0x80000000;
+        phase = phase + __hiloint2double(hi, 0);
+    } else {
+        if (phase >= 1.0) phase -= 2.0;
+    }
+    phase += inc;
+    return s;
+}
+
+#ifndef MXG_MODB_SMALL
+#define MXG_MODB_SMALL 1  // A/B (tools/build_ab.sh): 0 = every chunk of mode B through the full-range coefficients
+#endif
 // ---- fused subtractive voice (K2) ----------------------------------------------------------
 // MODE 0: out = adsr(lores(saw(f), c, r), trig)             (coefficients hoisted, bit-exact)
 // MODE 1: e = adsr(1., trig); out = lores(saw(f), e*cutoff, res) * e   (device coefficients)
@@ -470,7 +512,12 @@ __global__ void __launch_bounds__(256) env_kernel(size_t V, size_t N, const doub
 // the layout of mxg_osc_render_mix_rows, so that the grouped mix queue (comm.hip) folds them the same way.  ST = 3: no per-voice
 // block at all (out may be null).  The ticks, their order and the per-voice stores are the ones of MIX = false: the same bits.
 constexpr int kVoiceMixWin = 512;
-template <int MODE, int ST, bool PX, bool TPV, bool MIX>
+// DIET (round 6): the fast paths' instruction diet -- saw_tick's one-add wrap, release chunks taken speculatively, the sustain / release
+// test carried from chunk to chunk: 16.7 -> ~14 vector instructions per sample.  A lone wavefront pays ~5 cycles per instruction it
+// issues (profiles/r06_k2f_split.md), so banks up to 32 768 voices gain 7 % (36.6 -> 34 us), the mixdown form 6 % (52.3 -> 48.9), mode B
+// 9 % -- but plain mode A at 65 536 voices, where every SIMD holds exactly one wavefront and the store stream is the bound, LOSES
+// 2.5 us (47.2-47.8 -> 50.0-50.4 with every store flavour: profiles/r06_k2f_diet.md), so the launch leaves it off there.  Same bits.
+template <int MODE, int ST, bool PX, bool TPV, bool MIX, bool DIET>
 __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t N, const double *__restrict__ freq,
                              const double *__restrict__ cutoff, const double *__restrict__ res,
                              const double *__restrict__ coef, const int32_t *__restrict__ trig,
@@ -534,8 +581,10 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
     Env e;
     env_load(e, V, v, par, holdtime, dst, ist);
     const double inc = (1. / (sr / (freq[v]))) * 2.0;  // C:337
-    double c = 0, r = 0, cut = 0, rs = 0, kr = 0;
+    double c = 0, r = 0, cut = 0, rs = 0, kr = 0, nkr = 0;
     const double pisr = MXG_PI / sr;
+    // (mode B's small-angle chunks, lores_coeffs_sin_small: every cutoff of the chunk <= sr / 4; a NaN limit switches them off)
+    const double small_lim = (MXG_MODB_SMALL && 10.0 * pisr > 0x1p-26) ? 0.25 * sr : __builtin_nan("");
     if constexpr (MODE == 0) {
         c = coef[v];
         r = coef[V + v];
@@ -543,6 +592,7 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
         cut = cutoff[v];
         rs = res[v];
         kr = 2.0 / (rs < 1. ? 1. : rs);  // C:458; a NaN resonance stays NaN (rs < 1 is false, 2 / NaN)
+        nkr = -kr;
     }
     double *op = out + v;
     double *pp = out + (size_t)(threadIdx.x & 1) * V + (v & ~(size_t)1);  // pair rows: this lane's 16 bytes of row n + (lane & 1)
@@ -613,10 +663,37 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
         tile_rows(o, 8);
     };
     // consume the prologue loads here so no vmcnt(0) is needed inside the loop (see osc.hip K1m)
-    asm volatile("" : "+v"(phase), "+v"(hold), "+v"(c), "+v"(r), "+v"(cut), "+v"(rs), "+v"(kr));
+    asm volatile("" : "+v"(phase), "+v"(hold), "+v"(c), "+v"(r), "+v"(cut), "+v"(rs), "+v"(kr), "+v"(nkr));
     asm volatile("" : "+v"(f.x), "+v"(f.y), "+v"(e.amplitude), "+v"(e.output), "+v"(e.attack), "+v"(e.decay));
     asm volatile("" : "+v"(e.sustain), "+v"(e.release), "+v"(e.holdtime), "+v"(e.holdcount));
     constexpr int U = 8;
+    // mode B, one whole chunk from its eight envelope values: oscillator, coefficients, filter, product.  The coefficients take the
+    // small-angle form when every cutoff of the chunk, on every lane of the wavefront, is <= sr / 4 (a NaN compares false).
+    auto modb_chunk = [&](const double (&av)[U]) {
+        double cf[U], o[U];
+        bool small = true;
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            cf[i] = av[i] * cut;
+            small = small && cf[i] <= small_lim;
+        }
+        if (__all(small)) {
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                const double s = saw_tick<DIET>(phase, hold, inc);  // C:333-340
+                lores_coeffs_sin_small(cf[i], nkr, pisr, c, r);
+                o[i] = flt_lores(f, s, c, r) * av[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                const double s = saw_tick<DIET>(phase, hold, inc);  // C:333-340
+                lores_coeffs_sin(cf[i], kr, pisr, sr, c, r);
+                o[i] = flt_lores(f, s, c, r) * av[i];
+            }
+        }
+        emit(o);
+    };
     int tn[U];
     GateGroup<U, int32_t> gcur;  // shared gate: see gate_group_load
     const auto gate_on = [](int32_t t) { return t == 1; };  // the test of C:1363 / C:1425
@@ -631,6 +708,7 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
         asm volatile("" : "+v"(gcur.cls));
     }
     if constexpr (MIX) __builtin_amdgcn_s_setprio(2);  // the store-bound stream is the critical one: the consumer takes the issue slots it leaves
+    int fast_prev = 0;  // the previous chunk's steady state (1 sustain, 2 release, 0 neither or unknown)
     for (size_t n0 = 0; n0 < N; n0 += U) {
       if constexpr (MIX)
         if (n0 && (n0 & (size_t)(WIN - 1)) == 0) mixpc_window_close<WIN>(s_part, partial + wg * N * 2 + (n0 - WIN) * 2, WIN);
@@ -651,9 +729,12 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
             gate_group_load(gcur, trig, N, n0 / (64 * U), gate_on);
           }
         }
+        // (a sustain or release chunk moves no flag and no count of the envelope -- amplitude and output only -- so a wavefront found in
+        // one of the two stays there while the gate's class does: the five-compare test runs where the class changes, not every chunk)
         const int g = lane_value(gcur.cls, cc);
-        if (g > 0) fast = __all(env_in_sustain(e)) ? 1 : 0;
-        else if (g < 0) fast = __all(env_in_release(e)) ? 2 : 0;
+        if (g > 0) fast = (DIET && fast_prev == 1) ? 1 : (__all(env_in_sustain(e)) ? 1 : 0);
+        else if (g < 0) fast = (DIET && fast_prev == 2) ? 2 : (__all(env_in_release(e)) ? 2 : 0);
+        fast_prev = fast;
       }
       if (fast) {  // steady envelope: see env_in_sustain
         auto steady = [&](auto sustain) {
@@ -662,23 +743,65 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
                 // the envelope value, hence (cutoff, c, r), is the same for every sample of the chunk
                 lores_coeffs_sin((1.0 * e.amplitude) * cut, kr, pisr, sr, c, r);
             }
+            // A release chunk taken speculatively (C:1460-1463: while amplitude > 0, amplitude *= release; output = input*amplitude): the
+            // eight amplitudes are one multiply each; they are the reference's if its test held BEFORE each of them -- the incoming
+            // amplitude and the first seven products > 0, which for a release factor > 0 is a test of the incoming one and the seventh
+            // (the products of a factor <= 1 fall, those of a factor > 1 rise) -- on every lane.  One multiply more per sample for the
+            // output, where the guarded tick (env_release_tick) takes a compare and four selects besides.
+            double am[U];
+            bool spec = false;
+            if constexpr (!SUS && DIET) {
+                double a = e.amplitude;
+#pragma unroll
+                for (int i = 0; i < U; i++) {
+                    a = a * e.release;
+                    am[i] = a;
+                }
+                spec = __all(e.amplitude > 0. && e.release > 0. && am[U - 2] > 0.);
+            }
+            if constexpr (MODE == 1 && !SUS) {  // release: the eight envelope values first, then the chunk
+                double av[U];
+                if (spec) {
+#pragma unroll
+                    for (int i = 0; i < U; i++) av[i] = am[i];  // output = 1.0 * amplitude
+                    e.amplitude = am[U - 1];
+                    e.output = am[U - 1];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < U; i++) av[i] = env_release_tick(e, 1.0);
+                }
+                modb_chunk(av);
+                return;
+            }
+            if constexpr (MODE == 0 && !SUS) {
+                if (spec) {
+                    double os[U];
+#pragma unroll
+                    for (int i = 0; i < U; i++) {
+                        const double s = saw_tick<DIET>(phase, hold, inc);  // C:333-340
+                        os[i] = flt_lores(f, s, c, r) * am[i];
+                        if constexpr (!(PX || MIX)) {  // (8-byte streams: each store where its value is ready, not eight at the chunk's end)
+                            store1<ST>(op, os[i]);
+                            op += V;
+                        }
+                    }
+                    e.amplitude = am[U - 1];
+                    e.output = os[U - 1];
+                    if constexpr (PX || MIX) emit(os);
+                    return;
+                }
+            }
             double ov[U];
 #pragma unroll
             for (int i = 0; i < U; i++) {
                 double o;
                 if constexpr (MODE == 0) {
-                    double s = phase;  // saw C:333-340
-                    hold = s;
-                    if (phase >= 1.0) phase -= 2.0;
-                    phase += inc;
+                    const double s = saw_tick<DIET>(phase, hold, inc);  // C:333-340
                     double y = flt_lores(f, s, c, r);
                     o = SUS ? env_sustain_tick(e, y) : env_release_tick(e, y);
                 } else {
                     double a = SUS ? env_sustain_tick(e, 1.0) : env_release_tick(e, 1.0);
-                    double s = phase;
-                    hold = s;
-                    if (phase >= 1.0) phase -= 2.0;
-                    phase += inc;
+                    const double s = saw_tick<DIET>(phase, hold, inc);  // C:333-340
                     if constexpr (!SUS) lores_coeffs_sin(a * cut, kr, pisr, sr, c, r);
                     double y = flt_lores(f, s, c, r);
                     o = y * a;
@@ -715,10 +838,7 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
                 double y[U], o[U];
 #pragma unroll
                 for (int i = 0; i < U; i++) {
-                    double s = phase;  // saw C:333-340
-                    hold = s;
-                    if (phase >= 1.0) phase -= 2.0;
-                    phase += inc;
+                    const double s = saw_tick<DIET>(phase, hold, inc);  // C:333-340
                     y[i] = flt_lores(f, s, c, r);
                 }
                 Env s2 = e;
@@ -757,21 +877,12 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
             }
             if (__all(constant)) {
                 const double ones[U] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
-                double av[U], o[U];
+                double av[U];
                 Env s2 = e;
                 const bool ok = env_steady_chunk<U>(s2, ones, lane_gate, av);
                 if (__all(ok)) {
                     e = s2;
-#pragma unroll
-                    for (int i = 0; i < U; i++) {
-                        double s = phase;  // saw C:333-340
-                        hold = s;
-                        if (phase >= 1.0) phase -= 2.0;
-                        phase += inc;
-                        lores_coeffs_sin(av[i] * cut, kr, pisr, sr, c, r);
-                        o[i] = flt_lores(f, s, c, r) * av[i];
-                    }
-                    emit(o);
+                    modb_chunk(av);
                     continue;
                 }
             }
@@ -788,18 +899,12 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
         else t = lane_value(gcur.g[i], (int)((n0 / U) & 63));
         double o;
         if constexpr (MODE == 0) {
-            double s = phase;  // saw C:333-340
-            hold = s;
-            if (phase >= 1.0) phase -= 2.0;
-            phase += inc;
+            const double s = saw_tick<DIET>(phase, hold, inc);  // C:333-340
             double y = flt_lores(f, s, c, r);
             o = env_adsr(e, y, t);
         } else {
             double a = env_adsr(e, 1.0, t);
-            double s = phase;
-            hold = s;
-            if (phase >= 1.0) phase -= 2.0;
-            phase += inc;
+            const double s = saw_tick<DIET>(phase, hold, inc);  // C:333-340
             lores_coeffs_sin(a * cut, kr, pisr, sr, c, r);
             double y = flt_lores(f, s, c, r);
             o = y * a;
@@ -1052,12 +1157,14 @@ static int voice_launch(int mode, size_t V, size_t N, const double *d_freq, cons
     }
     const dim3 grid = mix ? grid_for(V, 256) : grid_for(V, block);
     double sr = (double)settings().sampleRate;
-#define MXG_VOICE_LAUNCH(M, S, X, P, MX)                                                            \
-    hipLaunchKernelGGL((voice_kernel<M, S, X, P, MX>), grid, dim3(block), 0, st, V, N, d_freq, \
+#define MXG_VOICE_LAUNCH(M, S, X, P, MX, D)                                                            \
+    hipLaunchKernelGGL((voice_kernel<M, S, X, P, MX, D>), grid, dim3(block), 0, st, V, N, d_freq, \
                        d_cutoff, d_res, d_coef, d_trig, tpv, d_par, d_holdtime, d_ost, d_fst,   \
                        d_dst, d_ist, d_out, sr, xcd, d_pan, d_rows)
+#define MXG_VOICE_LAUNCH1(M, S, X, P, MX) \
+    if ((M) == 1 || (MX) || diet) MXG_VOICE_LAUNCH(M, S, X, P, MX, true); else MXG_VOICE_LAUNCH(M, S, X, P, MX, ((M) == 1 || (MX)))
 #define MXG_VOICE_LAUNCH2(M, S, X, MX) \
-    if (tpv) MXG_VOICE_LAUNCH(M, S, X, true, MX); else MXG_VOICE_LAUNCH(M, S, X, false, MX)
+    if (tpv) MXG_VOICE_LAUNCH1(M, S, X, true, MX); else MXG_VOICE_LAUNCH1(M, S, X, false, MX)
 #define MXG_VOICE_LAUNCH3(M, MX)                           \
     switch (store) {                                       \
         case 1: MXG_VOICE_LAUNCH2(M, 1, false, MX); break; \
@@ -1066,6 +1173,10 @@ static int voice_launch(int mode, size_t V, size_t N, const double *d_freq, cons
         case 4: MXG_VOICE_LAUNCH2(M, 1, true, MX); break;  \
         default: MXG_VOICE_LAUNCH2(M, 0, false, MX); break; \
     }
+    // the fast paths' instruction diet (voice_kernel, DIET): always for mode B and the mixdown form; plain mode A everywhere but around
+    // 65 536 voices (knob voice_diet: 0 automatic, 1 off, 2 on -- plain mode A only)
+    const int diet_knob = tune_get("voice_diet");
+    const bool diet = diet_knob == 2 || (diet_knob == 0 && !(V >= 57344 && V < 73728));
     KernelTimer kt("voice_kernel", st);
     if (mix) {
         if (store == 5) {
@@ -1082,6 +1193,7 @@ static int voice_launch(int mode, size_t V, size_t N, const double *d_freq, cons
     }
 #undef MXG_VOICE_LAUNCH3
 #undef MXG_VOICE_LAUNCH2
+#undef MXG_VOICE_LAUNCH1
 #undef MXG_VOICE_LAUNCH
     return check_hip(hipGetLastError(), "voice_kernel launch");
 }
