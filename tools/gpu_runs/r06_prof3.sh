@@ -1,9 +1,5 @@
 #!/bin/bash
-# round 6: counters of the workloads whose kernels changed after the first profile pass (K1t one-round form + queue, mode B's polynomial sine, the ring sample bank)
+# round 6, late: the rocprofv3 passes of the three config-3 workloads again (K2f after the small-angle coefficients and the diet)
 cd $GRAFT_REPO_ROOT
-ONLY="config2_tables config3_modB sample_bank" bash tools/profile_r06.sh r06 2>&1 | tail -3
-# fp64 flops of the per-sample-modulated voice (the ONLY filter skips the extra passes of the script)
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r06/config3_modB/pmc_f64 -o b -- \
-    python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --kernel-events off --steps 16 --warmup 2 --workload config3 --voice-mode 1 > $GRAFT_REPO_ROOT/gpurun_out/prof_r06/config3_modB.f64.log 2>&1
-find $GRAFT_REPO_ROOT/gpurun_out/prof_r06 -name "*agent_info.csv" -delete; find $GRAFT_REPO_ROOT/gpurun_out/prof_r06 -name "*.db" -delete
+ONLY="config3 config3_mix config3_modB" bash tools/profile_r06.sh r06 > gpurun_out/prof3.log 2>&1
+tail -3 gpurun_out/prof3.log

@@ -26,7 +26,7 @@ run config2_mix 500 20 --mixdown fused
 run config2_tables 100 10 --workload tables
 run config3 512 20 --workload config3
 run config3_mix 512 20 --workload config3 --mixdown fused
-run config3_modB 64 8 --workload config3 --voice-mode 1
+run config3_modB 128 8 --workload config3 --voice-mode 1   # (128 blocks = one whole gate cycle: the step depends on the envelope's stage)
 run sample_bank 100 10 --workload sample_bank
 run config4 6 3 --workload config4
 run config4_walk 6 3 --workload config4 --mfcc-method walk
@@ -39,9 +39,11 @@ rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYC
     python $R/bench.py --no-cpu-baseline --kernel-events off --steps 3 --warmup 2 --workload config4 --mfcc-method mfma > $OUT/config4_mfma.mfma.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/config4_mfma/pmc_clk -o b -- \
     python $R/bench.py --no-cpu-baseline --kernel-events off --steps 3 --warmup 2 --workload config4 --mfcc-method mfma > $OUT/config4_mfma.clk.log 2>&1
-# fp64 flops of the per-sample-modulated voice
+fi
+# fp64 flops of the per-sample-modulated voice, over one whole gate cycle
+if [ -z "$ONLY" ] || echo " $ONLY " | grep -q " config3_modB "; then
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU --output-format csv -d $OUT/config3_modB/pmc_f64 -o b -- \
-    python $R/bench.py --no-cpu-baseline --kernel-events off --steps 16 --warmup 2 --workload config3 --voice-mode 1 > $OUT/config3_modB.f64.log 2>&1
+    python $R/bench.py --no-cpu-baseline --kernel-events off --steps 128 --warmup 0 --workload config3 --voice-mode 1 > $OUT/config3_modB.f64.log 2>&1
 fi
 # keep what travels back small: the counter CSVs of torch's start-up kernels are not needed
 find $OUT -name "*agent_info.csv" -delete; find $OUT -name "*.db" -delete; du -sh $OUT
