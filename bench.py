@@ -760,6 +760,15 @@ def main():
     fence()
     t1 = time.perf_counter()
     L.mxg_prof_enable(0)
+    if os.environ.get("MXG_PRINT_PACE") and args.workload == "config3":  # (diagnostics: K2f's pace controllers, csrc/mxg_pace.h)
+        buf = (ctypes.c_uint * 32)()
+        L.mxg_debug_voice_pace(ctypes.c_void_p(stream), buf)
+        w = list(buf)
+        for f, name in enumerate(("mode A", "mode B", "mode A + mix", "mode B + mix")):
+            q = w[8 * f: 8 * f + 8]
+            if q[0]:
+                print("pace[%s]: P %d  window %d lates %d booted %d  last mean lateness %d" % (
+                    name, q[0], q[1] & 255, (q[1] >> 8) & 255, q[1] >> 16, q[7]), file=sys.stderr)
     elapsed = t1 - t0
     step_ms_events = ev0.elapsed_time(ev1) / args.steps
     kernels = read_kernels(args.steps) if inline else {}

@@ -160,7 +160,9 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * 3 / 4 / 5 two samples of a lane pair exchanged into one 16-byte store per lane, plain / write-through (sc1) / non-temporal; two
  * voices per lane: 1 plain, 2 non-temporal, 3 write-through 16-byte stores), "voice_store" / "voice_xcd" (the same for the fused voice kernel; one voice
  * per lane only), "voice_mix_store" (the store stream of mxg_voice_render_mix*: 0 automatic = "voice_store"'s rule, 1 ... 5 its flavours),
- * "voice_diet" (the fused voice, mode A without mixdown: the fast paths' shorter instruction stream, same bits: 0 automatic = everywhere but around 65 536 voices, 1 off, 2 on),
+ * "voice_diet" (the fused voice, mode A without mixdown: 1 = the round-5 instruction stream of the fast paths, for comparison; same bits),
+ * "voice_pace" (the fused voice's paced store schedule, a chunk of 8 samples every P ticks of 10 ns: 0 automatic = a per-stream controller
+ * where every SIMD holds one wavefront of the bank, 57 344 ... 73 727 voices; 1 never; >= 2 a fixed P; timing only, same bits), "osc_pace" (the same for mxg_osc_render's pair-row kernels: 0 not paced, >= 2 a fixed P),
  * "tab_sides" (mxg_osc_render_tables*: 0 automatic = 1 workgroups of 256 lanes, one round of 8 voices at a time, two per CU; 2 = workgroups of 512 lanes, two rounds side by side),
  * "smp_ring" (the *AtSpeed players' window rows as rings: 0 automatic = samples beyond 1 GiB, 1 off, 2 on), "grain_spin_limit" (see mxg_granular_retries), "osc_xcd" (workgroups renumbered so that each of the eight XCDs renders
  * one contiguous eighth of the bank: 0 automatic, 1 off, 2 on), "grain_sync" (mxg_granular_render reads its error word back before it returns, 0|1;

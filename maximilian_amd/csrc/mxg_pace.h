@@ -1,0 +1,103 @@
+// mxg_pace.h -- the paced store schedule of the store-bound bank kernels (K1, K2f; round 6, profiles/r06_pace.md).
+//
+// Where a kernel's bound is its store stream -- 65 536 voices: one wavefront on every SIMD of the chip, each storing a 512-byte piece of
+// every row -- it is FASTEST when no wavefront ever meets a full store queue.  Left to run, the wavefronts reach the memory system's
+// back-pressure and the stream's efficiency collapses by a fifth (K2f: 51 us); started on a schedule -- chunk k (8 samples) not before
+// t0 + k P ticks of the constant 100 MHz counter (s_memrealtime), P a hair above the time the memory system needs for the chip's 8 rows --
+// the same instruction stream takes 41 us.  The optimum is a knee: a tick (10 ns) below it the collapse is back, above it the time is 64 P.
+//
+// So P is CONTROLLED, per stream and kernel form, by eight words in device scratch (zeroed once by the host):
+//   [0] P   [1] launches in the window | late ones among them << 8 | booted << 16
+//   [4:5] one 64-bit accumulator of the launch: reporters finished | reporters whose chunks were the cheap ones << 16 | the sum of their
+//   latenesses << 32 (ticks behind schedule at the last chunk, each capped at 8 P)   [7] the last launch's mean lateness (diagnostics)
+// One workgroup in sixteen reports: its first wavefront adds into [4:5]; the LAST reporter to finish judges the launch.  Only a
+// STORE-BOUND launch counts -- one whose chunks were (7 in 8) the cheap ones, far shorter than the period: a launch of expensive chunks
+// (the per-sample state machine, mode B's coefficients per sample) is behind from its first chunk, the schedule never binds and its
+// lateness says nothing about the memory system.  It was LATE if it ended, on average, more than half a period behind.  Near the knee
+// late launches come at a RATE that falls with P (measured: every other launch a tick below the knee, one in ten on it, one in fifty
+// three ticks above), and a tick costs 0.6 us per launch where a late launch costs ~6: the period worth having is the one with 5-10 %
+// late launches.  So: from the starting period P comes down a tick per launch until the first late one (a dozen launches); then windows
+// of 32 launches -- the fourth late launch of a window puts P up a tick at once, a window with at most one takes a tick off, anything
+// between holds.  P follows the box, its clocks and the other streams of the moment.  Timing only: the bits do not depend on it.
+#pragma once
+#include "mxg_common.h"
+
+namespace mxg {
+namespace {
+
+constexpr int kPaceWords = 8;
+constexpr unsigned kPaceWindow = 32, kPaceLatesUp = 4, kPaceLatesDown = 1;
+
+struct Pace {
+    unsigned P, t0, k, late, cheap;
+    __device__ __forceinline__ static unsigned now() { return (unsigned)__builtin_amdgcn_s_memrealtime(); }
+    // ctl: the controller's words or null; arg: the starting / fixed period (0 = not paced)
+    __device__ __forceinline__ void start(const unsigned *ctl, unsigned arg) {
+        P = arg;
+        if (ctl) {
+            const unsigned p = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p) P = p;
+        }
+        k = late = cheap = 0;
+        t0 = P ? now() : 0;
+    }
+    // the top of a chunk: wait for its slot (is_cheap: this chunk's arithmetic is far shorter than any period worth having)
+    __device__ __forceinline__ void wait(bool is_cheap) {
+        if (P) {
+            const unsigned due = t0 + k * P;
+            int d = (int)(now() - due);
+            while (d < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                d = (int)(now() - due);
+            }
+            late = (unsigned)d;
+            k++;
+            cheap += is_cheap ? 1u : 0u;
+        }
+    }
+    // the end of the launch, one lane per workgroup: fold, and the last workgroup updates the controller
+    // wg: this workgroup's number.  One workgroup in sixteen reports (256 workgroups' atomics on one line would queue for ~10 us).
+    __device__ __forceinline__ void finish(unsigned *ctl, unsigned arg, unsigned wg, unsigned nwg) const {
+        if (!ctl || !P || (wg & 15u)) return;
+        const unsigned nrep = (nwg + 15u) / 16u;
+        // ONE relaxed device-scope 64-bit atomic per reporter, no fence (an agent-scope fence would write the whole L2 back, +15 us per
+        // launch): tickets in bits 0-15, early waits in 16-31, the latenesses' sum above; the reporter that draws the last ticket has
+        // every other one's contribution in the value that comes back
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(ctl + 4);
+        const unsigned long long mine = ((unsigned long long)(late < 8 * P ? late : 8 * P) << 32) | ((unsigned long long)(cheap * 8 >= k * 7 ? 1u : 0u) << 16) | 1ull;
+        const unsigned long long all = atomicAdd(acc, mine) + mine;
+        if ((unsigned)(all & 0xffffu) != nrep) return;
+        atomicExch(acc, 0ull);
+        const unsigned worst = (unsigned)(all >> 32) / nrep, bound = (unsigned)((all >> 16) & 0xffffu);  // (the MEAN lateness: a single straggler is not a collapse)
+        const unsigned c1 = atomicAdd(&ctl[1], 0u);
+        unsigned p = P, w = c1 & 0xff, lates = (c1 >> 8) & 0xff, booted = c1 >> 16;
+        if (bound * 8 >= nrep * 7) {  // a store-bound launch: nearly every reporter's chunks were the cheap ones
+            const bool is_late = worst > p / 2;
+            if (!booted) {  // the descent from the starting period: a tick per launch on schedule, until the first late one
+                if (is_late) {
+                    p++;
+                    booted = 1;
+                } else if (p > arg - arg / 4) {
+                    p--;
+                }
+            } else {
+                lates += is_late ? 1 : 0;
+                ++w;
+                if (lates >= kPaceLatesUp) {  // at once: below the knee every other launch is late
+                    p++;
+                    w = lates = 0;
+                } else if (w >= kPaceWindow) {
+                    if (lates <= kPaceLatesDown && p > arg - arg / 4) p--;
+                    w = lates = 0;
+                }
+            }
+        }
+        if (p > 2 * arg) p = 2 * arg;
+        atomicExch(&ctl[0], p);
+        atomicExch(&ctl[1], w | (lates << 8) | (booted << 16));
+        atomicExch(&ctl[7], worst);
+    }
+};
+
+}  // namespace
+}  // namespace mxg

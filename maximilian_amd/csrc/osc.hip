@@ -79,7 +79,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
                            const double *__restrict__ p1, const double *__restrict__ p2,
                            double *__restrict__ phase_io, double *__restrict__ hold_io,
                            double *__restrict__ out, double sr, PartSync psync, int xcd, int p1ps, int passes, size_t v_begin,
-                           size_t v_end, size_t P) {
+                           size_t v_end, size_t P, unsigned pace_P) {
     // P: the row pitch of `out` in doubles (>= V; mxg_osc_render_pitch -- a bank whose natural pitch V * 8 is a multiple of 2 MB puts
     // the same column of every row on the same HBM channel: a caller that pads its rows by a few hundred bytes removes that)
     // [v_begin, v_end): the voices of the bank this launch renders (V stays the bank's size = the row pitch of `out`): a large bank
@@ -168,6 +168,23 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
         if constexpr (PX && VPL == 1 && !FPS) {
             double *op = out + (nA + (threadIdx.x & 1)) * P + (v0 & ~(size_t)1);
             if constexpr (!kLean) {
+                if (pace_P) {
+                    // the paced schedule (voice.hip, PACE): eight samples not before t0 + k P ticks of the 100 MHz counter
+                    const unsigned t0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+                    unsigned k = 0;
+                    for (; n + 8 <= nB; n += 8) {
+                        const unsigned due = t0 + k * pace_P;
+                        while ((int)((unsigned)__builtin_amdgcn_s_memrealtime() - due) < 0) __builtin_amdgcn_s_sleep(1);
+                        k++;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const double r0 = osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab);
+                            const double r1 = osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab);
+                            store_pair_rows<ST, false>(op, r0, r1);
+                            op += 2 * P;
+                        }
+                    }
+                }
 #pragma unroll 2
                 for (; n + 2 <= nB; n += 2) {
                     const double r0 = osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab);
@@ -750,7 +767,7 @@ osc_mix_fn pick_mix_wf(int wf, int store, int win) {
 }
 
 typedef void (*osc_fn)(size_t, size_t, const double *, const double *, const double *, double *,
-                       double *, double *, double, PartSync, int, int, int, size_t, size_t, size_t);
+                       double *, double *, double, PartSync, int, int, int, size_t, size_t, size_t, unsigned);
 
 // store: 0 plain 8 B, 1 nt 8 B, 2 pair rows (16 B) plain, 3 pair rows sc1, 4 pair rows nt      (one voice per lane)
 //        0 plain 16 B, 1 nt 16 B, 2 sc1 16 B                                                  (two voices per lane)
@@ -892,7 +909,7 @@ int osc_launch(const OscLaunch &L) {
         if (int s = part_sync_get(L.st, (size_t)grid.x * ((block + 63) / 64), split, &psync)) return s;
     KernelTimer kt("osc_kernel", L.st);
     hipLaunchKernelGGL(fn, grid, blk, 0, L.st, L.V, L.N, L.freq, L.p1, L.p2, L.phase, L.hold, L.out, (double)settings().sampleRate, psync,
-                       L.xcd, L.fps == 2 ? 1 : 0, passes, L.v_begin, L.v_end, L.P ? L.P : L.V);
+                       L.xcd, L.fps == 2 ? 1 : 0, passes, L.v_begin, L.v_end, L.P ? L.P : L.V, (unsigned)tune_get("osc_pace"));
     return check_hip(hipGetLastError(), "osc_kernel launch");
 }
 }  // namespace

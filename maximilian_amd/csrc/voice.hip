@@ -23,6 +23,7 @@
 #include "mxg_common.h"
 #include "mxg_env.h"
 #include "mxg_lanefold.h"
+#include "mxg_pace.h"
 #include "mxg_sincos.h"
 
 namespace mxg {
@@ -491,6 +492,9 @@ __device__ __forceinline__ double saw_tick(double &phase, double &hold, const do
     return s;
 }
 
+#ifndef MXG_VOICE_RUNS
+#define MXG_VOICE_RUNS 1  // A/B: 0 = the steady paths chunk by chunk
+#endif
 #ifndef MXG_MODB_SMALL
 #define MXG_MODB_SMALL 1  // A/B (tools/build_ab.sh): 0 = every chunk of mode B through the full-range coefficients
 #endif
@@ -513,10 +517,12 @@ __device__ __forceinline__ double saw_tick(double &phase, double &hold, const do
 // block at all (out may be null).  The ticks, their order and the per-voice stores are the ones of MIX = false: the same bits.
 constexpr int kVoiceMixWin = 512;
 // DIET (round 6): the fast paths' instruction diet -- saw_tick's one-add wrap, release chunks taken speculatively, the sustain / release
-// test carried from chunk to chunk: 16.7 -> ~14 vector instructions per sample.  A lone wavefront pays ~5 cycles per instruction it
-// issues (profiles/r06_k2f_split.md), so banks up to 32 768 voices gain 7 % (36.6 -> 34 us), the mixdown form 6 % (52.3 -> 48.9), mode B
-// 9 % -- but plain mode A at 65 536 voices, where every SIMD holds exactly one wavefront and the store stream is the bound, LOSES
-// 2.5 us (47.2-47.8 -> 50.0-50.4 with every store flavour: profiles/r06_k2f_diet.md), so the launch leaves it off there.  Same bits.
+// test carried from chunk to chunk and whole RUNS of steady chunks in one tight loop: 16.7 + 3.2 -> ~12.5 + 0.5 vector + scalar
+// instructions per sample.  A lone wavefront pays ~5 cycles per instruction it issues (profiles/r06_k2f_split.md): banks up to 32 768
+// voices 36.6 -> 27 us.  At 65 536 voices -- every SIMD holding exactly one wavefront, the store stream the bound -- a FASTER stream by
+// itself is SLOWER (47.7 -> 51 us: it runs into the memory system's back-pressure harder); there the kernel runs on the paced
+// schedule (PACE below, mxg_pace.h) and the short stream is what lets the period be short: 42 us.  Same bits (knob voice_diet = 1:
+// the round-5 stream, for comparison).
 template <int MODE, int ST, bool PX, bool TPV, bool MIX, bool DIET>
 __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t N, const double *__restrict__ freq,
                              const double *__restrict__ cutoff, const double *__restrict__ res,
@@ -525,7 +531,8 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
                              const int64_t *__restrict__ holdtime, double *__restrict__ ost,
                              double *__restrict__ fst, double *__restrict__ dst,
                              int64_t *__restrict__ ist, double *__restrict__ out, double sr, int xcd,
-                             const double *__restrict__ pan, double *__restrict__ partial) {
+                             const double *__restrict__ pan, double *__restrict__ partial, unsigned *__restrict__ pace_ctl,
+                             unsigned pace_arg) {
     constexpr int WIN = kVoiceMixWin;
     const size_t wg = (size_t)xcd_block(blockIdx.x, gridDim.x, xcd);
     const size_t gid = MIX ? wg * 256 + (threadIdx.x & 255) : wg * blockDim.x + threadIdx.x;  // (MIX: 256 voices per workgroup of 512 lanes)
@@ -707,6 +714,10 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
         gate_group_load(gcur, trig, N, 0, gate_on);
         asm volatile("" : "+v"(gcur.cls));
     }
+    // PACE (mxg_pace.h): chunk k not before t0 + k P ticks of the 100 MHz counter, P from the launch's controller
+    Pace pc;
+    pc.start(pace_ctl, pace_arg);
+    auto pace_wait = [&](bool is_cheap) { pc.wait(is_cheap); };
     if constexpr (MIX) __builtin_amdgcn_s_setprio(2);  // the store-bound stream is the critical one: the consumer takes the issue slots it leaves
     int fast_prev = 0;  // the previous chunk's steady state (1 sustain, 2 release, 0 neither or unknown)
     for (size_t n0 = 0; n0 < N; n0 += U) {
@@ -739,6 +750,7 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
       if (fast) {  // steady envelope: see env_in_sustain
         auto steady = [&](auto sustain) {
             constexpr bool SUS = decltype(sustain)::value;
+            pace_wait(MODE == 0 || SUS);  // (mode B's release chunks evaluate the coefficient pair per sample)
             if constexpr (MODE == 1 && SUS) {
                 // the envelope value, hence (cutoff, c, r), is the same for every sample of the chunk
                 lores_coeffs_sin((1.0 * e.amplitude) * cut, kr, pisr, sr, c, r);
@@ -815,9 +827,28 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
             }
             if constexpr (PX || MIX) emit(ov);
         };
-        if (fast == 1) steady(std::true_type{}); else steady(std::false_type{});
+        // RUNS (round 6, DIET): the gate's class of the group's 64 chunks sits in the lanes of gcur.cls, so the number of chunks from
+        // this one on that keep its class is a count of trailing ones -- and a sustain or release chunk leaves the wavefront in its
+        // state (see above): the whole run goes through ONE tight loop, a back-edge per chunk where the chunk-by-chunk form takes
+        // half a dozen branches, a v_readlane and the scalar tests around them (a lone wavefront refetches after every taken branch).
+        // A run ends with its group (512 samples = the mixdown form's window) at the latest; ragged chunks have class 0.
+        int run = 1;
+        if constexpr (DIET && !TPV && MXG_VOICE_RUNS) {
+            const int cc = (int)((n0 / U) & 63);
+            const unsigned long long same = (fast == 1 ? __ballot(gcur.cls > 0) : __ballot(gcur.cls < 0)) >> cc;  // (bit 0: this chunk)
+            const unsigned long long stop = ~same;
+            run = stop ? __builtin_ctzll(stop) : 64;
+            if (run > 64 - cc) run = 64 - cc;
+        }
+        if (fast == 1) {
+            for (int q = 0; q < run; q++) steady(std::true_type{});
+        } else {
+            for (int q = 0; q < run; q++) steady(std::false_type{});
+        }
+        n0 += (size_t)(run - 1) * U;
         continue;
       }
+      pace_wait(false);
       if constexpr (MODE == 0) {
         // The general steady chunk (mxg_env.h): the oscillator and the filter do not depend on the envelope, so their 8
         // samples are formed first; the envelope then takes them in one speculative chunk if every lane of the wavefront stays
@@ -932,6 +963,7 @@ __global__ void __launch_bounds__(MIX ? 512 : 256) voice_kernel(size_t V, size_t
     fst[3 * V + v] = f.o1;
     fst[4 * V + v] = f.o2;
     env_store(e, V, v, dst, ist);
+    if ((threadIdx.x & (MIX ? 255 : ~0u)) == 0 && (!MIX || threadIdx.x < 256)) pc.finish(pace_ctl, pace_arg, (unsigned)wg, gridDim.x);
 }
 
 inline dim3 grid_for(size_t V, int block) { return dim3((unsigned)((V + block - 1) / block)); }
@@ -942,6 +974,18 @@ inline dim3 grid_for(size_t V, int block) { return dim3((unsigned)((V + block - 
 using namespace mxg;
 
 extern "C" {
+
+// (diagnostics, not in maxigpu.h: the four pace controllers of a stream -- mode A / B x plain / mixdown, kPaceWords words each -- copied
+// to the host; tools/probes/pace_ctl.py)
+int mxg_debug_voice_pace(void *stream, unsigned *host) {
+    hipStream_t st = resolve_stream(stream);
+    unsigned *base = nullptr;
+    bool fresh = false;
+    if (int s = scratch_get(SCR_VOICE_PACE, st, 4 * kPaceWords * sizeof(unsigned), (void **)&base, &fresh)) return s;
+    if (fresh) MXG_HIP(hipMemsetAsync(base, 0, 4 * kPaceWords * sizeof(unsigned), st));
+    MXG_HIP(hipStreamSynchronize(st));
+    return check_hip(hipMemcpy(host, base, 4 * kPaceWords * sizeof(unsigned), hipMemcpyDeviceToHost), "pace words");
+}
 
 int mxg_filter_render(int kind, size_t V, size_t N, const double *d_in, const double *d_cutoff,
                       int cps, const double *d_res, int rps, const double *d_coef, double *d_st,
@@ -1160,7 +1204,7 @@ static int voice_launch(int mode, size_t V, size_t N, const double *d_freq, cons
 #define MXG_VOICE_LAUNCH(M, S, X, P, MX, D)                                                            \
     hipLaunchKernelGGL((voice_kernel<M, S, X, P, MX, D>), grid, dim3(block), 0, st, V, N, d_freq, \
                        d_cutoff, d_res, d_coef, d_trig, tpv, d_par, d_holdtime, d_ost, d_fst,   \
-                       d_dst, d_ist, d_out, sr, xcd, d_pan, d_rows)
+                       d_dst, d_ist, d_out, sr, xcd, d_pan, d_rows, pace_ctl, pace_arg)
 #define MXG_VOICE_LAUNCH1(M, S, X, P, MX) \
     if ((M) == 1 || (MX) || diet) MXG_VOICE_LAUNCH(M, S, X, P, MX, true); else MXG_VOICE_LAUNCH(M, S, X, P, MX, ((M) == 1 || (MX)))
 #define MXG_VOICE_LAUNCH2(M, S, X, MX) \
@@ -1173,10 +1217,26 @@ static int voice_launch(int mode, size_t V, size_t N, const double *d_freq, cons
         case 4: MXG_VOICE_LAUNCH2(M, 1, true, MX); break;  \
         default: MXG_VOICE_LAUNCH2(M, 0, false, MX); break; \
     }
-    // the fast paths' instruction diet (voice_kernel, DIET): always for mode B and the mixdown form; plain mode A everywhere but around
-    // 65 536 voices (knob voice_diet: 0 automatic, 1 off, 2 on -- plain mode A only)
+    // the fast paths' instruction diet (voice_kernel, DIET): always for mode B and the mixdown form; plain mode A unless the knob
+    // voice_diet says 1 (the round-5 instruction stream, kept for comparison)
     const int diet_knob = tune_get("voice_diet");
-    const bool diet = diet_knob == 2 || (diet_knob == 0 && !(V >= 57344 && V < 73728));
+    const bool diet = diet_knob != 1;
+    // the paced schedule (voice_kernel, PACE): knob voice_pace 0 = automatic (the controller, where every SIMD holds one wavefront of
+    // this bank: 57 344 ... 73 727 voices), 1 = never, >= 2 = a fixed period of that many 10 ns ticks per 8-sample chunk (sweeps)
+    const int pace_knob = tune_get("voice_pace");
+    unsigned *pace_ctl = nullptr;
+    unsigned pace_arg = 0;
+    if (pace_knob >= 2) {
+        pace_arg = (unsigned)pace_knob;
+    } else if (pace_knob == 0 && V >= 57344 && V < 73728) {
+        // the starting period: the chip's 8 rows at 6.6 TB/s, in ticks of 10 ns; one controller per stream and form
+        pace_arg = (unsigned)((double)V * 8 * 8 / 6.6e12 * 1e8 + 0.5);
+        bool fresh = false;
+        unsigned *base = nullptr;
+        if (int s = scratch_get(SCR_VOICE_PACE, st, 4 * kPaceWords * sizeof(unsigned), (void **)&base, &fresh)) return s;
+        if (fresh) MXG_HIP(hipMemsetAsync(base, 0, 4 * kPaceWords * sizeof(unsigned), st));
+        pace_ctl = base + kPaceWords * ((mode ? 1 : 0) + (mix ? 2 : 0));
+    }
     KernelTimer kt("voice_kernel", st);
     if (mix) {
         if (store == 5) {

@@ -250,8 +250,8 @@ def _long_gate(N, period=9000, duty=5000, offset=3):
 @pytest.mark.parametrize("mode", [0, 1])
 def test_voice_steady_state_paths_long_sequence(mx, port, mode, diet):
     """(diet: knob voice_diet -- the fast paths with and without round 6's shorter instruction stream: the one-add saw wrap, release
-    chunks taken speculatively -- including the chunk in which an amplitude underflows to 0 -- and the steady-state test carried
-    from chunk to chunk; mode B and the mixdown form always run the short one.)
+    chunks taken speculatively -- including the chunk in which an amplitude underflows to 0 -- the steady-state test carried
+    from chunk to chunk and whole runs of steady chunks in one loop; mode B and the mixdown form always run the short one.)
     The wave-uniform SUSTAIN / RELEASE fast paths of K2f against the oracle over 30 000 samples in ragged
     blocks: gate edges fall inside 8-sample chunks, the first wavefront shares one envelope (it enters
     sustain/release as a whole -> fast paths), the others mix fast and slow envelopes (some lanes still
@@ -361,7 +361,7 @@ def test_mix_rows_per_workgroup_same_bits(mx):
     assert_bits_equal(res[0], res[1], "rows 1 vs 2")
 
 
-@pytest.mark.parametrize("knob,value", [(b"voice_block", 64), (b"voice_block", 1024), (b"voice_nt", 1), (b"voice_diet", 1), (b"voice_diet", 2)])
+@pytest.mark.parametrize("knob,value", [(b"voice_block", 64), (b"voice_block", 1024), (b"voice_nt", 1), (b"voice_diet", 1), (b"voice_diet", 2), (b"voice_pace", 1), (b"voice_pace", 30)])
 def test_voice_launch_knobs_same_bits(mx, knob, value):
     L = mx.lib()
     V, N = 700, 300
@@ -387,6 +387,34 @@ def test_voice_launch_knobs_same_bits(mx, knob, value):
         L.mxg_tune(knob, prev)
     for r, g, name in zip(ref, got, ("voice", "filter", "env", "svf")):
         assert_bits_equal(g, r, "%s with %s=%d" % (name, knob.decode(), value))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_voice_paced_schedule_same_bits(mx, mode):
+    """The paced store schedule (csrc/mxg_pace.h: at 65 536 voices a chunk of 8 samples starts every P ticks of the 100 MHz counter, P
+    from a per-stream controller that the kernel itself updates) is timing only: block and state bit for bit as without it (knob
+    voice_pace 1) and as with a fixed period, over blocks that let the controller move (its words are in device scratch)."""
+    L = mx.lib()
+    V, N = 65536, 96
+    v = np.arange(V)
+    freq, cutoff, res = 50.0 + 7.0 * (v % 600), 300.0 + 5.0 * (v % 800), 1.0 + (v % 5)
+    trig = ((np.arange(N) % 130) < 70).astype(np.int32)
+    cu = cutoff if mode == 0 else np.full(V, 9000.0)
+
+    def run(pace):
+        prev = L.mxg_tune(b"voice_pace", pace)
+        try:
+            vb = mx.maxiVoiceBank(V)
+            vb.env.setAttack(1); vb.env.setDecay(5); vb.env.setSustain(0.5); vb.env.setRelease(20)
+            o = [vb.render(mode, freq, cu, res, trig, N).numpy() for _ in range(6)]
+            return o[-1], vb.flt_state.numpy().copy(), vb.env.dstate.numpy().copy(), vb.osc_state.numpy().copy()
+        finally:
+            L.mxg_tune(b"voice_pace", prev)
+    ref = run(1)
+    for pace in (0, 20, 90):
+        got = run(pace)
+        for a, b, what in zip(ref, got, ("block", "filter state", "envelope state", "osc state")):
+            assert_bits_equal(b, a, "voice_pace=%d, %s" % (pace, what))
 
 
 @pytest.mark.parametrize("store,xcd", [(3, 1), (4, 2), (5, 1), (4, 1), (2, 2)])
