@@ -19,6 +19,7 @@
 #include "mxg_sincos.h"
 #include "mxg_osc.h"
 #include "mxg_lanefold.h"
+#include "mxg_pace.h"
 
 namespace mxg {
 
@@ -79,7 +80,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
                            const double *__restrict__ p1, const double *__restrict__ p2,
                            double *__restrict__ phase_io, double *__restrict__ hold_io,
                            double *__restrict__ out, double sr, PartSync psync, int xcd, int p1ps, int passes, size_t v_begin,
-                           size_t v_end, size_t P, unsigned pace_P) {
+                           size_t v_end, size_t P, unsigned *__restrict__ pace_ctl, unsigned pace_arg) {
     // P: the row pitch of `out` in doubles (>= V; mxg_osc_render_pitch -- a bank whose natural pitch V * 8 is a multiple of 2 MB puts
     // the same column of every row on the same HBM channel: a caller that pads its rows by a few hundred bytes removes that)
     // [v_begin, v_end): the voices of the bank this launch renders (V stays the bank's size = the row pitch of `out`): a large bank
@@ -162,20 +163,19 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
             for (int j = 0; j < VPL; j++) q[j].sk = sintab_k();  // the two vector-register coefficients, loaded once (mxg_sincos.h)
         }
     }
+    // PACE (mxg_pace.h): where the launch asks for it (one part, one pass, a store-bound waveform at the size where every SIMD holds one
+    // wavefront) eight samples start every P ticks of the 100 MHz counter
+    Pace pc;
+    pc.start(pace_ctl, pace_arg);
     auto run = [&](auto trust_tag) {
         constexpr bool kTrust = decltype(trust_tag)::value;
         size_t n = nA;
         if constexpr (PX && VPL == 1 && !FPS) {
             double *op = out + (nA + (threadIdx.x & 1)) * P + (v0 & ~(size_t)1);
             if constexpr (!kLean) {
-                if (pace_P) {
-                    // the paced schedule (voice.hip, PACE): eight samples not before t0 + k P ticks of the 100 MHz counter
-                    const unsigned t0 = (unsigned)__builtin_amdgcn_s_memrealtime();
-                    unsigned k = 0;
+                if (pc.P) {  // the paced schedule (mxg_pace.h): eight samples per slot
                     for (; n + 8 <= nB; n += 8) {
-                        const unsigned due = t0 + k * pace_P;
-                        while ((int)((unsigned)__builtin_amdgcn_s_memrealtime() - due) < 0) __builtin_amdgcn_s_sleep(1);
-                        k++;
+                        pc.wait(true);
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
                             const double r0 = osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab);
@@ -205,6 +205,18 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
                 n = nA + 2 * (size_t)pairs;
             }
             o = out + n * P + v0;
+        }
+        if constexpr (VPL == 1 && !FPS && !PX && !kLean) {
+            if (pc.P) {  // the paced schedule, 8-byte store streams
+                for (; n + 8 <= nB; n += 8) {
+                    pc.wait(true);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        store1<ST>(o, osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab));
+                        o += P;
+                    }
+                }
+            }
         }
 #pragma unroll MXG_OSC_UNROLL
         for (; n < nB; n++) {
@@ -237,6 +249,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
             hold_io[v0 + j] = hd[j];
         }
     }
+    if (threadIdx.x == 0) pc.finish(pace_ctl, pace_arg, blockIdx.x, gridDim.x);
     }  // passes (time parts are launched with one pass only: the part counters are per wavefront of the grid)
 }
 
@@ -767,7 +780,7 @@ osc_mix_fn pick_mix_wf(int wf, int store, int win) {
 }
 
 typedef void (*osc_fn)(size_t, size_t, const double *, const double *, const double *, double *,
-                       double *, double *, double, PartSync, int, int, int, size_t, size_t, size_t, unsigned);
+                       double *, double *, double, PartSync, int, int, int, size_t, size_t, size_t, unsigned *, unsigned);
 
 // store: 0 plain 8 B, 1 nt 8 B, 2 pair rows (16 B) plain, 3 pair rows sc1, 4 pair rows nt      (one voice per lane)
 //        0 plain 16 B, 1 nt 16 B, 2 sc1 16 B                                                  (two voices per lane)
@@ -907,9 +920,20 @@ int osc_launch(const OscLaunch &L) {
     PartSync psync;
     if (split > 1)
         if (int s = part_sync_get(L.st, (size_t)grid.x * ((block + 63) / 64), split, &psync)) return s;
+    // the paced schedule (mxg_pace.h) as an EXPERIMENT only -- knob osc_pace >= 2: a fixed period in ticks of 10 ns per 8 samples; one
+    // part, one pass, one voice per lane, a waveform whose time is its store stream's.  K1's own stream (pair rows, write-through) already
+    // sits where the paced one ends up -- 40.8-41.2 us against 41.1-42.8 paced with 8-byte non-temporal stores and 44-45 paced with its own
+    // (profiles/r06_pace.md) -- so no launch is paced by default.
+    unsigned *pace_ctl = nullptr;
+    unsigned pace_arg = 0;
+    {
+        const int knob = tune_get("osc_pace");
+        const bool lean = ((MXG_K1_LEAN_MASK >> L.waveform) & 1) != 0;
+        if (split == 1 && passes == 1 && !fps && vpl == 1 && !lean && knob >= 2) pace_arg = (unsigned)knob;
+    }
     KernelTimer kt("osc_kernel", L.st);
     hipLaunchKernelGGL(fn, grid, blk, 0, L.st, L.V, L.N, L.freq, L.p1, L.p2, L.phase, L.hold, L.out, (double)settings().sampleRate, psync,
-                       L.xcd, L.fps == 2 ? 1 : 0, passes, L.v_begin, L.v_end, L.P ? L.P : L.V, (unsigned)tune_get("osc_pace"));
+                       L.xcd, L.fps == 2 ? 1 : 0, passes, L.v_begin, L.v_end, L.P ? L.P : L.V, pace_ctl, pace_arg);
     return check_hip(hipGetLastError(), "osc_kernel launch");
 }
 }  // namespace

@@ -1221,14 +1221,20 @@ static int voice_launch(int mode, size_t V, size_t N, const double *d_freq, cons
     // voice_diet says 1 (the round-5 instruction stream, kept for comparison)
     const int diet_knob = tune_get("voice_diet");
     const bool diet = diet_knob != 1;
-    // the paced schedule (voice_kernel, PACE): knob voice_pace 0 = automatic (the controller, where every SIMD holds one wavefront of
-    // this bank: 57 344 ... 73 727 voices), 1 = never, >= 2 = a fixed period of that many 10 ns ticks per 8-sample chunk (sweeps)
+    // the paced schedule (voice_kernel, PACE): knob voice_pace 0 = automatic, 1 = never, >= 2 = a fixed period of that many 10 ns ticks
+    // per 8-sample chunk (sweeps).  Automatic = the controller wherever the store stream is the bound AND the whole grid is resident at
+    // once (a schedule per workgroup means nothing to workgroups that wait for a CU): from 45 056 voices (below, the kernel's time is
+    // its own instruction stream's: 40 960 voices 32.7 -> 33.3 us) up to 196 608 for mode A (five wavefronts of 92 registers per SIMD;
+    // 262 144 voices, measured: 198 -> 205 us), 131 072 for mode B (two of 160-190), 65 536 for the mixdown form (one workgroup of
+    // 146 KB of LDS per CU: at 131 072 voices half the grid waits, 110 -> 142 us).  Measured with the controller, mode A:
+    // 49 152 voices 36.1 -> 32.7 us, 65 536 51.3 -> 42.4 (the round-5 stream without it: 47.7), 81 920 65.7 -> 54.5, 98 304 74.4 -> 68.4,
+    // 131 072 103.0 -> 87.7, 196 608 166.5 -> 132.8: the collapse of the store stream is not a matter of one wavefront per SIMD.
     const int pace_knob = tune_get("voice_pace");
     unsigned *pace_ctl = nullptr;
     unsigned pace_arg = 0;
     if (pace_knob >= 2) {
         pace_arg = (unsigned)pace_knob;
-    } else if (pace_knob == 0 && V >= 57344 && V < 73728) {
+    } else if (pace_knob == 0 && V >= 45056 && V <= (mix ? (size_t)65536 : (mode ? (size_t)131072 : (size_t)229375))) {
         // the starting period: the chip's 8 rows at 6.6 TB/s, in ticks of 10 ns; one controller per stream and form
         pace_arg = (unsigned)((double)V * 8 * 8 / 6.6e12 * 1e8 + 0.5);
         bool fresh = false;
