@@ -760,6 +760,15 @@ def main():
     fence()
     t1 = time.perf_counter()
     L.mxg_prof_enable(0)
+    if os.environ.get("MXG_PRINT_PACE") and args.workload == "config2":  # (diagnostics: K1's pace controllers, csrc/mxg_pace.h)
+        buf = (ctypes.c_uint * 128)()
+        L.mxg_debug_osc_pace(ctypes.c_void_p(stream), buf)
+        w = list(buf)
+        for f in range(16):
+            q = w[8 * f: 8 * f + 8]
+            if q[0]:
+                print("pace[waveform %d]: P %d  window %d lates %d booted %d  last mean lateness %d" % (
+                    f, q[0], q[1] & 255, (q[1] >> 8) & 255, q[1] >> 16, q[7]), file=sys.stderr)
     if os.environ.get("MXG_PRINT_PACE") and args.workload == "config3":  # (diagnostics: K2f's pace controllers, csrc/mxg_pace.h)
         buf = (ctypes.c_uint * 32)()
         L.mxg_debug_voice_pace(ctypes.c_void_p(stream), buf)

@@ -822,6 +822,7 @@ osc_fn pick_wf(int wf, bool fps, int vpl, int store) {
 namespace mxg {
 namespace {
 // one launch of K1 over the voices [v_begin, v_end) of a bank
+constexpr size_t kPacedFrom = 90112, kPacedTo = 327680;  // K1 on the controlled schedule: bank sizes (mxg_osc_render_pitch)
 struct OscLaunch {
     int waveform = 0;
     size_t V = 0, N = 0, P = 0;  // P: row pitch of `out` in doubles
@@ -833,6 +834,7 @@ struct OscLaunch {
     size_t v_begin = 0, v_end = 0;
     int vpl = 1, store = 0, xcd = 0;  // store: osc.hip pick<WF> numbering (0 plain 8 B ...)
     int split = 0, passes = 0, block = 256;  // 0 = automatic
+    bool paced = false;                      // the controlled schedule (mxg_pace.h): one voice per lane, one part, one pass
 };
 
 // The store stream of ONE launch over `count` voices, by waveform class and size (MI355X, 512-sample blocks, destination rotated;
@@ -920,16 +922,25 @@ int osc_launch(const OscLaunch &L) {
     PartSync psync;
     if (split > 1)
         if (int s = part_sync_get(L.st, (size_t)grid.x * ((block + 63) / 64), split, &psync)) return s;
-    // the paced schedule (mxg_pace.h) as an EXPERIMENT only -- knob osc_pace >= 2: a fixed period in ticks of 10 ns per 8 samples; one
-    // part, one pass, one voice per lane, a waveform whose time is its store stream's.  K1's own stream (pair rows, write-through) already
-    // sits where the paced one ends up -- 40.8-41.2 us against 41.1-42.8 paced with 8-byte non-temporal stores and 44-45 paced with its own
-    // (profiles/r06_pace.md) -- so no launch is paced by default.
+    // the paced schedule (mxg_pace.h): L.paced = the controller (mxg_osc_render_pitch decides where); knob osc_pace >= 2 = a fixed period in
+    // ticks of 10 ns per 8 samples (sweeps).  One part, one pass, one voice per lane, a waveform whose time is its store stream's.
     unsigned *pace_ctl = nullptr;
     unsigned pace_arg = 0;
     {
         const int knob = tune_get("osc_pace");
         const bool lean = ((MXG_K1_LEAN_MASK >> L.waveform) & 1) != 0;
-        if (split == 1 && passes == 1 && !fps && vpl == 1 && !lean && knob >= 2) pace_arg = (unsigned)knob;
+        if (split == 1 && passes == 1 && !fps && vpl == 1 && !lean) {
+            if (knob >= 2) {
+                pace_arg = (unsigned)knob;
+            } else if (L.paced) {
+                pace_arg = (unsigned)((double)count * 8 * 8 / 6.6e12 * 1e8 + 0.5);  // the starting period: the chip's 8 rows at 6.6 TB/s
+                bool fresh = false;
+                unsigned *base = nullptr;
+                if (int s = scratch_get(SCR_OSC_PACE, L.st, 16 * kPaceWords * sizeof(unsigned), (void **)&base, &fresh)) return s;
+                if (fresh) MXG_HIP(hipMemsetAsync(base, 0, 16 * kPaceWords * sizeof(unsigned), L.st));
+                pace_ctl = base + kPaceWords * (L.waveform & 15);
+            }
+        }
     }
     KernelTimer kt("osc_kernel", L.st);
     hipLaunchKernelGGL(fn, grid, blk, 0, L.st, L.V, L.N, L.freq, L.p1, L.p2, L.phase, L.hold, L.out, (double)settings().sampleRate, psync,
@@ -938,6 +949,17 @@ int osc_launch(const OscLaunch &L) {
 }
 }  // namespace
 }  // namespace mxg
+
+// (diagnostics, not in maxigpu.h: K1's pace controllers of a stream -- one per waveform, kPaceWords words each)
+extern "C" int mxg_debug_osc_pace(void *stream, unsigned *host) {
+    hipStream_t st = mxg::resolve_stream(stream);
+    unsigned *base = nullptr;
+    bool fresh = false;
+    if (int s = mxg::scratch_get(mxg::SCR_OSC_PACE, st, 16 * mxg::kPaceWords * sizeof(unsigned), (void **)&base, &fresh)) return s;
+    if (fresh) MXG_HIP(hipMemsetAsync(base, 0, 16 * mxg::kPaceWords * sizeof(unsigned), st));
+    MXG_HIP(hipStreamSynchronize(st));
+    return mxg::check_hip(hipMemcpy(host, base, 16 * mxg::kPaceWords * sizeof(unsigned), hipMemcpyDeviceToHost), "pace words");
+}
 
 extern "C" int mxg_osc_render(int waveform, size_t V, size_t N, const double *d_freq, int fps,
                               const double *d_p1, const double *d_p2, double *d_phase,
@@ -974,6 +996,24 @@ extern "C" int mxg_osc_render_pitch(int waveform, size_t V, size_t N, const doub
     // (Row pitches that are multiples of 2 MB -- 262 144 voices and its multiples -- take the passes badly: 524 288 voices 0.56, 1 048 576
     // 0.64 against 0.68-0.71 for one launch over the whole bank; 262 144 itself wants the XCD-contiguous numbering, 0.80 against 0.73.
     // profiles/r04_osc_grid.md.)
+    // ---- the paced schedule (round 6, mxg_pace.h; profiles/r06_pace.md) -------------------------------------------------------------------
+    // Between 90 112 and 327 680 voices the TABLE-FREE store-bound waveforms (phasor, saw, triangle, square, pulse, impulse, phasorBetween)
+    // stream best as the SIMPLEST launch -- one voice per lane, one pass, non-temporal 8-byte stores -- on the controlled schedule: eight
+    // samples every P ticks, P on the knee of the memory system's rate.  Measured with the controller (saw / square, us per 512-sample
+    // block, against the plan of launches below, which round 4 tuned for the free-running kernel): 98 304 voices 63.6-65.3 -> 60.0-61.9,
+    // 131 072 88.2-89.3 -> 78.1-78.7 (0.76 -> 0.86 of 8 TB/s), 196 608 135-141 -> 114.4-115.0 (0.88), 262 144 180-183 -> 153.3-155.6.
+    // Not below (69 632 ... 81 920 voices: the tuned launches are as fast or faster, 42-54 us against 51-56), not beyond (393 216 mixed;
+    // 524 288: 385 -> 630 us, the grid is no longer resident at once).  NOT sinebuf: with fixed periods it gains as much (131 072 voices
+    // 86.3 -> 78.3 us at P = 106), but its launches go late now and then at ANY period, the controller reads that as the knee and parks
+    // far above it (P = 128: 87.8 us) -- it keeps the plan below; and at 65 536 voices K1's own stream (pair rows, write-through) already
+    // sits where the paced one ends up (40.8-41.2 us against 41.1-42.8).  Knob osc_pace: 0 automatic, 1 never, >= 2 a fixed period.
+    const bool lean_wf = ((MXG_K1_LEAN_MASK >> waveform) & 1) != 0 || waveform == MXG_OSC_SINEBUF;  // (sinebuf: see below)
+    if (automatic && !fps && !lean_wf && xcd < 0 && tune_get("osc_pace") == 0 && tune_get("osc_passes") == 0 && tune_get("osc_split") == 0 &&
+        tune_get("osc_plan") == 0 && V >= kPacedFrom && V <= kPacedTo) {
+        OscLaunch A = L0;
+        A.v_begin = 0; A.v_end = V; A.vpl = 1; A.store = 1; A.xcd = 0; A.split = 1; A.passes = 1; A.block = 256; A.paced = true;
+        return osc_launch(A);
+    }
     int plan = tune_get("osc_plan");  // 0 automatic, 1 never, 2 / 3 always (main launch with natural / XCD-contiguous numbering)
     if (plan == 0) plan = (P % 262144) ? 2 : (V == 262144 ? 3 : 1);  // (the PITCH decides: padded rows take the passes well)
     if (automatic && pairs_ok && !heavy && xcd < 0 && tune_get("osc_passes") == 0 && tune_get("osc_split") == 0 && plan != 1 &&

@@ -172,6 +172,39 @@ def test_large_bank_launch_plan_same_bits(mx, port, wf, V, N):
     assert_bits_equal(bank.output.numpy()[sel], ehd, "output member")
 
 
+@pytest.mark.parametrize("wf,V,N", [(3, 98304 + 2, 200), (5, 131072, 136), (4, 196608 + 64, 77), (2, 262144, 64), (6, 131074, 100), (11, 100000, 130)])
+def test_paced_launch_same_bits(mx, port, wf, V, N):
+    """The table-free waveforms at 90 112 ... 327 680 voices are rendered by ONE simple launch on the paced schedule (csrc/mxg_pace.h:
+    eight samples every P ticks of the 100 MHz counter, P from a controller in device scratch that the kernel updates): three carried
+    blocks against the round-4 launch rules (knob osc_pace 1) bit for bit -- the schedule is timing only -- with a fixed period as
+    well, ragged block lengths, and a subsample of voices against the oracle."""
+    L = mx.lib()
+    rng = np.random.default_rng(V + wf)
+    freq = rng.uniform(20, 20000, V)
+    p1 = rng.uniform(0.1, 0.9, V) if wf in (6, 11) else None
+    p2 = rng.uniform(0.1, 0.9, V) if wf == 11 else None
+    if wf == 11:
+        p1, p2 = np.minimum(p1, p2), np.maximum(p1, p2) + 0.05
+
+    def run(pace):
+        prev = L.mxg_tune(b"osc_pace", pace)
+        try:
+            bank = mx.maxiOscBank(V)
+            outs = [bank.render(wf, freq, N, p1=p1, p2=p2).numpy() for _ in range(3)]
+            return np.concatenate(outs), bank.phase.numpy().copy(), bank.output.numpy().copy()
+        finally:
+            L.mxg_tune(b"osc_pace", prev)
+    ref = run(1)
+    for pace in (0, 60):
+        got = run(pace)
+        for a, b, what in zip(ref, got, ("blocks", "phase", "output member")):
+            assert_bits_equal(b, a, "osc_pace=%d, %s" % (pace, what))
+    sel = np.unique(np.concatenate([np.arange(0, V, 997), [V - 2, V - 1]]).astype(np.int64))
+    eo, eph, _ = port.osc(wf, freq[sel], 3 * N, p1=None if p1 is None else p1[sel], p2=None if p2 is None else p2[sel])
+    assert_bits_equal(ref[0][:, sel], eo, OSC[wf])
+    assert_bits_equal(ref[1][sel], eph, "phase")
+
+
 def test_empty_and_invalid(mx):
     L = mx.lib()
     bank = mx.maxiOscBank(4)
