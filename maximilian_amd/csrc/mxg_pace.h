@@ -64,7 +64,7 @@ struct Pace {
         // launch): tickets in bits 0-15, early waits in 16-31, the latenesses' sum above; the reporter that draws the last ticket has
         // every other one's contribution in the value that comes back
         unsigned long long *acc = reinterpret_cast<unsigned long long *>(ctl + 4);
-        const unsigned long long mine = ((unsigned long long)(late < 8 * P ? late : 8 * P) << 32) | ((unsigned long long)(cheap * 8 >= k * 7 ? 1u : 0u) << 16) | 1ull;
+        const unsigned long long mine = ((unsigned long long)(late < 8 * P ? late : 8 * P) << 32) | ((unsigned long long)(k && cheap * 8 >= k * 7 ? 1u : 0u) << 16) | 1ull;
         const unsigned long long all = atomicAdd(acc, mine) + mine;
         if ((unsigned)(all & 0xffffu) != nrep) return;
         atomicExch(acc, 0ull);

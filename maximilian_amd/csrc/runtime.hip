@@ -42,6 +42,7 @@ Tune g_tune[] = {
     {"voice_diet", 0, 0, 2},  // K2f plain mode A: 1 = the round-5 instruction stream of the fast paths (comparison); 0 / 2 = the short one (voice_kernel DIET)
     {"voice_pace", 0, 0, 4096},  // K2f: the paced schedule (a chunk every P ticks of 10 ns): 0 automatic (controller at the store-bound sizes whose grid is resident at once), 1 never, >= 2 fixed P
     {"osc_pace", 0, 0, 4096},  // K1: the paced schedule (eight samples every P ticks of 10 ns, mxg_pace.h): 0 automatic (controller + the simplest launch, table-free waveforms at 90 112 ... 327 680 voices), 1 never, >= 2 fixed P
+    {"smp_pace", 0, 0, 4096},  // the sample players: the paced schedule (mxg_pace.h): 0 automatic (play() at 45 056 ... 229 375 voices, controller), 1 never, >= 2 a fixed period for play and the *AtSpeed players
     {"osc_store", 0, 0, 5},  // K1 store stream (osc.hip pick<WF>): 0 automatic; one voice per lane: 1 plain 8 B, 2 nt 8 B, 3 / 4 / 5 pair rows (16 B) plain / sc1 / nt; two voices per lane: 1 plain, 2 nt, 3 sc1
     {"osc_xcd", 0, 0, 2},  // K1: 1 = every XCD renders one contiguous eighth of the bank (workgroup renumbering, mxg_common.h)
     {"osc_plan", 0, 0, 3},  // K1, large banks: the plan of launches (98 304-voice passes + a remainder launch): 0 automatic, 1 never, 2 / 3 always (natural / XCD-contiguous numbering)

@@ -18,6 +18,7 @@
 // sizes of the configs); per sample a lane gathers 1-4 neighbouring doubles (K5, 8 B out +
 // gather).  The buffer must be valid on [-4, len+5] with zero guards (mxg_sample_upload's layout, mxg_smp.h).
 #include "mxg_common.h"
+#include "mxg_pace.h"
 #include "mxg_advance.h"
 #include "mxg_smp.h"
 
@@ -173,6 +174,8 @@ struct SmpArgs {
     int32_t *tfirst;      // [V] in/out, modes 9-14
     double *out;
     int px_store;         // pair-row store flavour (smp_emit), 0 = 8-byte stores
+    unsigned pace_arg;    // the paced schedule (mxg_pace.h): the starting / fixed period in ticks of 10 ns per chunk, 0 = not paced
+    unsigned *pace_ctl;   // ... and its controller's words (play() on whole heads), or null
 };
 
 // PX: the whole chunks leave as 16-byte pair rows (emit_chunk, mxg_common.h) -- V even, out 16-byte aligned (round 4; same values, same
@@ -230,8 +233,13 @@ __global__ void __launch_bounds__(256) sample_kernel(SmpArgs A) {
                     d[j] = *reinterpret_cast<const double2v *>(q);
                 }
             };
+            // the paced schedule (mxg_pace.h): this path is a pure store stream (its loads hit the L2) -- 49.7 us free-running, 38.6 us
+            // on a period of 56 ticks at 65 536 voices (profiles/r06_pace.md)
+            Pace pc;
+            pc.start(A.pace_ctl, A.pace_arg);
             auto retire = [&](double2v(&d)[4]) {
                 const double o[8] = {d[0].x, d[0].y, d[1].x, d[1].y, d[2].x, d[2].y, d[3].x, d[3].y};
+                pc.wait(true);
                 emit_chunk<PX>(op, V, o, A.px_store);
                 __builtin_amdgcn_sched_barrier(0);
             };
@@ -261,7 +269,13 @@ __global__ void __launch_bounds__(256) sample_kernel(SmpArgs A) {
                 s.pos += 1.0;
             }
             A.position[v] = s.pos;
+            if (threadIdx.x == 0) pc.finish(A.pace_ctl, A.pace_arg, blockIdx.x, gridDim.x);
             return;
+        }
+        if (threadIdx.x == 0 && A.pace_ctl) {  // (a workgroup that takes the general path still hands in its ticket: not a store-bound launch)
+            Pace none;
+            none.start(A.pace_ctl, A.pace_arg);
+            none.finish(A.pace_ctl, A.pace_arg, blockIdx.x, gridDim.x);
         }
     }
     if (nfull > 0) {
@@ -412,6 +426,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RING ?
     const double x0 = A.a[v], sr = A.sr;
     const double step = (x0 * kChandiv) / s.step_div;  // the increment of smp_gen (C:1070)
     const bool can_skip = __all(step > 0.0 && step < HUGE_VAL && s.pos >= 0.0 && s.pos < HUGE_VAL);
+    Pace pc;
+    pc.start(nullptr, A.pace_arg);
     size_t n0 = 0, n1 = N;
     // the writer of the head is ALWAYS the last part (the last dispatched: it never waits for work that is not resident yet) --
     // where the wavefront cannot skip, the last part renders it whole; the other parts tell it when they have read the head
@@ -642,6 +658,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RING ?
                 o[i] = smp_eval<MODE>(q, val);
             }
         }
+        pc.wait(true);
         emit_chunk<PX>(op, V, o, A.px_store);
         smp_lds_sync();  // the rows are free again
     };
@@ -726,6 +743,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RING ?
                     ph = ph + step;
                     ic = (int)ph;
                 }
+                pc.wait(true);
                 emit_chunk<PX>(op, V, o, A.px_store);
                 smp_lds_sync();  // the rows are free again
             };
@@ -1001,10 +1019,25 @@ int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, siz
     int block = tune_get("voice_block");
     if (block > 256) block = 256;  // sample_kernel is compiled for <= 256 lanes per workgroup
     hipStream_t st = resolve_stream(stream);
-    const SmpArgs A = {V, N, d_samples, len, (double)q, (double)settings().sampleRate, d_a, nullptr,
-                       d_start, d_end, d_position, nullptr, nullptr, d_out, rw_store_choice(V, N, d_out, RW_WRITE_ONLY)};
+    SmpArgs A = {V, N, d_samples, len, (double)q, (double)settings().sampleRate, d_a, nullptr,
+                       d_start, d_end, d_position, nullptr, nullptr, d_out, rw_store_choice(V, N, d_out, RW_WRITE_ONLY), 0u, nullptr};
     const bool xmod = mode >= 4 && aps;
     const dim3 grid = grid_for(V, block);
+    {
+        // the paced schedule (mxg_pace.h; knob smp_pace: 0 automatic, 1 never, >= 2 a fixed period in ticks of 10 ns per 8 samples and
+        // wavefront): play() -- whose whole-chunk path is a pure store stream -- at the store-bound bank sizes, on the controller
+        const int knob = tune_get("smp_pace");
+        if (knob >= 2) {
+            A.pace_arg = (unsigned)knob;
+        } else if (knob == 0 && mode == 0 && V >= 45056 && V <= 229375) {
+            A.pace_arg = (unsigned)((double)V * 8 * 8 / 6.6e12 * 1e8 + 0.5);
+            bool fresh = false;
+            unsigned *base = nullptr;
+            if (int s2 = scratch_get(SCR_SMP_PACE, st, kPaceWords * sizeof(unsigned), (void **)&base, &fresh)) return s2;
+            if (fresh) MXG_HIP(hipMemsetAsync(base, 0, kPaceWords * sizeof(unsigned), st));
+            A.pace_ctl = base;
+        }
+    }
     if (mode >= 4 && mode <= 6 && !xmod) {
         size_t part_len = N;
         const int split = speed_parts(V, N, len, &part_len);
@@ -1069,7 +1102,7 @@ int mxg_sample_render_trig(int mode, size_t V, size_t N, const double *d_samples
     if (block > 256) block = 256;
     hipStream_t st = resolve_stream(stream);
     const SmpArgs A = {V, N, d_samples, len, (double)q, (double)settings().sampleRate, d_a, d_trig,
-                       d_p0, d_p1, d_position, d_tprev, d_tfirst, d_out, rw_store_choice(V, N, d_out, RW_WRITE_ONLY)};
+                       d_p0, d_p1, d_position, d_tprev, d_tfirst, d_out, rw_store_choice(V, N, d_out, RW_WRITE_ONLY), 0u, nullptr};
     const bool xmod = aps != 0;
     const dim3 grid = grid_for(V, block);
     switch (mode) {

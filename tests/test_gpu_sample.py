@@ -123,6 +123,40 @@ def test_play_with_heads_between_elements(mx, port, Ls, N):
     assert_bits_equal(bank.position.numpy(), ep, "head after three blocks")
 
 
+@pytest.mark.parametrize("V,N", [(65536, 100), (49152 + 70, 64), (131072, 40)])
+def test_play_paced_schedule_same_bits(mx, port, V, N):
+    """maxiSample::play() at the store-bound bank sizes runs its whole-chunk path on the paced schedule (csrc/mxg_pace.h: eight samples
+    every P ticks of the 100 MHz counter, P from a controller in device scratch that the kernel updates): five carried blocks against
+    the free-running kernel (knob smp_pace 1) and a fixed period, bit for bit; one wavefront of heads that wrap (general path beside
+    paced ones), a subsample of voices against the oracle."""
+    L = mx.lib()
+    rng = np.random.default_rng(V)
+    Ls = 30000
+    smp = rng.uniform(-1, 1, Ls)
+    pos0 = np.floor(rng.uniform(0, Ls - 5 * N - 16, V))
+    pos0[64:128] = Ls - 1 - rng.integers(0, 3 * N, 64)       # a wavefront whose heads wrap inside the blocks
+
+    def run(pace):
+        prev = L.mxg_tune(b"smp_pace", pace)
+        try:
+            bank = mx.maxiSampleBank(V)
+            bank.setSample(smp)
+            bank.position.upload(pos0)
+            o = np.concatenate([bank.render(0, N).numpy() for _ in range(5)])
+            return o, bank.position.numpy().copy()
+        finally:
+            L.mxg_tune(b"smp_pace", prev)
+    ref = run(1)
+    for pace in (0, 40):
+        got = run(pace)
+        assert_bits_equal(got[0], ref[0], "play, smp_pace=%d" % pace)
+        assert_bits_equal(got[1], ref[1], "heads, smp_pace=%d" % pace)
+    sel = np.unique(np.concatenate([np.arange(0, V, 1009), np.arange(60, 132)]))
+    e, ep = port.sample(0, smp, 5 * N, pos0[sel])
+    assert_bits_equal(ref[0][:, sel], e, "play against the oracle")
+    assert_bits_equal(ref[1][sel], ep, "heads against the oracle")
+
+
 @pytest.mark.parametrize("mode", range(9))
 @pytest.mark.parametrize("N", [1, 7, 8, 9, 16, 21, 203])
 def test_sample_ragged_blocks(mx, golden, port, mode, N):

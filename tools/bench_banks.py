@@ -12,6 +12,11 @@ V, B = 65536, 512
 if len(sys.argv) > 2 and sys.argv[1] == "--rw":    # knob rw_store: 1 = 8-byte streams, 2 / 3 / 4 = 16-byte pair rows plain / sc1 / nt (0 automatic)
     L.mxg_tune(b"rw_store", int(sys.argv[2]))
     print("# rw_store", sys.argv[2])
+for a in sys.argv[1:]:                             # KNOB=VALUE: any other knob of mxg_tune (A/B runs)
+    if "=" in a:
+        k, val = a.split("=")
+        L.mxg_tune(k.encode(), int(val))
+        print("#", a)
 rng = np.random.default_rng(1)
 e0, e1 = L.mxg_event_create(), L.mxg_event_create(); ms = ctypes.c_float()
 D = mx.DeviceBuffer.from_numpy
