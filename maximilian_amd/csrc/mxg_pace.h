@@ -57,7 +57,9 @@ struct Pace {
     }
     // the end of the launch, one lane per workgroup: fold, and the last workgroup updates the controller
     // wg: this workgroup's number.  One workgroup in sixteen reports (256 workgroups' atomics on one line would queue for ~10 us).
-    __device__ __forceinline__ void finish(unsigned *ctl, unsigned arg, unsigned wg, unsigned nwg) const {
+    // tolerant: a kernel whose launches go late now and then at ANY period (K1's sinebuf) -- the windows then take eight late launches
+    // for a tick up and up to four for a tick down, and the descent ends with two late launches in a row
+    __device__ __forceinline__ void finish(unsigned *ctl, unsigned arg, unsigned wg, unsigned nwg, bool tolerant = false) const {
         if (!ctl || !P || (wg & 15u)) return;
         const unsigned nrep = (nwg + 15u) / 16u;
         // ONE relaxed device-scope 64-bit atomic per reporter, no fence (an agent-scope fence would write the whole L2 back, +15 us per
@@ -70,31 +72,33 @@ struct Pace {
         atomicExch(acc, 0ull);
         const unsigned worst = (unsigned)(all >> 32) / nrep, bound = (unsigned)((all >> 16) & 0xffffu);  // (the MEAN lateness: a single straggler is not a collapse)
         const unsigned c1 = atomicAdd(&ctl[1], 0u);
-        unsigned p = P, w = c1 & 0xff, lates = (c1 >> 8) & 0xff, booted = c1 >> 16;
+        unsigned p = P, w = c1 & 0xff, lates = (c1 >> 8) & 0xff, booted = (c1 >> 16) & 0xff, strikes = c1 >> 24;
+        const unsigned up = tolerant ? 2 * kPaceLatesUp : kPaceLatesUp, down = tolerant ? 4 * kPaceLatesDown : kPaceLatesDown;
         if (bound * 8 >= nrep * 7) {  // a store-bound launch: nearly every reporter's chunks were the cheap ones
             const bool is_late = worst > p / 2;
             if (!booted) {  // the descent from the starting period: a tick per launch on schedule, until the first late one
-                if (is_late) {
+                strikes = is_late ? strikes + 1 : 0;
+                if (strikes >= (tolerant ? 2u : 1u)) {
                     p++;
                     booted = 1;
-                } else if (p > arg - arg / 4) {
+                } else if (!is_late && p > arg - arg / 4) {
                     p--;
                 }
             } else {
                 lates += is_late ? 1 : 0;
                 ++w;
-                if (lates >= kPaceLatesUp) {  // at once: below the knee every other launch is late
+                if (lates >= up) {  // at once: below the knee every other launch is late
                     p++;
                     w = lates = 0;
                 } else if (w >= kPaceWindow) {
-                    if (lates <= kPaceLatesDown && p > arg - arg / 4) p--;
+                    if (lates <= down && p > arg - arg / 4) p--;
                     w = lates = 0;
                 }
             }
         }
         if (p > 2 * arg) p = 2 * arg;
         atomicExch(&ctl[0], p);
-        atomicExch(&ctl[1], w | (lates << 8) | (booted << 16));
+        atomicExch(&ctl[1], w | (lates << 8) | (booted << 16) | (strikes << 24));
         atomicExch(&ctl[7], worst);
     }
 };

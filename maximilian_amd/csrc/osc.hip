@@ -249,7 +249,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
             hold_io[v0 + j] = hd[j];
         }
     }
-    if (threadIdx.x == 0) pc.finish(pace_ctl, pace_arg, blockIdx.x, gridDim.x);
+    if (threadIdx.x == 0) pc.finish(pace_ctl, pace_arg, blockIdx.x, gridDim.x, WF == MXG_OSC_SINEBUF);
     }  // passes (time parts are launched with one pass only: the part counters are per wavefront of the grid)
 }
 
@@ -822,7 +822,7 @@ osc_fn pick_wf(int wf, bool fps, int vpl, int store) {
 namespace mxg {
 namespace {
 // one launch of K1 over the voices [v_begin, v_end) of a bank
-constexpr size_t kPacedFrom = 90112, kPacedTo = 327680;  // K1 on the controlled schedule: bank sizes (mxg_osc_render_pitch)
+constexpr size_t kPacedFrom = 90112, kPacedFromSinebuf = 122880, kPacedTo = 327680;  // K1 on the controlled schedule: bank sizes (mxg_osc_render_pitch)
 struct OscLaunch {
     int waveform = 0;
     size_t V = 0, N = 0, P = 0;  // P: row pitch of `out` in doubles
@@ -1003,11 +1003,14 @@ extern "C" int mxg_osc_render_pitch(int waveform, size_t V, size_t N, const doub
     // block, against the plan of launches below, which round 4 tuned for the free-running kernel): 98 304 voices 63.6-65.3 -> 60.0-61.9,
     // 131 072 88.2-89.3 -> 78.1-78.7 (0.76 -> 0.86 of 8 TB/s), 196 608 135-141 -> 114.4-115.0 (0.88), 262 144 180-183 -> 153.3-155.6.
     // Not below (69 632 ... 81 920 voices: the tuned launches are as fast or faster, 42-54 us against 51-56), not beyond (393 216 mixed;
-    // 524 288: 385 -> 630 us, the grid is no longer resident at once).  NOT sinebuf: with fixed periods it gains as much (131 072 voices
-    // 86.3 -> 78.3 us at P = 106), but its launches go late now and then at ANY period, the controller reads that as the knee and parks
-    // far above it (P = 128: 87.8 us) -- it keeps the plan below; and at 65 536 voices K1's own stream (pair rows, write-through) already
-    // sits where the paced one ends up (40.8-41.2 us against 41.1-42.8).  Knob osc_pace: 0 automatic, 1 never, >= 2 a fixed period.
-    const bool lean_wf = ((MXG_K1_LEAN_MASK >> waveform) & 1) != 0 || waveform == MXG_OSC_SINEBUF;  // (sinebuf: see below)
+    // 524 288: 385 -> 630 us, the grid is no longer resident at once).  sinebuf from 122 880 voices, under the TOLERANT rule of the
+    // controller: its launches go late now and then at ANY period (one in ten or twenty), which the strict rule reads as the knee and
+    // parks far above it (131 072 voices: P = 128, 87.8 us); with eight late launches of 32 for a tick up and up to four for a tick
+    // down it holds P = 107-108, the optimum of the fixed-period sweep: 131 072 voices 88.2-89.9 -> 79.4-79.6 us (0.76 -> 0.85), 196 608
+    // 126.0-126.6 -> 119.9-120.2, 262 144 168.1-168.3 -> 160.0-160.3; at 98 304 voices the plan is as fast (63.6 against 63.4-64.0), and at
+    // 65 536 K1's own stream (pair rows, write-through) already sits where the paced one ends up (40.8-41.2 us against 41.1-42.8).
+    // Knob osc_pace: 0 automatic, 1 never, >= 2 a fixed period.
+    const bool lean_wf = ((MXG_K1_LEAN_MASK >> waveform) & 1) != 0 || (waveform == MXG_OSC_SINEBUF && V < kPacedFromSinebuf);
     if (automatic && !fps && !lean_wf && xcd < 0 && tune_get("osc_pace") == 0 && tune_get("osc_passes") == 0 && tune_get("osc_split") == 0 &&
         tune_get("osc_plan") == 0 && V >= kPacedFrom && V <= kPacedTo) {
         OscLaunch A = L0;

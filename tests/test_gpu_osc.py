@@ -172,9 +172,10 @@ def test_large_bank_launch_plan_same_bits(mx, port, wf, V, N):
     assert_bits_equal(bank.output.numpy()[sel], ehd, "output member")
 
 
-@pytest.mark.parametrize("wf,V,N", [(3, 98304 + 2, 200), (5, 131072, 136), (4, 196608 + 64, 77), (2, 262144, 64), (6, 131074, 100), (11, 100000, 130)])
+@pytest.mark.parametrize("wf,V,N", [(3, 98304 + 2, 200), (5, 131072, 136), (4, 196608 + 64, 77), (2, 262144, 64), (6, 131074, 100), (11, 100000, 130),
+                                      (8, 131072, 120), (8, 122880 + 6, 90), (8, 327680, 40)])
 def test_paced_launch_same_bits(mx, port, wf, V, N):
-    """The table-free waveforms at 90 112 ... 327 680 voices are rendered by ONE simple launch on the paced schedule (csrc/mxg_pace.h:
+    """The table-free waveforms at 90 112 ... 327 680 voices (sinebuf from 122 880) are rendered by ONE simple launch on the paced schedule (csrc/mxg_pace.h:
     eight samples every P ticks of the 100 MHz counter, P from a controller in device scratch that the kernel updates): three carried
     blocks against the round-4 launch rules (knob osc_pace 1) bit for bit -- the schedule is timing only -- with a fixed period as
     well, ragged block lengths, and a subsample of voices against the oracle."""
