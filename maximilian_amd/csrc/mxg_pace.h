@@ -36,7 +36,7 @@ struct Pace {
         P = arg;
         if (ctl) {
             const unsigned p = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (p) P = p;
+            if (p) P = p < 2 * arg ? p : 2 * arg;  // (whatever the words hold, a launch waits at most twice its starting schedule)
         }
         k = late = cheap = 0;
         t0 = P ? now() : 0;

@@ -934,11 +934,9 @@ int osc_launch(const OscLaunch &L) {
                 pace_arg = (unsigned)knob;
             } else if (L.paced) {
                 pace_arg = (unsigned)((double)count * 8 * 8 / 6.6e12 * 1e8 + 0.5);  // the starting period: the chip's 8 rows at 6.6 TB/s
-                bool fresh = false;
-                unsigned *base = nullptr;
-                if (int s = scratch_get(SCR_OSC_PACE, L.st, 16 * kPaceWords * sizeof(unsigned), (void **)&base, &fresh)) return s;
-                if (fresh) MXG_HIP(hipMemsetAsync(base, 0, 16 * kPaceWords * sizeof(unsigned), L.st));
-                pace_ctl = base + kPaceWords * (L.waveform & 15);
+                unsigned *base = pace_words(SCR_OSC_PACE, L.st, 16 * kPaceWords);
+                if (base) pace_ctl = base + kPaceWords * (L.waveform & 15);
+                else pace_arg = 0;  // (inside a graph capture before the first eager launch: not paced)
             }
         }
     }

@@ -143,6 +143,24 @@ int scratch_get(ScratchSlot slot, hipStream_t st, size_t bytes, void **out, bool
     return MXG_OK;
 }
 
+// The words of a pace controller (mxg_pace.h) in per-stream scratch, zeroed when first handed out; null -- the launch is then simply not
+// paced -- while `st` is being captured into a graph and the words do not exist yet (no allocation inside a capture; a graph captured
+// after the first eager launch carries the pointer and its replays keep the controller going).
+unsigned *pace_words(ScratchSlot slot, hipStream_t st, size_t nwords) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) return nullptr;
+    if (cap != hipStreamCaptureStatusNone) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_scratch.find(std::make_pair((int)slot, st));
+        return (it != g_scratch.end() && it->second.ptr && it->second.cap >= nwords * sizeof(unsigned)) ? (unsigned *)it->second.ptr : nullptr;
+    }
+    void *p = nullptr;
+    bool fresh = false;
+    if (scratch_get(slot, st, nwords * sizeof(unsigned), &p, &fresh) != MXG_OK) return nullptr;
+    if (fresh && hipMemsetAsync(p, 0, nwords * sizeof(unsigned), st) != hipSuccess) return nullptr;
+    return (unsigned *)p;
+}
+
 namespace {
 int *g_async_host = nullptr;  // pinned, device-mapped: kernels store a code, the host polls it without synchronising
 int *g_async_dev = nullptr;

@@ -1031,11 +1031,8 @@ int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, siz
             A.pace_arg = (unsigned)knob;
         } else if (knob == 0 && mode == 0 && V >= 45056 && V <= 229375) {
             A.pace_arg = (unsigned)((double)V * 8 * 8 / 6.6e12 * 1e8 + 0.5);
-            bool fresh = false;
-            unsigned *base = nullptr;
-            if (int s2 = scratch_get(SCR_SMP_PACE, st, kPaceWords * sizeof(unsigned), (void **)&base, &fresh)) return s2;
-            if (fresh) MXG_HIP(hipMemsetAsync(base, 0, kPaceWords * sizeof(unsigned), st));
-            A.pace_ctl = base;
+            A.pace_ctl = pace_words(SCR_SMP_PACE, st, kPaceWords);
+            if (!A.pace_ctl) A.pace_arg = 0;  // (inside a graph capture before the first eager launch: not paced)
         }
     }
     if (mode >= 4 && mode <= 6 && !xmod) {

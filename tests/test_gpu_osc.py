@@ -430,6 +430,48 @@ def test_render_and_mixdown_are_graph_capturable(mx):
     assert torch.equal(g_state[3], e[3]), "last mix"
 
 
+def test_paced_launches_are_graph_capturable(mx):
+    """A launch on the paced schedule (saw at 131 072 voices: csrc/mxg_pace.h) takes its controller's words from per-stream scratch.  Captured
+    into a hipGraph on a stream that has never launched it, it must not allocate inside the capture -- the launch is then simply not
+    paced; captured after an eager launch it carries the words, and the replays keep updating them.  Same bits either way."""
+    import torch
+    L = mx.lib()
+    V, B, K = 131072, 64, 4
+    dev = torch.device("cuda", 0)
+    freq = torch.from_numpy(20 + (np.arange(V) % 4096) * 4.8828125).to(dev)
+
+    def fresh():
+        return (torch.zeros(V, dtype=torch.float64, device=dev), torch.zeros(V, dtype=torch.float64, device=dev),
+                torch.empty((B, V), dtype=torch.float64, device=dev))
+
+    def block(st, phase, hold, out):
+        assert L.mxg_osc_render(3, V, B, freq.data_ptr(), 0, None, None, phase.data_ptr(), hold.data_ptr(), out.data_ptr(), st) == 0
+
+    ref = fresh()
+    s0 = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s0):
+        for _ in range(K):
+            block(s0.cuda_stream, *ref)
+    s0.synchronize()
+    for warm in (False, True):
+        s = torch.cuda.Stream(device=dev)      # a stream the library has no scratch for
+        st = s.cuda_stream
+        if warm:
+            w = fresh()
+            with torch.cuda.stream(s):
+                block(st, *w)
+            s.synchronize()
+        g_state = fresh()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            block(st, *g_state)
+        for _ in range(K):
+            graph.replay()
+        torch.cuda.synchronize()
+        for a, b, what in zip(ref, g_state, ("phase", "output member", "block")):
+            assert torch.equal(a, b), "graph replays (%s eager launch first): %s" % ("an" if warm else "no", what)
+
+
 def test_time_part_timeout_is_reported_and_state_kept(mx, port):
     """A time-split launch whose writer part does not get its sibling parts' signals (forced: knob part_fault makes it wait for
     one signal more than will ever come, part_spin_limit bounds the wait) must fail LOUDLY: the next synchronising call returns
