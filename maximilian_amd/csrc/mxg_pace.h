@@ -16,7 +16,7 @@
 // lateness says nothing about the memory system.  It was LATE if it ended, on average, more than half a period behind.  Near the knee
 // late launches come at a RATE that falls with P (measured: every other launch a tick below the knee, one in ten on it, one in fifty
 // three ticks above), and a tick costs 0.6 us per launch where a late launch costs ~6: the period worth having is the one with 5-10 %
-// late launches.  So: from the starting period P comes down a tick per launch until the first late one (a dozen launches); then windows
+// late launches.  So: from the starting period P comes down two ticks per launch until the first late one, then a tick per launch until the next (a dozen launches in all); then windows
 // of 32 launches -- the fourth late launch of a window puts P up a tick at once, a window with at most one takes a tick off, anything
 // between holds.  P follows the box, its clocks and the other streams of the moment.  Timing only: the bits do not depend on it.
 #pragma once
@@ -76,9 +76,19 @@ struct Pace {
         const unsigned up = tolerant ? 2 * kPaceLatesUp : kPaceLatesUp, down = tolerant ? 4 * kPaceLatesDown : kPaceLatesDown;
         if (bound * 8 >= nrep * 7) {  // a store-bound launch: nearly every reporter's chunks were the cheap ones
             const bool is_late = worst > p / 2;
-            if (!booted) {  // the descent from the starting period: a tick per launch on schedule, until the first late one
+            if (booted != 1) {
+                // the descent from the starting period (a safe one: the memory system takes it on every box seen): two ticks per launch
+                // on schedule until the first late one (booted 0 -> 2), then a tick per launch until the next late one (the tolerant
+                // rule: until two in a row), which puts P back up a tick and hands over to the windows (booted 1)
                 strikes = is_late ? strikes + 1 : 0;
-                if (strikes >= (tolerant ? 2u : 1u)) {
+                if (booted == 0) {
+                    if (is_late) {
+                        booted = 2;
+                        strikes = 0;
+                    } else if (p > arg - arg / 4 + 1) {
+                        p -= 2;
+                    }
+                } else if (strikes >= (tolerant ? 2u : 1u)) {
                     p++;
                     booted = 1;
                 } else if (!is_late && p > arg - arg / 4) {
