@@ -856,7 +856,7 @@ def main():
             V2 = 131072
             nb2 = V2 * B * 8
             b2 = OscBank(V2, max(1, -(-(1 << 31) // nb2)), "off", None)
-            ms2 = time_steps(b2.step, n_x, warm=48)  # (this bank runs on the paced schedule, csrc/mxg_pace.h: its controller finds the period within ~15 launches of a stream's first)
+            ms2 = time_steps(b2.step, n_x, warm=int(os.environ.get("MXG_NS_WARM", "96")))  # (this bank runs on the paced schedule, csrc/mxg_pace.h: its controller finds the period within ~15 launches of a stream's first)
             if os.environ.get("MXG_PRINT_PACE"):
                 buf = (ctypes.c_uint * 128)()
                 L.mxg_debug_osc_pace(ctypes.c_void_p(stream), buf)
