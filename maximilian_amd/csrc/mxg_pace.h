@@ -27,6 +27,7 @@ namespace {
 
 constexpr int kPaceWords = 8;
 constexpr unsigned kPaceWindow = 32, kPaceLatesUp = 4, kPaceLatesDown = 1;
+constexpr unsigned kPaceGaveUp = 0xffffffffu;  // ctl[0]: the schedule was given up on this stream (see Pace::finish)
 
 struct Pace {
     unsigned P, t0, k, late, cheap;
@@ -36,7 +37,8 @@ struct Pace {
         P = arg;
         if (ctl) {
             const unsigned p = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (p) P = p < 2 * arg ? p : 2 * arg;  // (whatever the words hold, a launch waits at most twice its starting schedule)
+            if (p == kPaceGaveUp) P = 0;                // (the controller gave the schedule up on this stream: free-running, see finish)
+            else if (p) P = p < 2 * arg ? p : 2 * arg;  // (whatever the words hold, a launch waits at most twice its starting schedule)
         }
         k = late = cheap = 0;
         t0 = P ? now() : 0;
@@ -106,7 +108,10 @@ struct Pace {
                 }
             }
         }
-        if (p > 2 * arg) p = 2 * arg;
+        // the safety net: a period half as long again as the starting one (itself ~10 % above every knee measured) means that the schedule
+        // does not describe this launch -- a grid that is not resident at once, a device of another shape, a neighbour that never lets
+        // go: the kernel would run at the pace of a schedule nobody needs.  The stream then goes back to the free-running kernel for good.
+        if (p > arg + arg / 2) p = kPaceGaveUp;
         atomicExch(&ctl[0], p);
         atomicExch(&ctl[1], w | (lates << 8) | (booted << 16) | (strikes << 24));
         atomicExch(&ctl[7], worst);
