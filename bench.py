@@ -766,9 +766,12 @@ def main():
         w = list(buf)
         for f in range(16):
             q = w[8 * f: 8 * f + 8]
-            if q[0]:
+            if f == 14 and q[1]:
+                print("trial[sinebuf, headline size]: verdict %d (1 free-running, else the period)  launches %d  sums of 32 mean durations: three periods %d %d %d, free-running %d" % (
+                    q[0], q[1], q[4], q[5], q[6], q[7]), file=sys.stderr)
+            elif q[0]:
                 print("pace[waveform %d]: P %d  window %d lates %d booted %d  last mean lateness %d" % (
-                    f, q[0], q[1] & 255, (q[1] >> 8) & 255, q[1] >> 16, q[7]), file=sys.stderr)
+                    f, q[0], q[1] & 255, (q[1] >> 8) & 255, (q[1] >> 16) & 255, q[7]), file=sys.stderr)
     if os.environ.get("MXG_PRINT_PACE") and args.workload == "config3":  # (diagnostics: K2f's pace controllers, csrc/mxg_pace.h)
         buf = (ctypes.c_uint * 32)()
         L.mxg_debug_voice_pace(ctypes.c_void_p(stream), buf)

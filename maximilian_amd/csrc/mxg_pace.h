@@ -118,5 +118,73 @@ struct Pace {
     }
 };
 
+// ---- free-running or paced, and at which period?  A trial on the device -------------------------------------------------------------
+// K1's sinebuf at 65 536 voices (the headline) has a free-running stream -- pair rows, write-through -- that sits ON the knee on some boxes
+// (40.4-41.3 us) and collapses on others (43.5-47.6 us, box by box and sometimes run by run); paced 8-byte stores on the right period take
+// 40.7 us on the first kind and 42.5 on the second -- but sinebuf is the waveform whose launches go late now and then at any period, and
+// inside 80 launches the lateness controller does not find that period.  So the DURATIONS decide, on the device: eight words --
+//   [0] the verdict (0 none yet, 1 free-running, >= 2 paced on that fixed period)   [1] launches so far   [2:3] this launch's accumulator
+//   (reporters | the sum of their durations << 32)   [4] ... [7] the sums of the mean durations of the four measured phases
+// -- and ONE kernel that holds both loops.  Launches 0 ... 31 run free (clocks and caches settle), then 32 launches each on the periods
+// 27/32, 29/32 and 31/32 of the starting one (the measured knees sit at 0.83-0.9 of it), then 32 free-running ones; the shortest mean
+// wins, a period only if it beats the free-running stream by 1.5 %.  After 16 384 launches the trial is repeated.  A run shorter than 160
+// launches never leaves the free-running kernel it always had.
+constexpr unsigned kTrialPhase = 32, kTrialEnd = 5 * kTrialPhase, kTrialAgain = kTrialEnd + 16384;
+
+struct PaceTrial {
+    unsigned t_begin, n, period;  // period: this launch's (0 = free-running)
+    __device__ __forceinline__ static unsigned candidate(unsigned arg, unsigned i) { return arg * (27u + 2u * i) / 32u; }  // i = 0, 1, 2
+    __device__ __forceinline__ void start(const unsigned *T, unsigned arg) {
+        t_begin = Pace::now();
+        n = 0;
+        period = 0;
+        if (T) {
+            const unsigned d = __hip_atomic_load(T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            n = __hip_atomic_load(T + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d) {
+                period = d >= 2 ? (d < 2 * arg ? d : 2 * arg) : 0;
+            } else {
+                const unsigned ph = n / kTrialPhase;  // 0 free, 1 ... 3 the candidates, 4 free
+                period = (ph >= 1 && ph <= 3) ? candidate(arg, ph - 1) : 0;
+            }
+        }
+    }
+    // the end of the launch, one lane per workgroup
+    __device__ __forceinline__ void finish(unsigned *T, unsigned arg, unsigned wg, unsigned nwg) const {
+        if (!T || (wg & 15u)) return;
+        const unsigned nrep = (nwg + 15u) / 16u;
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(T + 2);
+        const unsigned long long mine = ((unsigned long long)(Pace::now() - t_begin) << 32) | 1ull;
+        const unsigned long long all = atomicAdd(acc, mine) + mine;  // (relaxed, one line, no fence: see Pace::finish)
+        if ((unsigned)(all & 0xffffu) != nrep) return;
+        atomicExch(acc, 0ull);
+        const unsigned mean = (unsigned)(all >> 32) / nrep;
+        unsigned d = atomicAdd(&T[0], 0u), nn = n + 1;
+        if (!d) {
+            const unsigned ph = n / kTrialPhase;
+            if (ph >= 1 && ph <= 4) atomicAdd(&T[3 + ph], mean);
+            if (nn == kTrialEnd) {
+                const unsigned long long fr = (unsigned long long)atomicAdd(&T[7], 0u) * 197;  // (a period has to win by 1.5 %)
+                unsigned best = 1;
+                unsigned long long best_sum = fr;
+                for (unsigned i = 0; i < 3; i++) {
+                    const unsigned long long c = (unsigned long long)atomicAdd(&T[4 + i], 0u) * 200;
+                    if (c < best_sum) {
+                        best_sum = c;
+                        best = candidate(arg, i);
+                    }
+                }
+                d = best;
+            }
+        } else if (nn >= kTrialAgain) {
+            d = 0;
+            nn = 0;
+            for (unsigned i = 4; i < 8; i++) atomicExch(&T[i], 0u);
+        }
+        atomicExch(&T[0], d);
+        atomicExch(&T[1], nn);
+    }
+};
+
 }  // namespace
 }  // namespace mxg

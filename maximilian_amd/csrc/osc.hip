@@ -80,7 +80,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
                            const double *__restrict__ p1, const double *__restrict__ p2,
                            double *__restrict__ phase_io, double *__restrict__ hold_io,
                            double *__restrict__ out, double sr, PartSync psync, int xcd, int p1ps, int passes, size_t v_begin,
-                           size_t v_end, size_t P, unsigned *__restrict__ pace_ctl, unsigned pace_arg) {
+                           size_t v_end, size_t P, unsigned *__restrict__ pace_ctl, unsigned pace_arg, unsigned *__restrict__ trial) {
     // P: the row pitch of `out` in doubles (>= V; mxg_osc_render_pitch -- a bank whose natural pitch V * 8 is a multiple of 2 MB puts
     // the same column of every row on the same HBM channel: a caller that pads its rows by a few hundred bytes removes that)
     // [v_begin, v_end): the voices of the bank this launch renders (V stays the bank's size = the row pitch of `out`): a large bank
@@ -165,25 +165,29 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
     }
     // PACE (mxg_pace.h): where the launch asks for it (one part, one pass, a store-bound waveform at the size where every SIMD holds one
     // wavefront) eight samples start every P ticks of the 100 MHz counter
+    // (trial != null: this launch holds BOTH forms, the free-running pair rows and the paced 8-byte stream; the trial's words say which runs)
+    PaceTrial tr;
+    tr.start(trial, pace_arg);
     Pace pc;
-    pc.start(pace_ctl, pace_arg);
+    pc.start(trial ? nullptr : pace_ctl, trial ? tr.period : pace_arg);
     auto run = [&](auto trust_tag) {
         constexpr bool kTrust = decltype(trust_tag)::value;
         size_t n = nA;
         if constexpr (PX && VPL == 1 && !FPS) {
             double *op = out + (nA + (threadIdx.x & 1)) * P + (v0 & ~(size_t)1);
             if constexpr (!kLean) {
-                if (pc.P) {  // the paced schedule (mxg_pace.h): eight samples per slot
+                if (pc.P) {  // the paced schedule (mxg_pace.h): eight samples per slot, as non-temporal 8-byte stores (what the paced
+                             // stream wants: profiles/r06_pace.md; this kernel's own pair rows are the free-running form)
+                    double *o8 = out + nA * P + v0;
                     for (; n + 8 <= nB; n += 8) {
                         pc.wait(true);
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const double r0 = osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab);
-                            const double r1 = osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab);
-                            store_pair_rows<ST, false>(op, r0, r1);
-                            op += 2 * P;
+                        for (int u = 0; u < 8; u++) {
+                            store1<1>(o8, osc_tick<WF, kTrust, kFL>(ph[0], hd[0], q[0], s_tab, s_tab));
+                            o8 += P;
                         }
                     }
+                    op += (n - nA) * P;
                 }
 #pragma unroll 2
                 for (; n + 2 <= nB; n += 2) {
@@ -249,7 +253,10 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
             hold_io[v0 + j] = hd[j];
         }
     }
-    if (threadIdx.x == 0) pc.finish(pace_ctl, pace_arg, blockIdx.x, gridDim.x, WF == MXG_OSC_SINEBUF);
+    if (threadIdx.x == 0) {
+        pc.finish(trial ? nullptr : pace_ctl, pace_arg, blockIdx.x, gridDim.x, WF == MXG_OSC_SINEBUF);
+        tr.finish(trial, pace_arg, blockIdx.x, gridDim.x);
+    }
     }  // passes (time parts are launched with one pass only: the part counters are per wavefront of the grid)
 }
 
@@ -780,7 +787,7 @@ osc_mix_fn pick_mix_wf(int wf, int store, int win) {
 }
 
 typedef void (*osc_fn)(size_t, size_t, const double *, const double *, const double *, double *,
-                       double *, double *, double, PartSync, int, int, int, size_t, size_t, size_t, unsigned *, unsigned);
+                       double *, double *, double, PartSync, int, int, int, size_t, size_t, size_t, unsigned *, unsigned, unsigned *);
 
 // store: 0 plain 8 B, 1 nt 8 B, 2 pair rows (16 B) plain, 3 pair rows sc1, 4 pair rows nt      (one voice per lane)
 //        0 plain 16 B, 1 nt 16 B, 2 sc1 16 B                                                  (two voices per lane)
@@ -835,6 +842,7 @@ struct OscLaunch {
     int vpl = 1, store = 0, xcd = 0;  // store: osc.hip pick<WF> numbering (0 plain 8 B ...)
     int split = 0, passes = 0, block = 256;  // 0 = automatic
     bool paced = false;                      // the controlled schedule (mxg_pace.h): one voice per lane, one part, one pass
+    bool trial = false;                      // free-running or paced, decided by a trial on the device (mxg_pace.h, PaceTrial)
 };
 
 // The store stream of ONE launch over `count` voices, by waveform class and size (MI355X, 512-sample blocks, destination rotated;
@@ -940,9 +948,20 @@ int osc_launch(const OscLaunch &L) {
             }
         }
     }
+    // the trial (mxg_pace.h, PaceTrial): sinebuf at the headline's size, as the automatic rule launches it (pair rows, write-through, one
+    // voice per lane, one part, one pass) -- the same kernel also holds the paced 8-byte stream, and eight words on the device decide
+    // between them, and on the period, by the launches' measured durations
+    unsigned *trial = nullptr;
+    if (L.trial && !pace_arg && split == 1 && passes == 1 && !fps && vpl == 1 && store == 3 && tune_get("osc_pace") == 0) {
+        unsigned *base = pace_words(SCR_OSC_PACE, L.st, 16 * kPaceWords);
+        if (base) {
+            trial = base + kPaceWords * 14;
+            pace_arg = (unsigned)((double)count * 8 * 8 / 6.6e12 * 1e8 + 0.5);  // (the candidates are 27/32, 29/32, 31/32 of it: 54, 58, 62 at 65 536 voices)
+        }
+    }
     KernelTimer kt("osc_kernel", L.st);
     hipLaunchKernelGGL(fn, grid, blk, 0, L.st, L.V, L.N, L.freq, L.p1, L.p2, L.phase, L.hold, L.out, (double)settings().sampleRate, psync,
-                       L.xcd, L.fps == 2 ? 1 : 0, passes, L.v_begin, L.v_end, L.P ? L.P : L.V, pace_ctl, pace_arg);
+                       L.xcd, L.fps == 2 ? 1 : 0, passes, L.v_begin, L.v_end, L.P ? L.P : L.V, pace_ctl, pace_arg, trial);
     return check_hip(hipGetLastError(), "osc_kernel launch");
 }
 }  // namespace
@@ -1051,6 +1070,7 @@ extern "C" int mxg_osc_render_pitch(int waveform, size_t V, size_t N, const doub
     if (automatic) {
         osc_single_rule(A, V);
         if (xcd >= 0) A.xcd = xcd;
+        A.trial = waveform == MXG_OSC_SINEBUF && !fps && V >= 57344 && V < 73728;  // (every SIMD one wavefront: the headline's shape)
     } else {
         if (vpl == 0) vpl = 1;
         if (store < 0) {  // (the round-2 rule for 8-byte stores, knob osc_nt: non-temporal by block size)

@@ -430,6 +430,47 @@ def test_render_and_mixdown_are_graph_capturable(mx):
     assert torch.equal(g_state[3], e[3]), "last mix"
 
 
+def test_headline_trial_same_bits(mx, port):
+    """sinebuf at the headline's size is launched as ONE kernel that holds the free-running pair-row stream and the paced 8-byte one; a trial
+    on the device (csrc/mxg_pace.h, PaceTrial: 32 launches each free-running, on three periods, free-running again) picks by the
+    measured durations.  200 carried blocks through the trial and its verdict against the free-running kernel alone (knob osc_pace 1):
+    every block of the run and the state, bit for bit; the verdict is there after 160 launches; a subsample against the oracle."""
+    import ctypes
+    L = mx.lib()
+    V, N, K = 65536, 512, 200       # (a block the automatic rule streams through pair rows: 268 MB)
+    rng = np.random.default_rng(5)
+    freq = rng.uniform(20, 20000, V)
+
+    def run(pace):
+        prev = L.mxg_tune(b"osc_pace", pace)
+        try:
+            bank = mx.maxiOscBank(V)
+            acc = np.zeros(V)
+            last = None
+            for k in range(K):
+                o = bank.render(8, freq, N)
+                if k % 16 == 5 or k == K - 1:                # (blocks of every phase of the trial, and the last one)
+                    last = o.numpy()
+                    acc = acc + last[::7].sum(axis=0) * (k + 1)
+            buf = (ctypes.c_uint * 128)()
+            assert L.mxg_debug_osc_pace(bank.stream, buf) == 0
+            return acc, last, bank.phase.numpy().copy(), bank.output.numpy().copy(), list(buf)[8 * 14: 8 * 14 + 8]
+        finally:
+            L.mxg_tune(b"osc_pace", prev)
+    ref = run(1)
+    t0 = ref[4][1]                    # (the stream's launches so far: other tests share it)
+    got = run(0)
+    for a, b, what in zip(ref[:4], got[:4], ("fingerprint of every 16th block", "last block", "phase", "output member")):
+        assert_bits_equal(b, a, "trial against the free-running kernel: %s" % what)
+    t = got[4]
+    t[1] = t[1] - t0 if t[0] == 0 else t[1]
+    assert t[0] == 1 or 40 <= t[0] <= 70, "the trial's words after %d more launches: %r" % (K, t)
+    sel = np.arange(0, V, 997)
+    eo, eph, _ = port.osc(8, freq[sel], K * N)
+    assert_bits_equal(ref[1][:, sel], eo[-N:], "last block against the oracle")
+    assert_bits_equal(ref[2][sel], eph, "phase against the oracle")
+
+
 def test_paced_launches_are_graph_capturable(mx):
     """A launch on the paced schedule (saw at 131 072 voices: csrc/mxg_pace.h) takes its controller's words from per-stream scratch.  Captured
     into a hipGraph on a stream that has never launched it, it must not allocate inside the capture -- the launch is then simply not
