@@ -123,24 +123,31 @@ struct Pace {
 // (40.4-41.3 us) and collapses on others (43.5-47.6 us, box by box and sometimes run by run); paced 8-byte stores on the right period take
 // 40.7 us on the first kind and 42.5 on the second -- but sinebuf is the waveform whose launches go late now and then at any period, and
 // inside 80 launches the lateness controller does not find that period.  So the DURATIONS decide, on the device: eight words --
-//   [0] the verdict (0 none yet, 1 free-running, >= 2 paced on that fixed period)   [1] launches so far   [2:3] this launch's accumulator
+//   [0] the verdict (0 none yet, 1 free-running, >= 2 paced on that fixed period)   [1] launches so far | the block length's low 16 bits << 16   [2:3] this launch's accumulator
 //   (reporters | the sum of their durations << 32)   [4] ... [7] the sums of the mean durations of the four measured phases
 // -- and ONE kernel that holds both loops.  Launches 0 ... 31 run free (clocks and caches settle), then 32 launches each on the periods
 // 27/32, 29/32 and 31/32 of the starting one (the measured knees sit at 0.83-0.9 of it), then 32 free-running ones; the shortest mean
 // wins, a period only if it beats the free-running stream by 1.5 %.  After 16 384 launches the trial is repeated.  A run shorter than 160
 // launches never leaves the free-running kernel it always had.
-constexpr unsigned kTrialPhase = 32, kTrialEnd = 5 * kTrialPhase, kTrialAgain = kTrialEnd + 16384;
+constexpr unsigned kTrialPhase = 32, kTrialEnd = 5 * kTrialPhase, kTrialAgain = kTrialEnd + 16384;  // (kTrialAgain < 2^16: the count shares its word)
 
 struct PaceTrial {
-    unsigned t_begin, n, period;  // period: this launch's (0 = free-running)
+    unsigned t_begin, n, period, tag;  // period: this launch's (0 = free-running); tag: the block length's low 16 bits (durations of
+                                       // different block lengths do not compare: another length starts the trial again)
     __device__ __forceinline__ static unsigned candidate(unsigned arg, unsigned i) { return arg * (27u + 2u * i) / 32u; }  // i = 0, 1, 2
-    __device__ __forceinline__ void start(const unsigned *T, unsigned arg) {
+    __device__ __forceinline__ void start(const unsigned *T, unsigned arg, unsigned block_len) {
         t_begin = Pace::now();
         n = 0;
         period = 0;
+        tag = block_len & 0xffffu;
         if (T) {
-            const unsigned d = __hip_atomic_load(T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            n = __hip_atomic_load(T + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned d = __hip_atomic_load(T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned w1 = __hip_atomic_load(T + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            n = w1 & 0xffffu;
+            if ((w1 >> 16) != tag) {  // (another block length, or the first launch: from the start)
+                n = 0;
+                d = 0;
+            }
             if (d) {
                 period = d >= 2 ? (d < 2 * arg ? d : 2 * arg) : 0;
             } else {
@@ -160,6 +167,10 @@ struct PaceTrial {
         atomicExch(acc, 0ull);
         const unsigned mean = (unsigned)(all >> 32) / nrep;
         unsigned d = atomicAdd(&T[0], 0u), nn = n + 1;
+        if ((atomicAdd(&T[1], 0u) >> 16) != tag) {  // (see start)
+            d = 0;
+            for (unsigned i = 4; i < 8; i++) atomicExch(&T[i], 0u);
+        }
         if (!d) {
             const unsigned ph = n / kTrialPhase;
             if (ph >= 1 && ph <= 4) atomicAdd(&T[3 + ph], mean);
@@ -182,7 +193,7 @@ struct PaceTrial {
             for (unsigned i = 4; i < 8; i++) atomicExch(&T[i], 0u);
         }
         atomicExch(&T[0], d);
-        atomicExch(&T[1], nn);
+        atomicExch(&T[1], nn | (tag << 16));
     }
 };
 

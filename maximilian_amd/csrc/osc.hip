@@ -167,7 +167,7 @@ __global__ void osc_kernel(size_t V, size_t N, const double *__restrict__ freq,
     // wavefront) eight samples start every P ticks of the 100 MHz counter
     // (trial != null: this launch holds BOTH forms, the free-running pair rows and the paced 8-byte stream; the trial's words say which runs)
     PaceTrial tr;
-    tr.start(trial, pace_arg);
+    tr.start(trial, pace_arg, (unsigned)N);
     Pace pc;
     pc.start(trial ? nullptr : pace_ctl, trial ? tr.period : pace_arg);
     auto run = [&](auto trust_tag) {
