@@ -767,8 +767,8 @@ def main():
         for f in range(16):
             q = w[8 * f: 8 * f + 8]
             if f == 14 and q[1]:
-                print("trial[sinebuf, headline size]: verdict %d (1 free-running, else the period)  launches %d  sums of 32 mean durations: three periods %d %d %d, free-running %d" % (
-                    q[0], q[1] & 0xffff, q[4], q[5], q[6], q[7]), file=sys.stderr)
+                print("trial[sinebuf, headline size]: verdict %d (1 free-running, else the period)  launches %d  ticks per phase of 32 launches: free-running %d, the best period %d took %d" % (
+                    q[0], q[1] & 0xffff, q[4], q[6], q[5]), file=sys.stderr)
             elif q[0]:
                 print("pace[waveform %d]: P %d  window %d lates %d booted %d  last mean lateness %d" % (
                     f, q[0], q[1] & 255, (q[1] >> 8) & 255, (q[1] >> 16) & 255, q[7]), file=sys.stderr)

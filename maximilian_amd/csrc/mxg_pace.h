@@ -121,20 +121,25 @@ struct Pace {
 // ---- free-running or paced, and at which period?  A trial on the device -------------------------------------------------------------
 // K1's sinebuf at 65 536 voices (the headline) has a free-running stream -- pair rows, write-through -- that sits ON the knee on some boxes
 // (40.4-41.3 us) and collapses on others (43.5-47.6 us, box by box and sometimes run by run); paced 8-byte stores on the right period take
-// 40.7 us on the first kind and 42.5 on the second -- but sinebuf is the waveform whose launches go late now and then at any period, and
-// inside 80 launches the lateness controller does not find that period.  So the DURATIONS decide, on the device: eight words --
-//   [0] the verdict (0 none yet, 1 free-running, >= 2 paced on that fixed period)   [1] launches so far | the block length's low 16 bits << 16   [2:3] this launch's accumulator
-//   (reporters | the sum of their durations << 32)   [4] ... [7] the sums of the mean durations of the four measured phases
-// -- and ONE kernel that holds both loops.  Launches 0 ... 31 run free (clocks and caches settle), then 32 launches each on the periods
-// 27/32, 29/32 and 31/32 of the starting one (the measured knees sit at 0.83-0.9 of it), then 32 free-running ones; the shortest mean
-// wins, a period only if it beats the free-running stream by 1.5 %.  After 16 384 launches the trial is repeated.  A run shorter than 160
-// launches never leaves the free-running kernel it always had.
-constexpr unsigned kTrialPhase = 32, kTrialEnd = 5 * kTrialPhase, kTrialAgain = kTrialEnd + 16384;  // (kTrialAgain < 2^16: the count shares its word)
+// 40.7 us on the first kind and 42.5 on the worst of the second -- but sinebuf is the waveform whose launches go late now and then at any
+// period, and the lateness controller does not find that period quickly.  So the launches' WALL TIME decides, on the device: sixteen
+// words (two slots) --
+//   [0] the verdict (0 none yet, 1 free-running, >= 2 paced on that fixed period)   [1] launches so far | the block length's low 16 bits << 16
+//   [2:3] this launch's accumulator (reporters: the last one to finish acts)   [4] what the free-running phase took, in ticks
+//   [5] / [6] the best period's phase and the period   [8] the clock at the end of the last phase
+// -- and ONE kernel that holds both loops.  Phases of 32 launches: free-running (clocks and caches settle), free-running (measured:
+// the device clock from the end of the previous phase's last launch to the end of its own -- the wall time, gaps included), then the
+// periods 31/32, 29/32, 27/32 of the starting one, DESCENDING towards the knee (measured at 0.83-0.9 of it), for as long as each phase
+// is shorter than the one before: below the knee a phase is 10-30 % longer, and the descent stops there.  The best period wins if it
+// beats the free-running phase by 2 %.  Where the free-running stream is the best (most boxes) the trial costs two phases a few
+// per cent slower than it: 0.1 % of a 2000-launch run.  After 16 384 launches it is repeated; a run shorter than 96 launches never
+// leaves the free-running kernel it always had.
+constexpr unsigned kTrialPhase = 32, kTrialCandidates = 3, kTrialAgain = 16384 + 5 * kTrialPhase;  // (< 2^16: the count shares its word)
 
 struct PaceTrial {
-    unsigned t_begin, n, period, tag;  // period: this launch's (0 = free-running); tag: the block length's low 16 bits (durations of
+    unsigned t_begin, n, period, tag;  // period: this launch's (0 = free-running); tag: the block length's low 16 bits (wall times of
                                        // different block lengths do not compare: another length starts the trial again)
-    __device__ __forceinline__ static unsigned candidate(unsigned arg, unsigned i) { return arg * (27u + 2u * i) / 32u; }  // i = 0, 1, 2
+    __device__ __forceinline__ static unsigned candidate(unsigned arg, unsigned i) { return arg * (31u - 2u * i) / 32u; }  // i = 0, 1, 2: descending
     __device__ __forceinline__ void start(const unsigned *T, unsigned arg, unsigned block_len) {
         t_begin = Pace::now();
         n = 0;
@@ -151,8 +156,8 @@ struct PaceTrial {
             if (d) {
                 period = d >= 2 ? (d < 2 * arg ? d : 2 * arg) : 0;
             } else {
-                const unsigned ph = n / kTrialPhase;  // 0 free, 1 ... 3 the candidates, 4 free
-                period = (ph >= 1 && ph <= 3) ? candidate(arg, ph - 1) : 0;
+                const unsigned ph = n / kTrialPhase;  // 0, 1 free-running; 2 ... the candidates
+                period = (ph >= 2 && ph < 2 + kTrialCandidates) ? candidate(arg, ph - 2) : 0;
             }
         }
     }
@@ -161,36 +166,36 @@ struct PaceTrial {
         if (!T || (wg & 15u)) return;
         const unsigned nrep = (nwg + 15u) / 16u;
         unsigned long long *acc = reinterpret_cast<unsigned long long *>(T + 2);
-        const unsigned long long mine = ((unsigned long long)(Pace::now() - t_begin) << 32) | 1ull;
-        const unsigned long long all = atomicAdd(acc, mine) + mine;  // (relaxed, one line, no fence: see Pace::finish)
+        const unsigned long long all = atomicAdd(acc, 1ull) + 1ull;  // (relaxed, one line, no fence: see Pace::finish)
         if ((unsigned)(all & 0xffffu) != nrep) return;
         atomicExch(acc, 0ull);
-        const unsigned mean = (unsigned)(all >> 32) / nrep;
         unsigned d = atomicAdd(&T[0], 0u), nn = n + 1;
-        if ((atomicAdd(&T[1], 0u) >> 16) != tag) {  // (see start)
-            d = 0;
-            for (unsigned i = 4; i < 8; i++) atomicExch(&T[i], 0u);
-        }
+        if ((atomicAdd(&T[1], 0u) >> 16) != tag) d = 0;  // (see start)
         if (!d) {
-            const unsigned ph = n / kTrialPhase;
-            if (ph >= 1 && ph <= 4) atomicAdd(&T[3 + ph], mean);
-            if (nn == kTrialEnd) {
-                const unsigned long long fr = (unsigned long long)atomicAdd(&T[7], 0u) * 197;  // (a period has to win by 1.5 %)
-                unsigned best = 1;
-                unsigned long long best_sum = fr;
-                for (unsigned i = 0; i < 3; i++) {
-                    const unsigned long long c = (unsigned long long)atomicAdd(&T[4 + i], 0u) * 200;
-                    if (c < best_sum) {
-                        best_sum = c;
-                        best = candidate(arg, i);
+            if (nn % kTrialPhase == 0) {  // a phase ends with this launch
+                const unsigned t_now = Pace::now(), ph = n / kTrialPhase, wall = t_now - atomicAdd(&T[8], 0u);
+                atomicExch(&T[8], t_now);
+                if (ph == 1) {
+                    atomicExch(&T[4], wall);
+                    atomicExch(&T[5], 0xffffffffu);
+                    atomicExch(&T[6], 0u);
+                } else if (ph >= 2) {
+                    unsigned best = atomicAdd(&T[5], 0u), best_p = atomicAdd(&T[6], 0u);
+                    bool done = ph + 1 == 2 + kTrialCandidates;
+                    if (wall < best) {
+                        best = wall;
+                        best_p = candidate(arg, ph - 2);
+                        atomicExch(&T[5], best);
+                        atomicExch(&T[6], best_p);
+                    } else {
+                        done = true;  // longer than the period before it: that was the knee
                     }
+                    if (done) d = ((unsigned long long)best * 100 < (unsigned long long)atomicAdd(&T[4], 0u) * 98) ? best_p : 1u;
                 }
-                d = best;
             }
         } else if (nn >= kTrialAgain) {
             d = 0;
             nn = 0;
-            for (unsigned i = 4; i < 8; i++) atomicExch(&T[i], 0u);
         }
         atomicExch(&T[0], d);
         atomicExch(&T[1], nn | (tag << 16));

@@ -432,12 +432,12 @@ def test_render_and_mixdown_are_graph_capturable(mx):
 
 def test_headline_trial_same_bits(mx, port):
     """sinebuf at the headline's size is launched as ONE kernel that holds the free-running pair-row stream and the paced 8-byte one; a trial
-    on the device (csrc/mxg_pace.h, PaceTrial: 32 launches each free-running, on three periods, free-running again) picks by the
-    measured durations.  200 carried blocks through the trial and its verdict against the free-running kernel alone (knob osc_pace 1):
-    every block of the run and the state, bit for bit; the verdict is there after 160 launches; a subsample against the oracle."""
+    on the device (csrc/mxg_pace.h, PaceTrial: phases of 32 launches: free-running, then descending periods for as long as each is faster than the one before) picks by the
+    measured durations.  180 carried blocks through the trial and its verdict against the free-running kernel alone (knob osc_pace 1):
+    every block of the run and the state, bit for bit; the verdict is there within 160 launches; a subsample against the oracle."""
     import ctypes
     L = mx.lib()
-    V, N, K = 65536, 512, 200       # (a block the automatic rule streams through pair rows: 268 MB)
+    V, N, K = 65536, 512, 180       # (a block the automatic rule streams through pair rows: 268 MB; the verdict comes within 160 launches)
     rng = np.random.default_rng(5)
     freq = rng.uniform(20, 20000, V)
 
