@@ -63,6 +63,7 @@ inline int rw_store_choice(size_t V, size_t N, const void *d_out, RwFamily fam =
 // a device pointer of at least `bytes`.
 enum ScratchSlot { SCR_MIX_GAINS, SCR_OSC_MIX, SCR_GRAIN_ERR, SCR_GRAIN_SCHED, SCR_IFFT_OUT, SCR_IFFT_BUF, SCR_MFCC_RAW, SCR_CONVOLVE, SCR_GRAIN_MIX, SCR_PART_SYNC, SCR_OSCTAB_MARKS, SCR_OSCTAB_MARKS2, SCR_OSCTAB_CARRY, SCR_OSCTAB_SUM, SCR_VOICE_PACE, SCR_OSC_PACE, SCR_SMP_PACE, SCR_SLOTS };
 int scratch_get(ScratchSlot slot, hipStream_t st, size_t bytes, void **out, bool *fresh = nullptr);  // *fresh: newly allocated (contents undefined)
+unsigned pace_start_period(size_t bytes);  // a paced launch's starting period in ticks of the device's constant counter (runtime.hip); 0 = do not pace
 unsigned *pace_words(ScratchSlot slot, hipStream_t st, size_t nwords);  // a pace controller's words (runtime.hip), or null inside a capture
 
 // Optional per-kernel timing (mxg_prof_enable): a KernelTimer around a launch records two HIP events on the launch

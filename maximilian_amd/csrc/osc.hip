@@ -941,10 +941,10 @@ int osc_launch(const OscLaunch &L) {
             if (knob >= 2) {
                 pace_arg = (unsigned)knob;
             } else if (L.paced) {
-                pace_arg = (unsigned)((double)count * 8 * 8 / 6.6e12 * 1e8 + 0.5);  // the starting period: the chip's 8 rows at 6.6 TB/s
+                pace_arg = pace_start_period(count * 8 * 8);  // the chip's 8 rows
                 unsigned *base = pace_words(SCR_OSC_PACE, L.st, 16 * kPaceWords);
-                if (base) pace_ctl = base + kPaceWords * (L.waveform & 15);
-                else pace_arg = 0;  // (inside a graph capture before the first eager launch: not paced)
+                if (base && pace_arg) pace_ctl = base + kPaceWords * (L.waveform & 15);
+                else pace_arg = 0;  // (inside a graph capture before the first eager launch, or a device whose counter's rate is unknown: not paced)
             }
         }
     }
@@ -954,9 +954,9 @@ int osc_launch(const OscLaunch &L) {
     unsigned *trial = nullptr;
     if (L.trial && !pace_arg && split == 1 && passes == 1 && !fps && vpl == 1 && store == 3 && tune_get("osc_pace") == 0) {
         unsigned *base = pace_words(SCR_OSC_PACE, L.st, 16 * kPaceWords);
-        if (base) {
+        if (base && pace_start_period(count * 8 * 8)) {
             trial = base + kPaceWords * 14;
-            pace_arg = (unsigned)((double)count * 8 * 8 / 6.6e12 * 1e8 + 0.5);  // (the candidates are 27/32, 29/32, 31/32 of it: 54, 58, 62 at 65 536 voices)
+            pace_arg = pace_start_period(count * 8 * 8);  // (the candidates are 31/32, 29/32, 27/32 of it: 62, 58, 54 at 65 536 voices)
         }
     }
     KernelTimer kt("osc_kernel", L.st);

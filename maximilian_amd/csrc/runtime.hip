@@ -143,6 +143,20 @@ int scratch_get(ScratchSlot slot, hipStream_t st, size_t bytes, void **out, bool
     return MXG_OK;
 }
 
+// The starting period of a paced launch (mxg_pace.h), in ticks of the device's constant counter (s_memrealtime = HIP's wall clock: its
+// rate is a device attribute, 100 MHz on MI355X): the time the memory system needs for `bytes` (one chunk of the whole grid) at 6.6 TB/s
+// -- a rate it takes without back-pressure on every box seen; the controllers come down from there.  0 (= not paced) if the rate is
+// unknown or the schedule would be too coarse for the controller's one-tick steps (fewer than 24 ticks per chunk).
+unsigned pace_start_period(size_t bytes) {
+    static const double ticks_per_second = [] {
+        int dev = 0, khz = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) return 0.0;
+        return (double)khz * 1e3;
+    }();
+    const double p = (double)bytes / 6.6e12 * ticks_per_second + 0.5;
+    return (p >= 24.0 && p < 1e6) ? (unsigned)p : 0u;
+}
+
 // The words of a pace controller (mxg_pace.h) in per-stream scratch, zeroed when first handed out; null -- the launch is then simply not
 // paced -- while `st` is being captured into a graph and the words do not exist yet (no allocation inside a capture; a graph captured
 // after the first eager launch carries the pointer and its replays keep the controller going).

@@ -1030,9 +1030,9 @@ int mxg_sample_render(int mode, size_t V, size_t N, const double *d_samples, siz
         if (knob >= 2) {
             A.pace_arg = (unsigned)knob;
         } else if (knob == 0 && mode == 0 && V >= 45056 && V <= 229375) {
-            A.pace_arg = (unsigned)((double)V * 8 * 8 / 6.6e12 * 1e8 + 0.5);
-            A.pace_ctl = pace_words(SCR_SMP_PACE, st, kPaceWords);
-            if (!A.pace_ctl) A.pace_arg = 0;  // (inside a graph capture before the first eager launch: not paced)
+            A.pace_arg = pace_start_period(V * 8 * 8);
+            A.pace_ctl = A.pace_arg ? pace_words(SCR_SMP_PACE, st, kPaceWords) : nullptr;
+            if (!A.pace_ctl) A.pace_arg = 0;  // (inside a graph capture before the first eager launch, or a device whose counter's rate is unknown: not paced)
         }
     }
     if (mode >= 4 && mode <= 6 && !xmod) {

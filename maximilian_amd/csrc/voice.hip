@@ -1235,11 +1235,11 @@ static int voice_launch(int mode, size_t V, size_t N, const double *d_freq, cons
     if (pace_knob >= 2) {
         pace_arg = (unsigned)pace_knob;
     } else if (pace_knob == 0 && V >= 45056 && V <= (mix ? (size_t)65536 : (mode ? (size_t)131072 : (size_t)229375))) {
-        // the starting period: the chip's 8 rows at 6.6 TB/s, in ticks of 10 ns; one controller per stream and form
-        pace_arg = (unsigned)((double)V * 8 * 8 / 6.6e12 * 1e8 + 0.5);
+        // the starting period: the chip's 8 rows at 6.6 TB/s, in ticks of the device's constant counter (pace_start_period); one controller per stream and form
+        pace_arg = pace_start_period(V * 8 * 8);
         unsigned *base = pace_words(SCR_VOICE_PACE, st, 4 * kPaceWords);
-        if (base) pace_ctl = base + kPaceWords * ((mode ? 1 : 0) + (mix ? 2 : 0));
-        else pace_arg = 0;  // (inside a graph capture before the first eager launch: not paced)
+        if (base && pace_arg) pace_ctl = base + kPaceWords * ((mode ? 1 : 0) + (mix ? 2 : 0));
+        else pace_arg = 0;  // (inside a graph capture before the first eager launch, or a device whose counter's rate is unknown: not paced)
     }
     KernelTimer kt("voice_kernel", st);
     if (mix) {
