@@ -1,13 +1,16 @@
-// mxg_pace.h -- the paced store schedule of the store-bound bank kernels (K1, K2f; round 6, profiles/r06_pace.md).
+// mxg_pace.h -- the paced store schedule of the store-bound bank kernels (K2f, K1 beyond 65 536 voices, maxiSample::play; K1's headline
+// size through a trial, PaceTrial below; round 6, profiles/r06_pace.md).
 //
 // Where a kernel's bound is its store stream -- 65 536 voices: one wavefront on every SIMD of the chip, each storing a 512-byte piece of
 // every row -- it is FASTEST when no wavefront ever meets a full store queue.  Left to run, the wavefronts reach the memory system's
 // back-pressure and the stream's efficiency collapses by a fifth (K2f: 51 us); started on a schedule -- chunk k (8 samples) not before
-// t0 + k P ticks of the constant 100 MHz counter (s_memrealtime), P a hair above the time the memory system needs for the chip's 8 rows --
+// t0 + k P ticks of the device's constant counter (s_memrealtime: 100 MHz on MI355X, 10 ns a tick; the host takes the rate from
+// hipDeviceAttributeWallClockRate), P a hair above the time the memory system needs for the chip's 8 rows --
 // the same instruction stream takes 41 us.  The optimum is a knee: a tick (10 ns) below it the collapse is back, above it the time is 64 P.
 //
 // So P is CONTROLLED, per stream and kernel form, by eight words in device scratch (zeroed once by the host):
-//   [0] P   [1] launches in the window | late ones among them << 8 | booted << 16
+//   [0] P (kPaceGaveUp: the schedule was given up on this stream)   [1] launches in the window | late ones among them << 8 |
+//   the descent's stage << 16 | late launches in a row << 24
 //   [4:5] one 64-bit accumulator of the launch: reporters finished | reporters whose chunks were the cheap ones << 16 | the sum of their
 //   latenesses << 32 (ticks behind schedule at the last chunk, each capped at 8 P)   [7] the last launch's mean lateness (diagnostics)
 // One workgroup in sixteen reports: its first wavefront adds into [4:5]; the LAST reporter to finish judges the launch.  Only a
@@ -16,9 +19,12 @@
 // lateness says nothing about the memory system.  It was LATE if it ended, on average, more than half a period behind.  Near the knee
 // late launches come at a RATE that falls with P (measured: every other launch a tick below the knee, one in ten on it, one in fifty
 // three ticks above), and a tick costs 0.6 us per launch where a late launch costs ~6: the period worth having is the one with 5-10 %
-// late launches.  So: from the starting period P comes down two ticks per launch until the first late one, then a tick per launch until the next (a dozen launches in all); then windows
-// of 32 launches -- the fourth late launch of a window puts P up a tick at once, a window with at most one takes a tick off, anything
-// between holds.  P follows the box, its clocks and the other streams of the moment.  Timing only: the bits do not depend on it.
+// late launches.  So: from the starting period (a rate every box takes) P comes down two ticks per launch until the first late one,
+// then a tick per launch until the next (a dozen launches in all); then windows of 32 launches -- the fourth late launch of a window puts P up a tick at once, a window with at most one takes a tick off, anything
+// between holds (the TOLERANT rule, for K1's sinebuf whose launches go late now and then at any period: eight and four).  P follows the
+// box, its clocks and the other streams of the moment; a period half as long again as the starting one means the schedule does not
+// describe the launch at all (a grid that is not resident at once, a device of another shape) and gives it up for good.  Timing only: the
+// bits do not depend on it.
 #pragma once
 #include "mxg_common.h"
 
