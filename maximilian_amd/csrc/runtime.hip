@@ -149,8 +149,10 @@ int scratch_get(ScratchSlot slot, hipStream_t st, size_t bytes, void **out, bool
 // unknown or the schedule would be too coarse for the controller's one-tick steps (fewer than 24 ticks per chunk).
 unsigned pace_start_period(size_t bytes) {
     static const double ticks_per_second = [] {
-        int dev = 0, khz = 0;
+        int dev = 0, khz = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) return 0.0;
+        // (the bank sizes the launches pace at are those of the whole chip, 256 CUs: a partition of it, or another part, is not paced)
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus != 256) return 0.0;
         return (double)khz * 1e3;
     }();
     const double p = (double)bytes / 6.6e12 * ticks_per_second + 0.5;
