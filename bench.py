@@ -23,6 +23,11 @@ Prints ONE JSON line on rank 0: metric/value/unit/..., plus
   "cpu_baseline"  the reference's own per-sample CPU loop (oracle/_ref, the compiled reference; else the plain-C
                   port) timed on this host's cores on a bounded sample of the same workload (rank 0, N = 1 only),
                   multi-threaded ("cores") and single-threaded ("single_thread").
+
+Round 6: several of the kernels timed here run on the library's paced store schedule (csrc/mxg_pace.h) -- a controller, or for the
+headline's size a trial, kept in device scratch per stream; they settle within the first dozens of launches of a stream, which the
+warm-up loops cover.  MXG_PRINT_PACE=1 prints their words to stderr after the timed loop (diagnostics); `--tune voice_pace=1`,
+`osc_pace=1`, `smp_pace=1` switch the schedule off.
 """
 import argparse
 import ctypes
