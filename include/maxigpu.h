@@ -162,7 +162,7 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * per lane only), "voice_mix_store" (the store stream of mxg_voice_render_mix*: 0 automatic = "voice_store"'s rule, 1 ... 5 its flavours),
  * "voice_diet" (the fused voice, mode A without mixdown: 1 = the round-5 instruction stream of the fast paths, for comparison; same bits),
  * "voice_pace" (the fused voice's paced store schedule, a chunk of 8 samples every P ticks of 10 ns: 0 automatic = a per-stream controller
- * at the store-bound bank sizes whose whole grid is resident at once (45 056 ... 196 608 voices; mode B to 131 072, the mixdown form to 65 536); 1 never; >= 2 a fixed P; timing only, same bits), "osc_pace" (the same for mxg_osc_render: 0 automatic = the table-free waveforms at 90 112 ... 327 680 voices; 1 never; >= 2 a fixed P),
+ * at the store-bound bank sizes whose whole grid is resident at once (45 056 ... 262 144 voices; mode B to 131 072, the mixdown form to 65 536); 1 never; >= 2 a fixed P; timing only, same bits), "osc_pace" (the same for mxg_osc_render: 0 automatic = the table-free waveforms at 90 112 ... 327 680 voices; 1 never; >= 2 a fixed P),
  * "tab_sides" (mxg_osc_render_tables*: 0 automatic = 1 workgroups of 256 lanes, one round of 8 voices at a time, two per CU; 2 = workgroups of 512 lanes, two rounds side by side),
  * "smp_pace" (the paced schedule for mxg_sample_render: 0 automatic = play() at 45 056 ... 229 375 voices; 1 never; >= 2 a fixed P), "smp_ring" (the *AtSpeed players' window rows as rings: 0 automatic = samples beyond 1 GiB, 1 off, 2 on), "grain_spin_limit" (see mxg_granular_retries), "osc_xcd" (workgroups renumbered so that each of the eight XCDs renders
  * one contiguous eighth of the bank: 0 automatic, 1 off, 2 on), "grain_sync" (mxg_granular_render reads its error word back before it returns, 0|1;

@@ -1224,8 +1224,8 @@ static int voice_launch(int mode, size_t V, size_t N, const double *d_freq, cons
     // the paced schedule (voice_kernel, PACE): knob voice_pace 0 = automatic, 1 = never, >= 2 = a fixed period of that many 10 ns ticks
     // per 8-sample chunk (sweeps).  Automatic = the controller wherever the store stream is the bound AND the whole grid is resident at
     // once (a schedule per workgroup means nothing to workgroups that wait for a CU): from 45 056 voices (below, the kernel's time is
-    // its own instruction stream's: 40 960 voices 32.7 -> 33.3 us) up to 196 608 for mode A (five wavefronts of 92 registers per SIMD;
-    // 262 144 voices, measured: 198 -> 205 us), 131 072 for mode B (two of 160-190), 65 536 for the mixdown form (one workgroup of
+    // its own instruction stream's: 40 960 voices 32.7 -> 33.3 us) up to 262 144 for mode A (five wavefronts of 92 registers per SIMD: four
+    // workgroups per CU; 393 216 voices on fixed periods: 313 -> 426 us), 131 072 for mode B (two of 160-190), 65 536 for the mixdown form (one workgroup of
     // 146 KB of LDS per CU: at 131 072 voices half the grid waits, 110 -> 142 us).  Measured with the controller, mode A:
     // 49 152 voices 36.1 -> 32.7 us, 65 536 51.3 -> 42.4 (the round-5 stream without it: 47.7), 81 920 65.7 -> 54.5, 98 304 74.4 -> 68.4,
     // 131 072 103.0 -> 87.7, 196 608 166.5 -> 132.8: the collapse of the store stream is not a matter of one wavefront per SIMD.
@@ -1234,12 +1234,16 @@ static int voice_launch(int mode, size_t V, size_t N, const double *d_freq, cons
     unsigned pace_arg = 0;
     if (pace_knob >= 2) {
         pace_arg = (unsigned)pace_knob;
-    } else if (pace_knob == 0 && V >= 45056 && V <= (mix ? (size_t)65536 : (mode ? (size_t)131072 : (size_t)229375))) {
+    } else if (pace_knob == 0 && V >= 45056 && V <= (mix ? (size_t)65536 : (mode ? (size_t)131072 : (size_t)294911))) {
         // the starting period: the chip's 8 rows at 6.6 TB/s, in ticks of the device's constant counter (pace_start_period); one controller per stream and form
         pace_arg = pace_start_period(V * 8 * 8);
         unsigned *base = pace_words(SCR_VOICE_PACE, st, 4 * kPaceWords);
         if (base && pace_arg) pace_ctl = base + kPaceWords * ((mode ? 1 : 0) + (mix ? 2 : 0));
         else pace_arg = 0;  // (inside a graph capture before the first eager launch, or a device whose counter's rate is unknown: not paced)
+        // (a paced launch wants the NATURAL workgroup numbering -- the whole chip walking down the same rows: the XCD-contiguous one was
+        // round 3's answer to the free-running kernel's drift at large banks.  Fixed periods, mode A: 98 304 voices 67.2 -> 64.4 us,
+        // 196 608 146 -> 142, 262 144 192 -> 171 where the free-running kernel takes 198: profiles/r06_pace.md)
+        if (pace_ctl && tune_get("voice_xcd") == 0) xcd = 0;
     }
     KernelTimer kt("voice_kernel", st);
     if (mix) {
