@@ -160,7 +160,7 @@ int mxg_prof_overhead_ms(void *stream, int pairs, double *h_ms);
  * 3 / 4 / 5 two samples of a lane pair exchanged into one 16-byte store per lane, plain / write-through (sc1) / non-temporal; two
  * voices per lane: 1 plain, 2 non-temporal, 3 write-through 16-byte stores), "voice_store" / "voice_xcd" (the same for the fused voice kernel; one voice
  * per lane only), "voice_mix_store" (the store stream of mxg_voice_render_mix*: 0 automatic = "voice_store"'s rule, 1 ... 5 its flavours),
- * "voice_diet" (the fused voice, mode A without mixdown: 1 = the round-5 instruction stream of the fast paths, for comparison; same bits),
+ * "voice_diet" (the fused voice, mode A without mixdown: 0 automatic = the short instruction stream of the fast paths, except around 65 536 voices when the launch cannot be paced; 1 = the round-5 stream; 2 = the short one; same bits),
  * "voice_pace" (the fused voice's paced store schedule, a chunk of 8 samples every P ticks of 10 ns: 0 automatic = a per-stream controller
  * at the store-bound bank sizes whose whole grid is resident at once (45 056 ... 262 144 voices; mode B to 131 072, the mixdown form to 65 536); 1 never; >= 2 a fixed P; timing only, same bits), "osc_pace" (the same for mxg_osc_render: 0 automatic = the table-free waveforms at 90 112 ... 327 680 voices; 1 never; >= 2 a fixed P),
  * "tab_sides" (mxg_osc_render_tables*: 0 automatic = 1 workgroups of 256 lanes, one round of 8 voices at a time, two per CU; 2 = workgroups of 512 lanes, two rounds side by side),

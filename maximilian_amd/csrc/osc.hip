@@ -1029,7 +1029,9 @@ extern "C" int mxg_osc_render_pitch(int waveform, size_t V, size_t N, const doub
     // Knob osc_pace: 0 automatic, 1 never, >= 2 a fixed period.
     const bool lean_wf = ((MXG_K1_LEAN_MASK >> waveform) & 1) != 0 || (waveform == MXG_OSC_SINEBUF && V < kPacedFromSinebuf);
     if (automatic && !fps && !lean_wf && xcd < 0 && tune_get("osc_pace") == 0 && tune_get("osc_passes") == 0 && tune_get("osc_split") == 0 &&
-        tune_get("osc_plan") == 0 && V >= kPacedFrom && V <= kPacedTo) {
+        tune_get("osc_plan") == 0 && V >= kPacedFrom && V <= kPacedTo && pace_start_period(V * 8 * 8) &&
+        pace_words(SCR_OSC_PACE, st, 16 * kPaceWords)) {  // (no schedule to be had -- a capture before the stream's first eager launch, a device
+                                                            // that is not the whole chip: the plan below is the faster free-running launch)
         OscLaunch A = L0;
         A.v_begin = 0; A.v_end = V; A.vpl = 1; A.store = 1; A.xcd = 0; A.split = 1; A.passes = 1; A.block = 256; A.paced = true;
         return osc_launch(A);

@@ -1219,8 +1219,6 @@ static int voice_launch(int mode, size_t V, size_t N, const double *d_freq, cons
     }
     // the fast paths' instruction diet (voice_kernel, DIET): always for mode B and the mixdown form; plain mode A unless the knob
     // voice_diet says 1 (the round-5 instruction stream, kept for comparison)
-    const int diet_knob = tune_get("voice_diet");
-    const bool diet = diet_knob != 1;
     // the paced schedule (voice_kernel, PACE): knob voice_pace 0 = automatic, 1 = never, >= 2 = a fixed period of that many 10 ns ticks
     // per 8-sample chunk (sweeps).  Automatic = the controller wherever the store stream is the bound AND the whole grid is resident at
     // once (a schedule per workgroup means nothing to workgroups that wait for a CU): from 45 056 voices (below, the kernel's time is
@@ -1245,6 +1243,11 @@ static int voice_launch(int mode, size_t V, size_t N, const double *d_freq, cons
         // 196 608 146 -> 142, 262 144 192 -> 171 where the free-running kernel takes 198: profiles/r06_pace.md)
         if (pace_ctl && tune_get("voice_xcd") == 0) xcd = 0;
     }
+    // (plain mode A where every SIMD holds one wavefront and the launch could NOT be paced -- a capture before the stream's first eager
+    // launch, a device that is not the whole 256-CU chip, the knob: the short stream by itself is the slower one there, 50-51 us against
+    // the round-5 stream's 47.7, so that launch keeps the round-5 stream)
+    const int diet_knob = tune_get("voice_diet");
+    const bool diet = diet_knob == 2 || (diet_knob == 0 && !(!pace_arg && V >= 57344 && V < 73728));
     KernelTimer kt("voice_kernel", st);
     if (mix) {
         if (store == 5) {
