@@ -597,10 +597,22 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
     constexpr int kTabPad = (kTab + 1) & ~1;
     __shared__ __attribute__((aligned(16))) double s_all[kTabPad + 4 * kPcRing * kTileWave + 4 * WIN * 2 + 256 + 8];
     double *s_tab = s_all;
-    load_tab<WF, kPcFL>(s_tab);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool producer = wave < 4;
     const int pw = wave & 3;  // the pair
+    // (round 6, as in K1: the first pass's per-voice loads are REQUESTED before the table is staged -- behind the two barriers of the
+    // prologue they would be a round trip to memory of their own)
+    double ph_pre = 0, hd_pre = 0, f_pre = 0, a_pre = 0, b_pre = 0;
+    if (producer && (size_t)blockIdx.x * 256 < V) {
+        const size_t vr = (size_t)blockIdx.x * 256 + (size_t)pw * 64 + lane;
+        const size_t vv = vr < V ? vr : (STORE == 2 ? V - 2 + (vr & 1) : V - 1);
+        ph_pre = phase_io[vv];
+        hd_pre = hold_io[vv];
+        f_pre = freq[vv];
+        a_pre = p1 ? p1[vv] : 0.0;
+        b_pre = p2 ? p2[vv] : 0.0;
+    }
+    load_tab<WF, kPcFL>(s_tab);
     double *ring = s_all + kTabPad + pw * (kPcRing * kTileWave);
     double *s_part = s_all + kTabPad + 4 * kPcRing * kTileWave;  // [4 pairs][WIN][2]
     double *my_part = s_part + pw * (WIN * 2);
@@ -636,8 +648,8 @@ __global__ __launch_bounds__(512) void osc_mixpc_kernel(size_t V, size_t N, cons
         }
         __syncthreads();  // every consumer has its gains: the ring is free
         if (producer) {
-            double ph = phase_io[v], hd = hold_io[v];
-            OscPre q = osc_pre<WF>(freq[v], sr, p1 ? p1[v] : 0.0, p2 ? p2[v] : 0.0);
+            double ph = pass ? phase_io[v] : ph_pre, hd = pass ? hold_io[v] : hd_pre;
+            OscPre q = osc_pre<WF>(pass ? freq[v] : f_pre, sr, pass ? (p1 ? p1[v] : 0.0) : a_pre, pass ? (p2 ? p2[v] : 0.0) : b_pre);
             asm volatile("" : "+v"(ph), "+v"(hd));
             asm volatile("" : "+v"(q.inc), "+v"(q.k), "+v"(q.p1), "+v"(q.p2));
             double *o = out + v;
